@@ -1,0 +1,181 @@
+"""Neutral scene description shared by the product binding (capi.py) and the test oracle binding.
+
+The fields mirror the *inputs* of the reference's gi API (``/root/reference/src/gi/gtl/gi/Gi.h``):
+``GiVertex`` (:110-118), ``GiMeshDesc`` (:124-137), ``GiCameraDesc`` (:96-108), ``GiRenderSettings``
+(:139-159) and the light setters (:226-256).  Defaults of :class:`RenderSettings` are the Hydra render
+setting defaults of ``src/hdGatling/renderDelegate.cpp:93-110``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+# GiVertex: pos[3], u, norm[3], v, tangent[3], bitangentSign  (48 bytes)
+VERTEX_DTYPE = np.dtype([
+    ("pos", np.float32, 3), ("u", np.float32),
+    ("norm", np.float32, 3), ("v", np.float32),
+    ("tangent", np.float32, 3), ("bitangentSign", np.float32),
+])
+assert VERTEX_DTYPE.itemsize == 48
+
+# material classes (closed-form BSDFs, see DESIGN.md "Materials")
+MAT_DIFFUSE = 0
+MAT_USD_PREVIEW_SURFACE = 1
+MAT_OPEN_PBR = 2
+
+# parameter block indices (float p[48]); must match include/gi_c.h and oracle/gi_oracle.h
+P_BASE_COLOR = 0
+P_EMISSION = 3
+P_USE_SPECULAR_WORKFLOW = 6
+P_SPECULAR_COLOR = 7
+P_METALLIC = 10
+P_ROUGHNESS = 11
+P_CLEARCOAT = 12
+P_CLEARCOAT_ROUGHNESS = 13
+P_OPACITY = 14
+P_OPACITY_THRESHOLD = 15
+P_IOR = 16
+P_BASE_WEIGHT = 17
+P_SPECULAR_WEIGHT = 18
+P_COAT_COLOR = 19
+P_COAT_IOR = 22
+P_TRANSMISSION_WEIGHT = 23
+P_TRANSMISSION_COLOR = 24
+P_DIFFUSE_ROUGHNESS = 27
+P_COUNT = 48
+
+
+@dataclass
+class MaterialDesc:
+    name: str = "material"
+    klass: int = MAT_USD_PREVIEW_SURFACE
+    params: np.ndarray = field(default_factory=lambda: np.zeros(P_COUNT, np.float32))
+
+    @staticmethod
+    def usd_preview_surface(name="mat", diffuseColor=(0.18, 0.18, 0.18), emissiveColor=(0, 0, 0),
+                            useSpecularWorkflow=0, specularColor=(0, 0, 0), metallic=0.0, roughness=0.5,
+                            clearcoat=0.0, clearcoatRoughness=0.01, opacity=1.0, opacityThreshold=0.0,
+                            ior=1.5, klass=MAT_USD_PREVIEW_SURFACE) -> "MaterialDesc":
+        """UsdPreviewSurface inputs with the spec's fallback values."""
+        p = np.zeros(P_COUNT, np.float32)
+        p[P_BASE_COLOR:P_BASE_COLOR + 3] = diffuseColor
+        p[P_EMISSION:P_EMISSION + 3] = emissiveColor
+        p[P_USE_SPECULAR_WORKFLOW] = useSpecularWorkflow
+        p[P_SPECULAR_COLOR:P_SPECULAR_COLOR + 3] = specularColor
+        p[P_METALLIC] = metallic
+        p[P_ROUGHNESS] = roughness
+        p[P_CLEARCOAT] = clearcoat
+        p[P_CLEARCOAT_ROUGHNESS] = clearcoatRoughness
+        p[P_OPACITY] = opacity
+        p[P_OPACITY_THRESHOLD] = opacityThreshold
+        p[P_IOR] = ior
+        return MaterialDesc(name=name, klass=klass, params=p)
+
+
+@dataclass
+class MeshDesc:
+    name: str
+    vertices: np.ndarray            # VERTEX_DTYPE[N]
+    faces: np.ndarray               # uint32 [M,3]
+    material: int = 0               # index into SceneDesc.materials
+    id: int = 0
+    double_sided: bool = False
+    left_handed: bool = False
+    visible: bool = True
+    transform: np.ndarray = field(default_factory=lambda: np.eye(4, dtype=np.float32))  # USD row-vector convention
+    instance_transforms: np.ndarray = field(default_factory=lambda: np.eye(4, dtype=np.float32)[None].copy())
+    instance_ids: Optional[np.ndarray] = None
+
+
+@dataclass
+class SphereLight:
+    pos: tuple = (0, 0, 0)
+    base_emission: tuple = (0, 0, 0)
+    radius: tuple = (0.5, 0.5, 0.5)
+    diffuse: float = 1.0
+    specular: float = 1.0
+
+
+@dataclass
+class DistantLight:
+    direction: tuple = (0, 0, 0)
+    base_emission: tuple = (0, 0, 0)
+    angle: float = 0.0
+    diffuse: float = 1.0
+    specular: float = 1.0
+
+
+@dataclass
+class RectLight:
+    origin: tuple = (0, 0, 0)
+    t0: tuple = (1, 0, 0)
+    t1: tuple = (0, 1, 0)
+    base_emission: tuple = (0, 0, 0)
+    width: float = 1.0
+    height: float = 1.0
+    diffuse: float = 1.0
+    specular: float = 1.0
+
+
+@dataclass
+class DiskLight:
+    origin: tuple = (0, 0, 0)
+    t0: tuple = (1, 0, 0)
+    t1: tuple = (0, 1, 0)
+    base_emission: tuple = (0, 0, 0)
+    radius_x: float = 0.5
+    radius_y: float = 0.5
+    diffuse: float = 1.0
+    specular: float = 1.0
+
+
+@dataclass
+class CameraDesc:
+    position: tuple = (0, 0, 0)
+    forward: tuple = (0, 0, -1)
+    up: tuple = (0, 1, 0)
+    vfov: float = 0.8
+    f_stop: float = 0.0
+    focus_distance: float = 0.0
+    focal_length: float = 5.0
+    clip_start: float = 0.1
+    clip_end: float = 100.0
+    exposure: float = 0.0
+
+
+@dataclass
+class RenderSettings:
+    """Defaults: src/hdGatling/renderDelegate.cpp:93-110; colour clear value :229."""
+    spp: int = 1
+    max_bounces: int = 13
+    rr_bounce_offset: int = 3
+    rr_inv_min_term_prob: float = 0.95
+    max_sample_value: float = 10.0
+    filter_importance_sampling: bool = True
+    depth_of_field: bool = False
+    light_intensity_multiplier: float = 1.0
+    next_event_estimation: bool = False
+    clipping_planes: bool = False
+    medium_stack_size: int = 0
+    max_volume_walk_length: int = 7
+    jittered_sampling: bool = True
+    meters_per_scene_unit: float = 1.0
+    progressive_accumulation: bool = True
+    dome_light_camera_visible: bool = True
+    clear_color: tuple = (1.0, 1.0, 1.0, 1.0)
+
+
+@dataclass
+class SceneDesc:
+    meshes: List[MeshDesc] = field(default_factory=list)
+    materials: List[MaterialDesc] = field(default_factory=list)
+    sphere_lights: List[SphereLight] = field(default_factory=list)
+    distant_lights: List[DistantLight] = field(default_factory=list)
+    rect_lights: List[RectLight] = field(default_factory=list)
+    disk_lights: List[DiskLight] = field(default_factory=list)
+    camera: CameraDesc = field(default_factory=CameraDesc)
+
+    def triangle_count(self) -> int:
+        return int(sum(len(m.faces) * len(m.instance_transforms) for m in self.meshes if m.visible))

@@ -1,0 +1,1006 @@
+// gi_oracle.cpp -- CPU ORACLE (test infrastructure only; see gi_oracle.h header comment).
+//
+// Every function cites the reference file:line whose behaviour it restates.  Written from
+// scratch; no reference source is copied.  Build: see oracle/Makefile
+// (g++ -O2 -ffp-contract=off -fno-fast-math: the arithmetic contract forbids contraction).
+//
+// "parity unpinned": BSDF arithmetic (MDL SDK / MaterialX are not in /root/reference) and the
+// HW traversal's tie-breaking cannot be checked against the reference; see gi_oracle.h.
+
+#include "gi_oracle.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// vec3 helpers.  Operation order is part of the arithmetic contract.
+// ---------------------------------------------------------------------------------------------
+struct V3 { float x, y, z; };
+inline V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+inline V3 v3(const float* p) { return V3{p[0], p[1], p[2]}; }
+inline V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+inline V3 operator*(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+inline V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+inline V3 operator/(V3 a, float s) { return V3{a.x / s, a.y / s, a.z / s}; }
+inline float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline float length(V3 a) { return sqrtf(dot(a, a)); }
+inline V3 normalize(V3 a) { float inv = 1.0f / sqrtf(dot(a, a)); return a * inv; }
+inline float fmax2(float a, float b) { return a > b ? a : b; } // GLSL max(a,b) = a<b ? b : a (NaN-agnostic here)
+inline float fmin2(float a, float b) { return a < b ? a : b; }
+
+inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+const float ORC_PI = 3.1415926535897932384626433832795f; // common.glsl:9
+const float ORC_FLT_MAX = 3.402823466e38f;               // common.glsl:7
+const float ORC_FLT_MIN = 1.175494351e-38f;              // common.glsl:8
+
+// ---------------------------------------------------------------------------------------------
+// Polynomial transcendentals (arithmetic contract).  Cephes single-precision kernels
+// (public domain, S. Moshier) evaluated with plain mul/add.
+// ---------------------------------------------------------------------------------------------
+// sin/cos of 2*pi*x for x in [0,1].  Octant reduction is exact in fp32.
+inline void sincos2pi(float x, float* s, float* c)
+{
+  float y = x * 8.0f;              // exact
+  int q = (int)y;                  // 0..8
+  int j = (q + 1) >> 1;            // 0..4, nearest even octant boundary / 2
+  float z = y - (float)(2 * j);    // exact, in [-1,1]
+  float t = z * 0.78539816339744830962f; // * pi/4
+  float t2 = t * t;
+  float sp = ((-1.9515295891e-4f * t2 + 8.3321608736e-3f) * t2 - 1.6666654611e-1f) * t2 * t + t;
+  float cp = ((2.443315711809948e-5f * t2 - 1.388731625493765e-3f) * t2 + 4.166664568298827e-2f) * t2 * t2 - 0.5f * t2 + 1.0f;
+  switch (j & 3) {
+    case 0: *s = sp; *c = cp; break;
+    case 1: *s = cp; *c = -sp; break;
+    case 2: *s = -sp; *c = -cp; break;
+    default: *s = -cp; *c = sp; break;
+  }
+}
+
+// sin/cos of an arbitrary angle (radians) through the same kernel.
+inline void sincosr(float a, float* s, float* c)
+{
+  float r = a * 0.15915494309189533577f; // 1/(2 pi)
+  float f = r - floorf(r);               // [0,1)
+  sincos2pi(f, s, c);
+}
+
+// natural log, x > 0 (denormals handled).
+inline float logf_poly(float x)
+{
+  uint32_t b = f2u(x);
+  int e = 0;
+  if (b < 0x00800000u) { x = x * 16777216.0f; b = f2u(x); e = -24; }
+  e += (int)((b >> 23) & 0xffu) - 126;
+  float m = u2f((b & 0x007fffffu) | 0x3f000000u); // [0.5,1)
+  if (m < 0.707106781186547524f) { e -= 1; m = m + m - 1.0f; } else { m = m - 1.0f; }
+  float z = m * m;
+  float y = ((((((((7.0376836292e-2f * m - 1.1514610310e-1f) * m + 1.1676998740e-1f) * m - 1.2420140846e-1f) * m
+             + 1.4249322787e-1f) * m - 1.6668057665e-1f) * m + 2.0000714765e-1f) * m - 2.4999993993e-1f) * m
+             + 3.3333331174e-1f) * m * z;
+  float fe = (float)e;
+  y = y + (-2.12194440e-4f * fe);
+  y = y + (-0.5f * z);
+  float r = m + y;
+  r = r + 0.693359375f * fe;
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// half <-> float (glm::packHalf2x16 / GLSL unpackHalf2x16), round-to-nearest-even.
+// ---------------------------------------------------------------------------------------------
+inline uint16_t f32_to_f16(float f)
+{
+  uint32_t x = f2u(f);
+  uint32_t sign = (x >> 16) & 0x8000u;
+  uint32_t absx = x & 0x7fffffffu;
+  if (absx >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | ((absx > 0x7f800000u) ? 0x200u : 0u));
+  if (absx >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u); // overflow -> inf (>= 65520)
+  if (absx < 0x33000001u) return (uint16_t)sign;              // underflow -> 0 (<= 2^-25)
+  int exp = (int)(absx >> 23) - 127;
+  uint32_t man = (absx & 0x7fffffu) | 0x800000u;
+  if (exp < -14) { // subnormal half
+    int shift = -14 - exp + 13;
+    uint32_t r = man >> shift;
+    uint32_t rem = man & ((1u << shift) - 1u);
+    uint32_t half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (r & 1u))) r++;
+    return (uint16_t)(sign | r);
+  }
+  uint32_t r = ((uint32_t)(exp + 15) << 10) | ((man >> 13) & 0x3ffu);
+  uint32_t rem = man & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) r++;
+  return (uint16_t)(sign | r);
+}
+
+inline float f16_to_f32(uint16_t h)
+{
+  uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+  uint32_t exp = (h >> 10) & 0x1fu;
+  uint32_t man = h & 0x3ffu;
+  if (exp == 0) {
+    if (man == 0) return u2f(sign);
+    float v = (float)man * 5.9604644775390625e-8f; // 2^-24
+    return (sign ? -v : v);
+  }
+  if (exp == 31) return u2f(sign | 0x7f800000u | (man << 13));
+  return u2f(sign | ((exp + 112u) << 23) | (man << 13));
+}
+
+inline uint32_t pack_half2x16(float a, float b) { return (uint32_t)f32_to_f16(a) | ((uint32_t)f32_to_f16(b) << 16); }
+
+// ---------------------------------------------------------------------------------------------
+// common.glsl restatement
+// ---------------------------------------------------------------------------------------------
+// common.glsl:74-82 (hash_theironborn)
+inline uint32_t hash_init(uint32_t x)
+{
+  x ^= x >> 16; x *= 0x21f0aaadu; x ^= x >> 15; x *= 0xd35a2d97u; x ^= x >> 15;
+  return x;
+}
+// common.glsl:85-90; note the inout state is LCG-advanced and then the caller overwrites it
+// with the returned word (rng1d_next1f, common.glsl:92-96).
+inline uint32_t hash_pcg32(uint32_t& state)
+{
+  state = state * 747796405u + 2891336453u;
+  uint32_t word = ((state >> ((state >> 28) + 4u)) ^ state) * 277803737u;
+  return (word >> 22) ^ word;
+}
+inline float uint_as_float01(uint32_t v) { return u2f(0x3f800000u | (v >> 9)) - 1.0f; } // common.glsl:44-47
+inline float next1f(uint32_t& s) { s = hash_pcg32(s); return uint_as_float01(s); }
+inline uint32_t rng_init(uint32_t pixelIndex, uint32_t sampleIndex) { return hash_init(pixelIndex * (sampleIndex + 1u)); } // :121-124
+
+// common.glsl:128-137 (Duff et al.)
+inline void orthonormal_basis(V3 n, V3& b1, V3& b2)
+{
+  float nsign = (n.z >= 0.0f) ? 1.0f : -1.0f;
+  float a = -1.0f / (nsign + n.z);
+  float b = n.x * n.y * a;
+  b1 = v3(1.0f + nsign * n.x * n.x * a, nsign * b, -nsign * n.x);
+  b2 = v3(b, nsign + n.y * n.y * a, -n.y);
+}
+
+// common.glsl:143-162 (Waechter-Binder with origin 1/32, floatScale 1/65536, intScale 64)
+inline float offset_component(float p, float n)
+{
+  int io = (int)(n * 64.0f); // GLSL ivec3() truncates
+  int32_t pi = (int32_t)f2u(p);
+  int32_t moved = pi + ((p >= 0.0f) ? io : -io);
+  float ip = u2f((uint32_t)moved);
+  float fp = p + n * (1.0f / 65536.0f);
+  return (fabsf(p) >= (1.0f / 32.0f)) ? ip : fp;
+}
+inline V3 offset_ray_origin(V3 p, V3 n) { return v3(offset_component(p.x, n.x), offset_component(p.y, n.y), offset_component(p.z, n.z)); }
+
+// Gi.cpp:287-300 (_EncodeOctahedral/_EncodeDirection) with glm::packUnorm2x16 = round(clamp(v,0,1)*65535)
+inline uint32_t encode_direction(V3 v)
+{
+  v = normalize(v);
+  float s = fabsf(v.x) + fabsf(v.y) + fabsf(v.z);
+  v = v / s;
+  float px = v.x >= 0.0f ? 1.0f : -1.0f, py = v.y >= 0.0f ? 1.0f : -1.0f;
+  float ex, ey;
+  if (v.z < 0.0f) { ex = (1.0f - fabsf(v.y)) * px; ey = (1.0f - fabsf(v.x)) * py; } else { ex = v.x; ey = v.y; }
+  ex = ex * 0.5f + 0.5f; ey = ey * 0.5f + 0.5f;
+  ex = fmin2(fmax2(ex, 0.0f), 1.0f); ey = fmin2(fmax2(ey, 0.0f), 1.0f);
+  uint32_t ux = (uint32_t)nearbyintf(ex * 65535.0f), uy = (uint32_t)nearbyintf(ey * 65535.0f);
+  return ux | (uy << 16);
+}
+
+// common.glsl:181-207 (decode_octahedral/decode_direction); unpackUnorm2x16: c / 65535.0
+inline V3 decode_direction(uint32_t e)
+{
+  float ex = (float)(e & 0xffffu) / 65535.0f, ey = (float)(e >> 16) / 65535.0f;
+  ex = ex * 2.0f - 1.0f; ey = ey * 2.0f - 1.0f;
+  V3 v = v3(ex, ey, 1.0f - fabsf(ex) - fabsf(ey));
+  float t = fmax2(-v.z, 0.0f);
+  v.x += (v.x >= 0.0f) ? -t : t;
+  v.y += (v.y >= 0.0f) ? -t : t;
+  return normalize(v);
+}
+
+inline float luminance(V3 c) { return dot(c, v3(0.2126f, 0.7152f, 0.0722f)); } // common.glsl:254-257
+inline float safe_div(float a, float b) { return (b == 0.0f) ? 0.0f : (a / b); }        // :18-21
+inline V3 safe_div(V3 v, float f) { return (f == 0.0f) ? v3(0, 0, 0) : (v / f); }      // :23-26
+
+// common.glsl:210-220 (sample_hemisphere: cosine-weighted, z up)
+inline V3 sample_hemisphere(float x0, float x1)
+{
+  float a = sqrtf(x0);
+  float s, c; sincos2pi(x1, &s, &c);
+  return v3(a * c, a * s, sqrtf(1.0f - x0));
+}
+// common.glsl:223-230 (sample_sphere)
+inline V3 sample_sphere(float x0, float x1, V3 radius)
+{
+  float a = 1.0f - 2.0f * x0;
+  float b = sqrtf(1.0f - a * a);
+  float s, c; sincos2pi(x1, &s, &c);
+  return v3(b * c, b * s, a) * radius;
+}
+// common.glsl:233-252 (sample_disk, concentric)
+inline void sample_disk(float x0, float x1, float rx, float ry, float& ox, float& oy)
+{
+  float a = 2.0f * x0 - 1.0f, b = 2.0f * x1 - 1.0f;
+  float r0, r1, phi;
+  if ((a * a) > (b * b)) { r0 = rx * a; r1 = ry * a; phi = (ORC_PI / 4.0f) * (b / a); }
+  else { r0 = rx * b; r1 = ry * b; phi = (ORC_PI / 2.0f) - (ORC_PI / 4.0f) * safe_div(a, b); }
+  float s, c; sincosr(phi, &s, &c);
+  ox = r0 * c; oy = r1 * s;
+}
+
+// rp_main.rgen:118-130 (fisGauss, Box-Muller, sigma 0.375)
+inline void fis_gauss(float x0, float x1, float& ox, float& oy)
+{
+  float u1 = fmax2(1e-38f, x0);
+  float r = 0.375f * sqrtf(-2.0f * logf_poly(u1));
+  float s, c; sincos2pi(x1, &s, &c);
+  ox = c * r; oy = s * r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scene preparation (host packing restated)
+// ---------------------------------------------------------------------------------------------
+struct FVertex { V3 pos; float bsign; uint32_t n, t; float u, v; }; // rp_main.h:58-64
+struct Instance {
+  uint32_t mesh;
+  float o2w[12]; // rows of the 3x4 object-to-world (Gi.cpp:1191)
+  float w2o[9];  // inverse of the 3x3 part, row-major
+};
+struct Tri { V3 v0, e1, e2; uint32_t instance, prim; };
+struct MeshData { std::vector<FVertex> verts; const uint32_t* faces; uint32_t faceCount; int material; uint32_t flags; };
+
+// Light structs as the device sees them (rp_main.h:73-113), derived fields per Gi.cpp setters.
+struct SphereL { V3 pos; uint32_t ds; V3 em; float area; V3 radius; };
+struct DistantL { V3 dir; float angle; V3 em; uint32_t ds; float invPdf; };
+struct RectL { V3 origin; float width; V3 em; float height; uint32_t t0, t1, ds; };
+struct DiskL { V3 origin; float rx; V3 em; float ry; uint32_t t0, t1, ds; };
+
+struct BvhNode { float lo[3], hi[3]; uint32_t left, count; }; // count>0: leaf [left,left+count)
+
+struct Prepared {
+  std::vector<MeshData> meshes;
+  std::vector<Instance> instances;
+  std::vector<Tri> tris;
+  std::vector<SphereL> sphere; std::vector<DistantL> distant; std::vector<RectL> rect; std::vector<DiskL> disk;
+  const OrcMaterial* materials; uint32_t materialCount;
+  std::vector<BvhNode> bvh; std::vector<uint32_t> bvhTris; // used when tris.size() > 64
+};
+
+// world = local * M_prim * M_instance (USD row vectors; Gi.cpp:641-658, 1191).  Returns the 3x4 affine
+// A (column-vector form) as 12 floats, rows first.  glm mat4*mat4 order of operations.
+void compose_transform(const float* prim, const float* inst, float out[12])
+{
+  // P[r][c] row-major USD matrices.  Column-vector form: A = (P_prim * P_inst)^T.
+  // (P_prim*P_inst)[r][c] = sum_k prim[r][k]*inst[k][c]; A[c][r] = that.
+  for (int c = 0; c < 3; c++)
+    for (int r = 0; r < 4; r++) {
+      float acc = prim[r * 4 + 0] * inst[0 * 4 + c];
+      acc = acc + prim[r * 4 + 1] * inst[1 * 4 + c];
+      acc = acc + prim[r * 4 + 2] * inst[2 * 4 + c];
+      acc = acc + prim[r * 4 + 3] * inst[3 * 4 + c];
+      out[c * 4 + r] = acc;
+    }
+}
+
+void invert3x3(const float a[12], float inv[9])
+{
+  double m[3][3] = {{a[0], a[1], a[2]}, {a[4], a[5], a[6]}, {a[8], a[9], a[10]}};
+  double c00 = m[1][1] * m[2][2] - m[1][2] * m[2][1];
+  double c01 = m[1][2] * m[2][0] - m[1][0] * m[2][2];
+  double c02 = m[1][0] * m[2][1] - m[1][1] * m[2][0];
+  double det = m[0][0] * c00 + m[0][1] * c01 + m[0][2] * c02;
+  double id = 1.0 / det;
+  inv[0] = (float)(c00 * id);
+  inv[1] = (float)((m[0][2] * m[2][1] - m[0][1] * m[2][2]) * id);
+  inv[2] = (float)((m[0][1] * m[1][2] - m[0][2] * m[1][1]) * id);
+  inv[3] = (float)(c01 * id);
+  inv[4] = (float)((m[0][0] * m[2][2] - m[0][2] * m[2][0]) * id);
+  inv[5] = (float)((m[0][2] * m[1][0] - m[0][0] * m[1][2]) * id);
+  inv[6] = (float)(c02 * id);
+  inv[7] = (float)((m[0][1] * m[2][0] - m[0][0] * m[2][1]) * id);
+  inv[8] = (float)((m[0][0] * m[1][1] - m[0][1] * m[1][0]) * id);
+}
+
+// gl_ObjectToWorldEXT * vec4(p, w)
+inline V3 xform_point(const float a[12], V3 p, float w)
+{
+  return v3(((a[0] * p.x + a[1] * p.y) + a[2] * p.z) + a[3] * w,
+            ((a[4] * p.x + a[5] * p.y) + a[6] * p.z) + a[7] * w,
+            ((a[8] * p.x + a[9] * p.y) + a[10] * p.z) + a[11] * w);
+}
+// v * mat3(gl_WorldToObjectEXT)  == transpose(inv3x3) * v
+inline V3 xform_normal(const float w[9], V3 n)
+{
+  return v3((n.x * w[0] + n.y * w[3]) + n.z * w[6],
+            (n.x * w[1] + n.y * w[4]) + n.z * w[7],
+            (n.x * w[2] + n.y * w[5]) + n.z * w[8]);
+}
+
+void build_bvh(Prepared& P);
+
+void prepare(const OrcScene* s, Prepared& P)
+{
+  P.materials = s->materials; P.materialCount = s->materialCount;
+  P.meshes.resize(s->meshCount);
+  for (uint32_t mi = 0; mi < s->meshCount; mi++) {
+    const OrcMesh& m = s->meshes[mi];
+    MeshData& d = P.meshes[mi];
+    d.faces = m.faces; d.faceCount = m.faceCount; d.material = m.material;
+    d.flags = (m.isLeftHanded ? 1u : 0u) | (m.isDoubleSided ? 2u : 0u); // rp_main.h:115-116
+    d.verts.resize(m.vertexCount);
+    for (uint32_t i = 0; i < m.vertexCount; i++) { // Gi.cpp:848-861
+      const OrcVertex& v = m.vertices[i];
+      d.verts[i] = FVertex{v3(v.pos), v.bitangentSign, encode_direction(v3(v.norm)), encode_direction(v3(v.tangent)), v.u, v.v};
+    }
+    if (!m.visible || m.faceCount == 0 || m.material < 0) continue; // Gi.cpp:801-804, 818-822, 834-837
+    for (uint32_t ii = 0; ii < m.instanceCount; ii++) {             // Gi.cpp:1188-1202
+      Instance inst; inst.mesh = mi;
+      compose_transform(m.transform, m.instanceTransforms + 16 * ii, inst.o2w);
+      invert3x3(inst.o2w, inst.w2o);
+      uint32_t instIdx = (uint32_t)P.instances.size();
+      P.instances.push_back(inst);
+      for (uint32_t f = 0; f < m.faceCount; f++) {
+        V3 p0 = xform_point(inst.o2w, d.verts[m.faces[3 * f + 0]].pos, 1.0f);
+        V3 p1 = xform_point(inst.o2w, d.verts[m.faces[3 * f + 1]].pos, 1.0f);
+        V3 p2 = xform_point(inst.o2w, d.verts[m.faces[3 * f + 2]].pos, 1.0f);
+        P.tris.push_back(Tri{p0, p1 - p0, p2 - p0, instIdx, f});
+      }
+    }
+  }
+  for (uint32_t i = 0; i < s->sphereLightCount; i++) { // Gi.cpp:2573-2666
+    const OrcSphereLight& l = s->sphereLights[i];
+    float ab = powf(l.radius[0] * l.radius[1], 1.6f), ac = powf(l.radius[0] * l.radius[2], 1.6f), bc = powf(l.radius[1] * l.radius[2], 1.6f);
+    float area = (float)(powf((ab + ac + bc) / 3.0f, 1.0f / 1.6f) * 4.0f * M_PI);
+    P.sphere.push_back(SphereL{v3(l.pos), pack_half2x16(l.diffuse, l.specular), v3(l.baseEmission), area, v3(l.radius)});
+  }
+  for (uint32_t i = 0; i < s->distantLightCount; i++) { // Gi.cpp:2668-2746
+    const OrcDistantLight& l = s->distantLights[i];
+    float half = 0.5f * l.angle;
+    float invPdf = (half > 0.0f) ? (float)(2.0f * M_PI * (1.0f - cosf(half))) : 1.0f;
+    P.distant.push_back(DistantL{v3(l.direction), l.angle, v3(l.baseEmission), pack_half2x16(l.diffuse, l.specular), invPdf});
+  }
+  for (uint32_t i = 0; i < s->rectLightCount; i++) { // Gi.cpp:2748-2850
+    const OrcRectLight& l = s->rectLights[i];
+    P.rect.push_back(RectL{v3(l.origin), l.width, v3(l.baseEmission), l.height, encode_direction(v3(l.t0)), encode_direction(v3(l.t1)), pack_half2x16(l.diffuse, l.specular)});
+  }
+  for (uint32_t i = 0; i < s->diskLightCount; i++) { // Gi.cpp:2852-2940
+    const OrcDiskLight& l = s->diskLights[i];
+    P.disk.push_back(DiskL{v3(l.origin), l.radiusX, v3(l.baseEmission), l.radiusY, encode_direction(v3(l.t0)), encode_direction(v3(l.t1)), pack_half2x16(l.diffuse, l.specular)});
+  }
+  if (P.tris.size() > 64) build_bvh(P);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Traversal.  The reference uses the HW (traceRayEXT, rp_main.rgen:381-393/412-424); this is
+// the software contract: two-sided Moeller-Trumbore in world space on pre-transformed
+// triangles, accept tMin < t < tBest, ties broken towards the lower global triangle index.
+// ---------------------------------------------------------------------------------------------
+struct Hit { float t, u, v; uint32_t tri; };
+
+inline bool tri_test(const Tri& T, V3 o, V3 d, float tMin, float& tBest, uint32_t idx, Hit& h)
+{
+  V3 pv = cross(d, T.e2);
+  float det = dot(T.e1, pv);
+  if (det == 0.0f) return false;
+  float inv = 1.0f / det;
+  V3 tv = o - T.v0;
+  float u = dot(tv, pv) * inv;
+  if (!(u >= 0.0f)) return false;
+  V3 qv = cross(tv, T.e1);
+  float v = dot(d, qv) * inv;
+  if (!(v >= 0.0f) || !(u + v <= 1.0f)) return false;
+  float t = dot(T.e2, qv) * inv;
+  if (!(t > tMin)) return false;
+  if (t < tBest || (t == tBest && h.tri != 0xffffffffu && idx < h.tri)) { tBest = t; h = Hit{t, u, v, idx}; return true; }
+  return false;
+}
+
+void build_bvh_rec(Prepared& P, uint32_t node, uint32_t begin, uint32_t end, const std::vector<V3>& lo, const std::vector<V3>& hi)
+{
+  BvhNode& n = P.bvh[node];
+  for (int a = 0; a < 3; a++) { n.lo[a] = ORC_FLT_MAX; n.hi[a] = -ORC_FLT_MAX; }
+  float clo[3] = {ORC_FLT_MAX, ORC_FLT_MAX, ORC_FLT_MAX}, chi[3] = {-ORC_FLT_MAX, -ORC_FLT_MAX, -ORC_FLT_MAX};
+  for (uint32_t i = begin; i < end; i++) {
+    uint32_t t = P.bvhTris[i];
+    const float l[3] = {lo[t].x, lo[t].y, lo[t].z}, h[3] = {hi[t].x, hi[t].y, hi[t].z};
+    for (int a = 0; a < 3; a++) {
+      n.lo[a] = fmin2(n.lo[a], l[a]); n.hi[a] = fmax2(n.hi[a], h[a]);
+      float c = 0.5f * (l[a] + h[a]); clo[a] = fmin2(clo[a], c); chi[a] = fmax2(chi[a], c);
+    }
+  }
+  if (end - begin <= 4) { n.left = begin; n.count = end - begin; return; }
+  int axis = 0; float ext = chi[0] - clo[0];
+  for (int a = 1; a < 3; a++) if (chi[a] - clo[a] > ext) { ext = chi[a] - clo[a]; axis = a; }
+  uint32_t mid = (begin + end) / 2;
+  auto key = [&](uint32_t t) { const float l[3] = {lo[t].x, lo[t].y, lo[t].z}, h[3] = {hi[t].x, hi[t].y, hi[t].z}; return l[axis] + h[axis]; };
+  std::nth_element(P.bvhTris.begin() + begin, P.bvhTris.begin() + mid, P.bvhTris.begin() + end,
+                   [&](uint32_t a, uint32_t b) { return key(a) < key(b); });
+  uint32_t left = (uint32_t)P.bvh.size();
+  P.bvh.push_back(BvhNode{}); P.bvh.push_back(BvhNode{});
+  P.bvh[node].left = left; P.bvh[node].count = 0;
+  build_bvh_rec(P, left, begin, mid, lo, hi);
+  build_bvh_rec(P, left + 1, mid, end, lo, hi);
+}
+
+void build_bvh(Prepared& P)
+{
+  size_t n = P.tris.size();
+  std::vector<V3> lo(n), hi(n);
+  for (size_t i = 0; i < n; i++) {
+    const Tri& T = P.tris[i];
+    V3 a = T.v0, b = T.v0 + T.e1, c = T.v0 + T.e2;
+    lo[i] = v3(fmin2(a.x, fmin2(b.x, c.x)), fmin2(a.y, fmin2(b.y, c.y)), fmin2(a.z, fmin2(b.z, c.z)));
+    hi[i] = v3(fmax2(a.x, fmax2(b.x, c.x)), fmax2(a.y, fmax2(b.y, c.y)), fmax2(a.z, fmax2(b.z, c.z)));
+    // generous conservative padding: the box test must never cull a triangle tri_test would accept
+    V3 pad = v3(1e-4f * (1.0f + fabsf(hi[i].x - lo[i].x) + fabsf(hi[i].x)), 1e-4f * (1.0f + fabsf(hi[i].y - lo[i].y) + fabsf(hi[i].y)),
+                1e-4f * (1.0f + fabsf(hi[i].z - lo[i].z) + fabsf(hi[i].z)));
+    lo[i] = lo[i] - pad; hi[i] = hi[i] + pad;
+  }
+  P.bvhTris.resize(n);
+  for (size_t i = 0; i < n; i++) P.bvhTris[i] = (uint32_t)i;
+  P.bvh.reserve(2 * n);
+  P.bvh.push_back(BvhNode{});
+  build_bvh_rec(P, 0, 0, (uint32_t)n, lo, hi);
+}
+
+inline bool box_test(const BvhNode& n, V3 o, V3 inv, float tMin, float tMax)
+{
+  float t0 = tMin, t1 = tMax;
+  const float oo[3] = {o.x, o.y, o.z}, ii[3] = {inv.x, inv.y, inv.z};
+  for (int a = 0; a < 3; a++) {
+    float ta = (n.lo[a] - oo[a]) * ii[a], tb = (n.hi[a] - oo[a]) * ii[a];
+    if (ta > tb) { float x = ta; ta = tb; tb = x; }
+    if (ta != ta || tb != tb) continue; // 0*inf: ray inside slab plane -> do not cull
+    t0 = fmax2(t0, ta); t1 = fmin2(t1, tb);
+  }
+  return t0 <= t1 * 1.0001f + 1e-6f;
+}
+
+bool trace_closest(const Prepared& P, V3 o, V3 d, float tMin, float tMax, Hit& h)
+{
+  float tBest = tMax; bool any = false; h.tri = 0xffffffffu;
+  // accept tMin < t < tMax; h.tri == ~0 marks 'no hit yet' so the tie rule cannot admit t == tMax
+  if (P.bvh.empty()) {
+    for (uint32_t i = 0; i < P.tris.size(); i++) any |= tri_test(P.tris[i], o, d, tMin, tBest, i, h);
+    return any;
+  }
+  V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  uint32_t stack[128]; int sp = 0; stack[sp++] = 0;
+  while (sp) {
+    const BvhNode& n = P.bvh[stack[--sp]];
+    if (!box_test(n, o, inv, tMin, tBest)) continue;
+    if (n.count) { for (uint32_t i = n.left; i < n.left + n.count; i++) { uint32_t t = P.bvhTris[i]; any |= tri_test(P.tris[t], o, d, tMin, tBest, t, h); } }
+    else { stack[sp++] = n.left; stack[sp++] = n.left + 1; }
+  }
+  return any;
+}
+
+// Shadow rays: gl_RayFlagsTerminateOnFirstHitEXT (rp_main.rgen:405); any hit in (tMin,tMax) occludes.
+bool trace_any(const Prepared& P, V3 o, V3 d, float tMin, float tMax)
+{
+  Hit h; return trace_closest(P, o, d, tMin, tMax, h);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Shading state (mdl_shading_state.glsl:4-98)
+// ---------------------------------------------------------------------------------------------
+struct State { V3 normal, geomNormal, position, tangentU, tangentV; float u, v; bool frontFace; };
+
+void setup_shading_state(const Prepared& P, const Hit& h, V3 rayDir, State& st, const MeshData*& meshOut)
+{
+  const Tri& T = P.tris[h.tri];
+  const Instance& inst = P.instances[T.instance];
+  const MeshData& m = P.meshes[inst.mesh];
+  meshOut = &m;
+  const FVertex& a = m.verts[m.faces[3 * T.prim + 0]];
+  const FVertex& b = m.verts[m.faces[3 * T.prim + 1]];
+  const FVertex& c = m.verts[m.faces[3 * T.prim + 2]];
+  float bx = 1.0f - h.u - h.v, by = h.u, bz = h.v;                        // :17
+  V3 localPos = (a.pos * bx + b.pos * by) + c.pos * bz;                  // :24
+  st.position = xform_point(inst.o2w, localPos, 1.0f);                   // :25
+  V3 gn = normalize(cross(b.pos - a.pos, c.pos - a.pos));                // :27
+  gn = normalize(xform_normal(inst.w2o, gn));                            // :28
+  V3 n0 = decode_direction(a.n), n1 = decode_direction(b.n), n2 = decode_direction(c.n); // :31-33
+  V3 ln = normalize((n0 * bx + n1 * by) + n2 * bz);                      // :35
+  V3 n = normalize(xform_normal(inst.w2o, ln));                          // :36
+  st.frontFace = dot(gn, -rayDir) >= 0.0f;                               // :39
+  if (!st.frontFace) { gn = -gn; n = -n; }                               // :41-45
+  V3 t0 = decode_direction(a.t), t1 = decode_direction(b.t), t2 = decode_direction(c.t); // :48-50
+  V3 lt = normalize((t0 * bx + t1 * by) + t2 * bz);                      // :52
+  V3 tg = normalize(xform_point(inst.o2w, lt, 0.0f));                    // :53
+  tg = normalize(tg - n * dot(tg, n));                                   // :56
+  float bs = (bx * a.bsign + by * b.bsign) + bz * c.bsign;               // :58
+  st.tangentU = tg; st.tangentV = cross(n, tg) * bs;                     // :59
+  st.u = (bx * a.u + by * b.u) + bz * c.u; st.v = (bx * a.v + by * b.v) + bz * c.v; // :62-65
+  st.normal = n; st.geomNormal = gn;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Closed-form BSDFs (replace the MDL-generated mdl_bsdf_scattering_* entry points,
+// GlslShaderGen.cpp:181-193; contracts from mdl_types.glsl:158-238).  OUR definitions -- the
+// reference arithmetic lives in the MDL SDK and is unpinned (DESIGN.md section "Materials").
+// ---------------------------------------------------------------------------------------------
+enum { EV_ABSORB = 0, EV_DIFFUSE = 1, EV_GLOSSY = 2, EV_SPECULAR = 4, EV_REFLECTION = 8, EV_TRANSMISSION = 16 }; // mdl_types.glsl:123-137
+
+struct BsdfSample { V3 k2; V3 overPdf; float pdf; uint32_t event; };
+struct BsdfEval { V3 diffuse, glossy; float pdf; };
+
+inline V3 to_world(const State& st, V3 l) { return (st.tangentU * l.x + st.tangentV * l.y) + st.normal * l.z; }
+inline V3 to_local(const State& st, V3 w) { return v3(dot(w, st.tangentU), dot(w, st.tangentV), dot(w, st.normal)); }
+
+inline float schlick_w(float c) { float m = 1.0f - c; m = fmin2(fmax2(m, 0.0f), 1.0f); float m2 = m * m; return m2 * m2 * m; }
+inline float ggx_lambda_term(float a2, float c) { return sqrtf(a2 + (1.0f - a2) * c * c); }
+
+// GGX-Smith reflection lobe with VNDF sampling (Heitz 2018), isotropic alpha, local frame z = normal.
+struct GgxOut { V3 l2; float pdf; float g2OverG1; float kh; bool valid; };
+inline GgxOut ggx_sample(V3 l1, float alpha, float x0, float x1)
+{
+  GgxOut o; o.valid = false;
+  V3 vh = normalize(v3(alpha * l1.x, alpha * l1.y, l1.z));
+  float lensq = vh.x * vh.x + vh.y * vh.y;
+  V3 T1 = lensq > 0.0f ? v3(-vh.y, vh.x, 0.0f) * (1.0f / sqrtf(lensq)) : v3(1.0f, 0.0f, 0.0f);
+  V3 T2 = cross(vh, T1);
+  float r = sqrtf(x0);
+  float s, c; sincos2pi(x1, &s, &c);
+  float t1 = r * c, t2 = r * s;
+  float sm = 0.5f * (1.0f + vh.z);
+  t2 = (1.0f - sm) * sqrtf(fmax2(0.0f, 1.0f - t1 * t1)) + sm * t2;
+  V3 nh = (T1 * t1 + T2 * t2) + vh * sqrtf(fmax2(0.0f, (1.0f - t1 * t1) - t2 * t2));
+  V3 h = normalize(v3(alpha * nh.x, alpha * nh.y, fmax2(0.0f, nh.z)));
+  float kh = dot(l1, h);
+  V3 l2 = h * (2.0f * kh) - l1;
+  if (!(l2.z > 0.0f) || !(kh > 0.0f)) return o;
+  float a2 = alpha * alpha;
+  float nk1 = l1.z, nk2 = l2.z, nh2 = h.z * h.z;
+  float dd = nh2 * (a2 - 1.0f) + 1.0f;
+  float D = a2 / (ORC_PI * dd * dd);
+  float L1 = ggx_lambda_term(a2, nk1), L2 = ggx_lambda_term(a2, nk2);
+  float G1 = 2.0f * nk1 / (nk1 + L1);
+  float G2 = 2.0f * nk1 * nk2 / (nk2 * L1 + nk1 * L2);
+  o.l2 = l2; o.kh = kh; o.pdf = G1 * D / (4.0f * nk1); o.g2OverG1 = G2 / G1; o.valid = true;
+  return o;
+}
+// returns f*cos (without Fresnel) and pdf for given directions.
+inline void ggx_eval(V3 l1, V3 l2, float alpha, float& fcos, float& pdf, float& kh)
+{
+  fcos = 0.0f; pdf = 0.0f; kh = 0.0f;
+  if (!(l1.z > 0.0f) || !(l2.z > 0.0f)) return;
+  V3 h = normalize(l1 + l2);
+  kh = dot(l1, h);
+  float a2 = alpha * alpha;
+  float nk1 = l1.z, nk2 = l2.z, nh2 = h.z * h.z;
+  float dd = nh2 * (a2 - 1.0f) + 1.0f;
+  float D = a2 / (ORC_PI * dd * dd);
+  float L1 = ggx_lambda_term(a2, nk1), L2 = ggx_lambda_term(a2, nk2);
+  float G1 = 2.0f * nk1 / (nk1 + L1);
+  float G2 = 2.0f * nk1 * nk2 / (nk2 * L1 + nk1 * L2);
+  fcos = D * G2 / (4.0f * nk1);
+  pdf = G1 * D / (4.0f * nk1);
+}
+
+struct UpsParams { V3 albedo, F0; float alpha, coat, coatAlpha; };
+inline UpsParams ups_params(const OrcMaterial& m)
+{
+  UpsParams u;
+  V3 dc = v3(m.p + ORC_P_BASE_COLOR);
+  float r = m.p[ORC_P_ROUGHNESS], cr = m.p[ORC_P_CLEARCOAT_ROUGHNESS];
+  u.alpha = fmax2(r * r, 0.001f);
+  u.coatAlpha = fmax2(cr * cr, 0.001f);
+  u.coat = m.p[ORC_P_CLEARCOAT];
+  if (m.p[ORC_P_USE_SPECULAR_WORKFLOW] != 0.0f) { u.F0 = v3(m.p + ORC_P_SPECULAR_COLOR); u.albedo = dc; }
+  else {
+    float ior = m.p[ORC_P_IOR], metal = m.p[ORC_P_METALLIC];
+    float q = (1.0f - ior) / (1.0f + ior); float f0 = q * q;
+    u.F0 = v3(f0, f0, f0) * (1.0f - metal) + dc * metal;
+    u.albedo = dc * (1.0f - metal);
+  }
+  return u;
+}
+inline V3 schlick3(V3 F0, float c) { float w = schlick_w(c); return F0 + (v3(1, 1, 1) - F0) * w; }
+
+void bsdf_sample(const OrcMaterial& m, const State& st, V3 k1, const float xi[4], BsdfSample& out)
+{
+  out.event = EV_ABSORB; out.pdf = 0.0f; out.overPdf = v3(0, 0, 0); out.k2 = v3(0, 0, 0);
+  if (m.klass == ORC_MAT_DIFFUSE) {
+    V3 l = sample_hemisphere(xi[0], xi[1]);
+    V3 k2 = to_world(st, l);
+    if (!(l.z > 0.0f) || !(dot(k2, st.geomNormal) > 0.0f)) return;
+    out.k2 = k2; out.pdf = l.z / ORC_PI; out.overPdf = v3(m.p + ORC_P_BASE_COLOR); out.event = EV_DIFFUSE | EV_REFLECTION;
+    return;
+  }
+  if (m.klass == ORC_MAT_USD_PREVIEW_SURFACE) {
+    UpsParams u = ups_params(m);
+    V3 l1 = to_local(st, k1);
+    float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
+    float z = xi[2];
+    float Fc = u.coat * (0.04f + 0.96f * schlick_w(nk1));
+    if (z < Fc) {
+      GgxOut g = ggx_sample(l1, u.coatAlpha, xi[0], xi[1]);
+      V3 k2 = to_world(st, g.l2);
+      if (!g.valid || !(dot(k2, st.geomNormal) > 0.0f)) return;
+      float Fh = u.coat * (0.04f + 0.96f * schlick_w(g.kh));
+      float w = (Fh / Fc) * g.g2OverG1;
+      out.k2 = k2; out.pdf = Fc * g.pdf; out.overPdf = v3(w, w, w); out.event = EV_GLOSSY | EV_REFLECTION;
+      return;
+    }
+    z = (z - Fc) / (1.0f - Fc);
+    V3 Fs = schlick3(u.F0, nk1);
+    float ps = fmax2(Fs.x, fmax2(Fs.y, Fs.z));
+    if (z < ps) {
+      GgxOut g = ggx_sample(l1, u.alpha, xi[0], xi[1]);
+      V3 k2 = to_world(st, g.l2);
+      if (!g.valid || !(dot(k2, st.geomNormal) > 0.0f)) return;
+      V3 Fh = schlick3(u.F0, g.kh);
+      out.k2 = k2; out.pdf = (1.0f - Fc) * ps * g.pdf; out.overPdf = Fh * (g.g2OverG1 / ps); out.event = EV_GLOSSY | EV_REFLECTION;
+      return;
+    }
+    V3 l = sample_hemisphere(xi[0], xi[1]);
+    V3 k2 = to_world(st, l);
+    if (!(l.z > 0.0f) || !(dot(k2, st.geomNormal) > 0.0f)) return;
+    out.k2 = k2; out.pdf = (1.0f - Fc) * (1.0f - ps) * (l.z / ORC_PI);
+    out.overPdf = (u.albedo * (v3(1, 1, 1) - Fs)) * (1.0f / (1.0f - ps));
+    out.event = EV_DIFFUSE | EV_REFLECTION;
+    return;
+  }
+}
+
+void bsdf_evaluate(const OrcMaterial& m, const State& st, V3 k1, V3 k2, BsdfEval& out)
+{
+  out.diffuse = v3(0, 0, 0); out.glossy = v3(0, 0, 0); out.pdf = 0.0f;
+  float nk2 = dot(st.normal, k2);
+  if (!(nk2 > 0.0f)) return;
+  if (m.klass == ORC_MAT_DIFFUSE) {
+    float c = nk2 / ORC_PI;
+    out.diffuse = v3(m.p + ORC_P_BASE_COLOR) * c; out.pdf = c;
+    return;
+  }
+  if (m.klass == ORC_MAT_USD_PREVIEW_SURFACE) {
+    UpsParams u = ups_params(m);
+    V3 l1 = to_local(st, k1), l2 = to_local(st, k2);
+    float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
+    float Fc = u.coat * (0.04f + 0.96f * schlick_w(nk1));
+    V3 Fs = schlick3(u.F0, nk1);
+    float ps = fmax2(Fs.x, fmax2(Fs.y, Fs.z));
+    float fc, pc, khc; ggx_eval(l1, l2, u.coatAlpha, fc, pc, khc);
+    float fs, pss, khs; ggx_eval(l1, l2, u.alpha, fs, pss, khs);
+    float Fch = u.coat * (0.04f + 0.96f * schlick_w(khc));
+    V3 Fsh = schlick3(u.F0, khs);
+    float cd = l2.z / ORC_PI;
+    out.glossy = v3(Fch * fc, Fch * fc, Fch * fc) + (Fsh * fs) * (1.0f - Fc);
+    out.diffuse = (u.albedo * (v3(1, 1, 1) - Fs)) * (cd * (1.0f - Fc));
+    out.pdf = Fc * pc + (1.0f - Fc) * (ps * pss + (1.0f - ps) * cd);
+    return;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Light sampling (rp_main.chit:30-129)
+// ---------------------------------------------------------------------------------------------
+struct Uniforms {
+  uint32_t sphereCount, distantCount, rectCount, diskCount, total;
+  float lightIntensityMultiplier, sensorExposureScale;
+};
+
+void sample_light(const Prepared& P, const Uniforms& ubo, const float k4[4], V3 surfacePos,
+                  V3& dirToLight, float& dist, V3& power, float& invPdf, uint32_t& dsPacked)
+{
+  float sel = k4[0] * (float)ubo.total;
+  if (sel <= (float)ubo.sphereCount) { // :32-53
+    uint32_t idx = (uint32_t)(k4[1] * (float)ubo.sphereCount);
+    uint32_t last = ubo.sphereCount - 1u; if (idx > last) idx = last;
+    SphereL l = idx < P.sphere.size() ? P.sphere[idx] : SphereL{v3(0, 0, 0), 0, v3(0, 0, 0), 0.0f, v3(0, 0, 0)}; // zero-filled store (SyncBuffer.cpp:90)
+    V3 samplePos = l.pos + sample_sphere(k4[2], k4[3], l.radius);
+    V3 dir = samplePos - surfacePos;
+    dist = length(dir);
+    dirToLight = safe_div(dir, dist);
+    V3 ln = normalize(samplePos - l.pos);
+    float cosTheta = fmax2(0.0f, dot(-dirToLight, ln));
+    invPdf = safe_div((l.area > 0.0f) ? (l.area * cosTheta) : 1.0f, dist * dist);
+    power = l.em * ubo.lightIntensityMultiplier; dsPacked = l.ds;
+  } else if (sel <= (float)(ubo.sphereCount + ubo.distantCount)) { // :54-77
+    uint32_t idx = (uint32_t)(k4[1] * (float)ubo.distantCount);
+    uint32_t last = ubo.distantCount - 1u; if (idx > last) idx = last;
+    const DistantL& l = P.distant[idx];
+    dist = 100000.0f; dirToLight = -l.dir;
+    power = l.em * ubo.lightIntensityMultiplier; invPdf = l.invPdf; dsPacked = l.ds;
+    if (l.angle > 0.0f) {
+      V3 t1, t2; orthonormal_basis(dirToLight, t1, t2);
+      float phi = (k4[2] * 2.0f * ORC_PI) - ORC_PI;
+      float theta = k4[3] * l.angle;
+      float sp, cp, stt, ct; sincosr(phi, &sp, &cp); sincosr(theta, &stt, &ct);
+      dirToLight = normalize((t1 * cp + t2 * sp) * stt + dirToLight * ct);
+    }
+  } else if (sel <= (float)(ubo.sphereCount + ubo.distantCount + ubo.rectCount)) { // :78-103
+    uint32_t idx = (uint32_t)(k4[1] * (float)ubo.rectCount);
+    uint32_t last = ubo.rectCount - 1u; if (idx > last) idx = last;
+    const RectL& l = P.rect[idx];
+    float sx = (k4[2] - 0.5f) * l.width, sy = (k4[3] - 0.5f) * l.height;
+    V3 t0 = decode_direction(l.t0), t1 = decode_direction(l.t1);
+    V3 samplePos = (l.origin + t0 * sx) + t1 * sy;
+    V3 dir = samplePos - surfacePos;
+    dist = length(dir); dirToLight = safe_div(dir, dist);
+    V3 ln = cross(t1, t0);
+    float cosTheta = fmax2(0.0f, dot(-dirToLight, ln));
+    float area = l.width * l.height;
+    invPdf = safe_div((area > 0.0f) ? (area * cosTheta) : 1.0f, dist * dist);
+    power = l.em * ubo.lightIntensityMultiplier; dsPacked = l.ds;
+  } else { // :104-127
+    uint32_t idx = (uint32_t)(k4[1] * (float)ubo.diskCount);
+    uint32_t last = ubo.diskCount - 1u; if (idx > last) idx = last;
+    const DiskL& l = P.disk[idx];
+    float sx, sy; sample_disk(k4[2], k4[3], l.rx, l.ry, sx, sy);
+    V3 t0 = decode_direction(l.t0), t1 = decode_direction(l.t1);
+    V3 samplePos = (l.origin + t0 * sx) + t1 * sy;
+    V3 dir = samplePos - surfacePos;
+    dist = length(dir); dirToLight = safe_div(dir, dist);
+    V3 ln = cross(t1, t0);
+    float cosTheta = fmax2(0.0f, dot(-dirToLight, ln));
+    float area = l.rx * l.ry * ORC_PI;
+    invPdf = safe_div((area > 0.0f) ? (area * cosTheta) : 1.0f, dist * dist);
+    power = l.em * ubo.lightIntensityMultiplier; dsPacked = l.ds;
+  }
+  power = power * ubo.sensorExposureScale; // :126 (exp2(sensorExposure))
+  invPdf = invPdf * (float)ubo.total;      // :127
+}
+
+// ---------------------------------------------------------------------------------------------
+// The per-pixel megakernel (rp_main.rgen:185-521 with rp_main.chit/.miss inlined)
+// ---------------------------------------------------------------------------------------------
+struct Payload { // rp_main_payload.glsl:20-48
+  V3 throughput; uint32_t bitfield; V3 radiance; uint32_t rng; V3 origin, dir, neeToLight, neeContrib;
+};
+const uint32_t BOUNCES_MASK = 0x00000fffu, TERMINATE_FLAG = 0x80000000u, MEDIUM_MASK = 0x0f000000u; // rp_main_payload.glsl:3-9
+
+struct Frame {
+  const Prepared* P; const OrcCamera* cam; const OrcSettings* rs; Uniforms ubo;
+  V3 camPos, camFwd, camUp, camRight, L; float WX, HY; float lensRadius; V3 background; float clipNear, clipFar;
+  uint32_t width, height;
+};
+
+// rp_main.chit:132-493
+void closest_hit(const Frame& F, const Hit& h, Payload& pl, float hitT)
+{
+  const Prepared& P = *F.P;
+  State st; const MeshData* mesh;
+  V3 rayDir = pl.dir;
+  setup_shading_state(P, h, rayDir, st, mesh);
+  const OrcMaterial& mat = P.materials[mesh->material];
+  bool isLeftHanded = (mesh->flags & 1u) != 0, isDoubleSided = (mesh->flags & 2u) != 0;
+  V3 throughput = pl.throughput, radiance = pl.radiance;
+  (void)hitT; (void)isLeftHanded; // medium attenuation (:160-186) needs volume coefficients: not in the supported classes
+
+  // 5. emission (:293-343).  uniform EDF: edf*intensity == emission colour, pdf>0 iff cos>0
+  V3 em = v3(mat.p + ORC_P_EMISSION);
+  if (em.x != 0.0f || em.y != 0.0f || em.z != 0.0f) {
+    if (st.frontFace || !isDoubleSided) {
+      float c = dot(-rayDir, st.normal);
+      if (c > 0.0f) radiance = radiance + throughput * (em * F.ubo.sensorExposureScale);
+    }
+  }
+
+  // 6. BSDF importance sampling (:361-389)
+  float xi[4]; xi[0] = next1f(pl.rng); xi[1] = next1f(pl.rng); xi[2] = next1f(pl.rng); xi[3] = next1f(pl.rng);
+  BsdfSample bs; bsdf_sample(mat, st, -rayDir, xi, bs);
+  uint32_t eventType = bs.event;
+  throughput = throughput * bs.overPdf;
+  pl.dir = bs.k2;
+  bool isTransmission = (eventType & EV_TRANSMISSION) != 0;
+
+  // 7. NEE (:394-444)
+  if (F.rs->nextEventEstimation) {
+    if ((eventType & (EV_DIFFUSE | EV_GLOSSY)) != 0) {
+      float k4[4]; k4[0] = next1f(pl.rng); k4[1] = next1f(pl.rng); k4[2] = next1f(pl.rng); k4[3] = next1f(pl.rng);
+      V3 dirToLight; float lightDist; V3 lightPower; float invPdf; uint32_t ds;
+      sample_light(P, F.ubo, k4, st.position, dirToLight, lightDist, lightPower, invPdf, ds);
+      V3 nee = v3(0, 0, 0);
+      bool valid = (lightDist > 0.0f) && dot(dirToLight, st.geomNormal) > 0.0f;
+      if (valid) {
+        BsdfEval ev; bsdf_evaluate(mat, st, -rayDir, dirToLight, ev);
+        if (ev.pdf > 0.0f) {
+          float d = f16_to_f32((uint16_t)(ds & 0xffffu)), s = f16_to_f32((uint16_t)(ds >> 16));
+          V3 weight = throughput * (lightPower * invPdf);
+          nee = nee + (weight * ev.diffuse) * d;
+          nee = nee + (weight * ev.glossy) * s;
+        }
+      }
+      pl.neeToLight = dirToLight * lightDist;
+      pl.neeContrib = nee;
+    }
+  }
+  // medium toggle (:447-480) only on transmission: none of the supported classes transmit yet
+  if (eventType == EV_ABSORB) pl.bitfield |= TERMINATE_FLAG; // :483-486
+  V3 gn = st.geomNormal * (isTransmission ? -1.0f : 1.0f);
+  pl.origin = offset_ray_origin(st.position, gn);              // :488-489
+  pl.throughput = throughput; pl.radiance = radiance;
+}
+
+// rp_main.miss:55-86 with the 1x1 fallback dome (Gi.cpp:2184-2199, 2232-2238): texel = u8(clear*255)/255
+void miss(const Frame& F, Payload& pl)
+{
+  pl.bitfield |= TERMINATE_FLAG;
+  pl.radiance = pl.radiance + pl.throughput * F.background;
+}
+
+void render_pixel(const Frame& F, uint32_t px, uint32_t py, const float* prevColor, float* out, OrcCounters& cnt)
+{
+  const OrcSettings& rs = *F.rs;
+  uint32_t pixelIndex = px + py * F.width; // rp_main.rgen:195
+  float invSpp = 1.0f / (float)rs.spp;
+  V3 pixelColor = v3(0, 0, 0);
+  uint32_t maxBounces = rs.maxBounces < BOUNCES_MASK ? rs.maxBounces : BOUNCES_MASK; // :292
+  for (uint32_t s = 0; s < rs.spp; s++) { // :215
+    uint32_t sampleIndex = rs.sampleOffset + s;
+    uint32_t rng = rng_init(pixelIndex, sampleIndex);
+    float r0 = next1f(rng), r1 = next1f(rng); // :224 (always drawn)
+    float sox = 0.5f, soy = 0.5f;
+    if (rs.jitteredSampling) {
+      if (rs.filterImportanceSampling) { float gx, gy; fis_gauss(r0, r1, gx, gy); sox = 0.5f + gx; soy = 0.5f + gy; }
+      else { sox = r0; soy = r1; }
+    }
+    V3 Pp = (F.L + (F.camRight * ((float)px + sox)) * F.WX) + (F.camUp * ((float)py + soy)) * F.HY; // :239-242 (GLSL evaluates left to right)
+    V3 origin = F.camPos;
+    V3 dir = normalize(Pp - origin);
+    if (rs.depthOfField && F.lensRadius > 0.0f) { // :249-263
+      float z0 = next1f(rng), z1 = next1f(rng);
+      V3 focal = origin + dir * F.cam->focusDistance;
+      V3 ap = sample_hemisphere(z0, z1);
+      origin = origin + F.camRight * (ap.x * F.lensRadius);
+      origin = origin + F.camUp * (ap.y * F.lensRadius);
+      dir = normalize(focal - origin);
+    }
+    if (dir.x == 0.0f) dir.x += ORC_FLT_MIN; // :271
+    if (dir.y == 0.0f) dir.y += ORC_FLT_MIN;
+    if (dir.z == 0.0f) dir.z += ORC_FLT_MIN;
+    Payload pl; pl.throughput = v3(1, 1, 1); pl.bitfield = 0; pl.radiance = v3(0, 0, 0); pl.rng = rng;
+    pl.origin = origin; pl.dir = dir; pl.neeToLight = v3(0, 0, 0); pl.neeContrib = v3(0, 0, 0);
+    float cosCone = fmax2(1e-5f, dot(dir, F.camFwd)); // :287
+    float clipNear = F.clipNear / cosCone, clipFar = F.clipFar / cosCone;
+    while (true) { // :295
+      uint32_t bounce = pl.bitfield & BOUNCES_MASK;
+      if (bounce >= maxBounces || (pl.bitfield & TERMINATE_FLAG)) break;
+      float tMin = 0.0f, tMax = ORC_FLT_MAX;
+      if (rs.clippingPlanes && bounce == 0) { tMin = clipNear; tMax = clipFar; }
+      pl.neeContrib = v3(0, 0, 0); // :349
+      Hit h;
+      cnt.segments++; if (bounce < 64) cnt.bounceHistogram[bounce]++;
+      if (trace_closest(*F.P, pl.origin, pl.dir, tMin, tMax, h)) { cnt.hits++; closest_hit(F, h, pl, h.t); }
+      else miss(F, pl);
+      if (rs.nextEventEstimation) { // :397-438
+        float lightDist = length(pl.neeToLight);
+        V3 sdir = safe_div(pl.neeToLight, lightDist);
+        bool traceRay = luminance(pl.neeContrib) > 1e-6f && lightDist > 1e-9f;
+        bool shadowed = true;
+        if (traceRay) { cnt.shadowRays++; shadowed = trace_any(*F.P, pl.origin, sdir, 0.01f, lightDist); }
+        if (traceRay && !shadowed) pl.radiance = pl.radiance + pl.neeContrib;
+      }
+      if (length(pl.throughput) < 1e-9f) pl.bitfield |= TERMINATE_FLAG; // :441-444
+      if (bounce > rs.rrBounceOffset) { // :447-459
+        float k1 = next1f(pl.rng);
+        float mt = fmax2(pl.throughput.x, fmax2(pl.throughput.y, pl.throughput.z));
+        float p = fmin2(mt, rs.rrInvMinTermProb);
+        if (k1 > p) pl.bitfield |= TERMINATE_FLAG; else pl.throughput = pl.throughput / p;
+      }
+      pl.bitfield++; // :480
+    }
+    V3 rad = pl.radiance; // :489-498
+    float mv = fmax2(rad.x, fmax2(rad.y, rad.z));
+    if (mv > rs.maxSampleValue) rad = rad * (rs.maxSampleValue / mv);
+    V3 sc = v3(fmax2(0.0f, rad.x), fmax2(0.0f, rad.y), fmax2(0.0f, rad.z));
+    pixelColor = pixelColor + sc * invSpp;
+    cnt.samples++;
+  }
+  V3 prev = pixelColor; // :506-515
+  if (rs.progressiveAccumulation && rs.sampleOffset > 0 && prevColor) prev = v3(prevColor);
+  float invTotal = 1.0f / (float)(rs.sampleOffset + rs.spp); // Gi.cpp:2414
+  V3 c = (prev * (float)rs.sampleOffset + pixelColor * (float)rs.spp) * invTotal;
+  out[0] = c.x; out[1] = c.y; out[2] = c.z; out[3] = 1.0f;
+}
+
+void make_frame(Frame& F, const Prepared& P, const OrcCamera* cam, const OrcSettings* rs, const OrcRegion* rg)
+{
+  F.P = &P; F.cam = cam; F.rs = rs; F.width = rg->imageWidth; F.height = rg->imageHeight;
+  F.camPos = v3(cam->position);
+  F.camFwd = normalize(v3(cam->forward)); F.camUp = normalize(v3(cam->up)); // Gi.cpp:2375-2376
+  F.camRight = cross(F.camFwd, F.camUp);                                    // rp_main.rgen:199
+  float aspect = (float)F.width / (float)F.height;
+  float H = 1.0f, W = H * aspect;
+  float d = H / (2.0f * tanf(cam->vfov * 0.5f));                            // :204 (host-side libm; per-frame constant)
+  F.WX = W / (float)F.width; F.HY = H / (float)F.height;
+  V3 C = F.camPos + F.camFwd * d;
+  F.L = (C - F.camRight * W * 0.5f) - F.camUp * H * 0.5f;                   // :210 (left-to-right: (right*W)*0.5)
+  F.lensRadius = (cam->fStop > 0.0f) ? cam->focalLength / (2.0f * cam->fStop) : 0.0f; // Gi.cpp:2378-2382
+  uint32_t cr = pack_half2x16(cam->clipStart, cam->clipEnd);               // Gi.cpp:2419
+  F.clipNear = f16_to_f32((uint16_t)(cr & 0xffffu)); F.clipFar = f16_to_f32((uint16_t)(cr >> 16));
+  for (int i = 0; i < 3; i++) { // Gi.cpp:2196 glm::u8vec4(bg*255) truncates; RGBA8 unorm texel
+    float v = rs->clearColor[i] * 255.0f;
+    int q = (int)v; if (q < 0) q = 0; if (q > 255) q = q & 255; // u8 conversion wraps; clamp negatives to 0
+    float t = (float)q / 255.0f;
+    if (i == 0) F.background.x = t; else if (i == 1) F.background.y = t; else F.background.z = t;
+  }
+  F.ubo.sphereCount = (uint32_t)P.sphere.size(); F.ubo.distantCount = (uint32_t)P.distant.size();
+  F.ubo.rectCount = (uint32_t)P.rect.size(); F.ubo.diskCount = (uint32_t)P.disk.size();
+  F.ubo.total = F.ubo.sphereCount + F.ubo.distantCount + F.ubo.rectCount + F.ubo.diskCount;
+  F.ubo.lightIntensityMultiplier = rs->lightIntensityMultiplier;
+  F.ubo.sensorExposureScale = exp2f(cam->exposure); // rp_main.chit:126, 336 (host libm; per-frame constant)
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C API
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int orc_render(const OrcScene* scene, const OrcCamera* camera, const OrcSettings* settings,
+               const OrcRegion* region, const float* prevColor, float* colorOut,
+               OrcCounters* counters, int threads)
+{
+  if (!scene || !camera || !settings || !region || !colorOut) return 1;
+  if (settings->spp == 0 || region->imageWidth == 0 || region->imageHeight == 0 || region->rowEnd > region->imageHeight || region->rowBegin > region->rowEnd) return 2;
+  if (region->imageWidth > 65535u || region->imageHeight > 65535u) return 3; // imageDims packing, rp_main.h:38
+  Prepared P; prepare(scene, P);
+  Frame F; make_frame(F, P, camera, settings, region);
+  if (threads <= 0) threads = 1;
+  uint32_t rows = region->rowEnd - region->rowBegin;
+  std::vector<OrcCounters> tc((size_t)threads);
+  for (auto& c : tc) memset(&c, 0, sizeof(c));
+  std::atomic<uint32_t> nextRow{0};
+  auto work = [&](int ti) {
+    for (;;) {
+      uint32_t r = nextRow.fetch_add(1);
+      if (r >= rows) break;
+      uint32_t y = region->rowBegin + r;
+      for (uint32_t x = 0; x < F.width; x++) {
+        size_t o = ((size_t)r * F.width + x) * 4;
+        render_pixel(F, x, y, prevColor ? prevColor + o : nullptr, colorOut + o, tc[(size_t)ti]);
+      }
+    }
+  };
+  if (threads == 1) work(0);
+  else { std::vector<std::thread> th; for (int i = 0; i < threads; i++) th.emplace_back(work, i); for (auto& t : th) t.join(); }
+  if (counters) {
+    memset(counters, 0, sizeof(*counters));
+    for (auto& c : tc) {
+      counters->samples += c.samples; counters->segments += c.segments; counters->shadowRays += c.shadowRays; counters->hits += c.hits;
+      for (int i = 0; i < 64; i++) counters->bounceHistogram[i] += c.bounceHistogram[i];
+    }
+  }
+  return 0;
+}
+
+uint32_t orc_rng_init(uint32_t pixelIndex, uint32_t sampleIndex) { return rng_init(pixelIndex, sampleIndex); }
+float orc_rng_next1f(uint32_t* state) { return next1f(*state); }
+uint32_t orc_hash_pcg32(uint32_t* state) { return hash_pcg32(*state); }
+uint32_t orc_encode_direction(const float v[3]) { return encode_direction(v3(v)); }
+void orc_decode_direction(uint32_t e, float out[3]) { V3 d = decode_direction(e); out[0] = d.x; out[1] = d.y; out[2] = d.z; }
+void orc_offset_ray_origin(const float p[3], const float n[3], float out[3]) { V3 r = offset_ray_origin(v3(p), v3(n)); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+void orc_fis_gauss(float xi0, float xi1, float out[2]) { fis_gauss(xi0, xi1, out[0], out[1]); }
+void orc_sincos2pi(float x, float* s, float* c) { sincos2pi(x, s, c); }
+float orc_logf(float x) { return logf_poly(x); }
+uint32_t orc_pack_half2x16(float a, float b) { return pack_half2x16(a, b); }
+void orc_unpack_half2x16(uint32_t v, float out[2]) { out[0] = f16_to_f32((uint16_t)(v & 0xffffu)); out[1] = f16_to_f32((uint16_t)(v >> 16)); }
+void orc_orthonormal_basis(const float n[3], float b1[3], float b2[3]) { V3 a, b; orthonormal_basis(v3(n), a, b); b1[0] = a.x; b1[1] = a.y; b1[2] = a.z; b2[0] = b.x; b2[1] = b.y; b2[2] = b.z; }
+
+int orc_trace_closest(const OrcScene* scene, const float o[3], const float d[3], float tMin, float tMax,
+                      float* t, float* u, float* v, uint32_t* instance, uint32_t* prim)
+{
+  Prepared P; prepare(scene, P);
+  Hit h;
+  if (!trace_closest(P, v3(o), v3(d), tMin, tMax, h)) return 0;
+  *t = h.t; *u = h.u; *v = h.v; *instance = P.tris[h.tri].instance; *prim = P.tris[h.tri].prim;
+  return 1;
+}
+
+} // extern "C"

@@ -1,0 +1,185 @@
+/*
+ * gi_oracle.h -- CPU ORACLE for the gatling `gi/` render loop.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is a from-scratch CPU restatement of the reference's device hot path
+ * (/root/reference/src/gi/shaders/rp_main.rgen, rp_main.chit, rp_main.miss,
+ * rp_main_shadow.miss, common.glsl, mdl_shading_state.glsl, rp_main_payload.glsl,
+ * interface/rp_main.h) plus the host packing that defines its inputs
+ * (src/gi/impl/Gi.cpp:287-300, 641-658, 826-1157, 1188-1202, 2373-2426, 2573-2976).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or
+ * call this library, and only as the checker.  The product (gatling_amd/) never does.
+ *
+ * PARITY STATUS: "parity unpinned" for BSDF arithmetic and traversal tie-breaking:
+ * the reference's BSDF code lives in the MDL SDK 2024.1.4 + MaterialX (neither is in
+ * /root/reference), the reference needs a Vulkan-RT device + OpenUSD to run, and every
+ * reference image under src/hdGatling/testenv is a git-LFS stub.
+ * What IS pinned here: RNG, octahedral codec, ray offset, FIS, camera, bounce loop,
+ * Russian roulette, clamp, accumulate, light sampling -- restated from in-tree shader
+ * code and checked against derived known-answer vectors (tests/test_oracle_kat.py).
+ *
+ * Arithmetic contract shared with the HIP kernels (DESIGN.md section "Arithmetic contract"):
+ * fp32 only, no FMA contraction, IEEE +,-,*,/,sqrt, and the two polynomial
+ * transcendentals orc_sincos2pi / orc_logf below.  With that, HIP == oracle bit-for-bit.
+ */
+#ifndef GI_ORACLE_H
+#define GI_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* == GiVertex, Gi.h:110-118 */
+typedef struct OrcVertex {
+  float pos[3];
+  float u;
+  float norm[3];
+  float v;
+  float tangent[3];
+  float bitangentSign;
+} OrcVertex;
+
+/* Material classes (closed-form BSDFs; replaces MDL codegen). */
+enum {
+  ORC_MAT_DIFFUSE = 0,             /* C1 "PR1 ref model": Lambert + uniform emission */
+  ORC_MAT_USD_PREVIEW_SURFACE = 1, /* diffuse + GGX specular + clearcoat             */
+  ORC_MAT_OPEN_PBR = 2
+};
+
+/* Parameter block indices (float p[48]); shared by all classes where meaningful. */
+enum {
+  ORC_P_BASE_COLOR = 0,        /* 3: diffuseColor / base_color                    */
+  ORC_P_EMISSION = 3,          /* 3: emissiveColor / emission_color*luminance     */
+  ORC_P_USE_SPECULAR_WORKFLOW = 6,
+  ORC_P_SPECULAR_COLOR = 7,    /* 3 */
+  ORC_P_METALLIC = 10,
+  ORC_P_ROUGHNESS = 11,
+  ORC_P_CLEARCOAT = 12,
+  ORC_P_CLEARCOAT_ROUGHNESS = 13,
+  ORC_P_OPACITY = 14,
+  ORC_P_OPACITY_THRESHOLD = 15,
+  ORC_P_IOR = 16,
+  ORC_P_BASE_WEIGHT = 17,
+  ORC_P_SPECULAR_WEIGHT = 18,
+  ORC_P_COAT_COLOR = 19,       /* 3 */
+  ORC_P_COAT_IOR = 22,
+  ORC_P_TRANSMISSION_WEIGHT = 23,
+  ORC_P_TRANSMISSION_COLOR = 24, /* 3 */
+  ORC_P_DIFFUSE_ROUGHNESS = 27,
+  ORC_P_COUNT = 48
+};
+
+typedef struct OrcMaterial {
+  uint32_t klass;
+  uint32_t flags;
+  float p[ORC_P_COUNT];
+} OrcMaterial;
+
+typedef struct OrcMesh {
+  const OrcVertex* vertices;
+  uint32_t vertexCount;
+  const uint32_t* faces; /* 3 indices per face */
+  uint32_t faceCount;
+  int32_t id;
+  int32_t isDoubleSided;
+  int32_t isLeftHanded;
+  int32_t visible;
+  float transform[16];            /* USD row-major, row-vector convention (Gi.cpp:641-650) */
+  const float* instanceTransforms; /* instanceCount x 16, same convention (Gi.cpp:652-658)  */
+  uint32_t instanceCount;
+  int32_t material; /* index into OrcScene.materials */
+} OrcMesh;
+
+/* Light descriptions at *setter* level (Gi.cpp:2573-2976); derived fields are computed by the oracle. */
+typedef struct OrcSphereLight { float pos[3]; float baseEmission[3]; float radius[3]; float diffuse, specular; } OrcSphereLight;
+typedef struct OrcDistantLight { float direction[3]; float baseEmission[3]; float angle; float diffuse, specular; } OrcDistantLight;
+typedef struct OrcRectLight { float origin[3]; float t0[3]; float t1[3]; float baseEmission[3]; float width, height; float diffuse, specular; } OrcRectLight;
+typedef struct OrcDiskLight { float origin[3]; float t0[3]; float t1[3]; float baseEmission[3]; float radiusX, radiusY; float diffuse, specular; } OrcDiskLight;
+
+typedef struct OrcScene {
+  const OrcMesh* meshes; uint32_t meshCount;
+  const OrcMaterial* materials; uint32_t materialCount;
+  const OrcSphereLight* sphereLights; uint32_t sphereLightCount;
+  const OrcDistantLight* distantLights; uint32_t distantLightCount;
+  const OrcRectLight* rectLights; uint32_t rectLightCount;
+  const OrcDiskLight* diskLights; uint32_t diskLightCount;
+} OrcScene;
+
+/* == GiCameraDesc, Gi.h:96-108 */
+typedef struct OrcCamera {
+  float position[3];
+  float forward[3];
+  float up[3];
+  float vfov;
+  float fStop;
+  float focusDistance;
+  float focalLength;
+  float clipStart;
+  float clipEnd;
+  float exposure;
+} OrcCamera;
+
+/* == GiRenderSettings, Gi.h:139-159 (bools as int32) */
+typedef struct OrcSettings {
+  int32_t clippingPlanes;
+  int32_t depthOfField;
+  int32_t domeLightCameraVisible;
+  int32_t filterImportanceSampling;
+  int32_t jitteredSampling;
+  int32_t nextEventEstimation;
+  int32_t progressiveAccumulation;
+  uint32_t maxBounces;
+  uint32_t rrBounceOffset;
+  uint32_t spp;
+  uint32_t sampleOffset; /* scene->sampleOffset (Gi.cpp:2411) */
+  float lightIntensityMultiplier;
+  float maxSampleValue;
+  float rrInvMinTermProb;
+  float metersPerSceneUnit;
+  float clearColor[4]; /* Color AOV clear value == fallback dome colour (Gi.cpp:2184-2199) */
+} OrcSettings;
+
+typedef struct OrcRegion {
+  uint32_t imageWidth, imageHeight; /* full image (RNG uses global pixel index) */
+  uint32_t rowBegin, rowEnd;        /* rows [rowBegin,rowEnd) are rendered      */
+} OrcRegion;
+
+typedef struct OrcCounters {
+  uint64_t samples;
+  uint64_t segments;        /* closest-hit traces */
+  uint64_t shadowRays;      /* shadow traces actually traced (traceRay == true) */
+  uint64_t hits;
+  uint64_t bounceHistogram[64]; /* [b] = #paths that traced a segment at bounce b */
+} OrcCounters;
+
+/* Renders rows [rowBegin,rowEnd) into colorOut (RGBA32F, (rowEnd-rowBegin)*width*4 floats,
+ * row 0 = bottom, pixelIndex = x + y*width as in rp_main.rgen:195).  prevColor may be NULL
+ * (needed only when sampleOffset>0 && progressiveAccumulation).  threads<=0 -> 1 thread.
+ * Returns 0 on success. */
+int orc_render(const OrcScene* scene, const OrcCamera* camera, const OrcSettings* settings,
+               const OrcRegion* region, const float* prevColor, float* colorOut,
+               OrcCounters* counters, int threads);
+
+/* ---- known-answer helpers (restated common.glsl / Gi.cpp pieces) ---- */
+uint32_t orc_rng_init(uint32_t pixelIndex, uint32_t sampleIndex);     /* common.glsl:121-124 */
+float    orc_rng_next1f(uint32_t* state);                            /* common.glsl:92-96   */
+uint32_t orc_hash_pcg32(uint32_t* state);                            /* common.glsl:85-90   */
+uint32_t orc_encode_direction(const float v[3]);                     /* Gi.cpp:287-300      */
+void     orc_decode_direction(uint32_t e, float out[3]);             /* common.glsl:198-207 */
+void     orc_offset_ray_origin(const float p[3], const float n[3], float out[3]); /* common.glsl:143-162 */
+void     orc_fis_gauss(float xi0, float xi1, float out[2]);          /* rp_main.rgen:118-130 */
+void     orc_sincos2pi(float x, float* s, float* c);
+float    orc_logf(float x);
+uint32_t orc_pack_half2x16(float a, float b);
+void     orc_unpack_half2x16(uint32_t v, float out[2]);
+void     orc_orthonormal_basis(const float n[3], float b1[3], float b2[3]); /* common.glsl:128-137 */
+/* closest hit of a single ray against the scene (brute force); returns 1 on hit. */
+int      orc_trace_closest(const OrcScene* scene, const float o[3], const float d[3], float tMin, float tMax,
+                           float* t, float* u, float* v, uint32_t* instance, uint32_t* prim);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,229 @@
+"""ctypes binding of the CPU oracle (``oracle/libgi_oracle.so``).  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module,
+and only as the checker.  Nothing under ``gatling_amd/`` imports it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libgi_oracle.so")
+P_COUNT = 48
+
+
+class OrcMaterial(C.Structure):
+    _fields_ = [("klass", C.c_uint32), ("flags", C.c_uint32), ("p", C.c_float * P_COUNT)]
+
+
+class OrcMesh(C.Structure):
+    _fields_ = [("vertices", C.c_void_p), ("vertexCount", C.c_uint32),
+                ("faces", C.c_void_p), ("faceCount", C.c_uint32),
+                ("id", C.c_int32), ("isDoubleSided", C.c_int32), ("isLeftHanded", C.c_int32), ("visible", C.c_int32),
+                ("transform", C.c_float * 16),
+                ("instanceTransforms", C.c_void_p), ("instanceCount", C.c_uint32),
+                ("material", C.c_int32)]
+
+
+class OrcSphereLight(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("baseEmission", C.c_float * 3), ("radius", C.c_float * 3),
+                ("diffuse", C.c_float), ("specular", C.c_float)]
+
+
+class OrcDistantLight(C.Structure):
+    _fields_ = [("direction", C.c_float * 3), ("baseEmission", C.c_float * 3), ("angle", C.c_float),
+                ("diffuse", C.c_float), ("specular", C.c_float)]
+
+
+class OrcRectLight(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("t0", C.c_float * 3), ("t1", C.c_float * 3), ("baseEmission", C.c_float * 3),
+                ("width", C.c_float), ("height", C.c_float), ("diffuse", C.c_float), ("specular", C.c_float)]
+
+
+class OrcDiskLight(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("t0", C.c_float * 3), ("t1", C.c_float * 3), ("baseEmission", C.c_float * 3),
+                ("radiusX", C.c_float), ("radiusY", C.c_float), ("diffuse", C.c_float), ("specular", C.c_float)]
+
+
+class OrcScene(C.Structure):
+    _fields_ = [("meshes", C.c_void_p), ("meshCount", C.c_uint32),
+                ("materials", C.c_void_p), ("materialCount", C.c_uint32),
+                ("sphereLights", C.c_void_p), ("sphereLightCount", C.c_uint32),
+                ("distantLights", C.c_void_p), ("distantLightCount", C.c_uint32),
+                ("rectLights", C.c_void_p), ("rectLightCount", C.c_uint32),
+                ("diskLights", C.c_void_p), ("diskLightCount", C.c_uint32)]
+
+
+class OrcCamera(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("forward", C.c_float * 3), ("up", C.c_float * 3),
+                ("vfov", C.c_float), ("fStop", C.c_float), ("focusDistance", C.c_float), ("focalLength", C.c_float),
+                ("clipStart", C.c_float), ("clipEnd", C.c_float), ("exposure", C.c_float)]
+
+
+class OrcSettings(C.Structure):
+    _fields_ = [("clippingPlanes", C.c_int32), ("depthOfField", C.c_int32), ("domeLightCameraVisible", C.c_int32),
+                ("filterImportanceSampling", C.c_int32), ("jitteredSampling", C.c_int32),
+                ("nextEventEstimation", C.c_int32), ("progressiveAccumulation", C.c_int32),
+                ("maxBounces", C.c_uint32), ("rrBounceOffset", C.c_uint32), ("spp", C.c_uint32), ("sampleOffset", C.c_uint32),
+                ("lightIntensityMultiplier", C.c_float), ("maxSampleValue", C.c_float), ("rrInvMinTermProb", C.c_float),
+                ("metersPerSceneUnit", C.c_float), ("clearColor", C.c_float * 4)]
+
+
+class OrcRegion(C.Structure):
+    _fields_ = [("imageWidth", C.c_uint32), ("imageHeight", C.c_uint32), ("rowBegin", C.c_uint32), ("rowEnd", C.c_uint32)]
+
+
+class OrcCounters(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("shadowRays", C.c_uint64), ("hits", C.c_uint64),
+                ("bounceHistogram", C.c_uint64 * 64)]
+
+
+def build(force: bool = False) -> str:
+    """Compiles the oracle with the committed Makefile (g++, -ffp-contract=off)."""
+    src = os.path.join(_HERE, "gi_oracle.cpp")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(
+            os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "gi_oracle.h"))):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libgi_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_render.restype = C.c_int
+        L.orc_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_rng_init.restype = C.c_uint32
+        L.orc_rng_init.argtypes = [C.c_uint32, C.c_uint32]
+        L.orc_rng_next1f.restype = C.c_float
+        L.orc_rng_next1f.argtypes = [C.POINTER(C.c_uint32)]
+        L.orc_hash_pcg32.restype = C.c_uint32
+        L.orc_hash_pcg32.argtypes = [C.POINTER(C.c_uint32)]
+        L.orc_encode_direction.restype = C.c_uint32
+        L.orc_encode_direction.argtypes = [C.POINTER(C.c_float)]
+        L.orc_decode_direction.argtypes = [C.c_uint32, C.POINTER(C.c_float)]
+        L.orc_offset_ray_origin.argtypes = [C.POINTER(C.c_float)] * 3
+        L.orc_fis_gauss.argtypes = [C.c_float, C.c_float, C.POINTER(C.c_float)]
+        L.orc_sincos2pi.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orc_logf.restype = C.c_float
+        L.orc_logf.argtypes = [C.c_float]
+        L.orc_pack_half2x16.restype = C.c_uint32
+        L.orc_pack_half2x16.argtypes = [C.c_float, C.c_float]
+        L.orc_unpack_half2x16.argtypes = [C.c_uint32, C.POINTER(C.c_float)]
+        L.orc_orthonormal_basis.argtypes = [C.POINTER(C.c_float)] * 3
+        L.orc_trace_closest.restype = C.c_int
+        L.orc_trace_closest.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float,
+                                        C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        _lib = L
+    return _lib
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+class PackedScene:
+    """Keeps the numpy buffers alive while the C structs point into them."""
+
+    def __init__(self, scene):
+        self.keep = []
+        meshes = (OrcMesh * max(1, len(scene.meshes)))()
+        for i, m in enumerate(scene.meshes):
+            v = np.ascontiguousarray(m.vertices)
+            f = np.ascontiguousarray(m.faces, np.uint32)
+            it = np.ascontiguousarray(m.instance_transforms, np.float32).reshape(-1, 16)
+            self.keep += [v, f, it]
+            meshes[i].vertices = v.ctypes.data
+            meshes[i].vertexCount = len(v)
+            meshes[i].faces = f.ctypes.data
+            meshes[i].faceCount = len(f)
+            meshes[i].id = m.id
+            meshes[i].isDoubleSided = int(m.double_sided)
+            meshes[i].isLeftHanded = int(m.left_handed)
+            meshes[i].visible = int(m.visible)
+            meshes[i].transform = (C.c_float * 16)(*np.asarray(m.transform, np.float32).reshape(-1))
+            meshes[i].instanceTransforms = it.ctypes.data
+            meshes[i].instanceCount = len(it)
+            meshes[i].material = m.material
+        mats = (OrcMaterial * max(1, len(scene.materials)))()
+        for i, m in enumerate(scene.materials):
+            mats[i].klass = m.klass
+            mats[i].p = (C.c_float * P_COUNT)(*np.asarray(m.params, np.float32))
+        sl = (OrcSphereLight * max(1, len(scene.sphere_lights)))()
+        for i, l in enumerate(scene.sphere_lights):
+            sl[i] = OrcSphereLight(_f3(l.pos), _f3(l.base_emission), _f3(l.radius), l.diffuse, l.specular)
+        dl = (OrcDistantLight * max(1, len(scene.distant_lights)))()
+        for i, l in enumerate(scene.distant_lights):
+            dl[i] = OrcDistantLight(_f3(l.direction), _f3(l.base_emission), l.angle, l.diffuse, l.specular)
+        rl = (OrcRectLight * max(1, len(scene.rect_lights)))()
+        for i, l in enumerate(scene.rect_lights):
+            rl[i] = OrcRectLight(_f3(l.origin), _f3(l.t0), _f3(l.t1), _f3(l.base_emission), l.width, l.height, l.diffuse, l.specular)
+        kl = (OrcDiskLight * max(1, len(scene.disk_lights)))()
+        for i, l in enumerate(scene.disk_lights):
+            kl[i] = OrcDiskLight(_f3(l.origin), _f3(l.t0), _f3(l.t1), _f3(l.base_emission), l.radius_x, l.radius_y, l.diffuse, l.specular)
+        self.keep += [meshes, mats, sl, dl, rl, kl]
+        s = OrcScene()
+        s.meshes = C.addressof(meshes); s.meshCount = len(scene.meshes)
+        s.materials = C.addressof(mats); s.materialCount = len(scene.materials)
+        s.sphereLights = C.addressof(sl); s.sphereLightCount = len(scene.sphere_lights)
+        s.distantLights = C.addressof(dl); s.distantLightCount = len(scene.distant_lights)
+        s.rectLights = C.addressof(rl); s.rectLightCount = len(scene.rect_lights)
+        s.diskLights = C.addressof(kl); s.diskLightCount = len(scene.disk_lights)
+        self.c = s
+
+
+def _camera(cam) -> OrcCamera:
+    return OrcCamera(_f3(cam.position), _f3(cam.forward), _f3(cam.up), cam.vfov, cam.f_stop, cam.focus_distance,
+                     cam.focal_length, cam.clip_start, cam.clip_end, cam.exposure)
+
+
+def _settings(rs, sample_offset=0) -> OrcSettings:
+    s = OrcSettings()
+    s.clippingPlanes = int(rs.clipping_planes)
+    s.depthOfField = int(rs.depth_of_field)
+    s.domeLightCameraVisible = int(rs.dome_light_camera_visible)
+    s.filterImportanceSampling = int(rs.filter_importance_sampling)
+    s.jitteredSampling = int(rs.jittered_sampling)
+    s.nextEventEstimation = int(rs.next_event_estimation)
+    s.progressiveAccumulation = int(rs.progressive_accumulation)
+    s.maxBounces = rs.max_bounces
+    s.rrBounceOffset = rs.rr_bounce_offset
+    s.spp = rs.spp
+    s.sampleOffset = sample_offset
+    s.lightIntensityMultiplier = rs.light_intensity_multiplier
+    s.maxSampleValue = rs.max_sample_value
+    s.rrInvMinTermProb = rs.rr_inv_min_term_prob
+    s.metersPerSceneUnit = rs.meters_per_scene_unit
+    s.clearColor = (C.c_float * 4)(*rs.clear_color)
+    return s
+
+
+def render(scene, settings, width, height, rows=None, sample_offset=0, prev_color=None, threads=1):
+    """Renders with the oracle.  Returns (color float32 [rows,width,4] with row 0 = bottom, counters dict)."""
+    L = lib()
+    ps = PackedScene(scene)
+    r0, r1 = rows if rows is not None else (0, height)
+    out = np.zeros((r1 - r0, width, 4), np.float32)
+    cam, st = _camera(scene.camera), _settings(settings, sample_offset)
+    rg = OrcRegion(width, height, r0, r1)
+    cnt = OrcCounters()
+    prev = None
+    if prev_color is not None:
+        prev = np.ascontiguousarray(prev_color, np.float32)
+    rc = L.orc_render(C.addressof(ps.c), C.addressof(cam), C.addressof(st), C.addressof(rg),
+                      prev.ctypes.data if prev is not None else None, out.ctypes.data, C.addressof(cnt), threads)
+    if rc != 0:
+        raise RuntimeError(f"orc_render failed with code {rc}")
+    counters = {"samples": cnt.samples, "segments": cnt.segments, "shadow_rays": cnt.shadowRays, "hits": cnt.hits,
+                "bounce_histogram": [int(x) for x in cnt.bounceHistogram]}
+    return out, counters
