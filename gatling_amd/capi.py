@@ -1,0 +1,295 @@
+"""ctypes binding of the product library ``gatling_amd/libgatling_gi.so`` (C ABI: ``include/gi_c.h``).
+
+This is the harness-side mirror of the reference's gi interface
+(``/root/reference/src/gi/gtl/gi/Gi.h:199-261``): same entry points, same argument meaning.  There is no CPU
+fallback -- if the HIP library is missing or no GPU is visible, loading / ``giCInitialize`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .scene import P_COUNT, SceneDesc, RenderSettings
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgatling_gi.so")
+
+GI_C_OK = 0
+AOV_COLOR = 0
+FORMAT_INT32, FORMAT_FLOAT32, FORMAT_FLOAT32_VEC4 = 0, 1, 2
+OPTION_COUNT_TRAVERSAL, OPTION_KERNEL_TIMERS = 1, 2
+
+
+class GiCCameraDesc(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("forward", C.c_float * 3), ("up", C.c_float * 3), ("vfov", C.c_float),
+                ("fStop", C.c_float), ("focusDistance", C.c_float), ("focalLength", C.c_float), ("clipStart", C.c_float),
+                ("clipEnd", C.c_float), ("exposure", C.c_float)]
+
+
+class GiCMeshDesc(C.Structure):
+    _fields_ = [("faceCount", C.c_uint32), ("faces", C.c_void_p), ("faceIds", C.c_void_p), ("id", C.c_int32),
+                ("isDoubleSided", C.c_int32), ("isLeftHanded", C.c_int32), ("name", C.c_char_p), ("maxFaceId", C.c_uint32),
+                ("vertexCount", C.c_uint32), ("vertices", C.c_void_p)]
+
+
+class GiCRenderSettings(C.Structure):
+    _fields_ = [("clippingPlanes", C.c_int32), ("depthOfField", C.c_int32), ("domeLightCameraVisible", C.c_int32),
+                ("filterImportanceSampling", C.c_int32), ("frame", C.c_float), ("jitteredSampling", C.c_int32),
+                ("lightIntensityMultiplier", C.c_float), ("maxBounces", C.c_uint32), ("maxSampleValue", C.c_float),
+                ("maxVolumeWalkLength", C.c_uint32), ("mediumStackSize", C.c_uint32), ("metersPerSceneUnit", C.c_float),
+                ("nextEventEstimation", C.c_int32), ("progressiveAccumulation", C.c_int32), ("rrBounceOffset", C.c_uint32),
+                ("rrInvMinTermProb", C.c_float), ("spp", C.c_uint32), ("time", C.c_float)]
+
+
+class GiCAovBinding(C.Structure):
+    _fields_ = [("aovId", C.c_int32), ("clearValue", C.c_uint8 * 16), ("renderBuffer", C.c_void_p)]
+
+
+class GiCRenderParams(C.Structure):
+    _fields_ = [("aovBindings", C.POINTER(GiCAovBinding)), ("aovBindingCount", C.c_uint32), ("camera", GiCCameraDesc),
+                ("domeLight", C.c_void_p), ("renderSettings", GiCRenderSettings), ("scene", C.c_void_p),
+                ("rowBegin", C.c_uint32), ("rowEnd", C.c_uint32)]
+
+
+class GiCMaterialDesc(C.Structure):
+    _fields_ = [("klass", C.c_uint32), ("flags", C.c_uint32), ("p", C.c_float * P_COUNT)]
+
+
+class GiCRenderStats(C.Structure):
+    _fields_ = [("renderMs", C.c_double), ("bvhBuildMs", C.c_double), ("uploadMs", C.c_double), ("traceMs", C.c_double),
+                ("shadeMs", C.c_double), ("raygenMs", C.c_double), ("shadowMs", C.c_double),
+                ("samples", C.c_uint64), ("segments", C.c_uint64), ("shadowRays", C.c_uint64), ("nodesVisited", C.c_uint64),
+                ("trisTested", C.c_uint64), ("shadowNodesVisited", C.c_uint64), ("shadowTrisTested", C.c_uint64),
+                ("iterations", C.c_uint32), ("traceLaunches", C.c_uint32), ("nodeCount", C.c_uint32), ("triangleCount", C.c_uint32)]
+
+
+# every symbol include/gi_c.h declares: (name, restype, argtypes)
+_P, _F, _U, _I = C.c_void_p, C.c_float, C.c_uint32, C.c_int32
+_FP = C.POINTER(C.c_float)
+SYMBOLS = [
+    ("giCInitialize", C.c_int, [C.c_int]), ("giCTerminate", None, []), ("giCGetLastError", C.c_char_p, []),
+    ("giCCreateMaterial", _P, [_P, C.c_char_p, C.POINTER(GiCMaterialDesc)]), ("giCDestroyMaterial", None, [_P]),
+    ("giCCreateMesh", _P, [_P, C.POINTER(GiCMeshDesc)]), ("giCSetMeshTransform", None, [_P, _FP]),
+    ("giCSetMeshInstanceTransforms", None, [_P, _U, _FP]), ("giCSetMeshInstanceIds", None, [_P, _U, C.POINTER(C.c_int32)]),
+    ("giCSetMeshMaterial", None, [_P, _P]), ("giCSetMeshVisibility", None, [_P, _I]), ("giCDestroyMesh", None, [_P]),
+    ("giCRender", C.c_int, [C.POINTER(GiCRenderParams)]),
+    ("giCCreateScene", _P, []), ("giCDestroyScene", None, [_P]),
+    ("giCCreateSphereLight", _P, [_P]), ("giCDestroySphereLight", None, [_P, _P]), ("giCSetSphereLightPosition", None, [_P, _FP]),
+    ("giCSetSphereLightBaseEmission", None, [_P, _FP]), ("giCSetSphereLightRadius", None, [_P, _F, _F, _F]),
+    ("giCSetSphereLightDiffuseSpecular", None, [_P, _F, _F]),
+    ("giCCreateDistantLight", _P, [_P]), ("giCDestroyDistantLight", None, [_P, _P]), ("giCSetDistantLightDirection", None, [_P, _FP]),
+    ("giCSetDistantLightBaseEmission", None, [_P, _FP]), ("giCSetDistantLightAngle", None, [_P, _F]),
+    ("giCSetDistantLightDiffuseSpecular", None, [_P, _F, _F]),
+    ("giCCreateRectLight", _P, [_P]), ("giCDestroyRectLight", None, [_P, _P]), ("giCSetRectLightOrigin", None, [_P, _FP]),
+    ("giCSetRectLightTangents", None, [_P, _FP, _FP]), ("giCSetRectLightBaseEmission", None, [_P, _FP]),
+    ("giCSetRectLightDimensions", None, [_P, _F, _F]), ("giCSetRectLightDiffuseSpecular", None, [_P, _F, _F]),
+    ("giCCreateDiskLight", _P, [_P]), ("giCDestroyDiskLight", None, [_P, _P]), ("giCSetDiskLightOrigin", None, [_P, _FP]),
+    ("giCSetDiskLightTangents", None, [_P, _FP, _FP]), ("giCSetDiskLightBaseEmission", None, [_P, _FP]),
+    ("giCSetDiskLightRadius", None, [_P, _F, _F]), ("giCSetDiskLightDiffuseSpecular", None, [_P, _F, _F]),
+    ("giCCreateDomeLight", _P, [_P, C.c_char_p]), ("giCDestroyDomeLight", None, [_P]), ("giCSetDomeLightRotation", None, [_P, _FP]),
+    ("giCSetDomeLightBaseEmission", None, [_P, _FP]), ("giCSetDomeLightDiffuseSpecular", None, [_P, _F, _F]),
+    ("giCCreateRenderBuffer", _P, [_U, _U, _I]), ("giCDestroyRenderBuffer", None, [_P]), ("giCGetRenderBufferMem", _P, [_P]),
+    ("giCGetRenderBufferDeviceMem", _P, [_P]), ("giCSetRenderBufferDeviceOnly", None, [_P, _I]),
+    ("giCGetRenderStats", C.c_int, [_P, C.POINTER(GiCRenderStats)]), ("giCSetSceneOption", C.c_int, [_P, _I, _I]),
+    ("giCTraceRays", C.c_int, [_P, _U, _FP, _FP, _F, _F, _FP, C.POINTER(C.c_int32)]),
+]
+
+_lib = None
+
+
+def load_library():
+    """Loads libgatling_gi.so and types every entry point.  Raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _fp(values):
+    arr = (C.c_float * len(values))(*[float(v) for v in values])
+    return arr
+
+
+class GiError(RuntimeError):
+    pass
+
+
+_initialized = False
+
+
+def initialize(device: int = 0):
+    global _initialized
+    L = load_library()
+    if not _initialized:
+        if L.giCInitialize(device) != GI_C_OK:
+            raise GiError("giCInitialize failed: " + L.giCGetLastError().decode())
+        _initialized = True
+    return L
+
+
+def _camera(cam) -> GiCCameraDesc:
+    f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])
+    return GiCCameraDesc(f3(cam.position), f3(cam.forward), f3(cam.up), cam.vfov, cam.f_stop, cam.focus_distance,
+                         cam.focal_length, cam.clip_start, cam.clip_end, cam.exposure)
+
+
+def _settings(rs: RenderSettings) -> GiCRenderSettings:
+    s = GiCRenderSettings()
+    s.clippingPlanes = int(rs.clipping_planes); s.depthOfField = int(rs.depth_of_field)
+    s.domeLightCameraVisible = int(rs.dome_light_camera_visible); s.filterImportanceSampling = int(rs.filter_importance_sampling)
+    s.frame = 0.0; s.jitteredSampling = int(rs.jittered_sampling); s.lightIntensityMultiplier = rs.light_intensity_multiplier
+    s.maxBounces = rs.max_bounces; s.maxSampleValue = rs.max_sample_value; s.maxVolumeWalkLength = rs.max_volume_walk_length
+    s.mediumStackSize = rs.medium_stack_size; s.metersPerSceneUnit = rs.meters_per_scene_unit
+    s.nextEventEstimation = int(rs.next_event_estimation); s.progressiveAccumulation = int(rs.progressive_accumulation)
+    s.rrBounceOffset = rs.rr_bounce_offset; s.rrInvMinTermProb = rs.rr_inv_min_term_prob; s.spp = rs.spp; s.time = 0.0
+    return s
+
+
+class Scene:
+    """Feeds a :class:`SceneDesc` through the gi C ABI the way hdGatling feeds Hydra prims through Gi.h."""
+
+    def __init__(self, desc: SceneDesc, device: int = 0):
+        self.L = initialize(device)
+        L = self.L
+        self.desc = desc
+        self.handle = L.giCCreateScene()
+        if not self.handle:
+            raise GiError("giCCreateScene failed")
+        self.materials, self.meshes, self.lights = [], [], []
+        for m in desc.materials:
+            md = GiCMaterialDesc(m.klass, 0, (C.c_float * P_COUNT)(*np.asarray(m.params, np.float32)))
+            h = L.giCCreateMaterial(self.handle, m.name.encode(), C.byref(md))
+            if not h:
+                raise GiError("giCCreateMaterial failed: " + L.giCGetLastError().decode())
+            self.materials.append(h)
+        for m in desc.meshes:
+            v = np.ascontiguousarray(m.vertices)
+            f = np.ascontiguousarray(m.faces, np.uint32)
+            d = GiCMeshDesc(len(f), f.ctypes.data, None, m.id, int(m.double_sided), int(m.left_handed), m.name.encode(), 0,
+                            len(v), v.ctypes.data)
+            h = L.giCCreateMesh(self.handle, C.byref(d))
+            if not h:
+                raise GiError("giCCreateMesh failed: " + L.giCGetLastError().decode())
+            L.giCSetMeshTransform(h, _fp(np.asarray(m.transform, np.float32).reshape(-1)))
+            it = np.ascontiguousarray(m.instance_transforms, np.float32).reshape(-1, 16)
+            L.giCSetMeshInstanceTransforms(h, len(it), it.ctypes.data_as(_FP))
+            if m.instance_ids is not None:
+                ids = np.ascontiguousarray(m.instance_ids, np.int32)
+                L.giCSetMeshInstanceIds(h, len(ids), ids.ctypes.data_as(C.POINTER(C.c_int32)))
+            if m.material >= 0:
+                L.giCSetMeshMaterial(h, self.materials[m.material])
+            L.giCSetMeshVisibility(h, int(m.visible))
+            self.meshes.append(h)
+        for l in desc.sphere_lights:
+            h = L.giCCreateSphereLight(self.handle)
+            L.giCSetSphereLightPosition(h, _fp(l.pos)); L.giCSetSphereLightBaseEmission(h, _fp(l.base_emission))
+            L.giCSetSphereLightRadius(h, *[float(x) for x in l.radius]); L.giCSetSphereLightDiffuseSpecular(h, l.diffuse, l.specular)
+            self.lights.append(("sphere", h))
+        for l in desc.distant_lights:
+            h = L.giCCreateDistantLight(self.handle)
+            L.giCSetDistantLightDirection(h, _fp(l.direction)); L.giCSetDistantLightBaseEmission(h, _fp(l.base_emission))
+            L.giCSetDistantLightAngle(h, l.angle); L.giCSetDistantLightDiffuseSpecular(h, l.diffuse, l.specular)
+            self.lights.append(("distant", h))
+        for l in desc.rect_lights:
+            h = L.giCCreateRectLight(self.handle)
+            L.giCSetRectLightOrigin(h, _fp(l.origin)); L.giCSetRectLightTangents(h, _fp(l.t0), _fp(l.t1))
+            L.giCSetRectLightBaseEmission(h, _fp(l.base_emission)); L.giCSetRectLightDimensions(h, l.width, l.height)
+            L.giCSetRectLightDiffuseSpecular(h, l.diffuse, l.specular)
+            self.lights.append(("rect", h))
+        for l in desc.disk_lights:
+            h = L.giCCreateDiskLight(self.handle)
+            L.giCSetDiskLightOrigin(h, _fp(l.origin)); L.giCSetDiskLightTangents(h, _fp(l.t0), _fp(l.t1))
+            L.giCSetDiskLightBaseEmission(h, _fp(l.base_emission)); L.giCSetDiskLightRadius(h, l.radius_x, l.radius_y)
+            L.giCSetDiskLightDiffuseSpecular(h, l.diffuse, l.specular)
+            self.lights.append(("disk", h))
+        self._buffers = {}
+
+    def set_option(self, option: int, value: int):
+        if self.L.giCSetSceneOption(self.handle, option, value) != GI_C_OK:
+            raise GiError("giCSetSceneOption failed")
+
+    def color_buffer(self, width, height):
+        key = (width, height)
+        if key not in self._buffers:
+            rb = self.L.giCCreateRenderBuffer(width, height, FORMAT_FLOAT32_VEC4)
+            if not rb:
+                raise GiError("giCCreateRenderBuffer failed: " + self.L.giCGetLastError().decode())
+            self._buffers[key] = rb
+        return self._buffers[key]
+
+    def render(self, settings: RenderSettings, width: int, height: int, rows=None, device_only=False):
+        """One giCRender call.  Returns the colour AOV as float32 [rows, width, 4] (row 0 = bottom) -- a view of the
+        library-owned host memory copied out -- or None when ``device_only``."""
+        L = self.L
+        rb = self.color_buffer(width, height)
+        L.giCSetRenderBufferDeviceOnly(rb, int(device_only))
+        binding = GiCAovBinding()
+        binding.aovId = AOV_COLOR
+        clear = np.asarray(settings.clear_color, np.float32)
+        C.memmove(binding.clearValue, clear.ctypes.data, 16)
+        binding.renderBuffer = rb
+        p = GiCRenderParams()
+        p.aovBindings = C.pointer(binding)
+        p.aovBindingCount = 1
+        p.camera = _camera(self.desc.camera)
+        p.domeLight = None
+        p.renderSettings = _settings(settings)
+        p.scene = self.handle
+        r0, r1 = rows if rows is not None else (0, height)
+        p.rowBegin, p.rowEnd = r0, r1
+        if L.giCRender(C.byref(p)) != GI_C_OK:
+            raise GiError("giCRender failed: " + L.giCGetLastError().decode())
+        if device_only:
+            return None
+        mem = L.giCGetRenderBufferMem(rb)
+        full = np.ctypeslib.as_array(C.cast(mem, C.POINTER(C.c_float)), shape=(height, width, 4))
+        return full[r0:r1].copy()
+
+    def device_pointer(self, width, height) -> int:
+        return int(self.L.giCGetRenderBufferDeviceMem(self.color_buffer(width, height)))
+
+    def stats(self) -> dict:
+        s = GiCRenderStats()
+        if self.L.giCGetRenderStats(self.handle, C.byref(s)) != GI_C_OK:
+            raise GiError("giCGetRenderStats failed")
+        return {name: getattr(s, name) for name, _ in GiCRenderStats._fields_}
+
+    def trace_rays(self, origins, dirs, t_min=0.0, t_max=3.0e38):
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        n = len(o)
+        tuv = np.zeros((n, 3), np.float32)
+        ip = np.zeros((n, 2), np.int32)
+        rc = self.L.giCTraceRays(self.handle, n, o.ctypes.data_as(_FP), d.ctypes.data_as(_FP), t_min, t_max,
+                                 tuv.ctypes.data_as(_FP), ip.ctypes.data_as(C.POINTER(C.c_int32)))
+        if rc < 0:
+            raise GiError("giCTraceRays failed: " + self.L.giCGetLastError().decode())
+        return tuv, ip
+
+    def close(self):
+        if self.handle:
+            L = self.L
+            for rb in self._buffers.values():
+                L.giCDestroyRenderBuffer(rb)
+            self._buffers = {}
+            destroy = {"sphere": L.giCDestroySphereLight, "distant": L.giCDestroyDistantLight, "rect": L.giCDestroyRectLight,
+                       "disk": L.giCDestroyDiskLight}
+            for kind, h in self.lights:
+                destroy[kind](self.handle, h)
+            for h in self.meshes:
+                L.giCDestroyMesh(h)
+            for h in self.materials:
+                L.giCDestroyMaterial(h)
+            self.lights, self.meshes, self.materials = [], [], []
+            self.L.giCDestroyScene(self.handle)
+            self.handle = None

@@ -1,0 +1,235 @@
+// bvh8.cpp -- binned-SAH BVH2 -> greedy collapse to 8-wide -> octant slot assignment -> 8-bit quantisation.
+//
+// Replaces the opaque driver build behind cgpuCreateBlas/cgpuCreateTlas
+// (/root/reference/src/cgpu/impl/CgpuVk.cpp:2561-2854, PREFER_FAST_TRACE at :2575).  Instances are flattened into
+// world space before the build (DESIGN.md "Why one flat BVH"), so there is a single level.
+//
+// Conservativeness contract: a child's dequantised box always contains the (padded) boxes of everything below
+// it, so the traversal kernel can never cull a triangle the exact Moeller-Trumbore test would accept.
+
+#include "bvh8.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <queue>
+
+namespace gi {
+namespace {
+
+struct Box {
+  float lo[3], hi[3];
+  void reset() { for (int a = 0; a < 3; a++) { lo[a] = 3.0e38f; hi[a] = -3.0e38f; } }
+  void grow(const Box& b) { for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); } }
+  void grow(const float* p) { for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); } }
+  float area() const {
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    if (dx < 0.0f) return 0.0f;
+    return 2.0f * (dx * dy + dy * dz + dz * dx);
+  }
+};
+
+struct Node2 {
+  Box box;
+  uint32_t left = 0, right = 0; // children (internal)
+  uint32_t first = 0, count = 0; // leaf range in refs[]
+};
+
+constexpr int kBins = 16;
+constexpr uint32_t kMaxLeaf = 3; // 3-bit unary triangle count in Node8::meta
+
+struct Builder {
+  const std::vector<TriRec>& tris;
+  std::vector<Box> triBox;
+  std::vector<float> centroid; // 3 per tri
+  std::vector<uint32_t> refs;
+  std::vector<Node2> nodes;
+
+  explicit Builder(const std::vector<TriRec>& t) : tris(t) {}
+
+  void prepare()
+  {
+    size_t n = tris.size();
+    triBox.resize(n); centroid.resize(3 * n); refs.resize(n);
+    for (size_t i = 0; i < n; i++) {
+      const TriRec& t = tris[i];
+      Box b; b.reset();
+      float p1[3], p2[3];
+      for (int a = 0; a < 3; a++) { p1[a] = t.v0[a] + t.e1[a]; p2[a] = t.v0[a] + t.e2[a]; }
+      b.grow(t.v0); b.grow(p1); b.grow(p2);
+      for (int a = 0; a < 3; a++) {
+        // pad: the MT test works on {v0, v0+e1, v0+e2} in exact arithmetic; cover float rounding generously
+        float mag = std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a])) + (b.hi[a] - b.lo[a]);
+        float pad = mag * 9.5367431640625e-7f /* 2^-20 */ + 1.0e-30f;
+        b.lo[a] -= pad; b.hi[a] += pad;
+        centroid[3 * i + a] = 0.5f * (b.lo[a] + b.hi[a]);
+      }
+      triBox[i] = b; refs[i] = (uint32_t)i;
+    }
+  }
+
+  uint32_t build(uint32_t first, uint32_t count)
+  {
+    uint32_t idx = (uint32_t)nodes.size();
+    nodes.emplace_back();
+    Box box; box.reset(); Box cb; cb.reset();
+    for (uint32_t i = first; i < first + count; i++) { box.grow(triBox[refs[i]]); cb.grow(&centroid[3 * refs[i]]); }
+    nodes[idx].box = box;
+    if (count <= kMaxLeaf) { nodes[idx].first = first; nodes[idx].count = count; return idx; }
+
+    // binned SAH over the longest centroid axes
+    int bestAxis = -1; int bestSplit = -1; float bestCost = 3.0e38f;
+    for (int a = 0; a < 3; a++) {
+      float lo = cb.lo[a], ext = cb.hi[a] - cb.lo[a];
+      if (!(ext > 0.0f)) continue;
+      Box bb[kBins]; uint32_t bc[kBins];
+      for (int k = 0; k < kBins; k++) { bb[k].reset(); bc[k] = 0; }
+      float scale = (float)kBins / ext;
+      for (uint32_t i = first; i < first + count; i++) {
+        uint32_t r = refs[i];
+        int k = (int)((centroid[3 * r + a] - lo) * scale); k = std::min(std::max(k, 0), kBins - 1);
+        bb[k].grow(triBox[r]); bc[k]++;
+      }
+      float rightArea[kBins]; uint32_t rightCount[kBins];
+      Box acc; acc.reset(); uint32_t cnt = 0;
+      for (int k = kBins - 1; k > 0; k--) { acc.grow(bb[k]); cnt += bc[k]; rightArea[k] = acc.area(); rightCount[k] = cnt; }
+      acc.reset(); cnt = 0;
+      for (int k = 0; k < kBins - 1; k++) {
+        acc.grow(bb[k]); cnt += bc[k];
+        if (cnt == 0 || rightCount[k + 1] == 0) continue;
+        float cost = acc.area() * (float)cnt + rightArea[k + 1] * (float)rightCount[k + 1];
+        if (cost < bestCost) { bestCost = cost; bestAxis = a; bestSplit = k; }
+      }
+    }
+    uint32_t mid;
+    if (bestAxis >= 0) {
+      float lo = cb.lo[bestAxis], scale = (float)kBins / (cb.hi[bestAxis] - cb.lo[bestAxis]);
+      auto it = std::partition(refs.begin() + first, refs.begin() + first + count, [&](uint32_t r) {
+        int k = (int)((centroid[3 * r + bestAxis] - lo) * scale); k = std::min(std::max(k, 0), kBins - 1);
+        return k <= bestSplit;
+      });
+      mid = (uint32_t)(it - refs.begin());
+    } else {
+      mid = first + count / 2; // all centroids coincide: split by index
+    }
+    if (mid == first || mid == first + count) mid = first + count / 2;
+    uint32_t l = build(first, mid - first);
+    uint32_t r = build(mid, first + count - mid);
+    nodes[idx].left = l; nodes[idx].right = r;
+    return idx;
+  }
+};
+
+inline int exponentFor(float extent)
+{
+  // smallest e with 255 * 2^e >= extent
+  if (!(extent > 0.0f)) return -126;
+  int e; float m = std::frexp(extent / 255.0f, &e); // extent/255 = m * 2^e, m in [0.5,1)
+  if (m == 0.5f) e -= 1;
+  e = std::min(std::max(e, -126), 127);
+  while (255.0f * std::ldexp(1.0f, e) < extent && e < 127) e++;
+  return e;
+}
+
+} // namespace
+
+void buildBvh8(const std::vector<TriRec>& trisIn, Bvh8& out)
+{
+  out.nodes.clear(); out.tris.clear(); out.maxDepth = 0;
+  if (trisIn.empty()) {
+    Node8 root; std::memset(&root, 0, sizeof(root));
+    for (int a = 0; a < 3; a++) { root.e[a] = 127; for (int s = 0; s < 8; s++) { root.qlo[a][s] = 255; root.qhi[a][s] = 0; } }
+    out.nodes.push_back(root); out.maxDepth = 1;
+    return;
+  }
+  Builder B(trisIn);
+  B.prepare();
+  B.nodes.reserve(trisIn.size());
+  uint32_t root2 = B.build(0, (uint32_t)trisIn.size());
+
+  struct Item { uint32_t n2; uint32_t n8; uint32_t depth; };
+  std::queue<Item> q;
+  out.nodes.reserve(trisIn.size() / 4 + 16);
+  out.tris.reserve(trisIn.size());
+  out.nodes.emplace_back();
+  q.push({root2, 0, 1});
+
+  while (!q.empty()) {
+    Item it = q.front(); q.pop();
+    out.maxDepth = std::max(out.maxDepth, it.depth);
+    // --- gather up to 8 children by opening the largest internal child
+    uint32_t ch[8]; int n = 0;
+    const Node2& r = B.nodes[it.n2];
+    if (r.count > 0) { ch[n++] = it.n2; } // root that is itself a leaf
+    else { ch[n++] = r.left; ch[n++] = r.right; }
+    while (n < 8) {
+      int best = -1; float bestArea = -1.0f;
+      for (int i = 0; i < n; i++) {
+        const Node2& c = B.nodes[ch[i]];
+        if (c.count == 0 && c.box.area() > bestArea) { bestArea = c.box.area(); best = i; }
+      }
+      if (best < 0) break;
+      uint32_t opened = ch[best];
+      ch[best] = B.nodes[opened].left; ch[n++] = B.nodes[opened].right;
+    }
+    // --- node box + slot assignment (greedy max of centroid projection on the slot's octant direction)
+    Box nb; nb.reset();
+    for (int i = 0; i < n; i++) nb.grow(B.nodes[ch[i]].box);
+    float center[3]; for (int a = 0; a < 3; a++) center[a] = 0.5f * (nb.lo[a] + nb.hi[a]);
+    float cost[8][8];
+    for (int i = 0; i < n; i++) {
+      const Box& b = B.nodes[ch[i]].box;
+      float d[3]; for (int a = 0; a < 3; a++) d[a] = 0.5f * (b.lo[a] + b.hi[a]) - center[a];
+      for (int s = 0; s < 8; s++) cost[i][s] = ((s & 1) ? d[0] : -d[0]) + ((s & 2) ? d[1] : -d[1]) + ((s & 4) ? d[2] : -d[2]);
+    }
+    int slotOf[8]; bool slotUsed[8] = {false}; bool childDone[8] = {false};
+    for (int k = 0; k < n; k++) {
+      int bi = -1, bs = -1; float bc = -3.0e38f;
+      for (int i = 0; i < n; i++) if (!childDone[i]) for (int s = 0; s < 8; s++) if (!slotUsed[s] && cost[i][s] > bc) { bc = cost[i][s]; bi = i; bs = s; }
+      slotOf[bi] = bs; slotUsed[bs] = true; childDone[bi] = true;
+    }
+    int childInSlot[8]; for (int s = 0; s < 8; s++) childInSlot[s] = -1;
+    for (int i = 0; i < n; i++) childInSlot[slotOf[i]] = i;
+
+    // --- emit
+    Node8 node; std::memset(&node, 0, sizeof(node));
+    int ex[3];
+    for (int a = 0; a < 3; a++) { node.p[a] = nb.lo[a]; ex[a] = exponentFor(nb.hi[a] - nb.lo[a]); node.e[a] = (uint8_t)(ex[a] + 127); }
+    node.childBase = (uint32_t)out.nodes.size();
+    node.triBase = (uint32_t)out.tris.size();
+    uint32_t triOffset = 0;
+    for (int s = 0; s < 8; s++) {
+      int i = childInSlot[s];
+      if (i < 0) { for (int a = 0; a < 3; a++) { node.qlo[a][s] = 255; node.qhi[a][s] = 0; } continue; }
+      const Node2& c = B.nodes[ch[i]];
+      for (int a = 0; a < 3; a++) {
+        float scale = std::ldexp(1.0f, ex[a]);
+        int lo = (int)std::floor(((double)c.box.lo[a] - (double)node.p[a]) / (double)scale);
+        int hi = (int)std::ceil(((double)c.box.hi[a] - (double)node.p[a]) / (double)scale);
+        lo = std::min(std::max(lo, 0), 255); hi = std::min(std::max(hi, 0), 255);
+        while (lo > 0 && node.p[a] + (float)lo * scale > c.box.lo[a]) lo--;
+        while (hi < 255 && node.p[a] + (float)hi * scale < c.box.hi[a]) hi++;
+        node.qlo[a][s] = (uint8_t)lo; node.qhi[a][s] = (uint8_t)hi;
+      }
+      if (c.count > 0) { // leaf slot: unary count in the high 3 bits, triangle offset in the low 5
+        uint32_t unary = (1u << c.count) - 1u;
+        node.meta[s] = (uint8_t)((unary << 5) | triOffset);
+        for (uint32_t k = 0; k < c.count; k++) {
+          TriRec t = B.tris[B.refs[c.first + k]];
+          t.origId = B.refs[c.first + k];
+          out.tris.push_back(t);
+        }
+        triOffset += c.count;
+      } else {
+        node.imask |= (uint8_t)(1u << s);
+        node.meta[s] = (uint8_t)((1u << 5) | (24u + (uint32_t)s));
+        uint32_t childIdx = (uint32_t)out.nodes.size();
+        out.nodes.emplace_back();
+        q.push({ch[i], childIdx, it.depth + 1});
+      }
+    }
+    out.nodes[it.n8] = node;
+  }
+}
+
+} // namespace gi

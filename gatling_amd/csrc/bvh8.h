@@ -1,0 +1,22 @@
+// bvh8.h -- host-side builder of the 8-wide quantised BVH (replaces the driver's BLAS/TLAS build,
+// cgpuCreateBlas/cgpuCreateTlas, /root/reference/src/cgpu/impl/CgpuVk.cpp:2561-2854).
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "gi_types.h"
+
+namespace gi {
+
+struct Bvh8 {
+  std::vector<Node8> nodes;   // breadth-first: the top of the tree comes first (LDS staging)
+  std::vector<TriRec> tris;   // reordered so every node's leaf triangles are contiguous
+  uint32_t maxDepth = 0;
+};
+
+// `tris` in scene order (origId is assigned from the position).  Degenerate input (0 triangles) produces a
+// single empty root so traversal code needs no special case.
+void buildBvh8(const std::vector<TriRec>& tris, Bvh8& out);
+
+} // namespace gi

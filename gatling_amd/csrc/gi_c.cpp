@@ -1,0 +1,884 @@
+// gi_c.cpp -- host side of the MI355X-native gi core: scene containers, dirty flags, host packing, BVH build,
+// uploads, the wavefront bounce loop, render buffers.  Implements include/gi_c.h.
+//
+// Restates the host logic of /root/reference/src/gi/impl/Gi.cpp behind the same API shape:
+//   giCreateMesh/giSetMesh* (:620-782)          -> MeshData + dirty flags
+//   _giBuildGeometryStructures/_giCreateBvh (:784-1315) -> flatten instances, pack FVertex, build BVH8, upload
+//   giRender (:1989-2524)                        -> dirty handling, uniforms (:2373-2426), bounce loop, D2H
+//   light setters (:2573-2976)                   -> CPU mirrors of the 48-byte device structs, dense stores
+//   render buffers (:2978-3006)
+// GPU plumbing (src/cgpu, src/ggpu in the reference) is the HIP runtime: hipMalloc / hipMemcpyAsync / streams.
+
+#include "../../include/gi_c.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "bvh8.h"
+#include "gi_kernels.h"
+#include "gi_types.h"
+
+using namespace gi;
+
+// ---------------------------------------------------------------------------------------------------------------
+// global state (one giCInitialize per process, like Gi.cpp:244-259)
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+thread_local std::string t_lastError;
+void setError(const std::string& e) { t_lastError = e; fprintf(stderr, "[gatling_gi] error: %s\n", e.c_str()); }
+
+#define HIP_TRY(expr)                                                                                      \
+  do {                                                                                                     \
+    hipError_t _e = (expr);                                                                                \
+    if (_e != hipSuccess) { setError(std::string(#expr) + ": " + hipGetErrorString(_e)); return GI_C_ERROR; } \
+  } while (0)
+
+struct Context {
+  bool initialized = false;
+  int device = 0;
+  int cuCount = 256;
+  hipStream_t stream = nullptr;
+  std::mutex resourceMutex; // GPU resource destruction from sync threads (Gi.cpp:679-683)
+} g_ctx;
+
+double nowMs() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+template <typename T>
+struct DeviceBuffer {
+  T* ptr = nullptr;
+  size_t count = 0;
+  int alloc(size_t n)
+  {
+    if (n <= count && ptr) return GI_C_OK;
+    release();
+    if (n == 0) n = 1;
+    HIP_TRY(hipMalloc((void**)&ptr, n * sizeof(T)));
+    count = n;
+    return GI_C_OK;
+  }
+  int upload(const std::vector<T>& v, hipStream_t s)
+  {
+    if (alloc(v.size()) != GI_C_OK) return GI_C_ERROR;
+    if (!v.empty()) HIP_TRY(hipMemcpyAsync(ptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    return GI_C_OK;
+  }
+  void release() { if (ptr) { (void)hipFree(ptr); ptr = nullptr; count = 0; } }
+};
+
+// glm::packHalf2x16 (round to nearest even)
+uint16_t f32ToF16(float f)
+{
+  uint32_t x; memcpy(&x, &f, 4);
+  uint32_t sign = (x >> 16) & 0x8000u, absx = x & 0x7fffffffu;
+  if (absx >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | ((absx > 0x7f800000u) ? 0x200u : 0u));
+  if (absx >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);
+  if (absx < 0x33000001u) return (uint16_t)sign;
+  int exp = (int)(absx >> 23) - 127;
+  uint32_t man = (absx & 0x7fffffu) | 0x800000u;
+  if (exp < -14) {
+    int shift = -14 - exp + 13;
+    uint32_t r = man >> shift, rem = man & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (r & 1u))) r++;
+    return (uint16_t)(sign | r);
+  }
+  uint32_t r = ((uint32_t)(exp + 15) << 10) | ((man >> 13) & 0x3ffu), rem = man & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) r++;
+  return (uint16_t)(sign | r);
+}
+float f16ToF32(uint16_t h)
+{
+  uint32_t sign = ((uint32_t)h & 0x8000u) << 16, exp = (h >> 10) & 0x1fu, man = h & 0x3ffu, out;
+  if (exp == 0) { float v = (float)man * 5.9604644775390625e-8f; return sign ? -v : v; }
+  if (exp == 31) out = sign | 0x7f800000u | (man << 13); else out = sign | ((exp + 112u) << 23) | (man << 13);
+  float f; memcpy(&f, &out, 4); return f;
+}
+uint32_t packHalf2x16(float a, float b) { return (uint32_t)f32ToF16(a) | ((uint32_t)f32ToF16(b) << 16); }
+
+// _EncodeDirection, Gi.cpp:287-300 (glm::packUnorm2x16 rounds)
+uint32_t encodeDirection(const float* vin)
+{
+  float x = vin[0], y = vin[1], z = vin[2];
+  float inv = 1.0f / sqrtf((x * x + y * y) + z * z);
+  x *= inv; y *= inv; z *= inv;
+  float s = fabsf(x) + fabsf(y) + fabsf(z);
+  x /= s; y /= s; z /= s;
+  float px = x >= 0.0f ? 1.0f : -1.0f, py = y >= 0.0f ? 1.0f : -1.0f, ex, ey;
+  if (z < 0.0f) { ex = (1.0f - fabsf(y)) * px; ey = (1.0f - fabsf(x)) * py; } else { ex = x; ey = y; }
+  ex = ex * 0.5f + 0.5f; ey = ey * 0.5f + 0.5f;
+  ex = std::min(std::max(ex, 0.0f), 1.0f); ey = std::min(std::max(ey, 0.0f), 1.0f);
+  return (uint32_t)nearbyintf(ex * 65535.0f) | ((uint32_t)nearbyintf(ey * 65535.0f) << 16);
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// handle types
+// ---------------------------------------------------------------------------------------------------------------
+enum DirtyFlags : uint32_t { DIRTY_BVH = 1u, DIRTY_FRAMEBUFFER = 2u, DIRTY_LIGHTS = 4u, DIRTY_MATERIALS = 8u, DIRTY_ALL = 0xfu };
+
+struct GiCMaterial { GiCScene* scene; std::string name; GiCMaterialDesc desc; };
+
+struct GiCMesh {
+  GiCScene* scene;
+  std::string name;
+  std::vector<GiCVertex> vertices;
+  std::vector<GiCFace> faces;
+  std::vector<int32_t> faceIds;
+  int32_t id = 0;
+  bool doubleSided = false, flipFacing = false, visible = true;
+  uint32_t maxFaceId = 0;
+  float transform[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  std::vector<float> instanceTransforms; // 16 per instance; empty until giCSetMeshInstanceTransforms (as in Gi.cpp:620-638)
+  std::vector<int32_t> instanceIds;
+  GiCMaterial* material = nullptr;
+};
+
+// swap-remove dense store (GgpuDenseDataStore, src/ggpu/impl/DenseDataStore.cpp:35-93): the arrays stay dense so
+// the *LightCount uniforms are the live counts.
+template <typename Rec, typename Handle>
+struct DenseStore {
+  std::vector<Rec> recs;
+  std::vector<Handle*> owners;
+  uint32_t add(Handle* h, const Rec& r) { recs.push_back(r); owners.push_back(h); return (uint32_t)recs.size() - 1u; }
+  void remove(uint32_t idx);
+};
+
+struct GiCSphereLight { GiCScene* scene; uint32_t index; };
+struct GiCDistantLight { GiCScene* scene; uint32_t index; };
+struct GiCRectLight { GiCScene* scene; uint32_t index; };
+struct GiCDiskLight { GiCScene* scene; uint32_t index; };
+struct GiCDomeLight { GiCScene* scene; std::string filePath; float rotation[4] = {0, 0, 0, 1}; float baseEmission[3] = {1, 1, 1}; float diffuse = 1.0f, specular = 1.0f; };
+
+template <typename Rec, typename Handle>
+void DenseStore<Rec, Handle>::remove(uint32_t idx)
+{
+  uint32_t last = (uint32_t)recs.size() - 1u;
+  if (idx != last) { recs[idx] = recs[last]; owners[idx] = owners[last]; owners[idx]->index = idx; }
+  recs.pop_back(); owners.pop_back();
+}
+
+struct GiCRenderBuffer {
+  uint32_t width, height, stride;
+  size_t size;
+  void* deviceMem = nullptr;
+  void* hostMem = nullptr; // pinned (hipHostMalloc): the reference maps a HostVisible|HostCached buffer (Gi.cpp:2019-2031)
+  bool deviceOnly = false;
+};
+
+struct GiCScene {
+  std::mutex mutex;
+  uint32_t dirty = DIRTY_ALL;
+  std::vector<GiCMesh*> meshes;       // creation order (deterministic triangle ids; the reference uses an unordered_set)
+  std::vector<GiCMaterial*> materials;
+  DenseStore<SphereLightRec, GiCSphereLight> sphereLights;
+  DenseStore<DistantLightRec, GiCDistantLight> distantLights;
+  DenseStore<RectLightRec, GiCRectLight> rectLights;
+  DenseStore<DiskLightRec, GiCDiskLight> diskLights;
+  uint32_t sampleOffset = 0;
+  bool haveOldParams = false;
+  GiCCameraDesc oldCamera{};
+  GiCRenderSettings oldSettings{};
+  uint8_t oldClear[GI_C_MAX_AOV_COMP_SIZE] = {0};
+  uint32_t oldRowBegin = 0, oldRowEnd = 0;
+  GiCDomeLight* oldDome = nullptr;
+  float oldDomeEmission[3] = {0, 0, 0};
+  // device scene
+  DeviceBuffer<Node8> dNodes; DeviceBuffer<TriRec> dTris; DeviceBuffer<InstanceRec> dInstances; DeviceBuffer<MeshRec> dMeshes;
+  DeviceBuffer<uint32_t> dFaces; DeviceBuffer<FVertex> dVerts; DeviceBuffer<MaterialRec> dMaterials;
+  DeviceBuffer<SphereLightRec> dSphere; DeviceBuffer<DistantLightRec> dDistant; DeviceBuffer<RectLightRec> dRect; DeviceBuffer<DiskLightRec> dDisk;
+  uint32_t nodeCount = 0, triCount = 0, bvhDepth = 0;
+  // path state
+  DeviceBuffer<F4> sRayO, sRayD, sHit, sThr, sRad, sAcc, sNeeC, sNeeD;
+  DeviceBuffer<uint32_t> qA, qB, qRegen, qShadow;
+  DeviceBuffer<Counters> dCounters;
+  Counters* hCounters = nullptr; // pinned
+  // options + stats
+  bool countTraversal = false, kernelTimers = false;
+  GiCRenderStats stats{};
+  std::vector<hipEvent_t> eventPool;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// init
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* giCGetLastError(void) { return t_lastError.c_str(); }
+
+int giCInitialize(int deviceOrdinal)
+{
+  if (g_ctx.initialized) return GI_C_OK;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0) { setError("no HIP device available: this library has no CPU fallback"); return GI_C_ERROR; }
+  if (deviceOrdinal < 0 || deviceOrdinal >= n) { setError("device ordinal out of range"); return GI_C_ERROR; }
+  HIP_TRY(hipSetDevice(deviceOrdinal));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, deviceOrdinal));
+  g_ctx.device = deviceOrdinal;
+  g_ctx.cuCount = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+  g_ctx.initialized = true;
+  return GI_C_OK;
+}
+
+void giCTerminate(void)
+{
+  if (!g_ctx.initialized) return;
+  (void)hipStreamSynchronize(g_ctx.stream);
+  (void)hipStreamDestroy(g_ctx.stream);
+  g_ctx.stream = nullptr;
+  g_ctx.initialized = false;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// scene / material / mesh
+// ---------------------------------------------------------------------------------------------------------------
+GiCScene* giCCreateScene(void)
+{
+  if (!g_ctx.initialized) { setError("giCCreateScene before giCInitialize"); return nullptr; }
+  return new GiCScene();
+}
+
+void giCDestroyScene(GiCScene* s)
+{
+  if (!s) return;
+  std::lock_guard<std::mutex> g(g_ctx.resourceMutex);
+  (void)hipStreamSynchronize(g_ctx.stream);
+  s->dNodes.release(); s->dTris.release(); s->dInstances.release(); s->dMeshes.release(); s->dFaces.release(); s->dVerts.release();
+  s->dMaterials.release(); s->dSphere.release(); s->dDistant.release(); s->dRect.release(); s->dDisk.release();
+  s->sRayO.release(); s->sRayD.release(); s->sHit.release(); s->sThr.release(); s->sRad.release(); s->sAcc.release(); s->sNeeC.release(); s->sNeeD.release();
+  s->qA.release(); s->qB.release(); s->qRegen.release(); s->qShadow.release(); s->dCounters.release();
+  if (s->hCounters) (void)hipHostFree(s->hCounters);
+  for (hipEvent_t e : s->eventPool) (void)hipEventDestroy(e);
+  delete s;
+}
+
+GiCMaterial* giCCreateMaterial(GiCScene* scene, const char* name, const GiCMaterialDesc* desc)
+{
+  if (!scene || !desc) { setError("giCCreateMaterial: null argument"); return nullptr; }
+  if (desc->klass > GI_C_MAT_USD_PREVIEW_SURFACE) { setError("giCCreateMaterial: unsupported material class"); return nullptr; }
+  GiCMaterial* m = new GiCMaterial{scene, name ? name : "", *desc};
+  std::lock_guard<std::mutex> g(scene->mutex);
+  scene->materials.push_back(m);
+  scene->dirty |= DIRTY_MATERIALS | DIRTY_BVH | DIRTY_FRAMEBUFFER;
+  return m;
+}
+
+void giCDestroyMaterial(GiCMaterial* mat)
+{
+  if (!mat) return;
+  GiCScene* s = mat->scene;
+  {
+    std::lock_guard<std::mutex> g(s->mutex);
+    s->materials.erase(std::remove(s->materials.begin(), s->materials.end(), mat), s->materials.end());
+    for (GiCMesh* m : s->meshes) if (m->material == mat) m->material = nullptr;
+    s->dirty |= DIRTY_MATERIALS | DIRTY_BVH | DIRTY_FRAMEBUFFER;
+  }
+  delete mat;
+}
+
+GiCMesh* giCCreateMesh(GiCScene* scene, const GiCMeshDesc* d)
+{
+  if (!scene || !d) { setError("giCCreateMesh: null argument"); return nullptr; }
+  if ((d->faceCount && !d->faces) || (d->vertexCount && !d->vertices)) { setError("giCCreateMesh: null arrays"); return nullptr; }
+  for (uint32_t i = 0; i < d->faceCount; i++)
+    for (int k = 0; k < 3; k++)
+      if (d->faces[i].v_i[k] >= d->vertexCount) { setError("giCCreateMesh: face index out of range"); return nullptr; }
+  GiCMesh* m = new GiCMesh();
+  m->scene = scene; m->name = d->name ? d->name : "";
+  m->vertices.assign(d->vertices, d->vertices + d->vertexCount); // copies, like giProcessMeshData (Gi.cpp:628)
+  m->faces.assign(d->faces, d->faces + d->faceCount);
+  if (d->faceIds) m->faceIds.assign(d->faceIds, d->faceIds + d->faceCount);
+  m->id = d->id; m->doubleSided = d->isDoubleSided != 0; m->flipFacing = d->isLeftHanded != 0; m->maxFaceId = d->maxFaceId;
+  std::lock_guard<std::mutex> g(scene->mutex);
+  scene->meshes.push_back(m);
+  scene->dirty |= DIRTY_BVH | DIRTY_FRAMEBUFFER;
+  return m;
+}
+
+void giCSetMeshTransform(GiCMesh* mesh, const float* mat4x4)
+{
+  if (!mesh || !mat4x4) return;
+  memcpy(mesh->transform, mat4x4, sizeof(float) * 16);
+  std::lock_guard<std::mutex> g(mesh->scene->mutex);
+  mesh->scene->dirty |= DIRTY_BVH | DIRTY_FRAMEBUFFER;
+}
+
+void giCSetMeshInstanceTransforms(GiCMesh* mesh, uint32_t count, const float* transforms)
+{
+  if (!mesh || (count && !transforms)) return;
+  mesh->instanceTransforms.assign(transforms, transforms + (size_t)count * 16);
+  std::lock_guard<std::mutex> g(mesh->scene->mutex);
+  mesh->scene->dirty |= DIRTY_BVH | DIRTY_FRAMEBUFFER;
+}
+
+void giCSetMeshInstanceIds(GiCMesh* mesh, uint32_t count, const int32_t* ids)
+{
+  if (!mesh || (count && !ids)) return;
+  mesh->instanceIds.assign(ids, ids + count);
+  std::lock_guard<std::mutex> g(mesh->scene->mutex);
+  mesh->scene->dirty |= DIRTY_BVH | DIRTY_FRAMEBUFFER;
+}
+
+void giCSetMeshMaterial(GiCMesh* mesh, GiCMaterial* mat)
+{
+  if (!mesh) return;
+  mesh->material = mat;
+  std::lock_guard<std::mutex> g(mesh->scene->mutex);
+  mesh->scene->dirty |= DIRTY_BVH | DIRTY_FRAMEBUFFER;
+}
+
+void giCSetMeshVisibility(GiCMesh* mesh, int32_t visible)
+{
+  if (!mesh) return;
+  mesh->visible = visible != 0;
+  std::lock_guard<std::mutex> g(mesh->scene->mutex);
+  mesh->scene->dirty |= DIRTY_BVH | DIRTY_FRAMEBUFFER;
+}
+
+void giCDestroyMesh(GiCMesh* mesh)
+{
+  if (!mesh) return;
+  GiCScene* s = mesh->scene;
+  {
+    std::lock_guard<std::mutex> g(s->mutex);
+    s->meshes.erase(std::remove(s->meshes.begin(), s->meshes.end(), mesh), s->meshes.end());
+    s->dirty |= DIRTY_BVH | DIRTY_FRAMEBUFFER;
+  }
+  delete mesh;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// lights (defaults and derived fields: Gi.cpp:2573-2976)
+// ---------------------------------------------------------------------------------------------------------------
+#define LIGHT_DIRTY(l) (l)->scene->dirty |= DIRTY_LIGHTS | DIRTY_FRAMEBUFFER
+
+GiCSphereLight* giCCreateSphereLight(GiCScene* scene)
+{
+  if (!scene) return nullptr;
+  std::lock_guard<std::mutex> g(scene->mutex);
+  auto* l = new GiCSphereLight{scene, 0};
+  SphereLightRec r{}; r.ds = packHalf2x16(1.0f, 1.0f); r.area = 1.0f; r.radius[0] = r.radius[1] = r.radius[2] = 0.5f;
+  l->index = scene->sphereLights.add(l, r);
+  scene->dirty |= DIRTY_LIGHTS | DIRTY_FRAMEBUFFER;
+  return l;
+}
+void giCDestroySphereLight(GiCScene* scene, GiCSphereLight* l)
+{
+  if (!scene || !l) return;
+  std::lock_guard<std::mutex> g(scene->mutex);
+  scene->sphereLights.remove(l->index); scene->dirty |= DIRTY_LIGHTS | DIRTY_FRAMEBUFFER;
+  delete l;
+}
+void giCSetSphereLightPosition(GiCSphereLight* l, const float* p) { memcpy(l->scene->sphereLights.recs[l->index].pos, p, 12); LIGHT_DIRTY(l); }
+void giCSetSphereLightBaseEmission(GiCSphereLight* l, const float* c) { memcpy(l->scene->sphereLights.recs[l->index].em, c, 12); LIGHT_DIRTY(l); }
+void giCSetSphereLightRadius(GiCSphereLight* l, float rx, float ry, float rz)
+{
+  // Knud Thomsen ellipsoid surface approximation (Gi.cpp:2635-2651)
+  float ab = powf(rx * ry, 1.6f), ac = powf(rx * rz, 1.6f), bc = powf(ry * rz, 1.6f);
+  float area = float(powf((ab + ac + bc) / 3.0f, 1.0f / 1.6f) * 4.0f * M_PI);
+  SphereLightRec& r = l->scene->sphereLights.recs[l->index];
+  r.radius[0] = rx; r.radius[1] = ry; r.radius[2] = rz; r.area = area;
+  LIGHT_DIRTY(l);
+}
+void giCSetSphereLightDiffuseSpecular(GiCSphereLight* l, float d, float s) { l->scene->sphereLights.recs[l->index].ds = packHalf2x16(d, s); LIGHT_DIRTY(l); }
+
+GiCDistantLight* giCCreateDistantLight(GiCScene* scene)
+{
+  if (!scene) return nullptr;
+  std::lock_guard<std::mutex> g(scene->mutex);
+  auto* l = new GiCDistantLight{scene, 0};
+  DistantLightRec r{}; r.ds = packHalf2x16(1.0f, 1.0f); r.invPdf = 1.0f;
+  l->index = scene->distantLights.add(l, r);
+  scene->dirty |= DIRTY_LIGHTS | DIRTY_FRAMEBUFFER;
+  return l;
+}
+void giCDestroyDistantLight(GiCScene* scene, GiCDistantLight* l)
+{
+  if (!scene || !l) return;
+  std::lock_guard<std::mutex> g(scene->mutex);
+  scene->distantLights.remove(l->index); scene->dirty |= DIRTY_LIGHTS | DIRTY_FRAMEBUFFER;
+  delete l;
+}
+void giCSetDistantLightDirection(GiCDistantLight* l, const float* d) { memcpy(l->scene->distantLights.recs[l->index].dir, d, 12); LIGHT_DIRTY(l); }
+void giCSetDistantLightBaseEmission(GiCDistantLight* l, const float* c) { memcpy(l->scene->distantLights.recs[l->index].em, c, 12); LIGHT_DIRTY(l); }
+void giCSetDistantLightAngle(GiCDistantLight* l, float angle)
+{
+  float half = 0.5f * angle; // Gi.cpp:2723-2735
+  DistantLightRec& r = l->scene->distantLights.recs[l->index];
+  r.angle = angle; r.invPdf = (half > 0.0f) ? float(2.0f * M_PI * (1.0f - cosf(half))) : 1.0f;
+  LIGHT_DIRTY(l);
+}
+void giCSetDistantLightDiffuseSpecular(GiCDistantLight* l, float d, float s) { l->scene->distantLights.recs[l->index].ds = packHalf2x16(d, s); LIGHT_DIRTY(l); }
+
+GiCRectLight* giCCreateRectLight(GiCScene* scene)
+{
+  if (!scene) return nullptr;
+  std::lock_guard<std::mutex> g(scene->mutex);
+  auto* l = new GiCRectLight{scene, 0};
+  const float t0[3] = {1, 0, 0}, t1[3] = {0, 1, 0};
+  RectLightRec r{}; r.width = 1.0f; r.height = 1.0f; r.t0 = encodeDirection(t0); r.t1 = encodeDirection(t1); r.ds = packHalf2x16(1.0f, 1.0f);
+  l->index = scene->rectLights.add(l, r);
+  scene->dirty |= DIRTY_LIGHTS | DIRTY_FRAMEBUFFER;
+  return l;
+}
+void giCDestroyRectLight(GiCScene* scene, GiCRectLight* l)
+{
+  if (!scene || !l) return;
+  std::lock_guard<std::mutex> g(scene->mutex);
+  scene->rectLights.remove(l->index); scene->dirty |= DIRTY_LIGHTS | DIRTY_FRAMEBUFFER;
+  delete l;
+}
+void giCSetRectLightOrigin(GiCRectLight* l, const float* o) { memcpy(l->scene->rectLights.recs[l->index].origin, o, 12); LIGHT_DIRTY(l); }
+void giCSetRectLightTangents(GiCRectLight* l, const float* t0, const float* t1)
+{
+  RectLightRec& r = l->scene->rectLights.recs[l->index]; r.t0 = encodeDirection(t0); r.t1 = encodeDirection(t1); LIGHT_DIRTY(l);
+}
+void giCSetRectLightBaseEmission(GiCRectLight* l, const float* c) { memcpy(l->scene->rectLights.recs[l->index].em, c, 12); LIGHT_DIRTY(l); }
+void giCSetRectLightDimensions(GiCRectLight* l, float w, float h) { RectLightRec& r = l->scene->rectLights.recs[l->index]; r.width = w; r.height = h; LIGHT_DIRTY(l); }
+void giCSetRectLightDiffuseSpecular(GiCRectLight* l, float d, float s) { l->scene->rectLights.recs[l->index].ds = packHalf2x16(d, s); LIGHT_DIRTY(l); }
+
+GiCDiskLight* giCCreateDiskLight(GiCScene* scene)
+{
+  if (!scene) return nullptr;
+  std::lock_guard<std::mutex> g(scene->mutex);
+  auto* l = new GiCDiskLight{scene, 0};
+  const float t0[3] = {1, 0, 0}, t1[3] = {0, 1, 0};
+  DiskLightRec r{}; r.rx = 0.5f; r.ry = 0.5f; r.t0 = encodeDirection(t0); r.t1 = encodeDirection(t1); r.ds = packHalf2x16(1.0f, 1.0f);
+  l->index = scene->diskLights.add(l, r);
+  scene->dirty |= DIRTY_LIGHTS | DIRTY_FRAMEBUFFER;
+  return l;
+}
+void giCDestroyDiskLight(GiCScene* scene, GiCDiskLight* l)
+{
+  if (!scene || !l) return;
+  std::lock_guard<std::mutex> g(scene->mutex);
+  scene->diskLights.remove(l->index); scene->dirty |= DIRTY_LIGHTS | DIRTY_FRAMEBUFFER;
+  delete l;
+}
+void giCSetDiskLightOrigin(GiCDiskLight* l, const float* o) { memcpy(l->scene->diskLights.recs[l->index].origin, o, 12); LIGHT_DIRTY(l); }
+void giCSetDiskLightTangents(GiCDiskLight* l, const float* t0, const float* t1)
+{
+  DiskLightRec& r = l->scene->diskLights.recs[l->index]; r.t0 = encodeDirection(t0); r.t1 = encodeDirection(t1); LIGHT_DIRTY(l);
+}
+void giCSetDiskLightBaseEmission(GiCDiskLight* l, const float* c) { memcpy(l->scene->diskLights.recs[l->index].em, c, 12); LIGHT_DIRTY(l); }
+void giCSetDiskLightRadius(GiCDiskLight* l, float rx, float ry) { DiskLightRec& r = l->scene->diskLights.recs[l->index]; r.rx = rx; r.ry = ry; LIGHT_DIRTY(l); }
+void giCSetDiskLightDiffuseSpecular(GiCDiskLight* l, float d, float s) { l->scene->diskLights.recs[l->index].ds = packHalf2x16(d, s); LIGHT_DIRTY(l); }
+
+GiCDomeLight* giCCreateDomeLight(GiCScene* scene, const char* filePath)
+{
+  if (!scene) return nullptr;
+  std::lock_guard<std::mutex> g(scene->mutex);
+  auto* l = new GiCDomeLight(); l->scene = scene; l->filePath = filePath ? filePath : "";
+  return l;
+}
+void giCDestroyDomeLight(GiCDomeLight* l) { if (!l) return; std::lock_guard<std::mutex> g(l->scene->mutex); delete l; }
+void giCSetDomeLightRotation(GiCDomeLight* l, const float* q) { memcpy(l->rotation, q, 16); l->scene->dirty |= DIRTY_FRAMEBUFFER; }
+void giCSetDomeLightBaseEmission(GiCDomeLight* l, const float* c) { memcpy(l->baseEmission, c, 12); l->scene->dirty |= DIRTY_FRAMEBUFFER; }
+void giCSetDomeLightDiffuseSpecular(GiCDomeLight* l, float d, float s) { l->diffuse = d; l->specular = s; l->scene->dirty |= DIRTY_FRAMEBUFFER; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// render buffers (Gi.cpp:2978-3006; memory is created lazily by giRender, :1997-2034 -- here at creation so that
+// giCGetRenderBufferMem is valid immediately)
+// ---------------------------------------------------------------------------------------------------------------
+GiCRenderBuffer* giCCreateRenderBuffer(uint32_t width, uint32_t height, int32_t format)
+{
+  if (!g_ctx.initialized) { setError("giCCreateRenderBuffer before giCInitialize"); return nullptr; }
+  uint32_t stride = (format == GI_C_FORMAT_FLOAT32_VEC4) ? 16u : 4u;
+  auto* rb = new GiCRenderBuffer{width, height, stride, (size_t)width * height * stride};
+  size_t bytes = rb->size ? rb->size : 16;
+  if (hipMalloc(&rb->deviceMem, bytes) != hipSuccess || hipHostMalloc(&rb->hostMem, bytes, hipHostMallocDefault) != hipSuccess) {
+    setError("failed to allocate render buffer");
+    if (rb->deviceMem) (void)hipFree(rb->deviceMem);
+    delete rb; return nullptr;
+  }
+  (void)hipMemset(rb->deviceMem, 0, bytes);
+  memset(rb->hostMem, 0, bytes);
+  return rb;
+}
+void giCDestroyRenderBuffer(GiCRenderBuffer* rb)
+{
+  if (!rb) return;
+  std::lock_guard<std::mutex> g(g_ctx.resourceMutex);
+  (void)hipStreamSynchronize(g_ctx.stream);
+  if (rb->deviceMem) (void)hipFree(rb->deviceMem);
+  if (rb->hostMem) (void)hipHostFree(rb->hostMem);
+  delete rb;
+}
+void* giCGetRenderBufferMem(GiCRenderBuffer* rb) { return rb ? rb->hostMem : nullptr; }
+void* giCGetRenderBufferDeviceMem(GiCRenderBuffer* rb) { return rb ? rb->deviceMem : nullptr; }
+void giCSetRenderBufferDeviceOnly(GiCRenderBuffer* rb, int32_t deviceOnly) { if (rb) rb->deviceOnly = deviceOnly != 0; }
+
+int giCSetSceneOption(GiCScene* scene, int32_t option, int32_t value)
+{
+  if (!scene) return GI_C_ERROR;
+  if (option == GI_C_SCENE_OPTION_COUNT_TRAVERSAL) { scene->countTraversal = value != 0; return GI_C_OK; }
+  if (option == GI_C_SCENE_OPTION_KERNEL_TIMERS) { scene->kernelTimers = value != 0; return GI_C_OK; }
+  setError("unknown scene option"); return GI_C_ERROR;
+}
+
+int giCGetRenderStats(const GiCScene* scene, GiCRenderStats* out)
+{
+  if (!scene || !out) return GI_C_ERROR;
+  *out = scene->stats;
+  return GI_C_OK;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// scene build: flatten instances into world space, pack vertex data, build + upload the BVH8
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+// world = local * M_prim * M_instance with USD row vectors (Gi.cpp:641-658, 1191); returns rows of the 3x4
+// column-vector affine.  Same operation order as glm's mat4 * mat4.
+void composeTransform(const float* prim, const float* inst, float out[12])
+{
+  for (int c = 0; c < 3; c++)
+    for (int r = 0; r < 4; r++) {
+      float acc = prim[r * 4 + 0] * inst[0 * 4 + c];
+      acc = acc + prim[r * 4 + 1] * inst[1 * 4 + c];
+      acc = acc + prim[r * 4 + 2] * inst[2 * 4 + c];
+      acc = acc + prim[r * 4 + 3] * inst[3 * 4 + c];
+      out[c * 4 + r] = acc;
+    }
+}
+
+void invert3x3(const float a[12], float inv[9])
+{
+  double m[3][3] = {{a[0], a[1], a[2]}, {a[4], a[5], a[6]}, {a[8], a[9], a[10]}};
+  double c00 = m[1][1] * m[2][2] - m[1][2] * m[2][1];
+  double c01 = m[1][2] * m[2][0] - m[1][0] * m[2][2];
+  double c02 = m[1][0] * m[2][1] - m[1][1] * m[2][0];
+  double det = m[0][0] * c00 + m[0][1] * c01 + m[0][2] * c02;
+  double id = 1.0 / det;
+  inv[0] = (float)(c00 * id);
+  inv[1] = (float)((m[0][2] * m[2][1] - m[0][1] * m[2][2]) * id);
+  inv[2] = (float)((m[0][1] * m[1][2] - m[0][2] * m[1][1]) * id);
+  inv[3] = (float)(c01 * id);
+  inv[4] = (float)((m[0][0] * m[2][2] - m[0][2] * m[2][0]) * id);
+  inv[5] = (float)((m[0][2] * m[1][0] - m[0][0] * m[1][2]) * id);
+  inv[6] = (float)(c02 * id);
+  inv[7] = (float)((m[0][1] * m[2][0] - m[0][0] * m[2][1]) * id);
+  inv[8] = (float)((m[0][0] * m[1][1] - m[0][1] * m[1][0]) * id);
+}
+
+inline void xformPoint(const float a[12], const float p[3], float out[3])
+{
+  out[0] = ((a[0] * p[0] + a[1] * p[1]) + a[2] * p[2]) + a[3];
+  out[1] = ((a[4] * p[0] + a[5] * p[1]) + a[6] * p[2]) + a[7];
+  out[2] = ((a[8] * p[0] + a[9] * p[1]) + a[10] * p[2]) + a[11];
+}
+
+int buildScene(GiCScene* s)
+{
+  double t0 = nowMs();
+  std::vector<MeshRec> meshRecs; std::vector<uint32_t> faces; std::vector<FVertex> verts; std::vector<InstanceRec> instances; std::vector<TriRec> tris;
+  std::vector<MaterialRec> mats(s->materials.size());
+  for (size_t i = 0; i < s->materials.size(); i++) {
+    mats[i].klass = s->materials[i]->desc.klass; mats[i].flags = s->materials[i]->desc.flags;
+    memcpy(mats[i].p, s->materials[i]->desc.p, sizeof(float) * MAT_PARAM_COUNT);
+  }
+  for (GiCMesh* m : s->meshes) {
+    if (!m->visible) continue; // Gi.cpp:801-804
+    if (m->faces.empty()) continue;
+    auto mit = std::find(s->materials.begin(), s->materials.end(), m->material);
+    if (mit == s->materials.end()) { fprintf(stderr, "[gatling_gi] invalid BLAS material for mesh %s\n", m->name.c_str()); continue; } // Gi.cpp:818-822
+    MeshRec mr;
+    mr.faceOffset = (uint32_t)(faces.size() / 3); mr.vertexOffset = (uint32_t)verts.size(); mr.material = (uint32_t)(mit - s->materials.begin());
+    mr.flags = (m->flipFacing ? 1u : 0u) | (m->doubleSided ? 2u : 0u);
+    uint32_t meshIdx = (uint32_t)meshRecs.size();
+    meshRecs.push_back(mr);
+    for (const GiCFace& f : m->faces) { faces.push_back(f.v_i[0]); faces.push_back(f.v_i[1]); faces.push_back(f.v_i[2]); }
+    for (const GiCVertex& v : m->vertices) { // Gi.cpp:848-861
+      FVertex fv; memcpy(fv.pos, v.pos, 12); fv.bsign = v.bitangentSign;
+      fv.normal = encodeDirection(v.norm); fv.tangent = encodeDirection(v.tangent); fv.u = v.u; fv.v = v.v;
+      verts.push_back(fv);
+    }
+    size_t instCount = m->instanceTransforms.size() / 16;
+    for (size_t ii = 0; ii < instCount; ii++) { // Gi.cpp:1188-1202
+      InstanceRec ir{};
+      composeTransform(m->transform, &m->instanceTransforms[16 * ii], ir.o2w);
+      invert3x3(ir.o2w, ir.w2o);
+      ir.mesh = meshIdx; ir.instanceId = ii < m->instanceIds.size() ? m->instanceIds[ii] : (int32_t)ii;
+      uint32_t instIdx = (uint32_t)instances.size();
+      instances.push_back(ir);
+      for (uint32_t f = 0; f < (uint32_t)m->faces.size(); f++) {
+        float p0[3], p1[3], p2[3];
+        xformPoint(ir.o2w, m->vertices[m->faces[f].v_i[0]].pos, p0);
+        xformPoint(ir.o2w, m->vertices[m->faces[f].v_i[1]].pos, p1);
+        xformPoint(ir.o2w, m->vertices[m->faces[f].v_i[2]].pos, p2);
+        TriRec t;
+        for (int a = 0; a < 3; a++) { t.v0[a] = p0[a]; t.e1[a] = p1[a] - p0[a]; t.e2[a] = p2[a] - p0[a]; }
+        t.instance = instIdx; t.prim = f; t.origId = (uint32_t)tris.size();
+        tris.push_back(t);
+      }
+    }
+  }
+  Bvh8 bvh;
+  buildBvh8(tris, bvh);
+  double t1 = nowMs();
+  hipStream_t st = g_ctx.stream;
+  if (s->dNodes.upload(bvh.nodes, st) || s->dTris.upload(bvh.tris, st) || s->dInstances.upload(instances, st) || s->dMeshes.upload(meshRecs, st) ||
+      s->dFaces.upload(faces, st) || s->dVerts.upload(verts, st) || s->dMaterials.upload(mats, st))
+    return GI_C_ERROR;
+  HIP_TRY(hipStreamSynchronize(st)); // host vectors go out of scope
+  s->nodeCount = (uint32_t)bvh.nodes.size(); s->triCount = (uint32_t)bvh.tris.size(); s->bvhDepth = bvh.maxDepth;
+  s->stats.bvhBuildMs = t1 - t0; s->stats.uploadMs = nowMs() - t1;
+  s->stats.nodeCount = s->nodeCount; s->stats.triangleCount = s->triCount;
+  return GI_C_OK;
+}
+
+int uploadLights(GiCScene* s)
+{
+  hipStream_t st = g_ctx.stream;
+  if (s->dSphere.upload(s->sphereLights.recs, st) || s->dDistant.upload(s->distantLights.recs, st) || s->dRect.upload(s->rectLights.recs, st) ||
+      s->dDisk.upload(s->diskLights.recs, st))
+    return GI_C_ERROR;
+  HIP_TRY(hipStreamSynchronize(st));
+  return GI_C_OK;
+}
+
+bool settingsEqual(const GiCRenderSettings& a, const GiCRenderSettings& b) { return memcmp(&a, &b, sizeof(a)) == 0; }
+
+SceneView makeView(GiCScene* s)
+{
+  SceneView v{};
+  v.nodes = s->dNodes.ptr; v.tris = s->dTris.ptr; v.instances = s->dInstances.ptr; v.meshes = s->dMeshes.ptr; v.faces = s->dFaces.ptr;
+  v.verts = s->dVerts.ptr; v.materials = s->dMaterials.ptr; v.sphereLights = s->dSphere.ptr; v.distantLights = s->dDistant.ptr;
+  v.rectLights = s->dRect.ptr; v.diskLights = s->dDisk.ptr; v.nodeCount = s->nodeCount; v.triCount = s->triCount;
+  return v;
+}
+
+int ensurePathState(GiCScene* s, size_t slots)
+{
+  if (s->sRayO.alloc(slots) || s->sRayD.alloc(slots) || s->sHit.alloc(slots) || s->sThr.alloc(slots) || s->sRad.alloc(slots) || s->sAcc.alloc(slots) ||
+      s->sNeeC.alloc(slots) || s->sNeeD.alloc(slots) || s->qA.alloc(slots) || s->qB.alloc(slots) || s->qRegen.alloc(slots) || s->qShadow.alloc(slots) ||
+      s->dCounters.alloc(1))
+    return GI_C_ERROR;
+  if (!s->hCounters) HIP_TRY(hipHostMalloc((void**)&s->hCounters, sizeof(Counters), hipHostMallocDefault));
+  return GI_C_OK;
+}
+
+hipEvent_t poolEvent(GiCScene* s, size_t idx)
+{
+  while (s->eventPool.size() <= idx) { hipEvent_t e; (void)hipEventCreate(&e); s->eventPool.push_back(e); }
+  return s->eventPool[idx];
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// giCRender
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int giCRender(const GiCRenderParams* params)
+{
+  if (!g_ctx.initialized) { setError("giCRender before giCInitialize"); return GI_C_ERROR; }
+  if (!params || !params->scene) { setError("giCRender: null params/scene"); return GI_C_ERROR; }
+  GiCScene* s = params->scene;
+  const GiCRenderSettings& rs = params->renderSettings;
+  const GiCAovBinding* colorBinding = nullptr;
+  for (uint32_t i = 0; i < params->aovBindingCount; i++) {
+    if (!params->aovBindings[i].renderBuffer) { setError("giCRender: AOV binding without render buffer"); return GI_C_ERROR; }
+    if (params->aovBindings[i].aovId == GI_C_AOV_COLOR) colorBinding = &params->aovBindings[i];
+  }
+  if (params->aovBindingCount == 0) { setError("giCRender: no AOV bindings"); return GI_C_ERROR; }
+  if (rs.spp == 0) { setError("giCRender: spp must be > 0"); return GI_C_ERROR; }
+  if (rs.mediumStackSize != 0) { setError("giCRender: volumes (mediumStackSize > 0) are not supported yet"); return GI_C_ERROR; }
+  const GiCRenderBuffer* sizeRb = (colorBinding ? colorBinding : &params->aovBindings[0])->renderBuffer;
+  const uint32_t width = sizeRb->width, height = sizeRb->height;
+  if (width == 0 || height == 0) return GI_C_OK; // Render.Empty-style degenerate target: nothing to do
+  if (width > 65535u || height > 65535u) { setError("giCRender: image dimensions exceed 65535 (imageDims packing, rp_main.h:38)"); return GI_C_ERROR; }
+  uint32_t rowBegin = params->rowBegin, rowEnd = params->rowEnd ? params->rowEnd : height;
+  if (rowBegin > rowEnd || rowEnd > height) { setError("giCRender: bad row range"); return GI_C_ERROR; }
+
+  std::lock_guard<std::mutex> guard(s->mutex);
+  hipStream_t st = g_ctx.stream;
+  HIP_TRY(hipSetDevice(g_ctx.device));
+
+  // --- dirty handling (_CalcDirtyFlagsForRenderParams, Gi.cpp:1859-1987; sample offset reset :2125-2129)
+  uint8_t clear[GI_C_MAX_AOV_COMP_SIZE] = {0};
+  if (colorBinding) memcpy(clear, colorBinding->clearValue, GI_C_MAX_AOV_COMP_SIZE);
+  const float* domeEm = params->domeLight ? params->domeLight->baseEmission : nullptr;
+  if (!s->haveOldParams || memcmp(&s->oldCamera, &params->camera, sizeof(GiCCameraDesc)) != 0 || !settingsEqual(s->oldSettings, rs) ||
+      memcmp(s->oldClear, clear, sizeof(clear)) != 0 || s->oldRowBegin != rowBegin || s->oldRowEnd != rowEnd || s->oldDome != params->domeLight ||
+      (domeEm && memcmp(domeEm, s->oldDomeEmission, 12) != 0))
+    s->dirty |= DIRTY_FRAMEBUFFER;
+  s->haveOldParams = true; s->oldCamera = params->camera; s->oldSettings = rs; memcpy(s->oldClear, clear, sizeof(clear));
+  s->oldRowBegin = rowBegin; s->oldRowEnd = rowEnd; s->oldDome = params->domeLight;
+  if (domeEm) memcpy(s->oldDomeEmission, domeEm, 12);
+
+  s->stats.bvhBuildMs = 0.0; s->stats.uploadMs = 0.0;
+  if (s->dirty & (DIRTY_BVH | DIRTY_MATERIALS)) { if (buildScene(s) != GI_C_OK) return GI_C_ERROR; s->dirty &= ~(DIRTY_BVH | DIRTY_MATERIALS); s->dirty |= DIRTY_FRAMEBUFFER; }
+  if (s->dirty & DIRTY_LIGHTS) { if (uploadLights(s) != GI_C_OK) return GI_C_ERROR; s->dirty &= ~DIRTY_LIGHTS; s->dirty |= DIRTY_FRAMEBUFFER; }
+  if (!rs.progressiveAccumulation) s->dirty |= DIRTY_FRAMEBUFFER;
+  if (s->dirty & DIRTY_FRAMEBUFFER) { s->sampleOffset = 0; s->dirty &= ~DIRTY_FRAMEBUFFER; }
+
+  // --- non-colour AOVs: cleared to their clear value (the 16 auxiliary AOVs are a "next" row)
+  for (uint32_t i = 0; i < params->aovBindingCount; i++) {
+    const GiCAovBinding& b = params->aovBindings[i];
+    if (b.aovId == GI_C_AOV_COLOR) continue;
+    GiCRenderBuffer* rb = b.renderBuffer;
+    size_t n = (size_t)rb->width * rb->height;
+    for (size_t k = 0; k < n; k++) memcpy((uint8_t*)rb->hostMem + k * rb->stride, b.clearValue, rb->stride);
+    HIP_TRY(hipMemcpyAsync(rb->deviceMem, rb->hostMem, rb->size, hipMemcpyHostToDevice, st));
+  }
+  if (!colorBinding) { HIP_TRY(hipStreamSynchronize(st)); return GI_C_OK; } // rp_main.miss:70-72: colour work is skipped entirely
+  GiCRenderBuffer* colorRb = colorBinding->renderBuffer;
+  if (colorRb->stride != 16) { setError("giCRender: colour AOV needs a Float32Vec4 buffer"); return GI_C_ERROR; }
+
+  // --- uniforms (Gi.cpp:2373-2426; camera terms rp_main.rgen:199-212 evaluated once on the host)
+  const size_t slots = (size_t)(rowEnd - rowBegin) * width;
+  if (slots == 0) return GI_C_OK;
+  FrameUniforms U{};
+  {
+    const GiCCameraDesc& c = params->camera;
+    auto norm3 = [](const float* v, float* o) { float inv = 1.0f / sqrtf((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]); o[0] = v[0] * inv; o[1] = v[1] * inv; o[2] = v[2] * inv; };
+    norm3(c.forward, U.camFwd); norm3(c.up, U.camUp);
+    memcpy(U.camPos, c.position, 12);
+    U.camRight[0] = U.camFwd[1] * U.camUp[2] - U.camFwd[2] * U.camUp[1];
+    U.camRight[1] = U.camFwd[2] * U.camUp[0] - U.camFwd[0] * U.camUp[2];
+    U.camRight[2] = U.camFwd[0] * U.camUp[1] - U.camFwd[1] * U.camUp[0];
+    float aspect = (float)width / (float)height;
+    float H = 1.0f, W = H * aspect;
+    float d = H / (2.0f * tanf(c.vfov * 0.5f));
+    U.WX = W / (float)width; U.HY = H / (float)height;
+    for (int a = 0; a < 3; a++) {
+      float C = U.camPos[a] + U.camFwd[a] * d;
+      U.L[a] = (C - U.camRight[a] * W * 0.5f) - U.camUp[a] * H * 0.5f;
+    }
+    U.lensRadius = (c.fStop > 0.0f) ? c.focalLength / (2.0f * c.fStop) : 0.0f;
+    U.focusDistance = c.focusDistance;
+    uint32_t cr = packHalf2x16(c.clipStart, c.clipEnd);
+    U.clipNear = f16ToF32((uint16_t)(cr & 0xffffu)); U.clipFar = f16ToF32((uint16_t)(cr >> 16));
+    float cv[4]; memcpy(cv, clear, 16);
+    for (int a = 0; a < 3; a++) { // fallback dome texel: glm::u8vec4(bg * 255) as RGBA8 unorm (Gi.cpp:2194-2199)
+      int q = (int)(cv[a] * 255.0f); if (q < 0) q = 0; if (q > 255) q &= 255;
+      U.background[a] = (float)q / 255.0f;
+      if (params->domeLight) U.background[a] = params->domeLight->baseEmission[a]; // uniform dome: colour x emission multiplier (rp_main.miss:82-83)
+    }
+    U.exposureScale = exp2f(c.exposure);
+    U.spp = rs.spp; U.sampleOffset = s->sampleOffset; U.invSpp = 1.0f / (float)rs.spp; U.sppF = (float)rs.spp; U.sampleOffsetF = (float)s->sampleOffset;
+    U.invTotalSampleCount = 1.0f / float(s->sampleOffset + rs.spp);
+    U.maxSampleValue = rs.maxSampleValue; U.rrInvMinTermProb = rs.rrInvMinTermProb; U.lightIntensityMultiplier = rs.lightIntensityMultiplier;
+    U.maxBounces = std::min(rs.maxBounces, 0xfffu); U.rrBounceOffset = rs.rrBounceOffset & 0xffffu;
+    U.imageWidth = width; U.imageHeight = height; U.rowBegin = rowBegin; U.pixelCount = (uint32_t)slots;
+    U.flags = (rs.jitteredSampling ? FLAG_JITTER : 0u) | (rs.filterImportanceSampling ? FLAG_FIS : 0u) | (rs.depthOfField ? FLAG_DOF : 0u) |
+              (rs.clippingPlanes ? FLAG_CLIP : 0u) | (rs.nextEventEstimation ? FLAG_NEE : 0u) | (rs.progressiveAccumulation ? FLAG_PROGRESSIVE : 0u);
+    U.sphereCount = (uint32_t)s->sphereLights.recs.size(); U.distantCount = (uint32_t)s->distantLights.recs.size();
+    U.rectCount = (uint32_t)s->rectLights.recs.size(); U.diskCount = (uint32_t)s->diskLights.recs.size();
+    U.totalLightCount = U.sphereCount + U.distantCount + U.rectCount + U.diskCount;
+  }
+
+  if (ensurePathState(s, slots) != GI_C_OK) return GI_C_ERROR;
+  PathState ps{s->sRayO.ptr, s->sRayD.ptr, s->sHit.ptr, s->sThr.ptr, s->sRad.ptr, s->sAcc.ptr, s->sNeeC.ptr, s->sNeeD.ptr};
+  SceneView view = makeView(s);
+  uint32_t* queues[2] = {s->qA.ptr, s->qB.ptr};
+  F4* colorOut = reinterpret_cast<F4*>(colorRb->deviceMem);
+  const bool nee = rs.nextEventEstimation != 0;
+  const uint32_t wideBlocks = (uint32_t)std::min<size_t>((slots + 255) / 256, (size_t)g_ctx.cuCount * 8);
+  const uint32_t traceBlocks = (uint32_t)std::min<size_t>((slots + 255) / 256, (size_t)g_ctx.cuCount * 3);
+
+  // --- the bounce loop (rp_main.rgen:215, 295): every slot advances one stage per iteration
+  HIP_TRY(hipStreamSynchronize(st));
+  double tStart = nowMs();
+  launchInit(st, ps, s->qRegen.ptr, s->dCounters.ptr, (uint32_t)slots);
+  const uint64_t maxIters = (uint64_t)rs.spp * std::max(1u, U.maxBounces) + 2u;
+  uint32_t cur = Q_TRACE_A, next = Q_TRACE_B;
+  uint32_t iters = 0, traceLaunches = 0;
+  size_t ev = 0;
+  std::vector<int> evKind; // 0 raygen, 1 trace, 2 shade, 3 shadow
+  const bool timers = s->kernelTimers;
+  auto timed = [&](int kind, auto&& fn) {
+    if (timers) { (void)hipEventRecord(poolEvent(s, ev), st); fn(); (void)hipEventRecord(poolEvent(s, ev + 1), st); ev += 2; evKind.push_back(kind); }
+    else fn();
+  };
+  for (uint64_t it = 0; it < maxIters; it++) {
+    timed(0, [&] { launchRaygen(st, wideBlocks, U, ps, s->qRegen.ptr, queues[cur], s->dCounters.ptr, cur, colorOut); });
+    if (it >= rs.spp && (it % 8u) == 0u) { // a slot needs >= spp iterations; afterwards poll the queue sizes
+      HIP_TRY(hipMemcpyAsync(s->hCounters, s->dCounters.ptr, sizeof(uint32_t) * Q_COUNT, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      if (s->hCounters->count[cur] == 0) break; // raygen consumed the regen queue and produced no rays: done
+    }
+    timed(1, [&] { launchTrace(st, traceBlocks, false, s->countTraversal, view, ps, queues[cur], s->dCounters.ptr, cur); });
+    traceLaunches++;
+    launchReset(st, s->dCounters.ptr, next, Q_REGEN, Q_SHADOW);
+    timed(2, [&] { launchShade(st, wideBlocks, U, view, ps, queues[cur], queues[next], s->qRegen.ptr, s->qShadow.ptr, s->dCounters.ptr, cur, next); });
+    if (nee) timed(3, [&] { launchTrace(st, traceBlocks, true, s->countTraversal, view, ps, s->qShadow.ptr, s->dCounters.ptr, Q_SHADOW); });
+    std::swap(cur, next);
+    iters++;
+  }
+  HIP_TRY(hipMemcpyAsync(s->hCounters, s->dCounters.ptr, sizeof(Counters), hipMemcpyDeviceToHost, st));
+  if (!colorRb->deviceOnly) {
+    size_t off = (size_t)rowBegin * width * 16, bytes = slots * 16;
+    HIP_TRY(hipMemcpyAsync((uint8_t*)colorRb->hostMem + off, (uint8_t*)colorRb->deviceMem + off, bytes, hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
+  double tEnd = nowMs();
+
+  GiCRenderStats& S = s->stats;
+  S.renderMs = tEnd - tStart; S.samples = (uint64_t)slots * rs.spp; S.iterations = iters; S.traceLaunches = traceLaunches;
+  S.segments = s->hCounters->segments; S.shadowRays = s->hCounters->shadowRays; S.nodesVisited = s->hCounters->nodesVisited; S.trisTested = s->hCounters->trisTested;
+  S.shadowNodesVisited = s->hCounters->shadowNodesVisited; S.shadowTrisTested = s->hCounters->shadowTrisTested;
+  S.traceMs = S.shadeMs = S.raygenMs = S.shadowMs = 0.0;
+  if (timers) {
+    for (size_t k = 0; k < evKind.size(); k++) {
+      float ms = 0.0f; (void)hipEventElapsedTime(&ms, s->eventPool[2 * k], s->eventPool[2 * k + 1]);
+      if (evKind[k] == 0) S.raygenMs += ms; else if (evKind[k] == 1) S.traceMs += ms; else if (evKind[k] == 2) S.shadeMs += ms; else S.shadowMs += ms;
+    }
+  }
+  s->sampleOffset += rs.spp; // Gi.cpp:2515
+  return GI_C_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// giCTraceRays: closest hits through the device traversal kernel (parity tests of the BVH8 path)
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int giCTraceRays(GiCScene* s, uint32_t count, const float* origins, const float* dirs, float tMin, float tMax, float* outTUV, int32_t* outInstPrim)
+{
+  if (!g_ctx.initialized || !s || (count && (!origins || !dirs || !outTUV || !outInstPrim))) { setError("giCTraceRays: bad arguments"); return -1; }
+  if (count == 0) return 0;
+  std::lock_guard<std::mutex> guard(s->mutex);
+  hipStream_t st = g_ctx.stream;
+  if (s->dirty & (DIRTY_BVH | DIRTY_MATERIALS)) { if (buildScene(s) != GI_C_OK) return -1; s->dirty &= ~(DIRTY_BVH | DIRTY_MATERIALS); s->dirty |= DIRTY_FRAMEBUFFER; }
+  if (ensurePathState(s, count) != GI_C_OK) return -1;
+  std::vector<F4> ro(count), rd(count); std::vector<uint32_t> q(count);
+  for (uint32_t i = 0; i < count; i++) {
+    ro[i] = F4{origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], tMin};
+    rd[i] = F4{dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], tMax};
+    q[i] = i;
+  }
+  Counters c{}; c.count[Q_TRACE_A] = count;
+  if (hipMemcpyAsync(s->sRayO.ptr, ro.data(), count * sizeof(F4), hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(s->sRayD.ptr, rd.data(), count * sizeof(F4), hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(s->qA.ptr, q.data(), count * sizeof(uint32_t), hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(s->dCounters.ptr, &c, sizeof(c), hipMemcpyHostToDevice, st) != hipSuccess) { setError("giCTraceRays: upload failed"); return -1; }
+  PathState ps{s->sRayO.ptr, s->sRayD.ptr, s->sHit.ptr, s->sThr.ptr, s->sRad.ptr, s->sAcc.ptr, s->sNeeC.ptr, s->sNeeD.ptr};
+  uint32_t blocks = std::min<uint32_t>((count + 255u) / 256u, (uint32_t)g_ctx.cuCount * 3u);
+  launchTrace(st, blocks, false, false, makeView(s), ps, s->qA.ptr, s->dCounters.ptr, Q_TRACE_A);
+  std::vector<F4> hit(count);
+  std::vector<TriRec> tris(s->triCount);
+  if (hipMemcpyAsync(hit.data(), s->sHit.ptr, count * sizeof(F4), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      (s->triCount && hipMemcpyAsync(tris.data(), s->dTris.ptr, s->triCount * sizeof(TriRec), hipMemcpyDeviceToHost, st) != hipSuccess) ||
+      hipStreamSynchronize(st) != hipSuccess) { setError("giCTraceRays: readback failed"); return -1; }
+  int hits = 0;
+  for (uint32_t i = 0; i < count; i++) {
+    uint32_t tri; memcpy(&tri, &hit[i].w, 4);
+    outTUV[3 * i] = hit[i].x; outTUV[3 * i + 1] = hit[i].y; outTUV[3 * i + 2] = hit[i].z;
+    if (tri == 0xffffffffu || tri >= s->triCount) { outInstPrim[2 * i] = -1; outInstPrim[2 * i + 1] = -1; }
+    else { outInstPrim[2 * i] = (int32_t)tris[tri].instance; outInstPrim[2 * i + 1] = (int32_t)tris[tri].prim; hits++; }
+  }
+  return hits;
+}

@@ -1,0 +1,19 @@
+// gi_kernels.h -- host-side launch interface of the stage kernels (gi_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "gi_types.h"
+
+namespace gi {
+
+void launchInit(hipStream_t s, const PathState& st, uint32_t* qRegen, Counters* cnt, uint32_t n);
+void launchReset(hipStream_t s, Counters* cnt, uint32_t a, uint32_t b, uint32_t c);
+void launchRaygen(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const PathState& st, const uint32_t* qRegen, uint32_t* qTrace,
+                  Counters* cnt, uint32_t traceIdx, F4* colorOut);
+void launchTrace(hipStream_t s, uint32_t blocks, bool anyHit, bool count, const SceneView& sc, const PathState& st, const uint32_t* queue,
+                 Counters* cnt, uint32_t queueIdx);
+void launchShade(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const SceneView& sc, const PathState& st, const uint32_t* qCur,
+                 uint32_t* qNext, uint32_t* qRegen, uint32_t* qShadow, Counters* cnt, uint32_t curIdx, uint32_t nextIdx);
+
+} // namespace gi

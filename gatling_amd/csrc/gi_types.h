@@ -1,0 +1,137 @@
+// gi_types.h -- POD layouts shared by the host code (gi_c.cpp, bvh8.cpp) and the HIP kernels.
+// All structs are plain data in HBM; sizes are asserted.  See DESIGN.md "Data layout in HBM".
+#pragma once
+
+#include <stdint.h>
+
+namespace gi {
+
+// 8-wide quantised BVH node, 80 bytes (5 x 16 B loads).  Layout after Ylitie/Karras/Laine 2017
+// ("Efficient Incoherent Ray Traversal on GPUs Through Compressed Wide BVHs"), implemented from the paper.
+struct Node8 {
+  float p[3];        // quantisation origin (node AABB min)
+  uint8_t e[3];      // per-axis exponent: scale_i = 2^(e_i - 127) (float exponent field)
+  uint8_t imask;     // bit s set: slot s holds an internal node
+  uint32_t childBase; // index of the first internal child node (internal children are contiguous, slot order)
+  uint32_t triBase;   // index of the first triangle referenced by this node's leaf slots
+  uint8_t meta[8];    // 0: empty; internal: (1<<5)|(24+slot); leaf: (unary count<<5)|triangle offset
+  uint8_t qlo[3][8];  // quantised child AABB min, [axis][slot]
+  uint8_t qhi[3][8];  // quantised child AABB max
+};
+static_assert(sizeof(Node8) == 80, "Node8 must be 80 bytes");
+
+// Triangle record, 48 bytes (3 x 16 B loads): world-space vertex + edges, plus ids.
+struct TriRec {
+  float v0[3];
+  float e1[3];
+  float e2[3];
+  uint32_t instance; // index into InstanceRec[]
+  uint32_t prim;     // gl_PrimitiveID within the mesh
+  uint32_t origId;   // global triangle id in scene order (tie-break key, DESIGN.md "Traversal contract")
+};
+static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
+
+// == rp::FVertex (rp_main.h:58-64), 32 bytes
+struct FVertex {
+  float pos[3];
+  float bsign;
+  uint32_t normal;  // octahedral unorm2x16
+  uint32_t tangent; // octahedral unorm2x16
+  float u, v;
+};
+static_assert(sizeof(FVertex) == 32, "FVertex must be 32 bytes");
+
+// Replaces gl_ObjectToWorldEXT / gl_WorldToObjectEXT + BlasPayload (rp_main.h:118-123), 96 bytes
+struct InstanceRec {
+  float o2w[12]; // rows of the 3x4 object->world matrix
+  float w2o[9];  // inverse of its 3x3 part, row-major
+  uint32_t mesh;
+  int32_t instanceId;
+  uint32_t pad;
+};
+static_assert(sizeof(InstanceRec) == 96, "InstanceRec must be 96 bytes");
+
+struct MeshRec {
+  uint32_t faceOffset;   // into faces[] (in uint32 triples)
+  uint32_t vertexOffset; // into verts[]
+  uint32_t material;     // index into MaterialRec[]
+  uint32_t flags;        // bit0 flipFacing, bit1 doubleSided (rp_main.h:115-116)
+};
+static_assert(sizeof(MeshRec) == 16, "MeshRec must be 16 bytes");
+
+constexpr uint32_t MAT_PARAM_COUNT = 48;
+struct MaterialRec {
+  uint32_t klass;
+  uint32_t flags;
+  float p[MAT_PARAM_COUNT];
+};
+static_assert(sizeof(MaterialRec) == 200, "MaterialRec must be 200 bytes");
+
+// == rp::SphereLight / DistantLight / RectLight / DiskLight (rp_main.h:73-113), 48 bytes each
+struct SphereLightRec { float pos[3]; uint32_t ds; float em[3]; float area; float radius[3]; float pad; };
+struct DistantLightRec { float dir[3]; float angle; float em[3]; uint32_t ds; float pad[3]; float invPdf; };
+struct RectLightRec { float origin[3]; float width; float em[3]; float height; uint32_t t0, t1, ds; float pad; };
+struct DiskLightRec { float origin[3]; float rx; float em[3]; float ry; uint32_t t0, t1, ds; float pad; };
+static_assert(sizeof(SphereLightRec) == 48 && sizeof(DistantLightRec) == 48 && sizeof(RectLightRec) == 48 && sizeof(DiskLightRec) == 48, "lights are 48 bytes");
+
+// Per-frame constants (replaces rp::UniformData, rp_main.h:25-56; derived camera terms are computed once on
+// the host exactly as rp_main.rgen:199-212 does per pixel).
+struct FrameUniforms {
+  float camPos[3]; float WX;
+  float camFwd[3]; float HY;
+  float camUp[3]; float lensRadius;
+  float camRight[3]; float focusDistance;
+  float L[3]; float clipNear;
+  float background[3]; float clipFar;
+  float invSpp, sppF, sampleOffsetF, invTotalSampleCount;
+  float maxSampleValue, rrInvMinTermProb, lightIntensityMultiplier, exposureScale;
+  uint32_t spp, sampleOffset, maxBounces, rrBounceOffset;
+  uint32_t imageWidth, imageHeight, rowBegin, pixelCount; // pixelCount = slots of this tile
+  uint32_t flags; // FLAG_*
+  uint32_t sphereCount, distantCount, rectCount, diskCount, totalLightCount;
+  uint32_t pad[2];
+};
+enum : uint32_t {
+  FLAG_JITTER = 1u, FLAG_FIS = 2u, FLAG_DOF = 4u, FLAG_CLIP = 8u, FLAG_NEE = 16u, FLAG_PROGRESSIVE = 32u,
+};
+
+// Device-side scene view handed to the kernels.
+struct SceneView {
+  const Node8* nodes;
+  const TriRec* tris;
+  const InstanceRec* instances;
+  const MeshRec* meshes;
+  const uint32_t* faces;
+  const FVertex* verts;
+  const MaterialRec* materials;
+  const SphereLightRec* sphereLights;
+  const DistantLightRec* distantLights;
+  const RectLightRec* rectLights;
+  const DiskLightRec* diskLights;
+  uint32_t nodeCount;
+  uint32_t triCount;
+};
+
+// Wavefront path state, SoA over slots (one slot per pixel of the tile; DESIGN.md "Path state").
+struct alignas(16) F4 { float x, y, z, w; };
+
+struct PathState {
+  F4* rayO;  // origin.xyz, tMin
+  F4* rayD;  // dir.xyz, tMax
+  F4* hit;   // t, u, v, asfloat(triangle index in BVH order | 0xffffffff = miss)
+  F4* thr;   // throughput.xyz, asfloat(bitfield)   (rp_main_payload.glsl:24-33)
+  F4* rad;   // radiance.xyz, asfloat(rng state)
+  F4* acc;   // pixel_color accumulator.xyz, asfloat(sample index in flight | 0xffffffff = none yet)
+  F4* neeC;  // neeContrib.xyz, lightDist
+  F4* neeD;  // shadow ray dir.xyz, unused
+};
+
+// Work queues (slot indices) and their device-side counters.
+enum : uint32_t { Q_TRACE_A = 0, Q_TRACE_B = 1, Q_REGEN = 2, Q_SHADOW = 3, Q_COUNT = 4 };
+struct Counters {
+  uint32_t count[Q_COUNT];
+  uint32_t pad[4];
+  unsigned long long segments, shadowRays, nodesVisited, trisTested, shadowNodesVisited, shadowTrisTested;
+};
+
+} // namespace gi

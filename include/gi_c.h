@@ -1,0 +1,291 @@
+/*
+ * gi_c.h -- C ABI of the MI355X-native render core ("libgatling_gi.so").
+ *
+ * This is the drop-in boundary for the path BASELINE.json names: the `gi` render loop of
+ * pablode/gatling.  In the reference that boundary is the C++ API of
+ * /root/reference/src/gi/gtl/gi/Gi.h:199-261 (free functions over opaque structs, linked as a static
+ * library into hdGatling.so).  Every entry point below cites the Gi.h declaration it replaces; argument
+ * meaning, ownership and error behaviour follow the reference:
+ *   - the library owns every handle; callers destroy explicitly;
+ *   - giCCreateMesh COPIES all vertex/face data before returning (Gi.cpp:620-638);
+ *   - transforms are row-major 4x4 floats in USD's row-vector convention (Gi.cpp:641-658);
+ *   - setters only mark the scene dirty; BVH build + upload happen in the next giCRender
+ *     (hdGatling/renderDelegate.cpp:208-213);
+ *   - giCRender blocks until the AOVs are complete in host memory (Gi.cpp:2492-2502);
+ *   - status returns: GI_C_OK / GI_C_ERROR; creators return NULL on failure; no exceptions cross.
+ * Differences, all forced by plain-C types: std::vector / std::string_view arguments become
+ * pointer + count; MaterialX/MDL material creation (Gi.h:204-206) becomes giCCreateMaterial with a
+ * closed-form parameter block (DESIGN.md "Materials"); the gtl:: C++ shim on top of this header lives in
+ * include/gtl/gi/Gi.h.  Extensions that the reference does not have are marked [ext].
+ *
+ * The library is HIP-only: if no gfx950 device / HIP runtime is available giCInitialize fails
+ * (there is no CPU fallback).
+ */
+#ifndef GATLING_GI_C_H
+#define GATLING_GI_C_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GI_C_OK 0
+#define GI_C_ERROR 1
+
+#define GI_C_MAX_AOV_COMP_SIZE 16 /* Gi.h:32 */
+
+/* Gi.h:36-56 */
+typedef enum GiCAovId {
+  GI_C_AOV_COLOR = 0, GI_C_AOV_NORMAL, GI_C_AOV_NEE, GI_C_AOV_BARYCENTRICS, GI_C_AOV_TEXCOORDS, GI_C_AOV_BOUNCES,
+  GI_C_AOV_CLOCK_CYCLES, GI_C_AOV_OPACITY, GI_C_AOV_TANGENTS, GI_C_AOV_BITANGENTS, GI_C_AOV_THIN_WALLED,
+  GI_C_AOV_OBJECT_ID, GI_C_AOV_DEPTH, GI_C_AOV_FACE_ID, GI_C_AOV_INSTANCE_ID, GI_C_AOV_DOUBLE_SIDED, GI_C_AOV_ALBEDO,
+  GI_C_AOV_COUNT
+} GiCAovId;
+
+/* Gi.h:70-75 */
+typedef enum GiCRenderBufferFormat { GI_C_FORMAT_INT32 = 0, GI_C_FORMAT_FLOAT32 = 1, GI_C_FORMAT_FLOAT32_VEC4 = 2 } GiCRenderBufferFormat;
+
+typedef struct GiCScene GiCScene;
+typedef struct GiCMaterial GiCMaterial;
+typedef struct GiCMesh GiCMesh;
+typedef struct GiCSphereLight GiCSphereLight;
+typedef struct GiCDistantLight GiCDistantLight;
+typedef struct GiCRectLight GiCRectLight;
+typedef struct GiCDiskLight GiCDiskLight;
+typedef struct GiCDomeLight GiCDomeLight;
+typedef struct GiCRenderBuffer GiCRenderBuffer;
+
+/* Gi.h:96-108 (same layout) */
+typedef struct GiCCameraDesc {
+  float position[3];
+  float forward[3];
+  float up[3];
+  float vfov;
+  float fStop;
+  float focusDistance;
+  float focalLength;
+  float clipStart;
+  float clipEnd;
+  float exposure;
+} GiCCameraDesc;
+
+/* Gi.h:110-118 (same layout, 48 bytes) */
+typedef struct GiCVertex {
+  float pos[3];
+  float u;
+  float norm[3];
+  float v;
+  float tangent[3];
+  float bitangentSign;
+} GiCVertex;
+
+/* Gi.h:120-122 */
+typedef struct GiCFace { uint32_t v_i[3]; } GiCFace;
+
+/* Gi.h:124-137 with vectors flattened to pointer+count (primvars: SURVEY section 8f, not yet consumed) */
+typedef struct GiCMeshDesc {
+  uint32_t faceCount;
+  const GiCFace* faces;
+  const int32_t* faceIds; /* faceCount entries or NULL */
+  int32_t id;
+  int32_t isDoubleSided;
+  int32_t isLeftHanded;
+  const char* name;
+  uint32_t maxFaceId;
+  uint32_t vertexCount;
+  const GiCVertex* vertices;
+} GiCMeshDesc;
+
+/* Gi.h:139-159 (bools widened to int32 for a stable ABI) */
+typedef struct GiCRenderSettings {
+  int32_t clippingPlanes;
+  int32_t depthOfField;
+  int32_t domeLightCameraVisible;
+  int32_t filterImportanceSampling;
+  float frame;
+  int32_t jitteredSampling;
+  float lightIntensityMultiplier;
+  uint32_t maxBounces;
+  float maxSampleValue;
+  uint32_t maxVolumeWalkLength;
+  uint32_t mediumStackSize;
+  float metersPerSceneUnit;
+  int32_t nextEventEstimation;
+  int32_t progressiveAccumulation;
+  uint32_t rrBounceOffset;
+  float rrInvMinTermProb;
+  uint32_t spp;
+  float time;
+} GiCRenderSettings;
+
+/* Gi.h:161-166 */
+typedef struct GiCAovBinding {
+  int32_t aovId; /* GiCAovId */
+  uint8_t clearValue[GI_C_MAX_AOV_COMP_SIZE];
+  GiCRenderBuffer* renderBuffer;
+} GiCAovBinding;
+
+/* Gi.h:168-175 */
+typedef struct GiCRenderParams {
+  const GiCAovBinding* aovBindings;
+  uint32_t aovBindingCount;
+  GiCCameraDesc camera;
+  GiCDomeLight* domeLight;
+  GiCRenderSettings renderSettings;
+  GiCScene* scene;
+  /* [ext] multi-GPU sharding: render only image rows [rowBegin,rowEnd) of the full image whose size is the
+   * render buffers' size; rowEnd == 0 means "all rows".  RNG streams use the global pixel index so an N-way
+   * split is bit-identical to the single-GPU image. */
+  uint32_t rowBegin;
+  uint32_t rowEnd;
+} GiCRenderParams;
+
+/* Closed-form material classes: replaces MaterialX->MDL->GLSL codegen (src/mc, GlslShaderGen) */
+#define GI_C_MAT_DIFFUSE 0u             /* config C1 "diffuse only" model */
+#define GI_C_MAT_USD_PREVIEW_SURFACE 1u /* diffuse + GGX specular + clearcoat */
+#define GI_C_MAT_OPEN_PBR 2u
+#define GI_C_MAT_PARAM_COUNT 48u
+/* indices into GiCMaterialDesc.p */
+#define GI_C_P_BASE_COLOR 0
+#define GI_C_P_EMISSION 3
+#define GI_C_P_USE_SPECULAR_WORKFLOW 6
+#define GI_C_P_SPECULAR_COLOR 7
+#define GI_C_P_METALLIC 10
+#define GI_C_P_ROUGHNESS 11
+#define GI_C_P_CLEARCOAT 12
+#define GI_C_P_CLEARCOAT_ROUGHNESS 13
+#define GI_C_P_OPACITY 14
+#define GI_C_P_OPACITY_THRESHOLD 15
+#define GI_C_P_IOR 16
+#define GI_C_P_BASE_WEIGHT 17
+#define GI_C_P_SPECULAR_WEIGHT 18
+#define GI_C_P_COAT_COLOR 19
+#define GI_C_P_COAT_IOR 22
+#define GI_C_P_TRANSMISSION_WEIGHT 23
+#define GI_C_P_TRANSMISSION_COLOR 24
+#define GI_C_P_DIFFUSE_ROUGHNESS 27
+
+typedef struct GiCMaterialDesc {
+  uint32_t klass;
+  uint32_t flags;
+  float p[GI_C_MAT_PARAM_COUNT];
+} GiCMaterialDesc;
+
+/* [ext] per-frame statistics of the last giCRender on a scene (measurement) */
+typedef struct GiCRenderStats {
+  double renderMs;       /* wall time of the bounce loop incl. final D2H of the colour AOV */
+  double bvhBuildMs;     /* host BVH8 build (0 if not rebuilt)                              */
+  double uploadMs;       /* scene upload (0 if not rebuilt)                                 */
+  double traceMs;        /* sum of closest-hit traversal kernel time (HIP events)           */
+  double shadeMs;        /* sum of shade kernel time                                        */
+  double raygenMs;       /* sum of raygen/accumulate kernel time                            */
+  double shadowMs;       /* sum of shadow traversal kernel time                             */
+  uint64_t samples;      /* pixels * spp rendered by this call                              */
+  uint64_t segments;     /* closest-hit rays traced                                         */
+  uint64_t shadowRays;   /* shadow rays traced                                              */
+  uint64_t nodesVisited; /* BVH8 nodes fetched by closest-hit traversal (if counting on)    */
+  uint64_t trisTested;   /* triangles tested by closest-hit traversal (if counting on)      */
+  uint64_t shadowNodesVisited;
+  uint64_t shadowTrisTested;
+  uint32_t iterations;   /* wavefront iterations                                            */
+  uint32_t traceLaunches;
+  uint32_t nodeCount;    /* BVH8 nodes                                                      */
+  uint32_t triangleCount;
+} GiCRenderStats;
+
+/* Gi.h:199-200.  deviceOrdinal selects the HIP device (the reference picks one Vulkan device by score,
+ * CgpuVk.cpp:892-909).  One giCInitialize per process, like the reference's global state (Gi.cpp:244-259). */
+int giCInitialize(int deviceOrdinal);
+void giCTerminate(void);
+/* [ext] last error message of the calling thread's most recent failing call ("" if none) */
+const char* giCGetLastError(void);
+
+/* Gi.h:204-207 */
+GiCMaterial* giCCreateMaterial(GiCScene* scene, const char* name, const GiCMaterialDesc* desc);
+void giCDestroyMaterial(GiCMaterial* mat);
+
+/* Gi.h:209-216 */
+GiCMesh* giCCreateMesh(GiCScene* scene, const GiCMeshDesc* desc);
+void giCSetMeshTransform(GiCMesh* mesh, const float* mat4x4);
+void giCSetMeshInstanceTransforms(GiCMesh* mesh, uint32_t count, const float* transforms /* count x 16 */);
+void giCSetMeshInstanceIds(GiCMesh* mesh, uint32_t count, const int32_t* ids);
+void giCSetMeshMaterial(GiCMesh* mesh, GiCMaterial* mat);
+void giCSetMeshVisibility(GiCMesh* mesh, int32_t visible);
+void giCDestroyMesh(GiCMesh* mesh);
+
+/* Gi.h:218 */
+int giCRender(const GiCRenderParams* params);
+
+/* Gi.h:220-221 */
+GiCScene* giCCreateScene(void);
+void giCDestroyScene(GiCScene* scene);
+
+/* Gi.h:223-228 */
+GiCSphereLight* giCCreateSphereLight(GiCScene* scene);
+void giCDestroySphereLight(GiCScene* scene, GiCSphereLight* light);
+void giCSetSphereLightPosition(GiCSphereLight* light, const float* position);
+void giCSetSphereLightBaseEmission(GiCSphereLight* light, const float* rgb);
+void giCSetSphereLightRadius(GiCSphereLight* light, float radiusX, float radiusY, float radiusZ);
+void giCSetSphereLightDiffuseSpecular(GiCSphereLight* light, float diffuse, float specular);
+
+/* Gi.h:230-235 */
+GiCDistantLight* giCCreateDistantLight(GiCScene* scene);
+void giCDestroyDistantLight(GiCScene* scene, GiCDistantLight* light);
+void giCSetDistantLightDirection(GiCDistantLight* light, const float* direction);
+void giCSetDistantLightBaseEmission(GiCDistantLight* light, const float* rgb);
+void giCSetDistantLightAngle(GiCDistantLight* light, float angle);
+void giCSetDistantLightDiffuseSpecular(GiCDistantLight* light, float diffuse, float specular);
+
+/* Gi.h:237-243 */
+GiCRectLight* giCCreateRectLight(GiCScene* scene);
+void giCDestroyRectLight(GiCScene* scene, GiCRectLight* light);
+void giCSetRectLightOrigin(GiCRectLight* light, const float* origin);
+void giCSetRectLightTangents(GiCRectLight* light, const float* t0, const float* t1);
+void giCSetRectLightBaseEmission(GiCRectLight* light, const float* rgb);
+void giCSetRectLightDimensions(GiCRectLight* light, float width, float height);
+void giCSetRectLightDiffuseSpecular(GiCRectLight* light, float diffuse, float specular);
+
+/* Gi.h:245-251 */
+GiCDiskLight* giCCreateDiskLight(GiCScene* scene);
+void giCDestroyDiskLight(GiCScene* scene, GiCDiskLight* light);
+void giCSetDiskLightOrigin(GiCDiskLight* light, const float* origin);
+void giCSetDiskLightTangents(GiCDiskLight* light, const float* t0, const float* t1);
+void giCSetDiskLightBaseEmission(GiCDiskLight* light, const float* rgb);
+void giCSetDiskLightRadius(GiCDiskLight* light, float radiusX, float radiusY);
+void giCSetDiskLightDiffuseSpecular(GiCDiskLight* light, float diffuse, float specular);
+
+/* Gi.h:253-257.  Textured dome lights are a "next" row: filePath is recorded, the
+ * light behaves as a uniform dome of colour baseEmission. */
+GiCDomeLight* giCCreateDomeLight(GiCScene* scene, const char* filePath);
+void giCDestroyDomeLight(GiCDomeLight* light);
+void giCSetDomeLightRotation(GiCDomeLight* light, const float* quat);
+void giCSetDomeLightBaseEmission(GiCDomeLight* light, const float* rgb);
+void giCSetDomeLightDiffuseSpecular(GiCDomeLight* light, float diffuse, float specular);
+
+/* Gi.h:259-261 */
+GiCRenderBuffer* giCCreateRenderBuffer(uint32_t width, uint32_t height, int32_t format /* GiCRenderBufferFormat */);
+void giCDestroyRenderBuffer(GiCRenderBuffer* renderBuffer);
+void* giCGetRenderBufferMem(GiCRenderBuffer* renderBuffer);
+
+/* [ext] device-resident copy of the render buffer (valid after the first giCRender that bound it), so a
+ * multi-GPU caller can gather tiles with RCCL without a host round trip. */
+void* giCGetRenderBufferDeviceMem(GiCRenderBuffer* renderBuffer);
+/* [ext] when nonzero, giCRender leaves results on the device only (no D2H copy); default 0 = reference behaviour */
+void giCSetRenderBufferDeviceOnly(GiCRenderBuffer* renderBuffer, int32_t deviceOnly);
+/* [ext] statistics of the last giCRender on this scene; countTraversal != 0 in giCSetSceneOption enables
+ * node/triangle counters (slower; measurement runs only). */
+int giCGetRenderStats(const GiCScene* scene, GiCRenderStats* out);
+#define GI_C_SCENE_OPTION_COUNT_TRAVERSAL 1
+#define GI_C_SCENE_OPTION_KERNEL_TIMERS 2
+int giCSetSceneOption(GiCScene* scene, int32_t option, int32_t value);
+/* [ext] closest hit of one ray through the device traversal kernel (parity tests of the BVH8 path).
+ * Returns 1 on hit (t,u,v, instance, prim written), 0 on miss, <0 on error. */
+int giCTraceRays(GiCScene* scene, uint32_t count, const float* origins /*3*count*/, const float* dirs /*3*count*/,
+                 float tMin, float tMax, float* outTUV /*3*count*/, int32_t* outInstPrim /*2*count, -1 on miss*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
