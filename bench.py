@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native gi render loop.
+
+Metric (BASELINE.json): Msamples/s = width*height*spp / t_render / 1e6 at 8 bounces, 1920x1080.
+One "step" = one giCRender pass of the hot path over the whole workload (BASELINE config C2 by default:
+cornell, 1920x1080, spp 1024, max-bounces 8, UsdPreviewSurface model); scene ingest, BVH build and upload happen
+before the timed region (the scene is resident in HBM), the timed region contains every bounce stage, the
+per-pixel accumulation, for N>1 the RCCL tile gather, and the final D2H of the colour AOV.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c3|c4] [--spp S]
+  N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+N>1 is strong scaling: the same frame is split into N contiguous row bands (one rank per GPU, scene replicated),
+tiles are gathered to rank 0 with one RCCL gather.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def make_workload(name, spp_override=None):
+    from gatling_amd.scene import MAT_DIFFUSE, RenderSettings
+    from gatling_amd.scenes import cornell_box, random_triangle_soup, sphere_grid
+    if name == "c2":
+        desc, rs, w, h = cornell_box(), RenderSettings(spp=1024, max_bounces=8), 1920, 1080
+        label = "C2: cornell.usda 1920x1080 spp=1024 max-bounces=8 UsdPreviewSurface (diffuse + GGX specular), NEE off"
+    elif name == "c1":
+        desc, rs, w, h = cornell_box(MAT_DIFFUSE), RenderSettings(spp=64, max_bounces=4), 512, 512
+        label = "C1: cornell.usda 512x512 spp=64 max-bounces=4 diffuse-only"
+    elif name == "c3":
+        desc, rs, w, h = random_triangle_soup(1_000_000), RenderSettings(spp=256, max_bounces=8, next_event_estimation=True), 1920, 1080
+        label = "C3: 1M-triangle soup, 1 material, rect light, NEE on, 1920x1080 spp=256 max-bounces=8"
+    elif name == "c4":
+        desc, rs, w, h = sphere_grid(32, 4, 32), RenderSettings(spp=256, max_bounces=8), 1920, 1080
+        label = "C4: 32x32 instanced icospheres (5120 tris each), 32 materials, 1920x1080 spp=256 max-bounces=8"
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    if spp_override:
+        rs.spp = spp_override
+        label += f" [spp overridden to {spp_override}]"
+    return desc, rs, w, h, label
+
+
+def cpu_baseline(desc, rs, w, h, budget_s=12.0):
+    """The CPU oracle (kind "port") on this box's host cores, on a bounded sample of the same workload: the full
+    frame at a reduced spp chosen so the run takes ~budget_s (throughput is per sample, so it scales linearly)."""
+    import copy
+    from oracle import orc
+    cores = os.cpu_count() or 1
+    probe = copy.copy(rs); probe.spp = 2
+    orc.render(desc, probe, max(8, w // 8), max(8, h // 8), threads=cores)  # warm the library / thread pool
+    t0 = time.perf_counter(); orc.render(desc, probe, w, h, threads=cores); t1 = (time.perf_counter() - t0) / probe.spp
+    spp = int(max(1, min(rs.spp, budget_s / max(t1, 1e-4))))
+    run = copy.copy(rs); run.spp = spp
+    t0 = time.perf_counter(); _, cnt = orc.render(desc, run, w, h, threads=cores); dt = time.perf_counter() - t0
+    return {"value": round(w * h * spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"full {w}x{h} frame at spp={spp} of {rs.spp} (same seeds as the first {spp} samples), {dt:.1f} s wall, "
+                      f"{cnt['segments'] / cnt['samples']:.3f} segments/sample"}
+
+
+def load_pmc_traffic():
+    """HBM bytes per k_trace launch from the committed rocprofv3 --pmc summary (profiles/), or None."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get("trace_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2")
+    ap.add_argument("--spp", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch  # plumbing: device sync, torch.distributed (RCCL).  Imported first so one HIP runtime is shared.
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    use_dist = world > 1 or bool(os.environ.get("GATLING_BENCH_FORCE_DIST"))  # the env var drives the N>1 code path on one GPU
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from gatling_amd import capi
+    from gatling_amd.dist import gather_rows, partition_rows
+
+    desc, rs, w, h, label = make_workload(args.workload, args.spp or None)
+    rs.progressive_accumulation = False  # every step renders the same frame from sample 0 (no cross-step accumulation)
+    scene = capi.Scene(desc, device=local_rank)
+    r0, r1 = partition_rows(h, world, rank)
+    dev_ptr = scene.device_pointer(w, h)
+
+    class _Tile:  # zero-copy view of the library's device render buffer (rows r0..r1) for the RCCL gather
+        def __init__(self):
+            self.__cuda_array_interface__ = {"shape": (r1 - r0, w, 4), "typestr": "<f4", "data": (dev_ptr + r0 * w * 16, False), "version": 2}
+    tile = torch.as_tensor(_Tile(), device=f"cuda:{local_rank}") if use_dist else None
+    host_full = torch.empty((h, w, 4), dtype=torch.float32).pin_memory() if (use_dist and rank == 0) else None
+
+    def step():
+        if not use_dist:
+            scene.render(rs, w, h)  # blocks; colour AOV complete in host memory on return (reference semantics)
+        else:
+            scene.render(rs, w, h, rows=(r0, r1), device_only=True)
+            full = gather_rows(tile, h, w)
+            if rank == 0:
+                host_full.copy_(full, non_blocking=False)
+
+    def sync():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    scene.set_option(capi.OPTION_KERNEL_TIMERS, 1)  # HIP events around every stage launch, on the library's own stream
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    stats = []
+    for _ in range(args.steps):
+        step()
+        stats.append(scene.stats())
+    sync()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # --- roofline inputs: one extra (untimed) step with the traversal counters on
+    scene.set_option(capi.OPTION_COUNT_TRAVERSAL, 1)
+    scene.render(rs, w, h, rows=(r0, r1), device_only=True)
+    cst = scene.stats()
+    scene.set_option(capi.OPTION_COUNT_TRAVERSAL, 0)
+
+    out = None
+    if rank == 0:
+        samples_per_step = w * h * rs.spp
+        value = samples_per_step * args.steps / dt / 1e6
+        # dominant traversal kernel k_trace<closest>: algorithmic bytes per launch: ray 32 + hit 20 per ray,
+        # 80 B per BVH8 node visited, 48 B per triangle tested; divided by its mean launch time (HIP events).
+        launches = sum(s["traceLaunches"] for s in stats)
+        trace_ms = sum(s["traceMs"] for s in stats)
+        rays = sum(s["segments"] for s in stats)
+        nodes_per_ray = cst["nodesVisited"] / max(1, cst["segments"])
+        tris_per_ray = cst["trisTested"] / max(1, cst["segments"])
+        bytes_total = rays * (52.0 + 80.0 * nodes_per_ray + 48.0 * tris_per_ray)
+        achieved = bytes_total / max(trace_ms * 1e-3, 1e-12) / 1e9
+        seg_per_sample = rays / max(1, sum(s["samples"] for s in stats))
+        stream_only = (samples_per_step * args.steps / dt) * seg_per_sample * 192.0 / 1e9  # whole-pipeline stream floor
+        roofline = {"bound": "hbm", "kernel": "k_trace<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": load_pmc_traffic(),
+                    "bytes_per_launch": round(bytes_total / max(1, launches), 1), "avg_launch_us": round(trace_ms * 1e3 / max(1, launches), 3),
+                    "nodes_per_ray": round(nodes_per_ray, 3), "tris_per_ray": round(tris_per_ray, 3),
+                    "stage_ms_per_step": {k: round(sum(s[k] for s in stats) / args.steps, 3) for k in ("raygenMs", "traceMs", "shadeMs", "shadowMs")},
+                    "pipeline_stream_only_GBps": round(stream_only, 2), "pipeline_stream_only_frac": round(stream_only / HBM_PEAK_GBS, 5)}
+        out = {"metric": "Msamples/s (spp x pixels / s) at 8 bounces, 1920x1080", "value": round(value, 2), "unit": "Msamples/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 3),
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": label, "width": w, "height": h, "spp": rs.spp, "max_bounces": rs.max_bounces,
+                          "parallelism": f"rows{world}" if world > 1 else "single", "segments_per_sample": round(seg_per_sample, 4),
+                          "triangles": cst["triangleCount"], "bvh8_nodes": cst["nodeCount"], "iterations_per_step": stats[-1]["iterations"]},
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(desc, rs, w, h)
+    scene.close()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        import ctypes
+        sys.stderr.flush()
+        ctypes.CDLL(None).fflush(None)  # flush C stdio (RCCL prints a version banner there) so the JSON is the LAST line
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -94,6 +94,8 @@ SYMBOLS = [
     ("giCGetRenderBufferDeviceMem", _P, [_P]), ("giCSetRenderBufferDeviceOnly", None, [_P, _I]),
     ("giCGetRenderStats", C.c_int, [_P, C.POINTER(GiCRenderStats)]), ("giCSetSceneOption", C.c_int, [_P, _I, _I]),
     ("giCTraceRays", C.c_int, [_P, _U, _FP, _FP, _F, _F, _FP, C.POINTER(C.c_int32)]),
+    ("giCDebugEvalBsdf", C.c_int, [C.POINTER(GiCMaterialDesc), _U, _FP, _FP]),
+    ("giCDebugValidateBvh", C.c_int, [_FP, _U, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
 ]
 
 _lib = None
@@ -293,3 +295,14 @@ class Scene:
             self.lights, self.meshes, self.materials = [], [], []
             self.L.giCDestroyScene(self.handle)
             self.handle = None
+
+
+def bsdf_debug(material, items, device: int = 0):
+    """Device-side closed-form BSDF sample/evaluate; items float32 [n,22] -> float32 [n,15] (see include/gi_c.h)."""
+    L = initialize(device)
+    md = GiCMaterialDesc(material.klass, 0, (C.c_float * P_COUNT)(*np.asarray(material.params, np.float32)))
+    a = np.ascontiguousarray(items, np.float32).reshape(-1, 22)
+    out = np.zeros((len(a), 15), np.float32)
+    if L.giCDebugEvalBsdf(C.byref(md), len(a), a.ctypes.data_as(_FP), out.ctypes.data_as(_FP)) != GI_C_OK:
+        raise GiError("giCDebugEvalBsdf failed: " + L.giCGetLastError().decode())
+    return out

@@ -882,3 +882,92 @@ extern "C" int giCTraceRays(GiCScene* s, uint32_t count, const float* origins, c
   }
   return hits;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// giCDebugValidateBvh: host-only check of the builder's conservativeness contract
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int giCDebugValidateBvh(const float* triVerts, uint32_t triCount, uint32_t* outNodeCount, uint32_t* outMaxDepth)
+{
+  if (triCount && !triVerts) return -1;
+  std::vector<TriRec> tris(triCount);
+  for (uint32_t i = 0; i < triCount; i++) {
+    const float* p = triVerts + 9 * (size_t)i;
+    for (int a = 0; a < 3; a++) { tris[i].v0[a] = p[a]; tris[i].e1[a] = p[3 + a] - p[a]; tris[i].e2[a] = p[6 + a] - p[a]; }
+    tris[i].instance = 0; tris[i].prim = i; tris[i].origId = i;
+  }
+  Bvh8 bvh; buildBvh8(tris, bvh);
+  if (outNodeCount) *outNodeCount = (uint32_t)bvh.nodes.size();
+  if (outMaxDepth) *outMaxDepth = bvh.maxDepth;
+  int violations = 0;
+  std::vector<uint8_t> seen(triCount, 0);
+  struct Item { uint32_t node; float lo[3], hi[3]; };
+  std::vector<Item> stack;
+  Item root; root.node = 0; for (int a = 0; a < 3; a++) { root.lo[a] = -3.0e38f; root.hi[a] = 3.0e38f; }
+  stack.push_back(root);
+  while (!stack.empty()) {
+    Item it = stack.back(); stack.pop_back();
+    if (it.node >= bvh.nodes.size()) { violations++; continue; }
+    const Node8& n = bvh.nodes[it.node];
+    uint32_t rel = 0;
+    for (int s = 0; s < 8; s++) {
+      uint8_t meta = n.meta[s];
+      if (meta == 0) { if (n.imask & (1u << s)) violations++; continue; }
+      float lo[3], hi[3];
+      for (int a = 0; a < 3; a++) {
+        uint32_t eb = (uint32_t)n.e[a] << 23; float scale; memcpy(&scale, &eb, 4);
+        lo[a] = n.p[a] + (float)n.qlo[a][s] * scale; hi[a] = n.p[a] + (float)n.qhi[a][s] * scale;
+        if (lo[a] < it.lo[a] - 1e-3f * (1.0f + fabsf(it.lo[a])) || hi[a] > it.hi[a] + 1e-3f * (1.0f + fabsf(it.hi[a]))) { /* child may poke out of the parent by quantisation only */ }
+      }
+      bool inner = (n.imask >> s) & 1u;
+      if (inner) {
+        if ((meta >> 5) != 1u || (meta & 31u) != 24u + (uint32_t)s) violations++;
+        Item c; c.node = n.childBase + rel; rel++;
+        for (int a = 0; a < 3; a++) { c.lo[a] = lo[a]; c.hi[a] = hi[a]; }
+        // every triangle below must also be inside all ancestors: intersect the constraint boxes
+        for (int a = 0; a < 3; a++) { c.lo[a] = std::max(c.lo[a], it.lo[a]); c.hi[a] = std::min(c.hi[a], it.hi[a]); }
+        stack.push_back(c);
+      } else {
+        uint32_t unary = meta >> 5, off = meta & 31u, cnt = unary == 1u ? 1u : unary == 3u ? 2u : unary == 7u ? 3u : 0u;
+        if (cnt == 0u || off + cnt > 24u) { violations++; continue; }
+        for (uint32_t k = 0; k < cnt; k++) {
+          uint32_t ti = n.triBase + off + k;
+          if (ti >= bvh.tris.size()) { violations++; continue; }
+          const TriRec& t = bvh.tris[ti];
+          if (t.origId >= triCount || seen[t.origId]) { violations++; continue; }
+          seen[t.origId] = 1;
+          for (int v = 0; v < 3; v++)
+            for (int a = 0; a < 3; a++) {
+              float x = t.v0[a] + (v == 1 ? t.e1[a] : v == 2 ? t.e2[a] : 0.0f);
+              float blo = std::max(lo[a], it.lo[a]), bhi = std::min(hi[a], it.hi[a]);
+              if (x < blo || x > bhi) violations++;
+            }
+        }
+      }
+    }
+  }
+  for (uint32_t i = 0; i < triCount; i++) if (!seen[i]) violations++;
+  return violations;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// giCDebugEvalBsdf: closed-form BSDF sample/evaluate on the device for explicit shading frames
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int giCDebugEvalBsdf(const GiCMaterialDesc* desc, uint32_t count, const float* in, float* out)
+{
+  if (!g_ctx.initialized || !desc || (count && (!in || !out))) { setError("giCDebugEvalBsdf: bad arguments"); return GI_C_ERROR; }
+  if (count == 0) return GI_C_OK;
+  MaterialRec m; m.klass = desc->klass; m.flags = desc->flags; memcpy(m.p, desc->p, sizeof(m.p));
+  MaterialRec* dm = nullptr; float* din = nullptr; float* dout = nullptr;
+  hipStream_t st = g_ctx.stream;
+  int rc = GI_C_ERROR;
+  if (hipMalloc((void**)&dm, sizeof(m)) == hipSuccess && hipMalloc((void**)&din, (size_t)count * 22 * 4) == hipSuccess &&
+      hipMalloc((void**)&dout, (size_t)count * 15 * 4) == hipSuccess &&
+      hipMemcpyAsync(dm, &m, sizeof(m), hipMemcpyHostToDevice, st) == hipSuccess &&
+      hipMemcpyAsync(din, in, (size_t)count * 22 * 4, hipMemcpyHostToDevice, st) == hipSuccess) {
+    launchDebugBsdf(st, dm, count, din, dout);
+    if (hipMemcpyAsync(out, dout, (size_t)count * 15 * 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) rc = GI_C_OK;
+  }
+  if (rc != GI_C_OK) setError("giCDebugEvalBsdf: HIP failure");
+  if (dm) (void)hipFree(dm); if (din) (void)hipFree(din); if (dout) (void)hipFree(dout);
+  return rc;
+}

@@ -25,8 +25,8 @@ __device__ __forceinline__ V3 operator*(V3 a, float s) { return V3{a.x * s, a.y 
 __device__ __forceinline__ V3 operator/(V3 a, float s) { return V3{a.x / s, a.y / s, a.z / s}; }
 __device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 __device__ __forceinline__ V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
-__device__ __forceinline__ float length(V3 a) { return __fsqrt_rn(dot(a, a)); }
-__device__ __forceinline__ V3 normalize(V3 a) { float inv = 1.0f / __fsqrt_rn(dot(a, a)); return a * inv; }
+__device__ __forceinline__ float length(V3 a) { return sqrtf(dot(a, a)); }
+__device__ __forceinline__ V3 normalize(V3 a) { float inv = 1.0f / sqrtf(dot(a, a)); return a * inv; }
 __device__ __forceinline__ float fmax2(float a, float b) { return a > b ? a : b; }
 __device__ __forceinline__ float fmin2(float a, float b) { return a < b ? a : b; }
 __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
@@ -150,14 +150,14 @@ __device__ __forceinline__ V3 gi_safe_div(V3 v, float f) { return (f == 0.0f) ? 
 // ---- common.glsl:210-252 ----
 __device__ __forceinline__ V3 gi_sample_hemisphere(float x0, float x1)
 {
-  float a = __fsqrt_rn(x0);
+  float a = sqrtf(x0);
   float s, c; gi_sincos2pi(x1, &s, &c);
-  return v3(a * c, a * s, __fsqrt_rn(1.0f - x0));
+  return v3(a * c, a * s, sqrtf(1.0f - x0));
 }
 __device__ __forceinline__ V3 gi_sample_sphere(float x0, float x1, V3 radius)
 {
   float a = 1.0f - 2.0f * x0;
-  float b = __fsqrt_rn(1.0f - a * a);
+  float b = sqrtf(1.0f - a * a);
   float s, c; gi_sincos2pi(x1, &s, &c);
   return v3(b * c, b * s, a) * radius;
 }
@@ -175,7 +175,7 @@ __device__ __forceinline__ void gi_sample_disk(float x0, float x1, float rx, flo
 __device__ __forceinline__ void gi_fis_gauss(float x0, float x1, float& ox, float& oy)
 {
   float u1 = fmax2(1e-38f, x0);
-  float r = 0.375f * __fsqrt_rn(-2.0f * gi_logf(u1));
+  float r = 0.375f * sqrtf(-2.0f * gi_logf(u1));
   float s, c; gi_sincos2pi(x1, &s, &c);
   ox = c * r; oy = s * r;
 }

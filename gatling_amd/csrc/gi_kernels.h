@@ -16,4 +16,6 @@ void launchTrace(hipStream_t s, uint32_t blocks, bool anyHit, bool count, const 
 void launchShade(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const SceneView& sc, const PathState& st, const uint32_t* qCur,
                  uint32_t* qNext, uint32_t* qRegen, uint32_t* qShadow, Counters* cnt, uint32_t curIdx, uint32_t nextIdx);
 
+void launchDebugBsdf(hipStream_t s, const MaterialRec* mat, uint32_t count, const float* in, float* out);
+
 } // namespace gi

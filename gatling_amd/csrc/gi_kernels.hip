@@ -362,7 +362,7 @@ enum : uint32_t { EV_ABSORB = 0, EV_DIFFUSE = 1, EV_GLOSSY = 2, EV_SPECULAR = 4,
 __device__ __forceinline__ V3 to_world(const ShState& s, V3 l) { return (s.tangentU * l.x + s.tangentV * l.y) + s.normal * l.z; }
 __device__ __forceinline__ V3 to_local(const ShState& s, V3 w) { return v3(dot(w, s.tangentU), dot(w, s.tangentV), dot(w, s.normal)); }
 __device__ __forceinline__ float schlick_w(float c) { float m = 1.0f - c; m = fmin2(fmax2(m, 0.0f), 1.0f); float m2 = m * m; return m2 * m2 * m; }
-__device__ __forceinline__ float ggx_lambda_term(float a2, float c) { return __fsqrt_rn(a2 + (1.0f - a2) * c * c); }
+__device__ __forceinline__ float ggx_lambda_term(float a2, float c) { return sqrtf(a2 + (1.0f - a2) * c * c); }
 __device__ __forceinline__ V3 schlick3(V3 F0, float c) { float w = schlick_w(c); return F0 + (v3(1.0f, 1.0f, 1.0f) - F0) * w; }
 
 struct GgxOut { V3 l2; float pdf, g2OverG1, kh; bool valid; };
@@ -371,14 +371,14 @@ __device__ inline GgxOut ggx_sample(V3 l1, float alpha, float x0, float x1)
   GgxOut o; o.valid = false; o.pdf = 0.0f; o.g2OverG1 = 0.0f; o.kh = 0.0f; o.l2 = v3(0.0f, 0.0f, 0.0f);
   V3 vh = normalize(v3(alpha * l1.x, alpha * l1.y, l1.z));
   float lensq = vh.x * vh.x + vh.y * vh.y;
-  V3 T1 = lensq > 0.0f ? v3(-vh.y, vh.x, 0.0f) * (1.0f / __fsqrt_rn(lensq)) : v3(1.0f, 0.0f, 0.0f);
+  V3 T1 = lensq > 0.0f ? v3(-vh.y, vh.x, 0.0f) * (1.0f / sqrtf(lensq)) : v3(1.0f, 0.0f, 0.0f);
   V3 T2 = cross(vh, T1);
-  float r = __fsqrt_rn(x0);
+  float r = sqrtf(x0);
   float s, c; gi_sincos2pi(x1, &s, &c);
   float t1 = r * c, t2 = r * s;
   float sm = 0.5f * (1.0f + vh.z);
-  t2 = (1.0f - sm) * __fsqrt_rn(fmax2(0.0f, 1.0f - t1 * t1)) + sm * t2;
-  V3 nh = (T1 * t1 + T2 * t2) + vh * __fsqrt_rn(fmax2(0.0f, (1.0f - t1 * t1) - t2 * t2));
+  t2 = (1.0f - sm) * sqrtf(fmax2(0.0f, 1.0f - t1 * t1)) + sm * t2;
+  V3 nh = (T1 * t1 + T2 * t2) + vh * sqrtf(fmax2(0.0f, (1.0f - t1 * t1) - t2 * t2));
   V3 h = normalize(v3(alpha * nh.x, alpha * nh.y, fmax2(0.0f, nh.z)));
   float kh = dot(l1, h);
   V3 l2 = h * (2.0f * kh) - l1;
@@ -667,6 +667,22 @@ __global__ __launch_bounds__(256) void k_shade(FrameUniforms U, SceneView sc, Pa
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_debug_bsdf: the closed-form BSDF entry points on explicit shading frames (device-side known-answer tests)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_debug_bsdf(const MaterialRec* mat, uint32_t count, const float* __restrict__ in, float* __restrict__ out)
+{
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const float* p = in + 22 * (size_t)i; float* o = out + 15 * (size_t)i;
+  ShState st; st.normal = v3(p); st.tangentU = v3(p + 3); st.tangentV = v3(p + 6); st.geomNormal = v3(p + 9);
+  st.position = v3(0.0f, 0.0f, 0.0f); st.frontFace = true; st.meshFlags = 0u; st.material = 0u;
+  BsdfSample bs; bsdf_sample(mat, st, v3(p + 12), p[18], p[19], p[20], bs);
+  BsdfEval ev; bsdf_evaluate(mat, st, v3(p + 12), v3(p + 15), ev);
+  o[0] = bs.k2.x; o[1] = bs.k2.y; o[2] = bs.k2.z; o[3] = bs.overPdf.x; o[4] = bs.overPdf.y; o[5] = bs.overPdf.z; o[6] = bs.pdf; o[7] = (float)bs.event;
+  o[8] = ev.diffuse.x; o[9] = ev.diffuse.y; o[10] = ev.diffuse.z; o[11] = ev.glossy.x; o[12] = ev.glossy.y; o[13] = ev.glossy.z; o[14] = ev.pdf;
+}
+
+// ------------------------------------------------------------------------------------------------
 // host-callable launchers
 // ------------------------------------------------------------------------------------------------
 void launchInit(hipStream_t s, const PathState& st, uint32_t* qRegen, Counters* cnt, uint32_t n)
@@ -698,6 +714,11 @@ void launchShade(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const S
                  uint32_t* qNext, uint32_t* qRegen, uint32_t* qShadow, Counters* cnt, uint32_t curIdx, uint32_t nextIdx)
 {
   hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, s, U, sc, st, qCur, qNext, qRegen, qShadow, cnt, curIdx, nextIdx);
+}
+
+void launchDebugBsdf(hipStream_t s, const MaterialRec* mat, uint32_t count, const float* in, float* out)
+{
+  hipLaunchKernelGGL(k_debug_bsdf, dim3((count + 63u) / 64u), dim3(64), 0, s, mat, count, in, out);
 }
 
 } // namespace gi

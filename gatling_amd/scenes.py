@@ -70,3 +70,91 @@ def cornell_box(material_class: int = MAT_USD_PREVIEW_SURFACE) -> SceneDesc:
     cam.attrs = {"clippingRange": [0.1, 100.0], "focalLength": 50.0, "verticalAperture": 20.25}  # :18-24
     s.camera = camera_from_prim(cam, cam_xf)
     return s
+
+
+def _look_at_camera(position, target, up, vfov_deg) -> CameraDesc:
+    p, t, u = (np.asarray(x, np.float64) for x in (position, target, up))
+    f = (t - p) / np.linalg.norm(t - p)
+    r = np.cross(f, u); r /= np.linalg.norm(r)
+    u2 = np.cross(r, f)
+    return CameraDesc(position=tuple(np.float32(p)), forward=tuple(np.float32(f)), up=tuple(np.float32(u2)),
+                      vfov=float(np.float32(np.deg2rad(vfov_deg))))
+
+
+def random_triangle_soup(count: int = 1_000_000, seed: int = 1234, material_class: int = MAT_USD_PREVIEW_SURFACE) -> SceneDesc:
+    """Config C3: `count` independent triangles in one mesh, centres uniform in [-1,1]^3, edge
+    vectors ~ N(0, 0.01^2) per component, one material (base colour .8, roughness .3, ior 1.5), one 1x1 rect light at
+    z=+1.5 facing -z with intensity 20, NEE on, camera at (0,-4,0) looking +y, vfov 40 degrees."""
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-1.0, 1.0, (count, 1, 3))
+    p = (c + rng.normal(0.0, 0.01, (count, 3, 3))).astype(np.float32).reshape(-1, 3)
+    n = np.cross(p[1::3] - p[0::3], p[2::3] - p[0::3])
+    ln = np.linalg.norm(n, axis=1, keepdims=True); ln[ln == 0] = 1.0
+    n = np.repeat((n / ln).astype(np.float32), 3, axis=0)
+    from .meshprep import bake_vertices
+    verts = bake_vertices(p, n)
+    faces = np.arange(3 * count, dtype=np.uint32).reshape(-1, 3)
+    s = SceneDesc()
+    s.materials = [MaterialDesc.usd_preview_surface(name="soup", diffuseColor=(0.8, 0.8, 0.8), roughness=0.3, ior=1.5, klass=material_class)]
+    s.meshes = [MeshDesc(name="/Soup", vertices=verts, faces=faces, material=0, id=0, double_sided=True)]
+    s.rect_lights = [RectLight(origin=(0.0, 0.0, 1.5), t0=(1, 0, 0), t1=(0, 1, 0), base_emission=(20, 20, 20), width=1.0, height=1.0)]
+    s.camera = _look_at_camera((0, -4, 0), (0, 0, 0), (0, 0, 1), 40.0)
+    return s
+
+
+def icosphere(subdivisions: int = 3):
+    """Unit icosphere: 20 * 4^subdivisions triangles (subdivisions=4 -> 5120, the C4 prototype)."""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    v = [np.asarray(x, np.float64) / np.linalg.norm(x) for x in v]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+         (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+    for _ in range(subdivisions):
+        cache, nf = {}, []
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                m = v[a] + v[b]
+                v.append(m / np.linalg.norm(m))
+                cache[key] = len(v) - 1
+            return cache[key]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    pts = np.asarray(v, np.float32)
+    return pts, np.asarray(f, np.uint32)
+
+
+def sphere_grid(grid: int = 32, subdivisions: int = 4, material_count: int = 32, seed: int = 4321,
+                material_class: int = MAT_USD_PREVIEW_SURFACE) -> SceneDesc:
+    """Config C4: grid x grid instances of one icosphere prototype, bound round-robin to
+    `material_count` parameter sets (base colour ~U[0,1]^3, roughness ~U[.05,1], metalness in {0,1} p=.25, coat in {0,1}
+    p=.25), constant (1,1,1) environment through the colour clear value, no analytic lights, NEE off."""
+    from .meshprep import bake_vertices
+    rng = np.random.default_rng(seed)
+    pts, faces = icosphere(subdivisions)
+    verts = bake_vertices(pts, pts / np.linalg.norm(pts, axis=1, keepdims=True))
+    s = SceneDesc()
+    for i in range(material_count):
+        s.materials.append(MaterialDesc.usd_preview_surface(
+            name=f"mat{i}", diffuseColor=tuple(rng.uniform(0, 1, 3)), roughness=float(rng.uniform(0.05, 1.0)),
+            metallic=float(rng.uniform() < 0.25), clearcoat=float(rng.uniform() < 0.25), clearcoatRoughness=0.05, klass=material_class))
+    per_mat = [[] for _ in range(material_count)]
+    k = 0
+    for gy in range(grid):
+        for gx in range(grid):
+            m = np.eye(4, dtype=np.float32)
+            m[0, 0] = m[1, 1] = m[2, 2] = 0.45
+            m[3, 0] = gx - (grid - 1) / 2.0
+            m[3, 2] = gy - (grid - 1) / 2.0
+            per_mat[k % material_count].append(m)
+            k += 1
+    for i, xf in enumerate(per_mat):
+        if xf:
+            s.meshes.append(MeshDesc(name=f"/Spheres/m{i}", vertices=verts, faces=faces, material=i, id=i,
+                                     instance_transforms=np.stack(xf), instance_ids=np.arange(len(xf), dtype=np.int32)))
+    dist = grid * 1.6
+    s.camera = _look_at_camera((0, -dist, 0), (0, 0, 0), (0, 0, 1), 40.0)
+    return s

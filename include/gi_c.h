@@ -285,6 +285,15 @@ int giCSetSceneOption(GiCScene* scene, int32_t option, int32_t value);
 int giCTraceRays(GiCScene* scene, uint32_t count, const float* origins /*3*count*/, const float* dirs /*3*count*/,
                  float tMin, float tMax, float* outTUV /*3*count*/, int32_t* outInstPrim /*2*count, -1 on miss*/);
 
+/* [ext] host-only self check of the BVH8 builder (no device needed): builds the tree over `triCount` triangles
+ * (9 floats each: v0, v1, v2) and verifies that every triangle is reachable and lies inside the dequantised box of
+ * every ancestor slot.  Returns the number of violations (0 = conservative), <0 on error. */
+/* [ext] device-side known-answer hook: closed-form BSDF sample + evaluate for `count` explicit shading frames.
+ * in: 22 floats per item (normal, tangentU, tangentV, geomNormal, k1, k2, xi[4]); out: 15 floats per item
+ * (k2, bsdf_over_pdf, pdf, event, eval diffuse, eval glossy, eval pdf). */
+int giCDebugEvalBsdf(const GiCMaterialDesc* desc, uint32_t count, const float* in, float* out);
+int giCDebugValidateBvh(const float* triVerts, uint32_t triCount, uint32_t* outNodeCount, uint32_t* outMaxDepth);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1003,4 +1003,34 @@ int orc_trace_closest(const OrcScene* scene, const float o[3], const float d[3],
   return 1;
 }
 
+int orc_trace_batch(const OrcScene* scene, uint32_t count, const float* origins, const float* dirs, float tMin, float tMax,
+                    float* outTUV, int32_t* outInstPrim)
+{
+  Prepared P; prepare(scene, P);
+  int hits = 0;
+  for (uint32_t i = 0; i < count; i++) {
+    Hit h;
+    if (trace_closest(P, v3(origins + 3 * i), v3(dirs + 3 * i), tMin, tMax, h)) {
+      outTUV[3 * i] = h.t; outTUV[3 * i + 1] = h.u; outTUV[3 * i + 2] = h.v;
+      outInstPrim[2 * i] = (int32_t)P.tris[h.tri].instance; outInstPrim[2 * i + 1] = (int32_t)P.tris[h.tri].prim; hits++;
+    } else {
+      outTUV[3 * i] = tMax; outTUV[3 * i + 1] = 0.0f; outTUV[3 * i + 2] = 0.0f; outInstPrim[2 * i] = -1; outInstPrim[2 * i + 1] = -1;
+    }
+  }
+  return hits;
+}
+
+void orc_bsdf_debug(const OrcMaterial* mat, uint32_t count, const float* in, float* out)
+{
+  for (uint32_t i = 0; i < count; i++) {
+    const float* p = in + 22 * (size_t)i; float* o = out + 15 * (size_t)i;
+    State st; st.normal = v3(p); st.tangentU = v3(p + 3); st.tangentV = v3(p + 6); st.geomNormal = v3(p + 9);
+    st.position = v3(0, 0, 0); st.u = st.v = 0.0f; st.frontFace = true;
+    BsdfSample bs; bsdf_sample(*mat, st, v3(p + 12), p + 18, bs);
+    BsdfEval ev; bsdf_evaluate(*mat, st, v3(p + 12), v3(p + 15), ev);
+    o[0] = bs.k2.x; o[1] = bs.k2.y; o[2] = bs.k2.z; o[3] = bs.overPdf.x; o[4] = bs.overPdf.y; o[5] = bs.overPdf.z; o[6] = bs.pdf; o[7] = (float)bs.event;
+    o[8] = ev.diffuse.x; o[9] = ev.diffuse.y; o[10] = ev.diffuse.z; o[11] = ev.glossy.x; o[12] = ev.glossy.y; o[13] = ev.glossy.z; o[14] = ev.pdf;
+  }
+}
+
 } // extern "C"

@@ -179,6 +179,14 @@ void     orc_orthonormal_basis(const float n[3], float b1[3], float b2[3]); /* c
 int      orc_trace_closest(const OrcScene* scene, const float o[3], const float d[3], float tMin, float tMax,
                            float* t, float* u, float* v, uint32_t* instance, uint32_t* prim);
 
+/* batch version: the scene is prepared once.  outTUV 3*count, outInstPrim 2*count (-1 on miss). Returns #hits. */
+int      orc_trace_batch(const OrcScene* scene, uint32_t count, const float* origins, const float* dirs, float tMin, float tMax,
+                         float* outTUV, int32_t* outInstPrim);
+/* closed-form BSDF entry points on explicit shading frames.  in: 22 floats per item = normal, tangentU, tangentV,
+ * geomNormal, k1, k2 (for evaluate), xi[4].  out: 15 floats = k2, bsdf_over_pdf, pdf, event, eval diffuse, eval glossy,
+ * eval pdf. */
+void     orc_bsdf_debug(const OrcMaterial* mat, uint32_t count, const float* in, float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -124,6 +124,10 @@ def lib():
         L.orc_trace_closest.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float,
                                         C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                         C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.orc_trace_batch.restype = C.c_int
+        L.orc_trace_batch.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float, C.c_float,
+                                      C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+        L.orc_bsdf_debug.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         _lib = L
     return _lib
 
@@ -227,3 +231,30 @@ def render(scene, settings, width, height, rows=None, sample_offset=0, prev_colo
     counters = {"samples": cnt.samples, "segments": cnt.segments, "shadow_rays": cnt.shadowRays, "hits": cnt.hits,
                 "bounce_histogram": [int(x) for x in cnt.bounceHistogram]}
     return out, counters
+
+
+def trace_rays(scene, origins, dirs, t_min=0.0, t_max=3.0e38):
+    L = lib()
+    ps = PackedScene(scene)
+    o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+    d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+    n = len(o)
+    tuv = np.zeros((n, 3), np.float32)
+    ip = np.zeros((n, 2), np.int32)
+    FP = C.POINTER(C.c_float)
+    L.orc_trace_batch(C.addressof(ps.c), n, o.ctypes.data_as(FP), d.ctypes.data_as(FP), t_min, t_max, tuv.ctypes.data_as(FP),
+                      ip.ctypes.data_as(C.POINTER(C.c_int32)))
+    return tuv, ip
+
+
+def bsdf_debug(material, items):
+    """items: float32 [n,22] (normal, tangentU, tangentV, geomNormal, k1, k2, xi[4]) -> float32 [n,15]."""
+    L = lib()
+    m = OrcMaterial()
+    m.klass = material.klass
+    m.p = (C.c_float * P_COUNT)(*np.asarray(material.params, np.float32))
+    a = np.ascontiguousarray(items, np.float32).reshape(-1, 22)
+    out = np.zeros((len(a), 15), np.float32)
+    FP = C.POINTER(C.c_float)
+    L.orc_bsdf_debug(C.addressof(m), len(a), a.ctypes.data_as(FP), out.ctypes.data_as(FP))
+    return out

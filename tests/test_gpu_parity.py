@@ -1,0 +1,288 @@
+"""GPU parity tests (-m gpu): the HIP path through the C ABI vs the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact for integer work (segment / shadow-ray counts, hit ids).  For the float image the stated tolerance
+is SURVEY.md section 8d(i) -- |d| <= 1e-4 + 1e-3*|ref| for >= 99.9 % of pixels, the rest <= 0.05, mean error <= 1e-5
+(`assert_image_parity(exact=False)`) -- but because kernels and oracle follow the same arithmetic contract
+(fp32, no contraction, IEEE + - * / sqrt, polynomial sincos/log) every test here demands the stronger
+bit-identical image (`exact=True`)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+from make_golden import CASES, build_case  # noqa: E402
+
+from gatling_amd.scene import (MAT_DIFFUSE, MAT_USD_PREVIEW_SURFACE, CameraDesc, DiskLight, DistantLight, MaterialDesc, MeshDesc,
+                               RectLight, RenderSettings, SceneDesc, SphereLight)
+from gatling_amd.scenes import cornell_box, random_triangle_soup, sphere_grid
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def assert_image_parity(img, ref, exact=False):
+    assert img.shape == ref.shape and np.isfinite(img).all()
+    if exact:
+        bad = int((img.view(np.uint32) != ref.view(np.uint32)).any(axis=-1).sum())
+        assert bad == 0, f"{bad} pixels differ bitwise"
+        return
+    d = np.abs(img - ref)
+    within = (d <= 1e-4 + 1e-3 * np.abs(ref)).all(axis=-1)
+    assert within.mean() >= 0.999, f"only {within.mean():.5f} of pixels within tolerance"
+    assert d.max() <= 0.05
+    assert abs(float(img.mean()) - float(ref.mean())) <= 1e-5
+
+
+def render_both(gi, orc, desc, rs, w, h, exact=True, threads=4):
+    sc = gi.Scene(desc)
+    try:
+        img = sc.render(rs, w, h)
+        st = sc.stats()
+    finally:
+        sc.close()
+    ref, cnt = orc.render(desc, rs, w, h, threads=threads)
+    assert st["segments"] == cnt["segments"] and st["shadowRays"] == cnt["shadow_rays"] and st["samples"] == cnt["samples"]
+    assert_image_parity(img, ref, exact)
+    return img, ref, st
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_golden_fixtures(gi, name):
+    """Committed fixtures (tests/golden/make_golden.py): no oracle call needed on the GPU box for these."""
+    desc, rs, w, h = build_case(name)
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    sc = gi.Scene(desc)
+    try:
+        img = sc.render(rs, w, h)
+        st = sc.stats()
+    finally:
+        sc.close()
+    assert st["segments"] == int(g["segments"]) and st["shadowRays"] == int(g["shadow_rays"])
+    assert_image_parity(img, g["color"], exact=True)
+
+
+def test_c1_diffuse_bit_exact(gi, orc):
+    """Config C1 (cornell, diffuse-only model, 4 bounces) at a size the oracle finishes in seconds."""
+    render_both(gi, orc, cornell_box(MAT_DIFFUSE), RenderSettings(spp=8, max_bounces=4), 160, 90, exact=True)
+
+
+def test_c2_model_parity(gi, orc):
+    """Config C2's model (UsdPreviewSurface, 8 bounces) on a reduced image."""
+    render_both(gi, orc, cornell_box(MAT_USD_PREVIEW_SURFACE), RenderSettings(spp=8, max_bounces=8), 160, 90)
+
+
+SETTING_CASES = {
+    "no_jitter": dict(jittered_sampling=False),
+    "uniform_jitter": dict(filter_importance_sampling=False),
+    "dof": dict(depth_of_field=True),
+    "clip": dict(clipping_planes=True),
+    "rr_early": dict(rr_bounce_offset=0, rr_inv_min_term_prob=0.5),
+    "one_bounce": dict(max_bounces=1),
+    "clamp_low": dict(max_sample_value=0.5),
+    "black_bg": dict(clear_color=(0.0, 0.0, 0.0, 0.0)),
+}
+
+
+@pytest.mark.parametrize("case", sorted(SETTING_CASES))
+def test_render_settings_matrix(gi, orc, case):
+    kw = dict(spp=4, max_bounces=6)
+    kw.update(SETTING_CASES[case])
+    desc = cornell_box(MAT_DIFFUSE)
+    if case == "dof":
+        desc.camera.f_stop, desc.camera.focus_distance = 0.5, 6.5
+    if case == "clip":
+        desc.camera.clip_start, desc.camera.clip_end = 6.5, 7.8  # cuts through the box
+    render_both(gi, orc, desc, RenderSettings(**kw), 96, 54, exact=True)
+
+
+LIGHTS = {
+    "sphere": dict(sphere_lights=[SphereLight(pos=(0.3, -0.2, 0.4), base_emission=(6, 5, 4), radius=(0.15, 0.1, 0.2))]),
+    "distant": dict(distant_lights=[DistantLight(direction=(0.2, 0.5, -0.8), base_emission=(2, 2, 2), angle=0.1)]),
+    "distant_sharp": dict(distant_lights=[DistantLight(direction=(0.0, 0.6, -0.8), base_emission=(1.5, 1.5, 1.5), angle=0.0)]),
+    "rect": dict(rect_lights=[RectLight(origin=(0, 0, 0.9), t0=(1, 0, 0), t1=(0, -1, 0), base_emission=(10, 10, 10), width=0.7, height=0.5)]),
+    "disk": dict(disk_lights=[DiskLight(origin=(0, 0, 0.9), t0=(1, 0, 0), t1=(0, -1, 0), base_emission=(10, 8, 6), radius_x=0.3, radius_y=0.2)]),
+    "all": dict(sphere_lights=[SphereLight(pos=(0.3, -0.2, 0.4), base_emission=(6, 5, 4), radius=(0.1, 0.1, 0.1), diffuse=0.5, specular=2.0)],
+                distant_lights=[DistantLight(direction=(0.2, 0.5, -0.8), base_emission=(1, 1, 1), angle=0.05)],
+                rect_lights=[RectLight(origin=(0, 0, 0.9), t0=(1, 0, 0), t1=(0, -1, 0), base_emission=(10, 10, 10), width=0.7, height=0.5)],
+                disk_lights=[DiskLight(origin=(-0.5, 0.5, 0.9), t0=(1, 0, 0), t1=(0, -1, 0), base_emission=(10, 8, 6), radius_x=0.3, radius_y=0.2)]),
+    "none": dict(),  # zero lights with NEE on: reference reads slot 0 of a zero-filled store
+}
+
+
+@pytest.mark.parametrize("klass", [MAT_DIFFUSE, MAT_USD_PREVIEW_SURFACE])
+@pytest.mark.parametrize("lights", sorted(LIGHTS))
+def test_next_event_estimation(gi, orc, lights, klass):
+    desc = cornell_box(klass)
+    for k, v in LIGHTS[lights].items():
+        setattr(desc, k, v)
+    rs = RenderSettings(spp=4, max_bounces=5, next_event_estimation=True, light_intensity_multiplier=1.5)
+    desc.camera.exposure = 0.5
+    render_both(gi, orc, desc, rs, 96, 54)
+
+
+def test_progressive_accumulation_across_calls(gi, orc):
+    """scene->sampleOffset advances by spp per giRender and resets on any change (Gi.cpp:2125-2129, 2515)."""
+    desc = cornell_box(MAT_DIFFUSE)
+    rs = RenderSettings(spp=3, max_bounces=4)
+    sc = gi.Scene(desc)
+    try:
+        first = sc.render(rs, 64, 36)
+        second = sc.render(rs, 64, 36)
+        third = sc.render(RenderSettings(spp=3, max_bounces=5), 64, 36)  # settings change -> offset back to 0
+    finally:
+        sc.close()
+    r1, _ = orc.render(desc, rs, 64, 36, sample_offset=0)
+    r2, _ = orc.render(desc, rs, 64, 36, sample_offset=3, prev_color=r1)
+    r3, _ = orc.render(desc, RenderSettings(spp=3, max_bounces=5), 64, 36, sample_offset=0)
+    assert_image_parity(first, r1, exact=True)
+    assert_image_parity(second, r2, exact=True)
+    assert_image_parity(third, r3, exact=True)
+
+
+def test_row_sharding_is_bit_identical(gi):
+    """The multi-GPU partition (rowBegin/rowEnd) must reproduce the single-call image exactly."""
+    desc = cornell_box()
+    rs = RenderSettings(spp=4, max_bounces=6, progressive_accumulation=False)
+    sc = gi.Scene(desc)
+    try:
+        full = sc.render(rs, 80, 45)
+        parts = [sc.render(rs, 80, 45, rows=r) for r in ((0, 12), (12, 23), (23, 45))]
+    finally:
+        sc.close()
+    assert np.array_equal(np.concatenate(parts).view(np.uint32), full.view(np.uint32))
+
+
+def test_edge_cases(gi, orc):
+    """Empty scene, 1x1 target (the reference's Render.Empty1x1), invisible / instance-less / material-less meshes."""
+    cam = CameraDesc(position=(0, 0, 5))
+    empty = SceneDesc(materials=[MaterialDesc.usd_preview_surface()], camera=cam)
+    render_both(gi, orc, empty, RenderSettings(spp=2, max_bounces=3, clear_color=(0.5, 0.25, 1.0, 1.0)), 1, 1, exact=True)
+    render_both(gi, orc, empty, RenderSettings(spp=1, max_bounces=1), 7, 3, exact=True)
+    desc = cornell_box(MAT_DIFFUSE)
+    desc.meshes[6].visible = False
+    desc.meshes[7].instance_transforms = np.zeros((0, 4, 4), np.float32)
+    desc.meshes[5].material = -1
+    render_both(gi, orc, desc, RenderSettings(spp=2, max_bounces=4), 48, 27, exact=True)
+
+
+def test_error_behaviour(gi):
+    desc = cornell_box()
+    sc = gi.Scene(desc)
+    try:
+        with pytest.raises(gi.GiError):
+            sc.render(RenderSettings(spp=0), 8, 8)
+        with pytest.raises(gi.GiError):
+            sc.render(RenderSettings(spp=1, medium_stack_size=2), 8, 8)
+        img = sc.render(RenderSettings(spp=1, max_bounces=2), 8, 8)  # still usable afterwards
+        assert np.isfinite(img).all()
+    finally:
+        sc.close()
+
+
+def test_bsdf_known_answers_on_device(gi, orc):
+    """Closed-form BSDF sample/evaluate on random frames: device == oracle."""
+    rng = np.random.default_rng(5)
+    n = 4096
+    nrm = rng.normal(size=(n, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    t = np.cross(nrm, rng.normal(size=(n, 3))); t /= np.linalg.norm(t, axis=1, keepdims=True)
+    b = np.cross(nrm, t)
+
+    def hemi(z_min):
+        v = rng.normal(size=(n, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+        v[:, 2] = np.abs(v[:, 2]) * (1 - z_min) + z_min
+        v /= np.linalg.norm(v, axis=1, keepdims=True)
+        return v[:, :1] * t + v[:, 1:2] * b + v[:, 2:3] * nrm
+    items = np.concatenate([nrm, t, b, nrm, hemi(0.02), hemi(0.02), rng.uniform(size=(n, 4))], axis=1).astype(np.float32)
+    mats = [MaterialDesc.usd_preview_surface(diffuseColor=(0.7, 0.4, 0.2), klass=MAT_DIFFUSE),
+            MaterialDesc.usd_preview_surface(diffuseColor=(0.7, 0.4, 0.2), roughness=0.5),
+            MaterialDesc.usd_preview_surface(diffuseColor=(0.9, 0.6, 0.1), roughness=0.2, metallic=1.0),
+            MaterialDesc.usd_preview_surface(diffuseColor=(0.2, 0.4, 0.8), roughness=0.7, clearcoat=1.0, clearcoatRoughness=0.1),
+            MaterialDesc.usd_preview_surface(diffuseColor=(0.2, 0.4, 0.8), useSpecularWorkflow=1, specularColor=(0.3, 0.2, 0.1), roughness=0.05)]
+    for m in mats:
+        got, ref = gi.bsdf_debug(m, items), orc.bsdf_debug(m, items)
+        assert np.array_equal(got[:, 7], ref[:, 7])  # event types
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def _soup(n, seed=99):
+    d = random_triangle_soup(n, seed=seed)
+    return d
+
+
+def test_bvh_traversal_matches_oracle(gi, orc):
+    """Closest hits of random rays through the BVH8 kernel (tree larger than the LDS-staged top) vs the oracle's
+    independent traversal: identical triangle ids and bit-identical (t,u,v)."""
+    desc = _soup(30000)
+    rng = np.random.default_rng(3)
+    n = 20000
+    o = rng.uniform(-1.5, 1.5, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    d[:50, 0] = 0.0  # axis-parallel directions exercise the zero-component guard
+    sc = gi.Scene(desc)
+    try:
+        tuv, ip = sc.trace_rays(o, d)
+        assert sc.stats()["nodeCount"] > 384  # beyond LDS_NODES: exercises the global-memory node path
+    finally:
+        sc.close()
+    rtuv, rip = orc.trace_rays(desc, o, d)
+    assert np.array_equal(ip, rip)
+    hit = rip[:, 0] >= 0
+    assert 0.05 < hit.mean() < 1.0
+    assert np.array_equal(tuv[hit].view(np.uint32), rtuv[hit].view(np.uint32))
+
+
+def test_instanced_scene_parity(gi, orc):
+    """Instancing + several materials (C4's structure at small scale): flattened BVH vs the oracle."""
+    desc = sphere_grid(grid=4, subdivisions=1, material_count=5)
+    render_both(gi, orc, desc, RenderSettings(spp=4, max_bounces=6), 96, 54)
+
+
+def test_soup_scene_with_nee_parity(gi, orc):
+    """C3's structure at small scale: triangle soup, rect light, NEE on."""
+    desc = _soup(20000)
+    render_both(gi, orc, desc, RenderSettings(spp=2, max_bounces=5, next_event_estimation=True), 96, 54)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# full BASELINE.json sizes: size-independent properties (the oracle cannot render these in seconds)
+# ---------------------------------------------------------------------------------------------------------------
+def test_full_size_c2_properties(gi):
+    """1920x1080 cornell, 8 bounces: determinism, shard invariance, checksum-of-checksums, bounds."""
+    desc = cornell_box()
+    rs = RenderSettings(spp=8, max_bounces=8, progressive_accumulation=False)
+    w, h = 1920, 1080
+    sc = gi.Scene(desc)
+    try:
+        full = sc.render(rs, w, h)
+        st = sc.stats()
+        again = sc.render(rs, w, h)
+        bands = [sc.render(rs, w, h, rows=(r * 135, (r + 1) * 135)) for r in range(8)]  # the 8-GPU partition
+    finally:
+        sc.close()
+    assert np.isfinite(full).all() and (full[..., 3] == 1.0).all() and full[..., :3].min() >= 0.0
+    assert full[..., :3].max() <= rs.max_sample_value * (1 + 1e-5)  # per-sample clamp bounds every pixel mean
+    assert st["samples"] == w * h * 8 and st["samples"] <= st["segments"] <= st["samples"] * 8
+    assert np.array_equal(full.view(np.uint32), again.view(np.uint32))  # run-to-run determinism despite atomics in the queues
+    stitched = np.concatenate(bands)
+    assert np.array_equal(stitched.view(np.uint32), full.view(np.uint32))
+    row_sums = [int(b.view(np.uint32).astype(np.uint64).sum()) for b in bands]
+    assert sum(row_sums) == int(full.view(np.uint32).astype(np.uint64).sum())
+    # the open front shows the background on ~62 % of the pixels: those are exactly the quantised clear colour
+    assert 0.55 < float((full[..., :3] == 1.0).all(axis=-1).mean()) < 0.70
+
+
+def test_full_size_furnace(gi):
+    """Energy conservation at full HD: closed emitting Lambertian box, radiance = sum albedo^k."""
+    from test_oracle_render import _furnace
+    albedo, bounces = 0.5, 8
+    rs = RenderSettings(spp=4, max_bounces=bounces, rr_bounce_offset=100, max_sample_value=1e9)
+    sc = gi.Scene(_furnace(albedo))
+    try:
+        img = sc.render(rs, 1920, 1080)
+        st = sc.stats()
+    finally:
+        sc.close()
+    assert st["segments"] == 1920 * 1080 * 4 * bounces
+    np.testing.assert_allclose(img[..., :3], sum(albedo ** k for k in range(bounces)), rtol=1e-5)
