@@ -118,6 +118,38 @@ uint32_t encodeDirection(const float* vin)
   return (uint32_t)nearbyintf(ex * 65535.0f) | ((uint32_t)nearbyintf(ey * 65535.0f) << 16);
 }
 
+// decode_direction (common.glsl:198-207) evaluated once per vertex on the host, operation for operation what
+// gi_decode_direction / the oracle execute (IEEE fp32, no contraction), so results stay bit-identical.
+void decodeDirection(uint32_t e, float out[3])
+{
+  float ex = (float)(e & 0xffffu) / 65535.0f, ey = (float)(e >> 16) / 65535.0f;
+  ex = ex * 2.0f - 1.0f; ey = ey * 2.0f - 1.0f;
+  float x = ex, y = ey, z = 1.0f - fabsf(ex) - fabsf(ey);
+  float t = (-z > 0.0f) ? -z : 0.0f;
+  x += (x >= 0.0f) ? -t : t;
+  y += (y >= 0.0f) ? -t : t;
+  float inv = 1.0f / sqrtf((x * x + y * y) + z * z);
+  out[0] = x * inv; out[1] = y * inv; out[2] = z * inv;
+}
+
+// per-material constants of the closed-form BSDFs (DESIGN.md "Materials"); same fp32 formulas as the oracle's ups_params
+void deriveMaterialConstants(MaterialRec& m)
+{
+  const float* p = m.p;
+  float r = p[GI_C_P_ROUGHNESS], cr = p[GI_C_P_CLEARCOAT_ROUGHNESS];
+  float alpha = (r * r > 0.001f) ? r * r : 0.001f, coatAlpha = (cr * cr > 0.001f) ? cr * cr : 0.001f;
+  float albedo[3], F0[3];
+  if (p[GI_C_P_USE_SPECULAR_WORKFLOW] != 0.0f) {
+    for (int i = 0; i < 3; i++) { F0[i] = p[GI_C_P_SPECULAR_COLOR + i]; albedo[i] = p[GI_C_P_BASE_COLOR + i]; }
+  } else {
+    float ior = p[GI_C_P_IOR], metal = p[GI_C_P_METALLIC];
+    float q = (1.0f - ior) / (1.0f + ior), f0 = q * q;
+    for (int i = 0; i < 3; i++) { F0[i] = f0 * (1.0f - metal) + p[GI_C_P_BASE_COLOR + i] * metal; albedo[i] = p[GI_C_P_BASE_COLOR + i] * (1.0f - metal); }
+  }
+  for (int i = 0; i < 3; i++) { m.p[MP_ALBEDO + i] = albedo[i]; m.p[MP_F0 + i] = F0[i]; }
+  m.p[MP_ALPHA] = alpha; m.p[MP_COAT] = p[GI_C_P_CLEARCOAT]; m.p[MP_COAT_ALPHA] = coatAlpha;
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -192,13 +224,14 @@ struct GiCScene {
   GiCDomeLight* oldDome = nullptr;
   float oldDomeEmission[3] = {0, 0, 0};
   // device scene
-  DeviceBuffer<Node8> dNodes; DeviceBuffer<TriRec> dTris; DeviceBuffer<InstanceRec> dInstances; DeviceBuffer<MeshRec> dMeshes;
-  DeviceBuffer<uint32_t> dFaces; DeviceBuffer<FVertex> dVerts; DeviceBuffer<MaterialRec> dMaterials;
+  DeviceBuffer<Node8> dNodes; DeviceBuffer<TriRec> dTris; DeviceBuffer<InstanceRec> dInstances;
+  DeviceBuffer<FVertex> dVerts; DeviceBuffer<MaterialRec> dMaterials;
   DeviceBuffer<SphereLightRec> dSphere; DeviceBuffer<DistantLightRec> dDistant; DeviceBuffer<RectLightRec> dRect; DeviceBuffer<DiskLightRec> dDisk;
   uint32_t nodeCount = 0, triCount = 0, bvhDepth = 0;
   // path state
-  DeviceBuffer<F4> sRayO, sRayD, sHit, sThr, sRad, sAcc, sNeeC, sNeeD;
-  DeviceBuffer<uint32_t> qA, qB, qRegen, qShadow;
+  DeviceBuffer<Slot> slots;
+  DeviceBuffer<uint32_t> queues[Q_COUNT]; // NSHARD segments of queueCap entries each
+  uint32_t queueCap = 0;
   DeviceBuffer<Counters> dCounters;
   Counters* hCounters = nullptr; // pinned
   // options + stats
@@ -254,10 +287,11 @@ void giCDestroyScene(GiCScene* s)
   if (!s) return;
   std::lock_guard<std::mutex> g(g_ctx.resourceMutex);
   (void)hipStreamSynchronize(g_ctx.stream);
-  s->dNodes.release(); s->dTris.release(); s->dInstances.release(); s->dMeshes.release(); s->dFaces.release(); s->dVerts.release();
+  s->dNodes.release(); s->dTris.release(); s->dInstances.release(); s->dVerts.release();
   s->dMaterials.release(); s->dSphere.release(); s->dDistant.release(); s->dRect.release(); s->dDisk.release();
-  s->sRayO.release(); s->sRayD.release(); s->sHit.release(); s->sThr.release(); s->sRad.release(); s->sAcc.release(); s->sNeeC.release(); s->sNeeD.release();
-  s->qA.release(); s->qB.release(); s->qRegen.release(); s->qShadow.release(); s->dCounters.release();
+  s->slots.release();
+  for (auto& q : s->queues) q.release();
+  s->dCounters.release();
   if (s->hCounters) (void)hipHostFree(s->hCounters);
   for (hipEvent_t e : s->eventPool) (void)hipEventDestroy(e);
   delete s;
@@ -584,26 +618,27 @@ inline void xformPoint(const float a[12], const float p[3], float out[3])
 int buildScene(GiCScene* s)
 {
   double t0 = nowMs();
-  std::vector<MeshRec> meshRecs; std::vector<uint32_t> faces; std::vector<FVertex> verts; std::vector<InstanceRec> instances; std::vector<TriRec> tris;
+  std::vector<FVertex> verts; std::vector<InstanceRec> instances; std::vector<TriRec> tris;
   std::vector<MaterialRec> mats(s->materials.size());
   for (size_t i = 0; i < s->materials.size(); i++) {
     mats[i].klass = s->materials[i]->desc.klass; mats[i].flags = s->materials[i]->desc.flags;
     memcpy(mats[i].p, s->materials[i]->desc.p, sizeof(float) * MAT_PARAM_COUNT);
+    deriveMaterialConstants(mats[i]);
   }
+  uint32_t meshIdx = 0;
   for (GiCMesh* m : s->meshes) {
     if (!m->visible) continue; // Gi.cpp:801-804
     if (m->faces.empty()) continue;
     auto mit = std::find(s->materials.begin(), s->materials.end(), m->material);
     if (mit == s->materials.end()) { fprintf(stderr, "[gatling_gi] invalid BLAS material for mesh %s\n", m->name.c_str()); continue; } // Gi.cpp:818-822
-    MeshRec mr;
-    mr.faceOffset = (uint32_t)(faces.size() / 3); mr.vertexOffset = (uint32_t)verts.size(); mr.material = (uint32_t)(mit - s->materials.begin());
-    mr.flags = (m->flipFacing ? 1u : 0u) | (m->doubleSided ? 2u : 0u);
-    uint32_t meshIdx = (uint32_t)meshRecs.size();
-    meshRecs.push_back(mr);
-    for (const GiCFace& f : m->faces) { faces.push_back(f.v_i[0]); faces.push_back(f.v_i[1]); faces.push_back(f.v_i[2]); }
-    for (const GiCVertex& v : m->vertices) { // Gi.cpp:848-861
+    const uint32_t material = (uint32_t)(mit - s->materials.begin());
+    if (material > 0x00ffffffu) { setError("too many materials"); return GI_C_ERROR; }
+    const uint32_t matFlags = material | (((m->flipFacing ? 1u : 0u) | (m->doubleSided ? 2u : 0u)) << 30);
+    const uint32_t vertexOffset = (uint32_t)verts.size();
+    for (const GiCVertex& v : m->vertices) { // Gi.cpp:848-861: quantise normal/tangent to octahedral unorm2x16, then decode once
       FVertex fv; memcpy(fv.pos, v.pos, 12); fv.bsign = v.bitangentSign;
-      fv.normal = encodeDirection(v.norm); fv.tangent = encodeDirection(v.tangent); fv.u = v.u; fv.v = v.v;
+      decodeDirection(encodeDirection(v.norm), fv.normal); decodeDirection(encodeDirection(v.tangent), fv.tangent);
+      fv.u = v.u; fv.v = v.v;
       verts.push_back(fv);
     }
     size_t instCount = m->instanceTransforms.size() / 16;
@@ -620,18 +655,19 @@ int buildScene(GiCScene* s)
         xformPoint(ir.o2w, m->vertices[m->faces[f].v_i[1]].pos, p1);
         xformPoint(ir.o2w, m->vertices[m->faces[f].v_i[2]].pos, p2);
         TriRec t;
-        for (int a = 0; a < 3; a++) { t.v0[a] = p0[a]; t.e1[a] = p1[a] - p0[a]; t.e2[a] = p2[a] - p0[a]; }
-        t.instance = instIdx; t.prim = f; t.origId = (uint32_t)tris.size();
+        for (int a = 0; a < 3; a++) { t.v0[a] = p0[a]; t.e1[a] = p1[a] - p0[a]; t.e2[a] = p2[a] - p0[a]; t.vi[a] = vertexOffset + m->faces[f].v_i[a]; }
+        t.instance = instIdx; t.prim = f; t.origId = (uint32_t)tris.size(); t.matFlags = matFlags;
         tris.push_back(t);
       }
     }
+    meshIdx++;
   }
   Bvh8 bvh;
   buildBvh8(tris, bvh);
   double t1 = nowMs();
   hipStream_t st = g_ctx.stream;
-  if (s->dNodes.upload(bvh.nodes, st) || s->dTris.upload(bvh.tris, st) || s->dInstances.upload(instances, st) || s->dMeshes.upload(meshRecs, st) ||
-      s->dFaces.upload(faces, st) || s->dVerts.upload(verts, st) || s->dMaterials.upload(mats, st))
+  if (s->dNodes.upload(bvh.nodes, st) || s->dTris.upload(bvh.tris, st) || s->dInstances.upload(instances, st) ||
+      s->dVerts.upload(verts, st) || s->dMaterials.upload(mats, st))
     return GI_C_ERROR;
   HIP_TRY(hipStreamSynchronize(st)); // host vectors go out of scope
   s->nodeCount = (uint32_t)bvh.nodes.size(); s->triCount = (uint32_t)bvh.tris.size(); s->bvhDepth = bvh.maxDepth;
@@ -655,18 +691,31 @@ bool settingsEqual(const GiCRenderSettings& a, const GiCRenderSettings& b) { ret
 SceneView makeView(GiCScene* s)
 {
   SceneView v{};
-  v.nodes = s->dNodes.ptr; v.tris = s->dTris.ptr; v.instances = s->dInstances.ptr; v.meshes = s->dMeshes.ptr; v.faces = s->dFaces.ptr;
+  v.nodes = s->dNodes.ptr; v.tris = s->dTris.ptr; v.instances = s->dInstances.ptr;
   v.verts = s->dVerts.ptr; v.materials = s->dMaterials.ptr; v.sphereLights = s->dSphere.ptr; v.distantLights = s->dDistant.ptr;
   v.rectLights = s->dRect.ptr; v.diskLights = s->dDisk.ptr; v.nodeCount = s->nodeCount; v.triCount = s->triCount;
   return v;
 }
 
-int ensurePathState(GiCScene* s, size_t slots)
+// Per-shard queue capacity: a producer launch of G blocks gives shard s at most ceil(G/NSHARD) blocks, each appending
+// at most ceil(slots/(G*256))*256 items per queue; a queue can be fed by two launches before it is consumed
+// (e.g. REGEN by k_trace and k_shade, TRACE by k_shade and the next k_raygen), hence the factor 2.
+uint32_t shardCapacity(size_t slots, uint32_t gridA, uint32_t gridB)
 {
-  if (s->sRayO.alloc(slots) || s->sRayD.alloc(slots) || s->sHit.alloc(slots) || s->sThr.alloc(slots) || s->sRad.alloc(slots) || s->sAcc.alloc(slots) ||
-      s->sNeeC.alloc(slots) || s->sNeeD.alloc(slots) || s->qA.alloc(slots) || s->qB.alloc(slots) || s->qRegen.alloc(slots) || s->qShadow.alloc(slots) ||
-      s->dCounters.alloc(1))
-    return GI_C_ERROR;
+  auto bound = [&](uint32_t G) { size_t trips = (slots + (size_t)G * 256 - 1) / ((size_t)G * 256); return (size_t)((G + NSHARD - 1) / NSHARD) * trips * 256; };
+  size_t cap = 2 * std::max(bound(std::max(gridA, 1u)), bound(std::max(gridB, 1u))) + 256;
+  cap = std::max(cap, (slots + NSHARD - 1) / NSHARD + 256);
+  return (uint32_t)cap;
+}
+
+int ensurePathState(GiCScene* s, size_t slots, uint32_t gridA, uint32_t gridB)
+{
+  const uint32_t cap = shardCapacity(slots, gridA, gridB);
+  if (s->slots.alloc(slots) || s->dCounters.alloc(1)) return GI_C_ERROR;
+  if (cap > s->queueCap) {
+    for (auto& q : s->queues) if (q.alloc((size_t)cap * NSHARD)) return GI_C_ERROR;
+    s->queueCap = cap;
+  }
   if (!s->hCounters) HIP_TRY(hipHostMalloc((void**)&s->hCounters, sizeof(Counters), hipHostMallocDefault));
   return GI_C_OK;
 }
@@ -781,19 +830,19 @@ extern "C" int giCRender(const GiCRenderParams* params)
     U.totalLightCount = U.sphereCount + U.distantCount + U.rectCount + U.diskCount;
   }
 
-  if (ensurePathState(s, slots) != GI_C_OK) return GI_C_ERROR;
-  PathState ps{s->sRayO.ptr, s->sRayD.ptr, s->sHit.ptr, s->sThr.ptr, s->sRad.ptr, s->sAcc.ptr, s->sNeeC.ptr, s->sNeeD.ptr};
-  SceneView view = makeView(s);
-  uint32_t* queues[2] = {s->qA.ptr, s->qB.ptr};
-  F4* colorOut = reinterpret_cast<F4*>(colorRb->deviceMem);
-  const bool nee = rs.nextEventEstimation != 0;
   const uint32_t wideBlocks = (uint32_t)std::min<size_t>((slots + 255) / 256, (size_t)g_ctx.cuCount * 8);
   const uint32_t traceBlocks = (uint32_t)std::min<size_t>((slots + 255) / 256, (size_t)g_ctx.cuCount * 3);
+  if (ensurePathState(s, slots, wideBlocks, traceBlocks) != GI_C_OK) return GI_C_ERROR;
+  PathState ps{s->slots.ptr};
+  SceneView view = makeView(s);
+  QueueSet qs{}; for (uint32_t q = 0; q < Q_COUNT; q++) qs.items[q] = s->queues[q].ptr; qs.cap = s->queueCap;
+  F4* colorOut = reinterpret_cast<F4*>(colorRb->deviceMem);
+  const bool nee = rs.nextEventEstimation != 0;
 
   // --- the bounce loop (rp_main.rgen:215, 295): every slot advances one stage per iteration
   HIP_TRY(hipStreamSynchronize(st));
   double tStart = nowMs();
-  launchInit(st, ps, s->qRegen.ptr, s->dCounters.ptr, (uint32_t)slots);
+  launchInit(st, ps, qs, s->dCounters.ptr, (uint32_t)slots);
   const uint64_t maxIters = (uint64_t)rs.spp * std::max(1u, U.maxBounces) + 2u;
   uint32_t cur = Q_TRACE_A, next = Q_TRACE_B;
   uint32_t iters = 0, traceLaunches = 0;
@@ -805,20 +854,22 @@ extern "C" int giCRender(const GiCRenderParams* params)
     else fn();
   };
   for (uint64_t it = 0; it < maxIters; it++) {
-    timed(0, [&] { launchRaygen(st, wideBlocks, U, ps, s->qRegen.ptr, queues[cur], s->dCounters.ptr, cur, colorOut); });
+    timed(0, [&] { launchRaygen(st, wideBlocks, U, ps, qs, s->dCounters.ptr, cur, colorOut); });
     if (it >= rs.spp && (it % 8u) == 0u) { // a slot needs >= spp iterations; afterwards poll the queue sizes
-      HIP_TRY(hipMemcpyAsync(s->hCounters, s->dCounters.ptr, sizeof(uint32_t) * Q_COUNT, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(s->hCounters, s->dCounters.ptr, sizeof(uint32_t) * Q_COUNT * NSHARD, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
-      if (s->hCounters->count[cur] == 0) break; // raygen consumed the regen queue and produced no rays: done
+      uint32_t pending = 0; for (uint32_t k = 0; k < NSHARD; k++) pending += s->hCounters->count[cur][k];
+      if (pending == 0) break; // raygen consumed the regen queue and produced no rays: done
     }
-    timed(1, [&] { launchTrace(st, traceBlocks, false, s->countTraversal, view, ps, queues[cur], s->dCounters.ptr, cur); });
+    launchReset(st, s->dCounters.ptr, cur, next); // raygen consumed REGEN; trace/shade append to REGEN, HIT, SHADOW, TRACE[next]
+    timed(1, [&] { launchTrace(st, traceBlocks, false, s->countTraversal, view, ps, qs, s->dCounters.ptr, cur); });
     traceLaunches++;
-    launchReset(st, s->dCounters.ptr, next, Q_REGEN, Q_SHADOW);
-    timed(2, [&] { launchShade(st, wideBlocks, U, view, ps, queues[cur], queues[next], s->qRegen.ptr, s->qShadow.ptr, s->dCounters.ptr, cur, next); });
-    if (nee) timed(3, [&] { launchTrace(st, traceBlocks, true, s->countTraversal, view, ps, s->qShadow.ptr, s->dCounters.ptr, Q_SHADOW); });
+    timed(2, [&] { launchShade(st, wideBlocks, U, view, ps, qs, s->dCounters.ptr, next); });
+    if (nee) timed(3, [&] { launchTrace(st, traceBlocks, true, s->countTraversal, view, ps, qs, s->dCounters.ptr, Q_SHADOW); });
     std::swap(cur, next);
     iters++;
   }
+  launchReset(st, s->dCounters.ptr, cur, next); // account the last iteration's shadow rays (its trace queue is empty)
   HIP_TRY(hipMemcpyAsync(s->hCounters, s->dCounters.ptr, sizeof(Counters), hipMemcpyDeviceToHost, st));
   if (!colorRb->deviceOnly) {
     size_t off = (size_t)rowBegin * width * 16, bytes = slots * 16;
@@ -853,26 +904,37 @@ extern "C" int giCTraceRays(GiCScene* s, uint32_t count, const float* origins, c
   std::lock_guard<std::mutex> guard(s->mutex);
   hipStream_t st = g_ctx.stream;
   if (s->dirty & (DIRTY_BVH | DIRTY_MATERIALS)) { if (buildScene(s) != GI_C_OK) return -1; s->dirty &= ~(DIRTY_BVH | DIRTY_MATERIALS); s->dirty |= DIRTY_FRAMEBUFFER; }
-  if (ensurePathState(s, count) != GI_C_OK) return -1;
-  std::vector<F4> ro(count), rd(count); std::vector<uint32_t> q(count);
+  const uint32_t blocks = std::min<uint32_t>((count + 255u) / 256u, (uint32_t)g_ctx.cuCount * 3u);
+  if (ensurePathState(s, count, blocks, blocks) != GI_C_OK) return -1;
+  std::vector<Slot> host(count); std::vector<uint32_t> q(count);
   for (uint32_t i = 0; i < count; i++) {
-    ro[i] = F4{origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], tMin};
-    rd[i] = F4{dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], tMax};
+    memset(&host[i], 0, sizeof(Slot));
+    host[i].rayO = F4{origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], tMin};
+    host[i].rayD = F4{dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], tMax};
     q[i] = i;
   }
-  Counters c{}; c.count[Q_TRACE_A] = count;
-  if (hipMemcpyAsync(s->sRayO.ptr, ro.data(), count * sizeof(F4), hipMemcpyHostToDevice, st) != hipSuccess ||
-      hipMemcpyAsync(s->sRayD.ptr, rd.data(), count * sizeof(F4), hipMemcpyHostToDevice, st) != hipSuccess ||
-      hipMemcpyAsync(s->qA.ptr, q.data(), count * sizeof(uint32_t), hipMemcpyHostToDevice, st) != hipSuccess ||
+  Counters c{}; c.count[Q_TRACE_A][0] = count; // everything in shard 0 (capacity >= count/NSHARD + ... is not enough: use all shards)
+  {
+    const uint32_t per = (count + NSHARD - 1u) / NSHARD;
+    for (uint32_t k = 0; k < NSHARD; k++) { uint32_t lo = k * per; c.count[Q_TRACE_A][k] = lo < count ? std::min(per, count - lo) : 0u; }
+  }
+  std::vector<uint32_t> qhost((size_t)s->queueCap * NSHARD, 0u);
+  {
+    const uint32_t per = (count + NSHARD - 1u) / NSHARD;
+    for (uint32_t i = 0; i < count; i++) qhost[(size_t)(i / per) * s->queueCap + (i % per)] = q[i];
+  }
+  if (hipMemcpyAsync(s->slots.ptr, host.data(), count * sizeof(Slot), hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(s->queues[Q_TRACE_A].ptr, qhost.data(), qhost.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st) != hipSuccess ||
       hipMemcpyAsync(s->dCounters.ptr, &c, sizeof(c), hipMemcpyHostToDevice, st) != hipSuccess) { setError("giCTraceRays: upload failed"); return -1; }
-  PathState ps{s->sRayO.ptr, s->sRayD.ptr, s->sHit.ptr, s->sThr.ptr, s->sRad.ptr, s->sAcc.ptr, s->sNeeC.ptr, s->sNeeD.ptr};
-  uint32_t blocks = std::min<uint32_t>((count + 255u) / 256u, (uint32_t)g_ctx.cuCount * 3u);
-  launchTrace(st, blocks, false, false, makeView(s), ps, s->qA.ptr, s->dCounters.ptr, Q_TRACE_A);
-  std::vector<F4> hit(count);
+  PathState ps{s->slots.ptr};
+  QueueSet qs{}; for (uint32_t k = 0; k < Q_COUNT; k++) qs.items[k] = s->queues[k].ptr; qs.cap = s->queueCap;
+  launchTrace(st, blocks, false, false, makeView(s), ps, qs, s->dCounters.ptr, Q_TRACE_A);
   std::vector<TriRec> tris(s->triCount);
-  if (hipMemcpyAsync(hit.data(), s->sHit.ptr, count * sizeof(F4), hipMemcpyDeviceToHost, st) != hipSuccess ||
+  if (hipMemcpyAsync(host.data(), s->slots.ptr, count * sizeof(Slot), hipMemcpyDeviceToHost, st) != hipSuccess ||
       (s->triCount && hipMemcpyAsync(tris.data(), s->dTris.ptr, s->triCount * sizeof(TriRec), hipMemcpyDeviceToHost, st) != hipSuccess) ||
       hipStreamSynchronize(st) != hipSuccess) { setError("giCTraceRays: readback failed"); return -1; }
+  std::vector<F4> hit(count);
+  for (uint32_t i = 0; i < count; i++) hit[i] = host[i].hit;
   int hits = 0;
   for (uint32_t i = 0; i < count; i++) {
     uint32_t tri; memcpy(&tri, &hit[i].w, 4);
@@ -957,6 +1019,7 @@ extern "C" int giCDebugEvalBsdf(const GiCMaterialDesc* desc, uint32_t count, con
   if (!g_ctx.initialized || !desc || (count && (!in || !out))) { setError("giCDebugEvalBsdf: bad arguments"); return GI_C_ERROR; }
   if (count == 0) return GI_C_OK;
   MaterialRec m; m.klass = desc->klass; m.flags = desc->flags; memcpy(m.p, desc->p, sizeof(m.p));
+  deriveMaterialConstants(m);
   MaterialRec* dm = nullptr; float* din = nullptr; float* dout = nullptr;
   hipStream_t st = g_ctx.stream;
   int rc = GI_C_ERROR;

@@ -7,14 +7,11 @@
 
 namespace gi {
 
-void launchInit(hipStream_t s, const PathState& st, uint32_t* qRegen, Counters* cnt, uint32_t n);
-void launchReset(hipStream_t s, Counters* cnt, uint32_t a, uint32_t b, uint32_t c);
-void launchRaygen(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const PathState& st, const uint32_t* qRegen, uint32_t* qTrace,
-                  Counters* cnt, uint32_t traceIdx, F4* colorOut);
-void launchTrace(hipStream_t s, uint32_t blocks, bool anyHit, bool count, const SceneView& sc, const PathState& st, const uint32_t* queue,
-                 Counters* cnt, uint32_t queueIdx);
-void launchShade(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const SceneView& sc, const PathState& st, const uint32_t* qCur,
-                 uint32_t* qNext, uint32_t* qRegen, uint32_t* qShadow, Counters* cnt, uint32_t curIdx, uint32_t nextIdx);
+void launchInit(hipStream_t s, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t n);
+void launchReset(hipStream_t s, Counters* cnt, uint32_t traceCur, uint32_t traceNext);
+void launchRaygen(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t traceIdx, F4* colorOut);
+void launchTrace(hipStream_t s, uint32_t blocks, bool anyHit, bool count, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t queueIdx);
+void launchShade(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t nextIdx);
 
 void launchDebugBsdf(hipStream_t s, const MaterialRec* mat, uint32_t count, const float* in, float* out);
 

@@ -20,60 +20,129 @@
 namespace gi {
 
 // ------------------------------------------------------------------------------------------------
-// wave64 stream compaction: ballot + prefix popcount, one atomic per wave and queue
+// Stream compaction.  wave64 ballot + popcount prefix inside a wave, LDS aggregation over the 4 waves of a block,
+// ONE atomic per block, queue and loop trip -- on the block's own shard of the queue (see gi_types.h: NSHARD).
+// All stage kernels run block-uniform loops so the two barriers per trip are legal.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_append(bool pred, uint32_t value, uint32_t* __restrict__ queue, uint32_t* counter)
+constexpr uint32_t BLOCK = 256;
+constexpr uint32_t WAVES = BLOCK / 64;
+
+template <int NQ>
+struct AppendScratch { uint32_t wcount[2][NQ][WAVES]; uint32_t base[2][NQ]; };
+
+template <int NQ>
+__device__ __forceinline__ void block_append(AppendScratch<NQ>& sh, uint32_t trip, const bool (&pred)[NQ], uint32_t slot, const QueueSet& qs,
+                                             const uint32_t (&qid)[NQ], Counters* cnt)
 {
-  unsigned long long m = __ballot(pred);
-  if (m == 0ull) return;
-  uint32_t lane = __lane_id();
-  int leader = __ffsll((long long)m) - 1;
-  uint32_t base = 0;
-  if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
-  base = __shfl(base, leader);
-  if (pred) queue[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
+  const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6, par = trip & 1u, shard = blockIdx.x % NSHARD;
+  unsigned long long m[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    m[q] = __ballot(pred[q]);
+    if (lane == 0) sh.wcount[par][q][wave] = (uint32_t)__popcll(m[q]);
+  }
+  __syncthreads();
+  if (threadIdx.x < NQ) {
+    const uint32_t q = threadIdx.x;
+    uint32_t total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < WAVES; w++) total += sh.wcount[par][q][w];
+    sh.base[par][q] = total ? atomicAdd(&cnt->count[qid[q]][shard], total) : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    if (pred[q]) {
+      uint32_t off = sh.base[par][q] + (uint32_t)__popcll(m[q] & ((1ull << lane) - 1ull));
+      for (uint32_t w = 0; w < wave; w++) off += sh.wcount[par][q][w];
+      qs.items[qid[q]][shard * qs.cap + off] = slot;
+    }
+  }
+}
+
+// Reader side: the queue is the concatenation of its NSHARD segments.
+struct QueueReader { uint32_t pre[NSHARD + 1]; const uint32_t* items; uint32_t cap; };
+__device__ __forceinline__ void reader_init(QueueReader& r, const Counters* cnt, uint32_t q, const QueueSet& qs)
+{
+  r.pre[0] = 0;
+#pragma unroll
+  for (uint32_t s = 0; s < NSHARD; s++) r.pre[s + 1] = r.pre[s] + cnt->count[q][s];
+  r.items = qs.items[q]; r.cap = qs.cap;
+}
+__device__ __forceinline__ uint32_t reader_get(const QueueReader& r, uint32_t i)
+{
+  uint32_t s = 0, p = 0;
+#pragma unroll
+  for (uint32_t k = 1; k < NSHARD; k++) { const bool ge = i >= r.pre[k]; s += ge ? 1u : 0u; p = ge ? r.pre[k] : p; }
+  return r.items[s * r.cap + (i - p)];
 }
 
 __device__ __forceinline__ F4 ld4(const F4* p) { float4 v = *reinterpret_cast<const float4*>(p); return F4{v.x, v.y, v.z, v.w}; }
 __device__ __forceinline__ void st4(F4* p, float x, float y, float z, float w) { *reinterpret_cast<float4*>(p) = make_float4(x, y, z, w); }
+constexpr uint32_t MISS = 0xffffffffu;
 
 // ------------------------------------------------------------------------------------------------
 // k_init: every slot starts in the regen queue with "no sample in flight"
 // ------------------------------------------------------------------------------------------------
-__global__ void k_init(PathState st, uint32_t* qRegen, Counters* cnt, uint32_t n)
+__global__ void k_init(PathState st, QueueSet qs, Counters* cnt, uint32_t n)
 {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) {
-    cnt->count[Q_TRACE_A] = 0; cnt->count[Q_TRACE_B] = 0; cnt->count[Q_REGEN] = n; cnt->count[Q_SHADOW] = 0;
-    cnt->segments = 0; cnt->shadowRays = 0; cnt->nodesVisited = 0; cnt->trisTested = 0; cnt->shadowNodesVisited = 0; cnt->shadowTrisTested = 0;
+  const uint32_t per = (n + NSHARD - 1u) / NSHARD; // regen segment s = slots [s*per, min(n,(s+1)*per))
+  if (i < Q_COUNT * NSHARD) {
+    const uint32_t q = i / NSHARD, sdx = i % NSHARD;
+    uint32_t c = 0;
+    if (q == Q_REGEN) { const uint32_t lo = sdx * per; c = lo < n ? ((n - lo) < per ? (n - lo) : per) : 0u; }
+    cnt->count[q][sdx] = c;
   }
+  if (i == 0) { cnt->segments = 0; cnt->shadowRays = 0; cnt->nodesVisited = 0; cnt->trisTested = 0; cnt->shadowNodesVisited = 0; cnt->shadowTrisTested = 0; }
   for (; i < n; i += gridDim.x * blockDim.x) {
-    st4(&st.acc[i], 0.0f, 0.0f, 0.0f, u2f(0xffffffffu));
-    qRegen[i] = i;
+    st4(&st.slots[i].acc, 0.0f, 0.0f, 0.0f, u2f(0xffffffffu));
+    qs.items[Q_REGEN][(i / per) * qs.cap + (i % per)] = i;
   }
 }
 
-__global__ void k_reset(Counters* cnt, uint32_t a, uint32_t b, uint32_t c)
+// Between k_raygen and k_trace: account the rays about to be traced / the shadow rays just traced, then zero the
+// queues that this iteration's producers append to.
+__global__ void k_reset(Counters* cnt, uint32_t traceCur, uint32_t traceNext)
 {
-  if (threadIdx.x == 0) { cnt->count[a] = 0; cnt->count[b] = 0; cnt->count[c] = 0; }
+  const uint32_t t = threadIdx.x;
+  if (t == 0) {
+    uint32_t rays = 0, shadow = 0;
+    for (uint32_t s = 0; s < NSHARD; s++) { rays += cnt->count[traceCur][s]; shadow += cnt->count[Q_SHADOW][s]; }
+    cnt->segments += rays; cnt->shadowRays += shadow;
+  }
+  __syncthreads();
+  if (t < NSHARD) { cnt->count[traceNext][t] = 0; cnt->count[Q_REGEN][t] = 0; cnt->count[Q_SHADOW][t] = 0; cnt->count[Q_HIT][t] = 0; }
 }
 
 // ------------------------------------------------------------------------------------------------
 // k_raygen: persistent-thread ray generation + per-sample finish (rp_main.rgen:213-283, 483-515)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_raygen(FrameUniforms U, PathState st, const uint32_t* __restrict__ qRegen,
-                                                uint32_t* __restrict__ qTrace, Counters* cnt, uint32_t traceIdx, F4* __restrict__ colorOut)
+__global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st, QueueSet qs, Counters* cnt, uint32_t traceIdx, F4* __restrict__ colorOut)
 {
-  const uint32_t n = cnt->count[Q_REGEN];
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const uint32_t slot = qRegen[i];
-    F4 acc = ld4(&st.acc[slot]);
+  __shared__ AppendScratch<1> sh;
+  QueueReader rd; reader_init(rd, cnt, Q_REGEN, qs);
+  const uint32_t n = rd.pre[NSHARD];
+  const uint32_t stride = gridDim.x * BLOCK;
+  uint32_t trip = 0;
+  for (uint32_t base = blockIdx.x * BLOCK; base < n; base += stride, trip++) {
+    const uint32_t i = base + threadIdx.x;
+    bool more = false; uint32_t slot = 0;
+    if (i < n) {
+    slot = reader_get(rd, i);
+    Slot* S = &st.slots[slot];
+    F4 acc = ld4(&S->acc);
     uint32_t s = f2u(acc.w);
     V3 pixelColor = v3(acc.x, acc.y, acc.z);
     if (s != 0xffffffffu) { // finish the sample that just terminated (:489-498)
-      F4 r = ld4(&st.rad[slot]);
+      F4 r = ld4(&S->rad);
       V3 rad = v3(r.x, r.y, r.z);
+      if (f2u(S->hit.w) == MISS) {
+        // the path left the scene: uniform fallback dome == colour-AOV clear value (rp_main.miss:68-86, Gi.cpp:2184-2199,
+        // 2232-2238).  k_trace routes misses straight here; nothing after the miss can change the sample any more.
+        F4 tb = ld4(&S->thr);
+        rad = rad + v3(tb.x, tb.y, tb.z) * v3(U.background);
+      }
       float mv = fmax2(rad.x, fmax2(rad.y, rad.z));
       if (mv > U.maxSampleValue) rad = rad * (U.maxSampleValue / mv);
       V3 sc = v3(fmax2(0.0f, rad.x), fmax2(0.0f, rad.y), fmax2(0.0f, rad.z));
@@ -81,7 +150,7 @@ __global__ __launch_bounds__(256) void k_raygen(FrameUniforms U, PathState st, c
     }
     s = s + 1u; // 0xffffffff + 1 == 0
     const uint32_t pixelIndex = U.rowBegin * U.imageWidth + slot; // :195 (global index: RNG is tile independent)
-    bool more = s < U.spp;
+    more = s < U.spp;
     if (more) {
       const uint32_t px = pixelIndex % U.imageWidth, py = pixelIndex / U.imageWidth;
       uint32_t rng = gi_hash_init(pixelIndex * ((U.sampleOffset + s) + 1u)); // :223, common.glsl:121-124
@@ -111,18 +180,20 @@ __global__ __launch_bounds__(256) void k_raygen(FrameUniforms U, PathState st, c
         float cosCone = fmax2(1e-5f, dot(dir, v3(U.camFwd)));
         tMin = U.clipNear / cosCone; tMax = U.clipFar / cosCone;
       }
-      st4(&st.rayO[slot], origin.x, origin.y, origin.z, tMin);
-      st4(&st.rayD[slot], dir.x, dir.y, dir.z, tMax);
-      st4(&st.thr[slot], 1.0f, 1.0f, 1.0f, u2f(0u)); // :274-276
-      st4(&st.rad[slot], 0.0f, 0.0f, 0.0f, u2f(rng));
-      st4(&st.acc[slot], pixelColor.x, pixelColor.y, pixelColor.z, u2f(s));
+      st4(&S->rayO, origin.x, origin.y, origin.z, tMin);
+      st4(&S->rayD, dir.x, dir.y, dir.z, tMax);
+      st4(&S->thr, 1.0f, 1.0f, 1.0f, u2f(0u)); // :274-276
+      st4(&S->rad, 0.0f, 0.0f, 0.0f, u2f(rng));
+      st4(&S->acc, pixelColor.x, pixelColor.y, pixelColor.z, u2f(s));
     } else { // :506-515
       V3 prev = pixelColor;
       if ((U.flags & FLAG_PROGRESSIVE) && U.sampleOffset > 0u) { F4 p = ld4(&colorOut[pixelIndex]); prev = v3(p.x, p.y, p.z); }
       V3 c = (prev * U.sampleOffsetF + pixelColor * U.sppF) * U.invTotalSampleCount;
       st4(&colorOut[pixelIndex], c.x, c.y, c.z, 1.0f);
     }
-    wave_append(more, slot, qTrace, &cnt->count[traceIdx]);
+    }
+    const bool pred[1] = {more}; const uint32_t qid[1] = {traceIdx};
+    block_append<1>(sh, trip, pred, slot, qs, qid, cnt);
   }
 }
 
@@ -215,10 +286,10 @@ __device__ __forceinline__ bool traverse(const SceneView& sc, const uint4* s_nod
       const uint32_t triIdx = Gt.x + k;
       uint4 a, b, c;
       if (triIdx < ldsTris) { const uint4* p = s_tris + triIdx * 3u; a = p[0]; b = p[1]; c = p[2]; }
-      else { const uint4* p = reinterpret_cast<const uint4*>(sc.tris) + (size_t)triIdx * 3u; a = p[0]; b = p[1]; c = p[2]; }
+      else { const uint4* p = reinterpret_cast<const uint4*>(sc.tris) + (size_t)triIdx * 4u; a = p[0]; b = p[1]; c = p[2]; }
       if (COUNT) tc.tris++;
       const V3 v0 = v3(u2f(a.x), u2f(a.y), u2f(a.z)), e1 = v3(u2f(a.w), u2f(b.x), u2f(b.y)), e2 = v3(u2f(b.z), u2f(b.w), u2f(c.x));
-      const uint32_t orig = c.w;
+      const uint32_t orig = c.y;
       // two-sided Moeller-Trumbore, operation order == oracle tri_test
       const V3 pv = cross(d, e2);
       const float det = dot(e1, pv);
@@ -248,51 +319,57 @@ __device__ __forceinline__ bool traverse(const SceneView& sc, const uint4* s_nod
 }
 
 template <bool ANYHIT, bool COUNT>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState st, const uint32_t* __restrict__ queue, Counters* cnt, uint32_t queueIdx)
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t queueIdx)
 {
   __shared__ uint4 s_nodes[LDS_NODES * 5];
   __shared__ uint4 s_tris[LDS_TRIS * 3];
   __shared__ uint2 s_stack[LDS_STACK][TRACE_BLOCK];
-  const uint32_t n = cnt->count[queueIdx];
+  __shared__ AppendScratch<2> sh;
+  QueueReader rd; reader_init(rd, cnt, queueIdx, qs);
+  const uint32_t n = rd.pre[NSHARD];
   if (blockIdx.x * TRACE_BLOCK >= n) return; // whole block idle (uniform)
   const uint32_t ldsNodes = sc.nodeCount < LDS_NODES ? sc.nodeCount : LDS_NODES;
   const uint32_t ldsTris = sc.triCount <= LDS_TRIS ? sc.triCount : 0u;
   for (uint32_t i = threadIdx.x; i < ldsNodes * 5u; i += TRACE_BLOCK) s_nodes[i] = reinterpret_cast<const uint4*>(sc.nodes)[i];
-  for (uint32_t i = threadIdx.x; i < ldsTris * 3u; i += TRACE_BLOCK) s_tris[i] = reinterpret_cast<const uint4*>(sc.tris)[i];
+  for (uint32_t i = threadIdx.x; i < ldsTris * 3u; i += TRACE_BLOCK) s_tris[i] = reinterpret_cast<const uint4*>(sc.tris)[(i / 3u) * 4u + (i % 3u)];
   __syncthreads();
 
   TraceCounters tc{0u, 0u};
-  uint32_t rays = 0;
   const uint32_t stride = gridDim.x * TRACE_BLOCK;
-  for (uint32_t i = blockIdx.x * TRACE_BLOCK + threadIdx.x; i < n; i += stride) {
-    const uint32_t slot = queue[i];
-    rays++;
-    if (!ANYHIT) {
-      const F4 ro = ld4(&st.rayO[slot]), rd = ld4(&st.rayD[slot]);
-      float t, u, v; uint32_t tri;
-      traverse<false, COUNT>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, v3(ro.x, ro.y, ro.z), v3(rd.x, rd.y, rd.z), ro.w, rd.w, t, u, v, tri, tc);
-      st4(&st.hit[slot], t, u, v, u2f(tri));
-    } else {
-      // shadow ray (rp_main.rgen:397-429): origin = next ray origin, tMin 0.01, tMax = distance to the light sample
-      const F4 ro = ld4(&st.rayO[slot]), sd = ld4(&st.neeD[slot]), nc = ld4(&st.neeC[slot]);
-      float t, u, v; uint32_t tri;
-      const bool occluded = traverse<true, COUNT>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, v3(ro.x, ro.y, ro.z), v3(sd.x, sd.y, sd.z), 0.01f, nc.w, t, u, v, tri, tc);
-      if (!occluded) {
-        F4 r = ld4(&st.rad[slot]);
-        st4(&st.rad[slot], r.x + nc.x, r.y + nc.y, r.z + nc.z, r.w);
+  uint32_t trip = 0;
+  for (uint32_t base = blockIdx.x * TRACE_BLOCK; base < n; base += stride, trip++) {
+    const uint32_t i = base + threadIdx.x;
+    bool hit = false, miss = false; uint32_t slot = 0;
+    if (i < n) {
+      slot = reader_get(rd, i);
+      Slot* S = &st.slots[slot];
+      if (!ANYHIT) {
+        const F4 ro = ld4(&S->rayO), rdir = ld4(&S->rayD);
+        float t, u, v; uint32_t tri;
+        hit = traverse<false, COUNT>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), ro.w, rdir.w, t, u, v, tri, tc);
+        miss = !hit;
+        st4(&S->hit, t, u, v, u2f(tri));
+      } else {
+        // shadow ray (rp_main.rgen:397-429): origin = next ray origin, tMin 0.01, tMax = distance to the light sample
+        const F4 ro = ld4(&S->rayO), sd = ld4(&S->neeD), nc = ld4(&S->neeC);
+        float t, u, v; uint32_t tri;
+        const bool occluded = traverse<true, COUNT>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, v3(ro.x, ro.y, ro.z), v3(sd.x, sd.y, sd.z), 0.01f, nc.w, t, u, v, tri, tc);
+        if (!occluded) {
+          F4 r = ld4(&S->rad);
+          st4(&S->rad, r.x + nc.x, r.y + nc.y, r.z + nc.z, r.w);
+        }
       }
     }
-  }
-  // statistics: one atomic per wave
-  {
-    unsigned long long r = rays;
-    for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off);
-    if (__lane_id() == 0 && r) atomicAdd(ANYHIT ? &cnt->shadowRays : &cnt->segments, r);
-    if (COUNT) {
-      unsigned long long a = tc.nodes, b = tc.tris;
-      for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
-      if (__lane_id() == 0) { atomicAdd(ANYHIT ? &cnt->shadowNodesVisited : &cnt->nodesVisited, a); atomicAdd(ANYHIT ? &cnt->shadowTrisTested : &cnt->trisTested, b); }
+    if (!ANYHIT) {
+      // sort by outcome: hits go to the shade stage, misses straight to k_raygen (which adds the environment term)
+      const bool pred[2] = {hit, miss}; const uint32_t qid[2] = {Q_HIT, Q_REGEN};
+      block_append<2>(sh, trip, pred, slot, qs, qid, cnt);
     }
+  }
+  if (COUNT) { // measurement builds only: one atomic pair per wave
+    unsigned long long a = tc.nodes, b = tc.tris;
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+    if (__lane_id() == 0) { atomicAdd(ANYHIT ? &cnt->shadowNodesVisited : &cnt->nodesVisited, a); atomicAdd(ANYHIT ? &cnt->shadowTrisTested : &cnt->trisTested, b); }
   }
 }
 
@@ -314,43 +391,38 @@ __device__ __forceinline__ V3 xform_normal(const float* w, V3 n)
 
 __device__ __forceinline__ void setup_shading_state(const SceneView& sc, uint32_t triIdx, float hu, float hv, V3 rayDir, ShState& s)
 {
-  const uint4 tail = reinterpret_cast<const uint4*>(sc.tris)[(size_t)triIdx * 3u + 2u]; // e2.z, instance, prim, origId
-  const uint32_t instIdx = tail.y, prim = tail.z;
-  const InstanceRec* inst = &sc.instances[instIdx];
-  float o2w[12], w2o[9];
-  {
-    const float4* ip = reinterpret_cast<const float4*>(inst);
-    float4 r0 = ip[0], r1 = ip[1], r2 = ip[2], r3 = ip[3], r4 = ip[4], r5 = ip[5];
-    o2w[0] = r0.x; o2w[1] = r0.y; o2w[2] = r0.z; o2w[3] = r0.w; o2w[4] = r1.x; o2w[5] = r1.y; o2w[6] = r1.z; o2w[7] = r1.w;
-    o2w[8] = r2.x; o2w[9] = r2.y; o2w[10] = r2.z; o2w[11] = r2.w;
-    w2o[0] = r3.x; w2o[1] = r3.y; w2o[2] = r3.z; w2o[3] = r3.w; w2o[4] = r4.x; w2o[5] = r4.y; w2o[6] = r4.z; w2o[7] = r4.w; w2o[8] = r5.x;
-    const uint4 m = *reinterpret_cast<const uint4*>(&sc.meshes[f2u(r5.y)]);
-    s.material = m.z; s.meshFlags = m.w;
-    const uint32_t* f = sc.faces + ((size_t)m.x + prim) * 3u;
-    const uint32_t i0 = f[0], i1 = f[1], i2 = f[2];
-    const float4* vb = reinterpret_cast<const float4*>(sc.verts + m.y);
-    const float4 a1 = vb[2 * (size_t)i0], a2 = vb[2 * (size_t)i0 + 1];
-    const float4 b1 = vb[2 * (size_t)i1], b2 = vb[2 * (size_t)i1 + 1];
-    const float4 c1 = vb[2 * (size_t)i2], c2 = vb[2 * (size_t)i2 + 1];
-    const float bx = 1.0f - hu - hv, by = hu, bz = hv;
-    const V3 pa = v3(a1.x, a1.y, a1.z), pb = v3(b1.x, b1.y, b1.z), pc = v3(c1.x, c1.y, c1.z);
-    const V3 localPos = (pa * bx + pb * by) + pc * bz;
-    s.position = xform_point(o2w, localPos, 1.0f);
-    V3 gn = normalize(cross(pb - pa, pc - pa));
-    gn = normalize(xform_normal(w2o, gn));
-    const V3 n0 = gi_decode_direction(f2u(a2.x)), n1 = gi_decode_direction(f2u(b2.x)), n2 = gi_decode_direction(f2u(c2.x));
-    const V3 ln = normalize((n0 * bx + n1 * by) + n2 * bz);
-    V3 nrm = normalize(xform_normal(w2o, ln));
-    s.frontFace = dot(gn, -rayDir) >= 0.0f;
-    if (!s.frontFace) { gn = -gn; nrm = -nrm; }
-    const V3 t0 = gi_decode_direction(f2u(a2.y)), t1 = gi_decode_direction(f2u(b2.y)), t2 = gi_decode_direction(f2u(c2.y));
-    const V3 lt = normalize((t0 * bx + t1 * by) + t2 * bz);
-    V3 tg = normalize(xform_point(o2w, lt, 0.0f));
-    tg = normalize(tg - nrm * dot(tg, nrm));
-    const float bs = (bx * a1.w + by * b1.w) + bz * c1.w;
-    s.tangentU = tg; s.tangentV = cross(nrm, tg) * bs;
-    s.normal = nrm; s.geomNormal = gn;
-  }
+  // one dependent step: the triangle record's tail names the instance, the material and the three vertices
+  const uint4* tp = reinterpret_cast<const uint4*>(sc.tris) + (size_t)triIdx * 4u;
+  const uint4 tc = tp[2], td = tp[3]; // (e2.z, origId, instance, matFlags), (i0, i1, i2, prim)
+  s.material = tc.w & 0x00ffffffu; s.meshFlags = tc.w >> 30;
+  const float4* ip = reinterpret_cast<const float4*>(&sc.instances[tc.z]);
+  const float4* va = reinterpret_cast<const float4*>(&sc.verts[td.x]);
+  const float4* vb = reinterpret_cast<const float4*>(&sc.verts[td.y]);
+  const float4* vc = reinterpret_cast<const float4*>(&sc.verts[td.z]);
+  const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2], r3 = ip[3], r4 = ip[4], r5 = ip[5];
+  const float4 a1 = va[0], a2 = va[1], a3 = va[2];
+  const float4 b1 = vb[0], b2 = vb[1], b3 = vb[2];
+  const float4 c1 = vc[0], c2 = vc[1], c3 = vc[2];
+  const float o2w[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+  const float w2o[9] = {r3.x, r3.y, r3.z, r3.w, r4.x, r4.y, r4.z, r4.w, r5.x};
+  const float bx = 1.0f - hu - hv, by = hu, bz = hv;                                  // :17
+  const V3 pa = v3(a1.x, a1.y, a1.z), pb = v3(b1.x, b1.y, b1.z), pc = v3(c1.x, c1.y, c1.z);
+  const V3 localPos = (pa * bx + pb * by) + pc * bz;                                  // :24
+  s.position = xform_point(o2w, localPos, 1.0f);                                      // :25
+  V3 gn = normalize(cross(pb - pa, pc - pa));                                         // :27
+  gn = normalize(xform_normal(w2o, gn));                                              // :28
+  const V3 n0 = v3(a2.x, a2.y, a2.z), n1 = v3(b2.x, b2.y, b2.z), n2 = v3(c2.x, c2.y, c2.z); // decoded on the host (:31-33)
+  const V3 ln = normalize((n0 * bx + n1 * by) + n2 * bz);                             // :35
+  V3 nrm = normalize(xform_normal(w2o, ln));                                          // :36
+  s.frontFace = dot(gn, -rayDir) >= 0.0f;                                             // :39
+  if (!s.frontFace) { gn = -gn; nrm = -nrm; }                                         // :41-45
+  const V3 t0 = v3(a3.x, a3.y, a3.z), t1 = v3(b3.x, b3.y, b3.z), t2 = v3(c3.x, c3.y, c3.z); // decoded on the host (:48-50)
+  const V3 lt = normalize((t0 * bx + t1 * by) + t2 * bz);                             // :52
+  V3 tg = normalize(xform_point(o2w, lt, 0.0f));                                      // :53
+  tg = normalize(tg - nrm * dot(tg, nrm));                                            // :56
+  const float bs = (bx * a1.w + by * b1.w) + bz * c1.w;                               // :58
+  s.tangentU = tg; s.tangentV = cross(nrm, tg) * bs;                                  // :59
+  s.normal = nrm; s.geomNormal = gn;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -411,21 +483,14 @@ __device__ inline void ggx_eval(V3 l1, V3 l2, float alpha, float& fcos, float& p
 }
 
 struct UpsParams { V3 albedo, F0; float alpha, coat, coatAlpha; };
+// per-material constants are evaluated once on the host (gi_c.cpp: deriveMaterialConstants) with the same fp32
+// formulas the oracle evaluates per hit
 __device__ __forceinline__ UpsParams ups_params(const MaterialRec* m)
 {
   UpsParams u;
-  V3 dc = v3(m->p[0], m->p[1], m->p[2]);
-  float r = m->p[11], cr = m->p[13];
-  u.alpha = fmax2(r * r, 0.001f);
-  u.coatAlpha = fmax2(cr * cr, 0.001f);
-  u.coat = m->p[12];
-  if (m->p[6] != 0.0f) { u.F0 = v3(m->p[7], m->p[8], m->p[9]); u.albedo = dc; }
-  else {
-    float ior = m->p[16], metal = m->p[10];
-    float q = (1.0f - ior) / (1.0f + ior); float f0 = q * q;
-    u.F0 = v3(f0, f0, f0) * (1.0f - metal) + dc * metal;
-    u.albedo = dc * (1.0f - metal);
-  }
+  u.albedo = v3(m->p[MP_ALBEDO], m->p[MP_ALBEDO + 1], m->p[MP_ALBEDO + 2]);
+  u.F0 = v3(m->p[MP_F0], m->p[MP_F0 + 1], m->p[MP_F0 + 2]);
+  u.alpha = m->p[MP_ALPHA]; u.coat = m->p[MP_COAT]; u.coatAlpha = m->p[MP_COAT_ALPHA];
   return u;
 }
 
@@ -576,78 +641,73 @@ __device__ inline void sample_light(const SceneView& sc, const FrameUniforms& U,
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_shade: closest-hit / miss shading + the post-trace part of the bounce loop
-// (rp_main.chit:132-493, rp_main.miss:55-86, rp_main.rgen:397-480)
+// k_shade: closest-hit shading + the post-trace part of the bounce loop, over the HIT queue only
+// (rp_main.chit:132-493, rp_main.rgen:397-480).  Misses never get here (k_trace routes them to k_raygen).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_shade(FrameUniforms U, SceneView sc, PathState st, const uint32_t* __restrict__ qCur,
-                                               uint32_t* __restrict__ qNext, uint32_t* __restrict__ qRegen, uint32_t* __restrict__ qShadow,
-                                               Counters* cnt, uint32_t curIdx, uint32_t nextIdx)
+__global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t nextIdx)
 {
-  const uint32_t n = cnt->count[curIdx];
-  const uint32_t stride = gridDim.x * blockDim.x;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const uint32_t slot = qCur[i];
-    const F4 h = ld4(&st.hit[slot]);
-    const F4 tb = ld4(&st.thr[slot]);
-    const F4 rr = ld4(&st.rad[slot]);
+  __shared__ AppendScratch<3> sh;
+  QueueReader rdr; reader_init(rdr, cnt, Q_HIT, qs);
+  const uint32_t n = rdr.pre[NSHARD];
+  const uint32_t stride = gridDim.x * BLOCK;
+  uint32_t trip = 0;
+  for (uint32_t base = blockIdx.x * BLOCK; base < n; base += stride, trip++) {
+    const uint32_t i = base + threadIdx.x;
+    bool cont = false, ended = false, shadow = false; uint32_t slot = 0;
+    if (i < n) {
+    slot = reader_get(rdr, i);
+    Slot* S = &st.slots[slot];
+    const F4 h = ld4(&S->hit);
+    const F4 rd = ld4(&S->rayD);
+    const F4 tb = ld4(&S->thr);
+    const F4 rr = ld4(&S->rad);
     V3 throughput = v3(tb.x, tb.y, tb.z), radiance = v3(rr.x, rr.y, rr.z);
     uint32_t bitfield = f2u(tb.w), rng = f2u(rr.w);
     const uint32_t bounce = bitfield & 0x00000fffu;
-    const uint32_t tri = f2u(h.w);
-    bool shadow = false;
 
-    if (tri == 0xffffffffu) {
-      // miss: uniform fallback dome == colour-AOV clear value (rp_main.miss:68-86, Gi.cpp:2184-2199, 2232-2238)
-      bitfield |= 0x80000000u;
-      radiance = radiance + throughput * v3(U.background);
-    } else {
-      const F4 rd = ld4(&st.rayD[slot]);
-      const V3 rayDir = v3(rd.x, rd.y, rd.z);
-      ShState ss;
-      setup_shading_state(sc, tri, h.y, h.z, rayDir, ss);
-      const MaterialRec* mat = &sc.materials[ss.material];
-      const bool isDoubleSided = (ss.meshFlags & 2u) != 0u;
-      // emission (rp_main.chit:293-343): uniform EDF, radiance == emission colour where cos > 0
-      const V3 em = v3(mat->p[3], mat->p[4], mat->p[5]);
-      if (em.x != 0.0f || em.y != 0.0f || em.z != 0.0f) {
-        if (ss.frontFace || !isDoubleSided) {
-          const float c = dot(-rayDir, ss.normal);
-          if (c > 0.0f) radiance = radiance + throughput * (em * U.exposureScale);
-        }
+    const V3 rayDir = v3(rd.x, rd.y, rd.z);
+    ShState ss;
+    setup_shading_state(sc, f2u(h.w), h.y, h.z, rayDir, ss);
+    const MaterialRec* mat = &sc.materials[ss.material];
+    const bool isDoubleSided = (ss.meshFlags & 2u) != 0u;
+    // emission (rp_main.chit:293-343): uniform EDF, radiance == emission colour where cos > 0
+    const V3 em = v3(mat->p[3], mat->p[4], mat->p[5]);
+    if (em.x != 0.0f || em.y != 0.0f || em.z != 0.0f) {
+      if (ss.frontFace || !isDoubleSided) {
+        const float c = dot(-rayDir, ss.normal);
+        if (c > 0.0f) radiance = radiance + throughput * (em * U.exposureScale);
       }
-      // BSDF importance sampling (:361-389); xi = next4f, .w is drawn but unused by the closed forms
-      const float x0 = gi_next1f(rng), x1 = gi_next1f(rng), x2 = gi_next1f(rng); (void)gi_next1f(rng);
-      BsdfSample bs; bsdf_sample(mat, ss, -rayDir, x0, x1, x2, bs);
-      throughput = throughput * bs.overPdf;
-      const bool isTransmission = (bs.event & EV_TRANSMISSION) != 0u;
-      // NEE (:394-444)
-      if ((U.flags & FLAG_NEE) && (bs.event & (EV_DIFFUSE | EV_GLOSSY))) {
-        const float k0 = gi_next1f(rng), k1 = gi_next1f(rng), k2 = gi_next1f(rng), k3 = gi_next1f(rng);
-        V3 dirToLight, lightPower; float lightDist, invPdf; uint32_t ds;
-        sample_light(sc, U, k0, k1, k2, k3, ss.position, dirToLight, lightDist, lightPower, invPdf, ds);
-        V3 nee = v3(0.0f, 0.0f, 0.0f);
-        if ((lightDist > 0.0f) && dot(dirToLight, ss.geomNormal) > 0.0f) {
-          BsdfEval ev; bsdf_evaluate(mat, ss, -rayDir, dirToLight, ev);
-          if (ev.pdf > 0.0f) {
-            const float dmul = gi_half_to_float(ds & 0xffffu), smul = gi_half_to_float(ds >> 16);
-            const V3 weight = throughput * (lightPower * invPdf);
-            nee = nee + (weight * ev.diffuse) * dmul;
-            nee = nee + (weight * ev.glossy) * smul;
-          }
-        }
-        // rp_main.rgen:401-408: the shadow ray is traced only if it can contribute
-        const V3 toLight = dirToLight * lightDist;
-        const float ld = length(toLight);
-        const V3 sdir = gi_safe_div(toLight, ld);
-        shadow = gi_luminance(nee) > 1e-6f && ld > 1e-9f;
-        if (shadow) { st4(&st.neeC[slot], nee.x, nee.y, nee.z, ld); st4(&st.neeD[slot], sdir.x, sdir.y, sdir.z, 0.0f); }
-      }
-      if (bs.event == EV_ABSORB) bitfield |= 0x80000000u; // :483-486
-      const V3 gn = ss.geomNormal * (isTransmission ? -1.0f : 1.0f);
-      const V3 no = gi_offset_ray_origin(ss.position, gn); // :488-489
-      st4(&st.rayO[slot], no.x, no.y, no.z, 0.0f);
-      st4(&st.rayD[slot], bs.k2.x, bs.k2.y, bs.k2.z, GI_FLT_MAX);
     }
+    // BSDF importance sampling (:361-389); xi = next4f, .w is drawn but unused by the closed forms
+    const float x0 = gi_next1f(rng), x1 = gi_next1f(rng), x2 = gi_next1f(rng); (void)gi_next1f(rng);
+    BsdfSample bs; bsdf_sample(mat, ss, -rayDir, x0, x1, x2, bs);
+    throughput = throughput * bs.overPdf;
+    const bool isTransmission = (bs.event & EV_TRANSMISSION) != 0u;
+    // NEE (:394-444)
+    if ((U.flags & FLAG_NEE) && (bs.event & (EV_DIFFUSE | EV_GLOSSY))) {
+      const float k0 = gi_next1f(rng), k1 = gi_next1f(rng), k2 = gi_next1f(rng), k3 = gi_next1f(rng);
+      V3 dirToLight, lightPower; float lightDist, invPdf; uint32_t ds;
+      sample_light(sc, U, k0, k1, k2, k3, ss.position, dirToLight, lightDist, lightPower, invPdf, ds);
+      V3 nee = v3(0.0f, 0.0f, 0.0f);
+      if ((lightDist > 0.0f) && dot(dirToLight, ss.geomNormal) > 0.0f) {
+        BsdfEval ev; bsdf_evaluate(mat, ss, -rayDir, dirToLight, ev);
+        if (ev.pdf > 0.0f) {
+          const float dmul = gi_half_to_float(ds & 0xffffu), smul = gi_half_to_float(ds >> 16);
+          const V3 weight = throughput * (lightPower * invPdf);
+          nee = nee + (weight * ev.diffuse) * dmul;
+          nee = nee + (weight * ev.glossy) * smul;
+        }
+      }
+      // rp_main.rgen:401-408: the shadow ray is traced only if it can contribute
+      const V3 toLight = dirToLight * lightDist;
+      const float ld = length(toLight);
+      const V3 sdir = gi_safe_div(toLight, ld);
+      shadow = gi_luminance(nee) > 1e-6f && ld > 1e-9f;
+      if (shadow) { st4(&S->neeC, nee.x, nee.y, nee.z, ld); st4(&S->neeD, sdir.x, sdir.y, sdir.z, 0.0f); }
+    }
+    if (bs.event == EV_ABSORB) bitfield |= 0x80000000u; // :483-486
+    const V3 gn = ss.geomNormal * (isTransmission ? -1.0f : 1.0f);
+    const V3 no = gi_offset_ray_origin(ss.position, gn); // :488-489
     // rp_main.rgen:441-480
     if (length(throughput) < 1e-9f) bitfield |= 0x80000000u;
     if (bounce > U.rrBounceOffset) {
@@ -657,12 +717,15 @@ __global__ __launch_bounds__(256) void k_shade(FrameUniforms U, SceneView sc, Pa
       if (k > p) bitfield |= 0x80000000u; else throughput = throughput / p;
     }
     bitfield++;
-    const bool cont = ((bitfield & 0x00000fffu) < U.maxBounces) && !(bitfield & 0x80000000u); // loop test :298-304
-    st4(&st.thr[slot], throughput.x, throughput.y, throughput.z, u2f(bitfield));
-    st4(&st.rad[slot], radiance.x, radiance.y, radiance.z, u2f(rng));
-    wave_append(cont, slot, qNext, &cnt->count[nextIdx]);
-    wave_append(!cont, slot, qRegen, &cnt->count[Q_REGEN]);
-    wave_append(shadow, slot, qShadow, &cnt->count[Q_SHADOW]);
+    cont = ((bitfield & 0x00000fffu) < U.maxBounces) && !(bitfield & 0x80000000u); // loop test :298-304
+    ended = !cont;
+    st4(&S->rayO, no.x, no.y, no.z, 0.0f);
+    st4(&S->rayD, bs.k2.x, bs.k2.y, bs.k2.z, GI_FLT_MAX);
+    st4(&S->thr, throughput.x, throughput.y, throughput.z, u2f(bitfield));
+    st4(&S->rad, radiance.x, radiance.y, radiance.z, u2f(rng));
+    }
+    const bool pred[3] = {cont, ended, shadow}; const uint32_t qid[3] = {nextIdx, Q_REGEN, Q_SHADOW};
+    block_append<3>(sh, trip, pred, slot, qs, qid, cnt);
   }
 }
 
@@ -685,35 +748,32 @@ __global__ void k_debug_bsdf(const MaterialRec* mat, uint32_t count, const float
 // ------------------------------------------------------------------------------------------------
 // host-callable launchers
 // ------------------------------------------------------------------------------------------------
-void launchInit(hipStream_t s, const PathState& st, uint32_t* qRegen, Counters* cnt, uint32_t n)
+void launchInit(hipStream_t s, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t n)
 {
   uint32_t blocks = (n + 255u) / 256u; if (blocks > 4096u) blocks = 4096u; if (blocks == 0u) blocks = 1u;
-  hipLaunchKernelGGL(k_init, dim3(blocks), dim3(256), 0, s, st, qRegen, cnt, n);
+  hipLaunchKernelGGL(k_init, dim3(blocks), dim3(256), 0, s, st, qs, cnt, n);
 }
-void launchReset(hipStream_t s, Counters* cnt, uint32_t a, uint32_t b, uint32_t c)
+void launchReset(hipStream_t s, Counters* cnt, uint32_t traceCur, uint32_t traceNext)
 {
-  hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, s, cnt, a, b, c);
+  hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, s, cnt, traceCur, traceNext);
 }
-void launchRaygen(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const PathState& st, const uint32_t* qRegen, uint32_t* qTrace,
-                  Counters* cnt, uint32_t traceIdx, F4* colorOut)
+void launchRaygen(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t traceIdx, F4* colorOut)
 {
-  hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(256), 0, s, U, st, qRegen, qTrace, cnt, traceIdx, colorOut);
+  hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(BLOCK), 0, s, U, st, qs, cnt, traceIdx, colorOut);
 }
-void launchTrace(hipStream_t s, uint32_t blocks, bool anyHit, bool count, const SceneView& sc, const PathState& st, const uint32_t* queue,
-                 Counters* cnt, uint32_t queueIdx)
+void launchTrace(hipStream_t s, uint32_t blocks, bool anyHit, bool count, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t queueIdx)
 {
   if (!anyHit) {
-    if (count) hipLaunchKernelGGL((k_trace<false, true>), dim3(blocks), dim3(TRACE_BLOCK), 0, s, sc, st, queue, cnt, queueIdx);
-    else hipLaunchKernelGGL((k_trace<false, false>), dim3(blocks), dim3(TRACE_BLOCK), 0, s, sc, st, queue, cnt, queueIdx);
+    if (count) hipLaunchKernelGGL((k_trace<false, true>), dim3(blocks), dim3(TRACE_BLOCK), 0, s, sc, st, qs, cnt, queueIdx);
+    else hipLaunchKernelGGL((k_trace<false, false>), dim3(blocks), dim3(TRACE_BLOCK), 0, s, sc, st, qs, cnt, queueIdx);
   } else {
-    if (count) hipLaunchKernelGGL((k_trace<true, true>), dim3(blocks), dim3(TRACE_BLOCK), 0, s, sc, st, queue, cnt, queueIdx);
-    else hipLaunchKernelGGL((k_trace<true, false>), dim3(blocks), dim3(TRACE_BLOCK), 0, s, sc, st, queue, cnt, queueIdx);
+    if (count) hipLaunchKernelGGL((k_trace<true, true>), dim3(blocks), dim3(TRACE_BLOCK), 0, s, sc, st, qs, cnt, queueIdx);
+    else hipLaunchKernelGGL((k_trace<true, false>), dim3(blocks), dim3(TRACE_BLOCK), 0, s, sc, st, qs, cnt, queueIdx);
   }
 }
-void launchShade(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const SceneView& sc, const PathState& st, const uint32_t* qCur,
-                 uint32_t* qNext, uint32_t* qRegen, uint32_t* qShadow, Counters* cnt, uint32_t curIdx, uint32_t nextIdx)
+void launchShade(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t nextIdx)
 {
-  hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(256), 0, s, U, sc, st, qCur, qNext, qRegen, qShadow, cnt, curIdx, nextIdx);
+  hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, nextIdx);
 }
 
 void launchDebugBsdf(hipStream_t s, const MaterialRec* mat, uint32_t count, const float* in, float* out)

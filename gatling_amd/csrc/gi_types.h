@@ -20,26 +20,34 @@ struct Node8 {
 };
 static_assert(sizeof(Node8) == 80, "Node8 must be 80 bytes");
 
-// Triangle record, 48 bytes (3 x 16 B loads): world-space vertex + edges, plus ids.
+// Triangle record, 64 bytes.  Traversal reads the first 48 (3 x 16 B): world-space vertex + edges + tie-break id;
+// the shade stage reads the last 32: everything needed to fetch the hit's geometry in ONE dependent step
+// (instance, material, absolute vertex indices) instead of chasing instance -> mesh -> face -> vertices.
 struct TriRec {
   float v0[3];
   float e1[3];
   float e2[3];
-  uint32_t instance; // index into InstanceRec[]
-  uint32_t prim;     // gl_PrimitiveID within the mesh
-  uint32_t origId;   // global triangle id in scene order (tie-break key, DESIGN.md "Traversal contract")
+  uint32_t origId;    // global triangle id in scene order (tie-break key, DESIGN.md "Traversal contract")
+  uint32_t instance;  // index into InstanceRec[]
+  uint32_t matFlags;  // material index (low 24 bits) | mesh flags << 30 (bit0 flipFacing, bit1 doubleSided; rp_main.h:115-116)
+  uint32_t vi[3];     // absolute indices into the scene vertex array
+  uint32_t prim;      // gl_PrimitiveID within the mesh
 };
-static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
+static_assert(sizeof(TriRec) == 64, "TriRec must be 64 bytes");
 
-// == rp::FVertex (rp_main.h:58-64), 32 bytes
+// Vertex record, 48 bytes (3 x 16 B).  Same content as rp::FVertex (rp_main.h:58-64) but with the octahedral
+// unorm2x16 normal / tangent already DECODED (decode_direction, common.glsl:198-207, evaluated once on the host with
+// the same fp32 operations the shader would execute per hit): the quantisation the reference applies is preserved
+// bit-for-bit, the 6 decodes per hit are not repeated.
 struct FVertex {
   float pos[3];
   float bsign;
-  uint32_t normal;  // octahedral unorm2x16
-  uint32_t tangent; // octahedral unorm2x16
-  float u, v;
+  float normal[3];
+  float u;
+  float tangent[3];
+  float v;
 };
-static_assert(sizeof(FVertex) == 32, "FVertex must be 32 bytes");
+static_assert(sizeof(FVertex) == 48, "FVertex must be 48 bytes");
 
 // Replaces gl_ObjectToWorldEXT / gl_WorldToObjectEXT + BlasPayload (rp_main.h:118-123), 96 bytes
 struct InstanceRec {
@@ -51,15 +59,10 @@ struct InstanceRec {
 };
 static_assert(sizeof(InstanceRec) == 96, "InstanceRec must be 96 bytes");
 
-struct MeshRec {
-  uint32_t faceOffset;   // into faces[] (in uint32 triples)
-  uint32_t vertexOffset; // into verts[]
-  uint32_t material;     // index into MaterialRec[]
-  uint32_t flags;        // bit0 flipFacing, bit1 doubleSided (rp_main.h:115-116)
-};
-static_assert(sizeof(MeshRec) == 16, "MeshRec must be 16 bytes");
-
 constexpr uint32_t MAT_PARAM_COUNT = 48;
+// derived per-material constants, filled by the host into the spare tail of MaterialRec::p (same fp32 formulas the
+// oracle evaluates per hit)
+enum : uint32_t { MP_ALBEDO = 32, MP_F0 = 35, MP_ALPHA = 38, MP_COAT = 39, MP_COAT_ALPHA = 40 };
 struct MaterialRec {
   uint32_t klass;
   uint32_t flags;
@@ -100,8 +103,6 @@ struct SceneView {
   const Node8* nodes;
   const TriRec* tris;
   const InstanceRec* instances;
-  const MeshRec* meshes;
-  const uint32_t* faces;
   const FVertex* verts;
   const MaterialRec* materials;
   const SphereLightRec* sphereLights;
@@ -112,25 +113,39 @@ struct SceneView {
   uint32_t triCount;
 };
 
-// Wavefront path state, SoA over slots (one slot per pixel of the tile; DESIGN.md "Path state").
+// Wavefront path state: one 128-byte record per slot (one slot per pixel of the tile; DESIGN.md "Path state").
+// Array-of-structures ON PURPOSE: queues hold slots in arbitrary order, so every stage touches slots scattered over
+// the array; with one L2 line (128 B) per slot each stage moves exactly the lines it needs, while a SoA layout costs a
+// separate partially-used line per field.
 struct alignas(16) F4 { float x, y, z, w; };
 
-struct PathState {
-  F4* rayO;  // origin.xyz, tMin
-  F4* rayD;  // dir.xyz, tMax
-  F4* hit;   // t, u, v, asfloat(triangle index in BVH order | 0xffffffff = miss)
-  F4* thr;   // throughput.xyz, asfloat(bitfield)   (rp_main_payload.glsl:24-33)
-  F4* rad;   // radiance.xyz, asfloat(rng state)
-  F4* acc;   // pixel_color accumulator.xyz, asfloat(sample index in flight | 0xffffffff = none yet)
-  F4* neeC;  // neeContrib.xyz, lightDist
-  F4* neeD;  // shadow ray dir.xyz, unused
+struct alignas(128) Slot {
+  F4 rayO;  // origin.xyz, tMin
+  F4 rayD;  // dir.xyz, tMax
+  F4 hit;   // t, u, v, asfloat(triangle index in BVH order | 0xffffffff = miss)
+  F4 thr;   // throughput.xyz, asfloat(bitfield)   (rp_main_payload.glsl:24-33)
+  F4 rad;   // radiance.xyz, asfloat(rng state)
+  F4 acc;   // pixel_color accumulator.xyz, asfloat(sample index in flight | 0xffffffff = none yet)
+  F4 neeC;  // neeContrib.xyz, lightDist
+  F4 neeD;  // shadow ray dir.xyz, unused
 };
+static_assert(sizeof(Slot) == 128, "Slot must be one 128-byte line");
+
+struct PathState { Slot* slots; };
 
 // Work queues (slot indices) and their device-side counters.
-enum : uint32_t { Q_TRACE_A = 0, Q_TRACE_B = 1, Q_REGEN = 2, Q_SHADOW = 3, Q_COUNT = 4 };
+// Every queue is split into NSHARD segments (segment s holds items [s*cap, s*cap + count[q][s])): producers append to
+// the segment of their block (blockIdx % NSHARD, i.e. one per XCD in dispatch order), so the append counters are
+// NSHARD different words.  One device-scope atomic word sustains only ~88 updates/us on MI355X
+// (MI355X_MICROARCH.md "dequeue"); an unsharded per-wave append made every stage atomic-bound.
+enum : uint32_t { Q_TRACE_A = 0, Q_TRACE_B = 1, Q_REGEN = 2, Q_SHADOW = 3, Q_HIT = 4, Q_COUNT = 5 };
+constexpr uint32_t NSHARD = 8;
+struct QueueSet {
+  uint32_t* items[Q_COUNT]; // each NSHARD * cap entries
+  uint32_t cap;             // per-shard capacity
+};
 struct Counters {
-  uint32_t count[Q_COUNT];
-  uint32_t pad[4];
+  uint32_t count[Q_COUNT][NSHARD];
   unsigned long long segments, shadowRays, nodesVisited, trisTested, shadowNodesVisited, shadowTrisTested;
 };
 
