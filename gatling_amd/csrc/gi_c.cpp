@@ -17,6 +17,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -830,8 +831,19 @@ extern "C" int giCRender(const GiCRenderParams* params)
     U.totalLightCount = U.sphereCount + U.distantCount + U.rectCount + U.diskCount;
   }
 
-  const uint32_t wideBlocks = (uint32_t)std::min<size_t>((slots + 255) / 256, (size_t)g_ctx.cuCount * 8);
-  const uint32_t traceBlocks = (uint32_t)std::min<size_t>((slots + 255) / 256, (size_t)g_ctx.cuCount * 3);
+  // persistent grids: blocks per CU limited by registers (<= 7 waves/SIMD for k_trace) and, for k_trace, by the LDS it stages
+  uint32_t wideBlocks, traceBlocks;
+  {
+    SceneView v0 = makeView(s);
+    uint32_t ln, lt, ldsBytes; traceLdsLayout(v0, ln, lt, ldsBytes);
+    uint32_t perCu = std::min<uint32_t>(7u, (160u * 1024u) / (ldsBytes + 256u));
+    if (const char* e = getenv("GATLING_TRACE_BLOCKS_PER_CU")) perCu = (uint32_t)atoi(e);
+    uint32_t widePerCu = 8u;
+    if (const char* e = getenv("GATLING_WIDE_BLOCKS_PER_CU")) widePerCu = (uint32_t)atoi(e);
+    perCu = std::max(perCu, 1u); widePerCu = std::max(widePerCu, 1u);
+    wideBlocks = (uint32_t)std::min<size_t>((slots + 255) / 256, (size_t)g_ctx.cuCount * widePerCu);
+    traceBlocks = (uint32_t)std::min<size_t>((slots + 255) / 256, (size_t)g_ctx.cuCount * perCu);
+  }
   if (ensurePathState(s, slots, wideBlocks, traceBlocks) != GI_C_OK) return GI_C_ERROR;
   PathState ps{s->slots.ptr};
   SceneView view = makeView(s);
@@ -856,9 +868,9 @@ extern "C" int giCRender(const GiCRenderParams* params)
   for (uint64_t it = 0; it < maxIters; it++) {
     timed(0, [&] { launchRaygen(st, wideBlocks, U, ps, qs, s->dCounters.ptr, cur, colorOut); });
     if (it >= rs.spp && (it % 8u) == 0u) { // a slot needs >= spp iterations; afterwards poll the queue sizes
-      HIP_TRY(hipMemcpyAsync(s->hCounters, s->dCounters.ptr, sizeof(uint32_t) * Q_COUNT * NSHARD, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(s->hCounters, s->dCounters.ptr, sizeof(PaddedCounter) * Q_COUNT * NSHARD, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
-      uint32_t pending = 0; for (uint32_t k = 0; k < NSHARD; k++) pending += s->hCounters->count[cur][k];
+      uint32_t pending = 0; for (uint32_t k = 0; k < NSHARD; k++) pending += s->hCounters->count[cur][k].v;
       if (pending == 0) break; // raygen consumed the regen queue and produced no rays: done
     }
     launchReset(st, s->dCounters.ptr, cur, next); // raygen consumed REGEN; trace/shade append to REGEN, HIT, SHADOW, TRACE[next]
@@ -913,10 +925,10 @@ extern "C" int giCTraceRays(GiCScene* s, uint32_t count, const float* origins, c
     host[i].rayD = F4{dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], tMax};
     q[i] = i;
   }
-  Counters c{}; c.count[Q_TRACE_A][0] = count; // everything in shard 0 (capacity >= count/NSHARD + ... is not enough: use all shards)
+  Counters c{}; c.count[Q_TRACE_A][0].v = count; // everything in shard 0 (capacity >= count/NSHARD + ... is not enough: use all shards)
   {
     const uint32_t per = (count + NSHARD - 1u) / NSHARD;
-    for (uint32_t k = 0; k < NSHARD; k++) { uint32_t lo = k * per; c.count[Q_TRACE_A][k] = lo < count ? std::min(per, count - lo) : 0u; }
+    for (uint32_t k = 0; k < NSHARD; k++) { uint32_t lo = k * per; c.count[Q_TRACE_A][k].v = lo < count ? std::min(per, count - lo) : 0u; }
   }
   std::vector<uint32_t> qhost((size_t)s->queueCap * NSHARD, 0u);
   {

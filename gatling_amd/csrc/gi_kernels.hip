@@ -47,7 +47,7 @@ __device__ __forceinline__ void block_append(AppendScratch<NQ>& sh, uint32_t tri
     uint32_t total = 0;
 #pragma unroll
     for (uint32_t w = 0; w < WAVES; w++) total += sh.wcount[par][q][w];
-    sh.base[par][q] = total ? atomicAdd(&cnt->count[qid[q]][shard], total) : 0u;
+    sh.base[par][q] = total ? atomicAdd(&cnt->count[qid[q]][shard].v, total) : 0u;
   }
   __syncthreads();
 #pragma unroll
@@ -66,7 +66,7 @@ __device__ __forceinline__ void reader_init(QueueReader& r, const Counters* cnt,
 {
   r.pre[0] = 0;
 #pragma unroll
-  for (uint32_t s = 0; s < NSHARD; s++) r.pre[s + 1] = r.pre[s] + cnt->count[q][s];
+  for (uint32_t s = 0; s < NSHARD; s++) r.pre[s + 1] = r.pre[s] + cnt->count[q][s].v;
   r.items = qs.items[q]; r.cap = qs.cap;
 }
 __device__ __forceinline__ uint32_t reader_get(const QueueReader& r, uint32_t i)
@@ -92,7 +92,7 @@ __global__ void k_init(PathState st, QueueSet qs, Counters* cnt, uint32_t n)
     const uint32_t q = i / NSHARD, sdx = i % NSHARD;
     uint32_t c = 0;
     if (q == Q_REGEN) { const uint32_t lo = sdx * per; c = lo < n ? ((n - lo) < per ? (n - lo) : per) : 0u; }
-    cnt->count[q][sdx] = c;
+    cnt->count[q][sdx].v = c;
   }
   if (i == 0) { cnt->segments = 0; cnt->shadowRays = 0; cnt->nodesVisited = 0; cnt->trisTested = 0; cnt->shadowNodesVisited = 0; cnt->shadowTrisTested = 0; }
   for (; i < n; i += gridDim.x * blockDim.x) {
@@ -108,11 +108,11 @@ __global__ void k_reset(Counters* cnt, uint32_t traceCur, uint32_t traceNext)
   const uint32_t t = threadIdx.x;
   if (t == 0) {
     uint32_t rays = 0, shadow = 0;
-    for (uint32_t s = 0; s < NSHARD; s++) { rays += cnt->count[traceCur][s]; shadow += cnt->count[Q_SHADOW][s]; }
+    for (uint32_t s = 0; s < NSHARD; s++) { rays += cnt->count[traceCur][s].v; shadow += cnt->count[Q_SHADOW][s].v; }
     cnt->segments += rays; cnt->shadowRays += shadow;
   }
   __syncthreads();
-  if (t < NSHARD) { cnt->count[traceNext][t] = 0; cnt->count[Q_REGEN][t] = 0; cnt->count[Q_SHADOW][t] = 0; cnt->count[Q_HIT][t] = 0; }
+  if (t < NSHARD) { cnt->count[traceNext][t].v = 0; cnt->count[Q_REGEN][t].v = 0; cnt->count[Q_SHADOW][t].v = 0; cnt->count[Q_HIT][t].v = 0; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -204,8 +204,8 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st,
 //   * octant-ordered child visits (Ylitie et al. 2017), two-sided Moeller-Trumbore on 48-byte records
 // Traversal contract: accept tMin < t < tBest; ties go to the lower scene-order triangle id.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t LDS_NODES = 384;  // 30 KiB
-constexpr uint32_t LDS_TRIS = 128;   // 6 KiB
+constexpr uint32_t LDS_NODES = 384;  // upper bound: 30 KiB   (the launch stages min(nodeCount, LDS_NODES) nodes)
+constexpr uint32_t LDS_TRIS = 128;   // upper bound: 6 KiB    (all triangles when the scene has <= LDS_TRIS, else none)
 constexpr uint32_t LDS_STACK = 8;    // x 8 B x 256 lanes = 16 KiB
 constexpr uint32_t OVF_STACK = 40;
 constexpr uint32_t TRACE_BLOCK = 256;
@@ -319,17 +319,17 @@ __device__ __forceinline__ bool traverse(const SceneView& sc, const uint4* s_nod
 }
 
 template <bool ANYHIT, bool COUNT>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t queueIdx)
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t queueIdx, uint32_t ldsNodes, uint32_t ldsTris)
 {
-  __shared__ uint4 s_nodes[LDS_NODES * 5];
-  __shared__ uint4 s_tris[LDS_TRIS * 3];
-  __shared__ uint2 s_stack[LDS_STACK][TRACE_BLOCK];
+  // dynamic LDS, sized by the launch to what this scene actually stages: [stack | nodes | triangles]
+  extern __shared__ uint4 s_dyn[];
+  uint2 (*s_stack)[TRACE_BLOCK] = reinterpret_cast<uint2 (*)[TRACE_BLOCK]>(s_dyn);
+  uint4* s_nodes = s_dyn + (LDS_STACK * TRACE_BLOCK * sizeof(uint2)) / sizeof(uint4);
+  uint4* s_tris = s_nodes + ldsNodes * 5u;
   __shared__ AppendScratch<2> sh;
   QueueReader rd; reader_init(rd, cnt, queueIdx, qs);
   const uint32_t n = rd.pre[NSHARD];
   if (blockIdx.x * TRACE_BLOCK >= n) return; // whole block idle (uniform)
-  const uint32_t ldsNodes = sc.nodeCount < LDS_NODES ? sc.nodeCount : LDS_NODES;
-  const uint32_t ldsTris = sc.triCount <= LDS_TRIS ? sc.triCount : 0u;
   for (uint32_t i = threadIdx.x; i < ldsNodes * 5u; i += TRACE_BLOCK) s_nodes[i] = reinterpret_cast<const uint4*>(sc.nodes)[i];
   for (uint32_t i = threadIdx.x; i < ldsTris * 3u; i += TRACE_BLOCK) s_tris[i] = reinterpret_cast<const uint4*>(sc.tris)[(i / 3u) * 4u + (i % 3u)];
   __syncthreads();
@@ -761,14 +761,21 @@ void launchRaygen(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const 
 {
   hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(BLOCK), 0, s, U, st, qs, cnt, traceIdx, colorOut);
 }
+void traceLdsLayout(const SceneView& sc, uint32_t& ldsNodes, uint32_t& ldsTris, uint32_t& bytes)
+{
+  ldsNodes = sc.nodeCount < LDS_NODES ? sc.nodeCount : LDS_NODES;
+  ldsTris = sc.triCount <= LDS_TRIS ? sc.triCount : 0u;
+  bytes = LDS_STACK * TRACE_BLOCK * (uint32_t)sizeof(uint2) + ldsNodes * 80u + ldsTris * 48u;
+}
 void launchTrace(hipStream_t s, uint32_t blocks, bool anyHit, bool count, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t queueIdx)
 {
+  uint32_t ln, lt, bytes; traceLdsLayout(sc, ln, lt, bytes);
   if (!anyHit) {
-    if (count) hipLaunchKernelGGL((k_trace<false, true>), dim3(blocks), dim3(TRACE_BLOCK), 0, s, sc, st, qs, cnt, queueIdx);
-    else hipLaunchKernelGGL((k_trace<false, false>), dim3(blocks), dim3(TRACE_BLOCK), 0, s, sc, st, qs, cnt, queueIdx);
+    if (count) hipLaunchKernelGGL((k_trace<false, true>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, queueIdx, ln, lt);
+    else hipLaunchKernelGGL((k_trace<false, false>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, queueIdx, ln, lt);
   } else {
-    if (count) hipLaunchKernelGGL((k_trace<true, true>), dim3(blocks), dim3(TRACE_BLOCK), 0, s, sc, st, qs, cnt, queueIdx);
-    else hipLaunchKernelGGL((k_trace<true, false>), dim3(blocks), dim3(TRACE_BLOCK), 0, s, sc, st, qs, cnt, queueIdx);
+    if (count) hipLaunchKernelGGL((k_trace<true, true>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, queueIdx, ln, lt);
+    else hipLaunchKernelGGL((k_trace<true, false>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, queueIdx, ln, lt);
   }
 }
 void launchShade(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t nextIdx)

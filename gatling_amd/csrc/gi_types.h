@@ -144,8 +144,11 @@ struct QueueSet {
   uint32_t* items[Q_COUNT]; // each NSHARD * cap entries
   uint32_t cap;             // per-shard capacity
 };
+// Each append counter sits alone in its own 128-byte line: device-scope atomics are serialised per LINE at the memory
+// side, so counters sharing a line would share the ~88 updates/us budget.
+struct alignas(128) PaddedCounter { uint32_t v; uint32_t pad[31]; };
 struct Counters {
-  uint32_t count[Q_COUNT][NSHARD];
+  PaddedCounter count[Q_COUNT][NSHARD];
   unsigned long long segments, shadowRays, nodesVisited, trisTested, shadowNodesVisited, shadowTrisTested;
 };
 
