@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--workload", default="c2")
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-timers", action="store_true", help="do not record per-stage HIP events (roofline fields become 0)")
     args = ap.parse_args()
 
     import torch  # plumbing: device sync, torch.distributed (RCCL).  Imported first so one HIP runtime is shared.
@@ -133,7 +134,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    scene.set_option(capi.OPTION_KERNEL_TIMERS, 1)  # HIP events around every stage launch, on the library's own stream
+    scene.set_option(capi.OPTION_KERNEL_TIMERS, 0 if args.no_timers else 8)  # HIP events around the stage launches of every 8th iteration, on the library's own stream
     for _ in range(args.warmup):
         step()
     sync()
@@ -161,7 +162,7 @@ def main():
         value = samples_per_step * args.steps / dt / 1e6
         # dominant traversal kernel k_trace<closest>: algorithmic bytes per launch: ray 32 + hit 20 per ray,
         # 80 B per BVH8 node visited, 48 B per triangle tested; divided by its mean launch time (HIP events).
-        launches = sum(s["traceLaunches"] for s in stats)
+        launches = sum(s["traceLaunches"] for s in stats)  # traceMs is the sampled total scaled to all launches
         trace_ms = sum(s["traceMs"] for s in stats)
         rays = sum(s["segments"] for s in stats)
         nodes_per_ray = cst["nodesVisited"] / max(1, cst["segments"])

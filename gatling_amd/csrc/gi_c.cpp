@@ -231,12 +231,14 @@ struct GiCScene {
   uint32_t nodeCount = 0, triCount = 0, bvhDepth = 0;
   // path state
   DeviceBuffer<Slot> slots;
-  DeviceBuffer<uint32_t> queues[Q_COUNT]; // NSHARD segments of queueCap entries each
+  DeviceBuffer<uint32_t> qSlot[Q_COUNT]; // NSHARD segments of queueCap records each
+  DeviceBuffer<F4> qA[Q_COUNT], qB[Q_COUNT], qC[Q_COUNT];
   uint32_t queueCap = 0;
   DeviceBuffer<Counters> dCounters;
   Counters* hCounters = nullptr; // pinned
   // options + stats
   bool countTraversal = false, kernelTimers = false;
+  uint32_t kernelTimerStride = 1;
   GiCRenderStats stats{};
   std::vector<hipEvent_t> eventPool;
 };
@@ -291,7 +293,7 @@ void giCDestroyScene(GiCScene* s)
   s->dNodes.release(); s->dTris.release(); s->dInstances.release(); s->dVerts.release();
   s->dMaterials.release(); s->dSphere.release(); s->dDistant.release(); s->dRect.release(); s->dDisk.release();
   s->slots.release();
-  for (auto& q : s->queues) q.release();
+  for (uint32_t q = 0; q < Q_COUNT; q++) { s->qSlot[q].release(); s->qA[q].release(); s->qB[q].release(); s->qC[q].release(); }
   s->dCounters.release();
   if (s->hCounters) (void)hipHostFree(s->hCounters);
   for (hipEvent_t e : s->eventPool) (void)hipEventDestroy(e);
@@ -558,7 +560,7 @@ int giCSetSceneOption(GiCScene* scene, int32_t option, int32_t value)
 {
   if (!scene) return GI_C_ERROR;
   if (option == GI_C_SCENE_OPTION_COUNT_TRAVERSAL) { scene->countTraversal = value != 0; return GI_C_OK; }
-  if (option == GI_C_SCENE_OPTION_KERNEL_TIMERS) { scene->kernelTimers = value != 0; return GI_C_OK; }
+  if (option == GI_C_SCENE_OPTION_KERNEL_TIMERS) { scene->kernelTimers = value != 0; scene->kernelTimerStride = value > 0 ? (uint32_t)value : 1u; return GI_C_OK; }
   setError("unknown scene option"); return GI_C_ERROR;
 }
 
@@ -694,7 +696,7 @@ SceneView makeView(GiCScene* s)
   SceneView v{};
   v.nodes = s->dNodes.ptr; v.tris = s->dTris.ptr; v.instances = s->dInstances.ptr;
   v.verts = s->dVerts.ptr; v.materials = s->dMaterials.ptr; v.sphereLights = s->dSphere.ptr; v.distantLights = s->dDistant.ptr;
-  v.rectLights = s->dRect.ptr; v.diskLights = s->dDisk.ptr; v.nodeCount = s->nodeCount; v.triCount = s->triCount;
+  v.rectLights = s->dRect.ptr; v.diskLights = s->dDisk.ptr; v.nodeCount = s->nodeCount; v.triCount = s->triCount; v.bvhDepth = s->bvhDepth;
   return v;
 }
 
@@ -714,11 +716,25 @@ int ensurePathState(GiCScene* s, size_t slots, uint32_t gridA, uint32_t gridB)
   const uint32_t cap = shardCapacity(slots, gridA, gridB);
   if (s->slots.alloc(slots) || s->dCounters.alloc(1)) return GI_C_ERROR;
   if (cap > s->queueCap) {
-    for (auto& q : s->queues) if (q.alloc((size_t)cap * NSHARD)) return GI_C_ERROR;
+    const size_t n = (size_t)cap * NSHARD;
+    for (uint32_t q = 0; q < Q_COUNT; q++) {
+      const bool hasRecord = (q == Q_TRACE_A || q == Q_TRACE_B || q == Q_HIT || q == Q_SHADOW);
+      if (s->qSlot[q].alloc(n)) return GI_C_ERROR;
+      if (hasRecord && (s->qA[q].alloc(n) || s->qB[q].alloc(n))) return GI_C_ERROR;
+      if (q == Q_SHADOW && s->qC[q].alloc(n)) return GI_C_ERROR;
+    }
     s->queueCap = cap;
   }
   if (!s->hCounters) HIP_TRY(hipHostMalloc((void**)&s->hCounters, sizeof(Counters), hipHostMallocDefault));
   return GI_C_OK;
+}
+
+QueueSet makeQueueSet(GiCScene* s)
+{
+  QueueSet qs{};
+  for (uint32_t q = 0; q < Q_COUNT; q++) { qs.slot[q] = s->qSlot[q].ptr; qs.a[q] = s->qA[q].ptr; qs.b[q] = s->qB[q].ptr; qs.c[q] = s->qC[q].ptr; }
+  qs.cap = s->queueCap;
+  return qs;
 }
 
 hipEvent_t poolEvent(GiCScene* s, size_t idx)
@@ -847,7 +863,7 @@ extern "C" int giCRender(const GiCRenderParams* params)
   if (ensurePathState(s, slots, wideBlocks, traceBlocks) != GI_C_OK) return GI_C_ERROR;
   PathState ps{s->slots.ptr};
   SceneView view = makeView(s);
-  QueueSet qs{}; for (uint32_t q = 0; q < Q_COUNT; q++) qs.items[q] = s->queues[q].ptr; qs.cap = s->queueCap;
+  QueueSet qs = makeQueueSet(s);
   F4* colorOut = reinterpret_cast<F4*>(colorRb->deviceMem);
   const bool nee = rs.nextEventEstimation != 0;
 
@@ -856,32 +872,35 @@ extern "C" int giCRender(const GiCRenderParams* params)
   double tStart = nowMs();
   launchInit(st, ps, qs, s->dCounters.ptr, (uint32_t)slots);
   const uint64_t maxIters = (uint64_t)rs.spp * std::max(1u, U.maxBounces) + 2u;
-  uint32_t cur = Q_TRACE_A, next = Q_TRACE_B;
   uint32_t iters = 0, traceLaunches = 0;
   size_t ev = 0;
   std::vector<int> evKind; // 0 raygen, 1 trace, 2 shade, 3 shadow
   const bool timers = s->kernelTimers;
+  // HIP events around the stage launches of every `timerStride`-th iteration (events on every launch cost ~16 % of the
+  // frame); per-stage totals are scaled back up by the sampling factor.
+  const uint32_t timerStride = std::max(1u, s->kernelTimerStride);
+  uint64_t curIter = 0, sampledIters = 0;
   auto timed = [&](int kind, auto&& fn) {
-    if (timers) { (void)hipEventRecord(poolEvent(s, ev), st); fn(); (void)hipEventRecord(poolEvent(s, ev + 1), st); ev += 2; evKind.push_back(kind); }
+    if (timers && (curIter % timerStride) == 0u) { (void)hipEventRecord(poolEvent(s, ev), st); fn(); (void)hipEventRecord(poolEvent(s, ev + 1), st); ev += 2; evKind.push_back(kind); }
     else fn();
   };
+  const uint32_t pollEvery = 16;
   for (uint64_t it = 0; it < maxIters; it++) {
-    timed(0, [&] { launchRaygen(st, wideBlocks, U, ps, qs, s->dCounters.ptr, cur, colorOut); });
-    if (it >= rs.spp && (it % 8u) == 0u) { // a slot needs >= spp iterations; afterwards poll the queue sizes
+    const uint32_t par = (uint32_t)(it & 1u);
+    curIter = it; if (timers && (it % timerStride) == 0u) sampledIters++;
+    timed(0, [&] { launchRaygen(st, wideBlocks, U, ps, qs, s->dCounters.ptr, par, colorOut); });
+    if (it >= rs.spp && (it % pollEvery) == 0u) { // a slot needs >= spp iterations; afterwards poll the queue sizes
       HIP_TRY(hipMemcpyAsync(s->hCounters, s->dCounters.ptr, sizeof(PaddedCounter) * Q_COUNT * NSHARD, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
-      uint32_t pending = 0; for (uint32_t k = 0; k < NSHARD; k++) pending += s->hCounters->count[cur][k].v;
+      uint32_t pending = 0; for (uint32_t k = 0; k < NSHARD; k++) pending += s->hCounters->count[Q_TRACE_A + par][k].v;
       if (pending == 0) break; // raygen consumed the regen queue and produced no rays: done
     }
-    launchReset(st, s->dCounters.ptr, cur, next); // raygen consumed REGEN; trace/shade append to REGEN, HIT, SHADOW, TRACE[next]
-    timed(1, [&] { launchTrace(st, traceBlocks, false, s->countTraversal, view, ps, qs, s->dCounters.ptr, cur); });
+    timed(1, [&] { launchTrace(st, traceBlocks, false, s->countTraversal, view, ps, qs, s->dCounters.ptr, Q_TRACE_A + par, Q_REGEN_A + (par ^ 1u)); });
     traceLaunches++;
-    timed(2, [&] { launchShade(st, wideBlocks, U, view, ps, qs, s->dCounters.ptr, next); });
-    if (nee) timed(3, [&] { launchTrace(st, traceBlocks, true, s->countTraversal, view, ps, qs, s->dCounters.ptr, Q_SHADOW); });
-    std::swap(cur, next);
+    timed(2, [&] { launchShade(st, wideBlocks, U, view, ps, qs, s->dCounters.ptr, par); });
+    if (nee) timed(3, [&] { launchTrace(st, traceBlocks, true, s->countTraversal, view, ps, qs, s->dCounters.ptr, Q_SHADOW, Q_SHADOW); });
     iters++;
   }
-  launchReset(st, s->dCounters.ptr, cur, next); // account the last iteration's shadow rays (its trace queue is empty)
   HIP_TRY(hipMemcpyAsync(s->hCounters, s->dCounters.ptr, sizeof(Counters), hipMemcpyDeviceToHost, st));
   if (!colorRb->deviceOnly) {
     size_t off = (size_t)rowBegin * width * 16, bytes = slots * 16;
@@ -901,6 +920,9 @@ extern "C" int giCRender(const GiCRenderParams* params)
       float ms = 0.0f; (void)hipEventElapsedTime(&ms, s->eventPool[2 * k], s->eventPool[2 * k + 1]);
       if (evKind[k] == 0) S.raygenMs += ms; else if (evKind[k] == 1) S.traceMs += ms; else if (evKind[k] == 2) S.shadeMs += ms; else S.shadowMs += ms;
     }
+    // scale the sampled totals to the whole frame (the early-exit poll can leave one raygen-only iteration unsampled)
+    const double scale = sampledIters ? (double)(iters + 1) / (double)sampledIters : 1.0;
+    S.raygenMs *= scale; S.traceMs *= scale; S.shadeMs *= scale; S.shadowMs *= scale;
   }
   s->sampleOffset += rs.spp; // Gi.cpp:2515
   return GI_C_OK;
@@ -918,35 +940,34 @@ extern "C" int giCTraceRays(GiCScene* s, uint32_t count, const float* origins, c
   if (s->dirty & (DIRTY_BVH | DIRTY_MATERIALS)) { if (buildScene(s) != GI_C_OK) return -1; s->dirty &= ~(DIRTY_BVH | DIRTY_MATERIALS); s->dirty |= DIRTY_FRAMEBUFFER; }
   const uint32_t blocks = std::min<uint32_t>((count + 255u) / 256u, (uint32_t)g_ctx.cuCount * 3u);
   if (ensurePathState(s, count, blocks, blocks) != GI_C_OK) return -1;
-  std::vector<Slot> host(count); std::vector<uint32_t> q(count);
+  // ray records go straight into the TRACE_A queue (segment k holds rays [k*per, (k+1)*per))
+  const size_t qn = (size_t)s->queueCap * NSHARD;
+  std::vector<uint32_t> qslot(qn, 0u); std::vector<F4> qa(qn), qb(qn);
+  Counters c{};
+  const uint32_t per = (count + NSHARD - 1u) / NSHARD;
+  for (uint32_t k = 0; k < NSHARD; k++) { uint32_t lo = k * per; c.count[Q_TRACE_A][k].v = lo < count ? std::min(per, count - lo) : 0u; }
   for (uint32_t i = 0; i < count; i++) {
-    memset(&host[i], 0, sizeof(Slot));
-    host[i].rayO = F4{origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], tMin};
-    host[i].rayD = F4{dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], tMax};
-    q[i] = i;
+    size_t r = (size_t)(i / per) * s->queueCap + (i % per);
+    qslot[r] = i;
+    qa[r] = F4{origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], tMin};
+    qb[r] = F4{dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], tMax};
   }
-  Counters c{}; c.count[Q_TRACE_A][0].v = count; // everything in shard 0 (capacity >= count/NSHARD + ... is not enough: use all shards)
-  {
-    const uint32_t per = (count + NSHARD - 1u) / NSHARD;
-    for (uint32_t k = 0; k < NSHARD; k++) { uint32_t lo = k * per; c.count[Q_TRACE_A][k].v = lo < count ? std::min(per, count - lo) : 0u; }
-  }
-  std::vector<uint32_t> qhost((size_t)s->queueCap * NSHARD, 0u);
-  {
-    const uint32_t per = (count + NSHARD - 1u) / NSHARD;
-    for (uint32_t i = 0; i < count; i++) qhost[(size_t)(i / per) * s->queueCap + (i % per)] = q[i];
-  }
-  if (hipMemcpyAsync(s->slots.ptr, host.data(), count * sizeof(Slot), hipMemcpyHostToDevice, st) != hipSuccess ||
-      hipMemcpyAsync(s->queues[Q_TRACE_A].ptr, qhost.data(), qhost.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st) != hipSuccess ||
+  if (hipMemcpyAsync(s->qSlot[Q_TRACE_A].ptr, qslot.data(), qn * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(s->qA[Q_TRACE_A].ptr, qa.data(), qn * sizeof(F4), hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipMemcpyAsync(s->qB[Q_TRACE_A].ptr, qb.data(), qn * sizeof(F4), hipMemcpyHostToDevice, st) != hipSuccess ||
       hipMemcpyAsync(s->dCounters.ptr, &c, sizeof(c), hipMemcpyHostToDevice, st) != hipSuccess) { setError("giCTraceRays: upload failed"); return -1; }
   PathState ps{s->slots.ptr};
-  QueueSet qs{}; for (uint32_t k = 0; k < Q_COUNT; k++) qs.items[k] = s->queues[k].ptr; qs.cap = s->queueCap;
-  launchTrace(st, blocks, false, false, makeView(s), ps, qs, s->dCounters.ptr, Q_TRACE_A);
+  launchTrace(st, blocks, false, false, makeView(s), ps, makeQueueSet(s), s->dCounters.ptr, Q_TRACE_A, Q_REGEN_B);
   std::vector<TriRec> tris(s->triCount);
-  if (hipMemcpyAsync(host.data(), s->slots.ptr, count * sizeof(Slot), hipMemcpyDeviceToHost, st) != hipSuccess ||
+  if (hipMemcpyAsync(qslot.data(), s->qSlot[Q_HIT].ptr, qn * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipMemcpyAsync(qa.data(), s->qA[Q_HIT].ptr, qn * sizeof(F4), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipMemcpyAsync(&c, s->dCounters.ptr, sizeof(c), hipMemcpyDeviceToHost, st) != hipSuccess ||
       (s->triCount && hipMemcpyAsync(tris.data(), s->dTris.ptr, s->triCount * sizeof(TriRec), hipMemcpyDeviceToHost, st) != hipSuccess) ||
       hipStreamSynchronize(st) != hipSuccess) { setError("giCTraceRays: readback failed"); return -1; }
-  std::vector<F4> hit(count);
-  for (uint32_t i = 0; i < count; i++) hit[i] = host[i].hit;
+  std::vector<F4> hit(count, F4{tMax, 0.0f, 0.0f, 0.0f});
+  for (uint32_t i = 0; i < count; i++) { uint32_t m = 0xffffffffu; memcpy(&hit[i].w, &m, 4); }
+  for (uint32_t k = 0; k < NSHARD; k++)
+    for (uint32_t j = 0; j < c.count[Q_HIT][k].v; j++) { size_t r = (size_t)k * s->queueCap + j; if (qslot[r] < count) hit[qslot[r]] = qa[r]; }
   int hits = 0;
   for (uint32_t i = 0; i < count; i++) {
     uint32_t tri; memcpy(&tri, &hit[i].w, 4);

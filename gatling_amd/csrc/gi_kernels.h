@@ -8,12 +8,14 @@
 namespace gi {
 
 void launchInit(hipStream_t s, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t n);
-void launchReset(hipStream_t s, Counters* cnt, uint32_t traceCur, uint32_t traceNext);
-void launchRaygen(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t traceIdx, F4* colorOut);
+// `par` = iteration parity: k_raygen reads REGEN[par] and appends TRACE[par]; k_trace reads TRACE[par] and appends HIT and
+// REGEN[par^1]; k_shade reads HIT and appends TRACE[par^1], REGEN[par^1], SHADOW.
+void launchRaygen(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par, F4* colorOut);
 // LDS bytes one k_trace block needs for this scene (stack + staged nodes + staged triangles)
 void traceLdsLayout(const SceneView& sc, uint32_t& ldsNodes, uint32_t& ldsTris, uint32_t& bytes);
-void launchTrace(hipStream_t s, uint32_t blocks, bool anyHit, bool count, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t queueIdx);
-void launchShade(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t nextIdx);
+void launchTrace(hipStream_t s, uint32_t blocks, bool anyHit, bool count, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt,
+                 uint32_t qIn, uint32_t qMiss);
+void launchShade(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par);
 
 void launchDebugBsdf(hipStream_t s, const MaterialRec* mat, uint32_t count, const float* in, float* out);
 

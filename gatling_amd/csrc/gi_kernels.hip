@@ -3,10 +3,14 @@
 // Replaces the Vulkan ray-tracing megakernel of the reference:
 //   rp_main.rgen  (/root/reference/src/gi/shaders/rp_main.rgen:185-521)  -> k_raygen + the host bounce loop
 //   traceRayEXT   (rp_main.rgen:381-393, 412-424; HW BVH traversal)        -> k_trace<closest>, k_trace<any>
-//   rp_main.chit  (rp_main.chit:132-493) + rp_main.miss (:55-86)           -> k_shade
-//   rp_main_shadow.miss + the NEE add (rp_main.rgen:426-429)               -> k_trace<any> epilogue
+//   rp_main.chit  (rp_main.chit:132-493)                                   -> k_shade
+//   rp_main.miss  (:55-86), rp_main_shadow.miss, the NEE add (rgen:426-429) -> k_raygen (miss term), k_trace<any> epilogue
 // One slot per pixel of the tile walks its samples in order, so the per-pixel float accumulation order of
 // rp_main.rgen:498 is preserved exactly while different slots sit in different stages/queues.
+//
+// Data movement (DESIGN.md "Data layout"): rays, hits and shadow rays travel as RECORDS inside the queues -- producers
+// write them at the queue position they were allotted, consumers read them back fully coalesced -- and only the
+// 64-byte per-pixel Slot (throughput, radiance, accumulator) is gathered/scattered by slot index.
 //
 // Built with -ffp-contract=off (arithmetic contract, see gi_device_math.h).  Box tests inside the traversal use
 // explicit fmaf: they are conservative filters and never influence results.
@@ -22,7 +26,8 @@ namespace gi {
 // ------------------------------------------------------------------------------------------------
 // Stream compaction.  wave64 ballot + popcount prefix inside a wave, LDS aggregation over the 4 waves of a block,
 // ONE atomic per block, queue and loop trip -- on the block's own shard of the queue (see gi_types.h: NSHARD).
-// All stage kernels run block-uniform loops so the two barriers per trip are legal.
+// All stage kernels run block-uniform loops so the two barriers per trip are legal.  Returns, per queue, the index
+// at which the calling lane must write its record (valid where pred is set).
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t BLOCK = 256;
 constexpr uint32_t WAVES = BLOCK / 64;
@@ -31,8 +36,8 @@ template <int NQ>
 struct AppendScratch { uint32_t wcount[2][NQ][WAVES]; uint32_t base[2][NQ]; };
 
 template <int NQ>
-__device__ __forceinline__ void block_append(AppendScratch<NQ>& sh, uint32_t trip, const bool (&pred)[NQ], uint32_t slot, const QueueSet& qs,
-                                             const uint32_t (&qid)[NQ], Counters* cnt)
+__device__ __forceinline__ void block_append(AppendScratch<NQ>& sh, uint32_t trip, const bool (&pred)[NQ], const uint32_t (&qid)[NQ], uint32_t cap,
+                                             Counters* cnt, uint32_t (&outIdx)[NQ])
 {
   const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6, par = trip & 1u, shard = blockIdx.x % NSHARD;
   unsigned long long m[NQ];
@@ -52,37 +57,50 @@ __device__ __forceinline__ void block_append(AppendScratch<NQ>& sh, uint32_t tri
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < NQ; q++) {
-    if (pred[q]) {
-      uint32_t off = sh.base[par][q] + (uint32_t)__popcll(m[q] & ((1ull << lane) - 1ull));
-      for (uint32_t w = 0; w < wave; w++) off += sh.wcount[par][q][w];
-      qs.items[qid[q]][shard * qs.cap + off] = slot;
-    }
+    uint32_t off = sh.base[par][q] + (uint32_t)__popcll(m[q] & ((1ull << lane) - 1ull));
+    for (uint32_t w = 0; w < wave; w++) off += sh.wcount[par][q][w];
+    outIdx[q] = shard * cap + off;
   }
 }
 
-// Reader side: the queue is the concatenation of its NSHARD segments.
-struct QueueReader { uint32_t pre[NSHARD + 1]; const uint32_t* items; uint32_t cap; };
-__device__ __forceinline__ void reader_init(QueueReader& r, const Counters* cnt, uint32_t q, const QueueSet& qs)
+// Reader side: a queue is the concatenation of its NSHARD segments; maps a flat index to the record index.
+struct QueueReader { uint32_t pre[NSHARD + 1]; uint32_t cap; };
+__device__ __forceinline__ void reader_init(QueueReader& r, const Counters* cnt, uint32_t q, uint32_t cap)
 {
   r.pre[0] = 0;
 #pragma unroll
   for (uint32_t s = 0; s < NSHARD; s++) r.pre[s + 1] = r.pre[s] + cnt->count[q][s].v;
-  r.items = qs.items[q]; r.cap = qs.cap;
+  r.cap = cap;
 }
-__device__ __forceinline__ uint32_t reader_get(const QueueReader& r, uint32_t i)
+__device__ __forceinline__ uint32_t reader_index(const QueueReader& r, uint32_t i)
 {
   uint32_t s = 0, p = 0;
 #pragma unroll
   for (uint32_t k = 1; k < NSHARD; k++) { const bool ge = i >= r.pre[k]; s += ge ? 1u : 0u; p = ge ? r.pre[k] : p; }
-  return r.items[s * r.cap + (i - p)];
+  return s * r.cap + (i - p);
 }
 
 __device__ __forceinline__ F4 ld4(const F4* p) { float4 v = *reinterpret_cast<const float4*>(p); return F4{v.x, v.y, v.z, v.w}; }
 __device__ __forceinline__ void st4(F4* p, float x, float y, float z, float w) { *reinterpret_cast<float4*>(p) = make_float4(x, y, z, w); }
 constexpr uint32_t MISS = 0xffffffffu;
+constexpr uint32_t REGEN_MISSED = 0x80000000u; // flag on a regen-queue entry: the path left the scene (k_trace -> k_raygen)
+
+// Zeroes the counters of the queues that the producers of iteration `it` will append to.  Called by one thread of
+// k_raygen(it): none of these queues is read or appended by k_raygen(it) itself (it reads REGEN[it&1] and appends
+// TRACE[it&1]), and their previous consumers finished in iteration it-1 (stream order).
+__device__ __forceinline__ void zero_next_counters(Counters* cnt, uint32_t par)
+{
+  const uint32_t t = threadIdx.x;
+  if (t < NSHARD) {
+    cnt->count[Q_TRACE_A + (par ^ 1u)][t].v = 0;
+    cnt->count[Q_REGEN_A + (par ^ 1u)][t].v = 0;
+    cnt->count[Q_HIT][t].v = 0;
+    cnt->count[Q_SHADOW][t].v = 0;
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
-// k_init: every slot starts in the regen queue with "no sample in flight"
+// k_init: every slot starts in regen queue A with "no sample in flight"
 // ------------------------------------------------------------------------------------------------
 __global__ void k_init(PathState st, QueueSet qs, Counters* cnt, uint32_t n)
 {
@@ -91,109 +109,101 @@ __global__ void k_init(PathState st, QueueSet qs, Counters* cnt, uint32_t n)
   if (i < Q_COUNT * NSHARD) {
     const uint32_t q = i / NSHARD, sdx = i % NSHARD;
     uint32_t c = 0;
-    if (q == Q_REGEN) { const uint32_t lo = sdx * per; c = lo < n ? ((n - lo) < per ? (n - lo) : per) : 0u; }
+    if (q == Q_REGEN_A) { const uint32_t lo = sdx * per; c = lo < n ? ((n - lo) < per ? (n - lo) : per) : 0u; }
     cnt->count[q][sdx].v = c;
   }
   if (i == 0) { cnt->segments = 0; cnt->shadowRays = 0; cnt->nodesVisited = 0; cnt->trisTested = 0; cnt->shadowNodesVisited = 0; cnt->shadowTrisTested = 0; }
   for (; i < n; i += gridDim.x * blockDim.x) {
     st4(&st.slots[i].acc, 0.0f, 0.0f, 0.0f, u2f(0xffffffffu));
-    qs.items[Q_REGEN][(i / per) * qs.cap + (i % per)] = i;
+    qs.slot[Q_REGEN_A][(i / per) * qs.cap + (i % per)] = i;
   }
 }
 
-// Between k_raygen and k_trace: account the rays about to be traced / the shadow rays just traced, then zero the
-// queues that this iteration's producers append to.
-__global__ void k_reset(Counters* cnt, uint32_t traceCur, uint32_t traceNext)
-{
-  const uint32_t t = threadIdx.x;
-  if (t == 0) {
-    uint32_t rays = 0, shadow = 0;
-    for (uint32_t s = 0; s < NSHARD; s++) { rays += cnt->count[traceCur][s].v; shadow += cnt->count[Q_SHADOW][s].v; }
-    cnt->segments += rays; cnt->shadowRays += shadow;
-  }
-  __syncthreads();
-  if (t < NSHARD) { cnt->count[traceNext][t].v = 0; cnt->count[Q_REGEN][t].v = 0; cnt->count[Q_SHADOW][t].v = 0; cnt->count[Q_HIT][t].v = 0; }
-}
-
 // ------------------------------------------------------------------------------------------------
-// k_raygen: persistent-thread ray generation + per-sample finish (rp_main.rgen:213-283, 483-515)
+// k_raygen: persistent-thread ray generation + per-sample finish (rp_main.rgen:213-283, 483-515) + the miss term
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st, QueueSet qs, Counters* cnt, uint32_t traceIdx, F4* __restrict__ colorOut)
+__global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st, QueueSet qs, Counters* cnt, uint32_t par, F4* __restrict__ colorOut)
 {
   __shared__ AppendScratch<1> sh;
-  QueueReader rd; reader_init(rd, cnt, Q_REGEN, qs);
+  const uint32_t qIn = Q_REGEN_A + par, qOut = Q_TRACE_A + par;
+  QueueReader rd; reader_init(rd, cnt, qIn, qs.cap);
+  if (blockIdx.x == 0) zero_next_counters(cnt, par);
   const uint32_t n = rd.pre[NSHARD];
   const uint32_t stride = gridDim.x * BLOCK;
   uint32_t trip = 0;
   for (uint32_t base = blockIdx.x * BLOCK; base < n; base += stride, trip++) {
     const uint32_t i = base + threadIdx.x;
     bool more = false; uint32_t slot = 0;
+    V3 origin = v3(0.0f, 0.0f, 0.0f), dir = origin; float tMin = 0.0f, tMax = GI_FLT_MAX;
     if (i < n) {
-    slot = reader_get(rd, i);
-    Slot* S = &st.slots[slot];
-    F4 acc = ld4(&S->acc);
-    uint32_t s = f2u(acc.w);
-    V3 pixelColor = v3(acc.x, acc.y, acc.z);
-    if (s != 0xffffffffu) { // finish the sample that just terminated (:489-498)
-      F4 r = ld4(&S->rad);
-      V3 rad = v3(r.x, r.y, r.z);
-      if (f2u(S->hit.w) == MISS) {
-        // the path left the scene: uniform fallback dome == colour-AOV clear value (rp_main.miss:68-86, Gi.cpp:2184-2199,
-        // 2232-2238).  k_trace routes misses straight here; nothing after the miss can change the sample any more.
-        F4 tb = ld4(&S->thr);
-        rad = rad + v3(tb.x, tb.y, tb.z) * v3(U.background);
+      const uint32_t entry = qs.slot[qIn][reader_index(rd, i)];
+      slot = entry & ~REGEN_MISSED;
+      Slot* S = &st.slots[slot];
+      F4 acc = ld4(&S->acc);
+      uint32_t s = f2u(acc.w);
+      V3 pixelColor = v3(acc.x, acc.y, acc.z);
+      if (s != 0xffffffffu) { // finish the sample that just terminated (:489-498)
+        F4 r = ld4(&S->rad);
+        V3 rad = v3(r.x, r.y, r.z);
+        if (entry & REGEN_MISSED) {
+          // the path left the scene: uniform fallback dome == colour-AOV clear value (rp_main.miss:68-86, Gi.cpp:2184-2199,
+          // 2232-2238).  k_trace routes misses straight here; nothing after the miss can change the sample any more.
+          F4 tb = ld4(&S->thr);
+          rad = rad + v3(tb.x, tb.y, tb.z) * v3(U.background);
+        }
+        float mv = fmax2(rad.x, fmax2(rad.y, rad.z));
+        if (mv > U.maxSampleValue) rad = rad * (U.maxSampleValue / mv);
+        V3 sc = v3(fmax2(0.0f, rad.x), fmax2(0.0f, rad.y), fmax2(0.0f, rad.z));
+        pixelColor = pixelColor + sc * U.invSpp;
       }
-      float mv = fmax2(rad.x, fmax2(rad.y, rad.z));
-      if (mv > U.maxSampleValue) rad = rad * (U.maxSampleValue / mv);
-      V3 sc = v3(fmax2(0.0f, rad.x), fmax2(0.0f, rad.y), fmax2(0.0f, rad.z));
-      pixelColor = pixelColor + sc * U.invSpp;
+      s = s + 1u; // 0xffffffff + 1 == 0
+      const uint32_t pixelIndex = U.rowBegin * U.imageWidth + slot; // :195 (global index: RNG is tile independent)
+      more = s < U.spp;
+      if (more) {
+        const uint32_t px = pixelIndex % U.imageWidth, py = pixelIndex / U.imageWidth;
+        uint32_t rng = gi_hash_init(pixelIndex * ((U.sampleOffset + s) + 1u)); // :223, common.glsl:121-124
+        float r0 = gi_next1f(rng), r1 = gi_next1f(rng);                       // :224 (always drawn)
+        float sox = 0.5f, soy = 0.5f;
+        if (U.flags & FLAG_JITTER) {
+          if (U.flags & FLAG_FIS) { float gx, gy; gi_fis_gauss(r0, r1, gx, gy); sox = 0.5f + gx; soy = 0.5f + gy; }
+          else { sox = r0; soy = r1; }
+        }
+        V3 camRight = v3(U.camRight), camUp = v3(U.camUp), camPos = v3(U.camPos);
+        V3 P = (v3(U.L) + (camRight * ((float)px + sox)) * U.WX) + (camUp * ((float)py + soy)) * U.HY; // :239-242
+        origin = camPos;
+        dir = normalize(P - origin);
+        if ((U.flags & FLAG_DOF) && U.lensRadius > 0.0f) { // :249-263
+          float z0 = gi_next1f(rng), z1 = gi_next1f(rng);
+          V3 focal = origin + dir * U.focusDistance;
+          V3 ap = gi_sample_hemisphere(z0, z1);
+          origin = origin + camRight * (ap.x * U.lensRadius);
+          origin = origin + camUp * (ap.y * U.lensRadius);
+          dir = normalize(focal - origin);
+        }
+        if (dir.x == 0.0f) dir.x += GI_FLT_MIN; // :271
+        if (dir.y == 0.0f) dir.y += GI_FLT_MIN;
+        if (dir.z == 0.0f) dir.z += GI_FLT_MIN;
+        if (U.flags & FLAG_CLIP) { // :287-288, 308-314 (bounce 0 only)
+          float cosCone = fmax2(1e-5f, dot(dir, v3(U.camFwd)));
+          tMin = U.clipNear / cosCone; tMax = U.clipFar / cosCone;
+        }
+        st4(&S->thr, 1.0f, 1.0f, 1.0f, u2f(0u)); // :274-276
+        st4(&S->rad, 0.0f, 0.0f, 0.0f, u2f(rng));
+        st4(&S->acc, pixelColor.x, pixelColor.y, pixelColor.z, u2f(s));
+      } else { // :506-515
+        V3 prev = pixelColor;
+        if ((U.flags & FLAG_PROGRESSIVE) && U.sampleOffset > 0u) { F4 p = ld4(&colorOut[pixelIndex]); prev = v3(p.x, p.y, p.z); }
+        V3 c = (prev * U.sampleOffsetF + pixelColor * U.sppF) * U.invTotalSampleCount;
+        st4(&colorOut[pixelIndex], c.x, c.y, c.z, 1.0f);
+      }
     }
-    s = s + 1u; // 0xffffffff + 1 == 0
-    const uint32_t pixelIndex = U.rowBegin * U.imageWidth + slot; // :195 (global index: RNG is tile independent)
-    more = s < U.spp;
+    const bool pred[1] = {more}; const uint32_t qid[1] = {qOut}; uint32_t idx[1];
+    block_append<1>(sh, trip, pred, qid, qs.cap, cnt, idx);
     if (more) {
-      const uint32_t px = pixelIndex % U.imageWidth, py = pixelIndex / U.imageWidth;
-      uint32_t rng = gi_hash_init(pixelIndex * ((U.sampleOffset + s) + 1u)); // :223, common.glsl:121-124
-      float r0 = gi_next1f(rng), r1 = gi_next1f(rng);                       // :224 (always drawn)
-      float sox = 0.5f, soy = 0.5f;
-      if (U.flags & FLAG_JITTER) {
-        if (U.flags & FLAG_FIS) { float gx, gy; gi_fis_gauss(r0, r1, gx, gy); sox = 0.5f + gx; soy = 0.5f + gy; }
-        else { sox = r0; soy = r1; }
-      }
-      V3 camRight = v3(U.camRight), camUp = v3(U.camUp), camPos = v3(U.camPos);
-      V3 P = (v3(U.L) + (camRight * ((float)px + sox)) * U.WX) + (camUp * ((float)py + soy)) * U.HY; // :239-242
-      V3 origin = camPos;
-      V3 dir = normalize(P - origin);
-      if ((U.flags & FLAG_DOF) && U.lensRadius > 0.0f) { // :249-263
-        float z0 = gi_next1f(rng), z1 = gi_next1f(rng);
-        V3 focal = origin + dir * U.focusDistance;
-        V3 ap = gi_sample_hemisphere(z0, z1);
-        origin = origin + camRight * (ap.x * U.lensRadius);
-        origin = origin + camUp * (ap.y * U.lensRadius);
-        dir = normalize(focal - origin);
-      }
-      if (dir.x == 0.0f) dir.x += GI_FLT_MIN; // :271
-      if (dir.y == 0.0f) dir.y += GI_FLT_MIN;
-      if (dir.z == 0.0f) dir.z += GI_FLT_MIN;
-      float tMin = 0.0f, tMax = GI_FLT_MAX;
-      if (U.flags & FLAG_CLIP) { // :287-288, 308-314 (bounce 0 only)
-        float cosCone = fmax2(1e-5f, dot(dir, v3(U.camFwd)));
-        tMin = U.clipNear / cosCone; tMax = U.clipFar / cosCone;
-      }
-      st4(&S->rayO, origin.x, origin.y, origin.z, tMin);
-      st4(&S->rayD, dir.x, dir.y, dir.z, tMax);
-      st4(&S->thr, 1.0f, 1.0f, 1.0f, u2f(0u)); // :274-276
-      st4(&S->rad, 0.0f, 0.0f, 0.0f, u2f(rng));
-      st4(&S->acc, pixelColor.x, pixelColor.y, pixelColor.z, u2f(s));
-    } else { // :506-515
-      V3 prev = pixelColor;
-      if ((U.flags & FLAG_PROGRESSIVE) && U.sampleOffset > 0u) { F4 p = ld4(&colorOut[pixelIndex]); prev = v3(p.x, p.y, p.z); }
-      V3 c = (prev * U.sampleOffsetF + pixelColor * U.sppF) * U.invTotalSampleCount;
-      st4(&colorOut[pixelIndex], c.x, c.y, c.z, 1.0f);
+      qs.slot[qOut][idx[0]] = slot;
+      st4(&qs.a[qOut][idx[0]], origin.x, origin.y, origin.z, tMin);
+      st4(&qs.b[qOut][idx[0]], dir.x, dir.y, dir.z, tMax);
     }
-    }
-    const bool pred[1] = {more}; const uint32_t qid[1] = {traceIdx};
-    block_append<1>(sh, trip, pred, slot, qs, qid, cnt);
   }
 }
 
@@ -206,13 +216,15 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st,
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t LDS_NODES = 384;  // upper bound: 30 KiB   (the launch stages min(nodeCount, LDS_NODES) nodes)
 constexpr uint32_t LDS_TRIS = 128;   // upper bound: 6 KiB    (all triangles when the scene has <= LDS_TRIS, else none)
-constexpr uint32_t LDS_STACK = 8;    // x 8 B x 256 lanes = 16 KiB
-constexpr uint32_t OVF_STACK = 40;
+constexpr uint32_t OVF_STACK = 40;   // scratch overflow entries of the fallback variant (trees deeper than 16 levels)
 constexpr uint32_t TRACE_BLOCK = 256;
 
 struct TraceCounters { uint32_t nodes, tris; };
 
-template <bool ANYHIT, bool COUNT>
+// STACK = per-lane stack entries kept in LDS.  The traversal pushes at most one entry per tree level, so the host
+// picks STACK >= tree depth (8 or 16) and the scratch overflow (OVERFLOW) is compiled in only for deeper trees:
+// a kernel that declares scratch pays for it on every wave launch even if it never spills.
+template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW>
 __device__ __forceinline__ bool traverse(const SceneView& sc, const uint4* s_nodes, uint32_t ldsNodes, const uint4* s_tris, uint32_t ldsTris,
                                          uint2 (*s_stack)[TRACE_BLOCK], V3 o, V3 d, float tMin, float tMax,
                                          float& outT, float& outU, float& outV, uint32_t& outTri, TraceCounters& tc)
@@ -226,7 +238,7 @@ __device__ __forceinline__ bool traverse(const SceneView& sc, const uint4* s_nod
   const uint32_t octinv = (d.x >= 0.0f ? 1u : 0u) | (d.y >= 0.0f ? 2u : 0u) | (d.z >= 0.0f ? 4u : 0u);
 
   float tBest = tMax; uint32_t bestTri = 0xffffffffu, bestOrig = 0xffffffffu; float bestU = 0.0f, bestV = 0.0f;
-  uint2 overflow[OVF_STACK];
+  uint2 overflow[OVERFLOW ? OVF_STACK : 1];
   uint32_t sp = 0;
   uint2 G = make_uint2(0u, 0x80000000u); // virtual group holding only the root
   bool found = false;
@@ -236,7 +248,10 @@ __device__ __forceinline__ bool traverse(const SceneView& sc, const uint4* s_nod
     if (G.y & 0xff000000u) {
       const uint32_t bit = 31u - (uint32_t)__clz((int)(G.y & 0xff000000u));
       G.y &= ~(1u << bit);
-      if (G.y & 0xff000000u) { if (sp < LDS_STACK) s_stack[sp][tid] = G; else overflow[sp - LDS_STACK] = G; sp++; }
+      if (G.y & 0xff000000u) {
+        if (!OVERFLOW || sp < STACK) s_stack[sp < STACK ? sp : STACK - 1u][tid] = G; else overflow[sp - STACK] = G;
+        sp++;
+      }
       const uint32_t slot = (bit - 24u) ^ octinv;
       const uint32_t rel = (uint32_t)__popc((G.y & 0xffu) & ((1u << slot) - 1u));
       const uint32_t nodeIdx = G.x + rel;
@@ -311,24 +326,25 @@ __device__ __forceinline__ bool traverse(const SceneView& sc, const uint4* s_nod
     if (!(G.y & 0xff000000u)) {
       if (sp == 0u) break;
       sp--;
-      G = (sp < LDS_STACK) ? s_stack[sp][tid] : overflow[sp - LDS_STACK];
+      G = (!OVERFLOW || sp < STACK) ? s_stack[sp < STACK ? sp : STACK - 1u][tid] : overflow[sp - STACK];
     }
   }
   outT = tBest; outU = bestU; outV = bestV; outTri = bestTri;
   return found;
 }
 
-template <bool ANYHIT, bool COUNT>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t queueIdx, uint32_t ldsNodes, uint32_t ldsTris)
+template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t qMiss, uint32_t ldsNodes, uint32_t ldsTris)
 {
   // dynamic LDS, sized by the launch to what this scene actually stages: [stack | nodes | triangles]
   extern __shared__ uint4 s_dyn[];
   uint2 (*s_stack)[TRACE_BLOCK] = reinterpret_cast<uint2 (*)[TRACE_BLOCK]>(s_dyn);
-  uint4* s_nodes = s_dyn + (LDS_STACK * TRACE_BLOCK * sizeof(uint2)) / sizeof(uint4);
+  uint4* s_nodes = s_dyn + (STACK * TRACE_BLOCK * sizeof(uint2)) / sizeof(uint4);
   uint4* s_tris = s_nodes + ldsNodes * 5u;
   __shared__ AppendScratch<2> sh;
-  QueueReader rd; reader_init(rd, cnt, queueIdx, qs);
+  QueueReader rd; reader_init(rd, cnt, qIn, qs.cap);
   const uint32_t n = rd.pre[NSHARD];
+  if (blockIdx.x == 0 && threadIdx.x == 0) { if (ANYHIT) cnt->shadowRays += n; else cnt->segments += n; } // single writer per launch
   if (blockIdx.x * TRACE_BLOCK >= n) return; // whole block idle (uniform)
   for (uint32_t i = threadIdx.x; i < ldsNodes * 5u; i += TRACE_BLOCK) s_nodes[i] = reinterpret_cast<const uint4*>(sc.nodes)[i];
   for (uint32_t i = threadIdx.x; i < ldsTris * 3u; i += TRACE_BLOCK) s_tris[i] = reinterpret_cast<const uint4*>(sc.tris)[(i / 3u) * 4u + (i % 3u)];
@@ -340,30 +356,36 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
   for (uint32_t base = blockIdx.x * TRACE_BLOCK; base < n; base += stride, trip++) {
     const uint32_t i = base + threadIdx.x;
     bool hit = false, miss = false; uint32_t slot = 0;
+    float t = 0.0f, u = 0.0f, v = 0.0f; uint32_t tri = MISS; F4 rdir = F4{0.0f, 0.0f, 0.0f, 0.0f};
     if (i < n) {
-      slot = reader_get(rd, i);
-      Slot* S = &st.slots[slot];
+      const uint32_t r = reader_index(rd, i);
+      slot = qs.slot[qIn][r];
+      const F4 ro = ld4(&qs.a[qIn][r]);
+      rdir = ld4(&qs.b[qIn][r]);
       if (!ANYHIT) {
-        const F4 ro = ld4(&S->rayO), rdir = ld4(&S->rayD);
-        float t, u, v; uint32_t tri;
-        hit = traverse<false, COUNT>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), ro.w, rdir.w, t, u, v, tri, tc);
+        hit = traverse<false, COUNT, STACK, OVERFLOW>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), ro.w, rdir.w, t, u, v, tri, tc);
         miss = !hit;
-        st4(&S->hit, t, u, v, u2f(tri));
       } else {
         // shadow ray (rp_main.rgen:397-429): origin = next ray origin, tMin 0.01, tMax = distance to the light sample
-        const F4 ro = ld4(&S->rayO), sd = ld4(&S->neeD), nc = ld4(&S->neeC);
-        float t, u, v; uint32_t tri;
-        const bool occluded = traverse<true, COUNT>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, v3(ro.x, ro.y, ro.z), v3(sd.x, sd.y, sd.z), 0.01f, nc.w, t, u, v, tri, tc);
+        const bool occluded = traverse<true, COUNT, STACK, OVERFLOW>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), 0.01f, ro.w, t, u, v, tri, tc);
         if (!occluded) {
-          F4 r = ld4(&S->rad);
-          st4(&S->rad, r.x + nc.x, r.y + nc.y, r.z + nc.z, r.w);
+          const F4 nc = ld4(&qs.c[qIn][r]);
+          Slot* S = &st.slots[slot];
+          F4 rr = ld4(&S->rad);
+          st4(&S->rad, rr.x + nc.x, rr.y + nc.y, rr.z + nc.z, rr.w);
         }
       }
     }
     if (!ANYHIT) {
-      // sort by outcome: hits go to the shade stage, misses straight to k_raygen (which adds the environment term)
-      const bool pred[2] = {hit, miss}; const uint32_t qid[2] = {Q_HIT, Q_REGEN};
-      block_append<2>(sh, trip, pred, slot, qs, qid, cnt);
+      // sort by outcome: hits go to the shade stage as (slot, hit, direction) records, misses straight to k_raygen
+      const bool pred[2] = {hit, miss}; const uint32_t qid[2] = {Q_HIT, qMiss}; uint32_t idx[2];
+      block_append<2>(sh, trip, pred, qid, qs.cap, cnt, idx);
+      if (hit) {
+        qs.slot[Q_HIT][idx[0]] = slot;
+        st4(&qs.a[Q_HIT][idx[0]], t, u, v, u2f(tri));
+        st4(&qs.b[Q_HIT][idx[0]], rdir.x, rdir.y, rdir.z, 0.0f);
+      }
+      if (miss) qs.slot[qMiss][idx[1]] = slot | REGEN_MISSED;
     }
   }
   if (COUNT) { // measurement builds only: one atomic pair per wave
@@ -644,88 +666,100 @@ __device__ inline void sample_light(const SceneView& sc, const FrameUniforms& U,
 // k_shade: closest-hit shading + the post-trace part of the bounce loop, over the HIT queue only
 // (rp_main.chit:132-493, rp_main.rgen:397-480).  Misses never get here (k_trace routes them to k_raygen).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t nextIdx)
+__global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t par)
 {
   __shared__ AppendScratch<3> sh;
-  QueueReader rdr; reader_init(rdr, cnt, Q_HIT, qs);
+  const uint32_t qNext = Q_TRACE_A + (par ^ 1u), qRegen = Q_REGEN_A + (par ^ 1u);
+  QueueReader rdr; reader_init(rdr, cnt, Q_HIT, qs.cap);
   const uint32_t n = rdr.pre[NSHARD];
   const uint32_t stride = gridDim.x * BLOCK;
   uint32_t trip = 0;
   for (uint32_t base = blockIdx.x * BLOCK; base < n; base += stride, trip++) {
     const uint32_t i = base + threadIdx.x;
     bool cont = false, ended = false, shadow = false; uint32_t slot = 0;
+    V3 no = v3(0.0f, 0.0f, 0.0f), k2 = no, sdir = no, nee = no; float ld = 0.0f;
     if (i < n) {
-    slot = reader_get(rdr, i);
-    Slot* S = &st.slots[slot];
-    const F4 h = ld4(&S->hit);
-    const F4 rd = ld4(&S->rayD);
-    const F4 tb = ld4(&S->thr);
-    const F4 rr = ld4(&S->rad);
-    V3 throughput = v3(tb.x, tb.y, tb.z), radiance = v3(rr.x, rr.y, rr.z);
-    uint32_t bitfield = f2u(tb.w), rng = f2u(rr.w);
-    const uint32_t bounce = bitfield & 0x00000fffu;
+      const uint32_t r = reader_index(rdr, i);
+      slot = qs.slot[Q_HIT][r];
+      const F4 h = ld4(&qs.a[Q_HIT][r]);
+      const F4 rd = ld4(&qs.b[Q_HIT][r]);
+      Slot* S = &st.slots[slot];
+      const F4 tb = ld4(&S->thr);
+      const F4 rr = ld4(&S->rad);
+      V3 throughput = v3(tb.x, tb.y, tb.z), radiance = v3(rr.x, rr.y, rr.z);
+      uint32_t bitfield = f2u(tb.w), rng = f2u(rr.w);
+      const uint32_t bounce = bitfield & 0x00000fffu;
 
-    const V3 rayDir = v3(rd.x, rd.y, rd.z);
-    ShState ss;
-    setup_shading_state(sc, f2u(h.w), h.y, h.z, rayDir, ss);
-    const MaterialRec* mat = &sc.materials[ss.material];
-    const bool isDoubleSided = (ss.meshFlags & 2u) != 0u;
-    // emission (rp_main.chit:293-343): uniform EDF, radiance == emission colour where cos > 0
-    const V3 em = v3(mat->p[3], mat->p[4], mat->p[5]);
-    if (em.x != 0.0f || em.y != 0.0f || em.z != 0.0f) {
-      if (ss.frontFace || !isDoubleSided) {
-        const float c = dot(-rayDir, ss.normal);
-        if (c > 0.0f) radiance = radiance + throughput * (em * U.exposureScale);
-      }
-    }
-    // BSDF importance sampling (:361-389); xi = next4f, .w is drawn but unused by the closed forms
-    const float x0 = gi_next1f(rng), x1 = gi_next1f(rng), x2 = gi_next1f(rng); (void)gi_next1f(rng);
-    BsdfSample bs; bsdf_sample(mat, ss, -rayDir, x0, x1, x2, bs);
-    throughput = throughput * bs.overPdf;
-    const bool isTransmission = (bs.event & EV_TRANSMISSION) != 0u;
-    // NEE (:394-444)
-    if ((U.flags & FLAG_NEE) && (bs.event & (EV_DIFFUSE | EV_GLOSSY))) {
-      const float k0 = gi_next1f(rng), k1 = gi_next1f(rng), k2 = gi_next1f(rng), k3 = gi_next1f(rng);
-      V3 dirToLight, lightPower; float lightDist, invPdf; uint32_t ds;
-      sample_light(sc, U, k0, k1, k2, k3, ss.position, dirToLight, lightDist, lightPower, invPdf, ds);
-      V3 nee = v3(0.0f, 0.0f, 0.0f);
-      if ((lightDist > 0.0f) && dot(dirToLight, ss.geomNormal) > 0.0f) {
-        BsdfEval ev; bsdf_evaluate(mat, ss, -rayDir, dirToLight, ev);
-        if (ev.pdf > 0.0f) {
-          const float dmul = gi_half_to_float(ds & 0xffffu), smul = gi_half_to_float(ds >> 16);
-          const V3 weight = throughput * (lightPower * invPdf);
-          nee = nee + (weight * ev.diffuse) * dmul;
-          nee = nee + (weight * ev.glossy) * smul;
+      const V3 rayDir = v3(rd.x, rd.y, rd.z);
+      ShState ss;
+      setup_shading_state(sc, f2u(h.w), h.y, h.z, rayDir, ss);
+      const MaterialRec* mat = &sc.materials[ss.material];
+      const bool isDoubleSided = (ss.meshFlags & 2u) != 0u;
+      // emission (rp_main.chit:293-343): uniform EDF, radiance == emission colour where cos > 0
+      const V3 em = v3(mat->p[3], mat->p[4], mat->p[5]);
+      if (em.x != 0.0f || em.y != 0.0f || em.z != 0.0f) {
+        if (ss.frontFace || !isDoubleSided) {
+          const float c = dot(-rayDir, ss.normal);
+          if (c > 0.0f) radiance = radiance + throughput * (em * U.exposureScale);
         }
       }
-      // rp_main.rgen:401-408: the shadow ray is traced only if it can contribute
-      const V3 toLight = dirToLight * lightDist;
-      const float ld = length(toLight);
-      const V3 sdir = gi_safe_div(toLight, ld);
-      shadow = gi_luminance(nee) > 1e-6f && ld > 1e-9f;
-      if (shadow) { st4(&S->neeC, nee.x, nee.y, nee.z, ld); st4(&S->neeD, sdir.x, sdir.y, sdir.z, 0.0f); }
+      // BSDF importance sampling (:361-389); xi = next4f, .w is drawn but unused by the closed forms
+      const float x0 = gi_next1f(rng), x1 = gi_next1f(rng), x2 = gi_next1f(rng); (void)gi_next1f(rng);
+      BsdfSample bs; bsdf_sample(mat, ss, -rayDir, x0, x1, x2, bs);
+      throughput = throughput * bs.overPdf;
+      k2 = bs.k2;
+      const bool isTransmission = (bs.event & EV_TRANSMISSION) != 0u;
+      // NEE (:394-444)
+      if ((U.flags & FLAG_NEE) && (bs.event & (EV_DIFFUSE | EV_GLOSSY))) {
+        const float k0 = gi_next1f(rng), k1 = gi_next1f(rng), kk2 = gi_next1f(rng), k3 = gi_next1f(rng);
+        V3 dirToLight, lightPower; float lightDist, invPdf; uint32_t ds;
+        sample_light(sc, U, k0, k1, kk2, k3, ss.position, dirToLight, lightDist, lightPower, invPdf, ds);
+        if ((lightDist > 0.0f) && dot(dirToLight, ss.geomNormal) > 0.0f) {
+          BsdfEval ev; bsdf_evaluate(mat, ss, -rayDir, dirToLight, ev);
+          if (ev.pdf > 0.0f) {
+            const float dmul = gi_half_to_float(ds & 0xffffu), smul = gi_half_to_float(ds >> 16);
+            const V3 weight = throughput * (lightPower * invPdf);
+            nee = nee + (weight * ev.diffuse) * dmul;
+            nee = nee + (weight * ev.glossy) * smul;
+          }
+        }
+        // rp_main.rgen:401-408: the shadow ray is traced only if it can contribute
+        const V3 toLight = dirToLight * lightDist;
+        ld = length(toLight);
+        sdir = gi_safe_div(toLight, ld);
+        shadow = gi_luminance(nee) > 1e-6f && ld > 1e-9f;
+      }
+      if (bs.event == EV_ABSORB) bitfield |= 0x80000000u; // :483-486
+      const V3 gn = ss.geomNormal * (isTransmission ? -1.0f : 1.0f);
+      no = gi_offset_ray_origin(ss.position, gn); // :488-489
+      // rp_main.rgen:441-480
+      if (length(throughput) < 1e-9f) bitfield |= 0x80000000u;
+      if (bounce > U.rrBounceOffset) {
+        const float k = gi_next1f(rng);
+        const float mt = fmax2(throughput.x, fmax2(throughput.y, throughput.z));
+        const float p = fmin2(mt, U.rrInvMinTermProb);
+        if (k > p) bitfield |= 0x80000000u; else throughput = throughput / p;
+      }
+      bitfield++;
+      cont = ((bitfield & 0x00000fffu) < U.maxBounces) && !(bitfield & 0x80000000u); // loop test :298-304
+      ended = !cont;
+      st4(&S->thr, throughput.x, throughput.y, throughput.z, u2f(bitfield));
+      st4(&S->rad, radiance.x, radiance.y, radiance.z, u2f(rng));
     }
-    if (bs.event == EV_ABSORB) bitfield |= 0x80000000u; // :483-486
-    const V3 gn = ss.geomNormal * (isTransmission ? -1.0f : 1.0f);
-    const V3 no = gi_offset_ray_origin(ss.position, gn); // :488-489
-    // rp_main.rgen:441-480
-    if (length(throughput) < 1e-9f) bitfield |= 0x80000000u;
-    if (bounce > U.rrBounceOffset) {
-      const float k = gi_next1f(rng);
-      const float mt = fmax2(throughput.x, fmax2(throughput.y, throughput.z));
-      const float p = fmin2(mt, U.rrInvMinTermProb);
-      if (k > p) bitfield |= 0x80000000u; else throughput = throughput / p;
+    const bool pred[3] = {cont, ended, shadow}; const uint32_t qid[3] = {qNext, qRegen, Q_SHADOW}; uint32_t idx[3];
+    block_append<3>(sh, trip, pred, qid, qs.cap, cnt, idx);
+    if (cont) {
+      qs.slot[qNext][idx[0]] = slot;
+      st4(&qs.a[qNext][idx[0]], no.x, no.y, no.z, 0.0f);
+      st4(&qs.b[qNext][idx[0]], k2.x, k2.y, k2.z, GI_FLT_MAX);
     }
-    bitfield++;
-    cont = ((bitfield & 0x00000fffu) < U.maxBounces) && !(bitfield & 0x80000000u); // loop test :298-304
-    ended = !cont;
-    st4(&S->rayO, no.x, no.y, no.z, 0.0f);
-    st4(&S->rayD, bs.k2.x, bs.k2.y, bs.k2.z, GI_FLT_MAX);
-    st4(&S->thr, throughput.x, throughput.y, throughput.z, u2f(bitfield));
-    st4(&S->rad, radiance.x, radiance.y, radiance.z, u2f(rng));
+    if (ended) qs.slot[qRegen][idx[1]] = slot;
+    if (shadow) {
+      qs.slot[Q_SHADOW][idx[2]] = slot;
+      st4(&qs.a[Q_SHADOW][idx[2]], no.x, no.y, no.z, ld);
+      st4(&qs.b[Q_SHADOW][idx[2]], sdir.x, sdir.y, sdir.z, 0.0f);
+      st4(&qs.c[Q_SHADOW][idx[2]], nee.x, nee.y, nee.z, 0.0f);
     }
-    const bool pred[3] = {cont, ended, shadow}; const uint32_t qid[3] = {nextIdx, Q_REGEN, Q_SHADOW};
-    block_append<3>(sh, trip, pred, slot, qs, qid, cnt);
   }
 }
 
@@ -753,34 +787,34 @@ void launchInit(hipStream_t s, const PathState& st, const QueueSet& qs, Counters
   uint32_t blocks = (n + 255u) / 256u; if (blocks > 4096u) blocks = 4096u; if (blocks == 0u) blocks = 1u;
   hipLaunchKernelGGL(k_init, dim3(blocks), dim3(256), 0, s, st, qs, cnt, n);
 }
-void launchReset(hipStream_t s, Counters* cnt, uint32_t traceCur, uint32_t traceNext)
+void launchRaygen(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par, F4* colorOut)
 {
-  hipLaunchKernelGGL(k_reset, dim3(1), dim3(64), 0, s, cnt, traceCur, traceNext);
+  hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(BLOCK), 0, s, U, st, qs, cnt, par, colorOut);
 }
-void launchRaygen(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t traceIdx, F4* colorOut)
-{
-  hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(BLOCK), 0, s, U, st, qs, cnt, traceIdx, colorOut);
-}
+static uint32_t traceStackEntries(const SceneView& sc) { return sc.bvhDepth <= 8u ? 8u : 16u; }
 void traceLdsLayout(const SceneView& sc, uint32_t& ldsNodes, uint32_t& ldsTris, uint32_t& bytes)
 {
   ldsNodes = sc.nodeCount < LDS_NODES ? sc.nodeCount : LDS_NODES;
   ldsTris = sc.triCount <= LDS_TRIS ? sc.triCount : 0u;
-  bytes = LDS_STACK * TRACE_BLOCK * (uint32_t)sizeof(uint2) + ldsNodes * 80u + ldsTris * 48u;
+  bytes = traceStackEntries(sc) * TRACE_BLOCK * (uint32_t)sizeof(uint2) + ldsNodes * 80u + ldsTris * 48u;
 }
-void launchTrace(hipStream_t s, uint32_t blocks, bool anyHit, bool count, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t queueIdx)
+template <bool ANYHIT, bool COUNT>
+static void launchTraceVariant(hipStream_t s, uint32_t blocks, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t qMiss)
 {
   uint32_t ln, lt, bytes; traceLdsLayout(sc, ln, lt, bytes);
-  if (!anyHit) {
-    if (count) hipLaunchKernelGGL((k_trace<false, true>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, queueIdx, ln, lt);
-    else hipLaunchKernelGGL((k_trace<false, false>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, queueIdx, ln, lt);
-  } else {
-    if (count) hipLaunchKernelGGL((k_trace<true, true>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, queueIdx, ln, lt);
-    else hipLaunchKernelGGL((k_trace<true, false>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, queueIdx, ln, lt);
-  }
+  if (sc.bvhDepth <= 8u) hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 8, false>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
+  else if (sc.bvhDepth <= 16u) hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 16, false>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
+  else hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 16, true>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
 }
-void launchShade(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t nextIdx)
+void launchTrace(hipStream_t s, uint32_t blocks, bool anyHit, bool count, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt,
+                 uint32_t qIn, uint32_t qMiss)
 {
-  hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, nextIdx);
+  if (!anyHit) { if (count) launchTraceVariant<false, true>(s, blocks, sc, st, qs, cnt, qIn, qMiss); else launchTraceVariant<false, false>(s, blocks, sc, st, qs, cnt, qIn, qMiss); }
+  else { if (count) launchTraceVariant<true, true>(s, blocks, sc, st, qs, cnt, qIn, qMiss); else launchTraceVariant<true, false>(s, blocks, sc, st, qs, cnt, qIn, qMiss); }
+}
+void launchShade(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par)
+{
+  hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par);
 }
 
 void launchDebugBsdf(hipStream_t s, const MaterialRec* mat, uint32_t count, const float* in, float* out)

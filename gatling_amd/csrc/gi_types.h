@@ -111,38 +111,43 @@ struct SceneView {
   const DiskLightRec* diskLights;
   uint32_t nodeCount;
   uint32_t triCount;
+  uint32_t bvhDepth; // levels of the BVH8 (bounds the traversal stack)
 };
 
-// Wavefront path state: one 128-byte record per slot (one slot per pixel of the tile; DESIGN.md "Path state").
-// Array-of-structures ON PURPOSE: queues hold slots in arbitrary order, so every stage touches slots scattered over
-// the array; with one L2 line (128 B) per slot each stage moves exactly the lines it needs, while a SoA layout costs a
-// separate partially-used line per field.
+// Per-pixel path state that persists across stages: ONE 64-byte record per slot (one slot per pixel of the tile).
+// Everything that merely flows from one stage to the next (rays, hits, shadow rays) lives in the queues as records
+// written/read in queue order (coalesced); only this record is gathered/scattered by slot index, and 64 B is one
+// fabric request.  2.07 M slots = 133 MB at 1080p: resident in the 256 MB Infinity Cache.
 struct alignas(16) F4 { float x, y, z, w; };
 
-struct alignas(128) Slot {
-  F4 rayO;  // origin.xyz, tMin
-  F4 rayD;  // dir.xyz, tMax
-  F4 hit;   // t, u, v, asfloat(triangle index in BVH order | 0xffffffff = miss)
-  F4 thr;   // throughput.xyz, asfloat(bitfield)   (rp_main_payload.glsl:24-33)
-  F4 rad;   // radiance.xyz, asfloat(rng state)
-  F4 acc;   // pixel_color accumulator.xyz, asfloat(sample index in flight | 0xffffffff = none yet)
-  F4 neeC;  // neeContrib.xyz, lightDist
-  F4 neeD;  // shadow ray dir.xyz, unused
+struct alignas(64) Slot {
+  F4 thr;  // throughput.xyz, asfloat(bitfield)   (rp_main_payload.glsl:24-33)
+  F4 rad;  // radiance.xyz, asfloat(rng state)
+  F4 acc;  // pixel_color accumulator.xyz, asfloat(sample index in flight | 0xffffffff = none yet)
+  F4 pad;
 };
-static_assert(sizeof(Slot) == 128, "Slot must be one 128-byte line");
+static_assert(sizeof(Slot) == 64, "Slot must be 64 bytes");
 
 struct PathState { Slot* slots; };
 
-// Work queues (slot indices) and their device-side counters.
-// Every queue is split into NSHARD segments (segment s holds items [s*cap, s*cap + count[q][s])): producers append to
-// the segment of their block (blockIdx % NSHARD, i.e. one per XCD in dispatch order), so the append counters are
-// NSHARD different words.  One device-scope atomic word sustains only ~88 updates/us on MI355X
+// Work queues.  Every queue is split into NSHARD segments (segment s holds records [s*cap, s*cap + count[q][s])):
+// producers append to the segment of their block (blockIdx % NSHARD, i.e. one per XCD in dispatch order), so the append
+// counters are NSHARD different words.  One device-scope atomic word sustains only ~88 updates/us on MI355X
 // (MI355X_MICROARCH.md "dequeue"); an unsharded per-wave append made every stage atomic-bound.
-enum : uint32_t { Q_TRACE_A = 0, Q_TRACE_B = 1, Q_REGEN = 2, Q_SHADOW = 3, Q_HIT = 4, Q_COUNT = 5 };
+//   TRACE_A/B : slot, a = (origin, tMin), b = (direction, tMax)          -- the ray record (36 B)
+//   REGEN_A/B : slot | REGEN_MISSED                                       -- paths that ended (or left the scene)
+//   HIT       : slot, a = (t, u, v, triangle), b = (direction, -)         -- the hit record (36 B)
+//   SHADOW    : slot, a = (origin, distance), b = (direction, -), c = (neeContrib, -)
+// The A/B pairs alternate per iteration so that no counter has to be reset between a queue's consumer and its next
+// producers (k_raygen zeroes the counters of the following iteration, see zero_next_counters).
+enum : uint32_t { Q_TRACE_A = 0, Q_TRACE_B = 1, Q_REGEN_A = 2, Q_REGEN_B = 3, Q_HIT = 4, Q_SHADOW = 5, Q_COUNT = 6 };
 constexpr uint32_t NSHARD = 8;
 struct QueueSet {
-  uint32_t* items[Q_COUNT]; // each NSHARD * cap entries
-  uint32_t cap;             // per-shard capacity
+  uint32_t* slot[Q_COUNT]; // each NSHARD * cap entries
+  F4* a[Q_COUNT];          // null where the queue has no such field
+  F4* b[Q_COUNT];
+  F4* c[Q_COUNT];
+  uint32_t cap;            // per-shard capacity
 };
 // Each append counter sits alone in its own 128-byte line: device-scope atomics are serialised per LINE at the memory
 // side, so counters sharing a line would share the ~88 updates/us budget.

@@ -278,6 +278,8 @@ void giCSetRenderBufferDeviceOnly(GiCRenderBuffer* renderBuffer, int32_t deviceO
  * node/triangle counters (slower; measurement runs only). */
 int giCGetRenderStats(const GiCScene* scene, GiCRenderStats* out);
 #define GI_C_SCENE_OPTION_COUNT_TRAVERSAL 1
+/* value N > 0: record HIP events around the stage launches of every N-th wavefront iteration (1 = every launch; events
+ * on every launch cost ~16 % of a frame) and scale the per-stage totals accordingly; 0 = off */
 #define GI_C_SCENE_OPTION_KERNEL_TIMERS 2
 int giCSetSceneOption(GiCScene* scene, int32_t option, int32_t value);
 /* [ext] closest hit of one ray through the device traversal kernel (parity tests of the BVH8 path).

@@ -2,8 +2,9 @@
 import os, sys, json, subprocess
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def run(env, spp=256):
+    extra = env.pop("ARGS", "").split() if "ARGS" in env else []
     e = dict(os.environ); e.update(env)
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--spp", str(spp), "--no-cpu-baseline"], env=e, capture_output=True, text=True)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--spp", str(spp), "--no-cpu-baseline"] + extra, env=e, capture_output=True, text=True)
     line = [l for l in out.stdout.splitlines() if l.startswith("{")]
     if not line:
         print(env, "FAILED", out.stderr[-500:]); return
