@@ -65,12 +65,14 @@ def cpu_baseline(desc, rs, w, h, budget_s=12.0):
                       f"{cnt['segments'] / cnt['samples']:.3f} segments/sample"}
 
 
-def load_pmc_traffic():
-    """HBM bytes per k_trace launch from the committed rocprofv3 --pmc summary (profiles/), or None."""
+def load_pmc_traffic(workload):
+    """HBM bytes per k_trace launch from the committed rocprofv3 --pmc summary (profiles/pmc_traffic.json, produced by
+    tools/summarize_profile.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command), or None."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(p):
         try:
-            return json.load(open(p)).get("trace_bytes_per_launch")
+            j = json.load(open(p))
+            return j.get("trace_bytes_per_launch") if j.get("workload") == workload else None
         except Exception:
             return None
     return None
@@ -172,7 +174,7 @@ def main():
         seg_per_sample = rays / max(1, sum(s["samples"] for s in stats))
         stream_only = (samples_per_step * args.steps / dt) * seg_per_sample * 192.0 / 1e9  # whole-pipeline stream floor
         roofline = {"bound": "hbm", "kernel": "k_trace<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": load_pmc_traffic(),
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": load_pmc_traffic(args.workload),
                     "bytes_per_launch": round(bytes_total / max(1, launches), 1), "avg_launch_us": round(trace_ms * 1e3 / max(1, launches), 3),
                     "nodes_per_ray": round(nodes_per_ray, 3), "tris_per_ray": round(tris_per_ray, 3),
                     "stage_ms_per_step": {k: round(sum(s[k] for s in stats) / args.steps, 3) for k in ("raygenMs", "traceMs", "shadeMs", "shadowMs")},

@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--write")
     ap.add_argument("--tag", required=True)
     ap.add_argument("--note", default="")
+    ap.add_argument("--workload", default="c2")
+    ap.add_argument("--spp", type=int, default=64)
     args = ap.parse_args()
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     ks = kernel_stats(args.kernel_trace)
@@ -76,7 +78,9 @@ def main():
             js["trace_bytes_per_launch"] = tk["hbm_bytes_per_launch"]
     json.dump(js, open(os.path.join(ROOT, "profiles", f"{args.tag}_rocprofv3_summary.json"), "w"), indent=1)
     if pmc and "trace_bytes_per_launch" in js:
-        json.dump({"tag": args.tag, "trace_bytes_per_launch": js["trace_bytes_per_launch"], "source": os.path.basename(txt)},
+        json.dump({"tag": args.tag, "workload": args.workload, "spp": args.spp, "trace_bytes_per_launch": js["trace_bytes_per_launch"],
+                   "note": "HBM bytes per k_trace<closest> launch = 2*FETCH_SIZE + WRITE_SIZE (separate --pmc passes); launches at this spp carry the same "
+                           "ray count per launch as the full-spp run once all pixels are active", "source": os.path.basename(txt)},
                   open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
     print("\n".join(lines))
 
