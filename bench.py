@@ -48,7 +48,7 @@ def make_workload(name, spp_override=None):
     return desc, rs, w, h, label
 
 
-def cpu_baseline(desc, rs, w, h, budget_s=12.0):
+def cpu_baseline(desc, rs, w, h, budget_s=7.0):
     """The CPU oracle (kind "port") on this box's host cores, on a bounded sample of the same workload: the full
     frame at a reduced spp chosen so the run takes ~budget_s (throughput is per sample, so it scales linearly)."""
     import copy

@@ -231,6 +231,8 @@ struct GiCScene {
   uint32_t nodeCount = 0, triCount = 0, bvhDepth = 0;
   // path state
   DeviceBuffer<Slot> slots;
+  DeviceBuffer<float> sampleBuf; // per-sample colours of the current batch, [sample][pixel][3]
+  DeviceBuffer<F4> accum;        // per-pixel running sum across batches
   DeviceBuffer<uint32_t> qSlot[Q_COUNT]; // NSHARD segments of queueCap records each
   DeviceBuffer<F4> qA[Q_COUNT], qB[Q_COUNT], qC[Q_COUNT];
   uint32_t queueCap = 0;
@@ -239,6 +241,7 @@ struct GiCScene {
   // options + stats
   bool countTraversal = false, kernelTimers = false;
   uint32_t kernelTimerStride = 1;
+  uint64_t optPoolSlots = 0, optSampleBufferMb = 0; // 0 = default
   GiCRenderStats stats{};
   std::vector<hipEvent_t> eventPool;
 };
@@ -292,7 +295,7 @@ void giCDestroyScene(GiCScene* s)
   (void)hipStreamSynchronize(g_ctx.stream);
   s->dNodes.release(); s->dTris.release(); s->dInstances.release(); s->dVerts.release();
   s->dMaterials.release(); s->dSphere.release(); s->dDistant.release(); s->dRect.release(); s->dDisk.release();
-  s->slots.release();
+  s->slots.release(); s->sampleBuf.release(); s->accum.release();
   for (uint32_t q = 0; q < Q_COUNT; q++) { s->qSlot[q].release(); s->qA[q].release(); s->qB[q].release(); s->qC[q].release(); }
   s->dCounters.release();
   if (s->hCounters) (void)hipHostFree(s->hCounters);
@@ -561,6 +564,8 @@ int giCSetSceneOption(GiCScene* scene, int32_t option, int32_t value)
   if (!scene) return GI_C_ERROR;
   if (option == GI_C_SCENE_OPTION_COUNT_TRAVERSAL) { scene->countTraversal = value != 0; return GI_C_OK; }
   if (option == GI_C_SCENE_OPTION_KERNEL_TIMERS) { scene->kernelTimers = value != 0; scene->kernelTimerStride = value > 0 ? (uint32_t)value : 1u; return GI_C_OK; }
+  if (option == GI_C_SCENE_OPTION_POOL_SLOTS) { scene->optPoolSlots = value > 0 ? (uint64_t)value : 0; return GI_C_OK; }
+  if (option == GI_C_SCENE_OPTION_SAMPLE_BUFFER_MB) { scene->optSampleBufferMb = value > 0 ? (uint64_t)value : 0; return GI_C_OK; }
   setError("unknown scene option"); return GI_C_ERROR;
 }
 
@@ -805,8 +810,8 @@ extern "C" int giCRender(const GiCRenderParams* params)
   if (colorRb->stride != 16) { setError("giCRender: colour AOV needs a Float32Vec4 buffer"); return GI_C_ERROR; }
 
   // --- uniforms (Gi.cpp:2373-2426; camera terms rp_main.rgen:199-212 evaluated once on the host)
-  const size_t slots = (size_t)(rowEnd - rowBegin) * width;
-  if (slots == 0) return GI_C_OK;
+  const size_t pixels = (size_t)(rowEnd - rowBegin) * width;
+  if (pixels == 0) return GI_C_OK;
   FrameUniforms U{};
   {
     const GiCCameraDesc& c = params->camera;
@@ -839,7 +844,7 @@ extern "C" int giCRender(const GiCRenderParams* params)
     U.invTotalSampleCount = 1.0f / float(s->sampleOffset + rs.spp);
     U.maxSampleValue = rs.maxSampleValue; U.rrInvMinTermProb = rs.rrInvMinTermProb; U.lightIntensityMultiplier = rs.lightIntensityMultiplier;
     U.maxBounces = std::min(rs.maxBounces, 0xfffu); U.rrBounceOffset = rs.rrBounceOffset & 0xffffu;
-    U.imageWidth = width; U.imageHeight = height; U.rowBegin = rowBegin; U.pixelCount = (uint32_t)slots;
+    U.imageWidth = width; U.imageHeight = height; U.rowBegin = rowBegin; U.pixelCount = (uint32_t)pixels;
     U.flags = (rs.jitteredSampling ? FLAG_JITTER : 0u) | (rs.filterImportanceSampling ? FLAG_FIS : 0u) | (rs.depthOfField ? FLAG_DOF : 0u) |
               (rs.clippingPlanes ? FLAG_CLIP : 0u) | (rs.nextEventEstimation ? FLAG_NEE : 0u) | (rs.progressiveAccumulation ? FLAG_PROGRESSIVE : 0u);
     U.sphereCount = (uint32_t)s->sphereLights.recs.size(); U.distantCount = (uint32_t)s->distantLights.recs.size();
@@ -847,12 +852,23 @@ extern "C" int giCRender(const GiCRenderParams* params)
     U.totalLightCount = U.sphereCount + U.distantCount + U.rectCount + U.diskCount;
   }
 
-  // persistent grids: blocks per CU limited by registers (<= 7 waves/SIMD for k_trace) and, for k_trace, by the LDS it stages
+  // --- work decomposition (DESIGN.md "Persistent path pool"): work item = (pixel, sample); the frame is cut into batches of
+  // consecutive samples whose per-sample colour buffer fits the budget; a pool of `slots` paths is kept full from a running
+  // work counter until the batch's items run out.
+  auto envU64 = [](const char* name, uint64_t def) { const char* e = getenv(name); return e ? (uint64_t)strtoull(e, nullptr, 10) : def; };
+  const uint64_t budgetBytes = envU64("GATLING_SAMPLE_BUFFER_MB", s->optSampleBufferMb ? s->optSampleBufferMb : 2048) << 20;
+  const uint64_t poolMax = std::max<uint64_t>(64, envU64("GATLING_POOL_SLOTS", s->optPoolSlots ? s->optPoolSlots : (4u << 20)));
+  uint64_t batchSamples = std::min<uint64_t>(rs.spp, std::max<uint64_t>(1, budgetBytes / (pixels * 12)));
+  batchSamples = std::min<uint64_t>(batchSamples, std::max<uint64_t>(1, 0xffffffffull / pixels)); // work ids stay 32-bit
+  const uint32_t numBatches = (uint32_t)((rs.spp + batchSamples - 1) / batchSamples);
+  const size_t slots = (size_t)std::min<uint64_t>(poolMax, (uint64_t)pixels * batchSamples);
+
+  // persistent grids: blocks per CU limited by registers (<= 6 waves/SIMD for k_trace) and, for k_trace, by the LDS it stages
   uint32_t wideBlocks, traceBlocks;
   {
     SceneView v0 = makeView(s);
     uint32_t ln, lt, ldsBytes; traceLdsLayout(v0, ln, lt, ldsBytes);
-    uint32_t perCu = std::min<uint32_t>(7u, (160u * 1024u) / (ldsBytes + 256u));
+    uint32_t perCu = std::min<uint32_t>(6u, (160u * 1024u) / (ldsBytes + 256u));
     if (const char* e = getenv("GATLING_TRACE_BLOCKS_PER_CU")) perCu = (uint32_t)atoi(e);
     uint32_t widePerCu = 8u;
     if (const char* e = getenv("GATLING_WIDE_BLOCKS_PER_CU")) widePerCu = (uint32_t)atoi(e);
@@ -861,17 +877,16 @@ extern "C" int giCRender(const GiCRenderParams* params)
     traceBlocks = (uint32_t)std::min<size_t>((slots + 255) / 256, (size_t)g_ctx.cuCount * perCu);
   }
   if (ensurePathState(s, slots, wideBlocks, traceBlocks) != GI_C_OK) return GI_C_ERROR;
+  if (s->sampleBuf.alloc(pixels * batchSamples * 3) || s->accum.alloc(pixels)) return GI_C_ERROR;
   PathState ps{s->slots.ptr};
   SceneView view = makeView(s);
   QueueSet qs = makeQueueSet(s);
   F4* colorOut = reinterpret_cast<F4*>(colorRb->deviceMem);
   const bool nee = rs.nextEventEstimation != 0;
 
-  // --- the bounce loop (rp_main.rgen:215, 295): every slot advances one stage per iteration
+  // --- the bounce loop (rp_main.rgen:215, 295): every pool slot advances one stage per iteration
   HIP_TRY(hipStreamSynchronize(st));
   double tStart = nowMs();
-  launchInit(st, ps, qs, s->dCounters.ptr, (uint32_t)slots);
-  const uint64_t maxIters = (uint64_t)rs.spp * std::max(1u, U.maxBounces) + 2u;
   uint32_t iters = 0, traceLaunches = 0;
   size_t ev = 0;
   std::vector<int> evKind; // 0 raygen, 1 trace, 2 shade, 3 shadow
@@ -879,31 +894,42 @@ extern "C" int giCRender(const GiCRenderParams* params)
   // HIP events around the stage launches of every `timerStride`-th iteration (events on every launch cost ~16 % of the
   // frame); per-stage totals are scaled back up by the sampling factor.
   const uint32_t timerStride = std::max(1u, s->kernelTimerStride);
-  uint64_t curIter = 0, sampledIters = 0;
+  uint64_t curIter = 0, sampledIters = 0, totalIters = 0;
   auto timed = [&](int kind, auto&& fn) {
     if (timers && (curIter % timerStride) == 0u) { (void)hipEventRecord(poolEvent(s, ev), st); fn(); (void)hipEventRecord(poolEvent(s, ev + 1), st); ev += 2; evKind.push_back(kind); }
     else fn();
   };
   const uint32_t pollEvery = 16;
-  for (uint64_t it = 0; it < maxIters; it++) {
-    const uint32_t par = (uint32_t)(it & 1u);
-    curIter = it; if (timers && (it % timerStride) == 0u) sampledIters++;
-    timed(0, [&] { launchRaygen(st, wideBlocks, U, ps, qs, s->dCounters.ptr, par, colorOut); });
-    if (it >= rs.spp && (it % pollEvery) == 0u) { // a slot needs >= spp iterations; afterwards poll the queue sizes
-      HIP_TRY(hipMemcpyAsync(s->hCounters, s->dCounters.ptr, sizeof(PaddedCounter) * Q_COUNT * NSHARD, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipStreamSynchronize(st));
-      uint32_t pending = 0; for (uint32_t k = 0; k < NSHARD; k++) pending += s->hCounters->count[Q_TRACE_A + par][k].v;
-      if (pending == 0) break; // raygen consumed the regen queue and produced no rays: done
+  for (uint32_t batch = 0; batch < numBatches; batch++) {
+    U.batchFirstSample = (uint32_t)(batch * batchSamples);
+    U.batchSamples = (uint32_t)std::min<uint64_t>(batchSamples, rs.spp - (uint64_t)batch * batchSamples);
+    U.workTotal = (uint32_t)(pixels * U.batchSamples);
+    const uint32_t poolNow = (uint32_t)std::min<uint64_t>(slots, U.workTotal);
+    U.poolSlots = poolNow;
+    launchInit(st, ps, qs, s->dCounters.ptr, poolNow, batch == 0);
+    const uint64_t rounds = ((uint64_t)U.workTotal + poolNow - 1) / poolNow; // raygen rounds needed to hand out all work
+    const uint64_t maxIters = (rounds + 2) * (std::max(1u, U.maxBounces) + 1) + 8;
+    for (uint64_t it = 0; it < maxIters; it++) {
+      const uint32_t par = (uint32_t)(it & 1u);
+      curIter = totalIters; if (timers && (totalIters % timerStride) == 0u) sampledIters++;
+      timed(0, [&] { launchRaygen(st, wideBlocks, U, ps, qs, s->dCounters.ptr, par, s->sampleBuf.ptr); });
+      if (it >= rounds && (it % pollEvery) == 0u) { // all work cannot be handed out earlier; afterwards poll the queue sizes
+        HIP_TRY(hipMemcpyAsync(s->hCounters, s->dCounters.ptr, sizeof(PaddedCounter) * Q_COUNT * NSHARD, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        uint32_t pending = 0; for (uint32_t k = 0; k < NSHARD; k++) pending += s->hCounters->count[Q_TRACE_A + par][k].v;
+        if (pending == 0) { totalIters++; break; } // raygen consumed the regen queue and produced no rays: the pool has drained
+      }
+      timed(1, [&] { launchTrace(st, traceBlocks, false, s->countTraversal, view, ps, qs, s->dCounters.ptr, Q_TRACE_A + par, Q_REGEN_A + (par ^ 1u)); });
+      traceLaunches++;
+      timed(2, [&] { launchShade(st, wideBlocks, U, view, ps, qs, s->dCounters.ptr, par); });
+      if (nee) timed(3, [&] { launchTrace(st, traceBlocks, true, s->countTraversal, view, ps, qs, s->dCounters.ptr, Q_SHADOW, Q_SHADOW); });
+      iters++; totalIters++;
     }
-    timed(1, [&] { launchTrace(st, traceBlocks, false, s->countTraversal, view, ps, qs, s->dCounters.ptr, Q_TRACE_A + par, Q_REGEN_A + (par ^ 1u)); });
-    traceLaunches++;
-    timed(2, [&] { launchShade(st, wideBlocks, U, view, ps, qs, s->dCounters.ptr, par); });
-    if (nee) timed(3, [&] { launchTrace(st, traceBlocks, true, s->countTraversal, view, ps, qs, s->dCounters.ptr, Q_SHADOW, Q_SHADOW); });
-    iters++;
+    launchAccumulate(st, U, s->sampleBuf.ptr, s->accum.ptr, colorOut, batch == 0, batch + 1 == numBatches);
   }
   HIP_TRY(hipMemcpyAsync(s->hCounters, s->dCounters.ptr, sizeof(Counters), hipMemcpyDeviceToHost, st));
   if (!colorRb->deviceOnly) {
-    size_t off = (size_t)rowBegin * width * 16, bytes = slots * 16;
+    size_t off = (size_t)rowBegin * width * 16, bytes = pixels * 16;
     HIP_TRY(hipMemcpyAsync((uint8_t*)colorRb->hostMem + off, (uint8_t*)colorRb->deviceMem + off, bytes, hipMemcpyDeviceToHost, st));
   }
   HIP_TRY(hipStreamSynchronize(st));
@@ -911,7 +937,7 @@ extern "C" int giCRender(const GiCRenderParams* params)
   double tEnd = nowMs();
 
   GiCRenderStats& S = s->stats;
-  S.renderMs = tEnd - tStart; S.samples = (uint64_t)slots * rs.spp; S.iterations = iters; S.traceLaunches = traceLaunches;
+  S.renderMs = tEnd - tStart; S.samples = (uint64_t)pixels * rs.spp; S.iterations = iters; S.traceLaunches = traceLaunches;
   S.segments = s->hCounters->segments; S.shadowRays = s->hCounters->shadowRays; S.nodesVisited = s->hCounters->nodesVisited; S.trisTested = s->hCounters->trisTested;
   S.shadowNodesVisited = s->hCounters->shadowNodesVisited; S.shadowTrisTested = s->hCounters->shadowTrisTested;
   S.traceMs = S.shadeMs = S.raygenMs = S.shadowMs = 0.0;
@@ -921,7 +947,7 @@ extern "C" int giCRender(const GiCRenderParams* params)
       if (evKind[k] == 0) S.raygenMs += ms; else if (evKind[k] == 1) S.traceMs += ms; else if (evKind[k] == 2) S.shadeMs += ms; else S.shadowMs += ms;
     }
     // scale the sampled totals to the whole frame (the early-exit poll can leave one raygen-only iteration unsampled)
-    const double scale = sampledIters ? (double)(iters + 1) / (double)sampledIters : 1.0;
+    const double scale = sampledIters ? (double)totalIters / (double)sampledIters : 1.0;
     S.raygenMs *= scale; S.traceMs *= scale; S.shadeMs *= scale; S.shadowMs *= scale;
   }
   s->sampleOffset += rs.spp; // Gi.cpp:2515

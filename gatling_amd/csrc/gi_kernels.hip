@@ -100,9 +100,9 @@ __device__ __forceinline__ void zero_next_counters(Counters* cnt, uint32_t par)
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_init: every slot starts in regen queue A with "no sample in flight"
+// k_init: every pool slot starts in regen queue A with "no sample in flight"; no work handed out yet
 // ------------------------------------------------------------------------------------------------
-__global__ void k_init(PathState st, QueueSet qs, Counters* cnt, uint32_t n)
+__global__ void k_init(PathState st, QueueSet qs, Counters* cnt, uint32_t n, uint32_t resetStats)
 {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t per = (n + NSHARD - 1u) / NSHARD; // regen segment s = slots [s*per, min(n,(s+1)*per))
@@ -112,23 +112,32 @@ __global__ void k_init(PathState st, QueueSet qs, Counters* cnt, uint32_t n)
     if (q == Q_REGEN_A) { const uint32_t lo = sdx * per; c = lo < n ? ((n - lo) < per ? (n - lo) : per) : 0u; }
     cnt->count[q][sdx].v = c;
   }
-  if (i == 0) { cnt->segments = 0; cnt->shadowRays = 0; cnt->nodesVisited = 0; cnt->trisTested = 0; cnt->shadowNodesVisited = 0; cnt->shadowTrisTested = 0; }
+  if (i == 0) {
+    cnt->workBase[0].v = 0; cnt->workBase[1].v = 0;
+    if (resetStats) { cnt->segments = 0; cnt->shadowRays = 0; cnt->nodesVisited = 0; cnt->trisTested = 0; cnt->shadowNodesVisited = 0; cnt->shadowTrisTested = 0; }
+  }
   for (; i < n; i += gridDim.x * blockDim.x) {
-    st4(&st.slots[i].acc, 0.0f, 0.0f, 0.0f, u2f(0xffffffffu));
+    st4(&st.slots[i].id, 0.0f, 0.0f, 0.0f, 0.0f);
     qs.slot[Q_REGEN_A][(i / per) * qs.cap + (i % per)] = i;
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_raygen: persistent-thread ray generation + per-sample finish (rp_main.rgen:213-283, 483-515) + the miss term
+// k_raygen: persistent-thread ray generation (rp_main.rgen:213-283), the per-sample finish (:483-498) and the miss
+// term.  Entry i of the regen queue finishes its sample (if any) into the per-sample colour buffer and takes work item
+// workBase + i = (pixel w % P, sample w / P) -- consecutive entries get adjacent pixels of the same sample index.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st, QueueSet qs, Counters* cnt, uint32_t par, F4* __restrict__ colorOut)
+__global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st, QueueSet qs, Counters* cnt, uint32_t par, float* __restrict__ sampleBuf)
 {
   __shared__ AppendScratch<1> sh;
   const uint32_t qIn = Q_REGEN_A + par, qOut = Q_TRACE_A + par;
   QueueReader rd; reader_init(rd, cnt, qIn, qs.cap);
-  if (blockIdx.x == 0) zero_next_counters(cnt, par);
   const uint32_t n = rd.pre[NSHARD];
+  const uint32_t workBase = cnt->workBase[par].v;
+  if (blockIdx.x == 0) {
+    zero_next_counters(cnt, par);
+    if (threadIdx.x == 0) { const uint32_t left = U.workTotal - workBase; cnt->workBase[par ^ 1u].v = workBase + (n < left ? n : left); }
+  }
   const uint32_t stride = gridDim.x * BLOCK;
   uint32_t trip = 0;
   for (uint32_t base = blockIdx.x * BLOCK; base < n; base += stride, trip++) {
@@ -139,10 +148,8 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st,
       const uint32_t entry = qs.slot[qIn][reader_index(rd, i)];
       slot = entry & ~REGEN_MISSED;
       Slot* S = &st.slots[slot];
-      F4 acc = ld4(&S->acc);
-      uint32_t s = f2u(acc.w);
-      V3 pixelColor = v3(acc.x, acc.y, acc.z);
-      if (s != 0xffffffffu) { // finish the sample that just terminated (:489-498)
+      const F4 id = ld4(&S->id);
+      if (f2u(id.z) != 0u) { // finish the sample that just terminated (:489-496) -> per-sample colour buffer
         F4 r = ld4(&S->rad);
         V3 rad = v3(r.x, r.y, r.z);
         if (entry & REGEN_MISSED) {
@@ -153,16 +160,18 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st,
         }
         float mv = fmax2(rad.x, fmax2(rad.y, rad.z));
         if (mv > U.maxSampleValue) rad = rad * (U.maxSampleValue / mv);
-        V3 sc = v3(fmax2(0.0f, rad.x), fmax2(0.0f, rad.y), fmax2(0.0f, rad.z));
-        pixelColor = pixelColor + sc * U.invSpp;
+        float* dst = sampleBuf + ((size_t)f2u(id.y) * U.pixelCount + f2u(id.x)) * 3u;
+        dst[0] = fmax2(0.0f, rad.x); dst[1] = fmax2(0.0f, rad.y); dst[2] = fmax2(0.0f, rad.z);
       }
-      s = s + 1u; // 0xffffffff + 1 == 0
-      const uint32_t pixelIndex = U.rowBegin * U.imageWidth + slot; // :195 (global index: RNG is tile independent)
-      more = s < U.spp;
+      const uint32_t w = workBase + i; // < 2^32 by construction of the batches (host)
+      more = (i < U.workTotal - workBase) && (w < U.workTotal);
       if (more) {
+        const uint32_t pixelLocal = w % U.pixelCount, sLocal = w / U.pixelCount;
+        const uint32_t pixelIndex = U.rowBegin * U.imageWidth + pixelLocal; // :195 (global index: RNG is tile independent)
+        const uint32_t sampleIndex = U.sampleOffset + U.batchFirstSample + sLocal;
         const uint32_t px = pixelIndex % U.imageWidth, py = pixelIndex / U.imageWidth;
-        uint32_t rng = gi_hash_init(pixelIndex * ((U.sampleOffset + s) + 1u)); // :223, common.glsl:121-124
-        float r0 = gi_next1f(rng), r1 = gi_next1f(rng);                       // :224 (always drawn)
+        uint32_t rng = gi_hash_init(pixelIndex * (sampleIndex + 1u)); // :223, common.glsl:121-124
+        float r0 = gi_next1f(rng), r1 = gi_next1f(rng);               // :224 (always drawn)
         float sox = 0.5f, soy = 0.5f;
         if (U.flags & FLAG_JITTER) {
           if (U.flags & FLAG_FIS) { float gx, gy; gi_fis_gauss(r0, r1, gx, gy); sox = 0.5f + gx; soy = 0.5f + gy; }
@@ -189,12 +198,7 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st,
         }
         st4(&S->thr, 1.0f, 1.0f, 1.0f, u2f(0u)); // :274-276
         st4(&S->rad, 0.0f, 0.0f, 0.0f, u2f(rng));
-        st4(&S->acc, pixelColor.x, pixelColor.y, pixelColor.z, u2f(s));
-      } else { // :506-515
-        V3 prev = pixelColor;
-        if ((U.flags & FLAG_PROGRESSIVE) && U.sampleOffset > 0u) { F4 p = ld4(&colorOut[pixelIndex]); prev = v3(p.x, p.y, p.z); }
-        V3 c = (prev * U.sampleOffsetF + pixelColor * U.sppF) * U.invTotalSampleCount;
-        st4(&colorOut[pixelIndex], c.x, c.y, c.z, 1.0f);
+        st4(&S->id, u2f(pixelLocal), u2f(sLocal), u2f(1u), 0.0f);
       }
     }
     const bool pred[1] = {more}; const uint32_t qid[1] = {qOut}; uint32_t idx[1];
@@ -205,6 +209,30 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st,
       st4(&qs.b[qOut][idx[0]], dir.x, dir.y, dir.z, tMax);
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_accumulate: folds one batch of per-sample colours into the per-pixel running sum IN SAMPLE ORDER
+// (pixel_color += sample_color * invSpp, rp_main.rgen:498) and, after the last batch, writes the colour AOV with
+// the progressive blend of rp_main.rgen:506-515.  One thread per pixel; reads are coalesced across pixels.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_accumulate(FrameUniforms U, const float* __restrict__ sampleBuf, F4* __restrict__ accum, F4* __restrict__ colorOut,
+                                                      uint32_t firstBatch, uint32_t lastBatch)
+{
+  const uint32_t p = blockIdx.x * BLOCK + threadIdx.x;
+  if (p >= U.pixelCount) return;
+  V3 pixelColor = v3(0.0f, 0.0f, 0.0f);
+  if (!firstBatch) { const F4 a = ld4(&accum[p]); pixelColor = v3(a.x, a.y, a.z); }
+  for (uint32_t s = 0; s < U.batchSamples; s++) {
+    const float* src = sampleBuf + ((size_t)s * U.pixelCount + p) * 3u;
+    pixelColor = pixelColor + v3(src[0], src[1], src[2]) * U.invSpp;
+  }
+  if (!lastBatch) { st4(&accum[p], pixelColor.x, pixelColor.y, pixelColor.z, 0.0f); return; }
+  const uint32_t pixelIndex = U.rowBegin * U.imageWidth + p;
+  V3 prev = pixelColor;
+  if ((U.flags & FLAG_PROGRESSIVE) && U.sampleOffset > 0u) { const F4 q = ld4(&colorOut[pixelIndex]); prev = v3(q.x, q.y, q.z); }
+  const V3 c = (prev * U.sampleOffsetF + pixelColor * U.sppF) * U.invTotalSampleCount;
+  st4(&colorOut[pixelIndex], c.x, c.y, c.z, 1.0f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -782,14 +810,18 @@ __global__ void k_debug_bsdf(const MaterialRec* mat, uint32_t count, const float
 // ------------------------------------------------------------------------------------------------
 // host-callable launchers
 // ------------------------------------------------------------------------------------------------
-void launchInit(hipStream_t s, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t n)
+void launchInit(hipStream_t s, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t n, bool resetStats)
 {
   uint32_t blocks = (n + 255u) / 256u; if (blocks > 4096u) blocks = 4096u; if (blocks == 0u) blocks = 1u;
-  hipLaunchKernelGGL(k_init, dim3(blocks), dim3(256), 0, s, st, qs, cnt, n);
+  hipLaunchKernelGGL(k_init, dim3(blocks), dim3(256), 0, s, st, qs, cnt, n, resetStats ? 1u : 0u);
 }
-void launchRaygen(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par, F4* colorOut)
+void launchRaygen(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par, float* sampleBuf)
 {
-  hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(BLOCK), 0, s, U, st, qs, cnt, par, colorOut);
+  hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(BLOCK), 0, s, U, st, qs, cnt, par, sampleBuf);
+}
+void launchAccumulate(hipStream_t s, const FrameUniforms& U, const float* sampleBuf, F4* accum, F4* colorOut, bool firstBatch, bool lastBatch)
+{
+  hipLaunchKernelGGL(k_accumulate, dim3((U.pixelCount + BLOCK - 1u) / BLOCK), dim3(BLOCK), 0, s, U, sampleBuf, accum, colorOut, firstBatch ? 1u : 0u, lastBatch ? 1u : 0u);
 }
 static uint32_t traceStackEntries(const SceneView& sc) { return sc.bvhDepth <= 8u ? 8u : 16u; }
 void traceLdsLayout(const SceneView& sc, uint32_t& ldsNodes, uint32_t& ldsTris, uint32_t& bytes)

@@ -89,10 +89,12 @@ struct FrameUniforms {
   float invSpp, sppF, sampleOffsetF, invTotalSampleCount;
   float maxSampleValue, rrInvMinTermProb, lightIntensityMultiplier, exposureScale;
   uint32_t spp, sampleOffset, maxBounces, rrBounceOffset;
-  uint32_t imageWidth, imageHeight, rowBegin, pixelCount; // pixelCount = slots of this tile
+  uint32_t imageWidth, imageHeight, rowBegin, pixelCount; // pixelCount = pixels of this tile
+  uint32_t batchFirstSample, batchSamples, workTotal, poolSlots; // this batch: samples [first, first+count) of every tile pixel
   uint32_t flags; // FLAG_*
   uint32_t sphereCount, distantCount, rectCount, diskCount, totalLightCount;
   uint32_t pad[2];
+  uint32_t pad2[4];
 };
 enum : uint32_t {
   FLAG_JITTER = 1u, FLAG_FIS = 2u, FLAG_DOF = 4u, FLAG_CLIP = 8u, FLAG_NEE = 16u, FLAG_PROGRESSIVE = 32u,
@@ -114,16 +116,18 @@ struct SceneView {
   uint32_t bvhDepth; // levels of the BVH8 (bounds the traversal stack)
 };
 
-// Per-pixel path state that persists across stages: ONE 64-byte record per slot (one slot per pixel of the tile).
+// Path state that persists across stages: ONE 64-byte record per slot of the persistent path pool.  A slot carries one
+// (pixel, sample) work item at a time; when its path ends k_raygen hands it the next item (work id = running base +
+// position in the regen queue: no atomics), so the pool stays full until the work runs out, whatever the tile size.
 // Everything that merely flows from one stage to the next (rays, hits, shadow rays) lives in the queues as records
 // written/read in queue order (coalesced); only this record is gathered/scattered by slot index, and 64 B is one
-// fabric request.  2.07 M slots = 133 MB at 1080p: resident in the 256 MB Infinity Cache.
+// fabric request.  A 4 M-slot pool is 268 MB.
 struct alignas(16) F4 { float x, y, z, w; };
 
 struct alignas(64) Slot {
   F4 thr;  // throughput.xyz, asfloat(bitfield)   (rp_main_payload.glsl:24-33)
   F4 rad;  // radiance.xyz, asfloat(rng state)
-  F4 acc;  // pixel_color accumulator.xyz, asfloat(sample index in flight | 0xffffffff = none yet)
+  F4 id;   // asfloat(pixel index inside the tile), asfloat(sample index inside the batch), asfloat(1 = a sample is in flight), -
   F4 pad;
 };
 static_assert(sizeof(Slot) == 64, "Slot must be 64 bytes");
@@ -154,6 +158,7 @@ struct QueueSet {
 struct alignas(128) PaddedCounter { uint32_t v; uint32_t pad[31]; };
 struct Counters {
   PaddedCounter count[Q_COUNT][NSHARD];
+  PaddedCounter workBase[2]; // work items handed out before iteration parity p (k_raygen reads [p], writes [p^1])
   unsigned long long segments, shadowRays, nodesVisited, trisTested, shadowNodesVisited, shadowTrisTested;
 };
 

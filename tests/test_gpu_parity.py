@@ -154,6 +154,27 @@ def test_row_sharding_is_bit_identical(gi):
     assert np.array_equal(np.concatenate(parts).view(np.uint32), full.view(np.uint32))
 
 
+def test_pool_and_batch_invariance(gi, orc):
+    """Scheduling knobs must not change a bit: a 64-slot pool (every slot carries hundreds of work items in turn), a
+    pool larger than the work, and a 1 MiB sample buffer (several sample batches per frame, each with its own drain +
+    in-order accumulate) all reproduce the oracle image exactly."""
+    desc = cornell_box()
+    rs = RenderSettings(spp=24, max_bounces=6)
+    w, h = 160, 90
+    ref, cnt = orc.render(desc, rs, w, h, threads=4)
+    for pool, mb in ((64, 0), (1000, 1), (0, 1), (1 << 22, 0)):
+        sc = gi.Scene(desc)
+        try:
+            sc.set_option(gi.OPTION_POOL_SLOTS, pool)
+            sc.set_option(gi.OPTION_SAMPLE_BUFFER_MB, mb)
+            img = sc.render(rs, w, h)
+            st = sc.stats()
+        finally:
+            sc.close()
+        assert st["segments"] == cnt["segments"]
+        assert_image_parity(img, ref, exact=True)
+
+
 def test_edge_cases(gi, orc):
     """Empty scene, 1x1 target (the reference's Render.Empty1x1), invisible / instance-less / material-less meshes."""
     cam = CameraDesc(position=(0, 0, 5))
