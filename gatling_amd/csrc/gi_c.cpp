@@ -137,6 +137,30 @@ void decodeDirection(uint32_t e, float out[3])
 void deriveMaterialConstants(MaterialRec& m)
 {
   const float* p = m.p;
+  if (m.klass == GI_C_MAT_OPEN_PBR) { // same fp32 formulas as the oracle's opbr_params (open_pbr_surface.mtlx:306-373)
+    float bw = p[GI_C_P_BASE_WEIGHT], sw = p[GI_C_P_SPECULAR_WEIGHT];
+    float r = p[GI_C_P_ROUGHNESS], cr = p[GI_C_P_CLEARCOAT_ROUGHNESS], coat = p[GI_C_P_CLEARCOAT];
+    float cior = p[GI_C_P_COAT_IOR], ior = p[GI_C_P_IOR];
+    float qc = (cior - 1.0f) / (cior + 1.0f);
+    float ratio = ior / cior, inv = cior / ior;
+    float etaCoated = (ratio > 1.0f) ? ratio : inv;
+    float etaS = etaCoated * coat + ior * (1.0f - coat);
+    float q = (etaS - 1.0f) / (etaS + 1.0f);
+    float f0 = sw * (q * q); f0 = f0 > 0.0f ? f0 : 0.0f; f0 = f0 < 0.99999f ? f0 : 0.99999f;
+    float eps = ((etaS - 1.0f) > 0.0f ? 1.0f : ((etaS - 1.0f) < 0.0f ? -1.0f : 0.0f)) * sqrtf(f0);
+    float depth = p[GI_C_P_TRANSMISSION_DEPTH];
+    float out[MAT_PARAM_COUNT]; memcpy(out, p, sizeof(out));
+    for (int i = 0; i < 3; i++) {
+      out[MP_ALBEDO + i] = p[GI_C_P_BASE_COLOR + i] * bw;
+      out[MP_F0 + i] = p[GI_C_P_SPECULAR_COLOR + i] * sw;
+      float tc = p[GI_C_P_TRANSMISSION_COLOR + i]; tc = tc > 1e-6f ? tc : 1e-6f;
+      out[MP_SIGMA_A + i] = (depth > 0.0f) ? -logf(tc) / depth : 0.0f;
+    }
+    out[MP_ALPHA] = (r * r > 0.001f) ? r * r : 0.001f; out[MP_COAT] = coat; out[MP_COAT_ALPHA] = (cr * cr > 0.001f) ? cr * cr : 0.001f;
+    out[MP_COAT_F0] = qc * qc; out[MP_ETA] = (1.0f + eps) / (1.0f - eps);
+    memcpy(m.p, out, sizeof(out));
+    return;
+  }
   float r = p[GI_C_P_ROUGHNESS], cr = p[GI_C_P_CLEARCOAT_ROUGHNESS];
   float alpha = (r * r > 0.001f) ? r * r : 0.001f, coatAlpha = (cr * cr > 0.001f) ? cr * cr : 0.001f;
   float albedo[3], F0[3];
@@ -306,7 +330,7 @@ void giCDestroyScene(GiCScene* s)
 GiCMaterial* giCCreateMaterial(GiCScene* scene, const char* name, const GiCMaterialDesc* desc)
 {
   if (!scene || !desc) { setError("giCCreateMaterial: null argument"); return nullptr; }
-  if (desc->klass > GI_C_MAT_USD_PREVIEW_SURFACE) { setError("giCCreateMaterial: unsupported material class"); return nullptr; }
+  if (desc->klass > GI_C_MAT_OPEN_PBR) { setError("giCCreateMaterial: unsupported material class"); return nullptr; }
   GiCMaterial* m = new GiCMaterial{scene, name ? name : "", *desc};
   std::lock_guard<std::mutex> g(scene->mutex);
   scene->materials.push_back(m);
@@ -843,6 +867,7 @@ extern "C" int giCRender(const GiCRenderParams* params)
     U.spp = rs.spp; U.sampleOffset = s->sampleOffset; U.invSpp = 1.0f / (float)rs.spp; U.sppF = (float)rs.spp; U.sampleOffsetF = (float)s->sampleOffset;
     U.invTotalSampleCount = 1.0f / float(s->sampleOffset + rs.spp);
     U.maxSampleValue = rs.maxSampleValue; U.rrInvMinTermProb = rs.rrInvMinTermProb; U.lightIntensityMultiplier = rs.lightIntensityMultiplier;
+    U.metersPerSceneUnit = rs.metersPerSceneUnit;
     U.maxBounces = std::min(rs.maxBounces, 0xfffu); U.rrBounceOffset = rs.rrBounceOffset & 0xffffu;
     U.imageWidth = width; U.imageHeight = height; U.rowBegin = rowBegin; U.pixelCount = (uint32_t)pixels;
     U.flags = (rs.jitteredSampling ? FLAG_JITTER : 0u) | (rs.filterImportanceSampling ? FLAG_FIS : 0u) | (rs.depthOfField ? FLAG_DOF : 0u) |

@@ -81,6 +81,19 @@ __device__ __forceinline__ float gi_logf(float x)
   return r;
 }
 
+// exp(x), x <= 0 (Beer-Lambert transmittance): Cephes expf kernel, plain mul/add
+__device__ __forceinline__ float gi_expf(float x)
+{
+  if (x < -87.0f) return 0.0f;
+  if (x > 0.0f) x = 0.0f;
+  float fx = floorf(x * 1.44269504088896341f + 0.5f);
+  x = x - fx * 0.693359375f;
+  x = x - fx * -2.12194440e-4f;
+  float z = x * x;
+  float y = (((((1.9875691500e-4f * x + 1.3981999507e-3f) * x + 8.3334519073e-3f) * x + 4.1665795894e-2f) * x + 1.6666665459e-1f) * x + 5.0000001201e-1f) * z + x + 1.0f;
+  return y * u2f((uint32_t)((int)fx + 127) << 23);
+}
+
 // half -> float (exact), for the packed diffuse/specular light multipliers (rp_main.chit:431)
 __device__ __forceinline__ float gi_half_to_float(uint32_t h)
 {

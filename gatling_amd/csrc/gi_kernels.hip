@@ -547,6 +547,130 @@ __device__ __forceinline__ UpsParams ups_params(const MaterialRec* m)
 struct BsdfSample { V3 k2, overPdf; float pdf; uint32_t event; };
 struct BsdfEval { V3 diffuse, glossy; float pdf; };
 
+// ---- class 2: OpenPBR (lobe graph of src/gi/mtlx/open_pbr_surface.mtlx:99-635, closed forms of our own) ----
+__device__ __forceinline__ float fresnel_dielectric(float c, float eta)
+{
+  float sin2t = (1.0f - c * c) / (eta * eta);
+  if (!(sin2t < 1.0f)) return 1.0f;
+  float ct = sqrtf(1.0f - sin2t);
+  float rs = (c - eta * ct) / (c + eta * ct);
+  float rp = (eta * c - ct) / (eta * c + ct);
+  return 0.5f * (rs * rs + rp * rp);
+}
+__device__ __forceinline__ V3 schlick_f82(V3 F0, V3 tint, float c)
+{
+  const float w5 = 0.462664366f, K = 17.6513846f;
+  V3 one = v3(1.0f, 1.0f, 1.0f);
+  V3 fb = F0 + (one - F0) * w5;
+  V3 a = (fb * (one - tint)) * K;
+  float m = 1.0f - c; m = fmin2(fmax2(m, 0.0f), 1.0f);
+  float m2 = m * m, m5 = m2 * m2 * m, m6 = m5 * m;
+  V3 f = (F0 + (one - F0) * m5) - a * (c * m6);
+  return v3(fmin2(fmax2(f.x, 0.0f), 1.0f), fmin2(fmax2(f.y, 0.0f), 1.0f), fmin2(fmax2(f.z, 0.0f), 1.0f));
+}
+struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint; float metalness, alpha, coat, coatAlpha, coatF0, eta, tw, specWeight; };
+__device__ __forceinline__ OpbrParams opbr_params(const MaterialRec* m)
+{
+  OpbrParams o; const float* p = m->p;
+  o.albedo = v3(p[MP_ALBEDO], p[MP_ALBEDO + 1], p[MP_ALBEDO + 2]);
+  o.metalTint = v3(p[MP_F0], p[MP_F0 + 1], p[MP_F0 + 2]);
+  o.specColor = v3(p[7], p[8], p[9]);
+  o.specWeight = p[18]; o.metalness = p[10];
+  o.alpha = p[MP_ALPHA]; o.coat = p[MP_COAT]; o.coatAlpha = p[MP_COAT_ALPHA]; o.coatF0 = p[MP_COAT_F0]; o.eta = p[MP_ETA];
+  o.coatTint = v3(1.0f, 1.0f, 1.0f) * (1.0f - o.coat) + v3(p[19], p[20], p[21]) * o.coat;
+  o.tw = p[23];
+  o.transTint = (p[28] > 0.0f) ? v3(1.0f, 1.0f, 1.0f) : v3(p[24], p[25], p[26]);
+  return o;
+}
+
+__device__ inline void opbr_sample(const MaterialRec* m, const ShState& st, V3 k1, float x0, float x1, float x2, BsdfSample& out)
+{
+  OpbrParams o = opbr_params(m);
+  V3 l1 = to_local(st, k1);
+  float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
+  float z = x2;
+  float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1));
+  if (z < Fc) {
+    GgxOut g = ggx_sample(l1, o.coatAlpha, x0, x1);
+    V3 k2 = to_world(st, g.l2);
+    if (!g.valid || !(dot(k2, st.geomNormal) > 0.0f)) return;
+    float Fh = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(g.kh));
+    float w = (Fh / Fc) * g.g2OverG1;
+    out.k2 = k2; out.pdf = Fc * g.pdf; out.overPdf = v3(w, w, w); out.event = EV_GLOSSY | EV_REFLECTION;
+    return;
+  }
+  z = (z - Fc) / (1.0f - Fc);
+  if (z < o.metalness) {
+    GgxOut g = ggx_sample(l1, o.alpha, x0, x1);
+    V3 k2 = to_world(st, g.l2);
+    if (!g.valid || !(dot(k2, st.geomNormal) > 0.0f)) return;
+    V3 F = schlick_f82(o.albedo, o.metalTint, g.kh) * o.specWeight;
+    out.k2 = k2; out.pdf = (1.0f - Fc) * o.metalness * g.pdf; out.overPdf = (F * o.coatTint) * g.g2OverG1; out.event = EV_GLOSSY | EV_REFLECTION;
+    return;
+  }
+  z = (z - o.metalness) / (1.0f - o.metalness);
+  float eta = st.frontFace ? o.eta : 1.0f / o.eta;
+  float Fd = fresnel_dielectric(nk1, eta);
+  if (z < Fd) {
+    GgxOut g = ggx_sample(l1, o.alpha, x0, x1);
+    V3 k2 = to_world(st, g.l2);
+    if (!g.valid || !(dot(k2, st.geomNormal) > 0.0f)) return;
+    float Fh = fresnel_dielectric(g.kh, eta);
+    out.k2 = k2; out.pdf = (1.0f - Fc) * (1.0f - o.metalness) * Fd * g.pdf;
+    out.overPdf = (o.specColor * o.coatTint) * ((Fh / Fd) * g.g2OverG1); out.event = EV_GLOSSY | EV_REFLECTION;
+    return;
+  }
+  z = (z - Fd) / (1.0f - Fd);
+  if (z < o.tw) {
+    GgxOut g = ggx_sample(l1, o.alpha, x0, x1);
+    V3 h = normalize(l1 + g.l2);
+    float kh = dot(l1, h);
+    if (!g.valid || !(kh > 0.0f)) return;
+    float Fh = fresnel_dielectric(kh, eta);
+    float sin2t = (1.0f - kh * kh) / (eta * eta);
+    if (!(sin2t < 1.0f)) return;
+    float ct = sqrtf(1.0f - sin2t);
+    V3 lt = h * (kh / eta - ct) - l1 * (1.0f / eta);
+    V3 k2 = to_world(st, lt);
+    if (!(lt.z < 0.0f) || !(dot(k2, st.geomNormal) < 0.0f)) return;
+    float a2 = o.alpha * o.alpha, nk2 = -lt.z;
+    float L1 = ggx_lambda_term(a2, nk1), L2 = ggx_lambda_term(a2, nk2);
+    float G1 = 2.0f * nk1 / (nk1 + L1), G2 = 2.0f * nk1 * nk2 / (nk2 * L1 + nk1 * L2);
+    float w = ((1.0f - Fh) / (1.0f - Fd)) * (G2 / G1);
+    out.k2 = normalize(k2); out.pdf = (1.0f - Fc) * (1.0f - o.metalness) * (1.0f - Fd) * o.tw * g.pdf;
+    out.overPdf = (o.transTint * o.coatTint) * w; out.event = EV_GLOSSY | EV_TRANSMISSION;
+    return;
+  }
+  V3 l = gi_sample_hemisphere(x0, x1);
+  V3 k2 = to_world(st, l);
+  if (!(l.z > 0.0f) || !(dot(k2, st.geomNormal) > 0.0f)) return;
+  out.k2 = k2; out.pdf = (1.0f - Fc) * (1.0f - o.metalness) * (1.0f - Fd) * (1.0f - o.tw) * (l.z / GI_PI);
+  out.overPdf = o.albedo * o.coatTint; out.event = EV_DIFFUSE | EV_REFLECTION;
+}
+
+__device__ inline void opbr_evaluate(const MaterialRec* m, const ShState& st, V3 k1, V3 k2, BsdfEval& out)
+{
+  OpbrParams o = opbr_params(m);
+  V3 l1 = to_local(st, k1), l2 = to_local(st, k2);
+  float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
+  float eta = st.frontFace ? o.eta : 1.0f / o.eta;
+  float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1));
+  float Fd = fresnel_dielectric(nk1, eta);
+  float fc, pc, khc; ggx_eval(l1, l2, o.coatAlpha, fc, pc, khc);
+  float fs, ps, khs; ggx_eval(l1, l2, o.alpha, fs, ps, khs);
+  float Fch = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(khc));
+  V3 Fm = schlick_f82(o.albedo, o.metalTint, khs) * o.specWeight;
+  float Fdh = fresnel_dielectric(khs, eta);
+  float cd = l2.z / GI_PI;
+  float base = 1.0f - Fc, diel = 1.0f - o.metalness;
+  V3 gl = v3(Fch * fc, Fch * fc, Fch * fc);
+  gl = gl + ((Fm * o.coatTint) * fs) * (base * o.metalness);
+  gl = gl + ((o.specColor * o.coatTint) * (Fdh * fs)) * (base * diel);
+  out.glossy = gl;
+  out.diffuse = (o.albedo * o.coatTint) * (cd * base * diel * (1.0f - Fd) * (1.0f - o.tw));
+  out.pdf = Fc * pc + base * (o.metalness * ps + diel * (Fd * ps + (1.0f - Fd) * (1.0f - o.tw) * cd));
+}
+
 __device__ inline void bsdf_sample(const MaterialRec* m, const ShState& st, V3 k1, float x0, float x1, float x2, BsdfSample& out)
 {
   out.event = EV_ABSORB; out.pdf = 0.0f; out.overPdf = v3(0.0f, 0.0f, 0.0f); out.k2 = v3(0.0f, 0.0f, 0.0f);
@@ -592,6 +716,7 @@ __device__ inline void bsdf_sample(const MaterialRec* m, const ShState& st, V3 k
     out.event = EV_DIFFUSE | EV_REFLECTION;
     return;
   }
+  if (klass == 2u) { opbr_sample(m, st, k1, x0, x1, x2, out); return; }
 }
 
 __device__ inline void bsdf_evaluate(const MaterialRec* m, const ShState& st, V3 k1, V3 k2, BsdfEval& out)
@@ -622,6 +747,7 @@ __device__ inline void bsdf_evaluate(const MaterialRec* m, const ShState& st, V3
     out.pdf = Fc * pc + (1.0f - Fc) * (ps * pss + (1.0f - ps) * cd);
     return;
   }
+  if (klass == 2u) { opbr_evaluate(m, st, k1, k2, out); return; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -723,6 +849,13 @@ __global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, 
       setup_shading_state(sc, f2u(h.w), h.y, h.z, rayDir, ss);
       const MaterialRec* mat = &sc.materials[ss.material];
       const bool isDoubleSided = (ss.meshFlags & 2u) != 0u;
+      // volume attenuation with an empty medium stack (rp_main.chit:160-186): inside (1-bit toggle) -> Beer-Lambert with the
+      // HIT material's absorption coefficient (:169-173)
+      uint32_t mediumIdx = (bitfield & 0x0f000000u) >> 24; if (mediumIdx > 1u) mediumIdx = 1u;
+      if (mediumIdx > 0u && mat->klass == 2u) {
+        const float distance = h.x * U.metersPerSceneUnit;
+        throughput = throughput * v3(gi_expf(-mat->p[MP_SIGMA_A] * distance), gi_expf(-mat->p[MP_SIGMA_A + 1] * distance), gi_expf(-mat->p[MP_SIGMA_A + 2] * distance));
+      }
       // emission (rp_main.chit:293-343): uniform EDF, radiance == emission colour where cos > 0
       const V3 em = v3(mat->p[3], mat->p[4], mat->p[5]);
       if (em.x != 0.0f || em.y != 0.0f || em.z != 0.0f) {
@@ -756,6 +889,11 @@ __global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, 
         ld = length(toLight);
         sdir = gi_safe_div(toLight, ld);
         shadow = gi_luminance(nee) > 1e-6f && ld > 1e-9f;
+      }
+      if (isTransmission) { // medium toggle (:447-480), MEDIUM_STACK_SIZE == 0: inside/outside bit; walk counter reset
+        mediumIdx = 1u - mediumIdx;
+        bitfield &= ~0x00fff000u;
+        bitfield = (bitfield & ~0x0f000000u) | (mediumIdx << 24);
       }
       if (bs.event == EV_ABSORB) bitfield |= 0x80000000u; // :483-486
       const V3 gn = ss.geomNormal * (isTransmission ? -1.0f : 1.0f);
@@ -800,7 +938,7 @@ __global__ void k_debug_bsdf(const MaterialRec* mat, uint32_t count, const float
   if (i >= count) return;
   const float* p = in + 22 * (size_t)i; float* o = out + 15 * (size_t)i;
   ShState st; st.normal = v3(p); st.tangentU = v3(p + 3); st.tangentV = v3(p + 6); st.geomNormal = v3(p + 9);
-  st.position = v3(0.0f, 0.0f, 0.0f); st.frontFace = true; st.meshFlags = 0u; st.material = 0u;
+  st.position = v3(0.0f, 0.0f, 0.0f); st.frontFace = (p[21] < 0.5f); st.meshFlags = 0u; st.material = 0u;
   BsdfSample bs; bsdf_sample(mat, st, v3(p + 12), p[18], p[19], p[20], bs);
   BsdfEval ev; bsdf_evaluate(mat, st, v3(p + 12), v3(p + 15), ev);
   o[0] = bs.k2.x; o[1] = bs.k2.y; o[2] = bs.k2.z; o[3] = bs.overPdf.x; o[4] = bs.overPdf.y; o[5] = bs.overPdf.z; o[6] = bs.pdf; o[7] = (float)bs.event;

@@ -62,7 +62,9 @@ static_assert(sizeof(InstanceRec) == 96, "InstanceRec must be 96 bytes");
 constexpr uint32_t MAT_PARAM_COUNT = 48;
 // derived per-material constants, filled by the host into the spare tail of MaterialRec::p (same fp32 formulas the
 // oracle evaluates per hit)
-enum : uint32_t { MP_ALBEDO = 32, MP_F0 = 35, MP_ALPHA = 38, MP_COAT = 39, MP_COAT_ALPHA = 40 };
+// class 1 (UsdPreviewSurface): albedo, F0, alpha, coat, coatAlpha.  class 2 (OpenPBR): albedo = base_color*base_weight,
+// F0 slot = metal edge tint (specular_color*specular_weight), alpha, coat, coatAlpha, coatF0, modulated eta, sigma_a
+enum : uint32_t { MP_ALBEDO = 32, MP_F0 = 35, MP_ALPHA = 38, MP_COAT = 39, MP_COAT_ALPHA = 40, MP_COAT_F0 = 41, MP_ETA = 42, MP_SIGMA_A = 43 };
 struct MaterialRec {
   uint32_t klass;
   uint32_t flags;
@@ -88,13 +90,13 @@ struct FrameUniforms {
   float background[3]; float clipFar;
   float invSpp, sppF, sampleOffsetF, invTotalSampleCount;
   float maxSampleValue, rrInvMinTermProb, lightIntensityMultiplier, exposureScale;
+  float metersPerSceneUnit, padf[3];
   uint32_t spp, sampleOffset, maxBounces, rrBounceOffset;
   uint32_t imageWidth, imageHeight, rowBegin, pixelCount; // pixelCount = pixels of this tile
   uint32_t batchFirstSample, batchSamples, workTotal, poolSlots; // this batch: samples [first, first+count) of every tile pixel
   uint32_t flags; // FLAG_*
   uint32_t sphereCount, distantCount, rectCount, diskCount, totalLightCount;
   uint32_t pad[2];
-  uint32_t pad2[4];
 };
 enum : uint32_t {
   FLAG_JITTER = 1u, FLAG_FIS = 2u, FLAG_DOF = 4u, FLAG_CLIP = 8u, FLAG_NEE = 16u, FLAG_PROGRESSIVE = 32u,

@@ -44,6 +44,7 @@ P_COAT_IOR = 22
 P_TRANSMISSION_WEIGHT = 23
 P_TRANSMISSION_COLOR = 24
 P_DIFFUSE_ROUGHNESS = 27
+P_TRANSMISSION_DEPTH = 28
 P_COUNT = 48
 
 
@@ -72,6 +73,35 @@ class MaterialDesc:
         p[P_OPACITY_THRESHOLD] = opacityThreshold
         p[P_IOR] = ior
         return MaterialDesc(name=name, klass=klass, params=p)
+
+
+def _open_pbr(name="mat", base_weight=1.0, base_color=(0.8, 0.8, 0.8), base_metalness=0.0, specular_weight=1.0,
+              specular_color=(1, 1, 1), specular_roughness=0.3, specular_ior=1.5, transmission_weight=0.0,
+              transmission_color=(1, 1, 1), transmission_depth=0.0, coat_weight=0.0, coat_color=(1, 1, 1), coat_roughness=0.0,
+              coat_ior=1.6, emission_luminance=0.0, emission_color=(1, 1, 1), base_diffuse_roughness=0.0) -> MaterialDesc:
+    """open_pbr_surface inputs with the defaults of src/gi/mtlx/open_pbr_surface.mtlx:11-92 (the lobes this core implements)."""
+    p = np.zeros(P_COUNT, np.float32)
+    p[P_BASE_COLOR:P_BASE_COLOR + 3] = base_color
+    p[P_EMISSION:P_EMISSION + 3] = np.float32(emission_luminance) * np.asarray(emission_color, np.float32)
+    p[P_SPECULAR_COLOR:P_SPECULAR_COLOR + 3] = specular_color
+    p[P_METALLIC] = base_metalness
+    p[P_ROUGHNESS] = specular_roughness
+    p[P_CLEARCOAT] = coat_weight
+    p[P_CLEARCOAT_ROUGHNESS] = coat_roughness
+    p[P_OPACITY] = 1.0
+    p[P_IOR] = specular_ior
+    p[P_BASE_WEIGHT] = base_weight
+    p[P_SPECULAR_WEIGHT] = specular_weight
+    p[P_COAT_COLOR:P_COAT_COLOR + 3] = coat_color
+    p[P_COAT_IOR] = coat_ior
+    p[P_TRANSMISSION_WEIGHT] = transmission_weight
+    p[P_TRANSMISSION_COLOR:P_TRANSMISSION_COLOR + 3] = transmission_color
+    p[P_DIFFUSE_ROUGHNESS] = base_diffuse_roughness
+    p[P_TRANSMISSION_DEPTH] = transmission_depth
+    return MaterialDesc(name=name, klass=MAT_OPEN_PBR, params=p)
+
+
+MaterialDesc.open_pbr = staticmethod(_open_pbr)
 
 
 @dataclass

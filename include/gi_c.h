@@ -145,7 +145,7 @@ typedef struct GiCRenderParams {
 /* Closed-form material classes: replaces MaterialX->MDL->GLSL codegen (src/mc, GlslShaderGen) */
 #define GI_C_MAT_DIFFUSE 0u             /* config C1 "diffuse only" model */
 #define GI_C_MAT_USD_PREVIEW_SURFACE 1u /* diffuse + GGX specular + clearcoat */
-#define GI_C_MAT_OPEN_PBR 2u
+#define GI_C_MAT_OPEN_PBR 2u             /* coat + metal (F82-tint) + dielectric reflection + rough refraction + diffuse */
 #define GI_C_MAT_PARAM_COUNT 48u
 /* indices into GiCMaterialDesc.p */
 #define GI_C_P_BASE_COLOR 0
@@ -166,6 +166,7 @@ typedef struct GiCRenderParams {
 #define GI_C_P_TRANSMISSION_WEIGHT 23
 #define GI_C_P_TRANSMISSION_COLOR 24
 #define GI_C_P_DIFFUSE_ROUGHNESS 27
+#define GI_C_P_TRANSMISSION_DEPTH 28
 
 typedef struct GiCMaterialDesc {
   uint32_t klass;

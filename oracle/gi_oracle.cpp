@@ -97,6 +97,19 @@ inline float logf_poly(float x)
   return r;
 }
 
+// exp(x) for x <= 0 (Beer-Lambert transmittance), Cephes expf kernel with plain mul/add.
+inline float expf_poly(float x)
+{
+  if (x < -87.0f) return 0.0f;
+  if (x > 0.0f) x = 0.0f;
+  float fx = floorf(x * 1.44269504088896341f + 0.5f);
+  x = x - fx * 0.693359375f;
+  x = x - fx * -2.12194440e-4f;
+  float z = x * x;
+  float y = (((((1.9875691500e-4f * x + 1.3981999507e-3f) * x + 8.3334519073e-3f) * x + 4.1665795894e-2f) * x + 1.6666665459e-1f) * x + 5.0000001201e-1f) * z + x + 1.0f;
+  return y * u2f((uint32_t)((int)fx + 127) << 23);
+}
+
 // ---------------------------------------------------------------------------------------------
 // half <-> float (glm::packHalf2x16 / GLSL unpackHalf2x16), round-to-nearest-even.
 // ---------------------------------------------------------------------------------------------
@@ -610,6 +623,150 @@ inline UpsParams ups_params(const OrcMaterial& m)
 }
 inline V3 schlick3(V3 F0, float c) { float w = schlick_w(c); return F0 + (v3(1, 1, 1) - F0) * w; }
 
+// ---- class 2: OpenPBR (lobe graph of src/gi/mtlx/open_pbr_surface.mtlx:99-635, closed forms of our own) ----
+// exact dielectric Fresnel, eta = n_t / n_i, c = cos of the incident angle
+inline float fresnel_dielectric(float c, float eta)
+{
+  float sin2t = (1.0f - c * c) / (eta * eta);
+  if (!(sin2t < 1.0f)) return 1.0f;
+  float ct = sqrtf(1.0f - sin2t);
+  float rs = (c - eta * ct) / (c + eta * ct);
+  float rp = (eta * c - ct) / (eta * c + ct);
+  return 0.5f * (rs * rs + rp * rp);
+}
+// generalized Schlick with the F82-tint edge colour (metal_bsdf, open_pbr_surface.mtlx:434-441)
+inline V3 schlick_f82(V3 F0, V3 tint, float c)
+{
+  const float cb = 1.0f / 7.0f, w5 = 0.462664366f /* (6/7)^5 */, K = 17.6513846f /* 1 / (cb * (6/7)^6) */;
+  V3 one = v3(1, 1, 1);
+  V3 fb = F0 + (one - F0) * w5;
+  V3 a = (fb * (one - tint)) * K;
+  float m = 1.0f - c; m = fmin2(fmax2(m, 0.0f), 1.0f);
+  float m2 = m * m, m5 = m2 * m2 * m, m6 = m5 * m;
+  V3 f = (F0 + (one - F0) * m5) - a * (c * m6);
+  (void)cb;
+  return v3(fmin2(fmax2(f.x, 0.0f), 1.0f), fmin2(fmax2(f.y, 0.0f), 1.0f), fmin2(fmax2(f.z, 0.0f), 1.0f));
+}
+struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, sigmaA; float metalness, alpha, coat, coatAlpha, coatF0, eta, tw, specWeight; };
+inline OpbrParams opbr_params(const OrcMaterial& m)
+{
+  OpbrParams o; const float* p = m.p;
+  float bw = p[ORC_P_BASE_WEIGHT], sw = p[ORC_P_SPECULAR_WEIGHT];
+  o.albedo = v3(p + ORC_P_BASE_COLOR) * bw;
+  o.specColor = v3(p + ORC_P_SPECULAR_COLOR);
+  o.metalTint = o.specColor * sw;
+  o.specWeight = sw;
+  o.metalness = p[ORC_P_METALLIC];
+  float r = p[ORC_P_ROUGHNESS], cr = p[ORC_P_CLEARCOAT_ROUGHNESS];
+  o.alpha = fmax2(r * r, 0.001f); o.coatAlpha = fmax2(cr * cr, 0.001f);
+  o.coat = p[ORC_P_CLEARCOAT];
+  float cior = p[ORC_P_COAT_IOR]; float qc = (cior - 1.0f) / (cior + 1.0f); o.coatF0 = qc * qc;
+  V3 cc = v3(p + ORC_P_COAT_COLOR); o.coatTint = v3(1, 1, 1) * (1.0f - o.coat) + cc * o.coat;
+  // modulated_eta_s (open_pbr_surface.mtlx:306-366): specular_weight scales F0, eta follows
+  float ior = p[ORC_P_IOR];
+  float ratio = ior / cior, inv = cior / ior;
+  float etaCoated = (ratio > 1.0f) ? ratio : inv;
+  float etaS = etaCoated * o.coat + ior * (1.0f - o.coat);
+  float q = (etaS - 1.0f) / (etaS + 1.0f);
+  float f0 = fmin2(fmax2(sw * (q * q), 0.0f), 0.99999f);
+  float eps = ((etaS - 1.0f) > 0.0f ? 1.0f : ((etaS - 1.0f) < 0.0f ? -1.0f : 0.0f)) * sqrtf(f0);
+  o.eta = (1.0f + eps) / (1.0f - eps);
+  o.tw = p[ORC_P_TRANSMISSION_WEIGHT];
+  float depth = p[ORC_P_TRANSMISSION_DEPTH];
+  V3 tc = v3(p + ORC_P_TRANSMISSION_COLOR);
+  o.transTint = (depth > 0.0f) ? v3(1, 1, 1) : tc; // if_transmission_tint (:368-373)
+  o.sigmaA = (depth > 0.0f) ? v3(-logf(fmax2(tc.x, 1e-6f)) / depth, -logf(fmax2(tc.y, 1e-6f)) / depth, -logf(fmax2(tc.z, 1e-6f)) / depth) : v3(0, 0, 0);
+  return o;
+}
+
+void opbr_sample(const OrcMaterial& m, const State& st, V3 k1, const float xi[4], bool frontFace, BsdfSample& out)
+{
+  OpbrParams o = opbr_params(m);
+  V3 l1 = to_local(st, k1);
+  float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
+  float z = xi[2];
+  float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1));
+  if (z < Fc) { // coat reflection
+    GgxOut g = ggx_sample(l1, o.coatAlpha, xi[0], xi[1]);
+    V3 k2 = to_world(st, g.l2);
+    if (!g.valid || !(dot(k2, st.geomNormal) > 0.0f)) return;
+    float Fh = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(g.kh));
+    float w = (Fh / Fc) * g.g2OverG1;
+    out.k2 = k2; out.pdf = Fc * g.pdf; out.overPdf = v3(w, w, w); out.event = EV_GLOSSY | EV_REFLECTION;
+    return;
+  }
+  z = (z - Fc) / (1.0f - Fc);
+  if (z < o.metalness) { // metal
+    GgxOut g = ggx_sample(l1, o.alpha, xi[0], xi[1]);
+    V3 k2 = to_world(st, g.l2);
+    if (!g.valid || !(dot(k2, st.geomNormal) > 0.0f)) return;
+    V3 F = schlick_f82(o.albedo, o.metalTint, g.kh) * o.specWeight;
+    out.k2 = k2; out.pdf = (1.0f - Fc) * o.metalness * g.pdf; out.overPdf = (F * o.coatTint) * g.g2OverG1; out.event = EV_GLOSSY | EV_REFLECTION;
+    return;
+  }
+  z = (z - o.metalness) / (1.0f - o.metalness);
+  float eta = frontFace ? o.eta : 1.0f / o.eta; // rp_main.chit:188-189 with an empty medium stack
+  float Fd = fresnel_dielectric(nk1, eta);
+  if (z < Fd) { // dielectric reflection
+    GgxOut g = ggx_sample(l1, o.alpha, xi[0], xi[1]);
+    V3 k2 = to_world(st, g.l2);
+    if (!g.valid || !(dot(k2, st.geomNormal) > 0.0f)) return;
+    float Fh = fresnel_dielectric(g.kh, eta);
+    out.k2 = k2; out.pdf = (1.0f - Fc) * (1.0f - o.metalness) * Fd * g.pdf;
+    out.overPdf = (o.specColor * o.coatTint) * ((Fh / Fd) * g.g2OverG1); out.event = EV_GLOSSY | EV_REFLECTION;
+    return;
+  }
+  z = (z - Fd) / (1.0f - Fd);
+  if (z < o.tw) { // rough refraction through a VNDF-sampled micro-normal
+    GgxOut g = ggx_sample(l1, o.alpha, xi[0], xi[1]); // provides the half vector via l2 = reflect(l1, h)
+    V3 h = normalize(l1 + g.l2);
+    float kh = dot(l1, h);
+    if (!g.valid || !(kh > 0.0f)) return;
+    float Fh = fresnel_dielectric(kh, eta);
+    float sin2t = (1.0f - kh * kh) / (eta * eta);
+    if (!(sin2t < 1.0f)) return; // total internal reflection at this micro-normal: absorbed
+    float ct = sqrtf(1.0f - sin2t);
+    V3 lt = h * (kh / eta - ct) - l1 * (1.0f / eta);
+    V3 k2 = to_world(st, lt);
+    if (!(lt.z < 0.0f) || !(dot(k2, st.geomNormal) < 0.0f)) return;
+    float a2 = o.alpha * o.alpha, nk2 = -lt.z;
+    float L1 = ggx_lambda_term(a2, nk1), L2 = ggx_lambda_term(a2, nk2);
+    float G1 = 2.0f * nk1 / (nk1 + L1), G2 = 2.0f * nk1 * nk2 / (nk2 * L1 + nk1 * L2);
+    float w = ((1.0f - Fh) / (1.0f - Fd)) * (G2 / G1);
+    out.k2 = normalize(k2); out.pdf = (1.0f - Fc) * (1.0f - o.metalness) * (1.0f - Fd) * o.tw * g.pdf;
+    out.overPdf = (o.transTint * o.coatTint) * w; out.event = EV_GLOSSY | EV_TRANSMISSION;
+    return;
+  }
+  V3 l = sample_hemisphere(xi[0], xi[1]); // opaque base: Lambert (base_diffuse_roughness ignored)
+  V3 k2 = to_world(st, l);
+  if (!(l.z > 0.0f) || !(dot(k2, st.geomNormal) > 0.0f)) return;
+  out.k2 = k2; out.pdf = (1.0f - Fc) * (1.0f - o.metalness) * (1.0f - Fd) * (1.0f - o.tw) * (l.z / ORC_PI);
+  out.overPdf = o.albedo * o.coatTint; out.event = EV_DIFFUSE | EV_REFLECTION;
+}
+
+void opbr_evaluate(const OrcMaterial& m, const State& st, V3 k1, V3 k2, bool frontFace, BsdfEval& out)
+{
+  OpbrParams o = opbr_params(m);
+  V3 l1 = to_local(st, k1), l2 = to_local(st, k2);
+  float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
+  float eta = frontFace ? o.eta : 1.0f / o.eta;
+  float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1));
+  float Fd = fresnel_dielectric(nk1, eta);
+  float fc, pc, khc; ggx_eval(l1, l2, o.coatAlpha, fc, pc, khc);
+  float fs, ps, khs; ggx_eval(l1, l2, o.alpha, fs, ps, khs);
+  float Fch = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(khc));
+  V3 Fm = schlick_f82(o.albedo, o.metalTint, khs) * o.specWeight;
+  float Fdh = fresnel_dielectric(khs, eta);
+  float cd = l2.z / ORC_PI;
+  float base = 1.0f - Fc, diel = 1.0f - o.metalness;
+  V3 gl = v3(Fch * fc, Fch * fc, Fch * fc);
+  gl = gl + ((Fm * o.coatTint) * fs) * (base * o.metalness);
+  gl = gl + ((o.specColor * o.coatTint) * (Fdh * fs)) * (base * diel);
+  out.glossy = gl;
+  out.diffuse = (o.albedo * o.coatTint) * (cd * base * diel * (1.0f - Fd) * (1.0f - o.tw));
+  out.pdf = Fc * pc + base * (o.metalness * ps + diel * (Fd * ps + (1.0f - Fd) * (1.0f - o.tw) * cd));
+}
+
 void bsdf_sample(const OrcMaterial& m, const State& st, V3 k1, const float xi[4], BsdfSample& out)
 {
   out.event = EV_ABSORB; out.pdf = 0.0f; out.overPdf = v3(0, 0, 0); out.k2 = v3(0, 0, 0);
@@ -654,6 +811,7 @@ void bsdf_sample(const OrcMaterial& m, const State& st, V3 k1, const float xi[4]
     out.event = EV_DIFFUSE | EV_REFLECTION;
     return;
   }
+  if (m.klass == ORC_MAT_OPEN_PBR) { opbr_sample(m, st, k1, xi, st.frontFace, out); return; }
 }
 
 void bsdf_evaluate(const OrcMaterial& m, const State& st, V3 k1, V3 k2, BsdfEval& out)
@@ -683,6 +841,7 @@ void bsdf_evaluate(const OrcMaterial& m, const State& st, V3 k1, V3 k2, BsdfEval
     out.pdf = Fc * pc + (1.0f - Fc) * (ps * pss + (1.0f - ps) * cd);
     return;
   }
+  if (m.klass == ORC_MAT_OPEN_PBR) { opbr_evaluate(m, st, k1, k2, st.frontFace, out); return; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -779,7 +938,15 @@ void closest_hit(const Frame& F, const Hit& h, Payload& pl, float hitT)
   const OrcMaterial& mat = P.materials[mesh->material];
   bool isLeftHanded = (mesh->flags & 1u) != 0, isDoubleSided = (mesh->flags & 2u) != 0;
   V3 throughput = pl.throughput, radiance = pl.radiance;
-  (void)hitT; (void)isLeftHanded; // medium attenuation (:160-186) needs volume coefficients: not in the supported classes
+  (void)isLeftHanded;
+  // 3. volume attenuation with an empty medium stack (:160-186): inside (1-bit toggle) -> Beer-Lambert with the HIT material's
+  // absorption coefficient (:169-173)
+  uint32_t mediumIdx = (pl.bitfield & MEDIUM_MASK) >> 24; if (mediumIdx > 1u) mediumIdx = 1u; // shadeRayPayloadGetMediumIdx
+  if (mediumIdx > 0 && mat.klass == ORC_MAT_OPEN_PBR) {
+    OpbrParams o = opbr_params(mat);
+    float distance = hitT * F.rs->metersPerSceneUnit;
+    throughput = throughput * v3(expf_poly(-o.sigmaA.x * distance), expf_poly(-o.sigmaA.y * distance), expf_poly(-o.sigmaA.z * distance));
+  }
 
   // 5. emission (:293-343).  uniform EDF: edf*intensity == emission colour, pdf>0 iff cos>0
   V3 em = v3(mat.p + ORC_P_EMISSION);
@@ -819,7 +986,12 @@ void closest_hit(const Frame& F, const Hit& h, Payload& pl, float hitT)
       pl.neeContrib = nee;
     }
   }
-  // medium toggle (:447-480) only on transmission: none of the supported classes transmit yet
+  // medium toggle (:447-480): MEDIUM_STACK_SIZE == 0 -> inside/outside bit; the walk counter is reset
+  if (isTransmission) {
+    mediumIdx = 1u - mediumIdx;
+    pl.bitfield &= ~0x00fff000u;
+    pl.bitfield = (pl.bitfield & ~MEDIUM_MASK) | (mediumIdx << 24);
+  }
   if (eventType == EV_ABSORB) pl.bitfield |= TERMINATE_FLAG; // :483-486
   V3 gn = st.geomNormal * (isTransmission ? -1.0f : 1.0f);
   pl.origin = offset_ray_origin(st.position, gn);              // :488-489
@@ -989,6 +1161,7 @@ void orc_offset_ray_origin(const float p[3], const float n[3], float out[3]) { V
 void orc_fis_gauss(float xi0, float xi1, float out[2]) { fis_gauss(xi0, xi1, out[0], out[1]); }
 void orc_sincos2pi(float x, float* s, float* c) { sincos2pi(x, s, c); }
 float orc_logf(float x) { return logf_poly(x); }
+float orc_expf(float x) { return expf_poly(x); }
 uint32_t orc_pack_half2x16(float a, float b) { return pack_half2x16(a, b); }
 void orc_unpack_half2x16(uint32_t v, float out[2]) { out[0] = f16_to_f32((uint16_t)(v & 0xffffu)); out[1] = f16_to_f32((uint16_t)(v >> 16)); }
 void orc_orthonormal_basis(const float n[3], float b1[3], float b2[3]) { V3 a, b; orthonormal_basis(v3(n), a, b); b1[0] = a.x; b1[1] = a.y; b1[2] = a.z; b2[0] = b.x; b2[1] = b.y; b2[2] = b.z; }
@@ -1025,7 +1198,7 @@ void orc_bsdf_debug(const OrcMaterial* mat, uint32_t count, const float* in, flo
   for (uint32_t i = 0; i < count; i++) {
     const float* p = in + 22 * (size_t)i; float* o = out + 15 * (size_t)i;
     State st; st.normal = v3(p); st.tangentU = v3(p + 3); st.tangentV = v3(p + 6); st.geomNormal = v3(p + 9);
-    st.position = v3(0, 0, 0); st.u = st.v = 0.0f; st.frontFace = true;
+    st.position = v3(0, 0, 0); st.u = st.v = 0.0f; st.frontFace = (p[21] < 0.5f);
     BsdfSample bs; bsdf_sample(*mat, st, v3(p + 12), p + 18, bs);
     BsdfEval ev; bsdf_evaluate(*mat, st, v3(p + 12), v3(p + 15), ev);
     o[0] = bs.k2.x; o[1] = bs.k2.y; o[2] = bs.k2.z; o[3] = bs.overPdf.x; o[4] = bs.overPdf.y; o[5] = bs.overPdf.z; o[6] = bs.pdf; o[7] = (float)bs.event;

@@ -68,6 +68,7 @@ enum {
   ORC_P_TRANSMISSION_WEIGHT = 23,
   ORC_P_TRANSMISSION_COLOR = 24, /* 3 */
   ORC_P_DIFFUSE_ROUGHNESS = 27,
+  ORC_P_TRANSMISSION_DEPTH = 28,
   ORC_P_COUNT = 48
 };
 
@@ -171,6 +172,7 @@ void     orc_decode_direction(uint32_t e, float out[3]);             /* common.g
 void     orc_offset_ray_origin(const float p[3], const float n[3], float out[3]); /* common.glsl:143-162 */
 void     orc_fis_gauss(float xi0, float xi1, float out[2]);          /* rp_main.rgen:118-130 */
 void     orc_sincos2pi(float x, float* s, float* c);
+float    orc_expf(float x); /* x <= 0 */
 float    orc_logf(float x);
 uint32_t orc_pack_half2x16(float a, float b);
 void     orc_unpack_half2x16(uint32_t v, float out[2]);

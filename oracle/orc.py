@@ -116,6 +116,8 @@ def lib():
         L.orc_sincos2pi.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.orc_logf.restype = C.c_float
         L.orc_logf.argtypes = [C.c_float]
+        L.orc_expf.restype = C.c_float
+        L.orc_expf.argtypes = [C.c_float]
         L.orc_pack_half2x16.restype = C.c_uint32
         L.orc_pack_half2x16.argtypes = [C.c_float, C.c_float]
         L.orc_unpack_half2x16.argtypes = [C.c_uint32, C.POINTER(C.c_float)]

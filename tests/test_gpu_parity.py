@@ -220,7 +220,13 @@ def test_bsdf_known_answers_on_device(gi, orc):
             MaterialDesc.usd_preview_surface(diffuseColor=(0.7, 0.4, 0.2), roughness=0.5),
             MaterialDesc.usd_preview_surface(diffuseColor=(0.9, 0.6, 0.1), roughness=0.2, metallic=1.0),
             MaterialDesc.usd_preview_surface(diffuseColor=(0.2, 0.4, 0.8), roughness=0.7, clearcoat=1.0, clearcoatRoughness=0.1),
-            MaterialDesc.usd_preview_surface(diffuseColor=(0.2, 0.4, 0.8), useSpecularWorkflow=1, specularColor=(0.3, 0.2, 0.1), roughness=0.05)]
+            MaterialDesc.usd_preview_surface(diffuseColor=(0.2, 0.4, 0.8), useSpecularWorkflow=1, specularColor=(0.3, 0.2, 0.1), roughness=0.05),
+            MaterialDesc.open_pbr(),
+            MaterialDesc.open_pbr(base_color=(0.9, 0.5, 0.2), base_metalness=1.0, specular_color=(0.8, 0.9, 1.0), specular_roughness=0.25),
+            MaterialDesc.open_pbr(base_color=(0.3, 0.6, 0.2), coat_weight=0.8, coat_color=(0.9, 0.7, 0.6), coat_roughness=0.2, specular_weight=0.7),
+            MaterialDesc.open_pbr(transmission_weight=1.0, transmission_color=(0.6, 0.8, 0.9), transmission_depth=0.5, specular_roughness=0.1),
+            MaterialDesc.open_pbr(transmission_weight=0.6, base_metalness=0.3, coat_weight=0.4, specular_ior=1.33)]
+    items[: n // 2, 21] = 0.75  # xi.w >= 0.5: the debug hook shades these as back faces (eta inverted)
     for m in mats:
         got, ref = gi.bsdf_debug(m, items), orc.bsdf_debug(m, items)
         assert np.array_equal(got[:, 7], ref[:, 7])  # event types
@@ -252,6 +258,28 @@ def test_bvh_traversal_matches_oracle(gi, orc):
     hit = rip[:, 0] >= 0
     assert 0.05 < hit.mean() < 1.0
     assert np.array_equal(tuv[hit].view(np.uint32), rtuv[hit].view(np.uint32))
+
+
+def _glass_scene():
+    """Cornell box whose two blocks are OpenPBR glass (absorbing) and coated metal: refraction, the 1-bit medium toggle,
+    Beer-Lambert attenuation and the F82 metal lobe in one image."""
+    desc = cornell_box(MAT_USD_PREVIEW_SURFACE)
+    desc.materials.append(MaterialDesc.open_pbr(name="glass", transmission_weight=1.0, transmission_color=(0.7, 0.9, 0.8), transmission_depth=0.3,
+                                                specular_roughness=0.05, specular_ior=1.5))
+    desc.materials.append(MaterialDesc.open_pbr(name="metal", base_color=(0.95, 0.64, 0.54), base_metalness=1.0, specular_roughness=0.2,
+                                                coat_weight=0.5, coat_roughness=0.05))
+    desc.meshes[6].material = len(desc.materials) - 2
+    desc.meshes[7].material = len(desc.materials) - 1
+    return desc
+
+
+@pytest.mark.parametrize("nee", [False, True])
+def test_open_pbr_scene_parity(gi, orc, nee):
+    desc = _glass_scene()
+    if nee:
+        desc.rect_lights = [RectLight(origin=(0, 0, 0.9), t0=(1, 0, 0), t1=(0, -1, 0), base_emission=(10, 10, 10), width=0.7, height=0.5)]
+    img, ref, st = render_both(gi, orc, desc, RenderSettings(spp=8, max_bounces=10, next_event_estimation=nee, meters_per_scene_unit=2.0), 128, 72)
+    assert st["segments"] > 128 * 72 * 8 * 2
 
 
 def test_instanced_scene_parity(gi, orc):
