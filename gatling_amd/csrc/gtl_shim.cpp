@@ -1,0 +1,228 @@
+// gtl_shim.cpp -- the reference's C++ API (include/gtl/gi/Gi.h, mirroring /root/reference/src/gi/gtl/gi/Gi.h:199-261) on top of
+// the C ABI (include/gi_c.h).  Every function forwards 1:1; std::vector arguments become pointer + count.  The one
+// non-mechanical piece is material creation: a tiny scanner reads UsdPreviewSurface / open_pbr_surface nodes with constant
+// inputs out of a MaterialX document string (what hdGatling's material network compiler produces,
+// src/hdGatling/materialNetworkCompiler.cpp:667-720) and fills a closed-form parameter block.
+#include "../../include/gtl/gi/Gi.h"
+#include "../../include/gi_c.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+
+namespace gtl
+{
+  struct GiScene { GiCScene* h; };
+  struct GiMesh { GiCMesh* h; };
+  struct GiMaterial { GiCMaterial* h; };
+  struct GiRenderBuffer { GiCRenderBuffer* h; };
+  struct GiSphereLight { GiCSphereLight* h; };
+  struct GiDistantLight { GiCDistantLight* h; };
+  struct GiRectLight { GiCRectLight* h; };
+  struct GiDiskLight { GiCDiskLight* h; };
+  struct GiDomeLight { GiCDomeLight* h; };
+
+  namespace
+  {
+    GiAssetReader* s_assetReader = nullptr;
+
+    // ---- minimal MaterialX reader: first <UsdPreviewSurface|open_pbr_surface ...> element and its <input name value> children
+    struct MtlxNode { std::string category; std::map<std::string, std::string> inputs; };
+
+    std::string attr(const std::string& tag, const char* name)
+    {
+      std::string key = std::string(name) + "=\"";
+      size_t p = tag.find(key);
+      if (p == std::string::npos) return {};
+      p += key.size();
+      size_t e = tag.find('"', p);
+      return e == std::string::npos ? std::string() : tag.substr(p, e - p);
+    }
+
+    bool findSurfaceNode(const std::string& doc, MtlxNode& out)
+    {
+      static const char* kCats[] = {"UsdPreviewSurface", "open_pbr_surface"};
+      size_t best = std::string::npos; const char* bestCat = nullptr;
+      for (const char* c : kCats) {
+        std::string open = std::string("<") + c;
+        size_t p = 0;
+        while ((p = doc.find(open, p)) != std::string::npos) {
+          char nx = doc[p + open.size()];
+          if (nx == ' ' || nx == '\t' || nx == '\n' || nx == '\r' || nx == '>') break;
+          p += open.size();
+        }
+        if (p != std::string::npos && p < best) { best = p; bestCat = c; }
+      }
+      if (!bestCat) return false;
+      out.category = bestCat;
+      size_t close = doc.find(std::string("</") + bestCat, best);
+      size_t headEnd = doc.find('>', best);
+      if (headEnd == std::string::npos) return false;
+      if (doc[headEnd - 1] == '/' || close == std::string::npos) return true; // no inputs: all defaults
+      size_t p = headEnd;
+      while ((p = doc.find("<input", p)) != std::string::npos && p < close) {
+        size_t e = doc.find('>', p);
+        if (e == std::string::npos) break;
+        std::string tag = doc.substr(p, e - p + 1);
+        std::string name = attr(tag, "name"), value = attr(tag, "value");
+        if (!name.empty() && !value.empty() && attr(tag, "nodename").empty()) out.inputs[name] = value; // constants only
+        p = e;
+      }
+      return true;
+    }
+
+    int floats(const std::string& s, float* out, int maxN)
+    {
+      int n = 0; const char* p = s.c_str();
+      while (*p && n < maxN) {
+        char* end = nullptr;
+        float v = strtof(p, &end);
+        if (end == p) { if (!strncmp(p, "true", 4)) { v = 1.0f; end = (char*)p + 4; } else if (!strncmp(p, "false", 5)) { v = 0.0f; end = (char*)p + 5; } else { p++; continue; } }
+        out[n++] = v; p = end;
+        while (*p == ',' || *p == ' ') p++;
+      }
+      return n;
+    }
+
+    void setN(const MtlxNode& n, const char* name, float* dst, int count)
+    {
+      auto it = n.inputs.find(name);
+      if (it != n.inputs.end()) floats(it->second, dst, count);
+    }
+
+    bool descFromMtlx(const char* src, GiCMaterialDesc& d)
+    {
+      MtlxNode n;
+      if (!src || !findSurfaceNode(src, n)) return false;
+      memset(&d, 0, sizeof(d));
+      float* p = d.p;
+      if (n.category == "UsdPreviewSurface") {
+        d.klass = GI_C_MAT_USD_PREVIEW_SURFACE; // fallback values of the UsdPreviewSurface specification
+        p[GI_C_P_BASE_COLOR] = p[GI_C_P_BASE_COLOR + 1] = p[GI_C_P_BASE_COLOR + 2] = 0.18f;
+        p[GI_C_P_ROUGHNESS] = 0.5f; p[GI_C_P_CLEARCOAT_ROUGHNESS] = 0.01f; p[GI_C_P_OPACITY] = 1.0f; p[GI_C_P_IOR] = 1.5f;
+        setN(n, "diffuseColor", p + GI_C_P_BASE_COLOR, 3); setN(n, "emissiveColor", p + GI_C_P_EMISSION, 3);
+        setN(n, "useSpecularWorkflow", p + GI_C_P_USE_SPECULAR_WORKFLOW, 1); setN(n, "specularColor", p + GI_C_P_SPECULAR_COLOR, 3);
+        setN(n, "metallic", p + GI_C_P_METALLIC, 1); setN(n, "roughness", p + GI_C_P_ROUGHNESS, 1);
+        setN(n, "clearcoat", p + GI_C_P_CLEARCOAT, 1); setN(n, "clearcoatRoughness", p + GI_C_P_CLEARCOAT_ROUGHNESS, 1);
+        setN(n, "opacity", p + GI_C_P_OPACITY, 1); setN(n, "opacityThreshold", p + GI_C_P_OPACITY_THRESHOLD, 1); setN(n, "ior", p + GI_C_P_IOR, 1);
+        return true;
+      }
+      d.klass = GI_C_MAT_OPEN_PBR; // defaults: src/gi/mtlx/open_pbr_surface.mtlx:11-92
+      p[GI_C_P_BASE_WEIGHT] = 1.0f; p[GI_C_P_BASE_COLOR] = p[GI_C_P_BASE_COLOR + 1] = p[GI_C_P_BASE_COLOR + 2] = 0.8f;
+      p[GI_C_P_SPECULAR_WEIGHT] = 1.0f; p[GI_C_P_SPECULAR_COLOR] = p[GI_C_P_SPECULAR_COLOR + 1] = p[GI_C_P_SPECULAR_COLOR + 2] = 1.0f;
+      p[GI_C_P_ROUGHNESS] = 0.3f; p[GI_C_P_IOR] = 1.5f; p[GI_C_P_OPACITY] = 1.0f;
+      p[GI_C_P_TRANSMISSION_COLOR] = p[GI_C_P_TRANSMISSION_COLOR + 1] = p[GI_C_P_TRANSMISSION_COLOR + 2] = 1.0f;
+      p[GI_C_P_COAT_COLOR] = p[GI_C_P_COAT_COLOR + 1] = p[GI_C_P_COAT_COLOR + 2] = 1.0f; p[GI_C_P_COAT_IOR] = 1.6f;
+      float lum = 0.0f, ecol[3] = {1.0f, 1.0f, 1.0f};
+      setN(n, "base_weight", p + GI_C_P_BASE_WEIGHT, 1); setN(n, "base_color", p + GI_C_P_BASE_COLOR, 3);
+      setN(n, "base_diffuse_roughness", p + GI_C_P_DIFFUSE_ROUGHNESS, 1); setN(n, "base_metalness", p + GI_C_P_METALLIC, 1);
+      setN(n, "specular_weight", p + GI_C_P_SPECULAR_WEIGHT, 1); setN(n, "specular_color", p + GI_C_P_SPECULAR_COLOR, 3);
+      setN(n, "specular_roughness", p + GI_C_P_ROUGHNESS, 1); setN(n, "specular_ior", p + GI_C_P_IOR, 1);
+      setN(n, "transmission_weight", p + GI_C_P_TRANSMISSION_WEIGHT, 1); setN(n, "transmission_color", p + GI_C_P_TRANSMISSION_COLOR, 3);
+      setN(n, "transmission_depth", p + GI_C_P_TRANSMISSION_DEPTH, 1);
+      setN(n, "coat_weight", p + GI_C_P_CLEARCOAT, 1); setN(n, "coat_color", p + GI_C_P_COAT_COLOR, 3);
+      setN(n, "coat_roughness", p + GI_C_P_CLEARCOAT_ROUGHNESS, 1); setN(n, "coat_ior", p + GI_C_P_COAT_IOR, 1);
+      setN(n, "emission_luminance", &lum, 1); setN(n, "emission_color", ecol, 3); setN(n, "geometry_opacity", p + GI_C_P_OPACITY, 1);
+      for (int i = 0; i < 3; i++) p[GI_C_P_EMISSION + i] = lum * ecol[i];
+      return true;
+    }
+  }
+
+  GiStatus giInitialize(const GiInitParams&)
+  {
+    const char* dev = getenv("GATLING_DEVICE");
+    return giCInitialize(dev ? atoi(dev) : 0) == GI_C_OK ? GiStatus::Ok : GiStatus::Error;
+  }
+  void giTerminate() { giCTerminate(); }
+  void giRegisterAssetReader(GiAssetReader* reader) { s_assetReader = reader; }
+
+  GiMaterial* giCreateMaterialFromMtlxStr(GiScene* scene, const char* name, const char* mtlxSrc)
+  {
+    GiCMaterialDesc d;
+    if (!scene || !descFromMtlx(mtlxSrc, d)) return nullptr;
+    GiCMaterial* h = giCCreateMaterial(scene->h, name, &d);
+    return h ? new GiMaterial{h} : nullptr;
+  }
+  GiMaterial* giCreateMaterialFromMtlxDoc(GiScene*, const char*, const std::shared_ptr<void>) { return nullptr; }
+  GiMaterial* giCreateMaterialFromMdlFile(GiScene*, const char*, const char*, const char*, const GiMaterialParameters&) { return nullptr; }
+  void giDestroyMaterial(GiMaterial* mat) { if (!mat) return; giCDestroyMaterial(mat->h); delete mat; }
+
+  GiMesh* giCreateMesh(GiScene* scene, const GiMeshDesc& d)
+  {
+    static_assert(sizeof(GiVertex) == sizeof(GiCVertex) && sizeof(GiFace) == sizeof(GiCFace), "layouts must match Gi.h:110-122");
+    GiCMeshDesc c{};
+    c.faceCount = d.faceCount; c.faces = reinterpret_cast<const GiCFace*>(d.faces.data());
+    c.faceIds = d.faceIds.size() >= d.faceCount && d.faceCount ? d.faceIds.data() : nullptr;
+    c.id = d.id; c.isDoubleSided = d.isDoubleSided; c.isLeftHanded = d.isLeftHanded; c.name = d.name; c.maxFaceId = d.maxFaceId;
+    c.vertexCount = d.vertexCount; c.vertices = reinterpret_cast<const GiCVertex*>(d.vertices.data());
+    GiCMesh* h = scene ? giCCreateMesh(scene->h, &c) : nullptr;
+    return h ? new GiMesh{h} : nullptr;
+  }
+  void giSetMeshTransform(GiMesh* m, const float* mat4x4) { giCSetMeshTransform(m->h, mat4x4); }
+  void giSetMeshInstanceTransforms(GiMesh* m, uint32_t count, const float (*t)[4][4]) { giCSetMeshInstanceTransforms(m->h, count, reinterpret_cast<const float*>(t)); }
+  void giSetMeshInstancerPrimvars(GiMesh*, const std::vector<GiPrimvarData>&) {}
+  void giSetMeshInstanceIds(GiMesh* m, uint32_t count, int* ids) { giCSetMeshInstanceIds(m->h, count, ids); }
+  void giSetMeshMaterial(GiMesh* m, GiMaterial* mat) { giCSetMeshMaterial(m->h, mat ? mat->h : nullptr); }
+  void giSetMeshVisibility(GiMesh* m, bool visible) { giCSetMeshVisibility(m->h, visible); }
+  void giDestroyMesh(GiMesh* m) { if (!m) return; giCDestroyMesh(m->h); delete m; }
+
+  GiStatus giRender(const GiRenderParams& p)
+  {
+    std::vector<GiCAovBinding> aovs(p.aovBindings.size());
+    for (size_t i = 0; i < aovs.size(); i++) {
+      aovs[i].aovId = int(p.aovBindings[i].aovId);
+      memcpy(aovs[i].clearValue, p.aovBindings[i].clearValue, GI_C_MAX_AOV_COMP_SIZE);
+      aovs[i].renderBuffer = p.aovBindings[i].renderBuffer ? p.aovBindings[i].renderBuffer->h : nullptr;
+    }
+    GiCRenderParams c{};
+    c.aovBindings = aovs.data(); c.aovBindingCount = uint32_t(aovs.size());
+    static_assert(sizeof(GiCameraDesc) == sizeof(GiCCameraDesc), "layouts must match Gi.h:96-108");
+    memcpy(&c.camera, &p.camera, sizeof(GiCCameraDesc));
+    c.domeLight = p.domeLight ? p.domeLight->h : nullptr;
+    const GiRenderSettings& s = p.renderSettings;
+    c.renderSettings = {s.clippingPlanes, s.depthOfField, s.domeLightCameraVisible, s.filterImportanceSampling, s.frame, s.jitteredSampling,
+                        s.lightIntensityMultiplier, s.maxBounces, s.maxSampleValue, s.maxVolumeWalkLength, s.mediumStackSize, s.metersPerSceneUnit,
+                        s.nextEventEstimation, s.progressiveAccumulation, s.rrBounceOffset, s.rrInvMinTermProb, s.spp, s.time};
+    c.scene = p.scene ? p.scene->h : nullptr;
+    return giCRender(&c) == GI_C_OK ? GiStatus::Ok : GiStatus::Error;
+  }
+
+  GiScene* giCreateScene() { GiCScene* h = giCCreateScene(); return h ? new GiScene{h} : nullptr; }
+  void giDestroyScene(GiScene* s) { if (!s) return; giCDestroyScene(s->h); delete s; }
+
+#define GTL_LIGHT(Type, CType)                                                                                          \
+  Gi##Type##Light* giCreate##Type##Light(GiScene* scene) { auto* h = scene ? giCCreate##Type##Light(scene->h) : nullptr; return h ? new Gi##Type##Light{h} : nullptr; } \
+  void giDestroy##Type##Light(GiScene* scene, Gi##Type##Light* l) { if (!l) return; giCDestroy##Type##Light(scene->h, l->h); delete l; }
+  GTL_LIGHT(Sphere, GiCSphereLight) GTL_LIGHT(Distant, GiCDistantLight) GTL_LIGHT(Rect, GiCRectLight) GTL_LIGHT(Disk, GiCDiskLight)
+#undef GTL_LIGHT
+
+  void giSetSphereLightPosition(GiSphereLight* l, float* v) { giCSetSphereLightPosition(l->h, v); }
+  void giSetSphereLightBaseEmission(GiSphereLight* l, float* v) { giCSetSphereLightBaseEmission(l->h, v); }
+  void giSetSphereLightRadius(GiSphereLight* l, float x, float y, float z) { giCSetSphereLightRadius(l->h, x, y, z); }
+  void giSetSphereLightDiffuseSpecular(GiSphereLight* l, float d, float s) { giCSetSphereLightDiffuseSpecular(l->h, d, s); }
+  void giSetDistantLightDirection(GiDistantLight* l, float* v) { giCSetDistantLightDirection(l->h, v); }
+  void giSetDistantLightBaseEmission(GiDistantLight* l, float* v) { giCSetDistantLightBaseEmission(l->h, v); }
+  void giSetDistantLightAngle(GiDistantLight* l, float a) { giCSetDistantLightAngle(l->h, a); }
+  void giSetDistantLightDiffuseSpecular(GiDistantLight* l, float d, float s) { giCSetDistantLightDiffuseSpecular(l->h, d, s); }
+  void giSetRectLightOrigin(GiRectLight* l, float* v) { giCSetRectLightOrigin(l->h, v); }
+  void giSetRectLightTangents(GiRectLight* l, float* t0, float* t1) { giCSetRectLightTangents(l->h, t0, t1); }
+  void giSetRectLightBaseEmission(GiRectLight* l, float* v) { giCSetRectLightBaseEmission(l->h, v); }
+  void giSetRectLightDimensions(GiRectLight* l, float w, float h) { giCSetRectLightDimensions(l->h, w, h); }
+  void giSetRectLightDiffuseSpecular(GiRectLight* l, float d, float s) { giCSetRectLightDiffuseSpecular(l->h, d, s); }
+  void giSetDiskLightOrigin(GiDiskLight* l, float* v) { giCSetDiskLightOrigin(l->h, v); }
+  void giSetDiskLightTangents(GiDiskLight* l, float* t0, float* t1) { giCSetDiskLightTangents(l->h, t0, t1); }
+  void giSetDiskLightBaseEmission(GiDiskLight* l, float* v) { giCSetDiskLightBaseEmission(l->h, v); }
+  void giSetDiskLightRadius(GiDiskLight* l, float x, float y) { giCSetDiskLightRadius(l->h, x, y); }
+  void giSetDiskLightDiffuseSpecular(GiDiskLight* l, float d, float s) { giCSetDiskLightDiffuseSpecular(l->h, d, s); }
+
+  GiDomeLight* giCreateDomeLight(GiScene* scene, const char* filePath) { auto* h = scene ? giCCreateDomeLight(scene->h, filePath) : nullptr; return h ? new GiDomeLight{h} : nullptr; }
+  void giDestroyDomeLight(GiDomeLight* l) { if (!l) return; giCDestroyDomeLight(l->h); delete l; }
+  void giSetDomeLightRotation(GiDomeLight* l, float* q) { giCSetDomeLightRotation(l->h, q); }
+  void giSetDomeLightBaseEmission(GiDomeLight* l, float* v) { giCSetDomeLightBaseEmission(l->h, v); }
+  void giSetDomeLightDiffuseSpecular(GiDomeLight* l, float d, float s) { giCSetDomeLightDiffuseSpecular(l->h, d, s); }
+
+  GiRenderBuffer* giCreateRenderBuffer(uint32_t w, uint32_t h, GiRenderBufferFormat f) { auto* b = giCCreateRenderBuffer(w, h, int(f)); return b ? new GiRenderBuffer{b} : nullptr; }
+  void giDestroyRenderBuffer(GiRenderBuffer* b) { if (!b) return; giCDestroyRenderBuffer(b->h); delete b; }
+  void* giGetRenderBufferMem(GiRenderBuffer* b) { return b ? giCGetRenderBufferMem(b->h) : nullptr; }
+}

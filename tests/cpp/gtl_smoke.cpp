@@ -1,0 +1,68 @@
+// Drives the gi core through the reference's C++ API shape (include/gtl/gi/Gi.h): one quad + one emissive quad described as
+// MaterialX strings, rendered at 32x18.  Prints a checksum; exits non-zero on any API failure.  Built by tests/test_gtl_shim.py.
+#include <gtl/gi/Gi.h>
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+using namespace gtl;
+
+static GiMesh* quad(GiScene* scene, float z, float half, GiMaterial* mat, int id)
+{
+  std::vector<GiVertex> v(4);
+  const float p[4][2] = {{-half, -half}, {half, -half}, {half, half}, {-half, half}};
+  for (int i = 0; i < 4; i++) {
+    v[i] = GiVertex{{p[i][0], p[i][1], z}, 0.0f, {0, 0, 1}, 0.0f, {1, 0, 0}, 1.0f};
+  }
+  std::vector<GiFace> f = {{{0, 1, 2}}, {{0, 2, 3}}};
+  std::vector<int> faceIds = {0, 0};
+  std::vector<GiPrimvarData> primvars;
+  GiMeshDesc d{2, f, faceIds, id, true, false, "quad", 0, primvars, 4, v};
+  GiMesh* m = giCreateMesh(scene, d);
+  const float I[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+  giSetMeshTransform(m, &I[0][0]);
+  giSetMeshInstanceTransforms(m, 1, &I);
+  int ids[1] = {0};
+  giSetMeshInstanceIds(m, 1, ids);
+  giSetMeshMaterial(m, mat);
+  return m;
+}
+
+int main()
+{
+  std::vector<std::string> noPaths;
+  GiInitParams init{"", "", noPaths, nullptr, ""};
+  if (giInitialize(init) != GiStatus::Ok) { fprintf(stderr, "giInitialize failed\n"); return 2; }
+  GiScene* scene = giCreateScene();
+  const char* floorMtlx = "<materialx version=\"1.38\"><UsdPreviewSurface name=\"SR\" type=\"surfaceshader\">"
+                          "<input name=\"diffuseColor\" type=\"color3\" value=\"0.8, 0.2, 0.1\" /><input name=\"roughness\" type=\"float\" value=\"0.4\" />"
+                          "</UsdPreviewSurface></materialx>";
+  const char* lampMtlx = "<materialx version=\"1.39\"><open_pbr_surface name=\"L\" type=\"surfaceshader\">"
+                         "<input name=\"emission_luminance\" type=\"float\" value=\"5.0\" /><input name=\"emission_color\" type=\"color3\" value=\"1, 0.9, 0.8\" />"
+                         "</open_pbr_surface></materialx>";
+  GiMaterial* floorMat = giCreateMaterialFromMtlxStr(scene, "floor", floorMtlx);
+  GiMaterial* lampMat = giCreateMaterialFromMtlxStr(scene, "lamp", lampMtlx);
+  GiMaterial* unsupported = giCreateMaterialFromMtlxStr(scene, "x", "<materialx><standard_surface name=\"s\"/></materialx>");
+  if (!floorMat || !lampMat || unsupported) { fprintf(stderr, "material creation mismatch\n"); return 3; }
+  GiMesh* a = quad(scene, 0.0f, 2.0f, floorMat, 1);
+  GiMesh* b = quad(scene, 1.5f, 0.4f, lampMat, 2);
+  GiRenderBuffer* rb = giCreateRenderBuffer(32, 18, GiRenderBufferFormat::Float32Vec4);
+  GiRenderParams rp{};
+  GiAovBinding bind{GiAovId::Color, {0}, rb};
+  const float clear[4] = {0.1f, 0.1f, 0.1f, 1.0f};
+  memcpy(bind.clearValue, clear, 16);
+  rp.aovBindings.push_back(bind);
+  rp.camera = GiCameraDesc{{0, -3, 3}, {0, 0.7071068f, -0.7071068f}, {0, 0.7071068f, 0.7071068f}, 0.9f, 0, 0, 5.0f, 0.1f, 100.0f, 0};
+  rp.domeLight = nullptr;
+  rp.renderSettings = GiRenderSettings{false, false, true, true, 0, true, 1.0f, 6, 10.0f, 7, 0, 1.0f, false, true, 3, 0.95f, 8, 0};
+  rp.scene = scene;
+  if (giRender(rp) != GiStatus::Ok) { fprintf(stderr, "giRender failed\n"); return 4; }
+  const float* px = (const float*)giGetRenderBufferMem(rb);
+  double sum = 0; int lit = 0;
+  for (int i = 0; i < 32 * 18; i++) { sum += px[4 * i] + px[4 * i + 1] + px[4 * i + 2]; lit += px[4 * i] > 0.11f; if (px[4 * i + 3] != 1.0f) return 5; }
+  printf("gtl_smoke ok sum=%.6f lit=%d\n", sum, lit);
+  giDestroyMesh(a); giDestroyMesh(b); giDestroyMaterial(floorMat); giDestroyMaterial(lampMat);
+  giDestroyRenderBuffer(rb); giDestroyScene(scene); giTerminate();
+  return (lit > 50 && sum > 10.0) ? 0 : 6;
+}
