@@ -64,5 +64,5 @@ int main()
   printf("gtl_smoke ok sum=%.6f lit=%d\n", sum, lit);
   giDestroyMesh(a); giDestroyMesh(b); giDestroyMaterial(floorMat); giDestroyMaterial(lampMat);
   giDestroyRenderBuffer(rb); giDestroyScene(scene); giTerminate();
-  return (lit > 50 && sum > 10.0) ? 0 : 6;
+  return (lit >= 10 && sum > 10.0) ? 0 : 6;
 }
