@@ -177,8 +177,9 @@ class Scene:
         for m in desc.meshes:
             v = np.ascontiguousarray(m.vertices)
             f = np.ascontiguousarray(m.faces, np.uint32)
-            d = GiCMeshDesc(len(f), f.ctypes.data, None, m.id, int(m.double_sided), int(m.left_handed), m.name.encode(), 0,
-                            len(v), v.ctypes.data)
+            fid = np.ascontiguousarray(m.face_ids, np.int32) if m.face_ids is not None else None
+            d = GiCMeshDesc(len(f), f.ctypes.data, fid.ctypes.data if fid is not None else None, m.id, int(m.double_sided),
+                            int(m.left_handed), m.name.encode(), int(m.max_face_id), len(v), v.ctypes.data)
             h = L.giCCreateMesh(self.handle, C.byref(d))
             if not h:
                 raise GiError("giCCreateMesh failed: " + L.giCGetLastError().decode())
@@ -221,7 +222,7 @@ class Scene:
             raise GiError("giCSetSceneOption failed")
 
     def color_buffer(self, width, height):
-        key = (width, height)
+        key = ("color", width, height)
         if key not in self._buffers:
             rb = self.L.giCCreateRenderBuffer(width, height, FORMAT_FLOAT32_VEC4)
             if not rb:
@@ -256,6 +257,58 @@ class Scene:
         mem = L.giCGetRenderBufferMem(rb)
         full = np.ctypeslib.as_array(C.cast(mem, C.POINTER(C.c_float)), shape=(height, width, 4))
         return full[r0:r1].copy()
+
+    AOVS = {"normal": (1, FORMAT_FLOAT32_VEC4), "nee": (2, FORMAT_FLOAT32_VEC4), "barycentrics": (3, FORMAT_FLOAT32_VEC4),
+            "texcoords": (4, FORMAT_FLOAT32_VEC4), "bounces": (5, FORMAT_FLOAT32_VEC4), "opacity": (7, FORMAT_FLOAT32_VEC4),
+            "tangents": (8, FORMAT_FLOAT32_VEC4), "bitangents": (9, FORMAT_FLOAT32_VEC4), "thinWalled": (10, FORMAT_FLOAT32_VEC4),
+            "objectId": (11, FORMAT_INT32), "depth": (12, FORMAT_FLOAT32), "faceId": (13, FORMAT_INT32), "instanceId": (14, FORMAT_INT32),
+            "doubleSided": (15, FORMAT_FLOAT32_VEC4), "albedo": (16, FORMAT_FLOAT32_VEC4)}
+
+    def render_aovs(self, settings: RenderSettings, width: int, height: int, names, clear_values=None, with_color=True, rows=None):
+        """One giCRender call with the colour AOV (optional) plus the named non-colour AOVs bound (Gi.h:36-56, 161-166).
+        Returns {name: array}; vec3 AOVs come back as [h, w, 4] (the shader writes .xyz only), ids / depth as [h, w]."""
+        L = self.L
+        r0, r1 = rows if rows is not None else (0, height)
+        bindings = []
+        bufs = {}
+        if with_color:
+            bufs["color"] = (self.color_buffer(width, height), FORMAT_FLOAT32_VEC4, np.asarray(settings.clear_color, np.float32).tobytes(), AOV_COLOR)
+        for name in names:
+            aid, fmt = self.AOVS[name]
+            key = ("aov", name, width, height)
+            if key not in self._buffers:
+                self._buffers[key] = L.giCCreateRenderBuffer(width, height, fmt)
+            cv = (clear_values or {}).get(name, 0)
+            if fmt == FORMAT_INT32:
+                raw = np.int32(cv).tobytes() + b"\0" * 12
+            elif fmt == FORMAT_FLOAT32:
+                raw = np.float32(cv).tobytes() + b"\0" * 12
+            else:
+                cv4 = (list(cv) + [0, 0, 0, 0])[:4] if hasattr(cv, "__len__") else [cv] * 4
+                raw = np.asarray(cv4, np.float32).tobytes()
+            bufs[name] = (self._buffers[key], fmt, raw, aid)
+        arr = (GiCAovBinding * len(bufs))()
+        for i, (name, (rb, fmt, raw, aid)) in enumerate(bufs.items()):
+            arr[i].aovId = aid
+            C.memmove(arr[i].clearValue, raw, 16)
+            arr[i].renderBuffer = rb
+        p = GiCRenderParams()
+        p.aovBindings = C.cast(arr, C.POINTER(GiCAovBinding)); p.aovBindingCount = len(bufs)
+        p.camera = _camera(self.desc.camera); p.domeLight = None; p.renderSettings = _settings(settings); p.scene = self.handle
+        p.rowBegin, p.rowEnd = r0, r1
+        if L.giCRender(C.byref(p)) != GI_C_OK:
+            raise GiError("giCRender failed: " + L.giCGetLastError().decode())
+        out = {}
+        for name, (rb, fmt, raw, aid) in bufs.items():
+            mem = L.giCGetRenderBufferMem(rb)
+            if fmt == FORMAT_FLOAT32_VEC4:
+                a = np.ctypeslib.as_array(C.cast(mem, C.POINTER(C.c_float)), shape=(height, width, 4))
+            elif fmt == FORMAT_FLOAT32:
+                a = np.ctypeslib.as_array(C.cast(mem, C.POINTER(C.c_float)), shape=(height, width))
+            else:
+                a = np.ctypeslib.as_array(C.cast(mem, C.POINTER(C.c_int32)), shape=(height, width))
+            out[name] = a[r0:r1].copy()
+        return out
 
     def device_pointer(self, width, height) -> int:
         return int(self.L.giCGetRenderBufferDeviceMem(self.color_buffer(width, height)))

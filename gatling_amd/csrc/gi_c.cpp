@@ -250,7 +250,7 @@ struct GiCScene {
   float oldDomeEmission[3] = {0, 0, 0};
   // device scene
   DeviceBuffer<Node8> dNodes; DeviceBuffer<TriRec> dTris; DeviceBuffer<InstanceRec> dInstances;
-  DeviceBuffer<FVertex> dVerts; DeviceBuffer<MaterialRec> dMaterials;
+  DeviceBuffer<FVertex> dVerts; DeviceBuffer<MaterialRec> dMaterials; DeviceBuffer<int32_t> dTriFaceId;
   DeviceBuffer<SphereLightRec> dSphere; DeviceBuffer<DistantLightRec> dDistant; DeviceBuffer<RectLightRec> dRect; DeviceBuffer<DiskLightRec> dDisk;
   uint32_t nodeCount = 0, triCount = 0, bvhDepth = 0;
   // path state
@@ -317,7 +317,7 @@ void giCDestroyScene(GiCScene* s)
   if (!s) return;
   std::lock_guard<std::mutex> g(g_ctx.resourceMutex);
   (void)hipStreamSynchronize(g_ctx.stream);
-  s->dNodes.release(); s->dTris.release(); s->dInstances.release(); s->dVerts.release();
+  s->dNodes.release(); s->dTris.release(); s->dInstances.release(); s->dVerts.release(); s->dTriFaceId.release();
   s->dMaterials.release(); s->dSphere.release(); s->dDistant.release(); s->dRect.release(); s->dDisk.release();
   s->slots.release(); s->sampleBuf.release(); s->accum.release();
   for (uint32_t q = 0; q < Q_COUNT; q++) { s->qSlot[q].release(); s->qA[q].release(); s->qB[q].release(); s->qC[q].release(); }
@@ -650,7 +650,7 @@ inline void xformPoint(const float a[12], const float p[3], float out[3])
 int buildScene(GiCScene* s)
 {
   double t0 = nowMs();
-  std::vector<FVertex> verts; std::vector<InstanceRec> instances; std::vector<TriRec> tris;
+  std::vector<FVertex> verts; std::vector<InstanceRec> instances; std::vector<TriRec> tris; std::vector<int32_t> faceIdOf;
   std::vector<MaterialRec> mats(s->materials.size());
   for (size_t i = 0; i < s->materials.size(); i++) {
     mats[i].klass = s->materials[i]->desc.klass; mats[i].flags = s->materials[i]->desc.flags;
@@ -673,12 +673,27 @@ int buildScene(GiCScene* s)
       fv.u = v.u; fv.v = v.v;
       verts.push_back(fv);
     }
+    // FaceId AOV values, bug-compatible: face ids are stored with a 1/2/4-byte stride chosen from maxFaceId (Gi.cpp:878-885);
+    // the shader fetches the 32-bit word prim / (4/stride), shifts it by (prim % (4/stride)) * 8 bits (sic) and masks it
+    // with (stride*8 - 1) (rp_main.chit:231-240).  Evaluated once per primitive here.
+    std::vector<int32_t> meshFaceIdAov(m->faces.size());
+    {
+      const int stride = m->maxFaceId <= 255u ? 1 : (m->maxFaceId <= 65535u ? 2 : 4), invStride = 4 / stride;
+      std::vector<uint8_t> packed(((size_t)m->faces.size() * stride + 3) / 4 * 4, 0);
+      for (size_t i = 0; i < m->faces.size(); i++) { int32_t fid = i < m->faceIds.size() ? m->faceIds[i] : 0; memcpy(&packed[i * stride], &fid, stride); }
+      for (size_t i = 0; i < m->faces.size(); i++) {
+        int32_t word; memcpy(&word, &packed[(i / (size_t)invStride) * 4], 4);
+        word >>= (int)((i % (size_t)invStride) * 8);
+        meshFaceIdAov[i] = word & (stride * 8 - 1);
+      }
+    }
     size_t instCount = m->instanceTransforms.size() / 16;
     for (size_t ii = 0; ii < instCount; ii++) { // Gi.cpp:1188-1202
       InstanceRec ir{};
       composeTransform(m->transform, &m->instanceTransforms[16 * ii], ir.o2w);
       invert3x3(ir.o2w, ir.w2o);
       ir.mesh = meshIdx; ir.instanceId = ii < m->instanceIds.size() ? m->instanceIds[ii] : (int32_t)ii;
+      ir.pad = (uint32_t)m->id; // object id
       uint32_t instIdx = (uint32_t)instances.size();
       instances.push_back(ir);
       for (uint32_t f = 0; f < (uint32_t)m->faces.size(); f++) {
@@ -690,6 +705,7 @@ int buildScene(GiCScene* s)
         for (int a = 0; a < 3; a++) { t.v0[a] = p0[a]; t.e1[a] = p1[a] - p0[a]; t.e2[a] = p2[a] - p0[a]; t.vi[a] = vertexOffset + m->faces[f].v_i[a]; }
         t.instance = instIdx; t.prim = f; t.origId = (uint32_t)tris.size(); t.matFlags = matFlags;
         tris.push_back(t);
+        faceIdOf.push_back(meshFaceIdAov[f]);
       }
     }
     meshIdx++;
@@ -698,6 +714,9 @@ int buildScene(GiCScene* s)
   buildBvh8(tris, bvh);
   double t1 = nowMs();
   hipStream_t st = g_ctx.stream;
+  std::vector<int32_t> triFaceId(bvh.tris.size());
+  for (size_t i = 0; i < bvh.tris.size(); i++) triFaceId[i] = faceIdOf[bvh.tris[i].origId];
+  if (s->dTriFaceId.upload(triFaceId, st)) return GI_C_ERROR;
   if (s->dNodes.upload(bvh.nodes, st) || s->dTris.upload(bvh.tris, st) || s->dInstances.upload(instances, st) ||
       s->dVerts.upload(verts, st) || s->dMaterials.upload(mats, st))
     return GI_C_ERROR;
@@ -725,7 +744,7 @@ SceneView makeView(GiCScene* s)
   SceneView v{};
   v.nodes = s->dNodes.ptr; v.tris = s->dTris.ptr; v.instances = s->dInstances.ptr;
   v.verts = s->dVerts.ptr; v.materials = s->dMaterials.ptr; v.sphereLights = s->dSphere.ptr; v.distantLights = s->dDistant.ptr;
-  v.rectLights = s->dRect.ptr; v.diskLights = s->dDisk.ptr; v.nodeCount = s->nodeCount; v.triCount = s->triCount; v.bvhDepth = s->bvhDepth;
+  v.rectLights = s->dRect.ptr; v.diskLights = s->dDisk.ptr; v.triFaceId = s->dTriFaceId.ptr; v.nodeCount = s->nodeCount; v.triCount = s->triCount; v.bvhDepth = s->bvhDepth;
   return v;
 }
 
@@ -820,18 +839,46 @@ extern "C" int giCRender(const GiCRenderParams* params)
   if (!rs.progressiveAccumulation) s->dirty |= DIRTY_FRAMEBUFFER;
   if (s->dirty & DIRTY_FRAMEBUFFER) { s->sampleOffset = 0; s->dirty &= ~DIRTY_FRAMEBUFFER; }
 
-  // --- non-colour AOVs: cleared to their clear value (the 16 auxiliary AOVs are a "next" row)
+  // --- non-colour AOV bindings (Gi.h:36-56); NEE / Bounces / ClockCycles are not produced: they keep their clear value
+  AovTargets aovT{}; bool anyAov = false;
+  std::vector<GiCRenderBuffer*> aovBuffers;
   for (uint32_t i = 0; i < params->aovBindingCount; i++) {
     const GiCAovBinding& b = params->aovBindings[i];
     if (b.aovId == GI_C_AOV_COLOR) continue;
     GiCRenderBuffer* rb = b.renderBuffer;
-    size_t n = (size_t)rb->width * rb->height;
-    for (size_t k = 0; k < n; k++) memcpy((uint8_t*)rb->hostMem + k * rb->stride, b.clearValue, rb->stride);
-    HIP_TRY(hipMemcpyAsync(rb->deviceMem, rb->hostMem, rb->size, hipMemcpyHostToDevice, st));
+    if (rb->width != width || rb->height != height) { setError("giCRender: AOV buffers must share one size"); return GI_C_ERROR; }
+    if (b.aovId < 0 || b.aovId >= GI_C_AOV_COUNT) { setError("giCRender: bad AOV id"); return GI_C_ERROR; }
+    memcpy(aovT.clear[b.aovId], b.clearValue, 16);
+    const bool vec = rb->stride == 16;
+    F4* v4 = vec ? reinterpret_cast<F4*>(rb->deviceMem) : nullptr;
+    bool produced = true;
+    switch (b.aovId) {
+      case GI_C_AOV_NORMAL: aovT.normal = v4; break; case GI_C_AOV_BARYCENTRICS: aovT.barycentrics = v4; break;
+      case GI_C_AOV_TEXCOORDS: aovT.texcoords = v4; break; case GI_C_AOV_OPACITY: aovT.opacity = v4; break;
+      case GI_C_AOV_TANGENTS: aovT.tangents = v4; break; case GI_C_AOV_BITANGENTS: aovT.bitangents = v4; break;
+      case GI_C_AOV_THIN_WALLED: aovT.thinWalled = v4; break; case GI_C_AOV_DOUBLE_SIDED: aovT.doubleSided = v4; break;
+      case GI_C_AOV_ALBEDO: aovT.albedo = v4; break;
+      case GI_C_AOV_DEPTH: aovT.depth = vec ? nullptr : reinterpret_cast<float*>(rb->deviceMem); break;
+      case GI_C_AOV_OBJECT_ID: aovT.objectId = vec ? nullptr : reinterpret_cast<int32_t*>(rb->deviceMem); break;
+      case GI_C_AOV_FACE_ID: aovT.faceId = vec ? nullptr : reinterpret_cast<int32_t*>(rb->deviceMem); break;
+      case GI_C_AOV_INSTANCE_ID: aovT.instanceId = vec ? nullptr : reinterpret_cast<int32_t*>(rb->deviceMem); break;
+      default: produced = false; break;
+    }
+    if (produced) {
+      const bool wantsVec = !(b.aovId == GI_C_AOV_DEPTH || b.aovId == GI_C_AOV_OBJECT_ID || b.aovId == GI_C_AOV_FACE_ID || b.aovId == GI_C_AOV_INSTANCE_ID);
+      if (wantsVec != vec) { setError("giCRender: AOV render buffer format does not match the AOV (Gi.cpp:302-316)"); return GI_C_ERROR; }
+      anyAov = true; aovBuffers.push_back(rb);
+    } else { // fill with the clear value on the host
+      size_t n = (size_t)rb->width * rb->height;
+      for (size_t k = 0; k < n; k++) memcpy((uint8_t*)rb->hostMem + k * rb->stride, b.clearValue, rb->stride);
+      HIP_TRY(hipMemcpyAsync(rb->deviceMem, rb->hostMem, rb->size, hipMemcpyHostToDevice, st));
+    }
   }
-  if (!colorBinding) { HIP_TRY(hipStreamSynchronize(st)); return GI_C_OK; } // rp_main.miss:70-72: colour work is skipped entirely
-  GiCRenderBuffer* colorRb = colorBinding->renderBuffer;
-  if (colorRb->stride != 16) { setError("giCRender: colour AOV needs a Float32Vec4 buffer"); return GI_C_ERROR; }
+  if (!colorBinding && !anyAov) { HIP_TRY(hipStreamSynchronize(st)); return GI_C_OK; }
+  GiCRenderBuffer dummyColor{};
+  GiCRenderBuffer* colorRb = colorBinding ? colorBinding->renderBuffer : nullptr;
+  if (colorRb && colorRb->stride != 16) { setError("giCRender: colour AOV needs a Float32Vec4 buffer"); return GI_C_ERROR; }
+  (void)dummyColor;
 
   // --- uniforms (Gi.cpp:2373-2426; camera terms rp_main.rgen:199-212 evaluated once on the host)
   const size_t pixels = (size_t)(rowEnd - rowBegin) * width;
@@ -877,83 +924,97 @@ extern "C" int giCRender(const GiCRenderParams* params)
     U.totalLightCount = U.sphereCount + U.distantCount + U.rectCount + U.diskCount;
   }
 
-  // --- work decomposition (DESIGN.md "Persistent path pool"): work item = (pixel, sample); the frame is cut into batches of
-  // consecutive samples whose per-sample colour buffer fits the budget; a pool of `slots` paths is kept full from a running
-  // work counter until the batch's items run out.
-  auto envU64 = [](const char* name, uint64_t def) { const char* e = getenv(name); return e ? (uint64_t)strtoull(e, nullptr, 10) : def; };
-  const uint64_t budgetBytes = envU64("GATLING_SAMPLE_BUFFER_MB", s->optSampleBufferMb ? s->optSampleBufferMb : 2048) << 20;
-  const uint64_t poolMax = std::max<uint64_t>(64, envU64("GATLING_POOL_SLOTS", s->optPoolSlots ? s->optPoolSlots : (4u << 20)));
-  uint64_t batchSamples = std::min<uint64_t>(rs.spp, std::max<uint64_t>(1, budgetBytes / (pixels * 12)));
-  batchSamples = std::min<uint64_t>(batchSamples, std::max<uint64_t>(1, 0xffffffffull / pixels)); // work ids stay 32-bit
-  const uint32_t numBatches = (uint32_t)((rs.spp + batchSamples - 1) / batchSamples);
-  const size_t slots = (size_t)std::min<uint64_t>(poolMax, (uint64_t)pixels * batchSamples);
-
-  // persistent grids: blocks per CU limited by registers (<= 6 waves/SIMD for k_trace) and, for k_trace, by the LDS it stages
-  uint32_t wideBlocks, traceBlocks;
-  {
-    SceneView v0 = makeView(s);
-    uint32_t ln, lt, ldsBytes; traceLdsLayout(v0, ln, lt, ldsBytes);
-    uint32_t perCu = std::min<uint32_t>(6u, (160u * 1024u) / (ldsBytes + 256u));
-    if (const char* e = getenv("GATLING_TRACE_BLOCKS_PER_CU")) perCu = (uint32_t)atoi(e);
-    uint32_t widePerCu = 8u;
-    if (const char* e = getenv("GATLING_WIDE_BLOCKS_PER_CU")) widePerCu = (uint32_t)atoi(e);
-    perCu = std::max(perCu, 1u); widePerCu = std::max(widePerCu, 1u);
-    wideBlocks = (uint32_t)std::min<size_t>((slots + 255) / 256, (size_t)g_ctx.cuCount * widePerCu);
-    traceBlocks = (uint32_t)std::min<size_t>((slots + 255) / 256, (size_t)g_ctx.cuCount * perCu);
-  }
-  if (ensurePathState(s, slots, wideBlocks, traceBlocks) != GI_C_OK) return GI_C_ERROR;
-  if (s->sampleBuf.alloc(pixels * batchSamples * 3) || s->accum.alloc(pixels)) return GI_C_ERROR;
-  PathState ps{s->slots.ptr};
-  SceneView view = makeView(s);
-  QueueSet qs = makeQueueSet(s);
-  F4* colorOut = reinterpret_cast<F4*>(colorRb->deviceMem);
-  const bool nee = rs.nextEventEstimation != 0;
-
-  // --- the bounce loop (rp_main.rgen:215, 295): every pool slot advances one stage per iteration
-  HIP_TRY(hipStreamSynchronize(st));
   double tStart = nowMs();
   uint32_t iters = 0, traceLaunches = 0;
   size_t ev = 0;
   std::vector<int> evKind; // 0 raygen, 1 trace, 2 shade, 3 shadow
   const bool timers = s->kernelTimers;
-  // HIP events around the stage launches of every `timerStride`-th iteration (events on every launch cost ~16 % of the
-  // frame); per-stage totals are scaled back up by the sampling factor.
-  const uint32_t timerStride = std::max(1u, s->kernelTimerStride);
-  uint64_t curIter = 0, sampledIters = 0, totalIters = 0;
-  auto timed = [&](int kind, auto&& fn) {
-    if (timers && (curIter % timerStride) == 0u) { (void)hipEventRecord(poolEvent(s, ev), st); fn(); (void)hipEventRecord(poolEvent(s, ev + 1), st); ev += 2; evKind.push_back(kind); }
-    else fn();
-  };
-  const uint32_t pollEvery = 16;
-  for (uint32_t batch = 0; batch < numBatches; batch++) {
-    U.batchFirstSample = (uint32_t)(batch * batchSamples);
-    U.batchSamples = (uint32_t)std::min<uint64_t>(batchSamples, rs.spp - (uint64_t)batch * batchSamples);
-    U.workTotal = (uint32_t)(pixels * U.batchSamples);
-    const uint32_t poolNow = (uint32_t)std::min<uint64_t>(slots, U.workTotal);
-    U.poolSlots = poolNow;
-    launchInit(st, ps, qs, s->dCounters.ptr, poolNow, batch == 0);
-    const uint64_t rounds = ((uint64_t)U.workTotal + poolNow - 1) / poolNow; // raygen rounds needed to hand out all work
-    const uint64_t maxIters = (rounds + 2) * (std::max(1u, U.maxBounces) + 1) + 8;
-    for (uint64_t it = 0; it < maxIters; it++) {
-      const uint32_t par = (uint32_t)(it & 1u);
-      curIter = totalIters; if (timers && (totalIters % timerStride) == 0u) sampledIters++;
-      timed(0, [&] { launchRaygen(st, wideBlocks, U, ps, qs, s->dCounters.ptr, par, s->sampleBuf.ptr); });
-      if (it >= rounds && (it % pollEvery) == 0u) { // all work cannot be handed out earlier; afterwards poll the queue sizes
-        HIP_TRY(hipMemcpyAsync(s->hCounters, s->dCounters.ptr, sizeof(PaddedCounter) * Q_COUNT * NSHARD, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        uint32_t pending = 0; for (uint32_t k = 0; k < NSHARD; k++) pending += s->hCounters->count[Q_TRACE_A + par][k].v;
-        if (pending == 0) { totalIters++; break; } // raygen consumed the regen queue and produced no rays: the pool has drained
-      }
-      timed(1, [&] { launchTrace(st, traceBlocks, false, s->countTraversal, view, ps, qs, s->dCounters.ptr, Q_TRACE_A + par, Q_REGEN_A + (par ^ 1u)); });
-      traceLaunches++;
-      timed(2, [&] { launchShade(st, wideBlocks, U, view, ps, qs, s->dCounters.ptr, par); });
-      if (nee) timed(3, [&] { launchTrace(st, traceBlocks, true, s->countTraversal, view, ps, qs, s->dCounters.ptr, Q_SHADOW, Q_SHADOW); });
-      iters++; totalIters++;
+  uint64_t sampledIters = 0, totalIters = 0;
+  SceneView view = makeView(s);
+  if (ensurePathState(s, 1, 1, 1) != GI_C_OK) return GI_C_ERROR; // counters / pinned mirror exist even for AOV-only renders
+  if (colorRb) {
+    // --- work decomposition (DESIGN.md "Persistent path pool"): work item = (pixel, sample); the frame is cut into batches of
+    // consecutive samples whose per-sample colour buffer fits the budget; a pool of `slots` paths is kept full from a running
+    // work counter until the batch's items run out.
+    auto envU64 = [](const char* name, uint64_t def) { const char* e = getenv(name); return e ? (uint64_t)strtoull(e, nullptr, 10) : def; };
+    const uint64_t budgetBytes = envU64("GATLING_SAMPLE_BUFFER_MB", s->optSampleBufferMb ? s->optSampleBufferMb : 2048) << 20;
+    const uint64_t poolMax = std::max<uint64_t>(64, envU64("GATLING_POOL_SLOTS", s->optPoolSlots ? s->optPoolSlots : (4u << 20)));
+    uint64_t batchSamples = std::min<uint64_t>(rs.spp, std::max<uint64_t>(1, budgetBytes / (pixels * 12)));
+    batchSamples = std::min<uint64_t>(batchSamples, std::max<uint64_t>(1, 0xffffffffull / pixels)); // work ids stay 32-bit
+    const uint32_t numBatches = (uint32_t)((rs.spp + batchSamples - 1) / batchSamples);
+    const size_t slots = (size_t)std::min<uint64_t>(poolMax, (uint64_t)pixels * batchSamples);
+
+    // persistent grids: blocks per CU limited by registers (<= 6 waves/SIMD for k_trace) and, for k_trace, by the LDS it stages
+    uint32_t wideBlocks, traceBlocks;
+    {
+      SceneView v0 = makeView(s);
+      uint32_t ln, lt, ldsBytes; traceLdsLayout(v0, ln, lt, ldsBytes);
+      uint32_t perCu = std::min<uint32_t>(6u, (160u * 1024u) / (ldsBytes + 256u));
+      if (const char* e = getenv("GATLING_TRACE_BLOCKS_PER_CU")) perCu = (uint32_t)atoi(e);
+      uint32_t widePerCu = 8u;
+      if (const char* e = getenv("GATLING_WIDE_BLOCKS_PER_CU")) widePerCu = (uint32_t)atoi(e);
+      perCu = std::max(perCu, 1u); widePerCu = std::max(widePerCu, 1u);
+      wideBlocks = (uint32_t)std::min<size_t>((slots + 255) / 256, (size_t)g_ctx.cuCount * widePerCu);
+      traceBlocks = (uint32_t)std::min<size_t>((slots + 255) / 256, (size_t)g_ctx.cuCount * perCu);
     }
-    launchAccumulate(st, U, s->sampleBuf.ptr, s->accum.ptr, colorOut, batch == 0, batch + 1 == numBatches);
+    if (ensurePathState(s, slots, wideBlocks, traceBlocks) != GI_C_OK) return GI_C_ERROR;
+    if (s->sampleBuf.alloc(pixels * batchSamples * 3) || s->accum.alloc(pixels)) return GI_C_ERROR;
+    PathState ps{s->slots.ptr};
+    QueueSet qs = makeQueueSet(s);
+    F4* colorOut = reinterpret_cast<F4*>(colorRb->deviceMem);
+    const bool nee = rs.nextEventEstimation != 0;
+
+    // --- the bounce loop (rp_main.rgen:215, 295): every pool slot advances one stage per iteration
+    HIP_TRY(hipStreamSynchronize(st));
+    tStart = nowMs();
+    // HIP events around the stage launches of every `timerStride`-th iteration (events on every launch cost ~16 % of the
+    // frame); per-stage totals are scaled back up by the sampling factor.
+    const uint32_t timerStride = std::max(1u, s->kernelTimerStride);
+    uint64_t curIter = 0;
+    auto timed = [&](int kind, auto&& fn) {
+      if (timers && (curIter % timerStride) == 0u) { (void)hipEventRecord(poolEvent(s, ev), st); fn(); (void)hipEventRecord(poolEvent(s, ev + 1), st); ev += 2; evKind.push_back(kind); }
+      else fn();
+    };
+    const uint32_t pollEvery = 16;
+    for (uint32_t batch = 0; batch < numBatches; batch++) {
+      U.batchFirstSample = (uint32_t)(batch * batchSamples);
+      U.batchSamples = (uint32_t)std::min<uint64_t>(batchSamples, rs.spp - (uint64_t)batch * batchSamples);
+      U.workTotal = (uint32_t)(pixels * U.batchSamples);
+      const uint32_t poolNow = (uint32_t)std::min<uint64_t>(slots, U.workTotal);
+      U.poolSlots = poolNow;
+      launchInit(st, ps, qs, s->dCounters.ptr, poolNow, batch == 0);
+      const uint64_t rounds = ((uint64_t)U.workTotal + poolNow - 1) / poolNow; // raygen rounds needed to hand out all work
+      const uint64_t maxIters = (rounds + 2) * (std::max(1u, U.maxBounces) + 1) + 8;
+      for (uint64_t it = 0; it < maxIters; it++) {
+        const uint32_t par = (uint32_t)(it & 1u);
+        curIter = totalIters; if (timers && (totalIters % timerStride) == 0u) sampledIters++;
+        timed(0, [&] { launchRaygen(st, wideBlocks, U, ps, qs, s->dCounters.ptr, par, s->sampleBuf.ptr); });
+        if (it >= rounds && (it % pollEvery) == 0u) { // all work cannot be handed out earlier; afterwards poll the queue sizes
+          HIP_TRY(hipMemcpyAsync(s->hCounters, s->dCounters.ptr, sizeof(PaddedCounter) * Q_COUNT * NSHARD, hipMemcpyDeviceToHost, st));
+          HIP_TRY(hipStreamSynchronize(st));
+          uint32_t pending = 0; for (uint32_t k = 0; k < NSHARD; k++) pending += s->hCounters->count[Q_TRACE_A + par][k].v;
+          if (pending == 0) { totalIters++; break; } // raygen consumed the regen queue and produced no rays: the pool has drained
+        }
+        timed(1, [&] { launchTrace(st, traceBlocks, false, s->countTraversal, view, ps, qs, s->dCounters.ptr, Q_TRACE_A + par, Q_REGEN_A + (par ^ 1u)); });
+        traceLaunches++;
+        timed(2, [&] { launchShade(st, wideBlocks, U, view, ps, qs, s->dCounters.ptr, par); });
+        if (nee) timed(3, [&] { launchTrace(st, traceBlocks, true, s->countTraversal, view, ps, qs, s->dCounters.ptr, Q_SHADOW, Q_SHADOW); });
+        iters++; totalIters++;
+      }
+      launchAccumulate(st, U, s->sampleBuf.ptr, s->accum.ptr, colorOut, batch == 0, batch + 1 == numBatches);
+    }
+  }
+  if (anyAov) { // the non-colour AOV pass (k_aov) + read-back of the rows of this tile
+    launchAov(st, U, view, aovT);
+    if (hipGetLastError() != hipSuccess) { setError("k_aov launch failed"); return GI_C_ERROR; }
+    for (GiCRenderBuffer* rb : aovBuffers) {
+      if (rb->deviceOnly) continue;
+      size_t off = (size_t)rowBegin * width * rb->stride, bytes = pixels * rb->stride;
+      HIP_TRY(hipMemcpyAsync((uint8_t*)rb->hostMem + off, (uint8_t*)rb->deviceMem + off, bytes, hipMemcpyDeviceToHost, st));
+    }
   }
   HIP_TRY(hipMemcpyAsync(s->hCounters, s->dCounters.ptr, sizeof(Counters), hipMemcpyDeviceToHost, st));
-  if (!colorRb->deviceOnly) {
+  if (colorRb && !colorRb->deviceOnly) {
     size_t off = (size_t)rowBegin * width * 16, bytes = pixels * 16;
     HIP_TRY(hipMemcpyAsync((uint8_t*)colorRb->hostMem + off, (uint8_t*)colorRb->deviceMem + off, bytes, hipMemcpyDeviceToHost, st));
   }

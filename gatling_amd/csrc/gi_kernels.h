@@ -18,6 +18,7 @@ void launchTrace(hipStream_t s, uint32_t blocks, bool anyHit, bool count, const 
                  uint32_t qIn, uint32_t qMiss);
 void launchShade(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par);
 
+void launchAov(hipStream_t s, const FrameUniforms& U, const SceneView& sc, const AovTargets& A);
 void launchDebugBsdf(hipStream_t s, const MaterialRec* mat, uint32_t count, const float* in, float* out);
 
 } // namespace gi

@@ -122,6 +122,40 @@ __global__ void k_init(PathState st, QueueSet qs, Counters* cnt, uint32_t n, uin
   }
 }
 
+// Camera ray of (pixel, sample): RNG init, pixel jitter / filter importance sampling, thin lens, clip range
+// (rp_main.rgen:215-288).  Returns the RNG state after the draws the reference makes here.
+__device__ __forceinline__ void make_camera_ray(const FrameUniforms& U, uint32_t pixelIndex, uint32_t sampleIndex, V3& origin, V3& dir, float& tMin, float& tMax, uint32_t& rng)
+{
+  const uint32_t px = pixelIndex % U.imageWidth, py = pixelIndex / U.imageWidth;
+  rng = gi_hash_init(pixelIndex * (sampleIndex + 1u)); // :223, common.glsl:121-124
+  float r0 = gi_next1f(rng), r1 = gi_next1f(rng);     // :224 (always drawn)
+  float sox = 0.5f, soy = 0.5f;
+  if (U.flags & FLAG_JITTER) {
+    if (U.flags & FLAG_FIS) { float gx, gy; gi_fis_gauss(r0, r1, gx, gy); sox = 0.5f + gx; soy = 0.5f + gy; }
+    else { sox = r0; soy = r1; }
+  }
+  V3 camRight = v3(U.camRight), camUp = v3(U.camUp), camPos = v3(U.camPos);
+  V3 P = (v3(U.L) + (camRight * ((float)px + sox)) * U.WX) + (camUp * ((float)py + soy)) * U.HY; // :239-242
+  origin = camPos;
+  dir = normalize(P - origin);
+  if ((U.flags & FLAG_DOF) && U.lensRadius > 0.0f) { // :249-263
+    float z0 = gi_next1f(rng), z1 = gi_next1f(rng);
+    V3 focal = origin + dir * U.focusDistance;
+    V3 ap = gi_sample_hemisphere(z0, z1);
+    origin = origin + camRight * (ap.x * U.lensRadius);
+    origin = origin + camUp * (ap.y * U.lensRadius);
+    dir = normalize(focal - origin);
+  }
+  if (dir.x == 0.0f) dir.x += GI_FLT_MIN; // :271
+  if (dir.y == 0.0f) dir.y += GI_FLT_MIN;
+  if (dir.z == 0.0f) dir.z += GI_FLT_MIN;
+  tMin = 0.0f; tMax = GI_FLT_MAX;
+  if (U.flags & FLAG_CLIP) { // :287-288, 308-314 (bounce 0 only)
+    float cosCone = fmax2(1e-5f, dot(dir, v3(U.camFwd)));
+    tMin = U.clipNear / cosCone; tMax = U.clipFar / cosCone;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_raygen: persistent-thread ray generation (rp_main.rgen:213-283), the per-sample finish (:483-498) and the miss
 // term.  Entry i of the regen queue finishes its sample (if any) into the per-sample colour buffer and takes work item
@@ -169,33 +203,8 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st,
         const uint32_t pixelLocal = w % U.pixelCount, sLocal = w / U.pixelCount;
         const uint32_t pixelIndex = U.rowBegin * U.imageWidth + pixelLocal; // :195 (global index: RNG is tile independent)
         const uint32_t sampleIndex = U.sampleOffset + U.batchFirstSample + sLocal;
-        const uint32_t px = pixelIndex % U.imageWidth, py = pixelIndex / U.imageWidth;
-        uint32_t rng = gi_hash_init(pixelIndex * (sampleIndex + 1u)); // :223, common.glsl:121-124
-        float r0 = gi_next1f(rng), r1 = gi_next1f(rng);               // :224 (always drawn)
-        float sox = 0.5f, soy = 0.5f;
-        if (U.flags & FLAG_JITTER) {
-          if (U.flags & FLAG_FIS) { float gx, gy; gi_fis_gauss(r0, r1, gx, gy); sox = 0.5f + gx; soy = 0.5f + gy; }
-          else { sox = r0; soy = r1; }
-        }
-        V3 camRight = v3(U.camRight), camUp = v3(U.camUp), camPos = v3(U.camPos);
-        V3 P = (v3(U.L) + (camRight * ((float)px + sox)) * U.WX) + (camUp * ((float)py + soy)) * U.HY; // :239-242
-        origin = camPos;
-        dir = normalize(P - origin);
-        if ((U.flags & FLAG_DOF) && U.lensRadius > 0.0f) { // :249-263
-          float z0 = gi_next1f(rng), z1 = gi_next1f(rng);
-          V3 focal = origin + dir * U.focusDistance;
-          V3 ap = gi_sample_hemisphere(z0, z1);
-          origin = origin + camRight * (ap.x * U.lensRadius);
-          origin = origin + camUp * (ap.y * U.lensRadius);
-          dir = normalize(focal - origin);
-        }
-        if (dir.x == 0.0f) dir.x += GI_FLT_MIN; // :271
-        if (dir.y == 0.0f) dir.y += GI_FLT_MIN;
-        if (dir.z == 0.0f) dir.z += GI_FLT_MIN;
-        if (U.flags & FLAG_CLIP) { // :287-288, 308-314 (bounce 0 only)
-          float cosCone = fmax2(1e-5f, dot(dir, v3(U.camFwd)));
-          tMin = U.clipNear / cosCone; tMax = U.clipFar / cosCone;
-        }
+        uint32_t rng;
+        make_camera_ray(U, pixelIndex, sampleIndex, origin, dir, tMin, tMax, rng);
         st4(&S->thr, 1.0f, 1.0f, 1.0f, u2f(0u)); // :274-276
         st4(&S->rad, 0.0f, 0.0f, 0.0f, u2f(rng));
         st4(&S->id, u2f(pixelLocal), u2f(sLocal), u2f(1u), 0.0f);
@@ -930,6 +939,106 @@ __global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_aov: the non-colour AOVs (rp_main.rgen:132-183, 517-520; rp_main.chit:192-290).  They depend only on the primary hit
+// of each sample and are overwritten sample after sample, so they are produced by a separate per-pixel pass that
+// replays the camera rays of samples 0..spp-1 in order (same RNG streams) -- exact, and off the colour path's hot loop.
+// ------------------------------------------------------------------------------------------------
+__device__ inline V3 bsdf_albedo(const MaterialRec* m, const ShState& st, V3 k1)
+{
+  float nk1 = fmax2(dot(st.normal, k1), 1e-4f);
+  if (m->klass == 0u) return v3(m->p[0], m->p[1], m->p[2]);
+  if (m->klass == 1u) {
+    UpsParams u = ups_params(m);
+    float Fc = u.coat * (0.04f + 0.96f * schlick_w(nk1));
+    V3 Fs = schlick3(u.F0, nk1);
+    V3 diffuse = (u.albedo * (v3(1.0f, 1.0f, 1.0f) - Fs)) * (1.0f - Fc);
+    V3 glossy = v3(Fc, Fc, Fc) + Fs * (1.0f - Fc);
+    return diffuse + glossy;
+  }
+  OpbrParams o = opbr_params(m);
+  float eta = st.frontFace ? o.eta : 1.0f / o.eta;
+  float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1));
+  float Fd = fresnel_dielectric(nk1, eta);
+  float base = 1.0f - Fc, diel = 1.0f - o.metalness;
+  V3 diffuse = (o.albedo * o.coatTint) * (base * diel * (1.0f - Fd) * (1.0f - o.tw));
+  V3 glossy = v3(Fc, Fc, Fc) + ((schlick_f82(o.albedo, o.metalTint, nk1) * o.specWeight) * o.coatTint) * (base * o.metalness)
+              + (o.specColor * o.coatTint) * (base * diel * Fd);
+  return diffuse + glossy;
+}
+
+template <uint32_t STACK, bool OVERFLOW>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_aov(FrameUniforms U, SceneView sc, AovTargets A, uint32_t ldsNodes, uint32_t ldsTris)
+{
+  extern __shared__ uint4 s_dyn[];
+  uint2 (*s_stack)[TRACE_BLOCK] = reinterpret_cast<uint2 (*)[TRACE_BLOCK]>(s_dyn);
+  uint4* s_nodes = s_dyn + (STACK * TRACE_BLOCK * sizeof(uint2)) / sizeof(uint4);
+  uint4* s_tris = s_nodes + ldsNodes * 5u;
+  for (uint32_t i = threadIdx.x; i < ldsNodes * 5u; i += TRACE_BLOCK) s_nodes[i] = reinterpret_cast<const uint4*>(sc.nodes)[i];
+  for (uint32_t i = threadIdx.x; i < ldsTris * 3u; i += TRACE_BLOCK) s_tris[i] = reinterpret_cast<const uint4*>(sc.tris)[(i / 3u) * 4u + (i % 3u)];
+  __syncthreads();
+  const uint32_t p = blockIdx.x * TRACE_BLOCK + threadIdx.x;
+  if (p >= U.pixelCount) return;
+  const uint32_t pixelIndex = U.rowBegin * U.imageWidth + p;
+  auto put3 = [&](F4* buf, V3 v) { if (buf) { float* d = reinterpret_cast<float*>(&buf[pixelIndex]); d[0] = v.x; d[1] = v.y; d[2] = v.z; } };
+  auto clr3 = [&](F4* buf, int id) { put3(buf, v3(A.clear[id][0], A.clear[id][1], A.clear[id][2])); };
+  clr3(A.barycentrics, 3); clr3(A.texcoords, 4); clr3(A.opacity, 7); clr3(A.tangents, 8); clr3(A.bitangents, 9); clr3(A.thinWalled, 10);
+  if (A.objectId) A.objectId[pixelIndex] = (int)f2u(A.clear[11][0]);
+  if (A.depth) A.depth[pixelIndex] = A.clear[12][0];
+  if (A.faceId) A.faceId[pixelIndex] = (int)f2u(A.clear[13][0]);
+  if (A.instanceId) A.instanceId[pixelIndex] = (int)f2u(A.clear[14][0]);
+  clr3(A.doubleSided, 15);
+  V3 curNormal = v3(0.0f, 0.0f, 0.0f), curAlbedo = curNormal;
+  if (U.sampleOffset == 0u) { clr3(A.normal, 1); clr3(A.albedo, 16); curNormal = v3(A.clear[1][0], A.clear[1][1], A.clear[1][2]); curAlbedo = v3(A.clear[16][0], A.clear[16][1], A.clear[16][2]); }
+  else {
+    if (A.normal) { const F4 q = ld4(&A.normal[pixelIndex]); curNormal = v3(q.x, q.y, q.z); }
+    if (A.albedo) { const F4 q = ld4(&A.albedo[pixelIndex]); curAlbedo = v3(q.x, q.y, q.z); }
+  }
+  TraceCounters tc{0u, 0u};
+  const bool blend = (U.flags & FLAG_PROGRESSIVE) && U.sampleOffset > 0u;
+  for (uint32_t s = 0; s < U.spp; s++) {
+    V3 origin, dir; float tMin, tMax; uint32_t rng;
+    make_camera_ray(U, pixelIndex, U.sampleOffset + s, origin, dir, tMin, tMax, rng);
+    float t, u, v; uint32_t tri;
+    if (!traverse<false, false, STACK, OVERFLOW>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, origin, dir, tMin, tMax, t, u, v, tri, tc)) continue;
+    ShState ss;
+    setup_shading_state(sc, tri, u, v, dir, ss);
+    const uint4* tp = reinterpret_cast<const uint4*>(sc.tris) + (size_t)tri * 4u;
+    const uint32_t instIdx = tp[2].z;
+    put3(A.opacity, v3(1.0f, 0.0f, 0.0f));
+    put3(A.tangents, (ss.tangentU + v3(1.0f, 1.0f, 1.0f)) * 0.5f);
+    put3(A.bitangents, (ss.tangentV + v3(1.0f, 1.0f, 1.0f)) * 0.5f);
+    put3(A.barycentrics, v3(1.0f - u - v, u, v));
+    if (A.texcoords) {
+      const uint4 td = tp[3];
+      const float bx = 1.0f - u - v;
+      const FVertex* va = &sc.verts[td.x]; const FVertex* vb = &sc.verts[td.y]; const FVertex* vc = &sc.verts[td.z];
+      put3(A.texcoords, v3((bx * va->u + u * vb->u) + v * vc->u, (bx * va->v + u * vb->v) + v * vc->v, 0.0f));
+    }
+    put3(A.thinWalled, v3(0.0f, 1.0f, 0.0f));
+    if (A.objectId) A.objectId[pixelIndex] = (int)sc.instances[instIdx].pad;
+    if (A.depth) A.depth[pixelIndex] = 2.0f * gi_logf(t / U.clipNear) / gi_logf(U.clipFar / U.clipNear) - 1.0f;
+    if (A.faceId) A.faceId[pixelIndex] = sc.triFaceId[tri];
+    if (A.instanceId) A.instanceId[pixelIndex] = sc.instances[instIdx].instanceId;
+    put3(A.doubleSided, (ss.meshFlags & 2u) ? v3(0.0f, 1.0f, 0.0f) : v3(1.0f, 0.0f, 0.0f));
+    if (A.normal) {
+      const V3 pos = (ss.normal + v3(1.0f, 1.0f, 1.0f)) * 0.5f;
+      const V3 prev = blend ? curNormal : pos;
+      curNormal = (prev * U.sampleOffsetF + pos * U.sppF) * U.invTotalSampleCount;
+    }
+    if (A.albedo) {
+      const V3 al = bsdf_albedo(&sc.materials[ss.material], ss, -dir);
+      const V3 prev = blend ? curAlbedo : al;
+      curAlbedo = (prev * U.sampleOffsetF + al * U.sppF) * U.invTotalSampleCount;
+    }
+  }
+  put3(A.albedo, curAlbedo);
+  if (A.normal) { // rp_main.rgen:517-520
+    const V3 n = curNormal * 2.0f - v3(1.0f, 1.0f, 1.0f);
+    put3(A.normal, (normalize(n) + v3(1.0f, 1.0f, 1.0f)) * 0.5f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_debug_bsdf: the closed-form BSDF entry points on explicit shading frames (device-side known-answer tests)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_debug_bsdf(const MaterialRec* mat, uint32_t count, const float* __restrict__ in, float* __restrict__ out)
@@ -981,6 +1090,14 @@ void launchTrace(hipStream_t s, uint32_t blocks, bool anyHit, bool count, const 
 {
   if (!anyHit) { if (count) launchTraceVariant<false, true>(s, blocks, sc, st, qs, cnt, qIn, qMiss); else launchTraceVariant<false, false>(s, blocks, sc, st, qs, cnt, qIn, qMiss); }
   else { if (count) launchTraceVariant<true, true>(s, blocks, sc, st, qs, cnt, qIn, qMiss); else launchTraceVariant<true, false>(s, blocks, sc, st, qs, cnt, qIn, qMiss); }
+}
+void launchAov(hipStream_t s, const FrameUniforms& U, const SceneView& sc, const AovTargets& A)
+{
+  uint32_t ln, lt, bytes; traceLdsLayout(sc, ln, lt, bytes);
+  const uint32_t blocks = (U.pixelCount + TRACE_BLOCK - 1u) / TRACE_BLOCK;
+  if (sc.bvhDepth <= 8u) hipLaunchKernelGGL((k_aov<8, false>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, U, sc, A, ln, lt);
+  else if (sc.bvhDepth <= 16u) hipLaunchKernelGGL((k_aov<16, false>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, U, sc, A, ln, lt);
+  else hipLaunchKernelGGL((k_aov<16, true>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, U, sc, A, ln, lt);
 }
 void launchShade(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par)
 {

@@ -55,7 +55,7 @@ struct InstanceRec {
   float w2o[9];  // inverse of its 3x3 part, row-major
   uint32_t mesh;
   int32_t instanceId;
-  uint32_t pad;
+  uint32_t pad; // the mesh's object id (GiMeshDesc.id -> BlasPayloadBufferPreamble.objectId, rp_main.h:142-147)
 };
 static_assert(sizeof(InstanceRec) == 96, "InstanceRec must be 96 bytes");
 
@@ -113,9 +113,19 @@ struct SceneView {
   const DistantLightRec* distantLights;
   const RectLightRec* rectLights;
   const DiskLightRec* diskLights;
+  const int32_t* triFaceId; // per triangle (BVH order): the value the FaceId AOV shows (rp_main.chit:230-240)
   uint32_t nodeCount;
   uint32_t triCount;
   uint32_t bvhDepth; // levels of the BVH8 (bounds the traversal stack)
+};
+
+struct alignas(16) F4 { float x, y, z, w; };
+
+// Device buffers of the bound non-colour AOVs (null = not bound) and their clear values by GiAovId (Gi.h:36-56).
+struct AovTargets {
+  F4* normal; F4* barycentrics; F4* texcoords; F4* opacity; F4* tangents; F4* bitangents; F4* thinWalled; F4* doubleSided; F4* albedo;
+  float* depth; int32_t* objectId; int32_t* faceId; int32_t* instanceId;
+  float clear[17][4];
 };
 
 // Path state that persists across stages: ONE 64-byte record per slot of the persistent path pool.  A slot carries one
@@ -124,8 +134,6 @@ struct SceneView {
 // Everything that merely flows from one stage to the next (rays, hits, shadow rays) lives in the queues as records
 // written/read in queue order (coalesced); only this record is gathered/scattered by slot index, and 64 B is one
 // fabric request.  A 4 M-slot pool is 268 MB.
-struct alignas(16) F4 { float x, y, z, w; };
-
 struct alignas(64) Slot {
   F4 thr;  // throughput.xyz, asfloat(bitfield)   (rp_main_payload.glsl:24-33)
   F4 rad;  // radiance.xyz, asfloat(rng state)

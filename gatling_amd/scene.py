@@ -117,6 +117,8 @@ class MeshDesc:
     transform: np.ndarray = field(default_factory=lambda: np.eye(4, dtype=np.float32))  # USD row-vector convention
     instance_transforms: np.ndarray = field(default_factory=lambda: np.eye(4, dtype=np.float32)[None].copy())
     instance_ids: Optional[np.ndarray] = None
+    face_ids: Optional[np.ndarray] = None   # int32 per face (GiMeshDesc.faceIds); None = zeros
+    max_face_id: int = 0
 
 
 @dataclass

@@ -135,6 +135,9 @@ typedef struct GiCRenderParams {
   GiCDomeLight* domeLight;
   GiCRenderSettings renderSettings;
   GiCScene* scene;
+  /* Non-colour AOVs: Normal, Barycentrics, Texcoords, Opacity, Tangents, Bitangents, ThinWalled, ObjectId, Depth, FaceId, InstanceId,
+   * DoubleSided and Albedo are produced (vec3 AOVs need Float32Vec4 buffers, Depth Float32, ids Int32 -- Gi.cpp:302-316); NEE,
+   * Bounces and ClockCycles keep their clear value.  Without a Color binding no paths are traced (rp_main.miss:70-72). */
   /* [ext] multi-GPU sharding: render only image rows [rowBegin,rowEnd) of the full image whose size is the
    * render buffers' size; rowEnd == 0 means "all rows".  RNG streams use the global pixel index so an N-way
    * split is bit-identical to the single-GPU image. */

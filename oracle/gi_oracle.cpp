@@ -267,12 +267,12 @@ inline void fis_gauss(float x0, float x1, float& ox, float& oy)
 // ---------------------------------------------------------------------------------------------
 struct FVertex { V3 pos; float bsign; uint32_t n, t; float u, v; }; // rp_main.h:58-64
 struct Instance {
-  uint32_t mesh;
+  uint32_t mesh; int32_t instanceId;
   float o2w[12]; // rows of the 3x4 object-to-world (Gi.cpp:1191)
   float w2o[9];  // inverse of the 3x3 part, row-major
 };
 struct Tri { V3 v0, e1, e2; uint32_t instance, prim; };
-struct MeshData { std::vector<FVertex> verts; const uint32_t* faces; uint32_t faceCount; int material; uint32_t flags; };
+struct MeshData { std::vector<FVertex> verts; const uint32_t* faces; uint32_t faceCount; int material; uint32_t flags; int32_t objectId; std::vector<uint8_t> faceIdData; uint32_t faceIdStride; };
 
 // Light structs as the device sees them (rp_main.h:73-113), derived fields per Gi.cpp setters.
 struct SphereL { V3 pos; uint32_t ds; V3 em; float area; V3 radius; };
@@ -352,6 +352,10 @@ void prepare(const OrcScene* s, Prepared& P)
     MeshData& d = P.meshes[mi];
     d.faces = m.faces; d.faceCount = m.faceCount; d.material = m.material;
     d.flags = (m.isLeftHanded ? 1u : 0u) | (m.isDoubleSided ? 2u : 0u); // rp_main.h:115-116
+    d.objectId = m.id;
+    d.faceIdStride = m.maxFaceId <= 255u ? 1u : (m.maxFaceId <= 65535u ? 2u : 4u); // Gi.cpp:878-885
+    d.faceIdData.assign(((size_t)m.faceCount * d.faceIdStride + 3) / 4 * 4, 0);
+    for (uint32_t i = 0; i < m.faceCount; i++) { int32_t fid = m.faceIds ? m.faceIds[i] : 0; memcpy(&d.faceIdData[(size_t)i * d.faceIdStride], &fid, d.faceIdStride); }
     d.verts.resize(m.vertexCount);
     for (uint32_t i = 0; i < m.vertexCount; i++) { // Gi.cpp:848-861
       const OrcVertex& v = m.vertices[i];
@@ -359,7 +363,7 @@ void prepare(const OrcScene* s, Prepared& P)
     }
     if (!m.visible || m.faceCount == 0 || m.material < 0) continue; // Gi.cpp:801-804, 818-822, 834-837
     for (uint32_t ii = 0; ii < m.instanceCount; ii++) {             // Gi.cpp:1188-1202
-      Instance inst; inst.mesh = mi;
+      Instance inst; inst.mesh = mi; inst.instanceId = m.instanceIds ? m.instanceIds[ii] : (int32_t)ii;
       compose_transform(m.transform, m.instanceTransforms + 16 * ii, inst.o2w);
       invert3x3(inst.o2w, inst.w2o);
       uint32_t instIdx = (uint32_t)P.instances.size();
@@ -844,6 +848,30 @@ void bsdf_evaluate(const OrcMaterial& m, const State& st, V3 k1, V3 k2, BsdfEval
   if (m.klass == ORC_MAT_OPEN_PBR) { opbr_evaluate(m, st, k1, k2, st.frontFace, out); return; }
 }
 
+// mdl_bsdf_scattering_auxiliary stand-in (rp_main.chit:263-289): albedo_diffuse + albedo_glossy of the closed forms
+V3 bsdf_albedo(const OrcMaterial& m, const State& st, V3 k1)
+{
+  float nk1 = fmax2(dot(st.normal, k1), 1e-4f);
+  if (m.klass == ORC_MAT_DIFFUSE) return v3(m.p + ORC_P_BASE_COLOR);
+  if (m.klass == ORC_MAT_USD_PREVIEW_SURFACE) {
+    UpsParams u = ups_params(m);
+    float Fc = u.coat * (0.04f + 0.96f * schlick_w(nk1));
+    V3 Fs = schlick3(u.F0, nk1);
+    V3 diffuse = (u.albedo * (v3(1, 1, 1) - Fs)) * (1.0f - Fc);
+    V3 glossy = v3(Fc, Fc, Fc) + Fs * (1.0f - Fc);
+    return diffuse + glossy;
+  }
+  OpbrParams o = opbr_params(m);
+  float eta = st.frontFace ? o.eta : 1.0f / o.eta;
+  float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1));
+  float Fd = fresnel_dielectric(nk1, eta);
+  float base = 1.0f - Fc, diel = 1.0f - o.metalness;
+  V3 diffuse = (o.albedo * o.coatTint) * (base * diel * (1.0f - Fd) * (1.0f - o.tw));
+  V3 glossy = v3(Fc, Fc, Fc) + ((schlick_f82(o.albedo, o.metalTint, nk1) * o.specWeight) * o.coatTint) * (base * o.metalness)
+              + (o.specColor * o.coatTint) * (base * diel * Fd);
+  return diffuse + glossy;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Light sampling (rp_main.chit:30-129)
 // ---------------------------------------------------------------------------------------------
@@ -1108,6 +1136,81 @@ void make_frame(Frame& F, const Prepared& P, const OrcCamera* cam, const OrcSett
   F.ubo.sensorExposureScale = exp2f(cam->exposure); // rp_main.chit:126, 336 (host libm; per-frame constant)
 }
 
+// Non-colour AOVs of one pixel: clearAovs (rp_main.rgen:132-183), the bounce-0 writes of every sample in order
+// (rp_main.chit:192-290) and the final normal renormalisation (rp_main.rgen:517-520).
+void render_pixel_aovs(const Frame& F, uint32_t px, uint32_t py, size_t o, OrcAovs& A)
+{
+  const OrcSettings& rs = *F.rs;
+  uint32_t pixelIndex = px + py * F.width;
+  auto put3 = [&](float* buf, V3 v) { if (buf) { buf[4 * o] = v.x; buf[4 * o + 1] = v.y; buf[4 * o + 2] = v.z; } };
+  auto clr3 = [&](float* buf, int id) { put3(buf, v3(A.clear[id][0], A.clear[id][1], A.clear[id][2])); };
+  auto clri = [&](int32_t* buf, int id) { if (buf) memcpy(&buf[o], &A.clear[id][0], 4); };
+  clr3(A.barycentrics, 3); clr3(A.texcoords, 4); clr3(A.opacity, 7); clr3(A.tangents, 8); clr3(A.bitangents, 9); clr3(A.thinWalled, 10);
+  clri(A.objectId, 11); if (A.depth) A.depth[o] = A.clear[12][0]; clri(A.faceId, 13); clri(A.instanceId, 14); clr3(A.doubleSided, 15);
+  if (rs.sampleOffset == 0) { clr3(A.normal, 1); clr3(A.albedo, 16); }
+  float invTotal = 1.0f / (float)(rs.sampleOffset + rs.spp);
+  for (uint32_t s = 0; s < rs.spp; s++) {
+    uint32_t rng = rng_init(pixelIndex, rs.sampleOffset + s);
+    float r0 = next1f(rng), r1 = next1f(rng);
+    float sox = 0.5f, soy = 0.5f;
+    if (rs.jitteredSampling) {
+      if (rs.filterImportanceSampling) { float gx, gy; fis_gauss(r0, r1, gx, gy); sox = 0.5f + gx; soy = 0.5f + gy; }
+      else { sox = r0; soy = r1; }
+    }
+    V3 Pp = (F.L + (F.camRight * ((float)px + sox)) * F.WX) + (F.camUp * ((float)py + soy)) * F.HY;
+    V3 origin = F.camPos, dir = normalize(Pp - origin);
+    if (rs.depthOfField && F.lensRadius > 0.0f) {
+      float z0 = next1f(rng), z1 = next1f(rng);
+      V3 focal = origin + dir * F.cam->focusDistance;
+      V3 ap = sample_hemisphere(z0, z1);
+      origin = origin + F.camRight * (ap.x * F.lensRadius);
+      origin = origin + F.camUp * (ap.y * F.lensRadius);
+      dir = normalize(focal - origin);
+    }
+    if (dir.x == 0.0f) dir.x += ORC_FLT_MIN;
+    if (dir.y == 0.0f) dir.y += ORC_FLT_MIN;
+    if (dir.z == 0.0f) dir.z += ORC_FLT_MIN;
+    float tMin = 0.0f, tMax = ORC_FLT_MAX;
+    if (rs.clippingPlanes) { float cc = fmax2(1e-5f, dot(dir, F.camFwd)); tMin = F.clipNear / cc; tMax = F.clipFar / cc; }
+    Hit h;
+    if (!trace_closest(*F.P, origin, dir, tMin, tMax, h)) continue;
+    State st; const MeshData* mesh;
+    setup_shading_state(*F.P, h, dir, st, mesh);
+    const Tri& T = F.P->tris[h.tri];
+    const Instance& inst = F.P->instances[T.instance];
+    put3(A.opacity, v3(1, 0, 0));                                                         // chit:199-205 (no cutouts)
+    put3(A.tangents, (st.tangentU + v3(1, 1, 1)) * 0.5f);                                  // :206-208
+    put3(A.bitangents, (st.tangentV + v3(1, 1, 1)) * 0.5f);                                // :209-211
+    put3(A.barycentrics, v3(1.0f - h.u - h.v, h.u, h.v));                                  // :212-214
+    put3(A.texcoords, v3(st.u, st.v, 0.0f));                                               // :215-217
+    put3(A.thinWalled, v3(0, 1, 0));                                                       // :218-220 (no thin-walled materials)
+    if (A.objectId) A.objectId[o] = mesh->objectId;                                        // :221-224
+    if (A.depth) A.depth[o] = 2.0f * logf_poly(h.t / F.clipNear) / logf_poly(F.clipFar / F.clipNear) - 1.0f; // :225-229
+    if (A.faceId) {                                                                        // :230-240 (incl. the reference's mask)
+      int stride = (int)mesh->faceIdStride, invStride = 4 / stride;
+      int32_t word; memcpy(&word, &mesh->faceIdData[(size_t)(T.prim / (uint32_t)invStride) * 4], 4);
+      word >>= (int)((T.prim % (uint32_t)invStride) * 8);
+      A.faceId[o] = word & (stride * 8 - 1);
+    }
+    if (A.instanceId) A.instanceId[o] = inst.instanceId;                                   // :241-244
+    put3(A.doubleSided, (mesh->flags & 2u) ? v3(0, 1, 0) : v3(1, 0, 0));                   // :245-247
+    if (A.normal) {                                                                        // :250-259
+      V3 pos = (st.normal + v3(1, 1, 1)) * 0.5f, prev = pos;
+      if (rs.progressiveAccumulation && rs.sampleOffset > 0) prev = v3(A.normal + 4 * o);
+      put3(A.normal, (prev * (float)rs.sampleOffset + pos * (float)rs.spp) * invTotal);
+    }
+    if (A.albedo) {                                                                        // :261-289
+      V3 al = bsdf_albedo(F.P->materials[mesh->material], st, -dir), prev = al;
+      if (rs.progressiveAccumulation && rs.sampleOffset > 0) prev = v3(A.albedo + 4 * o);
+      put3(A.albedo, (prev * (float)rs.sampleOffset + al * (float)rs.spp) * invTotal);
+    }
+  }
+  if (A.normal) { // rgen:517-520
+    V3 n = v3(A.normal + 4 * o) * 2.0f - v3(1, 1, 1);
+    put3(A.normal, (normalize(n) + v3(1, 1, 1)) * 0.5f);
+  }
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -1149,6 +1252,16 @@ int orc_render(const OrcScene* scene, const OrcCamera* camera, const OrcSettings
       for (int i = 0; i < 64; i++) counters->bounceHistogram[i] += c.bounceHistogram[i];
     }
   }
+  return 0;
+}
+
+int orc_render_aovs(const OrcScene* scene, const OrcCamera* camera, const OrcSettings* settings, const OrcRegion* region, OrcAovs* aovs)
+{
+  if (!scene || !camera || !settings || !region || !aovs) return 1;
+  Prepared P; prepare(scene, P);
+  Frame F; make_frame(F, P, camera, settings, region);
+  for (uint32_t y = region->rowBegin; y < region->rowEnd; y++)
+    for (uint32_t x = 0; x < F.width; x++) render_pixel_aovs(F, x, y, (size_t)(y - region->rowBegin) * F.width + x, *aovs);
   return 0;
 }
 

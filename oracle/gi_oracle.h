@@ -91,6 +91,9 @@ typedef struct OrcMesh {
   const float* instanceTransforms; /* instanceCount x 16, same convention (Gi.cpp:652-658)  */
   uint32_t instanceCount;
   int32_t material; /* index into OrcScene.materials */
+  const int32_t* faceIds;     /* faceCount entries or NULL (GiMeshDesc.faceIds, Gi.h:127) */
+  uint32_t maxFaceId;         /* GiMeshDesc.maxFaceId: chooses the 1/2/4-byte face-id stride (Gi.cpp:878-885) */
+  const int32_t* instanceIds; /* instanceCount entries or NULL (Gi.cpp:660-670) */
 } OrcMesh;
 
 /* Light descriptions at *setter* level (Gi.cpp:2573-2976); derived fields are computed by the oracle. */
@@ -146,6 +149,17 @@ typedef struct OrcRegion {
   uint32_t imageWidth, imageHeight; /* full image (RNG uses global pixel index) */
   uint32_t rowBegin, rowEnd;        /* rows [rowBegin,rowEnd) are rendered      */
 } OrcRegion;
+
+/* Non-colour AOVs (rp_main.rgen:132-183, 517-520; rp_main.chit:192-290).  Buffers are (rowEnd-rowBegin)*width elements: vec3
+ * AOVs as 4 floats per pixel (std430 vec3[] stride; .w is never written), ids/depth as one int32/float.  NULL = not bound.
+ * clear[id] is the binding's 16-byte clear value.  NEE, Bounces and ClockCycles are not produced. */
+typedef struct OrcAovs {
+  float* normal; float* barycentrics; float* texcoords; float* opacity; float* tangents; float* bitangents; float* thinWalled;
+  float* doubleSided; float* albedo; float* depth;
+  int32_t* objectId; int32_t* faceId; int32_t* instanceId;
+  float clear[17][4];
+} OrcAovs;
+int orc_render_aovs(const OrcScene* scene, const OrcCamera* camera, const OrcSettings* settings, const OrcRegion* region, OrcAovs* aovs);
 
 typedef struct OrcCounters {
   uint64_t samples;

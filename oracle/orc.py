@@ -26,7 +26,16 @@ class OrcMesh(C.Structure):
                 ("id", C.c_int32), ("isDoubleSided", C.c_int32), ("isLeftHanded", C.c_int32), ("visible", C.c_int32),
                 ("transform", C.c_float * 16),
                 ("instanceTransforms", C.c_void_p), ("instanceCount", C.c_uint32),
-                ("material", C.c_int32)]
+                ("material", C.c_int32), ("faceIds", C.c_void_p), ("maxFaceId", C.c_uint32), ("instanceIds", C.c_void_p)]
+
+
+class OrcAovs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("normal", "barycentrics", "texcoords", "opacity", "tangents", "bitangents", "thinWalled",
+                                          "doubleSided", "albedo", "depth", "objectId", "faceId", "instanceId")] + [("clear", (C.c_float * 4) * 17)]
+
+
+AOV_IDS = {"normal": 1, "barycentrics": 3, "texcoords": 4, "opacity": 7, "tangents": 8, "bitangents": 9, "thinWalled": 10, "objectId": 11,
+           "depth": 12, "faceId": 13, "instanceId": 14, "doubleSided": 15, "albedo": 16}
 
 
 class OrcSphereLight(C.Structure):
@@ -161,6 +170,12 @@ class PackedScene:
             meshes[i].instanceTransforms = it.ctypes.data
             meshes[i].instanceCount = len(it)
             meshes[i].material = m.material
+            fid = getattr(m, "face_ids", None)
+            if fid is not None:
+                fid = np.ascontiguousarray(fid, np.int32); self.keep.append(fid); meshes[i].faceIds = fid.ctypes.data
+            meshes[i].maxFaceId = int(getattr(m, "max_face_id", 0))
+            if m.instance_ids is not None:
+                iid = np.ascontiguousarray(m.instance_ids, np.int32); self.keep.append(iid); meshes[i].instanceIds = iid.ctypes.data
         mats = (OrcMaterial * max(1, len(scene.materials)))()
         for i, m in enumerate(scene.materials):
             mats[i].klass = m.klass
@@ -260,3 +275,40 @@ def bsdf_debug(material, items):
     FP = C.POINTER(C.c_float)
     L.orc_bsdf_debug(C.addressof(m), len(a), a.ctypes.data_as(FP), out.ctypes.data_as(FP))
     return out
+
+
+def render_aovs(scene, settings, width, height, names, clear_values=None, sample_offset=0, prev=None, rows=None):
+    """Non-colour AOVs through the oracle.  names: subset of AOV_IDS; clear_values: {name: 4 floats or 1 int};
+    prev: {name: array} previous-call contents for the accumulating AOVs.  Returns {name: array}."""
+    L = lib()
+    L.orc_render_aovs.restype = C.c_int
+    L.orc_render_aovs.argtypes = [C.c_void_p] * 5
+    ps = PackedScene(scene)
+    r0, r1 = rows if rows is not None else (0, height)
+    n = (r1 - r0) * width
+    A = OrcAovs()
+    out = {}
+    for name in names:
+        aid = AOV_IDS[name]
+        cv = (clear_values or {}).get(name, 0)
+        if name in ("objectId", "faceId", "instanceId"):
+            arr = np.zeros(n, np.int32)
+            A.clear[aid][0] = np.frombuffer(np.int32(cv).tobytes(), np.float32)[0]
+        elif name == "depth":
+            arr = np.zeros(n, np.float32)
+            A.clear[aid][0] = float(cv)
+        else:
+            arr = np.zeros((n, 4), np.float32)
+            cv4 = (list(cv) + [0, 0, 0, 0])[:4] if hasattr(cv, "__len__") else [cv] * 4
+            for k in range(4):
+                A.clear[aid][k] = float(cv4[k])
+            if prev and name in prev:
+                arr[:] = np.asarray(prev[name], np.float32).reshape(n, 4)
+        out[name] = arr
+        setattr(A, name, arr.ctypes.data)
+    cam, st = _camera(scene.camera), _settings(settings, sample_offset)
+    rg = OrcRegion(width, height, r0, r1)
+    rc = L.orc_render_aovs(C.addressof(ps.c), C.addressof(cam), C.addressof(st), C.addressof(rg), C.addressof(A))
+    if rc != 0:
+        raise RuntimeError(f"orc_render_aovs failed with code {rc}")
+    return {k: (v.reshape(r1 - r0, width, 4) if v.ndim == 2 else v.reshape(r1 - r0, width)) for k, v in out.items()}

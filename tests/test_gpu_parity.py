@@ -175,6 +175,67 @@ def test_pool_and_batch_invariance(gi, orc):
         assert_image_parity(img, ref, exact=True)
 
 
+def _aov_scene():
+    desc = sphere_grid(grid=3, subdivisions=1, material_count=4)
+    rng = np.random.default_rng(8)
+    for i, m in enumerate(desc.meshes):
+        m.id = 100 + i
+        m.face_ids = rng.integers(0, 300, len(m.faces)).astype(np.int32)
+        m.max_face_id = 299 if i % 2 else 40  # 2-byte and 1-byte strides
+        m.instance_ids = np.arange(len(m.instance_transforms), dtype=np.int32) * 7 + i
+        m.double_sided = bool(i % 2)
+    desc.materials[1] = MaterialDesc.open_pbr(base_color=(0.9, 0.5, 0.2), base_metalness=1.0, coat_weight=0.5)
+    return desc
+
+
+AOV_NAMES = ["normal", "barycentrics", "texcoords", "opacity", "tangents", "bitangents", "thinWalled", "objectId", "depth", "faceId",
+             "instanceId", "doubleSided", "albedo"]
+AOV_CLEAR = {"normal": (0.5, 0.5, 0.5, 0.5), "objectId": -1, "faceId": -1, "instanceId": -1, "depth": 1.0, "albedo": (0.1, 0.2, 0.3, 0.0)}
+
+
+def _same(a, b):
+    return np.array_equal(a, b, equal_nan=True) if a.dtype.kind == "f" else np.array_equal(a, b)
+
+
+def test_non_colour_aovs(gi, orc):
+    """The 13 non-colour AOVs the core produces (rp_main.chit:192-290, rp_main.rgen:132-183, 517-520) == oracle, together with
+    the colour AOV in the same giRender call, then again as a progressive second call (the accumulating Normal/Albedo AOVs blend)."""
+    desc = _aov_scene()
+    rs = RenderSettings(spp=3, max_bounces=3, clipping_planes=True)
+    desc.camera.clip_start, desc.camera.clip_end = 0.5, 40.0
+    w, h = 64, 36
+    sc = gi.Scene(desc)
+    try:
+        first = sc.render_aovs(rs, w, h, AOV_NAMES, AOV_CLEAR)
+        second = sc.render_aovs(rs, w, h, AOV_NAMES, AOV_CLEAR)
+    finally:
+        sc.close()
+    ref_color, _ = orc.render(desc, rs, w, h)
+    ref1 = orc.render_aovs(desc, rs, w, h, AOV_NAMES, AOV_CLEAR)
+    ref2 = orc.render_aovs(desc, rs, w, h, AOV_NAMES, AOV_CLEAR, sample_offset=3, prev=ref1)
+    assert_image_parity(first["color"], ref_color, exact=True)
+    for name in AOV_NAMES:
+        assert _same(first[name], ref1[name]), name
+        assert _same(second[name], ref2[name]), name
+    hit = first["objectId"] >= 100
+    assert 0.1 < hit.mean() < 0.9 and set(np.unique(first["objectId"][hit])) <= {100, 101, 102, 103}
+    assert (first["faceId"][hit] >= 0).all() and (first["faceId"][hit] <= 15).all()  # the reference's (stride*8-1) mask, kept as is
+    assert np.isfinite(first["depth"][hit]).all() and (np.abs(first["depth"][hit]) <= 1.0).all()
+
+
+def test_aov_only_render_and_unproduced_aovs(gi):
+    """Without a colour binding nothing is path traced (rp_main.miss:70-72); NEE / Bounces keep their clear values."""
+    desc = cornell_box(MAT_DIFFUSE)
+    sc = gi.Scene(desc)
+    try:
+        out = sc.render_aovs(RenderSettings(spp=2, max_bounces=2), 48, 27, ["objectId", "nee", "bounces"], {"objectId": -1, "nee": (0.25, 0.5, 0.75, 1.0)},
+                             with_color=False)
+    finally:
+        sc.close()
+    assert "color" not in out and (out["objectId"] >= -1).all() and (out["objectId"] >= 0).mean() > 0.3
+    assert np.allclose(out["nee"], (0.25, 0.5, 0.75, 1.0)) and np.all(out["bounces"] == 0)
+
+
 def test_edge_cases(gi, orc):
     """Empty scene, 1x1 target (the reference's Render.Empty1x1), invisible / instance-less / material-less meshes."""
     cam = CameraDesc(position=(0, 0, 5))
