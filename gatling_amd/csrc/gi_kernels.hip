@@ -261,7 +261,7 @@ struct TraceCounters { uint32_t nodes, tris; };
 // STACK = per-lane stack entries kept in LDS.  The traversal pushes at most one entry per tree level, so the host
 // picks STACK >= tree depth (8 or 16) and the scratch overflow (OVERFLOW) is compiled in only for deeper trees:
 // a kernel that declares scratch pays for it on every wave launch even if it never spills.
-template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW>
+template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool ALL_LDS>
 __device__ __forceinline__ bool traverse(const SceneView& sc, const uint4* s_nodes, uint32_t ldsNodes, const uint4* s_tris, uint32_t ldsTris,
                                          uint2 (*s_stack)[TRACE_BLOCK], V3 o, V3 d, float tMin, float tMax,
                                          float& outT, float& outU, float& outV, uint32_t& outTri, TraceCounters& tc)
@@ -293,7 +293,7 @@ __device__ __forceinline__ bool traverse(const SceneView& sc, const uint4* s_nod
       const uint32_t rel = (uint32_t)__popc((G.y & 0xffu) & ((1u << slot) - 1u));
       const uint32_t nodeIdx = G.x + rel;
       uint4 n0, n1, n2, n3, n4;
-      if (nodeIdx < ldsNodes) { const uint4* p = s_nodes + nodeIdx * 5u; n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3]; n4 = p[4]; }
+      if (ALL_LDS || nodeIdx < ldsNodes) { const uint4* p = s_nodes + nodeIdx * 5u; n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3]; n4 = p[4]; }
       else { const uint4* p = reinterpret_cast<const uint4*>(sc.nodes) + (size_t)nodeIdx * 5u; n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3]; n4 = p[4]; }
       if (COUNT) tc.nodes++;
       // ray in the node's quantisation frame
@@ -337,25 +337,24 @@ __device__ __forceinline__ bool traverse(const SceneView& sc, const uint4* s_nod
       Gt.y &= Gt.y - 1u;
       const uint32_t triIdx = Gt.x + k;
       uint4 a, b, c;
-      if (triIdx < ldsTris) { const uint4* p = s_tris + triIdx * 3u; a = p[0]; b = p[1]; c = p[2]; }
+      if (ALL_LDS || triIdx < ldsTris) { const uint4* p = s_tris + triIdx * 3u; a = p[0]; b = p[1]; c = p[2]; }
       else { const uint4* p = reinterpret_cast<const uint4*>(sc.tris) + (size_t)triIdx * 4u; a = p[0]; b = p[1]; c = p[2]; }
       if (COUNT) tc.tris++;
       const V3 v0 = v3(u2f(a.x), u2f(a.y), u2f(a.z)), e1 = v3(u2f(a.w), u2f(b.x), u2f(b.y)), e2 = v3(u2f(b.z), u2f(b.w), u2f(c.x));
       const uint32_t orig = c.y;
-      // two-sided Moeller-Trumbore, operation order == oracle tri_test
+      // two-sided Moeller-Trumbore, operation order == oracle tri_test; evaluated branch-free (a wave almost always has a
+      // lane that passes each early-out, so predication is cheaper than exec-mask branches), one predicate at the end
       const V3 pv = cross(d, e2);
       const float det = dot(e1, pv);
-      if (det == 0.0f) continue;
       const float inv = 1.0f / det;
       const V3 tv = o - v0;
       const float u = dot(tv, pv) * inv;
-      if (!(u >= 0.0f)) continue;
       const V3 qv = cross(tv, e1);
       const float v = dot(d, qv) * inv;
-      if (!(v >= 0.0f) || !(u + v <= 1.0f)) continue;
       const float t = dot(e2, qv) * inv;
-      if (!(t > tMin)) continue;
-      if (t < tBest || (t == tBest && bestOrig != 0xffffffffu && orig < bestOrig)) {
+      const bool inside = (det != 0.0f) & (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > tMin);
+      const bool better = (t < tBest) | ((t == tBest) & (bestOrig != 0xffffffffu) & (orig < bestOrig));
+      if (inside & better) {
         tBest = t; bestU = u; bestV = v; bestTri = triIdx; bestOrig = orig; found = true;
         if (ANYHIT) { G.y = 0u; sp = 0u; break; }
       }
@@ -370,7 +369,7 @@ __device__ __forceinline__ bool traverse(const SceneView& sc, const uint4* s_nod
   return found;
 }
 
-template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW>
+template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool ALL_LDS>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t qMiss, uint32_t ldsNodes, uint32_t ldsTris)
 {
   // dynamic LDS, sized by the launch to what this scene actually stages: [stack | nodes | triangles]
@@ -400,11 +399,11 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
       const F4 ro = ld4(&qs.a[qIn][r]);
       rdir = ld4(&qs.b[qIn][r]);
       if (!ANYHIT) {
-        hit = traverse<false, COUNT, STACK, OVERFLOW>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), ro.w, rdir.w, t, u, v, tri, tc);
+        hit = traverse<false, COUNT, STACK, OVERFLOW, ALL_LDS>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), ro.w, rdir.w, t, u, v, tri, tc);
         miss = !hit;
       } else {
         // shadow ray (rp_main.rgen:397-429): origin = next ray origin, tMin 0.01, tMax = distance to the light sample
-        const bool occluded = traverse<true, COUNT, STACK, OVERFLOW>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), 0.01f, ro.w, t, u, v, tri, tc);
+        const bool occluded = traverse<true, COUNT, STACK, OVERFLOW, ALL_LDS>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), 0.01f, ro.w, t, u, v, tri, tc);
         if (!occluded) {
           const F4 nc = ld4(&qs.c[qIn][r]);
           Slot* S = &st.slots[slot];
@@ -999,7 +998,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_aov(FrameUniforms U, SceneView 
     V3 origin, dir; float tMin, tMax; uint32_t rng;
     make_camera_ray(U, pixelIndex, U.sampleOffset + s, origin, dir, tMin, tMax, rng);
     float t, u, v; uint32_t tri;
-    if (!traverse<false, false, STACK, OVERFLOW>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, origin, dir, tMin, tMax, t, u, v, tri, tc)) continue;
+    if (!traverse<false, false, STACK, OVERFLOW, false>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, origin, dir, tMin, tMax, t, u, v, tri, tc)) continue;
     ShState ss;
     setup_shading_state(sc, tri, u, v, dir, ss);
     const uint4* tp = reinterpret_cast<const uint4*>(sc.tris) + (size_t)tri * 4u;
@@ -1081,9 +1080,11 @@ template <bool ANYHIT, bool COUNT>
 static void launchTraceVariant(hipStream_t s, uint32_t blocks, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t qMiss)
 {
   uint32_t ln, lt, bytes; traceLdsLayout(sc, ln, lt, bytes);
-  if (sc.bvhDepth <= 8u) hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 8, false>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
-  else if (sc.bvhDepth <= 16u) hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 16, false>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
-  else hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 16, true>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
+  const bool allLds = ln == sc.nodeCount && lt == sc.triCount && sc.triCount > 0u; // the whole scene is staged in LDS
+  if (allLds && sc.bvhDepth <= 8u) hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 8, false, true>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
+  else if (sc.bvhDepth <= 8u) hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 8, false, false>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
+  else if (sc.bvhDepth <= 16u) hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 16, false, false>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
+  else hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 16, true, false>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
 }
 void launchTrace(hipStream_t s, uint32_t blocks, bool anyHit, bool count, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt,
                  uint32_t qIn, uint32_t qMiss)
