@@ -253,6 +253,7 @@ struct GiCScene {
   DeviceBuffer<FVertex> dVerts; DeviceBuffer<MaterialRec> dMaterials; DeviceBuffer<int32_t> dTriFaceId;
   DeviceBuffer<SphereLightRec> dSphere; DeviceBuffer<DistantLightRec> dDistant; DeviceBuffer<RectLightRec> dRect; DeviceBuffer<DiskLightRec> dDisk;
   uint32_t nodeCount = 0, triCount = 0, bvhDepth = 0;
+  uint32_t classMask = 0; // material classes that own at least one triangle (one k_shade launch per class)
   // path state
   DeviceBuffer<Slot> slots;
   DeviceBuffer<float> sampleBuf; // per-sample colours of the current batch, [sample][pixel][3]
@@ -658,6 +659,7 @@ int buildScene(GiCScene* s)
     deriveMaterialConstants(mats[i]);
   }
   uint32_t meshIdx = 0;
+  s->classMask = 0;
   for (GiCMesh* m : s->meshes) {
     if (!m->visible) continue; // Gi.cpp:801-804
     if (m->faces.empty()) continue;
@@ -665,7 +667,8 @@ int buildScene(GiCScene* s)
     if (mit == s->materials.end()) { fprintf(stderr, "[gatling_gi] invalid BLAS material for mesh %s\n", m->name.c_str()); continue; } // Gi.cpp:818-822
     const uint32_t material = (uint32_t)(mit - s->materials.begin());
     if (material > 0x00ffffffu) { setError("too many materials"); return GI_C_ERROR; }
-    const uint32_t matFlags = material | (((m->flipFacing ? 1u : 0u) | (m->doubleSided ? 2u : 0u)) << 30);
+    const uint32_t matFlags = material | ((mats[material].klass & 0xfu) << 24) | (((m->flipFacing ? 1u : 0u) | (m->doubleSided ? 2u : 0u)) << 30);
+    s->classMask |= 1u << (mats[material].klass & 0xfu);
     const uint32_t vertexOffset = (uint32_t)verts.size();
     for (const GiCVertex& v : m->vertices) { // Gi.cpp:848-861: quantise normal/tangent to octahedral unorm2x16, then decode once
       FVertex fv; memcpy(fv.pos, v.pos, 12); fv.bsign = v.bitangentSign;
@@ -766,7 +769,7 @@ int ensurePathState(GiCScene* s, size_t slots, uint32_t gridA, uint32_t gridB)
   if (cap > s->queueCap) {
     const size_t n = (size_t)cap * NSHARD;
     for (uint32_t q = 0; q < Q_COUNT; q++) {
-      const bool hasRecord = (q == Q_TRACE_A || q == Q_TRACE_B || q == Q_HIT || q == Q_SHADOW);
+      const bool hasRecord = (q == Q_TRACE_A || q == Q_TRACE_B || q >= Q_HIT || q == Q_SHADOW);
       if (s->qSlot[q].alloc(n)) return GI_C_ERROR;
       if (hasRecord && (s->qA[q].alloc(n) || s->qB[q].alloc(n))) return GI_C_ERROR;
       if (q == Q_SHADOW && s->qC[q].alloc(n)) return GI_C_ERROR;
@@ -997,7 +1000,8 @@ extern "C" int giCRender(const GiCRenderParams* params)
         }
         timed(1, [&] { launchTrace(st, traceBlocks, false, s->countTraversal, view, ps, qs, s->dCounters.ptr, Q_TRACE_A + par, Q_REGEN_A + (par ^ 1u)); });
         traceLaunches++;
-        timed(2, [&] { launchShade(st, wideBlocks, U, view, ps, qs, s->dCounters.ptr, par); });
+        for (uint32_t klass = 0; klass < MAT_CLASS_COUNT; klass++)
+          if (s->classMask & (1u << klass)) timed(2, [&] { launchShade(st, wideBlocks, klass, U, view, ps, qs, s->dCounters.ptr, par); });
         if (nee) timed(3, [&] { launchTrace(st, traceBlocks, true, s->countTraversal, view, ps, qs, s->dCounters.ptr, Q_SHADOW, Q_SHADOW); });
         iters++; totalIters++;
       }
@@ -1071,15 +1075,17 @@ extern "C" int giCTraceRays(GiCScene* s, uint32_t count, const float* origins, c
   PathState ps{s->slots.ptr};
   launchTrace(st, blocks, false, false, makeView(s), ps, makeQueueSet(s), s->dCounters.ptr, Q_TRACE_A, Q_REGEN_B);
   std::vector<TriRec> tris(s->triCount);
-  if (hipMemcpyAsync(qslot.data(), s->qSlot[Q_HIT].ptr, qn * 4, hipMemcpyDeviceToHost, st) != hipSuccess ||
-      hipMemcpyAsync(qa.data(), s->qA[Q_HIT].ptr, qn * sizeof(F4), hipMemcpyDeviceToHost, st) != hipSuccess ||
-      hipMemcpyAsync(&c, s->dCounters.ptr, sizeof(c), hipMemcpyDeviceToHost, st) != hipSuccess ||
+  if (hipMemcpyAsync(&c, s->dCounters.ptr, sizeof(c), hipMemcpyDeviceToHost, st) != hipSuccess ||
       (s->triCount && hipMemcpyAsync(tris.data(), s->dTris.ptr, s->triCount * sizeof(TriRec), hipMemcpyDeviceToHost, st) != hipSuccess) ||
       hipStreamSynchronize(st) != hipSuccess) { setError("giCTraceRays: readback failed"); return -1; }
   std::vector<F4> hit(count, F4{tMax, 0.0f, 0.0f, 0.0f});
   for (uint32_t i = 0; i < count; i++) { uint32_t m = 0xffffffffu; memcpy(&hit[i].w, &m, 4); }
-  for (uint32_t k = 0; k < NSHARD; k++)
-    for (uint32_t j = 0; j < c.count[Q_HIT][k].v; j++) { size_t r = (size_t)k * s->queueCap + j; if (qslot[r] < count) hit[qslot[r]] = qa[r]; }
+  for (uint32_t klass = 0; klass < MAT_CLASS_COUNT; klass++) {
+    if (hipMemcpy(qslot.data(), s->qSlot[Q_HIT + klass].ptr, qn * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(qa.data(), s->qA[Q_HIT + klass].ptr, qn * sizeof(F4), hipMemcpyDeviceToHost) != hipSuccess) { setError("giCTraceRays: readback failed"); return -1; }
+    for (uint32_t k = 0; k < NSHARD; k++)
+      for (uint32_t j = 0; j < c.count[Q_HIT + klass][k].v; j++) { size_t r = (size_t)k * s->queueCap + j; if (qslot[r] < count) hit[qslot[r]] = qa[r]; }
+  }
   int hits = 0;
   for (uint32_t i = 0; i < count; i++) {
     uint32_t tri; memcpy(&tri, &hit[i].w, 4);

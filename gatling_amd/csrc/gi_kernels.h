@@ -16,7 +16,8 @@ void launchAccumulate(hipStream_t s, const FrameUniforms& U, const float* sample
 void traceLdsLayout(const SceneView& sc, uint32_t& ldsNodes, uint32_t& ldsTris, uint32_t& bytes);
 void launchTrace(hipStream_t s, uint32_t blocks, bool anyHit, bool count, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt,
                  uint32_t qIn, uint32_t qMiss);
-void launchShade(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par);
+// one launch per material class present in the scene (the class is the sort key between k_trace and k_shade)
+void launchShade(hipStream_t s, uint32_t blocks, uint32_t klass, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par);
 
 void launchAov(hipStream_t s, const FrameUniforms& U, const SceneView& sc, const AovTargets& A);
 void launchDebugBsdf(hipStream_t s, const MaterialRec* mat, uint32_t count, const float* in, float* out);

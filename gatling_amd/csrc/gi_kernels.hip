@@ -94,7 +94,7 @@ __device__ __forceinline__ void zero_next_counters(Counters* cnt, uint32_t par)
   if (t < NSHARD) {
     cnt->count[Q_TRACE_A + (par ^ 1u)][t].v = 0;
     cnt->count[Q_REGEN_A + (par ^ 1u)][t].v = 0;
-    cnt->count[Q_HIT][t].v = 0;
+    for (uint32_t c = 0; c < MAT_CLASS_COUNT; c++) cnt->count[Q_HIT + c][t].v = 0;
     cnt->count[Q_SHADOW][t].v = 0;
   }
 }
@@ -264,7 +264,7 @@ struct TraceCounters { uint32_t nodes, tris; };
 template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool ALL_LDS>
 __device__ __forceinline__ bool traverse(const SceneView& sc, const uint4* s_nodes, uint32_t ldsNodes, const uint4* s_tris, uint32_t ldsTris,
                                          uint2 (*s_stack)[TRACE_BLOCK], V3 o, V3 d, float tMin, float tMax,
-                                         float& outT, float& outU, float& outV, uint32_t& outTri, TraceCounters& tc)
+                                         float& outT, float& outU, float& outV, uint32_t& outTri, uint32_t& outMat, TraceCounters& tc)
 {
   const uint32_t tid = threadIdx.x;
   // reciprocal direction for the slab tests only (guard against 0: boxes are padded, a huge finite value is safe)
@@ -274,7 +274,7 @@ __device__ __forceinline__ bool traverse(const SceneView& sc, const uint4* s_nod
   const float idx = 1.0f / gx, idy = 1.0f / gy, idz = 1.0f / gz;
   const uint32_t octinv = (d.x >= 0.0f ? 1u : 0u) | (d.y >= 0.0f ? 2u : 0u) | (d.z >= 0.0f ? 4u : 0u);
 
-  float tBest = tMax; uint32_t bestTri = 0xffffffffu, bestOrig = 0xffffffffu; float bestU = 0.0f, bestV = 0.0f;
+  float tBest = tMax; uint32_t bestTri = 0xffffffffu, bestOrig = 0xffffffffu, bestMat = 0u; float bestU = 0.0f, bestV = 0.0f;
   uint2 overflow[OVERFLOW ? OVF_STACK : 1];
   uint32_t sp = 0;
   uint2 G = make_uint2(0u, 0x80000000u); // virtual group holding only the root
@@ -355,7 +355,7 @@ __device__ __forceinline__ bool traverse(const SceneView& sc, const uint4* s_nod
       const bool inside = (det != 0.0f) & (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > tMin);
       const bool better = (t < tBest) | ((t == tBest) & (bestOrig != 0xffffffffu) & (orig < bestOrig));
       if (inside & better) {
-        tBest = t; bestU = u; bestV = v; bestTri = triIdx; bestOrig = orig; found = true;
+        tBest = t; bestU = u; bestV = v; bestTri = triIdx; bestOrig = orig; bestMat = c.w; found = true;
         if (ANYHIT) { G.y = 0u; sp = 0u; break; }
       }
     }
@@ -365,7 +365,7 @@ __device__ __forceinline__ bool traverse(const SceneView& sc, const uint4* s_nod
       G = (!OVERFLOW || sp < STACK) ? s_stack[sp < STACK ? sp : STACK - 1u][tid] : overflow[sp - STACK];
     }
   }
-  outT = tBest; outU = bestU; outV = bestV; outTri = bestTri;
+  outT = tBest; outU = bestU; outV = bestV; outTri = bestTri; outMat = bestMat;
   return found;
 }
 
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
   uint2 (*s_stack)[TRACE_BLOCK] = reinterpret_cast<uint2 (*)[TRACE_BLOCK]>(s_dyn);
   uint4* s_nodes = s_dyn + (STACK * TRACE_BLOCK * sizeof(uint2)) / sizeof(uint4);
   uint4* s_tris = s_nodes + ldsNodes * 5u;
-  __shared__ AppendScratch<2> sh;
+  __shared__ AppendScratch<1 + MAT_CLASS_COUNT> sh;
   QueueReader rd; reader_init(rd, cnt, qIn, qs.cap);
   const uint32_t n = rd.pre[NSHARD];
   if (blockIdx.x == 0 && threadIdx.x == 0) { if (ANYHIT) cnt->shadowRays += n; else cnt->segments += n; } // single writer per launch
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
   uint32_t trip = 0;
   for (uint32_t base = blockIdx.x * TRACE_BLOCK; base < n; base += stride, trip++) {
     const uint32_t i = base + threadIdx.x;
-    bool hit = false, miss = false; uint32_t slot = 0;
+    bool hit = false, miss = false; uint32_t slot = 0, mat = 0;
     float t = 0.0f, u = 0.0f, v = 0.0f; uint32_t tri = MISS; F4 rdir = F4{0.0f, 0.0f, 0.0f, 0.0f};
     if (i < n) {
       const uint32_t r = reader_index(rd, i);
@@ -399,11 +399,11 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
       const F4 ro = ld4(&qs.a[qIn][r]);
       rdir = ld4(&qs.b[qIn][r]);
       if (!ANYHIT) {
-        hit = traverse<false, COUNT, STACK, OVERFLOW, ALL_LDS>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), ro.w, rdir.w, t, u, v, tri, tc);
+        hit = traverse<false, COUNT, STACK, OVERFLOW, ALL_LDS>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), ro.w, rdir.w, t, u, v, tri, mat, tc);
         miss = !hit;
       } else {
         // shadow ray (rp_main.rgen:397-429): origin = next ray origin, tMin 0.01, tMax = distance to the light sample
-        const bool occluded = traverse<true, COUNT, STACK, OVERFLOW, ALL_LDS>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), 0.01f, ro.w, t, u, v, tri, tc);
+        const bool occluded = traverse<true, COUNT, STACK, OVERFLOW, ALL_LDS>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), 0.01f, ro.w, t, u, v, tri, mat, tc);
         if (!occluded) {
           const F4 nc = ld4(&qs.c[qIn][r]);
           Slot* S = &st.slots[slot];
@@ -413,15 +413,21 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
       }
     }
     if (!ANYHIT) {
-      // sort by outcome: hits go to the shade stage as (slot, hit, direction) records, misses straight to k_raygen
-      const bool pred[2] = {hit, miss}; const uint32_t qid[2] = {Q_HIT, qMiss}; uint32_t idx[2];
-      block_append<2>(sh, trip, pred, qid, qs.cap, cnt, idx);
+      // sort by outcome and material class: hits go to their class's shade queue as (slot, hit, direction) records, misses
+      // straight to k_raygen
+      const uint32_t klass = (mat >> 24) & 0xfu;
+      bool pred[1 + MAT_CLASS_COUNT]; uint32_t qid[1 + MAT_CLASS_COUNT]; uint32_t idx[1 + MAT_CLASS_COUNT];
+      pred[0] = miss; qid[0] = qMiss;
+#pragma unroll
+      for (uint32_t c = 0; c < MAT_CLASS_COUNT; c++) { pred[1 + c] = hit && klass == c; qid[1 + c] = Q_HIT + c; }
+      block_append<1 + MAT_CLASS_COUNT>(sh, trip, pred, qid, qs.cap, cnt, idx);
       if (hit) {
-        qs.slot[Q_HIT][idx[0]] = slot;
-        st4(&qs.a[Q_HIT][idx[0]], t, u, v, u2f(tri));
-        st4(&qs.b[Q_HIT][idx[0]], rdir.x, rdir.y, rdir.z, 0.0f);
+        const uint32_t q = Q_HIT + klass, r = idx[1 + klass];
+        qs.slot[q][r] = slot;
+        st4(&qs.a[q][r], t, u, v, u2f(tri));
+        st4(&qs.b[q][r], rdir.x, rdir.y, rdir.z, 0.0f);
       }
-      if (miss) qs.slot[qMiss][idx[1]] = slot | REGEN_MISSED;
+      if (miss) qs.slot[qMiss][idx[0]] = slot | REGEN_MISSED;
     }
   }
   if (COUNT) { // measurement builds only: one atomic pair per wave
@@ -679,10 +685,12 @@ __device__ inline void opbr_evaluate(const MaterialRec* m, const ShState& st, V3
   out.pdf = Fc * pc + base * (o.metalness * ps + diel * (Fd * ps + (1.0f - Fd) * (1.0f - o.tw) * cd));
 }
 
+constexpr uint32_t KLASS_DYNAMIC = 0xffffffffu; // read the class from the material record (debug / AOV paths)
+template <uint32_t KLASS>
 __device__ inline void bsdf_sample(const MaterialRec* m, const ShState& st, V3 k1, float x0, float x1, float x2, BsdfSample& out)
 {
   out.event = EV_ABSORB; out.pdf = 0.0f; out.overPdf = v3(0.0f, 0.0f, 0.0f); out.k2 = v3(0.0f, 0.0f, 0.0f);
-  const uint32_t klass = m->klass;
+  const uint32_t klass = (KLASS == KLASS_DYNAMIC) ? m->klass : KLASS;
   if (klass == 0u) {
     V3 l = gi_sample_hemisphere(x0, x1);
     V3 k2 = to_world(st, l);
@@ -727,12 +735,13 @@ __device__ inline void bsdf_sample(const MaterialRec* m, const ShState& st, V3 k
   if (klass == 2u) { opbr_sample(m, st, k1, x0, x1, x2, out); return; }
 }
 
+template <uint32_t KLASS>
 __device__ inline void bsdf_evaluate(const MaterialRec* m, const ShState& st, V3 k1, V3 k2, BsdfEval& out)
 {
   out.diffuse = v3(0.0f, 0.0f, 0.0f); out.glossy = v3(0.0f, 0.0f, 0.0f); out.pdf = 0.0f;
   float nk2 = dot(st.normal, k2);
   if (!(nk2 > 0.0f)) return;
-  const uint32_t klass = m->klass;
+  const uint32_t klass = (KLASS == KLASS_DYNAMIC) ? m->klass : KLASS;
   if (klass == 0u) {
     float c = nk2 / GI_PI;
     out.diffuse = v3(m->p[0], m->p[1], m->p[2]) * c; out.pdf = c;
@@ -828,11 +837,12 @@ __device__ inline void sample_light(const SceneView& sc, const FrameUniforms& U,
 // k_shade: closest-hit shading + the post-trace part of the bounce loop, over the HIT queue only
 // (rp_main.chit:132-493, rp_main.rgen:397-480).  Misses never get here (k_trace routes them to k_raygen).
 // ------------------------------------------------------------------------------------------------
+template <uint32_t KLASS>
 __global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t par)
 {
   __shared__ AppendScratch<3> sh;
-  const uint32_t qNext = Q_TRACE_A + (par ^ 1u), qRegen = Q_REGEN_A + (par ^ 1u);
-  QueueReader rdr; reader_init(rdr, cnt, Q_HIT, qs.cap);
+  const uint32_t qNext = Q_TRACE_A + (par ^ 1u), qRegen = Q_REGEN_A + (par ^ 1u), qHit = Q_HIT + KLASS;
+  QueueReader rdr; reader_init(rdr, cnt, qHit, qs.cap);
   const uint32_t n = rdr.pre[NSHARD];
   const uint32_t stride = gridDim.x * BLOCK;
   uint32_t trip = 0;
@@ -842,9 +852,9 @@ __global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, 
     V3 no = v3(0.0f, 0.0f, 0.0f), k2 = no, sdir = no, nee = no; float ld = 0.0f;
     if (i < n) {
       const uint32_t r = reader_index(rdr, i);
-      slot = qs.slot[Q_HIT][r];
-      const F4 h = ld4(&qs.a[Q_HIT][r]);
-      const F4 rd = ld4(&qs.b[Q_HIT][r]);
+      slot = qs.slot[qHit][r];
+      const F4 h = ld4(&qs.a[qHit][r]);
+      const F4 rd = ld4(&qs.b[qHit][r]);
       Slot* S = &st.slots[slot];
       const F4 tb = ld4(&S->thr);
       const F4 rr = ld4(&S->rad);
@@ -860,7 +870,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, 
       // volume attenuation with an empty medium stack (rp_main.chit:160-186): inside (1-bit toggle) -> Beer-Lambert with the
       // HIT material's absorption coefficient (:169-173)
       uint32_t mediumIdx = (bitfield & 0x0f000000u) >> 24; if (mediumIdx > 1u) mediumIdx = 1u;
-      if (mediumIdx > 0u && mat->klass == 2u) {
+      if (KLASS == 2u && mediumIdx > 0u) {
         const float distance = h.x * U.metersPerSceneUnit;
         throughput = throughput * v3(gi_expf(-mat->p[MP_SIGMA_A] * distance), gi_expf(-mat->p[MP_SIGMA_A + 1] * distance), gi_expf(-mat->p[MP_SIGMA_A + 2] * distance));
       }
@@ -874,7 +884,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, 
       }
       // BSDF importance sampling (:361-389); xi = next4f, .w is drawn but unused by the closed forms
       const float x0 = gi_next1f(rng), x1 = gi_next1f(rng), x2 = gi_next1f(rng); (void)gi_next1f(rng);
-      BsdfSample bs; bsdf_sample(mat, ss, -rayDir, x0, x1, x2, bs);
+      BsdfSample bs; bsdf_sample<KLASS>(mat, ss, -rayDir, x0, x1, x2, bs);
       throughput = throughput * bs.overPdf;
       k2 = bs.k2;
       const bool isTransmission = (bs.event & EV_TRANSMISSION) != 0u;
@@ -884,7 +894,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, 
         V3 dirToLight, lightPower; float lightDist, invPdf; uint32_t ds;
         sample_light(sc, U, k0, k1, kk2, k3, ss.position, dirToLight, lightDist, lightPower, invPdf, ds);
         if ((lightDist > 0.0f) && dot(dirToLight, ss.geomNormal) > 0.0f) {
-          BsdfEval ev; bsdf_evaluate(mat, ss, -rayDir, dirToLight, ev);
+          BsdfEval ev; bsdf_evaluate<KLASS>(mat, ss, -rayDir, dirToLight, ev);
           if (ev.pdf > 0.0f) {
             const float dmul = gi_half_to_float(ds & 0xffffu), smul = gi_half_to_float(ds >> 16);
             const V3 weight = throughput * (lightPower * invPdf);
@@ -998,7 +1008,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_aov(FrameUniforms U, SceneView 
     V3 origin, dir; float tMin, tMax; uint32_t rng;
     make_camera_ray(U, pixelIndex, U.sampleOffset + s, origin, dir, tMin, tMax, rng);
     float t, u, v; uint32_t tri;
-    if (!traverse<false, false, STACK, OVERFLOW, false>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, origin, dir, tMin, tMax, t, u, v, tri, tc)) continue;
+    uint32_t matUnused;
+    if (!traverse<false, false, STACK, OVERFLOW, false>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, origin, dir, tMin, tMax, t, u, v, tri, matUnused, tc)) continue;
     ShState ss;
     setup_shading_state(sc, tri, u, v, dir, ss);
     const uint4* tp = reinterpret_cast<const uint4*>(sc.tris) + (size_t)tri * 4u;
@@ -1047,8 +1058,8 @@ __global__ void k_debug_bsdf(const MaterialRec* mat, uint32_t count, const float
   const float* p = in + 22 * (size_t)i; float* o = out + 15 * (size_t)i;
   ShState st; st.normal = v3(p); st.tangentU = v3(p + 3); st.tangentV = v3(p + 6); st.geomNormal = v3(p + 9);
   st.position = v3(0.0f, 0.0f, 0.0f); st.frontFace = (p[21] < 0.5f); st.meshFlags = 0u; st.material = 0u;
-  BsdfSample bs; bsdf_sample(mat, st, v3(p + 12), p[18], p[19], p[20], bs);
-  BsdfEval ev; bsdf_evaluate(mat, st, v3(p + 12), v3(p + 15), ev);
+  BsdfSample bs; bsdf_sample<KLASS_DYNAMIC>(mat, st, v3(p + 12), p[18], p[19], p[20], bs);
+  BsdfEval ev; bsdf_evaluate<KLASS_DYNAMIC>(mat, st, v3(p + 12), v3(p + 15), ev);
   o[0] = bs.k2.x; o[1] = bs.k2.y; o[2] = bs.k2.z; o[3] = bs.overPdf.x; o[4] = bs.overPdf.y; o[5] = bs.overPdf.z; o[6] = bs.pdf; o[7] = (float)bs.event;
   o[8] = ev.diffuse.x; o[9] = ev.diffuse.y; o[10] = ev.diffuse.z; o[11] = ev.glossy.x; o[12] = ev.glossy.y; o[13] = ev.glossy.z; o[14] = ev.pdf;
 }
@@ -1100,9 +1111,11 @@ void launchAov(hipStream_t s, const FrameUniforms& U, const SceneView& sc, const
   else if (sc.bvhDepth <= 16u) hipLaunchKernelGGL((k_aov<16, false>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, U, sc, A, ln, lt);
   else hipLaunchKernelGGL((k_aov<16, true>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, U, sc, A, ln, lt);
 }
-void launchShade(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par)
+void launchShade(hipStream_t s, uint32_t blocks, uint32_t klass, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par)
 {
-  hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par);
+  if (klass == 0u) hipLaunchKernelGGL((k_shade<0u>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par);
+  else if (klass == 1u) hipLaunchKernelGGL((k_shade<1u>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par);
+  else hipLaunchKernelGGL((k_shade<2u>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par);
 }
 
 void launchDebugBsdf(hipStream_t s, const MaterialRec* mat, uint32_t count, const float* in, float* out)

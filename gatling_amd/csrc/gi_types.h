@@ -29,7 +29,7 @@ struct TriRec {
   float e2[3];
   uint32_t origId;    // global triangle id in scene order (tie-break key, DESIGN.md "Traversal contract")
   uint32_t instance;  // index into InstanceRec[]
-  uint32_t matFlags;  // material index (low 24 bits) | mesh flags << 30 (bit0 flipFacing, bit1 doubleSided; rp_main.h:115-116)
+  uint32_t matFlags;  // material index (bits 0-23) | material class (bits 24-27) | mesh flags << 30 (bit0 flipFacing, bit1 doubleSided; rp_main.h:115-116)
   uint32_t vi[3];     // absolute indices into the scene vertex array
   uint32_t prim;      // gl_PrimitiveID within the mesh
 };
@@ -150,11 +150,13 @@ struct PathState { Slot* slots; };
 // (MI355X_MICROARCH.md "dequeue"); an unsharded per-wave append made every stage atomic-bound.
 //   TRACE_A/B : slot, a = (origin, tMin), b = (direction, tMax)          -- the ray record (36 B)
 //   REGEN_A/B : slot | REGEN_MISSED                                       -- paths that ended (or left the scene)
-//   HIT       : slot, a = (t, u, v, triangle), b = (direction, -)         -- the hit record (36 B)
+//   HIT+class : slot, a = (t, u, v, triangle), b = (direction, -)         -- the hit record (36 B), one queue per material class
 //   SHADOW    : slot, a = (origin, distance), b = (direction, -), c = (neeContrib, -)
 // The A/B pairs alternate per iteration so that no counter has to be reset between a queue's consumer and its next
 // producers (k_raygen zeroes the counters of the following iteration, see zero_next_counters).
-enum : uint32_t { Q_TRACE_A = 0, Q_TRACE_B = 1, Q_REGEN_A = 2, Q_REGEN_B = 3, Q_HIT = 4, Q_SHADOW = 5, Q_COUNT = 6 };
+// HIT is one queue per material class (the sort key between trace and shade): Q_HIT + klass
+constexpr uint32_t MAT_CLASS_COUNT = 3;
+enum : uint32_t { Q_TRACE_A = 0, Q_TRACE_B = 1, Q_REGEN_A = 2, Q_REGEN_B = 3, Q_SHADOW = 4, Q_HIT = 5, Q_COUNT = Q_HIT + MAT_CLASS_COUNT };
 constexpr uint32_t NSHARD = 8;
 struct QueueSet {
   uint32_t* slot[Q_COUNT]; // each NSHARD * cap entries
