@@ -134,8 +134,19 @@ void decodeDirection(uint32_t e, float out[3])
 }
 
 // per-material constants of the closed-form BSDFs (DESIGN.md "Materials"); same fp32 formulas as the oracle's ups_params
+float cutoutOpacity(const MaterialRec& m) // same rule as the oracle's cutout_opacity
+{
+  float op = m.p[GI_C_P_OPACITY], th = m.p[GI_C_P_OPACITY_THRESHOLD];
+  float cl = op > 0.0f ? op : 0.0f; cl = cl < 1.0f ? cl : 1.0f;
+  if (m.klass == GI_C_MAT_OPEN_PBR) return cl;
+  if (th > 0.0f) return (op >= th) ? 1.0f : 0.0f;
+  return cl;
+}
+
 void deriveMaterialConstants(MaterialRec& m)
 {
+  const float cutout = cutoutOpacity(m);
+  struct SetCutout { MaterialRec& m; float v; ~SetCutout() { m.p[MP_CUTOUT] = v; } } setCutout{m, cutout};
   const float* p = m.p;
   if (m.klass == GI_C_MAT_OPEN_PBR) { // same fp32 formulas as the oracle's opbr_params (open_pbr_surface.mtlx:306-373)
     float bw = p[GI_C_P_BASE_WEIGHT], sw = p[GI_C_P_SPECULAR_WEIGHT];
@@ -253,6 +264,7 @@ struct GiCScene {
   DeviceBuffer<FVertex> dVerts; DeviceBuffer<MaterialRec> dMaterials; DeviceBuffer<int32_t> dTriFaceId;
   DeviceBuffer<SphereLightRec> dSphere; DeviceBuffer<DistantLightRec> dDistant; DeviceBuffer<RectLightRec> dRect; DeviceBuffer<DiskLightRec> dDisk;
   uint32_t nodeCount = 0, triCount = 0, bvhDepth = 0;
+  bool hasCutouts = false;
   uint32_t classMask = 0; // material classes that own at least one triangle (one k_shade launch per class)
   // path state
   DeviceBuffer<Slot> slots;
@@ -659,7 +671,7 @@ int buildScene(GiCScene* s)
     deriveMaterialConstants(mats[i]);
   }
   uint32_t meshIdx = 0;
-  s->classMask = 0;
+  s->classMask = 0; s->hasCutouts = false;
   for (GiCMesh* m : s->meshes) {
     if (!m->visible) continue; // Gi.cpp:801-804
     if (m->faces.empty()) continue;
@@ -667,7 +679,9 @@ int buildScene(GiCScene* s)
     if (mit == s->materials.end()) { fprintf(stderr, "[gatling_gi] invalid BLAS material for mesh %s\n", m->name.c_str()); continue; } // Gi.cpp:818-822
     const uint32_t material = (uint32_t)(mit - s->materials.begin());
     if (material > 0x00ffffffu) { setError("too many materials"); return GI_C_ERROR; }
-    const uint32_t matFlags = material | ((mats[material].klass & 0xfu) << 24) | (((m->flipFacing ? 1u : 0u) | (m->doubleSided ? 2u : 0u)) << 30);
+    const bool cutoutMat = mats[material].p[MP_CUTOUT] < 1.0f;
+    if (cutoutMat) s->hasCutouts = true;
+    const uint32_t matFlags = material | ((mats[material].klass & 0xfu) << 24) | (cutoutMat ? (1u << 28) : 0u) | (((m->flipFacing ? 1u : 0u) | (m->doubleSided ? 2u : 0u)) << 30);
     s->classMask |= 1u << (mats[material].klass & 0xfu);
     const uint32_t vertexOffset = (uint32_t)verts.size();
     for (const GiCVertex& v : m->vertices) { // Gi.cpp:848-861: quantise normal/tangent to octahedral unorm2x16, then decode once
@@ -747,7 +761,7 @@ SceneView makeView(GiCScene* s)
   SceneView v{};
   v.nodes = s->dNodes.ptr; v.tris = s->dTris.ptr; v.instances = s->dInstances.ptr;
   v.verts = s->dVerts.ptr; v.materials = s->dMaterials.ptr; v.sphereLights = s->dSphere.ptr; v.distantLights = s->dDistant.ptr;
-  v.rectLights = s->dRect.ptr; v.diskLights = s->dDisk.ptr; v.triFaceId = s->dTriFaceId.ptr; v.nodeCount = s->nodeCount; v.triCount = s->triCount; v.bvhDepth = s->bvhDepth;
+  v.rectLights = s->dRect.ptr; v.diskLights = s->dDisk.ptr; v.triFaceId = s->dTriFaceId.ptr; v.nodeCount = s->nodeCount; v.triCount = s->triCount; v.bvhDepth = s->bvhDepth; v.hasCutouts = s->hasCutouts ? 1u : 0u;
   return v;
 }
 

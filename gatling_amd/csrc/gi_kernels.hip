@@ -261,10 +261,19 @@ struct TraceCounters { uint32_t nodes, tris; };
 // STACK = per-lane stack entries kept in LDS.  The traversal pushes at most one entry per tree level, so the host
 // picks STACK >= tree depth (8 or 16) and the scratch overflow (OVERFLOW) is compiled in only for deeper trees:
 // a kernel that declares scratch pays for it on every wave launch even if it never spills.
-template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool ALL_LDS>
+// Any-hit randomness (rp_main.ahit:51-60), restated order-independently: stateless hash of the path's rng state and the
+// candidate's scene-order triangle id (see oracle cutout_random); the state itself is not advanced.
+__device__ __forceinline__ float cutout_random(uint32_t rng, uint32_t triId)
+{
+  uint32_t st = (rng ^ (triId * 0x9e3779b9u + 0x85ebca6bu)) * 747796405u + 2891336453u;
+  uint32_t word = ((st >> ((st >> 28) + 4u)) ^ st) * 277803737u;
+  return u2f(0x3f800000u | (((word >> 22) ^ word) >> 9)) - 1.0f;
+}
+
+template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool ALL_LDS, bool CUTOUT>
 __device__ __forceinline__ bool traverse(const SceneView& sc, const uint4* s_nodes, uint32_t ldsNodes, const uint4* s_tris, uint32_t ldsTris,
                                          uint2 (*s_stack)[TRACE_BLOCK], V3 o, V3 d, float tMin, float tMax,
-                                         float& outT, float& outU, float& outV, uint32_t& outTri, uint32_t& outMat, TraceCounters& tc)
+                                         float& outT, float& outU, float& outV, uint32_t& outTri, uint32_t& outMat, TraceCounters& tc, uint32_t rng = 0u)
 {
   const uint32_t tid = threadIdx.x;
   // reciprocal direction for the slab tests only (guard against 0: boxes are padded, a huge finite value is safe)
@@ -354,7 +363,12 @@ __device__ __forceinline__ bool traverse(const SceneView& sc, const uint4* s_nod
       const float t = dot(e2, qv) * inv;
       const bool inside = (det != 0.0f) & (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > tMin);
       const bool better = (t < tBest) | ((t == tBest) & (bestOrig != 0xffffffffu) & (orig < bestOrig));
-      if (inside & better) {
+      bool accept = inside & better;
+      if (CUTOUT && accept && (c.w & (1u << 28))) { // non-opaque material: stochastic cutout (ignoreIntersectionEXT, rp_main.ahit:57-60)
+        const float opacity = sc.materials[c.w & 0x00ffffffu].p[MP_CUTOUT];
+        accept = !(cutout_random(rng, orig) > opacity);
+      }
+      if (accept) {
         tBest = t; bestU = u; bestV = v; bestTri = triIdx; bestOrig = orig; bestMat = c.w; found = true;
         if (ANYHIT) { G.y = 0u; sp = 0u; break; }
       }
@@ -369,7 +383,7 @@ __device__ __forceinline__ bool traverse(const SceneView& sc, const uint4* s_nod
   return found;
 }
 
-template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool ALL_LDS>
+template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool ALL_LDS, bool CUTOUT>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t qMiss, uint32_t ldsNodes, uint32_t ldsTris)
 {
   // dynamic LDS, sized by the launch to what this scene actually stages: [stack | nodes | triangles]
@@ -398,12 +412,13 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
       slot = qs.slot[qIn][r];
       const F4 ro = ld4(&qs.a[qIn][r]);
       rdir = ld4(&qs.b[qIn][r]);
+      const uint32_t rng = CUTOUT ? f2u(st.slots[slot].rad.w) : 0u; // the any-hit test needs the path's rng state
       if (!ANYHIT) {
-        hit = traverse<false, COUNT, STACK, OVERFLOW, ALL_LDS>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), ro.w, rdir.w, t, u, v, tri, mat, tc);
+        hit = traverse<false, COUNT, STACK, OVERFLOW, ALL_LDS, CUTOUT>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), ro.w, rdir.w, t, u, v, tri, mat, tc, rng);
         miss = !hit;
       } else {
         // shadow ray (rp_main.rgen:397-429): origin = next ray origin, tMin 0.01, tMax = distance to the light sample
-        const bool occluded = traverse<true, COUNT, STACK, OVERFLOW, ALL_LDS>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), 0.01f, ro.w, t, u, v, tri, mat, tc);
+        const bool occluded = traverse<true, COUNT, STACK, OVERFLOW, ALL_LDS, CUTOUT>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), 0.01f, ro.w, t, u, v, tri, mat, tc, rng);
         if (!occluded) {
           const F4 nc = ld4(&qs.c[qIn][r]);
           Slot* S = &st.slots[slot];
@@ -1009,7 +1024,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_aov(FrameUniforms U, SceneView 
     make_camera_ray(U, pixelIndex, U.sampleOffset + s, origin, dir, tMin, tMax, rng);
     float t, u, v; uint32_t tri;
     uint32_t matUnused;
-    if (!traverse<false, false, STACK, OVERFLOW, false>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, origin, dir, tMin, tMax, t, u, v, tri, matUnused, tc)) continue;
+    if (!traverse<false, false, STACK, OVERFLOW, false, true>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, origin, dir, tMin, tMax, t, u, v, tri, matUnused, tc, rng)) continue;
     ShState ss;
     setup_shading_state(sc, tri, u, v, dir, ss);
     const uint4* tp = reinterpret_cast<const uint4*>(sc.tris) + (size_t)tri * 4u;
@@ -1087,21 +1102,27 @@ void traceLdsLayout(const SceneView& sc, uint32_t& ldsNodes, uint32_t& ldsTris, 
   ldsTris = sc.triCount <= LDS_TRIS ? sc.triCount : 0u;
   bytes = traceStackEntries(sc) * TRACE_BLOCK * (uint32_t)sizeof(uint2) + ldsNodes * 80u + ldsTris * 48u;
 }
-template <bool ANYHIT, bool COUNT>
+template <bool ANYHIT, bool COUNT, bool CUTOUT>
 static void launchTraceVariant(hipStream_t s, uint32_t blocks, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t qMiss)
 {
   uint32_t ln, lt, bytes; traceLdsLayout(sc, ln, lt, bytes);
   const bool allLds = ln == sc.nodeCount && lt == sc.triCount && sc.triCount > 0u; // the whole scene is staged in LDS
-  if (allLds && sc.bvhDepth <= 8u) hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 8, false, true>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
-  else if (sc.bvhDepth <= 8u) hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 8, false, false>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
-  else if (sc.bvhDepth <= 16u) hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 16, false, false>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
-  else hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 16, true, false>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
+  if (allLds && sc.bvhDepth <= 8u) hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 8, false, true, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
+  else if (sc.bvhDepth <= 8u) hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 8, false, false, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
+  else if (sc.bvhDepth <= 16u) hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 16, false, false, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
+  else hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 16, true, false, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
+}
+template <bool ANYHIT, bool COUNT>
+static void launchTraceCutout(hipStream_t s, uint32_t blocks, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t qMiss)
+{
+  if (sc.hasCutouts) launchTraceVariant<ANYHIT, COUNT, true>(s, blocks, sc, st, qs, cnt, qIn, qMiss);
+  else launchTraceVariant<ANYHIT, COUNT, false>(s, blocks, sc, st, qs, cnt, qIn, qMiss);
 }
 void launchTrace(hipStream_t s, uint32_t blocks, bool anyHit, bool count, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt,
                  uint32_t qIn, uint32_t qMiss)
 {
-  if (!anyHit) { if (count) launchTraceVariant<false, true>(s, blocks, sc, st, qs, cnt, qIn, qMiss); else launchTraceVariant<false, false>(s, blocks, sc, st, qs, cnt, qIn, qMiss); }
-  else { if (count) launchTraceVariant<true, true>(s, blocks, sc, st, qs, cnt, qIn, qMiss); else launchTraceVariant<true, false>(s, blocks, sc, st, qs, cnt, qIn, qMiss); }
+  if (!anyHit) { if (count) launchTraceCutout<false, true>(s, blocks, sc, st, qs, cnt, qIn, qMiss); else launchTraceCutout<false, false>(s, blocks, sc, st, qs, cnt, qIn, qMiss); }
+  else { if (count) launchTraceCutout<true, true>(s, blocks, sc, st, qs, cnt, qIn, qMiss); else launchTraceCutout<true, false>(s, blocks, sc, st, qs, cnt, qIn, qMiss); }
 }
 void launchAov(hipStream_t s, const FrameUniforms& U, const SceneView& sc, const AovTargets& A)
 {

@@ -29,7 +29,7 @@ struct TriRec {
   float e2[3];
   uint32_t origId;    // global triangle id in scene order (tie-break key, DESIGN.md "Traversal contract")
   uint32_t instance;  // index into InstanceRec[]
-  uint32_t matFlags;  // material index (bits 0-23) | material class (bits 24-27) | mesh flags << 30 (bit0 flipFacing, bit1 doubleSided; rp_main.h:115-116)
+  uint32_t matFlags;  // material index (bits 0-23) | material class (bits 24-27) | bit 28: cutout opacity < 1 | mesh flags << 30 (bit0 flipFacing, bit1 doubleSided; rp_main.h:115-116)
   uint32_t vi[3];     // absolute indices into the scene vertex array
   uint32_t prim;      // gl_PrimitiveID within the mesh
 };
@@ -64,7 +64,7 @@ constexpr uint32_t MAT_PARAM_COUNT = 48;
 // oracle evaluates per hit)
 // class 1 (UsdPreviewSurface): albedo, F0, alpha, coat, coatAlpha.  class 2 (OpenPBR): albedo = base_color*base_weight,
 // F0 slot = metal edge tint (specular_color*specular_weight), alpha, coat, coatAlpha, coatF0, modulated eta, sigma_a
-enum : uint32_t { MP_ALBEDO = 32, MP_F0 = 35, MP_ALPHA = 38, MP_COAT = 39, MP_COAT_ALPHA = 40, MP_COAT_F0 = 41, MP_ETA = 42, MP_SIGMA_A = 43 };
+enum : uint32_t { MP_ALBEDO = 32, MP_F0 = 35, MP_ALPHA = 38, MP_COAT = 39, MP_COAT_ALPHA = 40, MP_COAT_F0 = 41, MP_ETA = 42, MP_SIGMA_A = 43, MP_CUTOUT = 46 /* mdl_cutout_opacity, 1 = opaque */ };
 struct MaterialRec {
   uint32_t klass;
   uint32_t flags;
@@ -117,6 +117,7 @@ struct SceneView {
   uint32_t nodeCount;
   uint32_t triCount;
   uint32_t bvhDepth; // levels of the BVH8 (bounds the traversal stack)
+  uint32_t hasCutouts; // some triangle has cutout opacity < 1: traversal runs the any-hit test (needs the path rng)
 };
 
 struct alignas(16) F4 { float x, y, z, w; };

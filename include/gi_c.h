@@ -171,6 +171,7 @@ typedef struct GiCRenderParams {
 #define GI_C_P_DIFFUSE_ROUGHNESS 27
 #define GI_C_P_TRANSMISSION_DEPTH 28
 
+/* Note: p[GI_C_P_OPACITY] is the cutout opacity (1 = opaque); a zero-filled block is a fully transparent material. */
 typedef struct GiCMaterialDesc {
   uint32_t klass;
   uint32_t flags;

@@ -271,7 +271,7 @@ struct Instance {
   float o2w[12]; // rows of the 3x4 object-to-world (Gi.cpp:1191)
   float w2o[9];  // inverse of the 3x3 part, row-major
 };
-struct Tri { V3 v0, e1, e2; uint32_t instance, prim; };
+struct Tri { V3 v0, e1, e2; uint32_t instance, prim; float cutout; /* mdl_cutout_opacity of the material; 1 = opaque */ };
 struct MeshData { std::vector<FVertex> verts; const uint32_t* faces; uint32_t faceCount; int material; uint32_t flags; int32_t objectId; std::vector<uint8_t> faceIdData; uint32_t faceIdStride; };
 
 // Light structs as the device sees them (rp_main.h:73-113), derived fields per Gi.cpp setters.
@@ -342,6 +342,7 @@ inline V3 xform_normal(const float w[9], V3 n)
 }
 
 void build_bvh(Prepared& P);
+inline float cutout_opacity(const OrcMaterial& m);
 
 void prepare(const OrcScene* s, Prepared& P)
 {
@@ -372,7 +373,7 @@ void prepare(const OrcScene* s, Prepared& P)
         V3 p0 = xform_point(inst.o2w, d.verts[m.faces[3 * f + 0]].pos, 1.0f);
         V3 p1 = xform_point(inst.o2w, d.verts[m.faces[3 * f + 1]].pos, 1.0f);
         V3 p2 = xform_point(inst.o2w, d.verts[m.faces[3 * f + 2]].pos, 1.0f);
-        P.tris.push_back(Tri{p0, p1 - p0, p2 - p0, instIdx, f});
+        P.tris.push_back(Tri{p0, p1 - p0, p2 - p0, instIdx, f, cutout_opacity(s->materials[m.material])});
       }
     }
   }
@@ -406,7 +407,25 @@ void prepare(const OrcScene* s, Prepared& P)
 // ---------------------------------------------------------------------------------------------
 struct Hit { float t, u, v; uint32_t tri; };
 
-inline bool tri_test(const Tri& T, V3 o, V3 d, float tMin, float& tBest, uint32_t idx, Hit& h)
+// mdl_cutout_opacity of the closed forms: UsdPreviewSurface opacity with the opacityThreshold switch, OpenPBR geometry_opacity
+inline float cutout_opacity(const OrcMaterial& m)
+{
+  float op = m.p[ORC_P_OPACITY], th = m.p[ORC_P_OPACITY_THRESHOLD];
+  if (m.klass == ORC_MAT_OPEN_PBR) return fmin2(fmax2(op, 0.0f), 1.0f);
+  if (th > 0.0f) return (op >= th) ? 1.0f : 0.0f;
+  return fmin2(fmax2(op, 0.0f), 1.0f);
+}
+// Any-hit randomness (rp_main.ahit:51-60 draws next1f per candidate, in the driver's traversal order -- the one draw whose
+// order the reference leaves implementation-defined).  Restated order-independently: a stateless
+// hash of the path's rng state and the candidate's scene-order triangle id; the state itself is not advanced.
+inline float cutout_random(uint32_t rng, uint32_t triId)
+{
+  uint32_t st = (rng ^ (triId * 0x9e3779b9u + 0x85ebca6bu)) * 747796405u + 2891336453u;
+  uint32_t word = ((st >> ((st >> 28) + 4u)) ^ st) * 277803737u;
+  return uint_as_float01((word >> 22) ^ word);
+}
+
+inline bool tri_test(const Tri& T, V3 o, V3 d, float tMin, float& tBest, uint32_t idx, Hit& h, uint32_t rng)
 {
   V3 pv = cross(d, T.e2);
   float det = dot(T.e1, pv);
@@ -420,7 +439,10 @@ inline bool tri_test(const Tri& T, V3 o, V3 d, float tMin, float& tBest, uint32_
   if (!(v >= 0.0f) || !(u + v <= 1.0f)) return false;
   float t = dot(T.e2, qv) * inv;
   if (!(t > tMin)) return false;
-  if (t < tBest || (t == tBest && h.tri != 0xffffffffu && idx < h.tri)) { tBest = t; h = Hit{t, u, v, idx}; return true; }
+  if (t < tBest || (t == tBest && h.tri != 0xffffffffu && idx < h.tri)) {
+    if (T.cutout < 1.0f && cutout_random(rng, idx) > T.cutout) return false; // ignoreIntersectionEXT (rp_main.ahit:57-60)
+    tBest = t; h = Hit{t, u, v, idx}; return true;
+  }
   return false;
 }
 
@@ -485,12 +507,12 @@ inline bool box_test(const BvhNode& n, V3 o, V3 inv, float tMin, float tMax)
   return t0 <= t1 * 1.0001f + 1e-6f;
 }
 
-bool trace_closest(const Prepared& P, V3 o, V3 d, float tMin, float tMax, Hit& h)
+bool trace_closest(const Prepared& P, V3 o, V3 d, float tMin, float tMax, Hit& h, uint32_t rng = 0u)
 {
   float tBest = tMax; bool any = false; h.tri = 0xffffffffu;
   // accept tMin < t < tMax; h.tri == ~0 marks 'no hit yet' so the tie rule cannot admit t == tMax
   if (P.bvh.empty()) {
-    for (uint32_t i = 0; i < P.tris.size(); i++) any |= tri_test(P.tris[i], o, d, tMin, tBest, i, h);
+    for (uint32_t i = 0; i < P.tris.size(); i++) any |= tri_test(P.tris[i], o, d, tMin, tBest, i, h, rng);
     return any;
   }
   V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -498,16 +520,16 @@ bool trace_closest(const Prepared& P, V3 o, V3 d, float tMin, float tMax, Hit& h
   while (sp) {
     const BvhNode& n = P.bvh[stack[--sp]];
     if (!box_test(n, o, inv, tMin, tBest)) continue;
-    if (n.count) { for (uint32_t i = n.left; i < n.left + n.count; i++) { uint32_t t = P.bvhTris[i]; any |= tri_test(P.tris[t], o, d, tMin, tBest, t, h); } }
+    if (n.count) { for (uint32_t i = n.left; i < n.left + n.count; i++) { uint32_t t = P.bvhTris[i]; any |= tri_test(P.tris[t], o, d, tMin, tBest, t, h, rng); } }
     else { stack[sp++] = n.left; stack[sp++] = n.left + 1; }
   }
   return any;
 }
 
 // Shadow rays: gl_RayFlagsTerminateOnFirstHitEXT (rp_main.rgen:405); any hit in (tMin,tMax) occludes.
-bool trace_any(const Prepared& P, V3 o, V3 d, float tMin, float tMax)
+bool trace_any(const Prepared& P, V3 o, V3 d, float tMin, float tMax, uint32_t rng)
 {
-  Hit h; return trace_closest(P, o, d, tMin, tMax, h);
+  Hit h; return trace_closest(P, o, d, tMin, tMax, h, rng);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1075,14 +1097,14 @@ void render_pixel(const Frame& F, uint32_t px, uint32_t py, const float* prevCol
       pl.neeContrib = v3(0, 0, 0); // :349
       Hit h;
       cnt.segments++; if (bounce < 64) cnt.bounceHistogram[bounce]++;
-      if (trace_closest(*F.P, pl.origin, pl.dir, tMin, tMax, h)) { cnt.hits++; closest_hit(F, h, pl, h.t); }
+      if (trace_closest(*F.P, pl.origin, pl.dir, tMin, tMax, h, pl.rng)) { cnt.hits++; closest_hit(F, h, pl, h.t); }
       else miss(F, pl);
       if (rs.nextEventEstimation) { // :397-438
         float lightDist = length(pl.neeToLight);
         V3 sdir = safe_div(pl.neeToLight, lightDist);
         bool traceRay = luminance(pl.neeContrib) > 1e-6f && lightDist > 1e-9f;
         bool shadowed = true;
-        if (traceRay) { cnt.shadowRays++; shadowed = trace_any(*F.P, pl.origin, sdir, 0.01f, lightDist); }
+        if (traceRay) { cnt.shadowRays++; shadowed = trace_any(*F.P, pl.origin, sdir, 0.01f, lightDist, pl.rng); }
         if (traceRay && !shadowed) pl.radiance = pl.radiance + pl.neeContrib;
       }
       if (length(pl.throughput) < 1e-9f) pl.bitfield |= TERMINATE_FLAG; // :441-444
@@ -1173,7 +1195,7 @@ void render_pixel_aovs(const Frame& F, uint32_t px, uint32_t py, size_t o, OrcAo
     float tMin = 0.0f, tMax = ORC_FLT_MAX;
     if (rs.clippingPlanes) { float cc = fmax2(1e-5f, dot(dir, F.camFwd)); tMin = F.clipNear / cc; tMax = F.clipFar / cc; }
     Hit h;
-    if (!trace_closest(*F.P, origin, dir, tMin, tMax, h)) continue;
+    if (!trace_closest(*F.P, origin, dir, tMin, tMax, h, rng)) continue;
     State st; const MeshData* mesh;
     setup_shading_state(*F.P, h, dir, st, mesh);
     const Tri& T = F.P->tris[h.tri];

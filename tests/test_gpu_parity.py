@@ -343,6 +343,20 @@ def test_open_pbr_scene_parity(gi, orc, nee):
     assert st["segments"] > 128 * 72 * 8 * 2
 
 
+@pytest.mark.parametrize("nee", [False, True])
+def test_cutout_opacity_parity(gi, orc, nee):
+    """Stochastic cutouts (rp_main.ahit) on closest-hit and shadow rays, order-independent any-hit randomness."""
+    desc = cornell_box(MAT_USD_PREVIEW_SURFACE)
+    desc.materials.append(MaterialDesc.usd_preview_surface(name="half", diffuseColor=(0.2, 0.3, 0.9), opacity=0.5))
+    desc.materials.append(MaterialDesc.usd_preview_surface(name="masked", diffuseColor=(0.9, 0.9, 0.1), opacity=0.3, opacityThreshold=0.5))
+    desc.materials.append(MaterialDesc.open_pbr(name="veil", base_color=(0.9, 0.2, 0.2)))
+    desc.materials[-1].params[14] = 0.25  # geometry_opacity
+    desc.meshes[6].material, desc.meshes[7].material, desc.meshes[3].material = 4, 5, 6
+    if nee:
+        desc.rect_lights = [RectLight(origin=(0, 0, 0.9), t0=(1, 0, 0), t1=(0, -1, 0), base_emission=(10, 10, 10), width=0.7, height=0.5)]
+    render_both(gi, orc, desc, RenderSettings(spp=8, max_bounces=6, next_event_estimation=nee), 128, 72)
+
+
 def test_instanced_scene_parity(gi, orc):
     """Instancing + several materials (C4's structure at small scale): flattened BVH vs the oracle."""
     desc = sphere_grid(grid=4, subdivisions=1, material_count=5)

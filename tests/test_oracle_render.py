@@ -163,3 +163,32 @@ def test_expf_polynomial(orc):
     for x in np.concatenate([-np.float32(10.0) ** np.linspace(-6, 1.9, 300), np.float32([0.0, -0.5, -1.0, -87.5, -100.0])]).astype(np.float32):
         got = L.orc_expf(float(x))
         assert got == pytest.approx(np.exp(np.float64(x)), rel=3e-7, abs=1e-38)
+
+
+def test_cutout_opacity(orc):
+    """rp_main.ahit: opacity 1 == opaque; opacity 0 == the mesh is not there (the any-hit draw does not advance the path rng in
+    our order-independent restatement); opacityThreshold turns opacity into a binary mask; 0.5 lets about half the rays pass."""
+    rs = RenderSettings(spp=4, max_bounces=4)
+    base = cornell_box(MAT_DIFFUSE)
+    ref, _ = orc.render(base, rs, 48, 27)
+    gone = cornell_box(MAT_DIFFUSE); gone.meshes[6].visible = False; gone.meshes[7].visible = False
+    ref_gone, _ = orc.render(gone, rs, 48, 27)
+    from gatling_amd.scene import P_OPACITY, P_OPACITY_THRESHOLD
+    def with_opacity(op, th=0.0):
+        d = cornell_box(MAT_DIFFUSE)
+        m = MaterialDesc.usd_preview_surface(name="cut", diffuseColor=(0.8, 0.8, 0.8), klass=MAT_DIFFUSE, opacity=op, opacityThreshold=th)
+        d.materials.append(m); d.meshes[6].material = d.meshes[7].material = len(d.materials) - 1
+        return d
+    img1, _ = orc.render(with_opacity(1.0), rs, 48, 27)
+    assert np.array_equal(img1, ref)
+    # triangle ids are unchanged (the boxes are the last meshes), so "fully transparent" must equal "invisible" up to the
+    # 2^-23 chance per candidate that the hash returns exactly 0
+    img0, _ = orc.render(with_opacity(0.0), rs, 48, 27)
+    assert (img0 != ref_gone).any(axis=-1).sum() <= 2
+    imgt, _ = orc.render(with_opacity(0.3, th=0.5), rs, 48, 27)   # below the threshold -> masked out
+    assert (imgt != ref_gone).any(axis=-1).sum() <= 2
+    imgo, _ = orc.render(with_opacity(0.7, th=0.5), rs, 48, 27)   # above the threshold -> opaque
+    assert np.array_equal(imgo, ref)
+    half, _ = orc.render(with_opacity(0.5), rs, 48, 27)
+    d_full, d_none = np.abs(half - ref).mean(), np.abs(half - ref_gone).mean()
+    assert d_full > 1e-4 and d_none > 1e-4  # neither opaque nor absent
