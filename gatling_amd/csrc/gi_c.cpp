@@ -279,6 +279,7 @@ struct GiCScene {
   bool countTraversal = false, kernelTimers = false;
   uint32_t kernelTimerStride = 1;
   uint64_t optPoolSlots = 0, optSampleBufferMb = 0; // 0 = default
+  int32_t optTraceDyn = -1; // -1 = default; 0 = block-synchronous k_trace everywhere; N = k_trace_dyn refill threshold
   GiCRenderStats stats{};
   std::vector<hipEvent_t> eventPool;
 };
@@ -602,6 +603,7 @@ int giCSetSceneOption(GiCScene* scene, int32_t option, int32_t value)
   if (option == GI_C_SCENE_OPTION_COUNT_TRAVERSAL) { scene->countTraversal = value != 0; return GI_C_OK; }
   if (option == GI_C_SCENE_OPTION_KERNEL_TIMERS) { scene->kernelTimers = value != 0; scene->kernelTimerStride = value > 0 ? (uint32_t)value : 1u; return GI_C_OK; }
   if (option == GI_C_SCENE_OPTION_POOL_SLOTS) { scene->optPoolSlots = value > 0 ? (uint64_t)value : 0; return GI_C_OK; }
+  if (option == GI_C_SCENE_OPTION_TRACE_DYNAMIC) { scene->optTraceDyn = value < 0 ? -1 : (value > 64 ? 64 : value); return GI_C_OK; }
   if (option == GI_C_SCENE_OPTION_SAMPLE_BUFFER_MB) { scene->optSampleBufferMb = value > 0 ? (uint64_t)value : 0; return GI_C_OK; }
   setError("unknown scene option"); return GI_C_ERROR;
 }
@@ -730,6 +732,7 @@ int buildScene(GiCScene* s)
   Bvh8 bvh;
   buildBvh8(tris, bvh);
   double t1 = nowMs();
+  if (bvh.tris.size() >= (1u << 26)) { setError("scene has 2^26 or more triangles after instancing: the traversal queues pack (lane, triangle) into 32 bits"); return GI_C_ERROR; }
   hipStream_t st = g_ctx.stream;
   std::vector<int32_t> triFaceId(bvh.tris.size());
   for (size_t i = 0; i < bvh.tris.size(); i++) triFaceId[i] = faceIdOf[bvh.tris[i].origId];
@@ -768,6 +771,15 @@ SceneView makeView(GiCScene* s)
 // Per-shard queue capacity: a producer launch of G blocks gives shard s at most ceil(G/NSHARD) blocks, each appending
 // at most ceil(slots/(G*256))*256 items per queue; a queue can be fed by two launches before it is consumed
 // (e.g. REGEN by k_trace and k_shade, TRACE by k_shade and the next k_raygen), hence the factor 2.
+// k_trace_dyn refill threshold for scenes that do not fit LDS (0 = use the block-synchronous k_trace)
+static uint32_t traceDynRefill(const GiCScene* s)
+{
+  uint32_t r = s->optTraceDyn >= 0 ? (uint32_t)s->optTraceDyn : 16u;
+  if (const char* e = getenv("GATLING_TRACE_DYN")) r = (uint32_t)std::max(0, std::min(64, atoi(e)));
+  if (const char* e = getenv("GATLING_TRACE_DYN_SPILL8")) { if (r && atoi(e)) r |= TRACE_DYN_SPILL8; }
+  return r;
+}
+
 uint32_t shardCapacity(size_t slots, uint32_t gridA, uint32_t gridB)
 {
   auto bound = [&](uint32_t G) { size_t trips = (slots + (size_t)G * 256 - 1) / ((size_t)G * 256); return (size_t)((G + NSHARD - 1) / NSHARD) * trips * 256; };
@@ -966,7 +978,9 @@ extern "C" int giCRender(const GiCRenderParams* params)
     {
       SceneView v0 = makeView(s);
       uint32_t ln, lt, ldsBytes; traceLdsLayout(v0, ln, lt, ldsBytes);
-      uint32_t perCu = std::min<uint32_t>(6u, (160u * 1024u) / (ldsBytes + 256u));
+      uint32_t perCu = std::min<uint32_t>(6u, (160u * 1024u) / (ldsBytes + traceStaticLdsBytes() + 256u));
+      const bool allLds = ln == v0.nodeCount && lt == v0.triCount && v0.triCount > 0u;
+      if (!allLds && traceDynRefill(s)) perCu = 8u; // k_trace_dyn is persistent per wave: blocks beyond what is resident find the cursor exhausted
       if (const char* e = getenv("GATLING_TRACE_BLOCKS_PER_CU")) perCu = (uint32_t)atoi(e);
       uint32_t widePerCu = 8u;
       if (const char* e = getenv("GATLING_WIDE_BLOCKS_PER_CU")) widePerCu = (uint32_t)atoi(e);
@@ -980,6 +994,7 @@ extern "C" int giCRender(const GiCRenderParams* params)
     QueueSet qs = makeQueueSet(s);
     F4* colorOut = reinterpret_cast<F4*>(colorRb->deviceMem);
     const bool nee = rs.nextEventEstimation != 0;
+    const uint32_t dynRefill = traceDynRefill(s);
 
     // --- the bounce loop (rp_main.rgen:215, 295): every pool slot advances one stage per iteration
     HIP_TRY(hipStreamSynchronize(st));
@@ -1012,11 +1027,11 @@ extern "C" int giCRender(const GiCRenderParams* params)
           uint32_t pending = 0; for (uint32_t k = 0; k < NSHARD; k++) pending += s->hCounters->count[Q_TRACE_A + par][k].v;
           if (pending == 0) { totalIters++; break; } // raygen consumed the regen queue and produced no rays: the pool has drained
         }
-        timed(1, [&] { launchTrace(st, traceBlocks, false, s->countTraversal, view, ps, qs, s->dCounters.ptr, Q_TRACE_A + par, Q_REGEN_A + (par ^ 1u)); });
+        timed(1, [&] { launchTrace(st, traceBlocks, false, s->countTraversal, view, ps, qs, s->dCounters.ptr, Q_TRACE_A + par, Q_REGEN_A + (par ^ 1u), dynRefill, wideBlocks); });
         traceLaunches++;
         for (uint32_t klass = 0; klass < MAT_CLASS_COUNT; klass++)
           if (s->classMask & (1u << klass)) timed(2, [&] { launchShade(st, wideBlocks, klass, U, view, ps, qs, s->dCounters.ptr, par); });
-        if (nee) timed(3, [&] { launchTrace(st, traceBlocks, true, s->countTraversal, view, ps, qs, s->dCounters.ptr, Q_SHADOW, Q_SHADOW); });
+        if (nee) timed(3, [&] { launchTrace(st, traceBlocks, true, s->countTraversal, view, ps, qs, s->dCounters.ptr, Q_SHADOW, Q_SHADOW, dynRefill, wideBlocks); });
         iters++; totalIters++;
       }
       launchAccumulate(st, U, s->sampleBuf.ptr, s->accum.ptr, colorOut, batch == 0, batch + 1 == numBatches);
@@ -1087,7 +1102,7 @@ extern "C" int giCTraceRays(GiCScene* s, uint32_t count, const float* origins, c
       hipMemcpyAsync(s->qB[Q_TRACE_A].ptr, qb.data(), qn * sizeof(F4), hipMemcpyHostToDevice, st) != hipSuccess ||
       hipMemcpyAsync(s->dCounters.ptr, &c, sizeof(c), hipMemcpyHostToDevice, st) != hipSuccess) { setError("giCTraceRays: upload failed"); return -1; }
   PathState ps{s->slots.ptr};
-  launchTrace(st, blocks, false, false, makeView(s), ps, makeQueueSet(s), s->dCounters.ptr, Q_TRACE_A, Q_REGEN_B);
+  launchTrace(st, blocks, false, false, makeView(s), ps, makeQueueSet(s), s->dCounters.ptr, Q_TRACE_A, Q_REGEN_B, traceDynRefill(s), blocks);
   std::vector<TriRec> tris(s->triCount);
   if (hipMemcpyAsync(&c, s->dCounters.ptr, sizeof(c), hipMemcpyDeviceToHost, st) != hipSuccess ||
       (s->triCount && hipMemcpyAsync(tris.data(), s->dTris.ptr, s->triCount * sizeof(TriRec), hipMemcpyDeviceToHost, st) != hipSuccess) ||

@@ -97,6 +97,7 @@ __device__ __forceinline__ void zero_next_counters(Counters* cnt, uint32_t par)
     for (uint32_t c = 0; c < MAT_CLASS_COUNT; c++) cnt->count[Q_HIT + c][t].v = 0;
     cnt->count[Q_SHADOW][t].v = 0;
   }
+  if (t < 2u) cnt->cursor[t].v = 0; // k_trace_dyn's ray cursors (closest, shadow)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -113,7 +114,7 @@ __global__ void k_init(PathState st, QueueSet qs, Counters* cnt, uint32_t n, uin
     cnt->count[q][sdx].v = c;
   }
   if (i == 0) {
-    cnt->workBase[0].v = 0; cnt->workBase[1].v = 0;
+    cnt->workBase[0].v = 0; cnt->workBase[1].v = 0; cnt->cursor[0].v = 0; cnt->cursor[1].v = 0;
     if (resetStats) { cnt->segments = 0; cnt->shadowRays = 0; cnt->nodesVisited = 0; cnt->trisTested = 0; cnt->shadowNodesVisited = 0; cnt->shadowTrisTested = 0; }
   }
   for (; i < n; i += gridDim.x * blockDim.x) {
@@ -270,117 +271,251 @@ __device__ __forceinline__ float cutout_random(uint32_t rng, uint32_t triId)
   return u2f(0x3f800000u | (((word >> 22) ^ word) >> 9)) - 1.0f;
 }
 
+// Per-lane traversal state.  A ray is advanced by trav_step() one "group" at a time (one internal node, then the
+// triangles of its leaf children, then a pop) so that k_trace (one ray per lane until it finishes) and k_trace_dyn
+// (lanes refill from the queue as they finish) share the same arithmetic.
+struct RayTrav {
+  V3 o, d; float idx, idy, idz, tMin, tBest; uint32_t octinv;
+  uint32_t bestTri, bestOrig, bestMat; float bestU, bestV;
+  uint2 G; uint32_t sp; bool found;
+};
+
+__device__ __forceinline__ void trav_init(RayTrav& R, V3 o, V3 d, float tMin, float tMax)
+{
+  R.o = o; R.d = d; R.tMin = tMin; R.tBest = tMax;
+  // reciprocal direction for the slab tests only (guard against 0: boxes are padded, a huge finite value is safe)
+  const float gx = (fabsf(d.x) < 1e-30f) ? (d.x < 0.0f ? -1e-30f : 1e-30f) : d.x;
+  const float gy = (fabsf(d.y) < 1e-30f) ? (d.y < 0.0f ? -1e-30f : 1e-30f) : d.y;
+  const float gz = (fabsf(d.z) < 1e-30f) ? (d.z < 0.0f ? -1e-30f : 1e-30f) : d.z;
+  R.idx = 1.0f / gx; R.idy = 1.0f / gy; R.idz = 1.0f / gz;
+  R.octinv = (d.x >= 0.0f ? 1u : 0u) | (d.y >= 0.0f ? 2u : 0u) | (d.z >= 0.0f ? 4u : 0u);
+  R.bestTri = 0xffffffffu; R.bestOrig = 0xffffffffu; R.bestMat = 0u; R.bestU = 0.0f; R.bestV = 0.0f;
+  R.G = make_uint2(0u, 0x80000000u); // virtual group holding only the root
+  R.sp = 0u; R.found = false;
+}
+
+// Node half of a traversal step: takes the nearest unvisited child of the current node group (pushing the rest), tests
+// the ray against that node's 8 quantised child boxes and returns the triangle group (base, mask) of its hit leaf
+// children; R.G becomes the group of hit internal children.  Caller guarantees R.G has node bits.
+template <bool COUNT, uint32_t STACK, bool OVERFLOW, bool ALL_LDS>
+__device__ __forceinline__ uint2 trav_node(RayTrav& R, const SceneView& sc, const uint4* s_nodes, uint32_t ldsNodes,
+                                           uint2 (*s_stack)[TRACE_BLOCK], uint2 (&overflow)[OVERFLOW ? OVF_STACK : 1], TraceCounters& tc)
+{
+  const uint32_t tid = threadIdx.x;
+  const V3 o = R.o, d = R.d;
+  uint2 G = R.G;
+  uint32_t sp = R.sp;
+  const uint32_t octinv = R.octinv;
+  const uint32_t bit = 31u - (uint32_t)__clz((int)(G.y & 0xff000000u));
+  G.y &= ~(1u << bit);
+  if (G.y & 0xff000000u) {
+    if (!OVERFLOW || sp < STACK) s_stack[sp < STACK ? sp : STACK - 1u][tid] = G; else overflow[sp - STACK] = G;
+    sp++;
+  }
+  const uint32_t slot = (bit - 24u) ^ octinv;
+  const uint32_t rel = (uint32_t)__popc((G.y & 0xffu) & ((1u << slot) - 1u));
+  const uint32_t nodeIdx = G.x + rel;
+  uint4 n0, n1, n2, n3, n4;
+  if (ALL_LDS || nodeIdx < ldsNodes) { const uint4* p = s_nodes + nodeIdx * 5u; n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3]; n4 = p[4]; }
+  else { const uint4* p = reinterpret_cast<const uint4*>(sc.nodes) + (size_t)nodeIdx * 5u; n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3]; n4 = p[4]; }
+  if (COUNT) tc.nodes++;
+  // ray in the node's quantisation frame
+  const float sx = u2f((n0.w & 0xffu) << 23), sy = u2f(((n0.w >> 8) & 0xffu) << 23), sz = u2f(((n0.w >> 16) & 0xffu) << 23);
+  const float ax = sx * R.idx, ay = sy * R.idy, az = sz * R.idz;
+  const float bx = (u2f(n0.x) - o.x) * R.idx, by = (u2f(n0.y) - o.y) * R.idy, bz = (u2f(n0.z) - o.z) * R.idz;
+  // near/far plane bytes per axis, chosen by direction sign
+  const bool nxn = d.x < 0.0f, nyn = d.y < 0.0f, nzn = d.z < 0.0f;
+  const uint32_t qlox[2] = {n2.x, n2.y}, qloy[2] = {n2.z, n2.w}, qloz[2] = {n3.x, n3.y};
+  const uint32_t qhix[2] = {n3.z, n3.w}, qhiy[2] = {n4.x, n4.y}, qhiz[2] = {n4.z, n4.w};
+  const uint32_t metaw[2] = {n1.z, n1.w};
+  uint32_t hitmask = 0u;
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const uint32_t nearx = nxn ? qhix[h] : qlox[h], farx = nxn ? qlox[h] : qhix[h];
+    const uint32_t neary = nyn ? qhiy[h] : qloy[h], fary = nyn ? qloy[h] : qhiy[h];
+    const uint32_t nearz = nzn ? qhiz[h] : qloz[h], farz = nzn ? qloz[h] : qhiz[h];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t sh = 8u * (uint32_t)k;
+      const float t0x = fmaf((float)((nearx >> sh) & 0xffu), ax, bx), t1x = fmaf((float)((farx >> sh) & 0xffu), ax, bx);
+      const float t0y = fmaf((float)((neary >> sh) & 0xffu), ay, by), t1y = fmaf((float)((fary >> sh) & 0xffu), ay, by);
+      const float t0z = fmaf((float)((nearz >> sh) & 0xffu), az, bz), t1z = fmaf((float)((farz >> sh) & 0xffu), az, bz);
+      const float tn = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, R.tMin));
+      const float tf = fminf(fminf(t1x, t1y), fminf(t1z, R.tBest));
+      const uint32_t meta = (metaw[h] >> sh) & 0xffu;
+      if (tn <= tf * 1.00001f + 1e-30f && meta != 0u) {
+        const uint32_t inner = ((meta & 0x18u) == 0x18u) ? octinv : 0u;
+        hitmask |= (meta >> 5) << ((meta & 31u) ^ inner);
+      }
+    }
+  }
+  R.G = make_uint2(n1.x, (hitmask & 0xff000000u) | (n0.w >> 24));
+  R.sp = sp;
+  return make_uint2(n1.y, hitmask & 0x00ffffffu);
+}
+
+// End of a step: when the current group has no unvisited internal child left, continue with the stack top.
+// Returns true when the traversal is finished.
+template <uint32_t STACK, bool OVERFLOW>
+__device__ __forceinline__ bool trav_pop(RayTrav& R, uint2 (*s_stack)[TRACE_BLOCK], uint2 (&overflow)[OVERFLOW ? OVF_STACK : 1])
+{
+  if (R.G.y & 0xff000000u) return false;
+  if (R.sp == 0u) return true;
+  const uint32_t sp = --R.sp;
+  R.G = (!OVERFLOW || sp < STACK) ? s_stack[sp < STACK ? sp : STACK - 1u][threadIdx.x] : overflow[sp - STACK];
+  return false;
+}
+
+// Two-sided Moeller-Trumbore, operation order == oracle tri_test; evaluated branch-free (a wave almost always has a lane
+// that passes each early-out, so predication is cheaper than exec-mask branches).  `inside` excludes the t < tBest test.
+__device__ __forceinline__ bool tri_test(V3 o, V3 d, float tMin, const uint4& a, const uint4& b, const uint4& c, float& t, float& u, float& v)
+{
+  const V3 v0 = v3(u2f(a.x), u2f(a.y), u2f(a.z)), e1 = v3(u2f(a.w), u2f(b.x), u2f(b.y)), e2 = v3(u2f(b.z), u2f(b.w), u2f(c.x));
+  const V3 pv = cross(d, e2);
+  const float det = dot(e1, pv);
+  const float inv = 1.0f / det;
+  const V3 tv = o - v0;
+  u = dot(tv, pv) * inv;
+  const V3 qv = cross(tv, e1);
+  v = dot(d, qv) * inv;
+  t = dot(e2, qv) * inv;
+  return (det != 0.0f) & (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > tMin);
+}
+
+// Advances the ray by one group (node, then its leaf triangles one after the other, then pop); returns true when the
+// traversal is finished.  The per-lane form used by k_aov and the block-synchronous k_trace.
+template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool ALL_LDS, bool CUTOUT>
+__device__ __forceinline__ bool trav_step(RayTrav& R, const SceneView& sc, const uint4* s_nodes, uint32_t ldsNodes, const uint4* s_tris, uint32_t ldsTris,
+                                          uint2 (*s_stack)[TRACE_BLOCK], uint2 (&overflow)[OVERFLOW ? OVF_STACK : 1], TraceCounters& tc, uint32_t rng)
+{
+  uint2 Gt;
+  if (R.G.y & 0xff000000u) Gt = trav_node<COUNT, STACK, OVERFLOW, ALL_LDS>(R, sc, s_nodes, ldsNodes, s_stack, overflow, tc);
+  else { Gt = R.G; R.G = make_uint2(0u, 0u); }
+  // triangles of this node
+  while (Gt.y) {
+    const uint32_t k = (uint32_t)__ffs((int)Gt.y) - 1u;
+    Gt.y &= Gt.y - 1u;
+    const uint32_t triIdx = Gt.x + k;
+    uint4 a, b, c;
+    if (ALL_LDS || triIdx < ldsTris) { const uint4* p = s_tris + triIdx * 3u; a = p[0]; b = p[1]; c = p[2]; }
+    else { const uint4* p = reinterpret_cast<const uint4*>(sc.tris) + (size_t)triIdx * 4u; a = p[0]; b = p[1]; c = p[2]; }
+    if (COUNT) tc.tris++;
+    const uint32_t orig = c.y;
+    float t, u, v;
+    const bool inside = tri_test(R.o, R.d, R.tMin, a, b, c, t, u, v);
+    const bool better = (t < R.tBest) | ((t == R.tBest) & (R.bestOrig != 0xffffffffu) & (orig < R.bestOrig));
+    bool accept = inside & better;
+    if (CUTOUT && accept && (c.w & (1u << 28))) { // non-opaque material: stochastic cutout (ignoreIntersectionEXT, rp_main.ahit:57-60)
+      const float opacity = sc.materials[c.w & 0x00ffffffu].p[MP_CUTOUT];
+      accept = !(cutout_random(rng, orig) > opacity);
+    }
+    if (accept) {
+      R.tBest = t; R.bestU = u; R.bestV = v; R.bestTri = triIdx; R.bestOrig = orig; R.bestMat = c.w; R.found = true;
+      if (ANYHIT) { R.G.y = 0u; R.sp = 0u; break; }
+    }
+  }
+  return trav_pop<STACK, OVERFLOW>(R, s_stack, overflow);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wave-cooperative triangle stage.  The number of leaf triangles a node step yields varies from 0 to 24 per lane, so a
+// per-lane triangle loop runs as long as the busiest lane while most lanes sit idle (measured: 28 % of the lanes active).
+// Instead every lane appends its (ray lane, triangle) pairs to a per-wave LDS queue and the wave tests 64 pairs at a
+// time, one per lane, fetching the owning lane's ray with ds_bpermute.  The nearest hit of a ray is kept in LDS as the
+// 64-bit key (t bits << 32 | scene-order triangle id + 1) under atomicMin, which is exactly the oracle's
+// "t < tBest, ties to the lower scene-order id" rule and makes the result independent of the test order.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t TRI_ID_BITS = 26; // queue entry = ray lane << 26 | triangle index (the host refuses scenes with >= 2^26 triangles)
+struct WaveTri {
+  unsigned long long best[64]; // per ray lane: (t bits << 32) | (scene-order id + 1); low word 0 = no hit yet
+  uint4 hit[64];               // per ray lane: (triangle index, u bits, v bits, material word) of that hit
+  uint32_t queue[128];         // ring of pending (ray lane, triangle) pairs
+};
+
+template <bool COUNT, bool ALL_LDS, bool CUTOUT>
+__device__ __forceinline__ void wave_tri_batch(WaveTri& W, uint32_t head, uint32_t cnt, const RayTrav& R, uint32_t rng, const SceneView& sc,
+                                               const uint4* s_tris, uint32_t ldsTris, TraceCounters& tc)
+{
+  const uint32_t lane = __lane_id();
+  const bool act = lane < cnt;
+  const uint32_t e = act ? *(volatile uint32_t*)&W.queue[(head + lane) & 127u] : 0u;
+  const uint32_t rl = e >> TRI_ID_BITS, triIdx = e & ((1u << TRI_ID_BITS) - 1u);
+  // the owning lane's ray (executed by all lanes: wave-uniform control flow)
+  const V3 o = v3(__shfl(R.o.x, (int)rl), __shfl(R.o.y, (int)rl), __shfl(R.o.z, (int)rl));
+  const V3 d = v3(__shfl(R.d.x, (int)rl), __shfl(R.d.y, (int)rl), __shfl(R.d.z, (int)rl));
+  const float tMin = __shfl(R.tMin, (int)rl);
+  const uint32_t rrng = CUTOUT ? (uint32_t)__shfl((int)rng, (int)rl) : 0u;
+  if (act) {
+    uint4 a, b, c;
+    if (ALL_LDS || triIdx < ldsTris) { const uint4* p = s_tris + triIdx * 3u; a = p[0]; b = p[1]; c = p[2]; }
+    else { const uint4* p = reinterpret_cast<const uint4*>(sc.tris) + (size_t)triIdx * 4u; a = p[0]; b = p[1]; c = p[2]; }
+    if (COUNT) tc.tris++;
+    float t, u, v;
+    bool accept = tri_test(o, d, tMin, a, b, c, t, u, v);
+    if (CUTOUT && accept && (c.w & (1u << 28))) { // non-opaque material: stochastic cutout (ignoreIntersectionEXT, rp_main.ahit:57-60)
+      const float opacity = sc.materials[c.w & 0x00ffffffu].p[MP_CUTOUT];
+      accept = !(cutout_random(rrng, c.y) > opacity);
+    }
+    if (accept) {
+      const unsigned long long key = ((unsigned long long)f2u(t) << 32) | (unsigned long long)(c.y + 1u);
+      atomicMin(&W.best[rl], key);
+      if (*(volatile unsigned long long*)&W.best[rl] == key) W.hit[rl] = make_uint4(triIdx, f2u(u), f2u(v), c.w);
+    }
+  }
+}
+
+// One step of all rays of a wave: node phase per lane, then the cooperative triangle stage, then pop.  Wave-uniform
+// control flow; lanes without a ray (alive == false) only help testing triangles.  Returns true when this lane's ray is finished.
+template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool ALL_LDS, bool CUTOUT>
+__device__ __forceinline__ bool wave_step(RayTrav& R, bool alive, WaveTri& W, const SceneView& sc, const uint4* s_nodes, uint32_t ldsNodes,
+                                          const uint4* s_tris, uint32_t ldsTris, uint2 (*s_stack)[TRACE_BLOCK], uint2 (&overflow)[OVERFLOW ? OVF_STACK : 1],
+                                          TraceCounters& tc, uint32_t rng)
+{
+  const uint32_t lane = __lane_id();
+  uint2 Gt = make_uint2(0u, 0u);
+  if (alive) Gt = trav_node<COUNT, STACK, OVERFLOW, ALL_LDS>(R, sc, s_nodes, ldsNodes, s_stack, overflow, tc);
+  uint32_t head = 0u, tail = 0u; // wave-uniform
+  for (;;) {
+    const unsigned long long m = __ballot(Gt.y != 0u);
+    if (!m) break;
+    if (Gt.y) {
+      const uint32_t k = (uint32_t)__ffs((int)Gt.y) - 1u;
+      Gt.y &= Gt.y - 1u;
+      *(volatile uint32_t*)&W.queue[(tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & 127u] = (lane << TRI_ID_BITS) | (Gt.x + k);
+    }
+    tail += (uint32_t)__popcll(m);
+    if (tail - head >= 64u) { wave_tri_batch<COUNT, ALL_LDS, CUTOUT>(W, head, 64u, R, rng, sc, s_tris, ldsTris, tc); head += 64u; }
+  }
+  if (tail != head) wave_tri_batch<COUNT, ALL_LDS, CUTOUT>(W, head, tail - head, R, rng, sc, s_tris, ldsTris, tc);
+  bool done = false;
+  if (alive) {
+    const unsigned long long key = *(volatile unsigned long long*)&W.best[lane];
+    R.tBest = u2f((uint32_t)(key >> 32));
+    R.found = (uint32_t)key != 0u;
+    done = (ANYHIT && R.found) ? true : trav_pop<STACK, OVERFLOW>(R, s_stack, overflow);
+  }
+  return done;
+}
+
+// start of a ray in the cooperative scheme (after trav_init)
+__device__ __forceinline__ void wave_ray_begin(WaveTri& W, float tMax) { *(volatile unsigned long long*)&W.best[__lane_id()] = (unsigned long long)f2u(tMax) << 32; }
+// result of a finished ray
+__device__ __forceinline__ void wave_ray_end(WaveTri& W, RayTrav& R)
+{
+  __atomic_signal_fence(__ATOMIC_SEQ_CST); // compiler only: the winning lane's store precedes this load in the wave's program order
+  if (R.found) { const uint4 h = W.hit[__lane_id()]; R.bestTri = h.x; R.bestU = u2f(h.y); R.bestV = u2f(h.z); R.bestMat = h.w; }
+}
+
 template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool ALL_LDS, bool CUTOUT>
 __device__ __forceinline__ bool traverse(const SceneView& sc, const uint4* s_nodes, uint32_t ldsNodes, const uint4* s_tris, uint32_t ldsTris,
                                          uint2 (*s_stack)[TRACE_BLOCK], V3 o, V3 d, float tMin, float tMax,
                                          float& outT, float& outU, float& outV, uint32_t& outTri, uint32_t& outMat, TraceCounters& tc, uint32_t rng = 0u)
 {
-  const uint32_t tid = threadIdx.x;
-  // reciprocal direction for the slab tests only (guard against 0: boxes are padded, a huge finite value is safe)
-  const float gx = (fabsf(d.x) < 1e-30f) ? (d.x < 0.0f ? -1e-30f : 1e-30f) : d.x;
-  const float gy = (fabsf(d.y) < 1e-30f) ? (d.y < 0.0f ? -1e-30f : 1e-30f) : d.y;
-  const float gz = (fabsf(d.z) < 1e-30f) ? (d.z < 0.0f ? -1e-30f : 1e-30f) : d.z;
-  const float idx = 1.0f / gx, idy = 1.0f / gy, idz = 1.0f / gz;
-  const uint32_t octinv = (d.x >= 0.0f ? 1u : 0u) | (d.y >= 0.0f ? 2u : 0u) | (d.z >= 0.0f ? 4u : 0u);
-
-  float tBest = tMax; uint32_t bestTri = 0xffffffffu, bestOrig = 0xffffffffu, bestMat = 0u; float bestU = 0.0f, bestV = 0.0f;
+  RayTrav R; trav_init(R, o, d, tMin, tMax);
   uint2 overflow[OVERFLOW ? OVF_STACK : 1];
-  uint32_t sp = 0;
-  uint2 G = make_uint2(0u, 0x80000000u); // virtual group holding only the root
-  bool found = false;
-
-  for (;;) {
-    uint2 Gt;
-    if (G.y & 0xff000000u) {
-      const uint32_t bit = 31u - (uint32_t)__clz((int)(G.y & 0xff000000u));
-      G.y &= ~(1u << bit);
-      if (G.y & 0xff000000u) {
-        if (!OVERFLOW || sp < STACK) s_stack[sp < STACK ? sp : STACK - 1u][tid] = G; else overflow[sp - STACK] = G;
-        sp++;
-      }
-      const uint32_t slot = (bit - 24u) ^ octinv;
-      const uint32_t rel = (uint32_t)__popc((G.y & 0xffu) & ((1u << slot) - 1u));
-      const uint32_t nodeIdx = G.x + rel;
-      uint4 n0, n1, n2, n3, n4;
-      if (ALL_LDS || nodeIdx < ldsNodes) { const uint4* p = s_nodes + nodeIdx * 5u; n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3]; n4 = p[4]; }
-      else { const uint4* p = reinterpret_cast<const uint4*>(sc.nodes) + (size_t)nodeIdx * 5u; n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3]; n4 = p[4]; }
-      if (COUNT) tc.nodes++;
-      // ray in the node's quantisation frame
-      const float sx = u2f((n0.w & 0xffu) << 23), sy = u2f(((n0.w >> 8) & 0xffu) << 23), sz = u2f(((n0.w >> 16) & 0xffu) << 23);
-      const float ax = sx * idx, ay = sy * idy, az = sz * idz;
-      const float bx = (u2f(n0.x) - o.x) * idx, by = (u2f(n0.y) - o.y) * idy, bz = (u2f(n0.z) - o.z) * idz;
-      // near/far plane bytes per axis, chosen by direction sign
-      const bool nxn = d.x < 0.0f, nyn = d.y < 0.0f, nzn = d.z < 0.0f;
-      const uint32_t qlox[2] = {n2.x, n2.y}, qloy[2] = {n2.z, n2.w}, qloz[2] = {n3.x, n3.y};
-      const uint32_t qhix[2] = {n3.z, n3.w}, qhiy[2] = {n4.x, n4.y}, qhiz[2] = {n4.z, n4.w};
-      const uint32_t metaw[2] = {n1.z, n1.w};
-      uint32_t hitmask = 0u;
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const uint32_t nearx = nxn ? qhix[h] : qlox[h], farx = nxn ? qlox[h] : qhix[h];
-        const uint32_t neary = nyn ? qhiy[h] : qloy[h], fary = nyn ? qloy[h] : qhiy[h];
-        const uint32_t nearz = nzn ? qhiz[h] : qloz[h], farz = nzn ? qloz[h] : qhiz[h];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const uint32_t sh = 8u * (uint32_t)k;
-          const float t0x = fmaf((float)((nearx >> sh) & 0xffu), ax, bx), t1x = fmaf((float)((farx >> sh) & 0xffu), ax, bx);
-          const float t0y = fmaf((float)((neary >> sh) & 0xffu), ay, by), t1y = fmaf((float)((fary >> sh) & 0xffu), ay, by);
-          const float t0z = fmaf((float)((nearz >> sh) & 0xffu), az, bz), t1z = fmaf((float)((farz >> sh) & 0xffu), az, bz);
-          const float tn = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, tMin));
-          const float tf = fminf(fminf(t1x, t1y), fminf(t1z, tBest));
-          const uint32_t meta = (metaw[h] >> sh) & 0xffu;
-          if (tn <= tf * 1.00001f + 1e-30f && meta != 0u) {
-            const uint32_t inner = ((meta & 0x18u) == 0x18u) ? octinv : 0u;
-            hitmask |= (meta >> 5) << ((meta & 31u) ^ inner);
-          }
-        }
-      }
-      G = make_uint2(n1.x, (hitmask & 0xff000000u) | (n0.w >> 24));
-      Gt = make_uint2(n1.y, hitmask & 0x00ffffffu);
-    } else {
-      Gt = G; G = make_uint2(0u, 0u);
-    }
-    // triangles of this node
-    while (Gt.y) {
-      const uint32_t k = (uint32_t)__ffs((int)Gt.y) - 1u;
-      Gt.y &= Gt.y - 1u;
-      const uint32_t triIdx = Gt.x + k;
-      uint4 a, b, c;
-      if (ALL_LDS || triIdx < ldsTris) { const uint4* p = s_tris + triIdx * 3u; a = p[0]; b = p[1]; c = p[2]; }
-      else { const uint4* p = reinterpret_cast<const uint4*>(sc.tris) + (size_t)triIdx * 4u; a = p[0]; b = p[1]; c = p[2]; }
-      if (COUNT) tc.tris++;
-      const V3 v0 = v3(u2f(a.x), u2f(a.y), u2f(a.z)), e1 = v3(u2f(a.w), u2f(b.x), u2f(b.y)), e2 = v3(u2f(b.z), u2f(b.w), u2f(c.x));
-      const uint32_t orig = c.y;
-      // two-sided Moeller-Trumbore, operation order == oracle tri_test; evaluated branch-free (a wave almost always has a
-      // lane that passes each early-out, so predication is cheaper than exec-mask branches), one predicate at the end
-      const V3 pv = cross(d, e2);
-      const float det = dot(e1, pv);
-      const float inv = 1.0f / det;
-      const V3 tv = o - v0;
-      const float u = dot(tv, pv) * inv;
-      const V3 qv = cross(tv, e1);
-      const float v = dot(d, qv) * inv;
-      const float t = dot(e2, qv) * inv;
-      const bool inside = (det != 0.0f) & (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > tMin);
-      const bool better = (t < tBest) | ((t == tBest) & (bestOrig != 0xffffffffu) & (orig < bestOrig));
-      bool accept = inside & better;
-      if (CUTOUT && accept && (c.w & (1u << 28))) { // non-opaque material: stochastic cutout (ignoreIntersectionEXT, rp_main.ahit:57-60)
-        const float opacity = sc.materials[c.w & 0x00ffffffu].p[MP_CUTOUT];
-        accept = !(cutout_random(rng, orig) > opacity);
-      }
-      if (accept) {
-        tBest = t; bestU = u; bestV = v; bestTri = triIdx; bestOrig = orig; bestMat = c.w; found = true;
-        if (ANYHIT) { G.y = 0u; sp = 0u; break; }
-      }
-    }
-    if (!(G.y & 0xff000000u)) {
-      if (sp == 0u) break;
-      sp--;
-      G = (!OVERFLOW || sp < STACK) ? s_stack[sp < STACK ? sp : STACK - 1u][tid] : overflow[sp - STACK];
-    }
-  }
-  outT = tBest; outU = bestU; outV = bestV; outTri = bestTri; outMat = bestMat;
-  return found;
+  while (!trav_step<ANYHIT, COUNT, STACK, OVERFLOW, ALL_LDS, CUTOUT>(R, sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, overflow, tc, rng)) {}
+  outT = R.tBest; outU = R.bestU; outV = R.bestV; outTri = R.bestTri; outMat = R.bestMat;
+  return R.found;
 }
 
 template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool ALL_LDS, bool CUTOUT>
@@ -392,6 +527,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
   uint4* s_nodes = s_dyn + (STACK * TRACE_BLOCK * sizeof(uint2)) / sizeof(uint4);
   uint4* s_tris = s_nodes + ldsNodes * 5u;
   __shared__ AppendScratch<1 + MAT_CLASS_COUNT> sh;
+  __shared__ WaveTri s_wave[TRACE_BLOCK / 64];
+  WaveTri& W = s_wave[threadIdx.x >> 6];
   QueueReader rd; reader_init(rd, cnt, qIn, qs.cap);
   const uint32_t n = rd.pre[NSHARD];
   if (blockIdx.x == 0 && threadIdx.x == 0) { if (ANYHIT) cnt->shadowRays += n; else cnt->segments += n; } // single writer per launch
@@ -401,30 +538,39 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
   __syncthreads();
 
   TraceCounters tc{0u, 0u};
+  RayTrav R; trav_init(R, v3(0.0f, 0.0f, 0.0f), v3(0.0f, 0.0f, 1.0f), 0.0f, 0.0f);
+  uint2 overflow[OVERFLOW ? OVF_STACK : 1];
   const uint32_t stride = gridDim.x * TRACE_BLOCK;
   uint32_t trip = 0;
   for (uint32_t base = blockIdx.x * TRACE_BLOCK; base < n; base += stride, trip++) {
     const uint32_t i = base + threadIdx.x;
     bool hit = false, miss = false; uint32_t slot = 0, mat = 0;
     float t = 0.0f, u = 0.0f, v = 0.0f; uint32_t tri = MISS; F4 rdir = F4{0.0f, 0.0f, 0.0f, 0.0f};
+    bool alive = false; uint32_t r = 0u, rng = 0u;
     if (i < n) {
-      const uint32_t r = reader_index(rd, i);
+      r = reader_index(rd, i);
       slot = qs.slot[qIn][r];
       const F4 ro = ld4(&qs.a[qIn][r]);
       rdir = ld4(&qs.b[qIn][r]);
-      const uint32_t rng = CUTOUT ? f2u(st.slots[slot].rad.w) : 0u; // the any-hit test needs the path's rng state
+      rng = CUTOUT ? f2u(st.slots[slot].rad.w) : 0u; // the any-hit test needs the path's rng state
+      // shadow ray (rp_main.rgen:397-429): origin = next ray origin, tMin 0.01, tMax = distance to the light sample
+      if (!ANYHIT) trav_init(R, v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), ro.w, rdir.w);
+      else trav_init(R, v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), 0.01f, ro.w);
+      wave_ray_begin(W, R.tBest);
+      alive = true;
+    }
+    while (__ballot(alive)) {
+      if (wave_step<ANYHIT, COUNT, STACK, OVERFLOW, ALL_LDS, CUTOUT>(R, alive, W, sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, overflow, tc, rng)) alive = false;
+    }
+    if (i < n) {
+      wave_ray_end(W, R);
       if (!ANYHIT) {
-        hit = traverse<false, COUNT, STACK, OVERFLOW, ALL_LDS, CUTOUT>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), ro.w, rdir.w, t, u, v, tri, mat, tc, rng);
-        miss = !hit;
-      } else {
-        // shadow ray (rp_main.rgen:397-429): origin = next ray origin, tMin 0.01, tMax = distance to the light sample
-        const bool occluded = traverse<true, COUNT, STACK, OVERFLOW, ALL_LDS, CUTOUT>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), 0.01f, ro.w, t, u, v, tri, mat, tc, rng);
-        if (!occluded) {
-          const F4 nc = ld4(&qs.c[qIn][r]);
-          Slot* S = &st.slots[slot];
-          F4 rr = ld4(&S->rad);
-          st4(&S->rad, rr.x + nc.x, rr.y + nc.y, rr.z + nc.z, rr.w);
-        }
+        hit = R.found; miss = !hit; t = R.tBest; u = R.bestU; v = R.bestV; tri = R.bestTri; mat = R.bestMat;
+      } else if (!R.found) {
+        const F4 nc = ld4(&qs.c[qIn][r]);
+        Slot* S = &st.slots[slot];
+        F4 rr = ld4(&S->rad);
+        st4(&S->rad, rr.x + nc.x, rr.y + nc.y, rr.z + nc.z, rr.w);
       }
     }
     if (!ANYHIT) {
@@ -449,6 +595,128 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
     unsigned long long a = tc.nodes, b = tc.tris;
     for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
     if (__lane_id() == 0) { atomicAdd(ANYHIT ? &cnt->shadowNodesVisited : &cnt->nodesVisited, a); atomicAdd(ANYHIT ? &cnt->shadowTrisTested : &cnt->trisTested, b); }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_trace_dyn: traversal for scenes that do not fit LDS.  Ray cost has a long tail there (a ray through dense geometry
+// visits several times the average node count), so "one ray per lane until the whole block is done" leaves most lanes
+// idle.  Here every wave is persistent and independent: lanes that finish write their result IN PLACE over the ray
+// record (a = (t,u,v,tri), b.w = material word) and, once `refill` lanes of the wave are idle, the wave claims that many
+// new rays with one atomic on the launch's cursor.  No barriers, no appends; k_route then streams the results into the
+// per-class shade queues / the regen queue.  Per-ray arithmetic is trav_step's, i.e. identical to k_trace's.
+// ------------------------------------------------------------------------------------------------
+template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool CUTOUT>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_dyn(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t refill)
+{
+  extern __shared__ uint4 s_dyn[];
+  uint2 (*s_stack)[TRACE_BLOCK] = reinterpret_cast<uint2 (*)[TRACE_BLOCK]>(s_dyn);
+  __shared__ WaveTri s_wave[TRACE_BLOCK / 64];
+  WaveTri& W = s_wave[threadIdx.x >> 6];
+  QueueReader rd; reader_init(rd, cnt, qIn, qs.cap);
+  const uint32_t n = rd.pre[NSHARD];
+  if (blockIdx.x == 0 && threadIdx.x == 0) { if (ANYHIT) cnt->shadowRays += n; else cnt->segments += n; } // single writer per launch
+  uint32_t* cursor = &cnt->cursor[ANYHIT ? 1 : 0].v;
+  const uint32_t lane = __lane_id();
+  TraceCounters tc{0u, 0u};
+  RayTrav R; trav_init(R, v3(0.0f, 0.0f, 0.0f), v3(0.0f, 0.0f, 1.0f), 0.0f, 0.0f);
+  uint2 overflow[OVERFLOW ? OVF_STACK : 1];
+  bool alive = false;
+  uint32_t rec = 0u, rng = 0u;
+  // The wave claims rays 64 at a time (one atomic per chunk) and lane j prefetches ray j of the chunk into registers; lanes
+  // that run idle are then handed the chunk's rays in order with register shuffles, so a refill never waits on memory.
+  F4 pro = F4{0.0f, 0.0f, 0.0f, 0.0f}, prd = F4{0.0f, 0.0f, 0.0f, 0.0f}; uint32_t prec = 0u, prng = 0u;
+  uint32_t chunkCount = 0u, chunkUsed = 0u; // wave-uniform
+  auto next_chunk = [&]() {
+    uint32_t base = 0u;
+    if (lane == 0u) base = atomicAdd(cursor, 64u);
+    base = (uint32_t)__shfl((int)base, 0);
+    chunkCount = base < n ? (n - base < 64u ? n - base : 64u) : 0u;
+    chunkUsed = 0u;
+    if (lane < chunkCount) {
+      prec = reader_index(rd, base + lane);
+      pro = ld4(&qs.a[qIn][prec]);
+      prd = ld4(&qs.b[qIn][prec]);
+      if (CUTOUT) prng = f2u(st.slots[qs.slot[qIn][prec]].rad.w); // the any-hit test needs the path's rng state
+    }
+  };
+  next_chunk();
+  for (;;) {
+    const unsigned long long idle = __ballot(!alive);
+    const uint32_t nIdle = (uint32_t)__popcll(idle);
+    if (nIdle >= refill && chunkUsed < chunkCount) {
+      const uint32_t avail = chunkCount - chunkUsed, take = nIdle < avail ? nIdle : avail;
+      const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+      const int src = (int)((chunkUsed + rank) & 63u);
+      const F4 ro = F4{__shfl(pro.x, src), __shfl(pro.y, src), __shfl(pro.z, src), __shfl(pro.w, src)};
+      const F4 rdir = F4{__shfl(prd.x, src), __shfl(prd.y, src), __shfl(prd.z, src), __shfl(prd.w, src)};
+      const uint32_t srec = (uint32_t)__shfl((int)prec, src);
+      const uint32_t srng = CUTOUT ? (uint32_t)__shfl((int)prng, src) : 0u;
+      if (!alive && rank < take) {
+        rec = srec; rng = srng;
+        if (!ANYHIT) trav_init(R, v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), ro.w, rdir.w);
+        else trav_init(R, v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), 0.01f, ro.w); // shadow ray (rp_main.rgen:397-429)
+        wave_ray_begin(W, R.tBest);
+        alive = true;
+      }
+      chunkUsed += take;
+      if (chunkUsed == chunkCount) next_chunk(); // loads complete while the wave keeps traversing
+    }
+    if (!__ballot(alive)) { if (chunkCount == 0u) break; else continue; }
+    const bool done = wave_step<ANYHIT, COUNT, STACK, OVERFLOW, false, CUTOUT>(R, alive, W, sc, nullptr, 0u, nullptr, 0u, s_stack, overflow, tc, rng);
+    if (alive && done) {
+      alive = false;
+      wave_ray_end(W, R);
+      if (!ANYHIT) {
+        st4(&qs.a[qIn][rec], R.tBest, R.bestU, R.bestV, u2f(R.found ? R.bestTri : MISS));
+        reinterpret_cast<uint32_t*>(&qs.b[qIn][rec])[3] = R.bestMat;
+      } else if (!R.found) {
+        const F4 nc = ld4(&qs.c[qIn][rec]);
+        Slot* S = &st.slots[qs.slot[qIn][rec]];
+        F4 rr = ld4(&S->rad);
+        st4(&S->rad, rr.x + nc.x, rr.y + nc.y, rr.z + nc.z, rr.w);
+      }
+    }
+  }
+  if (COUNT) { // measurement builds only: one atomic pair per wave
+    unsigned long long a = tc.nodes, b = tc.tris;
+    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+    if (lane == 0) { atomicAdd(ANYHIT ? &cnt->shadowNodesVisited : &cnt->nodesVisited, a); atomicAdd(ANYHIT ? &cnt->shadowTrisTested : &cnt->trisTested, b); }
+  }
+}
+
+// k_route: sorts k_trace_dyn's in-place results by outcome and material class (same routing as k_trace's epilogue)
+__global__ __launch_bounds__(BLOCK) void k_route(QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t qMiss)
+{
+  __shared__ AppendScratch<1 + MAT_CLASS_COUNT> sh;
+  QueueReader rd; reader_init(rd, cnt, qIn, qs.cap);
+  const uint32_t n = rd.pre[NSHARD];
+  const uint32_t stride = gridDim.x * BLOCK;
+  uint32_t trip = 0;
+  for (uint32_t base = blockIdx.x * BLOCK; base < n; base += stride, trip++) {
+    const uint32_t i = base + threadIdx.x;
+    bool hit = false, miss = false; uint32_t slot = 0, klass = 0;
+    F4 h = F4{0.0f, 0.0f, 0.0f, 0.0f}, rdir = F4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (i < n) {
+      const uint32_t r = reader_index(rd, i);
+      slot = qs.slot[qIn][r];
+      h = ld4(&qs.a[qIn][r]);
+      rdir = ld4(&qs.b[qIn][r]);
+      hit = f2u(h.w) != MISS; miss = !hit;
+      klass = (f2u(rdir.w) >> 24) & 0xfu;
+    }
+    bool pred[1 + MAT_CLASS_COUNT]; uint32_t qid[1 + MAT_CLASS_COUNT]; uint32_t idx[1 + MAT_CLASS_COUNT];
+    pred[0] = miss; qid[0] = qMiss;
+#pragma unroll
+    for (uint32_t c = 0; c < MAT_CLASS_COUNT; c++) { pred[1 + c] = hit && klass == c; qid[1 + c] = Q_HIT + c; }
+    block_append<1 + MAT_CLASS_COUNT>(sh, trip, pred, qid, qs.cap, cnt, idx);
+    if (hit) {
+      const uint32_t q = Q_HIT + klass, r = idx[1 + klass];
+      qs.slot[q][r] = slot;
+      st4(&qs.a[q][r], h.x, h.y, h.z, h.w);
+      st4(&qs.b[q][r], rdir.x, rdir.y, rdir.z, 0.0f);
+    }
+    if (miss) qs.slot[qMiss][idx[0]] = slot | REGEN_MISSED;
   }
 }
 
@@ -1095,38 +1363,60 @@ void launchAccumulate(hipStream_t s, const FrameUniforms& U, const float* sample
 {
   hipLaunchKernelGGL(k_accumulate, dim3((U.pixelCount + BLOCK - 1u) / BLOCK), dim3(BLOCK), 0, s, U, sampleBuf, accum, colorOut, firstBatch ? 1u : 0u, lastBatch ? 1u : 0u);
 }
-static uint32_t traceStackEntries(const SceneView& sc) { return sc.bvhDepth <= 8u ? 8u : 16u; }
+static bool sceneFitsLds(const SceneView& sc) { return sc.nodeCount <= LDS_NODES && sc.triCount <= LDS_TRIS && sc.triCount > 0u; }
+static uint32_t traceStackEntries(const SceneView& sc) { return (sc.bvhDepth <= 4u && sceneFitsLds(sc)) ? 4u : (sc.bvhDepth <= 8u ? 8u : 16u); }
+uint32_t traceStaticLdsBytes() { return (uint32_t)(sizeof(WaveTri) * (TRACE_BLOCK / 64) + sizeof(AppendScratch<1 + MAT_CLASS_COUNT>)); }
 void traceLdsLayout(const SceneView& sc, uint32_t& ldsNodes, uint32_t& ldsTris, uint32_t& bytes)
 {
   ldsNodes = sc.nodeCount < LDS_NODES ? sc.nodeCount : LDS_NODES;
   ldsTris = sc.triCount <= LDS_TRIS ? sc.triCount : 0u;
   bytes = traceStackEntries(sc) * TRACE_BLOCK * (uint32_t)sizeof(uint2) + ldsNodes * 80u + ldsTris * 48u;
+  // (+ the kernels' static LDS: WaveTri per wave and the append scratch, see traceStaticLdsBytes)
 }
 template <bool ANYHIT, bool COUNT, bool CUTOUT>
-static void launchTraceVariant(hipStream_t s, uint32_t blocks, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t qMiss)
+static void launchTraceVariant(hipStream_t s, uint32_t blocks, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t qMiss,
+                               uint32_t dynRefill, uint32_t routeBlocks)
 {
   uint32_t ln, lt, bytes; traceLdsLayout(sc, ln, lt, bytes);
   const bool allLds = ln == sc.nodeCount && lt == sc.triCount && sc.triCount > 0u; // the whole scene is staged in LDS
-  if (allLds && sc.bvhDepth <= 8u) hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 8, false, true, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
+  if (!allLds && dynRefill) { // big scene: persistent waves with dynamic ray fetch, results routed by a streaming pass
+    // persistent waves pay the scratch set-up once, so trees deeper than 8 levels may keep 8 entries in LDS (more
+    // resident waves) and spill the rest (TRACE_DYN_SPILL8), or keep 16 in LDS
+    const bool spill8 = (dynRefill & TRACE_DYN_SPILL8) != 0u;
+    dynRefill &= 0xffu;
+    const uint32_t entries = (sc.bvhDepth <= 8u || spill8) ? 8u : 16u;
+    const uint32_t stackBytes = entries * TRACE_BLOCK * (uint32_t)sizeof(uint2);
+    if (sc.bvhDepth <= 8u) hipLaunchKernelGGL((k_trace_dyn<ANYHIT, COUNT, 8, false, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill);
+    else if (spill8) hipLaunchKernelGGL((k_trace_dyn<ANYHIT, COUNT, 8, true, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill);
+    else if (sc.bvhDepth <= 16u) hipLaunchKernelGGL((k_trace_dyn<ANYHIT, COUNT, 16, false, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill);
+    else hipLaunchKernelGGL((k_trace_dyn<ANYHIT, COUNT, 16, true, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill);
+    if (!ANYHIT) hipLaunchKernelGGL(k_route, dim3(routeBlocks), dim3(BLOCK), 0, s, qs, cnt, qIn, qMiss);
+    return;
+  }
+  if (allLds && sc.bvhDepth <= 4u) hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 4, false, true, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
+  else if (allLds && sc.bvhDepth <= 8u) hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 8, false, true, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
   else if (sc.bvhDepth <= 8u) hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 8, false, false, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
   else if (sc.bvhDepth <= 16u) hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 16, false, false, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
   else hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 16, true, false, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
 }
 template <bool ANYHIT, bool COUNT>
-static void launchTraceCutout(hipStream_t s, uint32_t blocks, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t qMiss)
+static void launchTraceCutout(hipStream_t s, uint32_t blocks, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t qMiss,
+                              uint32_t dynRefill, uint32_t routeBlocks)
 {
-  if (sc.hasCutouts) launchTraceVariant<ANYHIT, COUNT, true>(s, blocks, sc, st, qs, cnt, qIn, qMiss);
-  else launchTraceVariant<ANYHIT, COUNT, false>(s, blocks, sc, st, qs, cnt, qIn, qMiss);
+  if (sc.hasCutouts) launchTraceVariant<ANYHIT, COUNT, true>(s, blocks, sc, st, qs, cnt, qIn, qMiss, dynRefill, routeBlocks);
+  else launchTraceVariant<ANYHIT, COUNT, false>(s, blocks, sc, st, qs, cnt, qIn, qMiss, dynRefill, routeBlocks);
 }
 void launchTrace(hipStream_t s, uint32_t blocks, bool anyHit, bool count, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt,
-                 uint32_t qIn, uint32_t qMiss)
+                 uint32_t qIn, uint32_t qMiss, uint32_t dynRefill, uint32_t routeBlocks)
 {
-  if (!anyHit) { if (count) launchTraceCutout<false, true>(s, blocks, sc, st, qs, cnt, qIn, qMiss); else launchTraceCutout<false, false>(s, blocks, sc, st, qs, cnt, qIn, qMiss); }
-  else { if (count) launchTraceCutout<true, true>(s, blocks, sc, st, qs, cnt, qIn, qMiss); else launchTraceCutout<true, false>(s, blocks, sc, st, qs, cnt, qIn, qMiss); }
+  if ((dynRefill & 0xffu) > 64u) dynRefill = (dynRefill & ~0xffu) | 64u;
+  if (!anyHit) { if (count) launchTraceCutout<false, true>(s, blocks, sc, st, qs, cnt, qIn, qMiss, dynRefill, routeBlocks); else launchTraceCutout<false, false>(s, blocks, sc, st, qs, cnt, qIn, qMiss, dynRefill, routeBlocks); }
+  else { if (count) launchTraceCutout<true, true>(s, blocks, sc, st, qs, cnt, qIn, qMiss, dynRefill, routeBlocks); else launchTraceCutout<true, false>(s, blocks, sc, st, qs, cnt, qIn, qMiss, dynRefill, routeBlocks); }
 }
 void launchAov(hipStream_t s, const FrameUniforms& U, const SceneView& sc, const AovTargets& A)
 {
   uint32_t ln, lt, bytes; traceLdsLayout(sc, ln, lt, bytes);
+  bytes = (sc.bvhDepth <= 8u ? 8u : 16u) * TRACE_BLOCK * (uint32_t)sizeof(uint2) + ln * 80u + lt * 48u; // k_aov has no 4-entry variant
   const uint32_t blocks = (U.pixelCount + TRACE_BLOCK - 1u) / TRACE_BLOCK;
   if (sc.bvhDepth <= 8u) hipLaunchKernelGGL((k_aov<8, false>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, U, sc, A, ln, lt);
   else if (sc.bvhDepth <= 16u) hipLaunchKernelGGL((k_aov<16, false>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, U, sc, A, ln, lt);

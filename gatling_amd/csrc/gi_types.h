@@ -172,6 +172,7 @@ struct alignas(128) PaddedCounter { uint32_t v; uint32_t pad[31]; };
 struct Counters {
   PaddedCounter count[Q_COUNT][NSHARD];
   PaddedCounter workBase[2]; // work items handed out before iteration parity p (k_raygen reads [p], writes [p^1])
+  PaddedCounter cursor[2];   // k_trace_dyn: next unclaimed ray of this iteration's closest-hit [0] / shadow [1] queue
   unsigned long long segments, shadowRays, nodesVisited, trisTested, shadowNodesVisited, shadowTrisTested;
 };
 
