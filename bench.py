@@ -72,7 +72,9 @@ def load_pmc_traffic(workload):
     if os.path.exists(p):
         try:
             j = json.load(open(p))
-            return j.get("trace_bytes_per_launch") if j.get("workload") == workload else None
+            if "workload" in j:  # older single-entry layout
+                j = {j["workload"]: j}
+            return j.get(workload, {}).get("trace_bytes_per_launch")
         except Exception:
             return None
     return None
@@ -173,7 +175,8 @@ def main():
         achieved = bytes_total / max(trace_ms * 1e-3, 1e-12) / 1e9
         seg_per_sample = rays / max(1, sum(s["samples"] for s in stats))
         stream_only = (samples_per_step * args.steps / dt) * seg_per_sample * 192.0 / 1e9  # whole-pipeline stream floor
-        roofline = {"bound": "hbm", "kernel": "k_trace<closest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        kernel = "k_trace<closest>" if cst["triangleCount"] <= 128 else "k_trace_dyn<closest> + k_route"  # scene in LDS or not
+        roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": load_pmc_traffic(args.workload),
                     "bytes_per_launch": round(bytes_total / max(1, launches), 1), "avg_launch_us": round(trace_ms * 1e3 / max(1, launches), 3),
                     "nodes_per_ray": round(nodes_per_ray, 3), "tris_per_ray": round(tris_per_ray, 3),

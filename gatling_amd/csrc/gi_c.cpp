@@ -774,7 +774,7 @@ SceneView makeView(GiCScene* s)
 // k_trace_dyn refill threshold for scenes that do not fit LDS (0 = use the block-synchronous k_trace)
 static uint32_t traceDynRefill(const GiCScene* s)
 {
-  uint32_t r = s->optTraceDyn >= 0 ? (uint32_t)s->optTraceDyn : 16u;
+  uint32_t r = s->optTraceDyn >= 0 ? (uint32_t)s->optTraceDyn : 8u;
   if (const char* e = getenv("GATLING_TRACE_DYN")) r = (uint32_t)std::max(0, std::min(64, atoi(e)));
   if (const char* e = getenv("GATLING_TRACE_DYN_SPILL8")) { if (r && atoi(e)) r |= TRACE_DYN_SPILL8; }
   return r;

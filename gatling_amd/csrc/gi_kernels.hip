@@ -297,28 +297,32 @@ __device__ __forceinline__ void trav_init(RayTrav& R, V3 o, V3 d, float tMin, fl
 // Node half of a traversal step: takes the nearest unvisited child of the current node group (pushing the rest), tests
 // the ray against that node's 8 quantised child boxes and returns the triangle group (base, mask) of its hit leaf
 // children; R.G becomes the group of hit internal children.  Caller guarantees R.G has node bits.
-template <bool COUNT, uint32_t STACK, bool OVERFLOW, bool ALL_LDS>
-__device__ __forceinline__ uint2 trav_node(RayTrav& R, const SceneView& sc, const uint4* s_nodes, uint32_t ldsNodes,
-                                           uint2 (*s_stack)[TRACE_BLOCK], uint2 (&overflow)[OVERFLOW ? OVF_STACK : 1], TraceCounters& tc)
+// Node half of a traversal step, part 1: takes the nearest unvisited child of the current node group (pushing the rest)
+// and returns its node index.  Caller guarantees R.G has node bits.
+template <uint32_t STACK, bool OVERFLOW>
+__device__ __forceinline__ uint32_t trav_node_pick(RayTrav& R, uint2 (*s_stack)[TRACE_BLOCK], uint2 (&overflow)[OVERFLOW ? OVF_STACK : 1])
 {
   const uint32_t tid = threadIdx.x;
-  const V3 o = R.o, d = R.d;
   uint2 G = R.G;
   uint32_t sp = R.sp;
-  const uint32_t octinv = R.octinv;
   const uint32_t bit = 31u - (uint32_t)__clz((int)(G.y & 0xff000000u));
   G.y &= ~(1u << bit);
   if (G.y & 0xff000000u) {
     if (!OVERFLOW || sp < STACK) s_stack[sp < STACK ? sp : STACK - 1u][tid] = G; else overflow[sp - STACK] = G;
     sp++;
   }
-  const uint32_t slot = (bit - 24u) ^ octinv;
+  const uint32_t slot = (bit - 24u) ^ R.octinv;
   const uint32_t rel = (uint32_t)__popc((G.y & 0xffu) & ((1u << slot) - 1u));
-  const uint32_t nodeIdx = G.x + rel;
-  uint4 n0, n1, n2, n3, n4;
-  if (ALL_LDS || nodeIdx < ldsNodes) { const uint4* p = s_nodes + nodeIdx * 5u; n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3]; n4 = p[4]; }
-  else { const uint4* p = reinterpret_cast<const uint4*>(sc.nodes) + (size_t)nodeIdx * 5u; n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3]; n4 = p[4]; }
-  if (COUNT) tc.nodes++;
+  R.sp = sp;
+  return G.x + rel;
+}
+
+// Part 2: tests the ray against the node's 8 quantised child boxes and returns the triangle group (base, mask) of its hit
+// leaf children; R.G becomes the group of hit internal children.
+__device__ __forceinline__ uint2 trav_node_test(RayTrav& R, const uint4& n0, const uint4& n1, const uint4& n2, const uint4& n3, const uint4& n4)
+{
+  const V3 o = R.o, d = R.d;
+  const uint32_t octinv = R.octinv;
   // ray in the node's quantisation frame
   const float sx = u2f((n0.w & 0xffu) << 23), sy = u2f(((n0.w >> 8) & 0xffu) << 23), sz = u2f(((n0.w >> 16) & 0xffu) << 23);
   const float ax = sx * R.idx, ay = sy * R.idy, az = sz * R.idz;
@@ -350,8 +354,20 @@ __device__ __forceinline__ uint2 trav_node(RayTrav& R, const SceneView& sc, cons
     }
   }
   R.G = make_uint2(n1.x, (hitmask & 0xff000000u) | (n0.w >> 24));
-  R.sp = sp;
   return make_uint2(n1.y, hitmask & 0x00ffffffu);
+}
+
+// The per-lane composition (each lane fetches its own node: from LDS when staged there, else from global memory)
+template <bool COUNT, uint32_t STACK, bool OVERFLOW, bool ALL_LDS>
+__device__ __forceinline__ uint2 trav_node(RayTrav& R, const SceneView& sc, const uint4* s_nodes, uint32_t ldsNodes,
+                                           uint2 (*s_stack)[TRACE_BLOCK], uint2 (&overflow)[OVERFLOW ? OVF_STACK : 1], TraceCounters& tc)
+{
+  const uint32_t nodeIdx = trav_node_pick<STACK, OVERFLOW>(R, s_stack, overflow);
+  uint4 n0, n1, n2, n3, n4;
+  if (ALL_LDS || nodeIdx < ldsNodes) { const uint4* p = s_nodes + nodeIdx * 5u; n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3]; n4 = p[4]; }
+  else { const uint4* p = reinterpret_cast<const uint4*>(sc.nodes) + (size_t)nodeIdx * 5u; n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3]; n4 = p[4]; }
+  if (COUNT) tc.nodes++;
+  return trav_node_test(R, n0, n1, n2, n3, n4);
 }
 
 // End of a step: when the current group has no unvisited internal child left, continue with the stack top.
@@ -431,9 +447,18 @@ struct WaveTri {
   uint4 hit[64];               // per ray lane: (triangle index, u bits, v bits, material word) of that hit
   uint32_t queue[128];         // ring of pending (ray lane, triangle) pairs
 };
+// Staging buffer of the cooperative fetch (scenes in global memory).  A lane that loads its own 80-byte node issues five
+// 16-byte loads to a cache line no other lane touches, so every load instruction costs the L1 64 tag look-ups; measured,
+// the texture-address unit was busy 63 % of k_trace's time.  Instead lane i of the wave loads 16-byte piece (i % 5) of
+// the node that lane (i / 5) asked for: consecutive lanes read consecutive addresses, an instruction touches ~13-26 lines,
+// and the pieces meet again in LDS (conflict-free: 80 B and 48 B lane strides both map 16 lanes onto all 64 banks).
+struct WaveStage { uint4 buf[64 * 5]; };
+// Measured on C3 (1M-triangle soup): 35.4 ms with the cooperative fetch vs 29.6 ms without (the 20 KiB of staging per
+// block cost two resident blocks per CU and the extra LDS round trip outweighs the saved tag look-ups) -> off.
+constexpr bool TRACE_DYN_COOP_FETCH = false;
 
-template <bool COUNT, bool ALL_LDS, bool CUTOUT>
-__device__ __forceinline__ void wave_tri_batch(WaveTri& W, uint32_t head, uint32_t cnt, const RayTrav& R, uint32_t rng, const SceneView& sc,
+template <bool COUNT, bool ALL_LDS, bool CUTOUT, bool COOP>
+__device__ __forceinline__ void wave_tri_batch(WaveTri& W, WaveStage* S, uint32_t head, uint32_t cnt, const RayTrav& R, uint32_t rng, const SceneView& sc,
                                                const uint4* s_tris, uint32_t ldsTris, TraceCounters& tc)
 {
   const uint32_t lane = __lane_id();
@@ -445,9 +470,23 @@ __device__ __forceinline__ void wave_tri_batch(WaveTri& W, uint32_t head, uint32
   const V3 d = v3(__shfl(R.d.x, (int)rl), __shfl(R.d.y, (int)rl), __shfl(R.d.z, (int)rl));
   const float tMin = __shfl(R.tMin, (int)rl);
   const uint32_t rrng = CUTOUT ? (uint32_t)__shfl((int)rng, (int)rl) : 0u;
+  if (COOP) { // piece (flat % 3) of the triangle of entry (flat / 3), for flat = lane, 64 + lane, 128 + lane
+    uint4 piece[3];
+#pragma unroll
+    for (uint32_t cidx = 0; cidx < 3u; cidx++) {
+      const uint32_t flat = cidx * 64u + lane, owner = flat / 3u, part = flat - owner * 3u;
+      const uint32_t tIdx = (uint32_t)__shfl((int)triIdx, (int)owner);
+      piece[cidx] = make_uint4(0u, 0u, 0u, 0u);
+      if (owner < cnt) piece[cidx] = reinterpret_cast<const uint4*>(sc.tris)[(size_t)tIdx * 4u + part];
+    }
+#pragma unroll
+    for (uint32_t cidx = 0; cidx < 3u; cidx++) S->buf[cidx * 64u + lane] = piece[cidx];
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  }
   if (act) {
     uint4 a, b, c;
-    if (ALL_LDS || triIdx < ldsTris) { const uint4* p = s_tris + triIdx * 3u; a = p[0]; b = p[1]; c = p[2]; }
+    if (COOP) { const uint4* p = S->buf + lane * 3u; a = p[0]; b = p[1]; c = p[2]; }
+    else if (ALL_LDS || triIdx < ldsTris) { const uint4* p = s_tris + triIdx * 3u; a = p[0]; b = p[1]; c = p[2]; }
     else { const uint4* p = reinterpret_cast<const uint4*>(sc.tris) + (size_t)triIdx * 4u; a = p[0]; b = p[1]; c = p[2]; }
     if (COUNT) tc.tris++;
     float t, u, v;
@@ -466,14 +505,37 @@ __device__ __forceinline__ void wave_tri_batch(WaveTri& W, uint32_t head, uint32
 
 // One step of all rays of a wave: node phase per lane, then the cooperative triangle stage, then pop.  Wave-uniform
 // control flow; lanes without a ray (alive == false) only help testing triangles.  Returns true when this lane's ray is finished.
-template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool ALL_LDS, bool CUTOUT>
-__device__ __forceinline__ bool wave_step(RayTrav& R, bool alive, WaveTri& W, const SceneView& sc, const uint4* s_nodes, uint32_t ldsNodes,
+template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool ALL_LDS, bool CUTOUT, bool COOP>
+__device__ __forceinline__ bool wave_step(RayTrav& R, bool alive, WaveTri& W, WaveStage* S, const SceneView& sc, const uint4* s_nodes, uint32_t ldsNodes,
                                           const uint4* s_tris, uint32_t ldsTris, uint2 (*s_stack)[TRACE_BLOCK], uint2 (&overflow)[OVERFLOW ? OVF_STACK : 1],
                                           TraceCounters& tc, uint32_t rng)
 {
   const uint32_t lane = __lane_id();
   uint2 Gt = make_uint2(0u, 0u);
-  if (alive) Gt = trav_node<COUNT, STACK, OVERFLOW, ALL_LDS>(R, sc, s_nodes, ldsNodes, s_stack, overflow, tc);
+  if (!COOP) {
+    if (alive) Gt = trav_node<COUNT, STACK, OVERFLOW, ALL_LDS>(R, sc, s_nodes, ldsNodes, s_stack, overflow, tc);
+  } else {
+    uint32_t nodeIdx = 0xffffffffu;
+    if (alive) nodeIdx = trav_node_pick<STACK, OVERFLOW>(R, s_stack, overflow);
+    uint4 piece[5]; // piece (flat % 5) of the node lane (flat / 5) asked for, flat = lane, 64 + lane, ...
+#pragma unroll
+    for (uint32_t cidx = 0; cidx < 5u; cidx++) {
+      const uint32_t flat = cidx * 64u + lane, owner = flat / 5u, part = flat - owner * 5u;
+      const uint32_t nIdx = (uint32_t)__shfl((int)nodeIdx, (int)owner);
+      piece[cidx] = make_uint4(0u, 0u, 0u, 0u);
+      if (nIdx != 0xffffffffu) piece[cidx] = reinterpret_cast<const uint4*>(sc.nodes)[(size_t)nIdx * 5u + part];
+    }
+#pragma unroll
+    for (uint32_t cidx = 0; cidx < 5u; cidx++) S->buf[cidx * 64u + lane] = piece[cidx];
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    if (alive) {
+      const uint4* p = S->buf + lane * 5u;
+      const uint4 n0 = p[0], n1 = p[1], n2 = p[2], n3 = p[3], n4 = p[4];
+      if (COUNT) tc.nodes++;
+      Gt = trav_node_test(R, n0, n1, n2, n3, n4);
+    }
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  }
   uint32_t head = 0u, tail = 0u; // wave-uniform
   for (;;) {
     const unsigned long long m = __ballot(Gt.y != 0u);
@@ -484,9 +546,9 @@ __device__ __forceinline__ bool wave_step(RayTrav& R, bool alive, WaveTri& W, co
       *(volatile uint32_t*)&W.queue[(tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & 127u] = (lane << TRI_ID_BITS) | (Gt.x + k);
     }
     tail += (uint32_t)__popcll(m);
-    if (tail - head >= 64u) { wave_tri_batch<COUNT, ALL_LDS, CUTOUT>(W, head, 64u, R, rng, sc, s_tris, ldsTris, tc); head += 64u; }
+    if (tail - head >= 64u) { wave_tri_batch<COUNT, ALL_LDS, CUTOUT, COOP>(W, S, head, 64u, R, rng, sc, s_tris, ldsTris, tc); head += 64u; }
   }
-  if (tail != head) wave_tri_batch<COUNT, ALL_LDS, CUTOUT>(W, head, tail - head, R, rng, sc, s_tris, ldsTris, tc);
+  if (tail != head) wave_tri_batch<COUNT, ALL_LDS, CUTOUT, COOP>(W, S, head, tail - head, R, rng, sc, s_tris, ldsTris, tc);
   bool done = false;
   if (alive) {
     const unsigned long long key = *(volatile unsigned long long*)&W.best[lane];
@@ -560,7 +622,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
       alive = true;
     }
     while (__ballot(alive)) {
-      if (wave_step<ANYHIT, COUNT, STACK, OVERFLOW, ALL_LDS, CUTOUT>(R, alive, W, sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, overflow, tc, rng)) alive = false;
+      if (wave_step<ANYHIT, COUNT, STACK, OVERFLOW, ALL_LDS, CUTOUT, false>(R, alive, W, nullptr, sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, overflow, tc, rng)) alive = false;
     }
     if (i < n) {
       wave_ray_end(W, R);
@@ -607,12 +669,14 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
 // per-class shade queues / the regen queue.  Per-ray arithmetic is trav_step's, i.e. identical to k_trace's.
 // ------------------------------------------------------------------------------------------------
 template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool CUTOUT>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_dyn(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t refill)
+__device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t refill)
 {
   extern __shared__ uint4 s_dyn[];
   uint2 (*s_stack)[TRACE_BLOCK] = reinterpret_cast<uint2 (*)[TRACE_BLOCK]>(s_dyn);
   __shared__ WaveTri s_wave[TRACE_BLOCK / 64];
+  __shared__ WaveStage s_stage[TRACE_DYN_COOP_FETCH ? TRACE_BLOCK / 64 : 1];
   WaveTri& W = s_wave[threadIdx.x >> 6];
+  WaveStage* S = TRACE_DYN_COOP_FETCH ? &s_stage[threadIdx.x >> 6] : nullptr;
   QueueReader rd; reader_init(rd, cnt, qIn, qs.cap);
   const uint32_t n = rd.pre[NSHARD];
   if (blockIdx.x == 0 && threadIdx.x == 0) { if (ANYHIT) cnt->shadowRays += n; else cnt->segments += n; } // single writer per launch
@@ -663,7 +727,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_dyn(SceneView sc, PathSta
       if (chunkUsed == chunkCount) next_chunk(); // loads complete while the wave keeps traversing
     }
     if (!__ballot(alive)) { if (chunkCount == 0u) break; else continue; }
-    const bool done = wave_step<ANYHIT, COUNT, STACK, OVERFLOW, false, CUTOUT>(R, alive, W, sc, nullptr, 0u, nullptr, 0u, s_stack, overflow, tc, rng);
+    const bool done = wave_step<ANYHIT, COUNT, STACK, OVERFLOW, false, CUTOUT, TRACE_DYN_COOP_FETCH>(R, alive, W, S, sc, nullptr, 0u, nullptr, 0u, s_stack, overflow, tc, rng);
     if (alive && done) {
       alive = false;
       wave_ray_end(W, R);
@@ -683,6 +747,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace_dyn(SceneView sc, PathSta
     for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
     if (lane == 0) { atomicAdd(ANYHIT ? &cnt->shadowNodesVisited : &cnt->nodesVisited, a); atomicAdd(ANYHIT ? &cnt->shadowTrisTested : &cnt->trisTested, b); }
   }
+}
+
+template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool CUTOUT>
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_dyn(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t refill)
+{
+  trace_dyn_body<ANYHIT, COUNT, STACK, OVERFLOW, CUTOUT>(sc, st, qs, cnt, qIn, refill);
 }
 
 // k_route: sorts k_trace_dyn's in-place results by outcome and material class (same routing as k_trace's epilogue)

@@ -291,7 +291,7 @@ int giCGetRenderStats(const GiCScene* scene, GiCRenderStats* out);
 #define GI_C_SCENE_OPTION_POOL_SLOTS 3
 #define GI_C_SCENE_OPTION_SAMPLE_BUFFER_MB 4
 /* Traversal kernel for scenes whose BVH does not fit LDS: 0 = block-synchronous k_trace; N in 1..64 = persistent waves that
- * claim new rays once N lanes are idle (k_trace_dyn, default 16); -1 = default.  Results are identical either way. */
+ * claim new rays once N lanes are idle (k_trace_dyn, default 8); -1 = default.  Results are identical either way. */
 #define GI_C_SCENE_OPTION_TRACE_DYNAMIC 5
 int giCSetSceneOption(GiCScene* scene, int32_t option, int32_t value);
 /* [ext] closest hit of one ray through the device traversal kernel (parity tests of the BVH8 path).

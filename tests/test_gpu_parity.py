@@ -369,6 +369,27 @@ def test_soup_scene_with_nee_parity(gi, orc):
     render_both(gi, orc, desc, RenderSettings(spp=2, max_bounces=5, next_event_estimation=True), 96, 54)
 
 
+@pytest.mark.parametrize("scene_kind", ["soup", "instances"])
+def test_traversal_kernel_variants_agree(gi, orc, scene_kind):
+    """Scenes beyond LDS: the block-synchronous k_trace, k_trace_dyn (any refill threshold) and the oracle give the
+    same image bit for bit -- the kernels differ in scheduling (who tests which triangle when), never in arithmetic."""
+    from gatling_amd import capi
+    if scene_kind == "soup":
+        desc, rs, w, h = _soup(6000, seed=5), RenderSettings(spp=3, max_bounces=6, next_event_estimation=True), 80, 45
+    else:
+        desc, rs, w, h = sphere_grid(grid=3, subdivisions=2, material_count=4), RenderSettings(spp=3, max_bounces=6), 80, 45
+    rs.progressive_accumulation = False
+    ref, _ = orc.render(desc, rs, w, h, threads=4)
+    scene = gi.Scene(desc)
+    try:
+        for refill in (0, 1, 8, 33, 64):
+            scene.set_option(capi.OPTION_TRACE_DYNAMIC, refill)
+            img = scene.render(rs, w, h)
+            assert np.array_equal(img, ref), f"refill={refill}"
+    finally:
+        scene.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # full BASELINE.json sizes: size-independent properties (the oracle cannot render these in seconds)
 # ---------------------------------------------------------------------------------------------------------------

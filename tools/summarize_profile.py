@@ -73,15 +73,25 @@ def main():
     open(txt, "w").write("\n".join(lines) + "\n")
     js = {"tag": args.tag, "kernels": ks, "pmc": pmc}
     if pmc:
-        tk = next((v for k, v in pmc.items() if k.startswith("k_trace<false")), None)
+        # the traversal stage's launches: k_trace<closest> (scene in LDS) or k_trace_dyn<closest> + its k_route pass
+        tk = [v for k, v in pmc.items() if (k.startswith("k_trace<false") or k.startswith("k_trace_dyn<false")) and ", true," not in k[:30]]
         if tk:
-            js["trace_bytes_per_launch"] = tk["hbm_bytes_per_launch"]
+            js["trace_bytes_per_launch"] = max(v["hbm_bytes_per_launch"] for v in tk) + (pmc["k_route"]["hbm_bytes_per_launch"] if "k_route" in pmc else 0.0)
     json.dump(js, open(os.path.join(ROOT, "profiles", f"{args.tag}_rocprofv3_summary.json"), "w"), indent=1)
     if pmc and "trace_bytes_per_launch" in js:
-        json.dump({"tag": args.tag, "workload": args.workload, "spp": args.spp, "trace_bytes_per_launch": js["trace_bytes_per_launch"],
-                   "note": "HBM bytes per k_trace<closest> launch = 2*FETCH_SIZE + WRITE_SIZE (separate --pmc passes); launches at this spp carry the same "
-                           "ray count per launch as the full-spp run once all pixels are active", "source": os.path.basename(txt)},
-                  open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+        path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        table = {}
+        if os.path.exists(path):
+            try:
+                table = json.load(open(path))
+                if "workload" in table:  # older single-entry layout
+                    table = {table["workload"]: table}
+            except Exception:
+                table = {}
+        table[args.workload] = {"tag": args.tag, "workload": args.workload, "spp": args.spp, "trace_bytes_per_launch": js["trace_bytes_per_launch"],
+                                "note": "HBM bytes per traversal-stage launch = 2*FETCH_SIZE + WRITE_SIZE (separate --pmc passes); launches at this spp carry the "
+                                        "same ray count per launch as the full-spp run once all pixels are active", "source": os.path.basename(txt)}
+        json.dump(table, open(path, "w"), indent=1)
     print("\n".join(lines))
 
 
