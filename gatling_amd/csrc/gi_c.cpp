@@ -268,7 +268,7 @@ struct GiCScene {
   uint32_t classMask = 0; // material classes that own at least one triangle (one k_shade launch per class)
   // path state
   DeviceBuffer<Slot> slots;
-  DeviceBuffer<float> sampleBuf; // per-sample colours of the current batch, [sample][pixel][3]
+  DeviceBuffer<F4> sampleBuf; // per-sample colours of the current batch, [sample][pixel] (rgb, -)
   DeviceBuffer<F4> accum;        // per-pixel running sum across batches
   DeviceBuffer<uint32_t> qSlot[Q_COUNT]; // NSHARD segments of queueCap records each
   DeviceBuffer<F4> qA[Q_COUNT], qB[Q_COUNT], qC[Q_COUNT];
@@ -966,9 +966,9 @@ extern "C" int giCRender(const GiCRenderParams* params)
     // consecutive samples whose per-sample colour buffer fits the budget; a pool of `slots` paths is kept full from a running
     // work counter until the batch's items run out.
     auto envU64 = [](const char* name, uint64_t def) { const char* e = getenv(name); return e ? (uint64_t)strtoull(e, nullptr, 10) : def; };
-    const uint64_t budgetBytes = envU64("GATLING_SAMPLE_BUFFER_MB", s->optSampleBufferMb ? s->optSampleBufferMb : 2048) << 20;
+    const uint64_t budgetBytes = envU64("GATLING_SAMPLE_BUFFER_MB", s->optSampleBufferMb ? s->optSampleBufferMb : 8192) << 20;
     const uint64_t poolMax = std::max<uint64_t>(64, envU64("GATLING_POOL_SLOTS", s->optPoolSlots ? s->optPoolSlots : (4u << 20)));
-    uint64_t batchSamples = std::min<uint64_t>(rs.spp, std::max<uint64_t>(1, budgetBytes / (pixels * 12)));
+    uint64_t batchSamples = std::min<uint64_t>(rs.spp, std::max<uint64_t>(1, budgetBytes / (pixels * 16)));
     batchSamples = std::min<uint64_t>(batchSamples, std::max<uint64_t>(1, 0xffffffffull / pixels)); // work ids stay 32-bit
     const uint32_t numBatches = (uint32_t)((rs.spp + batchSamples - 1) / batchSamples);
     const size_t slots = (size_t)std::min<uint64_t>(poolMax, (uint64_t)pixels * batchSamples);
@@ -989,7 +989,7 @@ extern "C" int giCRender(const GiCRenderParams* params)
       traceBlocks = (uint32_t)std::min<size_t>((slots + 255) / 256, (size_t)g_ctx.cuCount * perCu);
     }
     if (ensurePathState(s, slots, wideBlocks, traceBlocks) != GI_C_OK) return GI_C_ERROR;
-    if (s->sampleBuf.alloc(pixels * batchSamples * 3) || s->accum.alloc(pixels)) return GI_C_ERROR;
+    if (s->sampleBuf.alloc(pixels * batchSamples) || s->accum.alloc(pixels)) return GI_C_ERROR;
     PathState ps{s->slots.ptr};
     QueueSet qs = makeQueueSet(s);
     F4* colorOut = reinterpret_cast<F4*>(colorRb->deviceMem);

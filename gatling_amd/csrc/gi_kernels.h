@@ -10,8 +10,8 @@ namespace gi {
 void launchInit(hipStream_t s, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t n, bool resetStats);
 // `par` = iteration parity: k_raygen reads REGEN[par] and appends TRACE[par]; k_trace reads TRACE[par] and appends HIT and
 // REGEN[par^1]; k_shade reads HIT and appends TRACE[par^1], REGEN[par^1], SHADOW.
-void launchRaygen(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par, float* sampleBuf);
-void launchAccumulate(hipStream_t s, const FrameUniforms& U, const float* sampleBuf, F4* accum, F4* colorOut, bool firstBatch, bool lastBatch);
+void launchRaygen(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par, F4* sampleBuf);
+void launchAccumulate(hipStream_t s, const FrameUniforms& U, const F4* sampleBuf, F4* accum, F4* colorOut, bool firstBatch, bool lastBatch);
 // LDS bytes one k_trace block needs for this scene (stack + staged nodes + staged triangles)
 uint32_t traceStaticLdsBytes(); // static LDS of the traversal kernels on top of traceLdsLayout's dynamic bytes
 void traceLdsLayout(const SceneView& sc, uint32_t& ldsNodes, uint32_t& ldsTris, uint32_t& bytes);

@@ -162,7 +162,7 @@ __device__ __forceinline__ void make_camera_ray(const FrameUniforms& U, uint32_t
 // term.  Entry i of the regen queue finishes its sample (if any) into the per-sample colour buffer and takes work item
 // workBase + i = (pixel w % P, sample w / P) -- consecutive entries get adjacent pixels of the same sample index.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st, QueueSet qs, Counters* cnt, uint32_t par, float* __restrict__ sampleBuf)
+__global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st, QueueSet qs, Counters* cnt, uint32_t par, F4* __restrict__ sampleBuf)
 {
   __shared__ AppendScratch<1> sh;
   const uint32_t qIn = Q_REGEN_A + par, qOut = Q_TRACE_A + par;
@@ -195,8 +195,8 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st,
         }
         float mv = fmax2(rad.x, fmax2(rad.y, rad.z));
         if (mv > U.maxSampleValue) rad = rad * (U.maxSampleValue / mv);
-        float* dst = sampleBuf + ((size_t)f2u(id.y) * U.pixelCount + f2u(id.x)) * 3u;
-        dst[0] = fmax2(0.0f, rad.x); dst[1] = fmax2(0.0f, rad.y); dst[2] = fmax2(0.0f, rad.z);
+        // one aligned 16-byte store: a 12-byte record straddles DRAM sectors and costs two read-modify-writes
+        st4(&sampleBuf[(size_t)f2u(id.y) * U.pixelCount + f2u(id.x)], fmax2(0.0f, rad.x), fmax2(0.0f, rad.y), fmax2(0.0f, rad.z), 0.0f);
       }
       const uint32_t w = workBase + i; // < 2^32 by construction of the batches (host)
       more = (i < U.workTotal - workBase) && (w < U.workTotal);
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st,
 // (pixel_color += sample_color * invSpp, rp_main.rgen:498) and, after the last batch, writes the colour AOV with
 // the progressive blend of rp_main.rgen:506-515.  One thread per pixel; reads are coalesced across pixels.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_accumulate(FrameUniforms U, const float* __restrict__ sampleBuf, F4* __restrict__ accum, F4* __restrict__ colorOut,
+__global__ __launch_bounds__(BLOCK) void k_accumulate(FrameUniforms U, const F4* __restrict__ sampleBuf, F4* __restrict__ accum, F4* __restrict__ colorOut,
                                                       uint32_t firstBatch, uint32_t lastBatch)
 {
   const uint32_t p = blockIdx.x * BLOCK + threadIdx.x;
@@ -234,8 +234,8 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(FrameUniforms U, const flo
   V3 pixelColor = v3(0.0f, 0.0f, 0.0f);
   if (!firstBatch) { const F4 a = ld4(&accum[p]); pixelColor = v3(a.x, a.y, a.z); }
   for (uint32_t s = 0; s < U.batchSamples; s++) {
-    const float* src = sampleBuf + ((size_t)s * U.pixelCount + p) * 3u;
-    pixelColor = pixelColor + v3(src[0], src[1], src[2]) * U.invSpp;
+    const F4 src = ld4(&sampleBuf[(size_t)s * U.pixelCount + p]);
+    pixelColor = pixelColor + v3(src.x, src.y, src.z) * U.invSpp;
   }
   if (!lastBatch) { st4(&accum[p], pixelColor.x, pixelColor.y, pixelColor.z, 0.0f); return; }
   const uint32_t pixelIndex = U.rowBegin * U.imageWidth + p;
@@ -1425,11 +1425,11 @@ void launchInit(hipStream_t s, const PathState& st, const QueueSet& qs, Counters
   uint32_t blocks = (n + 255u) / 256u; if (blocks > 4096u) blocks = 4096u; if (blocks == 0u) blocks = 1u;
   hipLaunchKernelGGL(k_init, dim3(blocks), dim3(256), 0, s, st, qs, cnt, n, resetStats ? 1u : 0u);
 }
-void launchRaygen(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par, float* sampleBuf)
+void launchRaygen(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par, F4* sampleBuf)
 {
   hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(BLOCK), 0, s, U, st, qs, cnt, par, sampleBuf);
 }
-void launchAccumulate(hipStream_t s, const FrameUniforms& U, const float* sampleBuf, F4* accum, F4* colorOut, bool firstBatch, bool lastBatch)
+void launchAccumulate(hipStream_t s, const FrameUniforms& U, const F4* sampleBuf, F4* accum, F4* colorOut, bool firstBatch, bool lastBatch)
 {
   hipLaunchKernelGGL(k_accumulate, dim3((U.pixelCount + BLOCK - 1u) / BLOCK), dim3(BLOCK), 0, s, U, sampleBuf, accum, colorOut, firstBatch ? 1u : 0u, lastBatch ? 1u : 0u);
 }
