@@ -260,7 +260,7 @@ struct GiCScene {
   GiCDomeLight* oldDome = nullptr;
   float oldDomeEmission[3] = {0, 0, 0};
   // device scene
-  DeviceBuffer<Node8> dNodes; DeviceBuffer<TriRec> dTris; DeviceBuffer<InstanceRec> dInstances;
+  DeviceBuffer<Node8> dNodes; DeviceBuffer<uint4> dNodesLine; uint32_t nodeStrideU4 = 5; DeviceBuffer<TriRec> dTris; DeviceBuffer<InstanceRec> dInstances;
   DeviceBuffer<FVertex> dVerts; DeviceBuffer<MaterialRec> dMaterials; DeviceBuffer<int32_t> dTriFaceId;
   DeviceBuffer<SphereLightRec> dSphere; DeviceBuffer<DistantLightRec> dDistant; DeviceBuffer<RectLightRec> dRect; DeviceBuffer<DiskLightRec> dDisk;
   uint32_t nodeCount = 0, triCount = 0, bvhDepth = 0;
@@ -331,7 +331,7 @@ void giCDestroyScene(GiCScene* s)
   if (!s) return;
   std::lock_guard<std::mutex> g(g_ctx.resourceMutex);
   (void)hipStreamSynchronize(g_ctx.stream);
-  s->dNodes.release(); s->dTris.release(); s->dInstances.release(); s->dVerts.release(); s->dTriFaceId.release();
+  s->dNodes.release(); s->dNodesLine.release(); s->dTris.release(); s->dInstances.release(); s->dVerts.release(); s->dTriFaceId.release();
   s->dMaterials.release(); s->dSphere.release(); s->dDistant.release(); s->dRect.release(); s->dDisk.release();
   s->slots.release(); s->sampleBuf.release(); s->accum.release();
   for (uint32_t q = 0; q < Q_COUNT; q++) { s->qSlot[q].release(); s->qA[q].release(); s->qB[q].release(); s->qC[q].release(); }
@@ -737,7 +737,18 @@ int buildScene(GiCScene* s)
   std::vector<int32_t> triFaceId(bvh.tris.size());
   for (size_t i = 0; i < bvh.tris.size(); i++) triFaceId[i] = faceIdOf[bvh.tris[i].origId];
   if (s->dTriFaceId.upload(triFaceId, st)) return GI_C_ERROR;
-  if (s->dNodes.upload(bvh.nodes, st) || s->dTris.upload(bvh.tris, st) || s->dInstances.upload(instances, st) ||
+  // Scenes whose BVH lives in global memory keep one node per 128-byte line (an 80-byte node at an 80-byte stride straddles
+  // two lines half of the time: one more L2 request per node visit); small scenes are staged in LDS anyway.
+  bool lineNodes = bvh.nodes.size() > 384;
+  if (const char* e = getenv("GATLING_NODE_LINES")) lineNodes = atoi(e) != 0;
+  s->nodeStrideU4 = lineNodes ? 8u : 5u;
+  std::vector<uint4> lined;
+  if (lineNodes) {
+    lined.assign(bvh.nodes.size() * 8, uint4{0u, 0u, 0u, 0u});
+    for (size_t i = 0; i < bvh.nodes.size(); i++) memcpy(&lined[i * 8], &bvh.nodes[i], sizeof(Node8));
+    if (s->dNodesLine.upload(lined, st)) return GI_C_ERROR;
+  }
+  if ((!lineNodes && s->dNodes.upload(bvh.nodes, st)) || s->dTris.upload(bvh.tris, st) || s->dInstances.upload(instances, st) ||
       s->dVerts.upload(verts, st) || s->dMaterials.upload(mats, st))
     return GI_C_ERROR;
   HIP_TRY(hipStreamSynchronize(st)); // host vectors go out of scope
@@ -762,7 +773,7 @@ bool settingsEqual(const GiCRenderSettings& a, const GiCRenderSettings& b) { ret
 SceneView makeView(GiCScene* s)
 {
   SceneView v{};
-  v.nodes = s->dNodes.ptr; v.tris = s->dTris.ptr; v.instances = s->dInstances.ptr;
+  v.nodes = s->nodeStrideU4 == 8u ? reinterpret_cast<const Node8*>(s->dNodesLine.ptr) : s->dNodes.ptr; v.nodeStrideU4 = s->nodeStrideU4; v.tris = s->dTris.ptr; v.instances = s->dInstances.ptr;
   v.verts = s->dVerts.ptr; v.materials = s->dMaterials.ptr; v.sphereLights = s->dSphere.ptr; v.distantLights = s->dDistant.ptr;
   v.rectLights = s->dRect.ptr; v.diskLights = s->dDisk.ptr; v.triFaceId = s->dTriFaceId.ptr; v.nodeCount = s->nodeCount; v.triCount = s->triCount; v.bvhDepth = s->bvhDepth; v.hasCutouts = s->hasCutouts ? 1u : 0u;
   return v;
@@ -967,7 +978,12 @@ extern "C" int giCRender(const GiCRenderParams* params)
     // work counter until the batch's items run out.
     auto envU64 = [](const char* name, uint64_t def) { const char* e = getenv(name); return e ? (uint64_t)strtoull(e, nullptr, 10) : def; };
     const uint64_t budgetBytes = envU64("GATLING_SAMPLE_BUFFER_MB", s->optSampleBufferMb ? s->optSampleBufferMb : 8192) << 20;
-    const uint64_t poolMax = std::max<uint64_t>(64, envU64("GATLING_POOL_SLOTS", s->optPoolSlots ? s->optPoolSlots : (4u << 20)));
+    // Pool size: a launch of k_trace_dyn ends when its longest ray ends, and ray cost is heavy-tailed in scenes beyond LDS
+    // (a 100-step ray outlives the average one six times over), so those scenes get a pool large enough to amortise that
+    // tail (measured on C3: 4 Mi slots 630, 16 Mi 790, 32 Mi 831 Msamples/s); LDS-resident scenes have uniform, short rays.
+    const bool sceneInLds = s->nodeCount <= 384u && s->triCount <= 128u;
+    const uint64_t poolDefault = sceneInLds ? (4u << 20) : (32u << 20);
+    const uint64_t poolMax = std::max<uint64_t>(64, envU64("GATLING_POOL_SLOTS", s->optPoolSlots ? s->optPoolSlots : poolDefault));
     uint64_t batchSamples = std::min<uint64_t>(rs.spp, std::max<uint64_t>(1, budgetBytes / (pixels * 16)));
     batchSamples = std::min<uint64_t>(batchSamples, std::max<uint64_t>(1, 0xffffffffull / pixels)); // work ids stay 32-bit
     const uint32_t numBatches = (uint32_t)((rs.spp + batchSamples - 1) / batchSamples);

@@ -288,7 +288,7 @@ __device__ __forceinline__ void trav_init(RayTrav& R, V3 o, V3 d, float tMin, fl
   const float gy = (fabsf(d.y) < 1e-30f) ? (d.y < 0.0f ? -1e-30f : 1e-30f) : d.y;
   const float gz = (fabsf(d.z) < 1e-30f) ? (d.z < 0.0f ? -1e-30f : 1e-30f) : d.z;
   R.idx = 1.0f / gx; R.idy = 1.0f / gy; R.idz = 1.0f / gz;
-  R.octinv = (d.x >= 0.0f ? 1u : 0u) | (d.y >= 0.0f ? 2u : 0u) | (d.z >= 0.0f ? 4u : 0u);
+  R.octinv = ((d.x >= 0.0f ? 1u : 0u) | (d.y >= 0.0f ? 2u : 0u) | (d.z >= 0.0f ? 4u : 0u)) * 0x01010101u; // replicated into the 4 bytes (trav_node_test)
   R.bestTri = 0xffffffffu; R.bestOrig = 0xffffffffu; R.bestMat = 0u; R.bestU = 0.0f; R.bestV = 0.0f;
   R.G = make_uint2(0u, 0x80000000u); // virtual group holding only the root
   R.sp = 0u; R.found = false;
@@ -311,46 +311,59 @@ __device__ __forceinline__ uint32_t trav_node_pick(RayTrav& R, uint2 (*s_stack)[
     if (!OVERFLOW || sp < STACK) s_stack[sp < STACK ? sp : STACK - 1u][tid] = G; else overflow[sp - STACK] = G;
     sp++;
   }
-  const uint32_t slot = (bit - 24u) ^ R.octinv;
+  const uint32_t slot = (bit - 24u) ^ (R.octinv & 7u);
   const uint32_t rel = (uint32_t)__popc((G.y & 0xffu) & ((1u << slot) - 1u));
   R.sp = sp;
   return G.x + rel;
 }
 
 // Part 2: tests the ray against the node's 8 quantised child boxes and returns the triangle group (base, mask) of its hit
-// leaf children; R.G becomes the group of hit internal children.
+// leaf children; R.G becomes the group of hit internal children.  The box test is a conservative filter (explicit fma,
+// far planes and tBest widened by 1e-5 relative), it never decides a result.  Written for the VALU: the two planes of an
+// axis go through one packed fma (v_pk_fma_f32), the per-child meta bytes (slot index, child bits, octant flip of internal
+// children) are decoded four at a time with byte-parallel integer ops, and empty slots (meta 0) contribute no bits, so
+// the hit mask is assembled without a branch.
+typedef float gi_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint2 trav_node_test(RayTrav& R, const uint4& n0, const uint4& n1, const uint4& n2, const uint4& n3, const uint4& n4)
 {
   const V3 o = R.o, d = R.d;
-  const uint32_t octinv = R.octinv;
-  // ray in the node's quantisation frame
+  constexpr float WIDEN = 1.00001f;
+  // ray in the node's quantisation frame: t(q) = q * a + b per axis; .x = near plane, .y = far plane (widened)
   const float sx = u2f((n0.w & 0xffu) << 23), sy = u2f(((n0.w >> 8) & 0xffu) << 23), sz = u2f(((n0.w >> 16) & 0xffu) << 23);
   const float ax = sx * R.idx, ay = sy * R.idy, az = sz * R.idz;
   const float bx = (u2f(n0.x) - o.x) * R.idx, by = (u2f(n0.y) - o.y) * R.idy, bz = (u2f(n0.z) - o.z) * R.idz;
+  const gi_f2 Ax = {ax, ax * WIDEN}, Ay = {ay, ay * WIDEN}, Az = {az, az * WIDEN};
+  const gi_f2 Bx = {bx, bx * WIDEN}, By = {by, by * WIDEN}, Bz = {bz, bz * WIDEN};
+  const float tFar = R.tBest * WIDEN, tNear = R.tMin;
   // near/far plane bytes per axis, chosen by direction sign
   const bool nxn = d.x < 0.0f, nyn = d.y < 0.0f, nzn = d.z < 0.0f;
   const uint32_t qlox[2] = {n2.x, n2.y}, qloy[2] = {n2.z, n2.w}, qloz[2] = {n3.x, n3.y};
   const uint32_t qhix[2] = {n3.z, n3.w}, qhiy[2] = {n4.x, n4.y}, qhiz[2] = {n4.z, n4.w};
   const uint32_t metaw[2] = {n1.z, n1.w};
+  const uint32_t oct4 = R.octinv;
   uint32_t hitmask = 0u;
 #pragma unroll
   for (int h = 0; h < 2; h++) {
     const uint32_t nearx = nxn ? qhix[h] : qlox[h], farx = nxn ? qlox[h] : qhix[h];
     const uint32_t neary = nyn ? qhiy[h] : qloy[h], fary = nyn ? qloy[h] : qhiy[h];
     const uint32_t nearz = nzn ? qhiz[h] : qloz[h], farz = nzn ? qloz[h] : qhiz[h];
+    // four meta bytes at once: bits 7-5 = child bits (1 = internal, unary count for leaves), bits 4-0 = slot index, where
+    // internal children (index 24..31, i.e. bits 4 and 3 set) are flipped by the ray octant
+    const uint32_t m4 = metaw[h];
+    const uint32_t inner4 = ((m4 & (m4 << 1)) >> 4) & 0x01010101u;
+    const uint32_t idx4 = (m4 ^ (oct4 & ((inner4 << 8) - inner4))) & 0x1f1f1f1fu; // (x << 8) - x == x * 0xff per byte, at full rate
+    const uint32_t bits4 = (m4 >> 5) & 0x07070707u;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const uint32_t sh = 8u * (uint32_t)k;
-      const float t0x = fmaf((float)((nearx >> sh) & 0xffu), ax, bx), t1x = fmaf((float)((farx >> sh) & 0xffu), ax, bx);
-      const float t0y = fmaf((float)((neary >> sh) & 0xffu), ay, by), t1y = fmaf((float)((fary >> sh) & 0xffu), ay, by);
-      const float t0z = fmaf((float)((nearz >> sh) & 0xffu), az, bz), t1z = fmaf((float)((farz >> sh) & 0xffu), az, bz);
-      const float tn = fmaxf(fmaxf(t0x, t0y), fmaxf(t0z, R.tMin));
-      const float tf = fminf(fminf(t1x, t1y), fminf(t1z, R.tBest));
-      const uint32_t meta = (metaw[h] >> sh) & 0xffu;
-      if (tn <= tf * 1.00001f + 1e-30f && meta != 0u) {
-        const uint32_t inner = ((meta & 0x18u) == 0x18u) ? octinv : 0u;
-        hitmask |= (meta >> 5) << ((meta & 31u) ^ inner);
-      }
+      const gi_f2 qx = {(float)((nearx >> sh) & 0xffu), (float)((farx >> sh) & 0xffu)};
+      const gi_f2 qy = {(float)((neary >> sh) & 0xffu), (float)((fary >> sh) & 0xffu)};
+      const gi_f2 qz = {(float)((nearz >> sh) & 0xffu), (float)((farz >> sh) & 0xffu)};
+      const gi_f2 tx = __builtin_elementwise_fma(qx, Ax, Bx), ty = __builtin_elementwise_fma(qy, Ay, By), tz = __builtin_elementwise_fma(qz, Az, Bz);
+      const float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, tNear));
+      const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, tFar));
+      const uint32_t contrib = ((bits4 >> sh) & 0xffu) << ((idx4 >> sh) & 0xffu);
+      hitmask |= (tn <= tf) ? contrib : 0u;
     }
   }
   R.G = make_uint2(n1.x, (hitmask & 0xff000000u) | (n0.w >> 24));
@@ -365,7 +378,7 @@ __device__ __forceinline__ uint2 trav_node(RayTrav& R, const SceneView& sc, cons
   const uint32_t nodeIdx = trav_node_pick<STACK, OVERFLOW>(R, s_stack, overflow);
   uint4 n0, n1, n2, n3, n4;
   if (ALL_LDS || nodeIdx < ldsNodes) { const uint4* p = s_nodes + nodeIdx * 5u; n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3]; n4 = p[4]; }
-  else { const uint4* p = reinterpret_cast<const uint4*>(sc.nodes) + (size_t)nodeIdx * 5u; n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3]; n4 = p[4]; }
+  else { const uint4* p = reinterpret_cast<const uint4*>(sc.nodes) + (size_t)nodeIdx * sc.nodeStrideU4; n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3]; n4 = p[4]; }
   if (COUNT) tc.nodes++;
   return trav_node_test(R, n0, n1, n2, n3, n4);
 }
@@ -523,7 +536,7 @@ __device__ __forceinline__ bool wave_step(RayTrav& R, bool alive, WaveTri& W, Wa
       const uint32_t flat = cidx * 64u + lane, owner = flat / 5u, part = flat - owner * 5u;
       const uint32_t nIdx = (uint32_t)__shfl((int)nodeIdx, (int)owner);
       piece[cidx] = make_uint4(0u, 0u, 0u, 0u);
-      if (nIdx != 0xffffffffu) piece[cidx] = reinterpret_cast<const uint4*>(sc.nodes)[(size_t)nIdx * 5u + part];
+      if (nIdx != 0xffffffffu) piece[cidx] = reinterpret_cast<const uint4*>(sc.nodes)[(size_t)nIdx * sc.nodeStrideU4 + part];
     }
 #pragma unroll
     for (uint32_t cidx = 0; cidx < 5u; cidx++) S->buf[cidx * 64u + lane] = piece[cidx];
@@ -595,7 +608,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
   const uint32_t n = rd.pre[NSHARD];
   if (blockIdx.x == 0 && threadIdx.x == 0) { if (ANYHIT) cnt->shadowRays += n; else cnt->segments += n; } // single writer per launch
   if (blockIdx.x * TRACE_BLOCK >= n) return; // whole block idle (uniform)
-  for (uint32_t i = threadIdx.x; i < ldsNodes * 5u; i += TRACE_BLOCK) s_nodes[i] = reinterpret_cast<const uint4*>(sc.nodes)[i];
+  for (uint32_t i = threadIdx.x; i < ldsNodes * 5u; i += TRACE_BLOCK) s_nodes[i] = reinterpret_cast<const uint4*>(sc.nodes)[(i / 5u) * sc.nodeStrideU4 + (i % 5u)];
   for (uint32_t i = threadIdx.x; i < ldsTris * 3u; i += TRACE_BLOCK) s_tris[i] = reinterpret_cast<const uint4*>(sc.tris)[(i / 3u) * 4u + (i % 3u)];
   __syncthreads();
 
@@ -750,7 +763,7 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
 }
 
 template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool CUTOUT>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace_dyn(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t refill)
+__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_trace_dyn(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t refill)
 {
   trace_dyn_body<ANYHIT, COUNT, STACK, OVERFLOW, CUTOUT>(sc, st, qs, cnt, qIn, refill);
 }
@@ -1335,7 +1348,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_aov(FrameUniforms U, SceneView 
   uint2 (*s_stack)[TRACE_BLOCK] = reinterpret_cast<uint2 (*)[TRACE_BLOCK]>(s_dyn);
   uint4* s_nodes = s_dyn + (STACK * TRACE_BLOCK * sizeof(uint2)) / sizeof(uint4);
   uint4* s_tris = s_nodes + ldsNodes * 5u;
-  for (uint32_t i = threadIdx.x; i < ldsNodes * 5u; i += TRACE_BLOCK) s_nodes[i] = reinterpret_cast<const uint4*>(sc.nodes)[i];
+  for (uint32_t i = threadIdx.x; i < ldsNodes * 5u; i += TRACE_BLOCK) s_nodes[i] = reinterpret_cast<const uint4*>(sc.nodes)[(i / 5u) * sc.nodeStrideU4 + (i % 5u)];
   for (uint32_t i = threadIdx.x; i < ldsTris * 3u; i += TRACE_BLOCK) s_tris[i] = reinterpret_cast<const uint4*>(sc.tris)[(i / 3u) * 4u + (i % 3u)];
   __syncthreads();
   const uint32_t p = blockIdx.x * TRACE_BLOCK + threadIdx.x;

@@ -104,7 +104,7 @@ enum : uint32_t {
 
 // Device-side scene view handed to the kernels.
 struct SceneView {
-  const Node8* nodes;
+  const Node8* nodes;      // nodeStrideU4 * 16 bytes apart (80-byte nodes packed, or one per 128-byte line)
   const TriRec* tris;
   const InstanceRec* instances;
   const FVertex* verts;
@@ -118,6 +118,7 @@ struct SceneView {
   uint32_t triCount;
   uint32_t bvhDepth; // levels of the BVH8 (bounds the traversal stack)
   uint32_t hasCutouts; // some triangle has cutout opacity < 1: traversal runs the any-hit test (needs the path rng)
+  uint32_t nodeStrideU4; // distance between nodes in 16-byte units: 5 (packed) or 8 (one node per 128-byte line)
 };
 
 struct alignas(16) F4 { float x, y, z, w; };
