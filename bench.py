@@ -7,7 +7,7 @@ cornell, 1920x1080, spp 1024, max-bounces 8, UsdPreviewSurface model); scene ing
 before the timed region (the scene is resident in HBM), the timed region contains every bounce stage, the
 per-pixel accumulation, for N>1 the RCCL tile gather, and the final D2H of the colour AOV.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c3|c4] [--spp S]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c3|c4|c5] [--spp S]
   N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 N>1 is strong scaling: the same frame is split into N contiguous row bands (one rank per GPU, scene replicated),
@@ -27,7 +27,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 
 def make_workload(name, spp_override=None):
     from gatling_amd.scene import MAT_DIFFUSE, RenderSettings
-    from gatling_amd.scenes import cornell_box, random_triangle_soup, sphere_grid
+    from gatling_amd.scenes import cornell_box, interior_scene, random_triangle_soup, sphere_grid
     if name == "c2":
         desc, rs, w, h = cornell_box(), RenderSettings(spp=1024, max_bounces=8), 1920, 1080
         label = "C2: cornell.usda 1920x1080 spp=1024 max-bounces=8 UsdPreviewSurface (diffuse + GGX specular), NEE off"
@@ -36,10 +36,13 @@ def make_workload(name, spp_override=None):
         label = "C1: cornell.usda 512x512 spp=64 max-bounces=4 diffuse-only"
     elif name == "c3":
         desc, rs, w, h = random_triangle_soup(1_000_000), RenderSettings(spp=256, max_bounces=8, next_event_estimation=True), 1920, 1080
-        label = "C3: 1M-triangle soup, 1 material, rect light, NEE on, 1920x1080 spp=256 max-bounces=8"
+        label = "C3: 1M-triangle soup, 1 OpenPBR material, rect light, NEE on, 1920x1080 spp=256 max-bounces=8"
     elif name == "c4":
         desc, rs, w, h = sphere_grid(32, 4, 32), RenderSettings(spp=256, max_bounces=8), 1920, 1080
-        label = "C4: 32x32 instanced icospheres (5120 tris each), 32 materials, 1920x1080 spp=256 max-bounces=8"
+        label = "C4: 32x32 instanced icospheres (5120 tris each), 32 OpenPBR/UsdPreviewSurface materials, 1920x1080 spp=256 max-bounces=8"
+    elif name == "c5":
+        desc, rs, w, h = interior_scene(), RenderSettings(spp=1024, max_bounces=8, next_event_estimation=True), 3840, 2160
+        label = "C5: interior, 10.24M instanced triangles, 51 materials, 4 rect lights, NEE on, 3840x2160 spp=1024 max-bounces=8"
     else:
         raise SystemExit(f"unknown workload {name}")
     if spp_override:

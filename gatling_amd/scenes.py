@@ -81,9 +81,10 @@ def _look_at_camera(position, target, up, vfov_deg) -> CameraDesc:
                       vfov=float(np.float32(np.deg2rad(vfov_deg))))
 
 
-def random_triangle_soup(count: int = 1_000_000, seed: int = 1234, material_class: int = MAT_USD_PREVIEW_SURFACE) -> SceneDesc:
+def random_triangle_soup(count: int = 1_000_000, seed: int = 1234, material_class: int = MAT_OPEN_PBR) -> SceneDesc:
     """Config C3: `count` independent triangles in one mesh, centres uniform in [-1,1]^3, edge
-    vectors ~ N(0, 0.01^2) per component, one material (base colour .8, roughness .3, ior 1.5), one 1x1 rect light at
+    vectors ~ N(0, 0.01^2) per component, one OpenPBR material with the defaults of open_pbr_surface.mtlx:11-92 (base colour .8,
+    specular roughness .3, ior 1.5; `material_class` selects the UsdPreviewSurface / diffuse stand-ins), one 1x1 rect light at
     z=+1.5 facing -z with intensity 20, NEE on, camera at (0,-4,0) looking +y, vfov 40 degrees."""
     rng = np.random.default_rng(seed)
     c = rng.uniform(-1.0, 1.0, (count, 1, 3))
@@ -95,7 +96,10 @@ def random_triangle_soup(count: int = 1_000_000, seed: int = 1234, material_clas
     verts = bake_vertices(p, n)
     faces = np.arange(3 * count, dtype=np.uint32).reshape(-1, 3)
     s = SceneDesc()
-    s.materials = [MaterialDesc.usd_preview_surface(name="soup", diffuseColor=(0.8, 0.8, 0.8), roughness=0.3, ior=1.5, klass=material_class)]
+    if material_class == MAT_OPEN_PBR:
+        s.materials = [MaterialDesc.open_pbr(name="soup")]
+    else:
+        s.materials = [MaterialDesc.usd_preview_surface(name="soup", diffuseColor=(0.8, 0.8, 0.8), roughness=0.3, ior=1.5, klass=material_class)]
     s.meshes = [MeshDesc(name="/Soup", vertices=verts, faces=faces, material=0, id=0, double_sided=True)]
     s.rect_lights = [RectLight(origin=(0.0, 0.0, 1.5), t0=(1, 0, 0), t1=(0, 1, 0), base_emission=(20, 20, 20), width=1.0, height=1.0)]
     s.camera = _look_at_camera((0, -4, 0), (0, 0, 0), (0, 0, 1), 40.0)
@@ -127,20 +131,34 @@ def icosphere(subdivisions: int = 3):
     return pts, np.asarray(f, np.uint32)
 
 
-def sphere_grid(grid: int = 32, subdivisions: int = 4, material_count: int = 32, seed: int = 4321,
-                material_class: int = MAT_USD_PREVIEW_SURFACE) -> SceneDesc:
+def _parameter_sets(rng, count, material_class=None):
+    """The material parameter sets of configs C4/C5: base colour ~U[0,1]^3, roughness ~U[.05,1],
+    metalness in {0,1} p=.25, coat weight in {0,1} p=.25, transmission weight in {0,1} p=.125; sets with transmission are
+    OpenPBR, the others alternate between OpenPBR and UsdPreviewSurface (or all use `material_class` when given)."""
+    mats = []
+    for i in range(count):
+        color, rough = tuple(rng.uniform(0, 1, 3)), float(rng.uniform(0.05, 1.0))
+        metal, coat, trans = float(rng.uniform() < 0.25), float(rng.uniform() < 0.25), float(rng.uniform() < 0.125)
+        klass = material_class if material_class is not None else (MAT_OPEN_PBR if (trans > 0 or i % 2 == 0) else MAT_USD_PREVIEW_SURFACE)
+        if klass == MAT_OPEN_PBR:
+            mats.append(MaterialDesc.open_pbr(name=f"mat{i}", base_color=color, specular_roughness=rough, base_metalness=metal, coat_weight=coat,
+                                              coat_roughness=0.05, transmission_weight=trans if material_class is None else 0.0))
+        else:
+            mats.append(MaterialDesc.usd_preview_surface(name=f"mat{i}", diffuseColor=color, roughness=rough, metallic=metal, clearcoat=coat,
+                                                         clearcoatRoughness=0.05, klass=klass))
+    return mats
+
+
+def sphere_grid(grid: int = 32, subdivisions: int = 4, material_count: int = 32, seed: int = 4321, material_class=None) -> SceneDesc:
     """Config C4: grid x grid instances of one icosphere prototype, bound round-robin to
-    `material_count` parameter sets (base colour ~U[0,1]^3, roughness ~U[.05,1], metalness in {0,1} p=.25, coat in {0,1}
-    p=.25), constant (1,1,1) environment through the colour clear value, no analytic lights, NEE off."""
+    `material_count` OpenPBR / UsdPreviewSurface parameter sets (_parameter_sets), constant (1,1,1) environment through the
+    colour clear value, no analytic lights, NEE off."""
     from .meshprep import bake_vertices
     rng = np.random.default_rng(seed)
     pts, faces = icosphere(subdivisions)
     verts = bake_vertices(pts, pts / np.linalg.norm(pts, axis=1, keepdims=True))
     s = SceneDesc()
-    for i in range(material_count):
-        s.materials.append(MaterialDesc.usd_preview_surface(
-            name=f"mat{i}", diffuseColor=tuple(rng.uniform(0, 1, 3)), roughness=float(rng.uniform(0.05, 1.0)),
-            metallic=float(rng.uniform() < 0.25), clearcoat=float(rng.uniform() < 0.25), clearcoatRoughness=0.05, klass=material_class))
+    s.materials = _parameter_sets(rng, material_count, material_class)
     per_mat = [[] for _ in range(material_count)]
     k = 0
     for gy in range(grid):
@@ -157,4 +175,60 @@ def sphere_grid(grid: int = 32, subdivisions: int = 4, material_count: int = 32,
                                      instance_transforms=np.stack(xf), instance_ids=np.arange(len(xf), dtype=np.int32)))
     dist = grid * 1.6
     s.camera = _look_at_camera((0, -dist, 0), (0, 0, 0), (0, 0, 1), 40.0)
+    return s
+
+
+def interior_scene(clutter_instances: int = 2000, subdivisions: int = 4, prototypes: int = 20, material_count: int = 50, seed: int = 9876) -> SceneDesc:
+    """Config C5: a 10 x 8 x 3 m room (12 triangles) filled with `clutter_instances` randomly
+    placed, scaled and rotated instances of `prototypes` lumpy icosphere meshes (20 * 4^subdivisions triangles each:
+    2000 x 5120 = 10.24 M triangles at the default size), `material_count` parameter sets as in C4, four 1 x 2 m rect
+    lights under the ceiling (intensity 30), NEE on.  Smaller arguments give the same structure at test size."""
+    from .meshprep import bake_vertices
+    rng = np.random.default_rng(seed)
+    s = SceneDesc()
+    s.materials = [MaterialDesc.usd_preview_surface(name="walls", diffuseColor=(0.7, 0.7, 0.7), roughness=0.8)] + _parameter_sets(rng, material_count)
+    # the room: inward-facing box, x in [-5,5], y in [-4,4], z in [0,3]
+    lo, hi = np.array([-5.0, -4.0, 0.0]), np.array([5.0, 4.0, 3.0])
+    corners = np.array([[lo[0], lo[1], lo[2]], [hi[0], lo[1], lo[2]], [hi[0], hi[1], lo[2]], [lo[0], hi[1], lo[2]],
+                        [lo[0], lo[1], hi[2]], [hi[0], lo[1], hi[2]], [hi[0], hi[1], hi[2]], [lo[0], hi[1], hi[2]]], np.float32)
+    quads = [((0, 1, 2, 3), (0, 0, 1)), ((7, 6, 5, 4), (0, 0, -1)), ((4, 5, 1, 0), (0, 1, 0)), ((6, 7, 3, 2), (0, -1, 0)),
+             ((7, 4, 0, 3), (1, 0, 0)), ((5, 6, 2, 1), (-1, 0, 0))]
+    rp, rn = [], []
+    for (a, b, c, d), nrm in quads:
+        for tri in ((a, b, c), (a, c, d)):
+            rp += [corners[i] for i in tri]
+            rn += [nrm] * 3
+    s.meshes.append(MeshDesc(name="/Room", vertices=bake_vertices(np.asarray(rp, np.float32), np.asarray(rn, np.float32)),
+                             faces=np.arange(36, dtype=np.uint32).reshape(-1, 3), material=0, id=0, double_sided=True))
+    # clutter prototypes: icospheres with smooth radial lumps
+    base, faces = icosphere(subdivisions)
+    protos = []
+    for _ in range(prototypes):
+        k = rng.normal(0.0, 1.0, (3, 3))
+        bump = 1.0 + 0.15 * np.sin(base @ k[0] * 3.0) + 0.1 * np.sin(base @ k[1] * 5.0 + 1.0) + 0.05 * np.sin(base @ k[2] * 9.0)
+        pts = (base * bump[:, None]).astype(np.float32)
+        fn = np.cross(pts[faces[:, 1]] - pts[faces[:, 0]], pts[faces[:, 2]] - pts[faces[:, 0]])
+        vn = np.zeros_like(pts, dtype=np.float64)
+        for c in range(3):
+            np.add.at(vn, faces[:, c], fn)
+        vn /= np.maximum(np.linalg.norm(vn, axis=1, keepdims=True), 1e-20)
+        protos.append(bake_vertices(pts, vn.astype(np.float32)))
+    groups = {}
+    for i in range(clutter_instances):
+        proto, mat = int(rng.integers(prototypes)), 1 + int(rng.integers(material_count))
+        scale = rng.uniform(0.08, 0.35) * rng.uniform(0.6, 1.4, 3)
+        axis = rng.normal(0, 1, 3); axis /= np.linalg.norm(axis)
+        ang = rng.uniform(0, 2 * np.pi)
+        K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+        m = np.eye(4, dtype=np.float32)
+        m[:3, :3] = (np.diag(scale) @ R.T).astype(np.float32)  # row-vector convention: p_world = p_local . M
+        m[3, :3] = (rng.uniform(-4.4, 4.4), rng.uniform(-3.4, 3.4), rng.uniform(0.3, 2.4))
+        groups.setdefault((proto, mat), []).append(m)
+    for n, ((proto, mat), xf) in enumerate(sorted(groups.items())):
+        s.meshes.append(MeshDesc(name=f"/Clutter/p{proto}_m{mat}", vertices=protos[proto], faces=faces, material=mat, id=1 + n,
+                                 instance_transforms=np.stack(xf), instance_ids=np.arange(len(xf), dtype=np.int32)))
+    for lx, ly in ((-2.5, -2.0), (2.5, -2.0), (-2.5, 2.0), (2.5, 2.0)):
+        s.rect_lights.append(RectLight(origin=(lx, ly, 2.95), t0=(1, 0, 0), t1=(0, 1, 0), base_emission=(30, 30, 30), width=1.0, height=2.0))  # normal = t1 x t0 = -z
+    s.camera = _look_at_camera((-4.5, -3.5, 1.6), (1.5, 1.0, 1.0), (0, 0, 1), 60.0)
     return s

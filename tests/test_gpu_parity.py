@@ -16,7 +16,7 @@ from make_golden import CASES, build_case  # noqa: E402
 
 from gatling_amd.scene import (MAT_DIFFUSE, MAT_USD_PREVIEW_SURFACE, CameraDesc, DiskLight, DistantLight, MaterialDesc, MeshDesc,
                                RectLight, RenderSettings, SceneDesc, SphereLight)
-from gatling_amd.scenes import cornell_box, random_triangle_soup, sphere_grid
+from gatling_amd.scenes import cornell_box, interior_scene, random_triangle_soup, sphere_grid
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -369,6 +369,13 @@ def test_soup_scene_with_nee_parity(gi, orc):
     render_both(gi, orc, desc, RenderSettings(spp=2, max_bounces=5, next_event_estimation=True), 96, 54)
 
 
+def test_interior_scene_parity(gi, orc):
+    """C5's structure at small scale: room + instanced clutter (affine instance transforms), three material classes incl.
+    transmission, four rect lights, NEE on."""
+    desc = interior_scene(clutter_instances=60, subdivisions=1, prototypes=4, material_count=12)
+    render_both(gi, orc, desc, RenderSettings(spp=3, max_bounces=6, next_event_estimation=True), 96, 54)
+
+
 @pytest.mark.parametrize("scene_kind", ["soup", "instances"])
 def test_traversal_kernel_variants_agree(gi, orc, scene_kind):
     """Scenes beyond LDS: the block-synchronous k_trace, k_trace_dyn (any refill threshold) and the oracle give the
@@ -431,3 +438,26 @@ def test_full_size_furnace(gi):
         sc.close()
     assert st["segments"] == 1920 * 1080 * 4 * bounces
     np.testing.assert_allclose(img[..., :3], sum(albedo ** k for k in range(bounces)), rtol=1e-5)
+
+
+def test_full_size_c5_row_bands(gi):
+    """C5 at full geometric size (10.24 M instanced triangles, 3840x2160): the 8 row bands the 8-GPU run renders
+    (270 rows each) are, band by band, bit-identical to the same rows of a whole-frame render -- at 1 spp so that the
+    test stays in seconds; the per-band RNG streams do not depend on spp."""
+    from gatling_amd.dist import partition_rows
+    desc = interior_scene()
+    rs = RenderSettings(spp=1, max_bounces=8, next_event_estimation=True, progressive_accumulation=False)
+    w, h = 3840, 2160
+    sc = gi.Scene(desc)
+    try:
+        full = sc.render(rs, w, h).copy()
+        st = sc.stats()
+        assert st["triangleCount"] == 2000 * 5120 + 12
+        assert np.isfinite(full).all() and full[..., :3].mean() > 0.01
+        for rank in (0, 3, 7):
+            r0, r1 = partition_rows(h, 8, rank)
+            assert r1 - r0 == 270
+            band = sc.render(rs, w, h, rows=(r0, r1))
+            assert band.shape[0] == 270 and np.array_equal(band, full[r0:r1]), f"band {rank}"
+    finally:
+        sc.close()
