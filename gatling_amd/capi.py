@@ -68,6 +68,15 @@ class GiCRenderStats(C.Structure):
 # every symbol include/gi_c.h declares: (name, restype, argtypes)
 _P, _F, _U, _I = C.c_void_p, C.c_float, C.c_uint32, C.c_int32
 _FP = C.POINTER(C.c_float)
+class GiCTextureDesc(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("rgba", C.c_void_p)]
+
+
+class GiCTextureBinding(C.Structure):
+    _fields_ = [("texture", C.c_void_p), ("wrapS", C.c_int32), ("wrapT", C.c_int32), ("channel", C.c_int32),
+                ("scale", C.c_float * 4), ("bias", C.c_float * 4)]
+
+
 SYMBOLS = [
     ("giCInitialize", C.c_int, [C.c_int]), ("giCTerminate", None, []), ("giCGetLastError", C.c_char_p, []),
     ("giCCreateMaterial", _P, [_P, C.c_char_p, C.POINTER(GiCMaterialDesc)]), ("giCDestroyMaterial", None, [_P]),
@@ -90,6 +99,9 @@ SYMBOLS = [
     ("giCSetDiskLightRadius", None, [_P, _F, _F]), ("giCSetDiskLightDiffuseSpecular", None, [_P, _F, _F]),
     ("giCCreateDomeLight", _P, [_P, C.c_char_p]), ("giCDestroyDomeLight", None, [_P]), ("giCSetDomeLightRotation", None, [_P, _FP]),
     ("giCSetDomeLightBaseEmission", None, [_P, _FP]), ("giCSetDomeLightDiffuseSpecular", None, [_P, _F, _F]),
+    ("giCSetDomeLightTexture", None, [_P, _P]),
+    ("giCCreateTexture", _P, [_P, C.POINTER(GiCTextureDesc)]), ("giCDestroyTexture", None, [_P]),
+    ("giCSetMaterialTexture", C.c_int, [_P, _I, C.POINTER(GiCTextureBinding)]),
     ("giCCreateRenderBuffer", _P, [_U, _U, _I]), ("giCDestroyRenderBuffer", None, [_P]), ("giCGetRenderBufferMem", _P, [_P]),
     ("giCGetRenderBufferDeviceMem", _P, [_P]), ("giCSetRenderBufferDeviceOnly", None, [_P, _I]),
     ("giCGetRenderStats", C.c_int, [_P, C.POINTER(GiCRenderStats)]), ("giCSetSceneOption", C.c_int, [_P, _I, _I]),
@@ -167,13 +179,31 @@ class Scene:
         self.handle = L.giCCreateScene()
         if not self.handle:
             raise GiError("giCCreateScene failed")
-        self.materials, self.meshes, self.lights = [], [], []
+        self.materials, self.meshes, self.lights, self.textures, self.dome = [], [], [], [], None
+        for t in getattr(desc, "textures", []):
+            a = np.ascontiguousarray(t, np.float32)
+            td = GiCTextureDesc(a.shape[1], a.shape[0], a.ctypes.data)
+            h = L.giCCreateTexture(self.handle, C.byref(td))  # copies the pixels
+            if not h:
+                raise GiError("giCCreateTexture failed: " + L.giCGetLastError().decode())
+            self.textures.append(h)
         for m in desc.materials:
             md = GiCMaterialDesc(m.klass, 0, (C.c_float * P_COUNT)(*np.asarray(m.params, np.float32)))
             h = L.giCCreateMaterial(self.handle, m.name.encode(), C.byref(md))
             if not h:
                 raise GiError("giCCreateMaterial failed: " + L.giCGetLastError().decode())
+            for slot, b in getattr(m, "textures", {}).items():
+                tb = GiCTextureBinding(self.textures[b.texture], int(b.wrap_s), int(b.wrap_t), int(b.channel), (C.c_float * 4)(*b.scale), (C.c_float * 4)(*b.bias))
+                if L.giCSetMaterialTexture(h, int(slot), C.byref(tb)) != GI_C_OK:
+                    raise GiError("giCSetMaterialTexture failed: " + L.giCGetLastError().decode())
             self.materials.append(h)
+        if getattr(desc, "dome_light", None) is not None:
+            d = desc.dome_light
+            self.dome = L.giCCreateDomeLight(self.handle, b"")
+            if d.texture >= 0:
+                L.giCSetDomeLightTexture(self.dome, self.textures[d.texture])
+            L.giCSetDomeLightRotation(self.dome, _fp(d.rotation)); L.giCSetDomeLightBaseEmission(self.dome, _fp(d.base_emission))
+            L.giCSetDomeLightDiffuseSpecular(self.dome, d.diffuse, d.specular)
         for m in desc.meshes:
             v = np.ascontiguousarray(m.vertices)
             f = np.ascontiguousarray(m.faces, np.uint32)
@@ -245,7 +275,7 @@ class Scene:
         p.aovBindings = C.pointer(binding)
         p.aovBindingCount = 1
         p.camera = _camera(self.desc.camera)
-        p.domeLight = None
+        p.domeLight = self.dome
         p.renderSettings = _settings(settings)
         p.scene = self.handle
         r0, r1 = rows if rows is not None else (0, height)
@@ -294,7 +324,7 @@ class Scene:
             arr[i].renderBuffer = rb
         p = GiCRenderParams()
         p.aovBindings = C.cast(arr, C.POINTER(GiCAovBinding)); p.aovBindingCount = len(bufs)
-        p.camera = _camera(self.desc.camera); p.domeLight = None; p.renderSettings = _settings(settings); p.scene = self.handle
+        p.camera = _camera(self.desc.camera); p.domeLight = self.dome; p.renderSettings = _settings(settings); p.scene = self.handle
         p.rowBegin, p.rowEnd = r0, r1
         if L.giCRender(C.byref(p)) != GI_C_OK:
             raise GiError("giCRender failed: " + L.giCGetLastError().decode())
@@ -345,7 +375,11 @@ class Scene:
                 L.giCDestroyMesh(h)
             for h in self.materials:
                 L.giCDestroyMaterial(h)
-            self.lights, self.meshes, self.materials = [], [], []
+            if self.dome:
+                L.giCDestroyDomeLight(self.dome)
+            for h in self.textures:
+                L.giCDestroyTexture(h)
+            self.lights, self.meshes, self.materials, self.textures, self.dome = [], [], [], [], None
             self.L.giCDestroyScene(self.handle)
             self.handle = None
 

@@ -193,7 +193,8 @@ void deriveMaterialConstants(MaterialRec& m)
 // ---------------------------------------------------------------------------------------------------------------
 enum DirtyFlags : uint32_t { DIRTY_BVH = 1u, DIRTY_FRAMEBUFFER = 2u, DIRTY_LIGHTS = 4u, DIRTY_MATERIALS = 8u, DIRTY_ALL = 0xfu };
 
-struct GiCMaterial { GiCScene* scene; std::string name; GiCMaterialDesc desc; };
+struct GiCTexture { GiCScene* scene; uint32_t width, height; std::vector<float> rgba; };
+struct GiCMaterial { GiCScene* scene; std::string name; GiCMaterialDesc desc; GiCTextureBinding tex[GI_C_TEX_SLOT_COUNT] = {}; };
 
 struct GiCMesh {
   GiCScene* scene;
@@ -224,7 +225,7 @@ struct GiCSphereLight { GiCScene* scene; uint32_t index; };
 struct GiCDistantLight { GiCScene* scene; uint32_t index; };
 struct GiCRectLight { GiCScene* scene; uint32_t index; };
 struct GiCDiskLight { GiCScene* scene; uint32_t index; };
-struct GiCDomeLight { GiCScene* scene; std::string filePath; float rotation[4] = {0, 0, 0, 1}; float baseEmission[3] = {1, 1, 1}; float diffuse = 1.0f, specular = 1.0f; };
+struct GiCDomeLight { GiCScene* scene; std::string filePath; GiCTexture* texture = nullptr; bool ownsTexture = false; float rotation[4] = {0, 0, 0, 1}; float baseEmission[3] = {1, 1, 1}; float diffuse = 1.0f, specular = 1.0f; };
 
 template <typename Rec, typename Handle>
 void DenseStore<Rec, Handle>::remove(uint32_t idx)
@@ -247,6 +248,8 @@ struct GiCScene {
   uint32_t dirty = DIRTY_ALL;
   std::vector<GiCMesh*> meshes;       // creation order (deterministic triangle ids; the reference uses an unordered_set)
   std::vector<GiCMaterial*> materials;
+  std::vector<GiCTexture*> textures;  // creation order
+  std::vector<DeviceBuffer<float>*> dTexels; DeviceBuffer<TextureRec> dTextures; // device copies (rebuilt with the materials)
   DenseStore<SphereLightRec, GiCSphereLight> sphereLights;
   DenseStore<DistantLightRec, GiCDistantLight> distantLights;
   DenseStore<RectLightRec, GiCRectLight> rectLights;
@@ -266,6 +269,7 @@ struct GiCScene {
   uint32_t nodeCount = 0, triCount = 0, bvhDepth = 0;
   bool hasCutouts = false;
   uint32_t classMask = 0; // material classes that own at least one triangle (one k_shade launch per class)
+  uint32_t classTextured = 0; // classes with at least one textured material in use (k_shade<class, TEXTURED>)
   // path state
   DeviceBuffer<Slot> slots;
   DeviceBuffer<F4> sampleBuf; // per-sample colours of the current batch, [sample][pixel] (rgb, -)
@@ -332,6 +336,8 @@ void giCDestroyScene(GiCScene* s)
   std::lock_guard<std::mutex> g(g_ctx.resourceMutex);
   (void)hipStreamSynchronize(g_ctx.stream);
   s->dNodes.release(); s->dNodesLine.release(); s->dTris.release(); s->dInstances.release(); s->dVerts.release(); s->dTriFaceId.release();
+  for (auto* b : s->dTexels) { b->release(); delete b; }
+  s->dTexels.clear(); s->dTextures.release();
   s->dMaterials.release(); s->dSphere.release(); s->dDistant.release(); s->dRect.release(); s->dDisk.release();
   s->slots.release(); s->sampleBuf.release(); s->accum.release();
   for (uint32_t q = 0; q < Q_COUNT; q++) { s->qSlot[q].release(); s->qA[q].release(); s->qB[q].release(); s->qC[q].release(); }
@@ -363,6 +369,43 @@ void giCDestroyMaterial(GiCMaterial* mat)
     s->dirty |= DIRTY_MATERIALS | DIRTY_BVH | DIRTY_FRAMEBUFFER;
   }
   delete mat;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// textures [ext]: decoded pixels in, device copies made with the next scene build (TextureManager.cpp:100-275 minus imgio)
+// ---------------------------------------------------------------------------------------------------------------
+GiCTexture* giCCreateTexture(GiCScene* scene, const GiCTextureDesc* desc)
+{
+  if (!scene || !desc || !desc->rgba || desc->width == 0 || desc->height == 0) { setError("giCCreateTexture: bad arguments"); return nullptr; }
+  auto* t = new GiCTexture{scene, desc->width, desc->height, std::vector<float>(desc->rgba, desc->rgba + (size_t)desc->width * desc->height * 4)};
+  std::lock_guard<std::mutex> g(scene->mutex);
+  scene->textures.push_back(t);
+  scene->dirty |= DIRTY_MATERIALS | DIRTY_FRAMEBUFFER;
+  return t;
+}
+
+void giCDestroyTexture(GiCTexture* tex)
+{
+  if (!tex) return;
+  GiCScene* s = tex->scene;
+  {
+    std::lock_guard<std::mutex> g(s->mutex);
+    s->textures.erase(std::remove(s->textures.begin(), s->textures.end(), tex), s->textures.end());
+    for (GiCMaterial* m : s->materials) for (auto& b : m->tex) if (b.texture == tex) b.texture = nullptr;
+    s->dirty |= DIRTY_MATERIALS | DIRTY_BVH | DIRTY_FRAMEBUFFER;
+  }
+  delete tex;
+}
+
+int giCSetMaterialTexture(GiCMaterial* mat, int32_t input, const GiCTextureBinding* binding)
+{
+  if (!mat || input < 0 || input >= GI_C_TEX_SLOT_COUNT) { setError("giCSetMaterialTexture: bad arguments"); return GI_C_ERROR; }
+  if (binding && binding->texture && binding->texture->scene != mat->scene) { setError("giCSetMaterialTexture: texture belongs to another scene"); return GI_C_ERROR; }
+  if (binding && (binding->wrapS < 0 || binding->wrapS > 3 || binding->wrapT < 0 || binding->wrapT > 3)) { setError("giCSetMaterialTexture: bad wrap mode"); return GI_C_ERROR; }
+  std::lock_guard<std::mutex> g(mat->scene->mutex);
+  if (binding) mat->tex[input] = *binding; else mat->tex[input] = GiCTextureBinding{};
+  mat->scene->dirty |= DIRTY_MATERIALS | DIRTY_BVH | DIRTY_FRAMEBUFFER;
+  return GI_C_OK;
 }
 
 GiCMesh* giCCreateMesh(GiCScene* scene, const GiCMeshDesc* d)
@@ -553,14 +596,96 @@ void giCSetDiskLightBaseEmission(GiCDiskLight* l, const float* c) { memcpy(l->sc
 void giCSetDiskLightRadius(GiCDiskLight* l, float rx, float ry) { DiskLightRec& r = l->scene->diskLights.recs[l->index]; r.rx = rx; r.ry = ry; LIGHT_DIRTY(l); }
 void giCSetDiskLightDiffuseSpecular(GiCDiskLight* l, float d, float s) { l->scene->diskLights.recs[l->index].ds = packHalf2x16(d, s); LIGHT_DIRTY(l); }
 
+
+// Minimal decoders for dome-light images: Radiance .hdr (RGBE, flat or new-style RLE scanlines, -Y +X orientation) and
+// .pfm (PF, little or big endian, rows bottom-up).  Output: float RGBA, row 0 = first image row (top).
+static bool loadHdrOrPfm(const char* path, uint32_t& w, uint32_t& h, std::vector<float>& out)
+{
+  FILE* f = fopen(path, "rb");
+  if (!f) return false;
+  std::vector<uint8_t> d;
+  { uint8_t buf[65536]; size_t n; while ((n = fread(buf, 1, sizeof(buf), f)) > 0) d.insert(d.end(), buf, buf + n); }
+  fclose(f);
+  size_t pos = 0;
+  auto line = [&]() { std::string l; while (pos < d.size() && d[pos] != '\n') l.push_back((char)d[pos++]); if (pos < d.size()) pos++; return l; };
+  if (d.size() > 2 && d[0] == 'P' && d[1] == 'F') { // PFM
+    line();
+    int iw = 0, ih = 0; { std::string l = line(); if (sscanf(l.c_str(), "%d %d", &iw, &ih) != 2) { std::string l2 = line(); iw = atoi(l.c_str()); ih = atoi(l2.c_str()); } }
+    const float scale = (float)atof(line().c_str());
+    if (iw <= 0 || ih <= 0 || pos + (size_t)iw * ih * 12 > d.size()) return false;
+    w = (uint32_t)iw; h = (uint32_t)ih; out.assign((size_t)w * h * 4, 1.0f);
+    for (uint32_t y = 0; y < h; y++)
+      for (uint32_t x = 0; x < w; x++)
+        for (int c = 0; c < 3; c++) {
+          uint8_t b[4]; memcpy(b, &d[pos + (((size_t)y * w + x) * 3 + c) * 4], 4);
+          if (scale > 0.0f) std::swap(b[0], b[3]), std::swap(b[1], b[2]); // positive scale = big endian
+          float v; memcpy(&v, b, 4);
+          out[((size_t)(h - 1 - y) * w + x) * 4 + c] = v;
+        }
+    return true;
+  }
+  std::string first = line();
+  if (first.rfind("#?", 0) != 0) return false;
+  for (;;) { std::string l = line(); if (l.empty()) break; if (pos >= d.size()) return false; }
+  int ih = 0, iw = 0; { std::string l = line(); if (sscanf(l.c_str(), "-Y %d +X %d", &ih, &iw) != 2) return false; }
+  if (iw <= 0 || ih <= 0) return false;
+  w = (uint32_t)iw; h = (uint32_t)ih; out.assign((size_t)w * h * 4, 1.0f);
+  std::vector<uint8_t> scan((size_t)w * 4);
+  for (uint32_t y = 0; y < h; y++) {
+    if (pos + 4 <= d.size() && d[pos] == 2 && d[pos + 1] == 2 && (((uint32_t)d[pos + 2] << 8) | d[pos + 3]) == w && w >= 8 && w < 32768) {
+      pos += 4;
+      for (int c = 0; c < 4; c++) {
+        uint32_t x = 0;
+        while (x < w) {
+          if (pos >= d.size()) return false;
+          uint8_t n = d[pos++];
+          if (n > 128) { n -= 128; if (pos >= d.size() || x + n > w) return false; uint8_t v = d[pos++]; for (uint8_t k = 0; k < n; k++) scan[(size_t)(x++) * 4 + c] = v; }
+          else { if (n == 0 || pos + n > d.size() || x + n > w) return false; for (uint8_t k = 0; k < n; k++) scan[(size_t)(x++) * 4 + c] = d[pos++]; }
+        }
+      }
+    } else {
+      if (pos + (size_t)w * 4 > d.size()) return false;
+      memcpy(scan.data(), &d[pos], (size_t)w * 4); pos += (size_t)w * 4;
+    }
+    for (uint32_t x = 0; x < w; x++) {
+      const uint8_t* p4 = &scan[(size_t)x * 4];
+      const float sc = p4[3] ? ldexpf(1.0f, (int)p4[3] - 136) : 0.0f;
+      float* o = &out[((size_t)y * w + x) * 4];
+      o[0] = (float)p4[0] * sc; o[1] = (float)p4[1] * sc; o[2] = (float)p4[2] * sc;
+    }
+  }
+  return true;
+}
+
 GiCDomeLight* giCCreateDomeLight(GiCScene* scene, const char* filePath)
 {
   if (!scene) return nullptr;
-  std::lock_guard<std::mutex> g(scene->mutex);
   auto* l = new GiCDomeLight(); l->scene = scene; l->filePath = filePath ? filePath : "";
+  // the reference decodes the file through imgio (Gi.cpp:2215-2230); here: Radiance RGBE and PFM, anything else stays unloaded
+  uint32_t w = 0, h = 0; std::vector<float> px;
+  if (!l->filePath.empty() && loadHdrOrPfm(l->filePath.c_str(), w, h, px)) {
+    GiCTextureDesc td{w, h, px.data()};
+    l->texture = giCCreateTexture(scene, &td);
+    l->ownsTexture = l->texture != nullptr;
+  } else if (!l->filePath.empty()) {
+    fprintf(stderr, "[gatling_gi] unable to load dome light texture at '%s' (only .hdr / .pfm are decoded in-library)\n", l->filePath.c_str());
+  }
   return l;
 }
-void giCDestroyDomeLight(GiCDomeLight* l) { if (!l) return; std::lock_guard<std::mutex> g(l->scene->mutex); delete l; }
+void giCDestroyDomeLight(GiCDomeLight* l)
+{
+  if (!l) return;
+  if (l->ownsTexture) giCDestroyTexture(l->texture);
+  std::lock_guard<std::mutex> g(l->scene->mutex);
+  l->scene->dirty |= DIRTY_FRAMEBUFFER;
+  delete l;
+}
+void giCSetDomeLightTexture(GiCDomeLight* l, GiCTexture* t)
+{
+  if (!l) return;
+  if (l->ownsTexture) { giCDestroyTexture(l->texture); l->ownsTexture = false; }
+  l->texture = t; l->scene->dirty |= DIRTY_FRAMEBUFFER;
+}
 void giCSetDomeLightRotation(GiCDomeLight* l, const float* q) { memcpy(l->rotation, q, 16); l->scene->dirty |= DIRTY_FRAMEBUFFER; }
 void giCSetDomeLightBaseEmission(GiCDomeLight* l, const float* c) { memcpy(l->baseEmission, c, 12); l->scene->dirty |= DIRTY_FRAMEBUFFER; }
 void giCSetDomeLightDiffuseSpecular(GiCDomeLight* l, float d, float s) { l->diffuse = d; l->specular = s; l->scene->dirty |= DIRTY_FRAMEBUFFER; }
@@ -668,12 +793,23 @@ int buildScene(GiCScene* s)
   std::vector<FVertex> verts; std::vector<InstanceRec> instances; std::vector<TriRec> tris; std::vector<int32_t> faceIdOf;
   std::vector<MaterialRec> mats(s->materials.size());
   for (size_t i = 0; i < s->materials.size(); i++) {
-    mats[i].klass = s->materials[i]->desc.klass; mats[i].flags = s->materials[i]->desc.flags;
+    mats[i].klass = s->materials[i]->desc.klass; mats[i].flags = s->materials[i]->desc.flags & ~MAT_FLAG_TEXTURED;
+    for (uint32_t slot = 0; slot < TEX_SLOT_COUNT; slot++) {
+      const GiCTextureBinding& b = s->materials[i]->tex[slot];
+      TexBindingRec& r = mats[i].tex[slot];
+      r = TexBindingRec{};
+      auto tit = b.texture ? std::find(s->textures.begin(), s->textures.end(), b.texture) : s->textures.end();
+      if (tit == s->textures.end()) continue;
+      r.tex = (uint32_t)(tit - s->textures.begin()) + 1u;
+      r.mode = (uint32_t)b.wrapS | ((uint32_t)b.wrapT << 8) | (((uint32_t)b.channel & 3u) << 16);
+      memcpy(r.scale, b.scale, 16); memcpy(r.bias, b.bias, 16);
+      mats[i].flags |= MAT_FLAG_TEXTURED;
+    }
     memcpy(mats[i].p, s->materials[i]->desc.p, sizeof(float) * MAT_PARAM_COUNT);
     deriveMaterialConstants(mats[i]);
   }
   uint32_t meshIdx = 0;
-  s->classMask = 0; s->hasCutouts = false;
+  s->classMask = 0; s->hasCutouts = false; s->classTextured = 0;
   for (GiCMesh* m : s->meshes) {
     if (!m->visible) continue; // Gi.cpp:801-804
     if (m->faces.empty()) continue;
@@ -685,6 +821,7 @@ int buildScene(GiCScene* s)
     if (cutoutMat) s->hasCutouts = true;
     const uint32_t matFlags = material | ((mats[material].klass & 0xfu) << 24) | (cutoutMat ? (1u << 28) : 0u) | (((m->flipFacing ? 1u : 0u) | (m->doubleSided ? 2u : 0u)) << 30);
     s->classMask |= 1u << (mats[material].klass & 0xfu);
+    if (mats[material].flags & MAT_FLAG_TEXTURED) s->classTextured |= 1u << (mats[material].klass & 0xfu);
     const uint32_t vertexOffset = (uint32_t)verts.size();
     for (const GiCVertex& v : m->vertices) { // Gi.cpp:848-861: quantise normal/tangent to octahedral unorm2x16, then decode once
       FVertex fv; memcpy(fv.pos, v.pos, 12); fv.bsign = v.bitangentSign;
@@ -737,6 +874,18 @@ int buildScene(GiCScene* s)
   std::vector<int32_t> triFaceId(bvh.tris.size());
   for (size_t i = 0; i < bvh.tris.size(); i++) triFaceId[i] = faceIdOf[bvh.tris[i].origId];
   if (s->dTriFaceId.upload(triFaceId, st)) return GI_C_ERROR;
+  { // textures: one device array per image + the TextureRec table
+    for (auto* b : s->dTexels) { b->release(); delete b; }
+    s->dTexels.clear();
+    std::vector<TextureRec> recs(s->textures.size());
+    for (size_t i = 0; i < s->textures.size(); i++) {
+      auto* b = new DeviceBuffer<float>();
+      s->dTexels.push_back(b);
+      if (b->upload(s->textures[i]->rgba, st)) return GI_C_ERROR;
+      recs[i] = TextureRec{b->ptr, s->textures[i]->width, s->textures[i]->height};
+    }
+    if (s->dTextures.upload(recs, st)) return GI_C_ERROR;
+  }
   // Scenes whose BVH lives in global memory keep one node per 128-byte line (an 80-byte node at an 80-byte stride straddles
   // two lines half of the time: one more L2 request per node visit); small scenes are staged in LDS anyway.
   bool lineNodes = bvh.nodes.size() > 384;
@@ -773,6 +922,7 @@ bool settingsEqual(const GiCRenderSettings& a, const GiCRenderSettings& b) { ret
 SceneView makeView(GiCScene* s)
 {
   SceneView v{};
+  v.textures = s->dTextures.ptr;
   v.nodes = s->nodeStrideU4 == 8u ? reinterpret_cast<const Node8*>(s->dNodesLine.ptr) : s->dNodes.ptr; v.nodeStrideU4 = s->nodeStrideU4; v.tris = s->dTris.ptr; v.instances = s->dInstances.ptr;
   v.verts = s->dVerts.ptr; v.materials = s->dMaterials.ptr; v.sphereLights = s->dSphere.ptr; v.distantLights = s->dDistant.ptr;
   v.rectLights = s->dRect.ptr; v.diskLights = s->dDisk.ptr; v.triFaceId = s->dTriFaceId.ptr; v.nodeCount = s->nodeCount; v.triCount = s->triCount; v.bvhDepth = s->bvhDepth; v.hasCutouts = s->hasCutouts ? 1u : 0u;
@@ -948,7 +1098,6 @@ extern "C" int giCRender(const GiCRenderParams* params)
     for (int a = 0; a < 3; a++) { // fallback dome texel: glm::u8vec4(bg * 255) as RGBA8 unorm (Gi.cpp:2194-2199)
       int q = (int)(cv[a] * 255.0f); if (q < 0) q = 0; if (q > 255) q &= 255;
       U.background[a] = (float)q / 255.0f;
-      if (params->domeLight) U.background[a] = params->domeLight->baseEmission[a]; // uniform dome: colour x emission multiplier (rp_main.miss:82-83)
     }
     U.exposureScale = exp2f(c.exposure);
     U.spp = rs.spp; U.sampleOffset = s->sampleOffset; U.invSpp = 1.0f / (float)rs.spp; U.sppF = (float)rs.spp; U.sampleOffsetF = (float)s->sampleOffset;
@@ -971,6 +1120,14 @@ extern "C" int giCRender(const GiCRenderParams* params)
   const bool timers = s->kernelTimers;
   uint64_t sampledIters = 0, totalIters = 0;
   SceneView view = makeView(s);
+  { // dome light (Gi.cpp:2201-2238, 2384-2396): an image-less dome light is ignored, like one whose file failed to load
+    const GiCDomeLight* dl = params->domeLight;
+    auto tit = (dl && dl->texture) ? std::find(s->textures.begin(), s->textures.end(), dl->texture) : s->textures.end();
+    view.domeTexture = tit != s->textures.end() ? (uint32_t)(tit - s->textures.begin()) + 1u : 0u;
+    view.domeCameraVisible = rs.domeLightCameraVisible ? 1u : 0u;
+    for (int a = 0; a < 4; a++) view.domeRotation[a] = dl ? dl->rotation[a] : (a == 3 ? 1.0f : 0.0f);
+    for (int a = 0; a < 3; a++) { view.domeEmission[a] = dl ? dl->baseEmission[a] : 1.0f; view.background[a] = U.background[a]; }
+  }
   if (ensurePathState(s, 1, 1, 1) != GI_C_OK) return GI_C_ERROR; // counters / pinned mirror exist even for AOV-only renders
   if (colorRb) {
     // --- work decomposition (DESIGN.md "Persistent path pool"): work item = (pixel, sample); the frame is cut into batches of
@@ -1046,7 +1203,7 @@ extern "C" int giCRender(const GiCRenderParams* params)
         timed(1, [&] { launchTrace(st, traceBlocks, false, s->countTraversal, view, ps, qs, s->dCounters.ptr, Q_TRACE_A + par, Q_REGEN_A + (par ^ 1u), dynRefill, wideBlocks); });
         traceLaunches++;
         for (uint32_t klass = 0; klass < MAT_CLASS_COUNT; klass++)
-          if (s->classMask & (1u << klass)) timed(2, [&] { launchShade(st, wideBlocks, klass, U, view, ps, qs, s->dCounters.ptr, par); });
+          if (s->classMask & (1u << klass)) timed(2, [&] { launchShade(st, wideBlocks, klass, (s->classTextured & (1u << klass)) != 0u, U, view, ps, qs, s->dCounters.ptr, par); });
         if (nee) timed(3, [&] { launchTrace(st, traceBlocks, true, s->countTraversal, view, ps, qs, s->dCounters.ptr, Q_SHADOW, Q_SHADOW, dynRefill, wideBlocks); });
         iters++; totalIters++;
       }
@@ -1214,7 +1371,7 @@ extern "C" int giCDebugEvalBsdf(const GiCMaterialDesc* desc, uint32_t count, con
 {
   if (!g_ctx.initialized || !desc || (count && (!in || !out))) { setError("giCDebugEvalBsdf: bad arguments"); return GI_C_ERROR; }
   if (count == 0) return GI_C_OK;
-  MaterialRec m; m.klass = desc->klass; m.flags = desc->flags; memcpy(m.p, desc->p, sizeof(m.p));
+  MaterialRec m{}; m.klass = desc->klass; m.flags = desc->flags & ~MAT_FLAG_TEXTURED; memcpy(m.p, desc->p, sizeof(m.p));
   deriveMaterialConstants(m);
   MaterialRec* dm = nullptr; float* din = nullptr; float* dout = nullptr;
   hipStream_t st = g_ctx.stream;

@@ -94,6 +94,41 @@ __device__ __forceinline__ float gi_expf(float x)
   return y * u2f((uint32_t)((int)fx + 127) << 23);
 }
 
+// atan2 / acos for the equirectangular dome lookup (rp_main.miss:46-53): Cephes atanf / asinf kernels, plain mul/add
+__device__ __forceinline__ float gi_atanf(float xx)
+{
+  float x = fabsf(xx), y;
+  if (x > 2.414213562373095f) { y = 1.5707963267948966f; x = -(1.0f / x); }
+  else if (x > 0.4142135623730950f) { y = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }
+  else y = 0.0f;
+  float z = x * x;
+  y = y + ((((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x);
+  return xx < 0.0f ? -y : y;
+}
+__device__ __forceinline__ float gi_atan2f(float y, float x)
+{
+  if (x == 0.0f) return y > 0.0f ? 1.5707963267948966f : (y < 0.0f ? -1.5707963267948966f : 0.0f);
+  float z = gi_atanf(y / x);
+  if (x < 0.0f) z = z + (y >= 0.0f ? 3.14159265358979323846f : -3.14159265358979323846f);
+  return z;
+}
+__device__ __forceinline__ float gi_asinf(float xx)
+{
+  float a = fabsf(xx), x, z; bool flag = false;
+  if (a > 0.5f) { z = 0.5f * (1.0f - a); x = sqrtf(z); flag = true; }
+  else { x = a; z = x * x; }
+  z = ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z + 1.6666752422e-1f) * z * x + x;
+  if (flag) { z = z + z; z = 1.5707963267948966f - z; }
+  return xx < 0.0f ? -z : z;
+}
+__device__ __forceinline__ float gi_acosf(float x)
+{
+  x = fmin2(fmax2(x, -1.0f), 1.0f);
+  if (x < -0.5f) return 3.14159265358979323846f - 2.0f * gi_asinf(sqrtf(0.5f * (1.0f + x)));
+  if (x > 0.5f) return 2.0f * gi_asinf(sqrtf(0.5f * (1.0f - x)));
+  return 1.5707963267948966f - gi_asinf(x);
+}
+
 // half -> float (exact), for the packed diffuse/specular light multipliers (rp_main.chit:431)
 __device__ __forceinline__ float gi_half_to_float(uint32_t h)
 {

@@ -593,7 +593,12 @@ __device__ __forceinline__ bool traverse(const SceneView& sc, const uint4* s_nod
   return R.found;
 }
 
-template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool ALL_LDS, bool CUTOUT>
+// rp_main.miss:55-86 for scenes with a dome light image (defined with the texture runtime below): adds
+// throughput * dome(direction) to the slot's radiance.  Without a dome image the miss term is the constant fallback dome,
+// which k_raygen applies when it retires the path (REGEN_MISSED).
+__device__ void dome_miss(const SceneView& sc, Slot* S, V3 rayDir);
+
+template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool ALL_LDS, bool CUTOUT, bool DOME>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t qMiss, uint32_t ldsNodes, uint32_t ldsTris)
 {
   // dynamic LDS, sized by the launch to what this scene actually stages: [stack | nodes | triangles]
@@ -663,7 +668,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
         st4(&qs.a[q][r], t, u, v, u2f(tri));
         st4(&qs.b[q][r], rdir.x, rdir.y, rdir.z, 0.0f);
       }
-      if (miss) qs.slot[qMiss][idx[0]] = slot | REGEN_MISSED;
+      if (miss) {
+        if (DOME) { dome_miss(sc, &st.slots[slot], v3(rdir.x, rdir.y, rdir.z)); qs.slot[qMiss][idx[0]] = slot; } // scene has a dome light image
+        else qs.slot[qMiss][idx[0]] = slot | REGEN_MISSED;
+      }
     }
   }
   if (COUNT) { // measurement builds only: one atomic pair per wave
@@ -769,7 +777,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 
 }
 
 // k_route: sorts k_trace_dyn's in-place results by outcome and material class (same routing as k_trace's epilogue)
-__global__ __launch_bounds__(BLOCK) void k_route(QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t qMiss)
+__global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t qMiss)
 {
   __shared__ AppendScratch<1 + MAT_CLASS_COUNT> sh;
   QueueReader rd; reader_init(rd, cnt, qIn, qs.cap);
@@ -799,14 +807,22 @@ __global__ __launch_bounds__(BLOCK) void k_route(QueueSet qs, Counters* cnt, uin
       st4(&qs.a[q][r], h.x, h.y, h.z, h.w);
       st4(&qs.b[q][r], rdir.x, rdir.y, rdir.z, 0.0f);
     }
-    if (miss) qs.slot[qMiss][idx[0]] = slot | REGEN_MISSED;
+    if (miss) {
+      if (sc.domeTexture) { dome_miss(sc, &st.slots[slot], v3(rdir.x, rdir.y, rdir.z)); qs.slot[qMiss][idx[0]] = slot; }
+      else qs.slot[qMiss][idx[0]] = slot | REGEN_MISSED;
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // Shading state (mdl_shading_state.glsl:4-98) from flat scene buffers
 // ------------------------------------------------------------------------------------------------
-struct ShState { V3 normal, geomNormal, position, tangentU, tangentV; bool frontFace; uint32_t meshFlags, material; };
+struct ShState {
+  V3 normal, geomNormal, position, tangentU, tangentV; bool frontFace; uint32_t meshFlags, material;
+  float u, v;                    // texture coordinate 0 (mdl_shading_state.glsl:62-65)
+  uint32_t texMask;              // bit per TEX_* slot whose value below replaces the material constant at this hit
+  V3 texBaseColor, texEmission; float texRoughness, texMetallic;
+};
 
 __device__ __forceinline__ V3 xform_point(const float* a, V3 p, float w)
 {
@@ -852,7 +868,118 @@ __device__ __forceinline__ void setup_shading_state(const SceneView& sc, uint32_
   tg = normalize(tg - nrm * dot(tg, nrm));                                            // :56
   const float bs = (bx * a1.w + by * b1.w) + bz * c1.w;                               // :58
   s.tangentU = tg; s.tangentV = cross(nrm, tg) * bs;                                  // :59
+  s.u = (bx * a2.w + by * b2.w) + bz * c2.w; s.v = (bx * a3.w + by * b3.w) + bz * c3.w; // :62-65
   s.normal = nrm; s.geomNormal = gn;
+  s.texMask = 0u; s.texBaseColor = v3(0.0f, 0.0f, 0.0f); s.texEmission = s.texBaseColor; s.texRoughness = 0.0f; s.texMetallic = 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Texture runtime (mdl_interface.glsl:8-38 apply_wrap_and_crop, :127-145 tex_lookup_float4_2d) over a software sampler:
+// bilinear, REPEAT addressing, LOD 0 (the reference's single sampler, Gi.cpp:388-392, CgpuVk.cpp:1985-1990).
+// Operation order == oracle sample_bilinear_repeat / tex_lookup_float4_2d.
+// ------------------------------------------------------------------------------------------------
+__device__ inline F4 sample_bilinear_repeat(const TextureRec& t, float u, float v)
+{
+  u = u - floorf(u); v = v - floorf(v);
+  const float x = u * (float)t.width - 0.5f, y = v * (float)t.height - 0.5f;
+  const float x0f = floorf(x), y0f = floorf(y);
+  const float fx = x - x0f, fy = y - y0f;
+  const int w = (int)t.width, h = (int)t.height;
+  int ix0 = (int)x0f, iy0 = (int)y0f;
+  if (ix0 < 0) ix0 += w;
+  if (iy0 < 0) iy0 += h;
+  int ix1 = ix0 + 1; if (ix1 >= w) ix1 -= w;
+  int iy1 = iy0 + 1; if (iy1 >= h) iy1 -= h;
+  const F4* tx = reinterpret_cast<const F4*>(t.texels);
+  const F4 t00 = ld4(&tx[(size_t)iy0 * w + ix0]), t10 = ld4(&tx[(size_t)iy0 * w + ix1]);
+  const F4 t01 = ld4(&tx[(size_t)iy1 * w + ix0]), t11 = ld4(&tx[(size_t)iy1 * w + ix1]);
+  const float gx = 1.0f - fx, gy = 1.0f - fy;
+  F4 o;
+  o.x = (t00.x * gx + t10.x * fx) * gy + (t01.x * gx + t11.x * fx) * fy;
+  o.y = (t00.y * gx + t10.y * fx) * gy + (t01.y * gx + t11.y * fx) * fy;
+  o.z = (t00.z * gx + t10.z * fx) * gy + (t01.z * gx + t11.z * fx) * fy;
+  o.w = (t00.w * gx + t10.w * fx) * gy + (t01.w * gx + t11.w * fx) * fy;
+  return o;
+}
+__device__ __forceinline__ float apply_wrap_and_crop(float coord, uint32_t wrap, uint32_t res) // crop = (0, 1)
+{
+  if (wrap == TEX_WRAP_REPEAT) coord = coord - floorf(coord);
+  else {
+    if (wrap == TEX_WRAP_MIRRORED_REPEAT) {
+      const float tmp = floorf(coord);
+      if (((int)tmp & 1) != 0) coord = 1.0f - (coord - tmp); else coord = coord - tmp;
+    }
+    const float inv_hdim = 0.5f / (float)res;
+    coord = fmin2(fmax2(coord, inv_hdim), 1.0f - inv_hdim);
+  }
+  return coord;
+}
+__device__ inline F4 tex_lookup_float4_2d(const TextureRec& t, float u, float v, uint32_t wrapU, uint32_t wrapV)
+{
+  if ((wrapU == TEX_WRAP_CLIP && (u < 0.0f || u > 1.0f)) || (wrapV == TEX_WRAP_CLIP && (v < 0.0f || v > 1.0f))) return F4{0.0f, 0.0f, 0.0f, 0.0f};
+  u = apply_wrap_and_crop(u, wrapU, t.width);
+  v = apply_wrap_and_crop(v, wrapV, t.height);
+  return sample_bilinear_repeat(t, u, v);
+}
+// mdl_adapt_normal (mdl_interface.glsl:238-256): Iray's shadow-terminator bend of a mapped normal
+__device__ __forceinline__ V3 adapt_normal(V3 rayDir, V3 geomNormal, V3 normal)
+{
+  const float dn = dot(rayDir, normal);
+  const V3 r = normalize(rayDir - normal * (2.0f * dn));
+  const float a = fmax2(0.0f, dot(r, -geomNormal));
+  const float b = dot(normal, geomNormal);
+  const V3 tangent = normalize(r + normal * (a / b));
+  return normalize(-rayDir + tangent);
+}
+// Evaluates the material's textured inputs at the hit (== oracle resolve_material); a normal map replaces the shading frame.
+__device__ inline void resolve_material_textures(const SceneView& sc, const MaterialRec* m, V3 rayDir, ShState& st)
+{
+#pragma unroll
+  for (uint32_t slot = 0; slot < TEX_SLOT_COUNT; slot++) {
+    const TexBindingRec& b = m->tex[slot];
+    if (b.tex == 0u) continue;
+    const F4 t = tex_lookup_float4_2d(sc.textures[b.tex - 1u], st.u, st.v, b.mode & 0xffu, (b.mode >> 8) & 0xffu);
+    const float val[4] = {t.x * b.scale[0] + b.bias[0], t.y * b.scale[1] + b.bias[1], t.z * b.scale[2] + b.bias[2], t.w * b.scale[3] + b.bias[3]};
+    const uint32_t ch = (b.mode >> 16) & 3u;
+    const float sel = ch == 0u ? val[0] : (ch == 1u ? val[1] : (ch == 2u ? val[2] : val[3]));
+    st.texMask |= 1u << slot;
+    if (slot == TEX_BASE_COLOR) st.texBaseColor = v3(val[0], val[1], val[2]);
+    else if (slot == TEX_EMISSION) st.texEmission = v3(val[0], val[1], val[2]);
+    else if (slot == TEX_ROUGHNESS) st.texRoughness = sel;
+    else if (slot == TEX_METALLIC) st.texMetallic = sel;
+    else {
+      V3 n = normalize((st.tangentU * val[0] + st.tangentV * val[1]) + st.normal * val[2]);
+      n = adapt_normal(rayDir, st.geomNormal, n);
+      const float hs = dot(cross(st.normal, st.tangentU), st.tangentV) >= 0.0f ? 1.0f : -1.0f;
+      const V3 tg = normalize(st.tangentU - n * dot(st.tangentU, n));
+      st.normal = n; st.tangentU = tg; st.tangentV = cross(n, tg) * hs;
+    }
+  }
+}
+
+__device__ __forceinline__ V3 quat_rotate_dir(const float* q, V3 dir) // rp_main.miss:38-44
+{
+  const V3 qv = v3(q[0], q[1], q[2]);
+  const V3 a = cross(qv, dir);
+  const V3 b = cross(qv, a);
+  return dir + ((a * q[3]) + b) * 2.0f;
+}
+__device__ void dome_miss(const SceneView& sc, Slot* S, V3 rayDir)
+{
+  const F4 tb = ld4(&S->thr);
+  const F4 rr = ld4(&S->rad);
+  const bool isPrimaryRay = (f2u(tb.w) & 0x00000fffu) == 0u;
+  const bool useFallback = !sc.domeCameraVisible && isPrimaryRay; // :76-80
+  V3 texel = v3(sc.background);
+  if (!useFallback) {
+    const V3 d = normalize(quat_rotate_dir(sc.domeRotation, rayDir)); // :83
+    const float u = (gi_atan2f(d.z, d.x) + 0.5f * GI_PI) / (2.0f * GI_PI); // :48-49
+    const float v = 1.0f - gi_acosf(d.y) / GI_PI;
+    const F4 t = sample_bilinear_repeat(sc.textures[sc.domeTexture - 1u], u, v);
+    texel = v3(t.x, t.y, t.z);
+  }
+  const V3 rad = v3(rr.x, rr.y, rr.z) + v3(tb.x, tb.y, tb.z) * (texel * v3(sc.domeEmission)); // :84-86
+  st4(&S->rad, rad.x, rad.y, rad.z, rr.w);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -915,12 +1042,24 @@ __device__ inline void ggx_eval(V3 l1, V3 l2, float alpha, float& fcos, float& p
 struct UpsParams { V3 albedo, F0; float alpha, coat, coatAlpha; };
 // per-material constants are evaluated once on the host (gi_c.cpp: deriveMaterialConstants) with the same fp32
 // formulas the oracle evaluates per hit
-__device__ __forceinline__ UpsParams ups_params(const MaterialRec* m)
+__device__ __forceinline__ UpsParams ups_params(const MaterialRec* m, const ShState& st)
 {
   UpsParams u;
   u.albedo = v3(m->p[MP_ALBEDO], m->p[MP_ALBEDO + 1], m->p[MP_ALBEDO + 2]);
   u.F0 = v3(m->p[MP_F0], m->p[MP_F0 + 1], m->p[MP_F0 + 2]);
   u.alpha = m->p[MP_ALPHA]; u.coat = m->p[MP_COAT]; u.coatAlpha = m->p[MP_COAT_ALPHA];
+  if (st.texMask & ((1u << TEX_BASE_COLOR) | (1u << TEX_ROUGHNESS) | (1u << TEX_METALLIC))) { // textured inputs: the oracle's per-hit formulas
+    const V3 dc = (st.texMask & (1u << TEX_BASE_COLOR)) ? st.texBaseColor : v3(m->p[0], m->p[1], m->p[2]);
+    const float r = (st.texMask & (1u << TEX_ROUGHNESS)) ? st.texRoughness : m->p[11];
+    u.alpha = fmax2(r * r, 0.001f);
+    if (m->p[6] != 0.0f) { u.F0 = v3(m->p[7], m->p[8], m->p[9]); u.albedo = dc; }
+    else {
+      const float ior = m->p[16], metal = (st.texMask & (1u << TEX_METALLIC)) ? st.texMetallic : m->p[10];
+      const float q = (1.0f - ior) / (1.0f + ior), f0 = q * q;
+      u.F0 = v3(f0, f0, f0) * (1.0f - metal) + dc * metal;
+      u.albedo = dc * (1.0f - metal);
+    }
+  }
   return u;
 }
 
@@ -949,7 +1088,7 @@ __device__ __forceinline__ V3 schlick_f82(V3 F0, V3 tint, float c)
   return v3(fmin2(fmax2(f.x, 0.0f), 1.0f), fmin2(fmax2(f.y, 0.0f), 1.0f), fmin2(fmax2(f.z, 0.0f), 1.0f));
 }
 struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint; float metalness, alpha, coat, coatAlpha, coatF0, eta, tw, specWeight; };
-__device__ __forceinline__ OpbrParams opbr_params(const MaterialRec* m)
+__device__ __forceinline__ OpbrParams opbr_params(const MaterialRec* m, const ShState& st)
 {
   OpbrParams o; const float* p = m->p;
   o.albedo = v3(p[MP_ALBEDO], p[MP_ALBEDO + 1], p[MP_ALBEDO + 2]);
@@ -960,12 +1099,15 @@ __device__ __forceinline__ OpbrParams opbr_params(const MaterialRec* m)
   o.coatTint = v3(1.0f, 1.0f, 1.0f) * (1.0f - o.coat) + v3(p[19], p[20], p[21]) * o.coat;
   o.tw = p[23];
   o.transTint = (p[28] > 0.0f) ? v3(1.0f, 1.0f, 1.0f) : v3(p[24], p[25], p[26]);
+  if (st.texMask & (1u << TEX_BASE_COLOR)) o.albedo = st.texBaseColor * p[17];
+  if (st.texMask & (1u << TEX_ROUGHNESS)) o.alpha = fmax2(st.texRoughness * st.texRoughness, 0.001f);
+  if (st.texMask & (1u << TEX_METALLIC)) o.metalness = st.texMetallic;
   return o;
 }
 
 __device__ inline void opbr_sample(const MaterialRec* m, const ShState& st, V3 k1, float x0, float x1, float x2, BsdfSample& out)
 {
-  OpbrParams o = opbr_params(m);
+  OpbrParams o = opbr_params(m, st);
   V3 l1 = to_local(st, k1);
   float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
   float z = x2;
@@ -1030,7 +1172,7 @@ __device__ inline void opbr_sample(const MaterialRec* m, const ShState& st, V3 k
 
 __device__ inline void opbr_evaluate(const MaterialRec* m, const ShState& st, V3 k1, V3 k2, BsdfEval& out)
 {
-  OpbrParams o = opbr_params(m);
+  OpbrParams o = opbr_params(m, st);
   V3 l1 = to_local(st, k1), l2 = to_local(st, k2);
   float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
   float eta = st.frontFace ? o.eta : 1.0f / o.eta;
@@ -1065,7 +1207,7 @@ __device__ inline void bsdf_sample(const MaterialRec* m, const ShState& st, V3 k
     return;
   }
   if (klass == 1u) {
-    UpsParams u = ups_params(m);
+    UpsParams u = ups_params(m, st);
     V3 l1 = to_local(st, k1);
     float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
     float z = x2;
@@ -1114,7 +1256,7 @@ __device__ inline void bsdf_evaluate(const MaterialRec* m, const ShState& st, V3
     return;
   }
   if (klass == 1u) {
-    UpsParams u = ups_params(m);
+    UpsParams u = ups_params(m, st);
     V3 l1 = to_local(st, k1), l2 = to_local(st, k2);
     float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
     float Fc = u.coat * (0.04f + 0.96f * schlick_w(nk1));
@@ -1203,7 +1345,7 @@ __device__ inline void sample_light(const SceneView& sc, const FrameUniforms& U,
 // k_shade: closest-hit shading + the post-trace part of the bounce loop, over the HIT queue only
 // (rp_main.chit:132-493, rp_main.rgen:397-480).  Misses never get here (k_trace routes them to k_raygen).
 // ------------------------------------------------------------------------------------------------
-template <uint32_t KLASS>
+template <uint32_t KLASS, bool TEXTURED>
 __global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t par)
 {
   __shared__ AppendScratch<3> sh;
@@ -1232,6 +1374,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, 
       ShState ss;
       setup_shading_state(sc, f2u(h.w), h.y, h.z, rayDir, ss);
       const MaterialRec* mat = &sc.materials[ss.material];
+      if (TEXTURED && (mat->flags & MAT_FLAG_TEXTURED)) resolve_material_textures(sc, mat, rayDir, ss); // else ss.texMask stays 0 and folds away
       const bool isDoubleSided = (ss.meshFlags & 2u) != 0u;
       // volume attenuation with an empty medium stack (rp_main.chit:160-186): inside (1-bit toggle) -> Beer-Lambert with the
       // HIT material's absorption coefficient (:169-173)
@@ -1241,7 +1384,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, 
         throughput = throughput * v3(gi_expf(-mat->p[MP_SIGMA_A] * distance), gi_expf(-mat->p[MP_SIGMA_A + 1] * distance), gi_expf(-mat->p[MP_SIGMA_A + 2] * distance));
       }
       // emission (rp_main.chit:293-343): uniform EDF, radiance == emission colour where cos > 0
-      const V3 em = v3(mat->p[3], mat->p[4], mat->p[5]);
+      const V3 em = (ss.texMask & (1u << TEX_EMISSION)) ? ss.texEmission : v3(mat->p[3], mat->p[4], mat->p[5]);
       if (em.x != 0.0f || em.y != 0.0f || em.z != 0.0f) {
         if (ss.frontFace || !isDoubleSided) {
           const float c = dot(-rayDir, ss.normal);
@@ -1323,14 +1466,14 @@ __device__ inline V3 bsdf_albedo(const MaterialRec* m, const ShState& st, V3 k1)
   float nk1 = fmax2(dot(st.normal, k1), 1e-4f);
   if (m->klass == 0u) return v3(m->p[0], m->p[1], m->p[2]);
   if (m->klass == 1u) {
-    UpsParams u = ups_params(m);
+    UpsParams u = ups_params(m, st);
     float Fc = u.coat * (0.04f + 0.96f * schlick_w(nk1));
     V3 Fs = schlick3(u.F0, nk1);
     V3 diffuse = (u.albedo * (v3(1.0f, 1.0f, 1.0f) - Fs)) * (1.0f - Fc);
     V3 glossy = v3(Fc, Fc, Fc) + Fs * (1.0f - Fc);
     return diffuse + glossy;
   }
-  OpbrParams o = opbr_params(m);
+  OpbrParams o = opbr_params(m, st);
   float eta = st.frontFace ? o.eta : 1.0f / o.eta;
   float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1));
   float Fd = fresnel_dielectric(nk1, eta);
@@ -1402,7 +1545,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_aov(FrameUniforms U, SceneView 
       curNormal = (prev * U.sampleOffsetF + pos * U.sppF) * U.invTotalSampleCount;
     }
     if (A.albedo) {
-      const V3 al = bsdf_albedo(&sc.materials[ss.material], ss, -dir);
+      const MaterialRec* am = &sc.materials[ss.material];
+      if (am->flags & MAT_FLAG_TEXTURED) resolve_material_textures(sc, am, dir, ss);
+      const V3 al = bsdf_albedo(am, ss, -dir);
       const V3 prev = blend ? curAlbedo : al;
       curAlbedo = (prev * U.sampleOffsetF + al * U.sppF) * U.invTotalSampleCount;
     }
@@ -1424,6 +1569,7 @@ __global__ void k_debug_bsdf(const MaterialRec* mat, uint32_t count, const float
   const float* p = in + 22 * (size_t)i; float* o = out + 15 * (size_t)i;
   ShState st; st.normal = v3(p); st.tangentU = v3(p + 3); st.tangentV = v3(p + 6); st.geomNormal = v3(p + 9);
   st.position = v3(0.0f, 0.0f, 0.0f); st.frontFace = (p[21] < 0.5f); st.meshFlags = 0u; st.material = 0u;
+  st.u = 0.0f; st.v = 0.0f; st.texMask = 0u;
   BsdfSample bs; bsdf_sample<KLASS_DYNAMIC>(mat, st, v3(p + 12), p[18], p[19], p[20], bs);
   BsdfEval ev; bsdf_evaluate<KLASS_DYNAMIC>(mat, st, v3(p + 12), v3(p + 15), ev);
   o[0] = bs.k2.x; o[1] = bs.k2.y; o[2] = bs.k2.z; o[3] = bs.overPdf.x; o[4] = bs.overPdf.y; o[5] = bs.overPdf.z; o[6] = bs.pdf; o[7] = (float)bs.event;
@@ -1473,14 +1619,19 @@ static void launchTraceVariant(hipStream_t s, uint32_t blocks, const SceneView& 
     else if (spill8) hipLaunchKernelGGL((k_trace_dyn<ANYHIT, COUNT, 8, true, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill);
     else if (sc.bvhDepth <= 16u) hipLaunchKernelGGL((k_trace_dyn<ANYHIT, COUNT, 16, false, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill);
     else hipLaunchKernelGGL((k_trace_dyn<ANYHIT, COUNT, 16, true, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill);
-    if (!ANYHIT) hipLaunchKernelGGL(k_route, dim3(routeBlocks), dim3(BLOCK), 0, s, qs, cnt, qIn, qMiss);
+    if (!ANYHIT) hipLaunchKernelGGL(k_route, dim3(routeBlocks), dim3(BLOCK), 0, s, sc, st, qs, cnt, qIn, qMiss);
     return;
   }
-  if (allLds && sc.bvhDepth <= 4u) hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 4, false, true, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
-  else if (allLds && sc.bvhDepth <= 8u) hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 8, false, true, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
-  else if (sc.bvhDepth <= 8u) hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 8, false, false, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
-  else if (sc.bvhDepth <= 16u) hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 16, false, false, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
-  else hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, 16, true, false, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt);
+  const bool dome = !ANYHIT && sc.domeTexture != 0u;
+#define GI_LAUNCH_TRACE(STACK, OVF, LDS) do { \
+    if (dome) hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, STACK, OVF, LDS, CUTOUT, !ANYHIT>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt); \
+    else hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, STACK, OVF, LDS, CUTOUT, false>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt); } while (0)
+  if (allLds && sc.bvhDepth <= 4u) GI_LAUNCH_TRACE(4, false, true);
+  else if (allLds && sc.bvhDepth <= 8u) GI_LAUNCH_TRACE(8, false, true);
+  else if (sc.bvhDepth <= 8u) GI_LAUNCH_TRACE(8, false, false);
+  else if (sc.bvhDepth <= 16u) GI_LAUNCH_TRACE(16, false, false);
+  else GI_LAUNCH_TRACE(16, true, false);
+#undef GI_LAUNCH_TRACE
 }
 template <bool ANYHIT, bool COUNT>
 static void launchTraceCutout(hipStream_t s, uint32_t blocks, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t qMiss,
@@ -1505,11 +1656,13 @@ void launchAov(hipStream_t s, const FrameUniforms& U, const SceneView& sc, const
   else if (sc.bvhDepth <= 16u) hipLaunchKernelGGL((k_aov<16, false>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, U, sc, A, ln, lt);
   else hipLaunchKernelGGL((k_aov<16, true>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, U, sc, A, ln, lt);
 }
-void launchShade(hipStream_t s, uint32_t blocks, uint32_t klass, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par)
+void launchShade(hipStream_t s, uint32_t blocks, uint32_t klass, bool textured, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par)
 {
-  if (klass == 0u) hipLaunchKernelGGL((k_shade<0u>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par);
-  else if (klass == 1u) hipLaunchKernelGGL((k_shade<1u>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par);
-  else hipLaunchKernelGGL((k_shade<2u>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par);
+#define GI_LAUNCH_SHADE(K) do { \
+    if (textured) hipLaunchKernelGGL((k_shade<K, true>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par); \
+    else hipLaunchKernelGGL((k_shade<K, false>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par); } while (0)
+  if (klass == 0u) GI_LAUNCH_SHADE(0u); else if (klass == 1u) GI_LAUNCH_SHADE(1u); else GI_LAUNCH_SHADE(2u);
+#undef GI_LAUNCH_SHADE
 }
 
 void launchDebugBsdf(hipStream_t s, const MaterialRec* mat, uint32_t count, const float* in, float* out)

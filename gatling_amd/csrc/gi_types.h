@@ -65,12 +65,26 @@ constexpr uint32_t MAT_PARAM_COUNT = 48;
 // class 1 (UsdPreviewSurface): albedo, F0, alpha, coat, coatAlpha.  class 2 (OpenPBR): albedo = base_color*base_weight,
 // F0 slot = metal edge tint (specular_color*specular_weight), alpha, coat, coatAlpha, coatF0, modulated eta, sigma_a
 enum : uint32_t { MP_ALBEDO = 32, MP_F0 = 35, MP_ALPHA = 38, MP_COAT = 39, MP_COAT_ALPHA = 40, MP_COAT_F0 = 41, MP_ETA = 42, MP_SIGMA_A = 43, MP_CUTOUT = 46 /* mdl_cutout_opacity, 1 = opaque */ };
+// Textured material inputs (UsdUVTexture semantics: value = texel * scale + bias at the hit's st).  Replaces the MDL
+// renderer runtime's tex_lookup_* path (mdl_interface.glsl:127-145) for the inputs the closed-form materials expose.
+enum : uint32_t { TEX_BASE_COLOR = 0, TEX_EMISSION = 1, TEX_ROUGHNESS = 2, TEX_METALLIC = 3, TEX_NORMAL = 4, TEX_SLOT_COUNT = 5 };
+enum : uint32_t { TEX_WRAP_CLAMP = 0, TEX_WRAP_REPEAT = 1, TEX_WRAP_MIRRORED_REPEAT = 2, TEX_WRAP_CLIP = 3 }; // mdl_types.glsl:117-120
+struct TexBindingRec {
+  uint32_t tex;   // texture index + 1; 0 = input not textured
+  uint32_t mode;  // wrapS | wrapT << 8 | channel << 16
+  float scale[4], bias[4];
+};
+constexpr uint32_t MAT_FLAG_TEXTURED = 1u << 31; // MaterialRec::flags: some input is textured (k_shade resolves the inputs per hit)
 struct MaterialRec {
   uint32_t klass;
   uint32_t flags;
   float p[MAT_PARAM_COUNT];
+  TexBindingRec tex[TEX_SLOT_COUNT];
 };
-static_assert(sizeof(MaterialRec) == 200, "MaterialRec must be 200 bytes");
+static_assert(sizeof(MaterialRec) == 400, "MaterialRec must be 400 bytes");
+// A texture: linear float RGBA texels, row 0 first.  (8-bit sources are decoded to linear float by the caller; a
+// compressed unorm8/half store is a later memory optimisation, the lookup arithmetic would not change.)
+struct TextureRec { const float* texels; uint32_t width, height; };
 
 // == rp::SphereLight / DistantLight / RectLight / DiskLight (rp_main.h:73-113), 48 bytes each
 struct SphereLightRec { float pos[3]; uint32_t ds; float em[3]; float area; float radius[3]; float pad; };
@@ -119,6 +133,13 @@ struct SceneView {
   uint32_t bvhDepth; // levels of the BVH8 (bounds the traversal stack)
   uint32_t hasCutouts; // some triangle has cutout opacity < 1: traversal runs the any-hit test (needs the path rng)
   uint32_t nodeStrideU4; // distance between nodes in 16-byte units: 5 (packed) or 8 (one node per 128-byte line)
+  const TextureRec* textures;
+  // dome light (rp_main.miss:38-86); domeTexture = index + 1 of the equirectangular image, 0 = fallback dome only
+  uint32_t domeTexture;
+  uint32_t domeCameraVisible; // GiRenderSettings.domeLightCameraVisible: primary rays see the dome image
+  float domeRotation[4];
+  float domeEmission[3];
+  float background[3];        // the fallback dome texel: colour clear value as RGBA8 unorm (Gi.cpp:2194-2199)
 };
 
 struct alignas(16) F4 { float x, y, z, w; };

@@ -49,10 +49,26 @@ P_COUNT = 48
 
 
 @dataclass
+class TextureBinding:
+    """One textured material input, UsdUVTexture semantics: value = texel * scale + bias, sampled at the hit's st."""
+    texture: int = -1                      # index into SceneDesc.textures
+    wrap_s: int = 1                        # TEX_WRAP_* (mdl_types.glsl:117-120): 0 clamp, 1 repeat, 2 mirrored repeat, 3 clip
+    wrap_t: int = 1
+    channel: int = 0                       # scalar inputs (roughness, metallic): channel of the scaled/biased texel
+    scale: tuple = (1.0, 1.0, 1.0, 1.0)
+    bias: tuple = (0.0, 0.0, 0.0, 0.0)
+
+
+TEX_WRAP_CLAMP, TEX_WRAP_REPEAT, TEX_WRAP_MIRRORED_REPEAT, TEX_WRAP_CLIP = 0, 1, 2, 3
+TEX_BASE_COLOR, TEX_EMISSION, TEX_ROUGHNESS, TEX_METALLIC, TEX_NORMAL, TEX_SLOT_COUNT = 0, 1, 2, 3, 4, 5
+
+
+@dataclass
 class MaterialDesc:
     name: str = "material"
     klass: int = MAT_USD_PREVIEW_SURFACE
     params: np.ndarray = field(default_factory=lambda: np.zeros(P_COUNT, np.float32))
+    textures: dict = field(default_factory=dict)   # TEX_* slot -> TextureBinding
 
     @staticmethod
     def usd_preview_surface(name="mat", diffuseColor=(0.18, 0.18, 0.18), emissiveColor=(0, 0, 0),
@@ -200,6 +216,16 @@ class RenderSettings:
 
 
 @dataclass
+class DomeLight:
+    """Gi.cpp:2943-2976: equirectangular environment texture, rotation quaternion (x, y, z, w), emission multiplier."""
+    texture: int = -1                      # index into SceneDesc.textures (the reference loads it from a file path)
+    rotation: tuple = (0.0, 0.0, 0.0, 1.0)
+    base_emission: tuple = (1.0, 1.0, 1.0)
+    diffuse: float = 1.0
+    specular: float = 1.0
+
+
+@dataclass
 class SceneDesc:
     meshes: List[MeshDesc] = field(default_factory=list)
     materials: List[MaterialDesc] = field(default_factory=list)
@@ -207,6 +233,8 @@ class SceneDesc:
     distant_lights: List[DistantLight] = field(default_factory=list)
     rect_lights: List[RectLight] = field(default_factory=list)
     disk_lights: List[DiskLight] = field(default_factory=list)
+    textures: List[np.ndarray] = field(default_factory=list)   # float32 [h, w, 4], linear, row 0 first (v = 0 side)
+    dome_light: Optional[DomeLight] = None
     camera: CameraDesc = field(default_factory=CameraDesc)
 
     def triangle_count(self) -> int:

@@ -10,7 +10,7 @@ from __future__ import annotations
 import numpy as np
 
 from .meshprep import build_mesh_arrays
-from .scene import (CameraDesc, MaterialDesc, MeshDesc, RectLight, SceneDesc, MAT_DIFFUSE, MAT_OPEN_PBR,
+from .scene import (CameraDesc, DomeLight, MaterialDesc, MeshDesc, RectLight, SceneDesc, TextureBinding, MAT_DIFFUSE, MAT_OPEN_PBR,
                     MAT_USD_PREVIEW_SURFACE)
 from .usda import camera_from_prim, Prim
 
@@ -231,4 +231,56 @@ def interior_scene(clutter_instances: int = 2000, subdivisions: int = 4, prototy
     for lx, ly in ((-2.5, -2.0), (2.5, -2.0), (-2.5, 2.0), (2.5, 2.0)):
         s.rect_lights.append(RectLight(origin=(lx, ly, 2.95), t0=(1, 0, 0), t1=(0, 1, 0), base_emission=(30, 30, 30), width=1.0, height=2.0))  # normal = t1 x t0 = -z
     s.camera = _look_at_camera((-4.5, -3.5, 1.6), (1.5, 1.0, 1.0), (0, 0, 1), 60.0)
+    return s
+
+
+def textured_scene(seed: int = 7, dome: bool = True, klass_sphere: int = MAT_OPEN_PBR) -> SceneDesc:
+    """Texture-path test scene: a ground quad tiled 3 x 3 in uv (exercises the wrap modes) with base-colour, roughness and
+    normal maps; a uv-mapped sphere with base-colour, metallic and emission maps; a rect light; optionally an equirectangular
+    dome light.  Textures are small procedural float images."""
+    from .meshprep import bake_vertices
+    from .scene import (TEX_BASE_COLOR, TEX_EMISSION, TEX_METALLIC, TEX_NORMAL, TEX_ROUGHNESS, TEX_WRAP_CLAMP, TEX_WRAP_CLIP,
+                        TEX_WRAP_MIRRORED_REPEAT, TEX_WRAP_REPEAT)
+    rng = np.random.default_rng(seed)
+    s = SceneDesc()
+
+    def tex(h, w, fn):
+        yy, xx = np.mgrid[0:h, 0:w]
+        a = np.zeros((h, w, 4), np.float32)
+        a[..., :3] = fn((xx + 0.5) / w, (yy + 0.5) / h)
+        a[..., 3] = 1.0
+        s.textures.append(a)
+        return len(s.textures) - 1
+
+    checker = tex(8, 8, lambda u, v: (0.15 + 0.7 * (((np.floor(u * 4) + np.floor(v * 4)) % 2)[..., None])) * np.array([1.0, 0.9, 0.8]))
+    noise = tex(16, 16, lambda u, v: rng.uniform(0.05, 0.95, u.shape + (3,)))
+    ramp = tex(4, 32, lambda u, v: np.stack([u, v, 1.0 - u], axis=-1))
+    bumps = tex(16, 16, lambda u, v: np.stack([0.5 + 0.25 * np.sin(u * 2 * np.pi * 2), 0.5 + 0.25 * np.cos(v * 2 * np.pi * 3), np.full_like(u, 0.9)], axis=-1))
+    glow = tex(8, 16, lambda u, v: np.stack([(u > 0.8) * 2.0, (v > 0.7) * 1.0, np.zeros_like(u)], axis=-1))
+
+    ground = MaterialDesc.usd_preview_surface(name="ground", diffuseColor=(0.5, 0.5, 0.5), roughness=0.4)
+    ground.textures = {TEX_BASE_COLOR: TextureBinding(texture=checker, wrap_s=TEX_WRAP_REPEAT, wrap_t=TEX_WRAP_MIRRORED_REPEAT),
+                       TEX_ROUGHNESS: TextureBinding(texture=noise, wrap_s=TEX_WRAP_CLAMP, wrap_t=TEX_WRAP_CLIP, channel=1, scale=(0.8,) * 4, bias=(0.1,) * 4),
+                       TEX_NORMAL: TextureBinding(texture=bumps, scale=(2.0, 2.0, 2.0, 1.0), bias=(-1.0, -1.0, -1.0, 0.0))}
+    if klass_sphere == MAT_OPEN_PBR:
+        ball = MaterialDesc.open_pbr(name="ball", base_color=(0.8, 0.8, 0.8), specular_roughness=0.25)
+    else:
+        ball = MaterialDesc.usd_preview_surface(name="ball", diffuseColor=(0.8, 0.8, 0.8), roughness=0.25)
+    ball.textures = {TEX_BASE_COLOR: TextureBinding(texture=ramp), TEX_METALLIC: TextureBinding(texture=noise, channel=2),
+                     TEX_EMISSION: TextureBinding(texture=glow, wrap_s=TEX_WRAP_CLAMP, wrap_t=TEX_WRAP_CLAMP)}
+    s.materials = [ground, ball]
+    gp = np.array([[-3, -3, 0], [3, -3, 0], [3, 3, 0], [-3, -3, 0], [3, 3, 0], [-3, 3, 0]], np.float32)
+    guv = np.array([[-1, -1], [2, -1], [2, 2], [-1, -1], [2, 2], [-1, 2]], np.float32)  # uv range [-1, 2]: outside [0,1] on purpose
+    s.meshes.append(MeshDesc(name="/Ground", vertices=bake_vertices(gp, np.tile([0, 0, 1], (6, 1)), guv), faces=np.arange(6, dtype=np.uint32).reshape(-1, 3),
+                             material=0, id=0, double_sided=True))
+    pts, faces = icosphere(2)
+    suv = np.stack([np.arctan2(pts[:, 1], pts[:, 0]) / (2 * np.pi) + 0.5, np.arccos(np.clip(pts[:, 2], -1, 1)) / np.pi], axis=1).astype(np.float32)
+    m = np.eye(4, dtype=np.float32); m[0, 0] = m[1, 1] = m[2, 2] = 0.9; m[3, 2] = 0.9
+    s.meshes.append(MeshDesc(name="/Ball", vertices=bake_vertices(pts, pts, suv), faces=faces, material=1, id=1, transform=m))
+    s.rect_lights = [RectLight(origin=(0.0, 0.0, 4.0), t0=(1, 0, 0), t1=(0, 1, 0), base_emission=(6, 6, 6), width=2.0, height=2.0)]
+    if dome:
+        env = tex(16, 32, lambda u, v: np.stack([0.2 + 1.5 * v, 0.3 + 0.5 * np.sin(u * 2 * np.pi) ** 2, 0.4 + 0.6 * u], axis=-1))
+        q = np.array([0.1, 0.3, -0.2, 0.9], np.float64); q /= np.linalg.norm(q)
+        s.dome_light = DomeLight(texture=env, rotation=tuple(np.float32(q)), base_emission=(0.9, 1.0, 1.1))
+    s.camera = _look_at_camera((0, -5.5, 2.2), (0, 0, 0.7), (0, 0, 1), 45.0)
     return s

@@ -178,6 +178,34 @@ typedef struct GiCMaterialDesc {
   float p[GI_C_MAT_PARAM_COUNT];
 } GiCMaterialDesc;
 
+/* [ext] Textures.  The reference loads images by file path inside gi (TextureManager.cpp:100-275 through imgio's PNG / JPEG /
+ * EXR / HDR / TIFF decoders, which are out of scope here) and samples them through the MDL renderer runtime
+ * (mdl_interface.glsl:8-38, 127-145).  This boundary takes DECODED pixels: linear float RGBA, row 0 first (the v = 0 side);
+ * the pixels are copied.  Lookups are bilinear, LOD 0, after the runtime's wrap handling. */
+typedef struct GiCTexture GiCTexture;
+typedef struct GiCTextureDesc { uint32_t width, height; const float* rgba; } GiCTextureDesc;
+GiCTexture* giCCreateTexture(GiCScene* scene, const GiCTextureDesc* desc);
+void giCDestroyTexture(GiCTexture* texture);
+
+/* texturable inputs of the closed-form materials (UsdUVTexture semantics: value = texel * scale + bias at the hit's st) */
+#define GI_C_TEX_BASE_COLOR 0 /* diffuseColor / base_color (rgb) */
+#define GI_C_TEX_EMISSION 1   /* emissiveColor / emission (rgb)  */
+#define GI_C_TEX_ROUGHNESS 2  /* scalar: `channel` of the texel  */
+#define GI_C_TEX_METALLIC 3   /* scalar                          */
+#define GI_C_TEX_NORMAL 4     /* tangent-space normal (rgb, usually scale 2 bias -1); bent by mdl_adapt_normal (mdl_interface.glsl:238-256) */
+#define GI_C_TEX_SLOT_COUNT 5
+#define GI_C_TEX_WRAP_CLAMP 0 /* mdl_types.glsl:117-120 */
+#define GI_C_TEX_WRAP_REPEAT 1
+#define GI_C_TEX_WRAP_MIRRORED_REPEAT 2
+#define GI_C_TEX_WRAP_CLIP 3
+typedef struct GiCTextureBinding {
+  GiCTexture* texture; /* NULL removes the binding */
+  int32_t wrapS, wrapT;
+  int32_t channel;
+  float scale[4], bias[4];
+} GiCTextureBinding;
+int giCSetMaterialTexture(GiCMaterial* material, int32_t input, const GiCTextureBinding* binding);
+
 /* [ext] per-frame statistics of the last giCRender on a scene (measurement) */
 typedef struct GiCRenderStats {
   double renderMs;       /* wall time of the bounce loop incl. final D2H of the colour AOV */
@@ -261,9 +289,12 @@ void giCSetDiskLightBaseEmission(GiCDiskLight* light, const float* rgb);
 void giCSetDiskLightRadius(GiCDiskLight* light, float radiusX, float radiusY);
 void giCSetDiskLightDiffuseSpecular(GiCDiskLight* light, float diffuse, float specular);
 
-/* Gi.h:253-257.  Textured dome lights are a "next" row: filePath is recorded, the
- * light behaves as a uniform dome of colour baseEmission. */
+/* Gi.h:253-257.  The dome light is an equirectangular image looked up by miss rays (rp_main.miss:46-86).  filePath is
+ * decoded when it is a Radiance .hdr (RGBE) or a .pfm; other formats need imgio (out of scope) -- hand the decoded pixels
+ * over with giCSetDomeLightTexture instead.  A dome light without an image is ignored, exactly like a dome light whose file
+ * fails to load in the reference (Gi.cpp:2221-2230): miss rays then see the fallback dome (the colour clear value). */
 GiCDomeLight* giCCreateDomeLight(GiCScene* scene, const char* filePath);
+void giCSetDomeLightTexture(GiCDomeLight* light, GiCTexture* texture); /* [ext] */
 void giCDestroyDomeLight(GiCDomeLight* light);
 void giCSetDomeLightRotation(GiCDomeLight* light, const float* quat);
 void giCSetDomeLightBaseEmission(GiCDomeLight* light, const float* rgb);

@@ -110,6 +110,42 @@ inline float expf_poly(float x)
   return y * u2f((uint32_t)((int)fx + 127) << 23);
 }
 
+// atan2(y, x) and acos(x) for the equirectangular dome lookup (rp_main.miss:46-53): Cephes atanf / asinf kernels with
+// plain mul/add (part of the arithmetic contract; |err| < 3e-7).
+inline float atanf_poly(float xx)
+{
+  float x = fabsf(xx), y;
+  if (x > 2.414213562373095f) { y = 1.5707963267948966f; x = -(1.0f / x); }
+  else if (x > 0.4142135623730950f) { y = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }
+  else y = 0.0f;
+  float z = x * x;
+  y = y + ((((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x);
+  return xx < 0.0f ? -y : y;
+}
+inline float atan2f_poly(float y, float x)
+{
+  if (x == 0.0f) return y > 0.0f ? 1.5707963267948966f : (y < 0.0f ? -1.5707963267948966f : 0.0f);
+  float z = atanf_poly(y / x);
+  if (x < 0.0f) z = z + (y >= 0.0f ? 3.14159265358979323846f : -3.14159265358979323846f);
+  return z;
+}
+inline float asinf_poly(float xx)
+{
+  float a = fabsf(xx), x, z; bool flag = false;
+  if (a > 0.5f) { z = 0.5f * (1.0f - a); x = sqrtf(z); flag = true; }
+  else { x = a; z = x * x; }
+  z = ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z + 1.6666752422e-1f) * z * x + x;
+  if (flag) { z = z + z; z = 1.5707963267948966f - z; }
+  return xx < 0.0f ? -z : z;
+}
+inline float acosf_poly(float x)
+{
+  x = fmin2(fmax2(x, -1.0f), 1.0f);
+  if (x < -0.5f) return 3.14159265358979323846f - 2.0f * asinf_poly(sqrtf(0.5f * (1.0f + x)));
+  if (x > 0.5f) return 2.0f * asinf_poly(sqrtf(0.5f * (1.0f - x)));
+  return 1.5707963267948966f - asinf_poly(x);
+}
+
 // ---------------------------------------------------------------------------------------------
 // half <-> float (glm::packHalf2x16 / GLSL unpackHalf2x16), round-to-nearest-even.
 // ---------------------------------------------------------------------------------------------
@@ -288,6 +324,7 @@ struct Prepared {
   std::vector<Tri> tris;
   std::vector<SphereL> sphere; std::vector<DistantL> distant; std::vector<RectL> rect; std::vector<DiskL> disk;
   const OrcMaterial* materials; uint32_t materialCount;
+  const OrcTexture* textures; uint32_t textureCount; const OrcDomeLight* dome;
   std::vector<BvhNode> bvh; std::vector<uint32_t> bvhTris; // used when tris.size() > 64
 };
 
@@ -347,6 +384,8 @@ inline float cutout_opacity(const OrcMaterial& m);
 void prepare(const OrcScene* s, Prepared& P)
 {
   P.materials = s->materials; P.materialCount = s->materialCount;
+  P.textures = s->textures; P.textureCount = s->textureCount;
+  P.dome = (s->dome && s->dome->texture >= 0 && (uint32_t)s->dome->texture < s->textureCount) ? s->dome : nullptr; // a dome light whose image failed to load is ignored (Gi.cpp:2221-2230)
   P.meshes.resize(s->meshCount);
   for (uint32_t mi = 0; mi < s->meshCount; mi++) {
     const OrcMesh& m = s->meshes[mi];
@@ -564,6 +603,91 @@ void setup_shading_state(const Prepared& P, const Hit& h, V3 rayDir, State& st, 
   st.tangentU = tg; st.tangentV = cross(n, tg) * bs;                     // :59
   st.u = (bx * a.u + by * b.u) + bz * c.u; st.v = (bx * a.v + by * b.v) + bz * c.v; // :62-65
   st.normal = n; st.geomNormal = gn;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Texture runtime (mdl_interface.glsl:8-38 apply_wrap_and_crop, :127-145 tex_lookup_float4_2d) over a software
+// sampler: bilinear, REPEAT addressing, LOD 0 (Gi.cpp:388-392; CgpuVk.cpp:1985-1990).  Filter weights are fp32 here
+// (the hardware's are 8-bit fixed point: unpinned).
+// ---------------------------------------------------------------------------------------------
+struct F4v { float x, y, z, w; };
+inline F4v sample_bilinear_repeat(const OrcTexture& t, float u, float v)
+{
+  u = u - floorf(u); v = v - floorf(v);
+  float x = u * (float)t.width - 0.5f, y = v * (float)t.height - 0.5f;
+  float x0f = floorf(x), y0f = floorf(y);
+  float fx = x - x0f, fy = y - y0f;
+  int w = (int)t.width, h = (int)t.height;
+  int ix0 = (int)x0f, iy0 = (int)y0f;
+  if (ix0 < 0) ix0 += w;
+  if (iy0 < 0) iy0 += h;
+  int ix1 = ix0 + 1; if (ix1 >= w) ix1 -= w;
+  int iy1 = iy0 + 1; if (iy1 >= h) iy1 -= h;
+  const float* t00 = t.rgba + 4 * ((size_t)iy0 * w + ix0); const float* t10 = t.rgba + 4 * ((size_t)iy0 * w + ix1);
+  const float* t01 = t.rgba + 4 * ((size_t)iy1 * w + ix0); const float* t11 = t.rgba + 4 * ((size_t)iy1 * w + ix1);
+  float gx = 1.0f - fx, gy = 1.0f - fy, o[4];
+  for (int c = 0; c < 4; c++) {
+    float top = t00[c] * gx + t10[c] * fx, bot = t01[c] * gx + t11[c] * fx;
+    o[c] = top * gy + bot * fy;
+  }
+  return F4v{o[0], o[1], o[2], o[3]};
+}
+inline float apply_wrap_and_crop(float coord, int wrap, int res) // crop = (0, 1)
+{
+  if (wrap == ORC_TEX_WRAP_REPEAT) coord = coord - floorf(coord);
+  else {
+    if (wrap == ORC_TEX_WRAP_MIRRORED_REPEAT) {
+      float tmp = floorf(coord);
+      if (((int)tmp & 1) != 0) coord = 1.0f - (coord - tmp); else coord = coord - tmp;
+    }
+    float inv_hdim = 0.5f / (float)res;
+    coord = fmin2(fmax2(coord, inv_hdim), 1.0f - inv_hdim);
+  }
+  return coord;
+}
+inline F4v tex_lookup_float4_2d(const OrcTexture& t, float u, float v, int wrapU, int wrapV)
+{
+  if ((wrapU == ORC_TEX_WRAP_CLIP && (u < 0.0f || u > 1.0f)) || (wrapV == ORC_TEX_WRAP_CLIP && (v < 0.0f || v > 1.0f))) return F4v{0, 0, 0, 0};
+  u = apply_wrap_and_crop(u, wrapU, (int)t.width);
+  v = apply_wrap_and_crop(v, wrapV, (int)t.height);
+  return sample_bilinear_repeat(t, u, v);
+}
+
+// mdl_adapt_normal (mdl_interface.glsl:238-256): Iray's shadow-terminator bend of a mapped normal
+inline V3 adapt_normal(V3 rayDir, V3 geomNormal, V3 normal)
+{
+  float dn = dot(rayDir, normal);
+  V3 r = normalize(rayDir - normal * (2.0f * dn)); // reflect(I, N)
+  float a = fmax2(0.0f, dot(r, -geomNormal));
+  float b = dot(normal, geomNormal);
+  V3 tangent = normalize(r + normal * (a / b));
+  return normalize(-rayDir + tangent);
+}
+
+// Per-hit material: the parameter block with its textured inputs evaluated at the hit's uv (UsdUVTexture: texel * scale + bias);
+// a normal map replaces the shading normal (tangent space -> world, adapt_normal, tangent frame re-orthonormalised).
+inline bool material_textured(const OrcMaterial& m) { for (int i = 0; i < ORC_TEX_SLOT_COUNT; i++) if (m.tex[i].texture >= 0) return true; return false; }
+OrcMaterial resolve_material(const Prepared& P, const OrcMaterial& m, State& st, V3 rayDir)
+{
+  OrcMaterial r = m;
+  for (int slot = 0; slot < ORC_TEX_SLOT_COUNT; slot++) {
+    const OrcTexBinding& b = m.tex[slot];
+    if (b.texture < 0 || (uint32_t)b.texture >= P.textureCount) continue;
+    F4v t = tex_lookup_float4_2d(P.textures[b.texture], st.u, st.v, b.wrapS, b.wrapT);
+    float val[4] = {t.x * b.scale[0] + b.bias[0], t.y * b.scale[1] + b.bias[1], t.z * b.scale[2] + b.bias[2], t.w * b.scale[3] + b.bias[3]};
+    if (slot == ORC_TEX_BASE_COLOR) { r.p[ORC_P_BASE_COLOR] = val[0]; r.p[ORC_P_BASE_COLOR + 1] = val[1]; r.p[ORC_P_BASE_COLOR + 2] = val[2]; }
+    else if (slot == ORC_TEX_EMISSION) { r.p[ORC_P_EMISSION] = val[0]; r.p[ORC_P_EMISSION + 1] = val[1]; r.p[ORC_P_EMISSION + 2] = val[2]; }
+    else if (slot == ORC_TEX_ROUGHNESS) r.p[ORC_P_ROUGHNESS] = val[b.channel & 3];
+    else if (slot == ORC_TEX_METALLIC) r.p[ORC_P_METALLIC] = val[b.channel & 3];
+    else { // ORC_TEX_NORMAL
+      V3 n = normalize((st.tangentU * val[0] + st.tangentV * val[1]) + st.normal * val[2]);
+      n = adapt_normal(rayDir, st.geomNormal, n);
+      float hs = dot(cross(st.normal, st.tangentU), st.tangentV) >= 0.0f ? 1.0f : -1.0f;
+      V3 tg = normalize(st.tangentU - n * dot(st.tangentU, n));
+      st.normal = n; st.tangentU = tg; st.tangentV = cross(n, tg) * hs;
+    }
+  }
+  return r;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -985,7 +1109,10 @@ void closest_hit(const Frame& F, const Hit& h, Payload& pl, float hitT)
   State st; const MeshData* mesh;
   V3 rayDir = pl.dir;
   setup_shading_state(P, h, rayDir, st, mesh);
-  const OrcMaterial& mat = P.materials[mesh->material];
+  const OrcMaterial& baseMat = P.materials[mesh->material];
+  OrcMaterial resolved;
+  if (material_textured(baseMat)) resolved = resolve_material(P, baseMat, st, rayDir);
+  const OrcMaterial& mat = material_textured(baseMat) ? resolved : baseMat;
   bool isLeftHanded = (mesh->flags & 1u) != 0, isDoubleSided = (mesh->flags & 2u) != 0;
   V3 throughput = pl.throughput, radiance = pl.radiance;
   (void)isLeftHanded;
@@ -1049,10 +1176,30 @@ void closest_hit(const Frame& F, const Hit& h, Payload& pl, float hitT)
 }
 
 // rp_main.miss:55-86 with the 1x1 fallback dome (Gi.cpp:2184-2199, 2232-2238): texel = u8(clear*255)/255
+inline V3 quat_rotate_dir(const float q[4], V3 dir) // rp_main.miss:38-44
+{
+  V3 qv = v3(q[0], q[1], q[2]);
+  V3 a = cross(qv, dir);
+  V3 b = cross(qv, a);
+  return dir + ((a * q[3]) + b) * 2.0f;
+}
 void miss(const Frame& F, Payload& pl)
 {
   pl.bitfield |= TERMINATE_FLAG;
-  pl.radiance = pl.radiance + pl.throughput * F.background;
+  const OrcDomeLight* dome = F.P->dome;
+  if (!dome) { pl.radiance = pl.radiance + pl.throughput * F.background; return; } // fallback dome, emission multiplier 1 (Gi.cpp:2385)
+  bool isPrimaryRay = (pl.bitfield & BOUNCES_MASK) == 0;
+  bool useFallback = !F.rs->domeLightCameraVisible && isPrimaryRay; // :76-80
+  V3 mult = v3(dome->baseEmission);
+  V3 texel = F.background;
+  if (!useFallback) {
+    V3 d = normalize(quat_rotate_dir(dome->rotation, pl.dir)); // :83
+    float u = (atan2f_poly(d.z, d.x) + 0.5f * ORC_PI) / (2.0f * ORC_PI); // :48-49
+    float v = 1.0f - acosf_poly(d.y) / ORC_PI;
+    F4v t = sample_bilinear_repeat(F.P->textures[dome->texture], u, v);
+    texel = v3(t.x, t.y, t.z);
+  }
+  pl.radiance = pl.radiance + pl.throughput * (texel * mult); // :84-86
 }
 
 void render_pixel(const Frame& F, uint32_t px, uint32_t py, const float* prevColor, float* out, OrcCounters& cnt)
@@ -1222,7 +1369,9 @@ void render_pixel_aovs(const Frame& F, uint32_t px, uint32_t py, size_t o, OrcAo
       put3(A.normal, (prev * (float)rs.sampleOffset + pos * (float)rs.spp) * invTotal);
     }
     if (A.albedo) {                                                                        // :261-289
-      V3 al = bsdf_albedo(F.P->materials[mesh->material], st, -dir), prev = al;
+      const OrcMaterial& bm = F.P->materials[mesh->material];
+      OrcMaterial rm; if (material_textured(bm)) rm = resolve_material(*F.P, bm, st, dir);
+      V3 al = bsdf_albedo(material_textured(bm) ? rm : bm, st, -dir), prev = al;
       if (rs.progressiveAccumulation && rs.sampleOffset > 0) prev = v3(A.albedo + 4 * o);
       put3(A.albedo, (prev * (float)rs.sampleOffset + al * (float)rs.spp) * invTotal);
     }
@@ -1239,6 +1388,14 @@ void render_pixel_aovs(const Frame& F, uint32_t px, uint32_t py, size_t o, OrcAo
 // C API
 // ---------------------------------------------------------------------------------------------
 extern "C" {
+float orc_atan2f(float y, float x) { return atan2f_poly(y, x); }
+float orc_acosf(float x) { return acosf_poly(x); }
+void orc_tex_lookup(const OrcTexture* t, float u, float v, int wrapU, int wrapV, float* out4)
+{
+  F4v r = tex_lookup_float4_2d(*t, u, v, wrapU, wrapV);
+  out4[0] = r.x; out4[1] = r.y; out4[2] = r.z; out4[3] = r.w;
+}
+
 
 int orc_render(const OrcScene* scene, const OrcCamera* camera, const OrcSettings* settings,
                const OrcRegion* region, const float* prevColor, float* colorOut,

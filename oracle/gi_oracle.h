@@ -72,10 +72,25 @@ enum {
   ORC_P_COUNT = 48
 };
 
+/* Texture runtime (mdl_interface.glsl:8-38, 127-145; mdl_types.glsl:117-120).  Texels are linear float RGBA, row 0 first
+ * (v = 0 side), as the harness decoded them; lookups are bilinear with REPEAT addressing (the reference's one sampler,
+ * Gi.cpp:388-392, CgpuVk.cpp:1985-1990) after apply_wrap_and_crop. */
+enum { ORC_TEX_WRAP_CLAMP = 0, ORC_TEX_WRAP_REPEAT = 1, ORC_TEX_WRAP_MIRRORED_REPEAT = 2, ORC_TEX_WRAP_CLIP = 3 };
+typedef struct OrcTexture { const float* rgba; uint32_t width, height; } OrcTexture;
+/* material inputs that can be driven by a texture (UsdUVTexture semantics: value = texel * scale + bias) */
+enum { ORC_TEX_BASE_COLOR = 0, ORC_TEX_EMISSION = 1, ORC_TEX_ROUGHNESS = 2, ORC_TEX_METALLIC = 3, ORC_TEX_NORMAL = 4, ORC_TEX_SLOT_COUNT = 5 };
+typedef struct OrcTexBinding {
+  int32_t texture; /* index into OrcScene.textures; < 0 = input not textured */
+  int32_t wrapS, wrapT;
+  int32_t channel; /* scalar inputs: which channel of the (scaled, biased) texel */
+  float scale[4], bias[4];
+} OrcTexBinding;
+
 typedef struct OrcMaterial {
   uint32_t klass;
   uint32_t flags;
   float p[ORC_P_COUNT];
+  OrcTexBinding tex[ORC_TEX_SLOT_COUNT];
 } OrcMaterial;
 
 typedef struct OrcMesh {
@@ -102,6 +117,7 @@ typedef struct OrcDistantLight { float direction[3]; float baseEmission[3]; floa
 typedef struct OrcRectLight { float origin[3]; float t0[3]; float t1[3]; float baseEmission[3]; float width, height; float diffuse, specular; } OrcRectLight;
 typedef struct OrcDiskLight { float origin[3]; float t0[3]; float t1[3]; float baseEmission[3]; float radiusX, radiusY; float diffuse, specular; } OrcDiskLight;
 
+struct OrcDomeLight;
 typedef struct OrcScene {
   const OrcMesh* meshes; uint32_t meshCount;
   const OrcMaterial* materials; uint32_t materialCount;
@@ -109,7 +125,12 @@ typedef struct OrcScene {
   const OrcDistantLight* distantLights; uint32_t distantLightCount;
   const OrcRectLight* rectLights; uint32_t rectLightCount;
   const OrcDiskLight* diskLights; uint32_t diskLightCount;
+  const OrcTexture* textures; uint32_t textureCount;
+  const struct OrcDomeLight* dome; /* NULL: only the fallback dome (colour clear value) */
 } OrcScene;
+
+/* Dome light (Gi.cpp:2943-2976; rp_main.miss:38-86): equirectangular texture, rotation quaternion (x,y,z,w), emission multiplier */
+typedef struct OrcDomeLight { int32_t texture; float rotation[4]; float baseEmission[3]; } OrcDomeLight;
 
 /* == GiCameraDesc, Gi.h:96-108 */
 typedef struct OrcCamera {
@@ -159,6 +180,9 @@ typedef struct OrcAovs {
   int32_t* objectId; int32_t* faceId; int32_t* instanceId;
   float clear[17][4];
 } OrcAovs;
+float orc_atan2f(float y, float x);
+float orc_acosf(float x);
+void orc_tex_lookup(const OrcTexture* t, float u, float v, int wrapU, int wrapV, float* out4);
 int orc_render_aovs(const OrcScene* scene, const OrcCamera* camera, const OrcSettings* settings, const OrcRegion* region, OrcAovs* aovs);
 
 typedef struct OrcCounters {

@@ -16,8 +16,36 @@ _LIB_PATH = os.path.join(_HERE, "libgi_oracle.so")
 P_COUNT = 48
 
 
+TEX_SLOT_COUNT = 5
+
+
+class OrcTexBinding(C.Structure):
+    _fields_ = [("texture", C.c_int32), ("wrapS", C.c_int32), ("wrapT", C.c_int32), ("channel", C.c_int32),
+                ("scale", C.c_float * 4), ("bias", C.c_float * 4)]
+
+
 class OrcMaterial(C.Structure):
-    _fields_ = [("klass", C.c_uint32), ("flags", C.c_uint32), ("p", C.c_float * P_COUNT)]
+    _fields_ = [("klass", C.c_uint32), ("flags", C.c_uint32), ("p", C.c_float * P_COUNT), ("tex", OrcTexBinding * TEX_SLOT_COUNT)]
+
+
+class OrcTexture(C.Structure):
+    _fields_ = [("rgba", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
+class OrcDomeLight(C.Structure):
+    _fields_ = [("texture", C.c_int32), ("rotation", C.c_float * 4), ("baseEmission", C.c_float * 3)]
+
+
+def fill_material(dst, m):
+    dst.klass = m.klass
+    dst.p = (C.c_float * P_COUNT)(*np.asarray(m.params, np.float32))
+    for slot in range(TEX_SLOT_COUNT):
+        b = getattr(m, "textures", {}).get(slot)
+        dst.tex[slot].texture = -1 if b is None else int(b.texture)
+        if b is not None:
+            dst.tex[slot].wrapS, dst.tex[slot].wrapT, dst.tex[slot].channel = int(b.wrap_s), int(b.wrap_t), int(b.channel)
+            dst.tex[slot].scale = (C.c_float * 4)(*b.scale)
+            dst.tex[slot].bias = (C.c_float * 4)(*b.bias)
 
 
 class OrcMesh(C.Structure):
@@ -64,7 +92,8 @@ class OrcScene(C.Structure):
                 ("sphereLights", C.c_void_p), ("sphereLightCount", C.c_uint32),
                 ("distantLights", C.c_void_p), ("distantLightCount", C.c_uint32),
                 ("rectLights", C.c_void_p), ("rectLightCount", C.c_uint32),
-                ("diskLights", C.c_void_p), ("diskLightCount", C.c_uint32)]
+                ("diskLights", C.c_void_p), ("diskLightCount", C.c_uint32),
+                ("textures", C.c_void_p), ("textureCount", C.c_uint32), ("dome", C.c_void_p)]
 
 
 class OrcCamera(C.Structure):
@@ -125,6 +154,11 @@ def lib():
         L.orc_sincos2pi.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.orc_logf.restype = C.c_float
         L.orc_logf.argtypes = [C.c_float]
+        L.orc_atan2f.restype = C.c_float
+        L.orc_atan2f.argtypes = [C.c_float, C.c_float]
+        L.orc_acosf.restype = C.c_float
+        L.orc_acosf.argtypes = [C.c_float]
+        L.orc_tex_lookup.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_float)]
         L.orc_expf.restype = C.c_float
         L.orc_expf.argtypes = [C.c_float]
         L.orc_pack_half2x16.restype = C.c_uint32
@@ -178,8 +212,17 @@ class PackedScene:
                 iid = np.ascontiguousarray(m.instance_ids, np.int32); self.keep.append(iid); meshes[i].instanceIds = iid.ctypes.data
         mats = (OrcMaterial * max(1, len(scene.materials)))()
         for i, m in enumerate(scene.materials):
-            mats[i].klass = m.klass
-            mats[i].p = (C.c_float * P_COUNT)(*np.asarray(m.params, np.float32))
+            fill_material(mats[i], m)
+        texs = (OrcTexture * max(1, len(getattr(scene, "textures", []))))()
+        for i, t in enumerate(getattr(scene, "textures", [])):
+            a = np.ascontiguousarray(t, np.float32)
+            assert a.ndim == 3 and a.shape[2] == 4
+            self.keep.append(a)
+            texs[i].rgba, texs[i].width, texs[i].height = a.ctypes.data, a.shape[1], a.shape[0]
+        dome = None
+        if getattr(scene, "dome_light", None) is not None:
+            d = scene.dome_light
+            dome = OrcDomeLight(int(d.texture), (C.c_float * 4)(*d.rotation), _f3(d.base_emission))
         sl = (OrcSphereLight * max(1, len(scene.sphere_lights)))()
         for i, l in enumerate(scene.sphere_lights):
             sl[i] = OrcSphereLight(_f3(l.pos), _f3(l.base_emission), _f3(l.radius), l.diffuse, l.specular)
@@ -192,7 +235,7 @@ class PackedScene:
         kl = (OrcDiskLight * max(1, len(scene.disk_lights)))()
         for i, l in enumerate(scene.disk_lights):
             kl[i] = OrcDiskLight(_f3(l.origin), _f3(l.t0), _f3(l.t1), _f3(l.base_emission), l.radius_x, l.radius_y, l.diffuse, l.specular)
-        self.keep += [meshes, mats, sl, dl, rl, kl]
+        self.keep += [meshes, mats, sl, dl, rl, kl, texs, dome]
         s = OrcScene()
         s.meshes = C.addressof(meshes); s.meshCount = len(scene.meshes)
         s.materials = C.addressof(mats); s.materialCount = len(scene.materials)
@@ -200,6 +243,8 @@ class PackedScene:
         s.distantLights = C.addressof(dl); s.distantLightCount = len(scene.distant_lights)
         s.rectLights = C.addressof(rl); s.rectLightCount = len(scene.rect_lights)
         s.diskLights = C.addressof(kl); s.diskLightCount = len(scene.disk_lights)
+        s.textures = C.addressof(texs); s.textureCount = len(getattr(scene, "textures", []))
+        s.dome = C.addressof(dome) if dome is not None else None
         self.c = s
 
 
@@ -268,8 +313,9 @@ def bsdf_debug(material, items):
     """items: float32 [n,22] (normal, tangentU, tangentV, geomNormal, k1, k2, xi[4]) -> float32 [n,15]."""
     L = lib()
     m = OrcMaterial()
-    m.klass = material.klass
-    m.p = (C.c_float * P_COUNT)(*np.asarray(material.params, np.float32))
+    fill_material(m, material)
+    for slot in range(TEX_SLOT_COUNT):
+        m.tex[slot].texture = -1  # the BSDF known-answer entry point evaluates the constant parameter block
     a = np.ascontiguousarray(items, np.float32).reshape(-1, 22)
     out = np.zeros((len(a), 15), np.float32)
     FP = C.POINTER(C.c_float)
@@ -312,3 +358,12 @@ def render_aovs(scene, settings, width, height, names, clear_values=None, sample
     if rc != 0:
         raise RuntimeError(f"orc_render_aovs failed with code {rc}")
     return {k: (v.reshape(r1 - r0, width, 4) if v.ndim == 2 else v.reshape(r1 - r0, width)) for k, v in out.items()}
+
+
+def tex_lookup(texture, u, v, wrap_u=1, wrap_v=1):
+    """tex_lookup_float4_2d of the oracle's texture runtime on a float32 [h, w, 4] image."""
+    a = np.ascontiguousarray(texture, np.float32)
+    t = OrcTexture(a.ctypes.data, a.shape[1], a.shape[0])
+    out = (C.c_float * 4)()
+    lib().orc_tex_lookup(C.addressof(t), float(u), float(v), int(wrap_u), int(wrap_v), out)
+    return np.array(out[:], np.float32)

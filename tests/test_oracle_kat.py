@@ -171,3 +171,42 @@ def test_cornell_camera_facts():
     assert cam.up[2] == 1.0 and cam.up[1] == pytest.approx(-4.371139e-8, rel=1e-6)
     d = 1.0 / (2.0 * math.tan(cam.vfov * 0.5))
     assert d == pytest.approx(2.4691358, rel=1e-6)
+
+
+def test_atan2_acos_polynomials(orc):
+    """Arithmetic contract of the dome lookup (rp_main.miss:48-49): polynomial atan2 / acos, accuracy vs libm."""
+    L = orc.lib()
+    rng = np.random.default_rng(3)
+    for y, x in np.concatenate([rng.normal(0, 1, (2000, 2)), [[0, 1], [0, -1], [1, 0], [-1, 0], [1e-20, 1], [1, 1e-20], [-1e-20, -1], [0, 0]]]).astype(np.float32):
+        assert L.orc_atan2f(float(y), float(x)) == pytest.approx(math.atan2(float(y), float(x)), abs=4e-7)
+    for x in np.concatenate([np.linspace(-1, 1, 4001), [-1.0000001, 1.0000001, 0.5, -0.5, 0.50000006, 0.99999994]]).astype(np.float32):
+        xc = min(1.0, max(-1.0, float(x)))  # inputs are clamped: normalize() may overshoot 1 by an ulp
+        assert L.orc_acosf(float(x)) == pytest.approx(math.acos(xc), abs=5e-7)
+
+
+def test_texture_runtime_kat(orc):
+    """mdl_interface.glsl:8-38, 127-145 over the software sampler: texel centres are exact, wrap modes as the runtime defines them."""
+    tex = np.zeros((4, 8, 4), np.float32)
+    tex[..., 0] = np.arange(8)[None, :]          # r = column
+    tex[..., 1] = np.arange(4)[:, None]          # g = row
+    tex[..., 2] = 1.0; tex[..., 3] = 0.5
+    CLAMP, REPEAT, MIRROR, CLIP = 0, 1, 2, 3
+    for col in range(8):
+        for row in range(4):
+            t = orc.tex_lookup(tex, (col + 0.5) / 8, (row + 0.5) / 4, REPEAT, REPEAT)
+            assert t.tolist() == [col, row, 1.0, 0.5]
+    # halfway between two texel centres: the average; across the border REPEAT blends with the opposite edge
+    assert orc.tex_lookup(tex, 1.0 / 8, 0.5 / 4, REPEAT, REPEAT)[0] == pytest.approx(0.5)
+    assert orc.tex_lookup(tex, 0.0, 0.5 / 4, REPEAT, REPEAT)[0] == pytest.approx(3.5)   # (0 + 7) / 2
+    assert orc.tex_lookup(tex, 1.25, 0.5 / 4, REPEAT, REPEAT)[0] == pytest.approx(orc.tex_lookup(tex, 0.25, 0.5 / 4, REPEAT, REPEAT)[0])
+    # CLAMP: coordinate clamped to [0.5/res, 1 - 0.5/res] -> edge texel, no bleed from the opposite edge
+    assert orc.tex_lookup(tex, -3.0, 0.5 / 4, CLAMP, REPEAT)[0] == 0.0
+    assert orc.tex_lookup(tex, 7.3, 0.5 / 4, CLAMP, REPEAT)[0] == 7.0
+    # MIRRORED_REPEAT: odd periods run backwards
+    assert orc.tex_lookup(tex, 1.0 + 0.5 / 8, 0.5 / 4, MIRROR, REPEAT)[0] == pytest.approx(7.0)
+    assert orc.tex_lookup(tex, 2.0 + 0.5 / 8, 0.5 / 4, MIRROR, REPEAT)[0] == pytest.approx(0.0)
+    assert orc.tex_lookup(tex, -0.5 / 8, 0.5 / 4, MIRROR, REPEAT)[0] == pytest.approx(0.0)
+    # CLIP: black outside [0, 1]
+    assert orc.tex_lookup(tex, 1.01, 0.5, CLIP, REPEAT).tolist() == [0, 0, 0, 0]
+    assert orc.tex_lookup(tex, 0.5, -0.01, REPEAT, CLIP).tolist() == [0, 0, 0, 0]
+    assert orc.tex_lookup(tex, 1.0, 0.5, CLIP, CLIP)[2] == 1.0

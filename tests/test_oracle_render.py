@@ -192,3 +192,74 @@ def test_cutout_opacity(orc):
     half, _ = orc.render(with_opacity(0.5), rs, 48, 27)
     d_full, d_none = np.abs(half - ref).mean(), np.abs(half - ref_gone).mean()
     assert d_full > 1e-4 and d_none > 1e-4  # neither opaque nor absent
+
+
+def test_dome_light_lookup(orc):
+    """rp_main.miss:38-86: no geometry, every primary ray returns texel(direction) * emission; camera-invisible domes show the
+    fallback colour times the emission multiplier; an image-less dome light is ignored (Gi.cpp:2221-2230)."""
+    from gatling_amd.scene import DomeLight, SceneDesc, CameraDesc
+    s = SceneDesc()
+    s.camera = CameraDesc(position=(0, 0, 0), forward=(0, 0, -1), up=(0, 1, 0), vfov=1.0)
+    env = np.zeros((8, 16, 4), np.float32)
+    env[..., 0] = np.linspace(0.0, 1.0, 8)[:, None]   # r grows with v (row): up is bright
+    env[..., 1] = 0.25; env[..., 3] = 1.0
+    s.textures = [env]
+    s.dome_light = DomeLight(texture=0, base_emission=(2.0, 1.0, 1.0))
+    rs = RenderSettings(spp=1, max_bounces=2, jittered_sampling=False, clear_color=(0.2, 0.4, 0.6, 1.0))
+    img, _ = orc.render(s, rs, 32, 16)
+    assert np.allclose(img[..., 1], 0.25) and np.allclose(img[..., 2], 0.0)
+    assert img[-1, 16, 0] > img[0, 16, 0]          # row 0 = bottom of the image = looking down = small v
+    centre = img[8, 16, 0]                          # looking along -z, horizon: v = 0.5 -> r interpolates to ~0.5, times emission 2
+    assert centre == pytest.approx(1.0, abs=0.15)
+    rs.dome_light_camera_visible = False
+    hidden, _ = orc.render(s, rs, 32, 16)
+    q = np.float32(np.floor(np.float32([0.2, 0.4, 0.6]) * 255.0)) / np.float32(255.0)
+    assert np.allclose(hidden[..., :3], q * np.float32([2.0, 1.0, 1.0]), atol=1e-6)
+    s.dome_light = DomeLight(texture=-1, base_emission=(2.0, 1.0, 1.0))
+    rs.dome_light_camera_visible = True
+    ignored, _ = orc.render(s, rs, 32, 16)
+    assert np.allclose(ignored[..., :3], q, atol=1e-6)
+    # rotating the dome by 180 degrees about y == rolling the image by half its width (up to filtering round-off)
+    s.dome_light = DomeLight(texture=0, rotation=(0.0, 1.0, 0.0, 0.0))
+    env2 = env.copy(); env2[..., 2] = np.linspace(0, 1, 16)[None, :]
+    s.textures = [env2]
+    rot, _ = orc.render(s, rs, 32, 16)
+    s.textures = [np.roll(env2, 8, axis=1)]; s.dome_light = DomeLight(texture=0)
+    rolled, _ = orc.render(s, rs, 32, 16)
+    assert np.allclose(rot, rolled, atol=2e-5)
+
+
+def test_textured_inputs(orc):
+    """Per-hit material inputs (UsdUVTexture semantics): a constant texture equals the constant parameter up to filter
+    round-off; scale/bias act per channel; the normal map changes shading but not geometry AOVs."""
+    from gatling_amd.scene import TextureBinding, TEX_BASE_COLOR, TEX_NORMAL
+    from gatling_amd.scenes import textured_scene
+    rs = RenderSettings(spp=4, max_bounces=4, next_event_estimation=True)
+    s = textured_scene(dome=False)
+    base, _ = orc.render(s, rs, 48, 27)
+    assert np.isfinite(base).all() and base[..., :3].mean() > 0.01
+    # ground base colour as a constant texture of the same value
+    s2 = textured_scene(dome=False)
+    const = np.zeros((2, 2, 4), np.float32); const[..., :3] = (0.5, 0.25, 0.125); const[..., 3] = 1
+    s2.textures.append(const)
+    s2.materials[0].textures[TEX_BASE_COLOR] = TextureBinding(texture=len(s2.textures) - 1)
+    a, _ = orc.render(s2, rs, 48, 27)
+    s3 = textured_scene(dome=False)
+    del s3.materials[0].textures[TEX_BASE_COLOR]
+    s3.materials[0].params[0:3] = (0.5, 0.25, 0.125)
+    b, _ = orc.render(s3, rs, 48, 27)
+    assert np.allclose(a, b, rtol=1e-4, atol=1e-4)
+    # scale 0.5 on a texture of twice the value: same again
+    s4 = textured_scene(dome=False)
+    s4.textures.append(const * np.float32([2, 2, 2, 1]))
+    s4.materials[0].textures[TEX_BASE_COLOR] = TextureBinding(texture=len(s4.textures) - 1, scale=(0.5, 0.5, 0.5, 1.0))
+    c, _ = orc.render(s4, rs, 48, 27)
+    assert np.allclose(a, c, rtol=1e-4, atol=1e-4)
+    # without the normal map the image changes, the Normal AOV (geometry state) does not
+    s5 = textured_scene(dome=False)
+    del s5.materials[0].textures[TEX_NORMAL]
+    d, _ = orc.render(s5, rs, 48, 27)
+    assert not np.allclose(base, d, atol=1e-3)
+    n1 = orc.render_aovs(s, rs, 48, 27, ["normal"])["normal"]
+    n2 = orc.render_aovs(s5, rs, 48, 27, ["normal"])["normal"]
+    assert np.array_equal(n1, n2)
