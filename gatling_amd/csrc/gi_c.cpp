@@ -164,8 +164,17 @@ void deriveMaterialConstants(MaterialRec& m)
     for (int i = 0; i < 3; i++) {
       out[MP_ALBEDO + i] = p[GI_C_P_BASE_COLOR + i] * bw;
       out[MP_F0 + i] = p[GI_C_P_SPECULAR_COLOR + i] * sw;
-      float tc = p[GI_C_P_TRANSMISSION_COLOR + i]; tc = tc > 1e-6f ? tc : 1e-6f;
-      out[MP_SIGMA_A + i] = (depth > 0.0f) ? -logf(tc) / depth : 0.0f;
+    }
+    { // dielectric base VDF (open_pbr_surface.mtlx:220-298): absorption = extinction - scattering, shifted to be non-negative
+      float ab[3];
+      for (int i = 0; i < 3; i++) {
+        float tc = p[GI_C_P_TRANSMISSION_COLOR + i]; tc = tc > 1e-6f ? tc : 1e-6f;
+        const float ext = (depth > 0.0f) ? -logf(tc) / depth : 0.0f;
+        const float sc = (depth > 0.0f) ? p[GI_C_P_TRANSMISSION_SCATTER + i] / depth : 0.0f;
+        ab[i] = ext - sc;
+      }
+      float mn = ab[0] < ab[1] ? ab[0] : ab[1]; mn = mn < ab[2] ? mn : ab[2];
+      for (int i = 0; i < 3; i++) out[MP_SIGMA_A + i] = (depth > 0.0f) ? ((0.0f > mn) ? ab[i] - mn : ab[i]) : 0.0f;
     }
     out[MP_ALPHA] = (r * r > 0.001f) ? r * r : 0.001f; out[MP_COAT] = coat; out[MP_COAT_ALPHA] = (cr * cr > 0.001f) ? cr * cr : 0.001f;
     out[MP_COAT_F0] = qc * qc; out[MP_ETA] = (1.0f + eps) / (1.0f - eps);
@@ -272,6 +281,7 @@ struct GiCScene {
   uint32_t classTextured = 0; // classes with at least one textured material in use (k_shade<class, TEXTURED>)
   // path state
   DeviceBuffer<Slot> slots;
+  DeviceBuffer<float> media; // per-slot medium stack + walkSegmentPdf (mediumStackSize > 0)
   DeviceBuffer<F4> sampleBuf; // per-sample colours of the current batch, [sample][pixel] (rgb, -)
   DeviceBuffer<F4> accum;        // per-pixel running sum across batches
   DeviceBuffer<uint32_t> qSlot[Q_COUNT]; // NSHARD segments of queueCap records each
@@ -339,7 +349,7 @@ void giCDestroyScene(GiCScene* s)
   for (auto* b : s->dTexels) { b->release(); delete b; }
   s->dTexels.clear(); s->dTextures.release();
   s->dMaterials.release(); s->dSphere.release(); s->dDistant.release(); s->dRect.release(); s->dDisk.release();
-  s->slots.release(); s->sampleBuf.release(); s->accum.release();
+  s->slots.release(); s->media.release(); s->sampleBuf.release(); s->accum.release();
   for (uint32_t q = 0; q < Q_COUNT; q++) { s->qSlot[q].release(); s->qA[q].release(); s->qB[q].release(); s->qC[q].release(); }
   s->dCounters.release();
   if (s->hCounters) (void)hipHostFree(s->hCounters);
@@ -999,7 +1009,7 @@ extern "C" int giCRender(const GiCRenderParams* params)
   }
   if (params->aovBindingCount == 0) { setError("giCRender: no AOV bindings"); return GI_C_ERROR; }
   if (rs.spp == 0) { setError("giCRender: spp must be > 0"); return GI_C_ERROR; }
-  if (rs.mediumStackSize != 0) { setError("giCRender: volumes (mediumStackSize > 0) are not supported yet"); return GI_C_ERROR; }
+  if (rs.mediumStackSize > MAX_MEDIUM_STACK) { setError("giCRender: mediumStackSize > 8 is not supported"); return GI_C_ERROR; }
   const GiCRenderBuffer* sizeRb = (colorBinding ? colorBinding : &params->aovBindings[0])->renderBuffer;
   const uint32_t width = sizeRb->width, height = sizeRb->height;
   if (width == 0 || height == 0) return GI_C_OK; // Render.Empty-style degenerate target: nothing to do
@@ -1104,6 +1114,8 @@ extern "C" int giCRender(const GiCRenderParams* params)
     U.invTotalSampleCount = 1.0f / float(s->sampleOffset + rs.spp);
     U.maxSampleValue = rs.maxSampleValue; U.rrInvMinTermProb = rs.rrInvMinTermProb; U.lightIntensityMultiplier = rs.lightIntensityMultiplier;
     U.metersPerSceneUnit = rs.metersPerSceneUnit;
+    U.mediumStackSize = rs.mediumStackSize; U.maxVolumeWalkLength = rs.maxVolumeWalkLength;
+    U.mediumStackSize = rs.mediumStackSize; U.maxVolumeWalkLength = rs.maxVolumeWalkLength;
     U.maxBounces = std::min(rs.maxBounces, 0xfffu); U.rrBounceOffset = rs.rrBounceOffset & 0xffffu;
     U.imageWidth = width; U.imageHeight = height; U.rowBegin = rowBegin; U.pixelCount = (uint32_t)pixels;
     U.flags = (rs.jitteredSampling ? FLAG_JITTER : 0u) | (rs.filterImportanceSampling ? FLAG_FIS : 0u) | (rs.depthOfField ? FLAG_DOF : 0u) |
@@ -1163,7 +1175,10 @@ extern "C" int giCRender(const GiCRenderParams* params)
     }
     if (ensurePathState(s, slots, wideBlocks, traceBlocks) != GI_C_OK) return GI_C_ERROR;
     if (s->sampleBuf.alloc(pixels * batchSamples) || s->accum.alloc(pixels)) return GI_C_ERROR;
-    PathState ps{s->slots.ptr};
+    const uint32_t mediaStride = rs.mediumStackSize ? rs.mediumStackSize * MEDIUM_FLOATS + 4u : 0u;
+    if (mediaStride && s->media.alloc(slots * mediaStride)) return GI_C_ERROR;
+    PathState ps{s->slots.ptr, s->media.ptr, mediaStride};
+    view.mediumStackSize = rs.mediumStackSize;
     QueueSet qs = makeQueueSet(s);
     F4* colorOut = reinterpret_cast<F4*>(colorRb->deviceMem);
     const bool nee = rs.nextEventEstimation != 0;
@@ -1203,7 +1218,7 @@ extern "C" int giCRender(const GiCRenderParams* params)
         timed(1, [&] { launchTrace(st, traceBlocks, false, s->countTraversal, view, ps, qs, s->dCounters.ptr, Q_TRACE_A + par, Q_REGEN_A + (par ^ 1u), dynRefill, wideBlocks); });
         traceLaunches++;
         for (uint32_t klass = 0; klass < MAT_CLASS_COUNT; klass++)
-          if (s->classMask & (1u << klass)) timed(2, [&] { launchShade(st, wideBlocks, klass, (s->classTextured & (1u << klass)) != 0u, U, view, ps, qs, s->dCounters.ptr, par); });
+          if (s->classMask & (1u << klass)) timed(2, [&] { launchShade(st, wideBlocks, klass, (s->classTextured & (1u << klass)) != 0u, rs.mediumStackSize != 0u, U, view, ps, qs, s->dCounters.ptr, par); });
         if (nee) timed(3, [&] { launchTrace(st, traceBlocks, true, s->countTraversal, view, ps, qs, s->dCounters.ptr, Q_SHADOW, Q_SHADOW, dynRefill, wideBlocks); });
         iters++; totalIters++;
       }
@@ -1274,7 +1289,7 @@ extern "C" int giCTraceRays(GiCScene* s, uint32_t count, const float* origins, c
       hipMemcpyAsync(s->qA[Q_TRACE_A].ptr, qa.data(), qn * sizeof(F4), hipMemcpyHostToDevice, st) != hipSuccess ||
       hipMemcpyAsync(s->qB[Q_TRACE_A].ptr, qb.data(), qn * sizeof(F4), hipMemcpyHostToDevice, st) != hipSuccess ||
       hipMemcpyAsync(s->dCounters.ptr, &c, sizeof(c), hipMemcpyHostToDevice, st) != hipSuccess) { setError("giCTraceRays: upload failed"); return -1; }
-  PathState ps{s->slots.ptr};
+  PathState ps{s->slots.ptr, nullptr, 0u};
   launchTrace(st, blocks, false, false, makeView(s), ps, makeQueueSet(s), s->dCounters.ptr, Q_TRACE_A, Q_REGEN_B, traceDynRefill(s), blocks);
   std::vector<TriRec> tris(s->triCount);
   if (hipMemcpyAsync(&c, s->dCounters.ptr, sizeof(c), hipMemcpyDeviceToHost, st) != hipSuccess ||

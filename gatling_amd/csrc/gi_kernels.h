@@ -20,7 +20,7 @@ void launchTrace(hipStream_t s, uint32_t blocks, bool anyHit, bool count, const 
 constexpr uint32_t TRACE_DYN_SPILL8 = 0x100u; // flag in dynRefill: 8 LDS stack entries + scratch overflow instead of 16 LDS entries
 // dynRefill: 0 = block-synchronous k_trace; N = scenes that do not fit LDS use k_trace_dyn (a wave refills once N lanes are idle) + k_route
 // one launch per material class present in the scene (the class is the sort key between k_trace and k_shade)
-void launchShade(hipStream_t s, uint32_t blocks, uint32_t klass, bool textured /* some material of the class has textured inputs */, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par);
+void launchShade(hipStream_t s, uint32_t blocks, uint32_t klass, bool textured /* some material of the class has textured inputs */, bool volume /* mediumStackSize > 0 */, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par);
 
 void launchAov(hipStream_t s, const FrameUniforms& U, const SceneView& sc, const AovTargets& A);
 void launchDebugBsdf(hipStream_t s, const MaterialRec* mat, uint32_t count, const float* in, float* out);

@@ -593,6 +593,21 @@ __device__ __forceinline__ bool traverse(const SceneView& sc, const uint4* s_nod
   return R.found;
 }
 
+// shadeRayPayloadGetMediumIdx / shadeRayPayloadIncrementWalk (rp_main_payload.glsl:60-90), literally (see the oracle's notes:
+// the increment lands in bit 0 of the bounce counter, the walk length never grows)
+__device__ __forceinline__ uint32_t payload_medium_idx(uint32_t bitfield, uint32_t stackSize)
+{
+  const uint32_t idx = (bitfield & 0x0f000000u) >> 24, mx = stackSize > 1u ? stackSize : 1u;
+  return idx < mx ? idx : mx;
+}
+__device__ __forceinline__ void payload_increment_walk(uint32_t& bitfield)
+{
+  uint32_t b = bitfield & 0x00fff000u;
+  b = (b + 1u) < 0x00fff000u ? (b + 1u) : 0x00fff000u;
+  bitfield &= ~0x00fff000u;
+  bitfield |= b;
+}
+
 // rp_main.miss:55-86 for scenes with a dome light image (defined with the texture runtime below): adds
 // throughput * dome(direction) to the slot's radiance.  Without a dome image the miss term is the constant fallback dome,
 // which k_raygen applies when it retires the path (REGEN_MISSED).
@@ -625,12 +640,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
   for (uint32_t base = blockIdx.x * TRACE_BLOCK; base < n; base += stride, trip++) {
     const uint32_t i = base + threadIdx.x;
     bool hit = false, miss = false; uint32_t slot = 0, mat = 0;
-    float t = 0.0f, u = 0.0f, v = 0.0f; uint32_t tri = MISS; F4 rdir = F4{0.0f, 0.0f, 0.0f, 0.0f};
+    float t = 0.0f, u = 0.0f, v = 0.0f; uint32_t tri = MISS; F4 rdir = F4{0.0f, 0.0f, 0.0f, 0.0f}, ro = rdir;
     bool alive = false; uint32_t r = 0u, rng = 0u;
     if (i < n) {
       r = reader_index(rd, i);
       slot = qs.slot[qIn][r];
-      const F4 ro = ld4(&qs.a[qIn][r]);
+      ro = ld4(&qs.a[qIn][r]);
       rdir = ld4(&qs.b[qIn][r]);
       rng = CUTOUT ? f2u(st.slots[slot].rad.w) : 0u; // the any-hit test needs the path's rng state
       // shadow ray (rp_main.rgen:397-429): origin = next ray origin, tMin 0.01, tMax = distance to the light sample
@@ -656,20 +671,25 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
     if (!ANYHIT) {
       // sort by outcome and material class: hits go to their class's shade queue as (slot, hit, direction) records, misses
       // straight to k_raygen
-      const uint32_t klass = (mat >> 24) & 0xfu;
+      uint32_t klass = (mat >> 24) & 0xfu;
+      bool volMiss = false; // the segment ended inside a medium: a scattering event for k_shade<2>, not a miss (rp_main.miss:57-66)
+      if (DOME && miss && sc.mediumStackSize) {
+        volMiss = payload_medium_idx(f2u(st.slots[slot].thr.w), sc.mediumStackSize < MAX_MEDIUM_STACK ? sc.mediumStackSize : MAX_MEDIUM_STACK) > 0u;
+        if (volMiss) { miss = false; klass = 2u; }
+      }
       bool pred[1 + MAT_CLASS_COUNT]; uint32_t qid[1 + MAT_CLASS_COUNT]; uint32_t idx[1 + MAT_CLASS_COUNT];
       pred[0] = miss; qid[0] = qMiss;
 #pragma unroll
-      for (uint32_t c = 0; c < MAT_CLASS_COUNT; c++) { pred[1 + c] = hit && klass == c; qid[1 + c] = Q_HIT + c; }
+      for (uint32_t c = 0; c < MAT_CLASS_COUNT; c++) { pred[1 + c] = (hit || volMiss) && klass == c; qid[1 + c] = Q_HIT + c; }
       block_append<1 + MAT_CLASS_COUNT>(sh, trip, pred, qid, qs.cap, cnt, idx);
-      if (hit) {
+      if (hit || volMiss) {
         const uint32_t q = Q_HIT + klass, r = idx[1 + klass];
         qs.slot[q][r] = slot;
-        st4(&qs.a[q][r], t, u, v, u2f(tri));
-        st4(&qs.b[q][r], rdir.x, rdir.y, rdir.z, 0.0f);
+        if (!volMiss) { st4(&qs.a[q][r], t, u, v, u2f(tri)); st4(&qs.b[q][r], rdir.x, rdir.y, rdir.z, 0.0f); }
+        else { st4(&qs.a[q][r], rdir.w, ro.x, ro.y, u2f(VOLUME_MISS)); st4(&qs.b[q][r], rdir.x, rdir.y, rdir.z, ro.z); } // (tMax, origin) ride along
       }
       if (miss) {
-        if (DOME) { dome_miss(sc, &st.slots[slot], v3(rdir.x, rdir.y, rdir.z)); qs.slot[qMiss][idx[0]] = slot; } // scene has a dome light image
+        if (DOME && sc.domeTexture) { dome_miss(sc, &st.slots[slot], v3(rdir.x, rdir.y, rdir.z)); qs.slot[qMiss][idx[0]] = slot; } // scene has a dome light image
         else qs.slot[qMiss][idx[0]] = slot | REGEN_MISSED;
       }
     }
@@ -753,8 +773,8 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
       alive = false;
       wave_ray_end(W, R);
       if (!ANYHIT) {
-        st4(&qs.a[qIn][rec], R.tBest, R.bestU, R.bestV, u2f(R.found ? R.bestTri : MISS));
-        reinterpret_cast<uint32_t*>(&qs.b[qIn][rec])[3] = R.bestMat;
+        if (R.found) { st4(&qs.a[qIn][rec], R.tBest, R.bestU, R.bestV, u2f(R.bestTri)); reinterpret_cast<uint32_t*>(&qs.b[qIn][rec])[3] = R.bestMat; }
+        else { st4(&qs.a[qIn][rec], R.tBest, R.o.x, R.o.y, u2f(MISS)); reinterpret_cast<float*>(&qs.b[qIn][rec])[3] = R.o.z; } // (tMax, origin): k_route needs them for scattering events
       } else if (!R.found) {
         const F4 nc = ld4(&qs.c[qIn][rec]);
         Slot* S = &st.slots[qs.slot[qIn][rec]];
@@ -786,7 +806,7 @@ __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, Que
   uint32_t trip = 0;
   for (uint32_t base = blockIdx.x * BLOCK; base < n; base += stride, trip++) {
     const uint32_t i = base + threadIdx.x;
-    bool hit = false, miss = false; uint32_t slot = 0, klass = 0;
+    bool hit = false, miss = false, volMiss = false; uint32_t slot = 0, klass = 0;
     F4 h = F4{0.0f, 0.0f, 0.0f, 0.0f}, rdir = F4{0.0f, 0.0f, 0.0f, 0.0f};
     if (i < n) {
       const uint32_t r = reader_index(rd, i);
@@ -795,17 +815,21 @@ __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, Que
       rdir = ld4(&qs.b[qIn][r]);
       hit = f2u(h.w) != MISS; miss = !hit;
       klass = (f2u(rdir.w) >> 24) & 0xfu;
+      if (miss && sc.mediumStackSize) { // the segment ended inside a medium: scattering event for k_shade<2> (rp_main.miss:57-66)
+        volMiss = payload_medium_idx(f2u(st.slots[slot].thr.w), sc.mediumStackSize < MAX_MEDIUM_STACK ? sc.mediumStackSize : MAX_MEDIUM_STACK) > 0u;
+        if (volMiss) { miss = false; klass = 2u; }
+      }
     }
     bool pred[1 + MAT_CLASS_COUNT]; uint32_t qid[1 + MAT_CLASS_COUNT]; uint32_t idx[1 + MAT_CLASS_COUNT];
     pred[0] = miss; qid[0] = qMiss;
 #pragma unroll
-    for (uint32_t c = 0; c < MAT_CLASS_COUNT; c++) { pred[1 + c] = hit && klass == c; qid[1 + c] = Q_HIT + c; }
+    for (uint32_t c = 0; c < MAT_CLASS_COUNT; c++) { pred[1 + c] = (hit || volMiss) && klass == c; qid[1 + c] = Q_HIT + c; }
     block_append<1 + MAT_CLASS_COUNT>(sh, trip, pred, qid, qs.cap, cnt, idx);
-    if (hit) {
+    if (hit || volMiss) {
       const uint32_t q = Q_HIT + klass, r = idx[1 + klass];
       qs.slot[q][r] = slot;
-      st4(&qs.a[q][r], h.x, h.y, h.z, h.w);
-      st4(&qs.b[q][r], rdir.x, rdir.y, rdir.z, 0.0f);
+      if (!volMiss) { st4(&qs.a[q][r], h.x, h.y, h.z, h.w); st4(&qs.b[q][r], rdir.x, rdir.y, rdir.z, 0.0f); }
+      else { st4(&qs.a[q][r], h.x, h.y, h.z, u2f(VOLUME_MISS)); st4(&qs.b[q][r], rdir.x, rdir.y, rdir.z, rdir.w); }
     }
     if (miss) {
       if (sc.domeTexture) { dome_miss(sc, &st.slots[slot], v3(rdir.x, rdir.y, rdir.z)); qs.slot[qMiss][idx[0]] = slot; }
@@ -820,6 +844,7 @@ __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, Que
 struct ShState {
   V3 normal, geomNormal, position, tangentU, tangentV; bool frontFace; uint32_t meshFlags, material;
   float u, v;                    // texture coordinate 0 (mdl_shading_state.glsl:62-65)
+  float ior1, ior2;              // Bsdf_sample_data.ior1/ior2 (rp_main.chit:188-189): < 0 = the material's own; 0 = empty-stack default
   uint32_t texMask;              // bit per TEX_* slot whose value below replaces the material constant at this hit
   V3 texBaseColor, texEmission; float texRoughness, texMetallic;
 };
@@ -870,6 +895,7 @@ __device__ __forceinline__ void setup_shading_state(const SceneView& sc, uint32_
   s.tangentU = tg; s.tangentV = cross(nrm, tg) * bs;                                  // :59
   s.u = (bx * a2.w + by * b2.w) + bz * c2.w; s.v = (bx * a3.w + by * b3.w) + bz * c3.w; // :62-65
   s.normal = nrm; s.geomNormal = gn;
+  s.ior1 = 0.0f; s.ior2 = 0.0f;
   s.texMask = 0u; s.texBaseColor = v3(0.0f, 0.0f, 0.0f); s.texEmission = s.texBaseColor; s.texRoughness = 0.0f; s.texMetallic = 0.0f;
 }
 
@@ -1039,6 +1065,15 @@ __device__ inline void ggx_eval(V3 l1, V3 l2, float alpha, float& fcos, float& p
   pdf = G1 * D / (4.0f * nk1);
 }
 
+// ior2 / ior1 of the interface (== oracle relative_eta): eta entering, 1/eta leaving when the medium stack is empty
+__device__ __forceinline__ float relative_eta(const ShState& st, float materialEta)
+{
+  float e1 = st.ior1 == 0.0f ? (st.frontFace ? 1.0f : -1.0f) : st.ior1;
+  float e2 = st.ior2 == 0.0f ? (st.frontFace ? -1.0f : 1.0f) : st.ior2;
+  if (e1 < 0.0f) e1 = materialEta;
+  if (e2 < 0.0f) e2 = materialEta;
+  return e2 / e1;
+}
 struct UpsParams { V3 albedo, F0; float alpha, coat, coatAlpha; };
 // per-material constants are evaluated once on the host (gi_c.cpp: deriveMaterialConstants) with the same fp32
 // formulas the oracle evaluates per hit
@@ -1131,7 +1166,7 @@ __device__ inline void opbr_sample(const MaterialRec* m, const ShState& st, V3 k
     return;
   }
   z = (z - o.metalness) / (1.0f - o.metalness);
-  float eta = st.frontFace ? o.eta : 1.0f / o.eta;
+  float eta = relative_eta(st, o.eta);
   float Fd = fresnel_dielectric(nk1, eta);
   if (z < Fd) {
     GgxOut g = ggx_sample(l1, o.alpha, x0, x1);
@@ -1175,7 +1210,7 @@ __device__ inline void opbr_evaluate(const MaterialRec* m, const ShState& st, V3
   OpbrParams o = opbr_params(m, st);
   V3 l1 = to_local(st, k1), l2 = to_local(st, k2);
   float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
-  float eta = st.frontFace ? o.eta : 1.0f / o.eta;
+  float eta = relative_eta(st, o.eta);
   float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1));
   float Fd = fresnel_dielectric(nk1, eta);
   float fc, pc, khc; ggx_eval(l1, l2, o.coatAlpha, fc, pc, khc);
@@ -1345,7 +1380,7 @@ __device__ inline void sample_light(const SceneView& sc, const FrameUniforms& U,
 // k_shade: closest-hit shading + the post-trace part of the bounce loop, over the HIT queue only
 // (rp_main.chit:132-493, rp_main.rgen:397-480).  Misses never get here (k_trace routes them to k_raygen).
 // ------------------------------------------------------------------------------------------------
-template <uint32_t KLASS, bool TEXTURED>
+template <uint32_t KLASS, bool TEXTURED, bool VOLUME>
 __global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t par)
 {
   __shared__ AppendScratch<3> sh;
@@ -1357,7 +1392,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, 
   for (uint32_t base = blockIdx.x * BLOCK; base < n; base += stride, trip++) {
     const uint32_t i = base + threadIdx.x;
     bool cont = false, ended = false, shadow = false; uint32_t slot = 0;
-    V3 no = v3(0.0f, 0.0f, 0.0f), k2 = no, sdir = no, nee = no; float ld = 0.0f;
+    V3 no = v3(0.0f, 0.0f, 0.0f), k2 = no, sdir = no, nee = no; float ld = 0.0f, tMaxNext = GI_FLT_MAX;
     if (i < n) {
       const uint32_t r = reader_index(rdr, i);
       slot = qs.slot[qHit][r];
@@ -1371,18 +1406,44 @@ __global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, 
       const uint32_t bounce = bitfield & 0x00000fffu;
 
       const V3 rayDir = v3(rd.x, rd.y, rd.z);
+      const uint32_t stackSize = VOLUME ? (U.mediumStackSize < MAX_MEDIUM_STACK ? U.mediumStackSize : MAX_MEDIUM_STACK) : 0u;
+      float* M = VOLUME ? st.media + (size_t)slot * st.mediaStride : nullptr; // this path's medium stack + walkSegmentPdf
+      uint32_t mediumIdx = payload_medium_idx(bitfield, stackSize);
+      if (VOLUME && f2u(h.w) == VOLUME_MISS) {
+        // the segment ended inside a medium before reaching a surface: scattering event (stepVolume, rp_main.miss:16-34).
+        // Record: h = (tMax, origin.x, origin.y, -), rd = (dir, origin.z)
+        const float* m = M + (mediumIdx - 1u) * MEDIUM_FLOATS;
+        const float* wp = M + stackSize * MEDIUM_FLOATS;
+        const float distance = h.x * U.metersPerSceneUnit;
+        const V3 sigS = v3(m[2], m[3], m[4]), sigT = v3(m[5], m[6], m[7]);
+        const V3 tr = v3(gi_expf(sigT.x * -distance), gi_expf(sigT.y * -distance), gi_expf(sigT.z * -distance));
+        const V3 density = sigT * tr;
+        const float pdf = dot(v3(wp[0], wp[1], wp[2]), density);
+        throughput = throughput * ((sigS * tr) / pdf);
+        no = v3(h.y, h.z, rd.w) + rayDir * distance;
+        k2 = rayDir;
+        bitfield |= 0x40000000u; // SHADE_RAY_PAYLOAD_VOLUME_WALK_MISS_FLAG
+        payload_increment_walk(bitfield);
+      } else {
       ShState ss;
       setup_shading_state(sc, f2u(h.w), h.y, h.z, rayDir, ss);
       const MaterialRec* mat = &sc.materials[ss.material];
       if (TEXTURED && (mat->flags & MAT_FLAG_TEXTURED)) resolve_material_textures(sc, mat, rayDir, ss); // else ss.texMask stays 0 and folds away
       const bool isDoubleSided = (ss.meshFlags & 2u) != 0u;
-      // volume attenuation with an empty medium stack (rp_main.chit:160-186): inside (1-bit toggle) -> Beer-Lambert with the
-      // HIT material's absorption coefficient (:169-173)
-      uint32_t mediumIdx = (bitfield & 0x0f000000u) >> 24; if (mediumIdx > 1u) mediumIdx = 1u;
-      if (KLASS == 2u && mediumIdx > 0u) {
+      // volume attenuation (rp_main.chit:160-186)
+      float prevMediumIor = 1.0f, nextMediumIor = 1.0f;
+      if (mediumIdx > 0u) {
         const float distance = h.x * U.metersPerSceneUnit;
-        throughput = throughput * v3(gi_expf(-mat->p[MP_SIGMA_A] * distance), gi_expf(-mat->p[MP_SIGMA_A + 1] * distance), gi_expf(-mat->p[MP_SIGMA_A + 2] * distance));
+        if (!VOLUME) { // empty medium stack: inside (1-bit toggle) -> Beer-Lambert with the HIT material's absorption coefficient (:169-173)
+          if (KLASS == 2u) throughput = throughput * v3(gi_expf(-mat->p[MP_SIGMA_A] * distance), gi_expf(-mat->p[MP_SIGMA_A + 1] * distance), gi_expf(-mat->p[MP_SIGMA_A + 2] * distance));
+        } else { // the medium on top of the stack (:174-184)
+          const float* m = M + (mediumIdx - 1u) * MEDIUM_FLOATS;
+          prevMediumIor = m[0];
+          if (mediumIdx > 1u) nextMediumIor = M[(mediumIdx - 2u) * MEDIUM_FLOATS];
+          throughput = throughput * v3(gi_expf(-m[5] * distance), gi_expf(-m[6] * distance), gi_expf(-m[7] * distance));
+        }
       }
+      if (VOLUME) { ss.ior1 = ss.frontFace ? prevMediumIor : -1.0f; ss.ior2 = ss.frontFace ? -1.0f : nextMediumIor; } // iorCurrent / iorOther (:188-189)
       // emission (rp_main.chit:293-343): uniform EDF, radiance == emission colour where cos > 0
       const V3 em = (ss.texMask & (1u << TEX_EMISSION)) ? ss.texEmission : v3(mat->p[3], mat->p[4], mat->p[5]);
       if (em.x != 0.0f || em.y != 0.0f || em.z != 0.0f) {
@@ -1417,14 +1478,29 @@ __global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, 
         sdir = gi_safe_div(toLight, ld);
         shadow = gi_luminance(nee) > 1e-6f && ld > 1e-9f;
       }
-      if (isTransmission) { // medium toggle (:447-480), MEDIUM_STACK_SIZE == 0: inside/outside bit; walk counter reset
-        mediumIdx = 1u - mediumIdx;
-        bitfield &= ~0x00fff000u;
-        bitfield = (bitfield & ~0x0f000000u) | (mediumIdx << 24);
+      if (isTransmission) { // medium stack (:447-480)
+        uint32_t newIdx = mediumIdx;
+        if (VOLUME) {
+          if (ss.frontFace) { // push the material's medium: mdl_ior, mdl_volume_{scattering,absorption}_coefficient, MEDIUM_DIRECTIONAL_BIAS
+            newIdx = mediumIdx + 1u;
+            if (newIdx <= stackSize) {
+              float* m = M + (newIdx - 1u) * MEDIUM_FLOATS;
+              if (KLASS == 2u) {
+                const float depth = mat->p[28];
+                const V3 sigS = (depth > 0.0f) ? v3(mat->p[29] / depth, mat->p[30] / depth, mat->p[31] / depth) : v3(0.0f, 0.0f, 0.0f);
+                const V3 sigT = v3(mat->p[MP_SIGMA_A], mat->p[MP_SIGMA_A + 1], mat->p[MP_SIGMA_A + 2]) + sigS;
+                m[0] = mat->p[MP_ETA]; m[1] = mat->p[47]; m[2] = sigS.x; m[3] = sigS.y; m[4] = sigS.z; m[5] = sigT.x; m[6] = sigT.y; m[7] = sigT.z;
+              } else { m[0] = 1.0f; m[1] = 0.0f; m[2] = 0.0f; m[3] = 0.0f; m[4] = 0.0f; m[5] = 0.0f; m[6] = 0.0f; m[7] = 0.0f; }
+            }
+          } else if (mediumIdx > 0u) newIdx = mediumIdx - 1u; // pop
+        } else newIdx = 1u - mediumIdx; // MEDIUM_STACK_SIZE == 0: toggle between inside and outside
+        bitfield &= ~0x00fff000u; // medium changed -> reset walk
+        bitfield = (bitfield & ~0x0f000000u) | ((newIdx << 24) & 0x0f000000u);
       }
       if (bs.event == EV_ABSORB) bitfield |= 0x80000000u; // :483-486
       const V3 gn = ss.geomNormal * (isTransmission ? -1.0f : 1.0f);
       no = gi_offset_ray_origin(ss.position, gn); // :488-489
+      }
       // rp_main.rgen:441-480
       if (length(throughput) < 1e-9f) bitfield |= 0x80000000u;
       if (bounce > U.rrBounceOffset) {
@@ -1433,9 +1509,42 @@ __global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, 
         const float p = fmin2(mt, U.rrInvMinTermProb);
         if (k > p) bitfield |= 0x80000000u; else throughput = throughput / p;
       }
+      if (VOLUME && (bitfield & 0x40000000u)) { // :462-477: the random walk continues in a Henyey-Greenstein direction
+        const float x0 = gi_next1f(rng), x1 = gi_next1f(rng);
+        const float g = M[(mediumIdx - 1u) * MEDIUM_FLOATS + 1u];
+        float cosTheta;
+        if (fabsf(g) < 1e-3f) cosTheta = 1.0f - 2.0f * x0;
+        else { const float sq = (1.0f - g * g) / ((1.0f - g) + (2.0f * g) * x0); cosTheta = ((1.0f + g * g) - sq * sq) / (2.0f * g); }
+        const float sinTheta = sqrtf(fmax2(0.0f, 1.0f - cosTheta * cosTheta));
+        float sp, cp; gi_sincos2pi(x1, &sp, &cp);
+        V3 t, b; gi_orthonormal_basis(k2, t, b);
+        k2 = ((t * sinTheta) * cp + (b * sinTheta) * sp) + k2 * cosTheta;
+        bitfield &= ~0x40000000u;
+      }
       bitfield++;
       cont = ((bitfield & 0x00000fffu) < U.maxBounces) && !(bitfield & 0x80000000u); // loop test :298-304
       ended = !cont;
+      if (VOLUME && cont) { // top of the next loop iteration (:317-346): distance to the next collision inside a scattering medium
+        const uint32_t idx2 = payload_medium_idx(bitfield, stackSize);
+        if (idx2 > 0u) {
+          const float* m = M + (idx2 - 1u) * MEDIUM_FLOATS;
+          float* wp = M + stackSize * MEDIUM_FLOATS;
+          V3 wpdf = v3(1.0f, 1.0f, 1.0f);
+          const uint32_t walkLength = (bitfield & 0x00fff000u) >> 12;
+          const V3 sigS = v3(m[2], m[3], m[4]), sigT = v3(m[5], m[6], m[7]);
+          if ((sigS.x > 0.0f || sigS.y > 0.0f || sigS.z > 0.0f) && walkLength <= U.maxVolumeWalkLength) {
+            const V3 albedo = v3(gi_safe_div(sigS.x, sigT.x), gi_safe_div(sigS.y, sigT.y), gi_safe_div(sigS.z, sigT.z));
+            const float x0 = gi_next1f(rng), x1 = gi_next1f(rng);
+            const V3 weights = throughput * albedo; // sampleDistance (:49-69)
+            const float sum = (weights.x + weights.y) + weights.z;
+            wpdf = (sum > 1e-9f) ? (weights / sum) : v3(1.0f / 3.0f, 1.0f / 3.0f, 1.0f / 3.0f);
+            float sg = (x0 < wpdf.x) ? sigT.x : ((x0 < (wpdf.x + wpdf.y)) ? sigT.y : sigT.z);
+            sg = sg * U.metersPerSceneUnit;
+            tMaxNext = -gi_logf(1.0f - x1) / sg;
+          }
+          wp[0] = wpdf.x; wp[1] = wpdf.y; wp[2] = wpdf.z;
+        }
+      }
       st4(&S->thr, throughput.x, throughput.y, throughput.z, u2f(bitfield));
       st4(&S->rad, radiance.x, radiance.y, radiance.z, u2f(rng));
     }
@@ -1444,7 +1553,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, 
     if (cont) {
       qs.slot[qNext][idx[0]] = slot;
       st4(&qs.a[qNext][idx[0]], no.x, no.y, no.z, 0.0f);
-      st4(&qs.b[qNext][idx[0]], k2.x, k2.y, k2.z, GI_FLT_MAX);
+      st4(&qs.b[qNext][idx[0]], k2.x, k2.y, k2.z, tMaxNext);
     }
     if (ended) qs.slot[qRegen][idx[1]] = slot;
     if (shadow) {
@@ -1474,7 +1583,7 @@ __device__ inline V3 bsdf_albedo(const MaterialRec* m, const ShState& st, V3 k1)
     return diffuse + glossy;
   }
   OpbrParams o = opbr_params(m, st);
-  float eta = st.frontFace ? o.eta : 1.0f / o.eta;
+  float eta = relative_eta(st, o.eta);
   float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1));
   float Fd = fresnel_dielectric(nk1, eta);
   float base = 1.0f - Fc, diel = 1.0f - o.metalness;
@@ -1569,7 +1678,7 @@ __global__ void k_debug_bsdf(const MaterialRec* mat, uint32_t count, const float
   const float* p = in + 22 * (size_t)i; float* o = out + 15 * (size_t)i;
   ShState st; st.normal = v3(p); st.tangentU = v3(p + 3); st.tangentV = v3(p + 6); st.geomNormal = v3(p + 9);
   st.position = v3(0.0f, 0.0f, 0.0f); st.frontFace = (p[21] < 0.5f); st.meshFlags = 0u; st.material = 0u;
-  st.u = 0.0f; st.v = 0.0f; st.texMask = 0u;
+  st.u = 0.0f; st.v = 0.0f; st.texMask = 0u; st.ior1 = 0.0f; st.ior2 = 0.0f;
   BsdfSample bs; bsdf_sample<KLASS_DYNAMIC>(mat, st, v3(p + 12), p[18], p[19], p[20], bs);
   BsdfEval ev; bsdf_evaluate<KLASS_DYNAMIC>(mat, st, v3(p + 12), v3(p + 15), ev);
   o[0] = bs.k2.x; o[1] = bs.k2.y; o[2] = bs.k2.z; o[3] = bs.overPdf.x; o[4] = bs.overPdf.y; o[5] = bs.overPdf.z; o[6] = bs.pdf; o[7] = (float)bs.event;
@@ -1622,7 +1731,7 @@ static void launchTraceVariant(hipStream_t s, uint32_t blocks, const SceneView& 
     if (!ANYHIT) hipLaunchKernelGGL(k_route, dim3(routeBlocks), dim3(BLOCK), 0, s, sc, st, qs, cnt, qIn, qMiss);
     return;
   }
-  const bool dome = !ANYHIT && sc.domeTexture != 0u;
+  const bool dome = !ANYHIT && (sc.domeTexture != 0u || sc.mediumStackSize != 0u); // misses need the slot: dome image lookup / scattering events
 #define GI_LAUNCH_TRACE(STACK, OVF, LDS) do { \
     if (dome) hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, STACK, OVF, LDS, CUTOUT, !ANYHIT>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt); \
     else hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, STACK, OVF, LDS, CUTOUT, false>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt); } while (0)
@@ -1656,11 +1765,13 @@ void launchAov(hipStream_t s, const FrameUniforms& U, const SceneView& sc, const
   else if (sc.bvhDepth <= 16u) hipLaunchKernelGGL((k_aov<16, false>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, U, sc, A, ln, lt);
   else hipLaunchKernelGGL((k_aov<16, true>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, U, sc, A, ln, lt);
 }
-void launchShade(hipStream_t s, uint32_t blocks, uint32_t klass, bool textured, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par)
+void launchShade(hipStream_t s, uint32_t blocks, uint32_t klass, bool textured, bool volume, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par)
 {
 #define GI_LAUNCH_SHADE(K) do { \
-    if (textured) hipLaunchKernelGGL((k_shade<K, true>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par); \
-    else hipLaunchKernelGGL((k_shade<K, false>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par); } while (0)
+    if (volume) { if (textured) hipLaunchKernelGGL((k_shade<K, true, true>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par); \
+                  else hipLaunchKernelGGL((k_shade<K, false, true>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par); } \
+    else if (textured) hipLaunchKernelGGL((k_shade<K, true, false>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par); \
+    else hipLaunchKernelGGL((k_shade<K, false, false>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par); } while (0)
   if (klass == 0u) GI_LAUNCH_SHADE(0u); else if (klass == 1u) GI_LAUNCH_SHADE(1u); else GI_LAUNCH_SHADE(2u);
 #undef GI_LAUNCH_SHADE
 }

@@ -110,7 +110,7 @@ struct FrameUniforms {
   uint32_t batchFirstSample, batchSamples, workTotal, poolSlots; // this batch: samples [first, first+count) of every tile pixel
   uint32_t flags; // FLAG_*
   uint32_t sphereCount, distantCount, rectCount, diskCount, totalLightCount;
-  uint32_t pad[2];
+  uint32_t mediumStackSize, maxVolumeWalkLength; // GiRenderSettings (Gi.h:150-151); stack size 0 = inside/outside toggle only
 };
 enum : uint32_t {
   FLAG_JITTER = 1u, FLAG_FIS = 2u, FLAG_DOF = 4u, FLAG_CLIP = 8u, FLAG_NEE = 16u, FLAG_PROGRESSIVE = 32u,
@@ -140,6 +140,7 @@ struct SceneView {
   float domeRotation[4];
   float domeEmission[3];
   float background[3];        // the fallback dome texel: colour clear value as RGBA8 unorm (Gi.cpp:2194-2199)
+  uint32_t mediumStackSize;   // > 0: rays that end inside a medium scatter instead of leaving the scene (rp_main.miss:57-66)
 };
 
 struct alignas(16) F4 { float x, y, z, w; };
@@ -165,7 +166,11 @@ struct alignas(64) Slot {
 };
 static_assert(sizeof(Slot) == 64, "Slot must be 64 bytes");
 
-struct PathState { Slot* slots; };
+// Medium stack of a path (MEDIUM_STACK_SIZE > 0; rp_main_payload.glsl:11-17, 37-40): per slot `mediaStride` floats =
+// stack entries of 8 floats (ior, bias, sigma_s[3], sigma_t[3]) followed by walkSegmentPdf (3 floats + pad).
+constexpr uint32_t MEDIUM_FLOATS = 8, MAX_MEDIUM_STACK = 8;
+constexpr uint32_t VOLUME_MISS = 0xfffffffeu; // "triangle" id of a hit record that is a scattering event inside a medium
+struct PathState { Slot* slots; float* media; uint32_t mediaStride; };
 
 // Work queues.  Every queue is split into NSHARD segments (segment s holds records [s*cap, s*cap + count[q][s])):
 // producers append to the segment of their block (blockIdx % NSHARD, i.e. one per XCD in dispatch order), so the append

@@ -45,6 +45,8 @@ P_TRANSMISSION_WEIGHT = 23
 P_TRANSMISSION_COLOR = 24
 P_DIFFUSE_ROUGHNESS = 27
 P_TRANSMISSION_DEPTH = 28
+P_TRANSMISSION_SCATTER = 29           # 3
+P_TRANSMISSION_SCATTER_ANISOTROPY = 47  # (32..46 hold the device's derived constants)
 P_COUNT = 48
 
 
@@ -94,7 +96,8 @@ class MaterialDesc:
 def _open_pbr(name="mat", base_weight=1.0, base_color=(0.8, 0.8, 0.8), base_metalness=0.0, specular_weight=1.0,
               specular_color=(1, 1, 1), specular_roughness=0.3, specular_ior=1.5, transmission_weight=0.0,
               transmission_color=(1, 1, 1), transmission_depth=0.0, coat_weight=0.0, coat_color=(1, 1, 1), coat_roughness=0.0,
-              coat_ior=1.6, emission_luminance=0.0, emission_color=(1, 1, 1), base_diffuse_roughness=0.0) -> MaterialDesc:
+              coat_ior=1.6, emission_luminance=0.0, emission_color=(1, 1, 1), base_diffuse_roughness=0.0,
+              transmission_scatter=(0, 0, 0), transmission_scatter_anisotropy=0.0) -> MaterialDesc:
     """open_pbr_surface inputs with the defaults of src/gi/mtlx/open_pbr_surface.mtlx:11-92 (the lobes this core implements)."""
     p = np.zeros(P_COUNT, np.float32)
     p[P_BASE_COLOR:P_BASE_COLOR + 3] = base_color
@@ -114,6 +117,8 @@ def _open_pbr(name="mat", base_weight=1.0, base_color=(0.8, 0.8, 0.8), base_meta
     p[P_TRANSMISSION_COLOR:P_TRANSMISSION_COLOR + 3] = transmission_color
     p[P_DIFFUSE_ROUGHNESS] = base_diffuse_roughness
     p[P_TRANSMISSION_DEPTH] = transmission_depth
+    p[P_TRANSMISSION_SCATTER:P_TRANSMISSION_SCATTER + 3] = transmission_scatter
+    p[P_TRANSMISSION_SCATTER_ANISOTROPY] = transmission_scatter_anisotropy
     return MaterialDesc(name=name, klass=MAT_OPEN_PBR, params=p)
 
 

@@ -284,3 +284,29 @@ def textured_scene(seed: int = 7, dome: bool = True, klass_sphere: int = MAT_OPE
         s.dome_light = DomeLight(texture=env, rotation=tuple(np.float32(q)), base_emission=(0.9, 1.0, 1.1))
     s.camera = _look_at_camera((0, -5.5, 2.2), (0, 0, 0.7), (0, 0, 1), 45.0)
     return s
+
+
+def volume_scene(scatter=(0.6, 0.3, 0.1), anisotropy: float = 0.3, nested: bool = True) -> SceneDesc:
+    """Participating-media test scene: a closed icosphere of scattering, absorbing glass (OpenPBR transmission with
+    transmission_depth / transmission_scatter / anisotropy) on a diffuse floor, optionally with a smaller clear-glass
+    sphere nested inside it (exercises the medium stack), lit by a rect light and the fallback dome."""
+    from .meshprep import bake_vertices
+    s = SceneDesc()
+    s.materials = [MaterialDesc.usd_preview_surface(name="floor", diffuseColor=(0.6, 0.6, 0.6), roughness=0.7),
+                   MaterialDesc.open_pbr(name="murky", base_color=(0.9, 0.9, 0.9), specular_roughness=0.1, specular_ior=1.33, transmission_weight=1.0,
+                                         transmission_color=(0.8, 0.5, 0.3), transmission_depth=0.6, transmission_scatter=scatter,
+                                         transmission_scatter_anisotropy=anisotropy),
+                   MaterialDesc.open_pbr(name="clear", specular_roughness=0.05, specular_ior=1.6, transmission_weight=1.0,
+                                         transmission_color=(0.6, 0.9, 0.7), transmission_depth=0.3)]
+    fp = np.array([[-4, -4, 0], [4, -4, 0], [4, 4, 0], [-4, -4, 0], [4, 4, 0], [-4, 4, 0]], np.float32)
+    s.meshes.append(MeshDesc(name="/Floor", vertices=bake_vertices(fp, np.tile([0, 0, 1], (6, 1))), faces=np.arange(6, dtype=np.uint32).reshape(-1, 3),
+                             material=0, id=0, double_sided=True))
+    pts, faces = icosphere(2)
+    m = np.eye(4, dtype=np.float32); m[3, 2] = 1.05
+    s.meshes.append(MeshDesc(name="/Murky", vertices=bake_vertices(pts, pts), faces=faces, material=1, id=1, transform=m))
+    if nested:
+        m2 = np.eye(4, dtype=np.float32); m2[0, 0] = m2[1, 1] = m2[2, 2] = 0.45; m2[3, :3] = (0.2, 0.0, 1.1)
+        s.meshes.append(MeshDesc(name="/Clear", vertices=bake_vertices(pts, pts), faces=faces, material=2, id=2, transform=m2))
+    s.rect_lights = [RectLight(origin=(0.5, -0.5, 4.0), t0=(1, 0, 0), t1=(0, 1, 0), base_emission=(12, 12, 12), width=1.5, height=1.5)]
+    s.camera = _look_at_camera((0, -4.5, 1.6), (0, 0, 1.0), (0, 0, 1), 40.0)
+    return s

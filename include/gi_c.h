@@ -170,6 +170,8 @@ typedef struct GiCRenderParams {
 #define GI_C_P_TRANSMISSION_COLOR 24
 #define GI_C_P_DIFFUSE_ROUGHNESS 27
 #define GI_C_P_TRANSMISSION_DEPTH 28
+#define GI_C_P_TRANSMISSION_SCATTER 29 /* 3: OpenPBR transmission_scatter (open_pbr_surface.mtlx:35) */
+#define GI_C_P_TRANSMISSION_SCATTER_ANISOTROPY 47 /* transmission_scatter_anisotropy (:37); slots 32..46 are reserved */
 
 /* Note: p[GI_C_P_OPACITY] is the cutout opacity (1 = opaque); a zero-filled block is a fully transparent material. */
 typedef struct GiCMaterialDesc {

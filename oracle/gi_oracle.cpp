@@ -574,7 +574,20 @@ bool trace_any(const Prepared& P, V3 o, V3 d, float tMin, float tMax, uint32_t r
 // ---------------------------------------------------------------------------------------------
 // Shading state (mdl_shading_state.glsl:4-98)
 // ---------------------------------------------------------------------------------------------
-struct State { V3 normal, geomNormal, position, tangentU, tangentV; float u, v; bool frontFace; };
+struct State {
+  V3 normal, geomNormal, position, tangentU, tangentV; float u, v; bool frontFace;
+  // Bsdf_sample_data.ior1 / ior2 (rp_main.chit:188-189): ior of the medium the ray travels in / of the other side;
+  // < 0 = BSDF_USE_MATERIAL_IOR.  Defaults = empty medium stack (vacuum outside).
+  float ior1 = 0.0f, ior2 = 0.0f;
+};
+inline float relative_eta(const State& st, float materialEta)
+{
+  float e1 = st.ior1 == 0.0f ? (st.frontFace ? 1.0f : -1.0f) : st.ior1;
+  float e2 = st.ior2 == 0.0f ? (st.frontFace ? -1.0f : 1.0f) : st.ior2;
+  if (e1 < 0.0f) e1 = materialEta;
+  if (e2 < 0.0f) e2 = materialEta;
+  return e2 / e1;
+}
 
 void setup_shading_state(const Prepared& P, const Hit& h, V3 rayDir, State& st, const MeshData*& meshOut)
 {
@@ -797,7 +810,7 @@ inline V3 schlick_f82(V3 F0, V3 tint, float c)
   (void)cb;
   return v3(fmin2(fmax2(f.x, 0.0f), 1.0f), fmin2(fmax2(f.y, 0.0f), 1.0f), fmin2(fmax2(f.z, 0.0f), 1.0f));
 }
-struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, sigmaA; float metalness, alpha, coat, coatAlpha, coatF0, eta, tw, specWeight; };
+struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, sigmaA, sigmaS; float metalness, alpha, coat, coatAlpha, coatF0, eta, tw, specWeight, anisotropy; };
 inline OpbrParams opbr_params(const OrcMaterial& m)
 {
   OpbrParams o; const float* p = m.p;
@@ -825,7 +838,16 @@ inline OpbrParams opbr_params(const OrcMaterial& m)
   float depth = p[ORC_P_TRANSMISSION_DEPTH];
   V3 tc = v3(p + ORC_P_TRANSMISSION_COLOR);
   o.transTint = (depth > 0.0f) ? v3(1, 1, 1) : tc; // if_transmission_tint (:368-373)
-  o.sigmaA = (depth > 0.0f) ? v3(-logf(fmax2(tc.x, 1e-6f)) / depth, -logf(fmax2(tc.y, 1e-6f)) / depth, -logf(fmax2(tc.z, 1e-6f)) / depth) : v3(0, 0, 0);
+  // dielectric base VDF (open_pbr_surface.mtlx:220-298): extinction = -ln(transmission_color)/depth, scattering =
+  // transmission_scatter/depth, absorption = extinction - scattering, shifted to be non-negative
+  V3 ext = (depth > 0.0f) ? v3(-logf(fmax2(tc.x, 1e-6f)) / depth, -logf(fmax2(tc.y, 1e-6f)) / depth, -logf(fmax2(tc.z, 1e-6f)) / depth) : v3(0, 0, 0);
+  V3 sc = (depth > 0.0f) ? v3(p[ORC_P_TRANSMISSION_SCATTER] / depth, p[ORC_P_TRANSMISSION_SCATTER + 1] / depth, p[ORC_P_TRANSMISSION_SCATTER + 2] / depth) : v3(0, 0, 0);
+  V3 ab = ext - sc;
+  float mn = fmin2(fmin2(ab.x, ab.y), ab.z);
+  if (0.0f > mn) ab = ab - v3(mn, mn, mn);
+  o.sigmaA = (depth > 0.0f) ? ab : v3(0, 0, 0);
+  o.sigmaS = sc;
+  o.anisotropy = p[ORC_P_TRANSMISSION_SCATTER_ANISOTROPY];
   return o;
 }
 
@@ -855,7 +877,8 @@ void opbr_sample(const OrcMaterial& m, const State& st, V3 k1, const float xi[4]
     return;
   }
   z = (z - o.metalness) / (1.0f - o.metalness);
-  float eta = frontFace ? o.eta : 1.0f / o.eta; // rp_main.chit:188-189 with an empty medium stack
+  float eta = relative_eta(st, o.eta); // ior2 / ior1 (rp_main.chit:188-189); empty stack: eta entering, 1/eta leaving
+  (void)frontFace;
   float Fd = fresnel_dielectric(nk1, eta);
   if (z < Fd) { // dielectric reflection
     GgxOut g = ggx_sample(l1, o.alpha, xi[0], xi[1]);
@@ -899,7 +922,7 @@ void opbr_evaluate(const OrcMaterial& m, const State& st, V3 k1, V3 k2, bool fro
   OpbrParams o = opbr_params(m);
   V3 l1 = to_local(st, k1), l2 = to_local(st, k2);
   float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
-  float eta = frontFace ? o.eta : 1.0f / o.eta;
+  float eta = relative_eta(st, o.eta); (void)frontFace;
   float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1));
   float Fd = fresnel_dielectric(nk1, eta);
   float fc, pc, khc; ggx_eval(l1, l2, o.coatAlpha, fc, pc, khc);
@@ -1008,7 +1031,7 @@ V3 bsdf_albedo(const OrcMaterial& m, const State& st, V3 k1)
     return diffuse + glossy;
   }
   OpbrParams o = opbr_params(m);
-  float eta = st.frontFace ? o.eta : 1.0f / o.eta;
+  float eta = relative_eta(st, o.eta);
   float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1));
   float Fd = fresnel_dielectric(nk1, eta);
   float base = 1.0f - Fc, diel = 1.0f - o.metalness;
@@ -1091,10 +1114,30 @@ void sample_light(const Prepared& P, const Uniforms& ubo, const float k4[4], V3 
 // ---------------------------------------------------------------------------------------------
 // The per-pixel megakernel (rp_main.rgen:185-521 with rp_main.chit/.miss inlined)
 // ---------------------------------------------------------------------------------------------
+struct Medium { V3 ior, sigma_s, sigma_t; float bias; }; // rp_main_payload.glsl:11-17
+const uint32_t MAX_MEDIUM_STACK = 8;
 struct Payload { // rp_main_payload.glsl:20-48
   V3 throughput; uint32_t bitfield; V3 radiance; uint32_t rng; V3 origin, dir, neeToLight, neeContrib;
+  Medium media[MAX_MEDIUM_STACK]; V3 walkSegmentPdf; float tMaxLast; // MEDIUM_STACK_SIZE > 0 (tMaxLast = gl_RayTmaxEXT of the segment)
 };
 const uint32_t BOUNCES_MASK = 0x00000fffu, TERMINATE_FLAG = 0x80000000u, MEDIUM_MASK = 0x0f000000u; // rp_main_payload.glsl:3-9
+const uint32_t WALK_MISS_FLAG = 0x40000000u, WALK_MASK = 0x00fff000u, WALK_OFFSET = 12;
+// shadeRayPayloadGetMediumIdx (rp_main_payload.glsl:76-90): the stored index may exceed the stack size, reads clamp it
+inline uint32_t payload_medium_idx(uint32_t bitfield, uint32_t stackSize)
+{
+  uint32_t idx = (bitfield & MEDIUM_MASK) >> 24, mx = stackSize > 1u ? stackSize : 1u;
+  return idx < mx ? idx : mx;
+}
+// shadeRayPayloadIncrementWalk (rp_main_payload.glsl:60-69), restated literally: the "+ 1" is applied to the MASKED, unshifted
+// field, so it lands in bit 0 -- outside the walk mask -- and is OR-ed into the bounce counter; the walk length itself never
+// grows (so maxVolumeWalkLength never triggers).  Kept bug-compatible, like the FaceId fetch.
+inline void payload_increment_walk(uint32_t& bitfield)
+{
+  uint32_t b = bitfield & WALK_MASK;
+  b = (b + 1u) < WALK_MASK ? (b + 1u) : WALK_MASK;
+  bitfield &= ~WALK_MASK;
+  bitfield |= b;
+}
 
 struct Frame {
   const Prepared* P; const OrcCamera* cam; const OrcSettings* rs; Uniforms ubo;
@@ -1118,12 +1161,25 @@ void closest_hit(const Frame& F, const Hit& h, Payload& pl, float hitT)
   (void)isLeftHanded;
   // 3. volume attenuation with an empty medium stack (:160-186): inside (1-bit toggle) -> Beer-Lambert with the HIT material's
   // absorption coefficient (:169-173)
-  uint32_t mediumIdx = (pl.bitfield & MEDIUM_MASK) >> 24; if (mediumIdx > 1u) mediumIdx = 1u; // shadeRayPayloadGetMediumIdx
-  if (mediumIdx > 0 && mat.klass == ORC_MAT_OPEN_PBR) {
-    OpbrParams o = opbr_params(mat);
+  const uint32_t stackSize = F.rs->mediumStackSize < MAX_MEDIUM_STACK ? F.rs->mediumStackSize : MAX_MEDIUM_STACK;
+  uint32_t mediumIdx = payload_medium_idx(pl.bitfield, stackSize);
+  float prevMediumIor = 1.0f, nextMediumIor = 1.0f;
+  if (mediumIdx > 0) {
     float distance = hitT * F.rs->metersPerSceneUnit;
-    throughput = throughput * v3(expf_poly(-o.sigmaA.x * distance), expf_poly(-o.sigmaA.y * distance), expf_poly(-o.sigmaA.z * distance));
+    if (stackSize == 0) { // :169-173: the HIT material's absorption coefficient
+      if (mat.klass == ORC_MAT_OPEN_PBR) {
+        OpbrParams o = opbr_params(mat);
+        throughput = throughput * v3(expf_poly(-o.sigmaA.x * distance), expf_poly(-o.sigmaA.y * distance), expf_poly(-o.sigmaA.z * distance));
+      }
+    } else { // :174-184: the medium on top of the stack
+      const Medium& md = pl.media[mediumIdx - 1];
+      prevMediumIor = md.ior.x;
+      if (mediumIdx > 1) nextMediumIor = pl.media[mediumIdx - 2].ior.x;
+      throughput = throughput * v3(expf_poly(-md.sigma_t.x * distance), expf_poly(-md.sigma_t.y * distance), expf_poly(-md.sigma_t.z * distance));
+    }
   }
+  st.ior1 = st.frontFace ? prevMediumIor : -1.0f; // iorCurrent / iorOther (:188-189; thin-walled is not modelled)
+  st.ior2 = st.frontFace ? -1.0f : nextMediumIor;
 
   // 5. emission (:293-343).  uniform EDF: edf*intensity == emission colour, pdf>0 iff cos>0
   V3 em = v3(mat.p + ORC_P_EMISSION);
@@ -1165,9 +1221,21 @@ void closest_hit(const Frame& F, const Hit& h, Payload& pl, float hitT)
   }
   // medium toggle (:447-480): MEDIUM_STACK_SIZE == 0 -> inside/outside bit; the walk counter is reset
   if (isTransmission) {
-    mediumIdx = 1u - mediumIdx;
-    pl.bitfield &= ~0x00fff000u;
-    pl.bitfield = (pl.bitfield & ~MEDIUM_MASK) | (mediumIdx << 24);
+    if (stackSize > 0) { // :450-473
+      if (st.frontFace) { // push
+        mediumIdx++;
+        if (mediumIdx <= stackSize) {
+          Medium md; md.ior = v3(1, 1, 1); md.sigma_s = v3(0, 0, 0); md.sigma_t = v3(0, 0, 0); md.bias = 0.0f;
+          if (mat.klass == ORC_MAT_OPEN_PBR) { // mdl_ior, mdl_volume_{absorption,scattering}_coefficient, MEDIUM_DIRECTIONAL_BIAS
+            OpbrParams o = opbr_params(mat);
+            md.ior = v3(o.eta, o.eta, o.eta); md.sigma_s = o.sigmaS; md.sigma_t = o.sigmaA + o.sigmaS; md.bias = o.anisotropy;
+          }
+          pl.media[mediumIdx - 1] = md;
+        }
+      } else if (mediumIdx > 0) mediumIdx--; // pop
+    } else mediumIdx = 1u - mediumIdx; // toggle between inside and outside
+    pl.bitfield &= ~WALK_MASK;
+    pl.bitfield = (pl.bitfield & ~MEDIUM_MASK) | ((mediumIdx << 24) & MEDIUM_MASK);
   }
   if (eventType == EV_ABSORB) pl.bitfield |= TERMINATE_FLAG; // :483-486
   V3 gn = st.geomNormal * (isTransmission ? -1.0f : 1.0f);
@@ -1185,6 +1253,21 @@ inline V3 quat_rotate_dir(const float q[4], V3 dir) // rp_main.miss:38-44
 }
 void miss(const Frame& F, Payload& pl)
 {
+  if (F.rs->mediumStackSize > 0) { // rp_main.miss:16-34, 57-66: inside a medium the segment ended in a scattering event
+    uint32_t mediumIdx = payload_medium_idx(pl.bitfield, F.rs->mediumStackSize < MAX_MEDIUM_STACK ? F.rs->mediumStackSize : MAX_MEDIUM_STACK);
+    if (mediumIdx > 0) {
+      float distance = pl.tMaxLast * F.rs->metersPerSceneUnit;
+      const Medium& m = pl.media[mediumIdx - 1];
+      V3 tr = v3(expf_poly(m.sigma_t.x * -distance), expf_poly(m.sigma_t.y * -distance), expf_poly(m.sigma_t.z * -distance));
+      V3 density = m.sigma_t * tr;
+      float pdf = dot(pl.walkSegmentPdf, density);
+      pl.throughput = pl.throughput * ((m.sigma_s * tr) / pdf);
+      pl.origin = pl.origin + pl.dir * distance;
+      pl.bitfield |= WALK_MISS_FLAG;
+      payload_increment_walk(pl.bitfield);
+      return;
+    }
+  }
   pl.bitfield |= TERMINATE_FLAG;
   const OrcDomeLight* dome = F.P->dome;
   if (!dome) { pl.radiance = pl.radiance + pl.throughput * F.background; return; } // fallback dome, emission multiplier 1 (Gi.cpp:2385)
@@ -1241,6 +1324,28 @@ void render_pixel(const Frame& F, uint32_t px, uint32_t py, const float* prevCol
       if (bounce >= maxBounces || (pl.bitfield & TERMINATE_FLAG)) break;
       float tMin = 0.0f, tMax = ORC_FLT_MAX;
       if (rs.clippingPlanes && bounce == 0) { tMin = clipNear; tMax = clipFar; }
+      const uint32_t stackSize = rs.mediumStackSize < MAX_MEDIUM_STACK ? rs.mediumStackSize : MAX_MEDIUM_STACK;
+      uint32_t mediumIdx = 0;
+      if (stackSize > 0) { // :317-346: distance to the next collision inside a scattering medium
+        mediumIdx = payload_medium_idx(pl.bitfield, stackSize);
+        if (mediumIdx > 0) {
+          const Medium& m = pl.media[mediumIdx - 1];
+          pl.walkSegmentPdf = v3(1, 1, 1);
+          uint32_t walkLength = (pl.bitfield & WALK_MASK) >> WALK_OFFSET;
+          bool hasScattering = m.sigma_s.x > 0.0f || m.sigma_s.y > 0.0f || m.sigma_s.z > 0.0f;
+          if (hasScattering && walkLength <= rs.maxVolumeWalkLength) {
+            V3 albedo = v3(safe_div(m.sigma_s.x, m.sigma_t.x), safe_div(m.sigma_s.y, m.sigma_t.y), safe_div(m.sigma_s.z, m.sigma_t.z));
+            float x0 = next1f(pl.rng), x1 = next1f(pl.rng);
+            V3 weights = pl.throughput * albedo; // sampleDistance (:49-69)
+            float sum = (weights.x + weights.y) + weights.z;
+            pl.walkSegmentPdf = (sum > 1e-9f) ? (weights / sum) : v3(1.0f / 3.0f, 1.0f / 3.0f, 1.0f / 3.0f);
+            float sg = (x0 < pl.walkSegmentPdf.x) ? m.sigma_t.x : ((x0 < (pl.walkSegmentPdf.x + pl.walkSegmentPdf.y)) ? m.sigma_t.y : m.sigma_t.z);
+            sg = sg * rs.metersPerSceneUnit;
+            tMax = -logf_poly(1.0f - x1) / sg; // collision free distance
+          }
+        }
+      }
+      pl.tMaxLast = tMax;
       pl.neeContrib = v3(0, 0, 0); // :349
       Hit h;
       cnt.segments++; if (bounce < 64) cnt.bounceHistogram[bounce]++;
@@ -1260,6 +1365,18 @@ void render_pixel(const Frame& F, uint32_t px, uint32_t py, const float* prevCol
         float mt = fmax2(pl.throughput.x, fmax2(pl.throughput.y, pl.throughput.z));
         float p = fmin2(mt, rs.rrInvMinTermProb);
         if (k1 > p) pl.bitfield |= TERMINATE_FLAG; else pl.throughput = pl.throughput / p;
+      }
+      if (stackSize > 0 && (pl.bitfield & WALK_MISS_FLAG) != 0) { // :462-477: continue the random walk in a new direction
+        float x0 = next1f(pl.rng), x1 = next1f(pl.rng);
+        float g = pl.media[mediumIdx - 1].bias; // mediumIdx as read at the top of this iteration
+        float cosTheta; // sampleHenyeyGreensteinCos (:72-82)
+        if (fabsf(g) < 1e-3f) cosTheta = 1.0f - 2.0f * x0;
+        else { float sq = (1.0f - g * g) / ((1.0f - g) + (2.0f * g) * x0); cosTheta = ((1.0f + g * g) - sq * sq) / (2.0f * g); }
+        float sinTheta = sqrtf(fmax2(0.0f, 1.0f - cosTheta * cosTheta));
+        float sp, cp; sincos2pi(x1, &sp, &cp); // phi = 2 pi xi.y
+        V3 t, b; orthonormal_basis(pl.dir, t, b);
+        pl.dir = ((t * sinTheta) * cp + (b * sinTheta) * sp) + pl.dir * cosTheta; // :95
+        pl.bitfield &= ~WALK_MISS_FLAG;
       }
       pl.bitfield++; // :480
     }

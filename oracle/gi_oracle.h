@@ -69,6 +69,8 @@ enum {
   ORC_P_TRANSMISSION_COLOR = 24, /* 3 */
   ORC_P_DIFFUSE_ROUGHNESS = 27,
   ORC_P_TRANSMISSION_DEPTH = 28,
+  ORC_P_TRANSMISSION_SCATTER = 29, /* 3 */
+  ORC_P_TRANSMISSION_SCATTER_ANISOTROPY = 47, /* (32..46 hold the device's derived constants) */
   ORC_P_COUNT = 48
 };
 
@@ -163,6 +165,8 @@ typedef struct OrcSettings {
   float maxSampleValue;
   float rrInvMinTermProb;
   float metersPerSceneUnit;
+  uint32_t mediumStackSize;     /* GiRenderSettings.mediumStackSize (Gi.h:151): 0 = inside/outside toggle only; <= 8 here */
+  uint32_t maxVolumeWalkLength; /* Gi.h:150 */
   float clearColor[4]; /* Color AOV clear value == fallback dome colour (Gi.cpp:2184-2199) */
 } OrcSettings;
 

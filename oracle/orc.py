@@ -108,7 +108,8 @@ class OrcSettings(C.Structure):
                 ("nextEventEstimation", C.c_int32), ("progressiveAccumulation", C.c_int32),
                 ("maxBounces", C.c_uint32), ("rrBounceOffset", C.c_uint32), ("spp", C.c_uint32), ("sampleOffset", C.c_uint32),
                 ("lightIntensityMultiplier", C.c_float), ("maxSampleValue", C.c_float), ("rrInvMinTermProb", C.c_float),
-                ("metersPerSceneUnit", C.c_float), ("clearColor", C.c_float * 4)]
+                ("metersPerSceneUnit", C.c_float), ("mediumStackSize", C.c_uint32), ("maxVolumeWalkLength", C.c_uint32),
+                ("clearColor", C.c_float * 4)]
 
 
 class OrcRegion(C.Structure):
@@ -270,6 +271,8 @@ def _settings(rs, sample_offset=0) -> OrcSettings:
     s.maxSampleValue = rs.max_sample_value
     s.rrInvMinTermProb = rs.rr_inv_min_term_prob
     s.metersPerSceneUnit = rs.meters_per_scene_unit
+    s.mediumStackSize = rs.medium_stack_size
+    s.maxVolumeWalkLength = rs.max_volume_walk_length
     s.clearColor = (C.c_float * 4)(*rs.clear_color)
     return s
 

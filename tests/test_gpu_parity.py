@@ -16,7 +16,7 @@ from make_golden import CASES, build_case  # noqa: E402
 
 from gatling_amd.scene import (MAT_DIFFUSE, MAT_USD_PREVIEW_SURFACE, CameraDesc, DiskLight, DistantLight, MaterialDesc, MeshDesc,
                                RectLight, RenderSettings, SceneDesc, SphereLight)
-from gatling_amd.scenes import cornell_box, interior_scene, random_triangle_soup, sphere_grid, textured_scene
+from gatling_amd.scenes import cornell_box, interior_scene, random_triangle_soup, sphere_grid, textured_scene, volume_scene
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -256,7 +256,7 @@ def test_error_behaviour(gi):
         with pytest.raises(gi.GiError):
             sc.render(RenderSettings(spp=0), 8, 8)
         with pytest.raises(gi.GiError):
-            sc.render(RenderSettings(spp=1, medium_stack_size=2), 8, 8)
+            sc.render(RenderSettings(spp=1, medium_stack_size=9), 8, 8)  # stacks deeper than 8 media are refused
         img = sc.render(RenderSettings(spp=1, max_bounces=2), 8, 8)  # still usable afterwards
         assert np.isfinite(img).all()
     finally:
@@ -423,6 +423,28 @@ def test_dome_light_image_file(gi, orc, tmp_path):
     assert np.array_equal(from_file, ref)
     q = np.floor(np.float32([0.3, 0.6, 0.9]) * np.float32(255.0)) / np.float32(255.0)
     assert np.array_equal(fallback[..., :3], np.broadcast_to(q.astype(np.float32), fallback[..., :3].shape))
+
+
+@pytest.mark.parametrize("stack,nee", [(1, True), (2, True), (2, False), (4, True)])
+def test_volume_medium_stack_parity(gi, orc, stack, nee):
+    """Participating media with a medium stack (rp_main.rgen:48-97, 317-346, 462-477; rp_main.miss:16-34; rp_main.chit:160-186,
+    447-480): distance sampling, Henyey-Greenstein random walk, nested dielectrics with relative IOR -- bit-identical to the
+    oracle, segment counts included (scattering events are segments without a surface hit)."""
+    desc = volume_scene()
+    rs = RenderSettings(spp=4, max_bounces=12, next_event_estimation=nee, medium_stack_size=stack)
+    render_both(gi, orc, desc, rs, 96, 54)
+
+
+def test_volume_stack_of_one_equals_toggle(gi):
+    """One absorbing, non-scattering, un-nested medium: mediumStackSize 1 reproduces the inside/outside toggle exactly."""
+    desc = volume_scene(scatter=(0, 0, 0), nested=False)
+    sc = gi.Scene(desc)
+    try:
+        a = sc.render(RenderSettings(spp=4, max_bounces=10, progressive_accumulation=False), 96, 54)
+        b = sc.render(RenderSettings(spp=4, max_bounces=10, progressive_accumulation=False, medium_stack_size=1), 96, 54)
+    finally:
+        sc.close()
+    assert np.array_equal(a, b)
 
 
 def test_interior_scene_parity(gi, orc):

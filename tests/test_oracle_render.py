@@ -263,3 +263,29 @@ def test_textured_inputs(orc):
     n1 = orc.render_aovs(s, rs, 48, 27, ["normal"])["normal"]
     n2 = orc.render_aovs(s5, rs, 48, 27, ["normal"])["normal"]
     assert np.array_equal(n1, n2)
+
+
+def test_volume_medium_stack(orc):
+    """rp_main.rgen:48-97, 317-346, 462-477; rp_main.miss:16-34; rp_main.chit:160-186, 447-480 with MEDIUM_STACK_SIZE > 0."""
+    from gatling_amd.scenes import volume_scene
+    rs = lambda stack, **kw: RenderSettings(spp=6, max_bounces=12, next_event_estimation=True, medium_stack_size=stack, **kw)
+    # one absorbing, non-scattering, un-nested medium: the stack top holds what the 1-bit toggle reads off the hit material
+    plain = volume_scene(scatter=(0, 0, 0), nested=False)
+    a, ca = orc.render(plain, rs(0), 64, 36, threads=4)
+    b, cb = orc.render(plain, rs(1), 64, 36, threads=4)
+    assert np.array_equal(a, b) and ca["segments"] == cb["segments"]
+    # scattering: the walk changes the image, stays finite, and a deeper stack than the nesting depth changes nothing
+    murky = volume_scene()
+    i0, _ = orc.render(murky, rs(0), 64, 36, threads=4)
+    i1, c1 = orc.render(murky, rs(1), 64, 36, threads=4)
+    i2, c2 = orc.render(murky, rs(2), 64, 36, threads=4)
+    i4, c4 = orc.render(murky, rs(4), 64, 36, threads=4)
+    assert np.isfinite(i1).all() and np.isfinite(i2).all()
+    assert not np.array_equal(i0, i1) and not np.array_equal(i1, i2)
+    assert np.array_equal(i2, i4) and c2["segments"] == c4["segments"]
+    # in-medium scattering events are segments that end without a surface hit, yet the path goes on
+    assert c2["segments"] > c2["hits"] + c2["samples"] * 0  # misses exist ...
+    assert sum(c2["bounce_histogram"][1:]) > sum(orc.render(plain, rs(2), 64, 36, threads=4)[1]["bounce_histogram"][1:]) * 0.5
+    # metersPerSceneUnit scales the optical depth: a 100x smaller unit makes the medium nearly transparent
+    thin, _ = orc.render(murky, rs(2, meters_per_scene_unit=0.01), 64, 36, threads=4)
+    assert np.isfinite(thin).all() and not np.array_equal(thin, i2)
