@@ -282,6 +282,7 @@ struct GiCScene {
   // path state
   DeviceBuffer<Slot> slots;
   DeviceBuffer<float> media; // per-slot medium stack + walkSegmentPdf (mediumStackSize > 0)
+  DeviceBuffer<F4> scratchColor; DeviceBuffer<unsigned long long> neeKey; // NEE / Bounces AOVs bound without / with the colour AOV
   DeviceBuffer<F4> sampleBuf; // per-sample colours of the current batch, [sample][pixel] (rgb, -)
   DeviceBuffer<F4> accum;        // per-pixel running sum across batches
   DeviceBuffer<uint32_t> qSlot[Q_COUNT]; // NSHARD segments of queueCap records each
@@ -349,7 +350,7 @@ void giCDestroyScene(GiCScene* s)
   for (auto* b : s->dTexels) { b->release(); delete b; }
   s->dTexels.clear(); s->dTextures.release();
   s->dMaterials.release(); s->dSphere.release(); s->dDistant.release(); s->dRect.release(); s->dDisk.release();
-  s->slots.release(); s->media.release(); s->sampleBuf.release(); s->accum.release();
+  s->slots.release(); s->media.release(); s->scratchColor.release(); s->neeKey.release(); s->sampleBuf.release(); s->accum.release();
   for (uint32_t q = 0; q < Q_COUNT; q++) { s->qSlot[q].release(); s->qA[q].release(); s->qB[q].release(); s->qC[q].release(); }
   s->dCounters.release();
   if (s->hCounters) (void)hipHostFree(s->hCounters);
@@ -1039,8 +1040,10 @@ extern "C" int giCRender(const GiCRenderParams* params)
   if (!rs.progressiveAccumulation) s->dirty |= DIRTY_FRAMEBUFFER;
   if (s->dirty & DIRTY_FRAMEBUFFER) { s->sampleOffset = 0; s->dirty &= ~DIRTY_FRAMEBUFFER; }
 
-  // --- non-colour AOV bindings (Gi.h:36-56); NEE / Bounces / ClockCycles are not produced: they keep their clear value
+  // --- non-colour AOV bindings (Gi.h:36-56); ClockCycles is not produced: it keeps its clear value.  NEE and Bounces follow
+  // whole paths: they are filled by the colour pass (clear value first), see PathState.
   AovTargets aovT{}; bool anyAov = false;
+  GiCRenderBuffer* neeRb = nullptr; GiCRenderBuffer* bouncesRb = nullptr;
   std::vector<GiCRenderBuffer*> aovBuffers;
   for (uint32_t i = 0; i < params->aovBindingCount; i++) {
     const GiCAovBinding& b = params->aovBindings[i];
@@ -1062,6 +1065,8 @@ extern "C" int giCRender(const GiCRenderParams* params)
       case GI_C_AOV_OBJECT_ID: aovT.objectId = vec ? nullptr : reinterpret_cast<int32_t*>(rb->deviceMem); break;
       case GI_C_AOV_FACE_ID: aovT.faceId = vec ? nullptr : reinterpret_cast<int32_t*>(rb->deviceMem); break;
       case GI_C_AOV_INSTANCE_ID: aovT.instanceId = vec ? nullptr : reinterpret_cast<int32_t*>(rb->deviceMem); break;
+      case GI_C_AOV_NEE: if (vec) neeRb = rb; produced = false; break;
+      case GI_C_AOV_BOUNCES: if (vec) bouncesRb = rb; produced = false; break;
       default: produced = false; break;
     }
     if (produced) {
@@ -1074,9 +1079,15 @@ extern "C" int giCRender(const GiCRenderParams* params)
       HIP_TRY(hipMemcpyAsync(rb->deviceMem, rb->hostMem, rb->size, hipMemcpyHostToDevice, st));
     }
   }
-  if (!colorBinding && !anyAov) { HIP_TRY(hipStreamSynchronize(st)); return GI_C_OK; }
+  if (!colorBinding && !anyAov && !neeRb && !bouncesRb) { HIP_TRY(hipStreamSynchronize(st)); return GI_C_OK; }
   GiCRenderBuffer dummyColor{};
   GiCRenderBuffer* colorRb = colorBinding ? colorBinding->renderBuffer : nullptr;
+  if (!colorRb && (neeRb || bouncesRb)) { // the path-following debug AOVs need the colour pass: render it into a scratch buffer
+    if (s->scratchColor.alloc((size_t)width * height)) return GI_C_ERROR;
+    dummyColor.width = width; dummyColor.height = height; dummyColor.stride = 16; dummyColor.size = (size_t)width * height * 16;
+    dummyColor.deviceMem = s->scratchColor.ptr; dummyColor.deviceOnly = true;
+    colorRb = &dummyColor;
+  }
   if (colorRb && colorRb->stride != 16) { setError("giCRender: colour AOV needs a Float32Vec4 buffer"); return GI_C_ERROR; }
   (void)dummyColor;
 
@@ -1177,7 +1188,13 @@ extern "C" int giCRender(const GiCRenderParams* params)
     if (s->sampleBuf.alloc(pixels * batchSamples) || s->accum.alloc(pixels)) return GI_C_ERROR;
     const uint32_t mediaStride = rs.mediumStackSize ? rs.mediumStackSize * MEDIUM_FLOATS + 4u : 0u;
     if (mediaStride && s->media.alloc(slots * mediaStride)) return GI_C_ERROR;
-    PathState ps{s->slots.ptr, s->media.ptr, mediaStride};
+    PathState ps{s->slots.ptr, s->media.ptr, mediaStride, nullptr, 0u, nullptr};
+    if (neeRb) {
+      if (s->neeKey.alloc(pixels)) return GI_C_ERROR;
+      HIP_TRY(hipMemsetAsync(s->neeKey.ptr, 0, pixels * sizeof(unsigned long long), st));
+      ps.neeKey = s->neeKey.ptr;
+    }
+    if (bouncesRb) ps.bouncesAov = reinterpret_cast<F4*>(bouncesRb->deviceMem);
     view.mediumStackSize = rs.mediumStackSize;
     QueueSet qs = makeQueueSet(s);
     F4* colorOut = reinterpret_cast<F4*>(colorRb->deviceMem);
@@ -1200,6 +1217,7 @@ extern "C" int giCRender(const GiCRenderParams* params)
       U.batchFirstSample = (uint32_t)(batch * batchSamples);
       U.batchSamples = (uint32_t)std::min<uint64_t>(batchSamples, rs.spp - (uint64_t)batch * batchSamples);
       U.workTotal = (uint32_t)(pixels * U.batchSamples);
+      ps.neeSampleBase = U.batchFirstSample;
       const uint32_t poolNow = (uint32_t)std::min<uint64_t>(slots, U.workTotal);
       U.poolSlots = poolNow;
       launchInit(st, ps, qs, s->dCounters.ptr, poolNow, batch == 0);
@@ -1223,6 +1241,12 @@ extern "C" int giCRender(const GiCRenderParams* params)
         iters++; totalIters++;
       }
       launchAccumulate(st, U, s->sampleBuf.ptr, s->accum.ptr, colorOut, batch == 0, batch + 1 == numBatches);
+    }
+    if (neeRb) launchResolveNee(st, s->neeKey.ptr, reinterpret_cast<F4*>(neeRb->deviceMem), (uint32_t)pixels, rowBegin * width);
+    for (GiCRenderBuffer* rb : {neeRb, bouncesRb}) {
+      if (!rb || rb->deviceOnly) continue;
+      size_t off = (size_t)rowBegin * width * rb->stride, bytes = pixels * rb->stride;
+      HIP_TRY(hipMemcpyAsync((uint8_t*)rb->hostMem + off, (uint8_t*)rb->deviceMem + off, bytes, hipMemcpyDeviceToHost, st));
     }
   }
   if (anyAov) { // the non-colour AOV pass (k_aov) + read-back of the rows of this tile
@@ -1289,7 +1313,7 @@ extern "C" int giCTraceRays(GiCScene* s, uint32_t count, const float* origins, c
       hipMemcpyAsync(s->qA[Q_TRACE_A].ptr, qa.data(), qn * sizeof(F4), hipMemcpyHostToDevice, st) != hipSuccess ||
       hipMemcpyAsync(s->qB[Q_TRACE_A].ptr, qb.data(), qn * sizeof(F4), hipMemcpyHostToDevice, st) != hipSuccess ||
       hipMemcpyAsync(s->dCounters.ptr, &c, sizeof(c), hipMemcpyHostToDevice, st) != hipSuccess) { setError("giCTraceRays: upload failed"); return -1; }
-  PathState ps{s->slots.ptr, nullptr, 0u};
+  PathState ps{s->slots.ptr, nullptr, 0u, nullptr, 0u, nullptr};
   launchTrace(st, blocks, false, false, makeView(s), ps, makeQueueSet(s), s->dCounters.ptr, Q_TRACE_A, Q_REGEN_B, traceDynRefill(s), blocks);
   std::vector<TriRec> tris(s->triCount);
   if (hipMemcpyAsync(&c, s->dCounters.ptr, sizeof(c), hipMemcpyDeviceToHost, st) != hipSuccess ||

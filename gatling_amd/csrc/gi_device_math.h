@@ -191,6 +191,19 @@ __device__ __forceinline__ V3 gi_decode_direction(uint32_t e)
   return normalize(v);
 }
 
+// colormap_inferno (colormap.glsl:42-53), Horner form with plain mul/add
+__device__ __forceinline__ V3 gi_colormap_inferno(float t)
+{
+  const V3 c0 = v3(0.0002189403691192265f, 0.001651004631001012f, -0.01948089843709184f);
+  const V3 c1 = v3(0.1065134194856116f, 0.5639564367884091f, 3.932712388889277f);
+  const V3 c2 = v3(11.60249308247187f, -3.972853965665698f, -15.9423941062914f);
+  const V3 c3 = v3(-41.70399613139459f, 17.43639888205313f, 44.35414519872813f);
+  const V3 c4 = v3(77.162935699427f, -33.40235894210092f, -81.80730925738993f);
+  const V3 c5 = v3(-71.31942824499214f, 32.62606426397723f, 73.20951985803202f);
+  const V3 c6 = v3(25.13112622477341f, -12.24266895238567f, -23.07032500287172f);
+  return c0 + (c1 + (c2 + (c3 + (c4 + (c5 + c6 * t) * t) * t) * t) * t) * t;
+}
+
 __device__ __forceinline__ float gi_luminance(V3 c) { return dot(c, v3(0.2126f, 0.7152f, 0.0722f)); }
 __device__ __forceinline__ float gi_safe_div(float a, float b) { return (b == 0.0f) ? 0.0f : (a / b); }
 __device__ __forceinline__ V3 gi_safe_div(V3 v, float f) { return (f == 0.0f) ? v3(0.0f, 0.0f, 0.0f) : (v / f); }

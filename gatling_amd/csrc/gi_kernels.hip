@@ -193,6 +193,13 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st,
           F4 tb = ld4(&S->thr);
           rad = rad + v3(tb.x, tb.y, tb.z) * v3(U.background);
         }
+        if (st.bouncesAov && U.batchFirstSample + f2u(id.y) == U.spp - 1u) { // Bounces AOV: the pixel's last sample (rp_main.rgen:483-486)
+          // a path that left the scene was routed here straight from k_trace, before the loop's bounce++ (rp_main.rgen:480)
+          const uint32_t bounces = ((f2u(S->thr.w) + ((entry & REGEN_MISSED) ? 1u : 0u)) & 0x00000fffu), maxB = U.maxBounces < 0x00000fffu ? U.maxBounces : 0x00000fffu;
+          const V3 c = gi_colormap_inferno((float)bounces / (float)maxB);
+          F4* dst = &st.bouncesAov[U.rowBegin * U.imageWidth + f2u(id.x)];
+          dst->x = c.x; dst->y = c.y; dst->z = c.z;
+        }
         float mv = fmax2(rad.x, fmax2(rad.y, rad.z));
         if (mv > U.maxSampleValue) rad = rad * (U.maxSampleValue / mv);
         // one aligned 16-byte store: a 12-byte record straddles DRAM sectors and costs two read-modify-writes
@@ -608,6 +615,24 @@ __device__ __forceinline__ void payload_increment_walk(uint32_t& bitfield)
   bitfield |= b;
 }
 
+// NEE AOV bookkeeping (see PathState): latest shadow-ray outcome per tile pixel in the reference's (sample, bounce) order
+__device__ __forceinline__ void nee_aov_record(const PathState& st, uint32_t slot, bool shadowed)
+{
+  const Slot* S = &st.slots[slot];
+  const F4 id = ld4(&S->id);
+  const unsigned long long order = ((unsigned long long)(st.neeSampleBase + f2u(id.y)) << 12) | (unsigned long long)(f2u(S->thr.w) & 0x00000fffu);
+  atomicMax(&st.neeKey[f2u(id.x)], (order << 1) | (shadowed ? 1ull : 0ull));
+}
+__global__ void k_resolve_nee(const unsigned long long* __restrict__ key, F4* __restrict__ aov, uint32_t pixelCount, uint32_t firstPixel)
+{
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= pixelCount) return;
+  const unsigned long long k = key[p];
+  if (k == 0ull) return; // no shadow ray traced for this pixel: the AOV keeps its clear value
+  F4* dst = &aov[firstPixel + p];
+  dst->x = (k & 1ull) ? 1.0f : 0.0f; dst->y = (k & 1ull) ? 0.0f : 1.0f; dst->z = 0.0f;
+}
+
 // rp_main.miss:55-86 for scenes with a dome light image (defined with the texture runtime below): adds
 // throughput * dome(direction) to the slot's radiance.  Without a dome image the miss term is the constant fallback dome,
 // which k_raygen applies when it retires the path (REGEN_MISSED).
@@ -661,11 +686,14 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
       wave_ray_end(W, R);
       if (!ANYHIT) {
         hit = R.found; miss = !hit; t = R.tBest; u = R.bestU; v = R.bestV; tri = R.bestTri; mat = R.bestMat;
-      } else if (!R.found) {
-        const F4 nc = ld4(&qs.c[qIn][r]);
-        Slot* S = &st.slots[slot];
-        F4 rr = ld4(&S->rad);
-        st4(&S->rad, rr.x + nc.x, rr.y + nc.y, rr.z + nc.z, rr.w);
+      } else {
+        if (!R.found) {
+          const F4 nc = ld4(&qs.c[qIn][r]);
+          Slot* S = &st.slots[slot];
+          F4 rr = ld4(&S->rad);
+          st4(&S->rad, rr.x + nc.x, rr.y + nc.y, rr.z + nc.z, rr.w);
+        }
+        if (st.neeKey) nee_aov_record(st, slot, R.found);
       }
     }
     if (!ANYHIT) {
@@ -775,11 +803,15 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
       if (!ANYHIT) {
         if (R.found) { st4(&qs.a[qIn][rec], R.tBest, R.bestU, R.bestV, u2f(R.bestTri)); reinterpret_cast<uint32_t*>(&qs.b[qIn][rec])[3] = R.bestMat; }
         else { st4(&qs.a[qIn][rec], R.tBest, R.o.x, R.o.y, u2f(MISS)); reinterpret_cast<float*>(&qs.b[qIn][rec])[3] = R.o.z; } // (tMax, origin): k_route needs them for scattering events
-      } else if (!R.found) {
-        const F4 nc = ld4(&qs.c[qIn][rec]);
-        Slot* S = &st.slots[qs.slot[qIn][rec]];
-        F4 rr = ld4(&S->rad);
-        st4(&S->rad, rr.x + nc.x, rr.y + nc.y, rr.z + nc.z, rr.w);
+      } else {
+        const uint32_t slot = qs.slot[qIn][rec];
+        if (!R.found) {
+          const F4 nc = ld4(&qs.c[qIn][rec]);
+          Slot* S = &st.slots[slot];
+          F4 rr = ld4(&S->rad);
+          st4(&S->rad, rr.x + nc.x, rr.y + nc.y, rr.z + nc.z, rr.w);
+        }
+        if (st.neeKey) nee_aov_record(st, slot, R.found);
       }
     }
   }
@@ -1006,6 +1038,7 @@ __device__ void dome_miss(const SceneView& sc, Slot* S, V3 rayDir)
   }
   const V3 rad = v3(rr.x, rr.y, rr.z) + v3(tb.x, tb.y, tb.z) * (texel * v3(sc.domeEmission)); // :84-86
   st4(&S->rad, rad.x, rad.y, rad.z, rr.w);
+  S->thr.w = u2f(f2u(tb.w) + 1u); // the loop's bounce++ (rp_main.rgen:480): the path retires, only the Bounces AOV reads it
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1774,6 +1807,11 @@ void launchShade(hipStream_t s, uint32_t blocks, uint32_t klass, bool textured, 
     else hipLaunchKernelGGL((k_shade<K, false, false>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par); } while (0)
   if (klass == 0u) GI_LAUNCH_SHADE(0u); else if (klass == 1u) GI_LAUNCH_SHADE(1u); else GI_LAUNCH_SHADE(2u);
 #undef GI_LAUNCH_SHADE
+}
+
+void launchResolveNee(hipStream_t s, const unsigned long long* key, F4* aov, uint32_t pixelCount, uint32_t firstPixel)
+{
+  hipLaunchKernelGGL(k_resolve_nee, dim3((pixelCount + 255u) / 256u), dim3(256), 0, s, key, aov, pixelCount, firstPixel);
 }
 
 void launchDebugBsdf(hipStream_t s, const MaterialRec* mat, uint32_t count, const float* in, float* out)

@@ -170,7 +170,14 @@ static_assert(sizeof(Slot) == 64, "Slot must be 64 bytes");
 // stack entries of 8 floats (ior, bias, sigma_s[3], sigma_t[3]) followed by walkSegmentPdf (3 floats + pad).
 constexpr uint32_t MEDIUM_FLOATS = 8, MAX_MEDIUM_STACK = 8;
 constexpr uint32_t VOLUME_MISS = 0xfffffffeu; // "triangle" id of a hit record that is a scattering event inside a medium
-struct PathState { Slot* slots; float* media; uint32_t mediaStride; };
+// Debug AOVs that follow whole paths (only when bound): Bounces = inferno colour of the bounce count of the pixel's LAST
+// sample (rp_main.rgen:483-486, written by k_raygen when that sample retires); NEE = outcome of the pixel's last traced
+// shadow ray in the reference's sequential order (rp_main.rgen:431-435): k_trace<any> keeps, per tile pixel, the maximum of
+// (sample << 12 | bounce) << 1 | shadowed, k_resolve_nee turns it into red / green.
+struct PathState {
+  Slot* slots; float* media; uint32_t mediaStride;
+  unsigned long long* neeKey; uint32_t neeSampleBase; F4* bouncesAov;
+};
 
 // Work queues.  Every queue is split into NSHARD segments (segment s holds records [s*cap, s*cap + count[q][s])):
 // producers append to the segment of their block (blockIdx % NSHARD, i.e. one per XCD in dispatch order), so the append

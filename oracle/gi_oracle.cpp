@@ -1285,7 +1285,21 @@ void miss(const Frame& F, Payload& pl)
   pl.radiance = pl.radiance + pl.throughput * (texel * mult); // :84-86
 }
 
-void render_pixel(const Frame& F, uint32_t px, uint32_t py, const float* prevColor, float* out, OrcCounters& cnt)
+// colormap_inferno (colormap.glsl:42-53)
+inline V3 colormap_inferno(float t)
+{
+  const V3 c0 = v3(0.0002189403691192265f, 0.001651004631001012f, -0.01948089843709184f);
+  const V3 c1 = v3(0.1065134194856116f, 0.5639564367884091f, 3.932712388889277f);
+  const V3 c2 = v3(11.60249308247187f, -3.972853965665698f, -15.9423941062914f);
+  const V3 c3 = v3(-41.70399613139459f, 17.43639888205313f, 44.35414519872813f);
+  const V3 c4 = v3(77.162935699427f, -33.40235894210092f, -81.80730925738993f);
+  const V3 c5 = v3(-71.31942824499214f, 32.62606426397723f, 73.20951985803202f);
+  const V3 c6 = v3(25.13112622477341f, -12.24266895238567f, -23.07032500287172f);
+  return c0 + (c1 + (c2 + (c3 + (c4 + (c5 + c6 * t) * t) * t) * t) * t) * t;
+}
+struct PathDebug { int lastNee = -1; uint32_t lastBounces = 0; }; // NEE / Bounces AOV sources (rp_main.rgen:431-435, 483-486)
+
+void render_pixel(const Frame& F, uint32_t px, uint32_t py, const float* prevColor, float* out, OrcCounters& cnt, PathDebug* dbg = nullptr)
 {
   const OrcSettings& rs = *F.rs;
   uint32_t pixelIndex = px + py * F.width; // rp_main.rgen:195
@@ -1356,7 +1370,7 @@ void render_pixel(const Frame& F, uint32_t px, uint32_t py, const float* prevCol
         V3 sdir = safe_div(pl.neeToLight, lightDist);
         bool traceRay = luminance(pl.neeContrib) > 1e-6f && lightDist > 1e-9f;
         bool shadowed = true;
-        if (traceRay) { cnt.shadowRays++; shadowed = trace_any(*F.P, pl.origin, sdir, 0.01f, lightDist, pl.rng); }
+        if (traceRay) { cnt.shadowRays++; shadowed = trace_any(*F.P, pl.origin, sdir, 0.01f, lightDist, pl.rng); if (dbg) dbg->lastNee = shadowed ? 1 : 0; }
         if (traceRay && !shadowed) pl.radiance = pl.radiance + pl.neeContrib;
       }
       if (length(pl.throughput) < 1e-9f) pl.bitfield |= TERMINATE_FLAG; // :441-444
@@ -1380,6 +1394,7 @@ void render_pixel(const Frame& F, uint32_t px, uint32_t py, const float* prevCol
       }
       pl.bitfield++; // :480
     }
+    if (dbg) dbg->lastBounces = pl.bitfield & BOUNCES_MASK; // :483-486
     V3 rad = pl.radiance; // :489-498
     float mv = fmax2(rad.x, fmax2(rad.y, rad.z));
     if (mv > rs.maxSampleValue) rad = rad * (rs.maxSampleValue / mv);
@@ -1557,7 +1572,20 @@ int orc_render_aovs(const OrcScene* scene, const OrcCamera* camera, const OrcSet
   Prepared P; prepare(scene, P);
   Frame F; make_frame(F, P, camera, settings, region);
   for (uint32_t y = region->rowBegin; y < region->rowEnd; y++)
-    for (uint32_t x = 0; x < F.width; x++) render_pixel_aovs(F, x, y, (size_t)(y - region->rowBegin) * F.width + x, *aovs);
+    for (uint32_t x = 0; x < F.width; x++) {
+      const size_t o = (size_t)(y - region->rowBegin) * F.width + x;
+      render_pixel_aovs(F, x, y, o, *aovs);
+      if (aovs->nee || aovs->bounces) { // these two follow the whole paths of the colour pass
+        PathDebug dbg; OrcCounters cnt{}; float colour[4];
+        render_pixel(F, x, y, nullptr, colour, cnt, &dbg);
+        uint32_t maxBounces = settings->maxBounces < BOUNCES_MASK ? settings->maxBounces : BOUNCES_MASK;
+        if (aovs->bounces) { V3 c = colormap_inferno((float)dbg.lastBounces / (float)maxBounces); aovs->bounces[4 * o] = c.x; aovs->bounces[4 * o + 1] = c.y; aovs->bounces[4 * o + 2] = c.z; }
+        if (aovs->nee) {
+          V3 c = dbg.lastNee < 0 ? v3(aovs->clear[2]) : (dbg.lastNee ? v3(1, 0, 0) : v3(0, 1, 0));
+          aovs->nee[4 * o] = c.x; aovs->nee[4 * o + 1] = c.y; aovs->nee[4 * o + 2] = c.z;
+        }
+      }
+    }
   return 0;
 }
 

@@ -177,12 +177,14 @@ typedef struct OrcRegion {
 
 /* Non-colour AOVs (rp_main.rgen:132-183, 517-520; rp_main.chit:192-290).  Buffers are (rowEnd-rowBegin)*width elements: vec3
  * AOVs as 4 floats per pixel (std430 vec3[] stride; .w is never written), ids/depth as one int32/float.  NULL = not bound.
- * clear[id] is the binding's 16-byte clear value.  NEE, Bounces and ClockCycles are not produced. */
+ * clear[id] is the binding's 16-byte clear value.  NEE (rp_main.rgen:431-435: outcome of the pixel's last traced shadow ray) and
+ * Bounces (:483-486: inferno colour of the last sample's bounce count) need the full paths; ClockCycles is not produced. */
 typedef struct OrcAovs {
   float* normal; float* barycentrics; float* texcoords; float* opacity; float* tangents; float* bitangents; float* thinWalled;
   float* doubleSided; float* albedo; float* depth;
   int32_t* objectId; int32_t* faceId; int32_t* instanceId;
   float clear[17][4];
+  float* nee; float* bounces;
 } OrcAovs;
 float orc_atan2f(float y, float x);
 float orc_acosf(float x);
