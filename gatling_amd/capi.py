@@ -77,6 +77,10 @@ class GiCTextureBinding(C.Structure):
                 ("scale", C.c_float * 4), ("bias", C.c_float * 4)]
 
 
+class GiCPrimvarData(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("type", C.c_int32), ("interpolation", C.c_int32), ("data", C.c_void_p), ("dataSize", C.c_uint64)]
+
+
 SYMBOLS = [
     ("giCInitialize", C.c_int, [C.c_int]), ("giCTerminate", None, []), ("giCGetLastError", C.c_char_p, []),
     ("giCCreateMaterial", _P, [_P, C.c_char_p, C.POINTER(GiCMaterialDesc)]), ("giCDestroyMaterial", None, [_P]),
@@ -102,6 +106,8 @@ SYMBOLS = [
     ("giCSetDomeLightTexture", None, [_P, _P]),
     ("giCCreateTexture", _P, [_P, C.POINTER(GiCTextureDesc)]), ("giCDestroyTexture", None, [_P]),
     ("giCSetMaterialTexture", C.c_int, [_P, _I, C.POINTER(GiCTextureBinding)]),
+    ("giCSetMeshPrimvars", C.c_int, [_P, _U, C.POINTER(GiCPrimvarData)]), ("giCSetMeshInstancerPrimvars", C.c_int, [_P, _U, C.POINTER(GiCPrimvarData)]),
+    ("giCSetMaterialPrimvarInput", C.c_int, [_P, _I, C.c_char_p]),
     ("giCCreateRenderBuffer", _P, [_U, _U, _I]), ("giCDestroyRenderBuffer", None, [_P]), ("giCGetRenderBufferMem", _P, [_P]),
     ("giCGetRenderBufferDeviceMem", _P, [_P]), ("giCSetRenderBufferDeviceOnly", None, [_P, _I]),
     ("giCGetRenderStats", C.c_int, [_P, C.POINTER(GiCRenderStats)]), ("giCSetSceneOption", C.c_int, [_P, _I, _I]),
@@ -196,6 +202,9 @@ class Scene:
                 tb = GiCTextureBinding(self.textures[b.texture], int(b.wrap_s), int(b.wrap_t), int(b.channel), (C.c_float * 4)(*b.scale), (C.c_float * 4)(*b.bias))
                 if L.giCSetMaterialTexture(h, int(slot), C.byref(tb)) != GI_C_OK:
                     raise GiError("giCSetMaterialTexture failed: " + L.giCGetLastError().decode())
+            for slot, name in getattr(m, "primvar_inputs", {}).items():
+                if L.giCSetMaterialPrimvarInput(h, int(slot), name.encode()) != GI_C_OK:
+                    raise GiError("giCSetMaterialPrimvarInput failed: " + L.giCGetLastError().decode())
             self.materials.append(h)
         if getattr(desc, "dome_light", None) is not None:
             d = desc.dome_light
@@ -219,6 +228,16 @@ class Scene:
             if m.instance_ids is not None:
                 ids = np.ascontiguousarray(m.instance_ids, np.int32)
                 L.giCSetMeshInstanceIds(h, len(ids), ids.ctypes.data_as(C.POINTER(C.c_int32)))
+            for attr, fn in (("primvars", L.giCSetMeshPrimvars), ("instancer_primvars", L.giCSetMeshInstancerPrimvars)):
+                pvs = getattr(m, attr, [])
+                if pvs:
+                    arr, keep = (GiCPrimvarData * len(pvs))(), []
+                    for k, pv in enumerate(pvs):
+                        d = np.ascontiguousarray(pv.data, np.float32).reshape(-1)
+                        keep.append(d)
+                        arr[k] = GiCPrimvarData(pv.name.encode(), int(pv.type), int(pv.interpolation), d.ctypes.data, d.nbytes)
+                    if fn(h, len(pvs), arr) != GI_C_OK:  # copies the data
+                        raise GiError("giCSetMesh*Primvars failed: " + L.giCGetLastError().decode())
             if m.material >= 0:
                 L.giCSetMeshMaterial(h, self.materials[m.material])
             L.giCSetMeshVisibility(h, int(m.visible))

@@ -203,7 +203,8 @@ void deriveMaterialConstants(MaterialRec& m)
 enum DirtyFlags : uint32_t { DIRTY_BVH = 1u, DIRTY_FRAMEBUFFER = 2u, DIRTY_LIGHTS = 4u, DIRTY_MATERIALS = 8u, DIRTY_ALL = 0xfu };
 
 struct GiCTexture { GiCScene* scene; uint32_t width, height; std::vector<float> rgba; };
-struct GiCMaterial { GiCScene* scene; std::string name; GiCMaterialDesc desc; GiCTextureBinding tex[GI_C_TEX_SLOT_COUNT] = {}; };
+struct GiCPrimvar { std::string name; int32_t type, interpolation; std::vector<float> data; };
+struct GiCMaterial { GiCScene* scene; std::string name; GiCMaterialDesc desc; GiCTextureBinding tex[GI_C_TEX_SLOT_COUNT] = {}; std::string primvarInput[GI_C_TEX_SLOT_COUNT]; };
 
 struct GiCMesh {
   GiCScene* scene;
@@ -217,6 +218,7 @@ struct GiCMesh {
   float transform[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   std::vector<float> instanceTransforms; // 16 per instance; empty until giCSetMeshInstanceTransforms (as in Gi.cpp:620-638)
   std::vector<int32_t> instanceIds;
+  std::vector<GiCPrimvar> primvars, instancerPrimvars;
   GiCMaterial* material = nullptr;
 };
 
@@ -258,6 +260,7 @@ struct GiCScene {
   std::vector<GiCMesh*> meshes;       // creation order (deterministic triangle ids; the reference uses an unordered_set)
   std::vector<GiCMaterial*> materials;
   std::vector<GiCTexture*> textures;  // creation order
+  DeviceBuffer<MeshRec> dMeshes; DeviceBuffer<float> dSceneData;
   std::vector<DeviceBuffer<float>*> dTexels; DeviceBuffer<TextureRec> dTextures; // device copies (rebuilt with the materials)
   DenseStore<SphereLightRec, GiCSphereLight> sphereLights;
   DenseStore<DistantLightRec, GiCDistantLight> distantLights;
@@ -348,7 +351,7 @@ void giCDestroyScene(GiCScene* s)
   (void)hipStreamSynchronize(g_ctx.stream);
   s->dNodes.release(); s->dNodesLine.release(); s->dTris.release(); s->dInstances.release(); s->dVerts.release(); s->dTriFaceId.release();
   for (auto* b : s->dTexels) { b->release(); delete b; }
-  s->dTexels.clear(); s->dTextures.release();
+  s->dTexels.clear(); s->dTextures.release(); s->dMeshes.release(); s->dSceneData.release();
   s->dMaterials.release(); s->dSphere.release(); s->dDistant.release(); s->dRect.release(); s->dDisk.release();
   s->slots.release(); s->media.release(); s->scratchColor.release(); s->neeKey.release(); s->sampleBuf.release(); s->accum.release();
   for (uint32_t q = 0; q < Q_COUNT; q++) { s->qSlot[q].release(); s->qA[q].release(); s->qB[q].release(); s->qC[q].release(); }
@@ -608,6 +611,35 @@ void giCSetDiskLightRadius(GiCDiskLight* l, float rx, float ry) { DiskLightRec& 
 void giCSetDiskLightDiffuseSpecular(GiCDiskLight* l, float d, float s) { l->scene->diskLights.recs[l->index].ds = packHalf2x16(d, s); LIGHT_DIRTY(l); }
 
 
+// ---------------------------------------------------------------------------------------------------------------
+// scene data (primvars): Gi.h:76-92, 134, 213
+// ---------------------------------------------------------------------------------------------------------------
+static int setPrimvars(GiCMesh* mesh, std::vector<GiCPrimvar>& dst, uint32_t count, const GiCPrimvarData* pv)
+{
+  if (!mesh || (count && !pv)) { setError("giCSetMesh*Primvars: bad arguments"); return GI_C_ERROR; }
+  std::vector<GiCPrimvar> v;
+  for (uint32_t i = 0; i < count; i++) {
+    if (!pv[i].name || pv[i].type < 0 || pv[i].type > GI_C_PRIMVAR_INT4 || pv[i].interpolation < 0 || pv[i].interpolation > GI_C_INTERP_VERTEX) { setError("giCSetMesh*Primvars: bad primvar"); return GI_C_ERROR; }
+    GiCPrimvar p{pv[i].name, pv[i].type, pv[i].interpolation, {}};
+    if (pv[i].type <= GI_C_PRIMVAR_VEC4 && pv[i].data) p.data.assign((const float*)pv[i].data, (const float*)pv[i].data + pv[i].dataSize / 4);
+    v.push_back(std::move(p));
+  }
+  std::lock_guard<std::mutex> g(mesh->scene->mutex);
+  dst = std::move(v);
+  mesh->scene->dirty |= DIRTY_BVH | DIRTY_FRAMEBUFFER; // Gi.cpp:685-700
+  return GI_C_OK;
+}
+int giCSetMeshPrimvars(GiCMesh* mesh, uint32_t count, const GiCPrimvarData* pv) { return mesh ? setPrimvars(mesh, mesh->primvars, count, pv) : (setError("giCSetMeshPrimvars: null mesh"), GI_C_ERROR); }
+int giCSetMeshInstancerPrimvars(GiCMesh* mesh, uint32_t count, const GiCPrimvarData* pv) { return mesh ? setPrimvars(mesh, mesh->instancerPrimvars, count, pv) : (setError("giCSetMeshInstancerPrimvars: null mesh"), GI_C_ERROR); }
+int giCSetMaterialPrimvarInput(GiCMaterial* mat, int32_t input, const char* name)
+{
+  if (!mat || input < 0 || input >= GI_C_TEX_SLOT_COUNT || input == GI_C_TEX_NORMAL) { setError("giCSetMaterialPrimvarInput: bad arguments"); return GI_C_ERROR; }
+  std::lock_guard<std::mutex> g(mat->scene->mutex);
+  mat->primvarInput[input] = name ? name : "";
+  mat->scene->dirty |= DIRTY_MATERIALS | DIRTY_BVH | DIRTY_FRAMEBUFFER;
+  return GI_C_OK;
+}
+
 // Minimal decoders for dome-light images: Radiance .hdr (RGBE, flat or new-style RLE scanlines, -Y +X orientation) and
 // .pfm (PF, little or big endian, rows bottom-up).  Output: float RGBA, row 0 = first image row (top).
 static bool loadHdrOrPfm(const char* path, uint32_t& w, uint32_t& h, std::vector<float>& out)
@@ -810,7 +842,10 @@ int buildScene(GiCScene* s)
       TexBindingRec& r = mats[i].tex[slot];
       r = TexBindingRec{};
       auto tit = b.texture ? std::find(s->textures.begin(), s->textures.end(), b.texture) : s->textures.end();
-      if (tit == s->textures.end()) continue;
+      if (tit == s->textures.end()) {
+        if (!s->materials[i]->primvarInput[slot].empty()) { r.mode = TEX_MODE_PRIMVAR; mats[i].flags |= MAT_FLAG_TEXTURED; }
+        continue;
+      }
       r.tex = (uint32_t)(tit - s->textures.begin()) + 1u;
       r.mode = (uint32_t)b.wrapS | ((uint32_t)b.wrapT << 8) | (((uint32_t)b.channel & 3u) << 16);
       memcpy(r.scale, b.scale, 16); memcpy(r.bias, b.bias, 16);
@@ -820,6 +855,7 @@ int buildScene(GiCScene* s)
     deriveMaterialConstants(mats[i]);
   }
   uint32_t meshIdx = 0;
+  std::vector<MeshRec> meshRecs; std::vector<float> sceneData;
   s->classMask = 0; s->hasCutouts = false; s->classTextured = 0;
   for (GiCMesh* m : s->meshes) {
     if (!m->visible) continue; // Gi.cpp:801-804
@@ -834,6 +870,28 @@ int buildScene(GiCScene* s)
     s->classMask |= 1u << (mats[material].klass & 0xfu);
     if (mats[material].flags & MAT_FLAG_TEXTURED) s->classTextured |= 1u << (mats[material].klass & 0xfu);
     const uint32_t vertexOffset = (uint32_t)verts.size();
+    { // scene data the mesh's material reads (Gi.cpp:905-1019): instancer primvars first, mesh primvars override, by name
+      MeshRec mr{}; mr.vertexOffset = vertexOffset;
+      for (uint32_t slot = 0; slot < TEX_SLOT_COUNT; slot++) {
+        const std::string& want = (*mit)->primvarInput[slot];
+        if (want.empty()) continue;
+        const GiCPrimvar* pv = nullptr;
+        for (const GiCPrimvar& p : m->instancerPrimvars) if (p.name == want && !p.data.empty()) { pv = &p; break; }
+        for (const GiCPrimvar& p : m->primvars) if (p.name == want && !p.data.empty()) { pv = &p; break; }
+        if (!pv || pv->type > GI_C_PRIMVAR_VEC4) continue; // SCENE_DATA_INVALID
+        const uint32_t stride = (uint32_t)pv->type + 1u;
+        size_t entries = 1; // what a lookup can index: zero-padded so that short arrays read 0 like the oracle
+        if (pv->interpolation == GI_C_INTERP_VERTEX) entries = m->vertices.size();
+        else if (pv->interpolation == GI_C_INTERP_UNIFORM) entries = m->faces.size();
+        else if (pv->interpolation == GI_C_INTERP_INSTANCE) { int32_t mx = (int32_t)(m->instanceTransforms.size() / 16) - 1; for (int32_t id : m->instanceIds) mx = std::max(mx, id); entries = (size_t)std::max(mx, 0) + 1; }
+        mr.sdOffset[slot] = (uint32_t)sceneData.size();
+        mr.sdInfo[slot] = 1u | ((stride - 1u) << 1) | ((uint32_t)pv->interpolation << 3);
+        const size_t need = std::max(entries * stride, pv->data.size());
+        sceneData.insert(sceneData.end(), pv->data.begin(), pv->data.end());
+        sceneData.resize(mr.sdOffset[slot] + need, 0.0f);
+      }
+      meshRecs.push_back(mr);
+    }
     for (const GiCVertex& v : m->vertices) { // Gi.cpp:848-861: quantise normal/tangent to octahedral unorm2x16, then decode once
       FVertex fv; memcpy(fv.pos, v.pos, 12); fv.bsign = v.bitangentSign;
       decodeDirection(encodeDirection(v.norm), fv.normal); decodeDirection(encodeDirection(v.tangent), fv.tangent);
@@ -885,6 +943,7 @@ int buildScene(GiCScene* s)
   std::vector<int32_t> triFaceId(bvh.tris.size());
   for (size_t i = 0; i < bvh.tris.size(); i++) triFaceId[i] = faceIdOf[bvh.tris[i].origId];
   if (s->dTriFaceId.upload(triFaceId, st)) return GI_C_ERROR;
+  if (s->dMeshes.upload(meshRecs, st) || s->dSceneData.upload(sceneData, st)) return GI_C_ERROR;
   { // textures: one device array per image + the TextureRec table
     for (auto* b : s->dTexels) { b->release(); delete b; }
     s->dTexels.clear();
@@ -933,7 +992,7 @@ bool settingsEqual(const GiCRenderSettings& a, const GiCRenderSettings& b) { ret
 SceneView makeView(GiCScene* s)
 {
   SceneView v{};
-  v.textures = s->dTextures.ptr;
+  v.textures = s->dTextures.ptr; v.meshes = s->dMeshes.ptr; v.sceneData = s->dSceneData.ptr;
   v.nodes = s->nodeStrideU4 == 8u ? reinterpret_cast<const Node8*>(s->dNodesLine.ptr) : s->dNodes.ptr; v.nodeStrideU4 = s->nodeStrideU4; v.tris = s->dTris.ptr; v.instances = s->dInstances.ptr;
   v.verts = s->dVerts.ptr; v.materials = s->dMaterials.ptr; v.sphereLights = s->dSphere.ptr; v.distantLights = s->dDistant.ptr;
   v.rectLights = s->dRect.ptr; v.diskLights = s->dDisk.ptr; v.triFaceId = s->dTriFaceId.ptr; v.nodeCount = s->nodeCount; v.triCount = s->triCount; v.bvhDepth = s->bvhDepth; v.hasCutouts = s->hasCutouts ? 1u : 0u;

@@ -876,6 +876,7 @@ __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, Que
 struct ShState {
   V3 normal, geomNormal, position, tangentU, tangentV; bool frontFace; uint32_t meshFlags, material;
   float u, v;                    // texture coordinate 0 (mdl_shading_state.glsl:62-65)
+  uint32_t mesh, prim, vi[3]; int32_t instanceId; float hu, hv; // renderer state for scene-data lookups (mdl_interface.glsl:281-301)
   float ior1, ior2;              // Bsdf_sample_data.ior1/ior2 (rp_main.chit:188-189): < 0 = the material's own; 0 = empty-stack default
   uint32_t texMask;              // bit per TEX_* slot whose value below replaces the material constant at this hit
   V3 texBaseColor, texEmission; float texRoughness, texMetallic;
@@ -927,6 +928,7 @@ __device__ __forceinline__ void setup_shading_state(const SceneView& sc, uint32_
   s.tangentU = tg; s.tangentV = cross(nrm, tg) * bs;                                  // :59
   s.u = (bx * a2.w + by * b2.w) + bz * c2.w; s.v = (bx * a3.w + by * b3.w) + bz * c3.w; // :62-65
   s.normal = nrm; s.geomNormal = gn;
+  s.mesh = f2u(r5.y); s.instanceId = (int32_t)f2u(r5.z); s.prim = td.w; s.vi[0] = td.x; s.vi[1] = td.y; s.vi[2] = td.z; s.hu = hu; s.hv = hv;
   s.ior1 = 0.0f; s.ior2 = 0.0f;
   s.texMask = 0u; s.texBaseColor = v3(0.0f, 0.0f, 0.0f); s.texEmission = s.texBaseColor; s.texRoughness = 0.0f; s.texMetallic = 0.0f;
 }
@@ -995,7 +997,31 @@ __device__ inline void resolve_material_textures(const SceneView& sc, const Mate
 #pragma unroll
   for (uint32_t slot = 0; slot < TEX_SLOT_COUNT; slot++) {
     const TexBindingRec& b = m->tex[slot];
-    if (b.tex == 0u) continue;
+    if (b.tex == 0u) {
+      if (!(b.mode & TEX_MODE_PRIMVAR) || slot == TEX_NORMAL) continue;
+      // scene_data_lookup_float3 / _float (mdl_interface.glsl:337-371, 398-424; == oracle scene_data_lookup)
+      const MeshRec& mr = sc.meshes[st.mesh];
+      const uint32_t info = mr.sdInfo[slot];
+      if (!(info & 1u)) continue; // SCENE_DATA_INVALID: the input keeps its constant
+      const uint32_t stride = ((info >> 1) & 3u) + 1u, interp = (info >> 3) & 3u;
+      uint32_t i0, i1, i2;
+      if (interp == 2u) i0 = i1 = i2 = st.prim;                       // uniform
+      else if (interp == 1u) i0 = i1 = i2 = (uint32_t)st.instanceId;  // instance
+      else if (interp == 0u) i0 = i1 = i2 = 0u;                       // constant
+      else { i0 = st.vi[0] - mr.vertexOffset; i1 = st.vi[1] - mr.vertexOffset; i2 = st.vi[2] - mr.vertexOffset; } // vertex
+      const float* d = sc.sceneData + mr.sdOffset[slot];
+      const float bx = 1.0f - st.hu - st.hv, by = st.hu, bz = st.hv;
+      const bool vec = slot == TEX_BASE_COLOR || slot == TEX_EMISSION;
+      float o[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (uint32_t c = 0; c < 3u; c++) if (c == 0u || vec) o[c] = (d[i0 * stride + c] * bx + d[i1 * stride + c] * by) + d[i2 * stride + c] * bz;
+      st.texMask |= 1u << slot;
+      if (slot == TEX_BASE_COLOR) st.texBaseColor = v3(o[0], o[1], o[2]);
+      else if (slot == TEX_EMISSION) st.texEmission = v3(o[0], o[1], o[2]);
+      else if (slot == TEX_ROUGHNESS) st.texRoughness = o[0];
+      else st.texMetallic = o[0];
+      continue;
+    }
     const F4 t = tex_lookup_float4_2d(sc.textures[b.tex - 1u], st.u, st.v, b.mode & 0xffu, (b.mode >> 8) & 0xffu);
     const float val[4] = {t.x * b.scale[0] + b.bias[0], t.y * b.scale[1] + b.bias[1], t.z * b.scale[2] + b.bias[2], t.w * b.scale[3] + b.bias[3]};
     const uint32_t ch = (b.mode >> 16) & 3u;
@@ -1711,7 +1737,7 @@ __global__ void k_debug_bsdf(const MaterialRec* mat, uint32_t count, const float
   const float* p = in + 22 * (size_t)i; float* o = out + 15 * (size_t)i;
   ShState st; st.normal = v3(p); st.tangentU = v3(p + 3); st.tangentV = v3(p + 6); st.geomNormal = v3(p + 9);
   st.position = v3(0.0f, 0.0f, 0.0f); st.frontFace = (p[21] < 0.5f); st.meshFlags = 0u; st.material = 0u;
-  st.u = 0.0f; st.v = 0.0f; st.texMask = 0u; st.ior1 = 0.0f; st.ior2 = 0.0f;
+  st.u = 0.0f; st.v = 0.0f; st.texMask = 0u; st.ior1 = 0.0f; st.ior2 = 0.0f; st.mesh = 0u; st.prim = 0u; st.vi[0] = st.vi[1] = st.vi[2] = 0u; st.instanceId = 0; st.hu = st.hv = 0.0f;
   BsdfSample bs; bsdf_sample<KLASS_DYNAMIC>(mat, st, v3(p + 12), p[18], p[19], p[20], bs);
   BsdfEval ev; bsdf_evaluate<KLASS_DYNAMIC>(mat, st, v3(p + 12), v3(p + 15), ev);
   o[0] = bs.k2.x; o[1] = bs.k2.y; o[2] = bs.k2.z; o[3] = bs.overPdf.x; o[4] = bs.overPdf.y; o[5] = bs.overPdf.z; o[6] = bs.pdf; o[7] = (float)bs.event;

@@ -74,7 +74,12 @@ struct TexBindingRec {
   uint32_t mode;  // wrapS | wrapT << 8 | channel << 16
   float scale[4], bias[4];
 };
-constexpr uint32_t MAT_FLAG_TEXTURED = 1u << 31; // MaterialRec::flags: some input is textured (k_shade resolves the inputs per hit)
+constexpr uint32_t MAT_FLAG_TEXTURED = 1u << 31; // MaterialRec::flags: some input is textured or primvar-driven (k_shade resolves the inputs per hit)
+constexpr uint32_t TEX_MODE_PRIMVAR = 1u << 24;   // TexBindingRec::mode: (no texture) the input reads the mesh's scene data for this slot
+// Scene data (primvars) of a mesh for the material inputs of ITS material (replaces BlasPayloadBufferPreamble::sceneDataInfos,
+// rp_main.h:125-148, Gi.cpp:905-1019): per input slot the float offset into SceneView::sceneData and
+// info = valid | (stride - 1) << 1 | interpolation << 3 (GiPrimvarInterpolation: constant, instance, uniform, vertex).
+struct MeshRec { uint32_t vertexOffset; uint32_t pad; uint32_t sdOffset[TEX_SLOT_COUNT]; uint32_t sdInfo[TEX_SLOT_COUNT]; };
 struct MaterialRec {
   uint32_t klass;
   uint32_t flags;
@@ -134,6 +139,8 @@ struct SceneView {
   uint32_t hasCutouts; // some triangle has cutout opacity < 1: traversal runs the any-hit test (needs the path rng)
   uint32_t nodeStrideU4; // distance between nodes in 16-byte units: 5 (packed) or 8 (one node per 128-byte line)
   const TextureRec* textures;
+  const MeshRec* meshes;     // indexed by InstanceRec::mesh
+  const float* sceneData;    // all primvar arrays the bound materials read
   // dome light (rp_main.miss:38-86); domeTexture = index + 1 of the equirectangular image, 0 = fallback dome only
   uint32_t domeTexture;
   uint32_t domeCameraVisible; // GiRenderSettings.domeLightCameraVisible: primary rays see the dome image

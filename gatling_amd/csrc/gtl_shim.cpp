@@ -28,7 +28,7 @@ namespace gtl
     GiAssetReader* s_assetReader = nullptr;
 
     // ---- minimal MaterialX reader: first <UsdPreviewSurface|open_pbr_surface ...> element and its <input name value> children
-    struct MtlxNode { std::string category; std::map<std::string, std::string> inputs; };
+    struct MtlxNode { std::string category; std::map<std::string, std::string> inputs; std::map<std::string, std::string> connections; /* input -> upstream node name */ };
 
     std::string attr(const std::string& tag, const char* name)
     {
@@ -66,10 +66,37 @@ namespace gtl
         if (e == std::string::npos) break;
         std::string tag = doc.substr(p, e - p + 1);
         std::string name = attr(tag, "name"), value = attr(tag, "value");
-        if (!name.empty() && !value.empty() && attr(tag, "nodename").empty()) out.inputs[name] = value; // constants only
+        if (!name.empty() && !value.empty() && attr(tag, "nodename").empty()) out.inputs[name] = value; // constants
+        else if (!name.empty() && !attr(tag, "nodename").empty()) out.connections[name] = attr(tag, "nodename");
         p = e;
       }
       return true;
+    }
+
+    // If `nodeName` is a primvar reader (MaterialX <geompropvalue geomprop=...>, or a UsdPrimvarReader_* with varname), its primvar name
+    std::string primvarOfNode(const std::string& doc, const std::string& nodeName)
+    {
+      const std::string key = "name=\"" + nodeName + "\"";
+      size_t p = 0;
+      while ((p = doc.find(key, p)) != std::string::npos) {
+        size_t lt = doc.rfind('<', p);
+        if (lt == std::string::npos) break;
+        size_t sp = doc.find_first_of(" \t\r\n>", lt);
+        const std::string cat = doc.substr(lt + 1, sp - lt - 1);
+        if (cat == "geompropvalue" || cat.rfind("UsdPrimvarReader", 0) == 0) {
+          size_t close = doc.find("</" + cat, p), q = p;
+          while ((q = doc.find("<input", q)) != std::string::npos && (close == std::string::npos || q < close)) {
+            size_t e = doc.find('>', q);
+            if (e == std::string::npos) break;
+            const std::string tag = doc.substr(q, e - q + 1), n = attr(tag, "name");
+            if (n == "geomprop" || n == "varname") return attr(tag, "value");
+            q = e;
+          }
+          return {};
+        }
+        p += key.size();
+      }
+      return {};
     }
 
     int floats(const std::string& s, float* out, int maxN)
@@ -91,10 +118,11 @@ namespace gtl
       if (it != n.inputs.end()) floats(it->second, dst, count);
     }
 
-    bool descFromMtlx(const char* src, GiCMaterialDesc& d)
+    bool descFromMtlx(const char* src, GiCMaterialDesc& d, std::string (&primvars)[GI_C_TEX_SLOT_COUNT])
     {
       MtlxNode n;
       if (!src || !findSurfaceNode(src, n)) return false;
+      auto bind = [&](const char* input, int slot) { auto it = n.connections.find(input); if (it != n.connections.end()) primvars[slot] = primvarOfNode(src, it->second); };
       memset(&d, 0, sizeof(d));
       float* p = d.p;
       if (n.category == "UsdPreviewSurface") {
@@ -106,6 +134,7 @@ namespace gtl
         setN(n, "metallic", p + GI_C_P_METALLIC, 1); setN(n, "roughness", p + GI_C_P_ROUGHNESS, 1);
         setN(n, "clearcoat", p + GI_C_P_CLEARCOAT, 1); setN(n, "clearcoatRoughness", p + GI_C_P_CLEARCOAT_ROUGHNESS, 1);
         setN(n, "opacity", p + GI_C_P_OPACITY, 1); setN(n, "opacityThreshold", p + GI_C_P_OPACITY_THRESHOLD, 1); setN(n, "ior", p + GI_C_P_IOR, 1);
+        bind("diffuseColor", GI_C_TEX_BASE_COLOR); bind("emissiveColor", GI_C_TEX_EMISSION); bind("roughness", GI_C_TEX_ROUGHNESS); bind("metallic", GI_C_TEX_METALLIC);
         return true;
       }
       d.klass = GI_C_MAT_OPEN_PBR; // defaults: src/gi/mtlx/open_pbr_surface.mtlx:11-92
@@ -120,11 +149,13 @@ namespace gtl
       setN(n, "specular_weight", p + GI_C_P_SPECULAR_WEIGHT, 1); setN(n, "specular_color", p + GI_C_P_SPECULAR_COLOR, 3);
       setN(n, "specular_roughness", p + GI_C_P_ROUGHNESS, 1); setN(n, "specular_ior", p + GI_C_P_IOR, 1);
       setN(n, "transmission_weight", p + GI_C_P_TRANSMISSION_WEIGHT, 1); setN(n, "transmission_color", p + GI_C_P_TRANSMISSION_COLOR, 3);
-      setN(n, "transmission_depth", p + GI_C_P_TRANSMISSION_DEPTH, 1);
+      setN(n, "transmission_depth", p + GI_C_P_TRANSMISSION_DEPTH, 1); setN(n, "transmission_scatter", p + GI_C_P_TRANSMISSION_SCATTER, 3);
+      setN(n, "transmission_scatter_anisotropy", p + GI_C_P_TRANSMISSION_SCATTER_ANISOTROPY, 1);
       setN(n, "coat_weight", p + GI_C_P_CLEARCOAT, 1); setN(n, "coat_color", p + GI_C_P_COAT_COLOR, 3);
       setN(n, "coat_roughness", p + GI_C_P_CLEARCOAT_ROUGHNESS, 1); setN(n, "coat_ior", p + GI_C_P_COAT_IOR, 1);
       setN(n, "emission_luminance", &lum, 1); setN(n, "emission_color", ecol, 3); setN(n, "geometry_opacity", p + GI_C_P_OPACITY, 1);
       for (int i = 0; i < 3; i++) p[GI_C_P_EMISSION + i] = lum * ecol[i];
+      bind("base_color", GI_C_TEX_BASE_COLOR); bind("specular_roughness", GI_C_TEX_ROUGHNESS); bind("base_metalness", GI_C_TEX_METALLIC);
       return true;
     }
   }
@@ -139,14 +170,23 @@ namespace gtl
 
   GiMaterial* giCreateMaterialFromMtlxStr(GiScene* scene, const char* name, const char* mtlxSrc)
   {
-    GiCMaterialDesc d;
-    if (!scene || !descFromMtlx(mtlxSrc, d)) return nullptr;
+    GiCMaterialDesc d; std::string primvars[GI_C_TEX_SLOT_COUNT];
+    if (!scene || !descFromMtlx(mtlxSrc, d, primvars)) return nullptr;
     GiCMaterial* h = giCCreateMaterial(scene->h, name, &d);
-    return h ? new GiMaterial{h} : nullptr;
+    if (!h) return nullptr;
+    for (int slot = 0; slot < GI_C_TEX_SLOT_COUNT; slot++) if (!primvars[slot].empty()) giCSetMaterialPrimvarInput(h, slot, primvars[slot].c_str());
+    return new GiMaterial{h};
   }
   GiMaterial* giCreateMaterialFromMtlxDoc(GiScene*, const char*, const std::shared_ptr<void>) { return nullptr; }
   GiMaterial* giCreateMaterialFromMdlFile(GiScene*, const char*, const char*, const char*, const GiMaterialParameters&) { return nullptr; }
   void giDestroyMaterial(GiMaterial* mat) { if (!mat) return; giCDestroyMaterial(mat->h); delete mat; }
+
+  static void setPrimvars(GiCMesh* h, const std::vector<GiPrimvarData>& pv, bool instancer)
+  {
+    std::vector<GiCPrimvarData> c(pv.size());
+    for (size_t i = 0; i < pv.size(); i++) c[i] = GiCPrimvarData{pv[i].name.c_str(), (int32_t)pv[i].type, (int32_t)pv[i].interpolation, pv[i].data.data(), (uint64_t)pv[i].data.size()};
+    if (instancer) giCSetMeshInstancerPrimvars(h, (uint32_t)c.size(), c.data()); else giCSetMeshPrimvars(h, (uint32_t)c.size(), c.data());
+  }
 
   GiMesh* giCreateMesh(GiScene* scene, const GiMeshDesc& d)
   {
@@ -157,11 +197,13 @@ namespace gtl
     c.id = d.id; c.isDoubleSided = d.isDoubleSided; c.isLeftHanded = d.isLeftHanded; c.name = d.name; c.maxFaceId = d.maxFaceId;
     c.vertexCount = d.vertexCount; c.vertices = reinterpret_cast<const GiCVertex*>(d.vertices.data());
     GiCMesh* h = scene ? giCCreateMesh(scene->h, &c) : nullptr;
-    return h ? new GiMesh{h} : nullptr;
+    if (!h) return nullptr;
+    setPrimvars(h, d.primvars, false);
+    return new GiMesh{h};
   }
   void giSetMeshTransform(GiMesh* m, const float* mat4x4) { giCSetMeshTransform(m->h, mat4x4); }
   void giSetMeshInstanceTransforms(GiMesh* m, uint32_t count, const float (*t)[4][4]) { giCSetMeshInstanceTransforms(m->h, count, reinterpret_cast<const float*>(t)); }
-  void giSetMeshInstancerPrimvars(GiMesh*, const std::vector<GiPrimvarData>&) {}
+  void giSetMeshInstancerPrimvars(GiMesh* m, const std::vector<GiPrimvarData>& pv) { setPrimvars(m->h, pv, true); }
   void giSetMeshInstanceIds(GiMesh* m, uint32_t count, int* ids) { giCSetMeshInstanceIds(m->h, count, ids); }
   void giSetMeshMaterial(GiMesh* m, GiMaterial* mat) { giCSetMeshMaterial(m->h, mat ? mat->h : nullptr); }
   void giSetMeshVisibility(GiMesh* m, bool visible) { giCSetMeshVisibility(m->h, visible); }

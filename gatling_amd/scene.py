@@ -71,6 +71,7 @@ class MaterialDesc:
     klass: int = MAT_USD_PREVIEW_SURFACE
     params: np.ndarray = field(default_factory=lambda: np.zeros(P_COUNT, np.float32))
     textures: dict = field(default_factory=dict)   # TEX_* slot -> TextureBinding
+    primvar_inputs: dict = field(default_factory=dict)   # TEX_* slot -> primvar name (UsdPrimvarReader; scene_data_lookup_*)
 
     @staticmethod
     def usd_preview_surface(name="mat", diffuseColor=(0.18, 0.18, 0.18), emissiveColor=(0, 0, 0),
@@ -125,6 +126,19 @@ def _open_pbr(name="mat", base_weight=1.0, base_color=(0.8, 0.8, 0.8), base_meta
 MaterialDesc.open_pbr = staticmethod(_open_pbr)
 
 
+PRIMVAR_FLOAT, PRIMVAR_VEC2, PRIMVAR_VEC3, PRIMVAR_VEC4 = 0, 1, 2, 3                       # GiPrimvarType (Gi.h:76-79)
+INTERP_CONSTANT, INTERP_INSTANCE, INTERP_UNIFORM, INTERP_VERTEX = 0, 1, 2, 3                # GiPrimvarInterpolation (Gi.h:81-84)
+
+
+@dataclass
+class Primvar:
+    """GiPrimvarData (Gi.h:86-92): float data, [n] or [n, components]."""
+    name: str
+    type: int
+    interpolation: int
+    data: np.ndarray
+
+
 @dataclass
 class MeshDesc:
     name: str
@@ -140,6 +154,8 @@ class MeshDesc:
     instance_ids: Optional[np.ndarray] = None
     face_ids: Optional[np.ndarray] = None   # int32 per face (GiMeshDesc.faceIds); None = zeros
     max_face_id: int = 0
+    primvars: list = field(default_factory=list)            # GiMeshDesc.primvars
+    instancer_primvars: list = field(default_factory=list)  # giSetMeshInstancerPrimvars
 
 
 @dataclass

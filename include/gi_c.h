@@ -208,6 +208,28 @@ typedef struct GiCTextureBinding {
 } GiCTextureBinding;
 int giCSetMaterialTexture(GiCMaterial* material, int32_t input, const GiCTextureBinding* binding);
 
+/* Scene data (primvars).  Gi.h:76-92: GiPrimvarData with the byte vector flattened to pointer + size; float types feed the
+ * closed-form material inputs, int types are accepted and ignored.  A material input bound to a primvar NAME reads the primvar
+ * of the hit mesh (instancer primvars first, mesh primvars override, Gi.cpp:913-929) through scene_data_lookup_float3 /
+ * _float (mdl_interface.glsl:281-301, 337-424): barycentric blend of the three vertex values, or the uniform / instance /
+ * constant value.  A mesh without that primvar keeps the input's constant.  A texture on the same input takes precedence. */
+#define GI_C_PRIMVAR_FLOAT 0
+#define GI_C_PRIMVAR_VEC2 1
+#define GI_C_PRIMVAR_VEC3 2
+#define GI_C_PRIMVAR_VEC4 3
+#define GI_C_PRIMVAR_INT 4
+#define GI_C_PRIMVAR_INT2 5
+#define GI_C_PRIMVAR_INT3 6
+#define GI_C_PRIMVAR_INT4 7
+#define GI_C_INTERP_CONSTANT 0
+#define GI_C_INTERP_INSTANCE 1
+#define GI_C_INTERP_UNIFORM 2
+#define GI_C_INTERP_VERTEX 3
+typedef struct GiCPrimvarData { const char* name; int32_t type; int32_t interpolation; const void* data; uint64_t dataSize; } GiCPrimvarData;
+int giCSetMeshPrimvars(GiCMesh* mesh, uint32_t count, const GiCPrimvarData* primvars);          /* GiMeshDesc.primvars (Gi.h:134) */
+int giCSetMeshInstancerPrimvars(GiCMesh* mesh, uint32_t count, const GiCPrimvarData* primvars); /* Gi.h:213 */
+int giCSetMaterialPrimvarInput(GiCMaterial* material, int32_t input, const char* primvarName);  /* [ext] NULL or "" removes it */
+
 /* [ext] per-frame statistics of the last giCRender on a scene (measurement) */
 typedef struct GiCRenderStats {
   double renderMs;       /* wall time of the bounce loop incl. final D2H of the colour AOV */

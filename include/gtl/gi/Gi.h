@@ -66,7 +66,7 @@ namespace gtl
     bool                              isLeftHanded;
     const char*                       name;
     uint32_t                          maxFaceId;
-    const std::vector<GiPrimvarData>& primvars;   // accepted, not consumed yet (scene-data lookups are a "next" row)
+    const std::vector<GiPrimvarData>& primvars;   // float primvars feed material inputs bound to them by name (scene_data_lookup_*)
     uint32_t                          vertexCount;
     const std::vector<GiVertex>&      vertices;
   };

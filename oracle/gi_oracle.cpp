@@ -308,7 +308,7 @@ struct Instance {
   float w2o[9];  // inverse of the 3x3 part, row-major
 };
 struct Tri { V3 v0, e1, e2; uint32_t instance, prim; float cutout; /* mdl_cutout_opacity of the material; 1 = opaque */ };
-struct MeshData { std::vector<FVertex> verts; const uint32_t* faces; uint32_t faceCount; int material; uint32_t flags; int32_t objectId; std::vector<uint8_t> faceIdData; uint32_t faceIdStride; };
+struct MeshData { std::vector<FVertex> verts; const uint32_t* faces; uint32_t faceCount; int material; uint32_t flags; int32_t objectId; std::vector<uint8_t> faceIdData; uint32_t faceIdStride; const OrcMesh* src; };
 
 // Light structs as the device sees them (rp_main.h:73-113), derived fields per Gi.cpp setters.
 struct SphereL { V3 pos; uint32_t ds; V3 em; float area; V3 radius; };
@@ -390,7 +390,7 @@ void prepare(const OrcScene* s, Prepared& P)
   for (uint32_t mi = 0; mi < s->meshCount; mi++) {
     const OrcMesh& m = s->meshes[mi];
     MeshData& d = P.meshes[mi];
-    d.faces = m.faces; d.faceCount = m.faceCount; d.material = m.material;
+    d.faces = m.faces; d.faceCount = m.faceCount; d.material = m.material; d.src = &m;
     d.flags = (m.isLeftHanded ? 1u : 0u) | (m.isDoubleSided ? 2u : 0u); // rp_main.h:115-116
     d.objectId = m.id;
     d.faceIdStride = m.maxFaceId <= 255u ? 1u : (m.maxFaceId <= 65535u ? 2u : 4u); // Gi.cpp:878-885
@@ -579,6 +579,8 @@ struct State {
   // Bsdf_sample_data.ior1 / ior2 (rp_main.chit:188-189): ior of the medium the ray travels in / of the other side;
   // < 0 = BSDF_USE_MATERIAL_IOR.  Defaults = empty medium stack (vacuum outside).
   float ior1 = 0.0f, ior2 = 0.0f;
+  // renderer state of the hit for scene-data lookups (mdl_interface.glsl:281-301)
+  const MeshData* mesh = nullptr; uint32_t prim = 0, hitIndices[3] = {0, 0, 0}; int32_t instanceId = 0; float bu = 0.0f, bv = 0.0f;
 };
 inline float relative_eta(const State& st, float materialEta)
 {
@@ -616,6 +618,8 @@ void setup_shading_state(const Prepared& P, const Hit& h, V3 rayDir, State& st, 
   st.tangentU = tg; st.tangentV = cross(n, tg) * bs;                     // :59
   st.u = (bx * a.u + by * b.u) + bz * c.u; st.v = (bx * a.v + by * b.v) + bz * c.v; // :62-65
   st.normal = n; st.geomNormal = gn;
+  st.mesh = &m; st.prim = T.prim; st.instanceId = inst.instanceId; st.bu = h.u; st.bv = h.v;
+  st.hitIndices[0] = m.faces[3 * T.prim + 0]; st.hitIndices[1] = m.faces[3 * T.prim + 1]; st.hitIndices[2] = m.faces[3 * T.prim + 2];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -679,12 +683,50 @@ inline V3 adapt_normal(V3 rayDir, V3 geomNormal, V3 normal)
 
 // Per-hit material: the parameter block with its textured inputs evaluated at the hit's uv (UsdUVTexture: texel * scale + bias);
 // a normal map replaces the shading normal (tangent space -> world, adapt_normal, tangent frame re-orthonormalised).
-inline bool material_textured(const OrcMaterial& m) { for (int i = 0; i < ORC_TEX_SLOT_COUNT; i++) if (m.tex[i].texture >= 0) return true; return false; }
+inline bool material_textured(const OrcMaterial& m) { for (int i = 0; i < ORC_TEX_SLOT_COUNT; i++) if (m.tex[i].texture >= 0 || m.primvarInput[i][0]) return true; return false; }
+// The primvar a scene-data name resolves to for this mesh: instancer primvars first, mesh primvars override (Gi.cpp:913-929)
+inline const OrcPrimvar* find_primvar(const OrcMesh& m, const char* name)
+{
+  const OrcPrimvar* found = nullptr;
+  for (uint32_t i = 0; i < m.instancerPrimvarCount; i++) if (!strncmp(m.instancerPrimvars[i].name, name, 64) && m.instancerPrimvars[i].floatCount) { found = &m.instancerPrimvars[i]; break; }
+  for (uint32_t i = 0; i < m.primvarCount; i++) if (!strncmp(m.primvars[i].name, name, 64) && m.primvars[i].floatCount) { found = &m.primvars[i]; break; }
+  return found;
+}
+// scene_data_lookup_float3 / _float (mdl_interface.glsl:337-371, 398-424) with get_scene_data_indices (:281-301)
+inline bool scene_data_lookup(const State& st, const char* name, int comps, float out[3])
+{
+  const OrcPrimvar* pv = st.mesh ? find_primvar(*st.mesh->src, name) : nullptr;
+  if (!pv || pv->type > ORC_PRIMVAR_VEC4) return false; // not found (SCENE_DATA_INVALID) -> default value; int primvars do not feed float inputs
+  const uint32_t stride = (uint32_t)pv->type + 1u;
+  uint32_t idx[3];
+  if (pv->interpolation == ORC_INTERP_UNIFORM) idx[0] = idx[1] = idx[2] = st.prim;
+  else if (pv->interpolation == ORC_INTERP_INSTANCE) idx[0] = idx[1] = idx[2] = (uint32_t)st.instanceId;
+  else if (pv->interpolation == ORC_INTERP_CONSTANT) idx[0] = idx[1] = idx[2] = 0u;
+  else { idx[0] = st.hitIndices[0]; idx[1] = st.hitIndices[1]; idx[2] = st.hitIndices[2]; }
+  const float bx = 1.0f - st.bu - st.bv, by = st.bu, bz = st.bv;
+  for (int c = 0; c < comps; c++) {
+    float v[3];
+    for (int k = 0; k < 3; k++) { size_t o = (size_t)idx[k] * stride + (size_t)c; v[k] = o < pv->floatCount ? pv->data[o] : 0.0f; }
+    out[c] = (v[0] * bx + v[1] * by) + v[2] * bz;
+  }
+  return true;
+}
 OrcMaterial resolve_material(const Prepared& P, const OrcMaterial& m, State& st, V3 rayDir)
 {
   OrcMaterial r = m;
   for (int slot = 0; slot < ORC_TEX_SLOT_COUNT; slot++) {
     const OrcTexBinding& b = m.tex[slot];
+    if ((b.texture < 0 || (uint32_t)b.texture >= P.textureCount) && m.primvarInput[slot][0] && slot != ORC_TEX_NORMAL) { // primvar-driven input
+      float v[3];
+      const bool vec = slot == ORC_TEX_BASE_COLOR || slot == ORC_TEX_EMISSION;
+      if (scene_data_lookup(st, m.primvarInput[slot], vec ? 3 : 1, v)) {
+        if (slot == ORC_TEX_BASE_COLOR) { r.p[ORC_P_BASE_COLOR] = v[0]; r.p[ORC_P_BASE_COLOR + 1] = v[1]; r.p[ORC_P_BASE_COLOR + 2] = v[2]; }
+        else if (slot == ORC_TEX_EMISSION) { r.p[ORC_P_EMISSION] = v[0]; r.p[ORC_P_EMISSION + 1] = v[1]; r.p[ORC_P_EMISSION + 2] = v[2]; }
+        else if (slot == ORC_TEX_ROUGHNESS) r.p[ORC_P_ROUGHNESS] = v[0];
+        else r.p[ORC_P_METALLIC] = v[0];
+      }
+      continue;
+    }
     if (b.texture < 0 || (uint32_t)b.texture >= P.textureCount) continue;
     F4v t = tex_lookup_float4_2d(P.textures[b.texture], st.u, st.v, b.wrapS, b.wrapT);
     float val[4] = {t.x * b.scale[0] + b.bias[0], t.y * b.scale[1] + b.bias[1], t.z * b.scale[2] + b.bias[2], t.w * b.scale[3] + b.bias[3]};

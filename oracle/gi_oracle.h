@@ -88,11 +88,19 @@ typedef struct OrcTexBinding {
   float scale[4], bias[4];
 } OrcTexBinding;
 
+/* Scene data (primvars; mdl_interface.glsl:260-479, Gi.cpp:905-1019): a material input may read a named primvar of the mesh
+ * (UsdPrimvarReader): float3 inputs use scene_data_lookup_float3, scalar inputs scene_data_lookup_float.  A texture on the same
+ * input wins. */
+enum { ORC_PRIMVAR_FLOAT = 0, ORC_PRIMVAR_VEC2, ORC_PRIMVAR_VEC3, ORC_PRIMVAR_VEC4, ORC_PRIMVAR_INT, ORC_PRIMVAR_INT2, ORC_PRIMVAR_INT3, ORC_PRIMVAR_INT4 }; /* Gi.h:76-79 */
+enum { ORC_INTERP_CONSTANT = 0, ORC_INTERP_INSTANCE, ORC_INTERP_UNIFORM, ORC_INTERP_VERTEX }; /* Gi.h:81-84 */
+typedef struct OrcPrimvar { char name[64]; int32_t type; int32_t interpolation; const float* data; uint32_t floatCount; } OrcPrimvar;
+
 typedef struct OrcMaterial {
   uint32_t klass;
   uint32_t flags;
   float p[ORC_P_COUNT];
   OrcTexBinding tex[ORC_TEX_SLOT_COUNT];
+  char primvarInput[ORC_TEX_SLOT_COUNT][64]; /* "" = input not driven by scene data */
 } OrcMaterial;
 
 typedef struct OrcMesh {
@@ -111,6 +119,8 @@ typedef struct OrcMesh {
   const int32_t* faceIds;     /* faceCount entries or NULL (GiMeshDesc.faceIds, Gi.h:127) */
   uint32_t maxFaceId;         /* GiMeshDesc.maxFaceId: chooses the 1/2/4-byte face-id stride (Gi.cpp:878-885) */
   const int32_t* instanceIds; /* instanceCount entries or NULL (Gi.cpp:660-670) */
+  const OrcPrimvar* primvars; uint32_t primvarCount;                   /* GiMeshDesc.primvars */
+  const OrcPrimvar* instancerPrimvars; uint32_t instancerPrimvarCount; /* giSetMeshInstancerPrimvars; mesh primvars override them (Gi.cpp:913-929) */
 } OrcMesh;
 
 /* Light descriptions at *setter* level (Gi.cpp:2573-2976); derived fields are computed by the oracle. */

@@ -25,7 +25,12 @@ class OrcTexBinding(C.Structure):
 
 
 class OrcMaterial(C.Structure):
-    _fields_ = [("klass", C.c_uint32), ("flags", C.c_uint32), ("p", C.c_float * P_COUNT), ("tex", OrcTexBinding * TEX_SLOT_COUNT)]
+    _fields_ = [("klass", C.c_uint32), ("flags", C.c_uint32), ("p", C.c_float * P_COUNT), ("tex", OrcTexBinding * TEX_SLOT_COUNT),
+                ("primvarInput", (C.c_char * 64) * TEX_SLOT_COUNT)]
+
+
+class OrcPrimvar(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("type", C.c_int32), ("interpolation", C.c_int32), ("data", C.c_void_p), ("floatCount", C.c_uint32)]
 
 
 class OrcTexture(C.Structure):
@@ -46,6 +51,7 @@ def fill_material(dst, m):
             dst.tex[slot].wrapS, dst.tex[slot].wrapT, dst.tex[slot].channel = int(b.wrap_s), int(b.wrap_t), int(b.channel)
             dst.tex[slot].scale = (C.c_float * 4)(*b.scale)
             dst.tex[slot].bias = (C.c_float * 4)(*b.bias)
+        dst.primvarInput[slot].value = getattr(m, "primvar_inputs", {}).get(slot, "").encode()
 
 
 class OrcMesh(C.Structure):
@@ -54,7 +60,8 @@ class OrcMesh(C.Structure):
                 ("id", C.c_int32), ("isDoubleSided", C.c_int32), ("isLeftHanded", C.c_int32), ("visible", C.c_int32),
                 ("transform", C.c_float * 16),
                 ("instanceTransforms", C.c_void_p), ("instanceCount", C.c_uint32),
-                ("material", C.c_int32), ("faceIds", C.c_void_p), ("maxFaceId", C.c_uint32), ("instanceIds", C.c_void_p)]
+                ("material", C.c_int32), ("faceIds", C.c_void_p), ("maxFaceId", C.c_uint32), ("instanceIds", C.c_void_p),
+                ("primvars", C.c_void_p), ("primvarCount", C.c_uint32), ("instancerPrimvars", C.c_void_p), ("instancerPrimvarCount", C.c_uint32)]
 
 
 class OrcAovs(C.Structure):
@@ -212,6 +219,17 @@ class PackedScene:
             meshes[i].maxFaceId = int(getattr(m, "max_face_id", 0))
             if m.instance_ids is not None:
                 iid = np.ascontiguousarray(m.instance_ids, np.int32); self.keep.append(iid); meshes[i].instanceIds = iid.ctypes.data
+            for attr, ptr, cnt in (("primvars", "primvars", "primvarCount"), ("instancer_primvars", "instancerPrimvars", "instancerPrimvarCount")):
+                pvs = getattr(m, attr, [])
+                if pvs:
+                    arr = (OrcPrimvar * len(pvs))()
+                    for k, pv in enumerate(pvs):
+                        d = np.ascontiguousarray(pv.data, np.float32).reshape(-1)
+                        self.keep.append(d)
+                        arr[k].name = pv.name.encode(); arr[k].type = int(pv.type); arr[k].interpolation = int(pv.interpolation)
+                        arr[k].data = d.ctypes.data; arr[k].floatCount = len(d)
+                    self.keep.append(arr)
+                    setattr(meshes[i], ptr, C.addressof(arr)); setattr(meshes[i], cnt, len(pvs))
         mats = (OrcMaterial * max(1, len(scene.materials)))()
         for i, m in enumerate(scene.materials):
             fill_material(mats[i], m)

@@ -8,7 +8,7 @@
 
 using namespace gtl;
 
-static GiMesh* quad(GiScene* scene, float z, float half, GiMaterial* mat, int id)
+static GiMesh* quad(GiScene* scene, float z, float half, GiMaterial* mat, int id, const float* displayColor = nullptr)
 {
   std::vector<GiVertex> v(4);
   const float p[4][2] = {{-half, -half}, {half, -half}, {half, half}, {-half, half}};
@@ -18,6 +18,11 @@ static GiMesh* quad(GiScene* scene, float z, float half, GiMaterial* mat, int id
   std::vector<GiFace> f = {{{0, 1, 2}}, {{0, 2, 3}}};
   std::vector<int> faceIds = {0, 0};
   std::vector<GiPrimvarData> primvars;
+  if (displayColor) { // constant displayColor primvar, as hdGatling hands it over (mesh.cpp primvar sync)
+    GiPrimvarData pv{"displayColor", GiPrimvarType::Vec3, GiPrimvarInterpolation::Constant, {}};
+    pv.data.resize(12); memcpy(pv.data.data(), displayColor, 12);
+    primvars.push_back(pv);
+  }
   GiMeshDesc d{2, f, faceIds, id, true, false, "quad", 0, primvars, 4, v};
   GiMesh* m = giCreateMesh(scene, d);
   const float I[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
@@ -35,8 +40,10 @@ int main()
   GiInitParams init{"", "", noPaths, nullptr, ""};
   if (giInitialize(init) != GiStatus::Ok) { fprintf(stderr, "giInitialize failed\n"); return 2; }
   GiScene* scene = giCreateScene();
-  const char* floorMtlx = "<materialx version=\"1.38\"><UsdPreviewSurface name=\"SR\" type=\"surfaceshader\">"
-                          "<input name=\"diffuseColor\" type=\"color3\" value=\"0.8, 0.2, 0.1\" /><input name=\"roughness\" type=\"float\" value=\"0.4\" />"
+  // diffuseColor comes from a primvar reader (UsdPrimvarReader_float3 -> MaterialX geompropvalue): scene_data_lookup_float3
+  const char* floorMtlx = "<materialx version=\"1.38\"><geompropvalue name=\"dc\" type=\"color3\"><input name=\"geomprop\" type=\"string\" value=\"displayColor\" /></geompropvalue>"
+                          "<UsdPreviewSurface name=\"SR\" type=\"surfaceshader\">"
+                          "<input name=\"diffuseColor\" type=\"color3\" nodename=\"dc\" /><input name=\"roughness\" type=\"float\" value=\"0.4\" />"
                           "</UsdPreviewSurface></materialx>";
   const char* lampMtlx = "<materialx version=\"1.39\"><open_pbr_surface name=\"L\" type=\"surfaceshader\">"
                          "<input name=\"emission_luminance\" type=\"float\" value=\"5.0\" /><input name=\"emission_color\" type=\"color3\" value=\"1, 0.9, 0.8\" />"
@@ -45,7 +52,8 @@ int main()
   GiMaterial* lampMat = giCreateMaterialFromMtlxStr(scene, "lamp", lampMtlx);
   GiMaterial* unsupported = giCreateMaterialFromMtlxStr(scene, "x", "<materialx><standard_surface name=\"s\"/></materialx>");
   if (!floorMat || !lampMat || unsupported) { fprintf(stderr, "material creation mismatch\n"); return 3; }
-  GiMesh* a = quad(scene, 0.0f, 2.0f, floorMat, 1);
+  const float green[3] = {0.1f, 0.8f, 0.1f};
+  GiMesh* a = quad(scene, 0.0f, 2.0f, floorMat, 1, green);
   GiMesh* b = quad(scene, 1.5f, 0.4f, lampMat, 2);
   GiRenderBuffer* rb = giCreateRenderBuffer(32, 18, GiRenderBufferFormat::Float32Vec4);
   GiRenderParams rp{};
@@ -59,8 +67,10 @@ int main()
   rp.scene = scene;
   if (giRender(rp) != GiStatus::Ok) { fprintf(stderr, "giRender failed\n"); return 4; }
   const float* px = (const float*)giGetRenderBufferMem(rb);
-  double sum = 0; int lit = 0;
-  for (int i = 0; i < 32 * 18; i++) { sum += px[4 * i] + px[4 * i + 1] + px[4 * i + 2]; lit += px[4 * i] > 0.11f; if (px[4 * i + 3] != 1.0f) return 5; }
+  double sum = 0, red = 0, grn = 0; int lit = 0;
+  for (int i = 0; i < 32 * 18; i++) { sum += px[4 * i] + px[4 * i + 1] + px[4 * i + 2]; red += px[4 * i]; grn += px[4 * i + 1]; lit += px[4 * i + 1] > 0.11f; if (px[4 * i + 3] != 1.0f) return 5; }
+  // the lamp is reddish (1, .9, .8): without the green primvar the image is red-heavy
+  if (!(grn > 1.05 * red)) { fprintf(stderr, "displayColor primvar not applied (r=%f g=%f)\n", red, grn); return 7; }
   printf("gtl_smoke ok sum=%.6f lit=%d\n", sum, lit);
   giDestroyMesh(a); giDestroyMesh(b); giDestroyMaterial(floorMat); giDestroyMaterial(lampMat);
   giDestroyRenderBuffer(rb); giDestroyScene(scene); giTerminate();

@@ -470,6 +470,40 @@ def test_nee_and_bounces_aovs(gi, orc, with_color):
     assert (1.0, 0.0, 0.0) in kinds and (0.0, 1.0, 0.0) in kinds  # both outcomes occur in this scene
 
 
+def test_scene_data_primvar_inputs(gi, orc):
+    """scene_data_lookup_float3 / _float (mdl_interface.glsl:281-301, 337-424) through the C ABI: material inputs driven by named
+    primvars with vertex, uniform, instance and constant interpolation, instancer primvars overridden by mesh primvars, a mesh
+    without the primvar keeping the constant, a short array reading zeros -- bit-identical to the oracle."""
+    from gatling_amd.scene import (INTERP_CONSTANT, INTERP_INSTANCE, INTERP_UNIFORM, INTERP_VERTEX, PRIMVAR_FLOAT, PRIMVAR_VEC3, PRIMVAR_VEC4, Primvar,
+                                   TEX_BASE_COLOR, TEX_EMISSION, TEX_METALLIC, TEX_ROUGHNESS)
+    rng = np.random.default_rng(21)
+    desc = sphere_grid(grid=3, subdivisions=1, material_count=3)
+    for mat in desc.materials:
+        mat.primvar_inputs = {TEX_BASE_COLOR: "displayColor", TEX_ROUGHNESS: "rough", TEX_METALLIC: "metal", TEX_EMISSION: "glow"}
+    for k, m in enumerate(desc.meshes):
+        nv, nf, ni = len(m.vertices), len(m.faces), len(m.instance_transforms)
+        if k == 0:
+            m.primvars = [Primvar("displayColor", PRIMVAR_VEC3, INTERP_VERTEX, rng.uniform(0, 1, (nv, 3))),
+                          Primvar("rough", PRIMVAR_FLOAT, INTERP_UNIFORM, rng.uniform(0.1, 0.9, nf)),
+                          Primvar("glow", PRIMVAR_VEC4, INTERP_CONSTANT, np.float32([[0.2, 0.1, 0.0, 1.0]]))]
+            m.instancer_primvars = [Primvar("metal", PRIMVAR_FLOAT, INTERP_INSTANCE, rng.uniform(0, 1, ni))]
+        elif k == 1:
+            m.instancer_primvars = [Primvar("displayColor", PRIMVAR_VEC3, INTERP_INSTANCE, rng.uniform(0, 1, (ni, 3))),
+                                    Primvar("rough", PRIMVAR_FLOAT, INTERP_INSTANCE, np.full(ni, 0.9, np.float32))]
+            m.primvars = [Primvar("rough", PRIMVAR_FLOAT, INTERP_VERTEX, rng.uniform(0.05, 0.5, nv - 7))]  # overrides the instancer's; 7 entries short
+        # k == 2: no primvars at all -> every input keeps its constant
+    rs = RenderSettings(spp=4, max_bounces=6)
+    render_both(gi, orc, desc, rs, 96, 54)
+    plain = sphere_grid(grid=3, subdivisions=1, material_count=3)
+    sc = gi.Scene(plain)
+    try:
+        ref_plain = sc.render(rs, 96, 54)
+    finally:
+        sc.close()
+    got, _, _ = render_both(gi, orc, desc, rs, 96, 54)
+    assert not np.array_equal(got, ref_plain)
+
+
 def test_interior_scene_parity(gi, orc):
     """C5's structure at small scale: room + instanced clutter (affine instance transforms), three material classes incl.
     transmission, four rect lights, NEE on."""
