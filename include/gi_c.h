@@ -84,7 +84,7 @@ typedef struct GiCVertex {
 /* Gi.h:120-122 */
 typedef struct GiCFace { uint32_t v_i[3]; } GiCFace;
 
-/* Gi.h:124-137 with vectors flattened to pointer+count (primvars: SURVEY section 8f, not yet consumed) */
+/* Gi.h:124-137 with vectors flattened to pointer+count; GiMeshDesc.primvars arrive through giCSetMeshPrimvars */
 typedef struct GiCMeshDesc {
   uint32_t faceCount;
   const GiCFace* faces;
