@@ -1220,9 +1220,9 @@ extern "C" int giCRender(const GiCRenderParams* params)
     const uint64_t budgetBytes = envU64("GATLING_SAMPLE_BUFFER_MB", s->optSampleBufferMb ? s->optSampleBufferMb : 8192) << 20;
     // Pool size: a launch of k_trace_dyn ends when its longest ray ends, and ray cost is heavy-tailed in scenes beyond LDS
     // (a 100-step ray outlives the average one six times over), so those scenes get a pool large enough to amortise that
-    // tail (measured on C3: 4 Mi slots 630, 16 Mi 790, 32 Mi 831 Msamples/s); LDS-resident scenes have uniform, short rays.
+    // tail (measured on C3 at spp 64 / 256: 4 Mi slots 630, 16 Mi 790, 32 Mi 831 / 810, 64 Mi - / 868 Msamples/s); LDS-resident scenes have uniform, short rays.
     const bool sceneInLds = s->nodeCount <= 384u && s->triCount <= 128u;
-    const uint64_t poolDefault = sceneInLds ? (4u << 20) : (32u << 20);
+    const uint64_t poolDefault = sceneInLds ? (4u << 20) : (64u << 20);
     const uint64_t poolMax = std::max<uint64_t>(64, envU64("GATLING_POOL_SLOTS", s->optPoolSlots ? s->optPoolSlots : poolDefault));
     uint64_t batchSamples = std::min<uint64_t>(rs.spp, std::max<uint64_t>(1, budgetBytes / (pixels * 16)));
     batchSamples = std::min<uint64_t>(batchSamples, std::max<uint64_t>(1, 0xffffffffull / pixels)); // work ids stay 32-bit
