@@ -1,0 +1,90 @@
+// gi_queues.h -- work queues of the wavefront loop: block-aggregated sharded appends, the reader side, record helpers.
+// Included by gi_kernels.hip only (device code, namespace gi).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "gi_device_math.h"
+#include "gi_types.h"
+
+namespace gi {
+
+// ------------------------------------------------------------------------------------------------
+// Stream compaction.  wave64 ballot + popcount prefix inside a wave, LDS aggregation over the 4 waves of a block,
+// ONE atomic per block, queue and loop trip -- on the block's own shard of the queue (see gi_types.h: NSHARD).
+// All stage kernels run block-uniform loops so the two barriers per trip are legal.  Returns, per queue, the index
+// at which the calling lane must write its record (valid where pred is set).
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t BLOCK = 256;
+constexpr uint32_t WAVES = BLOCK / 64;
+
+template <int NQ>
+struct AppendScratch { uint32_t wcount[2][NQ][WAVES]; uint32_t base[2][NQ]; };
+
+template <int NQ>
+__device__ __forceinline__ void block_append(AppendScratch<NQ>& sh, uint32_t trip, const bool (&pred)[NQ], const uint32_t (&qid)[NQ], uint32_t cap,
+                                             Counters* cnt, uint32_t (&outIdx)[NQ])
+{
+  const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6, par = trip & 1u, shard = blockIdx.x % NSHARD;
+  unsigned long long m[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    m[q] = __ballot(pred[q]);
+    if (lane == 0) sh.wcount[par][q][wave] = (uint32_t)__popcll(m[q]);
+  }
+  __syncthreads();
+  if (threadIdx.x < NQ) {
+    const uint32_t q = threadIdx.x;
+    uint32_t total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < WAVES; w++) total += sh.wcount[par][q][w];
+    sh.base[par][q] = total ? atomicAdd(&cnt->count[qid[q]][shard].v, total) : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    uint32_t off = sh.base[par][q] + (uint32_t)__popcll(m[q] & ((1ull << lane) - 1ull));
+    for (uint32_t w = 0; w < wave; w++) off += sh.wcount[par][q][w];
+    outIdx[q] = shard * cap + off;
+  }
+}
+
+// Reader side: a queue is the concatenation of its NSHARD segments; maps a flat index to the record index.
+struct QueueReader { uint32_t pre[NSHARD + 1]; uint32_t cap; };
+__device__ __forceinline__ void reader_init(QueueReader& r, const Counters* cnt, uint32_t q, uint32_t cap)
+{
+  r.pre[0] = 0;
+#pragma unroll
+  for (uint32_t s = 0; s < NSHARD; s++) r.pre[s + 1] = r.pre[s] + cnt->count[q][s].v;
+  r.cap = cap;
+}
+__device__ __forceinline__ uint32_t reader_index(const QueueReader& r, uint32_t i)
+{
+  uint32_t s = 0, p = 0;
+#pragma unroll
+  for (uint32_t k = 1; k < NSHARD; k++) { const bool ge = i >= r.pre[k]; s += ge ? 1u : 0u; p = ge ? r.pre[k] : p; }
+  return s * r.cap + (i - p);
+}
+
+__device__ __forceinline__ F4 ld4(const F4* p) { float4 v = *reinterpret_cast<const float4*>(p); return F4{v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ void st4(F4* p, float x, float y, float z, float w) { *reinterpret_cast<float4*>(p) = make_float4(x, y, z, w); }
+constexpr uint32_t MISS = 0xffffffffu;
+constexpr uint32_t REGEN_MISSED = 0x80000000u; // flag on a regen-queue entry: the path left the scene (k_trace -> k_raygen)
+
+// Zeroes the counters of the queues that the producers of iteration `it` will append to.  Called by one thread of
+// k_raygen(it): none of these queues is read or appended by k_raygen(it) itself (it reads REGEN[it&1] and appends
+// TRACE[it&1]), and their previous consumers finished in iteration it-1 (stream order).
+__device__ __forceinline__ void zero_next_counters(Counters* cnt, uint32_t par)
+{
+  const uint32_t t = threadIdx.x;
+  if (t < NSHARD) {
+    cnt->count[Q_TRACE_A + (par ^ 1u)][t].v = 0;
+    cnt->count[Q_REGEN_A + (par ^ 1u)][t].v = 0;
+    for (uint32_t c = 0; c < MAT_CLASS_COUNT; c++) cnt->count[Q_HIT + c][t].v = 0;
+    cnt->count[Q_SHADOW][t].v = 0;
+  }
+  if (t < 2u) cnt->cursor[t].v = 0; // k_trace_dyn's ray cursors (closest, shadow)
+}
+
+
+} // namespace gi

@@ -1,0 +1,359 @@
+// gi_traversal.h -- software traversal of the 8-wide quantised BVH: per-lane traversal state and node test, the per-lane step
+// (k_aov), the wave-cooperative triangle stage and wave_step (k_trace, k_trace_dyn).  Included by gi_kernels.hip only.
+#pragma once
+
+#include "gi_queues.h"
+
+namespace gi {
+
+// ------------------------------------------------------------------------------------------------
+// k_trace: software traversal of the 8-wide quantised BVH, one ray per lane.
+//   * persistent blocks stage the top of the tree (and, for small scenes, all triangles) into LDS once
+//   * per-lane traversal stack: 8 entries in LDS + scratch overflow
+//   * octant-ordered child visits (Ylitie et al. 2017), two-sided Moeller-Trumbore on 48-byte records
+// Traversal contract: accept tMin < t < tBest; ties go to the lower scene-order triangle id.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t LDS_NODES = 384;  // upper bound: 30 KiB   (the launch stages min(nodeCount, LDS_NODES) nodes)
+constexpr uint32_t LDS_TRIS = 128;   // upper bound: 6 KiB    (all triangles when the scene has <= LDS_TRIS, else none)
+constexpr uint32_t OVF_STACK = 40;   // scratch overflow entries of the fallback variant (trees deeper than 16 levels)
+constexpr uint32_t TRACE_BLOCK = 256;
+
+struct TraceCounters { uint32_t nodes, tris; };
+
+// STACK = per-lane stack entries kept in LDS.  The traversal pushes at most one entry per tree level, so the host
+// picks STACK >= tree depth (8 or 16) and the scratch overflow (OVERFLOW) is compiled in only for deeper trees:
+// a kernel that declares scratch pays for it on every wave launch even if it never spills.
+// Any-hit randomness (rp_main.ahit:51-60), restated order-independently: stateless hash of the path's rng state and the
+// candidate's scene-order triangle id (see oracle cutout_random); the state itself is not advanced.
+__device__ __forceinline__ float cutout_random(uint32_t rng, uint32_t triId)
+{
+  uint32_t st = (rng ^ (triId * 0x9e3779b9u + 0x85ebca6bu)) * 747796405u + 2891336453u;
+  uint32_t word = ((st >> ((st >> 28) + 4u)) ^ st) * 277803737u;
+  return u2f(0x3f800000u | (((word >> 22) ^ word) >> 9)) - 1.0f;
+}
+
+// Per-lane traversal state.  A ray is advanced by trav_step() one "group" at a time (one internal node, then the
+// triangles of its leaf children, then a pop) so that k_trace (one ray per lane until it finishes) and k_trace_dyn
+// (lanes refill from the queue as they finish) share the same arithmetic.
+struct RayTrav {
+  V3 o, d; float idx, idy, idz, tMin, tBest; uint32_t octinv;
+  uint32_t bestTri, bestOrig, bestMat; float bestU, bestV;
+  uint2 G; uint32_t sp; bool found;
+};
+
+__device__ __forceinline__ void trav_init(RayTrav& R, V3 o, V3 d, float tMin, float tMax)
+{
+  R.o = o; R.d = d; R.tMin = tMin; R.tBest = tMax;
+  // reciprocal direction for the slab tests only (guard against 0: boxes are padded, a huge finite value is safe)
+  const float gx = (fabsf(d.x) < 1e-30f) ? (d.x < 0.0f ? -1e-30f : 1e-30f) : d.x;
+  const float gy = (fabsf(d.y) < 1e-30f) ? (d.y < 0.0f ? -1e-30f : 1e-30f) : d.y;
+  const float gz = (fabsf(d.z) < 1e-30f) ? (d.z < 0.0f ? -1e-30f : 1e-30f) : d.z;
+  // v_rcp_f32 (1 ulp) instead of three IEEE divisions: the reciprocals only feed the box tests, whose far planes are widened by 1e-5
+  R.idx = __builtin_amdgcn_rcpf(gx); R.idy = __builtin_amdgcn_rcpf(gy); R.idz = __builtin_amdgcn_rcpf(gz);
+  R.octinv = ((d.x >= 0.0f ? 1u : 0u) | (d.y >= 0.0f ? 2u : 0u) | (d.z >= 0.0f ? 4u : 0u)) * 0x01010101u; // replicated into the 4 bytes (trav_node_test)
+  R.bestTri = 0xffffffffu; R.bestOrig = 0xffffffffu; R.bestMat = 0u; R.bestU = 0.0f; R.bestV = 0.0f;
+  R.G = make_uint2(0u, 0x80000000u); // virtual group holding only the root
+  R.sp = 0u; R.found = false;
+}
+
+// Node half of a traversal step: takes the nearest unvisited child of the current node group (pushing the rest), tests
+// the ray against that node's 8 quantised child boxes and returns the triangle group (base, mask) of its hit leaf
+// children; R.G becomes the group of hit internal children.  Caller guarantees R.G has node bits.
+// Node half of a traversal step, part 1: takes the nearest unvisited child of the current node group (pushing the rest)
+// and returns its node index.  Caller guarantees R.G has node bits.
+template <uint32_t STACK, bool OVERFLOW>
+__device__ __forceinline__ uint32_t trav_node_pick(RayTrav& R, uint2 (*s_stack)[TRACE_BLOCK], uint2 (&overflow)[OVERFLOW ? OVF_STACK : 1])
+{
+  const uint32_t tid = threadIdx.x;
+  uint2 G = R.G;
+  uint32_t sp = R.sp;
+  const uint32_t bit = 31u - (uint32_t)__clz((int)(G.y & 0xff000000u));
+  G.y &= ~(1u << bit);
+  if (G.y & 0xff000000u) {
+    if (!OVERFLOW || sp < STACK) s_stack[sp < STACK ? sp : STACK - 1u][tid] = G; else overflow[sp - STACK] = G;
+    sp++;
+  }
+  const uint32_t slot = (bit - 24u) ^ (R.octinv & 7u);
+  const uint32_t rel = (uint32_t)__popc((G.y & 0xffu) & ((1u << slot) - 1u));
+  R.sp = sp;
+  return G.x + rel;
+}
+
+// Part 2: tests the ray against the node's 8 quantised child boxes and returns the triangle group (base, mask) of its hit
+// leaf children; R.G becomes the group of hit internal children.  The box test is a conservative filter (explicit fma,
+// far planes and tBest widened by 1e-5 relative), it never decides a result.  Written for the VALU: the two planes of an
+// axis go through one packed fma (v_pk_fma_f32), the per-child meta bytes (slot index, child bits, octant flip of internal
+// children) are decoded four at a time with byte-parallel integer ops, and empty slots (meta 0) contribute no bits, so
+// the hit mask is assembled without a branch.
+typedef float gi_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 trav_node_test(RayTrav& R, const uint4& n0, const uint4& n1, const uint4& n2, const uint4& n3, const uint4& n4)
+{
+  const V3 o = R.o, d = R.d;
+  constexpr float WIDEN = 1.00001f;
+  // ray in the node's quantisation frame: t(q) = q * a + b per axis; .x = near plane, .y = far plane (widened)
+  const float sx = u2f((n0.w & 0xffu) << 23), sy = u2f(((n0.w >> 8) & 0xffu) << 23), sz = u2f(((n0.w >> 16) & 0xffu) << 23);
+  const float ax = sx * R.idx, ay = sy * R.idy, az = sz * R.idz;
+  const float bx = (u2f(n0.x) - o.x) * R.idx, by = (u2f(n0.y) - o.y) * R.idy, bz = (u2f(n0.z) - o.z) * R.idz;
+  const gi_f2 Ax = {ax, ax * WIDEN}, Ay = {ay, ay * WIDEN}, Az = {az, az * WIDEN};
+  const gi_f2 Bx = {bx, bx * WIDEN}, By = {by, by * WIDEN}, Bz = {bz, bz * WIDEN};
+  const float tFar = R.tBest * WIDEN, tNear = R.tMin;
+  // near/far plane bytes per axis, chosen by direction sign
+  const bool nxn = d.x < 0.0f, nyn = d.y < 0.0f, nzn = d.z < 0.0f;
+  const uint32_t qlox[2] = {n2.x, n2.y}, qloy[2] = {n2.z, n2.w}, qloz[2] = {n3.x, n3.y};
+  const uint32_t qhix[2] = {n3.z, n3.w}, qhiy[2] = {n4.x, n4.y}, qhiz[2] = {n4.z, n4.w};
+  const uint32_t metaw[2] = {n1.z, n1.w};
+  const uint32_t oct4 = R.octinv;
+  uint32_t hitmask = 0u;
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const uint32_t nearx = nxn ? qhix[h] : qlox[h], farx = nxn ? qlox[h] : qhix[h];
+    const uint32_t neary = nyn ? qhiy[h] : qloy[h], fary = nyn ? qloy[h] : qhiy[h];
+    const uint32_t nearz = nzn ? qhiz[h] : qloz[h], farz = nzn ? qloz[h] : qhiz[h];
+    // four meta bytes at once: bits 7-5 = child bits (1 = internal, unary count for leaves), bits 4-0 = slot index, where
+    // internal children (index 24..31, i.e. bits 4 and 3 set) are flipped by the ray octant
+    const uint32_t m4 = metaw[h];
+    const uint32_t inner4 = ((m4 & (m4 << 1)) >> 4) & 0x01010101u;
+    const uint32_t idx4 = (m4 ^ (oct4 & ((inner4 << 8) - inner4))) & 0x1f1f1f1fu; // (x << 8) - x == x * 0xff per byte, at full rate
+    const uint32_t bits4 = (m4 >> 5) & 0x07070707u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t sh = 8u * (uint32_t)k;
+      const gi_f2 qx = {(float)((nearx >> sh) & 0xffu), (float)((farx >> sh) & 0xffu)};
+      const gi_f2 qy = {(float)((neary >> sh) & 0xffu), (float)((fary >> sh) & 0xffu)};
+      const gi_f2 qz = {(float)((nearz >> sh) & 0xffu), (float)((farz >> sh) & 0xffu)};
+      const gi_f2 tx = __builtin_elementwise_fma(qx, Ax, Bx), ty = __builtin_elementwise_fma(qy, Ay, By), tz = __builtin_elementwise_fma(qz, Az, Bz);
+      const float tn = fmaxf(fmaxf(tx.x, ty.x), fmaxf(tz.x, tNear));
+      const float tf = fminf(fminf(tx.y, ty.y), fminf(tz.y, tFar));
+      const uint32_t contrib = ((bits4 >> sh) & 0xffu) << ((idx4 >> sh) & 0xffu);
+      hitmask |= (tn <= tf) ? contrib : 0u;
+    }
+  }
+  R.G = make_uint2(n1.x, (hitmask & 0xff000000u) | (n0.w >> 24));
+  return make_uint2(n1.y, hitmask & 0x00ffffffu);
+}
+
+// The per-lane composition (each lane fetches its own node: from LDS when staged there, else from global memory)
+template <bool COUNT, uint32_t STACK, bool OVERFLOW, bool ALL_LDS>
+__device__ __forceinline__ uint2 trav_node(RayTrav& R, const SceneView& sc, const uint4* s_nodes, uint32_t ldsNodes,
+                                           uint2 (*s_stack)[TRACE_BLOCK], uint2 (&overflow)[OVERFLOW ? OVF_STACK : 1], TraceCounters& tc)
+{
+  const uint32_t nodeIdx = trav_node_pick<STACK, OVERFLOW>(R, s_stack, overflow);
+  uint4 n0, n1, n2, n3, n4;
+  if (ALL_LDS || nodeIdx < ldsNodes) { const uint4* p = s_nodes + nodeIdx * 5u; n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3]; n4 = p[4]; }
+  else { const uint4* p = reinterpret_cast<const uint4*>(sc.nodes) + (size_t)nodeIdx * sc.nodeStrideU4; n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3]; n4 = p[4]; }
+  if (COUNT) tc.nodes++;
+  return trav_node_test(R, n0, n1, n2, n3, n4);
+}
+
+// End of a step: when the current group has no unvisited internal child left, continue with the stack top.
+// Returns true when the traversal is finished.
+template <uint32_t STACK, bool OVERFLOW>
+__device__ __forceinline__ bool trav_pop(RayTrav& R, uint2 (*s_stack)[TRACE_BLOCK], uint2 (&overflow)[OVERFLOW ? OVF_STACK : 1])
+{
+  if (R.G.y & 0xff000000u) return false;
+  if (R.sp == 0u) return true;
+  const uint32_t sp = --R.sp;
+  R.G = (!OVERFLOW || sp < STACK) ? s_stack[sp < STACK ? sp : STACK - 1u][threadIdx.x] : overflow[sp - STACK];
+  return false;
+}
+
+// Two-sided Moeller-Trumbore, operation order == oracle tri_test; evaluated branch-free (a wave almost always has a lane
+// that passes each early-out, so predication is cheaper than exec-mask branches).  `inside` excludes the t < tBest test.
+__device__ __forceinline__ bool tri_test(V3 o, V3 d, float tMin, const uint4& a, const uint4& b, const uint4& c, float& t, float& u, float& v)
+{
+  const V3 v0 = v3(u2f(a.x), u2f(a.y), u2f(a.z)), e1 = v3(u2f(a.w), u2f(b.x), u2f(b.y)), e2 = v3(u2f(b.z), u2f(b.w), u2f(c.x));
+  const V3 pv = cross(d, e2);
+  const float det = dot(e1, pv);
+  const float inv = 1.0f / det;
+  const V3 tv = o - v0;
+  u = dot(tv, pv) * inv;
+  const V3 qv = cross(tv, e1);
+  v = dot(d, qv) * inv;
+  t = dot(e2, qv) * inv;
+  return (det != 0.0f) & (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > tMin);
+}
+
+// Advances the ray by one group (node, then its leaf triangles one after the other, then pop); returns true when the
+// traversal is finished.  The per-lane form used by k_aov and the block-synchronous k_trace.
+template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool ALL_LDS, bool CUTOUT>
+__device__ __forceinline__ bool trav_step(RayTrav& R, const SceneView& sc, const uint4* s_nodes, uint32_t ldsNodes, const uint4* s_tris, uint32_t ldsTris,
+                                          uint2 (*s_stack)[TRACE_BLOCK], uint2 (&overflow)[OVERFLOW ? OVF_STACK : 1], TraceCounters& tc, uint32_t rng)
+{
+  uint2 Gt;
+  if (R.G.y & 0xff000000u) Gt = trav_node<COUNT, STACK, OVERFLOW, ALL_LDS>(R, sc, s_nodes, ldsNodes, s_stack, overflow, tc);
+  else { Gt = R.G; R.G = make_uint2(0u, 0u); }
+  // triangles of this node
+  while (Gt.y) {
+    const uint32_t k = (uint32_t)__ffs((int)Gt.y) - 1u;
+    Gt.y &= Gt.y - 1u;
+    const uint32_t triIdx = Gt.x + k;
+    uint4 a, b, c;
+    if (ALL_LDS || triIdx < ldsTris) { const uint4* p = s_tris + triIdx * 3u; a = p[0]; b = p[1]; c = p[2]; }
+    else { const uint4* p = reinterpret_cast<const uint4*>(sc.tris) + (size_t)triIdx * 4u; a = p[0]; b = p[1]; c = p[2]; }
+    if (COUNT) tc.tris++;
+    const uint32_t orig = c.y;
+    float t, u, v;
+    const bool inside = tri_test(R.o, R.d, R.tMin, a, b, c, t, u, v);
+    const bool better = (t < R.tBest) | ((t == R.tBest) & (R.bestOrig != 0xffffffffu) & (orig < R.bestOrig));
+    bool accept = inside & better;
+    if (CUTOUT && accept && (c.w & (1u << 28))) { // non-opaque material: stochastic cutout (ignoreIntersectionEXT, rp_main.ahit:57-60)
+      const float opacity = sc.materials[c.w & 0x00ffffffu].p[MP_CUTOUT];
+      accept = !(cutout_random(rng, orig) > opacity);
+    }
+    if (accept) {
+      R.tBest = t; R.bestU = u; R.bestV = v; R.bestTri = triIdx; R.bestOrig = orig; R.bestMat = c.w; R.found = true;
+      if (ANYHIT) { R.G.y = 0u; R.sp = 0u; break; }
+    }
+  }
+  return trav_pop<STACK, OVERFLOW>(R, s_stack, overflow);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wave-cooperative triangle stage.  The number of leaf triangles a node step yields varies from 0 to 24 per lane, so a
+// per-lane triangle loop runs as long as the busiest lane while most lanes sit idle (measured: 28 % of the lanes active).
+// Instead every lane appends its (ray lane, triangle) pairs to a per-wave LDS queue and the wave tests 64 pairs at a
+// time, one per lane, fetching the owning lane's ray with ds_bpermute.  The nearest hit of a ray is kept in LDS as the
+// 64-bit key (t bits << 32 | scene-order triangle id + 1) under atomicMin, which is exactly the oracle's
+// "t < tBest, ties to the lower scene-order id" rule and makes the result independent of the test order.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t TRI_ID_BITS = 26; // queue entry = ray lane << 26 | triangle index (the host refuses scenes with >= 2^26 triangles)
+struct WaveTri {
+  unsigned long long best[64]; // per ray lane: (t bits << 32) | (scene-order id + 1); low word 0 = no hit yet
+  uint4 hit[64];               // per ray lane: (triangle index, u bits, v bits, material word) of that hit
+  uint32_t queue[128];         // ring of pending (ray lane, triangle) pairs
+};
+// Staging buffer of the cooperative fetch (scenes in global memory).  A lane that loads its own 80-byte node issues five
+// 16-byte loads to a cache line no other lane touches, so every load instruction costs the L1 64 tag look-ups; measured,
+// the texture-address unit was busy 63 % of k_trace's time.  Instead lane i of the wave loads 16-byte piece (i % 5) of
+// the node that lane (i / 5) asked for: consecutive lanes read consecutive addresses, an instruction touches ~13-26 lines,
+// and the pieces meet again in LDS (conflict-free: 80 B and 48 B lane strides both map 16 lanes onto all 64 banks).
+struct WaveStage { uint4 buf[64 * 5]; };
+// Measured on C3 (1M-triangle soup): 35.4 ms with the cooperative fetch vs 29.6 ms without (the 20 KiB of staging per
+// block cost two resident blocks per CU and the extra LDS round trip outweighs the saved tag look-ups) -> off.
+constexpr bool TRACE_DYN_COOP_FETCH = false;
+
+template <bool COUNT, bool ALL_LDS, bool CUTOUT, bool COOP>
+__device__ __forceinline__ void wave_tri_batch(WaveTri& W, WaveStage* S, uint32_t head, uint32_t cnt, const RayTrav& R, uint32_t rng, const SceneView& sc,
+                                               const uint4* s_tris, uint32_t ldsTris, TraceCounters& tc)
+{
+  const uint32_t lane = __lane_id();
+  const bool act = lane < cnt;
+  const uint32_t e = act ? *(volatile uint32_t*)&W.queue[(head + lane) & 127u] : 0u;
+  const uint32_t rl = e >> TRI_ID_BITS, triIdx = e & ((1u << TRI_ID_BITS) - 1u);
+  // the owning lane's ray (executed by all lanes: wave-uniform control flow)
+  const V3 o = v3(__shfl(R.o.x, (int)rl), __shfl(R.o.y, (int)rl), __shfl(R.o.z, (int)rl));
+  const V3 d = v3(__shfl(R.d.x, (int)rl), __shfl(R.d.y, (int)rl), __shfl(R.d.z, (int)rl));
+  const float tMin = __shfl(R.tMin, (int)rl);
+  const uint32_t rrng = CUTOUT ? (uint32_t)__shfl((int)rng, (int)rl) : 0u;
+  if (COOP) { // piece (flat % 3) of the triangle of entry (flat / 3), for flat = lane, 64 + lane, 128 + lane
+    uint4 piece[3];
+#pragma unroll
+    for (uint32_t cidx = 0; cidx < 3u; cidx++) {
+      const uint32_t flat = cidx * 64u + lane, owner = flat / 3u, part = flat - owner * 3u;
+      const uint32_t tIdx = (uint32_t)__shfl((int)triIdx, (int)owner);
+      piece[cidx] = make_uint4(0u, 0u, 0u, 0u);
+      if (owner < cnt) piece[cidx] = reinterpret_cast<const uint4*>(sc.tris)[(size_t)tIdx * 4u + part];
+    }
+#pragma unroll
+    for (uint32_t cidx = 0; cidx < 3u; cidx++) S->buf[cidx * 64u + lane] = piece[cidx];
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  }
+  if (act) {
+    uint4 a, b, c;
+    if (COOP) { const uint4* p = S->buf + lane * 3u; a = p[0]; b = p[1]; c = p[2]; }
+    else if (ALL_LDS || triIdx < ldsTris) { const uint4* p = s_tris + triIdx * 3u; a = p[0]; b = p[1]; c = p[2]; }
+    else { const uint4* p = reinterpret_cast<const uint4*>(sc.tris) + (size_t)triIdx * 4u; a = p[0]; b = p[1]; c = p[2]; }
+    if (COUNT) tc.tris++;
+    float t, u, v;
+    bool accept = tri_test(o, d, tMin, a, b, c, t, u, v);
+    if (CUTOUT && accept && (c.w & (1u << 28))) { // non-opaque material: stochastic cutout (ignoreIntersectionEXT, rp_main.ahit:57-60)
+      const float opacity = sc.materials[c.w & 0x00ffffffu].p[MP_CUTOUT];
+      accept = !(cutout_random(rrng, c.y) > opacity);
+    }
+    if (accept) {
+      const unsigned long long key = ((unsigned long long)f2u(t) << 32) | (unsigned long long)(c.y + 1u);
+      atomicMin(&W.best[rl], key);
+      if (*(volatile unsigned long long*)&W.best[rl] == key) W.hit[rl] = make_uint4(triIdx, f2u(u), f2u(v), c.w);
+    }
+  }
+}
+
+// One step of all rays of a wave: node phase per lane, then the cooperative triangle stage, then pop.  Wave-uniform
+// control flow; lanes without a ray (alive == false) only help testing triangles.  Returns true when this lane's ray is finished.
+template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool ALL_LDS, bool CUTOUT, bool COOP>
+__device__ __forceinline__ bool wave_step(RayTrav& R, bool alive, WaveTri& W, WaveStage* S, const SceneView& sc, const uint4* s_nodes, uint32_t ldsNodes,
+                                          const uint4* s_tris, uint32_t ldsTris, uint2 (*s_stack)[TRACE_BLOCK], uint2 (&overflow)[OVERFLOW ? OVF_STACK : 1],
+                                          TraceCounters& tc, uint32_t rng)
+{
+  const uint32_t lane = __lane_id();
+  uint2 Gt = make_uint2(0u, 0u);
+  if (!COOP) {
+    if (alive) Gt = trav_node<COUNT, STACK, OVERFLOW, ALL_LDS>(R, sc, s_nodes, ldsNodes, s_stack, overflow, tc);
+  } else {
+    uint32_t nodeIdx = 0xffffffffu;
+    if (alive) nodeIdx = trav_node_pick<STACK, OVERFLOW>(R, s_stack, overflow);
+    uint4 piece[5]; // piece (flat % 5) of the node lane (flat / 5) asked for, flat = lane, 64 + lane, ...
+#pragma unroll
+    for (uint32_t cidx = 0; cidx < 5u; cidx++) {
+      const uint32_t flat = cidx * 64u + lane, owner = flat / 5u, part = flat - owner * 5u;
+      const uint32_t nIdx = (uint32_t)__shfl((int)nodeIdx, (int)owner);
+      piece[cidx] = make_uint4(0u, 0u, 0u, 0u);
+      if (nIdx != 0xffffffffu) piece[cidx] = reinterpret_cast<const uint4*>(sc.nodes)[(size_t)nIdx * sc.nodeStrideU4 + part];
+    }
+#pragma unroll
+    for (uint32_t cidx = 0; cidx < 5u; cidx++) S->buf[cidx * 64u + lane] = piece[cidx];
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    if (alive) {
+      const uint4* p = S->buf + lane * 5u;
+      const uint4 n0 = p[0], n1 = p[1], n2 = p[2], n3 = p[3], n4 = p[4];
+      if (COUNT) tc.nodes++;
+      Gt = trav_node_test(R, n0, n1, n2, n3, n4);
+    }
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  }
+  uint32_t head = 0u, tail = 0u; // wave-uniform
+  for (;;) {
+    const unsigned long long m = __ballot(Gt.y != 0u);
+    if (!m) break;
+    if (Gt.y) {
+      const uint32_t k = (uint32_t)__ffs((int)Gt.y) - 1u;
+      Gt.y &= Gt.y - 1u;
+      *(volatile uint32_t*)&W.queue[(tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & 127u] = (lane << TRI_ID_BITS) | (Gt.x + k);
+    }
+    tail += (uint32_t)__popcll(m);
+    if (tail - head >= 64u) { wave_tri_batch<COUNT, ALL_LDS, CUTOUT, COOP>(W, S, head, 64u, R, rng, sc, s_tris, ldsTris, tc); head += 64u; }
+  }
+  if (tail != head) wave_tri_batch<COUNT, ALL_LDS, CUTOUT, COOP>(W, S, head, tail - head, R, rng, sc, s_tris, ldsTris, tc);
+  bool done = false;
+  if (alive) {
+    const unsigned long long key = *(volatile unsigned long long*)&W.best[lane];
+    R.tBest = u2f((uint32_t)(key >> 32));
+    R.found = (uint32_t)key != 0u;
+    done = (ANYHIT && R.found) ? true : trav_pop<STACK, OVERFLOW>(R, s_stack, overflow);
+  }
+  return done;
+}
+
+// start of a ray in the cooperative scheme (after trav_init)
+__device__ __forceinline__ void wave_ray_begin(WaveTri& W, float tMax) { *(volatile unsigned long long*)&W.best[__lane_id()] = (unsigned long long)f2u(tMax) << 32; }
+// result of a finished ray
+__device__ __forceinline__ void wave_ray_end(WaveTri& W, RayTrav& R)
+{
+  __atomic_signal_fence(__ATOMIC_SEQ_CST); // compiler only: the winning lane's store precedes this load in the wave's program order
+  if (R.found) { const uint4 h = W.hit[__lane_id()]; R.bestTri = h.x; R.bestU = u2f(h.y); R.bestV = u2f(h.z); R.bestMat = h.w; }
+}
+
+template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool ALL_LDS, bool CUTOUT>
+__device__ __forceinline__ bool traverse(const SceneView& sc, const uint4* s_nodes, uint32_t ldsNodes, const uint4* s_tris, uint32_t ldsTris,
+                                         uint2 (*s_stack)[TRACE_BLOCK], V3 o, V3 d, float tMin, float tMax,
+                                         float& outT, float& outU, float& outV, uint32_t& outTri, uint32_t& outMat, TraceCounters& tc, uint32_t rng = 0u)
+{
+  RayTrav R; trav_init(R, o, d, tMin, tMax);
+  uint2 overflow[OVERFLOW ? OVF_STACK : 1];
+  while (!trav_step<ANYHIT, COUNT, STACK, OVERFLOW, ALL_LDS, CUTOUT>(R, sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, overflow, tc, rng)) {}
+  outT = R.tBest; outU = R.bestU; outV = R.bestV; outTri = R.bestTri; outMat = R.bestMat;
+  return R.found;
+}
+
+
+} // namespace gi
