@@ -504,6 +504,45 @@ def test_scene_data_primvar_inputs(gi, orc):
     assert not np.array_equal(got, ref_plain)
 
 
+def test_everything_at_once_parity(gi, orc):
+    """Feature interactions: textured + primvar-driven inputs, normal map, dome light, medium stack with scattering, cutouts, all four
+    light types with NEE, depth of field and clipping planes in ONE scene (the TEXTURED x VOLUME x DOME kernel specialisations),
+    across two render calls (progressive accumulation) -- bit-identical to the oracle."""
+    from gatling_amd.scene import INTERP_UNIFORM, PRIMVAR_VEC3, Primvar, TEX_BASE_COLOR, TEX_EMISSION, TextureBinding
+    desc = textured_scene(dome=True)
+    vol = volume_scene()
+    base = len(desc.materials)
+    desc.materials += vol.materials[1:]                    # murky + clear glass
+    for m in vol.meshes[1:]:
+        m.material += base - 1
+        m.transform = m.transform.copy(); m.transform[3, 0] += 1.6
+        desc.meshes.append(m)
+    cut = MaterialDesc.usd_preview_surface(name="leaf", diffuseColor=(0.2, 0.7, 0.2), opacity=0.5)
+    cut.primvar_inputs = {TEX_BASE_COLOR: "displayColor"}
+    desc.materials.append(cut)
+    from gatling_amd.meshprep import bake_vertices
+    qp = np.float32([[-2.2, -1.0, 0.2], [-1.2, -1.0, 0.2], [-1.2, -1.0, 1.6], [-2.2, -1.0, 0.2], [-1.2, -1.0, 1.6], [-2.2, -1.0, 1.6]])
+    quad = MeshDesc(name="/Leaf", vertices=bake_vertices(qp, np.tile([0, -1, 0], (6, 1))), faces=np.arange(6, dtype=np.uint32).reshape(-1, 3),
+                    material=len(desc.materials) - 1, id=7, double_sided=True)
+    quad.primvars = [Primvar("displayColor", PRIMVAR_VEC3, INTERP_UNIFORM, np.float32([[0.9, 0.3, 0.1], [0.1, 0.3, 0.9]]))]
+    desc.meshes.append(quad)
+    desc.sphere_lights = [SphereLight(pos=(-1.5, -1.5, 2.5), base_emission=(6, 5, 4), radius=(0.2, 0.2, 0.2))]
+    desc.distant_lights = [DistantLight(direction=(0.3, 0.4, -0.85), base_emission=(1.5, 1.5, 1.2), angle=0.05)]
+    desc.disk_lights = [DiskLight(origin=(1.5, 1.0, 3.0), t0=(1, 0, 0), t1=(0, 1, 0), base_emission=(8, 8, 8), radius_x=0.4, radius_y=0.3)]
+    desc.camera.f_stop = 2.0; desc.camera.focus_distance = 5.0; desc.camera.focal_length = 0.05
+    desc.camera.clip_start = 0.5; desc.camera.clip_end = 40.0
+    rs = RenderSettings(spp=3, max_bounces=10, next_event_estimation=True, medium_stack_size=2, depth_of_field=True, clipping_planes=True)
+    img1, ref1, _ = render_both(gi, orc, desc, rs, 96, 54)
+    sc = gi.Scene(desc)
+    try:
+        sc.render(rs, 96, 54)
+        img2 = sc.render(rs, 96, 54)  # second call accumulates on the first
+    finally:
+        sc.close()
+    ref2, _ = orc.render(desc, rs, 96, 54, sample_offset=3, prev_color=ref1, threads=4)
+    assert np.array_equal(img2, ref2)
+
+
 def test_interior_scene_parity(gi, orc):
     """C5's structure at small scale: room + instanced clutter (affine instance transforms), three material classes incl.
     transmission, four rect lights, NEE on."""
