@@ -112,17 +112,19 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from gatling_amd import capi
-    from gatling_amd.dist import gather_rows, partition_rows
+    from gatling_amd.dist import gather_rows, interleaved_rows
 
     desc, rs, w, h, label = make_workload(args.workload, args.spp or None)
     rs.progressive_accumulation = False  # every step renders the same frame from sample 0 (no cross-step accumulation)
     scene = capi.Scene(desc, device=local_rank)
-    r0, r1 = partition_rows(h, world, rank)
+    r0, r1, rstride = interleaved_rows(h, world, rank)  # rows rank::world: every rank's share costs the same (dist.py)
+    nrows = len(range(r0, r1, rstride))
     dev_ptr = scene.device_pointer(w, h)
 
     class _Tile:  # zero-copy view of the library's device render buffer (rows r0..r1) for the RCCL gather
         def __init__(self):
-            self.__cuda_array_interface__ = {"shape": (r1 - r0, w, 4), "typestr": "<f4", "data": (dev_ptr + r0 * w * 16, False), "version": 2}
+            self.__cuda_array_interface__ = {"shape": (nrows, w, 4), "typestr": "<f4", "data": (dev_ptr + r0 * w * 16, False), "version": 2,
+                                             "strides": (rstride * w * 16, 16, 4)}
     tile = torch.as_tensor(_Tile(), device=f"cuda:{local_rank}") if use_dist else None
     host_full = torch.empty((h, w, 4), dtype=torch.float32).pin_memory() if (use_dist and rank == 0) else None
 
@@ -130,8 +132,8 @@ def main():
         if not use_dist:
             scene.render(rs, w, h)  # blocks; colour AOV complete in host memory on return (reference semantics)
         else:
-            scene.render(rs, w, h, rows=(r0, r1), device_only=True)
-            full = gather_rows(tile, h, w)
+            scene.render(rs, w, h, rows=(r0, r1), device_only=True, row_stride=rstride)
+            full = gather_rows(tile, h, w, interleaved=True)
             if rank == 0:
                 host_full.copy_(full, non_blocking=False)
 
@@ -159,7 +161,7 @@ def main():
 
     # --- roofline inputs: one extra (untimed) step with the traversal counters on
     scene.set_option(capi.OPTION_COUNT_TRAVERSAL, 1)
-    scene.render(rs, w, h, rows=(r0, r1), device_only=True)
+    scene.render(rs, w, h, rows=(r0, r1), device_only=True, row_stride=rstride)
     cst = scene.stats()
     scene.set_option(capi.OPTION_COUNT_TRAVERSAL, 0)
 
@@ -189,7 +191,7 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": label, "width": w, "height": h, "spp": rs.spp, "max_bounces": rs.max_bounces,
-                          "parallelism": f"rows{world}" if world > 1 else "single", "segments_per_sample": round(seg_per_sample, 4),
+                          "parallelism": f"rows-interleaved{world}" if world > 1 else "single", "segments_per_sample": round(seg_per_sample, 4),
                           "triangles": cst["triangleCount"], "bvh8_nodes": cst["nodeCount"], "iterations_per_step": stats[-1]["iterations"]},
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:

@@ -50,7 +50,7 @@ class GiCAovBinding(C.Structure):
 class GiCRenderParams(C.Structure):
     _fields_ = [("aovBindings", C.POINTER(GiCAovBinding)), ("aovBindingCount", C.c_uint32), ("camera", GiCCameraDesc),
                 ("domeLight", C.c_void_p), ("renderSettings", GiCRenderSettings), ("scene", C.c_void_p),
-                ("rowBegin", C.c_uint32), ("rowEnd", C.c_uint32)]
+                ("rowBegin", C.c_uint32), ("rowEnd", C.c_uint32), ("rowStride", C.c_uint32)]
 
 
 class GiCMaterialDesc(C.Structure):
@@ -279,7 +279,7 @@ class Scene:
             self._buffers[key] = rb
         return self._buffers[key]
 
-    def render(self, settings: RenderSettings, width: int, height: int, rows=None, device_only=False):
+    def render(self, settings: RenderSettings, width: int, height: int, rows=None, device_only=False, row_stride=1):
         """One giCRender call.  Returns the colour AOV as float32 [rows, width, 4] (row 0 = bottom) -- a view of the
         library-owned host memory copied out -- or None when ``device_only``."""
         L = self.L
@@ -298,14 +298,14 @@ class Scene:
         p.renderSettings = _settings(settings)
         p.scene = self.handle
         r0, r1 = rows if rows is not None else (0, height)
-        p.rowBegin, p.rowEnd = r0, r1
+        p.rowBegin, p.rowEnd, p.rowStride = r0, r1, row_stride
         if L.giCRender(C.byref(p)) != GI_C_OK:
             raise GiError("giCRender failed: " + L.giCGetLastError().decode())
         if device_only:
             return None
         mem = L.giCGetRenderBufferMem(rb)
         full = np.ctypeslib.as_array(C.cast(mem, C.POINTER(C.c_float)), shape=(height, width, 4))
-        return full[r0:r1].copy()
+        return full[r0:r1:row_stride].copy()
 
     AOVS = {"normal": (1, FORMAT_FLOAT32_VEC4), "nee": (2, FORMAT_FLOAT32_VEC4), "barycentrics": (3, FORMAT_FLOAT32_VEC4),
             "texcoords": (4, FORMAT_FLOAT32_VEC4), "bounces": (5, FORMAT_FLOAT32_VEC4), "opacity": (7, FORMAT_FLOAT32_VEC4),
@@ -313,7 +313,7 @@ class Scene:
             "objectId": (11, FORMAT_INT32), "depth": (12, FORMAT_FLOAT32), "faceId": (13, FORMAT_INT32), "instanceId": (14, FORMAT_INT32),
             "doubleSided": (15, FORMAT_FLOAT32_VEC4), "albedo": (16, FORMAT_FLOAT32_VEC4)}
 
-    def render_aovs(self, settings: RenderSettings, width: int, height: int, names, clear_values=None, with_color=True, rows=None):
+    def render_aovs(self, settings: RenderSettings, width: int, height: int, names, clear_values=None, with_color=True, rows=None, row_stride=1):
         """One giCRender call with the colour AOV (optional) plus the named non-colour AOVs bound (Gi.h:36-56, 161-166).
         Returns {name: array}; vec3 AOVs come back as [h, w, 4] (the shader writes .xyz only), ids / depth as [h, w]."""
         L = self.L
@@ -344,7 +344,7 @@ class Scene:
         p = GiCRenderParams()
         p.aovBindings = C.cast(arr, C.POINTER(GiCAovBinding)); p.aovBindingCount = len(bufs)
         p.camera = _camera(self.desc.camera); p.domeLight = self.dome; p.renderSettings = _settings(settings); p.scene = self.handle
-        p.rowBegin, p.rowEnd = r0, r1
+        p.rowBegin, p.rowEnd, p.rowStride = r0, r1, row_stride
         if L.giCRender(C.byref(p)) != GI_C_OK:
             raise GiError("giCRender failed: " + L.giCGetLastError().decode())
         out = {}
@@ -356,7 +356,7 @@ class Scene:
                 a = np.ctypeslib.as_array(C.cast(mem, C.POINTER(C.c_float)), shape=(height, width))
             else:
                 a = np.ctypeslib.as_array(C.cast(mem, C.POINTER(C.c_int32)), shape=(height, width))
-            out[name] = a[r0:r1].copy()
+            out[name] = a[r0:r1:row_stride].copy()
         return out
 
     def device_pointer(self, width, height) -> int:

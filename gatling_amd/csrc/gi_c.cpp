@@ -271,7 +271,7 @@ struct GiCScene {
   GiCCameraDesc oldCamera{};
   GiCRenderSettings oldSettings{};
   uint8_t oldClear[GI_C_MAX_AOV_COMP_SIZE] = {0};
-  uint32_t oldRowBegin = 0, oldRowEnd = 0;
+  uint32_t oldRowBegin = 0, oldRowEnd = 0, oldRowStride = 1;
   GiCDomeLight* oldDome = nullptr;
   float oldDomeEmission[3] = {0, 0, 0};
   // device scene
@@ -1076,7 +1076,9 @@ extern "C" int giCRender(const GiCRenderParams* params)
   if (width == 0 || height == 0) return GI_C_OK; // Render.Empty-style degenerate target: nothing to do
   if (width > 65535u || height > 65535u) { setError("giCRender: image dimensions exceed 65535 (imageDims packing, rp_main.h:38)"); return GI_C_ERROR; }
   uint32_t rowBegin = params->rowBegin, rowEnd = params->rowEnd ? params->rowEnd : height;
+  const uint32_t rowStride = params->rowStride ? params->rowStride : 1u;
   if (rowBegin > rowEnd || rowEnd > height) { setError("giCRender: bad row range"); return GI_C_ERROR; }
+  const uint32_t tileRows = rowEnd > rowBegin ? (rowEnd - rowBegin + rowStride - 1u) / rowStride : 0u; // rows rowBegin + k * rowStride < rowEnd
 
   std::lock_guard<std::mutex> guard(s->mutex);
   hipStream_t st = g_ctx.stream;
@@ -1087,11 +1089,11 @@ extern "C" int giCRender(const GiCRenderParams* params)
   if (colorBinding) memcpy(clear, colorBinding->clearValue, GI_C_MAX_AOV_COMP_SIZE);
   const float* domeEm = params->domeLight ? params->domeLight->baseEmission : nullptr;
   if (!s->haveOldParams || memcmp(&s->oldCamera, &params->camera, sizeof(GiCCameraDesc)) != 0 || !settingsEqual(s->oldSettings, rs) ||
-      memcmp(s->oldClear, clear, sizeof(clear)) != 0 || s->oldRowBegin != rowBegin || s->oldRowEnd != rowEnd || s->oldDome != params->domeLight ||
+      memcmp(s->oldClear, clear, sizeof(clear)) != 0 || s->oldRowBegin != rowBegin || s->oldRowEnd != rowEnd || s->oldRowStride != rowStride || s->oldDome != params->domeLight ||
       (domeEm && memcmp(domeEm, s->oldDomeEmission, 12) != 0))
     s->dirty |= DIRTY_FRAMEBUFFER;
   s->haveOldParams = true; s->oldCamera = params->camera; s->oldSettings = rs; memcpy(s->oldClear, clear, sizeof(clear));
-  s->oldRowBegin = rowBegin; s->oldRowEnd = rowEnd; s->oldDome = params->domeLight;
+  s->oldRowBegin = rowBegin; s->oldRowEnd = rowEnd; s->oldRowStride = rowStride; s->oldDome = params->domeLight;
   if (domeEm) memcpy(s->oldDomeEmission, domeEm, 12);
 
   s->stats.bvhBuildMs = 0.0; s->stats.uploadMs = 0.0;
@@ -1152,7 +1154,13 @@ extern "C" int giCRender(const GiCRenderParams* params)
   (void)dummyColor;
 
   // --- uniforms (Gi.cpp:2373-2426; camera terms rp_main.rgen:199-212 evaluated once on the host)
-  const size_t pixels = (size_t)(rowEnd - rowBegin) * width;
+  const size_t pixels = (size_t)tileRows * width;
+  // device -> host copy of the tile's rows (one 2D copy: the rows are rowStride image rows apart)
+  auto copyTileRows = [&](GiCRenderBuffer* rb, size_t texel) -> hipError_t {
+    const size_t off = (size_t)rowBegin * width * texel, rowBytes = (size_t)width * texel, pitch = rowBytes * rowStride;
+    if (rowStride == 1u) return hipMemcpyAsync((uint8_t*)rb->hostMem + off, (uint8_t*)rb->deviceMem + off, rowBytes * tileRows, hipMemcpyDeviceToHost, st);
+    return hipMemcpy2DAsync((uint8_t*)rb->hostMem + off, pitch, (uint8_t*)rb->deviceMem + off, pitch, rowBytes, tileRows, hipMemcpyDeviceToHost, st);
+  };
   if (pixels == 0) return GI_C_OK;
   FrameUniforms U{};
   {
@@ -1188,7 +1196,7 @@ extern "C" int giCRender(const GiCRenderParams* params)
     U.mediumStackSize = rs.mediumStackSize; U.maxVolumeWalkLength = rs.maxVolumeWalkLength;
     U.mediumStackSize = rs.mediumStackSize; U.maxVolumeWalkLength = rs.maxVolumeWalkLength;
     U.maxBounces = std::min(rs.maxBounces, 0xfffu); U.rrBounceOffset = rs.rrBounceOffset & 0xffffu;
-    U.imageWidth = width; U.imageHeight = height; U.rowBegin = rowBegin; U.pixelCount = (uint32_t)pixels;
+    U.imageWidth = width; U.imageHeight = height; U.rowBegin = rowBegin; U.rowStride = rowStride; U.pixelCount = (uint32_t)pixels;
     U.flags = (rs.jitteredSampling ? FLAG_JITTER : 0u) | (rs.filterImportanceSampling ? FLAG_FIS : 0u) | (rs.depthOfField ? FLAG_DOF : 0u) |
               (rs.clippingPlanes ? FLAG_CLIP : 0u) | (rs.nextEventEstimation ? FLAG_NEE : 0u) | (rs.progressiveAccumulation ? FLAG_PROGRESSIVE : 0u);
     U.sphereCount = (uint32_t)s->sphereLights.recs.size(); U.distantCount = (uint32_t)s->distantLights.recs.size();
@@ -1302,11 +1310,10 @@ extern "C" int giCRender(const GiCRenderParams* params)
       }
       launchAccumulate(st, U, s->sampleBuf.ptr, s->accum.ptr, colorOut, batch == 0, batch + 1 == numBatches);
     }
-    if (neeRb) launchResolveNee(st, s->neeKey.ptr, reinterpret_cast<F4*>(neeRb->deviceMem), (uint32_t)pixels, rowBegin * width);
+    if (neeRb) launchResolveNee(st, U, s->neeKey.ptr, reinterpret_cast<F4*>(neeRb->deviceMem), (uint32_t)pixels);
     for (GiCRenderBuffer* rb : {neeRb, bouncesRb}) {
       if (!rb || rb->deviceOnly) continue;
-      size_t off = (size_t)rowBegin * width * rb->stride, bytes = pixels * rb->stride;
-      HIP_TRY(hipMemcpyAsync((uint8_t*)rb->hostMem + off, (uint8_t*)rb->deviceMem + off, bytes, hipMemcpyDeviceToHost, st));
+      HIP_TRY(copyTileRows(rb, rb->stride));
     }
   }
   if (anyAov) { // the non-colour AOV pass (k_aov) + read-back of the rows of this tile
@@ -1314,14 +1321,12 @@ extern "C" int giCRender(const GiCRenderParams* params)
     if (hipGetLastError() != hipSuccess) { setError("k_aov launch failed"); return GI_C_ERROR; }
     for (GiCRenderBuffer* rb : aovBuffers) {
       if (rb->deviceOnly) continue;
-      size_t off = (size_t)rowBegin * width * rb->stride, bytes = pixels * rb->stride;
-      HIP_TRY(hipMemcpyAsync((uint8_t*)rb->hostMem + off, (uint8_t*)rb->deviceMem + off, bytes, hipMemcpyDeviceToHost, st));
+      HIP_TRY(copyTileRows(rb, rb->stride));
     }
   }
   HIP_TRY(hipMemcpyAsync(s->hCounters, s->dCounters.ptr, sizeof(Counters), hipMemcpyDeviceToHost, st));
   if (colorRb && !colorRb->deviceOnly) {
-    size_t off = (size_t)rowBegin * width * 16, bytes = pixels * 16;
-    HIP_TRY(hipMemcpyAsync((uint8_t*)colorRb->hostMem + off, (uint8_t*)colorRb->deviceMem + off, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(copyTileRows(colorRb, 16));
   }
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());

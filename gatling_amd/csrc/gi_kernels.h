@@ -23,7 +23,7 @@ constexpr uint32_t TRACE_DYN_SPILL8 = 0x100u; // flag in dynRefill: 8 LDS stack 
 void launchShade(hipStream_t s, uint32_t blocks, uint32_t klass, bool textured /* some material of the class has textured inputs */, bool volume /* mediumStackSize > 0 */, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par);
 
 void launchAov(hipStream_t s, const FrameUniforms& U, const SceneView& sc, const AovTargets& A);
-void launchResolveNee(hipStream_t s, const unsigned long long* key, F4* aov, uint32_t pixelCount, uint32_t firstPixel);
+void launchResolveNee(hipStream_t s, const FrameUniforms& U, const unsigned long long* key, F4* aov, uint32_t pixelCount);
 void launchDebugBsdf(hipStream_t s, const MaterialRec* mat, uint32_t count, const float* in, float* out);
 
 } // namespace gi

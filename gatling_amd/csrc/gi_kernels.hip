@@ -124,7 +124,7 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st,
           // a path that left the scene was routed here straight from k_trace, before the loop's bounce++ (rp_main.rgen:480)
           const uint32_t bounces = ((f2u(S->thr.w) + ((entry & REGEN_MISSED) ? 1u : 0u)) & 0x00000fffu), maxB = U.maxBounces < 0x00000fffu ? U.maxBounces : 0x00000fffu;
           const V3 c = gi_colormap_inferno((float)bounces / (float)maxB);
-          F4* dst = &st.bouncesAov[U.rowBegin * U.imageWidth + f2u(id.x)];
+          F4* dst = &st.bouncesAov[tile_to_image_pixel(U, f2u(id.x))];
           dst->x = c.x; dst->y = c.y; dst->z = c.z;
         }
         float mv = fmax2(rad.x, fmax2(rad.y, rad.z));
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st,
       more = (i < U.workTotal - workBase) && (w < U.workTotal);
       if (more) {
         const uint32_t pixelLocal = w % U.pixelCount, sLocal = w / U.pixelCount;
-        const uint32_t pixelIndex = U.rowBegin * U.imageWidth + pixelLocal; // :195 (global index: RNG is tile independent)
+        const uint32_t pixelIndex = tile_to_image_pixel(U, pixelLocal); // :195 (global index: RNG is tile independent)
         const uint32_t sampleIndex = U.sampleOffset + U.batchFirstSample + sLocal;
         uint32_t rng;
         make_camera_ray(U, pixelIndex, sampleIndex, origin, dir, tMin, tMax, rng);
@@ -172,20 +172,20 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(FrameUniforms U, const F4*
     pixelColor = pixelColor + v3(src.x, src.y, src.z) * U.invSpp;
   }
   if (!lastBatch) { st4(&accum[p], pixelColor.x, pixelColor.y, pixelColor.z, 0.0f); return; }
-  const uint32_t pixelIndex = U.rowBegin * U.imageWidth + p;
+  const uint32_t pixelIndex = tile_to_image_pixel(U, p);
   V3 prev = pixelColor;
   if ((U.flags & FLAG_PROGRESSIVE) && U.sampleOffset > 0u) { const F4 q = ld4(&colorOut[pixelIndex]); prev = v3(q.x, q.y, q.z); }
   const V3 c = (prev * U.sampleOffsetF + pixelColor * U.sppF) * U.invTotalSampleCount;
   st4(&colorOut[pixelIndex], c.x, c.y, c.z, 1.0f);
 }
 
-__global__ void k_resolve_nee(const unsigned long long* __restrict__ key, F4* __restrict__ aov, uint32_t pixelCount, uint32_t firstPixel)
+__global__ void k_resolve_nee(FrameUniforms U, const unsigned long long* __restrict__ key, F4* __restrict__ aov, uint32_t pixelCount)
 {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= pixelCount) return;
   const unsigned long long k = key[p];
   if (k == 0ull) return; // no shadow ray traced for this pixel: the AOV keeps its clear value
-  F4* dst = &aov[firstPixel + p];
+  F4* dst = &aov[tile_to_image_pixel(U, p)];
   dst->x = (k & 1ull) ? 1.0f : 0.0f; dst->y = (k & 1ull) ? 0.0f : 1.0f; dst->z = 0.0f;
 }
 
@@ -650,7 +650,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_aov(FrameUniforms U, SceneView 
   __syncthreads();
   const uint32_t p = blockIdx.x * TRACE_BLOCK + threadIdx.x;
   if (p >= U.pixelCount) return;
-  const uint32_t pixelIndex = U.rowBegin * U.imageWidth + p;
+  const uint32_t pixelIndex = tile_to_image_pixel(U, p);
   auto put3 = [&](F4* buf, V3 v) { if (buf) { float* d = reinterpret_cast<float*>(&buf[pixelIndex]); d[0] = v.x; d[1] = v.y; d[2] = v.z; } };
   auto clr3 = [&](F4* buf, int id) { put3(buf, v3(A.clear[id][0], A.clear[id][1], A.clear[id][2])); };
   clr3(A.barycentrics, 3); clr3(A.texcoords, 4); clr3(A.opacity, 7); clr3(A.tangents, 8); clr3(A.bitangents, 9); clr3(A.thinWalled, 10);
@@ -821,9 +821,9 @@ void launchShade(hipStream_t s, uint32_t blocks, uint32_t klass, bool textured, 
 #undef GI_LAUNCH_SHADE
 }
 
-void launchResolveNee(hipStream_t s, const unsigned long long* key, F4* aov, uint32_t pixelCount, uint32_t firstPixel)
+void launchResolveNee(hipStream_t s, const FrameUniforms& U, const unsigned long long* key, F4* aov, uint32_t pixelCount)
 {
-  hipLaunchKernelGGL(k_resolve_nee, dim3((pixelCount + 255u) / 256u), dim3(256), 0, s, key, aov, pixelCount, firstPixel);
+  hipLaunchKernelGGL(k_resolve_nee, dim3((pixelCount + 255u) / 256u), dim3(256), 0, s, U, key, aov, pixelCount);
 }
 
 void launchDebugBsdf(hipStream_t s, const MaterialRec* mat, uint32_t count, const float* in, float* out)

@@ -68,6 +68,13 @@ __device__ __forceinline__ uint32_t reader_index(const QueueReader& r, uint32_t 
 
 __device__ __forceinline__ F4 ld4(const F4* p) { float4 v = *reinterpret_cast<const float4*>(p); return F4{v.x, v.y, v.z, v.w}; }
 __device__ __forceinline__ void st4(F4* p, float x, float y, float z, float w) { *reinterpret_cast<float4*>(p) = make_float4(x, y, z, w); }
+// tile-local pixel (row-major over the tile's rows) -> pixel index in the full image (rp_main.rgen:195); the tile's rows are
+// rowBegin, rowBegin + rowStride, ...
+__device__ __forceinline__ uint32_t tile_to_image_pixel(const FrameUniforms& U, uint32_t pixelLocal)
+{
+  const uint32_t row = pixelLocal / U.imageWidth, x = pixelLocal - row * U.imageWidth;
+  return (U.rowBegin + row * U.rowStride) * U.imageWidth + x;
+}
 constexpr uint32_t MISS = 0xffffffffu;
 constexpr uint32_t REGEN_MISSED = 0x80000000u; // flag on a regen-queue entry: the path left the scene (k_trace -> k_raygen)
 

@@ -116,6 +116,7 @@ struct FrameUniforms {
   uint32_t flags; // FLAG_*
   uint32_t sphereCount, distantCount, rectCount, diskCount, totalLightCount;
   uint32_t mediumStackSize, maxVolumeWalkLength; // GiRenderSettings (Gi.h:150-151); stack size 0 = inside/outside toggle only
+  uint32_t rowStride, padStride;                 // the tile's rows are rowBegin + k * rowStride (multi-GPU row interleaving)
 };
 enum : uint32_t {
   FLAG_JITTER = 1u, FLAG_FIS = 2u, FLAG_DOF = 4u, FLAG_CLIP = 8u, FLAG_NEE = 16u, FLAG_PROGRESSIVE = 32u,

@@ -19,11 +19,21 @@ def partition_rows(height: int, world_size: int, rank: int) -> Tuple[int, int]:
     return r0, r0 + base + (1 if rank < extra else 0)
 
 
-def gather_rows(local_tile, height: int, width: int, group=None, dst: int = 0):
+def interleaved_rows(height: int, world_size: int, rank: int) -> Tuple[int, int, int]:
+    """(rowBegin, rowEnd, rowStride) of rank's share when rows are dealt round-robin: rank, rank + N, rank + 2N, ...
+
+    Contiguous bands of a frame differ in cost (cornell 1080p, 8 bands: 0.61x .. 1.19x of the mean -- the slowest band sets
+    the frame time); every rank's interleaved share samples the whole image, so the shares cost the same."""
+    if world_size <= 0 or not (0 <= rank < world_size):
+        raise ValueError("bad rank/world_size")
+    return rank, height, world_size
+
+
+def gather_rows(local_tile, height: int, width: int, group=None, dst: int = 0, interleaved: bool = False):
     """Gathers [rows_r, width, 4] float32 tensors (device or CPU) into the full [height, width, 4] image on ``dst``.
 
-    Bands differ by at most one row; they are padded to a common size so a single gather moves everything
-    (C5: 16.6 MB per GPU at 4K -- one collective, no all-reduce: SURVEY.md section 8e)."""
+    The shares (contiguous bands, or rows rank::N when ``interleaved``) differ by at most one row; they are padded to a common
+    size so a single gather moves everything (C5: 16.6 MB per GPU at 4K -- one collective, no all-reduce: SURVEY.md section 8e)."""
     import torch
     import torch.distributed as dist
 
@@ -31,13 +41,17 @@ def gather_rows(local_tile, height: int, width: int, group=None, dst: int = 0):
     rank = dist.get_rank(group)
     max_rows = -(-height // world)
     pad = torch.zeros((max_rows, width, 4), dtype=local_tile.dtype, device=local_tile.device)
-    pad[: local_tile.shape[0]] = local_tile
+    pad[: local_tile.shape[0]] = local_tile  # also packs a strided (interleaved) device view
     out = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
     dist.gather(pad, out, dst=dst, group=group)
     if rank != dst:
         return None
     full = torch.empty((height, width, 4), dtype=local_tile.dtype, device=local_tile.device)
     for r in range(world):
-        r0, r1 = partition_rows(height, world, r)
-        full[r0:r1] = out[r][: r1 - r0]
+        if interleaved:
+            n = len(range(r, height, world))
+            full[r::world] = out[r][:n]
+        else:
+            r0, r1 = partition_rows(height, world, r)
+            full[r0:r1] = out[r][: r1 - r0]
     return full

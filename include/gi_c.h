@@ -143,6 +143,10 @@ typedef struct GiCRenderParams {
    * split is bit-identical to the single-GPU image. */
   uint32_t rowBegin;
   uint32_t rowEnd;
+  /* [ext] rows rowBegin, rowBegin + rowStride, ... below rowEnd (0 and 1 mean every row).  Rank r of N rendering
+   * (rowBegin = r, rowEnd = height, rowStride = N) gets an even share of cheap and expensive image regions: on the cornell frame
+   * contiguous eighths differ by 0.61x .. 1.19x of the mean cost. */
+  uint32_t rowStride;
 } GiCRenderParams;
 
 /* Closed-form material classes: replaces MaterialX->MDL->GLSL codegen (src/mc, GlslShaderGen) */

@@ -41,10 +41,14 @@ def _worker(rank, world, port, out_path):
     tile, _ = orc.render(desc, rs, w, h, rows=(r0, r1))
     dist.barrier()
     full = gather_rows(torch.from_numpy(tile), h, w)
+    # the row-interleaved shares bench.py uses (rows rank::world): here cut out of a whole-frame oracle render as a strided view
+    whole, _ = orc.render(desc, rs, w, h)
+    full_i = gather_rows(torch.from_numpy(whole)[rank::world], h, w, interleaved=True)
     if rank == 0:
+        assert torch.equal(full_i, torch.from_numpy(whole))
         np.save(out_path, full.numpy())
     else:
-        assert full is None
+        assert full is None and full_i is None
     dist.destroy_process_group()
 
 

@@ -11,6 +11,12 @@ import sys
 import numpy as np
 import pytest
 
+try:  # torch before the HIP library: loaded the other way round, torch does not see the GPU (two HIP runtimes in one process)
+    import torch
+    _TORCH_CUDA = torch.cuda.is_available()
+except Exception:  # pragma: no cover
+    torch, _TORCH_CUDA = None, False
+
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
 from make_golden import CASES, build_case  # noqa: E402
 
@@ -152,6 +158,59 @@ def test_row_sharding_is_bit_identical(gi):
     finally:
         sc.close()
     assert np.array_equal(np.concatenate(parts).view(np.uint32), full.view(np.uint32))
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_interleaved_row_sharding_is_bit_identical(gi, world):
+    """What bench.py --gpus N does: rank r renders rows r, r+N, ... (rowStride = N; balanced load) -- every share equals the same
+    rows of the single-call image, colour and AOVs alike, also for heights that N does not divide."""
+    from gatling_amd.dist import interleaved_rows
+    desc = cornell_box()
+    desc.rect_lights = [RectLight(origin=(0, 0, 0.9), t0=(1, 0, 0), t1=(0, -1, 0), base_emission=(10, 10, 10), width=0.7, height=0.5)]
+    rs = RenderSettings(spp=3, max_bounces=6, next_event_estimation=True, progressive_accumulation=False)
+    w, h = 64, 37
+    sc = gi.Scene(desc)
+    try:
+        full = sc.render(rs, w, h)
+        aov_full = sc.render_aovs(rs, w, h, ["normal", "objectId", "nee", "bounces"])
+        for rank in range(world):
+            r0, r1, stride = interleaved_rows(h, world, rank)
+            part = sc.render(rs, w, h, rows=(r0, r1), row_stride=stride)
+            assert part.shape[0] == len(range(rank, h, world))
+            assert np.array_equal(part.view(np.uint32), full[rank::world].view(np.uint32)), rank
+        sc.set_option(gi.OPTION_POOL_SLOTS, 512)  # a pool much smaller than the share: slots walk many rows
+        part = sc.render(rs, w, h, rows=(1, h), row_stride=world)
+        assert np.array_equal(part, full[1::world])
+        aov_part = sc.render_aovs(rs, w, h, ["normal", "objectId", "nee", "bounces"], rows=(1, h), row_stride=world)
+        for k in ("normal", "objectId", "nee", "bounces", "color"):
+            assert np.array_equal(aov_part[k], aov_full[k][1::world]), k
+    finally:
+        sc.close()
+
+
+def test_interleaved_share_as_strided_device_tensor(gi):
+    """bench.py hands RCCL a zero-copy torch view of the library's device render buffer; for interleaved shares that view is
+    strided (rows rank::N).  Checks the view (what gather_rows packs and sends) against the host copy of the same render."""
+    if not _TORCH_CUDA:
+        pytest.skip("needs torch on a GPU")
+    desc = cornell_box()
+    rs = RenderSettings(spp=2, max_bounces=4, progressive_accumulation=False)
+    w, h, world, rank = 48, 29, 8, 3
+    sc = gi.Scene(desc)
+    try:
+        host = sc.render(rs, w, h, rows=(rank, h), row_stride=world)
+        ptr = sc.device_pointer(w, h)
+        n = len(range(rank, h, world))
+
+        class _Tile:
+            __cuda_array_interface__ = {"shape": (n, w, 4), "typestr": "<f4", "data": (ptr + rank * w * 16, False), "version": 2,
+                                        "strides": (world * w * 16, 16, 4)}
+        dev = torch.as_tensor(_Tile(), device="cuda:0")
+        pad = torch.zeros((-(-h // world), w, 4), dtype=dev.dtype, device=dev.device)
+        pad[:n] = dev  # the packing step of gather_rows
+        assert np.array_equal(pad[:n].cpu().numpy(), host)
+    finally:
+        sc.close()
 
 
 def test_pool_and_batch_invariance(gi, orc):
