@@ -8,8 +8,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libgatling_gi.so")
-SOURCES = ["gi_c.cpp", "bvh8.cpp", "gi_kernels.hip", "gtl_shim.cpp"]
-HEADERS = ["gi_types.h", "gi_kernels.h", "gi_device_math.h", "gi_queues.h", "gi_traversal.h", "gi_shading.h", "bvh8.h", os.path.join("..", "..", "include", "gi_c.h"),
+SOURCES = ["gi_c.cpp", "gi_image.cpp", "bvh8.cpp", "gi_kernels.hip", "gtl_shim.cpp"]
+HEADERS = ["gi_types.h", "gi_kernels.h", "gi_device_math.h", "gi_queues.h", "gi_traversal.h", "gi_shading.h", "gi_image.h", "bvh8.h", os.path.join("..", "..", "include", "gi_c.h"),
            os.path.join("..", "..", "include", "gtl", "gi", "Gi.h")]
 # -ffp-contract=off: arithmetic contract.  No fast-math: IEEE divide/sqrt are part of it.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall"]
@@ -25,7 +25,7 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or needs_build():
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        cmd = [hipcc] + FLAGS + ["-o", LIB] + SOURCES
+        cmd = [hipcc] + FLAGS + ["-o", LIB] + SOURCES + ["-lz"]  # zlib: PNG inflate (gi_image.cpp)
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=CSRC)

@@ -105,6 +105,8 @@ SYMBOLS = [
     ("giCSetDomeLightBaseEmission", None, [_P, _FP]), ("giCSetDomeLightDiffuseSpecular", None, [_P, _F, _F]),
     ("giCSetDomeLightTexture", None, [_P, _P]),
     ("giCCreateTexture", _P, [_P, C.POINTER(GiCTextureDesc)]), ("giCDestroyTexture", None, [_P]),
+    ("giCCreateTextureFromFile", _P, [_P, C.c_char_p, _I]),
+    ("giCDebugDecodeImage", C.c_int, [C.c_char_p, _I, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _FP, C.c_uint64]),
     ("giCSetMaterialTexture", C.c_int, [_P, _I, C.POINTER(GiCTextureBinding)]),
     ("giCSetMeshPrimvars", C.c_int, [_P, _U, C.POINTER(GiCPrimvarData)]), ("giCSetMeshInstancerPrimvars", C.c_int, [_P, _U, C.POINTER(GiCPrimvarData)]),
     ("giCSetMaterialPrimvarInput", C.c_int, [_P, _I, C.c_char_p]),

@@ -25,6 +25,7 @@
 
 #include "bvh8.h"
 #include "gi_kernels.h"
+#include "gi_image.h"
 #include "gi_types.h"
 
 using namespace gi;
@@ -398,6 +399,25 @@ GiCTexture* giCCreateTexture(GiCScene* scene, const GiCTextureDesc* desc)
   return t;
 }
 
+GiCTexture* giCCreateTextureFromFile(GiCScene* scene, const char* filePath, int32_t srgbToLinear)
+{
+  if (!scene || !filePath) { setError("giCCreateTextureFromFile: bad arguments"); return nullptr; }
+  uint32_t w = 0, h = 0; std::vector<float> px;
+  if (!loadImageFile(filePath, srgbToLinear != 0, w, h, px)) { setError("giCCreateTextureFromFile: cannot decode the file (.png, .hdr and .pfm are supported)"); return nullptr; }
+  GiCTextureDesc td{w, h, px.data()};
+  return giCCreateTexture(scene, &td);
+}
+
+int giCDebugDecodeImage(const char* filePath, int32_t srgbToLinear, uint32_t* width, uint32_t* height, float* rgba, uint64_t rgbaFloats)
+{
+  uint32_t w = 0, h = 0; std::vector<float> px;
+  if (!filePath || !loadImageFile(filePath, srgbToLinear != 0, w, h, px)) return 0;
+  if (width) *width = w;
+  if (height) *height = h;
+  if (rgba && rgbaFloats >= px.size()) memcpy(rgba, px.data(), px.size() * sizeof(float));
+  return 1;
+}
+
 void giCDestroyTexture(GiCTexture* tex)
 {
   if (!tex) return;
@@ -640,78 +660,18 @@ int giCSetMaterialPrimvarInput(GiCMaterial* mat, int32_t input, const char* name
   return GI_C_OK;
 }
 
-// Minimal decoders for dome-light images: Radiance .hdr (RGBE, flat or new-style RLE scanlines, -Y +X orientation) and
-// .pfm (PF, little or big endian, rows bottom-up).  Output: float RGBA, row 0 = first image row (top).
-static bool loadHdrOrPfm(const char* path, uint32_t& w, uint32_t& h, std::vector<float>& out)
-{
-  FILE* f = fopen(path, "rb");
-  if (!f) return false;
-  std::vector<uint8_t> d;
-  { uint8_t buf[65536]; size_t n; while ((n = fread(buf, 1, sizeof(buf), f)) > 0) d.insert(d.end(), buf, buf + n); }
-  fclose(f);
-  size_t pos = 0;
-  auto line = [&]() { std::string l; while (pos < d.size() && d[pos] != '\n') l.push_back((char)d[pos++]); if (pos < d.size()) pos++; return l; };
-  if (d.size() > 2 && d[0] == 'P' && d[1] == 'F') { // PFM
-    line();
-    int iw = 0, ih = 0; { std::string l = line(); if (sscanf(l.c_str(), "%d %d", &iw, &ih) != 2) { std::string l2 = line(); iw = atoi(l.c_str()); ih = atoi(l2.c_str()); } }
-    const float scale = (float)atof(line().c_str());
-    if (iw <= 0 || ih <= 0 || pos + (size_t)iw * ih * 12 > d.size()) return false;
-    w = (uint32_t)iw; h = (uint32_t)ih; out.assign((size_t)w * h * 4, 1.0f);
-    for (uint32_t y = 0; y < h; y++)
-      for (uint32_t x = 0; x < w; x++)
-        for (int c = 0; c < 3; c++) {
-          uint8_t b[4]; memcpy(b, &d[pos + (((size_t)y * w + x) * 3 + c) * 4], 4);
-          if (scale > 0.0f) std::swap(b[0], b[3]), std::swap(b[1], b[2]); // positive scale = big endian
-          float v; memcpy(&v, b, 4);
-          out[((size_t)(h - 1 - y) * w + x) * 4 + c] = v;
-        }
-    return true;
-  }
-  std::string first = line();
-  if (first.rfind("#?", 0) != 0) return false;
-  for (;;) { std::string l = line(); if (l.empty()) break; if (pos >= d.size()) return false; }
-  int ih = 0, iw = 0; { std::string l = line(); if (sscanf(l.c_str(), "-Y %d +X %d", &ih, &iw) != 2) return false; }
-  if (iw <= 0 || ih <= 0) return false;
-  w = (uint32_t)iw; h = (uint32_t)ih; out.assign((size_t)w * h * 4, 1.0f);
-  std::vector<uint8_t> scan((size_t)w * 4);
-  for (uint32_t y = 0; y < h; y++) {
-    if (pos + 4 <= d.size() && d[pos] == 2 && d[pos + 1] == 2 && (((uint32_t)d[pos + 2] << 8) | d[pos + 3]) == w && w >= 8 && w < 32768) {
-      pos += 4;
-      for (int c = 0; c < 4; c++) {
-        uint32_t x = 0;
-        while (x < w) {
-          if (pos >= d.size()) return false;
-          uint8_t n = d[pos++];
-          if (n > 128) { n -= 128; if (pos >= d.size() || x + n > w) return false; uint8_t v = d[pos++]; for (uint8_t k = 0; k < n; k++) scan[(size_t)(x++) * 4 + c] = v; }
-          else { if (n == 0 || pos + n > d.size() || x + n > w) return false; for (uint8_t k = 0; k < n; k++) scan[(size_t)(x++) * 4 + c] = d[pos++]; }
-        }
-      }
-    } else {
-      if (pos + (size_t)w * 4 > d.size()) return false;
-      memcpy(scan.data(), &d[pos], (size_t)w * 4); pos += (size_t)w * 4;
-    }
-    for (uint32_t x = 0; x < w; x++) {
-      const uint8_t* p4 = &scan[(size_t)x * 4];
-      const float sc = p4[3] ? ldexpf(1.0f, (int)p4[3] - 136) : 0.0f;
-      float* o = &out[((size_t)y * w + x) * 4];
-      o[0] = (float)p4[0] * sc; o[1] = (float)p4[1] * sc; o[2] = (float)p4[2] * sc;
-    }
-  }
-  return true;
-}
-
 GiCDomeLight* giCCreateDomeLight(GiCScene* scene, const char* filePath)
 {
   if (!scene) return nullptr;
   auto* l = new GiCDomeLight(); l->scene = scene; l->filePath = filePath ? filePath : "";
-  // the reference decodes the file through imgio (Gi.cpp:2215-2230); here: Radiance RGBE and PFM, anything else stays unloaded
+  // the reference decodes the file through imgio (Gi.cpp:2215-2230); here: Radiance RGBE, PFM and PNG, anything else stays unloaded
   uint32_t w = 0, h = 0; std::vector<float> px;
-  if (!l->filePath.empty() && loadHdrOrPfm(l->filePath.c_str(), w, h, px)) {
+  if (!l->filePath.empty() && loadImageFile(l->filePath.c_str(), /*srgbToLinear=*/false, w, h, px)) {
     GiCTextureDesc td{w, h, px.data()};
     l->texture = giCCreateTexture(scene, &td);
     l->ownsTexture = l->texture != nullptr;
   } else if (!l->filePath.empty()) {
-    fprintf(stderr, "[gatling_gi] unable to load dome light texture at '%s' (only .hdr / .pfm are decoded in-library)\n", l->filePath.c_str());
+    fprintf(stderr, "[gatling_gi] unable to load dome light texture at '%s' (.hdr, .pfm and .png are decoded in-library)\n", l->filePath.c_str());
   }
   return l;
 }

@@ -15,7 +15,7 @@ namespace gtl
 {
   struct GiScene { GiCScene* h; };
   struct GiMesh { GiCMesh* h; };
-  struct GiMaterial { GiCMaterial* h; };
+  struct GiMaterial { GiCMaterial* h; std::vector<GiCTexture*> textures; /* created from the document's image nodes, owned by the material */ };
   struct GiRenderBuffer { GiCRenderBuffer* h; };
   struct GiSphereLight { GiCSphereLight* h; };
   struct GiDistantLight { GiCDistantLight* h; };
@@ -99,6 +99,35 @@ namespace gtl
       return {};
     }
 
+    // The upstream node `nodeName`: its category and its constant inputs (name -> value)
+    bool readNode(const std::string& doc, const std::string& nodeName, MtlxNode& out)
+    {
+      const std::string key = "name=\"" + nodeName + "\"";
+      size_t p = 0;
+      while ((p = doc.find(key, p)) != std::string::npos) {
+        size_t lt = doc.rfind('<', p);
+        if (lt == std::string::npos) break;
+        size_t sp = doc.find_first_of(" \t\r\n>", lt);
+        const std::string cat = doc.substr(lt + 1, sp - lt - 1);
+        if (cat != "input" && cat != "output") {
+          out.category = cat;
+          size_t headEnd = doc.find('>', p);
+          if (headEnd == std::string::npos || doc[headEnd - 1] == '/') return true;
+          size_t close = doc.find("</" + cat, p), q = headEnd;
+          while ((q = doc.find("<input", q)) != std::string::npos && (close == std::string::npos || q < close)) {
+            size_t e = doc.find('>', q);
+            if (e == std::string::npos) break;
+            const std::string tag = doc.substr(q, e - q + 1), n = attr(tag, "name");
+            if (!n.empty()) out.inputs[n] = attr(tag, "value");
+            q = e;
+          }
+          return true;
+        }
+        p += key.size();
+      }
+      return false;
+    }
+
     int floats(const std::string& s, float* out, int maxN)
     {
       int n = 0; const char* p = s.c_str();
@@ -118,11 +147,42 @@ namespace gtl
       if (it != n.inputs.end()) floats(it->second, dst, count);
     }
 
-    bool descFromMtlx(const char* src, GiCMaterialDesc& d, std::string (&primvars)[GI_C_TEX_SLOT_COUNT])
+    // a material input fed by an image node (UsdUVTexture / image / tiledimage): file + UsdUVTexture's wrap, scale, bias, colour space
+    struct ImageInput { std::string file; int wrapS = GI_C_TEX_WRAP_REPEAT, wrapT = GI_C_TEX_WRAP_REPEAT, channel = 0; float scale[4] = {1, 1, 1, 1}, bias[4] = {0, 0, 0, 0}; bool srgb = false; };
+    int wrapMode(const std::string& v)
+    {
+      if (v == "clamp") return GI_C_TEX_WRAP_CLAMP;
+      if (v == "mirror") return GI_C_TEX_WRAP_MIRRORED_REPEAT;
+      if (v == "black") return GI_C_TEX_WRAP_CLIP;
+      return GI_C_TEX_WRAP_REPEAT; // "repeat", "useMetadata", unset
+    }
+
+    bool descFromMtlx(const char* src, GiCMaterialDesc& d, std::string (&primvars)[GI_C_TEX_SLOT_COUNT], ImageInput (&images)[GI_C_TEX_SLOT_COUNT])
     {
       MtlxNode n;
       if (!src || !findSurfaceNode(src, n)) return false;
-      auto bind = [&](const char* input, int slot) { auto it = n.connections.find(input); if (it != n.connections.end()) primvars[slot] = primvarOfNode(src, it->second); };
+      const std::string doc = src;
+      auto bind = [&](const char* input, int slot) {
+        auto it = n.connections.find(input);
+        if (it == n.connections.end()) return;
+        primvars[slot] = primvarOfNode(doc, it->second);
+        MtlxNode up;
+        if (!primvars[slot].empty() || !readNode(doc, it->second, up)) return;
+        if (up.category != "UsdUVTexture" && up.category != "image" && up.category != "tiledimage") return;
+        ImageInput& im = images[slot];
+        im.file = up.inputs["file"];
+        im.wrapS = wrapMode(up.inputs.count("wrapS") ? up.inputs["wrapS"] : up.inputs["uaddressmode"]);
+        im.wrapT = wrapMode(up.inputs.count("wrapT") ? up.inputs["wrapT"] : up.inputs["vaddressmode"]);
+        if (up.inputs.count("scale")) floats(up.inputs["scale"], im.scale, 4);
+        if (up.inputs.count("bias")) floats(up.inputs["bias"], im.bias, 4);
+        const bool colour = slot == GI_C_TEX_BASE_COLOR || slot == GI_C_TEX_EMISSION;
+        const std::string cs = up.inputs.count("sourceColorSpace") ? up.inputs["sourceColorSpace"] : "auto";
+        im.srgb = cs == "sRGB" || (cs == "auto" && colour); // UsdUVTexture: auto = sRGB for 8-bit colour data
+        // which output feeds a scalar input: <input ... nodename="tex" output="g"/>
+        const std::string needle = std::string("name=\"") + input + "\"";
+        size_t q = doc.find(needle);
+        if (q != std::string::npos) { size_t e = doc.find('>', q); const std::string tag = doc.substr(q, e - q); const std::string o = attr(tag + " ", "output"); im.channel = o == "g" ? 1 : o == "b" ? 2 : o == "a" ? 3 : 0; }
+      };
       memset(&d, 0, sizeof(d));
       float* p = d.p;
       if (n.category == "UsdPreviewSurface") {
@@ -135,6 +195,7 @@ namespace gtl
         setN(n, "clearcoat", p + GI_C_P_CLEARCOAT, 1); setN(n, "clearcoatRoughness", p + GI_C_P_CLEARCOAT_ROUGHNESS, 1);
         setN(n, "opacity", p + GI_C_P_OPACITY, 1); setN(n, "opacityThreshold", p + GI_C_P_OPACITY_THRESHOLD, 1); setN(n, "ior", p + GI_C_P_IOR, 1);
         bind("diffuseColor", GI_C_TEX_BASE_COLOR); bind("emissiveColor", GI_C_TEX_EMISSION); bind("roughness", GI_C_TEX_ROUGHNESS); bind("metallic", GI_C_TEX_METALLIC);
+        bind("normal", GI_C_TEX_NORMAL);
         return true;
       }
       d.klass = GI_C_MAT_OPEN_PBR; // defaults: src/gi/mtlx/open_pbr_surface.mtlx:11-92
@@ -156,6 +217,7 @@ namespace gtl
       setN(n, "emission_luminance", &lum, 1); setN(n, "emission_color", ecol, 3); setN(n, "geometry_opacity", p + GI_C_P_OPACITY, 1);
       for (int i = 0; i < 3; i++) p[GI_C_P_EMISSION + i] = lum * ecol[i];
       bind("base_color", GI_C_TEX_BASE_COLOR); bind("specular_roughness", GI_C_TEX_ROUGHNESS); bind("base_metalness", GI_C_TEX_METALLIC);
+      bind("geometry_normal", GI_C_TEX_NORMAL);
       return true;
     }
   }
@@ -170,16 +232,32 @@ namespace gtl
 
   GiMaterial* giCreateMaterialFromMtlxStr(GiScene* scene, const char* name, const char* mtlxSrc)
   {
-    GiCMaterialDesc d; std::string primvars[GI_C_TEX_SLOT_COUNT];
-    if (!scene || !descFromMtlx(mtlxSrc, d, primvars)) return nullptr;
+    GiCMaterialDesc d; std::string primvars[GI_C_TEX_SLOT_COUNT]; ImageInput images[GI_C_TEX_SLOT_COUNT];
+    if (!scene || !descFromMtlx(mtlxSrc, d, primvars, images)) return nullptr;
     GiCMaterial* h = giCCreateMaterial(scene->h, name, &d);
     if (!h) return nullptr;
-    for (int slot = 0; slot < GI_C_TEX_SLOT_COUNT; slot++) if (!primvars[slot].empty()) giCSetMaterialPrimvarInput(h, slot, primvars[slot].c_str());
-    return new GiMaterial{h};
+    auto* mat = new GiMaterial{h, {}};
+    for (int slot = 0; slot < GI_C_TEX_SLOT_COUNT; slot++) {
+      if (!primvars[slot].empty()) giCSetMaterialPrimvarInput(h, slot, primvars[slot].c_str());
+      const ImageInput& im = images[slot];
+      if (im.file.empty()) continue;
+      GiCTexture* t = giCCreateTextureFromFile(scene->h, im.file.c_str(), im.srgb ? 1 : 0); // .png / .hdr / .pfm; others: the input keeps its constant
+      if (!t) continue;
+      mat->textures.push_back(t);
+      GiCTextureBinding b{t, im.wrapS, im.wrapT, im.channel, {im.scale[0], im.scale[1], im.scale[2], im.scale[3]}, {im.bias[0], im.bias[1], im.bias[2], im.bias[3]}};
+      giCSetMaterialTexture(h, slot, &b);
+    }
+    return mat;
   }
   GiMaterial* giCreateMaterialFromMtlxDoc(GiScene*, const char*, const std::shared_ptr<void>) { return nullptr; }
   GiMaterial* giCreateMaterialFromMdlFile(GiScene*, const char*, const char*, const char*, const GiMaterialParameters&) { return nullptr; }
-  void giDestroyMaterial(GiMaterial* mat) { if (!mat) return; giCDestroyMaterial(mat->h); delete mat; }
+  void giDestroyMaterial(GiMaterial* mat)
+  {
+    if (!mat) return;
+    giCDestroyMaterial(mat->h);
+    for (GiCTexture* t : mat->textures) giCDestroyTexture(t);
+    delete mat;
+  }
 
   static void setPrimvars(GiCMesh* h, const std::vector<GiPrimvarData>& pv, bool instancer)
   {

@@ -191,6 +191,10 @@ typedef struct GiCMaterialDesc {
 typedef struct GiCTexture GiCTexture;
 typedef struct GiCTextureDesc { uint32_t width, height; const float* rgba; } GiCTextureDesc;
 GiCTexture* giCCreateTexture(GiCScene* scene, const GiCTextureDesc* desc);
+/* [ext] decodes .png (8/16-bit, non-interlaced; srgbToLinear applies the sRGB EOTF to 8-bit colour), .hdr or .pfm in-library */
+GiCTexture* giCCreateTextureFromFile(GiCScene* scene, const char* filePath, int32_t srgbToLinear);
+/* [ext] the decoder alone (no device needed; tests): returns 1 and fills width/height (+ rgba if it holds width*height*4 floats) */
+int giCDebugDecodeImage(const char* filePath, int32_t srgbToLinear, uint32_t* width, uint32_t* height, float* rgba, uint64_t rgbaFloats);
 void giCDestroyTexture(GiCTexture* texture);
 
 /* texturable inputs of the closed-form materials (UsdUVTexture semantics: value = texel * scale + bias at the hit's st) */
@@ -318,7 +322,7 @@ void giCSetDiskLightRadius(GiCDiskLight* light, float radiusX, float radiusY);
 void giCSetDiskLightDiffuseSpecular(GiCDiskLight* light, float diffuse, float specular);
 
 /* Gi.h:253-257.  The dome light is an equirectangular image looked up by miss rays (rp_main.miss:46-86).  filePath is
- * decoded when it is a Radiance .hdr (RGBE) or a .pfm; other formats need imgio (out of scope) -- hand the decoded pixels
+ * decoded when it is a Radiance .hdr (RGBE), a .pfm or a .png; other formats need imgio (out of scope) -- hand the decoded pixels
  * over with giCSetDomeLightTexture instead.  A dome light without an image is ignored, exactly like a dome light whose file
  * fails to load in the reference (Gi.cpp:2221-2230): miss rays then see the fallback dome (the colour clear value). */
 GiCDomeLight* giCCreateDomeLight(GiCScene* scene, const char* filePath);

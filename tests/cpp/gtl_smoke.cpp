@@ -3,7 +3,9 @@
 #include <gtl/gi/Gi.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 using namespace gtl;
@@ -55,6 +57,16 @@ int main()
   const float green[3] = {0.1f, 0.8f, 0.1f};
   GiMesh* a = quad(scene, 0.0f, 2.0f, floorMat, 1, green);
   GiMesh* b = quad(scene, 1.5f, 0.4f, lampMat, 2);
+  // optional third quad whose diffuseColor is an image file (UsdUVTexture node -> giCCreateTextureFromFile inside the shim)
+  GiMaterial* texMat = nullptr; GiMesh* c = nullptr;
+  if (const char* png = getenv("GTL_SMOKE_PNG")) {
+    const std::string texMtlx = std::string("<materialx version=\"1.38\"><UsdUVTexture name=\"img\" type=\"multioutput\"><input name=\"file\" type=\"filename\" value=\"") + png +
+                                "\" /><input name=\"wrapS\" type=\"string\" value=\"repeat\" /></UsdUVTexture><UsdPreviewSurface name=\"T\" type=\"surfaceshader\">"
+                                "<input name=\"diffuseColor\" type=\"color3\" nodename=\"img\" output=\"rgb\" /></UsdPreviewSurface></materialx>";
+    texMat = giCreateMaterialFromMtlxStr(scene, "textured", texMtlx.c_str());
+    if (!texMat) { fprintf(stderr, "textured material not created\n"); return 8; }
+    c = quad(scene, 0.5f, 0.6f, texMat, 3);
+  }
   GiRenderBuffer* rb = giCreateRenderBuffer(32, 18, GiRenderBufferFormat::Float32Vec4);
   GiRenderParams rp{};
   GiAovBinding bind{GiAovId::Color, {0}, rb};
@@ -67,12 +79,15 @@ int main()
   rp.scene = scene;
   if (giRender(rp) != GiStatus::Ok) { fprintf(stderr, "giRender failed\n"); return 4; }
   const float* px = (const float*)giGetRenderBufferMem(rb);
-  double sum = 0, red = 0, grn = 0; int lit = 0;
-  for (int i = 0; i < 32 * 18; i++) { sum += px[4 * i] + px[4 * i + 1] + px[4 * i + 2]; red += px[4 * i]; grn += px[4 * i + 1]; lit += px[4 * i + 1] > 0.11f; if (px[4 * i + 3] != 1.0f) return 5; }
+  double sum = 0, red = 0, grn = 0, blu = 0; int lit = 0, bluish = 0;
+  for (int i = 0; i < 32 * 18; i++) { sum += px[4 * i] + px[4 * i + 1] + px[4 * i + 2]; red += px[4 * i]; grn += px[4 * i + 1]; blu += px[4 * i + 2]; bluish += px[4 * i + 2] > 2.0f * px[4 * i] && px[4 * i + 2] > 2.0f * px[4 * i + 1]; lit += px[4 * i + 1] > 0.11f; if (px[4 * i + 3] != 1.0f) return 5; }
   // the lamp is reddish (1, .9, .8): without the green primvar the image is red-heavy
   if (!(grn > 1.05 * red)) { fprintf(stderr, "displayColor primvar not applied (r=%f g=%f)\n", red, grn); return 7; }
-  printf("gtl_smoke ok sum=%.6f lit=%d\n", sum, lit);
-  giDestroyMesh(a); giDestroyMesh(b); giDestroyMaterial(floorMat); giDestroyMaterial(lampMat);
+  if (c && bluish < 5) { fprintf(stderr, "image-driven diffuseColor not applied (bluish pixels: %d)\n", bluish); return 9; }
+  (void)blu;
+  printf("gtl_smoke ok sum=%.6f lit=%d bluish=%d\n", sum, lit, bluish);
+  giDestroyMesh(a); giDestroyMesh(b); if (c) giDestroyMesh(c);
+  giDestroyMaterial(floorMat); giDestroyMaterial(lampMat); if (texMat) giDestroyMaterial(texMat);
   giDestroyRenderBuffer(rb); giDestroyScene(scene); giTerminate();
   return (lit >= 10 && sum > 10.0) ? 0 : 6;
 }

@@ -29,8 +29,14 @@ def test_cpp_client_compiles_and_links():
 
 
 @pytest.mark.gpu
-def test_cpp_client_renders(gi):
+def test_cpp_client_renders(gi, tmp_path):
     exe = _build()
-    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    # a solid blue 8-bit PNG for the client's UsdUVTexture-driven material (decoded in-library, sRGB -> linear)
+    import numpy as np
+    from test_capi_host import _write_png
+    blue = np.zeros((4, 4, 3), np.uint8); blue[..., 2] = 255
+    _write_png(tmp_path / "blue.png", blue, 2, 8, [0, 1])
+    env = dict(os.environ, GTL_SMOKE_PNG=str(tmp_path / "blue.png"))
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "gtl_smoke ok" in out.stdout
