@@ -203,7 +203,7 @@ void deriveMaterialConstants(MaterialRec& m)
 // ---------------------------------------------------------------------------------------------------------------
 enum DirtyFlags : uint32_t { DIRTY_BVH = 1u, DIRTY_FRAMEBUFFER = 2u, DIRTY_LIGHTS = 4u, DIRTY_MATERIALS = 8u, DIRTY_ALL = 0xfu };
 
-struct GiCTexture { GiCScene* scene; uint32_t width, height; std::vector<float> rgba; };
+struct GiCTexture { GiCScene* scene; uint32_t width, height; std::vector<float> rgba; std::string cacheKey; uint32_t refs = 1; };
 struct GiCPrimvar { std::string name; int32_t type, interpolation; std::vector<float> data; };
 struct GiCMaterial { GiCScene* scene; std::string name; GiCMaterialDesc desc; GiCTextureBinding tex[GI_C_TEX_SLOT_COUNT] = {}; std::string primvarInput[GI_C_TEX_SLOT_COUNT]; };
 
@@ -399,13 +399,22 @@ GiCTexture* giCCreateTexture(GiCScene* scene, const GiCTextureDesc* desc)
   return t;
 }
 
+// File textures are shared: a path that is already loaded (and still alive) yields the same texture with one more reference,
+// as GiTextureManager's weak-pointer cache does (TextureManager.cpp:100-150); giCDestroyTexture drops one reference.
 GiCTexture* giCCreateTextureFromFile(GiCScene* scene, const char* filePath, int32_t srgbToLinear)
 {
   if (!scene || !filePath) { setError("giCCreateTextureFromFile: bad arguments"); return nullptr; }
+  const std::string key = std::string(srgbToLinear ? "s:" : "l:") + filePath;
+  {
+    std::lock_guard<std::mutex> g(scene->mutex);
+    for (GiCTexture* t : scene->textures) if (t->cacheKey == key) { t->refs++; return t; }
+  }
   uint32_t w = 0, h = 0; std::vector<float> px;
   if (!loadImageFile(filePath, srgbToLinear != 0, w, h, px)) { setError("giCCreateTextureFromFile: cannot decode the file (.png, .hdr and .pfm are supported)"); return nullptr; }
   GiCTextureDesc td{w, h, px.data()};
-  return giCCreateTexture(scene, &td);
+  GiCTexture* t = giCCreateTexture(scene, &td);
+  if (t) { std::lock_guard<std::mutex> g(scene->mutex); t->cacheKey = key; }
+  return t;
 }
 
 int giCDebugDecodeImage(const char* filePath, int32_t srgbToLinear, uint32_t* width, uint32_t* height, float* rgba, uint64_t rgbaFloats)
@@ -424,6 +433,7 @@ void giCDestroyTexture(GiCTexture* tex)
   GiCScene* s = tex->scene;
   {
     std::lock_guard<std::mutex> g(s->mutex);
+    if (--tex->refs != 0u) return; // shared file texture still in use
     s->textures.erase(std::remove(s->textures.begin(), s->textures.end(), tex), s->textures.end());
     for (GiCMaterial* m : s->materials) for (auto& b : m->tex) if (b.texture == tex) b.texture = nullptr;
     s->dirty |= DIRTY_MATERIALS | DIRTY_BVH | DIRTY_FRAMEBUFFER;

@@ -191,7 +191,9 @@ typedef struct GiCMaterialDesc {
 typedef struct GiCTexture GiCTexture;
 typedef struct GiCTextureDesc { uint32_t width, height; const float* rgba; } GiCTextureDesc;
 GiCTexture* giCCreateTexture(GiCScene* scene, const GiCTextureDesc* desc);
-/* [ext] decodes .png (8/16-bit, non-interlaced; srgbToLinear applies the sRGB EOTF to 8-bit colour), .hdr or .pfm in-library */
+/* [ext] decodes .png (8/16-bit, non-interlaced; srgbToLinear applies the sRGB EOTF to 8-bit colour), .hdr or .pfm in-library;
+ * a (path, srgbToLinear) pair that is already loaded and alive returns the SAME handle with one more reference (the file cache of
+ * TextureManager.cpp:100-150); giCDestroyTexture releases one reference */
 GiCTexture* giCCreateTextureFromFile(GiCScene* scene, const char* filePath, int32_t srgbToLinear);
 /* [ext] the decoder alone (no device needed; tests): returns 1 and fills width/height (+ rgba if it holds width*height*4 floats) */
 int giCDebugDecodeImage(const char* filePath, int32_t srgbToLinear, uint32_t* width, uint32_t* height, float* rgba, uint64_t rgbaFloats);

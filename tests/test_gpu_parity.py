@@ -486,6 +486,27 @@ def test_dome_light_image_file(gi, orc, tmp_path):
     assert np.array_equal(fallback[..., :3], np.broadcast_to(q.astype(np.float32), fallback[..., :3].shape))
 
 
+def test_file_textures_are_shared_by_path(gi, tmp_path):
+    """giCCreateTextureFromFile hands out ONE texture per (path, colour space) while it is alive -- the reference's weak-pointer
+    file cache (TextureManager.cpp:100-150) -- and giCDestroyTexture releases one reference at a time."""
+    from gatling_amd.scene import SceneDesc
+    from test_capi_host import _write_png
+    img = np.full((2, 2, 3), 128, np.uint8)
+    _write_png(tmp_path / "a.png", img, 2, 8, [0, 1])
+    sc = gi.Scene(SceneDesc())
+    try:
+        L, path = sc.L, str(tmp_path / "a.png").encode()
+        t1 = L.giCCreateTextureFromFile(sc.handle, path, 1)
+        t2 = L.giCCreateTextureFromFile(sc.handle, path, 1)
+        t3 = L.giCCreateTextureFromFile(sc.handle, path, 0)  # other colour space: other pixels
+        assert t1 and t1 == t2 and t3 and t3 != t1
+        L.giCDestroyTexture(t1)                      # one of two references
+        assert L.giCCreateTextureFromFile(sc.handle, path, 1) == t2
+        L.giCDestroyTexture(t2); L.giCDestroyTexture(t2); L.giCDestroyTexture(t3)  # last references: freed
+    finally:
+        sc.close()
+
+
 @pytest.mark.parametrize("stack,nee", [(1, True), (2, True), (2, False), (4, True)])
 def test_volume_medium_stack_parity(gi, orc, stack, nee):
     """Participating media with a medium stack (rp_main.rgen:48-97, 317-346, 462-477; rp_main.miss:16-34; rp_main.chit:160-186,
