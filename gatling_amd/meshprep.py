@@ -83,7 +83,7 @@ def bake_vertices(points, normals, texcoords=None):
 
 
 def build_mesh_arrays(points, face_vertex_counts, face_vertex_indices, normals=None,
-                      normals_interpolation="vertex", left_handed=False):
+                      normals_interpolation="vertex", left_handed=False, texcoords=None):
     """Returns (vertices VERTEX_DTYPE[N], faces uint32[T,3]) the way hdGatling would hand them to giCreateMesh."""
     points = np.asarray(points, np.float32).reshape(-1, 3)
     tris, fvs = fan_triangulate(face_vertex_counts, face_vertex_indices, left_handed)
@@ -93,7 +93,8 @@ def build_mesh_arrays(points, face_vertex_counts, face_vertex_indices, normals=N
         pts = points[tris.reshape(-1).astype(np.int64)]
         nrm = normals[fvs.reshape(-1)]
         faces = np.arange(len(pts), dtype=np.uint32).reshape(-1, 3)
-        return bake_vertices(pts, nrm), faces
+        uv = np.asarray(texcoords, np.float32).reshape(-1, 2)[tris.reshape(-1).astype(np.int64)] if texcoords is not None else None
+        return bake_vertices(pts, nrm, uv), faces
     if normals is None:
         normals = smooth_normals(points, tris)
-    return bake_vertices(points, np.asarray(normals, np.float32).reshape(-1, 3)), tris.astype(np.uint32)
+    return bake_vertices(points, np.asarray(normals, np.float32).reshape(-1, 3), texcoords), tris.astype(np.uint32)

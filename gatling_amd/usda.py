@@ -10,6 +10,7 @@ The derivations that hdGatling performs between USD and the gi boundary are rest
 from __future__ import annotations
 
 import math
+import os
 import re
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
@@ -23,6 +24,7 @@ _TOKEN = re.compile(r"""
     \s+ | \#[^\n]* |
     (?P<str>"(?:[^"\\]|\\.)*") |
     (?P<path><[^>]*>) |
+    (?P<asset>@[^@]*@) |
     (?P<num>[-+]?(?:\d+\.?\d*(?:[eE][-+]?\d+)?|\.\d+(?:[eE][-+]?\d+)?)) |
     (?P<id>[A-Za-z_][A-Za-z0-9_:.\[\]]*) |
     (?P<p>[(){}\[\]=,])
@@ -51,6 +53,7 @@ class Prim:
     attrs: Dict[str, object] = field(default_factory=dict)
     attr_meta: Dict[str, dict] = field(default_factory=dict)
     children: List["Prim"] = field(default_factory=list)
+    specifier: str = "def"
 
 
 class _Parser:
@@ -83,6 +86,8 @@ class _Parser:
             return v[1:-1]
         if k == "path":
             return ("path", v[1:-1])
+        if k == "asset":
+            return ("asset", v[1:-1])
         return v  # identifier / token
 
     def seq(self, o, c):
@@ -134,14 +139,14 @@ class _Parser:
         self.expect("}")
 
     def prim(self, parent_path):
-        self.next()  # def
+        spec = self.next()[1]  # def / over / class
         k, v = self.next()
         typ = ""
         if k == "id":
             typ = v
             k, v = self.next()
         name = v[1:-1]
-        p = Prim(typ, name, f"{parent_path}/{name}")
+        p = Prim(typ, name, f"{parent_path}/{name}", specifier=spec)
         if self.peek()[1] == "(":
             p.meta = self.metadata()
         self.prim_body(p)
@@ -188,52 +193,184 @@ def camera_from_prim(prim: Prim, world: np.ndarray) -> CameraDesc:
 
 
 def _material_from_prim(prim: Prim, klass: int) -> MaterialDesc:
-    shader = next((c for c in prim.children if c.type == "Shader" and c.attrs.get("info:id") == "UsdPreviewSurface"), None)
-    kw = {}
+    """UsdPreviewSurface / open_pbr_surface constant inputs; inputs connected to a UsdPrimvarReader become primvar bindings.
+    ``custom int gatling:materialClass`` (written by usda_writer) overrides the class chosen by the caller."""
+    from .usda_writer import OPEN_PBR_ID, OPEN_PBR_INPUTS, SLOT_INPUTS
+    from .scene import MAT_OPEN_PBR, P_EMISSION
+    if prim.attrs.get("gatling:materialClass") is not None:
+        klass = int(prim.attrs["gatling:materialClass"])
+    shaders = {c.name: c for c in prim.children if c.type == "Shader"}
+    opbr = next((c for c in shaders.values() if c.attrs.get("info:id") == OPEN_PBR_ID), None)
+    shader = opbr or next((c for c in shaders.values() if c.attrs.get("info:id") == "UsdPreviewSurface"), None)
+    if opbr is not None:
+        m = MaterialDesc.open_pbr(name=prim.path)
+        a = opbr.attrs
+        for key, idx, comps in OPEN_PBR_INPUTS:
+            v = a.get(f"inputs:{key}")
+            if v is not None:
+                m.params[idx:idx + max(comps, 1)] = v
+        lum = a.get("inputs:emission_luminance")
+        col = a.get("inputs:emission_color")
+        m.params[P_EMISSION:P_EMISSION + 3] = np.float32(0.0 if lum is None else lum) * np.asarray([1, 1, 1] if col is None else col, np.float32)
+        m.klass = MAT_OPEN_PBR
+    else:
+        kw = {}
+        if shader is not None:
+            for key in ("diffuseColor", "emissiveColor", "specularColor"):
+                if shader.attrs.get(f"inputs:{key}") is not None:
+                    kw[key] = tuple(float(x) for x in shader.attrs[f"inputs:{key}"])
+            for key in ("useSpecularWorkflow", "metallic", "roughness", "clearcoat", "clearcoatRoughness", "opacity",
+                        "opacityThreshold", "ior"):
+                if shader.attrs.get(f"inputs:{key}") is not None:
+                    kw[key] = float(shader.attrs[f"inputs:{key}"])
+        m = MaterialDesc.usd_preview_surface(name=prim.path, klass=klass, **kw)
     if shader is not None:
-        for key in ("diffuseColor", "emissiveColor", "specularColor"):
-            if shader.attrs.get(f"inputs:{key}") is not None:
-                kw[key] = tuple(float(x) for x in shader.attrs[f"inputs:{key}"])
-        for key in ("useSpecularWorkflow", "metallic", "roughness", "clearcoat", "clearcoatRoughness", "opacity",
-                    "opacityThreshold", "ior"):
-            if shader.attrs.get(f"inputs:{key}") is not None:
-                kw[key] = float(shader.attrs[f"inputs:{key}"])
-    return MaterialDesc.usd_preview_surface(name=prim.path, klass=klass, **kw)
+        for slot, (ups, opbr_name, _rtype, _vtype) in SLOT_INPUTS.items():
+            conn = shader.attrs.get(f"inputs:{opbr_name if opbr is not None else ups}.connect")
+            if isinstance(conn, tuple) and conn[0] == "path":
+                reader = shaders.get(conn[1].split(".")[0].split("/")[-1])
+                if reader is not None and str(reader.attrs.get("info:id", "")).startswith("UsdPrimvarReader"):
+                    m.primvar_inputs[slot] = reader.attrs.get("inputs:varname")
+    return m
+
+
+def _quat_from_rows(m) -> tuple:
+    """Rotation quaternion (x, y, z, w) of a row-vector rotation matrix (GfMatrix4d::ExtractRotationQuat)."""
+    r = np.asarray(m, np.float64)[:3, :3].T  # column-vector form
+    w = math.sqrt(max(0.0, 1.0 + r[0, 0] + r[1, 1] + r[2, 2])) * 0.5
+    if w > 1e-6:
+        return ((r[2, 1] - r[1, 2]) / (4 * w), (r[0, 2] - r[2, 0]) / (4 * w), (r[1, 0] - r[0, 1]) / (4 * w), w)
+    k = int(np.argmax([r[0, 0], r[1, 1], r[2, 2]]))
+    i, j = (k + 1) % 3, (k + 2) % 3
+    q = [0.0, 0.0, 0.0, 0.0]
+    q[k] = math.sqrt(max(0.0, 1.0 + r[k, k] - r[i, i] - r[j, j])) * 0.5
+    q[i] = (r[i, k] + r[k, i]) / (4 * q[k]); q[j] = (r[j, k] + r[k, j]) / (4 * q[k]); q[3] = (r[j, i] - r[i, j]) / (4 * q[k])
+    return tuple(q)
+
+
+def _light_from_prim(scene: SceneDesc, prim: Prim, world: np.ndarray, base_dir: str):
+    """hdGatling's light sync (light.cpp:58-94 base emission; :110-135 sphere, :150-180 distant, :216-262 rect, :279-320 disk,
+    :336-400 dome), without colour temperature."""
+    from .scene import DiskLight, DistantLight, DomeLight, RectLight, SphereLight
+    a = prim.attrs
+    w = world.astype(np.float32).astype(np.float64)
+    tdir = lambda v: np.asarray(v, np.float64) @ w[:3, :3]
+    origin = tuple(np.float32(w[3, :3]))
+    intensity = float(a.get("inputs:intensity", 1.0) or 0.0) * 2.0 ** float(a.get("inputs:exposure", 0.0) or 0.0)
+    color = np.asarray(a.get("inputs:color") or (1, 1, 1), np.float32)
+    normalize = bool(float(a.get("inputs:normalize", 0) or 0))
+    diffuse, specular = float(a.get("inputs:diffuse", 1.0)), float(a.get("inputs:specular", 1.0))
+    em = lambda factor: tuple(color * np.float32(intensity / (factor if (normalize and factor > 0) else 1.0)))
+    unit = lambda v: tuple(np.float32(v / np.linalg.norm(v)))
+    if prim.type == "SphereLight":
+        r = float(a.get("inputs:radius", 0.5))
+        rx, ry, rz = tdir((r, 0, 0))[0], tdir((0, r, 0))[1], tdir((0, 0, r))[2]
+        area = (((rx * ry) ** 1.6 + (rx * rz) ** 1.6 + (ry * rz) ** 1.6) / 3.0) ** (1 / 1.6) * 4.0 * math.pi
+        scene.sphere_lights.append(SphereLight(origin, em(area), (float(rx), float(ry), float(rz)), diffuse, specular))
+    elif prim.type == "DistantLight":
+        angle = math.radians(float(a.get("inputs:angle", 0.53)))
+        nm = np.linalg.inv(w[:3, :3]).T
+        d = np.asarray((0.0, 0.0, -1.0)) @ nm
+        s = math.sin(angle * 0.5)
+        scene.distant_lights.append(DistantLight(unit(d), em(s * s * math.pi if s > 1e-6 else 0.0), angle, diffuse, specular))
+    elif prim.type in ("RectLight", "DiskLight"):
+        t0, t1 = unit(tdir((1, 0, 0))), unit(tdir((0, 1, 0)))
+        if prim.type == "RectLight":
+            wd = tdir((float(a.get("inputs:width", 1.0)), 0, 0))[0]
+            ht = tdir((0, float(a.get("inputs:height", 1.0)), 0))[1]
+            scene.rect_lights.append(RectLight(origin, t0, t1, em(wd * ht), float(wd), float(ht), diffuse, specular))
+        else:
+            r = float(a.get("inputs:radius", 0.5))
+            rx, ry = tdir((r, 0, 0))[0], tdir((0, r, 0))[1]
+            scene.disk_lights.append(DiskLight(origin, t0, t1, em(rx * ry * math.pi), float(rx), float(ry), diffuse, specular))
+    elif prim.type == "DomeLight":
+        tex = -1
+        f = a.get("inputs:texture:file")
+        if isinstance(f, tuple) and f[0] == "asset":
+            from .imageio import read_hdr
+            px = read_hdr(os.path.join(base_dir, f[1]))
+            if px is not None:
+                tex = len(scene.textures)
+                scene.textures.append(px)
+        q = _quat_from_rows(w)
+        scene.dome_light = DomeLight(tex, (float(q[0]), float(q[1]), float(q[2]), float(-q[3])), em(0.0), diffuse, specular)
+
+
+_PRIMVAR_TYPES = {"float": 0, "float2": 1, "float3": 2, "float4": 3, "color3f": 2, "texCoord2f": 1, "normal3f": 2, "vector3f": 2, "point3f": 2}
+_PRIMVAR_INTERP = {"constant": 0, "uniform": 2, "vertex": 3, "varying": 3}
 
 
 def load_usda(path: str, material_class: int = MAT_USD_PREVIEW_SURFACE) -> SceneDesc:
     """Builds the SceneDesc that hdGatling would feed through the gi boundary for this stage."""
+    from .scene import Primvar
     with open(path, "r") as f:
         root = parse_usda(f.read())
+    base_dir = os.path.dirname(os.path.abspath(path))
     scene = SceneDesc()
     materials: Dict[str, int] = {}
-    pending = []
+    pending = []          # (mesh prim, prototype-to-world, [instance transforms] or None)
+    prototypes = {}       # class prim path -> [(mesh prim, local transform inside the prototype)]
+    instances = {}        # class prim path -> [instance world transforms], in stage order
+    order = []            # first-use order of prototypes among the pending meshes
     camera = [None]
 
+    def collect_proto(prim: Prim, local: np.ndarray, out: list):
+        m = local
+        if prim.attrs.get("xformOp:transform") is not None:
+            m = _matrix(prim.attrs["xformOp:transform"]) @ local
+        if prim.type == "Mesh":
+            out.append((prim, m))
+        for c in prim.children:
+            collect_proto(c, m, out)
+
     def walk(prim: Prim, world: np.ndarray):
+        if prim.specifier == "class":
+            lst = []
+            for c in prim.children:
+                collect_proto(c, np.eye(4), lst)
+            prototypes[prim.path] = lst
+            return
         local = world
         if "xformOp:transform" in prim.attrs and prim.attrs["xformOp:transform"] is not None:
             local = _matrix(prim.attrs["xformOp:transform"]) @ world  # row vectors: p * M_child * M_parent
+        inh = prim.meta.get("inherits")
+        if isinstance(inh, tuple) and inh[0] == "path":  # an instance of a class prototype (native instancing)
+            if inh[1] not in instances:
+                instances[inh[1]] = []
+                order.append(("proto", inh[1]))
+            instances[inh[1]].append(local)
+            return
         if prim.type == "Material":
             materials[prim.path] = len(scene.materials)
             scene.materials.append(_material_from_prim(prim, material_class))
         elif prim.type == "Camera" and camera[0] is None:
             camera[0] = camera_from_prim(prim, local)
         elif prim.type == "Mesh":
+            order.append(("mesh", len(pending)))
             pending.append((prim, local))
+        elif prim.type in ("SphereLight", "DistantLight", "RectLight", "DiskLight", "DomeLight"):
+            _light_from_prim(scene, prim, local, base_dir)
         for c in prim.children:
             walk(c, local)
 
     walk(root, np.eye(4))
     if camera[0] is not None:
         scene.camera = camera[0]
-    for mesh_id, (prim, world) in enumerate(pending):
+    todo = []
+    for kind, key in order:
+        if kind == "mesh":
+            todo.append((pending[key][0], pending[key][1], None))
+        else:
+            for prim, local in prototypes.get(key, []):
+                todo.append((prim, local, instances[key]))
+    for mesh_id, (prim, world, inst) in enumerate(todo):
         a = prim.attrs
         nrm = a.get("normals")
         interp = prim.attr_meta.get("normals", {}).get("interpolation", "vertex")
         left = a.get("orientation", "rightHanded") == "leftHanded"
+        st = a.get("primvars:st") if prim.attr_meta.get("primvars:st", {}).get("interpolation", "vertex") == "vertex" else None
         verts, faces = build_mesh_arrays(a["points"], a["faceVertexCounts"], a["faceVertexIndices"],
-                                         normals=nrm, normals_interpolation=interp, left_handed=left)
+                                         normals=nrm, normals_interpolation=interp, left_handed=left, texcoords=st)
         binding = a.get("material:binding")
         mat = materials.get(binding[1], -1) if isinstance(binding, tuple) else -1
         if mat < 0:
@@ -241,7 +378,18 @@ def load_usda(path: str, material_class: int = MAT_USD_PREVIEW_SURFACE) -> Scene
                 materials["__default__"] = len(scene.materials)
                 scene.materials.append(MaterialDesc.usd_preview_surface(name="__default__", klass=material_class))
             mat = materials["__default__"]
-        scene.meshes.append(MeshDesc(name=prim.path, vertices=verts, faces=faces, material=mat, id=mesh_id,
-                                     double_sided=bool(float(a.get("doubleSided", 0) or 0)), left_handed=left,
-                                     transform=world.astype(np.float32)))
+        primvars = []
+        for key, val in a.items():
+            if key.startswith("primvars:") and key != "primvars:st" and val is not None:
+                meta = prim.attr_meta.get(key, {})
+                data = np.asarray(val, np.float32)
+                ptype = data.shape[1] - 1 if data.ndim == 2 else 0
+                primvars.append(Primvar(key[len("primvars:"):], ptype, _PRIMVAR_INTERP.get(meta.get("interpolation", "constant"), 0), data))
+        mesh = MeshDesc(name=prim.path, vertices=verts, faces=faces, material=mat, id=mesh_id,
+                        double_sided=bool(float(a.get("doubleSided", 0) or 0)), left_handed=left,
+                        visible=a.get("visibility", "inherited") != "invisible", transform=world.astype(np.float32), primvars=primvars)
+        if inst is not None:
+            mesh.instance_transforms = np.stack(inst).astype(np.float32)
+            mesh.instance_ids = np.arange(len(inst), dtype=np.int32)
+        scene.meshes.append(mesh)
     return scene
