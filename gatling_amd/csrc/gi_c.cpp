@@ -663,7 +663,7 @@ int giCSetMeshPrimvars(GiCMesh* mesh, uint32_t count, const GiCPrimvarData* pv) 
 int giCSetMeshInstancerPrimvars(GiCMesh* mesh, uint32_t count, const GiCPrimvarData* pv) { return mesh ? setPrimvars(mesh, mesh->instancerPrimvars, count, pv) : (setError("giCSetMeshInstancerPrimvars: null mesh"), GI_C_ERROR); }
 int giCSetMaterialPrimvarInput(GiCMaterial* mat, int32_t input, const char* name)
 {
-  if (!mat || input < 0 || input >= GI_C_TEX_SLOT_COUNT || input == GI_C_TEX_NORMAL) { setError("giCSetMaterialPrimvarInput: bad arguments"); return GI_C_ERROR; }
+  if (!mat || input < 0 || input >= GI_C_TEX_SLOT_COUNT || input == GI_C_TEX_NORMAL || input == GI_C_TEX_OPACITY) { setError("giCSetMaterialPrimvarInput: bad arguments"); return GI_C_ERROR; }
   std::lock_guard<std::mutex> g(mat->scene->mutex);
   mat->primvarInput[input] = name ? name : "";
   mat->scene->dirty |= DIRTY_MATERIALS | DIRTY_BVH | DIRTY_FRAMEBUFFER;
@@ -806,7 +806,7 @@ int buildScene(GiCScene* s)
   std::vector<FVertex> verts; std::vector<InstanceRec> instances; std::vector<TriRec> tris; std::vector<int32_t> faceIdOf;
   std::vector<MaterialRec> mats(s->materials.size());
   for (size_t i = 0; i < s->materials.size(); i++) {
-    mats[i].klass = s->materials[i]->desc.klass; mats[i].flags = s->materials[i]->desc.flags & ~MAT_FLAG_TEXTURED;
+    mats[i].klass = s->materials[i]->desc.klass; mats[i].flags = s->materials[i]->desc.flags & ~(MAT_FLAG_TEXTURED | MAT_FLAG_OPACITY_TEX);
     for (uint32_t slot = 0; slot < TEX_SLOT_COUNT; slot++) {
       const GiCTextureBinding& b = s->materials[i]->tex[slot];
       TexBindingRec& r = mats[i].tex[slot];
@@ -819,7 +819,7 @@ int buildScene(GiCScene* s)
       r.tex = (uint32_t)(tit - s->textures.begin()) + 1u;
       r.mode = (uint32_t)b.wrapS | ((uint32_t)b.wrapT << 8) | (((uint32_t)b.channel & 3u) << 16);
       memcpy(r.scale, b.scale, 16); memcpy(r.bias, b.bias, 16);
-      mats[i].flags |= MAT_FLAG_TEXTURED;
+      mats[i].flags |= slot == TEX_OPACITY ? MAT_FLAG_OPACITY_TEX : MAT_FLAG_TEXTURED; // opacity is looked up by the any-hit test, not by k_shade
     }
     memcpy(mats[i].p, s->materials[i]->desc.p, sizeof(float) * MAT_PARAM_COUNT);
     deriveMaterialConstants(mats[i]);
@@ -834,7 +834,7 @@ int buildScene(GiCScene* s)
     if (mit == s->materials.end()) { fprintf(stderr, "[gatling_gi] invalid BLAS material for mesh %s\n", m->name.c_str()); continue; } // Gi.cpp:818-822
     const uint32_t material = (uint32_t)(mit - s->materials.begin());
     if (material > 0x00ffffffu) { setError("too many materials"); return GI_C_ERROR; }
-    const bool cutoutMat = mats[material].p[MP_CUTOUT] < 1.0f;
+    const bool cutoutMat = mats[material].p[MP_CUTOUT] < 1.0f || (mats[material].flags & MAT_FLAG_OPACITY_TEX) != 0u;
     if (cutoutMat) s->hasCutouts = true;
     const uint32_t matFlags = material | ((mats[material].klass & 0xfu) << 24) | (cutoutMat ? (1u << 28) : 0u) | (((m->flipFacing ? 1u : 0u) | (m->doubleSided ? 2u : 0u)) << 30);
     s->classMask |= 1u << (mats[material].klass & 0xfu);
@@ -1445,7 +1445,7 @@ extern "C" int giCDebugEvalBsdf(const GiCMaterialDesc* desc, uint32_t count, con
 {
   if (!g_ctx.initialized || !desc || (count && (!in || !out))) { setError("giCDebugEvalBsdf: bad arguments"); return GI_C_ERROR; }
   if (count == 0) return GI_C_OK;
-  MaterialRec m{}; m.klass = desc->klass; m.flags = desc->flags & ~MAT_FLAG_TEXTURED; memcpy(m.p, desc->p, sizeof(m.p));
+  MaterialRec m{}; m.klass = desc->klass; m.flags = desc->flags & ~(MAT_FLAG_TEXTURED | MAT_FLAG_OPACITY_TEX); memcpy(m.p, desc->p, sizeof(m.p));
   deriveMaterialConstants(m);
   MaterialRec* dm = nullptr; float* din = nullptr; float* dout = nullptr;
   hipStream_t st = g_ctx.stream;

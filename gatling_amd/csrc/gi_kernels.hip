@@ -223,7 +223,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
       slot = qs.slot[qIn][r];
       ro = ld4(&qs.a[qIn][r]);
       rdir = ld4(&qs.b[qIn][r]);
-      rng = CUTOUT ? f2u(st.slots[slot].rad.w) : 0u; // the any-hit test needs the path's rng state
+      rng = CUTOUT ? (ANYHIT ? f2u(rdir.w) : f2u(st.slots[slot].rad.w)) : 0u; // the any-hit test needs the path's rng state (shadow rays carry their copy)
       // shadow ray (rp_main.rgen:397-429): origin = next ray origin, tMin 0.01, tMax = distance to the light sample
       if (!ANYHIT) trav_init(R, v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), ro.w, rdir.w);
       else trav_init(R, v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), 0.01f, ro.w);
@@ -321,7 +321,7 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
       prec = reader_index(rd, base + lane);
       pro = ld4(&qs.a[qIn][prec]);
       prd = ld4(&qs.b[qIn][prec]);
-      if (CUTOUT) prng = f2u(st.slots[qs.slot[qIn][prec]].rad.w); // the any-hit test needs the path's rng state
+      if (CUTOUT) prng = ANYHIT ? f2u(prd.w) : f2u(st.slots[qs.slot[qIn][prec]].rad.w); // the any-hit test needs the path's rng state (shadow rays carry their copy)
     }
   };
   next_chunk();
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, 
   uint32_t trip = 0;
   for (uint32_t base = blockIdx.x * BLOCK; base < n; base += stride, trip++) {
     const uint32_t i = base + threadIdx.x;
-    bool cont = false, ended = false, shadow = false; uint32_t slot = 0;
+    bool cont = false, ended = false, shadow = false; uint32_t slot = 0, rngShadow = 0u;
     V3 no = v3(0.0f, 0.0f, 0.0f), k2 = no, sdir = no, nee = no; float ld = 0.0f, tMaxNext = GI_FLT_MAX;
     if (i < n) {
       const uint32_t r = reader_index(rdr, i);
@@ -522,6 +522,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, 
         ld = length(toLight);
         sdir = gi_safe_div(toLight, ld);
         shadow = gi_luminance(nee) > 1e-6f && ld > 1e-9f;
+        rngShadow = rng; // the shadow payload gets a copy of the rng as it is HERE, before the Russian-roulette draw (rp_main.rgen:399)
       }
       if (isTransmission) { // medium stack (:447-480)
         uint32_t newIdx = mediumIdx;
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, 
     if (shadow) {
       qs.slot[Q_SHADOW][idx[2]] = slot;
       st4(&qs.a[Q_SHADOW][idx[2]], no.x, no.y, no.z, ld);
-      st4(&qs.b[Q_SHADOW][idx[2]], sdir.x, sdir.y, sdir.z, 0.0f);
+      st4(&qs.b[Q_SHADOW][idx[2]], sdir.x, sdir.y, sdir.z, u2f(rngShadow)); // .w: rng state for the any-hit test of cutouts
       st4(&qs.c[Q_SHADOW][idx[2]], nee.x, nee.y, nee.z, 0.0f);
     }
   }

@@ -4,6 +4,7 @@
 #pragma once
 
 #include "gi_queues.h"
+#include "gi_texture.h"
 
 namespace gi {
 
@@ -93,54 +94,6 @@ __device__ __forceinline__ void setup_shading_state(const SceneView& sc, uint32_
   s.texMask = 0u; s.texBaseColor = v3(0.0f, 0.0f, 0.0f); s.texEmission = s.texBaseColor; s.texRoughness = 0.0f; s.texMetallic = 0.0f;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Texture runtime (mdl_interface.glsl:8-38 apply_wrap_and_crop, :127-145 tex_lookup_float4_2d) over a software sampler:
-// bilinear, REPEAT addressing, LOD 0 (the reference's single sampler, Gi.cpp:388-392, CgpuVk.cpp:1985-1990).
-// Operation order == oracle sample_bilinear_repeat / tex_lookup_float4_2d.
-// ------------------------------------------------------------------------------------------------
-__device__ inline F4 sample_bilinear_repeat(const TextureRec& t, float u, float v)
-{
-  u = u - floorf(u); v = v - floorf(v);
-  const float x = u * (float)t.width - 0.5f, y = v * (float)t.height - 0.5f;
-  const float x0f = floorf(x), y0f = floorf(y);
-  const float fx = x - x0f, fy = y - y0f;
-  const int w = (int)t.width, h = (int)t.height;
-  int ix0 = (int)x0f, iy0 = (int)y0f;
-  if (ix0 < 0) ix0 += w;
-  if (iy0 < 0) iy0 += h;
-  int ix1 = ix0 + 1; if (ix1 >= w) ix1 -= w;
-  int iy1 = iy0 + 1; if (iy1 >= h) iy1 -= h;
-  const F4* tx = reinterpret_cast<const F4*>(t.texels);
-  const F4 t00 = ld4(&tx[(size_t)iy0 * w + ix0]), t10 = ld4(&tx[(size_t)iy0 * w + ix1]);
-  const F4 t01 = ld4(&tx[(size_t)iy1 * w + ix0]), t11 = ld4(&tx[(size_t)iy1 * w + ix1]);
-  const float gx = 1.0f - fx, gy = 1.0f - fy;
-  F4 o;
-  o.x = (t00.x * gx + t10.x * fx) * gy + (t01.x * gx + t11.x * fx) * fy;
-  o.y = (t00.y * gx + t10.y * fx) * gy + (t01.y * gx + t11.y * fx) * fy;
-  o.z = (t00.z * gx + t10.z * fx) * gy + (t01.z * gx + t11.z * fx) * fy;
-  o.w = (t00.w * gx + t10.w * fx) * gy + (t01.w * gx + t11.w * fx) * fy;
-  return o;
-}
-__device__ __forceinline__ float apply_wrap_and_crop(float coord, uint32_t wrap, uint32_t res) // crop = (0, 1)
-{
-  if (wrap == TEX_WRAP_REPEAT) coord = coord - floorf(coord);
-  else {
-    if (wrap == TEX_WRAP_MIRRORED_REPEAT) {
-      const float tmp = floorf(coord);
-      if (((int)tmp & 1) != 0) coord = 1.0f - (coord - tmp); else coord = coord - tmp;
-    }
-    const float inv_hdim = 0.5f / (float)res;
-    coord = fmin2(fmax2(coord, inv_hdim), 1.0f - inv_hdim);
-  }
-  return coord;
-}
-__device__ inline F4 tex_lookup_float4_2d(const TextureRec& t, float u, float v, uint32_t wrapU, uint32_t wrapV)
-{
-  if ((wrapU == TEX_WRAP_CLIP && (u < 0.0f || u > 1.0f)) || (wrapV == TEX_WRAP_CLIP && (v < 0.0f || v > 1.0f))) return F4{0.0f, 0.0f, 0.0f, 0.0f};
-  u = apply_wrap_and_crop(u, wrapU, t.width);
-  v = apply_wrap_and_crop(v, wrapV, t.height);
-  return sample_bilinear_repeat(t, u, v);
-}
 // mdl_adapt_normal (mdl_interface.glsl:238-256): Iray's shadow-terminator bend of a mapped normal
 __device__ __forceinline__ V3 adapt_normal(V3 rayDir, V3 geomNormal, V3 normal)
 {
@@ -155,7 +108,7 @@ __device__ __forceinline__ V3 adapt_normal(V3 rayDir, V3 geomNormal, V3 normal)
 __device__ inline void resolve_material_textures(const SceneView& sc, const MaterialRec* m, V3 rayDir, ShState& st)
 {
 #pragma unroll
-  for (uint32_t slot = 0; slot < TEX_SLOT_COUNT; slot++) {
+  for (uint32_t slot = 0; slot < TEX_OPACITY; slot++) { // TEX_OPACITY belongs to the any-hit test (cutout_opacity_at)
     const TexBindingRec& b = m->tex[slot];
     if (b.tex == 0u) {
       if (!(b.mode & TEX_MODE_PRIMVAR) || slot == TEX_NORMAL) continue;

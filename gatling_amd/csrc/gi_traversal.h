@@ -3,6 +3,7 @@
 #pragma once
 
 #include "gi_queues.h"
+#include "gi_texture.h"
 
 namespace gi {
 
@@ -197,7 +198,7 @@ __device__ __forceinline__ bool trav_step(RayTrav& R, const SceneView& sc, const
     const bool better = (t < R.tBest) | ((t == R.tBest) & (R.bestOrig != 0xffffffffu) & (orig < R.bestOrig));
     bool accept = inside & better;
     if (CUTOUT && accept && (c.w & (1u << 28))) { // non-opaque material: stochastic cutout (ignoreIntersectionEXT, rp_main.ahit:57-60)
-      const float opacity = sc.materials[c.w & 0x00ffffffu].p[MP_CUTOUT];
+      const float opacity = cutout_opacity_at(sc, c.w, triIdx, u, v);
       accept = !(cutout_random(rng, orig) > opacity);
     }
     if (accept) {
@@ -267,7 +268,7 @@ __device__ __forceinline__ void wave_tri_batch(WaveTri& W, WaveStage* S, uint32_
     float t, u, v;
     bool accept = tri_test(o, d, tMin, a, b, c, t, u, v);
     if (CUTOUT && accept && (c.w & (1u << 28))) { // non-opaque material: stochastic cutout (ignoreIntersectionEXT, rp_main.ahit:57-60)
-      const float opacity = sc.materials[c.w & 0x00ffffffu].p[MP_CUTOUT];
+      const float opacity = cutout_opacity_at(sc, c.w, triIdx, u, v);
       accept = !(cutout_random(rrng, c.y) > opacity);
     }
     if (accept) {

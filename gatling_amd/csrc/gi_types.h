@@ -67,13 +67,14 @@ constexpr uint32_t MAT_PARAM_COUNT = 48;
 enum : uint32_t { MP_ALBEDO = 32, MP_F0 = 35, MP_ALPHA = 38, MP_COAT = 39, MP_COAT_ALPHA = 40, MP_COAT_F0 = 41, MP_ETA = 42, MP_SIGMA_A = 43, MP_CUTOUT = 46 /* mdl_cutout_opacity, 1 = opaque */ };
 // Textured material inputs (UsdUVTexture semantics: value = texel * scale + bias at the hit's st).  Replaces the MDL
 // renderer runtime's tex_lookup_* path (mdl_interface.glsl:127-145) for the inputs the closed-form materials expose.
-enum : uint32_t { TEX_BASE_COLOR = 0, TEX_EMISSION = 1, TEX_ROUGHNESS = 2, TEX_METALLIC = 3, TEX_NORMAL = 4, TEX_SLOT_COUNT = 5 };
+enum : uint32_t { TEX_BASE_COLOR = 0, TEX_EMISSION = 1, TEX_ROUGHNESS = 2, TEX_METALLIC = 3, TEX_NORMAL = 4, TEX_OPACITY = 5 /* read by the any-hit test, not by k_shade */, TEX_SLOT_COUNT = 6 };
 enum : uint32_t { TEX_WRAP_CLAMP = 0, TEX_WRAP_REPEAT = 1, TEX_WRAP_MIRRORED_REPEAT = 2, TEX_WRAP_CLIP = 3 }; // mdl_types.glsl:117-120
 struct TexBindingRec {
   uint32_t tex;   // texture index + 1; 0 = input not textured
   uint32_t mode;  // wrapS | wrapT << 8 | channel << 16
   float scale[4], bias[4];
 };
+constexpr uint32_t MAT_FLAG_OPACITY_TEX = 1u << 30; // MaterialRec::flags: the cutout opacity is textured (the any-hit test looks it up at the candidate's st)
 constexpr uint32_t MAT_FLAG_TEXTURED = 1u << 31; // MaterialRec::flags: some input is textured or primvar-driven (k_shade resolves the inputs per hit)
 constexpr uint32_t TEX_MODE_PRIMVAR = 1u << 24;   // TexBindingRec::mode: (no texture) the input reads the mesh's scene data for this slot
 // Scene data (primvars) of a mesh for the material inputs of ITS material (replaces BlasPayloadBufferPreamble::sceneDataInfos,
@@ -86,7 +87,7 @@ struct MaterialRec {
   float p[MAT_PARAM_COUNT];
   TexBindingRec tex[TEX_SLOT_COUNT];
 };
-static_assert(sizeof(MaterialRec) == 400, "MaterialRec must be 400 bytes");
+static_assert(sizeof(MaterialRec) == 440, "MaterialRec must be 440 bytes");
 // A texture: linear float RGBA texels, row 0 first.  (8-bit sources are decoded to linear float by the caller; a
 // compressed unorm8/half store is a later memory optimisation, the lookup arithmetic would not change.)
 struct TextureRec { const float* texels; uint32_t width, height; };

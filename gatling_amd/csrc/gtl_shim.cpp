@@ -195,7 +195,7 @@ namespace gtl
         setN(n, "clearcoat", p + GI_C_P_CLEARCOAT, 1); setN(n, "clearcoatRoughness", p + GI_C_P_CLEARCOAT_ROUGHNESS, 1);
         setN(n, "opacity", p + GI_C_P_OPACITY, 1); setN(n, "opacityThreshold", p + GI_C_P_OPACITY_THRESHOLD, 1); setN(n, "ior", p + GI_C_P_IOR, 1);
         bind("diffuseColor", GI_C_TEX_BASE_COLOR); bind("emissiveColor", GI_C_TEX_EMISSION); bind("roughness", GI_C_TEX_ROUGHNESS); bind("metallic", GI_C_TEX_METALLIC);
-        bind("normal", GI_C_TEX_NORMAL);
+        bind("normal", GI_C_TEX_NORMAL); bind("opacity", GI_C_TEX_OPACITY); // typically the texture's alpha: <input name="opacity" nodename="tex" output="a"/>
         return true;
       }
       d.klass = GI_C_MAT_OPEN_PBR; // defaults: src/gi/mtlx/open_pbr_surface.mtlx:11-92
@@ -217,7 +217,7 @@ namespace gtl
       setN(n, "emission_luminance", &lum, 1); setN(n, "emission_color", ecol, 3); setN(n, "geometry_opacity", p + GI_C_P_OPACITY, 1);
       for (int i = 0; i < 3; i++) p[GI_C_P_EMISSION + i] = lum * ecol[i];
       bind("base_color", GI_C_TEX_BASE_COLOR); bind("specular_roughness", GI_C_TEX_ROUGHNESS); bind("base_metalness", GI_C_TEX_METALLIC);
-      bind("geometry_normal", GI_C_TEX_NORMAL);
+      bind("geometry_normal", GI_C_TEX_NORMAL); bind("geometry_opacity", GI_C_TEX_OPACITY);
       return true;
     }
   }

@@ -62,7 +62,7 @@ class TextureBinding:
 
 
 TEX_WRAP_CLAMP, TEX_WRAP_REPEAT, TEX_WRAP_MIRRORED_REPEAT, TEX_WRAP_CLIP = 0, 1, 2, 3
-TEX_BASE_COLOR, TEX_EMISSION, TEX_ROUGHNESS, TEX_METALLIC, TEX_NORMAL, TEX_SLOT_COUNT = 0, 1, 2, 3, 4, 5
+TEX_BASE_COLOR, TEX_EMISSION, TEX_ROUGHNESS, TEX_METALLIC, TEX_NORMAL, TEX_OPACITY, TEX_SLOT_COUNT = 0, 1, 2, 3, 4, 5, 6
 
 
 @dataclass

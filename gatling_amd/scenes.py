@@ -310,3 +310,50 @@ def volume_scene(scatter=(0.6, 0.3, 0.1), anisotropy: float = 0.3, nested: bool 
     s.rect_lights = [RectLight(origin=(0.5, -0.5, 4.0), t0=(1, 0, 0), t1=(0, 1, 0), base_emission=(12, 12, 12), width=1.5, height=1.5)]
     s.camera = _look_at_camera((0, -4.5, 1.6), (0, 0, 1.0), (0, 0, 1), 40.0)
     return s
+
+
+def leaf_card_scene(seed: int = 5, cards: int = 12) -> SceneDesc:
+    """Textured cutouts: a ground quad, a rect light and `cards` double-sided quads ("leaf cards") whose opacity comes from a
+    texture -- a leaf-shaped binary mask through UsdPreviewSurface's opacityThreshold, a soft-edged mask used stochastically, and
+    an OpenPBR geometry_opacity read from another channel -- so closest-hit AND shadow rays evaluate the any-hit test at each
+    candidate's st (rp_main.ahit:51-60)."""
+    from .meshprep import bake_vertices
+    from .scene import TEX_BASE_COLOR, TEX_OPACITY, TEX_WRAP_CLAMP, TEX_WRAP_REPEAT
+    rng = np.random.default_rng(seed)
+    s = SceneDesc()
+    yy, xx = np.mgrid[0:32, 0:32]
+    u, v = (xx + 0.5) / 32, (yy + 0.5) / 32
+    leaf = np.zeros((32, 32, 4), np.float32)
+    inside = ((u - 0.5) / 0.42) ** 2 + ((v - 0.5) / 0.28) ** 2 < 1.0
+    leaf[..., 0] = 0.15 + 0.2 * v; leaf[..., 1] = 0.45 + 0.4 * u; leaf[..., 2] = 0.1
+    leaf[..., 3] = inside.astype(np.float32)                                   # alpha: binary leaf mask
+    soft = np.zeros((16, 16, 4), np.float32)
+    r = np.sqrt(((np.mgrid[0:16, 0:16][1] + 0.5) / 16 - 0.5) ** 2 + ((np.mgrid[0:16, 0:16][0] + 0.5) / 16 - 0.5) ** 2)
+    soft[..., :3] = 0.7; soft[..., 1] = np.clip(1.2 - 2.4 * r, 0.0, 1.0); soft[..., 3] = 1.0   # green channel: radial falloff
+    s.textures = [leaf, soft]
+    ground = MaterialDesc.usd_preview_surface(name="ground", diffuseColor=(0.6, 0.6, 0.6), roughness=0.6)
+    masked = MaterialDesc.usd_preview_surface(name="leafMasked", diffuseColor=(0.2, 0.6, 0.1), roughness=0.5, opacityThreshold=0.5)
+    masked.textures = {TEX_BASE_COLOR: TextureBinding(texture=0, wrap_s=TEX_WRAP_CLAMP, wrap_t=TEX_WRAP_CLAMP),
+                       TEX_OPACITY: TextureBinding(texture=0, wrap_s=TEX_WRAP_CLAMP, wrap_t=TEX_WRAP_CLAMP, channel=3)}
+    veil = MaterialDesc.usd_preview_surface(name="veil", diffuseColor=(0.7, 0.3, 0.2), roughness=0.5)
+    veil.textures = {TEX_OPACITY: TextureBinding(texture=1, wrap_s=TEX_WRAP_REPEAT, wrap_t=TEX_WRAP_REPEAT, channel=1, scale=(1.0, 0.9, 1.0, 1.0), bias=(0.0, 0.05, 0.0, 0.0))}
+    pbr = MaterialDesc.open_pbr(name="pbrLeaf", base_color=(0.3, 0.5, 0.8), specular_roughness=0.4)
+    pbr.textures = {TEX_OPACITY: TextureBinding(texture=0, channel=3)}
+    s.materials = [ground, masked, veil, pbr]
+    gp = np.array([[-4, -4, 0], [4, -4, 0], [4, 4, 0], [-4, -4, 0], [4, 4, 0], [-4, 4, 0]], np.float32)
+    s.meshes.append(MeshDesc(name="/Ground", vertices=bake_vertices(gp, np.tile([0, 0, 1], (6, 1)), np.zeros((6, 2), np.float32)),
+                             faces=np.arange(6, dtype=np.uint32).reshape(-1, 3), material=0, id=0, double_sided=True))
+    quad = np.array([[-0.5, 0, -0.35], [0.5, 0, -0.35], [0.5, 0, 0.35], [-0.5, 0, -0.35], [0.5, 0, 0.35], [-0.5, 0, 0.35]], np.float32)
+    quv = np.array([[0, 0], [1, 0], [1, 1], [0, 0], [1, 1], [0, 1]], np.float32)
+    for i in range(cards):
+        a, b = rng.uniform(0, 2 * np.pi), rng.uniform(-0.6, 0.6)
+        ca, sa, cb, sb = np.cos(a), np.sin(a), np.cos(b), np.sin(b)
+        rz = np.array([[ca, sa, 0], [-sa, ca, 0], [0, 0, 1]]); rx = np.array([[1, 0, 0], [0, cb, sb], [0, -sb, cb]])
+        m = np.eye(4, dtype=np.float32)
+        m[:3, :3] = (rx @ rz * rng.uniform(0.8, 1.6)).astype(np.float32)
+        m[3, :3] = (rng.uniform(-1.6, 1.6), rng.uniform(-1.2, 1.2), rng.uniform(0.5, 1.8))
+        s.meshes.append(MeshDesc(name=f"/Card{i}", vertices=bake_vertices(quad, np.tile([0, -1, 0], (6, 1)), quv * (2.0 if i % 3 == 1 else 1.0)),
+                                 faces=np.arange(6, dtype=np.uint32).reshape(-1, 3), material=1 + i % 3, id=1 + i, double_sided=True, transform=m))
+    s.rect_lights = [RectLight(origin=(0.3, -0.2, 4.0), t0=(1, 0, 0), t1=(0, 1, 0), base_emission=(9, 9, 9), width=1.5, height=1.5)]
+    s.camera = _look_at_camera((0, -6.0, 2.6), (0, 0, 0.8), (0, 0, 1), 42.0)
+    return s

@@ -307,7 +307,7 @@ struct Instance {
   float o2w[12]; // rows of the 3x4 object-to-world (Gi.cpp:1191)
   float w2o[9];  // inverse of the 3x3 part, row-major
 };
-struct Tri { V3 v0, e1, e2; uint32_t instance, prim; float cutout; /* mdl_cutout_opacity of the material; 1 = opaque */ };
+struct Tri { V3 v0, e1, e2; uint32_t instance, prim; float cutout; /* mdl_cutout_opacity of the material; 1 = opaque */ int32_t opacityTexMat; /* >= 0: that material's opacity is textured */ };
 struct MeshData { std::vector<FVertex> verts; const uint32_t* faces; uint32_t faceCount; int material; uint32_t flags; int32_t objectId; std::vector<uint8_t> faceIdData; uint32_t faceIdStride; const OrcMesh* src; };
 
 // Light structs as the device sees them (rp_main.h:73-113), derived fields per Gi.cpp setters.
@@ -380,6 +380,7 @@ inline V3 xform_normal(const float w[9], V3 n)
 
 void build_bvh(Prepared& P);
 inline float cutout_opacity(const OrcMaterial& m);
+inline float cutout_rule(uint32_t klass, float op, float th);
 
 void prepare(const OrcScene* s, Prepared& P)
 {
@@ -412,7 +413,9 @@ void prepare(const OrcScene* s, Prepared& P)
         V3 p0 = xform_point(inst.o2w, d.verts[m.faces[3 * f + 0]].pos, 1.0f);
         V3 p1 = xform_point(inst.o2w, d.verts[m.faces[3 * f + 1]].pos, 1.0f);
         V3 p2 = xform_point(inst.o2w, d.verts[m.faces[3 * f + 2]].pos, 1.0f);
-        P.tris.push_back(Tri{p0, p1 - p0, p2 - p0, instIdx, f, cutout_opacity(s->materials[m.material])});
+        const OrcMaterial& mat = s->materials[m.material];
+        const bool opTex = mat.tex[ORC_TEX_OPACITY].texture >= 0 && (uint32_t)mat.tex[ORC_TEX_OPACITY].texture < s->textureCount;
+        P.tris.push_back(Tri{p0, p1 - p0, p2 - p0, instIdx, f, cutout_opacity(mat), opTex ? (int32_t)m.material : -1});
       }
     }
   }
@@ -447,13 +450,16 @@ void prepare(const OrcScene* s, Prepared& P)
 struct Hit { float t, u, v; uint32_t tri; };
 
 // mdl_cutout_opacity of the closed forms: UsdPreviewSurface opacity with the opacityThreshold switch, OpenPBR geometry_opacity
-inline float cutout_opacity(const OrcMaterial& m)
+inline float cutout_rule(uint32_t klass, float op, float th)
 {
-  float op = m.p[ORC_P_OPACITY], th = m.p[ORC_P_OPACITY_THRESHOLD];
-  if (m.klass == ORC_MAT_OPEN_PBR) return fmin2(fmax2(op, 0.0f), 1.0f);
+  if (klass == ORC_MAT_OPEN_PBR) return fmin2(fmax2(op, 0.0f), 1.0f);
   if (th > 0.0f) return (op >= th) ? 1.0f : 0.0f;
   return fmin2(fmax2(op, 0.0f), 1.0f);
 }
+inline float cutout_opacity(const OrcMaterial& m) { return cutout_rule(m.klass, m.p[ORC_P_OPACITY], m.p[ORC_P_OPACITY_THRESHOLD]); }
+// The same with a textured opacity input, evaluated at the CANDIDATE's st (rp_main.ahit:51-60 sets up the shading state of the
+// candidate hit and evaluates the material's cutout expression there); defined after the texture runtime.
+float cutout_opacity_textured(const struct Prepared& P, const struct Tri& T, float u, float v);
 // Any-hit randomness (rp_main.ahit:51-60 draws next1f per candidate, in the driver's traversal order -- the one draw whose
 // order the reference leaves implementation-defined).  Restated order-independently: a stateless
 // hash of the path's rng state and the candidate's scene-order triangle id; the state itself is not advanced.
@@ -464,7 +470,7 @@ inline float cutout_random(uint32_t rng, uint32_t triId)
   return uint_as_float01((word >> 22) ^ word);
 }
 
-inline bool tri_test(const Tri& T, V3 o, V3 d, float tMin, float& tBest, uint32_t idx, Hit& h, uint32_t rng)
+inline bool tri_test(const Prepared& P, const Tri& T, V3 o, V3 d, float tMin, float& tBest, uint32_t idx, Hit& h, uint32_t rng)
 {
   V3 pv = cross(d, T.e2);
   float det = dot(T.e1, pv);
@@ -479,7 +485,8 @@ inline bool tri_test(const Tri& T, V3 o, V3 d, float tMin, float& tBest, uint32_
   float t = dot(T.e2, qv) * inv;
   if (!(t > tMin)) return false;
   if (t < tBest || (t == tBest && h.tri != 0xffffffffu && idx < h.tri)) {
-    if (T.cutout < 1.0f && cutout_random(rng, idx) > T.cutout) return false; // ignoreIntersectionEXT (rp_main.ahit:57-60)
+    if (T.opacityTexMat >= 0) { if (cutout_random(rng, idx) > cutout_opacity_textured(P, T, u, v)) return false; }
+    else if (T.cutout < 1.0f && cutout_random(rng, idx) > T.cutout) return false; // ignoreIntersectionEXT (rp_main.ahit:57-60)
     tBest = t; h = Hit{t, u, v, idx}; return true;
   }
   return false;
@@ -551,7 +558,7 @@ bool trace_closest(const Prepared& P, V3 o, V3 d, float tMin, float tMax, Hit& h
   float tBest = tMax; bool any = false; h.tri = 0xffffffffu;
   // accept tMin < t < tMax; h.tri == ~0 marks 'no hit yet' so the tie rule cannot admit t == tMax
   if (P.bvh.empty()) {
-    for (uint32_t i = 0; i < P.tris.size(); i++) any |= tri_test(P.tris[i], o, d, tMin, tBest, i, h, rng);
+    for (uint32_t i = 0; i < P.tris.size(); i++) any |= tri_test(P, P.tris[i], o, d, tMin, tBest, i, h, rng);
     return any;
   }
   V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -559,7 +566,7 @@ bool trace_closest(const Prepared& P, V3 o, V3 d, float tMin, float tMax, Hit& h
   while (sp) {
     const BvhNode& n = P.bvh[stack[--sp]];
     if (!box_test(n, o, inv, tMin, tBest)) continue;
-    if (n.count) { for (uint32_t i = n.left; i < n.left + n.count; i++) { uint32_t t = P.bvhTris[i]; any |= tri_test(P.tris[t], o, d, tMin, tBest, t, h, rng); } }
+    if (n.count) { for (uint32_t i = n.left; i < n.left + n.count; i++) { uint32_t t = P.bvhTris[i]; any |= tri_test(P, P.tris[t], o, d, tMin, tBest, t, h, rng); } }
     else { stack[sp++] = n.left; stack[sp++] = n.left + 1; }
   }
   return any;
@@ -681,9 +688,21 @@ inline V3 adapt_normal(V3 rayDir, V3 geomNormal, V3 normal)
   return normalize(-rayDir + tangent);
 }
 
+float cutout_opacity_textured(const Prepared& P, const Tri& T, float hu, float hv)
+{
+  const OrcMaterial& m = P.materials[T.opacityTexMat];
+  const OrcTexBinding& b = m.tex[ORC_TEX_OPACITY];
+  const MeshData& md = P.meshes[P.instances[T.instance].mesh];
+  const FVertex& a = md.verts[md.faces[3 * T.prim + 0]], &bb = md.verts[md.faces[3 * T.prim + 1]], &c = md.verts[md.faces[3 * T.prim + 2]];
+  const float bx = 1.0f - hu - hv, by = hu, bz = hv;                       // mdl_shading_state.glsl:17
+  const float u = (bx * a.u + by * bb.u) + bz * c.u, v = (bx * a.v + by * bb.v) + bz * c.v; // :62-65
+  const F4v t = tex_lookup_float4_2d(P.textures[b.texture], u, v, b.wrapS, b.wrapT);
+  const float val[4] = {t.x * b.scale[0] + b.bias[0], t.y * b.scale[1] + b.bias[1], t.z * b.scale[2] + b.bias[2], t.w * b.scale[3] + b.bias[3]};
+  return cutout_rule(m.klass, val[b.channel & 3], m.p[ORC_P_OPACITY_THRESHOLD]);
+}
 // Per-hit material: the parameter block with its textured inputs evaluated at the hit's uv (UsdUVTexture: texel * scale + bias);
 // a normal map replaces the shading normal (tangent space -> world, adapt_normal, tangent frame re-orthonormalised).
-inline bool material_textured(const OrcMaterial& m) { for (int i = 0; i < ORC_TEX_SLOT_COUNT; i++) if (m.tex[i].texture >= 0 || m.primvarInput[i][0]) return true; return false; }
+inline bool material_textured(const OrcMaterial& m) { for (int i = 0; i < ORC_TEX_OPACITY; i++) if (m.tex[i].texture >= 0 || m.primvarInput[i][0]) return true; return false; }
 // The primvar a scene-data name resolves to for this mesh: instancer primvars first, mesh primvars override (Gi.cpp:913-929)
 inline const OrcPrimvar* find_primvar(const OrcMesh& m, const char* name)
 {
@@ -714,7 +733,7 @@ inline bool scene_data_lookup(const State& st, const char* name, int comps, floa
 OrcMaterial resolve_material(const Prepared& P, const OrcMaterial& m, State& st, V3 rayDir)
 {
   OrcMaterial r = m;
-  for (int slot = 0; slot < ORC_TEX_SLOT_COUNT; slot++) {
+  for (int slot = 0; slot < ORC_TEX_OPACITY; slot++) { // ORC_TEX_OPACITY belongs to the any-hit test (cutout_opacity_textured)
     const OrcTexBinding& b = m.tex[slot];
     if ((b.texture < 0 || (uint32_t)b.texture >= P.textureCount) && m.primvarInput[slot][0] && slot != ORC_TEX_NORMAL) { // primvar-driven input
       float v[3];

@@ -16,7 +16,7 @@ _LIB_PATH = os.path.join(_HERE, "libgi_oracle.so")
 P_COUNT = 48
 
 
-TEX_SLOT_COUNT = 5
+TEX_SLOT_COUNT = 6
 
 
 class OrcTexBinding(C.Structure):

@@ -415,7 +415,20 @@ def test_cutout_opacity_parity(gi, orc, nee):
     desc.meshes[6].material, desc.meshes[7].material, desc.meshes[3].material = 4, 5, 6
     if nee:
         desc.rect_lights = [RectLight(origin=(0, 0, 0.9), t0=(1, 0, 0), t1=(0, -1, 0), base_emission=(10, 10, 10), width=0.7, height=0.5)]
-    render_both(gi, orc, desc, RenderSettings(spp=8, max_bounces=6, next_event_estimation=nee), 128, 72)
+    # rr_bounce_offset 0: Russian roulette draws at every bounce, so a shadow ray's any-hit test must use the rng copy taken BEFORE that
+    # draw (rp_main.rgen:399) -- the slot's state afterwards is a different number
+    render_both(gi, orc, desc, RenderSettings(spp=8, max_bounces=6, next_event_estimation=nee, rr_bounce_offset=0 if nee else 3), 128, 72)
+
+
+@pytest.mark.parametrize("nee", [False, True])
+def test_textured_cutout_parity(gi, orc, nee):
+    """Opacity textures (binary leaf mask through opacityThreshold, a soft mask used stochastically, OpenPBR geometry_opacity from the
+    alpha channel) evaluated per candidate in the any-hit test of closest-hit and shadow rays -- bit-identical to the oracle."""
+    from gatling_amd.scenes import leaf_card_scene
+    desc = leaf_card_scene()
+    img, ref, st = render_both(gi, orc, desc, RenderSettings(spp=6, max_bounces=5, next_event_estimation=nee), 128, 72)
+    if nee:
+        assert st["shadowRays"] > 0
 
 
 def test_instanced_scene_parity(gi, orc):

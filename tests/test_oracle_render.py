@@ -289,3 +289,42 @@ def test_volume_medium_stack(orc):
     # metersPerSceneUnit scales the optical depth: a 100x smaller unit makes the medium nearly transparent
     thin, _ = orc.render(murky, rs(2, meters_per_scene_unit=0.01), 64, 36, threads=4)
     assert np.isfinite(thin).all() and not np.array_equal(thin, i2)
+
+
+def test_textured_cutout_opacity(orc):
+    """Opacity from a texture, evaluated at each candidate hit's st (rp_main.ahit:51-60): an all-one mask is the opaque card, an
+    all-zero mask removes the card, and a half mask through opacityThreshold is (up to edge pixels) the card cut in half."""
+    from gatling_amd.meshprep import bake_vertices
+    from gatling_amd.scene import MeshDesc, TEX_OPACITY, TEX_WRAP_CLAMP, TextureBinding
+    rs = RenderSettings(spp=4, max_bounces=4, next_event_estimation=True)
+
+    def scene(mask, x1=0.6, threshold=0.5):
+        d = cornell_box(MAT_DIFFUSE)
+        d.rect_lights = [RectLight(origin=(0, 0, 0.9), t0=(1, 0, 0), t1=(0, -1, 0), base_emission=(10, 10, 10), width=0.7, height=0.5)]
+        if mask is not None:
+            tex = np.ones((1, len(mask), 4), np.float32); tex[0, :, 3] = mask
+            d.textures = [tex]
+        m = MaterialDesc.usd_preview_surface(name="card", diffuseColor=(0.1, 0.7, 0.2), klass=MAT_DIFFUSE, opacityThreshold=threshold)
+        if mask is not None:
+            m.textures = {TEX_OPACITY: TextureBinding(texture=0, wrap_s=TEX_WRAP_CLAMP, wrap_t=TEX_WRAP_CLAMP, channel=3)}
+        d.materials.append(m)
+        p = np.array([[-0.6, -0.3, -0.5], [x1, -0.3, -0.5], [x1, -0.3, 0.4], [-0.6, -0.3, -0.5], [x1, -0.3, 0.4], [-0.6, -0.3, 0.4]], np.float32)
+        uv = np.array([[0, 0], [1, 0], [1, 1], [0, 0], [1, 1], [0, 1]], np.float32)
+        d.meshes.append(MeshDesc(name="/Card", vertices=bake_vertices(p, np.tile([0, -1, 0], (6, 1)), uv), faces=np.arange(6, dtype=np.uint32).reshape(-1, 3),
+                                 material=len(d.materials) - 1, id=99, double_sided=True))
+        return d
+    opaque, _ = orc.render(scene(None), rs, 64, 36)
+    ones, _ = orc.render(scene([1.0, 1.0]), rs, 64, 36)
+    assert np.array_equal(ones, opaque)
+    absent = scene(None); absent.meshes[-1].visible = False
+    ref_absent, _ = orc.render(absent, rs, 64, 36)
+    zeros, _ = orc.render(scene([0.0, 0.0]), rs, 64, 36)
+    assert (zeros != ref_absent).any(axis=-1).sum() <= 2   # the card is the last mesh: triangle ids of the rest are unchanged
+    # [1, 0] with clamp + bilinear: alpha falls from 1 at u = 0.25 to 0 at u = 0.75, the threshold 0.5 cuts at u = 0.5
+    half_mask, _ = orc.render(scene([1.0, 0.0]), rs, 64, 36)
+    half_geom, _ = orc.render(scene(None, x1=0.0), rs, 64, 36)
+    differing = (np.abs(half_mask - half_geom).max(axis=-1) > 0.25).mean()
+    assert differing < 0.03 and np.abs(half_mask - opaque).mean() > 1e-3 and np.abs(half_mask - ref_absent).mean() > 1e-3
+    # without a threshold the same ramp is used stochastically: between the two
+    soft, _ = orc.render(scene([1.0, 0.0], threshold=0.0), rs, 64, 36)
+    assert np.abs(soft - half_mask).mean() > 1e-4

@@ -10,7 +10,7 @@ import pytest
 
 from gatling_amd.scene import RenderSettings
 from gatling_amd.scenefile import load_scene, save_scene
-from gatling_amd.scenes import cornell_box, interior_scene, sphere_grid, textured_scene, volume_scene
+from gatling_amd.scenes import cornell_box, interior_scene, leaf_card_scene, sphere_grid, textured_scene, volume_scene
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tools", "gi_render")
@@ -48,6 +48,7 @@ SCENES = {
     "cornell": lambda: cornell_box(),
     "textured+dome": lambda: textured_scene(dome=True),
     "volume": lambda: volume_scene(),
+    "leaf cards": lambda: leaf_card_scene(),
     "instances": lambda: sphere_grid(grid=3, subdivisions=1, material_count=4),
     "interior": lambda: interior_scene(clutter_instances=12, subdivisions=1, prototypes=3, material_count=6),
 }
@@ -86,7 +87,7 @@ def test_c_harness_compiles_and_parses(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["cornell", "textured+dome", "volume", "interior"])
+@pytest.mark.parametrize("name", ["cornell", "textured+dome", "volume", "interior", "leaf cards"])
 def test_c_harness_renders_like_the_binding(gi, tmp_path, name):
     """The same scene through tools/gi_render (plain C over the C ABI) and through gatling_amd.capi (ctypes): identical images,
     whole frame and an interleaved row share; command-line overrides act like the settings they name."""
