@@ -204,6 +204,19 @@ __device__ __forceinline__ V3 gi_colormap_inferno(float t)
   return c0 + (c1 + (c2 + (c3 + (c4 + (c5 + c6 * t) * t) * t) * t) * t) * t;
 }
 
+// colormap_viridis (colormap.glsl:3-14)
+__device__ __forceinline__ V3 gi_colormap_viridis(float t)
+{
+  const V3 c0 = v3(0.2777273272234177f, 0.005407344544966578f, 0.3340998053353061f);
+  const V3 c1 = v3(0.1050930431085774f, 1.404613529898575f, 1.384590162594685f);
+  const V3 c2 = v3(-0.3308618287255563f, 0.214847559468213f, 0.09509516302823659f);
+  const V3 c3 = v3(-4.634230498983486f, -5.799100973351585f, -19.33244095627987f);
+  const V3 c4 = v3(6.228269936347081f, 14.17993336680509f, 56.69055260068105f);
+  const V3 c5 = v3(4.776384997670288f, -13.74514537774601f, -65.35303263337234f);
+  const V3 c6 = v3(-5.435455855934631f, 4.645852612178535f, 26.3124352495832f);
+  return c0 + (c1 + (c2 + (c3 + (c4 + (c5 + c6 * t) * t) * t) * t) * t) * t;
+}
+
 __device__ __forceinline__ float gi_luminance(V3 c) { return dot(c, v3(0.2126f, 0.7152f, 0.0722f)); }
 __device__ __forceinline__ float gi_safe_div(float a, float b) { return (b == 0.0f) ? 0.0f : (a / b); }
 __device__ __forceinline__ V3 gi_safe_div(V3 v, float f) { return (f == 0.0f) ? v3(0.0f, 0.0f, 0.0f) : (v / f); }

@@ -672,13 +672,19 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_aov(FrameUniforms U, SceneView 
     V3 origin, dir; float tMin, tMax; uint32_t rng;
     make_camera_ray(U, pixelIndex, U.sampleOffset + s, origin, dir, tMin, tMax, rng);
     float t, u, v; uint32_t tri;
-    uint32_t matUnused;
-    if (!traverse<false, false, STACK, OVERFLOW, false, true>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, origin, dir, tMin, tMax, t, u, v, tri, matUnused, tc, rng)) continue;
+    uint32_t matWord;
+    if (!traverse<false, false, STACK, OVERFLOW, false, true>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, origin, dir, tMin, tMax, t, u, v, tri, matWord, tc, rng)) continue;
     ShState ss;
     setup_shading_state(sc, tri, u, v, dir, ss);
     const uint4* tp = reinterpret_cast<const uint4*>(sc.tris) + (size_t)tri * 4u;
     const uint32_t instIdx = tp[2].z;
-    put3(A.opacity, v3(1.0f, 0.0f, 0.0f));
+    if (A.opacity) {
+      // rp_main.chit:199-205 writes (1,0,0) for materials without cutout transparency; for the others the any-hit shader has written
+      // viridis(opacity) (white for 0) of its last candidate (rp_main.ahit:45-49) -- restated as the ACCEPTED primary hit's opacity
+      V3 c = v3(1.0f, 0.0f, 0.0f);
+      if (matWord & (1u << 28)) { const float op = cutout_opacity_at(sc, matWord, tri, u, v); c = (op == 0.0f) ? v3(1.0f, 1.0f, 1.0f) : gi_colormap_viridis(op); }
+      put3(A.opacity, c);
+    }
     put3(A.tangents, (ss.tangentU + v3(1.0f, 1.0f, 1.0f)) * 0.5f);
     put3(A.bitangents, (ss.tangentV + v3(1.0f, 1.0f, 1.0f)) * 0.5f);
     put3(A.barycentrics, v3(1.0f - u - v, u, v));

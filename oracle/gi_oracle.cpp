@@ -1346,6 +1346,18 @@ void miss(const Frame& F, Payload& pl)
   pl.radiance = pl.radiance + pl.throughput * (texel * mult); // :84-86
 }
 
+// colormap_viridis (colormap.glsl:3-14)
+inline V3 colormap_viridis(float t)
+{
+  const V3 c0 = v3(0.2777273272234177f, 0.005407344544966578f, 0.3340998053353061f);
+  const V3 c1 = v3(0.1050930431085774f, 1.404613529898575f, 1.384590162594685f);
+  const V3 c2 = v3(-0.3308618287255563f, 0.214847559468213f, 0.09509516302823659f);
+  const V3 c3 = v3(-4.634230498983486f, -5.799100973351585f, -19.33244095627987f);
+  const V3 c4 = v3(6.228269936347081f, 14.17993336680509f, 56.69055260068105f);
+  const V3 c5 = v3(4.776384997670288f, -13.74514537774601f, -65.35303263337234f);
+  const V3 c6 = v3(-5.435455855934631f, 4.645852612178535f, 26.3124352495832f);
+  return c0 + (c1 + (c2 + (c3 + (c4 + (c5 + c6 * t) * t) * t) * t) * t) * t;
+}
 // colormap_inferno (colormap.glsl:42-53)
 inline V3 colormap_inferno(float t)
 {
@@ -1540,7 +1552,12 @@ void render_pixel_aovs(const Frame& F, uint32_t px, uint32_t py, size_t o, OrcAo
     setup_shading_state(*F.P, h, dir, st, mesh);
     const Tri& T = F.P->tris[h.tri];
     const Instance& inst = F.P->instances[T.instance];
-    put3(A.opacity, v3(1, 0, 0));                                                         // chit:199-205 (no cutouts)
+    { // chit:199-205: (1,0,0) without cutout transparency; else what the any-hit shader wrote (ahit:45-49), restated as the ACCEPTED
+      // primary hit's opacity through viridis (white for 0) -- the reference keeps the last candidate's, in driver order
+      V3 c = v3(1, 0, 0);
+      if (T.cutout < 1.0f || T.opacityTexMat >= 0) { float op = T.opacityTexMat >= 0 ? cutout_opacity_textured(*F.P, T, h.u, h.v) : T.cutout; c = (op == 0.0f) ? v3(1, 1, 1) : colormap_viridis(op); }
+      put3(A.opacity, c);
+    }
     put3(A.tangents, (st.tangentU + v3(1, 1, 1)) * 0.5f);                                  // :206-208
     put3(A.bitangents, (st.tangentV + v3(1, 1, 1)) * 0.5f);                                // :209-211
     put3(A.barycentrics, v3(1.0f - h.u - h.v, h.u, h.v));                                  // :212-214

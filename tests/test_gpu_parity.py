@@ -426,9 +426,21 @@ def test_textured_cutout_parity(gi, orc, nee):
     alpha channel) evaluated per candidate in the any-hit test of closest-hit and shadow rays -- bit-identical to the oracle."""
     from gatling_amd.scenes import leaf_card_scene
     desc = leaf_card_scene()
-    img, ref, st = render_both(gi, orc, desc, RenderSettings(spp=6, max_bounces=5, next_event_estimation=nee), 128, 72)
+    rs = RenderSettings(spp=6, max_bounces=5, next_event_estimation=nee)
+    img, ref, st = render_both(gi, orc, desc, rs, 128, 72)
     if nee:
         assert st["shadowRays"] > 0
+        return
+    # Opacity AOV: (1,0,0) on opaque materials, viridis(opacity of the accepted primary hit) on cutout materials (rp_main.ahit:45-49)
+    sc = gi.Scene(desc)
+    try:
+        got = sc.render_aovs(rs, 96, 54, ["opacity"], with_color=False)["opacity"]
+    finally:
+        sc.close()
+    want = orc.render_aovs(desc, rs, 96, 54, ["opacity"])["opacity"]
+    assert np.array_equal(got[..., :3], want[..., :3])
+    colours = {tuple(c) for c in np.round(want[..., :3].reshape(-1, 3), 4)}
+    assert (1.0, 0.0, 0.0) in colours and len(colours) > 3  # ground + several opacity levels on the cards
 
 
 def test_instanced_scene_parity(gi, orc):
