@@ -8,10 +8,16 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <string>
 
 namespace gi {
 namespace {
+
+// Image files are untrusted input: dimensions are bounded (and checked against the bytes actually present) BEFORE anything is
+// allocated, so a corrupt header can neither exhaust memory nor index out of bounds.
+constexpr uint64_t MAX_IMAGE_DIM = 65536, MAX_IMAGE_PIXELS = 1ull << 28;
+inline bool saneDims(long long w, long long h) { return w > 0 && h > 0 && (uint64_t)w <= MAX_IMAGE_DIM && (uint64_t)h <= MAX_IMAGE_DIM && (uint64_t)w * (uint64_t)h <= MAX_IMAGE_PIXELS; }
 
 // Minimal decoders for dome-light images: Radiance .hdr (RGBE, flat or new-style RLE scanlines, -Y +X orientation) and
 // .pfm (PF, little or big endian, rows bottom-up).  Output: float RGBA, row 0 = first image row (top).
@@ -23,7 +29,7 @@ static bool decodeHdrOrPfm(const std::vector<uint8_t>& d, uint32_t& w, uint32_t&
     line();
     int iw = 0, ih = 0; { std::string l = line(); if (sscanf(l.c_str(), "%d %d", &iw, &ih) != 2) { std::string l2 = line(); iw = atoi(l.c_str()); ih = atoi(l2.c_str()); } }
     const float scale = (float)atof(line().c_str());
-    if (iw <= 0 || ih <= 0 || pos + (size_t)iw * ih * 12 > d.size()) return false;
+    if (!saneDims(iw, ih) || pos + (size_t)iw * ih * 12 > d.size()) return false;
     w = (uint32_t)iw; h = (uint32_t)ih; out.assign((size_t)w * h * 4, 1.0f);
     for (uint32_t y = 0; y < h; y++)
       for (uint32_t x = 0; x < w; x++)
@@ -39,7 +45,11 @@ static bool decodeHdrOrPfm(const std::vector<uint8_t>& d, uint32_t& w, uint32_t&
   if (first.rfind("#?", 0) != 0) return false;
   for (;;) { std::string l = line(); if (l.empty()) break; if (pos >= d.size()) return false; }
   int ih = 0, iw = 0; { std::string l = line(); if (sscanf(l.c_str(), "-Y %d +X %d", &ih, &iw) != 2) return false; }
-  if (iw <= 0 || ih <= 0) return false;
+  if (!saneDims(iw, ih)) return false;
+  { // the smallest encoding of a scanline: flat = 4 bytes per pixel; RLE = 4-byte header + per channel one (count, value) pair per 127 pixels
+    const size_t rle = 4u + 8u * (((size_t)iw + 126u) / 127u), flat = (size_t)iw * 4u;
+    if ((d.size() - std::min(pos, d.size())) / std::min(rle, flat) < (size_t)ih) return false;
+  }
   w = (uint32_t)iw; h = (uint32_t)ih; out.assign((size_t)w * h * 4, 1.0f);
   std::vector<uint8_t> scan((size_t)w * 4);
   for (uint32_t y = 0; y < h; y++) {
@@ -91,10 +101,12 @@ static bool decodePng(const std::vector<uint8_t>& d, bool srgbToLinear, uint32_t
     else if (!memcmp(tag, "IEND", 4)) break;
     pos += 12 + (size_t)len;
   }
-  if (w == 0 || h == 0 || interlace != 0 || (depth != 8 && depth != 16 && !(ctype == 3 && (depth == 1 || depth == 2 || depth == 4)))) return false;
+  if (!saneDims(w, h) || interlace != 0 || (depth != 8 && depth != 16 && !(ctype == 3 && (depth == 1 || depth == 2 || depth == 4)))) return false;
+  if (ctype == 3 && depth > 8) return false; // palette indices are at most 8 bits
   const uint32_t channels = ctype == 0 ? 1u : ctype == 2 ? 3u : ctype == 3 ? 1u : ctype == 4 ? 2u : ctype == 6 ? 4u : 0u;
   if (!channels || (ctype == 3 && plte.empty())) return false;
   const size_t bpp = std::max<size_t>(1, channels * depth / 8), stride = ((size_t)w * channels * depth + 7) / 8;
+  if ((stride + 1) * (size_t)h > idat.size() * 1040u + 65536u) return false; // deflate cannot expand by more than ~1032:1
   std::vector<uint8_t> raw((stride + 1) * h);
   uLongf rawLen = (uLongf)raw.size();
   if (uncompress(raw.data(), &rawLen, idat.data(), (uLong)idat.size()) != Z_OK || rawLen != raw.size()) return false;
@@ -144,8 +156,10 @@ bool loadImageFile(const char* path, bool srgbToLinear, uint32_t& w, uint32_t& h
   std::vector<uint8_t> d;
   { uint8_t buf[65536]; size_t n; while ((n = fread(buf, 1, sizeof(buf), f)) > 0) d.insert(d.end(), buf, buf + n); }
   fclose(f);
-  if (d.size() >= 8 && d[0] == 0x89 && d[1] == 'P') return decodePng(d, srgbToLinear, w, h, out);
-  return decodeHdrOrPfm(d, w, h, out);
+  try {
+    if (d.size() >= 8 && d[0] == 0x89 && d[1] == 'P') return decodePng(d, srgbToLinear, w, h, out);
+    return decodeHdrOrPfm(d, w, h, out);
+  } catch (const std::exception&) { return false; } // allocation failure: the caller reports "cannot decode"
 }
 
 } // namespace gi

@@ -151,3 +151,43 @@ def test_png_decoder(tmp_path):
     assert np.array_equal(got[..., 3], np.where(idx == 1, np.float32(128 / 255.0), np.float32(1.0)).astype(np.float32))
     open(tmp_path / "bad.png", "wb").write(b"\x89PNG\r\n\x1a\nxxxx")
     assert L.giCDebugDecodeImage(str(tmp_path / "bad.png").encode(), 0, None, None, None, 0) == 0
+
+
+def test_image_decoders_survive_corrupt_files(tmp_path):
+    """Image files are untrusted input: truncated, bit-flipped, spliced and size-bombed .png / .hdr / .pfm files are either decoded or
+    refused -- never a crash, an uncaught exception or an allocation sized by a corrupt header (giCDebugDecodeImage needs no device)."""
+    L = capi.load_library()
+    rng = np.random.default_rng(0)
+    _write_png(tmp_path / "a.png", rng.integers(0, 255, (9, 7, 4)).astype(np.uint8), 6, 8, [0, 1, 2, 3, 4])
+    with open(tmp_path / "a.hdr", "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 5 +X 9\n" + rng.integers(1, 255, 5 * 9 * 4).astype(np.uint8).tobytes())
+    with open(tmp_path / "a.pfm", "wb") as f:
+        f.write(b"PF\n6 4\n-1.0\n" + rng.random(6 * 4 * 3).astype(np.float32).tobytes())
+
+    def decode(path):
+        w, h = C.c_uint32(), C.c_uint32()
+        ok = L.giCDebugDecodeImage(str(path).encode(), 1, C.byref(w), C.byref(h), None, 0)
+        if ok and w.value * h.value < 1 << 20:
+            buf = (C.c_float * (w.value * h.value * 4))()
+            ok = L.giCDebugDecodeImage(str(path).encode(), 1, C.byref(w), C.byref(h), buf, len(buf))
+        return bool(ok)
+    for name in ("a.png", "a.hdr", "a.pfm"):
+        assert decode(tmp_path / name)
+        blob = open(tmp_path / name, "rb").read()
+        for it in range(400):
+            b = bytearray(blob)
+            if it % 4 == 0:
+                b = b[:rng.integers(0, len(b))]
+            elif it % 4 == 1:
+                for _ in range(rng.integers(1, 6)):
+                    b[rng.integers(0, len(b))] = rng.integers(0, 256)
+            elif it % 4 == 2:
+                i = rng.integers(0, len(b)); b[i:i] = bytes(rng.integers(0, 256, rng.integers(1, 40)).astype(np.uint8))
+            else:
+                i = rng.integers(0, max(1, len(b) - 4)); b[i:i + 4] = bytes([255, 255, 255, 127])
+            p = tmp_path / ("m" + name[1:])
+            open(p, "wb").write(bytes(b))
+            decode(p)  # must return
+    for bomb in (b"#?RADIANCE\n\n-Y 60000 +X 60000\n", b"PF\n2000000000 2000000000\n-1.0\n"):
+        open(tmp_path / "bomb.hdr", "wb").write(bomb + b"\0" * 64)
+        assert not decode(tmp_path / "bomb.hdr")

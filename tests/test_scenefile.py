@@ -80,6 +80,14 @@ def test_c_harness_compiles_and_parses(tmp_path):
     assert f"{len(desc.textures)} textures, {len(desc.materials)} materials, {len(desc.meshes)} meshes, {tris} triangles" in out.stdout
     assert "dome 1, settings 1 (96x54 spp 4 bounces 6)" in out.stdout
     blob = open(tmp_path / "s.gscn", "rb").read()
+    rng = np.random.default_rng(1)
+    for it in range(60):  # corrupt counts / fields: parsed or refused (exit 0 or 1), never a crash
+        b = bytearray(blob)
+        i = int(rng.integers(0, min(len(b) - 4, 3000))) & ~3
+        b[i:i + 4] = bytes([255, 255, 255, 127]) if it % 2 else bytes(rng.integers(0, 256, 4).astype(np.uint8))
+        open(tmp_path / "fuzz.gscn", "wb").write(bytes(b))
+        res = subprocess.run([exe, str(tmp_path / "fuzz.gscn"), "--info"], capture_output=True, text=True)
+        assert res.returncode in (0, 1), res.returncode
     for cut in (3, 40, len(blob) // 2, len(blob) - 1):  # truncated files are refused, never read out of bounds
         open(tmp_path / "cut.gscn", "wb").write(blob[:cut])
         bad = subprocess.run([exe, str(tmp_path / "cut.gscn"), "--info"], capture_output=True, text=True)

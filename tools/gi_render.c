@@ -138,7 +138,9 @@ int main(int argc, char** argv)
 
   /* textures */
   const uint32_t nTex = rd_u32(&r);
+  if (nTex > (r.n - r.p) / 8u) return fail("corrupt .gscn file (texture count)");
   GiCTexture** textures = (GiCTexture**)calloc(nTex ? nTex : 1, sizeof *textures);
+  if (!textures) return fail("out of memory");
   for (uint32_t t = 0; t < nTex && !r.bad; t++) {
     GiCTextureDesc td;
     td.width = rd_u32(&r); td.height = rd_u32(&r);
@@ -147,7 +149,9 @@ int main(int argc, char** argv)
   }
   /* materials */
   const uint32_t nMat = rd_u32(&r);
+  if (nMat > (r.n - r.p) / 8u) return fail("corrupt .gscn file (material count)");
   GiCMaterial** materials = (GiCMaterial**)calloc(nMat ? nMat : 1, sizeof *materials);
+  if (!materials) return fail("out of memory");
   for (uint32_t m = 0; m < nMat && !r.bad; m++) {
     char* name = rd_str(&r);
     GiCMaterialDesc md;
@@ -190,7 +194,9 @@ int main(int argc, char** argv)
   }
   /* meshes */
   const uint32_t nMesh = rd_u32(&r);
+  if (nMesh > (r.n - r.p) / 8u) return fail("corrupt .gscn file (mesh count)");
   GiCMesh** meshes = (GiCMesh**)calloc(nMesh ? nMesh : 1, sizeof *meshes);
+  if (!meshes) return fail("out of memory");
   uint64_t triangles = 0, instancedTriangles = 0;
   for (uint32_t m = 0; m < nMesh && !r.bad; m++) {
     char* name = rd_str(&r);
@@ -220,8 +226,10 @@ int main(int argc, char** argv)
     }
     for (int which = 0; which < 2; which++) { /* mesh primvars, then instancer primvars */
       const uint32_t nPv = rd_u32(&r);
+      if (nPv > (r.n - r.p) / 16u) { r.bad = 1; break; }
       GiCPrimvarData* pv = (GiCPrimvarData*)calloc(nPv ? nPv : 1, sizeof *pv);
       char** names = (char**)calloc(nPv ? nPv : 1, sizeof *names);
+      if (!pv || !names) return fail("out of memory");
       for (uint32_t k = 0; k < nPv && !r.bad; k++) {
         names[k] = rd_str(&r);
         pv[k].name = names[k]; pv[k].type = rd_i32(&r); pv[k].interpolation = rd_i32(&r);
@@ -249,6 +257,7 @@ int main(int argc, char** argv)
     nLights[kind] = rd_u32(&r);
     if (nLights[kind] > (r.n - r.p) / (floats[kind] * 4u)) { r.bad = 1; break; }
     lights[kind] = (void**)calloc(nLights[kind] ? nLights[kind] : 1, sizeof(void*));
+    if (!lights[kind]) return fail("out of memory");
     for (uint32_t l = 0; l < nLights[kind] && !r.bad; l++) {
       float v[16];
       rd_f32(&r, v, floats[kind]);
