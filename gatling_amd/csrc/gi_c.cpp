@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -389,14 +390,20 @@ void giCDestroyMaterial(GiCMaterial* mat)
 // ---------------------------------------------------------------------------------------------------------------
 // textures [ext]: decoded pixels in, device copies made with the next scene build (TextureManager.cpp:100-275 minus imgio)
 // ---------------------------------------------------------------------------------------------------------------
+static GiCTexture* createTextureImpl(GiCScene* scene, const GiCTextureDesc* desc);
 GiCTexture* giCCreateTexture(GiCScene* scene, const GiCTextureDesc* desc)
 {
+  try { return createTextureImpl(scene, desc); }
+  catch (const std::exception& e) { setError(std::string("giCCreateTexture: ") + e.what()); return nullptr; }
+}
+static GiCTexture* createTextureImpl(GiCScene* scene, const GiCTextureDesc* desc)
+{
   if (!scene || !desc || !desc->rgba || desc->width == 0 || desc->height == 0) { setError("giCCreateTexture: bad arguments"); return nullptr; }
-  auto* t = new GiCTexture{scene, desc->width, desc->height, std::vector<float>(desc->rgba, desc->rgba + (size_t)desc->width * desc->height * 4)};
+  std::unique_ptr<GiCTexture> t(new GiCTexture{scene, desc->width, desc->height, std::vector<float>(desc->rgba, desc->rgba + (size_t)desc->width * desc->height * 4)});
   std::lock_guard<std::mutex> g(scene->mutex);
-  scene->textures.push_back(t);
+  scene->textures.push_back(t.get());
   scene->dirty |= DIRTY_MATERIALS | DIRTY_FRAMEBUFFER;
-  return t;
+  return t.release();
 }
 
 // File textures are shared: a path that is already loaded (and still alive) yields the same texture with one more reference,
@@ -452,23 +459,29 @@ int giCSetMaterialTexture(GiCMaterial* mat, int32_t input, const GiCTextureBindi
   return GI_C_OK;
 }
 
+static GiCMesh* createMeshImpl(GiCScene* scene, const GiCMeshDesc* d);
 GiCMesh* giCCreateMesh(GiCScene* scene, const GiCMeshDesc* d)
+{
+  try { return createMeshImpl(scene, d); }
+  catch (const std::exception& e) { setError(std::string("giCCreateMesh: ") + e.what()); return nullptr; }
+}
+static GiCMesh* createMeshImpl(GiCScene* scene, const GiCMeshDesc* d)
 {
   if (!scene || !d) { setError("giCCreateMesh: null argument"); return nullptr; }
   if ((d->faceCount && !d->faces) || (d->vertexCount && !d->vertices)) { setError("giCCreateMesh: null arrays"); return nullptr; }
   for (uint32_t i = 0; i < d->faceCount; i++)
     for (int k = 0; k < 3; k++)
       if (d->faces[i].v_i[k] >= d->vertexCount) { setError("giCCreateMesh: face index out of range"); return nullptr; }
-  GiCMesh* m = new GiCMesh();
+  std::unique_ptr<GiCMesh> m(new GiCMesh());
   m->scene = scene; m->name = d->name ? d->name : "";
   m->vertices.assign(d->vertices, d->vertices + d->vertexCount); // copies, like giProcessMeshData (Gi.cpp:628)
   m->faces.assign(d->faces, d->faces + d->faceCount);
   if (d->faceIds) m->faceIds.assign(d->faceIds, d->faceIds + d->faceCount);
   m->id = d->id; m->doubleSided = d->isDoubleSided != 0; m->flipFacing = d->isLeftHanded != 0; m->maxFaceId = d->maxFaceId;
   std::lock_guard<std::mutex> g(scene->mutex);
-  scene->meshes.push_back(m);
+  scene->meshes.push_back(m.get());
   scene->dirty |= DIRTY_BVH | DIRTY_FRAMEBUFFER;
-  return m;
+  return m.release();
 }
 
 void giCSetMeshTransform(GiCMesh* mesh, const float* mat4x4)
@@ -644,7 +657,13 @@ void giCSetDiskLightDiffuseSpecular(GiCDiskLight* l, float d, float s) { l->scen
 // ---------------------------------------------------------------------------------------------------------------
 // scene data (primvars): Gi.h:76-92, 134, 213
 // ---------------------------------------------------------------------------------------------------------------
+static int setPrimvarsImpl(GiCMesh* mesh, std::vector<GiCPrimvar>& dst, uint32_t count, const GiCPrimvarData* pv);
 static int setPrimvars(GiCMesh* mesh, std::vector<GiCPrimvar>& dst, uint32_t count, const GiCPrimvarData* pv)
+{
+  try { return setPrimvarsImpl(mesh, dst, count, pv); }
+  catch (const std::exception& e) { setError(std::string("giCSetMesh*Primvars: ") + e.what()); return GI_C_ERROR; }
+}
+static int setPrimvarsImpl(GiCMesh* mesh, std::vector<GiCPrimvar>& dst, uint32_t count, const GiCPrimvarData* pv)
 {
   if (!mesh || (count && !pv)) { setError("giCSetMesh*Primvars: bad arguments"); return GI_C_ERROR; }
   std::vector<GiCPrimvar> v;
@@ -1027,7 +1046,14 @@ hipEvent_t poolEvent(GiCScene* s, size_t idx)
 // ---------------------------------------------------------------------------------------------------------------
 // giCRender
 // ---------------------------------------------------------------------------------------------------------------
+// C++ exceptions (allocation failure on a huge scene) must not cross the C ABI: the heavy entry points run through a guarded wrapper
+static int giCRenderImpl(const GiCRenderParams* params);
 extern "C" int giCRender(const GiCRenderParams* params)
+{
+  try { return giCRenderImpl(params); }
+  catch (const std::exception& e) { setError(std::string("giCRender: ") + e.what()); return GI_C_ERROR; }
+}
+static int giCRenderImpl(const GiCRenderParams* params)
 {
   if (!g_ctx.initialized) { setError("giCRender before giCInitialize"); return GI_C_ERROR; }
   if (!params || !params->scene) { setError("giCRender: null params/scene"); return GI_C_ERROR; }
@@ -1323,7 +1349,13 @@ extern "C" int giCRender(const GiCRenderParams* params)
 // ---------------------------------------------------------------------------------------------------------------
 // giCTraceRays: closest hits through the device traversal kernel (parity tests of the BVH8 path)
 // ---------------------------------------------------------------------------------------------------------------
+static int giCTraceRaysImpl(GiCScene* s, uint32_t count, const float* origins, const float* dirs, float tMin, float tMax, float* outTUV, int32_t* outInstPrim);
 extern "C" int giCTraceRays(GiCScene* s, uint32_t count, const float* origins, const float* dirs, float tMin, float tMax, float* outTUV, int32_t* outInstPrim)
+{
+  try { return giCTraceRaysImpl(s, count, origins, dirs, tMin, tMax, outTUV, outInstPrim); }
+  catch (const std::exception& e) { setError(std::string("giCTraceRays: ") + e.what()); return -1; }
+}
+static int giCTraceRaysImpl(GiCScene* s, uint32_t count, const float* origins, const float* dirs, float tMin, float tMax, float* outTUV, int32_t* outInstPrim)
 {
   if (!g_ctx.initialized || !s || (count && (!origins || !dirs || !outTUV || !outInstPrim))) { setError("giCTraceRays: bad arguments"); return -1; }
   if (count == 0) return 0;
