@@ -310,7 +310,7 @@ class Scene:
         return full[r0:r1:row_stride].copy()
 
     AOVS = {"normal": (1, FORMAT_FLOAT32_VEC4), "nee": (2, FORMAT_FLOAT32_VEC4), "barycentrics": (3, FORMAT_FLOAT32_VEC4),
-            "texcoords": (4, FORMAT_FLOAT32_VEC4), "bounces": (5, FORMAT_FLOAT32_VEC4), "opacity": (7, FORMAT_FLOAT32_VEC4),
+            "texcoords": (4, FORMAT_FLOAT32_VEC4), "bounces": (5, FORMAT_FLOAT32_VEC4), "clockCycles": (6, FORMAT_FLOAT32_VEC4), "opacity": (7, FORMAT_FLOAT32_VEC4),
             "tangents": (8, FORMAT_FLOAT32_VEC4), "bitangents": (9, FORMAT_FLOAT32_VEC4), "thinWalled": (10, FORMAT_FLOAT32_VEC4),
             "objectId": (11, FORMAT_INT32), "depth": (12, FORMAT_FLOAT32), "faceId": (13, FORMAT_INT32), "instanceId": (14, FORMAT_INT32),
             "doubleSided": (15, FORMAT_FLOAT32_VEC4), "albedo": (16, FORMAT_FLOAT32_VEC4)}

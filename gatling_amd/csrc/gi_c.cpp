@@ -135,6 +135,16 @@ void decodeDirection(uint32_t e, float out[3])
   out[0] = x * inv; out[1] = y * inv; out[2] = z * inv;
 }
 
+// Turbo colour map (A. Mikhailov's polynomial fit of Google's Turbo look-up table; the reference indexes the 256-entry table,
+// Gi.cpp:338-341).  Same association as the oracle's turbo_colormap.
+void turboColormap(float x, float* rgb)
+{
+  const float x2 = x * x, x3 = x2 * x, x4 = x2 * x2, x5 = x4 * x;
+  rgb[0] = (((0.13572138f + 4.61539260f * x) + -42.66032258f * x2) + 132.13108234f * x3) + (-152.94239396f * x4 + 59.28637943f * x5);
+  rgb[1] = (((0.09140261f + 2.19418839f * x) + 4.84296658f * x2) + -14.18503333f * x3) + (4.27729857f * x4 + 2.82956604f * x5);
+  rgb[2] = (((0.10667330f + 12.64194608f * x) + -60.58204836f * x2) + 110.36276771f * x3) + (-89.90310912f * x4 + 27.34824973f * x5);
+}
+
 // per-material constants of the closed-form BSDFs (DESIGN.md "Materials"); same fp32 formulas as the oracle's ups_params
 float cutoutOpacity(const MaterialRec& m) // same rule as the oracle's cutout_opacity
 {
@@ -288,6 +298,7 @@ struct GiCScene {
   DeviceBuffer<Slot> slots;
   DeviceBuffer<float> media; // per-slot medium stack + walkSegmentPdf (mediumStackSize > 0)
   DeviceBuffer<F4> scratchColor; DeviceBuffer<unsigned long long> neeKey; // NEE / Bounces AOVs bound without / with the colour AOV
+  DeviceBuffer<uint32_t> pathSegments;                                    // ClockCycles AOV (cost proxy)
   DeviceBuffer<F4> sampleBuf; // per-sample colours of the current batch, [sample][pixel] (rgb, -)
   DeviceBuffer<F4> accum;        // per-pixel running sum across batches
   DeviceBuffer<uint32_t> qSlot[Q_COUNT]; // NSHARD segments of queueCap records each
@@ -355,7 +366,7 @@ void giCDestroyScene(GiCScene* s)
   for (auto* b : s->dTexels) { b->release(); delete b; }
   s->dTexels.clear(); s->dTextures.release(); s->dMeshes.release(); s->dSceneData.release();
   s->dMaterials.release(); s->dSphere.release(); s->dDistant.release(); s->dRect.release(); s->dDisk.release();
-  s->slots.release(); s->media.release(); s->scratchColor.release(); s->neeKey.release(); s->sampleBuf.release(); s->accum.release();
+  s->slots.release(); s->media.release(); s->scratchColor.release(); s->neeKey.release(); s->pathSegments.release(); s->sampleBuf.release(); s->accum.release();
   for (uint32_t q = 0; q < Q_COUNT; q++) { s->qSlot[q].release(); s->qA[q].release(); s->qB[q].release(); s->qC[q].release(); }
   s->dCounters.release();
   if (s->hCounters) (void)hipHostFree(s->hCounters);
@@ -1098,10 +1109,10 @@ static int giCRenderImpl(const GiCRenderParams* params)
   if (!rs.progressiveAccumulation) s->dirty |= DIRTY_FRAMEBUFFER;
   if (s->dirty & DIRTY_FRAMEBUFFER) { s->sampleOffset = 0; s->dirty &= ~DIRTY_FRAMEBUFFER; }
 
-  // --- non-colour AOV bindings (Gi.h:36-56); ClockCycles is not produced: it keeps its clear value.  NEE and Bounces follow
-  // whole paths: they are filled by the colour pass (clear value first), see PathState.
+  // --- non-colour AOV bindings (Gi.h:36-56).  NEE, Bounces and ClockCycles follow whole paths: they are filled by the colour pass
+  // (clear value first), see PathState.  ClockCycles is a deterministic cost proxy (ray segments per pixel), heat-mapped like the reference.
   AovTargets aovT{}; bool anyAov = false;
-  GiCRenderBuffer* neeRb = nullptr; GiCRenderBuffer* bouncesRb = nullptr;
+  GiCRenderBuffer* neeRb = nullptr; GiCRenderBuffer* bouncesRb = nullptr; GiCRenderBuffer* clockRb = nullptr;
   std::vector<GiCRenderBuffer*> aovBuffers;
   for (uint32_t i = 0; i < params->aovBindingCount; i++) {
     const GiCAovBinding& b = params->aovBindings[i];
@@ -1125,6 +1136,7 @@ static int giCRenderImpl(const GiCRenderParams* params)
       case GI_C_AOV_INSTANCE_ID: aovT.instanceId = vec ? nullptr : reinterpret_cast<int32_t*>(rb->deviceMem); break;
       case GI_C_AOV_NEE: if (vec) neeRb = rb; produced = false; break;
       case GI_C_AOV_BOUNCES: if (vec) bouncesRb = rb; produced = false; break;
+      case GI_C_AOV_CLOCK_CYCLES: if (vec) clockRb = rb; produced = false; break;
       default: produced = false; break;
     }
     if (produced) {
@@ -1137,10 +1149,10 @@ static int giCRenderImpl(const GiCRenderParams* params)
       HIP_TRY(hipMemcpyAsync(rb->deviceMem, rb->hostMem, rb->size, hipMemcpyHostToDevice, st));
     }
   }
-  if (!colorBinding && !anyAov && !neeRb && !bouncesRb) { HIP_TRY(hipStreamSynchronize(st)); return GI_C_OK; }
+  if (!colorBinding && !anyAov && !neeRb && !bouncesRb && !clockRb) { HIP_TRY(hipStreamSynchronize(st)); return GI_C_OK; }
   GiCRenderBuffer dummyColor{};
   GiCRenderBuffer* colorRb = colorBinding ? colorBinding->renderBuffer : nullptr;
-  if (!colorRb && (neeRb || bouncesRb)) { // the path-following debug AOVs need the colour pass: render it into a scratch buffer
+  if (!colorRb && (neeRb || bouncesRb || clockRb)) { // the path-following debug AOVs need the colour pass: render it into a scratch buffer
     if (s->scratchColor.alloc((size_t)width * height)) return GI_C_ERROR;
     dummyColor.width = width; dummyColor.height = height; dummyColor.stride = 16; dummyColor.size = (size_t)width * height * 16;
     dummyColor.deviceMem = s->scratchColor.ptr; dummyColor.deviceOnly = true;
@@ -1259,6 +1271,11 @@ static int giCRenderImpl(const GiCRenderParams* params)
       ps.neeKey = s->neeKey.ptr;
     }
     if (bouncesRb) ps.bouncesAov = reinterpret_cast<F4*>(bouncesRb->deviceMem);
+    if (clockRb) {
+      if (s->pathSegments.alloc(pixels)) return GI_C_ERROR;
+      HIP_TRY(hipMemsetAsync(s->pathSegments.ptr, 0, pixels * sizeof(uint32_t), st));
+      ps.pathSegments = s->pathSegments.ptr;
+    }
     view.mediumStackSize = rs.mediumStackSize;
     QueueSet qs = makeQueueSet(s);
     F4* colorOut = reinterpret_cast<F4*>(colorRb->deviceMem);
@@ -1307,6 +1324,24 @@ static int giCRenderImpl(const GiCRenderParams* params)
       launchAccumulate(st, U, s->sampleBuf.ptr, s->accum.ptr, colorOut, batch == 0, batch + 1 == numBatches);
     }
     if (neeRb) launchResolveNee(st, U, s->neeKey.ptr, reinterpret_cast<F4*>(neeRb->deviceMem), (uint32_t)pixels);
+    if (clockRb) { // ClockCycles: per-pixel cost -> heat map normalised to the frame maximum, on the host like _EncodeRenderBufferAsHeatmap (Gi.cpp:327-343)
+      std::vector<uint32_t> counts(pixels);
+      HIP_TRY(hipMemcpyAsync(counts.data(), s->pathSegments.ptr, pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      float maxValue = 0.0f;
+      for (uint32_t c : counts) maxValue = std::max(maxValue, (float)c);
+      float* img = reinterpret_cast<float*>(clockRb->hostMem);
+      for (size_t p = 0; p < pixels; p++) {
+        const size_t y = rowBegin + (p / width) * rowStride, x = p % width;
+        float* o = img + (y * width + x) * 4;
+        if (maxValue > 0.0f) {
+          const int idx = std::min((int)(((float)counts[p] / maxValue) * 255.0), 255);
+          turboColormap((float)idx / 255.0f, o);
+          o[3] = 255.0f;
+        } else { o[0] = (float)counts[p]; o[1] = 0.0f; o[2] = 0.0f; }
+      }
+      HIP_TRY(hipMemcpyAsync(clockRb->deviceMem, clockRb->hostMem, clockRb->size, hipMemcpyHostToDevice, st));
+    }
     for (GiCRenderBuffer* rb : {neeRb, bouncesRb}) {
       if (!rb || rb->deviceOnly) continue;
       HIP_TRY(copyTileRows(rb, rb->stride));

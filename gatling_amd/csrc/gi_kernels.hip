@@ -127,6 +127,7 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st,
           F4* dst = &st.bouncesAov[tile_to_image_pixel(U, f2u(id.x))];
           dst->x = c.x; dst->y = c.y; dst->z = c.z;
         }
+        if (st.pathSegments) atomicAdd(&st.pathSegments[f2u(id.x)], (f2u(S->thr.w) + ((entry & REGEN_MISSED) ? 1u : 0u)) & 0x00000fffu); // integer sum: order-free
         float mv = fmax2(rad.x, fmax2(rad.y, rad.z));
         if (mv > U.maxSampleValue) rad = rad * (U.maxSampleValue / mv);
         // one aligned 16-byte store: a 12-byte record straddles DRAM sectors and costs two read-modify-writes

@@ -186,6 +186,7 @@ constexpr uint32_t VOLUME_MISS = 0xfffffffeu; // "triangle" id of a hit record t
 struct PathState {
   Slot* slots; float* media; uint32_t mediaStride;
   unsigned long long* neeKey; uint32_t neeSampleBase; F4* bouncesAov;
+  uint32_t* pathSegments; // ClockCycles AOV (cost proxy): per tile pixel, the ray segments of all its samples so far (k_raygen adds a path's count when it retires)
 };
 
 // Work queues.  Every queue is split into NSHARD segments (segment s holds records [s*cap, s*cap + count[q][s])):

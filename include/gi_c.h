@@ -136,8 +136,10 @@ typedef struct GiCRenderParams {
   GiCRenderSettings renderSettings;
   GiCScene* scene;
   /* Non-colour AOVs: Normal, Barycentrics, Texcoords, Opacity, Tangents, Bitangents, ThinWalled, ObjectId, Depth, FaceId, InstanceId,
-   * DoubleSided and Albedo are produced (vec3 AOVs need Float32Vec4 buffers, Depth Float32, ids Int32 -- Gi.cpp:302-316); NEE,
-   * Bounces and ClockCycles keep their clear value.  Without a Color binding no paths are traced (rp_main.miss:70-72). */
+   * DoubleSided and Albedo are produced by a primary-hit pass (vec3 AOVs need Float32Vec4 buffers, Depth Float32, ids Int32 --
+   * Gi.cpp:302-316); NEE, Bounces and ClockCycles follow whole paths and are filled by the colour pass (which then runs even without a
+   * Color binding).  ClockCycles is a Turbo heat map, normalised to the frame maximum, alpha 255 (_EncodeRenderBufferAsHeatmap,
+   * Gi.cpp:327-343) of a deterministic cost proxy -- the ray segments traced for the pixel -- instead of the shader clock. */
   /* [ext] multi-GPU sharding: render only image rows [rowBegin,rowEnd) of the full image whose size is the
    * render buffers' size; rowEnd == 0 means "all rows".  RNG streams use the global pixel index so an N-way
    * split is bit-identical to the single-GPU image. */

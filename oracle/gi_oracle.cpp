@@ -1370,7 +1370,7 @@ inline V3 colormap_inferno(float t)
   const V3 c6 = v3(25.13112622477341f, -12.24266895238567f, -23.07032500287172f);
   return c0 + (c1 + (c2 + (c3 + (c4 + (c5 + c6 * t) * t) * t) * t) * t) * t;
 }
-struct PathDebug { int lastNee = -1; uint32_t lastBounces = 0; }; // NEE / Bounces AOV sources (rp_main.rgen:431-435, 483-486)
+struct PathDebug { int lastNee = -1; uint32_t lastBounces = 0; uint32_t totalSegments = 0; }; // NEE / Bounces AOV sources (rp_main.rgen:431-435, 483-486)
 
 void render_pixel(const Frame& F, uint32_t px, uint32_t py, const float* prevColor, float* out, OrcCounters& cnt, PathDebug* dbg = nullptr)
 {
@@ -1467,7 +1467,7 @@ void render_pixel(const Frame& F, uint32_t px, uint32_t py, const float* prevCol
       }
       pl.bitfield++; // :480
     }
-    if (dbg) dbg->lastBounces = pl.bitfield & BOUNCES_MASK; // :483-486
+    if (dbg) { dbg->lastBounces = pl.bitfield & BOUNCES_MASK; dbg->totalSegments += dbg->lastBounces; } // :483-486
     V3 rad = pl.radiance; // :489-498
     float mv = fmax2(rad.x, fmax2(rad.y, rad.z));
     if (mv > rs.maxSampleValue) rad = rad * (rs.maxSampleValue / mv);
@@ -1644,16 +1644,26 @@ int orc_render(const OrcScene* scene, const OrcCamera* camera, const OrcSettings
   return 0;
 }
 
+// Turbo colour map, polynomial fit (the reference indexes Google's 256-entry table, Gi.cpp:338-341)
+static void turbo_colormap(float x, float* rgb)
+{
+  const float x2 = x * x, x3 = x2 * x, x4 = x2 * x2, x5 = x4 * x;
+  rgb[0] = (((0.13572138f + 4.61539260f * x) + -42.66032258f * x2) + 132.13108234f * x3) + (-152.94239396f * x4 + 59.28637943f * x5);
+  rgb[1] = (((0.09140261f + 2.19418839f * x) + 4.84296658f * x2) + -14.18503333f * x3) + (4.27729857f * x4 + 2.82956604f * x5);
+  rgb[2] = (((0.10667330f + 12.64194608f * x) + -60.58204836f * x2) + 110.36276771f * x3) + (-89.90310912f * x4 + 27.34824973f * x5);
+}
+
 int orc_render_aovs(const OrcScene* scene, const OrcCamera* camera, const OrcSettings* settings, const OrcRegion* region, OrcAovs* aovs)
 {
   if (!scene || !camera || !settings || !region || !aovs) return 1;
   Prepared P; prepare(scene, P);
   Frame F; make_frame(F, P, camera, settings, region);
+  std::vector<uint32_t> segments(aovs->clockCycles ? (size_t)(region->rowEnd - region->rowBegin) * F.width : 0);
   for (uint32_t y = region->rowBegin; y < region->rowEnd; y++)
     for (uint32_t x = 0; x < F.width; x++) {
       const size_t o = (size_t)(y - region->rowBegin) * F.width + x;
       render_pixel_aovs(F, x, y, o, *aovs);
-      if (aovs->nee || aovs->bounces) { // these two follow the whole paths of the colour pass
+      if (aovs->nee || aovs->bounces || aovs->clockCycles) { // these follow the whole paths of the colour pass
         PathDebug dbg; OrcCounters cnt{}; float colour[4];
         render_pixel(F, x, y, nullptr, colour, cnt, &dbg);
         uint32_t maxBounces = settings->maxBounces < BOUNCES_MASK ? settings->maxBounces : BOUNCES_MASK;
@@ -1662,8 +1672,21 @@ int orc_render_aovs(const OrcScene* scene, const OrcCamera* camera, const OrcSet
           V3 c = dbg.lastNee < 0 ? v3(aovs->clear[2]) : (dbg.lastNee ? v3(1, 0, 0) : v3(0, 1, 0));
           aovs->nee[4 * o] = c.x; aovs->nee[4 * o + 1] = c.y; aovs->nee[4 * o + 2] = c.z;
         }
+        if (aovs->clockCycles) segments[o] = dbg.totalSegments;
       }
     }
+  if (aovs->clockCycles) { // _EncodeRenderBufferAsHeatmap (Gi.cpp:327-343) over the cost proxy
+    float maxValue = 0.0f;
+    for (uint32_t c : segments) maxValue = fmax2(maxValue, (float)c);
+    for (size_t o = 0; o < segments.size(); o++) {
+      float* dst = aovs->clockCycles + 4 * o;
+      if (maxValue > 0.0f) {
+        int idx = (int)(((float)segments[o] / maxValue) * 255.0); if (idx > 255) idx = 255;
+        turbo_colormap((float)idx / 255.0f, dst);
+        dst[3] = 255.0f;
+      } else { dst[0] = (float)segments[o]; dst[1] = 0.0f; dst[2] = 0.0f; }
+    }
+  }
   return 0;
 }
 

@@ -195,6 +195,7 @@ typedef struct OrcAovs {
   int32_t* objectId; int32_t* faceId; int32_t* instanceId;
   float clear[17][4];
   float* nee; float* bounces;
+  float* clockCycles; /* cost proxy: ray segments of all samples of the pixel, heat-mapped (Turbo) against the region's maximum */
 } OrcAovs;
 float orc_atan2f(float y, float x);
 float orc_acosf(float x);

@@ -67,11 +67,11 @@ class OrcMesh(C.Structure):
 class OrcAovs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("normal", "barycentrics", "texcoords", "opacity", "tangents", "bitangents", "thinWalled",
                                           "doubleSided", "albedo", "depth", "objectId", "faceId", "instanceId")] + [("clear", (C.c_float * 4) * 17)] + \
-               [("nee", C.c_void_p), ("bounces", C.c_void_p)]
+               [("nee", C.c_void_p), ("bounces", C.c_void_p), ("clockCycles", C.c_void_p)]
 
 
 AOV_IDS = {"normal": 1, "barycentrics": 3, "texcoords": 4, "opacity": 7, "tangents": 8, "bitangents": 9, "thinWalled": 10, "objectId": 11,
-           "depth": 12, "faceId": 13, "instanceId": 14, "doubleSided": 15, "albedo": 16, "nee": 2, "bounces": 5}
+           "depth": 12, "faceId": 13, "instanceId": 14, "doubleSided": 15, "albedo": 16, "nee": 2, "bounces": 5, "clockCycles": 6}
 
 
 class OrcSphereLight(C.Structure):

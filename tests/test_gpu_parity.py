@@ -563,14 +563,19 @@ def test_nee_and_bounces_aovs(gi, orc, with_color):
     desc.rect_lights = [RectLight(origin=(0, 0, 0.9), t0=(1, 0, 0), t1=(0, -1, 0), base_emission=(10, 10, 10), width=0.7, height=0.5)]
     rs = RenderSettings(spp=5, max_bounces=7, next_event_estimation=True)
     clear = {"nee": (0.25, 0.5, 0.75, 0.0), "bounces": (0.0, 0.0, 0.0, 0.0)}
-    ref = orc.render_aovs(desc, rs, 80, 45, ["nee", "bounces"], clear_values=clear)
+    names = ["nee", "bounces", "clockCycles"]
+    ref = orc.render_aovs(desc, rs, 80, 45, names, clear_values=clear)
     sc = gi.Scene(desc)
     try:
-        got = sc.render_aovs(rs, 80, 45, ["nee", "bounces"], clear_values=clear, with_color=with_color)
+        got = sc.render_aovs(rs, 80, 45, names, clear_values=clear, with_color=with_color)
     finally:
         sc.close()
     for k in ("nee", "bounces"):
         assert np.array_equal(got[k][..., :3], ref[k][..., :3]), k
+    # ClockCycles: the per-pixel cost (here: ray segments of all samples, a deterministic proxy for the reference's shader clock) as a
+    # Turbo heat map normalised to the frame maximum, alpha 255 (_EncodeRenderBufferAsHeatmap, Gi.cpp:327-343)
+    assert np.array_equal(got["clockCycles"], ref["clockCycles"])
+    assert (got["clockCycles"][..., 3] == 255.0).all() and len(np.unique(got["clockCycles"][..., :3].reshape(-1, 3), axis=0)) > 8
     kinds = {tuple(v) for v in np.unique(ref["nee"][..., :3].reshape(-1, 3), axis=0).tolist()}
     assert (1.0, 0.0, 0.0) in kinds and (0.0, 1.0, 0.0) in kinds  # both outcomes occur in this scene
 
