@@ -4,14 +4,19 @@
 
 Measured on MI355X (r01): 3.74 M secondary rays (bounces 1-3 mixed): random order 341 us, sorted by octant 331, by origin triangle
 308, by (triangle, octant) 290, by (4x4x4 origin cell, octant) 298 -- at most -15 %, less than a sorting pass over the ray records
-costs (>= 60 us for 4 M rays at 5 TB/s); camera rays cost 37 ps/ray, secondary rays 77-91 ps/ray whatever their order."""
+costs (>= 60 us for 4 M rays at 5 TB/s); camera rays cost 37 ps/ray, secondary rays 77-91 ps/ray whatever their order.
+`... exp_ray_order.py soup 1000000` (k_trace_dyn, scene beyond LDS): random 2061 us, best order (16^3 Morton cell, octant) 1848 us."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.getcwd())
 from gatling_amd import capi
 from gatling_amd.scenes import cornell_box
 
-desc = cornell_box()
+if len(sys.argv) > 1 and sys.argv[1] == "soup":   # a scene beyond LDS: k_trace_dyn, incoherent node/triangle fetches
+    from gatling_amd.scenes import random_triangle_soup
+    desc = random_triangle_soup(int(sys.argv[2]) if len(sys.argv) > 2 else 1000000, seed=1234)
+else:
+    desc = cornell_box()
 sc = capi.Scene(desc)
 rng = np.random.default_rng(1)
 N = 4 << 20
@@ -63,8 +68,14 @@ octant = (S_d[:, 0] >= 0) * 1 + (S_d[:, 1] >= 0) * 2 + (S_d[:, 2] >= 0) * 4
 lo, hi = S_o.min(0), S_o.max(0)
 cell = np.clip(((S_o - lo) / (hi - lo + 1e-9) * 4).astype(np.int64), 0, 3)
 morton = cell[:, 0] * 16 + cell[:, 1] * 4 + cell[:, 2]
+cell16 = np.clip(((S_o - lo) / (hi - lo + 1e-9) * 16).astype(np.int64), 0, 15)
+def part1by2(v):
+    v = (v | (v << 8)) & 0x00f00f; v = (v | (v << 4)) & 0x0c30c3; v = (v | (v << 2)) & 0x249249
+    return v
+morton16 = part1by2(cell16[:, 0]) | (part1by2(cell16[:, 1]) << 1) | (part1by2(cell16[:, 2]) << 2)
 orders = {"random mix": np.arange(len(S_o)), "by octant": np.argsort(octant, kind="stable"), "by origin triangle": np.argsort(S_t, kind="stable"),
-          "by triangle, octant": np.lexsort((octant, S_t)), "by 4x4x4 cell, octant": np.lexsort((octant, morton)), "by octant, cell": np.lexsort((morton, octant))}
+          "by triangle, octant": np.lexsort((octant, S_t)), "by 4x4x4 cell, octant": np.lexsort((octant, morton)), "by octant, cell": np.lexsort((morton, octant)),
+          "by 16^3 morton cell, octant": np.lexsort((octant, morton16)), "by octant, 16^3 morton": np.lexsort((morton16, octant))}
 for name, idx in orders.items():
     sc.trace_rays(S_o[idx].astype(np.float32), S_d[idx].astype(np.float32))
     print("order:", name, len(idx), flush=True)
