@@ -428,7 +428,7 @@ GiCTexture* giCCreateTextureFromFile(GiCScene* scene, const char* filePath, int3
     for (GiCTexture* t : scene->textures) if (t->cacheKey == key) { t->refs++; return t; }
   }
   uint32_t w = 0, h = 0; std::vector<float> px;
-  if (!loadImageFile(filePath, srgbToLinear != 0, w, h, px)) { setError("giCCreateTextureFromFile: cannot decode the file (.png, .hdr and .pfm are supported)"); return nullptr; }
+  if (!loadImageFile(filePath, srgbToLinear != 0, w, h, px)) { setError("giCCreateTextureFromFile: cannot decode the file (.png, baseline .jpg, .hdr and .pfm are supported)"); return nullptr; }
   GiCTextureDesc td{w, h, px.data()};
   GiCTexture* t = giCCreateTexture(scene, &td);
   if (t) { std::lock_guard<std::mutex> g(scene->mutex); t->cacheKey = key; }
@@ -711,7 +711,7 @@ GiCDomeLight* giCCreateDomeLight(GiCScene* scene, const char* filePath)
     l->texture = giCCreateTexture(scene, &td);
     l->ownsTexture = l->texture != nullptr;
   } else if (!l->filePath.empty()) {
-    fprintf(stderr, "[gatling_gi] unable to load dome light texture at '%s' (.hdr, .pfm and .png are decoded in-library)\n", l->filePath.c_str());
+    fprintf(stderr, "[gatling_gi] unable to load dome light texture at '%s' (.hdr, .pfm, .png and baseline .jpg are decoded in-library)\n", l->filePath.c_str());
   }
   return l;
 }

@@ -7,7 +7,7 @@
 
 namespace gi {
 
-// .hdr (Radiance RGBE), .pfm, .png (8/16-bit gray, gray+alpha, RGB, RGBA, palette; non-interlaced).  srgbToLinear applies the sRGB EOTF
+// .hdr (Radiance RGBE), .pfm, .png (8/16-bit gray, gray+alpha, RGB, RGBA, palette; non-interlaced), .jpg (baseline / extended sequential, Huffman).  srgbToLinear applies the sRGB EOTF
 // to the colour channels of 8-bit PNGs (UsdUVTexture sourceColorSpace = sRGB).
 bool loadImageFile(const char* path, bool srgbToLinear, uint32_t& width, uint32_t& height, std::vector<float>& rgba);
 

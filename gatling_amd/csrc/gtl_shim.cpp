@@ -241,7 +241,7 @@ namespace gtl
       if (!primvars[slot].empty()) giCSetMaterialPrimvarInput(h, slot, primvars[slot].c_str());
       const ImageInput& im = images[slot];
       if (im.file.empty()) continue;
-      GiCTexture* t = giCCreateTextureFromFile(scene->h, im.file.c_str(), im.srgb ? 1 : 0); // .png / .hdr / .pfm; others: the input keeps its constant
+      GiCTexture* t = giCCreateTextureFromFile(scene->h, im.file.c_str(), im.srgb ? 1 : 0); // .png / .jpg / .hdr / .pfm; others: the input keeps its constant
       if (!t) continue;
       mat->textures.push_back(t);
       GiCTextureBinding b{t, im.wrapS, im.wrapT, im.channel, {im.scale[0], im.scale[1], im.scale[2], im.scale[3]}, {im.bias[0], im.bias[1], im.bias[2], im.bias[3]}};

@@ -193,7 +193,8 @@ typedef struct GiCMaterialDesc {
 typedef struct GiCTexture GiCTexture;
 typedef struct GiCTextureDesc { uint32_t width, height; const float* rgba; } GiCTextureDesc;
 GiCTexture* giCCreateTexture(GiCScene* scene, const GiCTextureDesc* desc);
-/* [ext] decodes .png (8/16-bit, non-interlaced; srgbToLinear applies the sRGB EOTF to 8-bit colour), .hdr or .pfm in-library;
+/* [ext] decodes .png (8/16-bit, non-interlaced), baseline / extended-sequential .jpg (Huffman, 8-bit, grey or YCbCr, any subsampling,
+ * restart intervals; progressive files are refused), .hdr or .pfm in-library; srgbToLinear applies the sRGB EOTF to 8-bit colour;
  * a (path, srgbToLinear) pair that is already loaded and alive returns the SAME handle with one more reference (the file cache of
  * TextureManager.cpp:100-150); giCDestroyTexture releases one reference */
 GiCTexture* giCCreateTextureFromFile(GiCScene* scene, const char* filePath, int32_t srgbToLinear);
@@ -327,7 +328,7 @@ void giCSetDiskLightRadius(GiCDiskLight* light, float radiusX, float radiusY);
 void giCSetDiskLightDiffuseSpecular(GiCDiskLight* light, float diffuse, float specular);
 
 /* Gi.h:253-257.  The dome light is an equirectangular image looked up by miss rays (rp_main.miss:46-86).  filePath is
- * decoded when it is a Radiance .hdr (RGBE), a .pfm or a .png; other formats need imgio (out of scope) -- hand the decoded pixels
+ * decoded when it is a Radiance .hdr (RGBE), a .pfm, a .png or a baseline .jpg; other formats need imgio (out of scope) -- hand the decoded pixels
  * over with giCSetDomeLightTexture instead.  A dome light without an image is ignored, exactly like a dome light whose file
  * fails to load in the reference (Gi.cpp:2221-2230): miss rays then see the fallback dome (the colour clear value). */
 GiCDomeLight* giCCreateDomeLight(GiCScene* scene, const char* filePath);

@@ -123,7 +123,7 @@ namespace gtl
   void giSetDiskLightTangents(GiDiskLight*, float* t0, float* t1);
   void giSetDiskLightRadius(GiDiskLight*, float radiusX, float radiusY);
 
-  // ---- dome light (Gi.h:253-257): .hdr / .pfm files are decoded in-library, other formats arrive through giCSetDomeLightTexture ----
+  // ---- dome light (Gi.h:253-257): .hdr / .pfm / .png / baseline .jpg files are decoded in-library, other formats arrive through giCSetDomeLightTexture ----
   GiDomeLight* giCreateDomeLight(GiScene*, const char* filePath);
   void giDestroyDomeLight(GiDomeLight*);
   void giSetDomeLightRotation(GiDomeLight*, float* quat);

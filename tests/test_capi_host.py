@@ -159,6 +159,7 @@ def test_image_decoders_survive_corrupt_files(tmp_path):
     L = capi.load_library()
     rng = np.random.default_rng(0)
     _write_png(tmp_path / "a.png", rng.integers(0, 255, (9, 7, 4)).astype(np.uint8), 6, 8, [0, 1, 2, 3, 4])
+    _write_jpeg(tmp_path / "a.jpg", rng.integers(0, 255, (19, 23, 3)).astype(np.uint8), hv=(2, 2), dri=1)
     with open(tmp_path / "a.hdr", "wb") as f:
         f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 5 +X 9\n" + rng.integers(1, 255, 5 * 9 * 4).astype(np.uint8).tobytes())
     with open(tmp_path / "a.pfm", "wb") as f:
@@ -171,7 +172,7 @@ def test_image_decoders_survive_corrupt_files(tmp_path):
             buf = (C.c_float * (w.value * h.value * 4))()
             ok = L.giCDebugDecodeImage(str(path).encode(), 1, C.byref(w), C.byref(h), buf, len(buf))
         return bool(ok)
-    for name in ("a.png", "a.hdr", "a.pfm"):
+    for name in ("a.png", "a.jpg", "a.hdr", "a.pfm"):
         assert decode(tmp_path / name)
         blob = open(tmp_path / name, "rb").read()
         for it in range(400):
@@ -191,3 +192,148 @@ def test_image_decoders_survive_corrupt_files(tmp_path):
     for bomb in (b"#?RADIANCE\n\n-Y 60000 +X 60000\n", b"PF\n2000000000 2000000000\n-1.0\n"):
         open(tmp_path / "bomb.hdr", "wb").write(bomb + b"\0" * 64)
         assert not decode(tmp_path / "bomb.hdr")
+
+
+# ---- a small baseline JPEG encoder (test side only): custom single-length Huffman tables, optional chroma subsampling and restarts ----
+def _zigzag():
+    idx = sorted(((y + x, (y if (y + x) % 2 else x), y, x) for y in range(8) for x in range(8)))
+    return [y * 8 + x for _, _, y, x in idx]
+
+
+def _write_jpeg(path, img, hv=(1, 1), qscale=3, dri=0):
+    """Writes `img` (uint8 [h, w] or [h, w, 3]) as baseline JPEG and returns the image a decoder defined as 'float IDCT, +128, round,
+    chroma replicated, JFIF colour matrix, round' must produce (uint8, same shape)."""
+    from scipy.fft import dctn, idctn
+    img = np.asarray(img, np.uint8)
+    h, w = img.shape[:2]
+    colour = img.ndim == 3
+    if colour:
+        r, g, b = [img[..., k].astype(np.float64) for k in range(3)]
+        planes = [0.299 * r + 0.587 * g + 0.114 * b, -0.168736 * r - 0.331264 * g + 0.5 * b + 128.0, 0.5 * r - 0.418688 * g - 0.081312 * b + 128.0]
+        samp = [hv, (1, 1), (1, 1)]
+    else:
+        planes, samp = [img.astype(np.float64)], [(1, 1)]
+    hmax, vmax = max(s[0] for s in samp), max(s[1] for s in samp)
+    mw, mh = -(-w // (8 * hmax)), -(-h // (8 * vmax))
+    zz = _zigzag()
+    q = np.clip((1 + np.add.outer(np.arange(8), np.arange(8))) * qscale, 2, 255).astype(np.int64)  # one table for all components
+    comp_q, comp_rec = [], []
+    for p, (sh, sv) in zip(planes, samp):
+        full = np.pad(p, ((0, mh * 8 * vmax - h), (0, mw * 8 * hmax - w)), mode="edge")
+        fy, fx = vmax // sv, hmax // sh
+        sub = full.reshape(full.shape[0] // fy, fy, full.shape[1] // fx, fx).mean(axis=(1, 3))
+        sub = np.clip(np.floor(sub + 0.5), 0, 255)
+        by, bx = sub.shape[0] // 8, sub.shape[1] // 8
+        blocks = sub.reshape(by, 8, bx, 8).transpose(0, 2, 1, 3) - 128.0
+        coef = np.clip(np.rint(dctn(blocks, axes=(2, 3), norm="ortho") / q), -1023, 1023).astype(np.int64)
+        comp_q.append(coef)
+        rec = np.clip(np.floor(idctn((coef * q).astype(np.float64), axes=(2, 3), norm="ortho") + 128.5), 0, 255)
+        comp_rec.append(np.repeat(np.repeat(rec.transpose(0, 2, 1, 3).reshape(by * 8, bx * 8), fy, axis=0), fx, axis=1)[:h, :w])
+    if colour:
+        y, cb, cr = comp_rec
+        rgb = np.stack([y + 1.402 * (cr - 128), y - 0.344136 * (cb - 128) - 0.714136 * (cr - 128), y + 1.772 * (cb - 128)], axis=-1)
+        expected = np.clip(np.floor(rgb + 0.5), 0, 255).astype(np.uint8)
+    else:
+        expected = comp_rec[0].astype(np.uint8)
+    # Huffman tables: DC = 12 symbols of 4 bits, AC = 162 symbols of 8 bits (canonical codes = index)
+    dc_vals = list(range(12))
+    ac_vals = [0x00, 0xF0] + [(r << 4) | s for r in range(16) for s in range(1, 11)]
+    ac_code = {v: i for i, v in enumerate(ac_vals)}
+    bits = []
+
+    def put(code, n):
+        bits.extend((code >> (n - 1 - k)) & 1 for k in range(n))
+
+    def put_value(v):
+        s = int(abs(v)).bit_length()
+        return s, (v if v >= 0 else v + (1 << s) - 1)
+    out = bytearray(b"\xff\xd8")
+
+    def seg(marker, payload):
+        out.extend(bytes([0xff, marker]) + (len(payload) + 2).to_bytes(2, "big") + payload)
+    seg(0xdb, bytes([0]) + bytes(int(q.reshape(-1)[zz[k]]) for k in range(64)))
+    seg(0xc0, bytes([8]) + h.to_bytes(2, "big") + w.to_bytes(2, "big") + bytes([len(planes)]) +
+        b"".join(bytes([c + 1, (samp[c][0] << 4) | samp[c][1], 0]) for c in range(len(planes))))
+    seg(0xc4, bytes([0x00] + [12 if k == 4 else 0 for k in range(1, 17)] + dc_vals))
+    seg(0xc4, bytes([0x10] + [162 if k == 8 else 0 for k in range(1, 17)] + ac_vals))
+    if dri:
+        seg(0xdd, dri.to_bytes(2, "big"))
+    seg(0xda, bytes([len(planes)]) + b"".join(bytes([c + 1, 0x00]) for c in range(len(planes))) + bytes([0, 63, 0]))
+
+    def flush():
+        while len(bits) % 8:
+            bits.append(1)
+        for k in range(0, len(bits), 8):
+            byte = int("".join(map(str, bits[k:k + 8])), 2)
+            out.append(byte)
+            if byte == 0xff:
+                out.append(0)
+        bits.clear()
+    pred = [0] * len(planes)
+    count = 0
+    for my in range(mh):
+        for mx in range(mw):
+            if dri and count and count % dri == 0:
+                flush()
+                out.extend(bytes([0xff, 0xd0 + ((count // dri - 1) % 8)]))
+                pred = [0] * len(planes)
+            for c, (sh, sv) in enumerate(samp):
+                for by in range(sv):
+                    for bx in range(sh):
+                        blk = comp_q[c][my * sv + by, mx * sh + bx].reshape(-1)
+                        diff = int(blk[0]) - pred[c]; pred[c] = int(blk[0])
+                        s, val = put_value(diff)
+                        put(s, 4)
+                        if s:
+                            put(val, s)
+                        run = 0
+                        last = max([k for k in range(1, 64) if blk[zz[k]] != 0], default=0)
+                        for k in range(1, last + 1):
+                            v = int(blk[zz[k]])
+                            if v == 0:
+                                run += 1
+                                continue
+                            while run > 15:
+                                put(ac_code[0xF0], 8); run -= 16
+                            s, val = put_value(v)
+                            put(ac_code[(run << 4) | s], 8); put(val, s)
+                            run = 0
+                        if last < 63:
+                            put(ac_code[0x00], 8)
+            count += 1
+    flush()
+    out.extend(b"\xff\xd9")
+    open(path, "wb").write(bytes(out))
+    return expected
+
+
+@pytest.mark.parametrize("case", ["grey", "colour444", "colour420+restarts", "colour422"])
+def test_jpeg_decoder(tmp_path, case):
+    """Baseline JPEG (the format most UsdPreviewSurface assets ship their textures in; the reference decodes it through imgio):
+    Huffman decoding, dequantisation, IDCT, chroma upsampling, restart intervals, sizes that are not MCU multiples, 0xFF stuffing."""
+    L = capi.load_library()
+    rng = np.random.default_rng(3)
+    h, w = (21, 13) if case != "grey" else (17, 24)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([128 + 100 * np.sin(xx / 3.0), 128 + 90 * np.cos(yy / 4.0), 40 + 8 * ((xx + yy) % 9)], axis=-1) + rng.normal(0, 6, (h, w, 3))
+    img = np.clip(base, 0, 255).astype(np.uint8)
+    if case == "grey":
+        expected = _write_jpeg(tmp_path / "a.jpg", img[..., 0])
+        expected = np.repeat(expected[..., None], 3, axis=2)
+        img = np.repeat(img[..., :1], 3, axis=2)
+    else:
+        hv = {"colour444": (1, 1), "colour420+restarts": (2, 2), "colour422": (2, 1)}[case]
+        expected = _write_jpeg(tmp_path / "a.jpg", img, hv=hv, dri=2 if "restarts" in case else 0)
+    wv, hv_ = C.c_uint32(), C.c_uint32()
+    buf = (C.c_float * (w * h * 4))()
+    assert L.giCDebugDecodeImage(str(tmp_path / "a.jpg").encode(), 0, C.byref(wv), C.byref(hv_), buf, len(buf)) == 1
+    assert (wv.value, hv_.value) == (w, h)
+    got = np.rint(np.ctypeslib.as_array(buf).reshape(h, w, 4)[..., :3] * 255.0).astype(np.int64)
+    diff = np.abs(got - expected.astype(np.int64))
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.02, (diff.max(), (diff > 0).mean())   # float32 vs float64 IDCT: rare rounding ties
+    assert np.abs(got - img.astype(np.int64)).mean() < 12                                  # and it resembles the source image
+    # progressive files are refused, not mis-decoded
+    blob = bytearray(open(tmp_path / "a.jpg", "rb").read())
+    i = blob.index(b"\xff\xc0"); blob[i + 1] = 0xc2
+    open(tmp_path / "p.jpg", "wb").write(bytes(blob))
+    assert L.giCDebugDecodeImage(str(tmp_path / "p.jpg").encode(), 0, C.byref(wv), C.byref(hv_), None, 0) == 0
