@@ -426,7 +426,9 @@ __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, Que
 // k_shade: closest-hit shading + the post-trace part of the bounce loop, over the HIT queue only
 // (rp_main.chit:132-493, rp_main.rgen:397-480).  Misses never get here (k_trace routes them to k_raygen).
 // ------------------------------------------------------------------------------------------------
-template <uint32_t KLASS, bool TEXTURED, bool VOLUME>
+template <uint32_t KLASS, bool TEXTURED, bool VOLUME, bool NEE>
+// (forcing the plain variant to 5 waves/SIMD -- amdgpu_waves_per_eu((...) ? 5 : 1, 8): 90 VGPRs, no spills -- is SLOWER: C2 shade 178 -> 190 ms;
+// the stage is bound by the memory pipeline's scattered 16-byte requests, not by latency hiding)
 __global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t par)
 {
   __shared__ AppendScratch<3> sh;
@@ -505,7 +507,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, 
       k2 = bs.k2;
       const bool isTransmission = (bs.event & EV_TRANSMISSION) != 0u;
       // NEE (:394-444)
-      if ((U.flags & FLAG_NEE) && (bs.event & (EV_DIFFUSE | EV_GLOSSY))) {
+      if (NEE && (bs.event & (EV_DIFFUSE | EV_GLOSSY))) { // NEE is a compile-time variant: light sampling + BSDF evaluation cost registers even when off
         const float k0 = gi_next1f(rng), k1 = gi_next1f(rng), kk2 = gi_next1f(rng), k3 = gi_next1f(rng);
         V3 dirToLight, lightPower; float lightDist, invPdf; uint32_t ds;
         sample_light(sc, U, k0, k1, kk2, k3, ss.position, dirToLight, lightDist, lightPower, invPdf, ds);
@@ -820,12 +822,16 @@ void launchAov(hipStream_t s, const FrameUniforms& U, const SceneView& sc, const
 }
 void launchShade(hipStream_t s, uint32_t blocks, uint32_t klass, bool textured, bool volume, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par)
 {
+#define GI_LAUNCH_SHADE4(K, T, V, N) hipLaunchKernelGGL((k_shade<K, T, V, N>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par)
+#define GI_LAUNCH_SHADE3(K, T, V) do { if (nee) GI_LAUNCH_SHADE4(K, T, V, true); else GI_LAUNCH_SHADE4(K, T, V, false); } while (0)
 #define GI_LAUNCH_SHADE(K) do { \
-    if (volume) { if (textured) hipLaunchKernelGGL((k_shade<K, true, true>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par); \
-                  else hipLaunchKernelGGL((k_shade<K, false, true>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par); } \
-    else if (textured) hipLaunchKernelGGL((k_shade<K, true, false>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par); \
-    else hipLaunchKernelGGL((k_shade<K, false, false>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par); } while (0)
+    if (volume) { if (textured) GI_LAUNCH_SHADE3(K, true, true); else GI_LAUNCH_SHADE3(K, false, true); } \
+    else if (textured) GI_LAUNCH_SHADE3(K, true, false); \
+    else GI_LAUNCH_SHADE3(K, false, false); } while (0)
+  const bool nee = (U.flags & FLAG_NEE) != 0u;
   if (klass == 0u) GI_LAUNCH_SHADE(0u); else if (klass == 1u) GI_LAUNCH_SHADE(1u); else GI_LAUNCH_SHADE(2u);
+#undef GI_LAUNCH_SHADE4
+#undef GI_LAUNCH_SHADE3
 #undef GI_LAUNCH_SHADE
 }
 
