@@ -58,7 +58,9 @@ struct Builder {
   // Measured (C3 / C4 / C5): nodes per ray 16.6 / 6.9 / 20.1 -> 16.0 / 6.8 / 20.0 but triangles per ray 13.1 / 3.4 / 10.8 -> 18.5 / 5.1 / 22.4,
   // traversal 8-20 % slower: SAH leaves win.  Kept as an experiment knob (GATLING_BVH_BALANCED_BOTTOM=1).
   bool balancedBottom = false;
-  explicit Builder(const std::vector<TriRec>& t) : tris(t)
+  const float* extBoxes = nullptr; size_t extCount = 0; // box mode (TLAS over instances, BLAS over pre-padded triangle boxes): 6 floats per item
+  size_t itemCount() const { return extBoxes ? extCount : tris.size(); }
+  explicit Builder(const std::vector<TriRec>& t, const float* boxes = nullptr, size_t boxCount = 0) : tris(t), extBoxes(boxes), extCount(boxCount)
   {
     if (const char* e = getenv("GATLING_BVH_BALANCED_BOTTOM")) balancedBottom = atoi(e) != 0;
     int threads = (int)std::thread::hardware_concurrency();
@@ -69,7 +71,7 @@ struct Builder {
 
   void prepare()
   {
-    size_t n = tris.size();
+    size_t n = itemCount();
     triBox.resize(n); centroid.resize(3 * n); refs.resize(n);
     nodes.assign(n ? 2 * n - 1 : 1, Node2{});
     const int workers = (n > (1u << 16)) ? spareThreads.load() + 1 : 1;
@@ -82,6 +84,11 @@ struct Builder {
   void prepareRange(size_t begin, size_t end)
   {
     for (size_t i = begin; i < end; i++) {
+      if (extBoxes) { // the caller's boxes are taken as they are (already padded)
+        Box b; for (int a = 0; a < 3; a++) { b.lo[a] = extBoxes[6 * i + a]; b.hi[a] = extBoxes[6 * i + 3 + a]; centroid[3 * i + a] = 0.5f * (b.lo[a] + b.hi[a]); }
+        triBox[i] = b; refs[i] = (uint32_t)i;
+        continue;
+      }
       const TriRec& t = tris[i];
       Box b; b.reset();
       float p1[3], p2[3];
@@ -186,10 +193,12 @@ inline int exponentFor(float extent)
 
 } // namespace
 
-void buildBvh8(const std::vector<TriRec>& trisIn, Bvh8& out)
+static void buildCore(const std::vector<TriRec>& trisIn, const float* boxes, size_t boxCount, Bvh8& out, std::vector<uint32_t>* order)
 {
   out.nodes.clear(); out.tris.clear(); out.maxDepth = 0;
-  if (trisIn.empty()) {
+  if (order) order->clear();
+  const size_t itemCount = boxes ? boxCount : trisIn.size();
+  if (itemCount == 0) {
     Node8 root; std::memset(&root, 0, sizeof(root));
     for (int a = 0; a < 3; a++) { root.e[a] = 127; for (int s = 0; s < 8; s++) { root.qlo[a][s] = 255; root.qhi[a][s] = 0; } }
     out.nodes.push_back(root); out.maxDepth = 1;
@@ -198,16 +207,16 @@ void buildBvh8(const std::vector<TriRec>& trisIn, Bvh8& out)
   const bool timing = getenv("GATLING_BUILD_TIMING") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double tA = now();
-  Builder B(trisIn);
+  Builder B(trisIn, boxes, boxCount);
   B.prepare();
   const double tB = now();
-  uint32_t root2 = B.build(0, (uint32_t)trisIn.size(), 0u);
+  uint32_t root2 = B.build(0, (uint32_t)itemCount, 0u);
   const double tC = now();
 
   struct Item { uint32_t n2; uint32_t n8; uint32_t depth; };
   std::queue<Item> q;
-  out.nodes.reserve(trisIn.size() / 4 + 16);
-  out.tris.reserve(trisIn.size());
+  out.nodes.reserve(itemCount / 4 + 16);
+  if (order) order->reserve(itemCount); else out.tris.reserve(itemCount);
   out.nodes.emplace_back();
   q.push({root2, 0, 1});
 
@@ -253,7 +262,7 @@ void buildBvh8(const std::vector<TriRec>& trisIn, Bvh8& out)
     int ex[3];
     for (int a = 0; a < 3; a++) { node.p[a] = nb.lo[a]; ex[a] = exponentFor(nb.hi[a] - nb.lo[a]); node.e[a] = (uint8_t)(ex[a] + 127); }
     node.childBase = (uint32_t)out.nodes.size();
-    node.triBase = (uint32_t)out.tris.size();
+    node.triBase = (uint32_t)(order ? order->size() : out.tris.size());
     uint32_t triOffset = 0;
     for (int s = 0; s < 8; s++) {
       int i = childInSlot[s];
@@ -272,6 +281,7 @@ void buildBvh8(const std::vector<TriRec>& trisIn, Bvh8& out)
         uint32_t unary = (1u << c.count) - 1u;
         node.meta[s] = (uint8_t)((unary << 5) | triOffset);
         for (uint32_t k = 0; k < c.count; k++) {
+          if (order) { order->push_back(B.refs[c.first + k]); continue; }
           TriRec t = B.tris[B.refs[c.first + k]];
           t.origId = B.refs[c.first + k];
           out.tris.push_back(t);
@@ -287,7 +297,15 @@ void buildBvh8(const std::vector<TriRec>& trisIn, Bvh8& out)
     }
     out.nodes[it.n8] = node;
   }
-  if (timing) fprintf(stderr, "[gatling_gi] bvh8: prepare %.0f ms, bvh2 %.0f ms, collapse+quantise %.0f ms (%zu triangles, %zu nodes)\n", tB - tA, tC - tB, now() - tC, out.tris.size(), out.nodes.size());
+  if (timing) fprintf(stderr, "[gatling_gi] bvh8: prepare %.0f ms, bvh2 %.0f ms, collapse+quantise %.0f ms (%zu items, %zu nodes)\n", tB - tA, tC - tB, now() - tC, itemCount, out.nodes.size());
+}
+
+void buildBvh8(const std::vector<TriRec>& trisIn, Bvh8& out) { buildCore(trisIn, nullptr, 0, out, nullptr); }
+
+void buildBvh8Boxes(const float* boxes, size_t count, Bvh8& out, std::vector<uint32_t>& order)
+{
+  static const std::vector<TriRec> none;
+  buildCore(none, boxes, count, out, &order);
 }
 
 } // namespace gi

@@ -19,4 +19,8 @@ struct Bvh8 {
 // single empty root so traversal code needs no special case.
 void buildBvh8(const std::vector<TriRec>& tris, Bvh8& out);
 
+// The same tree over caller-supplied, already padded boxes (6 floats per item: min xyz, max xyz): the TLAS over instance bounds and
+// the per-mesh BLAS of the two-level layout.  `order[k]` is the item a leaf slot's k-th reference (Node8::triBase + offset) names.
+void buildBvh8Boxes(const float* boxes, size_t count, Bvh8& out, std::vector<uint32_t>& order);
+
 } // namespace gi

@@ -291,6 +291,8 @@ struct GiCScene {
   DeviceBuffer<FVertex> dVerts; DeviceBuffer<MaterialRec> dMaterials; DeviceBuffer<int32_t> dTriFaceId;
   DeviceBuffer<SphereLightRec> dSphere; DeviceBuffer<DistantLightRec> dDistant; DeviceBuffer<RectLightRec> dRect; DeviceBuffer<DiskLightRec> dDisk;
   uint32_t nodeCount = 0, triCount = 0, bvhDepth = 0;
+  DeviceBuffer<Node8> dTlasNodes, dBlasNodes; DeviceBuffer<uint32_t> dTlasItems, dFlatOfOrig; DeviceBuffer<BlasTri> dBlasTris; DeviceBuffer<InstTrav> dInstTrav;
+  bool twoLevel = false; int optTwoLevel = -1; // 1: build and use the two-level layout (scenes beyond LDS); otherwise the flat one
   bool hasCutouts = false;
   uint32_t classMask = 0; // material classes that own at least one triangle (one k_shade launch per class)
   uint32_t classTextured = 0; // classes with at least one textured material in use (k_shade<class, TEXTURED>)
@@ -363,6 +365,7 @@ void giCDestroyScene(GiCScene* s)
   std::lock_guard<std::mutex> g(g_ctx.resourceMutex);
   (void)hipStreamSynchronize(g_ctx.stream);
   s->dNodes.release(); s->dNodesLine.release(); s->dTris.release(); s->dInstances.release(); s->dVerts.release(); s->dTriFaceId.release();
+  s->dTlasNodes.release(); s->dBlasNodes.release(); s->dTlasItems.release(); s->dFlatOfOrig.release(); s->dBlasTris.release(); s->dInstTrav.release();
   for (auto* b : s->dTexels) { b->release(); delete b; }
   s->dTexels.clear(); s->dTextures.release(); s->dMeshes.release(); s->dSceneData.release();
   s->dMaterials.release(); s->dSphere.release(); s->dDistant.release(); s->dRect.release(); s->dDisk.release();
@@ -771,6 +774,7 @@ int giCSetSceneOption(GiCScene* scene, int32_t option, int32_t value)
   if (option == GI_C_SCENE_OPTION_COUNT_TRAVERSAL) { scene->countTraversal = value != 0; return GI_C_OK; }
   if (option == GI_C_SCENE_OPTION_KERNEL_TIMERS) { scene->kernelTimers = value != 0; scene->kernelTimerStride = value > 0 ? (uint32_t)value : 1u; return GI_C_OK; }
   if (option == GI_C_SCENE_OPTION_POOL_SLOTS) { scene->optPoolSlots = value > 0 ? (uint64_t)value : 0; return GI_C_OK; }
+  if (option == GI_C_SCENE_OPTION_TWO_LEVEL) { scene->optTwoLevel = value < 0 ? -1 : (value ? 1 : 0); scene->dirty |= DIRTY_BVH | DIRTY_FRAMEBUFFER; return GI_C_OK; }
   if (option == GI_C_SCENE_OPTION_TRACE_DYNAMIC) { scene->optTraceDyn = value < 0 ? -1 : (value > 64 ? 64 : value); return GI_C_OK; }
   if (option == GI_C_SCENE_OPTION_SAMPLE_BUFFER_MB) { scene->optSampleBufferMb = value > 0 ? (uint64_t)value : 0; return GI_C_OK; }
   setError("unknown scene option"); return GI_C_ERROR;
@@ -830,6 +834,74 @@ inline void xformPoint(const float a[12], const float p[3], float out[3])
   out[2] = ((a[8] * p[0] + a[9] * p[1]) + a[10] * p[2]) + a[11];
 }
 
+// Two-level layout (SceneView::tlasNodes ...): built next to the flat BVH for instanced scenes that do not fit LDS.  The flat
+// arrays stay (k_shade reads the hit's TriRec, k_aov / giCTraceRays traverse them); the two-level ones are what k_trace_dyn2 walks,
+// and they are small: one BLAS per MESH instead of one subtree per instance, so traversal stays in the caches.
+template <class MB>
+int buildTwoLevel(GiCScene* s, const std::vector<MB>& meshBuilds, const std::vector<InstanceRec>& instances, size_t flatTris, size_t flatNodes)
+{
+  s->twoLevel = false;
+  int want = s->optTwoLevel;
+  if (const char* e = getenv("GATLING_TWO_LEVEL")) want = atoi(e);
+  size_t uniqueTris = 0;
+  for (const MB& mb : meshBuilds) uniqueTris += mb.instCount ? mb.m->faces.size() : 0;
+  const bool beyondLds = flatNodes > 384u || flatTris > 128u;
+  (void)uniqueTris;
+  // Opt-in only.  Measured (r01k): although its working set is tiny (C4: 1.5 MB of BLAS nodes + 2.6 MB of mesh triangles instead of
+  // 41 + 335 MB) the first version is SLOWER than the flat layout -- C4 trace 185 -> 207 ms, C5 834 -> 1945 ms (29 instead of 20 nodes
+  // per ray: overlapping instance boxes, each visit pays a ray transform, a BLAS root and a restore; candidates cost a rebuild).
+  if (want <= 0 || instances.empty() || !beyondLds) return GI_C_OK;
+  std::vector<Node8> blasNodes; std::vector<BlasTri> blasTris; std::vector<InstTrav> instTrav(instances.size());
+  uint32_t blasDepth = 0;
+  std::vector<float> instBoxes(instances.size() * 6);
+  auto padBox = [](float* lo, float* hi) { // as bvh8.cpp pads triangle boxes: 2^-20 relative, covers the rounding of the exact test's inputs
+    for (int a = 0; a < 3; a++) { const float mag = std::max(std::fabs(lo[a]), std::fabs(hi[a])) + (hi[a] - lo[a]); const float pad = mag * 9.5367431640625e-7f + 1.0e-30f; lo[a] -= pad; hi[a] += pad; }
+  };
+  for (const MB& mb : meshBuilds) {
+    if (mb.instCount == 0) continue;
+    const GiCMesh* m = mb.m;
+    const size_t nf = m->faces.size();
+    std::vector<float> boxes(nf * 6);
+    float mlo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (size_t f = 0; f < nf; f++) {
+      float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+      for (int k = 0; k < 3; k++) { const float* p = m->vertices[m->faces[f].v_i[k]].pos; for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); } }
+      padBox(lo, hi);
+      for (int a = 0; a < 3; a++) { boxes[6 * f + a] = lo[a]; boxes[6 * f + 3 + a] = hi[a]; mlo[a] = std::min(mlo[a], lo[a]); mhi[a] = std::max(mhi[a], hi[a]); }
+    }
+    Bvh8 b; std::vector<uint32_t> order;
+    buildBvh8Boxes(boxes.data(), nf, b, order);
+    const uint32_t nodeBase = (uint32_t)blasNodes.size(), triBase = (uint32_t)blasTris.size();
+    for (Node8 n : b.nodes) { n.childBase += nodeBase; n.triBase += triBase; blasNodes.push_back(n); }
+    for (uint32_t f : order) blasTris.push_back(BlasTri{{mb.vertexOffset + m->faces[f].v_i[0], mb.vertexOffset + m->faces[f].v_i[1], mb.vertexOffset + m->faces[f].v_i[2]}, f});
+    blasDepth = std::max(blasDepth, b.maxDepth);
+    // object-space magnitude the transformed ray's rounding error scales with inside this mesh (see wave_step2)
+    const float extent = (std::fabs(mlo[0]) + std::fabs(mlo[1]) + std::fabs(mlo[2])) + (std::fabs(mhi[0]) + std::fabs(mhi[1]) + std::fabs(mhi[2]));
+    for (uint32_t ii = 0; ii < mb.instCount; ii++) {
+      const uint32_t inst = mb.instFirst + ii;
+      instTrav[inst] = InstTrav{nodeBase, mb.triFirst + ii * (uint32_t)nf, mb.matFlags, extent};
+      float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+      for (size_t f = 0; f < nf; f++)
+        for (int k = 0; k < 3; k++) { float p[3]; xformPoint(instances[inst].o2w, m->vertices[m->faces[f].v_i[k]].pos, p); for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); } }
+      padBox(lo, hi);
+      for (int a = 0; a < 3; a++) { instBoxes[6 * inst + a] = lo[a]; instBoxes[6 * inst + 3 + a] = hi[a]; }
+    }
+  }
+  Bvh8 tlas; std::vector<uint32_t> tlasItems;
+  buildBvh8Boxes(instBoxes.data(), instances.size(), tlas, tlasItems);
+  // per-lane stack: a TLAS level can leave a node group and an instance group behind, a BLAS level a node group
+  if (2u * tlas.maxDepth + blasDepth + 1u > 16u) { if (want > 0) fprintf(stderr, "[gatling_gi] two-level layout not used: trees too deep for the 16-entry stack\n"); return GI_C_OK; }
+  hipStream_t st = g_ctx.stream;
+  if (s->dTlasNodes.upload(tlas.nodes, st) || s->dTlasItems.upload(tlasItems, st) || s->dBlasNodes.upload(blasNodes, st) || s->dBlasTris.upload(blasTris, st) ||
+      s->dInstTrav.upload(instTrav, st))
+    return GI_C_ERROR;
+  HIP_TRY(hipStreamSynchronize(st));
+  s->twoLevel = true;
+  if (getenv("GATLING_BUILD_TIMING")) fprintf(stderr, "[gatling_gi] two-level: TLAS %zu nodes over %zu instances, %zu BLAS nodes, %zu mesh triangles (flat: %zu nodes, %zu triangles)\n",
+                                              tlas.nodes.size(), instances.size(), blasNodes.size(), blasTris.size(), flatNodes, flatTris);
+  return GI_C_OK;
+}
+
 int buildScene(GiCScene* s)
 {
   double t0 = nowMs();
@@ -855,6 +927,8 @@ int buildScene(GiCScene* s)
     deriveMaterialConstants(mats[i]);
   }
   uint32_t meshIdx = 0;
+  struct MeshBuild { const GiCMesh* m; uint32_t vertexOffset, matFlags, instFirst, instCount, triFirst; };
+  std::vector<MeshBuild> meshBuilds; // visible meshes in scene order (two-level layout)
   std::vector<MeshRec> meshRecs; std::vector<float> sceneData;
   s->classMask = 0; s->hasCutouts = false; s->classTextured = 0;
   for (GiCMesh* m : s->meshes) {
@@ -913,6 +987,7 @@ int buildScene(GiCScene* s)
       }
     }
     size_t instCount = m->instanceTransforms.size() / 16;
+    meshBuilds.push_back(MeshBuild{m, vertexOffset, matFlags, (uint32_t)instances.size(), (uint32_t)instCount, (uint32_t)tris.size()});
     for (size_t ii = 0; ii < instCount; ii++) { // Gi.cpp:1188-1202
       InstanceRec ir{};
       composeTransform(m->transform, &m->instanceTransforms[16 * ii], ir.o2w);
@@ -937,6 +1012,13 @@ int buildScene(GiCScene* s)
   }
   Bvh8 bvh;
   buildBvh8(tris, bvh);
+  if (buildTwoLevel(s, meshBuilds, instances, tris.size(), bvh.nodes.size()) != GI_C_OK) return GI_C_ERROR;
+  if (s->twoLevel) {
+    std::vector<uint32_t> flatOfOrig(bvh.tris.size());
+    for (size_t i = 0; i < bvh.tris.size(); i++) flatOfOrig[bvh.tris[i].origId] = (uint32_t)i;
+    if (s->dFlatOfOrig.upload(flatOfOrig, g_ctx.stream)) return GI_C_ERROR;
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  }
   double t1 = nowMs();
   if (bvh.tris.size() >= (1u << 26)) { setError("scene has 2^26 or more triangles after instancing: the traversal queues pack (lane, triangle) into 32 bits"); return GI_C_ERROR; }
   hipStream_t st = g_ctx.stream;
@@ -996,6 +1078,7 @@ SceneView makeView(GiCScene* s)
   v.textures = s->dTextures.ptr; v.meshes = s->dMeshes.ptr; v.sceneData = s->dSceneData.ptr;
   v.nodes = s->nodeStrideU4 == 8u ? reinterpret_cast<const Node8*>(s->dNodesLine.ptr) : s->dNodes.ptr; v.nodeStrideU4 = s->nodeStrideU4; v.tris = s->dTris.ptr; v.instances = s->dInstances.ptr;
   v.verts = s->dVerts.ptr; v.materials = s->dMaterials.ptr; v.sphereLights = s->dSphere.ptr; v.distantLights = s->dDistant.ptr;
+  v.tlasNodes = s->dTlasNodes.ptr; v.tlasItems = s->dTlasItems.ptr; v.blasNodes = s->dBlasNodes.ptr; v.blasTris = s->dBlasTris.ptr; v.instTrav = s->dInstTrav.ptr; v.flatOfOrig = s->dFlatOfOrig.ptr; v.twoLevel = s->twoLevel ? 1u : 0u;
   v.rectLights = s->dRect.ptr; v.diskLights = s->dDisk.ptr; v.triFaceId = s->dTriFaceId.ptr; v.nodeCount = s->nodeCount; v.triCount = s->triCount; v.bvhDepth = s->bvhDepth; v.hasCutouts = s->hasCutouts ? 1u : 0u;
   return v;
 }

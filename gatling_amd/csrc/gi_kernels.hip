@@ -289,7 +289,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
 // new rays with one atomic on the launch's cursor.  No barriers, no appends; k_route then streams the results into the
 // per-class shade queues / the regen queue.  Per-ray arithmetic is trav_step's, i.e. identical to k_trace's.
 // ------------------------------------------------------------------------------------------------
-template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool CUTOUT>
+template <bool TWO> struct DynRay { using type = RayTrav; };
+template <> struct DynRay<true> { using type = RayTrav2; };
+template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool CUTOUT, bool TWO = false>
 __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t refill)
 {
   extern __shared__ uint4 s_dyn[];
@@ -304,7 +306,9 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
   uint32_t* cursor = &cnt->cursor[ANYHIT ? 1 : 0].v;
   const uint32_t lane = __lane_id();
   TraceCounters tc{0u, 0u};
-  RayTrav R; trav_init(R, v3(0.0f, 0.0f, 0.0f), v3(0.0f, 0.0f, 1.0f), 0.0f, 0.0f);
+  typename DynRay<TWO>::type R;
+  auto ray_init = [&](V3 o, V3 d, float tMin, float tMax) { if constexpr (TWO) trav2_init(R, o, d, tMin, tMax); else trav_init(R, o, d, tMin, tMax); };
+  ray_init(v3(0.0f, 0.0f, 0.0f), v3(0.0f, 0.0f, 1.0f), 0.0f, 0.0f);
   uint2 overflow[OVERFLOW ? OVF_STACK : 1];
   bool alive = false;
   uint32_t rec = 0u, rng = 0u;
@@ -339,8 +343,8 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
       const uint32_t srng = CUTOUT ? (uint32_t)__shfl((int)prng, src) : 0u;
       if (!alive && rank < take) {
         rec = srec; rng = srng;
-        if (!ANYHIT) trav_init(R, v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), ro.w, rdir.w);
-        else trav_init(R, v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), 0.01f, ro.w); // shadow ray (rp_main.rgen:397-429)
+        if (!ANYHIT) ray_init(v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), ro.w, rdir.w);
+        else ray_init(v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), 0.01f, ro.w); // shadow ray (rp_main.rgen:397-429)
         wave_ray_begin(W, R.tBest);
         alive = true;
       }
@@ -348,13 +352,19 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
       if (chunkUsed == chunkCount) next_chunk(); // loads complete while the wave keeps traversing
     }
     if (!__ballot(alive)) { if (chunkCount == 0u) break; else continue; }
-    const bool done = wave_step<ANYHIT, COUNT, STACK, OVERFLOW, false, CUTOUT, TRACE_DYN_COOP_FETCH>(R, alive, W, S, sc, nullptr, 0u, nullptr, 0u, s_stack, overflow, tc, rng);
+    bool done;
+    if constexpr (TWO) done = wave_step2<ANYHIT, COUNT, CUTOUT>(R, alive, W, sc, s_stack, tc, rng);
+    else done = wave_step<ANYHIT, COUNT, STACK, OVERFLOW, false, CUTOUT, TRACE_DYN_COOP_FETCH>(R, alive, W, S, sc, nullptr, 0u, nullptr, 0u, s_stack, overflow, tc, rng);
     if (alive && done) {
       alive = false;
       wave_ray_end(W, R);
+      if constexpr (TWO) { if (!ANYHIT && R.found) R.bestTri = sc.flatOfOrig[R.bestTri]; } // scene-order id -> index of the hit's TriRec
       if (!ANYHIT) {
         if (R.found) { st4(&qs.a[qIn][rec], R.tBest, R.bestU, R.bestV, u2f(R.bestTri)); reinterpret_cast<uint32_t*>(&qs.b[qIn][rec])[3] = R.bestMat; }
-        else { st4(&qs.a[qIn][rec], R.tBest, R.o.x, R.o.y, u2f(MISS)); reinterpret_cast<float*>(&qs.b[qIn][rec])[3] = R.o.z; } // (tMax, origin): k_route needs them for scattering events
+        else { // (tMax, origin): k_route needs them for scattering events
+          V3 wo = R.o; if constexpr (TWO) wo = R.wo;
+          st4(&qs.a[qIn][rec], R.tBest, wo.x, wo.y, u2f(MISS)); reinterpret_cast<float*>(&qs.b[qIn][rec])[3] = wo.z;
+        }
       } else {
         const uint32_t slot = qs.slot[qIn][rec];
         if (!R.found) {
@@ -378,6 +388,12 @@ template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool CUTOUT>
 __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_trace_dyn(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t refill)
 {
   trace_dyn_body<ANYHIT, COUNT, STACK, OVERFLOW, CUTOUT>(sc, st, qs, cnt, qIn, refill);
+}
+// the two-level layout (wave_step2): 16 LDS stack entries, world + object-space ray in registers
+template <bool ANYHIT, bool COUNT, bool CUTOUT>
+__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_trace_dyn2(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t refill)
+{
+  trace_dyn_body<ANYHIT, COUNT, 16, false, CUTOUT, true>(sc, st, qs, cnt, qIn, refill);
 }
 
 // k_route: sorts k_trace_dyn's in-place results by outcome and material class (same routing as k_trace's epilogue)
@@ -775,6 +791,11 @@ static void launchTraceVariant(hipStream_t s, uint32_t blocks, const SceneView& 
   if (!allLds && dynRefill) { // big scene: persistent waves with dynamic ray fetch, results routed by a streaming pass
     // persistent waves pay the scratch set-up once, so trees deeper than 8 levels may keep 8 entries in LDS (more
     // resident waves) and spill the rest (TRACE_DYN_SPILL8), or keep 16 in LDS
+    if (sc.twoLevel) { // instanced scene: TLAS + shared per-mesh BLASes
+      hipLaunchKernelGGL((k_trace_dyn2<ANYHIT, COUNT, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), 16u * TRACE_BLOCK * (uint32_t)sizeof(uint2), s, sc, st, qs, cnt, qIn, dynRefill & 0xffu);
+      if (!ANYHIT) hipLaunchKernelGGL(k_route, dim3(routeBlocks), dim3(BLOCK), 0, s, sc, st, qs, cnt, qIn, qMiss);
+      return;
+    }
     const bool spill8 = (dynRefill & TRACE_DYN_SPILL8) != 0u;
     dynRefill &= 0xffu;
     const uint32_t entries = (sc.bvhDepth <= 8u || spill8) ? 8u : 16u;

@@ -87,7 +87,8 @@ __device__ __forceinline__ uint32_t trav_node_pick(RayTrav& R, uint2 (*s_stack)[
 // children) are decoded four at a time with byte-parallel integer ops, and empty slots (meta 0) contribute no bits, so
 // the hit mask is assembled without a branch.
 typedef float gi_f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint2 trav_node_test(RayTrav& R, const uint4& n0, const uint4& n1, const uint4& n2, const uint4& n3, const uint4& n4)
+template <bool SLACK = false>
+__device__ __forceinline__ uint2 trav_node_test(RayTrav& R, const uint4& n0, const uint4& n1, const uint4& n2, const uint4& n3, const uint4& n4, float slack = 0.0f)
 {
   const V3 o = R.o, d = R.d;
   constexpr float WIDEN = 1.00001f;
@@ -96,7 +97,10 @@ __device__ __forceinline__ uint2 trav_node_test(RayTrav& R, const uint4& n0, con
   const float ax = sx * R.idx, ay = sy * R.idy, az = sz * R.idz;
   const float bx = (u2f(n0.x) - o.x) * R.idx, by = (u2f(n0.y) - o.y) * R.idy, bz = (u2f(n0.z) - o.z) * R.idz;
   const gi_f2 Ax = {ax, ax * WIDEN}, Ay = {ay, ay * WIDEN}, Az = {az, az * WIDEN};
-  const gi_f2 Bx = {bx, bx * WIDEN}, By = {by, by * WIDEN}, Bz = {bz, bz * WIDEN};
+  // SLACK (two-level layout): the ray was transformed into the instance's object space in fp32; every box is grown by `slack`
+  // (an absolute object-space bound on that rounding) so the filter stays conservative for the WORLD-space exact test
+  const float ex = SLACK ? slack * fabsf(R.idx) : 0.0f, ey = SLACK ? slack * fabsf(R.idy) : 0.0f, ez = SLACK ? slack * fabsf(R.idz) : 0.0f;
+  const gi_f2 Bx = {bx - ex, (bx + ex) * WIDEN}, By = {by - ey, (by + ey) * WIDEN}, Bz = {bz - ez, (bz + ez) * WIDEN};
   const float tFar = R.tBest * WIDEN, tNear = R.tMin;
   // near/far plane bytes per axis, chosen by direction sign
   const bool nxn = d.x < 0.0f, nyn = d.y < 0.0f, nzn = d.z < 0.0f;
@@ -356,5 +360,154 @@ __device__ __forceinline__ bool traverse(const SceneView& sc, const uint4* s_nod
   return R.found;
 }
 
+
+
+// ------------------------------------------------------------------------------------------------
+// Two-level traversal (k_trace_dyn2; SceneView::tlasNodes ...).  Instanced scenes flattened into one BVH are HBM-latency bound: 5 M
+// flattened triangles + their subtrees are 0.4 GB of node / triangle records touched at random.  Here a lane walks the TLAS with
+// the world-space ray; a TLAS leaf reference names an instance: the lane transforms the ray into that instance's object space
+// (w2o, no renormalisation: t keeps its meaning) and walks the mesh's BLAS, which all instances share and which stays in the caches.
+// The box tests are filters only.  A candidate triangle is REBUILT in world space from the object-space vertices with the instance
+// transform -- the host's xformPoint arithmetic, so (v0, e1, e2) equal the flat layout's TriRec bit for bit -- and tested against the
+// WORLD-space ray by the same tri_test: hits, tie-breaks and any-hit decisions are those of the flat layout.
+// Stack (16 LDS entries; the host checks the bound): node groups as before, plus "instance groups" (x = TLAS_ITEM_TAG | first
+// reference, y = 24-bit mask of the hit leaf references) that wait below the BLAS entries of the instance being walked.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t TLAS_ITEM_TAG = 0x80000000u, NO_INSTANCE = 0xffffffffu;
+struct RayTrav2 : RayTrav { V3 wo, wd; uint32_t inst, spBase; float slack; };
+
+__device__ __forceinline__ void trav2_set_ray(RayTrav2& R, V3 o, V3 d)
+{
+  R.o = o; R.d = d;
+  const float gx = (fabsf(d.x) < 1e-30f) ? (d.x < 0.0f ? -1e-30f : 1e-30f) : d.x;
+  const float gy = (fabsf(d.y) < 1e-30f) ? (d.y < 0.0f ? -1e-30f : 1e-30f) : d.y;
+  const float gz = (fabsf(d.z) < 1e-30f) ? (d.z < 0.0f ? -1e-30f : 1e-30f) : d.z;
+  R.idx = __builtin_amdgcn_rcpf(gx); R.idy = __builtin_amdgcn_rcpf(gy); R.idz = __builtin_amdgcn_rcpf(gz);
+  R.octinv = ((d.x >= 0.0f ? 1u : 0u) | (d.y >= 0.0f ? 2u : 0u) | (d.z >= 0.0f ? 4u : 0u)) * 0x01010101u;
+}
+__device__ __forceinline__ void trav2_init(RayTrav2& R, V3 o, V3 d, float tMin, float tMax)
+{
+  trav_init(R, o, d, tMin, tMax);
+  R.wo = o; R.wd = d; R.inst = NO_INSTANCE; R.spBase = 0u; R.slack = 0.0f;
+}
+__device__ __forceinline__ void trav2_enter(RayTrav2& R, const SceneView& sc, uint32_t inst)
+{
+  const float4* ip = reinterpret_cast<const float4*>(&sc.instances[inst]);
+  const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2], r3 = ip[3], r4 = ip[4], r5 = ip[5]; // o2w rows | w2o[0..8], mesh, ids
+  const InstTrav tv = sc.instTrav[inst];
+  const V3 rel = v3(R.wo.x - r0.w, R.wo.y - r1.w, R.wo.z - r2.w); // o2w translation = column 3
+  const float w[9] = {r3.x, r3.y, r3.z, r3.w, r4.x, r4.y, r4.z, r4.w, r5.x};
+  const V3 o = v3((w[0] * rel.x + w[1] * rel.y) + w[2] * rel.z, (w[3] * rel.x + w[4] * rel.y) + w[5] * rel.z, (w[6] * rel.x + w[7] * rel.y) + w[8] * rel.z);
+  const V3 d = v3((w[0] * R.wd.x + w[1] * R.wd.y) + w[2] * R.wd.z, (w[3] * R.wd.x + w[4] * R.wd.y) + w[5] * R.wd.z, (w[6] * R.wd.x + w[7] * R.wd.y) + w[8] * R.wd.z);
+  // rounding of the transform: a few ulps of the summed term magnitudes, for the origin and -- over the distance the ray covers inside
+  // the mesh, <= |o'| + its extent -- for the direction; 4e-6 is > 30 ulps of that
+  const float m0 = (fabsf(w[0] * rel.x) + fabsf(w[1] * rel.y)) + fabsf(w[2] * rel.z), m1 = (fabsf(w[3] * rel.x) + fabsf(w[4] * rel.y)) + fabsf(w[5] * rel.z),
+              m2 = (fabsf(w[6] * rel.x) + fabsf(w[7] * rel.y)) + fabsf(w[8] * rel.z);
+  R.slack = 4.0e-6f * ((m0 + m1) + (m2 + tv.slack));
+  trav2_set_ray(R, o, d);
+  R.inst = inst; R.spBase = R.sp;
+  R.G = make_uint2(tv.blasRoot, 0x80000000u); // virtual group holding only the BLAS root
+}
+__device__ __forceinline__ void trav2_leave(RayTrav2& R)
+{
+  trav2_set_ray(R, R.wo, R.wd);
+  R.inst = NO_INSTANCE; R.slack = 0.0f;
+}
+
+// 64 (ray lane, mesh triangle) pairs: rebuild the world-space triangle of the owning lane's instance, then the flat layout's test
+template <bool COUNT, bool CUTOUT>
+__device__ __forceinline__ void wave_tri_batch2(WaveTri& W, uint32_t head, uint32_t cnt, const RayTrav2& R, uint32_t rng, const SceneView& sc, TraceCounters& tc)
+{
+  const uint32_t lane = __lane_id();
+  const bool act = lane < cnt;
+  const uint32_t e = act ? *(volatile uint32_t*)&W.queue[(head + lane) & 127u] : 0u;
+  const uint32_t rl = e >> TRI_ID_BITS, bt = e & ((1u << TRI_ID_BITS) - 1u);
+  const V3 o = v3(__shfl(R.wo.x, (int)rl), __shfl(R.wo.y, (int)rl), __shfl(R.wo.z, (int)rl));
+  const V3 d = v3(__shfl(R.wd.x, (int)rl), __shfl(R.wd.y, (int)rl), __shfl(R.wd.z, (int)rl));
+  const float tMin = __shfl(R.tMin, (int)rl);
+  const uint32_t inst = (uint32_t)__shfl((int)R.inst, (int)rl);
+  const uint32_t rrng = CUTOUT ? (uint32_t)__shfl((int)rng, (int)rl) : 0u;
+  if (act) {
+    const uint4 t4 = reinterpret_cast<const uint4*>(sc.blasTris)[bt]; // (i0, i1, i2, prim)
+    const float4* ip = reinterpret_cast<const float4*>(&sc.instances[inst]);
+    const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
+    const uint4 tv = reinterpret_cast<const uint4*>(sc.instTrav)[inst]; // (blasRoot, triBase, matFlags, slack)
+    const float4 pa = *reinterpret_cast<const float4*>(&sc.verts[t4.x]), pb = *reinterpret_cast<const float4*>(&sc.verts[t4.y]), pc = *reinterpret_cast<const float4*>(&sc.verts[t4.z]);
+    // host xformPoint (gi_c.cpp): ((a0 p0 + a1 p1) + a2 p2) + a3
+    const V3 p0 = v3(((r0.x * pa.x + r0.y * pa.y) + r0.z * pa.z) + r0.w, ((r1.x * pa.x + r1.y * pa.y) + r1.z * pa.z) + r1.w, ((r2.x * pa.x + r2.y * pa.y) + r2.z * pa.z) + r2.w);
+    const V3 p1 = v3(((r0.x * pb.x + r0.y * pb.y) + r0.z * pb.z) + r0.w, ((r1.x * pb.x + r1.y * pb.y) + r1.z * pb.z) + r1.w, ((r2.x * pb.x + r2.y * pb.y) + r2.z * pb.z) + r2.w);
+    const V3 p2 = v3(((r0.x * pc.x + r0.y * pc.y) + r0.z * pc.z) + r0.w, ((r1.x * pc.x + r1.y * pc.y) + r1.z * pc.z) + r1.w, ((r2.x * pc.x + r2.y * pc.y) + r2.z * pc.z) + r2.w);
+    const V3 e1 = p1 - p0, e2 = p2 - p0;
+    const uint32_t orig = tv.y + t4.w; // scene-order id in the flat numbering
+    const uint4 a = make_uint4(f2u(p0.x), f2u(p0.y), f2u(p0.z), f2u(e1.x)), b = make_uint4(f2u(e1.y), f2u(e1.z), f2u(e2.x), f2u(e2.y)), c = make_uint4(f2u(e2.z), orig, inst, tv.z);
+    if (COUNT) tc.tris++;
+    float t, u, v;
+    bool accept = tri_test(o, d, tMin, a, b, c, t, u, v);
+    if (CUTOUT && accept && (c.w & (1u << 28))) {
+      const float opacity = cutout_opacity_at(sc, c.w, sc.flatOfOrig[orig], u, v);
+      accept = !(cutout_random(rrng, orig) > opacity);
+    }
+    if (accept) {
+      const unsigned long long key = ((unsigned long long)f2u(t) << 32) | (unsigned long long)(orig + 1u);
+      atomicMin(&W.best[rl], key);
+      if (*(volatile unsigned long long*)&W.best[rl] == key) W.hit[rl] = make_uint4(orig, f2u(u), f2u(v), c.w); // .x = scene-order id; the kernel maps it to the flat index
+    }
+  }
+}
+
+template <bool ANYHIT, bool COUNT, bool CUTOUT>
+__device__ __forceinline__ bool wave_step2(RayTrav2& R, bool alive, WaveTri& W, const SceneView& sc, uint2 (*s_stack)[TRACE_BLOCK], TraceCounters& tc, uint32_t rng)
+{
+  const uint32_t lane = __lane_id(), tid = threadIdx.x;
+  uint2 none[1];
+  uint2 Gt = make_uint2(0u, 0u);
+  if (alive && (R.G.y & 0xff000000u)) {
+    const uint32_t nodeIdx = trav_node_pick<16u, false>(R, s_stack, none);
+    const bool top = R.inst == NO_INSTANCE;
+    const uint4* p = reinterpret_cast<const uint4*>(top ? sc.tlasNodes : sc.blasNodes) + (size_t)nodeIdx * 5u;
+    const uint4 n0 = p[0], n1 = p[1], n2 = p[2], n3 = p[3], n4 = p[4];
+    if (COUNT) tc.nodes++;
+    Gt = trav_node_test<true>(R, n0, n1, n2, n3, n4, R.slack);
+    if (top) { // hit leaf references name instances: they wait on the stack
+      if (Gt.y) { s_stack[R.sp][tid] = make_uint2(Gt.x | TLAS_ITEM_TAG, Gt.y); R.sp++; }
+      Gt.y = 0u;
+    }
+  }
+  uint32_t head = 0u, tail = 0u; // wave-uniform
+  for (;;) {
+    const unsigned long long m = __ballot(Gt.y != 0u);
+    if (!m) break;
+    if (Gt.y) {
+      const uint32_t k = (uint32_t)__ffs((int)Gt.y) - 1u;
+      Gt.y &= Gt.y - 1u;
+      *(volatile uint32_t*)&W.queue[(tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & 127u] = (lane << TRI_ID_BITS) | (Gt.x + k);
+    }
+    tail += (uint32_t)__popcll(m);
+    if (tail - head >= 64u) { wave_tri_batch2<COUNT, CUTOUT>(W, head, 64u, R, rng, sc, tc); head += 64u; }
+  }
+  if (tail != head) wave_tri_batch2<COUNT, CUTOUT>(W, head, tail - head, R, rng, sc, tc);
+  bool done = false;
+  if (alive) {
+    const unsigned long long key = *(volatile unsigned long long*)&W.best[lane];
+    R.tBest = u2f((uint32_t)(key >> 32));
+    R.found = (uint32_t)key != 0u;
+    if (ANYHIT && R.found) done = true;
+    else if (!(R.G.y & 0xff000000u)) {
+      if (R.inst != NO_INSTANCE && R.sp == R.spBase) trav2_leave(R); // this instance's BLAS is exhausted
+      if (R.sp == 0u) done = true;
+      else {
+        const uint32_t sp = --R.sp;
+        uint2 E = s_stack[sp][tid];
+        if (E.x & TLAS_ITEM_TAG) {
+          const uint32_t k = (uint32_t)__ffs((int)E.y) - 1u;
+          E.y &= E.y - 1u;
+          if (E.y) { s_stack[sp][tid] = E; R.sp = sp + 1u; }
+          trav2_enter(R, sc, sc.tlasItems[(E.x & ~TLAS_ITEM_TAG) + k]);
+        } else R.G = E;
+      }
+    }
+  }
+  return done;
+}
 
 } // namespace gi

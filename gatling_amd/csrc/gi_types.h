@@ -124,6 +124,10 @@ enum : uint32_t {
 };
 
 // Device-side scene view handed to the kernels.
+struct BlasTri { uint32_t vi[3]; uint32_t prim; };                          // absolute vertex indices + gl_PrimitiveID of a mesh triangle, 16 bytes
+struct InstTrav { uint32_t blasRoot, triBase, matFlags; float slack; };     // BLAS root node, scene-order id of the instance's first triangle
+                                                                            // (flat numbering), TriRec::matFlags of its mesh, object-space ray slack
+static_assert(sizeof(BlasTri) == 16 && sizeof(InstTrav) == 16, "two-level records are 16 bytes");
 struct SceneView {
   const Node8* nodes;      // nodeStrideU4 * 16 bytes apart (80-byte nodes packed, or one per 128-byte line)
   const TriRec* tris;
@@ -150,6 +154,14 @@ struct SceneView {
   float domeEmission[3];
   float background[3];        // the fallback dome texel: colour clear value as RGBA8 unorm (Gi.cpp:2194-2199)
   uint32_t mediumStackSize;   // > 0: rays that end inside a medium scatter instead of leaving the scene (rp_main.miss:57-66)
+  // Two-level layout for instanced scenes (k_trace_dyn2): a TLAS over instance bounds whose leaf references name instances, one BLAS
+  // per mesh in OBJECT space shared by all its instances.  Candidates are still tested as WORLD-space triangles (rebuilt from the
+  // object-space vertices with the instance transform, the host's own arithmetic), so results equal the flat layout's bit for bit.
+  const Node8* tlasNodes; const uint32_t* tlasItems;   // leaf reference k of a TLAS node = instance tlasItems[triBase + offset]
+  const Node8* blasNodes; const BlasTri* blasTris;     // all BLASes concatenated; Node8::childBase / triBase are absolute
+  const InstTrav* instTrav;                            // per instance
+  const uint32_t* flatOfOrig;                          // scene-order triangle id -> index into `tris` (BVH order)
+  uint32_t twoLevel;                                   // 0: not built
 };
 
 struct alignas(16) F4 { float x, y, z, w; };

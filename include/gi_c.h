@@ -362,6 +362,8 @@ int giCGetRenderStats(const GiCScene* scene, GiCRenderStats* out);
 /* Traversal kernel for scenes whose BVH does not fit LDS: 0 = block-synchronous k_trace; N in 1..64 = persistent waves that
  * claim new rays once N lanes are idle (k_trace_dyn, default 8); -1 = default.  Results are identical either way. */
 #define GI_C_SCENE_OPTION_TRACE_DYNAMIC 5
+#define GI_C_SCENE_OPTION_TWO_LEVEL 6     /* [ext] 1: two-level BVH (TLAS over instances + one object-space BLAS per mesh) for scenes beyond LDS; default 0: one
+                                             flat BVH over the instanced triangles (faster today); the image does not depend on it */
 int giCSetSceneOption(GiCScene* scene, int32_t option, int32_t value);
 /* [ext] closest hit of one ray through the device traversal kernel (parity tests of the BVH8 path).
  * Returns 1 on hit (t,u,v, instance, prim written), 0 on miss, <0 on error. */
