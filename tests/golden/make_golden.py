@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 from gatling_amd.scene import MAT_DIFFUSE, MAT_USD_PREVIEW_SURFACE, RectLight, RenderSettings, SphereLight  # noqa: E402
-from gatling_amd.scenes import cornell_box, interior_scene, sphere_grid, textured_scene, volume_scene  # noqa: E402
+from gatling_amd.scenes import cornell_box, interior_scene, leaf_card_scene, sphere_grid, textured_scene, volume_scene  # noqa: E402
 from oracle import orc  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -29,9 +29,10 @@ CASES = {
     "textured_dome_64x36_spp4_b6": ("textured", 64, 36, dict(spp=4, max_bounces=6, next_event_estimation=True), dict()),
     "volume_stack2_64x36_spp4_b12": ("volume", 64, 36, dict(spp=4, max_bounces=12, next_event_estimation=True, medium_stack_size=2), dict()),
     "instances_openpbr_64x36_spp4_b6": ("spheres", 64, 36, dict(spp=4, max_bounces=6), dict(grid=4, subdivisions=1, material_count=8)),
+    "leaf_cards_64x36_spp4_b5": ("leaves", 64, 36, dict(spp=4, max_bounces=5, next_event_estimation=True, rr_bounce_offset=0), dict()),
     "interior_64x36_spp3_b6": ("interior", 64, 36, dict(spp=3, max_bounces=6, next_event_estimation=True), dict(clutter_instances=40, subdivisions=1, prototypes=4, material_count=10)),
 }
-GENERATORS = {"textured": textured_scene, "volume": volume_scene, "spheres": sphere_grid, "interior": interior_scene}
+GENERATORS = {"textured": textured_scene, "volume": volume_scene, "spheres": sphere_grid, "interior": interior_scene, "leaves": leaf_card_scene}
 
 
 def build_case(name):
