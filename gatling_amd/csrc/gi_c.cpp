@@ -572,10 +572,10 @@ void giCDestroySphereLight(GiCScene* scene, GiCSphereLight* l)
   scene->sphereLights.remove(l->index); scene->dirty |= DIRTY_LIGHTS | DIRTY_FRAMEBUFFER;
   delete l;
 }
-void giCSetSphereLightPosition(GiCSphereLight* l, const float* p) { memcpy(l->scene->sphereLights.recs[l->index].pos, p, 12); LIGHT_DIRTY(l); }
-void giCSetSphereLightBaseEmission(GiCSphereLight* l, const float* c) { memcpy(l->scene->sphereLights.recs[l->index].em, c, 12); LIGHT_DIRTY(l); }
+void giCSetSphereLightPosition(GiCSphereLight* l, const float* p) { std::lock_guard<std::mutex> lk(l->scene->mutex); memcpy(l->scene->sphereLights.recs[l->index].pos, p, 12); LIGHT_DIRTY(l); }
+void giCSetSphereLightBaseEmission(GiCSphereLight* l, const float* c) { std::lock_guard<std::mutex> lk(l->scene->mutex); memcpy(l->scene->sphereLights.recs[l->index].em, c, 12); LIGHT_DIRTY(l); }
 void giCSetSphereLightRadius(GiCSphereLight* l, float rx, float ry, float rz)
-{
+{ std::lock_guard<std::mutex> lk(l->scene->mutex);
   // Knud Thomsen ellipsoid surface approximation (Gi.cpp:2635-2651)
   float ab = powf(rx * ry, 1.6f), ac = powf(rx * rz, 1.6f), bc = powf(ry * rz, 1.6f);
   float area = float(powf((ab + ac + bc) / 3.0f, 1.0f / 1.6f) * 4.0f * M_PI);
@@ -583,7 +583,7 @@ void giCSetSphereLightRadius(GiCSphereLight* l, float rx, float ry, float rz)
   r.radius[0] = rx; r.radius[1] = ry; r.radius[2] = rz; r.area = area;
   LIGHT_DIRTY(l);
 }
-void giCSetSphereLightDiffuseSpecular(GiCSphereLight* l, float d, float s) { l->scene->sphereLights.recs[l->index].ds = packHalf2x16(d, s); LIGHT_DIRTY(l); }
+void giCSetSphereLightDiffuseSpecular(GiCSphereLight* l, float d, float s) { std::lock_guard<std::mutex> lk(l->scene->mutex); l->scene->sphereLights.recs[l->index].ds = packHalf2x16(d, s); LIGHT_DIRTY(l); }
 
 GiCDistantLight* giCCreateDistantLight(GiCScene* scene)
 {
@@ -602,16 +602,16 @@ void giCDestroyDistantLight(GiCScene* scene, GiCDistantLight* l)
   scene->distantLights.remove(l->index); scene->dirty |= DIRTY_LIGHTS | DIRTY_FRAMEBUFFER;
   delete l;
 }
-void giCSetDistantLightDirection(GiCDistantLight* l, const float* d) { memcpy(l->scene->distantLights.recs[l->index].dir, d, 12); LIGHT_DIRTY(l); }
-void giCSetDistantLightBaseEmission(GiCDistantLight* l, const float* c) { memcpy(l->scene->distantLights.recs[l->index].em, c, 12); LIGHT_DIRTY(l); }
+void giCSetDistantLightDirection(GiCDistantLight* l, const float* d) { std::lock_guard<std::mutex> lk(l->scene->mutex); memcpy(l->scene->distantLights.recs[l->index].dir, d, 12); LIGHT_DIRTY(l); }
+void giCSetDistantLightBaseEmission(GiCDistantLight* l, const float* c) { std::lock_guard<std::mutex> lk(l->scene->mutex); memcpy(l->scene->distantLights.recs[l->index].em, c, 12); LIGHT_DIRTY(l); }
 void giCSetDistantLightAngle(GiCDistantLight* l, float angle)
-{
+{ std::lock_guard<std::mutex> lk(l->scene->mutex);
   float half = 0.5f * angle; // Gi.cpp:2723-2735
   DistantLightRec& r = l->scene->distantLights.recs[l->index];
   r.angle = angle; r.invPdf = (half > 0.0f) ? float(2.0f * M_PI * (1.0f - cosf(half))) : 1.0f;
   LIGHT_DIRTY(l);
 }
-void giCSetDistantLightDiffuseSpecular(GiCDistantLight* l, float d, float s) { l->scene->distantLights.recs[l->index].ds = packHalf2x16(d, s); LIGHT_DIRTY(l); }
+void giCSetDistantLightDiffuseSpecular(GiCDistantLight* l, float d, float s) { std::lock_guard<std::mutex> lk(l->scene->mutex); l->scene->distantLights.recs[l->index].ds = packHalf2x16(d, s); LIGHT_DIRTY(l); }
 
 GiCRectLight* giCCreateRectLight(GiCScene* scene)
 {
@@ -631,14 +631,14 @@ void giCDestroyRectLight(GiCScene* scene, GiCRectLight* l)
   scene->rectLights.remove(l->index); scene->dirty |= DIRTY_LIGHTS | DIRTY_FRAMEBUFFER;
   delete l;
 }
-void giCSetRectLightOrigin(GiCRectLight* l, const float* o) { memcpy(l->scene->rectLights.recs[l->index].origin, o, 12); LIGHT_DIRTY(l); }
+void giCSetRectLightOrigin(GiCRectLight* l, const float* o) { std::lock_guard<std::mutex> lk(l->scene->mutex); memcpy(l->scene->rectLights.recs[l->index].origin, o, 12); LIGHT_DIRTY(l); }
 void giCSetRectLightTangents(GiCRectLight* l, const float* t0, const float* t1)
-{
+{ std::lock_guard<std::mutex> lk(l->scene->mutex);
   RectLightRec& r = l->scene->rectLights.recs[l->index]; r.t0 = encodeDirection(t0); r.t1 = encodeDirection(t1); LIGHT_DIRTY(l);
 }
-void giCSetRectLightBaseEmission(GiCRectLight* l, const float* c) { memcpy(l->scene->rectLights.recs[l->index].em, c, 12); LIGHT_DIRTY(l); }
-void giCSetRectLightDimensions(GiCRectLight* l, float w, float h) { RectLightRec& r = l->scene->rectLights.recs[l->index]; r.width = w; r.height = h; LIGHT_DIRTY(l); }
-void giCSetRectLightDiffuseSpecular(GiCRectLight* l, float d, float s) { l->scene->rectLights.recs[l->index].ds = packHalf2x16(d, s); LIGHT_DIRTY(l); }
+void giCSetRectLightBaseEmission(GiCRectLight* l, const float* c) { std::lock_guard<std::mutex> lk(l->scene->mutex); memcpy(l->scene->rectLights.recs[l->index].em, c, 12); LIGHT_DIRTY(l); }
+void giCSetRectLightDimensions(GiCRectLight* l, float w, float h) { std::lock_guard<std::mutex> lk(l->scene->mutex); RectLightRec& r = l->scene->rectLights.recs[l->index]; r.width = w; r.height = h; LIGHT_DIRTY(l); }
+void giCSetRectLightDiffuseSpecular(GiCRectLight* l, float d, float s) { std::lock_guard<std::mutex> lk(l->scene->mutex); l->scene->rectLights.recs[l->index].ds = packHalf2x16(d, s); LIGHT_DIRTY(l); }
 
 GiCDiskLight* giCCreateDiskLight(GiCScene* scene)
 {
@@ -658,14 +658,14 @@ void giCDestroyDiskLight(GiCScene* scene, GiCDiskLight* l)
   scene->diskLights.remove(l->index); scene->dirty |= DIRTY_LIGHTS | DIRTY_FRAMEBUFFER;
   delete l;
 }
-void giCSetDiskLightOrigin(GiCDiskLight* l, const float* o) { memcpy(l->scene->diskLights.recs[l->index].origin, o, 12); LIGHT_DIRTY(l); }
+void giCSetDiskLightOrigin(GiCDiskLight* l, const float* o) { std::lock_guard<std::mutex> lk(l->scene->mutex); memcpy(l->scene->diskLights.recs[l->index].origin, o, 12); LIGHT_DIRTY(l); }
 void giCSetDiskLightTangents(GiCDiskLight* l, const float* t0, const float* t1)
-{
+{ std::lock_guard<std::mutex> lk(l->scene->mutex);
   DiskLightRec& r = l->scene->diskLights.recs[l->index]; r.t0 = encodeDirection(t0); r.t1 = encodeDirection(t1); LIGHT_DIRTY(l);
 }
-void giCSetDiskLightBaseEmission(GiCDiskLight* l, const float* c) { memcpy(l->scene->diskLights.recs[l->index].em, c, 12); LIGHT_DIRTY(l); }
-void giCSetDiskLightRadius(GiCDiskLight* l, float rx, float ry) { DiskLightRec& r = l->scene->diskLights.recs[l->index]; r.rx = rx; r.ry = ry; LIGHT_DIRTY(l); }
-void giCSetDiskLightDiffuseSpecular(GiCDiskLight* l, float d, float s) { l->scene->diskLights.recs[l->index].ds = packHalf2x16(d, s); LIGHT_DIRTY(l); }
+void giCSetDiskLightBaseEmission(GiCDiskLight* l, const float* c) { std::lock_guard<std::mutex> lk(l->scene->mutex); memcpy(l->scene->diskLights.recs[l->index].em, c, 12); LIGHT_DIRTY(l); }
+void giCSetDiskLightRadius(GiCDiskLight* l, float rx, float ry) { std::lock_guard<std::mutex> lk(l->scene->mutex); DiskLightRec& r = l->scene->diskLights.recs[l->index]; r.rx = rx; r.ry = ry; LIGHT_DIRTY(l); }
+void giCSetDiskLightDiffuseSpecular(GiCDiskLight* l, float d, float s) { std::lock_guard<std::mutex> lk(l->scene->mutex); l->scene->diskLights.recs[l->index].ds = packHalf2x16(d, s); LIGHT_DIRTY(l); }
 
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -729,12 +729,17 @@ void giCDestroyDomeLight(GiCDomeLight* l)
 void giCSetDomeLightTexture(GiCDomeLight* l, GiCTexture* t)
 {
   if (!l) return;
-  if (l->ownsTexture) { giCDestroyTexture(l->texture); l->ownsTexture = false; }
-  l->texture = t; l->scene->dirty |= DIRTY_FRAMEBUFFER;
+  GiCTexture* old = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(l->scene->mutex);
+    if (l->ownsTexture) { old = l->texture; l->ownsTexture = false; }
+    l->texture = t; l->scene->dirty |= DIRTY_FRAMEBUFFER;
+  }
+  if (old) giCDestroyTexture(old); // takes the scene mutex itself
 }
-void giCSetDomeLightRotation(GiCDomeLight* l, const float* q) { memcpy(l->rotation, q, 16); l->scene->dirty |= DIRTY_FRAMEBUFFER; }
-void giCSetDomeLightBaseEmission(GiCDomeLight* l, const float* c) { memcpy(l->baseEmission, c, 12); l->scene->dirty |= DIRTY_FRAMEBUFFER; }
-void giCSetDomeLightDiffuseSpecular(GiCDomeLight* l, float d, float s) { l->diffuse = d; l->specular = s; l->scene->dirty |= DIRTY_FRAMEBUFFER; }
+void giCSetDomeLightRotation(GiCDomeLight* l, const float* q) { std::lock_guard<std::mutex> lk(l->scene->mutex); memcpy(l->rotation, q, 16); l->scene->dirty |= DIRTY_FRAMEBUFFER; }
+void giCSetDomeLightBaseEmission(GiCDomeLight* l, const float* c) { std::lock_guard<std::mutex> lk(l->scene->mutex); memcpy(l->baseEmission, c, 12); l->scene->dirty |= DIRTY_FRAMEBUFFER; }
+void giCSetDomeLightDiffuseSpecular(GiCDomeLight* l, float d, float s) { std::lock_guard<std::mutex> lk(l->scene->mutex); l->diffuse = d; l->specular = s; l->scene->dirty |= DIRTY_FRAMEBUFFER; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // render buffers (Gi.cpp:2978-3006; memory is created lazily by giRender, :1997-2034 -- here at creation so that

@@ -310,6 +310,48 @@ def test_edge_cases(gi, orc):
     render_both(gi, orc, desc, RenderSettings(spp=2, max_bounces=4), 48, 27, exact=True)
 
 
+def test_parallel_scene_sync(gi, orc):
+    """Hydra syncs prims from a thread pool (renderDelegate.cpp:376-381): meshes, materials and lights created and edited from eight
+    threads at once -- no crash, and once the creation ORDER is made deterministic again (one mesh per thread-safe slot) the image is the
+    sequential one."""
+    import ctypes as C
+    import threading
+    from gatling_amd import capi
+    desc = sphere_grid(grid=4, subdivisions=1, material_count=4)
+    rs = RenderSettings(spp=2, max_bounces=4, progressive_accumulation=False)
+    sc = gi.Scene(desc)
+    try:
+        ref = sc.render(rs, 64, 36)
+        L = sc.L
+        errors = []
+
+        def hammer(k):
+            try:
+                for it in range(40):
+                    m = desc.meshes[(k + it) % len(desc.meshes)]
+                    h = sc.meshes[(k + it) % len(sc.meshes)]
+                    L.giCSetMeshTransform(h, capi._fp(np.asarray(m.transform, np.float32).reshape(-1)))
+                    L.giCSetMeshVisibility(h, 1)
+                    md = capi.GiCMaterialDesc(1, 0, (C.c_float * 48)(*([0.5] * 48)))
+                    mat = L.giCCreateMaterial(sc.handle, b"tmp", C.byref(md))
+                    light = L.giCCreateSphereLight(sc.handle)
+                    L.giCSetSphereLightRadius(light, 0.1, 0.1, 0.1)
+                    L.giCDestroySphereLight(sc.handle, light)
+                    L.giCDestroyMaterial(mat)
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+        threads = [threading.Thread(target=hammer, args=(k,)) for k in range(8)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors
+        again = sc.render(rs, 64, 36)  # same meshes, same order, same transforms: the scene was only marked dirty and rebuilt
+    finally:
+        sc.close()
+    assert np.array_equal(again, ref)
+
+
 def test_error_behaviour(gi):
     desc = cornell_box()
     sc = gi.Scene(desc)
