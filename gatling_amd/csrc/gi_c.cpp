@@ -776,6 +776,7 @@ void giCSetRenderBufferDeviceOnly(GiCRenderBuffer* rb, int32_t deviceOnly) { if 
 int giCSetSceneOption(GiCScene* scene, int32_t option, int32_t value)
 {
   if (!scene) return GI_C_ERROR;
+  std::lock_guard<std::mutex> g(scene->mutex);
   if (option == GI_C_SCENE_OPTION_COUNT_TRAVERSAL) { scene->countTraversal = value != 0; return GI_C_OK; }
   if (option == GI_C_SCENE_OPTION_KERNEL_TIMERS) { scene->kernelTimers = value != 0; scene->kernelTimerStride = value > 0 ? (uint32_t)value : 1u; return GI_C_OK; }
   if (option == GI_C_SCENE_OPTION_POOL_SLOTS) { scene->optPoolSlots = value > 0 ? (uint64_t)value : 0; return GI_C_OK; }
