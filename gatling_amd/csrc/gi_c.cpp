@@ -1098,6 +1098,7 @@ static uint32_t traceDynRefill(const GiCScene* s)
   uint32_t r = s->optTraceDyn >= 0 ? (uint32_t)s->optTraceDyn : 8u;
   if (const char* e = getenv("GATLING_TRACE_DYN")) r = (uint32_t)std::max(0, std::min(64, atoi(e)));
   if (const char* e = getenv("GATLING_TRACE_DYN_SPILL8")) { if (r && atoi(e)) r |= TRACE_DYN_SPILL8; }
+  if (const char* e = getenv("GATLING_DYN_CLAIM")) { if (r) r |= (uint32_t)std::max(1, std::min(1024, atoi(e) / 64)) << 16; } // rays per cursor atomic (experiments)
   return r;
 }
 

@@ -289,6 +289,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
 // new rays with one atomic on the launch's cursor.  No barriers, no appends; k_route then streams the results into the
 // per-class shade queues / the regen queue.  Per-ray arithmetic is trav_step's, i.e. identical to k_trace's.
 // ------------------------------------------------------------------------------------------------
+#ifndef GI_DYN_CLAIM
+#define GI_DYN_CLAIM 256
+#endif
+constexpr uint32_t DYN_CLAIM = GI_DYN_CLAIM; // rays per cursor atomic (multiple of 64)
 template <bool TWO> struct DynRay { using type = RayTrav; };
 template <> struct DynRay<true> { using type = RayTrav2; };
 template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool CUTOUT, bool TWO = false>
@@ -316,10 +320,18 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
   // that run idle are then handed the chunk's rays in order with register shuffles, so a refill never waits on memory.
   F4 pro = F4{0.0f, 0.0f, 0.0f, 0.0f}, prd = F4{0.0f, 0.0f, 0.0f, 0.0f}; uint32_t prec = 0u, prng = 0u;
   uint32_t chunkCount = 0u, chunkUsed = 0u; // wave-uniform
+  // Rays are claimed DYN_CLAIM at a time: a device-scope atomic on one address completes ~88 times per microsecond, so one claim per
+  // 64 rays (1 M claims for a 64 Mi-ray launch) was a 11 ms floor under every launch -- the reason no traversal optimisation showed.
+  const uint32_t claim = (refill >> 16) ? (refill >> 16) * 64u : DYN_CLAIM; refill &= 0xffu;
+  uint32_t claimBase = 0u, claimLeft = 0u; // wave-uniform
   auto next_chunk = [&]() {
-    uint32_t base = 0u;
-    if (lane == 0u) base = atomicAdd(cursor, 64u);
-    base = (uint32_t)__shfl((int)base, 0);
+    if (claimLeft == 0u) {
+      uint32_t b = 0u;
+      if (lane == 0u) b = atomicAdd(cursor, claim);
+      claimBase = (uint32_t)__shfl((int)b, 0); claimLeft = claim;
+    }
+    const uint32_t base = claimBase;
+    claimBase += 64u; claimLeft -= 64u;
     chunkCount = base < n ? (n - base < 64u ? n - base : 64u) : 0u;
     chunkUsed = 0u;
     if (lane < chunkCount) {
@@ -792,18 +804,22 @@ static void launchTraceVariant(hipStream_t s, uint32_t blocks, const SceneView& 
     // persistent waves pay the scratch set-up once, so trees deeper than 8 levels may keep 8 entries in LDS (more
     // resident waves) and spill the rest (TRACE_DYN_SPILL8), or keep 16 in LDS
     if (sc.twoLevel) { // instanced scene: TLAS + shared per-mesh BLASes
-      hipLaunchKernelGGL((k_trace_dyn2<ANYHIT, COUNT, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), 16u * TRACE_BLOCK * (uint32_t)sizeof(uint2), s, sc, st, qs, cnt, qIn, dynRefill & 0xffu);
+      hipLaunchKernelGGL((k_trace_dyn2<ANYHIT, COUNT, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), 16u * TRACE_BLOCK * (uint32_t)sizeof(uint2), s, sc, st, qs, cnt, qIn, (dynRefill & 0xffu) | ((dynRefill >> 16) << 16));
       if (!ANYHIT) hipLaunchKernelGGL(k_route, dim3(routeBlocks), dim3(BLOCK), 0, s, sc, st, qs, cnt, qIn, qMiss);
       return;
     }
     const bool spill8 = (dynRefill & TRACE_DYN_SPILL8) != 0u;
-    dynRefill &= 0xffu;
+    const uint32_t claimChunks = dynRefill >> 16;
+    dynRefill = (dynRefill & 0xffu) | (claimChunks << 16);
     const uint32_t entries = (sc.bvhDepth <= 8u || spill8) ? 8u : 16u;
     const uint32_t stackBytes = entries * TRACE_BLOCK * (uint32_t)sizeof(uint2);
-    if (sc.bvhDepth <= 8u) hipLaunchKernelGGL((k_trace_dyn<ANYHIT, COUNT, 8, false, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill);
-    else if (spill8) hipLaunchKernelGGL((k_trace_dyn<ANYHIT, COUNT, 8, true, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill);
-    else if (sc.bvhDepth <= 16u) hipLaunchKernelGGL((k_trace_dyn<ANYHIT, COUNT, 16, false, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill);
-    else hipLaunchKernelGGL((k_trace_dyn<ANYHIT, COUNT, 16, true, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill);
+#define GI_LAUNCH_DYN(K) do { \
+    if (sc.bvhDepth <= 8u) hipLaunchKernelGGL((K<ANYHIT, COUNT, 8, false, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill); \
+    else if (spill8) hipLaunchKernelGGL((K<ANYHIT, COUNT, 8, true, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill); \
+    else if (sc.bvhDepth <= 16u) hipLaunchKernelGGL((K<ANYHIT, COUNT, 16, false, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill); \
+    else hipLaunchKernelGGL((K<ANYHIT, COUNT, 16, true, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill); } while (0)
+    GI_LAUNCH_DYN(k_trace_dyn);
+#undef GI_LAUNCH_DYN
     if (!ANYHIT) hipLaunchKernelGGL(k_route, dim3(routeBlocks), dim3(BLOCK), 0, s, sc, st, qs, cnt, qIn, qMiss);
     return;
   }
