@@ -41,7 +41,7 @@ __global__ void k_init(PathState st, QueueSet qs, Counters* cnt, uint32_t n, uin
     cnt->count[q][sdx].v = c;
   }
   if (i == 0) {
-    cnt->workBase[0].v = 0; cnt->workBase[1].v = 0; cnt->cursor[0].v = 0; cnt->cursor[1].v = 0;
+    cnt->workBase[0].v = 0; cnt->workBase[1].v = 0; for (uint32_t k = 0; k < NCURSOR; k++) { cnt->cursor[0][k].v = 0; cnt->cursor[1][k].v = 0; }
     if (resetStats) { cnt->segments = 0; cnt->shadowRays = 0; cnt->nodesVisited = 0; cnt->trisTested = 0; cnt->shadowNodesVisited = 0; cnt->shadowTrisTested = 0; }
   }
   for (; i < n; i += gridDim.x * blockDim.x) {
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
 // per-class shade queues / the regen queue.  Per-ray arithmetic is trav_step's, i.e. identical to k_trace's.
 // ------------------------------------------------------------------------------------------------
 #ifndef GI_DYN_CLAIM
-#define GI_DYN_CLAIM 256
+#define GI_DYN_CLAIM 128
 #endif
 constexpr uint32_t DYN_CLAIM = GI_DYN_CLAIM; // rays per cursor atomic (multiple of 64)
 template <bool TWO> struct DynRay { using type = RayTrav; };
@@ -307,7 +307,7 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
   QueueReader rd; reader_init(rd, cnt, qIn, qs.cap);
   const uint32_t n = rd.pre[NSHARD];
   if (blockIdx.x == 0 && threadIdx.x == 0) { if (ANYHIT) cnt->shadowRays += n; else cnt->segments += n; } // single writer per launch
-  uint32_t* cursor = &cnt->cursor[ANYHIT ? 1 : 0].v;
+  PaddedCounter* cursors = cnt->cursor[ANYHIT ? 1 : 0];
   const uint32_t lane = __lane_id();
   TraceCounters tc{0u, 0u};
   typename DynRay<TWO>::type R;
@@ -323,16 +323,25 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
   // Rays are claimed DYN_CLAIM at a time: a device-scope atomic on one address completes ~88 times per microsecond, so one claim per
   // 64 rays (1 M claims for a 64 Mi-ray launch) was a 11 ms floor under every launch -- the reason no traversal optimisation showed.
   const uint32_t claim = (refill >> 16) ? (refill >> 16) * 64u : DYN_CLAIM; refill &= 0xffu;
+  // range k = rays [k * per, min(n, (k + 1) * per)); a wave starts on the range of its index and moves on when a range runs dry, so the
+  // ranges also balance each other at the end of the launch
+  const uint32_t per = ((n + NCURSOR - 1u) / NCURSOR + 63u) & ~63u;
+  uint32_t range = (blockIdx.x * (TRACE_BLOCK / 64u) + (threadIdx.x >> 6)) % NCURSOR, rangesTried = 0u;
   uint32_t claimBase = 0u, claimLeft = 0u; // wave-uniform
   auto next_chunk = [&]() {
-    if (claimLeft == 0u) {
+    while (claimLeft == 0u && rangesTried < NCURSOR) {
       uint32_t b = 0u;
-      if (lane == 0u) b = atomicAdd(cursor, claim);
-      claimBase = (uint32_t)__shfl((int)b, 0); claimLeft = claim;
+      if (lane == 0u) b = atomicAdd(&cursors[range].v, claim);
+      b = (uint32_t)__shfl((int)b, 0);
+      const uint32_t lo = range * per, hi = lo + per < n ? lo + per : n;
+      if (lo < hi && b < hi - lo) { claimBase = lo + b; claimLeft = (hi - lo - b) < claim ? ((hi - lo - b + 63u) & ~63u) : claim; rangesTried = 0u; }
+      else { range = (range + 1u) % NCURSOR; rangesTried++; }
     }
-    const uint32_t base = claimBase;
-    claimBase += 64u; claimLeft -= 64u;
-    chunkCount = base < n ? (n - base < 64u ? n - base : 64u) : 0u;
+    const uint32_t base = claimLeft ? claimBase : n;
+    if (claimLeft) { claimBase += 64u; claimLeft -= 64u; }
+    // rays of this chunk: up to the end of the claim's range (the last chunk of a range may be partial)
+    const uint32_t rhi = (range * per + per) < n ? (range * per + per) : n;
+    chunkCount = base < rhi ? (rhi - base < 64u ? rhi - base : 64u) : 0u;
     chunkUsed = 0u;
     if (lane < chunkCount) {
       prec = reader_index(rd, base + lane);

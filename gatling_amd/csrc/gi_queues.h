@@ -90,7 +90,7 @@ __device__ __forceinline__ void zero_next_counters(Counters* cnt, uint32_t par)
     for (uint32_t c = 0; c < MAT_CLASS_COUNT; c++) cnt->count[Q_HIT + c][t].v = 0;
     cnt->count[Q_SHADOW][t].v = 0;
   }
-  if (t < 2u) cnt->cursor[t].v = 0; // k_trace_dyn's ray cursors (closest, shadow)
+  if (t < 2u * NCURSOR) cnt->cursor[t / NCURSOR][t % NCURSOR].v = 0; // k_trace_dyn's ray cursors (closest, shadow)
 }
 
 

@@ -215,6 +215,7 @@ struct PathState {
 constexpr uint32_t MAT_CLASS_COUNT = 3;
 enum : uint32_t { Q_TRACE_A = 0, Q_TRACE_B = 1, Q_REGEN_A = 2, Q_REGEN_B = 3, Q_SHADOW = 4, Q_HIT = 5, Q_COUNT = Q_HIT + MAT_CLASS_COUNT };
 constexpr uint32_t NSHARD = 8;
+constexpr uint32_t NCURSOR = 8;
 struct QueueSet {
   uint32_t* slot[Q_COUNT]; // each NSHARD * cap entries
   F4* a[Q_COUNT];          // null where the queue has no such field
@@ -228,7 +229,9 @@ struct alignas(128) PaddedCounter { uint32_t v; uint32_t pad[31]; };
 struct Counters {
   PaddedCounter count[Q_COUNT][NSHARD];
   PaddedCounter workBase[2]; // work items handed out before iteration parity p (k_raygen reads [p], writes [p^1])
-  PaddedCounter cursor[2];   // k_trace_dyn: next unclaimed ray of this iteration's closest-hit [0] / shadow [1] queue
+  // k_trace_dyn: the launch's rays [0, n) are cut into NCURSOR equal ranges, each with its own cursor on its own 128-byte line (a
+  // device-scope atomic on one line completes ~88 times per microsecond; 8 lines, 8x that); [0]: closest-hit queue, [1]: shadow queue
+  PaddedCounter cursor[2][NCURSOR];
   unsigned long long segments, shadowRays, nodesVisited, trisTested, shadowNodesVisited, shadowTrisTested;
 };
 
