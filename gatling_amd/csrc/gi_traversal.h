@@ -227,6 +227,20 @@ struct WaveTri {
   uint4 hit[64];               // per ray lane: (triangle index, u bits, v bits, material word) of that hit
   uint32_t queue[128];         // ring of pending (ray lane, triangle) pairs
 };
+// WaveTri lives in LDS, but through a C++ reference the compiler only sees a generic pointer and emits FLAT loads / stores (vector-memory
+// path, each volatile one followed by s_waitcnt vmcnt(0), i.e. a stall on every outstanding global load).  These accessors cast back to
+// address space 3, so the exchanges are ds_read / ds_write with lgkmcnt waits.
+#define GI_LDS __attribute__((address_space(3)))
+typedef uint32_t gi_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void wt_queue_put(WaveTri& W, uint32_t i, uint32_t v) { *(volatile GI_LDS uint32_t*)&((GI_LDS WaveTri*)&W)->queue[i] = v; }
+__device__ __forceinline__ uint32_t wt_queue_get(WaveTri& W, uint32_t i) { return *(volatile GI_LDS uint32_t*)&((GI_LDS WaveTri*)&W)->queue[i]; }
+__device__ __forceinline__ void wt_best_put(WaveTri& W, uint32_t i, unsigned long long v) { *(volatile GI_LDS unsigned long long*)&((GI_LDS WaveTri*)&W)->best[i] = v; }
+__device__ __forceinline__ unsigned long long wt_best_get(WaveTri& W, uint32_t i) { return *(volatile GI_LDS unsigned long long*)&((GI_LDS WaveTri*)&W)->best[i]; }
+__device__ __forceinline__ void wt_best_min(WaveTri& W, uint32_t i, unsigned long long v)
+{ __hip_atomic_fetch_min((GI_LDS unsigned long long*)&((GI_LDS WaveTri*)&W)->best[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void wt_hit_put(WaveTri& W, uint32_t i, uint32_t x, uint32_t y, uint32_t z, uint32_t w)
+{ gi_u4 v = {x, y, z, w}; *(volatile GI_LDS gi_u4*)&((GI_LDS WaveTri*)&W)->hit[i] = v; }
+__device__ __forceinline__ uint4 wt_hit_get(WaveTri& W, uint32_t i) { const gi_u4 v = *(volatile GI_LDS gi_u4*)&((GI_LDS WaveTri*)&W)->hit[i]; return make_uint4(v.x, v.y, v.z, v.w); }
 // Staging buffer of the cooperative fetch (scenes in global memory).  A lane that loads its own 80-byte node issues five
 // 16-byte loads to a cache line no other lane touches, so every load instruction costs the L1 64 tag look-ups; measured,
 // the texture-address unit was busy 63 % of k_trace's time.  Instead lane i of the wave loads 16-byte piece (i % 5) of
@@ -243,7 +257,7 @@ __device__ __forceinline__ void wave_tri_batch(WaveTri& W, WaveStage* S, uint32_
 {
   const uint32_t lane = __lane_id();
   const bool act = lane < cnt;
-  const uint32_t e = act ? *(volatile uint32_t*)&W.queue[(head + lane) & 127u] : 0u;
+  const uint32_t e = act ? wt_queue_get(W, (head + lane) & 127u) : 0u;
   const uint32_t rl = e >> TRI_ID_BITS, triIdx = e & ((1u << TRI_ID_BITS) - 1u);
   // the owning lane's ray (executed by all lanes: wave-uniform control flow)
   const V3 o = v3(__shfl(R.o.x, (int)rl), __shfl(R.o.y, (int)rl), __shfl(R.o.z, (int)rl));
@@ -277,8 +291,8 @@ __device__ __forceinline__ void wave_tri_batch(WaveTri& W, WaveStage* S, uint32_
     }
     if (accept) {
       const unsigned long long key = ((unsigned long long)f2u(t) << 32) | (unsigned long long)(c.y + 1u);
-      atomicMin(&W.best[rl], key);
-      if (*(volatile unsigned long long*)&W.best[rl] == key) W.hit[rl] = make_uint4(triIdx, f2u(u), f2u(v), c.w);
+      wt_best_min(W, rl, key);
+      if (wt_best_get(W, rl) == key) wt_hit_put(W, rl, triIdx, f2u(u), f2u(v), c.w);
     }
   }
 }
@@ -323,7 +337,7 @@ __device__ __forceinline__ bool wave_step(RayTrav& R, bool alive, WaveTri& W, Wa
     if (Gt.y) {
       const uint32_t k = (uint32_t)__ffs((int)Gt.y) - 1u;
       Gt.y &= Gt.y - 1u;
-      *(volatile uint32_t*)&W.queue[(tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & 127u] = (lane << TRI_ID_BITS) | (Gt.x + k);
+      wt_queue_put(W, (tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & 127u, (lane << TRI_ID_BITS) | (Gt.x + k));
     }
     tail += (uint32_t)__popcll(m);
     if (tail - head >= 64u) { wave_tri_batch<COUNT, ALL_LDS, CUTOUT, COOP>(W, S, head, 64u, R, rng, sc, s_tris, ldsTris, tc); head += 64u; }
@@ -331,7 +345,7 @@ __device__ __forceinline__ bool wave_step(RayTrav& R, bool alive, WaveTri& W, Wa
   if (tail != head) wave_tri_batch<COUNT, ALL_LDS, CUTOUT, COOP>(W, S, head, tail - head, R, rng, sc, s_tris, ldsTris, tc);
   bool done = false;
   if (alive) {
-    const unsigned long long key = *(volatile unsigned long long*)&W.best[lane];
+    const unsigned long long key = wt_best_get(W, lane);
     R.tBest = u2f((uint32_t)(key >> 32));
     R.found = (uint32_t)key != 0u;
     done = (ANYHIT && R.found) ? true : trav_pop<STACK, OVERFLOW>(R, s_stack, overflow);
@@ -340,12 +354,12 @@ __device__ __forceinline__ bool wave_step(RayTrav& R, bool alive, WaveTri& W, Wa
 }
 
 // start of a ray in the cooperative scheme (after trav_init)
-__device__ __forceinline__ void wave_ray_begin(WaveTri& W, float tMax) { *(volatile unsigned long long*)&W.best[__lane_id()] = (unsigned long long)f2u(tMax) << 32; }
+__device__ __forceinline__ void wave_ray_begin(WaveTri& W, float tMax) { wt_best_put(W, __lane_id(), (unsigned long long)f2u(tMax) << 32); }
 // result of a finished ray
 __device__ __forceinline__ void wave_ray_end(WaveTri& W, RayTrav& R)
 {
   __atomic_signal_fence(__ATOMIC_SEQ_CST); // compiler only: the winning lane's store precedes this load in the wave's program order
-  if (R.found) { const uint4 h = W.hit[__lane_id()]; R.bestTri = h.x; R.bestU = u2f(h.y); R.bestV = u2f(h.z); R.bestMat = h.w; }
+  if (R.found) { const uint4 h = wt_hit_get(W, __lane_id()); R.bestTri = h.x; R.bestU = u2f(h.y); R.bestV = u2f(h.z); R.bestMat = h.w; }
 }
 
 template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool ALL_LDS, bool CUTOUT>
@@ -420,7 +434,7 @@ __device__ __forceinline__ void wave_tri_batch2(WaveTri& W, uint32_t head, uint3
 {
   const uint32_t lane = __lane_id();
   const bool act = lane < cnt;
-  const uint32_t e = act ? *(volatile uint32_t*)&W.queue[(head + lane) & 127u] : 0u;
+  const uint32_t e = act ? wt_queue_get(W, (head + lane) & 127u) : 0u;
   const uint32_t rl = e >> TRI_ID_BITS, bt = e & ((1u << TRI_ID_BITS) - 1u);
   const V3 o = v3(__shfl(R.wo.x, (int)rl), __shfl(R.wo.y, (int)rl), __shfl(R.wo.z, (int)rl));
   const V3 d = v3(__shfl(R.wd.x, (int)rl), __shfl(R.wd.y, (int)rl), __shfl(R.wd.z, (int)rl));
@@ -449,8 +463,8 @@ __device__ __forceinline__ void wave_tri_batch2(WaveTri& W, uint32_t head, uint3
     }
     if (accept) {
       const unsigned long long key = ((unsigned long long)f2u(t) << 32) | (unsigned long long)(orig + 1u);
-      atomicMin(&W.best[rl], key);
-      if (*(volatile unsigned long long*)&W.best[rl] == key) W.hit[rl] = make_uint4(orig, f2u(u), f2u(v), c.w); // .x = scene-order id; the kernel maps it to the flat index
+      wt_best_min(W, rl, key);
+      if (wt_best_get(W, rl) == key) wt_hit_put(W, rl, orig, f2u(u), f2u(v), c.w); // .x = scene-order id; the kernel maps it to the flat index
     }
   }
 }
@@ -480,7 +494,7 @@ __device__ __forceinline__ bool wave_step2(RayTrav2& R, bool alive, WaveTri& W, 
     if (Gt.y) {
       const uint32_t k = (uint32_t)__ffs((int)Gt.y) - 1u;
       Gt.y &= Gt.y - 1u;
-      *(volatile uint32_t*)&W.queue[(tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & 127u] = (lane << TRI_ID_BITS) | (Gt.x + k);
+      wt_queue_put(W, (tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & 127u, (lane << TRI_ID_BITS) | (Gt.x + k));
     }
     tail += (uint32_t)__popcll(m);
     if (tail - head >= 64u) { wave_tri_batch2<COUNT, CUTOUT>(W, head, 64u, R, rng, sc, tc); head += 64u; }
@@ -488,7 +502,7 @@ __device__ __forceinline__ bool wave_step2(RayTrav2& R, bool alive, WaveTri& W, 
   if (tail != head) wave_tri_batch2<COUNT, CUTOUT>(W, head, tail - head, R, rng, sc, tc);
   bool done = false;
   if (alive) {
-    const unsigned long long key = *(volatile unsigned long long*)&W.best[lane];
+    const unsigned long long key = wt_best_get(W, lane);
     R.tBest = u2f((uint32_t)(key >> 32));
     R.found = (uint32_t)key != 0u;
     if (ANYHIT && R.found) done = true;
