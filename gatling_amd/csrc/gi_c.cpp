@@ -501,40 +501,42 @@ static GiCMesh* createMeshImpl(GiCScene* scene, const GiCMeshDesc* d)
 void giCSetMeshTransform(GiCMesh* mesh, const float* mat4x4)
 {
   if (!mesh || !mat4x4) return;
+  std::lock_guard<std::mutex> g(mesh->scene->mutex); // buildScene reads the mesh under this lock (giCRender on another thread)
   memcpy(mesh->transform, mat4x4, sizeof(float) * 16);
-  std::lock_guard<std::mutex> g(mesh->scene->mutex);
   mesh->scene->dirty |= DIRTY_BVH | DIRTY_FRAMEBUFFER;
 }
 
 void giCSetMeshInstanceTransforms(GiCMesh* mesh, uint32_t count, const float* transforms)
 {
   if (!mesh || (count && !transforms)) return;
-  mesh->instanceTransforms.assign(transforms, transforms + (size_t)count * 16);
+  std::vector<float> copy(transforms, transforms + (size_t)count * 16); // copy outside the lock, swap inside
   std::lock_guard<std::mutex> g(mesh->scene->mutex);
+  mesh->instanceTransforms.swap(copy);
   mesh->scene->dirty |= DIRTY_BVH | DIRTY_FRAMEBUFFER;
 }
 
 void giCSetMeshInstanceIds(GiCMesh* mesh, uint32_t count, const int32_t* ids)
 {
   if (!mesh || (count && !ids)) return;
-  mesh->instanceIds.assign(ids, ids + count);
+  std::vector<int32_t> copy(ids, ids + count);
   std::lock_guard<std::mutex> g(mesh->scene->mutex);
+  mesh->instanceIds.swap(copy);
   mesh->scene->dirty |= DIRTY_BVH | DIRTY_FRAMEBUFFER;
 }
 
 void giCSetMeshMaterial(GiCMesh* mesh, GiCMaterial* mat)
 {
   if (!mesh) return;
-  mesh->material = mat;
   std::lock_guard<std::mutex> g(mesh->scene->mutex);
+  mesh->material = mat;
   mesh->scene->dirty |= DIRTY_BVH | DIRTY_FRAMEBUFFER;
 }
 
 void giCSetMeshVisibility(GiCMesh* mesh, int32_t visible)
 {
   if (!mesh) return;
-  mesh->visible = visible != 0;
   std::lock_guard<std::mutex> g(mesh->scene->mutex);
+  mesh->visible = visible != 0;
   mesh->scene->dirty |= DIRTY_BVH | DIRTY_FRAMEBUFFER;
 }
 
@@ -1089,9 +1091,6 @@ SceneView makeView(GiCScene* s)
   return v;
 }
 
-// Per-shard queue capacity: a producer launch of G blocks gives shard s at most ceil(G/NSHARD) blocks, each appending
-// at most ceil(slots/(G*256))*256 items per queue; a queue can be fed by two launches before it is consumed
-// (e.g. REGEN by k_trace and k_shade, TRACE by k_shade and the next k_raygen), hence the factor 2.
 // k_trace_dyn refill threshold for scenes that do not fit LDS (0 = use the block-synchronous k_trace)
 static uint32_t traceDynRefill(const GiCScene* s)
 {
@@ -1104,16 +1103,23 @@ static uint32_t traceDynRefill(const GiCScene* s)
 
 uint32_t shardCapacity(size_t slots, uint32_t gridA, uint32_t gridB)
 {
-  auto bound = [&](uint32_t G) { size_t trips = (slots + (size_t)G * 256 - 1) / ((size_t)G * 256); return (size_t)((G + NSHARD - 1) / NSHARD) * trips * 256; };
-  size_t cap = 2 * std::max(bound(std::max(gridA, 1u)), bound(std::max(gridB, 1u))) + 256;
-  cap = std::max(cap, (slots + NSHARD - 1) / NSHARD + 256);
-  return (uint32_t)cap;
+  // A queue holds at most `slots` records in total (a path sits in one queue at a time), but it is fed by SEVERAL launches before it is
+  // consumed -- TRACE[par] by k_raygen and one k_shade per material class, REGEN by k_trace / k_route, every k_shade and k_raygen
+  // (maxBounces == 0) -- and every launch starts dealing its blocks at shard 0.  A launch of G blocks that appends n records gives one
+  // shard at most ceil(G/NSHARD) * ceil(n/(256 G)) * 256 <= n/NSHARD + n/G + 32 G + 256 of them; summed over P producers with
+  // sum(n) <= slots this is slots/NSHARD + P * (slots/Gmin + 32 Gmax + 256).  block_append also raises Counters::overflow if a shard
+  // ever runs past its capacity (giCRender then fails instead of returning a corrupt image).
+  const size_t P = 2 + MAT_CLASS_COUNT;
+  const size_t gMin = std::max<size_t>(1, std::min(gridA, gridB)), gMax = std::max<size_t>(1, std::max(gridA, gridB));
+  const size_t cap = (slots + NSHARD - 1) / NSHARD + P * ((slots + gMin - 1) / gMin + 32 * gMax + 256);
+  return (uint32_t)std::min<size_t>(cap, slots + 256); // a shard can never hold more than the pool
 }
 
 int ensurePathState(GiCScene* s, size_t slots, uint32_t gridA, uint32_t gridB)
 {
   const uint32_t cap = shardCapacity(slots, gridA, gridB);
-  if (s->slots.alloc(slots) || s->dCounters.alloc(1)) return GI_C_ERROR;
+  if (s->slots.alloc(slots)) return GI_C_ERROR;
+  if (!s->dCounters.ptr) { if (s->dCounters.alloc(1)) return GI_C_ERROR; HIP_TRY(hipMemset(s->dCounters.ptr, 0, sizeof(Counters))); } // AOV-only renders never run k_init
   if (cap > s->queueCap) {
     const size_t n = (size_t)cap * NSHARD;
     for (uint32_t q = 0; q < Q_COUNT; q++) {
@@ -1355,7 +1361,7 @@ static int giCRenderImpl(const GiCRenderParams* params)
     const uint32_t mediaStride = rs.mediumStackSize ? rs.mediumStackSize * MEDIUM_FLOATS + 4u : 0u;
     if (mediaStride && s->media.alloc(slots * mediaStride)) return GI_C_ERROR;
     PathState ps{s->slots.ptr, s->media.ptr, mediaStride, nullptr, 0u, nullptr};
-    if (neeRb) {
+    if (neeRb && rs.nextEventEstimation) { // the reference compiles the NEE AOV write out with NEXT_EVENT_ESTIMATION (rp_main.rgen:397, 431)
       if (s->neeKey.alloc(pixels)) return GI_C_ERROR;
       HIP_TRY(hipMemsetAsync(s->neeKey.ptr, 0, pixels * sizeof(unsigned long long), st));
       ps.neeKey = s->neeKey.ptr;
@@ -1392,6 +1398,13 @@ static int giCRenderImpl(const GiCRenderParams* params)
       const uint32_t poolNow = (uint32_t)std::min<uint64_t>(slots, U.workTotal);
       U.poolSlots = poolNow;
       launchInit(st, ps, qs, s->dCounters.ptr, poolNow, batch == 0);
+      if (U.maxBounces == 0u) {
+        // rp_main.rgen:298-304: the bounce loop's exit test comes first, so with max-bounces 0 no ray is traced at all and every sample is
+        // black (no emission at the primary hit, no dome / background term); the accumulation still runs (progressive blend, alpha 1)
+        HIP_TRY(hipMemsetAsync(s->sampleBuf.ptr, 0, pixels * U.batchSamples * sizeof(F4), st));
+        launchAccumulate(st, U, s->sampleBuf.ptr, s->accum.ptr, colorOut, batch == 0, batch + 1 == numBatches);
+        continue;
+      }
       const uint64_t rounds = ((uint64_t)U.workTotal + poolNow - 1) / poolNow; // raygen rounds needed to hand out all work
       const uint64_t maxIters = (rounds + 2) * (std::max(1u, U.maxBounces) + 1) + 8;
       for (uint64_t it = 0; it < maxIters; it++) {
@@ -1413,7 +1426,7 @@ static int giCRenderImpl(const GiCRenderParams* params)
       }
       launchAccumulate(st, U, s->sampleBuf.ptr, s->accum.ptr, colorOut, batch == 0, batch + 1 == numBatches);
     }
-    if (neeRb) launchResolveNee(st, U, s->neeKey.ptr, reinterpret_cast<F4*>(neeRb->deviceMem), (uint32_t)pixels);
+    if (neeRb && ps.neeKey) launchResolveNee(st, U, s->neeKey.ptr, reinterpret_cast<F4*>(neeRb->deviceMem), (uint32_t)pixels);
     if (clockRb) { // ClockCycles: per-pixel cost -> heat map normalised to the frame maximum, on the host like _EncodeRenderBufferAsHeatmap (Gi.cpp:327-343)
       std::vector<uint32_t> counts(pixels);
       HIP_TRY(hipMemcpyAsync(counts.data(), s->pathSegments.ptr, pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -1431,6 +1444,11 @@ static int giCRenderImpl(const GiCRenderParams* params)
         } else { o[0] = (float)counts[p]; o[1] = 0.0f; o[2] = 0.0f; }
       }
       HIP_TRY(hipMemcpyAsync(clockRb->deviceMem, clockRb->hostMem, clockRb->size, hipMemcpyHostToDevice, st));
+    }
+    if (bouncesRb && U.maxBounces == 0u) { // rp_main.rgen:483-486 evaluates inferno(0 / 0) = NaN for every pixel of the tile
+      float* img = reinterpret_cast<float*>(bouncesRb->hostMem);
+      for (size_t p = 0; p < pixels; p++) { float* o = img + ((rowBegin + (p / width) * rowStride) * width + p % width) * 4; o[0] = o[1] = o[2] = NAN; }
+      HIP_TRY(hipMemcpyAsync(bouncesRb->deviceMem, bouncesRb->hostMem, bouncesRb->size, hipMemcpyHostToDevice, st));
     }
     for (GiCRenderBuffer* rb : {neeRb, bouncesRb}) {
       if (!rb || rb->deviceOnly) continue;
@@ -1457,6 +1475,7 @@ static int giCRenderImpl(const GiCRenderParams* params)
   S.renderMs = tEnd - tStart; S.samples = (uint64_t)pixels * rs.spp; S.iterations = iters; S.traceLaunches = traceLaunches;
   S.segments = s->hCounters->segments; S.shadowRays = s->hCounters->shadowRays; S.nodesVisited = s->hCounters->nodesVisited; S.trisTested = s->hCounters->trisTested;
   S.shadowNodesVisited = s->hCounters->shadowNodesVisited; S.shadowTrisTested = s->hCounters->shadowTrisTested;
+  if (s->hCounters->overflow) { setError("giCRender: a work-queue shard overflowed its capacity (internal sizing error); the image is invalid"); return GI_C_ERROR; }
   S.traceMs = S.shadeMs = S.raygenMs = S.shadowMs = 0.0;
   if (timers) {
     for (size_t k = 0; k < evKind.size(); k++) {

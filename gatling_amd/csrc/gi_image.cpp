@@ -340,9 +340,17 @@ bool loadImageFile(const char* path, bool srgbToLinear, uint32_t& w, uint32_t& h
   { uint8_t buf[65536]; size_t n; while ((n = fread(buf, 1, sizeof(buf), f)) > 0) d.insert(d.end(), buf, buf + n); }
   fclose(f);
   try {
-    if (d.size() >= 8 && d[0] == 0x89 && d[1] == 'P') return decodePng(d, srgbToLinear, w, h, out);
-    if (d.size() >= 4 && d[0] == 0xff && d[1] == 0xd8) return decodeJpeg(d, srgbToLinear, w, h, out);
-    return decodeHdrOrPfm(d, w, h, out);
+    bool ok;
+    if (d.size() >= 8 && d[0] == 0x89 && d[1] == 'P') ok = decodePng(d, srgbToLinear, w, h, out);
+    else if (d.size() >= 4 && d[0] == 0xff && d[1] == 0xd8) ok = decodeJpeg(d, srgbToLinear, w, h, out);
+    else ok = decodeHdrOrPfm(d, w, h, out);
+    if (!ok) return false;
+    // imgio's orientation: every decoder ends with _FlipImage, so row 0 of a loaded image is the file's BOTTOM scanline
+    // (src/imgio/impl/PngDecoder.cpp:78, HdrDecoder.cpp:41, JpegDecoder.cpp; pinned by REF_4C, src/imgio/impl/main.cpp:53-61) and
+    // texture coordinate v = 0 addresses the bottom of the picture.  The decoders above produce file order; flip once here.
+    const size_t rowFloats = (size_t)w * 4u;
+    for (uint32_t y = 0; y < h / 2u; y++) std::swap_ranges(out.begin() + (size_t)y * rowFloats, out.begin() + (size_t)(y + 1u) * rowFloats, out.begin() + (size_t)(h - 1u - y) * rowFloats);
+    return true;
   } catch (const std::exception&) { return false; } // allocation failure: the caller reports "cannot decode"
 }
 

@@ -1,5 +1,6 @@
 // gi_image.h -- the few image decoders the library carries itself (the reference reaches PNG / JPEG / EXR / HDR / TIFF through
-// imgio, src/imgio/impl/*: out of scope).  Everything decodes to float RGBA, row 0 = first image row.
+// imgio, src/imgio/impl/*: out of scope).  Everything decodes to float RGBA in imgio's
+// orientation: row 0 = the file's BOTTOM scanline (imgio flips after decoding; REF_4C in src/imgio/impl/main.cpp:53-61 pins it).
 #pragma once
 
 #include <cstdint>

@@ -41,7 +41,7 @@ __global__ void k_init(PathState st, QueueSet qs, Counters* cnt, uint32_t n, uin
     cnt->count[q][sdx].v = c;
   }
   if (i == 0) {
-    cnt->workBase[0].v = 0; cnt->workBase[1].v = 0; for (uint32_t k = 0; k < NCURSOR; k++) { cnt->cursor[0][k].v = 0; cnt->cursor[1][k].v = 0; }
+    cnt->overflow = 0u; cnt->workBase[0].v = 0; cnt->workBase[1].v = 0; for (uint32_t k = 0; k < NCURSOR; k++) { cnt->cursor[0][k].v = 0; cnt->cursor[1][k].v = 0; }
     if (resetStats) { cnt->segments = 0; cnt->shadowRays = 0; cnt->nodesVisited = 0; cnt->trisTested = 0; cnt->shadowNodesVisited = 0; cnt->shadowTrisTested = 0; }
   }
   for (; i < n; i += gridDim.x * blockDim.x) {
@@ -119,6 +119,7 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st,
           // 2232-2238).  k_trace routes misses straight here; nothing after the miss can change the sample any more.
           F4 tb = ld4(&S->thr);
           rad = rad + v3(tb.x, tb.y, tb.z) * v3(U.background);
+          if (st.neeKey && (f2u(tb.w) & 0x00000fffu) == 0u) nee_aov_record(st, slot, false); // primary miss: no light sampled, "not shadowed" (rp_main.rgen:431-435)
         }
         if (st.bouncesAov && U.batchFirstSample + f2u(id.y) == U.spp - 1u) { // Bounces AOV: the pixel's last sample (rp_main.rgen:483-486)
           // a path that left the scene was routed here straight from k_trace, before the loop's bounce++ (rp_main.rgen:480)
@@ -185,7 +186,7 @@ __global__ void k_resolve_nee(FrameUniforms U, const unsigned long long* __restr
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= pixelCount) return;
   const unsigned long long k = key[p];
-  if (k == 0ull) return; // no shadow ray traced for this pixel: the AOV keeps its clear value
+  if (k == 0ull) return; // no sample reached the shadow test (maxBounces == 0): the AOV keeps its clear value
   F4* dst = &aov[tile_to_image_pixel(U, p)];
   dst->x = (k & 1ull) ? 1.0f : 0.0f; dst->y = (k & 1ull) ? 0.0f : 1.0f; dst->z = 0.0f;
 }
@@ -239,13 +240,14 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
       if (!ANYHIT) {
         hit = R.found; miss = !hit; t = R.tBest; u = R.bestU; v = R.bestV; tri = R.bestTri; mat = R.bestMat;
       } else {
+        F4 nc = F4{0.0f, 0.0f, 0.0f, 0.0f}; // (neeContrib, 1 = emitted at bounce 0)
+        if (!R.found || st.neeKey) nc = ld4(&qs.c[qIn][r]);
         if (!R.found) {
-          const F4 nc = ld4(&qs.c[qIn][r]);
           Slot* S = &st.slots[slot];
           F4 rr = ld4(&S->rad);
           st4(&S->rad, rr.x + nc.x, rr.y + nc.y, rr.z + nc.z, rr.w);
         }
-        if (st.neeKey) nee_aov_record(st, slot, R.found);
+        if (st.neeKey && nc.w != 0.0f) nee_aov_record(st, slot, R.found);
       }
     }
     if (!ANYHIT) {
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
         else { st4(&qs.a[q][r], rdir.w, ro.x, ro.y, u2f(VOLUME_MISS)); st4(&qs.b[q][r], rdir.x, rdir.y, rdir.z, ro.z); } // (tMax, origin) ride along
       }
       if (miss) {
-        if (DOME && sc.domeTexture) { dome_miss(sc, &st.slots[slot], v3(rdir.x, rdir.y, rdir.z)); qs.slot[qMiss][idx[0]] = slot; } // scene has a dome light image
+        if (DOME && sc.domeTexture) { dome_miss(sc, st, slot, v3(rdir.x, rdir.y, rdir.z)); qs.slot[qMiss][idx[0]] = slot; } // scene has a dome light image
         else qs.slot[qMiss][idx[0]] = slot | REGEN_MISSED;
       }
     }
@@ -388,13 +390,14 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
         }
       } else {
         const uint32_t slot = qs.slot[qIn][rec];
+        F4 nc = F4{0.0f, 0.0f, 0.0f, 0.0f}; // (neeContrib, 1 = emitted at bounce 0)
+        if (!R.found || st.neeKey) nc = ld4(&qs.c[qIn][rec]);
         if (!R.found) {
-          const F4 nc = ld4(&qs.c[qIn][rec]);
           Slot* S = &st.slots[slot];
           F4 rr = ld4(&S->rad);
           st4(&S->rad, rr.x + nc.x, rr.y + nc.y, rr.z + nc.z, rr.w);
         }
-        if (st.neeKey) nee_aov_record(st, slot, R.found);
+        if (st.neeKey && nc.w != 0.0f) nee_aov_record(st, slot, R.found);
       }
     }
   }
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, Que
       else { st4(&qs.a[q][r], h.x, h.y, h.z, u2f(VOLUME_MISS)); st4(&qs.b[q][r], rdir.x, rdir.y, rdir.z, rdir.w); }
     }
     if (miss) {
-      if (sc.domeTexture) { dome_miss(sc, &st.slots[slot], v3(rdir.x, rdir.y, rdir.z)); qs.slot[qMiss][idx[0]] = slot; }
+      if (sc.domeTexture) { dome_miss(sc, st, slot, v3(rdir.x, rdir.y, rdir.z)); qs.slot[qMiss][idx[0]] = slot; }
       else qs.slot[qMiss][idx[0]] = slot | REGEN_MISSED;
     }
   }
@@ -476,7 +479,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, 
   uint32_t trip = 0;
   for (uint32_t base = blockIdx.x * BLOCK; base < n; base += stride, trip++) {
     const uint32_t i = base + threadIdx.x;
-    bool cont = false, ended = false, shadow = false; uint32_t slot = 0, rngShadow = 0u;
+    bool cont = false, ended = false, shadow = false, shadowFirst = false; uint32_t slot = 0, rngShadow = 0u;
     V3 no = v3(0.0f, 0.0f, 0.0f), k2 = no, sdir = no, nee = no; float ld = 0.0f, tMaxNext = GI_FLT_MAX;
     if (i < n) {
       const uint32_t r = reader_index(rdr, i);
@@ -564,6 +567,9 @@ __global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, 
         shadow = gi_luminance(nee) > 1e-6f && ld > 1e-9f;
         rngShadow = rng; // the shadow payload gets a copy of the rng as it is HERE, before the Russian-roulette draw (rp_main.rgen:399)
       }
+      // NEE AOV (rp_main.rgen:431-435): bounce 0 only; a shadow ray that is not traced counts as "not shadowed"
+      if (NEE && st.neeKey && bounce == 0u && !shadow) nee_aov_record(st, slot, false);
+      shadowFirst = bounce == 0u;
       if (isTransmission) { // medium stack (:447-480)
         uint32_t newIdx = mediumIdx;
         if (VOLUME) {
@@ -646,7 +652,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, 
       qs.slot[Q_SHADOW][idx[2]] = slot;
       st4(&qs.a[Q_SHADOW][idx[2]], no.x, no.y, no.z, ld);
       st4(&qs.b[Q_SHADOW][idx[2]], sdir.x, sdir.y, sdir.z, u2f(rngShadow)); // .w: rng state for the any-hit test of cutouts
-      st4(&qs.c[Q_SHADOW][idx[2]], nee.x, nee.y, nee.z, 0.0f);
+      st4(&qs.c[Q_SHADOW][idx[2]], nee.x, nee.y, nee.z, shadowFirst ? 1.0f : 0.0f);
     }
   }
 }

@@ -38,7 +38,9 @@ __device__ __forceinline__ void block_append(AppendScratch<NQ>& sh, uint32_t tri
     uint32_t total = 0;
 #pragma unroll
     for (uint32_t w = 0; w < WAVES; w++) total += sh.wcount[par][q][w];
-    sh.base[par][q] = total ? atomicAdd(&cnt->count[qid[q]][shard].v, total) : 0u;
+    uint32_t b = total ? atomicAdd(&cnt->count[qid[q]][shard].v, total) : 0u;
+    if (b + total > cap) { cnt->overflow = 1u; b = 0u; } // never write outside the shard; the host reports the render as failed
+    sh.base[par][q] = b;
   }
   __syncthreads();
 #pragma unroll
@@ -55,7 +57,7 @@ __device__ __forceinline__ void reader_init(QueueReader& r, const Counters* cnt,
 {
   r.pre[0] = 0;
 #pragma unroll
-  for (uint32_t s = 0; s < NSHARD; s++) r.pre[s + 1] = r.pre[s] + cnt->count[q][s].v;
+  for (uint32_t s = 0; s < NSHARD; s++) { const uint32_t c = cnt->count[q][s].v; r.pre[s + 1] = r.pre[s] + (c < cap ? c : cap); } // (clamped: see Counters::overflow)
   r.cap = cap;
 }
 __device__ __forceinline__ uint32_t reader_index(const QueueReader& r, uint32_t i)

@@ -23,12 +23,14 @@ __device__ __forceinline__ void payload_increment_walk(uint32_t& bitfield)
   bitfield |= b;
 }
 
-// NEE AOV bookkeeping (see PathState): latest shadow-ray outcome per tile pixel in the reference's (sample, bounce) order
+// NEE AOV bookkeeping (rp_main.rgen:431-435): the AOV shows the outcome of the shadow test at bounce 0 of the pixel's LAST sample
+// (a shadow ray that cannot contribute is dispatched with an empty interval and counts as "not shadowed").  Samples retire out of
+// order here, so every bounce-0 outcome is recorded as (sample + 1) << 1 | shadowed under atomicMax; PathState::neeKey is only
+// set when the AOV is bound AND next-event estimation is on (the reference compiles the block out otherwise).
 __device__ __forceinline__ void nee_aov_record(const PathState& st, uint32_t slot, bool shadowed)
 {
-  const Slot* S = &st.slots[slot];
-  const F4 id = ld4(&S->id);
-  const unsigned long long order = ((unsigned long long)(st.neeSampleBase + f2u(id.y)) << 12) | (unsigned long long)(f2u(S->thr.w) & 0x00000fffu);
+  const F4 id = ld4(&st.slots[slot].id);
+  const unsigned long long order = (unsigned long long)(st.neeSampleBase + f2u(id.y)) + 1ull;
   atomicMax(&st.neeKey[f2u(id.x)], (order << 1) | (shadowed ? 1ull : 0ull));
 }
 // ------------------------------------------------------------------------------------------------
@@ -161,11 +163,13 @@ __device__ __forceinline__ V3 quat_rotate_dir(const float* q, V3 dir) // rp_main
   const V3 b = cross(qv, a);
   return dir + ((a * q[3]) + b) * 2.0f;
 }
-__device__ inline void dome_miss(const SceneView& sc, Slot* S, V3 rayDir)
+__device__ inline void dome_miss(const SceneView& sc, const PathState& st, uint32_t slot, V3 rayDir)
 {
+  Slot* S = &st.slots[slot];
   const F4 tb = ld4(&S->thr);
   const F4 rr = ld4(&S->rad);
   const bool isPrimaryRay = (f2u(tb.w) & 0x00000fffu) == 0u;
+  if (st.neeKey && isPrimaryRay) nee_aov_record(st, slot, false); // a primary miss samples no light: "not shadowed" (rp_main.rgen:431-435)
   const bool useFallback = !sc.domeCameraVisible && isPrimaryRay; // :76-80
   V3 texel = v3(sc.background);
   if (!useFallback) {

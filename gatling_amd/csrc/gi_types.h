@@ -192,9 +192,10 @@ static_assert(sizeof(Slot) == 64, "Slot must be 64 bytes");
 constexpr uint32_t MEDIUM_FLOATS = 8, MAX_MEDIUM_STACK = 8;
 constexpr uint32_t VOLUME_MISS = 0xfffffffeu; // "triangle" id of a hit record that is a scattering event inside a medium
 // Debug AOVs that follow whole paths (only when bound): Bounces = inferno colour of the bounce count of the pixel's LAST
-// sample (rp_main.rgen:483-486, written by k_raygen when that sample retires); NEE = outcome of the pixel's last traced
-// shadow ray in the reference's sequential order (rp_main.rgen:431-435): k_trace<any> keeps, per tile pixel, the maximum of
-// (sample << 12 | bounce) << 1 | shadowed, k_resolve_nee turns it into red / green.
+// sample (rp_main.rgen:483-486, written by k_raygen when that sample retires); NEE = outcome of the shadow test at bounce 0 of the
+// pixel's last sample (rp_main.rgen:431-435; untraced = not shadowed): per tile pixel the maximum of (sample + 1) << 1 | shadowed over
+// all bounce-0 outcomes (k_shade, k_trace<any>, primary misses), which k_resolve_nee turns into red / green.  neeKey is null unless
+// the AOV is bound and next-event estimation is on.
 struct PathState {
   Slot* slots; float* media; uint32_t mediaStride;
   unsigned long long* neeKey; uint32_t neeSampleBase; F4* bouncesAov;
@@ -233,6 +234,7 @@ struct Counters {
   // device-scope atomic on one line completes ~88 times per microsecond; 8 lines, 8x that); [0]: closest-hit queue, [1]: shadow queue
   PaddedCounter cursor[2][NCURSOR];
   unsigned long long segments, shadowRays, nodesVisited, trisTested, shadowNodesVisited, shadowTrisTested;
+  uint32_t overflow; // set by block_append when a shard would run past its capacity (host sizing bug): giCRender fails loudly
 };
 
 } // namespace gi

@@ -1443,8 +1443,12 @@ void render_pixel(const Frame& F, uint32_t px, uint32_t py, const float* prevCol
         V3 sdir = safe_div(pl.neeToLight, lightDist);
         bool traceRay = luminance(pl.neeContrib) > 1e-6f && lightDist > 1e-9f;
         bool shadowed = true;
-        if (traceRay) { cnt.shadowRays++; shadowed = trace_any(*F.P, pl.origin, sdir, 0.01f, lightDist, pl.rng); if (dbg) dbg->lastNee = shadowed ? 1 : 0; }
+        if (traceRay) { cnt.shadowRays++; shadowed = trace_any(*F.P, pl.origin, sdir, 0.01f, lightDist, pl.rng); }
         if (traceRay && !shadowed) pl.radiance = pl.radiance + pl.neeContrib;
+        // NEE AOV (:431-435): written at bounce 0 only, for EVERY sample (the last one wins).  The reference dispatches the shadow ray
+        // unconditionally (tMin = tMax = 0 when it cannot contribute, :406-410): the empty interval misses, rp_main_shadow.miss clears
+        // `shadowed`, so an untraced shadow ray shows as "not shadowed" (green).
+        if (dbg && bounce == 0) dbg->lastNee = (traceRay && shadowed) ? 1 : 0;
       }
       if (length(pl.throughput) < 1e-9f) pl.bitfield |= TERMINATE_FLAG; // :441-444
       if (bounce > rs.rrBounceOffset) { // :447-459

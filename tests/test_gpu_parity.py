@@ -534,7 +534,7 @@ def test_dome_light_image_file(gi, orc, tmp_path):
     pixels[..., :3] = rgbe[..., :3].astype(np.float32) * np.ldexp(np.float32(1.0), rgbe[..., 3:4].astype(np.int32) - 136).astype(np.float32)
     desc = SceneDesc()
     desc.camera = CameraDesc(position=(0, 0, 0), forward=(0, 0, -1), up=(0, 1, 0), vfov=1.2)
-    desc.textures = [pixels]
+    desc.textures = [np.ascontiguousarray(pixels[::-1])]  # imgio orientation: row 0 of a loaded image = the file's bottom scanline
     desc.dome_light = DomeLight(texture=0)
     rs = RenderSettings(spp=2, max_bounces=2, clear_color=(0.3, 0.6, 0.9, 1.0))
     ref, _ = orc.render(desc, rs, 48, 24)
@@ -598,9 +598,10 @@ def test_volume_stack_of_one_equals_toggle(gi):
 
 @pytest.mark.parametrize("with_color", [True, False])
 def test_nee_and_bounces_aovs(gi, orc, with_color):
-    """The two debug AOVs that follow whole paths (rp_main.rgen:431-435, 483-486): outcome of the pixel's last traced shadow ray
-    in sequential (sample, bounce) order, inferno colour of the last sample's bounce count -- equal to the oracle although the
-    wavefront loop retires samples out of order; pixels without a shadow ray keep the clear value."""
+    """The two debug AOVs that follow whole paths.  NEE (rp_main.rgen:431-435): written at bounce 0 ONLY, for every sample (the last
+    one wins), red if that bounce's shadow ray was traced and occluded, green otherwise -- an untraced shadow ray is dispatched with
+    an empty interval, misses, and counts as "not shadowed", so with NEE on no pixel keeps the clear value.  Bounces (:483-486):
+    inferno colour of the last sample's bounce count.  Equal to the oracle although the wavefront loop retires samples out of order."""
     desc = cornell_box()
     desc.rect_lights = [RectLight(origin=(0, 0, 0.9), t0=(1, 0, 0), t1=(0, -1, 0), base_emission=(10, 10, 10), width=0.7, height=0.5)]
     rs = RenderSettings(spp=5, max_bounces=7, next_event_estimation=True)
@@ -619,7 +620,7 @@ def test_nee_and_bounces_aovs(gi, orc, with_color):
     assert np.array_equal(got["clockCycles"], ref["clockCycles"])
     assert (got["clockCycles"][..., 3] == 255.0).all() and len(np.unique(got["clockCycles"][..., :3].reshape(-1, 3), axis=0)) > 8
     kinds = {tuple(v) for v in np.unique(ref["nee"][..., :3].reshape(-1, 3), axis=0).tolist()}
-    assert (1.0, 0.0, 0.0) in kinds and (0.0, 1.0, 0.0) in kinds  # both outcomes occur in this scene
+    assert kinds == {(1.0, 0.0, 0.0), (0.0, 1.0, 0.0)}  # both outcomes occur, and nothing else: every pixel's bounce 0 writes the AOV
 
 
 def test_scene_data_primvar_inputs(gi, orc):
@@ -757,31 +758,116 @@ def test_two_level_layout_parity(gi, orc, scene_kind):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# full BASELINE.json sizes: size-independent properties (the oracle cannot render these in seconds)
+# full BASELINE.json sizes, against the checker: the oracle renders these on all host cores (C1 in full, as BASELINE.md 3.1 says;
+# C2 - C5 at the full resolution and the real scene at a reduced spp -- RNG streams, traversal and shading do not depend on spp)
 # ---------------------------------------------------------------------------------------------------------------
-def test_full_size_c2_properties(gi):
-    """1920x1080 cornell, 8 bounces: determinism, shard invariance, checksum-of-checksums, bounds."""
+_CORES = os.cpu_count() or 4
+
+
+def test_c1_full_baseline_bit_exact(gi, orc):
+    """BASELINE config C1 in full: cornell.usda 512x512, spp 64, max-bounces 4, diffuse-only -- 16.8 M samples, bit for bit."""
+    img, ref, st = render_both(gi, orc, cornell_box(MAT_DIFFUSE), RenderSettings(spp=64, max_bounces=4), 512, 512, exact=True, threads=_CORES)
+    assert st["samples"] == 512 * 512 * 64
+
+
+def test_c2_baseline_1080p_bit_exact(gi, orc):
+    """BASELINE config C2 at its resolution (1920x1080, 8 bounces, UsdPreviewSurface) and spp 8 against the oracle, plus the
+    size-independent properties: run-to-run determinism, the 8-GPU row partition (contiguous bands and interleaved rows) stitched ==
+    whole frame, a checksum of checksums, the per-sample clamp bound."""
     desc = cornell_box()
     rs = RenderSettings(spp=8, max_bounces=8, progressive_accumulation=False)
     w, h = 1920, 1080
     sc = gi.Scene(desc)
     try:
-        full = sc.render(rs, w, h)
+        full = sc.render(rs, w, h).copy()
         st = sc.stats()
-        again = sc.render(rs, w, h)
-        bands = [sc.render(rs, w, h, rows=(r * 135, (r + 1) * 135)) for r in range(8)]  # the 8-GPU partition
+        again = sc.render(rs, w, h).copy()
+        bands = [sc.render(rs, w, h, rows=(r * 135, (r + 1) * 135)).copy() for r in range(8)]
+        inter = [sc.render(rs, w, h, rows=(r, h), row_stride=8).copy() for r in (0, 5)]
     finally:
         sc.close()
-    assert np.isfinite(full).all() and (full[..., 3] == 1.0).all() and full[..., :3].min() >= 0.0
-    assert full[..., :3].max() <= rs.max_sample_value * (1 + 1e-5)  # per-sample clamp bounds every pixel mean
-    assert st["samples"] == w * h * 8 and st["samples"] <= st["segments"] <= st["samples"] * 8
-    assert np.array_equal(full.view(np.uint32), again.view(np.uint32))  # run-to-run determinism despite atomics in the queues
-    stitched = np.concatenate(bands)
-    assert np.array_equal(stitched.view(np.uint32), full.view(np.uint32))
-    row_sums = [int(b.view(np.uint32).astype(np.uint64).sum()) for b in bands]
-    assert sum(row_sums) == int(full.view(np.uint32).astype(np.uint64).sum())
-    # the open front shows the background on ~62 % of the pixels: those are exactly the quantised clear colour
-    assert 0.55 < float((full[..., :3] == 1.0).all(axis=-1).mean()) < 0.70
+    ref, cnt = orc.render(desc, rs, w, h, threads=_CORES)
+    assert st["segments"] == cnt["segments"] and st["samples"] == cnt["samples"] == w * h * 8
+    assert_image_parity(full, ref, exact=True)
+    assert np.array_equal(full.view(np.uint32), again.view(np.uint32))  # determinism despite atomics in the queues
+    assert np.array_equal(np.concatenate(bands).view(np.uint32), full.view(np.uint32))
+    for r, part in zip((0, 5), inter):
+        assert np.array_equal(part.view(np.uint32), full[r::8].view(np.uint32))
+    assert sum(int(b.view(np.uint32).astype(np.uint64).sum()) for b in bands) == int(full.view(np.uint32).astype(np.uint64).sum())
+    assert (full[..., 3] == 1.0).all() and full[..., :3].min() >= 0.0 and full[..., :3].max() <= rs.max_sample_value * (1 + 1e-5)
+    assert 0.55 < float((full[..., :3] == 1.0).all(axis=-1).mean()) < 0.70  # the open front shows the quantised clear colour
+
+
+def test_c3_baseline_1080p_bit_exact(gi, orc):
+    """BASELINE config C3 with the real scene (1 000 000-triangle soup, seed 1234, one OpenPBR material, rect light, NEE) at
+    1920x1080, spp 2: image, segment and shadow-ray counts equal the oracle's (independent BVH2 traversal)."""
+    desc = random_triangle_soup(1_000_000)
+    img, ref, st = render_both(gi, orc, desc, RenderSettings(spp=2, max_bounces=8, next_event_estimation=True), 1920, 1080, exact=True, threads=_CORES)
+    assert st["triangleCount"] == 1_000_000 and st["shadowRays"] > 0
+
+
+def test_c4_baseline_1080p_bit_exact(gi, orc):
+    """BASELINE config C4 with the real scene (32x32 instanced icospheres = 5 242 880 triangles, 32 OpenPBR / UsdPreviewSurface
+    parameter sets, seed 4321) at 1920x1080, spp 2."""
+    desc = sphere_grid(32, 4, 32)
+    img, ref, st = render_both(gi, orc, desc, RenderSettings(spp=2, max_bounces=8), 1920, 1080, exact=True, threads=_CORES)
+    assert st["triangleCount"] == 1024 * 5120
+
+
+def test_c5_baseline_band_bit_exact(gi, orc):
+    """BASELINE config C5 at full geometric size (10.24 M instanced triangles, 51 materials, 4 rect lights, NEE, 3840x2160): the
+    270-row band rank 3 of the 8-GPU partition at spp 1 equals the oracle's render of those rows, equals the same rows of a
+    whole-frame render, and so do bands 0 and 7 (the per-pixel RNG streams use the global pixel index)."""
+    from gatling_amd.dist import partition_rows
+    desc = interior_scene()
+    rs = RenderSettings(spp=1, max_bounces=8, next_event_estimation=True, progressive_accumulation=False)
+    w, h = 3840, 2160
+    sc = gi.Scene(desc)
+    try:
+        full = sc.render(rs, w, h).copy()
+        st = sc.stats()
+        assert st["triangleCount"] == 2000 * 5120 + 12
+        for rank in (0, 3, 7):
+            r0, r1 = partition_rows(h, 8, rank)
+            assert r1 - r0 == 270
+            band = sc.render(rs, w, h, rows=(r0, r1)).copy()
+            bst = sc.stats()
+            assert np.array_equal(band.view(np.uint32), full[r0:r1].view(np.uint32)), f"band {rank}"
+            if rank == 3:
+                ref, cnt = orc.render(desc, rs, w, h, rows=(r0, r1), threads=_CORES)
+                assert bst["segments"] == cnt["segments"] and bst["shadowRays"] == cnt["shadow_rays"]
+                assert_image_parity(band, ref, exact=True)
+    finally:
+        sc.close()
+    assert np.isfinite(full).all() and full[..., :3].mean() > 0.01
+
+
+def test_small_pool_three_material_classes(gi, orc):
+    """Queue sizing (shardCapacity): a pool of ~1-2 k slots with all three material classes present feeds TRACE / REGEN from up to
+    five launches that all start dealing blocks at shard 0; the image must still equal the oracle's and no shard may overflow
+    (giCRender would fail).  The pool is forced small with the scene option."""
+    desc = sphere_grid(grid=3, subdivisions=1, material_count=6)
+    desc.materials[0] = MaterialDesc.usd_preview_surface(name="lambert", diffuseColor=(0.7, 0.3, 0.2), klass=MAT_DIFFUSE)
+    assert {m.klass for m in desc.materials} == {0, 1, 2}
+    rs = RenderSettings(spp=2, max_bounces=6)
+    ref, cnt = orc.render(desc, rs, 32, 32, threads=4)
+    for pool in (1024, 1536, 2048):
+        sc = gi.Scene(desc)
+        try:
+            sc.set_option(gi.OPTION_POOL_SLOTS, pool)
+            img = sc.render(rs, 32, 32)
+            st = sc.stats()
+        finally:
+            sc.close()
+        assert st["segments"] == cnt["segments"]
+        assert_image_parity(img, ref, exact=True)
+
+
+def test_max_bounces_zero_is_black(gi, orc):
+    """rp_main.rgen:298-304: the bounce loop tests `bounce >= maxBounces` before tracing, so max-bounces 0 traces nothing: black
+    samples (no emission, no background term), alpha 1, zero segments."""
+    img, ref, st = render_both(gi, orc, cornell_box(), RenderSettings(spp=3, max_bounces=0), 48, 27, exact=True)
+    assert st["segments"] == 0 and (img[..., :3] == 0.0).all() and (img[..., 3] == 1.0).all()
 
 
 def test_full_size_furnace(gi):
@@ -797,26 +883,3 @@ def test_full_size_furnace(gi):
         sc.close()
     assert st["segments"] == 1920 * 1080 * 4 * bounces
     np.testing.assert_allclose(img[..., :3], sum(albedo ** k for k in range(bounces)), rtol=1e-5)
-
-
-def test_full_size_c5_row_bands(gi):
-    """C5 at full geometric size (10.24 M instanced triangles, 3840x2160): the 8 row bands the 8-GPU run renders
-    (270 rows each) are, band by band, bit-identical to the same rows of a whole-frame render -- at 1 spp so that the
-    test stays in seconds; the per-band RNG streams do not depend on spp."""
-    from gatling_amd.dist import partition_rows
-    desc = interior_scene()
-    rs = RenderSettings(spp=1, max_bounces=8, next_event_estimation=True, progressive_accumulation=False)
-    w, h = 3840, 2160
-    sc = gi.Scene(desc)
-    try:
-        full = sc.render(rs, w, h).copy()
-        st = sc.stats()
-        assert st["triangleCount"] == 2000 * 5120 + 12
-        assert np.isfinite(full).all() and full[..., :3].mean() > 0.01
-        for rank in (0, 3, 7):
-            r0, r1 = partition_rows(h, 8, rank)
-            assert r1 - r0 == 270
-            band = sc.render(rs, w, h, rows=(r0, r1))
-            assert band.shape[0] == 270 and np.array_equal(band, full[r0:r1]), f"band {rank}"
-    finally:
-        sc.close()

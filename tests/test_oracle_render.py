@@ -328,3 +328,22 @@ def test_textured_cutout_opacity(orc):
     # without a threshold the same ramp is used stochastically: between the two
     soft, _ = orc.render(scene([1.0, 0.0], threshold=0.0), rs, 64, 36)
     assert np.abs(soft - half_mask).mean() > 1e-4
+
+
+def test_nee_aov_is_the_bounce0_shadow_test(orc):
+    """rp_main.rgen:431-435: the NEE AOV is written at bounce 0 only, for every sample; a shadow ray that cannot contribute is
+    dispatched with tMin = tMax = 0 (:406-410), misses, and rp_main_shadow.miss clears `shadowed` -> green.  So with NEE compiled in
+    every pixel is red or green (primary misses included) and the result does not depend on later bounces; with NEE off the block is
+    compiled out and the AOV keeps its clear value."""
+    desc = cornell_box()
+    desc.rect_lights = [RectLight(origin=(0, 0, 0.9), t0=(1, 0, 0), t1=(0, -1, 0), base_emission=(10, 10, 10), width=0.7, height=0.5)]
+    clear = {"nee": (0.25, 0.5, 0.75, 0.0)}
+    a = orc.render_aovs(desc, RenderSettings(spp=3, max_bounces=1, next_event_estimation=True), 48, 27, ["nee"], clear_values=clear)["nee"][..., :3]
+    b = orc.render_aovs(desc, RenderSettings(spp=3, max_bounces=7, next_event_estimation=True), 48, 27, ["nee"], clear_values=clear)["nee"][..., :3]
+    assert np.array_equal(a, b)  # bounces > 0 never touch the AOV
+    kinds = {tuple(v) for v in np.unique(a.reshape(-1, 3), axis=0).tolist()}
+    assert kinds == {(1.0, 0.0, 0.0), (0.0, 1.0, 0.0)}
+    off = orc.render_aovs(desc, RenderSettings(spp=3, max_bounces=7), 48, 27, ["nee"], clear_values=clear)["nee"]
+    assert np.allclose(off, clear["nee"])
+    zero = orc.render_aovs(desc, RenderSettings(spp=3, max_bounces=0, next_event_estimation=True), 48, 27, ["nee"], clear_values=clear)["nee"]
+    assert np.allclose(zero, clear["nee"])  # the loop body never runs
