@@ -1,34 +1,63 @@
 """Builds the product library ``gatling_amd/libgatling_gi.so`` for gfx950 with hipcc (in-tree, so it travels to
-the GPU box with the repo snapshot)."""
+the GPU box with the repo snapshot).  Every translation unit is compiled to an object on its own (in parallel, and only
+when it or a header changed), then linked."""
 from __future__ import annotations
 
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
+OBJDIR = os.path.join(CSRC, "build")
 LIB = os.path.join(_HERE, "libgatling_gi.so")
-SOURCES = ["gi_c.cpp", "gi_image.cpp", "bvh8.cpp", "gi_kernels.hip", "gtl_shim.cpp"]
-HEADERS = ["gi_types.h", "gi_kernels.h", "gi_device_math.h", "gi_queues.h", "gi_traversal.h", "gi_shading.h", "gi_image.h", "bvh8.h", os.path.join("..", "..", "include", "gi_c.h"),
-           os.path.join("..", "..", "include", "gtl", "gi", "Gi.h")]
+SOURCES = ["gi_c.cpp", "gi_image.cpp", "bvh8.cpp", "gi_kernels.hip", "gi_path.hip", "gtl_shim.cpp"]
+HEADERS = ["gi_types.h", "gi_kernels.h", "gi_device_math.h", "gi_queues.h", "gi_traversal.h", "gi_texture.h", "gi_shading.h", "gi_stages.h", "gi_image.h", "bvh8.h",
+           os.path.join("..", "..", "include", "gi_c.h"), os.path.join("..", "..", "include", "gtl", "gi", "Gi.h"),
+           os.path.join("..", "..", "include", "gtl", "gb", "ParamTypes.h")]
 # -ffp-contract=off: arithmetic contract.  No fast-math: IEEE divide/sqrt are part of it.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall"]
+
+
+def _mtime(path: str) -> float:
+    return os.path.getmtime(path) if os.path.exists(path) else 0.0
+
+
+def _headers_mtime() -> float:
+    return max([_mtime(os.path.join(CSRC, h)) for h in HEADERS] + [_mtime(os.path.abspath(__file__))])
+
+
+def _obj(src: str) -> str:
+    return os.path.join(OBJDIR, src + ".o")
+
+
+def _stale(src: str, force: bool) -> bool:
+    return force or _mtime(_obj(src)) < max(_mtime(os.path.join(CSRC, src)), _headers_mtime())
 
 
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    return _mtime(LIB) == 0.0 or any(_stale(s, False) or _mtime(_obj(s)) > _mtime(LIB) for s in SOURCES)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    if force or needs_build():
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        cmd = [hipcc] + FLAGS + ["-o", LIB] + SOURCES + ["-lz"]  # zlib: PNG inflate (gi_image.cpp)
+    if not (force or needs_build()):
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(OBJDIR, exist_ok=True)
+
+    def compile_one(src: str) -> None:
+        cmd = [hipcc] + FLAGS + ["-c", src, "-o", _obj(src)]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=CSRC)
+
+    todo = [s for s in SOURCES if _stale(s, force)]
+    with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 2) or 1) as pool:
+        list(pool.map(compile_one, todo))
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [_obj(s) for s in SOURCES] + ["-lz"]  # zlib: PNG inflate (gi_image.cpp)
+    if verbose:
+        print(" ".join(link))
+    subprocess.check_call(link, cwd=CSRC)
     return LIB
 
 

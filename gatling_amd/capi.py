@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libgatling_gi.so")
 GI_C_OK = 0
 AOV_COLOR = 0
 FORMAT_INT32, FORMAT_FLOAT32, FORMAT_FLOAT32_VEC4 = 0, 1, 2
-OPTION_COUNT_TRAVERSAL, OPTION_KERNEL_TIMERS, OPTION_POOL_SLOTS, OPTION_SAMPLE_BUFFER_MB, OPTION_TRACE_DYNAMIC, OPTION_TWO_LEVEL = 1, 2, 3, 4, 5, 6
+OPTION_COUNT_TRAVERSAL, OPTION_KERNEL_TIMERS, OPTION_POOL_SLOTS, OPTION_SAMPLE_BUFFER_MB, OPTION_TRACE_DYNAMIC, OPTION_TWO_LEVEL, OPTION_FUSED_PATH = 1, 2, 3, 4, 5, 6, 7
 
 
 class GiCCameraDesc(C.Structure):

@@ -312,6 +312,7 @@ struct GiCScene {
   bool countTraversal = false, kernelTimers = false;
   uint32_t kernelTimerStride = 1;
   uint64_t optPoolSlots = 0, optSampleBufferMb = 0; // 0 = default
+  int32_t optFusedPath = -1; // -1 = default (on): LDS-resident scenes run the fused persistent kernel k_path; 0 = always the wavefront stage kernels
   int32_t optTraceDyn = -1; // -1 = default; 0 = block-synchronous k_trace everywhere; N = k_trace_dyn refill threshold
   GiCRenderStats stats{};
   std::vector<hipEvent_t> eventPool;
@@ -784,6 +785,7 @@ int giCSetSceneOption(GiCScene* scene, int32_t option, int32_t value)
   if (option == GI_C_SCENE_OPTION_POOL_SLOTS) { scene->optPoolSlots = value > 0 ? (uint64_t)value : 0; return GI_C_OK; }
   if (option == GI_C_SCENE_OPTION_TWO_LEVEL) { scene->optTwoLevel = value < 0 ? -1 : (value ? 1 : 0); scene->dirty |= DIRTY_BVH | DIRTY_FRAMEBUFFER; return GI_C_OK; }
   if (option == GI_C_SCENE_OPTION_TRACE_DYNAMIC) { scene->optTraceDyn = value < 0 ? -1 : (value > 64 ? 64 : value); return GI_C_OK; }
+  if (option == GI_C_SCENE_OPTION_FUSED_PATH) { scene->optFusedPath = value < 0 ? -1 : (value ? 1 : 0); return GI_C_OK; }
   if (option == GI_C_SCENE_OPTION_SAMPLE_BUFFER_MB) { scene->optSampleBufferMb = value > 0 ? (uint64_t)value : 0; return GI_C_OK; }
   setError("unknown scene option"); return GI_C_ERROR;
 }
@@ -1339,7 +1341,12 @@ static int giCRenderImpl(const GiCRenderParams* params)
     uint64_t batchSamples = std::min<uint64_t>(rs.spp, std::max<uint64_t>(1, budgetBytes / (pixels * 16)));
     batchSamples = std::min<uint64_t>(batchSamples, std::max<uint64_t>(1, 0xffffffffull / pixels)); // work ids stay 32-bit
     const uint32_t numBatches = (uint32_t)((rs.spp + batchSamples - 1) / batchSamples);
-    const size_t slots = (size_t)std::min<uint64_t>(poolMax, (uint64_t)pixels * batchSamples);
+    // LDS-resident scenes without medium stacks / dome images: the fused persistent kernel k_path (gi_path.hip) keeps the paths in
+    // registers -- no pool, no queues; the stage kernels below remain the path for everything else (and on request: option / env)
+    view.mediumStackSize = rs.mediumStackSize;
+    bool fused = pathKernelSupports(view) && s->optFusedPath != 0;
+    if (const char* e = getenv("GATLING_FUSED")) fused = fused && atoi(e) != 0;
+    const size_t slots = fused ? 1 : (size_t)std::min<uint64_t>(poolMax, (uint64_t)pixels * batchSamples);
 
     // persistent grids: blocks per CU limited by registers (<= 6 waves/SIMD for k_trace) and, for k_trace, by the LDS it stages
     uint32_t wideBlocks, traceBlocks;
@@ -1397,7 +1404,21 @@ static int giCRenderImpl(const GiCRenderParams* params)
       ps.neeSampleBase = U.batchFirstSample;
       const uint32_t poolNow = (uint32_t)std::min<uint64_t>(slots, U.workTotal);
       U.poolSlots = poolNow;
-      launchInit(st, ps, qs, s->dCounters.ptr, poolNow, batch == 0);
+      launchInit(st, ps, qs, s->dCounters.ptr, fused ? 0u : poolNow, batch == 0);
+      if (fused && U.maxBounces != 0u) {
+        // work items are claimed in chunks of consecutive ids; small frames get small chunks so that every resident wave finds work
+        uint32_t chunk = 2048u;
+        if (const char* e = getenv("GATLING_PATH_CHUNK")) chunk = (uint32_t)std::max(64, atoi(e));
+        const uint64_t waves = (uint64_t)g_ctx.cuCount * 16u;
+        chunk = (uint32_t)std::min<uint64_t>(chunk, std::max<uint64_t>(64u, ((uint64_t)U.workTotal / (waves * 4u)) & ~63ull));
+        curIter = totalIters; if (timers) sampledIters++;
+        if (timers) { (void)hipEventRecord(poolEvent(s, ev), st); }
+        launchPath(st, (uint32_t)g_ctx.cuCount, s->classMask, s->classTextured != 0u, s->countTraversal, chunk, U, view, ps, s->dCounters.ptr, s->sampleBuf.ptr);
+        if (timers) { (void)hipEventRecord(poolEvent(s, ev + 1), st); ev += 2; evKind.push_back(1); }
+        iters++; totalIters++; traceLaunches++;
+        launchAccumulate(st, U, s->sampleBuf.ptr, s->accum.ptr, colorOut, batch == 0, batch + 1 == numBatches);
+        continue;
+      }
       if (U.maxBounces == 0u) {
         // rp_main.rgen:298-304: the bounce loop's exit test comes first, so with max-bounces 0 no ray is traced at all and every sample is
         // black (no emission at the primary hit, no dome / background term); the accumulation still runs (progressive blend, alpha 1)

@@ -22,6 +22,11 @@ constexpr uint32_t TRACE_DYN_SPILL8 = 0x100u; // flag in dynRefill: 8 LDS stack 
 // one launch per material class present in the scene (the class is the sort key between k_trace and k_shade)
 void launchShade(hipStream_t s, uint32_t blocks, uint32_t klass, bool textured /* some material of the class has textured inputs */, bool volume /* mediumStackSize > 0 */, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par);
 
+// Fused persistent path kernel (gi_path.hip) for LDS-resident scenes; launchPath returns the resident blocks per CU it launched with
+bool pathKernelSupports(const SceneView& sc);
+int launchPath(hipStream_t s, uint32_t cuCount, uint32_t classMask, bool textured, bool count, uint32_t chunk, const FrameUniforms& U, const SceneView& sc,
+               const PathState& st, Counters* cnt, F4* sampleBuf);
+
 void launchAov(hipStream_t s, const FrameUniforms& U, const SceneView& sc, const AovTargets& A);
 void launchResolveNee(hipStream_t s, const FrameUniforms& U, const unsigned long long* key, F4* aov, uint32_t pixelCount);
 void launchDebugBsdf(hipStream_t s, const MaterialRec* mat, uint32_t count, const float* in, float* out);

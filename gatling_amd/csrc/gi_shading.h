@@ -27,11 +27,15 @@ __device__ __forceinline__ void payload_increment_walk(uint32_t& bitfield)
 // (a shadow ray that cannot contribute is dispatched with an empty interval and counts as "not shadowed").  Samples retire out of
 // order here, so every bounce-0 outcome is recorded as (sample + 1) << 1 | shadowed under atomicMax; PathState::neeKey is only
 // set when the AOV is bound AND next-event estimation is on (the reference compiles the block out otherwise).
+__device__ __forceinline__ void nee_aov_record_px(const PathState& st, uint32_t pixelLocal, uint32_t sampleLocal, bool shadowed)
+{
+  const unsigned long long order = (unsigned long long)(st.neeSampleBase + sampleLocal) + 1ull;
+  atomicMax(&st.neeKey[pixelLocal], (order << 1) | (shadowed ? 1ull : 0ull));
+}
 __device__ __forceinline__ void nee_aov_record(const PathState& st, uint32_t slot, bool shadowed)
 {
   const F4 id = ld4(&st.slots[slot].id);
-  const unsigned long long order = (unsigned long long)(st.neeSampleBase + f2u(id.y)) + 1ull;
-  atomicMax(&st.neeKey[f2u(id.x)], (order << 1) | (shadowed ? 1ull : 0ull));
+  nee_aov_record_px(st, f2u(id.x), f2u(id.y), shadowed);
 }
 // ------------------------------------------------------------------------------------------------
 // Shading state (mdl_shading_state.glsl:4-98) from flat scene buffers

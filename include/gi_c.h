@@ -364,6 +364,10 @@ int giCGetRenderStats(const GiCScene* scene, GiCRenderStats* out);
 #define GI_C_SCENE_OPTION_TRACE_DYNAMIC 5
 #define GI_C_SCENE_OPTION_TWO_LEVEL 6     /* [ext] 1: two-level BVH (TLAS over instances + one object-space BLAS per mesh) for scenes beyond LDS; default 0: one
                                              flat BVH over the instanced triangles (faster today); the image does not depend on it */
+/* [ext] Scenes whose whole BVH fits LDS (<= 384 nodes, <= 128 triangles; no medium stack, no dome image) are rendered by the fused
+ * persistent kernel k_path, which keeps the paths in registers (default, -1 / 1); 0 = run the wavefront stage kernels on them too.
+ * The image does not depend on it. */
+#define GI_C_SCENE_OPTION_FUSED_PATH 7
 int giCSetSceneOption(GiCScene* scene, int32_t option, int32_t value);
 /* [ext] closest hit of one ray through the device traversal kernel (parity tests of the BVH8 path).
  * Returns 1 on hit (t,u,v, instance, prim written), 0 on miss, <0 on error. */
