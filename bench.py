@@ -10,8 +10,15 @@ per-pixel accumulation, for N>1 the RCCL tile gather, and the final D2H of the c
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c3|c4|c5] [--spp S]
   N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-N>1 is strong scaling: the same frame is split into N contiguous row bands (one rank per GPU, scene replicated),
-tiles are gathered to rank 0 with one RCCL gather.  Rank 0 prints ONE JSON line.
+N>1 is strong scaling: the rows of the same frame are dealt round-robin to the N ranks (rank r renders rows r, r+N, ...:
+every share samples the whole image; one rank per GPU, scene replicated) and gathered to rank 0 with
+one RCCL gather.  Rank 0 prints ONE JSON line.
+
+roofline (what the line means): `frac` = HBM bytes the dominant kernel really moved (rocprofv3 PMC
+FETCH_SIZE / WRITE_SIZE, collected by this same run in separate `--pmc` passes of this same workload) / its mean launch
+time (HIP events on the library's stream, live) / 8 TB/s.  `algorithmic_frac` is the SURVEY 8d canonical-bytes figure (it
+counts node / triangle bytes whether they come from HBM, L2 or LDS, so it can exceed 1), `valu_frac` the share of the
+VALU issue cycles the kernel used; `bound` names the limiter the counters point to.
 """
 import argparse
 import json
@@ -68,19 +75,97 @@ def cpu_baseline(desc, rs, w, h, budget_s=7.0):
                       f"{cnt['segments'] / cnt['samples']:.3f} segments/sample"}
 
 
-def load_pmc_traffic(workload):
-    """HBM bytes per k_trace launch from the committed rocprofv3 --pmc summary (profiles/pmc_traffic.json, produced by
-    tools/summarize_profile.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command), or None."""
-    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+VALU_CYCLES_PER_INST = 2  # a wave64 VALU instruction issues over 2 cycles, 32 lanes/cycle (MI355X_MICROARCH.md "Wave scheduling"; consistent with k_path issuing
+                          # 4.86e10 VALU instructions in a 74 ms launch = 3.7 cycles per instruction and SIMD while its waves wait 63 % of their cycles)
+SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, max clock (MI355X_MICROARCH.md)
+PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"),
+              ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_INSTS_LDS", "SQ_WAVES"))
+
+
+def fetch_calibration():
+    """FETCH_SIZE / WRITE_SIZE scale factors (reported KiB -> bytes), calibrated with tools/pmc_calib on known byte counts
+    (profiles/pmc_calibration.json; MI355X_MICROARCH.md 'HBM': wide coalesced reads report exactly half)."""
+    cal = {"fetch": 2.0, "fetch_scattered": 1.0, "write": 1.0, "source": "MI355X_MICROARCH.md (wide coalesced reads x2), write uncalibrated"}
+    p = os.path.join(ROOT, "profiles", "pmc_calibration.json")
     if os.path.exists(p):
         try:
             j = json.load(open(p))
-            if "workload" in j:  # older single-entry layout
-                j = {j["workload"]: j}
-            return j.get(workload, {}).get("trace_bytes_per_launch")
+            cal.update({k: j[k] for k in ("fetch", "fetch_scattered", "write", "source") if k in j})
         except Exception:
-            return None
-    return None
+            pass
+    return cal
+
+
+def short_kernel(name):
+    return name.replace("gi::", "").replace("void ", "").split("(")[0]
+
+
+def pmc_live(workload, spp, timeout_s=240):
+    """Runs this workload once more per counter group under `rocprofv3 --pmc` (no tracing options: counters only) and returns
+    {kernel: {counter: sum, "dispatches": n, "pmc_us": mean duration under counter collection}} or (None, reason)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="gatling_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+    notes = []
+    try:
+        for i, group in enumerate(PMC_PASSES):
+            d = os.path.join(tmp, f"p{i}")
+            cmd = [exe, "--pmc", *group, "-d", d, "-o", "probe", "--", sys.executable, os.path.abspath(__file__), "--probe", "--workload", workload]
+            if spp:
+                cmd += ["--spp", str(spp)]
+            try:
+                r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                notes.append(f"pass {group[0]}: timeout"); continue
+            dbs = glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                notes.append(f"pass {group[0]}: rc {r.returncode}, {len(dbs)} db"); continue
+            cur = sqlite3.connect(dbs[0]).cursor()
+            rows = cur.execute("select kernel_name, counter_name, count(distinct dispatch_id), sum(value), sum(duration) * 1.0 / count(*) "
+                               "from counters_collection group by kernel_name, counter_name").fetchall()
+            for k, c, n, v, dur in rows:
+                e = out.setdefault(short_kernel(k), {})
+                e[c] = float(v); e["dispatches"] = int(n); e["pmc_us"] = float(dur) / 1e3
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    if not out:
+        return None, "; ".join(notes) or "no counters collected"
+    return out, "; ".join(notes)
+
+
+def reference_probe():
+    """the real reference next to the GPU path, when a build of it and a Vulkan ray-tracing device exist on
+    this box.  It is timed the way src/gatling/main.cpp:197-207 times itself ("Rendering finished (%.3fs)"), second run."""
+    import shutil
+    import subprocess
+    g, v = shutil.which("gatling"), shutil.which("vulkaninfo")
+    if not g or not v:
+        return {"status": "absent", "gatling": bool(g), "vulkaninfo": bool(v),
+                "note": "no reference build / Vulkan RT device on this box (BASELINE.md section 2); cpu_baseline.kind stays 'port'"}
+    scene = os.path.join(ROOT, "tests", "golden", "cornell.usda")
+    if not os.path.exists(scene):
+        return {"status": "no scene file", "gatling": True, "vulkaninfo": True}
+    times = []
+    for _ in range(2):  # first run pays MDL -> GLSL -> SPIR-V compilation and the BLAS / TLAS build
+        try:
+            r = subprocess.run([g, scene, "/tmp/gatling_ref.png", "--image-width", "1920", "--image-height", "1080", "--spp", "16", "--max-bounces", "8"],
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, text=True)
+        except Exception as e:  # noqa: BLE001
+            return {"status": f"failed: {e}"}
+        import re as _re
+        m = _re.search(r"Rendering finished \(([0-9.]+)s\)", r.stdout or "")
+        if r.returncode != 0 or not m:
+            return {"status": f"failed: rc {r.returncode}"}
+        times.append(float(m.group(1)))
+    return {"status": "timed", "value": round(1920 * 1080 * 16 / times[1] / 1e6, 4), "unit": "Msamples/s", "sample": "cornell 1920x1080 spp=16, second run", "cores": os.cpu_count()}
 
 
 def main():
@@ -92,7 +177,11 @@ def main():
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timers", action="store_true", help="do not record per-stage HIP events (roofline fields become 0)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes (roofline.traffic / frac become null)")
+    ap.add_argument("--probe", action="store_true", help=argparse.SUPPRESS)  # internal: one untimed step, no output (the --pmc passes run this)
     args = ap.parse_args()
+    if args.probe:
+        args.steps, args.warmup, args.no_timers, args.no_cpu_baseline, args.no_pmc = 1, 0, True, True, True
 
     import torch  # plumbing: device sync, torch.distributed (RCCL).  Imported first so one HIP runtime is shared.
     import torch.distributed as dist
@@ -159,6 +248,9 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    if args.probe:
+        scene.close()
+        return
     # --- roofline inputs: one extra (untimed) step with the traversal counters on
     scene.set_option(capi.OPTION_COUNT_TRAVERSAL, 1)
     scene.render(rs, w, h, rows=(r0, r1), device_only=True, row_stride=rstride)
@@ -180,13 +272,58 @@ def main():
         achieved = bytes_total / max(trace_ms * 1e-3, 1e-12) / 1e9
         seg_per_sample = rays / max(1, sum(s["samples"] for s in stats))
         stream_only = (samples_per_step * args.steps / dt) * seg_per_sample * 192.0 / 1e9  # whole-pipeline stream floor
-        kernel = "k_trace<closest>" if cst["triangleCount"] <= 128 else "k_trace_dyn<closest> + k_route"  # scene in LDS or not
-        roofline = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": load_pmc_traffic(args.workload),
-                    "bytes_per_launch": round(bytes_total / max(1, launches), 1), "avg_launch_us": round(trace_ms * 1e3 / max(1, launches), 3),
+        if stats[-1]["fusedPath"]:
+            kernel, prefixes = "k_path (fused persistent path kernel: raygen + closest hit + shade + shadow ray per lane)", ("k_path<",)
+        elif cst["triangleCount"] <= 128:
+            kernel, prefixes = "k_trace<closest>", ("k_trace<false",)
+        else:
+            kernel, prefixes = "k_trace_dyn<closest> + k_route", ("k_trace_dyn<false", "k_route")
+        avg_launch_s = trace_ms * 1e-3 / max(1, launches)
+        roofline = {"bound": "hbm", "kernel": kernel, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                    "algorithmic_GBps": round(achieved, 2), "algorithmic_frac": round(achieved / HBM_PEAK_GBS, 5),
+                    "bytes_per_launch": round(bytes_total / max(1, launches), 1), "avg_launch_us": round(avg_launch_s * 1e6, 3),
                     "nodes_per_ray": round(nodes_per_ray, 3), "tris_per_ray": round(tris_per_ray, 3),
                     "stage_ms_per_step": {k: round(sum(s[k] for s in stats) / args.steps, 3) for k in ("raygenMs", "traceMs", "shadeMs", "shadowMs")},
                     "pipeline_stream_only_GBps": round(stream_only, 2), "pipeline_stream_only_frac": round(stream_only / HBM_PEAK_GBS, 5)}
+        if world == 1 and not args.no_pmc:
+            scene.close(); scene = None  # the probe processes need the device memory (C5: 17 GB of queues per process)
+            pmc, note = pmc_live(args.workload, args.spp)
+            cal = fetch_calibration()
+            roofline["pmc_note"] = note or "ok"
+            if pmc:
+                dom = [v for k, v in pmc.items() if k.startswith(prefixes)]
+                # the closest-hit traversal launches: of the kernels that match, every one belongs to the traversal stage (k_route runs once per k_trace_dyn)
+                n = max([v.get("dispatches", 0) for k, v in pmc.items() if k.startswith(prefixes[0])] or [0])
+                if n:
+                    # k_trace_dyn's reads are per-lane 80-B node / 48-B triangle fetches = 64-B sector requests, which FETCH_SIZE reports at their
+                    # size; the coalesced x2 applies to streaming kernels only (profiles/pmc_calibration.json).  `traffic_upper` = everything x2.
+                    scattered = prefixes[0].startswith("k_trace_dyn")
+                    raw_fetch = sum(v.get("FETCH_SIZE", 0.0) for v in dom) * 1024.0 / n
+                    fetch = raw_fetch * (cal["fetch_scattered"] if scattered else cal["fetch"])
+                    write = sum(v.get("WRITE_SIZE", 0.0) for v in dom) * 1024.0 * cal["write"] / n
+                    have = any("FETCH_SIZE" in v for v in dom) and any("WRITE_SIZE" in v for v in dom)
+                    if have:
+                        roofline["traffic"] = round(fetch + write, 1)
+                        roofline["traffic_fetch"] = round(fetch, 1); roofline["traffic_write"] = round(write, 1)
+                        roofline["traffic_upper"] = round(raw_fetch * cal["fetch"] + write, 1)
+                        roofline["achieved"] = round((fetch + write) / max(avg_launch_s, 1e-12) / 1e9, 2)
+                        roofline["frac"] = round(roofline["achieved"] / HBM_PEAK_GBS, 5)
+                        roofline["calibration"] = cal
+                    main_k = [v for k, v in pmc.items() if k.startswith(prefixes[0])]
+                    valu = sum(v.get("SQ_INSTS_VALU", 0.0) for v in main_k) / n
+                    if valu:
+                        # VALU issue cycles used / available: instructions x 2 cycles / (1024 SIMDs x launch cycles at the 2.4 GHz max clock)
+                        roofline["valu_frac"] = round(valu * VALU_CYCLES_PER_INST / (SIMDS * avg_launch_s * CLOCK_HZ), 5)
+                        wc = sum(v.get("SQ_WAVE_CYCLES", 0.0) for v in main_k)
+                        if wc:
+                            roofline["wave_cycles_not_valu_frac"] = round(1.0 - sum(v.get("SQ_ACTIVE_INST_VALU", 0.0) for v in main_k) / wc, 5)
+                            roofline["wait_inst_any_frac"] = round(sum(v.get("SQ_WAIT_INST_ANY", 0.0) for v in main_k) / wc, 5)
+                    hit, miss = sum(v.get("TCC_HIT_sum", 0.0) for v in main_k), sum(v.get("TCC_MISS_sum", 0.0) for v in main_k)
+                    if hit + miss > 0:
+                        roofline["l2_hit_rate"] = round(hit / (hit + miss), 5)
+                    if roofline.get("valu_frac") is not None and roofline["frac"] is not None:
+                        roofline["bound"] = "valu" if roofline["valu_frac"] > roofline["frac"] else "hbm"
+                    roofline["pmc_kernels"] = {k: {c: (round(x, 1) if isinstance(x, float) else x) for c, x in v.items()} for k, v in pmc.items() if k.startswith(prefixes)}
         out = {"metric": "Msamples/s (spp x pixels / s) at 8 bounces, 1920x1080", "value": round(value, 2), "unit": "Msamples/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -196,7 +333,9 @@ def main():
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(desc, rs, w, h)
-    scene.close()
+            out["cpu_baseline"]["reference"] = reference_probe()
+    if scene is not None:
+        scene.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -1312,6 +1312,7 @@ static int giCRenderImpl(const GiCRenderParams* params)
 
   double tStart = nowMs();
   uint32_t iters = 0, traceLaunches = 0;
+  bool usedFused = false;
   size_t ev = 0;
   std::vector<int> evKind; // 0 raygen, 1 trace, 2 shade, 3 shadow
   const bool timers = s->kernelTimers;
@@ -1346,6 +1347,7 @@ static int giCRenderImpl(const GiCRenderParams* params)
     view.mediumStackSize = rs.mediumStackSize;
     bool fused = pathKernelSupports(view) && s->optFusedPath != 0;
     if (const char* e = getenv("GATLING_FUSED")) fused = fused && atoi(e) != 0;
+    usedFused = fused;
     const size_t slots = fused ? 1 : (size_t)std::min<uint64_t>(poolMax, (uint64_t)pixels * batchSamples);
 
     // persistent grids: blocks per CU limited by registers (<= 6 waves/SIMD for k_trace) and, for k_trace, by the LDS it stages
@@ -1493,7 +1495,7 @@ static int giCRenderImpl(const GiCRenderParams* params)
   double tEnd = nowMs();
 
   GiCRenderStats& S = s->stats;
-  S.renderMs = tEnd - tStart; S.samples = (uint64_t)pixels * rs.spp; S.iterations = iters; S.traceLaunches = traceLaunches;
+  S.renderMs = tEnd - tStart; S.samples = (uint64_t)pixels * rs.spp; S.iterations = iters; S.traceLaunches = traceLaunches; S.fusedPath = usedFused ? 1u : 0u;
   S.segments = s->hCounters->segments; S.shadowRays = s->hCounters->shadowRays; S.nodesVisited = s->hCounters->nodesVisited; S.trisTested = s->hCounters->trisTested;
   S.shadowNodesVisited = s->hCounters->shadowNodesVisited; S.shadowTrisTested = s->hCounters->shadowTrisTested;
   if (s->hCounters->overflow) { setError("giCRender: a work-queue shard overflowed its capacity (internal sizing error); the image is invalid"); return GI_C_ERROR; }

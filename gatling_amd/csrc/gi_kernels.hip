@@ -262,13 +262,26 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
 #define GI_DYN_CLAIM 128
 #endif
 constexpr uint32_t DYN_CLAIM = GI_DYN_CLAIM; // rays per cursor atomic (multiple of 64)
+constexpr uint32_t DYN_FLAG_XCD_RANGES = 1u;
+constexpr uint32_t DYN_LDS_NODES_DEFAULT = 0u;   // (GATLING_DYN_LDS_NODES)
+constexpr bool DYN_XCD_RANGES_DEFAULT = false;   // (GATLING_DYN_XCD)
+#ifndef GI_DYN_WAVES
+#define GI_DYN_WAVES 5
+#endif
 template <bool TWO> struct DynRay { using type = RayTrav; };
 template <> struct DynRay<true> { using type = RayTrav2; };
 template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool CUTOUT, bool TWO = false>
-__device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t refill)
+__device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t refill, uint32_t ldsNodes, uint32_t flags)
 {
   extern __shared__ uint4 s_dyn[];
   uint2 (*s_stack)[TRACE_BLOCK] = reinterpret_cast<uint2 (*)[TRACE_BLOCK]>(s_dyn);
+  // The top of the tree (breadth-first prefix: root + its children + ...) is visited by every ray; staged in LDS once per block, those
+  // visits cost an LDS read instead of an L2 round trip.  The one barrier of the kernel: afterwards the waves are independent.
+  uint4* s_nodes = s_dyn + (STACK * TRACE_BLOCK * sizeof(uint2)) / sizeof(uint4);
+  if (!TWO && ldsNodes) {
+    for (uint32_t i = threadIdx.x; i < ldsNodes * 5u; i += TRACE_BLOCK) s_nodes[i] = reinterpret_cast<const uint4*>(sc.nodes)[(i / 5u) * sc.nodeStrideU4 + (i % 5u)];
+    __syncthreads();
+  }
   __shared__ WaveTri s_wave[TRACE_BLOCK / 64];
   __shared__ WaveStage s_stage[TRACE_DYN_COOP_FETCH ? TRACE_BLOCK / 64 : 1];
   WaveTri& W = s_wave[threadIdx.x >> 6];
@@ -295,7 +308,9 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
   // range k = rays [k * per, min(n, (k + 1) * per)); a wave starts on the range of its index and moves on when a range runs dry, so the
   // ranges also balance each other at the end of the launch
   const uint32_t per = ((n + NCURSOR - 1u) / NCURSOR + 63u) & ~63u;
-  uint32_t range = (blockIdx.x * (TRACE_BLOCK / 64u) + (threadIdx.x >> 6)) % NCURSOR, rangesTried = 0u;
+  // DYN_FLAG_XCD_RANGES: all waves of a block start on the range of the block's XCD (workgroups are dealt to the 8 XCDs round-robin), so an
+  // XCD's L2 sees one eighth of the launch's rays -- with key-ordered queues, one key
+  uint32_t range = ((flags & DYN_FLAG_XCD_RANGES) ? blockIdx.x : (blockIdx.x * (TRACE_BLOCK / 64u) + (threadIdx.x >> 6))) % NCURSOR, rangesTried = 0u;
   uint32_t claimBase = 0u, claimLeft = 0u; // wave-uniform
   auto next_chunk = [&]() {
     while (claimLeft == 0u && rangesTried < NCURSOR) {
@@ -344,7 +359,7 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
     if (!__ballot(alive)) { if (chunkCount == 0u) break; else continue; }
     bool done;
     if constexpr (TWO) done = wave_step2<ANYHIT, COUNT, CUTOUT>(R, alive, W, sc, s_stack, tc, rng);
-    else done = wave_step<ANYHIT, COUNT, STACK, OVERFLOW, false, CUTOUT, TRACE_DYN_COOP_FETCH>(R, alive, W, S, sc, nullptr, 0u, nullptr, 0u, s_stack, overflow, tc, rng);
+    else done = wave_step<ANYHIT, COUNT, STACK, OVERFLOW, false, CUTOUT, TRACE_DYN_COOP_FETCH>(R, alive, W, S, sc, s_nodes, ldsNodes, nullptr, 0u, s_stack, overflow, tc, rng);
     if (alive && done) {
       alive = false;
       wave_ray_end(W, R);
@@ -376,15 +391,15 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
 }
 
 template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool CUTOUT>
-__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_trace_dyn(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t refill)
+__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(GI_DYN_WAVES, 8))) void k_trace_dyn(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t refill, uint32_t ldsNodes, uint32_t flags)
 {
-  trace_dyn_body<ANYHIT, COUNT, STACK, OVERFLOW, CUTOUT>(sc, st, qs, cnt, qIn, refill);
+  trace_dyn_body<ANYHIT, COUNT, STACK, OVERFLOW, CUTOUT>(sc, st, qs, cnt, qIn, refill, ldsNodes, flags);
 }
 // the two-level layout (wave_step2): 16 LDS stack entries, world + object-space ray in registers
 template <bool ANYHIT, bool COUNT, bool CUTOUT>
 __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_trace_dyn2(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t refill)
 {
-  trace_dyn_body<ANYHIT, COUNT, 16, false, CUTOUT, true>(sc, st, qs, cnt, qIn, refill);
+  trace_dyn_body<ANYHIT, COUNT, 16, false, CUTOUT, true>(sc, st, qs, cnt, qIn, refill, 0u, 0u);
 }
 
 // k_route: sorts k_trace_dyn's in-place results by outcome and material class (same routing as k_trace's epilogue)
@@ -652,12 +667,19 @@ static void launchTraceVariant(hipStream_t s, uint32_t blocks, const SceneView& 
     const uint32_t claimChunks = dynRefill >> 16;
     dynRefill = (dynRefill & 0xffu) | (claimChunks << 16);
     const uint32_t entries = (sc.bvhDepth <= 8u || spill8) ? 8u : 16u;
-    const uint32_t stackBytes = entries * TRACE_BLOCK * (uint32_t)sizeof(uint2);
+    // top-of-tree prefix staged in LDS: root + children + grandchildren (1 + 8 + 64 nodes = 5.8 KB) keeps 5 blocks per CU resident
+    static const int envLds = getenv("GATLING_DYN_LDS_NODES") ? atoi(getenv("GATLING_DYN_LDS_NODES")) : -1;
+    static const int envXcd = getenv("GATLING_DYN_XCD") ? atoi(getenv("GATLING_DYN_XCD")) : -1;
+    uint32_t dynLdsNodes = envLds >= 0 ? (uint32_t)envLds : DYN_LDS_NODES_DEFAULT;
+    if (dynLdsNodes > sc.nodeCount) dynLdsNodes = sc.nodeCount;
+    if (dynLdsNodes > 1024u) dynLdsNodes = 1024u;
+    const uint32_t dynFlags = (envXcd >= 0 ? envXcd != 0 : DYN_XCD_RANGES_DEFAULT) ? DYN_FLAG_XCD_RANGES : 0u;
+    const uint32_t stackBytes = entries * TRACE_BLOCK * (uint32_t)sizeof(uint2) + dynLdsNodes * 80u;
 #define GI_LAUNCH_DYN(K) do { \
-    if (sc.bvhDepth <= 8u) hipLaunchKernelGGL((K<ANYHIT, COUNT, 8, false, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill); \
-    else if (spill8) hipLaunchKernelGGL((K<ANYHIT, COUNT, 8, true, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill); \
-    else if (sc.bvhDepth <= 16u) hipLaunchKernelGGL((K<ANYHIT, COUNT, 16, false, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill); \
-    else hipLaunchKernelGGL((K<ANYHIT, COUNT, 16, true, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill); } while (0)
+    if (sc.bvhDepth <= 8u) hipLaunchKernelGGL((K<ANYHIT, COUNT, 8, false, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill, dynLdsNodes, dynFlags); \
+    else if (spill8) hipLaunchKernelGGL((K<ANYHIT, COUNT, 8, true, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill, dynLdsNodes, dynFlags); \
+    else if (sc.bvhDepth <= 16u) hipLaunchKernelGGL((K<ANYHIT, COUNT, 16, false, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill, dynLdsNodes, dynFlags); \
+    else hipLaunchKernelGGL((K<ANYHIT, COUNT, 16, true, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill, dynLdsNodes, dynFlags); } while (0)
     GI_LAUNCH_DYN(k_trace_dyn);
 #undef GI_LAUNCH_DYN
     if (!ANYHIT) hipLaunchKernelGGL(k_route, dim3(routeBlocks), dim3(BLOCK), 0, s, sc, st, qs, cnt, qIn, qMiss);

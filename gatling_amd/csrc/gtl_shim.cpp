@@ -6,6 +6,7 @@
 #include "../../include/gtl/gi/Gi.h"
 #include "../../include/gi_c.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -28,7 +29,8 @@ namespace gtl
     GiAssetReader* s_assetReader = nullptr;
 
     // ---- minimal MaterialX reader: first <UsdPreviewSurface|open_pbr_surface ...> element and its <input name value> children
-    struct MtlxNode { std::string category; std::map<std::string, std::string> inputs; std::map<std::string, std::string> connections; /* input -> upstream node name */ };
+    struct MtlxNode { std::string category; std::map<std::string, std::string> inputs; std::map<std::string, std::string> connections; /* input -> upstream node name */
+                      std::map<std::string, std::string> outputs; /* input -> which output of that node (connections through a nodegraph) */ };
 
     std::string attr(const std::string& tag, const char* name)
     {
@@ -66,8 +68,23 @@ namespace gtl
         if (e == std::string::npos) break;
         std::string tag = doc.substr(p, e - p + 1);
         std::string name = attr(tag, "name"), value = attr(tag, "value");
-        if (!name.empty() && !value.empty() && attr(tag, "nodename").empty()) out.inputs[name] = value; // constants
+        if (!name.empty() && !value.empty() && attr(tag, "nodename").empty() && attr(tag, "nodegraph").empty()) out.inputs[name] = value; // constants
         else if (!name.empty() && !attr(tag, "nodename").empty()) out.connections[name] = attr(tag, "nodename");
+        else if (!name.empty() && !attr(tag, "nodegraph").empty()) {
+          // HdMtlxCreateMtlxDocumentFromHdNetwork puts upstream nodes into a <nodegraph> and connects the surface input to one of its
+          // <output name=... nodename=...>: follow it to the node that feeds the output
+          const std::string ng = attr(tag, "nodegraph"), on = attr(tag, "output");
+          size_t g = doc.find("<nodegraph name=\"" + ng + "\"");
+          size_t gEnd = g == std::string::npos ? g : doc.find("</nodegraph>", g);
+          size_t q = g;
+          while (g != std::string::npos && (q = doc.find("<output", q)) != std::string::npos && q < gEnd) {
+            size_t oe = doc.find('>', q);
+            if (oe == std::string::npos) break;
+            const std::string otag = doc.substr(q, oe - q + 1);
+            if (on.empty() || attr(otag, "name") == on) { if (!attr(otag, "nodename").empty()) { out.connections[name] = attr(otag, "nodename"); out.outputs[name] = attr(otag, "output"); } break; }
+            q = oe;
+          }
+        }
         p = e;
       }
       return true;
@@ -181,7 +198,9 @@ namespace gtl
         // which output feeds a scalar input: <input ... nodename="tex" output="g"/>
         const std::string needle = std::string("name=\"") + input + "\"";
         size_t q = doc.find(needle);
-        if (q != std::string::npos) { size_t e = doc.find('>', q); const std::string tag = doc.substr(q, e - q); const std::string o = attr(tag + " ", "output"); im.channel = o == "g" ? 1 : o == "b" ? 2 : o == "a" ? 3 : 0; }
+        if (q != std::string::npos) { size_t e = doc.find('>', q); const std::string tag = doc.substr(q, e - q); std::string o = attr(tag + " ", "output");
+          if (n.outputs.count(input)) o = n.outputs[input];
+          im.channel = o == "g" ? 1 : o == "b" ? 2 : o == "a" ? 3 : 0; }
       };
       memset(&d, 0, sizeof(d));
       float* p = d.p;
@@ -230,10 +249,8 @@ namespace gtl
   void giTerminate() { giCTerminate(); }
   void giRegisterAssetReader(GiAssetReader* reader) { s_assetReader = reader; }
 
-  GiMaterial* giCreateMaterialFromMtlxStr(GiScene* scene, const char* name, const char* mtlxSrc)
+  static GiMaterial* makeMaterial(GiScene* scene, const char* name, const GiCMaterialDesc& d, const std::string (&primvars)[GI_C_TEX_SLOT_COUNT], const ImageInput (&images)[GI_C_TEX_SLOT_COUNT])
   {
-    GiCMaterialDesc d; std::string primvars[GI_C_TEX_SLOT_COUNT]; ImageInput images[GI_C_TEX_SLOT_COUNT];
-    if (!scene || !descFromMtlx(mtlxSrc, d, primvars, images)) return nullptr;
     GiCMaterial* h = giCCreateMaterial(scene->h, name, &d);
     if (!h) return nullptr;
     auto* mat = new GiMaterial{h, {}};
@@ -249,8 +266,110 @@ namespace gtl
     }
     return mat;
   }
-  GiMaterial* giCreateMaterialFromMtlxDoc(GiScene*, const char*, const std::shared_ptr<void>) { return nullptr; }
-  GiMaterial* giCreateMaterialFromMdlFile(GiScene*, const char*, const char*, const char*, const GiMaterialParameters&) { return nullptr; }
+
+  GiMaterial* giCreateMaterialFromMtlxStr(GiScene* scene, const char* name, const char* mtlxSrc)
+  {
+    GiCMaterialDesc d; std::string primvars[GI_C_TEX_SLOT_COUNT]; ImageInput images[GI_C_TEX_SLOT_COUNT];
+    if (!scene || !descFromMtlx(mtlxSrc, d, primvars, images)) return nullptr;
+    return makeMaterial(scene, name, d, primvars, images);
+  }
+
+  // MaterialX documents (hdGatling's path for every UsdPreviewSurface / MaterialX network, materialNetworkCompiler.cpp:667-686): the
+  // document is serialised by gtl_shim_mtlx.cpp -- the one translation unit that needs the MaterialX headers -- which registers itself here.
+  static GtlMtlxDocToXml s_docToXml = nullptr;
+  void gtlRegisterMtlxDocSerializer(GtlMtlxDocToXml fn) { s_docToXml = fn; }
+  GiMaterial* giCreateMaterialFromMtlxDoc(GiScene* scene, const char* name, const std::shared_ptr<void> doc)
+  {
+    if (!s_docToXml) { fprintf(stderr, "[gatling_gi] giCreateMaterialFromMtlxDoc: built without gtl_shim_mtlx.cpp (MaterialX headers not found at build time)\n"); return nullptr; }
+    if (!doc) return nullptr;
+    const std::string xml = s_docToXml(doc);
+    return giCreateMaterialFromMtlxStr(scene, name, xml.c_str());
+  }
+
+  // MDL modules (materialNetworkCompiler.cpp:619-665): no MDL compiler here; parameters are matched by NAME against three vocabularies --
+  // the OmniPBR family the reference ships (src/gi/mdl/OmniPBR.mdl:53-224), UsdPreviewSurface inputs, open_pbr_surface inputs.
+  GiMaterial* giCreateMaterialFromMdlFile(GiScene* scene, const char* name, const char* filePath, const char* subIdentifier, const GiMaterialParameters& params)
+  {
+    if (!scene) return nullptr;
+    auto num = [&](const char* key, float* dst, int n) -> bool {
+      auto it = params.find(key);
+      if (it == params.end()) return false;
+      const GiMaterialParameterValue& v = it->second;
+      float tmp[4] = {0, 0, 0, 0}; int have = 0;
+      if (auto* b = std::get_if<bool>(&v)) { tmp[0] = *b ? 1.0f : 0.0f; have = 1; }
+      else if (auto* i = std::get_if<int>(&v)) { tmp[0] = (float)*i; have = 1; }
+      else if (auto* f = std::get_if<float>(&v)) { tmp[0] = *f; have = 1; }
+      else if (auto* a = std::get_if<GbVec2f>(&v)) { tmp[0] = a->x; tmp[1] = a->y; have = 2; }
+      else if (auto* a3 = std::get_if<GbVec3f>(&v)) { tmp[0] = a3->x; tmp[1] = a3->y; tmp[2] = a3->z; have = 3; }
+      else if (auto* a4 = std::get_if<GbVec4f>(&v)) { tmp[0] = a4->x; tmp[1] = a4->y; tmp[2] = a4->z; tmp[3] = a4->w; have = 4; }
+      else if (auto* c = std::get_if<GbColor>(&v)) { tmp[0] = c->r; tmp[1] = c->g; tmp[2] = c->b; have = 3; }
+      else return false;
+      for (int k = 0; k < n; k++) dst[k] = have == 1 ? tmp[0] : tmp[k < have ? k : have - 1];
+      return true;
+    };
+    GiCMaterialDesc d; memset(&d, 0, sizeof(d));
+    std::string primvars[GI_C_TEX_SLOT_COUNT]; ImageInput images[GI_C_TEX_SLOT_COUNT];
+    auto tex = [&](const char* key, int slot, int channel) -> bool {
+      auto it = params.find(key);
+      if (it == params.end()) return false;
+      const GbTextureAsset* a = std::get_if<GbTextureAsset>(&it->second);
+      if (!a || a->absPath.empty()) return false;
+      images[slot].file = a->absPath; images[slot].srgb = a->isSrgb; images[slot].channel = channel;
+      return true;
+    };
+    float* p = d.p;
+    const std::string module = std::string(filePath ? filePath : "") + "::" + (subIdentifier ? subIdentifier : "");
+    bool known = false;
+    if (params.count("base_color") || params.count("specular_roughness") || params.count("base_metalness") || module.find("open_pbr") != std::string::npos) {
+      // open_pbr_surface vocabulary: the same defaults and inputs as the MaterialX route (src/gi/mtlx/open_pbr_surface.mtlx:11-92)
+      std::string xml = "<materialx version=\"1.39\"><open_pbr_surface name=\"m\" type=\"surfaceshader\">";
+      static const char* kOpbr[] = {"base_weight", "base_color", "base_diffuse_roughness", "base_metalness", "specular_weight", "specular_color", "specular_roughness", "specular_ior",
+                                    "transmission_weight", "transmission_color", "transmission_depth", "transmission_scatter", "transmission_scatter_anisotropy", "coat_weight", "coat_color",
+                                    "coat_roughness", "coat_ior", "emission_luminance", "emission_color", "geometry_opacity", "fuzz_weight", "fuzz_color", "fuzz_roughness", "geometry_thin_walled"};
+      for (const char* k : kOpbr) { float v[3]; if (num(k, v, 3)) { char buf[160]; snprintf(buf, sizeof(buf), "<input name=\"%s\" value=\"%.9g, %.9g, %.9g\" />", k, v[0], v[1], v[2]); xml += buf; } }
+      xml += "</open_pbr_surface></materialx>";
+      if (!descFromMtlx(xml.c_str(), d, primvars, images)) return nullptr;
+      tex("base_color", GI_C_TEX_BASE_COLOR, 0); tex("specular_roughness", GI_C_TEX_ROUGHNESS, 0); tex("base_metalness", GI_C_TEX_METALLIC, 0);
+      known = true;
+    } else {
+      d.klass = GI_C_MAT_USD_PREVIEW_SURFACE;
+      p[GI_C_P_BASE_COLOR] = p[GI_C_P_BASE_COLOR + 1] = p[GI_C_P_BASE_COLOR + 2] = 0.18f;
+      p[GI_C_P_ROUGHNESS] = 0.5f; p[GI_C_P_CLEARCOAT_ROUGHNESS] = 0.01f; p[GI_C_P_OPACITY] = 1.0f; p[GI_C_P_IOR] = 1.5f;
+      // UsdPreviewSurface vocabulary
+      known |= num("diffuseColor", p + GI_C_P_BASE_COLOR, 3); known |= num("emissiveColor", p + GI_C_P_EMISSION, 3);
+      known |= num("useSpecularWorkflow", p + GI_C_P_USE_SPECULAR_WORKFLOW, 1); known |= num("specularColor", p + GI_C_P_SPECULAR_COLOR, 3);
+      known |= num("metallic", p + GI_C_P_METALLIC, 1); known |= num("roughness", p + GI_C_P_ROUGHNESS, 1);
+      known |= num("clearcoat", p + GI_C_P_CLEARCOAT, 1); known |= num("clearcoatRoughness", p + GI_C_P_CLEARCOAT_ROUGHNESS, 1);
+      known |= num("opacity", p + GI_C_P_OPACITY, 1); known |= num("opacityThreshold", p + GI_C_P_OPACITY_THRESHOLD, 1); known |= num("ior", p + GI_C_P_IOR, 1);
+      // OmniPBR vocabulary (OmniPBR.mdl:53-224; module defaults: diffuse 0.2, roughness 0.5, metallic 0, emission off)
+      const bool omni = module.find("OmniPBR") != std::string::npos;
+      if (omni) { p[GI_C_P_BASE_COLOR] = p[GI_C_P_BASE_COLOR + 1] = p[GI_C_P_BASE_COLOR + 2] = 0.2f; known = true; }
+      float tint[3] = {1.0f, 1.0f, 1.0f};
+      known |= num("diffuse_color_constant", p + GI_C_P_BASE_COLOR, 3);
+      if (num("diffuse_tint", tint, 3)) for (int k = 0; k < 3; k++) p[GI_C_P_BASE_COLOR + k] *= tint[k];
+      known |= num("reflection_roughness_constant", p + GI_C_P_ROUGHNESS, 1); known |= num("metallic_constant", p + GI_C_P_METALLIC, 1);
+      float enableEm = 0.0f, emCol[3] = {1.0f, 0.1f, 0.1f}, emInt = 40.0f;
+      num("enable_emission", &enableEm, 1); num("emissive_color", emCol, 3); num("emissive_intensity", &emInt, 1);
+      if (enableEm != 0.0f) for (int k = 0; k < 3; k++) p[GI_C_P_EMISSION + k] = emCol[k] * emInt; // (cd/m2: the reference's unit handling is the MDL SDK's; not pinned)
+      float enableOp = 0.0f, opC = 1.0f;
+      num("enable_opacity", &enableOp, 1);
+      if (enableOp != 0.0f && num("opacity_constant", &opC, 1)) { p[GI_C_P_OPACITY] = opC; num("opacity_threshold", p + GI_C_P_OPACITY_THRESHOLD, 1); }
+      if (omni && module.find("ClearCoat") != std::string::npos) { float en = 0.0f, w = 1.0f; num("enable_clearcoat", &en, 1); num("clearcoat_weight", &w, 1); if (en != 0.0f) p[GI_C_P_CLEARCOAT] = w; num("clearcoat_roughness", p + GI_C_P_CLEARCOAT_ROUGHNESS, 1); }
+      if (tex("diffuse_texture", GI_C_TEX_BASE_COLOR, 0) || tex("diffuseColor", GI_C_TEX_BASE_COLOR, 0)) { known = true; for (int k = 0; k < 3; k++) images[GI_C_TEX_BASE_COLOR].scale[k] = tint[k]; }
+      float infl = 0.0f;
+      if (num("reflection_roughness_texture_influence", &infl, 1) && infl > 0.0f && tex("reflectionroughness_texture", GI_C_TEX_ROUGHNESS, 0)) {
+        images[GI_C_TEX_ROUGHNESS].scale[0] = infl; images[GI_C_TEX_ROUGHNESS].bias[0] = p[GI_C_P_ROUGHNESS] * (1.0f - infl); // lerp(constant, texel, influence)
+      }
+      if (num("metallic_texture_influence", &infl, 1) && infl > 0.0f && tex("metallic_texture", GI_C_TEX_METALLIC, 0)) {
+        images[GI_C_TEX_METALLIC].scale[0] = infl; images[GI_C_TEX_METALLIC].bias[0] = p[GI_C_P_METALLIC] * (1.0f - infl);
+      }
+      if (enableEm != 0.0f && tex("emissive_color_texture", GI_C_TEX_EMISSION, 0)) for (int k = 0; k < 3; k++) images[GI_C_TEX_EMISSION].scale[k] = emInt;
+      tex("normalmap_texture", GI_C_TEX_NORMAL, 0); tex("normal", GI_C_TEX_NORMAL, 0);
+      if (enableOp != 0.0f) { float ot = 0.0f; num("enable_opacity_texture", &ot, 1); if (ot != 0.0f) tex("opacity_texture", GI_C_TEX_OPACITY, 0); }
+    }
+    if (!known) { fprintf(stderr, "[gatling_gi] giCreateMaterialFromMdlFile(%s): no MDL compiler and no recognised parameter -- the delegate's default material is used\n", module.c_str()); return nullptr; }
+    return makeMaterial(scene, name, d, primvars, images);
+  }
   void giDestroyMaterial(GiMaterial* mat)
   {
     if (!mat) return;
@@ -270,10 +389,12 @@ namespace gtl
   {
     static_assert(sizeof(GiVertex) == sizeof(GiCVertex) && sizeof(GiFace) == sizeof(GiCFace), "layouts must match Gi.h:110-122");
     GiCMeshDesc c{};
-    c.faceCount = d.faceCount; c.faces = reinterpret_cast<const GiCFace*>(d.faces.data());
-    c.faceIds = d.faceIds.size() >= d.faceCount && d.faceCount ? d.faceIds.data() : nullptr;
+    // counts come from the vectors: the reference ignores desc.faceCount / vertexCount (Gi.cpp:628 passes the vectors on) and hdGatling
+    // leaves both at zero (designated initialisers, mesh.cpp:1092-1102)
+    c.faceCount = (uint32_t)d.faces.size(); c.faces = reinterpret_cast<const GiCFace*>(d.faces.data());
+    c.faceIds = d.faceIds.size() >= d.faces.size() && !d.faces.empty() ? d.faceIds.data() : nullptr;
     c.id = d.id; c.isDoubleSided = d.isDoubleSided; c.isLeftHanded = d.isLeftHanded; c.name = d.name; c.maxFaceId = d.maxFaceId;
-    c.vertexCount = d.vertexCount; c.vertices = reinterpret_cast<const GiCVertex*>(d.vertices.data());
+    c.vertexCount = (uint32_t)d.vertices.size(); c.vertices = reinterpret_cast<const GiCVertex*>(d.vertices.data());
     GiCMesh* h = scene ? giCCreateMesh(scene->h, &c) : nullptr;
     if (!h) return nullptr;
     setPrimvars(h, d.primvars, false);

@@ -264,6 +264,8 @@ typedef struct GiCRenderStats {
   uint32_t traceLaunches;
   uint32_t nodeCount;    /* BVH8 nodes                                                      */
   uint32_t triangleCount;
+  uint32_t fusedPath;    /* 1: the colour pass ran as the fused persistent kernel k_path (LDS-resident scene) */
+  uint32_t reserved0;
 } GiCRenderStats;
 
 /* Gi.h:199-200.  deviceOrdinal selects the HIP device (the reference picks one Vulkan device by score,

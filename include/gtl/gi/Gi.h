@@ -16,6 +16,8 @@
 #include <variant>
 #include <vector>
 
+#include <gtl/gb/ParamTypes.h>   // GbVec2f/3f/4f, GbColor, GbTextureAsset{absPath, isSrgb} -- as the reference does (Gi.h:28)
+
 namespace gtl
 {
   // ---- handles (Gi.h:58-68): opaque here as there; each wraps one giC* handle -------------------------------------------
@@ -38,7 +40,8 @@ namespace gtl
   struct GiCameraDesc                                                                                          // Gi.h:94-108 == GiCCameraDesc
   { float position[3], forward[3], up[3]; float vfov, fStop, focusDistance, focalLength, clipStart, clipEnd, exposure; };
   struct GiMeshDesc                                                                                            // Gi.h:124-137; arrays are copied by giCreateMesh
-  {
+  { // hdGatling fills this with designated initialisers and leaves faceCount / vertexCount at zero (mesh.cpp:1092-1102): like the reference
+    // (Gi.cpp:628), giCreateMesh takes the counts from the vectors and ignores the two count fields
     uint32_t faceCount; const std::vector<GiFace>& faces; const std::vector<int>& faceIds;
     int id; bool isDoubleSided; bool isLeftHanded; const char* name; uint32_t maxFaceId;
     const std::vector<GiPrimvarData>& primvars; // float primvars feed material inputs bound to them by name (scene_data_lookup_*)
@@ -67,9 +70,7 @@ namespace gtl
     virtual void close(GiAsset* asset) = 0;
   };
 
-  // stand-ins for <gtl/gb/ParamTypes.h>, needed only to spell GiMaterialParameters (Gi.h:196-197; MDL-file materials are refused)
-  struct GbVec2f { float x, y; }; struct GbVec3f { float x, y, z; }; struct GbVec4f { float x, y, z, w; }; struct GbColor { float r, g, b; };
-  struct GbTextureAsset { std::string resolvedPath; };
+  // Gi.h:196-197: what hdGatling's _TranslateMaterialParameters produces (materialNetworkCompiler.cpp:533-612)
   using GiMaterialParameterValue = std::variant<bool, int, float, GbVec2f, GbVec3f, GbVec4f, GbColor, GbTextureAsset>;
   using GiMaterialParameters = std::unordered_map<std::string, GiMaterialParameterValue>;
 
@@ -87,9 +88,16 @@ namespace gtl
   // become the GiCMaterialDesc parameter block, inputs fed by a primvar reader become scene-data bindings; everything else is nullptr,
   // which hdGatling answers with its default material (mesh.cpp:598-603).
   GiMaterial* giCreateMaterialFromMtlxStr(GiScene*, const char* name, const char* mtlxSrc);
-  GiMaterial* giCreateMaterialFromMtlxDoc(GiScene*, const char* name, const std::shared_ptr<void> doc); // nullptr: serialise the document and use ...FromMtlxStr
+  // doc is a MaterialX::DocumentPtr.  gtl_shim_mtlx.cpp (built when the MaterialX headers are found) serialises it with
+  // MaterialX::writeToXmlString and feeds the same scanner; without that translation unit the call fails with nullptr and a message.
+  GiMaterial* giCreateMaterialFromMtlxDoc(GiScene*, const char* name, const std::shared_ptr<void> doc);
+  using GtlMtlxDocToXml = std::string (*)(const std::shared_ptr<void>& doc);   // [ext] MaterialX::DocumentPtr -> XML text
+  void gtlRegisterMtlxDocSerializer(GtlMtlxDocToXml);                           // [ext] called by gtl_shim_mtlx.cpp's static initialiser
+  // There is no MDL compiler here.  The parameters hdGatling hands over by name are mapped onto the closed-form blocks: the OmniPBR
+  // family shipped with the reference (src/gi/mdl/OmniPBR*.mdl) -> the UsdPreviewSurface block, UsdPreviewSurface / open_pbr_surface
+  // spelled parameters directly; texture assets are decoded and bound.  Modules none of whose parameters are recognised: nullptr.
   GiMaterial* giCreateMaterialFromMdlFile(GiScene*, const char* name, const char* filePath, const char* subIdentifier,
-                                          const GiMaterialParameters& params = {});                      // nullptr: no MDL compiler
+                                          const GiMaterialParameters& params = {});
   void giDestroyMaterial(GiMaterial*);
 
   // ---- meshes (Gi.h:209-217): setters only mark the scene dirty, the BVH is rebuilt by the next giRender -------------------------

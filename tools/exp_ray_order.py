@@ -8,7 +8,7 @@ costs (>= 60 us for 4 M rays at 5 TB/s); camera rays cost 37 ps/ray, secondary r
 `... exp_ray_order.py soup 1000000` (k_trace_dyn, scene beyond LDS): random 2061 us, best order (16^3 Morton cell, octant) 1848 us."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gatling_amd import capi
 from gatling_amd.scenes import cornell_box
 
@@ -73,7 +73,10 @@ def part1by2(v):
     v = (v | (v << 8)) & 0x00f00f; v = (v | (v << 4)) & 0x0c30c3; v = (v | (v << 2)) & 0x249249
     return v
 morton16 = part1by2(cell16[:, 0]) | (part1by2(cell16[:, 1]) << 1) | (part1by2(cell16[:, 2]) << 2)
-orders = {"random mix": np.arange(len(S_o)), "by octant": np.argsort(octant, kind="stable"), "by origin triangle": np.argsort(S_t, kind="stable"),
+cell2 = np.clip(((S_o - lo) / (hi - lo + 1e-9) * 2).astype(np.int64), 0, 1)
+key2 = cell2[:, 0] * 4 + cell2[:, 1] * 2 + cell2[:, 2]
+orders = {"random mix": np.arange(len(S_o)), "by 2x2x2 cell (8 keys)": np.argsort(key2, kind="stable"), "by 2x2x2 cell, octant (64 keys)": np.lexsort((octant, key2)),
+          "by 4x4x4 cell (64 keys)": np.argsort(morton, kind="stable"), "by octant": np.argsort(octant, kind="stable"), "by origin triangle": np.argsort(S_t, kind="stable"),
           "by triangle, octant": np.lexsort((octant, S_t)), "by 4x4x4 cell, octant": np.lexsort((octant, morton)), "by octant, cell": np.lexsort((morton, octant)),
           "by 16^3 morton cell, octant": np.lexsort((octant, morton16)), "by octant, 16^3 morton": np.lexsort((morton16, octant))}
 for name, idx in orders.items():
