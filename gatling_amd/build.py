@@ -16,7 +16,18 @@ HEADERS = ["gi_types.h", "gi_kernels.h", "gi_device_math.h", "gi_queues.h", "gi_
            os.path.join("..", "..", "include", "gi_c.h"), os.path.join("..", "..", "include", "gtl", "gi", "Gi.h"),
            os.path.join("..", "..", "include", "gtl", "gb", "ParamTypes.h")]
 # -ffp-contract=off: arithmetic contract.  No fast-math: IEEE divide/sqrt are part of it.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall"]
+INCLUDE = os.path.join(_HERE, "..", "include")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-I", INCLUDE]
+
+
+def materialx_include():
+    """Directory holding <MaterialXFormat/XmlIo.h>, or None.  gtl_shim_mtlx.cpp (giCreateMaterialFromMtlxDoc) is built only when it exists:
+    $MATERIALX_ROOT/include, an OpenUSD install ($PXR_USD_LOCATION / $USD_ROOT) or the system include path."""
+    roots = [os.environ.get(k) for k in ("MATERIALX_ROOT", "PXR_USD_LOCATION", "USD_ROOT")] + ["/usr", "/usr/local", "/opt/local"]
+    for r in roots:
+        if r and os.path.exists(os.path.join(r, "include", "MaterialXFormat", "XmlIo.h")):
+            return os.path.join(r, "include")
+    return None
 
 
 def _mtime(path: str) -> float:
@@ -46,15 +57,19 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
 
     def compile_one(src: str) -> None:
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", _obj(src)]
+        cmd = [hipcc] + FLAGS + (["-I", mtlx] if mtlx and src == "gtl_shim_mtlx.cpp" else []) + ["-c", src, "-o", _obj(src)]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=CSRC)
 
-    todo = [s for s in SOURCES if _stale(s, force)]
+    sources = list(SOURCES)
+    mtlx = materialx_include()
+    if mtlx:
+        sources.append("gtl_shim_mtlx.cpp")
+    todo = [s for s in sources if _stale(s, force)]
     with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 2) or 1) as pool:
         list(pool.map(compile_one, todo))
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [_obj(s) for s in SOURCES] + ["-lz"]  # zlib: PNG inflate (gi_image.cpp)
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + [_obj(s) for s in sources] + ["-lz"]  # zlib: PNG inflate (gi_image.cpp)
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link, cwd=CSRC)

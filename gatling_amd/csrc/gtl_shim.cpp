@@ -179,6 +179,12 @@ namespace gtl
       MtlxNode n;
       if (!src || !findSurfaceNode(src, n)) return false;
       const std::string doc = src;
+      // an input fed by a <constant> node (hdGatling's network patchers emit those for colour / float mismatches) is a constant
+      for (auto it = n.connections.begin(); it != n.connections.end();) {
+        MtlxNode up;
+        if (readNode(doc, it->second, up) && up.category == "constant" && up.inputs.count("value")) { n.inputs[it->first] = up.inputs["value"]; it = n.connections.erase(it); }
+        else ++it;
+      }
       auto bind = [&](const char* input, int slot) {
         auto it = n.connections.find(input);
         if (it == n.connections.end()) return;
