@@ -75,8 +75,10 @@ def cpu_baseline(desc, rs, w, h, budget_s=7.0):
                       f"{cnt['segments'] / cnt['samples']:.3f} segments/sample"}
 
 
-VALU_CYCLES_PER_INST = 2  # a wave64 VALU instruction issues over 2 cycles, 32 lanes/cycle (MI355X_MICROARCH.md "Wave scheduling"; consistent with k_path issuing
-                          # 4.86e10 VALU instructions in a 74 ms launch = 3.7 cycles per instruction and SIMD while its waves wait 63 % of their cycles)
+VALU_CYCLES_PER_INST = 4  # a wave64 VALU instruction occupies a SIMD's 16 fp32 lanes for 4 cycles (157.3 TFLOP/s = 1024 SIMDs x 16 lanes x 2 (fma) x 2 (packed) x
+                          # 2.4 GHz).  Checked on k_path (r02b): resident waves per SIMD 3 -> 7 changes nothing (305.4 .. 306.1 ms) while the kernel issues
+                          # 4.86e10 VALU instructions per 74.2 ms launch = one per 3.76 cycles and SIMD: the pipe is saturated (passes whose 16 lanes
+                          # are all masked off are skipped, which is how the ratio can exceed 1)
 SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, max clock (MI355X_MICROARCH.md)
 PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"),
               ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_INSTS_LDS", "SQ_WAVES"))
@@ -312,7 +314,7 @@ def main():
                     main_k = [v for k, v in pmc.items() if k.startswith(prefixes[0])]
                     valu = sum(v.get("SQ_INSTS_VALU", 0.0) for v in main_k) / n
                     if valu:
-                        # VALU issue cycles used / available: instructions x 2 cycles / (1024 SIMDs x launch cycles at the 2.4 GHz max clock)
+                        # VALU issue cycles used / available: instructions x 4 cycles / (1024 SIMDs x launch cycles at the 2.4 GHz max clock)
                         roofline["valu_frac"] = round(valu * VALU_CYCLES_PER_INST / (SIMDS * avg_launch_s * CLOCK_HZ), 5)
                         wc = sum(v.get("SQ_WAVE_CYCLES", 0.0) for v in main_k)
                         if wc:

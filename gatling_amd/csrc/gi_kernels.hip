@@ -395,6 +395,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(GI_
 {
   trace_dyn_body<ANYHIT, COUNT, STACK, OVERFLOW, CUTOUT>(sc, st, qs, cnt, qIn, refill, ldsNodes, flags);
 }
+// the same body compiled for 6 waves/SIMD (80 VGPRs: the closest-hit variant spills 17 dwords to scratch); experiment, GATLING_DYN_WAVES=6
+template <bool ANYHIT, bool CUTOUT>
+__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_trace_dyn6(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t refill, uint32_t ldsNodes, uint32_t flags)
+{
+  trace_dyn_body<ANYHIT, false, 8, false, CUTOUT>(sc, st, qs, cnt, qIn, refill, ldsNodes, flags);
+}
 // the two-level layout (wave_step2): 16 LDS stack entries, world + object-space ray in registers
 template <bool ANYHIT, bool COUNT, bool CUTOUT>
 __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_trace_dyn2(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t refill)
@@ -675,6 +681,12 @@ static void launchTraceVariant(hipStream_t s, uint32_t blocks, const SceneView& 
     if (dynLdsNodes > 1024u) dynLdsNodes = 1024u;
     const uint32_t dynFlags = (envXcd >= 0 ? envXcd != 0 : DYN_XCD_RANGES_DEFAULT) ? DYN_FLAG_XCD_RANGES : 0u;
     const uint32_t stackBytes = entries * TRACE_BLOCK * (uint32_t)sizeof(uint2) + dynLdsNodes * 80u;
+    static const int envWaves = getenv("GATLING_DYN_WAVES") ? atoi(getenv("GATLING_DYN_WAVES")) : 5;
+    if (envWaves == 6 && !COUNT && sc.bvhDepth <= 8u) {
+      hipLaunchKernelGGL((k_trace_dyn6<ANYHIT, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill, dynLdsNodes, dynFlags);
+      if (!ANYHIT) hipLaunchKernelGGL(k_route, dim3(routeBlocks), dim3(BLOCK), 0, s, sc, st, qs, cnt, qIn, qMiss);
+      return;
+    }
 #define GI_LAUNCH_DYN(K) do { \
     if (sc.bvhDepth <= 8u) hipLaunchKernelGGL((K<ANYHIT, COUNT, 8, false, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill, dynLdsNodes, dynFlags); \
     else if (spill8) hipLaunchKernelGGL((K<ANYHIT, COUNT, 8, true, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill, dynLdsNodes, dynFlags); \

@@ -30,9 +30,9 @@
 
 namespace gi {
 
-constexpr uint32_t PATH_STACK = 8; // LDS traversal-stack entries per lane (the host checks bvhDepth <= 8)
+constexpr uint32_t PATH_STACK_MAX = 8; // LDS traversal-stack entries per lane: 4 for trees of depth <= 4 (cornell), else 8 (the host checks bvhDepth <= 8)
 
-template <uint32_t KLASS, bool TEXTURED, bool NEE, bool CUTOUT, bool COUNT>
+template <uint32_t KLASS, bool TEXTURED, bool NEE, bool CUTOUT, bool COUNT, uint32_t PATH_STACK>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_path(FrameUniforms U, SceneView sc, PathState st, Counters* cnt, F4* __restrict__ sampleBuf,
                                                       uint32_t ldsNodes, uint32_t ldsTris, uint32_t chunk)
 {
@@ -168,32 +168,44 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_path(FrameUniforms U, SceneView
 // ------------------------------------------------------------------------------------------------
 bool pathKernelSupports(const SceneView& sc)
 {
-  return sc.triCount > 0u && sc.nodeCount <= LDS_NODES && sc.triCount <= LDS_TRIS && sc.bvhDepth <= PATH_STACK && sc.mediumStackSize == 0u && sc.domeTexture == 0u && !sc.twoLevel;
+  return sc.triCount > 0u && sc.nodeCount <= LDS_NODES && sc.triCount <= LDS_TRIS && sc.bvhDepth <= PATH_STACK_MAX && sc.mediumStackSize == 0u && sc.domeTexture == 0u && !sc.twoLevel;
 }
 
 using PathKernel = void (*)(FrameUniforms, SceneView, PathState, Counters*, F4*, uint32_t, uint32_t, uint32_t);
 // Hot variants: one material class, no textures, no cutouts, no counters (the C1 / C2 paths).  Everything else runs the general
 // variant (class read from the material record, textures and cutouts compiled in).
+template <uint32_t STACK>
 static PathKernel pickPathKernel(uint32_t classMask, bool textured, bool nee, bool cutout, bool count)
 {
   const bool single = classMask == 1u || classMask == 2u || classMask == 4u;
   if (single && !textured && !cutout && !count) {
-    if (classMask == 1u) return nee ? k_path<0u, false, true, false, false> : k_path<0u, false, false, false, false>;
-    if (classMask == 2u) return nee ? k_path<1u, false, true, false, false> : k_path<1u, false, false, false, false>;
-    return nee ? k_path<2u, false, true, false, false> : k_path<2u, false, false, false, false>;
+    if (classMask == 1u) return nee ? k_path<0u, false, true, false, false, STACK> : k_path<0u, false, false, false, false, STACK>;
+    if (classMask == 2u) return nee ? k_path<1u, false, true, false, false, STACK> : k_path<1u, false, false, false, false, STACK>;
+    return nee ? k_path<2u, false, true, false, false, STACK> : k_path<2u, false, false, false, false, STACK>;
   }
-  if (count) return nee ? k_path<KLASS_DYNAMIC, true, true, true, true> : k_path<KLASS_DYNAMIC, true, false, true, true>;
-  return nee ? k_path<KLASS_DYNAMIC, true, true, true, false> : k_path<KLASS_DYNAMIC, true, false, true, false>;
+  if (count) return nee ? k_path<KLASS_DYNAMIC, true, true, true, true, STACK> : k_path<KLASS_DYNAMIC, true, false, true, true, STACK>;
+  return nee ? k_path<KLASS_DYNAMIC, true, true, true, false, STACK> : k_path<KLASS_DYNAMIC, true, false, true, false, STACK>;
 }
 
 int launchPath(hipStream_t s, uint32_t cuCount, uint32_t classMask, bool textured, bool count, uint32_t chunk, const FrameUniforms& U, const SceneView& sc,
                const PathState& st, Counters* cnt, F4* sampleBuf)
 {
   const uint32_t ldsNodes = sc.nodeCount, ldsTris = sc.triCount;
-  const uint32_t bytes = PATH_STACK * TRACE_BLOCK * (uint32_t)sizeof(uint2) + ldsNodes * 80u + ldsTris * 48u;
-  PathKernel k = pickPathKernel(classMask, textured, (U.flags & FLAG_NEE) != 0u, sc.hasCutouts != 0u, count);
-  int perCu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, reinterpret_cast<const void*>(k), (int)TRACE_BLOCK, bytes) != hipSuccess || perCu < 1) perCu = 2;
+  const uint32_t stack = sc.bvhDepth <= 4u ? 4u : 8u;
+  const uint32_t bytes = stack * TRACE_BLOCK * (uint32_t)sizeof(uint2) + ldsNodes * 80u + ldsTris * 48u;
+  const bool neeOn = (U.flags & FLAG_NEE) != 0u;
+  PathKernel k = stack == 4u ? pickPathKernel<4u>(classMask, textured, neeOn, sc.hasCutouts != 0u, count) : pickPathKernel<8u>(classMask, textured, neeOn, sc.hasCutouts != 0u, count);
+  // Resident blocks per CU (4 waves per block = 1 wave per SIMD and block): the smaller of what the 160 KiB of LDS and the 512-entry
+  // register file of a SIMD hold.  (hipOccupancyMaxActiveBlocksPerMultiprocessor answered 3 for a 35 KiB block: it does not know gfx950's LDS size.)
+  int perCu = 2;
+  hipFuncAttributes fa{};
+  if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k)) == hipSuccess && fa.numRegs > 0) {
+    const uint32_t regs = ((uint32_t)fa.numRegs + 7u) & ~7u, byRegs = 512u / regs;
+    const uint32_t byLds = (160u * 1024u) / (bytes + (uint32_t)fa.sharedSizeBytes + 256u);
+    perCu = (int)(byRegs < byLds ? byRegs : byLds);
+    if (perCu > 8) perCu = 8;
+    if (perCu < 1) perCu = 1;
+  }
   if (const char* e = getenv("GATLING_PATH_BLOCKS_PER_CU")) { const int v = atoi(e); if (v > 0) perCu = v; }
   // persistent grid: what is resident, but never more waves than chunks of work
   const uint64_t chunks = ((uint64_t)U.workTotal + chunk - 1u) / chunk;
