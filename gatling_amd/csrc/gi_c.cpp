@@ -188,6 +188,12 @@ void deriveMaterialConstants(MaterialRec& m)
       float mn = ab[0] < ab[1] ? ab[0] : ab[1]; mn = mn < ab[2] ? mn : ab[2];
       for (int i = 0; i < 3; i++) out[MP_SIGMA_A + i] = (depth > 0.0f) ? ((0.0f > mn) ? ab[i] - mn : ab[i]) : 0.0f;
     }
+    { // coat roughening (open_pbr_surface.mtlx:101-131), same fp32 operations as opbr_effective_roughness
+      const float c4 = (cr * cr) * (cr * cr), r4 = (r * r) * (r * r);
+      float t = 2.0f * c4 + r4; t = t < 1.0f ? t : 1.0f;
+      const float ra = sqrtf(sqrtf(t));
+      r = ra * coat + r * (1.0f - coat);
+    }
     out[MP_ALPHA] = (r * r > 0.001f) ? r * r : 0.001f; out[MP_COAT] = coat; out[MP_COAT_ALPHA] = (cr * cr > 0.001f) ? cr * cr : 0.001f;
     out[MP_COAT_F0] = qc * qc; out[MP_ETA] = (1.0f + eps) / (1.0f - eps);
     memcpy(m.p, out, sizeof(out));

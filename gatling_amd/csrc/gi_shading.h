@@ -45,6 +45,7 @@ struct ShState {
   float u, v;                    // texture coordinate 0 (mdl_shading_state.glsl:62-65)
   uint32_t mesh, prim, vi[3]; int32_t instanceId; float hu, hv; // renderer state for scene-data lookups (mdl_interface.glsl:281-301)
   float ior1, ior2;              // Bsdf_sample_data.ior1/ior2 (rp_main.chit:188-189): < 0 = the material's own; 0 = empty-stack default
+  bool thinWalled;               // mdl_thin_walled (rp_main.chit:155-157), set by shade_segment
   uint32_t texMask;              // bit per TEX_* slot whose value below replaces the material constant at this hit
   V3 texBaseColor, texEmission; float texRoughness, texMetallic;
 };
@@ -97,7 +98,7 @@ __device__ __forceinline__ void setup_shading_state(const SceneView& sc, uint32_
   s.normal = nrm; s.geomNormal = gn;
   s.mesh = f2u(r5.y); s.instanceId = (int32_t)f2u(r5.z); s.prim = td.w; s.vi[0] = td.x; s.vi[1] = td.y; s.vi[2] = td.z; s.hu = hu; s.hv = hv;
   s.ior1 = 0.0f; s.ior2 = 0.0f;
-  s.texMask = 0u; s.texBaseColor = v3(0.0f, 0.0f, 0.0f); s.texEmission = s.texBaseColor; s.texRoughness = 0.0f; s.texMetallic = 0.0f;
+  s.thinWalled = false; s.texMask = 0u; s.texBaseColor = v3(0.0f, 0.0f, 0.0f); s.texEmission = s.texBaseColor; s.texRoughness = 0.0f; s.texMetallic = 0.0f;
 }
 
 // mdl_adapt_normal (mdl_interface.glsl:238-256): Iray's shadow-terminator bend of a mapped normal
@@ -248,8 +249,9 @@ __device__ inline void ggx_eval(V3 l1, V3 l2, float alpha, float& fcos, float& p
 // ior2 / ior1 of the interface (== oracle relative_eta): eta entering, 1/eta leaving when the medium stack is empty
 __device__ __forceinline__ float relative_eta(const ShState& st, float materialEta)
 {
-  float e1 = st.ior1 == 0.0f ? (st.frontFace ? 1.0f : -1.0f) : st.ior1;
-  float e2 = st.ior2 == 0.0f ? (st.frontFace ? -1.0f : 1.0f) : st.ior2;
+  const bool outside = st.frontFace || st.thinWalled; // rp_main.chit:188-189
+  float e1 = st.ior1 == 0.0f ? (outside ? 1.0f : -1.0f) : st.ior1;
+  float e2 = st.ior2 == 0.0f ? (outside ? -1.0f : 1.0f) : st.ior2;
   if (e1 < 0.0f) e1 = materialEta;
   if (e2 < 0.0f) e2 = materialEta;
   return e2 / e1;
@@ -302,11 +304,57 @@ __device__ __forceinline__ V3 schlick_f82(V3 F0, V3 tint, float c)
   V3 f = (F0 + (one - F0) * m5) - a * (c * m6);
   return v3(fmin2(fmax2(f.x, 0.0f), 1.0f), fmin2(fmax2(f.y, 0.0f), 1.0f), fmin2(fmax2(f.z, 0.0f), 1.0f));
 }
-struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint; float metalness, alpha, coat, coatAlpha, coatF0, eta, tw, specWeight; };
+// The OpenPBR pieces below restate oracle/gi_oracle.cpp operation for operation (same names): coat roughening
+// (open_pbr_surface.mtlx:101-131), base darkening under the coat (:470-541), emission through the coat (:590-619), energy-preserving
+// Oren-Nayar for base_diffuse_roughness > 0 (:200-206; Portsmouth, Kutz, Hill 2024).
+__device__ __forceinline__ float opbr_effective_roughness(float r, float cr, float coat)
+{
+  float c4 = (cr * cr) * (cr * cr), r4 = (r * r) * (r * r);
+  float ra = sqrtf(sqrtf(fmin2(1.0f, 2.0f * c4 + r4)));
+  return ra * coat + r * (1.0f - coat);
+}
+__device__ __forceinline__ V3 opbr_base_darkening(V3 baseColor, float sw, float metalness, float coat, float coatF0, float cior, float coatDarkening)
+{
+  const float w = coat * coatDarkening;
+  if (w == 0.0f) return v3(1.0f, 1.0f, 1.0f);
+  const float K = 1.0f - (1.0f - coatF0) / (cior * cior);
+  const V3 Eb = (baseColor * sw) * metalness + baseColor * (1.0f - metalness);
+  const float n = 1.0f - K;
+  const V3 bd = v3(n / (1.0f - Eb.x * K), n / (1.0f - Eb.y * K), n / (1.0f - Eb.z * K));
+  return bd * w + v3(1.0f, 1.0f, 1.0f) * (1.0f - w);
+}
+__device__ __forceinline__ V3 opbr_emission_factor(float coat, V3 coatColor, float coatF0, float c)
+{
+  if (coat == 0.0f) return v3(1.0f, 1.0f, 1.0f);
+  const float f = (1.0f - coatF0) * (1.0f - schlick_w(c));
+  return (coatColor * f) * coat + v3(1.0f, 1.0f, 1.0f) * (1.0f - coat);
+}
+__device__ __forceinline__ float eon_albedo_fit(float mu, float r)
+{
+  const float mc = 1.0f - mu;
+  const float G = mc * (0.0571085289f + mc * (0.491881867f + mc * (-0.332181442f + mc * 0.0714429953f)));
+  return (1.0f + r * G) / (1.0f + 0.28779343f * r);
+}
+__device__ inline V3 eon_pi_f(V3 rho, float r, V3 l1, V3 l2)
+{
+  const float mi = l1.z, mo = l2.z;
+  const float s = l1.x * l2.x + l1.y * l2.y;
+  const float sOverT = s > 0.0f ? s / fmax2(mi, mo) : s;
+  const float AF = 1.0f / (1.0f + 0.28779343f * r);
+  const float ss = AF * (1.0f + r * sOverT);
+  const float EFo = eon_albedo_fit(mo, r), EFi = eon_albedo_fit(mi, r);
+  const float avgEF = AF * (1.0f + 0.07248828f * r);
+  const float ms = (fmax2(1e-7f, 1.0f - EFo) * fmax2(1e-7f, 1.0f - EFi)) / fmax2(1e-7f, 1.0f - avgEF);
+  const V3 rr = rho * rho;
+  const V3 rhoMs = v3((rr.x * avgEF) / (1.0f - rho.x * (1.0f - avgEF)), (rr.y * avgEF) / (1.0f - rho.y * (1.0f - avgEF)), (rr.z * avgEF) / (1.0f - rho.z * (1.0f - avgEF)));
+  return rho * ss + rhoMs * ms;
+}
+struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, baseColor; float metalness, alpha, coat, coatAlpha, coatF0, eta, tw, specWeight, baseWeight, diffRough; bool thinWalled; };
 __device__ __forceinline__ OpbrParams opbr_params(const MaterialRec* m, const ShState& st)
 {
   OpbrParams o; const float* p = m->p;
   o.albedo = v3(p[MP_ALBEDO], p[MP_ALBEDO + 1], p[MP_ALBEDO + 2]);
+  o.baseColor = v3(p[0], p[1], p[2]); o.baseWeight = p[17]; o.diffRough = p[27]; o.thinWalled = p[54] != 0.0f;
   o.metalTint = v3(p[MP_F0], p[MP_F0 + 1], p[MP_F0 + 2]);
   o.specColor = v3(p[7], p[8], p[9]);
   o.specWeight = p[18]; o.metalness = p[10];
@@ -314,9 +362,11 @@ __device__ __forceinline__ OpbrParams opbr_params(const MaterialRec* m, const Sh
   o.coatTint = v3(1.0f, 1.0f, 1.0f) * (1.0f - o.coat) + v3(p[19], p[20], p[21]) * o.coat;
   o.tw = p[23];
   o.transTint = (p[28] > 0.0f) ? v3(1.0f, 1.0f, 1.0f) : v3(p[24], p[25], p[26]);
-  if (st.texMask & (1u << TEX_BASE_COLOR)) o.albedo = st.texBaseColor * p[17];
-  if (st.texMask & (1u << TEX_ROUGHNESS)) o.alpha = fmax2(st.texRoughness * st.texRoughness, 0.001f);
+  if (st.texMask & (1u << TEX_BASE_COLOR)) { o.albedo = st.texBaseColor * p[17]; o.baseColor = st.texBaseColor; }
+  if (st.texMask & (1u << TEX_ROUGHNESS)) { const float r = opbr_effective_roughness(st.texRoughness, p[13], o.coat); o.alpha = fmax2(r * r, 0.001f); }
   if (st.texMask & (1u << TEX_METALLIC)) o.metalness = st.texMetallic;
+  // coat_substrate_attenuated = base_substrate * modulated_base_darkening * coat_attenuation (open_pbr_surface.mtlx:538-552)
+  o.coatTint = o.coatTint * opbr_base_darkening(o.baseColor, o.specWeight, o.metalness, o.coat, o.coatF0, p[22], p[48]);
   return o;
 }
 
@@ -368,6 +418,7 @@ __device__ inline void opbr_sample(const MaterialRec* m, const ShState& st, V3 k
     if (!(sin2t < 1.0f)) return;
     float ct = sqrtf(1.0f - sin2t);
     V3 lt = h * (kh / eta - ct) - l1 * (1.0f / eta);
+    if (o.thinWalled) lt = v3(g.l2.x, g.l2.y, -g.l2.z); // thin-walled: no refraction, the micro-facet reflection mirrored through the surface
     V3 k2 = to_world(st, lt);
     if (!(lt.z < 0.0f) || !(dot(k2, st.geomNormal) < 0.0f)) return;
     float a2 = o.alpha * o.alpha, nk2 = -lt.z;
@@ -382,7 +433,8 @@ __device__ inline void opbr_sample(const MaterialRec* m, const ShState& st, V3 k
   V3 k2 = to_world(st, l);
   if (!(l.z > 0.0f) || !(dot(k2, st.geomNormal) > 0.0f)) return;
   out.k2 = k2; out.pdf = (1.0f - Fc) * (1.0f - o.metalness) * (1.0f - Fd) * (1.0f - o.tw) * (l.z / GI_PI);
-  out.overPdf = o.albedo * o.coatTint; out.event = EV_DIFFUSE | EV_REFLECTION;
+  V3 rho = (o.diffRough > 0.0f) ? eon_pi_f(o.baseColor, o.diffRough, l1, l) * o.baseWeight : o.albedo;
+  out.overPdf = rho * o.coatTint; out.event = EV_DIFFUSE | EV_REFLECTION;
 }
 
 __device__ inline void opbr_evaluate(const MaterialRec* m, const ShState& st, V3 k1, V3 k2, BsdfEval& out)
@@ -404,7 +456,8 @@ __device__ inline void opbr_evaluate(const MaterialRec* m, const ShState& st, V3
   gl = gl + ((Fm * o.coatTint) * fs) * (base * o.metalness);
   gl = gl + ((o.specColor * o.coatTint) * (Fdh * fs)) * (base * diel);
   out.glossy = gl;
-  out.diffuse = (o.albedo * o.coatTint) * (cd * base * diel * (1.0f - Fd) * (1.0f - o.tw));
+  V3 rho = (o.diffRough > 0.0f && l2.z > 0.0f) ? eon_pi_f(o.baseColor, o.diffRough, l1, l2) * o.baseWeight : o.albedo;
+  out.diffuse = (rho * o.coatTint) * (cd * base * diel * (1.0f - Fd) * (1.0f - o.tw));
   out.pdf = Fc * pc + base * (o.metalness * ps + diel * (Fd * ps + (1.0f - Fd) * (1.0f - o.tw) * cd));
 }
 

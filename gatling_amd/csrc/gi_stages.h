@@ -105,13 +105,19 @@ __device__ __forceinline__ void shade_segment(const FrameUniforms& U, const Scen
       throughput = throughput * v3(gi_expf(-m[5] * distance), gi_expf(-m[6] * distance), gi_expf(-m[7] * distance));
     }
   }
-  if (VOLUME) { ss.ior1 = ss.frontFace ? prevMediumIor : -1.0f; ss.ior2 = ss.frontFace ? -1.0f : nextMediumIor; } // iorCurrent / iorOther (:188-189)
+  const bool thinWalled = ((KLASS == KLASS_DYNAMIC) ? mat->klass : KLASS) == 2u && mat->p[54] != 0.0f; // mdl_thin_walled (:155-157): OpenPBR geometry_thin_walled
+  ss.thinWalled = thinWalled;
+  if (VOLUME) { ss.ior1 = (ss.frontFace || thinWalled) ? prevMediumIor : -1.0f; ss.ior2 = (ss.frontFace || thinWalled) ? -1.0f : nextMediumIor; } // iorCurrent / iorOther (:188-189)
   // emission (rp_main.chit:293-343): uniform EDF, radiance == emission colour where cos > 0
-  const V3 em = (ss.texMask & (1u << TEX_EMISSION)) ? ss.texEmission : v3(mat->p[3], mat->p[4], mat->p[5]);
+  V3 em = (ss.texMask & (1u << TEX_EMISSION)) ? ss.texEmission : v3(mat->p[3], mat->p[4], mat->p[5]);
   if (em.x != 0.0f || em.y != 0.0f || em.z != 0.0f) {
     if (ss.frontFace || !isDoubleSided) {
       const float c = dot(-rayDir, ss.normal);
-      if (c > 0.0f) radiance = radiance + throughput * (em * U.exposureScale);
+      if (c > 0.0f) {
+        if (((KLASS == KLASS_DYNAMIC) ? mat->klass : KLASS) == 2u) // emission_edf (open_pbr_surface.mtlx:590-619): seen through the coat
+          em = em * opbr_emission_factor(mat->p[12], v3(mat->p[19], mat->p[20], mat->p[21]), mat->p[MP_COAT_F0], c);
+        radiance = radiance + throughput * (em * U.exposureScale);
+      }
     }
   }
   // BSDF importance sampling (:361-389); xi = next4f, .w is drawn but unused by the closed forms
@@ -143,7 +149,7 @@ __device__ __forceinline__ void shade_segment(const FrameUniforms& U, const Scen
   }
   // NEE AOV (rp_main.rgen:431-435): bounce 0 only; a shadow ray that is not traced counts as "not shadowed"
   shadowFirst = bounce == 0u; // the caller records "not shadowed" for the NEE AOV when shadowFirst && !shadow
-  if (isTransmission) { // medium stack (:447-480)
+  if (!thinWalled && isTransmission) { // medium stack (:447-480); a thin-walled surface has the same medium on both sides
     uint32_t newIdx = mediumIdx;
     if (VOLUME) {
       if (ss.frontFace) { // push the material's medium: mdl_ior, mdl_volume_{scattering,absorption}_coefficient, MEDIUM_DIRECTIONAL_BIAS

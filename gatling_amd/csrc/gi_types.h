@@ -59,7 +59,7 @@ struct InstanceRec {
 };
 static_assert(sizeof(InstanceRec) == 96, "InstanceRec must be 96 bytes");
 
-constexpr uint32_t MAT_PARAM_COUNT = 48;
+constexpr uint32_t MAT_PARAM_COUNT = 64;
 // derived per-material constants, filled by the host into the spare tail of MaterialRec::p (same fp32 formulas the
 // oracle evaluates per hit)
 // class 1 (UsdPreviewSurface): albedo, F0, alpha, coat, coatAlpha.  class 2 (OpenPBR): albedo = base_color*base_weight,
@@ -87,7 +87,7 @@ struct MaterialRec {
   float p[MAT_PARAM_COUNT];
   TexBindingRec tex[TEX_SLOT_COUNT];
 };
-static_assert(sizeof(MaterialRec) == 440, "MaterialRec must be 440 bytes");
+static_assert(sizeof(MaterialRec) == 504, "MaterialRec must be 504 bytes");
 // A texture: linear float RGBA texels, row 0 first.  (8-bit sources are decoded to linear float by the caller; a
 // compressed unorm8/half store is a later memory optimisation, the lookup arithmetic would not change.)
 struct TextureRec { const float* texels; uint32_t width, height; };

@@ -228,7 +228,8 @@ namespace gtl
       p[GI_C_P_SPECULAR_WEIGHT] = 1.0f; p[GI_C_P_SPECULAR_COLOR] = p[GI_C_P_SPECULAR_COLOR + 1] = p[GI_C_P_SPECULAR_COLOR + 2] = 1.0f;
       p[GI_C_P_ROUGHNESS] = 0.3f; p[GI_C_P_IOR] = 1.5f; p[GI_C_P_OPACITY] = 1.0f;
       p[GI_C_P_TRANSMISSION_COLOR] = p[GI_C_P_TRANSMISSION_COLOR + 1] = p[GI_C_P_TRANSMISSION_COLOR + 2] = 1.0f;
-      p[GI_C_P_COAT_COLOR] = p[GI_C_P_COAT_COLOR + 1] = p[GI_C_P_COAT_COLOR + 2] = 1.0f; p[GI_C_P_COAT_IOR] = 1.6f;
+      p[GI_C_P_COAT_COLOR] = p[GI_C_P_COAT_COLOR + 1] = p[GI_C_P_COAT_COLOR + 2] = 1.0f; p[GI_C_P_COAT_IOR] = 1.6f; p[GI_C_P_COAT_DARKENING] = 1.0f;
+      p[GI_C_P_FUZZ_COLOR] = p[GI_C_P_FUZZ_COLOR + 1] = p[GI_C_P_FUZZ_COLOR + 2] = 1.0f; p[GI_C_P_FUZZ_ROUGHNESS] = 0.5f;
       float lum = 0.0f, ecol[3] = {1.0f, 1.0f, 1.0f};
       setN(n, "base_weight", p + GI_C_P_BASE_WEIGHT, 1); setN(n, "base_color", p + GI_C_P_BASE_COLOR, 3);
       setN(n, "base_diffuse_roughness", p + GI_C_P_DIFFUSE_ROUGHNESS, 1); setN(n, "base_metalness", p + GI_C_P_METALLIC, 1);
@@ -238,7 +239,9 @@ namespace gtl
       setN(n, "transmission_depth", p + GI_C_P_TRANSMISSION_DEPTH, 1); setN(n, "transmission_scatter", p + GI_C_P_TRANSMISSION_SCATTER, 3);
       setN(n, "transmission_scatter_anisotropy", p + GI_C_P_TRANSMISSION_SCATTER_ANISOTROPY, 1);
       setN(n, "coat_weight", p + GI_C_P_CLEARCOAT, 1); setN(n, "coat_color", p + GI_C_P_COAT_COLOR, 3);
-      setN(n, "coat_roughness", p + GI_C_P_CLEARCOAT_ROUGHNESS, 1); setN(n, "coat_ior", p + GI_C_P_COAT_IOR, 1);
+      setN(n, "coat_roughness", p + GI_C_P_CLEARCOAT_ROUGHNESS, 1); setN(n, "coat_ior", p + GI_C_P_COAT_IOR, 1); setN(n, "coat_darkening", p + GI_C_P_COAT_DARKENING, 1);
+      setN(n, "fuzz_weight", p + GI_C_P_FUZZ_WEIGHT, 1); setN(n, "fuzz_color", p + GI_C_P_FUZZ_COLOR, 3); setN(n, "fuzz_roughness", p + GI_C_P_FUZZ_ROUGHNESS, 1); // carried, not modelled
+      setN(n, "geometry_thin_walled", p + GI_C_P_THIN_WALLED, 1);
       setN(n, "emission_luminance", &lum, 1); setN(n, "emission_color", ecol, 3); setN(n, "geometry_opacity", p + GI_C_P_OPACITY, 1);
       for (int i = 0; i < 3; i++) p[GI_C_P_EMISSION + i] = lum * ecol[i];
       bind("base_color", GI_C_TEX_BASE_COLOR); bind("specular_roughness", GI_C_TEX_ROUGHNESS); bind("base_metalness", GI_C_TEX_METALLIC);

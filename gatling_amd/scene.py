@@ -25,7 +25,7 @@ MAT_DIFFUSE = 0
 MAT_USD_PREVIEW_SURFACE = 1
 MAT_OPEN_PBR = 2
 
-# parameter block indices (float p[48]); must match include/gi_c.h and oracle/gi_oracle.h
+# parameter block indices (float p[64]); must match include/gi_c.h and oracle/gi_oracle.h
 P_BASE_COLOR = 0
 P_EMISSION = 3
 P_USE_SPECULAR_WORKFLOW = 6
@@ -47,7 +47,12 @@ P_DIFFUSE_ROUGHNESS = 27
 P_TRANSMISSION_DEPTH = 28
 P_TRANSMISSION_SCATTER = 29           # 3
 P_TRANSMISSION_SCATTER_ANISOTROPY = 47  # (32..46 hold the device's derived constants)
-P_COUNT = 48
+P_COAT_DARKENING = 48
+P_FUZZ_WEIGHT = 49
+P_FUZZ_COLOR = 50                    # 3
+P_FUZZ_ROUGHNESS = 53
+P_THIN_WALLED = 54
+P_COUNT = 64
 
 
 @dataclass
@@ -98,7 +103,8 @@ def _open_pbr(name="mat", base_weight=1.0, base_color=(0.8, 0.8, 0.8), base_meta
               specular_color=(1, 1, 1), specular_roughness=0.3, specular_ior=1.5, transmission_weight=0.0,
               transmission_color=(1, 1, 1), transmission_depth=0.0, coat_weight=0.0, coat_color=(1, 1, 1), coat_roughness=0.0,
               coat_ior=1.6, emission_luminance=0.0, emission_color=(1, 1, 1), base_diffuse_roughness=0.0,
-              transmission_scatter=(0, 0, 0), transmission_scatter_anisotropy=0.0) -> MaterialDesc:
+              transmission_scatter=(0, 0, 0), transmission_scatter_anisotropy=0.0, coat_darkening=1.0, fuzz_weight=0.0,
+              fuzz_color=(1, 1, 1), fuzz_roughness=0.5, geometry_thin_walled=False) -> MaterialDesc:
     """open_pbr_surface inputs with the defaults of src/gi/mtlx/open_pbr_surface.mtlx:11-92 (the lobes this core implements)."""
     p = np.zeros(P_COUNT, np.float32)
     p[P_BASE_COLOR:P_BASE_COLOR + 3] = base_color
@@ -120,6 +126,11 @@ def _open_pbr(name="mat", base_weight=1.0, base_color=(0.8, 0.8, 0.8), base_meta
     p[P_TRANSMISSION_DEPTH] = transmission_depth
     p[P_TRANSMISSION_SCATTER:P_TRANSMISSION_SCATTER + 3] = transmission_scatter
     p[P_TRANSMISSION_SCATTER_ANISOTROPY] = transmission_scatter_anisotropy
+    p[P_COAT_DARKENING] = coat_darkening
+    p[P_FUZZ_WEIGHT] = fuzz_weight                     # carried; the sheen lobe is not modelled
+    p[P_FUZZ_COLOR:P_FUZZ_COLOR + 3] = fuzz_color
+    p[P_FUZZ_ROUGHNESS] = fuzz_roughness
+    p[P_THIN_WALLED] = 1.0 if geometry_thin_walled else 0.0
     return MaterialDesc(name=name, klass=MAT_OPEN_PBR, params=p)
 
 

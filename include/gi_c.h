@@ -155,7 +155,7 @@ typedef struct GiCRenderParams {
 #define GI_C_MAT_DIFFUSE 0u             /* config C1 "diffuse only" model */
 #define GI_C_MAT_USD_PREVIEW_SURFACE 1u /* diffuse + GGX specular + clearcoat */
 #define GI_C_MAT_OPEN_PBR 2u             /* coat + metal (F82-tint) + dielectric reflection + rough refraction + diffuse */
-#define GI_C_MAT_PARAM_COUNT 48u
+#define GI_C_MAT_PARAM_COUNT 64u
 /* indices into GiCMaterialDesc.p */
 #define GI_C_P_BASE_COLOR 0
 #define GI_C_P_EMISSION 3
@@ -178,6 +178,12 @@ typedef struct GiCRenderParams {
 #define GI_C_P_TRANSMISSION_DEPTH 28
 #define GI_C_P_TRANSMISSION_SCATTER 29 /* 3: OpenPBR transmission_scatter (open_pbr_surface.mtlx:35) */
 #define GI_C_P_TRANSMISSION_SCATTER_ANISOTROPY 47 /* transmission_scatter_anisotropy (:37); slots 32..46 are reserved */
+#define GI_C_P_COAT_DARKENING 48   /* OpenPBR coat_darkening (open_pbr_surface.mtlx:64; default 1): strength of the base darkening under the coat (:470-541) */
+#define GI_C_P_FUZZ_WEIGHT 49      /* OpenPBR fuzz_weight / fuzz_color (3) / fuzz_roughness (:57-59): accepted and carried, the sheen lobe is not modelled */
+#define GI_C_P_FUZZ_COLOR 50
+#define GI_C_P_FUZZ_ROUGHNESS 53
+#define GI_C_P_THIN_WALLED 54      /* OpenPBR geometry_thin_walled (:88) != 0: MDL thin_walled semantics (rp_main.chit:153-157, 188-189, 447) */
+                                   /* slots 55..63: reserved, must be 0 */
 
 /* Note: p[GI_C_P_OPACITY] is the cutout opacity (1 = opaque); a zero-filled block is a fully transparent material. */
 typedef struct GiCMaterialDesc {

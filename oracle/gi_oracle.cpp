@@ -586,13 +586,15 @@ struct State {
   // Bsdf_sample_data.ior1 / ior2 (rp_main.chit:188-189): ior of the medium the ray travels in / of the other side;
   // < 0 = BSDF_USE_MATERIAL_IOR.  Defaults = empty medium stack (vacuum outside).
   float ior1 = 0.0f, ior2 = 0.0f;
+  bool thinWalled = false; // mdl_thin_walled (rp_main.chit:155-157): both sides of the surface see the medium the ray travels in
   // renderer state of the hit for scene-data lookups (mdl_interface.glsl:281-301)
   const MeshData* mesh = nullptr; uint32_t prim = 0, hitIndices[3] = {0, 0, 0}; int32_t instanceId = 0; float bu = 0.0f, bv = 0.0f;
 };
 inline float relative_eta(const State& st, float materialEta)
 {
-  float e1 = st.ior1 == 0.0f ? (st.frontFace ? 1.0f : -1.0f) : st.ior1;
-  float e2 = st.ior2 == 0.0f ? (st.frontFace ? -1.0f : 1.0f) : st.ior2;
+  const bool outside = st.frontFace || st.thinWalled; // rp_main.chit:188-189
+  float e1 = st.ior1 == 0.0f ? (outside ? 1.0f : -1.0f) : st.ior1;
+  float e2 = st.ior2 == 0.0f ? (outside ? -1.0f : 1.0f) : st.ior2;
   if (e1 < 0.0f) e1 = materialEta;
   if (e2 < 0.0f) e2 = materialEta;
   return e2 / e1;
@@ -871,21 +873,75 @@ inline V3 schlick_f82(V3 F0, V3 tint, float c)
   (void)cb;
   return v3(fmin2(fmax2(f.x, 0.0f), 1.0f), fmin2(fmax2(f.y, 0.0f), 1.0f), fmin2(fmax2(f.z, 0.0f), 1.0f));
 }
-struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, sigmaA, sigmaS; float metalness, alpha, coat, coatAlpha, coatF0, eta, tw, specWeight, anisotropy; };
+// Roughening of the base specular lobe under the coat (open_pbr_surface.mtlx:101-131):
+// effective_specular_roughness = mix(specular_roughness, min(1, 2 coat_roughness^4 + specular_roughness^4)^(1/4), coat_weight)
+inline float opbr_effective_roughness(float r, float cr, float coat)
+{
+  float c4 = (cr * cr) * (cr * cr), r4 = (r * r) * (r * r);
+  float ra = sqrtf(sqrtf(fmin2(1.0f, 2.0f * c4 + r4)));
+  return ra * coat + r * (1.0f - coat);
+}
+// Darkening of the base under the coat by internal reflections (:470-541): (1 - Kcoat) / (1 - Ebase Kcoat) blended in by coat_weight *
+// coat_darkening, with Kcoat = 1 - (1 - coat_F0) / coat_ior^2 and Ebase = mix(base_color, base_color * specular_weight, base_metalness)
+inline V3 opbr_base_darkening(V3 baseColor, float sw, float metalness, float coat, float coatF0, float cior, float coatDarkening)
+{
+  const float w = coat * coatDarkening;
+  if (w == 0.0f) return v3(1, 1, 1);
+  const float K = 1.0f - (1.0f - coatF0) / (cior * cior);
+  const V3 Eb = (baseColor * sw) * metalness + baseColor * (1.0f - metalness);
+  const float n = 1.0f - K;
+  const V3 bd = v3(n / (1.0f - Eb.x * K), n / (1.0f - Eb.y * K), n / (1.0f - Eb.z * K));
+  return bd * w + v3(1, 1, 1) * (1.0f - w);
+}
+// Emission seen through the coat (:590-619): mix(uncoated, coat_color * generalized_schlick_edf(color0 = 1 - coat_F0, color90 = 0,
+// exponent 5), coat_weight); c = cos between the shading normal and the direction the light leaves in
+inline V3 opbr_emission_factor(float coat, V3 coatColor, float coatF0, float c)
+{
+  if (coat == 0.0f) return v3(1, 1, 1);
+  const float f = (1.0f - coatF0) * (1.0f - schlick_w(c));
+  return (coatColor * f) * coat + v3(1, 1, 1) * (1.0f - coat);
+}
+// Energy-preserving Oren-Nayar (oren_nayar_diffuse_bsdf with energy_compensation, :200-206; Portsmouth, Kutz, Hill 2024: Fujii's
+// qualitative model plus a multiple-scattering lobe, directional albedo by the paper's polynomial fit).  Returns pi * f for albedo rho.
+inline float eon_albedo_fit(float mu, float r)
+{
+  const float mc = 1.0f - mu;
+  const float G = mc * (0.0571085289f + mc * (0.491881867f + mc * (-0.332181442f + mc * 0.0714429953f)));
+  return (1.0f + r * G) / (1.0f + 0.28779343f * r); // 0.5 - 2 / (3 pi)
+}
+inline V3 eon_pi_f(V3 rho, float r, V3 l1, V3 l2)
+{
+  const float mi = l1.z, mo = l2.z;
+  const float s = l1.x * l2.x + l1.y * l2.y; // dot(wi, wo) - mu_i mu_o
+  const float sOverT = s > 0.0f ? s / fmax2(mi, mo) : s;
+  const float AF = 1.0f / (1.0f + 0.28779343f * r);
+  const float ss = AF * (1.0f + r * sOverT);
+  const float EFo = eon_albedo_fit(mo, r), EFi = eon_albedo_fit(mi, r);
+  const float avgEF = AF * (1.0f + 0.07248828f * r); // 2/3 - 28 / (15 pi)
+  const float ms = (fmax2(1e-7f, 1.0f - EFo) * fmax2(1e-7f, 1.0f - EFi)) / fmax2(1e-7f, 1.0f - avgEF);
+  const V3 rr = rho * rho;
+  const V3 rhoMs = v3((rr.x * avgEF) / (1.0f - rho.x * (1.0f - avgEF)), (rr.y * avgEF) / (1.0f - rho.y * (1.0f - avgEF)), (rr.z * avgEF) / (1.0f - rho.z * (1.0f - avgEF)));
+  return rho * ss + rhoMs * ms;
+}
+struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, sigmaA, sigmaS, baseColor, coatColor; float metalness, alpha, coat, coatAlpha, coatF0, eta, tw, specWeight, anisotropy, baseWeight, diffRough; bool thinWalled; };
 inline OpbrParams opbr_params(const OrcMaterial& m)
 {
   OpbrParams o; const float* p = m.p;
   float bw = p[ORC_P_BASE_WEIGHT], sw = p[ORC_P_SPECULAR_WEIGHT];
+  o.baseColor = v3(p + ORC_P_BASE_COLOR); o.baseWeight = bw; o.diffRough = p[ORC_P_DIFFUSE_ROUGHNESS]; o.thinWalled = p[ORC_P_THIN_WALLED] != 0.0f;
   o.albedo = v3(p + ORC_P_BASE_COLOR) * bw;
   o.specColor = v3(p + ORC_P_SPECULAR_COLOR);
   o.metalTint = o.specColor * sw;
   o.specWeight = sw;
   o.metalness = p[ORC_P_METALLIC];
   float r = p[ORC_P_ROUGHNESS], cr = p[ORC_P_CLEARCOAT_ROUGHNESS];
-  o.alpha = fmax2(r * r, 0.001f); o.coatAlpha = fmax2(cr * cr, 0.001f);
   o.coat = p[ORC_P_CLEARCOAT];
+  r = opbr_effective_roughness(r, cr, o.coat);
+  o.alpha = fmax2(r * r, 0.001f); o.coatAlpha = fmax2(cr * cr, 0.001f);
   float cior = p[ORC_P_COAT_IOR]; float qc = (cior - 1.0f) / (cior + 1.0f); o.coatF0 = qc * qc;
-  V3 cc = v3(p + ORC_P_COAT_COLOR); o.coatTint = v3(1, 1, 1) * (1.0f - o.coat) + cc * o.coat;
+  V3 cc = v3(p + ORC_P_COAT_COLOR); o.coatColor = cc; o.coatTint = v3(1, 1, 1) * (1.0f - o.coat) + cc * o.coat;
+  // coat_substrate_attenuated = base_substrate * modulated_base_darkening * coat_attenuation (:538-552)
+  o.coatTint = o.coatTint * opbr_base_darkening(o.baseColor, sw, p[ORC_P_METALLIC], o.coat, o.coatF0, cior, p[ORC_P_COAT_DARKENING]);
   // modulated_eta_s (open_pbr_surface.mtlx:306-366): specular_weight scales F0, eta follows
   float ior = p[ORC_P_IOR];
   float ratio = ior / cior, inv = cior / ior;
@@ -961,6 +1017,8 @@ void opbr_sample(const OrcMaterial& m, const State& st, V3 k1, const float xi[4]
     if (!(sin2t < 1.0f)) return; // total internal reflection at this micro-normal: absorbed
     float ct = sqrtf(1.0f - sin2t);
     V3 lt = h * (kh / eta - ct) - l1 * (1.0f / eta);
+    // thin-walled (MDL: "transmission does not refract"): the micro-facet reflection direction, mirrored through the surface
+    if (o.thinWalled) lt = v3(g.l2.x, g.l2.y, -g.l2.z);
     V3 k2 = to_world(st, lt);
     if (!(lt.z < 0.0f) || !(dot(k2, st.geomNormal) < 0.0f)) return;
     float a2 = o.alpha * o.alpha, nk2 = -lt.z;
@@ -971,11 +1029,12 @@ void opbr_sample(const OrcMaterial& m, const State& st, V3 k1, const float xi[4]
     out.overPdf = (o.transTint * o.coatTint) * w; out.event = EV_GLOSSY | EV_TRANSMISSION;
     return;
   }
-  V3 l = sample_hemisphere(xi[0], xi[1]); // opaque base: Lambert (base_diffuse_roughness ignored)
+  V3 l = sample_hemisphere(xi[0], xi[1]); // opaque base: Lambert, or energy-preserving Oren-Nayar when base_diffuse_roughness > 0
   V3 k2 = to_world(st, l);
   if (!(l.z > 0.0f) || !(dot(k2, st.geomNormal) > 0.0f)) return;
   out.k2 = k2; out.pdf = (1.0f - Fc) * (1.0f - o.metalness) * (1.0f - Fd) * (1.0f - o.tw) * (l.z / ORC_PI);
-  out.overPdf = o.albedo * o.coatTint; out.event = EV_DIFFUSE | EV_REFLECTION;
+  V3 rho = (o.diffRough > 0.0f) ? eon_pi_f(o.baseColor, o.diffRough, l1, l) * o.baseWeight : o.albedo;
+  out.overPdf = rho * o.coatTint; out.event = EV_DIFFUSE | EV_REFLECTION;
 }
 
 void opbr_evaluate(const OrcMaterial& m, const State& st, V3 k1, V3 k2, bool frontFace, BsdfEval& out)
@@ -997,7 +1056,8 @@ void opbr_evaluate(const OrcMaterial& m, const State& st, V3 k1, V3 k2, bool fro
   gl = gl + ((Fm * o.coatTint) * fs) * (base * o.metalness);
   gl = gl + ((o.specColor * o.coatTint) * (Fdh * fs)) * (base * diel);
   out.glossy = gl;
-  out.diffuse = (o.albedo * o.coatTint) * (cd * base * diel * (1.0f - Fd) * (1.0f - o.tw));
+  V3 rho = (o.diffRough > 0.0f && l2.z > 0.0f) ? eon_pi_f(o.baseColor, o.diffRough, l1, l2) * o.baseWeight : o.albedo;
+  out.diffuse = (rho * o.coatTint) * (cd * base * diel * (1.0f - Fd) * (1.0f - o.tw));
   out.pdf = Fc * pc + base * (o.metalness * ps + diel * (Fd * ps + (1.0f - Fd) * (1.0f - o.tw) * cd));
 }
 
@@ -1239,15 +1299,23 @@ void closest_hit(const Frame& F, const Hit& h, Payload& pl, float hitT)
       throughput = throughput * v3(expf_poly(-md.sigma_t.x * distance), expf_poly(-md.sigma_t.y * distance), expf_poly(-md.sigma_t.z * distance));
     }
   }
-  st.ior1 = st.frontFace ? prevMediumIor : -1.0f; // iorCurrent / iorOther (:188-189; thin-walled is not modelled)
-  st.ior2 = st.frontFace ? -1.0f : nextMediumIor;
+  const bool thinWalled = mat.klass == ORC_MAT_OPEN_PBR && mat.p[ORC_P_THIN_WALLED] != 0.0f; // mdl_thin_walled (:155-157)
+  st.thinWalled = thinWalled;
+  st.ior1 = (st.frontFace || thinWalled) ? prevMediumIor : -1.0f; // iorCurrent / iorOther (:188-189)
+  st.ior2 = (st.frontFace || thinWalled) ? -1.0f : nextMediumIor;
 
   // 5. emission (:293-343).  uniform EDF: edf*intensity == emission colour, pdf>0 iff cos>0
   V3 em = v3(mat.p + ORC_P_EMISSION);
   if (em.x != 0.0f || em.y != 0.0f || em.z != 0.0f) {
     if (st.frontFace || !isDoubleSided) {
       float c = dot(-rayDir, st.normal);
-      if (c > 0.0f) radiance = radiance + throughput * (em * F.ubo.sensorExposureScale);
+      if (c > 0.0f) {
+        if (mat.klass == ORC_MAT_OPEN_PBR) { // emission_edf (open_pbr_surface.mtlx:590-619): seen through the coat
+          float cior = mat.p[ORC_P_COAT_IOR], qc = (cior - 1.0f) / (cior + 1.0f);
+          em = em * opbr_emission_factor(mat.p[ORC_P_CLEARCOAT], v3(mat.p + ORC_P_COAT_COLOR), qc * qc, c);
+        }
+        radiance = radiance + throughput * (em * F.ubo.sensorExposureScale);
+      }
     }
   }
 
@@ -1280,8 +1348,9 @@ void closest_hit(const Frame& F, const Hit& h, Payload& pl, float hitT)
       pl.neeContrib = nee;
     }
   }
-  // medium toggle (:447-480): MEDIUM_STACK_SIZE == 0 -> inside/outside bit; the walk counter is reset
-  if (isTransmission) {
+  // medium toggle (:447-480): MEDIUM_STACK_SIZE == 0 -> inside/outside bit; the walk counter is reset.  Thin-walled surfaces have the
+  // same medium on both sides: nothing changes (:447)
+  if (!thinWalled && isTransmission) {
     if (stackSize > 0) { // :450-473
       if (st.frontFace) { // push
         mediumIdx++;
@@ -1566,7 +1635,8 @@ void render_pixel_aovs(const Frame& F, uint32_t px, uint32_t py, size_t o, OrcAo
     put3(A.bitangents, (st.tangentV + v3(1, 1, 1)) * 0.5f);                                // :209-211
     put3(A.barycentrics, v3(1.0f - h.u - h.v, h.u, h.v));                                  // :212-214
     put3(A.texcoords, v3(st.u, st.v, 0.0f));                                               // :215-217
-    put3(A.thinWalled, v3(0, 1, 0));                                                       // :218-220 (no thin-walled materials)
+    { const OrcMaterial& tm = F.P->materials[mesh->material];                              // :218-220
+      put3(A.thinWalled, (tm.klass == ORC_MAT_OPEN_PBR && tm.p[ORC_P_THIN_WALLED] != 0.0f) ? v3(1, 0, 0) : v3(0, 1, 0)); }
     if (A.objectId) A.objectId[o] = mesh->objectId;                                        // :221-224
     if (A.depth) A.depth[o] = 2.0f * logf_poly(h.t / F.clipNear) / logf_poly(F.clipFar / F.clipNear) - 1.0f; // :225-229
     if (A.faceId) {                                                                        // :230-240 (incl. the reference's mask)
@@ -1741,6 +1811,7 @@ void orc_bsdf_debug(const OrcMaterial* mat, uint32_t count, const float* in, flo
     const float* p = in + 22 * (size_t)i; float* o = out + 15 * (size_t)i;
     State st; st.normal = v3(p); st.tangentU = v3(p + 3); st.tangentV = v3(p + 6); st.geomNormal = v3(p + 9);
     st.position = v3(0, 0, 0); st.u = st.v = 0.0f; st.frontFace = (p[21] < 0.5f);
+    st.thinWalled = mat->klass == ORC_MAT_OPEN_PBR && mat->p[ORC_P_THIN_WALLED] != 0.0f;
     BsdfSample bs; bsdf_sample(*mat, st, v3(p + 12), p + 18, bs);
     BsdfEval ev; bsdf_evaluate(*mat, st, v3(p + 12), v3(p + 15), ev);
     o[0] = bs.k2.x; o[1] = bs.k2.y; o[2] = bs.k2.z; o[3] = bs.overPdf.x; o[4] = bs.overPdf.y; o[5] = bs.overPdf.z; o[6] = bs.pdf; o[7] = (float)bs.event;

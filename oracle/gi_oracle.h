@@ -48,7 +48,7 @@ enum {
   ORC_MAT_OPEN_PBR = 2
 };
 
-/* Parameter block indices (float p[48]); shared by all classes where meaningful. */
+/* Parameter block indices (float p[64]); shared by all classes where meaningful. */
 enum {
   ORC_P_BASE_COLOR = 0,        /* 3: diffuseColor / base_color                    */
   ORC_P_EMISSION = 3,          /* 3: emissiveColor / emission_color*luminance     */
@@ -71,7 +71,10 @@ enum {
   ORC_P_TRANSMISSION_DEPTH = 28,
   ORC_P_TRANSMISSION_SCATTER = 29, /* 3 */
   ORC_P_TRANSMISSION_SCATTER_ANISOTROPY = 47, /* (32..46 hold the device's derived constants) */
-  ORC_P_COUNT = 48
+  ORC_P_COAT_DARKENING = 48,   /* open_pbr_surface.mtlx:64 */
+  ORC_P_FUZZ_WEIGHT = 49, ORC_P_FUZZ_COLOR = 50, ORC_P_FUZZ_ROUGHNESS = 53, /* :57-59, carried only */
+  ORC_P_THIN_WALLED = 54,      /* geometry_thin_walled (:88) */
+  ORC_P_COUNT = 64
 };
 
 /* Texture runtime (mdl_interface.glsl:8-38, 127-145; mdl_types.glsl:117-120).  Texels are linear float RGBA, row 0 first

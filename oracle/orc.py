@@ -13,7 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libgi_oracle.so")
-P_COUNT = 48
+P_COUNT = 64
 
 
 TEX_SLOT_COUNT = 6

@@ -24,7 +24,7 @@ def test_header_symbols_are_exported_and_bound():
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(capi.GiCCameraDesc) == 64 and C.sizeof(capi.GiCMaterialDesc) == 200
+    assert C.sizeof(capi.GiCCameraDesc) == 64 and C.sizeof(capi.GiCMaterialDesc) == 264
     assert C.sizeof(capi.GiCRenderSettings) == 72 and C.sizeof(capi.GiCAovBinding) == 32
     from gatling_amd.scene import VERTEX_DTYPE
     assert VERTEX_DTYPE.itemsize == 48  # GiVertex, Gi.h:110-118

@@ -332,7 +332,7 @@ def test_parallel_scene_sync(gi, orc):
                     h = sc.meshes[(k + it) % len(sc.meshes)]
                     L.giCSetMeshTransform(h, capi._fp(np.asarray(m.transform, np.float32).reshape(-1)))
                     L.giCSetMeshVisibility(h, 1)
-                    md = capi.GiCMaterialDesc(1, 0, (C.c_float * 48)(*([0.5] * 48)))
+                    md = capi.GiCMaterialDesc(1, 0, (C.c_float * capi.P_COUNT)(*([0.5] * capi.P_COUNT)))
                     mat = L.giCCreateMaterial(sc.handle, b"tmp", C.byref(md))
                     light = L.giCCreateSphereLight(sc.handle)
                     L.giCSetSphereLightRadius(light, 0.1, 0.1, 0.1)
@@ -389,12 +389,57 @@ def test_bsdf_known_answers_on_device(gi, orc):
             MaterialDesc.open_pbr(base_color=(0.9, 0.5, 0.2), base_metalness=1.0, specular_color=(0.8, 0.9, 1.0), specular_roughness=0.25),
             MaterialDesc.open_pbr(base_color=(0.3, 0.6, 0.2), coat_weight=0.8, coat_color=(0.9, 0.7, 0.6), coat_roughness=0.2, specular_weight=0.7),
             MaterialDesc.open_pbr(transmission_weight=1.0, transmission_color=(0.6, 0.8, 0.9), transmission_depth=0.5, specular_roughness=0.1),
-            MaterialDesc.open_pbr(transmission_weight=0.6, base_metalness=0.3, coat_weight=0.4, specular_ior=1.33)]
+            MaterialDesc.open_pbr(transmission_weight=0.6, base_metalness=0.3, coat_weight=0.4, specular_ior=1.33),
+            MaterialDesc.open_pbr(base_color=(0.8, 0.4, 0.2), base_diffuse_roughness=0.7, coat_weight=1.0, coat_roughness=0.5, coat_color=(0.9, 0.8, 0.7), coat_darkening=0.6),
+            MaterialDesc.open_pbr(base_color=(0.5, 0.5, 0.9), base_diffuse_roughness=1.0, specular_weight=0.3, base_weight=0.8),
+            MaterialDesc.open_pbr(transmission_weight=1.0, specular_roughness=0.3, specular_ior=1.45, geometry_thin_walled=True)]
     items[: n // 2, 21] = 0.75  # xi.w >= 0.5: the debug hook shades these as back faces (eta inverted)
     for m in mats:
         got, ref = gi.bsdf_debug(m, items), orc.bsdf_debug(m, items)
         assert np.array_equal(got[:, 7], ref[:, 7])  # event types
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+def test_c4_parameter_sets_bsdf_properties_on_device(gi, orc):
+    """The 32 material parameter sets of config C4 (sphere_grid / _parameter_sets; OpenPBR and UsdPreviewSurface, metal / coat /
+    transmission mixes), evaluated ON THE DEVICE through the debug hook: white-furnace bound (directional albedo of the white version
+    <= 1), consistency of evaluate() with the sampling routine (hemisphere integral of evaluate == mean sampled reflection weight, pdf
+    integrates to the reflection probability), Helmholtz reciprocity of evaluate() for the opaque sets -- and bit-equality with the oracle."""
+    import copy
+    from gatling_amd.scene import P_BASE_COLOR, P_TRANSMISSION_WEIGHT, P_CLEARCOAT, P_METALLIC, P_ROUGHNESS
+    from test_oracle_render import _frames
+    mats = sphere_grid(4, 1, 32).materials
+    assert len(mats) == 32
+    rng = np.random.default_rng(77)
+    for i, m in enumerate(mats):
+        white = copy.deepcopy(m); white.params[P_BASE_COLOR:P_BASE_COLOR + 3] = 1.0
+        for c in (0.9, 0.4):
+            items = _frames(60000, rng, c)
+            out = gi.bsdf_debug(white, items)
+            assert np.isfinite(out).all()
+            albedo = out[:, 3:6].mean(axis=0)
+            assert np.all(albedo <= 1.03) and np.all(albedo >= 0.0), (i, c, albedo)
+        items = _frames(120000, rng, 0.7)
+        out = gi.bsdf_debug(m, items)
+        if i % 8 == 0:
+            assert np.array_equal(out.view(np.uint32), orc.bsdf_debug(m, items).view(np.uint32))
+        refl = (out[:, 7].astype(int) & 8) != 0  # EV_REFLECTION
+        sampled = (out[:, 3:6] * refl[:, None]).mean(axis=0)
+        integ = (out[:, 8:11] + out[:, 11:14]).mean(axis=0) * (2 * np.pi)  # uniform hemisphere pdf 1 / (2 pi); evaluate returns bsdf * cos
+        # (uniform-direction quadrature of a GGX peak needs far more samples below roughness ~0.2 or under a 0.05-rough coat: those sets get a loose bound)
+        tol = 0.015 if (m.params[P_ROUGHNESS] > 0.2 and m.params[P_CLEARCOAT] == 0.0) else 0.08
+        np.testing.assert_allclose(integ, sampled, rtol=0.08, atol=tol, err_msg=f"set {i}")
+        np.testing.assert_allclose(out[:, 14].mean() * 2 * np.pi, refl.mean(), rtol=0.08, atol=tol, err_msg=f"set {i}")
+        # reciprocity f(k1, k2) = f(k2, k1) holds for the symmetric lobes; the layered forms weight the base by the view-side Fresnel only
+        # (1 - F(n.k1)), as MDL's fresnel_layer does, which is not symmetric: check the sets without coat / dielectric layering
+        if m.params[P_CLEARCOAT] == 0.0 and m.params[P_TRANSMISSION_WEIGHT] == 0.0 and m.params[P_METALLIC] == 1.0:
+            it = _frames(4000, rng, 0.6)
+            sw = it.copy(); sw[:, 12:15], sw[:, 15:18] = it[:, 15:18], it[:, 12:15]
+            a, b = gi.bsdf_debug(m, it), gi.bsdf_debug(m, sw)
+            ok = it[:, 17] > 0.05
+            fa = (a[ok, 8:14].reshape(-1, 2, 3).sum(axis=1)) / it[ok, 17:18]
+            fb = (b[ok, 8:14].reshape(-1, 2, 3).sum(axis=1)) / sw[ok, 17:18]
+            np.testing.assert_allclose(fa, fb, rtol=2e-3, atol=1e-6, err_msg=f"set {i}")
 
 
 def _soup(n, seed=99):

@@ -130,7 +130,10 @@ def _closed_form_materials():
             M.open_pbr(base_color=(1, 1, 1)),
             M.open_pbr(base_color=(1, 1, 1), base_metalness=1.0, specular_roughness=0.4),
             M.open_pbr(base_color=(1, 1, 1), coat_weight=1.0, coat_roughness=0.1),
-            M.open_pbr(base_color=(1, 1, 1), transmission_weight=1.0, specular_roughness=0.2)]
+            M.open_pbr(base_color=(1, 1, 1), transmission_weight=1.0, specular_roughness=0.2),
+            M.open_pbr(base_color=(1, 1, 1), base_diffuse_roughness=1.0, specular_weight=0.0),      # energy-preserving Oren-Nayar alone
+            M.open_pbr(base_color=(1, 1, 1), base_diffuse_roughness=0.6, coat_weight=1.0, coat_roughness=0.4, coat_darkening=1.0),
+            M.open_pbr(base_color=(1, 1, 1), transmission_weight=1.0, specular_roughness=0.3, geometry_thin_walled=True)]
 
 
 def test_closed_form_bsdfs_conserve_energy(orc):
@@ -148,7 +151,8 @@ def test_closed_form_evaluate_matches_sampling(orc):
     """For reflection lobes: integrating evaluate() over the hemisphere (uniform directions) reproduces the mean
     sampled weight of the reflected events, and the evaluate pdf integrates to the probability of reflecting."""
     rng = np.random.default_rng(22)
-    for m in _closed_form_materials()[:7]:  # the refraction lobe has no evaluate counterpart on the reflection side
+    mats = _closed_form_materials()
+    for m in mats[:7] + mats[8:10]:  # the refraction lobes have no evaluate counterpart on the reflection side
         items = _frames(200000, rng, 0.7)
         out = orc.bsdf_debug(m, items)
         refl = (out[:, 7].astype(int) & 8) != 0
@@ -347,3 +351,100 @@ def test_nee_aov_is_the_bounce0_shadow_test(orc):
     assert np.allclose(off, clear["nee"])
     zero = orc.render_aovs(desc, RenderSettings(spp=3, max_bounces=0, next_event_estimation=True), 48, 27, ["nee"], clear_values=clear)["nee"]
     assert np.allclose(zero, clear["nee"])  # the loop body never runs
+
+
+# ---- OpenPBR graph pieces (src/gi/mtlx/open_pbr_surface.mtlx): known answers recomputed here in numpy float32 from the graph's own nodes ----
+def _f32(x):
+    return np.float32(x)
+
+
+def test_openpbr_coat_roughening_and_darkening_known_answers(orc):
+    """effective_specular_roughness (mtlx:101-131) and modulated_base_darkening (:470-541) enter the closed form exactly as the graph
+    composes them: checked through the sampled weights of a smooth-ish coated dielectric against numpy float32 restatements."""
+    r, cr, coat, cior, bc, sw, metal, cd = _f32(0.3), _f32(0.5), _f32(1.0), _f32(1.6), np.float32([0.8, 0.4, 0.2]), _f32(1.0), _f32(0.0), _f32(1.0)
+    # :101-131
+    ra = np.sqrt(np.sqrt(np.minimum(_f32(1.0), _f32(2.0) * (cr * cr) * (cr * cr) + (r * r) * (r * r))))
+    r_eff = ra * coat + r * (_f32(1.0) - coat)
+    assert r_eff == pytest.approx(0.6040, abs=2e-4)  # (2 * 0.5^4 + 0.3^4)^(1/4)
+    # :470-541
+    f0c = ((cior - 1) / (cior + 1)) ** 2
+    K = _f32(1.0) - (_f32(1.0) - f0c) / (cior * cior)
+    Eb = (bc * sw) * metal + bc * (_f32(1.0) - metal)
+    bd = (_f32(1.0) - K) / (_f32(1.0) - Eb * K)
+    mod = bd * (coat * cd) + (_f32(1.0) - coat * cd)
+    m = MaterialDesc.open_pbr(base_color=tuple(bc), specular_roughness=float(r), coat_weight=float(coat), coat_roughness=float(cr), coat_ior=float(cior))
+    m0 = MaterialDesc.open_pbr(base_color=tuple(bc), specular_roughness=float(r), coat_weight=float(coat), coat_roughness=float(cr), coat_ior=float(cior), coat_darkening=0.0)
+    rng = np.random.default_rng(5)
+    items = _frames(4000, rng, 0.8)
+    a, b = orc.bsdf_debug(m, items), orc.bsdf_debug(m0, items)
+    diffuse = (a[:, 7].astype(int) & 1) != 0  # EV_DIFFUSE
+    assert diffuse.sum() > 500 and np.array_equal(a[:, 7], b[:, 7])
+    # the diffuse weight is base_color * coat_attenuation * darkening: the ratio with / without darkening is `mod`
+    np.testing.assert_allclose(a[diffuse, 3:6] / b[diffuse, 3:6], np.tile(mod, (diffuse.sum(), 1)), rtol=2e-6)
+    assert np.all(mod < 1.0) and np.all(mod > 0.3)
+    # roughening: with coat_ior = 1 the coat lobe has F0 = 0 (never sampled at normal incidence), Kcoat = 0 (no darkening) and eta_s =
+    # specular_ior, so the coated material must behave exactly like an uncoated one whose specular_roughness is r_eff
+    coated = MaterialDesc.open_pbr(base_color=tuple(bc), specular_roughness=float(r), coat_weight=1.0, coat_roughness=float(cr), coat_ior=1.0)
+    plain = MaterialDesc.open_pbr(base_color=tuple(bc), specular_roughness=float(r_eff))
+    top = _frames(4000, rng, 1.0)
+    np.testing.assert_array_equal(orc.bsdf_debug(coated, top)[:, :8], orc.bsdf_debug(plain, top)[:, :8])
+
+
+def test_openpbr_emission_through_coat(orc):
+    """emission_edf (mtlx:590-619): mix(uncoated, coat_color * (1 - coat_F0) * (1 - (1 - cos)^5), coat_weight) at normal incidence."""
+    from gatling_amd.scenes import cornell_box  # noqa: F401
+    v, f = build_mesh_arrays([(-50, -50, 0), (50, -50, 0), (50, 50, 0), (-50, 50, 0)], [4], [0, 1, 2, 3])
+    out = {}
+    for coat in (0.0, 1.0):
+        mat = MaterialDesc.open_pbr(base_color=(0, 0, 0), specular_weight=0.0, emission_luminance=2.0, emission_color=(1.0, 0.5, 0.25),
+                                    coat_weight=coat, coat_color=(0.5, 0.8, 1.0), coat_ior=1.6)
+        desc = SceneDesc(meshes=[MeshDesc("floor", v, f, 0, double_sided=True)], materials=[mat],
+                         camera=CameraDesc(position=(0, 0, 3), forward=(0, 0, -1), up=(0, 1, 0), vfov=0.02))
+        rs = RenderSettings(spp=4, max_bounces=1, clear_color=(0, 0, 0, 0), max_sample_value=1e9)
+        out[coat] = orc.render(desc, rs, 4, 4)[0][..., :3].mean(axis=(0, 1))
+    f0c = ((1.6 - 1) / (1.6 + 1)) ** 2
+    np.testing.assert_allclose(out[0.0], [2.0, 1.0, 0.5], rtol=1e-5)
+    np.testing.assert_allclose(out[1.0], np.array([2.0, 1.0, 0.5]) * np.array([0.5, 0.8, 1.0]) * (1 - f0c), rtol=1e-4)
+
+
+def test_eon_diffuse_is_reciprocal_energy_preserving_and_meets_lambert(orc):
+    """oren_nayar_diffuse_bsdf with energy_compensation (mtlx:200-206), energy-preserving Oren-Nayar: white albedo loses no energy
+    at any roughness, evaluate() is symmetric in (k1, k2), and roughness -> 0 meets the Lambert lobe."""
+    rng = np.random.default_rng(9)
+    for rough in (0.25, 1.0):
+        m = MaterialDesc.open_pbr(base_color=(1, 1, 1), base_diffuse_roughness=rough, specular_weight=0.0)
+        for c in (0.95, 0.5, 0.15):
+            out = orc.bsdf_debug(m, _frames(60000, rng, c))
+            albedo = out[:, 3:6].mean(axis=0)
+            np.testing.assert_allclose(albedo, 1.0, atol=0.02)  # E_ss + E_ms = 1 for rho = 1
+        items = _frames(2000, rng, 0.6)
+        swapped = items.copy(); swapped[:, 12:15], swapped[:, 15:18] = items[:, 15:18], items[:, 12:15]
+        a, b = orc.bsdf_debug(m, items), orc.bsdf_debug(m, swapped)
+        # evaluate returns bsdf * cos(k2): divide the cosines out before comparing
+        ok = items[:, 17] > 0.01  # (k1's cosine is clamped to 1e-4 inside the closed forms: leave grazing directions out)
+        fa, fb = a[ok, 8] / items[ok, 17], b[ok, 8] / swapped[ok, 17]
+        np.testing.assert_allclose(fa, fb, rtol=2e-5)
+    lam = orc.bsdf_debug(MaterialDesc.open_pbr(base_color=(0.7, 0.5, 0.3), specular_weight=0.0), _frames(500, np.random.default_rng(1), 0.7))
+    eon = orc.bsdf_debug(MaterialDesc.open_pbr(base_color=(0.7, 0.5, 0.3), specular_weight=0.0, base_diffuse_roughness=1e-4), _frames(500, np.random.default_rng(1), 0.7))
+    np.testing.assert_allclose(eon[:, 8:11], lam[:, 8:11], rtol=2e-4, atol=1e-7)
+
+
+def test_thin_walled_semantics(orc):
+    """mdl_thin_walled (rp_main.chit:155-157, 188-189, 218-220, 447): transmission leaves the inside/outside state alone (no Beer-Lambert
+    absorption behind a thin-walled pane, unlike a solid one), does not bend the ray, and the ThinWalled AOV turns red."""
+    pane_v, pane_f = build_mesh_arrays([(-1, -1, 0), (1, -1, 0), (1, 1, 0), (-1, 1, 0)], [4], [0, 1, 2, 3])
+    back_v, back_f = build_mesh_arrays([(-5, -5, -2), (5, -5, -2), (5, 5, -2), (-5, 5, -2)], [4], [0, 1, 2, 3])
+    imgs = {}
+    for thin in (False, True):
+        glass = MaterialDesc.open_pbr(base_color=(1, 1, 1), transmission_weight=1.0, transmission_color=(0.2, 0.6, 0.9), transmission_depth=0.5,
+                                      specular_roughness=0.0, specular_weight=0.0, geometry_thin_walled=thin)
+        wall = MaterialDesc.open_pbr(base_color=(0, 0, 0), specular_weight=0.0, emission_luminance=1.0)
+        desc = SceneDesc(meshes=[MeshDesc("pane", pane_v, pane_f, 0, double_sided=True), MeshDesc("wall", back_v, back_f, 1, double_sided=True)],
+                         materials=[glass, wall], camera=CameraDesc(position=(0.3, 0, 3), forward=(-0.1, 0, -1), up=(0, 1, 0), vfov=0.05))
+        rs = RenderSettings(spp=16, max_bounces=4, clear_color=(0, 0, 0, 0), max_sample_value=1e9, rr_bounce_offset=100, medium_stack_size=2)
+        imgs[thin] = orc.render(desc, rs, 4, 4)[0][..., :3].mean(axis=(0, 1))
+        aov = orc.render_aovs(desc, rs, 4, 4, ["thinWalled"])["thinWalled"][..., :3].mean(axis=(0, 1))
+        np.testing.assert_allclose(aov, [1, 0, 0] if thin else [0, 1, 0], atol=1e-6)
+    # solid pane: the transmission pushes the glass medium, the wall hit is attenuated by exp(-sigma_t d); thin-walled: nothing is pushed
+    assert np.allclose(imgs[True], imgs[True][0], rtol=1e-4) and imgs[True][0] > 0.9   # specular_weight 0 -> F = 0: everything passes, untinted (depth > 0)
+    assert imgs[False][0] < 0.1 * imgs[True][0] and imgs[False][2] > imgs[False][0]   # Beer-Lambert with the blue-ish transmission colour
