@@ -195,6 +195,8 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    if os.environ.get("GATLING_BENCH_SHARE_GPU"):  # tests: every rank on GPU 0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or bool(os.environ.get("GATLING_BENCH_FORCE_DIST"))  # the env var drives the N>1 code path on one GPU
     if use_dist:
@@ -203,52 +205,63 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from gatling_amd import capi
-    from gatling_amd.dist import gather_rows, interleaved_rows
+    from gatling_amd.dist import RowGather, interleaved_rows
 
-    desc, rs, w, h, label = make_workload(args.workload, args.spp or None)
-    rs.progressive_accumulation = False  # every step renders the same frame from sample 0 (no cross-step accumulation)
-    scene = capi.Scene(desc, device=local_rank)
-    r0, r1, rstride = interleaved_rows(h, world, rank)  # rows rank::world: every rank's share costs the same (dist.py)
-    nrows = len(range(r0, r1, rstride))
-    dev_ptr = scene.device_pointer(w, h)
+    def timed_run(workload, spp, steps, warmup, no_timers):
+        """Scene resident in HBM, `warmup` untimed steps, then exactly `steps` steps between barrier + synchronize; time = max over ranks."""
+        desc, rs, w, h, label = make_workload(workload, spp or None)
+        rs.progressive_accumulation = False  # every step renders the same frame from sample 0 (no cross-step accumulation)
+        scene = capi.Scene(desc, device=local_rank)
+        r0, r1, rstride = interleaved_rows(h, world, rank)  # rows rank::world: every rank's share costs the same (dist.py)
+        nrows = len(range(r0, r1, rstride))
+        dev_ptr = scene.device_pointer(w, h)
 
-    class _Tile:  # zero-copy view of the library's device render buffer (rows r0..r1) for the RCCL gather
-        def __init__(self):
-            self.__cuda_array_interface__ = {"shape": (nrows, w, 4), "typestr": "<f4", "data": (dev_ptr + r0 * w * 16, False), "version": 2,
-                                             "strides": (rstride * w * 16, 16, 4)}
-    tile = torch.as_tensor(_Tile(), device=f"cuda:{local_rank}") if use_dist else None
-    host_full = torch.empty((h, w, 4), dtype=torch.float32).pin_memory() if (use_dist and rank == 0) else None
+        class _Tile:  # zero-copy view of the library's device render buffer (rows r0..r1) for the RCCL gather
+            def __init__(self):
+                self.__cuda_array_interface__ = {"shape": (nrows, w, 4), "typestr": "<f4", "data": (dev_ptr + r0 * w * 16, False), "version": 2,
+                                                 "strides": (rstride * w * 16, 16, 4)}
+        tile = torch.as_tensor(_Tile(), device=f"cuda:{local_rank}") if use_dist else None
+        host_full = torch.empty((h, w, 4), dtype=torch.float32).pin_memory() if (use_dist and rank == 0) else None
+        gather = RowGather(h, w, torch.float32, torch.device("cuda", local_rank), interleaved=True) if use_dist else None  # buffers allocated once, outside the timed region
 
-    def step():
-        if not use_dist:
-            scene.render(rs, w, h)  # blocks; colour AOV complete in host memory on return (reference semantics)
-        else:
-            scene.render(rs, w, h, rows=(r0, r1), device_only=True, row_stride=rstride)
-            full = gather_rows(tile, h, w, interleaved=True)
-            if rank == 0:
-                host_full.copy_(full, non_blocking=False)
+        last = {}
 
-    def sync():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
+        def step():
+            if not use_dist:
+                last["img"] = scene.render(rs, w, h)  # blocks; colour AOV complete in host memory on return (reference semantics)
+            else:
+                scene.render(rs, w, h, rows=(r0, r1), device_only=True, row_stride=rstride)
+                full = gather(tile)
+                if rank == 0:
+                    host_full.copy_(full, non_blocking=False)
+                    last["img"] = host_full
+
+        def sync():
             torch.cuda.synchronize()
+            if use_dist:
+                dist.barrier()
+                torch.cuda.synchronize()
 
-    scene.set_option(capi.OPTION_KERNEL_TIMERS, 0 if args.no_timers else 8)  # HIP events around the stage launches of every 8th iteration, on the library's own stream
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    stats = []
-    for _ in range(args.steps):
-        step()
-        stats.append(scene.stats())
-    sync()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        scene.set_option(capi.OPTION_KERNEL_TIMERS, 0 if no_timers else 8)  # HIP events around the stage launches of every 8th iteration, on the library's own stream
+        for _ in range(warmup):
+            step()
+        sync()
+        t0 = time.perf_counter()
+        stats = []
+        for _ in range(steps):
+            step()
+            stats.append(scene.stats())
+        sync()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+
+        return {"desc": desc, "rs": rs, "w": w, "h": h, "label": label, "scene": scene, "rows": (r0, r1, rstride), "dt": dt, "stats": stats, "last": last}
+
+    R = timed_run(args.workload, args.spp, args.steps, args.warmup, args.no_timers)
+    desc, rs, w, h, label, scene, (r0, r1, rstride), dt, stats, last = (R[k] for k in ("desc", "rs", "w", "h", "label", "scene", "rows", "dt", "stats", "last"))
 
     if args.probe:
         scene.close()
@@ -333,11 +346,30 @@ def main():
                           "parallelism": f"rows-interleaved{world}" if world > 1 else "single", "segments_per_sample": round(seg_per_sample, 4),
                           "triangles": cst["triangleCount"], "bvh8_nodes": cst["nodeCount"], "iterations_per_step": stats[-1]["iterations"]},
                "roofline": roofline}
+        if os.environ.get("GATLING_BENCH_CHECKSUM"):  # tests: the frame rank 0 ends up with (host memory), as a checksum
+            import hashlib
+            img = last["img"]
+            out["image_checksum"] = hashlib.sha256((img.numpy() if hasattr(img, "numpy") else img).tobytes()).hexdigest()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(desc, rs, w, h)
             out["cpu_baseline"]["reference"] = reference_probe()
     if scene is not None:
         scene.close()
+    # N = 8 (the configuration C5 is specified on; BASELINE.json configs[4]): the tiled 4K interior as a second measurement in the same line.
+    # Every rank takes part (collectives inside); a failure is reported in the line instead of losing the headline number.
+    also = os.environ.get("GATLING_BENCH_ALSO", "c5" if world >= 8 else "")
+    if also and also != args.workload and not args.probe:
+        extra = {"workload": also}
+        try:
+            E = timed_run(also, int(os.environ.get("GATLING_BENCH_ALSO_SPP", "0")), 2, 1, True)
+            E["scene"].close()
+            samples = E["w"] * E["h"] * E["rs"].spp
+            extra.update({"config": E["label"], "value": round(samples * 2 / E["dt"] / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(E["dt"] * 1e3 / 2, 3),
+                          "steps": 2, "warmup": 1, "spp": E["rs"].spp, "width": E["w"], "height": E["h"], "n_gpus": world})
+        except Exception as e:  # noqa: BLE001
+            extra["error"] = repr(e)[:300]
+        if out is not None:
+            out["also"] = extra
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

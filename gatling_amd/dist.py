@@ -2,7 +2,8 @@
 gathered to rank 0 with one collective (RCCL over xGMI when the backend is "nccl"; gloo on CPU for tests).
 
 The reference has no multi-device path (it picks one Vulkan device, ``CgpuVk.cpp:892-909``); the partition follows
-SURVEY.md section 8e: shard by pixels (contiguous row bands) so that each pixel's sample-order sum stays on one GPU
+SURVEY.md section 8e: shard by pixels (whole rows: rank r renders rows r, r+N, ... -- interleaved_rows; contiguous bands are kept
+for comparison) so that each pixel's sample-order sum stays on one GPU
 and an N-way split is bit-identical to the single-GPU image; RNG streams use the global pixel index.
 """
 from __future__ import annotations
@@ -29,29 +30,41 @@ def interleaved_rows(height: int, world_size: int, rank: int) -> Tuple[int, int,
     return rank, height, world_size
 
 
-def gather_rows(local_tile, height: int, width: int, group=None, dst: int = 0, interleaved: bool = False):
-    """Gathers [rows_r, width, 4] float32 tensors (device or CPU) into the full [height, width, 4] image on ``dst``.
+class RowGather:
+    """One frame's gather of the per-rank row shares to ``dst``, with every buffer allocated ONCE (the padded send buffer, the
+    receive buffers and the assembled frame on ``dst``): calling it costs a pack copy, one ``dist.gather`` and, on ``dst``, the
+    re-interleave -- no allocation inside a timed region.
 
     The shares (contiguous bands, or rows rank::N when ``interleaved``) differ by at most one row; they are padded to a common
     size so a single gather moves everything (C5: 16.6 MB per GPU at 4K -- one collective, no all-reduce: SURVEY.md section 8e)."""
-    import torch
-    import torch.distributed as dist
 
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    max_rows = -(-height // world)
-    pad = torch.zeros((max_rows, width, 4), dtype=local_tile.dtype, device=local_tile.device)
-    pad[: local_tile.shape[0]] = local_tile  # also packs a strided (interleaved) device view
-    out = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    dist.gather(pad, out, dst=dst, group=group)
-    if rank != dst:
-        return None
-    full = torch.empty((height, width, 4), dtype=local_tile.dtype, device=local_tile.device)
-    for r in range(world):
-        if interleaved:
-            n = len(range(r, height, world))
-            full[r::world] = out[r][:n]
-        else:
-            r0, r1 = partition_rows(height, world, r)
-            full[r0:r1] = out[r][: r1 - r0]
-    return full
+    def __init__(self, height: int, width: int, dtype, device, group=None, dst: int = 0, interleaved: bool = False):
+        import torch
+        import torch.distributed as dist
+        self.group, self.dst, self.interleaved, self.height, self.width = group, dst, interleaved, height, width
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.max_rows = -(-height // self.world)
+        self.pad = torch.zeros((self.max_rows, width, 4), dtype=dtype, device=device)
+        self.out = [torch.empty_like(self.pad) for _ in range(self.world)] if self.rank == dst else None
+        self.full = torch.empty((height, width, 4), dtype=dtype, device=device) if self.rank == dst else None
+
+    def __call__(self, local_tile):
+        import torch.distributed as dist
+        self.pad[: local_tile.shape[0]].copy_(local_tile)  # also packs a strided (interleaved) device view
+        dist.gather(self.pad, self.out, dst=self.dst, group=self.group)
+        if self.rank != self.dst:
+            return None
+        for r in range(self.world):
+            if self.interleaved:
+                n = len(range(r, self.height, self.world))
+                self.full[r::self.world].copy_(self.out[r][:n])
+            else:
+                r0, r1 = partition_rows(self.height, self.world, r)
+                self.full[r0:r1].copy_(self.out[r][: r1 - r0])
+        return self.full
+
+
+def gather_rows(local_tile, height: int, width: int, group=None, dst: int = 0, interleaved: bool = False):
+    """One-off form of RowGather (allocates its buffers per call): gathers [rows_r, width, 4] float32 tensors (device or CPU) into the
+    full [height, width, 4] image on ``dst``; other ranks get None."""
+    return RowGather(height, width, local_tile.dtype, local_tile.device, group, dst, interleaved)(local_tile)
