@@ -170,7 +170,7 @@ def _settings(rs: RenderSettings) -> GiCRenderSettings:
     s = GiCRenderSettings()
     s.clippingPlanes = int(rs.clipping_planes); s.depthOfField = int(rs.depth_of_field)
     s.domeLightCameraVisible = int(rs.dome_light_camera_visible); s.filterImportanceSampling = int(rs.filter_importance_sampling)
-    s.frame = 0.0; s.jitteredSampling = int(rs.jittered_sampling); s.lightIntensityMultiplier = rs.light_intensity_multiplier
+    s.frame = float(getattr(rs, "frame", 0.0)); s.jitteredSampling = int(rs.jittered_sampling); s.lightIntensityMultiplier = rs.light_intensity_multiplier
     s.maxBounces = rs.max_bounces; s.maxSampleValue = rs.max_sample_value; s.maxVolumeWalkLength = rs.max_volume_walk_length
     s.mediumStackSize = rs.medium_stack_size; s.metersPerSceneUnit = rs.meters_per_scene_unit
     s.nextEventEstimation = int(rs.next_event_estimation); s.progressiveAccumulation = int(rs.progressive_accumulation)
@@ -236,7 +236,7 @@ class Scene:
                 if pvs:
                     arr, keep = (GiCPrimvarData * len(pvs))(), []
                     for k, pv in enumerate(pvs):
-                        d = np.ascontiguousarray(pv.data, np.float32).reshape(-1)
+                        d = np.ascontiguousarray(pv.data, np.int32 if int(pv.type) >= 4 else np.float32).reshape(-1)  # Int..Int4 (Gi.h:76-79)
                         keep.append(d)
                         arr[k] = GiCPrimvarData(pv.name.encode(), int(pv.type), int(pv.interpolation), d.ctypes.data, d.nbytes)
                     if fn(h, len(pvs), arr) != GI_C_OK:  # copies the data

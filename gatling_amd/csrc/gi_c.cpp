@@ -693,7 +693,8 @@ static int setPrimvarsImpl(GiCMesh* mesh, std::vector<GiCPrimvar>& dst, uint32_t
   for (uint32_t i = 0; i < count; i++) {
     if (!pv[i].name || pv[i].type < 0 || pv[i].type > GI_C_PRIMVAR_INT4 || pv[i].interpolation < 0 || pv[i].interpolation > GI_C_INTERP_VERTEX) { setError("giCSetMesh*Primvars: bad primvar"); return GI_C_ERROR; }
     GiCPrimvar p{pv[i].name, pv[i].type, pv[i].interpolation, {}};
-    if (pv[i].type <= GI_C_PRIMVAR_VEC4 && pv[i].data) p.data.assign((const float*)pv[i].data, (const float*)pv[i].data + pv[i].dataSize / 4);
+    // float and int32 elements are both 4 bytes: integer primvars keep their bit patterns in the float array (scene_data_lookup_int reads them back)
+    if (pv[i].data) p.data.assign((const float*)pv[i].data, (const float*)pv[i].data + pv[i].dataSize / 4);
     v.push_back(std::move(p));
   }
   std::lock_guard<std::mutex> g(mesh->scene->mutex);
@@ -931,7 +932,11 @@ int buildScene(GiCScene* s)
       r = TexBindingRec{};
       auto tit = b.texture ? std::find(s->textures.begin(), s->textures.end(), b.texture) : s->textures.end();
       if (tit == s->textures.end()) {
-        if (!s->materials[i]->primvarInput[slot].empty()) { r.mode = TEX_MODE_PRIMVAR; mats[i].flags |= MAT_FLAG_TEXTURED; }
+        if (!s->materials[i]->primvarInput[slot].empty()) {
+          r.mode = TEX_MODE_PRIMVAR; mats[i].flags |= MAT_FLAG_TEXTURED;
+          if (s->materials[i]->primvarInput[slot] == "CAMERA_POSITION") r.mode |= TEX_MODE_CAMERA_POSITION; // Frontend.cpp:251-252: named scene data answered from the UBO
+          if (s->materials[i]->primvarInput[slot] == "FRAME") r.mode |= TEX_MODE_FRAME;
+        }
         continue;
       }
       r.tex = (uint32_t)(tit - s->textures.begin()) + 1u;
@@ -968,14 +973,15 @@ int buildScene(GiCScene* s)
         const GiCPrimvar* pv = nullptr;
         for (const GiCPrimvar& p : m->instancerPrimvars) if (p.name == want && !p.data.empty()) { pv = &p; break; }
         for (const GiCPrimvar& p : m->primvars) if (p.name == want && !p.data.empty()) { pv = &p; break; }
-        if (!pv || pv->type > GI_C_PRIMVAR_VEC4) continue; // SCENE_DATA_INVALID
-        const uint32_t stride = (uint32_t)pv->type + 1u;
+        if (!pv) continue; // SCENE_DATA_INVALID
+        const bool isInt = pv->type > GI_C_PRIMVAR_VEC4; // Int .. Int4 (Gi.h:76-79)
+        const uint32_t stride = (uint32_t)(isInt ? pv->type - GI_C_PRIMVAR_INT : pv->type) + 1u;
         size_t entries = 1; // what a lookup can index: zero-padded so that short arrays read 0 like the oracle
         if (pv->interpolation == GI_C_INTERP_VERTEX) entries = m->vertices.size();
         else if (pv->interpolation == GI_C_INTERP_UNIFORM) entries = m->faces.size();
         else if (pv->interpolation == GI_C_INTERP_INSTANCE) { int32_t mx = (int32_t)(m->instanceTransforms.size() / 16) - 1; for (int32_t id : m->instanceIds) mx = std::max(mx, id); entries = (size_t)std::max(mx, 0) + 1; }
         mr.sdOffset[slot] = (uint32_t)sceneData.size();
-        mr.sdInfo[slot] = 1u | ((stride - 1u) << 1) | ((uint32_t)pv->interpolation << 3);
+        mr.sdInfo[slot] = 1u | ((stride - 1u) << 1) | ((uint32_t)pv->interpolation << 3) | (isInt ? SD_INFO_INT : 0u);
         const size_t need = std::max(entries * stride, pv->data.size());
         sceneData.insert(sceneData.end(), pv->data.begin(), pv->data.end());
         sceneData.resize(mr.sdOffset[slot] + need, 0.0f);
@@ -1330,7 +1336,8 @@ static int giCRenderImpl(const GiCRenderParams* params)
     view.domeTexture = tit != s->textures.end() ? (uint32_t)(tit - s->textures.begin()) + 1u : 0u;
     view.domeCameraVisible = rs.domeLightCameraVisible ? 1u : 0u;
     for (int a = 0; a < 4; a++) view.domeRotation[a] = dl ? dl->rotation[a] : (a == 3 ? 1.0f : 0.0f);
-    for (int a = 0; a < 3; a++) { view.domeEmission[a] = dl ? dl->baseEmission[a] : 1.0f; view.background[a] = U.background[a]; }
+    for (int a = 0; a < 3; a++) { view.domeEmission[a] = dl ? dl->baseEmission[a] : 1.0f; view.background[a] = U.background[a]; view.cameraPosition[a] = params->camera.position[a]; }
+    view.frame = rs.frame;
   }
   if (ensurePathState(s, 1, 1, 1) != GI_C_OK) return GI_C_ERROR; // counters / pinned mirror exist even for AOV-only renders
   if (colorRb) {

@@ -119,6 +119,18 @@ __device__ inline void resolve_material_textures(const SceneView& sc, const Mate
     const TexBindingRec& b = m->tex[slot];
     if (b.tex == 0u) {
       if (!(b.mode & TEX_MODE_PRIMVAR) || slot == TEX_NORMAL) continue;
+      const bool vec = slot == TEX_BASE_COLOR || slot == TEX_EMISSION;
+      // the two magic scene-data names (mdl_interface.glsl:329-334 float3 only, :390-395 float only)
+      if (vec && (b.mode & TEX_MODE_CAMERA_POSITION)) {
+        st.texMask |= 1u << slot;
+        if (slot == TEX_BASE_COLOR) st.texBaseColor = v3(sc.cameraPosition); else st.texEmission = v3(sc.cameraPosition);
+        continue;
+      }
+      if (!vec && (b.mode & TEX_MODE_FRAME)) {
+        st.texMask |= 1u << slot;
+        if (slot == TEX_ROUGHNESS) st.texRoughness = sc.frame; else st.texMetallic = sc.frame;
+        continue;
+      }
       // scene_data_lookup_float3 / _float (mdl_interface.glsl:337-371, 398-424; == oracle scene_data_lookup)
       const MeshRec& mr = sc.meshes[st.mesh];
       const uint32_t info = mr.sdInfo[slot];
@@ -131,10 +143,15 @@ __device__ inline void resolve_material_textures(const SceneView& sc, const Mate
       else { i0 = st.vi[0] - mr.vertexOffset; i1 = st.vi[1] - mr.vertexOffset; i2 = st.vi[2] - mr.vertexOffset; } // vertex
       const float* d = sc.sceneData + mr.sdOffset[slot];
       const float bx = 1.0f - st.hu - st.hv, by = st.hu, bz = st.hv;
-      const bool vec = slot == TEX_BASE_COLOR || slot == TEX_EMISSION;
       float o[3] = {0.0f, 0.0f, 0.0f};
+      if (info & SD_INFO_INT) { // scene_data_lookup_int / _int3 (:426-476): the value of the nearest vertex, per component, converted to float
+        const uint32_t pick = bx > by ? (bx > bz ? i0 : i2) : (by > bz ? i1 : i2);
+#pragma unroll
+        for (uint32_t c = 0; c < 3u; c++) if (c == 0u || vec) o[c] = (float)(int32_t)f2u(d[pick * stride + (c < stride ? c : stride - 1u)]);
+      } else {
 #pragma unroll
       for (uint32_t c = 0; c < 3u; c++) if (c == 0u || vec) o[c] = (d[i0 * stride + c] * bx + d[i1 * stride + c] * by) + d[i2 * stride + c] * bz;
+      }
       st.texMask |= 1u << slot;
       if (slot == TEX_BASE_COLOR) st.texBaseColor = v3(o[0], o[1], o[2]);
       else if (slot == TEX_EMISSION) st.texEmission = v3(o[0], o[1], o[2]);

@@ -77,6 +77,9 @@ struct TexBindingRec {
 constexpr uint32_t MAT_FLAG_OPACITY_TEX = 1u << 30; // MaterialRec::flags: the cutout opacity is textured (the any-hit test looks it up at the candidate's st)
 constexpr uint32_t MAT_FLAG_TEXTURED = 1u << 31; // MaterialRec::flags: some input is textured or primvar-driven (k_shade resolves the inputs per hit)
 constexpr uint32_t TEX_MODE_PRIMVAR = 1u << 24;   // TexBindingRec::mode: (no texture) the input reads the mesh's scene data for this slot
+constexpr uint32_t TEX_MODE_CAMERA_POSITION = 1u << 25; // ... the scene-data name is "CAMERA_POSITION": ubo.cameraPosition (mdl_interface.glsl:329-334, Frontend.cpp:251)
+constexpr uint32_t TEX_MODE_FRAME = 1u << 26;           // ... the scene-data name is "FRAME": ubo.frame (mdl_interface.glsl:390-395, Frontend.cpp:252)
+constexpr uint32_t SD_INFO_INT = 1u << 5;               // MeshRec::sdInfo: integer primvar, nearest-vertex interpolation (scene_data_lookup_int, mdl_interface.glsl:426-457)
 // Scene data (primvars) of a mesh for the material inputs of ITS material (replaces BlasPayloadBufferPreamble::sceneDataInfos,
 // rp_main.h:125-148, Gi.cpp:905-1019): per input slot the float offset into SceneView::sceneData and
 // info = valid | (stride - 1) << 1 | interpolation << 3 (GiPrimvarInterpolation: constant, instance, uniform, vertex).
@@ -153,6 +156,8 @@ struct SceneView {
   float domeRotation[4];
   float domeEmission[3];
   float background[3];        // the fallback dome texel: colour clear value as RGBA8 unorm (Gi.cpp:2194-2199)
+  float cameraPosition[3];    // ubo.cameraPosition / ubo.frame for the CAMERA_POSITION / FRAME scene-data names
+  float frame;
   uint32_t mediumStackSize;   // > 0: rays that end inside a medium scatter instead of leaving the scene (rp_main.miss:57-66)
   // Two-level layout for instanced scenes (k_trace_dyn2): a TLAS over instance bounds whose leaf references name instances, one BLAS
   // per mesh in OBJECT space shared by all its instances.  Candidates are still tested as WORLD-space triangles (rebuilt from the

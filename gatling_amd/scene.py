@@ -138,6 +138,7 @@ MaterialDesc.open_pbr = staticmethod(_open_pbr)
 
 
 PRIMVAR_FLOAT, PRIMVAR_VEC2, PRIMVAR_VEC3, PRIMVAR_VEC4 = 0, 1, 2, 3                       # GiPrimvarType (Gi.h:76-79)
+PRIMVAR_INT, PRIMVAR_INT2, PRIMVAR_INT3, PRIMVAR_INT4 = 4, 5, 6, 7
 INTERP_CONSTANT, INTERP_INSTANCE, INTERP_UNIFORM, INTERP_VERTEX = 0, 1, 2, 3                # GiPrimvarInterpolation (Gi.h:81-84)
 
 
@@ -239,6 +240,7 @@ class RenderSettings:
     next_event_estimation: bool = False
     clipping_planes: bool = False
     medium_stack_size: int = 0
+    frame: float = 0.0              # GiRenderSettings.frame (Gi.h:144): the FRAME scene data
     max_volume_walk_length: int = 7
     jittered_sampling: bool = True
     meters_per_scene_unit: float = 1.0

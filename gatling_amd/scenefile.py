@@ -19,7 +19,7 @@ setters (reference interface ``src/gi/gtl/gi/Gi.h:86-175``) -- written sequentia
     "END!"
 
     str     = u32 byteLength; bytes; zero padding to a multiple of 4
-    primvar = str name; i32 type, interpolation; u32 nFloats; f32 data[nFloats]
+    primvar = str name; i32 type, interpolation; u32 nElems; f32 | i32 data[nElems]   (i32 for the types Int .. Int4)
     flags   = 1 doubleSided | 2 leftHanded | 4 visible | 8 hasFaceIds | 16 hasInstanceIds
 """
 from __future__ import annotations
@@ -124,7 +124,7 @@ def save_scene(path, desc: SceneDesc, settings: RenderSettings = None, width: in
             for pvs in (m.primvars, m.instancer_primvars):
                 w.u32(len(pvs))
                 for pv in pvs:
-                    data = np.ascontiguousarray(pv.data, "<f4").reshape(-1)
+                    data = np.ascontiguousarray(pv.data, "<i4" if int(pv.type) >= 4 else "<f4").reshape(-1)  # Int..Int4: 4-byte elements too
                     w.string(pv.name)
                     w.i32(pv.type, pv.interpolation)
                     w.u32(len(data))
@@ -234,7 +234,7 @@ def load_scene(path):
                 pname = r.string()
                 ptype, interp = r.i32(), r.i32()
                 comps = (1, 2, 3, 4)[ptype & 3]
-                data = r.arr(r.u32(), "<f4")
+                data = r.arr(r.u32(), "<i4" if ptype >= 4 else "<f4")
                 pvs.append(Primvar(pname, ptype, interp, data.reshape(-1, comps) if comps > 1 else data))
             pv_lists.append(pvs)
         desc.meshes.append(MeshDesc(name, verts, faces, material=mat, id=mid, double_sided=bool(flags & F_DOUBLE_SIDED),

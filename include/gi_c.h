@@ -228,11 +228,13 @@ typedef struct GiCTextureBinding {
 } GiCTextureBinding;
 int giCSetMaterialTexture(GiCMaterial* material, int32_t input, const GiCTextureBinding* binding);
 
-/* Scene data (primvars).  Gi.h:76-92: GiPrimvarData with the byte vector flattened to pointer + size; float types feed the
- * closed-form material inputs, int types are accepted and ignored.  A material input bound to a primvar NAME reads the primvar
- * of the hit mesh (instancer primvars first, mesh primvars override, Gi.cpp:913-929) through scene_data_lookup_float3 /
- * _float (mdl_interface.glsl:281-301, 337-424): barycentric blend of the three vertex values, or the uniform / instance /
- * constant value.  A mesh without that primvar keeps the input's constant.  A texture on the same input takes precedence. */
+/* Scene data (primvars).  Gi.h:76-92: GiPrimvarData with the byte vector flattened to pointer + size; data = 4-byte elements (float, or int32 for
+ * the Int types).  A material input bound to a primvar NAME reads the primvar of the hit mesh (instancer primvars first, mesh primvars
+ * override, Gi.cpp:913-929) through scene_data_lookup_float3 / _float (mdl_interface.glsl:281-301, 337-424): barycentric blend of the
+ * three vertex values, or the uniform / instance / constant value; integer primvars go through scene_data_lookup_int (:426-476): the
+ * value of the NEAREST vertex (largest barycentric weight), converted to float.  The names "CAMERA_POSITION" (colour inputs) and
+ * "FRAME" (scalar inputs) are answered from the camera / GiCRenderSettings.frame like the reference's UBO short cuts (:329-334,
+ * 390-395).  A mesh without that primvar keeps the input's constant.  A texture on the same input takes precedence. */
 #define GI_C_PRIMVAR_FLOAT 0
 #define GI_C_PRIMVAR_VEC2 1
 #define GI_C_PRIMVAR_VEC3 2

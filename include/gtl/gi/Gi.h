@@ -29,7 +29,7 @@ namespace gtl
   { Color = 0, Normal, NEE, Barycentrics, Texcoords, Bounces, ClockCycles, Opacity, Tangents, Bitangents, ThinWalled, ObjectId, Depth,
     FaceId, InstanceId, DoubleSided, Albedo, COUNT };
   enum class GiRenderBufferFormat { Int32, Float32, Float32Vec4 };                                // Gi.h:70-75
-  enum class GiPrimvarType { Float, Vec2, Vec3, Vec4, Int, Int2, Int3, Int4 };                    // Gi.h:76-79 (int types: accepted, unused)
+  enum class GiPrimvarType { Float, Vec2, Vec3, Vec4, Int, Int2, Int3, Int4 };                    // Gi.h:76-79
   enum class GiPrimvarInterpolation { Constant, Instance, Uniform, Vertex, COUNT };               // Gi.h:81-84
   constexpr static const uint32_t GI_MAX_AOV_COMP_SIZE = 16;                                      // Gi.h:34
 

@@ -586,6 +586,7 @@ struct State {
   // Bsdf_sample_data.ior1 / ior2 (rp_main.chit:188-189): ior of the medium the ray travels in / of the other side;
   // < 0 = BSDF_USE_MATERIAL_IOR.  Defaults = empty medium stack (vacuum outside).
   float ior1 = 0.0f, ior2 = 0.0f;
+  V3 cameraPosition = {0, 0, 0}; float frame = 0.0f; // ubo.cameraPosition / ubo.frame for the CAMERA_POSITION / FRAME scene-data names
   bool thinWalled = false; // mdl_thin_walled (rp_main.chit:155-157): both sides of the surface see the medium the ray travels in
   // renderer state of the hit for scene-data lookups (mdl_interface.glsl:281-301)
   const MeshData* mesh = nullptr; uint32_t prim = 0, hitIndices[3] = {0, 0, 0}; int32_t instanceId = 0; float bu = 0.0f, bv = 0.0f;
@@ -716,15 +717,28 @@ inline const OrcPrimvar* find_primvar(const OrcMesh& m, const char* name)
 // scene_data_lookup_float3 / _float (mdl_interface.glsl:337-371, 398-424) with get_scene_data_indices (:281-301)
 inline bool scene_data_lookup(const State& st, const char* name, int comps, float out[3])
 {
+  // the two named scene data answered from the UBO (Frontend.cpp:251-252; mdl_interface.glsl:329-334 float3 only, :390-395 float only)
+  if (comps == 3 && !strcmp(name, "CAMERA_POSITION")) { out[0] = st.cameraPosition.x; out[1] = st.cameraPosition.y; out[2] = st.cameraPosition.z; return true; }
+  if (comps == 1 && !strcmp(name, "FRAME")) { out[0] = st.frame; return true; }
   const OrcPrimvar* pv = st.mesh ? find_primvar(*st.mesh->src, name) : nullptr;
-  if (!pv || pv->type > ORC_PRIMVAR_VEC4) return false; // not found (SCENE_DATA_INVALID) -> default value; int primvars do not feed float inputs
-  const uint32_t stride = (uint32_t)pv->type + 1u;
+  if (!pv) return false; // not found (SCENE_DATA_INVALID) -> default value
+  const bool isInt = pv->type > ORC_PRIMVAR_VEC4;
+  const uint32_t stride = (uint32_t)(isInt ? pv->type - ORC_PRIMVAR_INT : pv->type) + 1u;
   uint32_t idx[3];
   if (pv->interpolation == ORC_INTERP_UNIFORM) idx[0] = idx[1] = idx[2] = st.prim;
   else if (pv->interpolation == ORC_INTERP_INSTANCE) idx[0] = idx[1] = idx[2] = (uint32_t)st.instanceId;
   else if (pv->interpolation == ORC_INTERP_CONSTANT) idx[0] = idx[1] = idx[2] = 0u;
   else { idx[0] = st.hitIndices[0]; idx[1] = st.hitIndices[1]; idx[2] = st.hitIndices[2]; }
   const float bx = 1.0f - st.bu - st.bv, by = st.bu, bz = st.bv;
+  if (isInt) { // scene_data_lookup_int / _int3 (mdl_interface.glsl:426-476): nearest vertex, per component (index_offset = component), as float
+    const uint32_t pick = bx > by ? (bx > bz ? idx[0] : idx[2]) : (by > bz ? idx[1] : idx[2]);
+    for (int c = 0; c < comps; c++) {
+      size_t o = (size_t)pick * stride + (size_t)((uint32_t)c < stride ? (uint32_t)c : stride - 1u);
+      int32_t iv = 0; if (o < pv->floatCount) memcpy(&iv, &pv->data[o], 4);
+      out[c] = (float)iv;
+    }
+    return true;
+  }
   for (int c = 0; c < comps; c++) {
     float v[3];
     for (int k = 0; k < 3; k++) { size_t o = (size_t)idx[k] * stride + (size_t)c; v[k] = o < pv->floatCount ? pv->data[o] : 0.0f; }
@@ -1275,6 +1289,7 @@ void closest_hit(const Frame& F, const Hit& h, Payload& pl, float hitT)
   setup_shading_state(P, h, rayDir, st, mesh);
   const OrcMaterial& baseMat = P.materials[mesh->material];
   OrcMaterial resolved;
+  st.cameraPosition = v3(F.cam->position); st.frame = F.rs->frame;
   if (material_textured(baseMat)) resolved = resolve_material(P, baseMat, st, rayDir);
   const OrcMaterial& mat = material_textured(baseMat) ? resolved : baseMat;
   bool isLeftHanded = (mesh->flags & 1u) != 0, isDoubleSided = (mesh->flags & 2u) != 0;
@@ -1654,6 +1669,7 @@ void render_pixel_aovs(const Frame& F, uint32_t px, uint32_t py, size_t o, OrcAo
     }
     if (A.albedo) {                                                                        // :261-289
       const OrcMaterial& bm = F.P->materials[mesh->material];
+      st.cameraPosition = v3(F.cam->position); st.frame = F.rs->frame;
       OrcMaterial rm; if (material_textured(bm)) rm = resolve_material(*F.P, bm, st, dir);
       V3 al = bsdf_albedo(material_textured(bm) ? rm : bm, st, -dir), prev = al;
       if (rs.progressiveAccumulation && rs.sampleOffset > 0) prev = v3(A.albedo + 4 * o);

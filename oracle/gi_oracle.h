@@ -181,6 +181,7 @@ typedef struct OrcSettings {
   uint32_t mediumStackSize;     /* GiRenderSettings.mediumStackSize (Gi.h:151): 0 = inside/outside toggle only; <= 8 here */
   uint32_t maxVolumeWalkLength; /* Gi.h:150 */
   float clearColor[4]; /* Color AOV clear value == fallback dome colour (Gi.cpp:2184-2199) */
+  float frame;         /* GiRenderSettings.frame (Gi.h:144) -> ubo.frame, the value of the FRAME scene data (mdl_interface.glsl:390-395) */
 } OrcSettings;
 
 typedef struct OrcRegion {

@@ -117,7 +117,7 @@ class OrcSettings(C.Structure):
                 ("maxBounces", C.c_uint32), ("rrBounceOffset", C.c_uint32), ("spp", C.c_uint32), ("sampleOffset", C.c_uint32),
                 ("lightIntensityMultiplier", C.c_float), ("maxSampleValue", C.c_float), ("rrInvMinTermProb", C.c_float),
                 ("metersPerSceneUnit", C.c_float), ("mediumStackSize", C.c_uint32), ("maxVolumeWalkLength", C.c_uint32),
-                ("clearColor", C.c_float * 4)]
+                ("clearColor", C.c_float * 4), ("frame", C.c_float)]
 
 
 class OrcRegion(C.Structure):
@@ -224,7 +224,7 @@ class PackedScene:
                 if pvs:
                     arr = (OrcPrimvar * len(pvs))()
                     for k, pv in enumerate(pvs):
-                        d = np.ascontiguousarray(pv.data, np.float32).reshape(-1)
+                        d = np.ascontiguousarray(pv.data, np.int32 if int(pv.type) >= 4 else np.float32).reshape(-1)  # Int..Int4 keep their bits
                         self.keep.append(d)
                         arr[k].name = pv.name.encode(); arr[k].type = int(pv.type); arr[k].interpolation = int(pv.interpolation)
                         arr[k].data = d.ctypes.data; arr[k].floatCount = len(d)
@@ -286,6 +286,7 @@ def _settings(rs, sample_offset=0) -> OrcSettings:
     s.rrBounceOffset = rs.rr_bounce_offset
     s.spp = rs.spp
     s.sampleOffset = sample_offset
+    s.frame = float(getattr(rs, "frame", 0.0))
     s.lightIntensityMultiplier = rs.light_intensity_multiplier
     s.maxSampleValue = rs.max_sample_value
     s.rrInvMinTermProb = rs.rr_inv_min_term_prob

