@@ -81,7 +81,7 @@ VALU_CYCLES_PER_INST = 4  # a wave64 VALU instruction occupies a SIMD's 16 fp32 
                           # are all masked off are skipped, which is how the ratio can exceed 1)
 SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, max clock (MI355X_MICROARCH.md)
 PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"),
-              ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_INSTS_LDS", "SQ_WAVES"))
+              ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_THREAD_CYCLES_VALU"))
 
 
 def fetch_calibration():
@@ -333,6 +333,9 @@ def main():
                         if wc:
                             roofline["wave_cycles_not_valu_frac"] = round(1.0 - sum(v.get("SQ_ACTIVE_INST_VALU", 0.0) for v in main_k) / wc, 5)
                             roofline["wait_inst_any_frac"] = round(sum(v.get("SQ_WAIT_INST_ANY", 0.0) for v in main_k) / wc, 5)
+                    tc, av = sum(v.get("SQ_THREAD_CYCLES_VALU", 0.0) for v in main_k), sum(v.get("SQ_ACTIVE_INST_VALU", 0.0) for v in main_k)
+                    if tc and av:
+                        roofline["valu_lane_utilisation"] = round(tc / (64.0 * av), 5)  # active lanes per issued VALU instruction / 64
                     hit, miss = sum(v.get("TCC_HIT_sum", 0.0) for v in main_k), sum(v.get("TCC_MISS_sum", 0.0) for v in main_k)
                     if hit + miss > 0:
                         roofline["l2_hit_rate"] = round(hit / (hit + miss), 5)
