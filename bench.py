@@ -288,7 +288,7 @@ def main():
         seg_per_sample = rays / max(1, sum(s["samples"] for s in stats))
         stream_only = (samples_per_step * args.steps / dt) * seg_per_sample * 192.0 / 1e9  # whole-pipeline stream floor
         if stats[-1]["fusedPath"]:
-            kernel, prefixes = "k_path (fused persistent path kernel: raygen + closest hit + shade + shadow ray per lane)", ("k_path<",)
+            kernel, prefixes = "k_path / k_path_bw (fused persistent path kernel: raygen + closest hit + shade per path, wave-local wavefront when NEE is off)", ("k_path",)
         elif cst["triangleCount"] <= 128:
             kernel, prefixes = "k_trace<closest>", ("k_trace<false",)
         else:

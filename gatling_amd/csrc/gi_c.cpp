@@ -318,7 +318,7 @@ struct GiCScene {
   bool countTraversal = false, kernelTimers = false;
   uint32_t kernelTimerStride = 1;
   uint64_t optPoolSlots = 0, optSampleBufferMb = 0; // 0 = default
-  int32_t optFusedPath = -1; // -1 = default (on): LDS-resident scenes run the fused persistent kernel k_path; 0 = always the wavefront stage kernels
+  int32_t optFusedPath = -1; // -1 / 1 = default: LDS-resident scenes run the fused persistent kernels (k_path_bw without NEE, k_path with); 2 = k_path only; 0 = always the wavefront stage kernels
   int32_t optTraceDyn = -1; // -1 = default; 0 = block-synchronous k_trace everywhere; N = k_trace_dyn refill threshold
   GiCRenderStats stats{};
   std::vector<hipEvent_t> eventPool;
@@ -792,7 +792,7 @@ int giCSetSceneOption(GiCScene* scene, int32_t option, int32_t value)
   if (option == GI_C_SCENE_OPTION_POOL_SLOTS) { scene->optPoolSlots = value > 0 ? (uint64_t)value : 0; return GI_C_OK; }
   if (option == GI_C_SCENE_OPTION_TWO_LEVEL) { scene->optTwoLevel = value < 0 ? -1 : (value ? 1 : 0); scene->dirty |= DIRTY_BVH | DIRTY_FRAMEBUFFER; return GI_C_OK; }
   if (option == GI_C_SCENE_OPTION_TRACE_DYNAMIC) { scene->optTraceDyn = value < 0 ? -1 : (value > 64 ? 64 : value); return GI_C_OK; }
-  if (option == GI_C_SCENE_OPTION_FUSED_PATH) { scene->optFusedPath = value < 0 ? -1 : (value ? 1 : 0); return GI_C_OK; }
+  if (option == GI_C_SCENE_OPTION_FUSED_PATH) { scene->optFusedPath = value < 0 ? -1 : (value > 2 ? 1 : value); return GI_C_OK; }
   if (option == GI_C_SCENE_OPTION_SAMPLE_BUFFER_MB) { scene->optSampleBufferMb = value > 0 ? (uint64_t)value : 0; return GI_C_OK; }
   setError("unknown scene option"); return GI_C_ERROR;
 }
@@ -1428,7 +1428,9 @@ static int giCRenderImpl(const GiCRenderParams* params)
         chunk = (uint32_t)std::min<uint64_t>(chunk, std::max<uint64_t>(64u, ((uint64_t)U.workTotal / (waves * 4u)) & ~63ull));
         curIter = totalIters; if (timers) sampledIters++;
         if (timers) { (void)hipEventRecord(poolEvent(s, ev), st); }
-        launchPath(st, (uint32_t)g_ctx.cuCount, s->classMask, s->classTextured != 0u, s->countTraversal, chunk, U, view, ps, s->dCounters.ptr, s->sampleBuf.ptr);
+        static const int envBw = getenv("GATLING_PATH_BW") ? atoi(getenv("GATLING_PATH_BW")) : 1;
+        if (envBw && !nee && s->optFusedPath != 2) launchPathBw(st, (uint32_t)g_ctx.cuCount, s->classMask, s->classTextured != 0u, s->countTraversal, chunk, U, view, ps, s->dCounters.ptr, s->sampleBuf.ptr);
+        else launchPath(st, (uint32_t)g_ctx.cuCount, s->classMask, s->classTextured != 0u, s->countTraversal, chunk, U, view, ps, s->dCounters.ptr, s->sampleBuf.ptr);
         if (timers) { (void)hipEventRecord(poolEvent(s, ev + 1), st); ev += 2; evKind.push_back(1); }
         iters++; totalIters++; traceLaunches++;
         launchAccumulate(st, U, s->sampleBuf.ptr, s->accum.ptr, colorOut, batch == 0, batch + 1 == numBatches);

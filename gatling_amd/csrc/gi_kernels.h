@@ -24,6 +24,9 @@ void launchShade(hipStream_t s, uint32_t blocks, uint32_t klass, bool textured /
 
 // Fused persistent path kernel (gi_path.hip) for LDS-resident scenes; launchPath returns the resident blocks per CU it launched with
 bool pathKernelSupports(const SceneView& sc);
+// the same kernel as a wave-local wavefront (gi_path_bw.hip): path state and stage queues in LDS, every stage runs on full waves; NEE off only
+int launchPathBw(hipStream_t s, uint32_t cuCount, uint32_t classMask, bool textured, bool count, uint32_t chunk, const FrameUniforms& U, const SceneView& sc,
+                 const PathState& st, Counters* cnt, F4* sampleBuf);
 int launchPath(hipStream_t s, uint32_t cuCount, uint32_t classMask, bool textured, bool count, uint32_t chunk, const FrameUniforms& U, const SceneView& sc,
                const PathState& st, Counters* cnt, F4* sampleBuf);
 

@@ -375,7 +375,8 @@ int giCGetRenderStats(const GiCScene* scene, GiCRenderStats* out);
 #define GI_C_SCENE_OPTION_TWO_LEVEL 6     /* [ext] 1: two-level BVH (TLAS over instances + one object-space BLAS per mesh) for scenes beyond LDS; default 0: one
                                              flat BVH over the instanced triangles (faster today); the image does not depend on it */
 /* [ext] Scenes whose whole BVH fits LDS (<= 384 nodes, <= 128 triangles; no medium stack, no dome image) are rendered by the fused
- * persistent kernel k_path, which keeps the paths in registers (default, -1 / 1); 0 = run the wavefront stage kernels on them too.
+ * persistent kernels (default, -1 / 1: k_path_bw, the wave-local wavefront, when next-event estimation is off, else k_path, one path per
+ * lane in registers); 2 = k_path in both cases; 0 = run the wavefront stage kernels on them too.
  * The image does not depend on it. */
 #define GI_C_SCENE_OPTION_FUSED_PATH 7
 int giCSetSceneOption(GiCScene* scene, int32_t option, int32_t value);

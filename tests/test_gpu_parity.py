@@ -400,6 +400,27 @@ def test_bsdf_known_answers_on_device(gi, orc):
         assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
+def test_three_pipelines_for_lds_resident_scenes_agree(gi, orc):
+    """The same frame through the wavefront stage kernels (option 0), the lane-per-path fused kernel k_path (2) and the wave-local
+    wavefront k_path_bw (1, the default without NEE): bit-identical images and segment counts, also with cutouts / textures in play and
+    for work totals that do not fill the waves' path pools."""
+    from gatling_amd.capi import OPTION_FUSED_PATH
+    cases = [(cornell_box(), RenderSettings(spp=6, max_bounces=8), 96, 54), (cornell_box(MAT_DIFFUSE), RenderSettings(spp=3, max_bounces=4), 7, 5),
+             (cornell_box(), RenderSettings(spp=1, max_bounces=3, rr_bounce_offset=0), 33, 1)]
+    for desc, rs, w, h in cases:
+        ref, cnt = orc.render(desc, rs, w, h, threads=4)
+        for mode in (0, 2, 1):
+            sc = gi.Scene(desc)
+            try:
+                sc.set_option(OPTION_FUSED_PATH, mode)
+                img = sc.render(rs, w, h)
+                stats = sc.stats()
+            finally:
+                sc.close()
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (mode, w, h)
+            assert stats["segments"] == cnt["segments"] and stats["fusedPath"] == (1 if mode else 0)
+
+
 def test_c4_parameter_sets_bsdf_properties_on_device(gi, orc):
     """The 32 material parameter sets of config C4 (sphere_grid / _parameter_sets; OpenPBR and UsdPreviewSurface, metal / coat /
     transmission mixes), evaluated ON THE DEVICE through the debug hook: white-furnace bound (directional albedo of the white version
