@@ -152,9 +152,13 @@ def reference_probe():
     if not g or not v:
         return {"status": "absent", "gatling": bool(g), "vulkaninfo": bool(v),
                 "note": "no reference build / Vulkan RT device on this box (BASELINE.md section 2); cpu_baseline.kind stays 'port'"}
-    scene = os.path.join(ROOT, "tests", "golden", "cornell.usda")
-    if not os.path.exists(scene):
-        return {"status": "no scene file", "gatling": True, "vulkaninfo": True}
+    scene = os.path.join(os.environ.get("TMPDIR", "/tmp"), "gatling_bench_cornell.usda")
+    try:  # the C2 scene as .usda (same generator as the GPU run)
+        from gatling_amd.scenes import cornell_box
+        from gatling_amd.usda_writer import write_usda
+        write_usda(scene, cornell_box())
+    except Exception as e:  # noqa: BLE001
+        return {"status": f"could not write the scene file: {e!r}"[:200], "gatling": True, "vulkaninfo": True}
     times = []
     for _ in range(2):  # first run pays MDL -> GLSL -> SPIR-V compilation and the BLAS / TLAS build
         try:
