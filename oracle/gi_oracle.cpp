@@ -4,8 +4,12 @@
 // scratch; no reference source is copied.  Build: see oracle/Makefile
 // (g++ -O2 -ffp-contract=off -fno-fast-math: the arithmetic contract forbids contraction).
 //
-// "parity unpinned": BSDF arithmetic (MDL SDK / MaterialX are not in /root/reference) and the
-// HW traversal's tie-breaking cannot be checked against the reference; see gi_oracle.h.
+// "parity unpinned" for BSDF arithmetic (MDL SDK / MaterialX are not in /root/reference) and the HW traversal's
+// tie-breaking; see gi_oracle.h.  PINNED against the reference's own code: the helpers exported as orc_* / orc_dbg_*
+// (RNG, hashes, orthonormal basis, ray offset, octahedral codec, sampling maps, colour maps, payload bit fields, Russian
+// roulette, volume sampling, dome rotation, wrap / crop, normal adaption, sampleLight) are compared bit for bit -- within a
+// few ulp where sin / cos / log are involved -- with those functions compiled from /root/reference/src/gi/shaders
+// (oracle/ref/build_ref.py -> oracle/_ref/libgi_ref.so, tests/test_oracle_ref.py).
 
 #include "gi_oracle.h"
 
@@ -1388,6 +1392,31 @@ void closest_hit(const Frame& F, const Hit& h, Payload& pl, float hitT)
   pl.throughput = throughput; pl.radiance = radiance;
 }
 
+// rp_main.rgen:49-69 sampleDistance: the extinction coefficient of the channel picked in proportion to throughput * albedo
+inline float sample_distance(V3 albedo, V3 throughput, V3 sigma_t, float xi, V3& pdf)
+{
+  V3 weights = throughput * albedo;
+  float sum = (weights.x + weights.y) + weights.z;
+  pdf = (sum > 1e-9f) ? (weights / sum) : v3(1.0f / 3.0f, 1.0f / 3.0f, 1.0f / 3.0f);
+  return (xi < pdf.x) ? sigma_t.x : ((xi < (pdf.x + pdf.y)) ? sigma_t.y : sigma_t.z);
+}
+// rp_main.rgen:72-82 sampleHenyeyGreensteinCos
+inline float henyey_greenstein_cos(float r, float g)
+{
+  if (fabsf(g) < 1e-3f) return 1.0f - 2.0f * r;
+  float sq = (1.0f - g * g) / ((1.0f - g) + (2.0f * g) * r);
+  return ((1.0f + g * g) - sq * sq) / (2.0f * g);
+}
+// rp_main.rgen:100-113 russian_roulette: true = terminate
+inline bool russian_roulette(float k, float rrInvMinTermProb, V3& throughput)
+{
+  float mt = fmax2(throughput.x, fmax2(throughput.y, throughput.z));
+  float p = fmin2(mt, rrInvMinTermProb);
+  if (k > p) return true;
+  throughput = throughput / p;
+  return false;
+}
+
 // rp_main.miss:55-86 with the 1x1 fallback dome (Gi.cpp:2184-2199, 2232-2238): texel = u8(clear*255)/255
 inline V3 quat_rotate_dir(const float q[4], V3 dir) // rp_main.miss:38-44
 {
@@ -1507,10 +1536,7 @@ void render_pixel(const Frame& F, uint32_t px, uint32_t py, const float* prevCol
           if (hasScattering && walkLength <= rs.maxVolumeWalkLength) {
             V3 albedo = v3(safe_div(m.sigma_s.x, m.sigma_t.x), safe_div(m.sigma_s.y, m.sigma_t.y), safe_div(m.sigma_s.z, m.sigma_t.z));
             float x0 = next1f(pl.rng), x1 = next1f(pl.rng);
-            V3 weights = pl.throughput * albedo; // sampleDistance (:49-69)
-            float sum = (weights.x + weights.y) + weights.z;
-            pl.walkSegmentPdf = (sum > 1e-9f) ? (weights / sum) : v3(1.0f / 3.0f, 1.0f / 3.0f, 1.0f / 3.0f);
-            float sg = (x0 < pl.walkSegmentPdf.x) ? m.sigma_t.x : ((x0 < (pl.walkSegmentPdf.x + pl.walkSegmentPdf.y)) ? m.sigma_t.y : m.sigma_t.z);
+            float sg = sample_distance(albedo, pl.throughput, m.sigma_t, x0, pl.walkSegmentPdf);
             sg = sg * rs.metersPerSceneUnit;
             tMax = -logf_poly(1.0f - x1) / sg; // collision free distance
           }
@@ -1537,16 +1563,12 @@ void render_pixel(const Frame& F, uint32_t px, uint32_t py, const float* prevCol
       if (length(pl.throughput) < 1e-9f) pl.bitfield |= TERMINATE_FLAG; // :441-444
       if (bounce > rs.rrBounceOffset) { // :447-459
         float k1 = next1f(pl.rng);
-        float mt = fmax2(pl.throughput.x, fmax2(pl.throughput.y, pl.throughput.z));
-        float p = fmin2(mt, rs.rrInvMinTermProb);
-        if (k1 > p) pl.bitfield |= TERMINATE_FLAG; else pl.throughput = pl.throughput / p;
+        if (russian_roulette(k1, rs.rrInvMinTermProb, pl.throughput)) pl.bitfield |= TERMINATE_FLAG;
       }
       if (stackSize > 0 && (pl.bitfield & WALK_MISS_FLAG) != 0) { // :462-477: continue the random walk in a new direction
         float x0 = next1f(pl.rng), x1 = next1f(pl.rng);
         float g = pl.media[mediumIdx - 1].bias; // mediumIdx as read at the top of this iteration
-        float cosTheta; // sampleHenyeyGreensteinCos (:72-82)
-        if (fabsf(g) < 1e-3f) cosTheta = 1.0f - 2.0f * x0;
-        else { float sq = (1.0f - g * g) / ((1.0f - g) + (2.0f * g) * x0); cosTheta = ((1.0f + g * g) - sq * sq) / (2.0f * g); }
+        float cosTheta = henyey_greenstein_cos(x0, g);
         float sinTheta = sqrtf(fmax2(0.0f, 1.0f - cosTheta * cosTheta));
         float sp, cp; sincos2pi(x1, &sp, &cp); // phi = 2 pi xi.y
         V3 t, b; orthonormal_basis(pl.dir, t, b);
@@ -1833,6 +1855,39 @@ void orc_bsdf_debug(const OrcMaterial* mat, uint32_t count, const float* in, flo
     o[0] = bs.k2.x; o[1] = bs.k2.y; o[2] = bs.k2.z; o[3] = bs.overPdf.x; o[4] = bs.overPdf.y; o[5] = bs.overPdf.z; o[6] = bs.pdf; o[7] = (float)bs.event;
     o[8] = ev.diffuse.x; o[9] = ev.diffuse.y; o[10] = ev.diffuse.z; o[11] = ev.glossy.x; o[12] = ev.glossy.y; o[13] = ev.glossy.z; o[14] = ev.pdf;
   }
+}
+
+
+// ---- restated helpers one by one, for tests/test_oracle_ref.py (oracle/_ref = the reference's own functions compiled from /root/reference)
+void orc_dbg_sample_hemisphere(float x0, float x1, float* out) { V3 v = sample_hemisphere(x0, x1); out[0] = v.x; out[1] = v.y; out[2] = v.z; }
+void orc_dbg_sample_sphere(float x0, float x1, const float* radius, float* out) { V3 v = sample_sphere(x0, x1, v3(radius)); out[0] = v.x; out[1] = v.y; out[2] = v.z; }
+void orc_dbg_sample_disk(float x0, float x1, float rx, float ry, float* out) { sample_disk(x0, x1, rx, ry, out[0], out[1]); }
+float orc_dbg_luminance(const float* c) { return luminance(v3(c)); }
+float orc_dbg_safe_div(float a, float b) { return safe_div(a, b); }
+void orc_dbg_colormap(int which, float t, float* out) { V3 v = which == 0 ? colormap_viridis(t) : colormap_inferno(t); out[0] = v.x; out[1] = v.y; out[2] = v.z; }
+uint32_t orc_dbg_payload_medium_idx(uint32_t bitfield, uint32_t stackSize) { return payload_medium_idx(bitfield, stackSize); }
+uint32_t orc_dbg_payload_increment_walk(uint32_t bitfield) { payload_increment_walk(bitfield); return bitfield; }
+int orc_dbg_russian_roulette(float k, float rrInvMinTermProb, float* thr) { V3 t = v3(thr); bool term = russian_roulette(k, rrInvMinTermProb, t); thr[0] = t.x; thr[1] = t.y; thr[2] = t.z; return term ? 1 : 0; }
+float orc_dbg_sample_distance(const float* albedo, const float* throughput, const float* sigma_t, float xi, float* pdf)
+{ V3 p; float r = sample_distance(v3(albedo), v3(throughput), v3(sigma_t), xi, p); pdf[0] = p.x; pdf[1] = p.y; pdf[2] = p.z; return r; }
+float orc_dbg_hg_cos(float r, float g) { return henyey_greenstein_cos(r, g); }
+void orc_dbg_quat_rotate_dir(const float* q, const float* dir, float* out) { V3 v = quat_rotate_dir(q, v3(dir)); out[0] = v.x; out[1] = v.y; out[2] = v.z; }
+float orc_dbg_apply_wrap_and_crop(float coord, int wrap, int res) { return apply_wrap_and_crop(coord, wrap, res); }
+void orc_dbg_adapt_normal(const float* rayDir, const float* geomNormal, const float* normal, float* out) { V3 v = adapt_normal(v3(rayDir), v3(geomNormal), v3(normal)); out[0] = v.x; out[1] = v.y; out[2] = v.z; }
+// light arrays in the reference's 48-byte layouts (interface/rp_main.h:73-113), 12 dwords per light
+void orc_dbg_sample_light(const uint32_t* counts /* sphere, distant, rect, disk */, float lightIntensityMultiplier, float sensorExposureScale, const float* sphere,
+                          const float* distant, const float* rect, const float* disk, const float* k4, const float* pos, float* dirToLight, float* dist, float* power,
+                          float* invPdf, uint32_t* dsPacked)
+{
+  Prepared P;
+  auto u = [](float f) { uint32_t x; memcpy(&x, &f, 4); return x; };
+  for (uint32_t i = 0; i < counts[0]; i++) { const float* l = sphere + 12 * i; P.sphere.push_back(SphereL{v3(l), u(l[3]), v3(l + 4), l[7], v3(l + 8)}); }
+  for (uint32_t i = 0; i < counts[1]; i++) { const float* l = distant + 12 * i; P.distant.push_back(DistantL{v3(l), l[3], v3(l + 4), u(l[7]), l[11]}); }
+  for (uint32_t i = 0; i < counts[2]; i++) { const float* l = rect + 12 * i; P.rect.push_back(RectL{v3(l), l[3], v3(l + 4), l[7], u(l[8]), u(l[9]), u(l[10])}); }
+  for (uint32_t i = 0; i < counts[3]; i++) { const float* l = disk + 12 * i; P.disk.push_back(DiskL{v3(l), l[3], v3(l + 4), l[7], u(l[8]), u(l[9]), u(l[10])}); }
+  Uniforms ubo{counts[0], counts[1], counts[2], counts[3], counts[0] + counts[1] + counts[2] + counts[3], lightIntensityMultiplier, sensorExposureScale};
+  V3 d, p; sample_light(P, ubo, k4, v3(pos), d, *dist, p, *invPdf, *dsPacked);
+  dirToLight[0] = d.x; dirToLight[1] = d.y; dirToLight[2] = d.z; power[0] = p.x; power[1] = p.y; power[2] = p.z;
 }
 
 } // extern "C"

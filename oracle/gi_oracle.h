@@ -14,9 +14,13 @@
  * the reference's BSDF code lives in the MDL SDK 2024.1.4 + MaterialX (neither is in
  * /root/reference), the reference needs a Vulkan-RT device + OpenUSD to run, and every
  * reference image under src/hdGatling/testenv is a git-LFS stub.
- * What IS pinned here: RNG, octahedral codec, ray offset, FIS, camera, bounce loop,
- * Russian roulette, clamp, accumulate, light sampling -- restated from in-tree shader
- * code and checked against derived known-answer vectors (tests/test_oracle_kat.py).
+ * What IS pinned here: RNG, octahedral codec, ray offset, FIS, sampling maps, payload bit
+ * fields, Russian roulette, volume sampling, light sampling, dome rotation, texture wrap,
+ * normal adaption, colour maps -- checked against the reference's OWN functions, compiled
+ * from /root/reference/src/gi/shaders as C++ (oracle/ref/, oracle/_ref/libgi_ref.so;
+ * tests/test_oracle_ref.py: bit-exact, a few ulp where sin / cos / log are involved) -- and
+ * camera, bounce loop, clamp, accumulate restated from in-tree shader code with derived
+ * known-answer vectors (tests/test_oracle_kat.py).
  *
  * Arithmetic contract shared with the HIP kernels (DESIGN.md section "Arithmetic contract"):
  * fp32 only, no FMA contraction, IEEE +,-,*,/,sqrt, and the two polynomial

@@ -1,0 +1,210 @@
+"""The oracle's restatements against THE REFERENCE'S OWN CODE: oracle/_ref/libgi_ref.so is the set of pure functions of the reference's
+shader sources (common.glsl, colormap.glsl, rp_main_payload.glsl, and fisGauss / russian_roulette / sampleDistance /
+sampleHenyeyGreensteinCos / sampleVolumeScatteringDirection / quatRotateDir / sampleLight / apply_wrap_and_crop / mdl_adapt_normal cut out
+of rp_main.rgen / .miss / .chit / mdl_interface.glsl) compiled as C++ from /root/reference where they lie (oracle/ref/build_ref.py,
+oracle/ref/glsl_compat.h).  Integer / bit-level functions and fp32 arithmetic without transcendentals must agree BIT FOR BIT; functions
+that call sin / cos / log are compared within a few ulp (the reference uses the GPU's, this build libm's, the oracle its polynomials --
+D3 in DESIGN.md).
+
+The library is built here (in the authoring container, where /root/reference exists) and travels to the GPU box prebuilt; without
+either the tests skip."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF_LIB = os.path.join(ROOT, "oracle", "_ref", "libgi_ref.so")
+F3 = C.c_float * 3
+F4 = C.c_float * 4
+
+
+@pytest.fixture(scope="module")
+def ref():
+    if os.path.isdir("/root/reference/src/gi/shaders"):
+        sys.path.insert(0, os.path.join(ROOT, "oracle", "ref"))
+        import build_ref
+        build_ref.build()
+    if not os.path.exists(REF_LIB):
+        pytest.skip("oracle/_ref/libgi_ref.so not built (no /root/reference here)")
+    L = C.CDLL(REF_LIB)
+    for n in ("ref_rng1d_next1f", "ref_uint_as_float", "ref_luminance", "ref_safe_div", "ref_sample_distance", "ref_sample_hg_cos", "ref_apply_wrap_and_crop"):
+        getattr(L, n).restype = C.c_float
+    for n in ("ref_hash_theironborn", "ref_hash_pcg32", "ref_rng1d_init", "ref_encode_direction", "ref_payload_get_medium_idx_0", "ref_payload_get_medium_idx_2",
+              "ref_payload_get_medium_idx_8", "ref_payload_set_medium_idx_0", "ref_payload_set_medium_idx_2", "ref_payload_set_medium_idx_8", "ref_payload_increment_walk",
+              "ref_payload_get_walk"):
+        getattr(L, n).restype = C.c_uint32
+    return L
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import orc as o
+    L = o.lib()
+    for n in ("orc_dbg_luminance", "orc_dbg_safe_div", "orc_dbg_sample_distance", "orc_dbg_hg_cos", "orc_dbg_apply_wrap_and_crop", "orc_rng_next1f"):
+        getattr(L, n).restype = C.c_float
+    for n in ("orc_dbg_payload_medium_idx", "orc_dbg_payload_increment_walk", "orc_rng_init", "orc_hash_pcg32", "orc_encode_direction"):
+        getattr(L, n).restype = C.c_uint32
+    return L
+
+
+def f3(v):
+    return F3(*[float(x) for x in v])
+
+
+def bits(a):
+    return np.asarray(a, np.float32).view(np.uint32)
+
+
+def test_rng_and_hashes_bit_exact(ref, orc):
+    rng = np.random.default_rng(1)
+    for px, s in zip(rng.integers(0, 2 ** 32, 2000, dtype=np.uint64), rng.integers(0, 2 ** 20, 2000, dtype=np.uint64)):
+        assert ref.ref_rng1d_init(C.c_uint32(int(px)), C.c_uint32(int(s))) == orc.orc_rng_init(C.c_uint32(int(px)), C.c_uint32(int(s)))
+    for st in rng.integers(0, 2 ** 32, 2000, dtype=np.uint64):
+        a, b = C.c_uint32(int(st)), C.c_uint32(int(st))
+        assert ref.ref_hash_pcg32(C.byref(a)) == orc.orc_hash_pcg32(C.byref(b)) and a.value == b.value
+        a, b = C.c_uint32(int(st)), C.c_uint32(int(st))
+        fa, fb = ref.ref_rng1d_next1f(C.byref(a)), orc.orc_rng_next1f(C.byref(b))
+        assert bits(fa) == bits(fb) and a.value == b.value and 0.0 <= fa < 1.0
+
+
+def test_geometry_helpers_bit_exact(ref, orc):
+    rng = np.random.default_rng(2)
+    for _ in range(3000):
+        n = rng.normal(size=3); n /= np.linalg.norm(n)
+        if rng.uniform() < 0.1:
+            n = np.eye(3)[rng.integers(0, 3)] * rng.choice([-1.0, 1.0])
+        p = rng.normal(size=3) * 10.0 ** rng.uniform(-4, 3)
+        a1, a2, b1, b2, o1, o2 = F3(), F3(), F3(), F3(), F3(), F3()
+        ref.ref_orthonormal_basis(f3(n), a1, a2); orc.orc_orthonormal_basis(f3(n), b1, b2)
+        assert np.array_equal(bits(a1), bits(b1)) and np.array_equal(bits(a2), bits(b2))
+        ref.ref_offset_ray_origin(f3(p), f3(n), o1); orc.orc_offset_ray_origin(f3(p), f3(n), o2)
+        assert np.array_equal(bits(o1), bits(o2))
+        e = int(rng.integers(0, 2 ** 32))
+        ref.ref_decode_direction(C.c_uint32(e), o1); orc.orc_decode_direction(C.c_uint32(e), o2)
+        assert np.array_equal(bits(o1), bits(o2))
+        # the host packs with glm::packUnorm2x16 (Gi.cpp:287-300), the shader's encode_direction with packUnorm2x16: same code except on exact ties
+        ea, eb = ref.ref_encode_direction(f3(n)), orc.orc_encode_direction(f3(n))
+        assert abs((ea & 0xffff) - (eb & 0xffff)) <= 1 and abs((ea >> 16) - (eb >> 16)) <= 1
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        ref.ref_quat_rotate_dir(F4(*q), f3(n), o1); orc.orc_dbg_quat_rotate_dir(F4(*q), f3(n), o2)
+        assert np.array_equal(bits(o1), bits(o2))
+        c = rng.uniform(0, 4, 3)
+        assert bits(ref.ref_luminance(f3(c))) == bits(orc.orc_dbg_luminance(f3(c)))
+        x, y = float(rng.normal()), float(rng.choice([0.0, rng.normal()]))
+        assert bits(ref.ref_safe_div(C.c_float(x), C.c_float(y))) == bits(orc.orc_dbg_safe_div(C.c_float(x), C.c_float(y)))
+
+
+def test_colormaps_and_wrap_bit_exact(ref, orc):
+    rng = np.random.default_rng(3)
+    a, b = F3(), F3()
+    for t in np.concatenate([rng.uniform(0, 1, 500), [0.0, 1.0, 0.5]]):
+        for which in (0, 1):  # viridis (Opacity AOV), inferno (Bounces AOV)
+            ref.ref_colormap(which, C.c_float(t), a); orc.orc_dbg_colormap(which, C.c_float(t), b)
+            assert np.array_equal(bits(a), bits(b))
+    for coord in np.concatenate([rng.uniform(-3, 3, 2000), [0.0, 1.0, -1.0, 2.0, 0.5]]):
+        for wrap in (0, 1, 2):  # clamp, repeat, mirrored repeat (clip is decided before the call); crop = (0, 1) as everywhere in the reference
+            for res in (1, 4, 7, 256):
+                r = ref.ref_apply_wrap_and_crop(C.c_float(coord), wrap, C.c_float(0.0), C.c_float(1.0), res)
+                o = orc.orc_dbg_apply_wrap_and_crop(C.c_float(coord), wrap, res)
+                assert bits(r) == bits(o), (coord, wrap, res)
+
+
+def test_payload_bitfield_helpers_bit_exact(ref, orc):
+    rng = np.random.default_rng(4)
+    for bf in np.concatenate([rng.integers(0, 2 ** 32, 4000, dtype=np.uint64), [0, 0xffffffff, 0x0f000000, 0x00fff000, 0x00ffe000]]):
+        bf = int(bf)
+        for n in (0, 2, 8):
+            assert getattr(ref, f"ref_payload_get_medium_idx_{n}")(C.c_uint32(bf)) == orc.orc_dbg_payload_medium_idx(C.c_uint32(bf), n)
+        # the walk counter quirk (the +1 lands in the unshifted field) is the reference's, kept literally
+        assert ref.ref_payload_increment_walk(C.c_uint32(bf)) == orc.orc_dbg_payload_increment_walk(C.c_uint32(bf))
+
+
+def test_bounce_loop_pieces_bit_exact(ref, orc):
+    rng = np.random.default_rng(5)
+    pa, pb = F3(), F3()
+    for _ in range(3000):
+        thr = rng.uniform(0, 2, 3) * rng.choice([1.0, 1e-3])
+        k, rr = float(rng.uniform()), float(rng.choice([0.95, 0.5, 1.0]))
+        ta, tb = f3(thr), f3(thr)
+        assert ref.ref_russian_roulette(C.c_float(k), C.c_float(rr), ta) == orc.orc_dbg_russian_roulette(C.c_float(k), C.c_float(rr), tb)
+        assert np.array_equal(bits(ta), bits(tb))
+        alb, sig = rng.uniform(0, 1, 3), rng.uniform(0.1, 5, 3)
+        if rng.uniform() < 0.1:
+            thr = np.zeros(3)
+        xi = float(rng.uniform())
+        a = ref.ref_sample_distance(f3(alb), f3(thr), f3(sig), C.c_float(xi), pa)
+        b = orc.orc_dbg_sample_distance(f3(alb), f3(thr), f3(sig), C.c_float(xi), pb)
+        assert bits(a) == bits(b) and np.array_equal(bits(pa), bits(pb))
+        r, g = float(rng.uniform()), float(rng.choice([0.0, 5e-4, rng.uniform(-0.95, 0.95)]))
+        assert bits(ref.ref_sample_hg_cos(C.c_float(r), C.c_float(g))) == bits(orc.orc_dbg_hg_cos(C.c_float(r), C.c_float(g)))
+
+
+def test_sampling_maps_within_transcendental_tolerance(ref, orc):
+    """sin / cos / log differ between the GPU's built-ins, libm (this build) and the oracle's polynomials (|err| < 4e-7): a few ulp here."""
+    rng = np.random.default_rng(6)
+    a, b = F3(), F3()
+    a2, b2 = (C.c_float * 2)(), (C.c_float * 2)()
+    for _ in range(2000):
+        x0, x1 = float(rng.uniform()), float(rng.uniform())
+        ref.ref_sample_hemisphere(C.c_float(x0), C.c_float(x1), a); orc.orc_dbg_sample_hemisphere(C.c_float(x0), C.c_float(x1), b)
+        np.testing.assert_allclose(np.array(a), np.array(b), atol=1e-6)
+        rad = rng.uniform(0.1, 3, 3)
+        ref.ref_sample_sphere(C.c_float(x0), C.c_float(x1), f3(rad), a); orc.orc_dbg_sample_sphere(C.c_float(x0), C.c_float(x1), f3(rad), b)
+        np.testing.assert_allclose(np.array(a), np.array(b), atol=4e-6)
+        ref.ref_sample_disk(C.c_float(x0), C.c_float(x1), C.c_float(rad[0]), C.c_float(rad[1]), a2); orc.orc_dbg_sample_disk(C.c_float(x0), C.c_float(x1), C.c_float(rad[0]), C.c_float(rad[1]), b2)
+        np.testing.assert_allclose(np.array(a2), np.array(b2), atol=4e-6)
+        ref.ref_fis_gauss(C.c_float(x0), C.c_float(x1), a2); orc.orc_fis_gauss(C.c_float(x0), C.c_float(x1), b2)
+        np.testing.assert_allclose(np.array(a2), np.array(b2), atol=4e-6)
+        # mdl_adapt_normal: normalize / reflect chains only
+        rd = rng.normal(size=3); rd /= np.linalg.norm(rd)
+        gn = rng.normal(size=3); gn /= np.linalg.norm(gn)
+        if np.dot(gn, rd) > 0:
+            gn = -gn
+        nn = gn + 0.4 * rng.normal(size=3); nn /= np.linalg.norm(nn)
+        ref.ref_adapt_normal(f3(rd), f3(gn), f3(nn), f3(nn), a); orc.orc_dbg_adapt_normal(f3(rd), f3(gn), f3(nn), b)
+        np.testing.assert_allclose(np.array(a), np.array(b), atol=2e-6)
+
+
+def test_sample_light_matches_reference_chit(ref, orc):
+    """sampleLight (rp_main.chit:28-129) on all four light types through the reference's 48-byte light layouts (interface/rp_main.h:73-113):
+    selection, sample position, pdf, power and the packed diffuse / specular multipliers."""
+    from gatling_amd.scene import RectLight  # noqa: F401  (layouts are spelled out below)
+    rng = np.random.default_rng(7)
+    assert [ref.ref_light_struct_sizes(i) for i in range(4)] == [48, 48, 48, 48]
+
+    class Setup(C.Structure):
+        _fields_ = [("counts", C.c_uint32 * 4), ("mult", C.c_float), ("exposure", C.c_float), ("sphere", C.c_void_p), ("distant", C.c_void_p), ("rect", C.c_void_p), ("disk", C.c_void_p)]
+    for counts in ((2, 0, 0, 0), (0, 2, 0, 0), (0, 0, 3, 0), (0, 0, 0, 2), (1, 1, 2, 1), (0, 1, 1, 0)):
+        arrs = []
+        for kind, n in enumerate(counts):
+            a = np.zeros((max(n, 1), 12), np.float32)
+            for i in range(n):
+                t0 = rng.normal(size=3); t0 /= np.linalg.norm(t0)
+                t1 = np.cross(t0, rng.normal(size=3)); t1 /= np.linalg.norm(t1)
+                ds = np.uint32(int(rng.integers(0, 2 ** 32)))
+                if kind == 0:
+                    a[i] = [*rng.uniform(-2, 2, 3), 0, *rng.uniform(0, 5, 3), rng.uniform(0.1, 4), *rng.uniform(0.05, 0.5, 3), 0]; a[i].view(np.uint32)[3] = ds
+                elif kind == 1:
+                    d = rng.normal(size=3); d /= np.linalg.norm(d)
+                    a[i] = [*d, rng.choice([0.0, 0.05]), *rng.uniform(0, 5, 3), 0, 0, 0, 0, rng.uniform(0.5, 2)]; a[i].view(np.uint32)[7] = ds
+                else:
+                    a[i] = [*rng.uniform(-2, 2, 3), rng.uniform(0.2, 2), *rng.uniform(0, 5, 3), rng.uniform(0.2, 2), 0, 0, 0, 0]
+                    a[i].view(np.uint32)[8] = orc.orc_encode_direction(f3(t0)); a[i].view(np.uint32)[9] = orc.orc_encode_direction(f3(t1)); a[i].view(np.uint32)[10] = ds
+            arrs.append(np.ascontiguousarray(a))
+        s = Setup((C.c_uint32 * 4)(*counts), 1.5, 0.0, *[x.ctypes.data for x in arrs])
+        for _ in range(400):
+            k4, pos = F4(*rng.uniform(0, 1, 4)), f3(rng.uniform(-3, 3, 3))
+            da, db, pa, pb = F3(), F3(), F3(), F3()
+            dist_a, dist_b, ip_a, ip_b, ds_a, ds_b = C.c_float(), C.c_float(), C.c_float(), C.c_float(), C.c_uint32(), C.c_uint32()
+            ref.ref_sample_light(C.byref(s), k4, pos, da, C.byref(dist_a), pa, C.byref(ip_a), C.byref(ds_a))
+            orc.orc_dbg_sample_light((C.c_uint32 * 4)(*counts), C.c_float(1.5), C.c_float(1.0), arrs[0].ctypes.data_as(C.POINTER(C.c_float)), arrs[1].ctypes.data_as(C.POINTER(C.c_float)),
+                                     arrs[2].ctypes.data_as(C.POINTER(C.c_float)), arrs[3].ctypes.data_as(C.POINTER(C.c_float)), k4, pos, db, C.byref(dist_b), pb, C.byref(ip_b), C.byref(ds_b))
+            assert ds_a.value == ds_b.value
+            np.testing.assert_allclose(np.array(da), np.array(db), atol=3e-6)
+            np.testing.assert_allclose(dist_a.value, dist_b.value, rtol=3e-6)
+            np.testing.assert_allclose(np.array(pa), np.array(pb), rtol=1e-6)
+            np.testing.assert_allclose(ip_a.value, ip_b.value, rtol=2e-5, atol=1e-7)
