@@ -1874,6 +1874,34 @@ float orc_dbg_hg_cos(float r, float g) { return henyey_greenstein_cos(r, g); }
 void orc_dbg_quat_rotate_dir(const float* q, const float* dir, float* out) { V3 v = quat_rotate_dir(q, v3(dir)); out[0] = v.x; out[1] = v.y; out[2] = v.z; }
 float orc_dbg_apply_wrap_and_crop(float coord, int wrap, int res) { return apply_wrap_and_crop(coord, wrap, res); }
 void orc_dbg_adapt_normal(const float* rayDir, const float* geomNormal, const float* normal, float* out) { V3 v = adapt_normal(v3(rayDir), v3(geomNormal), v3(normal)); out[0] = v.x; out[1] = v.y; out[2] = v.z; }
+// setup_shading_state for one triangle given as three GiVertex (48 B each), the mesh transform and one instance transform (4x4 row-major,
+// USD convention).  out: position, normal, geom normal, tangentU, tangentV, (u, v, frontFace); fvertexOut (24 floats) = the packed vertices
+// the host uploads (rp_main.h:58-64), o2wOut (12) / w2oOut (9) = the composed object-to-world rows and the inverse of its 3x3 part.
+void orc_dbg_shading_state(const OrcVertex* verts, const float* meshTransform, const float* instanceTransform, const float* rayDir, float bu, float bv, float* out,
+                           float* fvertexOut, float* o2wOut, float* w2oOut)
+{
+  Prepared P;
+  static const uint32_t faces[3] = {0u, 1u, 2u};
+  MeshData d; d.faces = faces; d.faceCount = 1; d.material = 0; d.flags = 0; d.objectId = 0; d.faceIdStride = 1; d.src = nullptr;
+  for (int i = 0; i < 3; i++) d.verts.push_back(FVertex{v3(verts[i].pos), verts[i].bitangentSign, encode_direction(v3(verts[i].norm)), encode_direction(v3(verts[i].tangent)), verts[i].u, verts[i].v});
+  P.meshes.push_back(d);
+  Instance inst; inst.mesh = 0; inst.instanceId = 0;
+  compose_transform(meshTransform, instanceTransform, inst.o2w);
+  invert3x3(inst.o2w, inst.w2o);
+  P.instances.push_back(inst);
+  P.tris.push_back(Tri{v3(0, 0, 0), v3(0, 0, 0), v3(0, 0, 0), 0u, 0u, 1.0f, -1});
+  Hit h; h.t = 1.0f; h.u = bu; h.v = bv; h.tri = 0;
+  State st; const MeshData* m;
+  setup_shading_state(P, h, v3(rayDir), st, m);
+  const V3 o[5] = {st.position, st.normal, st.geomNormal, st.tangentU, st.tangentV};
+  for (int i = 0; i < 5; i++) { out[3 * i] = o[i].x; out[3 * i + 1] = o[i].y; out[3 * i + 2] = o[i].z; }
+  out[15] = st.u; out[16] = st.v; out[17] = st.frontFace ? 1.0f : 0.0f;
+  for (int i = 0; i < 3; i++) {
+    const FVertex& v = P.meshes[0].verts[i]; float* f = fvertexOut + 8 * i;
+    f[0] = v.pos.x; f[1] = v.pos.y; f[2] = v.pos.z; f[3] = v.bsign; memcpy(&f[4], &v.n, 4); memcpy(&f[5], &v.t, 4); f[6] = v.u; f[7] = v.v;
+  }
+  memcpy(o2wOut, inst.o2w, sizeof(inst.o2w)); memcpy(w2oOut, inst.w2o, sizeof(inst.w2o));
+}
 // light arrays in the reference's 48-byte layouts (interface/rp_main.h:73-113), 12 dwords per light
 void orc_dbg_sample_light(const uint32_t* counts /* sphere, distant, rect, disk */, float lightIntensityMultiplier, float sensorExposureScale, const float* sphere,
                           const float* distant, const float* rect, const float* disk, const float* k4, const float* pos, float* dirToLight, float* dist, float* power,

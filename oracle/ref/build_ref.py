@@ -6,7 +6,7 @@ GLSL is not C++: the recipe (a) writes lightly rewritten copies of the needed sh
 git-ignored, never committed -- where the only edits are the ones the language difference forces (parameter qualifiers `in` / `out` /
 `inout` become by-value / reference parameters, `#extension` lines go), and (b) compiles oracle/ref/ref_shim.cpp, which includes them
 under oracle/ref/glsl_compat.h (`float` -> a strict-fp32 class, vec types, the built-ins these functions use).  Whole files: common.glsl,
-aovs.glsl, colormap.glsl, rp_main_payload.glsl, interface/rp_main.h, interface/gtl.h is replaced by the shim's macros.  Single functions, cut
+aovs.glsl, colormap.glsl, rp_main_payload.glsl, mdl_shading_state.glsl, interface/rp_main.h; interface/gtl.h is replaced by the shim's macros.  Single functions, cut
 out by name: fisGauss, russian_roulette, sampleDistance, sampleHenyeyGreensteinCos, sampleVolumeScatteringDirection (rp_main.rgen),
 quatRotateDir (rp_main.miss), sampleLight (rp_main.chit), apply_wrap_and_crop, mdl_adapt_normal (mdl_interface.glsl).
 
@@ -24,7 +24,7 @@ OUT = os.path.join(os.path.dirname(HERE), "_ref")
 GEN = os.path.join(OUT, "gen")
 LIB = os.path.join(OUT, "libgi_ref.so")
 
-WHOLE = ["common.glsl", "aovs.glsl", "colormap.glsl", "rp_main_payload.glsl", "interface/rp_main.h"]
+WHOLE = ["common.glsl", "aovs.glsl", "colormap.glsl", "rp_main_payload.glsl", "interface/rp_main.h", "mdl_shading_state.glsl"]
 FUNCTIONS = {"rp_main.rgen": ["sampleDistance", "sampleHenyeyGreensteinCos", "sampleVolumeScatteringDirection", "russian_roulette", "fisGauss"],
              "rp_main.miss": ["quatRotateDir"], "rp_main.chit": ["sampleLight"], "mdl_interface.glsl": ["apply_wrap_and_crop", "mdl_adapt_normal"]}
 

@@ -101,10 +101,16 @@ struct vec4 {
   vec4() : x(0.0f), y(0.0f), z(0.0f), w(0.0f) {}
   vec4(Float a) : x(a), y(a), z(a), w(a) {}
   vec4(Float a, Float b, Float c, Float d) : x(a), y(b), z(c), w(d) {}
+  vec4(const vec3& v, Float d) : x(v.x), y(v.y), z(v.z), w(d) {}
   vec2 xy() const { return vec2(x, y); }
   vec2 zw() const { return vec2(z, w); }
   vec3 xyz() const { return vec3(x, y, z); }
 };
+// Matrices, column-major as in GLSL; products accumulate left to right (GLSL leaves the order to the driver; this is the oracle's order too,
+// so comparisons through these test the STRUCTURE of a computation -- which transform, which transpose -- not the driver's rounding)
+struct mat4x3 { vec3 c[4]; };                       // 4 columns of vec3 (gl_ObjectToWorldEXT / gl_WorldToObjectEXT)
+struct mat3 { vec3 c[3]; mat3() {} explicit mat3(const mat4x3& m) { c[0] = m.c[0]; c[1] = m.c[1]; c[2] = m.c[2]; } };
+inline vec4 make_vec4(const vec3& v, Float w) { return vec4(v.x, v.y, v.z, w); }
 struct uvec2 { uint x, y; };
 struct uvec4 {
   uint x, y, z, w;
@@ -135,6 +141,8 @@ inline Float length(const vec3& a) { return sqrt(dot(a, a)); }
 inline vec3 normalize(const vec3& a) { return a * (Float(1.0f) / sqrt(dot(a, a))); } // GLSL: x * inversesqrt(dot(x, x)); driver-defined ulp
 inline vec3 reflect(const vec3& i, const vec3& n) { return i - Float(2.0f) * dot(n, i) * n; }
 inline vec3 cross(const vec3& a, const vec3& b) { return vec3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+inline vec3 operator*(const mat4x3& m, const vec4& v) { return ((m.c[0] * v.x + m.c[1] * v.y) + m.c[2] * v.z) + m.c[3] * v.w; }
+inline vec3 operator*(const vec3& v, const mat3& m) { return vec3(dot(v, m.c[0]), dot(v, m.c[1]), dot(v, m.c[2])); }
 inline bvec3 greaterThanEqual(const vec3& a, const vec3& b) { return bvec3{a.x >= b.x, a.y >= b.y, a.z >= b.z}; }
 struct bvec2 { bool x, y; };
 inline bvec2 notEqual(const vec2& a, const vec2& b) { return bvec2{a.x != b.x, a.y != b.y}; }

@@ -31,7 +31,14 @@ using namespace glsl;
 static UniformData ubo;
 static const SphereLight* sphereLights; static const DistantLight* distantLights; static const RectLight* rectLights; static const DiskLight* diskLights;
 static vec3 gl_WorldRayDirectionEXT;
-struct State { vec3 normal; vec3 geom_normal; }; // the two members mdl_adapt_normal reads (mdl_types.glsl State)
+struct State { vec3 normal; vec3 geom_normal; vec3 position; vec3 tangent_u[1]; vec3 tangent_v[1]; vec3 text_coords[1]; }; // the members used here of mdl_types.glsl's State
+// what setup_mdl_shading_state reads besides its arguments: ray-tracing built-ins and the buffer references of rp_main_descriptors.glsl
+static mat4x3 gl_ObjectToWorldEXT, gl_WorldToObjectEXT;
+static uint gl_InstanceCustomIndexEXT = 0, gl_PrimitiveID = 0;
+static BlasPayload blas_payloads[1];
+static const Face* g_faces; static const FVertex* g_vertices;
+struct IndexBuffer { const Face* data; BlasPayloadBufferPreamble preamble; IndexBuffer(uint64_t) : data(g_faces), preamble() {} };
+struct VertexBuffer { const FVertex* data; VertexBuffer(uint64_t) : data(g_vertices) {} };
 #define TEX_WRAP_CLAMP 0
 #define TEX_WRAP_REPEAT 1
 #define TEX_WRAP_MIRRORED_REPEAT 2
@@ -60,6 +67,7 @@ namespace stack8 {
 #include "fn_sampleLight.h"
 #include "fn_apply_wrap_and_crop.h"
 #include "fn_mdl_adapt_normal.h"
+#include "mdl_shading_state.glsl"
 #undef float
 } // namespace ref
 
@@ -116,6 +124,23 @@ void ref_sample_light(const RefLightSetup* L, const float* k4, const float* surf
   vec3 d, p; Float di, ip; glsl::uint ds = 0;
   ref::sampleLight(vec4(k4[0], k4[1], k4[2], k4[3]), V3(surfacePos), d, di, p, ip, ds);
   put(dirToLight, d); *dist = di.v; put(power, p); *invPdf = ip.v; *diffuseSpecularPacked = ds;
+}
+// ---- mdl_shading_state.glsl: setup_mdl_shading_state for ONE triangle.  fvertex: 3 x 8 floats in the reference's packed vertex layout
+// (rp_main.h:58-64: pos, bitangent sign | encoded normal, encoded tangent (uint bits), u, v); o2w: 3x4 rows; w2o: 3x3 rows.
+// out: position, normal, geom normal, tangent_u, tangent_v, (u, v, frontFace)
+void ref_setup_shading_state(const float* fvertex, const float* o2w, const float* w2o, const float* rayDir, float bu, float bv, float* out)
+{
+  static const ref::Face face{0u, 1u, 2u};
+  ref::g_faces = &face; ref::g_vertices = (const ref::FVertex*)fvertex;
+  ref::blas_payloads[0].bufferAddress = 0; ref::blas_payloads[0].vertexOffset = 0; ref::blas_payloads[0].bitfield = 0;
+  for (int c = 0; c < 4; c++) ref::gl_ObjectToWorldEXT.c[c] = vec3(o2w[c], o2w[4 + c], o2w[8 + c]);
+  for (int c = 0; c < 3; c++) ref::gl_WorldToObjectEXT.c[c] = vec3(w2o[c], w2o[3 + c], w2o[6 + c]);
+  ref::gl_WorldToObjectEXT.c[3] = vec3(0.0f);
+  ref::gl_WorldRayDirectionEXT = V3(rayDir);
+  ref::State st; bool front = false;
+  ref::setup_mdl_shading_state(vec2(bu, bv), st, front);
+  put(out, st.position); put(out + 3, st.normal); put(out + 6, st.geom_normal); put(out + 9, st.tangent_u[0]); put(out + 12, st.tangent_v[0]);
+  out[15] = st.text_coords[0].x.v; out[16] = st.text_coords[0].y.v; out[17] = front ? 1.0f : 0.0f;
 }
 int ref_light_struct_sizes(int which) { return which == 0 ? (int)sizeof(ref::SphereLight) : which == 1 ? (int)sizeof(ref::DistantLight) : which == 2 ? (int)sizeof(ref::RectLight) : (int)sizeof(ref::DiskLight); }
 }
