@@ -9,7 +9,8 @@
 // (RNG, hashes, orthonormal basis, ray offset, octahedral codec, sampling maps, colour maps, payload bit fields, Russian
 // roulette, volume sampling, dome rotation, wrap / crop, normal adaption, sampleLight) are compared bit for bit -- within a
 // few ulp where sin / cos / log are involved -- with those functions compiled from /root/reference/src/gi/shaders
-// (oracle/ref/build_ref.py -> oracle/_ref/libgi_ref.so, tests/test_oracle_ref.py).
+// (oracle/ref/build_ref.py -> oracle/_ref/libgi_ref.so, tests/test_oracle_ref.py); the render loop as a whole is compared with the
+// reference's rgen / chit / miss shaders run on the CPU (oracle/ref/ref_loop.cpp, tests/test_oracle_ref_loop.py).
 
 #include "gi_oracle.h"
 
@@ -1916,6 +1917,82 @@ void orc_dbg_sample_light(const uint32_t* counts /* sphere, distant, rect, disk 
   Uniforms ubo{counts[0], counts[1], counts[2], counts[3], counts[0] + counts[1] + counts[2] + counts[3], lightIntensityMultiplier, sensorExposureScale};
   V3 d, p; sample_light(P, ubo, k4, v3(pos), d, *dist, p, *invPdf, *dsPacked);
   dirToLight[0] = d.x; dirToLight[1] = d.y; dirToLight[2] = d.z; power[0] = p.x; power[1] = p.y; power[2] = p.z;
+}
+
+// ---- hooks for oracle/ref/ref_loop.cpp: the reference's rp_main.rgen / .chit / .miss compiled as C++ call back here for what the
+// reference gets from the Vulkan driver and the MDL code generator -- the scene as the host packs it, ray queries, the closed-form
+// BSDF / EDF entry points.  Everything else (sample loop, camera, bounce loop, NEE, Russian roulette, volumes, accumulation) is the
+// reference's own text there, and tests/test_oracle_ref_loop.py compares its images with orc_render's.
+struct OrcHook {
+  Prepared P; Frame F; OrcCamera cam; OrcSettings rs; OrcRegion rg;
+  std::vector<std::vector<float>> packedVerts;                 // per mesh: 8 floats per vertex, rp_main.h:58-64
+  std::vector<float> lights[4];                                // 12 floats per light, rp_main.h:73-113
+};
+void* orc_hook_open(const OrcScene* scene, const OrcCamera* camera, const OrcSettings* settings, const OrcRegion* region)
+{
+  OrcHook* H = new OrcHook(); H->cam = *camera; H->rs = *settings; H->rg = *region;
+  prepare(scene, H->P); make_frame(H->F, H->P, &H->cam, &H->rs, &H->rg);
+  for (const MeshData& m : H->P.meshes) {
+    std::vector<float> pv(m.verts.size() * 8);
+    for (size_t i = 0; i < m.verts.size(); i++) { const FVertex& v = m.verts[i]; float* f = &pv[8 * i]; f[0] = v.pos.x; f[1] = v.pos.y; f[2] = v.pos.z; f[3] = v.bsign; memcpy(&f[4], &v.n, 4); memcpy(&f[5], &v.t, 4); f[6] = v.u; f[7] = v.v; }
+    H->packedVerts.push_back(std::move(pv));
+  }
+  auto put3 = [](float* d, V3 v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; };
+  auto putu = [](float* d, uint32_t u) { memcpy(d, &u, 4); };
+  for (const SphereL& l : H->P.sphere) { float f[12] = {0}; put3(f, l.pos); putu(f + 3, l.ds); put3(f + 4, l.em); f[7] = l.area; put3(f + 8, l.radius); H->lights[0].insert(H->lights[0].end(), f, f + 12); }
+  for (const DistantL& l : H->P.distant) { float f[12] = {0}; put3(f, l.dir); f[3] = l.angle; put3(f + 4, l.em); putu(f + 7, l.ds); f[11] = l.invPdf; H->lights[1].insert(H->lights[1].end(), f, f + 12); }
+  for (const RectL& l : H->P.rect) { float f[12] = {0}; put3(f, l.origin); f[3] = l.width; put3(f + 4, l.em); f[7] = l.height; putu(f + 8, l.t0); putu(f + 9, l.t1); putu(f + 10, l.ds); H->lights[2].insert(H->lights[2].end(), f, f + 12); }
+  for (const DiskL& l : H->P.disk) { float f[12] = {0}; put3(f, l.origin); f[3] = l.rx; put3(f + 4, l.em); f[7] = l.ry; putu(f + 8, l.t0); putu(f + 9, l.t1); putu(f + 10, l.ds); H->lights[3].insert(H->lights[3].end(), f, f + 12); }
+  return H;
+}
+void orc_hook_close(void* h) { delete (OrcHook*)h; }
+// out: background rgb (fallback dome texel), lens radius, clip range packed (as uint bits), exposure
+void orc_hook_frame(void* h, float* out) { OrcHook* H = (OrcHook*)h; out[0] = H->F.background.x; out[1] = H->F.background.y; out[2] = H->F.background.z; out[3] = H->F.lensRadius; uint32_t cr = pack_half2x16(H->cam.clipStart, H->cam.clipEnd); memcpy(&out[4], &cr, 4); }
+int orc_hook_trace(void* h, const float* o, const float* d, float tMin, float tMax, int anyHit, uint32_t rng, float* tuv, uint32_t* instPrim)
+{
+  OrcHook* H = (OrcHook*)h;
+  if (anyHit) return trace_any(H->P, v3(o), v3(d), tMin, tMax, rng) ? 1 : 0;
+  Hit hit;
+  if (!trace_closest(H->P, v3(o), v3(d), tMin, tMax, hit, rng)) return 0;
+  tuv[0] = hit.t; tuv[1] = hit.u; tuv[2] = hit.v; instPrim[0] = H->P.tris[hit.tri].instance; instPrim[1] = H->P.tris[hit.tri].prim;
+  return 1;
+}
+void orc_hook_instance(void* h, uint32_t inst, float* o2w, float* w2o, int32_t* info /* mesh, flags, material, objectId, instanceId */)
+{
+  OrcHook* H = (OrcHook*)h; const Instance& I = H->P.instances[inst]; const MeshData& m = H->P.meshes[I.mesh];
+  memcpy(o2w, I.o2w, sizeof(I.o2w)); memcpy(w2o, I.w2o, sizeof(I.w2o));
+  info[0] = (int32_t)I.mesh; info[1] = (int32_t)m.flags; info[2] = m.material; info[3] = m.objectId; info[4] = I.instanceId;
+}
+const float* orc_hook_mesh_vertices(void* h, uint32_t mesh) { return ((OrcHook*)h)->packedVerts[mesh].data(); }
+const uint32_t* orc_hook_mesh_faces(void* h, uint32_t mesh) { return ((OrcHook*)h)->P.meshes[mesh].faces; }
+void orc_hook_lights(void* h, uint32_t* counts, const float** ptrs) { OrcHook* H = (OrcHook*)h; for (int i = 0; i < 4; i++) { counts[i] = (uint32_t)(H->lights[i].size() / 12); ptrs[i] = H->lights[i].data(); } }
+// out: klass, emission rgb, sigma_a rgb, sigma_s rgb, ior, anisotropy, thinWalled
+void orc_hook_material(void* h, uint32_t mat, float* out)
+{
+  OrcHook* H = (OrcHook*)h; const OrcMaterial& m = H->P.materials[mat];
+  for (int i = 0; i < 13; i++) out[i] = 0.0f;
+  out[0] = (float)m.klass; out[1] = m.p[ORC_P_EMISSION]; out[2] = m.p[ORC_P_EMISSION + 1]; out[3] = m.p[ORC_P_EMISSION + 2]; out[10] = 1.0f;
+  if (m.klass == ORC_MAT_OPEN_PBR) { OpbrParams o = opbr_params(m); out[4] = o.sigmaA.x; out[5] = o.sigmaA.y; out[6] = o.sigmaA.z; out[7] = o.sigmaS.x; out[8] = o.sigmaS.y; out[9] = o.sigmaS.z; out[10] = o.eta; out[11] = o.anisotropy; out[12] = o.thinWalled ? 1.0f : 0.0f; }
+}
+static inline void hook_state(State& st, const float* frame, float ior1, float ior2, int thin)
+{ st.normal = v3(frame); st.tangentU = v3(frame + 3); st.tangentV = v3(frame + 6); st.geomNormal = v3(frame + 9); st.position = v3(0, 0, 0); st.u = st.v = 0.0f; st.frontFace = true; st.ior1 = ior1; st.ior2 = ior2; st.thinWalled = thin != 0; }
+void orc_hook_bsdf_sample(void* h, uint32_t mat, const float* frame, const float* k1, const float* xi, float ior1, float ior2, int thin, float* out)
+{
+  State st; hook_state(st, frame, ior1, ior2, thin);
+  BsdfSample bs; bsdf_sample(((OrcHook*)h)->P.materials[mat], st, v3(k1), xi, bs);
+  out[0] = bs.k2.x; out[1] = bs.k2.y; out[2] = bs.k2.z; out[3] = bs.overPdf.x; out[4] = bs.overPdf.y; out[5] = bs.overPdf.z; out[6] = bs.pdf; uint32_t e = bs.event; memcpy(&out[7], &e, 4);
+}
+void orc_hook_bsdf_evaluate(void* h, uint32_t mat, const float* frame, const float* k1, const float* k2, float ior1, float ior2, int thin, float* out)
+{
+  State st; hook_state(st, frame, ior1, ior2, thin);
+  BsdfEval ev; bsdf_evaluate(((OrcHook*)h)->P.materials[mat], st, v3(k1), v3(k2), ev);
+  out[0] = ev.diffuse.x; out[1] = ev.diffuse.y; out[2] = ev.diffuse.z; out[3] = ev.glossy.x; out[4] = ev.glossy.y; out[5] = ev.glossy.z; out[6] = ev.pdf;
+}
+void orc_hook_edf_factor(void* h, uint32_t mat, float c, float* out)
+{
+  const OrcMaterial& m = ((OrcHook*)h)->P.materials[mat]; V3 f = v3(1, 1, 1);
+  if (m.klass == ORC_MAT_OPEN_PBR) { float cior = m.p[ORC_P_COAT_IOR], qc = (cior - 1.0f) / (cior + 1.0f); f = opbr_emission_factor(m.p[ORC_P_CLEARCOAT], v3(m.p + ORC_P_COAT_COLOR), qc * qc, c); }
+  out[0] = f.x; out[1] = f.y; out[2] = f.z;
 }
 
 } // extern "C"

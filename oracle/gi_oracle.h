@@ -19,8 +19,10 @@
  * normal adaption, colour maps -- checked against the reference's OWN functions, compiled
  * from /root/reference/src/gi/shaders as C++ (oracle/ref/, oracle/_ref/libgi_ref.so;
  * tests/test_oracle_ref.py: bit-exact, a few ulp where sin / cos / log are involved) -- and
- * camera, bounce loop, clamp, accumulate restated from in-tree shader code with derived
- * known-answer vectors (tests/test_oracle_kat.py).
+ * the whole render loop: rp_main.rgen / .chit / .miss / _shadow.miss compiled the same way and
+ * RUN (oracle/ref/ref_loop.cpp; this oracle only answers their ray queries and MDL entry
+ * points through the orc_hook_* functions), images compared with orc_render's in
+ * tests/test_oracle_ref_loop.py: bit-identical on 90-100 % of the pixels, 4e-5 on the rest.
  *
  * Arithmetic contract shared with the HIP kernels (DESIGN.md section "Arithmetic contract"):
  * fp32 only, no FMA contraction, IEEE +,-,*,/,sqrt, and the two polynomial

@@ -33,7 +33,9 @@ def to_cpp(text: str) -> str:
     text = re.sub(r"^\s*#\s*extension[^\n]*\n", "\n", text, flags=re.M)
     text = re.sub(r"\b(?:inout|out)\s+(\w+)\s+(\w+)\s*([,)])", r"\1& \2\3", text)  # out / inout parameters -> references
     text = re.sub(r"\bin\s+(\w+)\s+(\w+)\s*([,)])", r"\1 \2\3", text)              # in parameters -> by value
-    text = re.sub(r"(?<=[\w\)\]])\.(xy|yx|zw|xyz|r|g|b)\b(?!\s*\()", r".\1()", text)      # swizzle reads -> member functions (glsl_compat.h)
+    text = re.sub(r"(?<=[\w\)\]])\.(xy|yx|zw|xyz|rgb|r|g|b)\b(?!\s*\()", r".\1()", text)      # swizzle reads -> member functions (glsl_compat.h)
+    # GLSL evaluates constructor arguments left to right; C++ does so only in a braced list (the draws of rng1d_next2f / next4f, common.glsl:106-119)
+    text = re.sub(r"return (vec[24])\(((?:\s*rng1d_next1f\(rng_state\)\s*,?)+)\s*\);", r"return \1{\2};", text)
     return text
 
 
@@ -51,6 +53,83 @@ def cut_function(text: str, name: str) -> str:
     return text[m.start():j] + "\n"
 
 
+LOOP_WHOLE = ["common.glsl", "aovs.glsl", "colormap.glsl", "rp_main_payload.glsl", "interface/rp_main.h", "mdl_types.glsl", "mdl_shading_state.glsl",
+              "rp_main_descriptors.glsl", "rp_main.rgen", "rp_main.chit", "rp_main.miss", "rp_main_shadow.miss"]
+# (name, -D flags): the feature macros GlslShaderGen.cpp derives from the render settings (src/gi/impl/GlslShaderGen.cpp:196-300)
+LOOP_VARIANTS = [("default", ["JITTERED_SAMPLING", "FILTER_IMPORTANCE_SAMPLING", "PROGRESSIVE_ACCUMULATION", "DOME_LIGHT_CAMERA_VISIBLE", "MEDIUM_STACK_SIZE=0"]),
+                 ("nee", ["JITTERED_SAMPLING", "FILTER_IMPORTANCE_SAMPLING", "PROGRESSIVE_ACCUMULATION", "DOME_LIGHT_CAMERA_VISIBLE", "MEDIUM_STACK_SIZE=0", "NEXT_EVENT_ESTIMATION"]),
+                 ("nee_stack2", ["JITTERED_SAMPLING", "FILTER_IMPORTANCE_SAMPLING", "PROGRESSIVE_ACCUMULATION", "DOME_LIGHT_CAMERA_VISIBLE", "MEDIUM_STACK_SIZE=2", "NEXT_EVENT_ESTIMATION"]),
+                 ("dof_clip_box", ["JITTERED_SAMPLING", "PROGRESSIVE_ACCUMULATION", "DOME_LIGHT_CAMERA_VISIBLE", "MEDIUM_STACK_SIZE=0", "DEPTH_OF_FIELD", "CLIPPING_PLANES"]),
+                 ("nojitter", ["DOME_LIGHT_CAMERA_VISIBLE", "MEDIUM_STACK_SIZE=0"])]
+
+
+def descriptors_to_cpp(text: str) -> str:
+    """rp_main_descriptors.glsl: `layout(...) [readonly] buffer Block { T name[]; };` -> `static T* name;`, `... uniform Block { T name; };` -> `static T name;`;
+    opaque resources (sampler, acceleration structure, texture arrays) and buffer-reference blocks are dropped (ref_loop.cpp declares what it uses)."""
+    out, lines, i = [], text.split("\n"), 0
+    one = re.compile(r"^\s*layout\([^)]*\)\s*(?:readonly\s+|writeonly\s+)*(?:uniform|buffer)\s+\w+\s*\{\s*(\w+)\s+(\w+)(\[\])?;\s*\};")
+    while i < len(lines):
+        ln = lines[i]
+        m = one.match(ln)
+        if m:
+            out.append(f"static {m.group(1)}{'*' if m.group(3) else ''} {m.group(2)};")
+        elif ln.lstrip().startswith("layout("):
+            depth = 0
+            while True:  # skip the whole statement
+                depth += lines[i].count("{") - lines[i].count("}")
+                if depth <= 0 and lines[i].rstrip().endswith(";"):
+                    break
+                i += 1
+        else:
+            out.append(ln)
+        i += 1
+    return "\n".join(out)
+
+
+def remove_function(text: str, name: str) -> str:
+    return text.replace(cut_function(text, name).rstrip("\n"), f"/* {name}: provided by ref_loop.cpp */")
+
+
+def loop_to_cpp(rel: str, text: str) -> str:
+    if rel == "rp_main_descriptors.glsl":
+        text = descriptors_to_cpp(text)
+    stem = rel.replace("rp_main", "").strip("._") or "rgen"
+    if rel == "rp_main.rgen":
+        text = re.sub(r"layout\([^)]*\)\s*rayPayloadEXT\s+(\w+)\s+(\w+);", r"static \1 \2;", text)
+    elif rel == "rp_main_shadow.miss":
+        text = re.sub(r"layout\([^)]*\)\s*rayPayloadInEXT\s+\w+\s+\w+;", "static ShadowRayPayload& rayPayload = shadowRayPayload;", text)
+    else:
+        text = re.sub(r"layout\([^)]*\)\s*rayPayloadInEXT\s+\w+\s+\w+;", "", text)
+    text = re.sub(r"^\s*hitAttributeEXT[^\n]*\n", "\n", text, flags=re.M)
+    text = re.sub(r"^\s*#\s*pragma\s+mdl_generated_code[^\n]*\n", "\n", text, flags=re.M)
+    text = re.sub(r'^\s*#\s*include\s+"mdl_interface.glsl"[^\n]*\n', "\n", text, flags=re.M)
+    if rel == "rp_main.miss":
+        text = remove_function(text, "sampleDomeLight")
+    names = {"rp_main.rgen": "rgen_main", "rp_main.chit": "chit_main", "rp_main.miss": "miss_main", "rp_main_shadow.miss": "shadow_miss_main"}
+    if rel in names:
+        text = re.sub(r"\bvoid\s+main\s*\(\s*\)", f"void {names[rel]}()", text)
+    return "#pragma once\n" + to_cpp(text)
+
+
+def build_loop(shaders: str, verbose=False):
+    """The whole-shader build: rp_main.rgen / .chit / .miss / _shadow.miss as C++ functions, one object per feature-macro variant."""
+    gen = os.path.join(OUT, "gen_loop")
+    os.makedirs(os.path.join(gen, "interface"), exist_ok=True)
+    open(os.path.join(gen, "interface", "gtl.h"), "w").write("/* stub: ref_loop.cpp defines the GLSL side of interface/gtl.h */\n")
+    for rel in LOOP_WHOLE:
+        open(os.path.join(gen, rel), "w").write(loop_to_cpp(rel, open(os.path.join(shaders, rel)).read()))
+    objs = []
+    for name, defs in LOOP_VARIANTS:
+        obj = os.path.join(OUT, f"ref_loop_{name}.o")
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-c", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused", "-Wno-attributes", "-Wno-unknown-pragmas", "-I", gen, "-I", HERE,
+               f"-DREF_VARIANT={name}"] + [f"-D{d}" for d in defs] + [os.path.join(HERE, "ref_loop.cpp"), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    return objs
+
+
 def build(reference="/root/reference", verbose=False) -> str:
     shaders = os.path.join(reference, "src", "gi", "shaders")
     if not os.path.isdir(shaders):
@@ -63,8 +142,10 @@ def build(reference="/root/reference", verbose=False) -> str:
         src = open(os.path.join(shaders, rel)).read()
         for n in names:
             open(os.path.join(GEN, f"fn_{n}.h"), "w").write(f"// {rel}: {n}\n" + to_cpp(cut_function(src, n)))
+    objs = build_loop(shaders, verbose)
+    oracle_dir = os.path.dirname(HERE)
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused", "-I", GEN, "-I", HERE,
-           os.path.join(HERE, "ref_shim.cpp"), "-o", LIB]
+           os.path.join(HERE, "ref_shim.cpp")] + objs + ["-o", LIB, "-L", oracle_dir, "-lgi_oracle", "-Wl,-rpath," + oracle_dir]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

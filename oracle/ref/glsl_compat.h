@@ -46,6 +46,7 @@ inline Float sin(Float a) { return Float(sinf(a.v)); }
 inline Float log(Float a) { return Float(logf(a.v)); }
 inline Float exp(Float a) { return Float(expf(a.v)); }
 inline Float exp2(Float a) { return Float(exp2f(a.v)); }
+inline Float tan(Float a) { return Float(tanf(a.v)); }
 inline Float abs(Float a) { return Float(fabsf(a.v)); }
 inline Float floor(Float a) { return Float(floorf(a.v)); }
 inline Float max(Float a, Float b) { return a.v < b.v ? b : a; } // GLSL: y if x < y else x
@@ -71,6 +72,7 @@ struct vec2 {
   vec2 yx() const { return vec2(y, x); }
 };
 struct bvec3 { bool x, y, z; };
+inline bool any(bvec3 b) { return b.x || b.y || b.z; }
 struct ivec3 {
   int x, y, z;
   ivec3() : x(0), y(0), z(0) {}
@@ -85,10 +87,14 @@ struct vec3 {
   vec3(Float a) : x(a), y(a), z(a) {}
   vec3(Float a, Float b_, Float c) : x(a), y(b_), z(c) {}
   vec3(const vec2& a, Float c) : x(a.x), y(a.y), z(c) {}
+  explicit vec3(bvec3 b) : x(b.x ? 1.0f : 0.0f), y(b.y ? 1.0f : 0.0f), z(b.z ? 1.0f : 0.0f) {}
   vec3 operator-() const { return vec3(-x, -y, -z); }
   vec3& operator/=(Float s) { x /= s; y /= s; z /= s; return *this; }
   vec3& operator*=(Float s) { x *= s; y *= s; z *= s; return *this; }
   vec3& operator+=(const vec3& o) { x += o.x; y += o.y; z += o.z; return *this; }
+  vec3& operator*=(const vec3& o) { x *= o.x; y *= o.y; z *= o.z; return *this; }
+  vec3 rgb() const { return *this; }
+  vec3 xyz() const { return *this; }
   vec2 xy() const { return vec2(x, y); }
   vec2 yx() const { return vec2(y, x); }
   Float r() const { return x; }
@@ -105,13 +111,16 @@ struct vec4 {
   vec2 xy() const { return vec2(x, y); }
   vec2 zw() const { return vec2(z, w); }
   vec3 xyz() const { return vec3(x, y, z); }
+  vec3 rgb() const { return vec3(x, y, z); }
 };
+struct ivec4 { int x, y, z, w; };
 // Matrices, column-major as in GLSL; products accumulate left to right (GLSL leaves the order to the driver; this is the oracle's order too,
 // so comparisons through these test the STRUCTURE of a computation -- which transform, which transpose -- not the driver's rounding)
 struct mat4x3 { vec3 c[4]; };                       // 4 columns of vec3 (gl_ObjectToWorldEXT / gl_WorldToObjectEXT)
 struct mat3 { vec3 c[3]; mat3() {} explicit mat3(const mat4x3& m) { c[0] = m.c[0]; c[1] = m.c[1]; c[2] = m.c[2]; } };
 inline vec4 make_vec4(const vec3& v, Float w) { return vec4(v.x, v.y, v.z, w); }
 struct uvec2 { uint x, y; };
+struct uvec3 { uint x, y, z; uvec2 xy() const { return uvec2{x, y}; } };
 struct uvec4 {
   uint x, y, z, w;
   uvec4() : x(0), y(0), z(0), w(0) {}
@@ -143,6 +152,9 @@ inline vec3 reflect(const vec3& i, const vec3& n) { return i - Float(2.0f) * dot
 inline vec3 cross(const vec3& a, const vec3& b) { return vec3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 inline vec3 operator*(const mat4x3& m, const vec4& v) { return ((m.c[0] * v.x + m.c[1] * v.y) + m.c[2] * v.z) + m.c[3] * v.w; }
 inline vec3 operator*(const vec3& v, const mat3& m) { return vec3(dot(v, m.c[0]), dot(v, m.c[1]), dot(v, m.c[2])); }
+inline bvec3 greaterThan(const vec3& a, const vec3& b) { return bvec3{a.x > b.x, a.y > b.y, a.z > b.z}; }
+inline bvec3 equal(const vec3& a, const vec3& b) { return bvec3{a.x == b.x, a.y == b.y, a.z == b.z}; }
+inline vec3 max(const vec3& a, const vec3& b) { return vec3(max(a.x, b.x), max(a.y, b.y), max(a.z, b.z)); }
 inline bvec3 greaterThanEqual(const vec3& a, const vec3& b) { return bvec3{a.x >= b.x, a.y >= b.y, a.z >= b.z}; }
 struct bvec2 { bool x, y; };
 inline bvec2 notEqual(const vec2& a, const vec2& b) { return bvec2{a.x != b.x, a.y != b.y}; }
@@ -156,6 +168,17 @@ inline vec3 intBitsToFloat(const ivec3& v) { return vec3(i2f(v.x), i2f(v.y), i2f
 inline Float uintBitsToFloat(uint u) { float f; memcpy(&f, &u, 4); return Float(f); }
 inline uint floatBitsToUint(Float f) { uint u; memcpy(&u, &f.v, 4); return u; }
 inline vec4 uintBitsToFloat(const uvec4& u) { return vec4(uintBitsToFloat(u.x), uintBitsToFloat(u.y), uintBitsToFloat(u.z), uintBitsToFloat(u.w)); }
+// unpackHalf2x16 (GLSL 4.60 section 8.4): two IEEE half floats, first component in the low bits
+inline Float half_to_float(uint h)
+{
+  const uint sgn = (h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+  uint o;
+  if (e == 0u) { if (m == 0u) o = sgn; else { int ee = -1; uint mm = m; do { ee++; mm <<= 1; } while (!(mm & 0x400u)); o = sgn | ((uint)(127 - 15 - ee) << 23) | ((mm & 0x3ffu) << 13); } }
+  else if (e == 31u) o = sgn | 0x7f800000u | (m << 13);
+  else o = sgn | ((e + 112u) << 23) | (m << 13);
+  return uintBitsToFloat(o);
+}
+inline vec2 unpackHalf2x16(uint p) { return vec2(half_to_float(p & 0xffffu), half_to_float(p >> 16)); }
 // GLSL 4.60 section 8.4: packUnorm2x16: round(clamp(c, 0, 1) * 65535.0), first component in the low bits; unpack: f / 65535.0
 inline uint packUnorm2x16(const vec2& v) { const uint a = (uint)nearbyintf(clamp(v.x, 0.0f, 1.0f).v * 65535.0f), b = (uint)nearbyintf(clamp(v.y, 0.0f, 1.0f).v * 65535.0f); return a | (b << 16); }
 inline vec2 unpackUnorm2x16(uint p) { return vec2(Float((float)(p & 0xffffu)) / Float(65535.0f), Float((float)(p >> 16)) / Float(65535.0f)); }
