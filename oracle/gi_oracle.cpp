@@ -1988,6 +1988,14 @@ void orc_hook_bsdf_evaluate(void* h, uint32_t mat, const float* frame, const flo
   BsdfEval ev; bsdf_evaluate(((OrcHook*)h)->P.materials[mat], st, v3(k1), v3(k2), ev);
   out[0] = ev.diffuse.x; out[1] = ev.diffuse.y; out[2] = ev.diffuse.z; out[3] = ev.glossy.x; out[4] = ev.glossy.y; out[5] = ev.glossy.z; out[6] = ev.pdf;
 }
+void orc_hook_bsdf_albedo(void* h, uint32_t mat, const float* frame, const float* k1, float ior1, float ior2, int thin, float* out)
+{
+  State st; hook_state(st, frame, ior1, ior2, thin);
+  V3 a = bsdf_albedo(((OrcHook*)h)->P.materials[mat], st, v3(k1)); out[0] = a.x; out[1] = a.y; out[2] = a.z;
+}
+// face ids packed as the reference packs them behind the BLAS payload preamble (Gi.cpp:878-905): stride bytes per face, read as 32-bit words
+const int32_t* orc_hook_mesh_face_ids(void* h, uint32_t mesh, uint32_t* stride)
+{ const MeshData& m = ((OrcHook*)h)->P.meshes[mesh]; *stride = m.faceIdStride; return (const int32_t*)m.faceIdData.data(); }
 void orc_hook_edf_factor(void* h, uint32_t mat, float c, float* out)
 {
   const OrcMaterial& m = ((OrcHook*)h)->P.materials[mat]; V3 f = v3(1, 1, 1);

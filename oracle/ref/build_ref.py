@@ -60,7 +60,9 @@ LOOP_VARIANTS = [("default", ["JITTERED_SAMPLING", "FILTER_IMPORTANCE_SAMPLING",
                  ("nee", ["JITTERED_SAMPLING", "FILTER_IMPORTANCE_SAMPLING", "PROGRESSIVE_ACCUMULATION", "DOME_LIGHT_CAMERA_VISIBLE", "MEDIUM_STACK_SIZE=0", "NEXT_EVENT_ESTIMATION"]),
                  ("nee_stack2", ["JITTERED_SAMPLING", "FILTER_IMPORTANCE_SAMPLING", "PROGRESSIVE_ACCUMULATION", "DOME_LIGHT_CAMERA_VISIBLE", "MEDIUM_STACK_SIZE=2", "NEXT_EVENT_ESTIMATION"]),
                  ("dof_clip_box", ["JITTERED_SAMPLING", "PROGRESSIVE_ACCUMULATION", "DOME_LIGHT_CAMERA_VISIBLE", "MEDIUM_STACK_SIZE=0", "DEPTH_OF_FIELD", "CLIPPING_PLANES"]),
-                 ("nojitter", ["DOME_LIGHT_CAMERA_VISIBLE", "MEDIUM_STACK_SIZE=0"])]
+                 ("nojitter", ["DOME_LIGHT_CAMERA_VISIBLE", "MEDIUM_STACK_SIZE=0"]),
+                 # every AOV but ClockCycles (bit 6: clockARB)
+                 ("aovs", ["JITTERED_SAMPLING", "FILTER_IMPORTANCE_SAMPLING", "PROGRESSIVE_ACCUMULATION", "DOME_LIGHT_CAMERA_VISIBLE", "MEDIUM_STACK_SIZE=0", "AOV_MASK=0x1ffbf"])]
 
 
 def descriptors_to_cpp(text: str) -> str:

@@ -27,6 +27,8 @@ void orc_hook_material(void* h, uint32_t mat, float* out);
 void orc_hook_bsdf_sample(void* h, uint32_t mat, const float* frame, const float* k1, const float* xi, float ior1, float ior2, int thin, float* out);
 void orc_hook_bsdf_evaluate(void* h, uint32_t mat, const float* frame, const float* k1, const float* k2, float ior1, float ior2, int thin, float* out);
 void orc_hook_edf_factor(void* h, uint32_t mat, float c, float* out);
+void orc_hook_bsdf_albedo(void* h, uint32_t mat, const float* frame, const float* k1, float ior1, float ior2, int thin, float* out);
+const int32_t* orc_hook_mesh_face_ids(void* h, uint32_t mesh, uint32_t* stride);
 }
 
 #define REF_CAT2(a, b) a##b
@@ -51,8 +53,10 @@ using namespace glsl;
 // ---- per-material macros of the generated hit shaders: the superset (the stubs below answer per material at run time)
 #define IS_EMISSIVE
 #define IS_THIN_WALLED
-// colour + the AOVs whose rules live in rgen / chit (normal, NEE, bounces)
+// colour + the AOVs whose rules live in rgen / chit (normal, NEE, bounces); the "aovs" variant asks for all but ClockCycles (clockARB, D6)
+#ifndef AOV_MASK
 #define AOV_MASK ((1 << 0) | (1 << 1) | (1 << 2) | (1 << 5))
+#endif
 
 #define float Float
 // ---- ray-tracing built-ins and resources the shaders name
@@ -74,7 +78,9 @@ static void traceRayEXT(AccelerationStructure&, uint rayFlags, uint cullMask, ui
 static void* g_hook;
 static const BlasPayload* blas_payloads;
 static const Face* g_faces; static const FVertex* g_vertices;
-struct IndexBuffer { const Face* data; BlasPayloadBufferPreamble preamble; IndexBuffer(uint64_t) : data(g_faces), preamble() {} };
+static BlasPayloadBufferPreamble g_preamble; static const int* g_faceIdWords;
+struct IndexBuffer { const Face* data; BlasPayloadBufferPreamble preamble; IndexBuffer(uint64_t) : data(g_faces), preamble(g_preamble) {} };
+struct RawIntBuffer { const int* data; RawIntBuffer(uint64_t) : data(g_faceIdWords) {} }; // faceIdsInfo's offset is 0 here
 struct VertexBuffer { const FVertex* data; VertexBuffer(uint64_t) : data(g_vertices) {} };
 static uint g_material; static bool g_thinWalled; static float g_matInfo[13];
 
@@ -93,7 +99,7 @@ static vec3 mdl_edf_emission_intensity(State) { return vec3(g_matInfo[1], g_matI
 static void mdl_bsdf_scattering_init(State&) {}
 static void mdl_bsdf_scattering_sample(Bsdf_sample_data& d, State st);
 static void mdl_bsdf_scattering_evaluate(Bsdf_evaluate_data& d, State st);
-static void mdl_bsdf_scattering_auxiliary(Bsdf_auxiliary_data& d, State st) { d.albedo_diffuse = vec3(0.0f); d.albedo_glossy = vec3(0.0f); }
+static void mdl_bsdf_scattering_auxiliary(Bsdf_auxiliary_data& d, State st);
 
 #include "mdl_shading_state.glsl"
 #include "rp_main.chit"
@@ -129,6 +135,13 @@ static void mdl_bsdf_scattering_evaluate(Bsdf_evaluate_data& d, State st)
   orc_hook_bsdf_evaluate(g_hook, g_material, fr, k1, k2, d.ior1.x.v, d.ior2.x.v, g_thinWalled ? 1 : 0, out);
   d.bsdf_diffuse = vec3(out[0], out[1], out[2]); d.bsdf_glossy = vec3(out[3], out[4], out[5]); d.pdf = out[6];
 }
+static void mdl_bsdf_scattering_auxiliary(Bsdf_auxiliary_data& d, State st)
+{
+  float fr[12], k1[3], out[3];
+  frame_of(st, fr); to3(d.k1, k1);
+  orc_hook_bsdf_albedo(g_hook, g_material, fr, k1, d.ior1.x.v, d.ior2.x.v, g_thinWalled ? 1 : 0, out);
+  d.albedo_diffuse = vec3(out[0], out[1], out[2]); d.albedo_glossy = vec3(0.0f); // the Albedo AOV only uses the sum (rp_main.chit:279)
+}
 
 // traceRayEXT: the oracle's traversal stands in for the acceleration structure; hit -> rp_main.chit, miss -> rp_main.miss (payload 0),
 // rp_main_shadow.miss (payload 1; the shadow hit group has no closest-hit shader)
@@ -155,6 +168,11 @@ static void traceRayEXT(AccelerationStructure&, uint rayFlags, uint, uint, uint,
   bp[0].bufferAddress = 0; bp[0].vertexOffset = 0; bp[0].bitfield = (uint)info[1]; // BLAS_PAYLOAD_BITFLAG_FLIP_FACING | _DOUBLE_SIDED (rp_main.h:115-116)
   blas_payloads = bp;
   g_material = (uint)info[2];
+  { // BlasPayloadBufferPreamble (Gi.cpp:886-905) and the instance-id buffer, for the ObjectId / FaceId / InstanceId AOVs
+    uint32_t stride = 1; g_faceIdWords = (const int*)orc_hook_mesh_face_ids(g_hook, (uint32_t)info[0], &stride);
+    g_preamble.objectId = info[3]; g_preamble.faceIdsInfo = (stride << FACE_ID_STRIDE_OFFSET) | 0u;
+    static std::vector<int> ids; if (ids.size() <= ip[0]) ids.resize(ip[0] + 1); ids[ip[0]] = info[4]; InstanceIds = ids.data();
+  }
   orc_hook_material(g_hook, g_material, reinterpret_cast<float*>(g_matInfo)); // (Float is a float)
   g_thinWalled = g_matInfo[12].v != 0.0f;
   chit_main();
@@ -169,7 +187,10 @@ struct RefLoopParams {
   float clearColor[4], clearNormal[4], clearNee[4], clearBounces[4];
 };
 #define REF_ENTRY REF_CAT(ref_loop_render_, REF_VARIANT)
-extern "C" int REF_ENTRY(void* hook, const RefLoopParams* p, const float* prevColor, float* color, float* normal, float* nee, float* bounces)
+// extra (may be null): 17 pointers indexed by AOV id (aovs.glsl:5-21), each null or float4 per pixel of the band (integer AOVs: the int's bits in .x);
+// clearExtra: their clear values; prevExtra: previous contents of the accumulating ones (normal = id 1 through `normal`, albedo = 16)
+extern "C" int REF_ENTRY(void* hook, const RefLoopParams* p, const float* prevColor, float* color, float* normal, float* nee, float* bounces, float* const* extra,
+                         const float* clearExtra, const float* prevAlbedo)
 {
   using namespace REF_NS;
   g_hook = hook;
@@ -198,13 +219,27 @@ extern "C" int REF_ENTRY(void* hook, const RefLoopParams* p, const float* prevCo
   clearF[1] = vec4(p->clearNormal[0], p->clearNormal[1], p->clearNormal[2], p->clearNormal[3]);
   clearF[2] = vec4(p->clearNee[0], p->clearNee[1], p->clearNee[2], p->clearNee[3]);
   clearF[5] = vec4(p->clearBounces[0], p->clearBounces[1], p->clearBounces[2], p->clearBounces[3]);
+  std::vector<vec3> v3Buf[17]; std::vector<int> iBuf[17]; std::vector<Float> depthBuf(n);
+  for (int id = 3; id < 17; id++) {
+    if (clearExtra) { clearF[id] = vec4(clearExtra[4 * id], clearExtra[4 * id + 1], clearExtra[4 * id + 2], clearExtra[4 * id + 3]); int ci; memcpy(&ci, &clearExtra[4 * id], 4); clearI[id] = ivec4{ci, 0, 0, 0}; }
+    v3Buf[id].resize(n); iBuf[id].resize(n);
+  }
   ClearValuesF = clearF.data(); ClearValuesI = clearI.data();
   ColorAov = colorBuf.data(); NormalsAov = normalBuf.data(); NeeAov = neeBuf.data(); BouncesAov = bouncesBuf.data();
+#if (AOV_MASK & 0x1ff98) == 0x1ff98 // the "aovs" variant: the descriptors declare an AOV only when its bit is set
+  BarycentricsAov = v3Buf[3].data(); TexcoordsAov = v3Buf[4].data(); OpacityAov = v3Buf[7].data(); TangentsAov = v3Buf[8].data(); BitangentsAov = v3Buf[9].data();
+  ThinWalledAov = v3Buf[10].data(); ObjectIdAov = iBuf[11].data(); DepthAov = depthBuf.data(); FaceIdAov = iBuf[13].data(); InstanceIdAov = iBuf[14].data();
+  DoubleSidedAov = v3Buf[15].data(); AlbedoAov = v3Buf[16].data();
+#else
+  if (extra) return 1;
+#endif
   for (uint32_t y = p->rowBegin; y < p->rowEnd; y++)
     for (uint32_t x = 0; x < p->width; x++) {
       const size_t pi = (size_t)y * p->width + x, o = ((size_t)(y - p->rowBegin) * p->width + x) * 4;
       if (prevColor) colorBuf[pi] = vec4(prevColor[o], prevColor[o + 1], prevColor[o + 2], prevColor[o + 3]);
       neeBuf[pi] = clearF[2].rgb(); bouncesBuf[pi] = clearF[5].rgb();
+      if (prevAlbedo) v3Buf[16][pi] = vec3(prevAlbedo[o], prevAlbedo[o + 1], prevAlbedo[o + 2]);
+      if (p->sampleOffset > 0 && normal) normalBuf[pi] = vec3(normal[o], normal[o + 1], normal[o + 2]); // in/out for the accumulating normal AOV
       gl_LaunchIDEXT = uvec3{x, y, 0u};
       rgen_main();
       const vec4 c = colorBuf[pi];
@@ -212,6 +247,13 @@ extern "C" int REF_ENTRY(void* hook, const RefLoopParams* p, const float* prevCo
       if (normal) { normal[o] = normalBuf[pi].x.v; normal[o + 1] = normalBuf[pi].y.v; normal[o + 2] = normalBuf[pi].z.v; normal[o + 3] = 0.0f; }
       if (nee) { nee[o] = neeBuf[pi].x.v; nee[o + 1] = neeBuf[pi].y.v; nee[o + 2] = neeBuf[pi].z.v; nee[o + 3] = 0.0f; }
       if (bounces) { bounces[o] = bouncesBuf[pi].x.v; bounces[o + 1] = bouncesBuf[pi].y.v; bounces[o + 2] = bouncesBuf[pi].z.v; bounces[o + 3] = 0.0f; }
+      if (extra)
+        for (int id = 3; id < 17; id++) {
+          float* e = extra[id]; if (!e) continue;
+          if (id == 11 || id == 13 || id == 14) { memcpy(&e[o], &iBuf[id][pi], 4); e[o + 1] = e[o + 2] = e[o + 3] = 0.0f; }
+          else if (id == 12) { e[o] = depthBuf[pi].v; e[o + 1] = e[o + 2] = e[o + 3] = 0.0f; }
+          else { e[o] = v3Buf[id][pi].x.v; e[o + 1] = v3Buf[id][pi].y.v; e[o + 2] = v3Buf[id][pi].z.v; e[o + 3] = 0.0f; }
+        }
     }
   return 0;
 }

@@ -62,7 +62,7 @@ def variant_of(rs):
     return "nee" if rs.next_event_estimation else "default"
 
 
-def render_ref_loop(ref, desc, rs, w, h, sample_offset=0, prev=None):
+def render_ref_loop(ref, desc, rs, w, h, sample_offset=0, prev=None, variant=None, extra=None, clear_extra=None, prev_normal=None, prev_albedo=None):
     from oracle import orc
     L = orc.lib()
     L.orc_hook_open.restype = C.c_void_p; L.orc_hook_open.argtypes = [C.c_void_p] * 4; L.orc_hook_close.argtypes = [C.c_void_p]
@@ -76,10 +76,22 @@ def render_ref_loop(ref, desc, rs, w, h, sample_offset=0, prev=None):
                           rs.light_intensity_multiplier, rs.meters_per_scene_unit, (C.c_float * 4)(*rs.clear_color), (C.c_float * 4)(0, 0, 0, 0), (C.c_float * 4)(0, 0, 0, 0), (C.c_float * 4)(0, 0, 0, 0))
         color, normal, nee, bounces = (np.zeros((h, w, 4), np.float32) for _ in range(4))
         pv = np.ascontiguousarray(prev, np.float32) if prev is not None else None
-        fn = getattr(ref, "ref_loop_render_" + variant_of(rs))
-        rc = fn(hook, C.byref(p), pv.ctypes.data_as(C.c_void_p) if pv is not None else None, color.ctypes.data_as(C.c_void_p), normal.ctypes.data_as(C.c_void_p),
-                nee.ctypes.data_as(C.c_void_p), bounces.ctypes.data_as(C.c_void_p))
+        fn = getattr(ref, "ref_loop_render_" + (variant or variant_of(rs)))
+        fn.argtypes = [C.c_void_p] * 10
+        ptrs, keep = None, []
+        if extra is not None:  # {aov id: float32 [h, w, 4] array to fill}
+            ptrs = (C.c_void_p * 17)()
+            for aid, arr in extra.items():
+                ptrs[aid] = arr.ctypes.data
+        ce = np.ascontiguousarray(clear_extra, np.float32) if clear_extra is not None else None
+        pa = np.ascontiguousarray(prev_albedo, np.float32) if prev_albedo is not None else None
+        if prev_normal is not None:
+            normal[:] = prev_normal
+        rc = fn(hook, C.addressof(p), pv.ctypes.data if pv is not None else None, color.ctypes.data, normal.ctypes.data, nee.ctypes.data, bounces.ctypes.data,
+                C.addressof(ptrs) if ptrs is not None else None, ce.ctypes.data if ce is not None else None, pa.ctypes.data if pa is not None else None)
         assert rc == 0
+        if extra is not None:
+            return color, normal
         return color, nee, bounces
     finally:
         L.orc_hook_close(hook)
@@ -155,3 +167,53 @@ def test_reference_loop_progressive_accumulation_and_debug_aovs(ref):
     aov = orc.render_aovs(desc, rs, w, h, ["nee", "bounces"], clear_values={"nee": (0, 0, 0, 0), "bounces": (0, 0, 0, 0)})
     assert (np.abs(nee[..., :3] - aov["nee"][..., :3]).max(axis=2) < 1e-6).mean() >= 0.99
     assert (np.abs(bounces[..., :3] - aov["bounces"][..., :3]).max(axis=2) < 1e-5).mean() >= 0.98
+
+
+def test_reference_loop_every_aov_rule(ref):
+    """All AOVs but ClockCycles (clockARB; D6) out of the reference's chit / rgen, on an instanced scene with face ids of both strides, object and
+    instance ids, single- and double-sided meshes and a thin-walled material; two progressive calls for the accumulating ones (normal, albedo)."""
+    from oracle import orc
+    from gatling_amd.scenes import interior_scene
+    desc, w, h = interior_scene(clutter_instances=40, subdivisions=1, prototypes=4, material_count=6), 48, 28
+    rng = np.random.default_rng(3)
+    desc.meshes[0].faces = desc.meshes[0].faces[:6]  # floor, ceiling and one wall of the room: some primary rays leave the scene
+    for i, m in enumerate(desc.meshes):
+        hi = 200 if i % 2 else 40000  # one and two bytes per face id (Gi.cpp:878-885)
+        m.face_ids, m.max_face_id = rng.integers(0, hi, len(m.faces)).astype(np.int32), hi
+        m.double_sided = (i % 3) != 1
+    desc.materials[2] = MaterialDesc.open_pbr(base_color=(0.3, 0.6, 0.4), transmission_weight=0.5, geometry_thin_walled=True)
+    rs = RenderSettings(spp=3, max_bounces=3, clipping_planes=False)
+    names = {"barycentrics": 3, "texcoords": 4, "opacity": 7, "tangents": 8, "bitangents": 9, "thinWalled": 10, "objectId": 11, "depth": 12, "faceId": 13, "instanceId": 14,
+             "doubleSided": 15, "albedo": 16}
+    clear = np.zeros((17, 4), np.float32)
+    clear_values = {}
+    for n, aid in names.items():
+        if n in ("objectId", "faceId", "instanceId"):
+            clear[aid, 0] = np.frombuffer(np.int32(-1).tobytes(), np.float32)[0]; clear_values[n] = -1
+        elif n == "depth":
+            clear[aid, 0] = 1.0; clear_values[n] = 1.0
+        else:
+            clear[aid] = (0.25, 0.5, 0.75, 0.0); clear_values[n] = (0.25, 0.5, 0.75, 0.0)
+    clear_values["normal"] = (0, 0, 0, 0)
+    o1 = orc.render_aovs(desc, rs, w, h, list(names) + ["normal"], clear_values=clear_values)
+    o2 = orc.render_aovs(desc, rs, w, h, ["normal", "albedo"], clear_values=clear_values, sample_offset=3, prev={"normal": o1["normal"], "albedo": o1["albedo"]})
+    ex = {aid: np.zeros((h, w, 4), np.float32) for aid in names.values()}
+    _, n1 = render_ref_loop(ref, desc, rs, w, h, variant="aovs", extra=ex, clear_extra=clear)
+    hit = (ex[11].view(np.int32)[..., 0] != -1)
+    assert 0.3 < hit.mean() < 1.0  # misses keep the clear values, checked below like everything else
+    for n, aid in names.items():
+        theirs, ours = ex[aid], o1[n]
+        if n in ("objectId", "faceId", "instanceId"):
+            assert np.array_equal(theirs.view(np.int32)[..., 0], ours), n
+        elif n == "depth":
+            assert np.abs(theirs[..., 0] - ours).max() < 2e-6, n  # log: libm vs polynomial (D3)
+        else:
+            assert (np.abs(theirs[..., :3] - ours[..., :3]).max(axis=2) <= 1e-6).mean() >= 0.995, (n, np.abs(theirs[..., :3] - ours[..., :3]).max())
+    # (the reference masks face ids with stride * 8 - 1, rp_main.chit:240: 7 or 15 -- kept bug-compatible)
+    assert len(np.unique(ex[13].view(np.int32)[..., 0])) > 8 and len(np.unique(ex[14].view(np.int32)[..., 0])) > 3
+    assert (ex[10][hit][:, 0] == 1.0).any() and (ex[15][hit][:, 0] == 1.0).any()  # a thin-walled and a single-sided surface are in view
+    assert (np.abs(n1[..., :3] - o1["normal"][..., :3]).max(axis=2) <= 1e-6).mean() >= 0.995
+    ex2 = {16: np.zeros((h, w, 4), np.float32)}
+    _, n2 = render_ref_loop(ref, desc, rs, w, h, sample_offset=3, variant="aovs", extra=ex2, clear_extra=clear, prev_normal=o1["normal"], prev_albedo=o1["albedo"])
+    assert (np.abs(n2[..., :3] - o2["normal"][..., :3]).max(axis=2) <= 1e-6).mean() >= 0.995
+    assert (np.abs(ex2[16][..., :3] - o2["albedo"][..., :3]).max(axis=2) <= 1e-6).mean() >= 0.995
