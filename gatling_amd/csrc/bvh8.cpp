@@ -39,6 +39,7 @@ struct Node2 {
   Box box;
   uint32_t left = 0, right = 0; // children (internal)
   uint32_t first = 0, count = 0; // leaf range in refs[]
+  uint32_t total = 0;            // references below this node: refs[first, first + total)
 };
 
 constexpr int kBins = 16;
@@ -58,6 +59,7 @@ struct Builder {
   // Measured (C3 / C4 / C5): nodes per ray 16.6 / 6.9 / 20.1 -> 16.0 / 6.8 / 20.0 but triangles per ray 13.1 / 3.4 / 10.8 -> 18.5 / 5.1 / 22.4,
   // traversal 8-20 % slower: SAH leaves win.  Kept as an experiment knob (GATLING_BVH_BALANCED_BOTTOM=1).
   bool balancedBottom = false;
+  uint32_t leafSize = kMaxLeaf; // the BVH2 stops splitting at this many references (1 for the cost-optimal collapse, which forms the leaves itself)
   const float* extBoxes = nullptr; size_t extCount = 0; // box mode (TLAS over instances, BLAS over pre-padded triangle boxes): 6 floats per item
   size_t itemCount() const { return extBoxes ? extCount : tris.size(); }
   explicit Builder(const std::vector<TriRec>& t, const float* boxes = nullptr, size_t boxCount = 0) : tris(t), extBoxes(boxes), extCount(boxCount)
@@ -109,8 +111,8 @@ struct Builder {
   {
     Box box; box.reset(); Box cb; cb.reset();
     for (uint32_t i = first; i < first + count; i++) { box.grow(triBox[refs[i]]); cb.grow(&centroid[3 * refs[i]]); }
-    nodes[idx].box = box;
-    if (count <= kMaxLeaf) { nodes[idx].first = first; nodes[idx].count = count; return idx; }
+    nodes[idx].box = box; nodes[idx].first = first; nodes[idx].total = count;
+    if (count <= leafSize) { nodes[idx].count = count; return idx; }
     if (balancedBottom && count <= kMaxLeaf * 8u) {
       // Bottom of the tree: SAH splits leave many 1- and 2-triangle leaves, i.e. half-empty 8-wide nodes (47 % of the child
       // slots were occupied on a 1 M-triangle soup).  A subtree of <= 24 triangles is instead cut into ceil(n/3) leaves of
@@ -208,10 +210,71 @@ static void buildCore(const std::vector<TriRec>& trisIn, const float* boxes, siz
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double tA = now();
   Builder B(trisIn, boxes, boxCount);
+  // Collapse rule.  1 (default): cost-optimal -- the BVH2 is built down to single references and a dynamic programme over it (Ylitie,
+  // Karras, Laine 2017, section 3.1, implemented from the paper) chooses per BVH2 node whether its subtree becomes a leaf slot (<= 3
+  // references), an 8-wide node, or part of its parent's child list, minimising  sum(area * (c_node | c_prim * references)).
+  // 0: the round-1 rule (SAH leaves of <= 3, then greedily open the child with the largest area until 8 slots are used).
+  int collapse = 1;
+  if (const char* e = getenv("GATLING_BVH_COLLAPSE")) collapse = atoi(e);
+  float cPrim = 0.25f; // measured on MI355X (profiles/r02j_collapse.txt): 0.25-0.3 is best on C3; the node test (~214 VALU instructions, one dependent 80-byte fetch) costs about four cooperative triangle tests
+  if (const char* e = getenv("GATLING_BVH_CPRIM")) cPrim = (float)atof(e);
+  if (collapse == 1) B.leafSize = 1;
   B.prepare();
   const double tB = now();
   uint32_t root2 = B.build(0, (uint32_t)itemCount, 0u);
   const double tC = now();
+
+  // ---- cost-optimal collapse: cost[n][i-1] = C(n, i), the cheapest way to represent subtree n as at most i slots of its ancestor's node
+  // eff[n][i-1]: slots actually used (1 = the subtree is ONE slot; whether leaf or 8-wide node: isLeaf[n]); split[n][j-2]: how many of j slots
+  // go to the left child when the subtree is spread over j >= 2 slots (j = 8: the child list of an 8-wide node rooted at n)
+  struct Dp { float c[7]; uint8_t eff[7]; uint8_t split[7]; uint8_t leaf; };
+  std::vector<Dp> dp;
+  if (collapse == 1) {
+    const size_t n2 = B.nodes.size();
+    dp.resize(n2);
+    for (size_t ii = n2; ii-- > 0;) { // children have larger indices than their parent (Builder::nodes)
+      const Node2& n = B.nodes[ii]; Dp& d = dp[ii];
+      const float area = n.box.area();
+      if (n.count > 0) { // a BVH2 leaf (one reference, or several with coincident centroids)
+        for (int i = 0; i < 7; i++) { d.c[i] = area * cPrim * (float)n.count; d.eff[i] = 1; d.split[i] = 0; }
+        d.leaf = 1;
+        continue;
+      }
+      const Dp& L = dp[n.left]; const Dp& R = dp[n.right];
+      float dist[9];
+      for (int j = 2; j <= 8; j++) {
+        float best = 3.0e38f; int bk = 1;
+        for (int k = std::max(1, j - 7); k <= std::min(7, j - 1); k++) { const float c = L.c[k - 1] + R.c[j - k - 1]; if (c < best) { best = c; bk = k; } }
+        dist[j] = best; d.split[j - 2] = (uint8_t)bk;
+      }
+      const float cLeaf = n.total <= kMaxLeaf ? area * cPrim * (float)n.total : 3.0e38f;
+      const float cInt = area + dist[8];
+      d.leaf = cLeaf <= cInt ? 1 : 0;
+      d.c[0] = d.leaf ? cLeaf : cInt; d.eff[0] = 1;
+      for (int i = 2; i <= 7; i++) {
+        if (dist[i] < d.c[i - 2]) { d.c[i - 1] = dist[i]; d.eff[i - 1] = (uint8_t)i; }
+        else { d.c[i - 1] = d.c[i - 2]; d.eff[i - 1] = d.eff[i - 2]; }
+      }
+    }
+  }
+  struct Child { uint32_t n2; bool leaf; };
+  // the child list of the 8-wide node rooted at BVH2 node `root` under the optimal collapse
+  auto gatherOptimal = [&](uint32_t root, Child* ch) {
+    int n = 0;
+    struct Todo { uint32_t n2; int slots; bool expand; };
+    Todo todo[32]; int tp = 0;
+    todo[tp++] = {root, 8, true};
+    while (tp > 0) {
+      Todo t = todo[--tp];
+      const Node2& nd = B.nodes[t.n2];
+      int j = t.slots;
+      if (!t.expand) { j = dp[t.n2].eff[t.slots - 1]; if (j == 1) { ch[n++] = {t.n2, dp[t.n2].leaf != 0}; continue; } }
+      const int k = dp[t.n2].split[j - 2];
+      todo[tp++] = {nd.right, j - k, false};
+      todo[tp++] = {nd.left, k, false};
+    }
+    return n;
+  };
 
   struct Item { uint32_t n2; uint32_t n8; uint32_t depth; };
   std::queue<Item> q;
@@ -223,20 +286,26 @@ static void buildCore(const std::vector<TriRec>& trisIn, const float* boxes, siz
   while (!q.empty()) {
     Item it = q.front(); q.pop();
     out.maxDepth = std::max(out.maxDepth, it.depth);
-    // --- gather up to 8 children by opening the largest internal child
-    uint32_t ch[8]; int n = 0;
+    // --- gather up to 8 children
+    uint32_t ch[8]; bool chLeaf[8]; int n = 0;
     const Node2& r = B.nodes[it.n2];
-    if (r.count > 0) { ch[n++] = it.n2; } // root that is itself a leaf
-    else { ch[n++] = r.left; ch[n++] = r.right; }
-    while (n < 8) {
-      int best = -1; float bestArea = -1.0f;
-      for (int i = 0; i < n; i++) {
-        const Node2& c = B.nodes[ch[i]];
-        if (c.count == 0 && c.box.area() > bestArea) { bestArea = c.box.area(); best = i; }
+    if (r.count > 0 || (collapse == 1 && r.total <= kMaxLeaf)) { ch[0] = it.n2; chLeaf[0] = true; n = 1; } // root that is itself a leaf
+    else if (collapse == 1) {
+      Child cs[8]; n = gatherOptimal(it.n2, cs);
+      for (int i = 0; i < n; i++) { ch[i] = cs[i].n2; chLeaf[i] = cs[i].leaf; }
+    } else { // by opening the largest internal child
+      ch[n++] = r.left; ch[n++] = r.right;
+      while (n < 8) {
+        int best = -1; float bestArea = -1.0f;
+        for (int i = 0; i < n; i++) {
+          const Node2& c = B.nodes[ch[i]];
+          if (c.count == 0 && c.box.area() > bestArea) { bestArea = c.box.area(); best = i; }
+        }
+        if (best < 0) break;
+        uint32_t opened = ch[best];
+        ch[best] = B.nodes[opened].left; ch[n++] = B.nodes[opened].right;
       }
-      if (best < 0) break;
-      uint32_t opened = ch[best];
-      ch[best] = B.nodes[opened].left; ch[n++] = B.nodes[opened].right;
+      for (int i = 0; i < n; i++) chLeaf[i] = B.nodes[ch[i]].count > 0;
     }
     // --- node box + slot assignment (greedy max of centroid projection on the slot's octant direction)
     Box nb; nb.reset();
@@ -277,16 +346,17 @@ static void buildCore(const std::vector<TriRec>& trisIn, const float* boxes, siz
         while (hi < 255 && node.p[a] + (float)hi * scale < c.box.hi[a]) hi++;
         node.qlo[a][s] = (uint8_t)lo; node.qhi[a][s] = (uint8_t)hi;
       }
-      if (c.count > 0) { // leaf slot: unary count in the high 3 bits, triangle offset in the low 5
-        uint32_t unary = (1u << c.count) - 1u;
+      if (chLeaf[i]) { // leaf slot: unary count in the high 3 bits, triangle offset in the low 5
+        const uint32_t cnt = c.total;
+        uint32_t unary = (1u << cnt) - 1u;
         node.meta[s] = (uint8_t)((unary << 5) | triOffset);
-        for (uint32_t k = 0; k < c.count; k++) {
+        for (uint32_t k = 0; k < cnt; k++) {
           if (order) { order->push_back(B.refs[c.first + k]); continue; }
           TriRec t = B.tris[B.refs[c.first + k]];
           t.origId = B.refs[c.first + k];
           out.tris.push_back(t);
         }
-        triOffset += c.count;
+        triOffset += cnt;
       } else {
         node.imask |= (uint8_t)(1u << s);
         node.meta[s] = (uint8_t)((1u << 5) | (24u + (uint32_t)s));

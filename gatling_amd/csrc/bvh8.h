@@ -2,6 +2,7 @@
 // cgpuCreateBlas/cgpuCreateTlas, /root/reference/src/cgpu/impl/CgpuVk.cpp:2561-2854).
 #pragma once
 
+#include <cstddef>
 #include <cstdint>
 #include <vector>
 
