@@ -216,7 +216,7 @@ static void buildCore(const std::vector<TriRec>& trisIn, const float* boxes, siz
   // 0: the round-1 rule (SAH leaves of <= 3, then greedily open the child with the largest area until 8 slots are used).
   int collapse = 1;
   if (const char* e = getenv("GATLING_BVH_COLLAPSE")) collapse = atoi(e);
-  float cPrim = 0.25f; // measured on MI355X (profiles/r02j_collapse.txt): 0.25-0.3 is best on C3; the node test (~214 VALU instructions, one dependent 80-byte fetch) costs about four cooperative triangle tests
+  float cPrim = 0.5f; // a triangle test costs about half a node test (~110 vs ~214 VALU instructions); measured flat between 0.2 and 0.5 (profiles/r02j_bvh_collapse.txt)
   if (const char* e = getenv("GATLING_BVH_CPRIM")) cPrim = (float)atof(e);
   if (collapse == 1) B.leafSize = 1;
   B.prepare();

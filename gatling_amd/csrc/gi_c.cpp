@@ -1076,7 +1076,7 @@ int buildScene(GiCScene* s)
       s->dVerts.upload(verts, st) || s->dMaterials.upload(mats, st))
     return GI_C_ERROR;
   HIP_TRY(hipStreamSynchronize(st)); // host vectors go out of scope
-  s->nodeCount = (uint32_t)bvh.nodes.size(); s->triCount = (uint32_t)bvh.tris.size(); s->bvhDepth = bvh.maxDepth;
+  s->nodeCount = (uint32_t)bvh.nodes.size(); s->triCount = (uint32_t)bvh.tris.size(); s->bvhDepth = bvh.maxDepth > 1u ? bvh.maxDepth - 1u : 1u; // stack entries a walk can need: a pick at level L pushes the rest of level L-1's group (gi_traversal.h trav_node_pick), the root level pushes nothing
   s->stats.bvhBuildMs = t1 - t0; s->stats.uploadMs = nowMs() - t1;
   s->stats.nodeCount = s->nodeCount; s->stats.triangleCount = s->triCount;
   return GI_C_OK;

@@ -144,7 +144,7 @@ struct SceneView {
   const int32_t* triFaceId; // per triangle (BVH order): the value the FaceId AOV shows (rp_main.chit:230-240)
   uint32_t nodeCount;
   uint32_t triCount;
-  uint32_t bvhDepth; // levels of the BVH8 (bounds the traversal stack)
+  uint32_t bvhDepth; // levels of the BVH8 below the root = the most traversal-stack entries a ray can need
   uint32_t hasCutouts; // some triangle has cutout opacity < 1: traversal runs the any-hit test (needs the path rng)
   uint32_t nodeStrideU4; // distance between nodes in 16-byte units: 5 (packed) or 8 (one node per 128-byte line)
   const TextureRec* textures;

@@ -36,22 +36,68 @@ static bool triTest(const Ray& r, const TriRec& T, float& t, float& u, float& v)
   return det != 0.0f && u >= 0.0f && v >= 0.0f && u + v <= 1.0f && t > r.tMin;
 }
 
-// closest hit; returns the triangle index in tree order or -1
-static int trace(const Bvh8& B, const Ray& r, float& tBest, RayStats& c, bool anyHit = false)
+// what an ideal visiting order would cost: children sorted by entry distance, culled again against the current tBest when popped
+static int traceSorted(const Bvh8& B, const Ray& r, float& tBest, RayStats& c, bool anyHit)
 {
-  struct Group { uint32_t childBase; uint32_t mask; uint8_t imask; }; // mask bit (slot ^ octinv): hit internal child in `slot`
+  struct Item { uint32_t node; float tn; };
+  Item stack[512]; int sp = 0;
+  const float id[3] = {1.0f / r.d[0], 1.0f / r.d[1], 1.0f / r.d[2]};
+  tBest = r.tMax; int best = -1;
+  stack[sp++] = {0, r.tMin};
+  c.rays++;
+  while (sp > 0) {
+    Item it = stack[--sp];
+    if (it.tn > tBest) continue;
+    const Node8& n = B.nodes[it.node]; c.nodes++;
+    float s[3] = {expScale(n.e[0]), expScale(n.e[1]), expScale(n.e[2])};
+    Item kids[8]; int nk = 0;
+    for (int k = 0; k < 8; k++) {
+      if (n.meta[k] == 0) continue;
+      float tn = r.tMin, tf = tBest * 1.00001f;
+      for (int a = 0; a < 3; a++) {
+        float lo = n.p[a] + (float)n.qlo[a][k] * s[a], hi = n.p[a] + (float)n.qhi[a][k] * s[a];
+        float t0 = (lo - r.o[a]) * id[a], t1 = (hi - r.o[a]) * id[a];
+        if (t0 > t1) { float x = t0; t0 = t1; t1 = x; }
+        tn = std::fmax(tn, t0); tf = std::fmin(tf, t1 * 1.00001f);
+      }
+      if (!(tn <= tf)) continue;
+      if (n.imask & (1u << k)) kids[nk++] = {n.childBase + (uint32_t)__builtin_popcount(n.imask & ((1u << k) - 1u)), tn};
+      else {
+        uint32_t cnt = (uint32_t)__builtin_popcount(n.meta[k] >> 5), off = n.meta[k] & 31u;
+        for (uint32_t j = 0; j < cnt; j++) {
+          c.tris++;
+          float t, u, v;
+          if (triTest(r, B.tris[n.triBase + off + j], t, u, v) && t < tBest) { tBest = t; best = (int)(n.triBase + off + j); if (anyHit) { c.hits++; return best; } }
+        }
+      }
+    }
+    for (int i = 1; i < nk; i++) { Item x = kids[i]; int j = i - 1; while (j >= 0 && kids[j].tn < x.tn) { kids[j + 1] = kids[j]; j--; } kids[j + 1] = x; } // farthest first
+    for (int i = 0; i < nk; i++) stack[sp++] = kids[i];
+  }
+  if (best >= 0) c.hits++;
+  return best;
+}
+
+// closest hit; returns the triangle index in tree order or -1
+static int trace(const Bvh8& B, const Ray& r, float& tBest, RayStats& c, bool anyHit = false);
+static int trace(const Bvh8& B, const Ray& r, float& tBest, RayStats& c, bool anyHit)
+{
+  static const int cull = getenv("BVHQ_CULL") ? atoi(getenv("BVHQ_CULL")) : 0;
+  struct Group { uint32_t childBase; uint32_t mask; uint8_t imask; float tn[8]; float tmin; }; // mask bit (slot ^ octinv): hit internal child in `slot`
+  static const bool sorted = getenv("BVHQ_SORTED") != nullptr;
+  if (sorted) return traceSorted(B, r, tBest, c, anyHit);
   Group stack[256]; int sp = 0;
   const float id[3] = {1.0f / r.d[0], 1.0f / r.d[1], 1.0f / r.d[2]};
   const uint32_t octinv = (r.d[0] >= 0.0f ? 1u : 0u) | (r.d[1] >= 0.0f ? 2u : 0u) | (r.d[2] >= 0.0f ? 4u : 0u);
   tBest = r.tMax; int best = -1;
   uint32_t nodeIdx = 0; bool have = true;
-  Group cur{0, 0, 0};
+  Group cur{0, 0, 0, {0}, 0};
   c.rays++;
   while (true) {
     if (have) {
       const Node8& n = B.nodes[nodeIdx]; c.nodes++;
       float s[3] = {expScale(n.e[0]), expScale(n.e[1]), expScale(n.e[2])};
-      uint32_t imaskHit = 0;
+      uint32_t imaskHit = 0; float tnk[8] = {0}; float gmin = 3.0e38f;
       for (int k = 0; k < 8; k++) {
         if (n.meta[k] == 0) continue;
         float tn = r.tMin, tf = tBest * 1.00001f;
@@ -62,7 +108,7 @@ static int trace(const Bvh8& B, const Ray& r, float& tBest, RayStats& c, bool an
           tn = std::fmax(tn, t0); tf = std::fmin(tf, t1 * 1.00001f);
         }
         if (!(tn <= tf)) continue;
-        if (n.imask & (1u << k)) imaskHit |= 1u << ((uint32_t)k ^ octinv);
+        if (n.imask & (1u << k)) { imaskHit |= 1u << ((uint32_t)k ^ octinv); tnk[k] = tn; gmin = std::fmin(gmin, tn); }
         else {
           uint32_t cnt = (uint32_t)__builtin_popcount(n.meta[k] >> 5), off = n.meta[k] & 31u;
           for (uint32_t j = 0; j < cnt; j++) {
@@ -73,13 +119,19 @@ static int trace(const Bvh8& B, const Ray& r, float& tBest, RayStats& c, bool an
         }
       }
       if (cur.mask) stack[sp++] = cur;
-      cur = Group{n.childBase, imaskHit, n.imask};
+      if (cull == 3 && imaskHit) { // min over the hit children but the one visited first
+        uint32_t fb = 31u - (uint32_t)__builtin_clz(imaskHit), fslot = fb ^ octinv; gmin = 3.0e38f;
+        for (int k = 0; k < 8; k++) if ((imaskHit >> ((uint32_t)k ^ octinv)) & 1u) if ((uint32_t)k != fslot) gmin = std::fmin(gmin, tnk[k]);
+      }
+      cur = Group{n.childBase, imaskHit, n.imask, {0}, gmin};
+      memcpy(cur.tn, tnk, sizeof(tnk));
       have = false;
     }
-    if (!cur.mask) { if (sp == 0) break; cur = stack[--sp]; }
+    if (!cur.mask) { if (sp == 0) break; cur = stack[--sp]; if (cull >= 2 && cur.tmin > tBest) { cur.mask = 0; continue; } }
     if (cur.mask) {
       uint32_t bit = 31u - (uint32_t)__builtin_clz(cur.mask); cur.mask &= ~(1u << bit);
       uint32_t slot = bit ^ octinv;
+      if (cull == 1 && cur.tn[slot] > tBest) continue;
       nodeIdx = cur.childBase + (uint32_t)__builtin_popcount(cur.imask & ((1u << slot) - 1u));
       have = true;
     }
