@@ -15,6 +15,7 @@
 // Built with -ffp-contract=off (arithmetic contract, see gi_device_math.h).  Box tests inside the traversal use
 // explicit fmaf: they are conservative filters and never influence results.
 
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include "gi_device_math.h"
@@ -263,6 +264,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
 #endif
 constexpr uint32_t DYN_CLAIM = GI_DYN_CLAIM; // rays per cursor atomic (multiple of 64)
 constexpr uint32_t DYN_FLAG_XCD_RANGES = 1u;
+constexpr uint32_t DYN_FLAG_FLUSH_SHIFT = 8u; // bits 8-15: wave_step_carry's flushAt (0 = flush the triangle ring at the end of every step)
+constexpr uint32_t DYN_FLUSH_AT_DEFAULT = 8u;
 constexpr uint32_t DYN_LDS_NODES_DEFAULT = 0u;   // (GATLING_DYN_LDS_NODES)
 constexpr bool DYN_XCD_RANGES_DEFAULT = false;   // (GATLING_DYN_XCD)
 #ifndef GI_DYN_WAVES
@@ -282,9 +285,10 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
     for (uint32_t i = threadIdx.x; i < ldsNodes * 5u; i += TRACE_BLOCK) s_nodes[i] = reinterpret_cast<const uint4*>(sc.nodes)[(i / 5u) * sc.nodeStrideU4 + (i % 5u)];
     __syncthreads();
   }
-  __shared__ WaveTri s_wave[TRACE_BLOCK / 64];
+  typedef typename std::conditional<TWO || TRACE_DYN_COOP_FETCH, WaveTri, WaveTriDyn>::type WT;
+  __shared__ WT s_wave[TRACE_BLOCK / 64];
   __shared__ WaveStage s_stage[TRACE_DYN_COOP_FETCH ? TRACE_BLOCK / 64 : 1];
-  WaveTri& W = s_wave[threadIdx.x >> 6];
+  WT& W = s_wave[threadIdx.x >> 6];
   WaveStage* S = TRACE_DYN_COOP_FETCH ? &s_stage[threadIdx.x >> 6] : nullptr;
   QueueReader rd; reader_init(rd, cnt, qIn, qs.cap);
   const uint32_t n = rd.pre[NSHARD];
@@ -298,6 +302,8 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
   uint2 overflow[OVERFLOW ? OVF_STACK : 1];
   bool alive = false;
   uint32_t rec = 0u, rng = 0u;
+  bool draining = false; uint32_t lastEnd = 0u, ringHead = 0u, ringTail = 0u; // wave_step_carry: the triangle ring persists across steps
+  const uint32_t flushAt = (flags >> DYN_FLAG_FLUSH_SHIFT) & 0xffu;
   // The wave claims rays 64 at a time (one atomic per chunk) and lane j prefetches ray j of the chunk into registers; lanes
   // that run idle are then handed the chunk's rays in order with register shuffles, so a refill never waits on memory.
   F4 pro = F4{0.0f, 0.0f, 0.0f, 0.0f}, prd = F4{0.0f, 0.0f, 0.0f, 0.0f}; uint32_t prec = 0u, prng = 0u;
@@ -351,7 +357,7 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
         if (!ANYHIT) ray_init(v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), ro.w, rdir.w);
         else ray_init(v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), 0.01f, ro.w); // shadow ray (rp_main.rgen:397-429)
         wave_ray_begin(W, R.tBest);
-        alive = true;
+        alive = true; draining = false; lastEnd = ringHead; // no pair of this ray is pending
       }
       chunkUsed += take;
       if (chunkUsed == chunkCount) next_chunk(); // loads complete while the wave keeps traversing
@@ -359,7 +365,8 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
     if (!__ballot(alive)) { if (chunkCount == 0u) break; else continue; }
     bool done;
     if constexpr (TWO) done = wave_step2<ANYHIT, COUNT, CUTOUT>(R, alive, W, sc, s_stack, tc, rng);
-    else done = wave_step<ANYHIT, COUNT, STACK, OVERFLOW, false, CUTOUT, TRACE_DYN_COOP_FETCH>(R, alive, W, S, sc, s_nodes, ldsNodes, nullptr, 0u, s_stack, overflow, tc, rng);
+    else if constexpr (TRACE_DYN_COOP_FETCH) done = wave_step<ANYHIT, COUNT, STACK, OVERFLOW, false, CUTOUT, true>(R, alive, W, S, sc, s_nodes, ldsNodes, nullptr, 0u, s_stack, overflow, tc, rng);
+    else done = wave_step_carry<ANYHIT, COUNT, STACK, OVERFLOW, CUTOUT>(R, alive, draining, lastEnd, ringHead, ringTail, flushAt, W, sc, s_nodes, ldsNodes, s_stack, overflow, tc, rng);
     if (alive && done) {
       alive = false;
       wave_ray_end(W, R);
@@ -679,7 +686,9 @@ static void launchTraceVariant(hipStream_t s, uint32_t blocks, const SceneView& 
     uint32_t dynLdsNodes = envLds >= 0 ? (uint32_t)envLds : DYN_LDS_NODES_DEFAULT;
     if (dynLdsNodes > sc.nodeCount) dynLdsNodes = sc.nodeCount;
     if (dynLdsNodes > 1024u) dynLdsNodes = 1024u;
-    const uint32_t dynFlags = (envXcd >= 0 ? envXcd != 0 : DYN_XCD_RANGES_DEFAULT) ? DYN_FLAG_XCD_RANGES : 0u;
+    static const int envFlush = getenv("GATLING_DYN_FLUSH") ? atoi(getenv("GATLING_DYN_FLUSH")) : -1;
+    const uint32_t flushAt = envFlush >= 0 ? (uint32_t)(envFlush > 64 ? 64 : envFlush) : DYN_FLUSH_AT_DEFAULT;
+    const uint32_t dynFlags = ((envXcd >= 0 ? envXcd != 0 : DYN_XCD_RANGES_DEFAULT) ? DYN_FLAG_XCD_RANGES : 0u) | (flushAt << DYN_FLAG_FLUSH_SHIFT);
     const uint32_t stackBytes = entries * TRACE_BLOCK * (uint32_t)sizeof(uint2) + dynLdsNodes * 80u;
     static const int envWaves = getenv("GATLING_DYN_WAVES") ? atoi(getenv("GATLING_DYN_WAVES")) : 5;
     if (envWaves == 6 && !COUNT && sc.bvhDepth <= 8u) {

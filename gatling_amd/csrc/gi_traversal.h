@@ -222,25 +222,28 @@ __device__ __forceinline__ bool trav_step(RayTrav& R, const SceneView& sc, const
 // "t < tBest, ties to the lower scene-order id" rule and makes the result independent of the test order.
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t TRI_ID_BITS = 26; // queue entry = ray lane << 26 | triangle index (the host refuses scenes with >= 2^26 triangles)
-struct WaveTri {
+template <uint32_t RING>
+struct WaveTriT {
   unsigned long long best[64]; // per ray lane: (t bits << 32) | (scene-order id + 1); low word 0 = no hit yet
   uint4 hit[64];               // per ray lane: (triangle index, u bits, v bits, material word) of that hit
-  uint32_t queue[128];         // ring of pending (ray lane, triangle) pairs
+  uint32_t queue[RING];        // ring of pending (ray lane, triangle) pairs
 };
+typedef WaveTriT<128> WaveTri;    // wave_step: the ring is emptied at the end of every step
+typedef WaveTriT<128> WaveTriDyn; // wave_step_carry: pairs wait for a full batch (a 256-entry ring with prefix-sum appends measured slower)
 // WaveTri lives in LDS, but through a C++ reference the compiler only sees a generic pointer and emits FLAT loads / stores (vector-memory
 // path, each volatile one followed by s_waitcnt vmcnt(0), i.e. a stall on every outstanding global load).  These accessors cast back to
 // address space 3, so the exchanges are ds_read / ds_write with lgkmcnt waits.
 #define GI_LDS __attribute__((address_space(3)))
 typedef uint32_t gi_u4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void wt_queue_put(WaveTri& W, uint32_t i, uint32_t v) { *(volatile GI_LDS uint32_t*)&((GI_LDS WaveTri*)&W)->queue[i] = v; }
-__device__ __forceinline__ uint32_t wt_queue_get(WaveTri& W, uint32_t i) { return *(volatile GI_LDS uint32_t*)&((GI_LDS WaveTri*)&W)->queue[i]; }
-__device__ __forceinline__ void wt_best_put(WaveTri& W, uint32_t i, unsigned long long v) { *(volatile GI_LDS unsigned long long*)&((GI_LDS WaveTri*)&W)->best[i] = v; }
-__device__ __forceinline__ unsigned long long wt_best_get(WaveTri& W, uint32_t i) { return *(volatile GI_LDS unsigned long long*)&((GI_LDS WaveTri*)&W)->best[i]; }
-__device__ __forceinline__ void wt_best_min(WaveTri& W, uint32_t i, unsigned long long v)
-{ __hip_atomic_fetch_min((GI_LDS unsigned long long*)&((GI_LDS WaveTri*)&W)->best[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void wt_hit_put(WaveTri& W, uint32_t i, uint32_t x, uint32_t y, uint32_t z, uint32_t w)
-{ gi_u4 v = {x, y, z, w}; *(volatile GI_LDS gi_u4*)&((GI_LDS WaveTri*)&W)->hit[i] = v; }
-__device__ __forceinline__ uint4 wt_hit_get(WaveTri& W, uint32_t i) { const gi_u4 v = *(volatile GI_LDS gi_u4*)&((GI_LDS WaveTri*)&W)->hit[i]; return make_uint4(v.x, v.y, v.z, v.w); }
+template <class WT> __device__ __forceinline__ void wt_queue_put(WT& W, uint32_t i, uint32_t v) { *(volatile GI_LDS uint32_t*)&((GI_LDS WT*)&W)->queue[i] = v; }
+template <class WT> __device__ __forceinline__ uint32_t wt_queue_get(WT& W, uint32_t i) { return *(volatile GI_LDS uint32_t*)&((GI_LDS WT*)&W)->queue[i]; }
+template <class WT> __device__ __forceinline__ void wt_best_put(WT& W, uint32_t i, unsigned long long v) { *(volatile GI_LDS unsigned long long*)&((GI_LDS WT*)&W)->best[i] = v; }
+template <class WT> __device__ __forceinline__ unsigned long long wt_best_get(WT& W, uint32_t i) { return *(volatile GI_LDS unsigned long long*)&((GI_LDS WT*)&W)->best[i]; }
+template <class WT> __device__ __forceinline__ void wt_best_min(WT& W, uint32_t i, unsigned long long v)
+{ __hip_atomic_fetch_min((GI_LDS unsigned long long*)&((GI_LDS WT*)&W)->best[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+template <class WT> __device__ __forceinline__ void wt_hit_put(WT& W, uint32_t i, uint32_t x, uint32_t y, uint32_t z, uint32_t w)
+{ gi_u4 v = {x, y, z, w}; *(volatile GI_LDS gi_u4*)&((GI_LDS WT*)&W)->hit[i] = v; }
+template <class WT> __device__ __forceinline__ uint4 wt_hit_get(WT& W, uint32_t i) { const gi_u4 v = *(volatile GI_LDS gi_u4*)&((GI_LDS WT*)&W)->hit[i]; return make_uint4(v.x, v.y, v.z, v.w); }
 // Staging buffer of the cooperative fetch (scenes in global memory).  A lane that loads its own 80-byte node issues five
 // 16-byte loads to a cache line no other lane touches, so every load instruction costs the L1 64 tag look-ups; measured,
 // the texture-address unit was busy 63 % of k_trace's time.  Instead lane i of the wave loads 16-byte piece (i % 5) of
@@ -251,13 +254,13 @@ struct WaveStage { uint4 buf[64 * 5]; };
 // block cost two resident blocks per CU and the extra LDS round trip outweighs the saved tag look-ups) -> off.
 constexpr bool TRACE_DYN_COOP_FETCH = false;
 
-template <bool COUNT, bool ALL_LDS, bool CUTOUT, bool COOP>
-__device__ __forceinline__ void wave_tri_batch(WaveTri& W, WaveStage* S, uint32_t head, uint32_t cnt, const RayTrav& R, uint32_t rng, const SceneView& sc,
+template <bool COUNT, bool ALL_LDS, bool CUTOUT, bool COOP, uint32_t RING_MASK = 127u, class WT = WaveTri>
+__device__ __forceinline__ void wave_tri_batch(WT& W, WaveStage* S, uint32_t head, uint32_t cnt, const RayTrav& R, uint32_t rng, const SceneView& sc,
                                                const uint4* s_tris, uint32_t ldsTris, TraceCounters& tc)
 {
   const uint32_t lane = __lane_id();
   const bool act = lane < cnt;
-  const uint32_t e = act ? wt_queue_get(W, (head + lane) & 127u) : 0u;
+  const uint32_t e = act ? wt_queue_get(W, (head + lane) & RING_MASK) : 0u;
   const uint32_t rl = e >> TRI_ID_BITS, triIdx = e & ((1u << TRI_ID_BITS) - 1u);
   // the owning lane's ray (executed by all lanes: wave-uniform control flow)
   const V3 o = v3(__shfl(R.o.x, (int)rl), __shfl(R.o.y, (int)rl), __shfl(R.o.z, (int)rl));
@@ -353,10 +356,59 @@ __device__ __forceinline__ bool wave_step(RayTrav& R, bool alive, WaveTri& W, Wa
   return done;
 }
 
+// wave_step with the triangle ring carried over from step to step (k_trace_dyn).  A node step yields fewer pairs than a batch holds once
+// the tree keeps its leaf slots small (C3: 64 lanes x 6.2 triangles / 17.1 nodes = 23 pairs per step, C4: 18), so flushing the ring at the
+// end of every step ran the ~110-instruction batch at a third of its lanes.  Here a batch runs when 64 pairs are pending; the rest waits.
+// A ray whose walk has ended while pairs of it are still pending is DRAINING: its lane keeps the ray (a pending pair fetches the ray from
+// its owner lane at batch time) and sits out the node phases until the ring has moved past its last pair (the ring is FIFO: `head` has
+// reached `lastEnd`).  The ring is flushed below 64 pairs when `flushAt` or more lanes are blocked like that, or when no lane walks.
+// flushAt == 0 flushes at the end of every step, i.e. wave_step's behaviour.  Results are those of wave_step (the hit key under atomicMin
+// does not depend on when a pair is tested); only the culling distance a walking ray sees may lag by a step or two.
+template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool CUTOUT>
+__device__ __forceinline__ bool wave_step_carry(RayTrav& R, bool alive, bool& draining, uint32_t& lastEnd, uint32_t& head, uint32_t& tail, uint32_t flushAt,
+                                                WaveTriDyn& W, const SceneView& sc, const uint4* s_nodes, uint32_t ldsNodes, uint2 (*s_stack)[TRACE_BLOCK],
+                                                uint2 (&overflow)[OVERFLOW ? OVF_STACK : 1], TraceCounters& tc, uint32_t rng)
+{
+  const uint32_t lane = __lane_id();
+  const bool walking = alive && !draining;
+  uint2 Gt = make_uint2(0u, 0u);
+  if (walking) Gt = trav_node<COUNT, STACK, OVERFLOW, false>(R, sc, s_nodes, ldsNodes, s_stack, overflow, tc);
+  for (;;) { // one ballot round per triangle; a batch as soon as 64 pairs are pending (<= 63 + 64 <= the ring's 128 entries)
+    const unsigned long long m = __ballot(Gt.y != 0u);
+    if (!m) break;
+    const bool push = Gt.y != 0u;
+    if (push) {
+      const uint32_t k = (uint32_t)__ffs((int)Gt.y) - 1u;
+      Gt.y &= Gt.y - 1u;
+      wt_queue_put(W, (tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & 127u, (lane << TRI_ID_BITS) | (Gt.x + k));
+    }
+    tail += (uint32_t)__popcll(m);
+    if (push) lastEnd = tail;
+    if (tail - head >= 64u) { wave_tri_batch<COUNT, false, CUTOUT, false>(W, nullptr, head, 64u, R, rng, sc, nullptr, 0u, tc); head += 64u; }
+  }
+  // the walk moves on before the ring is looked at (the pop does not depend on tBest) ...
+  if (walking && !ANYHIT && trav_pop<STACK, OVERFLOW>(R, s_stack, overflow)) draining = true;
+  if (tail != head) {
+    const unsigned long long blocked = __ballot(alive && draining && (int)(head - lastEnd) < 0);
+    const bool nobodyWalks = __ballot(alive && !draining) == 0ull;
+    if ((uint32_t)__popcll(blocked) >= flushAt || nobodyWalks) { wave_tri_batch<COUNT, false, CUTOUT, false>(W, nullptr, head, tail - head, R, rng, sc, nullptr, 0u, tc); head = tail; }
+  }
+  // ... and every ray picks up what the batches of this step found
+  bool done = false;
+  if (alive) {
+    const unsigned long long key = wt_best_get(W, lane);
+    R.tBest = u2f((uint32_t)(key >> 32));
+    R.found = (uint32_t)key != 0u;
+    if (ANYHIT && !draining && (R.found || trav_pop<STACK, OVERFLOW>(R, s_stack, overflow))) draining = true;
+    done = draining && (int)(head - lastEnd) >= 0;
+  }
+  return done;
+}
+
 // start of a ray in the cooperative scheme (after trav_init)
-__device__ __forceinline__ void wave_ray_begin(WaveTri& W, float tMax) { wt_best_put(W, __lane_id(), (unsigned long long)f2u(tMax) << 32); }
+template <class WT> __device__ __forceinline__ void wave_ray_begin(WT& W, float tMax) { wt_best_put(W, __lane_id(), (unsigned long long)f2u(tMax) << 32); }
 // result of a finished ray
-__device__ __forceinline__ void wave_ray_end(WaveTri& W, RayTrav& R)
+template <class WT> __device__ __forceinline__ void wave_ray_end(WT& W, RayTrav& R)
 {
   __atomic_signal_fence(__ATOMIC_SEQ_CST); // compiler only: the winning lane's store precedes this load in the wave's program order
   if (R.found) { const uint4 h = wt_hit_get(W, __lane_id()); R.bestTri = h.x; R.bestU = u2f(h.y); R.bestV = u2f(h.z); R.bestMat = h.w; }
