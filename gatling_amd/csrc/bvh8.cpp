@@ -17,6 +17,7 @@
 #include <chrono>
 #include <cstdio>
 #include <future>
+#include <memory>
 #include <queue>
 #include <thread>
 
@@ -45,6 +46,12 @@ struct Node2 {
 constexpr int kBins = 16;
 constexpr uint32_t kMaxLeaf = 3; // 3-bit unary triangle count in Node8::meta
 
+// Cost-optimal collapse (Ylitie, Karras, Laine 2017, section 3.1, implemented from the paper): c[i-1] = C(n, i), the cheapest way to
+// represent the subtree of BVH2 node n as at most i slots of an ancestor's 8-wide node; eff[i-1]: slots actually used (1 = the subtree is
+// ONE slot -- a leaf slot if `leaf`, else an 8-wide node of its own); split[j-2]: how many of j >= 2 slots go to the left child when the
+// subtree is spread over j slots (j = 8: the child list of the 8-wide node rooted at n)
+struct Dp { float c[7]; uint8_t eff[7]; uint8_t split[7]; uint8_t leaf; };
+
 struct Builder {
   const std::vector<TriRec>& tris;
   std::vector<Box> triBox;
@@ -59,6 +66,7 @@ struct Builder {
   // Measured (C3 / C4 / C5): nodes per ray 16.6 / 6.9 / 20.1 -> 16.0 / 6.8 / 20.0 but triangles per ray 13.1 / 3.4 / 10.8 -> 18.5 / 5.1 / 22.4,
   // traversal 8-20 % slower: SAH leaves win.  Kept as an experiment knob (GATLING_BVH_BALANCED_BOTTOM=1).
   bool balancedBottom = false;
+  std::unique_ptr<Dp[]> dp; float cPrim = 0.5f; // (not zero-initialised: 44 B per BVH2 node) filled bottom-up by build() when leafSize == 1 (each thread completes its own subtrees)
   uint32_t leafSize = kMaxLeaf; // the BVH2 stops splitting at this many references (1 for the cost-optimal collapse, which forms the leaves itself)
   const float* extBoxes = nullptr; size_t extCount = 0; // box mode (TLAS over instances, BLAS over pre-padded triangle boxes): 6 floats per item
   size_t itemCount() const { return extBoxes ? extCount : tris.size(); }
@@ -76,6 +84,7 @@ struct Builder {
     size_t n = itemCount();
     triBox.resize(n); centroid.resize(3 * n); refs.resize(n);
     nodes.assign(n ? 2 * n - 1 : 1, Node2{});
+    if (leafSize == 1u) dp.reset(new Dp[nodes.size()]);
     const int workers = (n > (1u << 16)) ? spareThreads.load() + 1 : 1;
     std::vector<std::future<void>> jobs;
     for (int w = 1; w < workers; w++) jobs.push_back(std::async(std::launch::async, [this, n, w, workers] { prepareRange(n * w / workers, n * (w + 1) / workers); }));
@@ -112,7 +121,7 @@ struct Builder {
     Box box; box.reset(); Box cb; cb.reset();
     for (uint32_t i = first; i < first + count; i++) { box.grow(triBox[refs[i]]); cb.grow(&centroid[3 * refs[i]]); }
     nodes[idx].box = box; nodes[idx].first = first; nodes[idx].total = count;
-    if (count <= leafSize) { nodes[idx].count = count; return idx; }
+    if (count <= leafSize) { nodes[idx].count = count; if (dp) dpNode(idx); return idx; }
     if (balancedBottom && count <= kMaxLeaf * 8u) {
       // Bottom of the tree: SAH splits leave many 1- and 2-triangle leaves, i.e. half-empty 8-wide nodes (47 % of the child
       // slots were occupied on a 1 M-triangle soup).  A subtree of <= 24 triangles is instead cut into ceil(n/3) leaves of
@@ -126,6 +135,7 @@ struct Builder {
       uint32_t l = build(first, leftCount, idx + 1u);
       uint32_t r = build(first + leftCount, count - leftCount, idx + 2u * leftCount);
       nodes[idx].left = l; nodes[idx].right = r;
+      if (dp) dpNode(idx);
       return idx;
     }
 
@@ -178,7 +188,34 @@ struct Builder {
       r = build(mid, count - leftCount, rightIdx);
     }
     nodes[idx].left = l; nodes[idx].right = r;
+    if (dp) dpNode(idx);
     return idx;
+  }
+
+  void dpNode(uint32_t ii)
+  {
+    const Node2& n = nodes[ii]; Dp& d = dp[ii];
+    const float area = n.box.area();
+    if (n.count > 0) { // a BVH2 leaf (one reference)
+      for (int i = 0; i < 7; i++) { d.c[i] = area * cPrim * (float)n.count; d.eff[i] = 1; d.split[i] = 0; }
+      d.leaf = 1;
+      return;
+    }
+    const Dp& L = dp[n.left]; const Dp& R = dp[n.right];
+    float dist[9];
+    for (int j = 2; j <= 8; j++) {
+      float best = 3.0e38f; int bk = 1;
+      for (int k = std::max(1, j - 7); k <= std::min(7, j - 1); k++) { const float c = L.c[k - 1] + R.c[j - k - 1]; if (c < best) { best = c; bk = k; } }
+      dist[j] = best; d.split[j - 2] = (uint8_t)bk;
+    }
+    const float cLeaf = n.total <= kMaxLeaf ? area * cPrim * (float)n.total : 3.0e38f;
+    const float cInt = area + dist[8];
+    d.leaf = cLeaf <= cInt ? 1 : 0;
+    d.c[0] = d.leaf ? cLeaf : cInt; d.eff[0] = 1;
+    for (int i = 2; i <= 7; i++) {
+      if (dist[i] < d.c[i - 2]) { d.c[i - 1] = dist[i]; d.eff[i - 1] = (uint8_t)i; }
+      else { d.c[i - 1] = d.c[i - 2]; d.eff[i - 1] = d.eff[i - 2]; }
+    }
   }
 };
 
@@ -218,45 +255,13 @@ static void buildCore(const std::vector<TriRec>& trisIn, const float* boxes, siz
   if (const char* e = getenv("GATLING_BVH_COLLAPSE")) collapse = atoi(e);
   float cPrim = 0.5f; // a triangle test costs about half a node test (~110 vs ~214 VALU instructions); measured flat between 0.2 and 0.5 (profiles/r02j_bvh_collapse.txt)
   if (const char* e = getenv("GATLING_BVH_CPRIM")) cPrim = (float)atof(e);
-  if (collapse == 1) B.leafSize = 1;
+  if (collapse == 1) { B.leafSize = 1; B.cPrim = cPrim; }
   B.prepare();
   const double tB = now();
   uint32_t root2 = B.build(0, (uint32_t)itemCount, 0u);
   const double tC = now();
 
-  // ---- cost-optimal collapse: cost[n][i-1] = C(n, i), the cheapest way to represent subtree n as at most i slots of its ancestor's node
-  // eff[n][i-1]: slots actually used (1 = the subtree is ONE slot; whether leaf or 8-wide node: isLeaf[n]); split[n][j-2]: how many of j slots
-  // go to the left child when the subtree is spread over j >= 2 slots (j = 8: the child list of an 8-wide node rooted at n)
-  struct Dp { float c[7]; uint8_t eff[7]; uint8_t split[7]; uint8_t leaf; };
-  std::vector<Dp> dp;
-  if (collapse == 1) {
-    const size_t n2 = B.nodes.size();
-    dp.resize(n2);
-    for (size_t ii = n2; ii-- > 0;) { // children have larger indices than their parent (Builder::nodes)
-      const Node2& n = B.nodes[ii]; Dp& d = dp[ii];
-      const float area = n.box.area();
-      if (n.count > 0) { // a BVH2 leaf (one reference, or several with coincident centroids)
-        for (int i = 0; i < 7; i++) { d.c[i] = area * cPrim * (float)n.count; d.eff[i] = 1; d.split[i] = 0; }
-        d.leaf = 1;
-        continue;
-      }
-      const Dp& L = dp[n.left]; const Dp& R = dp[n.right];
-      float dist[9];
-      for (int j = 2; j <= 8; j++) {
-        float best = 3.0e38f; int bk = 1;
-        for (int k = std::max(1, j - 7); k <= std::min(7, j - 1); k++) { const float c = L.c[k - 1] + R.c[j - k - 1]; if (c < best) { best = c; bk = k; } }
-        dist[j] = best; d.split[j - 2] = (uint8_t)bk;
-      }
-      const float cLeaf = n.total <= kMaxLeaf ? area * cPrim * (float)n.total : 3.0e38f;
-      const float cInt = area + dist[8];
-      d.leaf = cLeaf <= cInt ? 1 : 0;
-      d.c[0] = d.leaf ? cLeaf : cInt; d.eff[0] = 1;
-      for (int i = 2; i <= 7; i++) {
-        if (dist[i] < d.c[i - 2]) { d.c[i - 1] = dist[i]; d.eff[i - 1] = (uint8_t)i; }
-        else { d.c[i - 1] = d.c[i - 2]; d.eff[i - 1] = d.eff[i - 2]; }
-      }
-    }
-  }
+  const Dp* dp = B.dp.get();
   struct Child { uint32_t n2; bool leaf; };
   // the child list of the 8-wide node rooted at BVH2 node `root` under the optimal collapse
   auto gatherOptimal = [&](uint32_t root, Child* ch) {
@@ -276,96 +281,124 @@ static void buildCore(const std::vector<TriRec>& trisIn, const float* boxes, siz
     return n;
   };
 
-  struct Item { uint32_t n2; uint32_t n8; uint32_t depth; };
-  std::queue<Item> q;
-  out.nodes.reserve(itemCount / 4 + 16);
-  if (order) order->reserve(itemCount); else out.tris.reserve(itemCount);
-  out.nodes.emplace_back();
-  q.push({root2, 0, 1});
-
-  while (!q.empty()) {
-    Item it = q.front(); q.pop();
-    out.maxDepth = std::max(out.maxDepth, it.depth);
-    // --- gather up to 8 children
-    uint32_t ch[8]; bool chLeaf[8]; int n = 0;
-    const Node2& r = B.nodes[it.n2];
-    if (r.count > 0 || (collapse == 1 && r.total <= kMaxLeaf)) { ch[0] = it.n2; chLeaf[0] = true; n = 1; } // root that is itself a leaf
-    else if (collapse == 1) {
-      Child cs[8]; n = gatherOptimal(it.n2, cs);
-      for (int i = 0; i < n; i++) { ch[i] = cs[i].n2; chLeaf[i] = cs[i].leaf; }
-    } else { // by opening the largest internal child
-      ch[n++] = r.left; ch[n++] = r.right;
-      while (n < 8) {
-        int best = -1; float bestArea = -1.0f;
-        for (int i = 0; i < n; i++) {
-          const Node2& c = B.nodes[ch[i]];
-          if (c.count == 0 && c.box.area() > bestArea) { bestArea = c.box.area(); best = i; }
+  // ---- emit, one breadth-first level at a time (node and triangle order = the order a queue would give; the levels' nodes are planned
+  // and written in parallel, a prefix sum in between hands out child and triangle indices)
+  struct Pend { uint32_t n2; uint32_t n8; };
+  struct Plan { uint32_t ch[8]; int8_t childInSlot[8]; uint8_t leafMask; uint8_t n; uint32_t internal, tris; uint32_t childBase, triBase; Box nb; };
+  int workers = (int)std::thread::hardware_concurrency();
+  if (const char* e = getenv("GATLING_BUILD_THREADS")) workers = atoi(e);
+  workers = std::min(std::max(workers, 1), 32);
+  auto parallelFor = [&](size_t m, auto&& fn) {
+    const int w = m >= 2048 ? workers : 1;
+    if (w == 1) { for (size_t i = 0; i < m; i++) fn(i); return; }
+    std::vector<std::future<void>> jobs;
+    for (int t = 1; t < w; t++) jobs.push_back(std::async(std::launch::async, [&, t] { for (size_t i = m * t / w; i < m * (t + 1) / w; i++) fn(i); }));
+    for (size_t i = 0; i < m / w; i++) fn(i);
+    for (auto& j : jobs) j.get();
+  };
+  std::vector<Pend> level{{root2, 0u}}, next;
+  std::vector<Plan> plans;
+  out.nodes.resize(1);
+  size_t triCount = 0;
+  while (!level.empty()) {
+    out.maxDepth++;
+    const size_t m = level.size();
+    plans.resize(m);
+    parallelFor(m, [&](size_t li) {
+      Plan& P = plans[li]; const uint32_t n2 = level[li].n2;
+      // --- gather up to 8 children
+      uint32_t* ch = P.ch; bool chLeaf[8]; int n = 0;
+      const Node2& r = B.nodes[n2];
+      if (r.count > 0 || (collapse == 1 && r.total <= kMaxLeaf)) { ch[0] = n2; chLeaf[0] = true; n = 1; } // root that is itself a leaf
+      else if (collapse == 1) {
+        Child cs[8]; n = gatherOptimal(n2, cs);
+        for (int i = 0; i < n; i++) { ch[i] = cs[i].n2; chLeaf[i] = cs[i].leaf; }
+      } else { // by opening the largest internal child
+        ch[n++] = r.left; ch[n++] = r.right;
+        while (n < 8) {
+          int best = -1; float bestArea = -1.0f;
+          for (int i = 0; i < n; i++) {
+            const Node2& c = B.nodes[ch[i]];
+            if (c.count == 0 && c.box.area() > bestArea) { bestArea = c.box.area(); best = i; }
+          }
+          if (best < 0) break;
+          uint32_t opened = ch[best];
+          ch[best] = B.nodes[opened].left; ch[n++] = B.nodes[opened].right;
         }
-        if (best < 0) break;
-        uint32_t opened = ch[best];
-        ch[best] = B.nodes[opened].left; ch[n++] = B.nodes[opened].right;
+        for (int i = 0; i < n; i++) chLeaf[i] = B.nodes[ch[i]].count > 0;
       }
-      for (int i = 0; i < n; i++) chLeaf[i] = B.nodes[ch[i]].count > 0;
-    }
-    // --- node box + slot assignment (greedy max of centroid projection on the slot's octant direction)
-    Box nb; nb.reset();
-    for (int i = 0; i < n; i++) nb.grow(B.nodes[ch[i]].box);
-    float center[3]; for (int a = 0; a < 3; a++) center[a] = 0.5f * (nb.lo[a] + nb.hi[a]);
-    float cost[8][8];
-    for (int i = 0; i < n; i++) {
-      const Box& b = B.nodes[ch[i]].box;
-      float d[3]; for (int a = 0; a < 3; a++) d[a] = 0.5f * (b.lo[a] + b.hi[a]) - center[a];
-      for (int s = 0; s < 8; s++) cost[i][s] = ((s & 1) ? d[0] : -d[0]) + ((s & 2) ? d[1] : -d[1]) + ((s & 4) ? d[2] : -d[2]);
-    }
-    int slotOf[8]; bool slotUsed[8] = {false}; bool childDone[8] = {false};
-    for (int k = 0; k < n; k++) {
-      int bi = -1, bs = -1; float bc = -3.0e38f;
-      for (int i = 0; i < n; i++) if (!childDone[i]) for (int s = 0; s < 8; s++) if (!slotUsed[s] && cost[i][s] > bc) { bc = cost[i][s]; bi = i; bs = s; }
-      slotOf[bi] = bs; slotUsed[bs] = true; childDone[bi] = true;
-    }
-    int childInSlot[8]; for (int s = 0; s < 8; s++) childInSlot[s] = -1;
-    for (int i = 0; i < n; i++) childInSlot[slotOf[i]] = i;
-
-    // --- emit
-    Node8 node; std::memset(&node, 0, sizeof(node));
-    int ex[3];
-    for (int a = 0; a < 3; a++) { node.p[a] = nb.lo[a]; ex[a] = exponentFor(nb.hi[a] - nb.lo[a]); node.e[a] = (uint8_t)(ex[a] + 127); }
-    node.childBase = (uint32_t)out.nodes.size();
-    node.triBase = (uint32_t)(order ? order->size() : out.tris.size());
-    uint32_t triOffset = 0;
-    for (int s = 0; s < 8; s++) {
-      int i = childInSlot[s];
-      if (i < 0) { for (int a = 0; a < 3; a++) { node.qlo[a][s] = 255; node.qhi[a][s] = 0; } continue; }
-      const Node2& c = B.nodes[ch[i]];
-      for (int a = 0; a < 3; a++) {
-        float scale = std::ldexp(1.0f, ex[a]);
-        int lo = (int)std::floor(((double)c.box.lo[a] - (double)node.p[a]) / (double)scale);
-        int hi = (int)std::ceil(((double)c.box.hi[a] - (double)node.p[a]) / (double)scale);
-        lo = std::min(std::max(lo, 0), 255); hi = std::min(std::max(hi, 0), 255);
-        while (lo > 0 && node.p[a] + (float)lo * scale > c.box.lo[a]) lo--;
-        while (hi < 255 && node.p[a] + (float)hi * scale < c.box.hi[a]) hi++;
-        node.qlo[a][s] = (uint8_t)lo; node.qhi[a][s] = (uint8_t)hi;
+      // --- node box + slot assignment (greedy max of centroid projection on the slot's octant direction)
+      Box nb; nb.reset();
+      for (int i = 0; i < n; i++) nb.grow(B.nodes[ch[i]].box);
+      float center[3]; for (int a = 0; a < 3; a++) center[a] = 0.5f * (nb.lo[a] + nb.hi[a]);
+      float cost[8][8];
+      for (int i = 0; i < n; i++) {
+        const Box& b = B.nodes[ch[i]].box;
+        float d[3]; for (int a = 0; a < 3; a++) d[a] = 0.5f * (b.lo[a] + b.hi[a]) - center[a];
+        for (int s = 0; s < 8; s++) cost[i][s] = ((s & 1) ? d[0] : -d[0]) + ((s & 2) ? d[1] : -d[1]) + ((s & 4) ? d[2] : -d[2]);
       }
-      if (chLeaf[i]) { // leaf slot: unary count in the high 3 bits, triangle offset in the low 5
-        const uint32_t cnt = c.total;
-        uint32_t unary = (1u << cnt) - 1u;
-        node.meta[s] = (uint8_t)((unary << 5) | triOffset);
-        for (uint32_t k = 0; k < cnt; k++) {
-          if (order) { order->push_back(B.refs[c.first + k]); continue; }
-          TriRec t = B.tris[B.refs[c.first + k]];
-          t.origId = B.refs[c.first + k];
-          out.tris.push_back(t);
+      int slotOf[8]; bool slotUsed[8] = {false}; bool childDone[8] = {false};
+      for (int k = 0; k < n; k++) {
+        int bi = -1, bs = -1; float bc = -3.0e38f;
+        for (int i = 0; i < n; i++) if (!childDone[i]) for (int s = 0; s < 8; s++) if (!slotUsed[s] && cost[i][s] > bc) { bc = cost[i][s]; bi = i; bs = s; }
+        slotOf[bi] = bs; slotUsed[bs] = true; childDone[bi] = true;
+      }
+      for (int s = 0; s < 8; s++) P.childInSlot[s] = -1;
+      P.leafMask = 0; P.internal = 0; P.tris = 0; P.n = (uint8_t)n; P.nb = nb;
+      for (int i = 0; i < n; i++) {
+        P.childInSlot[slotOf[i]] = (int8_t)i;
+        if (chLeaf[i]) { P.leafMask |= (uint8_t)(1u << i); P.tris += B.nodes[ch[i]].total; } else P.internal++;
+      }
+    });
+    // --- indices: internal children and triangles in level order, slot order within a node
+    size_t nodeBase = out.nodes.size(), nodeEnd = nodeBase, triEnd = triCount;
+    for (size_t li = 0; li < m; li++) { plans[li].childBase = (uint32_t)nodeEnd; plans[li].triBase = (uint32_t)triEnd; nodeEnd += plans[li].internal; triEnd += plans[li].tris; }
+    out.nodes.resize(nodeEnd);
+    if (order) order->resize(triEnd); else out.tris.resize(triEnd);
+    next.resize(nodeEnd - nodeBase);
+    parallelFor(m, [&](size_t li) {
+      const Plan& P = plans[li];
+      Node8 node; std::memset(&node, 0, sizeof(node));
+      int ex[3]; float scale[3];
+      for (int a = 0; a < 3; a++) { node.p[a] = P.nb.lo[a]; ex[a] = exponentFor(P.nb.hi[a] - P.nb.lo[a]); node.e[a] = (uint8_t)(ex[a] + 127); scale[a] = std::ldexp(1.0f, ex[a]); }
+      node.childBase = P.childBase;
+      node.triBase = P.triBase;
+      uint32_t triOffset = 0, childIdx = P.childBase;
+      for (int s = 0; s < 8; s++) {
+        const int i = P.childInSlot[s];
+        if (i < 0) { for (int a = 0; a < 3; a++) { node.qlo[a][s] = 255; node.qhi[a][s] = 0; } continue; }
+        const Node2& c = B.nodes[P.ch[i]];
+        for (int a = 0; a < 3; a++) {
+          int lo = (int)std::floor(((double)c.box.lo[a] - (double)node.p[a]) / (double)scale[a]);
+          int hi = (int)std::ceil(((double)c.box.hi[a] - (double)node.p[a]) / (double)scale[a]);
+          lo = std::min(std::max(lo, 0), 255); hi = std::min(std::max(hi, 0), 255);
+          while (lo > 0 && node.p[a] + (float)lo * scale[a] > c.box.lo[a]) lo--;
+          while (hi < 255 && node.p[a] + (float)hi * scale[a] < c.box.hi[a]) hi++;
+          node.qlo[a][s] = (uint8_t)lo; node.qhi[a][s] = (uint8_t)hi;
         }
-        triOffset += cnt;
-      } else {
-        node.imask |= (uint8_t)(1u << s);
-        node.meta[s] = (uint8_t)((1u << 5) | (24u + (uint32_t)s));
-        uint32_t childIdx = (uint32_t)out.nodes.size();
-        out.nodes.emplace_back();
-        q.push({ch[i], childIdx, it.depth + 1});
+        if (P.leafMask & (1u << i)) { // leaf slot: unary count in the high 3 bits, triangle offset in the low 5
+          const uint32_t cnt = c.total;
+          uint32_t unary = (1u << cnt) - 1u;
+          node.meta[s] = (uint8_t)((unary << 5) | triOffset);
+          for (uint32_t k = 0; k < cnt; k++) {
+            const uint32_t ref = B.refs[c.first + k], dst = P.triBase + triOffset + k;
+            if (order) { (*order)[dst] = ref; continue; }
+            TriRec t = B.tris[ref];
+            t.origId = ref;
+            out.tris[dst] = t;
+          }
+          triOffset += cnt;
+        } else {
+          node.imask |= (uint8_t)(1u << s);
+          node.meta[s] = (uint8_t)((1u << 5) | (24u + (uint32_t)s));
+          next[childIdx - nodeBase] = Pend{P.ch[i], childIdx};
+          childIdx++;
+        }
       }
-    }
-    out.nodes[it.n8] = node;
+      out.nodes[level[li].n8] = node;
+    });
+    triCount = triEnd;
+    level.swap(next);
   }
   if (timing) fprintf(stderr, "[gatling_gi] bvh8: prepare %.0f ms, bvh2 %.0f ms, collapse+quantise %.0f ms (%zu items, %zu nodes)\n", tB - tA, tC - tB, now() - tC, itemCount, out.nodes.size());
 }

@@ -57,6 +57,23 @@ def test_bvh8_builder_is_conservative(n, seed):
         assert nodes.value >= n // 24
 
 
+def test_bvh8_builder_collapse_rules_and_thread_counts(monkeypatch):
+    """Both collapse rules stay conservative; the cost-optimal one fills the 8-wide nodes (fewer nodes for the same triangles) and is
+    independent of the number of builder threads (large enough an input for the parallel paths: > 2^16 triangles, levels > 2048 nodes)."""
+    rng = np.random.default_rng(11)
+    n = 150_000
+    v = (rng.uniform(-1, 1, (n, 1, 3)) + rng.normal(0, 0.01, (n, 3, 3))).astype(np.float32)
+    L = capi.load_library()
+    got = {}
+    for collapse, threads in ((0, 8), (1, 1), (1, 8)):
+        monkeypatch.setenv("GATLING_BVH_COLLAPSE", str(collapse)); monkeypatch.setenv("GATLING_BUILD_THREADS", str(threads))
+        nodes, depth = C.c_uint32(), C.c_uint32()
+        assert L.giCDebugValidateBvh(v.ctypes.data_as(capi._FP), n, C.byref(nodes), C.byref(depth)) == 0
+        got[(collapse, threads)] = (nodes.value, depth.value)
+    assert got[(1, 1)] == got[(1, 8)]
+    assert got[(1, 8)][0] < 0.95 * got[(0, 8)][0] and got[(1, 8)][1] <= 16
+
+
 def test_bvh8_builder_degenerate_inputs():
     """Axis-aligned planes (flat boxes), coincident triangles and huge coordinates."""
     L = capi.load_library()
