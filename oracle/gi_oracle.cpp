@@ -1875,6 +1875,23 @@ float orc_dbg_hg_cos(float r, float g) { return henyey_greenstein_cos(r, g); }
 void orc_dbg_quat_rotate_dir(const float* q, const float* dir, float* out) { V3 v = quat_rotate_dir(q, v3(dir)); out[0] = v.x; out[1] = v.y; out[2] = v.z; }
 float orc_dbg_apply_wrap_and_crop(float coord, int wrap, int res) { return apply_wrap_and_crop(coord, wrap, res); }
 void orc_dbg_adapt_normal(const float* rayDir, const float* geomNormal, const float* normal, float* out) { V3 v = adapt_normal(v3(rayDir), v3(geomNormal), v3(normal)); out[0] = v.x; out[1] = v.y; out[2] = v.z; }
+
+// scene_data_lookup (the restatement above) for one hit, for tests/test_oracle_ref.py: primvars as the boundary hands them over (mesh primvars
+// override instancer primvars of the same name), the hit's vertex indices / barycentrics / primitive id / instance id.  Returns 1 if the name resolved.
+int orc_dbg_scene_data_lookup(const OrcPrimvar* primvars, uint32_t primvarCount, const OrcPrimvar* instancerPrimvars, uint32_t instancerPrimvarCount, const char* name, int comps,
+                              const uint32_t* hitIndices, float bu, float bv, uint32_t prim, int32_t instanceId, const float* cameraPosition, float frame, float* out)
+{
+  OrcMesh src; memset(&src, 0, sizeof(src));
+  src.primvars = primvars; src.primvarCount = primvarCount; src.instancerPrimvars = instancerPrimvars; src.instancerPrimvarCount = instancerPrimvarCount;
+  MeshData md; md.faces = nullptr; md.faceCount = 0; md.material = 0; md.flags = 0; md.objectId = 0; md.faceIdStride = 1; md.src = &src;
+  State st; st.mesh = &md; st.prim = prim; st.instanceId = instanceId; st.bu = bu; st.bv = bv;
+  for (int i = 0; i < 3; i++) st.hitIndices[i] = hitIndices[i];
+  st.cameraPosition = v3(cameraPosition); st.frame = frame;
+  float v[3] = {0, 0, 0};
+  const bool ok = scene_data_lookup(st, name, comps, v);
+  for (int c = 0; c < comps && c < 3; c++) out[c] = v[c];
+  return ok ? 1 : 0;
+}
 // setup_shading_state for one triangle given as three GiVertex (48 B each), the mesh transform and one instance transform (4x4 row-major,
 // USD convention).  out: position, normal, geom normal, tangentU, tangentV, (u, v, frontFace); fvertexOut (24 floats) = the packed vertices
 // the host uploads (rp_main.h:58-64), o2wOut (12) / w2oOut (9) = the composed object-to-world rows and the inverse of its 3x3 part.

@@ -53,7 +53,7 @@ def cut_function(text: str, name: str) -> str:
     return text[m.start():j] + "\n"
 
 
-LOOP_WHOLE = ["common.glsl", "aovs.glsl", "colormap.glsl", "rp_main_payload.glsl", "interface/rp_main.h", "mdl_types.glsl", "mdl_shading_state.glsl",
+LOOP_WHOLE = ["common.glsl", "aovs.glsl", "colormap.glsl", "rp_main_payload.glsl", "interface/rp_main.h", "mdl_types.glsl", "mdl_shading_state.glsl", "mdl_renderer_state.glsl",
               "rp_main_descriptors.glsl", "rp_main.rgen", "rp_main.chit", "rp_main.miss", "rp_main_shadow.miss"]
 # (name, -D flags): the feature macros GlslShaderGen.cpp derives from the render settings (src/gi/impl/GlslShaderGen.cpp:196-300)
 LOOP_VARIANTS = [("default", ["JITTERED_SAMPLING", "FILTER_IMPORTANCE_SAMPLING", "PROGRESSIVE_ACCUMULATION", "DOME_LIGHT_CAMERA_VISIBLE", "MEDIUM_STACK_SIZE=0"]),
@@ -62,6 +62,9 @@ LOOP_VARIANTS = [("default", ["JITTERED_SAMPLING", "FILTER_IMPORTANCE_SAMPLING",
                  ("dof_clip_box", ["JITTERED_SAMPLING", "PROGRESSIVE_ACCUMULATION", "DOME_LIGHT_CAMERA_VISIBLE", "MEDIUM_STACK_SIZE=0", "DEPTH_OF_FIELD", "CLIPPING_PLANES"]),
                  ("nojitter", ["DOME_LIGHT_CAMERA_VISIBLE", "MEDIUM_STACK_SIZE=0"]),
                  # every AOV but ClockCycles (bit 6: clockARB)
+                 # the MDL renderer runtime's scene data (primvar) readers, mdl_interface.glsl:258-474, with the two named ids of Frontend.cpp:251-252
+                 ("scenedata", ["JITTERED_SAMPLING", "FILTER_IMPORTANCE_SAMPLING", "PROGRESSIVE_ACCUMULATION", "DOME_LIGHT_CAMERA_VISIBLE", "MEDIUM_STACK_SIZE=0", "SCENE_DATA_COUNT=6",
+                                "RENDERER_STATE_TYPE=mdl_renderer_state", "CAMERA_POSITION_SCENE_DATA_INDEX=7", "FRAME_SCENE_DATA_INDEX=8"]),
                  ("aovs", ["JITTERED_SAMPLING", "FILTER_IMPORTANCE_SAMPLING", "PROGRESSIVE_ACCUMULATION", "DOME_LIGHT_CAMERA_VISIBLE", "MEDIUM_STACK_SIZE=0", "AOV_MASK=0x1ffbf"])]
 
 
@@ -120,6 +123,11 @@ def build_loop(shaders: str, verbose=False):
     open(os.path.join(gen, "interface", "gtl.h"), "w").write("/* stub: ref_loop.cpp defines the GLSL side of interface/gtl.h */\n")
     for rel in LOOP_WHOLE:
         open(os.path.join(gen, rel), "w").write(loop_to_cpp(rel, open(os.path.join(shaders, rel)).read()))
+    # the scene-data readers of mdl_interface.glsl (from scene_data_isvalid up to, not including, the float4x4 stub); the rest of that file is
+    # the texture runtime over hardware samplers (deviation D5)
+    mi = open(os.path.join(shaders, "mdl_interface.glsl")).read()
+    a, b = mi.index("bool scene_data_isvalid"), mi.index("mat4 scene_data_lookup_float4x4")
+    open(os.path.join(gen, "fn_scene_data.h"), "w").write("// mdl_interface.glsl: scene data readers\n" + to_cpp(mi[a:b]))
     objs = []
     for name, defs in LOOP_VARIANTS:
         obj = os.path.join(OUT, f"ref_loop_{name}.o")

@@ -113,14 +113,26 @@ struct vec4 {
   vec3 xyz() const { return vec3(x, y, z); }
   vec3 rgb() const { return vec3(x, y, z); }
 };
-struct ivec4 { int x, y, z, w; };
+struct ivec4 { int x, y, z, w; ivec4() : x(0), y(0), z(0), w(0) {} ivec4(int a, int b, int c, int d) : x(a), y(b), z(c), w(d) {} };
+struct ivec2 { int x, y; ivec2() : x(0), y(0) {} ivec2(int a, int b) : x(a), y(b) {} };
 // Matrices, column-major as in GLSL; products accumulate left to right (GLSL leaves the order to the driver; this is the oracle's order too,
 // so comparisons through these test the STRUCTURE of a computation -- which transform, which transpose -- not the driver's rounding)
 struct mat4x3 { vec3 c[4]; };                       // 4 columns of vec3 (gl_ObjectToWorldEXT / gl_WorldToObjectEXT)
 struct mat3 { vec3 c[3]; mat3() {} explicit mat3(const mat4x3& m) { c[0] = m.c[0]; c[1] = m.c[1]; c[2] = m.c[2]; } };
 inline vec4 make_vec4(const vec3& v, Float w) { return vec4(v.x, v.y, v.z, w); }
 struct uvec2 { uint x, y; };
-struct uvec3 { uint x, y, z; uvec2 xy() const { return uvec2{x, y}; } };
+struct uvec3 {
+  uint x, y, z;
+  uvec3() : x(0), y(0), z(0) {}
+  explicit uvec3(uint a) : x(a), y(a), z(a) {}
+  uvec3(uint a, uint b, uint c) : x(a), y(b), z(c) {}
+  uvec2 xy() const { return uvec2{x, y}; }
+  uint& operator[](int i) { return i == 0 ? x : (i == 1 ? y : z); }
+  uint operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+};
+inline uvec3 operator*(const uvec3& a, uint b) { return uvec3(a.x * b, a.y * b, a.z * b); }
+inline uvec3 operator*(const uvec3& a, int b) { return a * (uint)b; }
+inline uvec3 operator+(const uvec3& a, int b) { return uvec3(a.x + (uint)b, a.y + (uint)b, a.z + (uint)b); }
 struct uvec4 {
   uint x, y, z, w;
   uvec4() : x(0), y(0), z(0), w(0) {}

@@ -84,7 +84,21 @@ struct RawIntBuffer { const int* data; RawIntBuffer(uint64_t) : data(g_faceIdWor
 struct VertexBuffer { const FVertex* data; VertexBuffer(uint64_t) : data(g_vertices) {} };
 static uint g_material; static bool g_thinWalled; static float g_matInfo[13];
 
+#ifndef SCENE_DATA_COUNT
+#define SCENE_DATA_COUNT 0
+#endif
+#if SCENE_DATA_COUNT > 0
+#include "mdl_renderer_state.glsl"
+#endif
 #include "mdl_types.glsl"
+#if SCENE_DATA_COUNT > 0
+// buffer references of the scene-data readers (mdl_interface.glsl:258-262): the "device address" is a host pointer here
+struct BufferRefInt { const int* data; BufferRefInt(uint64_t a) : data(reinterpret_cast<const int*>(a)) {} };
+struct BufferRefFloat { const Float* data; BufferRefFloat(uint64_t a) : data(reinterpret_cast<const Float*>(a)) {} };
+struct BufferRefVec2 { const vec2* data; BufferRefVec2(uint64_t a) : data(reinterpret_cast<const vec2*>(a)) {} };
+struct BufferRefVec4 { const vec4* data; BufferRefVec4(uint64_t a) : data(reinterpret_cast<const vec4*>(a)) {} };
+#include "fn_scene_data.h"
+#endif
 
 // ---- the entry points the MDL back end generates per material (GlslShaderGen.cpp:181-193), answered by the oracle's closed forms
 static inline void to3(const vec3& v, float* o);
@@ -257,3 +271,32 @@ extern "C" int REF_ENTRY(void* hook, const RefLoopParams* p, const float* prevCo
     }
   return 0;
 }
+
+#if SCENE_DATA_COUNT > 0
+// One scene-data read through the reference's readers.  kind: 1 float, 2 float2, 3 float3, 4 float4, 11..14 int .. int4.  infos: the six
+// sceneDataInfos words of the BLAS payload preamble (Gi.cpp:955-1018), buffer: the payload buffer they index into (offsets in units of 32 B).
+extern "C" void ref_scene_data_lookup(int kind, const uint32_t* infos, const void* buffer, const uint32_t* hitIndices, const float* bary, uint32_t primitiveId, int32_t instanceId,
+                                      int sceneDataId, int uniformLookup, const float* defaults, const float* cameraPosition, float frame, float* out)
+{
+  using namespace REF_NS;
+  State st; st.renderer_state.hitIndices = uvec3(hitIndices[0], hitIndices[1], hitIndices[2]); st.renderer_state.hitBarycentrics = vec2(bary[0], bary[1]);
+  st.renderer_state.sceneDataBufferAddress = reinterpret_cast<uint64_t>(buffer);
+  for (int i = 0; i < SCENE_DATA_COUNT; i++) st.renderer_state.sceneDataInfos[i] = infos[i];
+  gl_PrimitiveID = primitiveId; gl_InstanceID = 0; static int ids[1]; ids[0] = instanceId; InstanceIds = ids;
+  ubo.cameraPosition = vec3(cameraPosition[0], cameraPosition[1], cameraPosition[2]); ubo.frame = frame;
+  const bool ul = uniformLookup != 0;
+  int iv[4]; for (int c = 0; c < 4; c++) memcpy(&iv[c], &defaults[c], 4);
+  switch (kind) {
+  case 1: out[0] = scene_data_lookup_float(st, sceneDataId, defaults[0], ul).v; break;
+  case 2: { vec2 r = scene_data_lookup_float2(st, sceneDataId, vec2(defaults[0], defaults[1]), ul); out[0] = r.x.v; out[1] = r.y.v; } break;
+  case 3: { vec3 r = scene_data_lookup_float3(st, sceneDataId, vec3(defaults[0], defaults[1], defaults[2]), ul); out[0] = r.x.v; out[1] = r.y.v; out[2] = r.z.v; } break;
+  case 4: { vec4 r = scene_data_lookup_float4(st, sceneDataId, vec4(defaults[0], defaults[1], defaults[2], defaults[3]), ul); out[0] = r.x.v; out[1] = r.y.v; out[2] = r.z.v; out[3] = r.w.v; } break;
+  case 11: { int r = scene_data_lookup_int(st, sceneDataId, iv[0], ul); memcpy(&out[0], &r, 4); } break;
+  case 12: { ivec2 r = scene_data_lookup_int2(st, sceneDataId, ivec2(iv[0], iv[1]), ul); memcpy(&out[0], &r.x, 4); memcpy(&out[1], &r.y, 4); } break;
+  case 13: { ivec3 r = scene_data_lookup_int3(st, sceneDataId, ivec3(iv[0], iv[1], iv[2]), ul); memcpy(&out[0], &r.x, 4); memcpy(&out[1], &r.y, 4); memcpy(&out[2], &r.z, 4); } break;
+  case 14: { ivec4 r = scene_data_lookup_int4(st, sceneDataId, ivec4(iv[0], iv[1], iv[2], iv[3]), ul); memcpy(&out[0], &r.x, 4); memcpy(&out[1], &r.y, 4); memcpy(&out[2], &r.z, 4); memcpy(&out[3], &r.w, 4); } break;
+  default: break;
+  }
+}
+#endif
+

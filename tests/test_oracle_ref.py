@@ -242,3 +242,85 @@ def test_shading_state_matches_reference_setup_mdl_shading_state(ref, orc):
         worst = max(worst, np.abs(a - b).max() / max(1.0, np.abs(a).max()))
         assert np.array_equal(bits(a), bits(b)), (case, a, b)
     assert worst == 0.0
+
+
+def test_scene_data_readers_against_reference(ref, orc):
+    """The MDL renderer runtime's primvar readers -- scene_data_isvalid, get_scene_data_indices, scene_data_lookup_float / _float2 / _float3 /
+    _float4 / _int .. _int4 and the two named ids (mdl_interface.glsl:264-474) -- compiled from the reference and fed a BLAS payload buffer
+    packed as Gi.cpp:955-1018 packs it (32-byte aligned blocks, info word = offset / 32 | (components - 1) << 28 | interpolation << 30),
+    against the oracle's scene_data_lookup on the same primvars as the boundary hands them over.  Float reads agree bit for bit (same
+    v0 * bx + v1 * by + v2 * bz association), integer reads exactly (nearest-vertex rule, per component)."""
+    from oracle import orc as O
+    rng = np.random.default_rng(5)
+    nverts, nfaces, ninst = 40, 25, 6
+    counts = {0: 1, 1: ninst, 2: nfaces, 3: nverts}  # constant / instance / uniform / vertex (Gi.h:81-84)
+    # six scene-data slots: (type, interpolation); types 0..3 float..vec4, 4..7 int..int4 (Gi.h:76-79)
+    slots = [(2, 3), (0, 2), (7, 3), (1, 1), (4, 0), (3, 3)]
+    buffer = bytearray(64)  # the preamble region; readers only ever see offsets past it
+    infos, pvs, keep = [], [], []
+    for i, (ty, interp) in enumerate(slots):
+        comps = (ty % 4) + 1
+        n = counts[interp] * comps
+        data = (rng.integers(-50, 50, n).astype(np.int32).view(np.float32) if ty >= 4 else rng.uniform(-2, 2, n).astype(np.float32))
+        while len(buffer) % 32:
+            buffer += b"\0"
+        off = len(buffer)
+        buffer += data.tobytes()
+        infos.append((off // 32) | ((comps - 1) << 28) | (interp << 30))
+        keep.append(np.ascontiguousarray(data))
+        pv = O.OrcPrimvar(f"pv{i}".encode(), ty, interp, keep[-1].ctypes.data, n)
+        pvs.append(pv)
+    buffer += b"\0" * 64
+    buf = (C.c_char * len(buffer)).from_buffer(buffer)
+    infos_c = (C.c_uint32 * 6)(*infos)
+    pv_arr = (O.OrcPrimvar * len(pvs))(*pvs)
+    ref.ref_scene_data_lookup.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+    orc.orc_dbg_scene_data_lookup.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_char_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_uint32, C.c_int32, C.c_void_p, C.c_float, C.c_void_p]
+    cam, frame = f3((1.5, -2.0, 0.25)), 17.0
+    checked = 0
+    for trial in range(400):
+        hit = (C.c_uint32 * 3)(*rng.integers(0, nverts, 3))
+        bu = float(np.float32(rng.uniform(0, 1))); bv = float(np.float32(rng.uniform(0, 1 - bu)))
+        bary = (C.c_float * 2)(bu, bv)
+        prim, inst = int(rng.integers(0, nfaces)), int(rng.integers(0, ninst))
+        for i, (ty, interp) in enumerate(slots):
+            comps = (ty % 4) + 1
+            is_int = ty >= 4
+            want_comps = min(comps, 3)  # the oracle's materials read one or three components
+            if not is_int and comps == 2:
+                continue  # float2 has no consumer in the material model; its reader is compared below through kind 2 on its own
+            out_ref, out_orc, dflt = (C.c_float * 4)(), (C.c_float * 4)(), F4(9, 9, 9, 9)
+            kind = (10 if is_int else 0) + (1 if want_comps == 1 else 3)
+            ref.ref_scene_data_lookup(kind, infos_c, C.addressof(buf), hit, bary, prim, inst, i + 1, 0, dflt, cam, frame, out_ref)
+            ok = orc.orc_dbg_scene_data_lookup(pv_arr, len(pvs), None, 0, f"pv{i}".encode(), want_comps, hit, bu, bv, prim, inst, cam, C.c_float(frame), out_orc)
+            assert ok == 1
+            r = np.array(out_ref[:want_comps], np.float32)
+            if is_int:
+                r = r.view(np.int32).astype(np.float32)  # the oracle hands integer scene data to the material as floats
+            assert np.array_equal(r.view(np.uint32), np.array(out_orc[:want_comps], np.float32).view(np.uint32)), (trial, i, r, out_orc[:want_comps])
+            checked += 1
+    assert checked > 1500
+    # invalid ids and the named ids: 0, beyond the count, a slot marked invalid -> default; CAMERA_POSITION (float3 only), FRAME (float only)
+    infos_bad = (C.c_uint32 * 6)(*([infos[0], 0xFFFFFFFF] + infos[2:]))
+    hit, bary, dflt = (C.c_uint32 * 3)(1, 2, 3), (C.c_float * 2)(0.25, 0.5), F4(7, 8, 9, 10)
+    out = (C.c_float * 4)()
+    for sid in (0, 9, 2):
+        ref.ref_scene_data_lookup(3, infos_bad, C.addressof(buf), hit, bary, 0, 0, sid, 0, dflt, cam, frame, out)
+        assert list(out[:3]) == [7, 8, 9]
+    ref.ref_scene_data_lookup(3, infos_c, C.addressof(buf), hit, bary, 0, 0, 7, 0, dflt, cam, frame, out)
+    assert list(out[:3]) == [1.5, -2.0, 0.25]
+    ref.ref_scene_data_lookup(1, infos_c, C.addressof(buf), hit, bary, 0, 0, 8, 0, dflt, cam, frame, out)
+    assert out[0] == 17.0
+    o3 = (C.c_float * 4)()
+    assert orc.orc_dbg_scene_data_lookup(pv_arr, len(pvs), None, 0, b"CAMERA_POSITION", 3, hit, 0.25, 0.5, 0, 0, cam, C.c_float(frame), o3) == 1 and list(o3[:3]) == [1.5, -2.0, 0.25]
+    assert orc.orc_dbg_scene_data_lookup(pv_arr, len(pvs), None, 0, b"FRAME", 1, hit, 0.25, 0.5, 0, 0, cam, C.c_float(frame), o3) == 1 and o3[0] == 17.0
+    assert orc.orc_dbg_scene_data_lookup(pv_arr, len(pvs), None, 0, b"nope", 3, hit, 0.25, 0.5, 0, 0, cam, C.c_float(frame), o3) == 0
+    # the float2 and float4 readers on their own slots (interpolated in the same association)
+    for kind, slot in ((2, 3), (4, 5)):
+        ty, interp = slots[slot]; comps = ty + 1
+        ref.ref_scene_data_lookup(kind, infos_c, C.addressof(buf), hit, bary, 3, 4, slot + 1, 0, dflt, cam, frame, out)
+        d = keep[slot].reshape(-1, comps)
+        idx = [4, 4, 4] if interp == 1 else [1, 2, 3]
+        bx, by, bz = np.float32(1.0) - np.float32(0.25) - np.float32(0.5), np.float32(0.25), np.float32(0.5)
+        want = (d[idx[0]] * bx + d[idx[1]] * by) + d[idx[2]] * bz
+        assert np.array_equal(np.array(out[:comps], np.float32), want.astype(np.float32))
