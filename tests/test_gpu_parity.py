@@ -563,6 +563,54 @@ def test_soup_scene_with_nee_parity(gi, orc):
     render_both(gi, orc, desc, RenderSettings(spp=2, max_bounces=5, next_event_estimation=True), 96, 54)
 
 
+def _telescope(n, ratio):
+    """n triangles whose sizes and distances from the origin shrink geometrically: SAH peels them off one cluster at a time, so the tree is
+    as deep as trees get (host-side depth 39 ... 54 for the cases below against 8 ... 10 for BASELINE's scenes)."""
+    from gatling_amd.meshprep import bake_vertices
+    i = np.arange(n, dtype=np.float64)
+    s = ratio ** (-i)
+    c = np.stack([s * 3.0, 0.3 * s * ((i % 5) - 2), 0.05 * s * (i % 3)], 1)
+    tri = np.array([[0, -0.5, 0], [1, 0, 0.1], [0, 0.5, 0]])
+    p = (c[:, None, :] + tri[None] * s[:, None, None]).astype(np.float32).reshape(-1, 3)
+    nrm = np.cross(p[1::3] - p[0::3], p[2::3] - p[0::3]); nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-30)
+    desc = SceneDesc(meshes=[MeshDesc("telescope", bake_vertices(p, np.repeat(nrm.astype(np.float32), 3, axis=0)), np.arange(3 * n, dtype=np.uint32).reshape(-1, 3), 0, double_sided=True)],
+                     materials=[MaterialDesc.usd_preview_surface(diffuseColor=(0.8, 0.7, 0.6), roughness=0.5)],
+                     camera=CameraDesc(position=(1.6, 0.0, 3.2), forward=(-0.05, 0.0, -1.0), up=(0, 1, 0), vfov=0.9))
+    desc.rect_lights.append(RectLight(origin=(1.0, 0.0, 3.0), t0=(1, 0, 0), t1=(0, 1, 0), base_emission=(9, 9, 9), width=2.0, height=2.0))
+    return desc
+
+
+@pytest.mark.parametrize("n,ratio,spill8", [(100, 1.1, False), (400, 1.03, False), (2000, 1.006, False), (2000, 1.006, True), (400, 1.2, False)])
+def test_deep_trees_parity(gi, orc, monkeypatch, n, ratio, spill8):
+    """Trees deeper than BASELINE's scenes give (host-side depth 7 / 11 / 12 / 39): 100 triangles run the fused kernels with the 8-entry
+    stack nearly full, 400 and 2000 the 16-entry stack, `spill8` the 8-entry stack with the scratch overflow, the last case the deepest
+    tree the builder produces here (16 entries + overflow) -- images with shadow rays, and random rays, against the oracle.
+    The last case is compared by image only: its triangles shrink to 1e-32 at the origin, and a ray that passes within float resolution of
+    the origin makes the exact test's `dot(o - v0, d x e2)` cancel to exactly 0, so it "hits" a 5e-14-sized triangle it geometrically misses
+    by 1e-7 -- a hit no box test can promise to keep (3 of 4000 such rays differ between this tree and the oracle's)."""
+    if spill8:
+        monkeypatch.setenv("GATLING_TRACE_DYN_SPILL8", "1")
+    desc = _telescope(n, ratio)
+    render_both(gi, orc, desc, RenderSettings(spp=3, max_bounces=4, next_event_estimation=True), 80, 45)
+    if ratio ** (-n) < 1e-7:
+        return
+    rng = np.random.default_rng(n)
+    m = 4000
+    o = np.stack([rng.uniform(-0.2, 3.5, m), rng.uniform(-0.6, 0.6, m), rng.uniform(0.3, 2.0, m)], 1).astype(np.float32)
+    j = rng.integers(0, n, m); sj = ratio ** (-j.astype(np.float64))
+    t = np.stack([3.3 * sj, 0.3 * sj * ((j % 5) - 2), 0.05 * sj * (j % 3)], 1)  # aim at triangles of every size
+    d = (t - o); d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    sc = gi.Scene(desc)
+    try:
+        tuv, ip = sc.trace_rays(o, d)
+    finally:
+        sc.close()
+    rtuv, rip = orc.trace_rays(desc, o, d)
+    assert np.array_equal(ip, rip)
+    hit = rip[:, 0] >= 0
+    assert hit.mean() > 0.5 and np.array_equal(tuv[hit].view(np.uint32), rtuv[hit].view(np.uint32))
+
+
 @pytest.mark.parametrize("variant", ["openpbr+dome", "ups", "dome-hidden"])
 def test_textured_scene_parity(gi, orc, variant):
     """Texture runtime (mdl_interface.glsl:8-38, 127-145, 238-256) + dome light (rp_main.miss:38-86) through the C ABI:
