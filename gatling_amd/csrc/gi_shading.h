@@ -387,6 +387,9 @@ __device__ __forceinline__ OpbrParams opbr_params(const MaterialRec* m, const Sh
   return o;
 }
 
+// The lobe is chosen first (cheap, divergent), then ONE micro-facet sample serves whichever glossy lobe a lane took -- coat, metal,
+// dielectric reflection, transmission differ in the roughness they pass and in their weights, not in the sampling arithmetic -- so a wave
+// whose lanes took different lobes runs ggx_sample once instead of once per lobe.  Same operations per lane as the oracle's branch per lobe.
 __device__ inline void opbr_sample(const MaterialRec* m, const ShState& st, V3 k1, float x0, float x1, float x2, BsdfSample& out)
 {
   OpbrParams o = opbr_params(m, st);
@@ -394,39 +397,33 @@ __device__ inline void opbr_sample(const MaterialRec* m, const ShState& st, V3 k
   float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
   float z = x2;
   float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1));
-  if (z < Fc) {
-    GgxOut g = ggx_sample(l1, o.coatAlpha, x0, x1);
-    V3 k2 = to_world(st, g.l2);
-    if (!g.valid || !(dot(k2, st.geomNormal) > 0.0f)) return;
-    float Fh = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(g.kh));
-    float w = (Fh / Fc) * g.g2OverG1;
-    out.k2 = k2; out.pdf = Fc * g.pdf; out.overPdf = v3(w, w, w); out.event = EV_GLOSSY | EV_REFLECTION;
+  float eta = 0.0f, Fd = 0.0f;
+  uint32_t lobe = 0u; // 0 coat, 1 metal, 2 dielectric reflection, 3 transmission, 4 diffuse
+  if (!(z < Fc)) {
+    z = (z - Fc) / (1.0f - Fc);
+    lobe = 1u;
+    if (!(z < o.metalness)) {
+      z = (z - o.metalness) / (1.0f - o.metalness);
+      eta = relative_eta(st, o.eta);
+      Fd = fresnel_dielectric(nk1, eta);
+      lobe = 2u;
+      if (!(z < Fd)) {
+        z = (z - Fd) / (1.0f - Fd);
+        lobe = (z < o.tw) ? 3u : 4u;
+      }
+    }
+  }
+  if (lobe == 4u) {
+    V3 l = gi_sample_hemisphere(x0, x1);
+    V3 k2 = to_world(st, l);
+    if (!(l.z > 0.0f) || !(dot(k2, st.geomNormal) > 0.0f)) return;
+    out.k2 = k2; out.pdf = (1.0f - Fc) * (1.0f - o.metalness) * (1.0f - Fd) * (1.0f - o.tw) * (l.z / GI_PI);
+    V3 rho = (o.diffRough > 0.0f) ? eon_pi_f(o.baseColor, o.diffRough, l1, l) * o.baseWeight : o.albedo;
+    out.overPdf = rho * o.coatTint; out.event = EV_DIFFUSE | EV_REFLECTION;
     return;
   }
-  z = (z - Fc) / (1.0f - Fc);
-  if (z < o.metalness) {
-    GgxOut g = ggx_sample(l1, o.alpha, x0, x1);
-    V3 k2 = to_world(st, g.l2);
-    if (!g.valid || !(dot(k2, st.geomNormal) > 0.0f)) return;
-    V3 F = schlick_f82(o.albedo, o.metalTint, g.kh) * o.specWeight;
-    out.k2 = k2; out.pdf = (1.0f - Fc) * o.metalness * g.pdf; out.overPdf = (F * o.coatTint) * g.g2OverG1; out.event = EV_GLOSSY | EV_REFLECTION;
-    return;
-  }
-  z = (z - o.metalness) / (1.0f - o.metalness);
-  float eta = relative_eta(st, o.eta);
-  float Fd = fresnel_dielectric(nk1, eta);
-  if (z < Fd) {
-    GgxOut g = ggx_sample(l1, o.alpha, x0, x1);
-    V3 k2 = to_world(st, g.l2);
-    if (!g.valid || !(dot(k2, st.geomNormal) > 0.0f)) return;
-    float Fh = fresnel_dielectric(g.kh, eta);
-    out.k2 = k2; out.pdf = (1.0f - Fc) * (1.0f - o.metalness) * Fd * g.pdf;
-    out.overPdf = (o.specColor * o.coatTint) * ((Fh / Fd) * g.g2OverG1); out.event = EV_GLOSSY | EV_REFLECTION;
-    return;
-  }
-  z = (z - Fd) / (1.0f - Fd);
-  if (z < o.tw) {
-    GgxOut g = ggx_sample(l1, o.alpha, x0, x1);
+  const GgxOut g = ggx_sample(l1, lobe == 0u ? o.coatAlpha : o.alpha, x0, x1);
+  if (lobe == 3u) {
     V3 h = normalize(l1 + g.l2);
     float kh = dot(l1, h);
     if (!g.valid || !(kh > 0.0f)) return;
@@ -446,12 +443,21 @@ __device__ inline void opbr_sample(const MaterialRec* m, const ShState& st, V3 k
     out.overPdf = (o.transTint * o.coatTint) * w; out.event = EV_GLOSSY | EV_TRANSMISSION;
     return;
   }
-  V3 l = gi_sample_hemisphere(x0, x1);
-  V3 k2 = to_world(st, l);
-  if (!(l.z > 0.0f) || !(dot(k2, st.geomNormal) > 0.0f)) return;
-  out.k2 = k2; out.pdf = (1.0f - Fc) * (1.0f - o.metalness) * (1.0f - Fd) * (1.0f - o.tw) * (l.z / GI_PI);
-  V3 rho = (o.diffRough > 0.0f) ? eon_pi_f(o.baseColor, o.diffRough, l1, l) * o.baseWeight : o.albedo;
-  out.overPdf = rho * o.coatTint; out.event = EV_DIFFUSE | EV_REFLECTION;
+  V3 k2 = to_world(st, g.l2);
+  if (!g.valid || !(dot(k2, st.geomNormal) > 0.0f)) return;
+  out.k2 = k2; out.event = EV_GLOSSY | EV_REFLECTION;
+  if (lobe == 0u) {
+    float Fh = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(g.kh));
+    float w = (Fh / Fc) * g.g2OverG1;
+    out.pdf = Fc * g.pdf; out.overPdf = v3(w, w, w);
+  } else if (lobe == 1u) {
+    V3 F = schlick_f82(o.albedo, o.metalTint, g.kh) * o.specWeight;
+    out.pdf = (1.0f - Fc) * o.metalness * g.pdf; out.overPdf = (F * o.coatTint) * g.g2OverG1;
+  } else {
+    float Fh = fresnel_dielectric(g.kh, eta);
+    out.pdf = (1.0f - Fc) * (1.0f - o.metalness) * Fd * g.pdf;
+    out.overPdf = (o.specColor * o.coatTint) * ((Fh / Fd) * g.g2OverG1);
+  }
 }
 
 __device__ inline void opbr_evaluate(const MaterialRec* m, const ShState& st, V3 k1, V3 k2, BsdfEval& out)
@@ -497,24 +503,27 @@ __device__ inline void bsdf_sample(const MaterialRec* m, const ShState& st, V3 k
     float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
     float z = x2;
     float Fc = u.coat * (0.04f + 0.96f * schlick_w(nk1));
-    if (z < Fc) {
-      GgxOut g = ggx_sample(l1, u.coatAlpha, x0, x1);
-      V3 k2 = to_world(st, g.l2);
-      if (!g.valid || !(dot(k2, st.geomNormal) > 0.0f)) return;
-      float Fh = u.coat * (0.04f + 0.96f * schlick_w(g.kh));
-      float w = (Fh / Fc) * g.g2OverG1;
-      out.k2 = k2; out.pdf = Fc * g.pdf; out.overPdf = v3(w, w, w); out.event = EV_GLOSSY | EV_REFLECTION;
-      return;
+    V3 Fs = v3(0.0f, 0.0f, 0.0f); float ps = 0.0f;
+    uint32_t lobe = 0u; // 0 coat, 1 specular, 2 diffuse (one ggx_sample for both glossy lobes, see opbr_sample)
+    if (!(z < Fc)) {
+      z = (z - Fc) / (1.0f - Fc);
+      Fs = schlick3(u.F0, nk1);
+      ps = fmax2(Fs.x, fmax2(Fs.y, Fs.z));
+      lobe = (z < ps) ? 1u : 2u;
     }
-    z = (z - Fc) / (1.0f - Fc);
-    V3 Fs = schlick3(u.F0, nk1);
-    float ps = fmax2(Fs.x, fmax2(Fs.y, Fs.z));
-    if (z < ps) {
-      GgxOut g = ggx_sample(l1, u.alpha, x0, x1);
+    if (lobe != 2u) {
+      GgxOut g = ggx_sample(l1, lobe == 0u ? u.coatAlpha : u.alpha, x0, x1);
       V3 k2 = to_world(st, g.l2);
       if (!g.valid || !(dot(k2, st.geomNormal) > 0.0f)) return;
-      V3 Fh = schlick3(u.F0, g.kh);
-      out.k2 = k2; out.pdf = (1.0f - Fc) * ps * g.pdf; out.overPdf = Fh * (g.g2OverG1 / ps); out.event = EV_GLOSSY | EV_REFLECTION;
+      out.k2 = k2; out.event = EV_GLOSSY | EV_REFLECTION;
+      if (lobe == 0u) {
+        float Fh = u.coat * (0.04f + 0.96f * schlick_w(g.kh));
+        float w = (Fh / Fc) * g.g2OverG1;
+        out.pdf = Fc * g.pdf; out.overPdf = v3(w, w, w);
+      } else {
+        V3 Fh = schlick3(u.F0, g.kh);
+        out.pdf = (1.0f - Fc) * ps * g.pdf; out.overPdf = Fh * (g.g2OverG1 / ps);
+      }
       return;
     }
     V3 l = gi_sample_hemisphere(x0, x1);
