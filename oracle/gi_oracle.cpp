@@ -2005,6 +2005,21 @@ void orc_hook_bsdf_evaluate(void* h, uint32_t mat, const float* frame, const flo
   BsdfEval ev; bsdf_evaluate(((OrcHook*)h)->P.materials[mat], st, v3(k1), v3(k2), ev);
   out[0] = ev.diffuse.x; out[1] = ev.diffuse.y; out[2] = ev.diffuse.z; out[3] = ev.glossy.x; out[4] = ev.glossy.y; out[5] = ev.glossy.z; out[6] = ev.pdf;
 }
+// dome light of the scene: out = rotation quaternion (x, y, z, w), emission multiplier; returns 0 when only the fallback dome exists
+int orc_hook_dome(void* h, float* out)
+{
+  const OrcDomeLight* d = ((OrcHook*)h)->P.dome;
+  if (!d) return 0;
+  for (int i = 0; i < 4; i++) out[i] = d->rotation[i];
+  for (int i = 0; i < 3; i++) out[4 + i] = d->baseEmission[i];
+  return 1;
+}
+void orc_hook_dome_lookup(void* h, float u, float v, float* rgb)
+{
+  const Prepared& P = ((OrcHook*)h)->P;
+  F4v t = sample_bilinear_repeat(P.textures[P.dome->texture], u, v);
+  rgb[0] = t.x; rgb[1] = t.y; rgb[2] = t.z;
+}
 void orc_hook_bsdf_albedo(void* h, uint32_t mat, const float* frame, const float* k1, float ior1, float ior2, int thin, float* out)
 {
   State st; hook_state(st, frame, ior1, ior2, thin);

@@ -65,6 +65,8 @@ LOOP_VARIANTS = [("default", ["JITTERED_SAMPLING", "FILTER_IMPORTANCE_SAMPLING",
                  # the MDL renderer runtime's scene data (primvar) readers, mdl_interface.glsl:258-474, with the two named ids of Frontend.cpp:251-252
                  ("scenedata", ["JITTERED_SAMPLING", "FILTER_IMPORTANCE_SAMPLING", "PROGRESSIVE_ACCUMULATION", "DOME_LIGHT_CAMERA_VISIBLE", "MEDIUM_STACK_SIZE=0", "SCENE_DATA_COUNT=6",
                                 "RENDERER_STATE_TYPE=mdl_renderer_state", "CAMERA_POSITION_SCENE_DATA_INDEX=7", "FRAME_SCENE_DATA_INDEX=8"]),
+                 # a dome light the camera does not see (no DOME_LIGHT_CAMERA_VISIBLE: primary rays take the fallback texel, rp_main.miss:76-82)
+                 ("nee_domehidden", ["JITTERED_SAMPLING", "FILTER_IMPORTANCE_SAMPLING", "PROGRESSIVE_ACCUMULATION", "MEDIUM_STACK_SIZE=0", "NEXT_EVENT_ESTIMATION"]),
                  ("aovs", ["JITTERED_SAMPLING", "FILTER_IMPORTANCE_SAMPLING", "PROGRESSIVE_ACCUMULATION", "DOME_LIGHT_CAMERA_VISIBLE", "MEDIUM_STACK_SIZE=0", "AOV_MASK=0x1ffbf"])]
 
 
@@ -108,8 +110,6 @@ def loop_to_cpp(rel: str, text: str) -> str:
     text = re.sub(r"^\s*hitAttributeEXT[^\n]*\n", "\n", text, flags=re.M)
     text = re.sub(r"^\s*#\s*pragma\s+mdl_generated_code[^\n]*\n", "\n", text, flags=re.M)
     text = re.sub(r'^\s*#\s*include\s+"mdl_interface.glsl"[^\n]*\n', "\n", text, flags=re.M)
-    if rel == "rp_main.miss":
-        text = remove_function(text, "sampleDomeLight")
     names = {"rp_main.rgen": "rgen_main", "rp_main.chit": "chit_main", "rp_main.miss": "miss_main", "rp_main_shadow.miss": "shadow_miss_main"}
     if rel in names:
         text = re.sub(r"\bvoid\s+main\s*\(\s*\)", f"void {names[rel]}()", text)

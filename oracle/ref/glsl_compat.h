@@ -47,6 +47,8 @@ inline Float log(Float a) { return Float(logf(a.v)); }
 inline Float exp(Float a) { return Float(expf(a.v)); }
 inline Float exp2(Float a) { return Float(exp2f(a.v)); }
 inline Float tan(Float a) { return Float(tanf(a.v)); }
+inline Float atan(Float y, Float x) { return Float(atan2f(y.v, x.v)); }
+inline Float acos(Float a) { return Float(acosf(a.v)); }
 inline Float abs(Float a) { return Float(fabsf(a.v)); }
 inline Float floor(Float a) { return Float(floorf(a.v)); }
 inline Float max(Float a, Float b) { return a.v < b.v ? b : a; } // GLSL: y if x < y else x

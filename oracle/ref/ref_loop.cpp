@@ -27,6 +27,8 @@ void orc_hook_material(void* h, uint32_t mat, float* out);
 void orc_hook_bsdf_sample(void* h, uint32_t mat, const float* frame, const float* k1, const float* xi, float ior1, float ior2, int thin, float* out);
 void orc_hook_bsdf_evaluate(void* h, uint32_t mat, const float* frame, const float* k1, const float* k2, float ior1, float ior2, int thin, float* out);
 void orc_hook_edf_factor(void* h, uint32_t mat, float c, float* out);
+int orc_hook_dome(void* h, float* rotationEmission);
+void orc_hook_dome_lookup(void* h, float u, float v, float* rgb);
 void orc_hook_bsdf_albedo(void* h, uint32_t mat, const float* frame, const float* k1, float ior1, float ior2, int thin, float* out);
 const int32_t* orc_hook_mesh_face_ids(void* h, uint32_t mesh, uint32_t* stride);
 }
@@ -117,8 +119,20 @@ static void mdl_bsdf_scattering_auxiliary(Bsdf_auxiliary_data& d, State st);
 
 #include "mdl_shading_state.glsl"
 #include "rp_main.chit"
-static vec3 g_background;
-static vec3 sampleDomeLight(uint, vec3) { return g_background; } // no dome image in these runs: both texture slots hold the 1x1 fallback texel (Gi.cpp:2184-2238)
+// the two dome-light texture slots (Gi.cpp:2184-2238, 2330-2337): [0] the 1x1 fallback texel (the colour AOV's clear value), [1] the dome light's
+// equirectangular image, or the fallback again when the scene has none.  textureLod = the oracle's software sampler (bilinear, REPEAT; D5);
+// the lookup coordinates are rp_main.miss's own (sampleDomeLight: atan / acos of the rotated direction)
+static vec3 g_background; static bool g_hasDome;
+struct Tex2D { uint idx; }; static Tex2D textures_2d[2] = {{0u}, {1u}};
+struct SamplerT {}; static SamplerT tex_sampler;
+struct sampler2D { uint idx; sampler2D(const Tex2D& t, const SamplerT&) : idx(t.idx) {} };
+#define nonuniformEXT(x) (x)
+static vec4 textureLod(const sampler2D& s, vec2 uv, uint)
+{
+  if (s.idx == 0u || !g_hasDome) return vec4(g_background.x, g_background.y, g_background.z, 1.0f);
+  Float rgb[3]; orc_hook_dome_lookup(g_hook, uv.x.v, uv.y.v, reinterpret_cast<decltype(rgb[0].v)*>(rgb)); // (Float is a float)
+  return vec4(rgb[0], rgb[1], rgb[2], 1.0f);
+}
 #include "rp_main.miss"
 namespace shadow_miss {
 #include "rp_main_shadow.miss"
@@ -215,6 +229,8 @@ extern "C" int REF_ENTRY(void* hook, const RefLoopParams* p, const float* prevCo
   uint32_t counts[4]; const float* ptrs[4]; orc_hook_lights(hook, counts, ptrs);
   ubo.sphereLightCount = counts[0]; ubo.distantLightCount = counts[1]; ubo.rectLightCount = counts[2]; ubo.diskLightCount = counts[3];
   ubo.totalLightCount = counts[0] + counts[1] + counts[2] + counts[3];
+  static const float zeroLight[12] = {0}; // an empty light store still holds one zero-filled element (GgpuSyncBuffer: SyncBuffer.cpp:90), which sampleLight reads
+  for (int i = 0; i < 4; i++) if (counts[i] == 0u) ptrs[i] = zeroLight;
   sphereLights = (SphereLight*)ptrs[0]; distantLights = (DistantLight*)ptrs[1]; rectLights = (RectLight*)ptrs[2]; diskLights = (DiskLight*)ptrs[3];
   ubo.metersPerSceneUnit = p->metersPerSceneUnit; ubo.maxVolumeWalkLength = p->maxVolumeWalkLength;
   ubo.cameraPosition = vec3(p->camPos[0], p->camPos[1], p->camPos[2]);
@@ -227,6 +243,8 @@ extern "C" int REF_ENTRY(void* hook, const RefLoopParams* p, const float* prevCo
   uint32_t cr; memcpy(&cr, &fr[4], 4); ubo.clipRangePacked = cr;
   ubo.sensorExposure = p->exposure; ubo.frame = p->frame; ubo.time = p->time;
   ubo.domeLightRotation = vec4(0.0f, 0.0f, 0.0f, 1.0f); ubo.domeLightEmissionMultiplier = vec3(1.0f); // no dome light: the uniform fallback texture (Gi.cpp:2232-2238, 2384-2385)
+  float dm[7]; g_hasDome = orc_hook_dome(hook, dm) != 0;
+  if (g_hasDome) { ubo.domeLightRotation = vec4(dm[0], dm[1], dm[2], dm[3]); ubo.domeLightEmissionMultiplier = vec3(dm[4], dm[5], dm[6]); } // Gi.cpp:2384-2396
   const size_t n = (size_t)p->width * p->height;
   std::vector<vec4> colorBuf(n), clearF(17); std::vector<ivec4> clearI(17); std::vector<vec3> normalBuf(n), neeBuf(n), bouncesBuf(n);
   clearF[0] = vec4(p->clearColor[0], p->clearColor[1], p->clearColor[2], p->clearColor[3]);

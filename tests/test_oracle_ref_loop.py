@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 REF_LIB = os.path.join(ROOT, "oracle", "_ref", "libgi_ref.so")
 
-from gatling_amd.scene import (MAT_DIFFUSE, CameraDesc, DiskLight, DistantLight, MaterialDesc, MeshDesc, RectLight, RenderSettings,  # noqa: E402
+from gatling_amd.scene import (MAT_DIFFUSE, CameraDesc, DiskLight, DistantLight, DomeLight, MaterialDesc, MeshDesc, RectLight, RenderSettings,  # noqa: E402
                                SceneDesc, SphereLight)
 from gatling_amd.scenes import cornell_box, sphere_grid, volume_scene  # noqa: E402
 
@@ -53,6 +53,9 @@ def variant_of(rs):
     if rs.medium_stack_size:
         assert rs.next_event_estimation and rs.medium_stack_size == 2 and rs.jittered_sampling and rs.filter_importance_sampling
         return "nee_stack2"
+    if not rs.dome_light_camera_visible:
+        assert rs.next_event_estimation and not rs.medium_stack_size and rs.jittered_sampling and rs.filter_importance_sampling
+        return "nee_domehidden"
     if rs.depth_of_field or rs.clipping_planes:
         assert rs.depth_of_field and rs.clipping_planes and rs.jittered_sampling and not rs.filter_importance_sampling and not rs.next_event_estimation
         return "dof_clip_box"
@@ -119,6 +122,19 @@ def lights_scene():
     return desc
 
 
+def dome_scene():
+    """A sphere grid under an equirectangular dome light (rotated, tinted) and NO other light: rp_main.miss's rotation, atan / acos lookup
+    coordinates, emission multiplier and the camera-visibility rule -- and, NEE being on, sampleLight reading the zero-filled element an
+    empty light store still holds (SyncBuffer.cpp:90), which the oracle restates."""
+    desc = sphere_grid(grid=3, subdivisions=2, material_count=5)
+    v, u = np.meshgrid((np.arange(16) + 0.5) / 16, (np.arange(32) + 0.5) / 32, indexing="ij")
+    env = np.stack([0.2 + 1.5 * v, 0.3 + 0.5 * np.sin(u * 2 * np.pi) ** 2, 0.4 + 0.6 * u, np.ones_like(u)], axis=-1).astype(np.float32)
+    desc.textures.append(env)
+    q = np.array([0.1, 0.3, -0.2, 0.9]); q /= np.linalg.norm(q)
+    desc.dome_light = DomeLight(texture=len(desc.textures) - 1, rotation=tuple(np.float32(q)), base_emission=(0.9, 1.0, 1.1))
+    return desc
+
+
 CASES = {
     "cornell_diffuse": (lambda: cornell_box(MAT_DIFFUSE), RenderSettings(spp=6, max_bounces=5), 40, 24),
     "cornell_ups_rr": (lambda: cornell_box(), RenderSettings(spp=6, max_bounces=9, rr_bounce_offset=1), 40, 24),
@@ -127,6 +143,8 @@ CASES = {
     "openpbr_spheres": (lambda: sphere_grid(grid=3, subdivisions=2, material_count=9), RenderSettings(spp=4, max_bounces=6), 48, 28),
     "volume_stack2_nee": (lambda: volume_scene(), RenderSettings(spp=4, max_bounces=10, next_event_estimation=True, medium_stack_size=2, max_sample_value=1e9), 40, 24),
     "dof_clip_boxfilter": (lambda: cornell_box(), RenderSettings(spp=6, max_bounces=4, depth_of_field=True, clipping_planes=True, filter_importance_sampling=False), 40, 24),
+    "dome_visible": (dome_scene, RenderSettings(spp=4, max_bounces=5, next_event_estimation=True, clear_color=(0.05, 0.1, 0.2, 1.0)), 48, 28),
+    "dome_hidden": (dome_scene, RenderSettings(spp=4, max_bounces=5, next_event_estimation=True, dome_light_camera_visible=False, clear_color=(0.05, 0.1, 0.2, 1.0)), 48, 28),
     "nojitter": (lambda: cornell_box(), RenderSettings(spp=3, max_bounces=4, jittered_sampling=False, filter_importance_sampling=False), 40, 24),
 }
 
@@ -149,7 +167,8 @@ def test_reference_loop_image_equals_oracle(ref, name):
     good, dmean = close_enough(theirs, ours)
     assert np.isfinite(theirs).all() and ours[..., :3].mean() > 1e-3
     exact = (theirs[..., :3] == ours[..., :3]).all(axis=2).mean()
-    assert good >= 0.995 and dmean < 1e-5 and exact >= 0.85, (name, good, dmean, exact)  # measured: 0.90 .. 1.00 of the pixels bit-identical, the rest within 4e-5
+    # dome cases: every miss goes through atan / acos (libm there, polynomials here: D3), so fewer pixels are bit-identical (measured 0.70)
+    assert good >= 0.995 and dmean < 1e-5 and exact >= (0.6 if name.startswith("dome") else 0.85), (name, good, dmean, exact)  # measured: 0.90 .. 1.00 of the pixels bit-identical, the rest within 4e-5
     assert np.array_equal(theirs[..., 3], ours[..., 3])  # alpha 1
 
 
