@@ -1713,6 +1713,8 @@ void render_pixel_aovs(const Frame& F, uint32_t px, uint32_t py, size_t o, OrcAo
 extern "C" {
 float orc_atan2f(float y, float x) { return atan2f_poly(y, x); }
 float orc_acosf(float x) { return acosf_poly(x); }
+// the raw sampler alone (what stands in for the hardware sampler when the reference's tex_lookup_float4_2d runs on the CPU, oracle/ref/ref_shim.cpp)
+void orc_dbg_sample_bilinear(const OrcTexture* t, float u, float v, float* out4) { F4v r = sample_bilinear_repeat(*t, u, v); out4[0] = r.x; out4[1] = r.y; out4[2] = r.z; out4[3] = r.w; }
 void orc_tex_lookup(const OrcTexture* t, float u, float v, int wrapU, int wrapV, float* out4)
 {
   F4v r = tex_lookup_float4_2d(*t, u, v, wrapU, wrapV);

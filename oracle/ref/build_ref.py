@@ -26,7 +26,7 @@ LIB = os.path.join(OUT, "libgi_ref.so")
 
 WHOLE = ["common.glsl", "aovs.glsl", "colormap.glsl", "rp_main_payload.glsl", "interface/rp_main.h", "mdl_shading_state.glsl"]
 FUNCTIONS = {"rp_main.rgen": ["sampleDistance", "sampleHenyeyGreensteinCos", "sampleVolumeScatteringDirection", "russian_roulette", "fisGauss"],
-             "rp_main.miss": ["quatRotateDir"], "rp_main.chit": ["sampleLight"], "mdl_interface.glsl": ["apply_wrap_and_crop", "mdl_adapt_normal"]}
+             "rp_main.miss": ["quatRotateDir"], "rp_main.chit": ["sampleLight"], "mdl_interface.glsl": ["apply_wrap_and_crop", "mdl_adapt_normal", "tex_lookup_float4_2d"]}
 
 
 def to_cpp(text: str) -> str:

@@ -2,6 +2,7 @@
 // (recipe: oracle/ref/build_ref.py; output oracle/_ref/libgi_ref.so).  Test infrastructure: tests/test_oracle_ref.py compares the oracle's
 // restatements with these.  The files included below from oracle/_ref/gen/ are generated from the reference sources at build time.
 #include "glsl_compat.h"
+extern "C" void orc_dbg_sample_bilinear(const void* orcTexture, float u, float v, float* out4); // oracle/gi_oracle.cpp
 
 #include <cstdint>
 #undef UINT32_MAX // common.glsl declares a constant of this name
@@ -66,6 +67,22 @@ namespace stack8 {
 #include "fn_quatRotateDir.h"
 #include "fn_sampleLight.h"
 #include "fn_apply_wrap_and_crop.h"
+// tex_lookup_float4_2d (mdl_interface.glsl:127-145): the texture array, textureSize and texture() are the caller's image under the oracle's
+// software sampler (bilinear, REPEAT addressing, LOD 0 -- the reference's one hardware sampler, Gi.cpp:388-392; filter weights: D5)
+struct Tex2D { const void* rgba; int w, h; };
+static Tex2D textures_2d[1];
+struct SamplerT {}; static SamplerT tex_sampler;
+struct sampler2D { const Tex2D* t; sampler2D(const Tex2D& tex, const SamplerT&) : t(&tex) {} };
+#define nonuniformEXT(x) (x)
+#define TEXTURE_INDEX_OFFSET 0
+static ivec2 textureSize(const Tex2D& t, int) { return ivec2(t.w, t.h); }
+static vec4 texture(const sampler2D& s, vec2 uv)
+{
+  struct { const void* rgba; uint32_t w, h; } ot = {s.t->rgba, (uint32_t)s.t->w, (uint32_t)s.t->h};
+  Float o[4]; orc_dbg_sample_bilinear(&ot, uv.x.v, uv.y.v, reinterpret_cast<decltype(o[0].v)*>(o));
+  return vec4(o[0], o[1], o[2], o[3]);
+}
+#include "fn_tex_lookup_float4_2d.h"
 #include "fn_mdl_adapt_normal.h"
 #include "mdl_shading_state.glsl"
 #undef float
@@ -110,6 +127,13 @@ void ref_sample_volume_direction(float x0, float x1, float bias, float* dir) { v
 void ref_quat_rotate_dir(const float* q, const float* dir, float* out) { put(out, ref::quatRotateDir(vec4(q[0], q[1], q[2], q[3]), V3(dir))); }
 // ---- mdl_interface.glsl
 float ref_apply_wrap_and_crop(float coord, int wrap, float crop0, float crop1, int res) { return ref::apply_wrap_and_crop(Float(coord), wrap, vec2(crop0, crop1), res).v; }
+// tex: 0 = the invalid texture, 1 = the image given
+void ref_tex_lookup_float4_2d(const float* rgba, int w, int h, int tex, float u, float v, int wrapU, int wrapV, float* out)
+{
+  ref::textures_2d[0] = ref::Tex2D{rgba, w, h};
+  vec4 r = ref::tex_lookup_float4_2d(tex, vec2(u, v), wrapU, wrapV, vec2(0.0f, 1.0f), vec2(0.0f, 1.0f), Float(0.0f));
+  out[0] = r.x.v; out[1] = r.y.v; out[2] = r.z.v; out[3] = r.w.v;
+}
 void ref_adapt_normal(const float* rayDir, const float* geomNormal, const float* shadingNormal, const float* normal, float* out)
 { ref::gl_WorldRayDirectionEXT = V3(rayDir); ref::State s; s.normal = V3(shadingNormal); s.geom_normal = V3(geomNormal); put(out, ref::mdl_adapt_normal(s, V3(normal))); }
 // ---- rp_main.chit: sampleLight over caller-provided light arrays (layouts: interface/rp_main.h; 48 bytes each)

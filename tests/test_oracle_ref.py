@@ -324,3 +324,31 @@ def test_scene_data_readers_against_reference(ref, orc):
         bx, by, bz = np.float32(1.0) - np.float32(0.25) - np.float32(0.5), np.float32(0.25), np.float32(0.5)
         want = (d[idx[0]] * bx + d[idx[1]] * by) + d[idx[2]] * bz
         assert np.array_equal(np.array(out[:comps], np.float32), want.astype(np.float32))
+
+
+def test_tex_lookup_float4_2d_against_reference(ref, orc):
+    """tex_lookup_float4_2d (mdl_interface.glsl:127-145) from the reference -- the invalid texture, the CLIP early-out, wrap and crop per
+    axis with the texture's resolution, then the sampler -- against the oracle's tex_lookup_float4_2d over the same software sampler
+    (which stands in for the hardware one: deviation D5 is the filter weights only).  Bit for bit, all four wrap modes, coordinates far outside [0, 1]."""
+    from oracle import orc as O
+    rng = np.random.default_rng(8)
+    img = np.ascontiguousarray(rng.uniform(0, 1, (5, 7, 4)).astype(np.float32))
+    t = O.OrcTexture(img.ctypes.data, 7, 5)
+    ref.ref_tex_lookup_float4_2d.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p]
+    orc.orc_tex_lookup.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p]
+    a, b = (C.c_float * 4)(), (C.c_float * 4)()
+    n = 0
+    for wu in range(4):
+        for wv in range(4):
+            for _ in range(150):
+                u, v = (float(np.float32(x)) for x in rng.uniform(-3.0, 4.0, 2))
+                ref.ref_tex_lookup_float4_2d(img.ctypes.data, 7, 5, 1, u, v, wu, wv, a)
+                orc.orc_tex_lookup(C.addressof(t), u, v, wu, wv, b)
+                assert bits(a[:]).tolist() == bits(b[:]).tolist(), (wu, wv, u, v, a[:], b[:])
+                n += 1
+    for u, v in ((0.0, 0.0), (1.0, 1.0), (0.5, 1.0), (-0.0, 0.25)):  # the CLIP boundaries are inside
+        ref.ref_tex_lookup_float4_2d(img.ctypes.data, 7, 5, 1, u, v, 3, 3, a)
+        orc.orc_tex_lookup(C.addressof(t), u, v, 3, 3, b)
+        assert bits(a[:]).tolist() == bits(b[:]).tolist() and any(x != 0 for x in a[:])
+    ref.ref_tex_lookup_float4_2d(img.ctypes.data, 7, 5, 0, 0.3, 0.3, 1, 1, a)  # tex == 0: the invalid texture
+    assert list(a[:]) == [0, 0, 0, 0] and n == 2400
