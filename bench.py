@@ -229,15 +229,25 @@ def main():
         gather = RowGather(h, w, torch.float32, torch.device("cuda", local_rank), interleaved=True) if use_dist else None  # buffers allocated once, outside the timed region
 
         last = {}
+        # rank 0 hands the assembled frame to pinned host memory on a copy stream: the D2H of frame i (33 MB at 1080p, 133 MB at 4K) runs on the
+        # SDMA engines while the ranks render frame i + 1; the next gather waits for it before it overwrites the device frame, and the closing
+        # synchronize() of the timed region covers the last one
+        copy_stream = torch.cuda.Stream(device=local_rank) if (use_dist and rank == 0) else None
+        copied = torch.cuda.Event() if copy_stream is not None else None
 
         def step():
             if not use_dist:
                 last["img"] = scene.render(rs, w, h)  # blocks; colour AOV complete in host memory on return (reference semantics)
             else:
                 scene.render(rs, w, h, rows=(r0, r1), device_only=True, row_stride=rstride)
+                if copy_stream is not None and "img" in last:
+                    torch.cuda.current_stream().wait_event(copied)  # frame i - 1 has left the device frame buffer
                 full = gather(tile)
                 if rank == 0:
-                    host_full.copy_(full, non_blocking=False)
+                    copy_stream.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(copy_stream):
+                        host_full.copy_(full, non_blocking=True)
+                        copied.record(copy_stream)
                     last["img"] = host_full
 
         def sync():
