@@ -122,6 +122,17 @@ def lights_scene():
     return desc
 
 
+def thin_walled_scene():
+    """The volume scene (nested media, stack of 2) with a thin-walled, half-transmissive OpenPBR sheet in front of it: rp_main.chit's thin-walled
+    rules -- both sides see the medium the ray travels in (:188-189), transmission through it leaves the medium stack alone (:447)."""
+    from test_oracle_render import build_mesh_arrays
+    desc = volume_scene()
+    desc.materials.append(MaterialDesc.open_pbr(base_color=(0.8, 0.5, 0.3), transmission_weight=0.6, specular_roughness=0.25, geometry_thin_walled=True))
+    v, f = build_mesh_arrays([(-1.2, -1.6, 0.1), (1.2, -1.6, 0.1), (1.2, -1.6, 2.4), (-1.2, -1.6, 2.4)], [4], [0, 1, 2, 3])
+    desc.meshes.append(MeshDesc("sheet", v, f, len(desc.materials) - 1, double_sided=True))
+    return desc
+
+
 def dome_scene():
     """A sphere grid under an equirectangular dome light (rotated, tinted) and NO other light: rp_main.miss's rotation, atan / acos lookup
     coordinates, emission multiplier and the camera-visibility rule -- and, NEE being on, sampleLight reading the zero-filled element an
@@ -143,6 +154,7 @@ CASES = {
     "openpbr_spheres": (lambda: sphere_grid(grid=3, subdivisions=2, material_count=9), RenderSettings(spp=4, max_bounces=6), 48, 28),
     "volume_stack2_nee": (lambda: volume_scene(), RenderSettings(spp=4, max_bounces=10, next_event_estimation=True, medium_stack_size=2, max_sample_value=1e9), 40, 24),
     "dof_clip_boxfilter": (lambda: cornell_box(), RenderSettings(spp=6, max_bounces=4, depth_of_field=True, clipping_planes=True, filter_importance_sampling=False), 40, 24),
+    "thin_walled_stack2_nee": (thin_walled_scene, RenderSettings(spp=4, max_bounces=8, next_event_estimation=True, medium_stack_size=2, max_sample_value=1e9), 40, 24),
     "dome_visible": (dome_scene, RenderSettings(spp=4, max_bounces=5, next_event_estimation=True, clear_color=(0.05, 0.1, 0.2, 1.0)), 48, 28),
     "dome_hidden": (dome_scene, RenderSettings(spp=4, max_bounces=5, next_event_estimation=True, dome_light_camera_visible=False, clear_color=(0.05, 0.1, 0.2, 1.0)), 48, 28),
     "nojitter": (lambda: cornell_box(), RenderSettings(spp=3, max_bounces=4, jittered_sampling=False, filter_importance_sampling=False), 40, 24),
