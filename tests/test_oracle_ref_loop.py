@@ -133,6 +133,18 @@ def thin_walled_scene():
     return desc
 
 
+def settings_mix_scene():
+    """Cornell box with a left-handed block (BLAS payload flip-facing bit), single-sided walls, a sphere light, camera exposure -- rendered with a
+    tight sample clamp, an aggressive Russian roulette from the first bounce and a light-intensity multiplier."""
+    desc = cornell_box()
+    desc.meshes[-1].left_handed = True
+    for m in desc.meshes[:5]:
+        m.double_sided = False
+    desc.sphere_lights.append(SphereLight(pos=(0.8, -0.5, 2.0), base_emission=(5, 4, 3), radius=(0.2, 0.2, 0.2), diffuse=0.8, specular=0.5))
+    desc.camera.exposure = 0.7
+    return desc
+
+
 def dome_scene():
     """A sphere grid under an equirectangular dome light (rotated, tinted) and NO other light: rp_main.miss's rotation, atan / acos lookup
     coordinates, emission multiplier and the camera-visibility rule -- and, NEE being on, sampleLight reading the zero-filled element an
@@ -155,6 +167,8 @@ CASES = {
     "volume_stack2_nee": (lambda: volume_scene(), RenderSettings(spp=4, max_bounces=10, next_event_estimation=True, medium_stack_size=2, max_sample_value=1e9), 40, 24),
     "dof_clip_boxfilter": (lambda: cornell_box(), RenderSettings(spp=6, max_bounces=4, depth_of_field=True, clipping_planes=True, filter_importance_sampling=False), 40, 24),
     "thin_walled_stack2_nee": (thin_walled_scene, RenderSettings(spp=4, max_bounces=8, next_event_estimation=True, medium_stack_size=2, max_sample_value=1e9), 40, 24),
+    "settings_mix_nee": (settings_mix_scene, RenderSettings(spp=6, max_bounces=7, next_event_estimation=True, rr_bounce_offset=0, rr_inv_min_term_prob=0.8, max_sample_value=2.0,
+                                                          light_intensity_multiplier=2.5), 40, 24),
     "dome_visible": (dome_scene, RenderSettings(spp=4, max_bounces=5, next_event_estimation=True, clear_color=(0.05, 0.1, 0.2, 1.0)), 48, 28),
     "dome_hidden": (dome_scene, RenderSettings(spp=4, max_bounces=5, next_event_estimation=True, dome_light_camera_visible=False, clear_color=(0.05, 0.1, 0.2, 1.0)), 48, 28),
     "nojitter": (lambda: cornell_box(), RenderSettings(spp=3, max_bounces=4, jittered_sampling=False, filter_importance_sampling=False), 40, 24),
