@@ -253,6 +253,10 @@ struct WaveStage { uint4 buf[64 * 5]; };
 // Measured on C3 (1M-triangle soup): 35.4 ms with the cooperative fetch vs 29.6 ms without (the 20 KiB of staging per
 // block cost two resident blocks per CU and the extra LDS round trip outweighs the saved tag look-ups) -> off.
 constexpr bool TRACE_DYN_COOP_FETCH = false;
+#ifndef GI_WAVE_STEP_SCAN_APPEND
+#define GI_WAVE_STEP_SCAN_APPEND 1
+#endif
+constexpr bool WAVE_STEP_SCAN_APPEND = GI_WAVE_STEP_SCAN_APPEND != 0; // wave_step: pair positions from a wave prefix sum instead of one ballot round per triangle
 
 template <bool COUNT, bool ALL_LDS, bool CUTOUT, bool COOP, uint32_t RING_MASK = 127u, class WT = WaveTri>
 __device__ __forceinline__ void wave_tri_batch(WT& W, WaveStage* S, uint32_t head, uint32_t cnt, const RayTrav& R, uint32_t rng, const SceneView& sc,
@@ -334,7 +338,30 @@ __device__ __forceinline__ bool wave_step(RayTrav& R, bool alive, WaveTri& W, Wa
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
   }
   uint32_t head = 0u, tail = 0u; // wave-uniform
-  for (;;) {
+  if (WAVE_STEP_SCAN_APPEND && !COOP) {
+    // positions from a wave prefix sum over the per-lane pair counts (six DPP adds), then every lane writes its own pairs
+    const uint32_t cntL = (uint32_t)__popc(Gt.y);
+    int scan = (int)cntL;
+    scan += __builtin_amdgcn_update_dpp(0, scan, 0x111, 0xf, 0xf, false); // row_shr:1
+    scan += __builtin_amdgcn_update_dpp(0, scan, 0x112, 0xf, 0xf, false); // row_shr:2
+    scan += __builtin_amdgcn_update_dpp(0, scan, 0x114, 0xf, 0xf, false); // row_shr:4
+    scan += __builtin_amdgcn_update_dpp(0, scan, 0x118, 0xf, 0xf, false); // row_shr:8
+    scan += __builtin_amdgcn_update_dpp(0, scan, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+    scan += __builtin_amdgcn_update_dpp(0, scan, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane(scan, 63);
+    if (total <= 128u) {
+      uint32_t pos = (uint32_t)scan - cntL;
+      while (Gt.y) {
+        const uint32_t k = (uint32_t)__ffs((int)Gt.y) - 1u;
+        Gt.y &= Gt.y - 1u;
+        wt_queue_put(W, pos, (lane << TRI_ID_BITS) | (Gt.x + k));
+        pos++;
+      }
+      tail = total;
+      while (tail - head >= 64u) { wave_tri_batch<COUNT, ALL_LDS, CUTOUT, COOP>(W, S, head, 64u, R, rng, sc, s_tris, ldsTris, tc); head += 64u; }
+    }
+  }
+  for (;;) { // (more pairs than the ring holds, or the scan path off) one ballot round per triangle, a batch whenever 64 pairs are pending
     const unsigned long long m = __ballot(Gt.y != 0u);
     if (!m) break;
     if (Gt.y) {
