@@ -256,6 +256,10 @@ constexpr bool TRACE_DYN_COOP_FETCH = false;
 #ifndef GI_WAVE_STEP_SCAN_APPEND
 #define GI_WAVE_STEP_SCAN_APPEND 1
 #endif
+#ifndef GI_WAVE_STEP_CARRY_SCAN_APPEND
+#define GI_WAVE_STEP_CARRY_SCAN_APPEND 1
+#endif
+constexpr bool WAVE_STEP_CARRY_SCAN_APPEND = GI_WAVE_STEP_CARRY_SCAN_APPEND != 0;
 constexpr bool WAVE_STEP_SCAN_APPEND = GI_WAVE_STEP_SCAN_APPEND != 0; // wave_step: pair positions from a wave prefix sum instead of one ballot round per triangle
 
 template <bool COUNT, bool ALL_LDS, bool CUTOUT, bool COOP, uint32_t RING_MASK = 127u, class WT = WaveTri>
@@ -400,6 +404,29 @@ __device__ __forceinline__ bool wave_step_carry(RayTrav& R, bool alive, bool& dr
   const bool walking = alive && !draining;
   uint2 Gt = make_uint2(0u, 0u);
   if (walking) Gt = trav_node<COUNT, STACK, OVERFLOW, false>(R, sc, s_nodes, ldsNodes, s_stack, overflow, tc);
+  if (WAVE_STEP_CARRY_SCAN_APPEND) { // as in wave_step: positions from a wave prefix sum when the step's pairs fit behind the pending ones
+    const uint32_t cntL = (uint32_t)__popc(Gt.y);
+    int scan = (int)cntL;
+    scan += __builtin_amdgcn_update_dpp(0, scan, 0x111, 0xf, 0xf, false);
+    scan += __builtin_amdgcn_update_dpp(0, scan, 0x112, 0xf, 0xf, false);
+    scan += __builtin_amdgcn_update_dpp(0, scan, 0x114, 0xf, 0xf, false);
+    scan += __builtin_amdgcn_update_dpp(0, scan, 0x118, 0xf, 0xf, false);
+    scan += __builtin_amdgcn_update_dpp(0, scan, 0x142, 0xa, 0xf, false);
+    scan += __builtin_amdgcn_update_dpp(0, scan, 0x143, 0xc, 0xf, false);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane(scan, 63);
+    if (total != 0u && (tail - head) + total <= 128u) {
+      uint32_t pos = tail + (uint32_t)scan - cntL;
+      if (cntL) lastEnd = pos + cntL;
+      while (Gt.y) {
+        const uint32_t k = (uint32_t)__ffs((int)Gt.y) - 1u;
+        Gt.y &= Gt.y - 1u;
+        wt_queue_put(W, pos & 127u, (lane << TRI_ID_BITS) | (Gt.x + k));
+        pos++;
+      }
+      tail += total;
+      while (tail - head >= 64u) { wave_tri_batch<COUNT, false, CUTOUT, false>(W, nullptr, head, 64u, R, rng, sc, nullptr, 0u, tc); head += 64u; }
+    }
+  }
   for (;;) { // one ballot round per triangle; a batch as soon as 64 pairs are pending (<= 63 + 64 <= the ring's 128 entries)
     const unsigned long long m = __ballot(Gt.y != 0u);
     if (!m) break;
