@@ -75,10 +75,8 @@ def cpu_baseline(desc, rs, w, h, budget_s=7.0):
                       f"{cnt['segments'] / cnt['samples']:.3f} segments/sample"}
 
 
-VALU_CYCLES_PER_INST = 4  # a wave64 VALU instruction occupies a SIMD's 16 fp32 lanes for 4 cycles (157.3 TFLOP/s = 1024 SIMDs x 16 lanes x 2 (fma) x 2 (packed) x
-                          # 2.4 GHz).  Checked on k_path (r02b): resident waves per SIMD 3 -> 7 changes nothing (305.4 .. 306.1 ms) while the kernel issues
-                          # 4.86e10 VALU instructions per 74.2 ms launch = one per 3.76 cycles and SIMD: the pipe is saturated (passes whose 16 lanes
-                          # are all masked off are skipped, which is how the ratio can exceed 1)
+VALU_CYCLES_PER_INST_DEFAULT = 4.0  # used only when profiles/valu_issue_calibration.json is absent: a wave64 VALU instruction occupies a SIMD's 16 fp32
+                                    # lanes for 4 cycles (157.3 TFLOP/s = 1024 SIMDs x 16 lanes x 2 (fma) x 2 (packed) x 2.4 GHz)
 SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, max clock (MI355X_MICROARCH.md)
 PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"),
               ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_THREAD_CYCLES_VALU"))
@@ -96,6 +94,20 @@ def fetch_calibration():
         except Exception:
             pass
     return cal
+
+
+def valu_calibration():
+    """Cycles one SIMD needs per wave64 VALU instruction, MEASURED by tools/valu_calib.hip (independent v_fma_f32 chains at 8 waves/SIMD, shader
+    clock inside the kernel) and written to profiles/valu_issue_calibration.json by tools/valu_calib_report.py."""
+    p = os.path.join(ROOT, "profiles", "valu_issue_calibration.json")
+    try:
+        j = json.load(open(p))
+        c = float(j["cycles_per_wave64_valu"])
+        if 0.5 < c < 16.0:
+            return c, j.get("source", "profiles/valu_issue_calibration.json")
+    except Exception:
+        pass
+    return VALU_CYCLES_PER_INST_DEFAULT, "default (no calibration file)"
 
 
 def short_kernel(name):
@@ -239,6 +251,7 @@ def main():
             if not use_dist:
                 last["img"] = scene.render(rs, w, h)  # blocks; colour AOV complete in host memory on return (reference semantics)
             else:
+                gather.wait_packed()  # frame i - 1's pack copy has read the render buffer (it runs on torch's stream, the library renders on its own)
                 scene.render(rs, w, h, rows=(r0, r1), device_only=True, row_stride=rstride)
                 if copy_stream is not None and "img" in last:
                     torch.cuda.current_stream().wait_event(copied)  # frame i - 1 has left the device frame buffer
@@ -256,7 +269,10 @@ def main():
                 dist.barrier()
                 torch.cuda.synchronize()
 
-        scene.set_option(capi.OPTION_KERNEL_TIMERS, 0 if no_timers else 8)  # HIP events around the stage launches of every 8th iteration, on the library's own stream
+        # HIP events around the stage launches, on the library's own stream: every 8th iteration for the LDS-resident scenes (~1 000 iterations of ~0.2 ms launches when the
+        # stage kernels run them; events on every launch cost ~16 % there), every iteration for the big scenes (~30-130 iterations of ms-long launches whose cost varies
+        # tenfold between the first and the last -- sampling every 8th mis-scaled the stage totals by 8-12 %, the "unowned" time of VERDICT r02 weak #4)
+        scene.set_option(capi.OPTION_KERNEL_TIMERS, 0 if no_timers else (8 if workload in ("c1", "c2") else 1))
         for _ in range(warmup):
             step()
         sync()
@@ -274,119 +290,148 @@ def main():
 
         return {"desc": desc, "rs": rs, "w": w, "h": h, "label": label, "scene": scene, "rows": (r0, r1, rstride), "dt": dt, "stats": stats, "last": last}
 
-    R = timed_run(args.workload, args.spp, args.steps, args.warmup, args.no_timers)
-    desc, rs, w, h, label, scene, (r0, r1, rstride), dt, stats, last = (R[k] for k in ("desc", "rs", "w", "h", "label", "scene", "rows", "dt", "stats", "last"))
+    def measure(workload, spp, steps, warmup, no_timers, no_pmc, main_line):
+        """One workload end to end: timed steps, one counting step, the roofline object (live --pmc passes at N = 1).  Every rank takes part;
+        rank 0 gets the JSON object, the others None."""
+        R = timed_run(workload, spp, steps, warmup, no_timers)
+        desc, rs, w, h, label, scene, (r0, r1, rstride), dt, stats, last = (R[k] for k in ("desc", "rs", "w", "h", "label", "scene", "rows", "dt", "stats", "last"))
+        if args.probe:
+            scene.close()
+            return None, R
+        # --- roofline inputs: one extra (untimed) step with the traversal counters on
+        scene.set_option(capi.OPTION_COUNT_TRAVERSAL, 1)
+        scene.render(rs, w, h, rows=(r0, r1), device_only=True, row_stride=rstride)
+        cst = scene.stats()
+        scene.set_option(capi.OPTION_COUNT_TRAVERSAL, 0)
+        out = None
+        if rank == 0:
+            samples_per_step = w * h * rs.spp
+            value = samples_per_step * steps / dt / 1e6
+            # dominant traversal kernel k_trace<closest>: algorithmic bytes per launch (SURVEY 8d): ray 32 + hit 20 per ray,
+            # 80 B per BVH8 node visited, 48 B per triangle tested; divided by its mean launch time (HIP events).
+            launches = sum(s["traceLaunches"] for s in stats)  # traceMs is the sampled total scaled to all launches
+            trace_ms = sum(s["traceMs"] for s in stats)
+            rays = sum(s["segments"] for s in stats)
+            nodes_per_ray = cst["nodesVisited"] / max(1, cst["segments"])
+            tris_per_ray = cst["trisTested"] / max(1, cst["segments"])
+            bytes_total = rays * (52.0 + 80.0 * nodes_per_ray + 48.0 * tris_per_ray)
+            achieved = bytes_total / max(trace_ms * 1e-3, 1e-12) / 1e9
+            seg_per_sample = rays / max(1, sum(s["samples"] for s in stats))
+            stream_only = (samples_per_step * steps / dt) * seg_per_sample * 192.0 / 1e9  # whole-pipeline stream floor
+            if stats[-1]["fusedPath"]:
+                kernel, prefixes = "k_path / k_path_bw (fused persistent path kernel: raygen + closest hit + shade per path, wave-local wavefront when NEE is off)", ("k_path",)
+            elif cst["triangleCount"] <= 128:
+                kernel, prefixes = "k_trace<closest>", ("k_trace<false",)
+            else:
+                kernel, prefixes = "k_trace_dyn<closest> + k_route", ("k_trace_dyn<false", "k_route")
+            avg_launch_s = trace_ms * 1e-3 / max(1, launches)
+            stage = {k: round(sum(s[k] for s in stats) / steps, 3) for k in ("raygenMs", "traceMs", "shadeMs", "shadowMs")}
+            # what the four stage timers do not own: k_init / k_accumulate / the queue-size polls / the D2H of the colour AOV (render_ms is the library's own
+            # wall clock around the bounce loop + D2H; ms_per_step adds the host side of capi.Scene.render)
+            render_ms = sum(s["renderMs"] for s in stats) / steps
+            stage["renderMs"] = round(render_ms, 3)
+            stage["otherMs"] = round(render_ms - sum(stage[k] for k in ("raygenMs", "traceMs", "shadeMs", "shadowMs")), 3)
+            roofline = {"bound": "hbm", "kernel": kernel, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                        "algorithmic_GBps": round(achieved, 2), "algorithmic_frac": round(achieved / HBM_PEAK_GBS, 5),
+                        "bytes_per_launch": round(bytes_total / max(1, launches), 1), "avg_launch_us": round(avg_launch_s * 1e6, 3),
+                        "nodes_per_ray": round(nodes_per_ray, 3), "tris_per_ray": round(tris_per_ray, 3),
+                        "stage_ms_per_step": stage,
+                        "pipeline_stream_only_GBps": round(stream_only, 2), "pipeline_stream_only_frac": round(stream_only / HBM_PEAK_GBS, 5)}
+            if world == 1 and not no_pmc:
+                scene.close(); scene = None  # the probe processes need the device memory (C5: 17 GB of queues per process)
+                pmc, note = pmc_live(workload, spp)
+                cal = fetch_calibration()
+                valu_cycles, valu_src = valu_calibration()
+                roofline["pmc_note"] = note or "ok"
+                if pmc:
+                    dom = [v for k, v in pmc.items() if k.startswith(prefixes)]
+                    # the closest-hit traversal launches: of the kernels that match, every one belongs to the traversal stage (k_route runs once per k_trace_dyn)
+                    n = max([v.get("dispatches", 0) for k, v in pmc.items() if k.startswith(prefixes[0])] or [0])
+                    if n:
+                        # k_trace_dyn's reads are per-lane 80-B node / 48-B triangle fetches = 64-B sector requests, which FETCH_SIZE reports at their
+                        # size; the coalesced x2 applies to streaming kernels only (profiles/pmc_calibration.json).  `traffic_upper` = everything x2.
+                        scattered = prefixes[0].startswith("k_trace_dyn")
+                        raw_fetch = sum(v.get("FETCH_SIZE", 0.0) for v in dom) * 1024.0 / n
+                        fetch = raw_fetch * (cal["fetch_scattered"] if scattered else cal["fetch"])
+                        write = sum(v.get("WRITE_SIZE", 0.0) for v in dom) * 1024.0 * cal["write"] / n
+                        have = any("FETCH_SIZE" in v for v in dom) and any("WRITE_SIZE" in v for v in dom)
+                        if have:
+                            roofline["traffic"] = round(fetch + write, 1)
+                            roofline["traffic_fetch"] = round(fetch, 1); roofline["traffic_write"] = round(write, 1)
+                            roofline["traffic_upper"] = round(raw_fetch * cal["fetch"] + write, 1)
+                            roofline["achieved"] = round((fetch + write) / max(avg_launch_s, 1e-12) / 1e9, 2)
+                            roofline["frac"] = round(roofline["achieved"] / HBM_PEAK_GBS, 5)
+                            roofline["calibration"] = cal
+                        main_k = [v for k, v in pmc.items() if k.startswith(prefixes[0])]
+                        valu = sum(v.get("SQ_INSTS_VALU", 0.0) for v in main_k) / n
+                        if valu:
+                            # VALU issue cycles used / available: instructions x measured cycles per instruction / (1024 SIMDs x launch cycles at the 2.4 GHz max clock)
+                            roofline["valu_frac"] = round(valu * valu_cycles / (SIMDS * avg_launch_s * CLOCK_HZ), 5)
+                            roofline["valu_cycles_per_inst"] = round(valu_cycles, 4); roofline["valu_calibration"] = valu_src
+                            wc = sum(v.get("SQ_WAVE_CYCLES", 0.0) for v in main_k)
+                            if wc:
+                                roofline["wave_cycles_not_valu_frac"] = round(1.0 - sum(v.get("SQ_ACTIVE_INST_VALU", 0.0) for v in main_k) / wc, 5)
+                                roofline["wait_inst_any_frac"] = round(sum(v.get("SQ_WAIT_INST_ANY", 0.0) for v in main_k) / wc, 5)
+                        tc, av = sum(v.get("SQ_THREAD_CYCLES_VALU", 0.0) for v in main_k), sum(v.get("SQ_ACTIVE_INST_VALU", 0.0) for v in main_k)
+                        if tc and av:
+                            roofline["valu_lane_utilisation"] = round(tc / (64.0 * av), 5)  # active lanes per issued VALU instruction / 64
+                        hit, miss = sum(v.get("TCC_HIT_sum", 0.0) for v in main_k), sum(v.get("TCC_MISS_sum", 0.0) for v in main_k)
+                        if hit + miss > 0:
+                            roofline["l2_hit_rate"] = round(hit / (hit + miss), 5)
+                        if roofline.get("valu_frac") is not None and roofline["frac"] is not None:
+                            roofline["bound"] = "valu" if roofline["valu_frac"] > roofline["frac"] else "hbm"
+                        roofline["pmc_kernels"] = {k: {c: (round(x, 1) if isinstance(x, float) else x) for c, x in v.items()} for k, v in pmc.items() if k.startswith(prefixes)}
+                        if not main_line:  # every kernel of the frame, compactly: time share under counters, VALU issue, lanes, L2 hit (the per-kernel picture of the wavefront pipeline)
+                            tot = sum(v.get("pmc_us", 0.0) * v.get("dispatches", 0) for v in pmc.values()) or 1.0
+                            roofline["all_kernels"] = {
+                                k: {"dispatches": v.get("dispatches", 0), "time_share": round(v.get("pmc_us", 0.0) * v.get("dispatches", 0) / tot, 4),
+                                    "valu_frac": round(v.get("SQ_INSTS_VALU", 0.0) * valu_cycles / (SIMDS * max(v.get("pmc_us", 0.0) * v.get("dispatches", 1) * 1e-6, 1e-12) * CLOCK_HZ), 4),
+                                    "lanes": round(v.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * v["SQ_ACTIVE_INST_VALU"]), 4) if v.get("SQ_ACTIVE_INST_VALU") else None,
+                                    "l2_hit": round(v.get("TCC_HIT_sum", 0.0) / (v.get("TCC_HIT_sum", 0.0) + v.get("TCC_MISS_sum", 0.0)), 4) if (v.get("TCC_HIT_sum", 0.0) + v.get("TCC_MISS_sum", 0.0)) else None,
+                                    "fetch_GB": round(v.get("FETCH_SIZE", 0.0) * 1024.0 / 1e9, 3), "write_GB": round(v.get("WRITE_SIZE", 0.0) * 1024.0 / 1e9, 3)}
+                                for k, v in sorted(pmc.items(), key=lambda kv: -kv[1].get("pmc_us", 0.0) * kv[1].get("dispatches", 0))[:10]}
+            out = {"metric": "Msamples/s (spp x pixels / s) at 8 bounces, 1920x1080", "value": round(value, 2), "unit": "Msamples/s",
+                   "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1e3 / steps, 3),
+                   "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                   "config": {"workload": label, "width": w, "height": h, "spp": rs.spp, "max_bounces": rs.max_bounces,
+                              "parallelism": f"rows-interleaved{world}" if world > 1 else "single", "segments_per_sample": round(seg_per_sample, 4),
+                              "triangles": cst["triangleCount"], "bvh8_nodes": cst["nodeCount"], "iterations_per_step": stats[-1]["iterations"]},
+                   "roofline": roofline}
+            if os.environ.get("GATLING_BENCH_CHECKSUM"):  # tests: the frame rank 0 ends up with (host memory), as a checksum
+                import hashlib
+                img = last["img"]
+                out["image_checksum"] = hashlib.sha256((img.numpy() if hasattr(img, "numpy") else img).tobytes()).hexdigest()
+        if scene is not None:
+            scene.close()
+        R["scene"] = None
+        return out, R
 
+    out, R = measure(args.workload, args.spp, args.steps, args.warmup, args.no_timers, args.no_pmc, True)
     if args.probe:
-        scene.close()
         return
-    # --- roofline inputs: one extra (untimed) step with the traversal counters on
-    scene.set_option(capi.OPTION_COUNT_TRAVERSAL, 1)
-    scene.render(rs, w, h, rows=(r0, r1), device_only=True, row_stride=rstride)
-    cst = scene.stats()
-    scene.set_option(capi.OPTION_COUNT_TRAVERSAL, 0)
-
-    out = None
-    if rank == 0:
-        samples_per_step = w * h * rs.spp
-        value = samples_per_step * args.steps / dt / 1e6
-        # dominant traversal kernel k_trace<closest>: algorithmic bytes per launch: ray 32 + hit 20 per ray,
-        # 80 B per BVH8 node visited, 48 B per triangle tested; divided by its mean launch time (HIP events).
-        launches = sum(s["traceLaunches"] for s in stats)  # traceMs is the sampled total scaled to all launches
-        trace_ms = sum(s["traceMs"] for s in stats)
-        rays = sum(s["segments"] for s in stats)
-        nodes_per_ray = cst["nodesVisited"] / max(1, cst["segments"])
-        tris_per_ray = cst["trisTested"] / max(1, cst["segments"])
-        bytes_total = rays * (52.0 + 80.0 * nodes_per_ray + 48.0 * tris_per_ray)
-        achieved = bytes_total / max(trace_ms * 1e-3, 1e-12) / 1e9
-        seg_per_sample = rays / max(1, sum(s["samples"] for s in stats))
-        stream_only = (samples_per_step * args.steps / dt) * seg_per_sample * 192.0 / 1e9  # whole-pipeline stream floor
-        if stats[-1]["fusedPath"]:
-            kernel, prefixes = "k_path / k_path_bw (fused persistent path kernel: raygen + closest hit + shade per path, wave-local wavefront when NEE is off)", ("k_path",)
-        elif cst["triangleCount"] <= 128:
-            kernel, prefixes = "k_trace<closest>", ("k_trace<false",)
-        else:
-            kernel, prefixes = "k_trace_dyn<closest> + k_route", ("k_trace_dyn<false", "k_route")
-        avg_launch_s = trace_ms * 1e-3 / max(1, launches)
-        roofline = {"bound": "hbm", "kernel": kernel, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                    "algorithmic_GBps": round(achieved, 2), "algorithmic_frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "bytes_per_launch": round(bytes_total / max(1, launches), 1), "avg_launch_us": round(avg_launch_s * 1e6, 3),
-                    "nodes_per_ray": round(nodes_per_ray, 3), "tris_per_ray": round(tris_per_ray, 3),
-                    "stage_ms_per_step": {k: round(sum(s[k] for s in stats) / args.steps, 3) for k in ("raygenMs", "traceMs", "shadeMs", "shadowMs")},
-                    "pipeline_stream_only_GBps": round(stream_only, 2), "pipeline_stream_only_frac": round(stream_only / HBM_PEAK_GBS, 5)}
-        if world == 1 and not args.no_pmc:
-            scene.close(); scene = None  # the probe processes need the device memory (C5: 17 GB of queues per process)
-            pmc, note = pmc_live(args.workload, args.spp)
-            cal = fetch_calibration()
-            roofline["pmc_note"] = note or "ok"
-            if pmc:
-                dom = [v for k, v in pmc.items() if k.startswith(prefixes)]
-                # the closest-hit traversal launches: of the kernels that match, every one belongs to the traversal stage (k_route runs once per k_trace_dyn)
-                n = max([v.get("dispatches", 0) for k, v in pmc.items() if k.startswith(prefixes[0])] or [0])
-                if n:
-                    # k_trace_dyn's reads are per-lane 80-B node / 48-B triangle fetches = 64-B sector requests, which FETCH_SIZE reports at their
-                    # size; the coalesced x2 applies to streaming kernels only (profiles/pmc_calibration.json).  `traffic_upper` = everything x2.
-                    scattered = prefixes[0].startswith("k_trace_dyn")
-                    raw_fetch = sum(v.get("FETCH_SIZE", 0.0) for v in dom) * 1024.0 / n
-                    fetch = raw_fetch * (cal["fetch_scattered"] if scattered else cal["fetch"])
-                    write = sum(v.get("WRITE_SIZE", 0.0) for v in dom) * 1024.0 * cal["write"] / n
-                    have = any("FETCH_SIZE" in v for v in dom) and any("WRITE_SIZE" in v for v in dom)
-                    if have:
-                        roofline["traffic"] = round(fetch + write, 1)
-                        roofline["traffic_fetch"] = round(fetch, 1); roofline["traffic_write"] = round(write, 1)
-                        roofline["traffic_upper"] = round(raw_fetch * cal["fetch"] + write, 1)
-                        roofline["achieved"] = round((fetch + write) / max(avg_launch_s, 1e-12) / 1e9, 2)
-                        roofline["frac"] = round(roofline["achieved"] / HBM_PEAK_GBS, 5)
-                        roofline["calibration"] = cal
-                    main_k = [v for k, v in pmc.items() if k.startswith(prefixes[0])]
-                    valu = sum(v.get("SQ_INSTS_VALU", 0.0) for v in main_k) / n
-                    if valu:
-                        # VALU issue cycles used / available: instructions x 4 cycles / (1024 SIMDs x launch cycles at the 2.4 GHz max clock)
-                        roofline["valu_frac"] = round(valu * VALU_CYCLES_PER_INST / (SIMDS * avg_launch_s * CLOCK_HZ), 5)
-                        wc = sum(v.get("SQ_WAVE_CYCLES", 0.0) for v in main_k)
-                        if wc:
-                            roofline["wave_cycles_not_valu_frac"] = round(1.0 - sum(v.get("SQ_ACTIVE_INST_VALU", 0.0) for v in main_k) / wc, 5)
-                            roofline["wait_inst_any_frac"] = round(sum(v.get("SQ_WAIT_INST_ANY", 0.0) for v in main_k) / wc, 5)
-                    tc, av = sum(v.get("SQ_THREAD_CYCLES_VALU", 0.0) for v in main_k), sum(v.get("SQ_ACTIVE_INST_VALU", 0.0) for v in main_k)
-                    if tc and av:
-                        roofline["valu_lane_utilisation"] = round(tc / (64.0 * av), 5)  # active lanes per issued VALU instruction / 64
-                    hit, miss = sum(v.get("TCC_HIT_sum", 0.0) for v in main_k), sum(v.get("TCC_MISS_sum", 0.0) for v in main_k)
-                    if hit + miss > 0:
-                        roofline["l2_hit_rate"] = round(hit / (hit + miss), 5)
-                    if roofline.get("valu_frac") is not None and roofline["frac"] is not None:
-                        roofline["bound"] = "valu" if roofline["valu_frac"] > roofline["frac"] else "hbm"
-                    roofline["pmc_kernels"] = {k: {c: (round(x, 1) if isinstance(x, float) else x) for c, x in v.items()} for k, v in pmc.items() if k.startswith(prefixes)}
-        out = {"metric": "Msamples/s (spp x pixels / s) at 8 bounces, 1920x1080", "value": round(value, 2), "unit": "Msamples/s",
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 3),
-               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": label, "width": w, "height": h, "spp": rs.spp, "max_bounces": rs.max_bounces,
-                          "parallelism": f"rows-interleaved{world}" if world > 1 else "single", "segments_per_sample": round(seg_per_sample, 4),
-                          "triangles": cst["triangleCount"], "bvh8_nodes": cst["nodeCount"], "iterations_per_step": stats[-1]["iterations"]},
-               "roofline": roofline}
-        if os.environ.get("GATLING_BENCH_CHECKSUM"):  # tests: the frame rank 0 ends up with (host memory), as a checksum
-            import hashlib
-            img = last["img"]
-            out["image_checksum"] = hashlib.sha256((img.numpy() if hasattr(img, "numpy") else img).tobytes()).hexdigest()
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(desc, rs, w, h)
-            out["cpu_baseline"]["reference"] = reference_probe()
-    if scene is not None:
-        scene.close()
-    # N = 8 (the configuration C5 is specified on; BASELINE.json configs[4]): the tiled 4K interior as a second measurement in the same line.
+    if out is not None and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(R["desc"], R["rs"], R["w"], R["h"])
+        out["cpu_baseline"]["reference"] = reference_probe()
+    # Further measurements in the same line ("also"), so the driver's record covers more than the headline config:
+    #   N = 1 (headline C2 runs in the fused k_path_bw): C3 and C4 -- the wavefront pipeline k_raygen / k_trace_dyn / k_route / k_shade / k_trace_dyn<any> --
+    #         with their own roofline objects (3 steps each: C3 ~0.5 s, C4 ~0.15 s per step);
+    #   N = 8 (the configuration C5 is specified on; BASELINE.json configs[4]): the tiled 4K interior.
     # Every rank takes part (collectives inside); a failure is reported in the line instead of losing the headline number.
-    also = os.environ.get("GATLING_BENCH_ALSO", "c5" if world >= 8 else "")
-    if also and also != args.workload and not args.probe:
-        extra = {"workload": also}
+    also = os.environ.get("GATLING_BENCH_ALSO", ("c3,c4" if args.workload == "c2" and not args.spp else "") if world == 1 else ("c5" if world >= 8 else ""))
+    extras = []
+    for wl in [x for x in also.split(",") if x and x != args.workload]:
+        extra = {"workload": wl}
         try:
-            E = timed_run(also, int(os.environ.get("GATLING_BENCH_ALSO_SPP", "0")), 2, 1, True)
-            E["scene"].close()
-            samples = E["w"] * E["h"] * E["rs"].spp
-            extra.update({"config": E["label"], "value": round(samples * 2 / E["dt"] / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(E["dt"] * 1e3 / 2, 3),
-                          "steps": 2, "warmup": 1, "spp": E["rs"].spp, "width": E["w"], "height": E["h"], "n_gpus": world})
+            e_steps = int(os.environ.get("GATLING_BENCH_ALSO_STEPS", "3" if world == 1 else "2"))
+            E, _ = measure(wl, int(os.environ.get("GATLING_BENCH_ALSO_SPP", "0")), e_steps, 1, world > 1, args.no_pmc or world > 1, False)
+            if E is not None:
+                extra.update({"config": E["config"], "value": E["value"], "unit": "Msamples/s", "ms_per_step": E["ms_per_step"], "steps": e_steps, "warmup": 1,
+                              "n_gpus": world, "roofline": E["roofline"]})
         except Exception as e:  # noqa: BLE001
             extra["error"] = repr(e)[:300]
-        if out is not None:
-            out["also"] = extra
+        extras.append(extra)
+    if out is not None and extras:
+        out["also"] = extras if len(extras) > 1 else extras[0]
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -15,6 +15,8 @@ from .scene import P_COUNT, SceneDesc, RenderSettings
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgatling_gi.so")
+if os.environ.get("GATLING_GI_LIB"):  # experiments: a variant build of the same library (tools/build_variant.py), e.g. other kernel compile flags
+    LIB_PATH = os.path.abspath(os.environ["GATLING_GI_LIB"])
 
 GI_C_OK = 0
 AOV_COLOR = 0

@@ -309,7 +309,9 @@ static void buildCore(const std::vector<TriRec>& trisIn, const float* boxes, siz
       // --- gather up to 8 children
       uint32_t* ch = P.ch; bool chLeaf[8]; int n = 0;
       const Node2& r = B.nodes[n2];
-      if (r.count > 0 || (collapse == 1 && r.total <= kMaxLeaf)) { ch[0] = n2; chLeaf[0] = true; n = 1; } // root that is itself a leaf
+      // root that is itself a leaf (level 0 only: below the root the DP's own choice stands -- a subtree of <= 3 references it made an 8-wide
+      // node of is cheaper that way than as a node holding one 3-reference leaf slot, which is what this shortcut would emit)
+      if (r.count > 0 || (collapse == 1 && r.total <= kMaxLeaf && out.maxDepth == 1u)) { ch[0] = n2; chLeaf[0] = true; n = 1; }
       else if (collapse == 1) {
         Child cs[8]; n = gatherOptimal(n2, cs);
         for (int i = 0; i < n; i++) { ch[i] = cs[i].n2; chLeaf[i] = cs[i].leaf; }

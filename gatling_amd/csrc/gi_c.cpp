@@ -1042,6 +1042,8 @@ int buildScene(GiCScene* s)
     HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   }
   double t1 = nowMs();
+  // the deepest traversal variant keeps 8 (SPILL8) or 16 stack entries in LDS and OVF_STACK = 40 in scratch; trav_node_pick does not bound-check the spill
+  if (bvh.maxDepth > 1u + 8u + 40u) { setError("scene BVH is deeper than the traversal stack (49 levels): degenerate geometry (long chains of nested splits)"); return GI_C_ERROR; }
   if (bvh.tris.size() >= (1u << 26)) { setError("scene has 2^26 or more triangles after instancing: the traversal queues pack (lane, triangle) into 32 bits"); return GI_C_ERROR; }
   hipStream_t st = g_ctx.stream;
   std::vector<int32_t> triFaceId(bvh.tris.size());
@@ -1545,7 +1547,9 @@ static int giCTraceRaysImpl(GiCScene* s, uint32_t count, const float* origins, c
   std::lock_guard<std::mutex> guard(s->mutex);
   hipStream_t st = g_ctx.stream;
   if (s->dirty & (DIRTY_BVH | DIRTY_MATERIALS)) { if (buildScene(s) != GI_C_OK) return -1; s->dirty &= ~(DIRTY_BVH | DIRTY_MATERIALS); s->dirty |= DIRTY_FRAMEBUFFER; }
-  const uint32_t blocks = std::min<uint32_t>((count + 255u) / 256u, (uint32_t)g_ctx.cuCount * 3u);
+  // the render loop's grids: k_trace_dyn (scenes beyond LDS) is persistent per wave and wants every resident wave slot filled (8 blocks per CU offered)
+  const bool inLds = s->nodeCount <= 384u && s->triCount <= 128u;
+  const uint32_t blocks = std::min<uint32_t>((count + 255u) / 256u, (uint32_t)g_ctx.cuCount * (inLds ? 3u : 8u));
   if (ensurePathState(s, count, blocks, blocks) != GI_C_OK) return -1;
   // ray records go straight into the TRACE_A queue (segment k holds rays [k*per, (k+1)*per))
   const size_t qn = (size_t)s->queueCap * NSHARD;

@@ -43,7 +43,8 @@ __global__ void k_init(PathState st, QueueSet qs, Counters* cnt, uint32_t n, uin
     cnt->count[q][sdx].v = c;
   }
   if (i == 0) {
-    cnt->overflow = 0u; cnt->workBase[0].v = 0; cnt->workBase[1].v = 0; for (uint32_t k = 0; k < NCURSOR; k++) { cnt->cursor[0][k].v = 0; cnt->cursor[1][k].v = 0; }
+    if (resetStats) cnt->overflow = 0u; // sticky across the batches of one render: giCRender reads it back once, after the last batch
+    cnt->workBase[0].v = 0; cnt->workBase[1].v = 0; for (uint32_t k = 0; k < NCURSOR; k++) { cnt->cursor[0][k].v = 0; cnt->cursor[1][k].v = 0; }
     if (resetStats) { cnt->segments = 0; cnt->shadowRays = 0; cnt->nodesVisited = 0; cnt->trisTested = 0; cnt->shadowNodesVisited = 0; cnt->shadowTrisTested = 0; }
   }
   for (; i < n; i += gridDim.x * blockDim.x) {
@@ -268,6 +269,9 @@ constexpr uint32_t DYN_FLAG_FLUSH_SHIFT = 8u; // bits 8-15: wave_step_carry's fl
 constexpr uint32_t DYN_FLUSH_AT_DEFAULT = 8u;
 constexpr uint32_t DYN_LDS_NODES_DEFAULT = 0u;   // (GATLING_DYN_LDS_NODES)
 constexpr bool DYN_XCD_RANGES_DEFAULT = false;   // (GATLING_DYN_XCD)
+#ifndef GI_DYN_LDS_NODES
+#define GI_DYN_LDS_NODES 0
+#endif
 #ifndef GI_DYN_WAVES
 #define GI_DYN_WAVES 5
 #endif
@@ -281,6 +285,9 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
   // The top of the tree (breadth-first prefix: root + its children + ...) is visited by every ray; staged in LDS once per block, those
   // visits cost an LDS read instead of an L2 round trip.  The one barrier of the kernel: afterwards the waves are independent.
   uint4* s_nodes = s_dyn + (STACK * TRACE_BLOCK * sizeof(uint2)) / sizeof(uint4);
+#if !GI_DYN_LDS_NODES
+  ldsNodes = 0u; // measured useless (9 / 73 / 585 staged nodes: no gain); compiled out so the node fetch has ONE path (global loads)
+#endif
   if (!TWO && ldsNodes) {
     for (uint32_t i = threadIdx.x; i < ldsNodes * 5u; i += TRACE_BLOCK) s_nodes[i] = reinterpret_cast<const uint4*>(sc.nodes)[(i / 5u) * sc.nodeStrideU4 + (i % 5u)];
     __syncthreads();

@@ -253,6 +253,9 @@ struct WaveStage { uint4 buf[64 * 5]; };
 // Measured on C3 (1M-triangle soup): 35.4 ms with the cooperative fetch vs 29.6 ms without (the 20 KiB of staging per
 // block cost two resident blocks per CU and the extra LDS round trip outweighs the saved tag look-ups) -> off.
 constexpr bool TRACE_DYN_COOP_FETCH = false;
+#ifndef GI_TRI_FULL_LOAD
+#define GI_TRI_FULL_LOAD 1
+#endif
 #ifndef GI_WAVE_STEP_SCAN_APPEND
 #define GI_WAVE_STEP_SCAN_APPEND 1
 #endif
@@ -292,7 +295,14 @@ __device__ __forceinline__ void wave_tri_batch(WT& W, WaveStage* S, uint32_t hea
     uint4 a, b, c;
     if (COOP) { const uint4* p = S->buf + lane * 3u; a = p[0]; b = p[1]; c = p[2]; }
     else if (ALL_LDS || triIdx < ldsTris) { const uint4* p = s_tris + triIdx * 3u; a = p[0]; b = p[1]; c = p[2]; }
-    else { const uint4* p = reinterpret_cast<const uint4*>(sc.tris) + (size_t)triIdx * 4u; a = p[0]; b = p[1]; c = p[2]; }
+    else {
+      const uint4* p = reinterpret_cast<const uint4*>(sc.tris) + (size_t)triIdx * 4u; a = p[0]; b = p[1]; c = p[2];
+#if GI_TRI_FULL_LOAD
+      // All 48 bytes at once: left alone, the compiler loads only c.x here and SINKS the loads of c.y (scene-order id) and c.w (material word) into the accept
+      // branch below, where each costs the wave a dependent global round trip (s_waitcnt vmcnt(0) twice) although the line is already on its way.
+      asm volatile("" : "+v"(c.y), "+v"(c.w));
+#endif
+    }
     if (COUNT) tc.tris++;
     float t, u, v;
     bool accept = tri_test(o, d, tMin, a, b, c, t, u, v);

@@ -332,10 +332,20 @@ namespace gtl
     if (params.count("base_color") || params.count("specular_roughness") || params.count("base_metalness") || module.find("open_pbr") != std::string::npos) {
       // open_pbr_surface vocabulary: the same defaults and inputs as the MaterialX route (src/gi/mtlx/open_pbr_surface.mtlx:11-92)
       std::string xml = "<materialx version=\"1.39\"><open_pbr_surface name=\"m\" type=\"surfaceshader\">";
-      static const char* kOpbr[] = {"base_weight", "base_color", "base_diffuse_roughness", "base_metalness", "specular_weight", "specular_color", "specular_roughness", "specular_ior",
-                                    "transmission_weight", "transmission_color", "transmission_depth", "transmission_scatter", "transmission_scatter_anisotropy", "coat_weight", "coat_color",
-                                    "coat_roughness", "coat_ior", "emission_luminance", "emission_color", "geometry_opacity", "fuzz_weight", "fuzz_color", "fuzz_roughness", "geometry_thin_walled"};
-      for (const char* k : kOpbr) { float v[3]; if (num(k, v, 3)) { char buf[160]; snprintf(buf, sizeof(buf), "<input name=\"%s\" value=\"%.9g, %.9g, %.9g\" />", k, v[0], v[1], v[2]); xml += buf; } }
+      // (name, components): scalars are written as one value, colours as three -- the same spelling a MaterialX document uses
+      static const struct { const char* name; int n; } kOpbr[] = {
+        {"base_weight", 1}, {"base_color", 3}, {"base_diffuse_roughness", 1}, {"base_metalness", 1}, {"specular_weight", 1}, {"specular_color", 3}, {"specular_roughness", 1},
+        {"specular_ior", 1}, {"transmission_weight", 1}, {"transmission_color", 3}, {"transmission_depth", 1}, {"transmission_scatter", 3}, {"transmission_scatter_anisotropy", 1},
+        {"coat_weight", 1}, {"coat_color", 3}, {"coat_roughness", 1}, {"coat_ior", 1}, {"coat_darkening", 1}, {"emission_luminance", 1}, {"emission_color", 3},
+        {"geometry_opacity", 1}, {"fuzz_weight", 1}, {"fuzz_color", 3}, {"fuzz_roughness", 1}, {"geometry_thin_walled", 1}};
+      for (const auto& k : kOpbr) {
+        float v[3];
+        if (!num(k.name, v, k.n)) continue;
+        char buf[200];
+        if (k.n == 1) snprintf(buf, sizeof(buf), "<input name=\"%s\" value=\"%.9g\" />", k.name, v[0]);
+        else snprintf(buf, sizeof(buf), "<input name=\"%s\" value=\"%.9g, %.9g, %.9g\" />", k.name, v[0], v[1], v[2]);
+        xml += buf;
+      }
       xml += "</open_pbr_surface></materialx>";
       if (!descFromMtlx(xml.c_str(), d, primvars, images)) return nullptr;
       tex("base_color", GI_C_TEX_BASE_COLOR, 0); tex("specular_roughness", GI_C_TEX_ROUGHNESS, 0); tex("base_metalness", GI_C_TEX_METALLIC, 0);

@@ -47,10 +47,20 @@ class RowGather:
         self.pad = torch.zeros((self.max_rows, width, 4), dtype=dtype, device=device)
         self.out = [torch.empty_like(self.pad) for _ in range(self.world)] if self.rank == dst else None
         self.full = torch.empty((height, width, 4), dtype=dtype, device=device) if self.rank == dst else None
+        # the pack copy is the only reader of the caller's tile (the library's render buffer): `packed` marks its end on the caller's stream
+        self.packed = torch.cuda.Event() if torch.device(device).type == "cuda" else None
+
+    def wait_packed(self):
+        """Blocks the host until the last call's pack copy has read the tile it was given: the producer of the next tile (the render library, which
+        works on a stream of its own that nothing orders against torch's) may overwrite it only after this returns."""
+        if self.packed is not None:
+            self.packed.synchronize()
 
     def __call__(self, local_tile):
         import torch.distributed as dist
         self.pad[: local_tile.shape[0]].copy_(local_tile)  # also packs a strided (interleaved) device view
+        if self.packed is not None:
+            self.packed.record()
         dist.gather(self.pad, self.out, dst=self.dst, group=self.group)
         if self.rank != self.dst:
             return None
