@@ -97,17 +97,21 @@ def fetch_calibration():
 
 
 def valu_calibration():
-    """Cycles one SIMD needs per wave64 VALU instruction, MEASURED by tools/valu_calib.hip (independent v_fma_f32 chains at 8 waves/SIMD, shader
-    clock inside the kernel) and written to profiles/valu_issue_calibration.json by tools/valu_calib_report.py."""
+    """VALU issue ceilings MEASURED by tools/valu_calib.hip (profiles/valu_issue_calibration.json, written by tools/valu_calib_report.py): wave64 instructions
+    per SIMD and NANOSECOND at 8 waves/SIMD, chip-wide -- in wall time, because the shader clock sags under a full-chip VALU load (1.4-1.5 GHz measured, not
+    the 2.4 GHz maximum), so `cycles x 2.4 GHz` is not a rate.  "fp32": a stream of one fp32 class (v_fma_f32 / v_pk_fma_f32 / v_cvt / v_max3: ~0.53-0.59);
+    "mixed": alternating classes dual-issue (cvt + fma 1:1, int adds: ~1.04).  A real kernel's ceiling lies between the two."""
     p = os.path.join(ROOT, "profiles", "valu_issue_calibration.json")
+    out = {"fp32": CLOCK_HZ / VALU_CYCLES_PER_INST_DEFAULT / 1e9, "mixed": CLOCK_HZ / VALU_CYCLES_PER_INST_DEFAULT / 1e9, "source": "default (no calibration file): 4 cycles at 2.4 GHz"}
     try:
         j = json.load(open(p))
-        c = float(j["cycles_per_wave64_valu"])
-        if 0.5 < c < 16.0:
-            return c, j.get("source", "profiles/valu_issue_calibration.json")
+        rate = {r["op"]: float(r["wall_instr_per_simd_per_ns"]) for r in j["rows"] if int(r["waves_per_simd"]) == 8}
+        fp, mixed = rate["v_fma_f32"], max(rate.values())
+        if 0.05 < fp <= mixed < 4.0:
+            out = {"fp32": fp, "mixed": mixed, "source": j.get("source", "profiles/valu_issue_calibration.json")}
     except Exception:
         pass
-    return VALU_CYCLES_PER_INST_DEFAULT, "default (no calibration file)"
+    return out
 
 
 def short_kernel(name):
@@ -196,6 +200,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-timers", action="store_true", help="do not record per-stage HIP events (roofline fields become 0)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes (roofline.traffic / frac become null)")
+    ap.add_argument("--in-process", action="store_true", help="ONE process driving --gpus N devices inside the library (giCInitializeDevices: rows dealt to the devices per "
+                    "giCRender, shares copied into place on device 0) instead of one rank per GPU + RCCL gather; for comparing the two multi-GPU forms")
     ap.add_argument("--probe", action="store_true", help=argparse.SUPPRESS)  # internal: one untimed step, no output (the --pmc passes run this)
     args = ap.parse_args()
     if args.probe:
@@ -207,8 +213,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
+        if world == 1 and args.gpus > 1 and not args.in_process:
+            raise SystemExit("--gpus N > 1 must be launched through torch.distributed.run (one rank per GPU), or pass --in-process")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
     if os.environ.get("GATLING_BENCH_SHARE_GPU"):  # tests: every rank on GPU 0
@@ -222,6 +228,8 @@ def main():
 
     from gatling_amd import capi
     from gatling_amd.dist import RowGather, interleaved_rows
+    if args.in_process and world == 1 and args.gpus > 1:
+        capi.initialize(devices=list(range(args.gpus)))  # before the first Scene: one giCInitialize per process
 
     def timed_run(workload, spp, steps, warmup, no_timers):
         """Scene resident in HBM, `warmup` untimed steps, then exactly `steps` steps between barrier + synchronize; time = max over ranks."""
@@ -341,7 +349,7 @@ def main():
                 scene.close(); scene = None  # the probe processes need the device memory (C5: 17 GB of queues per process)
                 pmc, note = pmc_live(workload, spp)
                 cal = fetch_calibration()
-                valu_cycles, valu_src = valu_calibration()
+                vcal = valu_calibration()
                 roofline["pmc_note"] = note or "ok"
                 if pmc:
                     dom = [v for k, v in pmc.items() if k.startswith(prefixes)]
@@ -365,9 +373,12 @@ def main():
                         main_k = [v for k, v in pmc.items() if k.startswith(prefixes[0])]
                         valu = sum(v.get("SQ_INSTS_VALU", 0.0) for v in main_k) / n
                         if valu:
-                            # VALU issue cycles used / available: instructions x measured cycles per instruction / (1024 SIMDs x launch cycles at the 2.4 GHz max clock)
-                            roofline["valu_frac"] = round(valu * valu_cycles / (SIMDS * avg_launch_s * CLOCK_HZ), 5)
-                            roofline["valu_cycles_per_inst"] = round(valu_cycles, 4); roofline["valu_calibration"] = valu_src
+                            # VALU issue rate achieved (wave64 instructions per SIMD and ns over the launch) against the two measured ceilings
+                            rate = valu / (SIMDS * avg_launch_s * 1e9)
+                            roofline["valu_instr_per_simd_per_ns"] = round(rate, 5)
+                            roofline["valu_frac"] = round(rate / vcal["mixed"], 5)        # vs the dual-issue ceiling (alternating instruction classes)
+                            roofline["valu_frac_fp32_only"] = round(rate / vcal["fp32"], 5)  # vs a stream of fp32-class instructions only
+                            roofline["valu_calibration"] = {k: (round(v, 5) if isinstance(v, float) else v) for k, v in vcal.items()}
                             wc = sum(v.get("SQ_WAVE_CYCLES", 0.0) for v in main_k)
                             if wc:
                                 roofline["wave_cycles_not_valu_frac"] = round(1.0 - sum(v.get("SQ_ACTIVE_INST_VALU", 0.0) for v in main_k) / wc, 5)
@@ -379,22 +390,26 @@ def main():
                         if hit + miss > 0:
                             roofline["l2_hit_rate"] = round(hit / (hit + miss), 5)
                         if roofline.get("valu_frac") is not None and roofline["frac"] is not None:
+                            # the larger of the two fractions names the nearer roofline; when both are far (< 0.6) the kernel is bound by neither -- latency / the
+                            # vector-memory request path (tools/ta_calib.hip) -- and `bound` still names the nearer one, with the note saying so
                             roofline["bound"] = "valu" if roofline["valu_frac"] > roofline["frac"] else "hbm"
+                            if max(roofline["valu_frac"], roofline["frac"]) < 0.6:
+                                roofline["bound_note"] = "neither roofline is near: latency / vector-memory request rate bound (DESIGN.md section 4)"
                         roofline["pmc_kernels"] = {k: {c: (round(x, 1) if isinstance(x, float) else x) for c, x in v.items()} for k, v in pmc.items() if k.startswith(prefixes)}
                         if not main_line:  # every kernel of the frame, compactly: time share under counters, VALU issue, lanes, L2 hit (the per-kernel picture of the wavefront pipeline)
                             tot = sum(v.get("pmc_us", 0.0) * v.get("dispatches", 0) for v in pmc.values()) or 1.0
                             roofline["all_kernels"] = {
                                 k: {"dispatches": v.get("dispatches", 0), "time_share": round(v.get("pmc_us", 0.0) * v.get("dispatches", 0) / tot, 4),
-                                    "valu_frac": round(v.get("SQ_INSTS_VALU", 0.0) * valu_cycles / (SIMDS * max(v.get("pmc_us", 0.0) * v.get("dispatches", 1) * 1e-6, 1e-12) * CLOCK_HZ), 4),
+                                    "valu_frac": round(v.get("SQ_INSTS_VALU", 0.0) / (SIMDS * max(v.get("pmc_us", 0.0) * v.get("dispatches", 1) * 1e3, 1e-9)) / vcal["mixed"], 4),
                                     "lanes": round(v.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * v["SQ_ACTIVE_INST_VALU"]), 4) if v.get("SQ_ACTIVE_INST_VALU") else None,
                                     "l2_hit": round(v.get("TCC_HIT_sum", 0.0) / (v.get("TCC_HIT_sum", 0.0) + v.get("TCC_MISS_sum", 0.0)), 4) if (v.get("TCC_HIT_sum", 0.0) + v.get("TCC_MISS_sum", 0.0)) else None,
                                     "fetch_GB": round(v.get("FETCH_SIZE", 0.0) * 1024.0 / 1e9, 3), "write_GB": round(v.get("WRITE_SIZE", 0.0) * 1024.0 / 1e9, 3)}
                                 for k, v in sorted(pmc.items(), key=lambda kv: -kv[1].get("pmc_us", 0.0) * kv[1].get("dispatches", 0))[:10]}
             out = {"metric": "Msamples/s (spp x pixels / s) at 8 bounces, 1920x1080", "value": round(value, 2), "unit": "Msamples/s",
-                   "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1e3 / steps, 3),
+                   "n_gpus": args.gpus if args.in_process else world, "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1e3 / steps, 3),
                    "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                    "config": {"workload": label, "width": w, "height": h, "spp": rs.spp, "max_bounces": rs.max_bounces,
-                              "parallelism": f"rows-interleaved{world}" if world > 1 else "single", "segments_per_sample": round(seg_per_sample, 4),
+                              "parallelism": f"rows-interleaved{world}" if world > 1 else (f"in-process rows-interleaved{args.gpus}" if args.in_process and args.gpus > 1 else "single"), "segments_per_sample": round(seg_per_sample, 4),
                               "triangles": cst["triangleCount"], "bvh8_nodes": cst["nodeCount"], "iterations_per_step": stats[-1]["iterations"]},
                    "roofline": roofline}
             if os.environ.get("GATLING_BENCH_CHECKSUM"):  # tests: the frame rank 0 ends up with (host memory), as a checksum

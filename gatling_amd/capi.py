@@ -21,7 +21,7 @@ if os.environ.get("GATLING_GI_LIB"):  # experiments: a variant build of the same
 GI_C_OK = 0
 AOV_COLOR = 0
 FORMAT_INT32, FORMAT_FLOAT32, FORMAT_FLOAT32_VEC4 = 0, 1, 2
-OPTION_COUNT_TRAVERSAL, OPTION_KERNEL_TIMERS, OPTION_POOL_SLOTS, OPTION_SAMPLE_BUFFER_MB, OPTION_TRACE_DYNAMIC, OPTION_TWO_LEVEL, OPTION_FUSED_PATH = 1, 2, 3, 4, 5, 6, 7
+OPTION_COUNT_TRAVERSAL, OPTION_KERNEL_TIMERS, OPTION_POOL_SLOTS, OPTION_SAMPLE_BUFFER_MB, OPTION_TRACE_DYNAMIC, OPTION_TWO_LEVEL, OPTION_FUSED_PATH, OPTION_DEVICES = 1, 2, 3, 4, 5, 6, 7, 8
 
 
 class GiCCameraDesc(C.Structure):
@@ -85,7 +85,7 @@ class GiCPrimvarData(C.Structure):
 
 
 SYMBOLS = [
-    ("giCInitialize", C.c_int, [C.c_int]), ("giCTerminate", None, []), ("giCGetLastError", C.c_char_p, []),
+    ("giCInitialize", C.c_int, [C.c_int]), ("giCInitializeDevices", C.c_int, [C.POINTER(C.c_int32), C.c_uint32]), ("giCGetDeviceCount", C.c_uint32, []), ("giCTerminate", None, []), ("giCGetLastError", C.c_char_p, []),
     ("giCCreateMaterial", _P, [_P, C.c_char_p, C.POINTER(GiCMaterialDesc)]), ("giCDestroyMaterial", None, [_P]),
     ("giCCreateMesh", _P, [_P, C.POINTER(GiCMeshDesc)]), ("giCSetMeshTransform", None, [_P, _FP]),
     ("giCSetMeshInstanceTransforms", None, [_P, _U, _FP]), ("giCSetMeshInstanceIds", None, [_P, _U, C.POINTER(C.c_int32)]),
@@ -152,11 +152,18 @@ class GiError(RuntimeError):
 _initialized = False
 
 
-def initialize(device: int = 0):
+def initialize(device: int = 0, devices=None):
+    """One giCInitialize per process (Gi.cpp:244-259).  `devices` = list of HIP ordinals -> giCInitializeDevices: whole-frame renders are then dealt
+    row-wise to all of them inside the library (the first is the primary); $GATLING_DEVICES does the same for callers that pass nothing."""
     global _initialized
     L = load_library()
     if not _initialized:
-        if L.giCInitialize(device) != GI_C_OK:
+        if devices:
+            arr = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+            rc = L.giCInitializeDevices(arr, len(devices))
+        else:
+            rc = L.giCInitialize(device)
+        if rc != GI_C_OK:
             raise GiError("giCInitialize failed: " + L.giCGetLastError().decode())
         _initialized = True
     return L

@@ -22,6 +22,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bvh8.h"
@@ -45,11 +46,15 @@ void setError(const std::string& e) { t_lastError = e; fprintf(stderr, "[gatling
     if (_e != hipSuccess) { setError(std::string(#expr) + ": " + hipGetErrorString(_e)); return GI_C_ERROR; } \
   } while (0)
 
+// One entry per HIP device the library renders on (giCInitializeDevices / $GATLING_DEVICES; giCInitialize: one).  devs[0] is the PRIMARY device:
+// render buffers, textures and every single-device entry point live there; the others hold replicas of the scene and render row shares.
+struct DevCtx { int device = 0; int cuCount = 256; hipStream_t stream = nullptr; };
 struct Context {
   bool initialized = false;
-  int device = 0;
-  int cuCount = 256;
-  hipStream_t stream = nullptr;
+  int device = 0;               // == devs[0].device
+  int cuCount = 256;            // == devs[0].cuCount
+  hipStream_t stream = nullptr; // == devs[0].stream
+  std::vector<DevCtx> devs;
   std::mutex resourceMutex; // GPU resource destruction from sync threads (Gi.cpp:679-683)
 } g_ctx;
 
@@ -267,41 +272,23 @@ void DenseStore<Rec, Handle>::remove(uint32_t idx)
 struct GiCRenderBuffer {
   uint32_t width, height, stride;
   size_t size;
-  void* deviceMem = nullptr;
+  void* deviceMem = nullptr; // on the primary device
   void* hostMem = nullptr; // pinned (hipHostMalloc): the reference maps a HostVisible|HostCached buffer (Gi.cpp:2019-2031)
   bool deviceOnly = false;
+  bool scratch = false; // internal stand-in that lives in the rendering device's own scratch memory (no replicas)
+  std::vector<void*> replicaMem; // [slot - 1]: the same buffer on the other devices (multi-device renders), allocated on first use
 };
 
-struct GiCScene {
-  std::mutex mutex;
-  uint32_t dirty = DIRTY_ALL;
-  std::vector<GiCMesh*> meshes;       // creation order (deterministic triangle ids; the reference uses an unordered_set)
-  std::vector<GiCMaterial*> materials;
-  std::vector<GiCTexture*> textures;  // creation order
+// Everything a scene keeps in ONE device's memory: the scene arrays, the path pool, the queues, the per-render scratch.  GiCScene IS the primary
+// device's (inheritance keeps the single-device code reading `s->dNodes`); multi-device renders add one replica per further device.
+struct SceneDevice {
+  uint32_t slot = 0; // index into g_ctx.devs
   DeviceBuffer<MeshRec> dMeshes; DeviceBuffer<float> dSceneData;
   std::vector<DeviceBuffer<float>*> dTexels; DeviceBuffer<TextureRec> dTextures; // device copies (rebuilt with the materials)
-  DenseStore<SphereLightRec, GiCSphereLight> sphereLights;
-  DenseStore<DistantLightRec, GiCDistantLight> distantLights;
-  DenseStore<RectLightRec, GiCRectLight> rectLights;
-  DenseStore<DiskLightRec, GiCDiskLight> diskLights;
-  uint32_t sampleOffset = 0;
-  bool haveOldParams = false;
-  GiCCameraDesc oldCamera{};
-  GiCRenderSettings oldSettings{};
-  uint8_t oldClear[GI_C_MAX_AOV_COMP_SIZE] = {0};
-  uint32_t oldRowBegin = 0, oldRowEnd = 0, oldRowStride = 1;
-  GiCDomeLight* oldDome = nullptr;
-  float oldDomeEmission[3] = {0, 0, 0};
-  // device scene
-  DeviceBuffer<Node8> dNodes; DeviceBuffer<uint4> dNodesLine; uint32_t nodeStrideU4 = 5; DeviceBuffer<TriRec> dTris; DeviceBuffer<InstanceRec> dInstances;
+  DeviceBuffer<Node8> dNodes; DeviceBuffer<uint4> dNodesLine; DeviceBuffer<TriRec> dTris; DeviceBuffer<InstanceRec> dInstances;
   DeviceBuffer<FVertex> dVerts; DeviceBuffer<MaterialRec> dMaterials; DeviceBuffer<int32_t> dTriFaceId;
   DeviceBuffer<SphereLightRec> dSphere; DeviceBuffer<DistantLightRec> dDistant; DeviceBuffer<RectLightRec> dRect; DeviceBuffer<DiskLightRec> dDisk;
-  uint32_t nodeCount = 0, triCount = 0, bvhDepth = 0;
   DeviceBuffer<Node8> dTlasNodes, dBlasNodes; DeviceBuffer<uint32_t> dTlasItems, dFlatOfOrig; DeviceBuffer<BlasTri> dBlasTris; DeviceBuffer<InstTrav> dInstTrav;
-  bool twoLevel = false; int optTwoLevel = -1; // 1: build and use the two-level layout (scenes beyond LDS); otherwise the flat one
-  bool hasCutouts = false;
-  uint32_t classMask = 0; // material classes that own at least one triangle (one k_shade launch per class)
-  uint32_t classTextured = 0; // classes with at least one textured material in use (k_shade<class, TEXTURED>)
   // path state
   DeviceBuffer<Slot> slots;
   DeviceBuffer<float> media; // per-slot medium stack + walkSegmentPdf (mediumStackSize > 0)
@@ -314,15 +301,60 @@ struct GiCScene {
   uint32_t queueCap = 0;
   DeviceBuffer<Counters> dCounters;
   Counters* hCounters = nullptr; // pinned
+  GiCRenderStats stats{};
+  std::vector<hipEvent_t> eventPool;
+  void releaseAll();
+};
+
+struct GiCScene : SceneDevice {
+  std::mutex mutex;
+  uint32_t dirty = DIRTY_ALL;
+  std::vector<GiCMesh*> meshes;       // creation order (deterministic triangle ids; the reference uses an unordered_set)
+  std::vector<GiCMaterial*> materials;
+  std::vector<GiCTexture*> textures;  // creation order
+  DenseStore<SphereLightRec, GiCSphereLight> sphereLights;
+  DenseStore<DistantLightRec, GiCDistantLight> distantLights;
+  DenseStore<RectLightRec, GiCRectLight> rectLights;
+  DenseStore<DiskLightRec, GiCDiskLight> diskLights;
+  uint32_t sampleOffset = 0;
+  bool haveOldParams = false;
+  GiCCameraDesc oldCamera{};
+  GiCRenderSettings oldSettings{};
+  uint8_t oldClear[GI_C_MAX_AOV_COMP_SIZE] = {0};
+  uint32_t oldRowBegin = 0, oldRowEnd = 0, oldRowStride = 1;
+  GiCDomeLight* oldDome = nullptr;
+  float oldDomeEmission[3] = {0, 0, 0};
+  // the scene as built (the same on every device)
+  uint32_t nodeStrideU4 = 5;
+  uint32_t nodeCount = 0, triCount = 0, bvhDepth = 0;
+  bool twoLevel = false; int optTwoLevel = -1; // 1: build and use the two-level layout (scenes beyond LDS); otherwise the flat one
+  bool hasCutouts = false;
+  uint32_t classMask = 0; // material classes that own at least one triangle (one k_shade launch per class)
+  uint32_t classTextured = 0; // classes with at least one textured material in use (k_shade<class, TEXTURED>)
+  std::vector<std::unique_ptr<SceneDevice>> replicas; // devices 1 .. N-1 (created with the first build when the library runs on several devices)
   // options + stats
   bool countTraversal = false, kernelTimers = false;
   uint32_t kernelTimerStride = 1;
   uint64_t optPoolSlots = 0, optSampleBufferMb = 0; // 0 = default
   int32_t optFusedPath = -1; // -1 / 1 = default: LDS-resident scenes run the fused persistent kernels (k_path_bw without NEE, k_path with); 2 = k_path only; 0 = always the wavefront stage kernels
   int32_t optTraceDyn = -1; // -1 = default; 0 = block-synchronous k_trace everywhere; N = k_trace_dyn refill threshold
-  GiCRenderStats stats{};
-  std::vector<hipEvent_t> eventPool;
+  int32_t optDevices = 0;   // 0 = every device the library was initialised on; N = at most N of them
 };
+
+void SceneDevice::releaseAll()
+{
+  dNodes.release(); dNodesLine.release(); dTris.release(); dInstances.release(); dVerts.release(); dTriFaceId.release();
+  dTlasNodes.release(); dBlasNodes.release(); dTlasItems.release(); dFlatOfOrig.release(); dBlasTris.release(); dInstTrav.release();
+  for (auto* b : dTexels) { b->release(); delete b; }
+  dTexels.clear(); dTextures.release(); dMeshes.release(); dSceneData.release();
+  dMaterials.release(); dSphere.release(); dDistant.release(); dRect.release(); dDisk.release();
+  slots.release(); media.release(); scratchColor.release(); neeKey.release(); pathSegments.release(); sampleBuf.release(); accum.release();
+  for (uint32_t q = 0; q < Q_COUNT; q++) { qSlot[q].release(); qA[q].release(); qB[q].release(); qC[q].release(); }
+  dCounters.release();
+  if (hCounters) { (void)hipHostFree(hCounters); hCounters = nullptr; }
+  for (hipEvent_t e : eventPool) (void)hipEventDestroy(e);
+  eventPool.clear();
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // init
@@ -331,28 +363,73 @@ extern "C" {
 
 const char* giCGetLastError(void) { return t_lastError.c_str(); }
 
-int giCInitialize(int deviceOrdinal)
+// The device list: giCInitializeDevices' argument, else $GATLING_DEVICES ("0,1,2,3" or "all"), else the one ordinal of giCInitialize.  The same ordinal may be
+// listed twice (two contexts on one GPU): that is how the multi-device path is tested on a one-GPU box.
+static int initDevices(const std::vector<int>& ordinals)
 {
   if (g_ctx.initialized) return GI_C_OK;
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n == 0) { setError("no HIP device available: this library has no CPU fallback"); return GI_C_ERROR; }
-  if (deviceOrdinal < 0 || deviceOrdinal >= n) { setError("device ordinal out of range"); return GI_C_ERROR; }
-  HIP_TRY(hipSetDevice(deviceOrdinal));
-  hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, deviceOrdinal));
-  g_ctx.device = deviceOrdinal;
-  g_ctx.cuCount = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  HIP_TRY(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+  if (ordinals.empty()) { setError("empty device list"); return GI_C_ERROR; }
+  for (int d : ordinals) if (d < 0 || d >= n) { setError("device ordinal out of range"); return GI_C_ERROR; }
+  std::vector<DevCtx> devs;
+  for (int d : ordinals) {
+    DevCtx c; c.device = d;
+    HIP_TRY(hipSetDevice(d));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, d));
+    c.cuCount = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    devs.push_back(c);
+  }
+  // the row shares travel to the primary device over xGMI: peer access both ways (already-enabled / same-device errors are harmless)
+  for (size_t i = 1; i < devs.size(); i++) {
+    if (devs[i].device == devs[0].device) continue;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, devs[0].device, devs[i].device) == hipSuccess && can) {
+      (void)hipSetDevice(devs[0].device); (void)hipDeviceEnablePeerAccess(devs[i].device, 0);
+      (void)hipSetDevice(devs[i].device); (void)hipDeviceEnablePeerAccess(devs[0].device, 0);
+    }
+    (void)hipGetLastError();
+  }
+  HIP_TRY(hipSetDevice(devs[0].device));
+  g_ctx.devs = devs;
+  g_ctx.device = devs[0].device; g_ctx.cuCount = devs[0].cuCount; g_ctx.stream = devs[0].stream;
   g_ctx.initialized = true;
   return GI_C_OK;
 }
 
+int giCInitialize(int deviceOrdinal)
+{
+  if (g_ctx.initialized) return GI_C_OK;
+  std::vector<int> ordinals{deviceOrdinal};
+  if (const char* e = getenv("GATLING_DEVICES")) { // "0,1,2,3", or "all"
+    ordinals.clear();
+    if (!strcmp(e, "all")) { int n = 0; if (hipGetDeviceCount(&n) == hipSuccess) for (int d = 0; d < n; d++) ordinals.push_back(d); }
+    else for (const char* p = e; *p;) { char* end = nullptr; const long v = strtol(p, &end, 10); if (end == p) { p++; continue; } ordinals.push_back((int)v); p = end; }
+    if (ordinals.empty()) ordinals.push_back(deviceOrdinal);
+  }
+  return initDevices(ordinals);
+}
+
+int giCInitializeDevices(const int32_t* deviceOrdinals, uint32_t count)
+{
+  if (!deviceOrdinals || count == 0) { setError("giCInitializeDevices: empty device list"); return GI_C_ERROR; }
+  return initDevices(std::vector<int>(deviceOrdinals, deviceOrdinals + count));
+}
+
+uint32_t giCGetDeviceCount(void) { return g_ctx.initialized ? (uint32_t)g_ctx.devs.size() : 0u; }
+
 void giCTerminate(void)
 {
   if (!g_ctx.initialized) return;
-  (void)hipStreamSynchronize(g_ctx.stream);
-  (void)hipStreamDestroy(g_ctx.stream);
+  for (DevCtx& c : g_ctx.devs) {
+    (void)hipSetDevice(c.device);
+    (void)hipStreamSynchronize(c.stream);
+    (void)hipStreamDestroy(c.stream);
+  }
+  g_ctx.devs.clear();
   g_ctx.stream = nullptr;
   g_ctx.initialized = false;
 }
@@ -370,17 +447,14 @@ void giCDestroyScene(GiCScene* s)
 {
   if (!s) return;
   std::lock_guard<std::mutex> g(g_ctx.resourceMutex);
+  for (auto& r : s->replicas) {
+    (void)hipSetDevice(g_ctx.devs[r->slot].device);
+    (void)hipStreamSynchronize(g_ctx.devs[r->slot].stream);
+    r->releaseAll();
+  }
+  (void)hipSetDevice(g_ctx.device);
   (void)hipStreamSynchronize(g_ctx.stream);
-  s->dNodes.release(); s->dNodesLine.release(); s->dTris.release(); s->dInstances.release(); s->dVerts.release(); s->dTriFaceId.release();
-  s->dTlasNodes.release(); s->dBlasNodes.release(); s->dTlasItems.release(); s->dFlatOfOrig.release(); s->dBlasTris.release(); s->dInstTrav.release();
-  for (auto* b : s->dTexels) { b->release(); delete b; }
-  s->dTexels.clear(); s->dTextures.release(); s->dMeshes.release(); s->dSceneData.release();
-  s->dMaterials.release(); s->dSphere.release(); s->dDistant.release(); s->dRect.release(); s->dDisk.release();
-  s->slots.release(); s->media.release(); s->scratchColor.release(); s->neeKey.release(); s->pathSegments.release(); s->sampleBuf.release(); s->accum.release();
-  for (uint32_t q = 0; q < Q_COUNT; q++) { s->qSlot[q].release(); s->qA[q].release(); s->qB[q].release(); s->qC[q].release(); }
-  s->dCounters.release();
-  if (s->hCounters) (void)hipHostFree(s->hCounters);
-  for (hipEvent_t e : s->eventPool) (void)hipEventDestroy(e);
+  s->releaseAll();
   delete s;
 }
 
@@ -777,6 +851,9 @@ void giCDestroyRenderBuffer(GiCRenderBuffer* rb)
   (void)hipStreamSynchronize(g_ctx.stream);
   if (rb->deviceMem) (void)hipFree(rb->deviceMem);
   if (rb->hostMem) (void)hipHostFree(rb->hostMem);
+  for (size_t i = 0; i < rb->replicaMem.size(); i++)
+    if (rb->replicaMem[i] && i + 1 < g_ctx.devs.size()) { (void)hipSetDevice(g_ctx.devs[i + 1].device); (void)hipFree(rb->replicaMem[i]); }
+  (void)hipSetDevice(g_ctx.device);
   delete rb;
 }
 void* giCGetRenderBufferMem(GiCRenderBuffer* rb) { return rb ? rb->hostMem : nullptr; }
@@ -794,6 +871,7 @@ int giCSetSceneOption(GiCScene* scene, int32_t option, int32_t value)
   if (option == GI_C_SCENE_OPTION_TRACE_DYNAMIC) { scene->optTraceDyn = value < 0 ? -1 : (value > 64 ? 64 : value); return GI_C_OK; }
   if (option == GI_C_SCENE_OPTION_FUSED_PATH) { scene->optFusedPath = value < 0 ? -1 : (value > 2 ? 1 : value); return GI_C_OK; }
   if (option == GI_C_SCENE_OPTION_SAMPLE_BUFFER_MB) { scene->optSampleBufferMb = value > 0 ? (uint64_t)value : 0; return GI_C_OK; }
+  if (option == GI_C_SCENE_OPTION_DEVICES) { scene->optDevices = value > 0 ? value : 0; scene->dirty |= DIRTY_BVH | DIRTY_FRAMEBUFFER; /* replicas are made with the build */ return GI_C_OK; }
   setError("unknown scene option"); return GI_C_ERROR;
 }
 
@@ -854,8 +932,9 @@ inline void xformPoint(const float a[12], const float p[3], float out[3])
 // Two-level layout (SceneView::tlasNodes ...): built next to the flat BVH for instanced scenes that do not fit LDS.  The flat
 // arrays stay (k_shade reads the hit's TriRec, k_aov / giCTraceRays traverse them); the two-level ones are what k_trace_dyn2 walks,
 // and they are small: one BLAS per MESH instead of one subtree per instance, so traversal stays in the caches.
+struct TwoLevelHost { std::vector<Node8> tlasNodes, blasNodes; std::vector<uint32_t> tlasItems; std::vector<BlasTri> blasTris; std::vector<InstTrav> instTrav; };
 template <class MB>
-int buildTwoLevel(GiCScene* s, const std::vector<MB>& meshBuilds, const std::vector<InstanceRec>& instances, size_t flatTris, size_t flatNodes)
+int buildTwoLevel(GiCScene* s, const std::vector<MB>& meshBuilds, const std::vector<InstanceRec>& instances, size_t flatTris, size_t flatNodes, TwoLevelHost& out)
 {
   s->twoLevel = false;
   int want = s->optTwoLevel;
@@ -908,22 +987,73 @@ int buildTwoLevel(GiCScene* s, const std::vector<MB>& meshBuilds, const std::vec
   buildBvh8Boxes(instBoxes.data(), instances.size(), tlas, tlasItems);
   // per-lane stack: a TLAS level can leave a node group and an instance group behind, a BLAS level a node group
   if (2u * tlas.maxDepth + blasDepth + 1u > 16u) { if (want > 0) fprintf(stderr, "[gatling_gi] two-level layout not used: trees too deep for the 16-entry stack\n"); return GI_C_OK; }
-  hipStream_t st = g_ctx.stream;
-  if (s->dTlasNodes.upload(tlas.nodes, st) || s->dTlasItems.upload(tlasItems, st) || s->dBlasNodes.upload(blasNodes, st) || s->dBlasTris.upload(blasTris, st) ||
-      s->dInstTrav.upload(instTrav, st))
-    return GI_C_ERROR;
-  HIP_TRY(hipStreamSynchronize(st));
   s->twoLevel = true;
   if (getenv("GATLING_BUILD_TIMING")) fprintf(stderr, "[gatling_gi] two-level: TLAS %zu nodes over %zu instances, %zu BLAS nodes, %zu mesh triangles (flat: %zu nodes, %zu triangles)\n",
                                               tlas.nodes.size(), instances.size(), blasNodes.size(), blasTris.size(), flatNodes, flatTris);
+  out.tlasNodes.swap(tlas.nodes); out.tlasItems.swap(tlasItems); out.blasNodes.swap(blasNodes); out.blasTris.swap(blasTris); out.instTrav.swap(instTrav);
   return GI_C_OK;
 }
+
+// The scene as host arrays (built once per scene change) ...
+struct SceneHost {
+  std::vector<FVertex> verts; std::vector<InstanceRec> instances; std::vector<MaterialRec> mats; std::vector<MeshRec> meshRecs; std::vector<float> sceneData;
+  Bvh8 bvh; std::vector<int32_t> triFaceId; std::vector<uint32_t> flatOfOrig; TwoLevelHost two; bool lineNodes = false;
+};
+
+// ... and its upload into one device's memory (the primary's and every replica's: multi-device renders replicate the scene)
+int uploadSceneTo(GiCScene* s, SceneDevice& D, const SceneHost& H)
+{
+  const DevCtx& ctx = g_ctx.devs[D.slot];
+  HIP_TRY(hipSetDevice(ctx.device));
+  hipStream_t st = ctx.stream;
+  if (s->twoLevel) {
+    if (D.dTlasNodes.upload(H.two.tlasNodes, st) || D.dTlasItems.upload(H.two.tlasItems, st) || D.dBlasNodes.upload(H.two.blasNodes, st) || D.dBlasTris.upload(H.two.blasTris, st) ||
+        D.dInstTrav.upload(H.two.instTrav, st) || D.dFlatOfOrig.upload(H.flatOfOrig, st))
+      return GI_C_ERROR;
+  }
+  if (D.dTriFaceId.upload(H.triFaceId, st)) return GI_C_ERROR;
+  if (D.dMeshes.upload(H.meshRecs, st) || D.dSceneData.upload(H.sceneData, st)) return GI_C_ERROR;
+  { // textures: one device array per image + the TextureRec table
+    for (auto* b : D.dTexels) { b->release(); delete b; }
+    D.dTexels.clear();
+    std::vector<TextureRec> recs(s->textures.size());
+    for (size_t i = 0; i < s->textures.size(); i++) {
+      auto* b = new DeviceBuffer<float>();
+      D.dTexels.push_back(b);
+      if (b->upload(s->textures[i]->rgba, st)) return GI_C_ERROR;
+      recs[i] = TextureRec{b->ptr, s->textures[i]->width, s->textures[i]->height};
+    }
+    if (D.dTextures.upload(recs, st)) return GI_C_ERROR;
+    HIP_TRY(hipStreamSynchronize(st)); // `recs` goes out of scope
+  }
+  std::vector<uint4> lined;
+  if (H.lineNodes) {
+    lined.assign(H.bvh.nodes.size() * 8, uint4{0u, 0u, 0u, 0u});
+    for (size_t i = 0; i < H.bvh.nodes.size(); i++) memcpy(&lined[i * 8], &H.bvh.nodes[i], sizeof(Node8));
+    if (D.dNodesLine.upload(lined, st)) return GI_C_ERROR;
+  }
+  if ((!H.lineNodes && D.dNodes.upload(H.bvh.nodes, st)) || D.dTris.upload(H.bvh.tris, st) || D.dInstances.upload(H.instances, st) ||
+      D.dVerts.upload(H.verts, st) || D.dMaterials.upload(H.mats, st))
+    return GI_C_ERROR;
+  HIP_TRY(hipStreamSynchronize(st)); // host vectors may go out of scope
+  return GI_C_OK;
+}
+
+// devices a render of this scene may use (replicas exist for slots 1 .. n-1 after buildScene)
+uint32_t sceneDeviceCount(const GiCScene* s)
+{
+  uint32_t n = (uint32_t)g_ctx.devs.size();
+  if (s->optDevices > 0) n = std::min<uint32_t>(n, (uint32_t)s->optDevices);
+  return std::max(n, 1u);
+}
+SceneDevice& sceneDevice(GiCScene* s, uint32_t slot) { return slot == 0u ? static_cast<SceneDevice&>(*s) : *s->replicas[slot - 1u]; }
 
 int buildScene(GiCScene* s)
 {
   double t0 = nowMs();
-  std::vector<FVertex> verts; std::vector<InstanceRec> instances; std::vector<TriRec> tris; std::vector<int32_t> faceIdOf;
-  std::vector<MaterialRec> mats(s->materials.size());
+  SceneHost H;
+  std::vector<FVertex>& verts = H.verts; std::vector<InstanceRec>& instances = H.instances; std::vector<TriRec> tris; std::vector<int32_t> faceIdOf;
+  std::vector<MaterialRec>& mats = H.mats; mats.resize(s->materials.size());
   for (size_t i = 0; i < s->materials.size(); i++) {
     mats[i].klass = s->materials[i]->desc.klass; mats[i].flags = s->materials[i]->desc.flags & ~(MAT_FLAG_TEXTURED | MAT_FLAG_OPACITY_TEX);
     for (uint32_t slot = 0; slot < TEX_SLOT_COUNT; slot++) {
@@ -950,7 +1080,7 @@ int buildScene(GiCScene* s)
   uint32_t meshIdx = 0;
   struct MeshBuild { const GiCMesh* m; uint32_t vertexOffset, matFlags, instFirst, instCount, triFirst; };
   std::vector<MeshBuild> meshBuilds; // visible meshes in scene order (two-level layout)
-  std::vector<MeshRec> meshRecs; std::vector<float> sceneData;
+  std::vector<MeshRec>& meshRecs = H.meshRecs; std::vector<float>& sceneData = H.sceneData;
   s->classMask = 0; s->hasCutouts = false; s->classTextured = 0;
   for (GiCMesh* m : s->meshes) {
     if (!m->visible) continue; // Gi.cpp:801-804
@@ -1032,52 +1162,31 @@ int buildScene(GiCScene* s)
     }
     meshIdx++;
   }
-  Bvh8 bvh;
+  Bvh8& bvh = H.bvh;
   buildBvh8(tris, bvh);
-  if (buildTwoLevel(s, meshBuilds, instances, tris.size(), bvh.nodes.size()) != GI_C_OK) return GI_C_ERROR;
+  { std::vector<TriRec>().swap(tris); } // the BVH holds its own (leaf-ordered) copy
+  if (buildTwoLevel(s, meshBuilds, instances, bvh.tris.size(), bvh.nodes.size(), H.two) != GI_C_OK) return GI_C_ERROR;
   if (s->twoLevel) {
-    std::vector<uint32_t> flatOfOrig(bvh.tris.size());
-    for (size_t i = 0; i < bvh.tris.size(); i++) flatOfOrig[bvh.tris[i].origId] = (uint32_t)i;
-    if (s->dFlatOfOrig.upload(flatOfOrig, g_ctx.stream)) return GI_C_ERROR;
-    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    H.flatOfOrig.resize(bvh.tris.size());
+    for (size_t i = 0; i < bvh.tris.size(); i++) H.flatOfOrig[bvh.tris[i].origId] = (uint32_t)i;
   }
   double t1 = nowMs();
   // the deepest traversal variant keeps 8 (SPILL8) or 16 stack entries in LDS and OVF_STACK = 40 in scratch; trav_node_pick does not bound-check the spill
   if (bvh.maxDepth > 1u + 8u + 40u) { setError("scene BVH is deeper than the traversal stack (49 levels): degenerate geometry (long chains of nested splits)"); return GI_C_ERROR; }
   if (bvh.tris.size() >= (1u << 26)) { setError("scene has 2^26 or more triangles after instancing: the traversal queues pack (lane, triangle) into 32 bits"); return GI_C_ERROR; }
-  hipStream_t st = g_ctx.stream;
-  std::vector<int32_t> triFaceId(bvh.tris.size());
-  for (size_t i = 0; i < bvh.tris.size(); i++) triFaceId[i] = faceIdOf[bvh.tris[i].origId];
-  if (s->dTriFaceId.upload(triFaceId, st)) return GI_C_ERROR;
-  if (s->dMeshes.upload(meshRecs, st) || s->dSceneData.upload(sceneData, st)) return GI_C_ERROR;
-  { // textures: one device array per image + the TextureRec table
-    for (auto* b : s->dTexels) { b->release(); delete b; }
-    s->dTexels.clear();
-    std::vector<TextureRec> recs(s->textures.size());
-    for (size_t i = 0; i < s->textures.size(); i++) {
-      auto* b = new DeviceBuffer<float>();
-      s->dTexels.push_back(b);
-      if (b->upload(s->textures[i]->rgba, st)) return GI_C_ERROR;
-      recs[i] = TextureRec{b->ptr, s->textures[i]->width, s->textures[i]->height};
-    }
-    if (s->dTextures.upload(recs, st)) return GI_C_ERROR;
-  }
+  H.triFaceId.resize(bvh.tris.size());
+  for (size_t i = 0; i < bvh.tris.size(); i++) H.triFaceId[i] = faceIdOf[bvh.tris[i].origId];
   // Optional layout: one node per 128-byte line (an 80-byte node at an 80-byte stride straddles two lines half of the time).
   // Measured on C3/C4 it is 1-3 % SLOWER than the packed layout (the footprint grows 1.6x and the L2 hit rate drops), so it
   // stays an experiment knob (GATLING_NODE_LINES=1).
-  bool lineNodes = false;
-  if (const char* e = getenv("GATLING_NODE_LINES")) lineNodes = atoi(e) != 0;
-  s->nodeStrideU4 = lineNodes ? 8u : 5u;
-  std::vector<uint4> lined;
-  if (lineNodes) {
-    lined.assign(bvh.nodes.size() * 8, uint4{0u, 0u, 0u, 0u});
-    for (size_t i = 0; i < bvh.nodes.size(); i++) memcpy(&lined[i * 8], &bvh.nodes[i], sizeof(Node8));
-    if (s->dNodesLine.upload(lined, st)) return GI_C_ERROR;
-  }
-  if ((!lineNodes && s->dNodes.upload(bvh.nodes, st)) || s->dTris.upload(bvh.tris, st) || s->dInstances.upload(instances, st) ||
-      s->dVerts.upload(verts, st) || s->dMaterials.upload(mats, st))
-    return GI_C_ERROR;
-  HIP_TRY(hipStreamSynchronize(st)); // host vectors go out of scope
+  if (const char* e = getenv("GATLING_NODE_LINES")) H.lineNodes = atoi(e) != 0;
+  s->nodeStrideU4 = H.lineNodes ? 8u : 5u;
+  // one copy of the scene per device this scene renders on
+  const uint32_t nDev = sceneDeviceCount(s);
+  while (s->replicas.size() + 1u < nDev) { s->replicas.emplace_back(new SceneDevice()); s->replicas.back()->slot = (uint32_t)s->replicas.size(); }
+  for (uint32_t d = 0; d < nDev; d++)
+    if (uploadSceneTo(s, sceneDevice(s, d), H) != GI_C_OK) { (void)hipSetDevice(g_ctx.device); return GI_C_ERROR; }
+  HIP_TRY(hipSetDevice(g_ctx.device));
   s->nodeCount = (uint32_t)bvh.nodes.size(); s->triCount = (uint32_t)bvh.tris.size(); s->bvhDepth = bvh.maxDepth > 1u ? bvh.maxDepth - 1u : 1u; // stack entries a walk can need: a pick at level L pushes the rest of level L-1's group (gi_traversal.h trav_node_pick), the root level pushes nothing
   s->stats.bvhBuildMs = t1 - t0; s->stats.uploadMs = nowMs() - t1;
   s->stats.nodeCount = s->nodeCount; s->stats.triangleCount = s->triCount;
@@ -1086,26 +1195,33 @@ int buildScene(GiCScene* s)
 
 int uploadLights(GiCScene* s)
 {
-  hipStream_t st = g_ctx.stream;
-  if (s->dSphere.upload(s->sphereLights.recs, st) || s->dDistant.upload(s->distantLights.recs, st) || s->dRect.upload(s->rectLights.recs, st) ||
-      s->dDisk.upload(s->diskLights.recs, st))
-    return GI_C_ERROR;
-  HIP_TRY(hipStreamSynchronize(st));
+  const uint32_t nDev = std::min<uint32_t>(sceneDeviceCount(s), (uint32_t)s->replicas.size() + 1u);
+  for (uint32_t d = 0; d < nDev; d++) {
+    SceneDevice& D = sceneDevice(s, d);
+    HIP_TRY(hipSetDevice(g_ctx.devs[d].device));
+    hipStream_t st = g_ctx.devs[d].stream;
+    if (D.dSphere.upload(s->sphereLights.recs, st) || D.dDistant.upload(s->distantLights.recs, st) || D.dRect.upload(s->rectLights.recs, st) ||
+        D.dDisk.upload(s->diskLights.recs, st))
+      return GI_C_ERROR;
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  HIP_TRY(hipSetDevice(g_ctx.device));
   return GI_C_OK;
 }
 
 bool settingsEqual(const GiCRenderSettings& a, const GiCRenderSettings& b) { return memcmp(&a, &b, sizeof(a)) == 0; }
 
-SceneView makeView(GiCScene* s)
+SceneView makeView(GiCScene* s, SceneDevice& D)
 {
   SceneView v{};
-  v.textures = s->dTextures.ptr; v.meshes = s->dMeshes.ptr; v.sceneData = s->dSceneData.ptr;
-  v.nodes = s->nodeStrideU4 == 8u ? reinterpret_cast<const Node8*>(s->dNodesLine.ptr) : s->dNodes.ptr; v.nodeStrideU4 = s->nodeStrideU4; v.tris = s->dTris.ptr; v.instances = s->dInstances.ptr;
-  v.verts = s->dVerts.ptr; v.materials = s->dMaterials.ptr; v.sphereLights = s->dSphere.ptr; v.distantLights = s->dDistant.ptr;
-  v.tlasNodes = s->dTlasNodes.ptr; v.tlasItems = s->dTlasItems.ptr; v.blasNodes = s->dBlasNodes.ptr; v.blasTris = s->dBlasTris.ptr; v.instTrav = s->dInstTrav.ptr; v.flatOfOrig = s->dFlatOfOrig.ptr; v.twoLevel = s->twoLevel ? 1u : 0u;
-  v.rectLights = s->dRect.ptr; v.diskLights = s->dDisk.ptr; v.triFaceId = s->dTriFaceId.ptr; v.nodeCount = s->nodeCount; v.triCount = s->triCount; v.bvhDepth = s->bvhDepth; v.hasCutouts = s->hasCutouts ? 1u : 0u;
+  v.textures = D.dTextures.ptr; v.meshes = D.dMeshes.ptr; v.sceneData = D.dSceneData.ptr;
+  v.nodes = s->nodeStrideU4 == 8u ? reinterpret_cast<const Node8*>(D.dNodesLine.ptr) : D.dNodes.ptr; v.nodeStrideU4 = s->nodeStrideU4; v.tris = D.dTris.ptr; v.instances = D.dInstances.ptr;
+  v.verts = D.dVerts.ptr; v.materials = D.dMaterials.ptr; v.sphereLights = D.dSphere.ptr; v.distantLights = D.dDistant.ptr;
+  v.tlasNodes = D.dTlasNodes.ptr; v.tlasItems = D.dTlasItems.ptr; v.blasNodes = D.dBlasNodes.ptr; v.blasTris = D.dBlasTris.ptr; v.instTrav = D.dInstTrav.ptr; v.flatOfOrig = D.dFlatOfOrig.ptr; v.twoLevel = s->twoLevel ? 1u : 0u;
+  v.rectLights = D.dRect.ptr; v.diskLights = D.dDisk.ptr; v.triFaceId = D.dTriFaceId.ptr; v.nodeCount = s->nodeCount; v.triCount = s->triCount; v.bvhDepth = s->bvhDepth; v.hasCutouts = s->hasCutouts ? 1u : 0u;
   return v;
 }
+SceneView makeView(GiCScene* s) { return makeView(s, *s); }
 
 // k_trace_dyn refill threshold for scenes that do not fit LDS (0 = use the block-synchronous k_trace)
 static uint32_t traceDynRefill(const GiCScene* s)
@@ -1131,7 +1247,7 @@ uint32_t shardCapacity(size_t slots, uint32_t gridA, uint32_t gridB)
   return (uint32_t)std::min<size_t>(cap, slots + 256); // a shard can never hold more than the pool
 }
 
-int ensurePathState(GiCScene* s, size_t slots, uint32_t gridA, uint32_t gridB)
+int ensurePathState(SceneDevice* s, size_t slots, uint32_t gridA, uint32_t gridB)
 {
   const uint32_t cap = shardCapacity(slots, gridA, gridB);
   if (s->slots.alloc(slots)) return GI_C_ERROR;
@@ -1150,7 +1266,7 @@ int ensurePathState(GiCScene* s, size_t slots, uint32_t gridA, uint32_t gridB)
   return GI_C_OK;
 }
 
-QueueSet makeQueueSet(GiCScene* s)
+QueueSet makeQueueSet(SceneDevice* s)
 {
   QueueSet qs{};
   for (uint32_t q = 0; q < Q_COUNT; q++) { qs.slot[q] = s->qSlot[q].ptr; qs.a[q] = s->qA[q].ptr; qs.b[q] = s->qB[q].ptr; qs.c[q] = s->qC[q].ptr; }
@@ -1158,7 +1274,7 @@ QueueSet makeQueueSet(GiCScene* s)
   return qs;
 }
 
-hipEvent_t poolEvent(GiCScene* s, size_t idx)
+hipEvent_t poolEvent(SceneDevice* s, size_t idx)
 {
   while (s->eventPool.size() <= idx) { hipEvent_t e; (void)hipEventCreate(&e); s->eventPool.push_back(e); }
   return s->eventPool[idx];
@@ -1176,51 +1292,24 @@ extern "C" int giCRender(const GiCRenderParams* params)
   try { return giCRenderImpl(params); }
   catch (const std::exception& e) { setError(std::string("giCRender: ") + e.what()); return GI_C_ERROR; }
 }
-static int giCRenderImpl(const GiCRenderParams* params)
+// One device's part of a render: the rows rowBegin, rowBegin + rowStride, ... < rowEnd of the frame, on device D.slot with D's copy of the scene.  Called
+// under the scene mutex, after the dirty handling; with several devices, once per device from its own host thread (the bounce loop polls the queue sizes).
+struct RenderJob { const GiCRenderParams* params; const GiCAovBinding* colorBinding; uint32_t width, height, rowBegin, rowEnd, rowStride, tileRows; uint8_t clear[GI_C_MAX_AOV_COMP_SIZE]; bool readback; };
+
+static void* rbMem(GiCRenderBuffer* rb, uint32_t slot) { return (slot == 0u || rb->scratch) ? rb->deviceMem : rb->replicaMem[slot - 1u]; }
+
+static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
 {
-  if (!g_ctx.initialized) { setError("giCRender before giCInitialize"); return GI_C_ERROR; }
-  if (!params || !params->scene) { setError("giCRender: null params/scene"); return GI_C_ERROR; }
-  GiCScene* s = params->scene;
+  const DevCtx& ctx = g_ctx.devs[D.slot];
+  HIP_TRY(hipSetDevice(ctx.device));
+  hipStream_t st = ctx.stream;
+  const GiCRenderParams* params = job.params;
   const GiCRenderSettings& rs = params->renderSettings;
-  const GiCAovBinding* colorBinding = nullptr;
-  for (uint32_t i = 0; i < params->aovBindingCount; i++) {
-    if (!params->aovBindings[i].renderBuffer) { setError("giCRender: AOV binding without render buffer"); return GI_C_ERROR; }
-    if (params->aovBindings[i].aovId == GI_C_AOV_COLOR) colorBinding = &params->aovBindings[i];
-  }
-  if (params->aovBindingCount == 0) { setError("giCRender: no AOV bindings"); return GI_C_ERROR; }
-  if (rs.spp == 0) { setError("giCRender: spp must be > 0"); return GI_C_ERROR; }
-  if (rs.mediumStackSize > MAX_MEDIUM_STACK) { setError("giCRender: mediumStackSize > 8 is not supported"); return GI_C_ERROR; }
-  const GiCRenderBuffer* sizeRb = (colorBinding ? colorBinding : &params->aovBindings[0])->renderBuffer;
-  const uint32_t width = sizeRb->width, height = sizeRb->height;
-  if (width == 0 || height == 0) return GI_C_OK; // Render.Empty-style degenerate target: nothing to do
-  if (width > 65535u || height > 65535u) { setError("giCRender: image dimensions exceed 65535 (imageDims packing, rp_main.h:38)"); return GI_C_ERROR; }
-  uint32_t rowBegin = params->rowBegin, rowEnd = params->rowEnd ? params->rowEnd : height;
-  const uint32_t rowStride = params->rowStride ? params->rowStride : 1u;
-  if (rowBegin > rowEnd || rowEnd > height) { setError("giCRender: bad row range"); return GI_C_ERROR; }
-  const uint32_t tileRows = rowEnd > rowBegin ? (rowEnd - rowBegin + rowStride - 1u) / rowStride : 0u; // rows rowBegin + k * rowStride < rowEnd
-
-  std::lock_guard<std::mutex> guard(s->mutex);
-  hipStream_t st = g_ctx.stream;
-  HIP_TRY(hipSetDevice(g_ctx.device));
-
-  // --- dirty handling (_CalcDirtyFlagsForRenderParams, Gi.cpp:1859-1987; sample offset reset :2125-2129)
-  uint8_t clear[GI_C_MAX_AOV_COMP_SIZE] = {0};
-  if (colorBinding) memcpy(clear, colorBinding->clearValue, GI_C_MAX_AOV_COMP_SIZE);
-  const float* domeEm = params->domeLight ? params->domeLight->baseEmission : nullptr;
-  if (!s->haveOldParams || memcmp(&s->oldCamera, &params->camera, sizeof(GiCCameraDesc)) != 0 || !settingsEqual(s->oldSettings, rs) ||
-      memcmp(s->oldClear, clear, sizeof(clear)) != 0 || s->oldRowBegin != rowBegin || s->oldRowEnd != rowEnd || s->oldRowStride != rowStride || s->oldDome != params->domeLight ||
-      (domeEm && memcmp(domeEm, s->oldDomeEmission, 12) != 0))
-    s->dirty |= DIRTY_FRAMEBUFFER;
-  s->haveOldParams = true; s->oldCamera = params->camera; s->oldSettings = rs; memcpy(s->oldClear, clear, sizeof(clear));
-  s->oldRowBegin = rowBegin; s->oldRowEnd = rowEnd; s->oldRowStride = rowStride; s->oldDome = params->domeLight;
-  if (domeEm) memcpy(s->oldDomeEmission, domeEm, 12);
-
-  s->stats.bvhBuildMs = 0.0; s->stats.uploadMs = 0.0;
-  if (s->dirty & (DIRTY_BVH | DIRTY_MATERIALS)) { if (buildScene(s) != GI_C_OK) return GI_C_ERROR; s->dirty &= ~(DIRTY_BVH | DIRTY_MATERIALS); s->dirty |= DIRTY_FRAMEBUFFER; }
-  if (s->dirty & DIRTY_LIGHTS) { if (uploadLights(s) != GI_C_OK) return GI_C_ERROR; s->dirty &= ~DIRTY_LIGHTS; s->dirty |= DIRTY_FRAMEBUFFER; }
-  if (!rs.progressiveAccumulation) s->dirty |= DIRTY_FRAMEBUFFER;
-  if (s->dirty & DIRTY_FRAMEBUFFER) { s->sampleOffset = 0; s->dirty &= ~DIRTY_FRAMEBUFFER; }
-
+  const GiCAovBinding* colorBinding = job.colorBinding;
+  const uint32_t width = job.width, height = job.height, rowBegin = job.rowBegin, rowEnd = job.rowEnd, rowStride = job.rowStride, tileRows = job.tileRows;
+  const uint8_t* clear = job.clear;
+  (void)height; (void)rowEnd;
+  D.stats.bvhBuildMs = s->stats.bvhBuildMs; D.stats.uploadMs = s->stats.uploadMs;
   // --- non-colour AOV bindings (Gi.h:36-56).  NEE, Bounces and ClockCycles follow whole paths: they are filled by the colour pass
   // (clear value first), see PathState.  ClockCycles is a deterministic cost proxy (ray segments per pixel), heat-mapped like the reference.
   AovTargets aovT{}; bool anyAov = false;
@@ -1234,7 +1323,7 @@ static int giCRenderImpl(const GiCRenderParams* params)
     if (b.aovId < 0 || b.aovId >= GI_C_AOV_COUNT) { setError("giCRender: bad AOV id"); return GI_C_ERROR; }
     memcpy(aovT.clear[b.aovId], b.clearValue, 16);
     const bool vec = rb->stride == 16;
-    F4* v4 = vec ? reinterpret_cast<F4*>(rb->deviceMem) : nullptr;
+    F4* v4 = vec ? reinterpret_cast<F4*>(rbMem(rb, D.slot)) : nullptr;
     bool produced = true;
     switch (b.aovId) {
       case GI_C_AOV_NORMAL: aovT.normal = v4; break; case GI_C_AOV_BARYCENTRICS: aovT.barycentrics = v4; break;
@@ -1242,10 +1331,10 @@ static int giCRenderImpl(const GiCRenderParams* params)
       case GI_C_AOV_TANGENTS: aovT.tangents = v4; break; case GI_C_AOV_BITANGENTS: aovT.bitangents = v4; break;
       case GI_C_AOV_THIN_WALLED: aovT.thinWalled = v4; break; case GI_C_AOV_DOUBLE_SIDED: aovT.doubleSided = v4; break;
       case GI_C_AOV_ALBEDO: aovT.albedo = v4; break;
-      case GI_C_AOV_DEPTH: aovT.depth = vec ? nullptr : reinterpret_cast<float*>(rb->deviceMem); break;
-      case GI_C_AOV_OBJECT_ID: aovT.objectId = vec ? nullptr : reinterpret_cast<int32_t*>(rb->deviceMem); break;
-      case GI_C_AOV_FACE_ID: aovT.faceId = vec ? nullptr : reinterpret_cast<int32_t*>(rb->deviceMem); break;
-      case GI_C_AOV_INSTANCE_ID: aovT.instanceId = vec ? nullptr : reinterpret_cast<int32_t*>(rb->deviceMem); break;
+      case GI_C_AOV_DEPTH: aovT.depth = vec ? nullptr : reinterpret_cast<float*>(rbMem(rb, D.slot)); break;
+      case GI_C_AOV_OBJECT_ID: aovT.objectId = vec ? nullptr : reinterpret_cast<int32_t*>(rbMem(rb, D.slot)); break;
+      case GI_C_AOV_FACE_ID: aovT.faceId = vec ? nullptr : reinterpret_cast<int32_t*>(rbMem(rb, D.slot)); break;
+      case GI_C_AOV_INSTANCE_ID: aovT.instanceId = vec ? nullptr : reinterpret_cast<int32_t*>(rbMem(rb, D.slot)); break;
       case GI_C_AOV_NEE: if (vec) neeRb = rb; produced = false; break;
       case GI_C_AOV_BOUNCES: if (vec) bouncesRb = rb; produced = false; break;
       case GI_C_AOV_CLOCK_CYCLES: if (vec) clockRb = rb; produced = false; break;
@@ -1255,19 +1344,17 @@ static int giCRenderImpl(const GiCRenderParams* params)
       const bool wantsVec = !(b.aovId == GI_C_AOV_DEPTH || b.aovId == GI_C_AOV_OBJECT_ID || b.aovId == GI_C_AOV_FACE_ID || b.aovId == GI_C_AOV_INSTANCE_ID);
       if (wantsVec != vec) { setError("giCRender: AOV render buffer format does not match the AOV (Gi.cpp:302-316)"); return GI_C_ERROR; }
       anyAov = true; aovBuffers.push_back(rb);
-    } else { // fill with the clear value on the host
-      size_t n = (size_t)rb->width * rb->height;
-      for (size_t k = 0; k < n; k++) memcpy((uint8_t*)rb->hostMem + k * rb->stride, b.clearValue, rb->stride);
-      HIP_TRY(hipMemcpyAsync(rb->deviceMem, rb->hostMem, rb->size, hipMemcpyHostToDevice, st));
+    } else { // clear value everywhere (the host copy was filled by fillClearValues before the device threads started)
+      HIP_TRY(hipMemcpyAsync(rbMem(rb, D.slot), rb->hostMem, rb->size, hipMemcpyHostToDevice, st));
     }
   }
   if (!colorBinding && !anyAov && !neeRb && !bouncesRb && !clockRb) { HIP_TRY(hipStreamSynchronize(st)); return GI_C_OK; }
   GiCRenderBuffer dummyColor{};
   GiCRenderBuffer* colorRb = colorBinding ? colorBinding->renderBuffer : nullptr;
   if (!colorRb && (neeRb || bouncesRb || clockRb)) { // the path-following debug AOVs need the colour pass: render it into a scratch buffer
-    if (s->scratchColor.alloc((size_t)width * height)) return GI_C_ERROR;
+    if (D.scratchColor.alloc((size_t)width * height)) return GI_C_ERROR;
     dummyColor.width = width; dummyColor.height = height; dummyColor.stride = 16; dummyColor.size = (size_t)width * height * 16;
-    dummyColor.deviceMem = s->scratchColor.ptr; dummyColor.deviceOnly = true;
+    dummyColor.deviceMem = D.scratchColor.ptr; dummyColor.deviceOnly = true; dummyColor.scratch = true;
     colorRb = &dummyColor;
   }
   if (colorRb && colorRb->stride != 16) { setError("giCRender: colour AOV needs a Float32Vec4 buffer"); return GI_C_ERROR; }
@@ -1278,8 +1365,8 @@ static int giCRenderImpl(const GiCRenderParams* params)
   // device -> host copy of the tile's rows (one 2D copy: the rows are rowStride image rows apart)
   auto copyTileRows = [&](GiCRenderBuffer* rb, size_t texel) -> hipError_t {
     const size_t off = (size_t)rowBegin * width * texel, rowBytes = (size_t)width * texel, pitch = rowBytes * rowStride;
-    if (rowStride == 1u) return hipMemcpyAsync((uint8_t*)rb->hostMem + off, (uint8_t*)rb->deviceMem + off, rowBytes * tileRows, hipMemcpyDeviceToHost, st);
-    return hipMemcpy2DAsync((uint8_t*)rb->hostMem + off, pitch, (uint8_t*)rb->deviceMem + off, pitch, rowBytes, tileRows, hipMemcpyDeviceToHost, st);
+    if (rowStride == 1u) return hipMemcpyAsync((uint8_t*)rb->hostMem + off, (uint8_t*)rbMem(rb, D.slot) + off, rowBytes * tileRows, hipMemcpyDeviceToHost, st);
+    return hipMemcpy2DAsync((uint8_t*)rb->hostMem + off, pitch, (uint8_t*)rbMem(rb, D.slot) + off, pitch, rowBytes, tileRows, hipMemcpyDeviceToHost, st);
   };
   if (pixels == 0) return GI_C_OK;
   FrameUniforms U{};
@@ -1331,7 +1418,7 @@ static int giCRenderImpl(const GiCRenderParams* params)
   std::vector<int> evKind; // 0 raygen, 1 trace, 2 shade, 3 shadow
   const bool timers = s->kernelTimers;
   uint64_t sampledIters = 0, totalIters = 0;
-  SceneView view = makeView(s);
+  SceneView view = makeView(s, D);
   { // dome light (Gi.cpp:2201-2238, 2384-2396): an image-less dome light is ignored, like one whose file failed to load
     const GiCDomeLight* dl = params->domeLight;
     auto tit = (dl && dl->texture) ? std::find(s->textures.begin(), s->textures.end(), dl->texture) : s->textures.end();
@@ -1341,7 +1428,7 @@ static int giCRenderImpl(const GiCRenderParams* params)
     for (int a = 0; a < 3; a++) { view.domeEmission[a] = dl ? dl->baseEmission[a] : 1.0f; view.background[a] = U.background[a]; view.cameraPosition[a] = params->camera.position[a]; }
     view.frame = rs.frame;
   }
-  if (ensurePathState(s, 1, 1, 1) != GI_C_OK) return GI_C_ERROR; // counters / pinned mirror exist even for AOV-only renders
+  if (ensurePathState(&D, 1, 1, 1) != GI_C_OK) return GI_C_ERROR; // counters / pinned mirror exist even for AOV-only renders
   if (colorRb) {
     // --- work decomposition (DESIGN.md "Persistent path pool"): work item = (pixel, sample); the frame is cut into batches of
     // consecutive samples whose per-sample colour buffer fits the budget; a pool of `slots` paths is kept full from a running
@@ -1368,7 +1455,7 @@ static int giCRenderImpl(const GiCRenderParams* params)
     // persistent grids: blocks per CU limited by registers (<= 6 waves/SIMD for k_trace) and, for k_trace, by the LDS it stages
     uint32_t wideBlocks, traceBlocks;
     {
-      SceneView v0 = makeView(s);
+      SceneView v0 = makeView(s, D);
       uint32_t ln, lt, ldsBytes; traceLdsLayout(v0, ln, lt, ldsBytes);
       uint32_t perCu = std::min<uint32_t>(6u, (160u * 1024u) / (ldsBytes + traceStaticLdsBytes() + 256u));
       const bool allLds = ln == v0.nodeCount && lt == v0.triCount && v0.triCount > 0u;
@@ -1377,28 +1464,28 @@ static int giCRenderImpl(const GiCRenderParams* params)
       uint32_t widePerCu = 8u;
       if (const char* e = getenv("GATLING_WIDE_BLOCKS_PER_CU")) widePerCu = (uint32_t)atoi(e);
       perCu = std::max(perCu, 1u); widePerCu = std::max(widePerCu, 1u);
-      wideBlocks = (uint32_t)std::min<size_t>((slots + 255) / 256, (size_t)g_ctx.cuCount * widePerCu);
-      traceBlocks = (uint32_t)std::min<size_t>((slots + 255) / 256, (size_t)g_ctx.cuCount * perCu);
+      wideBlocks = (uint32_t)std::min<size_t>((slots + 255) / 256, (size_t)ctx.cuCount * widePerCu);
+      traceBlocks = (uint32_t)std::min<size_t>((slots + 255) / 256, (size_t)ctx.cuCount * perCu);
     }
-    if (ensurePathState(s, slots, wideBlocks, traceBlocks) != GI_C_OK) return GI_C_ERROR;
-    if (s->sampleBuf.alloc(pixels * batchSamples) || s->accum.alloc(pixels)) return GI_C_ERROR;
+    if (ensurePathState(&D, slots, wideBlocks, traceBlocks) != GI_C_OK) return GI_C_ERROR;
+    if (D.sampleBuf.alloc(pixels * batchSamples) || D.accum.alloc(pixels)) return GI_C_ERROR;
     const uint32_t mediaStride = rs.mediumStackSize ? rs.mediumStackSize * MEDIUM_FLOATS + 4u : 0u;
-    if (mediaStride && s->media.alloc(slots * mediaStride)) return GI_C_ERROR;
-    PathState ps{s->slots.ptr, s->media.ptr, mediaStride, nullptr, 0u, nullptr};
+    if (mediaStride && D.media.alloc(slots * mediaStride)) return GI_C_ERROR;
+    PathState ps{D.slots.ptr, D.media.ptr, mediaStride, nullptr, 0u, nullptr};
     if (neeRb && rs.nextEventEstimation) { // the reference compiles the NEE AOV write out with NEXT_EVENT_ESTIMATION (rp_main.rgen:397, 431)
-      if (s->neeKey.alloc(pixels)) return GI_C_ERROR;
-      HIP_TRY(hipMemsetAsync(s->neeKey.ptr, 0, pixels * sizeof(unsigned long long), st));
-      ps.neeKey = s->neeKey.ptr;
+      if (D.neeKey.alloc(pixels)) return GI_C_ERROR;
+      HIP_TRY(hipMemsetAsync(D.neeKey.ptr, 0, pixels * sizeof(unsigned long long), st));
+      ps.neeKey = D.neeKey.ptr;
     }
-    if (bouncesRb) ps.bouncesAov = reinterpret_cast<F4*>(bouncesRb->deviceMem);
+    if (bouncesRb) ps.bouncesAov = reinterpret_cast<F4*>(rbMem(bouncesRb, D.slot));
     if (clockRb) {
-      if (s->pathSegments.alloc(pixels)) return GI_C_ERROR;
-      HIP_TRY(hipMemsetAsync(s->pathSegments.ptr, 0, pixels * sizeof(uint32_t), st));
-      ps.pathSegments = s->pathSegments.ptr;
+      if (D.pathSegments.alloc(pixels)) return GI_C_ERROR;
+      HIP_TRY(hipMemsetAsync(D.pathSegments.ptr, 0, pixels * sizeof(uint32_t), st));
+      ps.pathSegments = D.pathSegments.ptr;
     }
     view.mediumStackSize = rs.mediumStackSize;
-    QueueSet qs = makeQueueSet(s);
-    F4* colorOut = reinterpret_cast<F4*>(colorRb->deviceMem);
+    QueueSet qs = makeQueueSet(&D);
+    F4* colorOut = reinterpret_cast<F4*>(rbMem(colorRb, D.slot));
     const bool nee = rs.nextEventEstimation != 0;
     const uint32_t dynRefill = traceDynRefill(s);
 
@@ -1410,7 +1497,7 @@ static int giCRenderImpl(const GiCRenderParams* params)
     const uint32_t timerStride = std::max(1u, s->kernelTimerStride);
     uint64_t curIter = 0;
     auto timed = [&](int kind, auto&& fn) {
-      if (timers && (curIter % timerStride) == 0u) { (void)hipEventRecord(poolEvent(s, ev), st); fn(); (void)hipEventRecord(poolEvent(s, ev + 1), st); ev += 2; evKind.push_back(kind); }
+      if (timers && (curIter % timerStride) == 0u) { (void)hipEventRecord(poolEvent(&D, ev), st); fn(); (void)hipEventRecord(poolEvent(&D, ev + 1), st); ev += 2; evKind.push_back(kind); }
       else fn();
     };
     const uint32_t pollEvery = 16;
@@ -1421,29 +1508,29 @@ static int giCRenderImpl(const GiCRenderParams* params)
       ps.neeSampleBase = U.batchFirstSample;
       const uint32_t poolNow = (uint32_t)std::min<uint64_t>(slots, U.workTotal);
       U.poolSlots = poolNow;
-      launchInit(st, ps, qs, s->dCounters.ptr, fused ? 0u : poolNow, batch == 0);
+      launchInit(st, ps, qs, D.dCounters.ptr, fused ? 0u : poolNow, batch == 0);
       if (fused && U.maxBounces != 0u) {
         // work items are claimed in chunks of consecutive ids; small frames get small chunks so that every resident wave finds work
         uint32_t chunk = 2048u;
         if (const char* e = getenv("GATLING_PATH_CHUNK")) chunk = (uint32_t)std::max(64, atoi(e));
-        const uint64_t waves = (uint64_t)g_ctx.cuCount * 16u;
+        const uint64_t waves = (uint64_t)ctx.cuCount * 16u;
         // (a wave's last chunk is the launch's tail: 16 claims per wave keep it at ~6 % of a small frame -- C1 5 895 -> 6 360 Msamples/s; C2 does not care, 256 ... 2048 measure the same)
         chunk = (uint32_t)std::min<uint64_t>(chunk, std::max<uint64_t>(64u, ((uint64_t)U.workTotal / (waves * 16u)) & ~63ull));
         curIter = totalIters; if (timers) sampledIters++;
-        if (timers) { (void)hipEventRecord(poolEvent(s, ev), st); }
+        if (timers) { (void)hipEventRecord(poolEvent(&D, ev), st); }
         static const int envBw = getenv("GATLING_PATH_BW") ? atoi(getenv("GATLING_PATH_BW")) : 1;
-        if (envBw && !nee && s->optFusedPath != 2) launchPathBw(st, (uint32_t)g_ctx.cuCount, s->classMask, s->classTextured != 0u, s->countTraversal, chunk, U, view, ps, s->dCounters.ptr, s->sampleBuf.ptr);
-        else launchPath(st, (uint32_t)g_ctx.cuCount, s->classMask, s->classTextured != 0u, s->countTraversal, chunk, U, view, ps, s->dCounters.ptr, s->sampleBuf.ptr);
-        if (timers) { (void)hipEventRecord(poolEvent(s, ev + 1), st); ev += 2; evKind.push_back(1); }
+        if (envBw && !nee && s->optFusedPath != 2) launchPathBw(st, (uint32_t)ctx.cuCount, s->classMask, s->classTextured != 0u, s->countTraversal, chunk, U, view, ps, D.dCounters.ptr, D.sampleBuf.ptr);
+        else launchPath(st, (uint32_t)ctx.cuCount, s->classMask, s->classTextured != 0u, s->countTraversal, chunk, U, view, ps, D.dCounters.ptr, D.sampleBuf.ptr);
+        if (timers) { (void)hipEventRecord(poolEvent(&D, ev + 1), st); ev += 2; evKind.push_back(1); }
         iters++; totalIters++; traceLaunches++;
-        launchAccumulate(st, U, s->sampleBuf.ptr, s->accum.ptr, colorOut, batch == 0, batch + 1 == numBatches);
+        launchAccumulate(st, U, D.sampleBuf.ptr, D.accum.ptr, colorOut, batch == 0, batch + 1 == numBatches);
         continue;
       }
       if (U.maxBounces == 0u) {
         // rp_main.rgen:298-304: the bounce loop's exit test comes first, so with max-bounces 0 no ray is traced at all and every sample is
         // black (no emission at the primary hit, no dome / background term); the accumulation still runs (progressive blend, alpha 1)
-        HIP_TRY(hipMemsetAsync(s->sampleBuf.ptr, 0, pixels * U.batchSamples * sizeof(F4), st));
-        launchAccumulate(st, U, s->sampleBuf.ptr, s->accum.ptr, colorOut, batch == 0, batch + 1 == numBatches);
+        HIP_TRY(hipMemsetAsync(D.sampleBuf.ptr, 0, pixels * U.batchSamples * sizeof(F4), st));
+        launchAccumulate(st, U, D.sampleBuf.ptr, D.accum.ptr, colorOut, batch == 0, batch + 1 == numBatches);
         continue;
       }
       const uint64_t rounds = ((uint64_t)U.workTotal + poolNow - 1) / poolNow; // raygen rounds needed to hand out all work
@@ -1451,26 +1538,26 @@ static int giCRenderImpl(const GiCRenderParams* params)
       for (uint64_t it = 0; it < maxIters; it++) {
         const uint32_t par = (uint32_t)(it & 1u);
         curIter = totalIters; if (timers && (totalIters % timerStride) == 0u) sampledIters++;
-        timed(0, [&] { launchRaygen(st, wideBlocks, U, ps, qs, s->dCounters.ptr, par, s->sampleBuf.ptr); });
+        timed(0, [&] { launchRaygen(st, wideBlocks, U, ps, qs, D.dCounters.ptr, par, D.sampleBuf.ptr); });
         if (it >= rounds && (it % pollEvery) == 0u) { // all work cannot be handed out earlier; afterwards poll the queue sizes
-          HIP_TRY(hipMemcpyAsync(s->hCounters, s->dCounters.ptr, sizeof(PaddedCounter) * Q_COUNT * NSHARD, hipMemcpyDeviceToHost, st));
+          HIP_TRY(hipMemcpyAsync(D.hCounters, D.dCounters.ptr, sizeof(PaddedCounter) * Q_COUNT * NSHARD, hipMemcpyDeviceToHost, st));
           HIP_TRY(hipStreamSynchronize(st));
-          uint32_t pending = 0; for (uint32_t k = 0; k < NSHARD; k++) pending += s->hCounters->count[Q_TRACE_A + par][k].v;
+          uint32_t pending = 0; for (uint32_t k = 0; k < NSHARD; k++) pending += D.hCounters->count[Q_TRACE_A + par][k].v;
           if (pending == 0) { totalIters++; break; } // raygen consumed the regen queue and produced no rays: the pool has drained
         }
-        timed(1, [&] { launchTrace(st, traceBlocks, false, s->countTraversal, view, ps, qs, s->dCounters.ptr, Q_TRACE_A + par, Q_REGEN_A + (par ^ 1u), dynRefill, wideBlocks); });
+        timed(1, [&] { launchTrace(st, traceBlocks, false, s->countTraversal, view, ps, qs, D.dCounters.ptr, Q_TRACE_A + par, Q_REGEN_A + (par ^ 1u), dynRefill, wideBlocks); });
         traceLaunches++;
         for (uint32_t klass = 0; klass < MAT_CLASS_COUNT; klass++)
-          if (s->classMask & (1u << klass)) timed(2, [&] { launchShade(st, wideBlocks, klass, (s->classTextured & (1u << klass)) != 0u, rs.mediumStackSize != 0u, U, view, ps, qs, s->dCounters.ptr, par); });
-        if (nee) timed(3, [&] { launchTrace(st, traceBlocks, true, s->countTraversal, view, ps, qs, s->dCounters.ptr, Q_SHADOW, Q_SHADOW, dynRefill, wideBlocks); });
+          if (s->classMask & (1u << klass)) timed(2, [&] { launchShade(st, wideBlocks, klass, (s->classTextured & (1u << klass)) != 0u, rs.mediumStackSize != 0u, U, view, ps, qs, D.dCounters.ptr, par); });
+        if (nee) timed(3, [&] { launchTrace(st, traceBlocks, true, s->countTraversal, view, ps, qs, D.dCounters.ptr, Q_SHADOW, Q_SHADOW, dynRefill, wideBlocks); });
         iters++; totalIters++;
       }
-      launchAccumulate(st, U, s->sampleBuf.ptr, s->accum.ptr, colorOut, batch == 0, batch + 1 == numBatches);
+      launchAccumulate(st, U, D.sampleBuf.ptr, D.accum.ptr, colorOut, batch == 0, batch + 1 == numBatches);
     }
-    if (neeRb && ps.neeKey) launchResolveNee(st, U, s->neeKey.ptr, reinterpret_cast<F4*>(neeRb->deviceMem), (uint32_t)pixels);
+    if (neeRb && ps.neeKey) launchResolveNee(st, U, D.neeKey.ptr, reinterpret_cast<F4*>(rbMem(neeRb, D.slot)), (uint32_t)pixels);
     if (clockRb) { // ClockCycles: per-pixel cost -> heat map normalised to the frame maximum, on the host like _EncodeRenderBufferAsHeatmap (Gi.cpp:327-343)
       std::vector<uint32_t> counts(pixels);
-      HIP_TRY(hipMemcpyAsync(counts.data(), s->pathSegments.ptr, pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(counts.data(), D.pathSegments.ptr, pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
       float maxValue = 0.0f;
       for (uint32_t c : counts) maxValue = std::max(maxValue, (float)c);
@@ -1484,15 +1571,15 @@ static int giCRenderImpl(const GiCRenderParams* params)
           o[3] = 255.0f;
         } else { o[0] = (float)counts[p]; o[1] = 0.0f; o[2] = 0.0f; }
       }
-      HIP_TRY(hipMemcpyAsync(clockRb->deviceMem, clockRb->hostMem, clockRb->size, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(rbMem(clockRb, D.slot), clockRb->hostMem, clockRb->size, hipMemcpyHostToDevice, st));
     }
     if (bouncesRb && U.maxBounces == 0u) { // rp_main.rgen:483-486 evaluates inferno(0 / 0) = NaN for every pixel of the tile
       float* img = reinterpret_cast<float*>(bouncesRb->hostMem);
       for (size_t p = 0; p < pixels; p++) { float* o = img + ((rowBegin + (p / width) * rowStride) * width + p % width) * 4; o[0] = o[1] = o[2] = NAN; }
-      HIP_TRY(hipMemcpyAsync(bouncesRb->deviceMem, bouncesRb->hostMem, bouncesRb->size, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(rbMem(bouncesRb, D.slot), bouncesRb->hostMem, bouncesRb->size, hipMemcpyHostToDevice, st));
     }
     for (GiCRenderBuffer* rb : {neeRb, bouncesRb}) {
-      if (!rb || rb->deviceOnly) continue;
+      if (!rb || rb->deviceOnly || !job.readback) continue;
       HIP_TRY(copyTileRows(rb, rb->stride));
     }
   }
@@ -1500,33 +1587,166 @@ static int giCRenderImpl(const GiCRenderParams* params)
     launchAov(st, U, view, aovT);
     if (hipGetLastError() != hipSuccess) { setError("k_aov launch failed"); return GI_C_ERROR; }
     for (GiCRenderBuffer* rb : aovBuffers) {
-      if (rb->deviceOnly) continue;
+      if (rb->deviceOnly || !job.readback) continue;
       HIP_TRY(copyTileRows(rb, rb->stride));
     }
   }
-  HIP_TRY(hipMemcpyAsync(s->hCounters, s->dCounters.ptr, sizeof(Counters), hipMemcpyDeviceToHost, st));
-  if (colorRb && !colorRb->deviceOnly) {
+  HIP_TRY(hipMemcpyAsync(D.hCounters, D.dCounters.ptr, sizeof(Counters), hipMemcpyDeviceToHost, st));
+  if (colorRb && !colorRb->deviceOnly && job.readback) {
     HIP_TRY(copyTileRows(colorRb, 16));
   }
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
   double tEnd = nowMs();
 
-  GiCRenderStats& S = s->stats;
+  GiCRenderStats& S = D.stats;
   S.renderMs = tEnd - tStart; S.samples = (uint64_t)pixels * rs.spp; S.iterations = iters; S.traceLaunches = traceLaunches; S.fusedPath = usedFused ? 1u : 0u;
-  S.segments = s->hCounters->segments; S.shadowRays = s->hCounters->shadowRays; S.nodesVisited = s->hCounters->nodesVisited; S.trisTested = s->hCounters->trisTested;
-  S.shadowNodesVisited = s->hCounters->shadowNodesVisited; S.shadowTrisTested = s->hCounters->shadowTrisTested;
-  if (s->hCounters->overflow) { setError("giCRender: a work-queue shard overflowed its capacity (internal sizing error); the image is invalid"); return GI_C_ERROR; }
+  S.segments = D.hCounters->segments; S.shadowRays = D.hCounters->shadowRays; S.nodesVisited = D.hCounters->nodesVisited; S.trisTested = D.hCounters->trisTested;
+  S.shadowNodesVisited = D.hCounters->shadowNodesVisited; S.shadowTrisTested = D.hCounters->shadowTrisTested;
+  if (D.hCounters->overflow) { setError("giCRender: a work-queue shard overflowed its capacity (internal sizing error); the image is invalid"); return GI_C_ERROR; }
   S.traceMs = S.shadeMs = S.raygenMs = S.shadowMs = 0.0;
   if (timers) {
     for (size_t k = 0; k < evKind.size(); k++) {
-      float ms = 0.0f; (void)hipEventElapsedTime(&ms, s->eventPool[2 * k], s->eventPool[2 * k + 1]);
+      float ms = 0.0f; (void)hipEventElapsedTime(&ms, D.eventPool[2 * k], D.eventPool[2 * k + 1]);
       if (evKind[k] == 0) S.raygenMs += ms; else if (evKind[k] == 1) S.traceMs += ms; else if (evKind[k] == 2) S.shadeMs += ms; else S.shadowMs += ms;
     }
     // scale the sampled totals to the whole frame (the early-exit poll can leave one raygen-only iteration unsampled)
     const double scale = sampledIters ? (double)totalIters / (double)sampledIters : 1.0;
     S.raygenMs *= scale; S.traceMs *= scale; S.shadeMs *= scale; S.shadowMs *= scale;
   }
+  return GI_C_OK;
+}
+
+// The frame on nDev devices: rows d, d + nDev, ... on device d (interleaved shares cost the same), every device from its own host thread;
+// then the shares of devices 1 .. n-1 are copied INTO PLACE in the primary device's render buffers (strided 2-D peer copies over xGMI: no staging buffer, no
+// re-interleave pass) and the primary does the one D2H.  Per-pixel arithmetic does not depend on which device renders a row (RNG streams use the global
+// pixel index), so the image is bit-identical to a one-device render.
+static int renderOnDevices(GiCScene* s, uint32_t nDev, const RenderJob& frame)
+{
+  const GiCRenderParams* params = frame.params;
+  // per-device copies of every bound render buffer
+  for (uint32_t i = 0; i < params->aovBindingCount; i++) {
+    GiCRenderBuffer* rb = params->aovBindings[i].renderBuffer;
+    if (rb->replicaMem.size() + 1u < g_ctx.devs.size()) rb->replicaMem.resize(g_ctx.devs.size() - 1u, nullptr);
+    for (uint32_t d = 1; d < nDev; d++) {
+      if (rb->replicaMem[d - 1u]) continue;
+      HIP_TRY(hipSetDevice(g_ctx.devs[d].device));
+      HIP_TRY(hipMalloc(&rb->replicaMem[d - 1u], rb->size ? rb->size : 16));
+      HIP_TRY(hipMemset(rb->replicaMem[d - 1u], 0, rb->size ? rb->size : 16));
+    }
+  }
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  std::vector<int> rcs(nDev, GI_C_OK); std::vector<std::string> errs(nDev);
+  auto work = [&](uint32_t d) {
+    RenderJob job = frame;
+    job.rowBegin = d; job.rowEnd = frame.height; job.rowStride = nDev; job.tileRows = (frame.height - d + nDev - 1u) / nDev; job.readback = false;
+    try { rcs[d] = renderOnDevice(s, sceneDevice(s, d), job); }
+    catch (const std::exception& e) { rcs[d] = GI_C_ERROR; t_lastError = e.what(); }
+    if (rcs[d] != GI_C_OK) errs[d] = t_lastError; // (thread-local)
+  };
+  std::vector<std::thread> threads;
+  for (uint32_t d = 1; d < nDev; d++) threads.emplace_back(work, d);
+  work(0u);
+  for (std::thread& t : threads) t.join();
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  for (uint32_t d = 0; d < nDev; d++) if (rcs[d] != GI_C_OK) { setError("device " + std::to_string(g_ctx.devs[d].device) + ": " + errs[d]); return GI_C_ERROR; }
+  // gather: rows d::nDev of device d -> the same rows of the primary's buffer, then the D2H of the whole frame
+  hipStream_t st = g_ctx.stream;
+  for (uint32_t i = 0; i < params->aovBindingCount; i++) {
+    GiCRenderBuffer* rb = params->aovBindings[i].renderBuffer;
+    const size_t rowBytes = (size_t)rb->width * rb->stride, pitch = rowBytes * nDev;
+    for (uint32_t d = 1; d < nDev; d++) {
+      const uint32_t rows = (rb->height - d + nDev - 1u) / nDev;
+      const size_t off = (size_t)d * rowBytes;
+      HIP_TRY(hipMemcpy2DAsync((uint8_t*)rb->deviceMem + off, pitch, (uint8_t*)rb->replicaMem[d - 1u] + off, pitch, rowBytes, rows, hipMemcpyDefault, st));
+    }
+    if (!rb->deviceOnly) HIP_TRY(hipMemcpyAsync(rb->hostMem, rb->deviceMem, rb->size, hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  // statistics: counts add up, times are the slowest device's
+  GiCRenderStats S = s->stats; // (device 0's, written by its renderOnDevice)
+  for (uint32_t d = 1; d < nDev; d++) {
+    const GiCRenderStats& R = sceneDevice(s, d).stats;
+    S.samples += R.samples; S.segments += R.segments; S.shadowRays += R.shadowRays; S.nodesVisited += R.nodesVisited; S.trisTested += R.trisTested;
+    S.shadowNodesVisited += R.shadowNodesVisited; S.shadowTrisTested += R.shadowTrisTested;
+    S.renderMs = std::max(S.renderMs, R.renderMs); S.traceMs = std::max(S.traceMs, R.traceMs); S.shadeMs = std::max(S.shadeMs, R.shadeMs);
+    S.raygenMs = std::max(S.raygenMs, R.raygenMs); S.shadowMs = std::max(S.shadowMs, R.shadowMs); S.iterations = std::max(S.iterations, R.iterations);
+    S.traceLaunches = std::max(S.traceLaunches, R.traceLaunches);
+  }
+  s->stats = S;
+  return GI_C_OK;
+}
+
+static int giCRenderImpl(const GiCRenderParams* params)
+{
+  if (!g_ctx.initialized) { setError("giCRender before giCInitialize"); return GI_C_ERROR; }
+  if (!params || !params->scene) { setError("giCRender: null params/scene"); return GI_C_ERROR; }
+  GiCScene* s = params->scene;
+  const GiCRenderSettings& rs = params->renderSettings;
+  const GiCAovBinding* colorBinding = nullptr;
+  for (uint32_t i = 0; i < params->aovBindingCount; i++) {
+    if (!params->aovBindings[i].renderBuffer) { setError("giCRender: AOV binding without render buffer"); return GI_C_ERROR; }
+    if (params->aovBindings[i].aovId == GI_C_AOV_COLOR) colorBinding = &params->aovBindings[i];
+  }
+  if (params->aovBindingCount == 0) { setError("giCRender: no AOV bindings"); return GI_C_ERROR; }
+  if (rs.spp == 0) { setError("giCRender: spp must be > 0"); return GI_C_ERROR; }
+  if (rs.mediumStackSize > MAX_MEDIUM_STACK) { setError("giCRender: mediumStackSize > 8 is not supported"); return GI_C_ERROR; }
+  const GiCRenderBuffer* sizeRb = (colorBinding ? colorBinding : &params->aovBindings[0])->renderBuffer;
+  const uint32_t width = sizeRb->width, height = sizeRb->height;
+  if (width == 0 || height == 0) return GI_C_OK; // Render.Empty-style degenerate target: nothing to do
+  if (width > 65535u || height > 65535u) { setError("giCRender: image dimensions exceed 65535 (imageDims packing, rp_main.h:38)"); return GI_C_ERROR; }
+  uint32_t rowBegin = params->rowBegin, rowEnd = params->rowEnd ? params->rowEnd : height;
+  const uint32_t rowStride = params->rowStride ? params->rowStride : 1u;
+  if (rowBegin > rowEnd || rowEnd > height) { setError("giCRender: bad row range"); return GI_C_ERROR; }
+  const uint32_t tileRows = rowEnd > rowBegin ? (rowEnd - rowBegin + rowStride - 1u) / rowStride : 0u; // rows rowBegin + k * rowStride < rowEnd
+
+  std::lock_guard<std::mutex> guard(s->mutex);
+  HIP_TRY(hipSetDevice(g_ctx.device));
+
+  // --- dirty handling (_CalcDirtyFlagsForRenderParams, Gi.cpp:1859-1987; sample offset reset :2125-2129)
+  uint8_t clear[GI_C_MAX_AOV_COMP_SIZE] = {0};
+  if (colorBinding) memcpy(clear, colorBinding->clearValue, GI_C_MAX_AOV_COMP_SIZE);
+  const float* domeEm = params->domeLight ? params->domeLight->baseEmission : nullptr;
+  if (!s->haveOldParams || memcmp(&s->oldCamera, &params->camera, sizeof(GiCCameraDesc)) != 0 || !settingsEqual(s->oldSettings, rs) ||
+      memcmp(s->oldClear, clear, sizeof(clear)) != 0 || s->oldRowBegin != rowBegin || s->oldRowEnd != rowEnd || s->oldRowStride != rowStride || s->oldDome != params->domeLight ||
+      (domeEm && memcmp(domeEm, s->oldDomeEmission, 12) != 0))
+    s->dirty |= DIRTY_FRAMEBUFFER;
+  s->haveOldParams = true; s->oldCamera = params->camera; s->oldSettings = rs; memcpy(s->oldClear, clear, sizeof(clear));
+  s->oldRowBegin = rowBegin; s->oldRowEnd = rowEnd; s->oldRowStride = rowStride; s->oldDome = params->domeLight;
+  if (domeEm) memcpy(s->oldDomeEmission, domeEm, 12);
+
+  s->stats.bvhBuildMs = 0.0; s->stats.uploadMs = 0.0; s->stats.nodeCount = s->nodeCount; s->stats.triangleCount = s->triCount;
+  if (s->dirty & (DIRTY_BVH | DIRTY_MATERIALS)) { if (buildScene(s) != GI_C_OK) return GI_C_ERROR; s->dirty &= ~(DIRTY_BVH | DIRTY_MATERIALS); s->dirty |= DIRTY_FRAMEBUFFER; }
+  if (s->dirty & DIRTY_LIGHTS) { if (uploadLights(s) != GI_C_OK) return GI_C_ERROR; s->dirty &= ~DIRTY_LIGHTS; s->dirty |= DIRTY_FRAMEBUFFER; }
+  if (!rs.progressiveAccumulation) s->dirty |= DIRTY_FRAMEBUFFER;
+  if (s->dirty & DIRTY_FRAMEBUFFER) { s->sampleOffset = 0; s->dirty &= ~DIRTY_FRAMEBUFFER; }
+
+
+  RenderJob job{params, colorBinding, width, height, rowBegin, rowEnd, rowStride, tileRows, {0}, true};
+  memcpy(job.clear, clear, sizeof(job.clear));
+  // AOVs the colour pass fills along whole paths (NEE, Bounces, ClockCycles) and unknown ids start from their clear value: host copy filled once, here
+  bool wantsClock = false;
+  for (uint32_t i = 0; i < params->aovBindingCount; i++) {
+    const GiCAovBinding& b = params->aovBindings[i];
+    GiCRenderBuffer* rb = b.renderBuffer;
+    const bool pathAov = b.aovId == GI_C_AOV_NEE || b.aovId == GI_C_AOV_BOUNCES || b.aovId == GI_C_AOV_CLOCK_CYCLES || b.aovId < 0 || b.aovId >= GI_C_AOV_COUNT;
+    if (b.aovId == GI_C_AOV_CLOCK_CYCLES) wantsClock = true;
+    if (b.aovId == GI_C_AOV_COLOR || !pathAov) continue;
+    const size_t n = (size_t)rb->width * rb->height;
+    for (size_t k = 0; k < n; k++) memcpy((uint8_t*)rb->hostMem + k * rb->stride, b.clearValue, rb->stride);
+  }
+  // --- one device, or the rows dealt to all of them
+  // Multi-device: a whole-frame render (the caller does not shard rows itself) with at least as many rows as devices.  ClockCycles is normalised to the
+  // frame maximum on the host (Gi.cpp:327-343), a cross-device reduction nobody needs fast: such renders stay on the primary device.
+  uint32_t nDev = std::min<uint32_t>(sceneDeviceCount(s), (uint32_t)s->replicas.size() + 1u);
+  if (rowStride != 1u || rowBegin != 0u || rowEnd != height || wantsClock || height < nDev) nDev = 1u;
+  int rc = GI_C_OK;
+  if (nDev == 1u) {
+    rc = renderOnDevice(s, *s, job);
+  } else {
+    rc = renderOnDevices(s, nDev, job);
+  }
+  if (rc != GI_C_OK) return rc;
   s->sampleOffset += rs.spp; // Gi.cpp:2515
   return GI_C_OK;
 }

@@ -254,7 +254,7 @@ struct WaveStage { uint4 buf[64 * 5]; };
 // block cost two resident blocks per CU and the extra LDS round trip outweighs the saved tag look-ups) -> off.
 constexpr bool TRACE_DYN_COOP_FETCH = false;
 #ifndef GI_TRI_FULL_LOAD
-#define GI_TRI_FULL_LOAD 1
+#define GI_TRI_FULL_LOAD 0 // measured (r03a, C3): loading all 48 bytes up front is SLOWER -- shadow rays 44.4 -> 50.2 ms, closest hit 131 -> 134-141 ms: the vector-memory request path, not the dependent round trip, is what the batch waits for
 #endif
 #ifndef GI_WAVE_STEP_SCAN_APPEND
 #define GI_WAVE_STEP_SCAN_APPEND 1

@@ -280,6 +280,14 @@ typedef struct GiCRenderStats {
  * CgpuVk.cpp:892-909).  One giCInitialize per process, like the reference's global state (Gi.cpp:244-259). */
 int giCInitialize(int deviceOrdinal);
 void giCTerminate(void);
+/* [ext] Multi-device form (north_star: "pixels/samples shard across the 8 GPUs of one node, scene replicated, tiles gathered"; the reference picks ONE
+ * device, CgpuVk.cpp:892-909).  The first ordinal is the primary device: render buffers, textures and the single-device entry points live there.  Every
+ * giCRender of a whole frame then deals the image rows round-robin to the devices (row r to device r mod N, scene replicated at build time, one host
+ * thread per device), and the shares are copied into the primary device's render buffer over xGMI (strided peer copies straight into place) before the
+ * one D2H -- the image is bit-identical to a one-device render.  giCInitialize does the same when $GATLING_DEVICES ("0,1,2,3" or "all") is set, which is
+ * how an unmodified caller (hdGatling) gets every GPU of the node.  Renders that shard rows themselves (rowStride > 1 / a row range) stay on the primary. */
+int giCInitializeDevices(const int32_t* deviceOrdinals, uint32_t count);
+uint32_t giCGetDeviceCount(void);
 /* [ext] last error message of the calling thread's most recent failing call ("" if none) */
 const char* giCGetLastError(void);
 
@@ -379,6 +387,8 @@ int giCGetRenderStats(const GiCScene* scene, GiCRenderStats* out);
  * lane in registers); 2 = k_path in both cases; 0 = run the wavefront stage kernels on them too.
  * The image does not depend on it. */
 #define GI_C_SCENE_OPTION_FUSED_PATH 7
+/* [ext] upper bound on the devices a giCRender of this scene uses (0 = all the library was initialised on; 1 = primary only). */
+#define GI_C_SCENE_OPTION_DEVICES 8
 int giCSetSceneOption(GiCScene* scene, int32_t option, int32_t value);
 /* [ext] closest hit of one ray through the device traversal kernel (parity tests of the BVH8 path).
  * Returns 1 on hit (t,u,v, instance, prim written), 0 on miss, <0 on error. */

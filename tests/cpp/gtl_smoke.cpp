@@ -85,7 +85,9 @@ int main()
   if (!(grn > 1.05 * red)) { fprintf(stderr, "displayColor primvar not applied (r=%f g=%f)\n", red, grn); return 7; }
   if (c && bluish < 5) { fprintf(stderr, "image-driven diffuseColor not applied (bluish pixels: %d)\n", bluish); return 9; }
   (void)blu;
-  printf("gtl_smoke ok sum=%.6f lit=%d bluish=%d\n", sum, lit, bluish);
+  unsigned long long hash = 1469598103934665603ull; // FNV-1a over the image bytes: equal hashes <=> bit-identical images (multi-device test)
+  for (size_t i = 0; i < (size_t)32 * 18 * 16; i++) { hash ^= ((const unsigned char*)px)[i]; hash *= 1099511628211ull; }
+  printf("gtl_smoke ok sum=%.6f lit=%d bluish=%d hash=%016llx\n", sum, lit, bluish, hash);
   giDestroyMesh(a); giDestroyMesh(b); if (c) giDestroyMesh(c);
   giDestroyMaterial(floorMat); giDestroyMaterial(lampMat); if (texMat) giDestroyMaterial(texMat);
   giDestroyRenderBuffer(rb); giDestroyScene(scene); giTerminate();

@@ -18,6 +18,10 @@ calib)  # VALU issue-rate calibration (tools/valu_calib.hip) + what the SQ count
   cp profiles/${TAG}_valu_issue_calibration.txt profiles/valu_issue_calibration.json $O/ 2>/dev/null
   cat $O/${TAG}_valu_calib_report.txt | cut -c1-200
   ;;
+ta)  # vector-memory request-path calibration (tools/ta_calib.hip): per-lane record fetches per ns and CU, by pattern and working set
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/ta_calib tools/ta_calib.hip 2>/dev/null
+  timeout 600 /tmp/ta_calib > $O/${TAG}_ta_calib.txt 2>&1; cut -c1-230 $O/${TAG}_ta_calib.txt
+  ;;
 tests)
   GATLING_BUILD_TIMING=1 timeout 1500 python -m pytest tests -x -q -m gpu > $O/${TAG}_pytest_gpu.log 2>&1; tail -5 $O/${TAG}_pytest_gpu.log
   python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
@@ -25,10 +29,10 @@ tests)
 variants)  # A/B of prebuilt library variants (tools/build_variant.py) on the stage timers, per workload
   for V in $VARIANTS; do
     L=""; [ $V != default ] && L=$GRAFT_REPO_ROOT/gatling_amd/variants/libgatling_gi_$V.so
-    for WS in ${VARIANT_WORKLOADS:-"c3:32 c4:32 c5:8 c2:128"}; do
+    for WS in ${VARIANT_WORKLOADS:-c3:32 c4:32 c5:8 c2:128}; do
       W=${WS%%:*}; S=${WS##*:}
       echo "== $V $W spp $S" | tee -a $O/${TAG}_variants.txt
-      GATLING_GI_LIB=$L timeout 600 python tools/gpu_variants.py $W $S ${VARIANT_ENVS:-"-"} 2>&1 | grep -v "^\[gatling_gi\]" | tee -a $O/${TAG}_variants.txt
+      GATLING_GI_LIB=$L timeout 600 python tools/gpu_variants.py $W $S ${VARIANT_ENVS:--} 2>&1 | grep -v "^\[gatling_gi\]" | tee -a $O/${TAG}_variants.txt
     done
   done
   ;;
@@ -46,7 +50,7 @@ benchall)
     timeout 900 python bench.py --workload $W $SP --steps 2 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench_$W.log 2>&1; echo "== $W"; tail -1 $O/${TAG}_bench_$W.log | python -c "$J"; done
   ;;
 prof)  # rocprofv3 --kernel-trace --stats of the bench command, per workload -> profiles/<tag>_<w>_rocprofv3_summary.*
-  for WS in ${PROF_WORKLOADS:-"c2:1024 c3:256 c4:256"}; do W=${WS%%:*}; S=${WS##*:}
+  for WS in ${PROF_WORKLOADS:-c2:1024 c3:256 c4:256}; do W=${WS%%:*}; S=${WS##*:}
     (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof/${TAG}_kt_$W -o $W -- python $GRAFT_REPO_ROOT/bench.py --workload $W --spp $S --steps 1 --warmup 1 --no-timers --no-cpu-baseline --no-pmc > $O/${TAG}_prof_kt_$W.log 2>&1)
     DB=$(find $O/prof/${TAG}_kt_$W -name "*_results.db" | head -1)
     python tools/summarize_profile.py --kernel-trace $DB --tag ${TAG}_$W --workload $W --spp $S > $O/${TAG}_summary_$W.txt 2>&1; head -14 $O/${TAG}_summary_$W.txt | cut -c1-160
@@ -54,7 +58,7 @@ prof)  # rocprofv3 --kernel-trace --stats of the bench command, per workload -> 
   done
   ;;
 order)  # ray order vs traversal time where the BVH misses the caches
-  for M in ${ORDER_MODES:-"instances interior"}; do
+  for M in ${ORDER_MODES:-instances interior}; do
     (cd /tmp && timeout 900 rocprofv3 --kernel-trace -d $O/prof/${TAG}_order_kt_$M -o t -- python $GRAFT_REPO_ROOT/tools/exp_ray_order.py $M > $O/${TAG}_order_$M.log 2>&1)
     (cd /tmp && timeout 900 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $O/prof/${TAG}_order_pmc_$M -o t -- python $GRAFT_REPO_ROOT/tools/exp_ray_order.py $M > $O/${TAG}_order_pmc_$M.log 2>&1)
     KT=$(find $O/prof/${TAG}_order_kt_$M -name "*_results.db" | head -1); PM=$(find $O/prof/${TAG}_order_pmc_$M -name "*_results.db" | head -1)

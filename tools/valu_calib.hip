@@ -24,9 +24,10 @@
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-enum Op : int { OP_FMA = 0, OP_PK_FMA, OP_CVT_UBYTE, OP_MOV, OP_ADD_U32, OP_FMA_DEP, OP_MIX_FMA_CVT, OP_MAX3, OP_COUNT };
+enum Op : int { OP_FMA = 0, OP_PK_FMA, OP_CVT_UBYTE, OP_MOV, OP_ADD_U32, OP_FMA_DEP, OP_MIX_FMA_CVT, OP_MAX3, OP_MIX_FMA_MAX3, OP_MIX_FMA_MOV, OP_MIX_FMA_ADDU, OP_MIX_CVT_ADDU, OP_MIX_PKFMA_CVT2, OP_COUNT };
 static const char* kOpName[OP_COUNT] = {"v_fma_f32", "v_pk_fma_f32", "v_cvt_f32_ubyte0", "v_mov_b32", "v_add_u32", "v_fma_f32 (dependent chain)",
-                                        "v_cvt_f32_ubyte0 + v_fma_f32 (1:1)", "v_max3_f32"};
+                                        "v_cvt_f32_ubyte0 + v_fma_f32 (1:1)", "v_max3_f32", "v_fma_f32 + v_max3_f32 (1:1)", "v_fma_f32 + v_mov_b32 (1:1)",
+                                        "v_fma_f32 + v_add_u32 (1:1)", "v_cvt_f32_ubyte0 + v_add_u32 (1:1)", "v_pk_fma_f32 + 2 v_cvt_f32_ubyte0 (node test)"};
 
 #define X8(S) S S S S S S S S
 
@@ -71,6 +72,26 @@ __global__ __launch_bounds__(256) void k_valu(uint32_t reps, float seed, unsigne
                       "v_cvt_f32_ubyte0 %4, %10\n v_fma_f32 %5, %5, %12, %13\n v_cvt_f32_ubyte0 %6, %11\n v_fma_f32 %7, %7, %12, %13\n")
                    : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
                    : "v"(u0), "v"(u1), "v"(u2), "v"(u3), "v"(m), "v"(c));
+    } else if (OP == OP_MIX_FMA_MAX3) {
+      asm volatile(X8("v_fma_f32 %0, %0, %8, %9\n v_max3_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_max3_f32 %3, %3, %8, %9\n"
+                      "v_fma_f32 %4, %4, %8, %9\n v_max3_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_max3_f32 %7, %7, %8, %9\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c));
+    } else if (OP == OP_MIX_FMA_MOV) {
+      asm volatile(X8("v_fma_f32 %0, %0, %8, %9\n v_mov_b32 %1, %10\n v_fma_f32 %2, %2, %8, %9\n v_mov_b32 %3, %11\n"
+                      "v_fma_f32 %4, %4, %8, %9\n v_mov_b32 %5, %10\n v_fma_f32 %6, %6, %8, %9\n v_mov_b32 %7, %11\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c), "v"(u0), "v"(u1));
+    } else if (OP == OP_MIX_FMA_ADDU) {
+      asm volatile(X8("v_fma_f32 %0, %0, %8, %9\n v_add_u32 %4, %4, %10\n v_fma_f32 %1, %1, %8, %9\n v_add_u32 %5, %5, %10\n"
+                      "v_fma_f32 %2, %2, %8, %9\n v_add_u32 %6, %6, %10\n v_fma_f32 %3, %3, %8, %9\n v_add_u32 %7, %7, %10\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(m), "v"(c), "v"(r));
+    } else if (OP == OP_MIX_CVT_ADDU) {
+      asm volatile(X8("v_cvt_f32_ubyte0 %0, %8\n v_add_u32 %4, %4, %10\n v_cvt_f32_ubyte0 %1, %9\n v_add_u32 %5, %5, %10\n"
+                      "v_cvt_f32_ubyte0 %2, %8\n v_add_u32 %6, %6, %10\n v_cvt_f32_ubyte0 %3, %9\n v_add_u32 %7, %7, %10\n")
+                   : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(u0), "v"(u1), "v"(r));
+    } else if (OP == OP_MIX_PKFMA_CVT2) { // the node test's inner pattern: two byte conversions feed one packed fma (12 instructions per group of 4 planes)
+      asm volatile(X8("v_cvt_f32_ubyte0 %4, %8\n v_cvt_f32_ubyte1 %5, %8\n v_pk_fma_f32 %0, %0, %10, %11\n v_cvt_f32_ubyte2 %6, %8\n v_cvt_f32_ubyte3 %7, %8\n v_pk_fma_f32 %1, %1, %10, %11\n"
+                      "v_cvt_f32_ubyte0 %4, %9\n v_cvt_f32_ubyte1 %5, %9\n v_pk_fma_f32 %2, %2, %10, %11\n v_cvt_f32_ubyte2 %6, %9\n v_cvt_f32_ubyte3 %7, %9\n v_pk_fma_f32 %3, %3, %10, %11\n")
+                   : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(u0), "v"(u1), "v"(pm), "v"(pa));
     } else if (OP == OP_MAX3) {
       asm volatile(X8("v_max3_f32 %0, %0, %8, %9\n v_max3_f32 %1, %1, %8, %9\n v_max3_f32 %2, %2, %8, %9\n v_max3_f32 %3, %3, %8, %9\n"
                       "v_max3_f32 %4, %4, %8, %9\n v_max3_f32 %5, %5, %8, %9\n v_max3_f32 %6, %6, %8, %9\n v_max3_f32 %7, %7, %8, %9\n")
@@ -104,7 +125,7 @@ static void run(int cus, int W, uint32_t reps, unsigned long long* dCycles, uint
   CHECK(hipMemcpy(cyc.data(), dCycles, waves * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   CHECK(hipMemcpy(hw.data(), dHw, waves * sizeof(uint32_t), hipMemcpyDeviceToHost));
   std::sort(cyc.begin(), cyc.end());
-  const double instrPerWave = (double)reps * 64.0, med = (double)cyc[waves / 2], mx = (double)cyc[waves - 1];
+  const double instrPerWave = (double)reps * (OP == OP_MIX_PKFMA_CVT2 ? 96.0 : 64.0), med = (double)cyc[waves / 2], mx = (double)cyc[waves - 1];
   // placement check: waves per (se, cu, simd) -- HW_ID: wave_id[3:0] simd_id[5:4] pipe[7:6] cu_id[11:8] sh[12] se_id[15:13] ... (gfx9 layout; xcc is not in HW_ID,
   // so distinct (se, sh, cu, simd) tuples are counted per XCD-agnostic key and the maximum share is reported instead of asserted)
   std::vector<uint32_t> keys(waves);
@@ -144,6 +165,11 @@ int main(int argc, char** argv)
     run<OP_ADD_U32>(cus, W, reps, dCycles, dHw, dSink, false);
     run<OP_MIX_FMA_CVT>(cus, W, reps, dCycles, dHw, dSink, false);
     run<OP_MAX3>(cus, W, reps, dCycles, dHw, dSink, false);
+    run<OP_MIX_FMA_MAX3>(cus, W, reps, dCycles, dHw, dSink, false);
+    run<OP_MIX_FMA_MOV>(cus, W, reps, dCycles, dHw, dSink, false);
+    run<OP_MIX_FMA_ADDU>(cus, W, reps, dCycles, dHw, dSink, false);
+    run<OP_MIX_CVT_ADDU>(cus, W, reps, dCycles, dHw, dSink, false);
+    run<OP_MIX_PKFMA_CVT2>(cus, W, reps, dCycles, dHw, dSink, false);
     if (W == 1) run<OP_FMA_DEP>(cus, W, reps / 4u, dCycles, dHw, dSink, false);
   }
   CHECK(hipFree(dCycles)); CHECK(hipFree(dHw)); CHECK(hipFree(dSink));

@@ -54,7 +54,11 @@ def main():
                      f"{r['implied_clock_GHz_at_that_rate']:12.4f} {int(r['max_waves_sharing_hw_key']):21d}")
     # the constant: plain fp32 VALU at 8 waves/SIMD (issue-saturated)
     sat = {r["op"]: r["cycles_per_instr_per_simd"] for r in rows if int(r["waves_per_simd"]) == 8}
+    rate = {r["op"]: r["wall_instr_per_simd_per_ns"] for r in rows if int(r["waves_per_simd"]) == 8}
     out = {"tag": a.tag, "device": dev, "rows": rows,
+           # wall-clock ceilings at 8 waves/SIMD (the shader clock sags under a full-chip VALU load, so cycles x 2.4 GHz is not a rate): wave64 instructions per SIMD and ns
+           "instr_per_simd_per_ns_fp32": rate.get("v_fma_f32"), "instr_per_simd_per_ns_int": rate.get("v_add_u32"),
+           "instr_per_simd_per_ns_mixed": rate.get("v_cvt_f32_ubyte0 + v_fma_f32 (1:1)"), "instr_per_simd_per_ns_node_test": rate.get("v_pk_fma_f32 + 2 v_cvt_f32_ubyte0 (node test)"),
            "cycles_per_wave64_valu": sat.get("v_fma_f32"), "cycles_per_wave64_pk_fma": sat.get("v_pk_fma_f32"),
            "cycles_per_wave64_cvt_ubyte": sat.get("v_cvt_f32_ubyte0"), "cycles_per_wave64_mov": sat.get("v_mov_b32"),
            "source": f"profiles/{a.tag}_valu_issue_calibration.txt"}
@@ -73,7 +77,7 @@ def main():
             op, w = names[i] if names and i < len(names) else ("?", 0)
             waves = p.get("SQ_WAVES", 0.0)
             reps = 2000 // 4 if "dependent" in op else 2000
-            expected = waves * reps * 64
+            expected = waves * reps * (96 if "node test" in op else 64)
             insts, act = p.get("SQ_INSTS_VALU", 0.0), p.get("SQ_ACTIVE_INST_VALU", 0.0)
             lines.append(f"{op:38s} {w:10d} {insts:16.0f} {expected:16.0f} {act:20.0f} {(act / insts if insts else 0):13.4f} {p.get('SQ_BUSY_CYCLES', 0.0):16.0f} {p.get('SQ_WAVE_CYCLES', 0.0):16.0f}")
             pm.append({"op": op, "waves_per_simd": w, **{k: v for k, v in p.items() if k != "kernel"}, "expected_valu_insts": expected})
