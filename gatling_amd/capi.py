@@ -190,7 +190,9 @@ def _settings(rs: RenderSettings) -> GiCRenderSettings:
 class Scene:
     """Feeds a :class:`SceneDesc` through the gi C ABI the way hdGatling feeds Hydra prims through Gi.h."""
 
-    def __init__(self, desc: SceneDesc, device: int = 0):
+    def __init__(self, desc: SceneDesc, device: int = 0, mtlx_materials=None):
+        """`mtlx_materials`: {material index: MaterialX document string} -- those materials are created through the gtl shim's MaterialX reader
+        (gtl::giCreateMaterialFromMtlxStr, what hdGatling calls) instead of giCCreateMaterial with the parameter block."""
         self.L = initialize(device)
         L = self.L
         self.desc = desc
@@ -205,7 +207,15 @@ class Scene:
             if not h:
                 raise GiError("giCCreateTexture failed: " + L.giCGetLastError().decode())
             self.textures.append(h)
-        for m in desc.materials:
+        for mi, m in enumerate(desc.materials):
+            if mtlx_materials and mi in mtlx_materials:
+                L.gtlCreateMaterialFromMtlxStrC.restype = C.c_void_p
+                L.gtlCreateMaterialFromMtlxStrC.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+                h = L.gtlCreateMaterialFromMtlxStrC(self.handle, m.name.encode(), mtlx_materials[mi].encode())
+                if not h:
+                    raise GiError("gtl::giCreateMaterialFromMtlxStr refused the document of material %d" % mi)
+                self.materials.append(h)
+                continue
             md = GiCMaterialDesc(m.klass, 0, (C.c_float * P_COUNT)(*np.asarray(m.params, np.float32)))
             h = L.giCCreateMaterial(self.handle, m.name.encode(), C.byref(md))
             if not h:

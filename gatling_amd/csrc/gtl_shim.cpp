@@ -283,6 +283,27 @@ namespace gtl
     return makeMaterial(scene, name, d, primvars, images);
   }
 
+  // [ext] C-linkage doors to the two material routes above, for harnesses that cannot call C++ (ctypes: tests/test_mtlx_parity.py drives the SAME reader
+  // hdGatling's documents go through and compares the image with the parameter-block route).  The wrapper object is dropped; the GiCMaterial lives on.
+  extern "C" GiCMaterial* gtlCreateMaterialFromMtlxStrC(GiCScene* scene, const char* name, const char* mtlxSrc)
+  {
+    if (!scene) return nullptr;
+    GiScene wrap{scene};
+    GiMaterial* m = giCreateMaterialFromMtlxStr(&wrap, name, mtlxSrc);
+    if (!m) return nullptr;
+    GiCMaterial* h = m->h;
+    delete m; // (file textures created for the document stay owned by the scene)
+    return h;
+  }
+  extern "C" int gtlMaterialDescFromMtlxStrC(const char* mtlxSrc, GiCMaterialDesc* out)
+  {
+    std::string primvars[GI_C_TEX_SLOT_COUNT]; ImageInput images[GI_C_TEX_SLOT_COUNT];
+    GiCMaterialDesc d;
+    if (!out || !descFromMtlx(mtlxSrc, d, primvars, images)) return GI_C_ERROR;
+    *out = d;
+    return GI_C_OK;
+  }
+
   // MaterialX documents (hdGatling's path for every UsdPreviewSurface / MaterialX network, materialNetworkCompiler.cpp:667-686): the
   // document is serialised by gtl_shim_mtlx.cpp -- the one translation unit that needs the MaterialX headers -- which registers itself here.
   static GtlMtlxDocToXml s_docToXml = nullptr;

@@ -1,0 +1,73 @@
+"""MaterialX documents for :class:`MaterialDesc` parameter blocks -- the inverse of the gtl shim's MaterialX reader
+(``gatling_amd/csrc/gtl_shim.cpp: descFromMtlx``), used by the parity tests of that reader (tests/test_mtlx_parity.py): a document written here and
+read back through ``gtl::giCreateMaterialFromMtlxStr`` must produce the parameter block it was written from, bit for bit, and therefore the same image.
+
+Two spellings of the same material, both of which hdGatling can hand over (src/hdGatling/materialNetworkCompiler.cpp:667-686):
+
+``direct``     ``<open_pbr_surface>`` / ``<UsdPreviewSurface>`` with constant ``<input name value>`` children;
+``nodegraph``  what ``HdMtlxCreateMtlxDocumentFromHdNetwork`` emits for a network whose inputs hang on upstream nodes: every input is connected
+               (``nodegraph=`` + ``output=``) to an ``<output>`` of a ``<nodegraph>``, which names the ``<constant>`` node carrying the value
+               (hdGatling's colour / float mismatch patchers insert exactly such constants), followed by a ``<surfacematerial>``.
+
+Floats are written with 9 significant digits, which round-trips every float32 through ``strtof``.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import scene as S
+
+
+def _f(v) -> str:
+    return "%.9g" % float(np.float32(v))
+
+
+def _vals(p, idx, n):
+    return ", ".join(_f(p[idx + k]) for k in range(n))
+
+
+def _inputs(m: S.MaterialDesc):
+    """(category, [(input name, MaterialX type, value string)]) for every input the shim reads."""
+    p = np.asarray(m.params, np.float32)
+    if m.klass == S.MAT_USD_PREVIEW_SURFACE:
+        return "UsdPreviewSurface", [
+            ("diffuseColor", "color3", _vals(p, S.P_BASE_COLOR, 3)), ("emissiveColor", "color3", _vals(p, S.P_EMISSION, 3)),
+            ("useSpecularWorkflow", "integer", _f(p[S.P_USE_SPECULAR_WORKFLOW])), ("specularColor", "color3", _vals(p, S.P_SPECULAR_COLOR, 3)),
+            ("metallic", "float", _f(p[S.P_METALLIC])), ("roughness", "float", _f(p[S.P_ROUGHNESS])), ("clearcoat", "float", _f(p[S.P_CLEARCOAT])),
+            ("clearcoatRoughness", "float", _f(p[S.P_CLEARCOAT_ROUGHNESS])), ("opacity", "float", _f(p[S.P_OPACITY])),
+            ("opacityThreshold", "float", _f(p[S.P_OPACITY_THRESHOLD])), ("ior", "float", _f(p[S.P_IOR]))]
+    if m.klass != S.MAT_OPEN_PBR:
+        raise ValueError("only UsdPreviewSurface and open_pbr_surface have a MaterialX spelling")
+    em = p[S.P_EMISSION:S.P_EMISSION + 3]
+    return "open_pbr_surface", [
+        ("base_weight", "float", _f(p[S.P_BASE_WEIGHT])), ("base_color", "color3", _vals(p, S.P_BASE_COLOR, 3)),
+        ("base_diffuse_roughness", "float", _f(p[S.P_DIFFUSE_ROUGHNESS])), ("base_metalness", "float", _f(p[S.P_METALLIC])),
+        ("specular_weight", "float", _f(p[S.P_SPECULAR_WEIGHT])), ("specular_color", "color3", _vals(p, S.P_SPECULAR_COLOR, 3)),
+        ("specular_roughness", "float", _f(p[S.P_ROUGHNESS])), ("specular_ior", "float", _f(p[S.P_IOR])),
+        ("transmission_weight", "float", _f(p[S.P_TRANSMISSION_WEIGHT])), ("transmission_color", "color3", _vals(p, S.P_TRANSMISSION_COLOR, 3)),
+        ("transmission_depth", "float", _f(p[S.P_TRANSMISSION_DEPTH])), ("transmission_scatter", "color3", _vals(p, S.P_TRANSMISSION_SCATTER, 3)),
+        ("transmission_scatter_anisotropy", "float", _f(p[S.P_TRANSMISSION_SCATTER_ANISOTROPY])),
+        ("coat_weight", "float", _f(p[S.P_CLEARCOAT])), ("coat_color", "color3", _vals(p, S.P_COAT_COLOR, 3)),
+        ("coat_roughness", "float", _f(p[S.P_CLEARCOAT_ROUGHNESS])), ("coat_ior", "float", _f(p[S.P_COAT_IOR])), ("coat_darkening", "float", _f(p[S.P_COAT_DARKENING])),
+        ("fuzz_weight", "float", _f(p[S.P_FUZZ_WEIGHT])), ("fuzz_color", "color3", _vals(p, S.P_FUZZ_COLOR, 3)), ("fuzz_roughness", "float", _f(p[S.P_FUZZ_ROUGHNESS])),
+        ("geometry_thin_walled", "boolean", "true" if p[S.P_THIN_WALLED] != 0.0 else "false"),
+        # the parameter block keeps luminance x colour: luminance 1 and the product as the colour reproduce it exactly
+        ("emission_luminance", "float", "1" if em.any() else "0"), ("emission_color", "color3", _vals(p, S.P_EMISSION, 3) if em.any() else "1, 1, 1"),
+        ("geometry_opacity", "float", _f(p[S.P_OPACITY]))]
+
+
+def material_to_mtlx(m: S.MaterialDesc, form: str = "direct") -> str:
+    cat, inputs = _inputs(m)
+    if form == "direct":
+        body = "".join(f'<input name="{n}" type="{t}" value="{v}" />' for n, t, v in inputs)
+        return f'<?xml version="1.0"?><materialx version="1.38"><{cat} name="SR_{m.name}" type="surfaceshader">{body}</{cat}></materialx>'
+    if form != "nodegraph":
+        raise ValueError(form)
+    ng, conn = [], []
+    for i, (n, t, v) in enumerate(inputs):
+        ct = "float" if t in ("integer", "boolean") else t  # (the patchers turn int / bool constants into floats; the shim parses true / false as well)
+        ng.append(f'<constant name="c{i}" type="{ct}"><input name="value" type="{ct}" value="{v}" /></constant><output name="out_{n}" type="{ct}" nodename="c{i}" />')
+        conn.append(f'<input name="{n}" type="{t}" nodegraph="NG_{m.name}" output="out_{n}" />')
+    return (f'<?xml version="1.0"?><materialx version="1.38"><nodegraph name="NG_{m.name}">{"".join(ng)}</nodegraph>'
+            f'<{cat} name="SR_{m.name}" type="surfaceshader">{"".join(conn)}</{cat}>'
+            f'<surfacematerial name="{m.name}" type="material"><input name="surfaceshader" type="surfaceshader" nodename="SR_{m.name}" /></surfacematerial></materialx>')

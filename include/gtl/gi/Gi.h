@@ -93,6 +93,8 @@ namespace gtl
   GiMaterial* giCreateMaterialFromMtlxDoc(GiScene*, const char* name, const std::shared_ptr<void> doc);
   using GtlMtlxDocToXml = std::string (*)(const std::shared_ptr<void>& doc);   // [ext] MaterialX::DocumentPtr -> XML text
   void gtlRegisterMtlxDocSerializer(GtlMtlxDocToXml);                           // [ext] called by gtl_shim_mtlx.cpp's static initialiser
+  // [ext] C-linkage doors to the MaterialX reader for harnesses without C++ (tests/test_mtlx_parity.py): `gtlCreateMaterialFromMtlxStrC(GiCScene*, name, xml)`
+  // = giCreateMaterialFromMtlxStr returning the C handle; `gtlMaterialDescFromMtlxStrC(xml, GiCMaterialDesc*)` = the parameter block alone (no device needed).
   // There is no MDL compiler here.  The parameters hdGatling hands over by name are mapped onto the closed-form blocks: the OmniPBR
   // family shipped with the reference (src/gi/mdl/OmniPBR*.mdl) -> the UsdPreviewSurface block, UsdPreviewSurface / open_pbr_surface
   // spelled parameters directly; texture assets are decoded and bound.  Modules none of whose parameters are recognised: nullptr.

@@ -36,6 +36,19 @@ variants)  # A/B of prebuilt library variants (tools/build_variant.py) on the st
     done
   done
   ;;
+nodelines)  # one BVH8 node per 128-byte line (GATLING_NODE_LINES=1, read at scene build) vs the packed 80-byte stride
+  for NL in 0 1; do for WS in c3:32 c4:32 c5:8; do W=${WS%%:*}; S=${WS##*:}
+    echo "== node_lines=$NL $W spp $S" | tee -a $O/${TAG}_nodelines.txt
+    GATLING_NODE_LINES=$NL timeout 600 python tools/gpu_variants.py $W $S - - 2>&1 | grep -v "^\[gatling_gi\]" | tee -a $O/${TAG}_nodelines.txt
+  done; done
+  ;;
+newtests)
+  timeout 900 python -m pytest tests/test_mtlx_parity.py tests/test_multi_device.py -x -q -m gpu 2>&1 | tail -5
+  ;;
+inprocess)  # bench.py --in-process: two device contexts on the one GPU of this box (the multi-device path inside the library), C2 at spp 128
+  GATLING_BENCH_ALSO= timeout 600 python bench.py --spp 128 --steps 2 --warmup 1 --no-pmc --no-cpu-baseline 2>&1 | tail -1 | cut -c1-400
+  GATLING_BENCH_ALSO= GATLING_DEVICES=0,0 timeout 600 python bench.py --spp 128 --steps 2 --warmup 1 --no-pmc --no-cpu-baseline 2>&1 | tail -1 | cut -c1-400
+  ;;
 twolevel)
   for WS in "c4:32" "c5:8"; do W=${WS%%:*}; S=${WS##*:}
     echo "== two-level $W spp $S" | tee -a $O/${TAG}_twolevel.txt
