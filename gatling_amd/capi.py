@@ -119,6 +119,7 @@ SYMBOLS = [
     ("giCTraceRays", C.c_int, [_P, _U, _FP, _FP, _F, _F, _FP, C.POINTER(C.c_int32)]),
     ("giCDebugEvalBsdf", C.c_int, [C.POINTER(GiCMaterialDesc), _U, _FP, _FP]),
     ("giCDebugValidateBvh", C.c_int, [_FP, _U, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("giCDebugValidatePartitionedBvh", C.c_int, [_FP, _U, _U, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
 ]
 
 _lib = None
@@ -287,6 +288,18 @@ class Scene:
             L.giCSetDiskLightDiffuseSpecular(h, l.diffuse, l.specular)
             self.lights.append(("disk", h))
         self._buffers = {}
+
+    def set_mesh_transform(self, mesh_index: int, matrix):
+        """giSetMeshTransform (Gi.h:213): a transform-only edit -- the next render updates the scene incrementally."""
+        m = np.ascontiguousarray(matrix, np.float32).reshape(16)
+        self.desc.meshes[mesh_index].transform = m.reshape(4, 4).copy()
+        self.L.giCSetMeshTransform(self.meshes[mesh_index], m.ctypes.data_as(_FP))
+
+    def set_mesh_instance_transforms(self, mesh_index: int, transforms):
+        """giSetMeshInstanceTransforms (Gi.h:214)."""
+        t = np.ascontiguousarray(transforms, np.float32).reshape(-1, 16)
+        self.desc.meshes[mesh_index].instance_transforms = t.reshape(-1, 4, 4).copy()
+        self.L.giCSetMeshInstanceTransforms(self.meshes[mesh_index], len(t), t.ctypes.data_as(_FP))
 
     def set_option(self, option: int, value: int):
         if self.L.giCSetSceneOption(self.handle, option, value) != GI_C_OK:

@@ -67,6 +67,7 @@ struct Builder {
   // traversal 8-20 % slower: SAH leaves win.  Kept as an experiment knob (GATLING_BVH_BALANCED_BOTTOM=1).
   bool balancedBottom = false;
   std::unique_ptr<Dp[]> dp; float cPrim = 0.5f; // (not zero-initialised: 44 B per BVH2 node) filled bottom-up by build() when leafSize == 1 (each thread completes its own subtrees)
+  uint32_t maxLeaf = kMaxLeaf;  // references a leaf slot may hold (1 for the top tree over subtrees: every leaf slot is then exactly one item)
   uint32_t leafSize = kMaxLeaf; // the BVH2 stops splitting at this many references (1 for the cost-optimal collapse, which forms the leaves itself)
   const float* extBoxes = nullptr; size_t extCount = 0; // box mode (TLAS over instances, BLAS over pre-padded triangle boxes): 6 floats per item
   size_t itemCount() const { return extBoxes ? extCount : tris.size(); }
@@ -208,7 +209,7 @@ struct Builder {
       for (int k = std::max(1, j - 7); k <= std::min(7, j - 1); k++) { const float c = L.c[k - 1] + R.c[j - k - 1]; if (c < best) { best = c; bk = k; } }
       dist[j] = best; d.split[j - 2] = (uint8_t)bk;
     }
-    const float cLeaf = n.total <= kMaxLeaf ? area * cPrim * (float)n.total : 3.0e38f;
+    const float cLeaf = n.total <= maxLeaf ? area * cPrim * (float)n.total : 3.0e38f;
     const float cInt = area + dist[8];
     d.leaf = cLeaf <= cInt ? 1 : 0;
     d.c[0] = d.leaf ? cLeaf : cInt; d.eff[0] = 1;
@@ -232,7 +233,9 @@ inline int exponentFor(float extent)
 
 } // namespace
 
-static void buildCore(const std::vector<TriRec>& trisIn, const float* boxes, size_t boxCount, Bvh8& out, std::vector<uint32_t>* order)
+// `itemRoots` (top mode, with `boxes`): every item is a subtree that already exists; its leaf slot becomes an INTERNAL child whose node is a copy of the item's
+// root node (absolute child / triangle indices inside), so the result is one ordinary tree -- the traversal kernels never learn it was assembled from pieces.
+static void buildCore(const std::vector<TriRec>& trisIn, const float* boxes, size_t boxCount, Bvh8& out, std::vector<uint32_t>* order, const Node8* itemRoots = nullptr)
 {
   out.nodes.clear(); out.tris.clear(); out.maxDepth = 0;
   if (order) order->clear();
@@ -255,6 +258,7 @@ static void buildCore(const std::vector<TriRec>& trisIn, const float* boxes, siz
   if (const char* e = getenv("GATLING_BVH_COLLAPSE")) collapse = atoi(e);
   float cPrim = 0.5f; // a triangle test costs about half a node test (~110 vs ~214 VALU instructions); measured flat between 0.2 and 0.5 (profiles/r02j_bvh_collapse.txt)
   if (const char* e = getenv("GATLING_BVH_CPRIM")) cPrim = (float)atof(e);
+  if (itemRoots) { collapse = 1; cPrim = 1.0f; B.maxLeaf = 1u; } // an item costs (at least) a node visit; one item per leaf slot
   if (collapse == 1) { B.leafSize = 1; B.cPrim = cPrim; }
   B.prepare();
   const double tB = now();
@@ -309,9 +313,10 @@ static void buildCore(const std::vector<TriRec>& trisIn, const float* boxes, siz
       // --- gather up to 8 children
       uint32_t* ch = P.ch; bool chLeaf[8]; int n = 0;
       const Node2& r = B.nodes[n2];
+      if (itemRoots && r.count > 0) { P.n = 0; P.internal = 0; P.tris = 0; P.leafMask = 0; return; } // a copied item root: written below, nothing to plan
       // root that is itself a leaf (level 0 only: below the root the DP's own choice stands -- a subtree of <= 3 references it made an 8-wide
       // node of is cheaper that way than as a node holding one 3-reference leaf slot, which is what this shortcut would emit)
-      if (r.count > 0 || (collapse == 1 && r.total <= kMaxLeaf && out.maxDepth == 1u)) { ch[0] = n2; chLeaf[0] = true; n = 1; }
+      if (r.count > 0 || (collapse == 1 && r.total <= B.maxLeaf && out.maxDepth == 1u)) { ch[0] = n2; chLeaf[0] = true; n = 1; }
       else if (collapse == 1) {
         Child cs[8]; n = gatherOptimal(n2, cs);
         for (int i = 0; i < n; i++) { ch[i] = cs[i].n2; chLeaf[i] = cs[i].leaf; }
@@ -349,7 +354,7 @@ static void buildCore(const std::vector<TriRec>& trisIn, const float* boxes, siz
       P.leafMask = 0; P.internal = 0; P.tris = 0; P.n = (uint8_t)n; P.nb = nb;
       for (int i = 0; i < n; i++) {
         P.childInSlot[slotOf[i]] = (int8_t)i;
-        if (chLeaf[i]) { P.leafMask |= (uint8_t)(1u << i); P.tris += B.nodes[ch[i]].total; } else P.internal++;
+        if (chLeaf[i] && !itemRoots) { P.leafMask |= (uint8_t)(1u << i); P.tris += B.nodes[ch[i]].total; } else P.internal++;
       }
     });
     // --- indices: internal children and triangles in level order, slot order within a node
@@ -360,6 +365,7 @@ static void buildCore(const std::vector<TriRec>& trisIn, const float* boxes, siz
     next.resize(nodeEnd - nodeBase);
     parallelFor(m, [&](size_t li) {
       const Plan& P = plans[li];
+      if (itemRoots && B.nodes[level[li].n2].count > 0) { out.nodes[level[li].n8] = itemRoots[B.refs[B.nodes[level[li].n2].first]]; return; }
       Node8 node; std::memset(&node, 0, sizeof(node));
       int ex[3]; float scale[3];
       for (int a = 0; a < 3; a++) { node.p[a] = P.nb.lo[a]; ex[a] = exponentFor(P.nb.hi[a] - P.nb.lo[a]); node.e[a] = (uint8_t)(ex[a] + 127); scale[a] = std::ldexp(1.0f, ex[a]); }
@@ -406,6 +412,13 @@ static void buildCore(const std::vector<TriRec>& trisIn, const float* boxes, siz
 }
 
 void buildBvh8(const std::vector<TriRec>& trisIn, Bvh8& out) { buildCore(trisIn, nullptr, 0, out, nullptr); }
+
+void buildTopBvh8(const float* boxes, size_t count, const Node8* itemRoots, Bvh8& out)
+{
+  static const std::vector<TriRec> none;
+  std::vector<uint32_t> order; // (unused: no leaf slot survives)
+  buildCore(none, boxes, count, out, &order, itemRoots);
+}
 
 void buildBvh8Boxes(const float* boxes, size_t count, Bvh8& out, std::vector<uint32_t>& order)
 {

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -223,7 +224,9 @@ void deriveMaterialConstants(MaterialRec& m)
 // ---------------------------------------------------------------------------------------------------------------
 // handle types
 // ---------------------------------------------------------------------------------------------------------------
-enum DirtyFlags : uint32_t { DIRTY_BVH = 1u, DIRTY_FRAMEBUFFER = 2u, DIRTY_LIGHTS = 4u, DIRTY_MATERIALS = 8u, DIRTY_ALL = 0xfu };
+// DIRTY_XFORM: only transforms of meshes that are part of the built scene changed -- the incremental path (updateTransforms) handles it unless a full
+// rebuild is due anyway.  The reference keeps each mesh's BLAS and rebuilds the TLAS (Gi.cpp:1180-1202).
+enum DirtyFlags : uint32_t { DIRTY_BVH = 1u, DIRTY_FRAMEBUFFER = 2u, DIRTY_LIGHTS = 4u, DIRTY_MATERIALS = 8u, DIRTY_ALL = 0xfu, DIRTY_XFORM = 16u };
 
 struct GiCTexture { GiCScene* scene; uint32_t width, height; std::vector<float> rgba; std::string cacheKey; uint32_t refs = 1; };
 struct GiCPrimvar { std::string name; int32_t type, interpolation; std::vector<float> data; };
@@ -243,6 +246,9 @@ struct GiCMesh {
   std::vector<int32_t> instanceIds;
   std::vector<GiCPrimvar> primvars, instancerPrimvars;
   GiCMaterial* material = nullptr;
+  bool xformDirty = false;  // transform / instance transforms changed since the last build or update ...
+  std::vector<uint8_t> instDirty; // ... and which instances (empty: all of them)
+  uint32_t builtInstances = 0xffffffffu; // instance count the built scene holds for this mesh (0xffffffff: not part of it)
 };
 
 // swap-remove dense store (GgpuDenseDataStore, src/ggpu/impl/DenseDataStore.cpp:35-93): the arrays stay dense so
@@ -306,6 +312,19 @@ struct SceneDevice {
   void releaseAll();
 };
 
+// The scene as host arrays (built once per scene change, kept for incremental transform updates) ...
+struct TwoLevelHost { std::vector<Node8> tlasNodes, blasNodes; std::vector<uint32_t> tlasItems; std::vector<BlasTri> blasTris; std::vector<InstTrav> instTrav; };
+struct MeshBuild { const GiCMesh* m; uint32_t vertexOffset, matFlags, instFirst, instCount, triFirst; uint32_t meshIdx; std::vector<int32_t> faceIdAov; };
+// One flattened mesh instance of a PARTITIONED scene (after the first transform edit): its own subtree in its own node range, its triangles in its own
+// (scene-order) range, joined by a top tree over the subtree roots (bvh8.h buildTopBvh8).  Moving it rebuilds these ranges and the top tree only.
+struct InstPart { uint32_t meshBuild, instInMesh; uint32_t triFirst, nf; uint32_t nodeOff, nodeCount, nodeCap, depth; float box[6]; };
+struct SceneHost {
+  std::vector<FVertex> verts; std::vector<InstanceRec> instances; std::vector<MaterialRec> mats; std::vector<MeshRec> meshRecs; std::vector<float> sceneData;
+  Bvh8 bvh; std::vector<int32_t> triFaceId; std::vector<uint32_t> flatOfOrig; TwoLevelHost two; bool lineNodes = false;
+  std::vector<MeshBuild> meshBuilds;
+  bool partitioned = false; std::vector<InstPart> parts; uint32_t topCap = 0; // partitioned layout: nodes [0, topCap) = top tree, then the parts' ranges
+};
+
 struct GiCScene : SceneDevice {
   std::mutex mutex;
   uint32_t dirty = DIRTY_ALL;
@@ -331,6 +350,7 @@ struct GiCScene : SceneDevice {
   bool hasCutouts = false;
   uint32_t classMask = 0; // material classes that own at least one triangle (one k_shade launch per class)
   uint32_t classTextured = 0; // classes with at least one textured material in use (k_shade<class, TEXTURED>)
+  std::unique_ptr<SceneHost> host; // the scene as host arrays, kept for incremental transform updates
   std::vector<std::unique_ptr<SceneDevice>> replicas; // devices 1 .. N-1 (created with the first build when the library runs on several devices)
   // options + stats
   bool countTraversal = false, kernelTimers = false;
@@ -584,7 +604,8 @@ void giCSetMeshTransform(GiCMesh* mesh, const float* mat4x4)
   if (!mesh || !mat4x4) return;
   std::lock_guard<std::mutex> g(mesh->scene->mutex); // buildScene reads the mesh under this lock (giCRender on another thread)
   memcpy(mesh->transform, mat4x4, sizeof(float) * 16);
-  mesh->scene->dirty |= DIRTY_BVH | DIRTY_FRAMEBUFFER;
+  if (mesh->builtInstances != 0xffffffffu) { mesh->xformDirty = true; mesh->instDirty.clear(); mesh->scene->dirty |= DIRTY_XFORM | DIRTY_FRAMEBUFFER; } // same triangles elsewhere: incremental update (every instance of the mesh moves)
+  else mesh->scene->dirty |= DIRTY_BVH | DIRTY_FRAMEBUFFER;
 }
 
 void giCSetMeshInstanceTransforms(GiCMesh* mesh, uint32_t count, const float* transforms)
@@ -592,8 +613,16 @@ void giCSetMeshInstanceTransforms(GiCMesh* mesh, uint32_t count, const float* tr
   if (!mesh || (count && !transforms)) return;
   std::vector<float> copy(transforms, transforms + (size_t)count * 16); // copy outside the lock, swap inside
   std::lock_guard<std::mutex> g(mesh->scene->mutex);
-  mesh->instanceTransforms.swap(copy);
-  mesh->scene->dirty |= DIRTY_BVH | DIRTY_FRAMEBUFFER;
+  mesh->instanceTransforms.swap(copy); // (`copy` now holds the previous transforms)
+  if (mesh->builtInstances == count && copy.size() == (size_t)count * 16) { // same instance count: instances moved -- note which
+    const bool all = mesh->xformDirty && mesh->instDirty.empty();
+    if (!all) {
+      if (mesh->instDirty.size() != count) mesh->instDirty.assign(count, 0);
+      for (uint32_t i = 0; i < count; i++) if (memcmp(&copy[16 * (size_t)i], &mesh->instanceTransforms[16 * (size_t)i], 64) != 0) mesh->instDirty[i] = 1;
+    }
+    mesh->xformDirty = true; mesh->scene->dirty |= DIRTY_XFORM | DIRTY_FRAMEBUFFER;
+  }
+  else mesh->scene->dirty |= DIRTY_BVH | DIRTY_FRAMEBUFFER;
 }
 
 void giCSetMeshInstanceIds(GiCMesh* mesh, uint32_t count, const int32_t* ids)
@@ -932,7 +961,6 @@ inline void xformPoint(const float a[12], const float p[3], float out[3])
 // Two-level layout (SceneView::tlasNodes ...): built next to the flat BVH for instanced scenes that do not fit LDS.  The flat
 // arrays stay (k_shade reads the hit's TriRec, k_aov / giCTraceRays traverse them); the two-level ones are what k_trace_dyn2 walks,
 // and they are small: one BLAS per MESH instead of one subtree per instance, so traversal stays in the caches.
-struct TwoLevelHost { std::vector<Node8> tlasNodes, blasNodes; std::vector<uint32_t> tlasItems; std::vector<BlasTri> blasTris; std::vector<InstTrav> instTrav; };
 template <class MB>
 int buildTwoLevel(GiCScene* s, const std::vector<MB>& meshBuilds, const std::vector<InstanceRec>& instances, size_t flatTris, size_t flatNodes, TwoLevelHost& out)
 {
@@ -969,13 +997,21 @@ int buildTwoLevel(GiCScene* s, const std::vector<MB>& meshBuilds, const std::vec
     buildBvh8Boxes(boxes.data(), nf, b, order);
     const uint32_t nodeBase = (uint32_t)blasNodes.size(), triBase = (uint32_t)blasTris.size();
     for (Node8 n : b.nodes) { n.childBase += nodeBase; n.triBase += triBase; blasNodes.push_back(n); }
-    for (uint32_t f : order) blasTris.push_back(BlasTri{{mb.vertexOffset + m->faces[f].v_i[0], mb.vertexOffset + m->faces[f].v_i[1], mb.vertexOffset + m->faces[f].v_i[2]}, f});
+    for (uint32_t f : order) {
+      BlasTri bt{};
+      memcpy(bt.p0, m->vertices[m->faces[f].v_i[0]].pos, 12); memcpy(bt.p1, m->vertices[m->faces[f].v_i[1]].pos, 12); memcpy(bt.p2, m->vertices[m->faces[f].v_i[2]].pos, 12);
+      bt.prim = f;
+      blasTris.push_back(bt);
+    }
     blasDepth = std::max(blasDepth, b.maxDepth);
     // object-space magnitude the transformed ray's rounding error scales with inside this mesh (see wave_step2)
     const float extent = (std::fabs(mlo[0]) + std::fabs(mlo[1]) + std::fabs(mlo[2])) + (std::fabs(mhi[0]) + std::fabs(mhi[1]) + std::fabs(mhi[2]));
     for (uint32_t ii = 0; ii < mb.instCount; ii++) {
       const uint32_t inst = mb.instFirst + ii;
-      instTrav[inst] = InstTrav{nodeBase, mb.triFirst + ii * (uint32_t)nf, mb.matFlags, extent};
+      InstTrav& tv = instTrav[inst];
+      tv = InstTrav{};
+      memcpy(tv.o2w, instances[inst].o2w, sizeof(tv.o2w)); memcpy(tv.w2o, instances[inst].w2o, sizeof(tv.w2o));
+      tv.blasRoot = nodeBase; tv.triBase = mb.triFirst + ii * (uint32_t)nf; tv.matFlags = mb.matFlags; tv.slack = extent;
       float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
       for (size_t f = 0; f < nf; f++)
         for (int k = 0; k < 3; k++) { float p[3]; xformPoint(instances[inst].o2w, m->vertices[m->faces[f].v_i[k]].pos, p); for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); } }
@@ -993,12 +1029,6 @@ int buildTwoLevel(GiCScene* s, const std::vector<MB>& meshBuilds, const std::vec
   out.tlasNodes.swap(tlas.nodes); out.tlasItems.swap(tlasItems); out.blasNodes.swap(blasNodes); out.blasTris.swap(blasTris); out.instTrav.swap(instTrav);
   return GI_C_OK;
 }
-
-// The scene as host arrays (built once per scene change) ...
-struct SceneHost {
-  std::vector<FVertex> verts; std::vector<InstanceRec> instances; std::vector<MaterialRec> mats; std::vector<MeshRec> meshRecs; std::vector<float> sceneData;
-  Bvh8 bvh; std::vector<int32_t> triFaceId; std::vector<uint32_t> flatOfOrig; TwoLevelHost two; bool lineNodes = false;
-};
 
 // ... and its upload into one device's memory (the primary's and every replica's: multi-device renders replicate the scene)
 int uploadSceneTo(GiCScene* s, SceneDevice& D, const SceneHost& H)
@@ -1051,7 +1081,10 @@ SceneDevice& sceneDevice(GiCScene* s, uint32_t slot) { return slot == 0u ? stati
 int buildScene(GiCScene* s)
 {
   double t0 = nowMs();
-  SceneHost H;
+  std::unique_ptr<SceneHost> hostPtr(new SceneHost());
+  SceneHost& H = *hostPtr;
+  s->host.reset(); // (a failed build leaves no stale host copy behind)
+  for (GiCMesh* m : s->meshes) { m->builtInstances = 0xffffffffu; m->xformDirty = false; m->instDirty.clear(); }
   std::vector<FVertex>& verts = H.verts; std::vector<InstanceRec>& instances = H.instances; std::vector<TriRec> tris; std::vector<int32_t> faceIdOf;
   std::vector<MaterialRec>& mats = H.mats; mats.resize(s->materials.size());
   for (size_t i = 0; i < s->materials.size(); i++) {
@@ -1078,8 +1111,7 @@ int buildScene(GiCScene* s)
     deriveMaterialConstants(mats[i]);
   }
   uint32_t meshIdx = 0;
-  struct MeshBuild { const GiCMesh* m; uint32_t vertexOffset, matFlags, instFirst, instCount, triFirst; };
-  std::vector<MeshBuild> meshBuilds; // visible meshes in scene order (two-level layout)
+  std::vector<MeshBuild>& meshBuilds = H.meshBuilds; // visible meshes in scene order (two-level layout, incremental updates)
   std::vector<MeshRec>& meshRecs = H.meshRecs; std::vector<float>& sceneData = H.sceneData;
   s->classMask = 0; s->hasCutouts = false; s->classTextured = 0;
   for (GiCMesh* m : s->meshes) {
@@ -1139,7 +1171,8 @@ int buildScene(GiCScene* s)
       }
     }
     size_t instCount = m->instanceTransforms.size() / 16;
-    meshBuilds.push_back(MeshBuild{m, vertexOffset, matFlags, (uint32_t)instances.size(), (uint32_t)instCount, (uint32_t)tris.size()});
+    m->builtInstances = (uint32_t)instCount;
+    meshBuilds.push_back(MeshBuild{m, vertexOffset, matFlags, (uint32_t)instances.size(), (uint32_t)instCount, (uint32_t)tris.size(), meshIdx, meshFaceIdAov});
     for (size_t ii = 0; ii < instCount; ii++) { // Gi.cpp:1188-1202
       InstanceRec ir{};
       composeTransform(m->transform, &m->instanceTransforms[16 * ii], ir.o2w);
@@ -1190,6 +1223,187 @@ int buildScene(GiCScene* s)
   s->nodeCount = (uint32_t)bvh.nodes.size(); s->triCount = (uint32_t)bvh.tris.size(); s->bvhDepth = bvh.maxDepth > 1u ? bvh.maxDepth - 1u : 1u; // stack entries a walk can need: a pick at level L pushes the rest of level L-1's group (gi_traversal.h trav_node_pick), the root level pushes nothing
   s->stats.bvhBuildMs = t1 - t0; s->stats.uploadMs = nowMs() - t1;
   s->stats.nodeCount = s->nodeCount; s->stats.triangleCount = s->triCount;
+  s->host = std::move(hostPtr);
+  return GI_C_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Incremental transform updates (the reference keeps every mesh's BLAS and rebuilds only the TLAS, Gi.cpp:1180-1202).
+//
+// A scene is first built as ONE tree over all instanced triangles (buildScene: the best tree).  The first time only transforms change, it is re-laid out
+// PARTITIONED: every flattened mesh instance gets its own subtree in its own node range and keeps its triangles in its own (scene-order) range; a top tree
+// over the subtree roots (buildTopBvh8: the roots are copied in as ordinary internal children) makes it one ordinary BVH8 again -- the traversal kernels, the
+// shading code and the triangle ids do not change, so images stay bit-identical to a full rebuild (traversal contract: results do not depend on the tree).
+// From then on moving an instance costs: its triangles re-transformed, its subtree rebuilt (a few thousand triangles), the top tree rebuilt (one item per
+// instance), and those ranges uploaded -- not a 10 M-triangle SAH build and a 0.7 GB upload.  Any other edit (geometry, materials, visibility, instance
+// counts) raises DIRTY_BVH and the next render rebuilds everything as one tree again.
+// ---------------------------------------------------------------------------------------------------------------
+void nodeBounds(const Node8& n, float box[6])
+{
+  for (int a = 0; a < 3; a++) { box[a] = 3.0e38f; box[3 + a] = -3.0e38f; }
+  for (int sl = 0; sl < 8; sl++) {
+    if (n.meta[sl] == 0) continue;
+    for (int a = 0; a < 3; a++) {
+      uint32_t eb = (uint32_t)n.e[a] << 23; float scale; memcpy(&scale, &eb, 4);
+      box[a] = std::min(box[a], n.p[a] + (float)n.qlo[a][sl] * scale); box[3 + a] = std::max(box[3 + a], n.p[a] + (float)n.qhi[a][sl] * scale);
+    }
+  }
+  // the dequantised planes are evaluated in fp32 here and with an fma on the device: one more ulp-scale pad keeps the item box outside both
+  for (int a = 0; a < 3; a++) { const float pad = (std::fabs(box[a]) + std::fabs(box[3 + a])) * 2.4e-7f + 1.0e-30f; box[a] -= pad; box[3 + a] += pad; }
+}
+
+// One instance's InstanceRec, world-space triangles (scene order) and subtree
+struct PartBuild { InstanceRec inst; Bvh8 bvh; };
+void buildPart(const MeshBuild& mb, uint32_t instInMesh, PartBuild& out)
+{
+  const GiCMesh* m = mb.m;
+  InstanceRec ir{};
+  composeTransform(m->transform, &m->instanceTransforms[16 * (size_t)instInMesh], ir.o2w);
+  invert3x3(ir.o2w, ir.w2o);
+  ir.mesh = mb.meshIdx; ir.instanceId = instInMesh < m->instanceIds.size() ? m->instanceIds[instInMesh] : (int32_t)instInMesh;
+  ir.pad = (uint32_t)m->id;
+  out.inst = ir;
+  const uint32_t nf = (uint32_t)m->faces.size(), instIdx = mb.instFirst + instInMesh;
+  std::vector<TriRec> tris(nf);
+  for (uint32_t f = 0; f < nf; f++) { // as buildScene (Gi.cpp:1188-1202)
+    float p0[3], p1[3], p2[3];
+    xformPoint(ir.o2w, m->vertices[m->faces[f].v_i[0]].pos, p0);
+    xformPoint(ir.o2w, m->vertices[m->faces[f].v_i[1]].pos, p1);
+    xformPoint(ir.o2w, m->vertices[m->faces[f].v_i[2]].pos, p2);
+    TriRec& t = tris[f];
+    for (int a = 0; a < 3; a++) { t.v0[a] = p0[a]; t.e1[a] = p1[a] - p0[a]; t.e2[a] = p2[a] - p0[a]; t.vi[a] = mb.vertexOffset + m->faces[f].v_i[a]; }
+    t.instance = instIdx; t.prim = f; t.origId = f; t.matFlags = mb.matFlags;
+  }
+  buildBvh8(tris, out.bvh);
+}
+
+// writes a built part into the scene arrays at the part's ranges (node / triangle indices rebased to absolute)
+void placePart(SceneHost& H, InstPart& P, const PartBuild& B)
+{
+  const MeshBuild& mb = H.meshBuilds[P.meshBuild];
+  P.nodeCount = (uint32_t)B.bvh.nodes.size(); P.depth = B.bvh.maxDepth;
+  for (uint32_t i = 0; i < P.nodeCount; i++) { Node8 n = B.bvh.nodes[i]; n.childBase += P.nodeOff; n.triBase += P.triFirst; H.bvh.nodes[P.nodeOff + i] = n; }
+  for (uint32_t k = 0; k < P.nf; k++) {
+    TriRec t = B.bvh.tris[k];
+    H.triFaceId[P.triFirst + k] = mb.faceIdAov[t.prim];
+    t.origId += P.triFirst; // scene-order id: the instance's triangles are numbered in face order from triFirst, as in buildScene
+    H.bvh.tris[P.triFirst + k] = t;
+  }
+  H.instances[mb.instFirst + P.instInMesh] = B.inst;
+  nodeBounds(H.bvh.nodes[P.nodeOff], P.box);
+}
+
+template <class Fn> void parallelOver(size_t n, Fn&& fn)
+{
+  int workers = (int)std::thread::hardware_concurrency();
+  if (const char* e = getenv("GATLING_BUILD_THREADS")) workers = atoi(e);
+  workers = (int)std::min<size_t>((size_t)std::min(std::max(workers, 1), 32), std::max<size_t>(n, 1));
+  if (workers <= 1) { for (size_t i = 0; i < n; i++) fn(i); return; }
+  std::atomic<size_t> next{0};
+  std::vector<std::thread> th;
+  for (int w = 0; w < workers; w++) th.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < n;) fn(i); });
+  for (auto& t : th) t.join();
+}
+
+int rebuildTop(GiCScene* s, SceneHost& H)
+{
+  std::vector<float> boxes(H.parts.size() * 6); std::vector<Node8> roots(H.parts.size());
+  uint32_t subDepth = 0;
+  for (size_t i = 0; i < H.parts.size(); i++) { memcpy(&boxes[6 * i], H.parts[i].box, 24); roots[i] = H.bvh.nodes[H.parts[i].nodeOff]; subDepth = std::max(subDepth, H.parts[i].depth); }
+  Bvh8 top;
+  buildTopBvh8(boxes.data(), H.parts.size(), roots.data(), top);
+  if (top.nodes.size() > H.topCap) { setError("internal: top tree larger than its reserved range"); return GI_C_ERROR; }
+  std::copy(top.nodes.begin(), top.nodes.end(), H.bvh.nodes.begin());
+  for (size_t i = top.nodes.size(); i < H.topCap; i++) memset(&H.bvh.nodes[i], 0, sizeof(Node8));
+  H.bvh.maxDepth = top.maxDepth + (subDepth > 0u ? subDepth - 1u : 0u); // the copied roots are the subtrees' first level
+  if (H.bvh.maxDepth > 1u + 8u + 40u) { setError("scene BVH is deeper than the traversal stack (49 levels)"); return GI_C_ERROR; }
+  s->bvhDepth = H.bvh.maxDepth > 1u ? H.bvh.maxDepth - 1u : 1u;
+  return GI_C_OK;
+}
+
+// true: handled incrementally; false: the caller must run a full buildScene (not an error)
+int updateTransforms(GiCScene* s, bool& handled)
+{
+  handled = false;
+  if (!s->host || s->twoLevel || s->host->lineNodes || s->triCount < 4096u) return GI_C_OK; // small scenes rebuild in no time (and must stay LDS-resident)
+  if (const char* e = getenv("GATLING_INCREMENTAL")) { if (!atoi(e)) return GI_C_OK; }
+  SceneHost& H = *s->host;
+  for (const MeshBuild& mb : H.meshBuilds) if (mb.m->builtInstances != mb.instCount) return GI_C_OK; // (cannot happen: count changes raise DIRTY_BVH)
+  const double t0 = nowMs();
+  std::vector<uint32_t> dirtyParts;
+  bool converted = false;
+  if (!H.partitioned) {
+    // --- one-time re-layout: every instance its own subtree + ranges (costs about one full build, in parallel over the instances)
+    std::vector<InstPart> parts;
+    for (uint32_t b = 0; b < (uint32_t)H.meshBuilds.size(); b++) {
+      const MeshBuild& mb = H.meshBuilds[b];
+      const uint32_t nf = (uint32_t)mb.m->faces.size();
+      for (uint32_t ii = 0; ii < mb.instCount; ii++) { InstPart P{}; P.meshBuild = b; P.instInMesh = ii; P.triFirst = mb.triFirst + ii * nf; P.nf = nf; parts.push_back(P); }
+    }
+    if (parts.empty()) return GI_C_OK;
+    std::vector<PartBuild> built(parts.size());
+    parallelOver(parts.size(), [&](size_t i) { buildPart(H.meshBuilds[parts[i].meshBuild], parts[i].instInMesh, built[i]); });
+    H.topCap = (uint32_t)parts.size() * 2u + 16u; // top nodes <= internal top nodes + one copied root per part
+    uint32_t off = H.topCap;
+    for (size_t i = 0; i < parts.size(); i++) { const uint32_t n = (uint32_t)built[i].bvh.nodes.size(); parts[i].nodeOff = off; parts[i].nodeCap = n + n / 4u + 8u; off += parts[i].nodeCap; }
+    H.bvh.nodes.assign(off, Node8{});
+    H.parts.swap(parts);
+    parallelOver(H.parts.size(), [&](size_t i) { placePart(H, H.parts[i], built[i]); });
+    H.partitioned = true; converted = true;
+  } else {
+    for (uint32_t i = 0; i < (uint32_t)H.parts.size(); i++) {
+      const GiCMesh* m = H.meshBuilds[H.parts[i].meshBuild].m;
+      if (m->xformDirty && (m->instDirty.empty() || m->instDirty[H.parts[i].instInMesh])) dirtyParts.push_back(i);
+    }
+    std::vector<PartBuild> built(dirtyParts.size());
+    parallelOver(dirtyParts.size(), [&](size_t k) { const InstPart& P = H.parts[dirtyParts[k]]; buildPart(H.meshBuilds[P.meshBuild], P.instInMesh, built[k]); });
+    for (size_t k = 0; k < dirtyParts.size(); k++)
+      if (built[k].bvh.nodes.size() > H.parts[dirtyParts[k]].nodeCap) { H.partitioned = false; H.parts.clear(); return GI_C_OK; } // a subtree outgrew its range (rare): full rebuild
+    parallelOver(dirtyParts.size(), [&](size_t k) { placePart(H, H.parts[dirtyParts[k]], built[k]); });
+  }
+  if (rebuildTop(s, H) != GI_C_OK) return GI_C_ERROR;
+  for (GiCMesh* m : s->meshes) { m->xformDirty = false; m->instDirty.clear(); }
+  const double t1 = nowMs();
+  // --- upload: everything after the re-layout, else the moved parts' ranges, their InstanceRecs and the top region
+  const uint32_t nDev = std::min<uint32_t>(sceneDeviceCount(s), (uint32_t)s->replicas.size() + 1u);
+  s->nodeCount = (uint32_t)H.bvh.nodes.size();
+  for (uint32_t d = 0; d < nDev; d++) {
+    SceneDevice& D = sceneDevice(s, d);
+    if (converted) { if (uploadSceneTo(s, D, H) != GI_C_OK) { (void)hipSetDevice(g_ctx.device); return GI_C_ERROR; } continue; }
+    const DevCtx& ctx = g_ctx.devs[d];
+    HIP_TRY(hipSetDevice(ctx.device));
+    hipStream_t st = ctx.stream;
+    HIP_TRY(hipMemcpyAsync(D.dNodes.ptr, H.bvh.nodes.data(), (size_t)H.topCap * sizeof(Node8), hipMemcpyHostToDevice, st));
+    for (uint32_t i : dirtyParts) {
+      const InstPart& P = H.parts[i];
+      const uint32_t instIdx = H.meshBuilds[P.meshBuild].instFirst + P.instInMesh;
+      HIP_TRY(hipMemcpyAsync(D.dNodes.ptr + P.nodeOff, &H.bvh.nodes[P.nodeOff], (size_t)P.nodeCount * sizeof(Node8), hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(D.dTris.ptr + P.triFirst, &H.bvh.tris[P.triFirst], (size_t)P.nf * sizeof(TriRec), hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(D.dTriFaceId.ptr + P.triFirst, &H.triFaceId[P.triFirst], (size_t)P.nf * sizeof(int32_t), hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(D.dInstances.ptr + instIdx, &H.instances[instIdx], sizeof(InstanceRec), hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  s->stats.bvhBuildMs = t1 - t0; s->stats.uploadMs = nowMs() - t1;
+  s->stats.nodeCount = s->nodeCount; s->stats.triangleCount = s->triCount;
+  if (getenv("GATLING_BUILD_TIMING")) fprintf(stderr, "[gatling_gi] transform update: %s, %zu part(s) rebuilt of %zu, host %.1f ms, upload %.1f ms\n",
+                                              converted ? "scene re-laid out as per-instance subtrees" : "incremental", converted ? H.parts.size() : dirtyParts.size(), H.parts.size(), t1 - t0, nowMs() - t1);
+  handled = true;
+  return GI_C_OK;
+}
+
+// brings the device scene up to date with the host-side edits: incremental for transform-only edits, else a full build
+int syncSceneGeometry(GiCScene* s)
+{
+  if ((s->dirty & DIRTY_XFORM) && !(s->dirty & (DIRTY_BVH | DIRTY_MATERIALS))) { // only transforms changed: re-transform / re-braid those instances
+    bool handled = false;
+    if (updateTransforms(s, handled) != GI_C_OK) return GI_C_ERROR;
+    if (!handled) s->dirty |= DIRTY_BVH;
+    s->dirty |= DIRTY_FRAMEBUFFER;
+  }
+  if (s->dirty & (DIRTY_BVH | DIRTY_MATERIALS)) { if (buildScene(s) != GI_C_OK) return GI_C_ERROR; s->dirty &= ~(DIRTY_BVH | DIRTY_MATERIALS); s->dirty |= DIRTY_FRAMEBUFFER; }
+  s->dirty &= ~DIRTY_XFORM;
   return GI_C_OK;
 }
 
@@ -1716,7 +1930,7 @@ static int giCRenderImpl(const GiCRenderParams* params)
   if (domeEm) memcpy(s->oldDomeEmission, domeEm, 12);
 
   s->stats.bvhBuildMs = 0.0; s->stats.uploadMs = 0.0; s->stats.nodeCount = s->nodeCount; s->stats.triangleCount = s->triCount;
-  if (s->dirty & (DIRTY_BVH | DIRTY_MATERIALS)) { if (buildScene(s) != GI_C_OK) return GI_C_ERROR; s->dirty &= ~(DIRTY_BVH | DIRTY_MATERIALS); s->dirty |= DIRTY_FRAMEBUFFER; }
+  if (syncSceneGeometry(s) != GI_C_OK) return GI_C_ERROR;
   if (s->dirty & DIRTY_LIGHTS) { if (uploadLights(s) != GI_C_OK) return GI_C_ERROR; s->dirty &= ~DIRTY_LIGHTS; s->dirty |= DIRTY_FRAMEBUFFER; }
   if (!rs.progressiveAccumulation) s->dirty |= DIRTY_FRAMEBUFFER;
   if (s->dirty & DIRTY_FRAMEBUFFER) { s->sampleOffset = 0; s->dirty &= ~DIRTY_FRAMEBUFFER; }
@@ -1766,7 +1980,7 @@ static int giCTraceRaysImpl(GiCScene* s, uint32_t count, const float* origins, c
   if (count == 0) return 0;
   std::lock_guard<std::mutex> guard(s->mutex);
   hipStream_t st = g_ctx.stream;
-  if (s->dirty & (DIRTY_BVH | DIRTY_MATERIALS)) { if (buildScene(s) != GI_C_OK) return -1; s->dirty &= ~(DIRTY_BVH | DIRTY_MATERIALS); s->dirty |= DIRTY_FRAMEBUFFER; }
+  if (syncSceneGeometry(s) != GI_C_OK) return -1;
   // the render loop's grids: k_trace_dyn (scenes beyond LDS) is persistent per wave and wants every resident wave slot filled (8 blocks per CU offered)
   const bool inLds = s->nodeCount <= 384u && s->triCount <= 128u;
   const uint32_t blocks = std::min<uint32_t>((count + 255u) / 256u, (uint32_t)g_ctx.cuCount * (inLds ? 3u : 8u));
@@ -1814,18 +2028,8 @@ static int giCTraceRaysImpl(GiCScene* s, uint32_t count, const float* origins, c
 // ---------------------------------------------------------------------------------------------------------------
 // giCDebugValidateBvh: host-only check of the builder's conservativeness contract
 // ---------------------------------------------------------------------------------------------------------------
-extern "C" int giCDebugValidateBvh(const float* triVerts, uint32_t triCount, uint32_t* outNodeCount, uint32_t* outMaxDepth)
+static int validateTree(const std::vector<Node8>& nodes, const std::vector<TriRec>& trisArr, uint32_t triCount)
 {
-  if (triCount && !triVerts) return -1;
-  std::vector<TriRec> tris(triCount);
-  for (uint32_t i = 0; i < triCount; i++) {
-    const float* p = triVerts + 9 * (size_t)i;
-    for (int a = 0; a < 3; a++) { tris[i].v0[a] = p[a]; tris[i].e1[a] = p[3 + a] - p[a]; tris[i].e2[a] = p[6 + a] - p[a]; }
-    tris[i].instance = 0; tris[i].prim = i; tris[i].origId = i;
-  }
-  Bvh8 bvh; buildBvh8(tris, bvh);
-  if (outNodeCount) *outNodeCount = (uint32_t)bvh.nodes.size();
-  if (outMaxDepth) *outMaxDepth = bvh.maxDepth;
   int violations = 0;
   std::vector<uint8_t> seen(triCount, 0);
   struct Item { uint32_t node; float lo[3], hi[3]; };
@@ -1834,8 +2038,8 @@ extern "C" int giCDebugValidateBvh(const float* triVerts, uint32_t triCount, uin
   stack.push_back(root);
   while (!stack.empty()) {
     Item it = stack.back(); stack.pop_back();
-    if (it.node >= bvh.nodes.size()) { violations++; continue; }
-    const Node8& n = bvh.nodes[it.node];
+    if (it.node >= nodes.size()) { violations++; continue; }
+    const Node8& n = nodes[it.node];
     uint32_t rel = 0;
     for (int s = 0; s < 8; s++) {
       uint8_t meta = n.meta[s];
@@ -1844,7 +2048,6 @@ extern "C" int giCDebugValidateBvh(const float* triVerts, uint32_t triCount, uin
       for (int a = 0; a < 3; a++) {
         uint32_t eb = (uint32_t)n.e[a] << 23; float scale; memcpy(&scale, &eb, 4);
         lo[a] = n.p[a] + (float)n.qlo[a][s] * scale; hi[a] = n.p[a] + (float)n.qhi[a][s] * scale;
-        if (lo[a] < it.lo[a] - 1e-3f * (1.0f + fabsf(it.lo[a])) || hi[a] > it.hi[a] + 1e-3f * (1.0f + fabsf(it.hi[a]))) { /* child may poke out of the parent by quantisation only */ }
       }
       bool inner = (n.imask >> s) & 1u;
       if (inner) {
@@ -1859,8 +2062,8 @@ extern "C" int giCDebugValidateBvh(const float* triVerts, uint32_t triCount, uin
         if (cnt == 0u || off + cnt > 24u) { violations++; continue; }
         for (uint32_t k = 0; k < cnt; k++) {
           uint32_t ti = n.triBase + off + k;
-          if (ti >= bvh.tris.size()) { violations++; continue; }
-          const TriRec& t = bvh.tris[ti];
+          if (ti >= trisArr.size()) { violations++; continue; }
+          const TriRec& t = trisArr[ti];
           if (t.origId >= triCount || seen[t.origId]) { violations++; continue; }
           seen[t.origId] = 1;
           for (int v = 0; v < 3; v++)
@@ -1875,6 +2078,53 @@ extern "C" int giCDebugValidateBvh(const float* triVerts, uint32_t triCount, uin
   }
   for (uint32_t i = 0; i < triCount; i++) if (!seen[i]) violations++;
   return violations;
+}
+
+extern "C" int giCDebugValidateBvh(const float* triVerts, uint32_t triCount, uint32_t* outNodeCount, uint32_t* outMaxDepth)
+{
+  if (triCount && !triVerts) return -1;
+  std::vector<TriRec> tris(triCount);
+  for (uint32_t i = 0; i < triCount; i++) {
+    const float* p = triVerts + 9 * (size_t)i;
+    for (int a = 0; a < 3; a++) { tris[i].v0[a] = p[a]; tris[i].e1[a] = p[3 + a] - p[a]; tris[i].e2[a] = p[6 + a] - p[a]; }
+    tris[i].instance = 0; tris[i].prim = i; tris[i].origId = i;
+  }
+  Bvh8 bvh; buildBvh8(tris, bvh);
+  if (outNodeCount) *outNodeCount = (uint32_t)bvh.nodes.size();
+  if (outMaxDepth) *outMaxDepth = bvh.maxDepth;
+  return validateTree(bvh.nodes, bvh.tris, triCount);
+}
+
+// The same check for the PARTITIONED layout of incremental updates: the triangles are cut into `partCount` consecutive ranges, every range gets its own
+// subtree in its own node range, and a top tree over the subtree roots (buildTopBvh8) joins them.  Returns the violations of the assembled tree.
+extern "C" int giCDebugValidatePartitionedBvh(const float* triVerts, uint32_t triCount, uint32_t partCount, uint32_t* outNodeCount, uint32_t* outMaxDepth)
+{
+  if (!triVerts || triCount == 0 || partCount == 0 || partCount > triCount) return -1;
+  const uint32_t topCap = partCount * 2u + 16u;
+  std::vector<Node8> nodes(topCap, Node8{}); std::vector<TriRec> trisAll(triCount);
+  std::vector<float> boxes(6 * (size_t)partCount); std::vector<Node8> roots(partCount);
+  uint32_t subDepth = 0;
+  for (uint32_t pi = 0; pi < partCount; pi++) {
+    const uint32_t first = (uint32_t)((uint64_t)triCount * pi / partCount), end = (uint32_t)((uint64_t)triCount * (pi + 1) / partCount);
+    std::vector<TriRec> tris(end - first);
+    for (uint32_t i = first; i < end; i++) {
+      const float* p = triVerts + 9 * (size_t)i; TriRec& t = tris[i - first];
+      for (int a = 0; a < 3; a++) { t.v0[a] = p[a]; t.e1[a] = p[3 + a] - p[a]; t.e2[a] = p[6 + a] - p[a]; }
+      t.instance = pi; t.prim = i - first; t.origId = i - first;
+    }
+    Bvh8 b; buildBvh8(tris, b);
+    const uint32_t off = (uint32_t)nodes.size();
+    for (Node8 n : b.nodes) { n.childBase += off; n.triBase += first; nodes.push_back(n); }
+    for (uint32_t k = 0; k < end - first; k++) { TriRec t = b.tris[k]; t.origId += first; trisAll[first + k] = t; }
+    roots[pi] = nodes[off]; nodeBounds(nodes[off], &boxes[6 * (size_t)pi]);
+    subDepth = std::max(subDepth, b.maxDepth);
+  }
+  Bvh8 top; buildTopBvh8(boxes.data(), partCount, roots.data(), top);
+  if (top.nodes.size() > topCap) return -2;
+  std::copy(top.nodes.begin(), top.nodes.end(), nodes.begin());
+  if (outNodeCount) *outNodeCount = (uint32_t)nodes.size();
+  if (outMaxDepth) *outMaxDepth = top.maxDepth + subDepth - 1u;
+  return validateTree(nodes, trisAll, triCount);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -47,10 +47,7 @@ __global__ void k_init(PathState st, QueueSet qs, Counters* cnt, uint32_t n, uin
     cnt->workBase[0].v = 0; cnt->workBase[1].v = 0; for (uint32_t k = 0; k < NCURSOR; k++) { cnt->cursor[0][k].v = 0; cnt->cursor[1][k].v = 0; }
     if (resetStats) { cnt->segments = 0; cnt->shadowRays = 0; cnt->nodesVisited = 0; cnt->trisTested = 0; cnt->shadowNodesVisited = 0; cnt->shadowTrisTested = 0; }
   }
-  for (; i < n; i += gridDim.x * blockDim.x) {
-    st4(&st.slots[i].id, 0.0f, 0.0f, 0.0f, 0.0f);
-    qs.slot[Q_REGEN_A][(i / per) * qs.cap + (i % per)] = i;
-  }
+  for (; i < n; i += gridDim.x * blockDim.x) qs.slot[Q_REGEN_A][(i / per) * qs.cap + (i % per)] = i | REGEN_FRESH; // the slots themselves stay untouched
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -77,9 +74,10 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st,
     V3 origin = v3(0.0f, 0.0f, 0.0f), dir = origin; float tMin = 0.0f, tMax = GI_FLT_MAX;
     if (i < n) {
       const uint32_t entry = qs.slot[qIn][reader_index(rd, i)];
-      slot = entry & ~REGEN_MISSED;
+      slot = entry & ~(REGEN_MISSED | REGEN_FRESH);
       Slot* S = &st.slots[slot];
-      const F4 id = ld4(&S->id);
+      F4 id = F4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (!(entry & REGEN_FRESH)) id = ld4(&S->id);
       if (f2u(id.z) != 0u) { // finish the sample that just terminated (:489-496) -> per-sample colour buffer
         F4 r = ld4(&S->rad);
         V3 rad = v3(r.x, r.y, r.z);

@@ -79,6 +79,8 @@ __device__ __forceinline__ uint32_t tile_to_image_pixel(const FrameUniforms& U, 
 }
 constexpr uint32_t MISS = 0xffffffffu;
 constexpr uint32_t REGEN_MISSED = 0x80000000u; // flag on a regen-queue entry: the path left the scene (k_trace -> k_raygen)
+constexpr uint32_t REGEN_FRESH = 0x40000000u;  // flag on a regen-queue entry written by k_init: the slot carries no sample yet and its memory is uninitialised -- k_raygen
+                                               // must not read it (this replaces a 64-byte write per slot in k_init: 4 GB and 2 ms per batch for the 64 Mi-slot pool)
 
 // Zeroes the counters of the queues that the producers of iteration `it` will append to.  Called by one thread of
 // k_raygen(it): none of these queues is read or appended by k_raygen(it) itself (it reads REGEN[it&1] and appends

@@ -522,9 +522,8 @@ __device__ __forceinline__ void trav2_init(RayTrav2& R, V3 o, V3 d, float tMin, 
 }
 __device__ __forceinline__ void trav2_enter(RayTrav2& R, const SceneView& sc, uint32_t inst)
 {
-  const float4* ip = reinterpret_cast<const float4*>(&sc.instances[inst]);
-  const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2], r3 = ip[3], r4 = ip[4], r5 = ip[5]; // o2w rows | w2o[0..8], mesh, ids
-  const InstTrav tv = sc.instTrav[inst];
+  const float4* ip = reinterpret_cast<const float4*>(&sc.instTrav[inst]); // one 128-byte line: o2w rows | w2o[0..8], blasRoot, triBase, matFlags | slack
+  const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2], r3 = ip[3], r4 = ip[4], r5 = ip[5], r6 = ip[6];
   const V3 rel = v3(R.wo.x - r0.w, R.wo.y - r1.w, R.wo.z - r2.w); // o2w translation = column 3
   const float w[9] = {r3.x, r3.y, r3.z, r3.w, r4.x, r4.y, r4.z, r4.w, r5.x};
   const V3 o = v3((w[0] * rel.x + w[1] * rel.y) + w[2] * rel.z, (w[3] * rel.x + w[4] * rel.y) + w[5] * rel.z, (w[6] * rel.x + w[7] * rel.y) + w[8] * rel.z);
@@ -533,10 +532,10 @@ __device__ __forceinline__ void trav2_enter(RayTrav2& R, const SceneView& sc, ui
   // the mesh, <= |o'| + its extent -- for the direction; 4e-6 is > 30 ulps of that
   const float m0 = (fabsf(w[0] * rel.x) + fabsf(w[1] * rel.y)) + fabsf(w[2] * rel.z), m1 = (fabsf(w[3] * rel.x) + fabsf(w[4] * rel.y)) + fabsf(w[5] * rel.z),
               m2 = (fabsf(w[6] * rel.x) + fabsf(w[7] * rel.y)) + fabsf(w[8] * rel.z);
-  R.slack = 4.0e-6f * ((m0 + m1) + (m2 + tv.slack));
+  R.slack = 4.0e-6f * ((m0 + m1) + (m2 + r6.x));
   trav2_set_ray(R, o, d);
   R.inst = inst; R.spBase = R.sp;
-  R.G = make_uint2(tv.blasRoot, 0x80000000u); // virtual group holding only the BLAS root
+  R.G = make_uint2(f2u(r5.y), 0x80000000u); // virtual group holding only the BLAS root
 }
 __device__ __forceinline__ void trav2_leave(RayTrav2& R)
 {
@@ -558,11 +557,13 @@ __device__ __forceinline__ void wave_tri_batch2(WaveTri& W, uint32_t head, uint3
   const uint32_t inst = (uint32_t)__shfl((int)R.inst, (int)rl);
   const uint32_t rrng = CUTOUT ? (uint32_t)__shfl((int)rng, (int)rl) : 0u;
   if (act) {
-    const uint4 t4 = reinterpret_cast<const uint4*>(sc.blasTris)[bt]; // (i0, i1, i2, prim)
-    const float4* ip = reinterpret_cast<const float4*>(&sc.instances[inst]);
-    const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2];
-    const uint4 tv = reinterpret_cast<const uint4*>(sc.instTrav)[inst]; // (blasRoot, triBase, matFlags, slack)
-    const float4 pa = *reinterpret_cast<const float4*>(&sc.verts[t4.x]), pb = *reinterpret_cast<const float4*>(&sc.verts[t4.y]), pc = *reinterpret_cast<const float4*>(&sc.verts[t4.z]);
+    const float4* tp = reinterpret_cast<const float4*>(&sc.blasTris[bt]);   // one line: p0.xyz p1.x | p1.yz p2.xy | p2.z prim
+    const float4 ta = tp[0], tb = tp[1], tq = tp[2];
+    const float4* ip = reinterpret_cast<const float4*>(&sc.instTrav[inst]); // one line (hot: the walk entered this instance through it)
+    const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2], r5 = ip[5];
+    const uint4 tv = make_uint4(f2u(r5.y), f2u(r5.z), f2u(r5.w), 0u); // (blasRoot, triBase, matFlags, -)
+    const float4 pa = make_float4(ta.x, ta.y, ta.z, 0.0f), pb = make_float4(ta.w, tb.x, tb.y, 0.0f), pc = make_float4(tb.z, tb.w, tq.x, 0.0f);
+    const uint4 t4 = make_uint4(0u, 0u, 0u, f2u(tq.y));
     // host xformPoint (gi_c.cpp): ((a0 p0 + a1 p1) + a2 p2) + a3
     const V3 p0 = v3(((r0.x * pa.x + r0.y * pa.y) + r0.z * pa.z) + r0.w, ((r1.x * pa.x + r1.y * pa.y) + r1.z * pa.z) + r1.w, ((r2.x * pa.x + r2.y * pa.y) + r2.z * pa.z) + r2.w);
     const V3 p1 = v3(((r0.x * pb.x + r0.y * pb.y) + r0.z * pb.z) + r0.w, ((r1.x * pb.x + r1.y * pb.y) + r1.z * pb.z) + r1.w, ((r2.x * pb.x + r2.y * pb.y) + r2.z * pb.z) + r2.w);

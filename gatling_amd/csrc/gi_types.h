@@ -127,10 +127,18 @@ enum : uint32_t {
 };
 
 // Device-side scene view handed to the kernels.
-struct BlasTri { uint32_t vi[3]; uint32_t prim; };                          // absolute vertex indices + gl_PrimitiveID of a mesh triangle, 16 bytes
-struct InstTrav { uint32_t blasRoot, triBase, matFlags; float slack; };     // BLAS root node, scene-order id of the instance's first triangle
-                                                                            // (flat numbering), TriRec::matFlags of its mesh, object-space ray slack
-static_assert(sizeof(BlasTri) == 16 && sizeof(InstTrav) == 16, "two-level records are 16 bytes");
+// Two-level layout records, each ONE cache line (r03: the traversal kernels are bound by the number of distinct lines a lane requests -- tools/ta_calib.hip --
+// so a candidate costs two lines, its mesh triangle and its instance, instead of the six the first version touched: index record, three vertices, instance
+// matrix, instance info):
+struct BlasTri { float p0[3], p1[3], p2[3]; uint32_t prim; uint32_t pad[6]; };  // object-space corners (the mesh's vertex positions, bit for bit) + gl_PrimitiveID, 64 bytes
+struct InstTrav {                                                               // what a walk needs of an instance, 128 bytes
+  float o2w[12];                       // rows of the object->world matrix (candidates are rebuilt in world space with the host's xformPoint arithmetic)
+  float w2o[9];                        // inverse of its 3x3 part (the ray enters the BLAS in object space)
+  uint32_t blasRoot, triBase, matFlags; // BLAS root node, scene-order id of the instance's first triangle (flat numbering), TriRec::matFlags of its mesh
+  float slack;                         // object-space magnitude the transformed ray's rounding error scales with
+  uint32_t pad[7];
+};
+static_assert(sizeof(BlasTri) == 64 && sizeof(InstTrav) == 128, "two-level records are one cache line each");
 struct SceneView {
   const Node8* nodes;      // nodeStrideU4 * 16 bytes apart (80-byte nodes packed, or one per 128-byte line)
   const TriRec* tris;

@@ -403,6 +403,10 @@ int giCTraceRays(GiCScene* scene, uint32_t count, const float* origins /*3*count
  * (k2, bsdf_over_pdf, pdf, event, eval diffuse, eval glossy, eval pdf). */
 int giCDebugEvalBsdf(const GiCMaterialDesc* desc, uint32_t count, const float* in, float* out);
 int giCDebugValidateBvh(const float* triVerts, uint32_t triCount, uint32_t* outNodeCount, uint32_t* outMaxDepth);
+/* [ext] the same host-only check for the partitioned layout incremental transform updates use: `partCount` consecutive triangle ranges, one
+ * subtree each, joined by a top tree over the subtree roots.  Returns the violations of the assembled tree (0 = every triangle reachable and inside every
+ * ancestor slot's box), <0 on error. */
+int giCDebugValidatePartitionedBvh(const float* triVerts, uint32_t triCount, uint32_t partCount, uint32_t* outNodeCount, uint32_t* outMaxDepth);
 
 #ifdef __cplusplus
 }
