@@ -18,6 +18,11 @@ HEADERS = ["gi_types.h", "gi_kernels.h", "gi_device_math.h", "gi_queues.h", "gi_
 # -ffp-contract=off: arithmetic contract.  No fast-math: IEEE divide/sqrt are part of it.
 INCLUDE = os.path.join(_HERE, "..", "include")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-I", INCLUDE]
+# Kernel translation units: no SLP vectorisation.  The vectoriser packs pairs of independent fp32 operations into v_pk_mul / v_pk_add / v_pk_fma, which on
+# gfx950 issue at the rate of the scalar forms (tools/valu_calib.hip) but need their operands in aligned register pairs -- the packing costs v_mov's (k_path_bw:
+# 313 -> 153 static moves, k_trace_dyn 238 -> 161) and registers.  Measured (r03c): C2 7 034 -> 7 506 Msamples/s at spp 128, C3 / C4 unchanged.  Results are
+# bit-identical (packed and scalar fp32 operations round the same way); the hand-written packed fma of the box test stays.
+KERNEL_FLAGS = ["-fno-slp-vectorize"]
 
 
 def materialx_include():
@@ -57,7 +62,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJDIR, exist_ok=True)
 
     def compile_one(src: str) -> None:
-        cmd = [hipcc] + FLAGS + (["-I", mtlx] if mtlx and src == "gtl_shim_mtlx.cpp" else []) + ["-c", src, "-o", _obj(src)]
+        cmd = [hipcc] + FLAGS + (KERNEL_FLAGS if src.endswith(".hip") else []) + (["-I", mtlx] if mtlx and src == "gtl_shim_mtlx.cpp" else []) + ["-c", src, "-o", _obj(src)]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=CSRC)

@@ -356,7 +356,7 @@ struct GiCScene : SceneDevice {
   bool countTraversal = false, kernelTimers = false;
   uint32_t kernelTimerStride = 1;
   uint64_t optPoolSlots = 0, optSampleBufferMb = 0; // 0 = default
-  int32_t optFusedPath = -1; // -1 / 1 = default: LDS-resident scenes run the fused persistent kernels (k_path_bw without NEE, k_path with); 2 = k_path only; 0 = always the wavefront stage kernels
+  int32_t optFusedPath = -1; // -1 = default: LDS-resident scenes run the fused persistent kernel k_path; 1 = k_path_bw (wave-local wavefront) when NEE is off; 2 = k_path; 0 = always the wavefront stage kernels
   int32_t optTraceDyn = -1; // -1 = default; 0 = block-synchronous k_trace everywhere; N = k_trace_dyn refill threshold
   int32_t optDevices = 0;   // 0 = every device the library was initialised on; N = at most N of them
 };
@@ -898,7 +898,7 @@ int giCSetSceneOption(GiCScene* scene, int32_t option, int32_t value)
   if (option == GI_C_SCENE_OPTION_POOL_SLOTS) { scene->optPoolSlots = value > 0 ? (uint64_t)value : 0; return GI_C_OK; }
   if (option == GI_C_SCENE_OPTION_TWO_LEVEL) { scene->optTwoLevel = value < 0 ? -1 : (value ? 1 : 0); scene->dirty |= DIRTY_BVH | DIRTY_FRAMEBUFFER; return GI_C_OK; }
   if (option == GI_C_SCENE_OPTION_TRACE_DYNAMIC) { scene->optTraceDyn = value < 0 ? -1 : (value > 64 ? 64 : value); return GI_C_OK; }
-  if (option == GI_C_SCENE_OPTION_FUSED_PATH) { scene->optFusedPath = value < 0 ? -1 : (value > 2 ? 1 : value); return GI_C_OK; }
+  if (option == GI_C_SCENE_OPTION_FUSED_PATH) { scene->optFusedPath = value < 0 ? -1 : (value > 2 ? -1 : value); return GI_C_OK; }
   if (option == GI_C_SCENE_OPTION_SAMPLE_BUFFER_MB) { scene->optSampleBufferMb = value > 0 ? (uint64_t)value : 0; return GI_C_OK; }
   if (option == GI_C_SCENE_OPTION_DEVICES) { scene->optDevices = value > 0 ? value : 0; scene->dirty |= DIRTY_BVH | DIRTY_FRAMEBUFFER; /* replicas are made with the build */ return GI_C_OK; }
   setError("unknown scene option"); return GI_C_ERROR;
@@ -1402,7 +1402,12 @@ int syncSceneGeometry(GiCScene* s)
     if (!handled) s->dirty |= DIRTY_BVH;
     s->dirty |= DIRTY_FRAMEBUFFER;
   }
-  if (s->dirty & (DIRTY_BVH | DIRTY_MATERIALS)) { if (buildScene(s) != GI_C_OK) return GI_C_ERROR; s->dirty &= ~(DIRTY_BVH | DIRTY_MATERIALS); s->dirty |= DIRTY_FRAMEBUFFER; }
+  if (s->dirty & (DIRTY_BVH | DIRTY_MATERIALS)) {
+    if (buildScene(s) != GI_C_OK) return GI_C_ERROR;
+    s->dirty &= ~(DIRTY_BVH | DIRTY_MATERIALS); s->dirty |= DIRTY_FRAMEBUFFER;
+    static const int envPart = getenv("GATLING_PARTITIONED") ? atoi(getenv("GATLING_PARTITIONED")) : 0; // measurement: lay every freshly built scene out as per-instance subtrees at once
+    if (envPart) { bool handled = false; if (updateTransforms(s, handled) != GI_C_OK) return GI_C_ERROR; }
+  }
   s->dirty &= ~DIRTY_XFORM;
   return GI_C_OK;
 }
@@ -1732,8 +1737,12 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
         chunk = (uint32_t)std::min<uint64_t>(chunk, std::max<uint64_t>(64u, ((uint64_t)U.workTotal / (waves * 16u)) & ~63ull));
         curIter = totalIters; if (timers) sampledIters++;
         if (timers) { (void)hipEventRecord(poolEvent(&D, ev), st); }
-        static const int envBw = getenv("GATLING_PATH_BW") ? atoi(getenv("GATLING_PATH_BW")) : 1;
-        if (envBw && !nee && s->optFusedPath != 2) launchPathBw(st, (uint32_t)ctx.cuCount, s->classMask, s->classTextured != 0u, s->countTraversal, chunk, U, view, ps, D.dCounters.ptr, D.sampleBuf.ptr);
+        // which fused kernel: k_path (one path per lane, in registers) unless the wave-local wavefront k_path_bw is asked for (option 1 / GATLING_PATH_BW=1).  Measured
+        // r03 on C2 (1080p, spp 256, SLP vectorisation off): k_path 55.4 ms per batch, k_path_bw 57.3 -- k_path's 114 VGPRs give 4 resident waves per SIMD (3 blocks
+        // per CU cost 11 %), k_path_bw's 168 VGPRs and 50 KB of LDS per block give 3; at 128 VGPRs k_path_bw spills 43 registers and falls to 84 ms.
+        static const int envBw = getenv("GATLING_PATH_BW") ? atoi(getenv("GATLING_PATH_BW")) : -1;
+        const bool useBw = !nee && (envBw >= 0 ? envBw != 0 : s->optFusedPath == 1);
+        if (useBw) launchPathBw(st, (uint32_t)ctx.cuCount, s->classMask, s->classTextured != 0u, s->countTraversal, chunk, U, view, ps, D.dCounters.ptr, D.sampleBuf.ptr);
         else launchPath(st, (uint32_t)ctx.cuCount, s->classMask, s->classTextured != 0u, s->countTraversal, chunk, U, view, ps, D.dCounters.ptr, D.sampleBuf.ptr);
         if (timers) { (void)hipEventRecord(poolEvent(&D, ev + 1), st); ev += 2; evKind.push_back(1); }
         iters++; totalIters++; traceLaunches++;

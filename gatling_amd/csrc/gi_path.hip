@@ -32,8 +32,11 @@ namespace gi {
 
 constexpr uint32_t PATH_STACK_MAX = 8; // LDS traversal-stack entries per lane: 4 for trees of depth <= 4 (cornell), else 8 (the host checks bvhDepth <= 8)
 
+#ifndef GI_PATH_WAVES
+#define GI_PATH_WAVES 4 // resident waves per SIMD the register allocation aims for (114 VGPRs without a hint)
+#endif
 template <uint32_t KLASS, bool TEXTURED, bool NEE, bool CUTOUT, bool COUNT, uint32_t PATH_STACK>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_path(FrameUniforms U, SceneView sc, PathState st, Counters* cnt, F4* __restrict__ sampleBuf,
+__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(GI_PATH_WAVES, 8))) void k_path(FrameUniforms U, SceneView sc, PathState st, Counters* cnt, F4* __restrict__ sampleBuf,
                                                       uint32_t ldsNodes, uint32_t ldsTris, uint32_t chunk)
 {
   extern __shared__ uint4 s_dyn[];

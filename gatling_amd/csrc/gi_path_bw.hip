@@ -37,8 +37,11 @@ enum : uint32_t { F_THR = 0, F_RAD = 3, F_BITS = 6, F_RNG = 7, F_WORK = 8, F_RO 
 constexpr uint32_t NO_WORK = 0xffffffffu; // F_WORK of a path that carries no sample (initial state)
 constexpr uint32_t PATH_BW_PATHS_DEFAULT = 96u; // paths per wave (GATLING_PATH_BW_PATHS): 3 blocks per CU; measured 96 / 128 / 160 / 192 / 256 -> 7426 / 6431 / 6621 / 6651 / 3814 Msamples/s on C2
 
+#ifndef GI_PATH_BW_WAVES
+#define GI_PATH_BW_WAVES 3 // resident waves per SIMD the register allocation aims for (168 VGPRs: 3; 4 needs <= 128 and spills 43 registers -- experiment knob)
+#endif
 template <uint32_t KLASS, bool TEXTURED, bool CUTOUT, bool COUNT, uint32_t STACK>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_path_bw(FrameUniforms U, SceneView sc, PathState st, Counters* cnt, F4* __restrict__ sampleBuf,
+__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(GI_PATH_BW_WAVES, 8))) void k_path_bw(FrameUniforms U, SceneView sc, PathState st, Counters* cnt, F4* __restrict__ sampleBuf,
                                                          uint32_t ldsNodes, uint32_t ldsTris, uint32_t chunk, uint32_t PW, uint32_t thrShade, uint32_t thrRegen, uint32_t thrDry)
 {
   extern __shared__ uint4 s_dyn[];

@@ -382,10 +382,9 @@ int giCGetRenderStats(const GiCScene* scene, GiCRenderStats* out);
 #define GI_C_SCENE_OPTION_TRACE_DYNAMIC 5
 #define GI_C_SCENE_OPTION_TWO_LEVEL 6     /* [ext] 1: two-level BVH (TLAS over instances + one object-space BLAS per mesh) for scenes beyond LDS; default 0: one
                                              flat BVH over the instanced triangles (faster today); the image does not depend on it */
-/* [ext] Scenes whose whole BVH fits LDS (<= 384 nodes, <= 128 triangles; no medium stack, no dome image) are rendered by the fused
- * persistent kernels (default, -1 / 1: k_path_bw, the wave-local wavefront, when next-event estimation is off, else k_path, one path per
- * lane in registers); 2 = k_path in both cases; 0 = run the wavefront stage kernels on them too.
- * The image does not depend on it. */
+/* [ext] Scenes whose whole BVH fits LDS (<= 384 nodes, <= 128 triangles; no medium stack, no dome image) are rendered by a fused persistent kernel:
+ * -1 (default) / 2 = k_path, one path per lane in registers; 1 = k_path_bw, the wave-local wavefront, when next-event estimation is off (k_path otherwise);
+ * 0 = run the wavefront stage kernels on them too.  The image does not depend on it. */
 #define GI_C_SCENE_OPTION_FUSED_PATH 7
 /* [ext] upper bound on the devices a giCRender of this scene uses (0 = all the library was initialised on; 1 = primary only). */
 #define GI_C_SCENE_OPTION_DEVICES 8

@@ -401,8 +401,8 @@ def test_bsdf_known_answers_on_device(gi, orc):
 
 
 def test_three_pipelines_for_lds_resident_scenes_agree(gi, orc):
-    """The same frame through the wavefront stage kernels (option 0), the lane-per-path fused kernel k_path (2) and the wave-local
-    wavefront k_path_bw (1, the default without NEE): bit-identical images and segment counts, also with cutouts / textures in play and
+    """The same frame through the wavefront stage kernels (option 0), the lane-per-path fused kernel k_path (2, the default) and the wave-local
+    wavefront k_path_bw (1): bit-identical images and segment counts, also with cutouts / textures in play and
     for work totals that do not fill the waves' path pools."""
     from gatling_amd.capi import OPTION_FUSED_PATH
     cases = [(cornell_box(), RenderSettings(spp=6, max_bounces=8), 96, 54), (cornell_box(MAT_DIFFUSE), RenderSettings(spp=3, max_bounces=4), 7, 5),

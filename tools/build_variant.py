@@ -27,7 +27,8 @@ def main():
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
     def compile_one(src):
-        subprocess.check_call([hipcc] + B.FLAGS + extra + ["-c", src, "-o", os.path.join(obj_dir, src + ".o")], cwd=B.CSRC)
+        base = [f for f in B.KERNEL_FLAGS if not ("-fslp-vectorize" in extra and f == "-fno-slp-vectorize")]
+        subprocess.check_call([hipcc] + B.FLAGS + base + extra + ["-c", src, "-o", os.path.join(obj_dir, src + ".o")], cwd=B.CSRC)
 
     with ThreadPoolExecutor(max_workers=3) as pool:
         list(pool.map(compile_one, KERNEL_TUS))
