@@ -30,6 +30,7 @@
 
 namespace gi {
 
+constexpr uint32_t PRE_FIELDS = 10; // prepared camera ray: origin, direction, tMin, tMax, rng state, work item
 constexpr uint32_t PATH_STACK_MAX = 8; // LDS traversal-stack entries per lane: 4 for trees of depth <= 4 (cornell), else 8 (the host checks bvhDepth <= 8)
 
 #ifndef GI_PATH_WAVES
@@ -61,30 +62,53 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(GI_
   TraceCounters tc{0u, 0u}, tcs{0u, 0u};
   uint2 overflow[1];
   RayTrav R;
+  // Camera rays are generated 64 at a time, by ALL lanes, into a per-wave LDS ring (r03): a trip regenerates only the ~45 % of the lanes whose path just ended,
+  // and make_camera_ray (hash, two draws, the Gaussian filter's log / sqrt / sincos, normalise) then ran at that lane utilisation on every trip.  Now the wave
+  // prepares the next 64 work items' rays whenever fewer than 64 are pending (one full-width pass every ~2 trips) and idle lanes just pop them.
+  __shared__ uint32_t s_pre[TRACE_BLOCK / 64][PRE_FIELDS][128]; // ring of 128 prepared rays per wave
+  GI_LDS uint32_t (*pre)[128] = (GI_LDS uint32_t (*)[128])&s_pre[threadIdx.x >> 6][0][0];
+  uint32_t preHead = 0u, preTail = 0u; // wave-uniform ring positions (monotonic; slot = position & 127)
 
   for (;;) {
+    __atomic_signal_fence(__ATOMIC_SEQ_CST); // (compiler only) the ring is exchanged between the lanes of this wave through LDS
     // --- regeneration (rp_main.rgen:213-283): idle lanes take the next work items w = sample * P + pixel
     unsigned long long idle = __ballot(!alive);
-    while (idle && !exhausted) {
-      if (chunkNext == chunkEnd) {
-        uint32_t b = 0u;
-        if (lane == 0u) b = atomicAdd(&cnt->cursor[0][0].v, chunk);
-        b = (uint32_t)__shfl((int)b, 0);
-        if (b >= U.workTotal) { exhausted = true; break; }
-        chunkNext = b; chunkEnd = (U.workTotal - b) < chunk ? U.workTotal : b + chunk;
+    const uint32_t nIdle = (uint32_t)__popcll(idle);
+    if (nIdle) {
+      // top the ring up to at least 64 prepared rays (or whatever work is left): every lane prepares one
+      while (preTail - preHead < 64u && !exhausted) {
+        if (chunkNext == chunkEnd) {
+          uint32_t b = 0u;
+          if (lane == 0u) b = atomicAdd(&cnt->cursor[0][0].v, chunk);
+          b = (uint32_t)__shfl((int)b, 0);
+          if (b >= U.workTotal) { exhausted = true; break; }
+          chunkNext = b; chunkEnd = (U.workTotal - b) < chunk ? U.workTotal : b + chunk;
+        }
+        const uint32_t avail = chunkEnd - chunkNext, take = avail < 64u ? avail : 64u;
+        if (lane < take) {
+          const uint32_t w = chunkNext + lane;
+          const uint32_t pl = w % U.pixelCount, sl = w / U.pixelCount;
+          V3 o, d; float t0, t1; uint32_t r;
+          make_camera_ray(U, tile_to_image_pixel(U, pl), U.sampleOffset + U.batchFirstSample + sl, o, d, t0, t1, r); // :195 (global pixel index: the RNG is tile independent)
+          const uint32_t slot = (preTail + lane) & 127u;
+          pre[0][slot] = f2u(o.x); pre[1][slot] = f2u(o.y); pre[2][slot] = f2u(o.z); pre[3][slot] = f2u(d.x); pre[4][slot] = f2u(d.y); pre[5][slot] = f2u(d.z);
+          pre[6][slot] = f2u(t0); pre[7][slot] = f2u(t1); pre[8][slot] = r; pre[9][slot] = w;
+        }
+        chunkNext += take; preTail += take;
       }
-      const uint32_t nIdle = (uint32_t)__popcll(idle), avail = chunkEnd - chunkNext, take = nIdle < avail ? nIdle : avail;
+      __atomic_signal_fence(__ATOMIC_SEQ_CST);
+      const uint32_t have = preTail - preHead, take = nIdle < have ? nIdle : have;
       const uint32_t rank = (uint32_t)__popcll(idle & below);
       if (!alive && rank < take) {
-        const uint32_t w = chunkNext + rank;
+        const uint32_t slot = (preHead + rank) & 127u;
+        ro = v3(u2f(pre[0][slot]), u2f(pre[1][slot]), u2f(pre[2][slot])); rdv = v3(u2f(pre[3][slot]), u2f(pre[4][slot]), u2f(pre[5][slot]));
+        tMin = u2f(pre[6][slot]); tMax = u2f(pre[7][slot]); rng = pre[8][slot];
+        const uint32_t w = pre[9][slot];
         pixelLocal = w % U.pixelCount; sLocal = w / U.pixelCount;
-        const uint32_t pixelIndex = tile_to_image_pixel(U, pixelLocal); // :195 (global index: the RNG is tile independent)
-        make_camera_ray(U, pixelIndex, U.sampleOffset + U.batchFirstSample + sLocal, ro, rdv, tMin, tMax, rng);
         thr = v3(1.0f, 1.0f, 1.0f); rad = v3(0.0f, 0.0f, 0.0f); bitfield = 0u; // :274-276
         alive = true;
       }
-      chunkNext += take;
-      idle = __ballot(!alive);
+      preHead += take;
     }
     if (!__ballot(alive)) break;
 
