@@ -366,7 +366,7 @@ __device__ inline V3 eon_pi_f(V3 rho, float r, V3 l1, V3 l2)
   const V3 rhoMs = v3((rr.x * avgEF) / (1.0f - rho.x * (1.0f - avgEF)), (rr.y * avgEF) / (1.0f - rho.y * (1.0f - avgEF)), (rr.z * avgEF) / (1.0f - rho.z * (1.0f - avgEF)));
   return rho * ss + rhoMs * ms;
 }
-struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, baseColor; float metalness, alpha, coat, coatAlpha, coatF0, eta, tw, specWeight, baseWeight, diffRough; bool thinWalled; };
+struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, baseColor, ssColor; float metalness, alpha, coat, coatAlpha, coatF0, eta, tw, specWeight, baseWeight, diffRough, ssWeight, ssAniso; bool thinWalled; };
 __device__ __forceinline__ OpbrParams opbr_params(const MaterialRec* m, const ShState& st)
 {
   OpbrParams o; const float* p = m->p;
@@ -384,8 +384,20 @@ __device__ __forceinline__ OpbrParams opbr_params(const MaterialRec* m, const Sh
   if (st.texMask & (1u << TEX_METALLIC)) o.metalness = st.texMetallic;
   // coat_substrate_attenuated = base_substrate * modulated_base_darkening * coat_attenuation (open_pbr_surface.mtlx:538-552)
   o.coatTint = o.coatTint * opbr_base_darkening(o.baseColor, o.specWeight, o.metalness, o.coat, o.coatF0, p[22], p[48]);
+  // thin-walled subsurface (open_pbr_surface.mtlx:140-196, 207-218); the volumetric form of non-thin-walled materials is not modelled
+  o.ssWeight = o.thinWalled ? p[55] : 0.0f;
+  o.ssColor = v3(p[56], p[57], p[58]); o.ssAniso = p[59];
   return o;
 }
+// the colour factors of subsurface_thin_walled's two lobes (the mix weight 1/2 is the lobe-selection probability and cancels): see the oracle's opbr_ss_*
+__device__ __forceinline__ V3 opbr_ss_color(const OpbrParams& o) { return v3(fmax2(o.ssColor.x, 0.0f), fmax2(o.ssColor.y, 0.0f), fmax2(o.ssColor.z, 0.0f)); }
+__device__ __forceinline__ V3 opbr_ss_reflect(const OpbrParams& o, V3 l1, V3 l2)
+{
+  const V3 c = opbr_ss_color(o);
+  const V3 rho = (o.diffRough > 0.0f) ? eon_pi_f(c, o.diffRough, l1, l2) : c;
+  return rho * (o.ssColor * (1.0f - o.ssAniso));
+}
+__device__ __forceinline__ V3 opbr_ss_transmit(const OpbrParams& o) { return opbr_ss_color(o) * (o.ssColor * (1.0f + o.ssAniso)); }
 
 // The lobe is chosen first (cheap, divergent), then ONE micro-facet sample serves whichever glossy lobe a lane took -- coat, metal,
 // dielectric reflection, transmission differ in the roughness they pass and in their weights, not in the sampling arithmetic -- so a wave
@@ -414,10 +426,30 @@ __device__ inline void opbr_sample(const MaterialRec* m, const ShState& st, V3 k
     }
   }
   if (lobe == 4u) {
-    V3 l = gi_sample_hemisphere(x0, x1);
+    const float pBase = (1.0f - Fc) * (1.0f - o.metalness) * (1.0f - Fd) * (1.0f - o.tw);
+    V3 l = gi_sample_hemisphere(x0, x1); // cosine-weighted, for every lobe of the opaque base
+    if (o.ssWeight > 0.0f) { // thin-walled subsurface takes subsurface_weight of the opaque base, half of it reflected, half transmitted
+      z = (z - o.tw) / (1.0f - o.tw);
+      if (z < o.ssWeight) {
+        const bool through = !((z / o.ssWeight) < 0.5f);
+        if (!(l.z > 0.0f)) return;
+        if (through) { // translucent_bsdf: Lambert on the far side
+          V3 k2 = to_world(st, v3(l.x, l.y, -l.z));
+          if (!(dot(k2, st.geomNormal) < 0.0f)) return;
+          out.k2 = k2; out.pdf = pBase * o.ssWeight * 0.5f * (l.z / GI_PI);
+          out.overPdf = opbr_ss_transmit(o) * o.coatTint; out.event = EV_DIFFUSE | EV_TRANSMISSION;
+          return;
+        }
+        V3 k2 = to_world(st, l);
+        if (!(dot(k2, st.geomNormal) > 0.0f)) return;
+        out.k2 = k2; out.pdf = pBase * o.ssWeight * 0.5f * (l.z / GI_PI);
+        out.overPdf = opbr_ss_reflect(o, l1, l) * o.coatTint; out.event = EV_DIFFUSE | EV_REFLECTION;
+        return;
+      }
+    }
     V3 k2 = to_world(st, l);
     if (!(l.z > 0.0f) || !(dot(k2, st.geomNormal) > 0.0f)) return;
-    out.k2 = k2; out.pdf = (1.0f - Fc) * (1.0f - o.metalness) * (1.0f - Fd) * (1.0f - o.tw) * (l.z / GI_PI);
+    out.k2 = k2; out.pdf = pBase * (1.0f - o.ssWeight) * (l.z / GI_PI);
     V3 rho = (o.diffRough > 0.0f) ? eon_pi_f(o.baseColor, o.diffRough, l1, l) * o.baseWeight : o.albedo;
     out.overPdf = rho * o.coatTint; out.event = EV_DIFFUSE | EV_REFLECTION;
     return;
@@ -480,7 +512,14 @@ __device__ inline void opbr_evaluate(const MaterialRec* m, const ShState& st, V3
   gl = gl + ((o.specColor * o.coatTint) * (Fdh * fs)) * (base * diel);
   out.glossy = gl;
   V3 rho = (o.diffRough > 0.0f && l2.z > 0.0f) ? eon_pi_f(o.baseColor, o.diffRough, l1, l2) * o.baseWeight : o.albedo;
-  out.diffuse = (rho * o.coatTint) * (cd * base * diel * (1.0f - Fd) * (1.0f - o.tw));
+  const float wBase = cd * base * diel * (1.0f - Fd) * (1.0f - o.tw);
+  if (o.ssWeight > 0.0f) { // reflection side of the thin-walled subsurface mix (the transmitted half lies below the surface: not reached by NEE)
+    const V3 ss = (l2.z > 0.0f) ? opbr_ss_reflect(o, l1, l2) : v3(0.0f, 0.0f, 0.0f);
+    out.diffuse = ((rho * (1.0f - o.ssWeight) + ss * (o.ssWeight * 0.5f)) * o.coatTint) * wBase;
+    out.pdf = Fc * pc + base * (o.metalness * ps + diel * (Fd * ps + (1.0f - Fd) * (1.0f - o.tw) * ((1.0f - o.ssWeight) + o.ssWeight * 0.5f) * cd));
+    return;
+  }
+  out.diffuse = (rho * o.coatTint) * wBase;
   out.pdf = Fc * pc + base * (o.metalness * ps + diel * (Fd * ps + (1.0f - Fd) * (1.0f - o.tw) * cd));
 }
 

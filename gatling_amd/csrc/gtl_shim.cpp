@@ -230,6 +230,7 @@ namespace gtl
       p[GI_C_P_TRANSMISSION_COLOR] = p[GI_C_P_TRANSMISSION_COLOR + 1] = p[GI_C_P_TRANSMISSION_COLOR + 2] = 1.0f;
       p[GI_C_P_COAT_COLOR] = p[GI_C_P_COAT_COLOR + 1] = p[GI_C_P_COAT_COLOR + 2] = 1.0f; p[GI_C_P_COAT_IOR] = 1.6f; p[GI_C_P_COAT_DARKENING] = 1.0f;
       p[GI_C_P_FUZZ_COLOR] = p[GI_C_P_FUZZ_COLOR + 1] = p[GI_C_P_FUZZ_COLOR + 2] = 1.0f; p[GI_C_P_FUZZ_ROUGHNESS] = 0.5f;
+      p[GI_C_P_SUBSURFACE_COLOR] = p[GI_C_P_SUBSURFACE_COLOR + 1] = p[GI_C_P_SUBSURFACE_COLOR + 2] = 0.8f;
       float lum = 0.0f, ecol[3] = {1.0f, 1.0f, 1.0f};
       setN(n, "base_weight", p + GI_C_P_BASE_WEIGHT, 1); setN(n, "base_color", p + GI_C_P_BASE_COLOR, 3);
       setN(n, "base_diffuse_roughness", p + GI_C_P_DIFFUSE_ROUGHNESS, 1); setN(n, "base_metalness", p + GI_C_P_METALLIC, 1);
@@ -242,6 +243,8 @@ namespace gtl
       setN(n, "coat_roughness", p + GI_C_P_CLEARCOAT_ROUGHNESS, 1); setN(n, "coat_ior", p + GI_C_P_COAT_IOR, 1); setN(n, "coat_darkening", p + GI_C_P_COAT_DARKENING, 1);
       setN(n, "fuzz_weight", p + GI_C_P_FUZZ_WEIGHT, 1); setN(n, "fuzz_color", p + GI_C_P_FUZZ_COLOR, 3); setN(n, "fuzz_roughness", p + GI_C_P_FUZZ_ROUGHNESS, 1); // carried, not modelled
       setN(n, "geometry_thin_walled", p + GI_C_P_THIN_WALLED, 1);
+      setN(n, "subsurface_weight", p + GI_C_P_SUBSURFACE_WEIGHT, 1); setN(n, "subsurface_color", p + GI_C_P_SUBSURFACE_COLOR, 3);
+      setN(n, "subsurface_scatter_anisotropy", p + GI_C_P_SUBSURFACE_ANISOTROPY, 1); // (subsurface_radius / _radius_scale only shape the volumetric form, which is not modelled)
       setN(n, "emission_luminance", &lum, 1); setN(n, "emission_color", ecol, 3); setN(n, "geometry_opacity", p + GI_C_P_OPACITY, 1);
       for (int i = 0; i < 3; i++) p[GI_C_P_EMISSION + i] = lum * ecol[i];
       bind("base_color", GI_C_TEX_BASE_COLOR); bind("specular_roughness", GI_C_TEX_ROUGHNESS); bind("base_metalness", GI_C_TEX_METALLIC);
@@ -358,7 +361,8 @@ namespace gtl
         {"base_weight", 1}, {"base_color", 3}, {"base_diffuse_roughness", 1}, {"base_metalness", 1}, {"specular_weight", 1}, {"specular_color", 3}, {"specular_roughness", 1},
         {"specular_ior", 1}, {"transmission_weight", 1}, {"transmission_color", 3}, {"transmission_depth", 1}, {"transmission_scatter", 3}, {"transmission_scatter_anisotropy", 1},
         {"coat_weight", 1}, {"coat_color", 3}, {"coat_roughness", 1}, {"coat_ior", 1}, {"coat_darkening", 1}, {"emission_luminance", 1}, {"emission_color", 3},
-        {"geometry_opacity", 1}, {"fuzz_weight", 1}, {"fuzz_color", 3}, {"fuzz_roughness", 1}, {"geometry_thin_walled", 1}};
+        {"geometry_opacity", 1}, {"fuzz_weight", 1}, {"fuzz_color", 3}, {"fuzz_roughness", 1}, {"geometry_thin_walled", 1},
+        {"subsurface_weight", 1}, {"subsurface_color", 3}, {"subsurface_scatter_anisotropy", 1}};
       for (const auto& k : kOpbr) {
         float v[3];
         if (!num(k.name, v, k.n)) continue;

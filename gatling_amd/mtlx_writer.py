@@ -51,6 +51,8 @@ def _inputs(m: S.MaterialDesc):
         ("coat_roughness", "float", _f(p[S.P_CLEARCOAT_ROUGHNESS])), ("coat_ior", "float", _f(p[S.P_COAT_IOR])), ("coat_darkening", "float", _f(p[S.P_COAT_DARKENING])),
         ("fuzz_weight", "float", _f(p[S.P_FUZZ_WEIGHT])), ("fuzz_color", "color3", _vals(p, S.P_FUZZ_COLOR, 3)), ("fuzz_roughness", "float", _f(p[S.P_FUZZ_ROUGHNESS])),
         ("geometry_thin_walled", "boolean", "true" if p[S.P_THIN_WALLED] != 0.0 else "false"),
+        ("subsurface_weight", "float", _f(p[S.P_SUBSURFACE_WEIGHT])), ("subsurface_color", "color3", _vals(p, S.P_SUBSURFACE_COLOR, 3)),
+        ("subsurface_scatter_anisotropy", "float", _f(p[S.P_SUBSURFACE_ANISOTROPY])),
         # the parameter block keeps luminance x colour: luminance 1 and the product as the colour reproduce it exactly
         ("emission_luminance", "float", "1" if em.any() else "0"), ("emission_color", "color3", _vals(p, S.P_EMISSION, 3) if em.any() else "1, 1, 1"),
         ("geometry_opacity", "float", _f(p[S.P_OPACITY]))]

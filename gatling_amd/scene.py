@@ -52,6 +52,9 @@ P_FUZZ_WEIGHT = 49
 P_FUZZ_COLOR = 50                    # 3
 P_FUZZ_ROUGHNESS = 53
 P_THIN_WALLED = 54
+P_SUBSURFACE_WEIGHT = 55
+P_SUBSURFACE_COLOR = 56              # 3
+P_SUBSURFACE_ANISOTROPY = 59
 P_COUNT = 64
 
 
@@ -104,7 +107,8 @@ def _open_pbr(name="mat", base_weight=1.0, base_color=(0.8, 0.8, 0.8), base_meta
               transmission_color=(1, 1, 1), transmission_depth=0.0, coat_weight=0.0, coat_color=(1, 1, 1), coat_roughness=0.0,
               coat_ior=1.6, emission_luminance=0.0, emission_color=(1, 1, 1), base_diffuse_roughness=0.0,
               transmission_scatter=(0, 0, 0), transmission_scatter_anisotropy=0.0, coat_darkening=1.0, fuzz_weight=0.0,
-              fuzz_color=(1, 1, 1), fuzz_roughness=0.5, geometry_thin_walled=False) -> MaterialDesc:
+              fuzz_color=(1, 1, 1), fuzz_roughness=0.5, geometry_thin_walled=False, subsurface_weight=0.0, subsurface_color=(0.8, 0.8, 0.8),
+              subsurface_scatter_anisotropy=0.0) -> MaterialDesc:
     """open_pbr_surface inputs with the defaults of src/gi/mtlx/open_pbr_surface.mtlx:11-92 (the lobes this core implements)."""
     p = np.zeros(P_COUNT, np.float32)
     p[P_BASE_COLOR:P_BASE_COLOR + 3] = base_color
@@ -131,6 +135,9 @@ def _open_pbr(name="mat", base_weight=1.0, base_color=(0.8, 0.8, 0.8), base_meta
     p[P_FUZZ_COLOR:P_FUZZ_COLOR + 3] = fuzz_color
     p[P_FUZZ_ROUGHNESS] = fuzz_roughness
     p[P_THIN_WALLED] = 1.0 if geometry_thin_walled else 0.0
+    p[P_SUBSURFACE_WEIGHT] = subsurface_weight         # modelled for thin-walled materials (open_pbr_surface.mtlx:140-196); the volumetric form is not
+    p[P_SUBSURFACE_COLOR:P_SUBSURFACE_COLOR + 3] = subsurface_color
+    p[P_SUBSURFACE_ANISOTROPY] = subsurface_scatter_anisotropy
     return MaterialDesc(name=name, klass=MAT_OPEN_PBR, params=p)
 
 

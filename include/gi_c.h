@@ -182,6 +182,9 @@ typedef struct GiCRenderParams {
 #define GI_C_P_FUZZ_WEIGHT 49      /* OpenPBR fuzz_weight / fuzz_color (3) / fuzz_roughness (:57-59): accepted and carried, the sheen lobe is not modelled */
 #define GI_C_P_FUZZ_COLOR 50
 #define GI_C_P_FUZZ_ROUGHNESS 53
+#define GI_C_P_SUBSURFACE_WEIGHT 55  /* OpenPBR subsurface_weight (open_pbr_surface.mtlx:43, 213-218); modelled for thin-walled materials (:140-196), else treated as 0 */
+#define GI_C_P_SUBSURFACE_COLOR 56   /* 3: subsurface_color (:45), default 0.8 */
+#define GI_C_P_SUBSURFACE_ANISOTROPY 59 /* subsurface_scatter_anisotropy (:51) */
 #define GI_C_P_THIN_WALLED 54      /* OpenPBR geometry_thin_walled (:88) != 0: MDL thin_walled semantics (rp_main.chit:153-157, 188-189, 447) */
                                    /* slots 55..63: reserved, must be 0 */
 

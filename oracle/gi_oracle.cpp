@@ -942,7 +942,7 @@ inline V3 eon_pi_f(V3 rho, float r, V3 l1, V3 l2)
   const V3 rhoMs = v3((rr.x * avgEF) / (1.0f - rho.x * (1.0f - avgEF)), (rr.y * avgEF) / (1.0f - rho.y * (1.0f - avgEF)), (rr.z * avgEF) / (1.0f - rho.z * (1.0f - avgEF)));
   return rho * ss + rhoMs * ms;
 }
-struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, sigmaA, sigmaS, baseColor, coatColor; float metalness, alpha, coat, coatAlpha, coatF0, eta, tw, specWeight, anisotropy, baseWeight, diffRough; bool thinWalled; };
+struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, sigmaA, sigmaS, baseColor, coatColor, ssColor; float metalness, alpha, coat, coatAlpha, coatF0, eta, tw, specWeight, anisotropy, baseWeight, diffRough, ssWeight, ssAniso; bool thinWalled; };
 inline OpbrParams opbr_params(const OrcMaterial& m)
 {
   OpbrParams o; const float* p = m.p;
@@ -984,8 +984,25 @@ inline OpbrParams opbr_params(const OrcMaterial& m)
   o.sigmaA = (depth > 0.0f) ? ab : v3(0, 0, 0);
   o.sigmaS = sc;
   o.anisotropy = p[ORC_P_TRANSMISSION_SCATTER_ANISOTROPY];
+  // thin-walled subsurface (open_pbr_surface.mtlx:140-196, 207-218): opaque_base = mix(diffuse_bsdf, subsurface_thin_walled, subsurface_weight); the
+  // volumetric subsurface_bsdf of non-thin-walled materials is not modelled (weight treated as 0)
+  o.ssWeight = o.thinWalled ? p[ORC_P_SUBSURFACE_WEIGHT] : 0.0f;
+  o.ssColor = v3(p + ORC_P_SUBSURFACE_COLOR); o.ssAniso = p[ORC_P_SUBSURFACE_ANISOTROPY];
   return o;
 }
+
+// subsurface_thin_walled = mix(reflection, transmission, 0.5) (:192-196) with
+//   reflection   = oren_nayar_diffuse_bsdf(color = max(subsurface_color, 0), roughness = base_diffuse_roughness) * (subsurface_color * (1 - anisotropy))   (:141-160)
+//   transmission = translucent_bsdf(color = max(subsurface_color, 0)) * (subsurface_color * (1 + anisotropy))                                              (:161-177)
+// The two lobes are chosen with the mix weight 1/2, so that weight cancels in bsdf / pdf; these are the remaining colour factors.
+inline V3 opbr_ss_color(const OpbrParams& o) { return v3(fmax2(o.ssColor.x, 0.0f), fmax2(o.ssColor.y, 0.0f), fmax2(o.ssColor.z, 0.0f)); }
+inline V3 opbr_ss_reflect(const OpbrParams& o, V3 l1, V3 l2)
+{
+  const V3 c = opbr_ss_color(o);
+  const V3 rho = (o.diffRough > 0.0f) ? eon_pi_f(c, o.diffRough, l1, l2) : c;
+  return rho * (o.ssColor * (1.0f - o.ssAniso));
+}
+inline V3 opbr_ss_transmit(const OpbrParams& o) { return opbr_ss_color(o) * (o.ssColor * (1.0f + o.ssAniso)); }
 
 void opbr_sample(const OrcMaterial& m, const State& st, V3 k1, const float xi[4], bool frontFace, BsdfSample& out)
 {
@@ -1048,10 +1065,30 @@ void opbr_sample(const OrcMaterial& m, const State& st, V3 k1, const float xi[4]
     out.overPdf = (o.transTint * o.coatTint) * w; out.event = EV_GLOSSY | EV_TRANSMISSION;
     return;
   }
-  V3 l = sample_hemisphere(xi[0], xi[1]); // opaque base: Lambert, or energy-preserving Oren-Nayar when base_diffuse_roughness > 0
-  V3 k2 = to_world(st, l);
+  const float pBase = (1.0f - Fc) * (1.0f - o.metalness) * (1.0f - Fd) * (1.0f - o.tw);
+  V3 l = sample_hemisphere(xi[0], xi[1]); // cosine-weighted, for every lobe of the opaque base
+  if (o.ssWeight > 0.0f) { // thin-walled subsurface takes subsurface_weight of the opaque base, half of it reflected, half transmitted
+    z = (z - o.tw) / (1.0f - o.tw);
+    if (z < o.ssWeight) {
+      const bool through = !((z / o.ssWeight) < 0.5f);
+      if (!(l.z > 0.0f)) return;
+      if (through) { // translucent_bsdf: Lambert on the far side
+        V3 k2 = to_world(st, v3(l.x, l.y, -l.z));
+        if (!(dot(k2, st.geomNormal) < 0.0f)) return;
+        out.k2 = k2; out.pdf = pBase * o.ssWeight * 0.5f * (l.z / ORC_PI);
+        out.overPdf = opbr_ss_transmit(o) * o.coatTint; out.event = EV_DIFFUSE | EV_TRANSMISSION;
+        return;
+      }
+      V3 k2 = to_world(st, l);
+      if (!(dot(k2, st.geomNormal) > 0.0f)) return;
+      out.k2 = k2; out.pdf = pBase * o.ssWeight * 0.5f * (l.z / ORC_PI);
+      out.overPdf = opbr_ss_reflect(o, l1, l) * o.coatTint; out.event = EV_DIFFUSE | EV_REFLECTION;
+      return;
+    }
+  }
+  V3 k2 = to_world(st, l); // opaque base: Lambert, or energy-preserving Oren-Nayar when base_diffuse_roughness > 0
   if (!(l.z > 0.0f) || !(dot(k2, st.geomNormal) > 0.0f)) return;
-  out.k2 = k2; out.pdf = (1.0f - Fc) * (1.0f - o.metalness) * (1.0f - Fd) * (1.0f - o.tw) * (l.z / ORC_PI);
+  out.k2 = k2; out.pdf = pBase * (1.0f - o.ssWeight) * (l.z / ORC_PI);
   V3 rho = (o.diffRough > 0.0f) ? eon_pi_f(o.baseColor, o.diffRough, l1, l) * o.baseWeight : o.albedo;
   out.overPdf = rho * o.coatTint; out.event = EV_DIFFUSE | EV_REFLECTION;
 }
@@ -1076,7 +1113,14 @@ void opbr_evaluate(const OrcMaterial& m, const State& st, V3 k1, V3 k2, bool fro
   gl = gl + ((o.specColor * o.coatTint) * (Fdh * fs)) * (base * diel);
   out.glossy = gl;
   V3 rho = (o.diffRough > 0.0f && l2.z > 0.0f) ? eon_pi_f(o.baseColor, o.diffRough, l1, l2) * o.baseWeight : o.albedo;
-  out.diffuse = (rho * o.coatTint) * (cd * base * diel * (1.0f - Fd) * (1.0f - o.tw));
+  const float wBase = cd * base * diel * (1.0f - Fd) * (1.0f - o.tw);
+  if (o.ssWeight > 0.0f) { // reflection side of the thin-walled subsurface mix (the transmitted half lies below the surface: not reached by NEE)
+    const V3 ss = (l2.z > 0.0f) ? opbr_ss_reflect(o, l1, l2) : v3(0, 0, 0);
+    out.diffuse = ((rho * (1.0f - o.ssWeight) + ss * (o.ssWeight * 0.5f)) * o.coatTint) * wBase;
+    out.pdf = Fc * pc + base * (o.metalness * ps + diel * (Fd * ps + (1.0f - Fd) * (1.0f - o.tw) * ((1.0f - o.ssWeight) + o.ssWeight * 0.5f) * cd));
+    return;
+  }
+  out.diffuse = (rho * o.coatTint) * wBase;
   out.pdf = Fc * pc + base * (o.metalness * ps + diel * (Fd * ps + (1.0f - Fd) * (1.0f - o.tw) * cd));
 }
 

@@ -392,7 +392,11 @@ def test_bsdf_known_answers_on_device(gi, orc):
             MaterialDesc.open_pbr(transmission_weight=0.6, base_metalness=0.3, coat_weight=0.4, specular_ior=1.33),
             MaterialDesc.open_pbr(base_color=(0.8, 0.4, 0.2), base_diffuse_roughness=0.7, coat_weight=1.0, coat_roughness=0.5, coat_color=(0.9, 0.8, 0.7), coat_darkening=0.6),
             MaterialDesc.open_pbr(base_color=(0.5, 0.5, 0.9), base_diffuse_roughness=1.0, specular_weight=0.3, base_weight=0.8),
-            MaterialDesc.open_pbr(transmission_weight=1.0, specular_roughness=0.3, specular_ior=1.45, geometry_thin_walled=True)]
+            MaterialDesc.open_pbr(transmission_weight=1.0, specular_roughness=0.3, specular_ior=1.45, geometry_thin_walled=True),
+            # thin-walled subsurface (open_pbr_surface.mtlx:140-196): alone, and mixed with the base diffuse under a coat with a rough Oren-Nayar reflection
+            MaterialDesc.open_pbr(base_color=(0.2, 0.4, 0.8), geometry_thin_walled=True, subsurface_weight=1.0, subsurface_color=(0.9, 0.6, 0.3), subsurface_scatter_anisotropy=0.25),
+            MaterialDesc.open_pbr(base_color=(0.7, 0.7, 0.2), geometry_thin_walled=True, subsurface_weight=0.55, subsurface_color=(0.4, 0.8, 0.5), subsurface_scatter_anisotropy=-0.4,
+                                  base_diffuse_roughness=0.6, coat_weight=0.5, coat_roughness=0.15, transmission_weight=0.2)]
     items[: n // 2, 21] = 0.75  # xi.w >= 0.5: the debug hook shades these as back faces (eta inverted)
     for m in mats:
         got, ref = gi.bsdf_debug(m, items), orc.bsdf_debug(m, items)
@@ -1022,3 +1026,27 @@ def test_full_size_furnace(gi):
         sc.close()
     assert st["segments"] == 1920 * 1080 * 4 * bounces
     np.testing.assert_allclose(img[..., :3], sum(albedo ** k for k in range(bounces)), rtol=1e-5)
+
+
+def test_thin_walled_subsurface_scene_parity(gi, orc):
+    """Leaf cards with a thin-walled subsurface material (half of the subsurface share is diffusely transmitted: light reaches the floor behind the cards) lit by
+    a rect light with NEE: image and counters bit-identical to the oracle; the cards must let light through."""
+    from gatling_amd.scenes import leaf_card_scene
+    imgs = {}
+    for w in (0.0, 0.9):
+        desc = leaf_card_scene()
+        for m in desc.materials:
+            if m.klass == 2:  # the cards' OpenPBR material
+                m.params[54] = 1.0; m.params[55] = w; m.params[56:59] = (0.35, 0.85, 0.25); m.params[59] = 0.3  # thin-walled, subsurface weight / colour / anisotropy
+        rs = RenderSettings(spp=4, max_bounces=6, next_event_estimation=True)
+        ref, cnt = orc.render(desc, rs, 80, 45, threads=8)
+        sc = gi.Scene(desc)
+        try:
+            img = sc.render(rs, 80, 45)
+            st = sc.stats()
+        finally:
+            sc.close()
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), w
+        assert st["segments"] == cnt["segments"] and st["shadowRays"] == cnt["shadow_rays"]
+        imgs[w] = img
+    assert not np.array_equal(imgs[0.0], imgs[0.9])

@@ -133,7 +133,10 @@ def _closed_form_materials():
             M.open_pbr(base_color=(1, 1, 1), transmission_weight=1.0, specular_roughness=0.2),
             M.open_pbr(base_color=(1, 1, 1), base_diffuse_roughness=1.0, specular_weight=0.0),      # energy-preserving Oren-Nayar alone
             M.open_pbr(base_color=(1, 1, 1), base_diffuse_roughness=0.6, coat_weight=1.0, coat_roughness=0.4, coat_darkening=1.0),
-            M.open_pbr(base_color=(1, 1, 1), transmission_weight=1.0, specular_roughness=0.3, geometry_thin_walled=True)]
+            M.open_pbr(base_color=(1, 1, 1), transmission_weight=1.0, specular_roughness=0.3, geometry_thin_walled=True),
+            M.open_pbr(base_color=(1, 1, 1), geometry_thin_walled=True, subsurface_weight=1.0, subsurface_color=(1, 1, 1), specular_weight=0.0),   # thin-walled subsurface alone
+            M.open_pbr(base_color=(1, 1, 1), geometry_thin_walled=True, subsurface_weight=0.6, subsurface_color=(1, 1, 1), subsurface_scatter_anisotropy=0.4,
+                       base_diffuse_roughness=0.5, coat_weight=0.5, coat_roughness=0.2)]
 
 
 def test_closed_form_bsdfs_conserve_energy(orc):
@@ -152,7 +155,7 @@ def test_closed_form_evaluate_matches_sampling(orc):
     sampled weight of the reflected events, and the evaluate pdf integrates to the probability of reflecting."""
     rng = np.random.default_rng(22)
     mats = _closed_form_materials()
-    for m in mats[:7] + mats[8:10]:  # the refraction lobes have no evaluate counterpart on the reflection side
+    for m in mats[:7] + mats[8:10] + mats[11:]:  # the refraction lobes have no evaluate counterpart on the reflection side
         items = _frames(200000, rng, 0.7)
         out = orc.bsdf_debug(m, items)
         refl = (out[:, 7].astype(int) & 8) != 0
@@ -160,6 +163,37 @@ def test_closed_form_evaluate_matches_sampling(orc):
         integ = (out[:, 8:11] + out[:, 11:14]).mean(axis=0) * (2 * np.pi)  # uniform hemisphere pdf = 1/(2 pi); bsdf*cos is returned
         np.testing.assert_allclose(integ, sampled, rtol=0.06, atol=0.01)
         np.testing.assert_allclose(out[:, 14].mean() * 2 * np.pi, refl.mean(), rtol=0.06, atol=0.01)
+
+
+def test_thin_walled_subsurface_lobes(orc):
+    """open_pbr_surface.mtlx:140-196, 207-218: opaque_base = mix(diffuse, subsurface_thin_walled, subsurface_weight) with
+    subsurface_thin_walled = 1/2 oren_nayar(max(c, 0)) * c (1 - g) + 1/2 translucent(max(c, 0)) * c (1 + g).  Known answers of the sampling routine for a
+    thin-walled sheet without specular reflection (F = 0) -- and: the volumetric form of a non-thin-walled material is not modelled (weight ignored)."""
+    rng = np.random.default_rng(5)
+    c, g, w = np.float32([0.9, 0.6, 0.3]), 0.25, 0.7
+    base = np.float32([0.2, 0.4, 0.8])
+    m = MaterialDesc.open_pbr(base_color=tuple(base), geometry_thin_walled=True, subsurface_weight=w, subsurface_color=tuple(c), subsurface_scatter_anisotropy=g,
+                              specular_weight=0.0)
+    out = orc.bsdf_debug(m, _frames(400000, rng, 0.8))
+    ev = out[:, 7].astype(int)
+    trans, refl = (ev & 16) != 0, (ev & 8) != 0
+    # lobe probabilities: transmitted half of the subsurface share, everything else reflected (cosine sampling never fails on a flat frame)
+    np.testing.assert_allclose(trans.mean(), 0.5 * w, atol=0.004)
+    np.testing.assert_allclose(refl.mean(), 1.0 - 0.5 * w, atol=0.004)
+    assert np.all(out[trans, 2] < 0.0) and np.all(out[refl, 2] > 0.0)                        # k2 below / above the surface
+    np.testing.assert_allclose(out[trans, 3:6], np.tile(c * c * np.float32(1 + g), (trans.sum(), 1)), rtol=2e-6)   # translucent: colour^2 (1 + g)
+    w_refl = np.unique(np.round(out[refl, 3:6], 5), axis=0)
+    expect = {tuple(np.round(base, 5)), tuple(np.round(c * c * np.float32(1 - g), 5))}        # base Lambert | subsurface reflection colour^2 (1 - g)
+    assert {tuple(r) for r in w_refl} == expect, w_refl
+    # evaluate() on the reflection side integrates to the mean sampled reflection weight; its pdf to the reflection probability
+    integ = (out[:, 8:11] + out[:, 11:14]).mean(axis=0) * (2 * np.pi)
+    np.testing.assert_allclose(integ, (out[:, 3:6] * refl[:, None]).mean(axis=0), rtol=0.02)
+    np.testing.assert_allclose(out[:, 14].mean() * 2 * np.pi, refl.mean(), rtol=0.02)
+    # not thin-walled: subsurface_weight changes nothing (volumetric subsurface_bsdf is not modelled)
+    a = MaterialDesc.open_pbr(base_color=tuple(base), subsurface_weight=w, subsurface_color=tuple(c))
+    b = MaterialDesc.open_pbr(base_color=tuple(base))
+    items = _frames(2000, rng, 0.6)
+    assert np.array_equal(orc.bsdf_debug(a, items), orc.bsdf_debug(b, items))
 
 
 def test_expf_polynomial(orc):
