@@ -292,7 +292,7 @@ struct SceneDevice {
   DeviceBuffer<MeshRec> dMeshes; DeviceBuffer<float> dSceneData;
   std::vector<DeviceBuffer<float>*> dTexels; DeviceBuffer<TextureRec> dTextures; // device copies (rebuilt with the materials)
   DeviceBuffer<Node8> dNodes; DeviceBuffer<uint4> dNodesLine; DeviceBuffer<TriRec> dTris; DeviceBuffer<InstanceRec> dInstances;
-  DeviceBuffer<FVertex> dVerts; DeviceBuffer<MaterialRec> dMaterials; DeviceBuffer<int32_t> dTriFaceId;
+  DeviceBuffer<FVertex> dVerts; DeviceBuffer<MaterialRec> dMaterials; DeviceBuffer<int32_t> dTriFaceId; DeviceBuffer<TriShade> dTriShade;
   DeviceBuffer<SphereLightRec> dSphere; DeviceBuffer<DistantLightRec> dDistant; DeviceBuffer<RectLightRec> dRect; DeviceBuffer<DiskLightRec> dDisk;
   DeviceBuffer<Node8> dTlasNodes, dBlasNodes; DeviceBuffer<uint32_t> dTlasItems, dFlatOfOrig; DeviceBuffer<BlasTri> dBlasTris; DeviceBuffer<InstTrav> dInstTrav;
   // path state
@@ -314,7 +314,7 @@ struct SceneDevice {
 
 // The scene as host arrays (built once per scene change, kept for incremental transform updates) ...
 struct TwoLevelHost { std::vector<Node8> tlasNodes, blasNodes; std::vector<uint32_t> tlasItems; std::vector<BlasTri> blasTris; std::vector<InstTrav> instTrav; };
-struct MeshBuild { const GiCMesh* m; uint32_t vertexOffset, matFlags, instFirst, instCount, triFirst; uint32_t meshIdx; std::vector<int32_t> faceIdAov; };
+struct MeshBuild { const GiCMesh* m; uint32_t vertexOffset, matFlags, instFirst, instCount, triFirst; uint32_t meshIdx; std::vector<int32_t> faceIdAov; uint32_t shadeBase = 0; };
 // One flattened mesh instance of a PARTITIONED scene (after the first transform edit): its own subtree in its own node range, its triangles in its own
 // (scene-order) range, joined by a top tree over the subtree roots (bvh8.h buildTopBvh8).  Moving it rebuilds these ranges and the top tree only.
 struct InstPart { uint32_t meshBuild, instInMesh; uint32_t triFirst, nf; uint32_t nodeOff, nodeCount, nodeCap, depth; float box[6]; };
@@ -322,6 +322,7 @@ struct SceneHost {
   std::vector<FVertex> verts; std::vector<InstanceRec> instances; std::vector<MaterialRec> mats; std::vector<MeshRec> meshRecs; std::vector<float> sceneData;
   Bvh8 bvh; std::vector<int32_t> triFaceId; std::vector<uint32_t> flatOfOrig; TwoLevelHost two; bool lineNodes = false;
   std::vector<MeshBuild> meshBuilds;
+  std::vector<TriShade> triShade; bool shadePacked = false; // one-line shading records per mesh triangle (scenes beyond LDS): TriRec::vi[0] indexes them
   bool partitioned = false; std::vector<InstPart> parts; uint32_t topCap = 0; // partitioned layout: nodes [0, topCap) = top tree, then the parts' ranges
 };
 
@@ -348,6 +349,7 @@ struct GiCScene : SceneDevice {
   uint32_t nodeCount = 0, triCount = 0, bvhDepth = 0;
   bool twoLevel = false; int optTwoLevel = -1; // 1: build and use the two-level layout (scenes beyond LDS); otherwise the flat one
   bool hasCutouts = false;
+  bool shadePacked = false; // the built scene carries TriShade records (beyond LDS)
   uint32_t classMask = 0; // material classes that own at least one triangle (one k_shade launch per class)
   uint32_t classTextured = 0; // classes with at least one textured material in use (k_shade<class, TEXTURED>)
   std::unique_ptr<SceneHost> host; // the scene as host arrays, kept for incremental transform updates
@@ -363,7 +365,7 @@ struct GiCScene : SceneDevice {
 
 void SceneDevice::releaseAll()
 {
-  dNodes.release(); dNodesLine.release(); dTris.release(); dInstances.release(); dVerts.release(); dTriFaceId.release();
+  dNodes.release(); dNodesLine.release(); dTris.release(); dInstances.release(); dVerts.release(); dTriFaceId.release(); dTriShade.release();
   dTlasNodes.release(); dBlasNodes.release(); dTlasItems.release(); dFlatOfOrig.release(); dBlasTris.release(); dInstTrav.release();
   for (auto* b : dTexels) { b->release(); delete b; }
   dTexels.clear(); dTextures.release(); dMeshes.release(); dSceneData.release();
@@ -1041,7 +1043,7 @@ int uploadSceneTo(GiCScene* s, SceneDevice& D, const SceneHost& H)
         D.dInstTrav.upload(H.two.instTrav, st) || D.dFlatOfOrig.upload(H.flatOfOrig, st))
       return GI_C_ERROR;
   }
-  if (D.dTriFaceId.upload(H.triFaceId, st)) return GI_C_ERROR;
+  if (D.dTriFaceId.upload(H.triFaceId, st) || D.dTriShade.upload(H.triShade, st)) return GI_C_ERROR;
   if (D.dMeshes.upload(H.meshRecs, st) || D.dSceneData.upload(H.sceneData, st)) return GI_C_ERROR;
   { // textures: one device array per image + the TextureRec table
     for (auto* b : D.dTexels) { b->release(); delete b; }
@@ -1209,6 +1211,29 @@ int buildScene(GiCScene* s)
   if (bvh.tris.size() >= (1u << 26)) { setError("scene has 2^26 or more triangles after instancing: the traversal queues pack (lane, triangle) into 32 bits"); return GI_C_ERROR; }
   H.triFaceId.resize(bvh.tris.size());
   for (size_t i = 0; i < bvh.tris.size(); i++) H.triFaceId[i] = faceIdOf[bvh.tris[i].origId];
+  // Scenes beyond LDS: one 128-byte shading record per mesh triangle (gi_types.h TriShade); the flattened triangles name theirs in vi[0].  LDS-resident
+  // scenes keep vertex indices there: the fused kernels are VALU-bound and read the host-decoded FVertex records.
+  H.shadePacked = bvh.nodes.size() > 384u || bvh.tris.size() > 128u;
+  if (const char* e = getenv("GATLING_SHADE_PACKED")) H.shadePacked = atoi(e) != 0;
+  H.triShade.clear();
+  if (H.shadePacked) {
+    std::vector<uint32_t> shadeBaseOfMesh(meshBuilds.size(), 0u);
+    for (MeshBuild& mb : meshBuilds) {
+      mb.shadeBase = (uint32_t)H.triShade.size(); shadeBaseOfMesh[mb.meshIdx] = mb.shadeBase;
+      const GiCMesh* m = mb.m;
+      for (const GiCFace& f : m->faces) {
+        TriShade q{};
+        for (int k = 0; k < 3; k++) {
+          const GiCVertex& v = m->vertices[f.v_i[k]];
+          memcpy(q.p[k], v.pos, 12); q.n[k] = encodeDirection(v.norm); q.t[k] = encodeDirection(v.tangent);
+          q.uv[k][0] = v.u; q.uv[k][1] = v.v; q.bsign[k] = v.bitangentSign; q.vi[k] = mb.vertexOffset + f.v_i[k];
+        }
+        H.triShade.push_back(q);
+      }
+    }
+    for (TriRec& t : bvh.tris) t.vi[0] = shadeBaseOfMesh[instances[t.instance].mesh] + t.prim;
+  }
+  s->shadePacked = H.shadePacked;
   // Optional layout: one node per 128-byte line (an 80-byte node at an 80-byte stride straddles two lines half of the time).
   // Measured on C3/C4 it is 1-3 % SLOWER than the packed layout (the footprint grows 1.6x and the L2 hit rate drops), so it
   // stays an experiment knob (GATLING_NODE_LINES=1).
@@ -1254,7 +1279,7 @@ void nodeBounds(const Node8& n, float box[6])
 
 // One instance's InstanceRec, world-space triangles (scene order) and subtree
 struct PartBuild { InstanceRec inst; Bvh8 bvh; };
-void buildPart(const MeshBuild& mb, uint32_t instInMesh, PartBuild& out)
+void buildPart(const MeshBuild& mb, uint32_t instInMesh, bool packed, PartBuild& out)
 {
   const GiCMesh* m = mb.m;
   InstanceRec ir{};
@@ -1273,6 +1298,7 @@ void buildPart(const MeshBuild& mb, uint32_t instInMesh, PartBuild& out)
     TriRec& t = tris[f];
     for (int a = 0; a < 3; a++) { t.v0[a] = p0[a]; t.e1[a] = p1[a] - p0[a]; t.e2[a] = p2[a] - p0[a]; t.vi[a] = mb.vertexOffset + m->faces[f].v_i[a]; }
     t.instance = instIdx; t.prim = f; t.origId = f; t.matFlags = mb.matFlags;
+    if (packed) t.vi[0] = mb.shadeBase + f;
   }
   buildBvh8(tris, out.bvh);
 }
@@ -1342,7 +1368,7 @@ int updateTransforms(GiCScene* s, bool& handled)
     }
     if (parts.empty()) return GI_C_OK;
     std::vector<PartBuild> built(parts.size());
-    parallelOver(parts.size(), [&](size_t i) { buildPart(H.meshBuilds[parts[i].meshBuild], parts[i].instInMesh, built[i]); });
+    parallelOver(parts.size(), [&](size_t i) { buildPart(H.meshBuilds[parts[i].meshBuild], parts[i].instInMesh, H.shadePacked, built[i]); });
     H.topCap = (uint32_t)parts.size() * 2u + 16u; // top nodes <= internal top nodes + one copied root per part
     uint32_t off = H.topCap;
     for (size_t i = 0; i < parts.size(); i++) { const uint32_t n = (uint32_t)built[i].bvh.nodes.size(); parts[i].nodeOff = off; parts[i].nodeCap = n + n / 4u + 8u; off += parts[i].nodeCap; }
@@ -1356,7 +1382,7 @@ int updateTransforms(GiCScene* s, bool& handled)
       if (m->xformDirty && (m->instDirty.empty() || m->instDirty[H.parts[i].instInMesh])) dirtyParts.push_back(i);
     }
     std::vector<PartBuild> built(dirtyParts.size());
-    parallelOver(dirtyParts.size(), [&](size_t k) { const InstPart& P = H.parts[dirtyParts[k]]; buildPart(H.meshBuilds[P.meshBuild], P.instInMesh, built[k]); });
+    parallelOver(dirtyParts.size(), [&](size_t k) { const InstPart& P = H.parts[dirtyParts[k]]; buildPart(H.meshBuilds[P.meshBuild], P.instInMesh, H.shadePacked, built[k]); });
     for (size_t k = 0; k < dirtyParts.size(); k++)
       if (built[k].bvh.nodes.size() > H.parts[dirtyParts[k]].nodeCap) { H.partitioned = false; H.parts.clear(); return GI_C_OK; } // a subtree outgrew its range (rare): full rebuild
     parallelOver(dirtyParts.size(), [&](size_t k) { placePart(H, H.parts[dirtyParts[k]], built[k]); });
@@ -1435,7 +1461,7 @@ SceneView makeView(GiCScene* s, SceneDevice& D)
   SceneView v{};
   v.textures = D.dTextures.ptr; v.meshes = D.dMeshes.ptr; v.sceneData = D.dSceneData.ptr;
   v.nodes = s->nodeStrideU4 == 8u ? reinterpret_cast<const Node8*>(D.dNodesLine.ptr) : D.dNodes.ptr; v.nodeStrideU4 = s->nodeStrideU4; v.tris = D.dTris.ptr; v.instances = D.dInstances.ptr;
-  v.verts = D.dVerts.ptr; v.materials = D.dMaterials.ptr; v.sphereLights = D.dSphere.ptr; v.distantLights = D.dDistant.ptr;
+  v.verts = D.dVerts.ptr; v.triShade = D.dTriShade.ptr; v.shadePacked = s->shadePacked ? 1u : 0u; v.materials = D.dMaterials.ptr; v.sphereLights = D.dSphere.ptr; v.distantLights = D.dDistant.ptr;
   v.tlasNodes = D.dTlasNodes.ptr; v.tlasItems = D.dTlasItems.ptr; v.blasNodes = D.dBlasNodes.ptr; v.blasTris = D.dBlasTris.ptr; v.instTrav = D.dInstTrav.ptr; v.flatOfOrig = D.dFlatOfOrig.ptr; v.twoLevel = s->twoLevel ? 1u : 0u;
   v.rectLights = D.dRect.ptr; v.diskLights = D.dDisk.ptr; v.triFaceId = D.dTriFaceId.ptr; v.nodeCount = s->nodeCount; v.triCount = s->triCount; v.bvhDepth = s->bvhDepth; v.hasCutouts = s->hasCutouts ? 1u : 0u;
   return v;

@@ -466,7 +466,7 @@ __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, Que
 // k_shade: closest-hit shading + the post-trace part of the bounce loop, over the HIT queue only
 // (rp_main.chit:132-493, rp_main.rgen:397-480).  Misses never get here (k_trace routes them to k_raygen).
 // ------------------------------------------------------------------------------------------------
-template <uint32_t KLASS, bool TEXTURED, bool VOLUME, bool NEE>
+template <uint32_t KLASS, bool TEXTURED, bool VOLUME, bool NEE, bool PACKED>
 // (forcing the plain variant to 5 waves/SIMD -- amdgpu_waves_per_eu((...) ? 5 : 1, 8): 90 VGPRs, no spills -- is SLOWER: C2 shade 178 -> 190 ms;
 // the stage is bound by the memory pipeline's scattered 16-byte requests, not by latency hiding)
 __global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t par)
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, 
       const F4 rr = ld4(&S->rad);
       ShadeIO io; io.throughput = v3(tb.x, tb.y, tb.z); io.radiance = v3(rr.x, rr.y, rr.z); io.bitfield = f2u(tb.w); io.rng = f2u(rr.w);
       float* M = VOLUME ? st.media + (size_t)slot * st.mediaStride : nullptr; // this path's medium stack + walkSegmentPdf
-      shade_segment<KLASS, TEXTURED, VOLUME, NEE>(U, sc, M, h, rd, io);
+      shade_segment<KLASS, TEXTURED, VOLUME, NEE, PACKED>(U, sc, M, h, rd, io);
       cont = io.cont; ended = !cont; shadow = io.shadow; shadowFirst = io.shadowFirst; no = io.no; k2 = io.k2; tMaxNext = io.tMaxNext;
       sdir = io.sdir; nee = io.nee; ld = io.ld; rngShadow = io.rngShadow;
       if (NEE && st.neeKey && shadowFirst && !shadow) nee_aov_record(st, slot, false); // NEE AOV (rp_main.rgen:431-435): an untraced shadow ray counts as "not shadowed"
@@ -543,7 +543,7 @@ __device__ inline V3 bsdf_albedo(const MaterialRec* m, const ShState& st, V3 k1)
   return diffuse + glossy;
 }
 
-template <uint32_t STACK, bool OVERFLOW>
+template <uint32_t STACK, bool OVERFLOW, bool PACKED>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_aov(FrameUniforms U, SceneView sc, AovTargets A, uint32_t ldsNodes, uint32_t ldsTris)
 {
   extern __shared__ uint4 s_dyn[];
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_aov(FrameUniforms U, SceneView 
     uint32_t matWord;
     if (!traverse<false, false, STACK, OVERFLOW, false, true>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, origin, dir, tMin, tMax, t, u, v, tri, matWord, tc, rng)) continue;
     ShState ss;
-    setup_shading_state(sc, tri, u, v, dir, ss);
+    setup_shading_state<PACKED>(sc, tri, u, v, dir, ss);
     const uint4* tp = reinterpret_cast<const uint4*>(sc.tris) + (size_t)tri * 4u;
     const uint32_t instIdx = tp[2].z;
     if (A.opacity) {
@@ -595,8 +595,11 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_aov(FrameUniforms U, SceneView 
     if (A.texcoords) {
       const uint4 td = tp[3];
       const float bx = 1.0f - u - v;
+      if (PACKED) { const TriShade& q = sc.triShade[td.x]; put3(A.texcoords, v3((bx * q.uv[0][0] + u * q.uv[1][0]) + v * q.uv[2][0], (bx * q.uv[0][1] + u * q.uv[1][1]) + v * q.uv[2][1], 0.0f)); }
+      else {
       const FVertex* va = &sc.verts[td.x]; const FVertex* vb = &sc.verts[td.y]; const FVertex* vc = &sc.verts[td.z];
       put3(A.texcoords, v3((bx * va->u + u * vb->u) + v * vc->u, (bx * va->v + u * vb->v) + v * vc->v, 0.0f));
+      }
     }
     { const MaterialRec* tm = &sc.materials[ss.material]; put3(A.thinWalled, (tm->klass == 2u && tm->p[54] != 0.0f) ? v3(1.0f, 0.0f, 0.0f) : v3(0.0f, 1.0f, 0.0f)); } // rp_main.chit:218-220
     if (A.objectId) A.objectId[pixelIndex] = (int)sc.instances[instIdx].pad;
@@ -741,13 +744,17 @@ void launchAov(hipStream_t s, const FrameUniforms& U, const SceneView& sc, const
   uint32_t ln, lt, bytes; traceLdsLayout(sc, ln, lt, bytes);
   bytes = (sc.bvhDepth <= 8u ? 8u : 16u) * TRACE_BLOCK * (uint32_t)sizeof(uint2) + ln * 80u + lt * 48u; // k_aov has no 4-entry variant
   const uint32_t blocks = (U.pixelCount + TRACE_BLOCK - 1u) / TRACE_BLOCK;
-  if (sc.bvhDepth <= 8u) hipLaunchKernelGGL((k_aov<8, false>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, U, sc, A, ln, lt);
-  else if (sc.bvhDepth <= 16u) hipLaunchKernelGGL((k_aov<16, false>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, U, sc, A, ln, lt);
-  else hipLaunchKernelGGL((k_aov<16, true>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, U, sc, A, ln, lt);
+#define GI_LAUNCH_AOV(P) do { \
+  if (sc.bvhDepth <= 8u) hipLaunchKernelGGL((k_aov<8, false, P>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, U, sc, A, ln, lt); \
+  else if (sc.bvhDepth <= 16u) hipLaunchKernelGGL((k_aov<16, false, P>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, U, sc, A, ln, lt); \
+  else hipLaunchKernelGGL((k_aov<16, true, P>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, U, sc, A, ln, lt); } while (0)
+  if (sc.shadePacked) GI_LAUNCH_AOV(true); else GI_LAUNCH_AOV(false);
+#undef GI_LAUNCH_AOV
 }
 void launchShade(hipStream_t s, uint32_t blocks, uint32_t klass, bool textured, bool volume, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par)
 {
-#define GI_LAUNCH_SHADE4(K, T, V, N) hipLaunchKernelGGL((k_shade<K, T, V, N>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par)
+#define GI_LAUNCH_SHADE4(K, T, V, N) do { if (sc.shadePacked) hipLaunchKernelGGL((k_shade<K, T, V, N, true>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par); \
+    else hipLaunchKernelGGL((k_shade<K, T, V, N, false>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par); } while (0)
 #define GI_LAUNCH_SHADE3(K, T, V) do { if (nee) GI_LAUNCH_SHADE4(K, T, V, true); else GI_LAUNCH_SHADE4(K, T, V, false); } while (0)
 #define GI_LAUNCH_SHADE(K) do { \
     if (volume) { if (textured) GI_LAUNCH_SHADE3(K, true, true); else GI_LAUNCH_SHADE3(K, false, true); } \

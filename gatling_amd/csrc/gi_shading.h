@@ -61,42 +61,58 @@ __device__ __forceinline__ V3 xform_normal(const float* w, V3 n)
   return v3((n.x * w[0] + n.y * w[3]) + n.z * w[6], (n.x * w[1] + n.y * w[4]) + n.z * w[7], (n.x * w[2] + n.y * w[5]) + n.z * w[8]);
 }
 
+// PACKED: the three corners come from the mesh triangle's one-line TriShade record (normals / tangents decoded here) instead of three FVertex records.
+template <bool PACKED = false>
 __device__ __forceinline__ void setup_shading_state(const SceneView& sc, uint32_t triIdx, float hu, float hv, V3 rayDir, ShState& s)
 {
-  // one dependent step: the triangle record's tail names the instance, the material and the three vertices
+  // one dependent step: the triangle record's tail names the instance, the material and the three vertices (or the shading record)
   const uint4* tp = reinterpret_cast<const uint4*>(sc.tris) + (size_t)triIdx * 4u;
-  const uint4 tc = tp[2], td = tp[3]; // (e2.z, origId, instance, matFlags), (i0, i1, i2, prim)
+  const uint4 tc = tp[2], td = tp[3]; // (e2.z, origId, instance, matFlags), (i0 | shading record, i1, i2, prim)
   s.material = tc.w & 0x00ffffffu; s.meshFlags = tc.w >> 30;
   const float4* ip = reinterpret_cast<const float4*>(&sc.instances[tc.z]);
-  const float4* va = reinterpret_cast<const float4*>(&sc.verts[td.x]);
-  const float4* vb = reinterpret_cast<const float4*>(&sc.verts[td.y]);
-  const float4* vc = reinterpret_cast<const float4*>(&sc.verts[td.z]);
   const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2], r3 = ip[3], r4 = ip[4], r5 = ip[5];
-  const float4 a1 = va[0], a2 = va[1], a3 = va[2];
-  const float4 b1 = vb[0], b2 = vb[1], b3 = vb[2];
-  const float4 c1 = vc[0], c2 = vc[1], c3 = vc[2];
+  V3 pa, pb, pc, n0, n1, n2, t0, t1, t2; float sa, sb, scg, ua, ub, uc, va_, vb_, vc_;
+  if (PACKED) {
+    const uint4* q = reinterpret_cast<const uint4*>(&sc.triShade[td.x]); // 7 x 16 bytes of one line
+    const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6];
+    pa = v3(u2f(q0.x), u2f(q0.y), u2f(q0.z)); pb = v3(u2f(q0.w), u2f(q1.x), u2f(q1.y)); pc = v3(u2f(q1.z), u2f(q1.w), u2f(q2.x));
+    n0 = gi_decode_direction(q2.y); n1 = gi_decode_direction(q2.z); n2 = gi_decode_direction(q2.w);
+    t0 = gi_decode_direction(q3.x); t1 = gi_decode_direction(q3.y); t2 = gi_decode_direction(q3.z);
+    ua = u2f(q3.w); va_ = u2f(q4.x); ub = u2f(q4.y); vb_ = u2f(q4.z); uc = u2f(q4.w); vc_ = u2f(q5.x);
+    sa = u2f(q5.y); sb = u2f(q5.z); scg = u2f(q5.w);
+    s.vi[0] = q6.x; s.vi[1] = q6.y; s.vi[2] = q6.z;
+  } else {
+    const float4* va = reinterpret_cast<const float4*>(&sc.verts[td.x]);
+    const float4* vb = reinterpret_cast<const float4*>(&sc.verts[td.y]);
+    const float4* vc = reinterpret_cast<const float4*>(&sc.verts[td.z]);
+    const float4 a1 = va[0], a2 = va[1], a3 = va[2];
+    const float4 b1 = vb[0], b2 = vb[1], b3 = vb[2];
+    const float4 c1 = vc[0], c2 = vc[1], c3 = vc[2];
+    pa = v3(a1.x, a1.y, a1.z); pb = v3(b1.x, b1.y, b1.z); pc = v3(c1.x, c1.y, c1.z);
+    n0 = v3(a2.x, a2.y, a2.z); n1 = v3(b2.x, b2.y, b2.z); n2 = v3(c2.x, c2.y, c2.z); // decoded on the host (:31-33)
+    t0 = v3(a3.x, a3.y, a3.z); t1 = v3(b3.x, b3.y, b3.z); t2 = v3(c3.x, c3.y, c3.z); // decoded on the host (:48-50)
+    sa = a1.w; sb = b1.w; scg = c1.w; ua = a2.w; ub = b2.w; uc = c2.w; va_ = a3.w; vb_ = b3.w; vc_ = c3.w;
+    s.vi[0] = td.x; s.vi[1] = td.y; s.vi[2] = td.z;
+  }
   const float o2w[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
   const float w2o[9] = {r3.x, r3.y, r3.z, r3.w, r4.x, r4.y, r4.z, r4.w, r5.x};
   const float bx = 1.0f - hu - hv, by = hu, bz = hv;                                  // :17
-  const V3 pa = v3(a1.x, a1.y, a1.z), pb = v3(b1.x, b1.y, b1.z), pc = v3(c1.x, c1.y, c1.z);
   const V3 localPos = (pa * bx + pb * by) + pc * bz;                                  // :24
   s.position = xform_point(o2w, localPos, 1.0f);                                      // :25
   V3 gn = normalize(cross(pb - pa, pc - pa));                                         // :27
   gn = normalize(xform_normal(w2o, gn));                                              // :28
-  const V3 n0 = v3(a2.x, a2.y, a2.z), n1 = v3(b2.x, b2.y, b2.z), n2 = v3(c2.x, c2.y, c2.z); // decoded on the host (:31-33)
   const V3 ln = normalize((n0 * bx + n1 * by) + n2 * bz);                             // :35
   V3 nrm = normalize(xform_normal(w2o, ln));                                          // :36
   s.frontFace = dot(gn, -rayDir) >= 0.0f;                                             // :39
   if (!s.frontFace) { gn = -gn; nrm = -nrm; }                                         // :41-45
-  const V3 t0 = v3(a3.x, a3.y, a3.z), t1 = v3(b3.x, b3.y, b3.z), t2 = v3(c3.x, c3.y, c3.z); // decoded on the host (:48-50)
   const V3 lt = normalize((t0 * bx + t1 * by) + t2 * bz);                             // :52
   V3 tg = normalize(xform_point(o2w, lt, 0.0f));                                      // :53
   tg = normalize(tg - nrm * dot(tg, nrm));                                            // :56
-  const float bs = (bx * a1.w + by * b1.w) + bz * c1.w;                               // :58
+  const float bs = (bx * sa + by * sb) + bz * scg;                                    // :58
   s.tangentU = tg; s.tangentV = cross(nrm, tg) * bs;                                  // :59
-  s.u = (bx * a2.w + by * b2.w) + bz * c2.w; s.v = (bx * a3.w + by * b3.w) + bz * c3.w; // :62-65
+  s.u = (bx * ua + by * ub) + bz * uc; s.v = (bx * va_ + by * vb_) + bz * vc_;        // :62-65
   s.normal = nrm; s.geomNormal = gn;
-  s.mesh = f2u(r5.y); s.instanceId = (int32_t)f2u(r5.z); s.prim = td.w; s.vi[0] = td.x; s.vi[1] = td.y; s.vi[2] = td.z; s.hu = hu; s.hv = hv;
+  s.mesh = f2u(r5.y); s.instanceId = (int32_t)f2u(r5.z); s.prim = td.w; s.hu = hu; s.hv = hv;
   s.ior1 = 0.0f; s.ior2 = 0.0f;
   s.thinWalled = false; s.texMask = 0u; s.texBaseColor = v3(0.0f, 0.0f, 0.0f); s.texEmission = s.texBaseColor; s.texRoughness = 0.0f; s.texMetallic = 0.0f;
 }

@@ -60,7 +60,7 @@ struct ShadeIO {
   V3 no, k2; float tMaxNext;                                         // out: next ray
   V3 sdir, nee; float ld; uint32_t rngShadow;                        // out: shadow ray direction / distance, NEE contribution, rng copy (rp_main.rgen:399)
 };
-template <uint32_t KLASS, bool TEXTURED, bool VOLUME, bool NEE>
+template <uint32_t KLASS, bool TEXTURED, bool VOLUME, bool NEE, bool PACKED = false>
 __device__ __forceinline__ void shade_segment(const FrameUniforms& U, const SceneView& sc, float* M /* medium stack of the path (VOLUME) */, const F4& h, const F4& rd, ShadeIO& io)
 {
   V3 throughput = io.throughput, radiance = io.radiance; uint32_t bitfield = io.bitfield, rng = io.rng;
@@ -88,7 +88,7 @@ __device__ __forceinline__ void shade_segment(const FrameUniforms& U, const Scen
     payload_increment_walk(bitfield);
   } else {
   ShState ss;
-  setup_shading_state(sc, f2u(h.w), h.y, h.z, rayDir, ss);
+  setup_shading_state<PACKED>(sc, f2u(h.w), h.y, h.z, rayDir, ss);
   const MaterialRec* mat = &sc.materials[ss.material];
   if (TEXTURED && (mat->flags & MAT_FLAG_TEXTURED)) resolve_material_textures(sc, mat, rayDir, ss); // else ss.texMask stays 0 and folds away
   const bool isDoubleSided = (ss.meshFlags & 2u) != 0u;

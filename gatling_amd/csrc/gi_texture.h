@@ -72,8 +72,15 @@ __device__ inline float cutout_opacity_at(const SceneView& sc, uint32_t matWord,
   if (!(m->flags & MAT_FLAG_OPACITY_TEX)) return m->p[MP_CUTOUT];
   const uint4 td = reinterpret_cast<const uint4*>(sc.tris)[(size_t)triIdx * 4u + 3u]; // (i0, i1, i2, prim)
   const float bx = 1.0f - hu - hv, by = hu, bz = hv;
-  const float u = (bx * sc.verts[td.x].u + by * sc.verts[td.y].u) + bz * sc.verts[td.z].u;
-  const float v = (bx * sc.verts[td.x].v + by * sc.verts[td.y].v) + bz * sc.verts[td.z].v;
+  float u, v;
+  if (sc.shadePacked) { // one line: the mesh triangle's shading record carries the three uv pairs
+    const TriShade& q = sc.triShade[td.x];
+    u = (bx * q.uv[0][0] + by * q.uv[1][0]) + bz * q.uv[2][0];
+    v = (bx * q.uv[0][1] + by * q.uv[1][1]) + bz * q.uv[2][1];
+  } else {
+    u = (bx * sc.verts[td.x].u + by * sc.verts[td.y].u) + bz * sc.verts[td.z].u;
+    v = (bx * sc.verts[td.x].v + by * sc.verts[td.y].v) + bz * sc.verts[td.z].v;
+  }
   const TexBindingRec& b = m->tex[TEX_OPACITY];
   const F4 t = tex_lookup_float4_2d(sc.textures[b.tex - 1u], u, v, b.mode & 0xffu, (b.mode >> 8) & 0xffu);
   const uint32_t ch = (b.mode >> 16) & 3u;

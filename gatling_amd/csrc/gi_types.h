@@ -49,6 +49,20 @@ struct FVertex {
 };
 static_assert(sizeof(FVertex) == 48, "FVertex must be 48 bytes");
 
+// Shading record of one MESH triangle, 128 bytes = one cache line (scenes beyond LDS, round 3).  The shade stage of the wavefront pipeline is bound by the
+// number of distinct lines a hit touches: three 48-byte vertices at arbitrary indices are 3 - 4.5 lines, this is one.  Normals and tangents
+// stay in the reference's octahedral unorm2x16 encoding (rp::FVertex, rp_main.h:58-64) and are decoded per hit with the operations the host runs per vertex
+// for FVertex (decode_direction, common.glsl:198-207), so both forms give the same bits.  Shared by all instances of the mesh; TriRec::vi[0] holds its index.
+struct TriShade {
+  float p[3][3];       // object-space corner positions
+  uint32_t n[3], t[3]; // encoded normals / tangents of the corners
+  float uv[3][2];      // texture coordinates
+  float bsign[3];      // bitangent signs
+  uint32_t vi[3];      // absolute vertex indices (scene-data lookups by vertex)
+  uint32_t pad[5];
+};
+static_assert(sizeof(TriShade) == 128, "TriShade must be one 128-byte line");
+
 // Replaces gl_ObjectToWorldEXT / gl_WorldToObjectEXT + BlasPayload (rp_main.h:118-123), 96 bytes
 struct InstanceRec {
   float o2w[12]; // rows of the 3x4 object->world matrix
@@ -144,6 +158,7 @@ struct SceneView {
   const TriRec* tris;
   const InstanceRec* instances;
   const FVertex* verts;
+  const TriShade* triShade; uint32_t shadePacked; // != 0: TriRec::vi[0] indexes triShade (scenes beyond LDS); 0: TriRec::vi are vertex indices (LDS-resident scenes, fused kernels)
   const MaterialRec* materials;
   const SphereLightRec* sphereLights;
   const DistantLightRec* distantLights;
