@@ -120,6 +120,7 @@ SYMBOLS = [
     ("giCDebugEvalBsdf", C.c_int, [C.POINTER(GiCMaterialDesc), _U, _FP, _FP]),
     ("giCDebugValidateBvh", C.c_int, [_FP, _U, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("giCDebugValidatePartitionedBvh", C.c_int, [_FP, _U, _U, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("giCDebugTexRuntime", C.c_int, [_FP, _U, _U, _U, _U, _FP, _FP]),
 ]
 
 _lib = None

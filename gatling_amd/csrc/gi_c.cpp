@@ -2185,3 +2185,25 @@ extern "C" int giCDebugEvalBsdf(const GiCMaterialDesc* desc, uint32_t count, con
   if (dm) (void)hipFree(dm); if (din) (void)hipFree(din); if (dout) (void)hipFree(dout);
   return rc;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// giCDebugTexRuntime: the MDL renderer runtime's remaining texture entry points (tex_texel_float4_2d, tex_resolution_2d, tex_lookup_float4_3d, tex_texel_float4_3d)
+// on the device, for explicit queries
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int giCDebugTexRuntime(const float* rgba, uint32_t width, uint32_t height, uint32_t depth, uint32_t count, const float* queries, float* out)
+{
+  if (!g_ctx.initialized || !rgba || !width || !height || !depth || (count && (!queries || !out))) { setError("giCDebugTexRuntime: bad arguments"); return GI_C_ERROR; }
+  if (count == 0) return GI_C_OK;
+  const size_t texFloats = (size_t)width * height * depth * 4;
+  float* dt = nullptr; float* dq = nullptr; float* dout = nullptr;
+  hipStream_t st = g_ctx.stream;
+  int rc = GI_C_ERROR;
+  if (hipMalloc((void**)&dt, texFloats * 4) == hipSuccess && hipMalloc((void**)&dq, (size_t)count * 32) == hipSuccess && hipMalloc((void**)&dout, (size_t)count * 16) == hipSuccess &&
+      hipMemcpyAsync(dt, rgba, texFloats * 4, hipMemcpyHostToDevice, st) == hipSuccess && hipMemcpyAsync(dq, queries, (size_t)count * 32, hipMemcpyHostToDevice, st) == hipSuccess) {
+    launchDebugTex(st, dt, width, height, depth, count, dq, dout);
+    if (hipMemcpyAsync(out, dout, (size_t)count * 16, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) rc = GI_C_OK;
+  }
+  if (rc != GI_C_OK) setError("giCDebugTexRuntime: HIP failure");
+  if (dt) (void)hipFree(dt); if (dq) (void)hipFree(dq); if (dout) (void)hipFree(dout);
+  return rc;
+}

@@ -33,5 +33,6 @@ int launchPath(hipStream_t s, uint32_t cuCount, uint32_t classMask, bool texture
 void launchAov(hipStream_t s, const FrameUniforms& U, const SceneView& sc, const AovTargets& A);
 void launchResolveNee(hipStream_t s, const FrameUniforms& U, const unsigned long long* key, F4* aov, uint32_t pixelCount);
 void launchDebugBsdf(hipStream_t s, const MaterialRec* mat, uint32_t count, const float* in, float* out);
+void launchDebugTex(hipStream_t s, const float* texels, uint32_t w, uint32_t h, uint32_t d, uint32_t count, const float* queries, float* out);
 
 } // namespace gi

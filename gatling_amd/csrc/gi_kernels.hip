@@ -644,6 +644,22 @@ __global__ void k_debug_bsdf(const MaterialRec* mat, uint32_t count, const float
   o[8] = ev.diffuse.x; o[9] = ev.diffuse.y; o[10] = ev.diffuse.z; o[11] = ev.glossy.x; o[12] = ev.glossy.y; o[13] = ev.glossy.z; o[14] = ev.pdf;
 }
 
+// k_debug_tex: the MDL runtime's remaining texture entry points on explicit queries (same layout as the oracle's orc_tex_runtime)
+__global__ void k_debug_tex(const float* texels, uint32_t w, uint32_t h, uint32_t d, uint32_t count, const float* __restrict__ queries, float* __restrict__ out)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const float* q = queries + 8 * (size_t)i;
+  const TextureRec t2{texels, w, h}; const TextureRec3 t3{texels, w, h, d};
+  const int kind = (int)q[0]; const bool valid = q[1] != 0.0f;
+  F4 r = F4{0.0f, 0.0f, 0.0f, 0.0f};
+  if (kind == 0) r = tex_texel_float4_2d(t2, valid, (int)q[2], (int)q[3]);
+  else if (kind == 1) { int rw, rh; tex_resolution_2d(t2, valid, rw, rh); r = F4{(float)rw, (float)rh, 0.0f, 0.0f}; }
+  else if (kind == 2) r = tex_lookup_float4_3d(t3, valid, q[2], q[3], q[4], (uint32_t)q[5], (uint32_t)q[6], (uint32_t)q[7]);
+  else r = tex_texel_float4_3d(t3, valid, (int)q[2], (int)q[3], (int)q[4]);
+  st4(reinterpret_cast<F4*>(out) + i, r.x, r.y, r.z, r.w);
+}
+
 // ------------------------------------------------------------------------------------------------
 // host-callable launchers
 // ------------------------------------------------------------------------------------------------
@@ -770,6 +786,11 @@ void launchShade(hipStream_t s, uint32_t blocks, uint32_t klass, bool textured, 
 void launchResolveNee(hipStream_t s, const FrameUniforms& U, const unsigned long long* key, F4* aov, uint32_t pixelCount)
 {
   hipLaunchKernelGGL(k_resolve_nee, dim3((pixelCount + 255u) / 256u), dim3(256), 0, s, U, key, aov, pixelCount);
+}
+
+void launchDebugTex(hipStream_t s, const float* texels, uint32_t w, uint32_t h, uint32_t d, uint32_t count, const float* queries, float* out)
+{
+  hipLaunchKernelGGL(k_debug_tex, dim3((count + 63u) / 64u), dim3(64), 0, s, texels, w, h, d, count, queries, out);
 }
 
 void launchDebugBsdf(hipStream_t s, const MaterialRec* mat, uint32_t count, const float* in, float* out)

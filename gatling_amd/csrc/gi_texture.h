@@ -54,6 +54,48 @@ __device__ inline F4 tex_lookup_float4_2d(const TextureRec& t, float u, float v,
   v = apply_wrap_and_crop(v, wrapV, t.height);
   return sample_bilinear_repeat(t, u, v);
 }
+// ------------------------------------------------------------------------------------------------
+// The remaining texture entry points of the MDL renderer runtime (mdl_interface.glsl:45-65 tex_lookup_float4_3d, :86-105 tex_texel_float4_3d, :167-186
+// tex_texel_float4_2d, :208-221 tex_resolution_2d).  Only MDL-generated code calls them -- none of the closed forms does -- so in this library they are
+// reachable through giCDebugTexRuntime only; they complete the runtime and are held to the oracle bit for bit.  `valid` false is the
+// reference's texture id 0 (the invalid texture).  The 3-D sampler is the 2-D one's trilinear extension (same deviation D5: software filter weights).
+// ------------------------------------------------------------------------------------------------
+struct TextureRec3 { const float* texels; uint32_t width, height, depth; }; // width x height x depth RGBA texels, slice by slice
+__device__ inline F4 tex_texel_float4_2d(const TextureRec& t, bool valid, int x, int y)
+{
+  if (!valid || x < 0 || x >= (int)t.width || y < 0 || y >= (int)t.height) return F4{0.0f, 0.0f, 0.0f, 0.0f};
+  return ld4(&reinterpret_cast<const F4*>(t.texels)[(size_t)y * t.width + (size_t)x]);
+}
+__device__ __forceinline__ void tex_resolution_2d(const TextureRec& t, bool valid, int& w, int& h) { w = valid ? (int)t.width : 0; h = valid ? (int)t.height : 0; }
+__device__ inline F4 sample_trilinear_repeat(const TextureRec3& t, float u, float v, float w)
+{
+  w = w - floorf(w);
+  const float z = w * (float)t.depth - 0.5f, z0f = floorf(z), fz = z - z0f, gz = 1.0f - fz;
+  const int d = (int)t.depth;
+  int iz0 = (int)z0f;
+  if (iz0 < 0) iz0 += d;
+  int iz1 = iz0 + 1; if (iz1 >= d) iz1 -= d;
+  const size_t slice = (size_t)t.width * t.height * 4u;
+  const TextureRec s0{t.texels + slice * (size_t)iz0, t.width, t.height}, s1{t.texels + slice * (size_t)iz1, t.width, t.height};
+  const F4 a = sample_bilinear_repeat(s0, u, v), b = sample_bilinear_repeat(s1, u, v);
+  return F4{a.x * gz + b.x * fz, a.y * gz + b.y * fz, a.z * gz + b.z * fz, a.w * gz + b.w * fz};
+}
+__device__ inline F4 tex_lookup_float4_3d(const TextureRec3& t, bool valid, float u, float v, float w, uint32_t wrapU, uint32_t wrapV, uint32_t wrapW)
+{
+  if (!valid || (wrapU == TEX_WRAP_CLIP && (u < 0.0f || u > 1.0f)) || (wrapV == TEX_WRAP_CLIP && (v < 0.0f || v > 1.0f)) ||
+      (wrapW == TEX_WRAP_CLIP && (w < 0.0f || w > 1.0f))) return F4{0.0f, 0.0f, 0.0f, 0.0f};
+  u = apply_wrap_and_crop(u, wrapU, t.width);
+  v = apply_wrap_and_crop(v, wrapV, t.height);
+  w = apply_wrap_and_crop(w, wrapW, t.depth);
+  return sample_trilinear_repeat(t, u, v, w);
+}
+__device__ inline F4 tex_texel_float4_3d(const TextureRec3& t, bool valid, int x, int y, int z)
+{
+  if (!valid || x < 0 || x >= (int)t.width || y < 0 || y >= (int)t.height || z < 0 || z >= (int)t.depth) return F4{0.0f, 0.0f, 0.0f, 0.0f};
+  return ld4(&reinterpret_cast<const F4*>(t.texels)[((size_t)z * t.height + (size_t)y) * t.width + (size_t)x]);
+}
+// scene_data_lookup_float4x4 (mdl_interface.glsl:476-479) is "return default_value; // TODO: not implemented" in the reference: the caller keeps its default.
+
 // mdl_cutout_opacity of the closed forms from the raw opacity value: UsdPreviewSurface opacity with the opacityThreshold switch, OpenPBR
 // geometry_opacity (== host cutoutOpacity / oracle cutout_opacity)
 __device__ __forceinline__ float cutout_rule(uint32_t klass, float op, float threshold)

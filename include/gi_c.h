@@ -404,6 +404,11 @@ int giCTraceRays(GiCScene* scene, uint32_t count, const float* origins /*3*count
  * in: 22 floats per item (normal, tangentU, tangentV, geomNormal, k1, k2, xi[4]); out: 15 floats per item
  * (k2, bsdf_over_pdf, pdf, event, eval diffuse, eval glossy, eval pdf). */
 int giCDebugEvalBsdf(const GiCMaterialDesc* desc, uint32_t count, const float* in, float* out);
+/* [ext] device-side hook for the MDL renderer runtime's remaining texture entry points (mdl_interface.glsl:45-65, 86-105, 167-221), which only MDL-generated code
+ * calls: `rgba` = width x height x depth RGBA float texels (slice by slice; depth 1 = a 2-D image); per query 8 floats (kind, valid, c0, c1, c2, wrapU, wrapV, wrapW)
+ * with kind 0 tex_texel_float4_2d(c0, c1), 1 tex_resolution_2d, 2 tex_lookup_float4_3d(c0, c1, c2; wraps), 3 tex_texel_float4_3d(c0, c1, c2); valid 0 = the invalid
+ * texture; per result 4 floats. */
+int giCDebugTexRuntime(const float* rgba, uint32_t width, uint32_t height, uint32_t depth, uint32_t count, const float* queries, float* out);
 int giCDebugValidateBvh(const float* triVerts, uint32_t triCount, uint32_t* outNodeCount, uint32_t* outMaxDepth);
 /* [ext] the same host-only check for the partitioned layout incremental transform updates use: `partCount` consecutive triangle ranges, one
  * subtree each, joined by a top tree over the subtree roots.  Returns the violations of the assembled tree (0 = every triangle reachable and inside every

@@ -685,6 +685,51 @@ inline F4v tex_lookup_float4_2d(const OrcTexture& t, float u, float v, int wrapU
   return sample_bilinear_repeat(t, u, v);
 }
 
+// The remaining texture entry points of the MDL renderer runtime.  Only MDL-generated code calls them (none of the closed forms does); restated so the
+// runtime is complete, held against the reference's text in tests/test_oracle_ref.py and against the device in tests/test_gpu_parity.py.
+// tex_texel_float4_2d (mdl_interface.glsl:167-186): integer texel fetch, (0,0,0,0) for the invalid texture and outside the image
+inline F4v tex_texel_float4_2d(const OrcTexture* t, int x, int y)
+{
+  if (!t) return F4v{0, 0, 0, 0};
+  if (x < 0 || x >= (int)t->width || y < 0 || y >= (int)t->height) return F4v{0, 0, 0, 0};
+  const float* p = t->rgba + 4 * ((size_t)y * t->width + (size_t)x);
+  return F4v{p[0], p[1], p[2], p[3]};
+}
+// tex_resolution_2d (:208-221)
+inline void tex_resolution_2d(const OrcTexture* t, int out[2]) { out[0] = t ? (int)t->width : 0; out[1] = t ? (int)t->height : 0; }
+// 3-D textures (:45-65, 86-105): width x height x depth texels, slice by slice; the sampler is the 2-D one's trilinear extension (D5: software weights)
+struct Tex3 { const float* rgba; uint32_t width, height, depth; };
+inline F4v sample_trilinear_repeat(const Tex3& t, float u, float v, float w)
+{
+  w = w - floorf(w);
+  const float z = w * (float)t.depth - 0.5f, z0f = floorf(z), fz = z - z0f, gz = 1.0f - fz;
+  int d = (int)t.depth, iz0 = (int)z0f;
+  if (iz0 < 0) iz0 += d;
+  int iz1 = iz0 + 1; if (iz1 >= d) iz1 -= d;
+  const size_t slice = (size_t)t.width * t.height * 4;
+  const OrcTexture s0{t.rgba + slice * (size_t)iz0, t.width, t.height}, s1{t.rgba + slice * (size_t)iz1, t.width, t.height};
+  const F4v a = sample_bilinear_repeat(s0, u, v), b = sample_bilinear_repeat(s1, u, v);
+  return F4v{a.x * gz + b.x * fz, a.y * gz + b.y * fz, a.z * gz + b.z * fz, a.w * gz + b.w * fz};
+}
+inline F4v tex_lookup_float4_3d(const Tex3* t, float u, float v, float w, int wrapU, int wrapV, int wrapW)
+{
+  if (!t || (wrapU == ORC_TEX_WRAP_CLIP && (u < 0.0f || u > 1.0f)) || (wrapV == ORC_TEX_WRAP_CLIP && (v < 0.0f || v > 1.0f)) ||
+      (wrapW == ORC_TEX_WRAP_CLIP && (w < 0.0f || w > 1.0f))) return F4v{0, 0, 0, 0};
+  u = apply_wrap_and_crop(u, wrapU, (int)t->width);
+  v = apply_wrap_and_crop(v, wrapV, (int)t->height);
+  w = apply_wrap_and_crop(w, wrapW, (int)t->depth);
+  return sample_trilinear_repeat(*t, u, v, w);
+}
+inline F4v tex_texel_float4_3d(const Tex3* t, int x, int y, int z)
+{
+  if (!t) return F4v{0, 0, 0, 0};
+  if (x < 0 || x >= (int)t->width || y < 0 || y >= (int)t->height || z < 0 || z >= (int)t->depth) return F4v{0, 0, 0, 0};
+  const float* p = t->rgba + 4 * (((size_t)z * t->height + (size_t)y) * t->width + (size_t)x);
+  return F4v{p[0], p[1], p[2], p[3]};
+}
+// scene_data_lookup_float4x4 (:476-479): "return default_value; // TODO: not implemented" in the reference -- restated as such
+inline void scene_data_lookup_float4x4(const float defaultValue[16], float out[16]) { memcpy(out, defaultValue, 64); }
+
 // mdl_adapt_normal (mdl_interface.glsl:238-256): Iray's shadow-terminator bend of a mapped normal
 inline V3 adapt_normal(V3 rayDir, V3 geomNormal, V3 normal)
 {
@@ -1759,6 +1804,25 @@ float orc_atan2f(float y, float x) { return atan2f_poly(y, x); }
 float orc_acosf(float x) { return acosf_poly(x); }
 // the raw sampler alone (what stands in for the hardware sampler when the reference's tex_lookup_float4_2d runs on the CPU, oracle/ref/ref_shim.cpp)
 void orc_dbg_sample_bilinear(const OrcTexture* t, float u, float v, float* out4) { F4v r = sample_bilinear_repeat(*t, u, v); out4[0] = r.x; out4[1] = r.y; out4[2] = r.z; out4[3] = r.w; }
+// The MDL runtime's remaining texture entry points: kind 0 tex_texel_float4_2d(x, y), 1 tex_resolution_2d, 2 tex_lookup_float4_3d(u, v, w, wraps), 3 tex_texel_float4_3d(x, y, z).
+// q = (kind, valid (0 = the invalid texture), c0, c1, c2, wrapU, wrapV, wrapW); integer coordinates are passed as exact floats.
+void orc_tex_runtime(const float* rgba, uint32_t w, uint32_t h, uint32_t d, uint32_t count, const float* queries, float* out)
+{
+  const OrcTexture t2{rgba, w, h}; const Tex3 t3{rgba, w, h, d};
+  for (uint32_t i = 0; i < count; i++) {
+    const float* q = queries + 8 * (size_t)i; float* o = out + 4 * (size_t)i;
+    const int kind = (int)q[0]; const bool valid = q[1] != 0.0f;
+    F4v r{0, 0, 0, 0};
+    if (kind == 0) r = tex_texel_float4_2d(valid ? &t2 : nullptr, (int)q[2], (int)q[3]);
+    else if (kind == 1) { int res[2]; tex_resolution_2d(valid ? &t2 : nullptr, res); r = F4v{(float)res[0], (float)res[1], 0, 0}; }
+    else if (kind == 2) r = tex_lookup_float4_3d(valid ? &t3 : nullptr, q[2], q[3], q[4], (int)q[5], (int)q[6], (int)q[7]);
+    else r = tex_texel_float4_3d(valid ? &t3 : nullptr, (int)q[2], (int)q[3], (int)q[4]);
+    o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w;
+  }
+}
+void orc_dbg_sample_trilinear(const float* rgba, uint32_t w, uint32_t h, uint32_t d, float u, float v, float ww, float* out4)
+{ const Tex3 t{rgba, w, h, d}; F4v r = sample_trilinear_repeat(t, u, v, ww); out4[0] = r.x; out4[1] = r.y; out4[2] = r.z; out4[3] = r.w; }
+void orc_scene_data_lookup_float4x4(const float* defaultValue, float* out) { scene_data_lookup_float4x4(defaultValue, out); }
 void orc_tex_lookup(const OrcTexture* t, float u, float v, int wrapU, int wrapV, float* out4)
 {
   F4v r = tex_lookup_float4_2d(*t, u, v, wrapU, wrapV);

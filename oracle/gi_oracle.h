@@ -255,6 +255,10 @@ int      orc_trace_batch(const OrcScene* scene, uint32_t count, const float* ori
  * eval pdf. */
 void     orc_bsdf_debug(const OrcMaterial* mat, uint32_t count, const float* in, float* out);
 
+/* the MDL runtime's remaining texture entry points (mdl_interface.glsl:45-65, 86-105, 167-221), 8 floats per query -> 4 per result (see gi_oracle.cpp) */
+void orc_tex_runtime(const float* rgba, uint32_t w, uint32_t h, uint32_t d, uint32_t count, const float* queries, float* out);
+void orc_dbg_sample_trilinear(const float* rgba, uint32_t w, uint32_t h, uint32_t d, float u, float v, float ww, float* out4);
+void orc_scene_data_lookup_float4x4(const float* defaultValue, float* out);
 #ifdef __cplusplus
 }
 #endif

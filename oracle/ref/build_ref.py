@@ -26,7 +26,8 @@ LIB = os.path.join(OUT, "libgi_ref.so")
 
 WHOLE = ["common.glsl", "aovs.glsl", "colormap.glsl", "rp_main_payload.glsl", "interface/rp_main.h", "mdl_shading_state.glsl"]
 FUNCTIONS = {"rp_main.rgen": ["sampleDistance", "sampleHenyeyGreensteinCos", "sampleVolumeScatteringDirection", "russian_roulette", "fisGauss"],
-             "rp_main.miss": ["quatRotateDir"], "rp_main.chit": ["sampleLight"], "mdl_interface.glsl": ["apply_wrap_and_crop", "mdl_adapt_normal", "tex_lookup_float4_2d"]}
+             "rp_main.miss": ["quatRotateDir"], "rp_main.chit": ["sampleLight"], "mdl_interface.glsl": ["apply_wrap_and_crop", "mdl_adapt_normal", "tex_lookup_float4_2d", "tex_texel_float4_2d", "tex_resolution_2d", "tex_lookup_float4_3d",
+                                    "tex_texel_float4_3d"]}
 
 
 def to_cpp(text: str) -> str:

@@ -3,6 +3,7 @@
 // restatements with these.  The files included below from oracle/_ref/gen/ are generated from the reference sources at build time.
 #include "glsl_compat.h"
 extern "C" void orc_dbg_sample_bilinear(const void* orcTexture, float u, float v, float* out4); // oracle/gi_oracle.cpp
+extern "C" void orc_dbg_sample_trilinear(const float* rgba, uint32_t w, uint32_t h, uint32_t d, float u, float v, float ww, float* out4);
 
 #include <cstdint>
 #undef UINT32_MAX // common.glsl declares a constant of this name
@@ -83,6 +84,25 @@ static vec4 texture(const sampler2D& s, vec2 uv)
   return vec4(o[0], o[1], o[2], o[3]);
 }
 #include "fn_tex_lookup_float4_2d.h"
+// the remaining texture entry points (mdl_interface.glsl:45-65, 86-105, 167-221): texelFetch is the texel itself; the 3-D sampler is the oracle's trilinear one (D5)
+typedef decltype(Float().v) RawF; // (`float` is the strict-fp32 class in here)
+static vec4 texelFetch(const sampler2D& s, ivec2 c, int)
+{ const RawF* p = (const RawF*)s.t->rgba + 4 * ((size_t)c.y * s.t->w + (size_t)c.x); return vec4(Float(p[0]), Float(p[1]), Float(p[2]), Float(p[3])); }
+struct Tex3D { const void* rgba; int w, h, d; };
+static Tex3D textures_3d[1];
+struct sampler3D { const Tex3D* t; sampler3D(const Tex3D& tex, const SamplerT&) : t(&tex) {} };
+static ivec3 textureSize(const Tex3D& t, int) { return ivec3(t.w, t.h, t.d); }
+static vec4 texture(const sampler3D& s, vec3 uvw)
+{
+  Float o[4]; orc_dbg_sample_trilinear((const RawF*)s.t->rgba, (uint32_t)s.t->w, (uint32_t)s.t->h, (uint32_t)s.t->d, uvw.x.v, uvw.y.v, uvw.z.v, reinterpret_cast<decltype(o[0].v)*>(o));
+  return vec4(o[0], o[1], o[2], o[3]);
+}
+static vec4 texelFetch(const sampler3D& s, ivec3 c, int)
+{ const RawF* p = (const RawF*)s.t->rgba + 4 * (((size_t)c.z * s.t->h + (size_t)c.y) * s.t->w + (size_t)c.x); return vec4(Float(p[0]), Float(p[1]), Float(p[2]), Float(p[3])); }
+#include "fn_tex_texel_float4_2d.h"
+#include "fn_tex_resolution_2d.h"
+#include "fn_tex_lookup_float4_3d.h"
+#include "fn_tex_texel_float4_3d.h"
 #include "fn_mdl_adapt_normal.h"
 #include "mdl_shading_state.glsl"
 #undef float
@@ -133,6 +153,21 @@ void ref_tex_lookup_float4_2d(const float* rgba, int w, int h, int tex, float u,
   ref::textures_2d[0] = ref::Tex2D{rgba, w, h};
   vec4 r = ref::tex_lookup_float4_2d(tex, vec2(u, v), wrapU, wrapV, vec2(0.0f, 1.0f), vec2(0.0f, 1.0f), Float(0.0f));
   out[0] = r.x.v; out[1] = r.y.v; out[2] = r.z.v; out[3] = r.w.v;
+}
+// the remaining texture entry points; same query layout as the oracle's orc_tex_runtime (kind, valid, c0, c1, c2, wrapU, wrapV, wrapW)
+void ref_tex_runtime(const float* rgba, int w, int h, int d, uint32_t count, const float* queries, float* out)
+{
+  ref::textures_2d[0] = ref::Tex2D{rgba, w, h}; ref::textures_3d[0] = ref::Tex3D{rgba, w, h, d};
+  for (uint32_t i = 0; i < count; i++) {
+    const float* q = queries + 8 * (size_t)i; float* o = out + 4 * (size_t)i;
+    const int kind = (int)q[0], tex = q[1] != 0.0f ? 1 : 0;
+    vec4 r(Float(0.0f), Float(0.0f), Float(0.0f), Float(0.0f));
+    if (kind == 0) r = ref::tex_texel_float4_2d(tex, ref::ivec2((int)q[2], (int)q[3]), ref::ivec2(0, 0), Float(0.0f));
+    else if (kind == 1) { const ref::ivec2 res = ref::tex_resolution_2d(tex, ref::ivec2(0, 0), Float(0.0f)); r = vec4(Float((float)res.x), Float((float)res.y), Float(0.0f), Float(0.0f)); }
+    else if (kind == 2) r = ref::tex_lookup_float4_3d(tex, vec3(q[2], q[3], q[4]), (int)q[5], (int)q[6], (int)q[7], vec2(0.0f, 1.0f), vec2(0.0f, 1.0f), vec2(0.0f, 1.0f), Float(0.0f));
+    else r = ref::tex_texel_float4_3d(tex, ref::ivec3((int)q[2], (int)q[3], (int)q[4]), Float(0.0f));
+    o[0] = r.x.v; o[1] = r.y.v; o[2] = r.z.v; o[3] = r.w.v;
+  }
 }
 void ref_adapt_normal(const float* rayDir, const float* geomNormal, const float* shadingNormal, const float* normal, float* out)
 { ref::gl_WorldRayDirectionEXT = V3(rayDir); ref::State s; s.normal = V3(shadingNormal); s.geom_normal = V3(geomNormal); put(out, ref::mdl_adapt_normal(s, V3(normal))); }

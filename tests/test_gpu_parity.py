@@ -1050,3 +1050,24 @@ def test_thin_walled_subsurface_scene_parity(gi, orc):
         assert st["segments"] == cnt["segments"] and st["shadowRays"] == cnt["shadow_rays"]
         imgs[w] = img
     assert not np.array_equal(imgs[0.0], imgs[0.9])
+
+
+def test_remaining_texture_entry_points_on_device(gi):
+    """tex_texel_float4_2d, tex_resolution_2d, tex_lookup_float4_3d, tex_texel_float4_3d (mdl_interface.glsl:45-65, 86-105, 167-221) on the device == the oracle,
+    which tests/test_oracle_ref.py holds to the reference's text: in range, outside, the invalid texture, every wrap mode."""
+    import ctypes as C
+    from oracle import orc as O
+    from test_oracle_ref import _tex_runtime_queries
+    rng = np.random.default_rng(13)
+    w, h, d, n = 6, 5, 4, 20000
+    vol = np.ascontiguousarray(rng.uniform(0, 1, (d, h, w, 4)).astype(np.float32))
+    q = _tex_runtime_queries(rng, w, h, d, n)
+    got, ref = np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)
+    FP = C.POINTER(C.c_float)
+    L = gi.load_library()
+    assert L.giCDebugTexRuntime(vol.ctypes.data_as(FP), w, h, d, n, q.ctypes.data_as(FP), got.ctypes.data_as(FP)) == gi.GI_C_OK
+    lib = O.lib()
+    lib.orc_tex_runtime.argtypes = [FP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, FP, FP]
+    lib.orc_tex_runtime(vol.ctypes.data_as(FP), w, h, d, n, q.ctypes.data_as(FP), ref.ctypes.data_as(FP))
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert np.abs(got).sum() > 0

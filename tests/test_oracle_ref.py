@@ -352,3 +352,43 @@ def test_tex_lookup_float4_2d_against_reference(ref, orc):
         assert bits(a[:]).tolist() == bits(b[:]).tolist() and any(x != 0 for x in a[:])
     ref.ref_tex_lookup_float4_2d(img.ctypes.data, 7, 5, 0, 0.3, 0.3, 1, 1, a)  # tex == 0: the invalid texture
     assert list(a[:]) == [0, 0, 0, 0] and n == 2400
+
+
+def _tex_runtime_queries(rng, w, h, d, n):
+    """(kind, valid, c0, c1, c2, wrapU, wrapV, wrapW) rows for the MDL runtime's remaining texture entry points: in range, outside, the invalid texture, all wraps."""
+    q = np.zeros((n, 8), np.float32)
+    q[:, 0] = rng.integers(0, 4, n)
+    q[:, 1] = rng.uniform(size=n) > 0.1
+    integer = (q[:, 0] == 0) | (q[:, 0] == 3)
+    q[:, 2] = np.where(integer, rng.integers(-2, w + 2, n), rng.uniform(-2.5, 3.5, n))
+    q[:, 3] = np.where(integer, rng.integers(-2, h + 2, n), rng.uniform(-2.5, 3.5, n))
+    q[:, 4] = np.where(integer, rng.integers(-2, d + 2, n), rng.uniform(-2.5, 3.5, n))
+    q[:, 5:8] = rng.integers(0, 4, (n, 3))
+    return np.ascontiguousarray(q)
+
+
+def test_remaining_texture_entry_points_against_reference(ref, orc):
+    """tex_texel_float4_2d (mdl_interface.glsl:167-186), tex_resolution_2d (:208-221), tex_lookup_float4_3d (:45-65), tex_texel_float4_3d (:86-105) -- the
+    runtime entry points only MDL-generated code calls -- from the reference's text against the oracle's restatements, bit for bit (the 3-D sampler is the oracle's
+    software trilinear one on both sides: deviation D5 is the filter weights only).  scene_data_lookup_float4x4 returns its default in the reference (:476-479)."""
+    rng = np.random.default_rng(12)
+    w, h, d, n = 5, 4, 3, 6000
+    vol = np.ascontiguousarray(rng.uniform(0, 1, (d, h, w, 4)).astype(np.float32))
+    q = _tex_runtime_queries(rng, w, h, d, n)
+    a, b = np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)
+    FP = C.POINTER(C.c_float)
+    ref.ref_tex_runtime.argtypes = [FP, C.c_int, C.c_int, C.c_int, C.c_uint32, FP, FP]
+    orc.orc_tex_runtime.argtypes = [FP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, FP, FP]
+    ref.ref_tex_runtime(vol.ctypes.data_as(FP), w, h, d, n, q.ctypes.data_as(FP), a.ctypes.data_as(FP))
+    orc.orc_tex_runtime(vol.ctypes.data_as(FP), w, h, d, n, q.ctypes.data_as(FP), b.ctypes.data_as(FP))
+    bad = np.nonzero((a.view(np.uint32) != b.view(np.uint32)).any(axis=1))[0]
+    assert bad.size == 0, (q[bad[:3]], a[bad[:3]], b[bad[:3]])
+    for kind in range(4):
+        sel = q[:, 0] == kind
+        assert sel.sum() > 1000 and np.abs(a[sel]).sum() > 0
+    res = a[(q[:, 0] == 1) & (q[:, 1] != 0)]
+    assert np.all(res[:, 0] == w) and np.all(res[:, 1] == h)
+    m = np.arange(16, dtype=np.float32); out = np.zeros(16, np.float32)
+    orc.orc_scene_data_lookup_float4x4.argtypes = [FP, FP]
+    orc.orc_scene_data_lookup_float4x4(m.ctypes.data_as(FP), out.ctypes.data_as(FP))
+    assert np.array_equal(m, out)
