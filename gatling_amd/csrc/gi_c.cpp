@@ -1685,7 +1685,8 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
     // tail (measured on C3 at spp 64 / 256: 4 Mi slots 630, 16 Mi 790, 32 Mi 831 / 810, 64 Mi - / 868 Msamples/s); LDS-resident scenes have uniform, short rays.
     const bool sceneInLds = s->nodeCount <= 384u && s->triCount <= 128u;
     const uint64_t poolDefault = sceneInLds ? (4u << 20) : (64u << 20);
-    const uint64_t poolMax = std::max<uint64_t>(64, envU64("GATLING_POOL_SLOTS", s->optPoolSlots ? s->optPoolSlots : poolDefault));
+    const uint64_t poolMax = std::min<uint64_t>((1ull << 30) - 1ull, // regen-queue entries keep two flag bits above the slot index (REGEN_MISSED, REGEN_FRESH)
+                                                std::max<uint64_t>(64, envU64("GATLING_POOL_SLOTS", s->optPoolSlots ? s->optPoolSlots : poolDefault)));
     uint64_t batchSamples = std::min<uint64_t>(rs.spp, std::max<uint64_t>(1, budgetBytes / (pixels * 16)));
     batchSamples = std::min<uint64_t>(batchSamples, std::max<uint64_t>(1, 0xffffffffull / pixels)); // work ids stay 32-bit
     const uint32_t numBatches = (uint32_t)((rs.spp + batchSamples - 1) / batchSamples);
