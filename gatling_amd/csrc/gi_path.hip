@@ -69,6 +69,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(GI_
   GI_LDS uint32_t (*pre)[128] = (GI_LDS uint32_t (*)[128])&s_pre[threadIdx.x >> 6][0][0];
   uint32_t preHead = 0u, preTail = 0u; // wave-uniform ring positions (monotonic; slot = position & 127)
 
+  unsigned long long pc[4] = {0ull, 0ull, 0ull, 0ull}, pl[4] = {0ull, 0ull, 0ull, 0ull}, trips = 0ull, tPrev = COUNT ? __builtin_readcyclecounter() : 0ull;
+  auto phase = [&](int k, unsigned long long lanes) { if (COUNT) { const unsigned long long t = __builtin_readcyclecounter(); pc[k] += t - tPrev; tPrev = t; pl[k] += lanes; } };
   for (;;) {
     __atomic_signal_fence(__ATOMIC_SEQ_CST); // (compiler only) the ring is exchanged between the lanes of this wave through LDS
     // --- regeneration (rp_main.rgen:213-283): idle lanes take the next work items w = sample * P + pixel
@@ -111,6 +113,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(GI_
       preHead += take;
     }
     if (!__ballot(alive)) break;
+    phase(0, nIdle); trips++;
 
     // --- closest hit (traceRayEXT, rp_main.rgen:381-393): all rays of the wave advance in steps, triangles are tested cooperatively
     trav_init(R, ro, rdv, tMin, alive ? tMax : 0.0f);
@@ -121,6 +124,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(GI_
     }
     bool ended = false, missed = false;
     ShadeIO io; io.shadow = false; io.shadowFirst = false; io.cont = false;
+    phase(1, (unsigned long long)__popcll(__ballot(alive)));
     if (alive) {
       nSeg++;
       wave_ray_end(W, R);
@@ -139,6 +143,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(GI_
       }
     }
     (void)missed;
+    phase(2, (unsigned long long)__popcll(__ballot(alive && R.found)));
 
     // --- shadow ray of this bounce (rp_main.rgen:397-429): origin = next ray origin, tMin 0.01, tMax = distance to the light sample
     if (NEE) {
@@ -175,8 +180,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(GI_
         alive = false;
       }
     }
+    phase(3, (unsigned long long)__popcll(__ballot(ended)));
   }
 
+  if (COUNT && lane == 0u) { for (int k = 0; k < 4; k++) { atomicAdd(&cnt->phaseCycles[k], pc[k]); atomicAdd(&cnt->phaseLanes[k], pl[k]); } atomicAdd(&cnt->phaseTrips, trips); }
   // statistics: one atomic per wave and counter
   unsigned long long a = nSeg, b = nShadow, c = tc.nodes, d = tc.tris, e = tcs.nodes, f = tcs.tris;
   for (int off = 32; off > 0; off >>= 1) {

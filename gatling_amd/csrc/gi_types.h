@@ -263,6 +263,9 @@ struct Counters {
   PaddedCounter cursor[2][NCURSOR];
   unsigned long long segments, shadowRays, nodesVisited, trisTested, shadowNodesVisited, shadowTrisTested;
   uint32_t overflow; // set by block_append when a shard would run past its capacity (host sizing bug): giCRender fails loudly
+  // k_path, counting builds only (GI_C_SCENE_OPTION_COUNT_TRAVERSAL): shader-clock cycles per phase summed over waves, lanes doing useful work per phase summed over
+  // trips, trips -- [0] regeneration, [1] closest-hit traversal, [2] shading, [3] shadow ray + finish (GATLING_PHASE_STATS=1 prints them)
+  unsigned long long phaseCycles[4], phaseLanes[4], phaseTrips;
 };
 
 } // namespace gi
