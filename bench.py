@@ -14,11 +14,16 @@ N>1 is strong scaling: the rows of the same frame are dealt round-robin to the N
 every share samples the whole image; one rank per GPU, scene replicated) and gathered to rank 0 with
 one RCCL gather.  Rank 0 prints ONE JSON line.
 
-roofline (what the line means): `frac` = HBM bytes the dominant kernel really moved (rocprofv3 PMC
-FETCH_SIZE / WRITE_SIZE, collected by this same run in separate `--pmc` passes of this same workload) / its mean launch
-time (HIP events on the library's stream, live) / 8 TB/s.  `algorithmic_frac` is the SURVEY 8d canonical-bytes figure (it
-counts node / triangle bytes whether they come from HBM, L2 or LDS, so it can exceed 1), `valu_frac` the share of the
-VALU issue cycles the kernel used; `bound` names the limiter the counters point to.
+roofline (what the line means): `frac` = HBM bytes the dominant kernel really moved (rocprofv3 PMC FETCH_SIZE / WRITE_SIZE, collected by this same run in
+separate `--pmc` passes of this same workload, calibrated with tools/pmc_calib.hip) / its mean launch time (HIP events on the library's stream, live) / 8 TB/s.
+`algorithmic_frac` is the SURVEY 8d canonical-bytes figure (it counts node / triangle bytes whether they come from HBM, L2 or LDS, so it can exceed 1).  The VALU
+side is reported in wall-clock terms against ceilings MEASURED by tools/valu_calib.hip (profiles/valu_issue_calibration.json): `valu_instr_per_simd_per_ns`,
+`valu_frac` = that / the dual-issue ceiling (alternating instruction classes, ~1.04), `valu_frac_fp32_only` = that / the single-class ceiling (~0.59).  `bound` names
+the nearer of the two rooflines; `bound_note` says when neither is near (the big-scene traversal is bound by the L1 -> L2 request path, tools/ta_calib.hip,
+DESIGN.md section 4).
+
+At N = 1 the default line carries, under `also`, configs C3 and C4 -- the wavefront pipeline (k_raygen / k_trace_dyn / k_route / k_shade / k_trace_dyn<any>) --
+each with its own roofline object and every kernel's time share / VALU rate / lanes / L2 hit (`all_kernels`); at N >= 8 config C5, tiled across the ranks.
 """
 import argparse
 import json
