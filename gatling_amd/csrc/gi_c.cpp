@@ -1248,6 +1248,7 @@ int buildScene(GiCScene* s)
   s->nodeCount = (uint32_t)bvh.nodes.size(); s->triCount = (uint32_t)bvh.tris.size(); s->bvhDepth = bvh.maxDepth > 1u ? bvh.maxDepth - 1u : 1u; // stack entries a walk can need: a pick at level L pushes the rest of level L-1's group (gi_traversal.h trav_node_pick), the root level pushes nothing
   s->stats.bvhBuildMs = t1 - t0; s->stats.uploadMs = nowMs() - t1;
   s->stats.nodeCount = s->nodeCount; s->stats.triangleCount = s->triCount;
+  if (getenv("GATLING_BUILD_TIMING")) fprintf(stderr, "[gatling_gi] scene: %u nodes, %u triangles, %u levels (traversal stack need %u)\n", s->nodeCount, s->triCount, bvh.maxDepth, s->bvhDepth);
   s->host = std::move(hostPtr);
   return GI_C_OK;
 }

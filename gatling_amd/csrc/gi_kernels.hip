@@ -704,7 +704,8 @@ static void launchTraceVariant(hipStream_t s, uint32_t blocks, const SceneView& 
     const bool spill8 = (dynRefill & TRACE_DYN_SPILL8) != 0u;
     const uint32_t claimChunks = dynRefill >> 16;
     dynRefill = (dynRefill & 0xffu) | (claimChunks << 16);
-    const uint32_t entries = (sc.bvhDepth <= 8u || spill8) ? 8u : 16u;
+    // 8 entries (16 KB per block), 12 (24 KB: 5 blocks per CU still fit next to the 8 KB of WaveTri) or 16 (32 KB: 4 blocks -- one wave per SIMD fewer)
+    const uint32_t entries = (sc.bvhDepth <= 8u || spill8) ? 8u : (sc.bvhDepth <= 12u ? 12u : 16u);
     // top-of-tree prefix staged in LDS: root + children + grandchildren (1 + 8 + 64 nodes = 5.8 KB) keeps 5 blocks per CU resident
     static const int envLds = getenv("GATLING_DYN_LDS_NODES") ? atoi(getenv("GATLING_DYN_LDS_NODES")) : -1;
     static const int envXcd = getenv("GATLING_DYN_XCD") ? atoi(getenv("GATLING_DYN_XCD")) : -1;
@@ -724,6 +725,7 @@ static void launchTraceVariant(hipStream_t s, uint32_t blocks, const SceneView& 
 #define GI_LAUNCH_DYN(K) do { \
     if (sc.bvhDepth <= 8u) hipLaunchKernelGGL((K<ANYHIT, COUNT, 8, false, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill, dynLdsNodes, dynFlags); \
     else if (spill8) hipLaunchKernelGGL((K<ANYHIT, COUNT, 8, true, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill, dynLdsNodes, dynFlags); \
+    else if (sc.bvhDepth <= 12u) hipLaunchKernelGGL((K<ANYHIT, COUNT, 12, false, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill, dynLdsNodes, dynFlags); \
     else if (sc.bvhDepth <= 16u) hipLaunchKernelGGL((K<ANYHIT, COUNT, 16, false, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill, dynLdsNodes, dynFlags); \
     else hipLaunchKernelGGL((K<ANYHIT, COUNT, 16, true, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill, dynLdsNodes, dynFlags); } while (0)
     GI_LAUNCH_DYN(k_trace_dyn);

@@ -252,7 +252,10 @@ template <class WT> __device__ __forceinline__ uint4 wt_hit_get(WT& W, uint32_t 
 struct WaveStage { uint4 buf[64 * 5]; };
 // Measured on C3 (1M-triangle soup): 35.4 ms with the cooperative fetch vs 29.6 ms without (the 20 KiB of staging per
 // block cost two resident blocks per CU and the extra LDS round trip outweighs the saved tag look-ups) -> off.
-constexpr bool TRACE_DYN_COOP_FETCH = false;
+#ifndef GI_TRACE_DYN_COOP
+#define GI_TRACE_DYN_COOP 0
+#endif
+constexpr bool TRACE_DYN_COOP_FETCH = GI_TRACE_DYN_COOP != 0; // (r03: re-measured as a variant build, see below)
 #ifndef GI_TRI_FULL_LOAD
 #define GI_TRI_FULL_LOAD 0 // measured (r03a, C3): loading all 48 bytes up front is SLOWER -- shadow rays 44.4 -> 50.2 ms, closest hit 131 -> 134-141 ms: the vector-memory request path, not the dependent round trip, is what the batch waits for
 #endif
