@@ -38,6 +38,8 @@ using namespace gi;
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 
+constexpr bool WORK_ORDER_PIXEL_MAJOR_DEFAULT = true;  // (GATLING_WORK_ORDER) FLAG_PIXEL_MAJOR, gi_queues.h work_item
+
 thread_local std::string t_lastError;
 void setError(const std::string& e) { t_lastError = e; fprintf(stderr, "[gatling_gi] error: %s\n", e.c_str()); }
 
@@ -1697,6 +1699,8 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
     bool fused = pathKernelSupports(view) && s->optFusedPath != 0;
     if (const char* e = getenv("GATLING_FUSED")) fused = fused && atoi(e) != 0;
     usedFused = fused;
+    // work order of the wavefront pipeline and layout of its per-sample buffer (gi_queues.h work_item); the fused kernels hand work out sample-major
+    { const char* e = getenv("GATLING_WORK_ORDER"); if (!fused && (e ? atoi(e) != 0 : WORK_ORDER_PIXEL_MAJOR_DEFAULT)) U.flags |= FLAG_PIXEL_MAJOR; }
     const size_t slots = fused ? 1 : (size_t)std::min<uint64_t>(poolMax, (uint64_t)pixels * batchSamples);
 
     // persistent grids: blocks per CU limited by registers (<= 6 waves/SIMD for k_trace) and, for k_trace, by the LDS it stages

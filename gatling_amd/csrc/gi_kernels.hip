@@ -100,12 +100,12 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st,
         float mv = fmax2(rad.x, fmax2(rad.y, rad.z));
         if (mv > U.maxSampleValue) rad = rad * (U.maxSampleValue / mv);
         // one aligned 16-byte store: a 12-byte record straddles DRAM sectors and costs two read-modify-writes
-        st4(&sampleBuf[(size_t)f2u(id.y) * U.pixelCount + f2u(id.x)], fmax2(0.0f, rad.x), fmax2(0.0f, rad.y), fmax2(0.0f, rad.z), 0.0f);
+        st4(&sampleBuf[sample_record(U, f2u(id.x), f2u(id.y))], fmax2(0.0f, rad.x), fmax2(0.0f, rad.y), fmax2(0.0f, rad.z), 0.0f);
       }
       const uint32_t w = workBase + i; // < 2^32 by construction of the batches (host)
       more = (i < U.workTotal - workBase) && (w < U.workTotal);
       if (more) {
-        const uint32_t pixelLocal = w % U.pixelCount, sLocal = w / U.pixelCount;
+        uint32_t pixelLocal, sLocal; work_item(U, w, pixelLocal, sLocal);
         const uint32_t pixelIndex = tile_to_image_pixel(U, pixelLocal); // :195 (global index: RNG is tile independent)
         const uint32_t sampleIndex = U.sampleOffset + U.batchFirstSample + sLocal;
         uint32_t rng;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st,
 // ------------------------------------------------------------------------------------------------
 // k_accumulate: folds one batch of per-sample colours into the per-pixel running sum IN SAMPLE ORDER
 // (pixel_color += sample_color * invSpp, rp_main.rgen:498) and, after the last batch, writes the colour AOV with
-// the progressive blend of rp_main.rgen:506-515.  One thread per pixel; reads are coalesced across pixels.
+// the progressive blend of rp_main.rgen:506-515.  One thread per pixel; reads are coalesced across pixels (sample-major buffer) or whole lines per thread (pixel-major).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_accumulate(FrameUniforms U, const F4* __restrict__ sampleBuf, F4* __restrict__ accum, F4* __restrict__ colorOut,
                                                       uint32_t firstBatch, uint32_t lastBatch)
@@ -137,9 +137,22 @@ __global__ __launch_bounds__(BLOCK) void k_accumulate(FrameUniforms U, const F4*
   if (p >= U.pixelCount) return;
   V3 pixelColor = v3(0.0f, 0.0f, 0.0f);
   if (!firstBatch) { const F4 a = ld4(&accum[p]); pixelColor = v3(a.x, a.y, a.z); }
-  for (uint32_t s = 0; s < U.batchSamples; s++) {
-    const F4 src = ld4(&sampleBuf[(size_t)s * U.pixelCount + p]);
-    pixelColor = pixelColor + v3(src.x, src.y, src.z) * U.invSpp;
+  if (U.flags & FLAG_PIXEL_MAJOR) { // the pixel's samples are one contiguous run: a thread streams its own lines, eight records (one 128-byte line) per round
+    const F4* src = sampleBuf + (size_t)p * U.batchSamples;
+    uint32_t s = 0;
+    for (; s + 8u <= U.batchSamples; s += 8u) {
+      F4 r[8];
+#pragma unroll
+      for (uint32_t k = 0; k < 8u; k++) r[k] = ld4(&src[s + k]);
+#pragma unroll
+      for (uint32_t k = 0; k < 8u; k++) pixelColor = pixelColor + v3(r[k].x, r[k].y, r[k].z) * U.invSpp;
+    }
+    for (; s < U.batchSamples; s++) { const F4 r = ld4(&src[s]); pixelColor = pixelColor + v3(r.x, r.y, r.z) * U.invSpp; }
+  } else {
+    for (uint32_t s = 0; s < U.batchSamples; s++) {
+      const F4 src = ld4(&sampleBuf[(size_t)s * U.pixelCount + p]);
+      pixelColor = pixelColor + v3(src.x, src.y, src.z) * U.invSpp;
+    }
   }
   if (!lastBatch) { st4(&accum[p], pixelColor.x, pixelColor.y, pixelColor.z, 0.0f); return; }
   const uint32_t pixelIndex = tile_to_image_pixel(U, p);

@@ -77,6 +77,33 @@ __device__ __forceinline__ uint32_t tile_to_image_pixel(const FrameUniforms& U, 
   const uint32_t row = pixelLocal / U.imageWidth, x = pixelLocal - row * U.imageWidth;
   return (U.rowBegin + row * U.rowStride) * U.imageWidth + x;
 }
+// Work item w of a batch -> (tile-local pixel, sample of the batch).  Any bijection gives the same image (a sample's RNG stream is a function of its pixel and
+// sample index alone, and k_accumulate sums a pixel's samples in sample order); it decides which rays sit next to each other in the queues.
+//   sample-major (w = sample * P + pixel): a wave holds 64 adjacent pixels of one sample index;
+//   pixel-major (FLAG_PIXEL_MAJOR, w = visit(pixel) * S + sample): a wave holds consecutive samples of ONE pixel -- camera rays that differ by the sub-pixel
+//   jitter only, so its lanes ask for the same nodes and triangles (one request per distinct line) -- and pixels are visited in 8x8 blocks.
+__device__ __forceinline__ uint32_t visit_to_pixel(const FrameUniforms& U, uint32_t q)
+{
+  const uint32_t W = U.imageWidth, rows = U.pixelCount / W;
+  const uint32_t band = q / (8u * W), j = q - band * 8u * W;
+  const uint32_t left = rows - band * 8u, r = left < 8u ? left : 8u; // rows of this band
+  const uint32_t nFull = W >> 3, t = j / (8u * r);
+  uint32_t x, y;
+  if (t < nFull) { const uint32_t k = j - t * 8u * r; x = 8u * t + (k & 7u); y = k >> 3; }
+  else { const uint32_t wr = W - 8u * nFull, k = j - nFull * 8u * r; y = k / wr; x = 8u * nFull + (k - y * wr); }
+  return (band * 8u + y) * W + x;
+}
+__device__ __forceinline__ void work_item(const FrameUniforms& U, uint32_t w, uint32_t& pixelLocal, uint32_t& sLocal)
+{
+  if (U.flags & FLAG_PIXEL_MAJOR) { const uint32_t q = w / U.batchSamples; sLocal = w - q * U.batchSamples; pixelLocal = visit_to_pixel(U, q); }
+  else { sLocal = w / U.pixelCount; pixelLocal = w - sLocal * U.pixelCount; }
+}
+// where sample `sLocal` of tile pixel `pixelLocal` lives in the per-sample colour buffer: next to the other samples of its pixel when the work order is
+// pixel-major (the lanes of a wave finish consecutive samples of one pixel: one contiguous run), next to the same sample of the neighbouring pixels otherwise
+__device__ __forceinline__ size_t sample_record(const FrameUniforms& U, uint32_t pixelLocal, uint32_t sLocal)
+{
+  return (U.flags & FLAG_PIXEL_MAJOR) ? (size_t)pixelLocal * U.batchSamples + sLocal : (size_t)sLocal * U.pixelCount + pixelLocal;
+}
 constexpr uint32_t MISS = 0xffffffffu;
 constexpr uint32_t REGEN_MISSED = 0x80000000u; // flag on a regen-queue entry: the path left the scene (k_trace -> k_raygen)
 constexpr uint32_t REGEN_FRESH = 0x40000000u;  // flag on a regen-queue entry written by k_init: the slot carries no sample yet and its memory is uninitialised -- k_raygen

@@ -138,6 +138,7 @@ struct FrameUniforms {
 };
 enum : uint32_t {
   FLAG_JITTER = 1u, FLAG_FIS = 2u, FLAG_DOF = 4u, FLAG_CLIP = 8u, FLAG_NEE = 16u, FLAG_PROGRESSIVE = 32u,
+  FLAG_PIXEL_MAJOR = 64u, // work order of the wavefront pipeline (gi_queues.h work_item)
 };
 
 // Device-side scene view handed to the kernels.
