@@ -221,9 +221,10 @@ def test_pool_and_batch_invariance(gi, orc):
     rs = RenderSettings(spp=24, max_bounces=6)
     w, h = 160, 90
     ref, cnt = orc.render(desc, rs, w, h, threads=4)
-    for pool, mb in ((64, 0), (1000, 1), (0, 1), (1 << 22, 0)):
+    for pool, mb, fused in ((64, 0, 0), (1000, 1, 0), (0, 1, 0), (1 << 22, 0, 0), (0, 1, -1)):
         sc = gi.Scene(desc)
         try:
+            sc.set_option(gi.OPTION_FUSED_PATH, fused)  # 0: the stage kernels (cornell would otherwise run the fused kernel, which has no pool)
             sc.set_option(gi.OPTION_POOL_SLOTS, pool)
             sc.set_option(gi.OPTION_SAMPLE_BUFFER_MB, mb)
             img = sc.render(rs, w, h)
@@ -232,6 +233,29 @@ def test_pool_and_batch_invariance(gi, orc):
             sc.close()
         assert st["segments"] == cnt["segments"]
         assert_image_parity(img, ref, exact=True)
+
+
+@pytest.mark.parametrize("w,h,spp,mb", [(96, 54, 5, 0), (37, 21, 3, 0), (100, 7, 9, 0), (8, 8, 2, 0), (155, 90, 7, 1)])
+def test_work_order_invariance(gi, orc, monkeypatch, w, h, spp, mb):
+    """The wavefront pipeline may hand its work items out sample-major or pixel-major (8x8 pixel blocks, a pixel's samples consecutive; gi_queues.h
+    work_item), with the per-sample buffer laid out to match: any bijection work item -> (pixel, sample) gives the oracle's image.  Widths and heights that
+    are no multiples of 8 exercise the ragged blocks; the 1 MiB sample buffer splits the frame into several batches."""
+    for desc, nee in ((cornell_box(), False), (_soup(3000), True)):
+        rs = RenderSettings(spp=spp, max_bounces=4, next_event_estimation=nee)
+        ref, cnt = orc.render(desc, rs, w, h, threads=4)
+        for order in ("0", "1"):
+            monkeypatch.setenv("GATLING_WORK_ORDER", order)
+            sc = gi.Scene(desc)
+            try:
+                sc.set_option(gi.OPTION_FUSED_PATH, 0)
+                sc.set_option(gi.OPTION_POOL_SLOTS, 777)
+                sc.set_option(gi.OPTION_SAMPLE_BUFFER_MB, mb)
+                img = sc.render(rs, w, h)
+                st = sc.stats()
+            finally:
+                sc.close()
+            assert st["fusedPath"] == 0 and st["segments"] == cnt["segments"], (order, st)
+            assert_image_parity(img, ref, exact=True)
 
 
 def _aov_scene():
