@@ -309,6 +309,8 @@ struct SceneDevice {
   uint32_t queueCap = 0;
   DeviceBuffer<Counters> dCounters;
   Counters* hCounters = nullptr; // pinned
+  static constexpr uint32_t POLL_RING = 4, POLL_LAG = 2; // drain test of the bounce loop: iteration it reads the queue sizes of iteration it - POLL_LAG (giCRenderImpl)
+  PaddedCounter* hPoll = nullptr; hipEvent_t pollEvent[POLL_RING] = {}; // pinned ring of queue-size snapshots + their completion events
   GiCRenderStats stats{};
   std::vector<hipEvent_t> eventPool;
   void releaseAll();
@@ -376,6 +378,7 @@ void SceneDevice::releaseAll()
   for (uint32_t q = 0; q < Q_COUNT; q++) { qSlot[q].release(); qA[q].release(); qB[q].release(); qC[q].release(); }
   dCounters.release();
   if (hCounters) { (void)hipHostFree(hCounters); hCounters = nullptr; }
+  if (hPoll) { (void)hipHostFree(hPoll); hPoll = nullptr; for (hipEvent_t& e : pollEvent) { (void)hipEventDestroy(e); e = nullptr; } }
   for (hipEvent_t e : eventPool) (void)hipEventDestroy(e);
   eventPool.clear();
 }
@@ -1511,6 +1514,10 @@ int ensurePathState(SceneDevice* s, size_t slots, uint32_t gridA, uint32_t gridB
     s->queueCap = cap;
   }
   if (!s->hCounters) HIP_TRY(hipHostMalloc((void**)&s->hCounters, sizeof(Counters), hipHostMallocDefault));
+  if (!s->hPoll) {
+    HIP_TRY(hipHostMalloc((void**)&s->hPoll, sizeof(PaddedCounter) * Q_COUNT * NSHARD * SceneDevice::POLL_RING, hipHostMallocDefault));
+    for (hipEvent_t& e : s->pollEvent) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
   return GI_C_OK;
 }
 
@@ -1664,6 +1671,8 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
   bool usedFused = false;
   size_t ev = 0;
   std::vector<int> evKind; // 0 raygen, 1 trace, 2 shade, 3 shadow
+  struct IterRow { size_t evEnd; uint64_t traced, hits, shadow, ended, cont; };
+  std::vector<IterRow> iterRows; // (GATLING_ITER_LOG)
   const bool timers = s->kernelTimers;
   uint64_t sampledIters = 0, totalIters = 0;
   SceneView view = makeView(s, D);
@@ -1751,7 +1760,7 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
       if (timers && (curIter % timerStride) == 0u) { (void)hipEventRecord(poolEvent(&D, ev), st); fn(); (void)hipEventRecord(poolEvent(&D, ev + 1), st); ev += 2; evKind.push_back(kind); }
       else fn();
     };
-    const uint32_t pollEvery = 16;
+    const bool iterLog = timers && timerStride == 1u && getenv("GATLING_ITER_LOG") && atoi(getenv("GATLING_ITER_LOG")) != 0;
     for (uint32_t batch = 0; batch < numBatches; batch++) {
       U.batchFirstSample = (uint32_t)(batch * batchSamples);
       U.batchSamples = (uint32_t)std::min<uint64_t>(batchSamples, rs.spp - (uint64_t)batch * batchSamples);
@@ -1794,17 +1803,35 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
         const uint32_t par = (uint32_t)(it & 1u);
         curIter = totalIters; if (timers && (totalIters % timerStride) == 0u) sampledIters++;
         timed(0, [&] { launchRaygen(st, wideBlocks, U, ps, qs, D.dCounters.ptr, par, D.sampleBuf.ptr); });
-        if (it >= rounds && (it % pollEvery) == 0u) { // all work cannot be handed out earlier; afterwards poll the queue sizes
-          HIP_TRY(hipMemcpyAsync(D.hCounters, D.dCounters.ptr, sizeof(PaddedCounter) * Q_COUNT * NSHARD, hipMemcpyDeviceToHost, st));
-          HIP_TRY(hipStreamSynchronize(st));
-          uint32_t pending = 0; for (uint32_t k = 0; k < NSHARD; k++) pending += D.hCounters->count[Q_TRACE_A + par][k].v;
-          if (pending == 0) { totalIters++; break; } // raygen consumed the regen queue and produced no rays: the pool has drained
+        if (it >= rounds) {
+          // All work cannot be handed out earlier.  From here on every iteration snapshots the queue sizes behind its k_raygen (asynchronous copy into a pinned ring)
+          // and tests the snapshot of POLL_LAG iterations ago: the wait is for work the GPU finished long ago -- it still holds the iterations in between, so the
+          // stream never runs dry -- and the loop stops at most POLL_LAG empty iterations after the pool drained.  (Until r03 the loop synchronised every 16th
+          // iteration: C4 ran 15 empty iterations of 0.2 ms each, `tools/exp_iter_log.py`.)
+          constexpr uint32_t R = SceneDevice::POLL_RING, LAG = SceneDevice::POLL_LAG;
+          constexpr size_t snapshot = (size_t)Q_COUNT * NSHARD;
+          HIP_TRY(hipMemcpyAsync(D.hPoll + (it % R) * snapshot, D.dCounters.ptr, sizeof(PaddedCounter) * snapshot, hipMemcpyDeviceToHost, st));
+          HIP_TRY(hipEventRecord(D.pollEvent[it % R], st));
+          if (it >= rounds + LAG) {
+            const uint64_t j = it - LAG;
+            HIP_TRY(hipEventSynchronize(D.pollEvent[j % R]));
+            const PaddedCounter* snap = D.hPoll + (j % R) * snapshot + (size_t)(Q_TRACE_A + (uint32_t)(j & 1u)) * NSHARD;
+            uint32_t pending = 0; for (uint32_t k = 0; k < NSHARD; k++) pending += snap[k].v;
+            if (pending == 0) { totalIters++; break; } // k_raygen(j) consumed the regen queue and produced no rays: the pool had drained
+          }
         }
         timed(1, [&] { launchTrace(st, traceBlocks, false, s->countTraversal, view, ps, qs, D.dCounters.ptr, Q_TRACE_A + par, Q_REGEN_A + (par ^ 1u), dynRefill, wideBlocks); });
         traceLaunches++;
         for (uint32_t klass = 0; klass < MAT_CLASS_COUNT; klass++)
           if (s->classMask & (1u << klass)) timed(2, [&] { launchShade(st, wideBlocks, klass, (s->classTextured & (1u << klass)) != 0u, rs.mediumStackSize != 0u, U, view, ps, qs, D.dCounters.ptr, par); });
         if (nee) timed(3, [&] { launchTrace(st, traceBlocks, true, s->countTraversal, view, ps, qs, D.dCounters.ptr, Q_SHADOW, Q_SHADOW, dynRefill, wideBlocks); });
+        if (iterLog) { // (GATLING_ITER_LOG, with kernel timers on every iteration: what each iteration's queues held -- one sync per iteration, for measurements only)
+          HIP_TRY(hipMemcpyAsync(D.hCounters, D.dCounters.ptr, sizeof(PaddedCounter) * Q_COUNT * NSHARD, hipMemcpyDeviceToHost, st));
+          HIP_TRY(hipStreamSynchronize(st));
+          auto total = [&](uint32_t q) { uint64_t n = 0; for (uint32_t k = 0; k < NSHARD; k++) n += D.hCounters->count[q][k].v; return n; };
+          uint64_t hits = 0; for (uint32_t c = 0; c < MAT_CLASS_COUNT; c++) hits += total(Q_HIT + c);
+          iterRows.push_back({ev, total(Q_TRACE_A + par), hits, total(Q_SHADOW), total(Q_REGEN_A + (par ^ 1u)), total(Q_TRACE_A + (par ^ 1u))});
+        }
         iters++; totalIters++;
       }
       launchAccumulate(st, U, D.sampleBuf.ptr, D.accum.ptr, colorOut, batch == 0, batch + 1 == numBatches);
@@ -1870,6 +1897,16 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
     for (size_t k = 0; k < evKind.size(); k++) {
       float ms = 0.0f; (void)hipEventElapsedTime(&ms, D.eventPool[2 * k], D.eventPool[2 * k + 1]);
       if (evKind[k] == 0) S.raygenMs += ms; else if (evKind[k] == 1) S.traceMs += ms; else if (evKind[k] == 2) S.shadeMs += ms; else S.shadowMs += ms;
+    }
+    if (!iterRows.empty()) { // per iteration: the stage times of its launches and what its queues held
+      size_t k = 0;
+      for (size_t r = 0; r < iterRows.size(); r++) {
+        double ms4[4] = {0.0, 0.0, 0.0, 0.0};
+        for (; 2 * k < iterRows[r].evEnd && k < evKind.size(); k++) { float ms = 0.0f; (void)hipEventElapsedTime(&ms, D.eventPool[2 * k], D.eventPool[2 * k + 1]); ms4[evKind[k]] += ms; }
+        fprintf(stderr, "[gatling_gi] iter %3zu: rays %9llu hits %9llu shadow %9llu ended %9llu continuing %9llu | raygen %7.3f trace+route %7.3f shade %7.3f shadow %7.3f ms\n", r,
+                (unsigned long long)iterRows[r].traced, (unsigned long long)iterRows[r].hits, (unsigned long long)iterRows[r].shadow, (unsigned long long)iterRows[r].ended,
+                (unsigned long long)iterRows[r].cont, ms4[0], ms4[1], ms4[2], ms4[3]);
+      }
     }
     // scale the sampled totals to the whole frame (the early-exit poll can leave one raygen-only iteration unsampled)
     const double scale = sampledIters ? (double)totalIters / (double)sampledIters : 1.0;
