@@ -276,7 +276,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
 #define GI_DYN_CLAIM 128
 #endif
 constexpr uint32_t DYN_CLAIM = GI_DYN_CLAIM; // rays per cursor atomic (multiple of 64)
-constexpr uint32_t DYN_FLAG_XCD_RANGES = 1u;
+constexpr uint32_t DYN_FLAG_XCD_RANGES = 1u, DYN_FLAG_PEEK = 2u; // PEEK: look at a cursor before claiming from it once one range was found dry (GATLING_DYN_PEEK, default off)
 constexpr uint32_t DYN_FLAG_FLUSH_SHIFT = 8u; // bits 8-15: wave_step_carry's flushAt (0 = flush the triangle ring at the end of every step)
 constexpr uint32_t DYN_FLUSH_AT_DEFAULT = 8u;
 constexpr uint32_t DYN_LDS_NODES_DEFAULT = 0u;   // (GATLING_DYN_LDS_NODES)
@@ -339,10 +339,15 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
   uint32_t claimBase = 0u, claimLeft = 0u; // wave-uniform
   auto next_chunk = [&]() {
     while (claimLeft == 0u && rangesTried < NCURSOR) {
-      uint32_t b = 0u;
-      if (lane == 0u) b = atomicAdd(&cursors[range].v, claim);
-      b = (uint32_t)__shfl((int)b, 0);
       const uint32_t lo = range * per, hi = lo + per < n ? lo + per : n;
+      // DYN_FLAG_PEEK (experiment, off): once a wave has found one range dry it LOOKS before claiming from the others.  At the end of a launch every wave walks
+      // all ranges to find them dry, and 8 192 waves x 8 atomics on 8 addresses (~88 per microsecond and address) are ~0.1 ms per launch -- the whole cost of an
+      // empty launch (tools/exp_iter_log.py: 0.10 -> 0.01 ms).  But full launches pay for it (same box, ABAB: C4 trace 77.3 -> 78.7 ms per frame, C3 shadow
+      // 89.7 -> 90.6) and the bounce loop now runs at most two empty iterations; looking before EVERY claim is far worse (C4 7.2 -> 9.4 ms per launch: the load
+      // queues behind the atomics on its line).
+      uint32_t b = 0xffffffffu;
+      if (lane == 0u && lo < hi && (rangesTried == 0u || !(flags & DYN_FLAG_PEEK) || __hip_atomic_load(&cursors[range].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < hi - lo)) b = atomicAdd(&cursors[range].v, claim);
+      b = (uint32_t)__shfl((int)b, 0);
       if (lo < hi && b < hi - lo) { claimBase = lo + b; claimLeft = (hi - lo - b) < claim ? ((hi - lo - b + 63u) & ~63u) : claim; rangesTried = 0u; }
       else { range = (range + 1u) % NCURSOR; rangesTried++; }
     }
@@ -727,7 +732,8 @@ static void launchTraceVariant(hipStream_t s, uint32_t blocks, const SceneView& 
     if (dynLdsNodes > 1024u) dynLdsNodes = 1024u;
     static const int envFlush = getenv("GATLING_DYN_FLUSH") ? atoi(getenv("GATLING_DYN_FLUSH")) : -1;
     const uint32_t flushAt = envFlush >= 0 ? (uint32_t)(envFlush > 64 ? 64 : envFlush) : DYN_FLUSH_AT_DEFAULT;
-    const uint32_t dynFlags = ((envXcd >= 0 ? envXcd != 0 : DYN_XCD_RANGES_DEFAULT) ? DYN_FLAG_XCD_RANGES : 0u) | (flushAt << DYN_FLAG_FLUSH_SHIFT);
+    static const int envPeek = getenv("GATLING_DYN_PEEK") ? atoi(getenv("GATLING_DYN_PEEK")) : 0;
+    const uint32_t dynFlags = ((envXcd >= 0 ? envXcd != 0 : DYN_XCD_RANGES_DEFAULT) ? DYN_FLAG_XCD_RANGES : 0u) | (envPeek ? DYN_FLAG_PEEK : 0u) | (flushAt << DYN_FLAG_FLUSH_SHIFT);
     const uint32_t stackBytes = entries * TRACE_BLOCK * (uint32_t)sizeof(uint2) + dynLdsNodes * 80u;
     static const int envWaves = getenv("GATLING_DYN_WAVES") ? atoi(getenv("GATLING_DYN_WAVES")) : 5;
     if (envWaves == 6 && !COUNT && sc.bvhDepth <= 8u) {
