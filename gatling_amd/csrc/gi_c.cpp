@@ -302,7 +302,7 @@ struct SceneDevice {
   DeviceBuffer<float> media; // per-slot medium stack + walkSegmentPdf (mediumStackSize > 0)
   DeviceBuffer<F4> scratchColor; DeviceBuffer<unsigned long long> neeKey; // NEE / Bounces AOVs bound without / with the colour AOV
   DeviceBuffer<uint32_t> pathSegments;                                    // ClockCycles AOV (cost proxy)
-  DeviceBuffer<F4> sampleBuf; // per-sample colours of the current batch, [sample][pixel] (rgb, -)
+  DeviceBuffer<F4> sampleBuf; // per-sample colours of the current batch (rgb, -): [pixel][sample] under the pixel-major work order of the stage kernels, [sample][pixel] otherwise (gi_queues.h sample_record)
   DeviceBuffer<F4> accum;        // per-pixel running sum across batches
   DeviceBuffer<uint32_t> qSlot[Q_COUNT]; // NSHARD segments of queueCap records each
   DeviceBuffer<F4> qA[Q_COUNT], qB[Q_COUNT], qC[Q_COUNT];

@@ -54,7 +54,7 @@ __global__ void k_init(PathState st, QueueSet qs, Counters* cnt, uint32_t n, uin
 // ------------------------------------------------------------------------------------------------
 // k_raygen: persistent-thread ray generation (rp_main.rgen:213-283), the per-sample finish (:483-498) and the miss
 // term.  Entry i of the regen queue finishes its sample (if any) into the per-sample colour buffer and takes work item
-// workBase + i = (pixel w % P, sample w / P) -- consecutive entries get adjacent pixels of the same sample index.
+// w = workBase + i, decoded by work_item (gi_queues.h): by default consecutive entries get consecutive samples of one pixel, pixels in 8x8 blocks.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st, QueueSet qs, Counters* cnt, uint32_t par, F4* __restrict__ sampleBuf)
 {

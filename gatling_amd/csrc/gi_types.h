@@ -207,7 +207,7 @@ struct AovTargets {
 // position in the regen queue: no atomics), so the pool stays full until the work runs out, whatever the tile size.
 // Everything that merely flows from one stage to the next (rays, hits, shadow rays) lives in the queues as records
 // written/read in queue order (coalesced); only this record is gathered/scattered by slot index, and 64 B is one
-// fabric request.  A 4 M-slot pool is 268 MB.
+// fabric request.  The default 64 Mi-slot pool is 4 GiB.
 struct alignas(64) Slot {
   F4 thr;  // throughput.xyz, asfloat(bitfield)   (rp_main_payload.glsl:24-33)
   F4 rad;  // radiance.xyz, asfloat(rng state)
