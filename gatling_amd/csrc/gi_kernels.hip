@@ -559,6 +559,10 @@ __device__ inline V3 bsdf_albedo(const MaterialRec* m, const ShState& st, V3 k1)
   V3 diffuse = (o.albedo * o.coatTint) * (base * diel * (1.0f - Fd) * (1.0f - o.tw));
   V3 glossy = v3(Fc, Fc, Fc) + ((schlick_f82(o.albedo, o.metalTint, nk1) * o.specWeight) * o.coatTint) * (base * o.metalness)
               + (o.specColor * o.coatTint) * (base * diel * Fd);
+  if (o.fuzzWeight > 0.0f) { // the fuzz layer keeps P = fuzz_weight * min(E, 1) of the light (tinted), what is beneath gets 1 - P
+    const float Pf = o.fuzzWeight * fmin2(fuzz_albedo(nk1, o.fuzzAlpha), 1.0f);
+    return (diffuse + glossy) * (1.0f - Pf) + o.fuzzColor * Pf;
+  }
   return diffuse + glossy;
 }
 

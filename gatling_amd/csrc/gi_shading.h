@@ -382,7 +382,7 @@ __device__ inline V3 eon_pi_f(V3 rho, float r, V3 l1, V3 l2)
   const V3 rhoMs = v3((rr.x * avgEF) / (1.0f - rho.x * (1.0f - avgEF)), (rr.y * avgEF) / (1.0f - rho.y * (1.0f - avgEF)), (rr.z * avgEF) / (1.0f - rho.z * (1.0f - avgEF)));
   return rho * ss + rhoMs * ms;
 }
-struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, baseColor, ssColor; float metalness, alpha, coat, coatAlpha, coatF0, eta, tw, specWeight, baseWeight, diffRough, ssWeight, ssAniso; bool thinWalled; };
+struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, baseColor, ssColor, fuzzColor; float metalness, alpha, coat, coatAlpha, coatF0, eta, tw, specWeight, baseWeight, diffRough, ssWeight, ssAniso, fuzzWeight, fuzzAlpha; bool thinWalled; };
 __device__ __forceinline__ OpbrParams opbr_params(const MaterialRec* m, const ShState& st)
 {
   OpbrParams o; const float* p = m->p;
@@ -403,7 +403,51 @@ __device__ __forceinline__ OpbrParams opbr_params(const MaterialRec* m, const Sh
   // thin-walled subsurface (open_pbr_surface.mtlx:140-196, 207-218); the volumetric form of non-thin-walled materials is not modelled
   o.ssWeight = o.thinWalled ? p[55] : 0.0f;
   o.ssColor = v3(p[56], p[57], p[58]); o.ssAniso = p[59];
+  // fuzz layer (open_pbr_surface.mtlx:569-581): sheen_bsdf(fuzz_weight, fuzz_color, fuzz_roughness) on top of the coat
+  o.fuzzWeight = fmin2(fmax2(p[49], 0.0f), 1.0f); o.fuzzColor = v3(p[50], p[51], p[52]); o.fuzzAlpha = fmin2(fmax2(p[53], 0.07f), 1.0f);
   return o;
+}
+// ---- fuzz (sheen) lobe, operation for operation the oracle's (oracle/gi_oracle.cpp "fuzz (sheen) lobe": the model, its sources and the layering rule are
+// described there): "Charlie" distribution x Ashikhmin / Neubelt visibility, directional albedo from the table of tools/gen_fuzz_albedo.py + 0.01.
+__device__ const float FUZZ_ALBEDO[16][17] = {
+// rows: alpha = 1/16 .. 1, columns: mu = 0 .. 1 in steps of 1/16 (tools/gen_fuzz_albedo.py)
+  {1.66603482e+00f, 1.05229735e+00f, 7.48142481e-01f, 5.42552471e-01f, 3.94544691e-01f, 2.85340458e-01f, 2.04062358e-01f, 1.43585801e-01f, 9.88851935e-02f, 6.62436262e-02f, 4.28260490e-02f, 2.64271554e-02f, 1.53114153e-02f, 8.10563751e-03f, 3.72325582e-03f, 1.30873080e-03f, 1.95315428e-04f},
+  {1.22866476e+00f, 8.68625820e-01f, 6.77242339e-01f, 5.38716376e-01f, 4.31280196e-01f, 3.45276922e-01f, 2.75279015e-01f, 2.17816725e-01f, 1.70480222e-01f, 1.31495669e-01f, 9.95000154e-02f, 7.34108016e-02f, 5.23458906e-02f, 3.55714411e-02f, 2.24667117e-02f, 1.24994880e-02f, 5.20835957e-03f},
+  {1.04291248e+00f, 7.75057077e-01f, 6.29255474e-01f, 5.20992339e-01f, 4.34587359e-01f, 3.63185972e-01f, 3.03000093e-01f, 2.51652122e-01f, 2.07522362e-01f, 1.69441670e-01f, 1.36528745e-01f, 1.08096354e-01f, 8.35938677e-02f, 6.25700131e-02f, 4.46479134e-02f, 2.95076892e-02f, 1.68739911e-02f},
+  {9.36414123e-01f, 7.16623902e-01f, 5.95793307e-01f, 5.04945695e-01f, 4.31368500e-01f, 3.69544923e-01f, 3.16451848e-01f, 2.70210087e-01f, 2.29553193e-01f, 1.93577752e-01f, 1.61611512e-01f, 1.33137539e-01f, 1.07747734e-01f, 8.51129442e-02f, 6.49628416e-02f, 4.70720194e-02f, 3.12500633e-02f},
+  {8.66332769e-01f, 6.76128209e-01f, 5.71131229e-01f, 4.91654038e-01f, 4.26739037e-01f, 3.71650100e-01f, 3.23803574e-01f, 2.81601369e-01f, 2.43972436e-01f, 2.10157394e-01f, 1.79594919e-01f, 1.51856542e-01f, 1.26606807e-01f, 1.03577562e-01f, 8.25508535e-02f, 6.33470416e-02f, 4.58163172e-02f},
+  {8.16336453e-01f, 6.46200657e-01f, 5.52162349e-01f, 4.80711669e-01f, 4.22050655e-01f, 3.71954530e-01f, 3.28124613e-01f, 2.89142847e-01f, 2.54061490e-01f, 2.22210526e-01f, 1.93096176e-01f, 1.66342735e-01f, 1.41657025e-01f, 1.18805535e-01f, 9.75991860e-02f, 7.78828189e-02f, 5.95276207e-02f},
+  {7.78707266e-01f, 6.23087585e-01f, 5.37092745e-01f, 4.71618980e-01f, 4.17691469e-01f, 3.71446818e-01f, 3.30786139e-01f, 2.94416696e-01f, 2.61475623e-01f, 2.31353760e-01f, 2.03602642e-01f, 1.77881300e-01f, 1.53923839e-01f, 1.31518483e-01f, 1.10493734e-01f, 9.07087103e-02f, 7.20463097e-02f},
+  {7.49280632e-01f, 6.04652286e-01f, 5.24816334e-01f, 4.63969946e-01f, 4.13753271e-01f, 3.70571792e-01f, 3.32474768e-01f, 2.98261851e-01f, 2.67132372e-01f, 2.38521293e-01f, 2.12012753e-01f, 1.87290415e-01f, 1.64107352e-01f, 1.42266646e-01f, 1.21608362e-01f, 1.02000684e-01f, 8.33334997e-02f},
+  {7.25595057e-01f, 5.89579582e-01f, 5.14612794e-01f, 4.57457095e-01f, 4.10229623e-01f, 3.69543940e-01f, 3.33563626e-01f, 3.01159322e-01f, 2.71578044e-01f, 2.44288355e-01f, 2.18898997e-01f, 1.95112124e-01f, 1.72694832e-01f, 1.51460946e-01f, 1.31258771e-01f, 1.11962639e-01f, 9.34669897e-02f},
+  {7.06095338e-01f, 5.77011704e-01f, 5.05992115e-01f, 4.51849908e-01f, 4.07083064e-01f, 3.68470997e-01f, 3.34268302e-01f, 3.03401917e-01f, 2.75156647e-01f, 2.49027595e-01f, 2.24642813e-01f, 2.01718882e-01f, 1.80033773e-01f, 1.59409523e-01f, 1.39700606e-01f, 1.20785803e-01f, 1.02562815e-01f},
+  {6.89747393e-01f, 5.66363335e-01f, 4.98608768e-01f, 4.46974337e-01f, 4.04269099e-01f, 3.67407918e-01f, 3.34719449e-01f, 3.05176616e-01f, 2.78094798e-01f, 2.52990693e-01f, 2.29507983e-01f, 2.07374871e-01f, 1.86378047e-01f, 1.66346103e-01f, 1.47138327e-01f, 1.28636986e-01f, 1.10742249e-01f},
+  {6.75835013e-01f, 5.57220221e-01f, 4.92211729e-01f, 4.42697257e-01f, 4.01744992e-01f, 3.66382241e-01f, 3.34999412e-01f, 3.06607515e-01f, 2.80547380e-01f, 2.56353587e-01f, 2.33682737e-01f, 2.12272644e-01f, 1.91917211e-01f, 1.72450408e-01f, 1.53735459e-01f, 1.35657445e-01f, 1.18118644e-01f},
+  {6.63845837e-01f, 5.49280763e-01f, 4.86614108e-01f, 4.38915670e-01f, 3.99472445e-01f, 3.65406990e-01f, 3.35161716e-01f, 3.07779849e-01f, 2.82623708e-01f, 2.59242892e-01f, 2.37304971e-01f, 2.16555879e-01f, 1.96795553e-01f, 1.77862525e-01f, 1.59623355e-01f, 1.41965449e-01f, 1.24793008e-01f},
+  {6.53402805e-01f, 5.42319357e-01f, 4.81673747e-01f, 4.35548574e-01f, 3.97418410e-01f, 3.64487261e-01f, 3.35242122e-01f, 3.08753759e-01f, 2.84402877e-01f, 2.61752009e-01f, 2.40478083e-01f, 2.20333964e-01f, 2.01124832e-01f, 1.82693094e-01f, 1.64908230e-01f, 1.47659644e-01f, 1.30853310e-01f},
+  {6.44222379e-01f, 5.36164165e-01f, 4.77280527e-01f, 4.32531655e-01f, 3.95554543e-01f, 3.63623768e-01f, 3.35264921e-01f, 3.09572637e-01f, 2.85943538e-01f, 2.63951302e-01f, 2.43281066e-01f, 2.23691702e-01f, 2.04992920e-01f, 1.87030569e-01f, 1.69676632e-01f, 1.52822360e-01f, 1.36375397e-01f},
+  {6.36086643e-01f, 5.30681610e-01f, 4.73347783e-01f, 4.29813147e-01f, 3.93856794e-01f, 3.62814993e-01f, 3.35247070e-01f, 3.10268551e-01f, 2.87289977e-01f, 2.65894860e-01f, 2.45775416e-01f, 2.26695850e-01f, 2.08469898e-01f, 1.90946430e-01f, 1.73999682e-01f, 1.57522544e-01f, 1.41424328e-01f},
+};
+__device__ __forceinline__ float fuzz_albedo(float mu, float alpha)
+{
+  const float x = fmin2(fmax2(mu, 0.0f), 1.0f) * 16.0f;
+  int i = (int)x; if (i > 15) i = 15;
+  const float fx = x - (float)i;
+  const float y = alpha * 16.0f - 1.0f;
+  int j = (int)y; if (j > 14) j = 14; if (j < 0) j = 0;
+  const float fy = y - (float)j;
+  const float a = FUZZ_ALBEDO[j][i] * (1.0f - fx) + FUZZ_ALBEDO[j][i + 1] * fx;
+  const float b = FUZZ_ALBEDO[j + 1][i] * (1.0f - fx) + FUZZ_ALBEDO[j + 1][i + 1] * fx;
+  return (a * (1.0f - fy) + b * fy) + 0.01f;
+}
+__device__ __forceinline__ float fuzz_dv(V3 l1, V3 l2, float alpha) // D * V for local directions with l1.z, l2.z > 0
+{
+  const V3 h = normalize(l1 + l2);
+  const float s2 = 1.0f - h.z * h.z;
+  if (!(s2 > 0.0f)) return 0.0f;
+  const float inv = 1.0f / alpha;
+  const float D = ((2.0f + inv) * gi_expf((0.5f * inv) * gi_logf(s2))) / (2.0f * GI_PI);
+  return D / (4.0f * ((l2.z + l1.z) - l2.z * l1.z));
 }
 // the colour factors of subsurface_thin_walled's two lobes (the mix weight 1/2 is the lobe-selection probability and cancels): see the oracle's opbr_ss_*
 __device__ __forceinline__ V3 opbr_ss_color(const OpbrParams& o) { return v3(fmax2(o.ssColor.x, 0.0f), fmax2(o.ssColor.y, 0.0f), fmax2(o.ssColor.z, 0.0f)); }
@@ -418,9 +462,8 @@ __device__ __forceinline__ V3 opbr_ss_transmit(const OpbrParams& o) { return opb
 // The lobe is chosen first (cheap, divergent), then ONE micro-facet sample serves whichever glossy lobe a lane took -- coat, metal,
 // dielectric reflection, transmission differ in the roughness they pass and in their weights, not in the sampling arithmetic -- so a wave
 // whose lanes took different lobes runs ggx_sample once instead of once per lobe.  Same operations per lane as the oracle's branch per lobe.
-__device__ inline void opbr_sample(const MaterialRec* m, const ShState& st, V3 k1, float x0, float x1, float x2, BsdfSample& out)
+__device__ inline void opbr_sample_base(const OpbrParams& o, const ShState& st, V3 k1, float x0, float x1, float x2, BsdfSample& out) // everything beneath the fuzz
 {
-  OpbrParams o = opbr_params(m, st);
   V3 l1 = to_local(st, k1);
   float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
   float z = x2;
@@ -508,9 +551,28 @@ __device__ inline void opbr_sample(const MaterialRec* m, const ShState& st, V3 k
   }
 }
 
-__device__ inline void opbr_evaluate(const MaterialRec* m, const ShState& st, V3 k1, V3 k2, BsdfEval& out)
+__device__ inline void opbr_sample(const MaterialRec* m, const ShState& st, V3 k1, float x0, float x1, float x2, BsdfSample& out)
 {
-  OpbrParams o = opbr_params(m, st);
+  const OpbrParams o = opbr_params(m, st);
+  if (!(o.fuzzWeight > 0.0f)) { opbr_sample_base(o, st, k1, x0, x1, x2, out); return; }
+  V3 l1 = to_local(st, k1);
+  const float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
+  const float Ef = fuzz_albedo(nk1, o.fuzzAlpha), Pf = o.fuzzWeight * fmin2(Ef, 1.0f);
+  if (x2 < Pf) { // the fuzz lobe, cosine-sampled
+    const V3 l = gi_sample_hemisphere(x0, x1);
+    const V3 k2 = to_world(st, l);
+    if (!(l.z > 0.0f) || !(dot(k2, st.geomNormal) > 0.0f)) return;
+    out.k2 = k2; out.pdf = Pf * (l.z / GI_PI);
+    out.overPdf = o.fuzzColor * ((fuzz_dv(l1, l, o.fuzzAlpha) * GI_PI) / Ef);
+    out.event = EV_GLOSSY | EV_REFLECTION;
+    return;
+  }
+  opbr_sample_base(o, st, k1, x0, x1, (x2 - Pf) / (1.0f - Pf), out);
+  out.pdf = out.pdf * (1.0f - Pf); // bsdf / pdf is unchanged: the layers beneath are weighted by the same 1 - P they are chosen with
+}
+
+__device__ inline void opbr_evaluate_base(const OpbrParams& o, const ShState& st, V3 k1, V3 k2, BsdfEval& out)
+{
   V3 l1 = to_local(st, k1), l2 = to_local(st, k2);
   float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
   float eta = relative_eta(st, o.eta);
@@ -537,6 +599,20 @@ __device__ inline void opbr_evaluate(const MaterialRec* m, const ShState& st, V3
   }
   out.diffuse = (rho * o.coatTint) * wBase;
   out.pdf = Fc * pc + base * (o.metalness * ps + diel * (Fd * ps + (1.0f - Fd) * (1.0f - o.tw) * cd));
+}
+__device__ inline void opbr_evaluate(const MaterialRec* m, const ShState& st, V3 k1, V3 k2, BsdfEval& out)
+{
+  const OpbrParams o = opbr_params(m, st);
+  opbr_evaluate_base(o, st, k1, k2, out);
+  if (!(o.fuzzWeight > 0.0f)) return;
+  V3 l1 = to_local(st, k1); const V3 l2 = to_local(st, k2);
+  const float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
+  const float Ef = fuzz_albedo(nk1, o.fuzzAlpha), Eb = fmin2(Ef, 1.0f), Pf = o.fuzzWeight * Eb, keep = 1.0f - Pf;
+  const float cd = fmax2(l2.z, 0.0f) / GI_PI;
+  const V3 sheen = (l2.z > 0.0f) ? o.fuzzColor * (((o.fuzzWeight * (Eb / Ef)) * fuzz_dv(l1, l2, o.fuzzAlpha)) * l2.z) : v3(0.0f, 0.0f, 0.0f);
+  out.glossy = out.glossy * keep + sheen;
+  out.diffuse = out.diffuse * keep;
+  out.pdf = Pf * cd + keep * out.pdf;
 }
 
 constexpr uint32_t KLASS_DYNAMIC = 0xffffffffu; // read the class from the material record (debug / AOV paths)

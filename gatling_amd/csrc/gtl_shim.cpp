@@ -241,7 +241,7 @@ namespace gtl
       setN(n, "transmission_scatter_anisotropy", p + GI_C_P_TRANSMISSION_SCATTER_ANISOTROPY, 1);
       setN(n, "coat_weight", p + GI_C_P_CLEARCOAT, 1); setN(n, "coat_color", p + GI_C_P_COAT_COLOR, 3);
       setN(n, "coat_roughness", p + GI_C_P_CLEARCOAT_ROUGHNESS, 1); setN(n, "coat_ior", p + GI_C_P_COAT_IOR, 1); setN(n, "coat_darkening", p + GI_C_P_COAT_DARKENING, 1);
-      setN(n, "fuzz_weight", p + GI_C_P_FUZZ_WEIGHT, 1); setN(n, "fuzz_color", p + GI_C_P_FUZZ_COLOR, 3); setN(n, "fuzz_roughness", p + GI_C_P_FUZZ_ROUGHNESS, 1); // carried, not modelled
+      setN(n, "fuzz_weight", p + GI_C_P_FUZZ_WEIGHT, 1); setN(n, "fuzz_color", p + GI_C_P_FUZZ_COLOR, 3); setN(n, "fuzz_roughness", p + GI_C_P_FUZZ_ROUGHNESS, 1);
       setN(n, "geometry_thin_walled", p + GI_C_P_THIN_WALLED, 1);
       setN(n, "subsurface_weight", p + GI_C_P_SUBSURFACE_WEIGHT, 1); setN(n, "subsurface_color", p + GI_C_P_SUBSURFACE_COLOR, 3);
       setN(n, "subsurface_scatter_anisotropy", p + GI_C_P_SUBSURFACE_ANISOTROPY, 1); // (subsurface_radius / _radius_scale only shape the volumetric form, which is not modelled)

@@ -131,7 +131,7 @@ def _open_pbr(name="mat", base_weight=1.0, base_color=(0.8, 0.8, 0.8), base_meta
     p[P_TRANSMISSION_SCATTER:P_TRANSMISSION_SCATTER + 3] = transmission_scatter
     p[P_TRANSMISSION_SCATTER_ANISOTROPY] = transmission_scatter_anisotropy
     p[P_COAT_DARKENING] = coat_darkening
-    p[P_FUZZ_WEIGHT] = fuzz_weight                     # carried; the sheen lobe is not modelled
+    p[P_FUZZ_WEIGHT] = fuzz_weight                     # fuzz (sheen) layer over the coat (open_pbr_surface.mtlx:569-581)
     p[P_FUZZ_COLOR:P_FUZZ_COLOR + 3] = fuzz_color
     p[P_FUZZ_ROUGHNESS] = fuzz_roughness
     p[P_THIN_WALLED] = 1.0 if geometry_thin_walled else 0.0

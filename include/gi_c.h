@@ -179,7 +179,7 @@ typedef struct GiCRenderParams {
 #define GI_C_P_TRANSMISSION_SCATTER 29 /* 3: OpenPBR transmission_scatter (open_pbr_surface.mtlx:35) */
 #define GI_C_P_TRANSMISSION_SCATTER_ANISOTROPY 47 /* transmission_scatter_anisotropy (:37); slots 32..46 are reserved */
 #define GI_C_P_COAT_DARKENING 48   /* OpenPBR coat_darkening (open_pbr_surface.mtlx:64; default 1): strength of the base darkening under the coat (:470-541) */
-#define GI_C_P_FUZZ_WEIGHT 49      /* OpenPBR fuzz_weight / fuzz_color (3) / fuzz_roughness (:57-59): accepted and carried, the sheen lobe is not modelled */
+#define GI_C_P_FUZZ_WEIGHT 49      /* OpenPBR fuzz_weight / fuzz_color (3) / fuzz_roughness (:57-59): the fuzz (sheen) layer over the coat (:569-581) */
 #define GI_C_P_FUZZ_COLOR 50
 #define GI_C_P_FUZZ_ROUGHNESS 53
 #define GI_C_P_SUBSURFACE_WEIGHT 55  /* OpenPBR subsurface_weight (open_pbr_surface.mtlx:43, 213-218); modelled for thin-walled materials (:140-196), else treated as 0 */

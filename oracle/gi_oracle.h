@@ -78,7 +78,7 @@ enum {
   ORC_P_TRANSMISSION_SCATTER = 29, /* 3 */
   ORC_P_TRANSMISSION_SCATTER_ANISOTROPY = 47, /* (32..46 hold the device's derived constants) */
   ORC_P_COAT_DARKENING = 48,   /* open_pbr_surface.mtlx:64 */
-  ORC_P_FUZZ_WEIGHT = 49, ORC_P_FUZZ_COLOR = 50, ORC_P_FUZZ_ROUGHNESS = 53, /* :57-59, carried only */
+  ORC_P_FUZZ_WEIGHT = 49, ORC_P_FUZZ_COLOR = 50, ORC_P_FUZZ_ROUGHNESS = 53, /* :57-59: the fuzz (sheen) layer (:569-581) */
   ORC_P_SUBSURFACE_WEIGHT = 55, ORC_P_SUBSURFACE_COLOR = 56, ORC_P_SUBSURFACE_ANISOTROPY = 59, /* :43-52; thin-walled subsurface (:140-196) */
   ORC_P_THIN_WALLED = 54,      /* geometry_thin_walled (:88) */
   ORC_P_COUNT = 64

@@ -20,7 +20,7 @@ except Exception:  # pragma: no cover
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
 from make_golden import CASES, build_case  # noqa: E402
 
-from gatling_amd.scene import (MAT_DIFFUSE, MAT_USD_PREVIEW_SURFACE, CameraDesc, DiskLight, DistantLight, MaterialDesc, MeshDesc,
+from gatling_amd.scene import (MAT_DIFFUSE, MAT_OPEN_PBR, MAT_USD_PREVIEW_SURFACE, CameraDesc, DiskLight, DistantLight, MaterialDesc, MeshDesc,
                                RectLight, RenderSettings, SceneDesc, SphereLight)
 from gatling_amd.scenes import cornell_box, interior_scene, random_triangle_soup, sphere_grid, textured_scene, volume_scene
 
@@ -420,7 +420,12 @@ def test_bsdf_known_answers_on_device(gi, orc):
             # thin-walled subsurface (open_pbr_surface.mtlx:140-196): alone, and mixed with the base diffuse under a coat with a rough Oren-Nayar reflection
             MaterialDesc.open_pbr(base_color=(0.2, 0.4, 0.8), geometry_thin_walled=True, subsurface_weight=1.0, subsurface_color=(0.9, 0.6, 0.3), subsurface_scatter_anisotropy=0.25),
             MaterialDesc.open_pbr(base_color=(0.7, 0.7, 0.2), geometry_thin_walled=True, subsurface_weight=0.55, subsurface_color=(0.4, 0.8, 0.5), subsurface_scatter_anisotropy=-0.4,
-                                  base_diffuse_roughness=0.6, coat_weight=0.5, coat_roughness=0.15, transmission_weight=0.2)]
+                                  base_diffuse_roughness=0.6, coat_weight=0.5, coat_roughness=0.15, transmission_weight=0.2),
+            # fuzz layer (open_pbr_surface.mtlx:569-581): alone over a dark base, smooth fuzz (albedo table's steep corner) over a coat, rough fuzz over metal
+            MaterialDesc.open_pbr(base_color=(0.05, 0.05, 0.05), specular_weight=0.2, fuzz_weight=1.0, fuzz_color=(0.9, 0.5, 0.3), fuzz_roughness=0.5),
+            MaterialDesc.open_pbr(base_color=(0.6, 0.2, 0.2), coat_weight=0.7, coat_roughness=0.1, fuzz_weight=0.8, fuzz_color=(0.8, 0.8, 1.0), fuzz_roughness=0.07),
+            MaterialDesc.open_pbr(base_color=(0.9, 0.7, 0.3), base_metalness=1.0, specular_roughness=0.35, fuzz_weight=0.45, fuzz_color=(1.0, 0.9, 0.8), fuzz_roughness=1.0),
+            MaterialDesc.open_pbr(base_color=(0.3, 0.5, 0.7), transmission_weight=0.5, fuzz_weight=0.3, fuzz_roughness=0.23)]
     items[: n // 2, 21] = 0.75  # xi.w >= 0.5: the debug hook shades these as back faces (eta inverted)
     for m in mats:
         got, ref = gi.bsdf_debug(m, items), orc.bsdf_debug(m, items)
@@ -1074,6 +1079,30 @@ def test_thin_walled_subsurface_scene_parity(gi, orc):
         assert st["segments"] == cnt["segments"] and st["shadowRays"] == cnt["shadow_rays"]
         imgs[w] = img
     assert not np.array_equal(imgs[0.0], imgs[0.9])
+
+
+def test_fuzz_layer_scene_parity(gi, orc):
+    """Velvet-like spheres (fuzz layer over dark and over coated bases, OpenPBR next to UsdPreviewSurface ones) lit by a rect light and the uniform dome, NEE on
+    and off: the wavefront pipeline's image == the oracle's, bit for bit, and the fuzz visibly brightens the silhouettes."""
+    desc = sphere_grid(grid=3, subdivisions=2, material_count=6)
+    fz = [(1.0, (0.9, 0.4, 0.3), 0.5), (0.8, (0.7, 0.8, 1.0), 0.1), (0.5, (1.0, 1.0, 1.0), 1.0)]
+    k = 0
+    for m in desc.materials:
+        if m.klass == MAT_OPEN_PBR and k < len(fz):
+            w, c, r = fz[k]; k += 1
+            m.params[49] = w; m.params[50:53] = c; m.params[53] = r
+    assert k >= 2
+    desc.rect_lights.append(RectLight(origin=(0.0, -3.0, 4.0), t0=(1, 0, 0), t1=(0, 0.8, 0.6), base_emission=(14, 13, 12), width=2.0, height=2.0))
+    for nee in (False, True):
+        img, _, _ = render_both(gi, orc, desc, RenderSettings(spp=3, max_bounces=5, next_event_estimation=nee), 96, 54)
+    plain = sphere_grid(grid=3, subdivisions=2, material_count=6)
+    plain.rect_lights = list(desc.rect_lights)
+    sc = gi.Scene(plain)
+    try:
+        ref = sc.render(RenderSettings(spp=3, max_bounces=5, next_event_estimation=True), 96, 54)
+    finally:
+        sc.close()
+    assert not np.array_equal(img, ref)
 
 
 def test_remaining_texture_entry_points_on_device(gi):

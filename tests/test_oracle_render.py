@@ -136,7 +136,10 @@ def _closed_form_materials():
             M.open_pbr(base_color=(1, 1, 1), transmission_weight=1.0, specular_roughness=0.3, geometry_thin_walled=True),
             M.open_pbr(base_color=(1, 1, 1), geometry_thin_walled=True, subsurface_weight=1.0, subsurface_color=(1, 1, 1), specular_weight=0.0),   # thin-walled subsurface alone
             M.open_pbr(base_color=(1, 1, 1), geometry_thin_walled=True, subsurface_weight=0.6, subsurface_color=(1, 1, 1), subsurface_scatter_anisotropy=0.4,
-                       base_diffuse_roughness=0.5, coat_weight=0.5, coat_roughness=0.2)]
+                       base_diffuse_roughness=0.5, coat_weight=0.5, coat_roughness=0.2),
+            M.open_pbr(base_color=(0, 0, 0), specular_weight=0.0, fuzz_weight=1.0, fuzz_color=(1, 1, 1), fuzz_roughness=0.5),                      # the fuzz lobe alone
+            M.open_pbr(base_color=(1, 1, 1), coat_weight=1.0, coat_roughness=0.1, fuzz_weight=1.0, fuzz_color=(1, 1, 1), fuzz_roughness=0.07),     # smooth fuzz (E > 1 at grazing views) over a coat
+            M.open_pbr(base_color=(1, 1, 1), base_metalness=1.0, specular_roughness=0.4, fuzz_weight=0.6, fuzz_color=(1, 1, 1), fuzz_roughness=1.0)]
 
 
 def test_closed_form_bsdfs_conserve_energy(orc):
@@ -163,6 +166,52 @@ def test_closed_form_evaluate_matches_sampling(orc):
         integ = (out[:, 8:11] + out[:, 11:14]).mean(axis=0) * (2 * np.pi)  # uniform hemisphere pdf = 1/(2 pi); bsdf*cos is returned
         np.testing.assert_allclose(integ, sampled, rtol=0.06, atol=0.01)
         np.testing.assert_allclose(out[:, 14].mean() * 2 * np.pi, refl.mean(), rtol=0.06, atol=0.01)
+
+
+def test_fuzz_layer(orc):
+    """open_pbr_surface.mtlx:569-581: sheen_bsdf(fuzz_weight, fuzz_color, fuzz_roughness) layered over the coat.  Our closed form (oracle/gi_oracle.cpp "fuzz
+    (sheen) lobe"): Charlie distribution x Ashikhmin/Neubelt visibility, chosen with P = w * min(E, 1) where E is the tabulated directional albedo + 0.01.
+    Checked against an INDEPENDENT numerical integration of the published formula (tools/gen_fuzz_albedo.py): the lobe's probability, its albedo, the
+    reciprocity of its value, and that fuzz_weight = 0 is the material without fuzz, bit for bit."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("gen_fuzz_albedo", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gen_fuzz_albedo.py"))
+    gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)
+    rng = np.random.default_rng(29)
+    tint = np.float32([0.9, 0.5, 0.25])
+    for w, r, c in ((1.0, 0.5, 0.8), (0.7, 1.0, 0.3), (1.0, 0.2, 0.6), (0.5, 0.07, 0.1)):
+        m = MaterialDesc.open_pbr(base_color=(0, 0, 0), specular_weight=0.0, fuzz_weight=w, fuzz_color=tuple(tint), fuzz_roughness=r)
+        out = orc.bsdf_debug(m, _frames(200000, rng, c))
+        chosen = out[:, 3] > 0.0                                  # black base, no specular: every event that carries light is the fuzz lobe
+        E = gen.albedo(c, max(r, 0.07), 300)                       # the true directional albedo of D * V
+        Pf = chosen.mean()
+        assert w * min(E, 1.0) - 0.01 <= Pf <= w * min(E + 0.025, 1.0) + 0.01, (w, r, c, E, Pf)   # P = w * min(E_table + 0.01, 1), E_table within [E - 0.0093, E + ...]
+        albedo = out[:, 3:6].mean(axis=0)                          # = tint * P * E / E_fit: never above tint * w, and the table's slack costs at most a few per cent
+        assert np.all(albedo <= tint * w * min(E, 1.0) * 1.02 + 0.003), (albedo, E)
+        assert np.all(albedo >= tint * w * min(E, 1.0) * (E / (E + 0.03)) * 0.97 - 0.003), (albedo, E)
+        assert np.all(out[chosen, 5] <= out[chosen, 3] + 1e-6)     # tinted by fuzz_color
+    # reciprocity of the lobe's value where E <= 1 on both sides: evaluate() returns f * cos(k2)
+    m = MaterialDesc.open_pbr(base_color=(0, 0, 0), specular_weight=0.0, fuzz_weight=1.0, fuzz_color=(1, 1, 1), fuzz_roughness=0.8)
+    n = 4000
+    a = rng.normal(size=(n, 3)); a[:, 2] = np.abs(a[:, 2]) + 0.3; a /= np.linalg.norm(a, axis=1, keepdims=True)
+    b = rng.normal(size=(n, 3)); b[:, 2] = np.abs(b[:, 2]) + 0.3; b /= np.linalg.norm(b, axis=1, keepdims=True)
+    base = _frames(n, rng, 0.5)
+    ab = base.copy(); ab[:, 12:15] = a; ab[:, 15:18] = b
+    ba = base.copy(); ba[:, 12:15] = b; ba[:, 15:18] = a
+    fab = orc.bsdf_debug(m, ab)[:, 11] / b[:, 2]; fba = orc.bsdf_debug(m, ba)[:, 11] / a[:, 2]
+    np.testing.assert_allclose(fab, fba, rtol=2e-5, atol=1e-7)
+    assert fab.min() > 0.0
+    # fuzz_weight = 0: colour and roughness of the fuzz change nothing, bit for bit
+    items = _frames(20000, rng, 0.4)
+    plain = orc.bsdf_debug(MaterialDesc.open_pbr(base_color=(0.7, 0.6, 0.5), coat_weight=0.5), items)
+    zero = orc.bsdf_debug(MaterialDesc.open_pbr(base_color=(0.7, 0.6, 0.5), coat_weight=0.5, fuzz_weight=0.0, fuzz_color=(0.2, 0.9, 0.1), fuzz_roughness=0.2), items)
+    assert np.array_equal(plain.view(np.uint32), zero.view(np.uint32))
+    # the layers beneath keep 1 - P of the light: a white diffuse base under a black fuzz loses exactly the fuzz's share
+    m0 = MaterialDesc.open_pbr(base_color=(1, 1, 1), specular_weight=0.0)
+    m1 = MaterialDesc.open_pbr(base_color=(1, 1, 1), specular_weight=0.0, fuzz_weight=1.0, fuzz_color=(0, 0, 0), fuzz_roughness=0.5)
+    items = _frames(200000, rng, 0.6)
+    a0 = orc.bsdf_debug(m0, items)[:, 3].mean(); a1 = orc.bsdf_debug(m1, items)[:, 3].mean()
+    E = gen.albedo(0.6, 0.5, 300)
+    assert abs(a1 - a0 * (1.0 - E)) < 0.02, (a0, a1, E)
 
 
 def test_thin_walled_subsurface_lobes(orc):
