@@ -279,6 +279,65 @@ __device__ inline void ggx_eval(V3 l1, V3 l2, float alpha, float& fcos, float& p
   pdf = G1 * D / (4.0f * nk1);
 }
 
+// Anisotropic form, operation for operation the oracle's (oracle/gi_oracle.cpp "Anisotropic form"): used only when ax != ay, so isotropic materials keep the
+// arithmetic above bit for bit.
+__device__ __forceinline__ float ggx_lambda_xy(float ax, float ay, V3 v) { return sqrtf(((ax * v.x) * (ax * v.x) + (ay * v.y) * (ay * v.y)) + v.z * v.z); }
+__device__ __forceinline__ float ggx_d_xy(float ax, float ay, V3 h)
+{
+  const float hx = h.x / ax, hy = h.y / ay;
+  const float dd = (hx * hx + hy * hy) + h.z * h.z;
+  return 1.0f / (((GI_PI * ax) * ay) * (dd * dd));
+}
+__device__ inline GgxOut ggx_sample_xy(V3 l1, float ax, float ay, float x0, float x1)
+{
+  GgxOut o; o.valid = false; o.pdf = 0.0f; o.g2OverG1 = 0.0f; o.kh = 0.0f; o.l2 = v3(0.0f, 0.0f, 0.0f);
+  V3 vh = normalize(v3(ax * l1.x, ay * l1.y, l1.z));
+  float lensq = vh.x * vh.x + vh.y * vh.y;
+  V3 T1 = lensq > 0.0f ? v3(-vh.y, vh.x, 0.0f) * (1.0f / sqrtf(lensq)) : v3(1.0f, 0.0f, 0.0f);
+  V3 T2 = cross(vh, T1);
+  float r = sqrtf(x0);
+  float s, c; gi_sincos2pi(x1, &s, &c);
+  float t1 = r * c, t2 = r * s;
+  float sm = 0.5f * (1.0f + vh.z);
+  t2 = (1.0f - sm) * sqrtf(fmax2(0.0f, 1.0f - t1 * t1)) + sm * t2;
+  V3 nh = (T1 * t1 + T2 * t2) + vh * sqrtf(fmax2(0.0f, (1.0f - t1 * t1) - t2 * t2));
+  V3 h = normalize(v3(ax * nh.x, ay * nh.y, fmax2(0.0f, nh.z)));
+  float kh = dot(l1, h);
+  V3 l2 = h * (2.0f * kh) - l1;
+  if (!(l2.z > 0.0f) || !(kh > 0.0f)) return o;
+  float nk1 = l1.z, nk2 = l2.z;
+  float D = ggx_d_xy(ax, ay, h);
+  float L1 = ggx_lambda_xy(ax, ay, l1), L2 = ggx_lambda_xy(ax, ay, l2);
+  float G1 = 2.0f * nk1 / (nk1 + L1);
+  float G2 = 2.0f * nk1 * nk2 / (nk2 * L1 + nk1 * L2);
+  o.l2 = l2; o.kh = kh; o.pdf = G1 * D / (4.0f * nk1); o.g2OverG1 = G2 / G1; o.valid = true;
+  return o;
+}
+__device__ inline void ggx_eval_xy(V3 l1, V3 l2, float ax, float ay, float& fcos, float& pdf, float& kh)
+{
+  fcos = 0.0f; pdf = 0.0f; kh = 0.0f;
+  if (!(l1.z > 0.0f) || !(l2.z > 0.0f)) return;
+  V3 h = normalize(l1 + l2);
+  kh = dot(l1, h);
+  float nk1 = l1.z, nk2 = l2.z;
+  float D = ggx_d_xy(ax, ay, h);
+  float L1 = ggx_lambda_xy(ax, ay, l1), L2 = ggx_lambda_xy(ax, ay, l2);
+  float G1 = 2.0f * nk1 / (nk1 + L1);
+  float G2 = 2.0f * nk1 * nk2 / (nk2 * L1 + nk1 * L2);
+  fcos = D * G2 / (4.0f * nk1);
+  pdf = G1 * D / (4.0f * nk1);
+}
+// open_pbr_anisotropy (open_pbr_surface.mtlx:133-136, 552-555): alpha_t = r^2 sqrt(2 / (1 + (1 - a)^2)), alpha_b = (1 - a) alpha_t
+__device__ __forceinline__ void opbr_anisotropy(float alpha, float a, float& ax, float& ay)
+{
+  ax = alpha; ay = alpha;
+  if (!(a > 0.0f)) return;
+  const float inv = 1.0f - fmin2(a, 1.0f);
+  ax = fmax2(alpha * sqrtf(2.0f / (1.0f + inv * inv)), 0.001f); ay = fmax2(inv * ax, 0.001f);
+}
+__device__ __forceinline__ GgxOut ggx_sample2(V3 l1, float ax, float ay, float x0, float x1) { return ax == ay ? ggx_sample(l1, ax, x0, x1) : ggx_sample_xy(l1, ax, ay, x0, x1); }
+__device__ __forceinline__ void ggx_eval2(V3 l1, V3 l2, float ax, float ay, float& fcos, float& pdf, float& kh) { if (ax == ay) ggx_eval(l1, l2, ax, fcos, pdf, kh); else ggx_eval_xy(l1, l2, ax, ay, fcos, pdf, kh); }
+
 // ior2 / ior1 of the interface (== oracle relative_eta): eta entering, 1/eta leaving when the medium stack is empty
 __device__ __forceinline__ float relative_eta(const ShState& st, float materialEta)
 {
@@ -382,12 +441,12 @@ __device__ inline V3 eon_pi_f(V3 rho, float r, V3 l1, V3 l2)
   const V3 rhoMs = v3((rr.x * avgEF) / (1.0f - rho.x * (1.0f - avgEF)), (rr.y * avgEF) / (1.0f - rho.y * (1.0f - avgEF)), (rr.z * avgEF) / (1.0f - rho.z * (1.0f - avgEF)));
   return rho * ss + rhoMs * ms;
 }
-struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, baseColor, ssColor, fuzzColor; float metalness, alpha, coat, coatAlpha, coatF0, eta, tw, specWeight, baseWeight, diffRough, ssWeight, ssAniso, fuzzWeight, fuzzAlpha; bool thinWalled; };
+struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, baseColor, ssColor, fuzzColor; float metalness, alpha, alphaY, coat, coatAlpha, coatAlphaY, coatF0, eta, tw, specWeight, baseWeight, diffRough, ssWeight, ssAniso, fuzzWeight, fuzzAlpha; bool thinWalled; };
 __device__ __forceinline__ OpbrParams opbr_params(const MaterialRec* m, const ShState& st)
 {
   OpbrParams o; const float* p = m->p;
   o.albedo = v3(p[MP_ALBEDO], p[MP_ALBEDO + 1], p[MP_ALBEDO + 2]);
-  o.baseColor = v3(p[0], p[1], p[2]); o.baseWeight = p[17]; o.diffRough = p[27]; o.thinWalled = p[54] != 0.0f;
+  o.baseColor = v3(p[0], p[1], p[2]); o.baseWeight = p[17]; o.diffRough = p[27]; const uint32_t feat = (uint32_t)p[MP_FEATURES]; o.thinWalled = (feat & MATF_THIN_WALLED) != 0u;
   o.metalTint = v3(p[MP_F0], p[MP_F0 + 1], p[MP_F0 + 2]);
   o.specColor = v3(p[7], p[8], p[9]);
   o.specWeight = p[18]; o.metalness = p[10];
@@ -398,13 +457,16 @@ __device__ __forceinline__ OpbrParams opbr_params(const MaterialRec* m, const Sh
   if (st.texMask & (1u << TEX_BASE_COLOR)) { o.albedo = st.texBaseColor * p[17]; o.baseColor = st.texBaseColor; }
   if (st.texMask & (1u << TEX_ROUGHNESS)) { const float r = opbr_effective_roughness(st.texRoughness, p[13], o.coat); o.alpha = fmax2(r * r, 0.001f); }
   if (st.texMask & (1u << TEX_METALLIC)) o.metalness = st.texMetallic;
+  o.alphaY = o.alpha; o.coatAlphaY = o.coatAlpha;
+  if (feat & MATF_ANISOTROPY) { opbr_anisotropy(o.alpha, p[60], o.alpha, o.alphaY); opbr_anisotropy(o.coatAlpha, p[61], o.coatAlpha, o.coatAlphaY); } // specular_roughness_anisotropy / coat_roughness_anisotropy
   // coat_substrate_attenuated = base_substrate * modulated_base_darkening * coat_attenuation (open_pbr_surface.mtlx:538-552)
   o.coatTint = o.coatTint * opbr_base_darkening(o.baseColor, o.specWeight, o.metalness, o.coat, o.coatF0, p[22], p[48]);
   // thin-walled subsurface (open_pbr_surface.mtlx:140-196, 207-218); the volumetric form of non-thin-walled materials is not modelled
   o.ssWeight = o.thinWalled ? p[55] : 0.0f;
   o.ssColor = v3(p[56], p[57], p[58]); o.ssAniso = p[59];
   // fuzz layer (open_pbr_surface.mtlx:569-581): sheen_bsdf(fuzz_weight, fuzz_color, fuzz_roughness) on top of the coat
-  o.fuzzWeight = fmin2(fmax2(p[49], 0.0f), 1.0f); o.fuzzColor = v3(p[50], p[51], p[52]); o.fuzzAlpha = fmin2(fmax2(p[53], 0.07f), 1.0f);
+  o.fuzzWeight = 0.0f; o.fuzzColor = v3(1.0f, 1.0f, 1.0f); o.fuzzAlpha = 0.5f;
+  if (feat & MATF_FUZZ) { o.fuzzWeight = fmin2(fmax2(p[49], 0.0f), 1.0f); o.fuzzColor = v3(p[50], p[51], p[52]); o.fuzzAlpha = fmin2(fmax2(p[53], 0.07f), 1.0f); }
   return o;
 }
 // ---- fuzz (sheen) lobe, operation for operation the oracle's (oracle/gi_oracle.cpp "fuzz (sheen) lobe": the model, its sources and the layering rule are
@@ -513,7 +575,7 @@ __device__ inline void opbr_sample_base(const OpbrParams& o, const ShState& st, 
     out.overPdf = rho * o.coatTint; out.event = EV_DIFFUSE | EV_REFLECTION;
     return;
   }
-  const GgxOut g = ggx_sample(l1, lobe == 0u ? o.coatAlpha : o.alpha, x0, x1);
+  const GgxOut g = ggx_sample2(l1, lobe == 0u ? o.coatAlpha : o.alpha, lobe == 0u ? o.coatAlphaY : o.alphaY, x0, x1);
   if (lobe == 3u) {
     V3 h = normalize(l1 + g.l2);
     float kh = dot(l1, h);
@@ -528,6 +590,7 @@ __device__ inline void opbr_sample_base(const OpbrParams& o, const ShState& st, 
     if (!(lt.z < 0.0f) || !(dot(k2, st.geomNormal) < 0.0f)) return;
     float a2 = o.alpha * o.alpha, nk2 = -lt.z;
     float L1 = ggx_lambda_term(a2, nk1), L2 = ggx_lambda_term(a2, nk2);
+    if (o.alpha != o.alphaY) { L1 = ggx_lambda_xy(o.alpha, o.alphaY, l1); L2 = ggx_lambda_xy(o.alpha, o.alphaY, lt); }
     float G1 = 2.0f * nk1 / (nk1 + L1), G2 = 2.0f * nk1 * nk2 / (nk2 * L1 + nk1 * L2);
     float w = ((1.0f - Fh) / (1.0f - Fd)) * (G2 / G1);
     out.k2 = normalize(k2); out.pdf = (1.0f - Fc) * (1.0f - o.metalness) * (1.0f - Fd) * o.tw * g.pdf;
@@ -578,8 +641,8 @@ __device__ inline void opbr_evaluate_base(const OpbrParams& o, const ShState& st
   float eta = relative_eta(st, o.eta);
   float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1));
   float Fd = fresnel_dielectric(nk1, eta);
-  float fc, pc, khc; ggx_eval(l1, l2, o.coatAlpha, fc, pc, khc);
-  float fs, ps, khs; ggx_eval(l1, l2, o.alpha, fs, ps, khs);
+  float fc, pc, khc; ggx_eval2(l1, l2, o.coatAlpha, o.coatAlphaY, fc, pc, khc);
+  float fs, ps, khs; ggx_eval2(l1, l2, o.alpha, o.alphaY, fs, ps, khs);
   float Fch = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(khc));
   V3 Fm = schlick_f82(o.albedo, o.metalTint, khs) * o.specWeight;
   float Fdh = fresnel_dielectric(khs, eta);

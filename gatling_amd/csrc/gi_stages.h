@@ -105,7 +105,7 @@ __device__ __forceinline__ void shade_segment(const FrameUniforms& U, const Scen
       throughput = throughput * v3(gi_expf(-m[5] * distance), gi_expf(-m[6] * distance), gi_expf(-m[7] * distance));
     }
   }
-  const bool thinWalled = ((KLASS == KLASS_DYNAMIC) ? mat->klass : KLASS) == 2u && mat->p[54] != 0.0f; // mdl_thin_walled (:155-157): OpenPBR geometry_thin_walled
+  const bool thinWalled = ((KLASS == KLASS_DYNAMIC) ? mat->klass : KLASS) == 2u && ((uint32_t)mat->p[MP_FEATURES] & MATF_THIN_WALLED) != 0u; // mdl_thin_walled (:155-157): OpenPBR geometry_thin_walled
   ss.thinWalled = thinWalled;
   if (VOLUME) { ss.ior1 = (ss.frontFace || thinWalled) ? prevMediumIor : -1.0f; ss.ior2 = (ss.frontFace || thinWalled) ? -1.0f : nextMediumIor; } // iorCurrent / iorOther (:188-189)
   // emission (rp_main.chit:293-343): uniform EDF, radiance == emission colour where cos > 0

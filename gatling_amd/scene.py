@@ -55,6 +55,8 @@ P_THIN_WALLED = 54
 P_SUBSURFACE_WEIGHT = 55
 P_SUBSURFACE_COLOR = 56              # 3
 P_SUBSURFACE_ANISOTROPY = 59
+P_SPECULAR_ANISOTROPY = 60
+P_COAT_ANISOTROPY = 61
 P_COUNT = 64
 
 
@@ -108,7 +110,7 @@ def _open_pbr(name="mat", base_weight=1.0, base_color=(0.8, 0.8, 0.8), base_meta
               coat_ior=1.6, emission_luminance=0.0, emission_color=(1, 1, 1), base_diffuse_roughness=0.0,
               transmission_scatter=(0, 0, 0), transmission_scatter_anisotropy=0.0, coat_darkening=1.0, fuzz_weight=0.0,
               fuzz_color=(1, 1, 1), fuzz_roughness=0.5, geometry_thin_walled=False, subsurface_weight=0.0, subsurface_color=(0.8, 0.8, 0.8),
-              subsurface_scatter_anisotropy=0.0) -> MaterialDesc:
+              subsurface_scatter_anisotropy=0.0, specular_roughness_anisotropy=0.0, coat_roughness_anisotropy=0.0) -> MaterialDesc:
     """open_pbr_surface inputs with the defaults of src/gi/mtlx/open_pbr_surface.mtlx:11-92 (the lobes this core implements)."""
     p = np.zeros(P_COUNT, np.float32)
     p[P_BASE_COLOR:P_BASE_COLOR + 3] = base_color
@@ -138,6 +140,8 @@ def _open_pbr(name="mat", base_weight=1.0, base_color=(0.8, 0.8, 0.8), base_meta
     p[P_SUBSURFACE_WEIGHT] = subsurface_weight         # modelled for thin-walled materials (open_pbr_surface.mtlx:140-196); the volumetric form is not
     p[P_SUBSURFACE_COLOR:P_SUBSURFACE_COLOR + 3] = subsurface_color
     p[P_SUBSURFACE_ANISOTROPY] = subsurface_scatter_anisotropy
+    p[P_SPECULAR_ANISOTROPY] = specular_roughness_anisotropy   # open_pbr_anisotropy (open_pbr_surface.mtlx:133-136, 552-555): highlights stretched along the tangent
+    p[P_COAT_ANISOTROPY] = coat_roughness_anisotropy
     return MaterialDesc(name=name, klass=MAT_OPEN_PBR, params=p)
 
 

@@ -893,6 +893,66 @@ inline void ggx_eval(V3 l1, V3 l2, float alpha, float& fcos, float& pdf, float& 
   pdf = G1 * D / (4.0f * nk1);
 }
 
+// Anisotropic form (specular_roughness_anisotropy / coat_roughness_anisotropy, open_pbr_surface.mtlx:27, 65, 133-136, 552-555): the same VNDF sampling with the
+// view stretched by (ax, ay) along (tangentU, tangentV), D = 1 / (pi ax ay (hx^2/ax^2 + hy^2/ay^2 + hz^2)^2) and the Smith term of the stretched direction.
+// Used only when ax != ay, so isotropic materials keep the arithmetic above bit for bit.
+inline float ggx_lambda_xy(float ax, float ay, V3 v) { return sqrtf(((ax * v.x) * (ax * v.x) + (ay * v.y) * (ay * v.y)) + v.z * v.z); }
+inline float ggx_d_xy(float ax, float ay, V3 h)
+{
+  const float hx = h.x / ax, hy = h.y / ay;
+  const float dd = (hx * hx + hy * hy) + h.z * h.z;
+  return 1.0f / (((ORC_PI * ax) * ay) * (dd * dd));
+}
+inline GgxOut ggx_sample_xy(V3 l1, float ax, float ay, float x0, float x1)
+{
+  GgxOut o; o.valid = false;
+  V3 vh = normalize(v3(ax * l1.x, ay * l1.y, l1.z));
+  float lensq = vh.x * vh.x + vh.y * vh.y;
+  V3 T1 = lensq > 0.0f ? v3(-vh.y, vh.x, 0.0f) * (1.0f / sqrtf(lensq)) : v3(1.0f, 0.0f, 0.0f);
+  V3 T2 = cross(vh, T1);
+  float r = sqrtf(x0);
+  float s, c; sincos2pi(x1, &s, &c);
+  float t1 = r * c, t2 = r * s;
+  float sm = 0.5f * (1.0f + vh.z);
+  t2 = (1.0f - sm) * sqrtf(fmax2(0.0f, 1.0f - t1 * t1)) + sm * t2;
+  V3 nh = (T1 * t1 + T2 * t2) + vh * sqrtf(fmax2(0.0f, (1.0f - t1 * t1) - t2 * t2));
+  V3 h = normalize(v3(ax * nh.x, ay * nh.y, fmax2(0.0f, nh.z)));
+  float kh = dot(l1, h);
+  V3 l2 = h * (2.0f * kh) - l1;
+  if (!(l2.z > 0.0f) || !(kh > 0.0f)) return o;
+  float nk1 = l1.z, nk2 = l2.z;
+  float D = ggx_d_xy(ax, ay, h);
+  float L1 = ggx_lambda_xy(ax, ay, l1), L2 = ggx_lambda_xy(ax, ay, l2);
+  float G1 = 2.0f * nk1 / (nk1 + L1);
+  float G2 = 2.0f * nk1 * nk2 / (nk2 * L1 + nk1 * L2);
+  o.l2 = l2; o.kh = kh; o.pdf = G1 * D / (4.0f * nk1); o.g2OverG1 = G2 / G1; o.valid = true;
+  return o;
+}
+inline void ggx_eval_xy(V3 l1, V3 l2, float ax, float ay, float& fcos, float& pdf, float& kh)
+{
+  fcos = 0.0f; pdf = 0.0f; kh = 0.0f;
+  if (!(l1.z > 0.0f) || !(l2.z > 0.0f)) return;
+  V3 h = normalize(l1 + l2);
+  kh = dot(l1, h);
+  float nk1 = l1.z, nk2 = l2.z;
+  float D = ggx_d_xy(ax, ay, h);
+  float L1 = ggx_lambda_xy(ax, ay, l1), L2 = ggx_lambda_xy(ax, ay, l2);
+  float G1 = 2.0f * nk1 / (nk1 + L1);
+  float G2 = 2.0f * nk1 * nk2 / (nk2 * L1 + nk1 * L2);
+  fcos = D * G2 / (4.0f * nk1);
+  pdf = G1 * D / (4.0f * nk1);
+}
+// the lobe's (ax, ay) of OpenPBR's open_pbr_anisotropy node: alpha_t = r^2 sqrt(2 / (1 + (1 - a)^2)), alpha_b = (1 - a) alpha_t (a = 0: both r^2)
+inline void opbr_anisotropy(float alpha, float a, float& ax, float& ay)
+{
+  ax = alpha; ay = alpha;
+  if (!(a > 0.0f)) return;
+  const float inv = 1.0f - fmin2(a, 1.0f);
+  ax = fmax2(alpha * sqrtf(2.0f / (1.0f + inv * inv)), 0.001f); ay = fmax2(inv * ax, 0.001f);
+}
+inline GgxOut ggx_sample2(V3 l1, float ax, float ay, float x0, float x1) { return ax == ay ? ggx_sample(l1, ax, x0, x1) : ggx_sample_xy(l1, ax, ay, x0, x1); }
+inline void ggx_eval2(V3 l1, V3 l2, float ax, float ay, float& fcos, float& pdf, float& kh) { if (ax == ay) ggx_eval(l1, l2, ax, fcos, pdf, kh); else ggx_eval_xy(l1, l2, ax, ay, fcos, pdf, kh); }
+
 struct UpsParams { V3 albedo, F0; float alpha, coat, coatAlpha; };
 inline UpsParams ups_params(const OrcMaterial& m)
 {
@@ -987,7 +1047,7 @@ inline V3 eon_pi_f(V3 rho, float r, V3 l1, V3 l2)
   const V3 rhoMs = v3((rr.x * avgEF) / (1.0f - rho.x * (1.0f - avgEF)), (rr.y * avgEF) / (1.0f - rho.y * (1.0f - avgEF)), (rr.z * avgEF) / (1.0f - rho.z * (1.0f - avgEF)));
   return rho * ss + rhoMs * ms;
 }
-struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, sigmaA, sigmaS, baseColor, coatColor, ssColor, fuzzColor; float metalness, alpha, coat, coatAlpha, coatF0, eta, tw, specWeight, anisotropy, baseWeight, diffRough, ssWeight, ssAniso, fuzzWeight, fuzzAlpha; bool thinWalled; };
+struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, sigmaA, sigmaS, baseColor, coatColor, ssColor, fuzzColor; float metalness, alpha, alphaY, coat, coatAlpha, coatAlphaY, coatF0, eta, tw, specWeight, anisotropy, baseWeight, diffRough, ssWeight, ssAniso, fuzzWeight, fuzzAlpha; bool thinWalled; };
 inline OpbrParams opbr_params(const OrcMaterial& m)
 {
   OpbrParams o; const float* p = m.p;
@@ -1002,6 +1062,7 @@ inline OpbrParams opbr_params(const OrcMaterial& m)
   o.coat = p[ORC_P_CLEARCOAT];
   r = opbr_effective_roughness(r, cr, o.coat);
   o.alpha = fmax2(r * r, 0.001f); o.coatAlpha = fmax2(cr * cr, 0.001f);
+  opbr_anisotropy(o.alpha, p[ORC_P_SPECULAR_ANISOTROPY], o.alpha, o.alphaY); opbr_anisotropy(o.coatAlpha, p[ORC_P_COAT_ANISOTROPY], o.coatAlpha, o.coatAlphaY); // :133-136, 552-555
   float cior = p[ORC_P_COAT_IOR]; float qc = (cior - 1.0f) / (cior + 1.0f); o.coatF0 = qc * qc;
   V3 cc = v3(p + ORC_P_COAT_COLOR); o.coatColor = cc; o.coatTint = v3(1, 1, 1) * (1.0f - o.coat) + cc * o.coat;
   // coat_substrate_attenuated = base_substrate * modulated_base_darkening * coat_attenuation (:538-552)
@@ -1105,7 +1166,7 @@ static void opbr_sample_base(const OpbrParams& o, const State& st, V3 k1, const 
   float z = xi[2];
   float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1));
   if (z < Fc) { // coat reflection
-    GgxOut g = ggx_sample(l1, o.coatAlpha, xi[0], xi[1]);
+    GgxOut g = ggx_sample2(l1, o.coatAlpha, o.coatAlphaY, xi[0], xi[1]);
     V3 k2 = to_world(st, g.l2);
     if (!g.valid || !(dot(k2, st.geomNormal) > 0.0f)) return;
     float Fh = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(g.kh));
@@ -1115,7 +1176,7 @@ static void opbr_sample_base(const OpbrParams& o, const State& st, V3 k1, const 
   }
   z = (z - Fc) / (1.0f - Fc);
   if (z < o.metalness) { // metal
-    GgxOut g = ggx_sample(l1, o.alpha, xi[0], xi[1]);
+    GgxOut g = ggx_sample2(l1, o.alpha, o.alphaY, xi[0], xi[1]);
     V3 k2 = to_world(st, g.l2);
     if (!g.valid || !(dot(k2, st.geomNormal) > 0.0f)) return;
     V3 F = schlick_f82(o.albedo, o.metalTint, g.kh) * o.specWeight;
@@ -1127,7 +1188,7 @@ static void opbr_sample_base(const OpbrParams& o, const State& st, V3 k1, const 
   (void)frontFace;
   float Fd = fresnel_dielectric(nk1, eta);
   if (z < Fd) { // dielectric reflection
-    GgxOut g = ggx_sample(l1, o.alpha, xi[0], xi[1]);
+    GgxOut g = ggx_sample2(l1, o.alpha, o.alphaY, xi[0], xi[1]);
     V3 k2 = to_world(st, g.l2);
     if (!g.valid || !(dot(k2, st.geomNormal) > 0.0f)) return;
     float Fh = fresnel_dielectric(g.kh, eta);
@@ -1137,7 +1198,7 @@ static void opbr_sample_base(const OpbrParams& o, const State& st, V3 k1, const 
   }
   z = (z - Fd) / (1.0f - Fd);
   if (z < o.tw) { // rough refraction through a VNDF-sampled micro-normal
-    GgxOut g = ggx_sample(l1, o.alpha, xi[0], xi[1]); // provides the half vector via l2 = reflect(l1, h)
+    GgxOut g = ggx_sample2(l1, o.alpha, o.alphaY, xi[0], xi[1]); // provides the half vector via l2 = reflect(l1, h)
     V3 h = normalize(l1 + g.l2);
     float kh = dot(l1, h);
     if (!g.valid || !(kh > 0.0f)) return;
@@ -1152,6 +1213,7 @@ static void opbr_sample_base(const OpbrParams& o, const State& st, V3 k1, const 
     if (!(lt.z < 0.0f) || !(dot(k2, st.geomNormal) < 0.0f)) return;
     float a2 = o.alpha * o.alpha, nk2 = -lt.z;
     float L1 = ggx_lambda_term(a2, nk1), L2 = ggx_lambda_term(a2, nk2);
+    if (o.alpha != o.alphaY) { L1 = ggx_lambda_xy(o.alpha, o.alphaY, l1); L2 = ggx_lambda_xy(o.alpha, o.alphaY, lt); }
     float G1 = 2.0f * nk1 / (nk1 + L1), G2 = 2.0f * nk1 * nk2 / (nk2 * L1 + nk1 * L2);
     float w = ((1.0f - Fh) / (1.0f - Fd)) * (G2 / G1);
     out.k2 = normalize(k2); out.pdf = (1.0f - Fc) * (1.0f - o.metalness) * (1.0f - Fd) * o.tw * g.pdf;
@@ -1214,8 +1276,8 @@ static void opbr_evaluate_base(const OpbrParams& o, const State& st, V3 k1, V3 k
   float eta = relative_eta(st, o.eta); (void)frontFace;
   float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1));
   float Fd = fresnel_dielectric(nk1, eta);
-  float fc, pc, khc; ggx_eval(l1, l2, o.coatAlpha, fc, pc, khc);
-  float fs, ps, khs; ggx_eval(l1, l2, o.alpha, fs, ps, khs);
+  float fc, pc, khc; ggx_eval2(l1, l2, o.coatAlpha, o.coatAlphaY, fc, pc, khc);
+  float fs, ps, khs; ggx_eval2(l1, l2, o.alpha, o.alphaY, fs, ps, khs);
   float Fch = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(khc));
   V3 Fm = schlick_f82(o.albedo, o.metalTint, khs) * o.specWeight;
   float Fdh = fresnel_dielectric(khs, eta);

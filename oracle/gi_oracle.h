@@ -81,6 +81,7 @@ enum {
   ORC_P_FUZZ_WEIGHT = 49, ORC_P_FUZZ_COLOR = 50, ORC_P_FUZZ_ROUGHNESS = 53, /* :57-59: the fuzz (sheen) layer (:569-581) */
   ORC_P_SUBSURFACE_WEIGHT = 55, ORC_P_SUBSURFACE_COLOR = 56, ORC_P_SUBSURFACE_ANISOTROPY = 59, /* :43-52; thin-walled subsurface (:140-196) */
   ORC_P_THIN_WALLED = 54,      /* geometry_thin_walled (:88) */
+  ORC_P_SPECULAR_ANISOTROPY = 60, ORC_P_COAT_ANISOTROPY = 61, /* specular_roughness_anisotropy (:27), coat_roughness_anisotropy (:65) */
   ORC_P_COUNT = 64
 };
 

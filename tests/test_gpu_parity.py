@@ -425,7 +425,12 @@ def test_bsdf_known_answers_on_device(gi, orc):
             MaterialDesc.open_pbr(base_color=(0.05, 0.05, 0.05), specular_weight=0.2, fuzz_weight=1.0, fuzz_color=(0.9, 0.5, 0.3), fuzz_roughness=0.5),
             MaterialDesc.open_pbr(base_color=(0.6, 0.2, 0.2), coat_weight=0.7, coat_roughness=0.1, fuzz_weight=0.8, fuzz_color=(0.8, 0.8, 1.0), fuzz_roughness=0.07),
             MaterialDesc.open_pbr(base_color=(0.9, 0.7, 0.3), base_metalness=1.0, specular_roughness=0.35, fuzz_weight=0.45, fuzz_color=(1.0, 0.9, 0.8), fuzz_roughness=1.0),
-            MaterialDesc.open_pbr(base_color=(0.3, 0.5, 0.7), transmission_weight=0.5, fuzz_weight=0.3, fuzz_roughness=0.23)]
+            MaterialDesc.open_pbr(base_color=(0.3, 0.5, 0.7), transmission_weight=0.5, fuzz_weight=0.3, fuzz_roughness=0.23),
+            # specular / coat anisotropy (open_pbr_surface.mtlx:133-136, 552-555): metal, dielectric with transmission, anisotropic coat over an isotropic base
+            MaterialDesc.open_pbr(base_color=(0.9, 0.8, 0.6), base_metalness=1.0, specular_roughness=0.45, specular_roughness_anisotropy=0.8),
+            MaterialDesc.open_pbr(base_color=(0.4, 0.6, 0.8), transmission_weight=0.7, specular_roughness=0.3, specular_roughness_anisotropy=0.5, specular_ior=1.4),
+            MaterialDesc.open_pbr(base_color=(0.6, 0.3, 0.3), specular_roughness=0.4, coat_weight=0.9, coat_roughness=0.35, coat_roughness_anisotropy=0.95, fuzz_weight=0.2),
+            MaterialDesc.open_pbr(base_color=(0.5, 0.5, 0.5), specular_roughness=0.2, specular_roughness_anisotropy=1.0, coat_weight=0.3, coat_roughness=0.1, coat_roughness_anisotropy=0.3)]
     items[: n // 2, 21] = 0.75  # xi.w >= 0.5: the debug hook shades these as back faces (eta inverted)
     for m in mats:
         got, ref = gi.bsdf_debug(m, items), orc.bsdf_debug(m, items)

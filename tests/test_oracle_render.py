@@ -139,7 +139,9 @@ def _closed_form_materials():
                        base_diffuse_roughness=0.5, coat_weight=0.5, coat_roughness=0.2),
             M.open_pbr(base_color=(0, 0, 0), specular_weight=0.0, fuzz_weight=1.0, fuzz_color=(1, 1, 1), fuzz_roughness=0.5),                      # the fuzz lobe alone
             M.open_pbr(base_color=(1, 1, 1), coat_weight=1.0, coat_roughness=0.1, fuzz_weight=1.0, fuzz_color=(1, 1, 1), fuzz_roughness=0.07),     # smooth fuzz (E > 1 at grazing views) over a coat
-            M.open_pbr(base_color=(1, 1, 1), base_metalness=1.0, specular_roughness=0.4, fuzz_weight=0.6, fuzz_color=(1, 1, 1), fuzz_roughness=1.0)]
+            M.open_pbr(base_color=(1, 1, 1), base_metalness=1.0, specular_roughness=0.4, fuzz_weight=0.6, fuzz_color=(1, 1, 1), fuzz_roughness=1.0),
+            M.open_pbr(base_color=(1, 1, 1), base_metalness=1.0, specular_roughness=0.5, specular_roughness_anisotropy=0.8),                         # anisotropic metal
+            M.open_pbr(base_color=(1, 1, 1), specular_roughness=0.4, specular_roughness_anisotropy=0.5, coat_weight=1.0, coat_roughness=0.3, coat_roughness_anisotropy=0.9)]
 
 
 def test_closed_form_bsdfs_conserve_energy(orc):
@@ -212,6 +214,43 @@ def test_fuzz_layer(orc):
     a0 = orc.bsdf_debug(m0, items)[:, 3].mean(); a1 = orc.bsdf_debug(m1, items)[:, 3].mean()
     E = gen.albedo(0.6, 0.5, 300)
     assert abs(a1 - a0 * (1.0 - E)) < 0.02, (a0, a1, E)
+
+
+def test_specular_anisotropy(orc):
+    """open_pbr_surface.mtlx:27, 65, 133-136, 552-555 (open_pbr_anisotropy): alpha_t = r^2 sqrt(2 / (1 + (1 - a)^2)) along the tangent, alpha_b = (1 - a) alpha_t.
+    The micro-normals of a GGX lobe with (alpha_t, alpha_b) have slope variances in that ratio; the lobe's value is reciprocal; anisotropy 0 is the isotropic lobe
+    bit for bit; a tangent frame rotated by 90 degrees swaps the stretch."""
+    rng = np.random.default_rng(31)
+    r, a = 0.3, 0.75                                          # (small enough that almost no sampled micro-normal reflects below the horizon: the medians below are untruncated)
+    at = r * r * np.sqrt(2.0 / (1.0 + (1.0 - a) ** 2)); ab = (1.0 - a) * at
+    m = MaterialDesc.open_pbr(base_color=(1, 1, 1), base_metalness=1.0, specular_roughness=r, specular_roughness_anisotropy=a)
+    items = _frames(200000, rng, 1.0)                        # normal incidence: the sampled half vector is the micro-normal distribution itself
+    out = orc.bsdf_debug(m, items)
+    ok = out[:, 7] != 0
+    k2 = out[ok, 0:3]
+    h = k2 + np.float32([0, 0, 1]); h /= np.linalg.norm(h, axis=1, keepdims=True)
+    sx, sy = np.abs(h[:, 0] / h[:, 2]), np.abs(h[:, 1] / h[:, 2])        # slopes: GGX slopes are heavy-tailed, compare medians (median |slope_x| = alpha_x * const)
+    np.testing.assert_allclose(np.median(sx) / np.median(sy), at / ab, rtol=0.05)
+    np.testing.assert_allclose(np.median(sx), at * 0.5774, rtol=0.06)  # marginal of the GGX slope distribution: P(|s| < a / sqrt(3)) = 1/2
+    # rotated frame: stretch follows the tangent
+    rot = items.copy(); rot[:, 3:6] = items[:, 6:9]; rot[:, 6:9] = -items[:, 3:6]
+    o2 = orc.bsdf_debug(m, rot); ok2 = o2[:, 7] != 0
+    h2 = o2[ok2, 0:3] + np.float32([0, 0, 1]); h2 /= np.linalg.norm(h2, axis=1, keepdims=True)
+    np.testing.assert_allclose(np.median(np.abs(h2[:, 1] / h2[:, 2])) / np.median(np.abs(h2[:, 0] / h2[:, 2])), at / ab, rtol=0.05)
+    # reciprocity of evaluate / cos
+    n = 4000
+    u = rng.normal(size=(n, 3)); u[:, 2] = np.abs(u[:, 2]) + 0.2; u /= np.linalg.norm(u, axis=1, keepdims=True)
+    v = rng.normal(size=(n, 3)); v[:, 2] = np.abs(v[:, 2]) + 0.2; v /= np.linalg.norm(v, axis=1, keepdims=True)
+    base = _frames(n, rng, 0.5)
+    uv = base.copy(); uv[:, 12:15] = u; uv[:, 15:18] = v
+    vu = base.copy(); vu[:, 12:15] = v; vu[:, 15:18] = u
+    fuv = orc.bsdf_debug(m, uv)[:, 11] / v[:, 2]; fvu = orc.bsdf_debug(m, vu)[:, 11] / u[:, 2]
+    np.testing.assert_allclose(fuv, fvu, rtol=3e-4, atol=1e-6)  # (the F82 Fresnel depends on k.h only: symmetric)
+    # anisotropy 0 == no anisotropy input at all, bit for bit
+    items = _frames(20000, rng, 0.4)
+    a0 = orc.bsdf_debug(MaterialDesc.open_pbr(base_color=(0.7, 0.6, 0.5), coat_weight=0.5, coat_roughness=0.2), items)
+    a1 = orc.bsdf_debug(MaterialDesc.open_pbr(base_color=(0.7, 0.6, 0.5), coat_weight=0.5, coat_roughness=0.2, specular_roughness_anisotropy=0.0, coat_roughness_anisotropy=0.0), items)
+    assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32))
 
 
 def test_thin_walled_subsurface_lobes(orc):
