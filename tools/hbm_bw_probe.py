@@ -1,3 +1,7 @@
+"""What the box's HBM does for plain streams (torch fill / copy / sum of 8 GiB): the yardstick for the stage kernels' byte rates (profiles/r03w_work_order.txt (8)).
+
+  gpurun -- python tools/hbm_bw_probe.py
+"""
 import torch, time
 x = torch.empty(8 << 30, dtype=torch.uint8, device='cuda')
 y = torch.empty(8 << 30, dtype=torch.uint8, device='cuda')

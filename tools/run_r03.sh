@@ -1,8 +1,7 @@
 #!/bin/bash
 # Round-3 GPU sessions, one script with selectable stages (replaces the per-experiment run_r02*.sh one-shots):
 #   gpurun --timeout 1500 -- 'bash tools/run_r03.sh <tag> calib tests variants bench prof order'
-# Everything lands under gpurun_out/<tag>_* (merged back by gpurun); copy what should be judged into profiles/ afterwards
-# (tools/collect_r03.sh <tag>).
+# Everything lands under gpurun_out/<tag>_* (merged back by gpurun); copy what should be judged into profiles/ afterwards.
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $O/prof
 TAG=$1; shift
 J='import json,sys; j=json.loads(sys.stdin.read()); r=j["roofline"]; print(j["value"], j["ms_per_step"], r["stage_ms_per_step"], {k: r.get(k) for k in ("bound","frac","valu_frac","valu_lane_utilisation","l2_hit_rate","traffic","nodes_per_ray","tris_per_ray","pmc_note")}); [print("  also", a.get("workload"), a.get("value"), a.get("ms_per_step"), a.get("error"), (a.get("roofline") or {}).get("stage_ms_per_step"), {k: (a.get("roofline") or {}).get(k) for k in ("frac","valu_frac","valu_lane_utilisation","l2_hit_rate")}) for a in (j.get("also") if isinstance(j.get("also"), list) else [j["also"]] if j.get("also") else [])]'
