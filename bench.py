@@ -262,7 +262,9 @@ def main():
 
         def step():
             if not use_dist:
-                last["img"] = scene.render(rs, w, h)  # blocks; colour AOV complete in host memory on return (reference semantics)
+                # blocks; the colour AOV is complete in the library's host memory on return (reference semantics: hdGatling reads giGetRenderBufferMem in place,
+                # renderBuffer.cpp:53-154) -- a view of it, not a second host copy through numpy (33 MB, ~4 ms per C2 step until r03)
+                last["img"] = scene.render(rs, w, h, copy=False)
             else:
                 gather.wait_packed()  # frame i - 1's pack copy has read the render buffer (it runs on torch's stream, the library renders on its own)
                 scene.render(rs, w, h, rows=(r0, r1), device_only=True, row_stride=rstride)

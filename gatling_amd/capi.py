@@ -315,9 +315,10 @@ class Scene:
             self._buffers[key] = rb
         return self._buffers[key]
 
-    def render(self, settings: RenderSettings, width: int, height: int, rows=None, device_only=False, row_stride=1):
-        """One giCRender call.  Returns the colour AOV as float32 [rows, width, 4] (row 0 = bottom) -- a view of the
-        library-owned host memory copied out -- or None when ``device_only``."""
+    def render(self, settings: RenderSettings, width: int, height: int, rows=None, device_only=False, row_stride=1, copy=True):
+        """One giCRender call.  Returns the colour AOV as float32 [rows, width, 4] (row 0 = bottom) -- the library-owned host
+        memory of giCGetRenderBufferMem copied out, or with ``copy=False`` a VIEW of it (the reference's contract, Gi.cpp:3003-3006:
+        the pointer stays valid, its contents are those of the last render, until the buffer is destroyed) -- or None when ``device_only``."""
         L = self.L
         rb = self.color_buffer(width, height)
         L.giCSetRenderBufferDeviceOnly(rb, int(device_only))
@@ -341,7 +342,7 @@ class Scene:
             return None
         mem = L.giCGetRenderBufferMem(rb)
         full = np.ctypeslib.as_array(C.cast(mem, C.POINTER(C.c_float)), shape=(height, width, 4))
-        return full[r0:r1:row_stride].copy()
+        return full[r0:r1:row_stride].copy() if copy else full[r0:r1:row_stride]
 
     AOVS = {"normal": (1, FORMAT_FLOAT32_VEC4), "nee": (2, FORMAT_FLOAT32_VEC4), "barycentrics": (3, FORMAT_FLOAT32_VEC4),
             "texcoords": (4, FORMAT_FLOAT32_VEC4), "bounces": (5, FORMAT_FLOAT32_VEC4), "clockCycles": (6, FORMAT_FLOAT32_VEC4), "opacity": (7, FORMAT_FLOAT32_VEC4),
