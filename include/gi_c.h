@@ -378,7 +378,7 @@ int giCGetRenderStats(const GiCScene* scene, GiCRenderStats* out);
 /* value N > 0: record HIP events around the stage launches of every N-th wavefront iteration (1 = every launch; events
  * on every launch cost ~16 % of a frame) and scale the per-stage totals accordingly; 0 = off */
 #define GI_C_SCENE_OPTION_KERNEL_TIMERS 2
-/* size of the persistent path pool (slots; default 4 Mi) and of the per-sample colour buffer (MiB; default 8192) -- results
+/* size of the persistent path pool (slots; default 4 Mi) and of the per-sample colour buffer (MiB; default 49152, at most a sixth of the device's memory) -- results
  * do not depend on either (tests/test_gpu_parity.py::test_pool_and_batch_invariance); 0 restores the default */
 #define GI_C_SCENE_OPTION_POOL_SLOTS 3
 #define GI_C_SCENE_OPTION_SAMPLE_BUFFER_MB 4
