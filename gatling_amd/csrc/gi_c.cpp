@@ -312,6 +312,7 @@ struct SceneDevice {
   uint32_t queueCap = 0;
   DeviceBuffer<Counters> dCounters;
   Counters* hCounters = nullptr; // pinned
+  uint64_t memTotalMb = 0;       // the device's memory (hipMemGetInfo, asked once): sizes the default sample-buffer budget
   static constexpr uint32_t POLL_RING = 4, POLL_LAG = 2; // drain test of the bounce loop: iteration it reads the queue sizes of iteration it - POLL_LAG (giCRenderImpl)
   PaddedCounter* hPoll = nullptr; hipEvent_t pollEvent[POLL_RING] = {}; // pinned ring of queue-size snapshots + their completion events
   GiCRenderStats stats{};
@@ -1696,8 +1697,8 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
     auto envU64 = [](const char* name, uint64_t def) { const char* e = getenv(name); return e ? (uint64_t)strtoull(e, nullptr, 10) : def; };
     // default budget of the per-sample colour buffer: 48 GiB of a 288 GB device (a sixth of whatever the device has) -- every batch ends in a drain / a kernel
     // tail, so fewer, larger batches are cheaper: C2 (34 GB for 1024 spp at 1080p) 4 batches -> 1, 215.5 -> 213.4 ms per step; the full C5 frame 17 -> 3
-    size_t memFree = 0, memTotal = 0; (void)hipMemGetInfo(&memFree, &memTotal);
-    const uint64_t defaultMb = std::max<uint64_t>(1024, std::min<uint64_t>(49152, (uint64_t)(memTotal >> 20) / 6));
+    if (!D.memTotalMb) { size_t memFree = 0, memTotal = 0; (void)hipMemGetInfo(&memFree, &memTotal); D.memTotalMb = std::max<uint64_t>(1, (uint64_t)(memTotal >> 20)); } // (asked once per device: a driver call)
+    const uint64_t defaultMb = std::max<uint64_t>(1024, std::min<uint64_t>(49152, D.memTotalMb / 6));
     const uint64_t budgetBytes = envU64("GATLING_SAMPLE_BUFFER_MB", s->optSampleBufferMb ? s->optSampleBufferMb : defaultMb) << 20;
     // Pool size: a launch of k_trace_dyn ends when its longest ray ends, and ray cost is heavy-tailed in scenes beyond LDS
     // (a 100-step ray outlives the average one six times over), so those scenes get a pool large enough to amortise that
