@@ -32,8 +32,8 @@ def interleaved_rows(height: int, world_size: int, rank: int) -> Tuple[int, int,
 
 class RowGather:
     """One frame's gather of the per-rank row shares to ``dst``, with every buffer allocated ONCE (the padded send buffer, the
-    receive buffers and the assembled frame on ``dst``): calling it costs a pack copy, one ``dist.gather`` and, on ``dst``, the
-    re-interleave -- no allocation inside a timed region.
+    receive buffer and the assembled frame on ``dst``): calling it costs a pack copy, one ``dist.gather`` and, on ``dst``, ONE
+    strided copy that re-interleaves the shares -- no allocation inside a timed region.
 
     The shares (contiguous bands, or rows rank::N when ``interleaved``) differ by at most one row; they are padded to a common
     size so a single gather moves everything (C5: 16.6 MB per GPU at 4K -- one collective, no all-reduce: SURVEY.md section 8e)."""
@@ -45,8 +45,12 @@ class RowGather:
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.max_rows = -(-height // self.world)
         self.pad = torch.zeros((self.max_rows, width, 4), dtype=dtype, device=device)
-        self.out = [torch.empty_like(self.pad) for _ in range(self.world)] if self.rank == dst else None
-        self.full = torch.empty((height, width, 4), dtype=dtype, device=device) if self.rank == dst else None
+        # ONE receive buffer [rank, row of the share, ...] whose slices are the gather's outputs, and the frame padded to max_rows * world rows: an interleaved
+        # frame is then the receive buffer with its first two axes swapped -- one strided copy on `dst` instead of one per rank
+        self.recv = torch.empty((self.world, self.max_rows, width, 4), dtype=dtype, device=device) if self.rank == dst else None
+        self.out = [self.recv[r] for r in range(self.world)] if self.rank == dst else None
+        self.full_padded = torch.empty((self.max_rows * self.world, width, 4), dtype=dtype, device=device) if self.rank == dst else None
+        self.full = self.full_padded[:height] if self.rank == dst else None
         # the pack copy is the only reader of the caller's tile (the library's render buffer): `packed` marks its end on the caller's stream
         self.packed = torch.cuda.Event() if torch.device(device).type == "cuda" else None
 
@@ -64,13 +68,12 @@ class RowGather:
         dist.gather(self.pad, self.out, dst=self.dst, group=self.group)
         if self.rank != self.dst:
             return None
+        if self.interleaved:  # row k * world + r of the frame is row k of rank r's share (rows past `height` are padding on both sides)
+            self.full_padded.view(self.max_rows, self.world, self.width, 4).copy_(self.recv.permute(1, 0, 2, 3))
+            return self.full
         for r in range(self.world):
-            if self.interleaved:
-                n = len(range(r, self.height, self.world))
-                self.full[r::self.world].copy_(self.out[r][:n])
-            else:
-                r0, r1 = partition_rows(self.height, self.world, r)
-                self.full[r0:r1].copy_(self.out[r][: r1 - r0])
+            r0, r1 = partition_rows(self.height, self.world, r)
+            self.full[r0:r1].copy_(self.out[r][: r1 - r0])
         return self.full
 
 
