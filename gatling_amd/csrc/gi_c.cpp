@@ -206,7 +206,8 @@ void deriveMaterialConstants(MaterialRec& m)
     out[MP_COAT_F0] = qc * qc; out[MP_ETA] = (1.0f + eps) / (1.0f - eps);
     // which optional lobes the material has, in the slot of the thin-walled switch: materials without them do not load their inputs per hit (gi_types.h MP_FEATURES)
     out[MP_FEATURES] = (float)((p[GI_C_P_THIN_WALLED] != 0.0f ? MATF_THIN_WALLED : 0u) | (p[GI_C_P_FUZZ_WEIGHT] > 0.0f ? MATF_FUZZ : 0u) |
-                               ((p[GI_C_P_SPECULAR_ANISOTROPY] > 0.0f || p[GI_C_P_COAT_ANISOTROPY] > 0.0f) ? MATF_ANISOTROPY : 0u));
+                               ((p[GI_C_P_SPECULAR_ANISOTROPY] > 0.0f || p[GI_C_P_COAT_ANISOTROPY] > 0.0f) ? MATF_ANISOTROPY : 0u) |
+                               (p[GI_C_P_THIN_FILM_WEIGHT] > 0.0f ? MATF_THIN_FILM : 0u));
     memcpy(m.p, out, sizeof(out));
     return;
   }

@@ -488,7 +488,7 @@ __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, Que
 template <uint32_t KLASS, bool TEXTURED, bool VOLUME, bool NEE, bool PACKED>
 // (forcing the plain variant to 5 waves/SIMD -- amdgpu_waves_per_eu((...) ? 5 : 1, 8): 90 VGPRs, no spills -- is SLOWER: C2 shade 178 -> 190 ms;
 // the stage is bound by the memory pipeline's scattered 16-byte requests, not by latency hiding)
-__global__ __launch_bounds__(BLOCK) void k_shade(FrameUniforms U, SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t par)
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((KLASS == 2u && !NEE && !TEXTURED && !VOLUME) ? 4 : 1, 8))) void k_shade(FrameUniforms U, SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t par)
 {
   __shared__ AppendScratch<3> sh;
   const uint32_t qNext = Q_TRACE_A + (par ^ 1u), qRegen = Q_REGEN_A + (par ^ 1u), qHit = Q_HIT + KLASS;
@@ -559,6 +559,12 @@ __device__ inline V3 bsdf_albedo(const MaterialRec* m, const ShState& st, V3 k1)
   V3 diffuse = (o.albedo * o.coatTint) * (base * diel * (1.0f - Fd) * (1.0f - o.tw));
   V3 glossy = v3(Fc, Fc, Fc) + ((schlick_f82(o.albedo, o.metalTint, nk1) * o.specWeight) * o.coatTint) * (base * o.metalness)
               + (o.specColor * o.coatTint) * (base * diel * Fd);
+  if (o.filmWeight > 0.0f) { // thin film: the two Fresnel factors carry the film's reflectance, what lies beneath the interface its complement
+    const V3 Fdf = opbr_film_dielectric(o, nk1, eta, Fd);
+    diffuse = ((o.albedo * o.coatTint) * (v3(1.0f, 1.0f, 1.0f) - Fdf)) * (base * diel * (1.0f - o.tw));
+    glossy = v3(Fc, Fc, Fc) + ((opbr_film_metal(o, nk1, schlick_f82(o.albedo, o.metalTint, nk1)) * o.specWeight) * o.coatTint) * (base * o.metalness)
+             + ((o.specColor * o.coatTint) * Fdf) * (base * diel);
+  }
   if (o.fuzzWeight > 0.0f) { // the fuzz layer keeps P = fuzz_weight * min(E, 1) of the light (tinted), what is beneath gets 1 - P
     const float Pf = o.fuzzWeight * fmin2(fuzz_albedo(nk1, o.fuzzAlpha), 1.0f);
     return (diffuse + glossy) * (1.0f - Pf) + o.fuzzColor * Pf;

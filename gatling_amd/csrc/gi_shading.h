@@ -441,7 +441,7 @@ __device__ inline V3 eon_pi_f(V3 rho, float r, V3 l1, V3 l2)
   const V3 rhoMs = v3((rr.x * avgEF) / (1.0f - rho.x * (1.0f - avgEF)), (rr.y * avgEF) / (1.0f - rho.y * (1.0f - avgEF)), (rr.z * avgEF) / (1.0f - rho.z * (1.0f - avgEF)));
   return rho * ss + rhoMs * ms;
 }
-struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, baseColor, ssColor, fuzzColor; float metalness, alpha, alphaY, coat, coatAlpha, coatAlphaY, coatF0, eta, tw, specWeight, baseWeight, diffRough, ssWeight, ssAniso, fuzzWeight, fuzzAlpha; bool thinWalled; };
+struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, baseColor, ssColor, fuzzColor; float metalness, alpha, alphaY, coat, coatAlpha, coatAlphaY, coatF0, eta, tw, specWeight, baseWeight, diffRough, ssWeight, ssAniso, fuzzWeight, fuzzAlpha, filmWeight, filmNm, filmIor; bool thinWalled; };
 __device__ __forceinline__ OpbrParams opbr_params(const MaterialRec* m, const ShState& st)
 {
   OpbrParams o; const float* p = m->p;
@@ -467,7 +467,39 @@ __device__ __forceinline__ OpbrParams opbr_params(const MaterialRec* m, const Sh
   // fuzz layer (open_pbr_surface.mtlx:569-581): sheen_bsdf(fuzz_weight, fuzz_color, fuzz_roughness) on top of the coat
   o.fuzzWeight = 0.0f; o.fuzzColor = v3(1.0f, 1.0f, 1.0f); o.fuzzAlpha = 0.5f;
   if (feat & MATF_FUZZ) { o.fuzzWeight = fmin2(fmax2(p[49], 0.0f), 1.0f); o.fuzzColor = v3(p[50], p[51], p[52]); o.fuzzAlpha = fmin2(fmax2(p[53], 0.07f), 1.0f); }
+  // thin film (open_pbr_surface.mtlx:300-304, 404-431, 450-464): weight, thickness in micrometres, ior (slot 6: OpenPBR records do not use useSpecularWorkflow)
+  o.filmWeight = 0.0f; o.filmNm = 0.0f; o.filmIor = 1.0f;
+  if (feat & MATF_THIN_FILM) { o.filmWeight = fmin2(fmax2(p[62], 0.0f), 1.0f); o.filmNm = fmax2(p[63], 0.0f) * 1000.0f; o.filmIor = fmax2(p[6], 1.0f); }
   return o;
+}
+// ---- thin film, operation for operation the oracle's (oracle/gi_oracle.cpp "thin film": Airy summation at three wavelengths; where it enters the lobes)
+__device__ inline float film_reflectance(float c, float nf, float n3, float d, float lam)
+{
+  const float s2 = 1.0f - c * c;
+  const float s2f = s2 / (nf * nf), s23 = s2 / (n3 * n3);
+  if (!(s2f < 1.0f) || !(s23 < 1.0f)) return 1.0f; // total internal reflection
+  const float cf = sqrtf(1.0f - s2f), c3 = sqrtf(1.0f - s23);
+  const float rs12 = (c - nf * cf) / (c + nf * cf), rp12 = (nf * c - cf) / (nf * c + cf);
+  const float rs23 = (nf * cf - n3 * c3) / (nf * cf + n3 * c3), rp23 = (n3 * cf - nf * c3) / (n3 * cf + nf * c3);
+  const float ph = ((2.0f * nf) * d * cf) / lam; // phase difference / (2 pi)
+  float sn, cs; gi_sincos2pi(ph - floorf(ph), &sn, &cs); (void)sn;
+  const float ps = rs12 * rs23, pp = rp12 * rp23;
+  const float Rs = ((rs12 * rs12 + rs23 * rs23) + (2.0f * ps) * cs) / ((1.0f + ps * ps) + (2.0f * ps) * cs);
+  const float Rp = ((rp12 * rp12 + rp23 * rp23) + (2.0f * pp) * cs) / ((1.0f + pp * pp) + (2.0f * pp) * cs);
+  return fmin2(fmax2(0.5f * (Rs + Rp), 0.0f), 1.0f);
+}
+__device__ inline V3 film_fresnel(float c, float nf, V3 n3, float d) { return v3(film_reflectance(c, nf, n3.x, d, 611.4f), film_reflectance(c, nf, n3.y, d, 548.4f), film_reflectance(c, nf, n3.z, d, 464.3f)); }
+__device__ inline V3 opbr_film_dielectric(const OpbrParams& o, float c, float eta, float Fplain)
+{
+  const float nf = (eta < 1.0f) ? o.filmIor * eta : o.filmIor;
+  return v3(Fplain, Fplain, Fplain) * (1.0f - o.filmWeight) + film_fresnel(c, nf, v3(eta, eta, eta), o.filmNm) * o.filmWeight;
+}
+__device__ inline V3 opbr_film_metal(const OpbrParams& o, float c, V3 Fplain)
+{
+  const V3 f0 = v3(fmin2(fmax2(o.albedo.x, 0.0f), 0.98f), fmin2(fmax2(o.albedo.y, 0.0f), 0.98f), fmin2(fmax2(o.albedo.z, 0.0f), 0.98f));
+  const V3 r = v3(sqrtf(f0.x), sqrtf(f0.y), sqrtf(f0.z));
+  const V3 n3 = v3((1.0f + r.x) / (1.0f - r.x), (1.0f + r.y) / (1.0f - r.y), (1.0f + r.z) / (1.0f - r.z));
+  return Fplain * (1.0f - o.filmWeight) + film_fresnel(c, o.filmIor, n3, o.filmNm) * o.filmWeight;
 }
 // ---- fuzz (sheen) lobe, operation for operation the oracle's (oracle/gi_oracle.cpp "fuzz (sheen) lobe": the model, its sources and the layering rule are
 // described there): "Charlie" distribution x Ashikhmin / Neubelt visibility, directional albedo from the table of tools/gen_fuzz_albedo.py + 0.01.
@@ -546,6 +578,8 @@ __device__ inline void opbr_sample_base(const OpbrParams& o, const ShState& st, 
       }
     }
   }
+  // thin film: everything beneath the dielectric interface is weighted by (1 - F_mix) / (1 - F_plain) per channel (lobes 3 and 4 only: eta and Fd are set there)
+  const V3 under = (o.filmWeight > 0.0f && lobe >= 3u) ? (v3(1.0f, 1.0f, 1.0f) - opbr_film_dielectric(o, nk1, eta, Fd)) * (1.0f / (1.0f - Fd)) : v3(1.0f, 1.0f, 1.0f);
   if (lobe == 4u) {
     const float pBase = (1.0f - Fc) * (1.0f - o.metalness) * (1.0f - Fd) * (1.0f - o.tw);
     V3 l = gi_sample_hemisphere(x0, x1); // cosine-weighted, for every lobe of the opaque base
@@ -559,12 +593,14 @@ __device__ inline void opbr_sample_base(const OpbrParams& o, const ShState& st, 
           if (!(dot(k2, st.geomNormal) < 0.0f)) return;
           out.k2 = k2; out.pdf = pBase * o.ssWeight * 0.5f * (l.z / GI_PI);
           out.overPdf = opbr_ss_transmit(o) * o.coatTint; out.event = EV_DIFFUSE | EV_TRANSMISSION;
+          if (o.filmWeight > 0.0f) out.overPdf = out.overPdf * under;
           return;
         }
         V3 k2 = to_world(st, l);
         if (!(dot(k2, st.geomNormal) > 0.0f)) return;
         out.k2 = k2; out.pdf = pBase * o.ssWeight * 0.5f * (l.z / GI_PI);
         out.overPdf = opbr_ss_reflect(o, l1, l) * o.coatTint; out.event = EV_DIFFUSE | EV_REFLECTION;
+        if (o.filmWeight > 0.0f) out.overPdf = out.overPdf * under;
         return;
       }
     }
@@ -573,6 +609,7 @@ __device__ inline void opbr_sample_base(const OpbrParams& o, const ShState& st, 
     out.k2 = k2; out.pdf = pBase * (1.0f - o.ssWeight) * (l.z / GI_PI);
     V3 rho = (o.diffRough > 0.0f) ? eon_pi_f(o.baseColor, o.diffRough, l1, l) * o.baseWeight : o.albedo;
     out.overPdf = rho * o.coatTint; out.event = EV_DIFFUSE | EV_REFLECTION;
+    if (o.filmWeight > 0.0f) out.overPdf = out.overPdf * under;
     return;
   }
   const GgxOut g = ggx_sample2(l1, lobe == 0u ? o.coatAlpha : o.alpha, lobe == 0u ? o.coatAlphaY : o.alphaY, x0, x1);
@@ -595,6 +632,7 @@ __device__ inline void opbr_sample_base(const OpbrParams& o, const ShState& st, 
     float w = ((1.0f - Fh) / (1.0f - Fd)) * (G2 / G1);
     out.k2 = normalize(k2); out.pdf = (1.0f - Fc) * (1.0f - o.metalness) * (1.0f - Fd) * o.tw * g.pdf;
     out.overPdf = (o.transTint * o.coatTint) * w; out.event = EV_GLOSSY | EV_TRANSMISSION;
+    if (o.filmWeight > 0.0f) out.overPdf = (o.transTint * o.coatTint) * ((v3(1.0f, 1.0f, 1.0f) - opbr_film_dielectric(o, kh, eta, Fh)) * ((G2 / G1) / (1.0f - Fd)));
     return;
   }
   V3 k2 = to_world(st, g.l2);
@@ -606,11 +644,13 @@ __device__ inline void opbr_sample_base(const OpbrParams& o, const ShState& st, 
     out.pdf = Fc * g.pdf; out.overPdf = v3(w, w, w);
   } else if (lobe == 1u) {
     V3 F = schlick_f82(o.albedo, o.metalTint, g.kh) * o.specWeight;
+    if (o.filmWeight > 0.0f) F = opbr_film_metal(o, g.kh, schlick_f82(o.albedo, o.metalTint, g.kh)) * o.specWeight;
     out.pdf = (1.0f - Fc) * o.metalness * g.pdf; out.overPdf = (F * o.coatTint) * g.g2OverG1;
   } else {
     float Fh = fresnel_dielectric(g.kh, eta);
     out.pdf = (1.0f - Fc) * (1.0f - o.metalness) * Fd * g.pdf;
     out.overPdf = (o.specColor * o.coatTint) * ((Fh / Fd) * g.g2OverG1);
+    if (o.filmWeight > 0.0f) out.overPdf = (o.specColor * o.coatTint) * (opbr_film_dielectric(o, g.kh, eta, Fh) * (g.g2OverG1 / Fd));
   }
 }
 
@@ -651,16 +691,26 @@ __device__ inline void opbr_evaluate_base(const OpbrParams& o, const ShState& st
   V3 gl = v3(Fch * fc, Fch * fc, Fch * fc);
   gl = gl + ((Fm * o.coatTint) * fs) * (base * o.metalness);
   gl = gl + ((o.specColor * o.coatTint) * (Fdh * fs)) * (base * diel);
+  V3 under = v3(1.0f, 1.0f, 1.0f);
+  if (o.filmWeight > 0.0f) { // thin film: colour Fresnel factors in the two glossy lobes, (1 - F_mix) / (1 - F_plain) on what lies beneath the interface
+    const V3 FmF = opbr_film_metal(o, khs, schlick_f82(o.albedo, o.metalTint, khs)) * o.specWeight;
+    gl = v3(Fch * fc, Fch * fc, Fch * fc);
+    gl = gl + ((FmF * o.coatTint) * fs) * (base * o.metalness);
+    gl = gl + ((o.specColor * o.coatTint) * (opbr_film_dielectric(o, khs, eta, Fdh) * fs)) * (base * diel);
+    under = (v3(1.0f, 1.0f, 1.0f) - opbr_film_dielectric(o, nk1, eta, Fd)) * (1.0f / (1.0f - Fd));
+  }
   out.glossy = gl;
   V3 rho = (o.diffRough > 0.0f && l2.z > 0.0f) ? eon_pi_f(o.baseColor, o.diffRough, l1, l2) * o.baseWeight : o.albedo;
   const float wBase = cd * base * diel * (1.0f - Fd) * (1.0f - o.tw);
   if (o.ssWeight > 0.0f) { // reflection side of the thin-walled subsurface mix (the transmitted half lies below the surface: not reached by NEE)
     const V3 ss = (l2.z > 0.0f) ? opbr_ss_reflect(o, l1, l2) : v3(0.0f, 0.0f, 0.0f);
     out.diffuse = ((rho * (1.0f - o.ssWeight) + ss * (o.ssWeight * 0.5f)) * o.coatTint) * wBase;
+    if (o.filmWeight > 0.0f) out.diffuse = out.diffuse * under;
     out.pdf = Fc * pc + base * (o.metalness * ps + diel * (Fd * ps + (1.0f - Fd) * (1.0f - o.tw) * ((1.0f - o.ssWeight) + o.ssWeight * 0.5f) * cd));
     return;
   }
   out.diffuse = (rho * o.coatTint) * wBase;
+  if (o.filmWeight > 0.0f) out.diffuse = out.diffuse * under;
   out.pdf = Fc * pc + base * (o.metalness * ps + diel * (Fd * ps + (1.0f - Fd) * (1.0f - o.tw) * cd));
 }
 __device__ inline void opbr_evaluate(const MaterialRec* m, const ShState& st, V3 k1, V3 k2, BsdfEval& out)

@@ -229,7 +229,7 @@ namespace gtl
       p[GI_C_P_ROUGHNESS] = 0.3f; p[GI_C_P_IOR] = 1.5f; p[GI_C_P_OPACITY] = 1.0f;
       p[GI_C_P_TRANSMISSION_COLOR] = p[GI_C_P_TRANSMISSION_COLOR + 1] = p[GI_C_P_TRANSMISSION_COLOR + 2] = 1.0f;
       p[GI_C_P_COAT_COLOR] = p[GI_C_P_COAT_COLOR + 1] = p[GI_C_P_COAT_COLOR + 2] = 1.0f; p[GI_C_P_COAT_IOR] = 1.6f; p[GI_C_P_COAT_DARKENING] = 1.0f;
-      p[GI_C_P_FUZZ_COLOR] = p[GI_C_P_FUZZ_COLOR + 1] = p[GI_C_P_FUZZ_COLOR + 2] = 1.0f; p[GI_C_P_FUZZ_ROUGHNESS] = 0.5f;
+      p[GI_C_P_FUZZ_COLOR] = p[GI_C_P_FUZZ_COLOR + 1] = p[GI_C_P_FUZZ_COLOR + 2] = 1.0f; p[GI_C_P_FUZZ_ROUGHNESS] = 0.5f; p[GI_C_P_THIN_FILM_THICKNESS] = 0.5f; p[GI_C_P_THIN_FILM_IOR] = 1.4f;
       p[GI_C_P_SUBSURFACE_COLOR] = p[GI_C_P_SUBSURFACE_COLOR + 1] = p[GI_C_P_SUBSURFACE_COLOR + 2] = 0.8f;
       float lum = 0.0f, ecol[3] = {1.0f, 1.0f, 1.0f};
       setN(n, "base_weight", p + GI_C_P_BASE_WEIGHT, 1); setN(n, "base_color", p + GI_C_P_BASE_COLOR, 3);
@@ -246,6 +246,7 @@ namespace gtl
       setN(n, "subsurface_weight", p + GI_C_P_SUBSURFACE_WEIGHT, 1); setN(n, "subsurface_color", p + GI_C_P_SUBSURFACE_COLOR, 3);
       setN(n, "subsurface_scatter_anisotropy", p + GI_C_P_SUBSURFACE_ANISOTROPY, 1); // (subsurface_radius / _radius_scale only shape the volumetric form, which is not modelled)
       setN(n, "specular_roughness_anisotropy", p + GI_C_P_SPECULAR_ANISOTROPY, 1); setN(n, "coat_roughness_anisotropy", p + GI_C_P_COAT_ANISOTROPY, 1);
+      setN(n, "thin_film_weight", p + GI_C_P_THIN_FILM_WEIGHT, 1); setN(n, "thin_film_thickness", p + GI_C_P_THIN_FILM_THICKNESS, 1); setN(n, "thin_film_ior", p + GI_C_P_THIN_FILM_IOR, 1);
       setN(n, "emission_luminance", &lum, 1); setN(n, "emission_color", ecol, 3); setN(n, "geometry_opacity", p + GI_C_P_OPACITY, 1);
       for (int i = 0; i < 3; i++) p[GI_C_P_EMISSION + i] = lum * ecol[i];
       bind("base_color", GI_C_TEX_BASE_COLOR); bind("specular_roughness", GI_C_TEX_ROUGHNESS); bind("base_metalness", GI_C_TEX_METALLIC);
@@ -363,7 +364,8 @@ namespace gtl
         {"specular_ior", 1}, {"transmission_weight", 1}, {"transmission_color", 3}, {"transmission_depth", 1}, {"transmission_scatter", 3}, {"transmission_scatter_anisotropy", 1},
         {"coat_weight", 1}, {"coat_color", 3}, {"coat_roughness", 1}, {"coat_ior", 1}, {"coat_darkening", 1}, {"emission_luminance", 1}, {"emission_color", 3},
         {"geometry_opacity", 1}, {"fuzz_weight", 1}, {"fuzz_color", 3}, {"fuzz_roughness", 1}, {"geometry_thin_walled", 1},
-        {"subsurface_weight", 1}, {"subsurface_color", 3}, {"subsurface_scatter_anisotropy", 1}, {"specular_roughness_anisotropy", 1}, {"coat_roughness_anisotropy", 1}};
+        {"subsurface_weight", 1}, {"subsurface_color", 3}, {"subsurface_scatter_anisotropy", 1}, {"specular_roughness_anisotropy", 1}, {"coat_roughness_anisotropy", 1},
+        {"thin_film_weight", 1}, {"thin_film_thickness", 1}, {"thin_film_ior", 1}};
       for (const auto& k : kOpbr) {
         float v[3];
         if (!num(k.name, v, k.n)) continue;

@@ -54,6 +54,7 @@ def _inputs(m: S.MaterialDesc):
         ("subsurface_weight", "float", _f(p[S.P_SUBSURFACE_WEIGHT])), ("subsurface_color", "color3", _vals(p, S.P_SUBSURFACE_COLOR, 3)),
         ("subsurface_scatter_anisotropy", "float", _f(p[S.P_SUBSURFACE_ANISOTROPY])),
         ("specular_roughness_anisotropy", "float", _f(p[S.P_SPECULAR_ANISOTROPY])), ("coat_roughness_anisotropy", "float", _f(p[S.P_COAT_ANISOTROPY])),
+        ("thin_film_weight", "float", _f(p[S.P_THIN_FILM_WEIGHT])), ("thin_film_thickness", "float", _f(p[S.P_THIN_FILM_THICKNESS])), ("thin_film_ior", "float", _f(p[S.P_THIN_FILM_IOR])),
         # the parameter block keeps luminance x colour: luminance 1 and the product as the colour reproduce it exactly
         ("emission_luminance", "float", "1" if em.any() else "0"), ("emission_color", "color3", _vals(p, S.P_EMISSION, 3) if em.any() else "1, 1, 1"),
         ("geometry_opacity", "float", _f(p[S.P_OPACITY]))]

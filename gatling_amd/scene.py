@@ -57,6 +57,9 @@ P_SUBSURFACE_COLOR = 56              # 3
 P_SUBSURFACE_ANISOTROPY = 59
 P_SPECULAR_ANISOTROPY = 60
 P_COAT_ANISOTROPY = 61
+P_THIN_FILM_WEIGHT = 62
+P_THIN_FILM_THICKNESS = 63           # micrometres
+P_THIN_FILM_IOR = 6                  # OpenPBR class only (the slot is useSpecularWorkflow for UsdPreviewSurface)
 P_COUNT = 64
 
 
@@ -110,7 +113,8 @@ def _open_pbr(name="mat", base_weight=1.0, base_color=(0.8, 0.8, 0.8), base_meta
               coat_ior=1.6, emission_luminance=0.0, emission_color=(1, 1, 1), base_diffuse_roughness=0.0,
               transmission_scatter=(0, 0, 0), transmission_scatter_anisotropy=0.0, coat_darkening=1.0, fuzz_weight=0.0,
               fuzz_color=(1, 1, 1), fuzz_roughness=0.5, geometry_thin_walled=False, subsurface_weight=0.0, subsurface_color=(0.8, 0.8, 0.8),
-              subsurface_scatter_anisotropy=0.0, specular_roughness_anisotropy=0.0, coat_roughness_anisotropy=0.0) -> MaterialDesc:
+              subsurface_scatter_anisotropy=0.0, specular_roughness_anisotropy=0.0, coat_roughness_anisotropy=0.0,
+              thin_film_weight=0.0, thin_film_thickness=0.5, thin_film_ior=1.4) -> MaterialDesc:
     """open_pbr_surface inputs with the defaults of src/gi/mtlx/open_pbr_surface.mtlx:11-92 (the lobes this core implements)."""
     p = np.zeros(P_COUNT, np.float32)
     p[P_BASE_COLOR:P_BASE_COLOR + 3] = base_color
@@ -142,6 +146,9 @@ def _open_pbr(name="mat", base_weight=1.0, base_color=(0.8, 0.8, 0.8), base_meta
     p[P_SUBSURFACE_ANISOTROPY] = subsurface_scatter_anisotropy
     p[P_SPECULAR_ANISOTROPY] = specular_roughness_anisotropy   # open_pbr_anisotropy (open_pbr_surface.mtlx:133-136, 552-555): highlights stretched along the tangent
     p[P_COAT_ANISOTROPY] = coat_roughness_anisotropy
+    p[P_THIN_FILM_WEIGHT] = thin_film_weight           # thin film on the dielectric and metal lobes (open_pbr_surface.mtlx:300-304, 404-431, 450-464)
+    p[P_THIN_FILM_THICKNESS] = thin_film_thickness
+    p[P_THIN_FILM_IOR] = thin_film_ior
     return MaterialDesc(name=name, klass=MAT_OPEN_PBR, params=p)
 
 

@@ -185,6 +185,9 @@ typedef struct GiCRenderParams {
 #define GI_C_P_SUBSURFACE_WEIGHT 55  /* OpenPBR subsurface_weight (open_pbr_surface.mtlx:43, 213-218); modelled for thin-walled materials (:140-196), else treated as 0 */
 #define GI_C_P_SUBSURFACE_COLOR 56   /* 3: subsurface_color (:45), default 0.8 */
 #define GI_C_P_SUBSURFACE_ANISOTROPY 59 /* subsurface_scatter_anisotropy (:51) */
+#define GI_C_P_THIN_FILM_WEIGHT 62    /* OpenPBR thin_film_weight (open_pbr_surface.mtlx:71, 426-431, 461-464): mixes a thin film's interference into the Fresnel factor of the dielectric and metal lobes */
+#define GI_C_P_THIN_FILM_THICKNESS 63 /* thin_film_thickness in micrometres (:73, 300-304), default 0.5 */
+#define GI_C_P_THIN_FILM_IOR 6        /* thin_film_ior (:75), default 1.4 -- OpenPBR class only: the slot is useSpecularWorkflow for UsdPreviewSurface */
 #define GI_C_P_SPECULAR_ANISOTROPY 60 /* OpenPBR specular_roughness_anisotropy (open_pbr_surface.mtlx:27, 133-136): GGX stretched along the tangent, alpha_t = r^2 sqrt(2 / (1 + (1 - a)^2)), alpha_b = (1 - a) alpha_t */
 #define GI_C_P_COAT_ANISOTROPY 61     /* coat_roughness_anisotropy (:65, 552-555); the coat uses the geometry tangent (geometry_coat_tangent is not a separate input here) */
 #define GI_C_P_THIN_WALLED 54      /* OpenPBR geometry_thin_walled (:88) != 0: MDL thin_walled semantics (rp_main.chit:153-157, 188-189, 447) */

@@ -1047,7 +1047,7 @@ inline V3 eon_pi_f(V3 rho, float r, V3 l1, V3 l2)
   const V3 rhoMs = v3((rr.x * avgEF) / (1.0f - rho.x * (1.0f - avgEF)), (rr.y * avgEF) / (1.0f - rho.y * (1.0f - avgEF)), (rr.z * avgEF) / (1.0f - rho.z * (1.0f - avgEF)));
   return rho * ss + rhoMs * ms;
 }
-struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, sigmaA, sigmaS, baseColor, coatColor, ssColor, fuzzColor; float metalness, alpha, alphaY, coat, coatAlpha, coatAlphaY, coatF0, eta, tw, specWeight, anisotropy, baseWeight, diffRough, ssWeight, ssAniso, fuzzWeight, fuzzAlpha; bool thinWalled; };
+struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, sigmaA, sigmaS, baseColor, coatColor, ssColor, fuzzColor; float metalness, alpha, alphaY, coat, coatAlpha, coatAlphaY, coatF0, eta, tw, specWeight, anisotropy, baseWeight, diffRough, ssWeight, ssAniso, fuzzWeight, fuzzAlpha, filmWeight, filmNm, filmIor; bool thinWalled; };
 inline OpbrParams opbr_params(const OrcMaterial& m)
 {
   OpbrParams o; const float* p = m.p;
@@ -1096,7 +1096,48 @@ inline OpbrParams opbr_params(const OrcMaterial& m)
   o.ssColor = v3(p + ORC_P_SUBSURFACE_COLOR); o.ssAniso = p[ORC_P_SUBSURFACE_ANISOTROPY];
   // fuzz layer (open_pbr_surface.mtlx:569-581): sheen_bsdf(fuzz_weight, fuzz_color, fuzz_roughness) on top of the coat
   o.fuzzWeight = fmin2(fmax2(p[ORC_P_FUZZ_WEIGHT], 0.0f), 1.0f); o.fuzzColor = v3(p + ORC_P_FUZZ_COLOR); o.fuzzAlpha = fmin2(fmax2(p[ORC_P_FUZZ_ROUGHNESS], 0.07f), 1.0f);
+  // thin film (open_pbr_surface.mtlx:300-304, 404-431, 450-464): thin_film_thickness is in micrometres (:301-304 converts to nanometres)
+  o.filmWeight = fmin2(fmax2(p[ORC_P_THIN_FILM_WEIGHT], 0.0f), 1.0f); o.filmNm = fmax2(p[ORC_P_THIN_FILM_THICKNESS], 0.0f) * 1000.0f; o.filmIor = fmax2(p[ORC_P_THIN_FILM_IOR], 1.0f);
   return o;
+}
+
+// ---- thin film: our closed form for dielectric_bsdf / generalized_schlick_bsdf(thinfilm_thickness, thinfilm_ior), which MaterialX maps onto MDL's df::thin_film
+// (a spectral evaluation inside the MDL SDK, not in the reference tree).  Airy summation of the film's two interfaces for unpolarised light (Born & Wolf 7.6),
+//   R = (r12^2 + r23^2 + 2 r12 r23 cos phi) / (1 + r12^2 r23^2 + 2 r12 r23 cos phi),   phi = 4 pi n_f d cos(theta_f) / lambda,   averaged over s and p,
+// at three wavelengths standing for R, G, B (611.4, 548.4, 464.3 nm: the dominant wavelengths of the sRGB primaries) -- no spectral integration, so the fringes
+// are more saturated than a spectral renderer's.  Indices are relative to the medium the ray comes from; a film of thickness 0 reproduces fresnel_dielectric.
+// Metals: the substrate index per channel is the real index with the lobe's F0, n = (1 + sqrt F0) / (1 - sqrt F0).
+// Where it enters: thin_film_weight mixes the film's reflectance into the Fresnel factor of the dielectric and metal lobes (mtlx :426-431, :461-464); the lobe
+// selection probabilities keep the plain Fresnel term, the weights carry the colour ratio, and everything beneath the dielectric interface is weighted by
+// (1 - F_mix) / (1 - F_plain) per channel, so a lobe and what lies under it still share the light.
+inline float film_reflectance(float c, float nf, float n3, float d, float lam)
+{
+  const float s2 = 1.0f - c * c;
+  const float s2f = s2 / (nf * nf), s23 = s2 / (n3 * n3);
+  if (!(s2f < 1.0f) || !(s23 < 1.0f)) return 1.0f; // total internal reflection
+  const float cf = sqrtf(1.0f - s2f), c3 = sqrtf(1.0f - s23);
+  const float rs12 = (c - nf * cf) / (c + nf * cf), rp12 = (nf * c - cf) / (nf * c + cf);
+  const float rs23 = (nf * cf - n3 * c3) / (nf * cf + n3 * c3), rp23 = (n3 * cf - nf * c3) / (n3 * cf + nf * c3);
+  const float ph = ((2.0f * nf) * d * cf) / lam; // phase difference / (2 pi)
+  float sn, cs; sincos2pi(ph - floorf(ph), &sn, &cs); (void)sn;
+  const float ps = rs12 * rs23, pp = rp12 * rp23;
+  const float Rs = ((rs12 * rs12 + rs23 * rs23) + (2.0f * ps) * cs) / ((1.0f + ps * ps) + (2.0f * ps) * cs);
+  const float Rp = ((rp12 * rp12 + rp23 * rp23) + (2.0f * pp) * cs) / ((1.0f + pp * pp) + (2.0f * pp) * cs);
+  return fmin2(fmax2(0.5f * (Rs + Rp), 0.0f), 1.0f);
+}
+inline V3 film_fresnel(float c, float nf, V3 n3, float d) { return v3(film_reflectance(c, nf, n3.x, d, 611.4f), film_reflectance(c, nf, n3.y, d, 548.4f), film_reflectance(c, nf, n3.z, d, 464.3f)); }
+// Fresnel factor of the dielectric lobe with the film mixed in: eta = relative index of the interface (entering: the material's, leaving: its reciprocal)
+inline V3 opbr_film_dielectric(const OpbrParams& o, float c, float eta, float Fplain)
+{
+  const float nf = (eta < 1.0f) ? o.filmIor * eta : o.filmIor;
+  return v3(Fplain, Fplain, Fplain) * (1.0f - o.filmWeight) + film_fresnel(c, nf, v3(eta, eta, eta), o.filmNm) * o.filmWeight;
+}
+inline V3 opbr_film_metal(const OpbrParams& o, float c, V3 Fplain)
+{
+  const V3 f0 = v3(fmin2(fmax2(o.albedo.x, 0.0f), 0.98f), fmin2(fmax2(o.albedo.y, 0.0f), 0.98f), fmin2(fmax2(o.albedo.z, 0.0f), 0.98f));
+  const V3 r = v3(sqrtf(f0.x), sqrtf(f0.y), sqrtf(f0.z));
+  const V3 n3 = v3((1.0f + r.x) / (1.0f - r.x), (1.0f + r.y) / (1.0f - r.y), (1.0f + r.z) / (1.0f - r.z));
+  return Fplain * (1.0f - o.filmWeight) + film_fresnel(c, o.filmIor, n3, o.filmNm) * o.filmWeight;
 }
 
 // ---- fuzz (sheen) lobe: our closed form for MaterialX sheen_bsdf / MDL df::sheen_bsdf, whose arithmetic is not in the reference tree.
@@ -1180,6 +1221,7 @@ static void opbr_sample_base(const OpbrParams& o, const State& st, V3 k1, const 
     V3 k2 = to_world(st, g.l2);
     if (!g.valid || !(dot(k2, st.geomNormal) > 0.0f)) return;
     V3 F = schlick_f82(o.albedo, o.metalTint, g.kh) * o.specWeight;
+    if (o.filmWeight > 0.0f) F = opbr_film_metal(o, g.kh, schlick_f82(o.albedo, o.metalTint, g.kh)) * o.specWeight;
     out.k2 = k2; out.pdf = (1.0f - Fc) * o.metalness * g.pdf; out.overPdf = (F * o.coatTint) * g.g2OverG1; out.event = EV_GLOSSY | EV_REFLECTION;
     return;
   }
@@ -1194,8 +1236,11 @@ static void opbr_sample_base(const OpbrParams& o, const State& st, V3 k1, const 
     float Fh = fresnel_dielectric(g.kh, eta);
     out.k2 = k2; out.pdf = (1.0f - Fc) * (1.0f - o.metalness) * Fd * g.pdf;
     out.overPdf = (o.specColor * o.coatTint) * ((Fh / Fd) * g.g2OverG1); out.event = EV_GLOSSY | EV_REFLECTION;
+    if (o.filmWeight > 0.0f) out.overPdf = (o.specColor * o.coatTint) * (opbr_film_dielectric(o, g.kh, eta, Fh) * (g.g2OverG1 / Fd));
     return;
   }
+  // under the film everything beneath the interface is weighted by (1 - F_mix) / (1 - F_plain) per channel
+  const V3 under = (o.filmWeight > 0.0f) ? (v3(1, 1, 1) - opbr_film_dielectric(o, nk1, eta, Fd)) * (1.0f / (1.0f - Fd)) : v3(1, 1, 1);
   z = (z - Fd) / (1.0f - Fd);
   if (z < o.tw) { // rough refraction through a VNDF-sampled micro-normal
     GgxOut g = ggx_sample2(l1, o.alpha, o.alphaY, xi[0], xi[1]); // provides the half vector via l2 = reflect(l1, h)
@@ -1218,6 +1263,7 @@ static void opbr_sample_base(const OpbrParams& o, const State& st, V3 k1, const 
     float w = ((1.0f - Fh) / (1.0f - Fd)) * (G2 / G1);
     out.k2 = normalize(k2); out.pdf = (1.0f - Fc) * (1.0f - o.metalness) * (1.0f - Fd) * o.tw * g.pdf;
     out.overPdf = (o.transTint * o.coatTint) * w; out.event = EV_GLOSSY | EV_TRANSMISSION;
+    if (o.filmWeight > 0.0f) out.overPdf = (o.transTint * o.coatTint) * ((v3(1, 1, 1) - opbr_film_dielectric(o, kh, eta, Fh)) * ((G2 / G1) / (1.0f - Fd)));
     return;
   }
   const float pBase = (1.0f - Fc) * (1.0f - o.metalness) * (1.0f - Fd) * (1.0f - o.tw);
@@ -1232,12 +1278,14 @@ static void opbr_sample_base(const OpbrParams& o, const State& st, V3 k1, const 
         if (!(dot(k2, st.geomNormal) < 0.0f)) return;
         out.k2 = k2; out.pdf = pBase * o.ssWeight * 0.5f * (l.z / ORC_PI);
         out.overPdf = opbr_ss_transmit(o) * o.coatTint; out.event = EV_DIFFUSE | EV_TRANSMISSION;
+        if (o.filmWeight > 0.0f) out.overPdf = out.overPdf * under;
         return;
       }
       V3 k2 = to_world(st, l);
       if (!(dot(k2, st.geomNormal) > 0.0f)) return;
       out.k2 = k2; out.pdf = pBase * o.ssWeight * 0.5f * (l.z / ORC_PI);
       out.overPdf = opbr_ss_reflect(o, l1, l) * o.coatTint; out.event = EV_DIFFUSE | EV_REFLECTION;
+      if (o.filmWeight > 0.0f) out.overPdf = out.overPdf * under;
       return;
     }
   }
@@ -1246,6 +1294,7 @@ static void opbr_sample_base(const OpbrParams& o, const State& st, V3 k1, const 
   out.k2 = k2; out.pdf = pBase * (1.0f - o.ssWeight) * (l.z / ORC_PI);
   V3 rho = (o.diffRough > 0.0f) ? eon_pi_f(o.baseColor, o.diffRough, l1, l) * o.baseWeight : o.albedo;
   out.overPdf = rho * o.coatTint; out.event = EV_DIFFUSE | EV_REFLECTION;
+  if (o.filmWeight > 0.0f) out.overPdf = out.overPdf * under;
 }
 
 void opbr_sample(const OrcMaterial& m, const State& st, V3 k1, const float xi[4], bool frontFace, BsdfSample& out)
@@ -1286,16 +1335,26 @@ static void opbr_evaluate_base(const OpbrParams& o, const State& st, V3 k1, V3 k
   V3 gl = v3(Fch * fc, Fch * fc, Fch * fc);
   gl = gl + ((Fm * o.coatTint) * fs) * (base * o.metalness);
   gl = gl + ((o.specColor * o.coatTint) * (Fdh * fs)) * (base * diel);
+  V3 under = v3(1, 1, 1);
+  if (o.filmWeight > 0.0f) { // thin film: colour Fresnel factors in the two glossy lobes, (1 - F_mix) / (1 - F_plain) on what lies beneath the interface
+    const V3 FmF = opbr_film_metal(o, khs, schlick_f82(o.albedo, o.metalTint, khs)) * o.specWeight;
+    gl = v3(Fch * fc, Fch * fc, Fch * fc);
+    gl = gl + ((FmF * o.coatTint) * fs) * (base * o.metalness);
+    gl = gl + ((o.specColor * o.coatTint) * (opbr_film_dielectric(o, khs, eta, Fdh) * fs)) * (base * diel);
+    under = (v3(1, 1, 1) - opbr_film_dielectric(o, nk1, eta, Fd)) * (1.0f / (1.0f - Fd));
+  }
   out.glossy = gl;
   V3 rho = (o.diffRough > 0.0f && l2.z > 0.0f) ? eon_pi_f(o.baseColor, o.diffRough, l1, l2) * o.baseWeight : o.albedo;
   const float wBase = cd * base * diel * (1.0f - Fd) * (1.0f - o.tw);
   if (o.ssWeight > 0.0f) { // reflection side of the thin-walled subsurface mix (the transmitted half lies below the surface: not reached by NEE)
     const V3 ss = (l2.z > 0.0f) ? opbr_ss_reflect(o, l1, l2) : v3(0, 0, 0);
     out.diffuse = ((rho * (1.0f - o.ssWeight) + ss * (o.ssWeight * 0.5f)) * o.coatTint) * wBase;
+    if (o.filmWeight > 0.0f) out.diffuse = out.diffuse * under;
     out.pdf = Fc * pc + base * (o.metalness * ps + diel * (Fd * ps + (1.0f - Fd) * (1.0f - o.tw) * ((1.0f - o.ssWeight) + o.ssWeight * 0.5f) * cd));
     return;
   }
   out.diffuse = (rho * o.coatTint) * wBase;
+  if (o.filmWeight > 0.0f) out.diffuse = out.diffuse * under;
   out.pdf = Fc * pc + base * (o.metalness * ps + diel * (Fd * ps + (1.0f - Fd) * (1.0f - o.tw) * cd));
 }
 
@@ -1412,6 +1471,12 @@ V3 bsdf_albedo(const OrcMaterial& m, const State& st, V3 k1)
   V3 diffuse = (o.albedo * o.coatTint) * (base * diel * (1.0f - Fd) * (1.0f - o.tw));
   V3 glossy = v3(Fc, Fc, Fc) + ((schlick_f82(o.albedo, o.metalTint, nk1) * o.specWeight) * o.coatTint) * (base * o.metalness)
               + (o.specColor * o.coatTint) * (base * diel * Fd);
+  if (o.filmWeight > 0.0f) { // thin film: the two Fresnel factors carry the film's reflectance, what lies beneath the interface its complement
+    const V3 Fdf = opbr_film_dielectric(o, nk1, eta, Fd);
+    diffuse = ((o.albedo * o.coatTint) * (v3(1, 1, 1) - Fdf)) * (base * diel * (1.0f - o.tw));
+    glossy = v3(Fc, Fc, Fc) + ((opbr_film_metal(o, nk1, schlick_f82(o.albedo, o.metalTint, nk1)) * o.specWeight) * o.coatTint) * (base * o.metalness)
+             + ((o.specColor * o.coatTint) * Fdf) * (base * diel);
+  }
   if (o.fuzzWeight > 0.0f) { // the fuzz layer keeps P = fuzz_weight * min(E, 1) of the light (tinted), what is beneath gets 1 - P
     const float Pf = o.fuzzWeight * fmin2(fuzz_albedo(nk1, o.fuzzAlpha), 1.0f);
     return (diffuse + glossy) * (1.0f - Pf) + o.fuzzColor * Pf;
@@ -2072,6 +2137,8 @@ void orc_fis_gauss(float xi0, float xi1, float out[2]) { fis_gauss(xi0, xi1, out
 void orc_sincos2pi(float x, float* s, float* c) { sincos2pi(x, s, c); }
 float orc_logf(float x) { return logf_poly(x); }
 float orc_expf(float x) { return expf_poly(x); }
+float orc_film_reflectance(float c, float nf, float n3, float d, float lam) { return film_reflectance(c, nf, n3, d, lam); }
+float orc_fresnel_dielectric(float c, float eta) { return fresnel_dielectric(c, eta); }
 uint32_t orc_pack_half2x16(float a, float b) { return pack_half2x16(a, b); }
 void orc_unpack_half2x16(uint32_t v, float out[2]) { out[0] = f16_to_f32((uint16_t)(v & 0xffffu)); out[1] = f16_to_f32((uint16_t)(v >> 16)); }
 void orc_orthonormal_basis(const float n[3], float b1[3], float b2[3]) { V3 a, b; orthonormal_basis(v3(n), a, b); b1[0] = a.x; b1[1] = a.y; b1[2] = a.z; b2[0] = b.x; b2[1] = b.y; b2[2] = b.z; }

@@ -81,6 +81,7 @@ enum {
   ORC_P_FUZZ_WEIGHT = 49, ORC_P_FUZZ_COLOR = 50, ORC_P_FUZZ_ROUGHNESS = 53, /* :57-59: the fuzz (sheen) layer (:569-581) */
   ORC_P_SUBSURFACE_WEIGHT = 55, ORC_P_SUBSURFACE_COLOR = 56, ORC_P_SUBSURFACE_ANISOTROPY = 59, /* :43-52; thin-walled subsurface (:140-196) */
   ORC_P_THIN_WALLED = 54,      /* geometry_thin_walled (:88) */
+  ORC_P_THIN_FILM_IOR = 6, ORC_P_THIN_FILM_WEIGHT = 62, ORC_P_THIN_FILM_THICKNESS = 63, /* OpenPBR thin_film_* (:71-76); slot 6 is useSpecularWorkflow for UsdPreviewSurface */
   ORC_P_SPECULAR_ANISOTROPY = 60, ORC_P_COAT_ANISOTROPY = 61, /* specular_roughness_anisotropy (:27), coat_roughness_anisotropy (:65) */
   ORC_P_COUNT = 64
 };
@@ -241,6 +242,8 @@ void     orc_fis_gauss(float xi0, float xi1, float out[2]);          /* rp_main.
 void     orc_sincos2pi(float x, float* s, float* c);
 float    orc_expf(float x); /* x <= 0 */
 float    orc_logf(float x);
+float    orc_film_reflectance(float cosTheta, float filmIor, float substrateIor, float thicknessNm, float wavelengthNm); /* thin film: Airy reflectance, unpolarised */
+float    orc_fresnel_dielectric(float cosTheta, float eta);
 uint32_t orc_pack_half2x16(float a, float b);
 void     orc_unpack_half2x16(uint32_t v, float out[2]);
 void     orc_orthonormal_basis(const float n[3], float b1[3], float b2[3]); /* common.glsl:128-137 */

@@ -170,6 +170,10 @@ def lib():
         L.orc_tex_lookup.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_float)]
         L.orc_expf.restype = C.c_float
         L.orc_expf.argtypes = [C.c_float]
+        L.orc_film_reflectance.restype = C.c_float
+        L.orc_film_reflectance.argtypes = [C.c_float] * 5
+        L.orc_fresnel_dielectric.restype = C.c_float
+        L.orc_fresnel_dielectric.argtypes = [C.c_float, C.c_float]
         L.orc_pack_half2x16.restype = C.c_uint32
         L.orc_pack_half2x16.argtypes = [C.c_float, C.c_float]
         L.orc_unpack_half2x16.argtypes = [C.c_uint32, C.POINTER(C.c_float)]

@@ -430,7 +430,12 @@ def test_bsdf_known_answers_on_device(gi, orc):
             MaterialDesc.open_pbr(base_color=(0.9, 0.8, 0.6), base_metalness=1.0, specular_roughness=0.45, specular_roughness_anisotropy=0.8),
             MaterialDesc.open_pbr(base_color=(0.4, 0.6, 0.8), transmission_weight=0.7, specular_roughness=0.3, specular_roughness_anisotropy=0.5, specular_ior=1.4),
             MaterialDesc.open_pbr(base_color=(0.6, 0.3, 0.3), specular_roughness=0.4, coat_weight=0.9, coat_roughness=0.35, coat_roughness_anisotropy=0.95, fuzz_weight=0.2),
-            MaterialDesc.open_pbr(base_color=(0.5, 0.5, 0.5), specular_roughness=0.2, specular_roughness_anisotropy=1.0, coat_weight=0.3, coat_roughness=0.1, coat_roughness_anisotropy=0.3)]
+            MaterialDesc.open_pbr(base_color=(0.5, 0.5, 0.5), specular_roughness=0.2, specular_roughness_anisotropy=1.0, coat_weight=0.3, coat_roughness=0.1, coat_roughness_anisotropy=0.3),
+            # thin film (open_pbr_surface.mtlx:300-304, 404-431, 450-464): on a dielectric with transmission (front and back faces: relative indices), on a metal, with everything else on
+            MaterialDesc.open_pbr(base_color=(0.7, 0.7, 0.7), transmission_weight=0.6, specular_roughness=0.2, thin_film_weight=1.0, thin_film_thickness=0.35, thin_film_ior=1.8),
+            MaterialDesc.open_pbr(base_color=(0.9, 0.6, 0.4), base_metalness=1.0, specular_roughness=0.3, thin_film_weight=0.8, thin_film_thickness=0.6, thin_film_ior=1.33),
+            MaterialDesc.open_pbr(base_color=(0.4, 0.5, 0.6), base_metalness=0.4, coat_weight=0.5, coat_roughness=0.1, fuzz_weight=0.3, specular_roughness_anisotropy=0.4,
+                                  geometry_thin_walled=True, subsurface_weight=0.5, thin_film_weight=0.5, thin_film_thickness=0.2, thin_film_ior=2.1)]
     items[: n // 2, 21] = 0.75  # xi.w >= 0.5: the debug hook shades these as back faces (eta inverted)
     for m in mats:
         got, ref = gi.bsdf_debug(m, items), orc.bsdf_debug(m, items)

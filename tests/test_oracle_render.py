@@ -141,7 +141,9 @@ def _closed_form_materials():
             M.open_pbr(base_color=(1, 1, 1), coat_weight=1.0, coat_roughness=0.1, fuzz_weight=1.0, fuzz_color=(1, 1, 1), fuzz_roughness=0.07),     # smooth fuzz (E > 1 at grazing views) over a coat
             M.open_pbr(base_color=(1, 1, 1), base_metalness=1.0, specular_roughness=0.4, fuzz_weight=0.6, fuzz_color=(1, 1, 1), fuzz_roughness=1.0),
             M.open_pbr(base_color=(1, 1, 1), base_metalness=1.0, specular_roughness=0.5, specular_roughness_anisotropy=0.8),                         # anisotropic metal
-            M.open_pbr(base_color=(1, 1, 1), specular_roughness=0.4, specular_roughness_anisotropy=0.5, coat_weight=1.0, coat_roughness=0.3, coat_roughness_anisotropy=0.9)]
+            M.open_pbr(base_color=(1, 1, 1), specular_roughness=0.4, specular_roughness_anisotropy=0.5, coat_weight=1.0, coat_roughness=0.3, coat_roughness_anisotropy=0.9),
+            M.open_pbr(base_color=(1, 1, 1), specular_roughness=0.3, thin_film_weight=1.0, thin_film_thickness=0.3, thin_film_ior=1.9),           # film on a dielectric: reflection up, base down
+            M.open_pbr(base_color=(1, 1, 1), base_metalness=1.0, specular_roughness=0.4, thin_film_weight=0.7, thin_film_thickness=0.55, thin_film_ior=1.33)]
 
 
 def test_closed_form_bsdfs_conserve_energy(orc):
@@ -251,6 +253,40 @@ def test_specular_anisotropy(orc):
     a0 = orc.bsdf_debug(MaterialDesc.open_pbr(base_color=(0.7, 0.6, 0.5), coat_weight=0.5, coat_roughness=0.2), items)
     a1 = orc.bsdf_debug(MaterialDesc.open_pbr(base_color=(0.7, 0.6, 0.5), coat_weight=0.5, coat_roughness=0.2, specular_roughness_anisotropy=0.0, coat_roughness_anisotropy=0.0), items)
     assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32))
+
+
+def test_thin_film(orc):
+    """open_pbr_surface.mtlx:300-304, 404-431, 450-464: thin_film_weight mixes a film's interference into the Fresnel factor of the dielectric and metal lobes.
+    Our closed form is the Airy summation at three wavelengths (oracle/gi_oracle.cpp "thin film").  Known answers of the reflectance: a film of zero or
+    half-wave thickness is invisible, a quarter-wave film of index sqrt(n) is the textbook anti-reflection coating; then the lobes: weight 0 changes nothing
+    bit for bit, a film raises the reflected share and lowers what passes by the same amount, colours appear."""
+    L = orc.lib()
+    n3, lam = 1.5, 550.0
+    nf = float(np.sqrt(n3))
+    for c in (1.0, 0.8, 0.45, 0.1):
+        assert abs(L.orc_film_reflectance(c, 1.7, n3, 0.0, lam) - L.orc_fresnel_dielectric(c, n3)) < 2e-6
+    assert abs(L.orc_film_reflectance(1.0, nf, n3, float(lam / (2 * nf)), lam) - L.orc_fresnel_dielectric(1.0, n3)) < 1e-5   # half-wave: absent
+    assert L.orc_film_reflectance(1.0, nf, n3, float(lam / (4 * nf)), lam) < 1e-6                                             # quarter-wave at sqrt(n): no reflection
+    assert L.orc_film_reflectance(1.0, 2.2, n3, float(lam / (4 * 2.2)), lam) > 4 * L.orc_fresnel_dielectric(1.0, n3)           # a dense quarter-wave film: a mirror coating
+    assert L.orc_film_reflectance(0.2, 1.4, 1.0 / 1.5, 300.0, lam) == 1.0                                                     # from inside, beyond the critical angle
+    rng = np.random.default_rng(33)
+    items = _frames(200000, rng, 0.8)
+    plain = MaterialDesc.open_pbr(base_color=(1, 1, 1), specular_roughness=0.25)
+    zero = MaterialDesc.open_pbr(base_color=(1, 1, 1), specular_roughness=0.25, thin_film_weight=0.0, thin_film_thickness=0.9, thin_film_ior=2.0)
+    film = MaterialDesc.open_pbr(base_color=(1, 1, 1), specular_roughness=0.25, thin_film_weight=1.0, thin_film_thickness=0.12, thin_film_ior=2.2)
+    a, z, f = orc.bsdf_debug(plain, items), orc.bsdf_debug(zero, items), orc.bsdf_debug(film, items)
+    assert np.array_equal(a.view(np.uint32), z.view(np.uint32))
+    glossy = (a[:, 7].astype(int) & 2) != 0                   # the same lobes are chosen (selection keeps the plain Fresnel term) ...
+    assert np.array_equal(a[:, 7], f[:, 7]) and np.array_equal(a[:, 0:3], f[:, 0:3])
+    ra, rf = (a[:, 3:6] * glossy[:, None]).mean(axis=0), (f[:, 3:6] * glossy[:, None]).mean(axis=0)
+    da, df = (a[:, 3:6] * ~glossy[:, None]).mean(axis=0), (f[:, 3:6] * ~glossy[:, None]).mean(axis=0)
+    assert np.all(rf > 1.2 * ra) and rf.max() > 2.0 * ra.max() and np.all(df < da)   # ... the film reflects more and lets less through,
+    np.testing.assert_allclose(rf + df, ra + da, rtol=0.03)   # what one side gains the other loses (white base: nothing is absorbed)
+    assert rf.max() / rf.min() > 1.05                         # and it is coloured
+    # metal: the film tints the reflection, energy stays below 1
+    m = MaterialDesc.open_pbr(base_color=(0.9, 0.9, 0.9), base_metalness=1.0, specular_roughness=0.3, thin_film_weight=1.0, thin_film_thickness=0.4, thin_film_ior=1.5)
+    o = orc.bsdf_debug(m, items)[:, 3:6].mean(axis=0)
+    assert np.all(o <= 1.0) and o.max() / o.min() > 1.03
 
 
 def test_thin_walled_subsurface_lobes(orc):
