@@ -1092,15 +1092,20 @@ def test_thin_walled_subsurface_scene_parity(gi, orc):
 
 
 def test_fuzz_layer_scene_parity(gi, orc):
-    """Velvet-like spheres (fuzz layer over dark and over coated bases, OpenPBR next to UsdPreviewSurface ones) lit by a rect light and the uniform dome, NEE on
-    and off: the wavefront pipeline's image == the oracle's, bit for bit, and the fuzz visibly brightens the silhouettes."""
+    """Spheres with OpenPBR's optional lobes -- fuzz over dark and over coated bases, brushed (anisotropic) highlights, a thin film -- next to UsdPreviewSurface
+    ones, lit by a rect light and the uniform dome, NEE on and off: the wavefront pipeline's image == the oracle's, bit for bit (the per-material feature word
+    the host derives decides which inputs k_shade loads), and the lobes visibly change the image."""
     desc = sphere_grid(grid=3, subdivisions=2, material_count=6)
     fz = [(1.0, (0.9, 0.4, 0.3), 0.5), (0.8, (0.7, 0.8, 1.0), 0.1), (0.5, (1.0, 1.0, 1.0), 1.0)]
     k = 0
     for m in desc.materials:
         if m.klass == MAT_OPEN_PBR and k < len(fz):
-            w, c, r = fz[k]; k += 1
+            w, c, r = fz[k]
             m.params[49] = w; m.params[50:53] = c; m.params[53] = r
+            if k == 0: m.params[60] = 0.8; m.params[61] = 0.5                              # specular / coat roughness anisotropy
+            if k == 1: m.params[62] = 1.0; m.params[63] = 0.35; m.params[6] = 1.7         # thin film: weight, thickness (um), ior
+            if k == 2: m.params[62] = 0.6; m.params[63] = 0.5; m.params[6] = 1.33; m.params[60] = 0.4
+            k += 1
     assert k >= 2
     desc.rect_lights.append(RectLight(origin=(0.0, -3.0, 4.0), t0=(1, 0, 0), t1=(0, 0.8, 0.6), base_emission=(14, 13, 12), width=2.0, height=2.0))
     for nee in (False, True):
