@@ -370,6 +370,7 @@ struct GiCScene : SceneDevice {
   int32_t optFusedPath = -1; // -1 = default: LDS-resident scenes run the fused persistent kernel k_path; 1 = k_path_bw (wave-local wavefront) when NEE is off; 2 = k_path; 0 = always the wavefront stage kernels
   int32_t optTraceDyn = -1; // -1 = default; 0 = block-synchronous k_trace everywhere; N = k_trace_dyn refill threshold
   int32_t optDevices = 0;   // 0 = every device the library was initialised on; N = at most N of them
+  uint32_t lastRenderDevices = 0; // devices the previous giCRender used: progressive accumulation blends against each device's own buffer, so a change restarts it
 };
 
 void SceneDevice::releaseAll()
@@ -912,7 +913,7 @@ int giCSetSceneOption(GiCScene* scene, int32_t option, int32_t value)
   if (option == GI_C_SCENE_OPTION_TRACE_DYNAMIC) { scene->optTraceDyn = value < 0 ? -1 : (value > 64 ? 64 : value); return GI_C_OK; }
   if (option == GI_C_SCENE_OPTION_FUSED_PATH) { scene->optFusedPath = value < 0 ? -1 : (value > 2 ? -1 : value); return GI_C_OK; }
   if (option == GI_C_SCENE_OPTION_SAMPLE_BUFFER_MB) { scene->optSampleBufferMb = value > 0 ? (uint64_t)value : 0; return GI_C_OK; }
-  if (option == GI_C_SCENE_OPTION_DEVICES) { scene->optDevices = value > 0 ? value : 0; scene->dirty |= DIRTY_BVH | DIRTY_FRAMEBUFFER; /* replicas are made with the build */ return GI_C_OK; }
+  if (option == GI_C_SCENE_OPTION_DEVICES) { scene->optDevices = value > 0 ? value : 0; scene->dirty |= DIRTY_BVH | DIRTY_LIGHTS | DIRTY_FRAMEBUFFER; /* replicas are made with the build; a NEW replica also needs the lights, which travel under DIRTY_LIGHTS only */ return GI_C_OK; }
   setError("unknown scene option"); return GI_C_ERROR;
 }
 
@@ -1251,7 +1252,7 @@ int buildScene(GiCScene* s)
   s->nodeStrideU4 = H.lineNodes ? 8u : 5u;
   // one copy of the scene per device this scene renders on
   const uint32_t nDev = sceneDeviceCount(s);
-  while (s->replicas.size() + 1u < nDev) { s->replicas.emplace_back(new SceneDevice()); s->replicas.back()->slot = (uint32_t)s->replicas.size(); }
+  while (s->replicas.size() + 1u < nDev) { s->replicas.emplace_back(new SceneDevice()); s->replicas.back()->slot = (uint32_t)s->replicas.size(); s->dirty |= DIRTY_LIGHTS; } // a new replica has no lights yet
   for (uint32_t d = 0; d < nDev; d++)
     if (uploadSceneTo(s, sceneDevice(s, d), H) != GI_C_OK) { (void)hipSetDevice(g_ctx.device); return GI_C_ERROR; }
   HIP_TRY(hipSetDevice(g_ctx.device));
@@ -2026,27 +2027,31 @@ static int giCRenderImpl(const GiCRenderParams* params)
   if (syncSceneGeometry(s) != GI_C_OK) return GI_C_ERROR;
   if (s->dirty & DIRTY_LIGHTS) { if (uploadLights(s) != GI_C_OK) return GI_C_ERROR; s->dirty &= ~DIRTY_LIGHTS; s->dirty |= DIRTY_FRAMEBUFFER; }
   if (!rs.progressiveAccumulation) s->dirty |= DIRTY_FRAMEBUFFER;
+  // --- one device, or the rows dealt to all of them
+  // Multi-device: a whole-frame render (the caller does not shard rows itself) with at least as many rows as devices.  ClockCycles is normalised to the
+  // frame maximum on the host (Gi.cpp:327-343), a cross-device reduction nobody needs fast: such renders stay on the primary device.
+  bool wantsClock = false;
+  for (uint32_t i = 0; i < params->aovBindingCount; i++) if (params->aovBindings[i].aovId == GI_C_AOV_CLOCK_CYCLES) wantsClock = true;
+  uint32_t nDev = std::min<uint32_t>(sceneDeviceCount(s), (uint32_t)s->replicas.size() + 1u);
+  if (rowStride != 1u || rowBegin != 0u || rowEnd != height || wantsClock || height < nDev) nDev = 1u;
+  // every device blends progressive frames against ITS OWN copy of the render buffers: when the device count of this call differs from the previous call's
+  // (a ClockCycles binding came or went, the DEVICES option changed) the copies disagree, so the accumulation restarts
+  if (s->lastRenderDevices != nDev) s->dirty |= DIRTY_FRAMEBUFFER;
+  s->lastRenderDevices = nDev;
   if (s->dirty & DIRTY_FRAMEBUFFER) { s->sampleOffset = 0; s->dirty &= ~DIRTY_FRAMEBUFFER; }
 
 
   RenderJob job{params, colorBinding, width, height, rowBegin, rowEnd, rowStride, tileRows, {0}, true};
   memcpy(job.clear, clear, sizeof(job.clear));
   // AOVs the colour pass fills along whole paths (NEE, Bounces, ClockCycles) and unknown ids start from their clear value: host copy filled once, here
-  bool wantsClock = false;
   for (uint32_t i = 0; i < params->aovBindingCount; i++) {
     const GiCAovBinding& b = params->aovBindings[i];
     GiCRenderBuffer* rb = b.renderBuffer;
     const bool pathAov = b.aovId == GI_C_AOV_NEE || b.aovId == GI_C_AOV_BOUNCES || b.aovId == GI_C_AOV_CLOCK_CYCLES || b.aovId < 0 || b.aovId >= GI_C_AOV_COUNT;
-    if (b.aovId == GI_C_AOV_CLOCK_CYCLES) wantsClock = true;
     if (b.aovId == GI_C_AOV_COLOR || !pathAov) continue;
     const size_t n = (size_t)rb->width * rb->height;
     for (size_t k = 0; k < n; k++) memcpy((uint8_t*)rb->hostMem + k * rb->stride, b.clearValue, rb->stride);
   }
-  // --- one device, or the rows dealt to all of them
-  // Multi-device: a whole-frame render (the caller does not shard rows itself) with at least as many rows as devices.  ClockCycles is normalised to the
-  // frame maximum on the host (Gi.cpp:327-343), a cross-device reduction nobody needs fast: such renders stay on the primary device.
-  uint32_t nDev = std::min<uint32_t>(sceneDeviceCount(s), (uint32_t)s->replicas.size() + 1u);
-  if (rowStride != 1u || rowBegin != 0u || rowEnd != height || wantsClock || height < nDev) nDev = 1u;
   int rc = GI_C_OK;
   if (nDev == 1u) {
     rc = renderOnDevice(s, *s, job);

@@ -202,7 +202,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(GI_
 // ------------------------------------------------------------------------------------------------
 bool pathKernelSupports(const SceneView& sc)
 {
-  return sc.triCount > 0u && sc.nodeCount <= LDS_NODES && sc.triCount <= LDS_TRIS && sc.bvhDepth <= PATH_STACK_MAX && sc.mediumStackSize == 0u && sc.domeTexture == 0u && !sc.twoLevel;
+  return sc.triCount > 0u && sc.nodeCount <= LDS_NODES && sc.triCount <= LDS_TRIS && sc.bvhDepth <= PATH_STACK_MAX && sc.mediumStackSize == 0u && sc.domeTexture == 0u && !sc.twoLevel
+         && !sc.shadePacked; // (GATLING_SHADE_PACKED=1 on an LDS-resident scene: TriRec::vi[0] is a shading-record index there, the fused kernels read vertex indices)
 }
 
 using PathKernel = void (*)(FrameUniforms, SceneView, PathState, Counters*, F4*, uint32_t, uint32_t, uint32_t);

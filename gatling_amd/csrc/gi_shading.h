@@ -697,7 +697,8 @@ __device__ inline void opbr_evaluate_base(const OpbrParams& o, const ShState& st
     gl = v3(Fch * fc, Fch * fc, Fch * fc);
     gl = gl + ((FmF * o.coatTint) * fs) * (base * o.metalness);
     gl = gl + ((o.specColor * o.coatTint) * (opbr_film_dielectric(o, khs, eta, Fdh) * fs)) * (base * diel);
-    under = (v3(1.0f, 1.0f, 1.0f) - opbr_film_dielectric(o, nk1, eta, Fd)) * (1.0f / (1.0f - Fd));
+    // total internal reflection (Fd == 1: back face beyond the critical angle): nothing lies beneath the interface -- without the guard 0 * (1 / 0) = NaN
+    under = (Fd < 1.0f) ? (v3(1.0f, 1.0f, 1.0f) - opbr_film_dielectric(o, nk1, eta, Fd)) * (1.0f / (1.0f - Fd)) : v3(0.0f, 0.0f, 0.0f);
   }
   out.glossy = gl;
   V3 rho = (o.diffRough > 0.0f && l2.z > 0.0f) ? eon_pi_f(o.baseColor, o.diffRough, l1, l2) * o.baseWeight : o.albedo;

@@ -191,7 +191,6 @@ typedef struct GiCRenderParams {
 #define GI_C_P_SPECULAR_ANISOTROPY 60 /* OpenPBR specular_roughness_anisotropy (open_pbr_surface.mtlx:27, 133-136): GGX stretched along the tangent, alpha_t = r^2 sqrt(2 / (1 + (1 - a)^2)), alpha_b = (1 - a) alpha_t */
 #define GI_C_P_COAT_ANISOTROPY 61     /* coat_roughness_anisotropy (:65, 552-555); the coat uses the geometry tangent (geometry_coat_tangent is not a separate input here) */
 #define GI_C_P_THIN_WALLED 54      /* OpenPBR geometry_thin_walled (:88) != 0: MDL thin_walled semantics (rp_main.chit:153-157, 188-189, 447) */
-                                   /* slots 55..63: reserved, must be 0 */
 
 /* Note: p[GI_C_P_OPACITY] is the cutout opacity (1 = opaque); a zero-filled block is a fully transparent material. */
 typedef struct GiCMaterialDesc {

@@ -1141,6 +1141,8 @@ inline V3 opbr_film_metal(const OpbrParams& o, float c, V3 Fplain)
 }
 
 // ---- fuzz (sheen) lobe: our closed form for MaterialX sheen_bsdf / MDL df::sheen_bsdf, whose arithmetic is not in the reference tree.
+// DEVIATION: the reference graph asks for sheen_bsdf mode="zeltner" (open_pbr_surface.mtlx:575) -- the LTC fit of Zeltner, Burley, Chiang 2022,
+// whose tables live in MaterialX's library; this is the Conty-Kulla ("Charlie") lobe instead, i.e. MaterialX's mode="conty_kulla".  Same inputs, a different lobe shape.
 // Micro-flake lobe D * V with the "Charlie" distribution D(h) = (2 + 1/a) sin(theta_h)^(1/a) / (2 pi) (Conty & Kulla 2017, a = fuzz_roughness in [0.07, 1]) and
 // the Ashikhmin / Neubelt visibility V = 1 / (4 (n.l + n.v - n.l n.v)).  Its directional albedo E(n.v, a) has no closed form: both implementations embed the
 // table of tools/gen_fuzz_albedo.py (numerical integration), interpolate it bilinearly and add 0.01 -- an upper bound of the true albedo for every a >= 0.07.
@@ -1341,7 +1343,8 @@ static void opbr_evaluate_base(const OpbrParams& o, const State& st, V3 k1, V3 k
     gl = v3(Fch * fc, Fch * fc, Fch * fc);
     gl = gl + ((FmF * o.coatTint) * fs) * (base * o.metalness);
     gl = gl + ((o.specColor * o.coatTint) * (opbr_film_dielectric(o, khs, eta, Fdh) * fs)) * (base * diel);
-    under = (v3(1, 1, 1) - opbr_film_dielectric(o, nk1, eta, Fd)) * (1.0f / (1.0f - Fd));
+    // total internal reflection (Fd == 1: back face beyond the critical angle): nothing lies beneath the interface -- without the guard 0 * (1 / 0) = NaN
+    under = (Fd < 1.0f) ? (v3(1, 1, 1) - opbr_film_dielectric(o, nk1, eta, Fd)) * (1.0f / (1.0f - Fd)) : v3(0, 0, 0);
   }
   out.glossy = gl;
   V3 rho = (o.diffRough > 0.0f && l2.z > 0.0f) ? eon_pi_f(o.baseColor, o.diffRough, l1, l2) * o.baseWeight : o.albedo;

@@ -287,6 +287,14 @@ def test_thin_film(orc):
     m = MaterialDesc.open_pbr(base_color=(0.9, 0.9, 0.9), base_metalness=1.0, specular_roughness=0.3, thin_film_weight=1.0, thin_film_thickness=0.4, thin_film_ior=1.5)
     o = orc.bsdf_debug(m, items)[:, 3:6].mean(axis=0)
     assert np.all(o <= 1.0) and o.max() / o.min() > 1.03
+    # from inside, beyond the critical angle (back face, relative eta 1 / 1.5, cos 0.2): total internal reflection -- the Fresnel term and the film's reflectance
+    # are both exactly 1, so "what lies beneath the interface" is 0 and not (1 - 1) * 1 / (1 - 1) = NaN (NEE added NaN radiance there)
+    inside = _frames(4000, rng, 0.2); inside[:, 21] = 1.0
+    for mat in (film, MaterialDesc.open_pbr(base_color=(0.7, 0.7, 0.7), transmission_weight=0.6, thin_film_weight=0.5, thin_film_thickness=0.35, thin_film_ior=1.8,
+                                           geometry_thin_walled=False, subsurface_weight=0.0)):
+        t = orc.bsdf_debug(mat, inside)
+        assert np.isfinite(t).all()
+        assert np.all(t[:, 8:11] == 0.0) and np.all(t[:, 14] > 0.0)     # nothing diffuse beneath a totally reflecting interface; the pdf stays that of the glossy lobes
 
 
 def test_thin_walled_subsurface_lobes(orc):
