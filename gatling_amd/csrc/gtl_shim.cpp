@@ -185,12 +185,23 @@ namespace gtl
         if (readNode(doc, it->second, up) && up.category == "constant" && up.inputs.count("value")) { n.inputs[it->first] = up.inputs["value"]; it = n.connections.erase(it); }
         else ++it;
       }
-      auto bind = [&](const char* input, int slot) {
+      // `constant` / `count`: where the input's constant lives in the parameter block -- a primvar reader's own fallback value (MaterialX <geompropvalue>'s
+      // `default`, UsdPrimvarReader's `fallback`) replaces it: that is what a mesh WITHOUT the primvar shows (hdGatling's default material reads displayColor
+      // with default 0.18, /root/reference/src/hdGatling/renderDelegate.cpp:64-78)
+      auto bind = [&](const char* input, int slot, float* constant = nullptr, int count = 0) {
         auto it = n.connections.find(input);
         if (it == n.connections.end()) return;
         primvars[slot] = primvarOfNode(doc, it->second);
         MtlxNode up;
-        if (!primvars[slot].empty() || !readNode(doc, it->second, up)) return;
+        if (!primvars[slot].empty()) {
+          if (constant && readNode(doc, it->second, up)) {
+            auto d = up.inputs.find("default");
+            if (d == up.inputs.end()) d = up.inputs.find("fallback");
+            if (d != up.inputs.end() && !d->second.empty()) { float v[4] = {0, 0, 0, 0}; const int got = floats(d->second, v, count < 4 ? count : 4); for (int i = 0; got > 0 && i < count; i++) constant[i] = v[i < got ? i : got - 1]; }
+          }
+          return;
+        }
+        if (!readNode(doc, it->second, up)) return;
         if (up.category != "UsdUVTexture" && up.category != "image" && up.category != "tiledimage") return;
         ImageInput& im = images[slot];
         im.file = up.inputs["file"];
@@ -219,7 +230,8 @@ namespace gtl
         setN(n, "metallic", p + GI_C_P_METALLIC, 1); setN(n, "roughness", p + GI_C_P_ROUGHNESS, 1);
         setN(n, "clearcoat", p + GI_C_P_CLEARCOAT, 1); setN(n, "clearcoatRoughness", p + GI_C_P_CLEARCOAT_ROUGHNESS, 1);
         setN(n, "opacity", p + GI_C_P_OPACITY, 1); setN(n, "opacityThreshold", p + GI_C_P_OPACITY_THRESHOLD, 1); setN(n, "ior", p + GI_C_P_IOR, 1);
-        bind("diffuseColor", GI_C_TEX_BASE_COLOR); bind("emissiveColor", GI_C_TEX_EMISSION); bind("roughness", GI_C_TEX_ROUGHNESS); bind("metallic", GI_C_TEX_METALLIC);
+        bind("diffuseColor", GI_C_TEX_BASE_COLOR, p + GI_C_P_BASE_COLOR, 3); bind("emissiveColor", GI_C_TEX_EMISSION, p + GI_C_P_EMISSION, 3);
+        bind("roughness", GI_C_TEX_ROUGHNESS, p + GI_C_P_ROUGHNESS, 1); bind("metallic", GI_C_TEX_METALLIC, p + GI_C_P_METALLIC, 1);
         bind("normal", GI_C_TEX_NORMAL); bind("opacity", GI_C_TEX_OPACITY); // typically the texture's alpha: <input name="opacity" nodename="tex" output="a"/>
         return true;
       }
@@ -249,7 +261,7 @@ namespace gtl
       setN(n, "thin_film_weight", p + GI_C_P_THIN_FILM_WEIGHT, 1); setN(n, "thin_film_thickness", p + GI_C_P_THIN_FILM_THICKNESS, 1); setN(n, "thin_film_ior", p + GI_C_P_THIN_FILM_IOR, 1);
       setN(n, "emission_luminance", &lum, 1); setN(n, "emission_color", ecol, 3); setN(n, "geometry_opacity", p + GI_C_P_OPACITY, 1);
       for (int i = 0; i < 3; i++) p[GI_C_P_EMISSION + i] = lum * ecol[i];
-      bind("base_color", GI_C_TEX_BASE_COLOR); bind("specular_roughness", GI_C_TEX_ROUGHNESS); bind("base_metalness", GI_C_TEX_METALLIC);
+      bind("base_color", GI_C_TEX_BASE_COLOR, p + GI_C_P_BASE_COLOR, 3); bind("specular_roughness", GI_C_TEX_ROUGHNESS, p + GI_C_P_ROUGHNESS, 1); bind("base_metalness", GI_C_TEX_METALLIC, p + GI_C_P_METALLIC, 1);
       bind("geometry_normal", GI_C_TEX_NORMAL); bind("geometry_opacity", GI_C_TEX_OPACITY);
       return true;
     }

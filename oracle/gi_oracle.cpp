@@ -2054,10 +2054,24 @@ int orc_render(const OrcScene* scene, const OrcCamera* camera, const OrcSettings
   if (!scene || !camera || !settings || !region || !colorOut) return 1;
   if (settings->spp == 0 || region->imageWidth == 0 || region->imageHeight == 0 || region->rowEnd > region->imageHeight || region->rowBegin > region->rowEnd) return 2;
   if (region->imageWidth > 65535u || region->imageHeight > 65535u) return 3; // imageDims packing, rp_main.h:38
+  std::vector<uint32_t> list(region->rowEnd - region->rowBegin);
+  for (uint32_t r = 0; r < (uint32_t)list.size(); r++) list[r] = region->rowBegin + r;
+  return orc_render_rows(scene, camera, settings, region, (uint32_t)list.size(), list.data(), prevColor, colorOut, counters, threads);
+}
+
+// The same for an explicit list of image rows (test infrastructure: one prepare() / BVH build for rows that are not adjacent, e.g. two rows of one rank's
+// interleaved share).  Output row r of colorOut / prevColor is image row rowList[r]; region supplies the image size only.
+int orc_render_rows(const OrcScene* scene, const OrcCamera* camera, const OrcSettings* settings, const OrcRegion* region, uint32_t rowCount, const uint32_t* rowList,
+                    const float* prevColor, float* colorOut, OrcCounters* counters, int threads)
+{
+  if (!scene || !camera || !settings || !region || !colorOut || (rowCount && !rowList)) return 1;
+  if (settings->spp == 0 || region->imageWidth == 0 || region->imageHeight == 0) return 2;
+  if (region->imageWidth > 65535u || region->imageHeight > 65535u) return 3;
+  for (uint32_t r = 0; r < rowCount; r++) if (rowList[r] >= region->imageHeight) return 2;
   Prepared P; prepare(scene, P);
   Frame F; make_frame(F, P, camera, settings, region);
   if (threads <= 0) threads = 1;
-  uint32_t rows = region->rowEnd - region->rowBegin;
+  uint32_t rows = rowCount;
   std::vector<OrcCounters> tc((size_t)threads);
   for (auto& c : tc) memset(&c, 0, sizeof(c));
   std::atomic<uint32_t> nextRow{0};
@@ -2065,7 +2079,7 @@ int orc_render(const OrcScene* scene, const OrcCamera* camera, const OrcSettings
     for (;;) {
       uint32_t r = nextRow.fetch_add(1);
       if (r >= rows) break;
-      uint32_t y = region->rowBegin + r;
+      uint32_t y = rowList[r];
       for (uint32_t x = 0; x < F.width; x++) {
         size_t o = ((size_t)r * F.width + x) * 4;
         render_pixel(F, x, y, prevColor ? prevColor + o : nullptr, colorOut + o, tc[(size_t)ti]);

@@ -230,6 +230,9 @@ typedef struct OrcCounters {
 int orc_render(const OrcScene* scene, const OrcCamera* camera, const OrcSettings* settings,
                const OrcRegion* region, const float* prevColor, float* colorOut,
                OrcCounters* counters, int threads);
+/* the same for an explicit list of image rows (output row r = image row rowList[r]; region gives the image size only) */
+int orc_render_rows(const OrcScene* scene, const OrcCamera* camera, const OrcSettings* settings, const OrcRegion* region, uint32_t rowCount, const uint32_t* rowList,
+                    const float* prevColor, float* colorOut, OrcCounters* counters, int threads);
 
 /* ---- known-answer helpers (restated common.glsl / Gi.cpp pieces) ---- */
 uint32_t orc_rng_init(uint32_t pixelIndex, uint32_t sampleIndex);     /* common.glsl:121-124 */

@@ -301,20 +301,30 @@ def _settings(rs, sample_offset=0) -> OrcSettings:
     return s
 
 
-def render(scene, settings, width, height, rows=None, sample_offset=0, prev_color=None, threads=1):
-    """Renders with the oracle.  Returns (color float32 [rows,width,4] with row 0 = bottom, counters dict)."""
+def render(scene, settings, width, height, rows=None, sample_offset=0, prev_color=None, threads=1, row_list=None):
+    """Renders with the oracle.  Returns (color float32 [rows,width,4] with row 0 = bottom, counters dict).  `row_list`: explicit image rows instead of a
+    contiguous range (one scene preparation for rows that are not adjacent)."""
     L = lib()
     ps = PackedScene(scene)
     r0, r1 = rows if rows is not None else (0, height)
-    out = np.zeros((r1 - r0, width, 4), np.float32)
     cam, st = _camera(scene.camera), _settings(settings, sample_offset)
-    rg = OrcRegion(width, height, r0, r1)
     cnt = OrcCounters()
     prev = None
     if prev_color is not None:
         prev = np.ascontiguousarray(prev_color, np.float32)
-    rc = L.orc_render(C.addressof(ps.c), C.addressof(cam), C.addressof(st), C.addressof(rg),
-                      prev.ctypes.data if prev is not None else None, out.ctypes.data, C.addressof(cnt), threads)
+    if row_list is not None:
+        rl = np.ascontiguousarray(row_list, np.uint32)
+        out = np.zeros((len(rl), width, 4), np.float32)
+        rg = OrcRegion(width, height, 0, height)
+        L.orc_render_rows.restype = C.c_int
+        L.orc_render_rows.argtypes = [C.c_void_p] * 4 + [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        rc = L.orc_render_rows(C.addressof(ps.c), C.addressof(cam), C.addressof(st), C.addressof(rg), len(rl), rl.ctypes.data,
+                               prev.ctypes.data if prev is not None else None, out.ctypes.data, C.addressof(cnt), threads)
+    else:
+        out = np.zeros((r1 - r0, width, 4), np.float32)
+        rg = OrcRegion(width, height, r0, r1)
+        rc = L.orc_render(C.addressof(ps.c), C.addressof(cam), C.addressof(st), C.addressof(rg),
+                          prev.ctypes.data if prev is not None else None, out.ctypes.data, C.addressof(cnt), threads)
     if rc != 0:
         raise RuntimeError(f"orc_render failed with code {rc}")
     counters = {"samples": cnt.samples, "segments": cnt.segments, "shadow_rays": cnt.shadowRays, "hits": cnt.hits,

@@ -141,10 +141,27 @@ def build_loop(shaders: str, verbose=False):
     return objs
 
 
+DEFAULT_MTLX = os.path.join(OUT, "hdgatling_default_material.mtlx")
+
+
+def extract_default_material(reference="/root/reference") -> str:
+    """hdGatling's fallback material -- the one reference-authored MaterialX document in the tree that is not a git-LFS stub -- cut verbatim out of
+    src/hdGatling/renderDelegate.cpp (the raw string `_defaultMaterialXMaterial`) into the git-ignored oracle/_ref/, so that the GPU box's tests can feed it
+    through gtl::giCreateMaterialFromMtlxStr (tests/test_mtlx_parity.py).  Generated at build time, never committed."""
+    src = open(os.path.join(reference, "src", "hdGatling", "renderDelegate.cpp")).read()
+    m = re.search(r'_defaultMaterialXMaterial\s*=\s*R"\((.*?)\)";', src, flags=re.S)
+    if not m:
+        raise SystemExit("renderDelegate.cpp: _defaultMaterialXMaterial not found")
+    os.makedirs(OUT, exist_ok=True)
+    open(DEFAULT_MTLX, "w").write(m.group(1))
+    return DEFAULT_MTLX
+
+
 def build(reference="/root/reference", verbose=False) -> str:
     shaders = os.path.join(reference, "src", "gi", "shaders")
     if not os.path.isdir(shaders):
         raise FileNotFoundError(shaders)
+    extract_default_material(reference)
     os.makedirs(os.path.join(GEN, "interface"), exist_ok=True)
     open(os.path.join(GEN, "interface", "gtl.h"), "w").write("/* stub: ref_shim.cpp defines the GLSL side of interface/gtl.h (its C++ side needs glm) */\n")
     for rel in WHOLE:

@@ -8,6 +8,7 @@ in the nodegraph spelling HdMtlxCreateMtlxDocumentFromHdNetwork emits -- reads b
 GPU: the scene whose materials were created from documents through gtl::giCreateMaterialFromMtlxStr renders the bit-identical image to the parameter-block scene and
 to the oracle."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -71,6 +72,71 @@ def test_defaults_and_refusals():
                 '<materialx><UsdPreviewSurfaceX name="near_miss"/></materialx>'):
         assert _desc_from_doc(L, xml) is None, xml
     assert L.gtlMaterialDescFromMtlxStrC(None, None) != capi.GI_C_OK
+
+
+REF_DELEGATE = "/root/reference/src/hdGatling/renderDelegate.cpp"
+DEFAULT_MTLX_COPY = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "hdgatling_default_material.mtlx")
+
+
+def _default_material_block():
+    """What hdGatling's fallback document means: UsdPreviewSurface defaults, diffuseColor = primvar displayColor, 0.18 grey where a mesh has none."""
+    m = S.MaterialDesc.usd_preview_surface(name="gatling_MAT_default", diffuseColor=(0.18, 0.18, 0.18))
+    m.primvar_inputs = {S.TEX_BASE_COLOR: "displayColor"}
+    return m
+
+
+@pytest.mark.skipif(not os.path.exists(REF_DELEGATE), reason="needs /root/reference (not on the GPU box)")
+def test_reference_default_material_document_reads_to_its_block():
+    """the one reference-AUTHORED MaterialX document in the tree -- hdGatling's fallback material, renderDelegate.cpp:64-78 -- cut out of
+    the reference source at test time and fed verbatim through the shim's reader (every other document of this file is written by gatling_amd/mtlx_writer.py)."""
+    import re
+    src = open(REF_DELEGATE).read()
+    xml = re.search(r'_defaultMaterialXMaterial\s*=\s*R"\((.*?)\)";', src, flags=re.S).group(1)
+    assert "gatling_GP_default" in xml and "displayColor" in xml
+    if os.path.exists(DEFAULT_MTLX_COPY):  # the copy oracle/ref/build_ref.py generates for the GPU box is this string
+        assert open(DEFAULT_MTLX_COPY).read() == xml
+    L = capi.load_library()
+    d = _desc_from_doc(L, xml)
+    want = _default_material_block()
+    assert d is not None and d.klass == S.MAT_USD_PREVIEW_SURFACE
+    assert np.array_equal(np.frombuffer(bytes(d.p), np.uint32), np.asarray(want.params, np.float32).view(np.uint32))
+    # the geompropvalue's `default` is what a mesh without the primvar shows: a different default must reach the block (0.18 is also the specification's default)
+    d2 = _desc_from_doc(L, xml.replace('value="0.18, 0.18, 0.18"', 'value="0.5, 0.25, 0.125"'))
+    want2 = S.MaterialDesc.usd_preview_surface(diffuseColor=(0.5, 0.25, 0.125))
+    assert np.array_equal(np.frombuffer(bytes(d2.p), np.uint32), np.asarray(want2.params, np.float32).view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_reference_default_material_document_renders_its_block_image(gi):
+    """The same document (the copy build_ref.py cut out of the reference at build time, oracle/_ref/ -- generated, git-ignored, travels with the snapshot) through
+    gtl::giCreateMaterialFromMtlxStr on the device: meshes with a vertex displayColor, an instance displayColor and none at all render the bit-identical image
+    to the equivalent parameter block + primvar binding, and to the oracle."""
+    if not os.path.exists(DEFAULT_MTLX_COPY):
+        pytest.skip("oracle/_ref/hdgatling_default_material.mtlx not generated (build() ran without /root/reference)")
+    from oracle import orc
+    xml = open(DEFAULT_MTLX_COPY).read()
+    desc = sphere_grid(3, 2, 3)
+    desc.materials = [_default_material_block()]
+    rng = np.random.default_rng(7)
+    for k, m in enumerate(desc.meshes):
+        m.material = 0
+        nv, ni = len(m.vertices), len(m.instance_transforms)
+        if k % 3 == 0:
+            m.primvars = [S.Primvar("displayColor", S.PRIMVAR_VEC3, S.INTERP_VERTEX, rng.uniform(0, 1, (nv, 3)))]
+        elif k % 3 == 1:
+            m.instancer_primvars = [S.Primvar("displayColor", S.PRIMVAR_VEC3, S.INTERP_INSTANCE, rng.uniform(0, 1, (ni, 3)))]
+    rs = S.RenderSettings(spp=4, max_bounces=5)
+    w, h = 80, 45
+    ref, cnt = orc.render(desc, rs, w, h, threads=8)
+    a = capi.Scene(desc); b = capi.Scene(desc, mtlx_materials={0: xml})
+    try:
+        ia, ib = a.render(rs, w, h).copy(), b.render(rs, w, h).copy()
+        assert b.stats()["segments"] == cnt["segments"]
+    finally:
+        a.close(); b.close()
+    assert np.array_equal(ia.view(np.uint32), ref.view(np.uint32)), "parameter block + primvar binding: image differs from the oracle"
+    assert np.array_equal(ib.view(np.uint32), ref.view(np.uint32)), "hdGatling's default-material document: image differs from the oracle"
+    assert len(np.unique(ib[..., :3].reshape(-1, 3), axis=0)) > 100   # the display colours are really in the picture
 
 
 @pytest.mark.gpu

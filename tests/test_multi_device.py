@@ -53,6 +53,31 @@ SCRIPT = textwrap.dedent("""
         for k in am:
             assert np.array_equal(am[k].view(np.uint32), asg[k].view(np.uint32)), "AOV " + k + " differs between the multi- and the one-device render"
         multi.close(); single.close()
+    # ADVICE r03: raising the device count AFTER a render creates replicas that never saw the lights (they travel under DIRTY_LIGHTS only), and a change of the
+    # device count between progressive frames leaves the replicas' buffers behind the primary's.  Lit scene, NEE: DEVICES 1 -> all -> 1, then progressive frames
+    # with a ClockCycles binding (forces one device) in between.
+    desc = interior_scene(clutter_instances=40, subdivisions=2, prototypes=4, material_count=6)
+    rs = RenderSettings(spp=2, max_bounces=4, next_event_estimation=True); w, h = 40, 18
+    ref, _ = orc.render(desc, rs, w, h, threads=4)
+    sc = capi.Scene(desc)
+    sc.set_option(capi.OPTION_DEVICES, 1)
+    one = sc.render(rs, w, h).copy()
+    sc.set_option(capi.OPTION_DEVICES, 0)
+    three = sc.render(rs, w, h).copy()
+    sc.set_option(capi.OPTION_DEVICES, 2)
+    two = sc.render(rs, w, h).copy()
+    for img in (one, three, two):
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), "image after a change of the device count differs from the oracle"
+    sc.set_option(capi.OPTION_DEVICES, 0)
+    p1 = sc.render(rs, w, h).copy()                       # frame 1 on three devices (the option change restarted the accumulation)
+    sc.render_aovs(rs, w, h, ["clockCycles"])             # a ClockCycles binding: one device; the device count changed -> accumulation restarts
+    p2 = sc.render(rs, w, h).copy()                       # three devices again -> restarts again: equals frame 1
+    p3 = sc.render(rs, w, h).copy()                       # second progressive frame on three devices
+    solo = capi.Scene(desc); solo.set_option(capi.OPTION_DEVICES, 1)
+    q1 = solo.render(rs, w, h).copy(); q2 = solo.render(rs, w, h).copy()
+    assert np.array_equal(p1.view(np.uint32), q1.view(np.uint32)) and np.array_equal(p2.view(np.uint32), q1.view(np.uint32)), "accumulation did not restart with the device count"
+    assert np.array_equal(p3.view(np.uint32), q2.view(np.uint32)), "progressive frame after a device-count change differs from the one-device run"
+    sc.close(); solo.close()
     print("multi-device ok")
 """)
 
