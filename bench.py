@@ -22,8 +22,10 @@ side is reported in wall-clock terms against ceilings MEASURED by tools/valu_cal
 the nearer of the two rooflines; `bound_note` says when neither is near (the big-scene traversal is bound by the L1 -> L2 request path, tools/ta_calib.hip,
 DESIGN.md section 4).
 
-At N = 1 the default line carries, under `also`, configs C3 and C4 -- the wavefront pipeline (k_raygen / k_trace_dyn / k_route / k_shade / k_trace_dyn<any>) --
-each with its own roofline object and every kernel's time share / VALU rate / lanes / L2 hit (`all_kernels`); at N >= 8 config C5, tiled across the ranks.
+At N = 1 the default line carries, under `also`, compact objects for configs C3 and C4 -- the wavefront pipeline (k_raygen / k_trace_dyn / k_route / k_shade /
+k_trace_dyn<any>) -- and for `c5share`, one rank's share of C5's 8-GPU partition at full spp (`projected_8gpu` = 8 x its rate), each with its own roofline fractions;
+at N >= 8 config C5 itself, tiled across the ranks.  Raw counters and every kernel's time share / VALU rate / lanes / L2 hit go to profiles/bench_last_pmc.json
+(and gpurun_out/ when it exists), not into the line.
 """
 import argparse
 import json
@@ -55,6 +57,9 @@ def make_workload(name, spp_override=None):
     elif name == "c5":
         desc, rs, w, h = interior_scene(), RenderSettings(spp=1024, max_bounces=8, next_event_estimation=True), 3840, 2160
         label = "C5: interior, 10.24M instanced triangles, 51 materials, 4 rect lights, NEE on, 3840x2160 spp=1024 max-bounces=8"
+    elif name == "c5share":  # rank 3's share of C5's 8-GPU partition (rows 3, 11, 19, ...): the per-GPU work of the configuration C5 is specified on, on ONE GPU
+        desc, rs, w, h = interior_scene(), RenderSettings(spp=1024, max_bounces=8, next_event_estimation=True), 3840, 2160
+        label = "C5 share 3/8: interior, 10.24M instanced triangles, NEE on, 3840x2160 spp=1024 max-bounces=8, rows 3::8 (270 of 2160)"
     else:
         raise SystemExit(f"unknown workload {name}")
     if spp_override:
@@ -242,6 +247,8 @@ def main():
         rs.progressive_accumulation = False  # every step renders the same frame from sample 0 (no cross-step accumulation)
         scene = capi.Scene(desc, device=local_rank)
         r0, r1, rstride = interleaved_rows(h, world, rank)  # rows rank::world: every rank's share costs the same (dist.py)
+        if workload == "c5share" and world == 1:
+            r0, r1, rstride = interleaved_rows(h, 8, 3)
         nrows = len(range(r0, r1, rstride))
         dev_ptr = scene.device_pointer(w, h)
 
@@ -264,7 +271,7 @@ def main():
             if not use_dist:
                 # blocks; the colour AOV is complete in the library's host memory on return (reference semantics: hdGatling reads giGetRenderBufferMem in place,
                 # renderBuffer.cpp:53-154) -- a view of it, not a second host copy through numpy (33 MB, ~4 ms per C2 step until r03)
-                last["img"] = scene.render(rs, w, h, copy=False)
+                last["img"] = scene.render(rs, w, h, copy=False) if rstride == 1 else scene.render(rs, w, h, rows=(r0, r1), row_stride=rstride, copy=False)
             else:
                 gather.wait_packed()  # frame i - 1's pack copy has read the render buffer (it runs on torch's stream, the library renders on its own)
                 scene.render(rs, w, h, rows=(r0, r1), device_only=True, row_stride=rstride)
@@ -320,7 +327,7 @@ def main():
         scene.set_option(capi.OPTION_COUNT_TRAVERSAL, 0)
         out = None
         if rank == 0:
-            samples_per_step = w * h * rs.spp
+            samples_per_step = (w * h if (world > 1 or rstride == 1) else len(range(r0, r1, rstride)) * w) * rs.spp  # (a share leg on one GPU counts the share's samples)
             value = samples_per_step * steps / dt / 1e6
             # dominant traversal kernel k_trace<closest>: algorithmic bytes per launch: ray 32 + hit 20 per ray,
             # 80 B per BVH8 node visited, 48 B per triangle tested; divided by its mean launch time (HIP events).
@@ -346,6 +353,7 @@ def main():
             render_ms = sum(s["renderMs"] for s in stats) / steps
             stage["renderMs"] = round(render_ms, 3)
             stage["otherMs"] = round(render_ms - sum(stage[k] for k in ("raygenMs", "traceMs", "shadeMs", "shadowMs")), 3)
+            raw = {}
             roofline = {"bound": "hbm", "kernel": kernel, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                         "algorithmic_GBps": round(achieved, 2), "algorithmic_frac": round(achieved / HBM_PEAK_GBS, 5),
                         "bytes_per_launch": round(bytes_total / max(1, launches), 1), "avg_launch_us": round(avg_launch_s * 1e6, 3),
@@ -402,10 +410,11 @@ def main():
                             roofline["bound"] = "valu" if roofline["valu_frac"] > roofline["frac"] else "hbm"
                             if max(roofline["valu_frac"], roofline["frac"]) < 0.6:
                                 roofline["bound_note"] = "neither roofline is near: latency / vector-memory request rate bound (DESIGN.md section 4)"
-                        roofline["pmc_kernels"] = {k: {c: (round(x, 1) if isinstance(x, float) else x) for c, x in v.items()} for k, v in pmc.items() if k.startswith(prefixes)}
-                        if not main_line:  # every kernel of the frame, compactly: time share under counters, VALU issue, lanes, L2 hit (the per-kernel picture of the wavefront pipeline)
+                        # raw counters and the per-kernel table go to a FILE (the driver keeps only the last 8 KB of output: r03's line lost C3's value to them)
+                        raw["pmc_kernels"] = {k: {c: (round(x, 1) if isinstance(x, float) else x) for c, x in v.items()} for k, v in pmc.items() if k.startswith(prefixes)}
+                        if True:  # every kernel of the frame, compactly: time share under counters, VALU issue, lanes, L2 hit (the per-kernel picture of the wavefront pipeline)
                             tot = sum(v.get("pmc_us", 0.0) * v.get("dispatches", 0) for v in pmc.values()) or 1.0
-                            roofline["all_kernels"] = {
+                            raw["all_kernels"] = {
                                 k: {"dispatches": v.get("dispatches", 0), "time_share": round(v.get("pmc_us", 0.0) * v.get("dispatches", 0) / tot, 4),
                                     "valu_frac": round(v.get("SQ_INSTS_VALU", 0.0) / (SIMDS * max(v.get("pmc_us", 0.0) * v.get("dispatches", 1) * 1e3, 1e-9)) / vcal["mixed"], 4),
                                     "lanes": round(v.get("SQ_THREAD_CYCLES_VALU", 0.0) / (64.0 * v["SQ_ACTIVE_INST_VALU"]), 4) if v.get("SQ_ACTIVE_INST_VALU") else None,
@@ -419,6 +428,7 @@ def main():
                               "parallelism": f"rows-interleaved{world}" if world > 1 else (f"in-process rows-interleaved{args.gpus}" if args.in_process and args.gpus > 1 else "single"), "segments_per_sample": round(seg_per_sample, 4),
                               "triangles": cst["triangleCount"], "bvh8_nodes": cst["nodeCount"], "iterations_per_step": stats[-1]["iterations"]},
                    "roofline": roofline}
+            out["_raw"] = raw
             if os.environ.get("GATLING_BENCH_CHECKSUM"):  # tests: the frame rank 0 ends up with (host memory), as a checksum
                 import hashlib
                 img = last["img"]
@@ -431,34 +441,56 @@ def main():
     out, R = measure(args.workload, args.spp, args.steps, args.warmup, args.no_timers, args.no_pmc, True)
     if args.probe:
         return
+    raws = {}
+    if out is not None:
+        raws[args.workload] = out.pop("_raw", {})
+        for k in ("calibration", "valu_calibration"):  # constants of the calibration files: kept in the side file, not in the line
+            if k in out["roofline"]:
+                raws[args.workload][k] = out["roofline"].pop(k)
     if out is not None and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(R["desc"], R["rs"], R["w"], R["h"])
         out["cpu_baseline"]["reference"] = reference_probe()
-    # Further measurements in the same line ("also"), so the driver's record covers more than the headline config:
-    #   N = 1 (headline C2 runs in the fused k_path_bw): C3 and C4 -- the wavefront pipeline k_raygen / k_trace_dyn / k_route / k_shade / k_trace_dyn<any> --
-    #         with their own roofline objects (3 steps each: C3 ~0.5 s, C4 ~0.15 s per step);
-    #   N = 8 (the configuration C5 is specified on; BASELINE.json configs[4]): the tiled 4K interior.
+    # Further measurements in the same line ("also"), so the driver's record covers every BASELINE config a single GPU can run:
+    #   N = 1 (the headline C2 runs in the fused k_path): C3 and C4 -- the wavefront pipeline k_raygen / k_trace_dyn / k_route / k_shade / k_trace_dyn<any> -- and
+    #         "c5share": rank 3's interleaved share of C5's 8-GPU partition at full spp, i.e. the per-GPU work of the configuration C5 is specified on
+    #         (`projected_8gpu` = 8 x the share's rate; DESIGN.md section 7 says what the projection leaves out);
+    #   N = 8: the tiled 4K interior itself.
+    # Each leg is a COMPACT object (value, ms_per_step, stage times, roofline fractions); raw counters and per-kernel tables go to profiles/bench_last_pmc.json.
     # Every rank takes part (collectives inside); a failure is reported in the line instead of losing the headline number.
-    also = os.environ.get("GATLING_BENCH_ALSO", ("c3,c4" if args.workload == "c2" and not args.spp else "") if world == 1 else ("c5" if world >= 8 else ""))
+    also = os.environ.get("GATLING_BENCH_ALSO", ("c3,c4,c5share" if args.workload == "c2" and not args.spp else "") if world == 1 else ("c5" if world >= 8 else ""))
     extras = []
     for wl in [x for x in also.split(",") if x and x != args.workload]:
         extra = {"workload": wl}
         try:
-            e_steps = int(os.environ.get("GATLING_BENCH_ALSO_STEPS", "3" if world == 1 else "2"))
+            e_steps = int(os.environ.get("GATLING_BENCH_ALSO_STEPS", ("2" if wl == "c5share" else "3") if world == 1 else "2"))
             E, _ = measure(wl, int(os.environ.get("GATLING_BENCH_ALSO_SPP", "0")), e_steps, 1, world > 1, args.no_pmc or world > 1, False)
             if E is not None:
-                extra.update({"config": E["config"], "value": E["value"], "unit": "Msamples/s", "ms_per_step": E["ms_per_step"], "steps": e_steps, "warmup": 1,
-                              "n_gpus": world, "roofline": E["roofline"]})
+                raws[wl] = E.pop("_raw", {})
+                r = E["roofline"]
+                extra.update({"label": E["config"]["workload"][:60], "value": E["value"], "unit": "Msamples/s", "ms_per_step": E["ms_per_step"], "steps": e_steps, "warmup": 1, "n_gpus": world,
+                              "segments_per_sample": E["config"]["segments_per_sample"], "iterations_per_step": E["config"]["iterations_per_step"],
+                              "stage_ms": r.get("stage_ms_per_step"),
+                              "roofline": {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "algorithmic_frac", "valu_frac", "valu_lane_utilisation",
+                                                                  "l2_hit_rate", "wait_inst_any_frac", "nodes_per_ray", "tris_per_ray", "pmc_note") if k in r}})
+                if wl == "c5share":
+                    extra["projected_8gpu"] = round(8.0 * E["value"], 1)
+                    extra["projection_note"] = "8 x the rate of one rank's share (rows 3::8 at full spp) on one GPU; leaves out the RCCL gather of 8 x 16.6 MB and rank imbalance (DESIGN.md section 7)"
         except Exception as e:  # noqa: BLE001
             extra["error"] = repr(e)[:300]
         extras.append(extra)
     if out is not None and extras:
-        out["also"] = extras if len(extras) > 1 else extras[0]
+        out["also"] = extras
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
         import ctypes
+        for d in (os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")):  # (gpurun_out/ is what travels back from a GPU box)
+            try:
+                if os.path.isdir(d):
+                    json.dump(raws, open(os.path.join(d, "bench_last_pmc.json"), "w"), indent=1)
+            except Exception:  # noqa: BLE001
+                pass
         sys.stderr.flush()
         ctypes.CDLL(None).fflush(None)  # flush C stdio (RCCL prints a version banner there) so the JSON is the LAST line
         print(json.dumps(out), flush=True)
