@@ -92,7 +92,7 @@ typedef float gi_f2 __attribute__((ext_vector_type(2)));
 // truncation rounds down).  The remainder a pick pushes keeps the field, and trav_pop drops a popped group whose bound lies beyond the ray's current tBest -- the
 // children were hit when the node was tested, but a nearer hit has been found since ("cull at pop", VERDICT r03 next #2a; tools/bvh_quality.cpp: -11.6 % node visits on C3).
 #ifndef GI_POP_CULL
-#define GI_POP_CULL 1
+#define GI_POP_CULL 0 // measured r04a (profiles/r04a_pop_cull.txt): node visits C3 -11.7 %, C4 -4.5 %, C5 -10.4 % as counted on the CPU -- and the traversal no faster (C3 47.8 -> 48.1 ms, C4 19.3 -> 20.9, C5 132.2 -> 136.5): the ~56 VALU + 16 SALU the bound costs per node test eat what the saved visits give
 #endif
 constexpr bool POP_CULL = GI_POP_CULL != 0;
 template <bool SLACK = false, bool CULL = false>
