@@ -310,6 +310,7 @@ struct SceneDevice {
   DeviceBuffer<F4> accum;        // per-pixel running sum across batches
   DeviceBuffer<uint32_t> qSlot[Q_COUNT]; // NSHARD segments of queueCap records each
   DeviceBuffer<F4> qA[Q_COUNT], qB[Q_COUNT], qC[Q_COUNT];
+  DeviceBuffer<FreshRec> qFresh[2]; // beside TRACE_A / TRACE_B: (rng, work item) of camera rays whose Slot is written only when they hit (FLAG_DEFER_SLOT)
   uint32_t queueCap = 0;
   DeviceBuffer<Counters> dCounters;
   Counters* hCounters = nullptr; // pinned
@@ -382,6 +383,7 @@ void SceneDevice::releaseAll()
   dMaterials.release(); dSphere.release(); dDistant.release(); dRect.release(); dDisk.release();
   slots.release(); media.release(); scratchColor.release(); neeKey.release(); pathSegments.release(); sampleBuf.release(); accum.release();
   for (uint32_t q = 0; q < Q_COUNT; q++) { qSlot[q].release(); qA[q].release(); qB[q].release(); qC[q].release(); }
+  qFresh[0].release(); qFresh[1].release();
   dCounters.release();
   if (hCounters) { (void)hipHostFree(hCounters); hCounters = nullptr; }
   if (hPoll) { (void)hipHostFree(hPoll); hPoll = nullptr; for (hipEvent_t& e : pollEvent) { (void)hipEventDestroy(e); e = nullptr; } }
@@ -1516,6 +1518,7 @@ int ensurePathState(SceneDevice* s, size_t slots, uint32_t gridA, uint32_t gridB
       if (s->qSlot[q].alloc(n)) return GI_C_ERROR;
       if (hasRecord && (s->qA[q].alloc(n) || s->qB[q].alloc(n))) return GI_C_ERROR;
       if (q == Q_SHADOW && s->qC[q].alloc(n)) return GI_C_ERROR;
+      if ((q == Q_TRACE_A || q == Q_TRACE_B) && s->qFresh[q - Q_TRACE_A].alloc(n)) return GI_C_ERROR;
     }
     s->queueCap = cap;
   }
@@ -1531,6 +1534,7 @@ QueueSet makeQueueSet(SceneDevice* s)
 {
   QueueSet qs{};
   for (uint32_t q = 0; q < Q_COUNT; q++) { qs.slot[q] = s->qSlot[q].ptr; qs.a[q] = s->qA[q].ptr; qs.b[q] = s->qB[q].ptr; qs.c[q] = s->qC[q].ptr; }
+  qs.fresh[0] = s->qFresh[0].ptr; qs.fresh[1] = s->qFresh[1].ptr;
   qs.cap = s->queueCap;
   return qs;
 }
@@ -1754,6 +1758,10 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
       ps.pathSegments = D.pathSegments.ptr;
     }
     view.mediumStackSize = rs.mediumStackSize;
+    // Deferred Slot initialisation (r04): k_raygen hands a camera ray its (rng, work item) beside the ray record instead of writing the path's 64-byte Slot; the
+    // slot is written where the first segment hits (k_route / k_trace) and a camera ray that leaves the scene retires there without ever touching one.  The
+    // debug AOVs that follow whole paths read the slot when a sample retires (NEE / Bounces / ClockCycles): renders that bind them keep the eager form.
+    { const char* e = getenv("GATLING_DEFER_SLOT"); if (!fused && (e ? atoi(e) != 0 : true) && !ps.neeKey && !ps.bouncesAov && !ps.pathSegments) U.flags |= FLAG_DEFER_SLOT; }
     QueueSet qs = makeQueueSet(&D);
     F4* colorOut = reinterpret_cast<F4*>(rbMem(colorRb, D.slot));
     const bool nee = rs.nextEventEstimation != 0;
@@ -1830,11 +1838,11 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
             if (pending == 0) { totalIters++; break; } // k_raygen(j) consumed the regen queue and produced no rays: the pool had drained
           }
         }
-        timed(1, [&] { launchTrace(st, traceBlocks, false, s->countTraversal, view, ps, qs, D.dCounters.ptr, Q_TRACE_A + par, Q_REGEN_A + (par ^ 1u), dynRefill, wideBlocks); });
+        timed(1, [&] { launchTrace(st, traceBlocks, false, s->countTraversal, view, ps, qs, D.dCounters.ptr, Q_TRACE_A + par, Q_REGEN_A + (par ^ 1u), dynRefill, wideBlocks, U, D.sampleBuf.ptr); });
         traceLaunches++;
         for (uint32_t klass = 0; klass < MAT_CLASS_COUNT; klass++)
           if (s->classMask & (1u << klass)) timed(2, [&] { launchShade(st, wideBlocks, klass, (s->classTextured & (1u << klass)) != 0u, rs.mediumStackSize != 0u, U, view, ps, qs, D.dCounters.ptr, par); });
-        if (nee) timed(3, [&] { launchTrace(st, traceBlocks, true, s->countTraversal, view, ps, qs, D.dCounters.ptr, Q_SHADOW, Q_SHADOW, dynRefill, wideBlocks); });
+        if (nee) timed(3, [&] { launchTrace(st, traceBlocks, true, s->countTraversal, view, ps, qs, D.dCounters.ptr, Q_SHADOW, Q_SHADOW, dynRefill, wideBlocks, U, D.sampleBuf.ptr); });
         if (iterLog) { // (GATLING_ITER_LOG, with kernel timers on every iteration: what each iteration's queues held -- one sync per iteration, for measurements only)
           HIP_TRY(hipMemcpyAsync(D.hCounters, D.dCounters.ptr, sizeof(PaddedCounter) * Q_COUNT * NSHARD, hipMemcpyDeviceToHost, st));
           HIP_TRY(hipStreamSynchronize(st));
@@ -2100,7 +2108,7 @@ static int giCTraceRaysImpl(GiCScene* s, uint32_t count, const float* origins, c
       hipMemcpyAsync(s->qB[Q_TRACE_A].ptr, qb.data(), qn * sizeof(F4), hipMemcpyHostToDevice, st) != hipSuccess ||
       hipMemcpyAsync(s->dCounters.ptr, &c, sizeof(c), hipMemcpyHostToDevice, st) != hipSuccess) { setError("giCTraceRays: upload failed"); return -1; }
   PathState ps{s->slots.ptr, nullptr, 0u, nullptr, 0u, nullptr};
-  launchTrace(st, blocks, false, false, makeView(s), ps, makeQueueSet(s), s->dCounters.ptr, Q_TRACE_A, Q_REGEN_B, traceDynRefill(s), blocks);
+  launchTrace(st, blocks, false, false, makeView(s), ps, makeQueueSet(s), s->dCounters.ptr, Q_TRACE_A, Q_REGEN_B, traceDynRefill(s), blocks, FrameUniforms{}, nullptr); // (no TRACE_FRESH entries: the uniforms are not read)
   std::vector<TriRec> tris(s->triCount);
   if (hipMemcpyAsync(&c, s->dCounters.ptr, sizeof(c), hipMemcpyDeviceToHost, st) != hipSuccess ||
       (s->triCount && hipMemcpyAsync(tris.data(), s->dTris.ptr, s->triCount * sizeof(TriRec), hipMemcpyDeviceToHost, st) != hipSuccess) ||

@@ -56,6 +56,32 @@ __global__ void k_init(PathState st, QueueSet qs, Counters* cnt, uint32_t n, uin
 // term.  Entry i of the regen queue finishes its sample (if any) into the per-sample colour buffer and takes work item
 // w = workBase + i, decoded by work_item (gi_queues.h): by default consecutive entries get consecutive samples of one pixel, pixels in 8x8 blocks.
 // ------------------------------------------------------------------------------------------------
+// A new path's Slot (rp_main.rgen:274-276): throughput 1, bitfield 0, radiance 0, the rng state after the camera draws, its work item
+__device__ __forceinline__ void slot_begin_path(Slot* S, uint32_t rng, uint32_t pixelLocal, uint32_t sLocal)
+{
+  st4(&S->thr, 1.0f, 1.0f, 1.0f, u2f(0u));
+  st4(&S->rad, 0.0f, 0.0f, 0.0f, u2f(rng));
+  st4(&S->id, u2f(pixelLocal), u2f(sLocal), u2f(1u), 0.0f);
+}
+// FLAG_DEFER_SLOT: the first segment of a camera path whose Slot k_raygen did not write has been traced.  A hit writes the Slot now (the path goes on exactly as
+// if k_raygen had written it).  A miss retires the sample on the spot -- radiance 0 + throughput 1 x background, then the per-sample finish, the arithmetic of
+// k_raygen's finish of a REGEN_MISSED entry (rp_main.miss:68-86, rp_main.rgen:489-496) -- and returns true: the slot goes back to the regen queue as REGEN_FRESH,
+// "nothing to finish, memory unwritten".  Scenes with a dome image or medium stacks need the slot at a miss (dome_miss / the scattering test): the caller writes
+// it first and takes the ordinary route.
+__device__ __forceinline__ void retire_fresh_miss(const FrameUniforms& U, const FreshRec& f, F4* __restrict__ sampleBuf)
+{
+  uint32_t pixelLocal, sLocal; work_item(U, f.work, pixelLocal, sLocal);
+  V3 rad = v3(0.0f, 0.0f, 0.0f) + v3(1.0f, 1.0f, 1.0f) * v3(U.background);
+  const float mv = fmax2(rad.x, fmax2(rad.y, rad.z));
+  if (mv > U.maxSampleValue) rad = rad * (U.maxSampleValue / mv);
+  st4(&sampleBuf[sample_record(U, pixelLocal, sLocal)], fmax2(0.0f, rad.x), fmax2(0.0f, rad.y), fmax2(0.0f, rad.z), 0.0f);
+}
+__device__ __forceinline__ void begin_fresh_path(const FrameUniforms& U, const PathState& st, uint32_t slot, const FreshRec& f)
+{
+  uint32_t pixelLocal, sLocal; work_item(U, f.work, pixelLocal, sLocal);
+  slot_begin_path(&st.slots[slot], f.rng, pixelLocal, sLocal);
+}
+
 __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st, QueueSet qs, Counters* cnt, uint32_t par, F4* __restrict__ sampleBuf)
 {
   __shared__ AppendScratch<1> sh;
@@ -71,7 +97,7 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st,
   uint32_t trip = 0;
   for (uint32_t base = blockIdx.x * BLOCK; base < n; base += stride, trip++) {
     const uint32_t i = base + threadIdx.x;
-    bool more = false; uint32_t slot = 0;
+    bool more = false; uint32_t slot = 0, rng = 0u; FreshRec fresh{0u, 0u};
     V3 origin = v3(0.0f, 0.0f, 0.0f), dir = origin; float tMin = 0.0f, tMax = GI_FLT_MAX;
     if (i < n) {
       const uint32_t entry = qs.slot[qIn][reader_index(rd, i)];
@@ -108,19 +134,19 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st,
         uint32_t pixelLocal, sLocal; work_item(U, w, pixelLocal, sLocal);
         const uint32_t pixelIndex = tile_to_image_pixel(U, pixelLocal); // :195 (global index: RNG is tile independent)
         const uint32_t sampleIndex = U.sampleOffset + U.batchFirstSample + sLocal;
-        uint32_t rng;
         make_camera_ray(U, pixelIndex, sampleIndex, origin, dir, tMin, tMax, rng);
-        st4(&S->thr, 1.0f, 1.0f, 1.0f, u2f(0u)); // :274-276
-        st4(&S->rad, 0.0f, 0.0f, 0.0f, u2f(rng));
-        st4(&S->id, u2f(pixelLocal), u2f(sLocal), u2f(1u), 0.0f);
+        fresh.rng = rng; fresh.work = w;
+        if (!(U.flags & FLAG_DEFER_SLOT)) slot_begin_path(S, rng, pixelLocal, sLocal); // :274-276 (deferred: written when the first segment hits, route_fresh)
       }
     }
     const bool pred[1] = {more}; const uint32_t qid[1] = {qOut}; uint32_t idx[1];
     block_append<1>(sh, trip, pred, qid, qs.cap, cnt, idx);
     if (more) {
-      qs.slot[qOut][idx[0]] = slot;
+      const bool defer = (U.flags & FLAG_DEFER_SLOT) != 0u;
+      qs.slot[qOut][idx[0]] = defer ? (slot | TRACE_FRESH) : slot;
       st4(&qs.a[qOut][idx[0]], origin.x, origin.y, origin.z, tMin);
       st4(&qs.b[qOut][idx[0]], dir.x, dir.y, dir.z, tMax);
+      if (defer) qs.fresh[par][idx[0]] = fresh; // 8 bytes beside the record, written and read in queue order
     }
   }
 }
@@ -173,7 +199,8 @@ __global__ void k_resolve_nee(FrameUniforms U, const unsigned long long* __restr
 }
 
 template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool ALL_LDS, bool CUTOUT, bool DOME>
-__global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t qMiss, uint32_t ldsNodes, uint32_t ldsTris)
+__global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t qMiss, uint32_t ldsNodes, uint32_t ldsTris,
+                                                       FrameUniforms U, F4* __restrict__ sampleBuf)
 {
   // dynamic LDS, sized by the launch to what this scene actually stages: [stack | nodes | triangles]
   extern __shared__ uint4 s_dyn[];
@@ -200,13 +227,14 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
     const uint32_t i = base + threadIdx.x;
     bool hit = false, miss = false; uint32_t slot = 0, mat = 0;
     float t = 0.0f, u = 0.0f, v = 0.0f; uint32_t tri = MISS; F4 rdir = F4{0.0f, 0.0f, 0.0f, 0.0f}, ro = rdir;
-    bool alive = false; uint32_t r = 0u, rng = 0u;
+    bool alive = false, fresh = false; uint32_t r = 0u, rng = 0u;
     if (i < n) {
       r = reader_index(rd, i);
       slot = qs.slot[qIn][r];
+      if (!ANYHIT) { fresh = (slot & TRACE_FRESH) != 0u; slot &= ~TRACE_FRESH; } // camera ray of a path whose Slot is still unwritten (FLAG_DEFER_SLOT)
       ro = ld4(&qs.a[qIn][r]);
       rdir = ld4(&qs.b[qIn][r]);
-      rng = CUTOUT ? (ANYHIT ? f2u(rdir.w) : f2u(st.slots[slot].rad.w)) : 0u; // the any-hit test needs the path's rng state (shadow rays carry their copy)
+      rng = CUTOUT ? (ANYHIT ? f2u(rdir.w) : (fresh ? qs.fresh[qIn - Q_TRACE_A][r].rng : f2u(st.slots[slot].rad.w))) : 0u; // the any-hit test needs the path's rng state (shadow rays carry their copy)
       // shadow ray (rp_main.rgen:397-429): origin = next ray origin, tMin 0.01, tMax = distance to the light sample
       if (!ANYHIT) trav_init(R, v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), ro.w, rdir.w);
       else trav_init(R, v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), 0.01f, ro.w);
@@ -235,6 +263,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
       // sort by outcome and material class: hits go to their class's shade queue as (slot, hit, direction) records, misses
       // straight to k_raygen
       uint32_t klass = (mat >> 24) & 0xfu;
+      bool retired = false;
+      if (fresh) { // first segment of a path k_raygen did not write: begin it now (hit, or a miss that needs the slot), or retire it here
+        const FreshRec f = qs.fresh[qIn - Q_TRACE_A][r];
+        if (hit || (DOME && (sc.domeTexture != 0u || sc.mediumStackSize != 0u))) begin_fresh_path(U, st, slot, f);
+        else { retire_fresh_miss(U, f, sampleBuf); retired = true; }
+      }
       bool volMiss = false; // the segment ended inside a medium: a scattering event for k_shade<2>, not a miss (rp_main.miss:57-66)
       if (DOME && miss && sc.mediumStackSize) {
         volMiss = payload_medium_idx(f2u(st.slots[slot].thr.w), sc.mediumStackSize < MAX_MEDIUM_STACK ? sc.mediumStackSize : MAX_MEDIUM_STACK) > 0u;
@@ -253,7 +287,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
       }
       if (miss) {
         if (DOME && sc.domeTexture) { dome_miss(sc, st, slot, v3(rdir.x, rdir.y, rdir.z)); qs.slot[qMiss][idx[0]] = slot; } // scene has a dome light image
-        else qs.slot[qMiss][idx[0]] = slot | REGEN_MISSED;
+        else qs.slot[qMiss][idx[0]] = slot | (retired ? REGEN_FRESH : REGEN_MISSED);
       }
     }
   }
@@ -361,7 +395,10 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
       prec = reader_index(rd, base + lane);
       pro = ld4(&qs.a[qIn][prec]);
       prd = ld4(&qs.b[qIn][prec]);
-      if (CUTOUT) prng = ANYHIT ? f2u(prd.w) : f2u(st.slots[qs.slot[qIn][prec]].rad.w); // the any-hit test needs the path's rng state (shadow rays carry their copy)
+      if (CUTOUT) { // the any-hit test needs the path's rng state (shadow rays carry their copy; a camera ray whose Slot is still unwritten has it beside the record)
+        if (ANYHIT) prng = f2u(prd.w);
+        else { const uint32_t sw = qs.slot[qIn][prec]; prng = (sw & TRACE_FRESH) ? qs.fresh[qIn - Q_TRACE_A][prec].rng : f2u(st.slots[sw].rad.w); }
+      }
     }
   };
   next_chunk();
@@ -440,7 +477,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 
 }
 
 // k_route: sorts k_trace_dyn's in-place results by outcome and material class (same routing as k_trace's epilogue)
-__global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t qMiss)
+__global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t qMiss, FrameUniforms U, F4* __restrict__ sampleBuf)
 {
   __shared__ AppendScratch<1 + MAT_CLASS_COUNT> sh;
   QueueReader rd; reader_init(rd, cnt, qIn, qs.cap);
@@ -449,15 +486,21 @@ __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, Que
   uint32_t trip = 0;
   for (uint32_t base = blockIdx.x * BLOCK; base < n; base += stride, trip++) {
     const uint32_t i = base + threadIdx.x;
-    bool hit = false, miss = false, volMiss = false; uint32_t slot = 0, klass = 0;
+    bool hit = false, miss = false, volMiss = false, retired = false; uint32_t slot = 0, klass = 0;
     F4 h = F4{0.0f, 0.0f, 0.0f, 0.0f}, rdir = F4{0.0f, 0.0f, 0.0f, 0.0f};
     if (i < n) {
       const uint32_t r = reader_index(rd, i);
       slot = qs.slot[qIn][r];
+      const bool fresh = (slot & TRACE_FRESH) != 0u; slot &= ~TRACE_FRESH; // camera ray of a path whose Slot is still unwritten (FLAG_DEFER_SLOT)
       h = ld4(&qs.a[qIn][r]);
       rdir = ld4(&qs.b[qIn][r]);
       hit = f2u(h.w) != MISS; miss = !hit;
       klass = (f2u(rdir.w) >> 24) & 0xfu;
+      if (fresh) { // begin the path now (hit, or a miss that needs the slot: dome image / medium stack), or retire the sample here without a Slot
+        const FreshRec f = qs.fresh[qIn - Q_TRACE_A][r];
+        if (hit || sc.domeTexture != 0u || sc.mediumStackSize != 0u) begin_fresh_path(U, st, slot, f);
+        else { retire_fresh_miss(U, f, sampleBuf); retired = true; }
+      }
       if (miss && sc.mediumStackSize) { // the segment ended inside a medium: scattering event for k_shade<2> (rp_main.miss:57-66)
         volMiss = payload_medium_idx(f2u(st.slots[slot].thr.w), sc.mediumStackSize < MAX_MEDIUM_STACK ? sc.mediumStackSize : MAX_MEDIUM_STACK) > 0u;
         if (volMiss) { miss = false; klass = 2u; }
@@ -476,7 +519,7 @@ __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, Que
     }
     if (miss) {
       if (sc.domeTexture) { dome_miss(sc, st, slot, v3(rdir.x, rdir.y, rdir.z)); qs.slot[qMiss][idx[0]] = slot; }
-      else qs.slot[qMiss][idx[0]] = slot | REGEN_MISSED;
+      else qs.slot[qMiss][idx[0]] = slot | (retired ? REGEN_FRESH : REGEN_MISSED);
     }
   }
 }
@@ -717,7 +760,7 @@ void traceLdsLayout(const SceneView& sc, uint32_t& ldsNodes, uint32_t& ldsTris, 
 }
 template <bool ANYHIT, bool COUNT, bool CUTOUT>
 static void launchTraceVariant(hipStream_t s, uint32_t blocks, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t qMiss,
-                               uint32_t dynRefill, uint32_t routeBlocks)
+                               uint32_t dynRefill, uint32_t routeBlocks, const FrameUniforms& U, F4* sampleBuf)
 {
   uint32_t ln, lt, bytes; traceLdsLayout(sc, ln, lt, bytes);
   const bool allLds = ln == sc.nodeCount && lt == sc.triCount && sc.triCount > 0u; // the whole scene is staged in LDS
@@ -726,7 +769,7 @@ static void launchTraceVariant(hipStream_t s, uint32_t blocks, const SceneView& 
     // resident waves) and spill the rest (TRACE_DYN_SPILL8), or keep 16 in LDS
     if (sc.twoLevel) { // instanced scene: TLAS + shared per-mesh BLASes
       hipLaunchKernelGGL((k_trace_dyn2<ANYHIT, COUNT, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), 16u * TRACE_BLOCK * (uint32_t)sizeof(uint2), s, sc, st, qs, cnt, qIn, (dynRefill & 0xffu) | ((dynRefill >> 16) << 16));
-      if (!ANYHIT) hipLaunchKernelGGL(k_route, dim3(routeBlocks), dim3(BLOCK), 0, s, sc, st, qs, cnt, qIn, qMiss);
+      if (!ANYHIT) hipLaunchKernelGGL(k_route, dim3(routeBlocks), dim3(BLOCK), 0, s, sc, st, qs, cnt, qIn, qMiss, U, sampleBuf);
       return;
     }
     const bool spill8 = (dynRefill & TRACE_DYN_SPILL8) != 0u;
@@ -748,7 +791,7 @@ static void launchTraceVariant(hipStream_t s, uint32_t blocks, const SceneView& 
     static const int envWaves = getenv("GATLING_DYN_WAVES") ? atoi(getenv("GATLING_DYN_WAVES")) : 5;
     if (envWaves == 6 && !COUNT && sc.bvhDepth <= 8u) {
       hipLaunchKernelGGL((k_trace_dyn6<ANYHIT, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill, dynLdsNodes, dynFlags);
-      if (!ANYHIT) hipLaunchKernelGGL(k_route, dim3(routeBlocks), dim3(BLOCK), 0, s, sc, st, qs, cnt, qIn, qMiss);
+      if (!ANYHIT) hipLaunchKernelGGL(k_route, dim3(routeBlocks), dim3(BLOCK), 0, s, sc, st, qs, cnt, qIn, qMiss, U, sampleBuf);
       return;
     }
 #define GI_LAUNCH_DYN(K) do { \
@@ -759,13 +802,13 @@ static void launchTraceVariant(hipStream_t s, uint32_t blocks, const SceneView& 
     else hipLaunchKernelGGL((K<ANYHIT, COUNT, 16, true, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill, dynLdsNodes, dynFlags); } while (0)
     GI_LAUNCH_DYN(k_trace_dyn);
 #undef GI_LAUNCH_DYN
-    if (!ANYHIT) hipLaunchKernelGGL(k_route, dim3(routeBlocks), dim3(BLOCK), 0, s, sc, st, qs, cnt, qIn, qMiss);
+    if (!ANYHIT) hipLaunchKernelGGL(k_route, dim3(routeBlocks), dim3(BLOCK), 0, s, sc, st, qs, cnt, qIn, qMiss, U, sampleBuf);
     return;
   }
   const bool dome = !ANYHIT && (sc.domeTexture != 0u || sc.mediumStackSize != 0u); // misses need the slot: dome image lookup / scattering events
 #define GI_LAUNCH_TRACE(STACK, OVF, LDS) do { \
-    if (dome) hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, STACK, OVF, LDS, CUTOUT, !ANYHIT>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt); \
-    else hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, STACK, OVF, LDS, CUTOUT, false>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt); } while (0)
+    if (dome) hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, STACK, OVF, LDS, CUTOUT, !ANYHIT>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt, U, sampleBuf); \
+    else hipLaunchKernelGGL((k_trace<ANYHIT, COUNT, STACK, OVF, LDS, CUTOUT, false>), dim3(blocks), dim3(TRACE_BLOCK), bytes, s, sc, st, qs, cnt, qIn, qMiss, ln, lt, U, sampleBuf); } while (0)
   if (allLds && sc.bvhDepth <= 4u) GI_LAUNCH_TRACE(4, false, true);
   else if (allLds && sc.bvhDepth <= 8u) GI_LAUNCH_TRACE(8, false, true);
   else if (sc.bvhDepth <= 8u) GI_LAUNCH_TRACE(8, false, false);
@@ -775,17 +818,18 @@ static void launchTraceVariant(hipStream_t s, uint32_t blocks, const SceneView& 
 }
 template <bool ANYHIT, bool COUNT>
 static void launchTraceCutout(hipStream_t s, uint32_t blocks, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t qMiss,
-                              uint32_t dynRefill, uint32_t routeBlocks)
+                              uint32_t dynRefill, uint32_t routeBlocks, const FrameUniforms& U, F4* sampleBuf)
 {
-  if (sc.hasCutouts) launchTraceVariant<ANYHIT, COUNT, true>(s, blocks, sc, st, qs, cnt, qIn, qMiss, dynRefill, routeBlocks);
-  else launchTraceVariant<ANYHIT, COUNT, false>(s, blocks, sc, st, qs, cnt, qIn, qMiss, dynRefill, routeBlocks);
+  if (sc.hasCutouts) launchTraceVariant<ANYHIT, COUNT, true>(s, blocks, sc, st, qs, cnt, qIn, qMiss, dynRefill, routeBlocks, U, sampleBuf);
+  else launchTraceVariant<ANYHIT, COUNT, false>(s, blocks, sc, st, qs, cnt, qIn, qMiss, dynRefill, routeBlocks, U, sampleBuf);
 }
+// U / sampleBuf: the frame's uniforms and per-sample colour buffer -- read only when the queue holds camera rays flagged TRACE_FRESH (FLAG_DEFER_SLOT)
 void launchTrace(hipStream_t s, uint32_t blocks, bool anyHit, bool count, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt,
-                 uint32_t qIn, uint32_t qMiss, uint32_t dynRefill, uint32_t routeBlocks)
+                 uint32_t qIn, uint32_t qMiss, uint32_t dynRefill, uint32_t routeBlocks, const FrameUniforms& U, F4* sampleBuf)
 {
   if ((dynRefill & 0xffu) > 64u) dynRefill = (dynRefill & ~0xffu) | 64u;
-  if (!anyHit) { if (count) launchTraceCutout<false, true>(s, blocks, sc, st, qs, cnt, qIn, qMiss, dynRefill, routeBlocks); else launchTraceCutout<false, false>(s, blocks, sc, st, qs, cnt, qIn, qMiss, dynRefill, routeBlocks); }
-  else { if (count) launchTraceCutout<true, true>(s, blocks, sc, st, qs, cnt, qIn, qMiss, dynRefill, routeBlocks); else launchTraceCutout<true, false>(s, blocks, sc, st, qs, cnt, qIn, qMiss, dynRefill, routeBlocks); }
+  if (!anyHit) { if (count) launchTraceCutout<false, true>(s, blocks, sc, st, qs, cnt, qIn, qMiss, dynRefill, routeBlocks, U, sampleBuf); else launchTraceCutout<false, false>(s, blocks, sc, st, qs, cnt, qIn, qMiss, dynRefill, routeBlocks, U, sampleBuf); }
+  else { if (count) launchTraceCutout<true, true>(s, blocks, sc, st, qs, cnt, qIn, qMiss, dynRefill, routeBlocks, U, sampleBuf); else launchTraceCutout<true, false>(s, blocks, sc, st, qs, cnt, qIn, qMiss, dynRefill, routeBlocks, U, sampleBuf); }
 }
 void launchAov(hipStream_t s, const FrameUniforms& U, const SceneView& sc, const AovTargets& A)
 {

@@ -105,6 +105,7 @@ __device__ __forceinline__ size_t sample_record(const FrameUniforms& U, uint32_t
   return (U.flags & FLAG_PIXEL_MAJOR) ? (size_t)pixelLocal * U.batchSamples + sLocal : (size_t)sLocal * U.pixelCount + pixelLocal;
 }
 constexpr uint32_t MISS = 0xffffffffu;
+constexpr uint32_t TRACE_FRESH = 0x80000000u;  // flag on a TRACE-queue slot word (FLAG_DEFER_SLOT): a camera ray whose Slot is still unwritten -- QueueSet::fresh holds its rng / work item
 constexpr uint32_t REGEN_MISSED = 0x80000000u; // flag on a regen-queue entry: the path left the scene (k_trace -> k_raygen)
 constexpr uint32_t REGEN_FRESH = 0x40000000u;  // flag on a regen-queue entry written by k_init: the slot carries no sample yet and its memory is uninitialised -- k_raygen
                                                // must not read it (this replaces a 64-byte write per slot in k_init: 4 GB and 2 ms per batch for the 64 Mi-slot pool)

@@ -142,6 +142,8 @@ struct FrameUniforms {
 enum : uint32_t {
   FLAG_JITTER = 1u, FLAG_FIS = 2u, FLAG_DOF = 4u, FLAG_CLIP = 8u, FLAG_NEE = 16u, FLAG_PROGRESSIVE = 32u,
   FLAG_PIXEL_MAJOR = 64u, // work order of the wavefront pipeline (gi_queues.h work_item)
+  FLAG_DEFER_SLOT = 128u, // wavefront pipeline: k_raygen does not write the Slot of a new camera path; its (rng, work item) travel beside the ray record and the
+                          // slot is written when the first segment HITS (k_route / k_trace); a camera ray that leaves the scene retires without ever touching a slot
 };
 
 // Device-side scene view handed to the kernels.
@@ -249,7 +251,9 @@ constexpr uint32_t MAT_CLASS_COUNT = 3;
 enum : uint32_t { Q_TRACE_A = 0, Q_TRACE_B = 1, Q_REGEN_A = 2, Q_REGEN_B = 3, Q_SHADOW = 4, Q_HIT = 5, Q_COUNT = Q_HIT + MAT_CLASS_COUNT };
 constexpr uint32_t NSHARD = 8;
 constexpr uint32_t NCURSOR = 8;
+struct FreshRec { uint32_t rng, work; }; // beside a camera ray's record (FLAG_DEFER_SLOT): rng state after the camera draws, work item id of the batch
 struct QueueSet {
+  FreshRec* fresh[2];      // TRACE_A / TRACE_B only; valid where the queue's slot word carries TRACE_FRESH
   uint32_t* slot[Q_COUNT]; // each NSHARD * cap entries
   F4* a[Q_COUNT];          // null where the queue has no such field
   F4* b[Q_COUNT];

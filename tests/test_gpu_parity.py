@@ -258,6 +258,34 @@ def test_work_order_invariance(gi, orc, monkeypatch, w, h, spp, mb):
             assert_image_parity(img, ref, exact=True)
 
 
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_deferred_slot_initialisation_is_invisible(gi, monkeypatch, name):
+    """FLAG_DEFER_SLOT (r04): k_raygen no longer writes a new path's Slot; its rng / work item travel beside the camera ray and the slot is written where the first
+    segment hits -- a camera ray that leaves the scene retires in k_route / k_trace without one.  Every golden fixture (open cornell box, dome image, medium stacks,
+    instanced spheres under a constant background, cutout cards, interior with NEE) through the wavefront stage kernels with the deferral on (default), off, with
+    a small pool (slots recycled many times: stale slot contents must never be read) and with the block-synchronous k_trace: the committed image, bit for bit."""
+    desc, rs, w, h = build_case(name)
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    for defer, pool, dyn in (("1", 0, -1), ("0", 0, -1), ("1", 301, -1), ("1", 0, 0), ("0", 301, 0)):
+        monkeypatch.setenv("GATLING_DEFER_SLOT", defer)
+        sc = gi.Scene(desc)
+        try:
+            sc.set_option(gi.OPTION_FUSED_PATH, 0)
+            if pool:
+                sc.set_option(gi.OPTION_POOL_SLOTS, pool)
+            sc.set_option(gi.OPTION_TRACE_DYNAMIC, dyn)
+            img = sc.render(rs, w, h)
+            st = sc.stats()
+            import copy
+            rs2 = copy.copy(rs); rs2.progressive_accumulation = False
+            again = sc.render(rs2, w, h)  # (a second frame from sample 0 over the same pool: every slot holds a finished path's leftovers)
+        finally:
+            sc.close()
+        assert st["fusedPath"] == 0 and st["segments"] == int(g["segments"]) and st["shadowRays"] == int(g["shadow_rays"]), (defer, pool, dyn)
+        assert_image_parity(img, g["color"], exact=True)
+        assert_image_parity(again, g["color"], exact=True)
+
+
 def _aov_scene():
     desc = sphere_grid(grid=3, subdivisions=1, material_count=4)
     rng = np.random.default_rng(8)
