@@ -21,6 +21,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -52,17 +54,30 @@ void setError(const std::string& e) { t_lastError = e; fprintf(stderr, "[gatling
 // One entry per HIP device the library renders on (giCInitializeDevices / $GATLING_DEVICES; giCInitialize: one).  devs[0] is the PRIMARY device:
 // render buffers, textures and every single-device entry point live there; the others hold replicas of the scene and render row shares.
 struct DevCtx { int device = 0; int cuCount = 256; hipStream_t stream = nullptr; };
+// One host thread per further device, created with the first multi-device render and kept until giCTerminate (a frame's share is handed to it as a job; until
+// r04 every frame created and joined its own std::threads).  The thread binds its HIP device once.
+struct DeviceWorker {
+  std::thread th; std::mutex m; std::condition_variable cv;
+  std::function<void()> job; bool busy = false, stop = false;
+  void start() { th = std::thread([this] { std::unique_lock<std::mutex> lk(m); for (;;) { cv.wait(lk, [this] { return busy || stop; }); if (stop) return; lk.unlock(); job(); lk.lock(); busy = false; cv.notify_all(); } }); }
+  void post(std::function<void()> fn) { { std::lock_guard<std::mutex> lk(m); job = std::move(fn); busy = true; } cv.notify_all(); }
+  void wait() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [this] { return !busy; }); }
+  void shutdown() { { std::lock_guard<std::mutex> lk(m); stop = true; } cv.notify_all(); if (th.joinable()) th.join(); }
+};
 struct Context {
   bool initialized = false;
   int device = 0;               // == devs[0].device
   int cuCount = 256;            // == devs[0].cuCount
   hipStream_t stream = nullptr; // == devs[0].stream
   std::vector<DevCtx> devs;
+  std::vector<std::unique_ptr<DeviceWorker>> workers; // [slot - 1], made on demand (renderOnDevices)
+  std::mutex workerMutex;   // one multi-device frame at a time owns the workers (two scenes may render concurrently)
   std::mutex resourceMutex; // GPU resource destruction from sync threads (Gi.cpp:679-683)
 } g_ctx;
 
 double nowMs() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+constexpr int GI_C_OUT_OF_MEMORY_INTERNAL = -77; // DeviceBuffer::alloc: hipErrorOutOfMemory (never returned through the C ABI)
 template <typename T>
 struct DeviceBuffer {
   T* ptr = nullptr;
@@ -72,10 +87,17 @@ struct DeviceBuffer {
     if (n <= count && ptr) return GI_C_OK;
     release();
     if (n == 0) n = 1;
-    HIP_TRY(hipMalloc((void**)&ptr, n * sizeof(T)));
+    const hipError_t e = hipMalloc((void**)&ptr, n * sizeof(T));
+    if (e != hipSuccess) {
+      ptr = nullptr;
+      // out of memory is an answer the render loop acts on (more batches, a smaller pool: renderOnDevice), not yet an error
+      if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); t_lastError = "hipMalloc: out of memory"; return GI_C_OUT_OF_MEMORY_INTERNAL; }
+      setError(std::string("hipMalloc: ") + hipGetErrorString(e)); return GI_C_ERROR;
+    }
     count = n;
     return GI_C_OK;
   }
+  size_t bytes() const { return ptr ? count * sizeof(T) : 0; }
   int upload(const std::vector<T>& v, hipStream_t s)
   {
     if (alloc(v.size()) != GI_C_OK) return GI_C_ERROR;
@@ -459,6 +481,8 @@ uint32_t giCGetDeviceCount(void) { return g_ctx.initialized ? (uint32_t)g_ctx.de
 void giCTerminate(void)
 {
   if (!g_ctx.initialized) return;
+  for (auto& w : g_ctx.workers) if (w) w->shutdown();
+  g_ctx.workers.clear();
   for (DevCtx& c : g_ctx.devs) {
     (void)hipSetDevice(c.device);
     (void)hipStreamSynchronize(c.stream);
@@ -1509,19 +1533,22 @@ uint32_t shardCapacity(size_t slots, uint32_t gridA, uint32_t gridB)
 int ensurePathState(SceneDevice* s, size_t slots, uint32_t gridA, uint32_t gridB)
 {
   const uint32_t cap = shardCapacity(slots, gridA, gridB);
-  if (s->slots.alloc(slots)) return GI_C_ERROR;
-  if (!s->dCounters.ptr) { if (s->dCounters.alloc(1)) return GI_C_ERROR; HIP_TRY(hipMemset(s->dCounters.ptr, 0, sizeof(Counters))); } // AOV-only renders never run k_init
+  int rc;
+#define GI_ALLOC(x) do { rc = (x); if (rc != GI_C_OK) return rc; } while (0) /* GI_C_ERROR, or GI_C_OUT_OF_MEMORY_INTERNAL for the caller's fallback */
+  GI_ALLOC(s->slots.alloc(slots));
+  if (!s->dCounters.ptr) { GI_ALLOC(s->dCounters.alloc(1)); HIP_TRY(hipMemset(s->dCounters.ptr, 0, sizeof(Counters))); } // AOV-only renders never run k_init
   if (cap > s->queueCap) {
     const size_t n = (size_t)cap * NSHARD;
     for (uint32_t q = 0; q < Q_COUNT; q++) {
       const bool hasRecord = (q == Q_TRACE_A || q == Q_TRACE_B || q >= Q_HIT || q == Q_SHADOW);
-      if (s->qSlot[q].alloc(n)) return GI_C_ERROR;
-      if (hasRecord && (s->qA[q].alloc(n) || s->qB[q].alloc(n))) return GI_C_ERROR;
-      if (q == Q_SHADOW && s->qC[q].alloc(n)) return GI_C_ERROR;
-      if ((q == Q_TRACE_A || q == Q_TRACE_B) && s->qFresh[q - Q_TRACE_A].alloc(n)) return GI_C_ERROR;
+      GI_ALLOC(s->qSlot[q].alloc(n));
+      if (hasRecord) { GI_ALLOC(s->qA[q].alloc(n)); GI_ALLOC(s->qB[q].alloc(n)); }
+      if (q == Q_SHADOW) GI_ALLOC(s->qC[q].alloc(n));
+      if (q == Q_TRACE_A || q == Q_TRACE_B) GI_ALLOC(s->qFresh[q - Q_TRACE_A].alloc(n));
     }
     s->queueCap = cap;
   }
+#undef GI_ALLOC
   if (!s->hCounters) HIP_TRY(hipHostMalloc((void**)&s->hCounters, sizeof(Counters), hipHostMallocDefault));
   if (!s->hPoll) {
     HIP_TRY(hipHostMalloc((void**)&s->hPoll, sizeof(PaddedCounter) * Q_COUNT * NSHARD * SceneDevice::POLL_RING, hipHostMallocDefault));
@@ -1960,10 +1987,13 @@ static int renderOnDevices(GiCScene* s, uint32_t nDev, const RenderJob& frame)
     catch (const std::exception& e) { rcs[d] = GI_C_ERROR; t_lastError = e.what(); }
     if (rcs[d] != GI_C_OK) errs[d] = t_lastError; // (thread-local)
   };
-  std::vector<std::thread> threads;
-  for (uint32_t d = 1; d < nDev; d++) threads.emplace_back(work, d);
-  work(0u);
-  for (std::thread& t : threads) t.join();
+  {
+    std::lock_guard<std::mutex> own(g_ctx.workerMutex);
+    while (g_ctx.workers.size() + 1u < nDev) { g_ctx.workers.emplace_back(new DeviceWorker()); g_ctx.workers.back()->start(); }
+    for (uint32_t d = 1; d < nDev; d++) g_ctx.workers[d - 1u]->post([&work, d] { work(d); });
+    work(0u);
+    for (uint32_t d = 1; d < nDev; d++) g_ctx.workers[d - 1u]->wait();
+  }
   HIP_TRY(hipSetDevice(g_ctx.device));
   for (uint32_t d = 0; d < nDev; d++) if (rcs[d] != GI_C_OK) { setError("device " + std::to_string(g_ctx.devs[d].device) + ": " + errs[d]); return GI_C_ERROR; }
   // gather: rows d::nDev of device d -> the same rows of the primary's buffer, then the D2H of the whole frame

@@ -433,10 +433,13 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
       wave_ray_end(W, R);
       if constexpr (TWO) { if (!ANYHIT && R.found) R.bestTri = sc.flatOfOrig[R.bestTri]; } // scene-order id -> index of the hit's TriRec
       if (!ANYHIT) {
-        if (R.found) { st4(&qs.a[qIn][rec], R.tBest, R.bestU, R.bestV, u2f(R.bestTri)); reinterpret_cast<uint32_t*>(&qs.b[qIn][rec])[3] = R.bestMat; }
-        else { // (tMax, origin): k_route needs them for scattering events
+        // ONE 16-byte store per finished ray: the material class k_route sorts by rides in the top four bits of the triangle word (triangle indices keep to
+        // TRI_ID_BITS = 26).  Until r04 the material word went into b.w as a second, 4-byte store into another line -- a second 32-byte sector written per ray
+        // (C3: 85 GB of write traffic per frame for 26 GB of results).
+        if (R.found) st4(&qs.a[qIn][rec], R.tBest, R.bestU, R.bestV, u2f(R.bestTri | (((R.bestMat >> 24) & 0xfu) << 28)));
+        else { // (tMax, origin): k_route needs them for scattering events (medium stacks only)
           V3 wo = R.o; if constexpr (TWO) wo = R.wo;
-          st4(&qs.a[qIn][rec], R.tBest, wo.x, wo.y, u2f(MISS)); reinterpret_cast<float*>(&qs.b[qIn][rec])[3] = wo.z;
+          st4(&qs.a[qIn][rec], R.tBest, wo.x, wo.y, u2f(MISS)); if (sc.mediumStackSize) reinterpret_cast<float*>(&qs.b[qIn][rec])[3] = wo.z;
         }
       } else {
         const uint32_t slot = qs.slot[qIn][rec];
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, Que
       h = ld4(&qs.a[qIn][r]);
       rdir = ld4(&qs.b[qIn][r]);
       hit = f2u(h.w) != MISS; miss = !hit;
-      klass = (f2u(rdir.w) >> 24) & 0xfu;
+      if (hit) { klass = f2u(h.w) >> 28; h.w = u2f(f2u(h.w) & 0x0fffffffu); } // k_trace_dyn's result word: triangle index | material class << 28
       if (fresh) { // begin the path now (hit, or a miss that needs the slot: dome image / medium stack), or retire the sample here without a Slot
         const FreshRec f = qs.fresh[qIn - Q_TRACE_A][r];
         if (hit || sc.domeTexture != 0u || sc.mediumStackSize != 0u) begin_fresh_path(U, st, slot, f);
