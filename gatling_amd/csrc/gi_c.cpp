@@ -1728,10 +1728,20 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
     // consecutive samples whose per-sample colour buffer fits the budget; a pool of `slots` paths is kept full from a running
     // work counter until the batch's items run out.
     auto envU64 = [](const char* name, uint64_t def) { const char* e = getenv(name); return e ? (uint64_t)strtoull(e, nullptr, 10) : def; };
-    // default budget of the per-sample colour buffer: 48 GiB of a 288 GB device (a sixth of whatever the device has) -- every batch ends in a drain / a kernel
-    // tail, so fewer, larger batches are cheaper: C2 (34 GB for 1024 spp at 1080p) 4 batches -> 1, 215.5 -> 213.4 ms per step; the full C5 frame 17 -> 3
-    if (!D.memTotalMb) { size_t memFree = 0, memTotal = 0; (void)hipMemGetInfo(&memFree, &memTotal); D.memTotalMb = std::max<uint64_t>(1, (uint64_t)(memTotal >> 20)); } // (asked once per device: a driver call)
-    const uint64_t defaultMb = std::max<uint64_t>(1024, std::min<uint64_t>(49152, D.memTotalMb / 6));
+    // Memory plan (r04).  The per-sample colour buffer wants to hold the whole frame's samples (every batch ends in a drain / a kernel tail: C2's 34 GB for 1024 spp at
+    // 1080p in one batch 213.4 ms per step, in four 215.5) and scenes beyond LDS want a 64 Mi-slot pool (17 GB with its queues) -- on an empty 288 GB device.  A Hydra
+    // plugin shares the device with other scenes, other processes and the host application, so the plan starts from what is FREE now (plus what this scene already
+    // holds in these buffers, which is reused), and an allocation that still fails (someone else was faster) is answered with a smaller plan -- more batches first,
+    // then a smaller pool -- never with a failed render while a workable plan exists.  Results do not depend on the plan (test_pool_and_batch_invariance).
+    size_t memFree = 0, memTotal = 0; (void)hipMemGetInfo(&memFree, &memTotal);
+    if (const char* e = getenv("GATLING_ASSUME_FREE_MB")) memFree = (size_t)strtoull(e, nullptr, 10) << 20; // tests: plan as if this much were free (a planner overtaken by another allocation: the fallback below must recover)
+    if (!D.memTotalMb) D.memTotalMb = std::max<uint64_t>(1, (uint64_t)(memTotal >> 20));
+    uint64_t held = D.sampleBuf.bytes() + D.slots.bytes() + D.media.bytes();
+    for (uint32_t q = 0; q < Q_COUNT; q++) held += D.qSlot[q].bytes() + D.qA[q].bytes() + D.qB[q].bytes() + D.qC[q].bytes();
+    held += D.qFresh[0].bytes() + D.qFresh[1].bytes();
+    const uint64_t availMb = ((uint64_t)memFree + held) >> 20;
+    const uint64_t capMb = std::max<uint64_t>(1024, std::min<uint64_t>(49152, D.memTotalMb / 6)); // the budget of an empty device: 48 GiB of 288 GB
+    const uint64_t defaultMb = std::max<uint64_t>(256, std::min<uint64_t>(capMb, availMb / 3));    // ... and a third of what is available now, 256 MiB at least
     const uint64_t budgetBytes = envU64("GATLING_SAMPLE_BUFFER_MB", s->optSampleBufferMb ? s->optSampleBufferMb : defaultMb) << 20;
     // Pool size: a launch of k_trace_dyn ends when its longest ray ends, and ray cost is heavy-tailed in scenes beyond LDS
     // (a 100-step ray outlives the average one six times over), so those scenes get a pool large enough to amortise that
@@ -1742,7 +1752,6 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
                                                 std::max<uint64_t>(64, envU64("GATLING_POOL_SLOTS", s->optPoolSlots ? s->optPoolSlots : poolDefault)));
     uint64_t batchSamples = std::min<uint64_t>(rs.spp, std::max<uint64_t>(1, budgetBytes / (pixels * 16)));
     batchSamples = std::min<uint64_t>(batchSamples, std::max<uint64_t>(1, 0xffffffffull / pixels)); // work ids stay 32-bit
-    const uint32_t numBatches = (uint32_t)((rs.spp + batchSamples - 1) / batchSamples);
     // LDS-resident scenes without medium stacks / dome images: the fused persistent kernel k_path (gi_path.hip) keeps the paths in
     // registers -- no pool, no queues; the stage kernels below remain the path for everything else (and on request: option / env)
     view.mediumStackSize = rs.mediumStackSize;
@@ -1751,11 +1760,11 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
     usedFused = fused;
     // work order of the wavefront pipeline and layout of its per-sample buffer (gi_queues.h work_item); the fused kernels hand work out sample-major
     { const char* e = getenv("GATLING_WORK_ORDER"); if (!fused && (e ? atoi(e) != 0 : WORK_ORDER_PIXEL_MAJOR_DEFAULT)) U.flags |= FLAG_PIXEL_MAJOR; }
-    const size_t slots = fused ? 1 : (size_t)std::min<uint64_t>(poolMax, (uint64_t)pixels * batchSamples);
+    size_t slots = fused ? 1 : (size_t)std::min<uint64_t>(poolMax, (uint64_t)pixels * batchSamples);
 
     // persistent grids: blocks per CU limited by registers (<= 6 waves/SIMD for k_trace) and, for k_trace, by the LDS it stages
-    uint32_t wideBlocks, traceBlocks;
-    {
+    uint32_t wideBlocks = 1u, traceBlocks = 1u;
+    auto sizeGrids = [&]() {
       SceneView v0 = makeView(s, D);
       uint32_t ln, lt, ldsBytes; traceLdsLayout(v0, ln, lt, ldsBytes);
       uint32_t perCu = std::min<uint32_t>(6u, (160u * 1024u) / (ldsBytes + traceStaticLdsBytes() + 256u));
@@ -1767,11 +1776,38 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
       perCu = std::max(perCu, 1u); widePerCu = std::max(widePerCu, 1u);
       wideBlocks = (uint32_t)std::min<size_t>((slots + 255) / 256, (size_t)ctx.cuCount * widePerCu);
       traceBlocks = (uint32_t)std::min<size_t>((slots + 255) / 256, (size_t)ctx.cuCount * perCu);
-    }
-    if (ensurePathState(&D, slots, wideBlocks, traceBlocks) != GI_C_OK) return GI_C_ERROR;
-    if (D.sampleBuf.alloc(pixels * batchSamples) || D.accum.alloc(pixels)) return GI_C_ERROR;
+    };
+    sizeGrids();
     const uint32_t mediaStride = rs.mediumStackSize ? rs.mediumStackSize * MEDIUM_FLOATS + 4u : 0u;
-    if (mediaStride && D.media.alloc(slots * mediaStride)) return GI_C_ERROR;
+    // what a plan costs: the slot pool with its queues (per slot: the Slot, the medium stack, and a share of every queue's records) and the sample buffer
+    auto planBytes = [&](size_t nSlots, uint64_t nBatch) -> uint64_t {
+      const uint64_t cap = shardCapacity(nSlots, wideBlocks, traceBlocks);
+      const uint64_t perQueueEntry = 4ull * Q_COUNT + 32ull * (2 + MAT_CLASS_COUNT + 1) + 16ull + 8ull * 2;
+      return (fused ? 0ull : (uint64_t)nSlots * (sizeof(Slot) + 4ull * mediaStride) + cap * NSHARD * perQueueEntry) + (uint64_t)pixels * nBatch * 16ull + (uint64_t)pixels * 16ull;
+    };
+    const bool pinnedPlan = getenv("GATLING_POOL_SLOTS") || s->optPoolSlots || getenv("GATLING_SAMPLE_BUFFER_MB") || s->optSampleBufferMb; // the caller's sizes are taken as given
+    auto shrink = [&]() -> bool { // the next smaller plan: halve the sample buffer down to 64 MiB (more batches), then the pool down to 64 Ki slots
+      if (batchSamples > 1 && (uint64_t)pixels * batchSamples * 16ull > (64ull << 20)) { batchSamples = std::max<uint64_t>(1, batchSamples / 2); if (!fused) slots = (size_t)std::min<uint64_t>(slots, (uint64_t)pixels * batchSamples); return true; }
+      if (!fused && slots > (64u << 10)) { slots /= 2; return true; }
+      return false;
+    };
+    if (!pinnedPlan) while (planBytes(slots, batchSamples) > (availMb << 20) - std::min<uint64_t>(availMb << 19, 512ull << 20) && shrink()) sizeGrids(); // (leave 512 MiB, or half of a tiny remainder)
+    for (int attempt = 0;; attempt++) {
+      int rc = fused ? GI_C_OK : ensurePathState(&D, slots, wideBlocks, traceBlocks);
+      if (rc == GI_C_OK) rc = D.sampleBuf.alloc(pixels * batchSamples);
+      if (rc == GI_C_OK) rc = D.accum.alloc(pixels);
+      if (rc == GI_C_OK && mediaStride) rc = D.media.alloc(slots * mediaStride);
+      if (rc == GI_C_OK) break;
+      if (rc != GI_C_OUT_OF_MEMORY_INTERNAL) return GI_C_ERROR;
+      // out of memory: drop what this scene holds in the resizable buffers (a half-grown plan must not stand in the way of the smaller one) and try the next plan
+      D.sampleBuf.release(); D.slots.release(); D.media.release();
+      for (uint32_t q = 0; q < Q_COUNT; q++) { D.qSlot[q].release(); D.qA[q].release(); D.qB[q].release(); D.qC[q].release(); }
+      D.qFresh[0].release(); D.qFresh[1].release(); D.queueCap = 0;
+      if (attempt >= 40 || !shrink()) { setError("giCRender: out of device memory even with the smallest sample buffer and path pool"); return GI_C_ERROR; }
+      sizeGrids();
+    }
+    const uint32_t numBatches = (uint32_t)((rs.spp + batchSamples - 1) / batchSamples);
+    D.stats.poolSlots = fused ? 0u : (uint32_t)slots; D.stats.batches = numBatches;
     PathState ps{D.slots.ptr, D.media.ptr, mediaStride, nullptr, 0u, nullptr};
     if (neeRb && rs.nextEventEstimation) { // the reference compiles the NEE AOV write out with NEXT_EVENT_ESTIMATION (rp_main.rgen:397, 431)
       if (D.neeKey.alloc(pixels)) return GI_C_ERROR;

@@ -280,6 +280,8 @@ typedef struct GiCRenderStats {
   uint32_t nodeCount;    /* BVH8 nodes                                                      */
   uint32_t triangleCount;
   uint32_t fusedPath;    /* 1: the colour pass ran as the fused persistent kernel k_path (LDS-resident scene) */
+  uint32_t batches;      /* sample batches the frame was cut into (per-sample colour buffer budget; memory plan of giCRender) */
+  uint32_t poolSlots;    /* slots of the persistent path pool this render used (0: fused kernel)                              */
   uint32_t reserved0;
 } GiCRenderStats;
 

@@ -2071,16 +2071,19 @@ int orc_render_rows(const OrcScene* scene, const OrcCamera* camera, const OrcSet
   Prepared P; prepare(scene, P);
   Frame F; make_frame(F, P, camera, settings, region);
   if (threads <= 0) threads = 1;
-  uint32_t rows = rowCount;
+  // work unit: 32 pixels of one row (whole rows left a 2-row request of a 4K frame on 2 of 256 cores: 13 minutes for 8 M samples)
+  const uint32_t CHUNK = 32u, chunksPerRow = (F.width + CHUNK - 1u) / CHUNK;
+  const uint64_t units = (uint64_t)rowCount * chunksPerRow;
   std::vector<OrcCounters> tc((size_t)threads);
   for (auto& c : tc) memset(&c, 0, sizeof(c));
-  std::atomic<uint32_t> nextRow{0};
+  std::atomic<uint64_t> nextUnit{0};
   auto work = [&](int ti) {
     for (;;) {
-      uint32_t r = nextRow.fetch_add(1);
-      if (r >= rows) break;
+      const uint64_t u = nextUnit.fetch_add(1);
+      if (u >= units) break;
+      const uint32_t r = (uint32_t)(u / chunksPerRow), x0 = (uint32_t)(u % chunksPerRow) * CHUNK, x1 = x0 + CHUNK < F.width ? x0 + CHUNK : F.width;
       uint32_t y = rowList[r];
-      for (uint32_t x = 0; x < F.width; x++) {
+      for (uint32_t x = x0; x < x1; x++) {
         size_t o = ((size_t)r * F.width + x) * 4;
         render_pixel(F, x, y, prevColor ? prevColor + o : nullptr, colorOut + o, tc[(size_t)ti]);
       }
