@@ -318,6 +318,10 @@ constexpr bool DYN_XCD_RANGES_DEFAULT = false;   // (GATLING_DYN_XCD)
 #ifndef GI_DYN_LDS_NODES
 #define GI_DYN_LDS_NODES 0
 #endif
+#ifndef GI_DYN_DEFER_FINISH
+#define GI_DYN_DEFER_FINISH 1
+#endif
+constexpr bool DYN_DEFER_FINISH = GI_DYN_DEFER_FINISH != 0;
 #ifndef GI_DYN_WAVES
 #define GI_DYN_WAVES 5
 #endif
@@ -401,11 +405,41 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
       }
     }
   };
+  // A finished ray's result is written when its lane is REFILLED, not in the step it ends (DYN_DEFER_FINISH): some lane of a wave ends in nearly every step (64 lanes,
+  // ~18 steps per ray), so the ~60-instruction finish ran almost every step at 3 of 64 lanes; the refill runs every third step (refill threshold 8) for all the
+  // lanes that ended since.  The result waits in the lane's registers and its LDS hit record, which nothing touches before wave_ray_begin.
+  bool pendingEnd = false;
+  auto finish_ray = [&]() {
+    pendingEnd = false;
+      wave_ray_end(W, R);
+      if constexpr (TWO) { if (!ANYHIT && R.found) R.bestTri = sc.flatOfOrig[R.bestTri]; } // scene-order id -> index of the hit's TriRec
+      if (!ANYHIT) {
+        // ONE 16-byte store per finished ray: the material class k_route sorts by rides in the top four bits of the triangle word (triangle indices keep to
+        // TRI_ID_BITS = 26).  Until r04 the material word went into b.w as a second, 4-byte store into another line -- a second 32-byte sector written per ray
+        // (C3: 85 GB of write traffic per frame for 26 GB of results).
+        if (R.found) st4(&qs.a[qIn][rec], R.tBest, R.bestU, R.bestV, u2f(R.bestTri | (((R.bestMat >> 24) & 0xfu) << 28)));
+        else { // (tMax, origin): k_route needs them for scattering events (medium stacks only)
+          V3 wo = R.o; if constexpr (TWO) wo = R.wo;
+          st4(&qs.a[qIn][rec], R.tBest, wo.x, wo.y, u2f(MISS)); if (sc.mediumStackSize) reinterpret_cast<float*>(&qs.b[qIn][rec])[3] = wo.z;
+        }
+      } else {
+        const uint32_t slot = qs.slot[qIn][rec];
+        F4 nc = F4{0.0f, 0.0f, 0.0f, 0.0f}; // (neeContrib, 1 = emitted at bounce 0)
+        if (!R.found || st.neeKey) nc = ld4(&qs.c[qIn][rec]);
+        if (!R.found) {
+          Slot* S = &st.slots[slot];
+          F4 rr = ld4(&S->rad);
+          st4(&S->rad, rr.x + nc.x, rr.y + nc.y, rr.z + nc.z, rr.w);
+        }
+        if (st.neeKey && nc.w != 0.0f) nee_aov_record(st, slot, R.found);
+      }
+  };
   next_chunk();
   for (;;) {
     const unsigned long long idle = __ballot(!alive);
     const uint32_t nIdle = (uint32_t)__popcll(idle);
     if (nIdle >= refill && chunkUsed < chunkCount) {
+      if (pendingEnd) finish_ray();
       const uint32_t avail = chunkCount - chunkUsed, take = nIdle < avail ? nIdle : avail;
       const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
       const int src = (int)((chunkUsed + rank) & 63u);
@@ -430,30 +464,10 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
     else done = wave_step_carry<ANYHIT, COUNT, STACK, OVERFLOW, CUTOUT>(R, alive, draining, lastEnd, ringHead, ringTail, flushAt, W, sc, s_nodes, ldsNodes, s_stack, overflow, tc, rng);
     if (alive && done) {
       alive = false;
-      wave_ray_end(W, R);
-      if constexpr (TWO) { if (!ANYHIT && R.found) R.bestTri = sc.flatOfOrig[R.bestTri]; } // scene-order id -> index of the hit's TriRec
-      if (!ANYHIT) {
-        // ONE 16-byte store per finished ray: the material class k_route sorts by rides in the top four bits of the triangle word (triangle indices keep to
-        // TRI_ID_BITS = 26).  Until r04 the material word went into b.w as a second, 4-byte store into another line -- a second 32-byte sector written per ray
-        // (C3: 85 GB of write traffic per frame for 26 GB of results).
-        if (R.found) st4(&qs.a[qIn][rec], R.tBest, R.bestU, R.bestV, u2f(R.bestTri | (((R.bestMat >> 24) & 0xfu) << 28)));
-        else { // (tMax, origin): k_route needs them for scattering events (medium stacks only)
-          V3 wo = R.o; if constexpr (TWO) wo = R.wo;
-          st4(&qs.a[qIn][rec], R.tBest, wo.x, wo.y, u2f(MISS)); if (sc.mediumStackSize) reinterpret_cast<float*>(&qs.b[qIn][rec])[3] = wo.z;
-        }
-      } else {
-        const uint32_t slot = qs.slot[qIn][rec];
-        F4 nc = F4{0.0f, 0.0f, 0.0f, 0.0f}; // (neeContrib, 1 = emitted at bounce 0)
-        if (!R.found || st.neeKey) nc = ld4(&qs.c[qIn][rec]);
-        if (!R.found) {
-          Slot* S = &st.slots[slot];
-          F4 rr = ld4(&S->rad);
-          st4(&S->rad, rr.x + nc.x, rr.y + nc.y, rr.z + nc.z, rr.w);
-        }
-        if (st.neeKey && nc.w != 0.0f) nee_aov_record(st, slot, R.found);
-      }
+      if (DYN_DEFER_FINISH) pendingEnd = true; else finish_ray();
     }
   }
+  if (pendingEnd) finish_ray(); // rays that ended after the launch's last refill
   if (COUNT) { // measurement builds only: one atomic pair per wave
     unsigned long long a = tc.nodes, b = tc.tris;
     for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
@@ -531,10 +545,13 @@ __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, Que
 // k_shade: closest-hit shading + the post-trace part of the bounce loop, over the HIT queue only
 // (rp_main.chit:132-493, rp_main.rgen:397-480).  Misses never get here (k_trace routes them to k_raygen).
 // ------------------------------------------------------------------------------------------------
+#ifndef GI_SHADE_NEE_WAVES
+#define GI_SHADE_NEE_WAVES 4
+#endif
 template <uint32_t KLASS, bool TEXTURED, bool VOLUME, bool NEE, bool PACKED>
 // (forcing the plain variant to 5 waves/SIMD -- amdgpu_waves_per_eu((...) ? 5 : 1, 8): 90 VGPRs, no spills -- is SLOWER: C2 shade 178 -> 190 ms;
 // the stage is bound by the memory pipeline's scattered 16-byte requests, not by latency hiding)
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((KLASS == 2u && !NEE && !TEXTURED && !VOLUME) ? 4 : 1, 8))) void k_shade(FrameUniforms U, SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t par)
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((KLASS == 2u && !TEXTURED && !VOLUME) ? GI_SHADE_NEE_WAVES : 1, 8))) void k_shade(FrameUniforms U, SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t par)
 {
   __shared__ AppendScratch<3> sh;
   const uint32_t qNext = Q_TRACE_A + (par ^ 1u), qRegen = Q_REGEN_A + (par ^ 1u), qHit = Q_HIT + KLASS;
