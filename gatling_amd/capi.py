@@ -111,6 +111,7 @@ SYMBOLS = [
     ("giCCreateTextureFromFile", _P, [_P, C.c_char_p, _I]),
     ("giCDebugDecodeImage", C.c_int, [C.c_char_p, _I, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _FP, C.c_uint64]),
     ("giCSetMaterialTexture", C.c_int, [_P, _I, C.POINTER(GiCTextureBinding)]),
+    ("giCSetMaterialTextureTransform", C.c_int, [_P, _I, _FP]),
     ("giCSetMeshPrimvars", C.c_int, [_P, _U, C.POINTER(GiCPrimvarData)]), ("giCSetMeshInstancerPrimvars", C.c_int, [_P, _U, C.POINTER(GiCPrimvarData)]),
     ("giCSetMaterialPrimvarInput", C.c_int, [_P, _I, C.c_char_p]),
     ("giCCreateRenderBuffer", _P, [_U, _U, _I]), ("giCDestroyRenderBuffer", None, [_P]), ("giCGetRenderBufferMem", _P, [_P]),
@@ -226,6 +227,8 @@ class Scene:
                 tb = GiCTextureBinding(self.textures[b.texture], int(b.wrap_s), int(b.wrap_t), int(b.channel), (C.c_float * 4)(*b.scale), (C.c_float * 4)(*b.bias))
                 if L.giCSetMaterialTexture(h, int(slot), C.byref(tb)) != GI_C_OK:
                     raise GiError("giCSetMaterialTexture failed: " + L.giCGetLastError().decode())
+                if getattr(b, "transform", None) is not None and L.giCSetMaterialTextureTransform(h, int(slot), _fp(b.transform)) != GI_C_OK:
+                    raise GiError("giCSetMaterialTextureTransform failed: " + L.giCGetLastError().decode())
             for slot, name in getattr(m, "primvar_inputs", {}).items():
                 if L.giCSetMaterialPrimvarInput(h, int(slot), name.encode()) != GI_C_OK:
                     raise GiError("giCSetMaterialPrimvarInput failed: " + L.giCGetLastError().decode())

@@ -258,7 +258,8 @@ enum DirtyFlags : uint32_t { DIRTY_BVH = 1u, DIRTY_FRAMEBUFFER = 2u, DIRTY_LIGHT
 
 struct GiCTexture { GiCScene* scene; uint32_t width, height; std::vector<float> rgba; std::string cacheKey; uint32_t refs = 1; };
 struct GiCPrimvar { std::string name; int32_t type, interpolation; std::vector<float> data; };
-struct GiCMaterial { GiCScene* scene; std::string name; GiCMaterialDesc desc; GiCTextureBinding tex[GI_C_TEX_SLOT_COUNT] = {}; std::string primvarInput[GI_C_TEX_SLOT_COUNT]; };
+struct GiCMaterial { GiCScene* scene; std::string name; GiCMaterialDesc desc; GiCTextureBinding tex[GI_C_TEX_SLOT_COUNT] = {}; std::string primvarInput[GI_C_TEX_SLOT_COUNT];
+                     float texXf[GI_C_TEX_SLOT_COUNT][6] = {}; bool hasTexXf[GI_C_TEX_SLOT_COUNT] = {}; /* giCSetMaterialTextureTransform */ };
 
 struct GiCMesh {
   GiCScene* scene;
@@ -609,6 +610,16 @@ int giCSetMaterialTexture(GiCMaterial* mat, int32_t input, const GiCTextureBindi
   if (binding && (binding->wrapS < 0 || binding->wrapS > 3 || binding->wrapT < 0 || binding->wrapT > 3)) { setError("giCSetMaterialTexture: bad wrap mode"); return GI_C_ERROR; }
   std::lock_guard<std::mutex> g(mat->scene->mutex);
   if (binding) mat->tex[input] = *binding; else mat->tex[input] = GiCTextureBinding{};
+  mat->scene->dirty |= DIRTY_MATERIALS | DIRTY_BVH | DIRTY_FRAMEBUFFER;
+  return GI_C_OK;
+}
+
+int giCSetMaterialTextureTransform(GiCMaterial* mat, int32_t input, const float* xf)
+{
+  if (!mat || input < 0 || input >= GI_C_TEX_SLOT_COUNT) { setError("giCSetMaterialTextureTransform: bad arguments"); return GI_C_ERROR; }
+  std::lock_guard<std::mutex> g(mat->scene->mutex);
+  mat->hasTexXf[input] = xf != nullptr;
+  if (xf) memcpy(mat->texXf[input], xf, sizeof(float) * 6);
   mat->scene->dirty |= DIRTY_MATERIALS | DIRTY_BVH | DIRTY_FRAMEBUFFER;
   return GI_C_OK;
 }
@@ -1144,6 +1155,7 @@ int buildScene(GiCScene* s)
       r.tex = (uint32_t)(tit - s->textures.begin()) + 1u;
       r.mode = (uint32_t)b.wrapS | ((uint32_t)b.wrapT << 8) | (((uint32_t)b.channel & 3u) << 16);
       memcpy(r.scale, b.scale, 16); memcpy(r.bias, b.bias, 16);
+      if (s->materials[i]->hasTexXf[slot]) { r.mode |= TEX_MODE_XFORM; memcpy(r.xf, s->materials[i]->texXf[slot], sizeof(r.xf)); }
       mats[i].flags |= slot == TEX_OPACITY ? MAT_FLAG_OPACITY_TEX : MAT_FLAG_TEXTURED; // opacity is looked up by the any-hit test, not by k_shade
     }
     memcpy(mats[i].p, s->materials[i]->desc.p, sizeof(float) * MAT_PARAM_COUNT);

@@ -175,7 +175,8 @@ __device__ inline void resolve_material_textures(const SceneView& sc, const Mate
       else st.texMetallic = o[0];
       continue;
     }
-    const F4 t = tex_lookup_float4_2d(sc.textures[b.tex - 1u], st.u, st.v, b.mode & 0xffu, (b.mode >> 8) & 0xffu);
+    float tu = st.u, tv = st.v; tex_transform_st(b, tu, tv);
+    const F4 t = tex_lookup_float4_2d(sc.textures[b.tex - 1u], tu, tv, b.mode & 0xffu, (b.mode >> 8) & 0xffu);
     const float val[4] = {t.x * b.scale[0] + b.bias[0], t.y * b.scale[1] + b.bias[1], t.z * b.scale[2] + b.bias[2], t.w * b.scale[3] + b.bias[3]};
     const uint32_t ch = (b.mode >> 16) & 3u;
     const float sel = ch == 0u ? val[0] : (ch == 1u ? val[1] : (ch == 2u ? val[2] : val[3]));

@@ -108,6 +108,15 @@ __device__ __forceinline__ float cutout_rule(uint32_t klass, float op, float thr
 // Cutout opacity of a candidate hit (rp_main.ahit:51-60 evaluates the material's cutout expression with the candidate's shading
 // state): the constant, or -- when the opacity input is textured -- channel `channel` of texel * scale + bias at the candidate's st
 // (st interpolated as setup_shading_state does, mdl_shading_state.glsl:62-65).
+// UsdTransform2d between the primvar reader and a UsdUVTexture's `st` (UsdPreviewSurface specification: scale, then rotation, then translation), folded into six
+// floats by the front end; fixed association, no contraction (== oracle tex_transform_st)
+__device__ __forceinline__ void tex_transform_st(const TexBindingRec& b, float& u, float& v)
+{
+  if (!(b.mode & TEX_MODE_XFORM)) return;
+  const float s = u, t = v;
+  u = (b.xf[0] * s + b.xf[1] * t) + b.xf[2];
+  v = (b.xf[3] * s + b.xf[4] * t) + b.xf[5];
+}
 __device__ inline float cutout_opacity_at(const SceneView& sc, uint32_t matWord, uint32_t triIdx, float hu, float hv)
 {
   const MaterialRec* m = &sc.materials[matWord & 0x00ffffffu];
@@ -124,6 +133,7 @@ __device__ inline float cutout_opacity_at(const SceneView& sc, uint32_t matWord,
     v = (bx * sc.verts[td.x].v + by * sc.verts[td.y].v) + bz * sc.verts[td.z].v;
   }
   const TexBindingRec& b = m->tex[TEX_OPACITY];
+  tex_transform_st(b, u, v);
   const F4 t = tex_lookup_float4_2d(sc.textures[b.tex - 1u], u, v, b.mode & 0xffu, (b.mode >> 8) & 0xffu);
   const uint32_t ch = (b.mode >> 16) & 3u;
   const float raw = ch == 0u ? t.x * b.scale[0] + b.bias[0] : (ch == 1u ? t.y * b.scale[1] + b.bias[1] : (ch == 2u ? t.z * b.scale[2] + b.bias[2] : t.w * b.scale[3] + b.bias[3]));

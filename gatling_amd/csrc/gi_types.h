@@ -88,13 +88,15 @@ enum : uint32_t { TEX_BASE_COLOR = 0, TEX_EMISSION = 1, TEX_ROUGHNESS = 2, TEX_M
 enum : uint32_t { TEX_WRAP_CLAMP = 0, TEX_WRAP_REPEAT = 1, TEX_WRAP_MIRRORED_REPEAT = 2, TEX_WRAP_CLIP = 3 }; // mdl_types.glsl:117-120
 struct TexBindingRec {
   uint32_t tex;   // texture index + 1; 0 = input not textured
-  uint32_t mode;  // wrapS | wrapT << 8 | channel << 16
+  uint32_t mode;  // wrapS | wrapT << 8 | channel << 16 | TEX_MODE_* flags
   float scale[4], bias[4];
+  float xf[6];    // TEX_MODE_XFORM: texture-coordinate transform of the lookup, s' = (xf[0] s + xf[1] t) + xf[2], t' = (xf[3] s + xf[4] t) + xf[5] (UsdTransform2d upstream of a UsdUVTexture's `st`)
 };
 constexpr uint32_t MAT_FLAG_OPACITY_TEX = 1u << 30; // MaterialRec::flags: the cutout opacity is textured (the any-hit test looks it up at the candidate's st)
 constexpr uint32_t MAT_FLAG_TEXTURED = 1u << 31; // MaterialRec::flags: some input is textured or primvar-driven (k_shade resolves the inputs per hit)
 constexpr uint32_t TEX_MODE_PRIMVAR = 1u << 24;   // TexBindingRec::mode: (no texture) the input reads the mesh's scene data for this slot
 constexpr uint32_t TEX_MODE_CAMERA_POSITION = 1u << 25; // ... the scene-data name is "CAMERA_POSITION": ubo.cameraPosition (mdl_interface.glsl:329-334, Frontend.cpp:251)
+constexpr uint32_t TEX_MODE_XFORM = 1u << 27;           // TexBindingRec::xf is not the identity
 constexpr uint32_t TEX_MODE_FRAME = 1u << 26;           // ... the scene-data name is "FRAME": ubo.frame (mdl_interface.glsl:390-395, Frontend.cpp:252)
 constexpr uint32_t SD_INFO_INT = 1u << 5;               // MeshRec::sdInfo: integer primvar, nearest-vertex interpolation (scene_data_lookup_int, mdl_interface.glsl:426-457)
 // Scene data (primvars) of a mesh for the material inputs of ITS material (replaces BlasPayloadBufferPreamble::sceneDataInfos,
@@ -107,7 +109,7 @@ struct MaterialRec {
   float p[MAT_PARAM_COUNT];
   TexBindingRec tex[TEX_SLOT_COUNT];
 };
-static_assert(sizeof(MaterialRec) == 504, "MaterialRec must be 504 bytes");
+static_assert(sizeof(MaterialRec) == 648, "MaterialRec must be 648 bytes");
 // A texture: linear float RGBA texels, row 0 first.  (8-bit sources are decoded to linear float by the caller; a
 // compressed unorm8/half store is a later memory optimisation, the lookup arithmetic would not change.)
 struct TextureRec { const float* texels; uint32_t width, height; };

@@ -8,6 +8,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <string>
@@ -135,7 +136,7 @@ namespace gtl
             size_t e = doc.find('>', q);
             if (e == std::string::npos) break;
             const std::string tag = doc.substr(q, e - q + 1), n = attr(tag, "name");
-            if (!n.empty()) out.inputs[n] = attr(tag, "value");
+            if (!n.empty()) { out.inputs[n] = attr(tag, "value"); if (!attr(tag, "nodename").empty()) out.connections[n] = attr(tag, "nodename"); }
             q = e;
           }
           return true;
@@ -165,7 +166,8 @@ namespace gtl
     }
 
     // a material input fed by an image node (UsdUVTexture / image / tiledimage): file + UsdUVTexture's wrap, scale, bias, colour space
-    struct ImageInput { std::string file; int wrapS = GI_C_TEX_WRAP_REPEAT, wrapT = GI_C_TEX_WRAP_REPEAT, channel = 0; float scale[4] = {1, 1, 1, 1}, bias[4] = {0, 0, 0, 0}; bool srgb = false; };
+    struct ImageInput { std::string file; int wrapS = GI_C_TEX_WRAP_REPEAT, wrapT = GI_C_TEX_WRAP_REPEAT, channel = 0; float scale[4] = {1, 1, 1, 1}, bias[4] = {0, 0, 0, 0}; bool srgb = false;
+                        bool hasXf = false; float xf[6] = {1, 0, 0, 0, 1, 0}; /* UsdTransform2d upstream of `st` */ };
     int wrapMode(const std::string& v)
     {
       if (v == "clamp") return GI_C_TEX_WRAP_CLAMP;
@@ -212,6 +214,20 @@ namespace gtl
         const bool colour = slot == GI_C_TEX_BASE_COLOR || slot == GI_C_TEX_EMISSION;
         const std::string cs = up.inputs.count("sourceColorSpace") ? up.inputs["sourceColorSpace"] : "auto";
         im.srgb = cs == "sRGB" || (cs == "auto" && colour); // UsdUVTexture: auto = sRGB for 8-bit colour data
+        // texture coordinates through a UsdTransform2d (UsdPreviewSurface specification: result = in * scale, rotated counter-clockwise by `rotation` degrees, +
+        // translation) -> the six floats of giCSetMaterialTextureTransform; cos / sin in double, rounded once (== gatling_amd/scene.py usd_transform_2d)
+        auto stc = up.connections.find("st"); if (stc == up.connections.end()) stc = up.connections.find("texcoord");
+        MtlxNode xfn;
+        if (stc != up.connections.end() && readNode(doc, stc->second, xfn) && xfn.category == "UsdTransform2d") {
+          float rot = 0.0f, sc2[2] = {1.0f, 1.0f}, tr[2] = {0.0f, 0.0f};
+          if (xfn.inputs.count("rotation")) floats(xfn.inputs["rotation"], &rot, 1);
+          if (xfn.inputs.count("scale")) floats(xfn.inputs["scale"], sc2, 2);
+          if (xfn.inputs.count("translation")) floats(xfn.inputs["translation"], tr, 2);
+          const double rad = (double)rot * 3.14159265358979323846 / 180.0, c = cos(rad), sn = sin(rad);
+          im.hasXf = true;
+          im.xf[0] = (float)(c * (double)sc2[0]); im.xf[1] = (float)(-sn * (double)sc2[1]); im.xf[2] = tr[0];
+          im.xf[3] = (float)(sn * (double)sc2[0]); im.xf[4] = (float)(c * (double)sc2[1]); im.xf[5] = tr[1];
+        }
         // which output feeds a scalar input: <input ... nodename="tex" output="g"/>
         const std::string needle = std::string("name=\"") + input + "\"";
         size_t q = doc.find(needle);
@@ -289,6 +305,7 @@ namespace gtl
       mat->textures.push_back(t);
       GiCTextureBinding b{t, im.wrapS, im.wrapT, im.channel, {im.scale[0], im.scale[1], im.scale[2], im.scale[3]}, {im.bias[0], im.bias[1], im.bias[2], im.bias[3]}};
       giCSetMaterialTexture(h, slot, &b);
+      if (im.hasXf) giCSetMaterialTextureTransform(h, slot, im.xf);
     }
     return mat;
   }
@@ -311,6 +328,16 @@ namespace gtl
     GiCMaterial* h = m->h;
     delete m; // (file textures created for the document stay owned by the scene)
     return h;
+  }
+  // [ext] what the reader makes of the image node feeding `slot`: 0 = no image, 1 = image, 2 = image with a texture-coordinate transform (xf6 filled)
+  extern "C" int gtlMtlxImageInputC(const char* mtlxSrc, int slot, float* xf6, char* fileOut, int fileCap)
+  {
+    std::string primvars[GI_C_TEX_SLOT_COUNT]; ImageInput images[GI_C_TEX_SLOT_COUNT];
+    GiCMaterialDesc d;
+    if (slot < 0 || slot >= GI_C_TEX_SLOT_COUNT || !descFromMtlx(mtlxSrc, d, primvars, images) || images[slot].file.empty()) return 0;
+    if (fileOut && fileCap > 0) { strncpy(fileOut, images[slot].file.c_str(), (size_t)fileCap - 1); fileOut[fileCap - 1] = 0; }
+    if (xf6) memcpy(xf6, images[slot].xf, sizeof(float) * 6);
+    return images[slot].hasXf ? 2 : 1;
   }
   extern "C" int gtlMaterialDescFromMtlxStrC(const char* mtlxSrc, GiCMaterialDesc* out)
   {

@@ -72,6 +72,17 @@ class TextureBinding:
     channel: int = 0                       # scalar inputs (roughness, metallic): channel of the scaled/biased texel
     scale: tuple = (1.0, 1.0, 1.0, 1.0)
     bias: tuple = (0.0, 0.0, 0.0, 0.0)
+    transform: Optional[tuple] = None      # UsdTransform2d upstream of `st`, folded: s' = (xf0 s + xf1 t) + xf2, t' = (xf3 s + xf4 t) + xf5 (see usd_transform_2d)
+
+
+def usd_transform_2d(rotation_deg=0.0, scale=(1.0, 1.0), translation=(0.0, 0.0)):
+    """The six floats of a UsdTransform2d node (UsdPreviewSurface specification: result = in * scale, rotated counter-clockwise by `rotation` degrees about the
+    origin, + translation).  cos / sin in double precision, rounded once to float32 -- the gtl shim's MaterialX reader (gtl_shim.cpp) does the same."""
+    import math
+    rad = float(np.float32(rotation_deg)) * 3.14159265358979323846 / 180.0   # (the inputs are float32 values of a document: converted first, then double arithmetic)
+    c, s = math.cos(rad), math.sin(rad)
+    sx, sy = float(np.float32(scale[0])), float(np.float32(scale[1]))
+    return tuple(float(np.float32(x)) for x in (c * sx, -s * sy, float(translation[0]), s * sx, c * sy, float(translation[1])))
 
 
 TEX_WRAP_CLAMP, TEX_WRAP_REPEAT, TEX_WRAP_MIRRORED_REPEAT, TEX_WRAP_CLIP = 0, 1, 2, 3

@@ -234,6 +234,11 @@ typedef struct GiCTextureBinding {
   float scale[4], bias[4];
 } GiCTextureBinding;
 int giCSetMaterialTexture(GiCMaterial* material, int32_t input, const GiCTextureBinding* binding);
+/* [ext] Texture-coordinate transform of an input's lookup: s' = (xf[0] s + xf[1] t) + xf[2], t' = (xf[3] s + xf[4] t) + xf[5]; NULL = identity.  What a UsdTransform2d
+ * node between the primvar reader and a UsdUVTexture's `st` means (UsdPreviewSurface specification: result = in * scale, rotated counter-clockwise by `rotation`
+ * degrees, + translation: xf = {c sx, -s sy, tx, s sx, c sy, ty}); the reference compiles the node through MaterialX -> MDL (src/mc/impl/MtlxMdlCodeGen.cpp:186-215),
+ * the gtl shim's MaterialX reader folds it into these six floats. */
+int giCSetMaterialTextureTransform(GiCMaterial* material, int32_t input, const float* xf);
 
 /* Scene data (primvars).  Gi.h:76-92: GiPrimvarData with the byte vector flattened to pointer + size; data = 4-byte elements (float, or int32 for
  * the Int types).  A material input bound to a primvar NAME reads the primvar of the hit mesh (instancer primvars first, mesh primvars

@@ -677,6 +677,16 @@ inline float apply_wrap_and_crop(float coord, int wrap, int res) // crop = (0, 1
   }
   return coord;
 }
+// UsdTransform2d between the primvar reader and a UsdUVTexture's `st` (UsdPreviewSurface specification: result = in * scale, rotated counter-clockwise by
+// `rotation` degrees, + translation), folded by the front end into six floats; the reference compiles the node through MaterialX -> MDL
+// (src/mc/impl/MtlxMdlCodeGen.cpp:186-215).  Fixed association, no contraction.
+inline void tex_transform_st(const OrcTexBinding& b, float& u, float& v)
+{
+  if (!b.hasTransform) return;
+  const float s = u, t = v;
+  u = (b.xf[0] * s + b.xf[1] * t) + b.xf[2];
+  v = (b.xf[3] * s + b.xf[4] * t) + b.xf[5];
+}
 inline F4v tex_lookup_float4_2d(const OrcTexture& t, float u, float v, int wrapU, int wrapV)
 {
   if ((wrapU == ORC_TEX_WRAP_CLIP && (u < 0.0f || u > 1.0f)) || (wrapV == ORC_TEX_WRAP_CLIP && (v < 0.0f || v > 1.0f))) return F4v{0, 0, 0, 0};
@@ -749,7 +759,8 @@ float cutout_opacity_textured(const Prepared& P, const Tri& T, float hu, float h
   const FVertex& a = md.verts[md.faces[3 * T.prim + 0]], &bb = md.verts[md.faces[3 * T.prim + 1]], &c = md.verts[md.faces[3 * T.prim + 2]];
   const float bx = 1.0f - hu - hv, by = hu, bz = hv;                       // mdl_shading_state.glsl:17
   const float u = (bx * a.u + by * bb.u) + bz * c.u, v = (bx * a.v + by * bb.v) + bz * c.v; // :62-65
-  const F4v t = tex_lookup_float4_2d(P.textures[b.texture], u, v, b.wrapS, b.wrapT);
+  float tu = u, tv = v; tex_transform_st(b, tu, tv);
+  const F4v t = tex_lookup_float4_2d(P.textures[b.texture], tu, tv, b.wrapS, b.wrapT);
   const float val[4] = {t.x * b.scale[0] + b.bias[0], t.y * b.scale[1] + b.bias[1], t.z * b.scale[2] + b.bias[2], t.w * b.scale[3] + b.bias[3]};
   return cutout_rule(m.klass, val[b.channel & 3], m.p[ORC_P_OPACITY_THRESHOLD]);
 }
@@ -813,7 +824,8 @@ OrcMaterial resolve_material(const Prepared& P, const OrcMaterial& m, State& st,
       continue;
     }
     if (b.texture < 0 || (uint32_t)b.texture >= P.textureCount) continue;
-    F4v t = tex_lookup_float4_2d(P.textures[b.texture], st.u, st.v, b.wrapS, b.wrapT);
+    float tu = st.u, tv = st.v; tex_transform_st(b, tu, tv);
+    F4v t = tex_lookup_float4_2d(P.textures[b.texture], tu, tv, b.wrapS, b.wrapT);
     float val[4] = {t.x * b.scale[0] + b.bias[0], t.y * b.scale[1] + b.bias[1], t.z * b.scale[2] + b.bias[2], t.w * b.scale[3] + b.bias[3]};
     if (slot == ORC_TEX_BASE_COLOR) { r.p[ORC_P_BASE_COLOR] = val[0]; r.p[ORC_P_BASE_COLOR + 1] = val[1]; r.p[ORC_P_BASE_COLOR + 2] = val[2]; }
     else if (slot == ORC_TEX_EMISSION) { r.p[ORC_P_EMISSION] = val[0]; r.p[ORC_P_EMISSION + 1] = val[1]; r.p[ORC_P_EMISSION + 2] = val[2]; }

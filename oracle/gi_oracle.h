@@ -98,6 +98,8 @@ typedef struct OrcTexBinding {
   int32_t wrapS, wrapT;
   int32_t channel; /* scalar inputs: which channel of the (scaled, biased) texel */
   float scale[4], bias[4];
+  int32_t hasTransform; /* UsdTransform2d upstream of the lookup's st (UsdPreviewSurface specification): s' = (xf[0] s + xf[1] t) + xf[2], t' = (xf[3] s + xf[4] t) + xf[5] */
+  float xf[6];
 } OrcTexBinding;
 
 /* Scene data (primvars; mdl_interface.glsl:260-479, Gi.cpp:905-1019): a material input may read a named primvar of the mesh

@@ -21,7 +21,7 @@ TEX_SLOT_COUNT = 6
 
 class OrcTexBinding(C.Structure):
     _fields_ = [("texture", C.c_int32), ("wrapS", C.c_int32), ("wrapT", C.c_int32), ("channel", C.c_int32),
-                ("scale", C.c_float * 4), ("bias", C.c_float * 4)]
+                ("scale", C.c_float * 4), ("bias", C.c_float * 4), ("hasTransform", C.c_int32), ("xf", C.c_float * 6)]
 
 
 class OrcMaterial(C.Structure):
@@ -51,6 +51,10 @@ def fill_material(dst, m):
             dst.tex[slot].wrapS, dst.tex[slot].wrapT, dst.tex[slot].channel = int(b.wrap_s), int(b.wrap_t), int(b.channel)
             dst.tex[slot].scale = (C.c_float * 4)(*b.scale)
             dst.tex[slot].bias = (C.c_float * 4)(*b.bias)
+            xf = getattr(b, "transform", None)
+            dst.tex[slot].hasTransform = 0 if xf is None else 1
+            if xf is not None:
+                dst.tex[slot].xf = (C.c_float * 6)(*[float(np.float32(x)) for x in xf])
         dst.primvarInput[slot].value = getattr(m, "primvar_inputs", {}).get(slot, "").encode()
 
 

@@ -286,6 +286,28 @@ def test_deferred_slot_initialisation_is_invisible(gi, monkeypatch, name):
         assert_image_parity(again, g["color"], exact=True)
 
 
+def test_texture_coordinate_transforms_on_device(gi, orc):
+    """UsdTransform2d folded into the texture bindings (gi_texture.h tex_transform_st): every textured input of the texture test scene and the textured cutout
+    opacity of the leaf cards (looked up inside the any-hit test) with a rotation + scale + translation -- device == oracle, bit for bit."""
+    from gatling_amd.scene import usd_transform_2d
+    desc = textured_scene()
+    k = 0
+    for m in desc.materials:
+        for slot, b in m.textures.items():
+            b.transform = usd_transform_2d(17.0 * (k + 1), (1.0 + 0.3 * k, 0.7 + 0.2 * k), (0.1 * k, -0.05 * k)); k += 1
+    assert k >= 6
+    render_both(gi, orc, desc, RenderSettings(spp=4, max_bounces=6, next_event_estimation=True), 96, 54, exact=True)
+    leaves, rs, w, h = build_case("leaf_cards_64x36_spp4_b5")
+    n = 0
+    for m in leaves.materials:
+        for slot, b in getattr(m, "textures", {}).items():
+            b.transform = usd_transform_2d(-40.0, (2.0, 1.5), (0.3, 0.6)); n += 1
+    assert n >= 1
+    img, ref, st = render_both(gi, orc, leaves, rs, w, h, exact=True)
+    g = np.load(os.path.join(GOLDEN, "leaf_cards_64x36_spp4_b5.npz"))
+    assert not np.array_equal(img, g["color"])     # the transform really moved the cutout pattern
+
+
 def _aov_scene():
     desc = sphere_grid(grid=3, subdivisions=1, material_count=4)
     rng = np.random.default_rng(8)
