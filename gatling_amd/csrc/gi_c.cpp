@@ -63,6 +63,7 @@ struct DeviceWorker {
   void post(std::function<void()> fn) { { std::lock_guard<std::mutex> lk(m); job = std::move(fn); busy = true; } cv.notify_all(); }
   void wait() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [this] { return !busy; }); }
   void shutdown() { { std::lock_guard<std::mutex> lk(m); stop = true; } cv.notify_all(); if (th.joinable()) th.join(); }
+  ~DeviceWorker() { shutdown(); } // (a process that exits without giCTerminate must not meet a joinable std::thread in a static destructor)
 };
 struct Context {
   bool initialized = false;

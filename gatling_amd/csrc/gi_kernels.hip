@@ -319,7 +319,7 @@ constexpr bool DYN_XCD_RANGES_DEFAULT = false;   // (GATLING_DYN_XCD)
 #define GI_DYN_LDS_NODES 0
 #endif
 #ifndef GI_DYN_DEFER_FINISH
-#define GI_DYN_DEFER_FINISH 1
+#define GI_DYN_DEFER_FINISH 0 // measured r04c (profiles/r04c_variants.txt): trace stage C3 48.9 vs 48.4 ms, C4 21.1 vs 20.9, C5 134.7 vs 135.1 -- nothing either way; off
 #endif
 constexpr bool DYN_DEFER_FINISH = GI_DYN_DEFER_FINISH != 0;
 #ifndef GI_DYN_WAVES
@@ -548,10 +548,11 @@ __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, Que
 #ifndef GI_SHADE_NEE_WAVES
 #define GI_SHADE_NEE_WAVES 4
 #endif
+// (r04c: the OpenPBR + NEE variant squeezed to 4 waves per SIMD -- 160 -> 128 VGPRs, 14 spilled -- is SLOWER: shade stage C3 14.4 -> 15.1 ms, C5 unchanged; it keeps its 3 waves)
 template <uint32_t KLASS, bool TEXTURED, bool VOLUME, bool NEE, bool PACKED>
 // (forcing the plain variant to 5 waves/SIMD -- amdgpu_waves_per_eu((...) ? 5 : 1, 8): 90 VGPRs, no spills -- is SLOWER: C2 shade 178 -> 190 ms;
 // the stage is bound by the memory pipeline's scattered 16-byte requests, not by latency hiding)
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((KLASS == 2u && !TEXTURED && !VOLUME) ? GI_SHADE_NEE_WAVES : 1, 8))) void k_shade(FrameUniforms U, SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t par)
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((KLASS == 2u && !TEXTURED && !VOLUME) ? (NEE ? 1 : GI_SHADE_NEE_WAVES) : 1, 8))) void k_shade(FrameUniforms U, SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t par)
 {
   __shared__ AppendScratch<3> sh;
   const uint32_t qNext = Q_TRACE_A + (par ^ 1u), qRegen = Q_REGEN_A + (par ^ 1u), qHit = Q_HIT + KLASS;
@@ -804,7 +805,8 @@ static void launchTraceVariant(hipStream_t s, uint32_t blocks, const SceneView& 
     if (dynLdsNodes > sc.nodeCount) dynLdsNodes = sc.nodeCount;
     if (dynLdsNodes > 1024u) dynLdsNodes = 1024u;
     static const int envFlush = getenv("GATLING_DYN_FLUSH") ? atoi(getenv("GATLING_DYN_FLUSH")) : -1;
-    const uint32_t flushAt = envFlush >= 0 ? (uint32_t)(envFlush > 64 ? 64 : envFlush) : DYN_FLUSH_AT_DEFAULT;
+    static const int envFlushShadow = getenv("GATLING_DYN_FLUSH_SHADOW") ? atoi(getenv("GATLING_DYN_FLUSH_SHADOW")) : -1; // (experiment: shadow rays end at their first hit, which a carried ring reports late)
+    const uint32_t flushAt = (ANYHIT && envFlushShadow >= 0) ? (uint32_t)(envFlushShadow > 64 ? 64 : envFlushShadow) : (envFlush >= 0 ? (uint32_t)(envFlush > 64 ? 64 : envFlush) : DYN_FLUSH_AT_DEFAULT);
     static const int envPeek = getenv("GATLING_DYN_PEEK") ? atoi(getenv("GATLING_DYN_PEEK")) : 0;
     const uint32_t dynFlags = ((envXcd >= 0 ? envXcd != 0 : DYN_XCD_RANGES_DEFAULT) ? DYN_FLAG_XCD_RANGES : 0u) | (envPeek ? DYN_FLAG_PEEK : 0u) | (flushAt << DYN_FLAG_FLUSH_SHIFT);
     const uint32_t stackBytes = entries * TRACE_BLOCK * (uint32_t)sizeof(uint2) + dynLdsNodes * 80u;
