@@ -805,7 +805,7 @@ static void launchTraceVariant(hipStream_t s, uint32_t blocks, const SceneView& 
     if (dynLdsNodes > sc.nodeCount) dynLdsNodes = sc.nodeCount;
     if (dynLdsNodes > 1024u) dynLdsNodes = 1024u;
     static const int envFlush = getenv("GATLING_DYN_FLUSH") ? atoi(getenv("GATLING_DYN_FLUSH")) : -1;
-    static const int envFlushShadow = getenv("GATLING_DYN_FLUSH_SHADOW") ? atoi(getenv("GATLING_DYN_FLUSH_SHADOW")) : -1; // (experiment: shadow rays end at their first hit, which a carried ring reports late)
+    const int envFlushShadow = getenv("GATLING_DYN_FLUSH_SHADOW") ? atoi(getenv("GATLING_DYN_FLUSH_SHADOW")) : -1; // (experiment: shadow rays end at their first hit, which a carried ring reports late)
     const uint32_t flushAt = (ANYHIT && envFlushShadow >= 0) ? (uint32_t)(envFlushShadow > 64 ? 64 : envFlushShadow) : (envFlush >= 0 ? (uint32_t)(envFlush > 64 ? 64 : envFlush) : DYN_FLUSH_AT_DEFAULT);
     static const int envPeek = getenv("GATLING_DYN_PEEK") ? atoi(getenv("GATLING_DYN_PEEK")) : 0;
     const uint32_t dynFlags = ((envXcd >= 0 ? envXcd != 0 : DYN_XCD_RANGES_DEFAULT) ? DYN_FLAG_XCD_RANGES : 0u) | (envPeek ? DYN_FLAG_PEEK : 0u) | (flushAt << DYN_FLAG_FLUSH_SHIFT);
