@@ -228,7 +228,19 @@ void deriveMaterialConstants(MaterialRec& m)
     out[MP_ALPHA] = (r * r > 0.001f) ? r * r : 0.001f; out[MP_COAT] = coat; out[MP_COAT_ALPHA] = (cr * cr > 0.001f) ? cr * cr : 0.001f;
     out[MP_COAT_F0] = qc * qc; out[MP_ETA] = (1.0f + eps) / (1.0f - eps);
     // which optional lobes the material has, in the slot of the thin-walled switch: materials without them do not load their inputs per hit (gi_types.h MP_FEATURES)
+    { // volumetric subsurface medium (oracle opbr_params "Volumetric subsurface", the same fp32 operations): extinction 1 / (radius * scale), albedo 1 - s^2
+      for (int i = 0; i < 3; i++) {
+        float c = p[GI_C_P_SUBSURFACE_COLOR + i]; c = c > 0.0f ? c : 0.0f; c = c < 1.0f ? c : 1.0f;
+        const float sq = sqrtf((9.59217f + 41.6808f * c) + (17.7126f * c) * c);
+        const float sv = (4.09712f + 4.20863f * c) - sq;
+        float alb = 1.0f - sv * sv; alb = alb > 0.0f ? alb : 0.0f; alb = alb < 1.0f ? alb : 1.0f;
+        float rr = p[GI_C_P_SUBSURFACE_RADIUS] * p[GI_C_P_SUBSURFACE_RADIUS_SCALE + i]; rr = rr > 1e-6f ? rr : 1e-6f;
+        m.sss[3 + i] = 1.0f / rr; m.sss[i] = alb * m.sss[3 + i];
+      }
+      m.sss[6] = m.sss[7] = 0.0f;
+    }
     out[MP_FEATURES] = (float)((p[GI_C_P_THIN_WALLED] != 0.0f ? MATF_THIN_WALLED : 0u) | (p[GI_C_P_FUZZ_WEIGHT] > 0.0f ? MATF_FUZZ : 0u) |
+                               ((p[GI_C_P_THIN_WALLED] == 0.0f && p[GI_C_P_SUBSURFACE_WEIGHT] > 0.0f) ? MATF_SSS_VOLUME : 0u) |
                                ((p[GI_C_P_SPECULAR_ANISOTROPY] > 0.0f || p[GI_C_P_COAT_ANISOTROPY] > 0.0f) ? MATF_ANISOTROPY : 0u) |
                                (p[GI_C_P_THIN_FILM_WEIGHT] > 0.0f ? MATF_THIN_FILM : 0u));
     memcpy(m.p, out, sizeof(out));

@@ -46,6 +46,7 @@ struct ShState {
   uint32_t mesh, prim, vi[3]; int32_t instanceId; float hu, hv; // renderer state for scene-data lookups (mdl_interface.glsl:281-301)
   float ior1, ior2;              // Bsdf_sample_data.ior1/ior2 (rp_main.chit:188-189): < 0 = the material's own; 0 = empty-stack default
   bool thinWalled;               // mdl_thin_walled (rp_main.chit:155-157), set by shade_segment
+  bool sssVolume;                // the render keeps a medium stack: OpenPBR's volumetric subsurface lobe is live (set by shade_segment)
   uint32_t texMask;              // bit per TEX_* slot whose value below replaces the material constant at this hit
   V3 texBaseColor, texEmission; float texRoughness, texMetallic;
 };
@@ -114,7 +115,7 @@ __device__ __forceinline__ void setup_shading_state(const SceneView& sc, uint32_
   s.normal = nrm; s.geomNormal = gn;
   s.mesh = f2u(r5.y); s.instanceId = (int32_t)f2u(r5.z); s.prim = td.w; s.hu = hu; s.hv = hv;
   s.ior1 = 0.0f; s.ior2 = 0.0f;
-  s.thinWalled = false; s.texMask = 0u; s.texBaseColor = v3(0.0f, 0.0f, 0.0f); s.texEmission = s.texBaseColor; s.texRoughness = 0.0f; s.texMetallic = 0.0f;
+  s.thinWalled = false; s.sssVolume = false; s.texMask = 0u; s.texBaseColor = v3(0.0f, 0.0f, 0.0f); s.texEmission = s.texBaseColor; s.texRoughness = 0.0f; s.texMetallic = 0.0f;
 }
 
 // mdl_adapt_normal (mdl_interface.glsl:238-256): Iray's shadow-terminator bend of a mapped normal
@@ -228,6 +229,7 @@ __device__ inline void dome_miss(const SceneView& sc, const PathState& st, uint3
 // (entry points GlslShaderGen.cpp:181-193; data contracts mdl_types.glsl:158-238)
 // ------------------------------------------------------------------------------------------------
 enum : uint32_t { EV_ABSORB = 0, EV_DIFFUSE = 1, EV_GLOSSY = 2, EV_SPECULAR = 4, EV_REFLECTION = 8, EV_TRANSMISSION = 16 };
+enum : uint32_t { EV_SUBSURFACE = 64 }; // [ours] beside EV_DIFFUSE | EV_TRANSMISSION: entered through the volumetric subsurface lobe (the medium pushed is MaterialRec::sss)
 
 __device__ __forceinline__ V3 to_world(const ShState& s, V3 l) { return (s.tangentU * l.x + s.tangentV * l.y) + s.normal * l.z; }
 __device__ __forceinline__ V3 to_local(const ShState& s, V3 w) { return v3(dot(w, s.tangentU), dot(w, s.tangentV), dot(w, s.normal)); }
@@ -442,7 +444,7 @@ __device__ inline V3 eon_pi_f(V3 rho, float r, V3 l1, V3 l2)
   const V3 rhoMs = v3((rr.x * avgEF) / (1.0f - rho.x * (1.0f - avgEF)), (rr.y * avgEF) / (1.0f - rho.y * (1.0f - avgEF)), (rr.z * avgEF) / (1.0f - rho.z * (1.0f - avgEF)));
   return rho * ss + rhoMs * ms;
 }
-struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, baseColor, ssColor, fuzzColor; float metalness, alpha, alphaY, coat, coatAlpha, coatAlphaY, coatF0, eta, tw, specWeight, baseWeight, diffRough, ssWeight, ssAniso, fuzzWeight, fuzzAlpha, filmWeight, filmNm, filmIor; bool thinWalled; };
+struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, baseColor, ssColor, fuzzColor; float metalness, alpha, alphaY, coat, coatAlpha, coatAlphaY, coatF0, eta, tw, specWeight, baseWeight, diffRough, ssWeight, ssAniso, fuzzWeight, fuzzAlpha, filmWeight, filmNm, filmIor; bool thinWalled, ssVolume; };
 __device__ __forceinline__ OpbrParams opbr_params(const MaterialRec* m, const ShState& st)
 {
   OpbrParams o; const float* p = m->p;
@@ -465,6 +467,9 @@ __device__ __forceinline__ OpbrParams opbr_params(const MaterialRec* m, const Sh
   // thin-walled subsurface (open_pbr_surface.mtlx:140-196, 207-218); the volumetric form of non-thin-walled materials is not modelled
   o.ssWeight = o.thinWalled ? p[55] : 0.0f;
   o.ssColor = v3(p[56], p[57], p[58]); o.ssAniso = p[59];
+  // volumetric subsurface (open_pbr_surface.mtlx:182-192; oracle opbr_params): live when the render keeps a medium stack; the coefficients are MaterialRec::sss
+  o.ssVolume = (feat & MATF_SSS_VOLUME) != 0u && st.sssVolume;
+  if (o.ssVolume) o.ssWeight = fmin2(p[55], 1.0f);
   // fuzz layer (open_pbr_surface.mtlx:569-581): sheen_bsdf(fuzz_weight, fuzz_color, fuzz_roughness) on top of the coat
   o.fuzzWeight = 0.0f; o.fuzzColor = v3(1.0f, 1.0f, 1.0f); o.fuzzAlpha = 0.5f;
   if (feat & MATF_FUZZ) { o.fuzzWeight = fmin2(fmax2(p[49], 0.0f), 1.0f); o.fuzzColor = v3(p[50], p[51], p[52]); o.fuzzAlpha = fmin2(fmax2(p[53], 0.07f), 1.0f); }
@@ -589,6 +594,14 @@ __device__ inline void opbr_sample_base(const OpbrParams& o, const ShState& st, 
       if (z < o.ssWeight) {
         const bool through = !((z / o.ssWeight) < 0.5f);
         if (!(l.z > 0.0f)) return;
+        if (o.ssVolume) { // volumetric form: the whole subsurface share enters (or, met from inside, leaves) by a cosine lobe on the far side, untinted
+          V3 k2 = to_world(st, v3(l.x, l.y, -l.z));
+          if (!(dot(k2, st.geomNormal) < 0.0f)) return;
+          out.k2 = k2; out.pdf = pBase * o.ssWeight * (l.z / GI_PI);
+          out.overPdf = o.coatTint; out.event = EV_DIFFUSE | EV_TRANSMISSION | EV_SUBSURFACE;
+          if (o.filmWeight > 0.0f) out.overPdf = out.overPdf * under;
+          return;
+        }
         if (through) { // translucent_bsdf: Lambert on the far side
           V3 k2 = to_world(st, v3(l.x, l.y, -l.z));
           if (!(dot(k2, st.geomNormal) < 0.0f)) return;
@@ -704,6 +717,12 @@ __device__ inline void opbr_evaluate_base(const OpbrParams& o, const ShState& st
   out.glossy = gl;
   V3 rho = (o.diffRough > 0.0f && l2.z > 0.0f) ? eon_pi_f(o.baseColor, o.diffRough, l1, l2) * o.baseWeight : o.albedo;
   const float wBase = cd * base * diel * (1.0f - Fd) * (1.0f - o.tw);
+  if (o.ssVolume) { // volumetric subsurface: its share of the opaque base transmits (not reached by NEE); the diffuse lobe keeps 1 - subsurface_weight
+    out.diffuse = ((rho * (1.0f - o.ssWeight)) * o.coatTint) * wBase;
+    if (o.filmWeight > 0.0f) out.diffuse = out.diffuse * under;
+    out.pdf = Fc * pc + base * (o.metalness * ps + diel * (Fd * ps + (1.0f - Fd) * (1.0f - o.tw) * (1.0f - o.ssWeight) * cd));
+    return;
+  }
   if (o.ssWeight > 0.0f) { // reflection side of the thin-walled subsurface mix (the transmitted half lies below the surface: not reached by NEE)
     const V3 ss = (l2.z > 0.0f) ? opbr_ss_reflect(o, l1, l2) : v3(0.0f, 0.0f, 0.0f);
     out.diffuse = ((rho * (1.0f - o.ssWeight) + ss * (o.ssWeight * 0.5f)) * o.coatTint) * wBase;

@@ -107,6 +107,7 @@ __device__ __forceinline__ void shade_segment(const FrameUniforms& U, const Scen
   }
   const bool thinWalled = ((KLASS == KLASS_DYNAMIC) ? mat->klass : KLASS) == 2u && ((uint32_t)mat->p[MP_FEATURES] & MATF_THIN_WALLED) != 0u; // mdl_thin_walled (:155-157): OpenPBR geometry_thin_walled
   ss.thinWalled = thinWalled;
+  ss.sssVolume = VOLUME; // a medium stack exists: OpenPBR's volumetric subsurface lobe is live
   if (VOLUME) { ss.ior1 = (ss.frontFace || thinWalled) ? prevMediumIor : -1.0f; ss.ior2 = (ss.frontFace || thinWalled) ? -1.0f : nextMediumIor; } // iorCurrent / iorOther (:188-189)
   // emission (rp_main.chit:293-343): uniform EDF, radiance == emission colour where cos > 0
   V3 em = (ss.texMask & (1u << TEX_EMISSION)) ? ss.texEmission : v3(mat->p[3], mat->p[4], mat->p[5]);
@@ -161,6 +162,7 @@ __device__ __forceinline__ void shade_segment(const FrameUniforms& U, const Scen
             const V3 sigS = (depth > 0.0f) ? v3(mat->p[29] / depth, mat->p[30] / depth, mat->p[31] / depth) : v3(0.0f, 0.0f, 0.0f);
             const V3 sigT = v3(mat->p[MP_SIGMA_A], mat->p[MP_SIGMA_A + 1], mat->p[MP_SIGMA_A + 2]) + sigS;
             m[0] = mat->p[MP_ETA]; m[1] = mat->p[47]; m[2] = sigS.x; m[3] = sigS.y; m[4] = sigS.z; m[5] = sigT.x; m[6] = sigT.y; m[7] = sigT.z;
+            if (bs.event & EV_SUBSURFACE) { m[1] = mat->p[59]; m[2] = mat->sss[0]; m[3] = mat->sss[1]; m[4] = mat->sss[2]; m[5] = mat->sss[3]; m[6] = mat->sss[4]; m[7] = mat->sss[5]; } // entered through the subsurface lobe
           } else { m[0] = 1.0f; m[1] = 0.0f; m[2] = 0.0f; m[3] = 0.0f; m[4] = 0.0f; m[5] = 0.0f; m[6] = 0.0f; m[7] = 0.0f; }
         }
       } else if (mediumIdx > 0u) newIdx = mediumIdx - 1u; // pop

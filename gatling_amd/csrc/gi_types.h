@@ -80,7 +80,8 @@ constexpr uint32_t MAT_PARAM_COUNT = 64;
 // F0 slot = metal edge tint (specular_color*specular_weight), alpha, coat, coatAlpha, coatF0, modulated eta, sigma_a
 // MP_FEATURES (OpenPBR records only): the device copy of the thin-walled switch p[54] carries a small bit set as a float -- which optional lobes the material has --
 // so that k_shade loads the fuzz / anisotropy inputs only for materials that use them (the stage is bound by its scattered requests, not by arithmetic)
-constexpr uint32_t MP_FEATURES = 54, MATF_THIN_WALLED = 1u, MATF_FUZZ = 2u, MATF_ANISOTROPY = 4u, MATF_THIN_FILM = 8u;
+constexpr uint32_t MP_FEATURES = 54, MATF_THIN_WALLED = 1u, MATF_FUZZ = 2u, MATF_ANISOTROPY = 4u, MATF_THIN_FILM = 8u,
+                   MATF_SSS_VOLUME = 16u; // not thin-walled, subsurface_weight > 0: the volumetric subsurface lobe (live in renders with a medium stack), coefficients in MaterialRec::sss
 enum : uint32_t { MP_ALBEDO = 32, MP_F0 = 35, MP_ALPHA = 38, MP_COAT = 39, MP_COAT_ALPHA = 40, MP_COAT_F0 = 41, MP_ETA = 42, MP_SIGMA_A = 43, MP_CUTOUT = 46 /* mdl_cutout_opacity, 1 = opaque */ };
 // Textured material inputs (UsdUVTexture semantics: value = texel * scale + bias at the hit's st).  Replaces the MDL
 // renderer runtime's tex_lookup_* path (mdl_interface.glsl:127-145) for the inputs the closed-form materials expose.
@@ -108,8 +109,9 @@ struct MaterialRec {
   uint32_t flags;
   float p[MAT_PARAM_COUNT];
   TexBindingRec tex[TEX_SLOT_COUNT];
+  float sss[8]; // volumetric subsurface medium (OpenPBR, derived on the host from subsurface_color / _radius / _radius_scale): sigma_s[3], sigma_t[3], -, -
 };
-static_assert(sizeof(MaterialRec) == 648, "MaterialRec must be 648 bytes");
+static_assert(sizeof(MaterialRec) == 680, "MaterialRec must be 680 bytes");
 // A texture: linear float RGBA texels, row 0 first.  (8-bit sources are decoded to linear float by the caller; a
 // compressed unorm8/half store is a later memory optimisation, the lookup arithmetic would not change.)
 struct TextureRec { const float* texels; uint32_t width, height; };

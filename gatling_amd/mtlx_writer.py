@@ -53,6 +53,7 @@ def _inputs(m: S.MaterialDesc):
         ("geometry_thin_walled", "boolean", "true" if p[S.P_THIN_WALLED] != 0.0 else "false"),
         ("subsurface_weight", "float", _f(p[S.P_SUBSURFACE_WEIGHT])), ("subsurface_color", "color3", _vals(p, S.P_SUBSURFACE_COLOR, 3)),
         ("subsurface_scatter_anisotropy", "float", _f(p[S.P_SUBSURFACE_ANISOTROPY])),
+        ("subsurface_radius", "float", _f(p[S.P_SUBSURFACE_RADIUS])), ("subsurface_radius_scale", "color3", _vals(p, S.P_SUBSURFACE_RADIUS_SCALE, 3)),
         ("specular_roughness_anisotropy", "float", _f(p[S.P_SPECULAR_ANISOTROPY])), ("coat_roughness_anisotropy", "float", _f(p[S.P_COAT_ANISOTROPY])),
         ("thin_film_weight", "float", _f(p[S.P_THIN_FILM_WEIGHT])), ("thin_film_thickness", "float", _f(p[S.P_THIN_FILM_THICKNESS])), ("thin_film_ior", "float", _f(p[S.P_THIN_FILM_IOR])),
         # the parameter block keeps luminance x colour: luminance 1 and the product as the colour reproduce it exactly

@@ -55,6 +55,8 @@ P_THIN_WALLED = 54
 P_SUBSURFACE_WEIGHT = 55
 P_SUBSURFACE_COLOR = 56              # 3
 P_SUBSURFACE_ANISOTROPY = 59
+P_SUBSURFACE_RADIUS = 32             # (slots 32..35 of the USER block; on the device these indices hold derived constants, written after the inputs were read)
+P_SUBSURFACE_RADIUS_SCALE = 33       # 3
 P_SPECULAR_ANISOTROPY = 60
 P_COAT_ANISOTROPY = 61
 P_THIN_FILM_WEIGHT = 62
@@ -125,7 +127,7 @@ def _open_pbr(name="mat", base_weight=1.0, base_color=(0.8, 0.8, 0.8), base_meta
               transmission_scatter=(0, 0, 0), transmission_scatter_anisotropy=0.0, coat_darkening=1.0, fuzz_weight=0.0,
               fuzz_color=(1, 1, 1), fuzz_roughness=0.5, geometry_thin_walled=False, subsurface_weight=0.0, subsurface_color=(0.8, 0.8, 0.8),
               subsurface_scatter_anisotropy=0.0, specular_roughness_anisotropy=0.0, coat_roughness_anisotropy=0.0,
-              thin_film_weight=0.0, thin_film_thickness=0.5, thin_film_ior=1.4) -> MaterialDesc:
+              thin_film_weight=0.0, thin_film_thickness=0.5, thin_film_ior=1.4, subsurface_radius=1.0, subsurface_radius_scale=(1.0, 0.5, 0.25)) -> MaterialDesc:
     """open_pbr_surface inputs with the defaults of src/gi/mtlx/open_pbr_surface.mtlx:11-92 (the lobes this core implements)."""
     p = np.zeros(P_COUNT, np.float32)
     p[P_BASE_COLOR:P_BASE_COLOR + 3] = base_color
@@ -152,7 +154,9 @@ def _open_pbr(name="mat", base_weight=1.0, base_color=(0.8, 0.8, 0.8), base_meta
     p[P_FUZZ_COLOR:P_FUZZ_COLOR + 3] = fuzz_color
     p[P_FUZZ_ROUGHNESS] = fuzz_roughness
     p[P_THIN_WALLED] = 1.0 if geometry_thin_walled else 0.0
-    p[P_SUBSURFACE_WEIGHT] = subsurface_weight         # modelled for thin-walled materials (open_pbr_surface.mtlx:140-196); the volumetric form is not
+    p[P_SUBSURFACE_WEIGHT] = subsurface_weight         # thin-walled form (open_pbr_surface.mtlx:140-196) always; volumetric form (:182-192) in renders with a medium stack
+    p[P_SUBSURFACE_RADIUS] = subsurface_radius         # mean free path = radius * radius_scale per channel (:47-50, 182-186)
+    p[P_SUBSURFACE_RADIUS_SCALE:P_SUBSURFACE_RADIUS_SCALE + 3] = subsurface_radius_scale
     p[P_SUBSURFACE_COLOR:P_SUBSURFACE_COLOR + 3] = subsurface_color
     p[P_SUBSURFACE_ANISOTROPY] = subsurface_scatter_anisotropy
     p[P_SPECULAR_ANISOTROPY] = specular_roughness_anisotropy   # open_pbr_anisotropy (open_pbr_surface.mtlx:133-136, 552-555): highlights stretched along the tangent

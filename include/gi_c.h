@@ -190,6 +190,10 @@ typedef struct GiCRenderParams {
 #define GI_C_P_THIN_FILM_IOR 6        /* thin_film_ior (:75), default 1.4 -- OpenPBR class only: the slot is useSpecularWorkflow for UsdPreviewSurface */
 #define GI_C_P_SPECULAR_ANISOTROPY 60 /* OpenPBR specular_roughness_anisotropy (open_pbr_surface.mtlx:27, 133-136): GGX stretched along the tangent, alpha_t = r^2 sqrt(2 / (1 + (1 - a)^2)), alpha_b = (1 - a) alpha_t */
 #define GI_C_P_COAT_ANISOTROPY 61     /* coat_roughness_anisotropy (:65, 552-555); the coat uses the geometry tangent (geometry_coat_tangent is not a separate input here) */
+#define GI_C_P_SUBSURFACE_RADIUS 32       /* OpenPBR subsurface_radius (open_pbr_surface.mtlx:47, default 1): with _RADIUS_SCALE the per-channel mean free path of the volumetric
+                                            subsurface_bsdf (:182-192) of materials that are not thin-walled; live in renders with a medium stack (mediumStackSize > 0) */
+#define GI_C_P_SUBSURFACE_RADIUS_SCALE 33 /* 3 floats, subsurface_radius_scale (:49, default 1, 0.5, 0.25).  Slots 32..35 are inputs of the USER block only: the device copy of a
+                                            material keeps derived constants at these indices (written after the inputs were read) */
 #define GI_C_P_THIN_WALLED 54      /* OpenPBR geometry_thin_walled (:88) != 0: MDL thin_walled semantics (rp_main.chit:153-157, 188-189, 447) */
 
 /* Note: p[GI_C_P_OPACITY] is the cutout opacity (1 = opaque); a zero-filled block is a fully transparent material. */

@@ -497,7 +497,10 @@ inline bool tri_test(const Prepared& P, const Tri& T, V3 o, V3 d, float tMin, fl
   return false;
 }
 
-void build_bvh_rec(Prepared& P, uint32_t node, uint32_t begin, uint32_t end, const std::vector<V3>& lo, const std::vector<V3>& hi)
+// (nodes are handed out by an atomic counter from a vector sized up front, so the two halves of a large range can be built by different threads: the TREE is the
+// same whatever the thread timing -- splits depend on the range alone -- only node numbers differ, and nothing depends on those)
+static std::atomic<uint32_t> g_bvhNext{0};
+void build_bvh_rec(Prepared& P, uint32_t node, uint32_t begin, uint32_t end, const std::vector<V3>& lo, const std::vector<V3>& hi, int depth = 0)
 {
   BvhNode& n = P.bvh[node];
   for (int a = 0; a < 3; a++) { n.lo[a] = ORC_FLT_MAX; n.hi[a] = -ORC_FLT_MAX; }
@@ -517,11 +520,16 @@ void build_bvh_rec(Prepared& P, uint32_t node, uint32_t begin, uint32_t end, con
   auto key = [&](uint32_t t) { const float l[3] = {lo[t].x, lo[t].y, lo[t].z}, h[3] = {hi[t].x, hi[t].y, hi[t].z}; return l[axis] + h[axis]; };
   std::nth_element(P.bvhTris.begin() + begin, P.bvhTris.begin() + mid, P.bvhTris.begin() + end,
                    [&](uint32_t a, uint32_t b) { return key(a) < key(b); });
-  uint32_t left = (uint32_t)P.bvh.size();
-  P.bvh.push_back(BvhNode{}); P.bvh.push_back(BvhNode{});
+  uint32_t left = g_bvhNext.fetch_add(2u);
   P.bvh[node].left = left; P.bvh[node].count = 0;
-  build_bvh_rec(P, left, begin, mid, lo, hi);
-  build_bvh_rec(P, left + 1, mid, end, lo, hi);
+  if (depth < 6 && end - begin > 200000u) { // a 10 M-triangle scene: 64 subtrees in parallel (the single-threaded build was most of the big-scene tests' time)
+    std::thread other([&, left, begin, mid, depth] { build_bvh_rec(P, left, begin, mid, lo, hi, depth + 1); });
+    build_bvh_rec(P, left + 1, mid, end, lo, hi, depth + 1);
+    other.join();
+    return;
+  }
+  build_bvh_rec(P, left, begin, mid, lo, hi, depth + 1);
+  build_bvh_rec(P, left + 1, mid, end, lo, hi, depth + 1);
 }
 
 void build_bvh(Prepared& P)
@@ -540,9 +548,10 @@ void build_bvh(Prepared& P)
   }
   P.bvhTris.resize(n);
   for (size_t i = 0; i < n; i++) P.bvhTris[i] = (uint32_t)i;
-  P.bvh.reserve(2 * n);
-  P.bvh.push_back(BvhNode{});
+  P.bvh.assign(2 * n + 2, BvhNode{}); // a binary tree over n leaves of >= 1 triangle has < 2 n nodes
+  g_bvhNext.store(1u);
   build_bvh_rec(P, 0, 0, (uint32_t)n, lo, hi);
+  P.bvh.resize(g_bvhNext.load());
 }
 
 inline bool box_test(const BvhNode& n, V3 o, V3 inv, float tMin, float tMax)
@@ -593,6 +602,7 @@ struct State {
   float ior1 = 0.0f, ior2 = 0.0f;
   V3 cameraPosition = {0, 0, 0}; float frame = 0.0f; // ubo.cameraPosition / ubo.frame for the CAMERA_POSITION / FRAME scene-data names
   bool thinWalled = false; // mdl_thin_walled (rp_main.chit:155-157): both sides of the surface see the medium the ray travels in
+  bool sssVolume = false;  // the render keeps a medium stack (mediumStackSize > 0): OpenPBR's volumetric subsurface_bsdf can be walked
   // renderer state of the hit for scene-data lookups (mdl_interface.glsl:281-301)
   const MeshData* mesh = nullptr; uint32_t prim = 0, hitIndices[3] = {0, 0, 0}; int32_t instanceId = 0; float bu = 0.0f, bv = 0.0f;
 };
@@ -848,6 +858,7 @@ OrcMaterial resolve_material(const Prepared& P, const OrcMaterial& m, State& st,
 // reference arithmetic lives in the MDL SDK and is unpinned (DESIGN.md section "Materials").
 // ---------------------------------------------------------------------------------------------
 enum { EV_ABSORB = 0, EV_DIFFUSE = 1, EV_GLOSSY = 2, EV_SPECULAR = 4, EV_REFLECTION = 8, EV_TRANSMISSION = 16 }; // mdl_types.glsl:123-137
+enum { EV_SUBSURFACE = 64 }; // [ours] beside EV_DIFFUSE | EV_TRANSMISSION: the path entered through the volumetric subsurface lobe -- the medium pushed is the subsurface medium
 
 struct BsdfSample { V3 k2; V3 overPdf; float pdf; uint32_t event; };
 struct BsdfEval { V3 diffuse, glossy; float pdf; };
@@ -1059,8 +1070,8 @@ inline V3 eon_pi_f(V3 rho, float r, V3 l1, V3 l2)
   const V3 rhoMs = v3((rr.x * avgEF) / (1.0f - rho.x * (1.0f - avgEF)), (rr.y * avgEF) / (1.0f - rho.y * (1.0f - avgEF)), (rr.z * avgEF) / (1.0f - rho.z * (1.0f - avgEF)));
   return rho * ss + rhoMs * ms;
 }
-struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, sigmaA, sigmaS, baseColor, coatColor, ssColor, fuzzColor; float metalness, alpha, alphaY, coat, coatAlpha, coatAlphaY, coatF0, eta, tw, specWeight, anisotropy, baseWeight, diffRough, ssWeight, ssAniso, fuzzWeight, fuzzAlpha, filmWeight, filmNm, filmIor; bool thinWalled; };
-inline OpbrParams opbr_params(const OrcMaterial& m)
+struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, sigmaA, sigmaS, baseColor, coatColor, ssColor, fuzzColor, sssSigmaS, sssSigmaT; bool ssVolume; float metalness, alpha, alphaY, coat, coatAlpha, coatAlphaY, coatF0, eta, tw, specWeight, anisotropy, baseWeight, diffRough, ssWeight, ssAniso, fuzzWeight, fuzzAlpha, filmWeight, filmNm, filmIor; bool thinWalled; };
+inline OpbrParams opbr_params(const OrcMaterial& m, bool sssVolume = false)
 {
   OpbrParams o; const float* p = m.p;
   float bw = p[ORC_P_BASE_WEIGHT], sw = p[ORC_P_SPECULAR_WEIGHT];
@@ -1106,6 +1117,29 @@ inline OpbrParams opbr_params(const OrcMaterial& m)
   // volumetric subsurface_bsdf of non-thin-walled materials is not modelled (weight treated as 0)
   o.ssWeight = o.thinWalled ? p[ORC_P_SUBSURFACE_WEIGHT] : 0.0f;
   o.ssColor = v3(p + ORC_P_SUBSURFACE_COLOR); o.ssAniso = p[ORC_P_SUBSURFACE_ANISOTROPY];
+  // Volumetric subsurface (open_pbr_surface.mtlx:182-192, 207-218: subsurface_bsdf(color, radius = subsurface_radius * subsurface_radius_scale, anisotropy) for
+  // materials that are NOT thin-walled), available when the render keeps a medium stack.  MaterialX maps the node onto MDL as a diffuse transmission at the
+  // boundary over a scattering volume -- neither library is in the reference tree, so this is our statement of that mapping (unpinned): the subsurface share of the
+  // opaque base enters the object by a cosine lobe on the far side (white tint) and pushes a medium with extinction 1 / radius per channel, single-scattering albedo
+  // 1 - s^2 with s = 4.09712 + 4.20863 c - sqrt(9.59217 + 41.6808 c + 17.7126 c^2) (van de Hoek's inversion of the multiple-scattering colour c, Kulla & Conty 2017)
+  // and Henyey-Greenstein g = subsurface_scatter_anisotropy; the walk and the exit are the medium stack's (rp_main.rgen:317-346, 462-477; the same layered BSDF
+  // is met from inside, where the subsurface lobe transmits outwards and pops the medium).
+  o.ssVolume = !o.thinWalled && sssVolume && p[ORC_P_SUBSURFACE_WEIGHT] > 0.0f;
+  o.sssSigmaS = v3(0, 0, 0); o.sssSigmaT = v3(0, 0, 0);
+  if (o.ssVolume) {
+    o.ssWeight = fmin2(p[ORC_P_SUBSURFACE_WEIGHT], 1.0f);
+    const float c3[3] = {fmax2(o.ssColor.x, 0.0f), fmax2(o.ssColor.y, 0.0f), fmax2(o.ssColor.z, 0.0f)};
+    float sS[3], sT[3];
+    for (int i = 0; i < 3; i++) {
+      const float c = fmin2(c3[i], 1.0f);
+      const float sq = sqrtf((9.59217f + 41.6808f * c) + (17.7126f * c) * c);
+      const float sv = (4.09712f + 4.20863f * c) - sq;
+      const float alb = fmin2(fmax2(1.0f - sv * sv, 0.0f), 1.0f);
+      const float r = fmax2(p[ORC_P_SUBSURFACE_RADIUS] * p[ORC_P_SUBSURFACE_RADIUS_SCALE + i], 1e-6f);
+      sT[i] = 1.0f / r; sS[i] = alb * sT[i];
+    }
+    o.sssSigmaS = v3(sS[0], sS[1], sS[2]); o.sssSigmaT = v3(sT[0], sT[1], sT[2]);
+  }
   // fuzz layer (open_pbr_surface.mtlx:569-581): sheen_bsdf(fuzz_weight, fuzz_color, fuzz_roughness) on top of the coat
   o.fuzzWeight = fmin2(fmax2(p[ORC_P_FUZZ_WEIGHT], 0.0f), 1.0f); o.fuzzColor = v3(p + ORC_P_FUZZ_COLOR); o.fuzzAlpha = fmin2(fmax2(p[ORC_P_FUZZ_ROUGHNESS], 0.07f), 1.0f);
   // thin film (open_pbr_surface.mtlx:300-304, 404-431, 450-464): thin_film_thickness is in micrometres (:301-304 converts to nanometres)
@@ -1287,6 +1321,14 @@ static void opbr_sample_base(const OpbrParams& o, const State& st, V3 k1, const 
     if (z < o.ssWeight) {
       const bool through = !((z / o.ssWeight) < 0.5f);
       if (!(l.z > 0.0f)) return;
+      if (o.ssVolume) { // volumetric form: the whole subsurface share enters (or, met from inside, leaves) by a cosine lobe on the far side, untinted
+        V3 k2 = to_world(st, v3(l.x, l.y, -l.z));
+        if (!(dot(k2, st.geomNormal) < 0.0f)) return;
+        out.k2 = k2; out.pdf = pBase * o.ssWeight * (l.z / ORC_PI);
+        out.overPdf = o.coatTint; out.event = EV_DIFFUSE | EV_TRANSMISSION | EV_SUBSURFACE;
+        if (o.filmWeight > 0.0f) out.overPdf = out.overPdf * under;
+        return;
+      }
       if (through) { // translucent_bsdf: Lambert on the far side
         V3 k2 = to_world(st, v3(l.x, l.y, -l.z));
         if (!(dot(k2, st.geomNormal) < 0.0f)) return;
@@ -1313,7 +1355,7 @@ static void opbr_sample_base(const OpbrParams& o, const State& st, V3 k1, const 
 
 void opbr_sample(const OrcMaterial& m, const State& st, V3 k1, const float xi[4], bool frontFace, BsdfSample& out)
 {
-  const OpbrParams o = opbr_params(m);
+  const OpbrParams o = opbr_params(m, st.sssVolume);
   if (!(o.fuzzWeight > 0.0f)) { opbr_sample_base(o, st, k1, xi, frontFace, out); return; }
   V3 l1 = to_local(st, k1);
   const float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
@@ -1361,6 +1403,12 @@ static void opbr_evaluate_base(const OpbrParams& o, const State& st, V3 k1, V3 k
   out.glossy = gl;
   V3 rho = (o.diffRough > 0.0f && l2.z > 0.0f) ? eon_pi_f(o.baseColor, o.diffRough, l1, l2) * o.baseWeight : o.albedo;
   const float wBase = cd * base * diel * (1.0f - Fd) * (1.0f - o.tw);
+  if (o.ssVolume) { // volumetric subsurface: its share of the opaque base transmits (not reached by NEE); the diffuse lobe keeps 1 - subsurface_weight
+    out.diffuse = ((rho * (1.0f - o.ssWeight)) * o.coatTint) * wBase;
+    if (o.filmWeight > 0.0f) out.diffuse = out.diffuse * under;
+    out.pdf = Fc * pc + base * (o.metalness * ps + diel * (Fd * ps + (1.0f - Fd) * (1.0f - o.tw) * (1.0f - o.ssWeight) * cd));
+    return;
+  }
   if (o.ssWeight > 0.0f) { // reflection side of the thin-walled subsurface mix (the transmitted half lies below the surface: not reached by NEE)
     const V3 ss = (l2.z > 0.0f) ? opbr_ss_reflect(o, l1, l2) : v3(0, 0, 0);
     out.diffuse = ((rho * (1.0f - o.ssWeight) + ss * (o.ssWeight * 0.5f)) * o.coatTint) * wBase;
@@ -1375,7 +1423,7 @@ static void opbr_evaluate_base(const OpbrParams& o, const State& st, V3 k1, V3 k
 
 void opbr_evaluate(const OrcMaterial& m, const State& st, V3 k1, V3 k2, bool frontFace, BsdfEval& out)
 {
-  const OpbrParams o = opbr_params(m);
+  const OpbrParams o = opbr_params(m, st.sssVolume);
   opbr_evaluate_base(o, st, k1, k2, frontFace, out);
   if (!(o.fuzzWeight > 0.0f)) return;
   V3 l1 = to_local(st, k1); const V3 l2 = to_local(st, k2);
@@ -1639,6 +1687,7 @@ void closest_hit(const Frame& F, const Hit& h, Payload& pl, float hitT)
   }
   const bool thinWalled = mat.klass == ORC_MAT_OPEN_PBR && mat.p[ORC_P_THIN_WALLED] != 0.0f; // mdl_thin_walled (:155-157)
   st.thinWalled = thinWalled;
+  st.sssVolume = stackSize > 0; // a medium stack exists: OpenPBR's volumetric subsurface lobe is live
   st.ior1 = (st.frontFace || thinWalled) ? prevMediumIor : -1.0f; // iorCurrent / iorOther (:188-189)
   st.ior2 = (st.frontFace || thinWalled) ? -1.0f : nextMediumIor;
 
@@ -1695,8 +1744,9 @@ void closest_hit(const Frame& F, const Hit& h, Payload& pl, float hitT)
         if (mediumIdx <= stackSize) {
           Medium md; md.ior = v3(1, 1, 1); md.sigma_s = v3(0, 0, 0); md.sigma_t = v3(0, 0, 0); md.bias = 0.0f;
           if (mat.klass == ORC_MAT_OPEN_PBR) { // mdl_ior, mdl_volume_{absorption,scattering}_coefficient, MEDIUM_DIRECTIONAL_BIAS
-            OpbrParams o = opbr_params(mat);
+            OpbrParams o = opbr_params(mat, true);
             md.ior = v3(o.eta, o.eta, o.eta); md.sigma_s = o.sigmaS; md.sigma_t = o.sigmaA + o.sigmaS; md.bias = o.anisotropy;
+            if (eventType & EV_SUBSURFACE) { md.sigma_s = o.sssSigmaS; md.sigma_t = o.sssSigmaT; md.bias = o.ssAniso; } // entered through the subsurface lobe
           }
           pl.media[mediumIdx - 1] = md;
         }

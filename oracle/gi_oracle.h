@@ -80,6 +80,7 @@ enum {
   ORC_P_COAT_DARKENING = 48,   /* open_pbr_surface.mtlx:64 */
   ORC_P_FUZZ_WEIGHT = 49, ORC_P_FUZZ_COLOR = 50, ORC_P_FUZZ_ROUGHNESS = 53, /* :57-59: the fuzz (sheen) layer (:569-581) */
   ORC_P_SUBSURFACE_WEIGHT = 55, ORC_P_SUBSURFACE_COLOR = 56, ORC_P_SUBSURFACE_ANISOTROPY = 59, /* :43-52; thin-walled subsurface (:140-196) */
+  ORC_P_SUBSURFACE_RADIUS = 32, ORC_P_SUBSURFACE_RADIUS_SCALE = 33, /* :47-50; the volumetric form (:182-192, 207-218), rendered with a medium stack */
   ORC_P_THIN_WALLED = 54,      /* geometry_thin_walled (:88) */
   ORC_P_THIN_FILM_IOR = 6, ORC_P_THIN_FILM_WEIGHT = 62, ORC_P_THIN_FILM_THICKNESS = 63, /* OpenPBR thin_film_* (:71-76); slot 6 is useSpecularWorkflow for UsdPreviewSurface */
   ORC_P_SPECULAR_ANISOTROPY = 60, ORC_P_COAT_ANISOTROPY = 61, /* specular_roughness_anisotropy (:27), coat_roughness_anisotropy (:65) */

@@ -308,6 +308,29 @@ def test_texture_coordinate_transforms_on_device(gi, orc):
     assert not np.array_equal(img, g["color"])     # the transform really moved the cutout pattern
 
 
+def test_volumetric_subsurface_on_device(gi, orc):
+    """OpenPBR's volumetric subsurface_bsdf (open_pbr_surface.mtlx:182-192) through the medium stack: diffuse-transmission entry, the subsurface medium pushed
+    (MaterialRec::sss), Henyey-Greenstein walk, exit through the same lobe from inside -- device == oracle bit for bit, with and without NEE, mixed with dielectric
+    transmission (two media of one material) and a coat; and with mediumStackSize 0 the lobe is off on both sides."""
+    desc = sphere_grid(3, 2, 6)
+    M = MaterialDesc
+    desc.materials = [M.open_pbr(name="wax", base_color=(0.9, 0.8, 0.6), subsurface_weight=1.0, subsurface_color=(0.9, 0.5, 0.3), subsurface_radius=0.15, specular_roughness=0.4),
+                      M.open_pbr(name="milk", base_color=(0.8, 0.8, 0.8), subsurface_weight=0.6, subsurface_color=(0.95, 0.93, 0.88), subsurface_radius=0.4,
+                                 subsurface_radius_scale=(1.0, 0.7, 0.4), subsurface_scatter_anisotropy=0.6, coat_weight=0.5, coat_roughness=0.1),
+                      M.open_pbr(name="jade", base_color=(0.2, 0.6, 0.3), subsurface_weight=0.8, subsurface_color=(0.3, 0.8, 0.4), subsurface_radius=0.05,
+                                 subsurface_scatter_anisotropy=-0.4, transmission_weight=0.3, transmission_color=(0.7, 0.9, 0.7), transmission_depth=0.5),
+                      M.open_pbr(name="thin", base_color=(0.5, 0.5, 0.9), geometry_thin_walled=True, subsurface_weight=0.7, subsurface_color=(0.4, 0.4, 0.9)),
+                      M.open_pbr(name="plain", base_color=(0.7, 0.7, 0.7)),
+                      M.usd_preview_surface(name="ups", diffuseColor=(0.6, 0.3, 0.2))]
+    desc.rect_lights = [RectLight(origin=(0.0, -1.0, 3.0), t0=(1, 0, 0), t1=(0, 1, 0), base_emission=(12, 12, 12), width=1.5, height=1.5)]
+    for nee in (False, True):
+        rs = RenderSettings(spp=4, max_bounces=24, next_event_estimation=nee, medium_stack_size=3)
+        img, ref, st = render_both(gi, orc, desc, rs, 80, 45, exact=True)
+    rs0 = RenderSettings(spp=4, max_bounces=24, medium_stack_size=0)
+    off, _, _ = render_both(gi, orc, desc, rs0, 80, 45, exact=True)
+    assert not np.array_equal(off, img)
+
+
 def _aov_scene():
     desc = sphere_grid(grid=3, subdivisions=1, material_count=4)
     rng = np.random.default_rng(8)

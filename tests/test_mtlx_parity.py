@@ -29,6 +29,7 @@ def _edge_cases():
             M.open_pbr(name="fuzz", fuzz_weight=0.5, fuzz_color=(0.2, 0.3, 0.4), fuzz_roughness=0.8),
             M.open_pbr(name="soap", transmission_weight=0.8, specular_roughness=0.05, thin_film_weight=1.0, thin_film_thickness=0.3, thin_film_ior=1.33),
             M.open_pbr(name="brushed", base_metalness=1.0, specular_roughness=0.35, specular_roughness_anisotropy=0.7, coat_weight=0.4, coat_roughness=0.2, coat_roughness_anisotropy=0.25),
+            M.open_pbr(name="wax", subsurface_weight=0.8, subsurface_color=(0.9, 0.5, 0.3), subsurface_radius=0.15, subsurface_radius_scale=(1.0, 0.6, 0.2), subsurface_scatter_anisotropy=0.3),
             M.usd_preview_surface(name="spec", useSpecularWorkflow=1, specularColor=(0.3, 0.4, 0.5), diffuseColor=(0.6, 0.1, 0.05), roughness=0.23, ior=1.7),
             M.usd_preview_surface(name="cut", opacity=0.37, opacityThreshold=0.5, emissiveColor=(0.5, 1.5, 2.5), clearcoat=0.7, clearcoatRoughness=0.2, metallic=0.33)]
 
