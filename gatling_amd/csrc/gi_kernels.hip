@@ -510,8 +510,9 @@ __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, Que
       slot = qs.slot[qIn][r];
       const bool fresh = (slot & TRACE_FRESH) != 0u; slot &= ~TRACE_FRESH; // camera ray of a path whose Slot is still unwritten (FLAG_DEFER_SLOT)
       h = ld4(&qs.a[qIn][r]);
-      rdir = ld4(&qs.b[qIn][r]);
       hit = f2u(h.w) != MISS; miss = !hit;
+      // the direction is copied into the hit record, or needed at a miss by the dome lookup / the scattering event; a plain miss (C4: three camera rays in four) does not read it
+      if (hit || sc.domeTexture != 0u || sc.mediumStackSize != 0u) rdir = ld4(&qs.b[qIn][r]);
       if (hit) { klass = f2u(h.w) >> 28; h.w = u2f(f2u(h.w) & 0x0fffffffu); } // k_trace_dyn's result word: triangle index | material class << 28
       if (fresh) { // begin the path now (hit, or a miss that needs the slot: dome image / medium stack), or retire the sample here without a Slot
         const FreshRec f = qs.fresh[qIn - Q_TRACE_A][r];
