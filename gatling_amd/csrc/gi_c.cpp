@@ -2097,7 +2097,7 @@ static int giCRenderImpl(const GiCRenderParams* params)
   }
   if (params->aovBindingCount == 0) { setError("giCRender: no AOV bindings"); return GI_C_ERROR; }
   if (rs.spp == 0) { setError("giCRender: spp must be > 0"); return GI_C_ERROR; }
-  if (rs.mediumStackSize > MAX_MEDIUM_STACK) { setError("giCRender: mediumStackSize > 8 is not supported"); return GI_C_ERROR; }
+  if (rs.mediumStackSize > MAX_MEDIUM_STACK) { setError("giCRender: mediumStackSize > 15 cannot be addressed (the payload's medium index has four bits, rp_main_payload.glsl:4-5)"); return GI_C_ERROR; }
   const GiCRenderBuffer* sizeRb = (colorBinding ? colorBinding : &params->aovBindings[0])->renderBuffer;
   const uint32_t width = sizeRb->width, height = sizeRb->height;
   if (width == 0 || height == 0) return GI_C_OK; // Render.Empty-style degenerate target: nothing to do

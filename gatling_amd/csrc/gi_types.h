@@ -227,7 +227,7 @@ static_assert(sizeof(Slot) == 64, "Slot must be 64 bytes");
 
 // Medium stack of a path (MEDIUM_STACK_SIZE > 0; rp_main_payload.glsl:11-17, 37-40): per slot `mediaStride` floats =
 // stack entries of 8 floats (ior, bias, sigma_s[3], sigma_t[3]) followed by walkSegmentPdf (3 floats + pad).
-constexpr uint32_t MEDIUM_FLOATS = 8, MAX_MEDIUM_STACK = 8;
+constexpr uint32_t MEDIUM_FLOATS = 8, MAX_MEDIUM_STACK = 15; // the payload's medium index has four bits (rp_main_payload.glsl:4-5): 15 is the deepest stack the reference can address
 constexpr uint32_t VOLUME_MISS = 0xfffffffeu; // "triangle" id of a hit record that is a scattering event inside a medium
 // Debug AOVs that follow whole paths (only when bound): Bounces = inferno colour of the bounce count of the pixel's LAST
 // sample (rp_main.rgen:483-486, written by k_raygen when that sample retires); NEE = outcome of the shadow test at bounce 0 of the

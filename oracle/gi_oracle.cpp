@@ -1621,7 +1621,7 @@ void sample_light(const Prepared& P, const Uniforms& ubo, const float k4[4], V3 
 // The per-pixel megakernel (rp_main.rgen:185-521 with rp_main.chit/.miss inlined)
 // ---------------------------------------------------------------------------------------------
 struct Medium { V3 ior, sigma_s, sigma_t; float bias; }; // rp_main_payload.glsl:11-17
-const uint32_t MAX_MEDIUM_STACK = 8;
+const uint32_t MAX_MEDIUM_STACK = 15; // the medium index field has four bits (rp_main_payload.glsl:4-5)
 struct Payload { // rp_main_payload.glsl:20-48
   V3 throughput; uint32_t bitfield; V3 radiance; uint32_t rng; V3 origin, dir, neeToLight, neeContrib;
   Medium media[MAX_MEDIUM_STACK]; V3 walkSegmentPdf; float tMaxLast; // MEDIUM_STACK_SIZE > 0 (tMaxLast = gl_RayTmaxEXT of the segment)

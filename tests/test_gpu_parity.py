@@ -456,7 +456,7 @@ def test_error_behaviour(gi):
         with pytest.raises(gi.GiError):
             sc.render(RenderSettings(spp=0), 8, 8)
         with pytest.raises(gi.GiError):
-            sc.render(RenderSettings(spp=1, medium_stack_size=9), 8, 8)  # stacks deeper than 8 media are refused
+            sc.render(RenderSettings(spp=1, medium_stack_size=16), 8, 8)  # the payload's medium index has four bits: stacks deeper than 15 cannot be addressed
         img = sc.render(RenderSettings(spp=1, max_bounces=2), 8, 8)  # still usable afterwards
         assert np.isfinite(img).all()
     finally:
@@ -804,7 +804,7 @@ def test_file_textures_are_shared_by_path(gi, tmp_path):
         sc.close()
 
 
-@pytest.mark.parametrize("stack,nee", [(1, True), (2, True), (2, False), (4, True)])
+@pytest.mark.parametrize("stack,nee", [(1, True), (2, True), (2, False), (4, True), (12, True), (15, False)])
 def test_volume_medium_stack_parity(gi, orc, stack, nee):
     """Participating media with a medium stack (rp_main.rgen:48-97, 317-346, 462-477; rp_main.miss:16-34; rp_main.chit:160-186,
     447-480): distance sampling, Henyey-Greenstein random walk, nested dielectrics with relative IOR -- bit-identical to the
