@@ -1037,6 +1037,10 @@ int buildTwoLevel(GiCScene* s, const std::vector<MB>& meshBuilds, const std::vec
   // Opt-in only.  Measured (r01k): although its working set is tiny (C4: 1.5 MB of BLAS nodes + 2.6 MB of mesh triangles instead of
   // 41 + 335 MB) the first version is SLOWER than the flat layout -- C4 trace 185 -> 207 ms, C5 834 -> 1945 ms (29 instead of 20 nodes
   // per ray: overlapping instance boxes, each visit pays a ray transform, a BLAS root and a restore; candidates cost a rebuild).
+  // ... except where the flat traversal cannot address the scene: its wave-cooperative triangle ring packs (lane, flat triangle) into 32 bits, 2^26 triangles; the
+  // two-level walk queues MESH triangles there (one BLAS per mesh), so heavily instanced scenes beyond that bound take it automatically (r04; the hit record's
+  // triangle word, flat index | class << 28, then bounds the scene at 2^28 flattened triangles)
+  if (flatTris >= ((size_t)1 << 26) && want < 0) want = 1;
   if (want <= 0 || instances.empty() || !beyondLds) return GI_C_OK;
   std::vector<Node8> blasNodes; std::vector<BlasTri> blasTris; std::vector<InstTrav> instTrav(instances.size());
   uint32_t blasDepth = 0;
@@ -1085,6 +1089,7 @@ int buildTwoLevel(GiCScene* s, const std::vector<MB>& meshBuilds, const std::vec
   Bvh8 tlas; std::vector<uint32_t> tlasItems;
   buildBvh8Boxes(instBoxes.data(), instances.size(), tlas, tlasItems);
   // per-lane stack: a TLAS level can leave a node group and an instance group behind, a BLAS level a node group
+  if (blasTris.size() >= ((size_t)1 << 26)) { if (want > 0) fprintf(stderr, "[gatling_gi] two-level layout not used: 2^26 or more unique mesh triangles\n"); return GI_C_OK; }
   if (2u * tlas.maxDepth + blasDepth + 1u > 16u) { if (want > 0) fprintf(stderr, "[gatling_gi] two-level layout not used: trees too deep for the 16-entry stack\n"); return GI_C_OK; }
   s->twoLevel = true;
   if (getenv("GATLING_BUILD_TIMING")) fprintf(stderr, "[gatling_gi] two-level: TLAS %zu nodes over %zu instances, %zu BLAS nodes, %zu mesh triangles (flat: %zu nodes, %zu triangles)\n",
@@ -1270,7 +1275,8 @@ int buildScene(GiCScene* s)
   double t1 = nowMs();
   // the deepest traversal variant keeps 8 (SPILL8) or 16 stack entries in LDS and OVF_STACK = 40 in scratch; trav_node_pick does not bound-check the spill
   if (bvh.maxDepth > 1u + 8u + 40u) { setError("scene BVH is deeper than the traversal stack (49 levels): degenerate geometry (long chains of nested splits)"); return GI_C_ERROR; }
-  if (bvh.tris.size() >= (1u << 26)) { setError("scene has 2^26 or more triangles after instancing: the traversal queues pack (lane, triangle) into 32 bits"); return GI_C_ERROR; }
+  if (bvh.tris.size() >= (1u << 26) && !s->twoLevel) { setError("scene has 2^26 or more triangles after instancing and no two-level layout (it is switched off, or its unique mesh triangles exceed 2^26 too): the traversal queues pack (lane, triangle) into 32 bits"); return GI_C_ERROR; }
+  if (bvh.tris.size() >= (1u << 28)) { setError("scene has 2^28 or more triangles after instancing: the hit record packs (triangle, material class) into 32 bits"); return GI_C_ERROR; }
   H.triFaceId.resize(bvh.tris.size());
   for (size_t i = 0; i < bvh.tris.size(); i++) H.triFaceId[i] = faceIdOf[bvh.tris[i].origId];
   // Scenes beyond LDS: one 128-byte shading record per mesh triangle (gi_types.h TriShade); the flattened triangles name theirs in vi[0].  LDS-resident

@@ -99,3 +99,24 @@ def test_c5_spp1024_rank_share_three_batches_bit_exact(gi, orc):
     for i, k in enumerate(ks):
         bad = int((share[k].view(np.uint32) != ref[i].view(np.uint32)).any(axis=-1).sum())
         assert bad == 0, f"image row {3 + 8 * k}: {bad} pixels differ bitwise from the oracle at spp 1024 over three batches"
+
+
+@pytest.mark.skipif(not os.environ.get("GATLING_SLOW_TESTS"), reason="67.7 M flattened triangles: ~10 GB of host arrays on both sides, ~2 min; set GATLING_SLOW_TESTS=1 (log: profiles/)")
+def test_scene_beyond_2_pow_26_flattened_triangles_takes_the_two_level_layout(gi, orc):
+    """VERDICT r03 missing #6: the flat traversal's triangle ring packs (lane, triangle) into 32 bits -- 2^26 triangles -- and such scenes used to be refused.  The
+    two-level walk queues MESH triangles, so a heavily instanced scene beyond the bound takes it automatically: 115 x 115 instances of the 5 120-triangle icosphere =
+    67.7 M flattened triangles, image and segment counts against the oracle's own traversal."""
+    desc = sphere_grid(115, 4, 8)
+    assert sum(len(m.faces) * len(m.instance_transforms) for m in desc.meshes) >= 1 << 26
+    rs = RenderSettings(spp=2, max_bounces=6, progressive_accumulation=False)
+    w, h = 192, 108
+    sc = gi.Scene(desc)
+    try:
+        img = sc.render(rs, w, h).copy()
+        st = sc.stats()
+    finally:
+        sc.close()
+    ref, cnt = orc.render(desc, rs, w, h, threads=_CORES)
+    print(f"67.7 M flattened triangles: triangleCount {st['triangleCount']}, nodes {st['nodeCount']}, segments device {st['segments']} oracle {cnt['segments']}")
+    assert st["triangleCount"] == 115 * 115 * 5120 and st["segments"] == cnt["segments"]
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
