@@ -81,6 +81,14 @@ __device__ __forceinline__ void begin_fresh_path(const FrameUniforms& U, const P
   uint32_t pixelLocal, sLocal; work_item(U, f.work, pixelLocal, sLocal);
   slot_begin_path(&st.slots[slot], f.rng, pixelLocal, sLocal);
 }
+// ... and when that first segment HIT: only the slot's work item is written here (16 bytes).  The hit record keeps the TRACE_FRESH flag and carries the rng state
+// in its spare word, and k_shade starts the path from constants -- throughput 1, radiance 0, bitfield 0 -- instead of gathering a slot that was written a moment
+// ago; it stores throughput and radiance as for every hit, which completes the slot.
+__device__ __forceinline__ void begin_fresh_hit(const FrameUniforms& U, const PathState& st, uint32_t slot, const FreshRec& f)
+{
+  uint32_t pixelLocal, sLocal; work_item(U, f.work, pixelLocal, sLocal);
+  st4(&st.slots[slot].id, u2f(pixelLocal), u2f(sLocal), u2f(1u), 0.0f);
+}
 
 __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st, QueueSet qs, Counters* cnt, uint32_t par, F4* __restrict__ sampleBuf)
 {
@@ -263,10 +271,11 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
       // sort by outcome and material class: hits go to their class's shade queue as (slot, hit, direction) records, misses
       // straight to k_raygen
       uint32_t klass = (mat >> 24) & 0xfu;
-      bool retired = false;
+      bool retired = false, freshHit = false; uint32_t freshRng = 0u;
       if (fresh) { // first segment of a path k_raygen did not write: begin it now (hit, or a miss that needs the slot), or retire it here
         const FreshRec f = qs.fresh[qIn - Q_TRACE_A][r];
-        if (hit || (DOME && (sc.domeTexture != 0u || sc.mediumStackSize != 0u))) begin_fresh_path(U, st, slot, f);
+        if (hit) { begin_fresh_hit(U, st, slot, f); freshRng = f.rng; freshHit = true; }
+        else if (DOME && (sc.domeTexture != 0u || sc.mediumStackSize != 0u)) begin_fresh_path(U, st, slot, f);
         else { retire_fresh_miss(U, f, sampleBuf); retired = true; }
       }
       bool volMiss = false; // the segment ended inside a medium: a scattering event for k_shade<2>, not a miss (rp_main.miss:57-66)
@@ -281,8 +290,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
       block_append<1 + MAT_CLASS_COUNT>(sh, trip, pred, qid, qs.cap, cnt, idx);
       if (hit || volMiss) {
         const uint32_t q = Q_HIT + klass, r = idx[1 + klass];
-        qs.slot[q][r] = slot;
-        if (!volMiss) { st4(&qs.a[q][r], t, u, v, u2f(tri)); st4(&qs.b[q][r], rdir.x, rdir.y, rdir.z, 0.0f); }
+        qs.slot[q][r] = freshHit ? (slot | TRACE_FRESH) : slot;
+        if (!volMiss) { st4(&qs.a[q][r], t, u, v, u2f(tri)); st4(&qs.b[q][r], rdir.x, rdir.y, rdir.z, u2f(freshRng)); }
         else { st4(&qs.a[q][r], rdir.w, ro.x, ro.y, u2f(VOLUME_MISS)); st4(&qs.b[q][r], rdir.x, rdir.y, rdir.z, ro.z); } // (tMax, origin) ride along
       }
       if (miss) {
@@ -503,7 +512,7 @@ __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, Que
   uint32_t trip = 0;
   for (uint32_t base = blockIdx.x * BLOCK; base < n; base += stride, trip++) {
     const uint32_t i = base + threadIdx.x;
-    bool hit = false, miss = false, volMiss = false, retired = false; uint32_t slot = 0, klass = 0;
+    bool hit = false, miss = false, volMiss = false, retired = false, freshHit = false; uint32_t slot = 0, klass = 0, freshRng = 0u;
     F4 h = F4{0.0f, 0.0f, 0.0f, 0.0f}, rdir = F4{0.0f, 0.0f, 0.0f, 0.0f};
     if (i < n) {
       const uint32_t r = reader_index(rd, i);
@@ -516,7 +525,8 @@ __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, Que
       if (hit) { klass = f2u(h.w) >> 28; h.w = u2f(f2u(h.w) & 0x0fffffffu); } // k_trace_dyn's result word: triangle index | material class << 28
       if (fresh) { // begin the path now (hit, or a miss that needs the slot: dome image / medium stack), or retire the sample here without a Slot
         const FreshRec f = qs.fresh[qIn - Q_TRACE_A][r];
-        if (hit || sc.domeTexture != 0u || sc.mediumStackSize != 0u) begin_fresh_path(U, st, slot, f);
+        if (hit) { begin_fresh_hit(U, st, slot, f); freshRng = f.rng; freshHit = true; }
+        else if (sc.domeTexture != 0u || sc.mediumStackSize != 0u) begin_fresh_path(U, st, slot, f);
         else { retire_fresh_miss(U, f, sampleBuf); retired = true; }
       }
       if (miss && sc.mediumStackSize) { // the segment ended inside a medium: scattering event for k_shade<2> (rp_main.miss:57-66)
@@ -531,8 +541,8 @@ __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, Que
     block_append<1 + MAT_CLASS_COUNT>(sh, trip, pred, qid, qs.cap, cnt, idx);
     if (hit || volMiss) {
       const uint32_t q = Q_HIT + klass, r = idx[1 + klass];
-      qs.slot[q][r] = slot;
-      if (!volMiss) { st4(&qs.a[q][r], h.x, h.y, h.z, h.w); st4(&qs.b[q][r], rdir.x, rdir.y, rdir.z, 0.0f); }
+      qs.slot[q][r] = freshHit ? (slot | TRACE_FRESH) : slot;
+      if (!volMiss) { st4(&qs.a[q][r], h.x, h.y, h.z, h.w); st4(&qs.b[q][r], rdir.x, rdir.y, rdir.z, u2f(freshRng)); }
       else { st4(&qs.a[q][r], h.x, h.y, h.z, u2f(VOLUME_MISS)); st4(&qs.b[q][r], rdir.x, rdir.y, rdir.z, rdir.w); }
     }
     if (miss) {
@@ -568,11 +578,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((KLASS ==
     if (i < n) {
       const uint32_t r = reader_index(rdr, i);
       slot = qs.slot[qHit][r];
+      const bool fresh = (slot & TRACE_FRESH) != 0u; slot &= ~TRACE_FRESH; // first hit of a path whose Slot holds only its work item yet (begin_fresh_hit)
       const F4 h = ld4(&qs.a[qHit][r]);
       const F4 rd = ld4(&qs.b[qHit][r]);
       Slot* S = &st.slots[slot];
-      const F4 tb = ld4(&S->thr);
-      const F4 rr = ld4(&S->rad);
+      F4 tb = F4{1.0f, 1.0f, 1.0f, u2f(0u)}, rr = F4{0.0f, 0.0f, 0.0f, rd.w}; // rp_main.rgen:274-276; the rng state came with the record
+      if (!fresh) { tb = ld4(&S->thr); rr = ld4(&S->rad); }
       ShadeIO io; io.throughput = v3(tb.x, tb.y, tb.z); io.radiance = v3(rr.x, rr.y, rr.z); io.bitfield = f2u(tb.w); io.rng = f2u(rr.w);
       float* M = VOLUME ? st.media + (size_t)slot * st.mediaStride : nullptr; // this path's medium stack + walkSegmentPdf
       shade_segment<KLASS, TEXTURED, VOLUME, NEE, PACKED>(U, sc, M, h, rd, io);
