@@ -629,7 +629,8 @@ __device__ inline V3 bsdf_albedo(const MaterialRec* m, const ShState& st, V3 k1)
   }
   OpbrParams o = opbr_params(m, st);
   float eta = relative_eta(st, o.eta);
-  float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1));
+  const float nk1c = st.hasCoatFrame ? fmax2(dot(st.coatNormal, k1), 1e-4f) : nk1; // the coat's Fresnel term in its own frame (geometry_coat_normal)
+  float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1c));
   float Fd = fresnel_dielectric(nk1, eta);
   float base = 1.0f - Fc, diel = 1.0f - o.metalness;
   V3 diffuse = (o.albedo * o.coatTint) * (base * diel * (1.0f - Fd) * (1.0f - o.tw));
@@ -742,7 +743,7 @@ __global__ void k_debug_bsdf(const MaterialRec* mat, uint32_t count, const float
   const float* p = in + 22 * (size_t)i; float* o = out + 15 * (size_t)i;
   ShState st; st.normal = v3(p); st.tangentU = v3(p + 3); st.tangentV = v3(p + 6); st.geomNormal = v3(p + 9);
   st.position = v3(0.0f, 0.0f, 0.0f); st.frontFace = (p[21] < 0.5f); st.meshFlags = 0u; st.material = 0u;
-  st.u = 0.0f; st.v = 0.0f; st.texMask = 0u; st.ior1 = 0.0f; st.ior2 = 0.0f; st.thinWalled = mat->klass == 2u && ((uint32_t)mat->p[MP_FEATURES] & MATF_THIN_WALLED) != 0u; st.sssVolume = false; st.mesh = 0u; st.prim = 0u; st.vi[0] = st.vi[1] = st.vi[2] = 0u; st.instanceId = 0; st.hu = st.hv = 0.0f;
+  st.u = 0.0f; st.v = 0.0f; st.texMask = 0u; st.ior1 = 0.0f; st.ior2 = 0.0f; st.thinWalled = mat->klass == 2u && ((uint32_t)mat->p[MP_FEATURES] & MATF_THIN_WALLED) != 0u; st.sssVolume = false; st.hasCoatFrame = false; st.mesh = 0u; st.prim = 0u; st.vi[0] = st.vi[1] = st.vi[2] = 0u; st.instanceId = 0; st.hu = st.hv = 0.0f;
   BsdfSample bs; bsdf_sample<KLASS_DYNAMIC>(mat, st, v3(p + 12), p[18], p[19], p[20], bs);
   BsdfEval ev; bsdf_evaluate<KLASS_DYNAMIC>(mat, st, v3(p + 12), v3(p + 15), ev);
   o[0] = bs.k2.x; o[1] = bs.k2.y; o[2] = bs.k2.z; o[3] = bs.overPdf.x; o[4] = bs.overPdf.y; o[5] = bs.overPdf.z; o[6] = bs.pdf; o[7] = (float)bs.event;

@@ -47,6 +47,7 @@ struct ShState {
   float ior1, ior2;              // Bsdf_sample_data.ior1/ior2 (rp_main.chit:188-189): < 0 = the material's own; 0 = empty-stack default
   bool thinWalled;               // mdl_thin_walled (rp_main.chit:155-157), set by shade_segment
   bool sssVolume;                // the render keeps a medium stack: OpenPBR's volumetric subsurface lobe is live (set by shade_segment)
+  bool hasCoatFrame; V3 coatNormal, coatTangentU, coatTangentV; // OpenPBR geometry_coat_normal (open_pbr_surface.mtlx:87, 560): the coat lobe's own frame (resolve_material_textures)
   uint32_t texMask;              // bit per TEX_* slot whose value below replaces the material constant at this hit
   V3 texBaseColor, texEmission; float texRoughness, texMetallic;
 };
@@ -115,7 +116,7 @@ __device__ __forceinline__ void setup_shading_state(const SceneView& sc, uint32_
   s.normal = nrm; s.geomNormal = gn;
   s.mesh = f2u(r5.y); s.instanceId = (int32_t)f2u(r5.z); s.prim = td.w; s.hu = hu; s.hv = hv;
   s.ior1 = 0.0f; s.ior2 = 0.0f;
-  s.thinWalled = false; s.sssVolume = false; s.texMask = 0u; s.texBaseColor = v3(0.0f, 0.0f, 0.0f); s.texEmission = s.texBaseColor; s.texRoughness = 0.0f; s.texMetallic = 0.0f;
+  s.thinWalled = false; s.sssVolume = false; s.hasCoatFrame = false; s.texMask = 0u; s.texBaseColor = v3(0.0f, 0.0f, 0.0f); s.texEmission = s.texBaseColor; s.texRoughness = 0.0f; s.texMetallic = 0.0f;
 }
 
 // mdl_adapt_normal (mdl_interface.glsl:238-256): Iray's shadow-terminator bend of a mapped normal
@@ -131,6 +132,19 @@ __device__ __forceinline__ V3 adapt_normal(V3 rayDir, V3 geomNormal, V3 normal)
 // Evaluates the material's textured inputs at the hit (== oracle resolve_material); a normal map replaces the shading frame.
 __device__ inline void resolve_material_textures(const SceneView& sc, const MaterialRec* m, V3 rayDir, ShState& st)
 {
+  { // geometry_coat_normal: a tangent-space map in the surface's own (unmapped) frame -> the coat lobe's frame; same treatment as the base normal map below
+    const TexBindingRec& b = m->tex[TEX_COAT_NORMAL];
+    if (m->klass == 2u && b.tex != 0u) {
+      float tu = st.u, tv = st.v; tex_transform_st(b, tu, tv);
+      const F4 t = tex_lookup_float4_2d(sc.textures[b.tex - 1u], tu, tv, b.mode & 0xffu, (b.mode >> 8) & 0xffu);
+      const float val[3] = {t.x * b.scale[0] + b.bias[0], t.y * b.scale[1] + b.bias[1], t.z * b.scale[2] + b.bias[2]};
+      V3 n = normalize((st.tangentU * val[0] + st.tangentV * val[1]) + st.normal * val[2]);
+      n = adapt_normal(rayDir, st.geomNormal, n);
+      const float hs = dot(cross(st.normal, st.tangentU), st.tangentV) >= 0.0f ? 1.0f : -1.0f;
+      const V3 tg = normalize(st.tangentU - n * dot(st.tangentU, n));
+      st.hasCoatFrame = true; st.coatNormal = n; st.coatTangentU = tg; st.coatTangentV = cross(n, tg) * hs;
+    }
+  }
 #pragma unroll
   for (uint32_t slot = 0; slot < TEX_OPACITY; slot++) { // TEX_OPACITY belongs to the any-hit test (cutout_opacity_at)
     const TexBindingRec& b = m->tex[slot];
@@ -233,6 +247,8 @@ enum : uint32_t { EV_SUBSURFACE = 64 }; // [ours] beside EV_DIFFUSE | EV_TRANSMI
 
 __device__ __forceinline__ V3 to_world(const ShState& s, V3 l) { return (s.tangentU * l.x + s.tangentV * l.y) + s.normal * l.z; }
 __device__ __forceinline__ V3 to_local(const ShState& s, V3 w) { return v3(dot(w, s.tangentU), dot(w, s.tangentV), dot(w, s.normal)); }
+__device__ __forceinline__ V3 to_world_coat(const ShState& s, V3 l) { return s.hasCoatFrame ? (s.coatTangentU * l.x + s.coatTangentV * l.y) + s.coatNormal * l.z : to_world(s, l); }
+__device__ __forceinline__ V3 to_local_coat(const ShState& s, V3 w) { return s.hasCoatFrame ? v3(dot(w, s.coatTangentU), dot(w, s.coatTangentV), dot(w, s.coatNormal)) : to_local(s, w); }
 __device__ __forceinline__ float schlick_w(float c) { float m = 1.0f - c; m = fmin2(fmax2(m, 0.0f), 1.0f); float m2 = m * m; return m2 * m2 * m; }
 __device__ __forceinline__ float ggx_lambda_term(float a2, float c) { return sqrtf(a2 + (1.0f - a2) * c * c); }
 __device__ __forceinline__ V3 schlick3(V3 F0, float c) { float w = schlick_w(c); return F0 + (v3(1.0f, 1.0f, 1.0f) - F0) * w; }
@@ -567,7 +583,10 @@ __device__ inline void opbr_sample_base(const OpbrParams& o, const ShState& st, 
   V3 l1 = to_local(st, k1);
   float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
   float z = x2;
-  float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1));
+  // the coat lobe lives in its own frame when geometry_coat_normal is mapped; its Fresnel term -- lobe probability and what it leaves for the base -- follows
+  V3 l1c = l1; float nk1c = nk1;
+  if (st.hasCoatFrame) { l1c = to_local_coat(st, k1); nk1c = fmax2(l1c.z, 1e-4f); l1c.z = nk1c; }
+  float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1c));
   float eta = 0.0f, Fd = 0.0f;
   uint32_t lobe = 0u; // 0 coat, 1 metal, 2 dielectric reflection, 3 transmission, 4 diffuse
   if (!(z < Fc)) {
@@ -626,7 +645,7 @@ __device__ inline void opbr_sample_base(const OpbrParams& o, const ShState& st, 
     if (o.filmWeight > 0.0f) out.overPdf = out.overPdf * under;
     return;
   }
-  const GgxOut g = ggx_sample2(l1, lobe == 0u ? o.coatAlpha : o.alpha, lobe == 0u ? o.coatAlphaY : o.alphaY, x0, x1);
+  const GgxOut g = ggx_sample2(lobe == 0u ? l1c : l1, lobe == 0u ? o.coatAlpha : o.alpha, lobe == 0u ? o.coatAlphaY : o.alphaY, x0, x1);
   if (lobe == 3u) {
     V3 h = normalize(l1 + g.l2);
     float kh = dot(l1, h);
@@ -649,7 +668,7 @@ __device__ inline void opbr_sample_base(const OpbrParams& o, const ShState& st, 
     if (o.filmWeight > 0.0f) out.overPdf = (o.transTint * o.coatTint) * ((v3(1.0f, 1.0f, 1.0f) - opbr_film_dielectric(o, kh, eta, Fh)) * ((G2 / G1) / (1.0f - Fd)));
     return;
   }
-  V3 k2 = to_world(st, g.l2);
+  V3 k2 = (lobe == 0u) ? to_world_coat(st, g.l2) : to_world(st, g.l2);
   if (!g.valid || !(dot(k2, st.geomNormal) > 0.0f)) return;
   out.k2 = k2; out.event = EV_GLOSSY | EV_REFLECTION;
   if (lobe == 0u) {
@@ -693,9 +712,11 @@ __device__ inline void opbr_evaluate_base(const OpbrParams& o, const ShState& st
   V3 l1 = to_local(st, k1), l2 = to_local(st, k2);
   float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
   float eta = relative_eta(st, o.eta);
-  float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1));
+  V3 l1c = l1, l2c = l2; float nk1c = nk1; // the coat lobe's own frame (geometry_coat_normal)
+  if (st.hasCoatFrame) { l1c = to_local_coat(st, k1); nk1c = fmax2(l1c.z, 1e-4f); l1c.z = nk1c; l2c = to_local_coat(st, k2); }
+  float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1c));
   float Fd = fresnel_dielectric(nk1, eta);
-  float fc, pc, khc; ggx_eval2(l1, l2, o.coatAlpha, o.coatAlphaY, fc, pc, khc);
+  float fc, pc, khc; ggx_eval2(l1c, l2c, o.coatAlpha, o.coatAlphaY, fc, pc, khc);
   float fs, ps, khs; ggx_eval2(l1, l2, o.alpha, o.alphaY, fs, ps, khs);
   float Fch = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(khc));
   V3 Fm = schlick_f82(o.albedo, o.metalTint, khs) * o.specWeight;

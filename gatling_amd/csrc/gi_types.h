@@ -85,7 +85,8 @@ constexpr uint32_t MP_FEATURES = 54, MATF_THIN_WALLED = 1u, MATF_FUZZ = 2u, MATF
 enum : uint32_t { MP_ALBEDO = 32, MP_F0 = 35, MP_ALPHA = 38, MP_COAT = 39, MP_COAT_ALPHA = 40, MP_COAT_F0 = 41, MP_ETA = 42, MP_SIGMA_A = 43, MP_CUTOUT = 46 /* mdl_cutout_opacity, 1 = opaque */ };
 // Textured material inputs (UsdUVTexture semantics: value = texel * scale + bias at the hit's st).  Replaces the MDL
 // renderer runtime's tex_lookup_* path (mdl_interface.glsl:127-145) for the inputs the closed-form materials expose.
-enum : uint32_t { TEX_BASE_COLOR = 0, TEX_EMISSION = 1, TEX_ROUGHNESS = 2, TEX_METALLIC = 3, TEX_NORMAL = 4, TEX_OPACITY = 5 /* read by the any-hit test, not by k_shade */, TEX_SLOT_COUNT = 6 };
+enum : uint32_t { TEX_BASE_COLOR = 0, TEX_EMISSION = 1, TEX_ROUGHNESS = 2, TEX_METALLIC = 3, TEX_NORMAL = 4, TEX_OPACITY = 5 /* read by the any-hit test, not by k_shade */,
+                  TEX_COAT_NORMAL = 6 /* OpenPBR geometry_coat_normal: the coat lobe's own shading frame */, TEX_SLOT_COUNT = 7 };
 enum : uint32_t { TEX_WRAP_CLAMP = 0, TEX_WRAP_REPEAT = 1, TEX_WRAP_MIRRORED_REPEAT = 2, TEX_WRAP_CLIP = 3 }; // mdl_types.glsl:117-120
 struct TexBindingRec {
   uint32_t tex;   // texture index + 1; 0 = input not textured
@@ -111,7 +112,7 @@ struct MaterialRec {
   TexBindingRec tex[TEX_SLOT_COUNT];
   float sss[8]; // volumetric subsurface medium (OpenPBR, derived on the host from subsurface_color / _radius / _radius_scale): sigma_s[3], sigma_t[3], -, -
 };
-static_assert(sizeof(MaterialRec) == 680, "MaterialRec must be 680 bytes");
+static_assert(sizeof(MaterialRec) == 744, "MaterialRec must be 744 bytes");
 // A texture: linear float RGBA texels, row 0 first.  (8-bit sources are decoded to linear float by the caller; a
 // compressed unorm8/half store is a later memory optimisation, the lookup arithmetic would not change.)
 struct TextureRec { const float* texels; uint32_t width, height; };

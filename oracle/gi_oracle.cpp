@@ -603,6 +603,8 @@ struct State {
   V3 cameraPosition = {0, 0, 0}; float frame = 0.0f; // ubo.cameraPosition / ubo.frame for the CAMERA_POSITION / FRAME scene-data names
   bool thinWalled = false; // mdl_thin_walled (rp_main.chit:155-157): both sides of the surface see the medium the ray travels in
   bool sssVolume = false;  // the render keeps a medium stack (mediumStackSize > 0): OpenPBR's volumetric subsurface_bsdf can be walked
+  // OpenPBR geometry_coat_normal (open_pbr_surface.mtlx:87, 560): the coat lobe's own shading frame, set by resolve_material when the input is mapped
+  bool hasCoatFrame = false; V3 coatNormal = {0, 0, 1}, coatTangentU = {1, 0, 0}, coatTangentV = {0, 1, 0};
   // renderer state of the hit for scene-data lookups (mdl_interface.glsl:281-301)
   const MeshData* mesh = nullptr; uint32_t prim = 0, hitIndices[3] = {0, 0, 0}; int32_t instanceId = 0; float bu = 0.0f, bv = 0.0f;
 };
@@ -776,7 +778,7 @@ float cutout_opacity_textured(const Prepared& P, const Tri& T, float hu, float h
 }
 // Per-hit material: the parameter block with its textured inputs evaluated at the hit's uv (UsdUVTexture: texel * scale + bias);
 // a normal map replaces the shading normal (tangent space -> world, adapt_normal, tangent frame re-orthonormalised).
-inline bool material_textured(const OrcMaterial& m) { for (int i = 0; i < ORC_TEX_OPACITY; i++) if (m.tex[i].texture >= 0 || m.primvarInput[i][0]) return true; return false; }
+inline bool material_textured(const OrcMaterial& m) { for (int i = 0; i < ORC_TEX_OPACITY; i++) if (m.tex[i].texture >= 0 || m.primvarInput[i][0]) return true; return m.tex[ORC_TEX_COAT_NORMAL].texture >= 0; }
 // The primvar a scene-data name resolves to for this mesh: instancer primvars first, mesh primvars override (Gi.cpp:913-929)
 inline const OrcPrimvar* find_primvar(const OrcMesh& m, const char* name)
 {
@@ -820,6 +822,19 @@ inline bool scene_data_lookup(const State& st, const char* name, int comps, floa
 OrcMaterial resolve_material(const Prepared& P, const OrcMaterial& m, State& st, V3 rayDir)
 {
   OrcMaterial r = m;
+  { // geometry_coat_normal: a tangent-space map in the surface's own (unmapped) frame -> the coat lobe's frame; same treatment as the base normal map below
+    const OrcTexBinding& b = m.tex[ORC_TEX_COAT_NORMAL];
+    if (m.klass == ORC_MAT_OPEN_PBR && b.texture >= 0 && (uint32_t)b.texture < P.textureCount) {
+      float tu = st.u, tv = st.v; tex_transform_st(b, tu, tv);
+      const F4v t = tex_lookup_float4_2d(P.textures[b.texture], tu, tv, b.wrapS, b.wrapT);
+      const float val[3] = {t.x * b.scale[0] + b.bias[0], t.y * b.scale[1] + b.bias[1], t.z * b.scale[2] + b.bias[2]};
+      V3 n = normalize((st.tangentU * val[0] + st.tangentV * val[1]) + st.normal * val[2]);
+      n = adapt_normal(rayDir, st.geomNormal, n);
+      const float hs = dot(cross(st.normal, st.tangentU), st.tangentV) >= 0.0f ? 1.0f : -1.0f;
+      const V3 tg = normalize(st.tangentU - n * dot(st.tangentU, n));
+      st.hasCoatFrame = true; st.coatNormal = n; st.coatTangentU = tg; st.coatTangentV = cross(n, tg) * hs;
+    }
+  }
   for (int slot = 0; slot < ORC_TEX_OPACITY; slot++) { // ORC_TEX_OPACITY belongs to the any-hit test (cutout_opacity_textured)
     const OrcTexBinding& b = m.tex[slot];
     if ((b.texture < 0 || (uint32_t)b.texture >= P.textureCount) && m.primvarInput[slot][0] && slot != ORC_TEX_NORMAL) { // primvar-driven input
@@ -865,6 +880,8 @@ struct BsdfEval { V3 diffuse, glossy; float pdf; };
 
 inline V3 to_world(const State& st, V3 l) { return (st.tangentU * l.x + st.tangentV * l.y) + st.normal * l.z; }
 inline V3 to_local(const State& st, V3 w) { return v3(dot(w, st.tangentU), dot(w, st.tangentV), dot(w, st.normal)); }
+inline V3 to_world_coat(const State& st, V3 l) { return st.hasCoatFrame ? (st.coatTangentU * l.x + st.coatTangentV * l.y) + st.coatNormal * l.z : to_world(st, l); }
+inline V3 to_local_coat(const State& st, V3 w) { return st.hasCoatFrame ? v3(dot(w, st.coatTangentU), dot(w, st.coatTangentV), dot(w, st.coatNormal)) : to_local(st, w); }
 
 inline float schlick_w(float c) { float m = 1.0f - c; m = fmin2(fmax2(m, 0.0f), 1.0f); float m2 = m * m; return m2 * m2 * m; }
 inline float ggx_lambda_term(float a2, float c) { return sqrtf(a2 + (1.0f - a2) * c * c); }
@@ -1253,10 +1270,13 @@ static void opbr_sample_base(const OpbrParams& o, const State& st, V3 k1, const 
   V3 l1 = to_local(st, k1);
   float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
   float z = xi[2];
-  float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1));
+  // the coat lobe lives in its own frame when geometry_coat_normal is mapped (:560); its Fresnel term -- lobe probability and what it leaves for the base -- follows
+  V3 l1c = l1; float nk1c = nk1;
+  if (st.hasCoatFrame) { l1c = to_local_coat(st, k1); nk1c = fmax2(l1c.z, 1e-4f); l1c.z = nk1c; }
+  float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1c));
   if (z < Fc) { // coat reflection
-    GgxOut g = ggx_sample2(l1, o.coatAlpha, o.coatAlphaY, xi[0], xi[1]);
-    V3 k2 = to_world(st, g.l2);
+    GgxOut g = ggx_sample2(l1c, o.coatAlpha, o.coatAlphaY, xi[0], xi[1]);
+    V3 k2 = to_world_coat(st, g.l2);
     if (!g.valid || !(dot(k2, st.geomNormal) > 0.0f)) return;
     float Fh = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(g.kh));
     float w = (Fh / Fc) * g.g2OverG1;
@@ -1379,9 +1399,11 @@ static void opbr_evaluate_base(const OpbrParams& o, const State& st, V3 k1, V3 k
   V3 l1 = to_local(st, k1), l2 = to_local(st, k2);
   float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
   float eta = relative_eta(st, o.eta); (void)frontFace;
-  float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1));
+  V3 l1c = l1, l2c = l2; float nk1c = nk1; // the coat lobe's own frame (geometry_coat_normal)
+  if (st.hasCoatFrame) { l1c = to_local_coat(st, k1); nk1c = fmax2(l1c.z, 1e-4f); l1c.z = nk1c; l2c = to_local_coat(st, k2); }
+  float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1c));
   float Fd = fresnel_dielectric(nk1, eta);
-  float fc, pc, khc; ggx_eval2(l1, l2, o.coatAlpha, o.coatAlphaY, fc, pc, khc);
+  float fc, pc, khc; ggx_eval2(l1c, l2c, o.coatAlpha, o.coatAlphaY, fc, pc, khc);
   float fs, ps, khs; ggx_eval2(l1, l2, o.alpha, o.alphaY, fs, ps, khs);
   float Fch = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(khc));
   V3 Fm = schlick_f82(o.albedo, o.metalTint, khs) * o.specWeight;
@@ -1528,7 +1550,8 @@ V3 bsdf_albedo(const OrcMaterial& m, const State& st, V3 k1)
   }
   OpbrParams o = opbr_params(m);
   float eta = relative_eta(st, o.eta);
-  float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1));
+  const float nk1c = st.hasCoatFrame ? fmax2(dot(st.coatNormal, k1), 1e-4f) : nk1; // the coat's Fresnel term in its own frame (geometry_coat_normal)
+  float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1c));
   float Fd = fresnel_dielectric(nk1, eta);
   float base = 1.0f - Fc, diel = 1.0f - o.metalness;
   V3 diffuse = (o.albedo * o.coatTint) * (base * diel * (1.0f - Fd) * (1.0f - o.tw));

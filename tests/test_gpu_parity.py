@@ -331,6 +331,35 @@ def test_volumetric_subsurface_on_device(gi, orc):
     assert not np.array_equal(off, img)
 
 
+def test_coat_normal_on_device(gi, orc):
+    """OpenPBR geometry_coat_normal as a seventh texture slot (gi_shading.h resolve_material_textures / to_local_coat): the coat lobe in its own frame -- sampling,
+    evaluation (NEE), Fresnel split with the base -- on the coated ball of the oracle test and on the texture scene's OpenPBR ball with base AND coat normal maps and a
+    texture-coordinate transform on the coat map: device == oracle bit for bit; the Albedo AOV follows the coat frame too."""
+    from test_oracle_render import _coated_ball
+    from gatling_amd.scene import TEX_COAT_NORMAL, TEX_NORMAL, TextureBinding, usd_transform_2d
+    yy, xx = np.mgrid[0:32, 0:64]
+    bumpy = np.zeros((32, 64, 4), np.float32)
+    bumpy[..., 0] = 0.5 + 0.35 * np.sin(xx * 1.7); bumpy[..., 1] = 0.5 + 0.35 * np.cos(yy * 2.3); bumpy[..., 2] = 0.85; bumpy[..., 3] = 1.0
+    rs = RenderSettings(spp=6, max_bounces=4, next_event_estimation=True)
+    render_both(gi, orc, _coated_ball(bumpy), rs, 64, 64, exact=True)
+    desc = textured_scene()
+    desc.textures.append(bumpy)
+    ball = desc.materials[1]
+    assert ball.klass == MAT_OPEN_PBR
+    ball.params = MaterialDesc.open_pbr(base_color=(0.8, 0.8, 0.8), specular_roughness=0.25, coat_weight=0.8, coat_roughness=0.1, coat_color=(0.9, 0.8, 0.7)).params
+    ball.textures[TEX_COAT_NORMAL] = TextureBinding(texture=len(desc.textures) - 1, scale=(2.0, 2.0, 2.0, 1.0), bias=(-1.0, -1.0, -1.0, 0.0),
+                                                   transform=usd_transform_2d(25.0, (3.0, 2.0), (0.1, 0.2)))
+    ball.textures[TEX_NORMAL] = TextureBinding(texture=3, scale=(2.0, 2.0, 2.0, 1.0), bias=(-1.0, -1.0, -1.0, 0.0))
+    img, ref, st = render_both(gi, orc, desc, RenderSettings(spp=4, max_bounces=6, next_event_estimation=True), 96, 54, exact=True)
+    sc = gi.Scene(desc)
+    try:
+        got = sc.render_aovs(RenderSettings(spp=2, max_bounces=2, progressive_accumulation=False), 96, 54, ["albedo"])["albedo"]
+    finally:
+        sc.close()
+    want = orc.render_aovs(desc, RenderSettings(spp=2, max_bounces=2, progressive_accumulation=False), 96, 54, ["albedo"])["albedo"]
+    assert np.array_equal(got[..., :3].view(np.uint32), want[..., :3].view(np.uint32))
+
+
 def _aov_scene():
     desc = sphere_grid(grid=3, subdivisions=1, material_count=4)
     rng = np.random.default_rng(8)

@@ -751,3 +751,43 @@ def test_volumetric_subsurface(orc):
     desc2, rs2 = _sss_ball(plain); rs2.medium_stack_size = 0
     d, _ = orc.render(desc2, rs2, w, h, threads=8)
     assert np.array_equal(c.view(np.uint32), d.view(np.uint32))
+
+
+def _coated_ball(coat_map, coat_weight=1.0, scale=(2.0, 2.0, 2.0, 1.0), bias=(-1.0, -1.0, -1.0, 0.0)):
+    from gatling_amd.meshprep import bake_vertices
+    from gatling_amd.scene import TEX_COAT_NORMAL, CameraDesc, MeshDesc, SceneDesc, TextureBinding
+    from gatling_amd.scenes import icosphere
+    pts, faces = icosphere(3)
+    uv = np.stack([np.arctan2(pts[:, 1], pts[:, 0]) / (2 * np.pi) + 0.5, np.arccos(np.clip(pts[:, 2], -1, 1)) / np.pi], axis=1).astype(np.float32)
+    s = SceneDesc()
+    m = MaterialDesc.open_pbr(base_color=(0.05, 0.05, 0.05), specular_weight=0.0, coat_weight=coat_weight, coat_roughness=0.15, coat_ior=1.6)
+    if coat_map is not None:
+        s.textures.append(coat_map)
+        m.textures = {TEX_COAT_NORMAL: TextureBinding(texture=0, scale=scale, bias=bias)}
+    s.materials = [m]
+    s.meshes = [MeshDesc(name="/Ball", vertices=bake_vertices(pts, pts, uv), faces=faces, material=0)]
+    s.rect_lights = [RectLight(origin=(0.0, -2.0, 3.0), t0=(1, 0, 0), t1=(0, 1, 0), base_emission=(30, 30, 30), width=0.6, height=0.6)]
+    s.camera = CameraDesc(position=(0.0, -3.2, 0.0), forward=(0.0, 1.0, 0.0), up=(0.0, 0.0, 1.0), vfov=0.7)
+    return s
+
+
+def test_coat_normal(orc):
+    """OpenPBR geometry_coat_normal (open_pbr_surface.mtlx:87, 560): a tangent-space normal map gives the coat lobe a shading frame of its own; the base keeps the
+    surface's.  A flat map is (to rounding) the unmapped material; a bumpy map breaks the coat's highlight up while a material without coat does not see it at all
+    (bit for bit); UsdPreviewSurface ignores the slot."""
+    rs = RenderSettings(spp=16, max_bounces=3, next_event_estimation=True, clear_color=(0.0, 0.0, 0.0, 0.0), max_sample_value=1e9)
+    w = h = 40
+    flat = np.zeros((4, 4, 4), np.float32); flat[..., :3] = (0.5, 0.5, 1.0); flat[..., 3] = 1.0
+    yy, xx = np.mgrid[0:32, 0:64]
+    bumpy = np.zeros((32, 64, 4), np.float32)
+    bumpy[..., 0] = 0.5 + 0.35 * np.sin(xx * 1.7); bumpy[..., 1] = 0.5 + 0.35 * np.cos(yy * 2.3); bumpy[..., 2] = 0.85; bumpy[..., 3] = 1.0
+    plain, _ = orc.render(_coated_ball(None), rs, w, h, threads=8)
+    a, _ = orc.render(_coated_ball(flat), rs, w, h, threads=8)
+    b, _ = orc.render(_coated_ball(bumpy), rs, w, h, threads=8)
+    assert np.isfinite(b).all()
+    np.testing.assert_allclose(a[..., :3].mean(), plain[..., :3].mean(), rtol=0.03)      # a flat map is the surface normal again (renormalised, Iray bend: not bit-identical)
+    assert np.abs(a - plain).mean() < 0.2 * np.abs(b - plain).mean()                      # ... while bumps really move the highlight
+    assert np.abs(b - plain).max() > 0.05
+    c0, _ = orc.render(_coated_ball(None, coat_weight=0.0), rs, w, h, threads=8)
+    c1, _ = orc.render(_coated_ball(bumpy, coat_weight=0.0), rs, w, h, threads=8)
+    assert np.array_equal(c0.view(np.uint32), c1.view(np.uint32))                          # no coat, no effect
