@@ -9,7 +9,7 @@ setters (reference interface ``src/gi/gtl/gi/Gi.h:86-175``) -- written sequentia
     GiCCameraDesc (16 x f32)
     u32 nTextures   { u32 width, height; f32 rgba[h * w * 4] }
     u32 nMaterials  { str name; u32 klass; u32 nParams; f32 params[nParams];
-                      6 x { i32 texture (-1: none), wrapS, wrapT, channel; f32 scale[4], bias[4] }; 6 x str primvarName }   (GI_C_TEX_* slots)
+                      7 x { i32 texture (-1: none), wrapS, wrapT, channel; f32 scale[4], bias[4]; u32 hasTransform; f32 xf[6] }; 7 x str primvarName }   (GI_C_TEX_* slots)
     u32 hasDome     [i32 texture; f32 rotation[4], baseEmission[3], diffuse, specular]
     u32 nMeshes     { str name; u32 nVertices, nFaces; i32 id; u32 flags; i32 material; u32 maxFaceId; f32 transform[16];
                       u32 nInstances; f32 instanceTransforms[nInstances * 16]; [i32 instanceIds[nInstances]]
@@ -31,8 +31,8 @@ import numpy as np
 from .scene import (CameraDesc, DiskLight, DistantLight, DomeLight, MaterialDesc, MeshDesc, P_COUNT, Primvar, RectLight, RenderSettings,
                     SceneDesc, SphereLight, TextureBinding, VERTEX_DTYPE)
 
-MAGIC, END, VERSION = b"GSCN", b"END!", 1
-TEX_SLOTS = 6
+MAGIC, END, VERSION = b"GSCN", b"END!", 2  # 2 (round 4): seven texture slots (geometry_coat_normal), a texture-coordinate transform per slot
+TEX_SLOTS = 7
 F_DOUBLE_SIDED, F_LEFT_HANDED, F_VISIBLE, F_FACE_IDS, F_INSTANCE_IDS = 1, 2, 4, 8, 16
 
 
@@ -94,6 +94,9 @@ def save_scene(path, desc: SceneDesc, settings: RenderSettings = None, width: in
                     b = TextureBinding()
                 w.i32(b.texture, b.wrap_s, b.wrap_t, b.channel)
                 w.f32(*b.scale, *b.bias)
+                xf = getattr(b, "transform", None)
+                w.u32(0 if xf is None else 1)
+                w.f32(*(xf if xf is not None else (1.0, 0.0, 0.0, 0.0, 1.0, 0.0)))
             for slot in range(TEX_SLOTS):
                 w.string(m.primvar_inputs.get(slot, ""))
         d = desc.dome_light
@@ -205,8 +208,10 @@ def load_scene(path):
         for slot in range(TEX_SLOTS):
             tex, ws, wt, ch = r.i32(), r.i32(), r.i32(), r.i32()
             sb = r.f32(8)
+            has_xf = r.u32()
+            xf = r.f32(6)
             if tex >= 0:
-                m.textures[slot] = TextureBinding(tex, ws, wt, ch, tuple(sb[:4]), tuple(sb[4:]))
+                m.textures[slot] = TextureBinding(tex, ws, wt, ch, tuple(sb[:4]), tuple(sb[4:]), tuple(float(x) for x in xf) if has_xf else None)
         for slot in range(TEX_SLOTS):
             s = r.string()
             if s:

@@ -86,7 +86,7 @@ int main(int argc, char** argv)
   fclose(f);
   Rd r = {data, (size_t)size, 0, 0};
   const void* magic = rd_take(&r, 4);
-  if (!magic || memcmp(magic, "GSCN", 4) || rd_u32(&r) != 1u) return fail("not a version-1 .gscn file");
+  if (!magic || memcmp(magic, "GSCN", 4) || rd_u32(&r) != 2u) return fail("not a version-2 .gscn file");
 
   FileSettings fs;
   memset(&fs, 0, sizeof fs);
@@ -167,9 +167,13 @@ int main(int argc, char** argv)
       const int32_t tex = rd_i32(&r);
       b.wrapS = rd_i32(&r); b.wrapT = rd_i32(&r); b.channel = rd_i32(&r);
       rd_f32(&r, b.scale, 4); rd_f32(&r, b.bias, 4);
+      const uint32_t hasXf = rd_u32(&r);
+      float xf[6];
+      rd_f32(&r, xf, 6);
       if (tex >= 0 && (uint32_t)tex < nTex && !infoOnly) {
         b.texture = textures[tex];
         if (giCSetMaterialTexture(materials[m], slot, &b) != GI_C_OK) { fprintf(stderr, "gi_render: giCSetMaterialTexture: %s\n", giCGetLastError()); return 1; }
+        if (hasXf && giCSetMaterialTextureTransform(materials[m], slot, xf) != GI_C_OK) { fprintf(stderr, "gi_render: giCSetMaterialTextureTransform: %s\n", giCGetLastError()); return 1; }
       }
     }
     for (int slot = 0; slot < GI_C_TEX_SLOT_COUNT; slot++) {
