@@ -567,29 +567,62 @@ inline bool box_test(const BvhNode& n, V3 o, V3 inv, float tMin, float tMax)
   return t0 <= t1 * 1.0001f + 1e-6f;
 }
 
-bool trace_closest(const Prepared& P, V3 o, V3 d, float tMin, float tMax, Hit& h, uint32_t rng = 0u)
+// box_test that also reports the entry distance (the same arithmetic)
+inline bool box_entry(const BvhNode& n, V3 o, V3 inv, float tMin, float tMax, float& entry)
+{
+  float t0 = tMin, t1 = tMax;
+  const float oo[3] = {o.x, o.y, o.z}, ii[3] = {inv.x, inv.y, inv.z};
+  for (int a = 0; a < 3; a++) {
+    float ta = (n.lo[a] - oo[a]) * ii[a], tb = (n.hi[a] - oo[a]) * ii[a];
+    if (ta > tb) { float x = ta; ta = tb; tb = x; }
+    if (ta != ta || tb != tb) continue;
+    t0 = fmax2(t0, ta); t1 = fmin2(t1, tb);
+  }
+  entry = t0;
+  return t0 <= t1 * 1.0001f + 1e-6f;
+}
+// Children are visited nearer first and a stacked node is dropped when its entry distance has been overtaken (r04: the unordered walk made the big-scene tests
+// minutes long).  Hits do not depend on the visiting order (tMin < t < tBest, ties to the lower triangle index), and the set of nodes visited is a superset of the
+// unordered walk's (a node that walk would enter passes both the test at push time and the distance check at pop time), so results are unchanged -- the golden
+// fixtures pin that.  ANY: stop at the first accepted hit (the boolean is the same).
+template <bool ANY>
+bool trace_walk(const Prepared& P, V3 o, V3 d, float tMin, float tMax, Hit& h, uint32_t rng)
 {
   float tBest = tMax; bool any = false; h.tri = 0xffffffffu;
   // accept tMin < t < tMax; h.tri == ~0 marks 'no hit yet' so the tie rule cannot admit t == tMax
   if (P.bvh.empty()) {
-    for (uint32_t i = 0; i < P.tris.size(); i++) any |= tri_test(P, P.tris[i], o, d, tMin, tBest, i, h, rng);
+    for (uint32_t i = 0; i < P.tris.size(); i++) { any |= tri_test(P, P.tris[i], o, d, tMin, tBest, i, h, rng); if (ANY && any) return true; }
     return any;
   }
   V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-  uint32_t stack[128]; int sp = 0; stack[sp++] = 0;
+  struct Item { uint32_t node; float entry; };
+  Item stack[160]; int sp = 0;
+  { float e; if (box_entry(P.bvh[0], o, inv, tMin, tBest, e)) stack[sp++] = Item{0u, e}; }
   while (sp) {
-    const BvhNode& n = P.bvh[stack[--sp]];
-    if (!box_test(n, o, inv, tMin, tBest)) continue;
-    if (n.count) { for (uint32_t i = n.left; i < n.left + n.count; i++) { uint32_t t = P.bvhTris[i]; any |= tri_test(P, P.tris[t], o, d, tMin, tBest, t, h, rng); } }
-    else { stack[sp++] = n.left; stack[sp++] = n.left + 1; }
+    const Item it = stack[--sp];
+    if (it.entry > tBest * 1.0001f + 1e-6f) continue;
+    const BvhNode& n = P.bvh[it.node];
+    if (n.count) {
+      for (uint32_t i = n.left; i < n.left + n.count; i++) { uint32_t t = P.bvhTris[i]; any |= tri_test(P, P.tris[t], o, d, tMin, tBest, t, h, rng); }
+      if (ANY && any) return true;
+    } else {
+      float el, er;
+      const bool hl = box_entry(P.bvh[n.left], o, inv, tMin, tBest, el), hr = box_entry(P.bvh[n.left + 1], o, inv, tMin, tBest, er);
+      if (hl && hr) {
+        if (el <= er) { stack[sp++] = Item{n.left + 1, er}; stack[sp++] = Item{n.left, el}; }
+        else { stack[sp++] = Item{n.left, el}; stack[sp++] = Item{n.left + 1, er}; }
+      } else if (hl) stack[sp++] = Item{n.left, el};
+      else if (hr) stack[sp++] = Item{n.left + 1, er};
+    }
   }
   return any;
 }
+bool trace_closest(const Prepared& P, V3 o, V3 d, float tMin, float tMax, Hit& h, uint32_t rng = 0u) { return trace_walk<false>(P, o, d, tMin, tMax, h, rng); }
 
 // Shadow rays: gl_RayFlagsTerminateOnFirstHitEXT (rp_main.rgen:405); any hit in (tMin,tMax) occludes.
 bool trace_any(const Prepared& P, V3 o, V3 d, float tMin, float tMax, uint32_t rng)
 {
-  Hit h; return trace_closest(P, o, d, tMin, tMax, h, rng);
+  Hit h; return trace_walk<true>(P, o, d, tMin, tMax, h, rng);
 }
 
 // ---------------------------------------------------------------------------------------------
