@@ -1571,7 +1571,7 @@ int ensurePathState(SceneDevice* s, size_t slots, uint32_t gridA, uint32_t gridB
   if (cap > s->queueCap) {
     const size_t n = (size_t)cap * NSHARD;
     for (uint32_t q = 0; q < Q_COUNT; q++) {
-      const bool hasRecord = (q == Q_TRACE_A || q == Q_TRACE_B || q >= Q_HIT || q == Q_SHADOW);
+      const bool hasRecord = (q == Q_TRACE_A || q == Q_TRACE_B || q == Q_SHADOW); // (the HIT queues hold indices into the TRACE queue: gi_queues.h)
       GI_ALLOC(s->qSlot[q].alloc(n));
       if (hasRecord) { GI_ALLOC(s->qA[q].alloc(n)); GI_ALLOC(s->qB[q].alloc(n)); }
       if (q == Q_SHADOW) GI_ALLOC(s->qC[q].alloc(n));
@@ -1813,7 +1813,7 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
     // what a plan costs: the slot pool with its queues (per slot: the Slot, the medium stack, and a share of every queue's records) and the sample buffer
     auto planBytes = [&](size_t nSlots, uint64_t nBatch) -> uint64_t {
       const uint64_t cap = shardCapacity(nSlots, wideBlocks, traceBlocks);
-      const uint64_t perQueueEntry = 4ull * Q_COUNT + 32ull * (2 + MAT_CLASS_COUNT + 1) + 16ull + 8ull * 2;
+      const uint64_t perQueueEntry = 4ull * Q_COUNT + 32ull * (2 + 1) + 16ull + 8ull * 2;
       return (fused ? 0ull : (uint64_t)nSlots * (sizeof(Slot) + 4ull * mediaStride) + cap * NSHARD * perQueueEntry) + (uint64_t)pixels * nBatch * 16ull + (uint64_t)pixels * 16ull;
     };
     const bool pinnedPlan = getenv("GATLING_POOL_SLOTS") || s->optPoolSlots || getenv("GATLING_SAMPLE_BUFFER_MB") || s->optSampleBufferMb; // the caller's sizes are taken as given
@@ -2212,11 +2212,16 @@ static int giCTraceRaysImpl(GiCScene* s, uint32_t count, const float* origins, c
       hipStreamSynchronize(st) != hipSuccess) { setError("giCTraceRays: readback failed"); return -1; }
   std::vector<F4> hit(count, F4{tMax, 0.0f, 0.0f, 0.0f});
   for (uint32_t i = 0; i < count; i++) { uint32_t m = 0xffffffffu; memcpy(&hit[i].w, &m, 4); }
+  // results stay in the ray records (a = t, u, v, triangle | class << 28); the class queues hold their indices
+  std::vector<uint32_t> hitIdx(qn);
+  if (hipMemcpy(qa.data(), s->qA[Q_TRACE_A].ptr, qn * sizeof(F4), hipMemcpyDeviceToHost) != hipSuccess) { setError("giCTraceRays: readback failed"); return -1; }
   for (uint32_t klass = 0; klass < MAT_CLASS_COUNT; klass++) {
-    if (hipMemcpy(qslot.data(), s->qSlot[Q_HIT + klass].ptr, qn * 4, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(qa.data(), s->qA[Q_HIT + klass].ptr, qn * sizeof(F4), hipMemcpyDeviceToHost) != hipSuccess) { setError("giCTraceRays: readback failed"); return -1; }
+    if (hipMemcpy(hitIdx.data(), s->qSlot[Q_HIT + klass].ptr, qn * 4, hipMemcpyDeviceToHost) != hipSuccess) { setError("giCTraceRays: readback failed"); return -1; }
     for (uint32_t k = 0; k < NSHARD; k++)
-      for (uint32_t j = 0; j < c.count[Q_HIT + klass][k].v; j++) { size_t r = (size_t)k * s->queueCap + j; if (qslot[r] < count) hit[qslot[r]] = qa[r]; }
+      for (uint32_t j = 0; j < c.count[Q_HIT + klass][k].v; j++) {
+        const uint32_t ri = hitIdx[(size_t)k * s->queueCap + j] & 0x3fffffffu;
+        if (ri < qn && qslot[ri] < count) { F4 h = qa[ri]; uint32_t w; memcpy(&w, &h.w, 4); w &= 0x0fffffffu; memcpy(&h.w, &w, 4); hit[qslot[ri]] = h; }
+      }
   }
   int hits = 0;
   for (uint32_t i = 0; i < count; i++) {

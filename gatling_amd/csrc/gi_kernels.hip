@@ -81,14 +81,7 @@ __device__ __forceinline__ void begin_fresh_path(const FrameUniforms& U, const P
   uint32_t pixelLocal, sLocal; work_item(U, f.work, pixelLocal, sLocal);
   slot_begin_path(&st.slots[slot], f.rng, pixelLocal, sLocal);
 }
-// ... and when that first segment HIT: only the slot's work item is written here (16 bytes).  The hit record keeps the TRACE_FRESH flag and carries the rng state
-// in its spare word, and k_shade starts the path from constants -- throughput 1, radiance 0, bitfield 0 -- instead of gathering a slot that was written a moment
-// ago; it stores throughput and radiance as for every hit, which completes the slot.
-__device__ __forceinline__ void begin_fresh_hit(const FrameUniforms& U, const PathState& st, uint32_t slot, const FreshRec& f)
-{
-  uint32_t pixelLocal, sLocal; work_item(U, f.work, pixelLocal, sLocal);
-  st4(&st.slots[slot].id, u2f(pixelLocal), u2f(sLocal), u2f(1u), 0.0f);
-}
+// (a first segment that HIT is begun by k_shade, which gathers the ray record and the FreshRec beside it and completes the Slot in one go)
 
 __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st, QueueSet qs, Counters* cnt, uint32_t par, F4* __restrict__ sampleBuf)
 {
@@ -271,10 +264,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
       // sort by outcome and material class: hits go to their class's shade queue as (slot, hit, direction) records, misses
       // straight to k_raygen
       uint32_t klass = (mat >> 24) & 0xfu;
-      bool retired = false, freshHit = false; uint32_t freshRng = 0u;
-      if (fresh) { // first segment of a path k_raygen did not write: begin it now (hit, or a miss that needs the slot), or retire it here
+      bool retired = false, freshHit = false;
+      if (fresh) { // first segment of a path k_raygen did not write: k_shade begins it (hit), or it is begun / retired here (miss)
         const FreshRec f = qs.fresh[qIn - Q_TRACE_A][r];
-        if (hit) { begin_fresh_hit(U, st, slot, f); freshRng = f.rng; freshHit = true; }
+        if (hit) freshHit = true;
         else if (DOME && (sc.domeTexture != 0u || sc.mediumStackSize != 0u)) begin_fresh_path(U, st, slot, f);
         else { retire_fresh_miss(U, f, sampleBuf); retired = true; }
       }
@@ -288,11 +281,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
 #pragma unroll
       for (uint32_t c = 0; c < MAT_CLASS_COUNT; c++) { pred[1 + c] = (hit || volMiss) && klass == c; qid[1 + c] = Q_HIT + c; }
       block_append<1 + MAT_CLASS_COUNT>(sh, trip, pred, qid, qs.cap, cnt, idx);
-      if (hit || volMiss) {
-        const uint32_t q = Q_HIT + klass, r = idx[1 + klass];
-        qs.slot[q][r] = freshHit ? (slot | TRACE_FRESH) : slot;
-        if (!volMiss) { st4(&qs.a[q][r], t, u, v, u2f(tri)); st4(&qs.b[q][r], rdir.x, rdir.y, rdir.z, u2f(freshRng)); }
-        else { st4(&qs.a[q][r], rdir.w, ro.x, ro.y, u2f(VOLUME_MISS)); st4(&qs.b[q][r], rdir.x, rdir.y, rdir.z, ro.z); } // (tMax, origin) ride along
+      if (hit || volMiss) { // the result stays in the ray's record (the form k_trace_dyn leaves), the class queue gets its index
+        if (!volMiss) st4(&qs.a[qIn][r], t, u, v, u2f(tri | (klass << 28)));
+        else { st4(&qs.a[qIn][r], rdir.w, ro.x, ro.y, u2f(MISS)); reinterpret_cast<float*>(&qs.b[qIn][r])[3] = ro.z; } // (tMax, origin) for the scattering event
+        qs.slot[Q_HIT + klass][idx[1 + klass]] = r | (freshHit ? HIT_FRESH : 0u) | (volMiss ? HIT_VOLUME : 0u);
       }
       if (miss) {
         if (DOME && sc.domeTexture) { dome_miss(sc, st, slot, v3(rdir.x, rdir.y, rdir.z)); qs.slot[qMiss][idx[0]] = slot; } // scene has a dome light image
@@ -512,22 +504,24 @@ __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, Que
   uint32_t trip = 0;
   for (uint32_t base = blockIdx.x * BLOCK; base < n; base += stride, trip++) {
     const uint32_t i = base + threadIdx.x;
-    bool hit = false, miss = false, volMiss = false, retired = false, freshHit = false; uint32_t slot = 0, klass = 0, freshRng = 0u;
+    bool hit = false, miss = false, volMiss = false, retired = false, freshHit = false; uint32_t slot = 0, klass = 0, rec = 0u;
     F4 h = F4{0.0f, 0.0f, 0.0f, 0.0f}, rdir = F4{0.0f, 0.0f, 0.0f, 0.0f};
     if (i < n) {
-      const uint32_t r = reader_index(rd, i);
+      const uint32_t r = reader_index(rd, i); rec = r;
       slot = qs.slot[qIn][r];
       const bool fresh = (slot & TRACE_FRESH) != 0u; slot &= ~TRACE_FRESH; // camera ray of a path whose Slot is still unwritten (FLAG_DEFER_SLOT)
       h = ld4(&qs.a[qIn][r]);
       hit = f2u(h.w) != MISS; miss = !hit;
-      // the direction is copied into the hit record, or needed at a miss by the dome lookup / the scattering event; a plain miss (C4: three camera rays in four) does not read it
-      if (hit || sc.domeTexture != 0u || sc.mediumStackSize != 0u) rdir = ld4(&qs.b[qIn][r]);
-      if (hit) { klass = f2u(h.w) >> 28; h.w = u2f(f2u(h.w) & 0x0fffffffu); } // k_trace_dyn's result word: triangle index | material class << 28
-      if (fresh) { // begin the path now (hit, or a miss that needs the slot: dome image / medium stack), or retire the sample here without a Slot
-        const FreshRec f = qs.fresh[qIn - Q_TRACE_A][r];
-        if (hit) { begin_fresh_hit(U, st, slot, f); freshRng = f.rng; freshHit = true; }
-        else if (sc.domeTexture != 0u || sc.mediumStackSize != 0u) begin_fresh_path(U, st, slot, f);
-        else { retire_fresh_miss(U, f, sampleBuf); retired = true; }
+      // the direction is needed at a miss by the dome lookup only (hits stay in place: k_shade gathers them)
+      if (miss && sc.domeTexture != 0u) rdir = ld4(&qs.b[qIn][r]);
+      if (hit) klass = f2u(h.w) >> 28; // k_trace_dyn's result word: triangle index | material class << 28
+      if (fresh) { // k_shade begins the path (hit); a miss that needs the slot (dome image / medium stack) begins it here, any other retires the sample without a Slot
+        if (hit) freshHit = true;
+        else {
+          const FreshRec f = qs.fresh[qIn - Q_TRACE_A][r];
+          if (sc.domeTexture != 0u || sc.mediumStackSize != 0u) begin_fresh_path(U, st, slot, f);
+          else { retire_fresh_miss(U, f, sampleBuf); retired = true; }
+        }
       }
       if (miss && sc.mediumStackSize) { // the segment ended inside a medium: scattering event for k_shade<2> (rp_main.miss:57-66)
         volMiss = payload_medium_idx(f2u(st.slots[slot].thr.w), sc.mediumStackSize < MAX_MEDIUM_STACK ? sc.mediumStackSize : MAX_MEDIUM_STACK) > 0u;
@@ -539,12 +533,7 @@ __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, Que
 #pragma unroll
     for (uint32_t c = 0; c < MAT_CLASS_COUNT; c++) { pred[1 + c] = (hit || volMiss) && klass == c; qid[1 + c] = Q_HIT + c; }
     block_append<1 + MAT_CLASS_COUNT>(sh, trip, pred, qid, qs.cap, cnt, idx);
-    if (hit || volMiss) {
-      const uint32_t q = Q_HIT + klass, r = idx[1 + klass];
-      qs.slot[q][r] = freshHit ? (slot | TRACE_FRESH) : slot;
-      if (!volMiss) { st4(&qs.a[q][r], h.x, h.y, h.z, h.w); st4(&qs.b[q][r], rdir.x, rdir.y, rdir.z, u2f(freshRng)); }
-      else { st4(&qs.a[q][r], h.x, h.y, h.z, u2f(VOLUME_MISS)); st4(&qs.b[q][r], rdir.x, rdir.y, rdir.z, rdir.w); }
-    }
+    if (hit || volMiss) qs.slot[Q_HIT + klass][idx[1 + klass]] = rec | (freshHit ? HIT_FRESH : 0u) | (volMiss ? HIT_VOLUME : 0u); // 4 bytes per hit: the record stays where it is
     if (miss) {
       if (sc.domeTexture) { dome_miss(sc, st, slot, v3(rdir.x, rdir.y, rdir.z)); qs.slot[qMiss][idx[0]] = slot; }
       else qs.slot[qMiss][idx[0]] = slot | (retired ? REGEN_FRESH : REGEN_MISSED);
@@ -576,14 +565,21 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((KLASS ==
     bool cont = false, ended = false, shadow = false, shadowFirst = false; uint32_t slot = 0, rngShadow = 0u;
     V3 no = v3(0.0f, 0.0f, 0.0f), k2 = no, sdir = no, nee = no; float ld = 0.0f, tMaxNext = GI_FLT_MAX;
     if (i < n) {
-      const uint32_t r = reader_index(rdr, i);
-      slot = qs.slot[qHit][r];
-      const bool fresh = (slot & TRACE_FRESH) != 0u; slot &= ~TRACE_FRESH; // first hit of a path whose Slot holds only its work item yet (begin_fresh_hit)
-      const F4 h = ld4(&qs.a[qHit][r]);
-      const F4 rd = ld4(&qs.b[qHit][r]);
+      const uint32_t e = qs.slot[qHit][reader_index(rdr, i)];
+      const uint32_t ri = e & HIT_INDEX_MASK, qT = Q_TRACE_A + par; // the ray's record in the queue it was traced from (untouched until the next iteration's producers)
+      const bool fresh = (e & HIT_FRESH) != 0u;
+      slot = qs.slot[qT][ri] & ~TRACE_FRESH;
+      F4 h = ld4(&qs.a[qT][ri]);
+      const F4 rd = ld4(&qs.b[qT][ri]);
+      h.w = (e & HIT_VOLUME) ? u2f(VOLUME_MISS) : u2f(f2u(h.w) & 0x0fffffffu); // strip the class bits / mark the scattering event for shade_segment
       Slot* S = &st.slots[slot];
-      F4 tb = F4{1.0f, 1.0f, 1.0f, u2f(0u)}, rr = F4{0.0f, 0.0f, 0.0f, rd.w}; // rp_main.rgen:274-276; the rng state came with the record
-      if (!fresh) { tb = ld4(&S->thr); rr = ld4(&S->rad); }
+      F4 tb = F4{1.0f, 1.0f, 1.0f, u2f(0u)}, rr = F4{0.0f, 0.0f, 0.0f, 0.0f}; // rp_main.rgen:274-276
+      if (fresh) { // first hit of a deferred path: its rng / work item are beside the ray record; the Slot is completed here (work item now, throughput / radiance below)
+        const FreshRec f = qs.fresh[par][ri];
+        rr.w = u2f(f.rng);
+        uint32_t pixelLocal, sLocal; work_item(U, f.work, pixelLocal, sLocal);
+        st4(&S->id, u2f(pixelLocal), u2f(sLocal), u2f(1u), 0.0f);
+      } else { tb = ld4(&S->thr); rr = ld4(&S->rad); }
       ShadeIO io; io.throughput = v3(tb.x, tb.y, tb.z); io.radiance = v3(rr.x, rr.y, rr.z); io.bitfield = f2u(tb.w); io.rng = f2u(rr.w);
       float* M = VOLUME ? st.media + (size_t)slot * st.mediaStride : nullptr; // this path's medium stack + walkSegmentPdf
       shade_segment<KLASS, TEXTURED, VOLUME, NEE, PACKED>(U, sc, M, h, rd, io);

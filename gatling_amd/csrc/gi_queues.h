@@ -105,6 +105,12 @@ __device__ __forceinline__ size_t sample_record(const FrameUniforms& U, uint32_t
   return (U.flags & FLAG_PIXEL_MAJOR) ? (size_t)pixelLocal * U.batchSamples + sLocal : (size_t)sLocal * U.pixelCount + pixelLocal;
 }
 constexpr uint32_t MISS = 0xffffffffu;
+// HIT queues (round 4): an entry is the INDEX of the ray's record in the TRACE queue it was traced from (k_trace_dyn / k_trace leave the result in place there:
+// a = (t, u, v, triangle | class << 28) or (tMax, origin.xy, MISS), b = (direction, - | origin.z)) plus two flags; k_shade gathers the record.  Until then k_route
+// copied 36 bytes per hit into the class queue.
+constexpr uint32_t HIT_FRESH = 0x80000000u;    // first hit of a path whose Slot is still unwritten: FreshRec beside the ray record has its rng / work item
+constexpr uint32_t HIT_VOLUME = 0x40000000u;   // not a hit: the segment ended inside a medium (scattering event, rp_main.miss:57-66)
+constexpr uint32_t HIT_INDEX_MASK = 0x3fffffffu;
 constexpr uint32_t TRACE_FRESH = 0x80000000u;  // flag on a TRACE-queue slot word (FLAG_DEFER_SLOT): a camera ray whose Slot is still unwritten -- QueueSet::fresh holds its rng / work item
 constexpr uint32_t REGEN_MISSED = 0x80000000u; // flag on a regen-queue entry: the path left the scene (k_trace -> k_raygen)
 constexpr uint32_t REGEN_FRESH = 0x40000000u;  // flag on a regen-queue entry written by k_init: the slot carries no sample yet and its memory is uninitialised -- k_raygen
