@@ -408,7 +408,12 @@ def main():
                             # the larger of the two fractions names the nearer roofline; when both are far (< 0.6) the kernel is bound by neither -- latency / the
                             # vector-memory request path (tools/ta_calib.hip) -- and `bound` still names the nearer one, with the note saying so
                             roofline["bound"] = "valu" if roofline["valu_frac"] > roofline["frac"] else "hbm"
-                            if max(roofline["valu_frac"], roofline["frac"]) < 0.6:
+                            if scattered:
+                                # measured, not inferred: N instructions added to the node test slow k_trace_dyn by N / (instructions per step) -- slope one
+                                # (profiles/r04k_valu_sensitivity.txt): the kernel sits on the single-class VALU issue ceiling, which is what valu_frac_fp32_only divides by
+                                roofline["bound"] = "valu"
+                                roofline["bound_note"] = "VALU issue (single-class ceiling, see valu_frac_fp32_only): +64 instructions per node test = +11 %, profiles/r04k_valu_sensitivity.txt"
+                            elif max(roofline["valu_frac"], roofline["frac"]) < 0.6:
                                 roofline["bound_note"] = "neither roofline is near: latency / vector-memory request rate bound (DESIGN.md section 4)"
                         # raw counters and the per-kernel table go to a FILE (the driver keeps only the last 8 KB of output: r03's line lost C3's value to them)
                         raw["pmc_kernels"] = {k: {c: (round(x, 1) if isinstance(x, float) else x) for c, x in v.items()} for k, v in pmc.items() if k.startswith(prefixes)}
@@ -471,7 +476,7 @@ def main():
                               "segments_per_sample": E["config"]["segments_per_sample"], "iterations_per_step": E["config"]["iterations_per_step"],
                               "stage_ms": r.get("stage_ms_per_step"),
                               "roofline": {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "algorithmic_frac", "valu_frac", "valu_lane_utilisation",
-                                                                  "l2_hit_rate", "wait_inst_any_frac", "nodes_per_ray", "tris_per_ray", "pmc_note") if k in r}})
+                                                                  "l2_hit_rate", "wait_inst_any_frac", "nodes_per_ray", "tris_per_ray", "pmc_note", "valu_frac_fp32_only", "bound_note") if k in r}})
                 if wl == "c5share":
                     extra["projected_8gpu"] = round(8.0 * E["value"], 1)
                     extra["projection_note"] = "8 x the rate of one rank's share (rows 3::8 at full spp) on one GPU; leaves out the RCCL gather of 8 x 16.6 MB and rank imbalance (DESIGN.md section 7)"

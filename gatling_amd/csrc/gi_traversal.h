@@ -91,6 +91,9 @@ typedef float gi_f2 __attribute__((ext_vector_type(2)));
 // distance of every child EXCEPT the one the next pick takes (the highest bit = first in octant order): the upper half of the fp32 minimum, truncated (t >= 0, so
 // truncation rounds down).  The remainder a pick pushes keeps the field, and trav_pop drops a popped group whose bound lies beyond the ray's current tBest -- the
 // children were hit when the node was tested, but a nearer hit has been found since ("cull at pop", VERDICT r03 next #2a; tools/bvh_quality.cpp: -11.6 % node visits on C3).
+#ifndef GI_NODE_TEST_PAD
+#define GI_NODE_TEST_PAD 0
+#endif
 #ifndef GI_POP_CULL
 #define GI_POP_CULL 0 // measured r04a (profiles/r04a_pop_cull.txt): node visits C3 -11.7 %, C4 -4.5 %, C5 -10.4 % as counted on the CPU -- and the traversal no faster (C3 47.8 -> 48.1 ms, C4 19.3 -> 20.9, C5 132.2 -> 136.5): the ~56 VALU + 16 SALU the bound costs per node test eat what the saved visits give
 #endif
@@ -148,6 +151,20 @@ __device__ __forceinline__ uint2 trav_node_test(RayTrav& R, const uint4& n0, con
       }
     }
   }
+#if GI_NODE_TEST_PAD
+  { // calibration builds only (tools/build_variant.py pad32 -DGI_NODE_TEST_PAD=32): N extra fp32 VALU instructions per node test, four independent chains, results kept
+    // alive but unused -- how the kernel's time answers to added instruction issue and to nothing else (profiles/r04k_valu_sensitivity.txt)
+    float p0 = ax, p1 = ay, p2 = az, p3 = bx;
+#pragma unroll
+    for (int i = 0; i < GI_NODE_TEST_PAD / 4; i++) {
+      asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(p0) : "v"(by), "v"(bz));
+      asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(p1) : "v"(by), "v"(bz));
+      asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(p2) : "v"(by), "v"(bz));
+      asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(p3) : "v"(by), "v"(bz));
+    }
+    asm volatile("" :: "v"(p0), "v"(p1), "v"(p2), "v"(p3));
+  }
+#endif
   R.G = make_uint2(n1.x, (hitmask & 0xff000000u) | (CULL ? ((f2u(tnRest) >> 8) & 0x00ffff00u) : 0u) | (n0.w >> 24));
   return make_uint2(n1.y, hitmask & 0x00ffffffu);
 }
