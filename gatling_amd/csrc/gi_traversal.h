@@ -111,7 +111,9 @@ __device__ __forceinline__ uint2 trav_node_test(RayTrav& R, const uint4& n0, con
   // SLACK (two-level layout): the ray was transformed into the instance's object space in fp32; every box is grown by `slack`
   // (an absolute object-space bound on that rounding) so the filter stays conservative for the WORLD-space exact test
   const float ex = SLACK ? slack * fabsf(R.idx) : 0.0f, ey = SLACK ? slack * fabsf(R.idy) : 0.0f, ez = SLACK ? slack * fabsf(R.idz) : 0.0f;
-  const gi_f2 Bx = {bx - ex, (bx + ex) * WIDEN}, By = {by - ey, (by + ey) * WIDEN}, Bz = {bz - ez, (bz + ez) * WIDEN};
+  // (without SLACK the `+ 0` must not be left to the compiler: x + 0 is not x for x = -0, so it keeps three adds per node test)
+  const gi_f2 Bx = SLACK ? gi_f2{bx - ex, (bx + ex) * WIDEN} : gi_f2{bx, bx * WIDEN}, By = SLACK ? gi_f2{by - ey, (by + ey) * WIDEN} : gi_f2{by, by * WIDEN},
+              Bz = SLACK ? gi_f2{bz - ez, (bz + ez) * WIDEN} : gi_f2{bz, bz * WIDEN};
   const float tFar = R.tBest * WIDEN, tNear = R.tMin;
   // near/far plane bytes per axis, chosen by direction sign
   const bool nxn = d.x < 0.0f, nyn = d.y < 0.0f, nzn = d.z < 0.0f;
