@@ -393,6 +393,7 @@ struct GiCScene : SceneDevice {
   // the scene as built (the same on every device)
   uint32_t nodeStrideU4 = 5;
   uint32_t nodeCount = 0, triCount = 0, bvhDepth = 0;
+  float bounds[6] = {0, 0, 0, 0, 0, 0}; bool boundsValid = false; // the flat tree's root bounds (nodeBounds + a relative pad), for FLAG_BOUNDS_RETIRE
   bool twoLevel = false; int optTwoLevel = -1; // 1: build and use the two-level layout (scenes beyond LDS); otherwise the flat one
   bool hasCutouts = false;
   bool shadePacked = false; // the built scene carries TriShade records (beyond LDS)
@@ -1146,6 +1147,22 @@ uint32_t sceneDeviceCount(const GiCScene* s)
 }
 SceneDevice& sceneDevice(GiCScene* s, uint32_t slot) { return slot == 0u ? static_cast<SceneDevice&>(*s) : *s->replicas[slot - 1u]; }
 
+void nodeBounds(const Node8& n, float box[6]);
+// The flat tree's root bounds for FLAG_BOUNDS_RETIRE: the dequantised child boxes of node 0 (which contain every triangle's padded box), padded once more by 1e-5 of
+// their magnitude and extent -- k_raygen's slab test adds its own per-ray rounding allowance on top.
+static void setSceneBounds(GiCScene* s, const std::vector<Node8>& nodes)
+{
+  s->boundsValid = false;
+  if (nodes.empty()) return;
+  float b[6]; nodeBounds(nodes[0], b);
+  for (int a = 0; a < 3; a++) {
+    if (!(b[a] <= b[3 + a]) || !std::isfinite(b[a]) || !std::isfinite(b[3 + a])) return; // empty root (no triangles) or overflowing planes: no early retire
+    const float pad = (std::fabs(b[a]) + std::fabs(b[3 + a]) + (b[3 + a] - b[a])) * 1.0e-5f + 1.0e-30f;
+    s->bounds[a] = b[a] - pad; s->bounds[3 + a] = b[3 + a] + pad;
+  }
+  s->boundsValid = true;
+}
+
 int buildScene(GiCScene* s)
 {
   double t0 = nowMs();
@@ -1314,6 +1331,7 @@ int buildScene(GiCScene* s)
     if (uploadSceneTo(s, sceneDevice(s, d), H) != GI_C_OK) { (void)hipSetDevice(g_ctx.device); return GI_C_ERROR; }
   HIP_TRY(hipSetDevice(g_ctx.device));
   s->nodeCount = (uint32_t)bvh.nodes.size(); s->triCount = (uint32_t)bvh.tris.size(); s->bvhDepth = bvh.maxDepth > 1u ? bvh.maxDepth - 1u : 1u; // stack entries a walk can need: a pick at level L pushes the rest of level L-1's group (gi_traversal.h trav_node_pick), the root level pushes nothing
+  setSceneBounds(s, bvh.nodes);
   s->stats.bvhBuildMs = t1 - t0; s->stats.uploadMs = nowMs() - t1;
   s->stats.nodeCount = s->nodeCount; s->stats.triangleCount = s->triCount;
   if (getenv("GATLING_BUILD_TIMING")) fprintf(stderr, "[gatling_gi] scene: %u nodes, %u triangles, %u levels (traversal stack need %u)\n", s->nodeCount, s->triCount, bvh.maxDepth, s->bvhDepth);
@@ -1462,6 +1480,7 @@ int updateTransforms(GiCScene* s, bool& handled)
   // --- upload: everything after the re-layout, else the moved parts' ranges, their InstanceRecs and the top region
   const uint32_t nDev = std::min<uint32_t>(sceneDeviceCount(s), (uint32_t)s->replicas.size() + 1u);
   s->nodeCount = (uint32_t)H.bvh.nodes.size();
+  setSceneBounds(s, H.bvh.nodes);
   for (uint32_t d = 0; d < nDev; d++) {
     SceneDevice& D = sceneDevice(s, d);
     if (converted) { if (uploadSceneTo(s, D, H) != GI_C_OK) { (void)hipSetDevice(g_ctx.device); return GI_C_ERROR; } continue; }
@@ -1860,6 +1879,19 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
     F4* colorOut = reinterpret_cast<F4*>(rbMem(colorRb, D.slot));
     const bool nee = rs.nextEventEstimation != 0;
     const uint32_t dynRefill = traceDynRefill(s);
+    // Bounds retire (r04n): on the k_trace_dyn path a deferred-slot camera ray that cannot reach the scene's bounds is retired by k_raygen itself (C4: 58 % of the
+    // camera rays, C3: ~45 %) -- same sample, same segment count, no ray record, no traversal step, no routing.  Not with a dome image / medium stack (a miss needs
+    // the slot), not in counting builds (the root visit of such a ray is part of nodes-per-ray), not on the two-level layout (bounds of the TLAS root: not kept).
+    {
+      SceneView v0 = view; uint32_t ln, lt, ldsBytes; traceLdsLayout(v0, ln, lt, ldsBytes);
+      const bool allLds = ln == v0.nodeCount && lt == v0.triCount && v0.triCount > 0u;
+      const char* e = getenv("GATLING_BOUNDS_RETIRE");
+      if ((U.flags & FLAG_DEFER_SLOT) && !allLds && dynRefill && !view.twoLevel && view.domeTexture == 0u && rs.mediumStackSize == 0u && !s->countTraversal && s->boundsValid &&
+          (e ? atoi(e) != 0 : true)) {
+        U.flags |= FLAG_BOUNDS_RETIRE;
+        for (int a = 0; a < 3; a++) { U.sceneLo[a] = s->bounds[a]; U.sceneHi[a] = s->bounds[3 + a]; }
+      }
+    }
 
     // --- the bounce loop (rp_main.rgen:215, 295): every pool slot advances one stage per iteration
     HIP_TRY(hipStreamSynchronize(st));
@@ -1928,7 +1960,10 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
             const uint64_t j = it - LAG;
             HIP_TRY(hipEventSynchronize(D.pollEvent[j % R]));
             const PaddedCounter* snap = D.hPoll + (j % R) * snapshot + (size_t)(Q_TRACE_A + (uint32_t)(j & 1u)) * NSHARD;
-            uint32_t pending = 0; for (uint32_t k = 0; k < NSHARD; k++) pending += snap[k].v;
+            // (FLAG_BOUNDS_RETIRE: a k_raygen whose camera rays all miss the scene's bounds queues no ray either, but hands its slots on -- REGEN[(j&1)^1], zero at
+            // this point otherwise -- and work is left)
+            const PaddedCounter* again = D.hPoll + (j % R) * snapshot + (size_t)(Q_REGEN_A + (uint32_t)((j & 1u) ^ 1u)) * NSHARD;
+            uint32_t pending = 0; for (uint32_t k = 0; k < NSHARD; k++) pending += snap[k].v + again[k].v;
             if (pending == 0) { totalIters++; break; } // k_raygen(j) consumed the regen queue and produced no rays: the pool had drained
           }
         }

@@ -83,15 +83,40 @@ __device__ __forceinline__ void begin_fresh_path(const FrameUniforms& U, const P
 }
 // (a first segment that HIT is begun by k_shade, which gathers the ray record and the FreshRec beside it and completes the Slot in one go)
 
+// FLAG_BOUNDS_RETIRE: can the ray reach the scene at all?  A slab test against the root node's bounds (host: padded beyond the dequantised child boxes), widened per
+// ray by 30 x the rounding error of (plane - origin) * (1 / d) and decided only by comparisons that a NaN fails -- so it answers "misses" for no ray whose walk
+// could accept a triangle (every triangle lies inside its leaf box, every leaf box inside the root's bounds; same contract as the node test).
+__device__ __forceinline__ bool ray_misses_bounds(const FrameUniforms& U, const V3& o, const V3& d, float tMin, float tMax)
+{
+  float tn = tMin, tf = tMax;
+  const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+  bool out = false;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const float lo = U.sceneLo[a], hi = U.sceneHi[a];
+    const float pad = (fabsf(oo[a]) + fmax2(fabsf(lo), fabsf(hi))) * 4.0e-6f;
+    if (dd[a] == 0.0f) { out = out || (oo[a] < lo - pad) || (oo[a] > hi + pad); continue; }
+    const float inv = 1.0f / dd[a];
+    const float t0 = ((lo - pad) - oo[a]) * inv, t1 = ((hi + pad) - oo[a]) * inv;
+    float nearT = t0 < t1 ? t0 : t1, farT = t0 < t1 ? t1 : t0; // (the padded planes keep their order; a NaN leaves the interval alone below)
+    nearT -= fabsf(nearT) * 1.0e-5f; farT += fabsf(farT) * 1.0e-5f;
+    if (nearT > tn) tn = nearT;
+    if (farT < tf) tf = farT;
+  }
+  return out || tn > tf;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st, QueueSet qs, Counters* cnt, uint32_t par, F4* __restrict__ sampleBuf)
 {
-  __shared__ AppendScratch<1> sh;
-  const uint32_t qIn = Q_REGEN_A + par, qOut = Q_TRACE_A + par;
+  __shared__ AppendScratch<2> sh;
+  const uint32_t qIn = Q_REGEN_A + par, qOut = Q_TRACE_A + par, qAgain = Q_REGEN_A + (par ^ 1u);
+  const bool boundsRetire = (U.flags & FLAG_BOUNDS_RETIRE) != 0u;
   QueueReader rd; reader_init(rd, cnt, qIn, qs.cap);
   const uint32_t n = rd.pre[NSHARD];
   const uint32_t workBase = cnt->workBase[par].v;
+  uint32_t nRetired = 0u;
   if (blockIdx.x == 0) {
-    zero_next_counters(cnt, par);
+    zero_next_counters(cnt, par, !boundsRetire);
     if (threadIdx.x == 0) { const uint32_t left = U.workTotal - workBase; cnt->workBase[par ^ 1u].v = workBase + (n < left ? n : left); }
   }
   const uint32_t stride = gridDim.x * BLOCK;
@@ -140,8 +165,12 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st,
         if (!(U.flags & FLAG_DEFER_SLOT)) slot_begin_path(S, rng, pixelLocal, sLocal); // :274-276 (deferred: written when the first segment hits, route_fresh)
       }
     }
-    const bool pred[1] = {more}; const uint32_t qid[1] = {qOut}; uint32_t idx[1];
-    block_append<1>(sh, trip, pred, qid, qs.cap, cnt, idx);
+    // a camera ray that cannot reach the scene: what k_route does with a fresh miss (retire_fresh_miss; the segment is counted below), minus the 52-byte record,
+    // the traversal step and the routing pass -- the slot goes straight to the next k_raygen
+    bool again = false;
+    if (boundsRetire && more && ray_misses_bounds(U, origin, dir, tMin, tMax)) { retire_fresh_miss(U, fresh, sampleBuf); more = false; again = true; nRetired++; }
+    const bool pred[2] = {more, again}; const uint32_t qid[2] = {qOut, qAgain}; uint32_t idx[2];
+    block_append<2>(sh, trip, pred, qid, qs.cap, cnt, idx);
     if (more) {
       const bool defer = (U.flags & FLAG_DEFER_SLOT) != 0u;
       qs.slot[qOut][idx[0]] = defer ? (slot | TRACE_FRESH) : slot;
@@ -149,6 +178,12 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st,
       st4(&qs.b[qOut][idx[0]], dir.x, dir.y, dir.z, tMax);
       if (defer) qs.fresh[par][idx[0]] = fresh; // 8 bytes beside the record, written and read in queue order
     }
+    if (again) qs.slot[qAgain][idx[1]] = slot | REGEN_FRESH;
+  }
+  if (boundsRetire) { // the retired camera rays are segments of their paths (Counters::segments equals the oracle's count): one atomic per wave
+    unsigned long long c = nRetired;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if (__lane_id() == 0u && c) atomicAdd(&cnt->segments, c);
   }
 }
 
@@ -500,6 +535,7 @@ __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, Que
   __shared__ AppendScratch<1 + MAT_CLASS_COUNT> sh;
   QueueReader rd; reader_init(rd, cnt, qIn, qs.cap);
   const uint32_t n = rd.pre[NSHARD];
+  if (blockIdx.x == 0 && (U.flags & FLAG_BOUNDS_RETIRE)) zero_consumed_regen(cnt, qIn - Q_TRACE_A); // (k_raygen no longer zeroes it: it appends to it)
   const uint32_t stride = gridDim.x * BLOCK;
   uint32_t trip = 0;
   for (uint32_t base = blockIdx.x * BLOCK; base < n; base += stride, trip++) {

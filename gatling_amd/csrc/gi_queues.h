@@ -119,17 +119,24 @@ constexpr uint32_t REGEN_FRESH = 0x40000000u;  // flag on a regen-queue entry wr
 // Zeroes the counters of the queues that the producers of iteration `it` will append to.  Called by one thread of
 // k_raygen(it): none of these queues is read or appended by k_raygen(it) itself (it reads REGEN[it&1] and appends
 // TRACE[it&1]), and their previous consumers finished in iteration it-1 (stream order).
-__device__ __forceinline__ void zero_next_counters(Counters* cnt, uint32_t par)
+// `zeroRegen` false (FLAG_BOUNDS_RETIRE): k_raygen(it) itself appends to REGEN[(it&1)^1], so that counter is zeroed one kernel earlier, by k_route(it-1)
+// (zero_consumed_regen), which runs after its last reader k_raygen(it-1).
+__device__ __forceinline__ void zero_next_counters(Counters* cnt, uint32_t par, bool zeroRegen)
 {
   const uint32_t t = threadIdx.x;
   if (t < NSHARD) {
     cnt->count[Q_TRACE_A + (par ^ 1u)][t].v = 0;
-    cnt->count[Q_REGEN_A + (par ^ 1u)][t].v = 0;
+    if (zeroRegen) cnt->count[Q_REGEN_A + (par ^ 1u)][t].v = 0;
     for (uint32_t c = 0; c < MAT_CLASS_COUNT; c++) cnt->count[Q_HIT + c][t].v = 0;
     cnt->count[Q_SHADOW][t].v = 0;
   }
   if (t < 2u * NCURSOR) cnt->cursor[t / NCURSOR][t % NCURSOR].v = 0; // k_trace_dyn's ray cursors (closest, shadow)
 }
 
+// k_route(it), block 0: REGEN[it&1] was read by k_raygen(it) and is next appended by k_raygen(it+1) (bounds retire) and k_route(it+1)
+__device__ __forceinline__ void zero_consumed_regen(Counters* cnt, uint32_t par)
+{
+  if (threadIdx.x < NSHARD) cnt->count[Q_REGEN_A + par][threadIdx.x].v = 0;
+}
 
 } // namespace gi

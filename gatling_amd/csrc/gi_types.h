@@ -143,12 +143,15 @@ struct FrameUniforms {
   uint32_t sphereCount, distantCount, rectCount, diskCount, totalLightCount;
   uint32_t mediumStackSize, maxVolumeWalkLength; // GiRenderSettings (Gi.h:150-151); stack size 0 = inside/outside toggle only
   uint32_t rowStride, padStride;                 // the tile's rows are rowBegin + k * rowStride (multi-GPU row interleaving)
+  float sceneLo[3], padLo, sceneHi[3], padHi;    // FLAG_BOUNDS_RETIRE: the root node's dequantised bounds, padded (host: sceneBoundsForRetire)
 };
 enum : uint32_t {
   FLAG_JITTER = 1u, FLAG_FIS = 2u, FLAG_DOF = 4u, FLAG_CLIP = 8u, FLAG_NEE = 16u, FLAG_PROGRESSIVE = 32u,
   FLAG_PIXEL_MAJOR = 64u, // work order of the wavefront pipeline (gi_queues.h work_item)
   FLAG_DEFER_SLOT = 128u, // wavefront pipeline: k_raygen does not write the Slot of a new camera path; its (rng, work item) travel beside the ray record and the
                           // slot is written when the first segment HITS (k_route / k_trace); a camera ray that leaves the scene retires without ever touching a slot
+  FLAG_BOUNDS_RETIRE = 256u, // with FLAG_DEFER_SLOT on the k_trace_dyn path: a camera ray whose slab interval against the scene bounds is empty is never queued --
+                             // k_raygen retires its sample (the arithmetic of retire_fresh_miss) and hands the slot straight to the next k_raygen
 };
 
 // Device-side scene view handed to the kernels.

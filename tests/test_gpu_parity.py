@@ -266,8 +266,10 @@ def test_deferred_slot_initialisation_is_invisible(gi, monkeypatch, name):
     a small pool (slots recycled many times: stale slot contents must never be read) and with the block-synchronous k_trace: the committed image, bit for bit."""
     desc, rs, w, h = build_case(name)
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
-    for defer, pool, dyn in (("1", 0, -1), ("0", 0, -1), ("1", 301, -1), ("1", 0, 0), ("0", 301, 0)):
+    for defer, pool, dyn in (("1", 0, -1), ("0", 0, -1), ("1", 301, -1), ("1", 0, 0), ("0", 301, 0), ("1", 64, -2)):
         monkeypatch.setenv("GATLING_DEFER_SLOT", defer)
+        monkeypatch.setenv("GATLING_BOUNDS_RETIRE", "0" if dyn == -2 else "1")  # (r04n: camera rays that miss the scene's bounds retire in k_raygen; -2 = default traversal without it)
+        dyn = -1 if dyn == -2 else dyn
         sc = gi.Scene(desc)
         try:
             sc.set_option(gi.OPTION_FUSED_PATH, 0)
@@ -284,6 +286,48 @@ def test_deferred_slot_initialisation_is_invisible(gi, monkeypatch, name):
         assert st["fusedPath"] == 0 and st["segments"] == int(g["segments"]) and st["shadowRays"] == int(g["shadow_rays"]), (defer, pool, dyn)
         assert_image_parity(img, g["color"], exact=True)
         assert_image_parity(again, g["color"], exact=True)
+
+
+def test_camera_rays_that_cannot_reach_the_scene_retire_in_raygen(gi, orc, monkeypatch):
+    """FLAG_BOUNDS_RETIRE (r04n): on the k_trace_dyn path k_raygen itself retires a deferred-slot camera ray whose slab interval against the scene's bounds is empty
+    (same sample, same segment count; no ray record, traversal step or routing pass) and hands the slot to the next k_raygen.  Cameras that make the test bite in
+    every way: the frame wider than the scene (most rays miss the bounds), looking away from it (ALL rays miss: whole iterations queue no ray at all and the loop
+    must still hand out every work item), inside the bounds (none miss), an axis-parallel view (direction components exactly 0), far away (the slab arithmetic at
+    1e4 x the scene's size), thin-lens depth of field (origins off the eye point) and clipping planes that end before the scene begins; each with the default pool
+    and a 301-slot pool (slots recycled hundreds of times), on and off: device == oracle bit for bit, same segment counts."""
+    import copy
+    from gatling_amd.scenes import _look_at_camera
+    base = random_triangle_soup(400_000, seed=77)
+    cams = {
+        "wide": _look_at_camera((0, -6, 0.3), (0, 0, 0), (0, 0, 1), 70.0),
+        "away": _look_at_camera((0, -4, 0), (0, -9, 0.5), (0, 0, 1), 40.0),
+        "inside": _look_at_camera((0.1, 0.2, -0.1), (1, 1, 0.2), (0, 0, 1), 60.0),
+        "axis": _look_at_camera((0, -4, 0), (0, 0, 0), (0, 0, 1), 40.0),
+        "far": _look_at_camera((3000, -20000, 900), (0, 0, 0), (0, 0, 1), 0.02),
+    }
+    cams["dof"] = copy.copy(cams["wide"]); cams["dof"].f_stop = 1.4; cams["dof"].focus_distance = 6.0; cams["dof"].focal_length = 0.6  # lens radius 0.21
+    cams["clipped"] = copy.copy(cams["axis"]); cams["clipped"].clip_start = 0.1; cams["clipped"].clip_end = 2.5
+    w, h = 96, 54
+    for name, cam in cams.items():
+        rs = RenderSettings(spp=3, max_bounces=5, next_event_estimation=True, progressive_accumulation=False, depth_of_field=name == "dof", clipping_planes=name == "clipped")
+        desc = copy.copy(base); desc.camera = cam
+        ref, cnt = orc.render(desc, rs, w, h, threads=4)
+        for retire, pool in (("1", 0), ("1", 301), ("0", 0)):
+            monkeypatch.setenv("GATLING_BOUNDS_RETIRE", retire)
+            sc = gi.Scene(desc)
+            try:
+                if pool:
+                    sc.set_option(gi.OPTION_POOL_SLOTS, pool)
+                img = sc.render(rs, w, h)
+                st = sc.stats()
+                again = sc.render(rs, w, h)
+            finally:
+                sc.close()
+            assert st["fusedPath"] == 0 and st["segments"] == cnt["segments"] and st["shadowRays"] == cnt["shadow_rays"], (name, retire, pool, st["segments"], cnt["segments"])
+            assert_image_parity(img, ref, exact=True)
+            assert_image_parity(again, ref, exact=True)
+        if name in ("away", "clipped"):
+            assert cnt["segments"] == w * h * rs.spp  # every path is its camera ray
 
 
 def test_texture_coordinate_transforms_on_device(gi, orc):
