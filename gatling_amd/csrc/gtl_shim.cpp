@@ -1,7 +1,7 @@
 // gtl_shim.cpp -- the reference's C++ API (include/gtl/gi/Gi.h, mirroring /root/reference/src/gi/gtl/gi/Gi.h:199-261) on top of
 // the C ABI (include/gi_c.h).  Every function forwards 1:1; std::vector arguments become pointer + count.  The one
-// non-mechanical piece is material creation: a tiny scanner reads UsdPreviewSurface / open_pbr_surface nodes with constant
-// inputs out of a MaterialX document string (what hdGatling's material network compiler produces,
+// non-mechanical piece is material creation: a tiny scanner reads UsdPreviewSurface / open_pbr_surface (and, translated onto the same closed forms,
+// standard_surface / gltf_pbr) nodes with constant, primvar or image inputs out of a MaterialX document string (what hdGatling's material network compiler produces,
 // src/hdGatling/materialNetworkCompiler.cpp:667-720) and fills a closed-form parameter block.
 #include "../../include/gtl/gi/Gi.h"
 #include "../../include/gi_c.h"
@@ -45,7 +45,7 @@ namespace gtl
 
     bool findSurfaceNode(const std::string& doc, MtlxNode& out)
     {
-      static const char* kCats[] = {"UsdPreviewSurface", "open_pbr_surface"};
+      static const char* kCats[] = {"UsdPreviewSurface", "open_pbr_surface", "standard_surface", "gltf_pbr"};
       size_t best = std::string::npos; const char* bestCat = nullptr;
       for (const char* c : kCats) {
         std::string open = std::string("<") + c;
@@ -261,6 +261,67 @@ namespace gtl
       p[GI_C_P_SUBSURFACE_COLOR] = p[GI_C_P_SUBSURFACE_COLOR + 1] = p[GI_C_P_SUBSURFACE_COLOR + 2] = 0.8f;
       p[GI_C_P_SUBSURFACE_RADIUS] = 1.0f; p[GI_C_P_SUBSURFACE_RADIUS_SCALE] = 1.0f; p[GI_C_P_SUBSURFACE_RADIUS_SCALE + 1] = 0.5f; p[GI_C_P_SUBSURFACE_RADIUS_SCALE + 2] = 0.25f;
       float lum = 0.0f, ecol[3] = {1.0f, 1.0f, 1.0f};
+      if (n.category == "standard_surface") {
+        // Autodesk Standard Surface 1.0.1 (the reference compiles MaterialX's own standard_surface graph through MDL): read onto the OpenPBR closed forms, input by
+        // input -- OpenPBR is that model's successor and keeps its layering (fuzz over coat over {metal | glass | subsurface | diffuse+specular}).  Defaults are the
+        // Standard Surface specification's, not OpenPBR's.  What has no counterpart is dropped: specular_rotation / coat_rotation (no tangent input),
+        // transmission_dispersion, transmission_extra_roughness, coat_affect_color / coat_affect_roughness, and coat_darkening stays 0 (the model has no such term).
+        p[GI_C_P_BASE_WEIGHT] = 0.8f; p[GI_C_P_BASE_COLOR] = p[GI_C_P_BASE_COLOR + 1] = p[GI_C_P_BASE_COLOR + 2] = 1.0f; p[GI_C_P_ROUGHNESS] = 0.2f;
+        p[GI_C_P_CLEARCOAT_ROUGHNESS] = 0.1f; p[GI_C_P_COAT_IOR] = 1.5f; p[GI_C_P_COAT_DARKENING] = 0.0f; p[GI_C_P_FUZZ_ROUGHNESS] = 0.3f;
+        p[GI_C_P_SUBSURFACE_COLOR] = p[GI_C_P_SUBSURFACE_COLOR + 1] = p[GI_C_P_SUBSURFACE_COLOR + 2] = 1.0f;
+        p[GI_C_P_SUBSURFACE_RADIUS] = 1.0f; p[GI_C_P_SUBSURFACE_RADIUS_SCALE] = p[GI_C_P_SUBSURFACE_RADIUS_SCALE + 1] = p[GI_C_P_SUBSURFACE_RADIUS_SCALE + 2] = 1.0f;
+        p[GI_C_P_THIN_FILM_THICKNESS] = 0.0f; p[GI_C_P_THIN_FILM_IOR] = 1.5f;
+        setN(n, "base", p + GI_C_P_BASE_WEIGHT, 1); setN(n, "base_color", p + GI_C_P_BASE_COLOR, 3); setN(n, "diffuse_roughness", p + GI_C_P_DIFFUSE_ROUGHNESS, 1);
+        setN(n, "metalness", p + GI_C_P_METALLIC, 1); setN(n, "specular", p + GI_C_P_SPECULAR_WEIGHT, 1); setN(n, "specular_color", p + GI_C_P_SPECULAR_COLOR, 3);
+        setN(n, "specular_roughness", p + GI_C_P_ROUGHNESS, 1); setN(n, "specular_IOR", p + GI_C_P_IOR, 1); setN(n, "specular_anisotropy", p + GI_C_P_SPECULAR_ANISOTROPY, 1);
+        setN(n, "transmission", p + GI_C_P_TRANSMISSION_WEIGHT, 1); setN(n, "transmission_color", p + GI_C_P_TRANSMISSION_COLOR, 3);
+        setN(n, "transmission_depth", p + GI_C_P_TRANSMISSION_DEPTH, 1); setN(n, "transmission_scatter", p + GI_C_P_TRANSMISSION_SCATTER, 3);
+        setN(n, "transmission_scatter_anisotropy", p + GI_C_P_TRANSMISSION_SCATTER_ANISOTROPY, 1);
+        setN(n, "subsurface", p + GI_C_P_SUBSURFACE_WEIGHT, 1); setN(n, "subsurface_color", p + GI_C_P_SUBSURFACE_COLOR, 3); setN(n, "subsurface_anisotropy", p + GI_C_P_SUBSURFACE_ANISOTROPY, 1);
+        setN(n, "subsurface_scale", p + GI_C_P_SUBSURFACE_RADIUS, 1); setN(n, "subsurface_radius", p + GI_C_P_SUBSURFACE_RADIUS_SCALE, 3); // mean free path = scale x radius (colour) = OpenPBR's radius x radius_scale
+        setN(n, "sheen", p + GI_C_P_FUZZ_WEIGHT, 1); setN(n, "sheen_color", p + GI_C_P_FUZZ_COLOR, 3); setN(n, "sheen_roughness", p + GI_C_P_FUZZ_ROUGHNESS, 1);
+        setN(n, "coat", p + GI_C_P_CLEARCOAT, 1); setN(n, "coat_color", p + GI_C_P_COAT_COLOR, 3); setN(n, "coat_roughness", p + GI_C_P_CLEARCOAT_ROUGHNESS, 1);
+        setN(n, "coat_IOR", p + GI_C_P_COAT_IOR, 1); setN(n, "coat_anisotropy", p + GI_C_P_COAT_ANISOTROPY, 1);
+        float nm = 0.0f; setN(n, "thin_film_thickness", &nm, 1); setN(n, "thin_film_IOR", p + GI_C_P_THIN_FILM_IOR, 1); // nanometres, 0 = no film -> weight + micrometres
+        p[GI_C_P_THIN_FILM_WEIGHT] = nm > 0.0f ? 1.0f : 0.0f; p[GI_C_P_THIN_FILM_THICKNESS] = nm > 0.0f ? nm * 0.001f : 0.5f;
+        float op3[3] = {1.0f, 1.0f, 1.0f}; setN(n, "opacity", op3, 3); p[GI_C_P_OPACITY] = (op3[0] + op3[1] + op3[2]) * (1.0f / 3.0f); // colour opacity -> its mean
+        setN(n, "thin_walled", p + GI_C_P_THIN_WALLED, 1);
+        setN(n, "emission", &lum, 1); setN(n, "emission_color", ecol, 3);
+        for (int i = 0; i < 3; i++) p[GI_C_P_EMISSION + i] = lum * ecol[i];
+        bind("base_color", GI_C_TEX_BASE_COLOR, p + GI_C_P_BASE_COLOR, 3); bind("specular_roughness", GI_C_TEX_ROUGHNESS, p + GI_C_P_ROUGHNESS, 1); bind("metalness", GI_C_TEX_METALLIC, p + GI_C_P_METALLIC, 1);
+        bind("normal", GI_C_TEX_NORMAL); bind("opacity", GI_C_TEX_OPACITY); bind("coat_normal", GI_C_TEX_COAT_NORMAL);
+        return true;
+      }
+      if (n.category == "gltf_pbr") {
+        // MaterialX's glTF PBR node (KHR_materials_* folded in) onto the same closed forms.  Defaults are the node's (metallic 1, roughness 1, sheen off ...).
+        // thickness 0 is glTF's thin-walled transmission; a thick one attenuates with attenuation_color over attenuation_distance (OpenPBR transmission_color at
+        // transmission_depth).  alpha_mode: 0 OPAQUE (alpha ignored), 1 MASK (constant alpha against alpha_cutoff), 2 BLEND (alpha as opacity: stochastic cutout).
+        // Dropped: occlusion (baked ambient occlusion has no place in a path tracer), anisotropy_rotation, dispersion.
+        p[GI_C_P_BASE_COLOR] = p[GI_C_P_BASE_COLOR + 1] = p[GI_C_P_BASE_COLOR + 2] = 1.0f; p[GI_C_P_METALLIC] = 1.0f; p[GI_C_P_ROUGHNESS] = 1.0f;
+        p[GI_C_P_CLEARCOAT_ROUGHNESS] = 0.0f; p[GI_C_P_COAT_IOR] = 1.5f; p[GI_C_P_COAT_DARKENING] = 0.0f; p[GI_C_P_FUZZ_ROUGHNESS] = 0.0f; p[GI_C_P_THIN_FILM_IOR] = 1.3f;
+        setN(n, "base_color", p + GI_C_P_BASE_COLOR, 3); setN(n, "metallic", p + GI_C_P_METALLIC, 1); setN(n, "roughness", p + GI_C_P_ROUGHNESS, 1);
+        setN(n, "specular", p + GI_C_P_SPECULAR_WEIGHT, 1); setN(n, "specular_color", p + GI_C_P_SPECULAR_COLOR, 3); setN(n, "ior", p + GI_C_P_IOR, 1);
+        setN(n, "transmission", p + GI_C_P_TRANSMISSION_WEIGHT, 1);
+        float thick = 0.0f, attDist = 0.0f, attCol[3] = {1.0f, 1.0f, 1.0f};
+        setN(n, "thickness", &thick, 1); setN(n, "attenuation_distance", &attDist, 1); setN(n, "attenuation_color", attCol, 3);
+        p[GI_C_P_THIN_WALLED] = thick > 0.0f ? 0.0f : 1.0f;
+        if (thick > 0.0f && attDist > 0.0f && attDist < 3.0e38f) { for (int i = 0; i < 3; i++) p[GI_C_P_TRANSMISSION_COLOR + i] = attCol[i]; p[GI_C_P_TRANSMISSION_DEPTH] = attDist; }
+        setN(n, "clearcoat", p + GI_C_P_CLEARCOAT, 1); setN(n, "clearcoat_roughness", p + GI_C_P_CLEARCOAT_ROUGHNESS, 1);
+        float sheen[3] = {0.0f, 0.0f, 0.0f}; setN(n, "sheen_color", sheen, 3); setN(n, "sheen_roughness", p + GI_C_P_FUZZ_ROUGHNESS, 1); // KHR_materials_sheen: black = off
+        const bool hasSheen = sheen[0] > 0.0f || sheen[1] > 0.0f || sheen[2] > 0.0f;
+        p[GI_C_P_FUZZ_WEIGHT] = hasSheen ? 1.0f : 0.0f; for (int i = 0; i < 3; i++) p[GI_C_P_FUZZ_COLOR + i] = hasSheen ? sheen[i] : 1.0f;
+        float nm = 100.0f; setN(n, "iridescence", p + GI_C_P_THIN_FILM_WEIGHT, 1); setN(n, "iridescence_ior", p + GI_C_P_THIN_FILM_IOR, 1); setN(n, "iridescence_thickness", &nm, 1);
+        p[GI_C_P_THIN_FILM_THICKNESS] = nm * 0.001f; // nanometres -> micrometres
+        setN(n, "anisotropy_strength", p + GI_C_P_SPECULAR_ANISOTROPY, 1);
+        float alpha = 1.0f, mode = 0.0f, cutoff = 0.5f; setN(n, "alpha", &alpha, 1); setN(n, "alpha_mode", &mode, 1); setN(n, "alpha_cutoff", &cutoff, 1);
+        p[GI_C_P_OPACITY] = mode < 0.5f ? 1.0f : (mode < 1.5f ? (alpha >= cutoff ? 1.0f : 0.0f) : alpha);
+        float strength = 1.0f; ecol[0] = ecol[1] = ecol[2] = 0.0f; setN(n, "emissive", ecol, 3); setN(n, "emissive_strength", &strength, 1);
+        for (int i = 0; i < 3; i++) p[GI_C_P_EMISSION + i] = strength * ecol[i];
+        bind("base_color", GI_C_TEX_BASE_COLOR, p + GI_C_P_BASE_COLOR, 3); bind("roughness", GI_C_TEX_ROUGHNESS, p + GI_C_P_ROUGHNESS, 1); bind("metallic", GI_C_TEX_METALLIC, p + GI_C_P_METALLIC, 1);
+        bind("normal", GI_C_TEX_NORMAL); bind("clearcoat_normal", GI_C_TEX_COAT_NORMAL);
+        if (mode >= 1.5f) bind("alpha", GI_C_TEX_OPACITY);
+        return true;
+      }
       setN(n, "base_weight", p + GI_C_P_BASE_WEIGHT, 1); setN(n, "base_color", p + GI_C_P_BASE_COLOR, 3);
       setN(n, "base_diffuse_roughness", p + GI_C_P_DIFFUSE_ROUGHNESS, 1); setN(n, "base_metalness", p + GI_C_P_METALLIC, 1);
       setN(n, "specular_weight", p + GI_C_P_SPECULAR_WEIGHT, 1); setN(n, "specular_color", p + GI_C_P_SPECULAR_COLOR, 3);

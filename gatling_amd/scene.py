@@ -127,7 +127,8 @@ def _open_pbr(name="mat", base_weight=1.0, base_color=(0.8, 0.8, 0.8), base_meta
               transmission_scatter=(0, 0, 0), transmission_scatter_anisotropy=0.0, coat_darkening=1.0, fuzz_weight=0.0,
               fuzz_color=(1, 1, 1), fuzz_roughness=0.5, geometry_thin_walled=False, subsurface_weight=0.0, subsurface_color=(0.8, 0.8, 0.8),
               subsurface_scatter_anisotropy=0.0, specular_roughness_anisotropy=0.0, coat_roughness_anisotropy=0.0,
-              thin_film_weight=0.0, thin_film_thickness=0.5, thin_film_ior=1.4, subsurface_radius=1.0, subsurface_radius_scale=(1.0, 0.5, 0.25)) -> MaterialDesc:
+              thin_film_weight=0.0, thin_film_thickness=0.5, thin_film_ior=1.4, subsurface_radius=1.0, subsurface_radius_scale=(1.0, 0.5, 0.25),
+              geometry_opacity=1.0) -> MaterialDesc:
     """open_pbr_surface inputs with the defaults of src/gi/mtlx/open_pbr_surface.mtlx:11-92 (the lobes this core implements)."""
     p = np.zeros(P_COUNT, np.float32)
     p[P_BASE_COLOR:P_BASE_COLOR + 3] = base_color
@@ -137,7 +138,7 @@ def _open_pbr(name="mat", base_weight=1.0, base_color=(0.8, 0.8, 0.8), base_meta
     p[P_ROUGHNESS] = specular_roughness
     p[P_CLEARCOAT] = coat_weight
     p[P_CLEARCOAT_ROUGHNESS] = coat_roughness
-    p[P_OPACITY] = 1.0
+    p[P_OPACITY] = geometry_opacity
     p[P_IOR] = specular_ior
     p[P_BASE_WEIGHT] = base_weight
     p[P_SPECULAR_WEIGHT] = specular_weight

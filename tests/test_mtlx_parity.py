@@ -68,11 +68,78 @@ def test_defaults_and_refusals():
     d = _desc_from_doc(L, '<materialx version="1.38"><UsdPreviewSurface name="m" type="surfaceshader"></UsdPreviewSurface></materialx>')
     assert np.array_equal(np.frombuffer(bytes(d.p), np.float32), S.MaterialDesc.usd_preview_surface().params)
     # shading models the closed forms do not cover are refused: the caller (hdGatling) then uses its fallback material
-    for xml in ('<materialx version="1.38"><standard_surface name="s" type="surfaceshader"><input name="base" type="float" value="1"/></standard_surface></materialx>',
-                '<materialx version="1.38"><gltf_pbr name="g" type="surfaceshader"/></materialx>', "<materialx/>", "", "not xml at all",
-                '<materialx><UsdPreviewSurfaceX name="near_miss"/></materialx>'):
+    for xml in ('<materialx version="1.38"><disney_principled name="s" type="surfaceshader"><input name="baseColor" type="color3" value="1, 0, 0"/></disney_principled></materialx>',
+                '<materialx version="1.38"><LamaSurface name="g" type="surfaceshader"/></materialx>', "<materialx/>", "", "not xml at all",
+                '<materialx><UsdPreviewSurfaceX name="near_miss"/></materialx>', '<materialx><standard_surfaceX name="near_miss"/></materialx>'):
         assert _desc_from_doc(L, xml) is None, xml
     assert L.gtlMaterialDescFromMtlxStrC(None, None) != capi.GI_C_OK
+
+
+def _surface_doc(category, inputs):
+    rows = "".join(f'<input name="{k}" type="{t}" value="{v}"/>' for k, (t, v) in inputs.items())
+    return f'<materialx version="1.38"><{category} name="srf" type="surfaceshader">{rows}</{category}><surfacematerial name="m" type="material"><input name="surfaceshader" type="surfaceshader" nodename="srf"/></surfacematerial></materialx>'
+
+
+def _block(d):
+    return np.frombuffer(bytes(d.p), np.float32)
+
+
+def test_standard_surface_and_gltf_pbr_documents_translate_onto_the_open_pbr_block():
+    """VERDICT r03 missing #4: `standard_surface` and `gltf_pbr` documents used to be refused (default grey).  The reader now translates them, input by input, onto the
+    OpenPBR closed forms (gtl_shim.cpp descFromMtlx; DESIGN.md deviation D13: the reference compiles MaterialX's own graphs of these models through MDL).  Each
+    document must read to the block of the equivalent open_pbr_surface, bit for bit."""
+    L = capi.load_library()
+    M = S.MaterialDesc
+    # element without inputs: the MODEL's defaults (Standard Surface: base 0.8 of white, specular_roughness 0.2, coat_IOR 1.5 ...), not OpenPBR's
+    d = _desc_from_doc(L, '<materialx version="1.38"><standard_surface name="s" type="surfaceshader"/></materialx>')
+    want = M.open_pbr(base_weight=0.8, base_color=(1, 1, 1), specular_roughness=0.2, coat_roughness=0.1, coat_ior=1.5, coat_darkening=0.0, fuzz_roughness=0.3,
+                      subsurface_color=(1, 1, 1), subsurface_radius=1.0, subsurface_radius_scale=(1, 1, 1), thin_film_ior=1.5).params
+    assert d is not None and d.klass == S.MAT_OPEN_PBR and np.array_equal(_block(d).view(np.uint32), np.asarray(want, np.float32).view(np.uint32)), (_block(d) - want).nonzero()
+    d = _desc_from_doc(L, '<materialx version="1.38"><gltf_pbr name="g" type="surfaceshader"/></materialx>')
+    want = M.open_pbr(base_color=(1, 1, 1), base_metalness=1.0, specular_roughness=1.0, coat_roughness=0.0, coat_ior=1.5, coat_darkening=0.0, fuzz_roughness=0.0,
+                      thin_film_ior=1.3, thin_film_thickness=np.float32(100.0) * np.float32(0.001), geometry_thin_walled=True).params
+    assert d is not None and d.klass == S.MAT_OPEN_PBR and np.array_equal(_block(d).view(np.uint32), np.asarray(want, np.float32).view(np.uint32)), (_block(d) - want).nonzero()
+    # every translated input of standard_surface
+    doc = _surface_doc("standard_surface", {
+        "base": ("float", "0.7"), "base_color": ("color3", "0.2, 0.4, 0.6"), "diffuse_roughness": ("float", "0.35"), "metalness": ("float", "0.25"),
+        "specular": ("float", "0.9"), "specular_color": ("color3", "0.9, 0.8, 0.7"), "specular_roughness": ("float", "0.15"), "specular_IOR": ("float", "1.33"),
+        "specular_anisotropy": ("float", "0.4"), "transmission": ("float", "0.3"), "transmission_color": ("color3", "0.8, 0.9, 1"), "transmission_depth": ("float", "0.5"),
+        "transmission_scatter": ("color3", "0.1, 0.2, 0.3"), "transmission_scatter_anisotropy": ("float", "0.2"), "subsurface": ("float", "0.45"),
+        "subsurface_color": ("color3", "0.9, 0.6, 0.5"), "subsurface_radius": ("color3", "1, 0.4, 0.2"), "subsurface_scale": ("float", "0.05"), "subsurface_anisotropy": ("float", "0.1"),
+        "sheen": ("float", "0.6"), "sheen_color": ("color3", "0.5, 0.5, 0.9"), "sheen_roughness": ("float", "0.45"), "coat": ("float", "0.75"), "coat_color": ("color3", "1, 0.9, 0.8"),
+        "coat_roughness": ("float", "0.05"), "coat_IOR": ("float", "1.45"), "coat_anisotropy": ("float", "0.3"), "thin_film_thickness": ("float", "550"),
+        "thin_film_IOR": ("float", "1.38"), "emission": ("float", "2.5"), "emission_color": ("color3", "1, 0.5, 0.25"), "opacity": ("color3", "0.9, 0.6, 0.3"), "thin_walled": ("boolean", "false"),
+        "specular_rotation": ("float", "0.3"), "transmission_dispersion": ("float", "20"), "coat_affect_color": ("float", "0.5")})   # (the last three: dropped)
+    d = _desc_from_doc(L, doc)
+    f = np.float32
+    want = M.open_pbr(base_weight=0.7, base_color=(0.2, 0.4, 0.6), base_diffuse_roughness=0.35, base_metalness=0.25, specular_weight=0.9, specular_color=(0.9, 0.8, 0.7),
+                      specular_roughness=0.15, specular_ior=1.33, specular_roughness_anisotropy=0.4, transmission_weight=0.3, transmission_color=(0.8, 0.9, 1.0),
+                      transmission_depth=0.5, transmission_scatter=(0.1, 0.2, 0.3), transmission_scatter_anisotropy=0.2, subsurface_weight=0.45, subsurface_color=(0.9, 0.6, 0.5),
+                      subsurface_radius=0.05, subsurface_radius_scale=(1.0, 0.4, 0.2), subsurface_scatter_anisotropy=0.1, fuzz_weight=0.6, fuzz_color=(0.5, 0.5, 0.9),
+                      fuzz_roughness=0.45, coat_weight=0.75, coat_color=(1.0, 0.9, 0.8), coat_roughness=0.05, coat_ior=1.45, coat_roughness_anisotropy=0.3, coat_darkening=0.0,
+                      thin_film_weight=1.0, thin_film_thickness=f(550.0) * f(0.001), thin_film_ior=1.38, emission_luminance=1.0,
+                      emission_color=(f(2.5) * f(1.0), f(2.5) * f(0.5), f(2.5) * f(0.25)), geometry_opacity=(f(0.9) + f(0.6) + f(0.3)) * f(1.0 / 3.0)).params
+    got = _block(d)
+    bad = np.nonzero(got.view(np.uint32) != np.asarray(want, np.float32).view(np.uint32))[0]
+    assert d.klass == S.MAT_OPEN_PBR and bad.size == 0, (bad.tolist(), got[bad].tolist(), np.asarray(want)[bad].tolist())
+    # gltf_pbr: thick transmission with attenuation, sheen, iridescence, clearcoat, MASK / BLEND alpha
+    doc = _surface_doc("gltf_pbr", {
+        "base_color": ("color3", "0.8, 0.3, 0.2"), "metallic": ("float", "0.1"), "roughness": ("float", "0.4"), "specular": ("float", "0.8"), "specular_color": ("color3", "1, 0.9, 0.9"),
+        "ior": ("float", "1.45"), "transmission": ("float", "0.6"), "thickness": ("float", "0.2"), "attenuation_distance": ("float", "0.75"), "attenuation_color": ("color3", "0.7, 0.9, 0.8"),
+        "clearcoat": ("float", "0.5"), "clearcoat_roughness": ("float", "0.08"), "sheen_color": ("color3", "0.3, 0.2, 0.1"), "sheen_roughness": ("float", "0.6"),
+        "iridescence": ("float", "0.7"), "iridescence_ior": ("float", "1.35"), "iridescence_thickness": ("float", "320"), "anisotropy_strength": ("float", "0.25"),
+        "alpha": ("float", "0.4"), "alpha_mode": ("integer", "2"), "emissive": ("color3", "0.5, 0.25, 0"), "emissive_strength": ("float", "4"), "occlusion": ("float", "0.5")})
+    d = _desc_from_doc(L, doc)
+    want = M.open_pbr(base_color=(0.8, 0.3, 0.2), base_metalness=0.1, specular_roughness=0.4, specular_weight=0.8, specular_color=(1.0, 0.9, 0.9), specular_ior=1.45,
+                      transmission_weight=0.6, transmission_color=(0.7, 0.9, 0.8), transmission_depth=0.75, coat_weight=0.5, coat_roughness=0.08, coat_ior=1.5, coat_darkening=0.0,
+                      fuzz_weight=1.0, fuzz_color=(0.3, 0.2, 0.1), fuzz_roughness=0.6, thin_film_weight=0.7, thin_film_ior=1.35, thin_film_thickness=f(320.0) * f(0.001),
+                      specular_roughness_anisotropy=0.25, geometry_opacity=0.4, emission_luminance=1.0, emission_color=(f(4.0) * f(0.5), f(4.0) * f(0.25), 0.0)).params
+    got = _block(d)
+    bad = np.nonzero(got.view(np.uint32) != np.asarray(want, np.float32).view(np.uint32))[0]
+    assert d.klass == S.MAT_OPEN_PBR and bad.size == 0, (bad.tolist(), got[bad].tolist(), np.asarray(want)[bad].tolist())
+    for mode, alpha, opacity in ((0, 0.3, 1.0), (1, 0.3, 0.0), (1, 0.6, 1.0), (2, 0.3, 0.3)):   # OPAQUE ignores alpha; MASK compares with alpha_cutoff (0.5); BLEND keeps it
+        d = _desc_from_doc(L, _surface_doc("gltf_pbr", {"alpha": ("float", str(alpha)), "alpha_mode": ("integer", str(mode))}))
+        assert _block(d)[capi.P_OPACITY if hasattr(capi, "P_OPACITY") else 14] == np.float32(opacity), (mode, alpha)
 
 
 REF_DELEGATE = "/root/reference/src/hdGatling/renderDelegate.cpp"
