@@ -136,7 +136,8 @@ namespace gtl
             size_t e = doc.find('>', q);
             if (e == std::string::npos) break;
             const std::string tag = doc.substr(q, e - q + 1), n = attr(tag, "name");
-            if (!n.empty()) { out.inputs[n] = attr(tag, "value"); if (!attr(tag, "nodename").empty()) out.connections[n] = attr(tag, "nodename"); }
+            if (!n.empty()) { out.inputs[n] = attr(tag, "value"); if (!attr(tag, "nodename").empty()) out.connections[n] = attr(tag, "nodename");
+                              if (!attr(tag, "colorspace").empty()) out.inputs[n + ":colorspace"] = attr(tag, "colorspace"); }
             q = e;
           }
           return true;
@@ -204,6 +205,33 @@ namespace gtl
           return;
         }
         if (!readNode(doc, it->second, up)) return;
+        // Between the image and the surface input MaterialX documents put per-channel affine nodes -- `normalmap` (2 x - 1, xy times its `scale`), `multiply` /
+        // `add` / `subtract` with a constant (tints, gains), `convert` / `dot` (pass-through) -- which fold into the binding's scale and bias: walking upstream,
+        // the value seen by the surface is S * x + B of the node's input x.  Anything else (a second texture, a procedural) ends the walk: the input keeps its constant.
+        float S[4] = {1, 1, 1, 1}, B[4] = {0, 0, 0, 0};
+        for (int depth = 0; depth < 8 && up.category != "UsdUVTexture" && up.category != "image" && up.category != "tiledimage"; depth++) {
+          const std::string cat = up.category;
+          float c[4] = {0, 0, 0, 0}; std::string next;
+          auto constantOf = [&](const char* in) { auto v = up.inputs.find(in); if (v == up.inputs.end() || v->second.empty() || up.connections.count(in)) return false;
+                                                  const int got = floats(v->second, c, 4); for (int i = got; got > 0 && i < 4; i++) c[i] = c[got - 1]; return got > 0; };
+          if (cat == "normalmap") {
+            if (!up.connections.count("in")) return;
+            float k = 1.0f; if (up.inputs.count("scale") && !up.inputs["scale"].empty() && !up.connections.count("scale")) floats(up.inputs["scale"], &k, 1);
+            const float kk[4] = {k, k, 1.0f, 1.0f};
+            for (int i = 0; i < 4; i++) { B[i] += S[i] * -kk[i]; S[i] *= 2.0f * kk[i]; }
+            next = up.connections["in"];
+          } else if (cat == "multiply" || cat == "add" || cat == "subtract") {
+            const bool c2 = constantOf("in2") && up.connections.count("in1"), c1 = !c2 && cat != "subtract" && constantOf("in1") && up.connections.count("in2");
+            if (!c1 && !c2) return;
+            next = up.connections[c2 ? "in1" : "in2"];
+            for (int i = 0; i < 4; i++) { if (cat == "multiply") S[i] *= c[i]; else if (cat == "add") B[i] += S[i] * c[i]; else B[i] -= S[i] * c[i]; }
+          } else if (cat == "convert" || cat == "dot") {
+            if (!up.connections.count("in")) return;
+            next = up.connections["in"];
+          } else return;
+          MtlxNode nx; if (!readNode(doc, next, nx)) return;
+          up = nx;
+        }
         if (up.category != "UsdUVTexture" && up.category != "image" && up.category != "tiledimage") return;
         ImageInput& im = images[slot];
         im.file = up.inputs["file"];
@@ -211,9 +239,12 @@ namespace gtl
         im.wrapT = wrapMode(up.inputs.count("wrapT") ? up.inputs["wrapT"] : up.inputs["vaddressmode"]);
         if (up.inputs.count("scale")) floats(up.inputs["scale"], im.scale, 4);
         if (up.inputs.count("bias")) floats(up.inputs["bias"], im.bias, 4);
+        for (int i = 0; i < 4; i++) { im.bias[i] = B[i] + S[i] * im.bias[i]; im.scale[i] = S[i] * im.scale[i]; } // (identity walk: x * 1 + 0 -- the values as written)
         const bool colour = slot == GI_C_TEX_BASE_COLOR || slot == GI_C_TEX_EMISSION;
         const std::string cs = up.inputs.count("sourceColorSpace") ? up.inputs["sourceColorSpace"] : "auto";
         im.srgb = cs == "sRGB" || (cs == "auto" && colour); // UsdUVTexture: auto = sRGB for 8-bit colour data
+        if (up.category != "UsdUVTexture") // MaterialX image nodes name the file's colour space on the `file` input; without one the file is taken as linear
+          im.srgb = up.inputs.count("file:colorspace") && up.inputs["file:colorspace"] == "srgb_texture";
         // texture coordinates through a UsdTransform2d (UsdPreviewSurface specification: result = in * scale, rotated counter-clockwise by `rotation` degrees, +
         // translation) -> the six floats of giCSetMaterialTextureTransform; cos / sin in double, rounded once (== gatling_amd/scene.py usd_transform_2d)
         auto stc = up.connections.find("st"); if (stc == up.connections.end()) stc = up.connections.find("texcoord");
@@ -400,6 +431,17 @@ namespace gtl
     if (slot < 0 || slot >= GI_C_TEX_SLOT_COUNT || !descFromMtlx(mtlxSrc, d, primvars, images) || images[slot].file.empty()) return 0;
     if (fileOut && fileCap > 0) { strncpy(fileOut, images[slot].file.c_str(), (size_t)fileCap - 1); fileOut[fileCap - 1] = 0; }
     if (xf6) memcpy(xf6, images[slot].xf, sizeof(float) * 6);
+    return images[slot].hasXf ? 2 : 1;
+  }
+  // [ext] the rest of that binding: scale[4], bias[4] (upstream normalmap / multiply / add nodes folded in), {sRGB decode, channel}; same return value
+  extern "C" int gtlMtlxImageBindingC(const char* mtlxSrc, int slot, float* scale4, float* bias4, int* srgbChannel2)
+  {
+    std::string primvars[GI_C_TEX_SLOT_COUNT]; ImageInput images[GI_C_TEX_SLOT_COUNT];
+    GiCMaterialDesc d;
+    if (slot < 0 || slot >= GI_C_TEX_SLOT_COUNT || !descFromMtlx(mtlxSrc, d, primvars, images) || images[slot].file.empty()) return 0;
+    if (scale4) memcpy(scale4, images[slot].scale, sizeof(float) * 4);
+    if (bias4) memcpy(bias4, images[slot].bias, sizeof(float) * 4);
+    if (srgbChannel2) { srgbChannel2[0] = images[slot].srgb ? 1 : 0; srgbChannel2[1] = images[slot].channel; }
     return images[slot].hasXf ? 2 : 1;
   }
   extern "C" int gtlMaterialDescFromMtlxStrC(const char* mtlxSrc, GiCMaterialDesc* out)

@@ -287,6 +287,56 @@ def test_usd_transform_2d_reaches_the_texture_binding():
     assert d is not None and d.klass == S.MAT_USD_PREVIEW_SURFACE and abs(d.p[capi.P_ROUGHNESS if hasattr(capi, "P_ROUGHNESS") else 11] - 0.7) < 1e-7
 
 
+MTLX_NATIVE_DOC = """<?xml version="1.0"?>
+<materialx version="1.39">
+  <nodegraph name="NG">
+    <tiledimage name="albedo" type="color3"><input name="file" type="filename" value="%(file)s" colorspace="srgb_texture" /></tiledimage>
+    <multiply name="tint" type="color3"><input name="in1" type="color3" nodename="albedo" /><input name="in2" type="color3" value="0.9, 0.5, 0.25" /></multiply>
+    <add name="lift" type="color3"><input name="in1" type="color3" nodename="tint" /><input name="in2" type="color3" value="0.02, 0.02, 0.02" /></add>
+    <image name="nrm" type="vector3"><input name="file" type="filename" value="%(file)s" /></image>
+    <normalmap name="nmap" type="vector3"><input name="in" type="vector3" nodename="nrm" /><input name="scale" type="float" value="0.5" /></normalmap>
+    <image name="rough" type="float"><input name="file" type="filename" value="%(file)s" /></image>
+    <multiply name="rgain" type="float"><input name="in1" type="float" value="0.8" /><input name="in2" type="float" nodename="rough" /></multiply>
+    <subtract name="rcut" type="float"><input name="in1" type="float" nodename="rgain" /><input name="in2" type="float" value="0.1" /></subtract>
+    <image name="metal" type="float"><input name="file" type="filename" value="%(file)s" /></image>
+    <noise2d name="speckle" type="float" />
+    <multiply name="procedural" type="float"><input name="in1" type="float" nodename="metal" /><input name="in2" type="float" nodename="speckle" /></multiply>
+    <output name="base_color_out" type="color3" nodename="lift" />
+    <output name="normal_out" type="vector3" nodename="nmap" />
+    <output name="rough_out" type="float" nodename="rcut" />
+    <output name="metal_out" type="float" nodename="procedural" />
+  </nodegraph>
+  <open_pbr_surface name="srf" type="surfaceshader">
+    <input name="base_color" type="color3" nodegraph="NG" output="base_color_out" />
+    <input name="geometry_normal" type="vector3" nodegraph="NG" output="normal_out" />
+    <input name="specular_roughness" type="float" nodegraph="NG" output="rough_out" />
+    <input name="base_metalness" type="float" nodegraph="NG" output="metal_out" />
+  </open_pbr_surface>
+  <surfacematerial name="mat" type="material"><input name="surfaceshader" type="surfaceshader" nodename="srf" /></surfacematerial>
+</materialx>"""
+
+
+def test_affine_nodes_between_image_and_surface_fold_into_the_binding():
+    """MaterialX-native networks put `normalmap`, `multiply`, `add`, `subtract` between an image and the surface input (USD's UsdUVTexture carries scale / bias
+    itself).  The reader folds such per-channel affine chains into the binding's scale and bias -- S * x + B composed upstream -- reads the file's colour space off
+    the `file` input, and stops at anything it cannot fold (here: a texture times a noise): that input keeps its constant, the rest of the material still binds."""
+    L = capi.load_library()
+    L.gtlMtlxImageBindingC.restype = C.c_int
+    L.gtlMtlxImageBindingC.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    doc = (MTLX_NATIVE_DOC % dict(file=_PNG)).encode()
+    sc, bi, fl = (C.c_float * 4)(), (C.c_float * 4)(), (C.c_int * 2)()
+    f = np.float32
+    assert L.gtlMtlxImageBindingC(doc, S.TEX_BASE_COLOR, sc, bi, fl) == 1 and fl[0] == 1   # sRGB decode from colorspace="srgb_texture"
+    assert np.array_equal(np.float32(list(sc))[:3], np.float32([0.9, 0.5, 0.25])) and np.array_equal(np.float32(list(bi))[:3], np.float32([0.02, 0.02, 0.02]))
+    assert L.gtlMtlxImageBindingC(doc, S.TEX_NORMAL, sc, bi, fl) == 1 and fl[0] == 0       # normalmap: (2 x - 1) * (scale, scale, 1)
+    assert list(sc)[:3] == [1.0, 1.0, 2.0] and list(bi)[:3] == [-0.5, -0.5, -1.0]
+    assert L.gtlMtlxImageBindingC(doc, S.TEX_ROUGHNESS, sc, bi, fl) == 1                   # 0.8 * x - 0.1 (constant on in1 of the multiply)
+    assert sc[0] == f(0.8) and bi[0] == f(0.0) - f(1.0) * f(0.1)
+    assert L.gtlMtlxImageBindingC(doc, S.TEX_METALLIC, sc, bi, fl) == 0                    # texture x noise: not foldable, the input keeps its constant
+    d = _desc_from_doc(L, doc.decode())
+    assert d is not None and d.klass == S.MAT_OPEN_PBR and d.p[10] == 0.0                  # base_metalness default
+
+
 @pytest.mark.gpu
 def test_usd_transform_2d_document_renders_the_bound_texture_image(gi):
     """The document above through gtl::giCreateMaterialFromMtlxStr (file texture decoded in-library, transform folded by the reader) against the scene whose material
