@@ -49,7 +49,7 @@ struct ShState {
   bool sssVolume;                // the render keeps a medium stack: OpenPBR's volumetric subsurface lobe is live (set by shade_segment)
   bool hasCoatFrame; V3 coatNormal, coatTangentU, coatTangentV; // OpenPBR geometry_coat_normal (open_pbr_surface.mtlx:87, 560): the coat lobe's own frame (resolve_material_textures)
   uint32_t texMask;              // bit per TEX_* slot whose value below replaces the material constant at this hit
-  V3 texBaseColor, texEmission; float texRoughness, texMetallic;
+  V3 texBaseColor, texEmission, texTransColor; float texRoughness, texMetallic, texTransWeight;
 };
 
 __device__ __forceinline__ V3 xform_point(const float* a, V3 p, float w)
@@ -116,7 +116,7 @@ __device__ __forceinline__ void setup_shading_state(const SceneView& sc, uint32_
   s.normal = nrm; s.geomNormal = gn;
   s.mesh = f2u(r5.y); s.instanceId = (int32_t)f2u(r5.z); s.prim = td.w; s.hu = hu; s.hv = hv;
   s.ior1 = 0.0f; s.ior2 = 0.0f;
-  s.thinWalled = false; s.sssVolume = false; s.hasCoatFrame = false; s.texMask = 0u; s.texBaseColor = v3(0.0f, 0.0f, 0.0f); s.texEmission = s.texBaseColor; s.texRoughness = 0.0f; s.texMetallic = 0.0f;
+  s.thinWalled = false; s.sssVolume = false; s.hasCoatFrame = false; s.texMask = 0u; s.texBaseColor = v3(0.0f, 0.0f, 0.0f); s.texEmission = s.texBaseColor; s.texRoughness = 0.0f; s.texMetallic = 0.0f; s.texTransColor = s.texBaseColor; s.texTransWeight = 0.0f;
 }
 
 // mdl_adapt_normal (mdl_interface.glsl:238-256): Iray's shadow-terminator bend of a mapped normal
@@ -146,20 +146,21 @@ __device__ inline void resolve_material_textures(const SceneView& sc, const Mate
     }
   }
 #pragma unroll
-  for (uint32_t slot = 0; slot < TEX_OPACITY; slot++) { // TEX_OPACITY belongs to the any-hit test (cutout_opacity_at)
+  for (uint32_t k = 0; k < SHADE_SLOT_COUNT; k++) { // TEX_OPACITY belongs to the any-hit test (cutout_opacity_at), TEX_COAT_NORMAL was resolved above
+    const uint32_t slot = shade_slot(k);
     const TexBindingRec& b = m->tex[slot];
     if (b.tex == 0u) {
       if (!(b.mode & TEX_MODE_PRIMVAR) || slot == TEX_NORMAL) continue;
-      const bool vec = slot == TEX_BASE_COLOR || slot == TEX_EMISSION;
+      const bool vec = slot == TEX_BASE_COLOR || slot == TEX_EMISSION || slot == TEX_TRANSMISSION_COLOR;
       // the two magic scene-data names (mdl_interface.glsl:329-334 float3 only, :390-395 float only)
       if (vec && (b.mode & TEX_MODE_CAMERA_POSITION)) {
         st.texMask |= 1u << slot;
-        if (slot == TEX_BASE_COLOR) st.texBaseColor = v3(sc.cameraPosition); else st.texEmission = v3(sc.cameraPosition);
+        if (slot == TEX_BASE_COLOR) st.texBaseColor = v3(sc.cameraPosition); else if (slot == TEX_EMISSION) st.texEmission = v3(sc.cameraPosition); else st.texTransColor = v3(sc.cameraPosition);
         continue;
       }
       if (!vec && (b.mode & TEX_MODE_FRAME)) {
         st.texMask |= 1u << slot;
-        if (slot == TEX_ROUGHNESS) st.texRoughness = sc.frame; else st.texMetallic = sc.frame;
+        if (slot == TEX_ROUGHNESS) st.texRoughness = sc.frame; else if (slot == TEX_METALLIC) st.texMetallic = sc.frame; else st.texTransWeight = sc.frame;
         continue;
       }
       // scene_data_lookup_float3 / _float (mdl_interface.glsl:337-371, 398-424; == oracle scene_data_lookup)
@@ -186,8 +187,10 @@ __device__ inline void resolve_material_textures(const SceneView& sc, const Mate
       st.texMask |= 1u << slot;
       if (slot == TEX_BASE_COLOR) st.texBaseColor = v3(o[0], o[1], o[2]);
       else if (slot == TEX_EMISSION) st.texEmission = v3(o[0], o[1], o[2]);
+      else if (slot == TEX_TRANSMISSION_COLOR) st.texTransColor = v3(o[0], o[1], o[2]);
       else if (slot == TEX_ROUGHNESS) st.texRoughness = o[0];
-      else st.texMetallic = o[0];
+      else if (slot == TEX_METALLIC) st.texMetallic = o[0];
+      else st.texTransWeight = o[0];
       continue;
     }
     float tu = st.u, tv = st.v; tex_transform_st(b, tu, tv);
@@ -198,8 +201,10 @@ __device__ inline void resolve_material_textures(const SceneView& sc, const Mate
     st.texMask |= 1u << slot;
     if (slot == TEX_BASE_COLOR) st.texBaseColor = v3(val[0], val[1], val[2]);
     else if (slot == TEX_EMISSION) st.texEmission = v3(val[0], val[1], val[2]);
+    else if (slot == TEX_TRANSMISSION_COLOR) st.texTransColor = v3(val[0], val[1], val[2]);
     else if (slot == TEX_ROUGHNESS) st.texRoughness = sel;
     else if (slot == TEX_METALLIC) st.texMetallic = sel;
+    else if (slot == TEX_TRANSMISSION_WEIGHT) st.texTransWeight = sel;
     else {
       V3 n = normalize((st.tangentU * val[0] + st.tangentV * val[1]) + st.normal * val[2]);
       n = adapt_normal(rayDir, st.geomNormal, n);
@@ -476,6 +481,8 @@ __device__ __forceinline__ OpbrParams opbr_params(const MaterialRec* m, const Sh
   if (st.texMask & (1u << TEX_BASE_COLOR)) { o.albedo = st.texBaseColor * p[17]; o.baseColor = st.texBaseColor; }
   if (st.texMask & (1u << TEX_ROUGHNESS)) { const float r = opbr_effective_roughness(st.texRoughness, p[13], o.coat); o.alpha = fmax2(r * r, 0.001f); }
   if (st.texMask & (1u << TEX_METALLIC)) o.metalness = st.texMetallic;
+  if (st.texMask & (1u << TEX_TRANSMISSION_WEIGHT)) o.tw = st.texTransWeight;
+  if ((st.texMask & (1u << TEX_TRANSMISSION_COLOR)) && !(p[28] > 0.0f)) o.transTint = st.texTransColor; // (with a depth the colour is the medium's: the material's constant)
   o.alphaY = o.alpha; o.coatAlphaY = o.coatAlpha;
   if (feat & MATF_ANISOTROPY) { opbr_anisotropy(o.alpha, p[60], o.alpha, o.alphaY); opbr_anisotropy(o.coatAlpha, p[61], o.coatAlpha, o.coatAlphaY); } // specular_roughness_anisotropy / coat_roughness_anisotropy
   // coat_substrate_attenuated = base_substrate * modulated_base_darkening * coat_attenuation (open_pbr_surface.mtlx:538-552)

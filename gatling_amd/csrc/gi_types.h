@@ -86,7 +86,11 @@ enum : uint32_t { MP_ALBEDO = 32, MP_F0 = 35, MP_ALPHA = 38, MP_COAT = 39, MP_CO
 // Textured material inputs (UsdUVTexture semantics: value = texel * scale + bias at the hit's st).  Replaces the MDL
 // renderer runtime's tex_lookup_* path (mdl_interface.glsl:127-145) for the inputs the closed-form materials expose.
 enum : uint32_t { TEX_BASE_COLOR = 0, TEX_EMISSION = 1, TEX_ROUGHNESS = 2, TEX_METALLIC = 3, TEX_NORMAL = 4, TEX_OPACITY = 5 /* read by the any-hit test, not by k_shade */,
-                  TEX_COAT_NORMAL = 6 /* OpenPBR geometry_coat_normal: the coat lobe's own shading frame */, TEX_SLOT_COUNT = 7 };
+                  TEX_COAT_NORMAL = 6 /* OpenPBR geometry_coat_normal: the coat lobe's own shading frame */,
+                  TEX_TRANSMISSION_WEIGHT = 7, TEX_TRANSMISSION_COLOR = 8 /* OpenPBR transmission_weight (scalar) / transmission_color (rgb: the surface tint of a medium-less, depth-0 transmission) */, TEX_SLOT_COUNT = 9 };
+// the slots k_shade resolves per hit, in resolve order (TEX_OPACITY belongs to the any-hit test, TEX_COAT_NORMAL is resolved before the base normal)
+constexpr uint32_t shade_slot(uint32_t k) { return k < TEX_OPACITY ? k : k + 2u; }
+constexpr uint32_t SHADE_SLOT_COUNT = 7;
 enum : uint32_t { TEX_WRAP_CLAMP = 0, TEX_WRAP_REPEAT = 1, TEX_WRAP_MIRRORED_REPEAT = 2, TEX_WRAP_CLIP = 3 }; // mdl_types.glsl:117-120
 struct TexBindingRec {
   uint32_t tex;   // texture index + 1; 0 = input not textured
@@ -112,7 +116,7 @@ struct MaterialRec {
   TexBindingRec tex[TEX_SLOT_COUNT];
   float sss[8]; // volumetric subsurface medium (OpenPBR, derived on the host from subsurface_color / _radius / _radius_scale): sigma_s[3], sigma_t[3], -, -
 };
-static_assert(sizeof(MaterialRec) == 744, "MaterialRec must be 744 bytes");
+static_assert(sizeof(MaterialRec) == 872, "MaterialRec must be 872 bytes");
 // A texture: linear float RGBA texels, row 0 first.  (8-bit sources are decoded to linear float by the caller; a
 // compressed unorm8/half store is a later memory optimisation, the lookup arithmetic would not change.)
 struct TextureRec { const float* texels; uint32_t width, height; };

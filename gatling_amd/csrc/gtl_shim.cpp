@@ -240,7 +240,7 @@ namespace gtl
         if (up.inputs.count("scale")) floats(up.inputs["scale"], im.scale, 4);
         if (up.inputs.count("bias")) floats(up.inputs["bias"], im.bias, 4);
         for (int i = 0; i < 4; i++) { im.bias[i] = B[i] + S[i] * im.bias[i]; im.scale[i] = S[i] * im.scale[i]; } // (identity walk: x * 1 + 0 -- the values as written)
-        const bool colour = slot == GI_C_TEX_BASE_COLOR || slot == GI_C_TEX_EMISSION;
+        const bool colour = slot == GI_C_TEX_BASE_COLOR || slot == GI_C_TEX_EMISSION || slot == GI_C_TEX_TRANSMISSION_COLOR;
         const std::string cs = up.inputs.count("sourceColorSpace") ? up.inputs["sourceColorSpace"] : "auto";
         im.srgb = cs == "sRGB" || (cs == "auto" && colour); // UsdUVTexture: auto = sRGB for 8-bit colour data
         if (up.category != "UsdUVTexture") // MaterialX image nodes name the file's colour space on the `file` input; without one the file is taken as linear
@@ -321,6 +321,7 @@ namespace gtl
         for (int i = 0; i < 3; i++) p[GI_C_P_EMISSION + i] = lum * ecol[i];
         bind("base_color", GI_C_TEX_BASE_COLOR, p + GI_C_P_BASE_COLOR, 3); bind("specular_roughness", GI_C_TEX_ROUGHNESS, p + GI_C_P_ROUGHNESS, 1); bind("metalness", GI_C_TEX_METALLIC, p + GI_C_P_METALLIC, 1);
         bind("normal", GI_C_TEX_NORMAL); bind("opacity", GI_C_TEX_OPACITY); bind("coat_normal", GI_C_TEX_COAT_NORMAL);
+        bind("transmission", GI_C_TEX_TRANSMISSION_WEIGHT, p + GI_C_P_TRANSMISSION_WEIGHT, 1); bind("transmission_color", GI_C_TEX_TRANSMISSION_COLOR, p + GI_C_P_TRANSMISSION_COLOR, 3);
         return true;
       }
       if (n.category == "gltf_pbr") {
@@ -349,7 +350,7 @@ namespace gtl
         float strength = 1.0f; ecol[0] = ecol[1] = ecol[2] = 0.0f; setN(n, "emissive", ecol, 3); setN(n, "emissive_strength", &strength, 1);
         for (int i = 0; i < 3; i++) p[GI_C_P_EMISSION + i] = strength * ecol[i];
         bind("base_color", GI_C_TEX_BASE_COLOR, p + GI_C_P_BASE_COLOR, 3); bind("roughness", GI_C_TEX_ROUGHNESS, p + GI_C_P_ROUGHNESS, 1); bind("metallic", GI_C_TEX_METALLIC, p + GI_C_P_METALLIC, 1);
-        bind("normal", GI_C_TEX_NORMAL); bind("clearcoat_normal", GI_C_TEX_COAT_NORMAL);
+        bind("normal", GI_C_TEX_NORMAL); bind("clearcoat_normal", GI_C_TEX_COAT_NORMAL); bind("transmission", GI_C_TEX_TRANSMISSION_WEIGHT, p + GI_C_P_TRANSMISSION_WEIGHT, 1);
         if (mode >= 1.5f) bind("alpha", GI_C_TEX_OPACITY);
         return true;
       }
@@ -373,6 +374,7 @@ namespace gtl
       for (int i = 0; i < 3; i++) p[GI_C_P_EMISSION + i] = lum * ecol[i];
       bind("base_color", GI_C_TEX_BASE_COLOR, p + GI_C_P_BASE_COLOR, 3); bind("specular_roughness", GI_C_TEX_ROUGHNESS, p + GI_C_P_ROUGHNESS, 1); bind("base_metalness", GI_C_TEX_METALLIC, p + GI_C_P_METALLIC, 1);
       bind("geometry_normal", GI_C_TEX_NORMAL); bind("geometry_opacity", GI_C_TEX_OPACITY); bind("geometry_coat_normal", GI_C_TEX_COAT_NORMAL);
+      bind("transmission_weight", GI_C_TEX_TRANSMISSION_WEIGHT, p + GI_C_P_TRANSMISSION_WEIGHT, 1); bind("transmission_color", GI_C_TEX_TRANSMISSION_COLOR, p + GI_C_P_TRANSMISSION_COLOR, 3);
       return true;
     }
   }

@@ -88,7 +88,8 @@ def usd_transform_2d(rotation_deg=0.0, scale=(1.0, 1.0), translation=(0.0, 0.0))
 
 
 TEX_WRAP_CLAMP, TEX_WRAP_REPEAT, TEX_WRAP_MIRRORED_REPEAT, TEX_WRAP_CLIP = 0, 1, 2, 3
-TEX_BASE_COLOR, TEX_EMISSION, TEX_ROUGHNESS, TEX_METALLIC, TEX_NORMAL, TEX_OPACITY, TEX_COAT_NORMAL, TEX_SLOT_COUNT = 0, 1, 2, 3, 4, 5, 6, 7  # TEX_COAT_NORMAL: OpenPBR geometry_coat_normal
+TEX_TRANSMISSION_WEIGHT, TEX_TRANSMISSION_COLOR = 7, 8  # OpenPBR transmission_weight (scalar) / transmission_color (rgb; tints the surface when transmission_depth is 0)
+TEX_BASE_COLOR, TEX_EMISSION, TEX_ROUGHNESS, TEX_METALLIC, TEX_NORMAL, TEX_OPACITY, TEX_COAT_NORMAL, TEX_SLOT_COUNT = 0, 1, 2, 3, 4, 5, 6, 9  # TEX_COAT_NORMAL: OpenPBR geometry_coat_normal
 
 
 @dataclass

@@ -9,7 +9,7 @@ setters (reference interface ``src/gi/gtl/gi/Gi.h:86-175``) -- written sequentia
     GiCCameraDesc (16 x f32)
     u32 nTextures   { u32 width, height; f32 rgba[h * w * 4] }
     u32 nMaterials  { str name; u32 klass; u32 nParams; f32 params[nParams];
-                      7 x { i32 texture (-1: none), wrapS, wrapT, channel; f32 scale[4], bias[4]; u32 hasTransform; f32 xf[6] }; 7 x str primvarName }   (GI_C_TEX_* slots)
+                      9 x { i32 texture (-1: none), wrapS, wrapT, channel; f32 scale[4], bias[4]; u32 hasTransform; f32 xf[6] }; 9 x str primvarName }   (GI_C_TEX_* slots)
     u32 hasDome     [i32 texture; f32 rotation[4], baseEmission[3], diffuse, specular]
     u32 nMeshes     { str name; u32 nVertices, nFaces; i32 id; u32 flags; i32 material; u32 maxFaceId; f32 transform[16];
                       u32 nInstances; f32 instanceTransforms[nInstances * 16]; [i32 instanceIds[nInstances]]
@@ -31,8 +31,8 @@ import numpy as np
 from .scene import (CameraDesc, DiskLight, DistantLight, DomeLight, MaterialDesc, MeshDesc, P_COUNT, Primvar, RectLight, RenderSettings,
                     SceneDesc, SphereLight, TextureBinding, VERTEX_DTYPE)
 
-MAGIC, END, VERSION = b"GSCN", b"END!", 2  # 2 (round 4): seven texture slots (geometry_coat_normal), a texture-coordinate transform per slot
-TEX_SLOTS = 7
+MAGIC, END, VERSION = b"GSCN", b"END!", 3  # 2 (round 4): seven texture slots (geometry_coat_normal), a texture-coordinate transform per slot; 3: nine (transmission weight / colour)
+TEX_SLOTS = 9
 F_DOUBLE_SIDED, F_LEFT_HANDED, F_VISIBLE, F_FACE_IDS, F_INSTANCE_IDS = 1, 2, 4, 8, 16
 
 

@@ -226,6 +226,8 @@ def _material_from_prim(prim: Prim, klass: int) -> MaterialDesc:
         m = MaterialDesc.usd_preview_surface(name=prim.path, klass=klass, **kw)
     if shader is not None:
         for slot, (ups, opbr_name, _rtype, _vtype) in SLOT_INPUTS.items():
+            if opbr is None and ups is None:
+                continue
             conn = shader.attrs.get(f"inputs:{opbr_name if opbr is not None else ups}.connect")
             if isinstance(conn, tuple) and conn[0] == "path":
                 reader = shaders.get(conn[1].split(".")[0].split("/")[-1])

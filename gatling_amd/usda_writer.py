@@ -29,7 +29,7 @@ from .scene import (INTERP_CONSTANT, INTERP_UNIFORM, INTERP_VERTEX, MAT_OPEN_PBR
                     P_CLEARCOAT, P_CLEARCOAT_ROUGHNESS, P_COAT_COLOR, P_COAT_DARKENING, P_COAT_IOR, P_DIFFUSE_ROUGHNESS, P_FUZZ_COLOR, P_FUZZ_ROUGHNESS, P_FUZZ_WEIGHT, P_THIN_WALLED, P_SUBSURFACE_WEIGHT, P_SUBSURFACE_COLOR, P_SUBSURFACE_ANISOTROPY, P_SUBSURFACE_RADIUS, P_SUBSURFACE_RADIUS_SCALE, P_SPECULAR_ANISOTROPY, P_COAT_ANISOTROPY, P_THIN_FILM_WEIGHT, P_THIN_FILM_THICKNESS, P_THIN_FILM_IOR, P_EMISSION, P_IOR, P_METALLIC, P_OPACITY,
                     P_OPACITY_THRESHOLD, P_ROUGHNESS, P_SPECULAR_COLOR, P_SPECULAR_WEIGHT, P_TRANSMISSION_COLOR, P_TRANSMISSION_DEPTH,
                     P_TRANSMISSION_SCATTER, P_TRANSMISSION_SCATTER_ANISOTROPY, P_TRANSMISSION_WEIGHT, P_USE_SPECULAR_WORKFLOW, SceneDesc,
-                    TEX_BASE_COLOR, TEX_EMISSION, TEX_METALLIC, TEX_NORMAL, TEX_ROUGHNESS)
+                    TEX_BASE_COLOR, TEX_EMISSION, TEX_METALLIC, TEX_NORMAL, TEX_ROUGHNESS, TEX_TRANSMISSION_COLOR, TEX_TRANSMISSION_WEIGHT)
 
 OPEN_PBR_ID = "ND_open_pbr_surface_surfaceshader"
 # (input name, parameter index, components) -- the inputs this core implements (open_pbr_surface.mtlx:11-92)
@@ -51,7 +51,9 @@ UPS_INPUTS = [("diffuseColor", P_BASE_COLOR, 3), ("emissiveColor", P_EMISSION, 3
 # texturable slot -> (UsdPreviewSurface input, OpenPBR input, primvar reader type, value type)
 SLOT_INPUTS = {TEX_BASE_COLOR: ("diffuseColor", "base_color", "float3", "color3f"), TEX_EMISSION: ("emissiveColor", "emission_color", "float3", "color3f"),
                TEX_ROUGHNESS: ("roughness", "specular_roughness", "float", "float"), TEX_METALLIC: ("metallic", "base_metalness", "float", "float"),
-               TEX_NORMAL: ("normal", "geometry_normal", "float3", "normal3f")}
+               TEX_NORMAL: ("normal", "geometry_normal", "float3", "normal3f"),
+               TEX_TRANSMISSION_WEIGHT: (None, "transmission_weight", "float", "float"),     # (OpenPBR only: UsdPreviewSurface has no transmission)
+               TEX_TRANSMISSION_COLOR: (None, "transmission_color", "float3", "color3f")}
 PRIMVAR_TYPES = {0: "float", 1: "float2", 2: "float3", 3: "float4"}
 PRIMVAR_INTERP = {INTERP_CONSTANT: "constant", INTERP_UNIFORM: "uniform", INTERP_VERTEX: "vertex"}
 
@@ -113,6 +115,8 @@ def _material_lines(i, m, root) -> list:
     bound = {}
     for slot, pv in m.primvar_inputs.items():
         ups, opbr, rtype, vtype = SLOT_INPUTS[slot]
+        if m.klass != MAT_OPEN_PBR and ups is None:
+            continue
         bound[opbr if m.klass == MAT_OPEN_PBR else ups] = (slot, pv, rtype, vtype)
     if m.klass == MAT_OPEN_PBR:
         out.append(f'                uniform token info:id = "{OPEN_PBR_ID}"')

@@ -227,7 +227,10 @@ void giCDestroyTexture(GiCTexture* texture);
 #define GI_C_TEX_NORMAL 4     /* tangent-space normal (rgb, usually scale 2 bias -1); bent by mdl_adapt_normal (mdl_interface.glsl:238-256) */
 #define GI_C_TEX_OPACITY 5    /* scalar: cutout opacity (UsdPreviewSurface opacity / OpenPBR geometry_opacity), evaluated per candidate hit by the any-hit test (rp_main.ahit:51-60); texture only */
 #define GI_C_TEX_COAT_NORMAL 6 /* vector: OpenPBR geometry_coat_normal (open_pbr_surface.mtlx:87, 560), a tangent-space normal map for the coat lobe's own shading frame (OpenPBR class only) */
-#define GI_C_TEX_SLOT_COUNT 7
+#define GI_C_TEX_TRANSMISSION_WEIGHT 7 /* scalar: OpenPBR transmission_weight (open_pbr_surface.mtlx:29) */
+#define GI_C_TEX_TRANSMISSION_COLOR 8  /* rgb: OpenPBR transmission_color (:31) -- the surface tint when transmission_depth is 0; with a depth the colour defines the MEDIUM's absorption,
+                                         * which stays the material's constant (a path's medium is pushed once, where it enters) */
+#define GI_C_TEX_SLOT_COUNT 9
 #define GI_C_TEX_WRAP_CLAMP 0 /* mdl_types.glsl:117-120 */
 #define GI_C_TEX_WRAP_REPEAT 1
 #define GI_C_TEX_WRAP_MIRRORED_REPEAT 2

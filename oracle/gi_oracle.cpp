@@ -811,7 +811,9 @@ float cutout_opacity_textured(const Prepared& P, const Tri& T, float hu, float h
 }
 // Per-hit material: the parameter block with its textured inputs evaluated at the hit's uv (UsdUVTexture: texel * scale + bias);
 // a normal map replaces the shading normal (tangent space -> world, adapt_normal, tangent frame re-orthonormalised).
-inline bool material_textured(const OrcMaterial& m) { for (int i = 0; i < ORC_TEX_OPACITY; i++) if (m.tex[i].texture >= 0 || m.primvarInput[i][0]) return true; return m.tex[ORC_TEX_COAT_NORMAL].texture >= 0; }
+inline int shade_slot(int k) { return k < ORC_TEX_OPACITY ? k : k + 2; } // the slots resolved per hit: 0..4, then transmission weight / colour (opacity: any-hit test; coat normal: before the base normal)
+const int SHADE_SLOT_COUNT = 7;
+inline bool material_textured(const OrcMaterial& m) { for (int k = 0; k < SHADE_SLOT_COUNT; k++) { const int i = shade_slot(k); if (m.tex[i].texture >= 0 || m.primvarInput[i][0]) return true; } return m.tex[ORC_TEX_COAT_NORMAL].texture >= 0; }
 // The primvar a scene-data name resolves to for this mesh: instancer primvars first, mesh primvars override (Gi.cpp:913-929)
 inline const OrcPrimvar* find_primvar(const OrcMesh& m, const char* name)
 {
@@ -868,16 +870,19 @@ OrcMaterial resolve_material(const Prepared& P, const OrcMaterial& m, State& st,
       st.hasCoatFrame = true; st.coatNormal = n; st.coatTangentU = tg; st.coatTangentV = cross(n, tg) * hs;
     }
   }
-  for (int slot = 0; slot < ORC_TEX_OPACITY; slot++) { // ORC_TEX_OPACITY belongs to the any-hit test (cutout_opacity_textured)
+  for (int k = 0; k < SHADE_SLOT_COUNT; k++) { // ORC_TEX_OPACITY belongs to the any-hit test (cutout_opacity_textured)
+    const int slot = shade_slot(k);
     const OrcTexBinding& b = m.tex[slot];
     if ((b.texture < 0 || (uint32_t)b.texture >= P.textureCount) && m.primvarInput[slot][0] && slot != ORC_TEX_NORMAL) { // primvar-driven input
       float v[3];
-      const bool vec = slot == ORC_TEX_BASE_COLOR || slot == ORC_TEX_EMISSION;
+      const bool vec = slot == ORC_TEX_BASE_COLOR || slot == ORC_TEX_EMISSION || slot == ORC_TEX_TRANSMISSION_COLOR;
       if (scene_data_lookup(st, m.primvarInput[slot], vec ? 3 : 1, v)) {
         if (slot == ORC_TEX_BASE_COLOR) { r.p[ORC_P_BASE_COLOR] = v[0]; r.p[ORC_P_BASE_COLOR + 1] = v[1]; r.p[ORC_P_BASE_COLOR + 2] = v[2]; }
         else if (slot == ORC_TEX_EMISSION) { r.p[ORC_P_EMISSION] = v[0]; r.p[ORC_P_EMISSION + 1] = v[1]; r.p[ORC_P_EMISSION + 2] = v[2]; }
+        else if (slot == ORC_TEX_TRANSMISSION_COLOR) { r.p[ORC_P_TRANSMISSION_COLOR] = v[0]; r.p[ORC_P_TRANSMISSION_COLOR + 1] = v[1]; r.p[ORC_P_TRANSMISSION_COLOR + 2] = v[2]; }
         else if (slot == ORC_TEX_ROUGHNESS) r.p[ORC_P_ROUGHNESS] = v[0];
-        else r.p[ORC_P_METALLIC] = v[0];
+        else if (slot == ORC_TEX_METALLIC) r.p[ORC_P_METALLIC] = v[0];
+        else r.p[ORC_P_TRANSMISSION_WEIGHT] = v[0];
       }
       continue;
     }
@@ -887,8 +892,10 @@ OrcMaterial resolve_material(const Prepared& P, const OrcMaterial& m, State& st,
     float val[4] = {t.x * b.scale[0] + b.bias[0], t.y * b.scale[1] + b.bias[1], t.z * b.scale[2] + b.bias[2], t.w * b.scale[3] + b.bias[3]};
     if (slot == ORC_TEX_BASE_COLOR) { r.p[ORC_P_BASE_COLOR] = val[0]; r.p[ORC_P_BASE_COLOR + 1] = val[1]; r.p[ORC_P_BASE_COLOR + 2] = val[2]; }
     else if (slot == ORC_TEX_EMISSION) { r.p[ORC_P_EMISSION] = val[0]; r.p[ORC_P_EMISSION + 1] = val[1]; r.p[ORC_P_EMISSION + 2] = val[2]; }
+    else if (slot == ORC_TEX_TRANSMISSION_COLOR) { r.p[ORC_P_TRANSMISSION_COLOR] = val[0]; r.p[ORC_P_TRANSMISSION_COLOR + 1] = val[1]; r.p[ORC_P_TRANSMISSION_COLOR + 2] = val[2]; }
     else if (slot == ORC_TEX_ROUGHNESS) r.p[ORC_P_ROUGHNESS] = val[b.channel & 3];
     else if (slot == ORC_TEX_METALLIC) r.p[ORC_P_METALLIC] = val[b.channel & 3];
+    else if (slot == ORC_TEX_TRANSMISSION_WEIGHT) r.p[ORC_P_TRANSMISSION_WEIGHT] = val[b.channel & 3];
     else { // ORC_TEX_NORMAL
       V3 n = normalize((st.tangentU * val[0] + st.tangentV * val[1]) + st.normal * val[2]);
       n = adapt_normal(rayDir, st.geomNormal, n);
@@ -1731,7 +1738,7 @@ void closest_hit(const Frame& F, const Hit& h, Payload& pl, float hitT)
     float distance = hitT * F.rs->metersPerSceneUnit;
     if (stackSize == 0) { // :169-173: the HIT material's absorption coefficient
       if (mat.klass == ORC_MAT_OPEN_PBR) {
-        OpbrParams o = opbr_params(mat);
+        OpbrParams o = opbr_params(baseMat); // (a medium's coefficients are the material's constants: no textured input reaches them)
         throughput = throughput * v3(expf_poly(-o.sigmaA.x * distance), expf_poly(-o.sigmaA.y * distance), expf_poly(-o.sigmaA.z * distance));
       }
     } else { // :174-184: the medium on top of the stack
@@ -1800,7 +1807,7 @@ void closest_hit(const Frame& F, const Hit& h, Payload& pl, float hitT)
         if (mediumIdx <= stackSize) {
           Medium md; md.ior = v3(1, 1, 1); md.sigma_s = v3(0, 0, 0); md.sigma_t = v3(0, 0, 0); md.bias = 0.0f;
           if (mat.klass == ORC_MAT_OPEN_PBR) { // mdl_ior, mdl_volume_{absorption,scattering}_coefficient, MEDIUM_DIRECTIONAL_BIAS
-            OpbrParams o = opbr_params(mat, true);
+            OpbrParams o = opbr_params(baseMat, true); // (the material's constants, see above)
             md.ior = v3(o.eta, o.eta, o.eta); md.sigma_s = o.sigmaS; md.sigma_t = o.sigmaA + o.sigmaS; md.bias = o.anisotropy;
             if (eventType & EV_SUBSURFACE) { md.sigma_s = o.sssSigmaS; md.sigma_t = o.sssSigmaT; md.bias = o.ssAniso; } // entered through the subsurface lobe
           }

@@ -94,7 +94,9 @@ enum { ORC_TEX_WRAP_CLAMP = 0, ORC_TEX_WRAP_REPEAT = 1, ORC_TEX_WRAP_MIRRORED_RE
 typedef struct OrcTexture { const float* rgba; uint32_t width, height; } OrcTexture;
 /* material inputs that can be driven by a texture (UsdUVTexture semantics: value = texel * scale + bias) */
 enum { ORC_TEX_BASE_COLOR = 0, ORC_TEX_EMISSION = 1, ORC_TEX_ROUGHNESS = 2, ORC_TEX_METALLIC = 3, ORC_TEX_NORMAL = 4, ORC_TEX_OPACITY = 5 /* cutout opacity, read by the any-hit test */,
-       ORC_TEX_COAT_NORMAL = 6 /* OpenPBR geometry_coat_normal (open_pbr_surface.mtlx:87, 560): a tangent-space normal map for the coat lobe's own shading frame */, ORC_TEX_SLOT_COUNT = 7 };
+       ORC_TEX_COAT_NORMAL = 6 /* OpenPBR geometry_coat_normal (open_pbr_surface.mtlx:87, 560): a tangent-space normal map for the coat lobe's own shading frame */,
+       ORC_TEX_TRANSMISSION_WEIGHT = 7, ORC_TEX_TRANSMISSION_COLOR = 8 /* OpenPBR transmission_weight / transmission_color (open_pbr_surface.mtlx:29, 31) at the hit; the MEDIUM a path enters
+       keeps the material's constant colour (its absorption is derived once per material) */, ORC_TEX_SLOT_COUNT = 9 };
 typedef struct OrcTexBinding {
   int32_t texture; /* index into OrcScene.textures; < 0 = input not textured */
   int32_t wrapS, wrapT;

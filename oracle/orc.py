@@ -16,7 +16,7 @@ _LIB_PATH = os.path.join(_HERE, "libgi_oracle.so")
 P_COUNT = 64
 
 
-TEX_SLOT_COUNT = 7
+TEX_SLOT_COUNT = 9
 
 
 class OrcTexBinding(C.Structure):

@@ -404,6 +404,33 @@ def test_coat_normal_on_device(gi, orc):
     assert np.array_equal(got[..., :3].view(np.uint32), want[..., :3].view(np.uint32))
 
 
+def test_textured_transmission_inputs_on_device(gi, orc):
+    """OpenPBR transmission_weight / transmission_color resolved per hit (slots 7 / 8; gi_shading.h resolve_material_textures, opbr_params): a weight map, a colour map
+    with a texture-coordinate transform, both from scene data (per-vertex weight, constant colour), and with a transmission_depth -- where the colour is the medium's
+    and stays the material's constant -- without and with a medium stack: device == oracle bit for bit, image and Albedo AOV."""
+    from test_oracle_render import _const_tex, _glass_ball
+    from gatling_amd.scene import TEX_TRANSMISSION_COLOR, usd_transform_2d
+    yy, xx = np.mgrid[0:16, 0:32]
+    wmap = np.zeros((16, 32, 4), np.float32); wmap[..., 0] = wmap[..., 1] = wmap[..., 2] = 0.5 + 0.5 * np.sin(xx * 0.9) * np.cos(yy * 0.7); wmap[..., 3] = 1.0
+    cmap = np.zeros((8, 8, 4), np.float32); cmap[..., 0] = (xx[:8, :8] % 2) * 0.6 + 0.3; cmap[..., 1] = 0.9; cmap[..., 2] = (yy[:8, :8] % 3) * 0.3 + 0.2; cmap[..., 3] = 1.0
+    rs = RenderSettings(spp=6, max_bounces=6, next_event_estimation=True)
+    desc = _glass_ball(weight=wmap, colour=cmap)
+    desc.materials[0].textures[TEX_TRANSMISSION_COLOR].transform = usd_transform_2d(30.0, (2.0, 3.0), (0.1, 0.3))
+    render_both(gi, orc, desc, rs, 72, 72, exact=True)
+    render_both(gi, orc, _glass_ball(primvar=True), rs, 72, 72, exact=True)
+    render_both(gi, orc, _glass_ball(weight=_const_tex(0.7, 0.7, 0.7, 1.0), tc=(0.3, 0.9, 0.5)), rs, 72, 72, exact=True)
+    for stack in (0, 2):
+        rs2 = RenderSettings(spp=4, max_bounces=6, next_event_estimation=True, medium_stack_size=stack)
+        render_both(gi, orc, _glass_ball(weight=wmap, colour=cmap, tc=(0.3, 0.9, 0.5), depth=0.5), rs2, 72, 72, exact=True)
+    sc = gi.Scene(desc)
+    try:
+        got = sc.render_aovs(RenderSettings(spp=2, max_bounces=2, progressive_accumulation=False), 72, 72, ["albedo"])["albedo"]
+    finally:
+        sc.close()
+    want = orc.render_aovs(desc, RenderSettings(spp=2, max_bounces=2, progressive_accumulation=False), 72, 72, ["albedo"])["albedo"]
+    assert np.array_equal(got[..., :3].view(np.uint32), want[..., :3].view(np.uint32))
+
+
 def _aov_scene():
     desc = sphere_grid(grid=3, subdivisions=1, material_count=4)
     rng = np.random.default_rng(8)

@@ -791,3 +791,72 @@ def test_coat_normal(orc):
     c0, _ = orc.render(_coated_ball(None, coat_weight=0.0), rs, w, h, threads=8)
     c1, _ = orc.render(_coated_ball(bumpy, coat_weight=0.0), rs, w, h, threads=8)
     assert np.array_equal(c0.view(np.uint32), c1.view(np.uint32))                          # no coat, no effect
+
+
+def _glass_ball(weight=None, colour=None, tw=0.0, tc=(1.0, 1.0, 1.0), depth=0.0, primvar=False):
+    """A uv-mapped ball over a lit back wall; `weight` / `colour`: textures for transmission_weight / transmission_color (None: the constants `tw` / `tc`)."""
+    from gatling_amd.meshprep import bake_vertices
+    from gatling_amd.scene import TEX_TRANSMISSION_COLOR, TEX_TRANSMISSION_WEIGHT, CameraDesc, MeshDesc, Primvar, SceneDesc, TextureBinding
+    from gatling_amd.scenes import icosphere
+    pts, faces = icosphere(3)
+    uv = np.stack([np.arctan2(pts[:, 1], pts[:, 0]) / (2 * np.pi) + 0.5, np.arccos(np.clip(pts[:, 2], -1, 1)) / np.pi], axis=1).astype(np.float32)
+    s = SceneDesc()
+    m = MaterialDesc.open_pbr(base_color=(0.8, 0.2, 0.1), specular_roughness=0.1, transmission_weight=tw, transmission_color=tc, transmission_depth=depth)
+    m.textures = {}
+    if weight is not None:
+        weight, wb = weight if isinstance(weight, tuple) else (weight, (0.0, 0.0, 0.0, 0.0))
+        s.textures.append(weight); m.textures[TEX_TRANSMISSION_WEIGHT] = TextureBinding(texture=len(s.textures) - 1, bias=wb)
+    if colour is not None:
+        colour, cb = colour if isinstance(colour, tuple) else (colour, (0.0, 0.0, 0.0, 0.0))
+        s.textures.append(colour); m.textures[TEX_TRANSMISSION_COLOR] = TextureBinding(texture=len(s.textures) - 1, bias=cb)
+    wall = MaterialDesc.open_pbr(base_color=(0.2, 0.6, 0.9))
+    s.materials = [m, wall]
+    ball = MeshDesc(name="/Ball", vertices=bake_vertices(pts, pts, uv), faces=faces, material=0)
+    if primvar:  # the same inputs from scene data: a per-vertex weight and a constant colour
+        ball.primvars = [Primvar("tw", 0, 3, (pts[:, 2] > 0).astype(np.float32)), Primvar("tcol", 2, 0, np.float32([0.3, 0.9, 0.5]))]
+        m.primvar_inputs = {TEX_TRANSMISSION_WEIGHT: "tw", TEX_TRANSMISSION_COLOR: "tcol"}
+    q = np.float32([[-3, 2.5, -3], [3, 2.5, -3], [3, 2.5, 3], [-3, 2.5, 3]])
+    s.meshes = [ball, MeshDesc(name="/Wall", vertices=bake_vertices(q, np.float32([[0, -1, 0]] * 4)), faces=np.uint32([[0, 1, 2], [0, 2, 3]]), material=1, double_sided=True)]
+    s.rect_lights = [RectLight(origin=(0.0, -2.0, 3.0), t0=(1, 0, 0), t1=(0, 1, 0), base_emission=(30, 30, 30), width=1.0, height=1.0)]
+    s.camera = CameraDesc(position=(0.0, -3.2, 0.0), forward=(0.0, 1.0, 0.0), up=(0.0, 0.0, 1.0), vfov=0.7)
+    return s
+
+
+def _const_tex(*rgba):
+    """(texture, bias) whose lookup is exactly `rgba` everywhere: black texels (a bilinear blend of equal non-zero texels need not return them bit for bit) + the binding's bias"""
+    return np.zeros((2, 2, 4), np.float32), tuple(float(x) for x in rgba)
+
+
+def test_textured_transmission_inputs(orc):
+    """OpenPBR transmission_weight / transmission_color as textured inputs (open_pbr_surface.mtlx:29, 31; VERDICT r03 missing #5).  A texture that holds one value IS
+    that constant, bit for bit (weight and colour, alone and together); a weight map that is 1 on the upper half of a ball and 0 on the lower makes the upper half
+    glass and leaves the lower half the opaque material; with a transmission_depth the colour belongs to the MEDIUM, which keeps the material's constant (a colour
+    texture then changes nothing), while the weight map still selects where the path may enter it."""
+    rs = RenderSettings(spp=8, max_bounces=6, next_event_estimation=True, progressive_accumulation=False)
+    w = h = 36
+    ref, _ = orc.render(_glass_ball(tw=0.7, tc=(0.3, 0.9, 0.5)), rs, w, h, threads=8)
+    a, _ = orc.render(_glass_ball(weight=_const_tex(0.7, 0.7, 0.7, 1.0), tc=(0.3, 0.9, 0.5)), rs, w, h, threads=8)
+    b, _ = orc.render(_glass_ball(colour=_const_tex(0.3, 0.9, 0.5, 1.0), tw=0.7), rs, w, h, threads=8)
+    c, _ = orc.render(_glass_ball(weight=_const_tex(0.7, 0.7, 0.7, 1.0), colour=_const_tex(0.3, 0.9, 0.5, 1.0), tw=0.1, tc=(1, 0, 0)), rs, w, h, threads=8)
+    for img in (a, b, c):
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+    # half glass / half opaque
+    half = np.zeros((8, 4, 4), np.float32); half[:4] = 1.0      # v < 0.5 (the upper hemisphere, v = acos(z) / pi) transmits
+    opaque, _ = orc.render(_glass_ball(tw=0.0), rs, w, h, threads=8)
+    glass, _ = orc.render(_glass_ball(tw=1.0), rs, w, h, threads=8)
+    mixed, _ = orc.render(_glass_ball(weight=half), rs, w, h, threads=8)
+    top, bottom = slice(h // 2 - 9, h // 2 - 3), slice(h // 2 + 3, h // 2 + 9)
+    cols = slice(w // 2 - 4, w // 2 + 4)
+    d = lambda x, y, rows: float(np.abs(x[rows, cols] - y[rows, cols]).mean())
+    span = min(d(glass, opaque, top), d(glass, opaque, bottom))
+    glass_rows, opaque_rows = (top, bottom) if d(mixed, glass, top) < d(mixed, opaque, top) else (bottom, top)   # (whichever way the image's rows run)
+    assert d(mixed, opaque, opaque_rows) < 0.25 * span and d(mixed, glass, glass_rows) < 0.5 * span, (d(mixed, opaque, opaque_rows), d(mixed, glass, glass_rows), span)
+    # scene data drives the same inputs
+    pv, _ = orc.render(_glass_ball(primvar=True), rs, w, h, threads=8)
+    assert np.isfinite(pv).all() and d(pv, opaque, glass_rows) > 0.25 * span and d(pv, opaque, opaque_rows) < 0.25 * span   # per-vertex weight: z > 0 transmits
+    # with a depth the colour is the medium's: constant per material (medium stack on and off)
+    for stack in (0, 2):
+        rs2 = RenderSettings(spp=4, max_bounces=6, next_event_estimation=True, progressive_accumulation=False, medium_stack_size=stack)
+        d0, _ = orc.render(_glass_ball(tw=1.0, tc=(0.3, 0.9, 0.5), depth=0.5), rs2, w, h, threads=8)
+        d1, _ = orc.render(_glass_ball(tw=1.0, tc=(0.3, 0.9, 0.5), depth=0.5, colour=_const_tex(0.9, 0.1, 0.1, 1.0)), rs2, w, h, threads=8)
+        assert np.array_equal(d0.view(np.uint32), d1.view(np.uint32)), stack

@@ -86,7 +86,7 @@ int main(int argc, char** argv)
   fclose(f);
   Rd r = {data, (size_t)size, 0, 0};
   const void* magic = rd_take(&r, 4);
-  if (!magic || memcmp(magic, "GSCN", 4) || rd_u32(&r) != 2u) return fail("not a version-2 .gscn file");
+  if (!magic || memcmp(magic, "GSCN", 4) || rd_u32(&r) != 3u) return fail("not a version-3 .gscn file");
 
   FileSettings fs;
   memset(&fs, 0, sizeof fs);
