@@ -52,8 +52,10 @@ int main()
                          "</open_pbr_surface></materialx>";
   GiMaterial* floorMat = giCreateMaterialFromMtlxStr(scene, "floor", floorMtlx);
   GiMaterial* lampMat = giCreateMaterialFromMtlxStr(scene, "lamp", lampMtlx);
-  GiMaterial* unsupported = giCreateMaterialFromMtlxStr(scene, "x", "<materialx><standard_surface name=\"s\"/></materialx>");
-  if (!floorMat || !lampMat || unsupported) { fprintf(stderr, "material creation mismatch\n"); return 3; }
+  GiMaterial* unsupported = giCreateMaterialFromMtlxStr(scene, "x", "<materialx><disney_principled name=\"s\"/></materialx>"); // no closed form: hdGatling's fallback material takes over
+  GiMaterial* translated = giCreateMaterialFromMtlxStr(scene, "y", "<materialx><standard_surface name=\"s\"/></materialx>");  // read onto the OpenPBR closed forms
+  if (!floorMat || !lampMat || unsupported || !translated) { fprintf(stderr, "material creation mismatch\n"); return 3; }
+  giDestroyMaterial(translated);
   const float green[3] = {0.1f, 0.8f, 0.1f};
   GiMesh* a = quad(scene, 0.0f, 2.0f, floorMat, 1, green);
   GiMesh* b = quad(scene, 1.5f, 0.4f, lampMat, 2);

@@ -47,7 +47,7 @@ static int traceSorted(const Bvh8& B, const Ray& r, float& tBest, RayStats& c, b
   c.rays++;
   while (sp > 0) {
     Item it = stack[--sp];
-    if (it.tn > tBest) continue;
+    static const bool noCull = getenv("BVHQ_SORTED_NOCULL") != nullptr; if (!noCull && it.tn > tBest) continue;
     const Node8& n = B.nodes[it.node]; c.nodes++;
     float s[3] = {expScale(n.e[0]), expScale(n.e[1]), expScale(n.e[2])};
     Item kids[8]; int nk = 0;
