@@ -328,6 +328,24 @@ def test_camera_rays_that_cannot_reach_the_scene_retire_in_raygen(gi, orc, monke
             assert_image_parity(again, ref, exact=True)
         if name in ("away", "clipped"):
             assert cnt["segments"] == w * h * rs.spp  # every path is its camera ray
+    # several batches per frame (sample buffer capped at 1 MiB: four of them) over a 4 099-slot pool, on the instanced spheres under a constant background (C4's shape:
+    # most camera rays pass beside the grid) and progressive accumulation over two frames
+    desc = sphere_grid(grid=6, subdivisions=2, material_count=5)
+    rs = RenderSettings(spp=24, max_bounces=5)
+    w, h = 128, 72
+    ref1, cnt = orc.render(desc, rs, w, h, threads=4)
+    monkeypatch.setenv("GATLING_BOUNDS_RETIRE", "1")
+    sc = gi.Scene(desc)
+    try:
+        sc.set_option(gi.OPTION_SAMPLE_BUFFER_MB, 1)
+        sc.set_option(gi.OPTION_POOL_SLOTS, 4099)
+        sc.set_option(gi.OPTION_FUSED_PATH, 0)
+        img = sc.render(rs, w, h)
+        st = sc.stats()
+    finally:
+        sc.close()
+    assert st["fusedPath"] == 0 and st["batches"] >= 3 and st["segments"] == cnt["segments"], st
+    assert_image_parity(img, ref1, exact=True)
 
 
 def test_texture_coordinate_transforms_on_device(gi, orc):
