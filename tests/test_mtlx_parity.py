@@ -365,3 +365,31 @@ def test_usd_transform_2d_document_renders_the_bound_texture_image(gi):
         a.close(); b.close()
     assert np.array_equal(ia.view(np.uint32), ref.view(np.uint32)), "texture binding with a transform: image differs from the oracle"
     assert np.array_equal(ib.view(np.uint32), ref.view(np.uint32)), "UsdTransform2d document: image differs from the oracle"
+
+
+def test_reader_survives_mangled_documents():
+    """hdGatling hands the reader whatever a material network serialises to; a malformed document must come back as "no material" (or a partly read one), never as a
+    crash of the host application: 6 000 truncations, byte flips, deletions and splices of the documents above through both doors (seeded)."""
+    import random
+    L = capi.load_library()
+    L.gtlMtlxImageBindingC.restype = C.c_int
+    L.gtlMtlxImageBindingC.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    docs = [MTLX_NATIVE_DOC % dict(file=_PNG), UV_TEX_DOC % dict(rot=33.0, sx=1.8, sy=0.6, tx=0.25, ty=-0.4, file=_PNG)]
+    for m in _edge_cases():
+        docs += [material_to_mtlx(m, "direct"), material_to_mtlx(m, "nodegraph")]
+    rng = random.Random(20260926)
+    sc, bi, fl = (C.c_float * 4)(), (C.c_float * 4)(), (C.c_int * 2)()
+    for _ in range(6000):
+        b = bytearray(rng.choice(docs).encode())
+        k = rng.randrange(4)
+        if k == 0:
+            b = b[:rng.randrange(len(b))]
+        elif k == 1:
+            for _ in range(rng.randrange(1, 6)):
+                b[rng.randrange(len(b))] = rng.choice(b'<>"=/ ax1')
+        elif k == 2:
+            i = rng.randrange(len(b)); del b[i:i + rng.randrange(40)]
+        else:
+            i, j = rng.randrange(len(b)), rng.randrange(len(b)); b[i:i] = b[j:j + rng.randrange(60)]
+        _desc_from_doc(L, bytes(b).decode("latin-1"))
+        L.gtlMtlxImageBindingC(bytes(b), rng.randrange(S.TEX_SLOT_COUNT), sc, bi, fl)
