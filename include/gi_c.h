@@ -270,7 +270,7 @@ int giCSetMaterialTextureTransform(GiCMaterial* material, int32_t input, const f
 typedef struct GiCPrimvarData { const char* name; int32_t type; int32_t interpolation; const void* data; uint64_t dataSize; } GiCPrimvarData;
 int giCSetMeshPrimvars(GiCMesh* mesh, uint32_t count, const GiCPrimvarData* primvars);          /* GiMeshDesc.primvars (Gi.h:134) */
 int giCSetMeshInstancerPrimvars(GiCMesh* mesh, uint32_t count, const GiCPrimvarData* primvars); /* Gi.h:213 */
-int giCSetMaterialPrimvarInput(GiCMaterial* material, int32_t input, const char* primvarName);  /* [ext] NULL or "" removes it */
+int giCSetMaterialPrimvarInput(GiCMaterial* material, int32_t input, const char* primvarName);  /* [ext] NULL or "" removes it; inputs: base colour, emission, roughness, metalness, transmission weight / colour (not the normal, opacity and coat-normal slots: texture only) */
 
 /* [ext] per-frame statistics of the last giCRender on a scene (measurement) */
 typedef struct GiCRenderStats {
