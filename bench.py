@@ -19,8 +19,8 @@ separate `--pmc` passes of this same workload, calibrated with tools/pmc_calib.h
 `algorithmic_frac` is the SURVEY 8d canonical-bytes figure (it counts node / triangle bytes whether they come from HBM, L2 or LDS, so it can exceed 1).  The VALU
 side is reported in wall-clock terms against ceilings MEASURED by tools/valu_calib.hip (profiles/valu_issue_calibration.json): `valu_instr_per_simd_per_ns`,
 `valu_frac` = that / the dual-issue ceiling (alternating instruction classes, ~1.04), `valu_frac_fp32_only` = that / the single-class ceiling (~0.59).  `bound` names
-the nearer of the two rooflines; `bound_note` says when neither is near (the big-scene traversal is bound by the L1 -> L2 request path, tools/ta_calib.hip,
-DESIGN.md section 4).
+the nearer of the two rooflines; `bound_note` says what was measured beyond that (the big-scene traversal follows its instruction count one to one,
+profiles/r04k_valu_sensitivity.txt, with no instruction class near its own ceiling, profiles/r04r_valu_mix.txt: DESIGN.md section 4).
 
 At N = 1 the default line carries, under `also`, compact objects for configs C3 and C4 -- the wavefront pipeline (k_raygen / k_trace_dyn / k_route / k_shade /
 k_trace_dyn<any>) -- and for `c5share`, one rank's share of C5's 8-GPU partition at full spp (`projected_8gpu` = 8 x its rate), each with its own roofline fractions;
@@ -410,9 +410,10 @@ def main():
                             roofline["bound"] = "valu" if roofline["valu_frac"] > roofline["frac"] else "hbm"
                             if scattered:
                                 # measured, not inferred: N instructions added to the node test slow k_trace_dyn by N / (instructions per step) -- slope one
-                                # (profiles/r04k_valu_sensitivity.txt): the kernel sits on the single-class VALU issue ceiling, which is what valu_frac_fp32_only divides by
+                                # (profiles/r04k_valu_sensitivity.txt).  Its mix (tools/valu_mix.py, profiles/r04r_valu_mix.txt): 16 % fp32 arithmetic, 33 % integer + conversions,
+                                # half moves / selects / compares / packed fma -- no class near its own ceiling: the rate is what 5 waves' dependent chains deliver
                                 roofline["bound"] = "valu"
-                                roofline["bound_note"] = "VALU issue (single-class ceiling, see valu_frac_fp32_only): +64 instructions per node test = +11 %, profiles/r04k_valu_sensitivity.txt"
+                                roofline["bound_note"] = "VALU issue along the waves' dependent chains: +64 instructions per node test = +11 % (slope one, profiles/r04k_valu_sensitivity.txt); no instruction class near its own ceiling (profiles/r04r_valu_mix.txt)"
                             elif max(roofline["valu_frac"], roofline["frac"]) < 0.6:
                                 roofline["bound_note"] = "neither roofline is near: latency / vector-memory request rate bound (DESIGN.md section 4)"
                         # raw counters and the per-kernel table go to a FILE (the driver keeps only the last 8 KB of output: r03's line lost C3's value to them)
