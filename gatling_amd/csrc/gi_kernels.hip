@@ -581,6 +581,9 @@ __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, Que
 // k_shade: closest-hit shading + the post-trace part of the bounce loop, over the HIT queue only
 // (rp_main.chit:132-493, rp_main.rgen:397-480).  Misses never get here (k_trace routes them to k_raygen).
 // ------------------------------------------------------------------------------------------------
+#ifndef GI_SHADE_NEE_FORCE
+#define GI_SHADE_NEE_FORCE 1 // (experiments: minimum waves per SIMD asked of the OpenPBR + NEE variant; 1 = what its 164 VGPRs allow, i.e. 3)
+#endif
 #ifndef GI_SHADE_NEE_WAVES
 #define GI_SHADE_NEE_WAVES 4
 #endif
@@ -588,7 +591,7 @@ __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, Que
 template <uint32_t KLASS, bool TEXTURED, bool VOLUME, bool NEE, bool PACKED>
 // (forcing the plain variant to 5 waves/SIMD -- amdgpu_waves_per_eu((...) ? 5 : 1, 8): 90 VGPRs, no spills -- is SLOWER: C2 shade 178 -> 190 ms;
 // the stage is bound by the memory pipeline's scattered 16-byte requests, not by latency hiding)
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((KLASS == 2u && !TEXTURED && !VOLUME) ? (NEE ? 1 : GI_SHADE_NEE_WAVES) : 1, 8))) void k_shade(FrameUniforms U, SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t par)
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((KLASS == 2u && !TEXTURED && !VOLUME) ? (NEE ? GI_SHADE_NEE_FORCE : GI_SHADE_NEE_WAVES) : 1, 8))) void k_shade(FrameUniforms U, SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t par)
 {
   __shared__ AppendScratch<3> sh;
   const uint32_t qNext = Q_TRACE_A + (par ^ 1u), qRegen = Q_REGEN_A + (par ^ 1u), qHit = Q_HIT + KLASS;
