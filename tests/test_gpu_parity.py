@@ -329,7 +329,7 @@ def test_camera_rays_that_cannot_reach_the_scene_retire_in_raygen(gi, orc, monke
         if name in ("away", "clipped"):
             assert cnt["segments"] == w * h * rs.spp  # every path is its camera ray
     # several batches per frame (sample buffer capped at 1 MiB: four of them) over a 4 099-slot pool, on the instanced spheres under a constant background (C4's shape:
-    # most camera rays pass beside the grid) and progressive accumulation over two frames
+    # most camera rays pass beside the grid)
     desc = sphere_grid(grid=6, subdivisions=2, material_count=5)
     rs = RenderSettings(spp=24, max_bounces=5)
     w, h = 128, 72
