@@ -346,6 +346,24 @@ def test_camera_rays_that_cannot_reach_the_scene_retire_in_raygen(gi, orc, monke
         sc.close()
     assert st["fusedPath"] == 0 and st["batches"] >= 3 and st["segments"] == cnt["segments"], st
     assert_image_parity(img, ref1, exact=True)
+    # retired samples go through the same running sum and progressive blend as any other: a second progressive frame, the sample-major work order, and rank 1's
+    # interleaved rows of a three-way split
+    ref2, _ = orc.render(desc, rs, w, h, sample_offset=rs.spp, prev_color=ref1, threads=4)
+    for order in ("1", "0"):
+        monkeypatch.setenv("GATLING_WORK_ORDER", order)
+        sc = gi.Scene(desc)
+        try:
+            sc.set_option(gi.OPTION_FUSED_PATH, 0)
+            a = sc.render(rs, w, h).copy()
+            b = sc.render(rs, w, h).copy()
+            rs1 = RenderSettings(spp=24, max_bounces=5, progressive_accumulation=False)
+            share = sc.render(rs1, w, h, rows=(1, h), row_stride=3).copy()
+        finally:
+            sc.close()
+        assert_image_parity(a, ref1, exact=True)
+        assert_image_parity(b, ref2, exact=True)
+        assert np.array_equal(share.view(np.uint32), ref1[1::3].view(np.uint32)), order
+    monkeypatch.delenv("GATLING_WORK_ORDER")
 
 
 def test_texture_coordinate_transforms_on_device(gi, orc):
