@@ -333,7 +333,7 @@ struct SceneDevice {
   uint32_t slot = 0; // index into g_ctx.devs
   DeviceBuffer<MeshRec> dMeshes; DeviceBuffer<float> dSceneData;
   std::vector<DeviceBuffer<float>*> dTexels; DeviceBuffer<TextureRec> dTextures; // device copies (rebuilt with the materials)
-  DeviceBuffer<Node8> dNodes; DeviceBuffer<uint4> dNodesLine; DeviceBuffer<TriRec> dTris; DeviceBuffer<InstanceRec> dInstances;
+  DeviceBuffer<Node8> dNodes; DeviceBuffer<TriRec> dTris; DeviceBuffer<InstanceRec> dInstances;
   DeviceBuffer<FVertex> dVerts; DeviceBuffer<MaterialRec> dMaterials; DeviceBuffer<int32_t> dTriFaceId; DeviceBuffer<TriShade> dTriShade;
   DeviceBuffer<SphereLightRec> dSphere; DeviceBuffer<DistantLightRec> dDistant; DeviceBuffer<RectLightRec> dRect; DeviceBuffer<DiskLightRec> dDisk;
   DeviceBuffer<Node8> dTlasNodes, dBlasNodes; DeviceBuffer<uint32_t> dTlasItems, dFlatOfOrig; DeviceBuffer<BlasTri> dBlasTris; DeviceBuffer<InstTrav> dInstTrav;
@@ -366,7 +366,7 @@ struct MeshBuild { const GiCMesh* m; uint32_t vertexOffset, matFlags, instFirst,
 struct InstPart { uint32_t meshBuild, instInMesh; uint32_t triFirst, nf; uint32_t nodeOff, nodeCount, nodeCap, depth; float box[6]; };
 struct SceneHost {
   std::vector<FVertex> verts; std::vector<InstanceRec> instances; std::vector<MaterialRec> mats; std::vector<MeshRec> meshRecs; std::vector<float> sceneData;
-  Bvh8 bvh; std::vector<int32_t> triFaceId; std::vector<uint32_t> flatOfOrig; TwoLevelHost two; bool lineNodes = false;
+  Bvh8 bvh; std::vector<int32_t> triFaceId; std::vector<uint32_t> flatOfOrig; TwoLevelHost two;
   std::vector<MeshBuild> meshBuilds;
   std::vector<TriShade> triShade; bool shadePacked = false; // one-line shading records per mesh triangle (scenes beyond LDS): TriRec::vi[0] indexes them
   bool partitioned = false; std::vector<InstPart> parts; uint32_t topCap = 0; // partitioned layout: nodes [0, topCap) = top tree, then the parts' ranges
@@ -391,7 +391,6 @@ struct GiCScene : SceneDevice {
   GiCDomeLight* oldDome = nullptr;
   float oldDomeEmission[3] = {0, 0, 0};
   // the scene as built (the same on every device)
-  uint32_t nodeStrideU4 = 5;
   uint32_t nodeCount = 0, triCount = 0, bvhDepth = 0;
   float bounds[6] = {0, 0, 0, 0, 0, 0}; bool boundsValid = false; // the flat tree's root bounds (nodeBounds + a relative pad), for FLAG_BOUNDS_RETIRE
   bool twoLevel = false; int optTwoLevel = -1; // 1: build and use the two-level layout (scenes beyond LDS); otherwise the flat one
@@ -413,7 +412,7 @@ struct GiCScene : SceneDevice {
 
 void SceneDevice::releaseAll()
 {
-  dNodes.release(); dNodesLine.release(); dTris.release(); dInstances.release(); dVerts.release(); dTriFaceId.release(); dTriShade.release();
+  dNodes.release(); dTris.release(); dInstances.release(); dVerts.release(); dTriFaceId.release(); dTriShade.release();
   dTlasNodes.release(); dBlasNodes.release(); dTlasItems.release(); dFlatOfOrig.release(); dBlasTris.release(); dInstTrav.release();
   for (auto* b : dTexels) { b->release(); delete b; }
   dTexels.clear(); dTextures.release(); dMeshes.release(); dSceneData.release();
@@ -1125,13 +1124,7 @@ int uploadSceneTo(GiCScene* s, SceneDevice& D, const SceneHost& H)
     if (D.dTextures.upload(recs, st)) return GI_C_ERROR;
     HIP_TRY(hipStreamSynchronize(st)); // `recs` goes out of scope
   }
-  std::vector<uint4> lined;
-  if (H.lineNodes) {
-    lined.assign(H.bvh.nodes.size() * 8, uint4{0u, 0u, 0u, 0u});
-    for (size_t i = 0; i < H.bvh.nodes.size(); i++) memcpy(&lined[i * 8], &H.bvh.nodes[i], sizeof(Node8));
-    if (D.dNodesLine.upload(lined, st)) return GI_C_ERROR;
-  }
-  if ((!H.lineNodes && D.dNodes.upload(H.bvh.nodes, st)) || D.dTris.upload(H.bvh.tris, st) || D.dInstances.upload(H.instances, st) ||
+  if (D.dNodes.upload(H.bvh.nodes, st) || D.dTris.upload(H.bvh.tris, st) || D.dInstances.upload(H.instances, st) ||
       D.dVerts.upload(H.verts, st) || D.dMaterials.upload(H.mats, st))
     return GI_C_ERROR;
   HIP_TRY(hipStreamSynchronize(st)); // host vectors may go out of scope
@@ -1319,11 +1312,6 @@ int buildScene(GiCScene* s)
     for (TriRec& t : bvh.tris) t.vi[0] = shadeBaseOfMesh[instances[t.instance].mesh] + t.prim;
   }
   s->shadePacked = H.shadePacked;
-  // Optional layout: one node per 128-byte line (an 80-byte node at an 80-byte stride straddles two lines half of the time).
-  // Measured on C3/C4 it is 1-3 % SLOWER than the packed layout (the footprint grows 1.6x and the L2 hit rate drops), so it
-  // stays an experiment knob (GATLING_NODE_LINES=1).
-  if (const char* e = getenv("GATLING_NODE_LINES")) H.lineNodes = atoi(e) != 0;
-  s->nodeStrideU4 = H.lineNodes ? 8u : 5u;
   // one copy of the scene per device this scene renders on
   const uint32_t nDev = sceneDeviceCount(s);
   while (s->replicas.size() + 1u < nDev) { s->replicas.emplace_back(new SceneDevice()); s->replicas.back()->slot = (uint32_t)s->replicas.size(); s->dirty |= DIRTY_LIGHTS; } // a new replica has no lights yet
@@ -1438,7 +1426,7 @@ int rebuildTop(GiCScene* s, SceneHost& H)
 int updateTransforms(GiCScene* s, bool& handled)
 {
   handled = false;
-  if (!s->host || s->twoLevel || s->host->lineNodes || s->triCount < 4096u) return GI_C_OK; // small scenes rebuild in no time (and must stay LDS-resident)
+  if (!s->host || s->twoLevel || s->triCount < 4096u) return GI_C_OK; // small scenes rebuild in no time (and must stay LDS-resident)
   if (const char* e = getenv("GATLING_INCREMENTAL")) { if (!atoi(e)) return GI_C_OK; }
   SceneHost& H = *s->host;
   for (const MeshBuild& mb : H.meshBuilds) if (mb.m->builtInstances != mb.instCount) return GI_C_OK; // (cannot happen: count changes raise DIRTY_BVH)
@@ -1548,7 +1536,7 @@ SceneView makeView(GiCScene* s, SceneDevice& D)
 {
   SceneView v{};
   v.textures = D.dTextures.ptr; v.meshes = D.dMeshes.ptr; v.sceneData = D.dSceneData.ptr;
-  v.nodes = s->nodeStrideU4 == 8u ? reinterpret_cast<const Node8*>(D.dNodesLine.ptr) : D.dNodes.ptr; v.nodeStrideU4 = s->nodeStrideU4; v.tris = D.dTris.ptr; v.instances = D.dInstances.ptr;
+  v.nodes = D.dNodes.ptr; v.tris = D.dTris.ptr; v.instances = D.dInstances.ptr;
   v.verts = D.dVerts.ptr; v.triShade = D.dTriShade.ptr; v.shadePacked = s->shadePacked ? 1u : 0u; v.materials = D.dMaterials.ptr; v.sphereLights = D.dSphere.ptr; v.distantLights = D.dDistant.ptr;
   v.tlasNodes = D.dTlasNodes.ptr; v.tlasItems = D.dTlasItems.ptr; v.blasNodes = D.dBlasNodes.ptr; v.blasTris = D.dBlasTris.ptr; v.instTrav = D.dInstTrav.ptr; v.flatOfOrig = D.dFlatOfOrig.ptr; v.twoLevel = s->twoLevel ? 1u : 0u;
   v.rectLights = D.dRect.ptr; v.diskLights = D.dDisk.ptr; v.triFaceId = D.dTriFaceId.ptr; v.nodeCount = s->nodeCount; v.triCount = s->triCount; v.bvhDepth = s->bvhDepth; v.hasCutouts = s->hasCutouts ? 1u : 0u;
@@ -1562,7 +1550,6 @@ static uint32_t traceDynRefill(const GiCScene* s)
   uint32_t r = s->optTraceDyn >= 0 ? (uint32_t)s->optTraceDyn : 8u;
   if (const char* e = getenv("GATLING_TRACE_DYN")) r = (uint32_t)std::max(0, std::min(64, atoi(e)));
   if (const char* e = getenv("GATLING_TRACE_DYN_SPILL8")) { if (r && atoi(e)) r |= TRACE_DYN_SPILL8; }
-  if (const char* e = getenv("GATLING_DYN_CLAIM")) { if (r) r |= (uint32_t)std::max(1, std::min(1024, atoi(e) / 64)) << 16; } // rays per cursor atomic (experiments)
   return r;
 }
 

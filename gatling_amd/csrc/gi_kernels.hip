@@ -250,7 +250,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
   const uint32_t n = rd.pre[NSHARD];
   if (blockIdx.x == 0 && threadIdx.x == 0) { if (ANYHIT) cnt->shadowRays += n; else cnt->segments += n; } // single writer per launch
   if (blockIdx.x * TRACE_BLOCK >= n) return; // whole block idle (uniform)
-  for (uint32_t i = threadIdx.x; i < ldsNodes * 5u; i += TRACE_BLOCK) s_nodes[i] = reinterpret_cast<const uint4*>(sc.nodes)[(i / 5u) * sc.nodeStrideU4 + (i % 5u)];
+  for (uint32_t i = threadIdx.x; i < ldsNodes * 5u; i += TRACE_BLOCK) s_nodes[i] = reinterpret_cast<const uint4*>(sc.nodes)[i];
   for (uint32_t i = threadIdx.x; i < ldsTris * 3u; i += TRACE_BLOCK) s_tris[i] = reinterpret_cast<const uint4*>(sc.tris)[(i / 3u) * 4u + (i % 3u)];
   __syncthreads();
 
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
       alive = true;
     }
     while (__ballot(alive)) {
-      if (wave_step<ANYHIT, COUNT, STACK, OVERFLOW, ALL_LDS, CUTOUT, false>(R, alive, W, nullptr, sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, overflow, tc, rng)) alive = false;
+      if (wave_step<ANYHIT, COUNT, STACK, OVERFLOW, ALL_LDS, CUTOUT>(R, alive, W, sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, overflow, tc, rng)) alive = false;
     }
     if (i < n) {
       wave_ray_end(W, R);
@@ -338,144 +338,99 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
 // k_trace_dyn: traversal for scenes that do not fit LDS.  Ray cost has a long tail there (a ray through dense geometry
 // visits several times the average node count), so "one ray per lane until the whole block is done" leaves most lanes
 // idle.  Here every wave is persistent and independent: lanes that finish write their result IN PLACE over the ray
-// record (a = (t,u,v,tri), b.w = material word) and, once `refill` lanes of the wave are idle, the wave claims that many
-// new rays with one atomic on the launch's cursor.  No barriers, no appends; k_route then streams the results into the
-// per-class shade queues / the regen queue.  Per-ray arithmetic is trav_step's, i.e. identical to k_trace's.
+// record (a = (t, u, v, triangle | class << 28) or (tMax, origin.xy, MISS)) and, once `refill` lanes of the wave are idle, the wave hands
+// them new rays.  No barriers, no appends; k_route then streams the results into the per-class shade queues / the regen queue.
+// Per-ray arithmetic is trav_step's, i.e. identical to k_trace's.
+//
+// The kernel is bound by instruction issue along each wave's dependent chain (its time follows the instruction count of a
+// step one to one), so the loop is written for few instructions per step:
+//   * a lane keeps only what the walk needs (RayWalk); the nearest hit lives in the wave's LDS record, where the winning lane of a triangle batch
+//     leaves the FINISHED 16-byte result -- ending a ray is one ds_read_b128 + one global store (the record is pre-set to the miss result when
+//     the ray begins);
+//   * the launch's rays are the queue's NSHARD shards, and shard k IS cursor range k: a claimed ray's record index is `shard * cap + position`,
+//     no search through the shard prefix sums;
+//   * everything wave-uniform (claims, chunk and ring bookkeeping) is forced into SGPRs with readfirstlane;
+//   * GI_DYN_NODES node visits per trip of the outer loop (refill test, ring flush test, result write and the loop-carried moves are paid once);
+//   * shadow walks (ANYHIT) end at their first hit, so near-to-far order buys them nothing: no octant flip in their node test.
 // ------------------------------------------------------------------------------------------------
-#ifndef GI_DYN_CLAIM
-#define GI_DYN_CLAIM 128
+constexpr uint32_t DYN_CLAIM = 128;   // rays per cursor atomic (a device-scope atomic on one line completes ~88 times per microsecond; 64 / 256 / 512 measured: r04x)
+constexpr uint32_t DYN_FLUSH_AT = 8;  // the triangle ring is flushed below 64 pairs once this many finished walks wait for it (0 / 2 / 24 measured: r04c)
+#ifndef GI_DYN_NODES
+#define GI_DYN_NODES 2
 #endif
-constexpr uint32_t DYN_CLAIM = GI_DYN_CLAIM; // rays per cursor atomic (multiple of 64)
-constexpr uint32_t DYN_FLAG_XCD_RANGES = 1u, DYN_FLAG_PEEK = 2u; // PEEK: look at a cursor before claiming from it once one range was found dry (GATLING_DYN_PEEK, default off)
-constexpr uint32_t DYN_FLAG_FLUSH_SHIFT = 8u; // bits 8-15: wave_step_carry's flushAt (0 = flush the triangle ring at the end of every step)
-constexpr uint32_t DYN_FLUSH_AT_DEFAULT = 8u;
-constexpr uint32_t DYN_LDS_NODES_DEFAULT = 0u;   // (GATLING_DYN_LDS_NODES)
-constexpr bool DYN_XCD_RANGES_DEFAULT = false;   // (GATLING_DYN_XCD)
-#ifndef GI_DYN_LDS_NODES
-#define GI_DYN_LDS_NODES 0
-#endif
-#ifndef GI_DYN_DEFER_FINISH
-#define GI_DYN_DEFER_FINISH 0 // measured r04c (profiles/r04c_variants.txt): trace stage C3 48.9 vs 48.4 ms, C4 21.1 vs 20.9, C5 134.7 vs 135.1 -- nothing either way; off
-#endif
-constexpr bool DYN_DEFER_FINISH = GI_DYN_DEFER_FINISH != 0;
+constexpr uint32_t DYN_NODES = GI_DYN_NODES;
 #ifndef GI_DYN_WAVES
 #define GI_DYN_WAVES 5
 #endif
-template <bool TWO> struct DynRay { using type = RayTrav; };
+
+template <bool TWO> struct DynRay { using type = RayWalk; };
 template <> struct DynRay<true> { using type = RayTrav2; };
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); } // wave-uniform by construction: keep it in an SGPR
+
 template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool CUTOUT, bool TWO = false>
-__device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t refill, uint32_t ldsNodes, uint32_t flags)
+__device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t refill)
 {
   extern __shared__ uint4 s_dyn[];
   uint2 (*s_stack)[TRACE_BLOCK] = reinterpret_cast<uint2 (*)[TRACE_BLOCK]>(s_dyn);
-  // The top of the tree (breadth-first prefix: root + its children + ...) is visited by every ray; staged in LDS once per block, those
-  // visits cost an LDS read instead of an L2 round trip.  The one barrier of the kernel: afterwards the waves are independent.
-  uint4* s_nodes = s_dyn + (STACK * TRACE_BLOCK * sizeof(uint2)) / sizeof(uint4);
-#if !GI_DYN_LDS_NODES
-  ldsNodes = 0u; // measured useless (9 / 73 / 585 staged nodes: no gain); compiled out so the node fetch has ONE path (global loads)
-#endif
-  if (!TWO && ldsNodes) {
-    for (uint32_t i = threadIdx.x; i < ldsNodes * 5u; i += TRACE_BLOCK) s_nodes[i] = reinterpret_cast<const uint4*>(sc.nodes)[(i / 5u) * sc.nodeStrideU4 + (i % 5u)];
-    __syncthreads();
-  }
-  typedef typename std::conditional<TWO || TRACE_DYN_COOP_FETCH, WaveTri, WaveTriDyn>::type WT;
-  __shared__ WT s_wave[TRACE_BLOCK / 64];
-  __shared__ WaveStage s_stage[TRACE_DYN_COOP_FETCH ? TRACE_BLOCK / 64 : 1];
-  WT& W = s_wave[threadIdx.x >> 6];
-  WaveStage* S = TRACE_DYN_COOP_FETCH ? &s_stage[threadIdx.x >> 6] : nullptr;
-  QueueReader rd; reader_init(rd, cnt, qIn, qs.cap);
-  const uint32_t n = rd.pre[NSHARD];
-  if (blockIdx.x == 0 && threadIdx.x == 0) { if (ANYHIT) cnt->shadowRays += n; else cnt->segments += n; } // single writer per launch
-  PaddedCounter* cursors = cnt->cursor[ANYHIT ? 1 : 0];
+  __shared__ WaveTri s_wave[TRACE_BLOCK / 64];
+  WaveTri& W = s_wave[threadIdx.x >> 6];
   const uint32_t lane = __lane_id();
+  // rays of shard k (lane k keeps the count; read back with readlane where a range is entered)
+  const uint32_t cap = qs.cap;
+  uint32_t shardCount = 0u;
+  if (lane < NSHARD) { const uint32_t c = cnt->count[qIn][lane].v; shardCount = c < cap ? c : cap; } // (clamped: see Counters::overflow)
+  if (blockIdx.x == 0 && threadIdx.x < 64u) { // single writer per launch
+    uint32_t n = shardCount;
+    for (int off = 4; off > 0; off >>= 1) n += __shfl_down(n, off);
+    if (threadIdx.x == 0) { if (ANYHIT) cnt->shadowRays += n; else cnt->segments += n; }
+  }
+  PaddedCounter* cursors = cnt->cursor[ANYHIT ? 1 : 0];
   TraceCounters tc{0u, 0u};
   typename DynRay<TWO>::type R;
-  auto ray_init = [&](V3 o, V3 d, float tMin, float tMax) { if constexpr (TWO) trav2_init(R, o, d, tMin, tMax); else trav_init(R, o, d, tMin, tMax); };
+  auto ray_init = [&](V3 o, V3 d, float tMin, float tMax) { if constexpr (TWO) trav2_init(R, o, d, tMin, tMax); else walk_init(R, o, d, tMin, tMax); };
   ray_init(v3(0.0f, 0.0f, 0.0f), v3(0.0f, 0.0f, 1.0f), 0.0f, 0.0f);
   uint2 overflow[OVERFLOW ? OVF_STACK : 1];
-  bool alive = false;
-  uint32_t rec = 0u, rng = 0u;
-  bool draining = false; uint32_t lastEnd = 0u, ringHead = 0u, ringTail = 0u; // wave_step_carry: the triangle ring persists across steps
-  const uint32_t flushAt = (flags >> DYN_FLAG_FLUSH_SHIFT) & 0xffu;
-  // The wave claims rays 64 at a time (one atomic per chunk) and lane j prefetches ray j of the chunk into registers; lanes
-  // that run idle are then handed the chunk's rays in order with register shuffles, so a refill never waits on memory.
+  bool alive = false, draining = false;
+  uint32_t rec = 0u, rng = 0u, lastEnd = 0u;
+  uint32_t ringHead = 0u, ringTail = 0u; // wave-uniform: the triangle ring persists across steps
+  refill = uni(refill & 0xffu);
+  // The wave claims rays DYN_CLAIM at a time from the cursor of a shard and takes them 64 at a time: lane j prefetches ray j of the chunk into registers; lanes
+  // that run idle are then handed the chunk's rays in order with register shuffles, so a refill never waits on memory.  A wave starts on the shard of its
+  // index and moves on when a shard runs dry, so the shards also balance each other at the end of the launch.
   F4 pro = F4{0.0f, 0.0f, 0.0f, 0.0f}, prd = F4{0.0f, 0.0f, 0.0f, 0.0f}; uint32_t prec = 0u, prng = 0u;
-  uint32_t chunkCount = 0u, chunkUsed = 0u; // wave-uniform
-  // Rays are claimed DYN_CLAIM at a time: a device-scope atomic on one address completes ~88 times per microsecond, so one claim per
-  // 64 rays (1 M claims for a 64 Mi-ray launch) was a 11 ms floor under every launch -- the reason no traversal optimisation showed.
-  const uint32_t claim = (refill >> 16) ? (refill >> 16) * 64u : DYN_CLAIM; refill &= 0xffu;
-  // range k = rays [k * per, min(n, (k + 1) * per)); a wave starts on the range of its index and moves on when a range runs dry, so the
-  // ranges also balance each other at the end of the launch
-  const uint32_t per = ((n + NCURSOR - 1u) / NCURSOR + 63u) & ~63u;
-  // DYN_FLAG_XCD_RANGES: all waves of a block start on the range of the block's XCD (workgroups are dealt to the 8 XCDs round-robin), so an
-  // XCD's L2 sees one eighth of the launch's rays -- with key-ordered queues, one key
-  uint32_t range = ((flags & DYN_FLAG_XCD_RANGES) ? blockIdx.x : (blockIdx.x * (TRACE_BLOCK / 64u) + (threadIdx.x >> 6))) % NCURSOR, rangesTried = 0u;
-  uint32_t claimBase = 0u, claimLeft = 0u; // wave-uniform
+  uint32_t chunkCount = 0u, chunkUsed = 0u;
+  uint32_t range = uni((blockIdx.x * (TRACE_BLOCK / 64u) + (threadIdx.x >> 6)) % NCURSOR), rangesTried = 0u, rangeEnd = 0u;
+  uint32_t claimBase = 0u, claimLeft = 0u;
   auto next_chunk = [&]() {
     while (claimLeft == 0u && rangesTried < NCURSOR) {
-      const uint32_t lo = range * per, hi = lo + per < n ? lo + per : n;
-      // DYN_FLAG_PEEK (experiment, off): once a wave has found one range dry it LOOKS before claiming from the others.  At the end of a launch every wave walks
-      // all ranges to find them dry, and 8 192 waves x 8 atomics on 8 addresses (~88 per microsecond and address) are ~0.1 ms per launch -- the whole cost of an
-      // empty launch (tools/exp_iter_log.py: 0.10 -> 0.01 ms).  But full launches pay for it (same box, ABAB: C4 trace 77.3 -> 78.7 ms per frame, C3 shadow
-      // 89.7 -> 90.6) and the bounce loop now runs at most two empty iterations; looking before EVERY claim is far worse (C4 7.2 -> 9.4 ms per launch: the load
-      // queues behind the atomics on its line).
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)shardCount, (int)range);
       uint32_t b = 0xffffffffu;
-      if (lane == 0u && lo < hi && (rangesTried == 0u || !(flags & DYN_FLAG_PEEK) || __hip_atomic_load(&cursors[range].v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < hi - lo)) b = atomicAdd(&cursors[range].v, claim);
-      b = (uint32_t)__shfl((int)b, 0);
-      if (lo < hi && b < hi - lo) { claimBase = lo + b; claimLeft = (hi - lo - b) < claim ? ((hi - lo - b + 63u) & ~63u) : claim; rangesTried = 0u; }
+      if (lane == 0u && hi != 0u) b = atomicAdd(&cursors[range].v, DYN_CLAIM);
+      b = uni(b);
+      if (b < hi) { claimBase = b; claimLeft = (hi - b) < DYN_CLAIM ? ((hi - b + 63u) & ~63u) : DYN_CLAIM; rangeEnd = hi; rangesTried = 0u; }
       else { range = (range + 1u) % NCURSOR; rangesTried++; }
     }
-    const uint32_t base = claimLeft ? claimBase : n;
-    if (claimLeft) { claimBase += 64u; claimLeft -= 64u; }
-    // rays of this chunk: up to the end of the claim's range (the last chunk of a range may be partial)
-    const uint32_t rhi = (range * per + per) < n ? (range * per + per) : n;
-    chunkCount = base < rhi ? (rhi - base < 64u ? rhi - base : 64u) : 0u;
-    chunkUsed = 0u;
-    if (lane < chunkCount) {
-      prec = reader_index(rd, base + lane);
-      pro = ld4(&qs.a[qIn][prec]);
-      prd = ld4(&qs.b[qIn][prec]);
-      if (CUTOUT) { // the any-hit test needs the path's rng state (shadow rays carry their copy; a camera ray whose Slot is still unwritten has it beside the record)
-        if (ANYHIT) prng = f2u(prd.w);
-        else { const uint32_t sw = qs.slot[qIn][prec]; prng = (sw & TRACE_FRESH) ? qs.fresh[qIn - Q_TRACE_A][prec].rng : f2u(st.slots[sw].rad.w); }
+    chunkCount = 0u; chunkUsed = 0u;
+    if (claimLeft) {
+      const uint32_t base = claimBase;
+      claimBase += 64u; claimLeft -= 64u;
+      chunkCount = rangeEnd - base < 64u ? rangeEnd - base : 64u; // (the last chunk of a shard may be partial)
+      if (lane < chunkCount) {
+        prec = range * cap + base + lane;
+        pro = ld4(&qs.a[qIn][prec]);
+        prd = ld4(&qs.b[qIn][prec]);
+        if (CUTOUT) { // the any-hit test needs the path's rng state (shadow rays carry their copy; a camera ray whose Slot is still unwritten has it beside the record)
+          if (ANYHIT) prng = f2u(prd.w);
+          else { const uint32_t sw = qs.slot[qIn][prec]; prng = (sw & TRACE_FRESH) ? qs.fresh[qIn - Q_TRACE_A][prec].rng : f2u(st.slots[sw].rad.w); }
+        }
       }
     }
-  };
-  // A finished ray's result is written when its lane is REFILLED, not in the step it ends (DYN_DEFER_FINISH): some lane of a wave ends in nearly every step (64 lanes,
-  // ~18 steps per ray), so the ~60-instruction finish ran almost every step at 3 of 64 lanes; the refill runs every third step (refill threshold 8) for all the
-  // lanes that ended since.  The result waits in the lane's registers and its LDS hit record, which nothing touches before wave_ray_begin.
-  bool pendingEnd = false;
-  auto finish_ray = [&]() {
-    pendingEnd = false;
-      wave_ray_end(W, R);
-      if constexpr (TWO) { if (!ANYHIT && R.found) R.bestTri = sc.flatOfOrig[R.bestTri]; } // scene-order id -> index of the hit's TriRec
-      if (!ANYHIT) {
-        // ONE 16-byte store per finished ray: the material class k_route sorts by rides in the top four bits of the triangle word (triangle indices keep to
-        // TRI_ID_BITS = 26).  Until r04 the material word went into b.w as a second, 4-byte store into another line -- a second 32-byte sector written per ray
-        // (C3: 85 GB of write traffic per frame for 26 GB of results).
-        if (R.found) st4(&qs.a[qIn][rec], R.tBest, R.bestU, R.bestV, u2f(R.bestTri | (((R.bestMat >> 24) & 0xfu) << 28)));
-        else { // (tMax, origin): k_route needs them for scattering events (medium stacks only)
-          V3 wo = R.o; if constexpr (TWO) wo = R.wo;
-          st4(&qs.a[qIn][rec], R.tBest, wo.x, wo.y, u2f(MISS)); if (sc.mediumStackSize) reinterpret_cast<float*>(&qs.b[qIn][rec])[3] = wo.z;
-        }
-      } else {
-        const uint32_t slot = qs.slot[qIn][rec];
-        F4 nc = F4{0.0f, 0.0f, 0.0f, 0.0f}; // (neeContrib, 1 = emitted at bounce 0)
-        if (!R.found || st.neeKey) nc = ld4(&qs.c[qIn][rec]);
-        if (!R.found) {
-          Slot* S = &st.slots[slot];
-          F4 rr = ld4(&S->rad);
-          st4(&S->rad, rr.x + nc.x, rr.y + nc.y, rr.z + nc.z, rr.w);
-        }
-        if (st.neeKey && nc.w != 0.0f) nee_aov_record(st, slot, R.found);
-      }
   };
   next_chunk();
   for (;;) {
     const unsigned long long idle = __ballot(!alive);
     const uint32_t nIdle = (uint32_t)__popcll(idle);
     if (nIdle >= refill && chunkUsed < chunkCount) {
-      if (pendingEnd) finish_ray();
       const uint32_t avail = chunkCount - chunkUsed, take = nIdle < avail ? nIdle : avail;
       const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
       const int src = (int)((chunkUsed + rank) & 63u);
@@ -488,22 +443,99 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
         if (!ANYHIT) ray_init(v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), ro.w, rdir.w);
         else ray_init(v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), 0.01f, ro.w); // shadow ray (rp_main.rgen:397-429)
         wave_ray_begin(W, R.tBest);
+        if (!ANYHIT) wt_hit_put(W, lane, f2u(R.tBest), f2u(ro.x), f2u(ro.y), MISS); // the result if nothing is hit: (tMax, origin) -- k_route needs them for scattering events (medium stacks only)
         alive = true; draining = false; lastEnd = ringHead; // no pair of this ray is pending
       }
       chunkUsed += take;
       if (chunkUsed == chunkCount) next_chunk(); // loads complete while the wave keeps traversing
-    }
-    if (!__ballot(alive)) { if (chunkCount == 0u) break; else continue; }
-    bool done;
+    } else if (nIdle == 64u) break; // nothing in flight and nothing left to claim (an exhausted chunk is replaced at once, so chunkUsed == chunkCount means there is none)
+    bool done = false;
     if constexpr (TWO) done = wave_step2<ANYHIT, COUNT, CUTOUT>(R, alive, W, sc, s_stack, tc, rng);
-    else if constexpr (TRACE_DYN_COOP_FETCH) done = wave_step<ANYHIT, COUNT, STACK, OVERFLOW, false, CUTOUT, true>(R, alive, W, S, sc, s_nodes, ldsNodes, nullptr, 0u, s_stack, overflow, tc, rng);
-    else done = wave_step_carry<ANYHIT, COUNT, STACK, OVERFLOW, CUTOUT>(R, alive, draining, lastEnd, ringHead, ringTail, flushAt, W, sc, s_nodes, ldsNodes, s_stack, overflow, tc, rng);
-    if (alive && done) {
+    else {
+      // The triangle ring is carried from step to step: a node step yields fewer pairs than a batch holds (C3: 23 per step, C4: 18), so flushing at the end of every step
+      // ran the ~110-instruction batch at a third of its lanes.  A batch runs when 64 pairs are pending; the rest waits.  A ray whose walk has ended while pairs of it are
+      // still pending is DRAINING: its lane keeps the ray (a pending pair fetches the ray from its owner lane at batch time) and sits out the node phases until the ring
+      // has moved past its last pair (the ring is FIFO: `head` has reached `lastEnd`).  The ring is flushed below 64 pairs when DYN_FLUSH_AT or more lanes are blocked like
+      // that, or when no lane walks.  Results do not depend on any of this (the hit key under atomicMin does not depend on when a pair is tested); only the culling distance
+      // a walking ray sees may lag by a step or two.
+      auto batch = [&](uint32_t n) { wave_tri_batch<COUNT, false, CUTOUT, !ANYHIT>(W, ringHead, n, R, rng, sc, nullptr, 0u, tc); ringHead += n; };
+#pragma unroll
+      for (uint32_t rep = 0; rep < DYN_NODES; rep++) {
+        const bool walking = alive && !draining;
+        uint2 Gt = make_uint2(0u, 0u);
+        if (walking) Gt = trav_node<COUNT, STACK, OVERFLOW, false, !ANYHIT>(R, sc, nullptr, 0u, s_stack, overflow, tc);
+        // positions from a wave prefix sum over the per-lane pair counts, then every lane writes its own pairs
+        const uint32_t cntL = (uint32_t)__popc(Gt.y);
+        const uint32_t scan = wave_scan_inclusive(cntL);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)scan, 63);
+        if (total != 0u) {
+          if ((ringTail - ringHead) + total <= 128u) {
+            uint32_t pos = ringTail + scan - cntL;
+            if (cntL) lastEnd = pos + cntL;
+            while (Gt.y) {
+              const uint32_t k = (uint32_t)__ffs((int)Gt.y) - 1u;
+              Gt.y &= Gt.y - 1u;
+              wt_queue_put(W, pos & 127u, (lane << TRI_ID_BITS) | (Gt.x + k));
+              pos++;
+            }
+            ringTail += total;
+            while (ringTail - ringHead >= 64u) batch(64u);
+          } else for (;;) { // (more pairs than the ring has room for) one ballot round per triangle; a batch as soon as 64 pairs are pending (<= 63 + 64 <= the ring's 128 entries)
+            const unsigned long long m = __ballot(Gt.y != 0u);
+            if (!m) break;
+            const bool push = Gt.y != 0u;
+            if (push) {
+              const uint32_t k = (uint32_t)__ffs((int)Gt.y) - 1u;
+              Gt.y &= Gt.y - 1u;
+              wt_queue_put(W, (ringTail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & 127u, (lane << TRI_ID_BITS) | (Gt.x + k));
+            }
+            ringTail += (uint32_t)__popcll(m);
+            if (push) lastEnd = ringTail;
+            if (ringTail - ringHead >= 64u) batch(64u);
+          }
+        }
+        // the walk moves on (a closest-hit walk's pop does not depend on tBest; a shadow walk ends at the first hit the batches have reported so far)
+        if (walking) {
+          if (!ANYHIT) { if (trav_pop<STACK, OVERFLOW>(R, s_stack, overflow)) draining = true; }
+          else if (rep + 1u < DYN_NODES) { if (wt_best_id(W, lane) != 0u || trav_pop<STACK, OVERFLOW>(R, s_stack, overflow)) draining = true; }
+        }
+        if (rep + 1u < DYN_NODES && !__ballot(alive && !draining)) break;
+      }
+      if (ringTail != ringHead) {
+        const unsigned long long blocked = __ballot(alive && draining && (int)(ringHead - lastEnd) < 0);
+        const bool nobodyWalks = __ballot(alive && !draining) == 0ull;
+        if ((uint32_t)__popcll(blocked) >= DYN_FLUSH_AT || nobodyWalks) batch(ringTail - ringHead);
+      }
+      // every ray picks up what the batches of this step found
+      if (alive) {
+        if (!ANYHIT) R.tBest = u2f(wt_best_t(W, lane));
+        else if (!draining && (wt_best_id(W, lane) != 0u || trav_pop<STACK, OVERFLOW>(R, s_stack, overflow))) draining = true;
+        done = draining && (int)(ringHead - lastEnd) >= 0;
+      }
+    }
+    if (alive && done) { // the ray's result, written in place over its record
       alive = false;
-      if (DYN_DEFER_FINISH) pendingEnd = true; else finish_ray();
+      if (!ANYHIT) {
+        // ONE 16-byte store per finished ray: the batches left the finished record in LDS (material class in the top four bits of the triangle word; until r04 the
+        // material word went into b.w as a second store into another line: C3 85 GB of write traffic per frame for 26 GB of results)
+        uint4 h = wt_hit_get(W, lane);
+        if constexpr (TWO) { if (h.w != MISS) h.w = sc.flatOfOrig[h.w & 0x0fffffffu] | (h.w & 0xf0000000u); } // scene-order id -> index of the hit's TriRec
+        st4(&qs.a[qIn][rec], u2f(h.x), u2f(h.y), u2f(h.z), u2f(h.w));
+        if (sc.mediumStackSize && h.w == MISS) { V3 wo = R.o; if constexpr (TWO) wo = R.wo; reinterpret_cast<float*>(&qs.b[qIn][rec])[3] = wo.z; }
+      } else {
+        const bool found = wt_best_id(W, lane) != 0u;
+        const uint32_t slot = qs.slot[qIn][rec];
+        F4 nc = F4{0.0f, 0.0f, 0.0f, 0.0f}; // (neeContrib, 1 = emitted at bounce 0)
+        if (!found || st.neeKey) nc = ld4(&qs.c[qIn][rec]);
+        if (!found) {
+          Slot* S = &st.slots[slot];
+          F4 rr = ld4(&S->rad);
+          st4(&S->rad, rr.x + nc.x, rr.y + nc.y, rr.z + nc.z, rr.w);
+        }
+        if (st.neeKey && nc.w != 0.0f) nee_aov_record(st, slot, found);
+      }
     }
   }
-  if (pendingEnd) finish_ray(); // rays that ended after the launch's last refill
   if (COUNT) { // measurement builds only: one atomic pair per wave
     unsigned long long a = tc.nodes, b = tc.tris;
     for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
@@ -512,21 +544,15 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
 }
 
 template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool CUTOUT>
-__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(GI_DYN_WAVES, 8))) void k_trace_dyn(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t refill, uint32_t ldsNodes, uint32_t flags)
+__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(GI_DYN_WAVES, 8))) void k_trace_dyn(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t refill)
 {
-  trace_dyn_body<ANYHIT, COUNT, STACK, OVERFLOW, CUTOUT>(sc, st, qs, cnt, qIn, refill, ldsNodes, flags);
-}
-// the same body compiled for 6 waves/SIMD (80 VGPRs: the closest-hit variant spills 17 dwords to scratch); experiment, GATLING_DYN_WAVES=6
-template <bool ANYHIT, bool CUTOUT>
-__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_trace_dyn6(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t refill, uint32_t ldsNodes, uint32_t flags)
-{
-  trace_dyn_body<ANYHIT, false, 8, false, CUTOUT>(sc, st, qs, cnt, qIn, refill, ldsNodes, flags);
+  trace_dyn_body<ANYHIT, COUNT, STACK, OVERFLOW, CUTOUT>(sc, st, qs, cnt, qIn, refill);
 }
 // the two-level layout (wave_step2): 16 LDS stack entries, world + object-space ray in registers
 template <bool ANYHIT, bool COUNT, bool CUTOUT>
 __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_trace_dyn2(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t refill)
 {
-  trace_dyn_body<ANYHIT, COUNT, 16, false, CUTOUT, true>(sc, st, qs, cnt, qIn, refill, 0u, 0u);
+  trace_dyn_body<ANYHIT, COUNT, 16, false, CUTOUT, true>(sc, st, qs, cnt, qIn, refill);
 }
 
 // k_route: sorts k_trace_dyn's in-place results by outcome and material class (same routing as k_trace's epilogue)
@@ -691,7 +717,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_aov(FrameUniforms U, SceneView 
   uint2 (*s_stack)[TRACE_BLOCK] = reinterpret_cast<uint2 (*)[TRACE_BLOCK]>(s_dyn);
   uint4* s_nodes = s_dyn + (STACK * TRACE_BLOCK * sizeof(uint2)) / sizeof(uint4);
   uint4* s_tris = s_nodes + ldsNodes * 5u;
-  for (uint32_t i = threadIdx.x; i < ldsNodes * 5u; i += TRACE_BLOCK) s_nodes[i] = reinterpret_cast<const uint4*>(sc.nodes)[(i / 5u) * sc.nodeStrideU4 + (i % 5u)];
+  for (uint32_t i = threadIdx.x; i < ldsNodes * 5u; i += TRACE_BLOCK) s_nodes[i] = reinterpret_cast<const uint4*>(sc.nodes)[i];
   for (uint32_t i = threadIdx.x; i < ldsTris * 3u; i += TRACE_BLOCK) s_tris[i] = reinterpret_cast<const uint4*>(sc.tris)[(i / 3u) * 4u + (i % 3u)];
   __syncthreads();
   const uint32_t p = blockIdx.x * TRACE_BLOCK + threadIdx.x;
@@ -836,41 +862,22 @@ static void launchTraceVariant(hipStream_t s, uint32_t blocks, const SceneView& 
   if (!allLds && dynRefill) { // big scene: persistent waves with dynamic ray fetch, results routed by a streaming pass
     // persistent waves pay the scratch set-up once, so trees deeper than 8 levels may keep 8 entries in LDS (more
     // resident waves) and spill the rest (TRACE_DYN_SPILL8), or keep 16 in LDS
+    const uint32_t refill = dynRefill & 0xffu;
     if (sc.twoLevel) { // instanced scene: TLAS + shared per-mesh BLASes
-      hipLaunchKernelGGL((k_trace_dyn2<ANYHIT, COUNT, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), 16u * TRACE_BLOCK * (uint32_t)sizeof(uint2), s, sc, st, qs, cnt, qIn, (dynRefill & 0xffu) | ((dynRefill >> 16) << 16));
+      hipLaunchKernelGGL((k_trace_dyn2<ANYHIT, COUNT, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), 16u * TRACE_BLOCK * (uint32_t)sizeof(uint2), s, sc, st, qs, cnt, qIn, refill);
       if (!ANYHIT) hipLaunchKernelGGL(k_route, dim3(routeBlocks), dim3(BLOCK), 0, s, sc, st, qs, cnt, qIn, qMiss, U, sampleBuf);
       return;
     }
     const bool spill8 = (dynRefill & TRACE_DYN_SPILL8) != 0u;
-    const uint32_t claimChunks = dynRefill >> 16;
-    dynRefill = (dynRefill & 0xffu) | (claimChunks << 16);
     // 8 entries (16 KB per block), 12 (24 KB: 5 blocks per CU still fit next to the 8 KB of WaveTri) or 16 (32 KB: 4 blocks -- one wave per SIMD fewer)
     const uint32_t entries = (sc.bvhDepth <= 8u || spill8) ? 8u : (sc.bvhDepth <= 12u ? 12u : 16u);
-    // top-of-tree prefix staged in LDS: root + children + grandchildren (1 + 8 + 64 nodes = 5.8 KB) keeps 5 blocks per CU resident
-    static const int envLds = getenv("GATLING_DYN_LDS_NODES") ? atoi(getenv("GATLING_DYN_LDS_NODES")) : -1;
-    static const int envXcd = getenv("GATLING_DYN_XCD") ? atoi(getenv("GATLING_DYN_XCD")) : -1;
-    uint32_t dynLdsNodes = envLds >= 0 ? (uint32_t)envLds : DYN_LDS_NODES_DEFAULT;
-    if (dynLdsNodes > sc.nodeCount) dynLdsNodes = sc.nodeCount;
-    if (dynLdsNodes > 1024u) dynLdsNodes = 1024u;
-    static const int envFlush = getenv("GATLING_DYN_FLUSH") ? atoi(getenv("GATLING_DYN_FLUSH")) : -1;
-    const int envFlushShadow = getenv("GATLING_DYN_FLUSH_SHADOW") ? atoi(getenv("GATLING_DYN_FLUSH_SHADOW")) : -1; // (experiment: shadow rays end at their first hit, which a carried ring reports late)
-    const uint32_t flushAt = (ANYHIT && envFlushShadow >= 0) ? (uint32_t)(envFlushShadow > 64 ? 64 : envFlushShadow) : (envFlush >= 0 ? (uint32_t)(envFlush > 64 ? 64 : envFlush) : DYN_FLUSH_AT_DEFAULT);
-    static const int envPeek = getenv("GATLING_DYN_PEEK") ? atoi(getenv("GATLING_DYN_PEEK")) : 0;
-    const uint32_t dynFlags = ((envXcd >= 0 ? envXcd != 0 : DYN_XCD_RANGES_DEFAULT) ? DYN_FLAG_XCD_RANGES : 0u) | (envPeek ? DYN_FLAG_PEEK : 0u) | (flushAt << DYN_FLAG_FLUSH_SHIFT);
-    const uint32_t stackBytes = entries * TRACE_BLOCK * (uint32_t)sizeof(uint2) + dynLdsNodes * 80u;
-    static const int envWaves = getenv("GATLING_DYN_WAVES") ? atoi(getenv("GATLING_DYN_WAVES")) : 5;
-    if (envWaves == 6 && !COUNT && sc.bvhDepth <= 8u) {
-      hipLaunchKernelGGL((k_trace_dyn6<ANYHIT, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill, dynLdsNodes, dynFlags);
-      if (!ANYHIT) hipLaunchKernelGGL(k_route, dim3(routeBlocks), dim3(BLOCK), 0, s, sc, st, qs, cnt, qIn, qMiss, U, sampleBuf);
-      return;
-    }
-#define GI_LAUNCH_DYN(K) do { \
-    if (sc.bvhDepth <= 8u) hipLaunchKernelGGL((K<ANYHIT, COUNT, 8, false, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill, dynLdsNodes, dynFlags); \
-    else if (spill8) hipLaunchKernelGGL((K<ANYHIT, COUNT, 8, true, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill, dynLdsNodes, dynFlags); \
-    else if (sc.bvhDepth <= 12u) hipLaunchKernelGGL((K<ANYHIT, COUNT, 12, false, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill, dynLdsNodes, dynFlags); \
-    else if (sc.bvhDepth <= 16u) hipLaunchKernelGGL((K<ANYHIT, COUNT, 16, false, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill, dynLdsNodes, dynFlags); \
-    else hipLaunchKernelGGL((K<ANYHIT, COUNT, 16, true, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, dynRefill, dynLdsNodes, dynFlags); } while (0)
-    GI_LAUNCH_DYN(k_trace_dyn);
+    const uint32_t stackBytes = entries * TRACE_BLOCK * (uint32_t)sizeof(uint2);
+#define GI_LAUNCH_DYN(STACK, OVF) hipLaunchKernelGGL((k_trace_dyn<ANYHIT, COUNT, STACK, OVF, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, refill)
+    if (sc.bvhDepth <= 8u) GI_LAUNCH_DYN(8, false);
+    else if (spill8) GI_LAUNCH_DYN(8, true);
+    else if (sc.bvhDepth <= 12u) GI_LAUNCH_DYN(12, false);
+    else if (sc.bvhDepth <= 16u) GI_LAUNCH_DYN(16, false);
+    else GI_LAUNCH_DYN(16, true);
 #undef GI_LAUNCH_DYN
     if (!ANYHIT) hipLaunchKernelGGL(k_route, dim3(routeBlocks), dim3(BLOCK), 0, s, sc, st, qs, cnt, qIn, qMiss, U, sampleBuf);
     return;

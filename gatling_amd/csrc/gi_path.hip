@@ -46,7 +46,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(GI_
   uint4* s_tris = s_nodes + ldsNodes * 5u;
   __shared__ WaveTri s_wave[TRACE_BLOCK / 64];
   WaveTri& W = s_wave[threadIdx.x >> 6];
-  for (uint32_t i = threadIdx.x; i < ldsNodes * 5u; i += TRACE_BLOCK) s_nodes[i] = reinterpret_cast<const uint4*>(sc.nodes)[(i / 5u) * sc.nodeStrideU4 + (i % 5u)];
+  for (uint32_t i = threadIdx.x; i < ldsNodes * 5u; i += TRACE_BLOCK) s_nodes[i] = reinterpret_cast<const uint4*>(sc.nodes)[i];
   for (uint32_t i = threadIdx.x; i < ldsTris * 3u; i += TRACE_BLOCK) s_tris[i] = reinterpret_cast<const uint4*>(sc.tris)[(i / 3u) * 4u + (i % 3u)];
   __syncthreads(); // the only barrier: from here on the waves of a block are independent
 
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(GI_
     wave_ray_begin(W, R.tBest);
     bool tAlive = alive;
     while (__ballot(tAlive)) {
-      if (wave_step<false, COUNT, PATH_STACK, false, true, CUTOUT, false>(R, tAlive, W, nullptr, sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, overflow, tc, rng)) tAlive = false;
+      if (wave_step<false, COUNT, PATH_STACK, false, true, CUTOUT>(R, tAlive, W, sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, overflow, tc, rng)) tAlive = false;
     }
     bool ended = false, missed = false;
     ShadeIO io; io.shadow = false; io.shadowFirst = false; io.cont = false;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(GI_
         wave_ray_begin(W, R.tBest);
         const bool traced = sAlive;
         while (__ballot(sAlive)) {
-          if (wave_step<true, COUNT, PATH_STACK, false, true, CUTOUT, false>(R, sAlive, W, nullptr, sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, overflow, tcs, io.rngShadow)) sAlive = false;
+          if (wave_step<true, COUNT, PATH_STACK, false, true, CUTOUT>(R, sAlive, W, sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, overflow, tcs, io.rngShadow)) sAlive = false;
         }
         if (traced) {
           nShadow++;

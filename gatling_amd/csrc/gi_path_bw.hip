@@ -54,7 +54,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(GI_
   // this wave's path state [F_COUNT][PW] and queues [3][PW]
   GI_LDS uint32_t* S = (GI_LDS uint32_t*)(s_tris + ldsTris * 3u) + (size_t)wave * (F_COUNT + 3u) * PW;
   GI_LDS uint32_t* qT = S + F_COUNT * PW; GI_LDS uint32_t* qS = qT + PW; GI_LDS uint32_t* qR = qS + PW;
-  for (uint32_t i = threadIdx.x; i < ldsNodes * 5u; i += TRACE_BLOCK) s_nodes[i] = reinterpret_cast<const uint4*>(sc.nodes)[(i / 5u) * sc.nodeStrideU4 + (i % 5u)];
+  for (uint32_t i = threadIdx.x; i < ldsNodes * 5u; i += TRACE_BLOCK) s_nodes[i] = reinterpret_cast<const uint4*>(sc.nodes)[i];
   for (uint32_t i = threadIdx.x; i < ldsTris * 3u; i += TRACE_BLOCK) s_tris[i] = reinterpret_cast<const uint4*>(sc.tris)[(i / 3u) * 4u + (i % 3u)];
   for (uint32_t p = lane; p < PW; p += 64u) { S[F_WORK * PW + p] = NO_WORK; qR[p] = p; } // every path starts "ended, nothing to finish"
   __syncthreads(); // the only barrier
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(GI_
       nT -= take;
     }
     if (!__ballot(alive)) continue;
-    const bool done = wave_step<false, COUNT, STACK, false, true, CUTOUT, false>(R, alive, W, nullptr, sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, overflow, tc, myRng);
+    const bool done = wave_step<false, COUNT, STACK, false, true, CUTOUT>(R, alive, W, sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, overflow, tc, myRng);
     const bool fin = alive && done;
     bool hit = false;
     if (fin) {

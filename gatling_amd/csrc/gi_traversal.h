@@ -36,13 +36,15 @@ __device__ __forceinline__ float cutout_random(uint32_t rng, uint32_t triId)
 // Per-lane traversal state.  A ray is advanced by trav_step() one "group" at a time (one internal node, then the
 // triangles of its leaf children, then a pop) so that k_trace (one ray per lane until it finishes) and k_trace_dyn
 // (lanes refill from the queue as they finish) share the same arithmetic.
-struct RayTrav {
-  V3 o, d; float idx, idy, idz, tMin, tBest; uint32_t octinv;
+// RayWalk is what a walk itself needs (k_trace_dyn keeps only this per lane: the nearest hit lives in the wave's LDS record); RayTrav adds the hit
+// bookkeeping of the per-lane form.
+struct RayWalk { V3 o, d; float idx, idy, idz, tMin, tBest; uint32_t octinv; uint2 G; uint32_t sp; };
+struct RayTrav : RayWalk {
   uint32_t bestTri, bestOrig, bestMat; float bestU, bestV;
-  uint2 G; uint32_t sp; bool found;
+  bool found;
 };
 
-__device__ __forceinline__ void trav_init(RayTrav& R, V3 o, V3 d, float tMin, float tMax)
+__device__ __forceinline__ void walk_init(RayWalk& R, V3 o, V3 d, float tMin, float tMax)
 {
   R.o = o; R.d = d; R.tMin = tMin; R.tBest = tMax;
   // reciprocal direction for the slab tests only (guard against 0: boxes are padded, a huge finite value is safe)
@@ -52,18 +54,20 @@ __device__ __forceinline__ void trav_init(RayTrav& R, V3 o, V3 d, float tMin, fl
   // v_rcp_f32 (1 ulp) instead of three IEEE divisions: the reciprocals only feed the box tests, whose far planes are widened by 1e-5
   R.idx = __builtin_amdgcn_rcpf(gx); R.idy = __builtin_amdgcn_rcpf(gy); R.idz = __builtin_amdgcn_rcpf(gz);
   R.octinv = ((d.x >= 0.0f ? 1u : 0u) | (d.y >= 0.0f ? 2u : 0u) | (d.z >= 0.0f ? 4u : 0u)) * 0x01010101u; // replicated into the 4 bytes (trav_node_test)
-  R.bestTri = 0xffffffffu; R.bestOrig = 0xffffffffu; R.bestMat = 0u; R.bestU = 0.0f; R.bestV = 0.0f;
   R.G = make_uint2(0u, 0x80000000u); // virtual group holding only the root
-  R.sp = 0u; R.found = false;
+  R.sp = 0u;
+}
+__device__ __forceinline__ void trav_init(RayTrav& R, V3 o, V3 d, float tMin, float tMax)
+{
+  walk_init(R, o, d, tMin, tMax);
+  R.bestTri = 0xffffffffu; R.bestOrig = 0xffffffffu; R.bestMat = 0u; R.bestU = 0.0f; R.bestV = 0.0f; R.found = false;
 }
 
-// Node half of a traversal step: takes the nearest unvisited child of the current node group (pushing the rest), tests
-// the ray against that node's 8 quantised child boxes and returns the triangle group (base, mask) of its hit leaf
-// children; R.G becomes the group of hit internal children.  Caller guarantees R.G has node bits.
-// Node half of a traversal step, part 1: takes the nearest unvisited child of the current node group (pushing the rest)
-// and returns its node index.  Caller guarantees R.G has node bits.
-template <uint32_t STACK, bool OVERFLOW>
-__device__ __forceinline__ uint32_t trav_node_pick(RayTrav& R, uint2 (*s_stack)[TRACE_BLOCK], uint2 (&overflow)[OVERFLOW ? OVF_STACK : 1])
+// Node half of a traversal step, part 1: takes the next unvisited child of the current node group (pushing the rest) and returns its node index.  Internal
+// children sit in bits 24-31 of G.y, flipped by the ray octant when the node was tested (ORDERED), so "highest bit first" is near-to-far along the ray.
+// Caller guarantees R.G has node bits.
+template <uint32_t STACK, bool OVERFLOW, bool ORDERED = true>
+__device__ __forceinline__ uint32_t trav_node_pick(RayWalk& R, uint2 (*s_stack)[TRACE_BLOCK], uint2 (&overflow)[OVERFLOW ? OVF_STACK : 1])
 {
   const uint32_t tid = threadIdx.x;
   uint2 G = R.G;
@@ -74,32 +78,21 @@ __device__ __forceinline__ uint32_t trav_node_pick(RayTrav& R, uint2 (*s_stack)[
     if (!OVERFLOW || sp < STACK) s_stack[sp < STACK ? sp : STACK - 1u][tid] = G; else overflow[sp - STACK] = G;
     sp++;
   }
-  const uint32_t slot = (bit - 24u) ^ (R.octinv & 7u);
+  const uint32_t slot = ORDERED ? (bit - 24u) ^ (R.octinv & 7u) : bit - 24u;
   const uint32_t rel = (uint32_t)__popc((G.y & 0xffu) & ((1u << slot) - 1u));
   R.sp = sp;
   return G.x + rel;
 }
 
-// Part 2: tests the ray against the node's 8 quantised child boxes and returns the triangle group (base, mask) of its hit
-// leaf children; R.G becomes the group of hit internal children.  The box test is a conservative filter (explicit fma,
-// far planes and tBest widened by 1e-5 relative), it never decides a result.  Written for the VALU: the two planes of an
-// axis go through one packed fma (v_pk_fma_f32), the per-child meta bytes (slot index, child bits, octant flip of internal
-// children) are decoded four at a time with byte-parallel integer ops, and empty slots (meta 0) contribute no bits, so
-// the hit mask is assembled without a branch.
+// Part 2: tests the ray against the node's 8 quantised child boxes and returns the triangle group (base, mask) of its hit leaf children; R.G becomes the group
+// of hit internal children.  The box test is a conservative filter (explicit fma, far planes and tBest widened by 1e-5 relative), it never decides a result.
+// Written for the VALU: the two planes of an axis go through one packed fma (v_pk_fma_f32 issues at the rate of v_fma_f32, tools/valu_calib.hip), the per-child
+// meta bytes (slot index, child bits, octant flip of internal children) are decoded four at a time with byte-parallel integer ops, and empty slots (meta 0)
+// contribute no bits, so the hit mask is assembled without a branch.  ORDERED = false (shadow walks: the first hit ends them, near-to-far buys nothing) leaves the
+// internal children in slot order and saves the flip.
 typedef float gi_f2 __attribute__((ext_vector_type(2)));
-// CULL (r04, closest-hit walks of k_trace_dyn): the group of hit internal children also carries, in the 16 spare bits of G.y (bits 8-23), a lower bound of the entry
-// distance of every child EXCEPT the one the next pick takes (the highest bit = first in octant order): the upper half of the fp32 minimum, truncated (t >= 0, so
-// truncation rounds down).  The remainder a pick pushes keeps the field, and trav_pop drops a popped group whose bound lies beyond the ray's current tBest -- the
-// children were hit when the node was tested, but a nearer hit has been found since ("cull at pop", VERDICT r03 next #2a; tools/bvh_quality.cpp: -11.6 % node visits on C3).
-#ifndef GI_NODE_TEST_PAD
-#define GI_NODE_TEST_PAD 0
-#endif
-#ifndef GI_POP_CULL
-#define GI_POP_CULL 0 // measured r04a (profiles/r04a_pop_cull.txt): node visits C3 -11.7 %, C4 -4.5 %, C5 -10.4 % as counted on the CPU -- and the traversal no faster (C3 47.8 -> 48.1 ms, C4 19.3 -> 20.9, C5 132.2 -> 136.5): the ~56 VALU + 16 SALU the bound costs per node test eat what the saved visits give
-#endif
-constexpr bool POP_CULL = GI_POP_CULL != 0;
-template <bool SLACK = false, bool CULL = false>
-__device__ __forceinline__ uint2 trav_node_test(RayTrav& R, const uint4& n0, const uint4& n1, const uint4& n2, const uint4& n3, const uint4& n4, float slack = 0.0f)
+template <bool SLACK = false, bool ORDERED = true>
+__device__ __forceinline__ uint2 trav_node_test(RayWalk& R, const uint4& n0, const uint4& n1, const uint4& n2, const uint4& n3, const uint4& n4, float slack = 0.0f)
 {
   const V3 o = R.o, d = R.d;
   constexpr float WIDEN = 1.00001f;
@@ -122,7 +115,6 @@ __device__ __forceinline__ uint2 trav_node_test(RayTrav& R, const uint4& n0, con
   const uint32_t metaw[2] = {n1.z, n1.w};
   const uint32_t oct4 = R.octinv;
   uint32_t hitmask = 0u;
-  uint32_t firstPos = 0u; float tnFirst = __builtin_inff(), tnRest = __builtin_inff(); // CULL: position / entry distance of the first hit internal child in visiting order, minimum over the others
 #pragma unroll
   for (int h = 0; h < 2; h++) {
     const uint32_t nearx = nxn ? qhix[h] : qlox[h], farx = nxn ? qlox[h] : qhix[h];
@@ -131,8 +123,13 @@ __device__ __forceinline__ uint2 trav_node_test(RayTrav& R, const uint4& n0, con
     // four meta bytes at once: bits 7-5 = child bits (1 = internal, unary count for leaves), bits 4-0 = slot index, where
     // internal children (index 24..31, i.e. bits 4 and 3 set) are flipped by the ray octant
     const uint32_t m4 = metaw[h];
-    const uint32_t inner4 = ((m4 & (m4 << 1)) >> 4) & 0x01010101u;
-    const uint32_t idx4 = (m4 ^ (oct4 & ((inner4 << 8) - inner4))) & 0x1f1f1f1fu; // (x << 8) - x == x * 0xff per byte, at full rate
+    uint32_t idx4 = m4 & 0x1f1f1f1fu;
+    if (ORDERED) {
+      const uint32_t inner4 = ((m4 & (m4 << 1)) >> 4) & 0x01010101u;
+      uint32_t hi4 = inner4 << 8;
+      asm volatile("" : "+v"(hi4)); // (x << 8) - x == x * 0xff per byte: kept as shift + subtract (left alone the compiler folds it into v_mul_lo_u32, a quarter-rate instruction)
+      idx4 = (m4 ^ (oct4 & (hi4 - inner4))) & 0x1f1f1f1fu;
+    }
     const uint32_t bits4 = (m4 >> 5) & 0x07070707u;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -146,58 +143,46 @@ __device__ __forceinline__ uint2 trav_node_test(RayTrav& R, const uint4& n0, con
       const uint32_t pos = (idx4 >> sh) & 0xffu;
       const uint32_t contrib = ((bits4 >> sh) & 0xffu) << pos;
       hitmask |= (tn <= tf) ? contrib : 0u;
-      if (CULL) { // internal children sit at positions 24-31 (leaf slots below); visiting order = highest position first
-        const bool inner = (tn <= tf) & (pos >= 24u), first = inner & (pos > firstPos);
-        tnRest = fminf(tnRest, first ? tnFirst : (inner ? tn : __builtin_inff()));
-        tnFirst = first ? tn : tnFirst; firstPos = first ? pos : firstPos;
-      }
     }
   }
-#if GI_NODE_TEST_PAD
-  { // calibration builds only (tools/build_variant.py pad32 -DGI_NODE_TEST_PAD=32): N extra fp32 VALU instructions per node test, four independent chains, results kept
-    // alive but unused -- how the kernel's time answers to added instruction issue and to nothing else (profiles/r04k_valu_sensitivity.txt)
-    float p0 = ax, p1 = ay, p2 = az, p3 = bx;
-#pragma unroll
-    for (int i = 0; i < GI_NODE_TEST_PAD / 4; i++) {
-      asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(p0) : "v"(by), "v"(bz));
-      asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(p1) : "v"(by), "v"(bz));
-      asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(p2) : "v"(by), "v"(bz));
-      asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(p3) : "v"(by), "v"(bz));
-    }
-    asm volatile("" :: "v"(p0), "v"(p1), "v"(p2), "v"(p3));
-  }
-#endif
-  R.G = make_uint2(n1.x, (hitmask & 0xff000000u) | (CULL ? ((f2u(tnRest) >> 8) & 0x00ffff00u) : 0u) | (n0.w >> 24));
+  R.G = make_uint2(n1.x, (hitmask & 0xff000000u) | (n0.w >> 24));
   return make_uint2(n1.y, hitmask & 0x00ffffffu);
 }
 
+// fetch of a node's five 16-byte pieces from global memory: 32-bit byte offset on the scalar base (a scene's node array stays below 4 GiB: the flat layout ends at
+// 2^26 triangles), two shift-adds instead of a 64-bit multiply-add
+__device__ __forceinline__ void node_load(const SceneView& sc, uint32_t nodeIdx, uint4& n0, uint4& n1, uint4& n2, uint4& n3, uint4& n4)
+{
+  uint32_t off = nodeIdx << 4;
+  asm volatile("" : "+v"(off)); // (keeps the compiler from folding the two shifts into a quarter-rate v_mul_lo_u32)
+  off += nodeIdx << 6;
+  const uint4* p = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(sc.nodes) + off);
+  n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3]; n4 = p[4];
+}
+
 // The per-lane composition (each lane fetches its own node: from LDS when staged there, else from global memory)
-template <bool COUNT, uint32_t STACK, bool OVERFLOW, bool ALL_LDS, bool CULL = false>
-__device__ __forceinline__ uint2 trav_node(RayTrav& R, const SceneView& sc, const uint4* s_nodes, uint32_t ldsNodes,
+template <bool COUNT, uint32_t STACK, bool OVERFLOW, bool ALL_LDS, bool ORDERED = true>
+__device__ __forceinline__ uint2 trav_node(RayWalk& R, const SceneView& sc, const uint4* s_nodes, uint32_t ldsNodes,
                                            uint2 (*s_stack)[TRACE_BLOCK], uint2 (&overflow)[OVERFLOW ? OVF_STACK : 1], TraceCounters& tc)
 {
-  const uint32_t nodeIdx = trav_node_pick<STACK, OVERFLOW>(R, s_stack, overflow);
+  const uint32_t nodeIdx = trav_node_pick<STACK, OVERFLOW, ORDERED>(R, s_stack, overflow);
   uint4 n0, n1, n2, n3, n4;
   if (ALL_LDS || nodeIdx < ldsNodes) { const uint4* p = s_nodes + nodeIdx * 5u; n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3]; n4 = p[4]; }
-  else { const uint4* p = reinterpret_cast<const uint4*>(sc.nodes) + (size_t)nodeIdx * sc.nodeStrideU4; n0 = p[0]; n1 = p[1]; n2 = p[2]; n3 = p[3]; n4 = p[4]; }
+  else node_load(sc, nodeIdx, n0, n1, n2, n3, n4);
   if (COUNT) tc.nodes++;
-  return trav_node_test<false, CULL>(R, n0, n1, n2, n3, n4);
+  return trav_node_test<false, ORDERED>(R, n0, n1, n2, n3, n4);
 }
 
 // End of a step: when the current group has no unvisited internal child left, continue with the stack top.
 // Returns true when the traversal is finished.
-template <uint32_t STACK, bool OVERFLOW, bool CULL = false>
-__device__ __forceinline__ bool trav_pop(RayTrav& R, uint2 (*s_stack)[TRACE_BLOCK], uint2 (&overflow)[OVERFLOW ? OVF_STACK : 1])
+template <uint32_t STACK, bool OVERFLOW>
+__device__ __forceinline__ bool trav_pop(RayWalk& R, uint2 (*s_stack)[TRACE_BLOCK], uint2 (&overflow)[OVERFLOW ? OVF_STACK : 1])
 {
   if (R.G.y & 0xff000000u) return false;
-  for (;;) {
-    if (R.sp == 0u) return true;
-    const uint32_t sp = --R.sp;
-    const uint2 G = (!OVERFLOW || sp < STACK) ? s_stack[sp < STACK ? sp : STACK - 1u][threadIdx.x] : overflow[sp - STACK];
-    // CULL: every child of the group lies beyond the nearest hit found since it was pushed (the bound is a truncated lower bound of their entry distances;
-    // compared against the widened tBest the box test itself uses, so nothing the box test would still accept is dropped)
-    if (!CULL || !(u2f((G.y & 0x00ffff00u) << 8) > R.tBest * 1.00001f)) { R.G = G; return false; }
-  }
+  if (R.sp == 0u) return true;
+  const uint32_t sp = --R.sp;
+  R.G = (!OVERFLOW || sp < STACK) ? s_stack[sp < STACK ? sp : STACK - 1u][threadIdx.x] : overflow[sp - STACK];
+  return false;
 }
 
 // Two-sided Moeller-Trumbore, operation order == oracle tri_test; evaluated branch-free (a wave almost always has a lane
@@ -260,90 +245,48 @@ __device__ __forceinline__ bool trav_step(RayTrav& R, const SceneView& sc, const
 // "t < tBest, ties to the lower scene-order id" rule and makes the result independent of the test order.
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t TRI_ID_BITS = 26; // queue entry = ray lane << 26 | triangle index (the host refuses scenes with >= 2^26 triangles)
-template <uint32_t RING>
-struct WaveTriT {
+struct WaveTri {
   unsigned long long best[64]; // per ray lane: (t bits << 32) | (scene-order id + 1); low word 0 = no hit yet
-  uint4 hit[64];               // per ray lane: (triangle index, u bits, v bits, material word) of that hit
-  uint32_t queue[RING];        // ring of pending (ray lane, triangle) pairs
+  uint4 hit[64];               // per ray lane: that hit as (triangle index, u bits, v bits, material word) -- k_trace_dyn: the finished result record (t, u, v, triangle | class << 28)
+  uint32_t queue[128];         // ring of pending (ray lane, triangle) pairs (a 256-entry ring measured slower)
 };
-typedef WaveTriT<128> WaveTri;    // wave_step: the ring is emptied at the end of every step
-typedef WaveTriT<128> WaveTriDyn; // wave_step_carry: pairs wait for a full batch (a 256-entry ring with prefix-sum appends measured slower)
 // WaveTri lives in LDS, but through a C++ reference the compiler only sees a generic pointer and emits FLAT loads / stores (vector-memory
 // path, each volatile one followed by s_waitcnt vmcnt(0), i.e. a stall on every outstanding global load).  These accessors cast back to
 // address space 3, so the exchanges are ds_read / ds_write with lgkmcnt waits.
 #define GI_LDS __attribute__((address_space(3)))
 typedef uint32_t gi_u4 __attribute__((ext_vector_type(4)));
-template <class WT> __device__ __forceinline__ void wt_queue_put(WT& W, uint32_t i, uint32_t v) { *(volatile GI_LDS uint32_t*)&((GI_LDS WT*)&W)->queue[i] = v; }
-template <class WT> __device__ __forceinline__ uint32_t wt_queue_get(WT& W, uint32_t i) { return *(volatile GI_LDS uint32_t*)&((GI_LDS WT*)&W)->queue[i]; }
-template <class WT> __device__ __forceinline__ void wt_best_put(WT& W, uint32_t i, unsigned long long v) { *(volatile GI_LDS unsigned long long*)&((GI_LDS WT*)&W)->best[i] = v; }
-template <class WT> __device__ __forceinline__ unsigned long long wt_best_get(WT& W, uint32_t i) { return *(volatile GI_LDS unsigned long long*)&((GI_LDS WT*)&W)->best[i]; }
-template <class WT> __device__ __forceinline__ void wt_best_min(WT& W, uint32_t i, unsigned long long v)
-{ __hip_atomic_fetch_min((GI_LDS unsigned long long*)&((GI_LDS WT*)&W)->best[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-template <class WT> __device__ __forceinline__ void wt_hit_put(WT& W, uint32_t i, uint32_t x, uint32_t y, uint32_t z, uint32_t w)
-{ gi_u4 v = {x, y, z, w}; *(volatile GI_LDS gi_u4*)&((GI_LDS WT*)&W)->hit[i] = v; }
-template <class WT> __device__ __forceinline__ uint4 wt_hit_get(WT& W, uint32_t i) { const gi_u4 v = *(volatile GI_LDS gi_u4*)&((GI_LDS WT*)&W)->hit[i]; return make_uint4(v.x, v.y, v.z, v.w); }
-// Staging buffer of the cooperative fetch (scenes in global memory).  A lane that loads its own 80-byte node issues five
-// 16-byte loads to a cache line no other lane touches, so every load instruction costs the L1 64 tag look-ups; measured,
-// the texture-address unit was busy 63 % of k_trace's time.  Instead lane i of the wave loads 16-byte piece (i % 5) of
-// the node that lane (i / 5) asked for: consecutive lanes read consecutive addresses, an instruction touches ~13-26 lines,
-// and the pieces meet again in LDS (conflict-free: 80 B and 48 B lane strides both map 16 lanes onto all 64 banks).
-struct WaveStage { uint4 buf[64 * 5]; };
-// Measured on C3 (1M-triangle soup): 35.4 ms with the cooperative fetch vs 29.6 ms without (the 20 KiB of staging per
-// block cost two resident blocks per CU and the extra LDS round trip outweighs the saved tag look-ups) -> off.
-#ifndef GI_TRACE_DYN_COOP
-#define GI_TRACE_DYN_COOP 0
-#endif
-constexpr bool TRACE_DYN_COOP_FETCH = GI_TRACE_DYN_COOP != 0; // (r03: re-measured as a variant build, see below)
-#ifndef GI_TRI_FULL_LOAD
-#define GI_TRI_FULL_LOAD 0 // measured (r03a, C3): loading all 48 bytes up front is SLOWER -- shadow rays 44.4 -> 50.2 ms, closest hit 131 -> 134-141 ms: the vector-memory request path, not the dependent round trip, is what the batch waits for
-#endif
-#ifndef GI_WAVE_STEP_SCAN_APPEND
-#define GI_WAVE_STEP_SCAN_APPEND 1
-#endif
-#ifndef GI_WAVE_STEP_CARRY_SCAN_APPEND
-#define GI_WAVE_STEP_CARRY_SCAN_APPEND 1
-#endif
-constexpr bool WAVE_STEP_CARRY_SCAN_APPEND = GI_WAVE_STEP_CARRY_SCAN_APPEND != 0;
-constexpr bool WAVE_STEP_SCAN_APPEND = GI_WAVE_STEP_SCAN_APPEND != 0; // wave_step: pair positions from a wave prefix sum instead of one ballot round per triangle
+__device__ __forceinline__ void wt_queue_put(WaveTri& W, uint32_t i, uint32_t v) { *(volatile GI_LDS uint32_t*)&((GI_LDS WaveTri*)&W)->queue[i] = v; }
+__device__ __forceinline__ uint32_t wt_queue_get(WaveTri& W, uint32_t i) { return *(volatile GI_LDS uint32_t*)&((GI_LDS WaveTri*)&W)->queue[i]; }
+__device__ __forceinline__ void wt_best_put(WaveTri& W, uint32_t i, unsigned long long v) { *(volatile GI_LDS unsigned long long*)&((GI_LDS WaveTri*)&W)->best[i] = v; }
+__device__ __forceinline__ unsigned long long wt_best_get(WaveTri& W, uint32_t i) { return *(volatile GI_LDS unsigned long long*)&((GI_LDS WaveTri*)&W)->best[i]; }
+__device__ __forceinline__ uint32_t wt_best_t(WaveTri& W, uint32_t i) { return ((volatile GI_LDS uint32_t*)&((GI_LDS WaveTri*)&W)->best[i])[1]; }   // t bits of the nearest hit so far (or of tMax)
+__device__ __forceinline__ uint32_t wt_best_id(WaveTri& W, uint32_t i) { return ((volatile GI_LDS uint32_t*)&((GI_LDS WaveTri*)&W)->best[i])[0]; }  // scene-order id + 1, 0 = no hit yet
+__device__ __forceinline__ void wt_best_min(WaveTri& W, uint32_t i, unsigned long long v)
+{ __hip_atomic_fetch_min((GI_LDS unsigned long long*)&((GI_LDS WaveTri*)&W)->best[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void wt_hit_put(WaveTri& W, uint32_t i, uint32_t x, uint32_t y, uint32_t z, uint32_t w)
+{ gi_u4 v = {x, y, z, w}; *(volatile GI_LDS gi_u4*)&((GI_LDS WaveTri*)&W)->hit[i] = v; }
+__device__ __forceinline__ uint4 wt_hit_get(WaveTri& W, uint32_t i) { const gi_u4 v = *(volatile GI_LDS gi_u4*)&((GI_LDS WaveTri*)&W)->hit[i]; return make_uint4(v.x, v.y, v.z, v.w); }
 
-template <bool COUNT, bool ALL_LDS, bool CUTOUT, bool COOP, uint32_t RING_MASK = 127u, class WT = WaveTri>
-__device__ __forceinline__ void wave_tri_batch(WT& W, WaveStage* S, uint32_t head, uint32_t cnt, const RayTrav& R, uint32_t rng, const SceneView& sc,
+// 64 (ray lane, triangle) pairs of the ring, one per lane.  RESULT_RECORD (k_trace_dyn): the winner leaves the ray's finished result record in WaveTri::hit.
+template <bool COUNT, bool ALL_LDS, bool CUTOUT, bool RESULT_RECORD = false>
+__device__ __forceinline__ void wave_tri_batch(WaveTri& W, uint32_t head, uint32_t cnt, const RayWalk& R, uint32_t rng, const SceneView& sc,
                                                const uint4* s_tris, uint32_t ldsTris, TraceCounters& tc)
 {
   const uint32_t lane = __lane_id();
   const bool act = lane < cnt;
-  const uint32_t e = act ? wt_queue_get(W, (head + lane) & RING_MASK) : 0u;
+  const uint32_t e = act ? wt_queue_get(W, (head + lane) & 127u) : 0u;
   const uint32_t rl = e >> TRI_ID_BITS, triIdx = e & ((1u << TRI_ID_BITS) - 1u);
   // the owning lane's ray (executed by all lanes: wave-uniform control flow)
   const V3 o = v3(__shfl(R.o.x, (int)rl), __shfl(R.o.y, (int)rl), __shfl(R.o.z, (int)rl));
   const V3 d = v3(__shfl(R.d.x, (int)rl), __shfl(R.d.y, (int)rl), __shfl(R.d.z, (int)rl));
   const float tMin = __shfl(R.tMin, (int)rl);
   const uint32_t rrng = CUTOUT ? (uint32_t)__shfl((int)rng, (int)rl) : 0u;
-  if (COOP) { // piece (flat % 3) of the triangle of entry (flat / 3), for flat = lane, 64 + lane, 128 + lane
-    uint4 piece[3];
-#pragma unroll
-    for (uint32_t cidx = 0; cidx < 3u; cidx++) {
-      const uint32_t flat = cidx * 64u + lane, owner = flat / 3u, part = flat - owner * 3u;
-      const uint32_t tIdx = (uint32_t)__shfl((int)triIdx, (int)owner);
-      piece[cidx] = make_uint4(0u, 0u, 0u, 0u);
-      if (owner < cnt) piece[cidx] = reinterpret_cast<const uint4*>(sc.tris)[(size_t)tIdx * 4u + part];
-    }
-#pragma unroll
-    for (uint32_t cidx = 0; cidx < 3u; cidx++) S->buf[cidx * 64u + lane] = piece[cidx];
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-  }
   if (act) {
     uint4 a, b, c;
-    if (COOP) { const uint4* p = S->buf + lane * 3u; a = p[0]; b = p[1]; c = p[2]; }
-    else if (ALL_LDS || triIdx < ldsTris) { const uint4* p = s_tris + triIdx * 3u; a = p[0]; b = p[1]; c = p[2]; }
-    else {
-      const uint4* p = reinterpret_cast<const uint4*>(sc.tris) + (size_t)triIdx * 4u; a = p[0]; b = p[1]; c = p[2];
-#if GI_TRI_FULL_LOAD
-      // All 48 bytes at once: left alone, the compiler loads only c.x here and SINKS the loads of c.y (scene-order id) and c.w (material word) into the accept
-      // branch below, where each costs the wave a dependent global round trip (s_waitcnt vmcnt(0) twice) although the line is already on its way.
-      asm volatile("" : "+v"(c.y), "+v"(c.w));
-#endif
-    }
+    // (the compiler loads c.x here and sinks the loads of c.y -- scene-order id -- and c.w -- material word -- into the accept branch; loading all 48 bytes
+    // up front measured SLOWER, r03a: the vector-memory request path, not the dependent round trip, is what the batch waits for)
+    if (ALL_LDS || triIdx < ldsTris) { const uint4* p = s_tris + triIdx * 3u; a = p[0]; b = p[1]; c = p[2]; }
+    else { const uint4* p = reinterpret_cast<const uint4*>(sc.tris) + (size_t)triIdx * 4u; a = p[0]; b = p[1]; c = p[2]; }
     if (COUNT) tc.tris++;
     float t, u, v;
     bool accept = tri_test(o, d, tMin, a, b, c, t, u, v);
@@ -354,58 +297,44 @@ __device__ __forceinline__ void wave_tri_batch(WT& W, WaveStage* S, uint32_t hea
     if (accept) {
       const unsigned long long key = ((unsigned long long)f2u(t) << 32) | (unsigned long long)(c.y + 1u);
       wt_best_min(W, rl, key);
-      if (wt_best_get(W, rl) == key) wt_hit_put(W, rl, triIdx, f2u(u), f2u(v), c.w);
+      if (wt_best_get(W, rl) == key) {
+        if (RESULT_RECORD) wt_hit_put(W, rl, f2u(t), f2u(u), f2u(v), triIdx | (((c.w >> 24) & 0xfu) << 28)); // the material class k_route sorts by rides in the top four bits
+        else wt_hit_put(W, rl, triIdx, f2u(u), f2u(v), c.w);
+      }
     }
   }
 }
 
-// One step of all rays of a wave: node phase per lane, then the cooperative triangle stage, then pop.  Wave-uniform
+// wave prefix sum (inclusive) over one value per lane: six DPP adds
+__device__ __forceinline__ uint32_t wave_scan_inclusive(uint32_t v)
+{
+  int scan = (int)v;
+  scan += __builtin_amdgcn_update_dpp(0, scan, 0x111, 0xf, 0xf, false); // row_shr:1
+  scan += __builtin_amdgcn_update_dpp(0, scan, 0x112, 0xf, 0xf, false); // row_shr:2
+  scan += __builtin_amdgcn_update_dpp(0, scan, 0x114, 0xf, 0xf, false); // row_shr:4
+  scan += __builtin_amdgcn_update_dpp(0, scan, 0x118, 0xf, 0xf, false); // row_shr:8
+  scan += __builtin_amdgcn_update_dpp(0, scan, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+  scan += __builtin_amdgcn_update_dpp(0, scan, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
+  return (uint32_t)scan;
+}
+
+// One step of all rays of a wave (k_trace: scenes staged in LDS): node phase per lane, then the cooperative triangle stage, then pop.  Wave-uniform
 // control flow; lanes without a ray (alive == false) only help testing triangles.  Returns true when this lane's ray is finished.
-template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool ALL_LDS, bool CUTOUT, bool COOP>
-__device__ __forceinline__ bool wave_step(RayTrav& R, bool alive, WaveTri& W, WaveStage* S, const SceneView& sc, const uint4* s_nodes, uint32_t ldsNodes,
+template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool ALL_LDS, bool CUTOUT>
+__device__ __forceinline__ bool wave_step(RayTrav& R, bool alive, WaveTri& W, const SceneView& sc, const uint4* s_nodes, uint32_t ldsNodes,
                                           const uint4* s_tris, uint32_t ldsTris, uint2 (*s_stack)[TRACE_BLOCK], uint2 (&overflow)[OVERFLOW ? OVF_STACK : 1],
                                           TraceCounters& tc, uint32_t rng)
 {
   const uint32_t lane = __lane_id();
   uint2 Gt = make_uint2(0u, 0u);
-  if (!COOP) {
-    if (alive) Gt = trav_node<COUNT, STACK, OVERFLOW, ALL_LDS>(R, sc, s_nodes, ldsNodes, s_stack, overflow, tc);
-  } else {
-    uint32_t nodeIdx = 0xffffffffu;
-    if (alive) nodeIdx = trav_node_pick<STACK, OVERFLOW>(R, s_stack, overflow);
-    uint4 piece[5]; // piece (flat % 5) of the node lane (flat / 5) asked for, flat = lane, 64 + lane, ...
-#pragma unroll
-    for (uint32_t cidx = 0; cidx < 5u; cidx++) {
-      const uint32_t flat = cidx * 64u + lane, owner = flat / 5u, part = flat - owner * 5u;
-      const uint32_t nIdx = (uint32_t)__shfl((int)nodeIdx, (int)owner);
-      piece[cidx] = make_uint4(0u, 0u, 0u, 0u);
-      if (nIdx != 0xffffffffu) piece[cidx] = reinterpret_cast<const uint4*>(sc.nodes)[(size_t)nIdx * sc.nodeStrideU4 + part];
-    }
-#pragma unroll
-    for (uint32_t cidx = 0; cidx < 5u; cidx++) S->buf[cidx * 64u + lane] = piece[cidx];
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-    if (alive) {
-      const uint4* p = S->buf + lane * 5u;
-      const uint4 n0 = p[0], n1 = p[1], n2 = p[2], n3 = p[3], n4 = p[4];
-      if (COUNT) tc.nodes++;
-      Gt = trav_node_test(R, n0, n1, n2, n3, n4);
-    }
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-  }
+  if (alive) Gt = trav_node<COUNT, STACK, OVERFLOW, ALL_LDS>(R, sc, s_nodes, ldsNodes, s_stack, overflow, tc);
   uint32_t head = 0u, tail = 0u; // wave-uniform
-  if (WAVE_STEP_SCAN_APPEND && !COOP) {
-    // positions from a wave prefix sum over the per-lane pair counts (six DPP adds), then every lane writes its own pairs
+  { // positions from a wave prefix sum over the per-lane pair counts, then every lane writes its own pairs
     const uint32_t cntL = (uint32_t)__popc(Gt.y);
-    int scan = (int)cntL;
-    scan += __builtin_amdgcn_update_dpp(0, scan, 0x111, 0xf, 0xf, false); // row_shr:1
-    scan += __builtin_amdgcn_update_dpp(0, scan, 0x112, 0xf, 0xf, false); // row_shr:2
-    scan += __builtin_amdgcn_update_dpp(0, scan, 0x114, 0xf, 0xf, false); // row_shr:4
-    scan += __builtin_amdgcn_update_dpp(0, scan, 0x118, 0xf, 0xf, false); // row_shr:8
-    scan += __builtin_amdgcn_update_dpp(0, scan, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
-    scan += __builtin_amdgcn_update_dpp(0, scan, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane(scan, 63);
+    const uint32_t scan = wave_scan_inclusive(cntL);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)scan, 63);
     if (total <= 128u) {
-      uint32_t pos = (uint32_t)scan - cntL;
+      uint32_t pos = scan - cntL;
       while (Gt.y) {
         const uint32_t k = (uint32_t)__ffs((int)Gt.y) - 1u;
         Gt.y &= Gt.y - 1u;
@@ -413,10 +342,10 @@ __device__ __forceinline__ bool wave_step(RayTrav& R, bool alive, WaveTri& W, Wa
         pos++;
       }
       tail = total;
-      while (tail - head >= 64u) { wave_tri_batch<COUNT, ALL_LDS, CUTOUT, COOP>(W, S, head, 64u, R, rng, sc, s_tris, ldsTris, tc); head += 64u; }
+      while (tail - head >= 64u) { wave_tri_batch<COUNT, ALL_LDS, CUTOUT>(W, head, 64u, R, rng, sc, s_tris, ldsTris, tc); head += 64u; }
     }
   }
-  for (;;) { // (more pairs than the ring holds, or the scan path off) one ballot round per triangle, a batch whenever 64 pairs are pending
+  for (;;) { // (more pairs than the ring holds) one ballot round per triangle, a batch whenever 64 pairs are pending
     const unsigned long long m = __ballot(Gt.y != 0u);
     if (!m) break;
     if (Gt.y) {
@@ -425,9 +354,9 @@ __device__ __forceinline__ bool wave_step(RayTrav& R, bool alive, WaveTri& W, Wa
       wt_queue_put(W, (tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & 127u, (lane << TRI_ID_BITS) | (Gt.x + k));
     }
     tail += (uint32_t)__popcll(m);
-    if (tail - head >= 64u) { wave_tri_batch<COUNT, ALL_LDS, CUTOUT, COOP>(W, S, head, 64u, R, rng, sc, s_tris, ldsTris, tc); head += 64u; }
+    if (tail - head >= 64u) { wave_tri_batch<COUNT, ALL_LDS, CUTOUT>(W, head, 64u, R, rng, sc, s_tris, ldsTris, tc); head += 64u; }
   }
-  if (tail != head) wave_tri_batch<COUNT, ALL_LDS, CUTOUT, COOP>(W, S, head, tail - head, R, rng, sc, s_tris, ldsTris, tc);
+  if (tail != head) wave_tri_batch<COUNT, ALL_LDS, CUTOUT>(W, head, tail - head, R, rng, sc, s_tris, ldsTris, tc);
   bool done = false;
   if (alive) {
     const unsigned long long key = wt_best_get(W, lane);
@@ -438,83 +367,10 @@ __device__ __forceinline__ bool wave_step(RayTrav& R, bool alive, WaveTri& W, Wa
   return done;
 }
 
-// wave_step with the triangle ring carried over from step to step (k_trace_dyn).  A node step yields fewer pairs than a batch holds once
-// the tree keeps its leaf slots small (C3: 64 lanes x 6.2 triangles / 17.1 nodes = 23 pairs per step, C4: 18), so flushing the ring at the
-// end of every step ran the ~110-instruction batch at a third of its lanes.  Here a batch runs when 64 pairs are pending; the rest waits.
-// A ray whose walk has ended while pairs of it are still pending is DRAINING: its lane keeps the ray (a pending pair fetches the ray from
-// its owner lane at batch time) and sits out the node phases until the ring has moved past its last pair (the ring is FIFO: `head` has
-// reached `lastEnd`).  The ring is flushed below 64 pairs when `flushAt` or more lanes are blocked like that, or when no lane walks.
-// flushAt == 0 flushes at the end of every step, i.e. wave_step's behaviour.  Results are those of wave_step (the hit key under atomicMin
-// does not depend on when a pair is tested); only the culling distance a walking ray sees may lag by a step or two.
-template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool CUTOUT>
-__device__ __forceinline__ bool wave_step_carry(RayTrav& R, bool alive, bool& draining, uint32_t& lastEnd, uint32_t& head, uint32_t& tail, uint32_t flushAt,
-                                                WaveTriDyn& W, const SceneView& sc, const uint4* s_nodes, uint32_t ldsNodes, uint2 (*s_stack)[TRACE_BLOCK],
-                                                uint2 (&overflow)[OVERFLOW ? OVF_STACK : 1], TraceCounters& tc, uint32_t rng)
-{
-  const uint32_t lane = __lane_id();
-  const bool walking = alive && !draining;
-  uint2 Gt = make_uint2(0u, 0u);
-  constexpr bool CULL = POP_CULL && !ANYHIT; // shadow rays stop at their first hit: tBest never shrinks before that
-  if (walking) Gt = trav_node<COUNT, STACK, OVERFLOW, false, CULL>(R, sc, s_nodes, ldsNodes, s_stack, overflow, tc);
-  if (WAVE_STEP_CARRY_SCAN_APPEND) { // as in wave_step: positions from a wave prefix sum when the step's pairs fit behind the pending ones
-    const uint32_t cntL = (uint32_t)__popc(Gt.y);
-    int scan = (int)cntL;
-    scan += __builtin_amdgcn_update_dpp(0, scan, 0x111, 0xf, 0xf, false);
-    scan += __builtin_amdgcn_update_dpp(0, scan, 0x112, 0xf, 0xf, false);
-    scan += __builtin_amdgcn_update_dpp(0, scan, 0x114, 0xf, 0xf, false);
-    scan += __builtin_amdgcn_update_dpp(0, scan, 0x118, 0xf, 0xf, false);
-    scan += __builtin_amdgcn_update_dpp(0, scan, 0x142, 0xa, 0xf, false);
-    scan += __builtin_amdgcn_update_dpp(0, scan, 0x143, 0xc, 0xf, false);
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane(scan, 63);
-    if (total != 0u && (tail - head) + total <= 128u) {
-      uint32_t pos = tail + (uint32_t)scan - cntL;
-      if (cntL) lastEnd = pos + cntL;
-      while (Gt.y) {
-        const uint32_t k = (uint32_t)__ffs((int)Gt.y) - 1u;
-        Gt.y &= Gt.y - 1u;
-        wt_queue_put(W, pos & 127u, (lane << TRI_ID_BITS) | (Gt.x + k));
-        pos++;
-      }
-      tail += total;
-      while (tail - head >= 64u) { wave_tri_batch<COUNT, false, CUTOUT, false>(W, nullptr, head, 64u, R, rng, sc, nullptr, 0u, tc); head += 64u; }
-    }
-  }
-  for (;;) { // one ballot round per triangle; a batch as soon as 64 pairs are pending (<= 63 + 64 <= the ring's 128 entries)
-    const unsigned long long m = __ballot(Gt.y != 0u);
-    if (!m) break;
-    const bool push = Gt.y != 0u;
-    if (push) {
-      const uint32_t k = (uint32_t)__ffs((int)Gt.y) - 1u;
-      Gt.y &= Gt.y - 1u;
-      wt_queue_put(W, (tail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & 127u, (lane << TRI_ID_BITS) | (Gt.x + k));
-    }
-    tail += (uint32_t)__popcll(m);
-    if (push) lastEnd = tail;
-    if (tail - head >= 64u) { wave_tri_batch<COUNT, false, CUTOUT, false>(W, nullptr, head, 64u, R, rng, sc, nullptr, 0u, tc); head += 64u; }
-  }
-  // the walk moves on before the ring is looked at (the pop does not depend on tBest) ...
-  if (walking && !ANYHIT && trav_pop<STACK, OVERFLOW, CULL>(R, s_stack, overflow)) draining = true;
-  if (tail != head) {
-    const unsigned long long blocked = __ballot(alive && draining && (int)(head - lastEnd) < 0);
-    const bool nobodyWalks = __ballot(alive && !draining) == 0ull;
-    if ((uint32_t)__popcll(blocked) >= flushAt || nobodyWalks) { wave_tri_batch<COUNT, false, CUTOUT, false>(W, nullptr, head, tail - head, R, rng, sc, nullptr, 0u, tc); head = tail; }
-  }
-  // ... and every ray picks up what the batches of this step found
-  bool done = false;
-  if (alive) {
-    const unsigned long long key = wt_best_get(W, lane);
-    R.tBest = u2f((uint32_t)(key >> 32));
-    R.found = (uint32_t)key != 0u;
-    if (ANYHIT && !draining && (R.found || trav_pop<STACK, OVERFLOW>(R, s_stack, overflow))) draining = true;
-    done = draining && (int)(head - lastEnd) >= 0;
-  }
-  return done;
-}
-
 // start of a ray in the cooperative scheme (after trav_init)
-template <class WT> __device__ __forceinline__ void wave_ray_begin(WT& W, float tMax) { wt_best_put(W, __lane_id(), (unsigned long long)f2u(tMax) << 32); }
+__device__ __forceinline__ void wave_ray_begin(WaveTri& W, float tMax) { wt_best_put(W, __lane_id(), (unsigned long long)f2u(tMax) << 32); }
 // result of a finished ray
-template <class WT> __device__ __forceinline__ void wave_ray_end(WT& W, RayTrav& R)
+__device__ __forceinline__ void wave_ray_end(WaveTri& W, RayTrav& R)
 {
   __atomic_signal_fence(__ATOMIC_SEQ_CST); // compiler only: the winning lane's store precedes this load in the wave's program order
   if (R.found) { const uint4 h = wt_hit_get(W, __lane_id()); R.bestTri = h.x; R.bestU = u2f(h.y); R.bestV = u2f(h.z); R.bestMat = h.w; }
@@ -546,7 +402,7 @@ __device__ __forceinline__ bool traverse(const SceneView& sc, const uint4* s_nod
 // reference, y = 24-bit mask of the hit leaf references) that wait below the BLAS entries of the instance being walked.
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t TLAS_ITEM_TAG = 0x80000000u, NO_INSTANCE = 0xffffffffu;
-struct RayTrav2 : RayTrav { V3 wo, wd; uint32_t inst, spBase; float slack; };
+struct RayTrav2 : RayWalk { V3 wo, wd; uint32_t inst, spBase; float slack; };
 
 __device__ __forceinline__ void trav2_set_ray(RayTrav2& R, V3 o, V3 d)
 {
@@ -559,7 +415,7 @@ __device__ __forceinline__ void trav2_set_ray(RayTrav2& R, V3 o, V3 d)
 }
 __device__ __forceinline__ void trav2_init(RayTrav2& R, V3 o, V3 d, float tMin, float tMax)
 {
-  trav_init(R, o, d, tMin, tMax);
+  walk_init(R, o, d, tMin, tMax);
   R.wo = o; R.wd = d; R.inst = NO_INSTANCE; R.spBase = 0u; R.slack = 0.0f;
 }
 __device__ __forceinline__ void trav2_enter(RayTrav2& R, const SceneView& sc, uint32_t inst)
@@ -623,7 +479,7 @@ __device__ __forceinline__ void wave_tri_batch2(WaveTri& W, uint32_t head, uint3
     if (accept) {
       const unsigned long long key = ((unsigned long long)f2u(t) << 32) | (unsigned long long)(orig + 1u);
       wt_best_min(W, rl, key);
-      if (wt_best_get(W, rl) == key) wt_hit_put(W, rl, orig, f2u(u), f2u(v), c.w); // .x = scene-order id; the kernel maps it to the flat index
+      if (wt_best_get(W, rl) == key) wt_hit_put(W, rl, f2u(t), f2u(u), f2u(v), orig | (((c.w >> 24) & 0xfu) << 28)); // the result record, with the SCENE-ORDER id: the kernel maps it to the flat index
     }
   }
 }
@@ -663,8 +519,7 @@ __device__ __forceinline__ bool wave_step2(RayTrav2& R, bool alive, WaveTri& W, 
   if (alive) {
     const unsigned long long key = wt_best_get(W, lane);
     R.tBest = u2f((uint32_t)(key >> 32));
-    R.found = (uint32_t)key != 0u;
-    if (ANYHIT && R.found) done = true;
+    if (ANYHIT && (uint32_t)key != 0u) done = true;
     else if (!(R.G.y & 0xff000000u)) {
       if (R.inst != NO_INSTANCE && R.sp == R.spBase) trav2_leave(R); // this instance's BLAS is exhausted
       if (R.sp == 0u) done = true;
