@@ -84,6 +84,31 @@ class GiCPrimvarData(C.Structure):
     _fields_ = [("name", C.c_char_p), ("type", C.c_int32), ("interpolation", C.c_int32), ("data", C.c_void_p), ("dataSize", C.c_uint64)]
 
 
+
+# asset reader / image loader hooks (include/gi_c.h: giCRegisterAssetReader, giCSetImageLoader)
+ASSET_OPEN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_char_p)
+ASSET_SIZE = C.CFUNCTYPE(C.c_uint64, C.c_void_p, C.c_void_p)
+ASSET_DATA = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p)
+ASSET_CLOSE = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+
+
+class GiCAssetReader(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("open", ASSET_OPEN), ("size", ASSET_SIZE), ("data", ASSET_DATA), ("close", ASSET_CLOSE)]
+
+
+class GiCDecodedImage(C.Structure):
+    _fields_ = [("format", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32), ("reserved", C.c_uint32), ("pixels", C.c_void_p), ("handle", C.c_void_p)]
+
+
+IMAGE_LOAD = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64, C.c_int32, C.POINTER(GiCDecodedImage))
+IMAGE_RELEASE = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(GiCDecodedImage))
+IMAGE_RGBA8_UNORM, IMAGE_RGB16_FLOAT, IMAGE_RGBA16_FLOAT, IMAGE_R32_FLOAT, IMAGE_RGBA32_FLOAT = 1, 2, 3, 4, 5
+
+
+class GiCImageLoader(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("load", IMAGE_LOAD), ("release", IMAGE_RELEASE)]
+
+
 SYMBOLS = [
     ("giCInitialize", C.c_int, [C.c_int]), ("giCInitializeDevices", C.c_int, [C.POINTER(C.c_int32), C.c_uint32]), ("giCGetDeviceCount", C.c_uint32, []), ("giCTerminate", None, []), ("giCGetLastError", C.c_char_p, []),
     ("giCCreateMaterial", _P, [_P, C.c_char_p, C.POINTER(GiCMaterialDesc)]), ("giCDestroyMaterial", None, [_P]),
@@ -110,6 +135,7 @@ SYMBOLS = [
     ("giCCreateTexture", _P, [_P, C.POINTER(GiCTextureDesc)]), ("giCDestroyTexture", None, [_P]),
     ("giCCreateTextureFromFile", _P, [_P, C.c_char_p, _I]),
     ("giCDebugDecodeImage", C.c_int, [C.c_char_p, _I, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _FP, C.c_uint64]),
+    ("giCRegisterAssetReader", None, [C.POINTER(GiCAssetReader)]), ("giCSetImageLoader", None, [C.POINTER(GiCImageLoader)]),
     ("giCSetMaterialTexture", C.c_int, [_P, _I, C.POINTER(GiCTextureBinding)]),
     ("giCSetMaterialTextureTransform", C.c_int, [_P, _I, _FP]),
     ("giCSetMeshPrimvars", C.c_int, [_P, _U, C.POINTER(GiCPrimvarData)]), ("giCSetMeshInstancerPrimvars", C.c_int, [_P, _U, C.POINTER(GiCPrimvarData)]),

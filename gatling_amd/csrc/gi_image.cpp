@@ -332,13 +332,10 @@ static bool decodeJpeg(const std::vector<uint8_t>& d, bool srgbToLinear, uint32_
 
 } // namespace
 
-bool loadImageFile(const char* path, bool srgbToLinear, uint32_t& w, uint32_t& h, std::vector<float>& out)
+bool decodeImageBytes(const uint8_t* bytes, size_t size, bool srgbToLinear, uint32_t& w, uint32_t& h, std::vector<float>& out)
 {
-  FILE* f = fopen(path, "rb");
-  if (!f) return false;
-  std::vector<uint8_t> d;
-  { uint8_t buf[65536]; size_t n; while ((n = fread(buf, 1, sizeof(buf), f)) > 0) d.insert(d.end(), buf, buf + n); }
-  fclose(f);
+  if (!bytes || size < 4) return false;
+  const std::vector<uint8_t> d(bytes, bytes + size);
   try {
     bool ok;
     if (d.size() >= 8 && d[0] == 0x89 && d[1] == 'P') ok = decodePng(d, srgbToLinear, w, h, out);
@@ -353,5 +350,17 @@ bool loadImageFile(const char* path, bool srgbToLinear, uint32_t& w, uint32_t& h
     return true;
   } catch (const std::exception&) { return false; } // allocation failure: the caller reports "cannot decode"
 }
+
+bool readFileBytes(const char* path, std::vector<uint8_t>& d)
+{
+  FILE* f = fopen(path, "rb");
+  if (!f) return false;
+  { uint8_t buf[65536]; size_t n; while ((n = fread(buf, 1, sizeof(buf), f)) > 0) d.insert(d.end(), buf, buf + n); }
+  fclose(f);
+  return true;
+}
+
+// 8-bit sRGB -> linear with the PNG decoder's arithmetic (an image handed over as RGBA8 by an external decoder equals the in-library decode of the same PNG bit for bit)
+float srgb8ToLinear(uint8_t v) { const float c = (float)v / 255.0f; return c <= 0.04045f ? c / 12.92f : powf((c + 0.055f) / 1.055f, 2.4f); }
 
 } // namespace gi

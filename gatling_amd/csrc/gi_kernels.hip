@@ -350,40 +350,35 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
 //   * the launch's rays are the queue's NSHARD shards, and shard k IS cursor range k: a claimed ray's record index is `shard * cap + position`,
 //     no search through the shard prefix sums;
 //   * everything wave-uniform (claims, chunk and ring bookkeeping) is forced into SGPRs with readfirstlane;
-//   * GI_DYN_NODES node visits per trip of the outer loop (refill test, ring flush test, result write and the loop-carried moves are paid once);
 //   * shadow walks (ANYHIT) end at their first hit, so near-to-far order buys them nothing: no octant flip in their node test.
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t DYN_CLAIM = 128;   // rays per cursor atomic (a device-scope atomic on one line completes ~88 times per microsecond; 64 / 256 / 512 measured: r04x)
 constexpr uint32_t DYN_FLUSH_AT = 8;  // the triangle ring is flushed below 64 pairs once this many finished walks wait for it (0 / 2 / 24 measured: r04c)
-#ifndef GI_DYN_NODES
-#define GI_DYN_NODES 2
-#endif
-constexpr uint32_t DYN_NODES = GI_DYN_NODES;
 #ifndef GI_DYN_WAVES
 #define GI_DYN_WAVES 5
+#endif
+#ifndef GI_DYN_STEAL
+#define GI_DYN_STEAL 1
+#endif
+constexpr uint32_t DYN_THIN_WALKERS = 8; // the ring is flushed at the end of every step while this few lanes walk (16: the same, r05d)
+#ifndef GI_DYN_SHADOW_ORDERED
+#define GI_DYN_SHADOW_ORDERED 0
 #endif
 
 template <bool TWO> struct DynRay { using type = RayWalk; };
 template <> struct DynRay<true> { using type = RayTrav2; };
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); } // wave-uniform by construction: keep it in an SGPR
 
-template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool CUTOUT, bool TWO = false>
-__device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t refill)
+// HELP: the instantiation with helper lanes (thin launches, below); a full launch runs the one without -- the bookkeeping alone (record and ring addresses computed from a
+// register instead of the lane number, the stack base) costs the full launches 3 - 6 % of their traversal time when it is compiled into their loop (r05g).
+template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool CUTOUT, bool TWO, bool HELP>
+__device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t refill, WaveTri& W,
+                                               uint32_t shardCount, uint32_t claim)
 {
   extern __shared__ uint4 s_dyn[];
   uint2 (*s_stack)[TRACE_BLOCK] = reinterpret_cast<uint2 (*)[TRACE_BLOCK]>(s_dyn);
-  __shared__ WaveTri s_wave[TRACE_BLOCK / 64];
-  WaveTri& W = s_wave[threadIdx.x >> 6];
   const uint32_t lane = __lane_id();
-  // rays of shard k (lane k keeps the count; read back with readlane where a range is entered)
   const uint32_t cap = qs.cap;
-  uint32_t shardCount = 0u;
-  if (lane < NSHARD) { const uint32_t c = cnt->count[qIn][lane].v; shardCount = c < cap ? c : cap; } // (clamped: see Counters::overflow)
-  if (blockIdx.x == 0 && threadIdx.x < 64u) { // single writer per launch
-    uint32_t n = shardCount;
-    for (int off = 4; off > 0; off >>= 1) n += __shfl_down(n, off);
-    if (threadIdx.x == 0) { if (ANYHIT) cnt->shadowRays += n; else cnt->segments += n; }
-  }
   PaddedCounter* cursors = cnt->cursor[ANYHIT ? 1 : 0];
   TraceCounters tc{0u, 0u};
   typename DynRay<TWO>::type R;
@@ -405,9 +400,9 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
     while (claimLeft == 0u && rangesTried < NCURSOR) {
       const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)shardCount, (int)range);
       uint32_t b = 0xffffffffu;
-      if (lane == 0u && hi != 0u) b = atomicAdd(&cursors[range].v, DYN_CLAIM);
+      if (lane == 0u && hi != 0u) b = atomicAdd(&cursors[range].v, claim);
       b = uni(b);
-      if (b < hi) { claimBase = b; claimLeft = (hi - b) < DYN_CLAIM ? ((hi - b + 63u) & ~63u) : DYN_CLAIM; rangeEnd = hi; rangesTried = 0u; }
+      if (b < hi) { claimBase = b; claimLeft = (hi - b) < claim ? ((hi - b + 63u) & ~63u) : claim; rangeEnd = hi; rangesTried = 0u; }
       else { range = (range + 1u) % NCURSOR; rangesTried++; }
     }
     chunkCount = 0u; chunkUsed = 0u;
@@ -426,6 +421,17 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
       }
     }
   };
+  // A ray's walk can be shared (flat layout): once the wave has nothing left to claim, lanes without a ray HELP the longest walks instead of idling -- a helper takes
+  // the bottom entry of a walking lane's traversal stack (the oldest deferred group, i.e. the largest subtree still to do), copies the ray and walks that part.  All
+  // lanes working on a ray report to the same LDS record (`key`: the lane that owns the ray -- the atomicMin hit key is order-independent, so the result does not
+  // change), pairs in the triangle ring name the owner (whose registers hold the ray until the end), and the owner's record counts its live helpers: the ray is
+  // finished when the owner's own walk has drained and that count is zero.  Why: a launch ends with its slowest ray, a 100-step ray outlives the average one six
+  // times over, and the thin launches of a low-spp frame (one sample per pixel and call is hdGatling's default) are NOTHING BUT that tail.  Only in thin launches:
+  // a helper walks far subtrees before the near hit that would have culled them is known, and in the tail of a full launch that extra work costs the waves that
+  // still have rays more than the tail shortens (r05f: trace +2.5 ... +5 % on C3 / C4 / C5 with helpers everywhere; a spp-1 frame -9 ... -16 % with them).
+  uint32_t keyReg = lane, base = 0u; // the lane whose LDS record this walk reports to; first stack entry that is still this walk's
+  bool helper = false;
+#define key (HELP ? keyReg : lane)
   next_chunk();
   for (;;) {
     const unsigned long long idle = __ballot(!alive);
@@ -443,12 +449,39 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
         if (!ANYHIT) ray_init(v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), ro.w, rdir.w);
         else ray_init(v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), 0.01f, ro.w); // shadow ray (rp_main.rgen:397-429)
         wave_ray_begin(W, R.tBest);
-        if (!ANYHIT) wt_hit_put(W, lane, f2u(R.tBest), f2u(ro.x), f2u(ro.y), MISS); // the result if nothing is hit: (tMax, origin) -- k_route needs them for scattering events (medium stacks only)
+        wt_hit_put(W, lane, f2u(ro.x), f2u(ro.y), MISS, 0u); // the result if nothing is hit: (tMax, origin.xy, MISS) -- k_route needs the origin for scattering events (medium stacks only); no helpers
         alive = true; draining = false; lastEnd = ringHead; // no pair of this ray is pending
+        keyReg = lane; base = 0u; helper = false;
       }
       chunkUsed += take;
       if (chunkUsed == chunkCount) next_chunk(); // loads complete while the wave keeps traversing
     } else if (nIdle == 64u) break; // nothing in flight and nothing left to claim (an exhausted chunk is replaced at once, so chunkUsed == chunkCount means there is none)
+    else if (HELP && chunkCount == 0u && nIdle != 0u) {
+      const unsigned long long donors = __ballot(alive && !draining && R.sp > base && base < STACK);
+      if (donors) {
+        // the k-th idle lane helps the k-th donor: donors leave their lane number in lane k (forward permute; the other lanes aim at lane 63, which no helper reads:
+        // with a non-donor in the wave there are at most 63 donors, ranks 0 .. 62)
+        const bool donor = alive && !draining && R.sp > base && base < STACK; // (entries beyond STACK live in the lane's scratch: OVERFLOW variants)
+        const uint32_t dRank = (uint32_t)__popcll(donors & ((1ull << lane) - 1ull)), tRank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+        const uint32_t compact = (uint32_t)__builtin_amdgcn_ds_permute((int)((donor ? dRank : 63u) << 2), (int)lane);
+        const uint32_t nPairs = (uint32_t)__popcll(donors) < nIdle ? (uint32_t)__popcll(donors) : nIdle;
+        const bool thief = !alive && tRank < nPairs;
+        const int from = (int)(uint32_t)__builtin_amdgcn_ds_bpermute((int)(tRank << 2), (int)compact); // (all lanes: wave-uniform control flow; only thieves use it)
+        const uint32_t dBase = (uint32_t)__shfl((int)base, from), dKey = (uint32_t)__shfl((int)key, from);
+        const V3 o = v3(__shfl(R.o.x, from), __shfl(R.o.y, from), __shfl(R.o.z, from)), d = v3(__shfl(R.d.x, from), __shfl(R.d.y, from), __shfl(R.d.z, from));
+        const float idx = __shfl(R.idx, from), idy = __shfl(R.idy, from), idz = __shfl(R.idz, from), tMin = __shfl(R.tMin, from), tBest = __shfl(R.tBest, from);
+        const uint32_t octinv = (uint32_t)__shfl((int)R.octinv, from), drng = CUTOUT ? (uint32_t)__shfl((int)rng, from) : 0u;
+        // a donor that was paired gives up its bottom entry (its rank is below the number of pairs)
+        if (donor && dRank < nPairs) base++;
+        if (thief) {
+          R.o = o; R.d = d; R.idx = idx; R.idy = idy; R.idz = idz; R.tMin = tMin; R.tBest = tBest; R.octinv = octinv; rng = drng;
+          R.G = s_stack[dBase][(threadIdx.x & ~63u) + (uint32_t)from]; // (bottom entries live in LDS for every STACK / OVERFLOW variant)
+          R.sp = 0u; base = 0u; keyReg = dKey; helper = true;
+          wt_helpers_add(W, key, 1u);
+          alive = true; draining = false; lastEnd = ringHead;
+        }
+      }
+    }
     bool done = false;
     if constexpr (TWO) done = wave_step2<ANYHIT, COUNT, CUTOUT>(R, alive, W, sc, s_stack, tc, rng);
     else {
@@ -456,83 +489,85 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
       // ran the ~110-instruction batch at a third of its lanes.  A batch runs when 64 pairs are pending; the rest waits.  A ray whose walk has ended while pairs of it are
       // still pending is DRAINING: its lane keeps the ray (a pending pair fetches the ray from its owner lane at batch time) and sits out the node phases until the ring
       // has moved past its last pair (the ring is FIFO: `head` has reached `lastEnd`).  The ring is flushed below 64 pairs when DYN_FLUSH_AT or more lanes are blocked like
-      // that, or when no lane walks.  Results do not depend on any of this (the hit key under atomicMin does not depend on when a pair is tested); only the culling distance
+      // that, or when few lanes walk.  Results do not depend on any of this (the hit key under atomicMin does not depend on when a pair is tested); only the culling distance
       // a walking ray sees may lag by a step or two.
-      auto batch = [&](uint32_t n) { wave_tri_batch<COUNT, false, CUTOUT, !ANYHIT>(W, ringHead, n, R, rng, sc, nullptr, 0u, tc); ringHead += n; };
-#pragma unroll
-      for (uint32_t rep = 0; rep < DYN_NODES; rep++) {
-        const bool walking = alive && !draining;
-        uint2 Gt = make_uint2(0u, 0u);
-        if (walking) Gt = trav_node<COUNT, STACK, OVERFLOW, false, !ANYHIT>(R, sc, nullptr, 0u, s_stack, overflow, tc);
-        // positions from a wave prefix sum over the per-lane pair counts, then every lane writes its own pairs
-        const uint32_t cntL = (uint32_t)__popc(Gt.y);
-        const uint32_t scan = wave_scan_inclusive(cntL);
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)scan, 63);
-        if (total != 0u) {
-          if ((ringTail - ringHead) + total <= 128u) {
-            uint32_t pos = ringTail + scan - cntL;
-            if (cntL) lastEnd = pos + cntL;
-            while (Gt.y) {
-              const uint32_t k = (uint32_t)__ffs((int)Gt.y) - 1u;
-              Gt.y &= Gt.y - 1u;
-              wt_queue_put(W, pos & 127u, (lane << TRI_ID_BITS) | (Gt.x + k));
-              pos++;
-            }
-            ringTail += total;
-            while (ringTail - ringHead >= 64u) batch(64u);
-          } else for (;;) { // (more pairs than the ring has room for) one ballot round per triangle; a batch as soon as 64 pairs are pending (<= 63 + 64 <= the ring's 128 entries)
-            const unsigned long long m = __ballot(Gt.y != 0u);
-            if (!m) break;
-            const bool push = Gt.y != 0u;
-            if (push) {
-              const uint32_t k = (uint32_t)__ffs((int)Gt.y) - 1u;
-              Gt.y &= Gt.y - 1u;
-              wt_queue_put(W, (ringTail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & 127u, (lane << TRI_ID_BITS) | (Gt.x + k));
-            }
-            ringTail += (uint32_t)__popcll(m);
-            if (push) lastEnd = ringTail;
-            if (ringTail - ringHead >= 64u) batch(64u);
+      auto batch = [&](uint32_t n) { wave_tri_batch<COUNT, false, CUTOUT, true>(W, ringHead, n, R, rng, sc, nullptr, 0u, tc); ringHead += n; };
+      const bool walking = alive && !draining;
+      uint2 Gt = make_uint2(0u, 0u);
+      if (walking) Gt = trav_node<COUNT, STACK, OVERFLOW, false, !ANYHIT || GI_DYN_SHADOW_ORDERED>(R, sc, nullptr, 0u, s_stack, overflow, tc);
+      // positions from a wave prefix sum over the per-lane pair counts, then every lane writes its own pairs
+      const uint32_t cntL = (uint32_t)__popc(Gt.y);
+      const uint32_t scan = wave_scan_inclusive(cntL);
+      const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)scan, 63);
+      if (total != 0u) {
+        const uint32_t tag = key << TRI_ID_BITS;
+        if ((ringTail - ringHead) + total <= 128u) {
+          uint32_t pos = ringTail + scan - cntL;
+          if (cntL) lastEnd = pos + cntL;
+          while (Gt.y) {
+            const uint32_t k = (uint32_t)__ffs((int)Gt.y) - 1u;
+            Gt.y &= Gt.y - 1u;
+            wt_queue_put(W, pos & 127u, tag | (Gt.x + k));
+            pos++;
           }
+          ringTail += total;
+          while (ringTail - ringHead >= 64u) batch(64u);
+        } else for (;;) { // (more pairs than the ring has room for) one ballot round per triangle; a batch as soon as 64 pairs are pending (<= 63 + 64 <= the ring's 128 entries)
+          const unsigned long long m = __ballot(Gt.y != 0u);
+          if (!m) break;
+          const bool push = Gt.y != 0u;
+          if (push) {
+            const uint32_t k = (uint32_t)__ffs((int)Gt.y) - 1u;
+            Gt.y &= Gt.y - 1u;
+            wt_queue_put(W, (ringTail + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & 127u, tag | (Gt.x + k));
+          }
+          ringTail += (uint32_t)__popcll(m);
+          if (push) lastEnd = ringTail;
+          if (ringTail - ringHead >= 64u) batch(64u);
         }
-        // the walk moves on (a closest-hit walk's pop does not depend on tBest; a shadow walk ends at the first hit the batches have reported so far)
-        if (walking) {
-          if (!ANYHIT) { if (trav_pop<STACK, OVERFLOW>(R, s_stack, overflow)) draining = true; }
-          else if (rep + 1u < DYN_NODES) { if (wt_best_id(W, lane) != 0u || trav_pop<STACK, OVERFLOW>(R, s_stack, overflow)) draining = true; }
-        }
-        if (rep + 1u < DYN_NODES && !__ballot(alive && !draining)) break;
       }
+      // the walk moves on before the ring is looked at (a closest-hit walk's pop does not depend on tBest)
+      if (!ANYHIT && walking && trav_pop<STACK, OVERFLOW>(R, s_stack, overflow, HELP ? base : 0u)) draining = true;
       if (ringTail != ringHead) {
         const unsigned long long blocked = __ballot(alive && draining && (int)(ringHead - lastEnd) < 0);
-        const bool nobodyWalks = __ballot(alive && !draining) == 0ull;
-        if ((uint32_t)__popcll(blocked) >= DYN_FLUSH_AT || nobodyWalks) batch(ringTail - ringHead);
+        // (a wave with few walks left -- the tail of a launch, or all of a thin launch -- fills the ring slowly: waiting for 64 pairs there only delays the
+        // distance its walks cull with, and with it the launch's last ray; r05d: C3 trace -3 %, shadow -8 %, a spp-1 frame -20 %)
+        const uint32_t walkers = (uint32_t)__popcll(__ballot(alive && !draining));
+        if ((uint32_t)__popcll(blocked) >= DYN_FLUSH_AT || walkers <= DYN_THIN_WALKERS) batch(ringTail - ringHead);
       }
       // every ray picks up what the batches of this step found
       if (alive) {
-        if (!ANYHIT) R.tBest = u2f(wt_best_t(W, lane));
-        else if (!draining && (wt_best_id(W, lane) != 0u || trav_pop<STACK, OVERFLOW>(R, s_stack, overflow))) draining = true;
+        if (!ANYHIT) R.tBest = u2f(wt_best_t(W, key));
+        else if (!draining && (wt_best_id(W, key) != 0u || trav_pop<STACK, OVERFLOW>(R, s_stack, overflow, HELP ? base : 0u))) draining = true; // a shadow walk ends at the first hit
         done = draining && (int)(ringHead - lastEnd) >= 0;
       }
     }
-    if (alive && done) { // the ray's result, written in place over its record
-      alive = false;
-      if (!ANYHIT) {
-        // ONE 16-byte store per finished ray: the batches left the finished record in LDS (material class in the top four bits of the triangle word; until r04 the
-        // material word went into b.w as a second store into another line: C3 85 GB of write traffic per frame for 26 GB of results)
-        uint4 h = wt_hit_get(W, lane);
-        if constexpr (TWO) { if (h.w != MISS) h.w = sc.flatOfOrig[h.w & 0x0fffffffu] | (h.w & 0xf0000000u); } // scene-order id -> index of the hit's TriRec
-        st4(&qs.a[qIn][rec], u2f(h.x), u2f(h.y), u2f(h.z), u2f(h.w));
-        if (sc.mediumStackSize && h.w == MISS) { V3 wo = R.o; if constexpr (TWO) wo = R.wo; reinterpret_cast<float*>(&qs.b[qIn][rec])[3] = wo.z; }
-      } else {
-        const bool found = wt_best_id(W, lane) != 0u;
-        const uint32_t slot = qs.slot[qIn][rec];
-        F4 nc = F4{0.0f, 0.0f, 0.0f, 0.0f}; // (neeContrib, 1 = emitted at bounce 0)
-        if (!found || st.neeKey) nc = ld4(&qs.c[qIn][rec]);
-        if (!found) {
-          Slot* S = &st.slots[slot];
-          F4 rr = ld4(&S->rad);
-          st4(&S->rad, rr.x + nc.x, rr.y + nc.y, rr.z + nc.z, rr.w);
+    if (alive && done) {
+      if (HELP && helper) { alive = false; wt_helpers_add(W, key, 0xffffffffu); } // this part of the ray is done; the owner writes the result
+      else {
+        const uint4 h = wt_hit_get(W, lane); // (u, v, triangle | class << 28) or (origin.xy, MISS); .w: helpers still walking parts of this ray
+        if (!HELP || h.w == 0u) { // the ray's result, written in place over its record
+          alive = false;
+          if (!ANYHIT) {
+            // ONE 16-byte store per finished ray: the batches left the finished record in LDS (material class in the top four bits of the triangle word; until r04 the
+            // material word went into b.w as a second store into another line: C3 85 GB of write traffic per frame for 26 GB of results)
+            uint32_t word = h.z;
+            if constexpr (TWO) { if (word != MISS) word = sc.flatOfOrig[word & 0x0fffffffu] | (word & 0xf0000000u); } // scene-order id -> index of the hit's TriRec
+            st4(&qs.a[qIn][rec], R.tBest, u2f(h.x), u2f(h.y), u2f(word));
+            if (sc.mediumStackSize && word == MISS) { V3 wo = R.o; if constexpr (TWO) wo = R.wo; reinterpret_cast<float*>(&qs.b[qIn][rec])[3] = wo.z; }
+          } else {
+            const bool found = wt_best_id(W, lane) != 0u;
+            const uint32_t slot = qs.slot[qIn][rec];
+            F4 nc = F4{0.0f, 0.0f, 0.0f, 0.0f}; // (neeContrib, 1 = emitted at bounce 0)
+            if (!found || st.neeKey) nc = ld4(&qs.c[qIn][rec]);
+            if (!found) {
+              Slot* S = &st.slots[slot];
+              F4 rr = ld4(&S->rad);
+              st4(&S->rad, rr.x + nc.x, rr.y + nc.y, rr.z + nc.z, rr.w);
+            }
+            if (st.neeKey && nc.w != 0.0f) nee_aov_record(st, slot, found);
+          }
         }
-        if (st.neeKey && nc.w != 0.0f) nee_aov_record(st, slot, found);
       }
     }
   }
@@ -543,16 +578,41 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
   }
 }
 
+#undef key
+// what every wave of a k_trace_dyn launch does first: the ray counts of the queue's shards (lane k keeps shard k's; read back with readlane where a range is entered),
+// the launch's total (one writer adds it to the frame's statistics), and the rays per cursor atomic -- DYN_CLAIM while every wave of the launch can have a claim of its own;
+// below that 64, so that the rays spread over twice as many waves: a launch lasts as long as its slowest wave, and in the thin launches of a low-spp frame
+// (hdGatling's default is ONE sample per pixel and call) that is all it lasts
+template <bool ANYHIT>
+__device__ __forceinline__ void trace_dyn_prologue(const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t& shardCount, uint32_t& claim)
+{
+  const uint32_t lane = __lane_id(), cap = qs.cap;
+  shardCount = 0u;
+  if (lane < NSHARD) { const uint32_t c = cnt->count[qIn][lane].v; shardCount = c < cap ? c : cap; } // (clamped: see Counters::overflow)
+  uint32_t nRays = shardCount;
+  for (int off = 4; off > 0; off >>= 1) nRays += __shfl_down(nRays, off);
+  nRays = uni(nRays);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { if (ANYHIT) cnt->shadowRays += nRays; else cnt->segments += nRays; } // single writer per launch
+  claim = nRays >= gridDim.x * (TRACE_BLOCK / 64u) * DYN_CLAIM ? DYN_CLAIM : 64u;
+}
 template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool CUTOUT>
 __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(GI_DYN_WAVES, 8))) void k_trace_dyn(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t refill)
 {
-  trace_dyn_body<ANYHIT, COUNT, STACK, OVERFLOW, CUTOUT>(sc, st, qs, cnt, qIn, refill);
+  __shared__ WaveTri s_wave[TRACE_BLOCK / 64];
+  uint32_t shardCount, claim;
+  trace_dyn_prologue<ANYHIT>(qs, cnt, qIn, shardCount, claim);
+  // a THIN launch -- fewer rays than two chunks per wave -- lasts as long as its slowest ray, not as its throughput allows: its idle lanes help (trace_dyn_body)
+  if (GI_DYN_STEAL && claim == 64u) trace_dyn_body<ANYHIT, COUNT, STACK, OVERFLOW, CUTOUT, false, true>(sc, st, qs, cnt, qIn, refill, s_wave[threadIdx.x >> 6], shardCount, claim);
+  else trace_dyn_body<ANYHIT, COUNT, STACK, OVERFLOW, CUTOUT, false, false>(sc, st, qs, cnt, qIn, refill, s_wave[threadIdx.x >> 6], shardCount, claim);
 }
 // the two-level layout (wave_step2): 16 LDS stack entries, world + object-space ray in registers
 template <bool ANYHIT, bool COUNT, bool CUTOUT>
 __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_trace_dyn2(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t refill)
 {
-  trace_dyn_body<ANYHIT, COUNT, 16, false, CUTOUT, true>(sc, st, qs, cnt, qIn, refill);
+  __shared__ WaveTri s_wave[TRACE_BLOCK / 64];
+  uint32_t shardCount, claim;
+  trace_dyn_prologue<ANYHIT>(qs, cnt, qIn, shardCount, claim);
+  trace_dyn_body<ANYHIT, COUNT, 16, false, CUTOUT, true, false>(sc, st, qs, cnt, qIn, refill, s_wave[threadIdx.x >> 6], shardCount, claim);
 }
 
 // k_route: sorts k_trace_dyn's in-place results by outcome and material class (same routing as k_trace's epilogue)

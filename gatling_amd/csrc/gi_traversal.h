@@ -175,11 +175,12 @@ __device__ __forceinline__ uint2 trav_node(RayWalk& R, const SceneView& sc, cons
 
 // End of a step: when the current group has no unvisited internal child left, continue with the stack top.
 // Returns true when the traversal is finished.
+// `base`: the stack entries below it are no longer this walk's (k_trace_dyn: handed to helper lanes).
 template <uint32_t STACK, bool OVERFLOW>
-__device__ __forceinline__ bool trav_pop(RayWalk& R, uint2 (*s_stack)[TRACE_BLOCK], uint2 (&overflow)[OVERFLOW ? OVF_STACK : 1])
+__device__ __forceinline__ bool trav_pop(RayWalk& R, uint2 (*s_stack)[TRACE_BLOCK], uint2 (&overflow)[OVERFLOW ? OVF_STACK : 1], uint32_t base = 0u)
 {
   if (R.G.y & 0xff000000u) return false;
-  if (R.sp == 0u) return true;
+  if (R.sp == base) return true;
   const uint32_t sp = --R.sp;
   R.G = (!OVERFLOW || sp < STACK) ? s_stack[sp < STACK ? sp : STACK - 1u][threadIdx.x] : overflow[sp - STACK];
   return false;
@@ -247,7 +248,8 @@ __device__ __forceinline__ bool trav_step(RayTrav& R, const SceneView& sc, const
 constexpr uint32_t TRI_ID_BITS = 26; // queue entry = ray lane << 26 | triangle index (the host refuses scenes with >= 2^26 triangles)
 struct WaveTri {
   unsigned long long best[64]; // per ray lane: (t bits << 32) | (scene-order id + 1); low word 0 = no hit yet
-  uint4 hit[64];               // per ray lane: that hit as (triangle index, u bits, v bits, material word) -- k_trace_dyn: the finished result record (t, u, v, triangle | class << 28)
+  uint4 hit[64];               // per ray lane: that hit as (triangle index, u bits, v bits, material word) -- k_trace_dyn: (u, v, triangle | class << 28) of the finished result
+                               // record (its t is the key's upper word), and in .w the number of helper lanes walking parts of this ray
   uint32_t queue[128];         // ring of pending (ray lane, triangle) pairs (a 256-entry ring measured slower)
 };
 // WaveTri lives in LDS, but through a C++ reference the compiler only sees a generic pointer and emits FLAT loads / stores (vector-memory
@@ -265,6 +267,10 @@ __device__ __forceinline__ void wt_best_min(WaveTri& W, uint32_t i, unsigned lon
 { __hip_atomic_fetch_min((GI_LDS unsigned long long*)&((GI_LDS WaveTri*)&W)->best[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void wt_hit_put(WaveTri& W, uint32_t i, uint32_t x, uint32_t y, uint32_t z, uint32_t w)
 { gi_u4 v = {x, y, z, w}; *(volatile GI_LDS gi_u4*)&((GI_LDS WaveTri*)&W)->hit[i] = v; }
+typedef uint32_t gi_u3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ void wt_hit_put3(WaveTri& W, uint32_t i, uint32_t x, uint32_t y, uint32_t z) { gi_u3 v = {x, y, z}; *(volatile GI_LDS gi_u3*)&((GI_LDS WaveTri*)&W)->hit[i] = v; } // (leaves .w alone)
+__device__ __forceinline__ uint32_t wt_helpers_add(WaveTri& W, uint32_t i, uint32_t v)
+{ return __hip_atomic_fetch_add(&((GI_LDS uint32_t*)&((GI_LDS WaveTri*)&W)->hit[i])[3], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ uint4 wt_hit_get(WaveTri& W, uint32_t i) { const gi_u4 v = *(volatile GI_LDS gi_u4*)&((GI_LDS WaveTri*)&W)->hit[i]; return make_uint4(v.x, v.y, v.z, v.w); }
 
 // 64 (ray lane, triangle) pairs of the ring, one per lane.  RESULT_RECORD (k_trace_dyn): the winner leaves the ray's finished result record in WaveTri::hit.
@@ -298,7 +304,7 @@ __device__ __forceinline__ void wave_tri_batch(WaveTri& W, uint32_t head, uint32
       const unsigned long long key = ((unsigned long long)f2u(t) << 32) | (unsigned long long)(c.y + 1u);
       wt_best_min(W, rl, key);
       if (wt_best_get(W, rl) == key) {
-        if (RESULT_RECORD) wt_hit_put(W, rl, f2u(t), f2u(u), f2u(v), triIdx | (((c.w >> 24) & 0xfu) << 28)); // the material class k_route sorts by rides in the top four bits
+        if (RESULT_RECORD) wt_hit_put3(W, rl, f2u(u), f2u(v), triIdx | (((c.w >> 24) & 0xfu) << 28)); // the material class k_route sorts by rides in the top four bits
         else wt_hit_put(W, rl, triIdx, f2u(u), f2u(v), c.w);
       }
     }
@@ -479,7 +485,7 @@ __device__ __forceinline__ void wave_tri_batch2(WaveTri& W, uint32_t head, uint3
     if (accept) {
       const unsigned long long key = ((unsigned long long)f2u(t) << 32) | (unsigned long long)(orig + 1u);
       wt_best_min(W, rl, key);
-      if (wt_best_get(W, rl) == key) wt_hit_put(W, rl, f2u(t), f2u(u), f2u(v), orig | (((c.w >> 24) & 0xfu) << 28)); // the result record, with the SCENE-ORDER id: the kernel maps it to the flat index
+      if (wt_best_get(W, rl) == key) wt_hit_put3(W, rl, f2u(u), f2u(v), orig | (((c.w >> 24) & 0xfu) << 28)); // the result record, with the SCENE-ORDER id: the kernel maps it to the flat index
     }
   }
 }

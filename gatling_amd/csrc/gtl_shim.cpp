@@ -385,7 +385,20 @@ namespace gtl
     return giCInitialize(dev ? atoi(dev) : 0) == GI_C_OK ? GiStatus::Ok : GiStatus::Error;
   }
   void giTerminate() { giCTerminate(); }
-  void giRegisterAssetReader(GiAssetReader* reader) { s_assetReader = reader; }
+  // Gi.h:201.  The reference hands the reader to its texture manager, which opens EVERY image through it (TextureManager.cpp:39-52; hdGatling's is backed by ArResolver,
+  // rendererPlugin.cpp:95-143, 189): the C++ object becomes the C ABI's four callbacks.
+  void giRegisterAssetReader(GiAssetReader* reader)
+  {
+    s_assetReader = reader;
+    if (!reader) { giCRegisterAssetReader(nullptr); return; }
+    GiCAssetReader r{};
+    r.user = reader;
+    r.open = [](void* u, const char* path) -> void* { return static_cast<GiAssetReader*>(u)->open(path); };
+    r.size = [](void* u, void* a) -> uint64_t { return (uint64_t)static_cast<GiAssetReader*>(u)->size(static_cast<GiAsset*>(a)); };
+    r.data = [](void* u, void* a) -> const void* { return static_cast<GiAssetReader*>(u)->data(static_cast<GiAsset*>(a)); };
+    r.close = [](void* u, void* a) { static_cast<GiAssetReader*>(u)->close(static_cast<GiAsset*>(a)); };
+    giCRegisterAssetReader(&r);
+  }
 
   static GiMaterial* makeMaterial(GiScene* scene, const char* name, const GiCMaterialDesc& d, const std::string (&primvars)[GI_C_TEX_SLOT_COUNT], const ImageInput (&images)[GI_C_TEX_SLOT_COUNT])
   {

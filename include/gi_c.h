@@ -215,8 +215,42 @@ GiCTexture* giCCreateTexture(GiCScene* scene, const GiCTextureDesc* desc);
  * a (path, srgbToLinear) pair that is already loaded and alive returns the SAME handle with one more reference (the file cache of
  * TextureManager.cpp:100-150); giCDestroyTexture releases one reference */
 GiCTexture* giCCreateTextureFromFile(GiCScene* scene, const char* filePath, int32_t srgbToLinear);
-/* [ext] the decoder alone (no device needed; tests): returns 1 and fills width/height (+ rgba if it holds width*height*4 floats) */
+/* [ext] the decoder alone (no device needed; tests): returns 1 and fills width/height (+ rgba if it holds width*height*4 floats).  Goes through the registered
+ * asset reader and image loader like giCCreateTextureFromFile / giCCreateDomeLight do. */
 int giCDebugDecodeImage(const char* filePath, int32_t srgbToLinear, uint32_t* width, uint32_t* height, float* rgba, uint64_t rgbaFloats);
+
+/* Asset reader -- replaces gtl::GiAssetReader (/root/reference/src/gi/gtl/gi/Gi.h:186-194, giRegisterAssetReader :201).  The reference reads EVERY image through it
+ * (TextureManager.cpp:39-52 `_ReadImage`: open -> size -> data -> decode -> close; hdGatling registers an ArResolver-backed one, rendererPlugin.cpp:95-143, 189), so
+ * paths a plain fopen cannot serve -- usdz package members, URI resolvers, search-path relative names -- load.  With a reader registered the library opens image
+ * `filePath`s (giCCreateTextureFromFile, giCCreateDomeLight, giCDebugDecodeImage) through it and never touches the file system for them; with none (the default, or
+ * after giCRegisterAssetReader(NULL)) it reads the file itself.  The struct is copied.  `open` returns an opaque asset or NULL; `data` stays valid until `close`. */
+typedef struct GiCAssetReader {
+  void* user;
+  void* (*open)(void* user, const char* path);
+  uint64_t (*size)(void* user, void* asset);
+  const void* (*data)(void* user, void* asset);
+  void (*close)(void* user, void* asset);
+} GiCAssetReader;
+void giCRegisterAssetReader(const GiCAssetReader* reader);
+
+/* Image loader hook -- the reference decodes image bytes with imgio (`ImgioLoadImage(data, size, &img, flags)`, TextureManager.cpp:48; PNG, JPEG incl. progressive,
+ * EXR, HDR, TIFF), which is outside this library (imgio stays as-is on the reference side).  The library's own decoders cover .png, baseline .jpg,
+ * .hdr and .pfm; a registered loader is asked FIRST for every image (bytes from the asset reader or the file), so a host that has imgio hands EXR / TIFF / progressive
+ * JPEG over through it.  `load` returns 1 and fills `out` (pixels in imgio's orientation: row 0 = the picture's BOTTOM scanline) or 0 = "not mine", in which case the
+ * in-library decoders are tried; `release` is called once for every successful `load` after the pixels have been copied.  keepHdr mirrors ImgioLoadFlags::KeepHdr
+ * (set for dome lights, Gi.cpp:2215-2230).  8-bit data is unorm; the sRGB EOTF is applied by the library when the texture was created with srgbToLinear. */
+#define GI_C_IMAGE_RGBA8_UNORM 1   /* imgio ImgioFormat::RGBA8_UNORM  */
+#define GI_C_IMAGE_RGB16_FLOAT 2   /*       ImgioFormat::RGB16_FLOAT  */
+#define GI_C_IMAGE_RGBA16_FLOAT 3  /*       ImgioFormat::RGBA16_FLOAT */
+#define GI_C_IMAGE_R32_FLOAT 4     /*       ImgioFormat::R32_FLOAT    */
+#define GI_C_IMAGE_RGBA32_FLOAT 5  /* [ext] */
+typedef struct GiCDecodedImage { uint32_t format, width, height, reserved; const void* pixels; void* handle; } GiCDecodedImage;
+typedef struct GiCImageLoader {
+  void* user;
+  int32_t (*load)(void* user, const char* path, const void* bytes, uint64_t size, int32_t keepHdr, GiCDecodedImage* out);
+  void (*release)(void* user, GiCDecodedImage* image);
+} GiCImageLoader;
+void giCSetImageLoader(const GiCImageLoader* loader); /* NULL: in-library decoders only (the default) */
 void giCDestroyTexture(GiCTexture* texture);
 
 /* texturable inputs of the closed-form materials (UsdUVTexture semantics: value = texel * scale + bias at the hit's st) */

@@ -377,3 +377,103 @@ def test_imgio_load_oriented_golden(name, ref):
         assert np.abs(got - np.int64(ref)).max() <= 1, got
     else:
         assert got.tolist() == ref, got
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Asset reader and image loader hooks (giCRegisterAssetReader / giCSetImageLoader): the reference reads EVERY image through the
+# registered GiAssetReader and decodes with imgio (/root/reference/src/gi/impl/TextureManager.cpp:39-52, rendererPlugin.cpp:95-143, 189)
+# ---------------------------------------------------------------------------------------------------------------
+class _MemoryAssets:
+    """A GiCAssetReader over a dict {path: bytes}: serves paths no fopen could (package-relative names, URIs)."""
+
+    def __init__(self, files):
+        self.files, self.open_assets, self.log = dict(files), {}, []
+        self._next = 1
+
+        def _open(user, path):
+            p = path.decode()
+            self.log.append(("open", p))
+            if p not in self.files:
+                return None
+            h = self._next; self._next += 1
+            self.open_assets[h] = C.create_string_buffer(self.files[p], len(self.files[p]))
+            return h
+
+        def _size(user, a):
+            return len(self.open_assets[a])
+
+        def _data(user, a):
+            return C.addressof(self.open_assets[a])
+
+        def _close(user, a):
+            self.log.append(("close", a)); del self.open_assets[a]
+
+        self.cbs = (capi.ASSET_OPEN(_open), capi.ASSET_SIZE(_size), capi.ASSET_DATA(_data), capi.ASSET_CLOSE(_close))
+        self.struct = capi.GiCAssetReader(None, *self.cbs)
+
+
+def _decode(L, path, srgb=0, n=64):
+    w, h = C.c_uint32(), C.c_uint32()
+    buf = (C.c_float * n)()
+    ok = L.giCDebugDecodeImage(path.encode(), srgb, C.byref(w), C.byref(h), buf, n)
+    return ok, w.value, h.value, np.ctypeslib.as_array(buf).copy()
+
+
+def test_asset_reader_serves_images_under_non_file_paths():
+    """With a reader registered every image path goes open -> size -> data -> close through it -- a name that is no file loads, and bit for
+    bit like the same bytes read from disk; a path the reader does not know fails (no fall-through to the file system)."""
+    L = capi.load_library()
+    g = os.path.join(ROOT, "tests", "golden", "imgio_4c")
+    disk = {n: _decode(L, os.path.join(g, n), srgb=1) for n in ("4c.png", "4c.hdr", "4c.jpg")}
+    assert all(d[0] == 1 for d in disk.values())
+    mem = _MemoryAssets({"usdz://scene.usdz[textures/" + n + "]": open(os.path.join(g, n), "rb").read() for n in disk})
+    L.giCRegisterAssetReader(C.byref(mem.struct))
+    try:
+        for n, ref in disk.items():
+            ok, w, h, px = _decode(L, "usdz://scene.usdz[textures/" + n + "]", srgb=1)
+            assert ok == 1 and (w, h) == ref[1:3] and np.array_equal(px.view(np.uint32), ref[3].view(np.uint32)), n
+        assert _decode(L, os.path.join(g, "4c.png"))[0] == 0  # the reader does not know the real file's path: not served
+        assert not mem.open_assets and sum(1 for e in mem.log if e[0] == "close") == 3  # every opened asset was closed
+    finally:
+        L.giCRegisterAssetReader(None)
+    assert _decode(L, os.path.join(g, "4c.png"))[0] == 1  # unregistered: direct file reads again
+
+
+def test_image_loader_hook_is_asked_first_and_can_decline():
+    """A registered loader decodes what the library cannot (here: a made-up "EXR") in imgio's formats, is released once per load, and a
+    0 return falls through to the in-library decoders."""
+    L = capi.load_library()
+    half = np.array([[0.5, 2.0, -1.0, 1.0], [65504.0, 6e-8, 0.0, 0.25]], np.float16)  # incl. the largest half and a subnormal
+    rgba8 = np.array([[10, 128, 255, 64]], np.uint8)
+    keep, calls = [], []
+
+    def _load(user, path, data, size, keep_hdr, out):
+        blob = C.string_at(data, size)
+        calls.append((path.decode(), blob[:4], keep_hdr))
+        if blob[:4] == b"EXR!":
+            arr = half if blob[4:5] == b"h" else rgba8
+            keep.append(arr)
+            out[0].format = capi.IMAGE_RGBA16_FLOAT if arr.dtype == np.float16 else capi.IMAGE_RGBA8_UNORM
+            out[0].width, out[0].height = arr.shape[0], 1
+            out[0].pixels = arr.ctypes.data
+            out[0].handle = len(keep)
+            return 1
+        return 0
+
+    released = []
+    loader = capi.GiCImageLoader(None, capi.IMAGE_LOAD(_load), capi.IMAGE_RELEASE(lambda user, img: released.append(img[0].handle)))
+    mem = _MemoryAssets({"a.exr": b"EXR!h", "b.exr": b"EXR!b", "c.png": open(os.path.join(ROOT, "tests", "golden", "imgio_4c", "4c.png"), "rb").read()})
+    L.giCRegisterAssetReader(C.byref(mem.struct)); L.giCSetImageLoader(C.byref(loader))
+    try:
+        ok, w, h, px = _decode(L, "a.exr")
+        assert ok == 1 and (w, h) == (2, 1) and np.array_equal(px[:8], half.astype(np.float32).ravel())
+        ok, w, h, px = _decode(L, "b.exr", srgb=1)
+        c = rgba8[0, :3] / np.float32(255.0)
+        lin = np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+        assert ok == 1 and (w, h) == (1, 1) and np.allclose(px[:3], lin, rtol=1e-6) and px[3] == np.float32(64) / np.float32(255)
+        ok, w, h, px = _decode(L, "c.png")  # declined by the loader: the in-library PNG decoder takes it
+        assert ok == 1 and (w, h) == (2, 2)
+        assert released == [1, 2] and [c[0] for c in calls] == ["a.exr", "b.exr", "c.png"]
+    finally:
+        L.giCSetImageLoader(None); L.giCRegisterAssetReader(None)
+    assert _decode(L, os.path.join(ROOT, "tests", "golden", "imgio_4c", "4c.png"))[0] == 1
