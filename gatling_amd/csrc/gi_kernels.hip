@@ -396,6 +396,8 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
   uint32_t chunkCount = 0u, chunkUsed = 0u;
   uint32_t range = uni((blockIdx.x * (TRACE_BLOCK / 64u) + (threadIdx.x >> 6)) % NCURSOR), rangesTried = 0u, rangeEnd = 0u;
   uint32_t claimBase = 0u, claimLeft = 0u;
+  // (End of a launch: every wave finds its shard dry and walks the other cursors, 8 atomics per wave.  Publishing "dry" bits on a line of their own and reading them first
+  // saves those atomics and changed no launch time, r05k: not built in.)
   auto next_chunk = [&]() {
     while (claimLeft == 0u && rangesTried < NCURSOR) {
       const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)shardCount, (int)range);
@@ -584,7 +586,7 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
 // below that 64, so that the rays spread over twice as many waves: a launch lasts as long as its slowest wave, and in the thin launches of a low-spp frame
 // (hdGatling's default is ONE sample per pixel and call) that is all it lasts
 template <bool ANYHIT>
-__device__ __forceinline__ void trace_dyn_prologue(const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t& shardCount, uint32_t& claim)
+__device__ __forceinline__ bool trace_dyn_prologue(const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t& shardCount, uint32_t& claim)
 {
   const uint32_t lane = __lane_id(), cap = qs.cap;
   shardCount = 0u;
@@ -594,13 +596,17 @@ __device__ __forceinline__ void trace_dyn_prologue(const QueueSet& qs, Counters*
   nRays = uni(nRays);
   if (blockIdx.x == 0 && threadIdx.x == 0) { if (ANYHIT) cnt->shadowRays += nRays; else cnt->segments += nRays; } // single writer per launch
   claim = nRays >= gridDim.x * (TRACE_BLOCK / 64u) * DYN_CLAIM ? DYN_CLAIM : 64u;
+  // Waves the launch has no chunk for leave at once, without touching the cursors: every wave that stays walks all NSHARD cursors before it gives up, and a device-scope
+  // atomic on one line completes ~88 times per microsecond -- 8 192 waves x 8 cursors were a 0.1 ms floor under every launch that held any ray at all, i.e. under each of
+  // the 13 thin launches of a spp-1 frame (r05: C4 233 rays, 0.146 ms).  ceil(n / 64) chunks + one ragged chunk per shard; the waves that stay claim until every shard is dry.
+  return (blockIdx.x * (TRACE_BLOCK / 64u) + (threadIdx.x >> 6)) < (nRays + 63u) / 64u + NSHARD;
 }
 template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool CUTOUT>
 __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(GI_DYN_WAVES, 8))) void k_trace_dyn(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t refill)
 {
   __shared__ WaveTri s_wave[TRACE_BLOCK / 64];
   uint32_t shardCount, claim;
-  trace_dyn_prologue<ANYHIT>(qs, cnt, qIn, shardCount, claim);
+  if (!trace_dyn_prologue<ANYHIT>(qs, cnt, qIn, shardCount, claim)) return;
   // a THIN launch -- fewer rays than two chunks per wave -- lasts as long as its slowest ray, not as its throughput allows: its idle lanes help (trace_dyn_body)
   if (GI_DYN_STEAL && claim == 64u) trace_dyn_body<ANYHIT, COUNT, STACK, OVERFLOW, CUTOUT, false, true>(sc, st, qs, cnt, qIn, refill, s_wave[threadIdx.x >> 6], shardCount, claim);
   else trace_dyn_body<ANYHIT, COUNT, STACK, OVERFLOW, CUTOUT, false, false>(sc, st, qs, cnt, qIn, refill, s_wave[threadIdx.x >> 6], shardCount, claim);
@@ -611,7 +617,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 
 {
   __shared__ WaveTri s_wave[TRACE_BLOCK / 64];
   uint32_t shardCount, claim;
-  trace_dyn_prologue<ANYHIT>(qs, cnt, qIn, shardCount, claim);
+  if (!trace_dyn_prologue<ANYHIT>(qs, cnt, qIn, shardCount, claim)) return;
   trace_dyn_body<ANYHIT, COUNT, 16, false, CUTOUT, true, false>(sc, st, qs, cnt, qIn, refill, s_wave[threadIdx.x >> 6], shardCount, claim);
 }
 

@@ -290,7 +290,8 @@ __device__ __forceinline__ void wave_tri_batch(WaveTri& W, uint32_t head, uint32
   if (act) {
     uint4 a, b, c;
     // (the compiler loads c.x here and sinks the loads of c.y -- scene-order id -- and c.w -- material word -- into the accept branch; loading all 48 bytes
-    // up front measured SLOWER, r03a: the vector-memory request path, not the dependent round trip, is what the batch waits for)
+    // up front measured SLOWER in full launches, r03a: the vector-memory request path, not the dependent round trip, is what the batch waits for -- and no faster in
+    // thin ones, r05i)
     if (ALL_LDS || triIdx < ldsTris) { const uint4* p = s_tris + triIdx * 3u; a = p[0]; b = p[1]; c = p[2]; }
     else { const uint4* p = reinterpret_cast<const uint4*>(sc.tris) + (size_t)triIdx * 4u; a = p[0]; b = p[1]; c = p[2]; }
     if (COUNT) tc.tris++;
