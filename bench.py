@@ -19,8 +19,8 @@ separate `--pmc` passes of this same workload, calibrated with tools/pmc_calib.h
 `algorithmic_frac` is the SURVEY 8d canonical-bytes figure (it counts node / triangle bytes whether they come from HBM, L2 or LDS, so it can exceed 1).  The VALU
 side is reported in wall-clock terms against ceilings MEASURED by tools/valu_calib.hip (profiles/valu_issue_calibration.json): `valu_instr_per_simd_per_ns`,
 `valu_frac` = that / the dual-issue ceiling (alternating instruction classes, ~1.04), `valu_frac_fp32_only` = that / the single-class ceiling (~0.59).  `bound` names
-the nearer of the two rooflines; `bound_note` says what was measured beyond that (the big-scene traversal follows its instruction count one to one,
-profiles/r04k_valu_sensitivity.txt, with no instruction class near its own ceiling, profiles/r04r_valu_mix.txt: DESIGN.md section 4).
+the nearer of the two rooflines as THIS run measured them; `bound_note` is set when neither is near; `prior_experiment_note` names what earlier calibration runs found for the
+kernel family (the big-scene traversal followed its instruction count one to one, profiles/r04k_valu_sensitivity.txt) -- a citation, not a result of the run.
 
 At N = 1 the default line carries, under `also`, compact objects for configs C3 and C4 -- the wavefront pipeline (k_raygen / k_trace_dyn / k_route / k_shade /
 k_trace_dyn<any>) -- and for `c5share`, one rank's share of C5's 8-GPU partition at full spp (`projected_8gpu` = 8 x its rate), each with its own roofline fractions;
@@ -197,7 +197,31 @@ def reference_probe():
         if r.returncode != 0 or not m:
             return {"status": f"failed: rc {r.returncode}"}
         times.append(float(m.group(1)))
-    return {"status": "timed", "value": round(1920 * 1080 * 16 / times[1] / 1e6, 4), "unit": "Msamples/s", "sample": "cornell 1920x1080 spp=16, second run", "cores": os.cpu_count()}
+    out = {"status": "timed", "value": round(1920 * 1080 * 16 / times[1] / 1e6, 4), "unit": "Msamples/s", "sample": "cornell 1920x1080 spp=16, second run", "cores": os.cpu_count()}
+    out["image_comparison"] = reference_image_comparison("/tmp/gatling_ref.png", 16)
+    return out
+
+
+def reference_image_comparison(ref_png, spp):
+    """SURVEY 8d(ii) on the image the reference just wrote: our C2 frame at the same spp, twice with disjoint sample offsets (the second through progressive
+    accumulation: B = 2 x accumulated - A), against the reference's sRGB8 file -- RMSE vs 2 x our Monte-Carlo standard error, mean luminance within 0.5 %, and the
+    reference's own differing-byte count (tools/compare_reference.py)."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import compare_reference as cr
+        from gatling_amd import capi
+        from gatling_amd.scene import RenderSettings
+        from gatling_amd.scenes import cornell_box
+        ref, is8 = cr.load_image(ref_png)
+        scene = capi.Scene(cornell_box())
+        rs = RenderSettings(spp=spp, max_bounces=8)  # progressive accumulation on: the second call renders samples [spp, 2 spp) and blends
+        a = scene.render(rs, 1920, 1080).copy()
+        acc = scene.render(rs, 1920, 1080).copy()
+        scene.close()
+        r = cr.compare(a, 2.0 * acc - a, ref, is8)
+        return {k: r[k] for k in ("pass", "rmse", "standard_error", "rmse_over_standard_error", "mean_luminance_rel_error", "srgb8_differing_bytes", "srgb8_bytes", "tolerance")}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:200]}
 
 
 def main():
@@ -407,15 +431,13 @@ def main():
                         if roofline.get("valu_frac") is not None and roofline["frac"] is not None:
                             # the larger of the two fractions names the nearer roofline; when both are far (< 0.6) the kernel is bound by neither -- latency / the
                             # vector-memory request path (tools/ta_calib.hip) -- and `bound` still names the nearer one, with the note saying so
-                            roofline["bound"] = "valu" if roofline["valu_frac"] > roofline["frac"] else "hbm"
-                            if scattered:
-                                # measured, not inferred: N instructions added to the node test slow k_trace_dyn by N / (instructions per step) -- slope one
-                                # (profiles/r04k_valu_sensitivity.txt).  Its mix (tools/valu_mix.py, profiles/r04r_valu_mix.txt): 16 % fp32 arithmetic, 33 % integer + conversions,
-                                # half moves / selects / compares / packed fma -- no class near its own ceiling: the rate is what 5 waves' dependent chains deliver
-                                roofline["bound"] = "valu"
-                                roofline["bound_note"] = "VALU issue along the waves' dependent chains: +64 instructions per node test = +11 % (slope one, profiles/r04k_valu_sensitivity.txt); no instruction class near its own ceiling (profiles/r04r_valu_mix.txt)"
-                            elif max(roofline["valu_frac"], roofline["frac"]) < 0.6:
+                            roofline["bound"] = "valu" if roofline["valu_frac"] > roofline["frac"] else "hbm"  # derived from THIS run's two fractions, nothing else
+                            if max(roofline["valu_frac"], roofline["frac"]) < 0.6:
                                 roofline["bound_note"] = "neither roofline is near: latency / vector-memory request rate bound (DESIGN.md section 4)"
+                            if scattered:
+                                # what earlier calibration experiments found for this kernel family (not a result of this run): N instructions added to the node test slowed
+                                # k_trace_dyn by N / (instructions per step), and no instruction class sat near its own ceiling
+                                roofline["prior_experiment_note"] = "r04: +64 VALU instructions per node test = +11 % traversal time (profiles/r04k_valu_sensitivity.txt); instruction mix profiles/r04r_valu_mix.txt"
                         # raw counters and the per-kernel table go to a FILE (the driver keeps only the last 8 KB of output: r03's line lost C3's value to them)
                         raw["pmc_kernels"] = {k: {c: (round(x, 1) if isinstance(x, float) else x) for c, x in v.items()} for k, v in pmc.items() if k.startswith(prefixes)}
                         if True:  # every kernel of the frame, compactly: time share under counters, VALU issue, lanes, L2 hit (the per-kernel picture of the wavefront pipeline)
@@ -463,13 +485,15 @@ def main():
     #   N = 8: the tiled 4K interior itself.
     # Each leg is a COMPACT object (value, ms_per_step, stage times, roofline fractions); raw counters and per-kernel tables go to profiles/bench_last_pmc.json.
     # Every rank takes part (collectives inside); a failure is reported in the line instead of losing the headline number.
-    also = os.environ.get("GATLING_BENCH_ALSO", ("c3,c4,c5share" if args.workload == "c2" and not args.spp else "") if world == 1 else ("c5" if world >= 8 else ""))
+    also = os.environ.get("GATLING_BENCH_ALSO", ("c1,c3,c4,c5share,c5@64" if args.workload == "c2" and not args.spp else "") if world == 1 else ("c5" if world >= 8 else ""))
     extras = []
-    for wl in [x for x in also.split(",") if x and x != args.workload]:
-        extra = {"workload": wl}
+    for wl_spec in [x for x in also.split(",") if x and x != args.workload]:
+        wl, _, wl_spp = wl_spec.partition("@")  # "c5@64": the workload at a reduced spp (the whole 4K frame of C5 on ONE GPU is 8.5 G samples at its own spp)
+        extra = {"workload": wl_spec}
         try:
-            e_steps = int(os.environ.get("GATLING_BENCH_ALSO_STEPS", ("2" if wl == "c5share" else "3") if world == 1 else "2"))
-            E, _ = measure(wl, int(os.environ.get("GATLING_BENCH_ALSO_SPP", "0")), e_steps, 1, world > 1, args.no_pmc or world > 1, False)
+            e_steps = int(os.environ.get("GATLING_BENCH_ALSO_STEPS", ("2" if wl in ("c5share", "c5") else "3") if world == 1 else "2"))
+            light = wl == "c1" or bool(wl_spp)  # no counter passes for the small / reduced legs: their kernels are the ones the full legs already characterise
+            E, _ = measure(wl, int(wl_spp or os.environ.get("GATLING_BENCH_ALSO_SPP", "0")), e_steps, 1, world > 1, args.no_pmc or world > 1 or light, False)
             if E is not None:
                 raws[wl] = E.pop("_raw", {})
                 r = E["roofline"]
@@ -477,13 +501,26 @@ def main():
                               "segments_per_sample": E["config"]["segments_per_sample"], "iterations_per_step": E["config"]["iterations_per_step"],
                               "stage_ms": r.get("stage_ms_per_step"),
                               "roofline": {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "algorithmic_frac", "valu_frac", "valu_lane_utilisation",
-                                                                  "l2_hit_rate", "wait_inst_any_frac", "nodes_per_ray", "tris_per_ray", "pmc_note", "valu_frac_fp32_only", "bound_note") if k in r}})
+                                                                  "l2_hit_rate", "wait_inst_any_frac", "nodes_per_ray", "tris_per_ray", "pmc_note", "valu_frac_fp32_only", "bound_note", "prior_experiment_note") if k in r}})
                 if wl == "c5share":
                     extra["projected_8gpu"] = round(8.0 * E["value"], 1)
                     extra["projection_note"] = "8 x the rate of one rank's share (rows 3::8 at full spp) on one GPU; leaves out the RCCL gather of 8 x 16.6 MB and rank imbalance (DESIGN.md section 7)"
         except Exception as e:  # noqa: BLE001
             extra["error"] = repr(e)[:300]
         extras.append(extra)
+    # The delegate's own default workload (hdGatling: ONE sample per pixel and giRender call, 13 bounces, progressive accumulation, renderDelegate.cpp:93-110):
+    # milliseconds of one blocking giCRender call incl. the D2H of the colour AOV, bounce-loop iterations per call -- compact legs c3@spp1 / c4@spp1 (tools/lowspp.py)
+    if out is not None and world == 1 and args.workload == "c2" and not args.spp and not os.environ.get("GATLING_BENCH_ALSO"):
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import lowspp
+            for wl in ("c3", "c4"):
+                for row in lowspp.measure(wl, [1], 20, quiet=True):
+                    extras.append({"workload": f"{wl}@spp1", "label": "one giCRender call per frame: spp 1, 13 bounces, progressive, 1920x1080, D2H included", "unit": "ms per call",
+                                   "ms_per_call": row["ms_per_call_mean"], "ms_per_call_min": row["ms_per_call_min"], "iterations_per_call": row["iterations"],
+                                   "value": row["Msamples_per_s"], "value_unit": "Msamples/s", "calls": row["calls"], "stage_ms": row["stage_ms"]})
+        except Exception as e:  # noqa: BLE001
+            extras.append({"workload": "lowspp", "error": repr(e)[:300]})
     if out is not None and extras:
         out["also"] = extras
     if use_dist:

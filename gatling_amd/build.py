@@ -12,7 +12,7 @@ CSRC = os.path.join(_HERE, "csrc")
 OBJDIR = os.path.join(CSRC, "build")
 LIB = os.path.join(_HERE, "libgatling_gi.so")
 SOURCES = ["gi_c.cpp", "gi_image.cpp", "bvh8.cpp", "gi_kernels.hip", "gi_path.hip", "gi_path_bw.hip", "gtl_shim.cpp"]
-HEADERS = ["gi_types.h", "gi_kernels.h", "gi_device_math.h", "gi_queues.h", "gi_traversal.h", "gi_texture.h", "gi_shading.h", "gi_stages.h", "gi_image.h", "bvh8.h",
+HEADERS = ["gi_types.h", "gi_kernels.h", "gi_device_math.h", "gi_queues.h", "gi_traversal.h", "gi_texture.h", "gi_shading.h", "gi_stages.h", "gi_image.h", "gi_options.h", "bvh8.h",
            os.path.join("..", "..", "include", "gi_c.h"), os.path.join("..", "..", "include", "gtl", "gi", "Gi.h"),
            os.path.join("..", "..", "include", "gtl", "gb", "ParamTypes.h")]
 # -ffp-contract=off: arithmetic contract.  No fast-math: IEEE divide/sqrt are part of it.

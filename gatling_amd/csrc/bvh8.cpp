@@ -8,6 +8,7 @@
 // it, so the traversal kernel can never cull a triangle the exact Moeller-Trumbore test would accept.
 
 #include "bvh8.h"
+#include "gi_options.h"
 
 #include <algorithm>
 #include <cmath>
@@ -63,9 +64,8 @@ struct Builder {
   std::vector<Node2> nodes;
   std::atomic<int> spareThreads{0};
 
-  // Measured (C3 / C4 / C5): nodes per ray 16.6 / 6.9 / 20.1 -> 16.0 / 6.8 / 20.0 but triangles per ray 13.1 / 3.4 / 10.8 -> 18.5 / 5.1 / 22.4,
-  // traversal 8-20 % slower: SAH leaves win.  Kept as an experiment knob (GATLING_BVH_BALANCED_BOTTOM=1).
-  bool balancedBottom = false;
+  // (cutting the bottom 24 triangles of a subtree into full leaves of three by object-median splits -- nodes per ray 16.6 / 6.9 / 20.1 -> 16.0 / 6.8 / 20.0 on
+  // C3 / C4 / C5 but triangles per ray 13.1 / 3.4 / 10.8 -> 18.5 / 5.1 / 22.4, traversal 8-20 % slower: SAH leaves win, r02)
   std::unique_ptr<Dp[]> dp; float cPrim = 0.5f; // (not zero-initialised: 44 B per BVH2 node) filled bottom-up by build() when leafSize == 1 (each thread completes its own subtrees)
   uint32_t maxLeaf = kMaxLeaf;  // references a leaf slot may hold (1 for the top tree over subtrees: every leaf slot is then exactly one item)
   uint32_t leafSize = kMaxLeaf; // the BVH2 stops splitting at this many references (1 for the cost-optimal collapse, which forms the leaves itself)
@@ -73,7 +73,6 @@ struct Builder {
   size_t itemCount() const { return extBoxes ? extCount : tris.size(); }
   explicit Builder(const std::vector<TriRec>& t, const float* boxes = nullptr, size_t boxCount = 0) : tris(t), extBoxes(boxes), extCount(boxCount)
   {
-    if (const char* e = getenv("GATLING_BVH_BALANCED_BOTTOM")) balancedBottom = atoi(e) != 0;
     int threads = (int)std::thread::hardware_concurrency();
     if (const char* e = getenv("GATLING_BUILD_THREADS")) threads = atoi(e);
     threads = std::min(std::max(threads, 1), 32); // several ranks build on one host: stay modest
@@ -123,23 +122,6 @@ struct Builder {
     for (uint32_t i = first; i < first + count; i++) { box.grow(triBox[refs[i]]); cb.grow(&centroid[3 * refs[i]]); }
     nodes[idx].box = box; nodes[idx].first = first; nodes[idx].total = count;
     if (count <= leafSize) { nodes[idx].count = count; if (dp) dpNode(idx); return idx; }
-    if (balancedBottom && count <= kMaxLeaf * 8u) {
-      // Bottom of the tree: SAH splits leave many 1- and 2-triangle leaves, i.e. half-empty 8-wide nodes (47 % of the child
-      // slots were occupied on a 1 M-triangle soup).  A subtree of <= 24 triangles is instead cut into ceil(n/3) leaves of
-      // three by object-median splits along the longest centroid axis, so that it collapses into ONE full BVH8 node.
-      const uint32_t leaves = (count + kMaxLeaf - 1u) / kMaxLeaf, leftLeaves = leaves / 2u;
-      const uint32_t leftCount = std::min(count - 1u, leftLeaves * kMaxLeaf);
-      int axis = 0; float ext = cb.hi[0] - cb.lo[0];
-      for (int a = 1; a < 3; a++) if (cb.hi[a] - cb.lo[a] > ext) { ext = cb.hi[a] - cb.lo[a]; axis = a; }
-      std::nth_element(refs.begin() + first, refs.begin() + first + leftCount, refs.begin() + first + count,
-                       [&](uint32_t x, uint32_t y) { const float cx = centroid[3 * x + axis], cy = centroid[3 * y + axis]; return cx < cy || (cx == cy && x < y); });
-      uint32_t l = build(first, leftCount, idx + 1u);
-      uint32_t r = build(first + leftCount, count - leftCount, idx + 2u * leftCount);
-      nodes[idx].left = l; nodes[idx].right = r;
-      if (dp) dpNode(idx);
-      return idx;
-    }
-
     // binned SAH over the longest centroid axes
     int bestAxis = -1; int bestSplit = -1; float bestCost = 3.0e38f;
     for (int a = 0; a < 3; a++) {
@@ -255,9 +237,8 @@ static void buildCore(const std::vector<TriRec>& trisIn, const float* boxes, siz
   // references), an 8-wide node, or part of its parent's child list, minimising  sum(area * (c_node | c_prim * references)).
   // 0: the round-1 rule (SAH leaves of <= 3, then greedily open the child with the largest area until 8 slots are used).
   int collapse = 1;
-  if (const char* e = getenv("GATLING_BVH_COLLAPSE")) collapse = atoi(e);
+  collapse = (int)optionValue("bvh_collapse", collapse);
   float cPrim = 0.5f; // a triangle test costs about half a node test (~110 vs ~214 VALU instructions); measured flat between 0.2 and 0.5 (profiles/r02j_bvh_collapse.txt)
-  if (const char* e = getenv("GATLING_BVH_CPRIM")) cPrim = (float)atof(e);
   if (itemRoots) { collapse = 1; cPrim = 1.0f; B.maxLeaf = 1u; } // an item costs (at least) a node visit; one item per leaf slot
   if (collapse == 1) { B.leafSize = 1; B.cPrim = cPrim; }
   B.prepare();

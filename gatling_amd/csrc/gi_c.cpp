@@ -31,6 +31,7 @@
 #include "bvh8.h"
 #include "gi_kernels.h"
 #include "gi_image.h"
+#include "gi_options.h"
 #include "gi_types.h"
 
 using namespace gi;
@@ -406,6 +407,9 @@ struct GiCScene : SceneDevice {
   uint64_t optPoolSlots = 0, optSampleBufferMb = 0; // 0 = default
   int32_t optFusedPath = -1; // -1 = default: LDS-resident scenes run the fused persistent kernel k_path; 1 = k_path_bw (wave-local wavefront) when NEE is off; 2 = k_path; 0 = always the wavefront stage kernels
   int32_t optTraceDyn = -1; // -1 = default; 0 = block-synchronous k_trace everywhere; N = k_trace_dyn refill threshold
+  // Visiting order of shadow walks (k_trace_dyn<any>; any order gives the same image): -1 = not chosen yet -- launches alternate between near-to-far (0) and slot order
+  // (1) and the frame's node-visit counts are added up below; once both orders have walked enough rays the cheaper one is kept until the tree is rebuilt.
+  int32_t shadowOrder = -1; uint64_t shadowOrderRays[2] = {0, 0}, shadowOrderSteps[2] = {0, 0};
   int32_t optDevices = 0;   // 0 = every device the library was initialised on; N = at most N of them
   uint32_t lastRenderDevices = 0; // devices the previous giCRender used: progressive accumulation blends against each device's own buffer, so a change restarts it
 };
@@ -1095,7 +1099,7 @@ int buildTwoLevel(GiCScene* s, const std::vector<MB>& meshBuilds, const std::vec
 {
   s->twoLevel = false;
   int want = s->optTwoLevel;
-  if (const char* e = getenv("GATLING_TWO_LEVEL")) want = atoi(e);
+  want = (int)optionValue("two_level", want);
   size_t uniqueTris = 0;
   for (const MB& mb : meshBuilds) uniqueTris += mb.instCount ? mb.m->faces.size() : 0;
   const bool beyondLds = flatNodes > 384u || flatTris > 128u;
@@ -1358,7 +1362,6 @@ int buildScene(GiCScene* s)
   // Scenes beyond LDS: one 128-byte shading record per mesh triangle (gi_types.h TriShade); the flattened triangles name theirs in vi[0].  LDS-resident
   // scenes keep vertex indices there: the fused kernels are VALU-bound and read the host-decoded FVertex records.
   H.shadePacked = bvh.nodes.size() > 384u || bvh.tris.size() > 128u;
-  if (const char* e = getenv("GATLING_SHADE_PACKED")) H.shadePacked = atoi(e) != 0;
   H.triShade.clear();
   if (H.shadePacked) {
     std::vector<uint32_t> shadeBaseOfMesh(meshBuilds.size(), 0u);
@@ -1378,6 +1381,7 @@ int buildScene(GiCScene* s)
     for (TriRec& t : bvh.tris) t.vi[0] = shadeBaseOfMesh[instances[t.instance].mesh] + t.prim;
   }
   s->shadePacked = H.shadePacked;
+  s->shadowOrder = -1; s->shadowOrderRays[0] = s->shadowOrderRays[1] = s->shadowOrderSteps[0] = s->shadowOrderSteps[1] = 0; // a new tree: the shadow walks' order is chosen anew
   // one copy of the scene per device this scene renders on
   const uint32_t nDev = sceneDeviceCount(s);
   while (s->replicas.size() + 1u < nDev) { s->replicas.emplace_back(new SceneDevice()); s->replicas.back()->slot = (uint32_t)s->replicas.size(); s->dirty |= DIRTY_LIGHTS; } // a new replica has no lights yet
@@ -1493,7 +1497,7 @@ int updateTransforms(GiCScene* s, bool& handled)
 {
   handled = false;
   if (!s->host || s->twoLevel || s->triCount < 4096u) return GI_C_OK; // small scenes rebuild in no time (and must stay LDS-resident)
-  if (const char* e = getenv("GATLING_INCREMENTAL")) { if (!atoi(e)) return GI_C_OK; }
+  if (!optionValue("incremental", 1)) return GI_C_OK;
   SceneHost& H = *s->host;
   for (const MeshBuild& mb : H.meshBuilds) if (mb.m->builtInstances != mb.instCount) return GI_C_OK; // (cannot happen: count changes raise DIRTY_BVH)
   const double t0 = nowMs();
@@ -1573,8 +1577,6 @@ int syncSceneGeometry(GiCScene* s)
   if (s->dirty & (DIRTY_BVH | DIRTY_MATERIALS)) {
     if (buildScene(s) != GI_C_OK) return GI_C_ERROR;
     s->dirty &= ~(DIRTY_BVH | DIRTY_MATERIALS); s->dirty |= DIRTY_FRAMEBUFFER;
-    static const int envPart = getenv("GATLING_PARTITIONED") ? atoi(getenv("GATLING_PARTITIONED")) : 0; // measurement: lay every freshly built scene out as per-instance subtrees at once
-    if (envPart) { bool handled = false; if (updateTransforms(s, handled) != GI_C_OK) return GI_C_ERROR; }
   }
   s->dirty &= ~DIRTY_XFORM;
   return GI_C_OK;
@@ -1614,8 +1616,8 @@ SceneView makeView(GiCScene* s) { return makeView(s, *s); }
 static uint32_t traceDynRefill(const GiCScene* s)
 {
   uint32_t r = s->optTraceDyn >= 0 ? (uint32_t)s->optTraceDyn : 8u;
-  if (const char* e = getenv("GATLING_TRACE_DYN")) r = (uint32_t)std::max(0, std::min(64, atoi(e)));
-  if (const char* e = getenv("GATLING_TRACE_DYN_SPILL8")) { if (r && atoi(e)) r |= TRACE_DYN_SPILL8; }
+  if (optionSet("trace_dyn")) r = (uint32_t)std::max(0L, std::min(64L, optionValue("trace_dyn", 8)));
+  if (r && optionValue("trace_dyn_spill8", 0)) r |= TRACE_DYN_SPILL8;
   return r;
 }
 
@@ -1830,14 +1832,14 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
     // --- work decomposition (DESIGN.md "Persistent path pool"): work item = (pixel, sample); the frame is cut into batches of
     // consecutive samples whose per-sample colour buffer fits the budget; a pool of `slots` paths is kept full from a running
     // work counter until the batch's items run out.
-    auto envU64 = [](const char* name, uint64_t def) { const char* e = getenv(name); return e ? (uint64_t)strtoull(e, nullptr, 10) : def; };
+    auto envU64 = [](const char* key, uint64_t def) { return optionSet(key) ? (uint64_t)optionValue(key, 0) : def; };
     // Memory plan (r04).  The per-sample colour buffer wants to hold the whole frame's samples (every batch ends in a drain / a kernel tail: C2's 34 GB for 1024 spp at
     // 1080p in one batch 213.4 ms per step, in four 215.5) and scenes beyond LDS want a 64 Mi-slot pool (17 GB with its queues) -- on an empty 288 GB device.  A Hydra
     // plugin shares the device with other scenes, other processes and the host application, so the plan starts from what is FREE now (plus what this scene already
     // holds in these buffers, which is reused), and an allocation that still fails (someone else was faster) is answered with a smaller plan -- more batches first,
     // then a smaller pool -- never with a failed render while a workable plan exists.  Results do not depend on the plan (test_pool_and_batch_invariance).
     size_t memFree = 0, memTotal = 0; (void)hipMemGetInfo(&memFree, &memTotal);
-    if (const char* e = getenv("GATLING_ASSUME_FREE_MB")) memFree = (size_t)strtoull(e, nullptr, 10) << 20; // tests: plan as if this much were free (a planner overtaken by another allocation: the fallback below must recover)
+    if (optionSet("assume_free_mb")) memFree = (size_t)optionValue("assume_free_mb", 0) << 20; // tests: plan as if this much were free (a planner overtaken by another allocation: the fallback below must recover)
     if (!D.memTotalMb) D.memTotalMb = std::max<uint64_t>(1, (uint64_t)(memTotal >> 20));
     uint64_t held = D.sampleBuf.bytes() + D.slots.bytes() + D.media.bytes();
     for (uint32_t q = 0; q < Q_COUNT; q++) held += D.qSlot[q].bytes() + D.qA[q].bytes() + D.qB[q].bytes() + D.qC[q].bytes();
@@ -1845,24 +1847,24 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
     const uint64_t availMb = ((uint64_t)memFree + held) >> 20;
     const uint64_t capMb = std::max<uint64_t>(1024, std::min<uint64_t>(49152, D.memTotalMb / 6)); // the budget of an empty device: 48 GiB of 288 GB
     const uint64_t defaultMb = std::max<uint64_t>(256, std::min<uint64_t>(capMb, availMb / 3));    // ... and a third of what is available now, 256 MiB at least
-    const uint64_t budgetBytes = envU64("GATLING_SAMPLE_BUFFER_MB", s->optSampleBufferMb ? s->optSampleBufferMb : defaultMb) << 20;
+    const uint64_t budgetBytes = envU64("sample_buffer_mb", s->optSampleBufferMb ? s->optSampleBufferMb : defaultMb) << 20;
     // Pool size: a launch of k_trace_dyn ends when its longest ray ends, and ray cost is heavy-tailed in scenes beyond LDS
     // (a 100-step ray outlives the average one six times over), so those scenes get a pool large enough to amortise that
     // tail (measured on C3 at spp 64 / 256: 4 Mi slots 630, 16 Mi 790, 32 Mi 831 / 810, 64 Mi - / 868 Msamples/s); LDS-resident scenes have uniform, short rays.
     const bool sceneInLds = s->nodeCount <= 384u && s->triCount <= 128u;
     const uint64_t poolDefault = sceneInLds ? (4u << 20) : (64u << 20);
     const uint64_t poolMax = std::min<uint64_t>((1ull << 30) - 1ull, // regen-queue entries keep two flag bits above the slot index (REGEN_MISSED, REGEN_FRESH)
-                                                std::max<uint64_t>(64, envU64("GATLING_POOL_SLOTS", s->optPoolSlots ? s->optPoolSlots : poolDefault)));
+                                                std::max<uint64_t>(64, envU64("pool_slots", s->optPoolSlots ? s->optPoolSlots : poolDefault)));
     uint64_t batchSamples = std::min<uint64_t>(rs.spp, std::max<uint64_t>(1, budgetBytes / (pixels * 16)));
     batchSamples = std::min<uint64_t>(batchSamples, std::max<uint64_t>(1, 0xffffffffull / pixels)); // work ids stay 32-bit
     // LDS-resident scenes without medium stacks / dome images: the fused persistent kernel k_path (gi_path.hip) keeps the paths in
     // registers -- no pool, no queues; the stage kernels below remain the path for everything else (and on request: option / env)
     view.mediumStackSize = rs.mediumStackSize;
     bool fused = pathKernelSupports(view) && s->optFusedPath != 0;
-    if (const char* e = getenv("GATLING_FUSED")) fused = fused && atoi(e) != 0;
+    fused = fused && optionValue("fused", 1) != 0;
     usedFused = fused;
     // work order of the wavefront pipeline and layout of its per-sample buffer (gi_queues.h work_item); the fused kernels hand work out sample-major
-    { const char* e = getenv("GATLING_WORK_ORDER"); if (!fused && (e ? atoi(e) != 0 : WORK_ORDER_PIXEL_MAJOR_DEFAULT)) U.flags |= FLAG_PIXEL_MAJOR; }
+    if (!fused && optionValue("work_order", WORK_ORDER_PIXEL_MAJOR_DEFAULT ? 1 : 0) != 0) U.flags |= FLAG_PIXEL_MAJOR;
     size_t slots = fused ? 1 : (size_t)std::min<uint64_t>(poolMax, (uint64_t)pixels * batchSamples);
 
     // persistent grids: blocks per CU limited by registers (<= 6 waves/SIMD for k_trace) and, for k_trace, by the LDS it stages
@@ -1873,9 +1875,7 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
       uint32_t perCu = std::min<uint32_t>(6u, (160u * 1024u) / (ldsBytes + traceStaticLdsBytes() + 256u));
       const bool allLds = ln == v0.nodeCount && lt == v0.triCount && v0.triCount > 0u;
       if (!allLds && traceDynRefill(s)) perCu = 8u; // k_trace_dyn is persistent per wave: blocks beyond what is resident find the cursor exhausted
-      if (const char* e = getenv("GATLING_TRACE_BLOCKS_PER_CU")) perCu = (uint32_t)atoi(e);
       uint32_t widePerCu = 8u;
-      if (const char* e = getenv("GATLING_WIDE_BLOCKS_PER_CU")) widePerCu = (uint32_t)atoi(e);
       perCu = std::max(perCu, 1u); widePerCu = std::max(widePerCu, 1u);
       wideBlocks = (uint32_t)std::min<size_t>((slots + 255) / 256, (size_t)ctx.cuCount * widePerCu);
       traceBlocks = (uint32_t)std::min<size_t>((slots + 255) / 256, (size_t)ctx.cuCount * perCu);
@@ -1888,7 +1888,7 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
       const uint64_t perQueueEntry = 4ull * Q_COUNT + 32ull * (2 + 1) + 16ull + 8ull * 2;
       return (fused ? 0ull : (uint64_t)nSlots * (sizeof(Slot) + 4ull * mediaStride) + cap * NSHARD * perQueueEntry) + (uint64_t)pixels * nBatch * 16ull + (uint64_t)pixels * 16ull;
     };
-    const bool pinnedPlan = getenv("GATLING_POOL_SLOTS") || s->optPoolSlots || getenv("GATLING_SAMPLE_BUFFER_MB") || s->optSampleBufferMb; // the caller's sizes are taken as given
+    const bool pinnedPlan = optionSet("pool_slots") || s->optPoolSlots || optionSet("sample_buffer_mb") || s->optSampleBufferMb; // the caller's sizes are taken as given
     auto shrink = [&]() -> bool { // the next smaller plan: halve the sample buffer down to 64 MiB (more batches), then the pool down to 64 Ki slots
       if (batchSamples > 1 && (uint64_t)pixels * batchSamples * 16ull > (64ull << 20)) { batchSamples = std::max<uint64_t>(1, batchSamples / 2); if (!fused) slots = (size_t)std::min<uint64_t>(slots, (uint64_t)pixels * batchSamples); return true; }
       if (!fused && slots > (64u << 10)) { slots /= 2; return true; }
@@ -1927,20 +1927,20 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
     // Deferred Slot initialisation (r04): k_raygen hands a camera ray its (rng, work item) beside the ray record instead of writing the path's 64-byte Slot; the
     // slot is written where the first segment hits (k_route / k_trace) and a camera ray that leaves the scene retires there without ever touching one.  The
     // debug AOVs that follow whole paths read the slot when a sample retires (NEE / Bounces / ClockCycles): renders that bind them keep the eager form.
-    { const char* e = getenv("GATLING_DEFER_SLOT"); if (!fused && (e ? atoi(e) != 0 : true) && !ps.neeKey && !ps.bouncesAov && !ps.pathSegments) U.flags |= FLAG_DEFER_SLOT; }
+    if (!fused && optionValue("defer_slot", 1) != 0 && !ps.neeKey && !ps.bouncesAov && !ps.pathSegments) U.flags |= FLAG_DEFER_SLOT;
     QueueSet qs = makeQueueSet(&D);
     F4* colorOut = reinterpret_cast<F4*>(rbMem(colorRb, D.slot));
     const bool nee = rs.nextEventEstimation != 0;
     const uint32_t dynRefill = traceDynRefill(s);
+    const int32_t shadowOrderNow = optionSet("shadow_order") ? (int32_t)optionValue("shadow_order", -1) : s->shadowOrder; // (GATLING_OPTIONS=shadow_order=0|1 pins it)
     // Bounds retire (r04n): on the k_trace_dyn path a deferred-slot camera ray that cannot reach the scene's bounds is retired by k_raygen itself (C4: 58 % of the
     // camera rays, C3: ~45 %) -- same sample, same segment count, no ray record, no traversal step, no routing.  Not with a dome image / medium stack (a miss needs
     // the slot), not in counting builds (the root visit of such a ray is part of nodes-per-ray), not on the two-level layout (bounds of the TLAS root: not kept).
     {
       SceneView v0 = view; uint32_t ln, lt, ldsBytes; traceLdsLayout(v0, ln, lt, ldsBytes);
       const bool allLds = ln == v0.nodeCount && lt == v0.triCount && v0.triCount > 0u;
-      const char* e = getenv("GATLING_BOUNDS_RETIRE");
       if ((U.flags & FLAG_DEFER_SLOT) && !allLds && dynRefill && !view.twoLevel && view.domeTexture == 0u && rs.mediumStackSize == 0u && !s->countTraversal && s->boundsValid &&
-          (e ? atoi(e) != 0 : true)) {
+          optionValue("bounds_retire", 1) != 0) {
         U.flags |= FLAG_BOUNDS_RETIRE;
         for (int a = 0; a < 3; a++) { U.sceneLo[a] = s->bounds[a]; U.sceneHi[a] = s->bounds[3 + a]; }
       }
@@ -1969,16 +1969,15 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
       if (fused && U.maxBounces != 0u) {
         // work items are claimed in chunks of consecutive ids; small frames get small chunks so that every resident wave finds work
         uint32_t chunk = 2048u;
-        if (const char* e = getenv("GATLING_PATH_CHUNK")) chunk = (uint32_t)std::max(64, atoi(e));
         const uint64_t waves = (uint64_t)ctx.cuCount * 16u;
         // (a wave's last chunk is the launch's tail: 16 claims per wave keep it at ~6 % of a small frame -- C1 5 895 -> 6 360 Msamples/s; C2 does not care, 256 ... 2048 measure the same)
         chunk = (uint32_t)std::min<uint64_t>(chunk, std::max<uint64_t>(64u, ((uint64_t)U.workTotal / (waves * 16u)) & ~63ull));
         curIter = totalIters; if (timers) sampledIters++;
         if (timers) { (void)hipEventRecord(poolEvent(&D, ev), st); }
-        // which fused kernel: k_path (one path per lane, in registers) unless the wave-local wavefront k_path_bw is asked for (option 1 / GATLING_PATH_BW=1).  Measured
+        // which fused kernel: k_path (one path per lane, in registers) unless the wave-local wavefront k_path_bw is asked for (GI_C_SCENE_OPTION_FUSED_PATH = 1 / GATLING_OPTIONS=path_bw=1).  Measured
         // r03 on C2 (1080p, spp 256, SLP vectorisation off): k_path 55.4 ms per batch, k_path_bw 57.3 -- k_path's 114 VGPRs give 4 resident waves per SIMD (3 blocks
         // per CU cost 11 %), k_path_bw's 168 VGPRs and 50 KB of LDS per block give 3; at 128 VGPRs k_path_bw spills 43 registers and falls to 84 ms.
-        static const int envBw = getenv("GATLING_PATH_BW") ? atoi(getenv("GATLING_PATH_BW")) : -1;
+        const int envBw = (int)optionValue("path_bw", -1);
         const bool useBw = !nee && (envBw >= 0 ? envBw != 0 : s->optFusedPath == 1);
         if (useBw) launchPathBw(st, (uint32_t)ctx.cuCount, s->classMask, s->classTextured != 0u, s->countTraversal, chunk, U, view, ps, D.dCounters.ptr, D.sampleBuf.ptr);
         else launchPath(st, (uint32_t)ctx.cuCount, s->classMask, s->classTextured != 0u, s->countTraversal, chunk, U, view, ps, D.dCounters.ptr, D.sampleBuf.ptr);
@@ -2024,7 +2023,10 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
         traceLaunches++;
         for (uint32_t klass = 0; klass < MAT_CLASS_COUNT; klass++)
           if (s->classMask & (1u << klass)) timed(2, [&] { launchShade(st, wideBlocks, klass, (s->classTextured & (1u << klass)) != 0u, rs.mediumStackSize != 0u, U, view, ps, qs, D.dCounters.ptr, par); });
-        if (nee) timed(3, [&] { launchTrace(st, traceBlocks, true, s->countTraversal, view, ps, qs, D.dCounters.ptr, Q_SHADOW, Q_SHADOW, dynRefill, wideBlocks, U, D.sampleBuf.ptr); });
+        if (nee) {
+          const int32_t order = shadowOrderNow >= 0 ? shadowOrderNow : (int32_t)(totalIters & 1u); // not chosen yet: alternate, and count (below)
+          timed(3, [&] { launchTrace(st, traceBlocks, true, s->countTraversal, view, ps, qs, D.dCounters.ptr, Q_SHADOW, Q_SHADOW, dynRefill | (order ? TRACE_DYN_SLOT_ORDER : 0u), wideBlocks, U, D.sampleBuf.ptr); });
+        }
         if (iterLog) { // (GATLING_ITER_LOG, with kernel timers on every iteration: what each iteration's queues held -- one sync per iteration, for measurements only)
           HIP_TRY(hipMemcpyAsync(D.hCounters, D.dCounters.ptr, sizeof(PaddedCounter) * Q_COUNT * NSHARD, hipMemcpyDeviceToHost, st));
           HIP_TRY(hipStreamSynchronize(st));
@@ -2085,7 +2087,21 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
   S.renderMs = tEnd - tStart; S.samples = (uint64_t)pixels * rs.spp; S.iterations = iters; S.traceLaunches = traceLaunches; S.fusedPath = usedFused ? 1u : 0u;
   S.segments = D.hCounters->segments; S.shadowRays = D.hCounters->shadowRays; S.nodesVisited = D.hCounters->nodesVisited; S.trisTested = D.hCounters->trisTested;
   S.shadowNodesVisited = D.hCounters->shadowNodesVisited; S.shadowTrisTested = D.hCounters->shadowTrisTested;
-  if (s->countTraversal && D.hCounters->phaseTrips && getenv("GATLING_PHASE_STATS")) { // k_path's phase split (counting build)
+  if (D.slot == 0u && s->shadowOrder < 0) { // choose the shadow walks' order once both have been measured on enough rays of this scene: fewer node visits per ray wins
+    for (int m = 0; m < 2; m++) {
+      s->shadowOrderRays[m] += D.hCounters->shadowOrderRays[m];
+      for (int k = 0; k < 16; k++) s->shadowOrderSteps[m] += D.hCounters->shadowOrderSteps[m][k].v;
+    }
+    constexpr uint64_t ENOUGH = 1u << 16;
+    if (s->shadowOrderRays[0] >= ENOUGH && s->shadowOrderRays[1] >= ENOUGH)
+    {
+      s->shadowOrder = (double)s->shadowOrderSteps[1] * (double)s->shadowOrderRays[0] < (double)s->shadowOrderSteps[0] * (double)s->shadowOrderRays[1] ? 1 : 0;
+      if (getenv("GATLING_BUILD_TIMING")) fprintf(stderr, "[gatling_gi] shadow walks: near-to-far %.3f node visits per ray (%llu rays), slot order %.3f (%llu rays) -> %s\n",
+                                                  (double)s->shadowOrderSteps[0] / (double)s->shadowOrderRays[0], (unsigned long long)s->shadowOrderRays[0],
+                                                  (double)s->shadowOrderSteps[1] / (double)s->shadowOrderRays[1], (unsigned long long)s->shadowOrderRays[1], s->shadowOrder ? "slot order" : "near-to-far");
+    }
+  }
+  if (s->countTraversal && D.hCounters->phaseTrips && optionValue("phase_stats", 0)) { // k_path's phase split (counting build)
     const Counters& c = *D.hCounters; const double tot = (double)(c.phaseCycles[0] + c.phaseCycles[1] + c.phaseCycles[2] + c.phaseCycles[3]);
     static const char* names[4] = {"regen", "trace", "shade", "shadow+finish"};
     for (int k = 0; k < 4; k++) fprintf(stderr, "[gatling_gi] k_path phase %-14s %5.1f %% of wave cycles, %5.1f of 64 lanes busy per trip\n", names[k], 100.0 * (double)c.phaseCycles[k] / tot, (double)c.phaseLanes[k] / (double)c.phaseTrips);

@@ -45,7 +45,8 @@ __global__ void k_init(PathState st, QueueSet qs, Counters* cnt, uint32_t n, uin
   if (i == 0) {
     if (resetStats) cnt->overflow = 0u; // sticky across the batches of one render: giCRender reads it back once, after the last batch
     cnt->workBase[0].v = 0; cnt->workBase[1].v = 0; for (uint32_t k = 0; k < NCURSOR; k++) { cnt->cursor[0][k].v = 0; cnt->cursor[1][k].v = 0; }
-    if (resetStats) { cnt->segments = 0; cnt->shadowRays = 0; cnt->nodesVisited = 0; cnt->trisTested = 0; cnt->shadowNodesVisited = 0; cnt->shadowTrisTested = 0;
+    if (resetStats) { cnt->shadowOrderRays[0] = 0; cnt->shadowOrderRays[1] = 0; for (int k = 0; k < 16; k++) { cnt->shadowOrderSteps[0][k].v = 0; cnt->shadowOrderSteps[1][k].v = 0; }
+                      cnt->segments = 0; cnt->shadowRays = 0; cnt->nodesVisited = 0; cnt->trisTested = 0; cnt->shadowNodesVisited = 0; cnt->shadowTrisTested = 0;
                       for (int k = 0; k < 4; k++) { cnt->phaseCycles[k] = 0; cnt->phaseLanes[k] = 0; } cnt->phaseTrips = 0; }
   }
   for (; i < n; i += gridDim.x * blockDim.x) qs.slot[Q_REGEN_A][(i / per) * qs.cap + (i % per)] = i | REGEN_FRESH; // the slots themselves stay untouched
@@ -352,18 +353,11 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
 //   * everything wave-uniform (claims, chunk and ring bookkeeping) is forced into SGPRs with readfirstlane;
 //   * shadow walks (ANYHIT) end at their first hit, so near-to-far order buys them nothing: no octant flip in their node test.
 // ------------------------------------------------------------------------------------------------
+constexpr uint32_t DYN_SLOT_ORDER = 0x200u; // bit in k_trace_dyn's `refill` argument (shadow launches): visit children in slot order
 constexpr uint32_t DYN_CLAIM = 128;   // rays per cursor atomic (a device-scope atomic on one line completes ~88 times per microsecond; 64 / 256 / 512 measured: r04x)
 constexpr uint32_t DYN_FLUSH_AT = 8;  // the triangle ring is flushed below 64 pairs once this many finished walks wait for it (0 / 2 / 24 measured: r04c)
-#ifndef GI_DYN_WAVES
-#define GI_DYN_WAVES 5
-#endif
-#ifndef GI_DYN_STEAL
-#define GI_DYN_STEAL 1
-#endif
+constexpr int DYN_WAVES = 5; // resident waves per SIMD the register allocation aims for (96 VGPRs; 6 waves spill and lose, r02)
 constexpr uint32_t DYN_THIN_WALKERS = 8; // the ring is flushed at the end of every step while this few lanes walk (16: the same, r05d)
-#ifndef GI_DYN_SHADOW_ORDERED
-#define GI_DYN_SHADOW_ORDERED 0
-#endif
 
 template <bool TWO> struct DynRay { using type = RayWalk; };
 template <> struct DynRay<true> { using type = RayTrav2; };
@@ -375,6 +369,11 @@ template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool CUTOUT, b
 __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t refill, WaveTri& W,
                                                uint32_t shardCount, uint32_t claim)
 {
+  // Shadow walks end at their first hit, so near-to-far order is not needed for the result -- and which order finds an occluder sooner depends on the scene (C3's soup:
+  // slot order visits 7 % fewer nodes; C5's interior, where the occluders sit near the shaded surface: 28 % more, r05c).  The host tells the launch which one to use
+  // (DYN_SLOT_ORDER: the octant flip is zero, so children are visited in slot order) and the kernel counts the walks' node visits for it to choose by.
+  const bool slotOrder = ANYHIT && !TWO && (refill & DYN_SLOT_ORDER) != 0u;
+  uint32_t walkSteps = 0u;
   extern __shared__ uint4 s_dyn[];
   uint2 (*s_stack)[TRACE_BLOCK] = reinterpret_cast<uint2 (*)[TRACE_BLOCK]>(s_dyn);
   const uint32_t lane = __lane_id();
@@ -449,7 +448,7 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
       if (!alive && rank < take) {
         rec = srec; rng = srng;
         if (!ANYHIT) ray_init(v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), ro.w, rdir.w);
-        else ray_init(v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), 0.01f, ro.w); // shadow ray (rp_main.rgen:397-429)
+        else { ray_init(v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), 0.01f, ro.w); if (slotOrder) R.octinv = 0u; } // shadow ray (rp_main.rgen:397-429)
         wave_ray_begin(W, R.tBest);
         wt_hit_put(W, lane, f2u(ro.x), f2u(ro.y), MISS, 0u); // the result if nothing is hit: (tMax, origin.xy, MISS) -- k_route needs the origin for scattering events (medium stacks only); no helpers
         alive = true; draining = false; lastEnd = ringHead; // no pair of this ray is pending
@@ -496,7 +495,7 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
       auto batch = [&](uint32_t n) { wave_tri_batch<COUNT, false, CUTOUT, true>(W, ringHead, n, R, rng, sc, nullptr, 0u, tc); ringHead += n; };
       const bool walking = alive && !draining;
       uint2 Gt = make_uint2(0u, 0u);
-      if (walking) Gt = trav_node<COUNT, STACK, OVERFLOW, false, !ANYHIT || GI_DYN_SHADOW_ORDERED>(R, sc, nullptr, 0u, s_stack, overflow, tc);
+      if (walking) { Gt = trav_node<COUNT, STACK, OVERFLOW, false>(R, sc, nullptr, 0u, s_stack, overflow, tc); if (ANYHIT && !TWO) walkSteps++; }
       // positions from a wave prefix sum over the per-lane pair counts, then every lane writes its own pairs
       const uint32_t cntL = (uint32_t)__popc(Gt.y);
       const uint32_t scan = wave_scan_inclusive(cntL);
@@ -573,6 +572,11 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
       }
     }
   }
+  if (ANYHIT && !TWO) { // node visits of this wave's shadow walks, for the host's choice of their order (one atomic per wave, on one of 16 lines)
+    uint32_t n = walkSteps;
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off);
+    if (lane == 0 && n) atomicAdd(&cnt->shadowOrderSteps[slotOrder ? 1 : 0][(blockIdx.x * (TRACE_BLOCK / 64u) + (threadIdx.x >> 6)) & 15u].v, n);
+  }
   if (COUNT) { // measurement builds only: one atomic pair per wave
     unsigned long long a = tc.nodes, b = tc.tris;
     for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
@@ -586,7 +590,7 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
 // below that 64, so that the rays spread over twice as many waves: a launch lasts as long as its slowest wave, and in the thin launches of a low-spp frame
 // (hdGatling's default is ONE sample per pixel and call) that is all it lasts
 template <bool ANYHIT>
-__device__ __forceinline__ bool trace_dyn_prologue(const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t& shardCount, uint32_t& claim)
+__device__ __forceinline__ bool trace_dyn_prologue(const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t refill, uint32_t& shardCount, uint32_t& claim)
 {
   const uint32_t lane = __lane_id(), cap = qs.cap;
   shardCount = 0u;
@@ -594,7 +598,7 @@ __device__ __forceinline__ bool trace_dyn_prologue(const QueueSet& qs, Counters*
   uint32_t nRays = shardCount;
   for (int off = 4; off > 0; off >>= 1) nRays += __shfl_down(nRays, off);
   nRays = uni(nRays);
-  if (blockIdx.x == 0 && threadIdx.x == 0) { if (ANYHIT) cnt->shadowRays += nRays; else cnt->segments += nRays; } // single writer per launch
+  if (blockIdx.x == 0 && threadIdx.x == 0) { if (ANYHIT) { cnt->shadowRays += nRays; cnt->shadowOrderRays[(refill & DYN_SLOT_ORDER) ? 1 : 0] += nRays; } else cnt->segments += nRays; } // single writer per launch
   claim = nRays >= gridDim.x * (TRACE_BLOCK / 64u) * DYN_CLAIM ? DYN_CLAIM : 64u;
   // Waves the launch has no chunk for leave at once, without touching the cursors: every wave that stays walks all NSHARD cursors before it gives up, and a device-scope
   // atomic on one line completes ~88 times per microsecond -- 8 192 waves x 8 cursors were a 0.1 ms floor under every launch that held any ray at all, i.e. under each of
@@ -602,13 +606,13 @@ __device__ __forceinline__ bool trace_dyn_prologue(const QueueSet& qs, Counters*
   return (blockIdx.x * (TRACE_BLOCK / 64u) + (threadIdx.x >> 6)) < (nRays + 63u) / 64u + NSHARD;
 }
 template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool CUTOUT>
-__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(GI_DYN_WAVES, 8))) void k_trace_dyn(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t refill)
+__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(DYN_WAVES, 8))) void k_trace_dyn(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t refill)
 {
   __shared__ WaveTri s_wave[TRACE_BLOCK / 64];
   uint32_t shardCount, claim;
-  if (!trace_dyn_prologue<ANYHIT>(qs, cnt, qIn, shardCount, claim)) return;
+  if (!trace_dyn_prologue<ANYHIT>(qs, cnt, qIn, refill, shardCount, claim)) return;
   // a THIN launch -- fewer rays than two chunks per wave -- lasts as long as its slowest ray, not as its throughput allows: its idle lanes help (trace_dyn_body)
-  if (GI_DYN_STEAL && claim == 64u) trace_dyn_body<ANYHIT, COUNT, STACK, OVERFLOW, CUTOUT, false, true>(sc, st, qs, cnt, qIn, refill, s_wave[threadIdx.x >> 6], shardCount, claim);
+  if (claim == 64u) trace_dyn_body<ANYHIT, COUNT, STACK, OVERFLOW, CUTOUT, false, true>(sc, st, qs, cnt, qIn, refill, s_wave[threadIdx.x >> 6], shardCount, claim);
   else trace_dyn_body<ANYHIT, COUNT, STACK, OVERFLOW, CUTOUT, false, false>(sc, st, qs, cnt, qIn, refill, s_wave[threadIdx.x >> 6], shardCount, claim);
 }
 // the two-level layout (wave_step2): 16 LDS stack entries, world + object-space ray in registers
@@ -617,7 +621,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 
 {
   __shared__ WaveTri s_wave[TRACE_BLOCK / 64];
   uint32_t shardCount, claim;
-  if (!trace_dyn_prologue<ANYHIT>(qs, cnt, qIn, shardCount, claim)) return;
+  if (!trace_dyn_prologue<ANYHIT>(qs, cnt, qIn, refill, shardCount, claim)) return;
   trace_dyn_body<ANYHIT, COUNT, 16, false, CUTOUT, true, false>(sc, st, qs, cnt, qIn, refill, s_wave[threadIdx.x >> 6], shardCount, claim);
 }
 
@@ -673,17 +677,13 @@ __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, Que
 // k_shade: closest-hit shading + the post-trace part of the bounce loop, over the HIT queue only
 // (rp_main.chit:132-493, rp_main.rgen:397-480).  Misses never get here (k_trace routes them to k_raygen).
 // ------------------------------------------------------------------------------------------------
-#ifndef GI_SHADE_NEE_FORCE
-#define GI_SHADE_NEE_FORCE 1 // (experiments: minimum waves per SIMD asked of the OpenPBR + NEE variant; 1 = what its 164 VGPRs allow, i.e. 3)
-#endif
-#ifndef GI_SHADE_NEE_WAVES
-#define GI_SHADE_NEE_WAVES 4
-#endif
-// (r04c: the OpenPBR + NEE variant squeezed to 4 waves per SIMD -- 160 -> 128 VGPRs, 14 spilled -- is SLOWER: shade stage C3 14.4 -> 15.1 ms, C5 unchanged; it keeps its 3 waves)
+// minimum resident waves per SIMD asked of the register allocator for the plain OpenPBR variants: without NEE 4 (128 VGPRs, 3 spilled: the natural 3 waves measured
+// slower, r04j); with NEE 1, i.e. what its 164 VGPRs allow -- 3 (squeezed to 4 waves it spills 14 and is slower, r04c)
+constexpr int SHADE_OPENPBR_PLAIN_WAVES = 4, SHADE_OPENPBR_NEE_WAVES = 1;
 template <uint32_t KLASS, bool TEXTURED, bool VOLUME, bool NEE, bool PACKED>
 // (forcing the plain variant to 5 waves/SIMD -- amdgpu_waves_per_eu((...) ? 5 : 1, 8): 90 VGPRs, no spills -- is SLOWER: C2 shade 178 -> 190 ms;
 // the stage is bound by the memory pipeline's scattered 16-byte requests, not by latency hiding)
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((KLASS == 2u && !TEXTURED && !VOLUME) ? (NEE ? GI_SHADE_NEE_FORCE : GI_SHADE_NEE_WAVES) : 1, 8))) void k_shade(FrameUniforms U, SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t par)
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((KLASS == 2u && !TEXTURED && !VOLUME) ? (NEE ? SHADE_OPENPBR_NEE_WAVES : SHADE_OPENPBR_PLAIN_WAVES) : 1, 8))) void k_shade(FrameUniforms U, SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t par)
 {
   __shared__ AppendScratch<3> sh;
   const uint32_t qNext = Q_TRACE_A + (par ^ 1u), qRegen = Q_REGEN_A + (par ^ 1u), qHit = Q_HIT + KLASS;
@@ -928,7 +928,7 @@ static void launchTraceVariant(hipStream_t s, uint32_t blocks, const SceneView& 
   if (!allLds && dynRefill) { // big scene: persistent waves with dynamic ray fetch, results routed by a streaming pass
     // persistent waves pay the scratch set-up once, so trees deeper than 8 levels may keep 8 entries in LDS (more
     // resident waves) and spill the rest (TRACE_DYN_SPILL8), or keep 16 in LDS
-    const uint32_t refill = dynRefill & 0xffu;
+    const uint32_t refill = (dynRefill & 0xffu) | (ANYHIT ? (dynRefill & DYN_SLOT_ORDER) : 0u);
     if (sc.twoLevel) { // instanced scene: TLAS + shared per-mesh BLASes
       hipLaunchKernelGGL((k_trace_dyn2<ANYHIT, COUNT, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), 16u * TRACE_BLOCK * (uint32_t)sizeof(uint2), s, sc, st, qs, cnt, qIn, refill);
       if (!ANYHIT) hipLaunchKernelGGL(k_route, dim3(routeBlocks), dim3(BLOCK), 0, s, sc, st, qs, cnt, qIn, qMiss, U, sampleBuf);

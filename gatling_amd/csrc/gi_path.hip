@@ -33,11 +33,9 @@ namespace gi {
 constexpr uint32_t PRE_FIELDS = 10; // prepared camera ray: origin, direction, tMin, tMax, rng state, work item
 constexpr uint32_t PATH_STACK_MAX = 8; // LDS traversal-stack entries per lane: 4 for trees of depth <= 4 (cornell), else 8 (the host checks bvhDepth <= 8)
 
-#ifndef GI_PATH_WAVES
-#define GI_PATH_WAVES 4 // resident waves per SIMD the register allocation aims for (114 VGPRs without a hint)
-#endif
+constexpr int PATH_WAVES = 4; // resident waves per SIMD the register allocation aims for (114 VGPRs without a hint; 3 cost 11 %, 5 spill 26 registers: r03)
 template <uint32_t KLASS, bool TEXTURED, bool NEE, bool CUTOUT, bool COUNT, uint32_t PATH_STACK>
-__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(GI_PATH_WAVES, 8))) void k_path(FrameUniforms U, SceneView sc, PathState st, Counters* cnt, F4* __restrict__ sampleBuf,
+__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(PATH_WAVES, 8))) void k_path(FrameUniforms U, SceneView sc, PathState st, Counters* cnt, F4* __restrict__ sampleBuf,
                                                       uint32_t ldsNodes, uint32_t ldsTris, uint32_t chunk)
 {
   extern __shared__ uint4 s_dyn[];
@@ -241,7 +239,6 @@ int launchPath(hipStream_t s, uint32_t cuCount, uint32_t classMask, bool texture
     if (perCu > 8) perCu = 8;
     if (perCu < 1) perCu = 1;
   }
-  if (const char* e = getenv("GATLING_PATH_BLOCKS_PER_CU")) { const int v = atoi(e); if (v > 0) perCu = v; }
   // persistent grid: what is resident, but never more waves than chunks of work
   const uint64_t chunks = ((uint64_t)U.workTotal + chunk - 1u) / chunk;
   uint64_t blocks = (uint64_t)cuCount * (uint64_t)perCu;

@@ -37,11 +37,9 @@ enum : uint32_t { F_THR = 0, F_RAD = 3, F_BITS = 6, F_RNG = 7, F_WORK = 8, F_RO 
 constexpr uint32_t NO_WORK = 0xffffffffu; // F_WORK of a path that carries no sample (initial state)
 constexpr uint32_t PATH_BW_PATHS_DEFAULT = 96u; // paths per wave (GATLING_PATH_BW_PATHS): 3 blocks per CU; measured 96 / 128 / 160 / 192 / 256 -> 7426 / 6431 / 6621 / 6651 / 3814 Msamples/s on C2
 
-#ifndef GI_PATH_BW_WAVES
-#define GI_PATH_BW_WAVES 3 // resident waves per SIMD the register allocation aims for (168 VGPRs: 3; 4 needs <= 128 and spills 43 registers -- experiment knob)
-#endif
+constexpr int PATH_BW_WAVES = 3; // resident waves per SIMD the register allocation aims for (168 VGPRs: 3; 4 needs <= 128 and spills 43 registers)
 template <uint32_t KLASS, bool TEXTURED, bool CUTOUT, bool COUNT, uint32_t STACK>
-__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(GI_PATH_BW_WAVES, 8))) void k_path_bw(FrameUniforms U, SceneView sc, PathState st, Counters* cnt, F4* __restrict__ sampleBuf,
+__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(PATH_BW_WAVES, 8))) void k_path_bw(FrameUniforms U, SceneView sc, PathState st, Counters* cnt, F4* __restrict__ sampleBuf,
                                                          uint32_t ldsNodes, uint32_t ldsTris, uint32_t chunk, uint32_t PW, uint32_t thrShade, uint32_t thrRegen, uint32_t thrDry)
 {
   extern __shared__ uint4 s_dyn[];
@@ -227,13 +225,8 @@ static PathBwKernel pickPathBwKernel(uint32_t classMask, bool textured, bool cut
 int launchPathBw(hipStream_t s, uint32_t cuCount, uint32_t classMask, bool textured, bool count, uint32_t chunk, const FrameUniforms& U, const SceneView& sc,
                  const PathState& st, Counters* cnt, F4* sampleBuf)
 {
-  static const int envPw = getenv("GATLING_PATH_BW_PATHS") ? atoi(getenv("GATLING_PATH_BW_PATHS")) : 0;
-  static const int envThrS = getenv("GATLING_PATH_BW_SHADE") ? atoi(getenv("GATLING_PATH_BW_SHADE")) : 0;
-  static const int envThrR = getenv("GATLING_PATH_BW_REGEN") ? atoi(getenv("GATLING_PATH_BW_REGEN")) : 0;
-  const uint32_t PW = envPw >= 64 ? ((uint32_t)envPw + 31u) & ~31u : PATH_BW_PATHS_DEFAULT;
-  static const int envDry = getenv("GATLING_PATH_BW_DRY") ? atoi(getenv("GATLING_PATH_BW_DRY")) : 0;
-  const uint32_t thrS = envThrS > 0 ? (uint32_t)(envThrS > 64 ? 64 : envThrS) : 48u, thrR = envThrR > 0 ? (uint32_t)(envThrR > 64 ? 64 : envThrR) : 32u;
-  const uint32_t thrDry = envDry > 0 ? (uint32_t)envDry : 16u;
+  const uint32_t PW = PATH_BW_PATHS_DEFAULT;
+  const uint32_t thrS = 48u, thrR = 32u, thrDry = 16u; // shade / regenerate / give-up thresholds (lanes); measured r02-r03
   const uint32_t ldsNodes = sc.nodeCount, ldsTris = sc.triCount;
   const uint32_t stack = sc.bvhDepth <= 4u ? 4u : 8u;
   const uint32_t bytes = stack * TRACE_BLOCK * (uint32_t)sizeof(uint2) + ldsNodes * 80u + ldsTris * 48u + (TRACE_BLOCK / 64u) * (F_COUNT + 3u) * PW * 4u;
@@ -248,7 +241,6 @@ int launchPathBw(hipStream_t s, uint32_t cuCount, uint32_t classMask, bool textu
     if (perCu < 1) perCu = 1;
   }
   if (bytes + 8192u > 64u * 1024u) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (const char* e = getenv("GATLING_PATH_BLOCKS_PER_CU")) { const int v = atoi(e); if (v > 0) perCu = v; }
   // persistent grid: what is resident, but never more waves than there are PW-sized shares of the work
   const uint64_t shares = ((uint64_t)U.workTotal + PW - 1u) / PW;
   uint64_t blocks = (uint64_t)cuCount * (uint64_t)perCu;

@@ -281,6 +281,10 @@ struct Counters {
   // device-scope atomic on one line completes ~88 times per microsecond; 8 lines, 8x that); [0]: closest-hit queue, [1]: shadow queue
   PaddedCounter cursor[2][NCURSOR];
   unsigned long long segments, shadowRays, nodesVisited, trisTested, shadowNodesVisited, shadowTrisTested;
+  // shadow walks in the two visiting orders (k_trace_dyn<any>: [0] near-to-far, [1] slot order): rays launched, and node visits summed per wave into one of 16 lines
+  // (the host picks the order a scene's shadow rays visit fewer nodes in, gi_c.cpp shadowOrder)
+  unsigned long long shadowOrderRays[2];
+  PaddedCounter shadowOrderSteps[2][16];
   uint32_t overflow; // set by block_append when a shard would run past its capacity (host sizing bug): giCRender fails loudly
   // k_path, counting builds only (GI_C_SCENE_OPTION_COUNT_TRAVERSAL): shader-clock cycles per phase summed over waves, lanes doing useful work per phase summed over
   // trips, trips -- [0] regeneration, [1] closest-hit traversal, [2] shading, [3] shadow ray + finish (GATLING_PHASE_STATS=1 prints them)

@@ -66,7 +66,7 @@ def test_bvh8_builder_collapse_rules_and_thread_counts(monkeypatch):
     L = capi.load_library()
     got = {}
     for collapse, threads in ((0, 8), (1, 1), (1, 8)):
-        monkeypatch.setenv("GATLING_BVH_COLLAPSE", str(collapse)); monkeypatch.setenv("GATLING_BUILD_THREADS", str(threads))
+        monkeypatch.setenv("GATLING_OPTIONS", f"bvh_collapse={collapse}"); monkeypatch.setenv("GATLING_BUILD_THREADS", str(threads))
         nodes, depth = C.c_uint32(), C.c_uint32()
         assert L.giCDebugValidateBvh(v.ctypes.data_as(capi._FP), n, C.byref(nodes), C.byref(depth)) == 0
         got[(collapse, threads)] = (nodes.value, depth.value)

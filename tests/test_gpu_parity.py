@@ -244,7 +244,7 @@ def test_work_order_invariance(gi, orc, monkeypatch, w, h, spp, mb):
         rs = RenderSettings(spp=spp, max_bounces=4, next_event_estimation=nee)
         ref, cnt = orc.render(desc, rs, w, h, threads=4)
         for order in ("0", "1"):
-            monkeypatch.setenv("GATLING_WORK_ORDER", order)
+            monkeypatch.setenv("GATLING_OPTIONS", f"work_order={order}")
             sc = gi.Scene(desc)
             try:
                 sc.set_option(gi.OPTION_FUSED_PATH, 0)
@@ -267,8 +267,7 @@ def test_deferred_slot_initialisation_is_invisible(gi, monkeypatch, name):
     desc, rs, w, h = build_case(name)
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     for defer, pool, dyn in (("1", 0, -1), ("0", 0, -1), ("1", 301, -1), ("1", 0, 0), ("0", 301, 0), ("1", 64, -2)):
-        monkeypatch.setenv("GATLING_DEFER_SLOT", defer)
-        monkeypatch.setenv("GATLING_BOUNDS_RETIRE", "0" if dyn == -2 else "1")  # (r04n: camera rays that miss the scene's bounds retire in k_raygen; -2 = default traversal without it)
+        monkeypatch.setenv("GATLING_OPTIONS", f"defer_slot={defer},bounds_retire={0 if dyn == -2 else 1}")  # (r04n: camera rays that miss the scene's bounds retire in k_raygen; -2 = default traversal without it)
         dyn = -1 if dyn == -2 else dyn
         sc = gi.Scene(desc)
         try:
@@ -313,7 +312,7 @@ def test_camera_rays_that_cannot_reach_the_scene_retire_in_raygen(gi, orc, monke
         desc = copy.copy(base); desc.camera = cam
         ref, cnt = orc.render(desc, rs, w, h, threads=4)
         for retire, pool in (("1", 0), ("1", 301), ("0", 0)):
-            monkeypatch.setenv("GATLING_BOUNDS_RETIRE", retire)
+            monkeypatch.setenv("GATLING_OPTIONS", f"bounds_retire={retire}")
             sc = gi.Scene(desc)
             try:
                 if pool:
@@ -334,7 +333,6 @@ def test_camera_rays_that_cannot_reach_the_scene_retire_in_raygen(gi, orc, monke
     rs = RenderSettings(spp=24, max_bounces=5)
     w, h = 128, 72
     ref1, cnt = orc.render(desc, rs, w, h, threads=4)
-    monkeypatch.setenv("GATLING_BOUNDS_RETIRE", "1")
     sc = gi.Scene(desc)
     try:
         sc.set_option(gi.OPTION_SAMPLE_BUFFER_MB, 1)
@@ -350,7 +348,7 @@ def test_camera_rays_that_cannot_reach_the_scene_retire_in_raygen(gi, orc, monke
     # interleaved rows of a three-way split
     ref2, _ = orc.render(desc, rs, w, h, sample_offset=rs.spp, prev_color=ref1, threads=4)
     for order in ("1", "0"):
-        monkeypatch.setenv("GATLING_WORK_ORDER", order)
+        monkeypatch.setenv("GATLING_OPTIONS", f"work_order={order}")
         sc = gi.Scene(desc)
         try:
             sc.set_option(gi.OPTION_FUSED_PATH, 0)
@@ -363,7 +361,7 @@ def test_camera_rays_that_cannot_reach_the_scene_retire_in_raygen(gi, orc, monke
         assert_image_parity(a, ref1, exact=True)
         assert_image_parity(b, ref2, exact=True)
         assert np.array_equal(share.view(np.uint32), ref1[1::3].view(np.uint32)), order
-    monkeypatch.delenv("GATLING_WORK_ORDER")
+    monkeypatch.delenv("GATLING_OPTIONS")
 
 
 def test_texture_coordinate_transforms_on_device(gi, orc):
@@ -815,6 +813,38 @@ def test_soup_scene_with_nee_parity(gi, orc):
     render_both(gi, orc, desc, RenderSettings(spp=2, max_bounces=5, next_event_estimation=True), 96, 54)
 
 
+@pytest.mark.parametrize("scene_kind", ["soup", "interior", "instances+cutouts"])
+def test_shadow_walk_order_and_helper_lanes_are_invisible(gi, orc, monkeypatch, scene_kind):
+    """k_trace_dyn's scheduling freedoms (round 5) change no bit: shadow walks visit children near-to-far or in slot order (pinned either way, and chosen by the library
+    from its own node-visit counts across frames), and in thin launches -- few rays per launch: here every launch -- idle lanes take over parts of the longest walks.
+    Images, segment and shadow-ray counts equal the oracle's in every mode and on every one of several progressive frames."""
+    if scene_kind == "soup":
+        desc, rs = _soup(30000, seed=3), RenderSettings(spp=2, max_bounces=6, next_event_estimation=True)
+    elif scene_kind == "interior":
+        desc, rs = interior_scene(clutter_instances=60, subdivisions=2, prototypes=4, material_count=8), RenderSettings(spp=2, max_bounces=6, next_event_estimation=True)
+    else:
+        desc = sphere_grid(grid=4, subdivisions=2, material_count=4)
+        desc.materials[1].params[14] = 0.5   # stochastic cutout: the any-hit draw inside shared walks
+        desc.rect_lights = [RectLight(origin=(0, 0, 6.0), t0=(1, 0, 0), t1=(0, 1, 0), base_emission=(15, 15, 15), width=3.0, height=3.0)]
+        rs = RenderSettings(spp=2, max_bounces=5, next_event_estimation=True, rr_bounce_offset=0)
+    w, h = 160, 90
+    frames, prev = [], None
+    for k in range(5):  # progressive frames: the library makes its own choice of the order between them (after 2^16 rays walked in either order)
+        img, cnt = orc.render(desc, rs, w, h, sample_offset=k * rs.spp, prev_color=prev, threads=8)
+        frames.append((img, cnt)); prev = img
+    for opts in ("shadow_order=0", "shadow_order=1", ""):
+        monkeypatch.setenv("GATLING_OPTIONS", opts)
+        sc = gi.Scene(desc)
+        try:
+            for k, (ref, cnt) in enumerate(frames):
+                img = sc.render(rs, w, h)
+                st = sc.stats()
+                assert st["segments"] == cnt["segments"] and st["shadowRays"] == cnt["shadowRays"], (opts, k, st)
+                assert_image_parity(img, ref, exact=True)
+        finally:
+            sc.close()
+
+
 def _telescope(n, ratio):
     """n triangles whose sizes and distances from the origin shrink geometrically: SAH peels them off one cluster at a time, so the tree is
     as deep as trees get (host-side depth 39 ... 54 for the cases below against 8 ... 10 for BASELINE's scenes)."""
@@ -841,7 +871,7 @@ def test_deep_trees_parity(gi, orc, monkeypatch, n, ratio, spill8):
     the origin makes the exact test's `dot(o - v0, d x e2)` cancel to exactly 0, so it "hits" a 5e-14-sized triangle it geometrically misses
     by 1e-7 -- a hit no box test can promise to keep (3 of 4000 such rays differ between this tree and the oracle's)."""
     if spill8:
-        monkeypatch.setenv("GATLING_TRACE_DYN_SPILL8", "1")
+        monkeypatch.setenv("GATLING_OPTIONS", "trace_dyn_spill8=1")
     desc = _telescope(n, ratio)
     render_both(gi, orc, desc, RenderSettings(spp=3, max_bounces=4, next_event_estimation=True), 80, 45)
     if ratio ** (-n) < 1e-7:

@@ -78,7 +78,7 @@ def test_failed_allocation_falls_back_to_a_smaller_plan(gi, monkeypatch):
         sc.close()
     hog = _hog(2048)
     try:
-        monkeypatch.setenv("GATLING_ASSUME_FREE_MB", str(280 * 1024))
+        monkeypatch.setenv("GATLING_OPTIONS", f"assume_free_mb={280 * 1024}")
         sc = gi.Scene(desc)
         try:
             img = sc.render(rs, w, h).copy(); st = sc.stats()

@@ -1,6 +1,6 @@
 import os, sys
 sys.path.insert(0, '/root/repo')
-os.environ["GATLING_PHASE_STATS"] = "1"
+os.environ["GATLING_OPTIONS"] = "phase_stats=1"
 from gatling_amd import capi
 from gatling_amd.scene import RenderSettings
 from gatling_amd.scenes import cornell_box

@@ -1,6 +1,6 @@
-"""One process, one scene build, many env-knob variants of the render loop (gi_c.cpp reads its knobs per giCRender).
+"""One process, one scene build, many option variants of the render loop (gi_options.h: $GATLING_OPTIONS is read per giCRender).
 
-  python tools/gpu_variants.py c3 16 - GATLING_TRACE_DYN=0 GATLING_TRACE_DYN=32,GATLING_TRACE_DYN_SPILL8=1
+  python tools/gpu_variants.py c3 16 - trace_dyn=0 trace_dyn=32,trace_dyn_spill8=1        ("-" = defaults)
 
 Prints per variant: Msamples/s, wall ms, per-stage ms (HIP events, every 4th iteration), and whether the image is
 bit-identical to the first variant's (it must be: the knobs change scheduling, never arithmetic)."""
@@ -18,20 +18,15 @@ from gatling_amd import capi  # noqa: E402
 
 def main():
     workload, spp = sys.argv[1], int(sys.argv[2])
-    variants = [dict(x.split("=") for x in a.split(",")) if a != "-" else {} for a in sys.argv[3:]] or [{}]
+    variants = [a if a != "-" else "" for a in sys.argv[3:]] or [""]
     desc, rs, w, h, label = make_workload(workload, spp)
     rs.progressive_accumulation = False
     t0 = time.perf_counter()
     scene = capi.Scene(desc)
     scene.set_option(capi.OPTION_KERNEL_TIMERS, 4)
     ref = None
-    touched = set()
     for v in variants:
-        for k in touched:
-            os.environ.pop(k, None)
-        for k, val in v.items():
-            os.environ[k] = val
-            touched.add(k)
+        os.environ["GATLING_OPTIONS"] = v
         img = scene.render(rs, w, h)  # warm-up (first variant: includes scene build + upload)
         if ref is None:
             print(f"# {label}: first render (with build) {time.perf_counter() - t0:.1f} s", flush=True)

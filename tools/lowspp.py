@@ -17,7 +17,7 @@ from gatling_amd import capi  # noqa: E402
 from gatling_amd.scene import RenderSettings  # noqa: E402
 
 
-def measure(workload, spps, calls):
+def measure(workload, spps, calls, quiet=False):
     desc, rs0, w, h, label = make_workload(workload)
     scene = capi.Scene(desc)
     out = []
@@ -40,7 +40,8 @@ def measure(workload, spps, calls):
                "Msamples_per_s": round(w * h * spp / (sum(ts) / len(ts)) / 1e3, 1), "iterations": st["iterations"], "renderMs": round(st["renderMs"], 3),
                "batches": st.get("batches"), "poolSlots": st.get("poolSlots"),
                "stage_ms": {k: round(tm[k], 3) for k in ("raygenMs", "traceMs", "shadeMs", "shadowMs", "renderMs")}}
-        print(json.dumps(row), flush=True)
+        if not quiet:
+            print(json.dumps(row), flush=True)
         out.append(row)
     scene.close()
     return out
