@@ -54,7 +54,9 @@ void setError(const std::string& e) { t_lastError = e; fprintf(stderr, "[gatling
 
 // One entry per HIP device the library renders on (giCInitializeDevices / $GATLING_DEVICES; giCInitialize: one).  devs[0] is the PRIMARY device:
 // render buffers, textures and every single-device entry point live there; the others hold replicas of the scene and render row shares.
-struct DevCtx { int device = 0; int cuCount = 256; hipStream_t stream = nullptr; };
+struct DevCtx { int device = 0; int cuCount = 256; hipStream_t stream = nullptr;
+                int peer = 1; /* 1: the primary device and this one address each other's memory (peer access enabled both ways, or the same physical device); 0: no peer access --
+                                 the device's row shares travel through pinned host memory; -1: hipDeviceCanAccessPeer / EnablePeerAccess failed with an error */ };
 // One host thread per further device, created with the first multi-device render and kept until giCTerminate (a frame's share is handed to it as a job; until
 // r04 every frame created and joined its own std::threads).  The thread binds its HIP device once.
 struct DeviceWorker {
@@ -326,6 +328,7 @@ struct GiCRenderBuffer {
   bool deviceOnly = false;
   bool scratch = false; // internal stand-in that lives in the rendering device's own scratch memory (no replicas)
   std::vector<void*> replicaMem; // [slot - 1]: the same buffer on the other devices (multi-device renders), allocated on first use
+  void* stageMem = nullptr; // pinned, rb->size: where the row shares of devices WITHOUT peer access to the primary pass through (allocated on first use)
 };
 
 // Everything a scene keeps in ONE device's memory: the scene arrays, the path pool, the queues, the per-render scratch.  GiCScene IS the primary
@@ -458,14 +461,20 @@ static int initDevices(const std::vector<int>& ordinals)
     HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     devs.push_back(c);
   }
-  // the row shares travel to the primary device over xGMI: peer access both ways (already-enabled / same-device errors are harmless)
+  // the row shares travel to the primary device over xGMI: peer access both ways.  The outcome is kept (giCGetDevicePeerAccess) and decides how a device's share is
+  // gathered: without peer access a hipMemcpyDefault between two devices silently stages through pageable host memory -- the library then does it itself, through a pinned buffer
   for (size_t i = 1; i < devs.size(); i++) {
-    if (devs[i].device == devs[0].device) continue;
-    int can = 0;
-    if (hipDeviceCanAccessPeer(&can, devs[0].device, devs[i].device) == hipSuccess && can) {
-      (void)hipSetDevice(devs[0].device); (void)hipDeviceEnablePeerAccess(devs[i].device, 0);
-      (void)hipSetDevice(devs[i].device); (void)hipDeviceEnablePeerAccess(devs[0].device, 0);
-    }
+    if (devs[i].device == devs[0].device) continue; // another context on the same GPU (tests): its memory is directly addressable
+    int can01 = 0, can10 = 0;
+    const hipError_t q0 = hipDeviceCanAccessPeer(&can01, devs[0].device, devs[i].device), q1 = hipDeviceCanAccessPeer(&can10, devs[i].device, devs[0].device);
+    if (q0 != hipSuccess || q1 != hipSuccess) { devs[i].peer = -1; (void)hipGetLastError(); continue; }
+    if (!can01 || !can10) { devs[i].peer = 0; continue; }
+    (void)hipSetDevice(devs[0].device); const hipError_t e0 = hipDeviceEnablePeerAccess(devs[i].device, 0);
+    (void)hipSetDevice(devs[i].device); const hipError_t e1 = hipDeviceEnablePeerAccess(devs[0].device, 0);
+    auto fine = [](hipError_t e) { return e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled; };
+    devs[i].peer = (fine(e0) && fine(e1)) ? 1 : -1;
+    if (devs[i].peer != 1) fprintf(stderr, "[gatling_gi] peer access between devices %d and %d could not be enabled (%s / %s): row shares of device %d go through pinned host memory\n",
+                                   devs[0].device, devs[i].device, hipGetErrorString(e0), hipGetErrorString(e1), devs[i].device);
     (void)hipGetLastError();
   }
   HIP_TRY(hipSetDevice(devs[0].device));
@@ -495,6 +504,7 @@ int giCInitializeDevices(const int32_t* deviceOrdinals, uint32_t count)
 }
 
 uint32_t giCGetDeviceCount(void) { return g_ctx.initialized ? (uint32_t)g_ctx.devs.size() : 0u; }
+int32_t giCGetDevicePeerAccess(uint32_t index) { return (g_ctx.initialized && index < g_ctx.devs.size()) ? (int32_t)g_ctx.devs[index].peer : -1; }
 
 void giCTerminate(void)
 {
@@ -1013,6 +1023,7 @@ void giCDestroyRenderBuffer(GiCRenderBuffer* rb)
   (void)hipStreamSynchronize(g_ctx.stream);
   if (rb->deviceMem) (void)hipFree(rb->deviceMem);
   if (rb->hostMem) (void)hipHostFree(rb->hostMem);
+  if (rb->stageMem) (void)hipHostFree(rb->stageMem);
   for (size_t i = 0; i < rb->replicaMem.size(); i++)
     if (rb->replicaMem[i] && i + 1 < g_ctx.devs.size()) { (void)hipSetDevice(g_ctx.devs[i + 1].device); (void)hipFree(rb->replicaMem[i]); }
   (void)hipSetDevice(g_ctx.device);
@@ -2175,7 +2186,16 @@ static int renderOnDevices(GiCScene* s, uint32_t nDev, const RenderJob& frame)
     for (uint32_t d = 1; d < nDev; d++) {
       const uint32_t rows = (rb->height - d + nDev - 1u) / nDev;
       const size_t off = (size_t)d * rowBytes;
-      HIP_TRY(hipMemcpy2DAsync((uint8_t*)rb->deviceMem + off, pitch, (uint8_t*)rb->replicaMem[d - 1u] + off, pitch, rowBytes, rows, hipMemcpyDefault, st));
+      if (g_ctx.devs[d].peer == 1 && optionValue("peer_copies", 1) != 0) { // strided 2-D peer copy over xGMI, straight into place
+        HIP_TRY(hipMemcpy2DAsync((uint8_t*)rb->deviceMem + off, pitch, (uint8_t*)rb->replicaMem[d - 1u] + off, pitch, rowBytes, rows, hipMemcpyDefault, st));
+      } else { // no peer access (or GATLING_OPTIONS=peer_copies=0): the share's rows -> pinned staging frame -> the primary's buffer, both strided, in place
+        if (!rb->stageMem) HIP_TRY(hipHostMalloc(&rb->stageMem, rb->size ? rb->size : 16, hipHostMallocPortable));
+        HIP_TRY(hipSetDevice(g_ctx.devs[d].device));
+        HIP_TRY(hipMemcpy2DAsync((uint8_t*)rb->stageMem + off, pitch, (uint8_t*)rb->replicaMem[d - 1u] + off, pitch, rowBytes, rows, hipMemcpyDeviceToHost, g_ctx.devs[d].stream));
+        HIP_TRY(hipStreamSynchronize(g_ctx.devs[d].stream));
+        HIP_TRY(hipSetDevice(g_ctx.device));
+        HIP_TRY(hipMemcpy2DAsync((uint8_t*)rb->deviceMem + off, pitch, (uint8_t*)rb->stageMem + off, pitch, rowBytes, rows, hipMemcpyHostToDevice, st));
+      }
     }
     if (!rb->deviceOnly) HIP_TRY(hipMemcpyAsync(rb->hostMem, rb->deviceMem, rb->size, hipMemcpyDeviceToHost, st));
   }

@@ -344,6 +344,10 @@ void giCTerminate(void);
  * how an unmodified caller (hdGatling) gets every GPU of the node.  Renders that shard rows themselves (rowStride > 1 / a row range) stay on the primary. */
 int giCInitializeDevices(const int32_t* deviceOrdinals, uint32_t count);
 uint32_t giCGetDeviceCount(void);
+/* [ext] can the primary device and device `index` of the list address each other's memory?  1 = yes (peer access enabled both ways, or the same physical device):
+ * row shares are gathered with strided peer copies over xGMI; 0 = no, -1 = the query / the enabling failed: that device's shares are staged through pinned host
+ * memory by the library (correct, slower).  tools/run_scale.sh prints it next to every multi-device measurement. */
+int32_t giCGetDevicePeerAccess(uint32_t index);
 /* [ext] last error message of the calling thread's most recent failing call ("" if none) */
 const char* giCGetLastError(void);
 

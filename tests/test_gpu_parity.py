@@ -839,7 +839,7 @@ def test_shadow_walk_order_and_helper_lanes_are_invisible(gi, orc, monkeypatch, 
             for k, (ref, cnt) in enumerate(frames):
                 img = sc.render(rs, w, h)
                 st = sc.stats()
-                assert st["segments"] == cnt["segments"] and st["shadowRays"] == cnt["shadowRays"], (opts, k, st)
+                assert st["segments"] == cnt["segments"] and st["shadowRays"] == cnt["shadow_rays"], (opts, k, st)
                 assert_image_parity(img, ref, exact=True)
         finally:
             sc.close()

@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_device_list_entry_points_exported():
     from gatling_amd import capi
     L = capi.load_library()
-    assert hasattr(L, "giCInitializeDevices") and hasattr(L, "giCGetDeviceCount")
+    assert hasattr(L, "giCInitializeDevices") and hasattr(L, "giCGetDeviceCount") and hasattr(L, "giCGetDevicePeerAccess")
+    assert L.giCGetDevicePeerAccess(0) == -1  # not initialised: no device list to ask about
     assert capi.OPTION_DEVICES == 8  # include/gi_c.h GI_C_SCENE_OPTION_DEVICES
 
 
@@ -86,6 +87,38 @@ SCRIPT = textwrap.dedent("""
 def test_rows_dealt_to_three_device_contexts_are_bit_identical(tmp_path):
     out = subprocess.run([sys.executable, "-c", SCRIPT % {"root": ROOT}], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "multi-device ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+STAGED = textwrap.dedent("""
+    import os, sys, numpy as np
+    sys.path.insert(0, %(root)r)
+    from gatling_amd import capi
+    from gatling_amd.scene import RenderSettings
+    from gatling_amd.scenes import cornell_box, sphere_grid
+    L = capi.initialize(devices=[0, 0, 0])
+    assert [L.giCGetDevicePeerAccess(i) for i in range(3)] == [1, 1, 1]   # contexts on one physical device address each other's memory
+    for desc, rs, w, h in ((cornell_box(), RenderSettings(spp=4, max_bounces=4), 64, 37), (sphere_grid(grid=4, subdivisions=2, material_count=4), RenderSettings(spp=3, max_bounces=5), 50, 21)):
+        imgs = {}
+        for opts in ("", "peer_copies=0"):   # peer copies into place / every share staged through pinned host memory (what a node without peer access gets)
+            os.environ["GATLING_OPTIONS"] = opts
+            sc = capi.Scene(desc)
+            a = sc.render(rs, w, h).copy(); b = sc.render(rs, w, h).copy()   # two progressive frames
+            aov = sc.render_aovs(RenderSettings(**{**rs.__dict__, "progressive_accumulation": False}), w, h, ["normal", "depth", "instanceId"])
+            imgs[opts] = (a, b, aov); sc.close()
+        (a0, b0, v0), (a1, b1, v1) = imgs[""], imgs["peer_copies=0"]
+        assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32)) and np.array_equal(b0.view(np.uint32), b1.view(np.uint32)), "staged gather differs from the peer-copy gather"
+        for k in v0:
+            assert np.array_equal(v0[k].view(np.uint32), v1[k].view(np.uint32)), "AOV " + k + " differs between the staged and the peer-copy gather"
+    print("staged gather ok")
+""")
+
+
+@pytest.mark.gpu
+def test_row_shares_staged_through_pinned_host_memory_equal_peer_copies(tmp_path):
+    """Nodes whose devices cannot address each other (hipDeviceCanAccessPeer = 0, or enabling fails): the library stages a device's row share through a pinned host
+    frame instead of letting hipMemcpyDefault do it through pageable memory.  GATLING_OPTIONS=peer_copies=0 forces that path on three contexts of the one test GPU."""
+    out = subprocess.run([sys.executable, "-c", STAGED % {"root": ROOT}], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "staged gather ok" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
 
 @pytest.mark.gpu
