@@ -110,7 +110,7 @@ class GiCImageLoader(C.Structure):
 
 
 SYMBOLS = [
-    ("giCInitialize", C.c_int, [C.c_int]), ("giCInitializeDevices", C.c_int, [C.POINTER(C.c_int32), C.c_uint32]), ("giCGetDeviceCount", C.c_uint32, []), ("giCGetDevicePeerAccess", C.c_int32, [C.c_uint32]), ("giCTerminate", None, []), ("giCGetLastError", C.c_char_p, []),
+    ("giCInitialize", C.c_int, [C.c_int]), ("giCInitializeDevices", C.c_int, [C.POINTER(C.c_int32), C.c_uint32]), ("giCGetDeviceCount", C.c_uint32, []), ("giCGetApiVersion", C.c_uint32, []), ("giCGetDevicePeerAccess", C.c_int32, [C.c_uint32]), ("giCTerminate", None, []), ("giCGetLastError", C.c_char_p, []),
     ("giCCreateMaterial", _P, [_P, C.c_char_p, C.POINTER(GiCMaterialDesc)]), ("giCDestroyMaterial", None, [_P]),
     ("giCCreateMesh", _P, [_P, C.POINTER(GiCMeshDesc)]), ("giCSetMeshTransform", None, [_P, _FP]),
     ("giCSetMeshInstanceTransforms", None, [_P, _U, _FP]), ("giCSetMeshInstanceIds", None, [_P, _U, C.POINTER(C.c_int32)]),

@@ -104,7 +104,7 @@ struct DeviceBuffer {
   size_t bytes() const { return ptr ? count * sizeof(T) : 0; }
   int upload(const std::vector<T>& v, hipStream_t s)
   {
-    if (alloc(v.size()) != GI_C_OK) return GI_C_ERROR;
+    if (const int rc = alloc(v.size())) { if (rc == GI_C_OUT_OF_MEMORY_INTERNAL) setError("hipMalloc: out of device memory (" + std::to_string(v.size() * sizeof(T)) + " bytes)"); return GI_C_ERROR; }
     if (!v.empty()) HIP_TRY(hipMemcpyAsync(ptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
     return GI_C_OK;
   }
@@ -503,6 +503,7 @@ int giCInitializeDevices(const int32_t* deviceOrdinals, uint32_t count)
   return initDevices(std::vector<int>(deviceOrdinals, deviceOrdinals + count));
 }
 
+uint32_t giCGetApiVersion(void) { return GI_C_API_VERSION; }
 uint32_t giCGetDeviceCount(void) { return g_ctx.initialized ? (uint32_t)g_ctx.devs.size() : 0u; }
 int32_t giCGetDevicePeerAccess(uint32_t index) { return (g_ctx.initialized && index < g_ctx.devs.size()) ? (int32_t)g_ctx.devs[index].peer : -1; }
 
@@ -550,6 +551,14 @@ GiCMaterial* giCCreateMaterial(GiCScene* scene, const char* name, const GiCMater
   if (!scene || !desc) { setError("giCCreateMaterial: null argument"); return nullptr; }
   if (desc->klass > GI_C_MAT_OPEN_PBR) { setError("giCCreateMaterial: unsupported material class"); return nullptr; }
   GiCMaterial* m = new GiCMaterial{scene, name ? name : "", *desc};
+  // subsurface_radius / subsurface_radius_scale joined the block in round 4 (slots 32..35, ignored before): a caller built against the older header leaves them 0, which
+  // would mean an extinction of 1e6 per scene unit.  An all-zero radius AND scale reads as "unset": OpenPBR's defaults (open_pbr_surface.mtlx:47-49: 1; 1, 0.5, 0.25)
+  if (desc->klass == GI_C_MAT_OPEN_PBR) {
+    float* p = m->desc.p;
+    if (p[GI_C_P_SUBSURFACE_RADIUS] == 0.0f && p[GI_C_P_SUBSURFACE_RADIUS_SCALE] == 0.0f && p[GI_C_P_SUBSURFACE_RADIUS_SCALE + 1] == 0.0f && p[GI_C_P_SUBSURFACE_RADIUS_SCALE + 2] == 0.0f) {
+      p[GI_C_P_SUBSURFACE_RADIUS] = 1.0f; p[GI_C_P_SUBSURFACE_RADIUS_SCALE] = 1.0f; p[GI_C_P_SUBSURFACE_RADIUS_SCALE + 1] = 0.5f; p[GI_C_P_SUBSURFACE_RADIUS_SCALE + 2] = 0.25f;
+    }
+  }
   std::lock_guard<std::mutex> g(scene->mutex);
   scene->materials.push_back(m);
   scene->dirty |= DIRTY_MATERIALS | DIRTY_BVH | DIRTY_FRAMEBUFFER;
@@ -1892,6 +1901,9 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
       traceBlocks = (uint32_t)std::min<size_t>((slots + 255) / 256, (size_t)ctx.cuCount * perCu);
     };
     sizeGrids();
+    // HIT-queue entries (and giCTraceRays) hold a TRACE-queue RECORD index in 30 bits (HIT_INDEX_MASK); records run up to shardCapacity * NSHARD, which exceeds the
+    // slot count by the shards' slack -- a pinned pool near 2^30 would push indices past the mask and k_shade would gather the wrong record
+    while (!fused && (uint64_t)shardCapacity(slots, wideBlocks, traceBlocks) * NSHARD > 0x3fffffffull /* HIT_INDEX_MASK, gi_queues.h */) { slots -= slots / 8; sizeGrids(); }
     const uint32_t mediaStride = rs.mediumStackSize ? rs.mediumStackSize * MEDIUM_FLOATS + 4u : 0u;
     // what a plan costs: the slot pool with its queues (per slot: the Slot, the medium stack, and a share of every queue's records) and the sample buffer
     auto planBytes = [&](size_t nSlots, uint64_t nBatch) -> uint64_t {
@@ -1911,7 +1923,7 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
       if (rc == GI_C_OK) rc = D.sampleBuf.alloc(pixels * batchSamples);
       if (rc == GI_C_OK) rc = D.accum.alloc(pixels);
       if (rc == GI_C_OK && mediaStride) rc = D.media.alloc(slots * mediaStride);
-      if (rc == GI_C_OK) break;
+      if (rc == GI_C_OK) { if (attempt > 0) t_lastError.clear(); break; } // (a smaller plan fitted: the "out of memory" of the larger ones is not this render's error)
       if (rc != GI_C_OUT_OF_MEMORY_INTERNAL) return GI_C_ERROR;
       // out of memory: drop what this scene holds in the resizable buffers (a half-grown plan must not stand in the way of the smaller one) and try the next plan
       D.sampleBuf.release(); D.slots.release(); D.media.release();

@@ -343,6 +343,10 @@ void giCTerminate(void);
  * one D2H -- the image is bit-identical to a one-device render.  giCInitialize does the same when $GATLING_DEVICES ("0,1,2,3" or "all") is set, which is
  * how an unmodified caller (hdGatling) gets every GPU of the node.  Renders that shard rows themselves (rowStride > 1 / a row range) stay on the primary. */
 int giCInitializeDevices(const int32_t* deviceOrdinals, uint32_t count);
+/* [ext] Version of this header's ABI: bumped whenever a struct grows or an entry point changes meaning (5: GiCRenderStats gained batches / poolSlots, GI_C_TEX_SLOT_COUNT 9,
+ * the subsurface radius slots of GiCMaterialDesc, the asset-reader / image-loader hooks).  A caller compares giCGetApiVersion() with the GI_C_API_VERSION it was built with. */
+#define GI_C_API_VERSION 5u
+uint32_t giCGetApiVersion(void);
 uint32_t giCGetDeviceCount(void);
 /* [ext] can the primary device and device `index` of the list address each other's memory?  1 = yes (peer access enabled both ways, or the same physical device):
  * row shares are gathered with strided peer copies over xGMI; 0 = no, -1 = the query / the enabling failed: that device's shares are staged through pinned host
