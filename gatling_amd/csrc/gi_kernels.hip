@@ -353,7 +353,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
 //   * everything wave-uniform (claims, chunk and ring bookkeeping) is forced into SGPRs with readfirstlane;
 //   * shadow walks (ANYHIT) end at their first hit, so near-to-far order buys them nothing: no octant flip in their node test.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t DYN_SLOT_ORDER = 0x200u; // bit in k_trace_dyn's `refill` argument (shadow launches): visit children in slot order
+constexpr uint32_t DYN_SLOT_ORDER = 0x200u; // bit in k_trace_dyn's `refill` argument (shadow launches): the launch is the slot-order instantiation (the prologue counts its rays as such)
 constexpr uint32_t DYN_CLAIM = 128;   // rays per cursor atomic (a device-scope atomic on one line completes ~88 times per microsecond; 64 / 256 / 512 measured: r04x)
 constexpr uint32_t DYN_FLUSH_AT = 8;  // the triangle ring is flushed below 64 pairs once this many finished walks wait for it (0 / 2 / 24 measured: r04c)
 constexpr int DYN_WAVES = 5; // resident waves per SIMD the register allocation aims for (96 VGPRs; 6 waves spill and lose, r02)
@@ -365,14 +365,14 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 
 // HELP: the instantiation with helper lanes (thin launches, below); a full launch runs the one without -- the bookkeeping alone (record and ring addresses computed from a
 // register instead of the lane number, the stack base) costs the full launches 3 - 6 % of their traversal time when it is compiled into their loop (r05g).
-template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool CUTOUT, bool TWO, bool HELP>
+template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool CUTOUT, bool TWO, bool HELP, bool SLOT = false>
 __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t refill, WaveTri& W,
                                                uint32_t shardCount, uint32_t claim)
 {
   // Shadow walks end at their first hit, so near-to-far order is not needed for the result -- and which order finds an occluder sooner depends on the scene (C3's soup:
   // slot order visits 7 % fewer nodes; C5's interior, where the occluders sit near the shaded surface: 28 % more, r05c).  The host tells the launch which one to use
-  // (DYN_SLOT_ORDER: the octant flip is zero, so children are visited in slot order) and the kernel counts the walks' node visits for it to choose by.
-  const bool slotOrder = ANYHIT && !TWO && (refill & DYN_SLOT_ORDER) != 0u;
+  // (the SLOT instantiation: no octant flip in the node test, children are visited in slot order) and the kernel counts the walks' node visits for it to choose by.
+  constexpr bool slotOrder = ANYHIT && !TWO && SLOT;
   uint32_t walkSteps = 0u;
   extern __shared__ uint4 s_dyn[];
   uint2 (*s_stack)[TRACE_BLOCK] = reinterpret_cast<uint2 (*)[TRACE_BLOCK]>(s_dyn);
@@ -448,7 +448,7 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
       if (!alive && rank < take) {
         rec = srec; rng = srng;
         if (!ANYHIT) ray_init(v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), ro.w, rdir.w);
-        else { ray_init(v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), 0.01f, ro.w); if (slotOrder) R.octinv = 0u; } // shadow ray (rp_main.rgen:397-429)
+        else ray_init(v3(ro.x, ro.y, ro.z), v3(rdir.x, rdir.y, rdir.z), 0.01f, ro.w); // shadow ray (rp_main.rgen:397-429)
         wave_ray_begin(W, R.tBest);
         wt_hit_put(W, lane, f2u(ro.x), f2u(ro.y), MISS, 0u); // the result if nothing is hit: (tMax, origin.xy, MISS) -- k_route needs the origin for scattering events (medium stacks only); no helpers
         alive = true; draining = false; lastEnd = ringHead; // no pair of this ray is pending
@@ -495,7 +495,7 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
       auto batch = [&](uint32_t n) { wave_tri_batch<COUNT, false, CUTOUT, true>(W, ringHead, n, R, rng, sc, nullptr, 0u, tc); ringHead += n; };
       const bool walking = alive && !draining;
       uint2 Gt = make_uint2(0u, 0u);
-      if (walking) { Gt = trav_node<COUNT, STACK, OVERFLOW, false>(R, sc, nullptr, 0u, s_stack, overflow, tc); if (ANYHIT && !TWO) walkSteps++; }
+      if (walking) { Gt = trav_node<COUNT, STACK, OVERFLOW, false, !slotOrder>(R, sc, nullptr, 0u, s_stack, overflow, tc); if (ANYHIT && !TWO) walkSteps++; }
       // positions from a wave prefix sum over the per-lane pair counts, then every lane writes its own pairs
       const uint32_t cntL = (uint32_t)__popc(Gt.y);
       const uint32_t scan = wave_scan_inclusive(cntL);
@@ -605,15 +605,15 @@ __device__ __forceinline__ bool trace_dyn_prologue(const QueueSet& qs, Counters*
   // the 13 thin launches of a spp-1 frame (r05: C4 233 rays, 0.146 ms).  ceil(n / 64) chunks + one ragged chunk per shard; the waves that stay claim until every shard is dry.
   return (blockIdx.x * (TRACE_BLOCK / 64u) + (threadIdx.x >> 6)) < (nRays + 63u) / 64u + NSHARD;
 }
-template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool CUTOUT>
+template <bool ANYHIT, bool COUNT, uint32_t STACK, bool OVERFLOW, bool CUTOUT, bool SLOT = false>
 __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(DYN_WAVES, 8))) void k_trace_dyn(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t refill)
 {
   __shared__ WaveTri s_wave[TRACE_BLOCK / 64];
   uint32_t shardCount, claim;
   if (!trace_dyn_prologue<ANYHIT>(qs, cnt, qIn, refill, shardCount, claim)) return;
   // a THIN launch -- fewer rays than two chunks per wave -- lasts as long as its slowest ray, not as its throughput allows: its idle lanes help (trace_dyn_body)
-  if (claim == 64u) trace_dyn_body<ANYHIT, COUNT, STACK, OVERFLOW, CUTOUT, false, true>(sc, st, qs, cnt, qIn, refill, s_wave[threadIdx.x >> 6], shardCount, claim);
-  else trace_dyn_body<ANYHIT, COUNT, STACK, OVERFLOW, CUTOUT, false, false>(sc, st, qs, cnt, qIn, refill, s_wave[threadIdx.x >> 6], shardCount, claim);
+  if (claim == 64u) trace_dyn_body<ANYHIT, COUNT, STACK, OVERFLOW, CUTOUT, false, true, SLOT>(sc, st, qs, cnt, qIn, refill, s_wave[threadIdx.x >> 6], shardCount, claim);
+  else trace_dyn_body<ANYHIT, COUNT, STACK, OVERFLOW, CUTOUT, false, false, SLOT>(sc, st, qs, cnt, qIn, refill, s_wave[threadIdx.x >> 6], shardCount, claim);
 }
 // the two-level layout (wave_step2): 16 LDS stack entries, world + object-space ray in registers
 template <bool ANYHIT, bool COUNT, bool CUTOUT>
@@ -938,7 +938,9 @@ static void launchTraceVariant(hipStream_t s, uint32_t blocks, const SceneView& 
     // 8 entries (16 KB per block), 12 (24 KB: 5 blocks per CU still fit next to the 8 KB of WaveTri) or 16 (32 KB: 4 blocks -- one wave per SIMD fewer)
     const uint32_t entries = (sc.bvhDepth <= 8u || spill8) ? 8u : (sc.bvhDepth <= 12u ? 12u : 16u);
     const uint32_t stackBytes = entries * TRACE_BLOCK * (uint32_t)sizeof(uint2);
-#define GI_LAUNCH_DYN(STACK, OVF) hipLaunchKernelGGL((k_trace_dyn<ANYHIT, COUNT, STACK, OVF, CUTOUT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, refill)
+#define GI_LAUNCH_DYN(STACK, OVF) do { \
+      if (ANYHIT && (refill & DYN_SLOT_ORDER)) hipLaunchKernelGGL((k_trace_dyn<ANYHIT, COUNT, STACK, OVF, CUTOUT, ANYHIT>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, refill); \
+      else hipLaunchKernelGGL((k_trace_dyn<ANYHIT, COUNT, STACK, OVF, CUTOUT, false>), dim3(blocks), dim3(TRACE_BLOCK), stackBytes, s, sc, st, qs, cnt, qIn, refill); } while (0)
     if (sc.bvhDepth <= 8u) GI_LAUNCH_DYN(8, false);
     else if (spill8) GI_LAUNCH_DYN(8, true);
     else if (sc.bvhDepth <= 12u) GI_LAUNCH_DYN(12, false);

@@ -723,15 +723,17 @@ __device__ inline void opbr_evaluate_base(const OpbrParams& o, const ShState& st
   if (st.hasCoatFrame) { l1c = to_local_coat(st, k1); nk1c = fmax2(l1c.z, 1e-4f); l1c.z = nk1c; l2c = to_local_coat(st, k2); }
   float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1c));
   float Fd = fresnel_dielectric(nk1, eta);
-  float fc, pc, khc; ggx_eval2(l1c, l2c, o.coatAlpha, o.coatAlphaY, fc, pc, khc);
+  // Lobes whose weight is exactly zero are not evaluated.  The oracle evaluates them and multiplies by the zero -- the same bits: every skipped factor is finite and
+  // non-negative (D, G, Fresnel terms of positive roughness and nk1 >= 1e-4), so its product with the zero weight is +0, and +0 added to a non-negative sum changes
+  // nothing.  (C3's material has neither coat nor metal: 2 of its 3 GGX evaluations per shadow-ray set-up.)
+  float fc = 0.0f, pc = 0.0f, khc = 0.0f, Fch = 0.0f;
+  if (o.coat != 0.0f) { ggx_eval2(l1c, l2c, o.coatAlpha, o.coatAlphaY, fc, pc, khc); Fch = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(khc)); }
   float fs, ps, khs; ggx_eval2(l1, l2, o.alpha, o.alphaY, fs, ps, khs);
-  float Fch = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(khc));
-  V3 Fm = schlick_f82(o.albedo, o.metalTint, khs) * o.specWeight;
   float Fdh = fresnel_dielectric(khs, eta);
   float cd = l2.z / GI_PI;
   float base = 1.0f - Fc, diel = 1.0f - o.metalness;
   V3 gl = v3(Fch * fc, Fch * fc, Fch * fc);
-  gl = gl + ((Fm * o.coatTint) * fs) * (base * o.metalness);
+  if (o.metalness != 0.0f) { const V3 Fm = schlick_f82(o.albedo, o.metalTint, khs) * o.specWeight; gl = gl + ((Fm * o.coatTint) * fs) * (base * o.metalness); }
   gl = gl + ((o.specColor * o.coatTint) * (Fdh * fs)) * (base * diel);
   V3 under = v3(1.0f, 1.0f, 1.0f);
   if (o.filmWeight > 0.0f) { // thin film: colour Fresnel factors in the two glossy lobes, (1 - F_mix) / (1 - F_plain) on what lies beneath the interface
