@@ -265,7 +265,7 @@ def main():
     if args.in_process and world == 1 and args.gpus > 1:
         capi.initialize(devices=list(range(args.gpus)))  # before the first Scene: one giCInitialize per process
 
-    def timed_run(workload, spp, steps, warmup, no_timers):
+    def timed_run(workload, spp, steps, warmup, no_timers, main_leg=True):
         """Scene resident in HBM, `warmup` untimed steps, then exactly `steps` steps between barrier + synchronize; time = max over ranks."""
         desc, rs, w, h, label = make_workload(workload, spp or None)
         rs.progressive_accumulation = False  # every step renders the same frame from sample 0 (no cross-step accumulation)
@@ -321,6 +321,10 @@ def main():
         scene.set_option(capi.OPTION_KERNEL_TIMERS, 0 if no_timers else (8 if workload in ("c1", "c2") else 1))
         for _ in range(warmup):
             step()
+        if not main_leg:  # further legs start on a GPU that idled through the CPU baseline and the counter passes: a 2 ms step (C1) needs more than one to bring the clocks back up
+            t_w = time.perf_counter()
+            while time.perf_counter() - t_w < 0.25:
+                step()
         sync()
         t0 = time.perf_counter()
         stats = []
@@ -339,7 +343,7 @@ def main():
     def measure(workload, spp, steps, warmup, no_timers, no_pmc, main_line):
         """One workload end to end: timed steps, one counting step, the roofline object (live --pmc passes at N = 1).  Every rank takes part;
         rank 0 gets the JSON object, the others None."""
-        R = timed_run(workload, spp, steps, warmup, no_timers)
+        R = timed_run(workload, spp, steps, warmup, no_timers, main_line)
         desc, rs, w, h, label, scene, (r0, r1, rstride), dt, stats, last = (R[k] for k in ("desc", "rs", "w", "h", "label", "scene", "rows", "dt", "stats", "last"))
         if args.probe:
             scene.close()
