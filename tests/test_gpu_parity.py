@@ -949,6 +949,64 @@ def test_dome_light_image_file(gi, orc, tmp_path):
     assert np.array_equal(fallback[..., :3], np.broadcast_to(q.astype(np.float32), fallback[..., :3].shape))
 
 
+def test_images_through_the_asset_reader_and_the_loader_hook_render_the_file_image(gi, tmp_path):
+    """The reference reads every image through the registered GiAssetReader and decodes it with imgio (TextureManager.cpp:39-52; rendererPlugin.cpp:95-143, 189).
+    A dome light whose path only the asset reader can serve renders the image of the same bytes on disk, bit for bit; so does one whose format ("EXR") only the
+    registered loader can decode -- asked with keepHdr set, as Gi.cpp:2215-2230 loads dome images; file textures under asset paths share the path cache."""
+    import ctypes as C
+    from gatling_amd import capi
+    from gatling_amd.scene import CameraDesc, SceneDesc
+    from test_capi_host import _MemoryAssets, _write_png
+    rng = np.random.default_rng(5)
+    _write_png(tmp_path / "sky.png", rng.integers(0, 256, (8, 16, 3), dtype=np.uint8), 2, 8, [0, 1, 2, 3, 4])
+    blob = open(tmp_path / "sky.png", "rb").read()
+    cam = CameraDesc(position=(0, 0, 0), forward=(0, 0, -1), up=(0, 1, 0), vfov=1.2)
+    rs = RenderSettings(spp=2, max_bounces=2)
+    L = capi.load_library()
+
+    def dome_render(path):
+        sc = gi.Scene(SceneDesc(camera=cam))
+        try:
+            sc.dome = L.giCCreateDomeLight(sc.handle, path.encode())
+            return sc.render(rs, 48, 24).copy()
+        finally:
+            sc.close()
+
+    from_file = dome_render(str(tmp_path / "sky.png"))
+    assert from_file[..., :3].std() > 0.05  # the image, not the fallback colour
+    w, h = C.c_uint32(), C.c_uint32()
+    px = np.empty(16 * 8 * 4, np.float32)
+    assert L.giCDebugDecodeImage(str(tmp_path / "sky.png").encode(), 0, C.byref(w), C.byref(h), px.ctypes.data_as(C.POINTER(C.c_float)), px.size) == 1
+    seen = []
+
+    def _load(user, path, data, size, keep_hdr, out):
+        if C.string_at(data, 4) != b"EXR!":
+            return 0
+        seen.append((path.decode(), keep_hdr))
+        out[0].format, out[0].width, out[0].height, out[0].pixels = capi.IMAGE_RGBA32_FLOAT, w.value, h.value, px.ctypes.data
+        return 1
+
+    loader = capi.GiCImageLoader(None, capi.IMAGE_LOAD(_load), capi.IMAGE_RELEASE(lambda user, img: None))
+    mem = _MemoryAssets({"pkg.usdz[env/sky.png]": blob, "pkg.usdz[env/sky.exr]": b"EXR!" + b"\0" * 60})
+    L.giCRegisterAssetReader(C.byref(mem.struct)); L.giCSetImageLoader(C.byref(loader))
+    try:
+        via_reader = dome_render("pkg.usdz[env/sky.png]")
+        via_loader = dome_render("pkg.usdz[env/sky.exr]")
+        sc = gi.Scene(SceneDesc(camera=cam))
+        try:
+            t1 = L.giCCreateTextureFromFile(sc.handle, b"pkg.usdz[env/sky.png]", 1)
+            t2 = L.giCCreateTextureFromFile(sc.handle, b"pkg.usdz[env/sky.png]", 1)
+            assert t1 and t1 == t2 and not L.giCCreateTextureFromFile(sc.handle, b"pkg.usdz[env/none.png]", 1)
+            L.giCDestroyTexture(t1); L.giCDestroyTexture(t2)
+        finally:
+            sc.close()
+    finally:
+        L.giCSetImageLoader(None); L.giCRegisterAssetReader(None)
+    assert np.array_equal(via_reader.view(np.uint32), from_file.view(np.uint32))
+    assert np.array_equal(via_loader.view(np.uint32), from_file.view(np.uint32))
+    assert seen == [("pkg.usdz[env/sky.exr]", 1)] and not mem.open_assets
+
+
 def test_file_textures_are_shared_by_path(gi, tmp_path):
     """giCCreateTextureFromFile hands out ONE texture per (path, colour space) while it is alive -- the reference's weak-pointer
     file cache (TextureManager.cpp:100-150) -- and giCDestroyTexture releases one reference at a time."""
