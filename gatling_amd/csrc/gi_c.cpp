@@ -1131,6 +1131,7 @@ int buildTwoLevel(GiCScene* s, const std::vector<MB>& meshBuilds, const std::vec
   // two-level walk queues MESH triangles there (one BLAS per mesh), so heavily instanced scenes beyond that bound take it automatically (r04; the hit record's
   // triangle word, flat index | class << 28, then bounds the scene at 2^28 flattened triangles)
   if (flatTris >= ((size_t)1 << 26) && want < 0) want = 1;
+  if (flatNodes * sizeof(Node8) >= ((size_t)1 << 32) && want < 0) want = 1; // (the flat walk addresses nodes by 32-bit byte offset, gi_traversal.h node_load: 53 M nodes -- beyond any 2^26-triangle tree)
   if (want <= 0 || instances.empty() || !beyondLds) return GI_C_OK;
   std::vector<Node8> blasNodes; std::vector<BlasTri> blasTris; std::vector<InstTrav> instTrav(instances.size());
   uint32_t blasDepth = 0;

@@ -31,6 +31,12 @@ variants)  # A/B of prebuilt library variants (tools/build_variant.py) on the st
     done
   done
   ;;
+slowtest)  # the whole C2 frame at spp 1024 against the oracle on all host cores (~3 min); log -> profiles/
+  GATLING_SLOW_TESTS=1 timeout 900 python -m pytest tests/test_gpu_full_spp.py -x -q -s -m gpu -k whole_frame > $O/${TAG}_c2_whole_frame_spp1024.log 2>&1; tail -4 $O/${TAG}_c2_whole_frame_spp1024.log
+  ;;
+bigscene)  # 67.7 M flattened triangles -> automatic two-level layout (slow: ~10 GB of host arrays on both sides)
+  GATLING_SLOW_TESTS=1 GATLING_BUILD_TIMING=1 timeout 1200 python -m pytest tests/test_gpu_full_spp.py -x -q -s -m gpu -k beyond_2_pow_26 > $O/${TAG}_scene_beyond_2p26.log 2>&1; tail -6 $O/${TAG}_scene_beyond_2p26.log
+  ;;
 lowspp)  # the delegate's default workload: one giRender per frame at spp 1 / 4 / 16, 13 bounces, progressive
   for V in ${LOWSPP_VARIANTS:-default}; do
     L=""; [ $V != default ] && L=$GRAFT_REPO_ROOT/gatling_amd/variants/libgatling_gi_$V.so
