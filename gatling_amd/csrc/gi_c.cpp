@@ -2023,6 +2023,10 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
         const uint32_t par = (uint32_t)(it & 1u);
         curIter = totalIters; if (timers && (totalIters % timerStride) == 0u) sampledIters++;
         timed(0, [&] { launchRaygen(st, wideBlocks, U, ps, qs, D.dCounters.ptr, par, D.sampleBuf.ptr); });
+        // A batch whose work fits the pool (a low-spp frame: hdGatling renders ONE sample per pixel and call) starts every path in iteration 0, a path traces at most
+        // maxBounces segments, one per iteration (the bounce counter, rp_main.rgen:298-304) -- so k_raygen(maxBounces) has just retired the last samples and nothing is in
+        // flight: no need to find that out two empty iterations later through the poll below (10 launches of ~90 in a spp-1 call).
+        if (rounds == 1 && it == (uint64_t)std::max(1u, U.maxBounces) && rs.mediumStackSize == 0u) { totalIters++; break; }
         if (it >= rounds) {
           // All work cannot be handed out earlier.  From here on every iteration snapshots the queue sizes behind its k_raygen (asynchronous copy into a pinned ring)
           // and tests the snapshot of POLL_LAG iterations ago: the wait is for work the GPU finished long ago -- it still holds the iterations in between, so the

@@ -351,13 +351,14 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
 //   * the launch's rays are the queue's NSHARD shards, and shard k IS cursor range k: a claimed ray's record index is `shard * cap + position`,
 //     no search through the shard prefix sums;
 //   * everything wave-uniform (claims, chunk and ring bookkeeping) is forced into SGPRs with readfirstlane;
-//   * shadow walks (ANYHIT) end at their first hit, so near-to-far order buys them nothing: no octant flip in their node test.
+//   * shadow walks (ANYHIT) end at their first hit, so near-to-far order is optional for them: the SLOT instantiation visits children in slot order (no octant flip
+//     in its node test) and the host launches whichever order the scene's shadow walks have been cheaper in (trace_dyn_body, gi_c.cpp shadowOrder).
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t DYN_SLOT_ORDER = 0x200u; // bit in k_trace_dyn's `refill` argument (shadow launches): the launch is the slot-order instantiation (the prologue counts its rays as such)
 constexpr uint32_t DYN_CLAIM = 128;   // rays per cursor atomic (a device-scope atomic on one line completes ~88 times per microsecond; 64 / 256 / 512 measured: r04x)
 constexpr uint32_t DYN_FLUSH_AT = 8;  // the triangle ring is flushed below 64 pairs once this many finished walks wait for it (0 / 2 / 24 measured: r04c)
 constexpr int DYN_WAVES = 5; // resident waves per SIMD the register allocation aims for (84 - 96 VGPRs).  6 waves (80 VGPRs, 3 - 8 dwords spilled) do not pay:
-                             // C3 trace 55.3 -> 56.2 ms, C5 119 -> 123 (profiles/r05r_six_waves_variants.txt) -- the SIMD's issue rate is shared, more waves do not raise it // resident waves per SIMD the register allocation aims for (96 VGPRs; 6 waves spill and lose, r02)
+                             // C3 trace 55.3 -> 56.2 ms, C5 119 -> 123 (profiles/r05r_six_waves_variants.txt) -- the SIMD's issue rate is shared, more waves do not raise it
 constexpr uint32_t DYN_THIN_WALKERS = 8; // the ring is flushed at the end of every step while this few lanes walk (16: the same, r05d)
 
 template <bool TWO> struct DynRay { using type = RayWalk; };
