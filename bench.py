@@ -437,11 +437,11 @@ def main():
                             # vector-memory request path (tools/ta_calib.hip) -- and `bound` still names the nearer one, with the note saying so
                             roofline["bound"] = "valu" if roofline["valu_frac"] > roofline["frac"] else "hbm"  # derived from THIS run's two fractions, nothing else
                             if max(roofline["valu_frac"], roofline["frac"]) < 0.6:
-                                roofline["bound_note"] = "neither roofline is near: latency / vector-memory request rate bound (DESIGN.md section 4)"
-                            if scattered:
-                                # what earlier calibration experiments found for this kernel family (not a result of this run): N instructions added to the node test slowed
-                                # k_trace_dyn by N / (instructions per step), and no instruction class sat near its own ceiling
-                                roofline["prior_experiment_note"] = "r04: +64 VALU instructions per node test = +11 % traversal time (profiles/r04k_valu_sensitivity.txt); instruction mix profiles/r04r_valu_mix.txt"
+                                roofline["bound_note"] = "neither measured fraction is near 1 (valu_frac: vs the dual-issue ceiling; valu_frac_fp32_only: vs a one-class stream)"
+                            if scattered and main_line:
+                                # what calibration experiments found for this kernel family (a citation, not a result of this run): its time follows its instruction COUNT --
+                                # +64 instructions per node test = +11 % (r04k), more waves or cheaper instruction classes change nothing (r05r, r05s); DESIGN.md section 4
+                                roofline["prior_experiment_note"] = "time follows instruction count: profiles/r04k_valu_sensitivity.txt, r05r_six_waves_variants.txt, r05s_node_test_perm_variants.txt"
                         # raw counters and the per-kernel table go to a FILE (the driver keeps only the last 8 KB of output: r03's line lost C3's value to them)
                         raw["pmc_kernels"] = {k: {c: (round(x, 1) if isinstance(x, float) else x) for c, x in v.items()} for k, v in pmc.items() if k.startswith(prefixes)}
                         if True:  # every kernel of the frame, compactly: time share under counters, VALU issue, lanes, L2 hit (the per-kernel picture of the wavefront pipeline)
@@ -501,14 +501,16 @@ def main():
             if E is not None:
                 raws[wl] = E.pop("_raw", {})
                 r = E["roofline"]
-                extra.update({"label": E["config"]["workload"][:60], "value": E["value"], "unit": "Msamples/s", "ms_per_step": E["ms_per_step"], "steps": e_steps, "warmup": 1, "n_gpus": world,
+                extra.update({"value": E["value"], "unit": "Msamples/s", "ms_per_step": E["ms_per_step"], "steps": e_steps, "n_gpus": world,
                               "segments_per_sample": E["config"]["segments_per_sample"], "iterations_per_step": E["config"]["iterations_per_step"],
                               "stage_ms": r.get("stage_ms_per_step"),
-                              "roofline": {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "algorithmic_frac", "valu_frac", "valu_lane_utilisation",
-                                                                  "l2_hit_rate", "wait_inst_any_frac", "nodes_per_ray", "tris_per_ray", "pmc_note", "valu_frac_fp32_only", "bound_note", "prior_experiment_note") if k in r}})
+                              "roofline": {k: r.get(k) for k in ("bound", "kernel", "achieved", "frac", "traffic", "avg_launch_us", "algorithmic_frac", "valu_frac", "valu_lane_utilisation",
+                                                                  "l2_hit_rate", "wait_inst_any_frac", "nodes_per_ray", "tris_per_ray", "valu_frac_fp32_only", "bound_note") if r.get(k) is not None}})  # (GB/s against 8 000; labels of the legs: make_workload / DESIGN.md section 4)
+                if r.get("pmc_note") not in (None, "ok"):
+                    extra["roofline"]["pmc_note"] = r["pmc_note"]
                 if wl == "c5share":
                     extra["projected_8gpu"] = round(8.0 * E["value"], 1)
-                    extra["projection_note"] = "8 x the rate of one rank's share (rows 3::8 at full spp) on one GPU; leaves out the RCCL gather of 8 x 16.6 MB and rank imbalance (DESIGN.md section 7)"
+                    extra["projection_note"] = "8 x one rank's share (rows 3::8, full spp) on ONE GPU; no multi-GPU run exists (DESIGN.md section 7)"
         except Exception as e:  # noqa: BLE001
             extra["error"] = repr(e)[:300]
         extras.append(extra)
@@ -520,7 +522,7 @@ def main():
             import lowspp
             for wl in ("c3", "c4"):
                 for row in lowspp.measure(wl, [1], 20, quiet=True):
-                    extras.append({"workload": f"{wl}@spp1", "label": "one giCRender call per frame: spp 1, 13 bounces, progressive, 1920x1080, D2H included", "unit": "ms per call",
+                    extras.append({"workload": f"{wl}@spp1", "what": "one giCRender per frame: spp 1, 13 bounces, progressive, D2H included", "unit": "ms per call",
                                    "ms_per_call": row["ms_per_call_mean"], "ms_per_call_min": row["ms_per_call_min"], "iterations_per_call": row["iterations"],
                                    "value": row["Msamples_per_s"], "value_unit": "Msamples/s", "calls": row["calls"], "stage_ms": row["stage_ms"]})
         except Exception as e:  # noqa: BLE001
