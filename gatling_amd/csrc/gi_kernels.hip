@@ -107,6 +107,9 @@ __device__ __forceinline__ bool ray_misses_bounds(const FrameUniforms& U, const 
   return out || tn > tf;
 }
 
+// RAYGEN_ITEMS regen entries per thread and trip: the trip is otherwise two barriers and an atomic round trip around a chain of dependent loads (entry -> slot ->
+// finished sample), and the entries of one thread are independent of each other.
+constexpr int RAYGEN_ITEMS = 2; // (1 -> 2: raygen stage -6 % on C3 / C4; 4: the same, r05x)
 __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st, QueueSet qs, Counters* cnt, uint32_t par, F4* __restrict__ sampleBuf)
 {
   __shared__ AppendScratch<2> sh;
@@ -120,66 +123,81 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st,
     zero_next_counters(cnt, par, !boundsRetire);
     if (threadIdx.x == 0) { const uint32_t left = U.workTotal - workBase; cnt->workBase[par ^ 1u].v = workBase + (n < left ? n : left); }
   }
-  const uint32_t stride = gridDim.x * BLOCK;
+  const uint32_t stride = gridDim.x * BLOCK * RAYGEN_ITEMS;
+  const uint32_t qid[2] = {qOut, qAgain};
   uint32_t trip = 0;
-  for (uint32_t base = blockIdx.x * BLOCK; base < n; base += stride, trip++) {
-    const uint32_t i = base + threadIdx.x;
-    bool more = false; uint32_t slot = 0, rng = 0u; FreshRec fresh{0u, 0u};
-    V3 origin = v3(0.0f, 0.0f, 0.0f), dir = origin; float tMin = 0.0f, tMax = GI_FLT_MAX;
-    if (i < n) {
-      const uint32_t entry = qs.slot[qIn][reader_index(rd, i)];
-      slot = entry & ~(REGEN_MISSED | REGEN_FRESH);
-      Slot* S = &st.slots[slot];
-      F4 id = F4{0.0f, 0.0f, 0.0f, 0.0f};
-      if (!(entry & REGEN_FRESH)) id = ld4(&S->id);
-      if (f2u(id.z) != 0u) { // finish the sample that just terminated (:489-496) -> per-sample colour buffer
-        F4 r = ld4(&S->rad);
-        V3 rad = v3(r.x, r.y, r.z);
-        if (entry & REGEN_MISSED) {
-          // the path left the scene: uniform fallback dome == colour-AOV clear value (rp_main.miss:68-86, Gi.cpp:2184-2199,
-          // 2232-2238).  k_trace routes misses straight here; nothing after the miss can change the sample any more.
-          F4 tb = ld4(&S->thr);
-          rad = rad + v3(tb.x, tb.y, tb.z) * v3(U.background);
-          if (st.neeKey && (f2u(tb.w) & 0x00000fffu) == 0u) nee_aov_record(st, slot, false); // primary miss: no light sampled, "not shadowed" (rp_main.rgen:431-435)
-        }
-        if (st.bouncesAov && U.batchFirstSample + f2u(id.y) == U.spp - 1u) { // Bounces AOV: the pixel's last sample (rp_main.rgen:483-486)
-          // a path that left the scene was routed here straight from k_trace, before the loop's bounce++ (rp_main.rgen:480)
-          const uint32_t bounces = ((f2u(S->thr.w) + ((entry & REGEN_MISSED) ? 1u : 0u)) & 0x00000fffu), maxB = U.maxBounces < 0x00000fffu ? U.maxBounces : 0x00000fffu;
-          const V3 c = gi_colormap_inferno((float)bounces / (float)maxB);
-          F4* dst = &st.bouncesAov[tile_to_image_pixel(U, f2u(id.x))];
-          dst->x = c.x; dst->y = c.y; dst->z = c.z;
-        }
-        if (st.pathSegments) atomicAdd(&st.pathSegments[f2u(id.x)], (f2u(S->thr.w) + ((entry & REGEN_MISSED) ? 1u : 0u)) & 0x00000fffu); // integer sum: order-free
-        float mv = fmax2(rad.x, fmax2(rad.y, rad.z));
-        if (mv > U.maxSampleValue) rad = rad * (U.maxSampleValue / mv);
-        // one aligned 16-byte store: a 12-byte record straddles DRAM sectors and costs two read-modify-writes
-        st4(&sampleBuf[sample_record(U, f2u(id.x), f2u(id.y))], fmax2(0.0f, rad.x), fmax2(0.0f, rad.y), fmax2(0.0f, rad.z), 0.0f);
-      }
-      const uint32_t w = workBase + i; // < 2^32 by construction of the batches (host)
-      more = (i < U.workTotal - workBase) && (w < U.workTotal);
-      if (more) {
-        uint32_t pixelLocal, sLocal; work_item(U, w, pixelLocal, sLocal);
-        const uint32_t pixelIndex = tile_to_image_pixel(U, pixelLocal); // :195 (global index: RNG is tile independent)
-        const uint32_t sampleIndex = U.sampleOffset + U.batchFirstSample + sLocal;
-        make_camera_ray(U, pixelIndex, sampleIndex, origin, dir, tMin, tMax, rng);
-        fresh.rng = rng; fresh.work = w;
-        if (!(U.flags & FLAG_DEFER_SLOT)) slot_begin_path(S, rng, pixelLocal, sLocal); // :274-276 (deferred: written when the first segment hits, route_fresh)
-      }
+  for (uint32_t base = blockIdx.x * BLOCK * RAYGEN_ITEMS; base < n; base += stride, trip++) {
+    uint32_t which[RAYGEN_ITEMS], idx[RAYGEN_ITEMS], slotOf[RAYGEN_ITEMS]; FreshRec freshOf[RAYGEN_ITEMS];
+    V3 originOf[RAYGEN_ITEMS], dirOf[RAYGEN_ITEMS]; float tMinOf[RAYGEN_ITEMS], tMaxOf[RAYGEN_ITEMS];
+    uint32_t entryOf[RAYGEN_ITEMS];
+#pragma unroll
+    for (int k = 0; k < RAYGEN_ITEMS; k++) { // every item's queue entry first: independent loads in flight
+      const uint32_t i = base + (uint32_t)k * BLOCK + threadIdx.x;
+      entryOf[k] = i < n ? qs.slot[qIn][reader_index(rd, i)] : 0u;
     }
-    // a camera ray that cannot reach the scene: what k_route does with a fresh miss (retire_fresh_miss; the segment is counted below), minus the 52-byte record,
-    // the traversal step and the routing pass -- the slot goes straight to the next k_raygen
-    bool again = false;
-    if (boundsRetire && more && ray_misses_bounds(U, origin, dir, tMin, tMax)) { retire_fresh_miss(U, fresh, sampleBuf); more = false; again = true; nRetired++; }
-    const bool pred[2] = {more, again}; const uint32_t qid[2] = {qOut, qAgain}; uint32_t idx[2];
-    block_append<2>(sh, trip, pred, qid, qs.cap, cnt, idx);
-    if (more) {
-      const bool defer = (U.flags & FLAG_DEFER_SLOT) != 0u;
-      qs.slot[qOut][idx[0]] = defer ? (slot | TRACE_FRESH) : slot;
-      st4(&qs.a[qOut][idx[0]], origin.x, origin.y, origin.z, tMin);
-      st4(&qs.b[qOut][idx[0]], dir.x, dir.y, dir.z, tMax);
-      if (defer) qs.fresh[par][idx[0]] = fresh; // 8 bytes beside the record, written and read in queue order
+#pragma unroll
+    for (int k = 0; k < RAYGEN_ITEMS; k++) {
+      const uint32_t i = base + (uint32_t)k * BLOCK + threadIdx.x;
+      bool more = false; uint32_t slot = 0, rng = 0u; FreshRec fresh{0u, 0u};
+      V3 origin = v3(0.0f, 0.0f, 0.0f), dir = origin; float tMin = 0.0f, tMax = GI_FLT_MAX;
+      if (i < n) {
+        const uint32_t entry = entryOf[k];
+        slot = entry & ~(REGEN_MISSED | REGEN_FRESH);
+        Slot* S = &st.slots[slot];
+        F4 id = F4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (!(entry & REGEN_FRESH)) id = ld4(&S->id);
+        if (f2u(id.z) != 0u) { // finish the sample that just terminated (:489-496) -> per-sample colour buffer
+          F4 r = ld4(&S->rad);
+          V3 rad = v3(r.x, r.y, r.z);
+          if (entry & REGEN_MISSED) {
+            // the path left the scene: uniform fallback dome == colour-AOV clear value (rp_main.miss:68-86, Gi.cpp:2184-2199,
+            // 2232-2238).  k_trace routes misses straight here; nothing after the miss can change the sample any more.
+            F4 tb = ld4(&S->thr);
+            rad = rad + v3(tb.x, tb.y, tb.z) * v3(U.background);
+            if (st.neeKey && (f2u(tb.w) & 0x00000fffu) == 0u) nee_aov_record(st, slot, false); // primary miss: no light sampled, "not shadowed" (rp_main.rgen:431-435)
+          }
+          if (st.bouncesAov && U.batchFirstSample + f2u(id.y) == U.spp - 1u) { // Bounces AOV: the pixel's last sample (rp_main.rgen:483-486)
+            // a path that left the scene was routed here straight from k_trace, before the loop's bounce++ (rp_main.rgen:480)
+            const uint32_t bounces = ((f2u(S->thr.w) + ((entry & REGEN_MISSED) ? 1u : 0u)) & 0x00000fffu), maxB = U.maxBounces < 0x00000fffu ? U.maxBounces : 0x00000fffu;
+            const V3 c = gi_colormap_inferno((float)bounces / (float)maxB);
+            F4* dst = &st.bouncesAov[tile_to_image_pixel(U, f2u(id.x))];
+            dst->x = c.x; dst->y = c.y; dst->z = c.z;
+          }
+          if (st.pathSegments) atomicAdd(&st.pathSegments[f2u(id.x)], (f2u(S->thr.w) + ((entry & REGEN_MISSED) ? 1u : 0u)) & 0x00000fffu); // integer sum: order-free
+          float mv = fmax2(rad.x, fmax2(rad.y, rad.z));
+          if (mv > U.maxSampleValue) rad = rad * (U.maxSampleValue / mv);
+          // one aligned 16-byte store: a 12-byte record straddles DRAM sectors and costs two read-modify-writes
+          st4(&sampleBuf[sample_record(U, f2u(id.x), f2u(id.y))], fmax2(0.0f, rad.x), fmax2(0.0f, rad.y), fmax2(0.0f, rad.z), 0.0f);
+        }
+        const uint32_t w = workBase + i; // < 2^32 by construction of the batches (host)
+        more = (i < U.workTotal - workBase) && (w < U.workTotal);
+        if (more) {
+          uint32_t pixelLocal, sLocal; work_item(U, w, pixelLocal, sLocal);
+          const uint32_t pixelIndex = tile_to_image_pixel(U, pixelLocal); // :195 (global index: RNG is tile independent)
+          const uint32_t sampleIndex = U.sampleOffset + U.batchFirstSample + sLocal;
+          make_camera_ray(U, pixelIndex, sampleIndex, origin, dir, tMin, tMax, rng);
+          fresh.rng = rng; fresh.work = w;
+          if (!(U.flags & FLAG_DEFER_SLOT)) slot_begin_path(S, rng, pixelLocal, sLocal); // :274-276 (deferred: written when the first segment hits, route_fresh)
+        }
+      }
+      // a camera ray that cannot reach the scene: what k_route does with a fresh miss (retire_fresh_miss; the segment is counted below), minus the 52-byte record,
+      // the traversal step and the routing pass -- the slot goes straight to the next k_raygen
+      bool again = false;
+      if (boundsRetire && more && ray_misses_bounds(U, origin, dir, tMin, tMax)) { retire_fresh_miss(U, fresh, sampleBuf); more = false; again = true; nRetired++; }
+      which[k] = more ? 0u : (again ? 1u : 2u);
+      slotOf[k] = slot; freshOf[k] = fresh; originOf[k] = origin; dirOf[k] = dir; tMinOf[k] = tMin; tMaxOf[k] = tMax;
     }
-    if (again) qs.slot[qAgain][idx[1]] = slot | REGEN_FRESH;
+    block_append_items<2, RAYGEN_ITEMS>(sh, trip, which, qid, qs.cap, cnt, idx);
+#pragma unroll
+    for (int k = 0; k < RAYGEN_ITEMS; k++) {
+      if (which[k] == 0u) {
+        const bool defer = (U.flags & FLAG_DEFER_SLOT) != 0u;
+        qs.slot[qOut][idx[k]] = defer ? (slotOf[k] | TRACE_FRESH) : slotOf[k];
+        st4(&qs.a[qOut][idx[k]], originOf[k].x, originOf[k].y, originOf[k].z, tMinOf[k]);
+        st4(&qs.b[qOut][idx[k]], dirOf[k].x, dirOf[k].y, dirOf[k].z, tMaxOf[k]);
+        if (defer) qs.fresh[par][idx[k]] = freshOf[k]; // 8 bytes beside the record, written and read in queue order
+      } else if (which[k] == 1u) qs.slot[qAgain][idx[k]] = slotOf[k] | REGEN_FRESH;
+    }
   }
   if (boundsRetire) { // the retired camera rays are segments of their paths (Counters::segments equals the oracle's count): one atomic per wave
     unsigned long long c = nRetired;
@@ -627,50 +645,65 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 
   trace_dyn_body<ANYHIT, COUNT, 16, false, CUTOUT, true, false>(sc, st, qs, cnt, qIn, refill, s_wave[threadIdx.x >> 6], shardCount, claim);
 }
 
-// k_route: sorts k_trace_dyn's in-place results by outcome and material class (same routing as k_trace's epilogue)
+// k_route: sorts k_trace_dyn's in-place results by outcome and material class (same routing as k_trace's epilogue).  A streaming pass whose trip is two barriers and
+// one atomic round trip: ROUTE_ITEMS results per thread and trip (independent loads in flight, a quarter of the trips).
+constexpr int ROUTE_ITEMS = 4; // (1 -> 4: trace + route stage -3.5 % on C4 / C5, -0.5 % on C3, r05w)
 __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t qMiss, FrameUniforms U, F4* __restrict__ sampleBuf)
 {
-  __shared__ AppendScratch<1 + MAT_CLASS_COUNT> sh;
+  constexpr uint32_t NQ = 1 + MAT_CLASS_COUNT, NONE = NQ;
+  __shared__ AppendScratch<NQ> sh;
   QueueReader rd; reader_init(rd, cnt, qIn, qs.cap);
   const uint32_t n = rd.pre[NSHARD];
   if (blockIdx.x == 0 && (U.flags & FLAG_BOUNDS_RETIRE)) zero_consumed_regen(cnt, qIn - Q_TRACE_A); // (k_raygen no longer zeroes it: it appends to it)
-  const uint32_t stride = gridDim.x * BLOCK;
+  const uint32_t stride = gridDim.x * BLOCK * ROUTE_ITEMS;
+  uint32_t qid[NQ]; qid[0] = qMiss;
+#pragma unroll
+  for (uint32_t c = 0; c < MAT_CLASS_COUNT; c++) qid[1 + c] = Q_HIT + c;
   uint32_t trip = 0;
-  for (uint32_t base = blockIdx.x * BLOCK; base < n; base += stride, trip++) {
-    const uint32_t i = base + threadIdx.x;
-    bool hit = false, miss = false, volMiss = false, retired = false, freshHit = false; uint32_t slot = 0, klass = 0, rec = 0u;
-    F4 h = F4{0.0f, 0.0f, 0.0f, 0.0f}, rdir = F4{0.0f, 0.0f, 0.0f, 0.0f};
-    if (i < n) {
-      const uint32_t r = reader_index(rd, i); rec = r;
-      slot = qs.slot[qIn][r];
-      const bool fresh = (slot & TRACE_FRESH) != 0u; slot &= ~TRACE_FRESH; // camera ray of a path whose Slot is still unwritten (FLAG_DEFER_SLOT)
-      h = ld4(&qs.a[qIn][r]);
-      hit = f2u(h.w) != MISS; miss = !hit;
-      // the direction is needed at a miss by the dome lookup only (hits stay in place: k_shade gathers them)
-      if (miss && sc.domeTexture != 0u) rdir = ld4(&qs.b[qIn][r]);
-      if (hit) klass = f2u(h.w) >> 28; // k_trace_dyn's result word: triangle index | material class << 28
-      if (fresh) { // k_shade begins the path (hit); a miss that needs the slot (dome image / medium stack) begins it here, any other retires the sample without a Slot
-        if (hit) freshHit = true;
-        else {
-          const FreshRec f = qs.fresh[qIn - Q_TRACE_A][r];
-          if (sc.domeTexture != 0u || sc.mediumStackSize != 0u) begin_fresh_path(U, st, slot, f);
-          else { retire_fresh_miss(U, f, sampleBuf); retired = true; }
+  for (uint32_t base = blockIdx.x * BLOCK * ROUTE_ITEMS; base < n; base += stride, trip++) {
+    uint32_t which[ROUTE_ITEMS], entry[ROUTE_ITEMS], idx[ROUTE_ITEMS]; F4 rdir[ROUTE_ITEMS]; uint32_t slotOf[ROUTE_ITEMS];
+    uint32_t rec[ROUTE_ITEMS], sw[ROUTE_ITEMS]; F4 h[ROUTE_ITEMS];
+#pragma unroll
+    for (int k = 0; k < ROUTE_ITEMS; k++) { // the loads of all items first: independent requests in flight
+      const uint32_t i = base + (uint32_t)k * BLOCK + threadIdx.x;
+      rec[k] = 0u; sw[k] = 0u; h[k] = F4{0.0f, 0.0f, 0.0f, u2f(MISS)};
+      if (i < n) { rec[k] = reader_index(rd, i); sw[k] = qs.slot[qIn][rec[k]]; h[k] = ld4(&qs.a[qIn][rec[k]]); }
+    }
+#pragma unroll
+    for (int k = 0; k < ROUTE_ITEMS; k++) {
+      const uint32_t i = base + (uint32_t)k * BLOCK + threadIdx.x;
+      which[k] = NONE; entry[k] = 0u; rdir[k] = F4{0.0f, 0.0f, 0.0f, 0.0f}; slotOf[k] = 0u;
+      if (i < n) {
+        const uint32_t r = rec[k];
+        uint32_t slot = sw[k];
+        const bool fresh = (slot & TRACE_FRESH) != 0u; slot &= ~TRACE_FRESH; // camera ray of a path whose Slot is still unwritten (FLAG_DEFER_SLOT)
+        bool hit = f2u(h[k].w) != MISS, miss = !hit, volMiss = false, retired = false, freshHit = false;
+        uint32_t klass = 0u;
+        // the direction is needed at a miss by the dome lookup only (hits stay in place: k_shade gathers them)
+        if (miss && sc.domeTexture != 0u) rdir[k] = ld4(&qs.b[qIn][r]);
+        if (hit) klass = f2u(h[k].w) >> 28; // k_trace_dyn's result word: triangle index | material class << 28
+        if (fresh) { // k_shade begins the path (hit); a miss that needs the slot (dome image / medium stack) begins it here, any other retires the sample without a Slot
+          if (hit) freshHit = true;
+          else {
+            const FreshRec f = qs.fresh[qIn - Q_TRACE_A][r];
+            if (sc.domeTexture != 0u || sc.mediumStackSize != 0u) begin_fresh_path(U, st, slot, f);
+            else { retire_fresh_miss(U, f, sampleBuf); retired = true; }
+          }
         }
-      }
-      if (miss && sc.mediumStackSize) { // the segment ended inside a medium: scattering event for k_shade<2> (rp_main.miss:57-66)
-        volMiss = payload_medium_idx(f2u(st.slots[slot].thr.w), sc.mediumStackSize < MAX_MEDIUM_STACK ? sc.mediumStackSize : MAX_MEDIUM_STACK) > 0u;
-        if (volMiss) { miss = false; klass = 2u; }
+        if (miss && sc.mediumStackSize) { // the segment ended inside a medium: scattering event for k_shade<2> (rp_main.miss:57-66)
+          volMiss = payload_medium_idx(f2u(st.slots[slot].thr.w), sc.mediumStackSize < MAX_MEDIUM_STACK ? sc.mediumStackSize : MAX_MEDIUM_STACK) > 0u;
+          if (volMiss) { miss = false; klass = 2u; }
+        }
+        slotOf[k] = slot;
+        if (hit || volMiss) { which[k] = 1u + klass; entry[k] = r | (freshHit ? HIT_FRESH : 0u) | (volMiss ? HIT_VOLUME : 0u); } // 4 bytes per hit: the record stays where it is
+        else { which[k] = 0u; entry[k] = sc.domeTexture ? slot : (slot | (retired ? REGEN_FRESH : REGEN_MISSED)); }
       }
     }
-    bool pred[1 + MAT_CLASS_COUNT]; uint32_t qid[1 + MAT_CLASS_COUNT]; uint32_t idx[1 + MAT_CLASS_COUNT];
-    pred[0] = miss; qid[0] = qMiss;
+    block_append_items<NQ, ROUTE_ITEMS>(sh, trip, which, qid, qs.cap, cnt, idx);
 #pragma unroll
-    for (uint32_t c = 0; c < MAT_CLASS_COUNT; c++) { pred[1 + c] = (hit || volMiss) && klass == c; qid[1 + c] = Q_HIT + c; }
-    block_append<1 + MAT_CLASS_COUNT>(sh, trip, pred, qid, qs.cap, cnt, idx);
-    if (hit || volMiss) qs.slot[Q_HIT + klass][idx[1 + klass]] = rec | (freshHit ? HIT_FRESH : 0u) | (volMiss ? HIT_VOLUME : 0u); // 4 bytes per hit: the record stays where it is
-    if (miss) {
-      if (sc.domeTexture) { dome_miss(sc, st, slot, v3(rdir.x, rdir.y, rdir.z)); qs.slot[qMiss][idx[0]] = slot; }
-      else qs.slot[qMiss][idx[0]] = slot | (retired ? REGEN_FRESH : REGEN_MISSED);
+    for (int k = 0; k < ROUTE_ITEMS; k++) {
+      if (which[k] == 0u) { if (sc.domeTexture) dome_miss(sc, st, slotOf[k], v3(rdir[k].x, rdir[k].y, rdir[k].z)); qs.slot[qMiss][idx[k]] = entry[k]; }
+      else if (which[k] < NQ) qs.slot[Q_HIT + which[k] - 1u][idx[k]] = entry[k];
     }
   }
 }
