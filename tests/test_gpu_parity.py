@@ -1038,6 +1038,20 @@ def test_volume_medium_stack_parity(gi, orc, stack, nee):
     render_both(gi, orc, desc, rs, 96, 54)
 
 
+@pytest.mark.parametrize("scene_kind", ["soup", "instances"])
+def test_medium_stack_in_scenes_beyond_lds(gi, orc, scene_kind):
+    """Medium stacks in scenes the persistent-wave traversal walks (k_trace_dyn + k_route: a segment that ends inside a medium is a scattering event routed to
+    k_shade<OpenPBR, VOLUME>; the miss record carries (tMax, origin)): a scattering dielectric in a 20 000-triangle soup / on instanced spheres, NEE on and off."""
+    desc = _soup(20000, seed=7) if scene_kind == "soup" else sphere_grid(grid=4, subdivisions=2, material_count=4)
+    p = np.array(desc.materials[0].params, np.float32, copy=True)
+    p[23] = 1.0; p[24:27] = (0.8, 0.9, 0.7); p[28] = 0.5; p[29:32] = (0.3, 0.3, 0.3)  # transmission weight, colour, depth, scatter: an absorbing, scattering medium
+    desc.materials[0].params = p
+    for stack, nee in ((2, True), (4, False)):
+        rs = RenderSettings(spp=3, max_bounces=8, next_event_estimation=nee, medium_stack_size=stack)
+        img, ref, st = render_both(gi, orc, desc, rs, 96, 54)
+        assert st["fusedPath"] == 0
+
+
 def test_volume_stack_of_one_equals_toggle(gi):
     """One absorbing, non-scattering, un-nested medium: mediumStackSize 1 reproduces the inside/outside toggle exactly."""
     desc = volume_scene(scatter=(0, 0, 0), nested=False)
