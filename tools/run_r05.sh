@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 GPU sessions, one script with selectable stages:
-#   gpurun --timeout 1500 -- 'bash tools/run_r05.sh <tag> quick variants lowspp tests bench prof'
+#   gpurun --timeout 1500 -- 'bash tools/run_r05.sh <tag> quick variants lowspp tests bench prof stallpmc'
 # Everything lands under gpurun_out/<tag>_* (merged back by gpurun); copy what should be judged into profiles/ afterwards.
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $O/prof
 TAG=$1; shift
@@ -66,6 +66,15 @@ prof)  # rocprofv3 --kernel-trace --stats of the bench command, per workload -> 
     python tools/summarize_profile.py --kernel-trace $DB --tag ${TAG}_$W --workload $W --spp $S > $O/${TAG}_summary_$W.txt 2>&1; head -14 $O/${TAG}_summary_$W.txt | cut -c1-160
     cp profiles/${TAG}_${W}_rocprofv3_summary.* $O/ 2>/dev/null
   done
+  ;;
+stallpmc)  # where a kernel's wave-cycles go: issue, waits, instruction fetch (separate --pmc passes, no trace options)
+  for SET in "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_IFETCH" "SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH_LEVEL" "SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS"; do
+    N=$(echo $SET | tr ' ' '_' | cut -c1-40)
+    (cd /tmp && timeout 300 rocprofv3 --pmc $SET -d $O/prof/${TAG}_$N -o pmc -- python $GRAFT_REPO_ROOT/tools/gpu_variants.py ${STALL_WORKLOAD:-c3} ${STALL_SPP:-32} - > $O/${TAG}_pmc_$N.log 2>&1)
+    DB=$(find $O/prof/${TAG}_$N -name "*_results.db" | head -1)
+    [ -n "$DB" ] && python tools/pmc_dump.py $DB | grep "${STALL_KERNELS:-k_shade\|k_trace_dyn<false, false\|^#}" >> $O/${TAG}_stall_counters.txt
+  done
+  cat $O/${TAG}_stall_counters.txt
   ;;
 valumix)
   for WS in ${MIX_WORKLOADS:-c3:32}; do W=${WS%%:*}; S=${WS##*:}
