@@ -2135,6 +2135,12 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
     for (int k = 0; k < 4; k++) fprintf(stderr, "[gatling_gi] k_path phase %-14s %5.1f %% of wave cycles, %5.1f of 64 lanes busy per trip\n", names[k], 100.0 * (double)c.phaseCycles[k] / tot, (double)c.phaseLanes[k] / (double)c.phaseTrips);
     fprintf(stderr, "[gatling_gi] k_path trips %llu, %.0f cycles per trip and wave\n", (unsigned long long)c.phaseTrips, tot / (double)c.phaseTrips);
   }
+  if (s->countTraversal && D.hCounters->dynStats[0] && optionValue("phase_stats", 0)) { // k_trace_dyn's lane accounting (counting build, closest-hit launches)
+    const unsigned long long* d = D.hCounters->dynStats; const double st = (double)d[0];
+    fprintf(stderr, "[gatling_gi] k_trace_dyn<closest> %llu wave steps: per step %.1f lanes hold a ray, %.1f run the node test, %.1f wait for the triangle ring; %.3f batches per step of %.1f pairs; "
+                    "a refill every %.2f steps, %.1f lanes each\n", d[0], (double)d[1] / st, (double)d[2] / st, (double)d[3] / st, (double)d[4] / st, d[4] ? (double)d[5] / (double)d[4] : 0.0,
+            d[6] ? st / (double)d[6] : 0.0, d[6] ? (double)d[7] / (double)d[6] : 0.0);
+  }
   if (D.hCounters->overflow) { setError("giCRender: a work-queue shard overflowed its capacity (internal sizing error); the image is invalid"); return GI_C_ERROR; }
   S.traceMs = S.shadeMs = S.raygenMs = S.shadowMs = 0.0;
   if (timers) {

@@ -47,7 +47,7 @@ __global__ void k_init(PathState st, QueueSet qs, Counters* cnt, uint32_t n, uin
     cnt->workBase[0].v = 0; cnt->workBase[1].v = 0; for (uint32_t k = 0; k < NCURSOR; k++) { cnt->cursor[0][k].v = 0; cnt->cursor[1][k].v = 0; }
     if (resetStats) { cnt->shadowOrderRays[0] = 0; cnt->shadowOrderRays[1] = 0; for (int k = 0; k < 16; k++) { cnt->shadowOrderSteps[0][k].v = 0; cnt->shadowOrderSteps[1][k].v = 0; }
                       cnt->segments = 0; cnt->shadowRays = 0; cnt->nodesVisited = 0; cnt->trisTested = 0; cnt->shadowNodesVisited = 0; cnt->shadowTrisTested = 0;
-                      for (int k = 0; k < 4; k++) { cnt->phaseCycles[k] = 0; cnt->phaseLanes[k] = 0; } cnt->phaseTrips = 0; }
+                      for (int k = 0; k < 4; k++) { cnt->phaseCycles[k] = 0; cnt->phaseLanes[k] = 0; } cnt->phaseTrips = 0; for (int k = 0; k < 8; k++) cnt->dynStats[k] = 0; }
   }
   for (; i < n; i += gridDim.x * blockDim.x) qs.slot[Q_REGEN_A][(i / per) * qs.cap + (i % per)] = i | REGEN_FRESH; // the slots themselves stay untouched
 }
@@ -453,6 +453,7 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
   uint32_t keyReg = lane, base = 0u; // the lane whose LDS record this walk reports to; first stack entry that is still this walk's
   bool helper = false;
 #define key (HELP ? keyReg : lane)
+  unsigned long long ds[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull}; // (COUNT) lane accounting, Counters::dynStats
   next_chunk();
   for (;;) {
     const unsigned long long idle = __ballot(!alive);
@@ -474,6 +475,7 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
         alive = true; draining = false; lastEnd = ringHead; // no pair of this ray is pending
         keyReg = lane; base = 0u; helper = false;
       }
+      if (COUNT) { ds[6]++; ds[7] += take; }
       chunkUsed += take;
       if (chunkUsed == chunkCount) next_chunk(); // loads complete while the wave keeps traversing
     } else if (nIdle == 64u) break; // nothing in flight and nothing left to claim (an exhausted chunk is replaced at once, so chunkUsed == chunkCount means there is none)
@@ -512,8 +514,9 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
       // has moved past its last pair (the ring is FIFO: `head` has reached `lastEnd`).  The ring is flushed below 64 pairs when DYN_FLUSH_AT or more lanes are blocked like
       // that, or when few lanes walk.  Results do not depend on any of this (the hit key under atomicMin does not depend on when a pair is tested); only the culling distance
       // a walking ray sees may lag by a step or two.
-      auto batch = [&](uint32_t n) { wave_tri_batch<COUNT, false, CUTOUT, true>(W, ringHead, n, R, rng, sc, nullptr, 0u, tc); ringHead += n; };
+      auto batch = [&](uint32_t n) { wave_tri_batch<COUNT, false, CUTOUT, true>(W, ringHead, n, R, rng, sc, nullptr, 0u, tc); ringHead += n; if (COUNT) { ds[4]++; ds[5] += n; } };
       const bool walking = alive && !draining;
+      if (COUNT) { ds[0]++; ds[1] += (unsigned long long)__popcll(__ballot(alive)); ds[2] += (unsigned long long)__popcll(__ballot(walking)); ds[3] += (unsigned long long)__popcll(__ballot(alive && draining)); }
       uint2 Gt = make_uint2(0u, 0u);
       if (walking) { Gt = trav_node<COUNT, STACK, OVERFLOW, false, !slotOrder>(R, sc, nullptr, 0u, s_stack, overflow, tc); if (ANYHIT && !TWO) walkSteps++; }
       // positions from a wave prefix sum over the per-lane pair counts, then every lane writes its own pairs
@@ -601,6 +604,7 @@ __device__ __forceinline__ void trace_dyn_body(const SceneView& sc, const PathSt
     unsigned long long a = tc.nodes, b = tc.tris;
     for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
     if (lane == 0) { atomicAdd(ANYHIT ? &cnt->shadowNodesVisited : &cnt->nodesVisited, a); atomicAdd(ANYHIT ? &cnt->shadowTrisTested : &cnt->trisTested, b); }
+    if (!ANYHIT && !TWO && lane == 0) for (int k = 0; k < 8; k++) atomicAdd(&cnt->dynStats[k], ds[k]);
   }
 }
 

@@ -25,7 +25,7 @@
 //   bvh_collapse         1         1 = cost-optimal collapse to 8-wide nodes, 0 = greedy
 //   shadow_order         -1        visiting order of shadow walks: -1 = measured per scene (gi_c.cpp shadowOrder), 0 = near-to-far, 1 = slot order
 //   peer_copies          1         multi-device gather: 0 = stage every device's row share through pinned host memory even where peer access exists
-//   phase_stats          0         counting builds: print k_path's phase split
+//   phase_stats          0         counting builds: print k_path's phase split / k_trace_dyn's lane accounting
 #pragma once
 
 #include <cstdlib>

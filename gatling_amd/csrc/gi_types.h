@@ -289,6 +289,9 @@ struct Counters {
   // k_path, counting builds only (GI_C_SCENE_OPTION_COUNT_TRAVERSAL): shader-clock cycles per phase summed over waves, lanes doing useful work per phase summed over
   // trips, trips -- [0] regeneration, [1] closest-hit traversal, [2] shading, [3] shadow ray + finish (GATLING_PHASE_STATS=1 prints them)
   unsigned long long phaseCycles[4], phaseLanes[4], phaseTrips;
+  // k_trace_dyn's closest-hit launches, counting builds only: [0] steps (loop trips of all waves), lanes per step that [1] hold a ray, [2] walk (run the node test),
+  // [3] wait for the triangle ring (drained walk, pairs pending); [4] triangle batches, [5] pairs in them, [6] steps in which some lane was refilled, [7] lanes refilled
+  unsigned long long dynStats[8];
 };
 
 } // namespace gi
