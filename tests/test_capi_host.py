@@ -445,15 +445,17 @@ def test_image_loader_hook_is_asked_first_and_can_decline():
     L = capi.load_library()
     half = np.array([[0.5, 2.0, -1.0, 1.0], [65504.0, 6e-8, 0.0, 0.25]], np.float16)  # incl. the largest half and a subnormal
     rgba8 = np.array([[10, 128, 255, 64]], np.uint8)
+    rgb16 = np.array([[0.5, 2.0, -1.0], [3e-5, 1024.0, 0.125]], np.float16)  # three channels: alpha comes back 1
+    r32 = np.array([[0.75], [1.0e-3]], np.float32)                            # one channel: replicated, alpha 1
     keep, calls = [], []
 
     def _load(user, path, data, size, keep_hdr, out):
         blob = C.string_at(data, size)
         calls.append((path.decode(), blob[:4], keep_hdr))
         if blob[:4] == b"EXR!":
-            arr = half if blob[4:5] == b"h" else rgba8
+            arr, fmt = {b"h": (half, capi.IMAGE_RGBA16_FLOAT), b"b": (rgba8, capi.IMAGE_RGBA8_UNORM), b"3": (rgb16, capi.IMAGE_RGB16_FLOAT), b"r": (r32, capi.IMAGE_R32_FLOAT)}[blob[4:5]]
             keep.append(arr)
-            out[0].format = capi.IMAGE_RGBA16_FLOAT if arr.dtype == np.float16 else capi.IMAGE_RGBA8_UNORM
+            out[0].format = fmt
             out[0].width, out[0].height = arr.shape[0], 1
             out[0].pixels = arr.ctypes.data
             out[0].handle = len(keep)
@@ -462,7 +464,7 @@ def test_image_loader_hook_is_asked_first_and_can_decline():
 
     released = []
     loader = capi.GiCImageLoader(None, capi.IMAGE_LOAD(_load), capi.IMAGE_RELEASE(lambda user, img: released.append(img[0].handle)))
-    mem = _MemoryAssets({"a.exr": b"EXR!h", "b.exr": b"EXR!b", "c.png": open(os.path.join(ROOT, "tests", "golden", "imgio_4c", "4c.png"), "rb").read()})
+    mem = _MemoryAssets({"a.exr": b"EXR!h", "b.exr": b"EXR!b", "d.exr": b"EXR!3", "e.exr": b"EXR!r", "c.png": open(os.path.join(ROOT, "tests", "golden", "imgio_4c", "4c.png"), "rb").read()})
     L.giCRegisterAssetReader(C.byref(mem.struct)); L.giCSetImageLoader(C.byref(loader))
     try:
         ok, w, h, px = _decode(L, "a.exr")
@@ -471,9 +473,15 @@ def test_image_loader_hook_is_asked_first_and_can_decline():
         c = rgba8[0, :3] / np.float32(255.0)
         lin = np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
         assert ok == 1 and (w, h) == (1, 1) and np.allclose(px[:3], lin, rtol=1e-6) and px[3] == np.float32(64) / np.float32(255)
+        ok, w, h, px = _decode(L, "d.exr")
+        want = np.concatenate([rgb16.astype(np.float32), np.ones((2, 1), np.float32)], axis=1).ravel()
+        assert ok == 1 and (w, h) == (2, 1) and np.array_equal(px[:8], want)
+        ok, w, h, px = _decode(L, "e.exr")
+        want = np.concatenate([np.repeat(r32, 3, axis=1), np.ones((2, 1), np.float32)], axis=1).ravel()
+        assert ok == 1 and (w, h) == (2, 1) and np.array_equal(px[:8], want)
         ok, w, h, px = _decode(L, "c.png")  # declined by the loader: the in-library PNG decoder takes it
         assert ok == 1 and (w, h) == (2, 2)
-        assert released == [1, 2] and [c[0] for c in calls] == ["a.exr", "b.exr", "c.png"]
+        assert released == [1, 2, 3, 4] and [c[0] for c in calls] == ["a.exr", "b.exr", "d.exr", "e.exr", "c.png"]
     finally:
         L.giCSetImageLoader(None); L.giCRegisterAssetReader(None)
     assert _decode(L, os.path.join(ROOT, "tests", "golden", "imgio_4c", "4c.png"))[0] == 1
