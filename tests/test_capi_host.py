@@ -21,6 +21,8 @@ def test_header_symbols_are_exported_and_bound():
     L = capi.load_library()
     for name in declared:
         assert getattr(L, name) is not None
+    # the ABI version the library was built with is the header's (a caller checks it before trusting struct layouts, include/gi_c.h)
+    assert L.giCGetApiVersion() == int(re.search(r"#define\s+GI_C_API_VERSION\s+(\d+)u", text).group(1))
 
 
 def test_struct_layouts_match_header():
