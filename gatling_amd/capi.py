@@ -65,7 +65,7 @@ class GiCRenderStats(C.Structure):
                 ("samples", C.c_uint64), ("segments", C.c_uint64), ("shadowRays", C.c_uint64), ("nodesVisited", C.c_uint64),
                 ("trisTested", C.c_uint64), ("shadowNodesVisited", C.c_uint64), ("shadowTrisTested", C.c_uint64),
                 ("iterations", C.c_uint32), ("traceLaunches", C.c_uint32), ("nodeCount", C.c_uint32), ("triangleCount", C.c_uint32),
-                ("fusedPath", C.c_uint32), ("batches", C.c_uint32), ("poolSlots", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("fusedPath", C.c_uint32), ("batches", C.c_uint32), ("poolSlots", C.c_uint32), ("inactiveTriangleCount", C.c_uint32)]
 
 
 # every symbol include/gi_c.h declares: (name, restype, argtypes)

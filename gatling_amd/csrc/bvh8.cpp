@@ -46,6 +46,7 @@ struct Node2 {
 
 constexpr int kBins = 16;
 constexpr uint32_t kMaxLeaf = 3; // 3-bit unary triangle count in Node8::meta
+constexpr float kMaxCoordinate = 1.0e18f; // bvh8.h "Inactive items"
 
 // Cost-optimal collapse (Ylitie, Karras, Laine 2017, section 3.1, implemented from the paper): c[i-1] = C(n, i), the cheapest way to
 // represent the subtree of BVH2 node n as at most i slots of an ancestor's 8-wide node; eff[i-1]: slots actually used (1 = the subtree is
@@ -71,6 +72,8 @@ struct Builder {
   uint32_t leafSize = kMaxLeaf; // the BVH2 stops splitting at this many references (1 for the cost-optimal collapse, which forms the leaves itself)
   const float* extBoxes = nullptr; size_t extCount = 0; // box mode (TLAS over instances, BLAS over pre-padded triangle boxes): 6 floats per item
   size_t itemCount() const { return extBoxes ? extCount : tris.size(); }
+  // Items the tree does not hold (bvh8.h "Inactive items"): refs[0, activeCount) are the active ones after prepare(), `inactive` the rest in input order.
+  std::vector<uint8_t> dead; std::vector<uint32_t> inactive; size_t activeCount = 0;
   explicit Builder(const std::vector<TriRec>& t, const float* boxes = nullptr, size_t boxCount = 0) : tris(t), extBoxes(boxes), extCount(boxCount)
   {
     int threads = (int)std::thread::hardware_concurrency();
@@ -82,28 +85,37 @@ struct Builder {
   void prepare()
   {
     size_t n = itemCount();
-    triBox.resize(n); centroid.resize(3 * n); refs.resize(n);
-    nodes.assign(n ? 2 * n - 1 : 1, Node2{});
-    if (leafSize == 1u) dp.reset(new Dp[nodes.size()]);
+    triBox.resize(n); centroid.resize(3 * n); refs.resize(n); dead.assign(n, 0);
     const int workers = (n > (1u << 16)) ? spareThreads.load() + 1 : 1;
     std::vector<std::future<void>> jobs;
     for (int w = 1; w < workers; w++) jobs.push_back(std::async(std::launch::async, [this, n, w, workers] { prepareRange(n * w / workers, n * (w + 1) / workers); }));
     prepareRange(0, n / workers);
     for (auto& j : jobs) j.get();
+    size_t k = 0;
+    for (size_t i = 0; i < n; i++) { if (dead[i]) inactive.push_back((uint32_t)i); else refs[k++] = (uint32_t)i; }
+    activeCount = k; refs.resize(k);
+    nodes.assign(k ? 2 * k - 1 : 1, Node2{});
+    if (leafSize == 1u) dp.reset(new Dp[nodes.size()]);
   }
+
+  // a coordinate the build can work with: finite and small enough that extents, areas and the padded planes stay far from overflow
+  static bool usable(float x) { return std::fabs(x) <= kMaxCoordinate; } // (false for NaN)
 
   void prepareRange(size_t begin, size_t end)
   {
     for (size_t i = begin; i < end; i++) {
       if (extBoxes) { // the caller's boxes are taken as they are (already padded)
         Box b; for (int a = 0; a < 3; a++) { b.lo[a] = extBoxes[6 * i + a]; b.hi[a] = extBoxes[6 * i + 3 + a]; centroid[3 * i + a] = 0.5f * (b.lo[a] + b.hi[a]); }
-        triBox[i] = b; refs[i] = (uint32_t)i;
+        triBox[i] = b;
+        for (int a = 0; a < 3; a++) if (!usable(b.lo[a]) || !usable(b.hi[a]) || !(b.lo[a] <= b.hi[a])) dead[i] = 1;
         continue;
       }
       const TriRec& t = tris[i];
       Box b; b.reset();
       float p1[3], p2[3];
       for (int a = 0; a < 3; a++) { p1[a] = t.v0[a] + t.e1[a]; p2[a] = t.v0[a] + t.e2[a]; }
+      for (int a = 0; a < 3; a++) if (!usable(t.v0[a]) || !usable(p1[a]) || !usable(p2[a])) dead[i] = 1;
+      if (dead[i]) continue;
       b.grow(t.v0); b.grow(p1); b.grow(p2);
       for (int a = 0; a < 3; a++) {
         // pad: the MT test works on {v0, v0+e1, v0+e2} in exact arithmetic; cover float rounding generously
@@ -112,7 +124,7 @@ struct Builder {
         b.lo[a] -= pad; b.hi[a] += pad;
         centroid[3 * i + a] = 0.5f * (b.lo[a] + b.hi[a]);
       }
-      triBox[i] = b; refs[i] = (uint32_t)i;
+      triBox[i] = b;
     }
   }
 
@@ -193,7 +205,7 @@ struct Builder {
     }
     const float cLeaf = n.total <= maxLeaf ? area * cPrim * (float)n.total : 3.0e38f;
     const float cInt = area + dist[8];
-    d.leaf = cLeaf <= cInt ? 1 : 0;
+    d.leaf = (n.total <= maxLeaf && cLeaf <= cInt) ? 1 : 0; // (the count is tested on its own: with overflowing areas cInt is +inf and the 3e38 stand-in would win)
     d.c[0] = d.leaf ? cLeaf : cInt; d.eff[0] = 1;
     for (int i = 2; i <= 7; i++) {
       if (dist[i] < d.c[i - 2]) { d.c[i - 1] = dist[i]; d.eff[i - 1] = (uint8_t)i; }
@@ -222,12 +234,13 @@ static void buildCore(const std::vector<TriRec>& trisIn, const float* boxes, siz
   out.nodes.clear(); out.tris.clear(); out.maxDepth = 0;
   if (order) order->clear();
   const size_t itemCount = boxes ? boxCount : trisIn.size();
-  if (itemCount == 0) {
+  out.activeTris = 0;
+  auto emptyRoot = [&] {
     Node8 root; std::memset(&root, 0, sizeof(root));
     for (int a = 0; a < 3; a++) { root.e[a] = 127; for (int s = 0; s < 8; s++) { root.qlo[a][s] = 255; root.qhi[a][s] = 0; } }
     out.nodes.push_back(root); out.maxDepth = 1;
-    return;
-  }
+  };
+  if (itemCount == 0) { emptyRoot(); return; }
   const bool timing = getenv("GATLING_BUILD_TIMING") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double tA = now();
@@ -242,8 +255,18 @@ static void buildCore(const std::vector<TriRec>& trisIn, const float* boxes, siz
   if (itemRoots) { collapse = 1; cPrim = 1.0f; B.maxLeaf = 1u; } // an item costs (at least) a node visit; one item per leaf slot
   if (collapse == 1) { B.leafSize = 1; B.cPrim = cPrim; }
   B.prepare();
+  // inactive items (bvh8.h) take no part in the tree; they keep their place in the numbering and sit, unreferenced, behind the leaf-ordered items
+  auto appendInactive = [&] {
+    if (itemRoots) return;
+    for (uint32_t ref : B.inactive) {
+      if (order) { order->push_back(ref); continue; }
+      TriRec t = trisIn[ref]; t.origId = ref; out.tris.push_back(t);
+    }
+  };
+  out.activeTris = (uint32_t)B.activeCount;
+  if (B.activeCount == 0) { emptyRoot(); appendInactive(); return; }
   const double tB = now();
-  uint32_t root2 = B.build(0, (uint32_t)itemCount, 0u);
+  uint32_t root2 = B.build(0, (uint32_t)B.activeCount, 0u);
   const double tC = now();
 
   const Dp* dp = B.dp.get();
@@ -389,6 +412,7 @@ static void buildCore(const std::vector<TriRec>& trisIn, const float* boxes, siz
     triCount = triEnd;
     level.swap(next);
   }
+  appendInactive();
   if (timing) fprintf(stderr, "[gatling_gi] bvh8: prepare %.0f ms, bvh2 %.0f ms, collapse+quantise %.0f ms (%zu items, %zu nodes)\n", tB - tA, tC - tB, now() - tC, itemCount, out.nodes.size());
 }
 

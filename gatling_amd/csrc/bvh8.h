@@ -14,7 +14,14 @@ struct Bvh8 {
   std::vector<Node8> nodes;   // breadth-first: the top of the tree comes first (LDS staging)
   std::vector<TriRec> tris;   // reordered so every node's leaf triangles are contiguous
   uint32_t maxDepth = 0;
+  uint32_t activeTris = 0;    // items the tree references: tris[0, activeTris) (order[0, activeTris) in box mode); the rest are inactive, see below
 };
+
+// Inactive items.  A triangle with a vertex that is not finite or lies beyond 1e18 in magnitude (a box with such a plane, or an inverted box) cannot be hit:
+// it is left out of the tree -- the Vulkan rule the reference inherits from its driver (a primitive whose first vertex has a NaN X is inactive,
+// /root/reference/src/cgpu/impl/CgpuVk.cpp:2561-2670 hands the buffers over as they are), widened to every coordinate and to magnitudes whose extents,
+// surface areas or dequantised planes would overflow fp32.  Inactive items keep their scene-order id (`origId`, `order[]`): they are stored BEHIND the
+// active ones, so `tris.size()` is still the input's size and ids / per-triangle side tables do not shift.
 
 // `tris` in scene order (origId is assigned from the position).  Degenerate input (0 triangles) produces a
 // single empty root so traversal code needs no special case.

@@ -412,7 +412,7 @@ struct GiCScene : SceneDevice {
   int32_t optTraceDyn = -1; // -1 = default; 0 = block-synchronous k_trace everywhere; N = k_trace_dyn refill threshold
   // Visiting order of shadow walks (k_trace_dyn<any>; any order gives the same image): -1 = not chosen yet -- launches alternate between near-to-far (0) and slot order
   // (1) and the frame's node-visit counts are added up below; once both orders have walked enough rays the cheaper one is kept until the tree is rebuilt.
-  int32_t shadowOrder = -1; uint64_t shadowOrderRays[2] = {0, 0}, shadowOrderSteps[2] = {0, 0};
+  std::atomic<int32_t> shadowOrder{-1}; /* read by every device worker at the start of its render, written by the primary at the end of its own */ uint64_t shadowOrderRays[2] = {0, 0}, shadowOrderSteps[2] = {0, 0};
   int32_t optDevices = 0;   // 0 = every device the library was initialised on; N = at most N of them
   uint32_t lastRenderDevices = 0; // devices the previous giCRender used: progressive accumulation blends against each device's own buffer, so a change restarts it
 };
@@ -642,7 +642,9 @@ static bool loadImage(const char* path, bool srgbToLinear, bool keepHdr, uint32_
   GiCDecodedImage img{};
   if (bytes && loader.load && loader.load(loader.user, path, bytes, (uint64_t)size, keepHdr ? 1 : 0, &img) == 1) {
     const size_t n = (size_t)img.width * img.height;
-    if (img.pixels && n > 0 && img.format >= GI_C_IMAGE_RGBA8_UNORM && img.format <= GI_C_IMAGE_RGBA32_FLOAT) {
+    // (a hook's answer is untrusted: a bogus width x height must not become a bad_alloc that leaves through the extern "C" callers, and release / close run whatever
+    // happens -- ADVICE r05.  2^28 texels = 4 GiB of fp32 RGBA is the cap; the reference's largest texture is bounded by maxImageDimension2D, 16 384^2 = 2^28)
+    if (img.pixels && n > 0 && n <= ((size_t)1 << 28) && img.format >= GI_C_IMAGE_RGBA8_UNORM && img.format <= GI_C_IMAGE_RGBA32_FLOAT) try {
       w = img.width; h = img.height; px.assign(n * 4, 1.0f);
       for (size_t i = 0; i < n; i++) {
         float* o = &px[i * 4];
@@ -655,7 +657,7 @@ static bool loadImage(const char* path, bool srgbToLinear, bool keepHdr, uint32_
         }
       }
       ok = true;
-    }
+    } catch (const std::exception&) { ok = false; px.clear(); }
     if (loader.release) loader.release(loader.user, &img);
   }
   if (!ok && bytes) ok = decodeImageBytes(bytes, size, srgbToLinear, w, h, px);
@@ -1111,6 +1113,40 @@ inline void xformPoint(const float a[12], const float p[3], float out[3])
   out[2] = ((a[8] * p[0] + a[9] * p[1]) + a[10] * p[2]) + a[11];
 }
 
+// Hostile geometry (bvh8.h "Inactive items").  A coordinate the build works with: finite, at most 1e18 in magnitude.
+inline bool usableCoordinate(float x) { return std::fabs(x) <= 1.0e18f; } // (false for NaN)
+// An instance the flattening can use: every entry of its affine finite and its 3x3 invertible with an inverse that is finite in fp32 (w2o transforms normals and,
+// in the two-level layout, rays).  Every triangle of an instance that is not -- a NaN or singular giCSetMeshTransform / instance transform -- is inactive.
+inline bool usableInstance(const InstanceRec& ir)
+{
+  for (int i = 0; i < 12; i++) if (!std::isfinite(ir.o2w[i])) return false;
+  for (int i = 0; i < 9; i++) if (!std::isfinite(ir.w2o[i])) return false;
+  return true;
+}
+// Shading attributes of a vertex as the scene build takes them: a normal or tangent with a non-finite component becomes +Z, a non-finite texture coordinate 0, a
+// non-finite bitangent sign +1 (the position is left alone: it decides whether the triangle is active).  The reference uploads what it is given (Gi.cpp:848-861) and
+// a NaN attribute is a NaN pixel there; here hostile attributes cost the shading of the faces that use them, nothing else.
+inline GiCVertex usableShadingAttributes(const GiCVertex& in)
+{
+  GiCVertex v = in;
+  auto direction = [](float* d) { if (!std::isfinite(d[0]) || !std::isfinite(d[1]) || !std::isfinite(d[2])) { d[0] = 0.0f; d[1] = 0.0f; d[2] = 1.0f; } };
+  direction(v.norm); direction(v.tangent);
+  if (!std::isfinite(v.u)) v.u = 0.0f;
+  if (!std::isfinite(v.v)) v.v = 0.0f;
+  if (!std::isfinite(v.bitangentSign)) v.bitangentSign = 1.0f;
+  return v;
+}
+// one flattened triangle (Gi.cpp:1188-1202 hands the instance transform to the TLAS; here it is applied); `usable` false: marked inactive for the builder
+inline void flattenTriangle(const InstanceRec& ir, bool usable, const GiCMesh* m, uint32_t f, TriRec& t)
+{
+  float p0[3], p1[3], p2[3];
+  xformPoint(ir.o2w, m->vertices[m->faces[f].v_i[0]].pos, p0);
+  xformPoint(ir.o2w, m->vertices[m->faces[f].v_i[1]].pos, p1);
+  xformPoint(ir.o2w, m->vertices[m->faces[f].v_i[2]].pos, p2);
+  for (int a = 0; a < 3; a++) { t.v0[a] = p0[a]; t.e1[a] = p1[a] - p0[a]; t.e2[a] = p2[a] - p0[a]; }
+  if (!usable) t.v0[0] = std::numeric_limits<float>::quiet_NaN();
+}
+
 // Two-level layout (SceneView::tlasNodes ...): built next to the flat BVH for instanced scenes that do not fit LDS.  The flat
 // arrays stay (k_shade reads the hit's TriRec, k_aov / giCTraceRays traverse them); the two-level ones are what k_trace_dyn2 walks,
 // and they are small: one BLAS per MESH instead of one subtree per instance, so traversal stays in the caches.
@@ -1147,9 +1183,11 @@ int buildTwoLevel(GiCScene* s, const std::vector<MB>& meshBuilds, const std::vec
     float mlo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mhi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
     for (size_t f = 0; f < nf; f++) {
       float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-      for (int k = 0; k < 3; k++) { const float* p = m->vertices[m->faces[f].v_i[k]].pos; for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); } }
-      padBox(lo, hi);
-      for (int a = 0; a < 3; a++) { boxes[6 * f + a] = lo[a]; boxes[6 * f + 3 + a] = hi[a]; mlo[a] = std::min(mlo[a], lo[a]); mhi[a] = std::max(mhi[a], hi[a]); }
+      bool faceOk = true; // (an unusable face keeps an inverted box: the builder leaves it out, and it must not widen the mesh magnitude below)
+      for (int k = 0; k < 3; k++) { const float* p = m->vertices[m->faces[f].v_i[k]].pos; for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); faceOk = faceOk && usableCoordinate(p[a]); } }
+      if (faceOk) padBox(lo, hi); else for (int a = 0; a < 3; a++) { lo[a] = 3.0e38f; hi[a] = -3.0e38f; }
+      for (int a = 0; a < 3; a++) { boxes[6 * f + a] = lo[a]; boxes[6 * f + 3 + a] = hi[a]; }
+      if (faceOk) for (int a = 0; a < 3; a++) { mlo[a] = std::min(mlo[a], lo[a]); mhi[a] = std::max(mhi[a], hi[a]); }
     }
     Bvh8 b; std::vector<uint32_t> order;
     buildBvh8Boxes(boxes.data(), nf, b, order);
@@ -1171,8 +1209,21 @@ int buildTwoLevel(GiCScene* s, const std::vector<MB>& meshBuilds, const std::vec
       memcpy(tv.o2w, instances[inst].o2w, sizeof(tv.o2w)); memcpy(tv.w2o, instances[inst].w2o, sizeof(tv.w2o));
       tv.blasRoot = nodeBase; tv.triBase = mb.triFirst + ii * (uint32_t)nf; tv.matFlags = mb.matFlags; tv.slack = extent;
       float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-      for (size_t f = 0; f < nf; f++)
-        for (int k = 0; k < 3; k++) { float p[3]; xformPoint(instances[inst].o2w, m->vertices[m->faces[f].v_i[k]].pos, p); for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); } }
+      // inactive triangles (bvh8.h): a face with an unusable OBJECT-space vertex is left out of the BLAS by the builder and out of this box; an unusable instance
+      // keeps the inverted box (the builder leaves it out of the TLAS).  A usable face whose WORLD-space vertex is unusable is inactive in the flat tree but would
+      // be walked here: such scenes keep the flat layout
+      if (usableInstance(instances[inst]))
+        for (size_t f = 0; f < nf; f++) {
+          bool objectOk = true, worldOk = true; float q[3][3];
+          for (int k = 0; k < 3; k++) {
+            const float* o = m->vertices[m->faces[f].v_i[k]].pos;
+            xformPoint(instances[inst].o2w, o, q[k]);
+            for (int a = 0; a < 3; a++) { objectOk = objectOk && usableCoordinate(o[a]); worldOk = worldOk && usableCoordinate(q[k][a]); }
+          }
+          if (!objectOk) continue;
+          if (!worldOk) { if (want > 0) fprintf(stderr, "[gatling_gi] two-level layout not used: an instance carries triangles that leave the usable coordinate range in world space\n"); return GI_C_OK; }
+          for (int k = 0; k < 3; k++) for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], q[k][a]); hi[a] = std::max(hi[a], q[k][a]); }
+        }
       padBox(lo, hi);
       for (int a = 0; a < 3; a++) { instBoxes[6 * inst + a] = lo[a]; instBoxes[6 * inst + 3 + a] = hi[a]; }
     }
@@ -1320,7 +1371,8 @@ int buildScene(GiCScene* s)
       }
       meshRecs.push_back(mr);
     }
-    for (const GiCVertex& v : m->vertices) { // Gi.cpp:848-861: quantise normal/tangent to octahedral unorm2x16, then decode once
+    for (const GiCVertex& vIn : m->vertices) { // Gi.cpp:848-861: quantise normal/tangent to octahedral unorm2x16, then decode once
+      const GiCVertex v = usableShadingAttributes(vIn);
       FVertex fv; memcpy(fv.pos, v.pos, 12); fv.bsign = v.bitangentSign;
       decodeDirection(encodeDirection(v.norm), fv.normal); decodeDirection(encodeDirection(v.tangent), fv.tangent);
       fv.u = v.u; fv.v = v.v;
@@ -1351,13 +1403,11 @@ int buildScene(GiCScene* s)
       ir.pad = (uint32_t)m->id; // object id
       uint32_t instIdx = (uint32_t)instances.size();
       instances.push_back(ir);
+      const bool usable = usableInstance(ir);
       for (uint32_t f = 0; f < (uint32_t)m->faces.size(); f++) {
-        float p0[3], p1[3], p2[3];
-        xformPoint(ir.o2w, m->vertices[m->faces[f].v_i[0]].pos, p0);
-        xformPoint(ir.o2w, m->vertices[m->faces[f].v_i[1]].pos, p1);
-        xformPoint(ir.o2w, m->vertices[m->faces[f].v_i[2]].pos, p2);
         TriRec t;
-        for (int a = 0; a < 3; a++) { t.v0[a] = p0[a]; t.e1[a] = p1[a] - p0[a]; t.e2[a] = p2[a] - p0[a]; t.vi[a] = vertexOffset + m->faces[f].v_i[a]; }
+        flattenTriangle(ir, usable, m, f, t);
+        for (int a = 0; a < 3; a++) t.vi[a] = vertexOffset + m->faces[f].v_i[a];
         t.instance = instIdx; t.prim = f; t.origId = (uint32_t)tris.size(); t.matFlags = matFlags;
         tris.push_back(t);
         faceIdOf.push_back(meshFaceIdAov[f]);
@@ -1368,6 +1418,14 @@ int buildScene(GiCScene* s)
   Bvh8& bvh = H.bvh;
   buildBvh8(tris, bvh);
   { std::vector<TriRec>().swap(tris); } // the BVH holds its own (leaf-ordered) copy
+  s->stats.inactiveTriangleCount = (uint32_t)bvh.tris.size() - bvh.activeTris;
+  if (bvh.activeTris < bvh.tris.size()) { // one line per mesh (bvh8.h "Inactive items")
+    std::vector<uint32_t> perMesh(meshBuilds.size(), 0u);
+    for (size_t i = bvh.activeTris; i < bvh.tris.size(); i++) perMesh[instances[bvh.tris[i].instance].mesh]++;
+    for (const MeshBuild& mb : meshBuilds)
+      if (perMesh[mb.meshIdx]) fprintf(stderr, "[gatling_gi] warning: mesh %s: %u of %zu instanced triangle(s) have a non-finite or out-of-range (> 1e18) vertex or a non-invertible transform and are inactive\n",
+                                       mb.m->name.c_str(), perMesh[mb.meshIdx], mb.m->faces.size() * (size_t)mb.instCount);
+  }
   if (buildTwoLevel(s, meshBuilds, instances, bvh.tris.size(), bvh.nodes.size(), H.two) != GI_C_OK) return GI_C_ERROR;
   if (s->twoLevel) {
     H.flatOfOrig.resize(bvh.tris.size());
@@ -1392,7 +1450,7 @@ int buildScene(GiCScene* s)
       for (const GiCFace& f : m->faces) {
         TriShade q{};
         for (int k = 0; k < 3; k++) {
-          const GiCVertex& v = m->vertices[f.v_i[k]];
+          const GiCVertex v = usableShadingAttributes(m->vertices[f.v_i[k]]);
           memcpy(q.p[k], v.pos, 12); q.n[k] = encodeDirection(v.norm); q.t[k] = encodeDirection(v.tangent);
           q.uv[k][0] = v.u; q.uv[k][1] = v.v; q.bsign[k] = v.bitangentSign; q.vi[k] = mb.vertexOffset + f.v_i[k];
         }
@@ -1456,13 +1514,11 @@ void buildPart(const MeshBuild& mb, uint32_t instInMesh, bool packed, PartBuild&
   out.inst = ir;
   const uint32_t nf = (uint32_t)m->faces.size(), instIdx = mb.instFirst + instInMesh;
   std::vector<TriRec> tris(nf);
-  for (uint32_t f = 0; f < nf; f++) { // as buildScene (Gi.cpp:1188-1202)
-    float p0[3], p1[3], p2[3];
-    xformPoint(ir.o2w, m->vertices[m->faces[f].v_i[0]].pos, p0);
-    xformPoint(ir.o2w, m->vertices[m->faces[f].v_i[1]].pos, p1);
-    xformPoint(ir.o2w, m->vertices[m->faces[f].v_i[2]].pos, p2);
+  const bool usable = usableInstance(ir);
+  for (uint32_t f = 0; f < nf; f++) { // as buildScene
     TriRec& t = tris[f];
-    for (int a = 0; a < 3; a++) { t.v0[a] = p0[a]; t.e1[a] = p1[a] - p0[a]; t.e2[a] = p2[a] - p0[a]; t.vi[a] = mb.vertexOffset + m->faces[f].v_i[a]; }
+    flattenTriangle(ir, usable, m, f, t);
+    for (int a = 0; a < 3; a++) t.vi[a] = mb.vertexOffset + m->faces[f].v_i[a];
     t.instance = instIdx; t.prim = f; t.origId = f; t.matFlags = mb.matFlags;
     if (packed) t.vi[0] = mb.shadeBase + f;
   }
@@ -1956,7 +2012,7 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
     F4* colorOut = reinterpret_cast<F4*>(rbMem(colorRb, D.slot));
     const bool nee = rs.nextEventEstimation != 0;
     const uint32_t dynRefill = traceDynRefill(s);
-    const int32_t shadowOrderNow = optionSet("shadow_order") ? (int32_t)optionValue("shadow_order", -1) : s->shadowOrder; // (GATLING_OPTIONS=shadow_order=0|1 pins it)
+    const int32_t shadowOrderNow = optionSet("shadow_order") ? (int32_t)optionValue("shadow_order", -1) : s->shadowOrder.load(); // (GATLING_OPTIONS=shadow_order=0|1 pins it)
     // Bounds retire (r04n): on the k_trace_dyn path a deferred-slot camera ray that cannot reach the scene's bounds is retired by k_raygen itself (C4: 58 % of the
     // camera rays, C3: ~45 %) -- same sample, same segment count, no ray record, no traversal step, no routing.  Not with a dome image / medium stack (a miss needs
     // the slot), not in counting builds (the root visit of such a ray is part of nodes-per-ray), not on the two-level layout (bounds of the TLAS root: not kept).
@@ -2052,7 +2108,9 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
         for (uint32_t klass = 0; klass < MAT_CLASS_COUNT; klass++)
           if (s->classMask & (1u << klass)) timed(2, [&] { launchShade(st, wideBlocks, klass, (s->classTextured & (1u << klass)) != 0u, rs.mediumStackSize != 0u, U, view, ps, qs, D.dCounters.ptr, par); });
         if (nee) {
-          const int32_t order = shadowOrderNow >= 0 ? shadowOrderNow : (int32_t)(totalIters & 1u); // not chosen yet: alternate, and count (below)
+          // (the slot-order flag belongs to k_trace_dyn: with dynamic refill off -- TRACE_DYNAMIC 0 -- dynRefill stays 0 so that launchTrace picks the block-synchronous
+          // k_trace the grid was sized for, and there is no order to measure)
+          const int32_t order = (dynRefill & 0xffu) == 0u ? 0 : (shadowOrderNow >= 0 ? shadowOrderNow : (int32_t)(totalIters & 1u)); // not chosen yet: alternate, and count (below)
           timed(3, [&] { launchTrace(st, traceBlocks, true, s->countTraversal, view, ps, qs, D.dCounters.ptr, Q_SHADOW, Q_SHADOW, dynRefill | (order ? TRACE_DYN_SLOT_ORDER : 0u), wideBlocks, U, D.sampleBuf.ptr); });
         }
         if (iterLog) { // (GATLING_ITER_LOG, with kernel timers on every iteration: what each iteration's queues held -- one sync per iteration, for measurements only)
@@ -2115,7 +2173,7 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
   S.renderMs = tEnd - tStart; S.samples = (uint64_t)pixels * rs.spp; S.iterations = iters; S.traceLaunches = traceLaunches; S.fusedPath = usedFused ? 1u : 0u;
   S.segments = D.hCounters->segments; S.shadowRays = D.hCounters->shadowRays; S.nodesVisited = D.hCounters->nodesVisited; S.trisTested = D.hCounters->trisTested;
   S.shadowNodesVisited = D.hCounters->shadowNodesVisited; S.shadowTrisTested = D.hCounters->shadowTrisTested;
-  if (D.slot == 0u && s->shadowOrder < 0) { // choose the shadow walks' order once both have been measured on enough rays of this scene: fewer node visits per ray wins
+  if (D.slot == 0u && colorRb && s->shadowOrder.load() < 0) { // (colorRb: an AOV-only render never ran k_init -- the counters would be the previous render's) choose the shadow walks' order once both have been measured on enough rays of this scene: fewer node visits per ray wins
     for (int m = 0; m < 2; m++) {
       s->shadowOrderRays[m] += D.hCounters->shadowOrderRays[m];
       for (int k = 0; k < 16; k++) s->shadowOrderSteps[m] += D.hCounters->shadowOrderSteps[m][k].v;
@@ -2126,7 +2184,7 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
       s->shadowOrder = (double)s->shadowOrderSteps[1] * (double)s->shadowOrderRays[0] < (double)s->shadowOrderSteps[0] * (double)s->shadowOrderRays[1] ? 1 : 0;
       if (getenv("GATLING_BUILD_TIMING")) fprintf(stderr, "[gatling_gi] shadow walks: near-to-far %.3f node visits per ray (%llu rays), slot order %.3f (%llu rays) -> %s\n",
                                                   (double)s->shadowOrderSteps[0] / (double)s->shadowOrderRays[0], (unsigned long long)s->shadowOrderRays[0],
-                                                  (double)s->shadowOrderSteps[1] / (double)s->shadowOrderRays[1], (unsigned long long)s->shadowOrderRays[1], s->shadowOrder ? "slot order" : "near-to-far");
+                                                  (double)s->shadowOrderSteps[1] / (double)s->shadowOrderRays[1], (unsigned long long)s->shadowOrderRays[1], s->shadowOrder.load() ? "slot order" : "near-to-far");
     }
   }
   if (s->countTraversal && D.hCounters->phaseTrips && optionValue("phase_stats", 0)) { // k_path's phase split (counting build)
@@ -2255,6 +2313,21 @@ static int giCRenderImpl(const GiCRenderParams* params)
   const uint32_t width = sizeRb->width, height = sizeRb->height;
   if (width == 0 || height == 0) return GI_C_OK; // Render.Empty-style degenerate target: nothing to do
   if (width > 65535u || height > 65535u) { setError("giCRender: image dimensions exceed 65535 (imageDims packing, rp_main.h:38)"); return GI_C_ERROR; }
+  { // a camera the ray generation can use (the reference passes whatever Hydra hands it, Gi.cpp:2373-2426; a NaN there is a NaN image): refused, with the field named
+    const GiCCameraDesc& c = params->camera;
+    const float fields[] = {c.position[0], c.position[1], c.position[2], c.forward[0], c.forward[1], c.forward[2], c.up[0], c.up[1], c.up[2],
+                            c.vfov, c.fStop, c.focusDistance, c.focalLength, c.clipStart, c.clipEnd, c.exposure};
+    for (float f : fields) if (!std::isfinite(f)) { setError("giCRender: the camera has a non-finite field"); return GI_C_ERROR; }
+    const float f2 = (c.forward[0] * c.forward[0] + c.forward[1] * c.forward[1]) + c.forward[2] * c.forward[2], u2 = (c.up[0] * c.up[0] + c.up[1] * c.up[1]) + c.up[2] * c.up[2];
+    if (!(f2 > 0.0f) || !(u2 > 0.0f) || !std::isfinite(f2) || !std::isfinite(u2) || !std::isfinite(1.0f / sqrtf(f2)) || !std::isfinite(1.0f / sqrtf(u2))) { setError("giCRender: the camera's forward or up vector cannot be normalised (zero, denormal or overflowing length)"); return GI_C_ERROR; }
+    if (!(c.vfov > 0.0f && c.vfov < 3.14159265f)) { setError("giCRender: the camera's vertical field of view must lie inside (0, pi) radians"); return GI_C_ERROR; }
+    if (!std::isfinite(1.0f / (2.0f * tanf(c.vfov * 0.5f)))) { setError("giCRender: the camera's vertical field of view is too small for the image plane distance to be finite"); return GI_C_ERROR; }
+  }
+  { // render settings that enter the arithmetic as floats
+    const float fields[] = {rs.rrInvMinTermProb, rs.lightIntensityMultiplier, rs.metersPerSceneUnit, rs.frame};
+    for (float f : fields) if (!std::isfinite(f)) { setError("giCRender: the render settings have a non-finite field"); return GI_C_ERROR; }
+    if (std::isnan(rs.maxSampleValue)) { setError("giCRender: maxSampleValue is NaN"); return GI_C_ERROR; } // (+inf: no clamp)
+  }
   uint32_t rowBegin = params->rowBegin, rowEnd = params->rowEnd ? params->rowEnd : height;
   const uint32_t rowStride = params->rowStride ? params->rowStride : 1u;
   if (rowBegin > rowEnd || rowEnd > height) { setError("giCRender: bad row range"); return GI_C_ERROR; }
@@ -2431,7 +2504,16 @@ static int validateTree(const std::vector<Node8>& nodes, const std::vector<TriRe
       }
     }
   }
-  for (uint32_t i = 0; i < triCount; i++) if (!seen[i]) violations++;
+  // every active triangle sits in exactly one leaf; an inactive one (bvh8.h: a vertex that is not finite or beyond 1e18) in none
+  std::vector<uint8_t> inactive(triCount, 0);
+  for (const TriRec& t : trisArr) {
+    if (t.origId >= triCount) { violations++; continue; }
+    for (int a = 0; a < 3; a++) {
+      const float x0 = t.v0[a], x1 = t.v0[a] + t.e1[a], x2 = t.v0[a] + t.e2[a];
+      if (!(std::fabs(x0) <= 1.0e18f) || !(std::fabs(x1) <= 1.0e18f) || !(std::fabs(x2) <= 1.0e18f)) inactive[t.origId] = 1;
+    }
+  }
+  for (uint32_t i = 0; i < triCount; i++) if ((seen[i] != 0) == (inactive[i] != 0)) violations++;
   return violations;
 }
 

@@ -329,7 +329,7 @@ typedef struct GiCRenderStats {
   uint32_t fusedPath;    /* 1: the colour pass ran as the fused persistent kernel k_path (LDS-resident scene) */
   uint32_t batches;      /* sample batches the frame was cut into (per-sample colour buffer budget; memory plan of giCRender) */
   uint32_t poolSlots;    /* slots of the persistent path pool this render used (0: fused kernel)                              */
-  uint32_t reserved0;
+  uint32_t inactiveTriangleCount; /* instanced triangles left out of the BVH: a non-finite or out-of-range (> 1e18) vertex, a non-invertible transform (was reserved0) */
 } GiCRenderStats;
 
 /* Gi.h:199-200.  deviceOrdinal selects the HIP device (the reference picks one Vulkan device by score,

@@ -487,3 +487,31 @@ def test_image_loader_hook_is_asked_first_and_can_decline():
     finally:
         L.giCSetImageLoader(None); L.giCRegisterAssetReader(None)
     assert _decode(L, os.path.join(ROOT, "tests", "golden", "imgio_4c", "4c.png"))[0] == 1
+
+
+def test_image_loader_hook_with_bogus_dimensions_fails_cleanly():
+    """A loader that answers with a size it has no pixels for (2^31-1 squared, or 2^16 x 2^16 = beyond the 2^28-texel cap) must cost a failed load, not the
+    process: no allocation is attempted, `release` and the asset's `close` still run, and the next load works."""
+    L = capi.load_library()
+    tiny = np.zeros(4, np.float32)
+    sizes = iter([(0x7fffffff, 0x7fffffff), (1 << 16, 1 << 16), (0, 5), (1, 1)])
+
+    def _load(user, path, data, size, keep_hdr, out):
+        out[0].format = capi.IMAGE_RGBA32_FLOAT
+        out[0].width, out[0].height = next(sizes)
+        out[0].pixels = tiny.ctypes.data
+        out[0].handle = 7
+        return 1
+
+    released = []
+    loader = capi.GiCImageLoader(None, capi.IMAGE_LOAD(_load), capi.IMAGE_RELEASE(lambda user, img: released.append(img[0].handle)))
+    mem = _MemoryAssets({"x.exr": b"EXR!....."})
+    L.giCRegisterAssetReader(C.byref(mem.struct)); L.giCSetImageLoader(C.byref(loader))
+    try:
+        for _ in range(3):
+            assert _decode(L, "x.exr")[0] == 0
+        ok, w, h, px = _decode(L, "x.exr")
+        assert ok == 1 and (w, h) == (1, 1)
+        assert released == [7, 7, 7, 7] and not mem.open_assets
+    finally:
+        L.giCSetImageLoader(None); L.giCRegisterAssetReader(None)
