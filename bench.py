@@ -325,8 +325,16 @@ def main():
         # and get their stage breakdown from one more, untimed step with them on; the main line keeps its events inside the timed region (one pair per fused launch).
         two_phase = (not main_leg) and timer_stride == 1
         scene.set_option(capi.OPTION_KERNEL_TIMERS, 0 if two_phase else timer_stride)
-        for _ in range(warmup):
+        # ingest / BVH build / upload are "reported separately": the first untimed step is the one that builds and uploads the scene (giCRender syncs the
+        # geometry lazily, like giRender's dirty handling) -- its wall time and the library's own build / upload clocks go into the line as first_frame_ms / build_ms / upload_ms
+        first = {"build_ms": None, "upload_ms": None, "first_frame_ms": None}
+        for i in range(warmup):
+            t_f = time.perf_counter()
             step()
+            if i == 0:
+                torch.cuda.synchronize()
+                s0 = scene.stats()
+                first = {"build_ms": round(s0["bvhBuildMs"], 2), "upload_ms": round(s0["uploadMs"], 2), "first_frame_ms": round((time.perf_counter() - t_f) * 1e3, 2)}
         if not main_leg:  # further legs start on a GPU that idled through the CPU baseline and the counter passes: a 2 ms step (C1) needs more than one to bring the clocks back
             t_w = time.perf_counter()  # up, and a big scene's second and third frames are still 0.2 - 1 % slower than its tenth (profiles/r05fh_clock_power_under_load.txt)
             while time.perf_counter() - t_w < 1.0:
@@ -351,7 +359,7 @@ def main():
             sync()
             timer_stats = [scene.stats()]
 
-        return {"desc": desc, "rs": rs, "w": w, "h": h, "label": label, "scene": scene, "rows": (r0, r1, rstride), "dt": dt, "stats": stats, "timer_stats": timer_stats, "last": last}
+        return {"desc": desc, "rs": rs, "w": w, "h": h, "label": label, "scene": scene, "rows": (r0, r1, rstride), "dt": dt, "stats": stats, "timer_stats": timer_stats, "last": last, "first": first}
 
     def measure(workload, spp, steps, warmup, no_timers, no_pmc, main_line):
         """One workload end to end: timed steps, one counting step, the roofline object (live --pmc passes at N = 1).  Every rank takes part;
@@ -474,6 +482,7 @@ def main():
                               "parallelism": f"rows-interleaved{world}" if world > 1 else (f"in-process rows-interleaved{args.gpus}" if args.in_process and args.gpus > 1 else "single"), "segments_per_sample": round(seg_per_sample, 4),
                               "triangles": cst["triangleCount"], "bvh8_nodes": cst["nodeCount"], "iterations_per_step": stats[-1]["iterations"]},
                    "roofline": roofline}
+            out.update(R["first"])  # build_ms / upload_ms / first_frame_ms (outside the timed region)
             out["_raw"] = raw
             if os.environ.get("GATLING_BENCH_CHECKSUM"):  # tests: the frame rank 0 ends up with (host memory), as a checksum
                 import hashlib
@@ -518,6 +527,7 @@ def main():
                 extra.update({"value": E["value"], "unit": "Msamples/s", "ms_per_step": E["ms_per_step"], "steps": e_steps, "n_gpus": world,
                               "events_in_timed_region": bool(wl in ("c1", "c2")),  # big-scene legs: stage_ms / avg_launch_us come from one untimed step after the timed ones (timed_run)
                               "segments_per_sample": E["config"]["segments_per_sample"], "iterations_per_step": E["config"]["iterations_per_step"],
+                              "build_ms": E.get("build_ms"), "upload_ms": E.get("upload_ms"), "first_frame_ms": E.get("first_frame_ms"),
                               "stage_ms": r.get("stage_ms_per_step"),
                               "roofline": {k: r.get(k) for k in ("bound", "kernel", "achieved", "frac", "traffic", "avg_launch_us", "algorithmic_frac", "valu_frac", "valu_lane_utilisation",
                                                                   "l2_hit_rate", "wait_inst_any_frac", "nodes_per_ray", "tris_per_ray", "valu_frac_fp32_only", "bound_note") if r.get(k) is not None}})  # (GB/s against 8 000; labels of the legs: make_workload / DESIGN.md section 4)

@@ -145,6 +145,7 @@ SYMBOLS = [
     ("giCGetRenderStats", C.c_int, [_P, C.POINTER(GiCRenderStats)]), ("giCSetSceneOption", C.c_int, [_P, _I, _I]),
     ("giCTraceRays", C.c_int, [_P, _U, _FP, _FP, _F, _F, _FP, C.POINTER(C.c_int32)]),
     ("giCDebugEvalBsdf", C.c_int, [C.POINTER(GiCMaterialDesc), _U, _FP, _FP]),
+    ("giCDebugShadeClass", C.c_int, [C.POINTER(GiCMaterialDesc)]),
     ("giCDebugValidateBvh", C.c_int, [_FP, _U, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("giCDebugValidatePartitionedBvh", C.c_int, [_FP, _U, _U, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("giCDebugTexRuntime", C.c_int, [_FP, _U, _U, _U, _U, _FP, _FP]),
@@ -467,6 +468,12 @@ class Scene:
             self.lights, self.meshes, self.materials, self.textures, self.dome = [], [], [], [], None
             self.L.giCDestroyScene(self.handle)
             self.handle = None
+
+
+def shade_class(material) -> int:
+    """giCDebugShadeClass: the k_shade variant (shade class) of an untextured material; host only."""
+    md = GiCMaterialDesc(material.klass, 0, (C.c_float * P_COUNT)(*np.asarray(material.params, np.float32)))
+    return int(load_library().giCDebugShadeClass(C.byref(md)))
 
 
 def bsdf_debug(material, items, device: int = 0):

@@ -41,7 +41,7 @@ using namespace gi;
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 
-constexpr bool WORK_ORDER_PIXEL_MAJOR_DEFAULT = true;  // (GATLING_WORK_ORDER) FLAG_PIXEL_MAJOR, gi_queues.h work_item
+constexpr bool WORK_ORDER_PIXEL_MAJOR_DEFAULT = true;  // (GATLING_OPTIONS work_order) FLAG_PIXEL_MAJOR, gi_queues.h work_item
 
 thread_local std::string t_lastError;
 void setError(const std::string& e) { t_lastError = e; fprintf(stderr, "[gatling_gi] error: %s\n", e.c_str()); }
@@ -54,7 +54,7 @@ void setError(const std::string& e) { t_lastError = e; fprintf(stderr, "[gatling
 
 // One entry per HIP device the library renders on (giCInitializeDevices / $GATLING_DEVICES; giCInitialize: one).  devs[0] is the PRIMARY device:
 // render buffers, textures and every single-device entry point live there; the others hold replicas of the scene and render row shares.
-struct DevCtx { int device = 0; int cuCount = 256; hipStream_t stream = nullptr;
+struct DevCtx { int device = 0; int cuCount = 256; hipStream_t stream = nullptr; hipStream_t stream2 = nullptr; /* the shadow launches of two-stream batches (renderOnDevice "two streams") */
                 int peer = 1; /* 1: the primary device and this one address each other's memory (peer access enabled both ways, or the same physical device); 0: no peer access --
                                  the device's row shares travel through pinned host memory; -1: hipDeviceCanAccessPeer / EnablePeerAccess failed with an error */ };
 // One host thread per further device, created with the first multi-device render and kept until giCTerminate (a frame's share is handed to it as a job; until
@@ -357,6 +357,7 @@ struct SceneDevice {
   uint64_t memTotalMb = 0;       // the device's memory (hipMemGetInfo, asked once): sizes the default sample-buffer budget
   static constexpr uint32_t POLL_RING = 4, POLL_LAG = 2; // drain test of the bounce loop: iteration it reads the queue sizes of iteration it - POLL_LAG (giCRenderImpl)
   PaddedCounter* hPoll = nullptr; hipEvent_t pollEvent[POLL_RING] = {}; // pinned ring of queue-size snapshots + their completion events
+  hipEvent_t evShade = nullptr, evShadow = nullptr; // two-stream batches: k_shade(i) done (the second stream's shadow launch waits for it) / shadow launch (i) done (k_raygen(i + 1) waits for it)
   GiCRenderStats stats{};
   std::vector<hipEvent_t> eventPool;
   void releaseAll();
@@ -402,6 +403,7 @@ struct GiCScene : SceneDevice {
   bool shadePacked = false; // the built scene carries TriShade records (beyond LDS)
   uint32_t classMask = 0; // material classes that own at least one triangle (one k_shade launch per class)
   uint32_t classTextured = 0; // classes with at least one textured material in use (k_shade<class, TEXTURED>)
+  uint32_t shadeClassMask = 0, shadeClassTextured = 0; // the same per SHADE class (gi_types.h: the HIT queues of the wavefront pipeline; classMask / classTextured pick the fused kernels)
   std::unique_ptr<SceneHost> host; // the scene as host arrays, kept for incremental transform updates
   std::vector<std::unique_ptr<SceneDevice>> replicas; // devices 1 .. N-1 (created with the first build when the library runs on several devices)
   // options + stats
@@ -429,6 +431,8 @@ void SceneDevice::releaseAll()
   qFresh[0].release(); qFresh[1].release();
   dCounters.release();
   if (hCounters) { (void)hipHostFree(hCounters); hCounters = nullptr; }
+  if (evShade) { (void)hipEventDestroy(evShade); evShade = nullptr; }
+  if (evShadow) { (void)hipEventDestroy(evShadow); evShadow = nullptr; }
   if (hPoll) { (void)hipHostFree(hPoll); hPoll = nullptr; for (hipEvent_t& e : pollEvent) { (void)hipEventDestroy(e); e = nullptr; } }
   for (hipEvent_t e : eventPool) (void)hipEventDestroy(e);
   eventPool.clear();
@@ -459,6 +463,7 @@ static int initDevices(const std::vector<int>& ordinals)
     HIP_TRY(hipGetDeviceProperties(&prop, d));
     c.cuCount = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
     devs.push_back(c);
   }
   // the row shares travel to the primary device over xGMI: peer access both ways.  The outcome is kept (giCGetDevicePeerAccess) and decides how a device's share is
@@ -516,6 +521,7 @@ void giCTerminate(void)
     (void)hipSetDevice(c.device);
     (void)hipStreamSynchronize(c.stream);
     (void)hipStreamDestroy(c.stream);
+    if (c.stream2) { (void)hipStreamSynchronize(c.stream2); (void)hipStreamDestroy(c.stream2); }
   }
   g_ctx.devs.clear();
   g_ctx.stream = nullptr;
@@ -1113,6 +1119,20 @@ inline void xformPoint(const float a[12], const float p[3], float out[3])
   out[2] = ((a[8] * p[0] + a[9] * p[1]) + a[10] * p[2]) + a[11];
 }
 
+// Shade class of a material (gi_types.h MAT_CLASS_COUNT): its BSDF class, or -- the reference's per-material feature #defines done the wavefront way,
+// GlslShaderGen.cpp:204-274, Gi.cpp:1545-1562 -- the specialised variant its hits are binned and shaded by.  OpenPBR BASE: every optional lobe absent (no coat, fuzz,
+// thin film, anisotropy, transmission, subsurface, not thin-walled), no bound texture / primvar input, every parameter finite (the variant drops products with exact
+// zeros, which a NaN or an infinity would not honour).  GATLING_OPTIONS=shade_variants=0 keeps every material in its full kernel (tests: same bits).
+uint32_t shadeClassOf(const MaterialRec& m)
+{
+  if (m.klass != GI_C_MAT_OPEN_PBR || optionValue("shade_variants", 1) == 0) return m.klass & 0xfu;
+  if (m.flags & MAT_FLAG_TEXTURED) return m.klass;
+  for (uint32_t i = 0; i < MAT_PARAM_COUNT; i++) if (!std::isfinite(m.p[i])) return m.klass;
+  if ((uint32_t)m.p[MP_FEATURES] != 0u) return m.klass;
+  if (m.p[MP_COAT] != 0.0f || m.p[GI_C_P_CLEARCOAT] != 0.0f || m.p[GI_C_P_TRANSMISSION_WEIGHT] != 0.0f) return m.klass;
+  return SHADE_CLASS_OPBR_BASE;
+}
+
 // Hostile geometry (bvh8.h "Inactive items").  A coordinate the build works with: finite, at most 1e18 in magnitude.
 inline bool usableCoordinate(float x) { return std::fabs(x) <= 1.0e18f; } // (false for NaN)
 // An instance the flattening can use: every entry of its affine finite and its 3x3 invertible with an inverse that is finite in fp32 (w2o transforms normals and,
@@ -1334,7 +1354,7 @@ int buildScene(GiCScene* s)
   uint32_t meshIdx = 0;
   std::vector<MeshBuild>& meshBuilds = H.meshBuilds; // visible meshes in scene order (two-level layout, incremental updates)
   std::vector<MeshRec>& meshRecs = H.meshRecs; std::vector<float>& sceneData = H.sceneData;
-  s->classMask = 0; s->hasCutouts = false; s->classTextured = 0;
+  s->classMask = 0; s->hasCutouts = false; s->classTextured = 0; s->shadeClassMask = 0; s->shadeClassTextured = 0;
   for (GiCMesh* m : s->meshes) {
     if (!m->visible) continue; // Gi.cpp:801-804
     if (m->faces.empty()) continue;
@@ -1344,9 +1364,10 @@ int buildScene(GiCScene* s)
     if (material > 0x00ffffffu) { setError("too many materials"); return GI_C_ERROR; }
     const bool cutoutMat = mats[material].p[MP_CUTOUT] < 1.0f || (mats[material].flags & MAT_FLAG_OPACITY_TEX) != 0u;
     if (cutoutMat) s->hasCutouts = true;
-    const uint32_t matFlags = material | ((mats[material].klass & 0xfu) << 24) | (cutoutMat ? (1u << 28) : 0u) | (((m->flipFacing ? 1u : 0u) | (m->doubleSided ? 2u : 0u)) << 30);
-    s->classMask |= 1u << (mats[material].klass & 0xfu);
-    if (mats[material].flags & MAT_FLAG_TEXTURED) s->classTextured |= 1u << (mats[material].klass & 0xfu);
+    const uint32_t shadeClass = shadeClassOf(mats[material]);
+    const uint32_t matFlags = material | (shadeClass << 24) | (cutoutMat ? (1u << 28) : 0u) | (((m->flipFacing ? 1u : 0u) | (m->doubleSided ? 2u : 0u)) << 30);
+    s->classMask |= 1u << (mats[material].klass & 0xfu); s->shadeClassMask |= 1u << shadeClass;
+    if (mats[material].flags & MAT_FLAG_TEXTURED) { s->classTextured |= 1u << (mats[material].klass & 0xfu); s->shadeClassTextured |= 1u << shadeClass; }
     const uint32_t vertexOffset = (uint32_t)verts.size();
     { // scene data the mesh's material reads (Gi.cpp:905-1019): instancer primvars first, mesh primvars override, by name
       MeshRec mr{}; mr.vertexOffset = vertexOffset;
@@ -1706,9 +1727,11 @@ uint32_t shardCapacity(size_t slots, uint32_t gridA, uint32_t gridB)
   // shard at most ceil(G/NSHARD) * ceil(n/(256 G)) * 256 <= n/NSHARD + n/G + 32 G + 256 of them; summed over P producers with
   // sum(n) <= slots this is slots/NSHARD + P * (slots/Gmin + 32 Gmax + 256).  block_append also raises Counters::overflow if a shard
   // ever runs past its capacity (giCRender then fails instead of returning a corrupt image).
-  const size_t P = 2 + MAT_CLASS_COUNT;
+  // (a producer that appends I records per thread and trip -- k_route: ROUTE_ITEMS, k_raygen: RAYGEN_ITEMS, gi_kernels.h APPEND_ITEMS_MAX -- deals 256 * I records per
+  // block and trip: the slack term is 32 * I * G + 256 * I)
+  const size_t P = 2 + MAT_CLASS_COUNT, I = APPEND_ITEMS_MAX;
   const size_t gMin = std::max<size_t>(1, std::min(gridA, gridB)), gMax = std::max<size_t>(1, std::max(gridA, gridB));
-  const size_t cap = (slots + NSHARD - 1) / NSHARD + P * ((slots + gMin - 1) / gMin + 32 * gMax + 256);
+  const size_t cap = (slots + NSHARD - 1) / NSHARD + P * ((slots + gMin - 1) / gMin + 32 * I * gMax + 256 * I);
   return (uint32_t)std::min<size_t>(cap, slots + 256); // a shard can never hold more than the pool
 }
 
@@ -2033,10 +2056,26 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
     // frame); per-stage totals are scaled back up by the sampling factor.
     const uint32_t timerStride = std::max(1u, s->kernelTimerStride);
     uint64_t curIter = 0;
-    auto timed = [&](int kind, auto&& fn) {
-      if (timers && (curIter % timerStride) == 0u) { (void)hipEventRecord(poolEvent(&D, ev), st); fn(); (void)hipEventRecord(poolEvent(&D, ev + 1), st); ev += 2; evKind.push_back(kind); }
+    auto timedOn = [&](hipStream_t on, int kind, auto&& fn) {
+      if (timers && (curIter % timerStride) == 0u) { (void)hipEventRecord(poolEvent(&D, ev), on); fn(); (void)hipEventRecord(poolEvent(&D, ev + 1), on); ev += 2; evKind.push_back(kind); }
       else fn();
     };
+    auto timed = [&](int kind, auto&& fn) { timedOn(st, kind, fn); };
+    // Two streams (the reference's default frame is ONE sample per pixel, renderDelegate.cpp:93-110).  In a batch whose work fits the
+    // pool every path starts in iteration 0, so from iteration 1 on k_raygen only FINISHES samples and the closest-hit launch of iteration i + 1 needs nothing from the
+    // shadow launch of iteration i -- which k_raygen(i + 1) (it reads the radiance of paths that ended) and k_shade(i + 1) (it goes on adding to it: the float order of
+    // rp_main.rgen:397-480) do need.  Such batches run
+    //     main stream:    Z(i)  [R(0)]  T(i) + route(i)   <wait for Sh(i-1)>   [R(i), i > 0]   S(i)
+    //     second stream:                                  <wait for S(i)>  Sh(i)
+    // so that Sh(i) runs beside T(i + 1): an iteration lasts max(trace, shadow) + raygen + shade instead of their sum.  Per-path arithmetic and per-pixel sample order are
+    // untouched (same kernels, same records); what changes is who zeroes which queue counter (gi_queues.h zero_next_counters / zero_closest_counters: Z = k_zero_closest).
+    // Not with a dome image (a miss adds the dome's radiance to the Slot in k_route while the previous bounce's shadow launch may still be adding to it: two float
+    // additions in an order that would depend on timing) or a medium stack.  GATLING_OPTIONS=two_stream=0 switches it off; two_stream_delay=1|2 (tests) holds the
+    // main | the second stream back for 0.3 ms per iteration so that the other one runs ahead.
+    const bool twoStreamOk = nee && rs.mediumStackSize == 0u && view.domeTexture == 0u && optionValue("two_stream", 1) != 0 && ctx.stream2 != nullptr;
+    const long twoStreamDelay = optionValue("two_stream_delay", 0);
+    hipStream_t st2 = ctx.stream2;
+    if (twoStreamOk && !D.evShade) { HIP_TRY(hipEventCreateWithFlags(&D.evShade, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&D.evShadow, hipEventDisableTiming)); }
     const bool iterLog = timers && timerStride == 1u && getenv("GATLING_ITER_LOG") && atoi(getenv("GATLING_ITER_LOG")) != 0;
     for (uint32_t batch = 0; batch < numBatches; batch++) {
       U.batchFirstSample = (uint32_t)(batch * batchSamples);
@@ -2075,10 +2114,18 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
       }
       const uint64_t rounds = ((uint64_t)U.workTotal + poolNow - 1) / poolNow; // raygen rounds needed to hand out all work
       const uint64_t maxIters = (rounds + 2) * (std::max(1u, U.maxBounces) + 1) + 8;
+      const bool two = twoStreamOk && rounds == 1 && !iterLog;
+      if (two) U.flags |= FLAG_TWO_STREAM; else U.flags &= ~FLAG_TWO_STREAM;
+      bool shadowInFlight = false;
       for (uint64_t it = 0; it < maxIters; it++) {
         const uint32_t par = (uint32_t)(it & 1u);
         curIter = totalIters; if (timers && (totalIters % timerStride) == 0u) sampledIters++;
-        timed(0, [&] { launchRaygen(st, wideBlocks, U, ps, qs, D.dCounters.ptr, par, D.sampleBuf.ptr); });
+        auto raygen = [&] { timed(0, [&] { launchRaygen(st, wideBlocks, U, ps, qs, D.dCounters.ptr, par, D.sampleBuf.ptr); }); };
+        // k_raygen(it) after the shadow launch of it - 1 (two streams, it > 0: it runs behind this iteration's closest-hit launch)
+        auto raygenBehindShadow = [&] { if (shadowInFlight) { (void)hipStreamWaitEvent(st, D.evShadow, 0); shadowInFlight = false; } raygen(); };
+        if (two) launchZeroClosest(st, D.dCounters.ptr, par);
+        if (!two || it == 0) raygen();
+        else if (rounds == 1 && it == (uint64_t)std::max(1u, U.maxBounces)) raygenBehindShadow(); // (the last k_raygen of the batch: the test below ends the loop)
         // A batch whose work fits the pool (a low-spp frame: hdGatling renders ONE sample per pixel and call) starts every path in iteration 0, a path traces at most
         // maxBounces segments, one per iteration (the bounce counter, rp_main.rgen:298-304) -- so k_raygen(maxBounces) has just retired the last samples and nothing is in
         // flight: no need to find that out two empty iterations later through the poll below (10 launches of ~90 in a spp-1 call).
@@ -2103,15 +2150,26 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
             if (pending == 0) { totalIters++; break; } // k_raygen(j) consumed the regen queue and produced no rays: the pool had drained
           }
         }
+        if (two && twoStreamDelay == 1) launchSpin(st, 300000ull);
         timed(1, [&] { launchTrace(st, traceBlocks, false, s->countTraversal, view, ps, qs, D.dCounters.ptr, Q_TRACE_A + par, Q_REGEN_A + (par ^ 1u), dynRefill, wideBlocks, U, D.sampleBuf.ptr); });
         traceLaunches++;
+        if (two && it > 0) raygenBehindShadow();
+        // one launch per shade class in use (scattering events inside a medium are routed to class 2, k_route: it is launched whenever a medium stack exists and OpenPBR does)
+        const uint32_t shadeMask = s->shadeClassMask | ((rs.mediumStackSize != 0u && (s->shadeClassMask & (1u << SHADE_CLASS_OPBR_BASE))) ? 4u : 0u);
         for (uint32_t klass = 0; klass < MAT_CLASS_COUNT; klass++)
-          if (s->classMask & (1u << klass)) timed(2, [&] { launchShade(st, wideBlocks, klass, (s->classTextured & (1u << klass)) != 0u, rs.mediumStackSize != 0u, U, view, ps, qs, D.dCounters.ptr, par); });
+          if (shadeMask & (1u << klass)) timed(2, [&] { launchShade(st, wideBlocks, klass, (s->shadeClassTextured & (1u << klass)) != 0u, rs.mediumStackSize != 0u, U, view, ps, qs, D.dCounters.ptr, par); });
         if (nee) {
           // (the slot-order flag belongs to k_trace_dyn: with dynamic refill off -- TRACE_DYNAMIC 0 -- dynRefill stays 0 so that launchTrace picks the block-synchronous
           // k_trace the grid was sized for, and there is no order to measure)
           const int32_t order = (dynRefill & 0xffu) == 0u ? 0 : (shadowOrderNow >= 0 ? shadowOrderNow : (int32_t)(totalIters & 1u)); // not chosen yet: alternate, and count (below)
-          timed(3, [&] { launchTrace(st, traceBlocks, true, s->countTraversal, view, ps, qs, D.dCounters.ptr, Q_SHADOW, Q_SHADOW, dynRefill | (order ? TRACE_DYN_SLOT_ORDER : 0u), wideBlocks, U, D.sampleBuf.ptr); });
+          hipStream_t on = st;
+          if (two) { // the shadow launch moves to the second stream, behind this iteration's k_shade
+            HIP_TRY(hipEventRecord(D.evShade, st)); HIP_TRY(hipStreamWaitEvent(st2, D.evShade, 0));
+            if (twoStreamDelay == 2) launchSpin(st2, 300000ull);
+            on = st2;
+          }
+          timedOn(on, 3, [&] { launchTrace(on, traceBlocks, true, s->countTraversal, view, ps, qs, D.dCounters.ptr, Q_SHADOW, Q_SHADOW, dynRefill | (order ? TRACE_DYN_SLOT_ORDER : 0u), wideBlocks, U, D.sampleBuf.ptr); });
+          if (two) { HIP_TRY(hipEventRecord(D.evShadow, st2)); shadowInFlight = true; }
         }
         if (iterLog) { // (GATLING_ITER_LOG, with kernel timers on every iteration: what each iteration's queues held -- one sync per iteration, for measurements only)
           HIP_TRY(hipMemcpyAsync(D.hCounters, D.dCounters.ptr, sizeof(PaddedCounter) * Q_COUNT * NSHARD, hipMemcpyDeviceToHost, st));
@@ -2122,8 +2180,10 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
         }
         iters++; totalIters++;
       }
+      if (shadowInFlight) { (void)hipStreamWaitEvent(st, D.evShadow, 0); shadowInFlight = false; } // (a batch that ended through the poll: its last shadow launches were empty)
       launchAccumulate(st, U, D.sampleBuf.ptr, D.accum.ptr, colorOut, batch == 0, batch + 1 == numBatches);
     }
+    U.flags &= ~FLAG_TWO_STREAM;
     if (neeRb && ps.neeKey) launchResolveNee(st, U, D.neeKey.ptr, reinterpret_cast<F4*>(rbMem(neeRb, D.slot)), (uint32_t)pixels);
     if (clockRb) { // ClockCycles: per-pixel cost -> heat map normalised to the frame maximum, on the host like _EncodeRenderBufferAsHeatmap (Gi.cpp:327-343)
       std::vector<uint32_t> counts(pixels);
@@ -2564,6 +2624,15 @@ extern "C" int giCDebugValidatePartitionedBvh(const float* triVerts, uint32_t tr
   return validateTree(nodes, trisAll, triCount);
 }
 
+// giCDebugShadeClass: which k_shade variant an (untextured) material's hits are binned for -- host only
+extern "C" int giCDebugShadeClass(const GiCMaterialDesc* desc)
+{
+  if (!desc) return -1;
+  MaterialRec m{}; m.klass = desc->klass; m.flags = desc->flags & ~(MAT_FLAG_TEXTURED | MAT_FLAG_OPACITY_TEX); memcpy(m.p, desc->p, sizeof(m.p));
+  deriveMaterialConstants(m);
+  return (int)shadeClassOf(m);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // giCDebugEvalBsdf: closed-form BSDF sample/evaluate on the device for explicit shading frames
 // ---------------------------------------------------------------------------------------------------------------
@@ -2573,6 +2642,7 @@ extern "C" int giCDebugEvalBsdf(const GiCMaterialDesc* desc, uint32_t count, con
   if (count == 0) return GI_C_OK;
   MaterialRec m{}; m.klass = desc->klass; m.flags = desc->flags & ~(MAT_FLAG_TEXTURED | MAT_FLAG_OPACITY_TEX); memcpy(m.p, desc->p, sizeof(m.p));
   deriveMaterialConstants(m);
+  const uint32_t shadeClass = shadeClassOf(m); // the variant the render would shade this material's hits with (GATLING_OPTIONS=shade_variants=0: always the full closed form)
   MaterialRec* dm = nullptr; float* din = nullptr; float* dout = nullptr;
   hipStream_t st = g_ctx.stream;
   int rc = GI_C_ERROR;
@@ -2580,7 +2650,7 @@ extern "C" int giCDebugEvalBsdf(const GiCMaterialDesc* desc, uint32_t count, con
       hipMalloc((void**)&dout, (size_t)count * 15 * 4) == hipSuccess &&
       hipMemcpyAsync(dm, &m, sizeof(m), hipMemcpyHostToDevice, st) == hipSuccess &&
       hipMemcpyAsync(din, in, (size_t)count * 22 * 4, hipMemcpyHostToDevice, st) == hipSuccess) {
-    launchDebugBsdf(st, dm, count, din, dout);
+    launchDebugBsdf(st, dm, shadeClass, count, din, dout);
     if (hipMemcpyAsync(out, dout, (size_t)count * 15 * 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) rc = GI_C_OK;
   }
   if (rc != GI_C_OK) setError("giCDebugEvalBsdf: HIP failure");

@@ -17,6 +17,7 @@ uint32_t traceStaticLdsBytes(); // static LDS of the traversal kernels on top of
 void traceLdsLayout(const SceneView& sc, uint32_t& ldsNodes, uint32_t& ldsTris, uint32_t& bytes);
 void launchTrace(hipStream_t s, uint32_t blocks, bool anyHit, bool count, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt,
                  uint32_t qIn, uint32_t qMiss, uint32_t dynRefill, uint32_t routeBlocks, const FrameUniforms& U, F4* sampleBuf);
+constexpr uint32_t APPEND_ITEMS_MAX = 4u; // most records a thread appends per trip of a streaming kernel (k_route ROUTE_ITEMS, k_raygen RAYGEN_ITEMS): sizes the queue shards' slack, gi_c.cpp shardCapacity
 constexpr uint32_t TRACE_DYN_SLOT_ORDER = 0x200u; // flag in dynRefill (shadow launches): children are visited in slot order instead of near-to-far (k_trace_dyn: DYN_SLOT_ORDER)
 constexpr uint32_t TRACE_DYN_SPILL8 = 0x100u; // flag in dynRefill: 8 LDS stack entries + scratch overflow instead of 16 LDS entries
 // dynRefill: 0 = block-synchronous k_trace; N = scenes that do not fit LDS use k_trace_dyn (a wave refills once N lanes are idle) + k_route
@@ -33,7 +34,9 @@ int launchPath(hipStream_t s, uint32_t cuCount, uint32_t classMask, bool texture
 
 void launchAov(hipStream_t s, const FrameUniforms& U, const SceneView& sc, const AovTargets& A);
 void launchResolveNee(hipStream_t s, const FrameUniforms& U, const unsigned long long* key, F4* aov, uint32_t pixelCount);
-void launchDebugBsdf(hipStream_t s, const MaterialRec* mat, uint32_t count, const float* in, float* out);
+void launchZeroClosest(hipStream_t s, Counters* cnt, uint32_t par); // FLAG_TWO_STREAM: in front of every closest-hit launch
+void launchSpin(hipStream_t s, unsigned long long ns);              // test hook: occupies a stream for ~ns nanoseconds
+void launchDebugBsdf(hipStream_t s, const MaterialRec* mat, uint32_t shadeClass, uint32_t count, const float* in, float* out);
 void launchDebugTex(hipStream_t s, const float* texels, uint32_t w, uint32_t h, uint32_t d, uint32_t count, const float* queries, float* out);
 
 } // namespace gi

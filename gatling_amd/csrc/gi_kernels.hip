@@ -109,7 +109,16 @@ __device__ __forceinline__ bool ray_misses_bounds(const FrameUniforms& U, const 
 
 // RAYGEN_ITEMS regen entries per thread and trip: the trip is otherwise two barriers and an atomic round trip around a chain of dependent loads (entry -> slot ->
 // finished sample), and the entries of one thread are independent of each other.
-constexpr int RAYGEN_ITEMS = 2; // (1 -> 2: raygen stage -6 % on C3 / C4; 4: the same, r05x)
+constexpr int RAYGEN_ITEMS = 2; static_assert(RAYGEN_ITEMS <= (int)APPEND_ITEMS_MAX, "shardCapacity's slack"); // (1 -> 2: raygen stage -6 % on C3 / C4; 4: the same, r05x)
+// FLAG_TWO_STREAM: the counters k_trace / k_route of iteration `par`'s parity need zeroed (gi_queues.h zero_closest_counters); one wave
+__global__ __launch_bounds__(64) void k_zero_closest(Counters* cnt, uint32_t par) { zero_closest_counters(cnt, par); }
+// test hook (GATLING_OPTIONS=two_stream_delay): holds a stream for about `ns` nanoseconds so that the other one runs ahead
+__global__ __launch_bounds__(64) void k_spin(unsigned long long ns, uint32_t* sink)
+{
+  const unsigned long long t0 = wall_clock64(); // 100 MHz constant clock
+  while ((wall_clock64() - t0) * 10ull < ns) { }
+  if (sink && threadIdx.x == 0xffffu) *sink = 0u;
+}
 __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st, QueueSet qs, Counters* cnt, uint32_t par, F4* __restrict__ sampleBuf)
 {
   __shared__ AppendScratch<2> sh;
@@ -120,7 +129,7 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st,
   const uint32_t workBase = cnt->workBase[par].v;
   uint32_t nRetired = 0u;
   if (blockIdx.x == 0) {
-    zero_next_counters(cnt, par, !boundsRetire);
+    zero_next_counters(cnt, par, !boundsRetire, (U.flags & FLAG_TWO_STREAM) != 0u);
     if (threadIdx.x == 0) { const uint32_t left = U.workTotal - workBase; cnt->workBase[par ^ 1u].v = workBase + (n < left ? n : left); }
   }
   const uint32_t stride = gridDim.x * BLOCK * RAYGEN_ITEMS;
@@ -651,14 +660,14 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 
 
 // k_route: sorts k_trace_dyn's in-place results by outcome and material class (same routing as k_trace's epilogue).  A streaming pass whose trip is two barriers and
 // one atomic round trip: ROUTE_ITEMS results per thread and trip (independent loads in flight, a quarter of the trips).
-constexpr int ROUTE_ITEMS = 4; // (1 -> 4: trace + route stage -3.5 % on C4 / C5, -0.5 % on C3, r05w)
+constexpr int ROUTE_ITEMS = 4; static_assert(ROUTE_ITEMS <= (int)APPEND_ITEMS_MAX, "shardCapacity's slack"); // (1 -> 4: trace + route stage -3.5 % on C4 / C5, -0.5 % on C3, r05w)
 __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t qMiss, FrameUniforms U, F4* __restrict__ sampleBuf)
 {
   constexpr uint32_t NQ = 1 + MAT_CLASS_COUNT, NONE = NQ;
   __shared__ AppendScratch<NQ> sh;
   QueueReader rd; reader_init(rd, cnt, qIn, qs.cap);
   const uint32_t n = rd.pre[NSHARD];
-  if (blockIdx.x == 0 && (U.flags & FLAG_BOUNDS_RETIRE)) zero_consumed_regen(cnt, qIn - Q_TRACE_A); // (k_raygen no longer zeroes it: it appends to it)
+  if (blockIdx.x == 0 && (U.flags & FLAG_BOUNDS_RETIRE) && !(U.flags & FLAG_TWO_STREAM)) zero_consumed_regen(cnt, qIn - Q_TRACE_A); // (k_raygen no longer zeroes it: it appends to it; two streams: k_zero_closest does)
   const uint32_t stride = gridDim.x * BLOCK * ROUTE_ITEMS;
   uint32_t qid[NQ]; qid[0] = qMiss;
 #pragma unroll
@@ -719,13 +728,19 @@ __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, Que
 // minimum resident waves per SIMD asked of the register allocator for the plain OpenPBR variants: without NEE 4 (128 VGPRs, 3 spilled: the natural 3 waves measured
 // slower, r04j); with NEE 1, i.e. what its 164 VGPRs allow -- 3 (squeezed to 4 waves it spills 14 and is slower, r04c)
 constexpr int SHADE_OPENPBR_PLAIN_WAVES = 4, SHADE_OPENPBR_NEE_WAVES = 1;
+#ifndef GI_SHADE_BASE_WAVES      // experiment knobs (tools/build_variant.py): minimum waves per SIMD asked for the OpenPBR BASE variant, without / with NEE
+#define GI_SHADE_BASE_WAVES 1
+#endif
+#ifndef GI_SHADE_BASE_NEE_WAVES
+#define GI_SHADE_BASE_NEE_WAVES 1
+#endif
 template <uint32_t KLASS, bool TEXTURED, bool VOLUME, bool NEE, bool PACKED>
 // (forcing the plain variant to 5 waves/SIMD -- amdgpu_waves_per_eu((...) ? 5 : 1, 8): 90 VGPRs, no spills -- is SLOWER: C2 shade 178 -> 190 ms;
 // the stage is bound by the memory pipeline's scattered 16-byte requests, not by latency hiding)
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((KLASS == 2u && !TEXTURED && !VOLUME) ? (NEE ? SHADE_OPENPBR_NEE_WAVES : SHADE_OPENPBR_PLAIN_WAVES) : 1, 8))) void k_shade(FrameUniforms U, SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t par)
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu((KLASS == 2u && !TEXTURED && !VOLUME) ? (NEE ? SHADE_OPENPBR_NEE_WAVES : SHADE_OPENPBR_PLAIN_WAVES) : (KLASS == SHADE_CLASS_OPBR_BASE ? (NEE ? GI_SHADE_BASE_NEE_WAVES : GI_SHADE_BASE_WAVES) : 1), 8))) void k_shade(FrameUniforms U, SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t par, uint32_t hitClass /* the HIT queue read: KLASS, or a variant's whose hits this launch shades with the full kernel */)
 {
   __shared__ AppendScratch<3> sh;
-  const uint32_t qNext = Q_TRACE_A + (par ^ 1u), qRegen = Q_REGEN_A + (par ^ 1u), qHit = Q_HIT + KLASS;
+  const uint32_t qNext = Q_TRACE_A + (par ^ 1u), qRegen = Q_REGEN_A + (par ^ 1u), qHit = Q_HIT + hitClass;
   QueueReader rdr; reader_init(rdr, cnt, qHit, qs.cap);
   const uint32_t n = rdr.pre[NSHARD];
   const uint32_t stride = gridDim.x * BLOCK;
@@ -902,7 +917,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_aov(FrameUniforms U, SceneView 
 // ------------------------------------------------------------------------------------------------
 // k_debug_bsdf: the closed-form BSDF entry points on explicit shading frames (device-side known-answer tests)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_debug_bsdf(const MaterialRec* mat, uint32_t count, const float* __restrict__ in, float* __restrict__ out)
+__global__ void k_debug_bsdf(const MaterialRec* mat, uint32_t shadeClass, uint32_t count, const float* __restrict__ in, float* __restrict__ out)
 {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
@@ -910,8 +925,9 @@ __global__ void k_debug_bsdf(const MaterialRec* mat, uint32_t count, const float
   ShState st; st.normal = v3(p); st.tangentU = v3(p + 3); st.tangentV = v3(p + 6); st.geomNormal = v3(p + 9);
   st.position = v3(0.0f, 0.0f, 0.0f); st.frontFace = (p[21] < 0.5f); st.meshFlags = 0u; st.material = 0u;
   st.u = 0.0f; st.v = 0.0f; st.texMask = 0u; st.ior1 = 0.0f; st.ior2 = 0.0f; st.thinWalled = mat->klass == 2u && ((uint32_t)mat->p[MP_FEATURES] & MATF_THIN_WALLED) != 0u; st.sssVolume = false; st.hasCoatFrame = false; st.mesh = 0u; st.prim = 0u; st.vi[0] = st.vi[1] = st.vi[2] = 0u; st.instanceId = 0; st.hu = st.hv = 0.0f;
-  BsdfSample bs; bsdf_sample<KLASS_DYNAMIC>(mat, st, v3(p + 12), p[18], p[19], p[20], bs);
-  BsdfEval ev; bsdf_evaluate<KLASS_DYNAMIC>(mat, st, v3(p + 12), v3(p + 15), ev);
+  BsdfSample bs; BsdfEval ev;
+  if (shadeClass == SHADE_CLASS_OPBR_BASE) { bsdf_sample<SHADE_CLASS_OPBR_BASE>(mat, st, v3(p + 12), p[18], p[19], p[20], bs); bsdf_evaluate<SHADE_CLASS_OPBR_BASE>(mat, st, v3(p + 12), v3(p + 15), ev); }
+  else { bsdf_sample<KLASS_DYNAMIC>(mat, st, v3(p + 12), p[18], p[19], p[20], bs); bsdf_evaluate<KLASS_DYNAMIC>(mat, st, v3(p + 12), v3(p + 15), ev); }
   o[0] = bs.k2.x; o[1] = bs.k2.y; o[2] = bs.k2.z; o[3] = bs.overPdf.x; o[4] = bs.overPdf.y; o[5] = bs.overPdf.z; o[6] = bs.pdf; o[7] = (float)bs.event;
   o[8] = ev.diffuse.x; o[9] = ev.diffuse.y; o[10] = ev.diffuse.z; o[11] = ev.glossy.x; o[12] = ev.glossy.y; o[13] = ev.glossy.z; o[14] = ev.pdf;
 }
@@ -1029,20 +1045,26 @@ void launchAov(hipStream_t s, const FrameUniforms& U, const SceneView& sc, const
 }
 void launchShade(hipStream_t s, uint32_t blocks, uint32_t klass, bool textured, bool volume, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par)
 {
-#define GI_LAUNCH_SHADE4(K, T, V, N) do { if (sc.shadePacked) hipLaunchKernelGGL((k_shade<K, T, V, N, true>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par); \
-    else hipLaunchKernelGGL((k_shade<K, T, V, N, false>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par); } while (0)
+  // `klass` is a SHADE class (gi_types.h): the HIT queue to read.  The OpenPBR BASE variant's kernel exists for untextured materials in renders without a medium stack;
+  // its hits go through the full OpenPBR kernel otherwise (same bits: gi_shading.h "BASE variant")
+  const uint32_t hitClass = klass;
+  if (klass == SHADE_CLASS_OPBR_BASE && (textured || volume)) klass = 2u;
+#define GI_LAUNCH_SHADE4(K, T, V, N) do { if (sc.shadePacked) hipLaunchKernelGGL((k_shade<K, T, V, N, true>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par, hitClass); \
+    else hipLaunchKernelGGL((k_shade<K, T, V, N, false>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par, hitClass); } while (0)
 #define GI_LAUNCH_SHADE3(K, T, V) do { if (nee) GI_LAUNCH_SHADE4(K, T, V, true); else GI_LAUNCH_SHADE4(K, T, V, false); } while (0)
 #define GI_LAUNCH_SHADE(K) do { \
     if (volume) { if (textured) GI_LAUNCH_SHADE3(K, true, true); else GI_LAUNCH_SHADE3(K, false, true); } \
     else if (textured) GI_LAUNCH_SHADE3(K, true, false); \
     else GI_LAUNCH_SHADE3(K, false, false); } while (0)
   const bool nee = (U.flags & FLAG_NEE) != 0u;
-  if (klass == 0u) GI_LAUNCH_SHADE(0u); else if (klass == 1u) GI_LAUNCH_SHADE(1u); else GI_LAUNCH_SHADE(2u);
+  if (klass == 0u) GI_LAUNCH_SHADE(0u); else if (klass == 1u) GI_LAUNCH_SHADE(1u); else if (klass == 2u) GI_LAUNCH_SHADE(2u); else GI_LAUNCH_SHADE3(SHADE_CLASS_OPBR_BASE, false, false);
 #undef GI_LAUNCH_SHADE4
 #undef GI_LAUNCH_SHADE3
 #undef GI_LAUNCH_SHADE
 }
 
+void launchZeroClosest(hipStream_t s, Counters* cnt, uint32_t par) { hipLaunchKernelGGL(k_zero_closest, dim3(1), dim3(64), 0, s, cnt, par); }
+void launchSpin(hipStream_t s, unsigned long long ns) { hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s, ns, (uint32_t*)nullptr); }
 void launchResolveNee(hipStream_t s, const FrameUniforms& U, const unsigned long long* key, F4* aov, uint32_t pixelCount)
 {
   hipLaunchKernelGGL(k_resolve_nee, dim3((pixelCount + 255u) / 256u), dim3(256), 0, s, U, key, aov, pixelCount);
@@ -1053,9 +1075,9 @@ void launchDebugTex(hipStream_t s, const float* texels, uint32_t w, uint32_t h, 
   hipLaunchKernelGGL(k_debug_tex, dim3((count + 63u) / 64u), dim3(64), 0, s, texels, w, h, d, count, queries, out);
 }
 
-void launchDebugBsdf(hipStream_t s, const MaterialRec* mat, uint32_t count, const float* in, float* out)
+void launchDebugBsdf(hipStream_t s, const MaterialRec* mat, uint32_t shadeClass, uint32_t count, const float* in, float* out)
 {
-  hipLaunchKernelGGL(k_debug_bsdf, dim3((count + 63u) / 64u), dim3(64), 0, s, mat, count, in, out);
+  hipLaunchKernelGGL(k_debug_bsdf, dim3((count + 63u) / 64u), dim3(64), 0, s, mat, shadeClass, count, in, out);
 }
 
 } // namespace gi

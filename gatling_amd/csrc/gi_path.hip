@@ -201,7 +201,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(PAT
 bool pathKernelSupports(const SceneView& sc)
 {
   return sc.triCount > 0u && sc.nodeCount <= LDS_NODES && sc.triCount <= LDS_TRIS && sc.bvhDepth <= PATH_STACK_MAX && sc.mediumStackSize == 0u && sc.domeTexture == 0u && !sc.twoLevel
-         && !sc.shadePacked; // (GATLING_SHADE_PACKED=1 on an LDS-resident scene: TriRec::vi[0] is a shading-record index there, the fused kernels read vertex indices)
+         && !sc.shadePacked; // (a scene whose shading records are packed -- never an LDS-resident one today: TriRec::vi[0] is a shading-record index there, the fused kernels read vertex indices)
 }
 
 using PathKernel = void (*)(FrameUniforms, SceneView, PathState, Counters*, F4*, uint32_t, uint32_t, uint32_t);

@@ -35,7 +35,7 @@ namespace gi {
 enum : uint32_t { F_THR = 0, F_RAD = 3, F_BITS = 6, F_RNG = 7, F_WORK = 8, F_RO = 9 /* origin, or the hit (t, u, v) */, F_RD = 12, F_TMIN = 15 /* tMin, or the hit triangle */,
                   F_TMAX = 16, F_COUNT = 17 };
 constexpr uint32_t NO_WORK = 0xffffffffu; // F_WORK of a path that carries no sample (initial state)
-constexpr uint32_t PATH_BW_PATHS_DEFAULT = 96u; // paths per wave (GATLING_PATH_BW_PATHS): 3 blocks per CU; measured 96 / 128 / 160 / 192 / 256 -> 7426 / 6431 / 6621 / 6651 / 3814 Msamples/s on C2
+constexpr uint32_t PATH_BW_PATHS_DEFAULT = 96u; // paths per wave (a compile-time choice since the environment interface shrank): 3 blocks per CU; measured 96 / 128 / 160 / 192 / 256 -> 7426 / 6431 / 6621 / 6651 / 3814 Msamples/s on C2
 
 constexpr int PATH_BW_WAVES = 3; // resident waves per SIMD the register allocation aims for (168 VGPRs: 3; 4 needs <= 128 and spills 43 registers)
 template <uint32_t KLASS, bool TEXTURED, bool CUTOUT, bool COUNT, uint32_t STACK>

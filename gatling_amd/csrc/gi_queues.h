@@ -170,16 +170,32 @@ constexpr uint32_t REGEN_FRESH = 0x40000000u;  // flag on a regen-queue entry wr
 // TRACE[it&1]), and their previous consumers finished in iteration it-1 (stream order).
 // `zeroRegen` false (FLAG_BOUNDS_RETIRE): k_raygen(it) itself appends to REGEN[(it&1)^1], so that counter is zeroed one kernel earlier, by k_route(it-1)
 // (zero_consumed_regen), which runs after its last reader k_raygen(it-1).
-__device__ __forceinline__ void zero_next_counters(Counters* cnt, uint32_t par, bool zeroRegen)
+// FLAG_TWO_STREAM (`twoStream`): iteration `it` runs  k_zero_closest, [k_raygen if it == 0,] k_trace, k_route, <wait for the shadow launch of it-1>, [k_raygen if it > 0,]
+// k_shade  on the main stream and its shadow launch on the second one.  k_raygen(it) then zeroes only what lies between it and the end of the iteration: TRACE[(it&1)^1]
+// (appended by k_shade(it); its count was last read by k_trace / k_route(it-1)), the SHADOW queue's counter and the shadow cursors (read by the shadow launch of it-1,
+// which k_raygen(it) has waited for; appended / used by k_shade(it) and its shadow launch).  What k_trace / k_route(it) append to or claim from is zeroed by
+// k_zero_closest(it) in front of them (zero_closest_counters).
+__device__ __forceinline__ void zero_next_counters(Counters* cnt, uint32_t par, bool zeroRegen, bool twoStream = false)
 {
   const uint32_t t = threadIdx.x;
   if (t < NSHARD) {
     cnt->count[Q_TRACE_A + (par ^ 1u)][t].v = 0;
-    if (zeroRegen) cnt->count[Q_REGEN_A + (par ^ 1u)][t].v = 0;
-    for (uint32_t c = 0; c < MAT_CLASS_COUNT; c++) cnt->count[Q_HIT + c][t].v = 0;
+    if (zeroRegen && !twoStream) cnt->count[Q_REGEN_A + (par ^ 1u)][t].v = 0;
+    if (!twoStream) for (uint32_t c = 0; c < MAT_CLASS_COUNT; c++) cnt->count[Q_HIT + c][t].v = 0;
     cnt->count[Q_SHADOW][t].v = 0;
   }
-  if (t < 2u * NCURSOR) cnt->cursor[t / NCURSOR][t % NCURSOR].v = 0; // k_trace_dyn's ray cursors (closest, shadow)
+  if (t < 2u * NCURSOR && (!twoStream || t >= NCURSOR)) cnt->cursor[t / NCURSOR][t % NCURSOR].v = 0; // k_trace_dyn's ray cursors (closest, shadow)
+}
+// k_zero_closest(it) (FLAG_TWO_STREAM), in front of k_trace(it): the HIT queues (last read by k_shade(it-1), appended by k_route(it)), REGEN[(it&1)^1] (last read by
+// k_raygen(it-1); appended by k_raygen(0)'s bounds retire, k_route(it) and k_shade(it)) and the closest-hit cursors (k_trace(it-1))
+__device__ __forceinline__ void zero_closest_counters(Counters* cnt, uint32_t par)
+{
+  const uint32_t t = threadIdx.x;
+  if (t < NSHARD) {
+    cnt->count[Q_REGEN_A + (par ^ 1u)][t].v = 0;
+    for (uint32_t c = 0; c < MAT_CLASS_COUNT; c++) cnt->count[Q_HIT + c][t].v = 0;
+  }
+  if (t < NCURSOR) cnt->cursor[0][t].v = 0;
 }
 
 // k_route(it), block 0: REGEN[it&1] was read by k_raygen(it) and is next appended by k_raygen(it+1) (bounds retire) and k_route(it+1)

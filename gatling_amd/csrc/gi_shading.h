@@ -779,6 +779,85 @@ __device__ inline void opbr_evaluate(const MaterialRec* m, const ShState& st, V3
   out.pdf = Pf * cd + keep * out.pdf;
 }
 
+// ------------------------------------------------------------------------------------------------
+// OpenPBR, BASE variant (shade class SHADE_CLASS_OPBR_BASE; the reference compiles its hit shaders per material with feature #defines,
+// GlslShaderGen.cpp:204-274 -- here the host sorts OpenPBR materials into two variants and k_route bins their hits apart).  A BASE material has no coat, no fuzz,
+// no thin film, no anisotropy, no transmission, no subsurface, is not thin-walled and binds no texture (gi_c.cpp shadeClassOf): what is left is the metal lobe, the
+// dielectric reflection and the (energy-preserving Oren-Nayar) diffuse base.  The functions below are opbr_sample / opbr_evaluate with those weights set to their
+// constants and every operation that is an exact identity under them removed -- x * 1, x / 1, x - 0, (1 - 0), a lobe the selection can never reach; additions of an
+// exact +0 stay where the sign of a zero could differ -- so a BASE material shades to the same bits through either variant
+// (test_shade_variants_are_bit_identical runs every scene through both).
+// ------------------------------------------------------------------------------------------------
+struct OpbrBaseParams { V3 albedo, metalTint, specColor, baseColor; float metalness, alpha, eta, specWeight, baseWeight, diffRough; };
+__device__ __forceinline__ OpbrBaseParams opbr_base_params(const MaterialRec* m)
+{
+  OpbrBaseParams o; const float* p = m->p;
+  o.albedo = v3(p[MP_ALBEDO], p[MP_ALBEDO + 1], p[MP_ALBEDO + 2]);
+  o.baseColor = v3(p[0], p[1], p[2]); o.baseWeight = p[17]; o.diffRough = p[27];
+  o.metalTint = v3(p[MP_F0], p[MP_F0 + 1], p[MP_F0 + 2]);
+  o.specColor = v3(p[7], p[8], p[9]);
+  o.specWeight = p[18]; o.metalness = p[10];
+  o.alpha = p[MP_ALPHA]; o.eta = p[MP_ETA];
+  return o;
+}
+__device__ inline void opbr_base_sample(const MaterialRec* m, const ShState& st, V3 k1, float x0, float x1, float x2, BsdfSample& out)
+{
+  const OpbrBaseParams o = opbr_base_params(m);
+  V3 l1 = to_local(st, k1);
+  const float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
+  float z = x2; // (Fc = 0: z = (z - 0) / (1 - 0))
+  float eta = 0.0f, Fd = 0.0f;
+  uint32_t lobe = 1u; // 1 metal, 2 dielectric reflection, 4 diffuse
+  if (!(z < o.metalness)) {
+    z = (z - o.metalness) / (1.0f - o.metalness);
+    eta = relative_eta(st, o.eta);
+    Fd = fresnel_dielectric(nk1, eta);
+    lobe = 2u;
+    if (!(z < Fd)) lobe = 4u; // (transmission_weight = 0: z < 0 never holds)
+  }
+  if (lobe == 4u) {
+    const float pBase = (1.0f - o.metalness) * (1.0f - Fd);
+    const V3 l = gi_sample_hemisphere(x0, x1);
+    const V3 k2 = to_world(st, l);
+    if (!(l.z > 0.0f) || !(dot(k2, st.geomNormal) > 0.0f)) return;
+    out.k2 = k2; out.pdf = pBase * (l.z / GI_PI);
+    out.overPdf = (o.diffRough > 0.0f) ? eon_pi_f(o.baseColor, o.diffRough, l1, l) * o.baseWeight : o.albedo;
+    out.event = EV_DIFFUSE | EV_REFLECTION;
+    return;
+  }
+  const GgxOut g = ggx_sample(l1, o.alpha, x0, x1);
+  const V3 k2 = to_world(st, g.l2);
+  if (!g.valid || !(dot(k2, st.geomNormal) > 0.0f)) return;
+  out.k2 = k2; out.event = EV_GLOSSY | EV_REFLECTION;
+  if (lobe == 1u) {
+    const V3 F = schlick_f82(o.albedo, o.metalTint, g.kh) * o.specWeight;
+    out.pdf = o.metalness * g.pdf; out.overPdf = F * g.g2OverG1;
+  } else {
+    const float Fh = fresnel_dielectric(g.kh, eta);
+    out.pdf = ((1.0f - o.metalness) * Fd) * g.pdf;
+    out.overPdf = o.specColor * ((Fh / Fd) * g.g2OverG1);
+  }
+}
+__device__ inline void opbr_base_evaluate(const MaterialRec* m, const ShState& st, V3 k1, V3 k2, BsdfEval& out)
+{
+  const OpbrBaseParams o = opbr_base_params(m);
+  V3 l1 = to_local(st, k1); const V3 l2 = to_local(st, k2);
+  const float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
+  const float eta = relative_eta(st, o.eta);
+  const float Fd = fresnel_dielectric(nk1, eta);
+  float fs, ps, khs; ggx_eval(l1, l2, o.alpha, fs, ps, khs);
+  const float Fdh = fresnel_dielectric(khs, eta);
+  const float cd = l2.z / GI_PI;
+  const float diel = 1.0f - o.metalness;
+  V3 gl = v3(0.0f, 0.0f, 0.0f); // (the coat term: Fch * fc = 0 * 0)
+  if (o.metalness != 0.0f) { const V3 Fm = schlick_f82(o.albedo, o.metalTint, khs) * o.specWeight; gl = gl + (Fm * fs) * o.metalness; }
+  gl = gl + (o.specColor * (Fdh * fs)) * diel;
+  out.glossy = gl;
+  const V3 rho = (o.diffRough > 0.0f && l2.z > 0.0f) ? eon_pi_f(o.baseColor, o.diffRough, l1, l2) * o.baseWeight : o.albedo;
+  out.diffuse = rho * ((cd * diel) * (1.0f - Fd));
+  out.pdf = 0.0f + (o.metalness * ps + diel * (Fd * ps + (1.0f - Fd) * cd)); // (Fc * pc = +0 first, as in opbr_evaluate_base)
+}
+
 constexpr uint32_t KLASS_DYNAMIC = 0xffffffffu; // read the class from the material record (debug / AOV paths)
 template <uint32_t KLASS>
 __device__ inline void bsdf_sample(const MaterialRec* m, const ShState& st, V3 k1, float x0, float x1, float x2, BsdfSample& out)
@@ -830,6 +909,7 @@ __device__ inline void bsdf_sample(const MaterialRec* m, const ShState& st, V3 k
     return;
   }
   if (klass == 2u) { opbr_sample(m, st, k1, x0, x1, x2, out); return; }
+  if (klass == SHADE_CLASS_OPBR_BASE) { opbr_base_sample(m, st, k1, x0, x1, x2, out); return; }
 }
 
 template <uint32_t KLASS>
@@ -862,6 +942,7 @@ __device__ inline void bsdf_evaluate(const MaterialRec* m, const ShState& st, V3
     return;
   }
   if (klass == 2u) { opbr_evaluate(m, st, k1, k2, out); return; }
+  if (klass == SHADE_CLASS_OPBR_BASE) { opbr_base_evaluate(m, st, k1, k2, out); return; }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -63,6 +63,7 @@ struct ShadeIO {
 template <uint32_t KLASS, bool TEXTURED, bool VOLUME, bool NEE, bool PACKED = false>
 __device__ __forceinline__ void shade_segment(const FrameUniforms& U, const SceneView& sc, float* M /* medium stack of the path (VOLUME) */, const F4& h, const F4& rd, ShadeIO& io)
 {
+  static_assert(KLASS != SHADE_CLASS_OPBR_BASE || (!TEXTURED && !VOLUME), "the BASE variant exists for untextured materials in renders without a medium stack (launchShade sends the others through the full kernel)");
   V3 throughput = io.throughput, radiance = io.radiance; uint32_t bitfield = io.bitfield, rng = io.rng;
   bool cont = false, shadow = false, shadowFirst = false; uint32_t rngShadow = 0u;
   V3 no = v3(0.0f, 0.0f, 0.0f), k2 = no, sdir = no, nee = no; float ld = 0.0f, tMaxNext = GI_FLT_MAX;
@@ -97,7 +98,7 @@ __device__ __forceinline__ void shade_segment(const FrameUniforms& U, const Scen
   if (mediumIdx > 0u) {
     const float distance = h.x * U.metersPerSceneUnit;
     if (!VOLUME) { // empty medium stack: inside (1-bit toggle) -> Beer-Lambert with the HIT material's absorption coefficient (:169-173)
-      if (((KLASS == KLASS_DYNAMIC) ? mat->klass : KLASS) == 2u) throughput = throughput * v3(gi_expf(-mat->p[MP_SIGMA_A] * distance), gi_expf(-mat->p[MP_SIGMA_A + 1] * distance), gi_expf(-mat->p[MP_SIGMA_A + 2] * distance));
+      if (((KLASS == KLASS_DYNAMIC) ? mat->klass : KLASS) == 2u || KLASS == SHADE_CLASS_OPBR_BASE) throughput = throughput * v3(gi_expf(-mat->p[MP_SIGMA_A] * distance), gi_expf(-mat->p[MP_SIGMA_A + 1] * distance), gi_expf(-mat->p[MP_SIGMA_A + 2] * distance));
     } else { // the medium on top of the stack (:174-184)
       const float* m = M + (mediumIdx - 1u) * MEDIUM_FLOATS;
       prevMediumIor = m[0];
@@ -115,7 +116,7 @@ __device__ __forceinline__ void shade_segment(const FrameUniforms& U, const Scen
     if (ss.frontFace || !isDoubleSided) {
       const float c = dot(-rayDir, ss.normal);
       if (c > 0.0f) {
-        if (((KLASS == KLASS_DYNAMIC) ? mat->klass : KLASS) == 2u) // emission_edf (open_pbr_surface.mtlx:590-619): seen through the coat
+        if (((KLASS == KLASS_DYNAMIC) ? mat->klass : KLASS) == 2u) // emission_edf (open_pbr_surface.mtlx:590-619): seen through the coat (BASE variant: no coat, factor 1)
           em = em * opbr_emission_factor(mat->p[12], v3(mat->p[19], mat->p[20], mat->p[21]), mat->p[MP_COAT_F0], c);
         radiance = radiance + throughput * (em * U.exposureScale);
       }
@@ -150,7 +151,7 @@ __device__ __forceinline__ void shade_segment(const FrameUniforms& U, const Scen
   }
   // NEE AOV (rp_main.rgen:431-435): bounce 0 only; a shadow ray that is not traced counts as "not shadowed"
   shadowFirst = bounce == 0u; // the caller records "not shadowed" for the NEE AOV when shadowFirst && !shadow
-  if (!thinWalled && isTransmission) { // medium stack (:447-480); a thin-walled surface has the same medium on both sides
+  if (KLASS != SHADE_CLASS_OPBR_BASE && !thinWalled && isTransmission) { // (a BASE material has no transmissive lobe) medium stack (:447-480); a thin-walled surface has the same medium on both sides
     uint32_t newIdx = mediumIdx;
     if (VOLUME) {
       if (ss.frontFace) { // push the material's medium: mdl_ior, mdl_volume_{scattering,absorption}_coefficient, MEDIUM_DIRECTIONAL_BIAS

@@ -154,6 +154,8 @@ enum : uint32_t {
   FLAG_PIXEL_MAJOR = 64u, // work order of the wavefront pipeline (gi_queues.h work_item)
   FLAG_DEFER_SLOT = 128u, // wavefront pipeline: k_raygen does not write the Slot of a new camera path; its (rng, work item) travel beside the ray record and the
                           // slot is written when the first segment HITS (k_route / k_trace); a camera ray that leaves the scene retires without ever touching a slot
+  FLAG_TWO_STREAM = 512u, // the shadow walks of bounce i run on a second stream beside the closest-hit walks of bounce i + 1 (gi_c.cpp "two streams"): k_raygen runs AFTER
+                          // the iteration's k_trace / k_route and zeroes only what k_shade and the shadow launch append to; k_zero_closest zeroes the rest before k_trace
   FLAG_BOUNDS_RETIRE = 256u, // with FLAG_DEFER_SLOT on the k_trace_dyn path: a camera ray whose slab interval against the scene bounds is empty is never queued --
                              // k_raygen retires its sample (the arithmetic of retire_fresh_miss) and hands the slot straight to the next k_raygen
 };
@@ -258,7 +260,10 @@ struct PathState {
 // The A/B pairs alternate per iteration so that no counter has to be reset between a queue's consumer and its next
 // producers (k_raygen zeroes the counters of the following iteration, see zero_next_counters).
 // HIT is one queue per material class (the sort key between trace and shade): Q_HIT + klass
-constexpr uint32_t MAT_CLASS_COUNT = 3;
+// ... more precisely per SHADE class: the material classes 0 .. 2 (diffuse, UsdPreviewSurface, OpenPBR with every lobe) and the specialised variants of a class.  The
+// shade class of a triangle's material rides in bits 24-27 of TriRec::matFlags (and from there in the top four bits of a hit word); MaterialRec::klass stays the
+// BSDF model.  SHADE_CLASS_OPBR_BASE: OpenPBR materials whose optional lobes are all absent (gi_shading.h "BASE variant", gi_c.cpp shadeClassOf).
+constexpr uint32_t MAT_CLASS_COUNT = 4, SHADE_CLASS_OPBR_BASE = 3;
 enum : uint32_t { Q_TRACE_A = 0, Q_TRACE_B = 1, Q_REGEN_A = 2, Q_REGEN_B = 3, Q_SHADOW = 4, Q_HIT = 5, Q_COUNT = Q_HIT + MAT_CLASS_COUNT };
 constexpr uint32_t NSHARD = 8;
 constexpr uint32_t NCURSOR = 8;
@@ -287,7 +292,7 @@ struct Counters {
   PaddedCounter shadowOrderSteps[2][16];
   uint32_t overflow; // set by block_append when a shard would run past its capacity (host sizing bug): giCRender fails loudly
   // k_path, counting builds only (GI_C_SCENE_OPTION_COUNT_TRAVERSAL): shader-clock cycles per phase summed over waves, lanes doing useful work per phase summed over
-  // trips, trips -- [0] regeneration, [1] closest-hit traversal, [2] shading, [3] shadow ray + finish (GATLING_PHASE_STATS=1 prints them)
+  // trips, trips -- [0] regeneration, [1] closest-hit traversal, [2] shading, [3] shadow ray + finish (GATLING_OPTIONS=phase_stats=1 prints them)
   unsigned long long phaseCycles[4], phaseLanes[4], phaseTrips;
   // k_trace_dyn's closest-hit launches, counting builds only: [0] steps (loop trips of all waves), lanes per step that [1] hold a ray, [2] walk (run the node test),
   // [3] wait for the triangle ring (drained walk, pairs pending); [4] triangle batches, [5] pairs in them, [6] steps in which some lane was refilled, [7] lanes refilled

@@ -465,6 +465,10 @@ int giCTraceRays(GiCScene* scene, uint32_t count, const float* origins /*3*count
  * in: 22 floats per item (normal, tangentU, tangentV, geomNormal, k1, k2, xi[4]); out: 15 floats per item
  * (k2, bsdf_over_pdf, pdf, event, eval diffuse, eval glossy, eval pdf). */
 int giCDebugEvalBsdf(const GiCMaterialDesc* desc, uint32_t count, const float* in, float* out);
+/* [ext] host-only: the shade class an untextured material's hits are binned and shaded by (k_shade variants; the reference compiles one hit shader per material with
+ * feature #defines, GlslShaderGen.cpp:204-274): 0 diffuse, 1 UsdPreviewSurface, 2 OpenPBR with every lobe, 3 OpenPBR BASE (no coat / fuzz / thin film / anisotropy /
+ * transmission / subsurface, not thin-walled, all parameters finite).  giCDebugEvalBsdf runs the variant this names.  <0 on error. */
+int giCDebugShadeClass(const GiCMaterialDesc* desc);
 /* [ext] device-side hook for the MDL renderer runtime's remaining texture entry points (mdl_interface.glsl:45-65, 86-105, 167-221), which only MDL-generated code
  * calls: `rgba` = width x height x depth RGBA float texels (slice by slice; depth 1 = a 2-D image); per query 8 floats (kind, valid, c0, c1, c2, wrapU, wrapV, wrapW)
  * with kind 0 tex_texel_float4_2d(c0, c1), 1 tex_resolution_2d, 2 tex_lookup_float4_3d(c0, c1, c2; wraps), 3 tex_texel_float4_3d(c0, c1, c2); valid 0 = the invalid

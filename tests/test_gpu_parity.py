@@ -1450,3 +1450,168 @@ def test_remaining_texture_entry_points_on_device(gi):
     lib.orc_tex_runtime(vol.ctypes.data_as(FP), w, h, d, n, q.ctypes.data_as(FP), ref.ctypes.data_as(FP))
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
     assert np.abs(got).sum() > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# k_shade variants (round 6): OpenPBR materials without optional lobes are binned apart and shaded by the BASE variant (gi_shading.h) -- the reference's
+# per-material feature #defines (GlslShaderGen.cpp:204-274, two hit groups per material Gi.cpp:1545-1562) done the wavefront way.  Same bits either way.
+# ---------------------------------------------------------------------------------------------------------------
+def test_base_variant_closed_forms_equal_the_full_ones(gi, orc, monkeypatch):
+    """giCDebugEvalBsdf runs the variant a material is binned for: random BASE parameter sets (metalness 0 .. 1, rough / smooth, Oren-Nayar, weights, ior, front and
+    back faces) through the BASE variant, through the full closed form (shade_variants=0) and through the oracle -- bit for bit, sample and evaluate."""
+    from gatling_amd import capi
+    from test_oracle_render import _frames
+    rng = np.random.default_rng(606)
+    for k in range(24):
+        m = MaterialDesc.open_pbr(base_color=tuple(rng.uniform(0, 1, 3)), base_weight=float(rng.uniform(0, 1)), base_metalness=float(rng.choice([0.0, 1.0, rng.uniform(0, 1)])),
+                                  specular_weight=float(rng.choice([0.0, 1.0, rng.uniform(0, 1)])), specular_color=tuple(rng.uniform(0, 1, 3)),
+                                  specular_roughness=float(rng.choice([0.0, 0.02, rng.uniform(0, 1)])), specular_ior=float(rng.uniform(1.0, 2.5)),
+                                  base_diffuse_roughness=float(rng.choice([0.0, rng.uniform(0, 1)])), emission_luminance=float(rng.choice([0.0, 2.0])),
+                                  coat_color=tuple(rng.uniform(0, 1, 3)), coat_roughness=float(rng.uniform(0, 1)), coat_darkening=float(rng.uniform(0, 1)))
+        monkeypatch.setenv("GATLING_OPTIONS", "shade_variants=1")
+        assert capi.shade_class(m) == 3
+        items = _frames(20000, rng, float(rng.uniform(0.05, 1.0)))
+        items[::7, 21] = 1.0  # back faces (relative_eta)
+        base = gi.bsdf_debug(m, items)
+        monkeypatch.setenv("GATLING_OPTIONS", "shade_variants=0")
+        full = gi.bsdf_debug(m, items)
+        assert np.array_equal(base.view(np.uint32), full.view(np.uint32)), k
+        assert np.array_equal(base.view(np.uint32), orc.bsdf_debug(m, items).view(np.uint32)), k
+
+
+@pytest.mark.parametrize("scene_kind", ["soup", "soup+nee", "grid+nee", "interior+nee", "grid+medium", "textured", "lds"])
+def test_shade_variants_are_bit_identical(gi, orc, monkeypatch, scene_kind):
+    """Whole renders with the variants on and off (and against the oracle): a one-material BASE soup (C3's shape), C4's mix of UsdPreviewSurface / full / BASE
+    OpenPBR sets, C5's interior, a render with a medium stack (BASE hits go through the full VOLUME kernel, scattering events are routed to class 2), a scene whose
+    OpenPBR material is textured (never BASE), and an LDS-resident scene through the stage kernels."""
+    from gatling_amd import capi
+    rs = RenderSettings(spp=3, max_bounces=6, next_event_estimation="nee" in scene_kind, progressive_accumulation=False)
+    opts = []
+    if scene_kind.startswith("soup"):
+        desc = _soup(20000, seed=11)
+    elif scene_kind == "grid+nee":
+        desc = sphere_grid(grid=6, subdivisions=2, material_count=32)
+        desc.rect_lights = [RectLight(origin=(0, 0, 8.0), t0=(1, 0, 0), t1=(0, 1, 0), base_emission=(15, 15, 15), width=4.0, height=4.0)]
+    elif scene_kind == "interior+nee":
+        desc = interior_scene(clutter_instances=120, subdivisions=1, prototypes=6, material_count=50)
+    elif scene_kind == "grid+medium":
+        desc = sphere_grid(grid=4, subdivisions=2, material_count=32)
+        p = np.array(desc.materials[2].params, np.float32, copy=True)
+        p[23] = 1.0; p[24:27] = (0.8, 0.9, 0.7); p[28] = 0.5; p[29:32] = (0.3, 0.3, 0.3)
+        desc.materials[2].params = p
+        rs.medium_stack_size = 3
+    elif scene_kind == "textured":
+        desc = textured_scene()
+    else:
+        desc = cornell_box()
+        desc.materials = [MaterialDesc.open_pbr(name="light", emission_luminance=1.0, emission_color=(8.5, 6, 4)), MaterialDesc.open_pbr(name="white"),
+                          MaterialDesc.open_pbr(name="red", base_color=(1, 0, 0), base_metalness=0.5), MaterialDesc.open_pbr(name="green", base_color=(0, 1, 0), coat_weight=0.5)]
+        opts = [(capi.OPTION_FUSED_PATH, 0)]
+    classes = {capi.shade_class(m) for m in desc.materials}
+    if scene_kind in ("grid+nee", "interior+nee", "grid+medium"):
+        assert {2, 3} <= classes
+    ref, cnt = orc.render(desc, rs, 96, 54, threads=4)
+    imgs = []
+    for variants in (1, 0):
+        monkeypatch.setenv("GATLING_OPTIONS", f"shade_variants={variants}")
+        sc = gi.Scene(desc)
+        try:
+            for k, v in opts:
+                sc.set_option(k, v)
+            imgs.append(sc.render(rs, 96, 54)); st = sc.stats()
+        finally:
+            sc.close()
+        assert st["segments"] == cnt["segments"] and st["shadowRays"] == cnt["shadow_rays"] and st["fusedPath"] == 0
+        assert_image_parity(imgs[-1], ref, exact=True)
+    assert np.array_equal(imgs[0].view(np.uint32), imgs[1].view(np.uint32))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# two streams (round 6): in batches whose work fits the pool the shadow launch of bounce i runs on a second stream beside the closest-hit launch of bounce i + 1
+# (gi_c.cpp "two streams"; the reference's default frame is one sample per pixel and giRender call, renderDelegate.cpp:93-110).  Scheduling only: same images.
+# ---------------------------------------------------------------------------------------------------------------
+_TWO_STREAM_MODES = ["two_stream=0", "two_stream=1", "two_stream=1,two_stream_delay=1", "two_stream=1,two_stream_delay=2"]
+
+
+@pytest.mark.parametrize("scene_kind", ["soup", "interior", "grid+cutouts", "lds", "one-bounce", "two-level"])
+def test_two_stream_iterations_are_invisible(gi, orc, monkeypatch, scene_kind):
+    """Every mode -- off, on, on with the main stream held back 0.3 ms per iteration (the shadow launch runs far ahead), on with the second stream held back (the next
+    closest-hit launch runs far ahead and k_raygen / k_shade really have to wait) -- gives the oracle's image, segment and shadow-ray counts, on several progressive frames;
+    a pool smaller than the batch (several raygen rounds) falls back to the single stream by itself."""
+    from gatling_amd import capi
+    rs = RenderSettings(spp=2, max_bounces=7, next_event_estimation=True, rr_bounce_offset=1)
+    opts = []
+    if scene_kind == "soup":
+        desc = _soup(20000, seed=21)
+    elif scene_kind == "interior":
+        desc = interior_scene(clutter_instances=100, subdivisions=1, prototypes=5, material_count=20)
+    elif scene_kind == "grid+cutouts":
+        desc = sphere_grid(grid=5, subdivisions=2, material_count=8)
+        desc.materials[1].params[14] = 0.4
+        desc.rect_lights = [RectLight(origin=(0, 0, 7.0), t0=(1, 0, 0), t1=(0, 1, 0), base_emission=(15, 15, 15), width=3.0, height=3.0)]
+    elif scene_kind == "lds":
+        desc = cornell_box()
+        desc.rect_lights = [RectLight(origin=(0, 0, 0.9), t0=(1, 0, 0), t1=(0, -1, 0), base_emission=(10, 10, 10), width=0.7, height=0.5)]
+        opts = [(capi.OPTION_FUSED_PATH, 0)]
+    elif scene_kind == "one-bounce":
+        desc = _soup(5000, seed=22); rs.max_bounces = 1
+    else:
+        desc = sphere_grid(grid=5, subdivisions=2, material_count=6)
+        desc.rect_lights = [RectLight(origin=(0, 0, 7.0), t0=(1, 0, 0), t1=(0, 1, 0), base_emission=(15, 15, 15), width=3.0, height=3.0)]
+        opts = [(capi.OPTION_TWO_LEVEL, 1)]
+    w, h = 96, 54
+    refs, prev = [], None
+    for k in range(3):
+        r, cnt = orc.render(desc, rs, w, h, sample_offset=k * rs.spp, prev_color=prev, threads=4)
+        refs.append((r, cnt)); prev = r
+    for mode in _TWO_STREAM_MODES + ["two_stream=1,pool_slots=2048"]:
+        monkeypatch.setenv("GATLING_OPTIONS", mode)
+        sc = gi.Scene(desc)
+        try:
+            for k_, v_ in opts:
+                sc.set_option(k_, v_)
+            for k in range(3):
+                img = sc.render(rs, w, h); st = sc.stats()
+                assert st["fusedPath"] == 0
+                assert st["segments"] == refs[k][1]["segments"] and st["shadowRays"] == refs[k][1]["shadow_rays"], (mode, k)
+                assert np.array_equal(img.view(np.uint32), refs[k][0].view(np.uint32)), (mode, k)
+        finally:
+            sc.close()
+
+
+def test_two_hundred_one_sample_calls_on_two_streams(gi, orc, monkeypatch):
+    """hdGatling's own loop: 200 giRender calls of ONE sample per pixel, 13 bounces, NEE, progressive accumulation -- every one of the 200 frames equals the oracle's
+    progressive frame (a scheduling race between the two streams would show as a stray pixel in some frame); the stream that is held back alternates between the calls."""
+    desc = _soup(8000, seed=23)
+    rs = RenderSettings(spp=1, next_event_estimation=True)   # the delegate's defaults: 13 bounces, Russian roulette from bounce 3
+    w, h = 64, 36
+    sc = gi.Scene(desc)
+    prev = None
+    try:
+        for k in range(200):
+            monkeypatch.setenv("GATLING_OPTIONS", ("two_stream=1", "two_stream=1,two_stream_delay=1", "two_stream=1,two_stream_delay=2")[k % 3] if k % 10 else "two_stream=0")
+            img = sc.render(rs, w, h)
+            ref, _ = orc.render(desc, rs, w, h, sample_offset=k, prev_color=prev, threads=4)
+            assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), k
+            prev = ref
+    finally:
+        sc.close()
+
+
+def test_two_stream_nee_and_bounces_aovs(gi, orc, monkeypatch):
+    """The path-following AOVs (NEE: the shadow test of bounce 0, written by the shadow launch; Bounces; ClockCycles) with the shadow launches on the second stream."""
+    desc = _soup(6000, seed=24)
+    rs = RenderSettings(spp=3, max_bounces=6, next_event_estimation=True)
+    clear = {"nee": (0.25, 0.5, 0.75, 0.0), "bounces": (0.0, 0.0, 0.0, 0.0)}
+    names = ["nee", "bounces", "clockCycles"]
+    ref = orc.render_aovs(desc, rs, 80, 45, names, clear_values=clear)
+    for mode in _TWO_STREAM_MODES:
+        monkeypatch.setenv("GATLING_OPTIONS", mode)
+        sc = gi.Scene(desc)
+        try:
+            got = sc.render_aovs(rs, 80, 45, names, clear_values=clear)
+        finally:
+            sc.close()
+        for k in ("nee", "bounces"):
+            assert np.array_equal(got[k][..., :3], ref[k][..., :3]), (mode, k)
+        assert np.array_equal(got["clockCycles"], ref["clockCycles"]), mode
