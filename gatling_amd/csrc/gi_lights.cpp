@@ -1,0 +1,196 @@
+// gi_lights.cpp -- light stores and setters, dome light, upload of the light records (Gi.cpp:2573-2976)
+// (one of the translation units gi_c.cpp was split into in round 6; shared declarations: gi_host.h)
+#include "gi_host.h"
+
+extern "C" {
+// ---------------------------------------------------------------------------------------------------------------
+// lights (defaults and derived fields: Gi.cpp:2573-2976)
+// ---------------------------------------------------------------------------------------------------------------
+#define LIGHT_DIRTY(l) (l)->scene->dirty |= DIRTY_LIGHTS | DIRTY_FRAMEBUFFER
+
+GiCSphereLight* giCCreateSphereLight(GiCScene* scene)
+{
+  if (!scene) return nullptr;
+  std::lock_guard<std::mutex> g(scene->mutex);
+  auto* l = new GiCSphereLight{scene, 0};
+  SphereLightRec r{}; r.ds = packHalf2x16(1.0f, 1.0f); r.area = 1.0f; r.radius[0] = r.radius[1] = r.radius[2] = 0.5f;
+  l->index = scene->sphereLights.add(l, r);
+  scene->dirty |= DIRTY_LIGHTS | DIRTY_FRAMEBUFFER;
+  return l;
+}
+void giCDestroySphereLight(GiCScene* scene, GiCSphereLight* l)
+{
+  if (!scene || !l) return;
+  std::lock_guard<std::mutex> g(scene->mutex);
+  scene->sphereLights.remove(l->index); scene->dirty |= DIRTY_LIGHTS | DIRTY_FRAMEBUFFER;
+  delete l;
+}
+void giCSetSphereLightPosition(GiCSphereLight* l, const float* p) { std::lock_guard<std::mutex> lk(l->scene->mutex);
+    memcpy(l->scene->sphereLights.recs[l->index].pos, p, 12); LIGHT_DIRTY(l); }
+void giCSetSphereLightBaseEmission(GiCSphereLight* l, const float* c) { std::lock_guard<std::mutex> lk(l->scene->mutex);
+    memcpy(l->scene->sphereLights.recs[l->index].em, c, 12); LIGHT_DIRTY(l); }
+void giCSetSphereLightRadius(GiCSphereLight* l, float rx, float ry, float rz)
+{ std::lock_guard<std::mutex> lk(l->scene->mutex);
+  // Knud Thomsen ellipsoid surface approximation (Gi.cpp:2635-2651)
+  float ab = powf(rx * ry, 1.6f), ac = powf(rx * rz, 1.6f), bc = powf(ry * rz, 1.6f);
+  float area = float(powf((ab + ac + bc) / 3.0f, 1.0f / 1.6f) * 4.0f * M_PI);
+  SphereLightRec& r = l->scene->sphereLights.recs[l->index];
+  r.radius[0] = rx; r.radius[1] = ry; r.radius[2] = rz; r.area = area;
+  LIGHT_DIRTY(l);
+}
+void giCSetSphereLightDiffuseSpecular(GiCSphereLight* l, float d, float s) { std::lock_guard<std::mutex> lk(l->scene->mutex);
+    l->scene->sphereLights.recs[l->index].ds = packHalf2x16(d, s); LIGHT_DIRTY(l); }
+
+GiCDistantLight* giCCreateDistantLight(GiCScene* scene)
+{
+  if (!scene) return nullptr;
+  std::lock_guard<std::mutex> g(scene->mutex);
+  auto* l = new GiCDistantLight{scene, 0};
+  DistantLightRec r{}; r.ds = packHalf2x16(1.0f, 1.0f); r.invPdf = 1.0f;
+  l->index = scene->distantLights.add(l, r);
+  scene->dirty |= DIRTY_LIGHTS | DIRTY_FRAMEBUFFER;
+  return l;
+}
+void giCDestroyDistantLight(GiCScene* scene, GiCDistantLight* l)
+{
+  if (!scene || !l) return;
+  std::lock_guard<std::mutex> g(scene->mutex);
+  scene->distantLights.remove(l->index); scene->dirty |= DIRTY_LIGHTS | DIRTY_FRAMEBUFFER;
+  delete l;
+}
+void giCSetDistantLightDirection(GiCDistantLight* l, const float* d) { std::lock_guard<std::mutex> lk(l->scene->mutex);
+    memcpy(l->scene->distantLights.recs[l->index].dir, d, 12); LIGHT_DIRTY(l); }
+void giCSetDistantLightBaseEmission(GiCDistantLight* l, const float* c) { std::lock_guard<std::mutex> lk(l->scene->mutex);
+    memcpy(l->scene->distantLights.recs[l->index].em, c, 12); LIGHT_DIRTY(l); }
+void giCSetDistantLightAngle(GiCDistantLight* l, float angle)
+{ std::lock_guard<std::mutex> lk(l->scene->mutex);
+  float half = 0.5f * angle; // Gi.cpp:2723-2735
+  DistantLightRec& r = l->scene->distantLights.recs[l->index];
+  r.angle = angle; r.invPdf = (half > 0.0f) ? float(2.0f * M_PI * (1.0f - cosf(half))) : 1.0f;
+  LIGHT_DIRTY(l);
+}
+void giCSetDistantLightDiffuseSpecular(GiCDistantLight* l, float d, float s) { std::lock_guard<std::mutex> lk(l->scene->mutex);
+    l->scene->distantLights.recs[l->index].ds = packHalf2x16(d, s); LIGHT_DIRTY(l); }
+
+GiCRectLight* giCCreateRectLight(GiCScene* scene)
+{
+  if (!scene) return nullptr;
+  std::lock_guard<std::mutex> g(scene->mutex);
+  auto* l = new GiCRectLight{scene, 0};
+  const float t0[3] = {1, 0, 0}, t1[3] = {0, 1, 0};
+  RectLightRec r{}; r.width = 1.0f; r.height = 1.0f; r.t0 = encodeDirection(t0); r.t1 = encodeDirection(t1); r.ds = packHalf2x16(1.0f, 1.0f);
+  l->index = scene->rectLights.add(l, r);
+  scene->dirty |= DIRTY_LIGHTS | DIRTY_FRAMEBUFFER;
+  return l;
+}
+void giCDestroyRectLight(GiCScene* scene, GiCRectLight* l)
+{
+  if (!scene || !l) return;
+  std::lock_guard<std::mutex> g(scene->mutex);
+  scene->rectLights.remove(l->index); scene->dirty |= DIRTY_LIGHTS | DIRTY_FRAMEBUFFER;
+  delete l;
+}
+void giCSetRectLightOrigin(GiCRectLight* l, const float* o) { std::lock_guard<std::mutex> lk(l->scene->mutex);
+    memcpy(l->scene->rectLights.recs[l->index].origin, o, 12); LIGHT_DIRTY(l); }
+void giCSetRectLightTangents(GiCRectLight* l, const float* t0, const float* t1)
+{ std::lock_guard<std::mutex> lk(l->scene->mutex);
+  RectLightRec& r = l->scene->rectLights.recs[l->index]; r.t0 = encodeDirection(t0); r.t1 = encodeDirection(t1); LIGHT_DIRTY(l);
+}
+void giCSetRectLightBaseEmission(GiCRectLight* l, const float* c) { std::lock_guard<std::mutex> lk(l->scene->mutex);
+    memcpy(l->scene->rectLights.recs[l->index].em, c, 12); LIGHT_DIRTY(l); }
+void giCSetRectLightDimensions(GiCRectLight* l, float w, float h) { std::lock_guard<std::mutex> lk(l->scene->mutex);
+    RectLightRec& r = l->scene->rectLights.recs[l->index]; r.width = w; r.height = h; LIGHT_DIRTY(l); }
+void giCSetRectLightDiffuseSpecular(GiCRectLight* l, float d, float s) { std::lock_guard<std::mutex> lk(l->scene->mutex);
+    l->scene->rectLights.recs[l->index].ds = packHalf2x16(d, s); LIGHT_DIRTY(l); }
+
+GiCDiskLight* giCCreateDiskLight(GiCScene* scene)
+{
+  if (!scene) return nullptr;
+  std::lock_guard<std::mutex> g(scene->mutex);
+  auto* l = new GiCDiskLight{scene, 0};
+  const float t0[3] = {1, 0, 0}, t1[3] = {0, 1, 0};
+  DiskLightRec r{}; r.rx = 0.5f; r.ry = 0.5f; r.t0 = encodeDirection(t0); r.t1 = encodeDirection(t1); r.ds = packHalf2x16(1.0f, 1.0f);
+  l->index = scene->diskLights.add(l, r);
+  scene->dirty |= DIRTY_LIGHTS | DIRTY_FRAMEBUFFER;
+  return l;
+}
+void giCDestroyDiskLight(GiCScene* scene, GiCDiskLight* l)
+{
+  if (!scene || !l) return;
+  std::lock_guard<std::mutex> g(scene->mutex);
+  scene->diskLights.remove(l->index); scene->dirty |= DIRTY_LIGHTS | DIRTY_FRAMEBUFFER;
+  delete l;
+}
+void giCSetDiskLightOrigin(GiCDiskLight* l, const float* o) { std::lock_guard<std::mutex> lk(l->scene->mutex);
+    memcpy(l->scene->diskLights.recs[l->index].origin, o, 12); LIGHT_DIRTY(l); }
+void giCSetDiskLightTangents(GiCDiskLight* l, const float* t0, const float* t1)
+{ std::lock_guard<std::mutex> lk(l->scene->mutex);
+  DiskLightRec& r = l->scene->diskLights.recs[l->index]; r.t0 = encodeDirection(t0); r.t1 = encodeDirection(t1); LIGHT_DIRTY(l);
+}
+void giCSetDiskLightBaseEmission(GiCDiskLight* l, const float* c) { std::lock_guard<std::mutex> lk(l->scene->mutex);
+    memcpy(l->scene->diskLights.recs[l->index].em, c, 12); LIGHT_DIRTY(l); }
+void giCSetDiskLightRadius(GiCDiskLight* l, float rx, float ry) { std::lock_guard<std::mutex> lk(l->scene->mutex);
+    DiskLightRec& r = l->scene->diskLights.recs[l->index]; r.rx = rx; r.ry = ry; LIGHT_DIRTY(l); }
+void giCSetDiskLightDiffuseSpecular(GiCDiskLight* l, float d, float s) { std::lock_guard<std::mutex> lk(l->scene->mutex);
+    l->scene->diskLights.recs[l->index].ds = packHalf2x16(d, s); LIGHT_DIRTY(l); }
+
+
+GiCDomeLight* giCCreateDomeLight(GiCScene* scene, const char* filePath)
+{
+  if (!scene) return nullptr;
+  auto* l = new GiCDomeLight(); l->scene = scene; l->filePath = filePath ? filePath : "";
+  // the reference decodes the file through imgio (Gi.cpp:2215-2230); here: Radiance RGBE, PFM and PNG, anything else stays unloaded
+  uint32_t w = 0, h = 0; std::vector<float> px;
+  if (!l->filePath.empty() && loadImage(l->filePath.c_str(), /*srgbToLinear=*/false, /*keepHdr=*/true, w, h, px)) {
+    GiCTextureDesc td{w, h, px.data()};
+    l->texture = giCCreateTexture(scene, &td);
+    l->ownsTexture = l->texture != nullptr;
+  } else if (!l->filePath.empty()) {
+    fprintf(stderr, "[gatling_gi] unable to load dome light texture at '%s' (.hdr, .pfm, .png and baseline .jpg are decoded in-library, other formats through giCSetImageLoader)\n", l->filePath.c_str());
+  }
+  return l;
+}
+void giCDestroyDomeLight(GiCDomeLight* l)
+{
+  if (!l) return;
+  if (l->ownsTexture) giCDestroyTexture(l->texture);
+  std::lock_guard<std::mutex> g(l->scene->mutex);
+  l->scene->dirty |= DIRTY_FRAMEBUFFER;
+  delete l;
+}
+void giCSetDomeLightTexture(GiCDomeLight* l, GiCTexture* t)
+{
+  if (!l) return;
+  GiCTexture* old = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(l->scene->mutex);
+    if (l->ownsTexture) { old = l->texture; l->ownsTexture = false; }
+    l->texture = t; l->scene->dirty |= DIRTY_FRAMEBUFFER;
+  }
+  if (old) giCDestroyTexture(old); // takes the scene mutex itself
+}
+void giCSetDomeLightRotation(GiCDomeLight* l, const float* q) { std::lock_guard<std::mutex> lk(l->scene->mutex); memcpy(l->rotation, q, 16);
+    l->scene->dirty |= DIRTY_FRAMEBUFFER; }
+void giCSetDomeLightBaseEmission(GiCDomeLight* l, const float* c) { std::lock_guard<std::mutex> lk(l->scene->mutex); memcpy(l->baseEmission, c, 12);
+    l->scene->dirty |= DIRTY_FRAMEBUFFER; }
+void giCSetDomeLightDiffuseSpecular(GiCDomeLight* l, float d, float s) { std::lock_guard<std::mutex> lk(l->scene->mutex); l->diffuse = d; l->specular = s;
+    l->scene->dirty |= DIRTY_FRAMEBUFFER; }
+
+} // extern "C"
+
+int uploadLights(GiCScene* s)
+{
+  const uint32_t nDev = std::min<uint32_t>(sceneDeviceCount(s), (uint32_t)s->replicas.size() + 1u);
+  for (uint32_t d = 0; d < nDev; d++) {
+    SceneDevice& D = sceneDevice(s, d);
+    HIP_TRY(hipSetDevice(g_ctx.devs[d].device));
+    hipStream_t st = g_ctx.devs[d].stream;
+    if (D.dSphere.upload(s->sphereLights.recs, st) || D.dDistant.upload(s->distantLights.recs, st) || D.dRect.upload(s->rectLights.recs, st) ||
+        D.dDisk.upload(s->diskLights.recs, st))
+      return GI_C_ERROR;
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  HIP_TRY(hipSetDevice(g_ctx.device));
+  return GI_C_OK;
+}
+

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <random>
 #include <vector>
 
@@ -79,6 +80,7 @@ static int traceSorted(const Bvh8& B, const Ray& r, float& tBest, RayStats& c, b
 }
 
 // closest hit; returns the triangle index in tree order or -1
+static std::vector<uint32_t>* g_visited = nullptr; // packet mode: the nodes a walk visits, in order
 static int trace(const Bvh8& B, const Ray& r, float& tBest, RayStats& c, bool anyHit = false);
 static int trace(const Bvh8& B, const Ray& r, float& tBest, RayStats& c, bool anyHit)
 {
@@ -96,6 +98,7 @@ static int trace(const Bvh8& B, const Ray& r, float& tBest, RayStats& c, bool an
   while (true) {
     if (have) {
       const Node8& n = B.nodes[nodeIdx]; c.nodes++;
+      if (g_visited) g_visited->push_back(nodeIdx);
       float s[3] = {expScale(n.e[0]), expScale(n.e[1]), expScale(n.e[2])};
       uint32_t imaskHit = 0; float tnk[8] = {0}; float gmin = 3.0e38f;
       for (int k = 0; k < 8; k++) {
@@ -181,6 +184,40 @@ int main(int argc, char** argv)
   for (const Node8& n : B.nodes) for (int k = 0; k < 8; k++) if (n.meta[k]) { slots++; if (!(n.imask & (1u << k))) { leafSlots++; leafTris += (size_t)__builtin_popcount(n.meta[k] >> 5); } }
   printf("%zu triangles, %zu nodes, depth %u, build %.0f ms, slot fill %.3f, triangles per leaf slot %.2f\n", tris.size(), B.nodes.size(), B.maxDepth, t1 - t0,
          (double)slots / (8.0 * B.nodes.size()), (double)leafTris / (double)leafSlots);
+  if (argc > 2 && !strcmp(argv[argc - 1], "packet")) {
+    // VERDICT r05 next #5, measured before built: in the pixel-major work order a wave's 64 camera rays are samples of ONE pixel (Gaussian pixel filter, sigma 0.375 px:
+    // gi_device_math.h gi_fis_gauss).  A wave-uniform walk would visit the UNION of the nodes its rays visit, one node per step, each step with the lanes whose own
+    // walk contains that node.  Per pixel: sum of the rays' visits (what the per-lane walks cost in lane-steps), size of the union (steps of the shared walk), and for
+    // every union node how many of the 64 rays visit it.  1920x1080 frame, every 30th pixel in x and y.
+    const int W = 1920, H = 1080; float th = std::tan(vfov / 2);
+    std::normal_distribution<float> G(0.0f, 0.375f);
+    double sumVisits = 0, sumUnion = 0, pixels = 0, hist[65] = {0}, sharedLaneSteps = 0;
+    double atLeast48 = 0;
+    std::vector<uint32_t> visited; std::vector<std::pair<uint32_t, uint32_t>> all;
+    for (int y = 15; y < H; y += 30) for (int x = 15; x < W; x += 30) {
+      all.clear();
+      RayStats dummy;
+      for (int sIdx = 0; sIdx < 64; sIdx++) {
+        Ray r; r.tMin = 0; r.tMax = 3.0e38f; memcpy(r.o, camPos, 12);
+        float px = x + 0.5f + G(rng), py = y + 0.5f + G(rng);
+        float dx = (px / W * 2 - 1) * th * W / H, dz = (py / H * 2 - 1) * th;
+        float d[3] = {dx, 1.0f, dz}, l = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        for (int k = 0; k < 3; k++) r.d[k] = d[k] / l;
+        visited.clear(); g_visited = &visited; float t; trace(B, r, t, dummy); g_visited = nullptr;
+        for (uint32_t n : visited) all.push_back({n, (uint32_t)sIdx});
+      }
+      std::sort(all.begin(), all.end());
+      sumVisits += (double)all.size(); pixels++;
+      for (size_t i = 0; i < all.size();) { size_t j = i; while (j < all.size() && all[j].first == all[i].first) j++; const size_t lanes = j - i; hist[lanes]++; sumUnion++; sharedLaneSteps += (double)lanes; if (lanes >= 48) atLeast48++; i = j; }
+    }
+    printf("packet walk of one pixel's 64 camera rays (%0.f pixels): per-lane walks %.1f node visits per pixel (%.2f per ray); the union is %.1f nodes per pixel = steps of a shared walk;\n"
+           "  lanes per shared step: mean %.1f of 64; steps with >= 48 lanes: %.1f %%;  per-lane walks at 0.79 lane utilisation need %.1f wave steps per pixel\n",
+           pixels, sumVisits / pixels, sumVisits / pixels / 64.0, sumUnion / pixels, sharedLaneSteps / sumUnion, 100.0 * atLeast48 / sumUnion, sumVisits / pixels / (64.0 * 0.79));
+    printf("  histogram (lanes: share of the shared walk's steps):");
+    for (int lo = 1; lo <= 64; lo += 8) { double a = 0; for (int k = lo; k < lo + 8 && k <= 64; k++) a += hist[k]; printf("  %d-%d: %.1f %%", lo, std::min(lo + 7, 64), 100.0 * a / sumUnion); }
+    printf("\n");
+    return 0;
+  }
   // rays: camera rays, then two diffuse bounces and a shadow ray towards (0,0,1.5) from every hit
   const int W = 480, H = 270; RayStats cam, sec, shd;
   std::uniform_real_distribution<float> U01(0.0f, 1.0f);
