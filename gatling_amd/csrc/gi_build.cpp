@@ -181,9 +181,10 @@ int buildTwoLevel(GiCScene* s, const std::vector<MB>& meshBuilds, const std::vec
             for (int a = 0; a < 3; a++) { objectOk = objectOk && usableCoordinate(o[a]); worldOk = worldOk && usableCoordinate(q[k][a]); }
           }
           if (!objectOk) continue;
-          if (!worldOk) { if (want > 0) fprintf(stderr,
-              "[gatling_gi] two-level layout not used: an instance carries triangles that leave the usable coordinate range in world space\n"); return GI_C_OK;
-              }
+          if (!worldOk) {
+            if (want > 0) fprintf(stderr, "[gatling_gi] two-level layout not used: an instance carries triangles that leave the usable coordinate range in world space\n");
+            return GI_C_OK;
+          }
           for (int k = 0; k < 3; k++) for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], q[k][a]); hi[a] = std::max(hi[a], q[k][a]); }
         }
       padBox(lo, hi);
@@ -193,10 +194,14 @@ int buildTwoLevel(GiCScene* s, const std::vector<MB>& meshBuilds, const std::vec
   Bvh8 tlas; std::vector<uint32_t> tlasItems;
   buildBvh8Boxes(instBoxes.data(), instances.size(), tlas, tlasItems);
   // per-lane stack: a TLAS level can leave a node group and an instance group behind, a BLAS level a node group
-  if (blasTris.size() >= ((size_t)1 << 26)) { if (want > 0) fprintf(stderr, "[gatling_gi] two-level layout not used: 2^26 or more unique mesh triangles\n");
-      return GI_C_OK; }
-  if (2u * tlas.maxDepth + blasDepth + 1u > 16u) { if (want > 0) fprintf(stderr,
-      "[gatling_gi] two-level layout not used: trees too deep for the 16-entry stack\n"); return GI_C_OK; }
+  if (blasTris.size() >= ((size_t)1 << 26)) {
+    if (want > 0) fprintf(stderr, "[gatling_gi] two-level layout not used: 2^26 or more unique mesh triangles\n");
+    return GI_C_OK;
+  }
+  if (2u * tlas.maxDepth + blasDepth + 1u > 16u) {
+    if (want > 0) fprintf(stderr, "[gatling_gi] two-level layout not used: trees too deep for the 16-entry stack\n");
+    return GI_C_OK;
+  }
   s->twoLevel = true;
   if (getenv("GATLING_BUILD_TIMING")) fprintf(stderr,
       "[gatling_gi] two-level: TLAS %zu nodes over %zu instances, %zu BLAS nodes, %zu mesh triangles (flat: %zu nodes, %zu triangles)\n",
