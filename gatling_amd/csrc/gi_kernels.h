@@ -10,7 +10,9 @@ namespace gi {
 void launchInit(hipStream_t s, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t n, bool resetStats);
 // `par` = iteration parity: k_raygen reads REGEN[par] and appends TRACE[par]; k_trace reads TRACE[par] and appends HIT and
 // REGEN[par^1]; k_shade reads HIT and appends TRACE[par^1], REGEN[par^1], SHADOW.
-void launchRaygen(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par, F4* sampleBuf);
+// FLAG_CAM_WALK in U.flags: the camera rays are traced inside (gi_camwalk.h; `sc` is the scene, `count` the traversal statistics of counting builds)
+void launchRaygen(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par, F4* sampleBuf,
+                  bool count);
 void launchAccumulate(hipStream_t s, const FrameUniforms& U, const F4* sampleBuf, F4* accum, F4* colorOut, bool firstBatch, bool lastBatch);
 // LDS bytes one k_trace block needs for this scene (stack + staged nodes + staged triangles)
 uint32_t traceStaticLdsBytes(); // static LDS of the traversal kernels on top of traceLdsLayout's dynamic bytes

@@ -156,6 +156,9 @@ enum : uint32_t {
                           // slot is written when the first segment HITS (k_route / k_trace); a camera ray that leaves the scene retires without ever touching a slot
   FLAG_TWO_STREAM = 512u, // the shadow walks of bounce i run on a second stream beside the closest-hit walks of bounce i + 1 (gi_c.cpp "two streams"): k_raygen runs AFTER
                           // the iteration's k_trace / k_route and zeroes only what k_shade and the shadow launch append to; k_zero_closest zeroes the rest before k_trace
+  FLAG_CAM_WALK = 1024u,  // k_raygen traces the camera rays it generates itself, 64 rays of a wave in one shared walk (gi_camwalk.h); implies FLAG_BOUNDS_RETIRE's counter
+                          // protocol (k_raygen appends to the NEXT regen queue: the slots of rays that missed)
+  FLAG_NO_BOUNDS_TEST = 2048u, // with FLAG_BOUNDS_RETIRE: keep its counter protocol but skip the slab test (counting builds: the root visit of every ray is counted)
   FLAG_BOUNDS_RETIRE = 256u, // with FLAG_DEFER_SLOT on the k_trace_dyn path: a camera ray whose slab interval against the scene bounds is empty is never queued --
                              // k_raygen retires its sample (the arithmetic of retire_fresh_miss) and hands the slot straight to the next k_raygen
 };

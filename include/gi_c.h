@@ -369,6 +369,19 @@ void giCSetMeshVisibility(GiCMesh* mesh, int32_t visible);
 void giCDestroyMesh(GiCMesh* mesh);
 
 /* Gi.h:218 */
+/* Hostile input (round 6; tests/test_hostile_inputs.py).  The reference copies what Hydra hands it (giCreateMesh, Gi.cpp:628) and leaves the rest to the Vulkan driver,
+ * which ignores inactive primitives (CgpuVk.cpp:2561-2670); this library builds its own BVH, so it states its rules:
+ *   - a triangle with a vertex that is not finite or lies beyond 1e18 in magnitude AFTER the instance transform is inactive: left out of the BVH, never hit, its
+ *     scene-order id kept (FaceId / ObjectId / InstanceId AOVs and giCTraceRays answers do not shift); one warning per mesh on stderr, the count in
+ *     GiCRenderStats.inactiveTriangleCount;
+ *   - every triangle of an instance whose composed transform has a non-finite entry or no finite inverse (NaN, singular, zero matrix) is inactive;
+ *   - a normal / tangent with a non-finite component is taken as +Z, a non-finite texture coordinate as 0, a non-finite bitangent sign as +1;
+ *   - giCRender refuses (GI_C_ERROR, giCGetLastError names the field): a camera with a non-finite field, a forward / up vector that cannot be normalised, a vertical
+ *     field of view outside (0, pi); non-finite float render settings (maxSampleValue may be +inf: no clamp); spp 0; mediumStackSize > 15; images beyond 65 535
+ *     pixels a side (imageDims is packed 16 + 16 bits, rp_main.h:25-56).  A 0 x N image is a no-op (GI_C_OK).  spp x pixels may exceed 2^32: the frame is cut
+ *     into batches of fewer than 2^32 work items.
+ * Never a crash, a hang or a NaN pixel from geometry; every accepted case renders the image the oracle renders from the same scene with the inactive triangles
+ * replaced by zero-area ones. */
 int giCRender(const GiCRenderParams* params);
 
 /* Gi.h:220-221 */
