@@ -8,7 +8,7 @@
 // which is a leaf, where its triangles are and which of the two quantised planes is the near one are scalar facts (the rays of a walk share their direction octant:
 // a lane whose octant differs from the wave's takes the ordinary route through the TRACE queue); a lane's part is the slab test itself -- six conversions, three packed
 // fma, min / max, one compare per child -- whose result is the child's LANE MASK, which is also all the wave-level stack needs.  Leaf triangles are tested on the
-// spot by the lanes of the leaf's mask (one scalar fetch per triangle), nearest hit and tie-break in registers.
+// spot by the lanes of the leaf's mask (a node's hit leaf triangles are fetched together, one per lane, and read back with readlane), nearest hit and tie-break in registers.
 //
 // Results are those of any other walk (DESIGN.md "Traversal contract"): the slab test is the conservative filter of trav_node_test (same arithmetic: explicit fma,
 // far plane and tBest widened by 1e-5), a lane takes part in a child exactly when its own test passes, triangles go through tri_test and the contract's accept rule
@@ -36,6 +36,7 @@ __device__ __forceinline__ unsigned long long uni64(unsigned long long v)
   return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
 }
 __device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); } // lane: wave-uniform
 
 // All 64 lanes call this (wave-uniform control flow).  `active`: the lane carries a ray; every active lane's direction octant is `oct` (bit 0 = d.x >= 0, ...).
 // Out: t, u, v and the result word (triangle index | shade class << 28, or MISS) -- the record k_trace_dyn leaves in a ray's place.
@@ -71,6 +72,11 @@ __device__ __forceinline__ void cam_walk(const SceneView& sc, CamStack& S, bool 
     const uint32_t imask = n0.w >> 24;
     uint32_t pending = 0u;
     unsigned long long lanesOf[8];
+    // The hit leaf slots' triangles are fetched TOGETHER: lane j takes the j-th of them (<= 24 per node) and remembers which lanes entered its leaf; the tests below
+    // then read a triangle out of its lane with readlane.  (The first version fetched them one after the other through the scalar cache: every triangle a dependent
+    // round trip, a dozen per walk on top of the node fetches -- 1.8 x the per-lane walk's time on C3, profiles/r06e_camwalk_first_version.log.)
+    uint32_t nT = 0u; // triangles gathered (wave-uniform)
+    uint32_t myTri = 0u; unsigned long long myMask = 0ull;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       lanesOf[k] = 0ull;
@@ -88,13 +94,20 @@ __device__ __forceinline__ void cam_walk(const SceneView& sc, CamStack& S, bool 
       const unsigned long long m = __ballot(in && (tn <= tf));
       if (m == 0ull) continue;
       if ((imask >> k) & 1u) { lanesOf[k] = m; pending |= 1u << k; continue; }
-      // a leaf slot: its 1 .. 3 triangles, tested by the lanes that entered it
+      // a leaf slot: its 1 .. 3 triangles join the node's batch
       const uint32_t unary = meta >> 5, cntT = unary == 1u ? 1u : (unary == 3u ? 2u : 3u), triFirst = n1.y + (meta & 31u);
-      const bool mine = ((m >> lane) & 1ull) != 0ull;
-      for (uint32_t j = 0; j < cntT; j++) {
-        const uint32_t triIdx = triFirst + j, toff = triIdx << 6; // 64-byte records (scenes on this path hold < 2^26 triangles)
-        const uint4 a = load_uniform_u4(sc.tris, toff), b = load_uniform_u4(sc.tris, toff + 16u), c = load_uniform_u4(sc.tris, toff + 32u);
-        if (mine) {
+      if (lane >= nT && lane < nT + cntT) { myTri = triFirst + (lane - nT); myMask = m; }
+      nT += cntT;
+    }
+    if (nT != 0u) {
+      uint4 ta = make_uint4(0u, 0u, 0u, 0u), tb = ta, tc4 = ta;
+      if (lane < nT) { const uint4* p = reinterpret_cast<const uint4*>(sc.tris) + (size_t)myTri * 4u; ta = p[0]; tb = p[1]; tc4 = p[2]; }
+      for (uint32_t j = 0; j < nT; j++) { // wave-uniform loop; triangle j lives in lane j
+        const uint4 a = make_uint4(rdl(ta.x, j), rdl(ta.y, j), rdl(ta.z, j), rdl(ta.w, j)), b = make_uint4(rdl(tb.x, j), rdl(tb.y, j), rdl(tb.z, j), rdl(tb.w, j)),
+                    c = make_uint4(rdl(tc4.x, j), rdl(tc4.y, j), rdl(tc4.z, j), rdl(tc4.w, j));
+        const uint32_t triIdx = rdl(myTri, j);
+        const unsigned long long m = ((unsigned long long)rdl((uint32_t)(myMask >> 32), j) << 32) | rdl((uint32_t)myMask, j);
+        if ((m >> lane) & 1ull) {
           if (COUNT) tc.tris++;
           float t, u, v;
           const bool inside = tri_test(o, d, tMin, a, b, c, t, u, v);

@@ -126,9 +126,16 @@ __global__ __launch_bounds__(64) void k_spin(unsigned long long ns, uint32_t* si
 // direction, (rng, work item) -- in the CAMERA REGION of the TRACE queue's arrays (records NSHARD * cap + i for regen entry i: no counter, written in entry order)
 // and its index in the HIT queue of its shade class, where k_shade finds it like any other first hit (HIT_FRESH).  A lane whose direction octant differs from the
 // wave's takes the ordinary route.  Needs the HIT counters zeroed BEFORE the kernel starts (k_zero_hit / k_zero_closest: this kernel's blocks append to them).
+#ifndef GI_CAM_ITEMS // experiment knob: regen entries (and so shared walks) per thread and trip of the CAM instantiations
+#define GI_CAM_ITEMS 2
+#endif
+#ifndef GI_CAM_WAVES // experiment knob (tools/build_variant.py): minimum waves per SIMD asked of the register allocator for the CAM instantiations
+#define GI_CAM_WAVES 1
+#endif
 template <bool CAM, bool COUNT, bool CUTOUT>
-__global__ __launch_bounds__(BLOCK) void k_raygen_t(FrameUniforms U, SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t par, F4* __restrict__ sampleBuf)
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CAM ? GI_CAM_WAVES : 1, 8))) void k_raygen_t(FrameUniforms U, SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t par, F4* __restrict__ sampleBuf)
 {
+  constexpr int ITEMS = CAM ? GI_CAM_ITEMS : RAYGEN_ITEMS; // regen entries per thread and trip
   constexpr int NQA = CAM ? 2 + (int)MAT_CLASS_COUNT : 2;
   __shared__ AppendScratch<NQA> sh;
   __shared__ CamStack s_cam[CAM ? BLOCK / 64 : 1];
@@ -143,22 +150,22 @@ __global__ __launch_bounds__(BLOCK) void k_raygen_t(FrameUniforms U, SceneView s
     zero_next_counters(cnt, par, !boundsRetire, (U.flags & FLAG_TWO_STREAM) != 0u, CAM);
     if (threadIdx.x == 0) { const uint32_t left = U.workTotal - workBase; cnt->workBase[par ^ 1u].v = workBase + (n < left ? n : left); }
   }
-  const uint32_t stride = gridDim.x * BLOCK * RAYGEN_ITEMS;
+  const uint32_t stride = gridDim.x * BLOCK * ITEMS;
   uint32_t qid[NQA]; qid[0] = qOut; qid[1] = qAgain;
   if constexpr (CAM) { for (uint32_t c = 0; c < MAT_CLASS_COUNT; c++) qid[2u + c] = Q_HIT + c; }
   uint32_t trip = 0;
-  for (uint32_t base = blockIdx.x * BLOCK * RAYGEN_ITEMS; base < n; base += stride, trip++) {
-    uint32_t which[RAYGEN_ITEMS], idx[RAYGEN_ITEMS], slotOf[RAYGEN_ITEMS]; FreshRec freshOf[RAYGEN_ITEMS];
-    V3 originOf[RAYGEN_ITEMS], dirOf[RAYGEN_ITEMS]; float tMinOf[RAYGEN_ITEMS], tMaxOf[RAYGEN_ITEMS];
-    uint32_t entryOf[RAYGEN_ITEMS];
-    F4 camHit[RAYGEN_ITEMS]; // (CAM) the walk's result record of a ray that hit
+  for (uint32_t base = blockIdx.x * BLOCK * ITEMS; base < n; base += stride, trip++) {
+    uint32_t which[ITEMS], idx[ITEMS], slotOf[ITEMS]; FreshRec freshOf[ITEMS];
+    V3 originOf[ITEMS], dirOf[ITEMS]; float tMinOf[ITEMS], tMaxOf[ITEMS];
+    uint32_t entryOf[ITEMS];
+    F4 camHit[ITEMS]; // (CAM) the walk's result record of a ray that hit
 #pragma unroll
-    for (int k = 0; k < RAYGEN_ITEMS; k++) { // every item's queue entry first: independent loads in flight
+    for (int k = 0; k < ITEMS; k++) { // every item's queue entry first: independent loads in flight
       const uint32_t i = base + (uint32_t)k * BLOCK + threadIdx.x;
       entryOf[k] = i < n ? qs.slot[qIn][reader_index(rd, i)] : 0u;
     }
 #pragma unroll
-    for (int k = 0; k < RAYGEN_ITEMS; k++) {
+    for (int k = 0; k < ITEMS; k++) {
       const uint32_t i = base + (uint32_t)k * BLOCK + threadIdx.x;
       bool more = false; uint32_t slot = 0, rng = 0u; FreshRec fresh{0u, 0u};
       V3 origin = v3(0.0f, 0.0f, 0.0f), dir = origin; float tMin = 0.0f, tMax = GI_FLT_MAX;
@@ -226,9 +233,9 @@ __global__ __launch_bounds__(BLOCK) void k_raygen_t(FrameUniforms U, SceneView s
       which[k] = more ? 0u : (again ? 1u : (camClass != 0xffffffffu ? 2u + camClass : (uint32_t)NQA));
       slotOf[k] = slot; freshOf[k] = fresh; originOf[k] = origin; dirOf[k] = dir; tMinOf[k] = tMin; tMaxOf[k] = tMax;
     }
-    block_append_items<NQA, RAYGEN_ITEMS>(sh, trip, which, qid, qs.cap, cnt, idx);
+    block_append_items<NQA, ITEMS>(sh, trip, which, qid, qs.cap, cnt, idx);
 #pragma unroll
-    for (int k = 0; k < RAYGEN_ITEMS; k++) {
+    for (int k = 0; k < ITEMS; k++) {
       if (CAM && which[k] >= 2u && which[k] < (uint32_t)NQA) { // a camera ray that hit: its finished record in the camera region, its index in the class's HIT queue
         const uint32_t rec = NSHARD * qs.cap + (base + (uint32_t)k * BLOCK + threadIdx.x);
         qs.slot[qOut][rec] = slotOf[k] | TRACE_FRESH;
