@@ -10,16 +10,14 @@ namespace gi {
 void launchInit(hipStream_t s, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t n, bool resetStats);
 // `par` = iteration parity: k_raygen reads REGEN[par] and appends TRACE[par]; k_trace reads TRACE[par] and appends HIT and
 // REGEN[par^1]; k_shade reads HIT and appends TRACE[par^1], REGEN[par^1], SHADOW.
-// FLAG_CAM_WALK in U.flags: the camera rays are traced inside (gi_camwalk.h; `sc` is the scene, `count` the traversal statistics of counting builds)
-void launchRaygen(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par, F4* sampleBuf,
-                  bool count);
+void launchRaygen(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par, F4* sampleBuf);
 void launchAccumulate(hipStream_t s, const FrameUniforms& U, const F4* sampleBuf, F4* accum, F4* colorOut, bool firstBatch, bool lastBatch);
 // LDS bytes one k_trace block needs for this scene (stack + staged nodes + staged triangles)
 uint32_t traceStaticLdsBytes(); // static LDS of the traversal kernels on top of traceLdsLayout's dynamic bytes
 void traceLdsLayout(const SceneView& sc, uint32_t& ldsNodes, uint32_t& ldsTris, uint32_t& bytes);
 void launchTrace(hipStream_t s, uint32_t blocks, bool anyHit, bool count, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt,
                  uint32_t qIn, uint32_t qMiss, uint32_t dynRefill, uint32_t routeBlocks, const FrameUniforms& U, F4* sampleBuf);
-constexpr uint32_t APPEND_ITEMS_MAX = 4u; // most records a thread appends per trip of a streaming kernel (k_route ROUTE_ITEMS, k_raygen RAYGEN_ITEMS): sizes the queue shards' slack, gi_c.cpp shardCapacity
+constexpr uint32_t APPEND_ITEMS_MAX = 4u; // most records a thread appends per trip of a streaming kernel (k_route ROUTE_ITEMS, k_raygen RAYGEN_ITEMS): sizes the queue shards' slack, gi_render.cpp shardCapacity
 constexpr uint32_t TRACE_DYN_SLOT_ORDER = 0x200u; // flag in dynRefill (shadow launches): children are visited in slot order instead of near-to-far (k_trace_dyn: DYN_SLOT_ORDER)
 constexpr uint32_t TRACE_DYN_SPILL8 = 0x100u; // flag in dynRefill: 8 LDS stack entries + scratch overflow instead of 16 LDS entries
 // dynRefill: 0 = block-synchronous k_trace; N = scenes that do not fit LDS use k_trace_dyn (a wave refills once N lanes are idle) + k_route

@@ -23,7 +23,6 @@
 #include "gi_types.h"
 #include "gi_queues.h"
 #include "gi_traversal.h"
-#include "gi_camwalk.h"
 #include "gi_shading.h"
 #include "gi_stages.h"
 
@@ -120,26 +119,9 @@ __global__ __launch_bounds__(64) void k_spin(unsigned long long ns, uint32_t* si
   while ((wall_clock64() - t0) * 10ull < ns) { }
   if (sink && threadIdx.x == 0xffffu) *sink = 0u;
 }
-// CAM (FLAG_CAM_WALK; scenes beyond LDS on the flat k_trace_dyn path, deferred slots, no dome image / medium stack): the camera rays a wave generates are traced HERE, by
-// the wave's shared walk (gi_camwalk.h) -- they never become records of the TRACE queue, k_trace_dyn does not see them, k_route does not route them.  A ray that
-// misses retires on the spot (what k_route does with a fresh miss); a ray that hits leaves the record k_trace_dyn would have left -- (t, u, v, triangle | class),
-// direction, (rng, work item) -- in the CAMERA REGION of the TRACE queue's arrays (records NSHARD * cap + i for regen entry i: no counter, written in entry order)
-// and its index in the HIT queue of its shade class, where k_shade finds it like any other first hit (HIT_FRESH).  A lane whose direction octant differs from the
-// wave's takes the ordinary route.  Needs the HIT counters zeroed BEFORE the kernel starts (k_zero_hit / k_zero_closest: this kernel's blocks append to them).
-#ifndef GI_CAM_ITEMS // experiment knob: regen entries (and so shared walks) per thread and trip of the CAM instantiations
-#define GI_CAM_ITEMS 2
-#endif
-#ifndef GI_CAM_WAVES // experiment knob (tools/build_variant.py): minimum waves per SIMD asked of the register allocator for the CAM instantiations
-#define GI_CAM_WAVES 1
-#endif
-template <bool CAM, bool COUNT, bool CUTOUT>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CAM ? GI_CAM_WAVES : 1, 8))) void k_raygen_t(FrameUniforms U, SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t par, F4* __restrict__ sampleBuf)
+__global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st, QueueSet qs, Counters* cnt, uint32_t par, F4* __restrict__ sampleBuf)
 {
-  constexpr int ITEMS = CAM ? GI_CAM_ITEMS : RAYGEN_ITEMS; // regen entries per thread and trip
-  constexpr int NQA = CAM ? 2 + (int)MAT_CLASS_COUNT : 2;
-  __shared__ AppendScratch<NQA> sh;
-  __shared__ CamStack s_cam[CAM ? BLOCK / 64 : 1];
-  TraceCounters tc{0u, 0u}; uint32_t nWalked = 0u;
+  __shared__ AppendScratch<2> sh;
   const uint32_t qIn = Q_REGEN_A + par, qOut = Q_TRACE_A + par, qAgain = Q_REGEN_A + (par ^ 1u);
   const bool boundsRetire = (U.flags & FLAG_BOUNDS_RETIRE) != 0u;
   QueueReader rd; reader_init(rd, cnt, qIn, qs.cap);
@@ -147,25 +129,23 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CAM ? GI_
   const uint32_t workBase = cnt->workBase[par].v;
   uint32_t nRetired = 0u;
   if (blockIdx.x == 0) {
-    zero_next_counters(cnt, par, !boundsRetire, (U.flags & FLAG_TWO_STREAM) != 0u, CAM);
+    zero_next_counters(cnt, par, !boundsRetire, (U.flags & FLAG_TWO_STREAM) != 0u);
     if (threadIdx.x == 0) { const uint32_t left = U.workTotal - workBase; cnt->workBase[par ^ 1u].v = workBase + (n < left ? n : left); }
   }
-  const uint32_t stride = gridDim.x * BLOCK * ITEMS;
-  uint32_t qid[NQA]; qid[0] = qOut; qid[1] = qAgain;
-  if constexpr (CAM) { for (uint32_t c = 0; c < MAT_CLASS_COUNT; c++) qid[2u + c] = Q_HIT + c; }
+  const uint32_t stride = gridDim.x * BLOCK * RAYGEN_ITEMS;
+  const uint32_t qid[2] = {qOut, qAgain};
   uint32_t trip = 0;
-  for (uint32_t base = blockIdx.x * BLOCK * ITEMS; base < n; base += stride, trip++) {
-    uint32_t which[ITEMS], idx[ITEMS], slotOf[ITEMS]; FreshRec freshOf[ITEMS];
-    V3 originOf[ITEMS], dirOf[ITEMS]; float tMinOf[ITEMS], tMaxOf[ITEMS];
-    uint32_t entryOf[ITEMS];
-    F4 camHit[ITEMS]; // (CAM) the walk's result record of a ray that hit
+  for (uint32_t base = blockIdx.x * BLOCK * RAYGEN_ITEMS; base < n; base += stride, trip++) {
+    uint32_t which[RAYGEN_ITEMS], idx[RAYGEN_ITEMS], slotOf[RAYGEN_ITEMS]; FreshRec freshOf[RAYGEN_ITEMS];
+    V3 originOf[RAYGEN_ITEMS], dirOf[RAYGEN_ITEMS]; float tMinOf[RAYGEN_ITEMS], tMaxOf[RAYGEN_ITEMS];
+    uint32_t entryOf[RAYGEN_ITEMS];
 #pragma unroll
-    for (int k = 0; k < ITEMS; k++) { // every item's queue entry first: independent loads in flight
+    for (int k = 0; k < RAYGEN_ITEMS; k++) { // every item's queue entry first: independent loads in flight
       const uint32_t i = base + (uint32_t)k * BLOCK + threadIdx.x;
       entryOf[k] = i < n ? qs.slot[qIn][reader_index(rd, i)] : 0u;
     }
 #pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
+    for (int k = 0; k < RAYGEN_ITEMS; k++) {
       const uint32_t i = base + (uint32_t)k * BLOCK + threadIdx.x;
       bool more = false; uint32_t slot = 0, rng = 0u; FreshRec fresh{0u, 0u};
       V3 origin = v3(0.0f, 0.0f, 0.0f), dir = origin; float tMin = 0.0f, tMax = GI_FLT_MAX;
@@ -212,39 +192,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CAM ? GI_
       // a camera ray that cannot reach the scene: what k_route does with a fresh miss (retire_fresh_miss; the segment is counted below), minus the 52-byte record,
       // the traversal step and the routing pass -- the slot goes straight to the next k_raygen
       bool again = false;
-      if (boundsRetire && !(U.flags & FLAG_NO_BOUNDS_TEST) && more && ray_misses_bounds(U, origin, dir, tMin, tMax)) { retire_fresh_miss(U, fresh, sampleBuf); more = false; again = true; nRetired++; }
-      uint32_t camClass = 0xffffffffu;
-      if (CAM) { // the wave's shared walk over the rays this item produced (wave-uniform: every lane calls it)
-        camHit[k] = F4{0.0f, 0.0f, 0.0f, 0.0f};
-        const unsigned long long have = __ballot(more);
-        if (have != 0ull) {
-          const uint32_t oct = (dir.x >= 0.0f ? 1u : 0u) | (dir.y >= 0.0f ? 2u : 0u) | (dir.z >= 0.0f ? 4u : 0u);
-          const uint32_t woct = (uint32_t)__builtin_amdgcn_readlane((int)oct, (int)(__ffsll((long long)have) - 1));
-          const bool walk = more && oct == woct; // (a lane of another octant keeps `more`: the ordinary route through the TRACE queue)
-          float t, u, v; uint32_t word;
-          cam_walk<COUNT, CUTOUT>(sc, s_cam[CAM ? (threadIdx.x >> 6) : 0], walk, woct, origin, dir, tMin, tMax, rng, t, u, v, word, tc);
-          if (walk) {
-            nWalked++; more = false;
-            if (word == MISS) { retire_fresh_miss(U, fresh, sampleBuf); again = true; } // what k_route does with a fresh miss
-            else { camHit[k] = F4{t, u, v, u2f(word)}; camClass = word >> 28; } // k_trace_dyn's result record: (t, u, v, triangle | shade class << 28)
-          }
-        }
-      }
-      which[k] = more ? 0u : (again ? 1u : (camClass != 0xffffffffu ? 2u + camClass : (uint32_t)NQA));
+      if (boundsRetire && more && ray_misses_bounds(U, origin, dir, tMin, tMax)) { retire_fresh_miss(U, fresh, sampleBuf); more = false; again = true; nRetired++; }
+      which[k] = more ? 0u : (again ? 1u : 2u);
       slotOf[k] = slot; freshOf[k] = fresh; originOf[k] = origin; dirOf[k] = dir; tMinOf[k] = tMin; tMaxOf[k] = tMax;
     }
-    block_append_items<NQA, ITEMS>(sh, trip, which, qid, qs.cap, cnt, idx);
+    block_append_items<2, RAYGEN_ITEMS>(sh, trip, which, qid, qs.cap, cnt, idx);
 #pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-      if (CAM && which[k] >= 2u && which[k] < (uint32_t)NQA) { // a camera ray that hit: its finished record in the camera region, its index in the class's HIT queue
-        const uint32_t rec = NSHARD * qs.cap + (base + (uint32_t)k * BLOCK + threadIdx.x);
-        qs.slot[qOut][rec] = slotOf[k] | TRACE_FRESH;
-        st4(&qs.a[qOut][rec], camHit[k].x, camHit[k].y, camHit[k].z, camHit[k].w);
-        st4(&qs.b[qOut][rec], dirOf[k].x, dirOf[k].y, dirOf[k].z, tMaxOf[k]);
-        qs.fresh[par][rec] = freshOf[k];
-        qs.slot[Q_HIT + which[k] - 2u][idx[k]] = rec | HIT_FRESH;
-        continue;
-      }
+    for (int k = 0; k < RAYGEN_ITEMS; k++) {
       if (which[k] == 0u) {
         const bool defer = (U.flags & FLAG_DEFER_SLOT) != 0u;
         qs.slot[qOut][idx[k]] = defer ? (slotOf[k] | TRACE_FRESH) : slotOf[k];
@@ -254,19 +208,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(CAM ? GI_
       } else if (which[k] == 1u) qs.slot[qAgain][idx[k]] = slotOf[k] | REGEN_FRESH;
     }
   }
-  if (boundsRetire || CAM) { // the retired / walked camera rays are segments of their paths (Counters::segments equals the oracle's count): one atomic per wave
-    unsigned long long c = nRetired + nWalked;
+  if (boundsRetire) { // the retired camera rays are segments of their paths (Counters::segments equals the oracle's count): one atomic per wave
+    unsigned long long c = nRetired;
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
     if (__lane_id() == 0u && c) atomicAdd(&cnt->segments, c);
   }
-  if (CAM && COUNT) { // measurement builds: the walk's node visits and triangle tests, per lane as in k_trace_dyn
-    unsigned long long a = tc.nodes, b = tc.tris;
-    for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
-    if (__lane_id() == 0u && (a | b)) { atomicAdd(&cnt->nodesVisited, a); atomicAdd(&cnt->trisTested, b); }
-  }
 }
-// the HIT queues' counters, zeroed in front of a k_raygen<CAM> (single-stream iterations; two-stream batches: k_zero_closest)
-__global__ __launch_bounds__(64) void k_zero_hit(Counters* cnt) { if (threadIdx.x < NSHARD) for (uint32_t c = 0; c < MAT_CLASS_COUNT; c++) cnt->count[Q_HIT + c][threadIdx.x].v = 0; }
 
 // ------------------------------------------------------------------------------------------------
 // k_accumulate: folds one batch of per-sample colours into the per-pixel running sum IN SAMPLE ORDER
@@ -432,7 +379,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
 //     no search through the shard prefix sums;
 //   * everything wave-uniform (claims, chunk and ring bookkeeping) is forced into SGPRs with readfirstlane;
 //   * shadow walks (ANYHIT) end at their first hit, so near-to-far order is optional for them: the SLOT instantiation visits children in slot order (no octant flip
-//     in its node test) and the host launches whichever order the scene's shadow walks have been cheaper in (trace_dyn_body, gi_c.cpp shadowOrder).
+//     in its node test) and the host launches whichever order the scene's shadow walks have been cheaper in (trace_dyn_body, gi_render.cpp shadowOrder).
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t DYN_SLOT_ORDER = 0x200u; // bit in k_trace_dyn's `refill` argument (shadow launches): the launch is the slot-order instantiation (the prologue counts its rays as such)
 constexpr uint32_t DYN_CLAIM = 128;   // rays per cursor atomic (a device-scope atomic on one line completes ~88 times per microsecond; 64 / 256 / 512 measured: r04x)
@@ -1009,14 +956,9 @@ void launchInit(hipStream_t s, const PathState& st, const QueueSet& qs, Counters
   uint32_t blocks = (n + 255u) / 256u; if (blocks > 4096u) blocks = 4096u; if (blocks == 0u) blocks = 1u;
   hipLaunchKernelGGL(k_init, dim3(blocks), dim3(256), 0, s, st, qs, cnt, n, resetStats ? 1u : 0u);
 }
-void launchRaygen(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par, F4* sampleBuf, bool count)
+void launchRaygen(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par, F4* sampleBuf)
 {
-  if (!(U.flags & FLAG_CAM_WALK)) { hipLaunchKernelGGL((k_raygen_t<false, false, false>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par, sampleBuf); return; }
-  if (!(U.flags & FLAG_TWO_STREAM)) hipLaunchKernelGGL(k_zero_hit, dim3(1), dim3(64), 0, s, cnt); // (two-stream batches: k_zero_closest has done it)
-  if (sc.hasCutouts) { if (count) hipLaunchKernelGGL((k_raygen_t<true, true, true>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par, sampleBuf);
-                       else hipLaunchKernelGGL((k_raygen_t<true, false, true>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par, sampleBuf); }
-  else { if (count) hipLaunchKernelGGL((k_raygen_t<true, true, false>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par, sampleBuf);
-         else hipLaunchKernelGGL((k_raygen_t<true, false, false>), dim3(blocks), dim3(BLOCK), 0, s, U, sc, st, qs, cnt, par, sampleBuf); }
+  hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(BLOCK), 0, s, U, st, qs, cnt, par, sampleBuf);
 }
 void launchAccumulate(hipStream_t s, const FrameUniforms& U, const F4* sampleBuf, F4* accum, F4* colorOut, bool firstBatch, bool lastBatch)
 {

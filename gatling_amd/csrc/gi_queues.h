@@ -175,14 +175,13 @@ constexpr uint32_t REGEN_FRESH = 0x40000000u;  // flag on a regen-queue entry wr
 // (appended by k_shade(it); its count was last read by k_trace / k_route(it-1)), the SHADOW queue's counter and the shadow cursors (read by the shadow launch of it-1,
 // which k_raygen(it) has waited for; appended / used by k_shade(it) and its shadow launch).  What k_trace / k_route(it) append to or claim from is zeroed by
 // k_zero_closest(it) in front of them (zero_closest_counters).
-// `camWalk` (k_raygen<CAM>): the kernel's own blocks append to the HIT queues, whose counters are zeroed in front of it (k_zero_hit / k_zero_closest) instead of here.
-__device__ __forceinline__ void zero_next_counters(Counters* cnt, uint32_t par, bool zeroRegen, bool twoStream = false, bool camWalk = false)
+__device__ __forceinline__ void zero_next_counters(Counters* cnt, uint32_t par, bool zeroRegen, bool twoStream = false)
 {
   const uint32_t t = threadIdx.x;
   if (t < NSHARD) {
     cnt->count[Q_TRACE_A + (par ^ 1u)][t].v = 0;
     if (zeroRegen && !twoStream) cnt->count[Q_REGEN_A + (par ^ 1u)][t].v = 0;
-    if (!twoStream && !camWalk) for (uint32_t c = 0; c < MAT_CLASS_COUNT; c++) cnt->count[Q_HIT + c][t].v = 0;
+    if (!twoStream) for (uint32_t c = 0; c < MAT_CLASS_COUNT; c++) cnt->count[Q_HIT + c][t].v = 0;
     cnt->count[Q_SHADOW][t].v = 0;
   }
   if (t < 2u * NCURSOR && (!twoStream || t >= NCURSOR)) cnt->cursor[t / NCURSOR][t % NCURSOR].v = 0; // k_trace_dyn's ray cursors (closest, shadow)

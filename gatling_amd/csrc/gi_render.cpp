@@ -56,13 +56,10 @@ int ensurePathState(SceneDevice* s, size_t slots, uint32_t gridA, uint32_t gridB
     const size_t n = (size_t)cap * NSHARD;
     for (uint32_t q = 0; q < Q_COUNT; q++) {
       const bool hasRecord = (q == Q_TRACE_A || q == Q_TRACE_B || q == Q_SHADOW); // (the HIT queues hold indices into the TRACE queue: gi_queues.h)
-      // the TRACE queues' arrays are twice the queue: records [n, 2 n) are the CAMERA REGION, where k_raygen<CAM> leaves the finished records of the camera rays it
-      // traced itself (gi_kernels.hip k_raygen_t: record n + i for regen entry i; the queue's counters never cover them)
-      const size_t nq = (q == Q_TRACE_A || q == Q_TRACE_B) ? 2 * n : n;
-      GI_ALLOC(s->qSlot[q].alloc(nq));
-      if (hasRecord) { GI_ALLOC(s->qA[q].alloc(nq)); GI_ALLOC(s->qB[q].alloc(nq)); }
+      GI_ALLOC(s->qSlot[q].alloc(n));
+      if (hasRecord) { GI_ALLOC(s->qA[q].alloc(n)); GI_ALLOC(s->qB[q].alloc(n)); }
       if (q == Q_SHADOW) GI_ALLOC(s->qC[q].alloc(n));
-      if (q == Q_TRACE_A || q == Q_TRACE_B) GI_ALLOC(s->qFresh[q - Q_TRACE_A].alloc(nq));
+      if (q == Q_TRACE_A || q == Q_TRACE_B) GI_ALLOC(s->qFresh[q - Q_TRACE_A].alloc(n));
     }
     s->queueCap = cap;
   }
@@ -304,13 +301,13 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
     // HIT-queue entries (and giCTraceRays) hold a TRACE-queue RECORD index in 30 bits (HIT_INDEX_MASK); records run up to shardCapacity * NSHARD, which exceeds
     // the
     // slot count by the shards' slack -- a pinned pool near 2^30 would push indices past the mask and k_shade would gather the wrong record
-    // (twice the queue: the camera region of the TRACE arrays, ensurePathState)
-    while (!fused && (uint64_t)shardCapacity(slots, wideBlocks, traceBlocks) * NSHARD * 2ull > 0x3fffffffull /* HIT_INDEX_MASK, gi_queues.h */) { slots -= slots / 8; sizeGrids(); }
+    while (!fused && (uint64_t)shardCapacity(slots, wideBlocks, traceBlocks) * NSHARD > 0x3fffffffull /* HIT_INDEX_MASK, gi_queues.h */) { slots -= slots / 8;
+        sizeGrids(); }
     const uint32_t mediaStride = rs.mediumStackSize ? rs.mediumStackSize * MEDIUM_FLOATS + 4u : 0u;
     // what a plan costs: the slot pool with its queues (per slot: the Slot, the medium stack, and a share of every queue's records) and the sample buffer
     auto planBytes = [&](size_t nSlots, uint64_t nBatch) -> uint64_t {
       const uint64_t cap = shardCapacity(nSlots, wideBlocks, traceBlocks);
-      const uint64_t perQueueEntry = 4ull * Q_COUNT + 32ull * (2 + 1) + 16ull + 8ull * 2 + 2ull * (4ull + 32ull + 8ull) /* the TRACE arrays' camera region */;
+      const uint64_t perQueueEntry = 4ull * Q_COUNT + 32ull * (2 + 1) + 16ull + 8ull * 2;
       return (fused ? 0ull : (uint64_t)nSlots * (sizeof(Slot) + 4ull * mediaStride) + cap * NSHARD * perQueueEntry) + (uint64_t)pixels * nBatch * 16ull + (uint64_t)pixels * 16ull;
     };
     // the caller's sizes are taken as given
@@ -379,14 +376,6 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
           optionValue("bounds_retire", 1) != 0) {
         U.flags |= FLAG_BOUNDS_RETIRE;
         for (int a = 0; a < 3; a++) { U.sceneLo[a] = s->bounds[a]; U.sceneHi[a] = s->bounds[3 + a]; }
-      }
-      // Camera walk (r06): on the same path k_raygen traces the camera rays it generates itself -- the 64 rays of a wave are samples of one pixel and walk the tree
-      // as ONE walk (gi_camwalk.h) -- so they never become TRACE records.  It appends to the next regen queue like the bounds retire (whose counter protocol it
-      // switches on; counting builds keep the protocol and skip the slab test, so that every ray's root visit is counted).  GATLING_OPTIONS=cam_walk=0: off.
-      if ((U.flags & FLAG_DEFER_SLOT) && !allLds && dynRefill && !view.twoLevel && view.domeTexture == 0u && rs.mediumStackSize == 0u && s->bvhDepth + 1u <= 18u /* CAM_STACK */ &&
-          optionValue("cam_walk", 1) != 0) {
-        U.flags |= FLAG_CAM_WALK;
-        if (!(U.flags & FLAG_BOUNDS_RETIRE)) U.flags |= FLAG_BOUNDS_RETIRE | FLAG_NO_BOUNDS_TEST;
       }
     }
 
@@ -475,7 +464,7 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
       for (uint64_t it = 0; it < maxIters; it++) {
         const uint32_t par = (uint32_t)(it & 1u);
         curIter = totalIters; if (timers && (totalIters % timerStride) == 0u) sampledIters++;
-        auto raygen = [&] { timed(0, [&] { launchRaygen(st, wideBlocks, U, view, ps, qs, D.dCounters.ptr, par, D.sampleBuf.ptr, s->countTraversal); }); };
+        auto raygen = [&] { timed(0, [&] { launchRaygen(st, wideBlocks, U, ps, qs, D.dCounters.ptr, par, D.sampleBuf.ptr); }); };
         // k_raygen(it) after the shadow launch of it - 1 (two streams, it > 0: it runs behind this iteration's closest-hit launch)
         auto raygenBehindShadow = [&] { if (shadowInFlight) { (void)hipStreamWaitEvent(st, D.evShadow, 0); shadowInFlight = false; } raygen(); };
         if (two) launchZeroClosest(st, D.dCounters.ptr, par);
@@ -508,8 +497,6 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
             // this point otherwise -- and work is left)
             const PaddedCounter* again = D.hPoll + (j % R) * snapshot + (size_t)(Q_REGEN_A + (uint32_t)((j & 1u) ^ 1u)) * NSHARD;
             uint32_t pending = 0; for (uint32_t k = 0; k < NSHARD; k++) pending += snap[k].v + again[k].v;
-            // (FLAG_CAM_WALK: k_raygen(j)'s camera rays that hit are in the HIT queues already -- zeroed in front of it -- not in TRACE[j & 1])
-            if (U.flags & FLAG_CAM_WALK) for (uint32_t c = 0; c < MAT_CLASS_COUNT; c++) for (uint32_t k = 0; k < NSHARD; k++) pending += (D.hPoll + (j % R) * snapshot + (size_t)(Q_HIT + c) * NSHARD)[k].v;
             if (pending == 0) { totalIters++; break; } // k_raygen(j) consumed the regen queue and produced no rays: the pool had drained
           }
         }

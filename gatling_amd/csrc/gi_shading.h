@@ -782,7 +782,7 @@ __device__ inline void opbr_evaluate(const MaterialRec* m, const ShState& st, V3
 // ------------------------------------------------------------------------------------------------
 // OpenPBR, BASE variant (shade class SHADE_CLASS_OPBR_BASE; the reference compiles its hit shaders per material with feature #defines,
 // GlslShaderGen.cpp:204-274 -- here the host sorts OpenPBR materials into two variants and k_route bins their hits apart).  A BASE material has no coat, no fuzz,
-// no thin film, no anisotropy, no transmission, no subsurface, is not thin-walled and binds no texture (gi_c.cpp shadeClassOf): what is left is the metal lobe, the
+// no thin film, no anisotropy, no transmission, no subsurface, is not thin-walled and binds no texture (gi_build.cpp shadeClassOf): what is left is the metal lobe, the
 // dielectric reflection and the (energy-preserving Oren-Nayar) diffuse base.  The functions below are opbr_sample / opbr_evaluate with those weights set to their
 // constants and every operation that is an exact identity under them removed -- x * 1, x / 1, x - 0, (1 - 0), a lobe the selection can never reach; additions of an
 // exact +0 stay where the sign of a zero could differ -- so a BASE material shades to the same bits through either variant

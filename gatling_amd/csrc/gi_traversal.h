@@ -469,7 +469,7 @@ __device__ __forceinline__ void wave_tri_batch2(WaveTri& W, uint32_t head, uint3
     const uint4 tv = make_uint4(f2u(r5.y), f2u(r5.z), f2u(r5.w), 0u); // (blasRoot, triBase, matFlags, -)
     const float4 pa = make_float4(ta.x, ta.y, ta.z, 0.0f), pb = make_float4(ta.w, tb.x, tb.y, 0.0f), pc = make_float4(tb.z, tb.w, tq.x, 0.0f);
     const uint4 t4 = make_uint4(0u, 0u, 0u, f2u(tq.y));
-    // host xformPoint (gi_c.cpp): ((a0 p0 + a1 p1) + a2 p2) + a3
+    // host xformPoint (gi_build.cpp): ((a0 p0 + a1 p1) + a2 p2) + a3
     const V3 p0 = v3(((r0.x * pa.x + r0.y * pa.y) + r0.z * pa.z) + r0.w, ((r1.x * pa.x + r1.y * pa.y) + r1.z * pa.z) + r1.w, ((r2.x * pa.x + r2.y * pa.y) + r2.z * pa.z) + r2.w);
     const V3 p1 = v3(((r0.x * pb.x + r0.y * pb.y) + r0.z * pb.z) + r0.w, ((r1.x * pb.x + r1.y * pb.y) + r1.z * pb.z) + r1.w, ((r2.x * pb.x + r2.y * pb.y) + r2.z * pb.z) + r2.w);
     const V3 p2 = v3(((r0.x * pc.x + r0.y * pc.y) + r0.z * pc.z) + r0.w, ((r1.x * pc.x + r1.y * pc.y) + r1.z * pc.z) + r1.w, ((r2.x * pc.x + r2.y * pc.y) + r2.z * pc.z) + r2.w);

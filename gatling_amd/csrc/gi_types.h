@@ -1,4 +1,4 @@
-// gi_types.h -- POD layouts shared by the host code (gi_c.cpp, bvh8.cpp) and the HIP kernels.
+// gi_types.h -- POD layouts shared by the host code (gi_host.h and the gi_*.cpp units, bvh8.cpp) and the HIP kernels.
 // All structs are plain data in HBM; sizes are asserted.  See DESIGN.md "Data layout in HBM".
 #pragma once
 
@@ -154,11 +154,8 @@ enum : uint32_t {
   FLAG_PIXEL_MAJOR = 64u, // work order of the wavefront pipeline (gi_queues.h work_item)
   FLAG_DEFER_SLOT = 128u, // wavefront pipeline: k_raygen does not write the Slot of a new camera path; its (rng, work item) travel beside the ray record and the
                           // slot is written when the first segment HITS (k_route / k_trace); a camera ray that leaves the scene retires without ever touching a slot
-  FLAG_TWO_STREAM = 512u, // the shadow walks of bounce i run on a second stream beside the closest-hit walks of bounce i + 1 (gi_c.cpp "two streams"): k_raygen runs AFTER
+  FLAG_TWO_STREAM = 512u, // the shadow walks of bounce i run on a second stream beside the closest-hit walks of bounce i + 1 (gi_render.cpp "two streams"): k_raygen runs AFTER
                           // the iteration's k_trace / k_route and zeroes only what k_shade and the shadow launch append to; k_zero_closest zeroes the rest before k_trace
-  FLAG_CAM_WALK = 1024u,  // k_raygen traces the camera rays it generates itself, 64 rays of a wave in one shared walk (gi_camwalk.h); implies FLAG_BOUNDS_RETIRE's counter
-                          // protocol (k_raygen appends to the NEXT regen queue: the slots of rays that missed)
-  FLAG_NO_BOUNDS_TEST = 2048u, // with FLAG_BOUNDS_RETIRE: keep its counter protocol but skip the slab test (counting builds: the root visit of every ray is counted)
   FLAG_BOUNDS_RETIRE = 256u, // with FLAG_DEFER_SLOT on the k_trace_dyn path: a camera ray whose slab interval against the scene bounds is empty is never queued --
                              // k_raygen retires its sample (the arithmetic of retire_fresh_miss) and hands the slot straight to the next k_raygen
 };
@@ -265,7 +262,7 @@ struct PathState {
 // HIT is one queue per material class (the sort key between trace and shade): Q_HIT + klass
 // ... more precisely per SHADE class: the material classes 0 .. 2 (diffuse, UsdPreviewSurface, OpenPBR with every lobe) and the specialised variants of a class.  The
 // shade class of a triangle's material rides in bits 24-27 of TriRec::matFlags (and from there in the top four bits of a hit word); MaterialRec::klass stays the
-// BSDF model.  SHADE_CLASS_OPBR_BASE: OpenPBR materials whose optional lobes are all absent (gi_shading.h "BASE variant", gi_c.cpp shadeClassOf).
+// BSDF model.  SHADE_CLASS_OPBR_BASE: OpenPBR materials whose optional lobes are all absent (gi_shading.h "BASE variant", gi_build.cpp shadeClassOf).
 constexpr uint32_t MAT_CLASS_COUNT = 4, SHADE_CLASS_OPBR_BASE = 3;
 enum : uint32_t { Q_TRACE_A = 0, Q_TRACE_B = 1, Q_REGEN_A = 2, Q_REGEN_B = 3, Q_SHADOW = 4, Q_HIT = 5, Q_COUNT = Q_HIT + MAT_CLASS_COUNT };
 constexpr uint32_t NSHARD = 8;
@@ -290,7 +287,7 @@ struct Counters {
   PaddedCounter cursor[2][NCURSOR];
   unsigned long long segments, shadowRays, nodesVisited, trisTested, shadowNodesVisited, shadowTrisTested;
   // shadow walks in the two visiting orders (k_trace_dyn<any>: [0] near-to-far, [1] slot order): rays launched, and node visits summed per wave into one of 16 lines
-  // (the host picks the order a scene's shadow rays visit fewer nodes in, gi_c.cpp shadowOrder)
+  // (the host picks the order a scene's shadow rays visit fewer nodes in, gi_render.cpp shadowOrder)
   unsigned long long shadowOrderRays[2];
   PaddedCounter shadowOrderSteps[2][16];
   uint32_t overflow; // set by block_append when a shard would run past its capacity (host sizing bug): giCRender fails loudly

@@ -518,7 +518,7 @@ def test_image_loader_hook_with_bogus_dimensions_fails_cleanly():
 
 
 def test_shade_class_of_materials(monkeypatch):
-    """Host classification behind the k_shade variants (gi_c.cpp shadeClassOf; the reference's per-material feature #defines, GlslShaderGen.cpp:204-274): an OpenPBR
+    """Host classification behind the k_shade variants (gi_build.cpp shadeClassOf; the reference's per-material feature #defines, GlslShaderGen.cpp:204-274): an OpenPBR
     material is BASE (3) only when every optional lobe is absent and every parameter finite; anything else keeps its BSDF class."""
     from gatling_amd.scene import MAT_DIFFUSE, MaterialDesc, P_FUZZ_COLOR
     O = MaterialDesc.open_pbr

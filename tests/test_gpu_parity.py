@@ -1528,7 +1528,7 @@ def test_shade_variants_are_bit_identical(gi, orc, monkeypatch, scene_kind):
 
 # ---------------------------------------------------------------------------------------------------------------
 # two streams (round 6): in batches whose work fits the pool the shadow launch of bounce i runs on a second stream beside the closest-hit launch of bounce i + 1
-# (gi_c.cpp "two streams"; the reference's default frame is one sample per pixel and giRender call, renderDelegate.cpp:93-110).  Scheduling only: same images.
+# (gi_render.cpp "two streams"; the reference's default frame is one sample per pixel and giRender call, renderDelegate.cpp:93-110).  Scheduling only: same images.
 # ---------------------------------------------------------------------------------------------------------------
 _TWO_STREAM_MODES = ["two_stream=0", "two_stream=1", "two_stream=1,two_stream_delay=1", "two_stream=1,two_stream_delay=2"]
 
@@ -1615,53 +1615,3 @@ def test_two_stream_nee_and_bounces_aovs(gi, orc, monkeypatch):
         for k in ("nee", "bounces"):
             assert np.array_equal(got[k][..., :3], ref[k][..., :3]), (mode, k)
         assert np.array_equal(got["clockCycles"], ref["clockCycles"]), mode
-
-
-# ---------------------------------------------------------------------------------------------------------------
-# camera walk (round 6): k_raygen traces the camera rays it generates itself, the 64 rays of a wave (samples of one pixel) in ONE shared walk (gi_camwalk.h) --
-# the reference's traceRayEXT for the primary segment, rp_main.rgen:381-393.  Same hits, same images.
-# ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("scene_kind", ["soup", "interior", "grid+cutouts", "inside", "dof+clip", "axis", "far"])
-def test_camera_walk_is_invisible(gi, orc, monkeypatch, scene_kind):
-    """With and without the walk, pixel-major and sample-major work orders (a wave's rays: one pixel's samples / 64 neighbouring pixels), a pool of several raygen
-    rounds, one and two streams, and a counting build: the oracle's image, segment and shadow-ray counts every time.  Cameras: outside, INSIDE the soup, a thin lens
-    with clip planes (origins and intervals differ per lane), looking exactly down an axis (the centre column's and row's jitter flips direction signs inside a
-    wave: lanes of another octant take the TRACE queue), and 2e4 units away (every ray of a wave in one leaf, or none)."""
-    from gatling_amd import capi
-    rs = RenderSettings(spp=4, max_bounces=5, next_event_estimation=True, progressive_accumulation=False)
-    if scene_kind == "interior":
-        desc = interior_scene(clutter_instances=100, subdivisions=1, prototypes=5, material_count=20)
-    elif scene_kind == "grid+cutouts":
-        desc = sphere_grid(grid=5, subdivisions=2, material_count=8)
-        desc.materials[1].params[14] = 0.4; desc.materials[2].params[14] = 0.7
-        desc.rect_lights = [RectLight(origin=(0, 0, 7.0), t0=(1, 0, 0), t1=(0, 1, 0), base_emission=(15, 15, 15), width=3.0, height=3.0)]
-    else:
-        desc = _soup(20000, seed=31)
-        if scene_kind == "inside":
-            desc.camera = CameraDesc(position=(0.1, 0.05, -0.1), forward=(0.3, 0.9, 0.2), up=(0, 0, 1), vfov=1.2)
-        elif scene_kind == "dof+clip":
-            desc.camera.f_stop, desc.camera.focus_distance, desc.camera.clip_start, desc.camera.clip_end = 0.4, 4.0, 3.4, 4.6
-            rs.depth_of_field = True; rs.clipping_planes = True
-        elif scene_kind == "axis":
-            desc.camera = CameraDesc(position=(0, -4, 0), forward=(0, 1, 0), up=(0, 0, 1), vfov=0.7)
-        elif scene_kind == "far":
-            desc.camera = CameraDesc(position=(0, -2.0e4, 0), forward=(0, 1, 0), up=(0, 0, 1), vfov=1.5e-4, clip_end=65504.0)
-    w, h = 97, 54  # (an odd width: waves straddle rows)
-    ref, cnt = orc.render(desc, rs, w, h, threads=4)
-    seen = []
-    for mode in ("cam_walk=0", "cam_walk=1", "cam_walk=1,work_order=0", "cam_walk=1,pool_slots=3000", "cam_walk=1,two_stream=0", "cam_walk=1,bounds_retire=0", "count"):
-        monkeypatch.setenv("GATLING_OPTIONS", "cam_walk=1" if mode == "count" else mode)
-        sc = gi.Scene(desc)
-        try:
-            if mode == "count":
-                sc.set_option(capi.OPTION_COUNT_TRAVERSAL, 1)
-            img = sc.render(rs, w, h); st = sc.stats()
-        finally:
-            sc.close()
-        assert st["fusedPath"] == 0
-        assert st["segments"] == cnt["segments"] and st["shadowRays"] == cnt["shadow_rays"], mode
-        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), (mode, int((img.view(np.uint32) != ref.view(np.uint32)).any(axis=-1).sum()))
-        if mode == "count":
-            assert st["nodesVisited"] >= st["segments"]  # every traced segment visits the root: the walk's visits are counted too
-        seen.append(mode)
-    assert len(seen) == 7

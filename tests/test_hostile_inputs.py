@@ -414,7 +414,7 @@ def test_refused_settings(gi):
 @pytest.mark.skipif((os.cpu_count() or 1) < 32, reason="the oracle needs ~60 M samples for the two bands: a many-core host")
 def test_more_than_2_pow_32_samples_in_one_call(gi, orc):
     """spp x pixels >= 2^32 in ONE giCRender (C2's frame at spp 2 100 = 4.35 G samples): work-item ids are 32-bit, so the frame is cut into batches of fewer than
-    2^32 items (gi_c.cpp memory plan); two bands of the image against the oracle at that spp."""
+    2^32 items (gi_render.cpp memory plan); two bands of the image against the oracle at that spp."""
     desc = cornell_box(MAT_USD_PREVIEW_SURFACE)
     rs = RenderSettings(spp=2100, max_bounces=8)
     w, h = 1920, 1080

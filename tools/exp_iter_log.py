@@ -1,4 +1,4 @@
-"""Per-iteration stage times and queue sizes of the wavefront pipeline (GATLING_ITER_LOG=1; gi_c.cpp prints one line per iteration to stderr).
+"""Per-iteration stage times and queue sizes of the wavefront pipeline (GATLING_ITER_LOG=1; gi_render.cpp prints one line per iteration to stderr).
 
   python tools/exp_iter_log.py c4 256               # workload, spp (the workload's own settings)
   python tools/exp_iter_log.py c4 1 delegate        # hdGatling's defaults instead: 13 bounces, progressive accumulation (the spp-1 viewport frame)
