@@ -259,6 +259,7 @@ struct GiCScene : SceneDevice {
   DenseStore<DistantLightRec, GiCDistantLight> distantLights;
   DenseStore<RectLightRec, GiCRectLight> rectLights;
   DenseStore<DiskLightRec, GiCDiskLight> diskLights;
+  uint32_t lightCounts[4] = {0, 0, 0, 0}; // sphere / distant / rect / disk lights the device arrays hold (uploadLights: the stores' records minus the unusable ones)
   uint32_t sampleOffset = 0;
   bool haveOldParams = false;
   GiCCameraDesc oldCamera{};

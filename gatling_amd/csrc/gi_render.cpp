@@ -213,8 +213,7 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
     U.imageWidth = width; U.imageHeight = height; U.rowBegin = rowBegin; U.rowStride = rowStride; U.pixelCount = (uint32_t)pixels;
     U.flags = (rs.jitteredSampling ? FLAG_JITTER : 0u) | (rs.filterImportanceSampling ? FLAG_FIS : 0u) | (rs.depthOfField ? FLAG_DOF : 0u) |
               (rs.clippingPlanes ? FLAG_CLIP : 0u) | (rs.nextEventEstimation ? FLAG_NEE : 0u) | (rs.progressiveAccumulation ? FLAG_PROGRESSIVE : 0u);
-    U.sphereCount = (uint32_t)s->sphereLights.recs.size(); U.distantCount = (uint32_t)s->distantLights.recs.size();
-    U.rectCount = (uint32_t)s->rectLights.recs.size(); U.diskCount = (uint32_t)s->diskLights.recs.size();
+    U.sphereCount = s->lightCounts[0]; U.distantCount = s->lightCounts[1]; U.rectCount = s->lightCounts[2]; U.diskCount = s->lightCounts[3]; // (uploadLights)
     U.totalLightCount = U.sphereCount + U.distantCount + U.rectCount + U.diskCount;
   }
 
@@ -758,6 +757,10 @@ static int giCRenderImpl(const GiCRenderParams* params)
     if (!(c.vfov > 0.0f && c.vfov < 3.14159265f)) { setError("giCRender: the camera's vertical field of view must lie inside (0, pi) radians");
         return GI_C_ERROR; }
     if (!std::isfinite(1.0f / (2.0f * tanf(c.vfov * 0.5f)))) { setError("giCRender: the camera's vertical field of view is too small for the image plane distance to be finite"); return GI_C_ERROR; }
+  }
+  if (const GiCDomeLight* dl = params->domeLight) { // (the dome light's setters take whatever they are given, like the reference's)
+    const float fields[] = {dl->rotation[0], dl->rotation[1], dl->rotation[2], dl->rotation[3], dl->baseEmission[0], dl->baseEmission[1], dl->baseEmission[2], dl->diffuse, dl->specular};
+    for (float f : fields) if (!std::isfinite(f)) { setError("giCRender: the dome light has a non-finite field"); return GI_C_ERROR; }
   }
   { // render settings that enter the arithmetic as floats
     const float fields[] = {rs.rrInvMinTermProb, rs.lightIntensityMultiplier, rs.metersPerSceneUnit, rs.frame};

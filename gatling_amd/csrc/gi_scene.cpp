@@ -31,6 +31,10 @@ GiCMaterial* giCCreateMaterial(GiCScene* scene, const char* name, const GiCMater
 {
   if (!scene || !desc) { setError("giCCreateMaterial: null argument"); return nullptr; }
   if (desc->klass > GI_C_MAT_OPEN_PBR) { setError("giCCreateMaterial: unsupported material class"); return nullptr; }
+  // Hostile input (include/gi_c.h): a non-finite parameter would be NaN radiance on every path that meets the material.  Refused like a material the reference
+  // fails to compile (giCreateMaterialFrom* return nullptr there, and hdGatling falls back to its default material, material.cpp)
+  for (uint32_t i = 0; i < MAT_PARAM_COUNT; i++)
+    if (!std::isfinite(desc->p[i])) { setError("giCCreateMaterial: parameter " + std::to_string(i) + " of material '" + (name ? name : "") + "' is not finite"); return nullptr; }
   GiCMaterial* m = new GiCMaterial{scene, name ? name : "", *desc};
   // subsurface_radius / subsurface_radius_scale joined the block in round 4 (slots 32..35, ignored before): a caller built against the older header leaves them
   // 0, which

@@ -375,8 +375,10 @@ void giCDestroyMesh(GiCMesh* mesh);
  *     scene-order id kept (FaceId / ObjectId / InstanceId AOVs and giCTraceRays answers do not shift); one warning per mesh on stderr, the count in
  *     GiCRenderStats.inactiveTriangleCount;
  *   - every triangle of an instance whose composed transform has a non-finite entry or no finite inverse (NaN, singular, zero matrix) is inactive;
+ *   - giCCreateMaterial refuses a parameter block with a non-finite entry (NULL, like a material the reference fails to compile: the caller falls back to its default
+ *     material); a light with a non-finite field is left out of the device arrays and the light counts until a setter repairs it (one warning on stderr);
  *   - a normal / tangent with a non-finite component is taken as +Z, a non-finite texture coordinate as 0, a non-finite bitangent sign as +1;
- *   - giCRender refuses (GI_C_ERROR, giCGetLastError names the field): a camera with a non-finite field, a forward / up vector that cannot be normalised, a vertical
+ *   - giCRender refuses (GI_C_ERROR, giCGetLastError names the field): a camera or dome light with a non-finite field, a forward / up vector that cannot be normalised, a vertical
  *     field of view outside (0, pi); non-finite float render settings (maxSampleValue may be +inf: no clamp); spp 0; mediumStackSize > 15; images beyond 65 535
  *     pixels a side (imageDims is packed 16 + 16 bits, rp_main.h:25-56).  A 0 x N image is a no-op (GI_C_OK).  spp x pixels may exceed 2^32: the frame is cut
  *     into batches of fewer than 2^32 work items.

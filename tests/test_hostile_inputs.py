@@ -429,3 +429,46 @@ def test_more_than_2_pow_32_samples_in_one_call(gi, orc):
         assert np.array_equal(img[rows].view(np.uint32), ref.view(np.uint32))
     finally:
         sc.close()
+
+
+@pytest.mark.gpu
+def test_unusable_lights_and_materials(gi, orc):
+    """A light with a NaN / inf field is ignored (the image is the oracle's of the scene without it) and comes back when a setter repairs it; a material with a
+    non-finite parameter is refused at creation; a dome light with a NaN rotation is refused at render time."""
+    import ctypes as C
+    from gatling_amd.scene import DistantLight, DomeLight, SphereLight
+    desc = random_triangle_soup(3000, seed=12)
+    good = SphereLight(pos=(0.5, -2.0, 1.0), base_emission=(30, 25, 20), radius=(0.2, 0.2, 0.2))
+    rs = RenderSettings(spp=3, max_bounces=4, next_event_estimation=True, progressive_accumulation=False)
+    clean = copy.deepcopy(desc); clean.sphere_lights = [good]
+    ref, cnt = orc.render(clean, rs, 80, 45, threads=4)
+    bad = copy.deepcopy(desc)
+    bad.sphere_lights = [SphereLight(pos=(float("nan"), 0, 0), base_emission=(5, 5, 5)), good, SphereLight(pos=(0, 0, 2), base_emission=(float("inf"), 1, 1))]
+    bad.distant_lights = [DistantLight(direction=(0, float("nan"), -1), base_emission=(1, 1, 1))]
+    bad.rect_lights = list(desc.rect_lights) + [RectLight(origin=(0, 0, 2), base_emission=(1, 1, 1), width=float("inf"))]
+    sc = gi.Scene(bad)
+    try:
+        img = sc.render(rs, 80, 45); st = sc.stats()
+        assert np.isfinite(img).all() and np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+        assert st["segments"] == cnt["segments"] and st["shadowRays"] == cnt["shadow_rays"]
+        # the first sphere light repaired: now two usable sphere lights
+        kind, h = sc.lights[0]
+        assert kind == "sphere"
+        sc.L.giCSetSphereLightPosition(h, capi._fp((0.0, 0.0, 2.0)))
+        img2 = sc.render(rs, 80, 45)
+        two = copy.deepcopy(desc); two.sphere_lights = [SphereLight(pos=(0.0, 0.0, 2.0), base_emission=(5, 5, 5)), good]
+        ref2, _ = orc.render(two, rs, 80, 45, threads=4)
+        assert np.array_equal(img2.view(np.uint32), ref2.view(np.uint32))
+    finally:
+        sc.close()
+    nanmat = copy.deepcopy(desc); nanmat.materials[0].params[3] = np.nan
+    with pytest.raises(capi.GiError, match="not finite"):
+        gi.Scene(nanmat)
+    dome = copy.deepcopy(desc); dome.textures = [np.full((4, 8, 4), 0.5, np.float32)]
+    dome.dome_light = DomeLight(texture=0, rotation=(0.0, float("nan"), 0.0, 1.0))
+    sc = gi.Scene(dome)
+    try:
+        with pytest.raises(capi.GiError, match="dome light"):
+            sc.render(rs, 32, 18)
+    finally:
+        sc.close()
