@@ -48,10 +48,8 @@ inline void xformPoint(const float a[12], const float p[3], float out[3])
 
 // Shade class of a material (gi_types.h MAT_CLASS_COUNT): its BSDF class, or -- the reference's per-material feature #defines done the wavefront way,
 // GlslShaderGen.cpp:204-274, Gi.cpp:1545-1562 -- the specialised variant its hits are binned and shaded by. OpenPBR BASE: every optional lobe absent (no coat,
-// fuzz,
-// thin film, anisotropy, transmission, subsurface, not thin-walled), no bound texture / primvar input, every parameter finite (the variant drops products with
-// exact
-// zeros, which a NaN or an infinity would not honour).  GATLING_OPTIONS=shade_variants=0 keeps every material in its full kernel (tests: same bits).
+// fuzz, thin film, anisotropy, transmission, subsurface, not thin-walled), no bound texture / primvar input, every parameter finite (the variant drops products
+// with exact zeros, which a NaN or an infinity would not honour). GATLING_OPTIONS=shade_variants=0 keeps every material in its full kernel (tests: same bits).
 uint32_t shadeClassOf(const MaterialRec& m)
 {
   if (m.klass != GI_C_MAT_OPEN_PBR || optionValue("shade_variants", 1) == 0) return m.klass & 0xfu;
@@ -65,8 +63,7 @@ uint32_t shadeClassOf(const MaterialRec& m)
 // Hostile geometry (bvh8.h "Inactive items").  A coordinate the build works with: finite, at most 1e18 in magnitude.
 inline bool usableCoordinate(float x) { return std::fabs(x) <= 1.0e18f; } // (false for NaN)
 // An instance the flattening can use: every entry of its affine finite and its 3x3 invertible with an inverse that is finite in fp32 (w2o transforms normals
-// and,
-// in the two-level layout, rays).  Every triangle of an instance that is not -- a NaN or singular giCSetMeshTransform / instance transform -- is inactive.
+// and, in the two-level layout, rays). Every triangle of an instance that is not -- a NaN or singular giCSetMeshTransform / instance transform -- is inactive.
 inline bool usableInstance(const InstanceRec& ir)
 {
   for (int i = 0; i < 12; i++) if (!std::isfinite(ir.o2w[i])) return false;
@@ -74,10 +71,8 @@ inline bool usableInstance(const InstanceRec& ir)
   return true;
 }
 // Shading attributes of a vertex as the scene build takes them: a normal or tangent with a non-finite component becomes +Z, a non-finite texture coordinate 0,
-// a
-// non-finite bitangent sign +1 (the position is left alone: it decides whether the triangle is active). The reference uploads what it is given (Gi.cpp:848-861)
-// and
-// a NaN attribute is a NaN pixel there; here hostile attributes cost the shading of the faces that use them, nothing else.
+// a non-finite bitangent sign +1 (the position is left alone: it decides whether the triangle is active). The reference uploads what it is given
+// (Gi.cpp:848-861) and a NaN attribute is a NaN pixel there; here hostile attributes cost the shading of the faces that use them, nothing else.
 inline GiCVertex usableShadingAttributes(const GiCVertex& in)
 {
   GiCVertex v = in;
@@ -113,13 +108,12 @@ int buildTwoLevel(GiCScene* s, const std::vector<MB>& meshBuilds, const std::vec
   for (const MB& mb : meshBuilds) uniqueTris += mb.instCount ? mb.m->faces.size() : 0;
   const bool beyondLds = flatNodes > 384u || flatTris > 128u;
   (void)uniqueTris;
-  // Opt-in only.  Measured (r01k): although its working set is tiny (C4: 1.5 MB of BLAS nodes + 2.6 MB of mesh triangles instead of
-  // 41 + 335 MB) the first version is SLOWER than the flat layout -- C4 trace 185 -> 207 ms, C5 834 -> 1945 ms (29 instead of 20 nodes
-  // per ray: overlapping instance boxes, each visit pays a ray transform, a BLAS root and a restore; candidates cost a rebuild).
-  // ... except where the flat traversal cannot address the scene: its wave-cooperative triangle ring packs (lane, flat triangle) into 32 bits, 2^26 triangles;
-  // the
-  // two-level walk queues MESH triangles there (one BLAS per mesh), so heavily instanced scenes beyond that bound take it automatically (r04; the hit record's
-  // triangle word, flat index | class << 28, then bounds the scene at 2^28 flattened triangles)
+  // Opt-in only. Measured (r01k): although its working set is tiny (C4: 1.5 MB of BLAS nodes + 2.6 MB of mesh triangles instead of 41 + 335 MB) the first
+  // version is SLOWER than the flat layout -- C4 trace 185 -> 207 ms, C5 834 -> 1945 ms (29 instead of 20 nodes per ray: overlapping instance boxes, each visit
+  // pays a ray transform, a BLAS root and a restore; candidates cost a rebuild). ... except where the flat traversal cannot address the scene: its
+  // wave-cooperative triangle ring packs (lane, flat triangle) into 32 bits, 2^26 triangles; the two-level walk queues MESH triangles there (one BLAS per
+  // mesh), so heavily instanced scenes beyond that bound take it automatically (r04; the hit record's triangle word, flat index | class << 28, then bounds the
+  // scene at 2^28 flattened triangles)
   if (flatTris >= ((size_t)1 << 26) && want < 0) want = 1;
   // (the flat walk addresses nodes by 32-bit byte offset, gi_traversal.h node_load: 53 M nodes -- beyond any 2^26-triangle tree)
   if (flatNodes * sizeof(Node8) >= ((size_t)1 << 32) && want < 0) want = 1;
@@ -168,10 +162,8 @@ int buildTwoLevel(GiCScene* s, const std::vector<MB>& meshBuilds, const std::vec
       tv.blasRoot = nodeBase; tv.triBase = mb.triFirst + ii * (uint32_t)nf; tv.matFlags = mb.matFlags; tv.slack = extent;
       float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
       // inactive triangles (bvh8.h): a face with an unusable OBJECT-space vertex is left out of the BLAS by the builder and out of this box; an unusable
-      // instance
-      // keeps the inverted box (the builder leaves it out of the TLAS). A usable face whose WORLD-space vertex is unusable is inactive in the flat tree but
-      // would
-      // be walked here: such scenes keep the flat layout
+      // instance keeps the inverted box (the builder leaves it out of the TLAS). A usable face whose WORLD-space vertex is unusable is inactive in the flat
+      // tree but would be walked here: such scenes keep the flat layout
       if (usableInstance(instances[inst]))
         for (size_t f = 0; f < nf; f++) {
           bool objectOk = true, worldOk = true; float q[3][3];
@@ -254,8 +246,7 @@ uint32_t sceneDeviceCount(const GiCScene* s)
 SceneDevice& sceneDevice(GiCScene* s, uint32_t slot) { return slot == 0u ? static_cast<SceneDevice&>(*s) : *s->replicas[slot - 1u]; }
 
 // The flat tree's root bounds for FLAG_BOUNDS_RETIRE: the dequantised child boxes of node 0 (which contain every triangle's padded box), padded once more by
-// 1e-5 of
-// their magnitude and extent -- k_raygen's slab test adds its own per-ray rounding allowance on top.
+// 1e-5 of their magnitude and extent -- k_raygen's slab test adds its own per-ray rounding allowance on top.
 static void setSceneBounds(GiCScene* s, const std::vector<Node8>& nodes)
 {
   s->boundsValid = false;

@@ -1,6 +1,5 @@
 // gi_c.cpp -- global state, initialisation, host-side arithmetic helpers, render buffers, scene options and statistics. Implements include/gi_c.h together with
-// the files below.
-// (one of the translation units gi_c.cpp was split into in round 6; shared declarations: gi_host.h)
+// the files below. (one of the translation units gi_c.cpp was split into in round 6; shared declarations: gi_host.h)
 #include "gi_host.h"
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -212,8 +211,7 @@ static int initDevices(const std::vector<int>& ordinals)
     devs.push_back(c);
   }
   // the row shares travel to the primary device over xGMI: peer access both ways. The outcome is kept (giCGetDevicePeerAccess) and decides how a device's share
-  // is
-  // gathered: without peer access a hipMemcpyDefault between two devices silently stages through pageable host memory -- the library then does it itself,
+  // is gathered: without peer access a hipMemcpyDefault between two devices silently stages through pageable host memory -- the library then does it itself,
   // through a pinned buffer
   for (size_t i = 1; i < devs.size(); i++) {
     if (devs[i].device == devs[0].device) continue; // another context on the same GPU (tests): its memory is directly addressable

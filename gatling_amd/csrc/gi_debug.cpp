@@ -219,8 +219,7 @@ extern "C" int giCDebugEvalBsdf(const GiCMaterialDesc* desc, uint32_t count, con
 
 // ---------------------------------------------------------------------------------------------------------------
 // giCDebugTexRuntime: the MDL renderer runtime's remaining texture entry points (tex_texel_float4_2d, tex_resolution_2d, tex_lookup_float4_3d,
-// tex_texel_float4_3d)
-// on the device, for explicit queries
+// tex_texel_float4_3d) on the device, for explicit queries
 // ---------------------------------------------------------------------------------------------------------------
 extern "C" int giCDebugTexRuntime(const float* rgba, uint32_t width, uint32_t height, uint32_t depth, uint32_t count, const float* queries, float* out)
 {

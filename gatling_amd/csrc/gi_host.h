@@ -289,8 +289,8 @@ struct GiCScene : SceneDevice {
   int32_t optFusedPath = -1;
   int32_t optTraceDyn = -1; // -1 = default; 0 = block-synchronous k_trace everywhere; N = k_trace_dyn refill threshold
   // Visiting order of shadow walks (k_trace_dyn<any>; any order gives the same image): -1 = not chosen yet -- launches alternate between near-to-far (0) and
-  // slot order
-  // (1) and the frame's node-visit counts are added up below; once both orders have walked enough rays the cheaper one is kept until the tree is rebuilt.
+  // slot order (1) and the frame's node-visit counts are added up below; once both orders have walked enough rays the cheaper one is kept until the tree is
+  // rebuilt.
   std::atomic<int32_t> shadowOrder{-1};
       /* read by every device worker at the start of its render, written by the primary at the end of its own */ uint64_t shadowOrderRays[2] = {0, 0},
       shadowOrderSteps[2] = {0, 0};
@@ -303,8 +303,7 @@ struct GiCScene : SceneDevice {
 // ---------------------------------------------------------------------------------------------------------------
 // functions the translation units share
 // ---------------------------------------------------------------------------------------------------------------
-// gi_textures.cpp
-// asset reader -> loader hook -> in-library decoders
+// gi_textures.cpp asset reader -> loader hook -> in-library decoders
 extern "C++" bool loadImage(const char* path, bool srgbToLinear, bool keepHdr, uint32_t& w, uint32_t& h, std::vector<float>& px);
 // gi_lights.cpp
 int uploadLights(GiCScene* s);

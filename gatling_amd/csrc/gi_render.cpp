@@ -30,15 +30,13 @@ uint32_t traceDynRefill(const GiCScene* s)
 
 uint32_t shardCapacity(size_t slots, uint32_t gridA, uint32_t gridB)
 {
-  // A queue holds at most `slots` records in total (a path sits in one queue at a time), but it is fed by SEVERAL launches before it is
-  // consumed -- TRACE[par] by k_raygen and one k_shade per material class, REGEN by k_trace / k_route, every k_shade and k_raygen
-  // (maxBounces == 0) -- and every launch starts dealing its blocks at shard 0.  A launch of G blocks that appends n records gives one
-  // shard at most ceil(G/NSHARD) * ceil(n/(256 G)) * 256 <= n/NSHARD + n/G + 32 G + 256 of them; summed over P producers with
-  // sum(n) <= slots this is slots/NSHARD + P * (slots/Gmin + 32 Gmax + 256).  block_append also raises Counters::overflow if a shard
-  // ever runs past its capacity (giCRender then fails instead of returning a corrupt image).
-  // (a producer that appends I records per thread and trip -- k_route: ROUTE_ITEMS, k_raygen: RAYGEN_ITEMS, gi_kernels.h APPEND_ITEMS_MAX -- deals 256 * I
-  // records per
-  // block and trip: the slack term is 32 * I * G + 256 * I)
+  // A queue holds at most `slots` records in total (a path sits in one queue at a time), but it is fed by SEVERAL launches before it is consumed -- TRACE[par]
+  // by k_raygen and one k_shade per material class, REGEN by k_trace / k_route, every k_shade and k_raygen (maxBounces == 0) -- and every launch starts dealing
+  // its blocks at shard 0. A launch of G blocks that appends n records gives one shard at most ceil(G/NSHARD) * ceil(n/(256 G)) * 256 <= n/NSHARD + n/G + 32 G
+  // + 256 of them; summed over P producers with sum(n) <= slots this is slots/NSHARD + P * (slots/Gmin + 32 Gmax + 256). block_append also raises
+  // Counters::overflow if a shard ever runs past its capacity (giCRender then fails instead of returning a corrupt image). (a producer that appends I records
+  // per thread and trip -- k_route: ROUTE_ITEMS, k_raygen: RAYGEN_ITEMS, gi_kernels.h APPEND_ITEMS_MAX -- deals 256 * I records per block and trip: the slack
+  // term is 32 * I * G + 256 * I)
   const size_t P = 2 + MAT_CLASS_COUNT, I = APPEND_ITEMS_MAX;
   const size_t gMin = std::max<size_t>(1, std::min(gridA, gridB)), gMax = std::max<size_t>(1, std::max(gridA, gridB));
   const size_t cap = (slots + NSHARD - 1) / NSHARD + P * ((slots + gMin - 1) / gMin + 32 * I * gMax + 256 * I);
@@ -244,14 +242,11 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
     // work counter until the batch's items run out.
     auto envU64 = [](const char* key, uint64_t def) { return optionSet(key) ? (uint64_t)optionValue(key, 0) : def; };
     // Memory plan (r04). The per-sample colour buffer wants to hold the whole frame's samples (every batch ends in a drain / a kernel tail: C2's 34 GB for 1024
-    // spp at
-    // 1080p in one batch 213.4 ms per step, in four 215.5) and scenes beyond LDS want a 64 Mi-slot pool (17 GB with its queues) -- on an empty 288 GB device.
-    // A Hydra
-    // plugin shares the device with other scenes, other processes and the host application, so the plan starts from what is FREE now (plus what this scene
-    // already
-    // holds in these buffers, which is reused), and an allocation that still fails (someone else was faster) is answered with a smaller plan -- more batches
-    // first,
-    // then a smaller pool -- never with a failed render while a workable plan exists.  Results do not depend on the plan (test_pool_and_batch_invariance).
+    // spp at 1080p in one batch 213.4 ms per step, in four 215.5) and scenes beyond LDS want a 64 Mi-slot pool (17 GB with its queues) -- on an empty 288 GB
+    // device. A Hydra plugin shares the device with other scenes, other processes and the host application, so the plan starts from what is FREE now (plus what
+    // this scene already holds in these buffers, which is reused), and an allocation that still fails (someone else was faster) is answered with a smaller plan
+    // -- more batches first, then a smaller pool -- never with a failed render while a workable plan exists. Results do not depend on the plan
+    // (test_pool_and_batch_invariance).
     size_t memFree = 0, memTotal = 0; (void)hipMemGetInfo(&memFree, &memTotal);
     // tests: plan as if this much were free (a planner overtaken by another allocation: the fallback below must recover)
     if (optionSet("assume_free_mb")) memFree = (size_t)optionValue("assume_free_mb", 0) << 20;
@@ -298,8 +293,7 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
     };
     sizeGrids();
     // HIT-queue entries (and giCTraceRays) hold a TRACE-queue RECORD index in 30 bits (HIT_INDEX_MASK); records run up to shardCapacity * NSHARD, which exceeds
-    // the
-    // slot count by the shards' slack -- a pinned pool near 2^30 would push indices past the mask and k_shade would gather the wrong record
+    // the slot count by the shards' slack -- a pinned pool near 2^30 would push indices past the mask and k_shade would gather the wrong record
     while (!fused && (uint64_t)shardCapacity(slots, wideBlocks, traceBlocks) * NSHARD > 0x3fffffffull /* HIT_INDEX_MASK, gi_queues.h */) { slots -= slots / 8;
         sizeGrids(); }
     const uint32_t mediaStride = rs.mediumStackSize ? rs.mediumStackSize * MEDIUM_FLOATS + 4u : 0u;
@@ -351,8 +345,7 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
     }
     view.mediumStackSize = rs.mediumStackSize;
     // Deferred Slot initialisation (r04): k_raygen hands a camera ray its (rng, work item) beside the ray record instead of writing the path's 64-byte Slot;
-    // the
-    // slot is written where the first segment hits (k_route / k_trace) and a camera ray that leaves the scene retires there without ever touching one.  The
+    // the slot is written where the first segment hits (k_route / k_trace) and a camera ray that leaves the scene retires there without ever touching one. The
     // debug AOVs that follow whole paths read the slot when a sample retires (NEE / Bounces / ClockCycles): renders that bind them keep the eager form.
     if (!fused && optionValue("defer_slot", 1) != 0 && !ps.neeKey && !ps.bouncesAov && !ps.pathSegments) U.flags |= FLAG_DEFER_SLOT;
     QueueSet qs = makeQueueSet(&D);
@@ -362,11 +355,9 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
     // (GATLING_OPTIONS=shadow_order=0|1 pins it)
     const int32_t shadowOrderNow = optionSet("shadow_order") ? (int32_t)optionValue("shadow_order", -1) : s->shadowOrder.load();
     // Bounds retire (r04n): on the k_trace_dyn path a deferred-slot camera ray that cannot reach the scene's bounds is retired by k_raygen itself (C4: 58 % of
-    // the
-    // camera rays, C3: ~45 %) -- same sample, same segment count, no ray record, no traversal step, no routing. Not with a dome image / medium stack (a miss
-    // needs
-    // the slot), not in counting builds (the root visit of such a ray is part of nodes-per-ray), not on the two-level layout (bounds of the TLAS root: not
-    // kept).
+    // the camera rays, C3: ~45 %) -- same sample, same segment count, no ray record, no traversal step, no routing. Not with a dome image / medium stack (a
+    // miss needs the slot), not in counting builds (the root visit of such a ray is part of nodes-per-ray), not on the two-level layout (bounds of the TLAS
+    // root: not kept).
     {
       SceneView v0 = view; uint32_t ln, lt, ldsBytes; traceLdsLayout(v0, ln, lt, ldsBytes);
       const bool allLds = ln == v0.nodeCount && lt == v0.triCount && v0.triCount > 0u;
@@ -392,23 +383,16 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
     };
     auto timed = [&](int kind, auto&& fn) { timedOn(st, kind, fn); };
     // Two streams (the reference's default frame is ONE sample per pixel, renderDelegate.cpp:93-110). In a batch
-    // whose work fits the
-    // pool every path starts in iteration 0, so from iteration 1 on k_raygen only FINISHES samples and the closest-hit launch of iteration i + 1 needs nothing
-    // from the
-    // shadow launch of iteration i -- which k_raygen(i + 1) (it reads the radiance of paths that ended) and k_shade(i + 1) (it goes on adding to it: the float
-    // order of
-    // rp_main.rgen:397-480) do need.  Such batches run
+    // whose work fits the pool every path starts in iteration 0, so from iteration 1 on k_raygen only FINISHES samples and the closest-hit launch of iteration
+    // i + 1 needs nothing from the shadow launch of iteration i -- which k_raygen(i + 1) (it reads the radiance of paths that ended) and k_shade(i + 1) (it
+    // goes on adding to it: the float order of rp_main.rgen:397-480) do need. Such batches run
     //     main stream:    Z(i)  [R(0)]  T(i) + route(i)   <wait for Sh(i-1)>   [R(i), i > 0]   S(i)
     //     second stream:                                  <wait for S(i)>  Sh(i)
     // so that Sh(i) runs beside T(i + 1): an iteration lasts max(trace, shadow) + raygen + shade instead of their sum. Per-path arithmetic and per-pixel sample
-    // order are
-    // untouched (same kernels, same records); what changes is who zeroes which queue counter (gi_queues.h zero_next_counters / zero_closest_counters: Z =
-    // k_zero_closest).
-    // Not with a dome image (a miss adds the dome's radiance to the Slot in k_route while the previous bounce's shadow launch may still be adding to it: two
-    // float
-    // additions in an order that would depend on timing) or a medium stack. GATLING_OPTIONS=two_stream=0 switches it off; two_stream_delay=1|2 (tests) holds
-    // the
-    // main | the second stream back for 0.3 ms per iteration so that the other one runs ahead.
+    // order are untouched (same kernels, same records); what changes is who zeroes which queue counter (gi_queues.h zero_next_counters / zero_closest_counters:
+    // Z = k_zero_closest). Not with a dome image (a miss adds the dome's radiance to the Slot in k_route while the previous bounce's shadow launch may still be
+    // adding to it: two float additions in an order that would depend on timing) or a medium stack. GATLING_OPTIONS=two_stream=0 switches it off;
+    // two_stream_delay=1|2 (tests) holds the main | the second stream back for 0.3 ms per iteration so that the other one runs ahead.
     const bool twoStreamOk = nee && rs.mediumStackSize == 0u && view.domeTexture == 0u && optionValue("two_stream", 1) != 0 && ctx.stream2 != nullptr;
     const long twoStreamDelay = optionValue("two_stream_delay", 0);
     hipStream_t st2 = ctx.stream2;
@@ -433,10 +417,9 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
         curIter = totalIters; if (timers) sampledIters++;
         if (timers) { (void)hipEventRecord(poolEvent(&D, ev), st); }
         // which fused kernel: k_path (one path per lane, in registers) unless the wave-local wavefront k_path_bw is asked for (GI_C_SCENE_OPTION_FUSED_PATH = 1
-        // / GATLING_OPTIONS=path_bw=1). Measured
-        // r03 on C2 (1080p, spp 256, SLP vectorisation off): k_path 55.4 ms per batch, k_path_bw 57.3 -- k_path's 114 VGPRs give 4 resident waves per SIMD (3
-        // blocks
-        // per CU cost 11 %), k_path_bw's 168 VGPRs and 50 KB of LDS per block give 3; at 128 VGPRs k_path_bw spills 43 registers and falls to 84 ms.
+        // / GATLING_OPTIONS=path_bw=1). Measured r03 on C2 (1080p, spp 256, SLP vectorisation off): k_path 55.4 ms per batch, k_path_bw 57.3 -- k_path's 114
+        // VGPRs give 4 resident waves per SIMD (3 blocks per CU cost 11 %), k_path_bw's 168 VGPRs and 50 KB of LDS per block give 3; at 128 VGPRs k_path_bw
+        // spills 43 registers and falls to 84 ms.
         const int envBw = (int)optionValue("path_bw", -1);
         const bool useBw = !nee && (envBw >= 0 ? envBw != 0 : s->optFusedPath == 1);
         if (useBw) launchPathBw(st, (uint32_t)ctx.cuCount, s->classMask, s->classTextured != 0u, s->countTraversal, chunk, U, view, ps, D.dCounters.ptr,
@@ -471,18 +454,14 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
         // (the last k_raygen of the batch: the test below ends the loop)
         else if (rounds == 1 && it == (uint64_t)std::max(1u, U.maxBounces)) raygenBehindShadow();
         // A batch whose work fits the pool (a low-spp frame: hdGatling renders ONE sample per pixel and call) starts every path in iteration 0, a path traces
-        // at most
-        // maxBounces segments, one per iteration (the bounce counter, rp_main.rgen:298-304) -- so k_raygen(maxBounces) has just retired the last samples and
-        // nothing is in
-        // flight: no need to find that out two empty iterations later through the poll below (10 launches of ~90 in a spp-1 call).
+        // at most maxBounces segments, one per iteration (the bounce counter, rp_main.rgen:298-304) -- so k_raygen(maxBounces) has just retired the last
+        // samples and nothing is in flight: no need to find that out two empty iterations later through the poll below (10 launches of ~90 in a spp-1 call).
         if (rounds == 1 && it == (uint64_t)std::max(1u, U.maxBounces) && rs.mediumStackSize == 0u) { totalIters++; break; }
         if (it >= rounds) {
           // All work cannot be handed out earlier. From here on every iteration snapshots the queue sizes behind its k_raygen (asynchronous copy into a pinned
-          // ring)
-          // and tests the snapshot of POLL_LAG iterations ago: the wait is for work the GPU finished long ago -- it still holds the iterations in between, so
-          // the
-          // stream never runs dry -- and the loop stops at most POLL_LAG empty iterations after the pool drained.  (Until r03 the loop synchronised every 16th
-          // iteration: C4 ran 15 empty iterations of 0.2 ms each, `tools/exp_iter_log.py`.)
+          // ring) and tests the snapshot of POLL_LAG iterations ago: the wait is for work the GPU finished long ago -- it still holds the iterations in
+          // between, so the stream never runs dry -- and the loop stops at most POLL_LAG empty iterations after the pool drained. (Until r03 the loop
+          // synchronised every 16th iteration: C4 ran 15 empty iterations of 0.2 ms each, `tools/exp_iter_log.py`.)
           constexpr uint32_t R = SceneDevice::POLL_RING, LAG = SceneDevice::POLL_LAG;
           constexpr size_t snapshot = (size_t)Q_COUNT * NSHARD;
           HIP_TRY(hipMemcpyAsync(D.hPoll + (it % R) * snapshot, D.dCounters.ptr, sizeof(PaddedCounter) * snapshot, hipMemcpyDeviceToHost, st));
@@ -492,8 +471,7 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
             HIP_TRY(hipEventSynchronize(D.pollEvent[j % R]));
             const PaddedCounter* snap = D.hPoll + (j % R) * snapshot + (size_t)(Q_TRACE_A + (uint32_t)(j & 1u)) * NSHARD;
             // (FLAG_BOUNDS_RETIRE: a k_raygen whose camera rays all miss the scene's bounds queues no ray either, but hands its slots on -- REGEN[(j&1)^1],
-            // zero at
-            // this point otherwise -- and work is left)
+            // zero at this point otherwise -- and work is left)
             const PaddedCounter* again = D.hPoll + (j % R) * snapshot + (size_t)(Q_REGEN_A + (uint32_t)((j & 1u) ^ 1u)) * NSHARD;
             uint32_t pending = 0; for (uint32_t k = 0; k < NSHARD; k++) pending += snap[k].v + again[k].v;
             if (pending == 0) { totalIters++; break; } // k_raygen(j) consumed the regen queue and produced no rays: the pool had drained
@@ -514,9 +492,7 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
               D.dCounters.ptr, par); });
         if (nee) {
           // (the slot-order flag belongs to k_trace_dyn: with dynamic refill off -- TRACE_DYNAMIC 0 -- dynRefill stays 0 so that launchTrace picks the
-          // block-synchronous
-          // k_trace the grid was sized for, and there is no order to measure)
-          // not chosen yet: alternate, and count (below)
+          // block-synchronous k_trace the grid was sized for, and there is no order to measure) not chosen yet: alternate, and count (below)
           const int32_t order = (dynRefill & 0xffu) == 0u ? 0 : (shadowOrderNow >= 0 ? shadowOrderNow : (int32_t)(totalIters & 1u));
           hipStream_t on = st;
           if (two) { // the shadow launch moves to the second stream, behind this iteration's k_shade

@@ -70,8 +70,8 @@ extern "C++" bool loadImage(const char* path, bool srgbToLinear, bool keepHdr, u
   if (bytes && loader.load && loader.load(loader.user, path, bytes, (uint64_t)size, keepHdr ? 1 : 0, &img) == 1) {
     const size_t n = (size_t)img.width * img.height;
     // (a hook's answer is untrusted: a bogus width x height must not become a bad_alloc that leaves through the extern "C" callers, and release / close run
-    // whatever
-    // happens -- ADVICE r05.  2^28 texels = 4 GiB of fp32 RGBA is the cap; the reference's largest texture is bounded by maxImageDimension2D, 16 384^2 = 2^28)
+    // whatever happens -- ADVICE r05. 2^28 texels = 4 GiB of fp32 RGBA is the cap; the reference's largest texture is bounded by maxImageDimension2D, 16 384^2
+    // = 2^28)
     if (img.pixels && n > 0 && n <= ((size_t)1 << 28) && img.format >= GI_C_IMAGE_RGBA8_UNORM && img.format <= GI_C_IMAGE_RGBA32_FLOAT) try {
       w = img.width; h = img.height; px.assign(n * 4, 1.0f);
       for (size_t i = 0; i < n; i++) {
