@@ -19,10 +19,14 @@ def load(path):
         j = json.loads(text)
     except json.JSONDecodeError:
         j = json.loads(text.strip().splitlines()[-1])
+    if "run" in j:  # the driver's record: the full line is the last line of the run's stdout
+        try:
+            line = [l for l in j["run"]["stdout_tail"].splitlines() if l.startswith('{"metric"')][-1]  # (the tail also holds the run's stderr)
+            return json.loads(line), j.get("head", "?")
+        except Exception:  # noqa: BLE001
+            pass
     if "parsed" in j and isinstance(j["parsed"], dict) and "value" in j["parsed"]:
         return j["parsed"], j.get("head", "?")
-    if "run" in j:
-        return json.loads(j["run"]["stdout_tail"].strip().splitlines()[-1]), j.get("head", "?")
     return j, "?"
 
 
