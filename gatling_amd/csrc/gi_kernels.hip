@@ -327,6 +327,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(SceneView sc, PathState s
       // sort by outcome and material class: hits go to their class's shade queue as (slot, hit, direction) records, misses
       // straight to k_raygen
       uint32_t klass = (mat >> 24) & 0xfu;
+      if (klass == SHADE_CLASS_OPBR_BASE && (U.flags & FLAG_MERGE_SHADE_VARIANTS)) klass = 2u; // thin batches: one OpenPBR launch (same bits: gi_shading.h "BASE variant")
       bool retired = false, freshHit = false;
       if (fresh) { // first segment of a path k_raygen did not write: k_shade begins it (hit), or it is begun / retired here (miss)
         const FreshRec f = qs.fresh[qIn - Q_TRACE_A][r];
@@ -695,6 +696,7 @@ __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, Que
         // the direction is needed at a miss by the dome lookup only (hits stay in place: k_shade gathers them)
         if (miss && sc.domeTexture != 0u) rdir[k] = ld4(&qs.b[qIn][r]);
         if (hit) klass = f2u(h[k].w) >> 28; // k_trace_dyn's result word: triangle index | material class << 28
+        if (klass == SHADE_CLASS_OPBR_BASE && (U.flags & FLAG_MERGE_SHADE_VARIANTS)) klass = 2u; // thin batches: one OpenPBR launch (same bits: gi_shading.h "BASE variant")
         if (fresh) { // k_shade begins the path (hit); a miss that needs the slot (dome image / medium stack) begins it here, any other retires the sample without a Slot
           if (hit) freshHit = true;
           else {

@@ -26,6 +26,7 @@
 //   shadow_order         -1        visiting order of shadow walks: -1 = measured per scene (gi_render.cpp shadowOrder), 0 = near-to-far, 1 = slot order
 //   peer_copies          1         multi-device gather: 0 = stage every device's row share through pinned host memory even where peer access exists
 //   shade_variants       1         OpenPBR materials without optional lobes are binned and shaded by the BASE variant of k_shade (gi_shading.h); 0 = the full kernel for all
+//   merge_shade_variants -1        -1 = thin batches (work fits the pool, <= 8 Mi items) bin BASE hits with the full OpenPBR class (one launch fewer per iteration); 0 / 1 = never / always
 //   two_stream           1         batches whose work fits the pool run their shadow launches on a second stream beside the next closest-hit launch (gi_render.cpp "two streams")
 //   two_stream_delay     0         tests: 1 / 2 = hold the main / the second stream back 0.3 ms per iteration so that the other one runs ahead
 //   phase_stats          0         counting builds: print k_path's phase split / k_trace_dyn's lane accounting

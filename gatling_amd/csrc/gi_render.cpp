@@ -440,6 +440,13 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
       }
       const uint64_t rounds = ((uint64_t)U.workTotal + poolNow - 1) / poolNow; // raygen rounds needed to hand out all work
       const uint64_t maxIters = (rounds + 2) * (std::max(1u, U.maxBounces) + 1) + 8;
+      // A thin batch (its work fits the pool and is small: the delegate's one sample per pixel and call) launches every kernel of an iteration for a few thousand hits:
+      // a further k_shade launch per iteration costs it more (C4: 13 x ~9 us of a 2.7 ms call) than the BASE variant saves, so its BASE hits are binned with class 2
+      // (GATLING_OPTIONS=merge_shade_variants=0 | 1: never | always)
+      const long mergeOpt = optionValue("merge_shade_variants", -1);
+      const bool thinBatch = rounds == 1 && U.workTotal <= (8u << 20);
+      if ((mergeOpt < 0 ? thinBatch : mergeOpt != 0) && (s->shadeClassMask & (1u << SHADE_CLASS_OPBR_BASE)) && (s->shadeClassMask & 4u)) U.flags |= FLAG_MERGE_SHADE_VARIANTS;
+      else U.flags &= ~FLAG_MERGE_SHADE_VARIANTS;
       const bool two = twoStreamOk && rounds == 1 && !iterLog;
       if (two) U.flags |= FLAG_TWO_STREAM; else U.flags &= ~FLAG_TWO_STREAM;
       bool shadowInFlight = false;
@@ -485,7 +492,8 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
         if (two && it > 0) raygenBehindShadow();
         // one launch per shade class in use (scattering events inside a medium are routed to class 2, k_route: it is launched whenever a medium stack exists
         // and OpenPBR does)
-        const uint32_t shadeMask = s->shadeClassMask | ((rs.mediumStackSize != 0u && (s->shadeClassMask & (1u << SHADE_CLASS_OPBR_BASE))) ? 4u : 0u);
+        uint32_t shadeMask = s->shadeClassMask | ((rs.mediumStackSize != 0u && (s->shadeClassMask & (1u << SHADE_CLASS_OPBR_BASE))) ? 4u : 0u);
+        if (U.flags & FLAG_MERGE_SHADE_VARIANTS) shadeMask = (shadeMask & ~(1u << SHADE_CLASS_OPBR_BASE)) | ((shadeMask >> SHADE_CLASS_OPBR_BASE) & 1u) << 2; // BASE hits sit in class 2's queue
         for (uint32_t klass = 0; klass < MAT_CLASS_COUNT; klass++)
           if (shadeMask & (1u << klass)) timed(2,
               [&] { launchShade(st, wideBlocks, klass, (s->shadeClassTextured & (1u << klass)) != 0u, rs.mediumStackSize != 0u, U, view, ps, qs,

@@ -156,6 +156,8 @@ enum : uint32_t {
                           // slot is written when the first segment HITS (k_route / k_trace); a camera ray that leaves the scene retires without ever touching a slot
   FLAG_TWO_STREAM = 512u, // the shadow walks of bounce i run on a second stream beside the closest-hit walks of bounce i + 1 (gi_render.cpp "two streams"): k_raygen runs AFTER
                           // the iteration's k_trace / k_route and zeroes only what k_shade and the shadow launch append to; k_zero_closest zeroes the rest before k_trace
+  FLAG_MERGE_SHADE_VARIANTS = 1024u, // k_route / k_trace bin the hits of a specialised shade class with its full class (a thin batch -- one sample per pixel and call --
+                                    // pays more for a further k_shade launch per iteration than the variant saves: gi_render.cpp)
   FLAG_BOUNDS_RETIRE = 256u, // with FLAG_DEFER_SLOT on the k_trace_dyn path: a camera ray whose slab interval against the scene bounds is empty is never queued --
                              // k_raygen retires its sample (the arithmetic of retire_fresh_miss) and hands the slot straight to the next k_raygen
 };

@@ -1512,8 +1512,8 @@ def test_shade_variants_are_bit_identical(gi, orc, monkeypatch, scene_kind):
         assert {2, 3} <= classes
     ref, cnt = orc.render(desc, rs, 96, 54, threads=4)
     imgs = []
-    for variants in (1, 0):
-        monkeypatch.setenv("GATLING_OPTIONS", f"shade_variants={variants}")
+    for mode in ("shade_variants=1,merge_shade_variants=0", "shade_variants=1,merge_shade_variants=1", "shade_variants=1", "shade_variants=0"):  # (the third: thin batch, merged by itself)
+        monkeypatch.setenv("GATLING_OPTIONS", mode)
         sc = gi.Scene(desc)
         try:
             for k, v in opts:
@@ -1523,7 +1523,7 @@ def test_shade_variants_are_bit_identical(gi, orc, monkeypatch, scene_kind):
             sc.close()
         assert st["segments"] == cnt["segments"] and st["shadowRays"] == cnt["shadow_rays"] and st["fusedPath"] == 0
         assert_image_parity(imgs[-1], ref, exact=True)
-    assert np.array_equal(imgs[0].view(np.uint32), imgs[1].view(np.uint32))
+    assert all(np.array_equal(imgs[0].view(np.uint32), im.view(np.uint32)) for im in imgs[1:])
 
 
 # ---------------------------------------------------------------------------------------------------------------
