@@ -36,17 +36,8 @@ GiCMaterial* giCCreateMaterial(GiCScene* scene, const char* name, const GiCMater
   for (uint32_t i = 0; i < MAT_PARAM_COUNT; i++)
     if (!std::isfinite(desc->p[i])) { setError("giCCreateMaterial: parameter " + std::to_string(i) + " of material '" + (name ? name : "") + "' is not finite"); return nullptr; }
   GiCMaterial* m = new GiCMaterial{scene, name ? name : "", *desc};
-  // subsurface_radius / subsurface_radius_scale joined the block in round 4 (slots 32..35, ignored before): a caller built against the older header leaves them
-  // 0, which would mean an extinction of 1e6 per scene unit. An all-zero radius AND scale reads as "unset": OpenPBR's defaults (open_pbr_surface.mtlx:47-49: 1;
-  // 1, 0.5, 0.25)
-  if (desc->klass == GI_C_MAT_OPEN_PBR) {
-    float* p = m->desc.p;
-    if (p[GI_C_P_SUBSURFACE_RADIUS] == 0.0f && p[GI_C_P_SUBSURFACE_RADIUS_SCALE] == 0.0f && p[GI_C_P_SUBSURFACE_RADIUS_SCALE + 1] == 0.0f
-        && p[GI_C_P_SUBSURFACE_RADIUS_SCALE + 2] == 0.0f) {
-      p[GI_C_P_SUBSURFACE_RADIUS] = 1.0f; p[GI_C_P_SUBSURFACE_RADIUS_SCALE] = 1.0f; p[GI_C_P_SUBSURFACE_RADIUS_SCALE + 1] = 0.5f;
-          p[GI_C_P_SUBSURFACE_RADIUS_SCALE + 2] = 0.25f;
-    }
-  }
+  // (subsurface_radius / subsurface_radius_scale, slots 32..35, are taken as given -- zeros included: the per-channel mean free path is clamped to 1e-6, as the oracle
+  // does.  Round 5 read an all-zero radius AND scale as "unset"; that guess belongs to the front ends, which set OpenPBR's defaults themselves: gtl_shim.cpp -- ADVICE r05)
   std::lock_guard<std::mutex> g(scene->mutex);
   scene->materials.push_back(m);
   scene->dirty |= DIRTY_MATERIALS | DIRTY_BVH | DIRTY_FRAMEBUFFER;

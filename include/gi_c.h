@@ -193,7 +193,8 @@ typedef struct GiCRenderParams {
 #define GI_C_P_SUBSURFACE_RADIUS 32       /* OpenPBR subsurface_radius (open_pbr_surface.mtlx:47, default 1): with _RADIUS_SCALE the per-channel mean free path of the volumetric
                                             subsurface_bsdf (:182-192) of materials that are not thin-walled; live in renders with a medium stack (mediumStackSize > 0) */
 #define GI_C_P_SUBSURFACE_RADIUS_SCALE 33 /* 3 floats, subsurface_radius_scale (:49, default 1, 0.5, 0.25).  Slots 32..35 are inputs of the USER block only: the device copy of a
-                                            material keeps derived constants at these indices (written after the inputs were read) */
+                                            material keeps derived constants at these indices (written after the inputs were read).  Taken as given: zeros are zeros (the mean free path is clamped to
+                                            1e-6 per channel); the OpenPBR defaults are the front ends' to set (gtl_shim.cpp does; API version 6) */
 #define GI_C_P_THIN_WALLED 54      /* OpenPBR geometry_thin_walled (:88) != 0: MDL thin_walled semantics (rp_main.chit:153-157, 188-189, 447) */
 
 /* Note: p[GI_C_P_OPACITY] is the cutout opacity (1 = opaque); a zero-filled block is a fully transparent material. */
@@ -344,8 +345,9 @@ void giCTerminate(void);
  * how an unmodified caller (hdGatling) gets every GPU of the node.  Renders that shard rows themselves (rowStride > 1 / a row range) stay on the primary. */
 int giCInitializeDevices(const int32_t* deviceOrdinals, uint32_t count);
 /* [ext] Version of this header's ABI: bumped whenever a struct grows or an entry point changes meaning (5: GiCRenderStats gained batches / poolSlots, GI_C_TEX_SLOT_COUNT 9,
- * the subsurface radius slots of GiCMaterialDesc, the asset-reader / image-loader hooks).  A caller compares giCGetApiVersion() with the GI_C_API_VERSION it was built with. */
-#define GI_C_API_VERSION 5u
+ * the subsurface radius slots of GiCMaterialDesc, the asset-reader / image-loader hooks; 6: GiCRenderStats.reserved0 became inactiveTriangleCount,
+ * giCDebugShadeClass, an all-zero subsurface radius is no longer read as "unset", the hostile-input rules above giCRender).  A caller compares giCGetApiVersion() with the GI_C_API_VERSION it was built with. */
+#define GI_C_API_VERSION 6u
 uint32_t giCGetApiVersion(void);
 uint32_t giCGetDeviceCount(void);
 /* [ext] can the primary device and device `index` of the list address each other's memory?  1 = yes (peer access enabled both ways, or the same physical device):
