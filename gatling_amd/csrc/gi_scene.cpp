@@ -94,6 +94,7 @@ void giCSetMeshTransform(GiCMesh* mesh, const float* mat4x4)
 
 void giCSetMeshInstanceTransforms(GiCMesh* mesh, uint32_t count, const float* transforms)
 {
+  try { // (a copy of the caller's array: an allocation failure must not cross the C ABI)
   if (!mesh || (count && !transforms)) return;
   std::vector<float> copy(transforms, transforms + (size_t)count * 16); // copy outside the lock, swap inside
   std::lock_guard<std::mutex> g(mesh->scene->mutex);
@@ -107,15 +108,18 @@ void giCSetMeshInstanceTransforms(GiCMesh* mesh, uint32_t count, const float* tr
     mesh->xformDirty = true; mesh->scene->dirty |= DIRTY_XFORM | DIRTY_FRAMEBUFFER;
   }
   else mesh->scene->dirty |= DIRTY_BVH | DIRTY_FRAMEBUFFER;
+  } catch (const std::exception& e) { setError(std::string("giCSetMeshInstanceTransforms: ") + e.what()); }
 }
 
 void giCSetMeshInstanceIds(GiCMesh* mesh, uint32_t count, const int32_t* ids)
 {
+  try { // (a copy of the caller's array: an allocation failure must not cross the C ABI)
   if (!mesh || (count && !ids)) return;
   std::vector<int32_t> copy(ids, ids + count);
   std::lock_guard<std::mutex> g(mesh->scene->mutex);
   mesh->instanceIds.swap(copy);
   mesh->scene->dirty |= DIRTY_BVH | DIRTY_FRAMEBUFFER;
+  } catch (const std::exception& e) { setError(std::string("giCSetMeshInstanceIds: ") + e.what()); }
 }
 
 void giCSetMeshMaterial(GiCMesh* mesh, GiCMaterial* mat)
