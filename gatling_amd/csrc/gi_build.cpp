@@ -404,7 +404,7 @@ int buildScene(GiCScene* s)
   if (bvh.tris.size() >= (1u << 28)) { setError("scene has 2^28 or more triangles after instancing: the hit record packs (triangle, material class) into 32 bits"); return GI_C_ERROR; }
   H.triFaceId.resize(bvh.tris.size());
   for (size_t i = 0; i < bvh.tris.size(); i++) H.triFaceId[i] = faceIdOf[bvh.tris[i].origId];
-  // Scenes beyond LDS: one 128-byte shading record per mesh triangle (gi_types.h TriShade); the flattened triangles name theirs in vi[0].  LDS-resident
+  // Scenes beyond LDS: one 160-byte shading record per mesh triangle (gi_types.h TriShade); the flattened triangles name theirs in vi[0].  LDS-resident
   // scenes keep vertex indices there: the fused kernels are VALU-bound and read the host-decoded FVertex records.
   H.shadePacked = bvh.nodes.size() > 384u || bvh.tris.size() > 128u;
   H.triShade.clear();
@@ -417,7 +417,7 @@ int buildScene(GiCScene* s)
         TriShade q{};
         for (int k = 0; k < 3; k++) {
           const GiCVertex v = usableShadingAttributes(m->vertices[f.v_i[k]]);
-          memcpy(q.p[k], v.pos, 12); q.n[k] = encodeDirection(v.norm); q.t[k] = encodeDirection(v.tangent);
+          memcpy(q.p[k], v.pos, 12); decodeDirection(encodeDirection(v.norm), q.n[k]); decodeDirection(encodeDirection(v.tangent), q.t[k]); // (Gi.cpp:848-861: quantised, then decoded once)
           q.uv[k][0] = v.u; q.uv[k][1] = v.v; q.bsign[k] = v.bitangentSign; q.vi[k] = mb.vertexOffset + f.v_i[k];
         }
         H.triShade.push_back(q);

@@ -63,7 +63,7 @@ __device__ __forceinline__ V3 xform_normal(const float* w, V3 n)
   return v3((n.x * w[0] + n.y * w[3]) + n.z * w[6], (n.x * w[1] + n.y * w[4]) + n.z * w[7], (n.x * w[2] + n.y * w[5]) + n.z * w[8]);
 }
 
-// PACKED: the three corners come from the mesh triangle's one-line TriShade record (normals / tangents decoded here) instead of three FVertex records.
+// PACKED: the three corners come from the mesh triangle's TriShade record (normals / tangents decoded on the host, as in FVertex) instead of three FVertex records.
 template <bool PACKED = false>
 __device__ __forceinline__ void setup_shading_state(const SceneView& sc, uint32_t triIdx, float hu, float hv, V3 rayDir, ShState& s)
 {
@@ -75,14 +75,14 @@ __device__ __forceinline__ void setup_shading_state(const SceneView& sc, uint32_
   const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2], r3 = ip[3], r4 = ip[4], r5 = ip[5];
   V3 pa, pb, pc, n0, n1, n2, t0, t1, t2; float sa, sb, scg, ua, ub, uc, va_, vb_, vc_;
   if (PACKED) {
-    const uint4* q = reinterpret_cast<const uint4*>(&sc.triShade[td.x]); // 7 x 16 bytes of one line
-    const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6];
+    const uint4* q = reinterpret_cast<const uint4*>(&sc.triShade[td.x]); // 10 x 16 bytes (two lines): positions, decoded normals and tangents, uv, signs, indices
+    const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7], q8 = q[8], q9 = q[9];
     pa = v3(u2f(q0.x), u2f(q0.y), u2f(q0.z)); pb = v3(u2f(q0.w), u2f(q1.x), u2f(q1.y)); pc = v3(u2f(q1.z), u2f(q1.w), u2f(q2.x));
-    n0 = gi_decode_direction(q2.y); n1 = gi_decode_direction(q2.z); n2 = gi_decode_direction(q2.w);
-    t0 = gi_decode_direction(q3.x); t1 = gi_decode_direction(q3.y); t2 = gi_decode_direction(q3.z);
-    ua = u2f(q3.w); va_ = u2f(q4.x); ub = u2f(q4.y); vb_ = u2f(q4.z); uc = u2f(q4.w); vc_ = u2f(q5.x);
-    sa = u2f(q5.y); sb = u2f(q5.z); scg = u2f(q5.w);
-    s.vi[0] = q6.x; s.vi[1] = q6.y; s.vi[2] = q6.z;
+    n0 = v3(u2f(q2.y), u2f(q2.z), u2f(q2.w)); n1 = v3(u2f(q3.x), u2f(q3.y), u2f(q3.z)); n2 = v3(u2f(q3.w), u2f(q4.x), u2f(q4.y)); // decoded on the host (gi_build.cpp)
+    t0 = v3(u2f(q4.z), u2f(q4.w), u2f(q5.x)); t1 = v3(u2f(q5.y), u2f(q5.z), u2f(q5.w)); t2 = v3(u2f(q6.x), u2f(q6.y), u2f(q6.z));
+    ua = u2f(q6.w); va_ = u2f(q7.x); ub = u2f(q7.y); vb_ = u2f(q7.z); uc = u2f(q7.w); vc_ = u2f(q8.x);
+    sa = u2f(q8.y); sb = u2f(q8.z); scg = u2f(q8.w);
+    s.vi[0] = q9.x; s.vi[1] = q9.y; s.vi[2] = q9.z;
   } else {
     const float4* va = reinterpret_cast<const float4*>(&sc.verts[td.x]);
     const float4* vb = reinterpret_cast<const float4*>(&sc.verts[td.y]);

@@ -49,19 +49,22 @@ struct FVertex {
 };
 static_assert(sizeof(FVertex) == 48, "FVertex must be 48 bytes");
 
-// Shading record of one MESH triangle, 128 bytes = one cache line (scenes beyond LDS, round 3).  The shade stage of the wavefront pipeline is bound by the
-// number of distinct lines a hit touches: three 48-byte vertices at arbitrary indices are 3 - 4.5 lines, this is one.  Normals and tangents
-// stay in the reference's octahedral unorm2x16 encoding (rp::FVertex, rp_main.h:58-64) and are decoded per hit with the operations the host runs per vertex
-// for FVertex (decode_direction, common.glsl:198-207), so both forms give the same bits.  Shared by all instances of the mesh; TriRec::vi[0] holds its index.
+// Shading record of one MESH triangle (scenes beyond LDS, round 3): three 48-byte vertices at arbitrary indices are 3 - 4.5 cache lines per hit, this record is
+// 160 bytes = two.  Until round 6 it was ONE 128-byte line with normals and tangents in the reference's octahedral unorm2x16 encoding (rp::FVertex, rp_main.h:58-64),
+// decoded per hit; now they are stored DECODED, as FVertex holds them -- decoded once on the host with the operations of decode_direction (common.glsl:198-207), so
+// both forms give the same bits -- because the shade stage is bound by its instruction count, not by its lines: six decodes were ~400
+// of the ~3 500 VALU instructions a wave of hits executes (two IEEE divisions, a square root and a third division each).  Shared by all instances of the mesh;
+// TriRec::vi[0] holds its index.
 struct TriShade {
   float p[3][3];       // object-space corner positions
-  uint32_t n[3], t[3]; // encoded normals / tangents of the corners
+  float n[3][3];       // decoded (unit) normals of the corners
+  float t[3][3];       // decoded tangents
   float uv[3][2];      // texture coordinates
   float bsign[3];      // bitangent signs
   uint32_t vi[3];      // absolute vertex indices (scene-data lookups by vertex)
-  uint32_t pad[5];
+  uint32_t pad;
 };
-static_assert(sizeof(TriShade) == 128, "TriShade must be one 128-byte line");
+static_assert(sizeof(TriShade) == 160, "TriShade is ten 16-byte pieces");
 
 // Replaces gl_ObjectToWorldEXT / gl_WorldToObjectEXT + BlasPayload (rp_main.h:118-123), 96 bytes
 struct InstanceRec {
