@@ -169,7 +169,7 @@ void SceneDevice::releaseAll()
   dTlasNodes.release(); dBlasNodes.release(); dTlasItems.release(); dFlatOfOrig.release(); dBlasTris.release(); dInstTrav.release();
   for (auto* b : dTexels) { b->release(); delete b; }
   dTexels.clear(); dTextures.release(); dMeshes.release(); dSceneData.release();
-  dMaterials.release(); dSphere.release(); dDistant.release(); dRect.release(); dDisk.release();
+  dMaterials.release(); dSphere.release(); dDistant.release(); dRect.release(); dDisk.release(); dRectFrames.release(); dDiskFrames.release();
   slots.release(); media.release(); scratchColor.release(); neeKey.release(); pathSegments.release(); sampleBuf.release(); accum.release();
   for (uint32_t q = 0; q < Q_COUNT; q++) { qSlot[q].release(); qA[q].release(); qB[q].release(); qC[q].release(); }
   qFresh[0].release(); qFresh[1].release();

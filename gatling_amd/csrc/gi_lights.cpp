@@ -194,19 +194,35 @@ template <class Rec> static std::vector<Rec> usableLights(const std::vector<Rec>
   return out;
 }
 
+// decoded tangents and normal of a rect / disk light (gi_types.h LightFrame): decode_direction twice, then cross(t1, t0) in the device's operation order
+template <class Rec> static std::vector<LightFrame> lightFrames(const std::vector<Rec>& recs)
+{
+  std::vector<LightFrame> out(recs.size());
+  for (size_t i = 0; i < recs.size(); i++) {
+    LightFrame f{};
+    decodeDirection(recs[i].t0, f.t0); decodeDirection(recs[i].t1, f.t1);
+    const float* a = f.t1; const float* b = f.t0; // gi_device_math.h cross(a, b)
+    f.n[0] = a[1] * b[2] - a[2] * b[1]; f.n[1] = a[2] * b[0] - a[0] * b[2]; f.n[2] = a[0] * b[1] - a[1] * b[0];
+    out[i] = f;
+  }
+  return out;
+}
+
 int uploadLights(GiCScene* s)
 {
   const std::vector<SphereLightRec> sphere = usableLights(s->sphereLights.recs, "sphere");
   const std::vector<DistantLightRec> distant = usableLights(s->distantLights.recs, "distant");
   const std::vector<RectLightRec> rect = usableLights(s->rectLights.recs, "rect");
   const std::vector<DiskLightRec> disk = usableLights(s->diskLights.recs, "disk");
+  const std::vector<LightFrame> rectFrames = lightFrames(rect), diskFrames = lightFrames(disk);
   s->lightCounts[0] = (uint32_t)sphere.size(); s->lightCounts[1] = (uint32_t)distant.size(); s->lightCounts[2] = (uint32_t)rect.size(); s->lightCounts[3] = (uint32_t)disk.size();
   const uint32_t nDev = std::min<uint32_t>(sceneDeviceCount(s), (uint32_t)s->replicas.size() + 1u);
   for (uint32_t d = 0; d < nDev; d++) {
     SceneDevice& D = sceneDevice(s, d);
     HIP_TRY(hipSetDevice(g_ctx.devs[d].device));
     hipStream_t st = g_ctx.devs[d].stream;
-    if (D.dSphere.upload(sphere, st) || D.dDistant.upload(distant, st) || D.dRect.upload(rect, st) || D.dDisk.upload(disk, st))
+    if (D.dSphere.upload(sphere, st) || D.dDistant.upload(distant, st) || D.dRect.upload(rect, st) || D.dDisk.upload(disk, st) ||
+        D.dRectFrames.upload(rectFrames, st) || D.dDiskFrames.upload(diskFrames, st))
       return GI_C_ERROR;
     HIP_TRY(hipStreamSynchronize(st));
   }

@@ -13,7 +13,7 @@ SceneView makeView(GiCScene* s, SceneDevice& D)
       v.sphereLights = D.dSphere.ptr; v.distantLights = D.dDistant.ptr;
   v.tlasNodes = D.dTlasNodes.ptr; v.tlasItems = D.dTlasItems.ptr; v.blasNodes = D.dBlasNodes.ptr; v.blasTris = D.dBlasTris.ptr; v.instTrav = D.dInstTrav.ptr;
       v.flatOfOrig = D.dFlatOfOrig.ptr; v.twoLevel = s->twoLevel ? 1u : 0u;
-  v.rectLights = D.dRect.ptr; v.diskLights = D.dDisk.ptr; v.triFaceId = D.dTriFaceId.ptr; v.nodeCount = s->nodeCount; v.triCount = s->triCount;
+  v.rectLights = D.dRect.ptr; v.diskLights = D.dDisk.ptr; v.rectFrames = D.dRectFrames.ptr; v.diskFrames = D.dDiskFrames.ptr; v.triFaceId = D.dTriFaceId.ptr; v.nodeCount = s->nodeCount; v.triCount = s->triCount;
       v.bvhDepth = s->bvhDepth; v.hasCutouts = s->hasCutouts ? 1u : 0u;
   return v;
 }

@@ -982,12 +982,13 @@ __device__ inline void sample_light(const SceneView& sc, const FrameUniforms& U,
     uint32_t idx = (uint32_t)(k1 * (float)U.rectCount);
     const uint32_t last = U.rectCount - 1u; if (idx > last) idx = last;
     const RectLightRec l = sc.rectLights[idx];
+    const LightFrame lf = sc.rectFrames[idx]; // gi_decode_direction(l.t0), gi_decode_direction(l.t1) and their cross product, evaluated once on the host (gi_types.h)
     float sx = (k2 - 0.5f) * l.width, sy = (k3 - 0.5f) * l.height;
-    V3 t0 = gi_decode_direction(l.t0), t1 = gi_decode_direction(l.t1);
+    V3 t0 = v3(lf.t0), t1 = v3(lf.t1);
     V3 samplePos = (v3(l.origin) + t0 * sx) + t1 * sy;
     V3 dir = samplePos - surfacePos;
     dist = length(dir); dirToLight = gi_safe_div(dir, dist);
-    V3 ln = cross(t1, t0);
+    V3 ln = v3(lf.n);
     float cosTheta = fmax2(0.0f, dot(-dirToLight, ln));
     float area = l.width * l.height;
     invPdf = gi_safe_div((area > 0.0f) ? (area * cosTheta) : 1.0f, dist * dist);
@@ -996,12 +997,13 @@ __device__ inline void sample_light(const SceneView& sc, const FrameUniforms& U,
     uint32_t idx = (uint32_t)(k1 * (float)U.diskCount);
     const uint32_t last = U.diskCount - 1u; if (idx > last) idx = last;
     const DiskLightRec l = sc.diskLights[idx];
+    const LightFrame lf = sc.diskFrames[idx];
     float sx, sy; gi_sample_disk(k2, k3, l.rx, l.ry, sx, sy);
-    V3 t0 = gi_decode_direction(l.t0), t1 = gi_decode_direction(l.t1);
+    V3 t0 = v3(lf.t0), t1 = v3(lf.t1);
     V3 samplePos = (v3(l.origin) + t0 * sx) + t1 * sy;
     V3 dir = samplePos - surfacePos;
     dist = length(dir); dirToLight = gi_safe_div(dir, dist);
-    V3 ln = cross(t1, t0);
+    V3 ln = v3(lf.n);
     float cosTheta = fmax2(0.0f, dot(-dirToLight, ln));
     float area = l.rx * l.ry * GI_PI;
     invPdf = gi_safe_div((area > 0.0f) ? (area * cosTheta) : 1.0f, dist * dist);

@@ -130,6 +130,11 @@ struct DistantLightRec { float dir[3]; float angle; float em[3]; uint32_t ds; fl
 struct RectLightRec { float origin[3]; float width; float em[3]; float height; uint32_t t0, t1, ds; float pad; };
 struct DiskLightRec { float origin[3]; float rx; float em[3]; float ry; uint32_t t0, t1, ds; float pad; };
 static_assert(sizeof(SphereLightRec) == 48 && sizeof(DistantLightRec) == 48 && sizeof(RectLightRec) == 48 && sizeof(DiskLightRec) == 48, "lights are 48 bytes");
+// Derived per rect / disk light, beside its 48-byte record (round 6): the two tangents DECODED (host: decode_direction's operations, as for FVertex) and the light's
+// normal cross(t1, t0) -- sample_light decoded both codes and took the cross product for every light sample of every hit (two IEEE divisions, a square root and a
+// third division per decode).  Same bits: the host runs the device's operations in the device's order, without contraction.
+struct LightFrame { float t0[3], pad0, t1[3], pad1, n[3], pad2; };
+static_assert(sizeof(LightFrame) == 48, "LightFrame is three 16-byte pieces");
 
 // Per-frame constants (replaces rp::UniformData, rp_main.h:25-56; derived camera terms are computed once on
 // the host exactly as rp_main.rgen:199-212 does per pixel).
@@ -189,6 +194,7 @@ struct SceneView {
   const DistantLightRec* distantLights;
   const RectLightRec* rectLights;
   const DiskLightRec* diskLights;
+  const LightFrame* rectFrames; const LightFrame* diskFrames; // decoded tangents + normal of rectLights[i] / diskLights[i]
   const int32_t* triFaceId; // per triangle (BVH order): the value the FaceId AOV shows (rp_main.chit:230-240)
   uint32_t nodeCount;
   uint32_t triCount;
