@@ -800,18 +800,28 @@ __device__ __forceinline__ OpbrBaseParams opbr_base_params(const MaterialRec* m)
   o.alpha = p[MP_ALPHA]; o.eta = p[MP_ETA];
   return o;
 }
-__device__ inline void opbr_base_sample(const MaterialRec* m, const ShState& st, V3 k1, float x0, float x1, float x2, BsdfSample& out)
+// What the sampling routine and the evaluation of ONE hit both start from: the view direction in the shading frame, the interface's relative ior and its Fresnel
+// term at the view direction.  With NEE both run for (nearly) every hit: shade_segment makes the context once and hands it to both -- the same function of the same
+// arguments, so the same bits -- instead of evaluating the 65-instruction Fresnel term (three divisions, a square root) twice.
+struct OpbrBaseCtx { V3 l1; float nk1, eta, Fd; bool have; };
+__device__ __forceinline__ OpbrBaseCtx opbr_base_ctx(const MaterialRec* m, const ShState& st, V3 k1)
+{
+  OpbrBaseCtx c; c.l1 = to_local(st, k1); c.nk1 = fmax2(c.l1.z, 1e-4f); c.l1.z = c.nk1;
+  c.eta = relative_eta(st, m->p[MP_ETA]); c.Fd = fresnel_dielectric(c.nk1, c.eta); c.have = true;
+  return c;
+}
+__device__ inline void opbr_base_sample(const MaterialRec* m, const ShState& st, V3 k1, float x0, float x1, float x2, BsdfSample& out, const OpbrBaseCtx* ctx = nullptr)
 {
   const OpbrBaseParams o = opbr_base_params(m);
-  V3 l1 = to_local(st, k1);
-  const float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
+  V3 l1 = ctx ? ctx->l1 : to_local(st, k1);
+  const float nk1 = ctx ? ctx->nk1 : fmax2(l1.z, 1e-4f); l1.z = nk1;
   float z = x2; // (Fc = 0: z = (z - 0) / (1 - 0))
   float eta = 0.0f, Fd = 0.0f;
   uint32_t lobe = 1u; // 1 metal, 2 dielectric reflection, 4 diffuse
   if (!(z < o.metalness)) {
     z = (z - o.metalness) / (1.0f - o.metalness);
-    eta = relative_eta(st, o.eta);
-    Fd = fresnel_dielectric(nk1, eta);
+    eta = ctx ? ctx->eta : relative_eta(st, o.eta);
+    Fd = ctx ? ctx->Fd : fresnel_dielectric(nk1, eta);
     lobe = 2u;
     if (!(z < Fd)) lobe = 4u; // (transmission_weight = 0: z < 0 never holds)
   }
@@ -838,13 +848,13 @@ __device__ inline void opbr_base_sample(const MaterialRec* m, const ShState& st,
     out.overPdf = o.specColor * ((Fh / Fd) * g.g2OverG1);
   }
 }
-__device__ inline void opbr_base_evaluate(const MaterialRec* m, const ShState& st, V3 k1, V3 k2, BsdfEval& out)
+__device__ inline void opbr_base_evaluate(const MaterialRec* m, const ShState& st, V3 k1, V3 k2, BsdfEval& out, const OpbrBaseCtx* ctx = nullptr)
 {
   const OpbrBaseParams o = opbr_base_params(m);
-  V3 l1 = to_local(st, k1); const V3 l2 = to_local(st, k2);
-  const float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
-  const float eta = relative_eta(st, o.eta);
-  const float Fd = fresnel_dielectric(nk1, eta);
+  V3 l1 = ctx ? ctx->l1 : to_local(st, k1); const V3 l2 = to_local(st, k2);
+  const float nk1 = ctx ? ctx->nk1 : fmax2(l1.z, 1e-4f); l1.z = nk1;
+  const float eta = ctx ? ctx->eta : relative_eta(st, o.eta);
+  const float Fd = ctx ? ctx->Fd : fresnel_dielectric(nk1, eta);
   float fs, ps, khs; ggx_eval(l1, l2, o.alpha, fs, ps, khs);
   const float Fdh = fresnel_dielectric(khs, eta);
   const float cd = l2.z / GI_PI;

@@ -124,7 +124,13 @@ __device__ __forceinline__ void shade_segment(const FrameUniforms& U, const Scen
   }
   // BSDF importance sampling (:361-389); xi = next4f, .w is drawn but unused by the closed forms
   const float x0 = gi_next1f(rng), x1 = gi_next1f(rng), x2 = gi_next1f(rng); (void)gi_next1f(rng);
-  BsdfSample bs; bsdf_sample<KLASS>(mat, ss, -rayDir, x0, x1, x2, bs);
+  BsdfSample bs;
+  OpbrBaseCtx baseCtx; baseCtx.have = false;
+  if constexpr (KLASS == SHADE_CLASS_OPBR_BASE && NEE) { // sample and evaluate share their starting point (gi_shading.h OpbrBaseCtx)
+    baseCtx = opbr_base_ctx(mat, ss, -rayDir);
+    bs.event = EV_ABSORB; bs.pdf = 0.0f; bs.overPdf = v3(0.0f, 0.0f, 0.0f); bs.k2 = v3(0.0f, 0.0f, 0.0f); // (bsdf_sample's initialisation)
+    opbr_base_sample(mat, ss, -rayDir, x0, x1, x2, bs, &baseCtx);
+  } else bsdf_sample<KLASS>(mat, ss, -rayDir, x0, x1, x2, bs);
   throughput = throughput * bs.overPdf;
   k2 = bs.k2;
   const bool isTransmission = (bs.event & EV_TRANSMISSION) != 0u;
@@ -134,7 +140,11 @@ __device__ __forceinline__ void shade_segment(const FrameUniforms& U, const Scen
     V3 dirToLight, lightPower; float lightDist, invPdf; uint32_t ds;
     sample_light(sc, U, k0, k1, kk2, k3, ss.position, dirToLight, lightDist, lightPower, invPdf, ds);
     if ((lightDist > 0.0f) && dot(dirToLight, ss.geomNormal) > 0.0f) {
-      BsdfEval ev; bsdf_evaluate<KLASS>(mat, ss, -rayDir, dirToLight, ev);
+      BsdfEval ev;
+      if constexpr (KLASS == SHADE_CLASS_OPBR_BASE && NEE) { // bsdf_evaluate's preamble, then the variant with the shared context
+        ev.diffuse = v3(0.0f, 0.0f, 0.0f); ev.glossy = v3(0.0f, 0.0f, 0.0f); ev.pdf = 0.0f;
+        if (dot(ss.normal, dirToLight) > 0.0f) opbr_base_evaluate(mat, ss, -rayDir, dirToLight, ev, &baseCtx);
+      } else bsdf_evaluate<KLASS>(mat, ss, -rayDir, dirToLight, ev);
       if (ev.pdf > 0.0f) {
         const float dmul = gi_half_to_float(ds & 0xffffu), smul = gi_half_to_float(ds >> 16);
         const V3 weight = throughput * (lightPower * invPdf);
