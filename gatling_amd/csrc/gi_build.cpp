@@ -214,7 +214,7 @@ int uploadSceneTo(GiCScene* s, SceneDevice& D, const SceneHost& H)
         D.dInstTrav.upload(H.two.instTrav, st) || D.dFlatOfOrig.upload(H.flatOfOrig, st))
       return GI_C_ERROR;
   }
-  if (D.dTriFaceId.upload(H.triFaceId, st) || D.dTriShade.upload(H.triShade, st)) return GI_C_ERROR;
+  if (D.dTriFaceId.upload(H.triFaceId, st) || D.dTriShade.upload(H.triShade, st) || D.dTriGeomNormal.upload(H.triGeomNormal, st)) return GI_C_ERROR;
   if (D.dMeshes.upload(H.meshRecs, st) || D.dSceneData.upload(H.sceneData, st)) return GI_C_ERROR;
   { // textures: one device array per image + the TextureRec table
     for (auto* b : D.dTexels) { b->release(); delete b; }
@@ -424,6 +424,26 @@ int buildScene(GiCScene* s)
       }
     }
     for (TriRec& t : bvh.tris) t.vi[0] = shadeBaseOfMesh[instances[t.instance].mesh] + t.prim;
+  }
+  // LDS-resident scenes (the fused kernels' and k_trace's shading path reads FVertex records): the world-space geometric normal of every flattened triangle, made
+  // here with setup_shading_state's operations in its order (mdl_shading_state.glsl:27-28: normalize(cross(pb - pa, pc - pa)) in object space, the normal transform,
+  // normalize again) -- two normalisations, a cross product and a transform per hit that depend on nothing but the triangle.  Same bits: IEEE + - * / sqrt without
+  // contraction on both sides, as for the decoded FVertex normals.
+  H.triGeomNormal.clear();
+  if (!H.shadePacked) {
+    H.triGeomNormal.resize(bvh.tris.size());
+    auto normalize3 = [](float* a) { const float inv = 1.0f / sqrtf((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]); a[0] = a[0] * inv; a[1] = a[1] * inv; a[2] = a[2] * inv; };
+    for (size_t i = 0; i < bvh.tris.size(); i++) {
+      const TriRec& t = bvh.tris[i];
+      const float* pa = verts[t.vi[0]].pos; const float* pb = verts[t.vi[1]].pos; const float* pc = verts[t.vi[2]].pos;
+      const float e1[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]}, e2[3] = {pc[0] - pa[0], pc[1] - pa[1], pc[2] - pa[2]};
+      float g[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+      normalize3(g);
+      const float* w = instances[t.instance].w2o;
+      float n[3] = {(g[0] * w[0] + g[1] * w[3]) + g[2] * w[6], (g[0] * w[1] + g[1] * w[4]) + g[2] * w[7], (g[0] * w[2] + g[1] * w[5]) + g[2] * w[8]};
+      normalize3(n);
+      H.triGeomNormal[i] = F4{n[0], n[1], n[2], 0.0f};
+    }
   }
   s->shadePacked = H.shadePacked;
   // a new tree: the shadow walks' order is chosen anew

@@ -165,7 +165,7 @@ void deriveMaterialConstants(MaterialRec& m)
 
 void SceneDevice::releaseAll()
 {
-  dNodes.release(); dTris.release(); dInstances.release(); dVerts.release(); dTriFaceId.release(); dTriShade.release();
+  dNodes.release(); dTris.release(); dInstances.release(); dVerts.release(); dTriFaceId.release(); dTriShade.release(); dTriGeomNormal.release();
   dTlasNodes.release(); dBlasNodes.release(); dTlasItems.release(); dFlatOfOrig.release(); dBlasTris.release(); dInstTrav.release();
   for (auto* b : dTexels) { b->release(); delete b; }
   dTexels.clear(); dTextures.release(); dMeshes.release(); dSceneData.release();

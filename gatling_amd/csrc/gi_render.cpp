@@ -9,7 +9,7 @@ SceneView makeView(GiCScene* s, SceneDevice& D)
   SceneView v{};
   v.textures = D.dTextures.ptr; v.meshes = D.dMeshes.ptr; v.sceneData = D.dSceneData.ptr;
   v.nodes = D.dNodes.ptr; v.tris = D.dTris.ptr; v.instances = D.dInstances.ptr;
-  v.verts = D.dVerts.ptr; v.triShade = D.dTriShade.ptr; v.shadePacked = s->shadePacked ? 1u : 0u; v.materials = D.dMaterials.ptr;
+  v.verts = D.dVerts.ptr; v.triShade = D.dTriShade.ptr; v.triGeomNormal = D.dTriGeomNormal.ptr; v.shadePacked = s->shadePacked ? 1u : 0u; v.materials = D.dMaterials.ptr;
       v.sphereLights = D.dSphere.ptr; v.distantLights = D.dDistant.ptr;
   v.tlasNodes = D.dTlasNodes.ptr; v.tlasItems = D.dTlasItems.ptr; v.blasNodes = D.dBlasNodes.ptr; v.blasTris = D.dBlasTris.ptr; v.instTrav = D.dInstTrav.ptr;
       v.flatOfOrig = D.dFlatOfOrig.ptr; v.twoLevel = s->twoLevel ? 1u : 0u;

@@ -101,8 +101,11 @@ __device__ __forceinline__ void setup_shading_state(const SceneView& sc, uint32_
   const float bx = 1.0f - hu - hv, by = hu, bz = hv;                                  // :17
   const V3 localPos = (pa * bx + pb * by) + pc * bz;                                  // :24
   s.position = xform_point(o2w, localPos, 1.0f);                                      // :25
-  V3 gn = normalize(cross(pb - pa, pc - pa));                                         // :27
-  gn = normalize(xform_normal(w2o, gn));                                              // :28
+  V3 gn;
+  if (PACKED) {
+    gn = normalize(cross(pb - pa, pc - pa));                                          // :27
+    gn = normalize(xform_normal(w2o, gn));                                            // :28
+  } else { const F4 g = ld4(&sc.triGeomNormal[triIdx]); gn = v3(g.x, g.y, g.z); }      // the same two lines, evaluated once per flattened triangle on the host (gi_build.cpp)
   const V3 ln = normalize((n0 * bx + n1 * by) + n2 * bz);                             // :35
   V3 nrm = normalize(xform_normal(w2o, ln));                                          // :36
   s.frontFace = dot(gn, -rayDir) >= 0.0f;                                             // :39

@@ -183,11 +183,13 @@ struct InstTrav {                                                               
   uint32_t pad[7];
 };
 static_assert(sizeof(BlasTri) == 64 && sizeof(InstTrav) == 128, "two-level records are one cache line each");
+struct alignas(16) F4 { float x, y, z, w; };
 struct SceneView {
   const Node8* nodes;      // packed, 80 bytes apart (one node per 128-byte line measured 1-3 % slower, r03c)
   const TriRec* tris;
   const InstanceRec* instances;
   const FVertex* verts;
+  const F4* triGeomNormal; // LDS-resident scenes (shadePacked == 0): the world-space geometric normal of every flattened triangle, made on the host with setup_shading_state's operations
   const TriShade* triShade; uint32_t shadePacked; // != 0: TriRec::vi[0] indexes triShade (scenes beyond LDS); 0: TriRec::vi are vertex indices (LDS-resident scenes, fused kernels)
   const MaterialRec* materials;
   const SphereLightRec* sphereLights;
@@ -222,7 +224,6 @@ struct SceneView {
   uint32_t twoLevel;                                   // 0: not built
 };
 
-struct alignas(16) F4 { float x, y, z, w; };
 
 // Device buffers of the bound non-colour AOVs (null = not bound) and their clear values by GiAovId (Gi.h:36-56).
 struct AovTargets {
