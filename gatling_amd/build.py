@@ -13,7 +13,7 @@ OBJDIR = os.path.join(CSRC, "build")
 LIB = os.path.join(_HERE, "libgatling_gi.so")
 # the host side of the C ABI (gi_c.cpp until round 6): built with -fvisibility=hidden, the API keeps default visibility through gi_host.h
 HOST_SOURCES = ["gi_c.cpp", "gi_scene.cpp", "gi_textures.cpp", "gi_lights.cpp", "gi_build.cpp", "gi_render.cpp", "gi_debug.cpp"]
-SOURCES = HOST_SOURCES + ["gi_image.cpp", "bvh8.cpp", "gi_kernels.hip", "gi_path.hip", "gi_path_bw.hip", "gtl_shim.cpp"]
+SOURCES = HOST_SOURCES + ["gi_image.cpp", "bvh8.cpp", "gi_kernels.hip", "gi_trace.hip", "gi_shade.hip", "gi_aov.hip", "gi_path.hip", "gi_path_bw.hip", "gtl_shim.cpp"]
 HEADERS = ["gi_host.h", "gi_types.h", "gi_kernels.h", "gi_device_math.h", "gi_queues.h", "gi_traversal.h", "gi_texture.h", "gi_shading.h", "gi_stages.h", "gi_image.h", "gi_options.h", "bvh8.h",
            os.path.join("..", "..", "include", "gi_c.h"), os.path.join("..", "..", "include", "gtl", "gi", "Gi.h"),
            os.path.join("..", "..", "include", "gtl", "gb", "ParamTypes.h")]

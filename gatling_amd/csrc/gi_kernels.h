@@ -1,4 +1,4 @@
-// gi_kernels.h -- host-side launch interface of the stage kernels (gi_kernels.hip).
+// gi_kernels.h -- host-side launch interface of the stage kernels (gi_kernels.hip, gi_trace.hip, gi_shade.hip, gi_aov.hip) and of the fused ones (gi_path.hip, gi_path_bw.hip).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -17,6 +17,8 @@ uint32_t traceStaticLdsBytes(); // static LDS of the traversal kernels on top of
 void traceLdsLayout(const SceneView& sc, uint32_t& ldsNodes, uint32_t& ldsTris, uint32_t& bytes);
 void launchTrace(hipStream_t s, uint32_t blocks, bool anyHit, bool count, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt,
                  uint32_t qIn, uint32_t qMiss, uint32_t dynRefill, uint32_t routeBlocks, const FrameUniforms& U, F4* sampleBuf);
+void launchRoute(hipStream_t s, uint32_t blocks, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t qMiss, const FrameUniforms& U,
+                 F4* sampleBuf); // (called by launchTrace behind a k_trace_dyn launch)
 constexpr uint32_t APPEND_ITEMS_MAX = 4u; // most records a thread appends per trip of a streaming kernel (k_route ROUTE_ITEMS, k_raygen RAYGEN_ITEMS): sizes the queue shards' slack, gi_render.cpp shardCapacity
 constexpr uint32_t TRACE_DYN_SLOT_ORDER = 0x200u; // flag in dynRefill (shadow launches): children are visited in slot order instead of near-to-far (k_trace_dyn: DYN_SLOT_ORDER)
 constexpr uint32_t TRACE_DYN_SPILL8 = 0x100u; // flag in dynRefill: 8 LDS stack entries + scratch overflow instead of 16 LDS entries

@@ -233,4 +233,31 @@ __device__ __forceinline__ void shade_segment(const FrameUniforms& U, const Scen
   io.sdir = sdir; io.nee = nee; io.ld = ld; io.rngShadow = rngShadow;
 }
 
+// A new path's Slot (rp_main.rgen:274-276): throughput 1, bitfield 0, radiance 0, the rng state after the camera draws, its work item
+__device__ __forceinline__ void slot_begin_path(Slot* S, uint32_t rng, uint32_t pixelLocal, uint32_t sLocal)
+{
+  st4(&S->thr, 1.0f, 1.0f, 1.0f, u2f(0u));
+  st4(&S->rad, 0.0f, 0.0f, 0.0f, u2f(rng));
+  st4(&S->id, u2f(pixelLocal), u2f(sLocal), u2f(1u), 0.0f);
+}
+// FLAG_DEFER_SLOT: the first segment of a camera path whose Slot k_raygen did not write has been traced.  A hit writes the Slot now (the path goes on exactly as
+// if k_raygen had written it).  A miss retires the sample on the spot -- radiance 0 + throughput 1 x background, then the per-sample finish, the arithmetic of
+// k_raygen's finish of a REGEN_MISSED entry (rp_main.miss:68-86, rp_main.rgen:489-496) -- and returns true: the slot goes back to the regen queue as REGEN_FRESH,
+// "nothing to finish, memory unwritten".  Scenes with a dome image or medium stacks need the slot at a miss (dome_miss / the scattering test): the caller writes
+// it first and takes the ordinary route.
+__device__ __forceinline__ void retire_fresh_miss(const FrameUniforms& U, const FreshRec& f, F4* __restrict__ sampleBuf)
+{
+  uint32_t pixelLocal, sLocal; work_item(U, f.work, pixelLocal, sLocal);
+  V3 rad = v3(0.0f, 0.0f, 0.0f) + v3(1.0f, 1.0f, 1.0f) * v3(U.background);
+  const float mv = fmax2(rad.x, fmax2(rad.y, rad.z));
+  if (mv > U.maxSampleValue) rad = rad * (U.maxSampleValue / mv);
+  st4(&sampleBuf[sample_record(U, pixelLocal, sLocal)], fmax2(0.0f, rad.x), fmax2(0.0f, rad.y), fmax2(0.0f, rad.z), 0.0f);
+}
+__device__ __forceinline__ void begin_fresh_path(const FrameUniforms& U, const PathState& st, uint32_t slot, const FreshRec& f)
+{
+  uint32_t pixelLocal, sLocal; work_item(U, f.work, pixelLocal, sLocal);
+  slot_begin_path(&st.slots[slot], f.rng, pixelLocal, sLocal);
+}
+// (a first segment that HIT is begun by k_shade, which gathers the ray record and the FreshRec beside it and completes the Slot in one go)
+
 } // namespace gi

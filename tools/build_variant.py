@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from gatling_amd import build as B  # noqa: E402
 
-KERNEL_TUS = ["gi_kernels.hip", "gi_path.hip", "gi_path_bw.hip"]
+KERNEL_TUS = ["gi_kernels.hip", "gi_trace.hip", "gi_shade.hip", "gi_aov.hip", "gi_path.hip", "gi_path_bw.hip"]
 
 
 def main():
@@ -30,7 +30,7 @@ def main():
         base = [f for f in B.KERNEL_FLAGS if not ("-fslp-vectorize" in extra and f == "-fno-slp-vectorize")]
         subprocess.check_call([hipcc] + B.FLAGS + base + extra + ["-c", src, "-o", os.path.join(obj_dir, src + ".o")], cwd=B.CSRC)
 
-    with ThreadPoolExecutor(max_workers=3) as pool:
+    with ThreadPoolExecutor(max_workers=6) as pool:
         list(pool.map(compile_one, KERNEL_TUS))
     objs = [os.path.join(obj_dir, s + ".o") if s in KERNEL_TUS else B._obj(s) for s in B.SOURCES]
     lib = os.path.join(out_dir, f"libgatling_gi_{name}.so")
