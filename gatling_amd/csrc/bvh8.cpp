@@ -67,7 +67,8 @@ struct Builder {
 
   // (cutting the bottom 24 triangles of a subtree into full leaves of three by object-median splits -- nodes per ray 16.6 / 6.9 / 20.1 -> 16.0 / 6.8 / 20.0 on
   // C3 / C4 / C5 but triangles per ray 13.1 / 3.4 / 10.8 -> 18.5 / 5.1 / 22.4, traversal 8-20 % slower: SAH leaves win, r02)
-  std::unique_ptr<Dp[]> dp; float cPrim = 0.5f; // (not zero-initialised: 44 B per BVH2 node) filled bottom-up by build() when leafSize == 1 (each thread completes its own subtrees)
+  // (not zero-initialised: 44 B per BVH2 node) filled bottom-up by build() when leafSize == 1 (each thread completes its own subtrees)
+  std::unique_ptr<Dp[]> dp; float cPrim = 0.5f;
   uint32_t maxLeaf = kMaxLeaf;  // references a leaf slot may hold (1 for the top tree over subtrees: every leaf slot is then exactly one item)
   uint32_t leafSize = kMaxLeaf; // the BVH2 stops splitting at this many references (1 for the cost-optimal collapse, which forms the leaves itself)
   const float* extBoxes = nullptr; size_t extCount = 0; // box mode (TLAS over instances, BLAS over pre-padded triangle boxes): 6 floats per item
@@ -88,7 +89,8 @@ struct Builder {
     triBox.resize(n); centroid.resize(3 * n); refs.resize(n); dead.assign(n, 0);
     const int workers = (n > (1u << 16)) ? spareThreads.load() + 1 : 1;
     std::vector<std::future<void>> jobs;
-    for (int w = 1; w < workers; w++) jobs.push_back(std::async(std::launch::async, [this, n, w, workers] { prepareRange(n * w / workers, n * (w + 1) / workers); }));
+    for (int w = 1; w < workers;
+        w++) jobs.push_back(std::async(std::launch::async, [this, n, w, workers] { prepareRange(n * w / workers, n * (w + 1) / workers); }));
     prepareRange(0, n / workers);
     for (auto& j : jobs) j.get();
     size_t k = 0;
@@ -105,7 +107,8 @@ struct Builder {
   {
     for (size_t i = begin; i < end; i++) {
       if (extBoxes) { // the caller's boxes are taken as they are (already padded)
-        Box b; for (int a = 0; a < 3; a++) { b.lo[a] = extBoxes[6 * i + a]; b.hi[a] = extBoxes[6 * i + 3 + a]; centroid[3 * i + a] = 0.5f * (b.lo[a] + b.hi[a]); }
+        Box b;
+            for (int a = 0; a < 3; a++) { b.lo[a] = extBoxes[6 * i + a]; b.hi[a] = extBoxes[6 * i + 3 + a]; centroid[3 * i + a] = 0.5f * (b.lo[a] + b.hi[a]); }
         triBox[i] = b;
         for (int a = 0; a < 3; a++) if (!usable(b.lo[a]) || !usable(b.hi[a]) || !(b.lo[a] <= b.hi[a])) dead[i] = 1;
         continue;
@@ -205,7 +208,8 @@ struct Builder {
     }
     const float cLeaf = n.total <= maxLeaf ? area * cPrim * (float)n.total : 3.0e38f;
     const float cInt = area + dist[8];
-    d.leaf = (n.total <= maxLeaf && cLeaf <= cInt) ? 1 : 0; // (the count is tested on its own: with overflowing areas cInt is +inf and the 3e38 stand-in would win)
+    // (the count is tested on its own: with overflowing areas cInt is +inf and the 3e38 stand-in would win)
+    d.leaf = (n.total <= maxLeaf && cLeaf <= cInt) ? 1 : 0;
     d.c[0] = d.leaf ? cLeaf : cInt; d.eff[0] = 1;
     for (int i = 2; i <= 7; i++) {
       if (dist[i] < d.c[i - 2]) { d.c[i - 1] = dist[i]; d.eff[i - 1] = (uint8_t)i; }
@@ -229,7 +233,8 @@ inline int exponentFor(float extent)
 
 // `itemRoots` (top mode, with `boxes`): every item is a subtree that already exists; its leaf slot becomes an INTERNAL child whose node is a copy of the item's
 // root node (absolute child / triangle indices inside), so the result is one ordinary tree -- the traversal kernels never learn it was assembled from pieces.
-static void buildCore(const std::vector<TriRec>& trisIn, const float* boxes, size_t boxCount, Bvh8& out, std::vector<uint32_t>* order, const Node8* itemRoots = nullptr)
+static void buildCore(const std::vector<TriRec>& trisIn, const float* boxes, size_t boxCount, Bvh8& out, std::vector<uint32_t>* order,
+    const Node8* itemRoots = nullptr)
 {
   out.nodes.clear(); out.tris.clear(); out.maxDepth = 0;
   if (order) order->clear();
@@ -251,7 +256,8 @@ static void buildCore(const std::vector<TriRec>& trisIn, const float* boxes, siz
   // 0: the round-1 rule (SAH leaves of <= 3, then greedily open the child with the largest area until 8 slots are used).
   int collapse = 1;
   collapse = (int)optionValue("bvh_collapse", collapse);
-  float cPrim = 0.5f; // a triangle test costs about half a node test (~110 vs ~214 VALU instructions); measured flat between 0.2 and 0.5 (profiles/r02j_bvh_collapse.txt)
+  // a triangle test costs about half a node test (~110 vs ~214 VALU instructions); measured flat between 0.2 and 0.5 (profiles/r02j_bvh_collapse.txt)
+  float cPrim = 0.5f;
   if (itemRoots) { collapse = 1; cPrim = 1.0f; B.maxLeaf = 1u; } // an item costs (at least) a node visit; one item per leaf slot
   if (collapse == 1) { B.leafSize = 1; B.cPrim = cPrim; }
   B.prepare();
@@ -363,7 +369,8 @@ static void buildCore(const std::vector<TriRec>& trisIn, const float* boxes, siz
     });
     // --- indices: internal children and triangles in level order, slot order within a node
     size_t nodeBase = out.nodes.size(), nodeEnd = nodeBase, triEnd = triCount;
-    for (size_t li = 0; li < m; li++) { plans[li].childBase = (uint32_t)nodeEnd; plans[li].triBase = (uint32_t)triEnd; nodeEnd += plans[li].internal; triEnd += plans[li].tris; }
+    for (size_t li = 0; li < m; li++) { plans[li].childBase = (uint32_t)nodeEnd; plans[li].triBase = (uint32_t)triEnd; nodeEnd += plans[li].internal;
+        triEnd += plans[li].tris; }
     out.nodes.resize(nodeEnd);
     if (order) order->resize(triEnd); else out.tris.resize(triEnd);
     next.resize(nodeEnd - nodeBase);
@@ -372,7 +379,8 @@ static void buildCore(const std::vector<TriRec>& trisIn, const float* boxes, siz
       if (itemRoots && B.nodes[level[li].n2].count > 0) { out.nodes[level[li].n8] = itemRoots[B.refs[B.nodes[level[li].n2].first]]; return; }
       Node8 node; std::memset(&node, 0, sizeof(node));
       int ex[3]; float scale[3];
-      for (int a = 0; a < 3; a++) { node.p[a] = P.nb.lo[a]; ex[a] = exponentFor(P.nb.hi[a] - P.nb.lo[a]); node.e[a] = (uint8_t)(ex[a] + 127); scale[a] = std::ldexp(1.0f, ex[a]); }
+      for (int a = 0; a < 3; a++) { node.p[a] = P.nb.lo[a]; ex[a] = exponentFor(P.nb.hi[a] - P.nb.lo[a]); node.e[a] = (uint8_t)(ex[a] + 127);
+          scale[a] = std::ldexp(1.0f, ex[a]); }
       node.childBase = P.childBase;
       node.triBase = P.triBase;
       uint32_t triOffset = 0, childIdx = P.childBase;
@@ -413,7 +421,8 @@ static void buildCore(const std::vector<TriRec>& trisIn, const float* boxes, siz
     level.swap(next);
   }
   appendInactive();
-  if (timing) fprintf(stderr, "[gatling_gi] bvh8: prepare %.0f ms, bvh2 %.0f ms, collapse+quantise %.0f ms (%zu items, %zu nodes)\n", tB - tA, tC - tB, now() - tC, itemCount, out.nodes.size());
+  if (timing) fprintf(stderr, "[gatling_gi] bvh8: prepare %.0f ms, bvh2 %.0f ms, collapse+quantise %.0f ms (%zu items, %zu nodes)\n", tB - tA, tC - tB,
+      now() - tC, itemCount, out.nodes.size());
 }
 
 void buildBvh8(const std::vector<TriRec>& trisIn, Bvh8& out) { buildCore(trisIn, nullptr, 0, out, nullptr); }

@@ -32,9 +32,9 @@ void buildBvh8(const std::vector<TriRec>& tris, Bvh8& out);
 void buildBvh8Boxes(const float* boxes, size_t count, Bvh8& out, std::vector<uint32_t>& order);
 
 // A tree over SUBTREES that already exist (incremental scene updates: one subtree per mesh instance, rebuilt alone when its transform changes).
-// `boxes`: the items' padded bounds; `itemRoots[i]`: the root node of item i with ABSOLUTE child / triangle indices.  Every item becomes an internal child whose
-// node is a copy of its root, so `out.nodes` (breadth-first, root at 0) together with the items' own node ranges is one ordinary BVH8; `out.maxDepth` counts
-// the levels down to and including the copied roots.
+// `boxes`: the items' padded bounds; `itemRoots[i]`: the root node of item i with ABSOLUTE child / triangle indices.  Every item becomes an internal child
+// whose node is a copy of its root, so `out.nodes` (breadth-first, root at 0) together with the items' own node ranges is one ordinary BVH8; `out.maxDepth`
+// counts the levels down to and including the copied roots.
 void buildTopBvh8(const float* boxes, size_t count, const Node8* itemRoots, Bvh8& out);
 
 } // namespace gi

@@ -1,5 +1,5 @@
-// gi_aov.hip -- k_aov, the non-colour AOVs of a frame (gfx950): replays the camera rays of every sample in order and writes what the reference's ray generation and
-// closest-hit shaders write for the primary hit (/root/reference/src/gi/shaders/rp_main.rgen:132-183, 517-520; rp_main.chit:192-290).
+// gi_aov.hip -- k_aov, the non-colour AOVs of a frame (gfx950): replays the camera rays of every sample in order and writes what the reference's ray generation
+// and closest-hit shaders write for the primary hit (/root/reference/src/gi/shaders/rp_main.rgen:132-183, 517-520; rp_main.chit:192-290).
 
 #include <type_traits>
 #include <hip/hip_runtime.h>
@@ -75,7 +75,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_aov(FrameUniforms U, SceneView 
   if (A.instanceId) A.instanceId[pixelIndex] = (int)f2u(A.clear[14][0]);
   clr3(A.doubleSided, 15);
   V3 curNormal = v3(0.0f, 0.0f, 0.0f), curAlbedo = curNormal;
-  if (U.sampleOffset == 0u) { clr3(A.normal, 1); clr3(A.albedo, 16); curNormal = v3(A.clear[1][0], A.clear[1][1], A.clear[1][2]); curAlbedo = v3(A.clear[16][0], A.clear[16][1], A.clear[16][2]); }
+  if (U.sampleOffset == 0u) { clr3(A.normal, 1); clr3(A.albedo, 16); curNormal = v3(A.clear[1][0], A.clear[1][1], A.clear[1][2]);
+      curAlbedo = v3(A.clear[16][0], A.clear[16][1], A.clear[16][2]); }
   else {
     if (A.normal) { const F4 q = ld4(&A.normal[pixelIndex]); curNormal = v3(q.x, q.y, q.z); }
     if (A.albedo) { const F4 q = ld4(&A.albedo[pixelIndex]); curAlbedo = v3(q.x, q.y, q.z); }
@@ -87,7 +88,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_aov(FrameUniforms U, SceneView 
     make_camera_ray(U, pixelIndex, U.sampleOffset + s, origin, dir, tMin, tMax, rng);
     float t, u, v; uint32_t tri;
     uint32_t matWord;
-    if (!traverse<false, false, STACK, OVERFLOW, false, true>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, origin, dir, tMin, tMax, t, u, v, tri, matWord, tc, rng)) continue;
+    if (!traverse<false, false, STACK, OVERFLOW, false,
+        true>(sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, origin, dir, tMin, tMax, t, u, v, tri, matWord, tc, rng)) continue;
     ShState ss;
     setup_shading_state<PACKED>(sc, tri, u, v, dir, ss);
     const uint4* tp = reinterpret_cast<const uint4*>(sc.tris) + (size_t)tri * 4u;
@@ -96,7 +98,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_aov(FrameUniforms U, SceneView 
       // rp_main.chit:199-205 writes (1,0,0) for materials without cutout transparency; for the others the any-hit shader has written
       // viridis(opacity) (white for 0) of its last candidate (rp_main.ahit:45-49) -- restated as the ACCEPTED primary hit's opacity
       V3 c = v3(1.0f, 0.0f, 0.0f);
-      if (matWord & (1u << 28)) { const float op = cutout_opacity_at(sc, matWord, tri, u, v); c = (op == 0.0f) ? v3(1.0f, 1.0f, 1.0f) : gi_colormap_viridis(op); }
+      if (matWord & (1u << 28)) { const float op = cutout_opacity_at(sc, matWord, tri, u, v); c = (op == 0.0f) ? v3(1.0f, 1.0f, 1.0f) : gi_colormap_viridis(op);
+          }
       put3(A.opacity, c);
     }
     put3(A.tangents, (ss.tangentU + v3(1.0f, 1.0f, 1.0f)) * 0.5f);
@@ -105,13 +108,16 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_aov(FrameUniforms U, SceneView 
     if (A.texcoords) {
       const uint4 td = tp[3];
       const float bx = 1.0f - u - v;
-      if (PACKED) { const TriShade& q = sc.triShade[td.x]; put3(A.texcoords, v3((bx * q.uv[0][0] + u * q.uv[1][0]) + v * q.uv[2][0], (bx * q.uv[0][1] + u * q.uv[1][1]) + v * q.uv[2][1], 0.0f)); }
+      if (PACKED) { const TriShade& q = sc.triShade[td.x];
+          put3(A.texcoords, v3((bx * q.uv[0][0] + u * q.uv[1][0]) + v * q.uv[2][0], (bx * q.uv[0][1] + u * q.uv[1][1]) + v * q.uv[2][1], 0.0f)); }
       else {
       const FVertex* va = &sc.verts[td.x]; const FVertex* vb = &sc.verts[td.y]; const FVertex* vc = &sc.verts[td.z];
       put3(A.texcoords, v3((bx * va->u + u * vb->u) + v * vc->u, (bx * va->v + u * vb->v) + v * vc->v, 0.0f));
       }
     }
-    { const MaterialRec* tm = &sc.materials[ss.material]; put3(A.thinWalled, (tm->klass == 2u && ((uint32_t)tm->p[MP_FEATURES] & MATF_THIN_WALLED) != 0u) ? v3(1.0f, 0.0f, 0.0f) : v3(0.0f, 1.0f, 0.0f)); } // rp_main.chit:218-220
+    // rp_main.chit:218-220
+    { const MaterialRec* tm = &sc.materials[ss.material];
+        put3(A.thinWalled, (tm->klass == 2u && ((uint32_t)tm->p[MP_FEATURES] & MATF_THIN_WALLED) != 0u) ? v3(1.0f, 0.0f, 0.0f) : v3(0.0f, 1.0f, 0.0f)); }
     if (A.objectId) A.objectId[pixelIndex] = (int)sc.instances[instIdx].pad;
     if (A.depth) A.depth[pixelIndex] = 2.0f * gi_logf(t / U.clipNear) / gi_logf(U.clipFar / U.clipNear) - 1.0f;
     if (A.faceId) A.faceId[pixelIndex] = sc.triFaceId[tri];

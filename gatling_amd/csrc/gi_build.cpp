@@ -174,7 +174,8 @@ int buildTwoLevel(GiCScene* s, const std::vector<MB>& meshBuilds, const std::vec
           }
           if (!objectOk) continue;
           if (!worldOk) {
-            if (want > 0) fprintf(stderr, "[gatling_gi] two-level layout not used: an instance carries triangles that leave the usable coordinate range in world space\n");
+            if (want > 0) fprintf(stderr,
+                "[gatling_gi] two-level layout not used: an instance carries triangles that leave the usable coordinate range in world space\n");
             return GI_C_OK;
           }
           for (int k = 0; k < 3; k++) for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], q[k][a]); hi[a] = std::max(hi[a], q[k][a]); }
@@ -388,7 +389,8 @@ int buildScene(GiCScene* s)
     std::vector<uint32_t> perMesh(meshBuilds.size(), 0u);
     for (size_t i = bvh.activeTris; i < bvh.tris.size(); i++) perMesh[instances[bvh.tris[i].instance].mesh]++;
     for (const MeshBuild& mb : meshBuilds)
-      if (perMesh[mb.meshIdx]) fprintf(stderr, "[gatling_gi] warning: mesh %s: %u of %zu instanced triangle(s) have a non-finite or out-of-range (> 1e18) vertex or a non-invertible transform and are inactive\n",
+      if (perMesh[mb.meshIdx]) fprintf(stderr, "[gatling_gi] warning: mesh %s: %u of %zu instanced triangle(s) have a non-finite or out-of-range (> 1e18) "
+                                                "vertex or a non-invertible transform and are inactive\n",
                                        mb.m->name.c_str(), perMesh[mb.meshIdx], mb.m->faces.size() * (size_t)mb.instCount);
   }
   if (buildTwoLevel(s, meshBuilds, instances, bvh.tris.size(), bvh.nodes.size(), H.two) != GI_C_OK) return GI_C_ERROR;
@@ -400,8 +402,15 @@ int buildScene(GiCScene* s)
   // the deepest traversal variant keeps 8 (SPILL8) or 16 stack entries in LDS and OVF_STACK = 40 in scratch; trav_node_pick does not bound-check the spill
   if (bvh.maxDepth > 1u + 8u + 40u) { setError("scene BVH is deeper than the traversal stack (49 levels): degenerate geometry (long chains of nested splits)");
       return GI_C_ERROR; }
-  if (bvh.tris.size() >= (1u << 26) && !s->twoLevel) { setError("scene has 2^26 or more triangles after instancing and no two-level layout (it is switched off, or its unique mesh triangles exceed 2^26 too): the traversal queues pack (lane, triangle) into 32 bits"); return GI_C_ERROR; }
-  if (bvh.tris.size() >= (1u << 28)) { setError("scene has 2^28 or more triangles after instancing: the hit record packs (triangle, material class) into 32 bits"); return GI_C_ERROR; }
+  if (bvh.tris.size() >= (1u << 26) && !s->twoLevel) {
+    setError("scene has 2^26 or more triangles after instancing and no two-level layout (it is switched off, or its unique mesh triangles exceed 2^26 too): "
+             "the traversal queues pack (lane, triangle) into 32 bits");
+    return GI_C_ERROR;
+  }
+  if (bvh.tris.size() >= (1u << 28)) {
+    setError("scene has 2^28 or more triangles after instancing: the hit record packs (triangle, material class) into 32 bits");
+    return GI_C_ERROR;
+  }
   H.triFaceId.resize(bvh.tris.size());
   for (size_t i = 0; i < bvh.tris.size(); i++) H.triFaceId[i] = faceIdOf[bvh.tris[i].origId];
   // Scenes beyond LDS: one 160-byte shading record per mesh triangle (gi_types.h TriShade); the flattened triangles name theirs in vi[0].  LDS-resident
@@ -417,7 +426,8 @@ int buildScene(GiCScene* s)
         TriShade q{};
         for (int k = 0; k < 3; k++) {
           const GiCVertex v = usableShadingAttributes(m->vertices[f.v_i[k]]);
-          memcpy(q.p[k], v.pos, 12); decodeDirection(encodeDirection(v.norm), q.n[k]); decodeDirection(encodeDirection(v.tangent), q.t[k]); // (Gi.cpp:848-861: quantised, then decoded once)
+          // (Gi.cpp:848-861: quantised, then decoded once)
+          memcpy(q.p[k], v.pos, 12); decodeDirection(encodeDirection(v.norm), q.n[k]); decodeDirection(encodeDirection(v.tangent), q.t[k]);
           q.uv[k][0] = v.u; q.uv[k][1] = v.v; q.bsign[k] = v.bitangentSign; q.vi[k] = mb.vertexOffset + f.v_i[k];
         }
         H.triShade.push_back(q);
@@ -425,14 +435,15 @@ int buildScene(GiCScene* s)
     }
     for (TriRec& t : bvh.tris) t.vi[0] = shadeBaseOfMesh[instances[t.instance].mesh] + t.prim;
   }
-  // LDS-resident scenes (the fused kernels' and k_trace's shading path reads FVertex records): the world-space geometric normal of every flattened triangle, made
-  // here with setup_shading_state's operations in its order (mdl_shading_state.glsl:27-28: normalize(cross(pb - pa, pc - pa)) in object space, the normal transform,
-  // normalize again) -- two normalisations, a cross product and a transform per hit that depend on nothing but the triangle.  Same bits: IEEE + - * / sqrt without
-  // contraction on both sides, as for the decoded FVertex normals.
+  // LDS-resident scenes (the fused kernels' and k_trace's shading path reads FVertex records): the world-space geometric normal of every flattened triangle,
+  // made here with setup_shading_state's operations in its order (mdl_shading_state.glsl:27-28: normalize(cross(pb - pa, pc - pa)) in object space, the normal
+  // transform, normalize again) -- two normalisations, a cross product and a transform per hit that depend on nothing but the triangle.  Same bits: IEEE + - *
+  // / sqrt without contraction on both sides, as for the decoded FVertex normals.
   H.triGeomNormal.clear();
   if (!H.shadePacked) {
     H.triGeomNormal.resize(bvh.tris.size());
-    auto normalize3 = [](float* a) { const float inv = 1.0f / sqrtf((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]); a[0] = a[0] * inv; a[1] = a[1] * inv; a[2] = a[2] * inv; };
+    auto normalize3 = [](float* a) { const float inv = 1.0f / sqrtf((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2]); a[0] = a[0] * inv; a[1] = a[1] * inv;
+        a[2] = a[2] * inv; };
     for (size_t i = 0; i < bvh.tris.size(); i++) {
       const TriRec& t = bvh.tris[i];
       const float* pa = verts[t.vi[0]].pos; const float* pb = verts[t.vi[1]].pos; const float* pc = verts[t.vi[2]].pos;

@@ -90,7 +90,8 @@ __device__ __forceinline__ float gi_expf(float x)
   x = x - fx * 0.693359375f;
   x = x - fx * -2.12194440e-4f;
   float z = x * x;
-  float y = (((((1.9875691500e-4f * x + 1.3981999507e-3f) * x + 8.3334519073e-3f) * x + 4.1665795894e-2f) * x + 1.6666665459e-1f) * x + 5.0000001201e-1f) * z + x + 1.0f;
+  float y = (((((1.9875691500e-4f * x + 1.3981999507e-3f) * x + 8.3334519073e-3f) * x + 4.1665795894e-2f) * x + 1.6666665459e-1f) * x + 5.0000001201e-1f) * z
+            + x + 1.0f;
   return y * u2f((uint32_t)((int)fx + 127) << 23);
 }
 

@@ -60,8 +60,9 @@ void setError(const std::string& e);
 // render buffers, textures and every single-device entry point live there; the others hold replicas of the scene and render row shares.
 struct DevCtx { int device = 0; int cuCount = 256; hipStream_t stream = nullptr; hipStream_t stream2 = nullptr;
     /* the shadow launches of two-stream batches (renderOnDevice "two streams") */
-                int peer = 1; /* 1: the primary device and this one address each other's memory (peer access enabled both ways, or the same physical device); 0: no peer access --
-                                 the device's row shares travel through pinned host memory; -1: hipDeviceCanAccessPeer / EnablePeerAccess failed with an error */ };
+                /* 1: the primary device and this one address each other's memory (peer access enabled both ways, or the same physical device); 0: no peer
+                   access -- the device's row shares travel through pinned host memory; -1: hipDeviceCanAccessPeer / EnablePeerAccess failed with an error */
+                int peer = 1; };
 // One host thread per further device, created with the first multi-device render and kept until giCTerminate (a frame's share is handed to it as a job; until
 // r04 every frame created and joined its own std::threads).  The thread binds its HIP device once.
 struct DeviceWorker {
@@ -111,7 +112,10 @@ struct DeviceBuffer {
   size_t bytes() const { return ptr ? count * sizeof(T) : 0; }
   int upload(const std::vector<T>& v, hipStream_t s)
   {
-    if (const int rc = alloc(v.size())) { if (rc == GI_C_OUT_OF_MEMORY_INTERNAL) setError("hipMalloc: out of device memory (" + std::to_string(v.size() * sizeof(T)) + " bytes)"); return GI_C_ERROR; }
+    if (const int rc = alloc(v.size())) {
+      if (rc == GI_C_OUT_OF_MEMORY_INTERNAL) setError("hipMalloc: out of device memory (" + std::to_string(v.size() * sizeof(T)) + " bytes)");
+      return GI_C_ERROR;
+    }
     if (!v.empty()) HIP_TRY(hipMemcpyAsync(ptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
     return GI_C_OK;
   }
@@ -204,7 +208,8 @@ struct SceneDevice {
   DeviceBuffer<MeshRec> dMeshes; DeviceBuffer<float> dSceneData;
   std::vector<DeviceBuffer<float>*> dTexels; DeviceBuffer<TextureRec> dTextures; // device copies (rebuilt with the materials)
   DeviceBuffer<Node8> dNodes; DeviceBuffer<TriRec> dTris; DeviceBuffer<InstanceRec> dInstances;
-  DeviceBuffer<FVertex> dVerts; DeviceBuffer<MaterialRec> dMaterials; DeviceBuffer<int32_t> dTriFaceId; DeviceBuffer<TriShade> dTriShade; DeviceBuffer<F4> dTriGeomNormal;
+  DeviceBuffer<FVertex> dVerts; DeviceBuffer<MaterialRec> dMaterials; DeviceBuffer<int32_t> dTriFaceId; DeviceBuffer<TriShade> dTriShade;
+      DeviceBuffer<F4> dTriGeomNormal;
   DeviceBuffer<SphereLightRec> dSphere; DeviceBuffer<DistantLightRec> dDistant; DeviceBuffer<RectLightRec> dRect; DeviceBuffer<DiskLightRec> dDisk;
   DeviceBuffer<LightFrame> dRectFrames, dDiskFrames; // decoded tangents + normal per rect / disk light (uploadLights)
   DeviceBuffer<Node8> dTlasNodes, dBlasNodes; DeviceBuffer<uint32_t> dTlasItems, dFlatOfOrig; DeviceBuffer<BlasTri> dBlasTris; DeviceBuffer<InstTrav> dInstTrav;
@@ -261,7 +266,8 @@ struct GiCScene : SceneDevice {
   DenseStore<DistantLightRec, GiCDistantLight> distantLights;
   DenseStore<RectLightRec, GiCRectLight> rectLights;
   DenseStore<DiskLightRec, GiCDiskLight> diskLights;
-  uint32_t lightCounts[4] = {0, 0, 0, 0}; // sphere / distant / rect / disk lights the device arrays hold (uploadLights: the stores' records minus the unusable ones)
+  // sphere / distant / rect / disk lights the device arrays hold (uploadLights: the stores' records minus the unusable ones)
+  uint32_t lightCounts[4] = {0, 0, 0, 0};
   uint32_t sampleOffset = 0;
   bool haveOldParams = false;
   GiCCameraDesc oldCamera{};

@@ -17,7 +17,8 @@ namespace {
 // Image files are untrusted input: dimensions are bounded (and checked against the bytes actually present) BEFORE anything is
 // allocated, so a corrupt header can neither exhaust memory nor index out of bounds.
 constexpr uint64_t MAX_IMAGE_DIM = 65536, MAX_IMAGE_PIXELS = 1ull << 28;
-inline bool saneDims(long long w, long long h) { return w > 0 && h > 0 && (uint64_t)w <= MAX_IMAGE_DIM && (uint64_t)h <= MAX_IMAGE_DIM && (uint64_t)w * (uint64_t)h <= MAX_IMAGE_PIXELS; }
+inline bool saneDims(long long w, long long h)
+{ return w > 0 && h > 0 && (uint64_t)w <= MAX_IMAGE_DIM && (uint64_t)h <= MAX_IMAGE_DIM && (uint64_t)w * (uint64_t)h <= MAX_IMAGE_PIXELS; }
 
 // Minimal decoders for dome-light images: Radiance .hdr (RGBE, flat or new-style RLE scanlines, -Y +X orientation) and
 // .pfm (PF, little or big endian, rows bottom-up).  Output: float RGBA, row 0 = first image row (top).
@@ -27,7 +28,8 @@ static bool decodeHdrOrPfm(const std::vector<uint8_t>& d, uint32_t& w, uint32_t&
   auto line = [&]() { std::string l; while (pos < d.size() && d[pos] != '\n') l.push_back((char)d[pos++]); if (pos < d.size()) pos++; return l; };
   if (d.size() > 2 && d[0] == 'P' && d[1] == 'F') { // PFM
     line();
-    int iw = 0, ih = 0; { std::string l = line(); if (sscanf(l.c_str(), "%d %d", &iw, &ih) != 2) { std::string l2 = line(); iw = atoi(l.c_str()); ih = atoi(l2.c_str()); } }
+    int iw = 0, ih = 0;
+        { std::string l = line(); if (sscanf(l.c_str(), "%d %d", &iw, &ih) != 2) { std::string l2 = line(); iw = atoi(l.c_str()); ih = atoi(l2.c_str()); } }
     const float scale = (float)atof(line().c_str());
     if (!saneDims(iw, ih) || pos + (size_t)iw * ih * 12 > d.size()) return false;
     w = (uint32_t)iw; h = (uint32_t)ih; out.assign((size_t)w * h * 4, 1.0f);
@@ -60,7 +62,8 @@ static bool decodeHdrOrPfm(const std::vector<uint8_t>& d, uint32_t& w, uint32_t&
         while (x < w) {
           if (pos >= d.size()) return false;
           uint8_t n = d[pos++];
-          if (n > 128) { n -= 128; if (pos >= d.size() || x + n > w) return false; uint8_t v = d[pos++]; for (uint8_t k = 0; k < n; k++) scan[(size_t)(x++) * 4 + c] = v; }
+          if (n > 128) { n -= 128; if (pos >= d.size() || x + n > w) return false; uint8_t v = d[pos++];
+              for (uint8_t k = 0; k < n; k++) scan[(size_t)(x++) * 4 + c] = v; }
           else { if (n == 0 || pos + n > d.size() || x + n > w) return false; for (uint8_t k = 0; k < n; k++) scan[(size_t)(x++) * 4 + c] = d[pos++]; }
         }
       }
@@ -120,7 +123,8 @@ static bool decodePng(const std::vector<uint8_t>& d, bool srgbToLinear, uint32_t
       const int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
       int pred = 0;
       if (filter == 1) pred = a; else if (filter == 2) pred = b; else if (filter == 3) pred = (a + b) / 2;
-      else if (filter == 4) { const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c); pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
+      else if (filter == 4) { const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+          pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
       else if (filter != 0) return false;
       cur[i] = (uint8_t)(line[1 + i] + pred);
     }
@@ -196,7 +200,8 @@ static inline int jpegExtend(int v, int s) { return (s && v < (1 << (s - 1))) ? 
 static bool decodeJpeg(const std::vector<uint8_t>& d, bool srgbToLinear, uint32_t& w, uint32_t& h, std::vector<float>& out)
 {
   static const uint8_t zigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
-                                     35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+                                     35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62,
+                                         63};
   if (d.size() < 4 || d[0] != 0xff || d[1] != 0xd8) return false;
   uint16_t qt[4][64]; bool qtDefined[4] = {false, false, false, false};
   JpegHuff hdc[4], hac[4];
@@ -204,7 +209,8 @@ static bool decodeJpeg(const std::vector<uint8_t>& d, bool srgbToLinear, uint32_
   int restartInterval = 0, hmax = 1, vmax = 1;
   bool haveFrame = false;
   float cosTab[8][8]; // cosTab[x][u] = C(u)/2 * cos((2x+1) u pi / 16)
-  for (int x = 0; x < 8; x++) for (int u = 0; u < 8; u++) cosTab[x][u] = (u == 0 ? 0.35355339059327379f : 0.5f) * cosf((float)((2 * x + 1) * u) * 0.19634954084936207f);
+  for (int x = 0; x < 8; x++) for (int u = 0; u < 8; u++) cosTab[x][u] = (u == 0
+      ? 0.35355339059327379f : 0.5f) * cosf((float)((2 * x + 1) * u) * 0.19634954084936207f);
   size_t pos = 2;
   while (pos + 4 <= d.size()) {
     if (d[pos] != 0xff) { pos++; continue; }
@@ -318,7 +324,8 @@ static bool decodeJpeg(const std::vector<uint8_t>& d, bool srgbToLinear, uint32_
           float s[3] = {0.0f, 128.0f, 128.0f};
           for (size_t c = 0; c < comps.size(); c++) s[c] = (float)comps[c].plane[((size_t)y * comps[c].v / vmax) * comps[c].bw + (size_t)x * comps[c].h / hmax];
           float r = s[0], g = s[0], bl = s[0];
-          if (comps.size() == 3) { r = s[0] + 1.402f * (s[2] - 128.0f); g = (s[0] - 0.344136f * (s[1] - 128.0f)) - 0.714136f * (s[2] - 128.0f); bl = s[0] + 1.772f * (s[1] - 128.0f); }
+          if (comps.size() == 3) { r = s[0] + 1.402f * (s[2] - 128.0f); g = (s[0] - 0.344136f * (s[1] - 128.0f)) - 0.714136f * (s[2] - 128.0f);
+              bl = s[0] + 1.772f * (s[1] - 128.0f); }
           float* o = &out[((size_t)y * w + x) * 4];
           const float rgb[3] = {r, g, bl};
           for (int k = 0; k < 3; k++) { float v8 = floorf(rgb[k] + 0.5f); v8 = v8 < 0.0f ? 0.0f : (v8 > 255.0f ? 255.0f : v8); o[k] = toLinear(v8 / 255.0f); }
@@ -346,7 +353,8 @@ bool decodeImageBytes(const uint8_t* bytes, size_t size, bool srgbToLinear, uint
     // (src/imgio/impl/PngDecoder.cpp:78, HdrDecoder.cpp:41, JpegDecoder.cpp; pinned by REF_4C, src/imgio/impl/main.cpp:53-61) and
     // texture coordinate v = 0 addresses the bottom of the picture.  The decoders above produce file order; flip once here.
     const size_t rowFloats = (size_t)w * 4u;
-    for (uint32_t y = 0; y < h / 2u; y++) std::swap_ranges(out.begin() + (size_t)y * rowFloats, out.begin() + (size_t)(y + 1u) * rowFloats, out.begin() + (size_t)(h - 1u - y) * rowFloats);
+    for (uint32_t y = 0; y < h / 2u; y++) std::swap_ranges(out.begin() + (size_t)y * rowFloats, out.begin() + (size_t)(y + 1u) * rowFloats,
+        out.begin() + (size_t)(h - 1u - y) * rowFloats);
     return true;
   } catch (const std::exception&) { return false; } // allocation failure: the caller reports "cannot decode"
 }
@@ -360,7 +368,8 @@ bool readFileBytes(const char* path, std::vector<uint8_t>& d)
   return true;
 }
 
-// 8-bit sRGB -> linear with the PNG decoder's arithmetic (an image handed over as RGBA8 by an external decoder equals the in-library decode of the same PNG bit for bit)
+// 8-bit sRGB -> linear with the PNG decoder's arithmetic (an image handed over as RGBA8
+// by an external decoder equals the in-library decode of the same PNG bit for bit)
 float srgb8ToLinear(uint8_t v) { const float c = (float)v / 255.0f; return c <= 0.04045f ? c / 12.92f : powf((c + 0.055f) / 1.055f, 2.4f); }
 
 } // namespace gi

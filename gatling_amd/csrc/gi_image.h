@@ -9,8 +9,8 @@
 
 namespace gi {
 
-// .hdr (Radiance RGBE), .pfm, .png (8/16-bit gray, gray+alpha, RGB, RGBA, palette; non-interlaced), .jpg (baseline / extended sequential, Huffman).  srgbToLinear applies the sRGB EOTF
-// to the colour channels of 8-bit PNGs (UsdUVTexture sourceColorSpace = sRGB).
+// .hdr (Radiance RGBE), .pfm, .png (8/16-bit gray, gray+alpha, RGB, RGBA, palette; non-interlaced), .jpg (baseline / extended sequential, Huffman).
+// srgbToLinear applies the sRGB EOTF to the colour channels of 8-bit PNGs (UsdUVTexture sourceColorSpace = sRGB).
 // (from the file's bytes: they may come from an asset reader instead of the file system, giCRegisterAssetReader)
 bool decodeImageBytes(const uint8_t* bytes, size_t size, bool srgbToLinear, uint32_t& width, uint32_t& height, std::vector<float>& rgba);
 bool readFileBytes(const char* path, std::vector<uint8_t>& bytes);

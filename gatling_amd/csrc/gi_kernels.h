@@ -1,4 +1,5 @@
-// gi_kernels.h -- host-side launch interface of the stage kernels (gi_kernels.hip, gi_trace.hip, gi_shade.hip, gi_aov.hip) and of the fused ones (gi_path.hip, gi_path_bw.hip).
+// gi_kernels.h -- host-side launch interface of the stage kernels (gi_kernels.hip,
+// gi_trace.hip, gi_shade.hip, gi_aov.hip) and of the fused ones (gi_path.hip, gi_path_bw.hip).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -17,14 +18,19 @@ uint32_t traceStaticLdsBytes(); // static LDS of the traversal kernels on top of
 void traceLdsLayout(const SceneView& sc, uint32_t& ldsNodes, uint32_t& ldsTris, uint32_t& bytes);
 void launchTrace(hipStream_t s, uint32_t blocks, bool anyHit, bool count, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt,
                  uint32_t qIn, uint32_t qMiss, uint32_t dynRefill, uint32_t routeBlocks, const FrameUniforms& U, F4* sampleBuf);
-void launchRoute(hipStream_t s, uint32_t blocks, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t qMiss, const FrameUniforms& U,
+void launchRoute(hipStream_t s, uint32_t blocks, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t qMiss,
+    const FrameUniforms& U,
                  F4* sampleBuf); // (called by launchTrace behind a k_trace_dyn launch)
-constexpr uint32_t APPEND_ITEMS_MAX = 4u; // most records a thread appends per trip of a streaming kernel (k_route ROUTE_ITEMS, k_raygen RAYGEN_ITEMS): sizes the queue shards' slack, gi_render.cpp shardCapacity
-constexpr uint32_t TRACE_DYN_SLOT_ORDER = 0x200u; // flag in dynRefill (shadow launches): children are visited in slot order instead of near-to-far (k_trace_dyn: DYN_SLOT_ORDER)
+// most records a thread appends per trip of a streaming kernel (k_route ROUTE_ITEMS,
+// k_raygen RAYGEN_ITEMS): sizes the queue shards' slack, gi_render.cpp shardCapacity
+constexpr uint32_t APPEND_ITEMS_MAX = 4u;
+// flag in dynRefill (shadow launches): children are visited in slot order instead of near-to-far (k_trace_dyn: DYN_SLOT_ORDER)
+constexpr uint32_t TRACE_DYN_SLOT_ORDER = 0x200u;
 constexpr uint32_t TRACE_DYN_SPILL8 = 0x100u; // flag in dynRefill: 8 LDS stack entries + scratch overflow instead of 16 LDS entries
 // dynRefill: 0 = block-synchronous k_trace; N = scenes that do not fit LDS use k_trace_dyn (a wave refills once N lanes are idle) + k_route
 // one launch per material class present in the scene (the class is the sort key between k_trace and k_shade)
-void launchShade(hipStream_t s, uint32_t blocks, uint32_t klass, bool textured /* some material of the class has textured inputs */, bool volume /* mediumStackSize > 0 */, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par);
+void launchShade(hipStream_t s, uint32_t blocks, uint32_t klass, bool textured /* some material of the class has textured inputs */,
+    bool volume /* mediumStackSize > 0 */, const FrameUniforms& U, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t par);
 
 // Fused persistent path kernel (gi_path.hip) for LDS-resident scenes; launchPath returns the resident blocks per CU it launched with
 bool pathKernelSupports(const SceneView& sc);

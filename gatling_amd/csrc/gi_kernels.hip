@@ -1,5 +1,6 @@
-// gi_kernels.hip -- the wavefront path tracer's stage kernels for gfx950 (CDNA4, wave64): this unit holds the STREAM kernels (k_init, k_raygen, k_route, k_accumulate,
-// the counter and debug helpers); the traversal kernels are in gi_trace.hip, k_shade in gi_shade.hip, k_aov in gi_aov.hip (one unit until round 6).
+// gi_kernels.hip -- the wavefront path tracer's stage kernels for gfx950 (CDNA4, wave64): this unit holds the STREAM kernels (k_init, k_raygen, k_route,
+// k_accumulate, the counter and debug helpers); the traversal kernels are in
+// gi_trace.hip, k_shade in gi_shade.hip, k_aov in gi_aov.hip (one unit until round 6).
 //
 // Replaces the Vulkan ray-tracing megakernel of the reference:
 //   rp_main.rgen  (/root/reference/src/gi/shaders/rp_main.rgen:185-521)  -> k_raygen + the host bounce loop
@@ -45,9 +46,12 @@ __global__ void k_init(PathState st, QueueSet qs, Counters* cnt, uint32_t n, uin
   if (i == 0) {
     if (resetStats) cnt->overflow = 0u; // sticky across the batches of one render: giCRender reads it back once, after the last batch
     cnt->workBase[0].v = 0; cnt->workBase[1].v = 0; for (uint32_t k = 0; k < NCURSOR; k++) { cnt->cursor[0][k].v = 0; cnt->cursor[1][k].v = 0; }
-    if (resetStats) { cnt->shadowOrderRays[0] = 0; cnt->shadowOrderRays[1] = 0; for (int k = 0; k < 16; k++) { cnt->shadowOrderSteps[0][k].v = 0; cnt->shadowOrderSteps[1][k].v = 0; }
-                      cnt->segments = 0; cnt->shadowRays = 0; cnt->nodesVisited = 0; cnt->trisTested = 0; cnt->shadowNodesVisited = 0; cnt->shadowTrisTested = 0;
-                      for (int k = 0; k < 4; k++) { cnt->phaseCycles[k] = 0; cnt->phaseLanes[k] = 0; } cnt->phaseTrips = 0; for (int k = 0; k < 8; k++) cnt->dynStats[k] = 0; }
+    if (resetStats) { cnt->shadowOrderRays[0] = 0; cnt->shadowOrderRays[1] = 0;
+        for (int k = 0; k < 16; k++) { cnt->shadowOrderSteps[0][k].v = 0; cnt->shadowOrderSteps[1][k].v = 0; }
+                      cnt->segments = 0; cnt->shadowRays = 0; cnt->nodesVisited = 0; cnt->trisTested = 0; cnt->shadowNodesVisited = 0;
+                          cnt->shadowTrisTested = 0;
+                      for (int k = 0; k < 4; k++) { cnt->phaseCycles[k] = 0; cnt->phaseLanes[k] = 0; } cnt->phaseTrips = 0;
+                          for (int k = 0; k < 8; k++) cnt->dynStats[k] = 0; }
   }
   for (; i < n; i += gridDim.x * blockDim.x) qs.slot[Q_REGEN_A][(i / per) * qs.cap + (i % per)] = i | REGEN_FRESH; // the slots themselves stay untouched
 }
@@ -57,9 +61,10 @@ __global__ void k_init(PathState st, QueueSet qs, Counters* cnt, uint32_t n, uin
 // term.  Entry i of the regen queue finishes its sample (if any) into the per-sample colour buffer and takes work item
 // w = workBase + i, decoded by work_item (gi_queues.h): by default consecutive entries get consecutive samples of one pixel, pixels in 8x8 blocks.
 // ------------------------------------------------------------------------------------------------
-// FLAG_BOUNDS_RETIRE: can the ray reach the scene at all?  A slab test against the root node's bounds (host: padded beyond the dequantised child boxes), widened per
-// ray by 30 x the rounding error of (plane - origin) * (1 / d) and decided only by comparisons that a NaN fails -- so it answers "misses" for no ray whose walk
-// could accept a triangle (every triangle lies inside its leaf box, every leaf box inside the root's bounds; same contract as the node test).
+// FLAG_BOUNDS_RETIRE: can the ray reach the scene at all?  A slab test against the root node's bounds (host: padded beyond the dequantised child boxes),
+// widened per ray by 30 x the rounding error of (plane - origin) * (1 / d) and decided only by comparisons that a NaN fails -- so it answers "misses" for no
+// ray whose walk could accept a triangle (every triangle lies inside its leaf box, every
+// leaf box inside the root's bounds; same contract as the node test).
 __device__ __forceinline__ bool ray_misses_bounds(const FrameUniforms& U, const V3& o, const V3& d, float tMin, float tMax)
 {
   float tn = tMin, tf = tMax;
@@ -80,9 +85,10 @@ __device__ __forceinline__ bool ray_misses_bounds(const FrameUniforms& U, const 
   return out || tn > tf;
 }
 
-// RAYGEN_ITEMS regen entries per thread and trip: the trip is otherwise two barriers and an atomic round trip around a chain of dependent loads (entry -> slot ->
-// finished sample), and the entries of one thread are independent of each other.
-constexpr int RAYGEN_ITEMS = 2; static_assert(RAYGEN_ITEMS <= (int)APPEND_ITEMS_MAX, "shardCapacity's slack"); // (1 -> 2: raygen stage -6 % on C3 / C4; 4: the same, r05x)
+// RAYGEN_ITEMS regen entries per thread and trip: the trip is otherwise two barriers and an atomic round trip around a chain of dependent loads (entry -> slot
+// -> finished sample), and the entries of one thread are independent of each other.
+// (1 -> 2: raygen stage -6 % on C3 / C4; 4: the same, r05x)
+constexpr int RAYGEN_ITEMS = 2; static_assert(RAYGEN_ITEMS <= (int)APPEND_ITEMS_MAX, "shardCapacity's slack");
 // FLAG_TWO_STREAM: the counters k_trace / k_route of iteration `par`'s parity need zeroed (gi_queues.h zero_closest_counters); one wave
 __global__ __launch_bounds__(64) void k_zero_closest(Counters* cnt, uint32_t par) { zero_closest_counters(cnt, par); }
 // test hook (GATLING_OPTIONS=two_stream_delay): holds a stream for about `ns` nanoseconds so that the other one runs ahead
@@ -136,16 +142,19 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st,
             // 2232-2238).  k_trace routes misses straight here; nothing after the miss can change the sample any more.
             F4 tb = ld4(&S->thr);
             rad = rad + v3(tb.x, tb.y, tb.z) * v3(U.background);
-            if (st.neeKey && (f2u(tb.w) & 0x00000fffu) == 0u) nee_aov_record(st, slot, false); // primary miss: no light sampled, "not shadowed" (rp_main.rgen:431-435)
+            // primary miss: no light sampled, "not shadowed" (rp_main.rgen:431-435)
+            if (st.neeKey && (f2u(tb.w) & 0x00000fffu) == 0u) nee_aov_record(st, slot, false);
           }
           if (st.bouncesAov && U.batchFirstSample + f2u(id.y) == U.spp - 1u) { // Bounces AOV: the pixel's last sample (rp_main.rgen:483-486)
             // a path that left the scene was routed here straight from k_trace, before the loop's bounce++ (rp_main.rgen:480)
-            const uint32_t bounces = ((f2u(S->thr.w) + ((entry & REGEN_MISSED) ? 1u : 0u)) & 0x00000fffu), maxB = U.maxBounces < 0x00000fffu ? U.maxBounces : 0x00000fffu;
+            const uint32_t bounces = ((f2u(S->thr.w) + ((entry & REGEN_MISSED) ? 1u : 0u)) & 0x00000fffu), maxB = U.maxBounces < 0x00000fffu
+                ? U.maxBounces : 0x00000fffu;
             const V3 c = gi_colormap_inferno((float)bounces / (float)maxB);
             F4* dst = &st.bouncesAov[tile_to_image_pixel(U, f2u(id.x))];
             dst->x = c.x; dst->y = c.y; dst->z = c.z;
           }
-          if (st.pathSegments) atomicAdd(&st.pathSegments[f2u(id.x)], (f2u(S->thr.w) + ((entry & REGEN_MISSED) ? 1u : 0u)) & 0x00000fffu); // integer sum: order-free
+          // integer sum: order-free
+          if (st.pathSegments) atomicAdd(&st.pathSegments[f2u(id.x)], (f2u(S->thr.w) + ((entry & REGEN_MISSED) ? 1u : 0u)) & 0x00000fffu);
           float mv = fmax2(rad.x, fmax2(rad.y, rad.z));
           if (mv > U.maxSampleValue) rad = rad * (U.maxSampleValue / mv);
           // one aligned 16-byte store: a 12-byte record straddles DRAM sectors and costs two read-modify-writes
@@ -159,13 +168,15 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st,
           const uint32_t sampleIndex = U.sampleOffset + U.batchFirstSample + sLocal;
           make_camera_ray(U, pixelIndex, sampleIndex, origin, dir, tMin, tMax, rng);
           fresh.rng = rng; fresh.work = w;
-          if (!(U.flags & FLAG_DEFER_SLOT)) slot_begin_path(S, rng, pixelLocal, sLocal); // :274-276 (deferred: written when the first segment hits, route_fresh)
+          // :274-276 (deferred: written when the first segment hits, route_fresh)
+          if (!(U.flags & FLAG_DEFER_SLOT)) slot_begin_path(S, rng, pixelLocal, sLocal);
         }
       }
-      // a camera ray that cannot reach the scene: what k_route does with a fresh miss (retire_fresh_miss; the segment is counted below), minus the 52-byte record,
-      // the traversal step and the routing pass -- the slot goes straight to the next k_raygen
+      // a camera ray that cannot reach the scene: what k_route does with a fresh miss (retire_fresh_miss; the segment is counted below), minus the 52-byte
+      // record, the traversal step and the routing pass -- the slot goes straight to the next k_raygen
       bool again = false;
-      if (boundsRetire && more && ray_misses_bounds(U, origin, dir, tMin, tMax)) { retire_fresh_miss(U, fresh, sampleBuf); more = false; again = true; nRetired++; }
+      if (boundsRetire && more && ray_misses_bounds(U, origin, dir, tMin, tMax)) { retire_fresh_miss(U, fresh, sampleBuf); more = false; again = true;
+          nRetired++; }
       which[k] = more ? 0u : (again ? 1u : 2u);
       slotOf[k] = slot; freshOf[k] = fresh; originOf[k] = origin; dirOf[k] = dir; tMinOf[k] = tMin; tMaxOf[k] = tMax;
     }
@@ -191,7 +202,8 @@ __global__ __launch_bounds__(BLOCK) void k_raygen(FrameUniforms U, PathState st,
 // ------------------------------------------------------------------------------------------------
 // k_accumulate: folds one batch of per-sample colours into the per-pixel running sum IN SAMPLE ORDER
 // (pixel_color += sample_color * invSpp, rp_main.rgen:498) and, after the last batch, writes the colour AOV with
-// the progressive blend of rp_main.rgen:506-515.  One thread per pixel; reads are coalesced across pixels (sample-major buffer) or whole lines per thread (pixel-major).
+// the progressive blend of rp_main.rgen:506-515.  One thread per pixel; reads are
+// coalesced across pixels (sample-major buffer) or whole lines per thread (pixel-major).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_accumulate(FrameUniforms U, const F4* __restrict__ sampleBuf, F4* __restrict__ accum, F4* __restrict__ colorOut,
                                                       uint32_t firstBatch, uint32_t lastBatch)
@@ -235,16 +247,19 @@ __global__ void k_resolve_nee(FrameUniforms U, const unsigned long long* __restr
   dst->x = (k & 1ull) ? 1.0f : 0.0f; dst->y = (k & 1ull) ? 0.0f : 1.0f; dst->z = 0.0f;
 }
 
-// k_route: sorts k_trace_dyn's in-place results by outcome and material class (same routing as k_trace's epilogue).  A streaming pass whose trip is two barriers and
-// one atomic round trip: ROUTE_ITEMS results per thread and trip (independent loads in flight, a quarter of the trips).
-constexpr int ROUTE_ITEMS = 4; static_assert(ROUTE_ITEMS <= (int)APPEND_ITEMS_MAX, "shardCapacity's slack"); // (1 -> 4: trace + route stage -3.5 % on C4 / C5, -0.5 % on C3, r05w)
-__global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t qMiss, FrameUniforms U, F4* __restrict__ sampleBuf)
+// k_route: sorts k_trace_dyn's in-place results by outcome and material class (same routing as k_trace's epilogue).  A streaming pass whose trip is two
+// barriers and one atomic round trip: ROUTE_ITEMS results per thread and trip (independent loads in flight, a quarter of the trips).
+// (1 -> 4: trace + route stage -3.5 % on C4 / C5, -0.5 % on C3, r05w)
+constexpr int ROUTE_ITEMS = 4; static_assert(ROUTE_ITEMS <= (int)APPEND_ITEMS_MAX, "shardCapacity's slack");
+__global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, QueueSet qs, Counters* cnt, uint32_t qIn, uint32_t qMiss, FrameUniforms U,
+    F4* __restrict__ sampleBuf)
 {
   constexpr uint32_t NQ = 1 + MAT_CLASS_COUNT, NONE = NQ;
   __shared__ AppendScratch<NQ> sh;
   QueueReader rd; reader_init(rd, cnt, qIn, qs.cap);
   const uint32_t n = rd.pre[NSHARD];
-  if (blockIdx.x == 0 && (U.flags & FLAG_BOUNDS_RETIRE) && !(U.flags & FLAG_TWO_STREAM)) zero_consumed_regen(cnt, qIn - Q_TRACE_A); // (k_raygen no longer zeroes it: it appends to it; two streams: k_zero_closest does)
+  // (k_raygen no longer zeroes it: it appends to it; two streams: k_zero_closest does)
+  if (blockIdx.x == 0 && (U.flags & FLAG_BOUNDS_RETIRE) && !(U.flags & FLAG_TWO_STREAM)) zero_consumed_regen(cnt, qIn - Q_TRACE_A);
   const uint32_t stride = gridDim.x * BLOCK * ROUTE_ITEMS;
   uint32_t qid[NQ]; qid[0] = qMiss;
 #pragma unroll
@@ -272,8 +287,10 @@ __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, Que
         // the direction is needed at a miss by the dome lookup only (hits stay in place: k_shade gathers them)
         if (miss && sc.domeTexture != 0u) rdir[k] = ld4(&qs.b[qIn][r]);
         if (hit) klass = f2u(h[k].w) >> 28; // k_trace_dyn's result word: triangle index | material class << 28
-        if (klass == SHADE_CLASS_OPBR_BASE && (U.flags & FLAG_MERGE_SHADE_VARIANTS)) klass = 2u; // thin batches: one OpenPBR launch (same bits: gi_shading.h "BASE variant")
-        if (fresh) { // k_shade begins the path (hit); a miss that needs the slot (dome image / medium stack) begins it here, any other retires the sample without a Slot
+        // thin batches: one OpenPBR launch (same bits: gi_shading.h "BASE variant")
+        if (klass == SHADE_CLASS_OPBR_BASE && (U.flags & FLAG_MERGE_SHADE_VARIANTS)) klass = 2u;
+        // k_shade begins the path (hit); a miss that needs the slot (dome image / medium stack) begins it here, any other retires the sample without a Slot
+        if (fresh) {
           if (hit) freshHit = true;
           else {
             const FreshRec f = qs.fresh[qIn - Q_TRACE_A][r];
@@ -286,7 +303,8 @@ __global__ __launch_bounds__(BLOCK) void k_route(SceneView sc, PathState st, Que
           if (volMiss) { miss = false; klass = 2u; }
         }
         slotOf[k] = slot;
-        if (hit || volMiss) { which[k] = 1u + klass; entry[k] = r | (freshHit ? HIT_FRESH : 0u) | (volMiss ? HIT_VOLUME : 0u); } // 4 bytes per hit: the record stays where it is
+        // 4 bytes per hit: the record stays where it is
+        if (hit || volMiss) { which[k] = 1u + klass; entry[k] = r | (freshHit ? HIT_FRESH : 0u) | (volMiss ? HIT_VOLUME : 0u); }
         else { which[k] = 0u; entry[k] = sc.domeTexture ? slot : (slot | (retired ? REGEN_FRESH : REGEN_MISSED)); }
       }
     }
@@ -329,10 +347,12 @@ void launchRaygen(hipStream_t s, uint32_t blocks, const FrameUniforms& U, const 
 }
 void launchAccumulate(hipStream_t s, const FrameUniforms& U, const F4* sampleBuf, F4* accum, F4* colorOut, bool firstBatch, bool lastBatch)
 {
-  hipLaunchKernelGGL(k_accumulate, dim3((U.pixelCount + BLOCK - 1u) / BLOCK), dim3(BLOCK), 0, s, U, sampleBuf, accum, colorOut, firstBatch ? 1u : 0u, lastBatch ? 1u : 0u);
+  hipLaunchKernelGGL(k_accumulate, dim3((U.pixelCount + BLOCK - 1u) / BLOCK), dim3(BLOCK), 0, s, U, sampleBuf, accum, colorOut, firstBatch ? 1u : 0u, lastBatch
+      ? 1u : 0u);
 }
 // k_route behind a k_trace_dyn launch (gi_trace.hip launchTrace)
-void launchRoute(hipStream_t s, uint32_t blocks, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t qMiss, const FrameUniforms& U,
+void launchRoute(hipStream_t s, uint32_t blocks, const SceneView& sc, const PathState& st, const QueueSet& qs, Counters* cnt, uint32_t qIn, uint32_t qMiss,
+    const FrameUniforms& U,
                  F4* sampleBuf)
 {
   hipLaunchKernelGGL(k_route, dim3(blocks), dim3(BLOCK), 0, s, sc, st, qs, cnt, qIn, qMiss, U, sampleBuf);

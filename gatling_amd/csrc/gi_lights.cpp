@@ -146,7 +146,8 @@ GiCDomeLight* giCCreateDomeLight(GiCScene* scene, const char* filePath)
     l->texture = giCCreateTexture(scene, &td);
     l->ownsTexture = l->texture != nullptr;
   } else if (!l->filePath.empty()) {
-    fprintf(stderr, "[gatling_gi] unable to load dome light texture at '%s' (.hdr, .pfm, .png and baseline .jpg are decoded in-library, other formats through giCSetImageLoader)\n", l->filePath.c_str());
+    fprintf(stderr, "[gatling_gi] unable to load dome light texture at '%s' (.hdr, .pfm, .png and baseline .jpg are decoded in-library, other formats through "
+                    "giCSetImageLoader)\n", l->filePath.c_str());
   }
   return l;
 }
@@ -178,14 +179,19 @@ void giCSetDomeLightDiffuseSpecular(GiCDomeLight* l, float d, float s) { std::lo
 
 } // extern "C"
 
-// Hostile input (include/gi_c.h): a light with a non-finite field is left out of the device arrays and of the *LightCount uniforms -- light sampling would turn it into
-// NaN radiance on every path that draws it (the reference uploads it as it is).  The stores keep it: a later setter call with a usable value brings it back.
+// Hostile input (include/gi_c.h): a light with a non-finite field is left out of the device arrays and of the *LightCount uniforms -- light sampling would turn
+// it into NaN radiance on every path that draws it (the reference uploads it as it
+// is).  The stores keep it: a later setter call with a usable value brings it back.
 static bool usableHalfPair(uint32_t ds) { return std::isfinite(f16ToF32((uint16_t)(ds & 0xffffu))) && std::isfinite(f16ToF32((uint16_t)(ds >> 16))); }
 template <size_t N> static bool allFinite(const float (&v)[N]) { for (float x : v) if (!std::isfinite(x)) return false; return true; }
-static bool usableLight(const SphereLightRec& l) { return allFinite(l.pos) && allFinite(l.em) && allFinite(l.radius) && std::isfinite(l.area) && usableHalfPair(l.ds); }
-static bool usableLight(const DistantLightRec& l) { return allFinite(l.dir) && allFinite(l.em) && std::isfinite(l.angle) && std::isfinite(l.invPdf) && usableHalfPair(l.ds); }
-static bool usableLight(const RectLightRec& l) { return allFinite(l.origin) && allFinite(l.em) && std::isfinite(l.width) && std::isfinite(l.height) && usableHalfPair(l.ds); }
-static bool usableLight(const DiskLightRec& l) { return allFinite(l.origin) && allFinite(l.em) && std::isfinite(l.rx) && std::isfinite(l.ry) && usableHalfPair(l.ds); }
+static bool usableLight(const SphereLightRec& l)
+{ return allFinite(l.pos) && allFinite(l.em) && allFinite(l.radius) && std::isfinite(l.area) && usableHalfPair(l.ds); }
+static bool usableLight(const DistantLightRec& l)
+{ return allFinite(l.dir) && allFinite(l.em) && std::isfinite(l.angle) && std::isfinite(l.invPdf) && usableHalfPair(l.ds); }
+static bool usableLight(const RectLightRec& l)
+{ return allFinite(l.origin) && allFinite(l.em) && std::isfinite(l.width) && std::isfinite(l.height) && usableHalfPair(l.ds); }
+static bool usableLight(const DiskLightRec& l)
+{ return allFinite(l.origin) && allFinite(l.em) && std::isfinite(l.rx) && std::isfinite(l.ry) && usableHalfPair(l.ds); }
 template <class Rec> static std::vector<Rec> usableLights(const std::vector<Rec>& in, const char* kind)
 {
   std::vector<Rec> out; out.reserve(in.size());
@@ -215,7 +221,8 @@ int uploadLights(GiCScene* s)
   const std::vector<RectLightRec> rect = usableLights(s->rectLights.recs, "rect");
   const std::vector<DiskLightRec> disk = usableLights(s->diskLights.recs, "disk");
   const std::vector<LightFrame> rectFrames = lightFrames(rect), diskFrames = lightFrames(disk);
-  s->lightCounts[0] = (uint32_t)sphere.size(); s->lightCounts[1] = (uint32_t)distant.size(); s->lightCounts[2] = (uint32_t)rect.size(); s->lightCounts[3] = (uint32_t)disk.size();
+  s->lightCounts[0] = (uint32_t)sphere.size(); s->lightCounts[1] = (uint32_t)distant.size(); s->lightCounts[2] = (uint32_t)rect.size();
+      s->lightCounts[3] = (uint32_t)disk.size();
   const uint32_t nDev = std::min<uint32_t>(sceneDeviceCount(s), (uint32_t)s->replicas.size() + 1u);
   for (uint32_t d = 0; d < nDev; d++) {
     SceneDevice& D = sceneDevice(s, d);

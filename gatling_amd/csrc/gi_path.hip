@@ -35,7 +35,8 @@ constexpr uint32_t PATH_STACK_MAX = 8; // LDS traversal-stack entries per lane: 
 
 constexpr int PATH_WAVES = 4; // resident waves per SIMD the register allocation aims for (114 VGPRs without a hint; 3 cost 11 %, 5 spill 26 registers: r03)
 template <uint32_t KLASS, bool TEXTURED, bool NEE, bool CUTOUT, bool COUNT, uint32_t PATH_STACK>
-__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(PATH_WAVES, 8))) void k_path(FrameUniforms U, SceneView sc, PathState st, Counters* cnt, F4* __restrict__ sampleBuf,
+__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(PATH_WAVES, 8))) void k_path(FrameUniforms U, SceneView sc, PathState st,
+    Counters* cnt, F4* __restrict__ sampleBuf,
                                                       uint32_t ldsNodes, uint32_t ldsTris, uint32_t chunk)
 {
   extern __shared__ uint4 s_dyn[];
@@ -68,7 +69,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(PAT
   uint32_t preHead = 0u, preTail = 0u; // wave-uniform ring positions (monotonic; slot = position & 127)
 
   unsigned long long pc[4] = {0ull, 0ull, 0ull, 0ull}, pl[4] = {0ull, 0ull, 0ull, 0ull}, trips = 0ull, tPrev = COUNT ? __builtin_readcyclecounter() : 0ull;
-  auto phase = [&](int k, unsigned long long lanes) { if (COUNT) { const unsigned long long t = __builtin_readcyclecounter(); pc[k] += t - tPrev; tPrev = t; pl[k] += lanes; } };
+  auto phase = [&](int k,
+      unsigned long long lanes) { if (COUNT) { const unsigned long long t = __builtin_readcyclecounter(); pc[k] += t - tPrev; tPrev = t; pl[k] += lanes; } };
   for (;;) {
     __atomic_signal_fence(__ATOMIC_SEQ_CST); // (compiler only) the ring is exchanged between the lanes of this wave through LDS
     // --- regeneration (rp_main.rgen:213-283): idle lanes take the next work items w = sample * P + pixel
@@ -89,7 +91,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(PAT
           const uint32_t w = chunkNext + lane;
           const uint32_t pl = w % U.pixelCount, sl = w / U.pixelCount;
           V3 o, d; float t0, t1; uint32_t r;
-          make_camera_ray(U, tile_to_image_pixel(U, pl), U.sampleOffset + U.batchFirstSample + sl, o, d, t0, t1, r); // :195 (global pixel index: the RNG is tile independent)
+          // :195 (global pixel index: the RNG is tile independent)
+          make_camera_ray(U, tile_to_image_pixel(U, pl), U.sampleOffset + U.batchFirstSample + sl, o, d, t0, t1, r);
           const uint32_t slot = (preTail + lane) & 127u;
           pre[0][slot] = f2u(o.x); pre[1][slot] = f2u(o.y); pre[2][slot] = f2u(o.z); pre[3][slot] = f2u(d.x); pre[4][slot] = f2u(d.y); pre[5][slot] = f2u(d.z);
           pre[6][slot] = f2u(t0); pre[7][slot] = f2u(t1); pre[8][slot] = r; pre[9][slot] = w;
@@ -118,7 +121,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(PAT
     wave_ray_begin(W, R.tBest);
     bool tAlive = alive;
     while (__ballot(tAlive)) {
-      if (wave_step<false, COUNT, PATH_STACK, false, true, CUTOUT>(R, tAlive, W, sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, overflow, tc, rng)) tAlive = false;
+      if (wave_step<false, COUNT, PATH_STACK, false, true,
+          CUTOUT>(R, tAlive, W, sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, overflow, tc, rng)) tAlive = false;
     }
     bool ended = false, missed = false;
     ShadeIO io; io.shadow = false; io.shadowFirst = false; io.cont = false;
@@ -131,7 +135,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(PAT
         const F4 h = F4{R.tBest, R.bestU, R.bestV, u2f(R.bestTri)}, rd = F4{rdv.x, rdv.y, rdv.z, 0.0f};
         shade_segment<KLASS, TEXTURED, false, NEE>(U, sc, nullptr, h, rd, io);
         thr = io.throughput; rad = io.radiance; bitfield = io.bitfield; rng = io.rng;
-        if (NEE && st.neeKey && io.shadowFirst && !io.shadow) nee_aov_record_px(st, pixelLocal, sLocal, false); // untraced shadow ray == "not shadowed" (rp_main.rgen:431-435)
+        // untraced shadow ray == "not shadowed" (rp_main.rgen:431-435)
+        if (NEE && st.neeKey && io.shadowFirst && !io.shadow) nee_aov_record_px(st, pixelLocal, sLocal, false);
         ended = !io.cont;
       } else { // rp_main.miss:68-86: uniform fallback dome == colour clear value; the loop's bounce++ still happens (rp_main.rgen:480)
         rad = rad + thr * v3(U.background);
@@ -151,7 +156,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(PAT
         wave_ray_begin(W, R.tBest);
         const bool traced = sAlive;
         while (__ballot(sAlive)) {
-          if (wave_step<true, COUNT, PATH_STACK, false, true, CUTOUT>(R, sAlive, W, sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, overflow, tcs, io.rngShadow)) sAlive = false;
+          if (wave_step<true, COUNT, PATH_STACK, false, true,
+              CUTOUT>(R, sAlive, W, sc, s_nodes, ldsNodes, s_tris, ldsTris, s_stack, overflow, tcs, io.rngShadow)) sAlive = false;
         }
         if (traced) {
           nShadow++;
@@ -181,7 +187,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(PAT
     phase(3, (unsigned long long)__popcll(__ballot(ended)));
   }
 
-  if (COUNT && lane == 0u) { for (int k = 0; k < 4; k++) { atomicAdd(&cnt->phaseCycles[k], pc[k]); atomicAdd(&cnt->phaseLanes[k], pl[k]); } atomicAdd(&cnt->phaseTrips, trips); }
+  if (COUNT
+      && lane == 0u) { for (int k = 0; k < 4; k++) { atomicAdd(&cnt->phaseCycles[k], pc[k]); atomicAdd(&cnt->phaseLanes[k], pl[k]);
+      } atomicAdd(&cnt->phaseTrips, trips); }
   // statistics: one atomic per wave and counter
   unsigned long long a = nSeg, b = nShadow, c = tc.nodes, d = tc.tris, e = tcs.nodes, f = tcs.tris;
   for (int off = 32; off > 0; off >>= 1) {
@@ -191,7 +199,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(PAT
   if (lane == 0u) {
     atomicAdd(&cnt->segments, a);
     if (NEE) atomicAdd(&cnt->shadowRays, b);
-    if (COUNT) { atomicAdd(&cnt->nodesVisited, c); atomicAdd(&cnt->trisTested, d); atomicAdd(&cnt->shadowNodesVisited, e); atomicAdd(&cnt->shadowTrisTested, f); }
+    if (COUNT) { atomicAdd(&cnt->nodesVisited, c); atomicAdd(&cnt->trisTested, d); atomicAdd(&cnt->shadowNodesVisited, e); atomicAdd(&cnt->shadowTrisTested, f);
+        }
   }
 }
 
@@ -200,8 +209,11 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(PAT
 // ------------------------------------------------------------------------------------------------
 bool pathKernelSupports(const SceneView& sc)
 {
-  return sc.triCount > 0u && sc.nodeCount <= LDS_NODES && sc.triCount <= LDS_TRIS && sc.bvhDepth <= PATH_STACK_MAX && sc.mediumStackSize == 0u && sc.domeTexture == 0u && !sc.twoLevel
-         && !sc.shadePacked; // (a scene whose shading records are packed -- never an LDS-resident one today: TriRec::vi[0] is a shading-record index there, the fused kernels read vertex indices)
+  return sc.triCount > 0u && sc.nodeCount <= LDS_NODES && sc.triCount <= LDS_TRIS && sc.bvhDepth <= PATH_STACK_MAX && sc.mediumStackSize == 0u
+      && sc.domeTexture == 0u && !sc.twoLevel
+         // (a scene whose shading records are packed -- never an LDS-resident one today:
+         // TriRec::vi[0] is a shading-record index there, the fused kernels read vertex indices)
+         && !sc.shadePacked;
 }
 
 using PathKernel = void (*)(FrameUniforms, SceneView, PathState, Counters*, F4*, uint32_t, uint32_t, uint32_t);
@@ -227,7 +239,8 @@ int launchPath(hipStream_t s, uint32_t cuCount, uint32_t classMask, bool texture
   const uint32_t stack = sc.bvhDepth <= 4u ? 4u : 8u;
   const uint32_t bytes = stack * TRACE_BLOCK * (uint32_t)sizeof(uint2) + ldsNodes * 80u + ldsTris * 48u;
   const bool neeOn = (U.flags & FLAG_NEE) != 0u;
-  PathKernel k = stack == 4u ? pickPathKernel<4u>(classMask, textured, neeOn, sc.hasCutouts != 0u, count) : pickPathKernel<8u>(classMask, textured, neeOn, sc.hasCutouts != 0u, count);
+  PathKernel k = stack == 4u
+      ? pickPathKernel<4u>(classMask, textured, neeOn, sc.hasCutouts != 0u, count) : pickPathKernel<8u>(classMask, textured, neeOn, sc.hasCutouts != 0u, count);
   // Resident blocks per CU (4 waves per block = 1 wave per SIMD and block): the smaller of what the 160 KiB of LDS and the 512-entry
   // register file of a SIMD hold.  (hipOccupancyMaxActiveBlocksPerMultiprocessor answered 3 for a 35 KiB block: it does not know gfx950's LDS size.)
   int perCu = 2;

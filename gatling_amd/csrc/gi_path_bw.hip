@@ -32,15 +32,20 @@
 namespace gi {
 
 // per-path state in LDS, one array of PW dwords per field
-enum : uint32_t { F_THR = 0, F_RAD = 3, F_BITS = 6, F_RNG = 7, F_WORK = 8, F_RO = 9 /* origin, or the hit (t, u, v) */, F_RD = 12, F_TMIN = 15 /* tMin, or the hit triangle */,
+enum : uint32_t { F_THR = 0, F_RAD = 3, F_BITS = 6, F_RNG = 7, F_WORK = 8, F_RO = 9 /* origin, or the hit (t, u, v) */, F_RD = 12,
+    F_TMIN = 15 /* tMin, or the hit triangle */,
                   F_TMAX = 16, F_COUNT = 17 };
 constexpr uint32_t NO_WORK = 0xffffffffu; // F_WORK of a path that carries no sample (initial state)
-constexpr uint32_t PATH_BW_PATHS_DEFAULT = 96u; // paths per wave (a compile-time choice since the environment interface shrank): 3 blocks per CU; measured 96 / 128 / 160 / 192 / 256 -> 7426 / 6431 / 6621 / 6651 / 3814 Msamples/s on C2
+// paths per wave (a compile-time choice since the environment interface shrank): 3 blocks per
+// CU; measured 96 / 128 / 160 / 192 / 256 -> 7426 / 6431 / 6621 / 6651 / 3814 Msamples/s on C2
+constexpr uint32_t PATH_BW_PATHS_DEFAULT = 96u;
 
 constexpr int PATH_BW_WAVES = 3; // resident waves per SIMD the register allocation aims for (168 VGPRs: 3; 4 needs <= 128 and spills 43 registers)
 template <uint32_t KLASS, bool TEXTURED, bool CUTOUT, bool COUNT, uint32_t STACK>
-__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(PATH_BW_WAVES, 8))) void k_path_bw(FrameUniforms U, SceneView sc, PathState st, Counters* cnt, F4* __restrict__ sampleBuf,
-                                                         uint32_t ldsNodes, uint32_t ldsTris, uint32_t chunk, uint32_t PW, uint32_t thrShade, uint32_t thrRegen, uint32_t thrDry)
+__global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(PATH_BW_WAVES, 8))) void k_path_bw(FrameUniforms U, SceneView sc, PathState st,
+    Counters* cnt, F4* __restrict__ sampleBuf,
+                                                         uint32_t ldsNodes, uint32_t ldsTris, uint32_t chunk, uint32_t PW, uint32_t thrShade, uint32_t thrRegen,
+                                                             uint32_t thrDry)
 {
   extern __shared__ uint4 s_dyn[];
   uint2 (*s_stack)[TRACE_BLOCK] = reinterpret_cast<uint2 (*)[TRACE_BLOCK]>(s_dyn);
@@ -150,7 +155,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(PAT
         const uint32_t pixelIndex = tile_to_image_pixel(U, pixelLocal); // :195 (global index: the RNG is tile independent)
         V3 ro, rdv; float tMin, tMax; uint32_t rng;
         make_camera_ray(U, pixelIndex, U.sampleOffset + U.batchFirstSample + sLocal, ro, rdv, tMin, tMax, rng);
-        stf(F_THR, p, 1.0f); stf(F_THR + 1u, p, 1.0f); stf(F_THR + 2u, p, 1.0f); stf(F_RAD, p, 0.0f); stf(F_RAD + 1u, p, 0.0f); stf(F_RAD + 2u, p, 0.0f); // :274-276
+        // :274-276
+        stf(F_THR, p, 1.0f); stf(F_THR + 1u, p, 1.0f); stf(F_THR + 2u, p, 1.0f); stf(F_RAD, p, 0.0f); stf(F_RAD + 1u, p, 0.0f); stf(F_RAD + 2u, p, 0.0f);
         stu(F_BITS, p, 0u); stu(F_RNG, p, rng); stu(F_WORK, p, myWork);
         stf(F_RO, p, ro.x); stf(F_RO + 1u, p, ro.y); stf(F_RO + 2u, p, ro.z); stf(F_RD, p, rdv.x); stf(F_RD + 1u, p, rdv.y); stf(F_RD + 2u, p, rdv.z);
         stf(F_TMIN, p, tMin); stf(F_TMAX, p, tMax);
@@ -168,7 +174,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) __attribute__((amdgpu_waves_per_eu(PAT
       if (!alive && rank < take) {
         const uint32_t p = qT[nT - 1u - rank];
         myPath = p; if (CUTOUT) myRng = ldu(F_RNG, p);
-        trav_init(R, v3(ldf(F_RO, p), ldf(F_RO + 1u, p), ldf(F_RO + 2u, p)), v3(ldf(F_RD, p), ldf(F_RD + 1u, p), ldf(F_RD + 2u, p)), ldf(F_TMIN, p), ldf(F_TMAX, p));
+        trav_init(R, v3(ldf(F_RO, p), ldf(F_RO + 1u, p), ldf(F_RO + 2u, p)), v3(ldf(F_RD, p), ldf(F_RD + 1u, p), ldf(F_RD + 2u, p)), ldf(F_TMIN, p),
+            ldf(F_TMAX, p));
         wave_ray_begin(W, R.tBest);
         alive = true;
       }
@@ -230,7 +237,8 @@ int launchPathBw(hipStream_t s, uint32_t cuCount, uint32_t classMask, bool textu
   const uint32_t ldsNodes = sc.nodeCount, ldsTris = sc.triCount;
   const uint32_t stack = sc.bvhDepth <= 4u ? 4u : 8u;
   const uint32_t bytes = stack * TRACE_BLOCK * (uint32_t)sizeof(uint2) + ldsNodes * 80u + ldsTris * 48u + (TRACE_BLOCK / 64u) * (F_COUNT + 3u) * PW * 4u;
-  PathBwKernel k = stack == 4u ? pickPathBwKernel<4u>(classMask, textured, sc.hasCutouts != 0u, count) : pickPathBwKernel<8u>(classMask, textured, sc.hasCutouts != 0u, count);
+  PathBwKernel k = stack == 4u
+      ? pickPathBwKernel<4u>(classMask, textured, sc.hasCutouts != 0u, count) : pickPathBwKernel<8u>(classMask, textured, sc.hasCutouts != 0u, count);
   int perCu = 2;
   hipFuncAttributes fa{};
   if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k)) == hipSuccess && fa.numRegs > 0) {

@@ -52,9 +52,11 @@ __device__ __forceinline__ void block_append(AppendScratch<NQ>& sh, uint32_t tri
 }
 
 // The same with ITEMS records per thread and trip (k_route, whose trip is otherwise the two barriers and the atomic's round trip: 0.33 ms per launch on C4 for
-// 8 GB of traffic): `which[k]` names the queue item k of this thread goes to (>= NQ: none).  One atomic per block, queue and trip as before, now for ITEMS * 256 records.
+// 8 GB of traffic): `which[k]` names the queue item k of this thread goes to (>= NQ:
+// none).  One atomic per block, queue and trip as before, now for ITEMS * 256 records.
 template <int NQ, int ITEMS>
-__device__ __forceinline__ void block_append_items(AppendScratch<NQ>& sh, uint32_t trip, const uint32_t (&which)[ITEMS], const uint32_t (&qid)[NQ], uint32_t cap,
+__device__ __forceinline__ void block_append_items(AppendScratch<NQ>& sh, uint32_t trip, const uint32_t (&which)[ITEMS], const uint32_t (&qid)[NQ],
+    uint32_t cap,
                                                    Counters* cnt, uint32_t (&outIdx)[ITEMS])
 {
   const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6, par = trip & 1u, shard = blockIdx.x % NSHARD;
@@ -106,7 +108,8 @@ __device__ __forceinline__ void reader_init(QueueReader& r, const Counters* cnt,
 {
   r.pre[0] = 0;
 #pragma unroll
-  for (uint32_t s = 0; s < NSHARD; s++) { const uint32_t c = cnt->count[q][s].v; r.pre[s + 1] = r.pre[s] + (c < cap ? c : cap); } // (clamped: see Counters::overflow)
+  // (clamped: see Counters::overflow)
+  for (uint32_t s = 0; s < NSHARD; s++) { const uint32_t c = cnt->count[q][s].v; r.pre[s + 1] = r.pre[s] + (c < cap ? c : cap); }
   r.cap = cap;
 }
 __device__ __forceinline__ uint32_t reader_index(const QueueReader& r, uint32_t i)
@@ -155,26 +158,28 @@ __device__ __forceinline__ size_t sample_record(const FrameUniforms& U, uint32_t
 }
 constexpr uint32_t MISS = 0xffffffffu;
 // HIT queues (round 4): an entry is the INDEX of the ray's record in the TRACE queue it was traced from (k_trace_dyn / k_trace leave the result in place there:
-// a = (t, u, v, triangle | class << 28) or (tMax, origin.xy, MISS), b = (direction, - | origin.z)) plus two flags; k_shade gathers the record.  Until then k_route
-// copied 36 bytes per hit into the class queue.
+// a = (t, u, v, triangle | class << 28) or (tMax, origin.xy, MISS), b = (direction, - | origin.z)) plus two flags; k_shade gathers the record.  Until then
+// k_route copied 36 bytes per hit into the class queue.
 constexpr uint32_t HIT_FRESH = 0x80000000u;    // first hit of a path whose Slot is still unwritten: FreshRec beside the ray record has its rng / work item
 constexpr uint32_t HIT_VOLUME = 0x40000000u;   // not a hit: the segment ended inside a medium (scattering event, rp_main.miss:57-66)
 constexpr uint32_t HIT_INDEX_MASK = 0x3fffffffu;
-constexpr uint32_t TRACE_FRESH = 0x80000000u;  // flag on a TRACE-queue slot word (FLAG_DEFER_SLOT): a camera ray whose Slot is still unwritten -- QueueSet::fresh holds its rng / work item
+// flag on a TRACE-queue slot word (FLAG_DEFER_SLOT): a camera ray whose Slot is still unwritten -- QueueSet::fresh holds its rng / work item
+constexpr uint32_t TRACE_FRESH = 0x80000000u;
 constexpr uint32_t REGEN_MISSED = 0x80000000u; // flag on a regen-queue entry: the path left the scene (k_trace -> k_raygen)
-constexpr uint32_t REGEN_FRESH = 0x40000000u;  // flag on a regen-queue entry written by k_init: the slot carries no sample yet and its memory is uninitialised -- k_raygen
-                                               // must not read it (this replaces a 64-byte write per slot in k_init: 4 GB and 2 ms per batch for the 64 Mi-slot pool)
+// flag on a regen-queue entry written by k_init: the slot carries no sample yet and its memory is uninitialised -- k_raygen
+// must not read it (this replaces a 64-byte write per slot in k_init: 4 GB and 2 ms per batch for the 64 Mi-slot pool)
+constexpr uint32_t REGEN_FRESH = 0x40000000u;
 
 // Zeroes the counters of the queues that the producers of iteration `it` will append to.  Called by one thread of
 // k_raygen(it): none of these queues is read or appended by k_raygen(it) itself (it reads REGEN[it&1] and appends
 // TRACE[it&1]), and their previous consumers finished in iteration it-1 (stream order).
 // `zeroRegen` false (FLAG_BOUNDS_RETIRE): k_raygen(it) itself appends to REGEN[(it&1)^1], so that counter is zeroed one kernel earlier, by k_route(it-1)
 // (zero_consumed_regen), which runs after its last reader k_raygen(it-1).
-// FLAG_TWO_STREAM (`twoStream`): iteration `it` runs  k_zero_closest, [k_raygen if it == 0,] k_trace, k_route, <wait for the shadow launch of it-1>, [k_raygen if it > 0,]
-// k_shade  on the main stream and its shadow launch on the second one.  k_raygen(it) then zeroes only what lies between it and the end of the iteration: TRACE[(it&1)^1]
-// (appended by k_shade(it); its count was last read by k_trace / k_route(it-1)), the SHADOW queue's counter and the shadow cursors (read by the shadow launch of it-1,
-// which k_raygen(it) has waited for; appended / used by k_shade(it) and its shadow launch).  What k_trace / k_route(it) append to or claim from is zeroed by
-// k_zero_closest(it) in front of them (zero_closest_counters).
+// FLAG_TWO_STREAM (`twoStream`): iteration `it` runs  k_zero_closest, [k_raygen if it == 0,] k_trace, k_route, <wait for the shadow launch of it-1>, [k_raygen
+// if it > 0,] k_shade  on the main stream and its shadow launch on the second one.  k_raygen(it) then zeroes only what lies between it and the end of the
+// iteration: TRACE[(it&1)^1] (appended by k_shade(it); its count was last read by k_trace / k_route(it-1)), the SHADOW queue's counter and the shadow cursors
+// (read by the shadow launch of it-1, which k_raygen(it) has waited for; appended / used by k_shade(it) and its shadow launch).  What k_trace / k_route(it)
+// append to or claim from is zeroed by k_zero_closest(it) in front of them (zero_closest_counters).
 __device__ __forceinline__ void zero_next_counters(Counters* cnt, uint32_t par, bool zeroRegen, bool twoStream = false)
 {
   const uint32_t t = threadIdx.x;
@@ -186,8 +191,8 @@ __device__ __forceinline__ void zero_next_counters(Counters* cnt, uint32_t par, 
   }
   if (t < 2u * NCURSOR && (!twoStream || t >= NCURSOR)) cnt->cursor[t / NCURSOR][t % NCURSOR].v = 0; // k_trace_dyn's ray cursors (closest, shadow)
 }
-// k_zero_closest(it) (FLAG_TWO_STREAM), in front of k_trace(it): the HIT queues (last read by k_shade(it-1), appended by k_route(it)), REGEN[(it&1)^1] (last read by
-// k_raygen(it-1); appended by k_raygen(0)'s bounds retire, k_route(it) and k_shade(it)) and the closest-hit cursors (k_trace(it-1))
+// k_zero_closest(it) (FLAG_TWO_STREAM), in front of k_trace(it): the HIT queues (last read by k_shade(it-1), appended by k_route(it)), REGEN[(it&1)^1] (last
+// read by k_raygen(it-1); appended by k_raygen(0)'s bounds retire, k_route(it) and k_shade(it)) and the closest-hit cursors (k_trace(it-1))
 __device__ __forceinline__ void zero_closest_counters(Counters* cnt, uint32_t par)
 {
   const uint32_t t = threadIdx.x;

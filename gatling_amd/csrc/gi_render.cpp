@@ -9,11 +9,13 @@ SceneView makeView(GiCScene* s, SceneDevice& D)
   SceneView v{};
   v.textures = D.dTextures.ptr; v.meshes = D.dMeshes.ptr; v.sceneData = D.dSceneData.ptr;
   v.nodes = D.dNodes.ptr; v.tris = D.dTris.ptr; v.instances = D.dInstances.ptr;
-  v.verts = D.dVerts.ptr; v.triShade = D.dTriShade.ptr; v.triGeomNormal = D.dTriGeomNormal.ptr; v.shadePacked = s->shadePacked ? 1u : 0u; v.materials = D.dMaterials.ptr;
+  v.verts = D.dVerts.ptr; v.triShade = D.dTriShade.ptr; v.triGeomNormal = D.dTriGeomNormal.ptr; v.shadePacked = s->shadePacked ? 1u : 0u;
+      v.materials = D.dMaterials.ptr;
       v.sphereLights = D.dSphere.ptr; v.distantLights = D.dDistant.ptr;
   v.tlasNodes = D.dTlasNodes.ptr; v.tlasItems = D.dTlasItems.ptr; v.blasNodes = D.dBlasNodes.ptr; v.blasTris = D.dBlasTris.ptr; v.instTrav = D.dInstTrav.ptr;
       v.flatOfOrig = D.dFlatOfOrig.ptr; v.twoLevel = s->twoLevel ? 1u : 0u;
-  v.rectLights = D.dRect.ptr; v.diskLights = D.dDisk.ptr; v.rectFrames = D.dRectFrames.ptr; v.diskFrames = D.dDiskFrames.ptr; v.triFaceId = D.dTriFaceId.ptr; v.nodeCount = s->nodeCount; v.triCount = s->triCount;
+  v.rectLights = D.dRect.ptr; v.diskLights = D.dDisk.ptr; v.rectFrames = D.dRectFrames.ptr; v.diskFrames = D.dDiskFrames.ptr; v.triFaceId = D.dTriFaceId.ptr;
+      v.nodeCount = s->nodeCount; v.triCount = s->triCount;
       v.bvhDepth = s->bvhDepth; v.hasCutouts = s->hasCutouts ? 1u : 0u;
   return v;
 }
@@ -301,7 +303,8 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
     auto planBytes = [&](size_t nSlots, uint64_t nBatch) -> uint64_t {
       const uint64_t cap = shardCapacity(nSlots, wideBlocks, traceBlocks);
       const uint64_t perQueueEntry = 4ull * Q_COUNT + 32ull * (2 + 1) + 16ull + 8ull * 2;
-      return (fused ? 0ull : (uint64_t)nSlots * (sizeof(Slot) + 4ull * mediaStride) + cap * NSHARD * perQueueEntry) + (uint64_t)pixels * nBatch * 16ull + (uint64_t)pixels * 16ull;
+      return (fused ? 0ull : (uint64_t)nSlots * (sizeof(Slot) + 4ull * mediaStride) + cap * NSHARD * perQueueEntry) + (uint64_t)pixels * nBatch * 16ull
+             + (uint64_t)pixels * 16ull;
     };
     // the caller's sizes are taken as given
     const bool pinnedPlan = optionSet("pool_slots") || s->optPoolSlots || optionSet("sample_buffer_mb") || s->optSampleBufferMb;
@@ -440,12 +443,14 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
       }
       const uint64_t rounds = ((uint64_t)U.workTotal + poolNow - 1) / poolNow; // raygen rounds needed to hand out all work
       const uint64_t maxIters = (rounds + 2) * (std::max(1u, U.maxBounces) + 1) + 8;
-      // A thin batch (its work fits the pool and is small: the delegate's one sample per pixel and call) launches every kernel of an iteration for a few thousand hits:
-      // a further k_shade launch per iteration costs it more (C4: 13 x ~9 us of a 2.7 ms call) than the BASE variant saves, so its BASE hits are binned with class 2
-      // (GATLING_OPTIONS=merge_shade_variants=0 | 1: never | always)
+      // A thin batch (its work fits the pool and is small: the delegate's one sample per
+      // pixel and call) launches every kernel of an iteration for a few thousand hits:
+      // a further k_shade launch per iteration costs it more (C4: 13 x ~9 us of a 2.7 ms call) than the BASE variant saves, so its BASE hits are binned with
+      // class 2 (GATLING_OPTIONS=merge_shade_variants=0 | 1: never | always)
       const long mergeOpt = optionValue("merge_shade_variants", -1);
       const bool thinBatch = rounds == 1 && U.workTotal <= (8u << 20);
-      if ((mergeOpt < 0 ? thinBatch : mergeOpt != 0) && (s->shadeClassMask & (1u << SHADE_CLASS_OPBR_BASE)) && (s->shadeClassMask & 4u)) U.flags |= FLAG_MERGE_SHADE_VARIANTS;
+      if ((mergeOpt < 0 ? thinBatch : mergeOpt != 0) && (s->shadeClassMask & (1u << SHADE_CLASS_OPBR_BASE))
+          && (s->shadeClassMask & 4u)) U.flags |= FLAG_MERGE_SHADE_VARIANTS;
       else U.flags &= ~FLAG_MERGE_SHADE_VARIANTS;
       const bool two = twoStreamOk && rounds == 1 && !iterLog;
       if (two) U.flags |= FLAG_TWO_STREAM; else U.flags &= ~FLAG_TWO_STREAM;
@@ -493,7 +498,8 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
         // one launch per shade class in use (scattering events inside a medium are routed to class 2, k_route: it is launched whenever a medium stack exists
         // and OpenPBR does)
         uint32_t shadeMask = s->shadeClassMask | ((rs.mediumStackSize != 0u && (s->shadeClassMask & (1u << SHADE_CLASS_OPBR_BASE))) ? 4u : 0u);
-        if (U.flags & FLAG_MERGE_SHADE_VARIANTS) shadeMask = (shadeMask & ~(1u << SHADE_CLASS_OPBR_BASE)) | ((shadeMask >> SHADE_CLASS_OPBR_BASE) & 1u) << 2; // BASE hits sit in class 2's queue
+        // BASE hits sit in class 2's queue
+        if (U.flags & FLAG_MERGE_SHADE_VARIANTS) shadeMask = (shadeMask & ~(1u << SHADE_CLASS_OPBR_BASE)) | ((shadeMask >> SHADE_CLASS_OPBR_BASE) & 1u) << 2;
         for (uint32_t klass = 0; klass < MAT_CLASS_COUNT; klass++)
           if (shadeMask & (1u << klass)) timed(2,
               [&] { launchShade(st, wideBlocks, klass, (s->shadeClassTextured & (1u << klass)) != 0u, rs.mediumStackSize != 0u, U, view, ps, qs,
@@ -605,7 +611,8 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
   }
   if (s->countTraversal && D.hCounters->dynStats[0] && optionValue("phase_stats", 0)) { // k_trace_dyn's lane accounting (counting build, closest-hit launches)
     const unsigned long long* d = D.hCounters->dynStats; const double st = (double)d[0];
-    fprintf(stderr, "[gatling_gi] k_trace_dyn<closest> %llu wave steps: per step %.1f lanes hold a ray, %.1f run the node test, %.1f wait for the triangle ring; %.3f batches per step of %.1f pairs; "
+    fprintf(stderr, "[gatling_gi] k_trace_dyn<closest> %llu wave steps: per step %.1f lanes hold a ray, %.1f run the node test, %.1f wait for the triangle "
+                    "ring; %.3f batches per step of %.1f pairs; "
                     "a refill every %.2f steps, %.1f lanes each\n", d[0], (double)d[1] / st, (double)d[2] / st, (double)d[3] / st, (double)d[4] / st, d[4]
                         ? (double)d[5] / (double)d[4] : 0.0,
             d[6] ? st / (double)d[6] : 0.0, d[6] ? (double)d[7] / (double)d[6] : 0.0);
@@ -624,7 +631,8 @@ static int renderOnDevice(GiCScene* s, SceneDevice& D, const RenderJob& job)
         double ms4[4] = {0.0, 0.0, 0.0, 0.0};
         for (; 2 * k < iterRows[r].evEnd && k < evKind.size(); k++) { float ms = 0.0f;
             (void)hipEventElapsedTime(&ms, D.eventPool[2 * k], D.eventPool[2 * k + 1]); ms4[evKind[k]] += ms; }
-        fprintf(stderr, "[gatling_gi] iter %3zu: rays %9llu hits %9llu shadow %9llu ended %9llu continuing %9llu | raygen %7.3f trace+route %7.3f shade %7.3f shadow %7.3f ms\n", r,
+        fprintf(stderr, "[gatling_gi] iter %3zu: rays %9llu hits %9llu shadow %9llu ended %9llu continuing %9llu | raygen %7.3f trace+route %7.3f shade %7.3f "
+                        "shadow %7.3f ms\n", r,
                 (unsigned long long)iterRows[r].traced, (unsigned long long)iterRows[r].hits, (unsigned long long)iterRows[r].shadow,
                     (unsigned long long)iterRows[r].ended,
                 (unsigned long long)iterRows[r].cont, ms4[0], ms4[1], ms4[2], ms4[3]);
@@ -723,7 +731,10 @@ static int giCRenderImpl(const GiCRenderParams* params)
   }
   if (params->aovBindingCount == 0) { setError("giCRender: no AOV bindings"); return GI_C_ERROR; }
   if (rs.spp == 0) { setError("giCRender: spp must be > 0"); return GI_C_ERROR; }
-  if (rs.mediumStackSize > MAX_MEDIUM_STACK) { setError("giCRender: mediumStackSize > 15 cannot be addressed (the payload's medium index has four bits, rp_main_payload.glsl:4-5)"); return GI_C_ERROR; }
+  if (rs.mediumStackSize > MAX_MEDIUM_STACK) {
+    setError("giCRender: mediumStackSize > 15 cannot be addressed (the payload's medium index has four bits, rp_main_payload.glsl:4-5)");
+    return GI_C_ERROR;
+  }
   const GiCRenderBuffer* sizeRb = (colorBinding ? colorBinding : &params->aovBindings[0])->renderBuffer;
   const uint32_t width = sizeRb->width, height = sizeRb->height;
   if (width == 0 || height == 0) return GI_C_OK; // Render.Empty-style degenerate target: nothing to do
@@ -737,13 +748,20 @@ static int giCRenderImpl(const GiCRenderParams* params)
     for (float f : fields) if (!std::isfinite(f)) { setError("giCRender: the camera has a non-finite field"); return GI_C_ERROR; }
     const float f2 = (c.forward[0] * c.forward[0] + c.forward[1] * c.forward[1]) + c.forward[2] * c.forward[2],
         u2 = (c.up[0] * c.up[0] + c.up[1] * c.up[1]) + c.up[2] * c.up[2];
-    if (!(f2 > 0.0f) || !(u2 > 0.0f) || !std::isfinite(f2) || !std::isfinite(u2) || !std::isfinite(1.0f / sqrtf(f2)) || !std::isfinite(1.0f / sqrtf(u2))) { setError("giCRender: the camera's forward or up vector cannot be normalised (zero, denormal or overflowing length)"); return GI_C_ERROR; }
+    if (!(f2 > 0.0f) || !(u2 > 0.0f) || !std::isfinite(f2) || !std::isfinite(u2) || !std::isfinite(1.0f / sqrtf(f2)) || !std::isfinite(1.0f / sqrtf(u2))) {
+      setError("giCRender: the camera's forward or up vector cannot be normalised (zero, denormal or overflowing length)");
+      return GI_C_ERROR;
+    }
     if (!(c.vfov > 0.0f && c.vfov < 3.14159265f)) { setError("giCRender: the camera's vertical field of view must lie inside (0, pi) radians");
         return GI_C_ERROR; }
-    if (!std::isfinite(1.0f / (2.0f * tanf(c.vfov * 0.5f)))) { setError("giCRender: the camera's vertical field of view is too small for the image plane distance to be finite"); return GI_C_ERROR; }
+    if (!std::isfinite(1.0f / (2.0f * tanf(c.vfov * 0.5f)))) {
+      setError("giCRender: the camera's vertical field of view is too small for the image plane distance to be finite");
+      return GI_C_ERROR;
+    }
   }
   if (const GiCDomeLight* dl = params->domeLight) { // (the dome light's setters take whatever they are given, like the reference's)
-    const float fields[] = {dl->rotation[0], dl->rotation[1], dl->rotation[2], dl->rotation[3], dl->baseEmission[0], dl->baseEmission[1], dl->baseEmission[2], dl->diffuse, dl->specular};
+    const float fields[] = {dl->rotation[0], dl->rotation[1], dl->rotation[2], dl->rotation[3], dl->baseEmission[0], dl->baseEmission[1], dl->baseEmission[2],
+        dl->diffuse, dl->specular};
     for (float f : fields) if (!std::isfinite(f)) { setError("giCRender: the dome light has a non-finite field"); return GI_C_ERROR; }
   }
   { // render settings that enter the arithmetic as floats

@@ -34,10 +34,12 @@ GiCMaterial* giCCreateMaterial(GiCScene* scene, const char* name, const GiCMater
   // Hostile input (include/gi_c.h): a non-finite parameter would be NaN radiance on every path that meets the material.  Refused like a material the reference
   // fails to compile (giCreateMaterialFrom* return nullptr there, and hdGatling falls back to its default material, material.cpp)
   for (uint32_t i = 0; i < MAT_PARAM_COUNT; i++)
-    if (!std::isfinite(desc->p[i])) { setError("giCCreateMaterial: parameter " + std::to_string(i) + " of material '" + (name ? name : "") + "' is not finite"); return nullptr; }
+    if (!std::isfinite(desc->p[i])) { setError("giCCreateMaterial: parameter " + std::to_string(i) + " of material '" + (name ? name : "") + "' is not finite");
+        return nullptr; }
   GiCMaterial* m = new GiCMaterial{scene, name ? name : "", *desc};
-  // (subsurface_radius / subsurface_radius_scale, slots 32..35, are taken as given -- zeros included: the per-channel mean free path is clamped to 1e-6, as the oracle
-  // does.  Round 5 read an all-zero radius AND scale as "unset"; that guess belongs to the front ends, which set OpenPBR's defaults themselves: gtl_shim.cpp -- ADVICE r05)
+  // (subsurface_radius / subsurface_radius_scale, slots 32..35, are taken as given -- zeros included: the per-channel mean free path is clamped to 1e-6, as the
+  // oracle does.  Round 5 read an all-zero radius AND scale as "unset"; that guess belongs
+  // to the front ends, which set OpenPBR's defaults themselves: gtl_shim.cpp -- ADVICE r05)
   std::lock_guard<std::mutex> g(scene->mutex);
   scene->materials.push_back(m);
   scene->dirty |= DIRTY_MATERIALS | DIRTY_BVH | DIRTY_FRAMEBUFFER;

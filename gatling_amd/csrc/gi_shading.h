@@ -47,7 +47,8 @@ struct ShState {
   float ior1, ior2;              // Bsdf_sample_data.ior1/ior2 (rp_main.chit:188-189): < 0 = the material's own; 0 = empty-stack default
   bool thinWalled;               // mdl_thin_walled (rp_main.chit:155-157), set by shade_segment
   bool sssVolume;                // the render keeps a medium stack: OpenPBR's volumetric subsurface lobe is live (set by shade_segment)
-  bool hasCoatFrame; V3 coatNormal, coatTangentU, coatTangentV; // OpenPBR geometry_coat_normal (open_pbr_surface.mtlx:87, 560): the coat lobe's own frame (resolve_material_textures)
+  // OpenPBR geometry_coat_normal (open_pbr_surface.mtlx:87, 560): the coat lobe's own frame (resolve_material_textures)
+  bool hasCoatFrame; V3 coatNormal, coatTangentU, coatTangentV;
   uint32_t texMask;              // bit per TEX_* slot whose value below replaces the material constant at this hit
   V3 texBaseColor, texEmission, texTransColor; float texRoughness, texMetallic, texTransWeight;
 };
@@ -63,7 +64,8 @@ __device__ __forceinline__ V3 xform_normal(const float* w, V3 n)
   return v3((n.x * w[0] + n.y * w[3]) + n.z * w[6], (n.x * w[1] + n.y * w[4]) + n.z * w[7], (n.x * w[2] + n.y * w[5]) + n.z * w[8]);
 }
 
-// PACKED: the three corners come from the mesh triangle's TriShade record (normals / tangents decoded on the host, as in FVertex) instead of three FVertex records.
+// PACKED: the three corners come from the mesh triangle's TriShade record (normals
+// / tangents decoded on the host, as in FVertex) instead of three FVertex records.
 template <bool PACKED = false>
 __device__ __forceinline__ void setup_shading_state(const SceneView& sc, uint32_t triIdx, float hu, float hv, V3 rayDir, ShState& s)
 {
@@ -75,10 +77,12 @@ __device__ __forceinline__ void setup_shading_state(const SceneView& sc, uint32_
   const float4 r0 = ip[0], r1 = ip[1], r2 = ip[2], r3 = ip[3], r4 = ip[4], r5 = ip[5];
   V3 pa, pb, pc, n0, n1, n2, t0, t1, t2; float sa, sb, scg, ua, ub, uc, va_, vb_, vc_;
   if (PACKED) {
-    const uint4* q = reinterpret_cast<const uint4*>(&sc.triShade[td.x]); // 10 x 16 bytes (two lines): positions, decoded normals and tangents, uv, signs, indices
+    // 10 x 16 bytes (two lines): positions, decoded normals and tangents, uv, signs, indices
+    const uint4* q = reinterpret_cast<const uint4*>(&sc.triShade[td.x]);
     const uint4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7], q8 = q[8], q9 = q[9];
     pa = v3(u2f(q0.x), u2f(q0.y), u2f(q0.z)); pb = v3(u2f(q0.w), u2f(q1.x), u2f(q1.y)); pc = v3(u2f(q1.z), u2f(q1.w), u2f(q2.x));
-    n0 = v3(u2f(q2.y), u2f(q2.z), u2f(q2.w)); n1 = v3(u2f(q3.x), u2f(q3.y), u2f(q3.z)); n2 = v3(u2f(q3.w), u2f(q4.x), u2f(q4.y)); // decoded on the host (gi_build.cpp)
+    // decoded on the host (gi_build.cpp)
+    n0 = v3(u2f(q2.y), u2f(q2.z), u2f(q2.w)); n1 = v3(u2f(q3.x), u2f(q3.y), u2f(q3.z)); n2 = v3(u2f(q3.w), u2f(q4.x), u2f(q4.y));
     t0 = v3(u2f(q4.z), u2f(q4.w), u2f(q5.x)); t1 = v3(u2f(q5.y), u2f(q5.z), u2f(q5.w)); t2 = v3(u2f(q6.x), u2f(q6.y), u2f(q6.z));
     ua = u2f(q6.w); va_ = u2f(q7.x); ub = u2f(q7.y); vb_ = u2f(q7.z); uc = u2f(q7.w); vc_ = u2f(q8.x);
     sa = u2f(q8.y); sb = u2f(q8.z); scg = u2f(q8.w);
@@ -105,7 +109,8 @@ __device__ __forceinline__ void setup_shading_state(const SceneView& sc, uint32_
   if (PACKED) {
     gn = normalize(cross(pb - pa, pc - pa));                                          // :27
     gn = normalize(xform_normal(w2o, gn));                                            // :28
-  } else { const F4 g = ld4(&sc.triGeomNormal[triIdx]); gn = v3(g.x, g.y, g.z); }      // the same two lines, evaluated once per flattened triangle on the host (gi_build.cpp)
+  // the same two lines, evaluated once per flattened triangle on the host (gi_build.cpp)
+  } else { const F4 g = ld4(&sc.triGeomNormal[triIdx]); gn = v3(g.x, g.y, g.z); }
   const V3 ln = normalize((n0 * bx + n1 * by) + n2 * bz);                             // :35
   V3 nrm = normalize(xform_normal(w2o, ln));                                          // :36
   s.frontFace = dot(gn, -rayDir) >= 0.0f;                                             // :39
@@ -119,7 +124,8 @@ __device__ __forceinline__ void setup_shading_state(const SceneView& sc, uint32_
   s.normal = nrm; s.geomNormal = gn;
   s.mesh = f2u(r5.y); s.instanceId = (int32_t)f2u(r5.z); s.prim = td.w; s.hu = hu; s.hv = hv;
   s.ior1 = 0.0f; s.ior2 = 0.0f;
-  s.thinWalled = false; s.sssVolume = false; s.hasCoatFrame = false; s.texMask = 0u; s.texBaseColor = v3(0.0f, 0.0f, 0.0f); s.texEmission = s.texBaseColor; s.texRoughness = 0.0f; s.texMetallic = 0.0f; s.texTransColor = s.texBaseColor; s.texTransWeight = 0.0f;
+  s.thinWalled = false; s.sssVolume = false; s.hasCoatFrame = false; s.texMask = 0u; s.texBaseColor = v3(0.0f, 0.0f, 0.0f); s.texEmission = s.texBaseColor;
+      s.texRoughness = 0.0f; s.texMetallic = 0.0f; s.texTransColor = s.texBaseColor; s.texTransWeight = 0.0f;
 }
 
 // mdl_adapt_normal (mdl_interface.glsl:238-256): Iray's shadow-terminator bend of a mapped normal
@@ -158,7 +164,8 @@ __device__ inline void resolve_material_textures(const SceneView& sc, const Mate
       // the two magic scene-data names (mdl_interface.glsl:329-334 float3 only, :390-395 float only)
       if (vec && (b.mode & TEX_MODE_CAMERA_POSITION)) {
         st.texMask |= 1u << slot;
-        if (slot == TEX_BASE_COLOR) st.texBaseColor = v3(sc.cameraPosition); else if (slot == TEX_EMISSION) st.texEmission = v3(sc.cameraPosition); else st.texTransColor = v3(sc.cameraPosition);
+        if (slot == TEX_BASE_COLOR) st.texBaseColor = v3(sc.cameraPosition); else if (slot == TEX_EMISSION) st.texEmission = v3(sc.cameraPosition);
+            else st.texTransColor = v3(sc.cameraPosition);
         continue;
       }
       if (!vec && (b.mode & TEX_MODE_FRAME)) {
@@ -251,12 +258,15 @@ __device__ inline void dome_miss(const SceneView& sc, const PathState& st, uint3
 // (entry points GlslShaderGen.cpp:181-193; data contracts mdl_types.glsl:158-238)
 // ------------------------------------------------------------------------------------------------
 enum : uint32_t { EV_ABSORB = 0, EV_DIFFUSE = 1, EV_GLOSSY = 2, EV_SPECULAR = 4, EV_REFLECTION = 8, EV_TRANSMISSION = 16 };
-enum : uint32_t { EV_SUBSURFACE = 64 }; // [ours] beside EV_DIFFUSE | EV_TRANSMISSION: entered through the volumetric subsurface lobe (the medium pushed is MaterialRec::sss)
+// [ours] beside EV_DIFFUSE | EV_TRANSMISSION: entered through the volumetric subsurface lobe (the medium pushed is MaterialRec::sss)
+enum : uint32_t { EV_SUBSURFACE = 64 };
 
 __device__ __forceinline__ V3 to_world(const ShState& s, V3 l) { return (s.tangentU * l.x + s.tangentV * l.y) + s.normal * l.z; }
 __device__ __forceinline__ V3 to_local(const ShState& s, V3 w) { return v3(dot(w, s.tangentU), dot(w, s.tangentV), dot(w, s.normal)); }
-__device__ __forceinline__ V3 to_world_coat(const ShState& s, V3 l) { return s.hasCoatFrame ? (s.coatTangentU * l.x + s.coatTangentV * l.y) + s.coatNormal * l.z : to_world(s, l); }
-__device__ __forceinline__ V3 to_local_coat(const ShState& s, V3 w) { return s.hasCoatFrame ? v3(dot(w, s.coatTangentU), dot(w, s.coatTangentV), dot(w, s.coatNormal)) : to_local(s, w); }
+__device__ __forceinline__ V3 to_world_coat(const ShState& s, V3 l)
+{ return s.hasCoatFrame ? (s.coatTangentU * l.x + s.coatTangentV * l.y) + s.coatNormal * l.z : to_world(s, l); }
+__device__ __forceinline__ V3 to_local_coat(const ShState& s, V3 w)
+{ return s.hasCoatFrame ? v3(dot(w, s.coatTangentU), dot(w, s.coatTangentV), dot(w, s.coatNormal)) : to_local(s, w); }
 __device__ __forceinline__ float schlick_w(float c) { float m = 1.0f - c; m = fmin2(fmax2(m, 0.0f), 1.0f); float m2 = m * m; return m2 * m2 * m; }
 __device__ __forceinline__ float ggx_lambda_term(float a2, float c) { return sqrtf(a2 + (1.0f - a2) * c * c); }
 __device__ __forceinline__ V3 schlick3(V3 F0, float c) { float w = schlick_w(c); return F0 + (v3(1.0f, 1.0f, 1.0f) - F0) * w; }
@@ -362,8 +372,10 @@ __device__ __forceinline__ void opbr_anisotropy(float alpha, float a, float& ax,
   const float inv = 1.0f - fmin2(a, 1.0f);
   ax = fmax2(alpha * sqrtf(2.0f / (1.0f + inv * inv)), 0.001f); ay = fmax2(inv * ax, 0.001f);
 }
-__device__ __forceinline__ GgxOut ggx_sample2(V3 l1, float ax, float ay, float x0, float x1) { return ax == ay ? ggx_sample(l1, ax, x0, x1) : ggx_sample_xy(l1, ax, ay, x0, x1); }
-__device__ __forceinline__ void ggx_eval2(V3 l1, V3 l2, float ax, float ay, float& fcos, float& pdf, float& kh) { if (ax == ay) ggx_eval(l1, l2, ax, fcos, pdf, kh); else ggx_eval_xy(l1, l2, ax, ay, fcos, pdf, kh); }
+__device__ __forceinline__ GgxOut ggx_sample2(V3 l1, float ax, float ay, float x0, float x1)
+{ return ax == ay ? ggx_sample(l1, ax, x0, x1) : ggx_sample_xy(l1, ax, ay, x0, x1); }
+__device__ __forceinline__ void ggx_eval2(V3 l1, V3 l2, float ax, float ay, float& fcos, float& pdf, float& kh)
+{ if (ax == ay) ggx_eval(l1, l2, ax, fcos, pdf, kh); else ggx_eval_xy(l1, l2, ax, ay, fcos, pdf, kh); }
 
 // ior2 / ior1 of the interface (== oracle relative_eta): eta entering, 1/eta leaving when the medium stack is empty
 __device__ __forceinline__ float relative_eta(const ShState& st, float materialEta)
@@ -465,15 +477,19 @@ __device__ inline V3 eon_pi_f(V3 rho, float r, V3 l1, V3 l2)
   const float avgEF = AF * (1.0f + 0.07248828f * r);
   const float ms = (fmax2(1e-7f, 1.0f - EFo) * fmax2(1e-7f, 1.0f - EFi)) / fmax2(1e-7f, 1.0f - avgEF);
   const V3 rr = rho * rho;
-  const V3 rhoMs = v3((rr.x * avgEF) / (1.0f - rho.x * (1.0f - avgEF)), (rr.y * avgEF) / (1.0f - rho.y * (1.0f - avgEF)), (rr.z * avgEF) / (1.0f - rho.z * (1.0f - avgEF)));
+  const V3 rhoMs = v3((rr.x * avgEF) / (1.0f - rho.x * (1.0f - avgEF)), (rr.y * avgEF) / (1.0f - rho.y * (1.0f - avgEF)),
+      (rr.z * avgEF) / (1.0f - rho.z * (1.0f - avgEF)));
   return rho * ss + rhoMs * ms;
 }
-struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, baseColor, ssColor, fuzzColor; float metalness, alpha, alphaY, coat, coatAlpha, coatAlphaY, coatF0, eta, tw, specWeight, baseWeight, diffRough, ssWeight, ssAniso, fuzzWeight, fuzzAlpha, filmWeight, filmNm, filmIor; bool thinWalled, ssVolume; };
+struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, baseColor, ssColor, fuzzColor;
+    float metalness, alpha, alphaY, coat, coatAlpha, coatAlphaY, coatF0, eta, tw, specWeight, baseWeight, diffRough, ssWeight, ssAniso, fuzzWeight, fuzzAlpha,
+    filmWeight, filmNm, filmIor; bool thinWalled, ssVolume; };
 __device__ __forceinline__ OpbrParams opbr_params(const MaterialRec* m, const ShState& st)
 {
   OpbrParams o; const float* p = m->p;
   o.albedo = v3(p[MP_ALBEDO], p[MP_ALBEDO + 1], p[MP_ALBEDO + 2]);
-  o.baseColor = v3(p[0], p[1], p[2]); o.baseWeight = p[17]; o.diffRough = p[27]; const uint32_t feat = (uint32_t)p[MP_FEATURES]; o.thinWalled = (feat & MATF_THIN_WALLED) != 0u;
+  o.baseColor = v3(p[0], p[1], p[2]); o.baseWeight = p[17]; o.diffRough = p[27]; const uint32_t feat = (uint32_t)p[MP_FEATURES];
+      o.thinWalled = (feat & MATF_THIN_WALLED) != 0u;
   o.metalTint = v3(p[MP_F0], p[MP_F0 + 1], p[MP_F0 + 2]);
   o.specColor = v3(p[7], p[8], p[9]);
   o.specWeight = p[18]; o.metalness = p[10];
@@ -485,9 +501,11 @@ __device__ __forceinline__ OpbrParams opbr_params(const MaterialRec* m, const Sh
   if (st.texMask & (1u << TEX_ROUGHNESS)) { const float r = opbr_effective_roughness(st.texRoughness, p[13], o.coat); o.alpha = fmax2(r * r, 0.001f); }
   if (st.texMask & (1u << TEX_METALLIC)) o.metalness = st.texMetallic;
   if (st.texMask & (1u << TEX_TRANSMISSION_WEIGHT)) o.tw = st.texTransWeight;
-  if ((st.texMask & (1u << TEX_TRANSMISSION_COLOR)) && !(p[28] > 0.0f)) o.transTint = st.texTransColor; // (with a depth the colour is the medium's: the material's constant)
+  // (with a depth the colour is the medium's: the material's constant)
+  if ((st.texMask & (1u << TEX_TRANSMISSION_COLOR)) && !(p[28] > 0.0f)) o.transTint = st.texTransColor;
   o.alphaY = o.alpha; o.coatAlphaY = o.coatAlpha;
-  if (feat & MATF_ANISOTROPY) { opbr_anisotropy(o.alpha, p[60], o.alpha, o.alphaY); opbr_anisotropy(o.coatAlpha, p[61], o.coatAlpha, o.coatAlphaY); } // specular_roughness_anisotropy / coat_roughness_anisotropy
+  // specular_roughness_anisotropy / coat_roughness_anisotropy
+  if (feat & MATF_ANISOTROPY) { opbr_anisotropy(o.alpha, p[60], o.alpha, o.alphaY); opbr_anisotropy(o.coatAlpha, p[61], o.coatAlpha, o.coatAlphaY); }
   // coat_substrate_attenuated = base_substrate * modulated_base_darkening * coat_attenuation (open_pbr_surface.mtlx:538-552)
   o.coatTint = o.coatTint * opbr_base_darkening(o.baseColor, o.specWeight, o.metalness, o.coat, o.coatF0, p[22], p[48]);
   // thin-walled subsurface (open_pbr_surface.mtlx:140-196, 207-218); the volumetric form of non-thin-walled materials is not modelled
@@ -498,7 +516,8 @@ __device__ __forceinline__ OpbrParams opbr_params(const MaterialRec* m, const Sh
   if (o.ssVolume) o.ssWeight = fmin2(p[55], 1.0f);
   // fuzz layer (open_pbr_surface.mtlx:569-581): sheen_bsdf(fuzz_weight, fuzz_color, fuzz_roughness) on top of the coat
   o.fuzzWeight = 0.0f; o.fuzzColor = v3(1.0f, 1.0f, 1.0f); o.fuzzAlpha = 0.5f;
-  if (feat & MATF_FUZZ) { o.fuzzWeight = fmin2(fmax2(p[49], 0.0f), 1.0f); o.fuzzColor = v3(p[50], p[51], p[52]); o.fuzzAlpha = fmin2(fmax2(p[53], 0.07f), 1.0f); }
+  if (feat & MATF_FUZZ) { o.fuzzWeight = fmin2(fmax2(p[49], 0.0f), 1.0f); o.fuzzColor = v3(p[50], p[51], p[52]); o.fuzzAlpha = fmin2(fmax2(p[53], 0.07f), 1.0f);
+      }
   // thin film (open_pbr_surface.mtlx:300-304, 404-431, 450-464): weight, thickness in micrometres, ior (slot 6: OpenPBR records do not use useSpecularWorkflow)
   o.filmWeight = 0.0f; o.filmNm = 0.0f; o.filmIor = 1.0f;
   if (feat & MATF_THIN_FILM) { o.filmWeight = fmin2(fmax2(p[62], 0.0f), 1.0f); o.filmNm = fmax2(p[63], 0.0f) * 1000.0f; o.filmIor = fmax2(p[6], 1.0f); }
@@ -520,7 +539,8 @@ __device__ inline float film_reflectance(float c, float nf, float n3, float d, f
   const float Rp = ((rp12 * rp12 + rp23 * rp23) + (2.0f * pp) * cs) / ((1.0f + pp * pp) + (2.0f * pp) * cs);
   return fmin2(fmax2(0.5f * (Rs + Rp), 0.0f), 1.0f);
 }
-__device__ inline V3 film_fresnel(float c, float nf, V3 n3, float d) { return v3(film_reflectance(c, nf, n3.x, d, 611.4f), film_reflectance(c, nf, n3.y, d, 548.4f), film_reflectance(c, nf, n3.z, d, 464.3f)); }
+__device__ inline V3 film_fresnel(float c, float nf, V3 n3, float d)
+{ return v3(film_reflectance(c, nf, n3.x, d, 611.4f), film_reflectance(c, nf, n3.y, d, 548.4f), film_reflectance(c, nf, n3.z, d, 464.3f)); }
 __device__ inline V3 opbr_film_dielectric(const OpbrParams& o, float c, float eta, float Fplain)
 {
   const float nf = (eta < 1.0f) ? o.filmIor * eta : o.filmIor;
@@ -537,22 +557,38 @@ __device__ inline V3 opbr_film_metal(const OpbrParams& o, float c, V3 Fplain)
 // described there): "Charlie" distribution x Ashikhmin / Neubelt visibility, directional albedo from the table of tools/gen_fuzz_albedo.py + 0.01.
 __device__ const float FUZZ_ALBEDO[16][17] = {
 // rows: alpha = 1/16 .. 1, columns: mu = 0 .. 1 in steps of 1/16 (tools/gen_fuzz_albedo.py)
-  {1.66603482e+00f, 1.05229735e+00f, 7.48142481e-01f, 5.42552471e-01f, 3.94544691e-01f, 2.85340458e-01f, 2.04062358e-01f, 1.43585801e-01f, 9.88851935e-02f, 6.62436262e-02f, 4.28260490e-02f, 2.64271554e-02f, 1.53114153e-02f, 8.10563751e-03f, 3.72325582e-03f, 1.30873080e-03f, 1.95315428e-04f},
-  {1.22866476e+00f, 8.68625820e-01f, 6.77242339e-01f, 5.38716376e-01f, 4.31280196e-01f, 3.45276922e-01f, 2.75279015e-01f, 2.17816725e-01f, 1.70480222e-01f, 1.31495669e-01f, 9.95000154e-02f, 7.34108016e-02f, 5.23458906e-02f, 3.55714411e-02f, 2.24667117e-02f, 1.24994880e-02f, 5.20835957e-03f},
-  {1.04291248e+00f, 7.75057077e-01f, 6.29255474e-01f, 5.20992339e-01f, 4.34587359e-01f, 3.63185972e-01f, 3.03000093e-01f, 2.51652122e-01f, 2.07522362e-01f, 1.69441670e-01f, 1.36528745e-01f, 1.08096354e-01f, 8.35938677e-02f, 6.25700131e-02f, 4.46479134e-02f, 2.95076892e-02f, 1.68739911e-02f},
-  {9.36414123e-01f, 7.16623902e-01f, 5.95793307e-01f, 5.04945695e-01f, 4.31368500e-01f, 3.69544923e-01f, 3.16451848e-01f, 2.70210087e-01f, 2.29553193e-01f, 1.93577752e-01f, 1.61611512e-01f, 1.33137539e-01f, 1.07747734e-01f, 8.51129442e-02f, 6.49628416e-02f, 4.70720194e-02f, 3.12500633e-02f},
-  {8.66332769e-01f, 6.76128209e-01f, 5.71131229e-01f, 4.91654038e-01f, 4.26739037e-01f, 3.71650100e-01f, 3.23803574e-01f, 2.81601369e-01f, 2.43972436e-01f, 2.10157394e-01f, 1.79594919e-01f, 1.51856542e-01f, 1.26606807e-01f, 1.03577562e-01f, 8.25508535e-02f, 6.33470416e-02f, 4.58163172e-02f},
-  {8.16336453e-01f, 6.46200657e-01f, 5.52162349e-01f, 4.80711669e-01f, 4.22050655e-01f, 3.71954530e-01f, 3.28124613e-01f, 2.89142847e-01f, 2.54061490e-01f, 2.22210526e-01f, 1.93096176e-01f, 1.66342735e-01f, 1.41657025e-01f, 1.18805535e-01f, 9.75991860e-02f, 7.78828189e-02f, 5.95276207e-02f},
-  {7.78707266e-01f, 6.23087585e-01f, 5.37092745e-01f, 4.71618980e-01f, 4.17691469e-01f, 3.71446818e-01f, 3.30786139e-01f, 2.94416696e-01f, 2.61475623e-01f, 2.31353760e-01f, 2.03602642e-01f, 1.77881300e-01f, 1.53923839e-01f, 1.31518483e-01f, 1.10493734e-01f, 9.07087103e-02f, 7.20463097e-02f},
-  {7.49280632e-01f, 6.04652286e-01f, 5.24816334e-01f, 4.63969946e-01f, 4.13753271e-01f, 3.70571792e-01f, 3.32474768e-01f, 2.98261851e-01f, 2.67132372e-01f, 2.38521293e-01f, 2.12012753e-01f, 1.87290415e-01f, 1.64107352e-01f, 1.42266646e-01f, 1.21608362e-01f, 1.02000684e-01f, 8.33334997e-02f},
-  {7.25595057e-01f, 5.89579582e-01f, 5.14612794e-01f, 4.57457095e-01f, 4.10229623e-01f, 3.69543940e-01f, 3.33563626e-01f, 3.01159322e-01f, 2.71578044e-01f, 2.44288355e-01f, 2.18898997e-01f, 1.95112124e-01f, 1.72694832e-01f, 1.51460946e-01f, 1.31258771e-01f, 1.11962639e-01f, 9.34669897e-02f},
-  {7.06095338e-01f, 5.77011704e-01f, 5.05992115e-01f, 4.51849908e-01f, 4.07083064e-01f, 3.68470997e-01f, 3.34268302e-01f, 3.03401917e-01f, 2.75156647e-01f, 2.49027595e-01f, 2.24642813e-01f, 2.01718882e-01f, 1.80033773e-01f, 1.59409523e-01f, 1.39700606e-01f, 1.20785803e-01f, 1.02562815e-01f},
-  {6.89747393e-01f, 5.66363335e-01f, 4.98608768e-01f, 4.46974337e-01f, 4.04269099e-01f, 3.67407918e-01f, 3.34719449e-01f, 3.05176616e-01f, 2.78094798e-01f, 2.52990693e-01f, 2.29507983e-01f, 2.07374871e-01f, 1.86378047e-01f, 1.66346103e-01f, 1.47138327e-01f, 1.28636986e-01f, 1.10742249e-01f},
-  {6.75835013e-01f, 5.57220221e-01f, 4.92211729e-01f, 4.42697257e-01f, 4.01744992e-01f, 3.66382241e-01f, 3.34999412e-01f, 3.06607515e-01f, 2.80547380e-01f, 2.56353587e-01f, 2.33682737e-01f, 2.12272644e-01f, 1.91917211e-01f, 1.72450408e-01f, 1.53735459e-01f, 1.35657445e-01f, 1.18118644e-01f},
-  {6.63845837e-01f, 5.49280763e-01f, 4.86614108e-01f, 4.38915670e-01f, 3.99472445e-01f, 3.65406990e-01f, 3.35161716e-01f, 3.07779849e-01f, 2.82623708e-01f, 2.59242892e-01f, 2.37304971e-01f, 2.16555879e-01f, 1.96795553e-01f, 1.77862525e-01f, 1.59623355e-01f, 1.41965449e-01f, 1.24793008e-01f},
-  {6.53402805e-01f, 5.42319357e-01f, 4.81673747e-01f, 4.35548574e-01f, 3.97418410e-01f, 3.64487261e-01f, 3.35242122e-01f, 3.08753759e-01f, 2.84402877e-01f, 2.61752009e-01f, 2.40478083e-01f, 2.20333964e-01f, 2.01124832e-01f, 1.82693094e-01f, 1.64908230e-01f, 1.47659644e-01f, 1.30853310e-01f},
-  {6.44222379e-01f, 5.36164165e-01f, 4.77280527e-01f, 4.32531655e-01f, 3.95554543e-01f, 3.63623768e-01f, 3.35264921e-01f, 3.09572637e-01f, 2.85943538e-01f, 2.63951302e-01f, 2.43281066e-01f, 2.23691702e-01f, 2.04992920e-01f, 1.87030569e-01f, 1.69676632e-01f, 1.52822360e-01f, 1.36375397e-01f},
-  {6.36086643e-01f, 5.30681610e-01f, 4.73347783e-01f, 4.29813147e-01f, 3.93856794e-01f, 3.62814993e-01f, 3.35247070e-01f, 3.10268551e-01f, 2.87289977e-01f, 2.65894860e-01f, 2.45775416e-01f, 2.26695850e-01f, 2.08469898e-01f, 1.90946430e-01f, 1.73999682e-01f, 1.57522544e-01f, 1.41424328e-01f},
+  {1.66603482e+00f, 1.05229735e+00f, 7.48142481e-01f, 5.42552471e-01f, 3.94544691e-01f, 2.85340458e-01f, 2.04062358e-01f, 1.43585801e-01f, 9.88851935e-02f,
+      6.62436262e-02f, 4.28260490e-02f, 2.64271554e-02f, 1.53114153e-02f, 8.10563751e-03f, 3.72325582e-03f, 1.30873080e-03f, 1.95315428e-04f},
+  {1.22866476e+00f, 8.68625820e-01f, 6.77242339e-01f, 5.38716376e-01f, 4.31280196e-01f, 3.45276922e-01f, 2.75279015e-01f, 2.17816725e-01f, 1.70480222e-01f,
+      1.31495669e-01f, 9.95000154e-02f, 7.34108016e-02f, 5.23458906e-02f, 3.55714411e-02f, 2.24667117e-02f, 1.24994880e-02f, 5.20835957e-03f},
+  {1.04291248e+00f, 7.75057077e-01f, 6.29255474e-01f, 5.20992339e-01f, 4.34587359e-01f, 3.63185972e-01f, 3.03000093e-01f, 2.51652122e-01f, 2.07522362e-01f,
+      1.69441670e-01f, 1.36528745e-01f, 1.08096354e-01f, 8.35938677e-02f, 6.25700131e-02f, 4.46479134e-02f, 2.95076892e-02f, 1.68739911e-02f},
+  {9.36414123e-01f, 7.16623902e-01f, 5.95793307e-01f, 5.04945695e-01f, 4.31368500e-01f, 3.69544923e-01f, 3.16451848e-01f, 2.70210087e-01f, 2.29553193e-01f,
+      1.93577752e-01f, 1.61611512e-01f, 1.33137539e-01f, 1.07747734e-01f, 8.51129442e-02f, 6.49628416e-02f, 4.70720194e-02f, 3.12500633e-02f},
+  {8.66332769e-01f, 6.76128209e-01f, 5.71131229e-01f, 4.91654038e-01f, 4.26739037e-01f, 3.71650100e-01f, 3.23803574e-01f, 2.81601369e-01f, 2.43972436e-01f,
+      2.10157394e-01f, 1.79594919e-01f, 1.51856542e-01f, 1.26606807e-01f, 1.03577562e-01f, 8.25508535e-02f, 6.33470416e-02f, 4.58163172e-02f},
+  {8.16336453e-01f, 6.46200657e-01f, 5.52162349e-01f, 4.80711669e-01f, 4.22050655e-01f, 3.71954530e-01f, 3.28124613e-01f, 2.89142847e-01f, 2.54061490e-01f,
+      2.22210526e-01f, 1.93096176e-01f, 1.66342735e-01f, 1.41657025e-01f, 1.18805535e-01f, 9.75991860e-02f, 7.78828189e-02f, 5.95276207e-02f},
+  {7.78707266e-01f, 6.23087585e-01f, 5.37092745e-01f, 4.71618980e-01f, 4.17691469e-01f, 3.71446818e-01f, 3.30786139e-01f, 2.94416696e-01f, 2.61475623e-01f,
+      2.31353760e-01f, 2.03602642e-01f, 1.77881300e-01f, 1.53923839e-01f, 1.31518483e-01f, 1.10493734e-01f, 9.07087103e-02f, 7.20463097e-02f},
+  {7.49280632e-01f, 6.04652286e-01f, 5.24816334e-01f, 4.63969946e-01f, 4.13753271e-01f, 3.70571792e-01f, 3.32474768e-01f, 2.98261851e-01f, 2.67132372e-01f,
+      2.38521293e-01f, 2.12012753e-01f, 1.87290415e-01f, 1.64107352e-01f, 1.42266646e-01f, 1.21608362e-01f, 1.02000684e-01f, 8.33334997e-02f},
+  {7.25595057e-01f, 5.89579582e-01f, 5.14612794e-01f, 4.57457095e-01f, 4.10229623e-01f, 3.69543940e-01f, 3.33563626e-01f, 3.01159322e-01f, 2.71578044e-01f,
+      2.44288355e-01f, 2.18898997e-01f, 1.95112124e-01f, 1.72694832e-01f, 1.51460946e-01f, 1.31258771e-01f, 1.11962639e-01f, 9.34669897e-02f},
+  {7.06095338e-01f, 5.77011704e-01f, 5.05992115e-01f, 4.51849908e-01f, 4.07083064e-01f, 3.68470997e-01f, 3.34268302e-01f, 3.03401917e-01f, 2.75156647e-01f,
+      2.49027595e-01f, 2.24642813e-01f, 2.01718882e-01f, 1.80033773e-01f, 1.59409523e-01f, 1.39700606e-01f, 1.20785803e-01f, 1.02562815e-01f},
+  {6.89747393e-01f, 5.66363335e-01f, 4.98608768e-01f, 4.46974337e-01f, 4.04269099e-01f, 3.67407918e-01f, 3.34719449e-01f, 3.05176616e-01f, 2.78094798e-01f,
+      2.52990693e-01f, 2.29507983e-01f, 2.07374871e-01f, 1.86378047e-01f, 1.66346103e-01f, 1.47138327e-01f, 1.28636986e-01f, 1.10742249e-01f},
+  {6.75835013e-01f, 5.57220221e-01f, 4.92211729e-01f, 4.42697257e-01f, 4.01744992e-01f, 3.66382241e-01f, 3.34999412e-01f, 3.06607515e-01f, 2.80547380e-01f,
+      2.56353587e-01f, 2.33682737e-01f, 2.12272644e-01f, 1.91917211e-01f, 1.72450408e-01f, 1.53735459e-01f, 1.35657445e-01f, 1.18118644e-01f},
+  {6.63845837e-01f, 5.49280763e-01f, 4.86614108e-01f, 4.38915670e-01f, 3.99472445e-01f, 3.65406990e-01f, 3.35161716e-01f, 3.07779849e-01f, 2.82623708e-01f,
+      2.59242892e-01f, 2.37304971e-01f, 2.16555879e-01f, 1.96795553e-01f, 1.77862525e-01f, 1.59623355e-01f, 1.41965449e-01f, 1.24793008e-01f},
+  {6.53402805e-01f, 5.42319357e-01f, 4.81673747e-01f, 4.35548574e-01f, 3.97418410e-01f, 3.64487261e-01f, 3.35242122e-01f, 3.08753759e-01f, 2.84402877e-01f,
+      2.61752009e-01f, 2.40478083e-01f, 2.20333964e-01f, 2.01124832e-01f, 1.82693094e-01f, 1.64908230e-01f, 1.47659644e-01f, 1.30853310e-01f},
+  {6.44222379e-01f, 5.36164165e-01f, 4.77280527e-01f, 4.32531655e-01f, 3.95554543e-01f, 3.63623768e-01f, 3.35264921e-01f, 3.09572637e-01f, 2.85943538e-01f,
+      2.63951302e-01f, 2.43281066e-01f, 2.23691702e-01f, 2.04992920e-01f, 1.87030569e-01f, 1.69676632e-01f, 1.52822360e-01f, 1.36375397e-01f},
+  {6.36086643e-01f, 5.30681610e-01f, 4.73347783e-01f, 4.29813147e-01f, 3.93856794e-01f, 3.62814993e-01f, 3.35247070e-01f, 3.10268551e-01f, 2.87289977e-01f,
+      2.65894860e-01f, 2.45775416e-01f, 2.26695850e-01f, 2.08469898e-01f, 1.90946430e-01f, 1.73999682e-01f, 1.57522544e-01f, 1.41424328e-01f},
 };
 __device__ __forceinline__ float fuzz_albedo(float mu, float alpha)
 {
@@ -588,7 +624,8 @@ __device__ __forceinline__ V3 opbr_ss_transmit(const OpbrParams& o) { return opb
 // The lobe is chosen first (cheap, divergent), then ONE micro-facet sample serves whichever glossy lobe a lane took -- coat, metal,
 // dielectric reflection, transmission differ in the roughness they pass and in their weights, not in the sampling arithmetic -- so a wave
 // whose lanes took different lobes runs ggx_sample once instead of once per lobe.  Same operations per lane as the oracle's branch per lobe.
-__device__ inline void opbr_sample_base(const OpbrParams& o, const ShState& st, V3 k1, float x0, float x1, float x2, BsdfSample& out) // everything beneath the fuzz
+// everything beneath the fuzz
+__device__ inline void opbr_sample_base(const OpbrParams& o, const ShState& st, V3 k1, float x0, float x1, float x2, BsdfSample& out)
 {
   V3 l1 = to_local(st, k1);
   float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
@@ -613,8 +650,10 @@ __device__ inline void opbr_sample_base(const OpbrParams& o, const ShState& st, 
       }
     }
   }
-  // thin film: everything beneath the dielectric interface is weighted by (1 - F_mix) / (1 - F_plain) per channel (lobes 3 and 4 only: eta and Fd are set there)
-  const V3 under = (o.filmWeight > 0.0f && lobe >= 3u) ? (v3(1.0f, 1.0f, 1.0f) - opbr_film_dielectric(o, nk1, eta, Fd)) * (1.0f / (1.0f - Fd)) : v3(1.0f, 1.0f, 1.0f);
+  // thin film: everything beneath the dielectric interface is weighted by (1 - F_mix)
+  // / (1 - F_plain) per channel (lobes 3 and 4 only: eta and Fd are set there)
+  const V3 under = (o.filmWeight > 0.0f && lobe >= 3u)
+      ? (v3(1.0f, 1.0f, 1.0f) - opbr_film_dielectric(o, nk1, eta, Fd)) * (1.0f / (1.0f - Fd)) : v3(1.0f, 1.0f, 1.0f);
   if (lobe == 4u) {
     const float pBase = (1.0f - Fc) * (1.0f - o.metalness) * (1.0f - Fd) * (1.0f - o.tw);
     V3 l = gi_sample_hemisphere(x0, x1); // cosine-weighted, for every lobe of the opaque base
@@ -675,7 +714,8 @@ __device__ inline void opbr_sample_base(const OpbrParams& o, const ShState& st, 
     float w = ((1.0f - Fh) / (1.0f - Fd)) * (G2 / G1);
     out.k2 = normalize(k2); out.pdf = (1.0f - Fc) * (1.0f - o.metalness) * (1.0f - Fd) * o.tw * g.pdf;
     out.overPdf = (o.transTint * o.coatTint) * w; out.event = EV_GLOSSY | EV_TRANSMISSION;
-    if (o.filmWeight > 0.0f) out.overPdf = (o.transTint * o.coatTint) * ((v3(1.0f, 1.0f, 1.0f) - opbr_film_dielectric(o, kh, eta, Fh)) * ((G2 / G1) / (1.0f - Fd)));
+    if (o.filmWeight > 0.0f) out.overPdf = (o.transTint * o.coatTint) * ((v3(1.0f, 1.0f, 1.0f) - opbr_film_dielectric(o, kh, eta,
+        Fh)) * ((G2 / G1) / (1.0f - Fd)));
     return;
   }
   V3 k2 = (lobe == 0u) ? to_world_coat(st, g.l2) : to_world(st, g.l2);
@@ -726,9 +766,9 @@ __device__ inline void opbr_evaluate_base(const OpbrParams& o, const ShState& st
   if (st.hasCoatFrame) { l1c = to_local_coat(st, k1); nk1c = fmax2(l1c.z, 1e-4f); l1c.z = nk1c; l2c = to_local_coat(st, k2); }
   float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1c));
   float Fd = fresnel_dielectric(nk1, eta);
-  // Lobes whose weight is exactly zero are not evaluated.  The oracle evaluates them and multiplies by the zero -- the same bits: every skipped factor is finite and
-  // non-negative (D, G, Fresnel terms of positive roughness and nk1 >= 1e-4), so its product with the zero weight is +0, and +0 added to a non-negative sum changes
-  // nothing.  (C3's material has neither coat nor metal: 2 of its 3 GGX evaluations per shadow-ray set-up.)
+  // Lobes whose weight is exactly zero are not evaluated.  The oracle evaluates them and multiplies by the zero -- the same bits: every skipped factor is
+  // finite and non-negative (D, G, Fresnel terms of positive roughness and nk1 >= 1e-4), so its product with the zero weight is +0, and +0 added to a
+  // non-negative sum changes nothing.  (C3's material has neither coat nor metal: 2 of its 3 GGX evaluations per shadow-ray set-up.)
   float fc = 0.0f, pc = 0.0f, khc = 0.0f, Fch = 0.0f;
   if (o.coat != 0.0f) { ggx_eval2(l1c, l2c, o.coatAlpha, o.coatAlphaY, fc, pc, khc); Fch = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(khc)); }
   float fs, ps, khs; ggx_eval2(l1, l2, o.alpha, o.alphaY, fs, ps, khs);
@@ -784,11 +824,11 @@ __device__ inline void opbr_evaluate(const MaterialRec* m, const ShState& st, V3
 
 // ------------------------------------------------------------------------------------------------
 // OpenPBR, BASE variant (shade class SHADE_CLASS_OPBR_BASE; the reference compiles its hit shaders per material with feature #defines,
-// GlslShaderGen.cpp:204-274 -- here the host sorts OpenPBR materials into two variants and k_route bins their hits apart).  A BASE material has no coat, no fuzz,
-// no thin film, no anisotropy, no transmission, no subsurface, is not thin-walled and binds no texture (gi_build.cpp shadeClassOf): what is left is the metal lobe, the
-// dielectric reflection and the (energy-preserving Oren-Nayar) diffuse base.  The functions below are opbr_sample / opbr_evaluate with those weights set to their
-// constants and every operation that is an exact identity under them removed -- x * 1, x / 1, x - 0, (1 - 0), a lobe the selection can never reach; additions of an
-// exact +0 stay where the sign of a zero could differ -- so a BASE material shades to the same bits through either variant
+// GlslShaderGen.cpp:204-274 -- here the host sorts OpenPBR materials into two variants and k_route bins their hits apart).  A BASE material has no coat, no
+// fuzz, no thin film, no anisotropy, no transmission, no subsurface, is not thin-walled and binds no texture (gi_build.cpp shadeClassOf): what is left is the
+// metal lobe, the dielectric reflection and the (energy-preserving Oren-Nayar) diffuse base.  The functions below are opbr_sample / opbr_evaluate with those
+// weights set to their constants and every operation that is an exact identity under them removed -- x * 1, x / 1, x - 0, (1 - 0), a lobe the selection can
+// never reach; additions of an exact +0 stay where the sign of a zero could differ -- so a BASE material shades to the same bits through either variant
 // (test_shade_variants_are_bit_identical runs every scene through both).
 // ------------------------------------------------------------------------------------------------
 struct OpbrBaseParams { V3 albedo, metalTint, specColor, baseColor; float metalness, alpha, eta, specWeight, baseWeight, diffRough; };
@@ -803,9 +843,9 @@ __device__ __forceinline__ OpbrBaseParams opbr_base_params(const MaterialRec* m)
   o.alpha = p[MP_ALPHA]; o.eta = p[MP_ETA];
   return o;
 }
-// What the sampling routine and the evaluation of ONE hit both start from: the view direction in the shading frame, the interface's relative ior and its Fresnel
-// term at the view direction.  With NEE both run for (nearly) every hit: shade_segment makes the context once and hands it to both -- the same function of the same
-// arguments, so the same bits -- instead of evaluating the 65-instruction Fresnel term (three divisions, a square root) twice.
+// What the sampling routine and the evaluation of ONE hit both start from: the view direction in the shading frame, the interface's relative ior and its
+// Fresnel term at the view direction.  With NEE both run for (nearly) every hit: shade_segment makes the context once and hands it to both -- the same function
+// of the same arguments, so the same bits -- instead of evaluating the 65-instruction Fresnel term (three divisions, a square root) twice.
 struct OpbrBaseCtx { V3 l1; float nk1, eta, Fd; bool have; };
 __device__ __forceinline__ OpbrBaseCtx opbr_base_ctx(const MaterialRec* m, const ShState& st, V3 k1)
 {
@@ -813,7 +853,8 @@ __device__ __forceinline__ OpbrBaseCtx opbr_base_ctx(const MaterialRec* m, const
   c.eta = relative_eta(st, m->p[MP_ETA]); c.Fd = fresnel_dielectric(c.nk1, c.eta); c.have = true;
   return c;
 }
-__device__ inline void opbr_base_sample(const MaterialRec* m, const ShState& st, V3 k1, float x0, float x1, float x2, BsdfSample& out, const OpbrBaseCtx* ctx = nullptr)
+__device__ inline void opbr_base_sample(const MaterialRec* m, const ShState& st, V3 k1, float x0, float x1, float x2, BsdfSample& out,
+    const OpbrBaseCtx* ctx = nullptr)
 {
   const OpbrBaseParams o = opbr_base_params(m);
   V3 l1 = ctx ? ctx->l1 : to_local(st, k1);
@@ -969,7 +1010,8 @@ __device__ inline void sample_light(const SceneView& sc, const FrameUniforms& U,
     uint32_t idx = (uint32_t)(k1 * (float)U.sphereCount);
     const uint32_t last = U.sphereCount - 1u; if (idx > last) idx = last;
     V3 pos = v3(0.0f, 0.0f, 0.0f), em = pos, radius = pos; float area = 0.0f; dsPacked = 0u;
-    if (idx < U.sphereCount) { const SphereLightRec l = sc.sphereLights[idx]; pos = v3(l.pos); em = v3(l.em); radius = v3(l.radius); area = l.area; dsPacked = l.ds; }
+    if (idx < U.sphereCount) { const SphereLightRec l = sc.sphereLights[idx]; pos = v3(l.pos); em = v3(l.em); radius = v3(l.radius); area = l.area;
+        dsPacked = l.ds; }
     V3 samplePos = pos + gi_sample_sphere(k2, k3, radius);
     V3 dir = samplePos - surfacePos;
     dist = length(dir);
@@ -995,7 +1037,8 @@ __device__ inline void sample_light(const SceneView& sc, const FrameUniforms& U,
     uint32_t idx = (uint32_t)(k1 * (float)U.rectCount);
     const uint32_t last = U.rectCount - 1u; if (idx > last) idx = last;
     const RectLightRec l = sc.rectLights[idx];
-    const LightFrame lf = sc.rectFrames[idx]; // gi_decode_direction(l.t0), gi_decode_direction(l.t1) and their cross product, evaluated once on the host (gi_types.h)
+    // gi_decode_direction(l.t0), gi_decode_direction(l.t1) and their cross product, evaluated once on the host (gi_types.h)
+    const LightFrame lf = sc.rectFrames[idx];
     float sx = (k2 - 0.5f) * l.width, sy = (k3 - 0.5f) * l.height;
     V3 t0 = v3(lf.t0), t1 = v3(lf.t1);
     V3 samplePos = (v3(l.origin) + t0 * sx) + t1 * sy;

@@ -8,7 +8,8 @@ namespace gi {
 
 // Camera ray of (pixel, sample): RNG init, pixel jitter / filter importance sampling, thin lens, clip range
 // (rp_main.rgen:215-288).  Returns the RNG state after the draws the reference makes here.
-__device__ __forceinline__ void make_camera_ray(const FrameUniforms& U, uint32_t pixelIndex, uint32_t sampleIndex, V3& origin, V3& dir, float& tMin, float& tMax, uint32_t& rng)
+__device__ __forceinline__ void make_camera_ray(const FrameUniforms& U, uint32_t pixelIndex, uint32_t sampleIndex, V3& origin, V3& dir, float& tMin,
+    float& tMax, uint32_t& rng)
 {
   const uint32_t px = pixelIndex % U.imageWidth, py = pixelIndex / U.imageWidth;
   rng = gi_hash_init(pixelIndex * (sampleIndex + 1u)); // :223, common.glsl:121-124
@@ -61,9 +62,11 @@ struct ShadeIO {
   V3 sdir, nee; float ld; uint32_t rngShadow;                        // out: shadow ray direction / distance, NEE contribution, rng copy (rp_main.rgen:399)
 };
 template <uint32_t KLASS, bool TEXTURED, bool VOLUME, bool NEE, bool PACKED = false>
-__device__ __forceinline__ void shade_segment(const FrameUniforms& U, const SceneView& sc, float* M /* medium stack of the path (VOLUME) */, const F4& h, const F4& rd, ShadeIO& io)
+__device__ __forceinline__ void shade_segment(const FrameUniforms& U, const SceneView& sc, float* M /* medium stack of the path (VOLUME) */, const F4& h,
+    const F4& rd, ShadeIO& io)
 {
-  static_assert(KLASS != SHADE_CLASS_OPBR_BASE || (!TEXTURED && !VOLUME), "the BASE variant exists for untextured materials in renders without a medium stack (launchShade sends the others through the full kernel)");
+  static_assert(KLASS != SHADE_CLASS_OPBR_BASE || (!TEXTURED && !VOLUME),
+      "the BASE variant exists for untextured materials in renders without a medium stack (launchShade sends the others through the full kernel)");
   V3 throughput = io.throughput, radiance = io.radiance; uint32_t bitfield = io.bitfield, rng = io.rng;
   bool cont = false, shadow = false, shadowFirst = false; uint32_t rngShadow = 0u;
   V3 no = v3(0.0f, 0.0f, 0.0f), k2 = no, sdir = no, nee = no; float ld = 0.0f, tMaxNext = GI_FLT_MAX;
@@ -98,7 +101,9 @@ __device__ __forceinline__ void shade_segment(const FrameUniforms& U, const Scen
   if (mediumIdx > 0u) {
     const float distance = h.x * U.metersPerSceneUnit;
     if (!VOLUME) { // empty medium stack: inside (1-bit toggle) -> Beer-Lambert with the HIT material's absorption coefficient (:169-173)
-      if (((KLASS == KLASS_DYNAMIC) ? mat->klass : KLASS) == 2u || KLASS == SHADE_CLASS_OPBR_BASE) throughput = throughput * v3(gi_expf(-mat->p[MP_SIGMA_A] * distance), gi_expf(-mat->p[MP_SIGMA_A + 1] * distance), gi_expf(-mat->p[MP_SIGMA_A + 2] * distance));
+      if (((KLASS == KLASS_DYNAMIC) ? mat->klass : KLASS) == 2u
+          || KLASS == SHADE_CLASS_OPBR_BASE) throughput = throughput * v3(gi_expf(-mat->p[MP_SIGMA_A] * distance), gi_expf(-mat->p[MP_SIGMA_A + 1] * distance),
+          gi_expf(-mat->p[MP_SIGMA_A + 2] * distance));
     } else { // the medium on top of the stack (:174-184)
       const float* m = M + (mediumIdx - 1u) * MEDIUM_FLOATS;
       prevMediumIor = m[0];
@@ -106,17 +111,20 @@ __device__ __forceinline__ void shade_segment(const FrameUniforms& U, const Scen
       throughput = throughput * v3(gi_expf(-m[5] * distance), gi_expf(-m[6] * distance), gi_expf(-m[7] * distance));
     }
   }
-  const bool thinWalled = ((KLASS == KLASS_DYNAMIC) ? mat->klass : KLASS) == 2u && ((uint32_t)mat->p[MP_FEATURES] & MATF_THIN_WALLED) != 0u; // mdl_thin_walled (:155-157): OpenPBR geometry_thin_walled
+  // mdl_thin_walled (:155-157): OpenPBR geometry_thin_walled
+  const bool thinWalled = ((KLASS == KLASS_DYNAMIC) ? mat->klass : KLASS) == 2u && ((uint32_t)mat->p[MP_FEATURES] & MATF_THIN_WALLED) != 0u;
   ss.thinWalled = thinWalled;
   ss.sssVolume = VOLUME; // a medium stack exists: OpenPBR's volumetric subsurface lobe is live
-  if (VOLUME) { ss.ior1 = (ss.frontFace || thinWalled) ? prevMediumIor : -1.0f; ss.ior2 = (ss.frontFace || thinWalled) ? -1.0f : nextMediumIor; } // iorCurrent / iorOther (:188-189)
+  // iorCurrent / iorOther (:188-189)
+  if (VOLUME) { ss.ior1 = (ss.frontFace || thinWalled) ? prevMediumIor : -1.0f; ss.ior2 = (ss.frontFace || thinWalled) ? -1.0f : nextMediumIor; }
   // emission (rp_main.chit:293-343): uniform EDF, radiance == emission colour where cos > 0
   V3 em = (ss.texMask & (1u << TEX_EMISSION)) ? ss.texEmission : v3(mat->p[3], mat->p[4], mat->p[5]);
   if (em.x != 0.0f || em.y != 0.0f || em.z != 0.0f) {
     if (ss.frontFace || !isDoubleSided) {
       const float c = dot(-rayDir, ss.normal);
       if (c > 0.0f) {
-        if (((KLASS == KLASS_DYNAMIC) ? mat->klass : KLASS) == 2u) // emission_edf (open_pbr_surface.mtlx:590-619): seen through the coat (BASE variant: no coat, factor 1)
+        // emission_edf (open_pbr_surface.mtlx:590-619): seen through the coat (BASE variant: no coat, factor 1)
+        if (((KLASS == KLASS_DYNAMIC) ? mat->klass : KLASS) == 2u)
           em = em * opbr_emission_factor(mat->p[12], v3(mat->p[19], mat->p[20], mat->p[21]), mat->p[MP_COAT_F0], c);
         radiance = radiance + throughput * (em * U.exposureScale);
       }
@@ -161,7 +169,8 @@ __device__ __forceinline__ void shade_segment(const FrameUniforms& U, const Scen
   }
   // NEE AOV (rp_main.rgen:431-435): bounce 0 only; a shadow ray that is not traced counts as "not shadowed"
   shadowFirst = bounce == 0u; // the caller records "not shadowed" for the NEE AOV when shadowFirst && !shadow
-  if (KLASS != SHADE_CLASS_OPBR_BASE && !thinWalled && isTransmission) { // (a BASE material has no transmissive lobe) medium stack (:447-480); a thin-walled surface has the same medium on both sides
+  // (a BASE material has no transmissive lobe) medium stack (:447-480); a thin-walled surface has the same medium on both sides
+  if (KLASS != SHADE_CLASS_OPBR_BASE && !thinWalled && isTransmission) {
     uint32_t newIdx = mediumIdx;
     if (VOLUME) {
       if (ss.frontFace) { // push the material's medium: mdl_ior, mdl_volume_{scattering,absorption}_coefficient, MEDIUM_DIRECTIONAL_BIAS
@@ -173,7 +182,9 @@ __device__ __forceinline__ void shade_segment(const FrameUniforms& U, const Scen
             const V3 sigS = (depth > 0.0f) ? v3(mat->p[29] / depth, mat->p[30] / depth, mat->p[31] / depth) : v3(0.0f, 0.0f, 0.0f);
             const V3 sigT = v3(mat->p[MP_SIGMA_A], mat->p[MP_SIGMA_A + 1], mat->p[MP_SIGMA_A + 2]) + sigS;
             m[0] = mat->p[MP_ETA]; m[1] = mat->p[47]; m[2] = sigS.x; m[3] = sigS.y; m[4] = sigS.z; m[5] = sigT.x; m[6] = sigT.y; m[7] = sigT.z;
-            if (bs.event & EV_SUBSURFACE) { m[1] = mat->p[59]; m[2] = mat->sss[0]; m[3] = mat->sss[1]; m[4] = mat->sss[2]; m[5] = mat->sss[3]; m[6] = mat->sss[4]; m[7] = mat->sss[5]; } // entered through the subsurface lobe
+            // entered through the subsurface lobe
+            if (bs.event & EV_SUBSURFACE) { m[1] = mat->p[59]; m[2] = mat->sss[0]; m[3] = mat->sss[1]; m[4] = mat->sss[2]; m[5] = mat->sss[3];
+                m[6] = mat->sss[4]; m[7] = mat->sss[5]; }
           } else { m[0] = 1.0f; m[1] = 0.0f; m[2] = 0.0f; m[3] = 0.0f; m[4] = 0.0f; m[5] = 0.0f; m[6] = 0.0f; m[7] = 0.0f; }
         }
       } else if (mediumIdx > 0u) newIdx = mediumIdx - 1u; // pop
@@ -240,11 +251,11 @@ __device__ __forceinline__ void slot_begin_path(Slot* S, uint32_t rng, uint32_t 
   st4(&S->rad, 0.0f, 0.0f, 0.0f, u2f(rng));
   st4(&S->id, u2f(pixelLocal), u2f(sLocal), u2f(1u), 0.0f);
 }
-// FLAG_DEFER_SLOT: the first segment of a camera path whose Slot k_raygen did not write has been traced.  A hit writes the Slot now (the path goes on exactly as
-// if k_raygen had written it).  A miss retires the sample on the spot -- radiance 0 + throughput 1 x background, then the per-sample finish, the arithmetic of
-// k_raygen's finish of a REGEN_MISSED entry (rp_main.miss:68-86, rp_main.rgen:489-496) -- and returns true: the slot goes back to the regen queue as REGEN_FRESH,
-// "nothing to finish, memory unwritten".  Scenes with a dome image or medium stacks need the slot at a miss (dome_miss / the scattering test): the caller writes
-// it first and takes the ordinary route.
+// FLAG_DEFER_SLOT: the first segment of a camera path whose Slot k_raygen did not write has been traced.  A hit writes the Slot now (the path goes on exactly
+// as if k_raygen had written it).  A miss retires the sample on the spot -- radiance 0 + throughput 1 x background, then the per-sample finish, the arithmetic
+// of k_raygen's finish of a REGEN_MISSED entry (rp_main.miss:68-86, rp_main.rgen:489-496) -- and returns true: the slot goes back to the regen queue as
+// REGEN_FRESH, "nothing to finish, memory unwritten".  Scenes with a dome image or medium stacks need the slot at a miss (dome_miss / the scattering test): the
+// caller writes it first and takes the ordinary route.
 __device__ __forceinline__ void retire_fresh_miss(const FrameUniforms& U, const FreshRec& f, F4* __restrict__ sampleBuf)
 {
   uint32_t pixelLocal, sLocal; work_item(U, f.work, pixelLocal, sLocal);

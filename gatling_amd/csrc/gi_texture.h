@@ -66,7 +66,8 @@ __device__ inline F4 tex_texel_float4_2d(const TextureRec& t, bool valid, int x,
   if (!valid || x < 0 || x >= (int)t.width || y < 0 || y >= (int)t.height) return F4{0.0f, 0.0f, 0.0f, 0.0f};
   return ld4(&reinterpret_cast<const F4*>(t.texels)[(size_t)y * t.width + (size_t)x]);
 }
-__device__ __forceinline__ void tex_resolution_2d(const TextureRec& t, bool valid, int& w, int& h) { w = valid ? (int)t.width : 0; h = valid ? (int)t.height : 0; }
+__device__ __forceinline__ void tex_resolution_2d(const TextureRec& t, bool valid, int& w, int& h)
+{ w = valid ? (int)t.width : 0; h = valid ? (int)t.height : 0; }
 __device__ inline F4 sample_trilinear_repeat(const TextureRec3& t, float u, float v, float w)
 {
   w = w - floorf(w);
@@ -108,8 +109,8 @@ __device__ __forceinline__ float cutout_rule(uint32_t klass, float op, float thr
 // Cutout opacity of a candidate hit (rp_main.ahit:51-60 evaluates the material's cutout expression with the candidate's shading
 // state): the constant, or -- when the opacity input is textured -- channel `channel` of texel * scale + bias at the candidate's st
 // (st interpolated as setup_shading_state does, mdl_shading_state.glsl:62-65).
-// UsdTransform2d between the primvar reader and a UsdUVTexture's `st` (UsdPreviewSurface specification: scale, then rotation, then translation), folded into six
-// floats by the front end; fixed association, no contraction (== oracle tex_transform_st)
+// UsdTransform2d between the primvar reader and a UsdUVTexture's `st` (UsdPreviewSurface specification: scale, then rotation, then translation), folded into
+// six floats by the front end; fixed association, no contraction (== oracle tex_transform_st)
 __device__ __forceinline__ void tex_transform_st(const TexBindingRec& b, float& u, float& v)
 {
   if (!(b.mode & TEX_MODE_XFORM)) return;
@@ -136,7 +137,8 @@ __device__ inline float cutout_opacity_at(const SceneView& sc, uint32_t matWord,
   tex_transform_st(b, u, v);
   const F4 t = tex_lookup_float4_2d(sc.textures[b.tex - 1u], u, v, b.mode & 0xffu, (b.mode >> 8) & 0xffu);
   const uint32_t ch = (b.mode >> 16) & 3u;
-  const float raw = ch == 0u ? t.x * b.scale[0] + b.bias[0] : (ch == 1u ? t.y * b.scale[1] + b.bias[1] : (ch == 2u ? t.z * b.scale[2] + b.bias[2] : t.w * b.scale[3] + b.bias[3]));
+  const float raw = ch == 0u
+      ? t.x * b.scale[0] + b.bias[0] : (ch == 1u ? t.y * b.scale[1] + b.bias[1] : (ch == 2u ? t.z * b.scale[2] + b.bias[2] : t.w * b.scale[3] + b.bias[3]));
   return cutout_rule(m->klass, raw, m->p[15]); // p[15] = opacityThreshold
 }
 

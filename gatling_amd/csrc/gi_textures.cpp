@@ -107,7 +107,11 @@ GiCTexture* giCCreateTextureFromFile(GiCScene* scene, const char* filePath, int3
     for (GiCTexture* t : scene->textures) if (t->cacheKey == key) { t->refs++; return t; }
   }
   uint32_t w = 0, h = 0; std::vector<float> px;
-  if (!loadImage(filePath, srgbToLinear != 0, /*keepHdr=*/false, w, h, px)) { setError("giCCreateTextureFromFile: cannot open or decode the image (in-library: .png, baseline .jpg, .hdr, .pfm; other formats through giCSetImageLoader)"); return nullptr; }
+  if (!loadImage(filePath, srgbToLinear != 0, /*keepHdr=*/false, w, h, px)) {
+    setError("giCCreateTextureFromFile: cannot open or decode the image (in-library: .png, baseline .jpg, .hdr, .pfm; other formats through "
+             "giCSetImageLoader)");
+    return nullptr;
+  }
   GiCTextureDesc td{w, h, px.data()};
   GiCTexture* t = giCCreateTexture(scene, &td);
   if (t) { std::lock_guard<std::mutex> g(scene->mutex); t->cacheKey = key; }

@@ -88,11 +88,12 @@ __device__ __forceinline__ uint32_t trav_node_pick(RayWalk& R, uint2 (*s_stack)[
 // of hit internal children.  The box test is a conservative filter (explicit fma, far planes and tBest widened by 1e-5 relative), it never decides a result.
 // Written for the VALU: the two planes of an axis go through one packed fma (v_pk_fma_f32 issues at the rate of v_fma_f32, tools/valu_calib.hip), the per-child
 // meta bytes (slot index, child bits, octant flip of internal children) are decoded four at a time with byte-parallel integer ops, and empty slots (meta 0)
-// contribute no bits, so the hit mask is assembled without a branch.  ORDERED = false (shadow walks: the first hit ends them, near-to-far buys nothing) leaves the
-// internal children in slot order and saves the flip.
+// contribute no bits, so the hit mask is assembled without a branch.  ORDERED = false (shadow walks: the first hit ends them, near-to-far buys nothing) leaves
+// the internal children in slot order and saves the flip.
 typedef float gi_f2 __attribute__((ext_vector_type(2)));
 template <bool SLACK = false, bool ORDERED = true>
-__device__ __forceinline__ uint2 trav_node_test(RayWalk& R, const uint4& n0, const uint4& n1, const uint4& n2, const uint4& n3, const uint4& n4, float slack = 0.0f)
+__device__ __forceinline__ uint2 trav_node_test(RayWalk& R, const uint4& n0, const uint4& n1, const uint4& n2, const uint4& n3, const uint4& n4,
+    float slack = 0.0f)
 {
   const V3 o = R.o, d = R.d;
   constexpr float WIDEN = 1.00001f;
@@ -127,7 +128,8 @@ __device__ __forceinline__ uint2 trav_node_test(RayWalk& R, const uint4& n0, con
     if (ORDERED) {
       const uint32_t inner4 = ((m4 & (m4 << 1)) >> 4) & 0x01010101u;
       uint32_t hi4 = inner4 << 8;
-      asm volatile("" : "+v"(hi4)); // (x << 8) - x == x * 0xff per byte: kept as shift + subtract (left alone the compiler folds it into v_mul_lo_u32, a quarter-rate instruction)
+      // (x << 8) - x == x * 0xff per byte: kept as shift + subtract (left alone the compiler folds it into v_mul_lo_u32, a quarter-rate instruction)
+      asm volatile("" : "+v"(hi4));
       idx4 = (m4 ^ (oct4 & (hi4 - inner4))) & 0x1f1f1f1fu;
     }
     const uint32_t bits4 = (m4 >> 5) & 0x07070707u;
@@ -149,8 +151,8 @@ __device__ __forceinline__ uint2 trav_node_test(RayWalk& R, const uint4& n0, con
   return make_uint2(n1.y, hitmask & 0x00ffffffu);
 }
 
-// fetch of a node's five 16-byte pieces from global memory: 32-bit byte offset on the scalar base (a scene's node array stays below 4 GiB: the flat layout ends at
-// 2^26 triangles), two shift-adds instead of a 64-bit multiply-add
+// fetch of a node's five 16-byte pieces from global memory: 32-bit byte offset on the scalar base (a scene's node array stays below 4 GiB: the flat layout ends
+// at 2^26 triangles), two shift-adds instead of a 64-bit multiply-add
 __device__ __forceinline__ void node_load(const SceneView& sc, uint32_t nodeIdx, uint4& n0, uint4& n1, uint4& n2, uint4& n3, uint4& n4)
 {
   uint32_t off = nodeIdx << 4;
@@ -248,8 +250,9 @@ __device__ __forceinline__ bool trav_step(RayTrav& R, const SceneView& sc, const
 constexpr uint32_t TRI_ID_BITS = 26; // queue entry = ray lane << 26 | triangle index (the host refuses scenes with >= 2^26 triangles)
 struct WaveTri {
   unsigned long long best[64]; // per ray lane: (t bits << 32) | (scene-order id + 1); low word 0 = no hit yet
-  uint4 hit[64];               // per ray lane: that hit as (triangle index, u bits, v bits, material word) -- k_trace_dyn: (u, v, triangle | class << 28) of the finished result
-                               // record (its t is the key's upper word), and in .w the number of helper lanes walking parts of this ray
+  // per ray lane: that hit as (triangle index, u bits, v bits, material word) -- k_trace_dyn: (u, v, triangle | class << 28) of
+  // the finished result record (its t is the key's upper word), and in .w the number of helper lanes walking parts of this ray
+  uint4 hit[64];
   uint32_t queue[128];         // ring of pending (ray lane, triangle) pairs (a 256-entry ring measured slower)
 };
 // WaveTri lives in LDS, but through a C++ reference the compiler only sees a generic pointer and emits FLAT loads / stores (vector-memory
@@ -259,19 +262,26 @@ struct WaveTri {
 typedef uint32_t gi_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void wt_queue_put(WaveTri& W, uint32_t i, uint32_t v) { *(volatile GI_LDS uint32_t*)&((GI_LDS WaveTri*)&W)->queue[i] = v; }
 __device__ __forceinline__ uint32_t wt_queue_get(WaveTri& W, uint32_t i) { return *(volatile GI_LDS uint32_t*)&((GI_LDS WaveTri*)&W)->queue[i]; }
-__device__ __forceinline__ void wt_best_put(WaveTri& W, uint32_t i, unsigned long long v) { *(volatile GI_LDS unsigned long long*)&((GI_LDS WaveTri*)&W)->best[i] = v; }
-__device__ __forceinline__ unsigned long long wt_best_get(WaveTri& W, uint32_t i) { return *(volatile GI_LDS unsigned long long*)&((GI_LDS WaveTri*)&W)->best[i]; }
-__device__ __forceinline__ uint32_t wt_best_t(WaveTri& W, uint32_t i) { return ((volatile GI_LDS uint32_t*)&((GI_LDS WaveTri*)&W)->best[i])[1]; }   // t bits of the nearest hit so far (or of tMax)
-__device__ __forceinline__ uint32_t wt_best_id(WaveTri& W, uint32_t i) { return ((volatile GI_LDS uint32_t*)&((GI_LDS WaveTri*)&W)->best[i])[0]; }  // scene-order id + 1, 0 = no hit yet
+__device__ __forceinline__ void wt_best_put(WaveTri& W, uint32_t i, unsigned long long v)
+{ *(volatile GI_LDS unsigned long long*)&((GI_LDS WaveTri*)&W)->best[i] = v; }
+__device__ __forceinline__ unsigned long long wt_best_get(WaveTri& W, uint32_t i)
+{ return *(volatile GI_LDS unsigned long long*)&((GI_LDS WaveTri*)&W)->best[i]; }
+// t bits of the nearest hit so far (or of tMax)
+__device__ __forceinline__ uint32_t wt_best_t(WaveTri& W, uint32_t i) { return ((volatile GI_LDS uint32_t*)&((GI_LDS WaveTri*)&W)->best[i])[1]; }
+// scene-order id + 1, 0 = no hit yet
+__device__ __forceinline__ uint32_t wt_best_id(WaveTri& W, uint32_t i) { return ((volatile GI_LDS uint32_t*)&((GI_LDS WaveTri*)&W)->best[i])[0]; }
 __device__ __forceinline__ void wt_best_min(WaveTri& W, uint32_t i, unsigned long long v)
 { __hip_atomic_fetch_min((GI_LDS unsigned long long*)&((GI_LDS WaveTri*)&W)->best[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void wt_hit_put(WaveTri& W, uint32_t i, uint32_t x, uint32_t y, uint32_t z, uint32_t w)
 { gi_u4 v = {x, y, z, w}; *(volatile GI_LDS gi_u4*)&((GI_LDS WaveTri*)&W)->hit[i] = v; }
 typedef uint32_t gi_u3 __attribute__((ext_vector_type(3)));
-__device__ __forceinline__ void wt_hit_put3(WaveTri& W, uint32_t i, uint32_t x, uint32_t y, uint32_t z) { gi_u3 v = {x, y, z}; *(volatile GI_LDS gi_u3*)&((GI_LDS WaveTri*)&W)->hit[i] = v; } // (leaves .w alone)
+// (leaves .w alone)
+__device__ __forceinline__ void wt_hit_put3(WaveTri& W, uint32_t i, uint32_t x, uint32_t y, uint32_t z)
+{ gi_u3 v = {x, y, z}; *(volatile GI_LDS gi_u3*)&((GI_LDS WaveTri*)&W)->hit[i] = v; }
 __device__ __forceinline__ uint32_t wt_helpers_add(WaveTri& W, uint32_t i, uint32_t v)
 { return __hip_atomic_fetch_add(&((GI_LDS uint32_t*)&((GI_LDS WaveTri*)&W)->hit[i])[3], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ uint4 wt_hit_get(WaveTri& W, uint32_t i) { const gi_u4 v = *(volatile GI_LDS gi_u4*)&((GI_LDS WaveTri*)&W)->hit[i]; return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint4 wt_hit_get(WaveTri& W, uint32_t i)
+{ const gi_u4 v = *(volatile GI_LDS gi_u4*)&((GI_LDS WaveTri*)&W)->hit[i]; return make_uint4(v.x, v.y, v.z, v.w); }
 
 // 64 (ray lane, triangle) pairs of the ring, one per lane.  RESULT_RECORD (k_trace_dyn): the winner leaves the ray's finished result record in WaveTri::hit.
 template <bool COUNT, bool ALL_LDS, bool CUTOUT, bool RESULT_RECORD = false>
@@ -290,8 +300,8 @@ __device__ __forceinline__ void wave_tri_batch(WaveTri& W, uint32_t head, uint32
   if (act) {
     uint4 a, b, c;
     // (the compiler loads c.x here and sinks the loads of c.y -- scene-order id -- and c.w -- material word -- into the accept branch; loading all 48 bytes
-    // up front measured SLOWER in full launches, r03a: the vector-memory request path, not the dependent round trip, is what the batch waits for -- and no faster in
-    // thin ones, r05i)
+    // up front measured SLOWER in full launches, r03a: the vector-memory request path, not the dependent round trip, is what the batch waits for -- and no
+    // faster in thin ones, r05i)
     if (ALL_LDS || triIdx < ldsTris) { const uint4* p = s_tris + triIdx * 3u; a = p[0]; b = p[1]; c = p[2]; }
     else { const uint4* p = reinterpret_cast<const uint4*>(sc.tris) + (size_t)triIdx * 4u; a = p[0]; b = p[1]; c = p[2]; }
     if (COUNT) tc.tris++;
@@ -305,7 +315,8 @@ __device__ __forceinline__ void wave_tri_batch(WaveTri& W, uint32_t head, uint32
       const unsigned long long key = ((unsigned long long)f2u(t) << 32) | (unsigned long long)(c.y + 1u);
       wt_best_min(W, rl, key);
       if (wt_best_get(W, rl) == key) {
-        if (RESULT_RECORD) wt_hit_put3(W, rl, f2u(u), f2u(v), triIdx | (((c.w >> 24) & 0xfu) << 28)); // the material class k_route sorts by rides in the top four bits
+        // the material class k_route sorts by rides in the top four bits
+        if (RESULT_RECORD) wt_hit_put3(W, rl, f2u(u), f2u(v), triIdx | (((c.w >> 24) & 0xfu) << 28));
         else wt_hit_put(W, rl, triIdx, f2u(u), f2u(v), c.w);
       }
     }
@@ -432,7 +443,8 @@ __device__ __forceinline__ void trav2_enter(RayTrav2& R, const SceneView& sc, ui
   const V3 rel = v3(R.wo.x - r0.w, R.wo.y - r1.w, R.wo.z - r2.w); // o2w translation = column 3
   const float w[9] = {r3.x, r3.y, r3.z, r3.w, r4.x, r4.y, r4.z, r4.w, r5.x};
   const V3 o = v3((w[0] * rel.x + w[1] * rel.y) + w[2] * rel.z, (w[3] * rel.x + w[4] * rel.y) + w[5] * rel.z, (w[6] * rel.x + w[7] * rel.y) + w[8] * rel.z);
-  const V3 d = v3((w[0] * R.wd.x + w[1] * R.wd.y) + w[2] * R.wd.z, (w[3] * R.wd.x + w[4] * R.wd.y) + w[5] * R.wd.z, (w[6] * R.wd.x + w[7] * R.wd.y) + w[8] * R.wd.z);
+  const V3 d = v3((w[0] * R.wd.x + w[1] * R.wd.y) + w[2] * R.wd.z, (w[3] * R.wd.x + w[4] * R.wd.y) + w[5] * R.wd.z,
+      (w[6] * R.wd.x + w[7] * R.wd.y) + w[8] * R.wd.z);
   // rounding of the transform: a few ulps of the summed term magnitudes, for the origin and -- over the distance the ray covers inside
   // the mesh, <= |o'| + its extent -- for the direction; 4e-6 is > 30 ulps of that
   const float m0 = (fabsf(w[0] * rel.x) + fabsf(w[1] * rel.y)) + fabsf(w[2] * rel.z), m1 = (fabsf(w[3] * rel.x) + fabsf(w[4] * rel.y)) + fabsf(w[5] * rel.z),
@@ -450,7 +462,8 @@ __device__ __forceinline__ void trav2_leave(RayTrav2& R)
 
 // 64 (ray lane, mesh triangle) pairs: rebuild the world-space triangle of the owning lane's instance, then the flat layout's test
 template <bool COUNT, bool CUTOUT>
-__device__ __forceinline__ void wave_tri_batch2(WaveTri& W, uint32_t head, uint32_t cnt, const RayTrav2& R, uint32_t rng, const SceneView& sc, TraceCounters& tc)
+__device__ __forceinline__ void wave_tri_batch2(WaveTri& W, uint32_t head, uint32_t cnt, const RayTrav2& R, uint32_t rng, const SceneView& sc,
+    TraceCounters& tc)
 {
   const uint32_t lane = __lane_id();
   const bool act = lane < cnt;
@@ -470,12 +483,16 @@ __device__ __forceinline__ void wave_tri_batch2(WaveTri& W, uint32_t head, uint3
     const float4 pa = make_float4(ta.x, ta.y, ta.z, 0.0f), pb = make_float4(ta.w, tb.x, tb.y, 0.0f), pc = make_float4(tb.z, tb.w, tq.x, 0.0f);
     const uint4 t4 = make_uint4(0u, 0u, 0u, f2u(tq.y));
     // host xformPoint (gi_build.cpp): ((a0 p0 + a1 p1) + a2 p2) + a3
-    const V3 p0 = v3(((r0.x * pa.x + r0.y * pa.y) + r0.z * pa.z) + r0.w, ((r1.x * pa.x + r1.y * pa.y) + r1.z * pa.z) + r1.w, ((r2.x * pa.x + r2.y * pa.y) + r2.z * pa.z) + r2.w);
-    const V3 p1 = v3(((r0.x * pb.x + r0.y * pb.y) + r0.z * pb.z) + r0.w, ((r1.x * pb.x + r1.y * pb.y) + r1.z * pb.z) + r1.w, ((r2.x * pb.x + r2.y * pb.y) + r2.z * pb.z) + r2.w);
-    const V3 p2 = v3(((r0.x * pc.x + r0.y * pc.y) + r0.z * pc.z) + r0.w, ((r1.x * pc.x + r1.y * pc.y) + r1.z * pc.z) + r1.w, ((r2.x * pc.x + r2.y * pc.y) + r2.z * pc.z) + r2.w);
+    const V3 p0 = v3(((r0.x * pa.x + r0.y * pa.y) + r0.z * pa.z) + r0.w, ((r1.x * pa.x + r1.y * pa.y) + r1.z * pa.z) + r1.w,
+        ((r2.x * pa.x + r2.y * pa.y) + r2.z * pa.z) + r2.w);
+    const V3 p1 = v3(((r0.x * pb.x + r0.y * pb.y) + r0.z * pb.z) + r0.w, ((r1.x * pb.x + r1.y * pb.y) + r1.z * pb.z) + r1.w,
+        ((r2.x * pb.x + r2.y * pb.y) + r2.z * pb.z) + r2.w);
+    const V3 p2 = v3(((r0.x * pc.x + r0.y * pc.y) + r0.z * pc.z) + r0.w, ((r1.x * pc.x + r1.y * pc.y) + r1.z * pc.z) + r1.w,
+        ((r2.x * pc.x + r2.y * pc.y) + r2.z * pc.z) + r2.w);
     const V3 e1 = p1 - p0, e2 = p2 - p0;
     const uint32_t orig = tv.y + t4.w; // scene-order id in the flat numbering
-    const uint4 a = make_uint4(f2u(p0.x), f2u(p0.y), f2u(p0.z), f2u(e1.x)), b = make_uint4(f2u(e1.y), f2u(e1.z), f2u(e2.x), f2u(e2.y)), c = make_uint4(f2u(e2.z), orig, inst, tv.z);
+    const uint4 a = make_uint4(f2u(p0.x), f2u(p0.y), f2u(p0.z), f2u(e1.x)), b = make_uint4(f2u(e1.y), f2u(e1.z), f2u(e2.x), f2u(e2.y)),
+        c = make_uint4(f2u(e2.z), orig, inst, tv.z);
     if (COUNT) tc.tris++;
     float t, u, v;
     bool accept = tri_test(o, d, tMin, a, b, c, t, u, v);
@@ -486,13 +503,15 @@ __device__ __forceinline__ void wave_tri_batch2(WaveTri& W, uint32_t head, uint3
     if (accept) {
       const unsigned long long key = ((unsigned long long)f2u(t) << 32) | (unsigned long long)(orig + 1u);
       wt_best_min(W, rl, key);
-      if (wt_best_get(W, rl) == key) wt_hit_put3(W, rl, f2u(u), f2u(v), orig | (((c.w >> 24) & 0xfu) << 28)); // the result record, with the SCENE-ORDER id: the kernel maps it to the flat index
+      // the result record, with the SCENE-ORDER id: the kernel maps it to the flat index
+      if (wt_best_get(W, rl) == key) wt_hit_put3(W, rl, f2u(u), f2u(v), orig | (((c.w >> 24) & 0xfu) << 28));
     }
   }
 }
 
 template <bool ANYHIT, bool COUNT, bool CUTOUT>
-__device__ __forceinline__ bool wave_step2(RayTrav2& R, bool alive, WaveTri& W, const SceneView& sc, uint2 (*s_stack)[TRACE_BLOCK], TraceCounters& tc, uint32_t rng)
+__device__ __forceinline__ bool wave_step2(RayTrav2& R, bool alive, WaveTri& W, const SceneView& sc, uint2 (*s_stack)[TRACE_BLOCK], TraceCounters& tc,
+    uint32_t rng)
 {
   const uint32_t lane = __lane_id(), tid = threadIdx.x;
   uint2 none[1];

@@ -29,7 +29,9 @@ struct TriRec {
   float e2[3];
   uint32_t origId;    // global triangle id in scene order (tie-break key, DESIGN.md "Traversal contract")
   uint32_t instance;  // index into InstanceRec[]
-  uint32_t matFlags;  // material index (bits 0-23) | material class (bits 24-27) | bit 28: cutout opacity < 1 | mesh flags << 30 (bit0 flipFacing, bit1 doubleSided; rp_main.h:115-116)
+  // material index (bits 0-23) | material class (bits 24-27) | bit 28: cutout opacity
+  // < 1 | mesh flags << 30 (bit0 flipFacing, bit1 doubleSided; rp_main.h:115-116)
+  uint32_t matFlags;
   uint32_t vi[3];     // absolute indices into the scene vertex array
   uint32_t prim;      // gl_PrimitiveID within the mesh
 };
@@ -50,10 +52,11 @@ struct FVertex {
 static_assert(sizeof(FVertex) == 48, "FVertex must be 48 bytes");
 
 // Shading record of one MESH triangle (scenes beyond LDS, round 3): three 48-byte vertices at arbitrary indices are 3 - 4.5 cache lines per hit, this record is
-// 160 bytes = two.  Until round 6 it was ONE 128-byte line with normals and tangents in the reference's octahedral unorm2x16 encoding (rp::FVertex, rp_main.h:58-64),
-// decoded per hit; now they are stored DECODED, as FVertex holds them -- decoded once on the host with the operations of decode_direction (common.glsl:198-207), so
-// both forms give the same bits -- because the shade stage is bound by its instruction count, not by its lines: six decodes were ~400
-// of the ~3 500 VALU instructions a wave of hits executes (two IEEE divisions, a square root and a third division each).  Shared by all instances of the mesh;
+// 160 bytes = two.  Until round 6 it was ONE 128-byte line with normals and tangents in the reference's octahedral unorm2x16 encoding (rp::FVertex,
+// rp_main.h:58-64), decoded per hit; now they are stored DECODED, as FVertex holds them -- decoded once on the host with the operations of decode_direction
+// (common.glsl:198-207), so both forms give the same bits -- because the shade stage is bound by its instruction count, not by its lines (DESIGN.md section 4,
+// r05ea): six decodes were ~400 of the ~3 500 VALU instructions a wave of hits executes (two IEEE
+// divisions, a square root and a third division each).  Shared by all instances of the mesh;
 // TriRec::vi[0] holds its index.
 struct TriShade {
   float p[3][3];       // object-space corner positions
@@ -81,16 +84,21 @@ constexpr uint32_t MAT_PARAM_COUNT = 64;
 // oracle evaluates per hit)
 // class 1 (UsdPreviewSurface): albedo, F0, alpha, coat, coatAlpha.  class 2 (OpenPBR): albedo = base_color*base_weight,
 // F0 slot = metal edge tint (specular_color*specular_weight), alpha, coat, coatAlpha, coatF0, modulated eta, sigma_a
-// MP_FEATURES (OpenPBR records only): the device copy of the thin-walled switch p[54] carries a small bit set as a float -- which optional lobes the material has --
-// so that k_shade loads the fuzz / anisotropy inputs only for materials that use them (the stage is bound by its scattered requests, not by arithmetic)
+// MP_FEATURES (OpenPBR records only): the device copy of the thin-walled switch p[54] carries a small bit set as a float -- which optional lobes the material
+// has -- so that k_shade loads the fuzz / anisotropy inputs only for materials that use them (the stage is bound by its scattered requests, not by arithmetic)
 constexpr uint32_t MP_FEATURES = 54, MATF_THIN_WALLED = 1u, MATF_FUZZ = 2u, MATF_ANISOTROPY = 4u, MATF_THIN_FILM = 8u,
-                   MATF_SSS_VOLUME = 16u; // not thin-walled, subsurface_weight > 0: the volumetric subsurface lobe (live in renders with a medium stack), coefficients in MaterialRec::sss
-enum : uint32_t { MP_ALBEDO = 32, MP_F0 = 35, MP_ALPHA = 38, MP_COAT = 39, MP_COAT_ALPHA = 40, MP_COAT_F0 = 41, MP_ETA = 42, MP_SIGMA_A = 43, MP_CUTOUT = 46 /* mdl_cutout_opacity, 1 = opaque */ };
+                   // not thin-walled, subsurface_weight > 0: the volumetric subsurface lobe
+                   // (live in renders with a medium stack), coefficients in MaterialRec::sss
+                   MATF_SSS_VOLUME = 16u;
+enum : uint32_t { MP_ALBEDO = 32, MP_F0 = 35, MP_ALPHA = 38, MP_COAT = 39, MP_COAT_ALPHA = 40, MP_COAT_F0 = 41, MP_ETA = 42, MP_SIGMA_A = 43,
+    MP_CUTOUT = 46 /* mdl_cutout_opacity, 1 = opaque */ };
 // Textured material inputs (UsdUVTexture semantics: value = texel * scale + bias at the hit's st).  Replaces the MDL
 // renderer runtime's tex_lookup_* path (mdl_interface.glsl:127-145) for the inputs the closed-form materials expose.
-enum : uint32_t { TEX_BASE_COLOR = 0, TEX_EMISSION = 1, TEX_ROUGHNESS = 2, TEX_METALLIC = 3, TEX_NORMAL = 4, TEX_OPACITY = 5 /* read by the any-hit test, not by k_shade */,
+enum : uint32_t { TEX_BASE_COLOR = 0, TEX_EMISSION = 1, TEX_ROUGHNESS = 2, TEX_METALLIC = 3, TEX_NORMAL = 4,
+    TEX_OPACITY = 5 /* read by the any-hit test, not by k_shade */,
                   TEX_COAT_NORMAL = 6 /* OpenPBR geometry_coat_normal: the coat lobe's own shading frame */,
-                  TEX_TRANSMISSION_WEIGHT = 7, TEX_TRANSMISSION_COLOR = 8 /* OpenPBR transmission_weight (scalar) / transmission_color (rgb: the surface tint of a medium-less, depth-0 transmission) */, TEX_SLOT_COUNT = 9 };
+                  /* OpenPBR transmission_weight (scalar) / transmission_color (rgb: the surface tint of a medium-less, depth-0 transmission) */
+                  TEX_TRANSMISSION_WEIGHT = 7, TEX_TRANSMISSION_COLOR = 8, TEX_SLOT_COUNT = 9 };
 // the slots k_shade resolves per hit, in resolve order (TEX_OPACITY belongs to the any-hit test, TEX_COAT_NORMAL is resolved before the base normal)
 constexpr uint32_t shade_slot(uint32_t k) { return k < TEX_OPACITY ? k : k + 2u; }
 constexpr uint32_t SHADE_SLOT_COUNT = 7;
@@ -99,15 +107,19 @@ struct TexBindingRec {
   uint32_t tex;   // texture index + 1; 0 = input not textured
   uint32_t mode;  // wrapS | wrapT << 8 | channel << 16 | TEX_MODE_* flags
   float scale[4], bias[4];
-  float xf[6];    // TEX_MODE_XFORM: texture-coordinate transform of the lookup, s' = (xf[0] s + xf[1] t) + xf[2], t' = (xf[3] s + xf[4] t) + xf[5] (UsdTransform2d upstream of a UsdUVTexture's `st`)
+  // TEX_MODE_XFORM: texture-coordinate transform of the lookup, s' = (xf[0] s + xf[1] t) +
+  // xf[2], t' = (xf[3] s + xf[4] t) + xf[5] (UsdTransform2d upstream of a UsdUVTexture's `st`)
+  float xf[6];
 };
 constexpr uint32_t MAT_FLAG_OPACITY_TEX = 1u << 30; // MaterialRec::flags: the cutout opacity is textured (the any-hit test looks it up at the candidate's st)
 constexpr uint32_t MAT_FLAG_TEXTURED = 1u << 31; // MaterialRec::flags: some input is textured or primvar-driven (k_shade resolves the inputs per hit)
 constexpr uint32_t TEX_MODE_PRIMVAR = 1u << 24;   // TexBindingRec::mode: (no texture) the input reads the mesh's scene data for this slot
-constexpr uint32_t TEX_MODE_CAMERA_POSITION = 1u << 25; // ... the scene-data name is "CAMERA_POSITION": ubo.cameraPosition (mdl_interface.glsl:329-334, Frontend.cpp:251)
+// ... the scene-data name is "CAMERA_POSITION": ubo.cameraPosition (mdl_interface.glsl:329-334, Frontend.cpp:251)
+constexpr uint32_t TEX_MODE_CAMERA_POSITION = 1u << 25;
 constexpr uint32_t TEX_MODE_XFORM = 1u << 27;           // TexBindingRec::xf is not the identity
 constexpr uint32_t TEX_MODE_FRAME = 1u << 26;           // ... the scene-data name is "FRAME": ubo.frame (mdl_interface.glsl:390-395, Frontend.cpp:252)
-constexpr uint32_t SD_INFO_INT = 1u << 5;               // MeshRec::sdInfo: integer primvar, nearest-vertex interpolation (scene_data_lookup_int, mdl_interface.glsl:426-457)
+// MeshRec::sdInfo: integer primvar, nearest-vertex interpolation (scene_data_lookup_int, mdl_interface.glsl:426-457)
+constexpr uint32_t SD_INFO_INT = 1u << 5;
 // Scene data (primvars) of a mesh for the material inputs of ITS material (replaces BlasPayloadBufferPreamble::sceneDataInfos,
 // rp_main.h:125-148, Gi.cpp:905-1019): per input slot the float offset into SceneView::sceneData and
 // info = valid | (stride - 1) << 1 | interpolation << 3 (GiPrimvarInterpolation: constant, instance, uniform, vertex).
@@ -130,9 +142,9 @@ struct DistantLightRec { float dir[3]; float angle; float em[3]; uint32_t ds; fl
 struct RectLightRec { float origin[3]; float width; float em[3]; float height; uint32_t t0, t1, ds; float pad; };
 struct DiskLightRec { float origin[3]; float rx; float em[3]; float ry; uint32_t t0, t1, ds; float pad; };
 static_assert(sizeof(SphereLightRec) == 48 && sizeof(DistantLightRec) == 48 && sizeof(RectLightRec) == 48 && sizeof(DiskLightRec) == 48, "lights are 48 bytes");
-// Derived per rect / disk light, beside its 48-byte record (round 6): the two tangents DECODED (host: decode_direction's operations, as for FVertex) and the light's
-// normal cross(t1, t0) -- sample_light decoded both codes and took the cross product for every light sample of every hit (two IEEE divisions, a square root and a
-// third division per decode).  Same bits: the host runs the device's operations in the device's order, without contraction.
+// Derived per rect / disk light, beside its 48-byte record (round 6): the two tangents DECODED (host: decode_direction's operations, as for FVertex) and the
+// light's normal cross(t1, t0) -- sample_light decoded both codes and took the cross product for every light sample of every hit (two IEEE divisions, a square
+// root and a third division per decode).  Same bits: the host runs the device's operations in the device's order, without contraction.
 struct LightFrame { float t0[3], pad0, t1[3], pad1, n[3], pad2; };
 static_assert(sizeof(LightFrame) == 48, "LightFrame is three 16-byte pieces");
 
@@ -160,21 +172,26 @@ struct FrameUniforms {
 enum : uint32_t {
   FLAG_JITTER = 1u, FLAG_FIS = 2u, FLAG_DOF = 4u, FLAG_CLIP = 8u, FLAG_NEE = 16u, FLAG_PROGRESSIVE = 32u,
   FLAG_PIXEL_MAJOR = 64u, // work order of the wavefront pipeline (gi_queues.h work_item)
-  FLAG_DEFER_SLOT = 128u, // wavefront pipeline: k_raygen does not write the Slot of a new camera path; its (rng, work item) travel beside the ray record and the
-                          // slot is written when the first segment HITS (k_route / k_trace); a camera ray that leaves the scene retires without ever touching a slot
-  FLAG_TWO_STREAM = 512u, // the shadow walks of bounce i run on a second stream beside the closest-hit walks of bounce i + 1 (gi_render.cpp "two streams"): k_raygen runs AFTER
-                          // the iteration's k_trace / k_route and zeroes only what k_shade and the shadow launch append to; k_zero_closest zeroes the rest before k_trace
-  FLAG_MERGE_SHADE_VARIANTS = 1024u, // k_route / k_trace bin the hits of a specialised shade class with its full class (a thin batch -- one sample per pixel and call --
-                                    // pays more for a further k_shade launch per iteration than the variant saves: gi_render.cpp)
-  FLAG_BOUNDS_RETIRE = 256u, // with FLAG_DEFER_SLOT on the k_trace_dyn path: a camera ray whose slab interval against the scene bounds is empty is never queued --
-                             // k_raygen retires its sample (the arithmetic of retire_fresh_miss) and hands the slot straight to the next k_raygen
+  // wavefront pipeline: k_raygen does not write the Slot of a new camera path; its (rng, work item) travel beside the ray record and the
+  // slot is written when the first segment HITS (k_route / k_trace); a camera ray that leaves the scene retires without ever touching a slot
+  FLAG_DEFER_SLOT = 128u,
+  // the shadow walks of bounce i run on a second stream beside the closest-hit walks of bounce i + 1 (gi_render.cpp "two streams"): k_raygen runs AFTER
+  // the iteration's k_trace / k_route and zeroes only what k_shade and the shadow launch append to; k_zero_closest zeroes the rest before k_trace
+  FLAG_TWO_STREAM = 512u,
+  // k_route / k_trace bin the hits of a specialised shade class with its full class (a thin batch -- one sample per
+  // pixel and call -- pays more for a further k_shade launch per iteration than the variant saves: gi_render.cpp)
+  FLAG_MERGE_SHADE_VARIANTS = 1024u,
+  // with FLAG_DEFER_SLOT on the k_trace_dyn path: a camera ray whose slab interval against the scene bounds is empty is never
+  // queued -- k_raygen retires its sample (the arithmetic of retire_fresh_miss) and hands the slot straight to the next k_raygen
+  FLAG_BOUNDS_RETIRE = 256u,
 };
 
 // Device-side scene view handed to the kernels.
 // Two-level layout records, each ONE cache line (r03: the traversal kernels are bound by the number of distinct lines a lane requests -- tools/ta_calib.hip --
 // so a candidate costs two lines, its mesh triangle and its instance, instead of the six the first version touched: index record, three vertices, instance
 // matrix, instance info):
-struct BlasTri { float p0[3], p1[3], p2[3]; uint32_t prim; uint32_t pad[6]; };  // object-space corners (the mesh's vertex positions, bit for bit) + gl_PrimitiveID, 64 bytes
+// object-space corners (the mesh's vertex positions, bit for bit) + gl_PrimitiveID, 64 bytes
+struct BlasTri { float p0[3], p1[3], p2[3]; uint32_t prim; uint32_t pad[6]; };
 struct InstTrav {                                                               // what a walk needs of an instance, 128 bytes
   float o2w[12];                       // rows of the object->world matrix (candidates are rebuilt in world space with the host's xformPoint arithmetic)
   float w2o[9];                        // inverse of its 3x3 part (the ray enters the BLAS in object space)
@@ -189,8 +206,11 @@ struct SceneView {
   const TriRec* tris;
   const InstanceRec* instances;
   const FVertex* verts;
-  const F4* triGeomNormal; // LDS-resident scenes (shadePacked == 0): the world-space geometric normal of every flattened triangle, made on the host with setup_shading_state's operations
-  const TriShade* triShade; uint32_t shadePacked; // != 0: TriRec::vi[0] indexes triShade (scenes beyond LDS); 0: TriRec::vi are vertex indices (LDS-resident scenes, fused kernels)
+  // LDS-resident scenes (shadePacked == 0): the world-space geometric normal of
+  // every flattened triangle, made on the host with setup_shading_state's operations
+  const F4* triGeomNormal;
+  // != 0: TriRec::vi[0] indexes triShade (scenes beyond LDS); 0: TriRec::vi are vertex indices (LDS-resident scenes, fused kernels)
+  const TriShade* triShade; uint32_t shadePacked;
   const MaterialRec* materials;
   const SphereLightRec* sphereLights;
   const DistantLightRec* distantLights;
@@ -248,7 +268,8 @@ static_assert(sizeof(Slot) == 64, "Slot must be 64 bytes");
 
 // Medium stack of a path (MEDIUM_STACK_SIZE > 0; rp_main_payload.glsl:11-17, 37-40): per slot `mediaStride` floats =
 // stack entries of 8 floats (ior, bias, sigma_s[3], sigma_t[3]) followed by walkSegmentPdf (3 floats + pad).
-constexpr uint32_t MEDIUM_FLOATS = 8, MAX_MEDIUM_STACK = 15; // the payload's medium index has four bits (rp_main_payload.glsl:4-5): 15 is the deepest stack the reference can address
+// the payload's medium index has four bits (rp_main_payload.glsl:4-5): 15 is the deepest stack the reference can address
+constexpr uint32_t MEDIUM_FLOATS = 8, MAX_MEDIUM_STACK = 15;
 constexpr uint32_t VOLUME_MISS = 0xfffffffeu; // "triangle" id of a hit record that is a scattering event inside a medium
 // Debug AOVs that follow whole paths (only when bound): Bounces = inferno colour of the bounce count of the pixel's LAST
 // sample (rp_main.rgen:483-486, written by k_raygen when that sample retires); NEE = outcome of the shadow test at bounce 0 of the
@@ -258,7 +279,8 @@ constexpr uint32_t VOLUME_MISS = 0xfffffffeu; // "triangle" id of a hit record t
 struct PathState {
   Slot* slots; float* media; uint32_t mediaStride;
   unsigned long long* neeKey; uint32_t neeSampleBase; F4* bouncesAov;
-  uint32_t* pathSegments; // ClockCycles AOV (cost proxy): per tile pixel, the ray segments of all its samples so far (k_raygen adds a path's count when it retires)
+  // ClockCycles AOV (cost proxy): per tile pixel, the ray segments of all its samples so far (k_raygen adds a path's count when it retires)
+  uint32_t* pathSegments;
 };
 
 // Work queues.  Every queue is split into NSHARD segments (segment s holds records [s*cap, s*cap + count[q][s])):
@@ -272,9 +294,10 @@ struct PathState {
 // The A/B pairs alternate per iteration so that no counter has to be reset between a queue's consumer and its next
 // producers (k_raygen zeroes the counters of the following iteration, see zero_next_counters).
 // HIT is one queue per material class (the sort key between trace and shade): Q_HIT + klass
-// ... more precisely per SHADE class: the material classes 0 .. 2 (diffuse, UsdPreviewSurface, OpenPBR with every lobe) and the specialised variants of a class.  The
-// shade class of a triangle's material rides in bits 24-27 of TriRec::matFlags (and from there in the top four bits of a hit word); MaterialRec::klass stays the
-// BSDF model.  SHADE_CLASS_OPBR_BASE: OpenPBR materials whose optional lobes are all absent (gi_shading.h "BASE variant", gi_build.cpp shadeClassOf).
+// ... more precisely per SHADE class: the material classes 0 .. 2 (diffuse, UsdPreviewSurface, OpenPBR with every lobe) and the specialised variants of a
+// class.  The shade class of a triangle's material rides in bits 24-27 of TriRec::matFlags (and from there in the top four bits of a hit word);
+// MaterialRec::klass stays the BSDF model.  SHADE_CLASS_OPBR_BASE: OpenPBR materials whose
+// optional lobes are all absent (gi_shading.h "BASE variant", gi_build.cpp shadeClassOf).
 constexpr uint32_t MAT_CLASS_COUNT = 4, SHADE_CLASS_OPBR_BASE = 3;
 enum : uint32_t { Q_TRACE_A = 0, Q_TRACE_B = 1, Q_REGEN_A = 2, Q_REGEN_B = 3, Q_SHADOW = 4, Q_HIT = 5, Q_COUNT = Q_HIT + MAT_CLASS_COUNT };
 constexpr uint32_t NSHARD = 8;
@@ -298,16 +321,17 @@ struct Counters {
   // device-scope atomic on one line completes ~88 times per microsecond; 8 lines, 8x that); [0]: closest-hit queue, [1]: shadow queue
   PaddedCounter cursor[2][NCURSOR];
   unsigned long long segments, shadowRays, nodesVisited, trisTested, shadowNodesVisited, shadowTrisTested;
-  // shadow walks in the two visiting orders (k_trace_dyn<any>: [0] near-to-far, [1] slot order): rays launched, and node visits summed per wave into one of 16 lines
-  // (the host picks the order a scene's shadow rays visit fewer nodes in, gi_render.cpp shadowOrder)
+  // shadow walks in the two visiting orders (k_trace_dyn<any>: [0] near-to-far, [1] slot order): rays launched, and node visits summed per wave into one of 16
+  // lines (the host picks the order a scene's shadow rays visit fewer nodes in, gi_render.cpp shadowOrder)
   unsigned long long shadowOrderRays[2];
   PaddedCounter shadowOrderSteps[2][16];
   uint32_t overflow; // set by block_append when a shard would run past its capacity (host sizing bug): giCRender fails loudly
-  // k_path, counting builds only (GI_C_SCENE_OPTION_COUNT_TRAVERSAL): shader-clock cycles per phase summed over waves, lanes doing useful work per phase summed over
-  // trips, trips -- [0] regeneration, [1] closest-hit traversal, [2] shading, [3] shadow ray + finish (GATLING_OPTIONS=phase_stats=1 prints them)
+  // k_path, counting builds only (GI_C_SCENE_OPTION_COUNT_TRAVERSAL): shader-clock cycles per phase summed over waves, lanes doing useful work per phase summed
+  // over trips, trips -- [0] regeneration, [1] closest-hit traversal, [2] shading, [3] shadow ray + finish (GATLING_OPTIONS=phase_stats=1 prints them)
   unsigned long long phaseCycles[4], phaseLanes[4], phaseTrips;
-  // k_trace_dyn's closest-hit launches, counting builds only: [0] steps (loop trips of all waves), lanes per step that [1] hold a ray, [2] walk (run the node test),
-  // [3] wait for the triangle ring (drained walk, pairs pending); [4] triangle batches, [5] pairs in them, [6] steps in which some lane was refilled, [7] lanes refilled
+  // k_trace_dyn's closest-hit launches, counting builds only: [0] steps (loop trips of all waves), lanes per step that [1] hold a ray, [2] walk (run the node
+  // test), [3] wait for the triangle ring (drained walk, pairs pending); [4] triangle
+  // batches, [5] pairs in them, [6] steps in which some lane was refilled, [7] lanes refilled
   unsigned long long dynStats[8];
 };
 

@@ -1,8 +1,8 @@
 // gtl_shim.cpp -- the reference's C++ API (include/gtl/gi/Gi.h, mirroring /root/reference/src/gi/gtl/gi/Gi.h:199-261) on top of
 // the C ABI (include/gi_c.h).  Every function forwards 1:1; std::vector arguments become pointer + count.  The one
 // non-mechanical piece is material creation: a tiny scanner reads UsdPreviewSurface / open_pbr_surface (and, translated onto the same closed forms,
-// standard_surface / gltf_pbr) nodes with constant, primvar or image inputs out of a MaterialX document string (what hdGatling's material network compiler produces,
-// src/hdGatling/materialNetworkCompiler.cpp:667-720) and fills a closed-form parameter block.
+// standard_surface / gltf_pbr) nodes with constant, primvar or image inputs out of a MaterialX document string (what hdGatling's material network compiler
+// produces, src/hdGatling/materialNetworkCompiler.cpp:667-720) and fills a closed-form parameter block.
 #include "../../include/gtl/gi/Gi.h"
 #include "../../include/gi_c.h"
 
@@ -30,7 +30,8 @@ namespace gtl
     GiAssetReader* s_assetReader = nullptr;
 
     // ---- minimal MaterialX reader: first <UsdPreviewSurface|open_pbr_surface ...> element and its <input name value> children
-    struct MtlxNode { std::string category; std::map<std::string, std::string> inputs; std::map<std::string, std::string> connections; /* input -> upstream node name */
+    struct MtlxNode { std::string category; std::map<std::string, std::string> inputs; std::map<std::string, std::string> connections;
+        /* input -> upstream node name */
                       std::map<std::string, std::string> outputs; /* input -> which output of that node (connections through a nodegraph) */ };
 
     std::string attr(const std::string& tag, const char* name)
@@ -82,7 +83,9 @@ namespace gtl
             size_t oe = doc.find('>', q);
             if (oe == std::string::npos) break;
             const std::string otag = doc.substr(q, oe - q + 1);
-            if (on.empty() || attr(otag, "name") == on) { if (!attr(otag, "nodename").empty()) { out.connections[name] = attr(otag, "nodename"); out.outputs[name] = attr(otag, "output"); } break; }
+            if (on.empty()
+                || attr(otag, "name") == on) { if (!attr(otag, "nodename").empty()) { out.connections[name] = attr(otag, "nodename");
+                out.outputs[name] = attr(otag, "output"); } break; }
             q = oe;
           }
         }
@@ -153,7 +156,8 @@ namespace gtl
       while (*p && n < maxN) {
         char* end = nullptr;
         float v = strtof(p, &end);
-        if (end == p) { if (!strncmp(p, "true", 4)) { v = 1.0f; end = (char*)p + 4; } else if (!strncmp(p, "false", 5)) { v = 0.0f; end = (char*)p + 5; } else { p++; continue; } }
+        if (end == p) { if (!strncmp(p, "true", 4)) { v = 1.0f; end = (char*)p + 4; } else if (!strncmp(p, "false", 5)) { v = 0.0f; end = (char*)p + 5;
+            } else { p++; continue; } }
         out[n++] = v; p = end;
         while (*p == ',' || *p == ' ') p++;
       }
@@ -167,7 +171,8 @@ namespace gtl
     }
 
     // a material input fed by an image node (UsdUVTexture / image / tiledimage): file + UsdUVTexture's wrap, scale, bias, colour space
-    struct ImageInput { std::string file; int wrapS = GI_C_TEX_WRAP_REPEAT, wrapT = GI_C_TEX_WRAP_REPEAT, channel = 0; float scale[4] = {1, 1, 1, 1}, bias[4] = {0, 0, 0, 0}; bool srgb = false;
+    struct ImageInput { std::string file; int wrapS = GI_C_TEX_WRAP_REPEAT, wrapT = GI_C_TEX_WRAP_REPEAT, channel = 0;
+        float scale[4] = {1, 1, 1, 1}, bias[4] = {0, 0, 0, 0}; bool srgb = false;
                         bool hasXf = false; float xf[6] = {1, 0, 0, 0, 1, 0}; /* UsdTransform2d upstream of `st` */ };
     int wrapMode(const std::string& v)
     {
@@ -185,7 +190,8 @@ namespace gtl
       // an input fed by a <constant> node (hdGatling's network patchers emit those for colour / float mismatches) is a constant
       for (auto it = n.connections.begin(); it != n.connections.end();) {
         MtlxNode up;
-        if (readNode(doc, it->second, up) && up.category == "constant" && up.inputs.count("value")) { n.inputs[it->first] = up.inputs["value"]; it = n.connections.erase(it); }
+        if (readNode(doc, it->second, up) && up.category == "constant" && up.inputs.count("value")) { n.inputs[it->first] = up.inputs["value"];
+            it = n.connections.erase(it); }
         else ++it;
       }
       // `constant` / `count`: where the input's constant lives in the parameter block -- a primvar reader's own fallback value (MaterialX <geompropvalue>'s
@@ -200,20 +206,24 @@ namespace gtl
           if (constant && readNode(doc, it->second, up)) {
             auto d = up.inputs.find("default");
             if (d == up.inputs.end()) d = up.inputs.find("fallback");
-            if (d != up.inputs.end() && !d->second.empty()) { float v[4] = {0, 0, 0, 0}; const int got = floats(d->second, v, count < 4 ? count : 4); for (int i = 0; got > 0 && i < count; i++) constant[i] = v[i < got ? i : got - 1]; }
+            if (d != up.inputs.end() && !d->second.empty()) { float v[4] = {0, 0, 0, 0}; const int got = floats(d->second, v, count < 4 ? count : 4);
+                for (int i = 0; got > 0 && i < count; i++) constant[i] = v[i < got ? i : got - 1]; }
           }
           return;
         }
         if (!readNode(doc, it->second, up)) return;
         // Between the image and the surface input MaterialX documents put per-channel affine nodes -- `normalmap` (2 x - 1, xy times its `scale`), `multiply` /
-        // `add` / `subtract` with a constant (tints, gains), `convert` / `dot` (pass-through) -- which fold into the binding's scale and bias: walking upstream,
-        // the value seen by the surface is S * x + B of the node's input x.  Anything else (a second texture, a procedural) ends the walk: the input keeps its constant.
+        // `add` / `subtract` with a constant (tints, gains), `convert` / `dot` (pass-through) -- which fold into the binding's scale and bias: walking
+        // upstream, the value seen by the surface is S * x + B of the node's input x.  Anything
+        // else (a second texture, a procedural) ends the walk: the input keeps its constant.
         float S[4] = {1, 1, 1, 1}, B[4] = {0, 0, 0, 0};
         for (int depth = 0; depth < 8 && up.category != "UsdUVTexture" && up.category != "image" && up.category != "tiledimage"; depth++) {
           const std::string cat = up.category;
           float c[4] = {0, 0, 0, 0}; std::string next;
-          auto constantOf = [&](const char* in) { auto v = up.inputs.find(in); if (v == up.inputs.end() || v->second.empty() || up.connections.count(in)) return false;
-                                                  const int got = floats(v->second, c, 4); for (int i = got; got > 0 && i < 4; i++) c[i] = c[got - 1]; return got > 0; };
+          auto constantOf = [&](const char* in) { auto v = up.inputs.find(in);
+              if (v == up.inputs.end() || v->second.empty() || up.connections.count(in)) return false;
+                                                  const int got = floats(v->second, c, 4); for (int i = got; got > 0 && i < 4; i++) c[i] = c[got - 1];
+                                                      return got > 0; };
           if (cat == "normalmap") {
             if (!up.connections.count("in")) return;
             float k = 1.0f; if (up.inputs.count("scale") && !up.inputs["scale"].empty() && !up.connections.count("scale")) floats(up.inputs["scale"], &k, 1);
@@ -239,14 +249,15 @@ namespace gtl
         im.wrapT = wrapMode(up.inputs.count("wrapT") ? up.inputs["wrapT"] : up.inputs["vaddressmode"]);
         if (up.inputs.count("scale")) floats(up.inputs["scale"], im.scale, 4);
         if (up.inputs.count("bias")) floats(up.inputs["bias"], im.bias, 4);
-        for (int i = 0; i < 4; i++) { im.bias[i] = B[i] + S[i] * im.bias[i]; im.scale[i] = S[i] * im.scale[i]; } // (identity walk: x * 1 + 0 -- the values as written)
+        // (identity walk: x * 1 + 0 -- the values as written)
+        for (int i = 0; i < 4; i++) { im.bias[i] = B[i] + S[i] * im.bias[i]; im.scale[i] = S[i] * im.scale[i]; }
         const bool colour = slot == GI_C_TEX_BASE_COLOR || slot == GI_C_TEX_EMISSION || slot == GI_C_TEX_TRANSMISSION_COLOR;
         const std::string cs = up.inputs.count("sourceColorSpace") ? up.inputs["sourceColorSpace"] : "auto";
         im.srgb = cs == "sRGB" || (cs == "auto" && colour); // UsdUVTexture: auto = sRGB for 8-bit colour data
         if (up.category != "UsdUVTexture") // MaterialX image nodes name the file's colour space on the `file` input; without one the file is taken as linear
           im.srgb = up.inputs.count("file:colorspace") && up.inputs["file:colorspace"] == "srgb_texture";
-        // texture coordinates through a UsdTransform2d (UsdPreviewSurface specification: result = in * scale, rotated counter-clockwise by `rotation` degrees, +
-        // translation) -> the six floats of giCSetMaterialTextureTransform; cos / sin in double, rounded once (== gatling_amd/scene.py usd_transform_2d)
+        // texture coordinates through a UsdTransform2d (UsdPreviewSurface specification: result = in * scale, rotated counter-clockwise by `rotation` degrees,
+        // + translation) -> the six floats of giCSetMaterialTextureTransform; cos / sin in double, rounded once (== gatling_amd/scene.py usd_transform_2d)
         auto stc = up.connections.find("st"); if (stc == up.connections.end()) stc = up.connections.find("texcoord");
         MtlxNode xfn;
         if (stc != up.connections.end() && readNode(doc, stc->second, xfn) && xfn.category == "UsdTransform2d") {
@@ -288,69 +299,89 @@ namespace gtl
       p[GI_C_P_ROUGHNESS] = 0.3f; p[GI_C_P_IOR] = 1.5f; p[GI_C_P_OPACITY] = 1.0f;
       p[GI_C_P_TRANSMISSION_COLOR] = p[GI_C_P_TRANSMISSION_COLOR + 1] = p[GI_C_P_TRANSMISSION_COLOR + 2] = 1.0f;
       p[GI_C_P_COAT_COLOR] = p[GI_C_P_COAT_COLOR + 1] = p[GI_C_P_COAT_COLOR + 2] = 1.0f; p[GI_C_P_COAT_IOR] = 1.6f; p[GI_C_P_COAT_DARKENING] = 1.0f;
-      p[GI_C_P_FUZZ_COLOR] = p[GI_C_P_FUZZ_COLOR + 1] = p[GI_C_P_FUZZ_COLOR + 2] = 1.0f; p[GI_C_P_FUZZ_ROUGHNESS] = 0.5f; p[GI_C_P_THIN_FILM_THICKNESS] = 0.5f; p[GI_C_P_THIN_FILM_IOR] = 1.4f;
+      p[GI_C_P_FUZZ_COLOR] = p[GI_C_P_FUZZ_COLOR + 1] = p[GI_C_P_FUZZ_COLOR + 2] = 1.0f; p[GI_C_P_FUZZ_ROUGHNESS] = 0.5f; p[GI_C_P_THIN_FILM_THICKNESS] = 0.5f;
+          p[GI_C_P_THIN_FILM_IOR] = 1.4f;
       p[GI_C_P_SUBSURFACE_COLOR] = p[GI_C_P_SUBSURFACE_COLOR + 1] = p[GI_C_P_SUBSURFACE_COLOR + 2] = 0.8f;
-      p[GI_C_P_SUBSURFACE_RADIUS] = 1.0f; p[GI_C_P_SUBSURFACE_RADIUS_SCALE] = 1.0f; p[GI_C_P_SUBSURFACE_RADIUS_SCALE + 1] = 0.5f; p[GI_C_P_SUBSURFACE_RADIUS_SCALE + 2] = 0.25f;
+      p[GI_C_P_SUBSURFACE_RADIUS] = 1.0f; p[GI_C_P_SUBSURFACE_RADIUS_SCALE] = 1.0f; p[GI_C_P_SUBSURFACE_RADIUS_SCALE + 1] = 0.5f;
+          p[GI_C_P_SUBSURFACE_RADIUS_SCALE + 2] = 0.25f;
       float lum = 0.0f, ecol[3] = {1.0f, 1.0f, 1.0f};
       if (n.category == "standard_surface") {
-        // Autodesk Standard Surface 1.0.1 (the reference compiles MaterialX's own standard_surface graph through MDL): read onto the OpenPBR closed forms, input by
-        // input -- OpenPBR is that model's successor and keeps its layering (fuzz over coat over {metal | glass | subsurface | diffuse+specular}).  Defaults are the
-        // Standard Surface specification's, not OpenPBR's.  What has no counterpart is dropped: specular_rotation / coat_rotation (no tangent input),
-        // transmission_dispersion, transmission_extra_roughness, coat_affect_color / coat_affect_roughness, and coat_darkening stays 0 (the model has no such term).
+        // Autodesk Standard Surface 1.0.1 (the reference compiles MaterialX's own standard_surface graph through MDL): read onto the OpenPBR closed forms,
+        // input by input -- OpenPBR is that model's successor and keeps its layering (fuzz over coat over {metal | glass | subsurface | diffuse+specular}).
+        // Defaults are the Standard Surface specification's, not OpenPBR's.  What has no counterpart is dropped: specular_rotation / coat_rotation (no tangent
+        // input), transmission_dispersion, transmission_extra_roughness, coat_affect_color
+        // / coat_affect_roughness, and coat_darkening stays 0 (the model has no such term).
         p[GI_C_P_BASE_WEIGHT] = 0.8f; p[GI_C_P_BASE_COLOR] = p[GI_C_P_BASE_COLOR + 1] = p[GI_C_P_BASE_COLOR + 2] = 1.0f; p[GI_C_P_ROUGHNESS] = 0.2f;
         p[GI_C_P_CLEARCOAT_ROUGHNESS] = 0.1f; p[GI_C_P_COAT_IOR] = 1.5f; p[GI_C_P_COAT_DARKENING] = 0.0f; p[GI_C_P_FUZZ_ROUGHNESS] = 0.3f;
         p[GI_C_P_SUBSURFACE_COLOR] = p[GI_C_P_SUBSURFACE_COLOR + 1] = p[GI_C_P_SUBSURFACE_COLOR + 2] = 1.0f;
-        p[GI_C_P_SUBSURFACE_RADIUS] = 1.0f; p[GI_C_P_SUBSURFACE_RADIUS_SCALE] = p[GI_C_P_SUBSURFACE_RADIUS_SCALE + 1] = p[GI_C_P_SUBSURFACE_RADIUS_SCALE + 2] = 1.0f;
+        p[GI_C_P_SUBSURFACE_RADIUS] = 1.0f;
+            p[GI_C_P_SUBSURFACE_RADIUS_SCALE] = p[GI_C_P_SUBSURFACE_RADIUS_SCALE + 1] = p[GI_C_P_SUBSURFACE_RADIUS_SCALE + 2] = 1.0f;
         p[GI_C_P_THIN_FILM_THICKNESS] = 0.0f; p[GI_C_P_THIN_FILM_IOR] = 1.5f;
-        setN(n, "base", p + GI_C_P_BASE_WEIGHT, 1); setN(n, "base_color", p + GI_C_P_BASE_COLOR, 3); setN(n, "diffuse_roughness", p + GI_C_P_DIFFUSE_ROUGHNESS, 1);
-        setN(n, "metalness", p + GI_C_P_METALLIC, 1); setN(n, "specular", p + GI_C_P_SPECULAR_WEIGHT, 1); setN(n, "specular_color", p + GI_C_P_SPECULAR_COLOR, 3);
-        setN(n, "specular_roughness", p + GI_C_P_ROUGHNESS, 1); setN(n, "specular_IOR", p + GI_C_P_IOR, 1); setN(n, "specular_anisotropy", p + GI_C_P_SPECULAR_ANISOTROPY, 1);
+        setN(n, "base", p + GI_C_P_BASE_WEIGHT, 1); setN(n, "base_color", p + GI_C_P_BASE_COLOR, 3);
+            setN(n, "diffuse_roughness", p + GI_C_P_DIFFUSE_ROUGHNESS, 1);
+        setN(n, "metalness", p + GI_C_P_METALLIC, 1); setN(n, "specular", p + GI_C_P_SPECULAR_WEIGHT, 1);
+            setN(n, "specular_color", p + GI_C_P_SPECULAR_COLOR, 3);
+        setN(n, "specular_roughness", p + GI_C_P_ROUGHNESS, 1); setN(n, "specular_IOR", p + GI_C_P_IOR, 1);
+            setN(n, "specular_anisotropy", p + GI_C_P_SPECULAR_ANISOTROPY, 1);
         setN(n, "transmission", p + GI_C_P_TRANSMISSION_WEIGHT, 1); setN(n, "transmission_color", p + GI_C_P_TRANSMISSION_COLOR, 3);
         setN(n, "transmission_depth", p + GI_C_P_TRANSMISSION_DEPTH, 1); setN(n, "transmission_scatter", p + GI_C_P_TRANSMISSION_SCATTER, 3);
         setN(n, "transmission_scatter_anisotropy", p + GI_C_P_TRANSMISSION_SCATTER_ANISOTROPY, 1);
-        setN(n, "subsurface", p + GI_C_P_SUBSURFACE_WEIGHT, 1); setN(n, "subsurface_color", p + GI_C_P_SUBSURFACE_COLOR, 3); setN(n, "subsurface_anisotropy", p + GI_C_P_SUBSURFACE_ANISOTROPY, 1);
-        setN(n, "subsurface_scale", p + GI_C_P_SUBSURFACE_RADIUS, 1); setN(n, "subsurface_radius", p + GI_C_P_SUBSURFACE_RADIUS_SCALE, 3); // mean free path = scale x radius (colour) = OpenPBR's radius x radius_scale
+        setN(n, "subsurface", p + GI_C_P_SUBSURFACE_WEIGHT, 1); setN(n, "subsurface_color", p + GI_C_P_SUBSURFACE_COLOR, 3);
+            setN(n, "subsurface_anisotropy", p + GI_C_P_SUBSURFACE_ANISOTROPY, 1);
+        // mean free path = scale x radius (colour) = OpenPBR's radius x radius_scale
+        setN(n, "subsurface_scale", p + GI_C_P_SUBSURFACE_RADIUS, 1); setN(n, "subsurface_radius", p + GI_C_P_SUBSURFACE_RADIUS_SCALE, 3);
         setN(n, "sheen", p + GI_C_P_FUZZ_WEIGHT, 1); setN(n, "sheen_color", p + GI_C_P_FUZZ_COLOR, 3); setN(n, "sheen_roughness", p + GI_C_P_FUZZ_ROUGHNESS, 1);
         setN(n, "coat", p + GI_C_P_CLEARCOAT, 1); setN(n, "coat_color", p + GI_C_P_COAT_COLOR, 3); setN(n, "coat_roughness", p + GI_C_P_CLEARCOAT_ROUGHNESS, 1);
         setN(n, "coat_IOR", p + GI_C_P_COAT_IOR, 1); setN(n, "coat_anisotropy", p + GI_C_P_COAT_ANISOTROPY, 1);
-        float nm = 0.0f; setN(n, "thin_film_thickness", &nm, 1); setN(n, "thin_film_IOR", p + GI_C_P_THIN_FILM_IOR, 1); // nanometres, 0 = no film -> weight + micrometres
+        // nanometres, 0 = no film -> weight + micrometres
+        float nm = 0.0f; setN(n, "thin_film_thickness", &nm, 1); setN(n, "thin_film_IOR", p + GI_C_P_THIN_FILM_IOR, 1);
         p[GI_C_P_THIN_FILM_WEIGHT] = nm > 0.0f ? 1.0f : 0.0f; p[GI_C_P_THIN_FILM_THICKNESS] = nm > 0.0f ? nm * 0.001f : 0.5f;
-        float op3[3] = {1.0f, 1.0f, 1.0f}; setN(n, "opacity", op3, 3); p[GI_C_P_OPACITY] = (op3[0] + op3[1] + op3[2]) * (1.0f / 3.0f); // colour opacity -> its mean
+        // colour opacity -> its mean
+        float op3[3] = {1.0f, 1.0f, 1.0f}; setN(n, "opacity", op3, 3); p[GI_C_P_OPACITY] = (op3[0] + op3[1] + op3[2]) * (1.0f / 3.0f);
         setN(n, "thin_walled", p + GI_C_P_THIN_WALLED, 1);
         setN(n, "emission", &lum, 1); setN(n, "emission_color", ecol, 3);
         for (int i = 0; i < 3; i++) p[GI_C_P_EMISSION + i] = lum * ecol[i];
-        bind("base_color", GI_C_TEX_BASE_COLOR, p + GI_C_P_BASE_COLOR, 3); bind("specular_roughness", GI_C_TEX_ROUGHNESS, p + GI_C_P_ROUGHNESS, 1); bind("metalness", GI_C_TEX_METALLIC, p + GI_C_P_METALLIC, 1);
+        bind("base_color", GI_C_TEX_BASE_COLOR, p + GI_C_P_BASE_COLOR, 3); bind("specular_roughness", GI_C_TEX_ROUGHNESS, p + GI_C_P_ROUGHNESS, 1);
+            bind("metalness", GI_C_TEX_METALLIC, p + GI_C_P_METALLIC, 1);
         bind("normal", GI_C_TEX_NORMAL); bind("opacity", GI_C_TEX_OPACITY); bind("coat_normal", GI_C_TEX_COAT_NORMAL);
-        bind("transmission", GI_C_TEX_TRANSMISSION_WEIGHT, p + GI_C_P_TRANSMISSION_WEIGHT, 1); bind("transmission_color", GI_C_TEX_TRANSMISSION_COLOR, p + GI_C_P_TRANSMISSION_COLOR, 3);
+        bind("transmission", GI_C_TEX_TRANSMISSION_WEIGHT, p + GI_C_P_TRANSMISSION_WEIGHT, 1);
+            bind("transmission_color", GI_C_TEX_TRANSMISSION_COLOR, p + GI_C_P_TRANSMISSION_COLOR, 3);
         return true;
       }
       if (n.category == "gltf_pbr") {
         // MaterialX's glTF PBR node (KHR_materials_* folded in) onto the same closed forms.  Defaults are the node's (metallic 1, roughness 1, sheen off ...).
-        // thickness 0 is glTF's thin-walled transmission; a thick one attenuates with attenuation_color over attenuation_distance (OpenPBR transmission_color at
-        // transmission_depth).  alpha_mode: 0 OPAQUE (alpha ignored), 1 MASK (constant alpha against alpha_cutoff), 2 BLEND (alpha as opacity: stochastic cutout).
+        // thickness 0 is glTF's thin-walled transmission; a thick one attenuates with attenuation_color over attenuation_distance (OpenPBR transmission_color
+        // at transmission_depth).  alpha_mode: 0 OPAQUE (alpha ignored), 1 MASK (constant
+        // alpha against alpha_cutoff), 2 BLEND (alpha as opacity: stochastic cutout).
         // Dropped: occlusion (baked ambient occlusion has no place in a path tracer), anisotropy_rotation, dispersion.
         p[GI_C_P_BASE_COLOR] = p[GI_C_P_BASE_COLOR + 1] = p[GI_C_P_BASE_COLOR + 2] = 1.0f; p[GI_C_P_METALLIC] = 1.0f; p[GI_C_P_ROUGHNESS] = 1.0f;
-        p[GI_C_P_CLEARCOAT_ROUGHNESS] = 0.0f; p[GI_C_P_COAT_IOR] = 1.5f; p[GI_C_P_COAT_DARKENING] = 0.0f; p[GI_C_P_FUZZ_ROUGHNESS] = 0.0f; p[GI_C_P_THIN_FILM_IOR] = 1.3f;
+        p[GI_C_P_CLEARCOAT_ROUGHNESS] = 0.0f; p[GI_C_P_COAT_IOR] = 1.5f; p[GI_C_P_COAT_DARKENING] = 0.0f; p[GI_C_P_FUZZ_ROUGHNESS] = 0.0f;
+            p[GI_C_P_THIN_FILM_IOR] = 1.3f;
         setN(n, "base_color", p + GI_C_P_BASE_COLOR, 3); setN(n, "metallic", p + GI_C_P_METALLIC, 1); setN(n, "roughness", p + GI_C_P_ROUGHNESS, 1);
         setN(n, "specular", p + GI_C_P_SPECULAR_WEIGHT, 1); setN(n, "specular_color", p + GI_C_P_SPECULAR_COLOR, 3); setN(n, "ior", p + GI_C_P_IOR, 1);
         setN(n, "transmission", p + GI_C_P_TRANSMISSION_WEIGHT, 1);
         float thick = 0.0f, attDist = 0.0f, attCol[3] = {1.0f, 1.0f, 1.0f};
         setN(n, "thickness", &thick, 1); setN(n, "attenuation_distance", &attDist, 1); setN(n, "attenuation_color", attCol, 3);
         p[GI_C_P_THIN_WALLED] = thick > 0.0f ? 0.0f : 1.0f;
-        if (thick > 0.0f && attDist > 0.0f && attDist < 3.0e38f) { for (int i = 0; i < 3; i++) p[GI_C_P_TRANSMISSION_COLOR + i] = attCol[i]; p[GI_C_P_TRANSMISSION_DEPTH] = attDist; }
+        if (thick > 0.0f && attDist > 0.0f && attDist < 3.0e38f) { for (int i = 0; i < 3; i++) p[GI_C_P_TRANSMISSION_COLOR + i] = attCol[i];
+            p[GI_C_P_TRANSMISSION_DEPTH] = attDist; }
         setN(n, "clearcoat", p + GI_C_P_CLEARCOAT, 1); setN(n, "clearcoat_roughness", p + GI_C_P_CLEARCOAT_ROUGHNESS, 1);
-        float sheen[3] = {0.0f, 0.0f, 0.0f}; setN(n, "sheen_color", sheen, 3); setN(n, "sheen_roughness", p + GI_C_P_FUZZ_ROUGHNESS, 1); // KHR_materials_sheen: black = off
+        // KHR_materials_sheen: black = off
+        float sheen[3] = {0.0f, 0.0f, 0.0f}; setN(n, "sheen_color", sheen, 3); setN(n, "sheen_roughness", p + GI_C_P_FUZZ_ROUGHNESS, 1);
         const bool hasSheen = sheen[0] > 0.0f || sheen[1] > 0.0f || sheen[2] > 0.0f;
         p[GI_C_P_FUZZ_WEIGHT] = hasSheen ? 1.0f : 0.0f; for (int i = 0; i < 3; i++) p[GI_C_P_FUZZ_COLOR + i] = hasSheen ? sheen[i] : 1.0f;
-        float nm = 100.0f; setN(n, "iridescence", p + GI_C_P_THIN_FILM_WEIGHT, 1); setN(n, "iridescence_ior", p + GI_C_P_THIN_FILM_IOR, 1); setN(n, "iridescence_thickness", &nm, 1);
+        float nm = 100.0f; setN(n, "iridescence", p + GI_C_P_THIN_FILM_WEIGHT, 1); setN(n, "iridescence_ior", p + GI_C_P_THIN_FILM_IOR, 1);
+            setN(n, "iridescence_thickness", &nm, 1);
         p[GI_C_P_THIN_FILM_THICKNESS] = nm * 0.001f; // nanometres -> micrometres
         setN(n, "anisotropy_strength", p + GI_C_P_SPECULAR_ANISOTROPY, 1);
         float alpha = 1.0f, mode = 0.0f, cutoff = 0.5f; setN(n, "alpha", &alpha, 1); setN(n, "alpha_mode", &mode, 1); setN(n, "alpha_cutoff", &cutoff, 1);
         p[GI_C_P_OPACITY] = mode < 0.5f ? 1.0f : (mode < 1.5f ? (alpha >= cutoff ? 1.0f : 0.0f) : alpha);
         float strength = 1.0f; ecol[0] = ecol[1] = ecol[2] = 0.0f; setN(n, "emissive", ecol, 3); setN(n, "emissive_strength", &strength, 1);
         for (int i = 0; i < 3; i++) p[GI_C_P_EMISSION + i] = strength * ecol[i];
-        bind("base_color", GI_C_TEX_BASE_COLOR, p + GI_C_P_BASE_COLOR, 3); bind("roughness", GI_C_TEX_ROUGHNESS, p + GI_C_P_ROUGHNESS, 1); bind("metallic", GI_C_TEX_METALLIC, p + GI_C_P_METALLIC, 1);
-        bind("normal", GI_C_TEX_NORMAL); bind("clearcoat_normal", GI_C_TEX_COAT_NORMAL); bind("transmission", GI_C_TEX_TRANSMISSION_WEIGHT, p + GI_C_P_TRANSMISSION_WEIGHT, 1);
+        bind("base_color", GI_C_TEX_BASE_COLOR, p + GI_C_P_BASE_COLOR, 3); bind("roughness", GI_C_TEX_ROUGHNESS, p + GI_C_P_ROUGHNESS, 1);
+            bind("metallic", GI_C_TEX_METALLIC, p + GI_C_P_METALLIC, 1);
+        bind("normal", GI_C_TEX_NORMAL); bind("clearcoat_normal", GI_C_TEX_COAT_NORMAL);
+            bind("transmission", GI_C_TEX_TRANSMISSION_WEIGHT, p + GI_C_P_TRANSMISSION_WEIGHT, 1);
         if (mode >= 1.5f) bind("alpha", GI_C_TEX_OPACITY);
         return true;
       }
@@ -362,19 +393,25 @@ namespace gtl
       setN(n, "transmission_depth", p + GI_C_P_TRANSMISSION_DEPTH, 1); setN(n, "transmission_scatter", p + GI_C_P_TRANSMISSION_SCATTER, 3);
       setN(n, "transmission_scatter_anisotropy", p + GI_C_P_TRANSMISSION_SCATTER_ANISOTROPY, 1);
       setN(n, "coat_weight", p + GI_C_P_CLEARCOAT, 1); setN(n, "coat_color", p + GI_C_P_COAT_COLOR, 3);
-      setN(n, "coat_roughness", p + GI_C_P_CLEARCOAT_ROUGHNESS, 1); setN(n, "coat_ior", p + GI_C_P_COAT_IOR, 1); setN(n, "coat_darkening", p + GI_C_P_COAT_DARKENING, 1);
-      setN(n, "fuzz_weight", p + GI_C_P_FUZZ_WEIGHT, 1); setN(n, "fuzz_color", p + GI_C_P_FUZZ_COLOR, 3); setN(n, "fuzz_roughness", p + GI_C_P_FUZZ_ROUGHNESS, 1);
+      setN(n, "coat_roughness", p + GI_C_P_CLEARCOAT_ROUGHNESS, 1); setN(n, "coat_ior", p + GI_C_P_COAT_IOR, 1);
+          setN(n, "coat_darkening", p + GI_C_P_COAT_DARKENING, 1);
+      setN(n, "fuzz_weight", p + GI_C_P_FUZZ_WEIGHT, 1); setN(n, "fuzz_color", p + GI_C_P_FUZZ_COLOR, 3);
+          setN(n, "fuzz_roughness", p + GI_C_P_FUZZ_ROUGHNESS, 1);
       setN(n, "geometry_thin_walled", p + GI_C_P_THIN_WALLED, 1);
       setN(n, "subsurface_weight", p + GI_C_P_SUBSURFACE_WEIGHT, 1); setN(n, "subsurface_color", p + GI_C_P_SUBSURFACE_COLOR, 3);
       setN(n, "subsurface_scatter_anisotropy", p + GI_C_P_SUBSURFACE_ANISOTROPY, 1);
-      setN(n, "subsurface_radius", p + GI_C_P_SUBSURFACE_RADIUS, 1); setN(n, "subsurface_radius_scale", p + GI_C_P_SUBSURFACE_RADIUS_SCALE, 3); // the volumetric form's mean free path
+      // the volumetric form's mean free path
+      setN(n, "subsurface_radius", p + GI_C_P_SUBSURFACE_RADIUS, 1); setN(n, "subsurface_radius_scale", p + GI_C_P_SUBSURFACE_RADIUS_SCALE, 3);
       setN(n, "specular_roughness_anisotropy", p + GI_C_P_SPECULAR_ANISOTROPY, 1); setN(n, "coat_roughness_anisotropy", p + GI_C_P_COAT_ANISOTROPY, 1);
-      setN(n, "thin_film_weight", p + GI_C_P_THIN_FILM_WEIGHT, 1); setN(n, "thin_film_thickness", p + GI_C_P_THIN_FILM_THICKNESS, 1); setN(n, "thin_film_ior", p + GI_C_P_THIN_FILM_IOR, 1);
+      setN(n, "thin_film_weight", p + GI_C_P_THIN_FILM_WEIGHT, 1); setN(n, "thin_film_thickness", p + GI_C_P_THIN_FILM_THICKNESS, 1);
+          setN(n, "thin_film_ior", p + GI_C_P_THIN_FILM_IOR, 1);
       setN(n, "emission_luminance", &lum, 1); setN(n, "emission_color", ecol, 3); setN(n, "geometry_opacity", p + GI_C_P_OPACITY, 1);
       for (int i = 0; i < 3; i++) p[GI_C_P_EMISSION + i] = lum * ecol[i];
-      bind("base_color", GI_C_TEX_BASE_COLOR, p + GI_C_P_BASE_COLOR, 3); bind("specular_roughness", GI_C_TEX_ROUGHNESS, p + GI_C_P_ROUGHNESS, 1); bind("base_metalness", GI_C_TEX_METALLIC, p + GI_C_P_METALLIC, 1);
+      bind("base_color", GI_C_TEX_BASE_COLOR, p + GI_C_P_BASE_COLOR, 3); bind("specular_roughness", GI_C_TEX_ROUGHNESS, p + GI_C_P_ROUGHNESS, 1);
+          bind("base_metalness", GI_C_TEX_METALLIC, p + GI_C_P_METALLIC, 1);
       bind("geometry_normal", GI_C_TEX_NORMAL); bind("geometry_opacity", GI_C_TEX_OPACITY); bind("geometry_coat_normal", GI_C_TEX_COAT_NORMAL);
-      bind("transmission_weight", GI_C_TEX_TRANSMISSION_WEIGHT, p + GI_C_P_TRANSMISSION_WEIGHT, 1); bind("transmission_color", GI_C_TEX_TRANSMISSION_COLOR, p + GI_C_P_TRANSMISSION_COLOR, 3);
+      bind("transmission_weight", GI_C_TEX_TRANSMISSION_WEIGHT, p + GI_C_P_TRANSMISSION_WEIGHT, 1);
+          bind("transmission_color", GI_C_TEX_TRANSMISSION_COLOR, p + GI_C_P_TRANSMISSION_COLOR, 3);
       return true;
     }
   }
@@ -385,8 +422,8 @@ namespace gtl
     return giCInitialize(dev ? atoi(dev) : 0) == GI_C_OK ? GiStatus::Ok : GiStatus::Error;
   }
   void giTerminate() { giCTerminate(); }
-  // Gi.h:201.  The reference hands the reader to its texture manager, which opens EVERY image through it (TextureManager.cpp:39-52; hdGatling's is backed by ArResolver,
-  // rendererPlugin.cpp:95-143, 189): the C++ object becomes the C ABI's four callbacks.
+  // Gi.h:201.  The reference hands the reader to its texture manager, which opens EVERY image through it (TextureManager.cpp:39-52; hdGatling's is backed by
+  // ArResolver, rendererPlugin.cpp:95-143, 189): the C++ object becomes the C ABI's four callbacks.
   void giRegisterAssetReader(GiAssetReader* reader)
   {
     s_assetReader = reader;
@@ -400,7 +437,8 @@ namespace gtl
     giCRegisterAssetReader(&r);
   }
 
-  static GiMaterial* makeMaterial(GiScene* scene, const char* name, const GiCMaterialDesc& d, const std::string (&primvars)[GI_C_TEX_SLOT_COUNT], const ImageInput (&images)[GI_C_TEX_SLOT_COUNT])
+  static GiMaterial* makeMaterial(GiScene* scene, const char* name, const GiCMaterialDesc& d, const std::string (&primvars)[GI_C_TEX_SLOT_COUNT],
+      const ImageInput (&images)[GI_C_TEX_SLOT_COUNT])
   {
     GiCMaterial* h = giCCreateMaterial(scene->h, name, &d);
     if (!h) return nullptr;
@@ -412,7 +450,8 @@ namespace gtl
       GiCTexture* t = giCCreateTextureFromFile(scene->h, im.file.c_str(), im.srgb ? 1 : 0); // .png / .jpg / .hdr / .pfm; others: the input keeps its constant
       if (!t) continue;
       mat->textures.push_back(t);
-      GiCTextureBinding b{t, im.wrapS, im.wrapT, im.channel, {im.scale[0], im.scale[1], im.scale[2], im.scale[3]}, {im.bias[0], im.bias[1], im.bias[2], im.bias[3]}};
+      GiCTextureBinding b{t, im.wrapS, im.wrapT, im.channel, {im.scale[0], im.scale[1], im.scale[2], im.scale[3]},
+          {im.bias[0], im.bias[1], im.bias[2], im.bias[3]}};
       giCSetMaterialTexture(h, slot, &b);
       if (im.hasXf) giCSetMaterialTextureTransform(h, slot, im.xf);
     }
@@ -474,7 +513,8 @@ namespace gtl
   void gtlRegisterMtlxDocSerializer(GtlMtlxDocToXml fn) { s_docToXml = fn; }
   GiMaterial* giCreateMaterialFromMtlxDoc(GiScene* scene, const char* name, const std::shared_ptr<void> doc)
   {
-    if (!s_docToXml) { fprintf(stderr, "[gatling_gi] giCreateMaterialFromMtlxDoc: built without gtl_shim_mtlx.cpp (MaterialX headers not found at build time)\n"); return nullptr; }
+    if (!s_docToXml) { fprintf(stderr,
+        "[gatling_gi] giCreateMaterialFromMtlxDoc: built without gtl_shim_mtlx.cpp (MaterialX headers not found at build time)\n"); return nullptr; }
     if (!doc) return nullptr;
     const std::string xml = s_docToXml(doc);
     return giCreateMaterialFromMtlxStr(scene, name, xml.c_str());
@@ -519,11 +559,14 @@ namespace gtl
       std::string xml = "<materialx version=\"1.39\"><open_pbr_surface name=\"m\" type=\"surfaceshader\">";
       // (name, components): scalars are written as one value, colours as three -- the same spelling a MaterialX document uses
       static const struct { const char* name; int n; } kOpbr[] = {
-        {"base_weight", 1}, {"base_color", 3}, {"base_diffuse_roughness", 1}, {"base_metalness", 1}, {"specular_weight", 1}, {"specular_color", 3}, {"specular_roughness", 1},
-        {"specular_ior", 1}, {"transmission_weight", 1}, {"transmission_color", 3}, {"transmission_depth", 1}, {"transmission_scatter", 3}, {"transmission_scatter_anisotropy", 1},
+        {"base_weight", 1}, {"base_color", 3}, {"base_diffuse_roughness", 1}, {"base_metalness", 1}, {"specular_weight", 1}, {"specular_color", 3},
+            {"specular_roughness", 1},
+        {"specular_ior", 1}, {"transmission_weight", 1}, {"transmission_color", 3}, {"transmission_depth", 1}, {"transmission_scatter", 3},
+            {"transmission_scatter_anisotropy", 1},
         {"coat_weight", 1}, {"coat_color", 3}, {"coat_roughness", 1}, {"coat_ior", 1}, {"coat_darkening", 1}, {"emission_luminance", 1}, {"emission_color", 3},
         {"geometry_opacity", 1}, {"fuzz_weight", 1}, {"fuzz_color", 3}, {"fuzz_roughness", 1}, {"geometry_thin_walled", 1},
-        {"subsurface_weight", 1}, {"subsurface_color", 3}, {"subsurface_scatter_anisotropy", 1}, {"specular_roughness_anisotropy", 1}, {"coat_roughness_anisotropy", 1},
+        {"subsurface_weight", 1}, {"subsurface_color", 3}, {"subsurface_scatter_anisotropy", 1}, {"specular_roughness_anisotropy", 1},
+            {"coat_roughness_anisotropy", 1},
         {"thin_film_weight", 1}, {"thin_film_thickness", 1}, {"thin_film_ior", 1}};
       for (const auto& k : kOpbr) {
         float v[3];
@@ -556,15 +599,19 @@ namespace gtl
       known |= num("reflection_roughness_constant", p + GI_C_P_ROUGHNESS, 1); known |= num("metallic_constant", p + GI_C_P_METALLIC, 1);
       float enableEm = 0.0f, emCol[3] = {1.0f, 0.1f, 0.1f}, emInt = 40.0f;
       num("enable_emission", &enableEm, 1); num("emissive_color", emCol, 3); num("emissive_intensity", &emInt, 1);
-      if (enableEm != 0.0f) for (int k = 0; k < 3; k++) p[GI_C_P_EMISSION + k] = emCol[k] * emInt; // (cd/m2: the reference's unit handling is the MDL SDK's; not pinned)
+      // (cd/m2: the reference's unit handling is the MDL SDK's; not pinned)
+      if (enableEm != 0.0f) for (int k = 0; k < 3; k++) p[GI_C_P_EMISSION + k] = emCol[k] * emInt;
       float enableOp = 0.0f, opC = 1.0f;
       num("enable_opacity", &enableOp, 1);
       if (enableOp != 0.0f && num("opacity_constant", &opC, 1)) { p[GI_C_P_OPACITY] = opC; num("opacity_threshold", p + GI_C_P_OPACITY_THRESHOLD, 1); }
-      if (omni && module.find("ClearCoat") != std::string::npos) { float en = 0.0f, w = 1.0f; num("enable_clearcoat", &en, 1); num("clearcoat_weight", &w, 1); if (en != 0.0f) p[GI_C_P_CLEARCOAT] = w; num("clearcoat_roughness", p + GI_C_P_CLEARCOAT_ROUGHNESS, 1); }
-      if (tex("diffuse_texture", GI_C_TEX_BASE_COLOR, 0) || tex("diffuseColor", GI_C_TEX_BASE_COLOR, 0)) { known = true; for (int k = 0; k < 3; k++) images[GI_C_TEX_BASE_COLOR].scale[k] = tint[k]; }
+      if (omni && module.find("ClearCoat") != std::string::npos) { float en = 0.0f, w = 1.0f; num("enable_clearcoat", &en, 1); num("clearcoat_weight", &w, 1);
+          if (en != 0.0f) p[GI_C_P_CLEARCOAT] = w; num("clearcoat_roughness", p + GI_C_P_CLEARCOAT_ROUGHNESS, 1); }
+      if (tex("diffuse_texture", GI_C_TEX_BASE_COLOR, 0) || tex("diffuseColor", GI_C_TEX_BASE_COLOR, 0)) { known = true;
+          for (int k = 0; k < 3; k++) images[GI_C_TEX_BASE_COLOR].scale[k] = tint[k]; }
       float infl = 0.0f;
       if (num("reflection_roughness_texture_influence", &infl, 1) && infl > 0.0f && tex("reflectionroughness_texture", GI_C_TEX_ROUGHNESS, 0)) {
-        images[GI_C_TEX_ROUGHNESS].scale[0] = infl; images[GI_C_TEX_ROUGHNESS].bias[0] = p[GI_C_P_ROUGHNESS] * (1.0f - infl); // lerp(constant, texel, influence)
+        // lerp(constant, texel, influence)
+        images[GI_C_TEX_ROUGHNESS].scale[0] = infl; images[GI_C_TEX_ROUGHNESS].bias[0] = p[GI_C_P_ROUGHNESS] * (1.0f - infl);
       }
       if (num("metallic_texture_influence", &infl, 1) && infl > 0.0f && tex("metallic_texture", GI_C_TEX_METALLIC, 0)) {
         images[GI_C_TEX_METALLIC].scale[0] = infl; images[GI_C_TEX_METALLIC].bias[0] = p[GI_C_P_METALLIC] * (1.0f - infl);
@@ -573,7 +620,9 @@ namespace gtl
       tex("normalmap_texture", GI_C_TEX_NORMAL, 0); tex("normal", GI_C_TEX_NORMAL, 0);
       if (enableOp != 0.0f) { float ot = 0.0f; num("enable_opacity_texture", &ot, 1); if (ot != 0.0f) tex("opacity_texture", GI_C_TEX_OPACITY, 0); }
     }
-    if (!known) { fprintf(stderr, "[gatling_gi] giCreateMaterialFromMdlFile(%s): no MDL compiler and no recognised parameter -- the delegate's default material is used\n", module.c_str()); return nullptr; }
+    if (!known) { fprintf(stderr,
+        "[gatling_gi] giCreateMaterialFromMdlFile(%s): no MDL compiler and no recognised parameter -- the delegate's default material is used\n",
+        module.c_str()); return nullptr; }
     return makeMaterial(scene, name, d, primvars, images);
   }
   void giDestroyMaterial(GiMaterial* mat)
@@ -587,7 +636,8 @@ namespace gtl
   static void setPrimvars(GiCMesh* h, const std::vector<GiPrimvarData>& pv, bool instancer)
   {
     std::vector<GiCPrimvarData> c(pv.size());
-    for (size_t i = 0; i < pv.size(); i++) c[i] = GiCPrimvarData{pv[i].name.c_str(), (int32_t)pv[i].type, (int32_t)pv[i].interpolation, pv[i].data.data(), (uint64_t)pv[i].data.size()};
+    for (size_t i = 0; i < pv.size(); i++) c[i] = GiCPrimvarData{pv[i].name.c_str(), (int32_t)pv[i].type, (int32_t)pv[i].interpolation, pv[i].data.data(),
+        (uint64_t)pv[i].data.size()};
     if (instancer) giCSetMeshInstancerPrimvars(h, (uint32_t)c.size(), c.data()); else giCSetMeshPrimvars(h, (uint32_t)c.size(), c.data());
   }
 
@@ -607,7 +657,8 @@ namespace gtl
     return new GiMesh{h};
   }
   void giSetMeshTransform(GiMesh* m, const float* mat4x4) { giCSetMeshTransform(m->h, mat4x4); }
-  void giSetMeshInstanceTransforms(GiMesh* m, uint32_t count, const float (*t)[4][4]) { giCSetMeshInstanceTransforms(m->h, count, reinterpret_cast<const float*>(t)); }
+  void giSetMeshInstanceTransforms(GiMesh* m, uint32_t count, const float (*t)[4][4])
+  { giCSetMeshInstanceTransforms(m->h, count, reinterpret_cast<const float*>(t)); }
   void giSetMeshInstancerPrimvars(GiMesh* m, const std::vector<GiPrimvarData>& pv) { setPrimvars(m->h, pv, true); }
   void giSetMeshInstanceIds(GiMesh* m, uint32_t count, int* ids) { giCSetMeshInstanceIds(m->h, count, ids); }
   void giSetMeshMaterial(GiMesh* m, GiMaterial* mat) { giCSetMeshMaterial(m->h, mat ? mat->h : nullptr); }
@@ -639,7 +690,8 @@ namespace gtl
   void giDestroyScene(GiScene* s) { if (!s) return; giCDestroyScene(s->h); delete s; }
 
 #define GTL_LIGHT(Type, CType)                                                                                          \
-  Gi##Type##Light* giCreate##Type##Light(GiScene* scene) { auto* h = scene ? giCCreate##Type##Light(scene->h) : nullptr; return h ? new Gi##Type##Light{h} : nullptr; } \
+  Gi##Type##Light* giCreate##Type##Light(GiScene* scene) \
+  { auto* h = scene ? giCCreate##Type##Light(scene->h) : nullptr; return h ? new Gi##Type##Light{h} : nullptr; } \
   void giDestroy##Type##Light(GiScene* scene, Gi##Type##Light* l) { if (!l) return; giCDestroy##Type##Light(scene->h, l->h); delete l; }
   GTL_LIGHT(Sphere, GiCSphereLight) GTL_LIGHT(Distant, GiCDistantLight) GTL_LIGHT(Rect, GiCRectLight) GTL_LIGHT(Disk, GiCDiskLight)
 #undef GTL_LIGHT
@@ -663,13 +715,15 @@ namespace gtl
   void giSetDiskLightRadius(GiDiskLight* l, float x, float y) { giCSetDiskLightRadius(l->h, x, y); }
   void giSetDiskLightDiffuseSpecular(GiDiskLight* l, float d, float s) { giCSetDiskLightDiffuseSpecular(l->h, d, s); }
 
-  GiDomeLight* giCreateDomeLight(GiScene* scene, const char* filePath) { auto* h = scene ? giCCreateDomeLight(scene->h, filePath) : nullptr; return h ? new GiDomeLight{h} : nullptr; }
+  GiDomeLight* giCreateDomeLight(GiScene* scene, const char* filePath)
+  { auto* h = scene ? giCCreateDomeLight(scene->h, filePath) : nullptr; return h ? new GiDomeLight{h} : nullptr; }
   void giDestroyDomeLight(GiDomeLight* l) { if (!l) return; giCDestroyDomeLight(l->h); delete l; }
   void giSetDomeLightRotation(GiDomeLight* l, float* q) { giCSetDomeLightRotation(l->h, q); }
   void giSetDomeLightBaseEmission(GiDomeLight* l, float* v) { giCSetDomeLightBaseEmission(l->h, v); }
   void giSetDomeLightDiffuseSpecular(GiDomeLight* l, float d, float s) { giCSetDomeLightDiffuseSpecular(l->h, d, s); }
 
-  GiRenderBuffer* giCreateRenderBuffer(uint32_t w, uint32_t h, GiRenderBufferFormat f) { auto* b = giCCreateRenderBuffer(w, h, int(f)); return b ? new GiRenderBuffer{b} : nullptr; }
+  GiRenderBuffer* giCreateRenderBuffer(uint32_t w, uint32_t h, GiRenderBufferFormat f)
+  { auto* b = giCCreateRenderBuffer(w, h, int(f)); return b ? new GiRenderBuffer{b} : nullptr; }
   void giDestroyRenderBuffer(GiRenderBuffer* b) { if (!b) return; giCDestroyRenderBuffer(b->h); delete b; }
   void* giGetRenderBufferMem(GiRenderBuffer* b) { return b ? giCGetRenderBufferMem(b->h) : nullptr; }
 }

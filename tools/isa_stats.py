@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static instruction counts of the kernels in a device assembly file (hipcc --cuda-device-only -S): VALU / SALU / LDS / VMEM per kernel, VGPRs, occupancy.
 
-  python tools/isa_stats.py /tmp/isa/gi_kernels.s [name filter]      (tools/isa_stats.py --build gi_kernels.hip [filter] compiles first)"""
+  python tools/isa_stats.py /tmp/isa/gi_trace.s [name filter]      (tools/isa_stats.py --build gi_trace.hip [filter] compiles first)"""
 import os
 import re
 import subprocess

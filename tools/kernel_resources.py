@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """VGPRs / scratch / occupancy of the kernels of one translation unit (hipcc -Rpass-analysis=kernel-resource-usage), one line per kernel.
 
-  python tools/kernel_resources.py gi_kernels.hip [name filter] [-- extra hipcc flags]"""
+  python tools/kernel_resources.py gi_trace.hip [name filter] [-- extra hipcc flags]"""
 import os
 import re
 import subprocess
