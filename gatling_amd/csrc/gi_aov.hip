@@ -22,7 +22,7 @@ namespace gi {
 __device__ inline V3 bsdf_albedo(const MaterialRec* m, const ShState& st, V3 k1)
 {
   float nk1 = fmax2(dot(st.normal, k1), 1e-4f);
-  if (m->klass == 0u) return v3(m->p[0], m->p[1], m->p[2]);
+  if (m->klass == 0u) return diffuse_class_color(m, st);
   if (m->klass == 1u) {
     UpsParams u = ups_params(m, st);
     float Fc = u.coat * (0.04f + 0.96f * schlick_w(nk1));

@@ -912,6 +912,13 @@ __device__ inline void opbr_base_evaluate(const MaterialRec* m, const ShState& s
   out.pdf = 0.0f + (o.metalness * ps + diel * (Fd * ps + (1.0f - Fd) * cd)); // (Fc * pc = +0 first, as in opbr_evaluate_base)
 }
 
+// class 0 (diffuse only): the colour is the material's, or the hit's textured / primvar-driven base colour (found by the differential campaign of round 6,
+// tests/fuzz_parity.py: the class ignored its base-colour binding while the oracle -- and every other class -- honours it)
+__device__ __forceinline__ V3 diffuse_class_color(const MaterialRec* m, const ShState& st)
+{
+  return (st.texMask & (1u << TEX_BASE_COLOR)) ? st.texBaseColor : v3(m->p[0], m->p[1], m->p[2]);
+}
+
 constexpr uint32_t KLASS_DYNAMIC = 0xffffffffu; // read the class from the material record (debug / AOV paths)
 template <uint32_t KLASS>
 __device__ inline void bsdf_sample(const MaterialRec* m, const ShState& st, V3 k1, float x0, float x1, float x2, BsdfSample& out)
@@ -922,7 +929,7 @@ __device__ inline void bsdf_sample(const MaterialRec* m, const ShState& st, V3 k
     V3 l = gi_sample_hemisphere(x0, x1);
     V3 k2 = to_world(st, l);
     if (!(l.z > 0.0f) || !(dot(k2, st.geomNormal) > 0.0f)) return;
-    out.k2 = k2; out.pdf = l.z / GI_PI; out.overPdf = v3(m->p[0], m->p[1], m->p[2]); out.event = EV_DIFFUSE | EV_REFLECTION;
+    out.k2 = k2; out.pdf = l.z / GI_PI; out.overPdf = diffuse_class_color(m, st); out.event = EV_DIFFUSE | EV_REFLECTION;
     return;
   }
   if (klass == 1u) {
@@ -975,7 +982,7 @@ __device__ inline void bsdf_evaluate(const MaterialRec* m, const ShState& st, V3
   const uint32_t klass = (KLASS == KLASS_DYNAMIC) ? m->klass : KLASS;
   if (klass == 0u) {
     float c = nk2 / GI_PI;
-    out.diffuse = v3(m->p[0], m->p[1], m->p[2]) * c; out.pdf = c;
+    out.diffuse = diffuse_class_color(m, st) * c; out.pdf = c;
     return;
   }
   if (klass == 1u) {

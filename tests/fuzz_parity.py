@@ -1,0 +1,226 @@
+"""Differential campaign: random renders (tests/fuzz_scenes.py) through the C ABI on the GPU and through the oracle, compared bit for bit (test infrastructure).
+
+  python tests/fuzz_parity.py 0:500 [--threads 64] [--log gpurun_out/fuzz.log] [--keep-going]
+
+Per case: the colour image of one giCRender call == the oracle's, the frame's segment / shadow-ray / sample counts, optionally a second (progressive) call and
+the 13 non-colour AOVs.  Prints one line per case and a summary; exit status 1 if any case differs."""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+import traceback
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from fuzz_scenes import random_case  # noqa: E402
+
+AOV_NAMES = ["normal", "barycentrics", "texcoords", "opacity", "tangents", "bitangents", "thinWalled", "objectId", "depth", "faceId", "instanceId", "doubleSided", "albedo"]
+AOV_CLEAR = {"normal": (0.5, 0.5, 0.5, 0.5), "objectId": -1, "faceId": -1, "instanceId": -1, "depth": 1.0, "albedo": (0.1, 0.2, 0.3, 0.0)}
+
+
+def differing(a, b):
+    """Number of pixels whose bits differ (NaNs of any payload count as equal to NaNs: the host's and the device's default NaN differ in sign)."""
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    if a.shape != b.shape: return -1
+    if a.dtype.kind == "f":
+        ne = (a.view(np.uint32) != b.view(np.uint32)) & ~(np.isnan(a) & np.isnan(b))
+    else:
+        ne = a != b
+    return int(ne.reshape(len(ne.reshape(-1)) // (a.shape[-1] if a.ndim == 3 else 1), -1).any(axis=-1).sum())
+
+
+def run_case(gi, orc, seed, threads=8):
+    """{"seed", "status": "same" | "differs" | "refused" | "error", "detail", ...} of one case."""
+    desc, rs, w, h, ex = random_case(seed)
+    info = {"seed": seed, "tris": desc.triangle_count(), "w": w, "h": h, "spp": rs.spp, "bounces": rs.max_bounces, "nee": rs.next_event_estimation,
+            "media": rs.medium_stack_size, "materials": len(desc.materials), "big": ex["big"], "aovs": ex["aovs"], "second": ex["second_call"]}
+    t0 = time.perf_counter()
+    try:
+        sc = gi.Scene(desc)
+    except Exception as e:  # the host refused the scene: the oracle has no say
+        return dict(info, status="refused", detail=str(e)[:200])
+    try:
+        try:
+            aov = sc.render_aovs(rs, w, h, AOV_NAMES, AOV_CLEAR) if ex["aovs"] else None   # (the colour AOV is bound in the same call)
+            img = aov["color"] if aov is not None else sc.render(rs, w, h)
+            st = sc.stats()
+            img2 = sc.render(rs, w, h) if ex["second_call"] else None
+        except gi.GiError as e:
+            return dict(info, status="refused", detail=str(e)[:200])
+    finally:
+        sc.close()
+    info["gpu_s"] = round(time.perf_counter() - t0, 3)
+    t0 = time.perf_counter()
+    ref, cnt = orc.render(desc, rs, w, h, threads=threads)
+    problems = []
+    bad = differing(img, ref)
+    if bad: problems.append(f"colour: {bad} of {w * h} pixels")
+    if (st["segments"], st["shadowRays"], st["samples"]) != (cnt["segments"], cnt["shadow_rays"], cnt["samples"]):
+        problems.append(f"counts: segments {st['segments']} / {cnt['segments']}, shadow rays {st['shadowRays']} / {cnt['shadow_rays']}, samples {st['samples']} / {cnt['samples']}")
+    if img2 is not None:
+        ref2, _ = orc.render(desc, rs, w, h, threads=threads, sample_offset=rs.spp, prev_color=ref)
+        bad = differing(img2, ref2)
+        if bad: problems.append(f"second call: {bad} pixels")
+    if aov is not None:
+        refa = orc.render_aovs(desc, rs, w, h, AOV_NAMES, AOV_CLEAR)
+        for name in AOV_NAMES:
+            bad = differing(np.asarray(aov[name]).reshape(np.asarray(refa[name]).shape), refa[name])
+            if bad: problems.append(f"aov {name}: {bad}")
+    info["cpu_s"] = round(time.perf_counter() - t0, 3)
+    info["finite"] = bool(np.isfinite(img).all())
+    return dict(info, status="differs" if problems else "same", detail="; ".join(problems))
+
+
+def _differs(gi, orc, desc, rs, w, h, threads):
+    try:
+        sc = gi.Scene(desc)
+    except Exception:
+        return False
+    try:
+        img = sc.render(rs, w, h); st = sc.stats()
+    except gi.GiError:
+        return False
+    finally:
+        sc.close()
+    ref, cnt = orc.render(desc, rs, w, h, threads=threads)
+    return differing(img, ref) != 0 or (st["segments"], st["shadowRays"]) != (cnt["segments"], cnt["shadow_rays"])
+
+
+def reduce_case(gi, orc, seed, threads=8):
+    """Greedy reduction of a differing case: drops lights, meshes, instances, texture bindings, resets material parameters and render settings one at a time while
+    the colour image (or the counts) still differ; prints what is left."""
+    import copy
+    import dataclasses
+    from gatling_amd.scene import MaterialDesc, MAT_OPEN_PBR
+    desc, rs, w, h, ex = random_case(seed)
+    if not _differs(gi, orc, desc, rs, w, h, threads):
+        print(f"seed {seed}: the first colour call does not differ (second call / AOVs only)"); return
+    def attempt(mut):
+        nonlocal desc, rs
+        d2, r2 = copy.deepcopy(desc), dataclasses.replace(rs)
+        if mut(d2, r2) is False: return False
+        if _differs(gi, orc, d2, r2, w, h, threads): desc, rs = d2, r2; return True
+        return False
+    changed = True
+    while changed:
+        changed = False
+        for name in ("sphere_lights", "distant_lights", "rect_lights", "disk_lights"):
+            k = 0
+            while k < len(getattr(desc, name)):
+                if attempt(lambda d, r: getattr(d, name).pop(k)): changed = True
+                else: k += 1
+        if desc.dome_light is not None and attempt(lambda d, r: setattr(d, "dome_light", None)): changed = True
+        k = 0
+        while k < len(desc.meshes):
+            if len(desc.meshes) > 1 and attempt(lambda d, r: d.meshes.pop(k)): changed = True
+            else: k += 1
+        for k, m in enumerate(desc.meshes):
+            if len(m.instance_transforms) > 1:
+                def one(d, r, k=k):
+                    d.meshes[k].instance_transforms = d.meshes[k].instance_transforms[:1].copy(); d.meshes[k].instance_ids = None
+                if attempt(one): changed = True
+            if not np.array_equal(m.instance_transforms[0], np.eye(4, dtype=np.float32)):
+                def ident(d, r, k=k): d.meshes[k].instance_transforms = np.eye(4, dtype=np.float32)[None].copy(); d.meshes[k].instance_ids = None
+                if attempt(ident): changed = True
+            if not np.array_equal(m.transform, np.eye(4, dtype=np.float32)):
+                if attempt(lambda d, r, k=k: setattr(d.meshes[k], "transform", np.eye(4, dtype=np.float32))): changed = True
+            for flag, plain in (("double_sided", False), ("left_handed", False)):
+                if getattr(m, flag) != plain and attempt(lambda d, r, k=k, flag=flag, plain=plain: setattr(d.meshes[k], flag, plain)): changed = True
+            if len(m.faces) > 1:   # halve the faces
+                for half in (0, 1):
+                    def cut(d, r, k=k, half=half):
+                        f = d.meshes[k].faces; n = len(f) // 2
+                        d.meshes[k].faces = (f[:n] if half == 0 else f[n:]).copy()
+                        if d.meshes[k].face_ids is not None: d.meshes[k].face_ids = (d.meshes[k].face_ids[:n] if half == 0 else d.meshes[k].face_ids[n:]).copy()
+                    if attempt(cut): changed = True; break
+        used = sorted({m.material for m in desc.meshes})
+        for mi in used:
+            mat = desc.materials[mi]
+            for slot in list(mat.textures):
+                if attempt(lambda d, r, mi=mi, slot=slot: d.materials[mi].textures.pop(slot)): changed = True
+            ref = MaterialDesc.open_pbr() if mat.klass == MAT_OPEN_PBR else MaterialDesc.usd_preview_surface(klass=mat.klass)
+            for i in range(len(mat.params)):
+                if mat.params[i] != ref.params[i]:
+                    def reset(d, r, mi=mi, i=i, v=ref.params[i]): d.materials[mi].params[i] = v
+                    if attempt(reset): changed = True
+        plain = RenderSettingsDefaults()
+        for f, v in plain.items():
+            if getattr(rs, f) != v and attempt(lambda d, r, f=f, v=v: setattr(r, f, v)): changed = True
+        for f in ("spp", "max_bounces"):
+            while getattr(rs, f) > (1 if f == "spp" else 0) and attempt(lambda d, r, f=f: setattr(r, f, getattr(r, f) - 1)): changed = True
+    np.set_printoptions(precision=9, suppress=False, linewidth=200)
+    print(f"== seed {seed} reduced: {w}x{h}", rs)
+    print("camera", desc.camera)
+    for name in ("sphere_lights", "distant_lights", "rect_lights", "disk_lights", "dome_light"):
+        if getattr(desc, name): print(name, getattr(desc, name))
+    for m in desc.meshes:
+        print("mesh", m.name, "faces", len(m.faces), "material", m.material, "double_sided", m.double_sided, "left_handed", m.left_handed, "instances", len(m.instance_transforms),
+              "transform", m.transform.reshape(-1).tolist())
+        if len(m.faces) <= 2:
+            for f in m.faces: print("   face", [(m.vertices[i]["pos"].tolist(), m.vertices[i]["norm"].tolist()) for i in f])
+    for mi in sorted({m.material for m in desc.meshes}):
+        mat = desc.materials[mi]
+        ref = MaterialDesc.open_pbr() if mat.klass == MAT_OPEN_PBR else MaterialDesc.usd_preview_surface(klass=mat.klass)
+        print("material", mi, "klass", mat.klass, "non-default params", {i: float(mat.params[i]) for i in range(len(mat.params)) if mat.params[i] != ref.params[i]},
+              "textures", {k: v for k, v in mat.textures.items()})
+    sc = gi.Scene(desc)
+    try:
+        img = sc.render(rs, w, h); st = sc.stats()
+    finally:
+        sc.close()
+    ref, cnt = orc.render(desc, rs, w, h, threads=threads)
+    ne = (img.view(np.uint32) != ref.view(np.uint32)).any(axis=-1)
+    ys, xs = np.nonzero(ne)
+    print("differing pixels", int(ne.sum()), "counts", (st["segments"], st["shadowRays"]), (cnt["segments"], cnt["shadow_rays"]))
+    for y, x in list(zip(ys, xs))[:4]:
+        print("  pixel", x, y, "hip", img[y, x].tolist(), "oracle", ref[y, x].tolist())
+
+
+def RenderSettingsDefaults():
+    return {"next_event_estimation": False, "medium_stack_size": 0, "depth_of_field": False, "clipping_planes": False, "filter_importance_sampling": False,
+            "jittered_sampling": False, "light_intensity_multiplier": 1.0, "max_sample_value": 1.0e6, "rr_bounce_offset": 100, "meters_per_scene_unit": 1.0,
+            "dome_light_camera_visible": True, "clear_color": (0.0, 0.0, 0.0, 0.0)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("seeds", help="first:last (exclusive) or a comma list")
+    ap.add_argument("--threads", type=int, default=min(64, os.cpu_count() or 8))
+    ap.add_argument("--log", default=None)
+    ap.add_argument("--reduce", action="store_true", help="reduce each differing case of the list to what still differs")
+    a = ap.parse_args()
+    seeds = list(range(*map(int, a.seeds.split(":")))) if ":" in a.seeds else [int(x) for x in a.seeds.split(",")]
+    from gatling_amd import capi as gi
+    from oracle import orc
+    orc.build(); orc.lib(); gi.initialize(0)
+    if a.reduce:
+        for seed in seeds:
+            try: reduce_case(gi, orc, seed, a.threads)
+            except Exception: traceback.print_exc()
+        return 0
+    log = open(a.log, "w") if a.log else None
+    tally = {}
+    t0 = time.perf_counter()
+    for seed in seeds:
+        try:
+            r = run_case(gi, orc, seed, a.threads)
+        except Exception:
+            r = {"seed": seed, "status": "error", "detail": traceback.format_exc(limit=3).replace("\n", " | ")[-400:]}
+        tally[r["status"]] = tally.get(r["status"], 0) + 1
+        line = " ".join(f"{k}={v}" for k, v in r.items())
+        if r["status"] != "same" or log is None: print(line, flush=True)
+        if log: log.write(line + "\n"); log.flush()
+    summary = f"# {len(seeds)} cases in {time.perf_counter() - t0:.0f} s: " + ", ".join(f"{v} {k}" for k, v in sorted(tally.items()))
+    print(summary)
+    if log: log.write(summary + "\n")
+    return 1 if tally.get("differs", 0) or tally.get("error", 0) else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

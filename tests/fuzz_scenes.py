@@ -1,0 +1,218 @@
+"""Random scenes for the differential test of the HIP path against the oracle (test infrastructure).
+
+`random_case(seed)` draws a whole render -- meshes (planes, boxes, spheres, triangle soups with degenerate members; transformed, mirrored, instanced, some
+beyond what the kernels keep in LDS), materials of the three BSDF models with every optional lobe switched on, off or in between, textured inputs with every
+wrap mode, all four analytic light types, a dome image, camera (depth of field, clipping planes) and render settings (next event estimation, Russian roulette
+offsets, medium stacks, clamping, filter importance sampling) -- from one integer, so a mismatch is reproduced by its seed.
+
+  python tests/fuzz_parity.py 0:500          the campaign (GPU box): every case through the C ABI and through the oracle, images compared bit for bit
+  tests/test_gpu_fuzz.py                     a fixed sample of it in the GPU suite
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from gatling_amd.meshprep import bake_vertices, smooth_normals  # noqa: E402
+from gatling_amd.scene import (MAT_DIFFUSE, MAT_OPEN_PBR, MAT_USD_PREVIEW_SURFACE, TEX_BASE_COLOR, TEX_COAT_NORMAL, TEX_EMISSION, TEX_METALLIC,  # noqa: E402
+                               TEX_NORMAL, TEX_OPACITY, TEX_ROUGHNESS, TEX_TRANSMISSION_COLOR, TEX_TRANSMISSION_WEIGHT, CameraDesc, DiskLight, DistantLight,
+                               DomeLight, MaterialDesc, MeshDesc, RectLight, RenderSettings, SceneDesc, SphereLight, TextureBinding, usd_transform_2d)
+from gatling_amd.scenes import icosphere  # noqa: E402
+
+
+def _weight(rng):
+    """A lobe weight: off, fully on, or in between."""
+    c = rng.uniform()
+    return 0.0 if c < 0.45 else (1.0 if c < 0.6 else float(rng.uniform(0.02, 0.98)))
+
+
+def _color(rng, lo=0.0, hi=1.0):
+    return tuple(float(x) for x in rng.uniform(lo, hi, 3))
+
+
+def _rotation(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _transform(rng, spread=2.0, scale=(0.3, 1.5)):
+    """USD row-vector 4x4: rotation x (sometimes non-uniform, sometimes mirrored) scale, then a translation."""
+    s = np.full(3, rng.uniform(*scale))
+    if rng.uniform() < 0.3: s = rng.uniform(*scale, 3)
+    if rng.uniform() < 0.12: s[int(rng.integers(3))] *= -1.0
+    m = np.eye(4)
+    m[:3, :3] = np.diag(s) @ _rotation(rng)
+    m[3, :3] = rng.uniform(-spread, spread, 3)
+    return m.astype(np.float32)
+
+
+def _texture(rng):
+    h, w = int(rng.integers(1, 17)), int(rng.integers(1, 17))
+    a = rng.uniform(0.0, 1.0, (h, w, 4)).astype(np.float32)
+    if rng.uniform() < 0.3: a[..., :3] *= np.float32(rng.uniform(1.0, 6.0))     # HDR texels
+    if rng.uniform() < 0.4: a[..., 3] = (a[..., 3] > 0.5).astype(np.float32)     # a binary mask in alpha
+    return a
+
+
+def _binding(rng, ntex, vector=False):
+    b = TextureBinding(texture=int(rng.integers(ntex)), wrap_s=int(rng.integers(4)), wrap_t=int(rng.integers(4)), channel=int(rng.integers(4)))
+    if vector: b.scale, b.bias = (2.0, 2.0, 2.0, 1.0), (-1.0, -1.0, -1.0, 0.0)
+    elif rng.uniform() < 0.5:
+        b.scale, b.bias = tuple(float(x) for x in rng.uniform(0.2, 1.2, 4)), tuple(float(x) for x in rng.uniform(-0.1, 0.2, 4))
+    if rng.uniform() < 0.3:
+        b.transform = usd_transform_2d(float(rng.uniform(-180, 180)), tuple(rng.uniform(0.3, 3.0, 2)), tuple(rng.uniform(-1, 1, 2)))
+    return b
+
+
+def _material(rng, i, ntex):
+    klass = int(rng.choice([MAT_DIFFUSE, MAT_USD_PREVIEW_SURFACE, MAT_OPEN_PBR], p=[0.12, 0.33, 0.55]))
+    emission = _color(rng, 0.0, 4.0) if rng.uniform() < 0.15 else (0.0, 0.0, 0.0)
+    opacity = float(rng.uniform(0.05, 0.95)) if rng.uniform() < 0.15 else 1.0
+    if klass != MAT_OPEN_PBR:
+        m = MaterialDesc.usd_preview_surface(
+            name=f"m{i}", diffuseColor=_color(rng), emissiveColor=emission, useSpecularWorkflow=int(rng.uniform() < 0.3), specularColor=_color(rng),
+            metallic=_weight(rng), roughness=float(rng.choice([0.0, 1.0, rng.uniform(0.02, 1.0)], p=[0.05, 0.05, 0.9])), clearcoat=_weight(rng),
+            clearcoatRoughness=float(rng.uniform(0.0, 1.0)), opacity=opacity, opacityThreshold=float(rng.uniform(0.1, 0.9)) if rng.uniform() < 0.5 else 0.0,
+            ior=float(rng.choice([1.0, 1.5, rng.uniform(1.05, 2.5)])), klass=klass)
+    else:
+        lum = float(rng.uniform(0.5, 5.0)) if emission != (0.0, 0.0, 0.0) else 0.0
+        m = MaterialDesc.open_pbr(
+            name=f"m{i}", base_weight=float(rng.choice([1.0, rng.uniform(0.0, 1.0)])), base_color=_color(rng), base_metalness=_weight(rng),
+            specular_weight=float(rng.choice([1.0, 0.0, rng.uniform(0.0, 1.0)], p=[0.6, 0.1, 0.3])), specular_color=_color(rng, 0.3, 1.0),
+            specular_roughness=float(rng.choice([0.0, 1.0, rng.uniform(0.02, 1.0)], p=[0.05, 0.05, 0.9])), specular_ior=float(rng.choice([1.5, rng.uniform(1.02, 2.5)])),
+            transmission_weight=_weight(rng) if rng.uniform() < 0.4 else 0.0, transmission_color=_color(rng, 0.2, 1.0),
+            transmission_depth=float(rng.uniform(0.1, 2.0)) if rng.uniform() < 0.5 else 0.0, coat_weight=_weight(rng), coat_color=_color(rng, 0.3, 1.0),
+            coat_roughness=float(rng.uniform(0.0, 1.0)), coat_ior=float(rng.uniform(1.1, 2.2)), emission_luminance=lum, emission_color=_color(rng),
+            base_diffuse_roughness=float(rng.uniform(0.0, 1.0)) if rng.uniform() < 0.4 else 0.0,
+            transmission_scatter=_color(rng) if rng.uniform() < 0.3 else (0.0, 0.0, 0.0), transmission_scatter_anisotropy=float(rng.uniform(-0.8, 0.8)),
+            coat_darkening=float(rng.choice([1.0, 0.0, rng.uniform(0.0, 1.0)])), fuzz_weight=_weight(rng) if rng.uniform() < 0.5 else 0.0, fuzz_color=_color(rng),
+            fuzz_roughness=float(rng.uniform(0.0, 1.0)), geometry_thin_walled=bool(rng.uniform() < 0.2),
+            subsurface_weight=_weight(rng) if rng.uniform() < 0.3 else 0.0, subsurface_color=_color(rng),
+            subsurface_scatter_anisotropy=float(rng.uniform(-0.8, 0.8)), specular_roughness_anisotropy=float(rng.uniform(0.0, 1.0)) if rng.uniform() < 0.3 else 0.0,
+            coat_roughness_anisotropy=float(rng.uniform(0.0, 1.0)) if rng.uniform() < 0.3 else 0.0, thin_film_weight=_weight(rng) if rng.uniform() < 0.3 else 0.0,
+            thin_film_thickness=float(rng.uniform(0.05, 1.5)), thin_film_ior=float(rng.uniform(1.1, 2.0)), subsurface_radius=float(rng.uniform(0.05, 2.0)),
+            subsurface_radius_scale=_color(rng, 0.1, 1.0), geometry_opacity=opacity)
+    if ntex and rng.uniform() < 0.4:
+        slots = [TEX_BASE_COLOR, TEX_EMISSION, TEX_ROUGHNESS, TEX_METALLIC, TEX_NORMAL, TEX_OPACITY]
+        if klass == MAT_OPEN_PBR: slots += [TEX_COAT_NORMAL, TEX_TRANSMISSION_WEIGHT, TEX_TRANSMISSION_COLOR]
+        if klass == MAT_DIFFUSE: slots = [TEX_BASE_COLOR, TEX_EMISSION, TEX_OPACITY]
+        for slot in slots:
+            if rng.uniform() < 0.35:
+                m.textures[slot] = _binding(rng, ntex, vector=slot in (TEX_NORMAL, TEX_COAT_NORMAL))
+    return m
+
+
+def _sphere_uv(p):
+    return np.stack([np.arctan2(p[:, 1], p[:, 0]) / (2 * np.pi) + 0.5, np.arccos(np.clip(p[:, 2], -1, 1)) / np.pi], axis=1).astype(np.float32)
+
+
+def _prototype(rng, big):
+    """(vertices, faces) of one mesh in object space."""
+    kind = rng.choice(["plane", "box", "sphere", "soup"], p=[0.2, 0.15, 0.35, 0.3])
+    if kind == "plane":
+        e = float(rng.uniform(1.0, 5.0))
+        p = np.array([[-e, -e, 0], [e, -e, 0], [e, e, 0], [-e, e, 0]], np.float32)
+        uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32) * np.float32(rng.uniform(0.5, 3.0)) - np.float32(rng.uniform(0.0, 1.0))
+        return bake_vertices(p, np.tile([0, 0, 1], (4, 1)), uv), np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+    if kind == "box":
+        c = np.array([[x, y, z] for x in (-1, 1) for y in (-1, 1) for z in (-1, 1)], np.float32) * rng.uniform(0.2, 1.0, 3).astype(np.float32)
+        quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+        pts, nrm, faces = [], [], []
+        for q in quads:
+            a, b, cc, d = (c[k] for k in q)
+            n = np.cross(b - a, cc - a); n /= max(float(np.linalg.norm(n)), 1e-20)
+            k = len(pts); pts += [a, b, cc, d]; nrm += [n] * 4; faces += [(k, k + 1, k + 2), (k, k + 2, k + 3)]
+        uv = np.tile(np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32), (6, 1))
+        return bake_vertices(np.array(pts), np.array(nrm), uv), np.array(faces, np.uint32)
+    if kind == "sphere":
+        pts, faces = icosphere(int(rng.integers(4, 6)) if big else int(rng.integers(0, 4)))
+        return bake_vertices(pts * np.float32(rng.uniform(0.3, 1.2)), pts, _sphere_uv(pts)), faces
+    n = int(rng.integers(3000, 20000)) if big else int(rng.integers(1, 200))
+    size = float(rng.uniform(0.02, 0.2)) if big else float(rng.uniform(0.1, 1.0))
+    c = rng.uniform(-1.5, 1.5, (n, 1, 3))
+    p = (c + rng.normal(scale=size, size=(n, 3, 3))).astype(np.float32).reshape(-1, 3)
+    if n >= 4 and rng.uniform() < 0.3:   # degenerate members: a point, a needle, a repeated vertex
+        p[0:3] = p[0]; p[5] = p[4]; p[8] = (p[6] + p[7]) * np.float32(0.5)
+    faces = np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)
+    if rng.uniform() < 0.5:
+        fn = np.cross(p[1::3] - p[0::3], p[2::3] - p[0::3]); ln = np.linalg.norm(fn, axis=1, keepdims=True); ln[ln == 0] = 1.0
+        nrm = np.repeat(fn / ln, 3, axis=0); nrm[np.abs(nrm).sum(axis=1) == 0] = (0, 0, 1)
+    else:
+        nrm = smooth_normals(p, faces) if rng.uniform() < 0.5 else rng.normal(size=(3 * n, 3))
+        ln = np.linalg.norm(nrm, axis=1, keepdims=True); ln[ln == 0] = 1.0; nrm = nrm / ln
+        nrm[np.abs(nrm).sum(axis=1) == 0] = (0, 0, 1)
+    return bake_vertices(p, nrm, rng.uniform(-1.0, 2.0, (3 * n, 2)).astype(np.float32)), faces
+
+
+def _frame(rng):
+    r = _rotation(rng)
+    return tuple(float(x) for x in r[0]), tuple(float(x) for x in r[1])
+
+
+def random_case(seed: int):
+    """(SceneDesc, RenderSettings, width, height, extras) of case `seed`; extras: {"aovs": bool, "second_call": bool}."""
+    rng = np.random.default_rng([0x6a71, seed])
+    s = SceneDesc()
+    s.textures = [_texture(rng) for _ in range(int(rng.integers(0, 4)))]
+    s.materials = [_material(rng, i, len(s.textures)) for i in range(int(rng.integers(1, 7)))]
+    big = rng.uniform() < 0.3
+    n_mesh = int(rng.integers(1, 7))
+    for k in range(n_mesh):
+        v, f = _prototype(rng, big and k == 0)
+        md = MeshDesc(name=f"/fuzz/mesh{k}", vertices=v, faces=f, material=int(rng.integers(len(s.materials))), id=int(rng.integers(0, 1000)),
+                      double_sided=bool(rng.uniform() < 0.5), left_handed=bool(rng.uniform() < 0.12), visible=bool(rng.uniform() < 0.94), transform=_transform(rng))
+        if rng.uniform() < 0.3:
+            ni = int(rng.integers(2, 5))
+            md.instance_transforms = np.stack([_transform(rng, spread=3.0, scale=(0.5, 1.2)) for _ in range(ni)])
+            if rng.uniform() < 0.5: md.instance_ids = rng.integers(0, 100, ni).astype(np.int32)
+        if rng.uniform() < 0.3:
+            md.face_ids = rng.integers(0, 16, len(f)).astype(np.int32); md.max_face_id = 15
+        s.meshes.append(md)
+    for _ in range(int(rng.integers(0, 3))):
+        s.sphere_lights.append(SphereLight(pos=tuple(rng.uniform(-3, 3, 3)), base_emission=_color(rng, 0, 30),
+                                           radius=(0.0, 0.0, 0.0) if rng.uniform() < 0.1 else tuple(rng.uniform(0.05, 0.6, 3)),
+                                           diffuse=float(rng.choice([1.0, rng.uniform(0, 2)])), specular=float(rng.choice([1.0, rng.uniform(0, 2)]))))
+    if rng.uniform() < 0.3:
+        s.distant_lights.append(DistantLight(direction=tuple(rng.normal(size=3)), base_emission=_color(rng, 0, 4), angle=float(rng.choice([0.0, rng.uniform(0.01, 0.3)])),
+                                             diffuse=float(rng.uniform(0.5, 1.5)), specular=float(rng.uniform(0.5, 1.5))))
+    for _ in range(int(rng.integers(0, 3))):
+        t0, t1 = _frame(rng)
+        s.rect_lights.append(RectLight(origin=tuple(rng.uniform(-3, 3, 3)), t0=t0, t1=t1, base_emission=_color(rng, 0, 20), width=float(rng.uniform(0.1, 2.5)),
+                                       height=float(rng.uniform(0.1, 2.5)), diffuse=float(rng.uniform(0.5, 1.5)), specular=float(rng.uniform(0.5, 1.5))))
+    for _ in range(int(rng.integers(0, 2))):
+        t0, t1 = _frame(rng)
+        s.disk_lights.append(DiskLight(origin=tuple(rng.uniform(-3, 3, 3)), t0=t0, t1=t1, base_emission=_color(rng, 0, 20), radius_x=float(rng.uniform(0.1, 1.5)),
+                                       radius_y=float(rng.uniform(0.1, 1.5)), diffuse=float(rng.uniform(0.5, 1.5)), specular=float(rng.uniform(0.5, 1.5))))
+    if s.textures and rng.uniform() < 0.35:
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        s.dome_light = DomeLight(texture=int(rng.integers(len(s.textures))), rotation=tuple(np.float32(q)), base_emission=_color(rng, 0.2, 1.5),
+                                 diffuse=float(rng.uniform(0.5, 1.5)), specular=float(rng.uniform(0.5, 1.5)))
+    # camera: somewhere on a shell around the origin, looking near it
+    d = rng.normal(size=3); d /= np.linalg.norm(d)
+    pos = d * rng.uniform(2.5, 9.0)
+    fwd = rng.uniform(-0.7, 0.7, 3) - pos; fwd /= np.linalg.norm(fwd)
+    up = np.cross(np.cross(fwd, rng.normal(size=3)), fwd); up /= np.linalg.norm(up)
+    dist = float(np.linalg.norm(pos))
+    s.camera = CameraDesc(position=tuple(np.float32(pos)), forward=tuple(np.float32(fwd)), up=tuple(np.float32(up)), vfov=float(rng.uniform(0.3, 1.6)),
+                          f_stop=float(rng.uniform(0.5, 8.0)), focus_distance=float(rng.uniform(0.5, 1.5)) * dist, focal_length=float(rng.uniform(5.0, 80.0)),
+                          clip_start=float(rng.uniform(0.01, 0.6)) * dist, clip_end=float(rng.uniform(0.9, 3.0)) * dist)
+    rs = RenderSettings(
+        spp=int(rng.integers(1, 7)), max_bounces=int(rng.integers(0, 10)), rr_bounce_offset=int(rng.integers(0, 6)), rr_inv_min_term_prob=float(rng.uniform(0.5, 1.0)),
+        max_sample_value=float(rng.choice([10.0, 1.0e6, 0.5])), filter_importance_sampling=bool(rng.uniform() < 0.7), depth_of_field=bool(rng.uniform() < 0.3),
+        light_intensity_multiplier=float(rng.choice([1.0, 0.5, 3.0])), next_event_estimation=bool(rng.uniform() < 0.5), clipping_planes=bool(rng.uniform() < 0.25),
+        medium_stack_size=int(rng.choice([0, 0, 0, 1, 2, 4])), frame=0.0, max_volume_walk_length=int(rng.integers(1, 9)), jittered_sampling=bool(rng.uniform() < 0.8),
+        meters_per_scene_unit=float(rng.choice([1.0, 0.01, 2.5])), progressive_accumulation=True, dome_light_camera_visible=bool(rng.uniform() < 0.8),
+        clear_color=tuple(float(x) for x in rng.uniform(0.0, 1.0, 4)))
+    w, h = int(rng.integers(1, 72)), int(rng.integers(1, 44))
+    if big: w, h = min(w, 48), min(h, 27)
+    return s, rs, w, h, {"aovs": bool(rng.uniform() < 0.3), "second_call": bool(rng.uniform() < 0.3), "big": bool(big)}
