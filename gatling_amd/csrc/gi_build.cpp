@@ -331,7 +331,9 @@ int buildScene(GiCScene* s)
             for (int32_t id : m->instanceIds) mx = std::max(mx, id); entries = (size_t)std::max(mx, 0) + 1; }
         mr.sdOffset[slot] = (uint32_t)sceneData.size();
         mr.sdInfo[slot] = 1u | ((stride - 1u) << 1) | ((uint32_t)pv->interpolation << 3) | (isInt ? SD_INFO_INT : 0u);
-        const size_t need = std::max(entries * stride, pv->data.size());
+        // (+ 2: a three-component lookup of a one- or two-component primvar reads up to two floats past its last entry -- the reference's stride arithmetic,
+        // mdl_interface.glsl:343-349, finds its neighbour in the packed buffer there; here, as in the oracle, zeros.  Found by tests/fuzz_parity.py)
+        const size_t need = std::max(entries * stride, pv->data.size()) + 2u;
         sceneData.insert(sceneData.end(), pv->data.begin(), pv->data.end());
         sceneData.resize(mr.sdOffset[slot] + need, 0.0f);
       }

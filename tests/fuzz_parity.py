@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from fuzz_scenes import random_case  # noqa: E402
+from fuzz_scenes import apply_edit, random_case  # noqa: E402
 
 AOV_NAMES = ["normal", "barycentrics", "texcoords", "opacity", "tangents", "bitangents", "thinWalled", "objectId", "depth", "faceId", "instanceId", "doubleSided", "albedo"]
 AOV_CLEAR = {"normal": (0.5, 0.5, 0.5, 0.5), "objectId": -1, "faceId": -1, "instanceId": -1, "depth": 1.0, "albedo": (0.1, 0.2, 0.3, 0.0)}
@@ -32,46 +32,76 @@ def differing(a, b):
         ne = (a.view(np.uint32) != b.view(np.uint32)) & ~(np.isnan(a) & np.isnan(b))
     else:
         ne = a != b
-    return int(ne.reshape(len(ne.reshape(-1)) // (a.shape[-1] if a.ndim == 3 else 1), -1).any(axis=-1).sum())
+    return int(ne.any(axis=-1).sum()) if a.ndim == 3 else int(ne.sum())
 
 
 def run_case(gi, orc, seed, threads=8):
     """{"seed", "status": "same" | "differs" | "refused" | "error", "detail", ...} of one case."""
+    import dataclasses
     desc, rs, w, h, ex = random_case(seed)
+    rows = ex.get("rows")
     info = {"seed": seed, "tris": desc.triangle_count(), "w": w, "h": h, "spp": rs.spp, "bounces": rs.max_bounces, "nee": rs.next_event_estimation,
-            "media": rs.medium_stack_size, "materials": len(desc.materials), "big": ex["big"], "aovs": ex["aovs"], "second": ex["second_call"]}
+            "media": rs.medium_stack_size, "materials": len(desc.materials), "big": ex["big"], "aovs": ex["aovs"], "second": ex["second_call"],
+            "rows": rows, "edit": ex.get("edit"), "options": ex.get("options") or "-"}
+    if rows: r0, r1, stride = rows
+    else: r0, r1, stride = 0, h, 1
+    row_list = list(range(r0, r1, stride))
     t0 = time.perf_counter()
-    try:
-        sc = gi.Scene(desc)
-    except Exception as e:  # the host refused the scene: the oracle has no say
-        return dict(info, status="refused", detail=str(e)[:200])
+    os.environ["GATLING_OPTIONS"] = ex.get("options") or ""
     try:
         try:
-            aov = sc.render_aovs(rs, w, h, AOV_NAMES, AOV_CLEAR) if ex["aovs"] else None   # (the colour AOV is bound in the same call)
-            img = aov["color"] if aov is not None else sc.render(rs, w, h)
-            st = sc.stats()
-            img2 = sc.render(rs, w, h) if ex["second_call"] else None
-        except gi.GiError as e:
+            sc = gi.Scene(desc)
+        except Exception as e:  # the host refused the scene: the oracle has no say
             return dict(info, status="refused", detail=str(e)[:200])
+        try:
+            try:
+                kw = {"rows": (r0, r1), "row_stride": stride}
+                aov = sc.render_aovs(rs, w, h, AOV_NAMES, AOV_CLEAR, **kw) if ex["aovs"] else None   # (the colour AOV is bound in the same call)
+                img = aov["color"] if aov is not None else sc.render(rs, w, h, **kw)
+                st = sc.stats()
+                img2 = sc.render(rs, w, h, **kw) if ex["second_call"] else None
+                img3 = None
+                if ex.get("edit"):
+                    k = apply_edit(desc, ex["edit"], ex["edit_seed"])   # (sc.desc IS desc: the oracle renders the edited description)
+                    m = desc.meshes[k]
+                    if ex["edit"] == "transforms": sc.set_mesh_instance_transforms(k, m.instance_transforms)
+                    elif ex["edit"] == "visibility": sc.L.giCSetMeshVisibility(sc.meshes[k], int(m.visible))
+                    else: sc.L.giCSetMeshMaterial(sc.meshes[k], sc.materials[m.material])
+                    rs3 = dataclasses.replace(rs, progressive_accumulation=False)
+                    img3 = sc.render(rs3, w, h, **kw)
+            except gi.GiError as e:
+                return dict(info, status="refused", detail=str(e)[:200])
+        finally:
+            sc.close()
     finally:
-        sc.close()
+        os.environ["GATLING_OPTIONS"] = ""
     info["gpu_s"] = round(time.perf_counter() - t0, 3)
     t0 = time.perf_counter()
-    ref, cnt = orc.render(desc, rs, w, h, threads=threads)
     problems = []
+    if ex.get("edit"):   # the oracle sees the scene as it was before the edit first
+        before, _, _, _, _ = random_case(seed)
+    else:
+        before = desc
+    okw = {"threads": threads, "row_list": row_list} if rows else {"threads": threads}
+    ref, cnt = orc.render(before, rs, w, h, **okw)
     bad = differing(img, ref)
-    if bad: problems.append(f"colour: {bad} of {w * h} pixels")
+    if bad: problems.append(f"colour: {bad} of {len(row_list) * w} pixels")
     if (st["segments"], st["shadowRays"], st["samples"]) != (cnt["segments"], cnt["shadow_rays"], cnt["samples"]):
         problems.append(f"counts: segments {st['segments']} / {cnt['segments']}, shadow rays {st['shadowRays']} / {cnt['shadow_rays']}, samples {st['samples']} / {cnt['samples']}")
     if img2 is not None:
-        ref2, _ = orc.render(desc, rs, w, h, threads=threads, sample_offset=rs.spp, prev_color=ref)
+        ref2, _ = orc.render(before, rs, w, h, sample_offset=rs.spp, prev_color=ref, **okw)
         bad = differing(img2, ref2)
         if bad: problems.append(f"second call: {bad} pixels")
     if aov is not None:
-        refa = orc.render_aovs(desc, rs, w, h, AOV_NAMES, AOV_CLEAR)
+        refa = orc.render_aovs(before, rs, w, h, AOV_NAMES, AOV_CLEAR)
         for name in AOV_NAMES:
-            bad = differing(np.asarray(aov[name]).reshape(np.asarray(refa[name]).shape), refa[name])
+            full = np.asarray(refa[name]); full = full.reshape((h, w, 4) if full.size == h * w * 4 else (h, w))
+            bad = differing(np.asarray(aov[name]), full[r0:r1:stride])
             if bad: problems.append(f"aov {name}: {bad}")
+    if img3 is not None:
+        ref3, _ = orc.render(desc, dataclasses.replace(rs, progressive_accumulation=False), w, h, **okw)
+        bad = differing(img3, ref3)
+        if bad: problems.append(f"after the edit ({ex['edit']}): {bad} pixels")
     info["cpu_s"] = round(time.perf_counter() - t0, 3)
     info["finite"] = bool(np.isfinite(img).all())
     return dict(info, status="differs" if problems else "same", detail="; ".join(problems))
@@ -99,6 +129,8 @@ def reduce_case(gi, orc, seed, threads=8):
     import dataclasses
     from gatling_amd.scene import MaterialDesc, MAT_OPEN_PBR
     desc, rs, w, h, ex = random_case(seed)
+    os.environ["GATLING_OPTIONS"] = ex.get("options") or ""
+    print(f"== seed {seed}: options {ex.get('options') or '-'} rows {ex.get('rows')} edit {ex.get('edit')}")
     if not _differs(gi, orc, desc, rs, w, h, threads):
         print(f"seed {seed}: the first colour call does not differ (second call / AOVs only)"); return
     def attempt(mut):
@@ -132,6 +164,11 @@ def reduce_case(gi, orc, seed, threads=8):
                 if attempt(lambda d, r, k=k: setattr(d.meshes[k], "transform", np.eye(4, dtype=np.float32))): changed = True
             for flag, plain in (("double_sided", False), ("left_handed", False)):
                 if getattr(m, flag) != plain and attempt(lambda d, r, k=k, flag=flag, plain=plain: setattr(d.meshes[k], flag, plain)): changed = True
+            for attr in ("primvars", "instancer_primvars"):
+                j = 0
+                while j < len(getattr(desc.meshes[k], attr)):
+                    if attempt(lambda d, r, k=k, attr=attr, j=j: getattr(d.meshes[k], attr).pop(j)): changed = True
+                    else: j += 1
             if len(m.faces) > 1:   # halve the faces
                 for half in (0, 1):
                     def cut(d, r, k=k, half=half):
@@ -144,6 +181,8 @@ def reduce_case(gi, orc, seed, threads=8):
             mat = desc.materials[mi]
             for slot in list(mat.textures):
                 if attempt(lambda d, r, mi=mi, slot=slot: d.materials[mi].textures.pop(slot)): changed = True
+            for slot in list(mat.primvar_inputs):
+                if attempt(lambda d, r, mi=mi, slot=slot: d.materials[mi].primvar_inputs.pop(slot)): changed = True
             ref = MaterialDesc.open_pbr() if mat.klass == MAT_OPEN_PBR else MaterialDesc.usd_preview_surface(klass=mat.klass)
             for i in range(len(mat.params)):
                 if mat.params[i] != ref.params[i]:
@@ -164,11 +203,13 @@ def reduce_case(gi, orc, seed, threads=8):
               "transform", m.transform.reshape(-1).tolist())
         if len(m.faces) <= 2:
             for f in m.faces: print("   face", [(m.vertices[i]["pos"].tolist(), m.vertices[i]["norm"].tolist()) for i in f])
+        for attr in ("primvars", "instancer_primvars"):
+            for pv in getattr(m, attr): print("  ", attr, pv.name, "type", pv.type, "interp", pv.interpolation, "n", len(np.asarray(pv.data).reshape(-1)), np.asarray(pv.data).reshape(-1)[:8])
     for mi in sorted({m.material for m in desc.meshes}):
         mat = desc.materials[mi]
         ref = MaterialDesc.open_pbr() if mat.klass == MAT_OPEN_PBR else MaterialDesc.usd_preview_surface(klass=mat.klass)
         print("material", mi, "klass", mat.klass, "non-default params", {i: float(mat.params[i]) for i in range(len(mat.params)) if mat.params[i] != ref.params[i]},
-              "textures", {k: v for k, v in mat.textures.items()})
+              "textures", {k: v for k, v in mat.textures.items()}, "primvar inputs", mat.primvar_inputs)
     sc = gi.Scene(desc)
     try:
         img = sc.render(rs, w, h); st = sc.stats()

@@ -20,6 +20,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from gatling_amd.meshprep import bake_vertices, smooth_normals  # noqa: E402
+from gatling_amd.scene import (INTERP_CONSTANT, INTERP_INSTANCE, INTERP_UNIFORM, INTERP_VERTEX, PRIMVAR_FLOAT, PRIMVAR_INT, PRIMVAR_INT3, PRIMVAR_VEC2, PRIMVAR_VEC3,  # noqa: E402
+                               PRIMVAR_VEC4, Primvar)
 from gatling_amd.scene import (MAT_DIFFUSE, MAT_OPEN_PBR, MAT_USD_PREVIEW_SURFACE, TEX_BASE_COLOR, TEX_COAT_NORMAL, TEX_EMISSION, TEX_METALLIC,  # noqa: E402
                                TEX_NORMAL, TEX_OPACITY, TEX_ROUGHNESS, TEX_TRANSMISSION_COLOR, TEX_TRANSMISSION_WEIGHT, CameraDesc, DiskLight, DistantLight,
                                DomeLight, MaterialDesc, MeshDesc, RectLight, RenderSettings, SceneDesc, SphereLight, TextureBinding, usd_transform_2d)
@@ -109,7 +111,34 @@ def _material(rng, i, ntex):
         for slot in slots:
             if rng.uniform() < 0.35:
                 m.textures[slot] = _binding(rng, ntex, vector=slot in (TEX_NORMAL, TEX_COAT_NORMAL))
+    if rng.uniform() < 0.2:   # UsdPrimvarReader inputs (scene data of the mesh; the two names the reference resolves from the frame's uniforms)
+        for slot in [TEX_BASE_COLOR, TEX_EMISSION, TEX_ROUGHNESS, TEX_METALLIC] + ([TEX_TRANSMISSION_WEIGHT, TEX_TRANSMISSION_COLOR] if klass == MAT_OPEN_PBR else []):
+            if slot not in m.textures and rng.uniform() < 0.4:
+                m.primvar_inputs[slot] = str(rng.choice(["pvA", "pvB", "pvC", "pvI", "CAMERA_POSITION", "FRAME", "missing"]))
     return m
+
+
+def _primvars(rng, nv, nf, ni):
+    """Mesh primvars and instancer primvars under the names the materials may read (some absent, one short of its count)."""
+    def data(kind, n):
+        if kind == PRIMVAR_FLOAT: return rng.uniform(0.0, 1.0, n)
+        if kind == PRIMVAR_VEC2: return rng.uniform(0.0, 1.0, (n, 2))
+        if kind == PRIMVAR_VEC3: return rng.uniform(0.0, 1.0, (n, 3))
+        if kind == PRIMVAR_VEC4: return rng.uniform(0.0, 1.0, (n, 4))
+        if kind == PRIMVAR_INT: return rng.integers(0, 2, n)
+        return rng.integers(0, 2, (n, 3))
+    mesh, inst = [], []
+    for name in ("pvA", "pvB", "pvC", "pvI"):
+        if rng.uniform() < 0.3: continue
+        kind = int(rng.choice([PRIMVAR_INT, PRIMVAR_INT3])) if name == "pvI" else int(rng.choice([PRIMVAR_FLOAT, PRIMVAR_VEC2, PRIMVAR_VEC3, PRIMVAR_VEC4]))
+        interp = int(rng.choice([INTERP_CONSTANT, INTERP_UNIFORM, INTERP_VERTEX, INTERP_INSTANCE]))
+        if interp == INTERP_INSTANCE:
+            inst.append(Primvar(name, kind, interp, data(kind, ni)))
+        else:
+            n = {INTERP_CONSTANT: 1, INTERP_UNIFORM: nf, INTERP_VERTEX: nv}[interp]
+            if n > 4 and rng.uniform() < 0.1: n -= 3     # fewer values than elements
+            mesh.append(Primvar(name, kind, interp, data(kind, n)))
+    return mesh, inst
 
 
 def _sphere_uv(p):
@@ -177,6 +206,8 @@ def random_case(seed: int):
             if rng.uniform() < 0.5: md.instance_ids = rng.integers(0, 100, ni).astype(np.int32)
         if rng.uniform() < 0.3:
             md.face_ids = rng.integers(0, 16, len(f)).astype(np.int32); md.max_face_id = 15
+        if s.materials[md.material].primvar_inputs or rng.uniform() < 0.1:
+            md.primvars, md.instancer_primvars = _primvars(rng, len(v), len(f), len(md.instance_transforms))
         s.meshes.append(md)
     for _ in range(int(rng.integers(0, 3))):
         s.sphere_lights.append(SphereLight(pos=tuple(rng.uniform(-3, 3, 3)), base_emission=_color(rng, 0, 30),
@@ -215,4 +246,35 @@ def random_case(seed: int):
         clear_color=tuple(float(x) for x in rng.uniform(0.0, 1.0, 4)))
     w, h = int(rng.integers(1, 72)), int(rng.integers(1, 44))
     if big: w, h = min(w, 48), min(h, 27)
-    return s, rs, w, h, {"aovs": bool(rng.uniform() < 0.3), "second_call": bool(rng.uniform() < 0.3), "big": bool(big)}
+    rs.frame = float(rng.integers(0, 100))
+    extras = {"aovs": bool(rng.uniform() < 0.3), "second_call": bool(rng.uniform() < 0.3), "big": bool(big)}
+    # equivalent schedules of the library ($GATLING_OPTIONS, gi_options.h): none may change a bit
+    opts = []
+    if rng.uniform() < 0.5:
+        for key, values in (("trace_dyn", [0, 8, 32]), ("trace_dyn_spill8", [1]), ("two_level", [1]), ("work_order", [0]), ("defer_slot", [0]), ("bounds_retire", [0]),
+                            ("fused", [0]), ("path_bw", [1]), ("pool_slots", [4096, 65536]), ("bvh_collapse", [0]), ("shadow_order", [0, 1]), ("shade_variants", [0]),
+                            ("merge_shade_variants", [0, 1]), ("two_stream", [0]), ("two_stream_delay", [1, 2])):
+            if rng.uniform() < 0.2: opts.append(f"{key}={int(rng.choice(values))}")
+    extras["options"] = ",".join(opts)
+    # a row range / an interleaved row share of the image instead of all of it (multi-GPU partition of one frame)
+    extras["rows"] = None
+    if h >= 4 and rng.uniform() < 0.2:
+        r0 = int(rng.integers(0, h - 1)); extras["rows"] = (r0, int(rng.integers(r0 + 1, h + 1)), int(rng.choice([1, 1, 2, 3])))
+    # an edit between two renders: instance transforms, visibility, a material swap
+    extras["edit"] = str(rng.choice(["transforms", "visibility", "material"])) if rng.uniform() < 0.2 else None
+    extras["edit_seed"] = int(rng.integers(1 << 30))
+    return s, rs, w, h, extras
+
+
+def apply_edit(desc, kind, edit_seed):
+    """The scene of `random_case` after its edit (a new SceneDesc description of the same meshes; what the incremental update must equal)."""
+    rng = np.random.default_rng(edit_seed)
+    k = int(rng.integers(len(desc.meshes)))
+    m = desc.meshes[k]
+    if kind == "transforms":
+        m.instance_transforms = np.stack([_transform(rng, spread=3.0, scale=(0.5, 1.2)) for _ in range(len(m.instance_transforms))])
+    elif kind == "visibility":
+        m.visible = not m.visible
+    else:
+        m.material = int(rng.integers(len(desc.materials)))
+    return k

@@ -893,13 +893,16 @@ def test_deep_trees_parity(gi, orc, monkeypatch, n, ratio, spill8):
     assert hit.mean() > 0.5 and np.array_equal(tuv[hit].view(np.uint32), rtuv[hit].view(np.uint32))
 
 
-@pytest.mark.parametrize("variant", ["openpbr+dome", "ups", "dome-hidden"])
+@pytest.mark.parametrize("variant", ["openpbr+dome", "ups", "dome-hidden", "diffuse"])
 def test_textured_scene_parity(gi, orc, variant):
     """Texture runtime (mdl_interface.glsl:8-38, 127-145, 238-256) + dome light (rp_main.miss:38-86) through the C ABI:
     base-colour / roughness / metallic / emission / normal maps with all four wrap modes, scale and bias, equirectangular
-    dome with rotation and emission multiplier -- bit-identical to the oracle, colour and Albedo / Normal AOVs."""
-    from gatling_amd.scene import MAT_OPEN_PBR, MAT_USD_PREVIEW_SURFACE
+    dome with rotation and emission multiplier -- bit-identical to the oracle, colour and Albedo / Normal AOVs.  "diffuse": both materials of the diffuse-only class,
+    whose base colour follows its texture too (the defect the differential campaign of round 6 found: tests/fuzz_parity.py, profiles/r06t_fuzz_parity_first_campaign.log)."""
+    from gatling_amd.scene import MAT_DIFFUSE, MAT_OPEN_PBR, MAT_USD_PREVIEW_SURFACE
     desc = textured_scene(dome=variant != "ups", klass_sphere=MAT_USD_PREVIEW_SURFACE if variant == "ups" else MAT_OPEN_PBR)
+    if variant == "diffuse":
+        for m in desc.materials: m.klass = MAT_DIFFUSE
     rs = RenderSettings(spp=4, max_bounces=6, next_event_estimation=True, dome_light_camera_visible=variant != "dome-hidden")
     render_both(gi, orc, desc, rs, 96, 54)
     sc = gi.Scene(desc)
@@ -1148,6 +1151,35 @@ def test_scene_data_int_primvars_and_named_ubo_values(gi, orc):
     # nearest, not blended: a vertex-interpolated 0/1 integer colour only ever yields the corner colours at the primary hit
     alb = orc.render_aovs(desc, RenderSettings(spp=1, max_bounces=1, jittered_sampling=False), 96, 54, ["albedo"])["albedo"]
     assert np.isfinite(alb).all()
+
+
+def test_colour_inputs_reading_narrow_primvars(gi, orc):
+    """A three-component input bound to a one- or two-component primvar: the reference's float3 lookup applies the primvar's own stride and reads the next two
+    floats of the packed buffer (mdl_interface.glsl:343-349) -- for the last entry whatever follows the array.  Here, on both sides, what lies past an array is zero
+    (gi_build.cpp pads it): a constant float makes the colour (x, 0, 0), a vertex-interpolated float2 blends (x, y, next x).  Found by the differential campaign of
+    round 6 (tests/fuzz_parity.py, profiles/r06w_fuzz_parity_extended_first_run.log): the packed neighbour showed through."""
+    from gatling_amd.scene import (INTERP_CONSTANT, INTERP_INSTANCE, INTERP_VERTEX, PRIMVAR_FLOAT, PRIMVAR_VEC2, PRIMVAR_VEC3, Primvar, TEX_BASE_COLOR, TEX_EMISSION,
+                                   TEX_ROUGHNESS)
+    rng = np.random.default_rng(71)
+    desc = sphere_grid(grid=3, subdivisions=1, material_count=3)
+    desc.materials[0].primvar_inputs = {TEX_BASE_COLOR: "narrow", TEX_ROUGHNESS: "rough"}
+    desc.materials[1].primvar_inputs = {TEX_EMISSION: "narrow", TEX_BASE_COLOR: "pair"}
+    desc.materials[2].primvar_inputs = {TEX_BASE_COLOR: "perInstance"}
+    for m in desc.meshes:
+        nv, ni = len(m.vertices), len(m.instance_transforms)
+        m.primvars = [Primvar("narrow", PRIMVAR_FLOAT, INTERP_CONSTANT, np.float32([0.6])),              # packed first: the next array is its neighbour
+                      Primvar("pair", PRIMVAR_VEC2, INTERP_VERTEX, rng.uniform(0.1, 0.9, (nv, 2))),
+                      Primvar("rough", PRIMVAR_VEC3, INTERP_VERTEX, rng.uniform(0.2, 0.8, (nv, 3)))]
+        m.instancer_primvars = [Primvar("perInstance", PRIMVAR_FLOAT, INTERP_INSTANCE, rng.uniform(0.2, 0.9, ni))]
+    for nee in (False, True):
+        render_both(gi, orc, desc, RenderSettings(spp=4, max_bounces=4, next_event_estimation=nee), 96, 54)
+    alb = orc.render_aovs(desc, RenderSettings(spp=1, max_bounces=1, jittered_sampling=False), 96, 54, ["albedo"])["albedo"]
+    sc = gi.Scene(desc)
+    try:
+        got = sc.render_aovs(RenderSettings(spp=1, max_bounces=1, jittered_sampling=False), 96, 54, ["albedo"], with_color=False)["albedo"]
+    finally:
+        sc.close()
+    assert np.array_equal(got[..., :3], alb.reshape(got.shape)[..., :3])
 
 
 def test_everything_at_once_parity(gi, orc):
