@@ -42,7 +42,7 @@ def run_case(gi, orc, seed, threads=8):
     rows = ex.get("rows")
     info = {"seed": seed, "tris": desc.triangle_count(), "w": w, "h": h, "spp": rs.spp, "bounces": rs.max_bounces, "nee": rs.next_event_estimation,
             "media": rs.medium_stack_size, "materials": len(desc.materials), "big": ex["big"], "aovs": ex["aovs"], "second": ex["second_call"],
-            "rows": rows, "edit": ex.get("edit"), "options": ex.get("options") or "-"}
+            "rows": rows, "edit": ex.get("edit"), "hostile": ex.get("hostile", False), "options": ex.get("options") or "-"}
     if rows: r0, r1, stride = rows
     else: r0, r1, stride = 0, h, 1
     row_list = list(range(r0, r1, stride))
@@ -82,6 +82,9 @@ def run_case(gi, orc, seed, threads=8):
         before, _, _, _, _ = random_case(seed)
     else:
         before = desc
+    if ex.get("hostile"):   # the oracle renders the documented reading of hostile geometry, written with ordinary triangles
+        from test_hostile_inputs import sanitised
+        before = sanitised(before); desc = sanitised(desc)
     okw = {"threads": threads, "row_list": row_list} if rows else {"threads": threads}
     ref, cnt = orc.render(before, rs, w, h, **okw)
     bad = differing(img, ref)
@@ -118,8 +121,14 @@ def _differs(gi, orc, desc, rs, w, h, threads):
         return False
     finally:
         sc.close()
+    if _HOSTILE[0]:
+        from test_hostile_inputs import sanitised
+        desc = sanitised(desc)
     ref, cnt = orc.render(desc, rs, w, h, threads=threads)
     return differing(img, ref) != 0 or (st["segments"], st["shadowRays"]) != (cnt["segments"], cnt["shadow_rays"])
+
+
+_HOSTILE = [False]   # reduce_case: the case under reduction has hostile geometry (the oracle renders its sanitised form)
 
 
 def reduce_case(gi, orc, seed, threads=8):
@@ -130,7 +139,8 @@ def reduce_case(gi, orc, seed, threads=8):
     from gatling_amd.scene import MaterialDesc, MAT_OPEN_PBR
     desc, rs, w, h, ex = random_case(seed)
     os.environ["GATLING_OPTIONS"] = ex.get("options") or ""
-    print(f"== seed {seed}: options {ex.get('options') or '-'} rows {ex.get('rows')} edit {ex.get('edit')}")
+    _HOSTILE[0] = bool(ex.get("hostile"))
+    print(f"== seed {seed}: hostile {ex.get('hostile')} options {ex.get('options') or '-'} rows {ex.get('rows')} edit {ex.get('edit')}")
     if not _differs(gi, orc, desc, rs, w, h, threads):
         print(f"seed {seed}: the first colour call does not differ (second call / AOVs only)"); return
     def attempt(mut):
@@ -202,7 +212,14 @@ def reduce_case(gi, orc, seed, threads=8):
         print("mesh", m.name, "faces", len(m.faces), "material", m.material, "double_sided", m.double_sided, "left_handed", m.left_handed, "instances", len(m.instance_transforms),
               "transform", m.transform.reshape(-1).tolist())
         if len(m.faces) <= 2:
-            for f in m.faces: print("   face", [(m.vertices[i]["pos"].tolist(), m.vertices[i]["norm"].tolist()) for i in f])
+            for f in m.faces: print("   face", [(m.vertices[i]["pos"].tolist(), m.vertices[i]["norm"].tolist(), m.vertices[i]["tangent"].tolist(), float(m.vertices[i]["u"]),
+                                                 float(m.vertices[i]["v"]), float(m.vertices[i]["bitangentSign"])) for i in f])
+        if _HOSTILE[0]:
+            print("   instance transforms", np.asarray(m.instance_transforms).reshape(-1, 16).tolist())
+            v = m.vertices
+            badv = [i for i in range(len(v)) if not (np.isfinite(v["pos"][i]).all() and np.isfinite(v["norm"][i]).all() and np.isfinite(v["tangent"][i]).all()
+                                                   and np.isfinite(v["u"][i]) and np.isfinite(v["v"][i]) and np.isfinite(v["bitangentSign"][i]) and (np.abs(v["pos"][i]) <= 1e18).all())]
+            print("   hostile vertices", [(i, v[i].tolist()) for i in badv[:6]], "used by faces", [int(k) for k in range(len(m.faces)) if set(m.faces[k].tolist()) & set(badv)][:8])
         for attr in ("primvars", "instancer_primvars"):
             for pv in getattr(m, attr): print("  ", attr, pv.name, "type", pv.type, "interp", pv.interpolation, "n", len(np.asarray(pv.data).reshape(-1)), np.asarray(pv.data).reshape(-1)[:8])
     for mi in sorted({m.material for m in desc.meshes}):
@@ -215,7 +232,11 @@ def reduce_case(gi, orc, seed, threads=8):
         img = sc.render(rs, w, h); st = sc.stats()
     finally:
         sc.close()
-    ref, cnt = orc.render(desc, rs, w, h, threads=threads)
+    if _HOSTILE[0]:
+        from test_hostile_inputs import sanitised
+        ref, cnt = orc.render(sanitised(desc), rs, w, h, threads=threads)
+    else:
+        ref, cnt = orc.render(desc, rs, w, h, threads=threads)
     ne = (img.view(np.uint32) != ref.view(np.uint32)).any(axis=-1)
     ys, xs = np.nonzero(ne)
     print("differing pixels", int(ne.sum()), "counts", (st["segments"], st["shadowRays"]), (cnt["segments"], cnt["shadow_rays"]))

@@ -260,6 +260,28 @@ def random_case(seed: int):
     extras["rows"] = None
     if h >= 4 and rng.uniform() < 0.2:
         r0 = int(rng.integers(0, h - 1)); extras["rows"] = (r0, int(rng.integers(r0 + 1, h + 1)), int(rng.choice([1, 1, 2, 3])))
+    # hostile geometry (include/gi_c.h "Hostile input"): non-finite / out-of-range positions make their triangles inactive, unusable instance transforms their
+    # instances; non-finite shading attributes take stand-ins.  The oracle renders tests/test_hostile_inputs.py sanitised() of the same description.
+    extras["hostile"] = False
+    if rng.uniform() < 0.1:
+        extras["hostile"] = True
+        for m in s.meshes:
+            if rng.uniform() < 0.6:
+                v = m.vertices.copy()
+                for _ in range(int(rng.integers(1, 4))):
+                    field, k = str(rng.choice(["pos", "pos", "norm", "tangent", "u", "bitangentSign"])), int(rng.integers(len(v)))
+                    bad = np.float32(rng.choice([np.nan, np.inf, -np.inf, 3.0e38]))
+                    if field in ("u", "bitangentSign"): v[field][k] = bad if np.isinf(bad) or np.isnan(bad) else np.float32(np.nan)
+                    elif field == "pos": v[field][k, int(rng.integers(3))] = bad
+                    else: v[field][k, int(rng.integers(3))] = np.float32(np.nan)
+                m.vertices = v
+            if rng.uniform() < 0.25:
+                it = np.array(m.instance_transforms, np.float32).copy(); k = int(rng.integers(len(it)))
+                kind = rng.uniform()
+                if kind < 0.4: it[k, int(rng.integers(3)), int(rng.integers(3))] = np.nan
+                elif kind < 0.7: it[k, :3, :3] = 0.0                       # singular
+                else: it[k, 2, :3] = it[k, 1, :3]                          # two equal axes: singular
+                m.instance_transforms = it
     # an edit between two renders: instance transforms, visibility, a material swap
     extras["edit"] = str(rng.choice(["transforms", "visibility", "material"])) if rng.uniform() < 0.2 else None
     extras["edit_seed"] = int(rng.integers(1 << 30))

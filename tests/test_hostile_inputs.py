@@ -108,6 +108,27 @@ def _usable(x):
         return np.abs(x) <= np.float32(1e18)      # False for NaN
 
 
+def _usable_instance(prim, inst) -> bool:
+    """include/gi_c.h "Hostile input": an instance is usable when every entry of its object-to-world affine -- composed in fp32, four products summed left to right
+    (gi_build.cpp composeTransform) -- is finite and the inverse of its 3 x 3 part -- adjugate over determinant in double, rounded to fp32 (invert3x3) -- is finite
+    too.  (A matrix that is singular on paper usually is NOT singular after the fp32 composition: its huge inverse is finite and the instance renders, flat.)"""
+    with np.errstate(all="ignore"):
+        o2w = np.zeros((3, 4), np.float32)
+        for c in range(3):
+            for r in range(4):
+                acc = np.float32(prim[r, 0] * inst[0, c])
+                for k in (1, 2, 3): acc = np.float32(acc + np.float32(prim[r, k] * inst[k, c]))
+                o2w[c, r] = acc
+        if not np.isfinite(o2w).all(): return False
+        m = o2w[:, :3].astype(np.float64)
+        c00 = m[1, 1] * m[2, 2] - m[1, 2] * m[2, 1]; c01 = m[1, 2] * m[2, 0] - m[1, 0] * m[2, 2]; c02 = m[1, 0] * m[2, 1] - m[1, 1] * m[2, 0]
+        det = m[0, 0] * c00 + m[0, 1] * c01 + m[0, 2] * c02
+        inv_det = np.float64(1.0) / det
+        adj = [c00, m[0, 2] * m[2, 1] - m[0, 1] * m[2, 2], m[0, 1] * m[1, 2] - m[0, 2] * m[1, 1], c01, m[0, 0] * m[2, 2] - m[0, 2] * m[2, 0],
+               m[0, 2] * m[1, 0] - m[0, 0] * m[1, 2], c02, m[0, 1] * m[2, 0] - m[0, 0] * m[2, 1], m[0, 0] * m[1, 1] - m[0, 1] * m[1, 0]]
+        return bool(np.isfinite(np.array([a * inv_det for a in adj]).astype(np.float32)).all())
+
+
 def sanitised(desc: SceneDesc) -> SceneDesc:
     """The scene the library renders, written with ordinary geometry: faces that use an unusable vertex become zero-area faces on a usable vertex of their mesh
     (same face count and order: ids do not shift), unusable positions are moved onto that vertex, unusable instances get the all-zero transform (every triangle
@@ -132,11 +153,7 @@ def sanitised(desc: SceneDesc) -> SceneDesc:
         m.vertices, m.faces = v, f
         it = np.array(m.instance_transforms, np.float32).reshape(-1, 4, 4).copy()
         for i in range(len(it)):
-            with np.errstate(all="ignore"):
-                o2w = np.asarray(m.transform, np.float64) @ it[i].astype(np.float64)
-                det = np.linalg.det(o2w[:3, :3]) if np.isfinite(o2w[:3, :3]).all() else np.nan
-                usable = np.isfinite(o2w[:, :3]).all() and np.isfinite(det) and det != 0.0
-            if not usable:
+            if not _usable_instance(np.asarray(m.transform, np.float32).reshape(4, 4), it[i]):
                 it[i] = 0.0; it[i, 3, 3] = 1.0
         if not np.isfinite(np.asarray(m.transform)).all():   # (every instance of such a mesh was unusable: NaN times anything)
             m.transform = np.eye(4, dtype=np.float32)
