@@ -38,6 +38,10 @@ static int giCTraceRaysImpl(GiCScene* s, uint32_t count, const float* origins, c
       hipMemcpyAsync(s->qA[Q_TRACE_A].ptr, qa.data(), qn * sizeof(F4), hipMemcpyHostToDevice, st) != hipSuccess ||
       hipMemcpyAsync(s->qB[Q_TRACE_A].ptr, qb.data(), qn * sizeof(F4), hipMemcpyHostToDevice, st) != hipSuccess ||
       hipMemcpyAsync(s->dCounters.ptr, &c, sizeof(c), hipMemcpyHostToDevice, st) != hipSuccess) { setError("giCTraceRays: upload failed"); return -1; }
+  // Cut-out materials: the any-hit test of a closest-hit walk draws from the path's random state, which it reads from the ray's Slot -- here slot i of a pool no
+  // path has written (or that an earlier render left behind).  The rays of this entry point carry the state 0, like the oracle's (found by tests/fuzz_parity.py:
+  // a quarter of the random scenes with cut-outs answered giCTraceRays with other triangles than the oracle, and not the same ones twice).
+  if (hipMemsetAsync(s->slots.ptr, 0, (size_t)count * sizeof(Slot), st) != hipSuccess) { setError("giCTraceRays: clearing the slots failed"); return -1; }
   PathState ps{s->slots.ptr, nullptr, 0u, nullptr, 0u, nullptr};
   // (no TRACE_FRESH entries: the uniforms are not read)
   launchTrace(st, blocks, false, false, makeView(s), ps, makeQueueSet(s), s->dCounters.ptr, Q_TRACE_A, Q_REGEN_B, traceDynRefill(s), blocks, FrameUniforms{},
@@ -50,11 +54,15 @@ static int giCTraceRaysImpl(GiCScene* s, uint32_t count, const float* origins, c
   for (uint32_t i = 0; i < count; i++) { uint32_t m = 0xffffffffu; memcpy(&hit[i].w, &m, 4); }
   // results stay in the ray records (a = t, u, v, triangle | class << 28); the class queues hold their indices
   std::vector<uint32_t> hitIdx(qn);
-  if (hipMemcpy(qa.data(), s->qA[Q_TRACE_A].ptr, qn * sizeof(F4), hipMemcpyDeviceToHost) != hipSuccess) { setError("giCTraceRays: readback failed"); return -1;
-      }
+  if (hipMemcpy(qa.data(), s->qA[Q_TRACE_A].ptr, qn * sizeof(F4), hipMemcpyDeviceToHost) != hipSuccess) {
+    setError("giCTraceRays: readback failed");
+    return -1;
+  }
   for (uint32_t klass = 0; klass < MAT_CLASS_COUNT; klass++) {
-    if (hipMemcpy(hitIdx.data(), s->qSlot[Q_HIT + klass].ptr, qn * 4, hipMemcpyDeviceToHost) != hipSuccess) { setError("giCTraceRays: readback failed");
-        return -1; }
+    if (hipMemcpy(hitIdx.data(), s->qSlot[Q_HIT + klass].ptr, qn * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+      setError("giCTraceRays: readback failed");
+      return -1;
+    }
     for (uint32_t k = 0; k < NSHARD; k++)
       for (uint32_t j = 0; j < c.count[Q_HIT + klass][k].v; j++) {
         const uint32_t ri = hitIdx[(size_t)k * s->queueCap + j] & 0x3fffffffu;

@@ -471,7 +471,8 @@ int giCGetRenderStats(const GiCScene* scene, GiCRenderStats* out);
 #define GI_C_SCENE_OPTION_DEVICES 8
 int giCSetSceneOption(GiCScene* scene, int32_t option, int32_t value);
 /* [ext] closest hit of one ray through the device traversal kernel (parity tests of the BVH8 path).
- * Returns 1 on hit (t,u,v, instance, prim written), 0 on miss, <0 on error. */
+ * Returns 1 on hit (t,u,v, instance, prim written), 0 on miss, <0 on error.  Candidates on cut-out materials pass the any-hit test of the render
+ * (rp_main.ahit:51-60) with the random state 0: the answer is a function of the ray and the scene alone. */
 int giCTraceRays(GiCScene* scene, uint32_t count, const float* origins /*3*count*/, const float* dirs /*3*count*/,
                  float tMin, float tMax, float* outTUV /*3*count*/, int32_t* outInstPrim /*2*count, -1 on miss*/);
 

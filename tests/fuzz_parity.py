@@ -42,19 +42,28 @@ def run_case(gi, orc, seed, threads=8):
     rows = ex.get("rows")
     info = {"seed": seed, "tris": desc.triangle_count(), "w": w, "h": h, "spp": rs.spp, "bounces": rs.max_bounces, "nee": rs.next_event_estimation,
             "media": rs.medium_stack_size, "materials": len(desc.materials), "big": ex["big"], "aovs": ex["aovs"], "second": ex["second_call"],
-            "rows": rows, "edit": ex.get("edit"), "hostile": ex.get("hostile", False), "options": ex.get("options") or "-"}
+            "rows": rows, "edit": ex.get("edit"), "hostile": ex.get("hostile", False), "mtlx": len(ex.get("mtlx") or {}), "rays": ex.get("trace_rays", 0), "options": ex.get("options") or "-"}
     if rows: r0, r1, stride = rows
     else: r0, r1, stride = 0, h, 1
     row_list = list(range(r0, r1, stride))
     t0 = time.perf_counter()
     os.environ["GATLING_OPTIONS"] = ex.get("options") or ""
     try:
+        docs = None
+        if ex.get("mtlx"):
+            from gatling_amd.mtlx_writer import material_to_mtlx
+            docs = {mi: material_to_mtlx(desc.materials[mi], form) for mi, form in ex["mtlx"].items()}
         try:
-            sc = gi.Scene(desc)
+            sc = gi.Scene(desc, mtlx_materials=docs)
         except Exception as e:  # the host refused the scene: the oracle has no say
             return dict(info, status="refused", detail=str(e)[:200])
         try:
             try:
+                rays = None
+                if ex.get("trace_rays"):   # closest hits of a batch of rays (giCTraceRays), before anything was rendered
+                    rr = np.random.default_rng(ex["trace_seed"]); nr = ex["trace_rays"]
+                    ro = rr.uniform(-4, 4, (nr, 3)).astype(np.float32); rd = rr.normal(size=(nr, 3)); rd = (rd / np.linalg.norm(rd, axis=1, keepdims=True)).astype(np.float32)
+                    rays = (ro, rd, sc.trace_rays(ro, rd))
                 kw = {"rows": (r0, r1), "row_stride": stride}
                 aov = sc.render_aovs(rs, w, h, AOV_NAMES, AOV_CLEAR, **kw) if ex["aovs"] else None   # (the colour AOV is bound in the same call)
                 img = aov["color"] if aov is not None else sc.render(rs, w, h, **kw)
@@ -101,6 +110,12 @@ def run_case(gi, orc, seed, threads=8):
             full = np.asarray(refa[name]); full = full.reshape((h, w, 4) if full.size == h * w * 4 else (h, w))
             bad = differing(np.asarray(aov[name]), full[r0:r1:stride])
             if bad: problems.append(f"aov {name}: {bad}")
+    if rays is not None:
+        ro, rd, (tuv, ip) = rays
+        rtuv, rip = orc.trace_rays(before, ro, rd)
+        hit = rip[:, 0] >= 0
+        if not np.array_equal(ip, rip): problems.append(f"trace_rays: {int((ip != rip).any(axis=1).sum())} of {len(ip)} hits name another triangle")
+        elif not np.array_equal(tuv[hit].view(np.uint32), rtuv[hit].view(np.uint32)): problems.append("trace_rays: t / u / v differ")
     if img3 is not None:
         ref3, _ = orc.render(desc, dataclasses.replace(rs, progressive_accumulation=False), w, h, **okw)
         bad = differing(img3, ref3)
@@ -244,6 +259,44 @@ def reduce_case(gi, orc, seed, threads=8):
         print("  pixel", x, y, "hip", img[y, x].tolist(), "oracle", ref[y, x].tolist())
 
 
+def bsdf_case(gi, orc, seed, n=2048):
+    """One random material (tests/fuzz_scenes.py _material, no bindings) on n random shading frames, view / light directions and random numbers -- grazing and
+    below-horizon directions, geometric normals off the shading normal, random numbers at 0 and just below 1, both facings -- through giCDebugEvalBsdf and through
+    the oracle's entry points: the 15 outputs per item (sampled direction, weight, pdf, event; evaluated diffuse / glossy / pdf) bit for bit."""
+    from fuzz_scenes import _material
+    rng = np.random.default_rng([0xb5df, seed])
+    mat = _material(rng, 0, 0)
+    mat.primvar_inputs = {}
+    nrm = rng.normal(size=(n, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    t = np.cross(nrm, rng.normal(size=(n, 3))); t /= np.linalg.norm(t, axis=1, keepdims=True)
+    b = np.cross(nrm, t)
+
+    def direction(kind):
+        v = rng.normal(size=(n, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+        z = np.abs(v[:, 2])
+        if kind == "grazing": z = z * 10.0 ** rng.uniform(-6, 0, n)
+        elif kind == "any": z = v[:, 2]
+        v[:, 2] = z; v /= np.linalg.norm(v, axis=1, keepdims=True)
+        return v[:, :1] * t + v[:, 1:2] * b + v[:, 2:3] * nrm
+    k1 = np.where(rng.uniform(size=(n, 1)) < 0.3, direction("grazing"), direction("up"))
+    k2 = np.where(rng.uniform(size=(n, 1)) < 0.3, direction("grazing"), np.where(rng.uniform(size=(n, 1)) < 0.3, direction("any"), direction("up")))
+    gn = nrm + rng.normal(scale=0.3, size=(n, 3)) * (rng.uniform(size=(n, 1)) < 0.5); gn /= np.linalg.norm(gn, axis=1, keepdims=True)
+    xi = rng.uniform(size=(n, 4))
+    edge = rng.uniform(size=(n, 3))
+    xi[:, :3] = np.where(edge < 0.03, 0.0, np.where(edge < 0.06, np.float32(1.0) - np.float32(2.0 ** -24), xi[:, :3]))
+    xi[:, 3] = rng.uniform(size=n) < 0.3   # back-facing items
+    items = np.concatenate([nrm, t, b, gn, k1, k2, xi], axis=1).astype(np.float32)
+    got = gi.bsdf_debug(mat, items)
+    want = orc.bsdf_debug(mat, items)
+    ne = (got.view(np.uint32) != want.view(np.uint32)) & ~(np.isnan(got) & np.isnan(want))
+    rows = np.nonzero(ne.any(axis=1))[0]
+    detail = ""
+    if len(rows):
+        r = int(rows[0])
+        detail = f"{len(rows)} of {n} items; first: item {r} columns {np.nonzero(ne[r])[0].tolist()} hip {got[r].tolist()} oracle {want[r].tolist()} input {items[r].tolist()} klass {mat.klass} params {[float(x) for x in mat.params]}"
+    return {"seed": seed, "klass": mat.klass, "finite": bool(np.isfinite(got).all()), "status": "differs" if len(rows) else "same", "detail": detail}
+
+
 def RenderSettingsDefaults():
     return {"next_event_estimation": False, "medium_stack_size": 0, "depth_of_field": False, "clipping_planes": False, "filter_importance_sampling": False,
             "jittered_sampling": False, "light_intensity_multiplier": 1.0, "max_sample_value": 1.0e6, "rr_bounce_offset": 100, "meters_per_scene_unit": 1.0,
@@ -256,6 +309,7 @@ def main():
     ap.add_argument("--threads", type=int, default=min(64, os.cpu_count() or 8))
     ap.add_argument("--log", default=None)
     ap.add_argument("--reduce", action="store_true", help="reduce each differing case of the list to what still differs")
+    ap.add_argument("--bsdf", action="store_true", help="the seeds are BSDF cases (one random material on 2 048 random frames / directions each) instead of renders")
     a = ap.parse_args()
     seeds = list(range(*map(int, a.seeds.split(":")))) if ":" in a.seeds else [int(x) for x in a.seeds.split(",")]
     from gatling_amd import capi as gi
@@ -271,7 +325,7 @@ def main():
     t0 = time.perf_counter()
     for seed in seeds:
         try:
-            r = run_case(gi, orc, seed, a.threads)
+            r = bsdf_case(gi, orc, seed) if a.bsdf else run_case(gi, orc, seed, a.threads)
         except Exception:
             r = {"seed": seed, "status": "error", "detail": traceback.format_exc(limit=3).replace("\n", " | ")[-400:]}
         tally[r["status"]] = tally.get(r["status"], 0) + 1

@@ -285,6 +285,15 @@ def random_case(seed: int):
     # an edit between two renders: instance transforms, visibility, a material swap
     extras["edit"] = str(rng.choice(["transforms", "visibility", "material"])) if rng.uniform() < 0.2 else None
     extras["edit_seed"] = int(rng.integers(1 << 30))
+    # (drawn last, so that earlier seeds keep their scenes) materials handed over as MaterialX documents through the gtl shim's reader, the way hdGatling does;
+    # a batch of rays through giCTraceRays
+    extras["mtlx"] = {}
+    if rng.uniform() < 0.25:
+        for mi, m in enumerate(s.materials):
+            if m.klass != MAT_DIFFUSE and not m.textures and not m.primvar_inputs and rng.uniform() < 0.6:
+                extras["mtlx"][mi] = str(rng.choice(["direct", "nodegraph"]))
+    extras["trace_rays"] = int(rng.integers(1, 3000)) if rng.uniform() < 0.15 else 0
+    extras["trace_seed"] = int(rng.integers(1 << 30))
     return s, rs, w, h, extras
 
 

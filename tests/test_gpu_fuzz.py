@@ -5,7 +5,7 @@ import os
 
 import pytest
 
-from fuzz_parity import run_case
+from fuzz_parity import bsdf_case, run_case
 
 _FIRST, _LAST = (int(x) for x in os.environ.get("GATLING_FUZZ_SEEDS", "0:96").split(":"))
 
@@ -20,3 +20,11 @@ def test_random_renders_match_the_oracle(gi, orc, block):
             failures.append(f"seed {seed}: {r['status']}: {r['detail']}")
     assert not failures, "\n".join(failures)
 
+
+
+@pytest.mark.gpu
+def test_random_materials_on_random_frames_match_the_oracle(gi, orc):
+    """The BSDF half of the campaign (`tests/fuzz_parity.py --bsdf`): 48 random materials x 2 048 frames / directions / random numbers each, grazing and below-horizon
+    directions and random numbers at 0 and 1 - 2^-24 included: giCDebugEvalBsdf == the oracle's entry points, all 15 outputs, bit for bit."""
+    failures = [f"seed {r['seed']}: {r['detail'][:600]}" for r in (bsdf_case(gi, orc, seed) for seed in range(48)) if r["status"] != "same"]
+    assert not failures, "\n".join(failures)
