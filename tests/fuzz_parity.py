@@ -35,6 +35,42 @@ def differing(a, b):
     return int(ne.any(axis=-1).sum()) if a.ndim == 3 else int(ne.sum())
 
 
+def apply_to_scene(gi, sc, desc, op):
+    """The edit of tests/fuzz_scenes.py apply_edit through the C ABI, on the live scene."""
+    import ctypes as C
+    L, kind = sc.L, op["op"]
+    fp = lambda v: (C.c_float * len(v))(*[float(x) for x in v])  # noqa: E731
+    if "mesh" in op:
+        k = op["mesh"]
+        if kind == "mesh_remove":
+            L.giCDestroyMesh(sc.meshes.pop(k)); return
+        m = desc.meshes[k]
+        if kind == "transforms": sc.set_mesh_instance_transforms(k, m.instance_transforms)
+        elif kind == "visibility": L.giCSetMeshVisibility(sc.meshes[k], int(m.visible))
+        elif kind == "material": L.giCSetMeshMaterial(sc.meshes[k], sc.materials[m.material])
+        else: sc.set_mesh_transform(k, m.transform)
+        return
+    name, i = op["light"]
+    short = name.split("_")[0]
+    if kind == "light_add":
+        l = desc.sphere_lights[i]; h = L.giCCreateSphereLight(sc.handle)
+        L.giCSetSphereLightPosition(h, fp(l.pos)); L.giCSetSphereLightBaseEmission(h, fp(l.base_emission))
+        L.giCSetSphereLightRadius(h, *[float(x) for x in l.radius]); L.giCSetSphereLightDiffuseSpecular(h, l.diffuse, l.specular)
+        # (the wrapper keeps its lights in creation order: spheres first)
+        at = sum(1 for kk, _ in sc.lights if kk == "sphere")
+        sc.lights.insert(at, ("sphere", h)); return
+    idx = [j for j, (kk, _) in enumerate(sc.lights) if kk == short][i]
+    h = sc.lights[idx][1]
+    if kind == "light_remove":
+        {"sphere": L.giCDestroySphereLight, "distant": L.giCDestroyDistantLight, "rect": L.giCDestroyRectLight, "disk": L.giCDestroyDiskLight}[short](sc.handle, h)
+        sc.lights.pop(idx); return
+    l = getattr(desc, name)[i]
+    if short == "sphere": L.giCSetSphereLightPosition(h, fp(l.pos)); L.giCSetSphereLightBaseEmission(h, fp(l.base_emission))
+    elif short == "distant": L.giCSetDistantLightDirection(h, fp(l.direction)); L.giCSetDistantLightBaseEmission(h, fp(l.base_emission))
+    elif short == "rect": L.giCSetRectLightOrigin(h, fp(l.origin)); L.giCSetRectLightBaseEmission(h, fp(l.base_emission))
+    else: L.giCSetDiskLightOrigin(h, fp(l.origin)); L.giCSetDiskLightBaseEmission(h, fp(l.base_emission))
+
+
 def run_case(gi, orc, seed, threads=8):
     """{"seed", "status": "same" | "differs" | "refused" | "error", "detail", ...} of one case."""
     import dataclasses
@@ -71,11 +107,8 @@ def run_case(gi, orc, seed, threads=8):
                 img2 = sc.render(rs, w, h, **kw) if ex["second_call"] else None
                 img3 = None
                 if ex.get("edit"):
-                    k = apply_edit(desc, ex["edit"], ex["edit_seed"])   # (sc.desc IS desc: the oracle renders the edited description)
-                    m = desc.meshes[k]
-                    if ex["edit"] == "transforms": sc.set_mesh_instance_transforms(k, m.instance_transforms)
-                    elif ex["edit"] == "visibility": sc.L.giCSetMeshVisibility(sc.meshes[k], int(m.visible))
-                    else: sc.L.giCSetMeshMaterial(sc.meshes[k], sc.materials[m.material])
+                    op = apply_edit(desc, ex["edit"], ex["edit_seed"])   # (sc.desc IS desc: the oracle renders the edited description)
+                    apply_to_scene(gi, sc, desc, op)
                     rs3 = dataclasses.replace(rs, progressive_accumulation=False)
                     img3 = sc.render(rs3, w, h, **kw)
             except gi.GiError as e:

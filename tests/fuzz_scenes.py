@@ -283,7 +283,7 @@ def random_case(seed: int):
                 else: it[k, 2, :3] = it[k, 1, :3]                          # two equal axes: singular
                 m.instance_transforms = it
     # an edit between two renders: instance transforms, visibility, a material swap
-    extras["edit"] = str(rng.choice(["transforms", "visibility", "material"])) if rng.uniform() < 0.2 else None
+    extras["edit"] = str(rng.choice(["transforms", "visibility", "material", "mesh_transform", "mesh_remove", "light_move", "light_remove", "light_add"])) if rng.uniform() < 0.25 else None
     extras["edit_seed"] = int(rng.integers(1 << 30))
     # (drawn last, so that earlier seeds keep their scenes) materials handed over as MaterialX documents through the gtl shim's reader, the way hdGatling does;
     # a batch of rays through giCTraceRays
@@ -298,14 +298,36 @@ def random_case(seed: int):
 
 
 def apply_edit(desc, kind, edit_seed):
-    """The scene of `random_case` after its edit (a new SceneDesc description of the same meshes; what the incremental update must equal)."""
+    """Edits the description the way the case's edit changes the scene (what the library's incremental update must equal) and returns the operation for the driver:
+    {"op": ..., "mesh": index} or {"op": ..., "light": (list name, index)}."""
     rng = np.random.default_rng(edit_seed)
     k = int(rng.integers(len(desc.meshes)))
     m = desc.meshes[k]
+    lights = [(name, i) for name in ("sphere_lights", "distant_lights", "rect_lights", "disk_lights") for i in range(len(getattr(desc, name)))]
+    if kind in ("light_move", "light_remove") and not lights: kind = "light_add"
+    if kind == "mesh_remove" and len(desc.meshes) == 1: kind = "visibility"
     if kind == "transforms":
         m.instance_transforms = np.stack([_transform(rng, spread=3.0, scale=(0.5, 1.2)) for _ in range(len(m.instance_transforms))])
     elif kind == "visibility":
         m.visible = not m.visible
-    else:
+    elif kind == "material":
         m.material = int(rng.integers(len(desc.materials)))
-    return k
+    elif kind == "mesh_transform":
+        m.transform = _transform(rng)
+    elif kind == "mesh_remove":
+        desc.meshes.pop(k)
+    elif kind == "light_add":
+        desc.sphere_lights.append(SphereLight(pos=tuple(rng.uniform(-3, 3, 3)), base_emission=_color(rng, 0, 30), radius=tuple(rng.uniform(0.05, 0.6, 3))))
+        return {"op": kind, "light": ("sphere_lights", len(desc.sphere_lights) - 1)}
+    else:
+        name, i = lights[int(rng.integers(len(lights)))]
+        if kind == "light_remove":
+            getattr(desc, name).pop(i)
+        else:
+            l = getattr(desc, name)[i]
+            if name == "sphere_lights": l.pos = tuple(rng.uniform(-3, 3, 3))
+            elif name == "distant_lights": l.direction = tuple(rng.normal(size=3))
+            else: l.origin = tuple(rng.uniform(-3, 3, 3))
+            l.base_emission = _color(rng, 0, 20)
+        return {"op": kind, "light": (name, i)}
+    return {"op": kind, "mesh": k}
