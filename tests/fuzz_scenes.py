@@ -201,15 +201,17 @@ def random_case(seed: int):
         md = MeshDesc(name=f"/fuzz/mesh{k}", vertices=v, faces=f, material=int(rng.integers(len(s.materials))), id=int(rng.integers(0, 1000)),
                       double_sided=bool(rng.uniform() < 0.5), left_handed=bool(rng.uniform() < 0.12), visible=bool(rng.uniform() < 0.94), transform=_transform(rng))
         if rng.uniform() < 0.3:
-            ni = int(rng.integers(2, 5))
+            ni = int(rng.integers(2, 5)) if rng.uniform() < 0.85 else int(rng.integers(5, 60))
             md.instance_transforms = np.stack([_transform(rng, spread=3.0, scale=(0.5, 1.2)) for _ in range(ni)])
             if rng.uniform() < 0.5: md.instance_ids = rng.integers(0, 100, ni).astype(np.int32)
         if rng.uniform() < 0.3:
-            md.face_ids = rng.integers(0, 16, len(f)).astype(np.int32); md.max_face_id = 15
+            md.max_face_id = int(rng.choice([15, 255, 300, 70000]))   # (the face-id stride is 1, 2 or 4 bytes: Gi.cpp:878-885)
+            md.face_ids = rng.integers(0, md.max_face_id + 1, len(f)).astype(np.int32)
         if s.materials[md.material].primvar_inputs or rng.uniform() < 0.1:
             md.primvars, md.instancer_primvars = _primvars(rng, len(v), len(f), len(md.instance_transforms))
         s.meshes.append(md)
-    for _ in range(int(rng.integers(0, 3))):
+    many = rng.uniform() < 0.05   # a light list long enough that the pick of one light matters
+    for _ in range(int(rng.integers(0, 3)) if not many else int(rng.integers(10, 40))):
         s.sphere_lights.append(SphereLight(pos=tuple(rng.uniform(-3, 3, 3)), base_emission=_color(rng, 0, 30),
                                            radius=(0.0, 0.0, 0.0) if rng.uniform() < 0.1 else tuple(rng.uniform(0.05, 0.6, 3)),
                                            diffuse=float(rng.choice([1.0, rng.uniform(0, 2)])), specular=float(rng.choice([1.0, rng.uniform(0, 2)]))))
@@ -238,7 +240,7 @@ def random_case(seed: int):
                           f_stop=float(rng.uniform(0.5, 8.0)), focus_distance=float(rng.uniform(0.5, 1.5)) * dist, focal_length=float(rng.uniform(5.0, 80.0)),
                           clip_start=float(rng.uniform(0.01, 0.6)) * dist, clip_end=float(rng.uniform(0.9, 3.0)) * dist)
     rs = RenderSettings(
-        spp=int(rng.integers(1, 7)), max_bounces=int(rng.integers(0, 10)), rr_bounce_offset=int(rng.integers(0, 6)), rr_inv_min_term_prob=float(rng.uniform(0.5, 1.0)),
+        spp=int(rng.integers(1, 7)) if rng.uniform() < 0.9 else int(rng.integers(7, 20)), max_bounces=int(rng.integers(0, 10)) if rng.uniform() < 0.8 else int(rng.integers(10, 16)), rr_bounce_offset=int(rng.integers(0, 6)), rr_inv_min_term_prob=float(rng.uniform(0.5, 1.0)),
         max_sample_value=float(rng.choice([10.0, 1.0e6, 0.5])), filter_importance_sampling=bool(rng.uniform() < 0.7), depth_of_field=bool(rng.uniform() < 0.3),
         light_intensity_multiplier=float(rng.choice([1.0, 0.5, 3.0])), next_event_estimation=bool(rng.uniform() < 0.5), clipping_planes=bool(rng.uniform() < 0.25),
         medium_stack_size=int(rng.choice([0, 0, 0, 1, 2, 4])), frame=0.0, max_volume_walk_length=int(rng.integers(1, 9)), jittered_sampling=bool(rng.uniform() < 0.8),
@@ -321,8 +323,8 @@ def apply_edit(desc, kind, edit_seed):
         return {"op": kind, "light": ("sphere_lights", len(desc.sphere_lights) - 1)}
     else:
         name, i = lights[int(rng.integers(len(lights)))]
-        if kind == "light_remove":
-            getattr(desc, name).pop(i)
+        if kind == "light_remove":   # the reference's dense store fills the hole with the LAST element (DenseDataStore.cpp:45-68), and so does the library
+            lst = getattr(desc, name); lst[i] = lst[-1]; lst.pop()
         else:
             l = getattr(desc, name)[i]
             if name == "sphere_lights": l.pos = tuple(rng.uniform(-3, 3, 3))
