@@ -71,10 +71,12 @@ def apply_to_scene(gi, sc, desc, op):
     else: L.giCSetDiskLightOrigin(h, fp(l.origin)); L.giCSetDiskLightBaseEmission(h, fp(l.base_emission))
 
 
-def run_case(gi, orc, seed, threads=8):
-    """{"seed", "status": "same" | "differs" | "refused" | "error", "detail", ...} of one case."""
+def run_case(gi, orc, seed, threads=8, use_options=True):
+    """{"seed", "status": "same" | "differs" | "refused" | "error", "detail", ...} of one case.  `use_options` False: the case runs under the library's default
+    schedule ($GATLING_OPTIONS is process-wide: concurrent cases cannot each have their own)."""
     import dataclasses
     desc, rs, w, h, ex = random_case(seed)
+    if not use_options: ex["options"] = ""
     rows = ex.get("rows")
     info = {"seed": seed, "tris": desc.triangle_count(), "w": w, "h": h, "spp": rs.spp, "bounces": rs.max_bounces, "nee": rs.next_event_estimation,
             "media": rs.medium_stack_size, "materials": len(desc.materials), "big": ex["big"], "aovs": ex["aovs"], "second": ex["second_call"],
@@ -83,7 +85,7 @@ def run_case(gi, orc, seed, threads=8):
     else: r0, r1, stride = 0, h, 1
     row_list = list(range(r0, r1, stride))
     t0 = time.perf_counter()
-    os.environ["GATLING_OPTIONS"] = ex.get("options") or ""
+    if use_options: os.environ["GATLING_OPTIONS"] = ex.get("options") or ""
     try:
         docs = None
         if ex.get("mtlx"):
@@ -116,8 +118,17 @@ def run_case(gi, orc, seed, threads=8):
         finally:
             sc.close()
     finally:
-        os.environ["GATLING_OPTIONS"] = ""
+        if use_options: os.environ["GATLING_OPTIONS"] = ""
     info["gpu_s"] = round(time.perf_counter() - t0, 3)
+    with _ORACLE_LOCK:   # (the oracle is test infrastructure with state of its own: one case at a time, also under --concurrent)
+        return _compare(orc, seed, desc, rs, w, h, ex, info, threads, rows, row_list, r0, r1, stride, img, st, img2, img3, aov, rays)
+
+
+_ORACLE_LOCK = __import__("threading").Lock()
+
+
+def _compare(orc, seed, desc, rs, w, h, ex, info, threads, rows, row_list, r0, r1, stride, img, st, img2, img3, aov, rays):
+    import dataclasses
     t0 = time.perf_counter()
     problems = []
     if ex.get("edit"):   # the oracle sees the scene as it was before the edit first
@@ -342,6 +353,8 @@ def main():
     ap.add_argument("--threads", type=int, default=min(64, os.cpu_count() or 8))
     ap.add_argument("--log", default=None)
     ap.add_argument("--reduce", action="store_true", help="reduce each differing case of the list to what still differs")
+    ap.add_argument("--concurrent", type=int, default=1, help="this many host threads run cases at the same time, each on scenes of its own (the library serialises "
+                    "nothing but what shares state: include/gi_c.h); the oracle then runs single-threaded per case")
     ap.add_argument("--bsdf", action="store_true", help="the seeds are BSDF cases (one random material on 2 048 random frames / directions each) instead of renders")
     a = ap.parse_args()
     seeds = list(range(*map(int, a.seeds.split(":")))) if ":" in a.seeds else [int(x) for x in a.seeds.split(",")]
@@ -356,11 +369,19 @@ def main():
     log = open(a.log, "w") if a.log else None
     tally = {}
     t0 = time.perf_counter()
-    for seed in seeds:
+    def one(seed):
         try:
-            r = bsdf_case(gi, orc, seed) if a.bsdf else run_case(gi, orc, seed, a.threads)
+            if a.bsdf: return bsdf_case(gi, orc, seed)
+            return run_case(gi, orc, seed, a.threads if a.concurrent == 1 else 1, use_options=a.concurrent == 1)
         except Exception:
-            r = {"seed": seed, "status": "error", "detail": traceback.format_exc(limit=3).replace("\n", " | ")[-400:]}
+            return {"seed": seed, "status": "error", "detail": traceback.format_exc(limit=3).replace("\n", " | ")[-400:]}
+    if a.concurrent > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        os.environ["GATLING_OPTIONS"] = ""
+        results = ThreadPoolExecutor(max_workers=a.concurrent).map(one, seeds)
+    else:
+        results = (one(seed) for seed in seeds)
+    for r in results:
         tally[r["status"]] = tally.get(r["status"], 0) + 1
         line = " ".join(f"{k}={v}" for k, v in r.items())
         if r["status"] != "same" or log is None: print(line, flush=True)
