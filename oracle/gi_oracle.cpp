@@ -499,8 +499,8 @@ inline bool tri_test(const Prepared& P, const Tri& T, V3 o, V3 d, float tMin, fl
 
 // (nodes are handed out by an atomic counter from a vector sized up front, so the two halves of a large range can be built by different threads: the TREE is the
 // same whatever the thread timing -- splits depend on the range alone -- only node numbers differ, and nothing depends on those)
-static std::atomic<uint32_t> g_bvhNext{0};
-void build_bvh_rec(Prepared& P, uint32_t node, uint32_t begin, uint32_t end, const std::vector<V3>& lo, const std::vector<V3>& hi, int depth = 0)
+// (the counter belongs to ONE build: two scenes may be prepared at the same time -- tests/fuzz_parity.py --concurrent found it shared)
+void build_bvh_rec(Prepared& P, std::atomic<uint32_t>& next, uint32_t node, uint32_t begin, uint32_t end, const std::vector<V3>& lo, const std::vector<V3>& hi, int depth = 0)
 {
   BvhNode& n = P.bvh[node];
   for (int a = 0; a < 3; a++) { n.lo[a] = ORC_FLT_MAX; n.hi[a] = -ORC_FLT_MAX; }
@@ -520,16 +520,16 @@ void build_bvh_rec(Prepared& P, uint32_t node, uint32_t begin, uint32_t end, con
   auto key = [&](uint32_t t) { const float l[3] = {lo[t].x, lo[t].y, lo[t].z}, h[3] = {hi[t].x, hi[t].y, hi[t].z}; return l[axis] + h[axis]; };
   std::nth_element(P.bvhTris.begin() + begin, P.bvhTris.begin() + mid, P.bvhTris.begin() + end,
                    [&](uint32_t a, uint32_t b) { return key(a) < key(b); });
-  uint32_t left = g_bvhNext.fetch_add(2u);
+  uint32_t left = next.fetch_add(2u);
   P.bvh[node].left = left; P.bvh[node].count = 0;
   if (depth < 6 && end - begin > 200000u) { // a 10 M-triangle scene: 64 subtrees in parallel (the single-threaded build was most of the big-scene tests' time)
-    std::thread other([&, left, begin, mid, depth] { build_bvh_rec(P, left, begin, mid, lo, hi, depth + 1); });
-    build_bvh_rec(P, left + 1, mid, end, lo, hi, depth + 1);
+    std::thread other([&, left, begin, mid, depth] { build_bvh_rec(P, next, left, begin, mid, lo, hi, depth + 1); });
+    build_bvh_rec(P, next, left + 1, mid, end, lo, hi, depth + 1);
     other.join();
     return;
   }
-  build_bvh_rec(P, left, begin, mid, lo, hi, depth + 1);
-  build_bvh_rec(P, left + 1, mid, end, lo, hi, depth + 1);
+  build_bvh_rec(P, next, left, begin, mid, lo, hi, depth + 1);
+  build_bvh_rec(P, next, left + 1, mid, end, lo, hi, depth + 1);
 }
 
 void build_bvh(Prepared& P)
@@ -549,9 +549,9 @@ void build_bvh(Prepared& P)
   P.bvhTris.resize(n);
   for (size_t i = 0; i < n; i++) P.bvhTris[i] = (uint32_t)i;
   P.bvh.assign(2 * n + 2, BvhNode{}); // a binary tree over n leaves of >= 1 triangle has < 2 n nodes
-  g_bvhNext.store(1u);
-  build_bvh_rec(P, 0, 0, (uint32_t)n, lo, hi);
-  P.bvh.resize(g_bvhNext.load());
+  std::atomic<uint32_t> next{1u};
+  build_bvh_rec(P, next, 0, 0, (uint32_t)n, lo, hi);
+  P.bvh.resize(next.load());
 }
 
 inline bool box_test(const BvhNode& n, V3 o, V3 inv, float tMin, float tMax)
