@@ -21,7 +21,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from fuzz_scenes import apply_edit, random_case  # noqa: E402
 
 AOV_NAMES = ["normal", "barycentrics", "texcoords", "opacity", "tangents", "bitangents", "thinWalled", "objectId", "depth", "faceId", "instanceId", "doubleSided", "albedo"]
-AOV_CLEAR = {"normal": (0.5, 0.5, 0.5, 0.5), "objectId": -1, "faceId": -1, "instanceId": -1, "depth": 1.0, "albedo": (0.1, 0.2, 0.3, 0.0)}
+PATH_AOV_NAMES = ["nee", "bounces", "clockCycles"]
+AOV_CLEAR = {"nee": (0.25, 0.5, 0.75, 0.0), "normal": (0.5, 0.5, 0.5, 0.5), "objectId": -1, "faceId": -1, "instanceId": -1, "depth": 1.0, "albedo": (0.1, 0.2, 0.3, 0.0)}
 
 
 def differing(a, b):
@@ -103,7 +104,9 @@ def run_case(gi, orc, seed, threads=8, use_options=True):
                     ro = rr.uniform(-4, 4, (nr, 3)).astype(np.float32); rd = rr.normal(size=(nr, 3)); rd = (rd / np.linalg.norm(rd, axis=1, keepdims=True)).astype(np.float32)
                     rays = (ro, rd, sc.trace_rays(ro, rd))
                 kw = {"rows": (r0, r1), "row_stride": stride}
-                aov = sc.render_aovs(rs, w, h, AOV_NAMES, AOV_CLEAR, **kw) if ex["aovs"] else None   # (the colour AOV is bound in the same call)
+                # (the colour AOV is bound in the same call; whole-frame cases also bind the three AOVs that follow whole paths: NEE, Bounces, ClockCycles)
+                names = AOV_NAMES + (PATH_AOV_NAMES if not rows else [])
+                aov = sc.render_aovs(rs, w, h, names, AOV_CLEAR, **kw) if ex["aovs"] else None
                 img = aov["color"] if aov is not None else sc.render(rs, w, h, **kw)
                 st = sc.stats()
                 img2 = sc.render(rs, w, h, **kw) if ex["second_call"] else None
@@ -149,10 +152,13 @@ def _compare(orc, seed, desc, rs, w, h, ex, info, threads, rows, row_list, r0, r
         bad = differing(img2, ref2)
         if bad: problems.append(f"second call: {bad} pixels")
     if aov is not None:
-        refa = orc.render_aovs(before, rs, w, h, AOV_NAMES, AOV_CLEAR)
-        for name in AOV_NAMES:
+        names = AOV_NAMES + (PATH_AOV_NAMES if not rows else [])
+        refa = orc.render_aovs(before, rs, w, h, names, AOV_CLEAR)
+        for name in names:
             full = np.asarray(refa[name]); full = full.reshape((h, w, 4) if full.size == h * w * 4 else (h, w))
-            bad = differing(np.asarray(aov[name]), full[r0:r1:stride])
+            got = np.asarray(aov[name])
+            if name in ("nee", "bounces"): got, full = got[..., :3], full[..., :3]   # (the shader writes .xyz)
+            bad = differing(got, full[r0:r1:stride])
             if bad: problems.append(f"aov {name}: {bad}")
     if rays is not None:
         ro, rd, (tuv, ip) = rays
