@@ -81,7 +81,7 @@ def run_case(gi, orc, seed, threads=8, use_options=True):
     rows = ex.get("rows")
     info = {"seed": seed, "tris": desc.triangle_count(), "w": w, "h": h, "spp": rs.spp, "bounces": rs.max_bounces, "nee": rs.next_event_estimation,
             "media": rs.medium_stack_size, "materials": len(desc.materials), "big": ex["big"], "aovs": ex["aovs"], "second": ex["second_call"],
-            "rows": rows, "edit": ex.get("edit"), "hostile": ex.get("hostile", False), "mtlx": len(ex.get("mtlx") or {}), "rays": ex.get("trace_rays", 0), "options": ex.get("options") or "-"}
+            "rows": rows, "edit": ex.get("edit"), "hostile": ex.get("hostile", False), "mtlx": len(ex.get("mtlx") or {}), "rays": ex.get("trace_rays", 0), "scene_options": "/".join(f"{o}={v}" for o, v in ex.get("scene_options") or []) or "-", "options": ex.get("options") or "-"}
     if rows: r0, r1, stride = rows
     else: r0, r1, stride = 0, h, 1
     row_list = list(range(r0, r1, stride))
@@ -98,6 +98,7 @@ def run_case(gi, orc, seed, threads=8, use_options=True):
             return dict(info, status="refused", detail=str(e)[:200])
         try:
             try:
+                for opt, val in ex.get("scene_options") or []: sc.set_option(opt, val)
                 rays = None
                 if ex.get("trace_rays"):   # closest hits of a batch of rays (giCTraceRays), before anything was rendered
                     rr = np.random.default_rng(ex["trace_seed"]); nr = ex["trace_rays"]

@@ -294,6 +294,11 @@ def random_case(seed: int):
         for mi, m in enumerate(s.materials):
             if m.klass != MAT_DIFFUSE and not m.textures and not m.primvar_inputs and rng.uniform() < 0.6:
                 extras["mtlx"][mi] = str(rng.choice(["direct", "nodegraph"]))
+    # scene options of the C ABI (include/gi_c.h GI_C_SCENE_OPTION_*): the counting instantiations of the kernels, the stage timers, the schedules by option
+    extras["scene_options"] = []
+    if rng.uniform() < 0.25:
+        for opt, values in ((1, [1]), (2, [1, 4]), (5, [0, 16]), (6, [1]), (7, [0, 1, 2])):   # COUNT_TRAVERSAL, KERNEL_TIMERS, TRACE_DYNAMIC, TWO_LEVEL, FUSED_PATH
+            if rng.uniform() < 0.35: extras["scene_options"].append((opt, int(rng.choice(values))))
     extras["trace_rays"] = int(rng.integers(1, 3000)) if rng.uniform() < 0.15 else 0
     extras["trace_seed"] = int(rng.integers(1 << 30))
     return s, rs, w, h, extras
