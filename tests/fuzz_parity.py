@@ -78,6 +78,9 @@ def run_case(gi, orc, seed, threads=8, use_options=True):
     import dataclasses
     desc, rs, w, h, ex = random_case(seed)
     if not use_options: ex["options"] = ""
+    if _SCALE[0] > 1:   # --scale: the same case on an image `scale` times as wide and as high (more work than the path pool holds: batches, chunked sample buffers)
+        S = _SCALE[0]; w, h = w * S, h * S
+        if ex.get("rows"): ex["rows"] = (ex["rows"][0] * S, ex["rows"][1] * S, ex["rows"][2])
     rows = ex.get("rows")
     info = {"seed": seed, "tris": desc.triangle_count(), "w": w, "h": h, "spp": rs.spp, "bounces": rs.max_bounces, "nee": rs.next_event_estimation,
             "media": rs.medium_stack_size, "materials": len(desc.materials), "big": ex["big"], "aovs": ex["aovs"], "second": ex["second_call"],
@@ -129,6 +132,7 @@ def run_case(gi, orc, seed, threads=8, use_options=True):
 
 
 _ORACLE_LOCK = __import__("threading").Lock()
+_SCALE = [1]
 
 
 def _compare(orc, seed, desc, rs, w, h, ex, info, threads, rows, row_list, r0, r1, stride, img, st, img2, img3, aov, rays):
@@ -362,12 +366,14 @@ def main():
     ap.add_argument("--reduce", action="store_true", help="reduce each differing case of the list to what still differs")
     ap.add_argument("--concurrent", type=int, default=1, help="this many host threads run cases at the same time, each on scenes of its own (the library serialises "
                     "nothing but what shares state: include/gi_c.h); the oracle then runs single-threaded per case")
+    ap.add_argument("--scale", type=int, default=1, help="render every case `scale` times as wide and as high")
     ap.add_argument("--bsdf", action="store_true", help="the seeds are BSDF cases (one random material on 2 048 random frames / directions each) instead of renders")
     a = ap.parse_args()
     seeds = list(range(*map(int, a.seeds.split(":")))) if ":" in a.seeds else [int(x) for x in a.seeds.split(",")]
     from gatling_amd import capi as gi
     from oracle import orc
     orc.build(); orc.lib(); gi.initialize(0)
+    _SCALE[0] = max(1, a.scale)
     if a.reduce:
         for seed in seeds:
             try: reduce_case(gi, orc, seed, a.threads)
