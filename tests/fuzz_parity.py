@@ -1,9 +1,17 @@
 """Differential campaign: random renders (tests/fuzz_scenes.py) through the C ABI on the GPU and through the oracle, compared bit for bit (test infrastructure).
 
-  python tests/fuzz_parity.py 0:500 [--threads 64] [--log gpurun_out/fuzz.log] [--keep-going]
+  python tests/fuzz_parity.py 0:500 [--threads 64] [--log gpurun_out/fuzz.log]      renders: seeds first:last (exclusive) or a comma list
+  python tests/fuzz_parity.py 129,219 --reduce                                      shrink differing cases to what still differs and print what is left
+  python tests/fuzz_parity.py 0:20000 --bsdf                                        one random material on 2 048 random frames / directions per seed
+  python tests/fuzz_parity.py 0:4000 --concurrent 4                                 four host threads render scenes of their own at the same time
+  python tests/fuzz_parity.py 0:1500 --scale 12                                     the same cases on images 12 times as wide and as high
+  GATLING_DEVICES=0,0,0 python tests/fuzz_parity.py 0:4000                          every whole-frame render dealt to three device contexts
 
-Per case: the colour image of one giCRender call == the oracle's, the frame's segment / shadow-ray / sample counts, optionally a second (progressive) call and
-the 13 non-colour AOVs.  Prints one line per case and a summary; exit status 1 if any case differs."""
+Per render case: the colour image of one giCRender call == the oracle's, the frame's segment / shadow-ray / sample counts, and as the seed decides a second
+(progressive) call, the 13 (whole frames: 16) non-colour AOVs, a row range or an interleaved row share, an edit of the live scene followed by a third call, a batch
+of rays through giCTraceRays, materials handed over as MaterialX documents, scene options, one of the schedules of gi_options.h, hostile geometry (the oracle then
+renders tests/test_hostile_inputs.py sanitised() of the description).  Prints one line per case and a summary; exit status 1 if any case differs.  The campaigns
+that were run, and what they found, are listed in DESIGN.md section 8 (logs under profiles/)."""
 from __future__ import annotations
 
 import argparse

@@ -166,33 +166,6 @@ def process(path):
     return changed
 
 
-def reflow_paragraphs(path):
-    """Second pass: a run of prose comment lines that holds a wrap remainder (a line of at most three words that is not the run's last) is re-flowed as one paragraph."""
-    lines, out, i, fixed = open(path).read().split("\n"), [], 0, 0
-    def prose(l):
-        t = l.lstrip()
-        return t.startswith("// ") and not t.startswith("//  ") and "   " not in t[3:] and not re.match(r"// -{8,}", t)
-    while i < len(lines):
-        if not prose(lines[i]):
-            out.append(lines[i]); i += 1; continue
-        indent = lines[i][:len(lines[i]) - len(lines[i].lstrip())]
-        j = i
-        while j < len(lines) and prose(lines[j]) and lines[j].startswith(indent + "// "): j += 1
-        run = lines[i:j]
-        if any(len(l.split()) <= 4 for l in run[:-1]) and len(run) > 1:   # ("//" + three words)
-            out += reflow_comment(indent, " ".join(l.lstrip()[3:].strip() for l in run)); fixed += 1
-        else:
-            out += run
-        i = j
-    open(path, "w").write("\n".join(out))
-    return fixed
-
-
 if __name__ == "__main__":
-    args = sys.argv[1:]
-    if args and args[0] == "--reflow":
-        for p in args[1:]:
-            print(p, reflow_paragraphs(p), "paragraphs re-flowed")
-    else:
-        for p in args:
-            print(p, process(p), "lines wrapped")
+    for p in sys.argv[1:]:
+        print(p, process(p), "lines wrapped")
