@@ -61,7 +61,7 @@ class _Writer:
 def _settings_words(rs: RenderSettings) -> bytes:
     """GiCRenderSettings, field for field (include/gi_c.h; Gi.h:139-159)."""
     return struct.pack("<4if i f I f 2I f 2i I f I f", int(rs.clipping_planes), int(rs.depth_of_field), int(rs.dome_light_camera_visible),
-                       int(rs.filter_importance_sampling), 0.0, int(rs.jittered_sampling), rs.light_intensity_multiplier, rs.max_bounces,
+                       int(rs.filter_importance_sampling), float(rs.frame), int(rs.jittered_sampling), rs.light_intensity_multiplier, rs.max_bounces,
                        rs.max_sample_value, rs.max_volume_walk_length, rs.medium_stack_size, rs.meters_per_scene_unit,
                        int(rs.next_event_estimation), int(rs.progressive_accumulation), rs.rr_bounce_offset, rs.rr_inv_min_term_prob, rs.spp, 0.0)
 
@@ -191,7 +191,7 @@ def load_scene(path):
         width, height = r.u32(), r.u32()
         v = struct.unpack("<4if i f I f 2I f 2i I f I f", r.take(72))
         settings = RenderSettings(clipping_planes=bool(v[0]), depth_of_field=bool(v[1]), dome_light_camera_visible=bool(v[2]),
-                                  filter_importance_sampling=bool(v[3]), jittered_sampling=bool(v[5]), light_intensity_multiplier=v[6],
+                                  filter_importance_sampling=bool(v[3]), frame=v[4], jittered_sampling=bool(v[5]), light_intensity_multiplier=v[6],
                                   max_bounces=v[7], max_sample_value=v[8], max_volume_walk_length=v[9], medium_stack_size=v[10],
                                   meters_per_scene_unit=v[11], next_event_estimation=bool(v[12]), progressive_accumulation=bool(v[13]),
                                   rr_bounce_offset=v[14], rr_inv_min_term_prob=v[15], spp=v[16], clear_color=tuple(r.f32(4)))

@@ -141,6 +141,7 @@ def run_case(gi, orc, seed, threads=8, use_options=True):
 
 _ORACLE_LOCK = __import__("threading").Lock()
 _SCALE = [1]
+_HARNESS = []
 
 
 def _compare(orc, seed, desc, rs, w, h, ex, info, threads, rows, row_list, r0, r1, stride, img, st, img2, img3, aov, rays):
@@ -360,6 +361,35 @@ def bsdf_case(gi, orc, seed, n=2048):
     return {"seed": seed, "klass": mat.klass, "finite": bool(np.isfinite(got).all()), "status": "differs" if len(rows) else "same", "detail": detail}
 
 
+def gscn_case(orc, seed, threads, tmpdir):
+    """The case written to a scene file (gatling_amd/scenefile.py), rendered by the plain-C client tools/gi_render (strict C99 over include/gi_c.h, its own parser of
+    the file) in a process of its own, against the oracle on the description in memory: the file format, its two implementations and the client on the whole generator."""
+    import subprocess
+    from gatling_amd.scenefile import save_scene
+    from test_scenefile import _build_harness
+    desc, rs, w, h, ex = random_case(seed)
+    info = {"seed": seed, "tris": desc.triangle_count(), "w": w, "h": h, "spp": rs.spp, "bounces": rs.max_bounces, "hostile": ex["hostile"]}
+    if ex["hostile"]:
+        from test_hostile_inputs import sanitised
+        ref_desc = sanitised(desc)
+    else:
+        ref_desc = desc
+    path, out = os.path.join(tmpdir, f"s{seed}.gscn"), os.path.join(tmpdir, f"o{seed}.raw")
+    save_scene(path, desc, rs, w, h)
+    if not _HARNESS: _HARNESS.append(_build_harness())   # (compiled once per campaign)
+    run = subprocess.run([_HARNESS[0], path, out], capture_output=True, text=True, timeout=300)
+    try:
+        if run.returncode != 0:
+            return dict(info, status="refused", detail=(run.stdout + run.stderr).strip().replace("\n", " | ")[-300:])
+        img = np.fromfile(out, np.float32).reshape(h, w, 4)
+    finally:
+        for f in (path, out):
+            if os.path.exists(f): os.remove(f)
+    ref, _ = orc.render(ref_desc, rs, w, h, threads=threads)
+    bad = differing(img, ref)
+    return dict(info, status="differs" if bad else "same", detail=f"colour: {bad} of {w * h} pixels" if bad else "")
+
+
 def RenderSettingsDefaults():
     return {"next_event_estimation": False, "medium_stack_size": 0, "depth_of_field": False, "clipping_planes": False, "filter_importance_sampling": False,
             "jittered_sampling": False, "light_intensity_multiplier": 1.0, "max_sample_value": 1.0e6, "rr_bounce_offset": 100, "meters_per_scene_unit": 1.0,
@@ -374,6 +404,7 @@ def main():
     ap.add_argument("--reduce", action="store_true", help="reduce each differing case of the list to what still differs")
     ap.add_argument("--concurrent", type=int, default=1, help="this many host threads run cases at the same time, each on scenes of its own (the library serialises "
                     "nothing but what shares state: include/gi_c.h); the oracle then runs single-threaded per case")
+    ap.add_argument("--gscn", action="store_true", help="each case through a scene file and the plain-C client tools/gi_render instead of the ctypes binding")
     ap.add_argument("--scale", type=int, default=1, help="render every case `scale` times as wide and as high")
     ap.add_argument("--bsdf", action="store_true", help="the seeds are BSDF cases (one random material on 2 048 random frames / directions each) instead of renders")
     a = ap.parse_args()
@@ -387,12 +418,15 @@ def main():
             try: reduce_case(gi, orc, seed, a.threads)
             except Exception: traceback.print_exc()
         return 0
+    import tempfile
+    tmpdir = tempfile.mkdtemp(prefix="fuzz_gscn_") if a.gscn else None
     log = open(a.log, "w") if a.log else None
     tally = {}
     t0 = time.perf_counter()
     def one(seed):
         try:
             if a.bsdf: return bsdf_case(gi, orc, seed)
+            if a.gscn: return gscn_case(orc, seed, a.threads, tmpdir)
             return run_case(gi, orc, seed, a.threads if a.concurrent == 1 else 1, use_options=a.concurrent == 1)
         except Exception:
             return {"seed": seed, "status": "error", "detail": traceback.format_exc(limit=3).replace("\n", " | ")[-400:]}

@@ -57,7 +57,13 @@ SCENES = {
 @pytest.mark.parametrize("name", sorted(SCENES))
 def test_gscn_round_trip(tmp_path, name):
     desc = SCENES[name]()
-    rs = RenderSettings(spp=3, max_bounces=5, next_event_estimation=True, medium_stack_size=2, clear_color=(0.25, 0.5, 0.75, 1.0))
+    # (every field away from its default: `frame` -- the FRAME scene-data value -- was written as 0 until the differential campaign's scenes went through the file)
+    rs = RenderSettings(spp=3, max_bounces=5, rr_bounce_offset=2, rr_inv_min_term_prob=0.75, max_sample_value=4.0, filter_importance_sampling=False, depth_of_field=True,
+                        light_intensity_multiplier=1.5, next_event_estimation=True, clipping_planes=True, medium_stack_size=2, frame=17.0, max_volume_walk_length=5,
+                        jittered_sampling=False, meters_per_scene_unit=0.01, progressive_accumulation=False, dome_light_camera_visible=False,
+                        clear_color=(0.25, 0.5, 0.75, 1.0))
+    defaults = RenderSettings()
+    assert all(getattr(rs, f.name) != getattr(defaults, f.name) for f in dataclasses.fields(rs)), "a new settings field: give it a non-default value here"
     save_scene(tmp_path / "s.gscn", desc, rs, 96, 54)
     got, got_rs, w, h = load_scene(tmp_path / "s.gscn")
     assert (w, h) == (96, 54)
