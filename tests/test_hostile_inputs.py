@@ -428,6 +428,52 @@ def test_refused_settings(gi):
 
 
 @pytest.mark.gpu
+def test_refused_aov_bindings_and_row_ranges(gi, orc):
+    """giCRender with bindings it cannot use -- none, a binding without a buffer, AOV buffers of another size than the colour buffer, an id outside the enumeration,
+    a depth AOV bound to a four-component buffer and a normal AOV to a one-component one -- and with row ranges outside the image: refused with a message, nothing
+    written, and the scene renders to the oracle's bits afterwards."""
+    import ctypes as C
+    desc = cornell_box(MAT_DIFFUSE)
+    rs = RenderSettings(spp=2, max_bounces=3)
+    w, h = 24, 14
+    sc = gi.Scene(desc)
+    L = sc.L
+    made = []
+    try:
+        def buffer(ww, hh, fmt):
+            rb = L.giCCreateRenderBuffer(ww, hh, fmt); assert rb; made.append(rb); return rb
+        color, small, one, vec = buffer(w, h, capi.FORMAT_FLOAT32_VEC4), buffer(w // 2, h, capi.FORMAT_FLOAT32_VEC4), buffer(w, h, capi.FORMAT_FLOAT32), buffer(w, h, capi.FORMAT_FLOAT32_VEC4)
+
+        def call(bindings, rows=(0, 0, 0)):
+            arr = (capi.GiCAovBinding * max(len(bindings), 1))()
+            for i, (aid, rb) in enumerate(bindings):
+                arr[i].aovId = aid; arr[i].renderBuffer = rb
+            p = capi.GiCRenderParams()
+            p.aovBindings = C.cast(arr, C.POINTER(capi.GiCAovBinding)) if bindings else None; p.aovBindingCount = len(bindings)
+            p.camera = capi._camera(desc.camera); p.domeLight = None; p.renderSettings = capi._settings(rs); p.scene = sc.handle
+            p.rowBegin, p.rowEnd, p.rowStride = rows
+            return L.giCRender(C.byref(p)), (L.giCGetLastError() or b"").decode()
+        NORMAL, DEPTH = sc.AOVS["normal"][0], sc.AOVS["depth"][0]
+        refused = [([], (0, 0, 0), "no AOV bindings"), ([(capi.AOV_COLOR, None)], (0, 0, 0), "without render buffer"),
+                   ([(capi.AOV_COLOR, color), (NORMAL, small)], (0, 0, 0), "share one size"), ([(capi.AOV_COLOR, color), (99, vec)], (0, 0, 0), "bad AOV id"),
+                   ([(capi.AOV_COLOR, color), (-3, vec)], (0, 0, 0), "bad AOV id"), ([(capi.AOV_COLOR, color), (DEPTH, vec)], (0, 0, 0), "format"),
+                   ([(capi.AOV_COLOR, color), (NORMAL, one)], (0, 0, 0), "format"), ([(capi.AOV_COLOR, color)], (0, h + 1, 1), "row range"),
+                   ([(capi.AOV_COLOR, color)], (h, h - 1, 1), "row range"), ([(capi.AOV_COLOR, color)], (5, 3, 2), "row range")]
+        for bindings, rows, message in refused:
+            rc, err = call(bindings, rows)
+            assert rc != capi.GI_C_OK and message in err, (bindings, rows, err)
+        # accepted edge cases: an empty row range renders nothing; a stride beyond the image renders its first row only
+        assert call([(capi.AOV_COLOR, color)], (3, 3, 1))[0] == capi.GI_C_OK
+        assert call([(capi.AOV_COLOR, color)], (2, h, 1000))[0] == capi.GI_C_OK
+        img = sc.render(rs, w, h)
+    finally:
+        for rb in made: L.giCDestroyRenderBuffer(rb)
+        sc.close()
+    ref, _ = orc.render(desc, rs, w, h, threads=4)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.gpu
 @pytest.mark.skipif((os.cpu_count() or 1) < 32, reason="the oracle needs ~60 M samples for the two bands: a many-core host")
 def test_more_than_2_pow_32_samples_in_one_call(gi, orc):
     """spp x pixels >= 2^32 in ONE giCRender (C2's frame at spp 2 100 = 4.35 G samples): work-item ids are 32-bit, so the frame is cut into batches of fewer than
