@@ -249,6 +249,20 @@ def random_case(seed: int):
     w, h = int(rng.integers(1, 72)), int(rng.integers(1, 44))
     if big: w, h = min(w, 48), min(h, 27)
     rs.frame = float(rng.integers(0, 100))
+    # rare corners: no geometry at all, a mesh without faces or without a material, a dome without an image, degenerate settings and cameras
+    corner = rng.uniform()
+    if corner < 0.01: s.meshes = []
+    elif corner < 0.02: s.meshes[0].faces = np.zeros((0, 3), np.uint32); s.meshes[0].face_ids = None
+    elif corner < 0.04: s.meshes[int(rng.integers(len(s.meshes)))].material = -1
+    elif corner < 0.06 and s.dome_light is None: s.dome_light = DomeLight(texture=-1, base_emission=_color(rng, 0.2, 1.5))
+    elif corner < 0.08: rs.rr_inv_min_term_prob = float(rng.choice([0.0, 1.0])); rs.rr_bounce_offset = 0
+    elif corner < 0.10: rs.light_intensity_multiplier = 0.0
+    elif corner < 0.12: rs.max_sample_value = 0.0
+    elif corner < 0.14: s.camera.vfov = float(rng.choice([1.0e-3, 3.1]))
+    elif corner < 0.16: s.camera.f_stop = 0.0; rs.depth_of_field = True
+    elif corner < 0.18: s.camera.clip_start, s.camera.clip_end = s.camera.clip_end, s.camera.clip_start; rs.clipping_planes = True
+    elif corner < 0.20:
+        for l in s.sphere_lights + s.rect_lights + s.disk_lights + s.distant_lights: l.diffuse = 0.0; l.specular = float(rng.choice([0.0, 1.0]))
     extras = {"aovs": bool(rng.uniform() < 0.3), "second_call": bool(rng.uniform() < 0.3), "big": bool(big)}
     # equivalent schedules of the library ($GATLING_OPTIONS, gi_options.h): none may change a bit
     opts = []
@@ -308,10 +322,14 @@ def apply_edit(desc, kind, edit_seed):
     """Edits the description the way the case's edit changes the scene (what the library's incremental update must equal) and returns the operation for the driver:
     {"op": ..., "mesh": index} or {"op": ..., "light": (list name, index)}."""
     rng = np.random.default_rng(edit_seed)
-    k = int(rng.integers(len(desc.meshes)))
-    m = desc.meshes[k]
+    if not desc.meshes:   # (the empty scene: nothing to edit but the lights)
+        kind = "light_add"; k = 0; m = None
+    else:
+        k = int(rng.integers(len(desc.meshes)))
+        m = desc.meshes[k]
     lights = [(name, i) for name in ("sphere_lights", "distant_lights", "rect_lights", "disk_lights") for i in range(len(getattr(desc, name)))]
     if kind in ("light_move", "light_remove") and not lights: kind = "light_add"
+    if m is None and kind not in ("light_move", "light_remove"): kind = "light_add"
     if kind == "mesh_remove" and len(desc.meshes) == 1: kind = "visibility"
     if kind == "transforms":
         m.instance_transforms = np.stack([_transform(rng, spread=3.0, scale=(0.5, 1.2)) for _ in range(len(m.instance_transforms))])
