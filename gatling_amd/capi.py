@@ -146,6 +146,7 @@ SYMBOLS = [
     ("giCTraceRays", C.c_int, [_P, _U, _FP, _FP, _F, _F, _FP, C.POINTER(C.c_int32)]),
     ("giCDebugEvalBsdf", C.c_int, [C.POINTER(GiCMaterialDesc), _U, _FP, _FP]),
     ("giCDebugShadeClass", C.c_int, [C.POINTER(GiCMaterialDesc)]),
+    ("giCDebugCheckSqrt", C.c_int64, [C.c_uint32, C.c_uint64]),
     ("giCDebugValidateBvh", C.c_int, [_FP, _U, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("giCDebugValidatePartitionedBvh", C.c_int, [_FP, _U, _U, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("giCDebugTexRuntime", C.c_int, [_FP, _U, _U, _U, _U, _FP, _FP]),

@@ -250,3 +250,20 @@ extern "C" int giCDebugTexRuntime(const float* rgba, uint32_t width, uint32_t he
   return rc;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// giCDebugCheckSqrt: the kernels' square root (gi_device_math.h gi_sqrt) against the compiler's correctly rounded sqrtf for the `count` bit patterns from `first` on
+// (count = 2^32: every float).  Returns the number of arguments whose results differ, or -1 on error.
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int64_t giCDebugCheckSqrt(uint32_t first, uint64_t count)
+{
+  if (!g_ctx.initialized) { setError("giCDebugCheckSqrt before giCInitialize"); return -1; }
+  unsigned long long* d = nullptr; unsigned long long h = 0ull;
+  if (hipMalloc(&d, sizeof(h)) != hipSuccess) { setError("giCDebugCheckSqrt: hipMalloc failed"); return -1; }
+  bool ok = hipMemsetAsync(d, 0, sizeof(h), g_ctx.stream) == hipSuccess;
+  if (ok) { launchDebugSqrt(g_ctx.stream, first, (unsigned long long)count, d); ok = hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, g_ctx.stream) == hipSuccess; }
+  ok = ok && hipStreamSynchronize(g_ctx.stream) == hipSuccess;
+  (void)hipFree(d);
+  if (!ok) { setError("giCDebugCheckSqrt: device error"); return -1; }
+  return (int64_t)h;
+}

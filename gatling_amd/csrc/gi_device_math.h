@@ -25,8 +25,31 @@ __device__ __forceinline__ V3 operator*(V3 a, float s) { return V3{a.x * s, a.y 
 __device__ __forceinline__ V3 operator/(V3 a, float s) { return V3{a.x / s, a.y / s, a.z / s}; }
 __device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 __device__ __forceinline__ V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
-__device__ __forceinline__ float length(V3 a) { return sqrtf(dot(a, a)); }
-__device__ __forceinline__ V3 normalize(V3 a) { float inv = 1.0f / sqrtf(dot(a, a)); return a * inv; }
+// Square root, correctly rounded like sqrtf (the oracle's), in fewer instructions for ordinary arguments.  The compiler expands sqrtf into 16 VALU instructions: scale
+// by 2^32 below 2^-96, v_sqrt_f32 (1 ulp), a +- 1 ulp correction by two residuals, unscale, and a class test that returns +-0 and +inf unchanged.  For x in
+// [2^-95, +inf) the scaling and the class test select nothing, and what is left -- taken here literally -- is 9 instructions after a two-instruction range test; any
+// other argument (zeros, denormals, negatives, NaN, +inf) goes to sqrtf.  Same bits by construction; tests/test_gpu_parity.py runs all 2^32 arguments through both.
+// Measured on one box, libraries alternating (profiles/r06zp_lean_sqrt_variants.txt): `k_path` 201.1 / 201.3 -> 199.8 / 199.6 ms per C2 launch at spp 1024 (it is
+// bound by its VALU issue rate and held 12 roots in 2 407 instructions); the shade stage C3 9.3 -> 9.15 ms but C5 26.9 -> 27.75 and C4 3.3 -> 3.5 (the second copy of
+// every root and its branch cost the UsdPreviewSurface kernel more than the five instructions save): the lean form is compiled into the fused kernels only.
+__device__ __forceinline__ float gi_sqrt(float x)
+{
+#if !defined(GI_LEAN_SQRT)   // a translation unit asks for the lean form before it includes this header: the fused kernels do (gi_path.hip), the stage kernels do not
+  return sqrtf(x);
+#else
+  if (__builtin_expect((__builtin_bit_cast(uint32_t, x) - 0x10000000u) < (0x7f800000u - 0x10000000u), 1)) {
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float lo = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, s) - 1u), hi = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, s) + 1u);
+    const float rlo = __builtin_fmaf(-lo, s, x), rhi = __builtin_fmaf(-hi, s, x);
+    s = (rlo <= 0.0f) ? lo : s;
+    s = (rhi > 0.0f) ? hi : s;
+    return s;
+  }
+  return sqrtf(x);
+#endif
+}
+__device__ __forceinline__ float length(V3 a) { return gi_sqrt(dot(a, a)); }
+__device__ __forceinline__ V3 normalize(V3 a) { float inv = 1.0f / gi_sqrt(dot(a, a)); return a * inv; }
 __device__ __forceinline__ float fmax2(float a, float b) { return a > b ? a : b; }
 __device__ __forceinline__ float fmin2(float a, float b) { return a < b ? a : b; }
 __device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
@@ -116,7 +139,7 @@ __device__ __forceinline__ float gi_atan2f(float y, float x)
 __device__ __forceinline__ float gi_asinf(float xx)
 {
   float a = fabsf(xx), x, z; bool flag = false;
-  if (a > 0.5f) { z = 0.5f * (1.0f - a); x = sqrtf(z); flag = true; }
+  if (a > 0.5f) { z = 0.5f * (1.0f - a); x = gi_sqrt(z); flag = true; }
   else { x = a; z = x * x; }
   z = ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z + 1.6666752422e-1f) * z * x + x;
   if (flag) { z = z + z; z = 1.5707963267948966f - z; }
@@ -125,8 +148,8 @@ __device__ __forceinline__ float gi_asinf(float xx)
 __device__ __forceinline__ float gi_acosf(float x)
 {
   x = fmin2(fmax2(x, -1.0f), 1.0f);
-  if (x < -0.5f) return 3.14159265358979323846f - 2.0f * gi_asinf(sqrtf(0.5f * (1.0f + x)));
-  if (x > 0.5f) return 2.0f * gi_asinf(sqrtf(0.5f * (1.0f - x)));
+  if (x < -0.5f) return 3.14159265358979323846f - 2.0f * gi_asinf(gi_sqrt(0.5f * (1.0f + x)));
+  if (x > 0.5f) return 2.0f * gi_asinf(gi_sqrt(0.5f * (1.0f - x)));
   return 1.5707963267948966f - gi_asinf(x);
 }
 
@@ -225,14 +248,14 @@ __device__ __forceinline__ V3 gi_safe_div(V3 v, float f) { return (f == 0.0f) ? 
 // ---- common.glsl:210-252 ----
 __device__ __forceinline__ V3 gi_sample_hemisphere(float x0, float x1)
 {
-  float a = sqrtf(x0);
+  float a = gi_sqrt(x0);
   float s, c; gi_sincos2pi(x1, &s, &c);
-  return v3(a * c, a * s, sqrtf(1.0f - x0));
+  return v3(a * c, a * s, gi_sqrt(1.0f - x0));
 }
 __device__ __forceinline__ V3 gi_sample_sphere(float x0, float x1, V3 radius)
 {
   float a = 1.0f - 2.0f * x0;
-  float b = sqrtf(1.0f - a * a);
+  float b = gi_sqrt(1.0f - a * a);
   float s, c; gi_sincos2pi(x1, &s, &c);
   return v3(b * c, b * s, a) * radius;
 }
@@ -250,7 +273,7 @@ __device__ __forceinline__ void gi_sample_disk(float x0, float x1, float rx, flo
 __device__ __forceinline__ void gi_fis_gauss(float x0, float x1, float& ox, float& oy)
 {
   float u1 = fmax2(1e-38f, x0);
-  float r = 0.375f * sqrtf(-2.0f * gi_logf(u1));
+  float r = 0.375f * gi_sqrt(-2.0f * gi_logf(u1));
   float s, c; gi_sincos2pi(x1, &s, &c);
   ox = c * r; oy = s * r;
 }

@@ -45,6 +45,7 @@ void launchResolveNee(hipStream_t s, const FrameUniforms& U, const unsigned long
 void launchZeroClosest(hipStream_t s, Counters* cnt, uint32_t par); // FLAG_TWO_STREAM: in front of every closest-hit launch
 void launchSpin(hipStream_t s, unsigned long long ns);              // test hook: occupies a stream for ~ns nanoseconds
 void launchDebugBsdf(hipStream_t s, const MaterialRec* mat, uint32_t shadeClass, uint32_t count, const float* in, float* out);
+void launchDebugSqrt(hipStream_t s, uint32_t first, unsigned long long count, unsigned long long* mismatches); // gi_sqrt against sqrtf over bit patterns
 void launchDebugTex(hipStream_t s, const float* texels, uint32_t w, uint32_t h, uint32_t d, uint32_t count, const float* queries, float* out);
 
 } // namespace gi

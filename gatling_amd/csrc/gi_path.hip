@@ -20,6 +20,7 @@
 
 #include <hip/hip_runtime.h>
 
+#define GI_LEAN_SQRT 1 // gi_device_math.h gi_sqrt: the correctly rounded square root without the steps ordinary arguments do not need
 #include "gi_device_math.h"
 #include "gi_kernels.h"
 #include "gi_types.h"
@@ -260,6 +261,24 @@ int launchPath(hipStream_t s, uint32_t cuCount, uint32_t classMask, bool texture
   if (blocks == 0u) blocks = 1u;
   hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(TRACE_BLOCK), bytes, s, U, sc, st, cnt, sampleBuf, ldsNodes, ldsTris, chunk);
   return perCu;
+}
+
+// k_debug_sqrt: gi_sqrt (gi_device_math.h) against sqrtf over a range of bit patterns; counts the arguments whose results differ in a bit (NaN against NaN is equal
+// whatever the payload: both come out of v_sqrt_f32 here, but the contract does not say so)
+__global__ void k_debug_sqrt(uint32_t first, unsigned long long count, unsigned long long* mismatches)
+{
+  unsigned long long bad = 0ull;
+  for (unsigned long long i = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < count; i += (unsigned long long)gridDim.x * blockDim.x) {
+    const float x = u2f(first + (uint32_t)i);
+    const float a = gi_sqrt(x), b = sqrtf(x);
+    if (f2u(a) != f2u(b) && !(a != a && b != b)) bad++;
+  }
+  if (bad) atomicAdd(mismatches, bad);
+}
+
+void launchDebugSqrt(hipStream_t s, uint32_t first, unsigned long long count, unsigned long long* mismatches)
+{
+  hipLaunchKernelGGL(k_debug_sqrt, dim3(4096), dim3(256), 0, s, first, count, mismatches);
 }
 
 } // namespace gi

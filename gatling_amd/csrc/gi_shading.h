@@ -268,7 +268,7 @@ __device__ __forceinline__ V3 to_world_coat(const ShState& s, V3 l)
 __device__ __forceinline__ V3 to_local_coat(const ShState& s, V3 w)
 { return s.hasCoatFrame ? v3(dot(w, s.coatTangentU), dot(w, s.coatTangentV), dot(w, s.coatNormal)) : to_local(s, w); }
 __device__ __forceinline__ float schlick_w(float c) { float m = 1.0f - c; m = fmin2(fmax2(m, 0.0f), 1.0f); float m2 = m * m; return m2 * m2 * m; }
-__device__ __forceinline__ float ggx_lambda_term(float a2, float c) { return sqrtf(a2 + (1.0f - a2) * c * c); }
+__device__ __forceinline__ float ggx_lambda_term(float a2, float c) { return gi_sqrt(a2 + (1.0f - a2) * c * c); }
 __device__ __forceinline__ V3 schlick3(V3 F0, float c) { float w = schlick_w(c); return F0 + (v3(1.0f, 1.0f, 1.0f) - F0) * w; }
 
 struct GgxOut { V3 l2; float pdf, g2OverG1, kh; bool valid; };
@@ -277,14 +277,14 @@ __device__ inline GgxOut ggx_sample(V3 l1, float alpha, float x0, float x1)
   GgxOut o; o.valid = false; o.pdf = 0.0f; o.g2OverG1 = 0.0f; o.kh = 0.0f; o.l2 = v3(0.0f, 0.0f, 0.0f);
   V3 vh = normalize(v3(alpha * l1.x, alpha * l1.y, l1.z));
   float lensq = vh.x * vh.x + vh.y * vh.y;
-  V3 T1 = lensq > 0.0f ? v3(-vh.y, vh.x, 0.0f) * (1.0f / sqrtf(lensq)) : v3(1.0f, 0.0f, 0.0f);
+  V3 T1 = lensq > 0.0f ? v3(-vh.y, vh.x, 0.0f) * (1.0f / gi_sqrt(lensq)) : v3(1.0f, 0.0f, 0.0f);
   V3 T2 = cross(vh, T1);
-  float r = sqrtf(x0);
+  float r = gi_sqrt(x0);
   float s, c; gi_sincos2pi(x1, &s, &c);
   float t1 = r * c, t2 = r * s;
   float sm = 0.5f * (1.0f + vh.z);
-  t2 = (1.0f - sm) * sqrtf(fmax2(0.0f, 1.0f - t1 * t1)) + sm * t2;
-  V3 nh = (T1 * t1 + T2 * t2) + vh * sqrtf(fmax2(0.0f, (1.0f - t1 * t1) - t2 * t2));
+  t2 = (1.0f - sm) * gi_sqrt(fmax2(0.0f, 1.0f - t1 * t1)) + sm * t2;
+  V3 nh = (T1 * t1 + T2 * t2) + vh * gi_sqrt(fmax2(0.0f, (1.0f - t1 * t1) - t2 * t2));
   V3 h = normalize(v3(alpha * nh.x, alpha * nh.y, fmax2(0.0f, nh.z)));
   float kh = dot(l1, h);
   V3 l2 = h * (2.0f * kh) - l1;
@@ -318,7 +318,7 @@ __device__ inline void ggx_eval(V3 l1, V3 l2, float alpha, float& fcos, float& p
 
 // Anisotropic form, operation for operation the oracle's (oracle/gi_oracle.cpp "Anisotropic form"): used only when ax != ay, so isotropic materials keep the
 // arithmetic above bit for bit.
-__device__ __forceinline__ float ggx_lambda_xy(float ax, float ay, V3 v) { return sqrtf(((ax * v.x) * (ax * v.x) + (ay * v.y) * (ay * v.y)) + v.z * v.z); }
+__device__ __forceinline__ float ggx_lambda_xy(float ax, float ay, V3 v) { return gi_sqrt(((ax * v.x) * (ax * v.x) + (ay * v.y) * (ay * v.y)) + v.z * v.z); }
 __device__ __forceinline__ float ggx_d_xy(float ax, float ay, V3 h)
 {
   const float hx = h.x / ax, hy = h.y / ay;
@@ -330,14 +330,14 @@ __device__ inline GgxOut ggx_sample_xy(V3 l1, float ax, float ay, float x0, floa
   GgxOut o; o.valid = false; o.pdf = 0.0f; o.g2OverG1 = 0.0f; o.kh = 0.0f; o.l2 = v3(0.0f, 0.0f, 0.0f);
   V3 vh = normalize(v3(ax * l1.x, ay * l1.y, l1.z));
   float lensq = vh.x * vh.x + vh.y * vh.y;
-  V3 T1 = lensq > 0.0f ? v3(-vh.y, vh.x, 0.0f) * (1.0f / sqrtf(lensq)) : v3(1.0f, 0.0f, 0.0f);
+  V3 T1 = lensq > 0.0f ? v3(-vh.y, vh.x, 0.0f) * (1.0f / gi_sqrt(lensq)) : v3(1.0f, 0.0f, 0.0f);
   V3 T2 = cross(vh, T1);
-  float r = sqrtf(x0);
+  float r = gi_sqrt(x0);
   float s, c; gi_sincos2pi(x1, &s, &c);
   float t1 = r * c, t2 = r * s;
   float sm = 0.5f * (1.0f + vh.z);
-  t2 = (1.0f - sm) * sqrtf(fmax2(0.0f, 1.0f - t1 * t1)) + sm * t2;
-  V3 nh = (T1 * t1 + T2 * t2) + vh * sqrtf(fmax2(0.0f, (1.0f - t1 * t1) - t2 * t2));
+  t2 = (1.0f - sm) * gi_sqrt(fmax2(0.0f, 1.0f - t1 * t1)) + sm * t2;
+  V3 nh = (T1 * t1 + T2 * t2) + vh * gi_sqrt(fmax2(0.0f, (1.0f - t1 * t1) - t2 * t2));
   V3 h = normalize(v3(ax * nh.x, ay * nh.y, fmax2(0.0f, nh.z)));
   float kh = dot(l1, h);
   V3 l2 = h * (2.0f * kh) - l1;
@@ -370,7 +370,7 @@ __device__ __forceinline__ void opbr_anisotropy(float alpha, float a, float& ax,
   ax = alpha; ay = alpha;
   if (!(a > 0.0f)) return;
   const float inv = 1.0f - fmin2(a, 1.0f);
-  ax = fmax2(alpha * sqrtf(2.0f / (1.0f + inv * inv)), 0.001f); ay = fmax2(inv * ax, 0.001f);
+  ax = fmax2(alpha * gi_sqrt(2.0f / (1.0f + inv * inv)), 0.001f); ay = fmax2(inv * ax, 0.001f);
 }
 __device__ __forceinline__ GgxOut ggx_sample2(V3 l1, float ax, float ay, float x0, float x1)
 { return ax == ay ? ggx_sample(l1, ax, x0, x1) : ggx_sample_xy(l1, ax, ay, x0, x1); }
@@ -419,7 +419,7 @@ __device__ __forceinline__ float fresnel_dielectric(float c, float eta)
 {
   float sin2t = (1.0f - c * c) / (eta * eta);
   if (!(sin2t < 1.0f)) return 1.0f;
-  float ct = sqrtf(1.0f - sin2t);
+  float ct = gi_sqrt(1.0f - sin2t);
   float rs = (c - eta * ct) / (c + eta * ct);
   float rp = (eta * c - ct) / (eta * c + ct);
   return 0.5f * (rs * rs + rp * rp);
@@ -441,7 +441,7 @@ __device__ __forceinline__ V3 schlick_f82(V3 F0, V3 tint, float c)
 __device__ __forceinline__ float opbr_effective_roughness(float r, float cr, float coat)
 {
   float c4 = (cr * cr) * (cr * cr), r4 = (r * r) * (r * r);
-  float ra = sqrtf(sqrtf(fmin2(1.0f, 2.0f * c4 + r4)));
+  float ra = gi_sqrt(gi_sqrt(fmin2(1.0f, 2.0f * c4 + r4)));
   return ra * coat + r * (1.0f - coat);
 }
 __device__ __forceinline__ V3 opbr_base_darkening(V3 baseColor, float sw, float metalness, float coat, float coatF0, float cior, float coatDarkening)
@@ -529,7 +529,7 @@ __device__ inline float film_reflectance(float c, float nf, float n3, float d, f
   const float s2 = 1.0f - c * c;
   const float s2f = s2 / (nf * nf), s23 = s2 / (n3 * n3);
   if (!(s2f < 1.0f) || !(s23 < 1.0f)) return 1.0f; // total internal reflection
-  const float cf = sqrtf(1.0f - s2f), c3 = sqrtf(1.0f - s23);
+  const float cf = gi_sqrt(1.0f - s2f), c3 = gi_sqrt(1.0f - s23);
   const float rs12 = (c - nf * cf) / (c + nf * cf), rp12 = (nf * c - cf) / (nf * c + cf);
   const float rs23 = (nf * cf - n3 * c3) / (nf * cf + n3 * c3), rp23 = (n3 * cf - nf * c3) / (n3 * cf + nf * c3);
   const float ph = ((2.0f * nf) * d * cf) / lam; // phase difference / (2 pi)
@@ -549,7 +549,7 @@ __device__ inline V3 opbr_film_dielectric(const OpbrParams& o, float c, float et
 __device__ inline V3 opbr_film_metal(const OpbrParams& o, float c, V3 Fplain)
 {
   const V3 f0 = v3(fmin2(fmax2(o.albedo.x, 0.0f), 0.98f), fmin2(fmax2(o.albedo.y, 0.0f), 0.98f), fmin2(fmax2(o.albedo.z, 0.0f), 0.98f));
-  const V3 r = v3(sqrtf(f0.x), sqrtf(f0.y), sqrtf(f0.z));
+  const V3 r = v3(gi_sqrt(f0.x), gi_sqrt(f0.y), gi_sqrt(f0.z));
   const V3 n3 = v3((1.0f + r.x) / (1.0f - r.x), (1.0f + r.y) / (1.0f - r.y), (1.0f + r.z) / (1.0f - r.z));
   return Fplain * (1.0f - o.filmWeight) + film_fresnel(c, o.filmIor, n3, o.filmNm) * o.filmWeight;
 }
@@ -702,7 +702,7 @@ __device__ inline void opbr_sample_base(const OpbrParams& o, const ShState& st, 
     float Fh = fresnel_dielectric(kh, eta);
     float sin2t = (1.0f - kh * kh) / (eta * eta);
     if (!(sin2t < 1.0f)) return;
-    float ct = sqrtf(1.0f - sin2t);
+    float ct = gi_sqrt(1.0f - sin2t);
     V3 lt = h * (kh / eta - ct) - l1 * (1.0f / eta);
     if (o.thinWalled) lt = v3(g.l2.x, g.l2.y, -g.l2.z); // thin-walled: no refraction, the micro-facet reflection mirrored through the surface
     V3 k2 = to_world(st, lt);

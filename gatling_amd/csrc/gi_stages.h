@@ -210,7 +210,7 @@ __device__ __forceinline__ void shade_segment(const FrameUniforms& U, const Scen
     float cosTheta;
     if (fabsf(g) < 1e-3f) cosTheta = 1.0f - 2.0f * x0;
     else { const float sq = (1.0f - g * g) / ((1.0f - g) + (2.0f * g) * x0); cosTheta = ((1.0f + g * g) - sq * sq) / (2.0f * g); }
-    const float sinTheta = sqrtf(fmax2(0.0f, 1.0f - cosTheta * cosTheta));
+    const float sinTheta = gi_sqrt(fmax2(0.0f, 1.0f - cosTheta * cosTheta));
     float sp, cp; gi_sincos2pi(x1, &sp, &cp);
     V3 t, b; gi_orthonormal_basis(k2, t, b);
     k2 = ((t * sinTheta) * cp + (b * sinTheta) * sp) + k2 * cosTheta;

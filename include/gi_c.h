@@ -487,6 +487,9 @@ int giCDebugEvalBsdf(const GiCMaterialDesc* desc, uint32_t count, const float* i
  * feature #defines, GlslShaderGen.cpp:204-274): 0 diffuse, 1 UsdPreviewSurface, 2 OpenPBR with every lobe, 3 OpenPBR BASE (no coat / fuzz / thin film / anisotropy /
  * transmission / subsurface, not thin-walled, all parameters finite).  giCDebugEvalBsdf runs the variant this names.  <0 on error. */
 int giCDebugShadeClass(const GiCMaterialDesc* desc);
+/* [ext] device self check: the kernels' square root (the compiler's correctly rounded expansion without the steps that ordinary arguments do not need) against sqrtf
+ * for the `count` float bit patterns from `first` on; count = 2^32 covers every float.  Returns the number of arguments whose results differ (0), -1 on error. */
+int64_t giCDebugCheckSqrt(uint32_t first, uint64_t count);
 /* [ext] device-side hook for the MDL renderer runtime's remaining texture entry points (mdl_interface.glsl:45-65, 86-105, 167-221), which only MDL-generated code
  * calls: `rgba` = width x height x depth RGBA float texels (slice by slice; depth 1 = a 2-D image); per query 8 floats (kind, valid, c0, c1, c2, wrapU, wrapV, wrapW)
  * with kind 0 tex_texel_float4_2d(c0, c1), 1 tex_resolution_2d, 2 tex_lookup_float4_3d(c0, c1, c2; wraps), 3 tex_texel_float4_3d(c0, c1, c2); valid 0 = the invalid

@@ -597,6 +597,15 @@ def test_error_behaviour(gi):
         sc.close()
 
 
+def test_device_square_root_is_the_correctly_rounded_one(gi):
+    """gi_device_math.h gi_sqrt -- the compiler's correctly rounded sqrtf expansion with the denormal scaling and the zero / infinity fix-up taken off the path of
+    arguments in [2^-95, +inf) -- equals sqrtf for EVERY float: all 2^32 bit patterns on the device, a second of one GPU (the arithmetic contract of DESIGN.md
+    section 2 says IEEE square root; the oracle's is the host's)."""
+    L = gi.load_library()
+    assert L.giCDebugCheckSqrt(0, 1 << 32) == 0
+    assert L.giCDebugCheckSqrt(0x0f000000, 0x02000000) == 0   # around the range test's lower edge
+
+
 def test_bsdf_known_answers_on_device(gi, orc):
     """Closed-form BSDF sample/evaluate on random frames: device == oracle."""
     rng = np.random.default_rng(5)
