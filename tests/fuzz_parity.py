@@ -92,7 +92,7 @@ def run_case(gi, orc, seed, threads=8, use_options=True):
     rows = ex.get("rows")
     info = {"seed": seed, "tris": desc.triangle_count(), "w": w, "h": h, "spp": rs.spp, "bounces": rs.max_bounces, "nee": rs.next_event_estimation,
             "media": rs.medium_stack_size, "materials": len(desc.materials), "big": ex["big"], "aovs": ex["aovs"], "second": ex["second_call"],
-            "rows": rows, "edit": ex.get("edit"), "hostile": ex.get("hostile", False), "mtlx": len(ex.get("mtlx") or {}), "rays": ex.get("trace_rays", 0), "scene_options": "/".join(f"{o}={v}" for o, v in ex.get("scene_options") or []) or "-", "options": ex.get("options") or "-"}
+            "rows": rows, "edit": ex.get("edit"), "hostile": ex.get("hostile", False), "extreme": ex.get("extreme") or "-", "mtlx": len(ex.get("mtlx") or {}), "rays": ex.get("trace_rays", 0), "scene_options": "/".join(f"{o}={v}" for o, v in ex.get("scene_options") or []) or "-", "options": ex.get("options") or "-"}
     if rows: r0, r1, stride = rows
     else: r0, r1, stride = 0, h, 1
     row_list = list(range(r0, r1, stride))
@@ -142,6 +142,7 @@ def run_case(gi, orc, seed, threads=8, use_options=True):
 _ORACLE_LOCK = __import__("threading").Lock()
 _SCALE = [1]
 _HARNESS = []
+_BSDF_RANGES = [False]
 
 
 def _compare(orc, seed, desc, rs, w, h, ex, info, threads, rows, row_list, r0, r1, stride, img, st, img2, img3, aov, rays):
@@ -331,6 +332,10 @@ def bsdf_case(gi, orc, seed, n=2048):
     rng = np.random.default_rng([0xb5df, seed])
     mat = _material(rng, 0, 0)
     mat.primvar_inputs = {}
+    if _BSDF_RANGES[0]:   # --ranges: material inputs outside their documented ranges (finite: nothing is refused)
+        for _ in range(int(rng.integers(1, 5))):
+            i = int(rng.integers(0, 64))
+            if i not in (6, 14, 15, 54): mat.params[i] = np.float32(rng.choice([-1.0, -0.25, 1.5, 7.0, 0.3, 50.0, 1.0e-6, 1.0e6]))
     nrm = rng.normal(size=(n, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
     t = np.cross(nrm, rng.normal(size=(n, 3))); t /= np.linalg.norm(t, axis=1, keepdims=True)
     b = np.cross(nrm, t)
@@ -404,6 +409,7 @@ def main():
     ap.add_argument("--reduce", action="store_true", help="reduce each differing case of the list to what still differs")
     ap.add_argument("--concurrent", type=int, default=1, help="this many host threads run cases at the same time, each on scenes of its own (the library serialises "
                     "nothing but what shares state: include/gi_c.h); the oracle then runs single-threaded per case")
+    ap.add_argument("--ranges", action="store_true", help="with --bsdf: material inputs outside their documented ranges")
     ap.add_argument("--gscn", action="store_true", help="each case through a scene file and the plain-C client tools/gi_render instead of the ctypes binding")
     ap.add_argument("--scale", type=int, default=1, help="render every case `scale` times as wide and as high")
     ap.add_argument("--bsdf", action="store_true", help="the seeds are BSDF cases (one random material on 2 048 random frames / directions each) instead of renders")
@@ -412,7 +418,7 @@ def main():
     from gatling_amd import capi as gi
     from oracle import orc
     orc.build(); orc.lib(); gi.initialize(0)
-    _SCALE[0] = max(1, a.scale)
+    _SCALE[0] = max(1, a.scale); _BSDF_RANGES[0] = a.ranges
     if a.reduce:
         for seed in seeds:
             try: reduce_case(gi, orc, seed, a.threads)

@@ -301,6 +301,36 @@ def random_case(seed: int):
     # an edit between two renders: instance transforms, visibility, a material swap
     extras["edit"] = str(rng.choice(["transforms", "visibility", "material", "mesh_transform", "mesh_remove", "light_move", "light_remove", "light_add"])) if rng.uniform() < 0.25 else None
     extras["edit_seed"] = int(rng.integers(1 << 30))
+    # numerical extremes (finite, so nothing is refused): the whole scene shrunk or blown up, emission that overflows fp32 along a path, material inputs outside
+    # their documented ranges.  Images may hold inf / NaN: they must be the SAME inf / NaN on both sides (the comparison takes any NaN for any NaN)
+    extras["extreme"] = None
+    if rng.uniform() < 0.12:
+        # ("ranges" -- material inputs outside their documented ranges -- is drawn only under $GATLING_FUZZ_RANGES=1: such inputs reach float -> int conversions of
+        # non-finite values, whose result the language leaves open and the host and the device fill in differently; 1 of ~1 400 such renders traced other shadow rays
+        # than the oracle, with the same image.  The 6 000 out-of-range materials of `--bsdf --ranges` are identical call by call: profiles/r06zu_bsdf_ranges.log)
+        kind = str(rng.choice(["scale", "emission", "ranges"])); extras["extreme"] = kind
+        if kind == "ranges" and os.environ.get("GATLING_FUZZ_RANGES", "0") != "1": kind = extras["extreme"] = "emission"
+        if kind == "scale":
+            # (not below 1e-2: in scenes shrunk to 1e-4 units 3 of ~1 400 cases differed from the oracle by one to four path segments -- the Moeller-Trumbore test, the
+            # contract's arbiter, accepts hits with determinants around 1e-20 whose position lies outside every bounding box, and which of those a walk meets depends
+            # on the tree it walks: DESIGN.md section 8, profiles/r06zs_fuzz_parity_extremes.log)
+            f = np.float32(10.0 ** rng.uniform(-2, 5))
+            for m in s.meshes: m.transform = m.transform.copy(); m.transform[3, :3] *= f; m.transform[:3, :3] *= f
+            for l in s.sphere_lights: l.pos = tuple(np.float32(l.pos) * f); l.radius = tuple(np.float32(l.radius) * f)
+            for l in s.rect_lights: l.origin = tuple(np.float32(l.origin) * f); l.width *= float(f); l.height *= float(f)
+            for l in s.disk_lights: l.origin = tuple(np.float32(l.origin) * f); l.radius_x *= float(f); l.radius_y *= float(f)
+            c = s.camera; c.position = tuple(np.float32(c.position) * f); c.focus_distance *= float(f); c.clip_start *= float(f); c.clip_end *= float(f)
+        elif kind == "emission":
+            g = float(10.0 ** rng.uniform(10, 37))
+            for l in s.sphere_lights + s.rect_lights + s.disk_lights + s.distant_lights: l.base_emission = tuple(float(x) * g for x in l.base_emission)
+            for m in s.materials: m.params[3:6] *= np.float32(min(g, 1e30))
+            rs.max_sample_value = float(rng.choice([10.0, 1.0e38, float("inf")]))
+        else:
+            for m in s.materials:
+                for _ in range(int(rng.integers(1, 5))):
+                    i = int(rng.integers(0, 64))
+                    if i in (6, 14, 15, 54): continue   # switches and the cutout pair keep their meaning
+                    m.params[i] = np.float32(rng.choice([-1.0, -0.25, 1.5, 7.0, 0.3, 50.0, 1.0e-6, 1.0e6]))
     # (drawn last, so that earlier seeds keep their scenes) materials handed over as MaterialX documents through the gtl shim's reader, the way hdGatling does;
     # a batch of rays through giCTraceRays
     extras["mtlx"] = {}
