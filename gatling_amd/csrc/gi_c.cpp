@@ -140,12 +140,16 @@ void deriveMaterialConstants(MaterialRec& m)
         float rr = p[GI_C_P_SUBSURFACE_RADIUS] * p[GI_C_P_SUBSURFACE_RADIUS_SCALE + i]; rr = rr > 1e-6f ? rr : 1e-6f;
         m.sss[3 + i] = 1.0f / rr; m.sss[i] = alb * m.sss[3 + i];
       }
-      m.sss[6] = m.sss[7] = 0.0f;
+      m.sss[6] = 1.0f; m.sss[7] = 0.0f;
     }
+    // geometry_coat_tangent (open_pbr_surface.mtlx:91, 561) as the turn of the frame's tangent a document binds to it: only an anisotropic coat can tell
+    // (the oracle's condition, opbr_params; the same two libm calls on the same angle)
+    const bool coatTurned = p[GI_C_P_CLEARCOAT] > 0.0f && p[GI_C_P_COAT_ANISOTROPY] > 0.0f && p[GI_C_P_COAT_ROTATION] != 0.0f;
+    if (coatTurned) { const float a = 6.2831855f * p[GI_C_P_COAT_ROTATION]; m.sss[6] = cosf(a); m.sss[7] = sinf(a); }
     out[MP_FEATURES] = (float)((p[GI_C_P_THIN_WALLED] != 0.0f ? MATF_THIN_WALLED : 0u) | (p[GI_C_P_FUZZ_WEIGHT] > 0.0f ? MATF_FUZZ : 0u) |
                                ((p[GI_C_P_THIN_WALLED] == 0.0f && p[GI_C_P_SUBSURFACE_WEIGHT] > 0.0f) ? MATF_SSS_VOLUME : 0u) |
                                ((p[GI_C_P_SPECULAR_ANISOTROPY] > 0.0f || p[GI_C_P_COAT_ANISOTROPY] > 0.0f) ? MATF_ANISOTROPY : 0u) |
-                               (p[GI_C_P_THIN_FILM_WEIGHT] > 0.0f ? MATF_THIN_FILM : 0u));
+                               (p[GI_C_P_THIN_FILM_WEIGHT] > 0.0f ? MATF_THIN_FILM : 0u) | (coatTurned ? MATF_COAT_ROTATION : 0u));
     memcpy(m.p, out, sizeof(out));
     return;
   }

@@ -483,7 +483,14 @@ __device__ inline V3 eon_pi_f(V3 rho, float r, V3 l1, V3 l2)
 }
 struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, baseColor, ssColor, fuzzColor;
     float metalness, alpha, alphaY, coat, coatAlpha, coatAlphaY, coatF0, eta, tw, specWeight, baseWeight, diffRough, ssWeight, ssAniso, fuzzWeight, fuzzAlpha,
-    filmWeight, filmNm, filmIor; bool thinWalled, ssVolume; };
+    filmWeight, filmNm, filmIor, coatRotC, coatRotS; bool thinWalled, ssVolume, coatRot; };
+// geometry_coat_tangent (open_pbr_surface.mtlx:91, 561): the coat lobe's tangent is the frame's tangent turned by coat rotation turns towards its bitangent --
+// what a document binds to the input (rotate3d of Tworld about the normal; Standard Surface's coat_rotation).  The turn is applied to the local x / y of a
+// direction in the coat's frame (the surface's, or geometry_coat_normal's), with the cosine / sine the host derived (MaterialRec::sss[6..7]); == oracle.
+__device__ __forceinline__ V3 coat_turn_local(const OpbrParams& o, V3 l)
+{ return v3(l.x * o.coatRotC + l.y * o.coatRotS, l.y * o.coatRotC - l.x * o.coatRotS, l.z); }
+__device__ __forceinline__ V3 coat_turn_world(const OpbrParams& o, V3 l)
+{ return v3(l.x * o.coatRotC - l.y * o.coatRotS, l.x * o.coatRotS + l.y * o.coatRotC, l.z); }
 __device__ __forceinline__ OpbrParams opbr_params(const MaterialRec* m, const ShState& st)
 {
   OpbrParams o; const float* p = m->p;
@@ -506,6 +513,8 @@ __device__ __forceinline__ OpbrParams opbr_params(const MaterialRec* m, const Sh
   o.alphaY = o.alpha; o.coatAlphaY = o.coatAlpha;
   // specular_roughness_anisotropy / coat_roughness_anisotropy
   if (feat & MATF_ANISOTROPY) { opbr_anisotropy(o.alpha, p[60], o.alpha, o.alphaY); opbr_anisotropy(o.coatAlpha, p[61], o.coatAlpha, o.coatAlphaY); }
+  o.coatRot = (feat & MATF_COAT_ROTATION) != 0u; o.coatRotC = 1.0f; o.coatRotS = 0.0f;
+  if (o.coatRot) { o.coatRotC = m->sss[6]; o.coatRotS = m->sss[7]; } // geometry_coat_tangent
   // coat_substrate_attenuated = base_substrate * modulated_base_darkening * coat_attenuation (open_pbr_surface.mtlx:538-552)
   o.coatTint = o.coatTint * opbr_base_darkening(o.baseColor, o.specWeight, o.metalness, o.coat, o.coatF0, p[22], p[48]);
   // thin-walled subsurface (open_pbr_surface.mtlx:140-196, 207-218); the volumetric form of non-thin-walled materials is not modelled
@@ -633,6 +642,7 @@ __device__ inline void opbr_sample_base(const OpbrParams& o, const ShState& st, 
   // the coat lobe lives in its own frame when geometry_coat_normal is mapped; its Fresnel term -- lobe probability and what it leaves for the base -- follows
   V3 l1c = l1; float nk1c = nk1;
   if (st.hasCoatFrame) { l1c = to_local_coat(st, k1); nk1c = fmax2(l1c.z, 1e-4f); l1c.z = nk1c; }
+  if (o.coatRot) l1c = coat_turn_local(o, l1c);
   float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1c));
   float eta = 0.0f, Fd = 0.0f;
   uint32_t lobe = 0u; // 0 coat, 1 metal, 2 dielectric reflection, 3 transmission, 4 diffuse
@@ -718,7 +728,7 @@ __device__ inline void opbr_sample_base(const OpbrParams& o, const ShState& st, 
         Fh)) * ((G2 / G1) / (1.0f - Fd)));
     return;
   }
-  V3 k2 = (lobe == 0u) ? to_world_coat(st, g.l2) : to_world(st, g.l2);
+  V3 k2 = (lobe == 0u) ? to_world_coat(st, o.coatRot ? coat_turn_world(o, g.l2) : g.l2) : to_world(st, g.l2);
   if (!g.valid || !(dot(k2, st.geomNormal) > 0.0f)) return;
   out.k2 = k2; out.event = EV_GLOSSY | EV_REFLECTION;
   if (lobe == 0u) {
@@ -764,6 +774,7 @@ __device__ inline void opbr_evaluate_base(const OpbrParams& o, const ShState& st
   float eta = relative_eta(st, o.eta);
   V3 l1c = l1, l2c = l2; float nk1c = nk1; // the coat lobe's own frame (geometry_coat_normal)
   if (st.hasCoatFrame) { l1c = to_local_coat(st, k1); nk1c = fmax2(l1c.z, 1e-4f); l1c.z = nk1c; l2c = to_local_coat(st, k2); }
+  if (o.coatRot) { l1c = coat_turn_local(o, l1c); l2c = coat_turn_local(o, l2c); }
   float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1c));
   float Fd = fresnel_dielectric(nk1, eta);
   // Lobes whose weight is exactly zero are not evaluated.  The oracle evaluates them and multiplies by the zero -- the same bits: every skipped factor is

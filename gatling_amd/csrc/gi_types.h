@@ -89,7 +89,9 @@ constexpr uint32_t MAT_PARAM_COUNT = 64;
 constexpr uint32_t MP_FEATURES = 54, MATF_THIN_WALLED = 1u, MATF_FUZZ = 2u, MATF_ANISOTROPY = 4u, MATF_THIN_FILM = 8u,
                    // not thin-walled, subsurface_weight > 0: the volumetric subsurface lobe
                    // (live in renders with a medium stack), coefficients in MaterialRec::sss
-                   MATF_SSS_VOLUME = 16u;
+                   MATF_SSS_VOLUME = 16u,
+                   // geometry_coat_tangent: an anisotropic coat whose tangent is turned (cosine / sine in MaterialRec::sss[6..7])
+                   MATF_COAT_ROTATION = 32u;
 enum : uint32_t { MP_ALBEDO = 32, MP_F0 = 35, MP_ALPHA = 38, MP_COAT = 39, MP_COAT_ALPHA = 40, MP_COAT_F0 = 41, MP_ETA = 42, MP_SIGMA_A = 43,
     MP_CUTOUT = 46 /* mdl_cutout_opacity, 1 = opaque */ };
 // Textured material inputs (UsdUVTexture semantics: value = texel * scale + bias at the hit's st).  Replaces the MDL
@@ -129,7 +131,9 @@ struct MaterialRec {
   uint32_t flags;
   float p[MAT_PARAM_COUNT];
   TexBindingRec tex[TEX_SLOT_COUNT];
-  float sss[8]; // volumetric subsurface medium (OpenPBR, derived on the host from subsurface_color / _radius / _radius_scale): sigma_s[3], sigma_t[3], -, -
+  // volumetric subsurface medium (OpenPBR, derived on the host from subsurface_color / _radius / _radius_scale): sigma_s[3], sigma_t[3]; then the
+  // cosine and the sine of the coat tangent's turn (MATF_COAT_ROTATION)
+  float sss[8];
 };
 static_assert(sizeof(MaterialRec) == 872, "MaterialRec must be 872 bytes");
 // A texture: linear float RGBA texels, row 0 first.  (8-bit sources are decoded to linear float by the caller; a

@@ -308,9 +308,9 @@ namespace gtl
       if (n.category == "standard_surface") {
         // Autodesk Standard Surface 1.0.1 (the reference compiles MaterialX's own standard_surface graph through MDL): read onto the OpenPBR closed forms,
         // input by input -- OpenPBR is that model's successor and keeps its layering (fuzz over coat over {metal | glass | subsurface | diffuse+specular}).
-        // Defaults are the Standard Surface specification's, not OpenPBR's.  What has no counterpart is dropped: specular_rotation / coat_rotation (no tangent
-        // input), transmission_dispersion, transmission_extra_roughness, coat_affect_color
-        // / coat_affect_roughness, and coat_darkening stays 0 (the model has no such term).
+        // Defaults are the Standard Surface specification's, not OpenPBR's.  coat_rotation (turns; the model's graph rotates the tangent by 360 x it about the
+        // normal) is the coat tangent's turn.  What has no counterpart is dropped: specular_rotation, transmission_dispersion, transmission_extra_roughness,
+        // coat_affect_color / coat_affect_roughness, and coat_darkening stays 0 (the model has no such term).
         p[GI_C_P_BASE_WEIGHT] = 0.8f; p[GI_C_P_BASE_COLOR] = p[GI_C_P_BASE_COLOR + 1] = p[GI_C_P_BASE_COLOR + 2] = 1.0f; p[GI_C_P_ROUGHNESS] = 0.2f;
         p[GI_C_P_CLEARCOAT_ROUGHNESS] = 0.1f; p[GI_C_P_COAT_IOR] = 1.5f; p[GI_C_P_COAT_DARKENING] = 0.0f; p[GI_C_P_FUZZ_ROUGHNESS] = 0.3f;
         p[GI_C_P_SUBSURFACE_COLOR] = p[GI_C_P_SUBSURFACE_COLOR + 1] = p[GI_C_P_SUBSURFACE_COLOR + 2] = 1.0f;
@@ -333,6 +333,7 @@ namespace gtl
         setN(n, "sheen", p + GI_C_P_FUZZ_WEIGHT, 1); setN(n, "sheen_color", p + GI_C_P_FUZZ_COLOR, 3); setN(n, "sheen_roughness", p + GI_C_P_FUZZ_ROUGHNESS, 1);
         setN(n, "coat", p + GI_C_P_CLEARCOAT, 1); setN(n, "coat_color", p + GI_C_P_COAT_COLOR, 3); setN(n, "coat_roughness", p + GI_C_P_CLEARCOAT_ROUGHNESS, 1);
         setN(n, "coat_IOR", p + GI_C_P_COAT_IOR, 1); setN(n, "coat_anisotropy", p + GI_C_P_COAT_ANISOTROPY, 1);
+        setN(n, "coat_rotation", p + GI_C_P_COAT_ROTATION, 1);
         // nanometres, 0 = no film -> weight + micrometres
         float nm = 0.0f; setN(n, "thin_film_thickness", &nm, 1); setN(n, "thin_film_IOR", p + GI_C_P_THIN_FILM_IOR, 1);
         p[GI_C_P_THIN_FILM_WEIGHT] = nm > 0.0f ? 1.0f : 0.0f; p[GI_C_P_THIN_FILM_THICKNESS] = nm > 0.0f ? nm * 0.001f : 0.5f;
@@ -405,6 +406,22 @@ namespace gtl
       setN(n, "specular_roughness_anisotropy", p + GI_C_P_SPECULAR_ANISOTROPY, 1); setN(n, "coat_roughness_anisotropy", p + GI_C_P_COAT_ANISOTROPY, 1);
       setN(n, "thin_film_weight", p + GI_C_P_THIN_FILM_WEIGHT, 1); setN(n, "thin_film_thickness", p + GI_C_P_THIN_FILM_THICKNESS, 1);
           setN(n, "thin_film_ior", p + GI_C_P_THIN_FILM_IOR, 1);
+      setN(n, "coat_rotation", p + GI_C_P_COAT_ROTATION, 1); // [ext] the turn as a plain float (what the flat parameter vocabularies below carry)
+      { // geometry_coat_tangent (open_pbr_surface.mtlx:91, 561) as documents feed it: <rotate3d in=tangent amount=DEGREES axis=normal>, optionally behind a
+        // <normalize> -- the turn of the coat's tangent, GI_C_P_COAT_ROTATION = amount / 360.  Anything else upstream keeps the geometry tangent.
+        auto it = n.connections.find("geometry_coat_tangent");
+        MtlxNode up;
+        if (it != n.connections.end() && readNode(doc, it->second, up)) {
+          if (up.category == "normalize" && up.connections.count("in")) {
+            const std::string src2 = up.connections["in"];
+            up = MtlxNode(); (void)readNode(doc, src2, up);
+          }
+          if (up.category == "rotate3d" && up.inputs.count("amount")) {
+            float deg = 0.0f; floats(up.inputs["amount"], &deg, 1);
+            p[GI_C_P_COAT_ROTATION] = deg / 360.0f;
+          }
+        }
+      }
       setN(n, "emission_luminance", &lum, 1); setN(n, "emission_color", ecol, 3); setN(n, "geometry_opacity", p + GI_C_P_OPACITY, 1);
       for (int i = 0; i < 3; i++) p[GI_C_P_EMISSION + i] = lum * ecol[i];
       bind("base_color", GI_C_TEX_BASE_COLOR, p + GI_C_P_BASE_COLOR, 3); bind("specular_roughness", GI_C_TEX_ROUGHNESS, p + GI_C_P_ROUGHNESS, 1);
@@ -566,7 +583,7 @@ namespace gtl
         {"coat_weight", 1}, {"coat_color", 3}, {"coat_roughness", 1}, {"coat_ior", 1}, {"coat_darkening", 1}, {"emission_luminance", 1}, {"emission_color", 3},
         {"geometry_opacity", 1}, {"fuzz_weight", 1}, {"fuzz_color", 3}, {"fuzz_roughness", 1}, {"geometry_thin_walled", 1},
         {"subsurface_weight", 1}, {"subsurface_color", 3}, {"subsurface_scatter_anisotropy", 1}, {"specular_roughness_anisotropy", 1},
-            {"coat_roughness_anisotropy", 1},
+            {"coat_roughness_anisotropy", 1}, {"coat_rotation", 1},
         {"thin_film_weight", 1}, {"thin_film_thickness", 1}, {"thin_film_ior", 1}};
       for (const auto& k : kOpbr) {
         float v[3];

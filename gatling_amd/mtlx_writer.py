@@ -55,17 +55,35 @@ def _inputs(m: S.MaterialDesc):
         ("subsurface_scatter_anisotropy", "float", _f(p[S.P_SUBSURFACE_ANISOTROPY])),
         ("subsurface_radius", "float", _f(p[S.P_SUBSURFACE_RADIUS])), ("subsurface_radius_scale", "color3", _vals(p, S.P_SUBSURFACE_RADIUS_SCALE, 3)),
         ("specular_roughness_anisotropy", "float", _f(p[S.P_SPECULAR_ANISOTROPY])), ("coat_roughness_anisotropy", "float", _f(p[S.P_COAT_ANISOTROPY])),
+        # [ext] the turn of the coat's tangent as a plain float on the surface node (round-trips every float32); material_to_mtlx(coat_tangent="rotate3d")
+        # writes the spelling documents use for geometry_coat_tangent instead
+        ("coat_rotation", "float", _f(p[S.P_COAT_ROTATION])),
         ("thin_film_weight", "float", _f(p[S.P_THIN_FILM_WEIGHT])), ("thin_film_thickness", "float", _f(p[S.P_THIN_FILM_THICKNESS])), ("thin_film_ior", "float", _f(p[S.P_THIN_FILM_IOR])),
         # the parameter block keeps luminance x colour: luminance 1 and the product as the colour reproduce it exactly
         ("emission_luminance", "float", "1" if em.any() else "0"), ("emission_color", "color3", _vals(p, S.P_EMISSION, 3) if em.any() else "1, 1, 1"),
         ("geometry_opacity", "float", _f(p[S.P_OPACITY]))]
 
 
-def material_to_mtlx(m: S.MaterialDesc, form: str = "direct") -> str:
+def material_to_mtlx(m: S.MaterialDesc, form: str = "direct", coat_tangent: str = "ext") -> str:
+    """``coat_tangent="rotate3d"`` spells the coat tangent's turn the way documents feed ``geometry_coat_tangent`` (open_pbr_surface.mtlx:91, 561):
+    ``<rotate3d in=<tangent> amount=degrees axis=<normal>>`` behind a ``<normalize>`` (the shim divides the degrees by 360, so only turns whose degrees are
+    exact round-trip bit for bit); the default writes the [ext] ``coat_rotation`` float."""
     cat, inputs = _inputs(m)
+    extra, tail = "", ""
+    if coat_tangent == "rotate3d" and cat == "open_pbr_surface":
+        deg = _f(np.float32(m.params[S.P_COAT_ROTATION]) * np.float32(360.0))
+        inputs = [i for i in inputs if i[0] != "coat_rotation"]
+        extra = (f'<tangent name="T_{m.name}" type="vector3"><input name="space" type="string" value="world" /></tangent>'
+                 f'<normal name="N_{m.name}" type="vector3"><input name="space" type="string" value="world" /></normal>'
+                 f'<rotate3d name="R_{m.name}" type="vector3"><input name="in" type="vector3" nodename="T_{m.name}" />'
+                 f'<input name="amount" type="float" value="{deg}" /><input name="axis" type="vector3" nodename="N_{m.name}" /></rotate3d>'
+                 f'<normalize name="CT_{m.name}" type="vector3"><input name="in" type="vector3" nodename="R_{m.name}" /></normalize>')
+        tail = f'<input name="geometry_coat_tangent" type="vector3" nodename="CT_{m.name}" />'
+    elif coat_tangent != "ext":
+        raise ValueError(coat_tangent)
     if form == "direct":
         body = "".join(f'<input name="{n}" type="{t}" value="{v}" />' for n, t, v in inputs)
-        return f'<?xml version="1.0"?><materialx version="1.38"><{cat} name="SR_{m.name}" type="surfaceshader">{body}</{cat}></materialx>'
+        return f'<?xml version="1.0"?><materialx version="1.38">{extra}<{cat} name="SR_{m.name}" type="surfaceshader">{body}{tail}</{cat}></materialx>'
     if form != "nodegraph":
         raise ValueError(form)
     ng, conn = [], []
@@ -73,6 +91,6 @@ def material_to_mtlx(m: S.MaterialDesc, form: str = "direct") -> str:
         ct = "float" if t in ("integer", "boolean") else t  # (the patchers turn int / bool constants into floats; the shim parses true / false as well)
         ng.append(f'<constant name="c{i}" type="{ct}"><input name="value" type="{ct}" value="{v}" /></constant><output name="out_{n}" type="{ct}" nodename="c{i}" />')
         conn.append(f'<input name="{n}" type="{t}" nodegraph="NG_{m.name}" output="out_{n}" />')
-    return (f'<?xml version="1.0"?><materialx version="1.38"><nodegraph name="NG_{m.name}">{"".join(ng)}</nodegraph>'
-            f'<{cat} name="SR_{m.name}" type="surfaceshader">{"".join(conn)}</{cat}>'
+    return (f'<?xml version="1.0"?><materialx version="1.38"><nodegraph name="NG_{m.name}">{"".join(ng)}</nodegraph>{extra}'
+            f'<{cat} name="SR_{m.name}" type="surfaceshader">{"".join(conn)}{tail}</{cat}>'
             f'<surfacematerial name="{m.name}" type="material"><input name="surfaceshader" type="surfaceshader" nodename="SR_{m.name}" /></surfacematerial></materialx>')

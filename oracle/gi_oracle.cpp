@@ -922,6 +922,9 @@ inline V3 to_world(const State& st, V3 l) { return (st.tangentU * l.x + st.tange
 inline V3 to_local(const State& st, V3 w) { return v3(dot(w, st.tangentU), dot(w, st.tangentV), dot(w, st.normal)); }
 inline V3 to_world_coat(const State& st, V3 l) { return st.hasCoatFrame ? (st.coatTangentU * l.x + st.coatTangentV * l.y) + st.coatNormal * l.z : to_world(st, l); }
 inline V3 to_local_coat(const State& st, V3 w) { return st.hasCoatFrame ? v3(dot(w, st.coatTangentU), dot(w, st.coatTangentV), dot(w, st.coatNormal)) : to_local(st, w); }
+// geometry_coat_tangent: the turn applied to the local x / y of a direction in the coat's frame (c, s: opbr_params)
+inline V3 coat_turn_local(float c, float s, V3 l) { return v3(l.x * c + l.y * s, l.y * c - l.x * s, l.z); }
+inline V3 coat_turn_world(float c, float s, V3 l) { return v3(l.x * c - l.y * s, l.x * s + l.y * c, l.z); }
 
 inline float schlick_w(float c) { float m = 1.0f - c; m = fmin2(fmax2(m, 0.0f), 1.0f); float m2 = m * m; return m2 * m2 * m; }
 inline float ggx_lambda_term(float a2, float c) { return sqrtf(a2 + (1.0f - a2) * c * c); }
@@ -1127,7 +1130,7 @@ inline V3 eon_pi_f(V3 rho, float r, V3 l1, V3 l2)
   const V3 rhoMs = v3((rr.x * avgEF) / (1.0f - rho.x * (1.0f - avgEF)), (rr.y * avgEF) / (1.0f - rho.y * (1.0f - avgEF)), (rr.z * avgEF) / (1.0f - rho.z * (1.0f - avgEF)));
   return rho * ss + rhoMs * ms;
 }
-struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, sigmaA, sigmaS, baseColor, coatColor, ssColor, fuzzColor, sssSigmaS, sssSigmaT; bool ssVolume; float metalness, alpha, alphaY, coat, coatAlpha, coatAlphaY, coatF0, eta, tw, specWeight, anisotropy, baseWeight, diffRough, ssWeight, ssAniso, fuzzWeight, fuzzAlpha, filmWeight, filmNm, filmIor; bool thinWalled; };
+struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, sigmaA, sigmaS, baseColor, coatColor, ssColor, fuzzColor, sssSigmaS, sssSigmaT; bool ssVolume; float metalness, alpha, alphaY, coat, coatAlpha, coatAlphaY, coatF0, eta, tw, specWeight, anisotropy, baseWeight, diffRough, ssWeight, ssAniso, fuzzWeight, fuzzAlpha, filmWeight, filmNm, filmIor; bool thinWalled;  bool coatRot; float coatRotC, coatRotS; };
 inline OpbrParams opbr_params(const OrcMaterial& m, bool sssVolume = false)
 {
   OpbrParams o; const float* p = m.p;
@@ -1143,6 +1146,10 @@ inline OpbrParams opbr_params(const OrcMaterial& m, bool sssVolume = false)
   r = opbr_effective_roughness(r, cr, o.coat);
   o.alpha = fmax2(r * r, 0.001f); o.coatAlpha = fmax2(cr * cr, 0.001f);
   opbr_anisotropy(o.alpha, p[ORC_P_SPECULAR_ANISOTROPY], o.alpha, o.alphaY); opbr_anisotropy(o.coatAlpha, p[ORC_P_COAT_ANISOTROPY], o.coatAlpha, o.coatAlphaY); // :133-136, 552-555
+  // geometry_coat_tangent (:91, 561: the coat's dielectric_bsdf takes a tangent of its own).  Modelled in the form a document binds to it -- rotate3d of Tworld about
+  // the normal, Standard Surface's coat_rotation: the frame's tangent turned by p[36] turns towards its bitangent.  Only an anisotropic coat can tell.
+  o.coatRot = p[ORC_P_CLEARCOAT] > 0.0f && p[ORC_P_COAT_ANISOTROPY] > 0.0f && p[ORC_P_COAT_ROTATION] != 0.0f; o.coatRotC = 1.0f; o.coatRotS = 0.0f;
+  if (o.coatRot) { const float a = 6.2831855f * p[ORC_P_COAT_ROTATION]; o.coatRotC = cosf(a); o.coatRotS = sinf(a); }
   float cior = p[ORC_P_COAT_IOR]; float qc = (cior - 1.0f) / (cior + 1.0f); o.coatF0 = qc * qc;
   V3 cc = v3(p + ORC_P_COAT_COLOR); o.coatColor = cc; o.coatTint = v3(1, 1, 1) * (1.0f - o.coat) + cc * o.coat;
   // coat_substrate_attenuated = base_substrate * modulated_base_darkening * coat_attenuation (:538-552)
@@ -1313,10 +1320,11 @@ static void opbr_sample_base(const OpbrParams& o, const State& st, V3 k1, const 
   // the coat lobe lives in its own frame when geometry_coat_normal is mapped (:560); its Fresnel term -- lobe probability and what it leaves for the base -- follows
   V3 l1c = l1; float nk1c = nk1;
   if (st.hasCoatFrame) { l1c = to_local_coat(st, k1); nk1c = fmax2(l1c.z, 1e-4f); l1c.z = nk1c; }
+  if (o.coatRot) l1c = coat_turn_local(o.coatRotC, o.coatRotS, l1c);
   float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1c));
   if (z < Fc) { // coat reflection
     GgxOut g = ggx_sample2(l1c, o.coatAlpha, o.coatAlphaY, xi[0], xi[1]);
-    V3 k2 = to_world_coat(st, g.l2);
+    V3 k2 = to_world_coat(st, o.coatRot ? coat_turn_world(o.coatRotC, o.coatRotS, g.l2) : g.l2);
     if (!g.valid || !(dot(k2, st.geomNormal) > 0.0f)) return;
     float Fh = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(g.kh));
     float w = (Fh / Fc) * g.g2OverG1;
@@ -1441,6 +1449,7 @@ static void opbr_evaluate_base(const OpbrParams& o, const State& st, V3 k1, V3 k
   float eta = relative_eta(st, o.eta); (void)frontFace;
   V3 l1c = l1, l2c = l2; float nk1c = nk1; // the coat lobe's own frame (geometry_coat_normal)
   if (st.hasCoatFrame) { l1c = to_local_coat(st, k1); nk1c = fmax2(l1c.z, 1e-4f); l1c.z = nk1c; l2c = to_local_coat(st, k2); }
+  if (o.coatRot) { l1c = coat_turn_local(o.coatRotC, o.coatRotS, l1c); l2c = coat_turn_local(o.coatRotC, o.coatRotS, l2c); }
   float Fc = o.coat * (o.coatF0 + (1.0f - o.coatF0) * schlick_w(nk1c));
   float Fd = fresnel_dielectric(nk1, eta);
   float fc, pc, khc; ggx_eval2(l1c, l2c, o.coatAlpha, o.coatAlphaY, fc, pc, khc);

@@ -438,6 +438,35 @@ def test_coat_normal_on_device(gi, orc):
     assert np.array_equal(got[..., :3].view(np.uint32), want[..., :3].view(np.uint32))
 
 
+def test_coat_tangent_on_device(gi, orc):
+    """OpenPBR geometry_coat_tangent as a turn of the coat's tangent (GI_C_P_COAT_ROTATION; gi_shading.h coat_turn_local / coat_turn_world, cosine and sine from the
+    host in MaterialRec::sss[6..7]): an anisotropic coat with its tangent turned, sampled and evaluated (NEE) -- on the coated ball alone, with a coat normal map (the
+    turn applies inside the map's frame), beside an untouched material in one scene, through the fused kernels (no NEE) and with a medium stack: device == oracle
+    bit for bit; the turn changes the image; the class the material is binned to is the full OpenPBR one."""
+    from test_oracle_render import _coated_ball
+    yy, xx = np.mgrid[0:32, 0:64]
+    bumpy = np.zeros((32, 64, 4), np.float32)
+    bumpy[..., 0] = 0.5 + 0.35 * np.sin(xx * 1.7); bumpy[..., 1] = 0.5 + 0.35 * np.cos(yy * 2.3); bumpy[..., 2] = 0.85; bumpy[..., 3] = 1.0
+    def ball(turn, coat_map=None):
+        d = _coated_ball(coat_map)
+        d.materials[0].params = MaterialDesc.open_pbr(base_color=(0.05, 0.05, 0.05), specular_weight=0.0, coat_weight=1.0, coat_roughness=0.3, coat_ior=1.6,
+                                                      coat_roughness_anisotropy=0.85, coat_rotation=turn).params
+        return d
+    rs = RenderSettings(spp=6, max_bounces=4, next_event_estimation=True)
+    plain, _, _ = render_both(gi, orc, ball(0.0), rs, 64, 64, exact=True)
+    turned, _, _ = render_both(gi, orc, ball(0.125), rs, 64, 64, exact=True)
+    assert not np.array_equal(plain, turned)
+    render_both(gi, orc, ball(0.3, bumpy), rs, 64, 64, exact=True)
+    render_both(gi, orc, ball(-0.2), RenderSettings(spp=5, max_bounces=5), 48, 48, exact=True)
+    render_both(gi, orc, ball(0.7), RenderSettings(spp=4, max_bounces=5, next_event_estimation=True, medium_stack_size=3), 48, 48, exact=True)
+    desc = textured_scene()
+    b = desc.materials[1]
+    assert b.klass == MAT_OPEN_PBR
+    b.params = MaterialDesc.open_pbr(base_color=(0.8, 0.8, 0.8), specular_roughness=0.25, coat_weight=0.8, coat_roughness=0.2, coat_color=(0.9, 0.8, 0.7),
+                                     coat_roughness_anisotropy=0.6, coat_rotation=0.45).params
+    render_both(gi, orc, desc, RenderSettings(spp=4, max_bounces=6, next_event_estimation=True), 96, 54, exact=True)
+
+
 def test_textured_transmission_inputs_on_device(gi, orc):
     """OpenPBR transmission_weight / transmission_color resolved per hit (slots 7 / 8; gi_shading.h resolve_material_textures, opbr_params): a weight map, a colour map
     with a texture-coordinate transform, both from scene data (per-vertex weight, constant colour), and with a transmission_depth -- where the colour is the medium's
@@ -647,6 +676,12 @@ def test_bsdf_known_answers_on_device(gi, orc):
             MaterialDesc.open_pbr(base_color=(0.4, 0.6, 0.8), transmission_weight=0.7, specular_roughness=0.3, specular_roughness_anisotropy=0.5, specular_ior=1.4),
             MaterialDesc.open_pbr(base_color=(0.6, 0.3, 0.3), specular_roughness=0.4, coat_weight=0.9, coat_roughness=0.35, coat_roughness_anisotropy=0.95, fuzz_weight=0.2),
             MaterialDesc.open_pbr(base_color=(0.5, 0.5, 0.5), specular_roughness=0.2, specular_roughness_anisotropy=1.0, coat_weight=0.3, coat_roughness=0.1, coat_roughness_anisotropy=0.3),
+            # geometry_coat_tangent (open_pbr_surface.mtlx:91, 561) as a turn of the coat's tangent: alone, over an anisotropic metal, negative / beyond one turn with fuzz
+            MaterialDesc.open_pbr(base_color=(0.5, 0.5, 0.5), specular_weight=0.0, coat_weight=1.0, coat_ior=3.0, coat_roughness=0.3, coat_roughness_anisotropy=0.75, coat_rotation=0.125),
+            MaterialDesc.open_pbr(base_color=(0.9, 0.8, 0.6), base_metalness=1.0, specular_roughness=0.4, specular_roughness_anisotropy=0.7, coat_weight=0.6, coat_roughness=0.25,
+                                  coat_roughness_anisotropy=0.5, coat_rotation=0.3),
+            MaterialDesc.open_pbr(base_color=(0.6, 0.3, 0.3), specular_roughness=0.4, coat_weight=0.9, coat_roughness=0.35, coat_roughness_anisotropy=0.95, fuzz_weight=0.2, coat_rotation=-1.71),
+            MaterialDesc.open_pbr(base_color=(0.6, 0.3, 0.3), coat_weight=0.9, coat_roughness=0.35, coat_roughness_anisotropy=0.0, coat_rotation=0.4),   # isotropic coat: not read
             # thin film (open_pbr_surface.mtlx:300-304, 404-431, 450-464): on a dielectric with transmission (front and back faces: relative indices), on a metal, with everything else on
             MaterialDesc.open_pbr(base_color=(0.7, 0.7, 0.7), transmission_weight=0.6, specular_roughness=0.2, thin_film_weight=1.0, thin_film_thickness=0.35, thin_film_ior=1.8),
             MaterialDesc.open_pbr(base_color=(0.9, 0.6, 0.4), base_metalness=1.0, specular_roughness=0.3, thin_film_weight=0.8, thin_film_thickness=0.6, thin_film_ior=1.33),

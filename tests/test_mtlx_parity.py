@@ -29,9 +29,32 @@ def _edge_cases():
             M.open_pbr(name="fuzz", fuzz_weight=0.5, fuzz_color=(0.2, 0.3, 0.4), fuzz_roughness=0.8),
             M.open_pbr(name="soap", transmission_weight=0.8, specular_roughness=0.05, thin_film_weight=1.0, thin_film_thickness=0.3, thin_film_ior=1.33),
             M.open_pbr(name="brushed", base_metalness=1.0, specular_roughness=0.35, specular_roughness_anisotropy=0.7, coat_weight=0.4, coat_roughness=0.2, coat_roughness_anisotropy=0.25),
+            M.open_pbr(name="combed", coat_weight=0.7, coat_roughness=0.3, coat_roughness_anisotropy=0.8, coat_rotation=0.3137),
             M.open_pbr(name="wax", subsurface_weight=0.8, subsurface_color=(0.9, 0.5, 0.3), subsurface_radius=0.15, subsurface_radius_scale=(1.0, 0.6, 0.2), subsurface_scatter_anisotropy=0.3),
             M.usd_preview_surface(name="spec", useSpecularWorkflow=1, specularColor=(0.3, 0.4, 0.5), diffuseColor=(0.6, 0.1, 0.05), roughness=0.23, ior=1.7),
             M.usd_preview_surface(name="cut", opacity=0.37, opacityThreshold=0.5, emissiveColor=(0.5, 1.5, 2.5), clearcoat=0.7, clearcoatRoughness=0.2, metallic=0.33)]
+
+
+def test_coat_tangent_spellings_read_back():
+    """geometry_coat_tangent (open_pbr_surface.mtlx:91, 561) fed the way documents feed it -- <rotate3d in=<tangent> amount=degrees axis=<normal>> behind a
+    <normalize>, on the surface node or next to a nodegraph -- reads back as the turn (degrees / 360, exact for these), a bare rotate3d too; anything else
+    upstream keeps the geometry tangent; Standard Surface's coat_rotation is the same turn."""
+    L = capi.load_library()
+    for turns in (0.125, 0.25, -0.5, 0.75):
+        m = S.MaterialDesc.open_pbr(name="combed", coat_weight=0.7, coat_roughness=0.3, coat_roughness_anisotropy=0.8, coat_rotation=turns)
+        for form in ("direct", "nodegraph"):
+            doc = material_to_mtlx(m, form, coat_tangent="rotate3d")
+            assert "coat_rotation" not in doc and "rotate3d" in doc
+            d = _desc_from_doc(L, doc)
+            assert d is not None and np.array_equal(np.frombuffer(bytes(d.p), np.uint32), np.asarray(m.params, np.float32).view(np.uint32)), (turns, form)
+        bare = material_to_mtlx(m, "direct", coat_tangent="rotate3d").replace('nodename="CT_combed"', 'nodename="R_combed"')
+        assert _desc_from_doc(L, bare).p[S.P_COAT_ROTATION] == np.float32(turns)
+        other = material_to_mtlx(m, "direct", coat_tangent="rotate3d").replace('nodename="CT_combed"', 'nodename="T_combed"')   # the plain tangent
+        assert _desc_from_doc(L, other).p[S.P_COAT_ROTATION] == 0.0
+    ss = ('<materialx version="1.38"><standard_surface name="s" type="surfaceshader"><input name="coat" type="float" value="0.6" />'
+          '<input name="coat_anisotropy" type="float" value="0.5" /><input name="coat_rotation" type="float" value="0.2" /></standard_surface></materialx>')
+    d = _desc_from_doc(L, ss)
+    assert d.klass == S.MAT_OPEN_PBR and d.p[S.P_COAT_ROTATION] == np.float32(0.2) and d.p[S.P_COAT_ANISOTROPY] == np.float32(0.5)
 
 
 def _c4_sets():

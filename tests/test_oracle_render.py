@@ -255,6 +255,71 @@ def test_specular_anisotropy(orc):
     assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32))
 
 
+def test_coat_tangent(orc):
+    """open_pbr_surface.mtlx:91, 561 (geometry_coat_tangent feeds the coat's dielectric_bsdf a tangent of its own), in the form documents bind it:
+    the geometry tangent turned by coat_rotation turns towards the bitangent.  The stretch of an anisotropic coat's micro-normals follows the turned axes; a
+    quarter turn is the frame with tangent and bitangent exchanged; half a turn is no turn (GGX is even); without an anisotropic coat the input is not read
+    (bit for bit); evaluate stays reciprocal and consistent with sampling; nothing beneath the coat moves."""
+    rng = np.random.default_rng(61)
+    r, a = 0.3, 0.75
+    at = r * r * np.sqrt(2.0 / (1.0 + (1.0 - a) ** 2)); ab = (1.0 - a) * at
+    # only the coat reflects glossily: no specular reflection beneath it (specular_weight 0), a dense coat so that a quarter of the samples take it
+    def mat(rot, **kw):
+        d = dict(base_color=(0.5, 0.5, 0.5), specular_weight=0.0, coat_weight=1.0, coat_ior=3.0, coat_roughness=r, coat_roughness_anisotropy=a, coat_rotation=rot)
+        d.update(kw)
+        return MaterialDesc.open_pbr(**d)
+    items = _frames(400000, rng, 1.0)
+    for turns in (0.0, 0.125, 0.3):
+        out = orc.bsdf_debug(mat(turns), items)
+        coat = out[:, 7].astype(int) == (2 | 8)             # EV_GLOSSY | EV_REFLECTION
+        assert 0.15 < coat.mean() < 0.35
+        h = out[coat, 0:3] + np.float32([0, 0, 1]); h /= np.linalg.norm(h, axis=1, keepdims=True)
+        c, s_ = np.cos(2 * np.pi * turns), np.sin(2 * np.pi * turns)
+        sx = np.abs((h[:, 0] * c + h[:, 1] * s_) / h[:, 2]); sy = np.abs((h[:, 1] * c - h[:, 0] * s_) / h[:, 2])
+        np.testing.assert_allclose(np.median(sx) / np.median(sy), at / ab, rtol=0.06)
+        np.testing.assert_allclose(np.median(sx), at * 0.5774, rtol=0.07)
+    # an eighth of a turn: the stretch lies on the diagonal, the geometry axes see the same spread
+    h = out = None
+    o8 = orc.bsdf_debug(mat(0.125), items); c8 = o8[:, 7].astype(int) == 10
+    h8 = o8[c8, 0:3] + np.float32([0, 0, 1]); h8 /= np.linalg.norm(h8, axis=1, keepdims=True)
+    np.testing.assert_allclose(np.median(np.abs(h8[:, 0])) / np.median(np.abs(h8[:, 1])), 1.0, rtol=0.05)
+    # a quarter turn == the frame (tangentV, -tangentU) without a turn; half a turn == no turn (to rounding: cos / sin of the fp32 angle)
+    ev = _frames(20000, rng, 0.45)
+    swapped = ev.copy(); swapped[:, 3:6] = ev[:, 6:9]; swapped[:, 6:9] = -ev[:, 3:6]
+    q, f0 = orc.bsdf_debug(mat(0.25), ev), orc.bsdf_debug(mat(0.0), swapped)
+    np.testing.assert_allclose(q[:, 8:15], f0[:, 8:15], rtol=2e-4, atol=2e-6)
+    same = (q[:, 7] == f0[:, 7]) & (q[:, 7] == 10)          # the coat's own samples (the diffuse base beneath follows the exchanged frame, as it must)
+    assert same.sum() > 2000 and (q[:, 7] == f0[:, 7]).mean() > 0.999
+    np.testing.assert_allclose(q[same, 0:7], f0[same, 0:7], rtol=2e-3, atol=2e-5)
+    hlf, z = orc.bsdf_debug(mat(0.5), ev), orc.bsdf_debug(mat(0.0), ev)
+    np.testing.assert_allclose(hlf[:, 8:15], z[:, 8:15], rtol=2e-4, atol=2e-6)
+    assert not np.allclose(orc.bsdf_debug(mat(0.125), ev)[:, 11:14], z[:, 11:14], rtol=1e-2)      # ... and an eighth is a different material
+    # not read without an anisotropic coat: bit for bit the material without the input
+    for kw in (dict(coat_roughness_anisotropy=0.0), dict(coat_weight=0.0), dict(coat_weight=0.0, specular_weight=1.0, specular_roughness_anisotropy=0.6)):
+        a0, a1 = orc.bsdf_debug(mat(0.0, **kw), ev), orc.bsdf_debug(mat(0.37, **kw), ev)
+        assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32)), kw
+    # the lobes beneath keep the surface's frame: an anisotropic metal under a turned, isotropic-looking... (the base's glossy samples do not move)
+    under = dict(base_metalness=1.0, specular_weight=1.0, specular_roughness=0.35, specular_roughness_anisotropy=0.7, coat_ior=1.5)
+    b0, b1 = orc.bsdf_debug(mat(0.0, **under), ev), orc.bsdf_debug(mat(0.2, **under), ev)
+    metal = (b0[:, 7] == b1[:, 7]) & (ev[:, 20] >= 0.3)      # xi.z above the coat's share at this incidence: the metal lobe on both sides
+    assert metal.sum() > 5000 and np.array_equal(b0[metal, 0:3].view(np.uint32), b1[metal, 0:3].view(np.uint32))
+    # reciprocity of the turned coat's evaluate / cos, and evaluate == sampling
+    n = 4000
+    u = rng.normal(size=(n, 3)); u[:, 2] = np.abs(u[:, 2]) + 0.2; u /= np.linalg.norm(u, axis=1, keepdims=True)
+    v = rng.normal(size=(n, 3)); v[:, 2] = np.abs(v[:, 2]) + 0.2; v /= np.linalg.norm(v, axis=1, keepdims=True)
+    base = _frames(n, rng, 0.5)
+    uv = base.copy(); uv[:, 12:15] = u; uv[:, 15:18] = v
+    vu = base.copy(); vu[:, 12:15] = v; vu[:, 15:18] = u
+    black = mat(0.2, base_color=(0, 0, 0))                   # the coat alone (its Fresnel factor depends on k.h only: symmetric)
+    fuv = orc.bsdf_debug(black, uv)[:, 11] / v[:, 2]; fvu = orc.bsdf_debug(black, vu)[:, 11] / u[:, 2]
+    np.testing.assert_allclose(fuv, fvu, rtol=3e-4, atol=1e-6)
+    big = _frames(300000, rng, 0.7)
+    o = orc.bsdf_debug(mat(0.2), big)
+    refl = (o[:, 7].astype(int) & 8) != 0
+    np.testing.assert_allclose((o[:, 8:11] + o[:, 11:14]).mean(axis=0) * (2 * np.pi), (o[:, 3:6] * refl[:, None]).mean(axis=0), rtol=0.06, atol=0.01)
+    np.testing.assert_allclose(o[:, 14].mean() * 2 * np.pi, refl.mean(), rtol=0.06, atol=0.01)
+
+
 def test_thin_film(orc):
     """open_pbr_surface.mtlx:300-304, 404-431, 450-464: thin_film_weight mixes a film's interference into the Fresnel factor of the dielectric and metal lobes.
     Our closed form is the Airy summation at three wavelengths (oracle/gi_oracle.cpp "thin film").  Known answers of the reflectance: a film of zero or

@@ -91,3 +91,14 @@ def test_round_tripped_scene_renders_identically(orc, tmp_path):
     ia, _ = orc.render(a, rs, 48, 27)
     ib, _ = orc.render(b, rs, 48, 27)
     assert np.array_equal(ia, ib)
+
+
+def test_usda_keeps_the_coat_tangent_turn(tmp_path):
+    """geometry_coat_tangent as the [ext] coat_rotation float of the flat OpenPBR vocabulary (usda_writer OPEN_PBR_INPUTS, gtl_shim.cpp kOpbr): the block comes back bit for bit."""
+    from gatling_amd.scene import P_COAT_ROTATION, MaterialDesc
+    a = SCENES[sorted(SCENES)[0]]()
+    a.materials[0] = MaterialDesc.open_pbr(name=a.materials[0].name, coat_weight=0.6, coat_roughness=0.3, coat_roughness_anisotropy=0.4, coat_rotation=0.3137)
+    write_usda(tmp_path / "s.usda", a)
+    b = load_usda(str(tmp_path / "s.usda"))
+    assert b.materials[0].params[P_COAT_ROTATION] == np.float32(0.3137)
+    assert np.array_equal(np.asarray(a.materials[0].params, np.float32).view(np.uint32), np.asarray(b.materials[0].params, np.float32).view(np.uint32))
