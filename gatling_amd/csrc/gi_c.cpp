@@ -142,14 +142,22 @@ void deriveMaterialConstants(MaterialRec& m)
       }
       m.sss[6] = 1.0f; m.sss[7] = 0.0f;
     }
-    // geometry_coat_tangent (open_pbr_surface.mtlx:91, 561) as the turn of the frame's tangent a document binds to it: only an anisotropic coat can tell
-    // (the oracle's condition, opbr_params; the same two libm calls on the same angle)
-    const bool coatTurned = p[GI_C_P_CLEARCOAT] > 0.0f && p[GI_C_P_COAT_ANISOTROPY] > 0.0f && p[GI_C_P_COAT_ROTATION] != 0.0f;
+    // geometry_tangent / geometry_coat_tangent (open_pbr_surface.mtlx:89, 91; 385 ... 457, 561) as the turns of the frame's tangent documents bind to them:
+    // only anisotropic lobes can tell (the oracle's conditions, opbr_params; the same libm calls on the same angles).  sss[6..7]: the coat's turn, [8..9]: the base
+    // lobes', [10..11]: the coat's relative to the turned base frame (k_shade turns the frame in place; a coat without a frame of its own starts from there)
+    const bool specTurned = p[GI_C_P_SPECULAR_ANISOTROPY] > 0.0f && p[GI_C_P_SPECULAR_ROTATION] != 0.0f;
+    const bool coatTurned = p[GI_C_P_CLEARCOAT] > 0.0f && p[GI_C_P_COAT_ANISOTROPY] > 0.0f && (p[GI_C_P_COAT_ROTATION] != 0.0f || specTurned);
+    m.sss[8] = 1.0f; m.sss[9] = 0.0f; m.sss[10] = 1.0f; m.sss[11] = 0.0f;
     if (coatTurned) { const float a = 6.2831855f * p[GI_C_P_COAT_ROTATION]; m.sss[6] = cosf(a); m.sss[7] = sinf(a); }
+    if (specTurned) {
+      const float a = 6.2831855f * p[GI_C_P_SPECULAR_ROTATION], r = 6.2831855f * (p[GI_C_P_COAT_ROTATION] - p[GI_C_P_SPECULAR_ROTATION]);
+      m.sss[8] = cosf(a); m.sss[9] = sinf(a); m.sss[10] = cosf(r); m.sss[11] = sinf(r);
+    }
     out[MP_FEATURES] = (float)((p[GI_C_P_THIN_WALLED] != 0.0f ? MATF_THIN_WALLED : 0u) | (p[GI_C_P_FUZZ_WEIGHT] > 0.0f ? MATF_FUZZ : 0u) |
                                ((p[GI_C_P_THIN_WALLED] == 0.0f && p[GI_C_P_SUBSURFACE_WEIGHT] > 0.0f) ? MATF_SSS_VOLUME : 0u) |
                                ((p[GI_C_P_SPECULAR_ANISOTROPY] > 0.0f || p[GI_C_P_COAT_ANISOTROPY] > 0.0f) ? MATF_ANISOTROPY : 0u) |
-                               (p[GI_C_P_THIN_FILM_WEIGHT] > 0.0f ? MATF_THIN_FILM : 0u) | (coatTurned ? MATF_COAT_ROTATION : 0u));
+                               (p[GI_C_P_THIN_FILM_WEIGHT] > 0.0f ? MATF_THIN_FILM : 0u) | (coatTurned ? MATF_COAT_ROTATION : 0u) |
+                               (specTurned ? MATF_SPEC_ROTATION : 0u));
     memcpy(m.p, out, sizeof(out));
     return;
   }

@@ -105,6 +105,7 @@ __global__ void k_debug_bsdf(const MaterialRec* mat, uint32_t shadeClass, uint32
   st.u = 0.0f; st.v = 0.0f; st.texMask = 0u; st.ior1 = 0.0f; st.ior2 = 0.0f;
       st.thinWalled = mat->klass == 2u && ((uint32_t)mat->p[MP_FEATURES] & MATF_THIN_WALLED) != 0u; st.sssVolume = false; st.hasCoatFrame = false; st.mesh = 0u;
       st.prim = 0u; st.vi[0] = st.vi[1] = st.vi[2] = 0u; st.instanceId = 0; st.hu = st.hv = 0.0f;
+  if (mat->klass == 2u && ((uint32_t)mat->p[MP_FEATURES] & MATF_SPEC_ROTATION)) spec_turn_frame(mat, st); // geometry_tangent, as the shade stage does
   BsdfSample bs; BsdfEval ev;
   if (shadeClass == SHADE_CLASS_OPBR_BASE) { bsdf_sample<SHADE_CLASS_OPBR_BASE>(mat, st, v3(p + 12), p[18], p[19], p[20], bs);
       bsdf_evaluate<SHADE_CLASS_OPBR_BASE>(mat, st, v3(p + 12), v3(p + 15), ev); }

@@ -491,6 +491,16 @@ __device__ __forceinline__ V3 coat_turn_local(const OpbrParams& o, V3 l)
 { return v3(l.x * o.coatRotC + l.y * o.coatRotS, l.y * o.coatRotC - l.x * o.coatRotS, l.z); }
 __device__ __forceinline__ V3 coat_turn_world(const OpbrParams& o, V3 l)
 { return v3(l.x * o.coatRotC - l.y * o.coatRotS, l.x * o.coatRotS + l.y * o.coatRotC, l.z); }
+// geometry_tangent (open_pbr_surface.mtlx:89; 385, 402, 410, 449, 457: the tangent of the dielectric and conductor lobes) in the form documents feed it -- the
+// geometry tangent turned about the normal (Standard Surface's specular_rotation, glTF's anisotropy_rotation): the shading frame's tangents are turned IN PLACE
+// once per hit, before the BSDF runs (no lobe beneath the coat can tell a turned frame from a turned tangent: the diffuse lobes depend on the normal only).
+// Called by the shade stage and the BSDF debug kernel for OpenPBR materials with MATF_SPEC_ROTATION; == oracle opbr_enter.
+__device__ __forceinline__ void spec_turn_frame(const MaterialRec* m, ShState& st)
+{
+  const float c = m->sss[8], s = m->sss[9];
+  const V3 tu = st.tangentU * c + st.tangentV * s, tv = st.tangentV * c - st.tangentU * s;
+  st.tangentU = tu; st.tangentV = tv;
+}
 __device__ __forceinline__ OpbrParams opbr_params(const MaterialRec* m, const ShState& st)
 {
   OpbrParams o; const float* p = m->p;
@@ -514,7 +524,10 @@ __device__ __forceinline__ OpbrParams opbr_params(const MaterialRec* m, const Sh
   // specular_roughness_anisotropy / coat_roughness_anisotropy
   if (feat & MATF_ANISOTROPY) { opbr_anisotropy(o.alpha, p[60], o.alpha, o.alphaY); opbr_anisotropy(o.coatAlpha, p[61], o.coatAlpha, o.coatAlphaY); }
   o.coatRot = (feat & MATF_COAT_ROTATION) != 0u; o.coatRotC = 1.0f; o.coatRotS = 0.0f;
-  if (o.coatRot) { o.coatRotC = m->sss[6]; o.coatRotS = m->sss[7]; } // geometry_coat_tangent
+  if (o.coatRot) { // geometry_coat_tangent; over a turned base frame (spec_turn_frame) a coat without a frame of its own takes its turn relative to that frame
+    const uint32_t at = ((feat & MATF_SPEC_ROTATION) && !st.hasCoatFrame) ? 10u : 6u;
+    o.coatRotC = m->sss[at]; o.coatRotS = m->sss[at + 1u];
+  }
   // coat_substrate_attenuated = base_substrate * modulated_base_darkening * coat_attenuation (open_pbr_surface.mtlx:538-552)
   o.coatTint = o.coatTint * opbr_base_darkening(o.baseColor, o.specWeight, o.metalness, o.coat, o.coatF0, p[22], p[48]);
   // thin-walled subsurface (open_pbr_surface.mtlx:140-196, 207-218); the volumetric form of non-thin-walled materials is not modelled

@@ -95,6 +95,8 @@ __device__ __forceinline__ void shade_segment(const FrameUniforms& U, const Scen
   setup_shading_state<PACKED>(sc, f2u(h.w), h.y, h.z, rayDir, ss);
   const MaterialRec* mat = &sc.materials[ss.material];
   if (TEXTURED && (mat->flags & MAT_FLAG_TEXTURED)) resolve_material_textures(sc, mat, rayDir, ss); // else ss.texMask stays 0 and folds away
+  // geometry_tangent: the base lobes' tangent turned (full OpenPBR class only: an anisotropic material is never BASE); after the coat's own frame was made
+  if ((KLASS == 2u || (KLASS == KLASS_DYNAMIC && mat->klass == 2u)) && ((uint32_t)mat->p[MP_FEATURES] & MATF_SPEC_ROTATION)) spec_turn_frame(mat, ss);
   const bool isDoubleSided = (ss.meshFlags & 2u) != 0u;
   // volume attenuation (rp_main.chit:160-186)
   float prevMediumIor = 1.0f, nextMediumIor = 1.0f;

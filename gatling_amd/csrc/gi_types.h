@@ -91,7 +91,10 @@ constexpr uint32_t MP_FEATURES = 54, MATF_THIN_WALLED = 1u, MATF_FUZZ = 2u, MATF
                    // (live in renders with a medium stack), coefficients in MaterialRec::sss
                    MATF_SSS_VOLUME = 16u,
                    // geometry_coat_tangent: an anisotropic coat whose tangent is turned (cosine / sine in MaterialRec::sss[6..7])
-                   MATF_COAT_ROTATION = 32u;
+                   MATF_COAT_ROTATION = 32u,
+                   // geometry_tangent: anisotropic base lobes whose tangent is turned: k_shade turns the shading frame's tangents in place before the
+                   // BSDF runs (cosine / sine in sss[8..9]; sss[10..11] = the coat's turn relative to that frame, for coats without a frame of their own)
+                   MATF_SPEC_ROTATION = 64u;
 enum : uint32_t { MP_ALBEDO = 32, MP_F0 = 35, MP_ALPHA = 38, MP_COAT = 39, MP_COAT_ALPHA = 40, MP_COAT_F0 = 41, MP_ETA = 42, MP_SIGMA_A = 43,
     MP_CUTOUT = 46 /* mdl_cutout_opacity, 1 = opaque */ };
 // Textured material inputs (UsdUVTexture semantics: value = texel * scale + bias at the hit's st).  Replaces the MDL
@@ -132,10 +135,10 @@ struct MaterialRec {
   float p[MAT_PARAM_COUNT];
   TexBindingRec tex[TEX_SLOT_COUNT];
   // volumetric subsurface medium (OpenPBR, derived on the host from subsurface_color / _radius / _radius_scale): sigma_s[3], sigma_t[3]; then the
-  // cosine and the sine of the coat tangent's turn (MATF_COAT_ROTATION)
-  float sss[8];
+  // cosine and the sine of the coat tangent's turn (MATF_COAT_ROTATION), of the base lobes' (MATF_SPEC_ROTATION), of the coat's relative to the latter
+  float sss[12];
 };
-static_assert(sizeof(MaterialRec) == 872, "MaterialRec must be 872 bytes");
+static_assert(sizeof(MaterialRec) == 888, "MaterialRec must be 888 bytes");
 // A texture: linear float RGBA texels, row 0 first.  (8-bit sources are decoded to linear float by the caller; a
 // compressed unorm8/half store is a later memory optimisation, the lookup arithmetic would not change.)
 struct TextureRec { const float* texels; uint32_t width, height; };

@@ -308,8 +308,8 @@ namespace gtl
       if (n.category == "standard_surface") {
         // Autodesk Standard Surface 1.0.1 (the reference compiles MaterialX's own standard_surface graph through MDL): read onto the OpenPBR closed forms,
         // input by input -- OpenPBR is that model's successor and keeps its layering (fuzz over coat over {metal | glass | subsurface | diffuse+specular}).
-        // Defaults are the Standard Surface specification's, not OpenPBR's.  coat_rotation (turns; the model's graph rotates the tangent by 360 x it about the
-        // normal) is the coat tangent's turn.  What has no counterpart is dropped: specular_rotation, transmission_dispersion, transmission_extra_roughness,
+        // Defaults are the Standard Surface specification's, not OpenPBR's.  specular_rotation / coat_rotation (turns; the model's graph rotates the tangent by
+        // 360 x it about the normal) are the tangents' turns.  What has no counterpart is dropped: transmission_dispersion, transmission_extra_roughness,
         // coat_affect_color / coat_affect_roughness, and coat_darkening stays 0 (the model has no such term).
         p[GI_C_P_BASE_WEIGHT] = 0.8f; p[GI_C_P_BASE_COLOR] = p[GI_C_P_BASE_COLOR + 1] = p[GI_C_P_BASE_COLOR + 2] = 1.0f; p[GI_C_P_ROUGHNESS] = 0.2f;
         p[GI_C_P_CLEARCOAT_ROUGHNESS] = 0.1f; p[GI_C_P_COAT_IOR] = 1.5f; p[GI_C_P_COAT_DARKENING] = 0.0f; p[GI_C_P_FUZZ_ROUGHNESS] = 0.3f;
@@ -333,7 +333,7 @@ namespace gtl
         setN(n, "sheen", p + GI_C_P_FUZZ_WEIGHT, 1); setN(n, "sheen_color", p + GI_C_P_FUZZ_COLOR, 3); setN(n, "sheen_roughness", p + GI_C_P_FUZZ_ROUGHNESS, 1);
         setN(n, "coat", p + GI_C_P_CLEARCOAT, 1); setN(n, "coat_color", p + GI_C_P_COAT_COLOR, 3); setN(n, "coat_roughness", p + GI_C_P_CLEARCOAT_ROUGHNESS, 1);
         setN(n, "coat_IOR", p + GI_C_P_COAT_IOR, 1); setN(n, "coat_anisotropy", p + GI_C_P_COAT_ANISOTROPY, 1);
-        setN(n, "coat_rotation", p + GI_C_P_COAT_ROTATION, 1);
+        setN(n, "coat_rotation", p + GI_C_P_COAT_ROTATION, 1); setN(n, "specular_rotation", p + GI_C_P_SPECULAR_ROTATION, 1);
         // nanometres, 0 = no film -> weight + micrometres
         float nm = 0.0f; setN(n, "thin_film_thickness", &nm, 1); setN(n, "thin_film_IOR", p + GI_C_P_THIN_FILM_IOR, 1);
         p[GI_C_P_THIN_FILM_WEIGHT] = nm > 0.0f ? 1.0f : 0.0f; p[GI_C_P_THIN_FILM_THICKNESS] = nm > 0.0f ? nm * 0.001f : 0.5f;
@@ -354,7 +354,7 @@ namespace gtl
         // thickness 0 is glTF's thin-walled transmission; a thick one attenuates with attenuation_color over attenuation_distance (OpenPBR transmission_color
         // at transmission_depth).  alpha_mode: 0 OPAQUE (alpha ignored), 1 MASK (constant
         // alpha against alpha_cutoff), 2 BLEND (alpha as opacity: stochastic cutout).
-        // Dropped: occlusion (baked ambient occlusion has no place in a path tracer), anisotropy_rotation, dispersion.
+        // Dropped: occlusion (baked ambient occlusion has no place in a path tracer), dispersion.
         p[GI_C_P_BASE_COLOR] = p[GI_C_P_BASE_COLOR + 1] = p[GI_C_P_BASE_COLOR + 2] = 1.0f; p[GI_C_P_METALLIC] = 1.0f; p[GI_C_P_ROUGHNESS] = 1.0f;
         p[GI_C_P_CLEARCOAT_ROUGHNESS] = 0.0f; p[GI_C_P_COAT_IOR] = 1.5f; p[GI_C_P_COAT_DARKENING] = 0.0f; p[GI_C_P_FUZZ_ROUGHNESS] = 0.0f;
             p[GI_C_P_THIN_FILM_IOR] = 1.3f;
@@ -375,6 +375,7 @@ namespace gtl
             setN(n, "iridescence_thickness", &nm, 1);
         p[GI_C_P_THIN_FILM_THICKNESS] = nm * 0.001f; // nanometres -> micrometres
         setN(n, "anisotropy_strength", p + GI_C_P_SPECULAR_ANISOTROPY, 1);
+        { float rad = 0.0f; setN(n, "anisotropy_rotation", &rad, 1); p[GI_C_P_SPECULAR_ROTATION] = rad / 6.2831855f; } // radians from the tangent -> turns
         float alpha = 1.0f, mode = 0.0f, cutoff = 0.5f; setN(n, "alpha", &alpha, 1); setN(n, "alpha_mode", &mode, 1); setN(n, "alpha_cutoff", &cutoff, 1);
         p[GI_C_P_OPACITY] = mode < 0.5f ? 1.0f : (mode < 1.5f ? (alpha >= cutoff ? 1.0f : 0.0f) : alpha);
         float strength = 1.0f; ecol[0] = ecol[1] = ecol[2] = 0.0f; setN(n, "emissive", ecol, 3); setN(n, "emissive_strength", &strength, 1);
@@ -406,22 +407,24 @@ namespace gtl
       setN(n, "specular_roughness_anisotropy", p + GI_C_P_SPECULAR_ANISOTROPY, 1); setN(n, "coat_roughness_anisotropy", p + GI_C_P_COAT_ANISOTROPY, 1);
       setN(n, "thin_film_weight", p + GI_C_P_THIN_FILM_WEIGHT, 1); setN(n, "thin_film_thickness", p + GI_C_P_THIN_FILM_THICKNESS, 1);
           setN(n, "thin_film_ior", p + GI_C_P_THIN_FILM_IOR, 1);
-      setN(n, "coat_rotation", p + GI_C_P_COAT_ROTATION, 1); // [ext] the turn as a plain float (what the flat parameter vocabularies below carry)
-      { // geometry_coat_tangent (open_pbr_surface.mtlx:91, 561) as documents feed it: <rotate3d in=tangent amount=DEGREES axis=normal>, optionally behind a
-        // <normalize> -- the turn of the coat's tangent, GI_C_P_COAT_ROTATION = amount / 360.  Anything else upstream keeps the geometry tangent.
-        auto it = n.connections.find("geometry_coat_tangent");
+      // [ext] the tangents' turns as plain floats (what the flat parameter vocabularies below carry)
+      setN(n, "coat_rotation", p + GI_C_P_COAT_ROTATION, 1); setN(n, "specular_rotation", p + GI_C_P_SPECULAR_ROTATION, 1);
+      // geometry_tangent / geometry_coat_tangent (open_pbr_surface.mtlx:89, 91; 385 ... 457, 561) as documents feed them: <rotate3d in=tangent amount=DEGREES
+      // axis=normal>, optionally behind a <normalize> -- the turn of that tangent, degrees / 360.  Anything else upstream keeps the geometry tangent.
+      auto tangentTurn = [&](const char* input, int slot) {
+        auto it = n.connections.find(input);
         MtlxNode up;
-        if (it != n.connections.end() && readNode(doc, it->second, up)) {
-          if (up.category == "normalize" && up.connections.count("in")) {
-            const std::string src2 = up.connections["in"];
-            up = MtlxNode(); (void)readNode(doc, src2, up);
-          }
-          if (up.category == "rotate3d" && up.inputs.count("amount")) {
-            float deg = 0.0f; floats(up.inputs["amount"], &deg, 1);
-            p[GI_C_P_COAT_ROTATION] = deg / 360.0f;
-          }
+        if (it == n.connections.end() || !readNode(doc, it->second, up)) return;
+        if (up.category == "normalize" && up.connections.count("in")) {
+          const std::string src2 = up.connections["in"];
+          up = MtlxNode(); (void)readNode(doc, src2, up);
         }
-      }
+        if (up.category == "rotate3d" && up.inputs.count("amount")) {
+          float deg = 0.0f; floats(up.inputs["amount"], &deg, 1);
+          p[slot] = deg / 360.0f;
+        }
+      };
+      tangentTurn("geometry_coat_tangent", GI_C_P_COAT_ROTATION); tangentTurn("geometry_tangent", GI_C_P_SPECULAR_ROTATION);
       setN(n, "emission_luminance", &lum, 1); setN(n, "emission_color", ecol, 3); setN(n, "geometry_opacity", p + GI_C_P_OPACITY, 1);
       for (int i = 0; i < 3; i++) p[GI_C_P_EMISSION + i] = lum * ecol[i];
       bind("base_color", GI_C_TEX_BASE_COLOR, p + GI_C_P_BASE_COLOR, 3); bind("specular_roughness", GI_C_TEX_ROUGHNESS, p + GI_C_P_ROUGHNESS, 1);
@@ -583,7 +586,7 @@ namespace gtl
         {"coat_weight", 1}, {"coat_color", 3}, {"coat_roughness", 1}, {"coat_ior", 1}, {"coat_darkening", 1}, {"emission_luminance", 1}, {"emission_color", 3},
         {"geometry_opacity", 1}, {"fuzz_weight", 1}, {"fuzz_color", 3}, {"fuzz_roughness", 1}, {"geometry_thin_walled", 1},
         {"subsurface_weight", 1}, {"subsurface_color", 3}, {"subsurface_scatter_anisotropy", 1}, {"specular_roughness_anisotropy", 1},
-            {"coat_roughness_anisotropy", 1}, {"coat_rotation", 1},
+            {"coat_roughness_anisotropy", 1}, {"coat_rotation", 1}, {"specular_rotation", 1},
         {"thin_film_weight", 1}, {"thin_film_thickness", 1}, {"thin_film_ior", 1}};
       for (const auto& k : kOpbr) {
         float v[3];

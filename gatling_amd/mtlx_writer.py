@@ -57,7 +57,7 @@ def _inputs(m: S.MaterialDesc):
         ("specular_roughness_anisotropy", "float", _f(p[S.P_SPECULAR_ANISOTROPY])), ("coat_roughness_anisotropy", "float", _f(p[S.P_COAT_ANISOTROPY])),
         # [ext] the turn of the coat's tangent as a plain float on the surface node (round-trips every float32); material_to_mtlx(coat_tangent="rotate3d")
         # writes the spelling documents use for geometry_coat_tangent instead
-        ("coat_rotation", "float", _f(p[S.P_COAT_ROTATION])),
+        ("coat_rotation", "float", _f(p[S.P_COAT_ROTATION])), ("specular_rotation", "float", _f(p[S.P_SPECULAR_ROTATION])),
         ("thin_film_weight", "float", _f(p[S.P_THIN_FILM_WEIGHT])), ("thin_film_thickness", "float", _f(p[S.P_THIN_FILM_THICKNESS])), ("thin_film_ior", "float", _f(p[S.P_THIN_FILM_IOR])),
         # the parameter block keeps luminance x colour: luminance 1 and the product as the colour reproduce it exactly
         ("emission_luminance", "float", "1" if em.any() else "0"), ("emission_color", "color3", _vals(p, S.P_EMISSION, 3) if em.any() else "1, 1, 1"),
@@ -67,18 +67,19 @@ def _inputs(m: S.MaterialDesc):
 def material_to_mtlx(m: S.MaterialDesc, form: str = "direct", coat_tangent: str = "ext") -> str:
     """``coat_tangent="rotate3d"`` spells the coat tangent's turn the way documents feed ``geometry_coat_tangent`` (open_pbr_surface.mtlx:91, 561):
     ``<rotate3d in=<tangent> amount=degrees axis=<normal>>`` behind a ``<normalize>`` (the shim divides the degrees by 360, so only turns whose degrees are
-    exact round-trip bit for bit); the default writes the [ext] ``coat_rotation`` float."""
+    exact round-trip bit for bit), and ``geometry_tangent`` (:89) likewise; the default writes the [ext] ``coat_rotation`` / ``specular_rotation`` floats."""
     cat, inputs = _inputs(m)
     extra, tail = "", ""
     if coat_tangent == "rotate3d" and cat == "open_pbr_surface":
-        deg = _f(np.float32(m.params[S.P_COAT_ROTATION]) * np.float32(360.0))
-        inputs = [i for i in inputs if i[0] != "coat_rotation"]
+        inputs = [i for i in inputs if i[0] not in ("coat_rotation", "specular_rotation")]
         extra = (f'<tangent name="T_{m.name}" type="vector3"><input name="space" type="string" value="world" /></tangent>'
-                 f'<normal name="N_{m.name}" type="vector3"><input name="space" type="string" value="world" /></normal>'
-                 f'<rotate3d name="R_{m.name}" type="vector3"><input name="in" type="vector3" nodename="T_{m.name}" />'
-                 f'<input name="amount" type="float" value="{deg}" /><input name="axis" type="vector3" nodename="N_{m.name}" /></rotate3d>'
-                 f'<normalize name="CT_{m.name}" type="vector3"><input name="in" type="vector3" nodename="R_{m.name}" /></normalize>')
-        tail = f'<input name="geometry_coat_tangent" type="vector3" nodename="CT_{m.name}" />'
+                 f'<normal name="N_{m.name}" type="vector3"><input name="space" type="string" value="world" /></normal>')
+        for tag, idx, inp in (("Coat", S.P_COAT_ROTATION, "geometry_coat_tangent"), ("Spec", S.P_SPECULAR_ROTATION, "geometry_tangent")):
+            deg = _f(np.float32(m.params[idx]) * np.float32(360.0))
+            extra += (f'<rotate3d name="{tag}R_{m.name}" type="vector3"><input name="in" type="vector3" nodename="T_{m.name}" />'
+                      f'<input name="amount" type="float" value="{deg}" /><input name="axis" type="vector3" nodename="N_{m.name}" /></rotate3d>'
+                      f'<normalize name="{tag}T_{m.name}" type="vector3"><input name="in" type="vector3" nodename="{tag}R_{m.name}" /></normalize>')
+            tail += f'<input name="{inp}" type="vector3" nodename="{tag}T_{m.name}" />'
     elif coat_tangent != "ext":
         raise ValueError(coat_tangent)
     if form == "direct":

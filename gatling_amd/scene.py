@@ -60,6 +60,7 @@ P_SUBSURFACE_RADIUS_SCALE = 33       # 3
 P_SPECULAR_ANISOTROPY = 60
 P_COAT_ANISOTROPY = 61
 P_COAT_ROTATION = 36                 # geometry_coat_tangent as a turn of the tangent, in turns (USER block only, like 32..35)
+P_SPECULAR_ROTATION = 37             # geometry_tangent likewise: the tangent of the dielectric / conductor lobes
 P_THIN_FILM_WEIGHT = 62
 P_THIN_FILM_THICKNESS = 63           # micrometres
 P_THIN_FILM_IOR = 6                  # OpenPBR class only (the slot is useSpecularWorkflow for UsdPreviewSurface)
@@ -130,7 +131,7 @@ def _open_pbr(name="mat", base_weight=1.0, base_color=(0.8, 0.8, 0.8), base_meta
               fuzz_color=(1, 1, 1), fuzz_roughness=0.5, geometry_thin_walled=False, subsurface_weight=0.0, subsurface_color=(0.8, 0.8, 0.8),
               subsurface_scatter_anisotropy=0.0, specular_roughness_anisotropy=0.0, coat_roughness_anisotropy=0.0,
               thin_film_weight=0.0, thin_film_thickness=0.5, thin_film_ior=1.4, subsurface_radius=1.0, subsurface_radius_scale=(1.0, 0.5, 0.25),
-              geometry_opacity=1.0, coat_rotation=0.0) -> MaterialDesc:
+              geometry_opacity=1.0, coat_rotation=0.0, specular_rotation=0.0) -> MaterialDesc:
     """open_pbr_surface inputs with the defaults of src/gi/mtlx/open_pbr_surface.mtlx:11-92 (the lobes this core implements)."""
     p = np.zeros(P_COUNT, np.float32)
     p[P_BASE_COLOR:P_BASE_COLOR + 3] = base_color
@@ -165,6 +166,7 @@ def _open_pbr(name="mat", base_weight=1.0, base_color=(0.8, 0.8, 0.8), base_meta
     p[P_SPECULAR_ANISOTROPY] = specular_roughness_anisotropy   # open_pbr_anisotropy (open_pbr_surface.mtlx:133-136, 552-555): highlights stretched along the tangent
     p[P_COAT_ANISOTROPY] = coat_roughness_anisotropy
     p[P_COAT_ROTATION] = coat_rotation                 # geometry_coat_tangent (:91, 561) = rotate3d(Tworld, 360 * coat_rotation degrees, N)
+    p[P_SPECULAR_ROTATION] = specular_rotation         # geometry_tangent (:89) likewise
     p[P_THIN_FILM_WEIGHT] = thin_film_weight           # thin film on the dielectric and metal lobes (open_pbr_surface.mtlx:300-304, 404-431, 450-464)
     p[P_THIN_FILM_THICKNESS] = thin_film_thickness
     p[P_THIN_FILM_IOR] = thin_film_ior

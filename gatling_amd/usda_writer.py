@@ -26,7 +26,7 @@ import re
 import numpy as np
 
 from .scene import (INTERP_CONSTANT, INTERP_UNIFORM, INTERP_VERTEX, MAT_OPEN_PBR, MAT_USD_PREVIEW_SURFACE, P_BASE_COLOR, P_BASE_WEIGHT,
-                    P_CLEARCOAT, P_CLEARCOAT_ROUGHNESS, P_COAT_COLOR, P_COAT_ROTATION, P_COAT_DARKENING, P_COAT_IOR, P_DIFFUSE_ROUGHNESS, P_FUZZ_COLOR, P_FUZZ_ROUGHNESS, P_FUZZ_WEIGHT, P_THIN_WALLED, P_SUBSURFACE_WEIGHT, P_SUBSURFACE_COLOR, P_SUBSURFACE_ANISOTROPY, P_SUBSURFACE_RADIUS, P_SUBSURFACE_RADIUS_SCALE, P_SPECULAR_ANISOTROPY, P_COAT_ANISOTROPY, P_THIN_FILM_WEIGHT, P_THIN_FILM_THICKNESS, P_THIN_FILM_IOR, P_EMISSION, P_IOR, P_METALLIC, P_OPACITY,
+                    P_CLEARCOAT, P_CLEARCOAT_ROUGHNESS, P_COAT_COLOR, P_COAT_ROTATION, P_SPECULAR_ROTATION, P_COAT_DARKENING, P_COAT_IOR, P_DIFFUSE_ROUGHNESS, P_FUZZ_COLOR, P_FUZZ_ROUGHNESS, P_FUZZ_WEIGHT, P_THIN_WALLED, P_SUBSURFACE_WEIGHT, P_SUBSURFACE_COLOR, P_SUBSURFACE_ANISOTROPY, P_SUBSURFACE_RADIUS, P_SUBSURFACE_RADIUS_SCALE, P_SPECULAR_ANISOTROPY, P_COAT_ANISOTROPY, P_THIN_FILM_WEIGHT, P_THIN_FILM_THICKNESS, P_THIN_FILM_IOR, P_EMISSION, P_IOR, P_METALLIC, P_OPACITY,
                     P_OPACITY_THRESHOLD, P_ROUGHNESS, P_SPECULAR_COLOR, P_SPECULAR_WEIGHT, P_TRANSMISSION_COLOR, P_TRANSMISSION_DEPTH,
                     P_TRANSMISSION_SCATTER, P_TRANSMISSION_SCATTER_ANISOTROPY, P_TRANSMISSION_WEIGHT, P_USE_SPECULAR_WORKFLOW, SceneDesc,
                     TEX_BASE_COLOR, TEX_EMISSION, TEX_METALLIC, TEX_NORMAL, TEX_ROUGHNESS, TEX_TRANSMISSION_COLOR, TEX_TRANSMISSION_WEIGHT)
@@ -43,7 +43,7 @@ OPEN_PBR_INPUTS = [("base_weight", P_BASE_WEIGHT, 1), ("base_color", P_BASE_COLO
                    ("fuzz_roughness", P_FUZZ_ROUGHNESS, 1), ("geometry_thin_walled", P_THIN_WALLED, 0), ("geometry_opacity", P_OPACITY, 1),
                    ("subsurface_weight", P_SUBSURFACE_WEIGHT, 1), ("subsurface_color", P_SUBSURFACE_COLOR, 3), ("subsurface_scatter_anisotropy", P_SUBSURFACE_ANISOTROPY, 1),
                    ("subsurface_radius", P_SUBSURFACE_RADIUS, 1), ("subsurface_radius_scale", P_SUBSURFACE_RADIUS_SCALE, 3),
-                   ("specular_roughness_anisotropy", P_SPECULAR_ANISOTROPY, 1), ("coat_roughness_anisotropy", P_COAT_ANISOTROPY, 1), ("coat_rotation", P_COAT_ROTATION, 1),
+                   ("specular_roughness_anisotropy", P_SPECULAR_ANISOTROPY, 1), ("coat_roughness_anisotropy", P_COAT_ANISOTROPY, 1), ("coat_rotation", P_COAT_ROTATION, 1), ("specular_rotation", P_SPECULAR_ROTATION, 1),
                    ("thin_film_weight", P_THIN_FILM_WEIGHT, 1), ("thin_film_thickness", P_THIN_FILM_THICKNESS, 1), ("thin_film_ior", P_THIN_FILM_IOR, 1)]
 UPS_INPUTS = [("diffuseColor", P_BASE_COLOR, 3), ("emissiveColor", P_EMISSION, 3), ("useSpecularWorkflow", P_USE_SPECULAR_WORKFLOW, 0),
               ("specularColor", P_SPECULAR_COLOR, 3), ("metallic", P_METALLIC, 1), ("roughness", P_ROUGHNESS, 1), ("clearcoat", P_CLEARCOAT, 1),

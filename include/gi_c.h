@@ -177,7 +177,7 @@ typedef struct GiCRenderParams {
 #define GI_C_P_DIFFUSE_ROUGHNESS 27
 #define GI_C_P_TRANSMISSION_DEPTH 28
 #define GI_C_P_TRANSMISSION_SCATTER 29 /* 3: OpenPBR transmission_scatter (open_pbr_surface.mtlx:35) */
-#define GI_C_P_TRANSMISSION_SCATTER_ANISOTROPY 47 /* transmission_scatter_anisotropy (:37); slots 37..46 are reserved (32..36: subsurface radius, coat rotation) */
+#define GI_C_P_TRANSMISSION_SCATTER_ANISOTROPY 47 /* transmission_scatter_anisotropy (:37); slots 38..46 are reserved (32..37: subsurface radius, coat / specular rotation) */
 #define GI_C_P_COAT_DARKENING 48   /* OpenPBR coat_darkening (open_pbr_surface.mtlx:64; default 1): strength of the base darkening under the coat (:470-541) */
 #define GI_C_P_FUZZ_WEIGHT 49      /* OpenPBR fuzz_weight / fuzz_color (3) / fuzz_roughness (:57-59): the fuzz (sheen) layer over the coat (:569-581) */
 #define GI_C_P_FUZZ_COLOR 50
@@ -193,7 +193,11 @@ typedef struct GiCRenderParams {
 #define GI_C_P_COAT_ROTATION 36       /* OpenPBR geometry_coat_tangent (open_pbr_surface.mtlx:91, 561) in the form documents bind it: the geometry tangent turned by this many
                                          TURNS (1 = 360 degrees) towards the bitangent, about the coat's normal (rotate3d of Tworld; Standard Surface's coat_rotation).
                                          0 = the geometry tangent.  Read for an anisotropic coat only (coat weight and coat_roughness_anisotropy > 0).  Like 32..35 an input
-                                         of the USER block only (API version 7; slots 37..46 stay reserved) */
+                                         of the USER block only (API version 7) */
+#define GI_C_P_SPECULAR_ROTATION 37   /* OpenPBR geometry_tangent (open_pbr_surface.mtlx:89; the tangent of the dielectric and conductor lobes, :385 ... 457) in the same form:
+                                         the geometry tangent turned by this many turns towards the bitangent (Standard Surface's specular_rotation; glTF's anisotropy_rotation
+                                         / 2 pi).  Read for anisotropic base lobes only (specular_roughness_anisotropy > 0); the coat keeps the geometry tangent and its own
+                                         turn.  USER block only (API version 7; slots 38..46 stay reserved) */
 #define GI_C_P_SUBSURFACE_RADIUS 32       /* OpenPBR subsurface_radius (open_pbr_surface.mtlx:47, default 1): with _RADIUS_SCALE the per-channel mean free path of the volumetric
                                             subsurface_bsdf (:182-192) of materials that are not thin-walled; live in renders with a medium stack (mediumStackSize > 0) */
 #define GI_C_P_SUBSURFACE_RADIUS_SCALE 33 /* 3 floats, subsurface_radius_scale (:49, default 1, 0.5, 0.25).  Slots 32..35 are inputs of the USER block only: the device copy of a
@@ -351,7 +355,7 @@ int giCInitializeDevices(const int32_t* deviceOrdinals, uint32_t count);
 /* [ext] Version of this header's ABI: bumped whenever a struct grows or an entry point changes meaning (5: GiCRenderStats gained batches / poolSlots, GI_C_TEX_SLOT_COUNT 9,
  * the subsurface radius slots of GiCMaterialDesc, the asset-reader / image-loader hooks; 6: GiCRenderStats.reserved0 became inactiveTriangleCount,
  * giCDebugShadeClass, an all-zero subsurface radius is no longer read as "unset", the hostile-input rules above giCRender;
- * 7: GI_C_P_COAT_ROTATION, a slot that was reserved).  A caller compares giCGetApiVersion() with the GI_C_API_VERSION it was built with. */
+ * 7: GI_C_P_COAT_ROTATION / GI_C_P_SPECULAR_ROTATION, slots that were reserved).  A caller compares giCGetApiVersion() with the GI_C_API_VERSION it was built with. */
 #define GI_C_API_VERSION 7u
 uint32_t giCGetApiVersion(void);
 uint32_t giCGetDeviceCount(void);

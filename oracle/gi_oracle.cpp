@@ -1130,7 +1130,7 @@ inline V3 eon_pi_f(V3 rho, float r, V3 l1, V3 l2)
   const V3 rhoMs = v3((rr.x * avgEF) / (1.0f - rho.x * (1.0f - avgEF)), (rr.y * avgEF) / (1.0f - rho.y * (1.0f - avgEF)), (rr.z * avgEF) / (1.0f - rho.z * (1.0f - avgEF)));
   return rho * ss + rhoMs * ms;
 }
-struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, sigmaA, sigmaS, baseColor, coatColor, ssColor, fuzzColor, sssSigmaS, sssSigmaT; bool ssVolume; float metalness, alpha, alphaY, coat, coatAlpha, coatAlphaY, coatF0, eta, tw, specWeight, anisotropy, baseWeight, diffRough, ssWeight, ssAniso, fuzzWeight, fuzzAlpha, filmWeight, filmNm, filmIor; bool thinWalled;  bool coatRot; float coatRotC, coatRotS; };
+struct OpbrParams { V3 albedo, metalTint, specColor, transTint, coatTint, sigmaA, sigmaS, baseColor, coatColor, ssColor, fuzzColor, sssSigmaS, sssSigmaT; bool ssVolume; float metalness, alpha, alphaY, coat, coatAlpha, coatAlphaY, coatF0, eta, tw, specWeight, anisotropy, baseWeight, diffRough, ssWeight, ssAniso, fuzzWeight, fuzzAlpha, filmWeight, filmNm, filmIor; bool thinWalled;  bool coatRot, specRot; float coatRotC, coatRotS, coatRelC, coatRelS, specRotC, specRotS; };
 inline OpbrParams opbr_params(const OrcMaterial& m, bool sssVolume = false)
 {
   OpbrParams o; const float* p = m.p;
@@ -1148,8 +1148,17 @@ inline OpbrParams opbr_params(const OrcMaterial& m, bool sssVolume = false)
   opbr_anisotropy(o.alpha, p[ORC_P_SPECULAR_ANISOTROPY], o.alpha, o.alphaY); opbr_anisotropy(o.coatAlpha, p[ORC_P_COAT_ANISOTROPY], o.coatAlpha, o.coatAlphaY); // :133-136, 552-555
   // geometry_coat_tangent (:91, 561: the coat's dielectric_bsdf takes a tangent of its own).  Modelled in the form a document binds to it -- rotate3d of Tworld about
   // the normal, Standard Surface's coat_rotation: the frame's tangent turned by p[36] turns towards its bitangent.  Only an anisotropic coat can tell.
-  o.coatRot = p[ORC_P_CLEARCOAT] > 0.0f && p[ORC_P_COAT_ANISOTROPY] > 0.0f && p[ORC_P_COAT_ROTATION] != 0.0f; o.coatRotC = 1.0f; o.coatRotS = 0.0f;
+  // geometry_tangent (:89; the tangent of the dielectric and conductor lobes, :385, 402, 410, 449, 457) in the same form (Standard Surface's specular_rotation,
+  // glTF's anisotropy_rotation): p[37] turns; opbr_enter turns the shading frame before the lobes run.  A coat without a frame of its own then starts from the turned
+  // frame: its turn relative to it (coatRel) keeps it on the geometry tangent + p[36].
+  o.specRot = p[ORC_P_SPECULAR_ANISOTROPY] > 0.0f && p[ORC_P_SPECULAR_ROTATION] != 0.0f;
+  o.coatRot = p[ORC_P_CLEARCOAT] > 0.0f && p[ORC_P_COAT_ANISOTROPY] > 0.0f && (p[ORC_P_COAT_ROTATION] != 0.0f || o.specRot);
+  o.coatRotC = 1.0f; o.coatRotS = 0.0f; o.specRotC = 1.0f; o.specRotS = 0.0f; o.coatRelC = 1.0f; o.coatRelS = 0.0f;
   if (o.coatRot) { const float a = 6.2831855f * p[ORC_P_COAT_ROTATION]; o.coatRotC = cosf(a); o.coatRotS = sinf(a); }
+  if (o.specRot) {
+    const float a = 6.2831855f * p[ORC_P_SPECULAR_ROTATION], r = 6.2831855f * (p[ORC_P_COAT_ROTATION] - p[ORC_P_SPECULAR_ROTATION]);
+    o.specRotC = cosf(a); o.specRotS = sinf(a); o.coatRelC = cosf(r); o.coatRelS = sinf(r);
+  }
   float cior = p[ORC_P_COAT_IOR]; float qc = (cior - 1.0f) / (cior + 1.0f); o.coatF0 = qc * qc;
   V3 cc = v3(p + ORC_P_COAT_COLOR); o.coatColor = cc; o.coatTint = v3(1, 1, 1) * (1.0f - o.coat) + cc * o.coat;
   // coat_substrate_attenuated = base_substrate * modulated_base_darkening * coat_attenuation (:538-552)
@@ -1421,9 +1430,22 @@ static void opbr_sample_base(const OpbrParams& o, const State& st, V3 k1, const 
   if (o.filmWeight > 0.0f) out.overPdf = out.overPdf * under;
 }
 
-void opbr_sample(const OrcMaterial& m, const State& st, V3 k1, const float xi[4], bool frontFace, BsdfSample& out)
+// The parameters of a hit and the frame its lobes run in: geometry_tangent turns the frame's tangents (every lobe beneath the coat sees the turned frame -- the
+// diffuse ones depend on the normal only), and the coat takes its relative turn unless geometry_coat_normal gave it a frame of its own (made from the unturned tangent).
+static OpbrParams opbr_enter(const OrcMaterial& m, const State& stIn, State& st)
 {
-  const OpbrParams o = opbr_params(m, st.sssVolume);
+  OpbrParams o = opbr_params(m, stIn.sssVolume);
+  st = stIn;
+  if (o.specRot) {
+    st.tangentU = stIn.tangentU * o.specRotC + stIn.tangentV * o.specRotS; st.tangentV = stIn.tangentV * o.specRotC - stIn.tangentU * o.specRotS;
+    if (!stIn.hasCoatFrame) { o.coatRotC = o.coatRelC; o.coatRotS = o.coatRelS; }
+  }
+  return o;
+}
+
+void opbr_sample(const OrcMaterial& m, const State& stIn, V3 k1, const float xi[4], bool frontFace, BsdfSample& out)
+{
+  State st; const OpbrParams o = opbr_enter(m, stIn, st);
   if (!(o.fuzzWeight > 0.0f)) { opbr_sample_base(o, st, k1, xi, frontFace, out); return; }
   V3 l1 = to_local(st, k1);
   const float nk1 = fmax2(l1.z, 1e-4f); l1.z = nk1;
@@ -1492,9 +1514,9 @@ static void opbr_evaluate_base(const OpbrParams& o, const State& st, V3 k1, V3 k
   out.pdf = Fc * pc + base * (o.metalness * ps + diel * (Fd * ps + (1.0f - Fd) * (1.0f - o.tw) * cd));
 }
 
-void opbr_evaluate(const OrcMaterial& m, const State& st, V3 k1, V3 k2, bool frontFace, BsdfEval& out)
+void opbr_evaluate(const OrcMaterial& m, const State& stIn, V3 k1, V3 k2, bool frontFace, BsdfEval& out)
 {
-  const OpbrParams o = opbr_params(m, st.sssVolume);
+  State st; const OpbrParams o = opbr_enter(m, stIn, st);
   opbr_evaluate_base(o, st, k1, k2, frontFace, out);
   if (!(o.fuzzWeight > 0.0f)) return;
   V3 l1 = to_local(st, k1); const V3 l2 = to_local(st, k2);

@@ -85,6 +85,7 @@ enum {
   ORC_P_THIN_FILM_IOR = 6, ORC_P_THIN_FILM_WEIGHT = 62, ORC_P_THIN_FILM_THICKNESS = 63, /* OpenPBR thin_film_* (:71-76); slot 6 is useSpecularWorkflow for UsdPreviewSurface */
   ORC_P_SPECULAR_ANISOTROPY = 60, ORC_P_COAT_ANISOTROPY = 61, /* specular_roughness_anisotropy (:27), coat_roughness_anisotropy (:65) */
   ORC_P_COAT_ROTATION = 36,    /* geometry_coat_tangent (:91, 561) as a document binds it: Tworld turned by this many turns towards the bitangent (rotate3d about the normal) */
+  ORC_P_SPECULAR_ROTATION = 37, /* geometry_tangent (:89; 385 ... 457) in the same form: the tangent of the dielectric and conductor lobes, turned */
   ORC_P_COUNT = 64
 };
 

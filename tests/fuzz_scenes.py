@@ -104,7 +104,8 @@ def _material(rng, i, ntex):
             coat_roughness_anisotropy=float(rng.uniform(0.0, 1.0)) if rng.uniform() < 0.3 else 0.0, thin_film_weight=_weight(rng) if rng.uniform() < 0.3 else 0.0,
             thin_film_thickness=float(rng.uniform(0.05, 1.5)), thin_film_ior=float(rng.uniform(1.1, 2.0)), subsurface_radius=float(rng.uniform(0.05, 2.0)),
             subsurface_radius_scale=_color(rng, 0.1, 1.0), geometry_opacity=opacity,
-            coat_rotation=float(rng.choice([0.125, 0.25, rng.uniform(-2.0, 2.0)])) if rng.uniform() < 0.5 else 0.0)   # geometry_coat_tangent as a turn
+            coat_rotation=float(rng.choice([0.125, 0.25, rng.uniform(-2.0, 2.0)])) if rng.uniform() < 0.5 else 0.0,   # geometry_coat_tangent as a turn
+            specular_rotation=float(rng.choice([0.125, 0.25, rng.uniform(-2.0, 2.0)])) if rng.uniform() < 0.5 else 0.0)   # geometry_tangent likewise
     if ntex and rng.uniform() < 0.4:
         slots = [TEX_BASE_COLOR, TEX_EMISSION, TEX_ROUGHNESS, TEX_METALLIC, TEX_NORMAL, TEX_OPACITY]
         if klass == MAT_OPEN_PBR: slots += [TEX_COAT_NORMAL, TEX_TRANSMISSION_WEIGHT, TEX_TRANSMISSION_COLOR]

@@ -526,10 +526,10 @@ def test_shade_class_of_materials(monkeypatch):
     assert capi.shade_class(MaterialDesc.usd_preview_surface(metallic=0.5)) == 1
     for base in (O(), O(base_metalness=1.0, specular_roughness=0.05), O(base_diffuse_roughness=0.8, base_weight=0.5), O(emission_luminance=3.0), O(specular_weight=0.0),
                  O(geometry_opacity=0.5), O(coat_color=(0.1, 0.2, 0.3), coat_roughness=0.9), O(fuzz_color=(0.3, 0.3, 0.3)), O(transmission_color=(0.2, 0.3, 0.4), transmission_depth=2.0),
-                 O(coat_rotation=0.3)):   # (a turned coat tangent without a coat is not read)
+                 O(coat_rotation=0.3), O(specular_rotation=0.3)):   # (a turned tangent without an anisotropic lobe is not read)
         assert capi.shade_class(base) == 3
     for full in (O(coat_weight=0.1), O(fuzz_weight=0.2), O(transmission_weight=1e-3), O(geometry_thin_walled=True), O(specular_roughness_anisotropy=0.3),
-                 O(coat_roughness_anisotropy=0.3), O(coat_weight=0.5, coat_roughness_anisotropy=0.3, coat_rotation=0.2), O(thin_film_weight=0.5), O(subsurface_weight=0.5), O(geometry_thin_walled=True, subsurface_weight=0.5)):
+                 O(coat_roughness_anisotropy=0.3), O(coat_weight=0.5, coat_roughness_anisotropy=0.3, coat_rotation=0.2), O(specular_roughness_anisotropy=0.3, specular_rotation=0.2), O(thin_film_weight=0.5), O(subsurface_weight=0.5), O(geometry_thin_walled=True, subsurface_weight=0.5)):
         assert capi.shade_class(full) == 2
     for k, bad in ((P_FUZZ_COLOR, np.nan), (0, np.inf), (22, -1.0)):  # (coat ior -1: the coat's F0 is infinite -- 0 * inf is not 0)
         m = O(); m.params[k] = bad

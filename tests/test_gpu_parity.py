@@ -439,7 +439,7 @@ def test_coat_normal_on_device(gi, orc):
 
 
 def test_coat_tangent_on_device(gi, orc):
-    """OpenPBR geometry_coat_tangent as a turn of the coat's tangent (GI_C_P_COAT_ROTATION; gi_shading.h coat_turn_local / coat_turn_world, cosine and sine from the
+    """OpenPBR geometry_coat_tangent / geometry_tangent as turns of the coat's / the base lobes' tangent (GI_C_P_COAT_ROTATION, GI_C_P_SPECULAR_ROTATION; gi_shading.h coat_turn_local / coat_turn_world, cosine and sine from the
     host in MaterialRec::sss[6..7]): an anisotropic coat with its tangent turned, sampled and evaluated (NEE) -- on the coated ball alone, with a coat normal map (the
     turn applies inside the map's frame), beside an untouched material in one scene, through the fused kernels (no NEE) and with a medium stack: device == oracle
     bit for bit; the turn changes the image; the class the material is binned to is the full OpenPBR one."""
@@ -464,6 +464,24 @@ def test_coat_tangent_on_device(gi, orc):
     assert b.klass == MAT_OPEN_PBR
     b.params = MaterialDesc.open_pbr(base_color=(0.8, 0.8, 0.8), specular_roughness=0.25, coat_weight=0.8, coat_roughness=0.2, coat_color=(0.9, 0.8, 0.7),
                                      coat_roughness_anisotropy=0.6, coat_rotation=0.45).params
+    render_both(gi, orc, desc, RenderSettings(spp=4, max_bounces=6, next_event_estimation=True), 96, 54, exact=True)
+    # geometry_tangent (GI_C_P_SPECULAR_ROTATION; gi_shading.h spec_turn_frame: the shading frame's tangents turned in place before the BSDF): a brushed metal ball,
+    # then the same under an anisotropic coat (the coat's relative turn), with a coat normal map (the coat's absolute turn in the map's frame), without NEE, with a
+    # medium stack; and on the texture scene's ball with a base normal map
+    def brushed(turn, coat=0.0, coat_turn=0.0, coat_map=None):
+        d = _coated_ball(coat_map)
+        d.materials[0].params = MaterialDesc.open_pbr(base_color=(0.9, 0.7, 0.4), base_metalness=1.0, specular_roughness=0.35, specular_roughness_anisotropy=0.85, specular_rotation=turn,
+                                                      coat_weight=coat, coat_roughness=0.25, coat_ior=1.6, coat_roughness_anisotropy=0.7, coat_rotation=coat_turn).params
+        return d
+    plain, _, _ = render_both(gi, orc, brushed(0.0), rs, 64, 64, exact=True)
+    turned, _, _ = render_both(gi, orc, brushed(0.125), rs, 64, 64, exact=True)
+    assert not np.array_equal(plain, turned)
+    render_both(gi, orc, brushed(0.3, coat=0.7), rs, 64, 64, exact=True)
+    render_both(gi, orc, brushed(-0.2, coat=0.7, coat_turn=0.6, coat_map=bumpy), rs, 64, 64, exact=True)
+    render_both(gi, orc, brushed(0.4, coat=0.5, coat_turn=0.1), RenderSettings(spp=5, max_bounces=5), 48, 48, exact=True)
+    render_both(gi, orc, brushed(0.7), RenderSettings(spp=4, max_bounces=5, next_event_estimation=True, medium_stack_size=3), 48, 48, exact=True)
+    b.params = MaterialDesc.open_pbr(base_color=(0.8, 0.8, 0.8), specular_roughness=0.3, specular_roughness_anisotropy=0.7, specular_rotation=0.15, transmission_weight=0.3,
+                                     coat_weight=0.5, coat_roughness=0.2, coat_roughness_anisotropy=0.6).params
     render_both(gi, orc, desc, RenderSettings(spp=4, max_bounces=6, next_event_estimation=True), 96, 54, exact=True)
 
 
@@ -682,6 +700,16 @@ def test_bsdf_known_answers_on_device(gi, orc):
                                   coat_roughness_anisotropy=0.5, coat_rotation=0.3),
             MaterialDesc.open_pbr(base_color=(0.6, 0.3, 0.3), specular_roughness=0.4, coat_weight=0.9, coat_roughness=0.35, coat_roughness_anisotropy=0.95, fuzz_weight=0.2, coat_rotation=-1.71),
             MaterialDesc.open_pbr(base_color=(0.6, 0.3, 0.3), coat_weight=0.9, coat_roughness=0.35, coat_roughness_anisotropy=0.0, coat_rotation=0.4),   # isotropic coat: not read
+            # geometry_tangent (open_pbr_surface.mtlx:89) as a turn of the base lobes' tangent: metal, dielectric with transmission and a rough diffuse base, under an
+            # anisotropic coat without / with a turn of its own (the coat's relative turn), with fuzz and thin film, isotropic base (not read)
+            MaterialDesc.open_pbr(base_color=(0.9, 0.8, 0.6), base_metalness=1.0, specular_roughness=0.45, specular_roughness_anisotropy=0.8, specular_rotation=0.125),
+            MaterialDesc.open_pbr(base_color=(0.4, 0.6, 0.8), transmission_weight=0.6, specular_roughness=0.3, specular_roughness_anisotropy=0.5, specular_ior=1.4, base_diffuse_roughness=0.7,
+                                  specular_rotation=-0.31),
+            MaterialDesc.open_pbr(base_color=(0.5, 0.5, 0.5), specular_roughness=0.2, specular_roughness_anisotropy=1.0, coat_weight=0.5, coat_roughness=0.2, coat_roughness_anisotropy=0.6,
+                                  specular_rotation=0.2),
+            MaterialDesc.open_pbr(base_color=(0.5, 0.5, 0.5), base_metalness=0.5, specular_roughness=0.3, specular_roughness_anisotropy=0.7, coat_weight=0.5, coat_roughness=0.2,
+                                  coat_roughness_anisotropy=0.6, specular_rotation=0.2, coat_rotation=0.45, fuzz_weight=0.3, thin_film_weight=0.6, thin_film_thickness=0.3),
+            MaterialDesc.open_pbr(base_color=(0.6, 0.3, 0.3), specular_roughness=0.4, specular_rotation=0.4, coat_weight=0.4, coat_roughness_anisotropy=0.5),
             # thin film (open_pbr_surface.mtlx:300-304, 404-431, 450-464): on a dielectric with transmission (front and back faces: relative indices), on a metal, with everything else on
             MaterialDesc.open_pbr(base_color=(0.7, 0.7, 0.7), transmission_weight=0.6, specular_roughness=0.2, thin_film_weight=1.0, thin_film_thickness=0.35, thin_film_ior=1.8),
             MaterialDesc.open_pbr(base_color=(0.9, 0.6, 0.4), base_metalness=1.0, specular_roughness=0.3, thin_film_weight=0.8, thin_film_thickness=0.6, thin_film_ior=1.33),

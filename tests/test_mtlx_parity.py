@@ -29,7 +29,7 @@ def _edge_cases():
             M.open_pbr(name="fuzz", fuzz_weight=0.5, fuzz_color=(0.2, 0.3, 0.4), fuzz_roughness=0.8),
             M.open_pbr(name="soap", transmission_weight=0.8, specular_roughness=0.05, thin_film_weight=1.0, thin_film_thickness=0.3, thin_film_ior=1.33),
             M.open_pbr(name="brushed", base_metalness=1.0, specular_roughness=0.35, specular_roughness_anisotropy=0.7, coat_weight=0.4, coat_roughness=0.2, coat_roughness_anisotropy=0.25),
-            M.open_pbr(name="combed", coat_weight=0.7, coat_roughness=0.3, coat_roughness_anisotropy=0.8, coat_rotation=0.3137),
+            M.open_pbr(name="combed", coat_weight=0.7, coat_roughness=0.3, coat_roughness_anisotropy=0.8, coat_rotation=0.3137, specular_roughness_anisotropy=0.4, specular_rotation=-0.077),
             M.open_pbr(name="wax", subsurface_weight=0.8, subsurface_color=(0.9, 0.5, 0.3), subsurface_radius=0.15, subsurface_radius_scale=(1.0, 0.6, 0.2), subsurface_scatter_anisotropy=0.3),
             M.usd_preview_surface(name="spec", useSpecularWorkflow=1, specularColor=(0.3, 0.4, 0.5), diffuseColor=(0.6, 0.1, 0.05), roughness=0.23, ior=1.7),
             M.usd_preview_surface(name="cut", opacity=0.37, opacityThreshold=0.5, emissiveColor=(0.5, 1.5, 2.5), clearcoat=0.7, clearcoatRoughness=0.2, metallic=0.33)]
@@ -38,23 +38,31 @@ def _edge_cases():
 def test_coat_tangent_spellings_read_back():
     """geometry_coat_tangent (open_pbr_surface.mtlx:91, 561) fed the way documents feed it -- <rotate3d in=<tangent> amount=degrees axis=<normal>> behind a
     <normalize>, on the surface node or next to a nodegraph -- reads back as the turn (degrees / 360, exact for these), a bare rotate3d too; anything else
-    upstream keeps the geometry tangent; Standard Surface's coat_rotation is the same turn."""
+    upstream keeps the geometry tangent; geometry_tangent (:89) likewise; Standard Surface's coat_rotation / specular_rotation are the same turns, glTF's
+    anisotropy_rotation is radians."""
     L = capi.load_library()
     for turns in (0.125, 0.25, -0.5, 0.75):
-        m = S.MaterialDesc.open_pbr(name="combed", coat_weight=0.7, coat_roughness=0.3, coat_roughness_anisotropy=0.8, coat_rotation=turns)
+        m = S.MaterialDesc.open_pbr(name="combed", coat_weight=0.7, coat_roughness=0.3, coat_roughness_anisotropy=0.8, coat_rotation=turns,
+                                    specular_roughness_anisotropy=0.5, specular_rotation=0.25 - turns)
         for form in ("direct", "nodegraph"):
             doc = material_to_mtlx(m, form, coat_tangent="rotate3d")
-            assert "coat_rotation" not in doc and "rotate3d" in doc
+            assert "coat_rotation" not in doc and "specular_rotation" not in doc and doc.count("<rotate3d") == 2
             d = _desc_from_doc(L, doc)
             assert d is not None and np.array_equal(np.frombuffer(bytes(d.p), np.uint32), np.asarray(m.params, np.float32).view(np.uint32)), (turns, form)
-        bare = material_to_mtlx(m, "direct", coat_tangent="rotate3d").replace('nodename="CT_combed"', 'nodename="R_combed"')
+        bare = material_to_mtlx(m, "direct", coat_tangent="rotate3d").replace('nodename="CoatT_combed"', 'nodename="CoatR_combed"')
         assert _desc_from_doc(L, bare).p[S.P_COAT_ROTATION] == np.float32(turns)
-        other = material_to_mtlx(m, "direct", coat_tangent="rotate3d").replace('nodename="CT_combed"', 'nodename="T_combed"')   # the plain tangent
-        assert _desc_from_doc(L, other).p[S.P_COAT_ROTATION] == 0.0
+        other = material_to_mtlx(m, "direct", coat_tangent="rotate3d").replace('nodename="CoatT_combed"', 'nodename="T_combed"')   # the plain tangent
+        assert _desc_from_doc(L, other).p[S.P_COAT_ROTATION] == 0.0 and _desc_from_doc(L, other).p[S.P_SPECULAR_ROTATION] == np.float32(0.25 - turns)
     ss = ('<materialx version="1.38"><standard_surface name="s" type="surfaceshader"><input name="coat" type="float" value="0.6" />'
-          '<input name="coat_anisotropy" type="float" value="0.5" /><input name="coat_rotation" type="float" value="0.2" /></standard_surface></materialx>')
+          '<input name="coat_anisotropy" type="float" value="0.5" /><input name="coat_rotation" type="float" value="0.2" />'
+          '<input name="specular_anisotropy" type="float" value="0.3" /><input name="specular_rotation" type="float" value="0.7" /></standard_surface></materialx>')
     d = _desc_from_doc(L, ss)
     assert d.klass == S.MAT_OPEN_PBR and d.p[S.P_COAT_ROTATION] == np.float32(0.2) and d.p[S.P_COAT_ANISOTROPY] == np.float32(0.5)
+    assert d.p[S.P_SPECULAR_ROTATION] == np.float32(0.7) and d.p[S.P_SPECULAR_ANISOTROPY] == np.float32(0.3)
+    gltf = ('<materialx version="1.38"><gltf_pbr name="g" type="surfaceshader"><input name="anisotropy_strength" type="float" value="0.6" />'
+            '<input name="anisotropy_rotation" type="float" value="1.5707964" /></gltf_pbr></materialx>')          # radians, counter-clockwise from the tangent
+    d = _desc_from_doc(L, gltf)
+    assert d is not None and abs(d.p[S.P_SPECULAR_ROTATION] - 0.25) < 1e-7 and d.p[S.P_SPECULAR_ANISOTROPY] == np.float32(0.6)
 
 
 def _c4_sets():
@@ -132,7 +140,8 @@ def test_standard_surface_and_gltf_pbr_documents_translate_onto_the_open_pbr_blo
         "sheen": ("float", "0.6"), "sheen_color": ("color3", "0.5, 0.5, 0.9"), "sheen_roughness": ("float", "0.45"), "coat": ("float", "0.75"), "coat_color": ("color3", "1, 0.9, 0.8"),
         "coat_roughness": ("float", "0.05"), "coat_IOR": ("float", "1.45"), "coat_anisotropy": ("float", "0.3"), "thin_film_thickness": ("float", "550"),
         "thin_film_IOR": ("float", "1.38"), "emission": ("float", "2.5"), "emission_color": ("color3", "1, 0.5, 0.25"), "opacity": ("color3", "0.9, 0.6, 0.3"), "thin_walled": ("boolean", "false"),
-        "specular_rotation": ("float", "0.3"), "transmission_dispersion": ("float", "20"), "coat_affect_color": ("float", "0.5")})   # (the last three: dropped)
+        "specular_rotation": ("float", "0.3"), "coat_rotation": ("float", "0.6"), "transmission_dispersion": ("float", "20"),
+            "coat_affect_color": ("float", "0.5")})   # (the last two: dropped)
     d = _desc_from_doc(L, doc)
     f = np.float32
     want = M.open_pbr(base_weight=0.7, base_color=(0.2, 0.4, 0.6), base_diffuse_roughness=0.35, base_metalness=0.25, specular_weight=0.9, specular_color=(0.9, 0.8, 0.7),
@@ -141,7 +150,8 @@ def test_standard_surface_and_gltf_pbr_documents_translate_onto_the_open_pbr_blo
                       subsurface_radius=0.05, subsurface_radius_scale=(1.0, 0.4, 0.2), subsurface_scatter_anisotropy=0.1, fuzz_weight=0.6, fuzz_color=(0.5, 0.5, 0.9),
                       fuzz_roughness=0.45, coat_weight=0.75, coat_color=(1.0, 0.9, 0.8), coat_roughness=0.05, coat_ior=1.45, coat_roughness_anisotropy=0.3, coat_darkening=0.0,
                       thin_film_weight=1.0, thin_film_thickness=f(550.0) * f(0.001), thin_film_ior=1.38, emission_luminance=1.0,
-                      emission_color=(f(2.5) * f(1.0), f(2.5) * f(0.5), f(2.5) * f(0.25)), geometry_opacity=(f(0.9) + f(0.6) + f(0.3)) * f(1.0 / 3.0)).params
+                      emission_color=(f(2.5) * f(1.0), f(2.5) * f(0.5), f(2.5) * f(0.25)), geometry_opacity=(f(0.9) + f(0.6) + f(0.3)) * f(1.0 / 3.0), specular_rotation=0.3,
+                      coat_rotation=0.6).params
     got = _block(d)
     bad = np.nonzero(got.view(np.uint32) != np.asarray(want, np.float32).view(np.uint32))[0]
     assert d.klass == S.MAT_OPEN_PBR and bad.size == 0, (bad.tolist(), got[bad].tolist(), np.asarray(want)[bad].tolist())

@@ -320,6 +320,71 @@ def test_coat_tangent(orc):
     np.testing.assert_allclose(o[:, 14].mean() * 2 * np.pi, refl.mean(), rtol=0.06, atol=0.01)
 
 
+def test_base_tangent(orc):
+    """open_pbr_surface.mtlx:89 (geometry_tangent: the tangent of the dielectric and conductor lobes, :385, 402, 410, 449, 457) in the form documents bind it -- the
+    geometry tangent turned by specular_rotation turns.  The stretch of an anisotropic metal's micro-normals follows the turned axes; a quarter turn is the frame with
+    tangent and bitangent exchanged (every lobe); half a turn evaluates like no turn; without anisotropic base lobes the input is not read (bit for bit); the coat keeps
+    the geometry tangent (and its own turn) whatever the base does; evaluate stays reciprocal and consistent with sampling."""
+    rng = np.random.default_rng(62)
+    r, a = 0.3, 0.75
+    at = r * r * np.sqrt(2.0 / (1.0 + (1.0 - a) ** 2)); ab = (1.0 - a) * at
+    def metal(rot, **kw):
+        d = dict(base_color=(1, 1, 1), base_metalness=1.0, specular_roughness=r, specular_roughness_anisotropy=a, specular_rotation=rot)
+        d.update(kw)
+        return MaterialDesc.open_pbr(**d)
+    items = _frames(200000, rng, 1.0)
+    for turns in (0.125, 0.3, -0.9):
+        out = orc.bsdf_debug(metal(turns), items)
+        ok = out[:, 7] != 0
+        h = out[ok, 0:3] + np.float32([0, 0, 1]); h /= np.linalg.norm(h, axis=1, keepdims=True)
+        c, s_ = np.cos(2 * np.pi * turns), np.sin(2 * np.pi * turns)
+        sx = np.abs((h[:, 0] * c + h[:, 1] * s_) / h[:, 2]); sy = np.abs((h[:, 1] * c - h[:, 0] * s_) / h[:, 2])
+        np.testing.assert_allclose(np.median(sx) / np.median(sy), at / ab, rtol=0.05)
+        np.testing.assert_allclose(np.median(sx), at * 0.5774, rtol=0.06)
+    # a quarter turn == the frame (tangentV, -tangentU), for a material with every lobe beneath the coat; half a turn evaluates like none
+    ev = _frames(20000, rng, 0.45)
+    swapped = ev.copy(); swapped[:, 3:6] = ev[:, 6:9]; swapped[:, 6:9] = -ev[:, 3:6]
+    def mixed(rot, **kw):
+        d = dict(base_color=(0.6, 0.5, 0.4), base_metalness=0.4, specular_roughness=0.35, specular_roughness_anisotropy=0.6, transmission_weight=0.3, base_diffuse_roughness=0.5,
+                 specular_rotation=rot)
+        d.update(kw)
+        return MaterialDesc.open_pbr(**d)
+    q, f0 = orc.bsdf_debug(mixed(0.25), ev), orc.bsdf_debug(mixed(0.0), swapped)
+    same = q[:, 7] == f0[:, 7]
+    assert same.mean() > 0.999
+    np.testing.assert_allclose(q[:, 8:15], f0[:, 8:15], rtol=3e-4, atol=3e-6)
+    np.testing.assert_allclose(q[same, 0:7], f0[same, 0:7], rtol=3e-3, atol=3e-5)
+    hlf, z = orc.bsdf_debug(mixed(0.5), ev), orc.bsdf_debug(mixed(0.0), ev)
+    np.testing.assert_allclose(hlf[:, 8:15], z[:, 8:15], rtol=3e-4, atol=3e-6)
+    assert not np.allclose(orc.bsdf_debug(mixed(0.125), ev)[:, 11:14], z[:, 11:14], rtol=1e-2)
+    # not read without anisotropic base lobes: bit for bit the material without the input (an anisotropic COAT does not count)
+    for kw in (dict(specular_roughness_anisotropy=0.0), dict(specular_roughness_anisotropy=0.0, coat_weight=0.6, coat_roughness=0.3, coat_roughness_anisotropy=0.7, coat_rotation=0.1)):
+        a0, a1 = orc.bsdf_debug(mixed(0.0, **kw), ev), orc.bsdf_debug(mixed(0.37, **kw), ev)
+        assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32)), kw
+    # the coat stays on the geometry tangent (+ its own turn) when the base turns: the coat's own samples do not move (to the rounding of the relative turn)
+    for coat_turn in (0.0, 0.1):
+        coated = dict(specular_weight=0.0, base_metalness=0.0, transmission_weight=0.0, coat_weight=1.0, coat_ior=3.0, coat_roughness=0.3, coat_roughness_anisotropy=0.75, coat_rotation=coat_turn)
+        c0, c1 = orc.bsdf_debug(mixed(0.0, **coated), ev), orc.bsdf_debug(mixed(0.3, **coated), ev)
+        coat = (c0[:, 7] == 10) & (c1[:, 7] == 10)
+        assert coat.sum() > 2000
+        np.testing.assert_allclose(c1[coat, 0:7], c0[coat, 0:7], rtol=2e-3, atol=2e-5)
+        np.testing.assert_allclose(c1[:, 11:14], c0[:, 11:14], rtol=3e-4, atol=3e-6)            # specular_weight 0: the glossy part IS the coat
+    # reciprocity (metal: its Fresnel factor depends on k.h only) and evaluate == sampling, both turns at once
+    n = 4000
+    u = rng.normal(size=(n, 3)); u[:, 2] = np.abs(u[:, 2]) + 0.2; u /= np.linalg.norm(u, axis=1, keepdims=True)
+    v = rng.normal(size=(n, 3)); v[:, 2] = np.abs(v[:, 2]) + 0.2; v /= np.linalg.norm(v, axis=1, keepdims=True)
+    base = _frames(n, rng, 0.5)
+    uv = base.copy(); uv[:, 12:15] = u; uv[:, 15:18] = v
+    vu = base.copy(); vu[:, 12:15] = v; vu[:, 15:18] = u
+    fuv = orc.bsdf_debug(metal(0.2), uv)[:, 11] / v[:, 2]; fvu = orc.bsdf_debug(metal(0.2), vu)[:, 11] / u[:, 2]
+    np.testing.assert_allclose(fuv, fvu, rtol=3e-4, atol=1e-6)
+    big = _frames(300000, rng, 0.7)
+    o = orc.bsdf_debug(mixed(0.2, transmission_weight=0.0, coat_weight=0.5, coat_roughness=0.25, coat_roughness_anisotropy=0.6, coat_rotation=-0.15), big)
+    refl = (o[:, 7].astype(int) & 8) != 0
+    np.testing.assert_allclose((o[:, 8:11] + o[:, 11:14]).mean(axis=0) * (2 * np.pi), (o[:, 3:6] * refl[:, None]).mean(axis=0), rtol=0.06, atol=0.01)
+    np.testing.assert_allclose(o[:, 14].mean() * 2 * np.pi, refl.mean(), rtol=0.06, atol=0.01)
+
+
 def test_thin_film(orc):
     """open_pbr_surface.mtlx:300-304, 404-431, 450-464: thin_film_weight mixes a film's interference into the Fresnel factor of the dielectric and metal lobes.
     Our closed form is the Airy summation at three wavelengths (oracle/gi_oracle.cpp "thin film").  Known answers of the reflectance: a film of zero or

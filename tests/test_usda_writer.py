@@ -97,7 +97,8 @@ def test_usda_keeps_the_coat_tangent_turn(tmp_path):
     """geometry_coat_tangent as the [ext] coat_rotation float of the flat OpenPBR vocabulary (usda_writer OPEN_PBR_INPUTS, gtl_shim.cpp kOpbr): the block comes back bit for bit."""
     from gatling_amd.scene import P_COAT_ROTATION, MaterialDesc
     a = SCENES[sorted(SCENES)[0]]()
-    a.materials[0] = MaterialDesc.open_pbr(name=a.materials[0].name, coat_weight=0.6, coat_roughness=0.3, coat_roughness_anisotropy=0.4, coat_rotation=0.3137)
+    a.materials[0] = MaterialDesc.open_pbr(name=a.materials[0].name, coat_weight=0.6, coat_roughness=0.3, coat_roughness_anisotropy=0.4, coat_rotation=0.3137,
+                                           specular_roughness_anisotropy=0.2, specular_rotation=-0.41)
     write_usda(tmp_path / "s.usda", a)
     b = load_usda(str(tmp_path / "s.usda"))
     assert b.materials[0].params[P_COAT_ROTATION] == np.float32(0.3137)
